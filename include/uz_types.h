@@ -1,0 +1,154 @@
+/* uz_types.h -- plain-C views of the decoded inputs of the per-DNM phasing path.
+ *
+ * Shared by the C ABI (include/unfazed_hip.h), the HIP sources and the CPU
+ * oracle (oracle/).  All pointers in these views are HOST pointers owned by the
+ * caller; the library copies what it needs into HBM at upload time.
+ *
+ * Column semantics follow the libraries the reference reads its inputs with
+ * (cyvcf2 / pysam) -- see unfazed_amd/model.py.
+ */
+#ifndef UZ_TYPES_H
+#define UZ_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* genotype codes: reference unfazed/utils.py:2-5 */
+#define UZ_HOM_REF 0
+#define UZ_HET 1
+#define UZ_GT_UNKNOWN 2
+#define UZ_HOM_ALT 3
+
+#define UZ_U16_MISSING 0xFFFFu /* cyvcf2's -1 (missing depth / GQ) in the 16-bit columns */
+
+/* site flags */
+#define UZ_SF_COMPLEX 1u /* reference informative_site_finder.py:239-243 */
+
+/* site class byte written by the site-scan kernel (one per site per family) */
+#define UZ_CL_HET 0x01u       /* usable for extended read-backed phasing (:268-284) */
+#define UZ_CL_CAND 0x02u      /* informative site, SNV / breakpoint mode (:292-320) */
+#define UZ_CL_ALT_DAD 0x04u   /* alt_parent is dad (else mom) -- valid when a pattern matched */
+#define UZ_CL_DEL_SHIFT 3     /* bits 3-4: candidate code for a DEL (0 none, 1 ref_parent, 2 alt_parent) */
+#define UZ_CL_DUP_SHIFT 5     /* bits 5-6: same for a DUP (get_kid_allele, :76-134) */
+#define UZ_KA_NONE 0
+#define UZ_KA_REF_PARENT 1
+#define UZ_KA_ALT_PARENT 2
+
+/* DNM variant type */
+#define UZ_VT_POINT 0 /* POINT / SNV / INDEL */
+#define UZ_VT_DEL 1
+#define UZ_VT_DUP 2
+#define UZ_VT_OTHER_SV 3
+
+/* DNM flags */
+#define UZ_DF_FETCH_FALLBACK 1u /* contig resolved through the renamed-contig fallback: fetch [pos,pos+1) (read_collector.py:386-392) */
+
+/* candidate flags in the find output */
+#define UZ_CF_ALT_DAD 0x1u
+#define UZ_CF_KA_SHIFT 1 /* bits 1-2: kid_allele code (CNV mode) */
+
+/* segment aux bits */
+#define UZ_AUX_MATE_SAME_TID 1u
+#define UZ_AUX_HAS_SA 2u
+#define UZ_AUX_DECODE_BAD 4u
+
+/* per-DNM status of the read stage */
+#define UZ_ST_OK 0             /* a record exists */
+#define UZ_ST_NO_CAND 1        /* "No usable informative sites" (snv_phaser.py:254-262) */
+#define UZ_ST_NO_OVERLAP 2     /* "No reads overlap informative sites" (snv_phaser.py:158-166) */
+#define UZ_ST_REF_EXCEPTION 3  /* the reference raises inside the worker (KeyError in connect_reads): no record */
+#define UZ_ST_SKIPPED 4        /* not run (host filtered: autophase, no genotype, ...) */
+
+/* origin codes of the integer decision rule (unfazed.py:206-234) */
+#define UZ_OR_NONE 0
+#define UZ_OR_DAD 1
+#define UZ_OR_MOM 2
+#define UZ_OR_AMBIGUOUS 3
+
+typedef struct uz_params {
+    int32_t search_dist;        /* --search-dist */
+    int32_t min_gt_qual;        /* --min-gt-qual: GQ threshold AND base-quality threshold (read_collector.py:361-362) */
+    int32_t min_depth;          /* --min-depth */
+    int32_t min_map_qual;       /* --min-map-qual */
+    int32_t readlen;            /* --readlen */
+    int32_t split_error_margin; /* --split-error-margin */
+    int32_t no_extended;        /* --no-extended */
+    int32_t read_goal;          /* EXTENDED_RB_READ_GOAL = --insert-size-max-sample (read_collector.py:369-370) */
+    int32_t evidence_min_ratio; /* --evidence-min-ratio */
+    int32_t reserved0;
+    double ab_homref[2];
+    double ab_homalt[2];
+    double ab_het[2];
+} uz_params;
+
+/* sites table: records of the sites VCF in file order, grouped by contig */
+typedef struct uz_sites_view {
+    int64_t n_sites;
+    int32_t n_contigs;
+    int32_t reserved0;
+    const int64_t *contig_off; /* [n_contigs+1] */
+    const int32_t *pos;        /* [S] Variant.start (0-based) */
+    const uint8_t *sflags;     /* [S] UZ_SF_* */
+    const uint8_t *ref_base;   /* [S] ASCII, 0 for complex records */
+    const uint8_t *alt_base;   /* [S] */
+} uz_sites_view;
+
+/* genotype columns of one trio, member order kid, dad, mom */
+typedef struct uz_family_view {
+    const uint8_t *gt;            /* [S] kid | dad<<2 | mom<<4 (cyvcf2 gt_types codes) */
+    const uint16_t *ref_depth[3]; /* [S] each; UZ_U16_MISSING = -1 */
+    const uint16_t *alt_depth[3];
+    const uint16_t *gq[3];        /* floor(GQ); UZ_U16_MISSING = -1 */
+} uz_family_view;
+
+/* alignment records of one BAM in file (coordinate) order */
+typedef struct uz_reads_view {
+    int64_t n_segs; /* < 2^31 */
+    int32_t n_contigs;
+    int32_t reserved0;
+    const int64_t *contig_off; /* [n_contigs+1] */
+    const int32_t *max_span;   /* [n_contigs] max(end-start) */
+    const int32_t *start;      /* reference_start */
+    const int32_t *end;        /* bam_endpos */
+    const uint16_t *flag;
+    const uint8_t *mapq;
+    const uint8_t *aux;        /* UZ_AUX_* */
+    const int32_t *tlen;
+    const uint32_t *qname;     /* interned query-name id */
+    const int32_t *mate;       /* record pysam's mate() returns, -1 = ValueError */
+    const uint32_t *cigar_off;
+    const uint16_t *n_cigar;
+    const uint32_t *cigar;     /* BAM encoding len<<4|op */
+    const uint16_t *l_seq;
+    const uint32_t *sq_off16;  /* row offset into seq/qual in 16-byte units */
+    const uint8_t *seq;        /* ASCII */
+    const uint8_t *qual;
+    int64_t n_cigar_total;
+    int64_t n_sq_bytes;
+    uint32_t n_qnames;
+    uint32_t reserved1;
+} uz_reads_view;
+
+/* one batch of DNMs of one kid (one family, one BAM) */
+typedef struct uz_dnms_view {
+    int32_t n;
+    int32_t reserved0;
+    const int32_t *contig;      /* sites-table contig id, -1 = contig absent from the sites file */
+    const int32_t *rcontig;     /* reads-table contig id, -1 = absent */
+    const int32_t *start;       /* 0-based */
+    const int32_t *end;
+    const uint8_t *vartype;     /* UZ_VT_* */
+    const uint8_t *dflags;      /* UZ_DF_* */
+    const uint8_t *mult;        /* list-entry multiplicity (1; >1 reproduces find_many's duplicate appends) */
+    const uint32_t *allele_off; /* [2n+1]: REF of DNM d = alleles[off[2d]..off[2d+1]), ALT = [off[2d+1]..off[2d+2]) */
+    const uint8_t *alleles;
+    double cutoff;              /* concordant_upper_len of this kid (read_collector.py:11-25) */
+} uz_dnms_view;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UZ_TYPES_H */

@@ -1,0 +1,121 @@
+"""ctypes wrapper of oracle/liboracle.so -- TEST INFRASTRUCTURE (see uz_oracle.c).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from unfazed_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "uz_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "uz_types.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+    return so
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32),
+        ("status", C.POINTER(C.c_int32)),
+        ("init_off", C.POINTER(C.c_int64)),
+        ("init_seg", C.POINTER(C.c_int32)),
+        ("grp_off", C.POINTER(C.c_int64)),
+        ("grp_q", C.POINTER(C.c_int32)),
+        ("vote_off", C.POINTER(C.c_int64)),
+        ("vote_val", C.POINTER(C.c_int32)),
+        ("counts", C.POINTER(C.c_int32)),
+        ("origin", C.POINTER(C.c_int32)),
+        ("evidence", C.POINTER(C.c_int32)),
+    ]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.uzo_classify.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.uzo_classify.restype = None
+        L.uzo_find.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 5
+        L.uzo_find.restype = C.c_int
+        L.uzo_phase.argtypes = [C.c_void_p] * 4 + [C.c_void_p] * 5 + [C.c_int32, C.c_int32, C.c_int, C.POINTER(C.POINTER(Result))]
+        L.uzo_phase.restype = C.c_int
+        L.uzo_result_free.argtypes = [C.POINTER(Result)]
+        L.uzo_result_free.restype = None
+        L.uzo_concordant_cutoff.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
+        L.uzo_concordant_cutoff.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+def classify(params, sites, fam):
+    n = sites.view.n_sites
+    cls = np.zeros(n, dtype=np.uint8)
+    lib().uzo_classify(C.byref(params), sites.ref(), fam.ref(), 0, n, cls.ctypes.data)
+    return cls
+
+
+def find(params, sites, fam, dnms, mode):
+    """-> cand_off, cand_idx, cand_flags, het_off, het_idx"""
+    n = dnms.view.n
+    co = np.zeros(n + 1, dtype=np.int64)
+    ho = np.zeros(n + 1, dtype=np.int64)
+    L = lib()
+    L.uzo_find(C.byref(params), sites.ref(), fam.ref(), dnms.ref(), mode, co.ctypes.data, None, None, ho.ctypes.data, None)
+    ci = np.zeros(max(1, int(co[n])), dtype=np.int32)
+    cf = np.zeros(max(1, int(co[n])), dtype=np.uint8)
+    hi = np.zeros(max(1, int(ho[n])), dtype=np.int32)
+    L.uzo_find(C.byref(params), sites.ref(), fam.ref(), dnms.ref(), mode, co.ctypes.data, ci.ctypes.data,
+               cf.ctypes.data, ho.ctypes.data, hi.ctypes.data)
+    return co, ci[: int(co[n])], cf[: int(co[n])], ho, hi[: int(ho[n])]
+
+
+def _arr(ptr, n, dtype):
+    if n <= 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def phase(params, sites, reads, dnms, found, d_lo=0, d_hi=None, keep_lists=True):
+    co, ci, cf, ho, hi = found
+    n = dnms.view.n
+    if d_hi is None:
+        d_hi = n
+    ci = np.ascontiguousarray(ci if ci.size else np.zeros(1, np.int32))
+    cf = np.ascontiguousarray(cf if cf.size else np.zeros(1, np.uint8))
+    hi = np.ascontiguousarray(hi if hi.size else np.zeros(1, np.int32))
+    out = C.POINTER(Result)()
+    rc = lib().uzo_phase(C.byref(params), sites.ref(), reads.ref(), dnms.ref(), co.ctypes.data, ci.ctypes.data,
+                         cf.ctypes.data, ho.ctypes.data, hi.ctypes.data, d_lo, d_hi, 1 if keep_lists else 0,
+                         C.byref(out))
+    assert rc == 0
+    r = out.contents
+    res = dict(
+        status=_arr(r.status, n, np.int32),
+        counts=_arr(r.counts, 4 * n, np.int32).reshape(n, 4),
+        origin=_arr(r.origin, n, np.int32),
+        evidence=_arr(r.evidence, n, np.int32),
+    )
+    if keep_lists:
+        io = _arr(r.init_off, 2 * n + 1, np.int64)
+        go = _arr(r.grp_off, 2 * n + 1, np.int64)
+        vo = _arr(r.vote_off, 4 * n + 1, np.int64)
+        res.update(
+            init_off=io, init_seg=_arr(r.init_seg, int(io[-1]), np.int32),
+            grp_off=go, grp_q=_arr(r.grp_q, int(go[-1]), np.int32),
+            vote_off=vo, vote_val=_arr(r.vote_val, int(vo[-1]), np.int32),
+        )
+    lib().uzo_result_free(out)
+    return res
+
+
+def concordant_cutoff(tlen, readlen):
+    t = np.ascontiguousarray(tlen, dtype=np.int32)
+    return lib().uzo_concordant_cutoff(t.ctypes.data, t.shape[0], readlen)

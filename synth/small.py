@@ -1,0 +1,413 @@
+"""Small-scale synthetic trio generator (record level, Python/numpy).
+
+Test and golden-vector infrastructure only -- never on the product path.
+Produces the *decoded records* (unfazed_amd.model.SiteRecord / Segment) of a
+synthetic trio: a sites VCF with Mendelian genotypes around a list of proxy
+de novo mutations, and a 30x paired-end pile-up of the kid sampled from the
+kid's two haplotypes, with knobs for the awkward cases the reference's logic
+branches on (multi-allelic / indel / '*' records, unknown genotypes, low GQ or
+depth, soft clips, indels, >10 CIGAR ops, low-quality runs, duplicates,
+secondary / supplementary copies, unmapped or far mates, overlapping mates,
+clustered het sites, base errors).
+
+The large-scale generator used by bench.py lives in synth/uzsynth.h (C, shared
+between gcc and hipcc); this one favours coverage of edge cases over speed.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from unfazed_amd.model import (
+    FDUP,
+    FMREVERSE,
+    FMUNMAP,
+    FPAIRED,
+    FPROPER,
+    FQCFAIL,
+    FREAD1,
+    FREAD2,
+    FREVERSE,
+    FSECONDARY,
+    FSUPP,
+    FUNMAP,
+    OP_D,
+    OP_EQ,
+    OP_I,
+    OP_M,
+    OP_S,
+    OP_X,
+    Segment,
+    SiteRecord,
+)
+
+BASES = "ACGT"
+
+
+def refbase(tid: int, pos: int) -> str:
+    x = (pos * 0x9E3779B1 + tid * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12
+    return BASES[x & 3]
+
+
+def otherbase(b: str, k: int) -> str:
+    return BASES[(BASES.index(b) + 1 + (k % 3)) % 4]
+
+
+@dataclass
+class SmallConfig:
+    seed: int = 1
+    n_dnms: int = 20
+    contigs: List[str] = field(default_factory=lambda: ["1", "2"])
+    dnm_spacing: int = 30000
+    search_dist: int = 5000
+    site_rate: float = 1.0 / 550.0
+    cluster_prob: float = 0.3  # chance a DNM gets a dense cluster of het sites nearby
+    coverage_per_hap: float = 15.0
+    readlen: int = 151
+    ins_mean: float = 450.0
+    ins_sd: float = 50.0
+    base_err: float = 0.004
+    lowq_prob: float = 0.03
+    mapq0_prob: float = 0.03
+    softclip_prob: float = 0.01
+    indel_prob: float = 0.005
+    odd_read_prob: float = 0.02  # dup / qcfail / secondary / supp / mate problems / many ops
+    complex_site_prob: float = 0.03
+    bad_gt_prob: float = 0.05  # unknown GT, low GQ, low depth, missing AD
+    indel_dnm_frac: float = 0.15
+    mnp_dnm_frac: float = 0.05
+    kids: List[str] = field(default_factory=lambda: ["kid1"])
+    chr_prefix: str = ""
+    pad: int = 1000  # reads are generated within search_dist + pad of each DNM
+
+
+@dataclass
+class SmallDataset:
+    samples: List[str]
+    contigs: List[str]
+    sites: List[SiteRecord]
+    reads: Dict[str, List[Segment]]  # kid -> records in BAM order
+    dnms: List[dict]
+    pedigrees: Dict[str, dict]
+    truth: Dict[str, str]  # dnm key -> "dad"/"mom"
+
+
+def _poisson_depth(rng, lam=30.0):
+    return int(rng.poisson(lam))
+
+
+def make_small(cfg: SmallConfig) -> SmallDataset:
+    rng = np.random.RandomState(cfg.seed)
+    contigs = [cfg.chr_prefix + c for c in cfg.contigs]
+    samples: List[str] = []
+    pedigrees: Dict[str, dict] = {}
+    for k, kid in enumerate(cfg.kids):
+        dad, mom = "dad%d" % (k + 1), "mom%d" % (k + 1)
+        samples += [kid, dad, mom]
+        pedigrees[kid] = {"kid": kid, "dad": dad, "mom": mom, "sex": str(1 + (k % 2))}
+    # deliberately not in kid,dad,mom column order
+    perm = rng.permutation(len(samples))
+    samples = [samples[i] for i in perm]
+    col = {s: i for i, s in enumerate(samples)}
+    ns = len(samples)
+
+    W = cfg.search_dist + cfg.pad
+    # ---- DNMs ---------------------------------------------------------
+    dnms: List[dict] = []
+    truth: Dict[str, str] = {}
+    per_contig = (cfg.n_dnms + len(contigs) - 1) // len(contigs)
+    dnm_meta = []
+    for d in range(cfg.n_dnms):
+        tid = d // per_contig
+        slot = d % per_contig
+        pos = 2 * W + 5000 + slot * cfg.dnm_spacing + int(rng.randint(0, max(1, cfg.dnm_spacing // 4)))
+        kid = cfg.kids[d % len(cfg.kids)]
+        u = rng.rand()
+        ref = refbase(tid, pos)
+        if u < cfg.indel_dnm_frac:
+            k = int(rng.randint(1, 6))
+            if rng.rand() < 0.5:  # insertion after the anchor base
+                alt = ref + "".join(BASES[int(x)] for x in rng.randint(0, 4, size=k))
+                kind = "ins"
+            else:
+                ref = "".join(refbase(tid, pos + j) for j in range(k + 1))
+                alt = ref[0]
+                kind = "del"
+        elif u < cfg.indel_dnm_frac + cfg.mnp_dnm_frac:
+            ref = refbase(tid, pos) + refbase(tid, pos + 1)
+            alt = otherbase(ref[0], d) + otherbase(ref[1], d + 1)
+            kind = "mnp"
+        else:
+            alt = otherbase(ref, d)
+            kind = "snv"
+        origin = "dad" if rng.rand() < 0.5 else "mom"
+        end = pos + len(ref)
+        dn = {
+            "chrom": contigs[tid],
+            "start": pos,
+            "end": end,
+            "kid": kid,
+            "vartype": "POINT",
+            "bam": "mem://%s.bam" % kid,
+            "cram_ref": None,
+        }
+        dnms.append(dn)
+        truth["{chrom}_{start}_{end}_{kid}_{vartype}".format(**dn)] = origin
+        dnm_meta.append(dict(tid=tid, pos=pos, ref=ref, alt=alt, kind=kind, origin=origin, kid=kid,
+                             td=int(rng.randint(0, 2)), tm=int(rng.randint(0, 2))))
+
+    # ---- sites --------------------------------------------------------
+    # haplotypes per trio: allele (0/1) on dad h0,h1 / mom h0,h1 at each site
+    site_recs: List[SiteRecord] = []
+    # site list per DNM for read generation: (pos, ref, alt, pat_allele, mat_allele)
+    dnm_sites: List[List[tuple]] = [[] for _ in dnms]
+    raw_sites = []  # (tid, pos, payload)
+    for d, m in enumerate(dnm_meta):
+        lo, hi = m["pos"] - W - 600, m["pos"] + W + 600
+        n = rng.poisson((hi - lo) * cfg.site_rate)
+        poss = set(int(x) for x in rng.randint(lo, hi, size=n))
+        if rng.rand() < cfg.cluster_prob:
+            c0 = m["pos"] + int(rng.randint(-1500, 1500))
+            poss |= set(int(x) for x in rng.randint(c0 - 700, c0 + 700, size=int(rng.randint(5, 12))))
+        poss.discard(m["pos"])
+        for p in sorted(poss):
+            raw_sites.append((m["tid"], p, d))
+    # DNM records themselves
+    for d, m in enumerate(dnm_meta):
+        raw_sites.append((m["tid"], m["pos"], -1 - d))
+    raw_sites.sort(key=lambda x: (x[0], x[1]))
+
+    for tid, p, tag in raw_sites:
+        gts = [0] * ns
+        rds = [0] * ns
+        ads = [0] * ns
+        gqs = [99.0] * ns
+        if tag < 0:  # the DNM's own record: kid het, everyone else hom-ref
+            m = dnm_meta[-1 - tag]
+            ref, alts = m["ref"], [m["alt"]]
+            for s in samples:
+                depth = max(12, _poisson_depth(rng))
+                g = 1 if s == m["kid"] else 0
+                a = int(rng.binomial(depth, 0.5)) if g == 1 else 0
+                gts[col[s]], rds[col[s]], ads[col[s]] = g, depth - a, a
+            site_recs.append(SiteRecord(contigs[tid], p, ref, alts, gts, rds, ads, gqs))
+            if rng.rand() < 0.08:  # a second record at the same position -> "too many genotypes"
+                site_recs.append(SiteRecord(contigs[tid], p, ref, [otherbase(ref[0], 7)], gts, rds, ads, gqs))
+            continue
+        d = tag
+        m = dnm_meta[d]
+        ref = refbase(tid, p)
+        alt = otherbase(ref, p)
+        f = float(rng.rand()) ** 2 * 0.9 + 0.05
+        hap = {}
+        for k, kid in enumerate(cfg.kids):
+            dad, mom = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
+            dh = [int(rng.rand() < f), int(rng.rand() < f)]
+            mh = [int(rng.rand() < f), int(rng.rand() < f)]
+            if kid == m["kid"]:
+                pat, mat = dh[m["td"]], mh[m["tm"]]
+            else:
+                pat, mat = dh[int(rng.randint(0, 2))], mh[int(rng.randint(0, 2))]
+            hap[kid] = (pat, mat)
+            for s, g in ((kid, pat + mat), (dad, dh[0] + dh[1]), (mom, mh[0] + mh[1])):
+                depth = _poisson_depth(rng)
+                pr = (0.01, 0.5, 0.99)[g]
+                a = int(rng.binomial(depth, pr)) if depth > 0 else 0
+                gts[col[s]] = (0, 1, 3)[g]
+                rds[col[s]], ads[col[s]] = depth - a, a
+                gqs[col[s]] = 99.0 if rng.rand() < 0.93 else float(rng.randint(0, 61))
+        alts = [alt]
+        u = rng.rand()
+        if u < cfg.complex_site_prob:
+            w = int(rng.randint(0, 4))
+            if w == 0:
+                alts = [alt, otherbase(ref, p + 1)]
+            elif w == 1:
+                ref = ref + refbase(tid, p + 1)
+            elif w == 2:
+                alts = [alt + "T"]
+            else:
+                alts = ["*"]
+        if rng.rand() < cfg.bad_gt_prob:
+            s = samples[int(rng.randint(0, ns))]
+            w = int(rng.randint(0, 5))
+            if w == 0:
+                gts[col[s]] = 2
+            elif w == 1:
+                gqs[col[s]] = float(rng.randint(0, 25)) + (0.5 if rng.rand() < 0.3 else 0.0)
+            elif w == 2:
+                rds[col[s]], ads[col[s]] = int(rng.randint(0, 6)), int(rng.randint(0, 6))
+            elif w == 3:
+                rds[col[s]], ads[col[s]], gqs[col[s]] = -1, -1, -1.0
+            else:
+                rds[col[s]], ads[col[s]] = 0, 0
+        site_recs.append(SiteRecord(contigs[tid], p, ref, alts, gts, rds, ads, gqs))
+        if len(ref) == 1 and len(alts) == 1 and len(alts[0]) == 1 and alts[0] != "*":
+            pat, mat = hap[m["kid"]]
+            dnm_sites[d].append((p, ref, alt, pat, mat))
+
+    # ---- reads --------------------------------------------------------
+    reads: Dict[str, List[Segment]] = {kid: [] for kid in cfg.kids}
+    L = cfg.readlen
+    qn = 0
+
+    def hap_base(d, tid, q, h, sites_by_pos):
+        """base of haplotype h (0 = paternal, 1 = maternal) at reference position q"""
+        m = dnm_meta[d]
+        st = sites_by_pos.get(q)
+        b = refbase(tid, q)
+        if st is not None:
+            b = st[2] if st[3 + h] else st[1]
+        return b
+
+    for d, m in enumerate(dnm_meta):
+        tid, p = m["tid"], m["pos"]
+        sites_by_pos = {s[0]: s for s in dnm_sites[d]}
+        dnm_h = 0 if m["origin"] == "dad" else 1
+        lo, hi = p - W, p + W
+        n_pairs = int(round(cfg.coverage_per_hap * (hi - lo) / (2.0 * L)))
+        out = reads[m["kid"]]
+        for h in (0, 1):
+            for _ in range(n_pairs):
+                ins = int(np.clip(rng.normal(cfg.ins_mean, cfg.ins_sd), 2 * L, 900))
+                odd = rng.rand() < cfg.odd_read_prob
+                oddkind = int(rng.randint(0, 9)) if odd else -1
+                if oddkind == 0:  # overlapping mates
+                    ins = int(rng.randint(L + 5, 2 * L - 5))
+                fs = int(rng.randint(lo - ins, hi))
+                name = "q%07d" % qn
+                qn += 1
+                segs = []
+                for which in (0, 1):
+                    a = fs if which == 0 else fs + ins - L
+                    carries_dnm = h == dnm_h
+                    seq, qual, cigar, start = _make_read(
+                        rng, cfg, d, m, tid, a, h, carries_dnm, sites_by_pos, hap_base, oddkind, which
+                    )
+                    flag = FPAIRED | FPROPER | (FREAD1 if which == 0 else FREAD2)
+                    flag |= FMREVERSE if which == 0 else FREVERSE
+                    mapq = 0 if rng.rand() < cfg.mapq0_prob else 60
+                    segs.append(Segment(name, flag, tid, start, mapq, cigar, tid, 0,
+                                        ins if which == 0 else -ins, seq, qual))
+                segs[0].mpos, segs[1].mpos = segs[1].pos, segs[0].pos
+                extra = []
+                if oddkind == 1:
+                    segs[int(rng.randint(0, 2))].flag |= FDUP
+                elif oddkind == 2:
+                    segs[int(rng.randint(0, 2))].flag |= FQCFAIL
+                elif oddkind == 3:  # a secondary copy of read 1 placed first at the same position
+                    s0 = segs[0]
+                    extra.append(Segment(name, s0.flag | FSECONDARY, tid, s0.pos, s0.mapq, list(s0.cigar),
+                                         tid, s0.mpos, s0.tlen, s0.seq, list(s0.qual)))
+                elif oddkind == 4:  # supplementary piece with an SA tag
+                    s1 = segs[1]
+                    extra.append(Segment(name, s1.flag | FSUPP, tid, max(0, s1.pos - 40), s1.mapq,
+                                         [(OP_M, 60), (OP_S, L - 60)], tid, s1.mpos, s1.tlen, s1.seq,
+                                         list(s1.qual), has_sa=True))
+                    s1.has_sa = True
+                elif oddkind == 5:  # mate unmapped
+                    segs[0].flag |= FMUNMAP
+                    segs[0].flag &= ~FPROPER
+                    segs[1].flag |= FUNMAP
+                    segs[1].flag &= ~FPROPER
+                    segs[1].pos = segs[0].pos
+                    segs[1].cigar = []
+                    segs[1].mapq = 0
+                    segs[0].mpos = segs[0].pos
+                    segs[0].tlen = segs[1].tlen = 0
+                elif oddkind == 6:  # mate on another contig
+                    other = (tid + 1) % len(contigs)
+                    segs[0].mtid = other
+                    segs[1].tid = other
+                    segs[1].mtid = tid
+                    segs[0].tlen = segs[1].tlen = 0
+                    segs[0].flag &= ~FPROPER
+                    segs[1].flag &= ~FPROPER
+                elif oddkind == 7:  # unpaired read
+                    segs = [segs[0]]
+                    segs[0].flag = 0
+                    segs[0].mtid, segs[0].mpos, segs[0].tlen = -1, -1, 0
+                # oddkind 8: many-ops read, produced inside _make_read
+                out.extend(extra + segs)
+    for kid in reads:
+        reads[kid].sort(key=lambda s: (s.tid if s.tid >= 0 else 1 << 30, s.pos))
+    return SmallDataset(samples, contigs, site_recs, reads, dnms, pedigrees, truth)
+
+
+def _make_read(rng, cfg, d, m, tid, a, h, carries_dnm, sites_by_pos, hap_base, oddkind, which):
+    """Sequence/qualities/CIGAR of one read whose first aligned base would be ``a``."""
+    L = cfg.readlen
+    p = m["pos"]
+    cigar: List[tuple] = []
+    seq: List[str] = []
+    # --- how the read walks the reference -----------------------------
+    ops: List[tuple] = []  # (op, len)
+    start = a
+    kind = m["kind"]
+    covers_anchor = a <= p < a + L - 12 and (p - a) >= 1
+    if carries_dnm and kind in ("ins", "del") and covers_anchor:
+        x = p - a + 1
+        k = abs(len(m["alt"]) - len(m["ref"]))
+        if kind == "ins":
+            ops = [(OP_M, x), (OP_I, k), (OP_M, L - x - k)]
+        else:
+            ops = [(OP_M, x), (OP_D, k), (OP_M, L - x)]
+    elif oddkind == 8 and which == 0:
+        # 11+ CIGAR operations using =/X; same bases, just a different encoding
+        ops = []
+        left = L
+        for i in range(6):
+            ops += [(OP_EQ, 10), (OP_X, 1)]
+            left -= 11
+        ops.append((OP_M, left))
+    else:
+        u = rng.rand()
+        if u < cfg.softclip_prob:
+            c = int(rng.randint(3, 30))
+            if rng.rand() < 0.5:
+                ops = [(OP_S, c), (OP_M, L - c)]
+                start = a + c
+            else:
+                ops = [(OP_M, L - c), (OP_S, c)]
+        elif u < cfg.softclip_prob + cfg.indel_prob:
+            k = int(rng.randint(1, 4))
+            x = int(rng.randint(20, L - 30))
+            if rng.rand() < 0.5:
+                ops = [(OP_M, x), (OP_I, k), (OP_M, L - x - k)]
+            else:
+                ops = [(OP_M, x), (OP_D, k), (OP_M, L - x)]
+        else:
+            ops = [(OP_M, L)]
+    # --- bases ---------------------------------------------------------
+    q = start
+    for op, l in ops:
+        if op in (OP_M, OP_EQ, OP_X):
+            for j in range(l):
+                b = hap_base(d, tid, q, h, sites_by_pos)
+                if carries_dnm and kind in ("snv", "mnp") and p <= q < p + len(m["alt"]):
+                    b = m["alt"][q - p]
+                seq.append(b)
+                q += 1
+        elif op == OP_I:
+            if carries_dnm and kind == "ins" and q == p + 1:
+                seq.extend(m["alt"][1:])
+            else:
+                seq.extend(BASES[int(x)] for x in rng.randint(0, 4, size=l))
+        elif op == OP_S:
+            seq.extend(BASES[int(x)] for x in rng.randint(0, 4, size=l))
+        elif op == OP_D:
+            q += l
+    n = len(seq)
+    err = rng.rand(n) < cfg.base_err
+    for i in np.nonzero(err)[0]:
+        seq[i] = otherbase(seq[i], int(rng.randint(0, 3)))
+    qual = np.where(rng.rand(n) < cfg.lowq_prob, 12, 37).astype(np.uint8)
+    if rng.rand() < 0.01:  # a low-quality run: >10 bases below threshold
+        s0 = int(rng.randint(0, n - 20))
+        qual[s0 : s0 + 15] = 8
+    return "".join(seq), [int(x) for x in qual], ops, start

@@ -1,0 +1,266 @@
+"""ctypes mirror of include/uz_types.h plus builders that wrap the host tables
+(unfazed_amd.model) into those views.  No compute here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .model import ReadsTable, SitesTable
+
+# status / origin codes (include/uz_types.h)
+ST_OK, ST_NO_CAND, ST_NO_OVERLAP, ST_REF_EXCEPTION, ST_SKIPPED = 0, 1, 2, 3, 4
+OR_NONE, OR_DAD, OR_MOM, OR_AMBIGUOUS = 0, 1, 2, 3
+VT_POINT, VT_DEL, VT_DUP, VT_OTHER_SV = 0, 1, 2, 3
+DF_FETCH_FALLBACK = 1
+CF_ALT_DAD = 1
+CF_KA_SHIFT = 1
+CL_HET, CL_CAND, CL_ALT_DAD = 1, 2, 4
+CL_DEL_SHIFT, CL_DUP_SHIFT = 3, 5
+FIND_WHOLE_REGION = 1
+FIND_SECOND_WINDOW = 2
+
+_p = C.c_void_p
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("search_dist", C.c_int32),
+        ("min_gt_qual", C.c_int32),
+        ("min_depth", C.c_int32),
+        ("min_map_qual", C.c_int32),
+        ("readlen", C.c_int32),
+        ("split_error_margin", C.c_int32),
+        ("no_extended", C.c_int32),
+        ("read_goal", C.c_int32),
+        ("evidence_min_ratio", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("ab_homref", C.c_double * 2),
+        ("ab_homalt", C.c_double * 2),
+        ("ab_het", C.c_double * 2),
+    ]
+
+
+def make_params(
+    search_dist=5000,
+    min_gt_qual=20,
+    min_depth=10,
+    min_map_qual=1,
+    readlen=151,
+    split_error_margin=5,
+    no_extended=False,
+    insert_size_max_sample=1000000,
+    evidence_min_ratio=10,
+    ab_homref=(0.0, 0.2),
+    ab_homalt=(0.8, 1.0),
+    ab_het=(0.2, 0.8),
+) -> Params:
+    """Defaults are the reference's CLI defaults (reference __main__.py:23-223)."""
+    p = Params()
+    p.search_dist = int(search_dist)
+    p.min_gt_qual = int(min_gt_qual)
+    p.min_depth = int(min_depth)
+    p.min_map_qual = int(min_map_qual)
+    p.readlen = int(readlen)
+    p.split_error_margin = int(split_error_margin)
+    p.no_extended = 1 if no_extended else 0
+    p.read_goal = int(insert_size_max_sample)
+    p.evidence_min_ratio = int(evidence_min_ratio)
+    p.ab_homref[0], p.ab_homref[1] = float(ab_homref[0]), float(ab_homref[1])
+    p.ab_homalt[0], p.ab_homalt[1] = float(ab_homalt[0]), float(ab_homalt[1])
+    p.ab_het[0], p.ab_het[1] = float(ab_het[0]), float(ab_het[1])
+    return p
+
+
+class SitesView(C.Structure):
+    _fields_ = [
+        ("n_sites", C.c_int64),
+        ("n_contigs", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("contig_off", _p),
+        ("pos", _p),
+        ("sflags", _p),
+        ("ref_base", _p),
+        ("alt_base", _p),
+    ]
+
+
+class FamilyView(C.Structure):
+    _fields_ = [
+        ("gt", _p),
+        ("ref_depth", _p * 3),
+        ("alt_depth", _p * 3),
+        ("gq", _p * 3),
+    ]
+
+
+class ReadsView(C.Structure):
+    _fields_ = [
+        ("n_segs", C.c_int64),
+        ("n_contigs", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("contig_off", _p),
+        ("max_span", _p),
+        ("start", _p),
+        ("end", _p),
+        ("flag", _p),
+        ("mapq", _p),
+        ("aux", _p),
+        ("tlen", _p),
+        ("qname", _p),
+        ("mate", _p),
+        ("cigar_off", _p),
+        ("n_cigar", _p),
+        ("cigar", _p),
+        ("l_seq", _p),
+        ("sq_off16", _p),
+        ("seq", _p),
+        ("qual", _p),
+        ("n_cigar_total", C.c_int64),
+        ("n_sq_bytes", C.c_int64),
+        ("n_qnames", C.c_uint32),
+        ("reserved1", C.c_uint32),
+    ]
+
+
+class DnmsView(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("contig", _p),
+        ("rcontig", _p),
+        ("start", _p),
+        ("end", _p),
+        ("vartype", _p),
+        ("dflags", _p),
+        ("mult", _p),
+        ("allele_off", _p),
+        ("alleles", _p),
+        ("cutoff", C.c_double),
+    ]
+
+
+def _ptr(a: np.ndarray) -> int:
+    return a.ctypes.data if a.size else 0
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Held:
+    """A ctypes view plus the numpy arrays it points into (kept alive)."""
+
+    def __init__(self, view, arrays):
+        self.view = view
+        self.arrays = arrays
+
+    def ref(self):
+        return C.byref(self.view)
+
+
+def sites_view(t: SitesTable) -> Held:
+    arrs = dict(
+        contig_off=_c(t.contig_off, np.int64),
+        pos=_c(t.pos, np.int32),
+        sflags=_c(t.sflags, np.uint8),
+        ref_base=_c(t.ref_base, np.uint8),
+        alt_base=_c(t.alt_base, np.uint8),
+    )
+    v = SitesView()
+    v.n_sites = t.n_sites
+    v.n_contigs = len(t.contigs)
+    for k, a in arrs.items():
+        setattr(v, k, _ptr(a))
+    return Held(v, arrs)
+
+
+def family_view(gt: np.ndarray, rd: np.ndarray, ad: np.ndarray, gq: np.ndarray) -> Held:
+    """gt u8[S]; rd/ad/gq u16[3][S] in kid, dad, mom order."""
+    gt = _c(gt, np.uint8)
+    rd = [_c(rd[m], np.uint16) for m in range(3)]
+    ad = [_c(ad[m], np.uint16) for m in range(3)]
+    gq = [_c(gq[m], np.uint16) for m in range(3)]
+    v = FamilyView()
+    v.gt = _ptr(gt)
+    for m in range(3):
+        v.ref_depth[m] = _ptr(rd[m])
+        v.alt_depth[m] = _ptr(ad[m])
+        v.gq[m] = _ptr(gq[m])
+    return Held(v, dict(gt=gt, rd=rd, ad=ad, gq=gq))
+
+
+def reads_view(t: ReadsTable) -> Held:
+    arrs = dict(
+        contig_off=_c(t.contig_off, np.int64),
+        max_span=_c(t.max_span, np.int32),
+        start=_c(t.start, np.int32),
+        end=_c(t.end, np.int32),
+        flag=_c(t.flag, np.uint16),
+        mapq=_c(t.mapq, np.uint8),
+        aux=_c(t.aux, np.uint8),
+        tlen=_c(t.tlen, np.int32),
+        qname=_c(t.qname, np.uint32),
+        mate=_c(t.mate, np.int32),
+        cigar_off=_c(t.cigar_off, np.uint32),
+        n_cigar=_c(t.n_cigar, np.uint16),
+        cigar=_c(t.cigar, np.uint32),
+        l_seq=_c(t.l_seq, np.uint16),
+        sq_off16=_c(t.sq_off16, np.uint32),
+        seq=_c(t.seq, np.uint8),
+        qual=_c(t.qual, np.uint8),
+    )
+    v = ReadsView()
+    v.n_segs = t.n_segs
+    v.n_contigs = len(t.contigs)
+    for k, a in arrs.items():
+        setattr(v, k, _ptr(a))
+    v.n_cigar_total = int(arrs["cigar"].shape[0])
+    v.n_sq_bytes = int(arrs["seq"].shape[0])
+    v.n_qnames = int(t.qname.max()) + 1 if t.n_segs else 0
+    return Held(v, arrs)
+
+
+def dnms_view(
+    contig: Sequence[int],
+    rcontig: Sequence[int],
+    start: Sequence[int],
+    end: Sequence[int],
+    vartype: Sequence[int],
+    refs: Sequence[bytes],
+    alts: Sequence[bytes],
+    cutoff: float,
+    dflags: Optional[Sequence[int]] = None,
+    mult: Optional[Sequence[int]] = None,
+) -> Held:
+    n = len(start)
+    off = np.zeros(2 * n + 1, dtype=np.uint32)
+    blob: List[bytes] = []
+    o = 0
+    for d in range(n):
+        off[2 * d] = o
+        blob.append(refs[d])
+        o += len(refs[d])
+        off[2 * d + 1] = o
+        blob.append(alts[d])
+        o += len(alts[d])
+    off[2 * n] = o
+    alleles = np.frombuffer(b"".join(blob) + b"\0", dtype=np.uint8).copy()
+    arrs = dict(
+        contig=_c(contig, np.int32),
+        rcontig=_c(rcontig, np.int32),
+        start=_c(start, np.int32),
+        end=_c(end, np.int32),
+        vartype=_c(vartype, np.uint8),
+        dflags=_c(dflags if dflags is not None else np.zeros(n), np.uint8),
+        mult=_c(mult if mult is not None else np.ones(n), np.uint8),
+        allele_off=off,
+        alleles=alleles,
+    )
+    v = DnmsView()
+    v.n = n
+    for k, a in arrs.items():
+        setattr(v, k, _ptr(a))
+    v.cutoff = float(cutoff)
+    return Held(v, arrs)

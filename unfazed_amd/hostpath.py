@@ -1,0 +1,515 @@
+"""Host side of the per-DNM phasing path: everything the reference does around
+the hot loops that is NOT arithmetic over sites/reads -- DNM bookkeeping,
+contig-name resolution, the REF/ALT lookup, autophasing, messages, list order
+and the `records` schema.  The arithmetic itself is done
+by a *backend* object over the decoded column tables; the product backend is
+unfazed_amd.engine.HipEngine (HIP kernels behind the C ABI).
+
+Mirrors, by name and argument meaning:
+  find / find_many      reference informative_site_finder.py:167-344 / :601-661
+  run_read_phasing      reference snv_phaser.py:206-299
+  run_cnv_phasing       reference sv_phaser.py:357-423
+"""
+from __future__ import annotations
+
+import sys
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import abi
+from .model import ReadsTable, SitesTable
+
+SEX_KEY = {"male": 1, "female": 2}  # reference utils.py:6
+SV_TYPES = ["DEL", "DUP", "INV", "CNV", "DUP:TANDEM", "DEL:ME", "CPX", "CTX"]  # utils.py:8
+SNV_TYPES = ["POINT", "SNV", "INDEL"]  # utils.py:9
+# reference utils.py:26-43
+grch37_par1 = {"x": [10001, 2781479], "y": [10001, 2781479]}
+grch37_par2 = {"x": [155701383, 156030895], "y": [56887903, 57217415]}
+grch38_par1 = {"x": [60001, 2699520], "y": [10001, 2649520]}
+grch38_par2 = {"x": [154931044, 155260560], "y": [59034050, 59363566]}
+
+
+def get_prefix(sites: SitesTable) -> str:
+    """reference utils.py:46-52 -- decided by the first record of the sites file."""
+    if sites.n_sites == 0:
+        return ""
+    chrom = sites.contigs[0]
+    return chrom[:3] if "chr" in chrom.lower() else ""
+
+
+def autophaseable(denovo: dict, pedigrees: dict, build: str) -> bool:
+    """reference informative_site_finder.py:137-164 (same test as snv_phaser.py:302-328)."""
+    chrom = denovo["chrom"].lower().strip("chr")
+    if chrom not in ["y", "x"]:
+        return False
+    if int(pedigrees[denovo["kid"]]["sex"]) != SEX_KEY["male"]:
+        return False
+    if build not in ["37", "38"]:
+        return False
+    par1, par2 = (grch37_par1, grch37_par2) if build == "37" else (grch38_par1, grch38_par2)
+    if (
+        par1[chrom][0] <= denovo["start"] <= par1[chrom][1]
+        or par2[chrom][0] <= denovo["start"] <= par2[chrom][1]
+    ):
+        return False
+    return True
+
+
+def vartype_code(vartype: str) -> int:
+    if vartype == "DEL":
+        return abi.VT_DEL
+    if vartype == "DUP":
+        return abi.VT_DUP
+    if vartype in SV_TYPES:
+        return abi.VT_OTHER_SV
+    return abi.VT_POINT
+
+
+def concordant_cutoff(tlen_head: np.ndarray, readlen: int, stdevs: int) -> float:
+    """reference read_collector.py:11-25, literally (quirk Q8: the percentile
+    overwrites the array, so the stdev is 0 and --stdevs has no effect)."""
+    insert_sizes = np.abs(np.asarray(tlen_head, dtype=np.int64) - (readlen * 2))
+    insert_sizes = np.percentile(insert_sizes, 99.5)
+    frag_len = int(np.mean(insert_sizes))
+    stdev = np.std(insert_sizes)
+    return frag_len + (stdev * stdevs)
+
+
+class _Log:
+    def __init__(self, quiet: bool):
+        self.quiet = quiet
+
+    def __call__(self, msg: str):
+        if not self.quiet:
+            print(msg, file=sys.stderr)
+
+
+class PhasingHost:
+    """Drives one backend over one sites table and the reads tables of the kids."""
+
+    def __init__(self, backend, sites: SitesTable, reads_by_bam: Dict[str, ReadsTable]):
+        self.backend = backend
+        self.sites = sites
+        self.reads_by_bam = reads_by_bam
+        self.prefix = get_prefix(sites)
+        self._sites_h = backend.upload_sites(sites)
+        self._fam_h: Dict[tuple, object] = {}
+        self._reads_h: Dict[str, object] = {}
+        self.cutoffs: Dict[str, float] = {}  # reference snv_phaser.py:14 concordant_upper_lens
+
+    # ------------------------------------------------------------ handles
+    def family(self, kid: str, dad: str, mom: str):
+        key = (kid, dad, mom)
+        if key not in self._fam_h:
+            gt, rd, ad, gq = self.sites.family_columns(kid, dad, mom)
+            self._fam_h[key] = self.backend.add_family(self._sites_h, gt, rd, ad, gq)
+        return self._fam_h[key]
+
+    def reads(self, bam: str):
+        if bam not in self._reads_h:
+            self._reads_h[bam] = self.backend.upload_reads(self.reads_by_bam[bam])
+        return self._reads_h[bam]
+
+    # --------------------------------------------------------------- find
+    def find(
+        self,
+        dnms: List[dict],
+        pedigrees: dict,
+        search_dist: int,
+        threads: int,
+        build: str,
+        multithread_proc_min: int,
+        quiet_mode: bool,
+        params: abi.Params,
+        whole_region: bool = True,
+        attach: bool = True,
+    ):
+        """informative_site_finder.find: annotates the DNM dicts in place with
+        `candidate_sites` / `het_sites` and returns the list in the reference's order.
+        Also returns, per returned DNM, the raw index lists (for the read stage)."""
+        log = _Log(quiet_mode)
+        many = len(dnms) >= multithread_proc_min  # :206
+        if len(dnms) <= 0:
+            return None, {}
+        sites = self.sites
+        sample_set = set(sites.samples)
+        params.search_dist = int(search_dist)
+
+        if many:
+            order, auto_tail = self._find_many_order(dnms, pedigrees, build)
+        else:
+            order, auto_tail = list(range(len(dnms))), []
+
+        # which DNMs get scanned, and with which sites-contig
+        scan: List[int] = []
+        contig_of: Dict[int, int] = {}
+        mult_of: Dict[int, int] = {}
+        dead_chroms = set()
+        if many:
+            mults = self._find_many_multiplicity(dnms, order)
+            if whole_region:
+                dead_chroms = self._find_many_keyerror_chroms(dnms, order, threads)
+        for i in order:
+            dn = dnms[i]
+            if not many and autophaseable(dn, pedigrees, build):  # :216-217
+                continue
+            kid = dn["kid"]
+            dad, mom = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
+            missing = False
+            for s in (kid, dad, mom):
+                if s not in sample_set:
+                    # the reference prints the un-formatted template (:226, :430)
+                    log("{} missing from SNV vcf/bcf" if not many else "{} missing from SNV bcf")
+                    missing = True
+            if missing:
+                continue
+            name = self.prefix + dn["chrom"].strip("chr")  # :18,:27 (quirk Q2)
+            if many and name != dn["chrom"]:
+                c = -1  # find_many keys its look-ups by the literal chrom (quirk Q3)
+            else:
+                c = sites.contig_index.get(name, -1)
+            if many and dn["chrom"] in dead_chroms:
+                c = -1
+            scan.append(i)
+            contig_of[i] = c
+            mult_of[i] = mults[i] if many else 1
+
+        found: Dict[int, dict] = {}
+        by_kid: Dict[str, List[int]] = {}
+        for i in scan:
+            by_kid.setdefault(dnms[i]["kid"], []).append(i)
+        mode = (abi.FIND_WHOLE_REGION if whole_region else 0) | (0 if many else abi.FIND_SECOND_WINDOW)
+        for kid, idxs in by_kid.items():
+            dad, mom = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
+            fam = self.family(kid, dad, mom)
+            n = len(idxs)
+            dv = abi.dnms_view(
+                contig=[contig_of[i] for i in idxs],
+                rcontig=[-1] * n,
+                start=[int(dnms[i]["start"]) for i in idxs],
+                end=[int(dnms[i]["end"]) for i in idxs],
+                vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
+                refs=[b""] * n,
+                alts=[b""] * n,
+                cutoff=0.0,
+                mult=[mult_of[i] for i in idxs],
+            )
+            co, ci, cf, ho, hi = self.backend.find(fam, dv, params, mode)
+            for k, i in enumerate(idxs):
+                found[i] = dict(
+                    cand_idx=ci[co[k] : co[k + 1]],
+                    cand_flags=cf[co[k] : co[k + 1]],
+                    het_idx=hi[ho[k] : ho[k + 1]],
+                )
+        if attach:
+            for i in scan:
+                dn = dnms[i]
+                f = found[i]
+                dad, mom = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
+                cands = self._site_dicts(f["cand_idx"], f["cand_flags"], dad, mom, whole_region)
+                hets = self._site_dicts(f["het_idx"], None, dad, mom, False)
+                if many:
+                    # find_many only creates the keys on first append (:481-482, :540-541)
+                    if cands:
+                        dn["candidate_sites"] = cands
+                    if hets:
+                        dn["het_sites"] = hets
+                else:
+                    dn["candidate_sites"] = cands  # :341-342
+                    dn["het_sites"] = hets
+        ret = [dnms[i] for i in order] + [dnms[i] for i in auto_tail]
+        ret_idx = order + auto_tail
+        return ret, {"order": ret_idx, "found": found, "many": many}
+
+    def _site_dicts(self, idx, flags, dad, mom, with_kid_allele):
+        s = self.sites
+        out = []
+        for k, j in enumerate(idx):
+            j = int(j)
+            d = {"pos": int(s.pos[j]), "ref_allele": chr(s.ref_base[j]), "alt_allele": chr(s.alt_base[j])}
+            if flags is not None:
+                fl = int(flags[k])
+                if with_kid_allele:
+                    d["kid_allele"] = ("ref_parent", "alt_parent")[((fl >> abi.CF_KA_SHIFT) & 3) - 1]
+                if fl & abi.CF_ALT_DAD:
+                    d["alt_parent"], d["ref_parent"] = dad, mom
+                else:
+                    d["alt_parent"], d["ref_parent"] = mom, dad
+            out.append(d)
+        return out
+
+    # find_many bookkeeping (create_lookups :347-396 and the flattening :647-661)
+    def _find_many_order(self, dnms, pedigrees, build):
+        auto, non = [], []
+        for i, dn in enumerate(dnms):
+            (auto if autophaseable(dn, pedigrees, build) else non).append(i)
+        vbs: Dict[str, Dict[str, Dict[int, List[int]]]] = {}
+        for i in non:
+            dn = dnms[i]
+            vbs.setdefault(dn["kid"], {}).setdefault(dn["chrom"], {}).setdefault(int(dn["start"]), []).append(i)
+        order = []
+        for kid in vbs:
+            for chrom in vbs[kid]:
+                for pos in vbs[kid][chrom]:
+                    order.extend(vbs[kid][chrom][pos])
+        return order, auto
+
+    def _find_many_multiplicity(self, dnms, order):
+        """How many times find_many appends each site to a DNM's lists: once per
+        occurrence of the kid in samples_by_location[chrom][start] (:385-395, :406-410,
+        :454): DNMs of the kid starting there plus DNMs of the kid ending there with
+        end - start > 2 (quirk Q6)."""
+        sbl: Dict[tuple, Dict[str, int]] = {}
+        for i in order:
+            dn = dnms[i]
+            st, en = int(dn["start"]), int(dn["end"])
+            k = (dn["chrom"], st)
+            sbl.setdefault(k, {})
+            sbl[k][dn["kid"]] = sbl[k].get(dn["kid"], 0) + 1
+            if (en - st) > 2:
+                k = (dn["chrom"], en)
+                sbl.setdefault(k, {})
+                sbl[k][dn["kid"]] = sbl[k].get(dn["kid"], 0) + 1
+        out = {}
+        for i in order:
+            dn = dnms[i]
+            m = sbl[(dn["chrom"], int(dn["start"]))][dn["kid"]]
+            if m > 255:
+                raise OverflowError("more than 255 DNMs of one kid share a start position")
+            out[i] = m
+        return out
+
+    def _find_many_keyerror_chroms(self, dnms, order, threads):
+        """find_many with whole_region=True indexes vars_by_sample[...][dn_loc] with
+        the END keys as well (:412-415): KeyError on the first variant of the chromosome
+        unless every end key is also a start of the same kid (quirk Q7).  With
+        threads != 1 the worker's exception is swallowed and the chromosome yields
+        nothing; with threads == 1 the reference crashes -- mirrored as KeyError."""
+        starts = set()
+        for i in order:
+            dn = dnms[i]
+            starts.add((dn["kid"], dn["chrom"], int(dn["start"])))
+        dead = set()
+        for i in order:
+            dn = dnms[i]
+            st, en = int(dn["start"]), int(dn["end"])
+            if (en - st) > 2 and (dn["kid"], dn["chrom"], en) not in starts:
+                dead.add(dn["chrom"])
+        if dead and threads == 1:
+            raise KeyError("find_many(whole_region=True): reference raises KeyError (SURVEY.md quirk Q7)")
+        return dead
+
+    # ------------------------------------------------------ read phasing
+    def get_refalt(self, chrom: str, pos: int):
+        """reference snv_phaser.py:73-84: REF of the first and ALTs of all records
+        overlapping 1-based [pos, pos+1]."""
+        name = self.prefix + chrom.strip("chr")
+        idx = self.sites.query(name, int(pos), int(pos) + 1)
+        ref = None
+        alts: List[str] = []
+        for j in idx:
+            if ref is None:
+                ref = self.sites.ref_str[int(j)]
+            alts.extend(self.sites.alt_strs[int(j)])
+        return ref, alts
+
+    def kid_cutoff(self, kid: str, bam: str, readlen: int, stdevs: int) -> float:
+        if kid not in self.cutoffs or not self.cutoffs[kid]:  # snv_phaser.py:133-135, read_collector.py:377
+            rt = self.reads_by_bam[bam]
+            head = getattr(rt, "tlen_head", None)
+            if head is None:
+                head = rt.tlen
+            self.cutoffs[kid] = concordant_cutoff(head, readlen, stdevs)
+        return self.cutoffs[kid]
+
+    def resolve_reads_contig(self, rt: ReadsTable, chrom: str):
+        """reference read_collector.py:384-392: fetch on the literal name, on
+        ValueError retry with the chr prefix toggled and the narrower window."""
+        if chrom in rt.contig_index:
+            return rt.contig_index[chrom], 0
+        alt = chrom.strip("chr") if "chr" in chrom else "chr" + chrom
+        if alt in rt.contig_index:
+            return rt.contig_index[alt], abi.DF_FETCH_FALLBACK
+        return -1, 0
+
+    def run_read_phasing(
+        self,
+        dnms,
+        pedigrees,
+        threads,
+        build,
+        no_extended,
+        multithread_proc_min,
+        quiet_mode,
+        params: abi.Params,
+        search_dist,
+        insert_size_max_sample,
+        stdevs,
+        readlen,
+        want_lists=True,
+    ):
+        """reference snv_phaser.py:206-299 (+ multithread_read_phasing :87-203)."""
+        log = _Log(quiet_mode)
+        params.no_extended = 1 if no_extended else 0
+        params.read_goal = int(insert_size_max_sample)
+        params.readlen = int(readlen)
+        ret, info = self.find(
+            dnms, pedigrees, search_dist, threads, build, multithread_proc_min, quiet_mode, params,
+            whole_region=False,
+        )
+        records: Dict[str, dict] = {}
+        if ret is None:
+            return records
+        found = info["found"]
+        # pass 1: host-side filters in the reference's order; collect the device batch per kid
+        plan = []  # (dnm index, action)
+        batch: Dict[tuple, List[int]] = {}
+        prep: Dict[int, dict] = {}
+        sample_set = set(self.sites.samples)
+        for i in info["order"]:
+            dn = dnms[i]
+            dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
+            if autophaseable(dn, pedigrees, build):  # snv_phaser.py:251, :302-352
+                plan.append((i, "auto"))
+                continue
+            f = found.get(i)
+            if f is None or len(f["cand_idx"]) == 0:  # :254-262
+                plan.append((i, "nocand"))
+                continue
+            if dn["kid"] not in sample_set:  # :109-110
+                plan.append((i, "silent"))
+                continue
+            ref, alts = self.get_refalt(dn["chrom"], dn["start"])  # :111-116
+            if len(alts) < 1:
+                plan.append((i, "nogt"))
+                continue
+            if len(alts) > 1:
+                plan.append((i, "manygt"))
+                continue
+            rt = self.reads_by_bam[dn["bam"]]
+            tid, fl = self.resolve_reads_contig(rt, dn["chrom"])
+            if tid < 0:
+                plan.append((i, "silent"))  # ValueError out of the worker: no record
+                continue
+            prep[i] = dict(ref=ref.encode("ascii"), alt=alts[0].encode("ascii"), tid=tid, dflags=fl)
+            batch.setdefault((dn["kid"], dn["bam"]), []).append(i)
+            plan.append((i, "phase"))
+        # pass 2: device
+        results: Dict[int, dict] = {}
+        for (kid, bam), idxs in batch.items():
+            dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
+            fam = self.family(kid, dad_id, mom_id)
+            rh = self.reads(bam)
+            cutoff = self.kid_cutoff(kid, bam, readlen, stdevs)
+            name_of = {}
+            for i in idxs:
+                nm = self.prefix + dnms[i]["chrom"].strip("chr")
+                name_of[i] = self.sites.contig_index.get(nm, -1)
+            dv = abi.dnms_view(
+                contig=[name_of[i] for i in idxs],
+                rcontig=[prep[i]["tid"] for i in idxs],
+                start=[int(dnms[i]["start"]) for i in idxs],
+                end=[int(dnms[i]["end"]) for i in idxs],
+                vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
+                refs=[prep[i]["ref"] for i in idxs],
+                alts=[prep[i]["alt"] for i in idxs],
+                cutoff=cutoff,
+                dflags=[prep[i]["dflags"] for i in idxs],
+            )
+            fl = [found[i] for i in idxs]
+            res = self.backend.phase(fam, rh, dv, params, fl, want_lists)
+            for k, i in enumerate(idxs):
+                results[i] = (res, k)
+        # pass 3: records, in the reference's order
+        for i, action in plan:
+            dn = dnms[i]
+            dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
+            region = {"chrom": dn["chrom"], "start": dn["start"], "end": dn["end"]}
+            key = "_".join([str(v) for v in region.values()] + [dn["kid"], dn["vartype"]])
+            if action == "auto":
+                records[key] = {
+                    "region": region, "vartype": dn["vartype"], "kid": dn["kid"], "dad": dad_id, "mom": mom_id,
+                    "cnv_dad_sites": "NA", "cnv_mom_sites": "NA", "cnv_evidence_type": "SEX-CHROM",
+                    "dad_sites": "", "mom_sites": "", "evidence_type": "SEX-CHROM",
+                    "dad_reads": [], "mom_reads": [],
+                }
+            elif action == "nocand":
+                log("No usable informative sites for variant {}:{}-{}".format(dn["chrom"], dn["start"], dn["end"]))
+            elif action == "nogt":
+                log("No usable genotype for variant {chrom}:{start}-{end}".format(**region))
+            elif action == "manygt":
+                log("Too many genotypes for variant {chrom}:{start}-{end}".format(**region))
+            elif action == "phase":
+                res, k = results[i]
+                st = int(res["status"][k])
+                if st == abi.ST_NO_OVERLAP:
+                    log("No reads overlap informative sites for variant {chrom}:{start}-{end}".format(**region))
+                    continue
+                if st != abi.ST_OK:
+                    continue
+                rt = self.reads_by_bam[dn["bam"]]
+                lists = res.get("lists")
+                if lists is not None:
+                    dr, mr, ds, ms = lists[k]
+                    dad_reads = [rt.qnames[q] for q in dr]
+                    mom_reads = [rt.qnames[q] for q in mr]
+                    dad_sites = [str(p) for p in ds]
+                    mom_sites = [str(p) for p in ms]
+                else:
+                    c = res["counts"][k]
+                    dad_reads, mom_reads = [None] * int(c[0]), [None] * int(c[1])
+                    dad_sites, mom_sites = [None] * int(c[2]), [None] * int(c[3])
+                records[key] = {
+                    "region": region, "vartype": dn["vartype"], "kid": dn["kid"], "dad": dad_id, "mom": mom_id,
+                    "dad_sites": dad_sites, "mom_sites": mom_sites, "evidence_type": "readbacked",
+                    "dad_reads": dad_reads, "mom_reads": mom_reads,
+                    "cnv_dad_sites": "", "cnv_mom_sites": "", "cnv_evidence_type": "",
+                }
+        return records
+
+    # ------------------------------------------------------- CNV phasing
+    def run_cnv_phasing(self, dnms, pedigrees, threads, build, multithread_proc_min, quiet_mode, params):
+        """reference sv_phaser.py:357-423 with phase_by_snvs (:71-85) and
+        multithread_cnv_phasing (:269-301): allele-balance phasing of DEL/DUP."""
+        log = _Log(quiet_mode)
+        ret, info = self.find(
+            dnms, pedigrees, 0, threads, build, multithread_proc_min, quiet_mode, params, whole_region=True
+        )
+        records: Dict[str, dict] = {}
+        if ret is None:
+            return records
+        for i in info["order"]:
+            dn = dnms[i]
+            dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
+            # sv_phaser.autophase writes the record but returns None (quirk Q18): fall through
+            region = {"chrom": dn["chrom"], "start": dn["start"], "end": dn["end"]}
+            key = "_".join([str(r) for r in region.values()] + [dn["kid"], dn["vartype"]])
+            if autophaseable(dn, pedigrees, build):
+                records[key] = {
+                    "region": region, "vartype": dn["vartype"], "kid": dn["kid"], "dad": dad_id, "mom": mom_id,
+                    "cnv_dad_sites": "NA", "cnv_mom_sites": "NA", "cnv_evidence_type": "SEX-CHROM",
+                    "dad_sites": "", "mom_sites": "", "evidence_type": "SEX-CHROM",
+                    "dad_reads": [], "mom_reads": [],
+                }
+            if dn["vartype"] not in ["DEL", "DUP"]:  # :401
+                continue
+            if "candidate_sites" not in dn or len(dn["candidate_sites"]) == 0:  # :404-412
+                log("No usable informative sites for allele-balance phasing of variant {}:{}-{}".format(
+                    dn["chrom"], dn["start"], dn["end"]))
+                continue
+            cs = dn["candidate_sites"]
+            origin = {cs[0]["ref_parent"]: [], cs[0]["alt_parent"]: []}  # :75-78
+            for s in cs:
+                origin[s[s["kid_allele"]]].append(s)  # :81-84
+            ev = {dad_id: [], mom_id: []}
+            for parent in ev:
+                if parent in origin and len(origin[parent]) > 0:
+                    ev[parent] = [str(o["pos"]) for o in origin[parent]]
+            records[key] = {
+                "region": region, "vartype": dn["vartype"], "kid": dn["kid"], "dad": dad_id, "mom": mom_id,
+                "cnv_dad_sites": ev[dad_id], "cnv_mom_sites": ev[mom_id], "cnv_evidence_type": "ALLELE-BALANCE",
+                "dad_sites": "", "mom_sites": "", "evidence_type": "",
+                "dad_reads": [], "mom_reads": [],
+            }
+        return records
