@@ -1,0 +1,121 @@
+/* unfazed_hip.h -- C ABI of the MI355X (gfx950) per-DNM phasing path.
+ *
+ * The reference (unfazed v1.0.3) has no FFI seam; the drop-in boundary is the
+ * pair of Python calls its driver makes (reference unfazed/unfazed.py:601-646):
+ *     phase_snvs(dnms, kids, pedigrees, sites, threads, build, ...)  snv_phaser.py:356-399
+ *     phase_svs (same 20 positional parameters)                      sv_phaser.py:427-493
+ * unfazed_amd/snv_phaser.py and sv_phaser.py keep those two signatures and call
+ * the entry points below through ctypes (INTEGRATION.md shows the stub a
+ * maintainer of the reference would add).  Each entry point names the reference
+ * code it replaces.
+ *
+ * Conventions: every function returns 0 on success or a negative UZ_E_* code;
+ * uz_last_error() gives the message.  No C++ exception, exit() or stdio crosses
+ * this boundary.  All pointers are caller-owned HOST memory unless the function
+ * name says `_device`.  One host thread drives one context; contexts are
+ * independent (multi-GPU = one context per process/GPU, DNMs sharded by the
+ * caller, no collective).
+ */
+#ifndef UNFAZED_HIP_H
+#define UNFAZED_HIP_H
+
+#include <stdint.h>
+
+#include "uz_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UZ_E_ARG (-1)      /* bad argument / unknown handle */
+#define UZ_E_HIP (-2)      /* a HIP runtime call failed */
+#define UZ_E_NODEVICE (-3) /* no gfx950 device visible */
+#define UZ_E_STATE (-4)    /* call order (e.g. fetch before find) */
+#define UZ_E_RANGE (-5)    /* input exceeds an index range of the device layout */
+
+#define UZ_FIND_WHOLE_REGION 1  /* find(..., whole_region=True): CNV interior, sv_phaser.py:375-389 */
+#define UZ_FIND_SECOND_WINDOW 2 /* find()'s second window around `end` (informative_site_finder.py:32-40); find_many has none */
+
+/* kernels whose launches are timed with HIP events on the context's stream */
+#define UZ_K_SITE_SCAN 0   /* K1 site classify (the roofline kernel) */
+#define UZ_K_WINDOW_COUNT 1
+#define UZ_K_WINDOW_FILL 2
+#define UZ_K_SEG_QC 3
+#define UZ_K_PHASE 4
+#define UZ_K_COUNT 8
+
+typedef struct uz_ctx uz_ctx;
+
+/* ---- context ---------------------------------------------------------- */
+int uz_create(int device, uz_ctx **out);
+void uz_destroy(uz_ctx *ctx);
+const char *uz_last_error(const uz_ctx *ctx);
+int uz_sync(uz_ctx *ctx);
+/* thresholds: replaces the module globals the reference sets per call
+ * (informative_site_finder.py:187-204, read_collector.py:361-370) */
+int uz_set_params(uz_ctx *ctx, const uz_params *p);
+
+/* ---- staging ---------------------------------------------------------- */
+/* Sites file columns -> HBM.  Replaces cyvcf2.VCF(...) + per-DNM tabix queries
+ * (informative_site_finder.py:213, :42; find_many :558-568). */
+int uz_sites_upload(uz_ctx *ctx, const uz_sites_view *sites, int *sites_id);
+/* Genotype columns of one trio -> HBM (gt_types / gt_ref_depths / gt_alt_depths /
+ * gt_quals of informative_site_finder.py:257-260). */
+int uz_family_upload(uz_ctx *ctx, int sites_id, const uz_family_view *fam, int *fam_id);
+/* Alignment records of one BAM -> HBM.  Replaces pysam.AlignmentFile + fetch +
+ * mate (read_collector.py:372-385, :400, :167, :185). */
+int uz_reads_upload(uz_ctx *ctx, const uz_reads_view *reads, int *reads_id);
+/* Same three, for columns that already live in HBM (device pointers in the
+ * views; the library does not copy or free them). */
+int uz_sites_adopt_device(uz_ctx *ctx, const uz_sites_view *sites, int *sites_id);
+int uz_family_adopt_device(uz_ctx *ctx, int sites_id, const uz_family_view *fam, int *fam_id);
+int uz_reads_adopt_device(uz_ctx *ctx, const uz_reads_view *reads, int *reads_id);
+int uz_sites_free(uz_ctx *ctx, int sites_id); /* also frees its families */
+int uz_reads_free(uz_ctx *ctx, int reads_id);
+
+/* ---- site stage ------------------------------------------------------- */
+/* K1: one streaming pass over the family's columns -> one class byte per site
+ * (UZ_CL_*).  Replaces is_high_quality_site (:46-73), get_kid_allele (:76-134) and
+ * the DNM-independent part of find()'s per-variant body (:239-339 = :442-543). */
+int uz_site_scan(uz_ctx *ctx, int fam_id);
+int uz_site_classes(uz_ctx *ctx, int fam_id, uint8_t *cls_out /* [n_sites] */);
+
+/* K2: per-DNM window emit.  Replaces get_position (:10-43) / get_close_vars
+ * (:399-420) and the list building of find (:262-343).  Runs uz_site_scan first
+ * if the family's classes are stale.  Writes the CSR offsets; the lists stay in
+ * HBM for uz_phase and can be copied out with uz_find_fetch. */
+int uz_find(uz_ctx *ctx, int fam_id, const uz_dnms_view *dnms, int mode,
+            int64_t *cand_off /* [n+1] */, int64_t *het_off /* [n+1] */);
+int uz_find_fetch(uz_ctx *ctx, int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx);
+
+/* ---- read stage ------------------------------------------------------- */
+/* Everything multithread_read_phasing does after get_refalt (snv_phaser.py:131-203):
+ * collect_reads_snv (+ group_reads_by_haplotype / connect_reads), match_informative_sites,
+ * phase_by_reads, the unique-name / unique-site tally and summarize_record's integer
+ * read-backed decision (unfazed.py:193-234).  Runs the window emit for the batch first
+ * (find_mode: UZ_FIND_SECOND_WINDOW for find, 0 for find_many; never WHOLE_REGION),
+ * whose lists can be read back with uz_find_fetch afterwards.
+ * counts = dad_reads, mom_reads, dad_sites, mom_sites per DNM. */
+int uz_phase(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode,
+             int32_t *status /* [n] UZ_ST_* */, int32_t *counts /* [4n] */,
+             int32_t *origin /* [n] UZ_OR_* */, int32_t *evidence /* [n] */);
+/* Vote lists of the last uz_phase (for --verbose and the records dict):
+ * vote_off[4n+1] then vote_val: dad_reads (qname ids, ascending), mom_reads,
+ * dad_sites (positions, ascending), mom_sites.  Call with vote_val == NULL to get
+ * the offsets / total first. */
+int uz_phase_votes(uz_ctx *ctx, int64_t *vote_off /* [4n+1] */, int32_t *vote_val);
+/* Haplotype groups after connect_reads of the last uz_phase (diagnostics / tests):
+ * grp_off[2n+1] then grp_q: "ref" set then "alt" set (qname ids, ascending). */
+int uz_phase_groups(uz_ctx *ctx, int64_t *grp_off /* [2n+1] */, int32_t *grp_q);
+
+/* ---- measurement ------------------------------------------------------ */
+/* HIP-event timing of the kernels launched on the context's stream since the
+ * last reset: total milliseconds and launch count per UZ_K_* id. */
+int uz_prof_enable(uz_ctx *ctx, int on);
+int uz_prof_reset(uz_ctx *ctx);
+int uz_prof_get(uz_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNFAZED_HIP_H */

@@ -1,0 +1,119 @@
+"""Vectorised (numpy) synthetic sites table + DNM list at benchmark scale.
+
+Test / bench infrastructure.  Produces the device-facing columns directly
+(no record objects): a whole-genome-like sorted sites table for one trio and a
+list of DNM coordinates placed on existing sites (kid het, parents hom-ref), as
+SURVEY.md 8(d) configs 2/3 describe.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+GRCH38_LEN = [
+    248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+    138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+    83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415,
+]
+
+
+@dataclass
+class SitesColumns:
+    contig_names: List[str]
+    contig_off: np.ndarray  # int64 [nc+1]
+    pos: np.ndarray  # int32
+    sflags: np.ndarray  # uint8
+    ref_base: np.ndarray
+    alt_base: np.ndarray
+    gt: np.ndarray  # uint8 packed kid|dad<<2|mom<<4
+    rd: np.ndarray  # uint16 [3][S]
+    ad: np.ndarray
+    gq: np.ndarray
+
+    @property
+    def n(self):
+        return int(self.pos.shape[0])
+
+
+def make_sites(n_sites: int, seed: int = 202, contig_lens=None, complex_frac=0.02, weird_frac=0.01) -> SitesColumns:
+    rng = np.random.default_rng(seed)
+    lens = np.array(contig_lens if contig_lens is not None else GRCH38_LEN, dtype=np.float64)
+    per = np.floor(lens / lens.sum() * n_sites).astype(np.int64)
+    per[0] += n_sites - per.sum()
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    off[1:] = np.cumsum(per)
+    pos = np.empty(n_sites, dtype=np.int32)
+    for c in range(len(lens)):
+        k = int(per[c])
+        if k == 0:
+            continue
+        step = lens[c] / k
+        base = (np.arange(k) * step).astype(np.int64)
+        jit = (rng.random(k) * max(1.0, step - 1)).astype(np.int64)
+        pos[off[c]: off[c + 1]] = (base + jit + 1).astype(np.int32)
+    S = n_sites
+    f = rng.random(S) ** 3
+    dh = (rng.random((2, S)) < f).astype(np.uint8)
+    mh = (rng.random((2, S)) < f).astype(np.uint8)
+    td = rng.integers(0, 2, S)
+    tm = rng.integers(0, 2, S)
+    pat = np.where(td == 0, dh[0], dh[1])
+    mat = np.where(tm == 0, mh[0], mh[1])
+    code = np.array([0, 1, 3], dtype=np.uint8)
+    g = np.stack([code[pat + mat], code[dh[0] + dh[1]], code[mh[0] + mh[1]]])
+    depth = rng.poisson(30.0, (3, S)).astype(np.int64)
+    p_alt = np.where(g == 0, 0.01, np.where(g == 1, 0.5, 0.99))
+    ad = rng.binomial(depth, p_alt).astype(np.int64)
+    rd = depth - ad
+    gq = np.where(rng.random((3, S)) < 0.93, 99, rng.integers(0, 61, (3, S))).astype(np.int64)
+    # awkward values: unknown genotypes, missing fields, zero depth
+    w = rng.random((3, S)) < weird_frac
+    kind = rng.integers(0, 4, (3, S))
+    g = np.where(w & (kind == 0), 2, g).astype(np.uint8)
+    miss = w & (kind == 1)
+    rd = np.where(miss, 0xFFFF, rd)
+    ad = np.where(miss, 0xFFFF, ad)
+    gq = np.where(w & (kind == 2), 0xFFFF, gq)
+    zero = w & (kind == 3)
+    rd = np.where(zero, 0, rd)
+    ad = np.where(zero, 0, ad)
+    sflags = (rng.random(S) < complex_frac).astype(np.uint8)
+    ref_i = rng.integers(0, 4, S)
+    alt_i = (ref_i + rng.integers(1, 4, S)) % 4
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    ref_base = np.where(sflags == 1, 0, bases[ref_i]).astype(np.uint8)
+    alt_base = np.where(sflags == 1, 0, bases[alt_i]).astype(np.uint8)
+    gt = (g[0] | (g[1] << 2) | (g[2] << 4)).astype(np.uint8)
+    names = [str(i + 1) for i in range(22)] + ["X", "Y"]
+    names = names[: len(lens)] if len(lens) <= 24 else [str(i + 1) for i in range(len(lens))]
+    return SitesColumns(
+        names, off, pos, sflags, ref_base, alt_base, gt,
+        np.ascontiguousarray(rd.astype(np.uint16)), np.ascontiguousarray(ad.astype(np.uint16)),
+        np.ascontiguousarray(gq.astype(np.uint16)),
+    )
+
+
+def place_dnms(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1):
+    """Pick n_dnms sites (stratified over the table) and turn them into the DNMs' own
+    records: kid het, parents hom-ref, good depth/GQ.  Returns (site index, contig id,
+    start, end) arrays; `end - start` > 1 marks a small deletion."""
+    rng = np.random.default_rng(seed)
+    S = sc.n
+    step = S / n_dnms
+    idx = (np.arange(n_dnms) * step + rng.random(n_dnms) * step * 0.5).astype(np.int64)
+    idx = np.minimum(idx, S - 1)
+    sc.gt[idx] = 1  # kid het, dad/mom hom-ref
+    sc.sflags[idx] = 0
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    sc.ref_base[idx] = bases[rng.integers(0, 4, n_dnms)]
+    sc.alt_base[idx] = bases[(np.searchsorted(bases, sc.ref_base[idx]) + 1) % 4]
+    for m in range(3):
+        sc.rd[m][idx] = 30 if m else 15
+        sc.ad[m][idx] = 0 if m else 15
+        sc.gq[m][idx] = 99
+    contig = (np.searchsorted(sc.contig_off, idx, side="right") - 1).astype(np.int32)
+    start = sc.pos[idx].astype(np.int32)
+    dlen = np.where(rng.random(n_dnms) < indel_frac, rng.integers(2, 11, n_dnms), 1).astype(np.int32)
+    return idx, contig, start, start + dlen

@@ -25,7 +25,7 @@ class OracleBackend:
         sites_h, fv = fam
         return orc.find(params, sites_h, fv, dv, mode)
 
-    def phase(self, fam, reads_h, dv, params, found_list, want_lists=True):
+    def phase(self, fam, reads_h, dv, params, found_list, want_lists=True, find_mode=2):
         sites_h, fv = fam
         n = dv.view.n
         co = np.zeros(n + 1, dtype=np.int64)

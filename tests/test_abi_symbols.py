@@ -1,0 +1,49 @@
+"""CPU-side checks of the C-ABI library: it builds, loads and exports every symbol
+include/unfazed_hip.h declares.  No compute call (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "unfazed_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(uz_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    L = ctypes.CDLL(hip_lib)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+
+
+def test_binding_lists_the_same_symbols(hip_lib):
+    from unfazed_amd import engine
+    assert sorted(engine.EXPORTS) == declared_symbols()
+    engine.load_library()
+
+
+def test_no_device_is_a_loud_error(hip_lib):
+    """Without a GPU uz_create must fail with a code, and the Python engine must raise."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    from unfazed_amd.engine import HipEngine, UnfazedHipError
+    try:
+        HipEngine(0)
+    except UnfazedHipError:
+        return
+    raise AssertionError("HipEngine() succeeded without a device")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "unfazed_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dp, fn)).read()
+                assert "oracle" not in src.replace("the oracle", "").replace("CPU oracle", "") or fn == "abi.py", fn

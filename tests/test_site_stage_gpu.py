@@ -1,0 +1,91 @@
+"""GPU parity of the site stage (K1 site scan, K2 window emit) against the CPU
+oracle on the same seeded columns, through the C ABI.  Bit-exact (integer/byte)."""
+import numpy as np
+import pytest
+
+from synth.sites_np import make_sites, place_dnms
+from unfazed_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _views(sc):
+    sv = abi.SitesView()
+    arrs = dict(contig_off=sc.contig_off, pos=sc.pos, sflags=sc.sflags, ref_base=sc.ref_base, alt_base=sc.alt_base)
+    sv.n_sites = sc.n
+    sv.n_contigs = len(sc.contig_off) - 1
+    for k, a in arrs.items():
+        setattr(sv, k, a.ctypes.data)
+    return abi.Held(sv, arrs), abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
+
+
+class _Sites:
+    """minimal object the engine's upload_sites accepts"""
+    def __init__(self, sc):
+        self.contig_off, self.pos, self.sflags, self.ref_base, self.alt_base = sc.contig_off, sc.pos, sc.sflags, sc.ref_base, sc.alt_base
+        self.contigs = sc.contig_names
+        self.n_sites = sc.n
+
+
+PARAM_SETS = [
+    dict(),
+    dict(min_gt_qual=30, min_depth=0, ab_het=(0.3, 0.7)),
+    dict(min_gt_qual=0, min_depth=25, ab_homref=(0.0, 0.05), ab_homalt=(0.95, 1.0), ab_het=(0.45, 0.55)),
+    dict(min_gt_qual=-5, min_depth=-5),
+]
+
+
+@pytest.mark.parametrize("n_sites", [0, 1, 7, 8, 9, 4097, 300_001])
+def test_site_scan_matches_oracle(engine, n_sites):
+    from oracle import oracle as orc
+    sc = make_sites(max(n_sites, 1), seed=7 + n_sites, contig_lens=[5e6, 3e6, 1e6], weird_frac=0.08, complex_frac=0.05)
+    if n_sites == 0:
+        for name in ("pos", "sflags", "ref_base", "alt_base", "gt"):
+            setattr(sc, name, getattr(sc, name)[:0])
+        sc.rd, sc.ad, sc.gq = sc.rd[:, :0].copy(), sc.ad[:, :0].copy(), sc.gq[:, :0].copy()
+        sc.contig_off = np.zeros_like(sc.contig_off)
+    sh, fh = _views(sc)
+    sid = engine.upload_sites(_Sites(sc))
+    fid = engine.add_family(sid, sc.gt, sc.rd, sc.ad, sc.gq)
+    for kw in PARAM_SETS:
+        P = abi.make_params(**kw)
+        want = orc.classify(P, sh, fh)
+        got = engine.classify(fid, P, sc.n)
+        assert np.array_equal(want, got), (kw, np.nonzero(want != got)[0][:10])
+    engine.free_sites(sid)
+
+
+@pytest.mark.parametrize("mode", [0, abi.FIND_SECOND_WINDOW, abi.FIND_WHOLE_REGION])
+def test_window_emit_matches_oracle(engine, mode):
+    from oracle import oracle as orc
+    sc = make_sites(400_000, seed=11, contig_lens=[4e7, 2e7, 1e7], weird_frac=0.03)
+    idx, contig, start, end = place_dnms(sc, 3000, seed=5)
+    rng = np.random.default_rng(3)
+    n = len(start)
+    vt = np.zeros(n, dtype=np.uint8)
+    mult = np.ones(n, dtype=np.uint8)
+    if mode & abi.FIND_WHOLE_REGION:
+        vt = rng.integers(1, 4, n).astype(np.uint8)
+        end = (start + rng.integers(1000, 200000, n)).astype(np.int32)
+        sd = 0
+    else:
+        # long events exercise the second window (and overlapping windows), mult the find_many duplicates
+        long = rng.random(n) < 0.2
+        end = np.where(long, start + rng.integers(4000, 20000, n), end).astype(np.int32)
+        mult = np.where(rng.random(n) < 0.1, 2, 1).astype(np.uint8)
+        sd = 5000
+    contig = contig.copy()
+    contig[::97] = -1  # contig missing from the sites file
+    start[5] = 10  # window clipped at the contig start
+    end[5] = 11
+    sh, fh = _views(sc)
+    sid = engine.upload_sites(_Sites(sc))
+    fid = engine.add_family(sid, sc.gt, sc.rd, sc.ad, sc.gq)
+    P = abi.make_params(search_dist=sd)
+    dv = abi.dnms_view(contig, [-1] * n, start, end, vt, [b""] * n, [b""] * n, 0.0, mult=mult)
+    want = orc.find(P, sh, fh, dv, mode)
+    got = engine.find(fid, dv, P, mode)
+    for a, b, name in zip(want, got, ("cand_off", "cand_idx", "cand_flags", "het_off", "het_idx")):
+        assert np.array_equal(a, b), name
+    assert want[0][-1] > 100 and want[3][-1] > 100
+    engine.free_sites(sid)

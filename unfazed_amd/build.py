@@ -1,0 +1,36 @@
+"""Builds unfazed_amd/libunfazed_hip.so in-tree with hipcc for gfx950.
+(hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.)"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = ["abi.hip", "k_sites.hip", "k_reads.hip"]
+LIB = os.path.join(_HERE, "libunfazed_hip.so")
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    csrc = os.path.join(_HERE, "csrc")
+    inc = os.path.join(_HERE, "..", "include")
+    srcs = [os.path.join(csrc, s) for s in SRC]
+    deps = srcs + [os.path.join(csrc, "uz_ctx.hpp"), os.path.join(csrc, "wg.hpp"),
+                   os.path.join(inc, "uz_types.h"), os.path.join(inc, "unfazed_hip.h")]
+    deps = [d for d in deps if os.path.exists(d)]
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-Wall", "-Wno-unused-parameter", "-I", inc, "-I", csrc] + list(extra_flags) + srcs + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

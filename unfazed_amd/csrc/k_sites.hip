@@ -1,0 +1,390 @@
+// k_sites.hip -- site stage on gfx950.
+//
+//   K1  k_site_scan     one streaming pass over a trio's genotype columns -> one class
+//                       byte per site (UZ_CL_*).  HBM-bound: 19 B read + 1 B written per site
+//                       (gt 1 + 9 x u16 columns; DESIGN.md "K1").  Each lane owns SPT consecutive
+//                       sites so every column is read with 16-byte (SPT=8) or 2x16-byte (SPT=16)
+//                       fully coalesced loads, all issued before the first use.
+//   K2  k_window        per-DNM window bounds (two binary searches on pos[]) and ordered
+//                       emission of the candidate / het lists (count pass, scan, fill pass).
+//
+// Logic restated from reference unfazed/informative_site_finder.py: is_high_quality_site
+// (:46-73), get_kid_allele (:76-134), the per-variant body of find (:239-339, duplicated at
+// :442-543) and get_position (:10-43).  No MFMA: there is no contraction here.
+#include "uz_ctx.hpp"
+
+namespace {
+
+struct SiteParams {
+    int32_t min_gt_qual, min_depth;
+    double lo_ref, hi_ref, lo_het, hi_het, lo_alt, hi_alt; // allele-balance windows per genotype
+};
+
+__device__ __forceinline__ int dec16(uint32_t v) { return v == UZ_U16_MISSING ? -1 : (int)v; }
+
+// is_high_quality_site (:46-73) given the member's allele balance
+__device__ __forceinline__ bool hq(const SiteParams &P, int gt, int rd, int ad, int gq, double ab) {
+    const bool ok = (gt != UZ_GT_UNKNOWN) & (gq >= P.min_gt_qual) & ((rd + ad) >= P.min_depth);
+    // selects, not an indexed table: a run-time index into the by-value struct would go to scratch
+    const double lo = gt == UZ_HOM_REF ? P.lo_ref : (gt == UZ_HOM_ALT ? P.lo_alt : P.lo_het);
+    const double hi = gt == UZ_HOM_REF ? P.hi_ref : (gt == UZ_HOM_ALT ? P.hi_alt : P.hi_het);
+    return ok & (lo <= ab) & (ab <= hi);
+}
+
+__device__ __forceinline__ uint8_t classify_site(const SiteParams &P, uint32_t g, int rdk, int adk, int gqk, int rdd,
+                                                 int add, int gqd, int rdm, int adm, int gqm) {
+    const int kid = g & 3, dad = (g >> 2) & 3, mom = (g >> 4) & 3;
+    // allele balances: numpy int32 / float -> IEEE double division (0/0 -> NaN -> every test false)
+    const double abk = (double)adk / (double)(rdk + adk);
+    const double abd = (double)add / (double)(rdd + add);
+    const double abm = (double)adm / (double)(rdm + adm);
+    const bool hqk = hq(P, kid, rdk, adk, gqk, abk);
+    const bool hqd = hq(P, dad, rdd, add, gqd, abd);
+    const bool hqm = hq(P, mom, rdm, adm, gqm, abm);
+    uint32_t c = 0;
+    if (kid == UZ_HET && hqd && hqm) c |= UZ_CL_HET; // :268-284
+    // parental pattern :307-320
+    bool pattern = false, alt_dad = false;
+    if ((dad == UZ_HET || dad == UZ_HOM_ALT) && mom == UZ_HOM_REF) { pattern = true; alt_dad = true; }
+    else if ((mom == UZ_HET || mom == UZ_HOM_ALT) && dad == UZ_HOM_REF) { pattern = true; alt_dad = false; }
+    else if (mom == UZ_HET && dad == UZ_HOM_ALT) { pattern = true; alt_dad = true; }
+    else if (dad == UZ_HET && mom == UZ_HOM_ALT) { pattern = true; alt_dad = false; }
+    if (pattern && alt_dad) c |= UZ_CL_ALT_DAD;
+    if (hqd && hqm && pattern) {
+        if (kid == UZ_HET && hqk) c |= UZ_CL_CAND; // :292-295
+        // hemizygous unique-allele check :324-337
+        bool unique = true;
+        if (kid == UZ_HOM_ALT || kid == UZ_HOM_REF) {
+            const bool het_in = (dad == UZ_HET) || (mom == UZ_HET);
+            const bool hom_in = (dad != UZ_HET && dad != UZ_GT_UNKNOWN) || (mom != UZ_HET && mom != UZ_GT_UNKNOWN);
+            if (het_in && hom_in) {
+                if ((dad == UZ_HOM_ALT || dad == UZ_HOM_REF) && kid == dad) unique = false;
+                if ((mom == UZ_HOM_ALT || mom == UZ_HOM_REF) && kid == mom) unique = false;
+            }
+        }
+        if (unique) {
+            // get_kid_allele :76-134 for a DEL and for a DUP
+            uint32_t kdel = UZ_KA_NONE, kdup = UZ_KA_NONE;
+            if ((rdk + adk) > 4) { // :80
+                if (kid == UZ_HOM_ALT) kdel = UZ_KA_REF_PARENT;
+                else if (kid == UZ_HOM_REF) kdel = UZ_KA_ALT_PARENT;
+            }
+            if (rdk > 2 && adk > 2 && (rdk + adk) > P.min_depth && kid == UZ_HET) { // :89-97
+                const double s = abd + abm;
+                const bool shared_dup = ((s < 1.0) && (abk > 0.5)) || ((s > 1.0) && (abk < 0.5)); // :110-116
+                if (!shared_dup) {
+                    if (abk >= 0.67) kdup = UZ_KA_ALT_PARENT;      // :119-121
+                    else if (abk <= 0.33) kdup = UZ_KA_REF_PARENT; // :122-124
+                }
+            }
+            c |= kdel << UZ_CL_DEL_SHIFT;
+            c |= kdup << UZ_CL_DUP_SHIFT;
+        }
+    }
+    return (uint8_t)c;
+}
+
+template <int SPT>
+struct ColVec; // SPT u16 values
+template <>
+struct ColVec<8> {
+    uint4 v;
+    __device__ __forceinline__ void load(const uint16_t *p) { v = *reinterpret_cast<const uint4 *>(p); }
+    __device__ __forceinline__ uint32_t get(int i) const {
+        const uint32_t w = (&v.x)[i >> 1];
+        return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+    }
+};
+template <>
+struct ColVec<16> {
+    uint4 v[2];
+    __device__ __forceinline__ void load(const uint16_t *p) {
+        v[0] = reinterpret_cast<const uint4 *>(p)[0];
+        v[1] = reinterpret_cast<const uint4 *>(p)[1];
+    }
+    __device__ __forceinline__ uint32_t get(int i) const {
+        const uint32_t w = (&v[i >> 3].x)[(i & 7) >> 1];
+        return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+    }
+};
+
+struct FamPtrs {
+    const uint8_t *gt;
+    const uint16_t *rd[3], *ad[3], *gq[3];
+};
+
+template <int SPT>
+__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restrict__ cls, int64_t n, SiteParams P) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t base = t * SPT;
+    if (base >= n) return;
+    if (base + SPT <= n) {
+        // issue all 19-20 vector loads before the first use
+        ColVec<SPT> c[9];
+        uint32_t gw[SPT / 4];
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            c[m].load(f.rd[m] + base);
+            c[3 + m].load(f.ad[m] + base);
+            c[6 + m].load(f.gq[m] + base);
+        }
+        if constexpr (SPT == 16) {
+            const uint4 g = *reinterpret_cast<const uint4 *>(f.gt + base);
+            gw[0] = g.x; gw[1] = g.y; gw[2] = g.z; gw[3] = g.w;
+        } else {
+            const uint2 g = *reinterpret_cast<const uint2 *>(f.gt + base);
+            gw[0] = g.x; gw[1] = g.y;
+        }
+        uint32_t out[SPT / 4];
+#pragma unroll
+        for (int w = 0; w < SPT / 4; w++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int i = w * 4 + b;
+                const uint32_t g = (gw[w] >> (8 * b)) & 0xFFu;
+                uint32_t cl = 0;
+                if (!(g & 0x40u)) // bit 6: complex record (:239-244)
+                    cl = classify_site(P, g, dec16(c[0].get(i)), dec16(c[3].get(i)), dec16(c[6].get(i)),
+                                       dec16(c[1].get(i)), dec16(c[4].get(i)), dec16(c[7].get(i)),
+                                       dec16(c[2].get(i)), dec16(c[5].get(i)), dec16(c[8].get(i)));
+                o |= cl << (8 * b);
+            }
+            out[w] = o;
+        }
+        if constexpr (SPT == 16)
+            *reinterpret_cast<uint4 *>(cls + base) = make_uint4(out[0], out[1], out[2], out[3]);
+        else
+            *reinterpret_cast<uint2 *>(cls + base) = make_uint2(out[0], out[1]);
+    } else {
+        for (int64_t i = base; i < n; i++) {
+            const uint32_t g = f.gt[i];
+            uint8_t cl = 0;
+            if (!(g & 0x40u))
+                cl = classify_site(P, g, dec16(f.rd[0][i]), dec16(f.ad[0][i]), dec16(f.gq[0][i]), dec16(f.rd[1][i]),
+                                   dec16(f.ad[1][i]), dec16(f.gq[1][i]), dec16(f.rd[2][i]), dec16(f.ad[2][i]),
+                                   dec16(f.gq[2][i]));
+            cls[i] = cl;
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t lower_bound(const int32_t *a, int64_t lo, int64_t hi, int64_t v) {
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t)a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct WinArgs {
+    int32_t n;
+    const int32_t *contig, *start, *end;
+    const uint8_t *vartype, *mult;
+    const int64_t *contig_off;
+    int32_t n_contigs;
+    const int32_t *pos;
+    const uint8_t *cls;
+    int64_t sd;
+    int mode;
+};
+
+// One lane per DNM, sites visited in the reference's order: by position, window-1 copy before
+// window-2 copy (= stable sort of the concatenated windows, :341-342), each entry `mult` times.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32_t *cnt_h, const int64_t *off_c,
+                                                const int64_t *off_h, int32_t *cand_idx, uint8_t *cand_flags,
+                                                int32_t *het_idx) {
+    const int32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= a.n) return;
+    int64_t nc = 0, nh = 0;
+    int64_t oc = 0, oh = 0;
+    if (FILL) { oc = off_c[d]; oh = off_h[d]; }
+    const int32_t c = a.contig[d];
+    if (c >= 0 && c < a.n_contigs) {
+        const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
+        const int64_t st = a.start[d], en = a.end[d];
+        const bool whole = a.mode & UZ_FIND_WHOLE_REGION;
+        int64_t w[2][2];
+        int nw = 1;
+        if (whole) { w[0][0] = st - a.sd; w[0][1] = en + a.sd; }
+        else {
+            w[0][0] = st - a.sd; w[0][1] = st + a.sd; // 1-based POS window built from the 0-based start (:24-31)
+            if ((a.mode & UZ_FIND_SECOND_WINDOW) && (en - st) > a.sd) { w[1][0] = en - a.sd; w[1][1] = en + a.sd; nw = 2; }
+        }
+        for (int k = 0; k < nw; k++) if (w[k][0] < 1) w[k][0] = 1;
+        const int vt = a.vartype[d];
+        const int mult = a.mult[d];
+        const bool small_event = (en - st) < 20;
+        int64_t i = lower_bound(a.pos, clo, chi, w[0][0] - 1);
+        const int64_t hi_all = lower_bound(a.pos, clo, chi, w[nw - 1][1]);
+        while (i < hi_all) {
+            const int32_t p = a.pos[i];
+            int64_t j = i + 1;
+            while (j < hi_all && a.pos[j] == p) j++;
+            const int64_t pos1 = (int64_t)p + 1;
+            if (!(small_event && p >= st && p < en)) { // :253-256
+                for (int k = 0; k < nw; k++) {
+                    if (pos1 < w[k][0] || pos1 > w[k][1]) continue;
+                    for (int64_t s = i; s < j; s++) {
+                        const uint32_t cl = a.cls[s];
+                        if (!cl) continue;
+                        uint32_t ka = 0;
+                        bool is_c;
+                        if (whole) {
+                            if (vt == UZ_VT_DEL) ka = (cl >> UZ_CL_DEL_SHIFT) & 3;
+                            else if (vt == UZ_VT_DUP) ka = (cl >> UZ_CL_DUP_SHIFT) & 3;
+                            is_c = ka != 0;
+                        } else is_c = (cl & UZ_CL_CAND) != 0;
+                        const bool is_h = (cl & UZ_CL_HET) != 0;
+                        for (int r = 0; r < mult; r++) {
+                            if (is_h) {
+                                if (FILL) het_idx[oh + nh] = (int32_t)s;
+                                nh++;
+                            }
+                            if (is_c) {
+                                if (FILL) {
+                                    cand_idx[oc + nc] = (int32_t)s;
+                                    cand_flags[oc + nc] = (uint8_t)(((cl & UZ_CL_ALT_DAD) ? UZ_CF_ALT_DAD : 0) | (ka << UZ_CF_KA_SHIFT));
+                                }
+                                nc++;
+                            }
+                        }
+                    }
+                }
+            }
+            i = j;
+        }
+    }
+    if (!FILL) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
+}
+
+// exclusive scan of two count arrays into int64 offsets (n+1 entries); one workgroup
+__global__ __launch_bounds__(1024) void k_scan2(int32_t n, const int32_t *c0, const int32_t *c1, int64_t *o0, int64_t *o1) {
+    __shared__ int64_t part[2][1024];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int32_t chunk = (n + nt - 1) / nt;
+    const int32_t lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+    int64_t s0 = 0, s1 = 0;
+    for (int32_t i = lo; i < hi; i++) { s0 += c0[i]; s1 += c1[i]; }
+    part[0][t] = s0; part[1][t] = s1;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {
+        int64_t a0 = 0, a1 = 0;
+        if (t >= off) { a0 = part[0][t - off]; a1 = part[1][t - off]; }
+        __syncthreads();
+        part[0][t] += a0; part[1][t] += a1;
+        __syncthreads();
+    }
+    int64_t r0 = part[0][t] - s0, r1 = part[1][t] - s1; // exclusive prefix of this thread's chunk
+    for (int32_t i = lo; i < hi; i++) {
+        o0[i] = r0; o1[i] = r1;
+        r0 += c0[i]; r1 += c1[i];
+    }
+    if (t == nt - 1) { o0[n] = part[0][t]; o1[n] = part[1][t]; }
+}
+
+SiteParams make_site_params(const uz_params &p) {
+    SiteParams s;
+    s.min_gt_qual = p.min_gt_qual;
+    s.min_depth = p.min_depth;
+    s.lo_ref = p.ab_homref[0]; s.hi_ref = p.ab_homref[1];
+    s.lo_alt = p.ab_homalt[0]; s.hi_alt = p.ab_homalt[1];
+    s.lo_het = p.ab_het[0]; s.hi_het = p.ab_het[1];
+    return s;
+}
+
+bool site_params_equal(const uz_params &a, const uz_params &b) {
+    return a.min_gt_qual == b.min_gt_qual && a.min_depth == b.min_depth &&
+           memcmp(a.ab_homref, b.ab_homref, sizeof(a.ab_homref)) == 0 &&
+           memcmp(a.ab_homalt, b.ab_homalt, sizeof(a.ab_homalt)) == 0 &&
+           memcmp(a.ab_het, b.ab_het, sizeof(a.ab_het)) == 0;
+}
+
+} // namespace
+
+__global__ void k_fold_complex(uint8_t *gt, const uint8_t *sflags, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) gt[i] = (uint8_t)((gt[i] & 0x3Fu) | ((sflags[i] & UZ_SF_COMPLEX) ? 0x40u : 0u));
+}
+
+void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n) {
+    if (n <= 0) return;
+    const int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fold_complex, dim3((unsigned)nb), dim3(256), 0, c->stream, gt, sflags, n);
+    UZ_HIP(hipGetLastError());
+}
+
+bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f) { return f.cls_valid && site_params_equal(f.cls_params, c->P); }
+
+#ifndef UZ_SITE_SPT
+#define UZ_SITE_SPT 8
+#endif
+
+void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s) {
+    if (s.n > 0) {
+        FamPtrs fp;
+        fp.gt = f.gt;
+        for (int m = 0; m < 3; m++) { fp.rd[m] = f.rd[m]; fp.ad[m] = f.ad[m]; fp.gq[m] = f.gq[m]; }
+        const SiteParams sp = make_site_params(c->P);
+        constexpr int SPT = UZ_SITE_SPT;
+        const int64_t nthreads = (s.n + SPT - 1) / SPT;
+        const int64_t nb = (nthreads + 255) / 256;
+        ProfScope ps(c, UZ_K_SITE_SCAN);
+        hipLaunchKernelGGL(k_site_scan<SPT>, dim3((unsigned)nb), dim3(256), 0, c->stream, fp, f.cls, s.n, sp);
+        UZ_HIP(hipGetLastError());
+    }
+    f.cls_valid = true;
+    f.cls_params = c->P;
+}
+
+void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode) {
+    const int32_t n = c->dn.n;
+    c->cnt_c.ensure((size_t)n + 1);
+    c->cnt_h.ensure((size_t)n + 1);
+    c->cand_off.ensure((size_t)n + 1);
+    c->het_off.ensure((size_t)n + 1);
+    c->cand_off_h.assign((size_t)n + 1, 0);
+    c->het_off_h.assign((size_t)n + 1, 0);
+    c->n_cand = c->n_het = 0;
+    if (n > 0) {
+        WinArgs a;
+        a.n = n;
+        a.contig = c->dn.contig.p; a.start = c->dn.start.p; a.end = c->dn.end.p;
+        a.vartype = c->dn.vartype.p; a.mult = c->dn.mult.p;
+        a.contig_off = s.contig_off; a.n_contigs = s.n_contigs;
+        a.pos = s.pos; a.cls = f.cls;
+        a.sd = c->P.search_dist;
+        a.mode = mode;
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        {
+            ProfScope ps(c, UZ_K_WINDOW_COUNT);
+            hipLaunchKernelGGL(k_window<false>, dim3(nb), dim3(256), 0, c->stream, a, c->cnt_c.p, c->cnt_h.p,
+                               (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr,
+                               (uint8_t *)nullptr, (int32_t *)nullptr);
+            UZ_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, c->stream, n, c->cnt_c.p, c->cnt_h.p, c->cand_off.p,
+                               c->het_off.p);
+            UZ_HIP(hipGetLastError());
+        }
+        UZ_HIP(hipMemcpyAsync(c->cand_off_h.data(), c->cand_off.p, ((size_t)n + 1) * sizeof(int64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+        UZ_HIP(hipMemcpyAsync(c->het_off_h.data(), c->het_off.p, ((size_t)n + 1) * sizeof(int64_t),
+                              hipMemcpyDeviceToHost, c->stream));
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        c->n_cand = c->cand_off_h[n];
+        c->n_het = c->het_off_h[n];
+        c->cand_idx.ensure((size_t)c->n_cand + 1);
+        c->cand_flags.ensure((size_t)c->n_cand + 1);
+        c->het_idx.ensure((size_t)c->n_het + 1);
+        {
+            ProfScope ps(c, UZ_K_WINDOW_FILL);
+            hipLaunchKernelGGL(k_window<true>, dim3(nb), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
+                               (int32_t *)nullptr, (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p,
+                               c->cand_idx.p, c->cand_flags.p, c->het_idx.p);
+            UZ_HIP(hipGetLastError());
+        }
+    }
+    c->find_valid = true;
+    c->find_mode = mode;
+}

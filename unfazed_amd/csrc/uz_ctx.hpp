@@ -1,0 +1,169 @@
+// uz_ctx.hpp -- internal state of the C ABI context (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "unfazed_hip.h"
+
+struct UzError {
+    int code;
+    std::string msg;
+};
+
+#define UZ_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            throw UzError{UZ_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__)};               \
+    } while (0)
+
+#define UZ_REQUIRE(cond, code, text)          \
+    do {                                      \
+        if (!(cond)) throw UzError{code, text}; \
+    } while (0)
+
+// grow-only device buffer
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    void ensure(size_t n) {
+        if (n <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        size_t want = n + n / 4 + 64;
+        UZ_HIP(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct SitesDev {
+    bool live = false, owned = false;
+    int64_t n = 0;
+    int32_t n_contigs = 0;
+    std::vector<int64_t> contig_off_h;
+    int64_t *contig_off = nullptr;
+    int32_t *pos = nullptr;
+    uint8_t *sflags = nullptr, *ref_base = nullptr, *alt_base = nullptr;
+};
+
+struct FamilyDev {
+    bool live = false, owned = false;
+    int sites_id = -1;
+    uint8_t *gt = nullptr; // bits 0-5 genotypes; bit 6 = the site's complex flag, folded in at upload
+    uint16_t *rd[3] = {nullptr, nullptr, nullptr};
+    uint16_t *ad[3] = {nullptr, nullptr, nullptr};
+    uint16_t *gq[3] = {nullptr, nullptr, nullptr};
+    uint8_t *cls = nullptr;
+    bool cls_valid = false;
+    uz_params cls_params;
+};
+
+struct ReadsDev {
+    bool live = false, owned = false;
+    int64_t n = 0;
+    int32_t n_contigs = 0;
+    uint32_t n_qnames = 0;
+    int64_t n_cigar_total = 0, n_sq_bytes = 0;
+    int64_t *contig_off = nullptr;
+    int32_t *max_span = nullptr;
+    int32_t *start = nullptr, *end = nullptr;
+    uint16_t *flag = nullptr;
+    uint8_t *mapq = nullptr, *aux = nullptr;
+    int32_t *tlen = nullptr;
+    uint32_t *qname = nullptr;
+    int32_t *mate = nullptr;
+    uint32_t *cigar_off = nullptr;
+    uint16_t *n_cigar = nullptr;
+    uint32_t *cigar = nullptr;
+    uint16_t *l_seq = nullptr;
+    uint32_t *sq_off16 = nullptr;
+    uint8_t *seq = nullptr, *qual = nullptr;
+    // K3a output: per-segment QC bits for the parameters in qc_params
+    uint8_t *qc = nullptr;
+    bool qc_valid = false;
+    uz_params qc_params;
+};
+
+// DNM batch staged on the device
+struct DnmsDev {
+    int32_t n = 0;
+    DevBuf<int32_t> contig, rcontig, start, end;
+    DevBuf<uint8_t> vartype, dflags, mult;
+    DevBuf<uint32_t> allele_off;
+    DevBuf<uint8_t> alleles;
+    double cutoff = 0;
+};
+
+struct ProfSlot {
+    double total_ms = 0;
+    int64_t launches = 0;
+};
+struct ProfPending {
+    int kernel;
+    hipEvent_t a, b;
+};
+
+struct uz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uz_params P;
+    std::string err;
+    std::vector<SitesDev> sites;
+    std::vector<FamilyDev> fams;
+    std::vector<ReadsDev> reads;
+
+    // last find
+    bool find_valid = false;
+    int find_fam = -1, find_mode = 0;
+    DnmsDev dn;
+    DevBuf<int32_t> cnt_c, cnt_h;
+    DevBuf<int64_t> cand_off, het_off;
+    DevBuf<int32_t> cand_idx, het_idx;
+    DevBuf<uint8_t> cand_flags;
+    int64_t n_cand = 0, n_het = 0;
+    std::vector<int64_t> cand_off_h, het_off_h;
+
+    // last phase (k_reads.hip)
+    bool phase_valid = false;
+    int32_t phase_n = 0;
+    void *phase_state = nullptr;
+
+    // profiling
+    bool prof_on = false;
+    ProfSlot prof[UZ_K_COUNT];
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+// profiling helpers (abi.hip)
+void uz_prof_begin(uz_ctx *c, int kernel, hipEvent_t *a, hipEvent_t *b);
+void uz_prof_end(uz_ctx *c, int kernel, hipEvent_t a, hipEvent_t b);
+void uz_prof_drain(uz_ctx *c);
+
+struct ProfScope {
+    uz_ctx *c;
+    int k;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(uz_ctx *c_, int k_) : c(c_), k(k_) { uz_prof_begin(c, k, &a, &b); }
+    ~ProfScope() { uz_prof_end(c, k, a, b); }
+};
+
+// stage launchers
+void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s);
+void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode);
+void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d);
+void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
+                     int32_t *origin, int32_t *evidence);
+int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);
+int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q);
+void uz_phase_state_free(uz_ctx *c);

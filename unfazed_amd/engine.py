@@ -1,0 +1,242 @@
+"""ctypes binding of libunfazed_hip.so (include/unfazed_hip.h) and the backend
+object the host path drives.  There is no CPU fallback: if the library or a
+gfx950 device is missing, construction raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunfazed_hip.so")
+
+K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE = 0, 1, 2, 3, 4
+
+EXPORTS = [
+    "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
+    "uz_sites_upload", "uz_family_upload", "uz_reads_upload",
+    "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
+    "uz_sites_free", "uz_reads_free",
+    "uz_site_scan", "uz_site_classes", "uz_find", "uz_find_fetch",
+    "uz_phase", "uz_phase_votes", "uz_phase_groups",
+    "uz_prof_enable", "uz_prof_reset", "uz_prof_get",
+]
+
+_lib = None
+
+
+class UnfazedHipError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the HIP library and declare the prototypes.  Fails loudly."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise UnfazedHipError(
+            "%s not found: build it with `python -m unfazed_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the phasing path." % p
+        )
+    L = C.CDLL(p)
+    vp, i32, i64p = C.c_void_p, C.c_int, C.c_void_p
+    L.uz_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.uz_destroy.argtypes = [vp]
+    L.uz_destroy.restype = None
+    L.uz_last_error.argtypes = [vp]
+    L.uz_last_error.restype = C.c_char_p
+    L.uz_sync.argtypes = [vp]
+    L.uz_set_params.argtypes = [vp, vp]
+    for f in ("uz_sites_upload", "uz_reads_upload", "uz_sites_adopt_device", "uz_reads_adopt_device"):
+        getattr(L, f).argtypes = [vp, vp, C.POINTER(C.c_int)]
+    for f in ("uz_family_upload", "uz_family_adopt_device"):
+        getattr(L, f).argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
+    L.uz_sites_free.argtypes = [vp, C.c_int]
+    L.uz_reads_free.argtypes = [vp, C.c_int]
+    L.uz_site_scan.argtypes = [vp, C.c_int]
+    L.uz_site_classes.argtypes = [vp, C.c_int, vp]
+    L.uz_find.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
+    L.uz_find_fetch.argtypes = [vp, vp, vp, vp]
+    L.uz_phase.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.uz_phase_votes.argtypes = [vp, vp, vp]
+    L.uz_phase_groups.argtypes = [vp, vp, vp]
+    L.uz_prof_enable.argtypes = [vp, C.c_int]
+    L.uz_prof_reset.argtypes = [vp]
+    L.uz_prof_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("uz_destroy", "uz_last_error"):
+            fn.restype = C.c_int
+    if path is None:
+        _lib = L
+    return L
+
+
+class HipEngine:
+    """One context on one GPU.  Backend interface used by hostpath.PhasingHost."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.uz_create(int(device), C.byref(h))
+        if rc != 0:
+            raise UnfazedHipError(
+                "uz_create(device=%d) failed with %d: a gfx950 (MI355X) device is required; "
+                "there is no CPU fallback" % (device, rc)
+            )
+        self.h = h
+        self.device = device
+        self._keep: List[object] = []
+        self._params = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.uz_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            msg = self.L.uz_last_error(self.h)
+            raise UnfazedHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    # -------------------------------------------------------------- staging
+    def set_params(self, params: abi.Params):
+        self._ck(self.L.uz_set_params(self.h, C.byref(params)), "uz_set_params")
+        self._params = params
+
+    def upload_sites(self, sites) -> int:
+        v = abi.sites_view(sites)
+        sid = C.c_int(-1)
+        self._ck(self.L.uz_sites_upload(self.h, v.ref(), C.byref(sid)), "uz_sites_upload")
+        return sid.value
+
+    def add_family(self, sites_h: int, gt, rd, ad, gq) -> int:
+        v = abi.family_view(gt, rd, ad, gq)
+        fid = C.c_int(-1)
+        self._ck(self.L.uz_family_upload(self.h, int(sites_h), v.ref(), C.byref(fid)), "uz_family_upload")
+        return fid.value
+
+    def upload_reads(self, reads) -> int:
+        v = abi.reads_view(reads)
+        rid = C.c_int(-1)
+        self._ck(self.L.uz_reads_upload(self.h, v.ref(), C.byref(rid)), "uz_reads_upload")
+        return rid.value
+
+    def adopt_sites(self, view: abi.SitesView) -> int:
+        sid = C.c_int(-1)
+        self._ck(self.L.uz_sites_adopt_device(self.h, C.byref(view), C.byref(sid)), "uz_sites_adopt_device")
+        return sid.value
+
+    def adopt_family(self, sites_h: int, view: abi.FamilyView) -> int:
+        fid = C.c_int(-1)
+        self._ck(self.L.uz_family_adopt_device(self.h, int(sites_h), C.byref(view), C.byref(fid)), "uz_family_adopt_device")
+        return fid.value
+
+    def adopt_reads(self, view: abi.ReadsView) -> int:
+        rid = C.c_int(-1)
+        self._ck(self.L.uz_reads_adopt_device(self.h, C.byref(view), C.byref(rid)), "uz_reads_adopt_device")
+        return rid.value
+
+    def free_sites(self, sid: int):
+        self._ck(self.L.uz_sites_free(self.h, int(sid)), "uz_sites_free")
+
+    def free_reads(self, rid: int):
+        self._ck(self.L.uz_reads_free(self.h, int(rid)), "uz_reads_free")
+
+    def sync(self):
+        self._ck(self.L.uz_sync(self.h), "uz_sync")
+
+    # ----------------------------------------------------------- site stage
+    def site_scan(self, fam: int):
+        self._ck(self.L.uz_site_scan(self.h, int(fam)), "uz_site_scan")
+
+    def classify(self, fam: int, params: abi.Params, n_sites: int) -> np.ndarray:
+        self.set_params(params)
+        out = np.zeros(max(1, n_sites), dtype=np.uint8)
+        self._ck(self.L.uz_site_classes(self.h, int(fam), out.ctypes.data), "uz_site_classes")
+        return out[:n_sites]
+
+    def find(self, fam: int, dv: abi.Held, params: abi.Params, mode: int, fetch: bool = True):
+        self.set_params(params)
+        n = dv.view.n
+        co = np.zeros(n + 1, dtype=np.int64)
+        ho = np.zeros(n + 1, dtype=np.int64)
+        self._ck(self.L.uz_find(self.h, int(fam), dv.ref(), int(mode), co.ctypes.data, ho.ctypes.data), "uz_find")
+        if not fetch:
+            return co, None, None, ho, None
+        ci, cf, hi = self._fetch(int(co[n]), int(ho[n]))
+        return co, ci, cf, ho, hi
+
+    def _fetch(self, nc: int, nh: int):
+        ci = np.zeros(max(1, nc), dtype=np.int32)
+        cf = np.zeros(max(1, nc), dtype=np.uint8)
+        hi = np.zeros(max(1, nh), dtype=np.int32)
+        self._ck(self.L.uz_find_fetch(self.h, ci.ctypes.data, cf.ctypes.data, hi.ctypes.data), "uz_find_fetch")
+        return ci[:nc], cf[:nc], hi[:nh]
+
+    # ----------------------------------------------------------- read stage
+    def phase_raw(self, fam: int, reads_h: int, dv: abi.Held, params: abi.Params, find_mode: int):
+        self.set_params(params)
+        n = dv.view.n
+        status = np.zeros(max(1, n), dtype=np.int32)
+        counts = np.zeros(max(1, 4 * n), dtype=np.int32)
+        origin = np.zeros(max(1, n), dtype=np.int32)
+        evidence = np.zeros(max(1, n), dtype=np.int32)
+        self._ck(
+            self.L.uz_phase(self.h, int(fam), int(reads_h), dv.ref(), int(find_mode), status.ctypes.data,
+                            counts.ctypes.data, origin.ctypes.data, evidence.ctypes.data),
+            "uz_phase",
+        )
+        return dict(status=status[:n], counts=counts[: 4 * n].reshape(n, 4), origin=origin[:n], evidence=evidence[:n])
+
+    def votes(self, n: int):
+        vo = np.zeros(4 * n + 1, dtype=np.int64)
+        self._ck(self.L.uz_phase_votes(self.h, vo.ctypes.data, None), "uz_phase_votes")
+        vv = np.zeros(max(1, int(vo[-1])), dtype=np.int32)
+        self._ck(self.L.uz_phase_votes(self.h, vo.ctypes.data, vv.ctypes.data), "uz_phase_votes")
+        return vo, vv[: int(vo[-1])]
+
+    def groups(self, n: int):
+        go = np.zeros(2 * n + 1, dtype=np.int64)
+        self._ck(self.L.uz_phase_groups(self.h, go.ctypes.data, None), "uz_phase_groups")
+        gq = np.zeros(max(1, int(go[-1])), dtype=np.int32)
+        self._ck(self.L.uz_phase_groups(self.h, go.ctypes.data, gq.ctypes.data), "uz_phase_groups")
+        return go, gq[: int(go[-1])]
+
+    def phase(self, fam: int, reads_h: int, dv: abi.Held, params: abi.Params, found_list, want_lists: bool = True,
+              find_mode: int = abi.FIND_SECOND_WINDOW):
+        """Backend entry used by PhasingHost.run_read_phasing (found_list is ignored:
+        the window lists are recomputed on the device for the batch)."""
+        r = self.phase_raw(fam, reads_h, dv, params, find_mode)
+        n = dv.view.n
+        if want_lists:
+            vo, vv = self.votes(n)
+            r["lists"] = [tuple(vv[vo[4 * k + j]: vo[4 * k + j + 1]] for j in range(4)) for k in range(n)]
+        else:
+            r["lists"] = None
+        return r
+
+    # ---------------------------------------------------------- measurement
+    def prof_enable(self, on: bool = True):
+        self._ck(self.L.uz_prof_enable(self.h, 1 if on else 0), "uz_prof_enable")
+
+    def prof_reset(self):
+        self._ck(self.L.uz_prof_reset(self.h), "uz_prof_reset")
+
+    def prof_get(self, kernel: int):
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        self._ck(self.L.uz_prof_get(self.h, int(kernel), C.byref(ms), C.byref(n)), "uz_prof_get")
+        return ms.value, n.value

@@ -198,6 +198,7 @@ class PhasingHost:
             co, ci, cf, ho, hi = self.backend.find(fam, dv, params, mode)
             for k, i in enumerate(idxs):
                 found[i] = dict(
+                    mult=mult_of[i],
                     cand_idx=ci[co[k] : co[k + 1]],
                     cand_flags=cf[co[k] : co[k + 1]],
                     het_idx=hi[ho[k] : ho[k + 1]],
@@ -220,7 +221,7 @@ class PhasingHost:
                     dn["het_sites"] = hets
         ret = [dnms[i] for i in order] + [dnms[i] for i in auto_tail]
         ret_idx = order + auto_tail
-        return ret, {"order": ret_idx, "found": found, "many": many}
+        return ret, {"order": ret_idx, "found": found, "many": many, "mode": mode}
 
     def _site_dicts(self, idx, flags, dad, mom, with_kid_allele):
         s = self.sites
@@ -314,13 +315,14 @@ class PhasingHost:
             alts.extend(self.sites.alt_strs[int(j)])
         return ref, alts
 
-    def kid_cutoff(self, kid: str, bam: str, readlen: int, stdevs: int) -> float:
+    def kid_cutoff(self, kid: str, bam: str, readlen: int, stdevs: int, insert_size_max_sample: int) -> float:
         if kid not in self.cutoffs or not self.cutoffs[kid]:  # snv_phaser.py:133-135, read_collector.py:377
             rt = self.reads_by_bam[bam]
             head = getattr(rt, "tlen_head", None)
             if head is None:
                 head = rt.tlen
-            self.cutoffs[kid] = concordant_cutoff(head, readlen, stdevs)
+            # the first insert_size_max_sample + 1 records of the file (read_collector.py:13-17)
+            self.cutoffs[kid] = concordant_cutoff(head[: int(insert_size_max_sample) + 1], readlen, stdevs)
         return self.cutoffs[kid]
 
     def resolve_reads_contig(self, rt: ReadsTable, chrom: str):
@@ -401,7 +403,7 @@ class PhasingHost:
             dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
             fam = self.family(kid, dad_id, mom_id)
             rh = self.reads(bam)
-            cutoff = self.kid_cutoff(kid, bam, readlen, stdevs)
+            cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
             name_of = {}
             for i in idxs:
                 nm = self.prefix + dnms[i]["chrom"].strip("chr")
@@ -416,9 +418,10 @@ class PhasingHost:
                 alts=[prep[i]["alt"] for i in idxs],
                 cutoff=cutoff,
                 dflags=[prep[i]["dflags"] for i in idxs],
+                mult=[found[i]["mult"] for i in idxs],
             )
             fl = [found[i] for i in idxs]
-            res = self.backend.phase(fam, rh, dv, params, fl, want_lists)
+            res = self.backend.phase(fam, rh, dv, params, fl, want_lists, find_mode=info["mode"])
             for k, i in enumerate(idxs):
                 results[i] = (res, k)
         # pass 3: records, in the reference's order
