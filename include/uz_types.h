@@ -61,6 +61,7 @@ extern "C" {
 #define UZ_ST_NO_OVERLAP 2     /* "No reads overlap informative sites" (snv_phaser.py:158-166) */
 #define UZ_ST_REF_EXCEPTION 3  /* the reference raises inside the worker (KeyError in connect_reads): no record */
 #define UZ_ST_SKIPPED 4        /* not run (host filtered: autophase, no genotype, ...) */
+#define UZ_ST_CAPACITY 5       /* a per-DNM size exceeds the device layout (>= 2^20 list entries): reported, never silently dropped */
 
 /* origin codes of the integer decision rule (unfazed.py:206-234) */
 #define UZ_OR_NONE 0

@@ -1,0 +1,62 @@
+// emu_phase.cpp -- CPU emulation harness of the per-DNM read-stage kernel body
+// (unfazed_amd/csrc/phase_body.hpp compiled with -DUZ_EMU: one lane, phases run
+// sequentially).  DEBUGGING AID for the authoring container (no GPU there): it lets
+// tests/test_emu_phase.py run the exact kernel logic against the oracle on CPU.
+// Never loaded by the product.
+#define UZ_EMU 1
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "phase_body.hpp"
+
+extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *Rv, const uz_dnms_view *D,
+                         const int64_t *cand_off, const int32_t *cand_idx, const uint8_t *cand_flags,
+                         const int64_t *het_off, const int32_t *het_idx, int32_t *status, int32_t *counts,
+                         int32_t *origin, int32_t *evidence, long long *list_start, int32_t *list_len, int32_t *pool,
+                         long long pool_cap, long long *pool_used) {
+    std::vector<uint8_t> qc((size_t)Rv->n_segs + 1);
+    RD R;
+    R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
+    R.start = Rv->start; R.end = Rv->end; R.flag = Rv->flag; R.mapq = Rv->mapq; R.aux = Rv->aux; R.tlen = Rv->tlen;
+    R.qname = Rv->qname; R.mate = Rv->mate; R.cigar_off = Rv->cigar_off; R.n_cigar = Rv->n_cigar; R.cigar = Rv->cigar;
+    R.l_seq = Rv->l_seq; R.sq_off16 = Rv->sq_off16; R.seq = Rv->seq; R.qual = Rv->qual; R.qc = qc.data();
+    for (int64_t i = 0; i < Rv->n_segs; i++) qc[i] = uz_seg_qc(R, (int)i, P->min_map_qual, P->min_gt_qual);
+    PhaseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = D->n;
+    a.min_gt_qual = P->min_gt_qual; a.readlen = P->readlen; a.no_extended = P->no_extended;
+    a.read_goal = P->read_goal; a.evidence_min_ratio = P->evidence_min_ratio; a.cutoff = D->cutoff;
+    a.spos = S->pos; a.sref = S->ref_base; a.salt = S->alt_base;
+    a.cand_off = cand_off; a.het_off = het_off; a.cand_idx = cand_idx; a.het_idx = het_idx; a.cand_flags = cand_flags;
+    a.rcontig = D->rcontig; a.dstart = D->start; a.dflags = D->dflags; a.allele_off = D->allele_off; a.alleles = D->alleles;
+    a.R = R;
+    a.status = status; a.counts = counts; a.origin = origin; a.evidence = evidence;
+    a.want_lists = 1; a.pool = pool; a.pool_cap = (unsigned long long)pool_cap;
+    unsigned long long cursor = 0;
+    a.pool_cursor = &cursor; a.list_start = list_start; a.list_len = list_len;
+    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 2;
+    for (int d = 0; d < D->n; d++) {
+        int32_t b[5];
+        uz_phase_bounds(a, d, b);
+        if (b[0] > mA) mA = b[0];
+        if (b[1] > mT) mT = b[1];
+        if (b[2] > mH) mH = b[2];
+        if (b[3] > mC) mC = b[3];
+        long long M = (long long)b[1] + 4LL * b[0] * (b[4] + 1);
+        if (M > mM) mM = M;
+    }
+    Caps caps;
+    caps.A = (int)mA; caps.T = (int)mT; caps.H = (int)mH; caps.C = (int)mC; caps.I = (int)(4 * mA);
+    long long p2 = 1; while (p2 < mM) p2 <<= 1;
+    caps.M = (int)p2;
+    Scr s;
+    const size_t bytes = uz_scratch_carve(nullptr, caps, s);
+    std::vector<uint8_t> scratch(bytes + 256, 0xCD);
+    uz_scratch_carve(scratch.data(), caps, s);
+    a.scratch = scratch.data(); a.scratch_per_wg = bytes; a.caps = caps;
+    WgShared sh;
+    for (int d = 0; d < D->n; d++) uz_phase_dnm(a, s, &sh, d);
+    *pool_used = (long long)cursor;
+    return 0;
+}

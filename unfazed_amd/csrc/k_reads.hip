@@ -1,9 +1,228 @@
-// k_reads.hip -- read stage (placeholder until the kernels land)
+// k_reads.hip -- read stage on gfx950: K3a per-segment QC pre-pass, the sizing pass and the
+// per-DNM phase kernel (phase_body.hpp), plus the host-side launch sequence.
+//
+// Launch shape: a persistent grid of 256-lane workgroups (a few per CU) pulls DNM indices from
+// one device counter; each workgroup owns a scratch region in HBM sized from the sizing pass.
+// The per-DNM working set (tens of KB) stays L2-resident; scans and small sorts go through LDS.
 #include "uz_ctx.hpp"
+#include "phase_body.hpp"
+
+#include <algorithm>
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qual, int min_base_qual, uint8_t *qc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) qc[i] = uz_seg_qc(R, (int)i, min_map_qual, min_base_qual);
+}
+
+__global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < a.n) uz_phase_bounds(a, d, bounds + 5 * (size_t)d);
+}
+
+__global__ __launch_bounds__(WG_NT) void k_phase(PhaseArgs a) {
+    __shared__ WgShared sh;
+    Scr s;
+    uz_scratch_carve(a.scratch + (size_t)blockIdx.x * a.scratch_per_wg, a.caps, s);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.bcast[0] = atomicAdd(a.work_cursor, 1);
+        __syncthreads();
+        const int d = sh.bcast[0];
+        if (d >= a.n) break;
+        uz_phase_dnm(a, s, &sh, d);
+    }
+}
+
+struct PhaseState {
+    DevBuf<uint8_t> scratch;
+    DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len;
+    DevBuf<long long> list_start;
+    DevBuf<unsigned long long> pool_cursor;
+    std::vector<long long> list_start_h;
+    std::vector<int32_t> list_len_h;
+    bool have_lists = false;
+    int32_t n = 0;
+};
+
+RD make_rd(const ReadsDev &r) {
+    RD R;
+    R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
+    R.start = r.start; R.end = r.end; R.flag = r.flag; R.mapq = r.mapq; R.aux = r.aux; R.tlen = r.tlen;
+    R.qname = r.qname; R.mate = r.mate; R.cigar_off = r.cigar_off; R.n_cigar = r.n_cigar; R.cigar = r.cigar;
+    R.l_seq = r.l_seq; R.sq_off16 = r.sq_off16; R.seq = r.seq; R.qual = r.qual; R.qc = r.qc;
+    return R;
+}
+
+int next_pow2(long long v) {
+    long long p = 1;
+    while (p < v) p <<= 1;
+    return (int)p;
+}
+
+} // namespace
+
+void uz_phase_state_free(uz_ctx *c) {
+    PhaseState *st = (PhaseState *)c->phase_state;
+    if (!st) return;
+    st->scratch.release(); st->bounds.release(); st->status.release(); st->counts.release(); st->origin.release();
+    st->evidence.release(); st->cursor.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
+    st->pool_cursor.release();
+    delete st;
+    c->phase_state = nullptr;
+}
+
+int uz_want_lists = 1; // uz_phase always keeps the lists available for uz_phase_votes / uz_phase_groups
+
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
                      int32_t *origin, int32_t *evidence) {
-    throw UzError{UZ_E_STATE, "read stage not built"};
+    if (!c->phase_state) c->phase_state = new PhaseState();
+    PhaseState *st = (PhaseState *)c->phase_state;
+    const int32_t n = c->dn.n;
+    st->n = n;
+    st->have_lists = false;
+    c->phase_n = n;
+    if (n <= 0) { c->phase_valid = true; return; }
+
+    // K3a: per-segment QC bits for the current thresholds
+    if (!(r.qc_valid && r.qc_params.min_map_qual == c->P.min_map_qual && r.qc_params.min_gt_qual == c->P.min_gt_qual)) {
+        if (r.n > 0) {
+            ProfScope ps(c, UZ_K_SEG_QC);
+            const unsigned nb = (unsigned)((r.n + 255) / 256);
+            hipLaunchKernelGGL(k_seg_qc, dim3(nb), dim3(256), 0, c->stream, make_rd(r), r.n, c->P.min_map_qual,
+                               c->P.min_gt_qual, r.qc);
+            UZ_HIP(hipGetLastError());
+        }
+        r.qc_valid = true;
+        r.qc_params = c->P;
+    }
+
+    PhaseArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n = n;
+    a.min_gt_qual = c->P.min_gt_qual; a.readlen = c->P.readlen; a.no_extended = c->P.no_extended;
+    a.read_goal = c->P.read_goal; a.evidence_min_ratio = c->P.evidence_min_ratio;
+    a.cutoff = c->dn.cutoff;
+    a.spos = s.pos; a.sref = s.ref_base; a.salt = s.alt_base;
+    a.cand_off = c->cand_off.p; a.het_off = c->het_off.p;
+    a.cand_idx = c->cand_idx.p; a.het_idx = c->het_idx.p; a.cand_flags = c->cand_flags.p;
+    a.rcontig = c->dn.rcontig.p; a.dstart = c->dn.start.p; a.dflags = c->dn.dflags.p;
+    a.allele_off = c->dn.allele_off.p; a.alleles = c->dn.alleles.p;
+    a.R = make_rd(r);
+
+    // sizing pass -> scratch capacities (max over the batch)
+    st->bounds.ensure((size_t)5 * n);
+    {
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
+        UZ_HIP(hipGetLastError());
+    }
+    std::vector<int32_t> bh((size_t)5 * n);
+    UZ_HIP(hipMemcpyAsync(bh.data(), st->bounds.p, bh.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    UZ_HIP(hipStreamSynchronize(c->stream));
+    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
+    for (int32_t d = 0; d < n; d++) {
+        const int32_t *b = &bh[(size_t)5 * d];
+        mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
+        mH = std::max<long long>(mH, b[2]); mC = std::max<long long>(mC, b[3]);
+        const long long I = 4LL * b[0];
+        const long long M = (long long)b[1] + I * (b[4] + 1);
+        mM = std::max(mM, M);
+        sumP += std::min<long long>(M, 4096) + b[3];
+    }
+    Caps caps;
+    caps.A = (int32_t)mA; caps.T = (int32_t)mT; caps.H = (int32_t)mH; caps.C = (int32_t)mC;
+    caps.I = (int32_t)(4 * mA);
+    caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
+    Scr dummy;
+    const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
+    hipDeviceProp_t prop;
+    UZ_HIP(hipGetDeviceProperties(&prop, c->device));
+    int grid = prop.multiProcessorCount * 6;
+    if (grid > n) grid = n;
+    const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
+    while (grid > 1 && (size_t)grid * per_wg > budget) grid /= 2;
+    st->scratch.ensure((size_t)grid * per_wg);
+    a.scratch = st->scratch.p; a.scratch_per_wg = per_wg; a.caps = caps;
+
+    st->status.ensure(n); st->counts.ensure((size_t)4 * n); st->origin.ensure(n); st->evidence.ensure(n);
+    st->cursor.ensure(4);
+    a.status = st->status.p; a.counts = st->counts.p; a.origin = st->origin.p; a.evidence = st->evidence.p;
+    a.work_cursor = st->cursor.p;
+    a.want_lists = uz_want_lists;
+    size_t pool_cap = (size_t)std::min<long long>(4 * sumP + 1024, (long long)1 << 31);
+    st->pool.ensure(pool_cap);
+    st->pool_cursor.ensure(2); st->list_start.ensure(n); st->list_len.ensure((size_t)6 * n);
+    a.pool = st->pool.p; a.pool_cap = pool_cap; a.pool_cursor = st->pool_cursor.p;
+    a.list_start = st->list_start.p; a.list_len = st->list_len.p;
+
+    for (int attempt = 0; attempt < 4; attempt++) {
+        UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
+        UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
+        {
+            ProfScope ps(c, UZ_K_PHASE);
+            hipLaunchKernelGGL(k_phase, dim3((unsigned)grid), dim3(WG_NT), 0, c->stream, a);
+            UZ_HIP(hipGetLastError());
+        }
+        unsigned long long used = 0;
+        UZ_HIP(hipMemcpyAsync(&used, st->pool_cursor.p, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        if (!a.want_lists || used <= a.pool_cap) break;
+        // list pool too small: grow to the exact demand and run again
+        pool_cap = (size_t)used + 1024;
+        st->pool.ensure(pool_cap);
+        a.pool = st->pool.p; a.pool_cap = pool_cap;
+    }
+    if (status) UZ_HIP(hipMemcpyAsync(status, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (counts) UZ_HIP(hipMemcpyAsync(counts, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (origin) UZ_HIP(hipMemcpyAsync(origin, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (evidence) UZ_HIP(hipMemcpyAsync(evidence, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    UZ_HIP(hipStreamSynchronize(c->stream));
+    st->have_lists = a.want_lists != 0;
+    c->phase_valid = true;
 }
-int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val) { return UZ_E_STATE; }
-int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q) { return UZ_E_STATE; }
-void uz_phase_state_free(uz_ctx *c) {}
+
+static void fetch_list_index(uz_ctx *c, PhaseState *st) {
+    const size_t n = (size_t)st->n;
+    st->list_start_h.resize(n);
+    st->list_len_h.resize(6 * n);
+    if (!n) return;
+    UZ_HIP(hipMemcpyAsync(st->list_start_h.data(), st->list_start.p, n * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    UZ_HIP(hipMemcpyAsync(st->list_len_h.data(), st->list_len.p, 6 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    UZ_HIP(hipStreamSynchronize(c->stream));
+}
+
+// gathers lists [k0, k1) of every DNM (k in the 6-list layout) into CSR form
+static int gather_lists(uz_ctx *c, int k0, int k1, int64_t *off, int32_t *val) {
+    PhaseState *st = (PhaseState *)c->phase_state;
+    UZ_REQUIRE(st && st->have_lists, UZ_E_STATE, "no lists kept by the last uz_phase");
+    fetch_list_index(c, st);
+    const int nk = k1 - k0;
+    int64_t total = 0;
+    for (int32_t d = 0; d < st->n; d++)
+        for (int k = 0; k < nk; k++) {
+            off[(size_t)nk * d + k] = total;
+            if (st->list_start_h[d] >= 0) total += st->list_len_h[(size_t)6 * d + k0 + k];
+        }
+    off[(size_t)nk * st->n] = total;
+    if (!val || total == 0) return 0;
+    // copy the used part of the pool once, then slice on the host
+    unsigned long long used = 0;
+    UZ_HIP(hipMemcpy(&used, st->pool_cursor.p, sizeof(used), hipMemcpyDeviceToHost));
+    std::vector<int32_t> pool((size_t)used);
+    if (used) UZ_HIP(hipMemcpy(pool.data(), st->pool.p, (size_t)used * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int32_t d = 0; d < st->n; d++) {
+        if (st->list_start_h[d] < 0) continue;
+        long long src = st->list_start_h[d];
+        for (int k = 0; k < 6; k++) {
+            const int len = st->list_len_h[(size_t)6 * d + k];
+            if (k >= k0 && k < k1 && len) memcpy(val + off[(size_t)nk * d + (k - k0)], pool.data() + src, (size_t)len * sizeof(int32_t));
+            src += len;
+        }
+    }
+    return 0;
+}
+
+int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val) { return gather_lists(c, 0, 4, vote_off, vote_val); }
+int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q) { return gather_lists(c, 4, 6, grp_off, grp_q); }

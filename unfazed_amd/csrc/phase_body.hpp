@@ -1,0 +1,784 @@
+// phase_body.hpp -- the per-DNM read stage as block-parallel phases (see wg.hpp).
+//
+// One workgroup phases one DNM at a time:
+//   A  DNM reads         collect_reads_snv :382-425 (+ snv/indel_match_alleles :266-336)
+//   B  registration      group_reads_by_haplotype :165-222 (fetch at every het site)
+//   C  seeding           :223-249
+//   S  pair table        one sort of (qname, sequence) keys gives dense pair ids, the
+//                        per-pair read_sites lists in append order and "last writer wins"
+//                        for fetched_reads (quirk Q11)
+//   D  static tables     finder / candidate alleles per list entry (get_allele_at :56-73)
+//   E  chaining          connect_reads :76-152 as a level-synchronous BFS; every unassigned
+//                        pair takes the attempt of minimum sequential rank (64-bit atomicMin),
+//                        winners sorted by rank form the next level
+//   F  join + vote       match_informative_sites (site_searcher.py:50-78), phase_by_reads
+//                        (snv_phaser.py:16-70), unique-name / unique-site tally (:169-185) and
+//                        the integer decision of summarize_record (unfazed.py:206-234)
+// (file names relative to reference unfazed/; read_collector.py unless stated)
+#pragma once
+#include "uz_types.h"
+#include "wg.hpp"
+
+#define UZ_QC_GOOD 1u      // goodread(read) :28-53
+#define UZ_QC_GOOD_DISC 2u // goodread(read, True)
+#define UZ_QC_NM5 4u       // <= 5 CIGAR ops other than M/= :190-196
+#define UZ_QC_NONE5 8u     // <= 5 query bases without a reference position :200-203, :405-408
+
+#define UZ_OP_M 0
+#define UZ_OP_I 1
+#define UZ_OP_D 2
+#define UZ_OP_N 3
+#define UZ_OP_S 4
+#define UZ_OP_EQ 7
+#define UZ_OP_X 8
+
+struct RD { // alignment-record columns (device pointers)
+    const int64_t *contig_off;
+    const int32_t *max_span;
+    int32_t n_contigs;
+    const int32_t *start, *end;
+    const uint16_t *flag;
+    const uint8_t *mapq, *aux;
+    const int32_t *tlen;
+    const uint32_t *qname;
+    const int32_t *mate;
+    const uint32_t *cigar_off;
+    const uint16_t *n_cigar;
+    const uint32_t *cigar;
+    const uint16_t *l_seq;
+    const uint32_t *sq_off16;
+    const uint8_t *seq, *qual;
+    const uint8_t *qc;
+};
+
+struct Caps { // per-workgroup scratch capacities (elements)
+    int32_t A, T, H, C, I, M;
+};
+
+struct Scr {
+    uint8_t *a_cls;
+    int32_t *a_flag[2];
+    int32_t *LR, *LA;
+    int32_t *hpos, *hcanon, *h_a, *h_off, *sr_off;
+    uint8_t *sr_exists;
+    int32_t *cpos;
+    uint32_t *cvote;
+    int32_t *t_ov, *t_pass;
+    int32_t *reg_h, *reg_seg, *reg_pair;
+    uint8_t *cbase;
+    int32_t *i_seg, *i_qp, *i_L, *i_R, *i_soff, *i_pair;
+    uint8_t *i_hb;
+    unsigned long long *keys;
+    int32_t *seq_h;
+    int32_t *srt_h, *srt_pid, *srt_flag;
+    uint8_t *srt_fb;
+    int32_t *rs_off, *rs_len, *fet0, *fet1;
+    uint32_t *grp, *pvote, *pq;
+    unsigned long long *key;
+    uint8_t *assigned;
+    int32_t *fr_pair[2], *fr_pos[2];
+    uint8_t *fr_hap[2];
+    int32_t *o_flag;
+    int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
+};
+
+// carve the scratch region; with base == nullptr it only measures (returns bytes)
+template <typename T>
+UZ_HD void uz_carve(uint8_t *base, size_t &off, T *&p, size_t n) {
+    off = (off + 15) & ~(size_t)15;
+    p = reinterpret_cast<T *>(base + off);
+    off += n * sizeof(T);
+}
+UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
+    size_t o = 0;
+    const size_t A = (size_t)c.A + 1, T = (size_t)c.T + 1, H = (size_t)c.H + 2, C = (size_t)c.C + 1, I = (size_t)c.I + 2, M = (size_t)c.M + 2;
+    const size_t FR = (M > I ? M : I) + 1;
+    uz_carve(base, o, s.a_cls, A);
+    uz_carve(base, o, s.a_flag[0], A); uz_carve(base, o, s.a_flag[1], A);
+    uz_carve(base, o, s.LR, 2 * A); uz_carve(base, o, s.LA, 2 * A);
+    uz_carve(base, o, s.hpos, H); uz_carve(base, o, s.hcanon, H); uz_carve(base, o, s.h_a, H);
+    uz_carve(base, o, s.h_off, H); uz_carve(base, o, s.sr_off, H); uz_carve(base, o, s.sr_exists, H);
+    uz_carve(base, o, s.cpos, C); uz_carve(base, o, s.cvote, C);
+    uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T);
+    uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
+    uz_carve(base, o, s.i_seg, I); uz_carve(base, o, s.i_qp, I); uz_carve(base, o, s.i_L, I); uz_carve(base, o, s.i_R, I);
+    uz_carve(base, o, s.i_soff, I); uz_carve(base, o, s.i_pair, I); uz_carve(base, o, s.i_hb, I);
+    uz_carve(base, o, s.keys, M); uz_carve(base, o, s.seq_h, M);
+    uz_carve(base, o, s.srt_h, M); uz_carve(base, o, s.srt_pid, M); uz_carve(base, o, s.srt_flag, M); uz_carve(base, o, s.srt_fb, M);
+    uz_carve(base, o, s.rs_off, M); uz_carve(base, o, s.rs_len, M); uz_carve(base, o, s.fet0, M); uz_carve(base, o, s.fet1, M);
+    uz_carve(base, o, s.grp, M); uz_carve(base, o, s.pvote, M); uz_carve(base, o, s.pq, M);
+    uz_carve(base, o, s.key, M); uz_carve(base, o, s.assigned, M);
+    for (int k = 0; k < 2; k++) { uz_carve(base, o, s.fr_pair[k], FR); uz_carve(base, o, s.fr_pos[k], FR); uz_carve(base, o, s.fr_hap[k], FR); }
+    uz_carve(base, o, s.o_flag, M + C + 2);
+    uz_carve(base, o, s.misc, 8);
+    return (o + 255) & ~(size_t)255;
+}
+
+struct PhaseArgs {
+    int32_t n;
+    int32_t min_gt_qual, readlen, no_extended, read_goal, evidence_min_ratio;
+    double cutoff;
+    // sites + window lists
+    const int32_t *spos;
+    const uint8_t *sref, *salt;
+    const int64_t *cand_off, *het_off;
+    const int32_t *cand_idx, *het_idx;
+    const uint8_t *cand_flags;
+    // DNMs
+    const int32_t *rcontig, *dstart;
+    const uint8_t *dflags;
+    const uint32_t *allele_off;
+    const uint8_t *alleles;
+    RD R;
+    // results
+    int32_t *status, *counts, *origin, *evidence;
+    // optional lists: bump-allocated from one pool
+    int32_t want_lists;
+    int32_t *pool;
+    unsigned long long pool_cap;
+    unsigned long long *pool_cursor;
+    long long *list_start; // [n] start of this DNM's block in the pool, -1 = none / overflow
+    int32_t *list_len;     // [6n] dad_reads, mom_reads, dad_sites, mom_sites, ref group, alt group
+    // scheduling + scratch
+    int32_t *work_cursor;
+    uint8_t *scratch;
+    unsigned long long scratch_per_wg;
+    Caps caps;
+};
+
+// ------------------------------------------------------------------ helpers
+UZ_DEV long long uz_lower_bound(const int32_t *a, long long lo, long long hi, long long v) {
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if ((long long)a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// pysam fetch(contig, lo, hi): candidates are records with start in [lo - max_span, hi);
+// the caller still tests end > lo.
+UZ_DEV void uz_fetch_range(const RD &R, int tid, long long lo, long long hi, long long &a, long long &b) {
+    if (tid < 0 || tid >= R.n_contigs) { a = b = 0; return; }
+    const long long clo = R.contig_off[tid], chi = R.contig_off[tid + 1];
+    a = uz_lower_bound(R.start, clo, chi, lo - R.max_span[tid]);
+    b = uz_lower_bound(R.start, clo, chi, hi);
+}
+
+// index of `pos` in get_reference_positions(full_length=True), -1 if absent
+UZ_DEV int uz_qidx(const RD &R, int seg, long long pos) {
+    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    long long r = R.start[seg];
+    int q = 0;
+    const int nc = R.n_cigar[seg];
+    for (int k = 0; k < nc; k++) {
+        const int op = c[k] & 15, l = (int)(c[k] >> 4);
+        if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X) {
+            if (pos >= r && pos < r + l) return q + (int)(pos - r);
+            q += l; r += l;
+        } else if (op == UZ_OP_I || op == UZ_OP_S) q += l;
+        else if (op == UZ_OP_D || op == UZ_OP_N) r += l;
+    }
+    return -1;
+}
+UZ_DEV int uz_refpos_len(const RD &R, int seg) {
+    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    int q = 0;
+    const int nc = R.n_cigar[seg];
+    for (int k = 0; k < nc; k++) {
+        const int op = c[k] & 15, l = (int)(c[k] >> 4);
+        if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X || op == UZ_OP_I || op == UZ_OP_S) q += l;
+    }
+    return q;
+}
+UZ_DEV const uint8_t *uz_seq(const RD &R, int seg) { return R.seq + ((size_t)R.sq_off16[seg] << 4); }
+UZ_DEV const uint8_t *uz_qual(const RD &R, int seg) { return R.qual + ((size_t)R.sq_off16[seg] << 4); }
+
+// get_allele_at :56-73 -> pointer to n bases or nullptr (False)
+UZ_DEV const uint8_t *uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n) {
+    const int i = uz_qidx(R, read, pos);
+    if (i >= 0) {
+        if (i < 4 || i > readlen - 4) return nullptr;
+        if ((int)R.l_seq[read] > i + n) return uz_seq(R, read) + i;
+        return nullptr; // the mate is not consulted (quirk Q10)
+    } else if (mate >= 0) {
+        const int j = uz_qidx(R, mate, pos);
+        if (j >= 0) {
+            if (j < 4 || j > readlen - 4) return nullptr;
+            if ((int)R.l_seq[mate] > j + n) return uz_seq(R, mate) + j;
+        }
+    }
+    return nullptr;
+}
+
+// binary_search (site_searcher.py:6-47): the result list is [qp, qp+1..R, qp-1..L]; returns its length
+UZ_DEV int uz_bsearch(long long start, long long end, const int32_t *pos, int n, int &qp_out, int &L, int &Rr) {
+    int qs = 0, qe = n - 1, qsp = -1, qep = -1;
+    while (qe > -1) {
+        if (qs > qe) break;
+        if (qs == qsp && qe == qep) break;
+        qsp = qs; qep = qe;
+        const int qp = (qe + qs) / 2;
+        const long long p = pos[qp];
+        if (start <= p && p < end) {
+            int r = qp, l = qp;
+            while (r + 1 < n && start <= pos[r + 1] && pos[r + 1] <= end) r++;
+            while (l - 1 >= 0 && start <= pos[l - 1] && pos[l - 1] <= end) l--;
+            qp_out = qp; L = l; Rr = r;
+            return r - l + 1;
+        } else if (p > start) qe = qp - 1;
+        else if (p < start) qs = qp + 1;
+    }
+    qp_out = 0; L = 0; Rr = -1;
+    return 0;
+}
+UZ_DEV int uz_bsearch_nth(int m, int qp, int L, int Rr) {
+    if (m == 0) return qp;
+    if (m <= Rr - qp) return qp + m;
+    return qp - (m - (Rr - qp));
+}
+
+// the filters shared by the DNM fetch and the het-site fetch (:395-418 / :181-214), without the
+// site-specific parts.  Returns the mate or -1.
+UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, int seg) {
+    const uint32_t qc = R.qc[seg];
+    long long ins = (long long)R.tlen[seg] - 2LL * a.readlen;
+    if (ins < 0) ins = -ins;
+    if (!(qc & UZ_QC_GOOD) || (double)ins > a.cutoff) return -1;
+    const int mate = R.mate[seg];
+    if (mate < 0) return -1;
+    const uint32_t qm = R.qc[mate];
+    if (!(qm & UZ_QC_GOOD)) return -1;
+    if (!(qc & UZ_QC_NONE5) || !(qm & UZ_QC_NONE5)) return -1;
+    const long long rs = R.start[seg], re = R.end[seg], ms = R.start[mate], me = R.end[mate];
+    if ((ms <= rs && rs <= me) || (ms <= re && re <= me)) return -1; // mates overlap
+    return mate;
+}
+
+// Phase A classification of one record fetched at the DNM: 0 none, 1 "ref", 2 "alt"
+UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long long flo, long long position,
+                                const uint8_t *ref, int ref_len, const uint8_t *alt, int alt_len) {
+    if (!((long long)R.end[seg] > flo)) return 0;
+    const int mate = uz_pair_ok(R, a, seg);
+    if (mate < 0) return 0;
+    if (ref_len == alt_len) { // snv_match_alleles :296-336
+        const uint8_t *al = uz_allele_at(R, a.readlen, seg, mate, position, ref_len);
+        if (!al) return 0;
+        bool eq = true;
+        for (int k = 0; k < ref_len; k++) eq &= al[k] == ref[k];
+        if (eq) return 1;
+        eq = true;
+        for (int k = 0; k < alt_len; k++) eq &= al[k] == alt[k];
+        return eq ? 2 : 0;
+    }
+    // indel_match_alleles :266-293
+    const int var_len = ref_len > alt_len ? ref_len : alt_len;
+    const int rp = uz_qidx(R, seg, position);
+    if (rp < 0) return 0;
+    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    bool has_id = false;
+    int oi = 0;
+    const int nc = R.n_cigar[seg];
+    for (int k = 0; k < nc && oi < rp + var_len; k++) { // per-op expansion indexed by the query index (quirk Q16)
+        const int op = c[k] & 15, l = (int)(c[k] >> 4);
+        const int a0 = oi > rp ? oi : rp, a1 = (oi + l) < (rp + var_len) ? (oi + l) : (rp + var_len);
+        if (a0 < a1 && (op == UZ_OP_I || op == UZ_OP_D)) has_id = true;
+        oi += l;
+    }
+    const uint8_t *ql = uz_qual(R, seg);
+    const int ls = R.l_seq[seg];
+    for (int k = rp; k < rp + var_len && k < ls; k++)
+        if ((int)ql[k] < a.min_gt_qual) return 0;
+    if (has_id) return 2;
+    if (7 < rp && rp < uz_refpos_len(R, seg) - 7) return 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------ one DNM
+UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) {
+    const RD &R = a.R;
+    const long long c0 = a.cand_off[d], h0 = a.het_off[d];
+    const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);
+    WG_SYNC();
+    WG_T0 {
+        a.status[d] = UZ_ST_NO_CAND;
+        a.origin[d] = UZ_OR_NONE; a.evidence[d] = 0;
+        for (int k = 0; k < 4; k++) a.counts[4 * d + k] = 0;
+        if (a.want_lists) { a.list_start[d] = -1; for (int k = 0; k < 6; k++) a.list_len[6 * d + k] = 0; }
+    }
+    if (nc <= 0) return; // snv_phaser.py:254-262
+    WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
+    const int tid = a.rcontig[d];
+    const long long position = a.dstart[d];
+    const uint8_t *ref = a.alleles + a.allele_off[2 * d];
+    const int ref_len = (int)(a.allele_off[2 * d + 1] - a.allele_off[2 * d]);
+    const uint8_t *alt = a.alleles + a.allele_off[2 * d + 1];
+    const int alt_len = (int)(a.allele_off[2 * d + 2] - a.allele_off[2 * d + 1]);
+    const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
+
+    WG_FOR(k, nc) { s.cpos[k] = a.spos[a.cand_idx[c0 + k]]; s.cvote[k] = 0; }
+    WG_FOR(k, nh) s.hpos[k] = a.spos[a.het_idx[h0 + k]];
+
+    // ---- A: DNM reads -> ordered "ref" / "alt" lists (each hit contributes read, mate)
+    long long fa, fb;
+    uz_fetch_range(R, tid, flo, position + 1, fa, fb);
+    const int nA = (int)(fb - fa);
+    if (nA > a.caps.A || nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+    WG_FOR(i, nA) {
+        const int cl = uz_classify_dnm_read(R, a, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
+        s.a_cls[i] = (uint8_t)cl;
+        s.a_flag[0][i] = cl == 1;
+        s.a_flag[1][i] = cl == 2;
+    }
+    WG_SYNC();
+    const int n_ref = wg_exscan(s.a_flag[0], nA, sh);
+    const int n_alt = wg_exscan(s.a_flag[1], nA, sh);
+    WG_FOR(i, nA) {
+        const int cl = s.a_cls[i];
+        if (cl) {
+            int32_t *L = cl == 1 ? s.LR : s.LA;
+            const int k = s.a_flag[cl - 1][i];
+            L[2 * k] = (int)(fa + i);
+            L[2 * k + 1] = R.mate[fa + i];
+        }
+    }
+    WG_SYNC();
+    // init elements in seeding order: "ref" list then "alt" list (:226)
+    const int nI = 2 * (n_ref + n_alt);
+    WG_FOR(m, nI) {
+        const bool is_ref = m < 2 * n_ref;
+        s.i_seg[m] = is_ref ? s.LR[m] : s.LA[m - 2 * n_ref];
+        s.i_hb[m] = is_ref ? 0 : 1;
+    }
+    WG_SYNC();
+
+    int E = 0, S = 0, P = 0;
+    bool exception = false;
+    if (!a.no_extended) {
+        // ---- B: registration at every het site, in list order
+        WG_FOR(h, nh) {
+            long long ha, hb;
+            uz_fetch_range(R, tid, s.hpos[h], (long long)s.hpos[h] + 1, ha, hb);
+            s.h_a[h] = (int)ha;
+            s.h_off[h] = (int)(hb - ha);
+            s.hcanon[h] = h; // fixed below
+            s.sr_exists[h] = 0;
+        }
+        WG_SYNC();
+        WG_FOR(h, nh) { // first het index with the same position (the list is sorted by position)
+            int c = h;
+            while (c > 0 && s.hpos[c - 1] == s.hpos[h]) c--;
+            s.hcanon[h] = c;
+        }
+        const int T = wg_exscan(s.h_off, nh, sh);
+        if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+        WG_T0 s.h_off[nh] = T;
+        WG_SYNC();
+        WG_FOR(t, T) {
+            int lo = 0, hi = nh; // last h with h_off[h] <= t
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.h_off[mid] <= t) lo = mid; else hi = mid; }
+            // skip empty ranges that share the same offset
+            const int h = lo;
+            const int seg = s.h_a[h] + (t - s.h_off[h]);
+            s.reg_h[t] = h; // provisional: het index of work item t
+            s.t_ov[t] = (long long)R.end[seg] > (long long)s.hpos[h];
+        }
+        WG_SYNC();
+        // enumerate index of the fetch iterator = overlapping records before this one at the same site
+        WG_FOR(t, T) s.t_pass[t] = s.t_ov[t];
+        WG_SYNC();
+        (void)wg_exscan(s.t_pass, T, sh);
+        WG_FOR(t, T) {
+            const int h = s.reg_h[t];
+            const int seg = s.h_a[h] + (t - s.h_off[h]);
+            bool ok = s.t_ov[t] != 0;
+            if (ok) {
+                const int ei = s.t_pass[t] - s.t_pass[s.h_off[h]];
+                ok = !(ei > a.read_goal); // :179
+            }
+            if (ok) ok = uz_pair_ok(R, a, seg) >= 0 && (R.qc[seg] & UZ_QC_NM5);
+            s.t_ov[t] = ok;
+        }
+        WG_SYNC();
+        WG_FOR(t, T) s.t_pass[t] = s.t_ov[t];
+        WG_SYNC();
+        E = wg_exscan(s.t_pass, T, sh);
+        // compact in place is unsafe across lanes: stage through seq_h / keys
+        WG_FOR(t, T) {
+            if (s.t_ov[t]) {
+                const int k = s.t_pass[t];
+                const int h = s.reg_h[t];
+                s.seq_h[k] = h;
+                s.srt_h[k] = s.h_a[h] + (t - s.h_off[h]);
+            }
+        }
+        WG_SYNC();
+        WG_FOR(k, E) { s.reg_h[k] = s.seq_h[k]; s.reg_seg[k] = s.srt_h[k]; }
+        // site_reads range of het index h: entries [sr_off[h], sr_off[h+1])
+        WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.t_pass[s.h_off[h]] : E) : E;
+        WG_SYNC();
+        WG_FOR(h, nh) {
+            // a canonical site exists in site_reads once any of its duplicates registered a read (:217-218)
+            if (s.sr_off[h + 1] > s.sr_off[h]) s.sr_exists[s.hcanon[h]] = 1;
+        }
+        // ---- C: seeding (:226-249): matches of every init element among the het sites
+        WG_FOR(m, nI) {
+            const int seg = s.i_seg[m];
+            int nm = 0, qp = 0, L = 0, Rr = -1;
+            if (R.mate[seg] >= 0) nm = uz_bsearch(R.start[seg], R.end[seg], s.hpos, nh, qp, L, Rr);
+            s.i_qp[m] = qp; s.i_L[m] = L; s.i_R[m] = Rr;
+            s.i_soff[m] = nm;
+        }
+        WG_SYNC();
+        S = wg_exscan(s.i_soff, nI, sh);
+        WG_T0 s.i_soff[nI] = S;
+        WG_SYNC();
+        if (S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
+        WG_FOR(m, nI) {
+            const int nm = s.i_soff[m + 1] - s.i_soff[m];
+            for (int j = 0; j < nm; j++) s.seq_h[E + s.i_soff[m] + j] = uz_bsearch_nth(j, s.i_qp[m], s.i_L[m], s.i_R[m]);
+        }
+        WG_SYNC();
+    }
+    // ---- S: pair table.  Keys (qname << 24 | seq): registrations seq < E, seeds, then one
+    // presence entry per init element (seq >= E + S) so that every grouped pair has an id.
+    const int M = E + S + nI;
+    if (M >= (1 << 20) || M > a.caps.M || nI > a.caps.I) { // rank-key field widths / scratch: loud, never silent
+        WG_T0 a.status[d] = UZ_ST_CAPACITY;
+        return;
+    }
+    WG_FOR(x, M) {
+        uint32_t q;
+        if (x < E) q = R.qname[s.reg_seg[x]];
+        else if (x < E + S) {
+            int lo = 0, hi = nI; // init element owning seed x - E
+            const int sx = x - E;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.i_soff[mid] <= sx) lo = mid; else hi = mid; }
+            q = R.qname[s.i_seg[lo]];
+        } else q = R.qname[s.i_seg[x - E - S]];
+        s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
+    }
+    WG_SYNC();
+    wg_sort64(s.keys, M, sh);
+    WG_FOR(x, M) s.srt_flag[x] = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
+    WG_SYNC();
+    WG_FOR(x, M) s.srt_pid[x] = s.srt_flag[x];
+    WG_SYNC();
+    P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1
+    WG_FOR(x, M) {
+        const int pid = s.srt_pid[x] + s.srt_flag[x] - 1;
+        s.srt_pid[x] = pid;
+        const int seq = (int)(s.keys[x] & 0xFFFFFF);
+        if (s.srt_flag[x]) { s.rs_off[pid] = x; s.pq[pid] = (uint32_t)(s.keys[x] >> 24); }
+        if (seq < E) s.reg_pair[seq] = pid;
+        else if (seq >= E + S) s.i_pair[seq - E - S] = pid;
+        s.srt_h[x] = seq < E + S ? s.seq_h[seq] : -1;
+    }
+    WG_T0 s.rs_off[P] = M;
+    WG_SYNC();
+    WG_FOR(p, P) {
+        const int x0 = s.rs_off[p], x1 = s.rs_off[p + 1];
+        int len = 0, f0 = -1, f1 = -1;
+        for (int x = x0; x < x1; x++) { // ascending sequence = the reference's time order
+            const int seq = (int)(s.keys[x] & 0xFFFFFF);
+            if (seq < E + S) len++;
+            if (seq < E) { f0 = s.reg_seg[seq]; f1 = R.mate[f0]; }          // :222
+            else if (seq >= E + S) {                                        // :233-234
+                const int sg = s.i_seg[seq - E - S];
+                if (R.mate[sg] >= 0) { f0 = sg; f1 = R.mate[sg]; }
+            }
+        }
+        if (len >= 4096) s.misc[2] = 1; // rank key: 12 bits for the read_sites index
+        s.rs_len[p] = len;
+        s.fet0[p] = f0; s.fet1[p] = f1;
+        s.grp[p] = 0; s.pvote[p] = 0;
+        s.key[p] = ~0ULL;
+        s.assigned[p] = 0;
+    }
+    WG_SYNC();
+    WG_FOR(m, nI) wg_atomic_or(&s.grp[s.i_pair[m]], s.i_hb[m] ? 2u : 1u); // :230
+    WG_SYNC();
+    if (s.misc[2]) { WG_SYNC(); WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+
+    if (!a.no_extended) {
+        // ---- D: static allele tables
+        WG_FOR(x, M) {
+            uint8_t fbv = 0;
+            const int h = s.srt_h[x];
+            if (h >= 0) {
+                const int p = s.srt_pid[x];
+                const uint8_t *al = s.fet0[p] >= 0 ? uz_allele_at(R, a.readlen, s.fet0[p], s.fet1[p], s.hpos[h], 1) : nullptr; // :91-96
+                if (al) {
+                    const int si = a.het_idx[h0 + h];
+                    if (*al == a.sref[si] || *al == a.salt[si]) fbv = *al; // :98-105
+                }
+            }
+            s.srt_fb[x] = fbv;
+        }
+        WG_FOR(k, E) {
+            uint8_t cb = 0;
+            const int p = s.reg_pair[k];
+            const int prim = s.fet0[p];
+            const long long hp = s.hpos[s.reg_h[k]];
+            const int rp = uz_qidx(R, prim, hp); // :114-124 -- the primary segment must cover the site
+            if (rp >= 4 && rp <= a.readlen - 4 && (int)R.l_seq[prim] > rp + 1 && (int)uz_qual(R, prim)[rp] >= a.min_gt_qual)
+                cb = uz_seq(R, prim)[rp];
+            s.cbase[k] = cb;
+        }
+        WG_SYNC();
+        // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
+        int F = nI, cur = 0;
+        WG_FOR(e, nI) {
+            const int na = 2 * n_alt;
+            const int m = e < na ? (2 * n_ref + e) : (e - na);
+            s.fr_pair[0][e] = s.i_pair[m];
+            s.fr_pos[0][e] = -1;
+            s.fr_hap[0][e] = s.i_hb[m];
+        }
+        WG_SYNC();
+        WG_FOR(p, P) if (s.grp[p]) s.assigned[p] = 1;
+        WG_SYNC();
+        while (F > 0) {
+            WG_FOR(e, F) {
+                const int p = s.fr_pair[cur][e];
+                const int fpos = s.fr_pos[cur][e];
+                const int hap = s.fr_hap[cur][e];
+                const int x0 = s.rs_off[p], len = s.rs_len[p];
+                for (int j = 0; j < len; j++) {
+                    const int h = s.srt_h[x0 + j];
+                    if (s.hpos[h] == fpos) continue;            // :89-90
+                    const uint8_t fbv = s.srt_fb[x0 + j];
+                    if (!fbv) continue;                          // :104-105
+                    const int canon = s.hcanon[h];
+                    if (!s.sr_exists[canon]) { s.misc[0] = 1; continue; } // :106 KeyError
+                    const int si = a.het_idx[h0 + h];
+                    const uint8_t nonf = fbv == a.sref[si] ? a.salt[si] : a.sref[si];
+                    int hl = canon; // last het index of the run of equal positions
+                    while (hl + 1 < nh && s.hpos[hl + 1] == s.hpos[canon]) hl++;
+                    const int k0 = s.sr_off[canon], k1 = s.sr_off[hl + 1];
+                    for (int k = k0; k < k1; k++) {
+                        const int p2 = s.reg_pair[k];
+                        if (s.assigned[p2]) continue;            // :108-110 (assigned before this level)
+                        const uint8_t cb = s.cbase[k];
+                        if (!cb) continue;
+                        int target;
+                        if (cb == fbv) target = hap;             // :134-136
+                        else if (cb == nonf) target = hap ^ 1;   // :137-141
+                        else continue;
+                        const unsigned long long key =
+                            ((((unsigned long long)e << 12 | (unsigned long long)j) << 20 | (unsigned long long)(k - k0)) << 1) | (unsigned long long)target;
+                        wg_atomic_min64(&s.key[p2], key);
+                    }
+                }
+            }
+            WG_SYNC();
+            // winners in the order the reference appends them: "ref" targets by rank, then "alt"
+            // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
+            // sorting the keys alone is enough: the pair is recovered from the rank.
+            WG_FOR(p, P) s.o_flag[p] = (!s.assigned[p] && s.key[p] != ~0ULL) ? 1 : 0;
+            WG_SYNC();
+            const int W = wg_exscan(s.o_flag, P, sh);
+            WG_FOR(p, P) {
+                if (!s.assigned[p] && s.key[p] != ~0ULL) {
+                    const unsigned long long k = s.key[p];
+                    s.keys[s.o_flag[p]] = ((k & 1ULL) << 63) | (k >> 1);
+                }
+            }
+            WG_SYNC();
+            wg_sort64(s.keys, W, sh);
+            WG_FOR(w, W) {
+                const unsigned long long ok = s.keys[w];
+                const int e = (int)((ok >> 32) & 0xFFFFF), j = (int)((ok >> 20) & 0xFFF), krel = (int)(ok & 0xFFFFF);
+                const int pe = s.fr_pair[cur][e];
+                const int h = s.srt_h[s.rs_off[pe] + j];
+                const int p = s.reg_pair[s.sr_off[s.hcanon[h]] + krel];
+                s.fr_pair[cur ^ 1][w] = p;
+                s.fr_pos[cur ^ 1][w] = s.hpos[h];
+                s.fr_hap[cur ^ 1][w] = (uint8_t)(ok >> 63);
+            }
+            WG_SYNC();
+            WG_FOR(w, W) {
+                const int p = s.fr_pair[cur ^ 1][w];
+                s.assigned[p] = 1;
+                s.grp[p] |= s.fr_hap[cur ^ 1][w] ? 2u : 1u;
+                s.key[p] = ~0ULL;
+            }
+            WG_SYNC();
+            F = W;
+            cur ^= 1;
+        }
+        exception = s.misc[0] != 0;
+    }
+    WG_SYNC();
+    if (exception) {
+        WG_T0 a.status[d] = UZ_ST_REF_EXCEPTION;
+        return;
+    }
+
+    // ---- F: join + vote.  Items: extended -> both fetched segments of every grouped pair per
+    // haplotype (:254-263); --no-extended -> the init list elements themselves.
+    const int n_items = a.no_extended ? nI : 4 * P;
+    WG_FOR(it, n_items) {
+        int seg, hb, p;
+        if (a.no_extended) { seg = s.i_seg[it]; hb = s.i_hb[it]; p = s.i_pair[it]; }
+        else {
+            p = it >> 2; hb = (it >> 1) & 1;
+            if (!(s.grp[p] & (1u << hb)) || s.fet0[p] < 0) continue;
+            seg = (it & 1) ? s.fet1[p] : s.fet0[p];
+        }
+        int qp, L, Rr;
+        const int nm = uz_bsearch(R.start[seg], R.end[seg], s.cpos, nc, qp, L, Rr);
+        if (nm <= 0) continue;
+        bool dad_alt = false, mom_alt = false;
+        for (int ci = L; ci <= Rr; ci++) {
+            if (a.cand_flags[c0 + ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
+        }
+        if (dad_alt && mom_alt) continue; // site_searcher.py:74-75
+        wg_atomic_add(&s.misc[1], 1);
+        for (int ci = L; ci <= Rr; ci++) {
+            const int rp = uz_qidx(R, seg, s.cpos[ci]); // snv_phaser.py:28-33
+            if (rp < 0 || rp >= (int)R.l_seq[seg]) continue;
+            const uint8_t b = uz_seq(R, seg)[rp];
+            const int si = a.cand_idx[c0 + ci];
+            bool from_ref;
+            if (b == a.sref[si]) from_ref = true;       // :41-42
+            else if (b == a.salt[si]) from_ref = false; // :43-44
+            else continue;
+            const bool alt_is_dad = (a.cand_flags[c0 + ci] & UZ_CF_ALT_DAD) != 0;
+            const bool to_alt_parent = (from_ref && hb == 0) || (!from_ref && hb == 1); // :52-69
+            const bool to_dad = to_alt_parent ? alt_is_dad : !alt_is_dad;
+            wg_atomic_or(&s.pvote[p], to_dad ? 1u : 2u);
+            wg_atomic_or(&s.cvote[ci], to_dad ? 1u : 2u);
+        }
+    }
+    WG_SYNC();
+    const int n_match = s.misc[1];
+    WG_SYNC();
+    if (n_match <= 0) {
+        WG_T0 a.status[d] = UZ_ST_NO_OVERLAP; // snv_phaser.py:158-166
+        return;
+    }
+    // unique positions: fold the votes of records sharing a position onto the first of the run
+    WG_FOR(ci, nc) {
+        if (ci == 0 || s.cpos[ci - 1] != s.cpos[ci]) {
+            uint32_t v = 0;
+            for (int k = ci; k < nc && s.cpos[k] == s.cpos[ci]; k++) v |= s.cvote[k];
+            s.o_flag[ci] = (int)v;
+        } else s.o_flag[ci] = 0;
+    }
+    WG_SYNC();
+    WG_FOR(ci, nc) s.cvote[ci] = (uint32_t)s.o_flag[ci];
+    WG_SYNC();
+    // counts (and optional lists) through four flag scans; pairs are in ascending qname order
+    int cnt[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int n = k < 2 ? P : (k < 4 ? nc : P);
+        int32_t *fl = s.o_flag;
+        WG_FOR(i, n) {
+            int v;
+            if (k < 2) v = (s.pvote[i] >> k) & 1;
+            else if (k < 4) v = (s.cvote[i] >> (k - 2)) & 1;
+            else v = (s.grp[i] >> (k - 4)) & 1;
+            fl[i] = v;
+        }
+        WG_SYNC();
+        cnt[k] = (k < 4 || a.want_lists) ? wg_exscan(fl, n, sh) : 0;
+        if (a.want_lists) {
+            // one bump allocation per DNM, made when the first list is known: reserve the upper bound 2P + 2nc + 2P
+            if (k == 0) {
+                WG_T0 {
+                    const unsigned long long need = (unsigned long long)(4 * P + 2 * nc);
+                    const unsigned long long at = wg_atomic_add64(a.pool_cursor, need);
+                    a.list_start[d] = (at + need <= a.pool_cap) ? (long long)at : -1;
+                }
+                WG_SYNC();
+            }
+            const long long base = a.list_start[d];
+            if (base >= 0) {
+                long long off = base;
+                for (int kk = 0; kk < k; kk++) off += cnt[kk];
+                WG_FOR(i, n) {
+                    int v;
+                    if (k < 2) v = (s.pvote[i] >> k) & 1;
+                    else if (k < 4) v = (s.cvote[i] >> (k - 2)) & 1;
+                    else v = (s.grp[i] >> (k - 4)) & 1;
+                    if (v) a.pool[off + fl[i]] = (k < 2 || k >= 4) ? (int32_t)s.pq[i] : s.cpos[i];
+                }
+            }
+            WG_T0 a.list_len[6 * d + k] = cnt[k];
+            WG_SYNC();
+        }
+    }
+    WG_T0 {
+        a.status[d] = UZ_ST_OK;
+        for (int k = 0; k < 4; k++) a.counts[4 * d + k] = cnt[k];
+        // summarize_record, read-backed branch: unfazed.py:206-234
+        const long long dr = cnt[0], mr = cnt[1], r = a.evidence_min_ratio;
+        if (dr > 0 && dr >= r * mr) { a.origin[d] = UZ_OR_DAD; a.evidence[d] = cnt[2]; }
+        else if (mr > 0 && mr >= r * dr) { a.origin[d] = UZ_OR_MOM; a.evidence[d] = cnt[3]; }
+        else if (dr > 0 && mr > 0) { a.origin[d] = UZ_OR_AMBIGUOUS; a.evidence[d] = (int32_t)(dr + mr); }
+    }
+}
+
+// ------------------------------------------------------------------ sizing
+// Upper bounds of the per-DNM working set, computed before the scratch is sized:
+//   b[0] records in the DNM fetch range, b[1] sum of the het-site fetch ranges, b[2] het sites,
+//   b[3] candidates, b[4] max het sites inside any window of max_span+1 bases (bounds the
+//   seeding matches of one init element).
+UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
+    const RD &R = a.R;
+    const long long h0 = a.het_off[d];
+    const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - h0);
+    b[0] = b[1] = b[4] = 0;
+    b[2] = nh; b[3] = nc;
+    if (nc <= 0) return;
+    const int tid = a.rcontig[d];
+    const long long position = a.dstart[d];
+    const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
+    long long fa, fb;
+    uz_fetch_range(R, tid, flo, position + 1, fa, fb);
+    b[0] = (int32_t)(fb - fa);
+    if (a.no_extended) return;
+    long long T = 0;
+    const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;
+    int mh = 0, left = 0;
+    for (int h = 0; h < nh; h++) {
+        const long long hp = a.spos[a.het_idx[h0 + h]];
+        long long ha, hb;
+        uz_fetch_range(R, tid, hp, hp + 1, ha, hb);
+        T += hb - ha;
+        while ((long long)a.spos[a.het_idx[h0 + left]] < hp - span - 1) left++;
+        if (h - left + 1 > mh) mh = h - left + 1;
+    }
+    b[1] = (int32_t)(T > 0x7FFFFFF0LL ? 0x7FFFFFF0LL : T);
+    b[4] = mh;
+}
+
+// per-segment QC bits (K3a): goodread (:28-53) and the two CIGAR counts of :190-203
+UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual, int min_base_qual) {
+    const uint32_t f = R.flag[seg];
+    const uint32_t aux = R.aux[seg];
+    if (aux & UZ_AUX_DECODE_BAD) return 0; // no CIGAR / SEQ / QUAL: never a good read (unpinned)
+    const bool base_ok = !((f & 512u) || (f & 4u) || (f & 1024u) || (int)R.mapq[seg] < min_map_qual || (f & 256u) ||
+                           (f & 2048u) || (f & 8u) || !(aux & UZ_AUX_MATE_SAME_TID)); // :31-41
+    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    const int nc = R.n_cigar[seg];
+    int nonmatch = 0, none = 0;
+    for (int k = 0; k < nc; k++) {
+        const int op = c[k] & 15, l = (int)(c[k] >> 4);
+        if (op != UZ_OP_M && op != UZ_OP_EQ) nonmatch++;
+        if (op == UZ_OP_I || op == UZ_OP_S) none += l;
+    }
+    uint8_t qc = 0;
+    if (base_ok) {
+        qc |= UZ_QC_GOOD_DISC;
+        const uint8_t *q = uz_qual(R, seg);
+        const int ls = R.l_seq[seg];
+        int low = 0;
+        for (int k = 0; k < ls; k++) low += (int)q[k] < min_base_qual; // :43-46
+        if (low <= 10 && nc <= 10) qc |= UZ_QC_GOOD; // "mismatches" counts every CIGAR op (quirk Q9)
+    }
+    if (nonmatch <= 5) qc |= UZ_QC_NM5;
+    if (none <= 5) qc |= UZ_QC_NONE5;
+    return qc;
+}

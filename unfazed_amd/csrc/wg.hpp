@@ -1,0 +1,118 @@
+// wg.hpp -- workgroup-level building blocks of the per-DNM kernels.
+//
+// The per-DNM read stage is written as a sequence of block-parallel phases
+// (WG_FOR loops separated by barriers) over arrays in a per-workgroup scratch
+// region.  The same source compiles two ways:
+//   * hipcc, gfx950: WG_FOR strides the loop over the 256 lanes of the workgroup,
+//     WG_SYNC is __syncthreads(), scans/sorts go through LDS;
+//   * -DUZ_EMU (g++, tests/emu only): one lane, loops run sequentially.  This is
+//     a debugging aid for the authoring container, which has no GPU; it is never
+//     loaded by the product.
+// For the two builds to agree, no phase may depend on the order in which lanes
+// reach an atomic: order-sensitive steps use explicit ranks, scans and sorts.
+#pragma once
+#include <cstdint>
+
+#ifdef UZ_EMU
+#include <algorithm>
+#define UZ_DEV static inline
+#define UZ_HD static inline
+#define WG_NT 1
+#define WG_TID 0
+#define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
+#define WG_SYNC() ((void)0)
+#define WG_T0 if (true)
+UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
+UZ_DEV int wg_atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
+UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
+UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+#else
+#include <hip/hip_runtime.h>
+#define UZ_DEV __device__ __forceinline__
+#define UZ_HD __host__ __device__ inline
+#define WG_NT 256
+#define WG_TID ((int)threadIdx.x)
+#define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += WG_NT)
+#define WG_SYNC() __syncthreads()
+#define WG_T0 if (threadIdx.x == 0)
+UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
+UZ_DEV int wg_atomic_add(int *p, int v) { return atomicAdd(p, v); }
+UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
+UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+#endif
+
+#define WG_SORT_LDS_CAP 2048 // u64 keys sorted in LDS (16 KiB); larger sorts run in the scratch region
+
+struct WgShared {
+    int part[WG_NT + 1];
+    unsigned long long sortbuf[WG_SORT_LDS_CAP];
+    int bcast[4];
+};
+
+// In-place exclusive scan of a[0..n) -> returns the total.  Block-uniform call.
+UZ_DEV int wg_exscan(int *a, int n, WgShared *sh) {
+#ifdef UZ_EMU
+    int s = 0;
+    for (int i = 0; i < n; i++) { int v = a[i]; a[i] = s; s += v; }
+    return s;
+#else
+    __syncthreads();
+    const int t = threadIdx.x;
+    const int chunk = (n + WG_NT - 1) / WG_NT;
+    int lo = t * chunk; if (lo > n) lo = n;
+    int hi = lo + chunk; if (hi > n) hi = n;
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += a[i];
+    sh->part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < WG_NT; off <<= 1) {
+        const int v = t >= off ? sh->part[t - off] : 0;
+        __syncthreads();
+        sh->part[t] += v;
+        __syncthreads();
+    }
+    int run = sh->part[t] - s;
+    const int total = sh->part[WG_NT - 1];
+    for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
+    __syncthreads();
+    return total;
+#endif
+}
+
+// Ascending sort of a[0..n) (distinct keys).  a must have room for the next power of two.
+UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh) {
+#ifdef UZ_EMU
+    std::sort(a, a + n);
+#else
+    __syncthreads();
+    if (n <= 1) return;
+    int N = 1;
+    while (N < n) N <<= 1;
+    unsigned long long *w = a;
+    const bool in_lds = N <= WG_SORT_LDS_CAP;
+    if (in_lds) {
+        w = sh->sortbuf;
+        for (int i = threadIdx.x; i < N; i += WG_NT) w[i] = i < n ? a[i] : ~0ULL;
+    } else {
+        for (int i = n + (int)threadIdx.x; i < N; i += WG_NT) w[i] = ~0ULL;
+    }
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < N; i += WG_NT) {
+                const int x = i ^ j;
+                if (x > i) {
+                    const unsigned long long u = w[i], v = w[x];
+                    const bool up = (i & k) == 0;
+                    if ((u > v) == up) { w[i] = v; w[x] = u; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (in_lds) {
+        for (int i = threadIdx.x; i < n; i += WG_NT) a[i] = w[i];
+        __syncthreads();
+    }
+#endif
+}
