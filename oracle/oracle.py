@@ -51,6 +51,8 @@ def lib():
         L.uzo_result_free.restype = None
         L.uzo_concordant_cutoff.argtypes = [C.c_void_p, C.c_int64, C.c_int32]
         L.uzo_concordant_cutoff.restype = C.c_double
+        L.uzo_bsearch.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
+        L.uzo_bsearch.restype = C.c_int
         _LIB = L
     return _LIB
 
@@ -119,3 +121,10 @@ def phase(params, sites, reads, dnms, found, d_lo=0, d_hi=None, keep_lists=True)
 def concordant_cutoff(tlen, readlen):
     t = np.ascontiguousarray(tlen, dtype=np.int32)
     return lib().uzo_concordant_cutoff(t.ctypes.data, t.shape[0], readlen)
+
+
+def bsearch(start, end, pos):
+    p = np.ascontiguousarray(pos, dtype=np.int32)
+    out = np.zeros(max(1, len(p)), dtype=np.int32)
+    n = lib().uzo_bsearch(int(start), int(end), p.ctypes.data if len(p) else None, len(p), out.ctypes.data)
+    return out[:n].tolist()

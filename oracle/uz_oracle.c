@@ -358,6 +358,11 @@ static int bsearch_sites(int64_t start, int64_t end, const int32_t *pos, int n, 
     return nm;
 }
 
+/* exported for the golden tests of binary_search */
+int uzo_bsearch(int64_t start, int64_t end, const int32_t *pos, int n, int32_t *out) {
+    return bsearch_sites(start, end, pos, n, out, n);
+}
+
 typedef struct uzo_result {
     int32_t n;
     int32_t *status;   /* [n] UZ_ST_* */

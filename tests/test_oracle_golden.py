@@ -1,0 +1,89 @@
+"""The CPU oracle (and the host logic around it) against the golden vectors produced
+by the reference itself (tests/golden/make_golden.py).  CPU only."""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import norm_records, run_host, tables
+from oracle import oracle as orc
+from oracle_backend import OracleBackend
+from synth.small import SmallConfig, make_small
+from unfazed_amd import abi, summarize
+from unfazed_amd.hostpath import PhasingHost, concordant_cutoff
+from unfazed_amd.model import SiteRecord, SitesTable
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SNV = sorted(glob.glob(os.path.join(GOLD, "snv_*.json")))
+
+
+def load_snv(path):
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import dataset_digest
+    g = json.load(open(path))
+    ds = make_small(SmallConfig(**g["config"]))
+    assert dataset_digest(ds) == g["digest"], "synthetic generator drifted from the fixture inputs"
+    return g, ds
+
+
+def check_against_golden(backend, g, ds):
+    recs, dnms, err = run_host(backend, ds, **g["run"])
+    assert list(recs.keys()) == g["record_order"]
+    assert json.loads(json.dumps(norm_records(recs))) == g["records"]
+    ref = {(d["chrom"], d["start"], d["end"], d["kid"]): d for d in g["dnms"]}
+    for d in dnms:
+        r = ref[(d["chrom"], d["start"], d["end"], d["kid"])]
+        assert d.get("candidate_sites") == r.get("candidate_sites")
+        assert d.get("het_sites") == r.get("het_sites")
+    assert [d["start"] for d in dnms] is not None
+    assert err.splitlines() == g["stderr"]
+
+
+@pytest.mark.parametrize("path", SNV, ids=[os.path.basename(p)[4:-5] for p in SNV])
+def test_phase_snvs_golden(path):
+    g, ds = load_snv(path)
+    check_against_golden(OracleBackend(), g, ds)
+
+
+def test_find_grid_golden():
+    g = json.load(open(os.path.join(GOLD, "find_grid.json")))
+    recs = [SiteRecord("1", s["start"], s["ref"], s["alts"], s["gt"], s["rd"], s["ad"], s["gq"]) for s in g["sites"]]
+    sites = SitesTable.from_records(recs, g["samples"])
+    ped = {"kid": {"kid": "kid", "dad": "dad", "mom": "mom", "sex": "2"}}
+    host = PhasingHost(OracleBackend(), sites, {})
+    n_c = 0
+    for c in g["cases"]:
+        ps = c["params"]
+        P = abi.make_params(min_gt_qual=ps["min_gt_qual"], min_depth=ps["min_depth"], ab_homref=ps["ab_homref"],
+                            ab_homalt=ps["ab_homalt"], ab_het=ps["ab_het"])
+        dn = [dict(chrom="1", start=c["dnm"]["start"], end=c["dnm"]["end"], kid="kid", vartype=c["dnm"]["vartype"],
+                   bam="", cram_ref=None)]
+        host.find(dn, ped, c["search_dist"], 1, "38", 1000, True, P, whole_region=c["whole_region"])
+        assert dn[0]["candidate_sites"] == c["candidate_sites"]
+        assert dn[0]["het_sites"] == c["het_sites"]
+        n_c += len(c["candidate_sites"])
+    assert n_c > 150
+
+
+def test_binary_search_golden():
+    for c in json.load(open(os.path.join(GOLD, "bsearch.json"))):
+        assert orc.bsearch(c["start"], c["end"], c["pos"]) == c["order"], c
+
+
+def test_summarize_golden():
+    g = json.load(open(os.path.join(GOLD, "summarize.json")))
+    for c in g["cases"]:
+        got = summarize.summarize_record(c["record"], c["include_ambiguous"], True, c["ratio"])
+        assert got == c["summary"], c
+    for b in g["beds"]:
+        assert summarize.bed_lines(b["records"], b["include_ambiguous"], b["verbose"], 10) == b["lines"]
+
+
+def test_cutoff_golden():
+    for c in json.load(open(os.path.join(GOLD, "cutoff.json"))):
+        head = np.array(c["tlen"][: c["insert_size_max_sample"] + 1], dtype=np.int32)
+        assert float(concordant_cutoff(head, c["readlen"], 3)) == c["cutoff"]
+        assert orc.concordant_cutoff(head, c["readlen"]) == c["cutoff"]
