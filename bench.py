@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""bench.py -- phased DNMs/s of the per-DNM phasing path on MI355X (BASELINE.json metric).
+
+One "step" = one whole pass of the hot path over one batch of synthetic DNMs with every
+input column already resident in HBM: K1 site scan over the whole sites table, K2 window
+emit, K3a per-record QC, the per-DNM collect / chain / join / vote kernel, and the copy of
+the per-DNM results (status, 4 counts, origin, evidence) back to the host.
+
+Workload (BASELINE.json configs[2]): N synthetic SNV/INDEL DNMs
+(90/10) of one trio, whole-genome-like sites table (default 20 M sites, 24 contigs), 30x
+paired-end pile-up within +-6 kb of every DNM, extended read-backed phasing on.  The data
+are generated in place in HBM by synth/uzsynth_hip.hip (no host copy of the read table).
+
+Multi-GPU: DNMs shard embarrassingly, one process per GPU, no collective on the data path;
+every rank phases its own batch (weak scaling); the only communication is the barrier and
+the max-over-ranks of the elapsed time.
+
+Extra objects on the JSON line: `roofline` for the K1 site-scan kernel (HBM-bound;
+algorithmic bytes = 20 B/site: 19 read + 1 written) measured with HIP events on
+the library's stream, and `cpu_baseline`: the CPU oracle (a C port of the reference's
+algorithm, oracle/) timed on this box's host cores on a bounded sample of the same DNMs,
+whose results are also compared with the GPU's (parity at bench scale).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dnms", type=int, default=int(os.environ.get("UZ_BENCH_DNMS", 100000)), help="DNMs per GPU")
+    ap.add_argument("--sites", type=int, default=int(os.environ.get("UZ_BENCH_SITES", 20000000)))
+    ap.add_argument("--cpu-dnms", type=int, default=4000, help="DNMs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X GPU: there is no CPU fallback for the phasing path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from synth import bigsynth
+    from synth.sites_np import make_sites, place_dnms_full
+    from unfazed_amd import abi, build
+    from unfazed_amd.engine import HipEngine, K_PHASE, K_SEG_QC, K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL
+
+    build.build()
+    t_gen = time.time()
+    sc = make_sites(args.sites, seed=202)
+    dn = place_dnms_full(sc, args.dnms, seed=201 + 1000 * rank)
+    cfg = bigsynth.make_cfg(seed=203 + 1000 * rank, n_pairs=1200, half_width=6000, n_dnms=dn.n)
+    wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, device=local_rank)
+    t_gen = time.time() - t_gen
+
+    eng = HipEngine(local_rank)
+    P = abi.make_params()  # the reference's CLI defaults
+    eng.set_params(P)
+    sid = eng.adopt_sites(wl.sites_view())
+    fid = eng.adopt_family(sid, wl.family_view())
+    rid = eng.adopt_reads(wl.reads_view())
+    # concordant insert cutoff: host scalar per kid (read_collector.py:11-25) from the first records
+    head = wl.dev.get(wl.out_ptrs["tlen"], (min(wl.n_segs, 1000001),), np.int32)
+    from unfazed_amd.hostpath import concordant_cutoff
+    cutoff = concordant_cutoff(head, P.readlen, 3)
+    n = dn.n
+    dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
+
+    def step():
+        eng.drop_derived()
+        return eng.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.sync()
+
+    for _ in range(args.warmup):
+        res = step()
+    eng.prof_enable(True)
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE)}
+    eng.prof_enable(False)
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n * args.steps / elapsed
+    status = res["status"]
+    phased = int(((status == abi.ST_OK) & ((res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM))).sum())
+    truth = np.where(dn.origin == 0, abi.OR_DAD, abi.OR_MOM)
+    called = (status == abi.ST_OK) & ((res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM))
+    correct = int((res["origin"][called] == truth[called]).sum())
+
+    k1_ms, k1_n = prof[K_SITE_SCAN]
+    k1_us = k1_ms / max(1, k1_n) * 1e3
+    bytes_per_site = 20.0  # 19 B read (packed trio GT + 9 x u16) + 1 B class written; DESIGN.md "K1"
+    achieved = bytes_per_site * sc.n / (k1_us * 1e-6) / 1e9 if k1_n else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if int(tj.get("n_sites", -1)) == sc.n:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_site_scan", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
+                "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
+        cpu = cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, res)
+
+    if rank == 0:
+        out = {
+            "metric": "phased DNMs/sec", "value": round(value, 1), "unit": "DNMs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 allele balance)",
+            "data": "synthetic",
+            "config": {"workload": "100k synthetic SNV/INDEL DNMs, whole-genome sites VCF, --no-extended off (BASELINE configs[2])"
+                       if n == 100000 else "%d synthetic SNV/INDEL DNMs per GPU, extended on" % n,
+                       "dnms_per_gpu": n, "sites": sc.n, "coverage": "30x", "search_dist": 5000, "pairs_per_dnm": cfg.n_pairs,
+                       "alignment_records": wl.n_segs, "parallelism": "dnm-shard x%d, no collective" % world},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels_ms_per_step": {
+                "site_scan": round(prof[K_SITE_SCAN][0] / args.steps, 3),
+                "window_count+scan": round(prof[K_WINDOW_COUNT][0] / args.steps, 3),
+                "window_fill": round(prof[K_WINDOW_FILL][0] / args.steps, 3),
+                "seg_qc": round(prof[K_SEG_QC][0] / args.steps, 3),
+                "phase": round(prof[K_PHASE][0] / args.steps, 3),
+            },
+            "calls": {"phased": phased, "correct_vs_truth": correct,
+                      "status_counts": np.bincount(status, minlength=6).tolist()},
+            "generate_s": round(t_gen, 1),
+        }
+        print(json.dumps(out))
+    wl.free()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, gpu_res):
+    """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first
+    `cpu_dnms` DNMs of the GPU's batch (their read blocks are copied back from HBM), 1, 2 and all
+    cores (threads over DNM ranges, as the reference's thread pool over DNMs); its results are
+    compared with the GPU's."""
+    from oracle import oracle as orc
+    from synth import bigsynth
+    from unfazed_amd import abi
+    m = min(args.cpu_dnms, dn.n)
+    cols = wl.download_block(0, m)
+    nseg = 2 * cfg.n_pairs
+    nc = len(sc.contig_off) - 1
+    cols["contig_off"] = bigsynth._reads_contig_off(dn.contig, 0, m, nc, nseg)
+    cols["max_span"] = np.full(nc, bigsynth.READLEN + 12, dtype=np.int32)
+    rv = abi.ReadsView()
+    rv.n_segs = m * nseg
+    rv.n_contigs = nc
+    for k, a in cols.items():
+        setattr(rv, k, a.ctypes.data)
+    rv.n_cigar_total = m * nseg * bigsynth.MAXOPS
+    rv.n_sq_bytes = m * nseg * bigsynth.ROW
+    rv.n_qnames = m * cfg.n_pairs
+    rh = abi.Held(rv, cols)
+    sv = abi.SitesView()
+    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags,
+                ref_base=sc.ref_base, alt_base=sc.alt_base)
+    sv.n_sites, sv.n_contigs = sc.n, nc
+    for k, a in keep.items():
+        setattr(sv, k, a.ctypes.data)
+    sh = abi.Held(sv, keep)
+    # the GPU folded the complex flag into bit 6 of its own copy of gt; the host copy is untouched
+    fh = abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
+    dv = abi.dnms_view(dn.contig[:m], dn.contig[:m], dn.start[:m], dn.end[:m], np.zeros(m, np.uint8), dn.refs[:m],
+                       dn.alts[:m], cutoff)
+    orc.lib()
+
+    def run(threads):
+        found = [None]
+        parts = [None] * threads
+        t0 = time.perf_counter()
+        found[0] = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+        bounds = np.linspace(0, m, threads + 1).astype(int)
+
+        def work(i):
+            parts[i] = orc.phase(P, sh, rh, dv, found[0], d_lo=int(bounds[i]), d_hi=int(bounds[i + 1]), keep_lists=False)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        st = np.full(m, abi.ST_SKIPPED, np.int32)
+        cnt = np.zeros((m, 4), np.int32)
+        org = np.zeros(m, np.int32)
+        ev = np.zeros(m, np.int32)
+        for i, p in enumerate(parts):
+            a, b = int(bounds[i]), int(bounds[i + 1])
+            st[a:b], cnt[a:b], org[a:b], ev[a:b] = p["status"][a:b], p["counts"][a:b], p["origin"][a:b], p["evidence"][a:b]
+        return dt, dict(status=st, counts=cnt, origin=org, evidence=ev)
+
+    cores = os.cpu_count() or 1
+    dt1, r1 = run(1)
+    dt2, _ = run(2)
+    dtc, rc = run(cores)
+    mism = 0
+    for k in ("status", "counts", "origin", "evidence"):
+        mism += int(np.any(np.asarray(gpu_res[k][:m]) != r1[k], axis=None if r1[k].ndim == 1 else 1).sum()) if r1[k].ndim > 1 \
+            else int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
+        mism += int((rc[k] != r1[k]).sum())
+    return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",
+            "sample": "first %d DNMs of the GPU batch (read blocks copied back from HBM), oracle find+phase, %d threads over DNM ranges"
+                      % (m, cores),
+            "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
+            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
+            "parity_mismatches_vs_gpu": mism}
+
+
+if __name__ == "__main__":
+    main()

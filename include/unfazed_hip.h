@@ -70,6 +70,10 @@ int uz_reads_upload(uz_ctx *ctx, const uz_reads_view *reads, int *reads_id);
 int uz_sites_adopt_device(uz_ctx *ctx, const uz_sites_view *sites, int *sites_id);
 int uz_family_adopt_device(uz_ctx *ctx, int sites_id, const uz_family_view *fam, int *fam_id);
 int uz_reads_adopt_device(uz_ctx *ctx, const uz_reads_view *reads, int *reads_id);
+/* Forget the derived columns (site classes of every family, per-record QC bits) so that the
+ * next uz_find / uz_phase recomputes them: a timed "whole job" pass starts from the staged
+ * inputs only. */
+int uz_drop_derived(uz_ctx *ctx);
 int uz_sites_free(uz_ctx *ctx, int sites_id); /* also frees its families */
 int uz_reads_free(uz_ctx *ctx, int reads_id);
 

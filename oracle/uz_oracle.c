@@ -408,7 +408,11 @@ typedef struct {
 } qscratch;
 
 static void touch(qscratch *Q, uint32_t q) {
-    if (!Q->is_touched[q]) { Q->is_touched[q] = 1; iv_push(&Q->touched, (int32_t)q); }
+    if (!Q->is_touched[q]) {
+        Q->is_touched[q] = 1;
+        Q->fet0[q] = Q->fet1[q] = -1; /* lazily initialised: a call only pays for the names it touches */
+        iv_push(&Q->touched, (int32_t)q);
+    }
 }
 
 typedef struct { int32_t q; int64_t found_pos; } nr_item; /* [readname, found_pos] */
@@ -445,9 +449,10 @@ int uzo_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *R
     Q.has_rs = (uint8_t *)calloc(nq, 1);
     Q.fet0 = (int32_t *)malloc(nq * sizeof(int32_t));
     Q.fet1 = (int32_t *)malloc(nq * sizeof(int32_t));
-    for (uint32_t i = 0; i < nq; i++) Q.fet0[i] = Q.fet1[i] = -1;
     Q.grp = (uint8_t *)calloc(nq, 1);
     Q.is_touched = (uint8_t *)calloc(nq, 1);
+    ivec all_touched = {0};
+    uint8_t *ever = (uint8_t *)calloc(nq, 1);
 
     for (int32_t d = 0; d < n; d++) {
         res->init_off[2 * d] = res->init_off[2 * d + 1] = init_all.n;
@@ -733,6 +738,7 @@ int uzo_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *R
         /* reset per-DNM scratch */
         for (int64_t t = 0; t < Q.touched.n; t++) {
             uint32_t q = (uint32_t)Q.touched.v[t];
+            if (!ever[q]) { ever[q] = 1; iv_push(&all_touched, (int32_t)q); }
             Q.read_sites[q].n = 0; Q.has_rs[q] = 0; Q.fet0[q] = Q.fet1[q] = -1; Q.grp[q] = 0; Q.is_touched[q] = 0;
         }
         Q.touched.n = 0;
@@ -744,8 +750,10 @@ int uzo_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *R
     res->grp_off[2 * n] = grp_all.n;
     res->vote_off[4 * n] = vote_all.n;
     res->init_seg = init_all.v; res->grp_q = grp_all.v; res->vote_val = vote_all.v;
-    for (uint32_t i = 0; i < nq; i++) free(Q.read_sites[i].v);
-    free(Q.read_sites); free(Q.has_rs); free(Q.fet0); free(Q.fet1); free(Q.grp); free(Q.is_touched); free(Q.touched.v);
+    /* read_sites vectors are only ever allocated for touched names; they were kept for reuse */
+    for (int64_t t = 0; t < all_touched.n; t++) free(Q.read_sites[all_touched.v[t]].v);
+    free(all_touched.v);
+    free(Q.read_sites); free(ever); free(Q.has_rs); free(Q.fet0); free(Q.fet1); free(Q.grp); free(Q.is_touched); free(Q.touched.v);
     free(X.good_cache);
     *out = res;
     return 0;

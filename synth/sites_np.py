@@ -31,6 +31,7 @@ class SitesColumns:
     rd: np.ndarray  # uint16 [3][S]
     ad: np.ndarray
     gq: np.ndarray
+    khap: np.ndarray = None  # uint8: bit0 allele on the kid's paternal haplotype, bit1 maternal
 
     @property
     def n(self):
@@ -92,7 +93,55 @@ def make_sites(n_sites: int, seed: int = 202, contig_lens=None, complex_frac=0.0
         names, off, pos, sflags, ref_base, alt_base, gt,
         np.ascontiguousarray(rd.astype(np.uint16)), np.ascontiguousarray(ad.astype(np.uint16)),
         np.ascontiguousarray(gq.astype(np.uint16)),
+        khap=(pat | (mat << 1)).astype(np.uint8),
     )
+
+
+@dataclass
+class DnmColumns:
+    site_idx: np.ndarray  # int32: the DNM's own record in the sites table
+    contig: np.ndarray  # int32
+    start: np.ndarray  # int32 (0-based)
+    end: np.ndarray
+    kind: np.ndarray  # uint8 0 SNV, 1 insertion, 2 deletion
+    length: np.ndarray  # uint8 inserted / deleted bases
+    origin: np.ndarray  # uint8 0 = paternal haplotype (dad) carries the DNM, 1 = maternal
+    refs: list
+    alts: list
+
+    @property
+    def n(self):
+        return int(self.start.shape[0])
+
+
+def place_dnms_full(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1, min_gap=13500) -> DnmColumns:
+    """place_dnms plus the DNM kinds (90 % SNV, 10 % small INDEL),
+    the origin haplotype and the REF/ALT strings; checks that read windows cannot overlap."""
+    idx, contig, start, _ = place_dnms(sc, n_dnms, seed=seed, indel_frac=0.0)
+    rng = np.random.default_rng(seed + 7)
+    n = n_dnms
+    is_indel = rng.random(n) < indel_frac
+    kind = np.where(is_indel, rng.integers(1, 3, n), 0).astype(np.uint8)
+    length = np.where(is_indel, rng.integers(1, 11, n), 0).astype(np.uint8)
+    origin = rng.integers(0, 2, n).astype(np.uint8)
+    end = (start + 1 + np.where(kind == 2, length, 0)).astype(np.int32)
+    same = contig[1:] == contig[:-1]
+    gaps = (start[1:] - start[:-1])[same]
+    if gaps.size and gaps.min() < min_gap:
+        raise ValueError("synthetic DNMs closer than %d bp (%d): lower n_dnms or raise n_sites" % (min_gap, gaps.min()))
+    sc.khap[idx] = 0
+    refs, alts = [], []
+    for i in range(n):
+        r = bytes([sc.ref_base[idx[i]]])
+        a = bytes([sc.alt_base[idx[i]]])
+        if kind[i] == 1:
+            a = r + b"A" * int(length[i])
+        elif kind[i] == 2:
+            r = r + b"C" * int(length[i])
+            a = r[:1]
+        refs.append(r)
+        alts.append(a)
+    return DnmColumns(idx.astype(np.int32), contig, start, end, kind, length, origin, refs, alts)
 
 
 def place_dnms(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1):

@@ -338,6 +338,13 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_view *v, int *id) {
     });
 }
 
+int uz_drop_derived(uz_ctx *c) {
+    return guarded(c, [&] {
+        for (auto &f : c->fams) f.cls_valid = false;
+        for (auto &r : c->reads) r.qc_valid = false;
+    });
+}
+
 int uz_sites_free(uz_ctx *c, int sites_id) {
     return guarded(c, [&] {
         SitesDev &s = sites_of(c, sites_id);

@@ -11,9 +11,43 @@
 
 namespace {
 
+// K3a: per-record QC bits.  The only heavy part is counting the base qualities below the
+// threshold (151 bytes per record): a workgroup takes 256 consecutive records and walks their
+// quality rows as 16-byte chunks, consecutive lanes on consecutive chunks, so the loads are
+// full-width and coalesced (rows are 16-byte aligned); per-record counts are combined in LDS.
 __global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qual, int min_base_qual, uint8_t *qc) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) qc[i] = uz_seg_qc(R, (int)i, min_map_qual, min_base_qual);
+    __shared__ int low[256];
+    __shared__ int maxch;
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int t = threadIdx.x;
+    const int64_t mine = r0 + t;
+    low[t] = 0;
+    if (t == 0) maxch = 0;
+    __syncthreads();
+    int ls = 0;
+    if (mine < n && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) ls = R.l_seq[mine];
+    if (ls) atomicMax(&maxch, (ls + 15) >> 4);
+    __syncthreads();
+    const int nch = maxch;
+    const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
+    for (int it = t; it < 256 * nch; it += 256) {
+        const int rl = it / nch, ch = it - rl * nch;
+        const int64_t r = r0 + rl;
+        if (r >= n || (R.aux[r] & UZ_AUX_DECODE_BAD)) continue;
+        const int len = (int)R.l_seq[r] - 16 * ch;
+        if (len <= 0) continue;
+        const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)R.sq_off16[r] + ch) << 4));
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            c += (k < len) & (q < thr);
+        }
+        if (c) atomicAdd(&low[rl], c);
+    }
+    __syncthreads();
+    if (mine < n) qc[mine] = uz_seg_qc_flags(R, (int)mine, min_map_qual, low[t]);
 }
 
 __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {

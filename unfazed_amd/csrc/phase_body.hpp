@@ -754,8 +754,9 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
     b[4] = mh;
 }
 
-// per-segment QC bits (K3a): goodread (:28-53) and the two CIGAR counts of :190-203
-UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual, int min_base_qual) {
+// per-segment QC bits (K3a): goodread (:28-53) and the two CIGAR counts of :190-203, given the
+// number of base qualities below the threshold
+UZ_DEV uint8_t uz_seg_qc_flags(const RD &R, int seg, int min_map_qual, int low) {
     const uint32_t f = R.flag[seg];
     const uint32_t aux = R.aux[seg];
     if (aux & UZ_AUX_DECODE_BAD) return 0; // no CIGAR / SEQ / QUAL: never a good read (unpinned)
@@ -772,13 +773,18 @@ UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual, int min_base_qu
     uint8_t qc = 0;
     if (base_ok) {
         qc |= UZ_QC_GOOD_DISC;
-        const uint8_t *q = uz_qual(R, seg);
-        const int ls = R.l_seq[seg];
-        int low = 0;
-        for (int k = 0; k < ls; k++) low += (int)q[k] < min_base_qual; // :43-46
-        if (low <= 10 && nc <= 10) qc |= UZ_QC_GOOD; // "mismatches" counts every CIGAR op (quirk Q9)
+        if (low <= 10 && nc <= 10) qc |= UZ_QC_GOOD; // :43-52; "mismatches" counts every CIGAR op (quirk Q9)
     }
     if (nonmatch <= 5) qc |= UZ_QC_NM5;
     if (none <= 5) qc |= UZ_QC_NONE5;
     return qc;
+}
+UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual, int min_base_qual) {
+    int low = 0;
+    if (!(R.aux[seg] & UZ_AUX_DECODE_BAD)) {
+        const uint8_t *q = uz_qual(R, seg);
+        const int ls = R.l_seq[seg];
+        for (int k = 0; k < ls; k++) low += (int)q[k] < min_base_qual; // :43-46
+    }
+    return uz_seg_qc_flags(R, seg, min_map_qual, low);
 }

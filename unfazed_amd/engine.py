@@ -20,7 +20,7 @@ EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
     "uz_sites_upload", "uz_family_upload", "uz_reads_upload",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
-    "uz_sites_free", "uz_reads_free",
+    "uz_sites_free", "uz_reads_free", "uz_drop_derived",
     "uz_site_scan", "uz_site_classes", "uz_find", "uz_find_fetch",
     "uz_phase", "uz_phase_votes", "uz_phase_groups",
     "uz_prof_enable", "uz_prof_reset", "uz_prof_get",
@@ -57,6 +57,7 @@ def load_library(path: Optional[str] = None):
         getattr(L, f).argtypes = [vp, vp, C.POINTER(C.c_int)]
     for f in ("uz_family_upload", "uz_family_adopt_device"):
         getattr(L, f).argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
+    L.uz_drop_derived.argtypes = [vp]
     L.uz_sites_free.argtypes = [vp, C.c_int]
     L.uz_reads_free.argtypes = [vp, C.c_int]
     L.uz_site_scan.argtypes = [vp, C.c_int]
@@ -154,6 +155,9 @@ class HipEngine:
 
     def free_reads(self, rid: int):
         self._ck(self.L.uz_reads_free(self.h, int(rid)), "uz_reads_free")
+
+    def drop_derived(self):
+        self._ck(self.L.uz_drop_derived(self.h), "uz_drop_derived")
 
     def sync(self):
         self._ck(self.L.uz_sync(self.h), "uz_sync")
