@@ -81,6 +81,8 @@ int uz_reads_free(uz_ctx *ctx, int reads_id);
 /* K1: one streaming pass over the family's columns -> one class byte per site
  * (UZ_CL_*).  Replaces is_high_quality_site (:46-73), get_kid_allele (:76-134) and
  * the DNM-independent part of find()'s per-variant body (:239-339 = :442-543). */
+/* uz_site_scan / uz_site_classes compute every class bit; uz_find / uz_phase in SNV / breakpoint
+ * mode run the variant without the DEL / DUP codes, which only whole_region=True reads (:286-291). */
 int uz_site_scan(uz_ctx *ctx, int fam_id);
 int uz_site_classes(uz_ctx *ctx, int fam_id, uint8_t *cls_out /* [n_sites] */);
 

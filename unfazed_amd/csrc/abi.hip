@@ -3,7 +3,7 @@
 #include "uz_ctx.hpp"
 
 void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n);
-bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f);
+bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv);
 
 namespace {
 
@@ -173,6 +173,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.contig.release(); c->dn.rcontig.release(); c->dn.start.release(); c->dn.end.release();
     c->dn.vartype.release(); c->dn.dflags.release(); c->dn.mult.release(); c->dn.allele_off.release();
     c->dn.alleles.release();
+    c->ab_lut.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -366,7 +367,7 @@ int uz_reads_free(uz_ctx *c, int reads_id) {
 int uz_site_scan(uz_ctx *c, int fam_id) {
     return guarded(c, [&] {
         FamilyDev &f = fam_of(c, fam_id);
-        uz_launch_site_scan(c, f, sites_of(c, f.sites_id));
+        uz_launch_site_scan(c, f, sites_of(c, f.sites_id), true);
     });
 }
 
@@ -375,7 +376,7 @@ int uz_site_classes(uz_ctx *c, int fam_id, uint8_t *out) {
         FamilyDev &f = fam_of(c, fam_id);
         SitesDev &s = sites_of(c, f.sites_id);
         UZ_REQUIRE(out != nullptr, UZ_E_ARG, "null output");
-        if (!uz_site_scan_fresh(c, f)) uz_launch_site_scan(c, f, s);
+        if (!uz_site_scan_fresh(c, f, true)) uz_launch_site_scan(c, f, s, true);
         if (s.n) UZ_HIP(hipMemcpyAsync(out, f.cls, (size_t)s.n, hipMemcpyDeviceToHost, c->stream));
         UZ_HIP(hipStreamSynchronize(c->stream));
     });
@@ -388,7 +389,8 @@ int uz_find(uz_ctx *c, int fam_id, const uz_dnms_view *d, int mode, int64_t *can
         c->find_valid = false;
         c->phase_valid = false;
         uz_stage_dnms(c, d);
-        if (!uz_site_scan_fresh(c, f)) uz_launch_site_scan(c, f, s);
+        const bool cnv = (mode & UZ_FIND_WHOLE_REGION) != 0;
+        if (!uz_site_scan_fresh(c, f, cnv)) uz_launch_site_scan(c, f, s, cnv);
         uz_launch_find(c, f, s, mode);
         c->find_fam = fam_id;
         if (cand_off) memcpy(cand_off, c->cand_off_h.data(), ((size_t)d->n + 1) * sizeof(int64_t));
@@ -421,7 +423,7 @@ int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int fin
         c->find_valid = false;
         c->phase_valid = false;
         uz_stage_dnms(c, d);
-        if (!uz_site_scan_fresh(c, f)) uz_launch_site_scan(c, f, s);
+        if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
         uz_launch_find(c, f, s, find_mode);
         c->find_fam = fam_id;
         uz_launch_phase(c, f, s, r, status, counts, origin, evidence);

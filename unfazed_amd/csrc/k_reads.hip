@@ -17,32 +17,35 @@ namespace {
 // full-width and coalesced (rows are 16-byte aligned); per-record counts are combined in LDS.
 __global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qual, int min_base_qual, uint8_t *qc) {
     __shared__ int low[256];
+    __shared__ uint32_t row16[256]; // quality row offset (16-byte units) of each record of the block
+    __shared__ int len[256];        // bases to examine (0 for records without qualities)
     __shared__ int maxch;
     const int64_t r0 = (int64_t)blockIdx.x * 256;
     const int t = threadIdx.x;
     const int64_t mine = r0 + t;
     low[t] = 0;
     if (t == 0) maxch = 0;
-    __syncthreads();
     int ls = 0;
-    if (mine < n && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) ls = R.l_seq[mine];
+    uint32_t ro = 0;
+    if (mine < n && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) { ls = R.l_seq[mine]; ro = R.sq_off16[mine]; }
+    row16[t] = ro;
+    len[t] = ls;
+    __syncthreads();
     if (ls) atomicMax(&maxch, (ls + 15) >> 4);
     __syncthreads();
     const int nch = maxch;
     const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
     for (int it = t; it < 256 * nch; it += 256) {
         const int rl = it / nch, ch = it - rl * nch;
-        const int64_t r = r0 + rl;
-        if (r >= n || (R.aux[r] & UZ_AUX_DECODE_BAD)) continue;
-        const int len = (int)R.l_seq[r] - 16 * ch;
-        if (len <= 0) continue;
-        const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)R.sq_off16[r] + ch) << 4));
+        const int l = len[rl] - 16 * ch;
+        if (l <= 0) continue;
+        const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl] + ch) << 4));
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         int c = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            c += (k < len) & (q < thr);
+            c += (k < l) & (q < thr);
         }
         if (c) atomicAdd(&low[rl], c);
     }

@@ -13,6 +13,8 @@
 // :442-543) and get_position (:10-43).  No MFMA: there is no contraction here.
 #include "uz_ctx.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 struct SiteParams {
@@ -22,25 +24,72 @@ struct SiteParams {
 
 __device__ __forceinline__ int dec16(uint32_t v) { return v == UZ_U16_MISSING ? -1 : (int)v; }
 
-// is_high_quality_site (:46-73) given the member's allele balance
-__device__ __forceinline__ bool hq(const SiteParams &P, int gt, int rd, int ad, int gq, double ab) {
-    const bool ok = (gt != UZ_GT_UNKNOWN) & (gq >= P.min_gt_qual) & ((rd + ad) >= P.min_depth);
-    // selects, not an indexed table: a run-time index into the by-value struct would go to scratch
-    const double lo = gt == UZ_HOM_REF ? P.lo_ref : (gt == UZ_HOM_ALT ? P.lo_alt : P.lo_het);
-    const double hi = gt == UZ_HOM_REF ? P.hi_ref : (gt == UZ_HOM_ALT ? P.hi_alt : P.hi_het);
-    return ok & (lo <= ab) & (ab <= hi);
+// Allele-balance window test without a division on the hot path.  For a fixed total depth t the
+// correctly rounded quotient RN(a / t) is monotone in the integer a, so the set of alt depths a with
+//     lo <= RN(a / t) <= hi
+// is an interval [amin[t], amax[t]].  k_build_ab_lut finds it once per parameter set with the SAME
+// IEEE f64 division the reference's numpy expression performs (informative_site_finder.py:69-71),
+// for every total the 16-bit columns can produce: t = rd + ad in [-2, 131068] (-1 = missing).
+// t == 0 (0/0 -> NaN, +-1/0 -> +-inf) is not an interval in general and keeps two pass bits instead.
+// A 30x genome touches a few hundred bytes of the table (L1-resident); the table is 3 MiB.
+#define UZ_AB_T_MIN (-2)
+#define UZ_AB_T_MAX 131068
+#define UZ_AB_LUT_N (UZ_AB_T_MAX - UZ_AB_T_MIN + 1)
+__device__ __forceinline__ double ab_lo(const SiteParams &P, int gt) { return gt == UZ_HOM_REF ? P.lo_ref : (gt == UZ_HOM_ALT ? P.lo_alt : P.lo_het); }
+__device__ __forceinline__ double ab_hi(const SiteParams &P, int gt) { return gt == UZ_HOM_REF ? P.hi_ref : (gt == UZ_HOM_ALT ? P.hi_alt : P.hi_het); }
+
+__global__ void k_build_ab_lut(SiteParams P, int2 *lut) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * UZ_AB_LUT_N) return;
+    const int cls = i / UZ_AB_LUT_N, t = i % UZ_AB_LUT_N + UZ_AB_T_MIN;
+    const int gt = cls == 0 ? UZ_HOM_REF : (cls == 1 ? UZ_HET : UZ_HOM_ALT);
+    const double lo = ab_lo(P, gt), hi = ab_hi(P, gt);
+    int2 r = make_int2(0x7FFFFFFF, -0x7FFFFFFF); // empty interval
+    if (t > 0) {
+        // a over every decodable depth: -1 (missing) .. 65534; a/t is increasing in a
+        int l = -1, h = 65535; // smallest a with lo <= RN(a/t); 65535 = none
+        while (l < h) { const int m = l + ((h - l) >> 1); if (lo <= (double)m / (double)t) h = m; else l = m + 1; }
+        const int amin = l;
+        l = -2; h = 65534; // largest a with RN(a/t) <= hi; -2 = none
+        while (l < h) { const int m = l + ((h - l + 1) >> 1); if ((double)m / (double)t <= hi) l = m; else h = m - 1; }
+        if (amin <= 65534 && l >= -1) r = make_int2(amin, l);
+    } else if (t < 0) {
+        // only a in {-1, 0} can give a negative total (one or both depths missing)
+        int amin = 0x7FFFFFFF, amax = -0x7FFFFFFF;
+        for (int a = -1; a <= 0; a++) {
+            const double ab = (double)a / (double)t;
+            if (lo <= ab && ab <= hi) { if (a < amin) amin = a; if (a > amax) amax = a; }
+        }
+        r = make_int2(amin, amax); // any subset of {-1, 0} is an interval
+    } else {
+        // t == 0: a = 0 -> NaN (never passes), a = +-1 -> +-inf.  x = pass bit of a = -1, y = of a = +1
+        const double pinf = 1.0 / 0.0, ninf = -1.0 / 0.0;
+        r = make_int2((lo <= ninf && ninf <= hi) ? 1 : 0, (lo <= pinf && pinf <= hi) ? 1 : 0);
+    }
+    lut[i] = r;
 }
 
-__device__ __forceinline__ uint8_t classify_site(const SiteParams &P, uint32_t g, int rdk, int adk, int gqk, int rdd,
-                                                 int add, int gqd, int rdm, int adm, int gqm) {
+// is_high_quality_site (:46-73)
+__device__ __forceinline__ bool hq(const SiteParams &P, const int2 *__restrict__ lut, int gt, int rd, int ad, int gq) {
+    const int t = rd + ad;
+    const bool ok = (gt != UZ_GT_UNKNOWN) & (gq >= P.min_gt_qual) & (t >= P.min_depth);
+    const int cls = gt == UZ_HOM_REF ? 0 : (gt == UZ_HOM_ALT ? 2 : 1);
+    const int2 b = lut[cls * UZ_AB_LUT_N + (t - UZ_AB_T_MIN)];
+    const bool in_iv = (ad >= b.x) & (ad <= b.y);
+    const bool in_t0 = ((ad == 1) & (b.y != 0)) | ((ad == -1) & (b.x != 0));
+    return ok & (t != 0 ? in_iv : in_t0);
+}
+
+// CNV = false: SNV / breakpoint mode only (class bits HET, CAND, ALT_DAD) -- what find(...,
+// whole_region=False) evaluates (:292-295); CNV = true adds the DEL / DUP codes of get_kid_allele,
+// which only find(..., whole_region=True) reaches (:286-291).
+template <bool CNV>
+__device__ __forceinline__ uint8_t classify_site(const SiteParams &P, const int2 *__restrict__ lut, uint32_t g, int rdk,
+                                                 int adk, int gqk, int rdd, int add, int gqd, int rdm, int adm, int gqm) {
     const int kid = g & 3, dad = (g >> 2) & 3, mom = (g >> 4) & 3;
-    // allele balances: numpy int32 / float -> IEEE double division (0/0 -> NaN -> every test false)
-    const double abk = (double)adk / (double)(rdk + adk);
-    const double abd = (double)add / (double)(rdd + add);
-    const double abm = (double)adm / (double)(rdm + adm);
-    const bool hqk = hq(P, kid, rdk, adk, gqk, abk);
-    const bool hqd = hq(P, dad, rdd, add, gqd, abd);
-    const bool hqm = hq(P, mom, rdm, adm, gqm, abm);
+    const bool hqk = hq(P, lut, kid, rdk, adk, gqk);
+    const bool hqd = hq(P, lut, dad, rdd, add, gqd);
+    const bool hqm = hq(P, lut, mom, rdm, adm, gqm);
     uint32_t c = 0;
     if (kid == UZ_HET && hqd && hqm) c |= UZ_CL_HET; // :268-284
     // parental pattern :307-320
@@ -52,6 +101,7 @@ __device__ __forceinline__ uint8_t classify_site(const SiteParams &P, uint32_t g
     if (pattern && alt_dad) c |= UZ_CL_ALT_DAD;
     if (hqd && hqm && pattern) {
         if (kid == UZ_HET && hqk) c |= UZ_CL_CAND; // :292-295
+        if constexpr (CNV) {
         // hemizygous unique-allele check :324-337
         bool unique = true;
         if (kid == UZ_HOM_ALT || kid == UZ_HOM_REF) {
@@ -69,7 +119,10 @@ __device__ __forceinline__ uint8_t classify_site(const SiteParams &P, uint32_t g
                 if (kid == UZ_HOM_ALT) kdel = UZ_KA_REF_PARENT;
                 else if (kid == UZ_HOM_REF) kdel = UZ_KA_ALT_PARENT;
             }
-            if (rdk > 2 && adk > 2 && (rdk + adk) > P.min_depth && kid == UZ_HET) { // :89-97
+            if (rdk > 2 && adk > 2 && (rdk + adk) > P.min_depth && kid == UZ_HET) { // :89-97 (a few % of the sites)
+                const double abk = (double)adk / (double)(rdk + adk);
+                const double abd = (double)add / (double)(rdd + add);
+                const double abm = (double)adm / (double)(rdm + adm);
                 const double s = abd + abm;
                 const bool shared_dup = ((s < 1.0) && (abk > 0.5)) || ((s > 1.0) && (abk < 0.5)); // :110-116
                 if (!shared_dup) {
@@ -79,6 +132,7 @@ __device__ __forceinline__ uint8_t classify_site(const SiteParams &P, uint32_t g
             }
             c |= kdel << UZ_CL_DEL_SHIFT;
             c |= kdup << UZ_CL_DUP_SHIFT;
+        }
         }
     }
     return (uint8_t)c;
@@ -113,11 +167,15 @@ struct FamPtrs {
     const uint16_t *rd[3], *ad[3], *gq[3];
 };
 
-template <int SPT>
-__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restrict__ cls, int64_t n, SiteParams P) {
+template <int SPT, bool CNV>
+__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restrict__ cls, int64_t n, SiteParams Pk, const int2 *__restrict__ lut) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t base = t * SPT;
     if (base >= n) return;
+    // Read the thresholds into registers up front.  Left in the kernarg struct, `c ? P.a : P.b` is
+    // compiled as a select of ADDRESSES followed by a per-lane global load (6 extra vector loads and
+    // waits per site); on copies it is a v_cndmask between SGPR pairs.
+    const SiteParams P = {Pk.min_gt_qual, Pk.min_depth, Pk.lo_ref, Pk.hi_ref, Pk.lo_het, Pk.hi_het, Pk.lo_alt, Pk.hi_alt};
     if (base + SPT <= n) {
         // issue all 19-20 vector loads before the first use
         ColVec<SPT> c[9];
@@ -145,7 +203,7 @@ __global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restric
                 const uint32_t g = (gw[w] >> (8 * b)) & 0xFFu;
                 uint32_t cl = 0;
                 if (!(g & 0x40u)) // bit 6: complex record (:239-244)
-                    cl = classify_site(P, g, dec16(c[0].get(i)), dec16(c[3].get(i)), dec16(c[6].get(i)),
+                    cl = classify_site<CNV>(P, lut, g, dec16(c[0].get(i)), dec16(c[3].get(i)), dec16(c[6].get(i)),
                                        dec16(c[1].get(i)), dec16(c[4].get(i)), dec16(c[7].get(i)),
                                        dec16(c[2].get(i)), dec16(c[5].get(i)), dec16(c[8].get(i)));
                 o |= cl << (8 * b);
@@ -161,7 +219,7 @@ __global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restric
             const uint32_t g = f.gt[i];
             uint8_t cl = 0;
             if (!(g & 0x40u))
-                cl = classify_site(P, g, dec16(f.rd[0][i]), dec16(f.ad[0][i]), dec16(f.gq[0][i]), dec16(f.rd[1][i]),
+                cl = classify_site<CNV>(P, lut, g, dec16(f.rd[0][i]), dec16(f.ad[0][i]), dec16(f.gq[0][i]), dec16(f.rd[1][i]),
                                    dec16(f.ad[1][i]), dec16(f.gq[1][i]), dec16(f.rd[2][i]), dec16(f.ad[2][i]),
                                    dec16(f.gq[2][i]));
             cls[i] = cl;
@@ -315,25 +373,39 @@ void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n) {
     UZ_HIP(hipGetLastError());
 }
 
-bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f) { return f.cls_valid && site_params_equal(f.cls_params, c->P); }
+bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv) {
+    return f.cls_valid && (f.cls_has_cnv || !need_cnv) && site_params_equal(f.cls_params, c->P);
+}
 
 #ifndef UZ_SITE_SPT
 #define UZ_SITE_SPT 8
 #endif
 
-void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s) {
+void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv) {
     if (s.n > 0) {
         FamPtrs fp;
         fp.gt = f.gt;
         for (int m = 0; m < 3; m++) { fp.rd[m] = f.rd[m]; fp.ad[m] = f.ad[m]; fp.gq[m] = f.gq[m]; }
         const SiteParams sp = make_site_params(c->P);
-        constexpr int SPT = UZ_SITE_SPT;
-        const int64_t nthreads = (s.n + SPT - 1) / SPT;
-        const int64_t nb = (nthreads + 255) / 256;
+        if (!(c->ab_lut_valid && site_params_equal(c->ab_lut_params, c->P))) {
+            c->ab_lut.ensure((size_t)3 * UZ_AB_LUT_N * 2);
+            hipLaunchKernelGGL(k_build_ab_lut, dim3((3 * UZ_AB_LUT_N + 255) / 256), dim3(256), 0, c->stream, sp, (int2 *)c->ab_lut.p);
+            UZ_HIP(hipGetLastError());
+            c->ab_lut_valid = true;
+            c->ab_lut_params = c->P;
+        }
+        static const int spt = [] { const char *e = getenv("UZ_SITE_SPT"); return e ? atoi(e) : UZ_SITE_SPT; }();
         ProfScope ps(c, UZ_K_SITE_SCAN);
-        hipLaunchKernelGGL(k_site_scan<SPT>, dim3((unsigned)nb), dim3(256), 0, c->stream, fp, f.cls, s.n, sp);
+        auto launch = [&](auto kern, int SPT) {
+            const int64_t nthreads = (s.n + SPT - 1) / SPT;
+            const int64_t nb = (nthreads + 255) / 256;
+            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), 0, c->stream, fp, f.cls, s.n, sp, (const int2 *)c->ab_lut.p);
+        };
+        if (spt == 16) { if (with_cnv) launch(k_site_scan<16, true>, 16); else launch(k_site_scan<16, false>, 16); }
+        else { if (with_cnv) launch(k_site_scan<8, true>, 8); else launch(k_site_scan<8, false>, 8); }
         UZ_HIP(hipGetLastError());
     }
+    f.cls_has_cnv = with_cnv;
     f.cls_valid = true;
     f.cls_params = c->P;
 }

@@ -65,6 +65,7 @@ struct FamilyDev {
     uint16_t *gq[3] = {nullptr, nullptr, nullptr};
     uint8_t *cls = nullptr;
     bool cls_valid = false;
+    bool cls_has_cnv = false; // DEL / DUP codes (bits 3-6) computed
     uz_params cls_params;
 };
 
@@ -122,6 +123,11 @@ struct uz_ctx {
     std::vector<FamilyDev> fams;
     std::vector<ReadsDev> reads;
 
+    // allele-balance threshold table of K1 (k_sites.hip), rebuilt when the thresholds change
+    DevBuf<int32_t> ab_lut;
+    bool ab_lut_valid = false;
+    uz_params ab_lut_params;
+
     // last find
     bool find_valid = false;
     int find_fam = -1, find_mode = 0;
@@ -159,7 +165,7 @@ struct ProfScope {
 };
 
 // stage launchers
-void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s);
+void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode);
 void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d);
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
