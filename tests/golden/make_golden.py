@@ -234,9 +234,137 @@ def gen_cutoff():
     print("cutoff", len(cases))
 
 
+def make_cnv_dataset(seed=31, n=10):
+    """synth.small trio plus DEL / DUP / INV events laid over the site-rich windows, with the kid's
+    genotypes / depths inside the events re-drawn as a hemizygous deletion or a 2:1 duplication."""
+    rng = np.random.RandomState(seed)
+    ds = make_small(SmallConfig(seed=seed, n_dnms=n, coverage_per_hap=1.0, site_rate=1 / 250.0))
+    col = {s: i for i, s in enumerate(ds.samples)}
+    k = col["kid1"]
+    svs = []
+    for i, d in enumerate(ds.dnms):
+        vt = ["DEL", "DUP", "DEL", "DUP", "INV"][i % 5]
+        st, en = d["start"] - int(rng.randint(500, 4000)), d["start"] + int(rng.randint(500, 4000))
+        svs.append({"chrom": d["chrom"], "start": st, "end": en, "kid": "kid1", "vartype": vt, "bam": "", "cram_ref": None})
+        for r in ds.sites:
+            if r.chrom != d["chrom"] or not (st <= r.start <= en):
+                continue
+            u = rng.rand()
+            if vt == "DEL" and u < 0.7:
+                depth = int(rng.randint(3, 25))
+                if rng.rand() < 0.5:
+                    r.gt_types[k], r.ref_depths[k], r.alt_depths[k] = 0, depth, 0
+                else:
+                    r.gt_types[k], r.ref_depths[k], r.alt_depths[k] = 3, 0, depth
+            elif vt == "DUP" and u < 0.7:
+                a, b = [(20, 10), (10, 20), (30, 14), (14, 30), (22, 11), (3, 9), (16, 15), (67, 33)][rng.randint(8)]
+                r.gt_types[k], r.ref_depths[k], r.alt_depths[k] = 1, a, b
+    # two events of the same kid sharing a start (find_many multiplicity), one tiny event
+    svs.append(dict(svs[0]))
+    svs.append({"chrom": ds.dnms[1]["chrom"], "start": ds.dnms[1]["start"] - 5, "end": ds.dnms[1]["start"] + 7, "kid": "kid1",
+                "vartype": "DEL", "bam": "", "cram_ref": None})
+    ds.dnms = svs
+    return ds
+
+
+def gen_cnv():
+    """G8: run_cnv_phasing (allele-balance phasing of DEL / DUP) through find()."""
+    cyvcf2, pysam, isf, rc, ss, sp, svp, uz = refrun._import()
+    ds = make_cnv_dataset()
+    vcf, bams = refrun.register(ds, "cnv")
+    cases = []
+    for ps in (dict(ab_homref=[0.0, 0.2], ab_homalt=[0.8, 1.0], ab_het=[0.2, 0.8], min_gt_qual=20, min_depth=10),
+               dict(ab_homref=[0.0, 0.3], ab_homalt=[0.7, 1.0], ab_het=[0.1, 0.9], min_gt_qual=10, min_depth=4)):
+        dnms = copy.deepcopy(ds.dnms)
+        err = io.StringIO()
+        svp.QUIET_MODE = False
+        with warnings.catch_warnings(), contextlib.redirect_stderr(err):
+            warnings.simplefilter("ignore")
+            recs = svp.run_cnv_phasing(dnms, ds.pedigrees, vcf, 1, "38", 1000, ps["ab_homref"], ps["ab_homalt"], ps["ab_het"],
+                                       ps["min_gt_qual"], ps["min_depth"])
+        summaries = {k: uz.summarize_record(copy.deepcopy(r), True, True, 10) for k, r in recs.items()}
+        cases.append(dict(params=ps, records=recs, record_order=list(recs.keys()), stderr=err.getvalue().splitlines(),
+                          dnms=dnms, summaries=summaries))
+        print("cnv", len(recs), "records")
+    with open(os.path.join(HERE, "cnv.json"), "w") as fh:
+        json.dump(dict(digest=dataset_digest(ds), cases=cases), fh)
+
+
+CLI_CFG = dict(seed=77, n_dnms=10, kids=["kidA", "kidB"], odd_read_prob=0.1)
+
+
+def gen_cli():
+    """Whole driver (reference unfazed.unfazed(args)): BED text and the per-sample GT / UOPS / UET of the
+    annotated VCF, for VCF and BED DNM input."""
+    import argparse
+    import tempfile
+    from filesio import dump_dataset
+    cyvcf2, pysam, isf, rc, ss, sp, svp, uz = refrun._import()
+    ds = make_small(SmallConfig(**CLI_CFG))
+    tmp = tempfile.mkdtemp()
+    paths = dump_dataset(ds, tmp)
+    cyvcf2.register(paths["sites"], ds.samples, ds.sites)
+    want = {(d["chrom"], d["start"]) for d in ds.dnms}
+    seen, dn_recs = set(), []
+    for r in ds.sites:
+        if (r.chrom, r.start) in want and (r.chrom, r.start) not in seen:
+            seen.add((r.chrom, r.start))
+            r.genotypes = [[0, 1, False] if g == 1 else ([1, 1, False] if g == 3 else ([-1, -1, False] if g == 2 else [0, 0, False]))
+                           for g in r.gt_types]
+            dn_recs.append(r)
+    cyvcf2.register(paths["dnm_vcf"], ds.samples, dn_recs)
+    for kid, segs in ds.reads.items():
+        pysam.register(paths["bams"][kid], ds.contigs, segs)
+    runs = []
+    for dnm_key, out_type, amb, verbose in (("dnm_vcf", "bed", False, False), ("dnm_vcf", "bed", True, True),
+                                            ("dnm_bed", "bed", True, False), ("dnm_vcf", "vcf", False, False),
+                                            ("dnm_vcf", "vcf", True, False)):
+        args = argparse.Namespace(
+            dnms=paths[dnm_key], sites=paths["sites"], ped=paths["ped"], bam_dir=None,
+            bam_pairs=[[k, v] for k, v in paths["bams"].items()], threads=1, output_type=out_type,
+            include_ambiguous=amb, verbose=verbose, outfile="/dev/stdout", reference=None, build="38",
+            no_extended=False, multiread_proc_min=1000, quiet=True, min_gt_qual=20, min_depth=10,
+            ab_homref=[0.0, 0.2], ab_homalt=[0.8, 1.0], ab_het=[0.2, 0.8], evidence_min_ratio=10, search_dist=5000,
+            insert_size_max_sample=1000000, min_map_qual=1, stdevs=3, readlen=151, split_error_margin=5, max_reads=100)
+        sp.concordant_upper_lens.clear()
+        buf = io.StringIO()
+        writers = []
+        orig_writer = uz.Writer
+
+        class W(orig_writer):
+            def __init__(self, *a, **k):
+                orig_writer.__init__(self, *a, **k)
+                writers.append(self)
+        uz.Writer = W
+        try:
+            with warnings.catch_warnings(), contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                warnings.simplefilter("ignore")
+                uz.unfazed(args)
+        finally:
+            uz.Writer = orig_writer
+        run = dict(dnms=dnm_key, output_type=out_type, include_ambiguous=amb, verbose=verbose)
+        if out_type == "bed":
+            run["lines"] = buf.getvalue().splitlines()
+        else:
+            body = []
+            for v in writers[0].records:
+                body.append(dict(chrom=v.CHROM, pos=v.POS, genotypes=[[int(g[0]), int(g[1]), bool(g[2])] for g in v.genotypes],
+                                 uops=[float(x) for x in v.formats["UOPS"]], uet=[float(x) for x in v.formats["UET"]]))
+            run["body"] = body
+            run["header_added"] = writers[0].tmpl.header_lines + [d["ID"] for d in writers[0].tmpl.formats_added]
+        runs.append(run)
+        print("cli", dnm_key, out_type, amb, len(run.get("lines", run.get("body"))))
+    with open(os.path.join(HERE, "cli.json"), "w") as fh:
+        json.dump(dict(config=CLI_CFG, digest=dataset_digest(ds), runs=runs), fh)
+
+
 if __name__ == "__main__":
     assert refrun.available(), "/root/reference is required to generate golden vectors"
-    which = sys.argv[1:] or ["snv", "grid", "bsearch", "summarize", "cutoff"]
+    which = sys.argv[1:] or ["snv", "grid", "bsearch", "summarize", "cutoff", "cnv"]
+    if "cnv" in which:
+        gen_cnv()
+    if "cli" in which or not sys.argv[1:]:
+        gen_cli()
     if "snv" in which:
         gen_snv()
     if "grid" in which:

@@ -87,3 +87,41 @@ def test_cutoff_golden():
         head = np.array(c["tlen"][: c["insert_size_max_sample"] + 1], dtype=np.int32)
         assert float(concordant_cutoff(head, c["readlen"], 3)) == c["cutoff"]
         assert orc.concordant_cutoff(head, c["readlen"]) == c["cutoff"]
+
+
+def run_cnv(backend, ds, ps):
+    import contextlib
+    import copy
+    import io
+    sites, reads = tables(ds)
+    host = PhasingHost(backend, sites, reads)
+    P = abi.make_params(min_gt_qual=ps["min_gt_qual"], min_depth=ps["min_depth"], ab_homref=ps["ab_homref"],
+                        ab_homalt=ps["ab_homalt"], ab_het=ps["ab_het"])
+    dn = copy.deepcopy(ds.dnms)
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err):
+        recs = host.run_cnv_phasing(dn, ds.pedigrees, 1, "38", 1000, False, P)
+    return recs, dn, err.getvalue()
+
+
+def check_cnv_golden(backend):
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import dataset_digest, make_cnv_dataset
+    g = json.load(open(os.path.join(GOLD, "cnv.json")))
+    ds = make_cnv_dataset()
+    assert dataset_digest(ds) == g["digest"]
+    for c in g["cases"]:
+        recs, dn, err = run_cnv(backend, ds, c["params"])
+        assert list(recs.keys()) == c["record_order"]
+        assert json.loads(json.dumps(recs)) == c["records"]
+        assert err.splitlines() == c["stderr"]
+        for d, r in zip(dn, c["dnms"]):
+            assert d.get("candidate_sites") == r.get("candidate_sites")
+            assert d.get("het_sites") == r.get("het_sites")
+        for k, r in recs.items():
+            assert summarize.summarize_record(r, True, True, 10) == c["summaries"][k]
+
+
+def test_cnv_allele_balance_golden():
+    check_cnv_golden(OracleBackend())

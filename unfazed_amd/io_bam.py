@@ -1,0 +1,135 @@
+"""BAM decoder (BGZF via zlib, pure Python) into unfazed_amd.model.Segment, and a
+minimal BAM writer used to build test inputs.
+
+Replaces what the reference gets from pysam.AlignmentFile:
+records in file order with flag, mapq, reference_start, CIGAR, mate contig / position,
+tlen, query name, sequence, qualities and the presence of an SA tag.  CRAM is not decoded.
+The whole file is decoded once ("decoded once on the host"); region queries and mate lookups
+then run on the column table (unfazed_amd.model.ReadsTable).  A native decoder is listed under
+"next" in DESIGN.md; this one favours clarity.
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import List, Sequence, Tuple
+
+from .model import Segment
+
+_SEQ = "=ACMGRSVTWYHKDBN"
+_SEQ_PAIR = [a + b for a in _SEQ for b in _SEQ]
+
+
+def _bgzf_inflate(path: str) -> bytes:
+    out = []
+    with open(path, "rb") as fh:
+        data = fh.read()
+    pos = 0
+    n = len(data)
+    while pos < n:
+        d = zlib.decompressobj(31)
+        out.append(d.decompress(data[pos:]))
+        used = n - pos - len(d.unused_data)
+        if used <= 0:
+            break
+        pos += used
+    return b"".join(out)
+
+
+def read_bam(path: str) -> Tuple[List[str], List[Segment]]:
+    """-> (contig names, records in file order)"""
+    buf = _bgzf_inflate(path)
+    if buf[:4] != b"BAM\x01":
+        raise ValueError("%s is not a BAM file" % path)
+    (l_text,) = struct.unpack_from("<i", buf, 4)
+    off = 8 + l_text
+    (n_ref,) = struct.unpack_from("<i", buf, off)
+    off += 4
+    contigs = []
+    for _ in range(n_ref):
+        (l_name,) = struct.unpack_from("<i", buf, off)
+        contigs.append(buf[off + 4: off + 4 + l_name - 1].decode())
+        off += 4 + l_name + 4
+    segs: List[Segment] = []
+    n = len(buf)
+    while off + 4 <= n:
+        (block_size,) = struct.unpack_from("<i", buf, off)
+        p = off + 4
+        ref_id, pos, l_name, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", buf, p)
+        p += 32
+        qname = buf[p: p + l_name - 1].decode()
+        p += l_name
+        cigar = []
+        for k in range(n_cig):
+            (v,) = struct.unpack_from("<I", buf, p + 4 * k)
+            cigar.append((v & 15, v >> 4))
+        p += 4 * n_cig
+        nb = (l_seq + 1) // 2
+        sb = buf[p: p + nb]
+        seq = "".join(_SEQ_PAIR[b] for b in sb)[:l_seq]
+        p += nb
+        q = buf[p: p + l_seq]
+        qual = None if (l_seq == 0 or q[0] == 0xFF) else list(q)
+        p += l_seq
+        end = off + 4 + block_size
+        has_sa = _has_tag(buf, p, end, b"SA")
+        segs.append(Segment(qname, flag, ref_id, pos, mapq, cigar, mtid, mpos, tlen, seq, qual, has_sa))
+        off = end
+    return contigs, segs
+
+
+_TAG_SIZE = {b"A": 1, b"c": 1, b"C": 1, b"s": 2, b"S": 2, b"i": 4, b"I": 4, b"f": 4}
+
+
+def _has_tag(buf: bytes, p: int, end: int, tag: bytes) -> bool:
+    while p + 3 <= end:
+        t, typ = buf[p: p + 2], buf[p + 2: p + 3]
+        p += 3
+        if t == tag:
+            return True
+        if typ in _TAG_SIZE:
+            p += _TAG_SIZE[typ]
+        elif typ in (b"Z", b"H"):
+            p = buf.index(b"\0", p) + 1
+        elif typ == b"B":
+            sub = buf[p: p + 1]
+            (cnt,) = struct.unpack_from("<i", buf, p + 1)
+            p += 5 + cnt * _TAG_SIZE[sub]
+        else:
+            return False
+    return False
+
+
+# ------------------------------------------------------------------ writer (tests)
+def _bgzf_block(data: bytes) -> bytes:
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(data) + comp.flush()
+    bsize = len(cdata) + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize)
+            + cdata + struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+
+
+def write_bam(path: str, contigs: Sequence[Tuple[str, int]], segs: Sequence[Segment]) -> None:
+    """Writes a coordinate-sorted BAM (records are written in the order given)."""
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in contigs)
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(contigs)))
+    for name, length in contigs:
+        out += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", length)
+    code = {c: i for i, c in enumerate(_SEQ)}
+    for s in segs:
+        name = s.qname.encode() + b"\0"
+        l_seq = len(s.seq) if s.seq else 0
+        sq = bytearray((l_seq + 1) // 2)
+        for i, ch in enumerate(s.seq or ""):
+            sq[i >> 1] |= code[ch] << (4 if i % 2 == 0 else 0)
+        qual = bytes(s.qual) if s.qual is not None else b"\xff" * l_seq
+        tags = b"SAZx,1,+,10M,60,0;\0" if s.has_sa else b""
+        body = struct.pack("<iiBBHHHiiii", s.tid, s.pos, len(name), s.mapq, 4680, len(s.cigar), s.flag, l_seq, s.mtid,
+                           s.mpos, s.tlen) + name + b"".join(struct.pack("<I", (l << 4) | op) for op, l in s.cigar) + \
+            bytes(sq) + qual + tags
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as fh:
+        data = bytes(out)
+        for i in range(0, len(data), 60000):
+            fh.write(_bgzf_block(data[i: i + 60000]))
+        fh.write(_bgzf_block(b""))  # BGZF EOF marker

@@ -1,0 +1,88 @@
+"""Decoded-input caches and the backend handle shared by the phase_snvs / phase_svs
+mirrors: one sites table per sites file, one reads table per BAM, one PhasingHost per
+sites file.  Inputs can be real files (decoded by io_vcf / io_bam) or tables registered
+in memory under a name (tests, callers that already hold decoded columns)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from .hostpath import PhasingHost
+from .model import ReadsTable, SitesTable
+
+_SITES: Dict[str, SitesTable] = {}
+_READS: Dict[str, ReadsTable] = {}
+_HOSTS: Dict[tuple, PhasingHost] = {}
+_BACKEND = None
+
+
+def register_sites(name: str, table: SitesTable) -> None:
+    _SITES[name] = table
+    for k in [k for k in _HOSTS if k[0] == name]:
+        del _HOSTS[k]
+
+
+def register_reads(name: str, table: ReadsTable) -> None:
+    _READS[name] = table
+    _HOSTS.clear()
+
+
+def set_backend(backend) -> None:
+    """Use an explicit backend object (default: one HipEngine on device 0, created lazily)."""
+    global _BACKEND
+    _BACKEND = backend
+    _HOSTS.clear()
+
+
+def get_backend():
+    global _BACKEND
+    if _BACKEND is None:
+        from .engine import HipEngine  # raises without libunfazed_hip.so / a gfx950 device
+        _BACKEND = HipEngine(0)
+    return _BACKEND
+
+
+def load_sites(name_or_table) -> (str, SitesTable):
+    if isinstance(name_or_table, SitesTable):
+        key = "table@%d" % id(name_or_table)
+        _SITES[key] = name_or_table
+        return key, name_or_table
+    if name_or_table not in _SITES:
+        from .io_vcf import read_vcf
+        samples, recs, _ = read_vcf(name_or_table)
+        _SITES[name_or_table] = SitesTable.from_records(recs, samples)
+    return name_or_table, _SITES[name_or_table]
+
+
+def load_reads(name: str, insert_size_max_sample: int = 1000000) -> ReadsTable:
+    if name not in _READS:
+        if name[-4:] == "cram":
+            raise NotImplementedError("CRAM input is not decoded by this build (BAM only)")
+        from .io_bam import read_bam
+        contigs, segs = read_bam(name)
+        t = ReadsTable.from_segments(segs, contigs)
+        t.tlen_head = np.array([s.tlen for s in segs[: int(insert_size_max_sample) + 1]], dtype=np.int32)
+        _READS[name] = t
+    return _READS[name]
+
+
+class _LazyReads(dict):
+    """reads_by_bam mapping that decodes a BAM on first use"""
+
+    def __init__(self, insert_size_max_sample):
+        super().__init__()
+        self.cap = insert_size_max_sample
+
+    def __missing__(self, key):
+        self[key] = load_reads(key, self.cap)
+        return self[key]
+
+
+def host_for(sites, insert_size_max_sample: int = 1000000) -> PhasingHost:
+    key, table = load_sites(sites)
+    backend = get_backend()
+    hk = (key, id(backend))
+    if hk not in _HOSTS:
+        _HOSTS[hk] = PhasingHost(backend, table, _LazyReads(insert_size_max_sample))
+    return _HOSTS[hk]

@@ -1,0 +1,39 @@
+"""Multi-GPU driver: DNMs are independent, so a node phases them as contiguous shards, one
+process per GPU, with NO collective on the data path.  The only
+communication is the final gather of the per-shard `records` dicts on rank 0 (host objects,
+through whatever torch.distributed backend is up: nccl = RCCL on the GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+
+def shard_bounds(n: int, world: int) -> List[int]:
+    """Contiguous, near-equal shards: [b[r], b[r+1]) for rank r."""
+    return [(n * r) // world for r in range(world + 1)]
+
+
+def shard_dnms(dnms: List[dict], rank: int, world: int) -> List[dict]:
+    """Sort by (chrom, start, end, kid) -- neighbours share site windows and read blocks -- and
+    take this rank's contiguous slice."""
+    order = sorted(range(len(dnms)), key=lambda i: (str(dnms[i]["chrom"]), int(dnms[i]["start"]),
+                                                    int(dnms[i]["end"]), str(dnms[i]["kid"])))
+    b = shard_bounds(len(order), world)
+    return [dnms[i] for i in order[b[rank]: b[rank + 1]]]
+
+
+def phase_sharded(phase_fn, dnms: List[dict], *args, rank: int = 0, world: int = 1, dist=None, **kw) -> Optional[Dict[str, dict]]:
+    """Run `phase_fn(shard, *args, **kw)` (phase_snvs / phase_svs) on this rank's shard and gather the
+    records on rank 0 (returns None on the other ranks).  With world == 1 this is a plain call."""
+    mine = shard_dnms(dnms, rank, world) if world > 1 else dnms
+    recs = phase_fn(mine, *args, **kw) if mine else {}
+    if world == 1 or dist is None:
+        return recs
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(recs, gathered, dst=0)
+    if rank != 0:
+        return None
+    merged: Dict[str, dict] = {}
+    for part in gathered:
+        merged.update(part)
+    return merged
