@@ -9,6 +9,9 @@
 #include <vector>
 
 #include "phase_body.hpp"
+#ifdef UZ_EMU_STATS
+extern "C" { long long uz_emu_stats[16]; }
+#endif
 
 extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *Rv, const uz_dnms_view *D,
                          const int64_t *cand_off, const int32_t *cand_idx, const uint8_t *cand_flags,
@@ -21,6 +24,9 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     R.start = Rv->start; R.end = Rv->end; R.flag = Rv->flag; R.mapq = Rv->mapq; R.aux = Rv->aux; R.tlen = Rv->tlen;
     R.qname = Rv->qname; R.mate = Rv->mate; R.cigar_off = Rv->cigar_off; R.n_cigar = Rv->n_cigar; R.cigar = Rv->cigar;
     R.l_seq = Rv->l_seq; R.sq_off16 = Rv->sq_off16; R.seq = Rv->seq; R.qual = Rv->qual; R.qc = qc.data();
+    std::vector<int32_t> coarse((size_t)(Rv->n_segs >> 12) + 2);
+    for (int64_t k = 0; (k << 12) < Rv->n_segs; k++) coarse[k] = Rv->start[k << 12];
+    R.coarse = coarse.data();
     for (int64_t i = 0; i < Rv->n_segs; i++) qc[i] = uz_seg_qc(R, (int)i, P->min_map_qual, P->min_gt_qual);
     PhaseArgs a;
     memset(&a, 0, sizeof(a));
@@ -35,6 +41,8 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     a.want_lists = 1; a.pool = pool; a.pool_cap = (unsigned long long)pool_cap;
     unsigned long long cursor = 0;
     a.pool_cursor = &cursor; a.list_start = list_start; a.list_len = list_len;
+    std::vector<int32_t> pre_win((size_t)2 * D->n + 2), pre_ha((size_t)het_off[D->n] + 2), pre_hl((size_t)het_off[D->n] + 2);
+    a.pre_win = pre_win.data(); a.pre_ha = pre_ha.data(); a.pre_hl = pre_hl.data();
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 2;
     for (int d = 0; d < D->n; d++) {
         int32_t b[5];
@@ -56,7 +64,13 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     uz_scratch_carve(scratch.data(), caps, s);
     a.scratch = scratch.data(); a.scratch_per_wg = bytes; a.caps = caps;
     WgShared sh;
-    for (int d = 0; d < D->n; d++) uz_phase_dnm(a, s, &sh, d);
+    // exercise all placements: no LDS arena, a tiny one (mixed LDS / HBM arrays), a roomy one
+    static const int arena_sizes[3] = {0, 3072, 65536};
+    std::vector<uint8_t> arena(65536 + 64);
+    for (int d = 0; d < D->n; d++) {
+        a.lds_arena_bytes = arena_sizes[d % 3];
+        uz_phase_dnm(a, s, &sh, a.lds_arena_bytes ? arena.data() : nullptr, d);
+    }
     *pool_used = (long long)cursor;
     return 0;
 }

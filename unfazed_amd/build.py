@@ -13,23 +13,24 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None):
     csrc = os.path.join(_HERE, "csrc")
     inc = os.path.join(_HERE, "..", "include")
     srcs = [os.path.join(csrc, s) for s in SRC]
     deps = srcs + [os.path.join(csrc, "uz_ctx.hpp"), os.path.join(csrc, "wg.hpp"),
                    os.path.join(inc, "uz_types.h"), os.path.join(inc, "unfazed_hip.h")]
     deps = [d for d in deps if os.path.exists(d)]
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
-        return LIB
+    lib = out or LIB
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-parameter", "-I", inc, "-I", csrc] + list(extra_flags) + srcs + ["-o", LIB + ".tmp"]
+           "-Wall", "-Wno-unused-parameter", "-I", inc, "-I", csrc] + list(extra_flags) + srcs + ["-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(lib + ".tmp", lib)
+    return lib
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 
 void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n);
 bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv);
+void uz_build_coarse(uz_ctx *c, ReadsDev &r);
 
 namespace {
 
@@ -89,7 +90,7 @@ void free_reads(ReadsDev &r) {
         (void)hipFree(r.n_cigar); (void)hipFree(r.cigar); (void)hipFree(r.l_seq); (void)hipFree(r.sq_off16);
         (void)hipFree(r.seq); (void)hipFree(r.qual);
     }
-    (void)hipFree(r.contig_off); (void)hipFree(r.max_span); (void)hipFree(r.qc);
+    (void)hipFree(r.contig_off); (void)hipFree(r.max_span); (void)hipFree(r.qc); (void)hipFree(r.coarse);
     r = ReadsDev();
 }
 
@@ -315,6 +316,7 @@ static void reads_fill(uz_ctx *c, const uz_reads_view *v, ReadsDev &r, bool copy
         r.seq = const_cast<uint8_t *>(v->seq); r.qual = const_cast<uint8_t *>(v->qual);
     }
     UZ_HIP(hipMalloc((void **)&r.qc, n + 64));
+    uz_build_coarse(c, r);
     UZ_HIP(hipStreamSynchronize(c->stream));
 }
 

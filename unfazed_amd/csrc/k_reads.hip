@@ -8,6 +8,8 @@
 #include "phase_body.hpp"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
 
 __global__ __launch_bounds__(WG_NT) void k_phase(PhaseArgs a) {
     __shared__ WgShared sh;
+    extern __shared__ __attribute__((aligned(16))) uint8_t uz_lds_arena[];
     Scr s;
     uz_scratch_carve(a.scratch + (size_t)blockIdx.x * a.scratch_per_wg, a.caps, s);
     for (;;) {
@@ -68,13 +71,13 @@ __global__ __launch_bounds__(WG_NT) void k_phase(PhaseArgs a) {
         __syncthreads();
         const int d = sh.bcast[0];
         if (d >= a.n) break;
-        uz_phase_dnm(a, s, &sh, d);
+        uz_phase_dnm(a, s, &sh, a.lds_arena_bytes > 0 ? uz_lds_arena : nullptr, d);
     }
 }
 
 struct PhaseState {
     DevBuf<uint8_t> scratch;
-    DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len;
+    DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len, pre_win, pre_ha, pre_hl;
     DevBuf<long long> list_start;
     DevBuf<unsigned long long> pool_cursor;
     std::vector<long long> list_start_h;
@@ -83,12 +86,17 @@ struct PhaseState {
     int32_t n = 0;
 };
 
+__global__ void k_build_coarse(const int32_t *start, int64_t n, int32_t *coarse) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((k << 12) < n) coarse[k] = start[k << 12];
+}
+
 RD make_rd(const ReadsDev &r) {
     RD R;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
     R.start = r.start; R.end = r.end; R.flag = r.flag; R.mapq = r.mapq; R.aux = r.aux; R.tlen = r.tlen;
     R.qname = r.qname; R.mate = r.mate; R.cigar_off = r.cigar_off; R.n_cigar = r.n_cigar; R.cigar = r.cigar;
-    R.l_seq = r.l_seq; R.sq_off16 = r.sq_off16; R.seq = r.seq; R.qual = r.qual; R.qc = r.qc;
+    R.l_seq = r.l_seq; R.sq_off16 = r.sq_off16; R.seq = r.seq; R.qual = r.qual; R.qc = r.qc; R.coarse = r.coarse;
     return R;
 }
 
@@ -100,11 +108,20 @@ int next_pow2(long long v) {
 
 } // namespace
 
+void uz_build_coarse(uz_ctx *c, ReadsDev &r) {
+    const int64_t nk = (r.n >> 12) + 2;
+    UZ_HIP(hipMalloc((void **)&r.coarse, (size_t)nk * sizeof(int32_t)));
+    if (r.n > 0) {
+        hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, c->stream, r.start, r.n, r.coarse);
+        UZ_HIP(hipGetLastError());
+    }
+}
+
 void uz_phase_state_free(uz_ctx *c) {
     PhaseState *st = (PhaseState *)c->phase_state;
     if (!st) return;
     st->scratch.release(); st->bounds.release(); st->status.release(); st->counts.release(); st->origin.release();
-    st->evidence.release(); st->cursor.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
+    st->evidence.release(); st->cursor.release(); st->pre_win.release(); st->pre_ha.release(); st->pre_hl.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
     st->pool_cursor.release();
     delete st;
     c->phase_state = nullptr;
@@ -150,6 +167,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
 
     // sizing pass -> scratch capacities (max over the batch)
     st->bounds.ensure((size_t)5 * n);
+    st->pre_win.ensure((size_t)2 * n); st->pre_ha.ensure((size_t)c->n_het + 1); st->pre_hl.ensure((size_t)c->n_het + 1);
+    a.pre_win = st->pre_win.p; a.pre_ha = st->pre_ha.p; a.pre_hl = st->pre_hl.p;
     {
         const unsigned nb = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
@@ -176,7 +195,16 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
     hipDeviceProp_t prop;
     UZ_HIP(hipGetDeviceProperties(&prop, c->device));
-    int grid = prop.multiProcessorCount * 6;
+    static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 20) * 1024; }();
+    static const int wgs_per_cu = [] {
+        const char *e = getenv("UZ_PHASE_WGS_PER_CU");
+        if (e) return atoi(e);
+        const int by_lds = (160 * 1024) / (arena_bytes + (int)sizeof(WgShared) + 512);
+        const int by_threads = 2048 / WG_NT;
+        return by_lds < by_threads ? (by_lds > 0 ? by_lds : 1) : by_threads;
+    }();
+    a.lds_arena_bytes = arena_bytes;
+    int grid = prop.multiProcessorCount * wgs_per_cu;
     if (grid > n) grid = n;
     const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
     while (grid > 1 && (size_t)grid * per_wg > budget) grid /= 2;
@@ -194,12 +222,18 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.pool = st->pool.p; a.pool_cap = pool_cap; a.pool_cursor = st->pool_cursor.p;
     a.list_start = st->list_start.p; a.list_len = st->list_len.p;
 
+#ifdef UZ_PHASE_TIMING
+    static DevBuf<unsigned long long> timing;
+    timing.ensure(16);
+    UZ_HIP(hipMemsetAsync(timing.p, 0, 16 * sizeof(unsigned long long), c->stream));
+    a.timing = timing.p;
+#endif
     for (int attempt = 0; attempt < 4; attempt++) {
         UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
         UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
         {
             ProfScope ps(c, UZ_K_PHASE);
-            hipLaunchKernelGGL(k_phase, dim3((unsigned)grid), dim3(WG_NT), 0, c->stream, a);
+            hipLaunchKernelGGL(k_phase, dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
             UZ_HIP(hipGetLastError());
         }
         unsigned long long used = 0;
@@ -211,6 +245,18 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         st->pool.ensure(pool_cap);
         a.pool = st->pool.p; a.pool_cap = pool_cap;
     }
+#ifdef UZ_PHASE_TIMING
+    {
+        unsigned long long t[16];
+        UZ_HIP(hipMemcpy(t, timing.p, sizeof(t), hipMemcpyDeviceToHost));
+        const char *nm[8] = {"A", "B", "C", "sort", "pairs", "D", "E", "F"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += t[k];
+        fprintf(stderr, "[phase timing]");
+        for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)t[k] / (double)(tot ? tot : 1));
+        fprintf(stderr, " | ticks/DNM %.0f\n", (double)tot / n);
+    }
+#endif
     if (status) UZ_HIP(hipMemcpyAsync(status, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (counts) UZ_HIP(hipMemcpyAsync(counts, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (origin) UZ_HIP(hipMemcpyAsync(origin, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

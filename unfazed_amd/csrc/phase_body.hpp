@@ -19,6 +19,24 @@
 #include "uz_types.h"
 #include "wg.hpp"
 
+// Diagnostic build only (-DUZ_PHASE_TIMING): lane 0 adds the shader-clock ticks spent between
+// phase boundaries into a.timing[k]; never compiled into the product library.
+#if defined(UZ_PHASE_TIMING) && !defined(UZ_EMU)
+#define UZ_TICK(k)                                                                     \
+    do {                                                                               \
+        __syncthreads();                                                               \
+        if (threadIdx.x == 0) {                                                        \
+            const unsigned long long now__ = __builtin_amdgcn_s_memtime();             \
+            atomicAdd(&a.timing[k], now__ - tick__);                                   \
+            tick__ = now__;                                                            \
+        }                                                                              \
+    } while (0)
+#define UZ_TICK_INIT unsigned long long tick__ = __builtin_amdgcn_s_memtime()
+#else
+#define UZ_TICK(k) ((void)0)
+#define UZ_TICK_INIT ((void)0)
+#endif
+
 #define UZ_QC_GOOD 1u      // goodread(read) :28-53
 #define UZ_QC_GOOD_DISC 2u // goodread(read, True)
 #define UZ_QC_NM5 4u       // <= 5 CIGAR ops other than M/= :190-196
@@ -32,6 +50,9 @@
 #define UZ_OP_EQ 7
 #define UZ_OP_X 8
 
+#ifdef UZ_EMU_STATS
+extern "C" long long uz_emu_stats[16];
+#endif
 struct RD { // alignment-record columns (device pointers)
     const int64_t *contig_off;
     const int32_t *max_span;
@@ -49,6 +70,7 @@ struct RD { // alignment-record columns (device pointers)
     const uint32_t *sq_off16;
     const uint8_t *seq, *qual;
     const uint8_t *qc;
+    const int32_t *coarse; // start[] of every 4096th record (L2-resident search index), may be null
 };
 
 struct Caps { // per-workgroup scratch capacities (elements)
@@ -79,6 +101,7 @@ struct Scr {
     int32_t *fr_pair[2], *fr_pos[2];
     uint8_t *fr_hap[2];
     int32_t *o_flag;
+    int32_t *q_cnt, *q_fill; // counting sort of the pair-table keys over the query-name id range
     int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
 };
 
@@ -110,9 +133,32 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.key, M); uz_carve(base, o, s.assigned, M);
     for (int k = 0; k < 2; k++) { uz_carve(base, o, s.fr_pair[k], FR); uz_carve(base, o, s.fr_pos[k], FR); uz_carve(base, o, s.fr_hap[k], FR); }
     uz_carve(base, o, s.o_flag, M + C + 2);
+    uz_carve(base, o, s.q_cnt, 2 * M + 1026); uz_carve(base, o, s.q_fill, 2 * M + 1026);
     uz_carve(base, o, s.misc, 8);
     return (o + 255) & ~(size_t)255;
 }
+
+// Per-DNM placement of the working arrays: LDS first.  The scratch region in HBM has room for the
+// largest DNM of the batch, but a typical DNM needs a few tens of KB, and every phase boundary waits
+// for its outstanding stores: in LDS that wait is ~100 cycles instead of a round trip to memory.
+// Arrays are placed in the workgroup's LDS arena in the order they are requested, with their ACTUAL
+// sizes; whatever does not fit keeps its pointer into the HBM scratch (the code is address-space
+// agnostic).  "Temporary" arrays live above the persistent ones and are recycled at phase boundaries.
+struct Arena {
+    uint8_t *base;
+    int cap, pers, tmp;
+};
+template <typename T>
+UZ_DEV void ar_p(Arena &ar, T *&ptr, size_t n) { // persistent for the rest of the DNM
+    const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
+    if (ar.pers + b <= ar.cap) { ptr = reinterpret_cast<T *>(ar.base + ar.pers); ar.pers += b; ar.tmp = ar.pers; }
+}
+template <typename T>
+UZ_DEV void ar_t(Arena &ar, T *&ptr, size_t n) { // until the next ar_reset
+    const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
+    if (ar.tmp + b <= ar.cap) { ptr = reinterpret_cast<T *>(ar.base + ar.tmp); ar.tmp += b; }
+}
+UZ_DEV void ar_reset(Arena &ar) { ar.tmp = ar.pers; }
 
 struct PhaseArgs {
     int32_t n;
@@ -144,6 +190,13 @@ struct PhaseArgs {
     uint8_t *scratch;
     unsigned long long scratch_per_wg;
     Caps caps;
+    int32_t lds_arena_bytes;
+    // fetch ranges found by the sizing pass (one lane per DNM, all DNMs in flight at once, so the
+    // binary searches overlap instead of serialising inside the per-DNM workgroup)
+    int32_t *pre_win; // [2n]   first / one-past-last record of the DNM fetch
+    int32_t *pre_ha;  // [n_het] first record of every het-site fetch range
+    int32_t *pre_hl;  // [n_het] its length
+    unsigned long long *timing; // diagnostic builds only
 };
 
 // ------------------------------------------------------------------ helpers
@@ -155,13 +208,48 @@ UZ_DEV long long uz_lower_bound(const int32_t *a, long long lo, long long hi, lo
     return lo;
 }
 
+// lower bound on the start column with the first steps taken on the coarse index: a plain binary
+// search over a 1 GB column is ~25 dependent HBM misses; the index keeps all but the last dozen in L2.
+UZ_DEV long long uz_lower_bound_c(const RD &R, long long lo, long long hi, long long v) {
+    if (R.coarse && hi - lo > 8192) {
+        const long long kl = (lo + 4095) >> 12, kh = hi >> 12;
+        long long a = kl, b = kh;
+        while (a < b) {
+            const long long mid = a + ((b - a) >> 1);
+            if ((long long)R.coarse[mid] < v) a = mid + 1; else b = mid;
+        }
+        const long long nlo = a > kl ? ((a - 1) << 12) : lo;
+        const long long nhi = a < kh ? (a << 12) : hi;
+        lo = nlo; hi = nhi;
+    }
+    return uz_lower_bound(R.start, lo, hi, v);
+}
+
 // pysam fetch(contig, lo, hi): candidates are records with start in [lo - max_span, hi);
 // the caller still tests end > lo.
 UZ_DEV void uz_fetch_range(const RD &R, int tid, long long lo, long long hi, long long &a, long long &b) {
     if (tid < 0 || tid >= R.n_contigs) { a = b = 0; return; }
     const long long clo = R.contig_off[tid], chi = R.contig_off[tid + 1];
-    a = uz_lower_bound(R.start, clo, chi, lo - R.max_span[tid]);
-    b = uz_lower_bound(R.start, clo, chi, hi);
+    a = uz_lower_bound_c(R, clo, chi, lo - R.max_span[tid]);
+    b = uz_lower_bound_c(R, a, chi, hi);
+}
+// the same inside a record range [wa, wb) already known to contain the answer (the DNM's window)
+UZ_DEV void uz_fetch_range_in(const RD &R, int tid, long long wa, long long wb, long long lo, long long hi, long long &a, long long &b) {
+    if (tid < 0 || tid >= R.n_contigs) { a = b = 0; return; }
+    a = uz_lower_bound(R.start, wa, wb, lo - R.max_span[tid]);
+    b = uz_lower_bound(R.start, a, wb, hi);
+}
+// record range covering every fetch of one DNM: the DNM position and all of its het sites
+UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &wb) {
+    const long long position = a.dstart[d];
+    long long lo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1, hi = position + 1;
+    const long long h0 = a.het_off[d], h1 = a.het_off[d + 1];
+    if (h1 > h0 && !a.no_extended) { // the het list is sorted by position
+        const long long p0 = a.spos[a.het_idx[h0]], p1 = a.spos[a.het_idx[h1 - 1]];
+        if (p0 < lo) lo = p0;
+        if (p1 + 1 > hi) hi = p1 + 1;
+    }
+    uz_fetch_range(a.R, a.rcontig[d], lo, hi, wa, wb);
 }
 
 // index of `pos` in get_reference_positions(full_length=True), -1 if absent
@@ -294,8 +382,11 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long l
 }
 
 // ------------------------------------------------------------------ one DNM
-UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) {
+UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_t *lds_arena, int d) {
     const RD &R = a.R;
+    Scr s = sg; // pointers into the HBM scratch; re-pointed into LDS below where the arrays fit
+    Arena ar = {lds_arena, lds_arena ? a.lds_arena_bytes : 0, 0, 0};
+    int32_t *stg1 = sg.seq_h, *stg2 = sg.srt_h; // staging of the ordered compaction in phase B
     const long long c0 = a.cand_off[d], h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);
     WG_SYNC();
@@ -306,8 +397,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
         if (a.want_lists) { a.list_start[d] = -1; for (int k = 0; k < 6; k++) a.list_len[6 * d + k] = 0; }
     }
     if (nc <= 0) return; // snv_phaser.py:254-262
+    if (nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+    ar_p(ar, s.misc, 8);
+    ar_p(ar, s.cpos, nc + 1); ar_p(ar, s.cvote, nc + 1);
+    ar_p(ar, s.hpos, nh + 1); ar_p(ar, s.hcanon, nh + 1); ar_p(ar, s.h_a, nh + 1);
+    ar_p(ar, s.h_off, nh + 2); ar_p(ar, s.sr_off, nh + 2); ar_p(ar, s.sr_exists, nh + 1);
     WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
-    const int tid = a.rcontig[d];
+    (void)a.rcontig;
     const long long position = a.dstart[d];
     const uint8_t *ref = a.alleles + a.allele_off[2 * d];
     const int ref_len = (int)(a.allele_off[2 * d + 1] - a.allele_off[2 * d]);
@@ -315,14 +411,21 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
     const int alt_len = (int)(a.allele_off[2 * d + 2] - a.allele_off[2 * d + 1]);
     const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
 
+    UZ_TICK_INIT;
     WG_FOR(k, nc) { s.cpos[k] = a.spos[a.cand_idx[c0 + k]]; s.cvote[k] = 0; }
     WG_FOR(k, nh) s.hpos[k] = a.spos[a.het_idx[h0 + k]];
 
     // ---- A: DNM reads -> ordered "ref" / "alt" lists (each hit contributes read, mate)
-    long long fa, fb;
-    uz_fetch_range(R, tid, flo, position + 1, fa, fb);
+    const long long fa = a.pre_win[2 * d], fb = a.pre_win[2 * d + 1];
     const int nA = (int)(fb - fa);
-    if (nA > a.caps.A || nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+    if (nA > a.caps.A) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+    {
+        const size_t ni = 2 * (size_t)nA + 2; // at most two list elements per fetched record
+        ar_p(ar, s.i_seg, ni); ar_p(ar, s.i_hb, ni); ar_p(ar, s.i_pair, ni); ar_p(ar, s.i_soff, ni);
+        ar_p(ar, s.i_qp, ni); ar_p(ar, s.i_L, ni); ar_p(ar, s.i_R, ni);
+        ar_t(ar, s.a_cls, nA + 1); ar_t(ar, s.a_flag[0], nA + 1); ar_t(ar, s.a_flag[1], nA + 1);
+        ar_t(ar, s.LR, ni); ar_t(ar, s.LA, ni);
+    }
     WG_FOR(i, nA) {
         const int cl = uz_classify_dnm_read(R, a, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
         s.a_cls[i] = (uint8_t)cl;
@@ -351,15 +454,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
     }
     WG_SYNC();
 
+    UZ_TICK(0); // A
     int E = 0, S = 0, P = 0;
     bool exception = false;
     if (!a.no_extended) {
         // ---- B: registration at every het site, in list order
         WG_FOR(h, nh) {
-            long long ha, hb;
-            uz_fetch_range(R, tid, s.hpos[h], (long long)s.hpos[h] + 1, ha, hb);
-            s.h_a[h] = (int)ha;
-            s.h_off[h] = (int)(hb - ha);
+            s.h_a[h] = a.pre_ha[h0 + h];
+            s.h_off[h] = a.pre_hl[h0 + h];
             s.hcanon[h] = h; // fixed below
             s.sr_exists[h] = 0;
         }
@@ -371,6 +473,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
         }
         const int T = wg_exscan(s.h_off, nh, sh);
         if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+        ar_reset(ar);
+        ar_p(ar, s.reg_h, T + 1); ar_p(ar, s.reg_seg, T + 1); ar_p(ar, s.reg_pair, T + 1); ar_p(ar, s.cbase, T + 1);
+        ar_t(ar, s.t_ov, T + 1); ar_t(ar, s.t_pass, T + 1); ar_t(ar, stg1, T + 1); ar_t(ar, stg2, T + 1);
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
         WG_FOR(t, T) {
@@ -402,17 +507,17 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
         WG_FOR(t, T) s.t_pass[t] = s.t_ov[t];
         WG_SYNC();
         E = wg_exscan(s.t_pass, T, sh);
-        // compact in place is unsafe across lanes: stage through seq_h / keys
+        // compacting in place is unsafe across lanes: stage, then copy
         WG_FOR(t, T) {
             if (s.t_ov[t]) {
                 const int k = s.t_pass[t];
                 const int h = s.reg_h[t];
-                s.seq_h[k] = h;
-                s.srt_h[k] = s.h_a[h] + (t - s.h_off[h]);
+                stg1[k] = h;
+                stg2[k] = s.h_a[h] + (t - s.h_off[h]);
             }
         }
         WG_SYNC();
-        WG_FOR(k, E) { s.reg_h[k] = s.seq_h[k]; s.reg_seg[k] = s.srt_h[k]; }
+        WG_FOR(k, E) { s.reg_h[k] = stg1[k]; s.reg_seg[k] = stg2[k]; }
         // site_reads range of het index h: entries [sr_off[h], sr_off[h+1])
         WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.t_pass[s.h_off[h]] : E) : E;
         WG_SYNC();
@@ -420,6 +525,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
             // a canonical site exists in site_reads once any of its duplicates registered a read (:217-218)
             if (s.sr_off[h + 1] > s.sr_off[h]) s.sr_exists[s.hcanon[h]] = 1;
         }
+        UZ_TICK(1); // B
         // ---- C: seeding (:226-249): matches of every init element among the het sites
         WG_FOR(m, nI) {
             const int seg = s.i_seg[m];
@@ -432,19 +538,32 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
         S = wg_exscan(s.i_soff, nI, sh);
         WG_T0 s.i_soff[nI] = S;
         WG_SYNC();
+        ar_reset(ar);
+        ar_p(ar, s.seq_h, S + 1); // het index of every seed entry
         if (S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
         WG_FOR(m, nI) {
             const int nm = s.i_soff[m + 1] - s.i_soff[m];
-            for (int j = 0; j < nm; j++) s.seq_h[E + s.i_soff[m] + j] = uz_bsearch_nth(j, s.i_qp[m], s.i_L[m], s.i_R[m]);
+            for (int j = 0; j < nm; j++) s.seq_h[s.i_soff[m] + j] = uz_bsearch_nth(j, s.i_qp[m], s.i_L[m], s.i_R[m]);
         }
         WG_SYNC();
     }
+    UZ_TICK(2); // C
     // ---- S: pair table.  Keys (qname << 24 | seq): registrations seq < E, seeds, then one
     // presence entry per init element (seq >= E + S) so that every grouped pair has an id.
     const int M = E + S + nI;
     if (M >= (1 << 20) || M > a.caps.M || nI > a.caps.I) { // rank-key field widths / scratch: loud, never silent
         WG_T0 a.status[d] = UZ_ST_CAPACITY;
         return;
+    }
+    {
+        ar_reset(ar);
+        int mp2 = 2;
+        while (mp2 < M) mp2 <<= 1;
+        ar_p(ar, s.keys, mp2 + 1); ar_p(ar, s.key, M + 1);
+        ar_p(ar, s.srt_h, M + 1); ar_p(ar, s.srt_pid, M + 1); ar_p(ar, s.srt_fb, M + 1);
+        ar_p(ar, s.rs_off, M + 2); ar_p(ar, s.rs_len, M + 1); ar_p(ar, s.fet0, M + 1); ar_p(ar, s.fet1, M + 1);
+        ar_p(ar, s.grp, M + 1); ar_p(ar, s.pvote, M + 1); ar_p(ar, s.pq, M + 1); ar_p(ar, s.assigned, M + 1);
+        ar_t(ar, s.srt_flag, M + 1);
     }
     WG_FOR(x, M) {
         uint32_t q;
@@ -458,7 +577,52 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
         s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
     }
     WG_SYNC();
-    wg_sort64(s.keys, M, sh);
+    // Sort by (query-name id, sequence).  Name ids are interned in file order, so the names met
+    // around one locus span a short id range: a counting sort over that range (stable order inside
+    // a bucket restored by a tiny insertion sort) replaces the 60+ barrier stages of a bitonic sort.
+    // Wider ranges fall back to the bitonic sort; both give the same array.
+    {
+        WG_T0 { sh->bcast[1] = 0x7FFFFFFF; sh->bcast[2] = -1; }
+        WG_SYNC();
+        WG_FOR(x, M) {
+            const int q = (int)(s.keys[x] >> 24);
+            wg_atomic_min32(&sh->bcast[1], q);
+            wg_atomic_max32(&sh->bcast[2], q);
+        }
+        WG_SYNC();
+        const int qmin = sh->bcast[1], qrange = M > 0 ? sh->bcast[2] - sh->bcast[1] + 1 : 0;
+        WG_SYNC();
+        if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
+            ar_t(ar, s.q_cnt, qrange + 2); ar_t(ar, s.q_fill, qrange + 2);
+            WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
+            WG_SYNC();
+            WG_FOR(x, M) wg_atomic_add(&s.q_cnt[(int)(s.keys[x] >> 24) - qmin], 1);
+            WG_SYNC();
+            (void)wg_exscan(s.q_cnt, qrange, sh);
+            WG_FOR(x, M) {
+                const int b = (int)(s.keys[x] >> 24) - qmin;
+                s.key[s.q_cnt[b] + wg_atomic_add(&s.q_fill[b], 1)] = s.keys[x];
+            }
+            WG_SYNC();
+            WG_FOR(b, qrange) {
+                const int n_b = s.q_fill[b];
+                if (n_b > 1) {
+                    unsigned long long *v = s.key + s.q_cnt[b];
+                    for (int i = 1; i < n_b; i++) {
+                        const unsigned long long kx = v[i];
+                        int j = i - 1;
+                        while (j >= 0 && v[j] > kx) { v[j + 1] = v[j]; j--; }
+                        v[j + 1] = kx;
+                    }
+                }
+            }
+            WG_SYNC();
+            WG_FOR(x, M) s.keys[x] = s.key[x];
+            WG_SYNC();
+        } else
+            wg_sort64(s.keys, M, sh);
+    }
+    UZ_TICK(3); // sort
     WG_FOR(x, M) s.srt_flag[x] = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
     WG_SYNC();
     WG_FOR(x, M) s.srt_pid[x] = s.srt_flag[x];
@@ -471,7 +635,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
         if (s.srt_flag[x]) { s.rs_off[pid] = x; s.pq[pid] = (uint32_t)(s.keys[x] >> 24); }
         if (seq < E) s.reg_pair[seq] = pid;
         else if (seq >= E + S) s.i_pair[seq - E - S] = pid;
-        s.srt_h[x] = seq < E + S ? s.seq_h[seq] : -1;
+        s.srt_h[x] = seq < E ? s.reg_h[seq] : (seq < E + S ? s.seq_h[seq - E] : -1);
     }
     WG_T0 s.rs_off[P] = M;
     WG_SYNC();
@@ -499,6 +663,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
     WG_SYNC();
     if (s.misc[2]) { WG_SYNC(); WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
 
+#ifdef UZ_EMU_STATS
+    uz_emu_stats[0] += E; uz_emu_stats[1] += S; uz_emu_stats[2] += nI; uz_emu_stats[3] += P; uz_emu_stats[7] += nh; uz_emu_stats[8] += nc; uz_emu_stats[9]++;
+    { int T_ = 0; if (!a.no_extended) T_ = s.h_off[nh]; uz_emu_stats[10] += T_; }
+#endif
+    UZ_TICK(4); // pair table
     if (!a.no_extended) {
         // ---- D: static allele tables
         WG_FOR(x, M) {
@@ -525,8 +694,15 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
             s.cbase[k] = cb;
         }
         WG_SYNC();
+        UZ_TICK(5); // D
         // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
         int F = nI, cur = 0;
+        {
+            ar_reset(ar);
+            const size_t fr = (size_t)(P > nI ? P : nI) + 2;
+            for (int k = 0; k < 2; k++) { ar_t(ar, s.fr_pair[k], fr); ar_t(ar, s.fr_pos[k], fr); ar_t(ar, s.fr_hap[k], fr); }
+            ar_t(ar, s.o_flag, P + 2);
+        }
         WG_FOR(e, nI) {
             const int na = 2 * n_alt;
             const int m = e < na ? (2 * n_ref + e) : (e - na);
@@ -584,16 +760,24 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
                 }
             }
             WG_SYNC();
-            wg_sort64(s.keys, W, sh);
+            // position in the next frontier = rank of the (target, rank) key among the winners: counted
+            // directly while a level has few winners (one barrier), sorted otherwise
+            const bool by_count = W <= 96;
+            if (!by_count) wg_sort64(s.keys, W, sh);
             WG_FOR(w, W) {
                 const unsigned long long ok = s.keys[w];
+                int posn = w;
+                if (by_count) {
+                    posn = 0;
+                    for (int v = 0; v < W; v++) posn += s.keys[v] < ok;
+                }
                 const int e = (int)((ok >> 32) & 0xFFFFF), j = (int)((ok >> 20) & 0xFFF), krel = (int)(ok & 0xFFFFF);
                 const int pe = s.fr_pair[cur][e];
                 const int h = s.srt_h[s.rs_off[pe] + j];
                 const int p = s.reg_pair[s.sr_off[s.hcanon[h]] + krel];
-                s.fr_pair[cur ^ 1][w] = p;
-                s.fr_pos[cur ^ 1][w] = s.hpos[h];
-                s.fr_hap[cur ^ 1][w] = (uint8_t)(ok >> 63);
+                s.fr_pair[cur ^ 1][posn] = p;
+                s.fr_pos[cur ^ 1][posn] = s.hpos[h];
+                s.fr_hap[cur ^ 1][posn] = (uint8_t)(ok >> 63);
             }
             WG_SYNC();
             WG_FOR(w, W) {
@@ -603,9 +787,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
                 s.key[p] = ~0ULL;
             }
             WG_SYNC();
+#ifdef UZ_EMU_STATS
+            uz_emu_stats[4]++; if (W > uz_emu_stats[5]) uz_emu_stats[5] = W; uz_emu_stats[6] += W;
+#endif
             F = W;
             cur ^= 1;
         }
+        UZ_TICK(6); // E
         exception = s.misc[0] != 0;
     }
     WG_SYNC();
@@ -616,6 +804,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
 
     // ---- F: join + vote.  Items: extended -> both fetched segments of every grouped pair per
     // haplotype (:254-263); --no-extended -> the init list elements themselves.
+    ar_reset(ar);
+    s.o_flag = sg.o_flag;
+    ar_t(ar, s.o_flag, (size_t)(P > nc ? P : nc) + 2);
     const int n_items = a.no_extended ? nI : 4 * P;
     WG_FOR(it, n_items) {
         int seg, hb, p;
@@ -709,6 +900,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &s, WgShared *sh, int d) 
             WG_SYNC();
         }
     }
+    UZ_TICK(7); // F
     WG_T0 {
         a.status[d] = UZ_ST_OK;
         for (int k = 0; k < 4; k++) a.counts[4 * d + k] = cnt[k];
@@ -731,13 +923,16 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
     const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - h0);
     b[0] = b[1] = b[4] = 0;
     b[2] = nh; b[3] = nc;
+    a.pre_win[2 * d] = a.pre_win[2 * d + 1] = 0;
     if (nc <= 0) return;
     const int tid = a.rcontig[d];
     const long long position = a.dstart[d];
     const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
-    long long fa, fb;
-    uz_fetch_range(R, tid, flo, position + 1, fa, fb);
+    long long wa, wb, fa, fb;
+    uz_dnm_window(a, d, wa, wb);
+    uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
     b[0] = (int32_t)(fb - fa);
+    a.pre_win[2 * d] = (int32_t)fa; a.pre_win[2 * d + 1] = (int32_t)fb;
     if (a.no_extended) return;
     long long T = 0;
     const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;
@@ -745,7 +940,8 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
     for (int h = 0; h < nh; h++) {
         const long long hp = a.spos[a.het_idx[h0 + h]];
         long long ha, hb;
-        uz_fetch_range(R, tid, hp, hp + 1, ha, hb);
+        uz_fetch_range_in(R, tid, wa, wb, hp, hp + 1, ha, hb);
+        a.pre_ha[h0 + h] = (int32_t)ha; a.pre_hl[h0 + h] = (int32_t)(hb - ha);
         T += hb - ha;
         while ((long long)a.spos[a.het_idx[h0 + left]] < hp - span - 1) left++;
         if (h - left + 1 > mh) mh = h - left + 1;

@@ -24,24 +24,33 @@
 #define WG_T0 if (true)
 UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
 UZ_DEV int wg_atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
+UZ_DEV void wg_atomic_min32(int *p, int v) { if (v < *p) *p = v; }
+UZ_DEV void wg_atomic_max32(int *p, int v) { if (v > *p) *p = v; }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 #else
 #include <hip/hip_runtime.h>
 #define UZ_DEV __device__ __forceinline__
 #define UZ_HD __host__ __device__ inline
-#define WG_NT 256
+#ifndef UZ_WG_NT
+#define UZ_WG_NT 256
+#endif
+#define WG_NT UZ_WG_NT
 #define WG_TID ((int)threadIdx.x)
 #define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += WG_NT)
 #define WG_SYNC() __syncthreads()
 #define WG_T0 if (threadIdx.x == 0)
 UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 UZ_DEV int wg_atomic_add(int *p, int v) { return atomicAdd(p, v); }
+UZ_DEV void wg_atomic_min32(int *p, int v) { atomicMin(p, v); }
+UZ_DEV void wg_atomic_max32(int *p, int v) { atomicMax(p, v); }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 #endif
 
-#define WG_SORT_LDS_CAP 2048 // u64 keys sorted in LDS (16 KiB); larger sorts run in the scratch region
+#ifndef WG_SORT_LDS_CAP
+#define WG_SORT_LDS_CAP 512 // u64 keys copied into the 4 KiB LDS sort buffer; larger sorts run in place (LDS arena or HBM scratch)
+#endif
 
 struct WgShared {
     int part[WG_NT + 1];
@@ -50,6 +59,8 @@ struct WgShared {
 };
 
 // In-place exclusive scan of a[0..n) -> returns the total.  Block-uniform call.
+// Each lane sums a contiguous chunk, lanes are combined with wave shuffles (no barrier) and the
+// waves through WG_NT/64 words of LDS: three barriers per call.
 UZ_DEV int wg_exscan(int *a, int n, WgShared *sh) {
 #ifdef UZ_EMU
     int s = 0;
@@ -63,16 +74,23 @@ UZ_DEV int wg_exscan(int *a, int n, WgShared *sh) {
     int hi = lo + chunk; if (hi > n) hi = n;
     int s = 0;
     for (int i = lo; i < hi; i++) s += a[i];
-    sh->part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < WG_NT; off <<= 1) {
-        const int v = t >= off ? sh->part[t - off] : 0;
-        __syncthreads();
-        sh->part[t] += v;
-        __syncthreads();
+    int incl = s;
+    const int lane = t & 63;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    int run = sh->part[t] - s;
-    const int total = sh->part[WG_NT - 1];
+    if (lane == 63) sh->part[t >> 6] = incl;
+    __syncthreads();
+    int wave_prefix = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < WG_NT / 64; w++) {
+        const int v = sh->part[w];
+        if (w < (t >> 6)) wave_prefix += v;
+        total += v;
+    }
+    int run = wave_prefix + incl - s;
     for (int i = lo; i < hi; i++) { const int v = a[i]; a[i] = run; run += v; }
     __syncthreads();
     return total;

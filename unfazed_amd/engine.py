@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunfazed_hip.so")
+LIB_PATH = os.environ.get("UZ_HIP_LIB", os.path.join(_HERE, "libunfazed_hip.so"))
 
 K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE = 0, 1, 2, 3, 4
 
