@@ -259,6 +259,17 @@ static int goodread(rctx *X, int32_t i) {
     return ok;
 }
 
+/* goodread(read, discordant=True): read_collector.py:28-42 (flag / mapq / mate checks only) */
+static int goodread_disc(rctx *X, int32_t i) {
+    const uz_reads_view *R = X->R;
+    uint16_t f = R->flag[i];
+    if (R->aux[i] & UZ_AUX_DECODE_BAD) return 0;
+    if ((f & 512) || (f & 4) || (f & 1024) || (int)R->mapq[i] < X->P->min_map_qual || (f & 256) || (f & 2048) ||
+        (f & 8) || !(R->aux[i] & UZ_AUX_MATE_SAME_TID))
+        return 0;
+    return 1;
+}
+
 /* index of `pos` in get_reference_positions(full_length=True), -1 if absent */
 static int qidx(const uz_reads_view *R, int32_t i, int64_t pos) {
     const uint32_t *c = R->cigar + R->cigar_off[i];
@@ -356,6 +367,106 @@ static int bsearch_sites(int64_t start, int64_t end, const int32_t *pos, int n, 
         else if (pos[qp] < start) qs = qp + 1;
     }
     return nm;
+}
+
+/* collect_reads_sv: read_collector.py:476-596, up to the hand-off to group_reads_by_haplotype.
+ * Appends the supporting segments (in order) to `alt`. */
+static void collect_sv(rctx *X, const uz_params *P, int32_t tid, int64_t start, int64_t end, double cutoff, ivec *alt) {
+    const uz_reads_view *R = X->R;
+    ivec supporting = {0}, banned = {0};
+    const double var_len = fabs((double)end - (double)start); /* :477 */
+    const int64_t icut = (int64_t)cutoff;
+    const int64_t bp[2] = {start, end};
+    for (int w = 0; w < 2; w++) { /* :478 */
+        const int64_t position = bp[w];
+        int64_t lo = position - icut, hi = position + icut; /* :481-485 */
+        if (lo < 0) lo = 0;
+        banned.n = 0; /* :498 a fresh list per breakpoint */
+        int64_t a, b;
+        fetch_range(R, tid, lo, hi, &a, &b);
+        for (int64_t i = a; i < b; i++) {
+            if (!(R->end[i] > lo)) continue;
+            const int32_t read = (int32_t)i;
+            const int32_t q = (int32_t)R->qname[read];
+            int is_banned = 0;
+            for (int64_t k = 0; k < banned.n; k++) if (banned.v[k] == q) { is_banned = 1; break; }
+            if (is_banned) continue;                 /* :501-502 */
+            if (!goodread_disc(X, read)) continue;   /* :503-504 */
+            const int32_t mate = R->mate[read];      /* :507-510 */
+            if (mate < 0) continue;
+            const int64_t insert = llabs((int64_t)R->tlen[read] - 2 * (int64_t)P->readlen); /* :511 */
+            if (!goodread_disc(X, mate)) continue;   /* :512-513 */
+            /* :515-522 M/= among the first / last 10 entries of the per-base expansion of ALL ops */
+            const uint32_t *c = R->cigar + R->cigar_off[read];
+            const int nc = R->n_cigar[read];
+            int64_t total = 0;
+            for (int k = 0; k < nc; k++) total += (int64_t)(c[k] >> 4);
+            int start_m = 0, end_m = 0;
+            {
+                int64_t o = 0;
+                for (int k = 0; k < nc; k++) {
+                    const int op = c[k] & 15;
+                    const int64_t l = (int64_t)(c[k] >> 4);
+                    const int64_t s0 = o, s1 = o + l; /* entries [s0, s1) */
+                    if (op == OP_M || op == OP_EQ) {
+                        int64_t x1 = s1 < 10 ? s1 : 10;
+                        if (x1 > s0) start_m += (int)(x1 - s0);
+                        int64_t t0 = total - 10 > 0 ? total - 10 : 0;
+                        int64_t y0 = s0 > t0 ? s0 : t0;
+                        if (s1 > y0) end_m += (int)(s1 - y0);
+                    }
+                    o = s1;
+                }
+            }
+            if (end_m < 7 && start_m < 7) { iv_push(&banned, q); continue; } /* :520-522 */
+            const int64_t rs = R->start[read], re = R->end[read];
+            if (R->aux[read] & UZ_AUX_HAS_SA) { /* :524-533 split read clipped near the breakpoint */
+                const int64_t m = P->split_error_margin;
+                if ((position - m <= rs && rs <= position + m) || (position - m <= re && re <= position + m)) {
+                    iv_push(&supporting, read); iv_push(&supporting, mate);
+                }
+            } else if ((double)insert > cutoff && 0.7 < fabs(var_len / (double)insert) && fabs(var_len / (double)insert) < 1.3) { /* :534-536 */
+                const int32_t mate2 = R->mate[read]; /* :539-542 */
+                if (mate2 < 0) continue;
+                const int64_t ms = R->start[mate2];
+                const int64_t left0 = ms < rs ? ms : rs, right0 = ms > rs ? ms : rs; /* :543-550 */
+                const int64_t wig = (int64_t)cutoff;                                 /* :551 */
+                if (!((start - wig) < left0 && left0 < (start + wig) && (end - wig) < right0 && right0 < (end + wig))) continue;
+                iv_push(&supporting, mate2); iv_push(&supporting, read);             /* :562-563 */
+            } else { /* :564-586 clipped reads that are not split alignments */
+                int rp = qidx(R, read, position);
+                if (rp < 0) rp = qidx(R, read, position - 1);
+                if (rp < 0) rp = qidx(R, read, position + 1);
+                if (rp < 0) continue;
+                const int len = refpos_len(R, read);
+                if (rp < 2 || rp > len - 4) continue; /* :574-575 */
+                /* before = set(refpos[:rp-1]) == {None}: the first rp-1 query bases have no reference position */
+                int lead = 0, trail = 0;
+                for (int k = 0; k < nc; k++) {
+                    const int op = c[k] & 15;
+                    if (op == OP_S || op == OP_I) lead += (int)(c[k] >> 4);
+                    else if (op == OP_M || op == OP_EQ || op == OP_X) break;
+                }
+                for (int k = nc - 1; k >= 0; k--) {
+                    const int op = c[k] & 15;
+                    if (op == OP_S || op == OP_I) trail += (int)(c[k] >> 4);
+                    else if (op == OP_M || op == OP_EQ || op == OP_X) break;
+                }
+                if (lead >= rp - 1 || trail >= len - (rp + 1)) { iv_push(&supporting, mate); iv_push(&supporting, read); } /* :579-586 */
+            }
+        }
+    }
+    /* :588-596 -- `banned_reads` is the list of the LAST breakpoint only */
+    ivec filtered = {0};
+    for (int64_t k = 0; k < supporting.n; k++) {
+        const int32_t q = (int32_t)R->qname[supporting.v[k]];
+        int is_banned = 0;
+        for (int64_t j = 0; j < banned.n; j++) if (banned.v[j] == q) { is_banned = 1; break; }
+        if (!is_banned) iv_push(&filtered, supporting.v[k]);
+    }
+    if (filtered.n >= 2) /* :594-595 */
+        for (int64_t k = 0; k < filtered.n; k++) iv_push(alt, filtered.v[k]);
+    free(supporting.v); free(banned.v); free(filtered.v);
 }
 
 /* exported for the golden tests of binary_search */
@@ -485,10 +596,13 @@ int uzo_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *R
         ivec lists[2];
         memset(lists, 0, sizeof(lists)); /* [0] = "alt", [1] = "ref" (informative_reads, read_collector.py:393) */
 
+        const int is_sv = D->vartype[d] != UZ_VT_POINT; /* phase_svs -> collect_reads_sv (sv_phaser.py:111) */
+        if (is_sv) collect_sv(&X, P, tid, D->start[d], D->end[d], cutoff, &lists[0]);
         /* ---- collect_reads_snv :382-425 ---- */
         int64_t fa, fb;
         int64_t flo = (D->dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1; /* :385 / :392 */
         fetch_range(R, tid, flo, position + 1, &fa, &fb);
+        if (is_sv) fb = fa;
         for (int64_t i = fa; i < fb; i++) {
             if (!(R->end[i] > flo)) continue;
             int32_t read = (int32_t)i;

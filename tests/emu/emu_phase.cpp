@@ -33,15 +33,16 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     a.n = D->n;
     a.min_gt_qual = P->min_gt_qual; a.readlen = P->readlen; a.no_extended = P->no_extended;
     a.read_goal = P->read_goal; a.evidence_min_ratio = P->evidence_min_ratio; a.cutoff = D->cutoff;
+    a.split_error_margin = P->split_error_margin;
     a.spos = S->pos; a.sref = S->ref_base; a.salt = S->alt_base;
     a.cand_off = cand_off; a.het_off = het_off; a.cand_idx = cand_idx; a.het_idx = het_idx; a.cand_flags = cand_flags;
-    a.rcontig = D->rcontig; a.dstart = D->start; a.dflags = D->dflags; a.allele_off = D->allele_off; a.alleles = D->alleles;
+    a.rcontig = D->rcontig; a.dstart = D->start; a.dend = D->end; a.dflags = D->dflags; a.vartype = D->vartype; a.allele_off = D->allele_off; a.alleles = D->alleles;
     a.R = R;
     a.status = status; a.counts = counts; a.origin = origin; a.evidence = evidence;
     a.want_lists = 1; a.pool = pool; a.pool_cap = (unsigned long long)pool_cap;
     unsigned long long cursor = 0;
     a.pool_cursor = &cursor; a.list_start = list_start; a.list_len = list_len;
-    std::vector<int32_t> pre_win((size_t)2 * D->n + 2), pre_ha((size_t)het_off[D->n] + 2), pre_hl((size_t)het_off[D->n] + 2);
+    std::vector<int32_t> pre_win((size_t)4 * D->n + 4), pre_ha((size_t)het_off[D->n] + 2), pre_hl((size_t)het_off[D->n] + 2);
     a.pre_win = pre_win.data(); a.pre_ha = pre_ha.data(); a.pre_hl = pre_hl.data();
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 2;
     for (int d = 0; d < D->n; d++) {

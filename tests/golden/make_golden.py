@@ -290,6 +290,30 @@ def gen_cnv():
         json.dump(dict(digest=dataset_digest(ds), cases=cases), fh)
 
 
+SV_CASES = [
+    ("default", dict(seed=41, n_svs=8), dict()),
+    ("no_extended", dict(seed=42, n_svs=8), dict(no_extended=True)),
+    ("params", dict(seed=43, n_svs=8), dict(search_dist=2000, min_gt_qual=10, split_error_margin=0)),
+]
+
+
+def gen_sv():
+    """phase_svs end to end: allele-balance + read-backed SV evidence (collect_reads_sv) and their merge."""
+    from synth.small_sv import SvConfig, make_small_sv
+    cyvcf2, pysam, isf, rc, ss, sp, svp, uz = refrun._import()
+    for name, cfgkw, runkw in SV_CASES:
+        ds = make_small_sv(SvConfig(**cfgkw))
+        recs, dnms, err, cutoffs = refrun.run_phase_svs(ds, tag="sv_" + name, **runkw)
+        for d in dnms:
+            d["bam"] = "mem://%s.bam" % d["kid"]
+        summaries = {k: uz.summarize_record(copy.deepcopy(r), True, False, 10) for k, r in recs.items()}
+        out = dict(config=cfgkw, run=runkw, digest=dataset_digest(ds), record_order=list(recs.keys()),
+                   records=norm_records(recs), dnms=dnms, stderr=err.splitlines(), summaries=summaries)
+        with open(os.path.join(HERE, "sv_%s.json" % name), "w") as fh:
+            json.dump(out, fh, sort_keys=True)
+        print("sv", name, len(recs), "records", sum(1 for r in recs.values() if r["dad_reads"] or r["mom_reads"]), "read-backed")
+
+
 CLI_CFG = dict(seed=77, n_dnms=10, kids=["kidA", "kidB"], odd_read_prob=0.1)
 
 
@@ -363,6 +387,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["snv", "grid", "bsearch", "summarize", "cutoff", "cnv"]
     if "cnv" in which:
         gen_cnv()
+    if "sv" in which or not sys.argv[1:]:
+        gen_sv()
     if "cli" in which or not sys.argv[1:]:
         gen_cli()
     if "snv" in which:

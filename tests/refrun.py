@@ -90,3 +90,25 @@ def run_find(ds, tag="ds", whole_region=False, **kw):
             whole_region=whole_region,
         )
     return out, err.getvalue()
+
+
+def run_phase_svs(ds, tag="sv", **kw):
+    """-> (records, annotated dnm list, stderr text)"""
+    cyvcf2, pysam, isf, rc, ss, sp, svp, uz = _import()
+    a = dict(DEFAULTS)
+    a.update(kw)
+    vcf, bams = register(ds, tag)
+    dnms = copy.deepcopy(ds.dnms)
+    for d in dnms:
+        d["bam"] = bams[d["kid"]]
+    svp.concordant_upper_lens.clear()
+    err = io.StringIO()
+    with warnings.catch_warnings(), contextlib.redirect_stderr(err):
+        warnings.simplefilter("ignore")
+        recs = svp.phase_svs(
+            dnms, list(ds.pedigrees), ds.pedigrees, vcf, a["threads"], a["build"], a["no_extended"],
+            a["multithread_proc_min"], a["quiet_mode"], a["ab_homref"], a["ab_homalt"], a["ab_het"],
+            a["min_gt_qual"], a["min_depth"], a["search_dist"], a["insert_size_max_sample"], a["stdevs"],
+            a["min_map_qual"], a["readlen"], a["split_error_margin"],
+        )
+    return recs, dnms, err.getvalue(), dict(svp.concordant_upper_lens)

@@ -56,3 +56,33 @@ def test_kernel_body_matches_oracle(ci):
                     assert np.array_equal(gq[go[2 * d + j]: go[2 * d + j + 1]], got["lists"][d][4 + j])
         n_ok += int((want["status"] == abi.ST_OK).sum())
     assert n_ok >= 1
+
+
+def test_kernel_body_matches_oracle_sv():
+    """SV read-backed path: collect_reads_sv around both breakpoints, then the shared chaining / vote."""
+    from synth.small_sv import SvConfig, make_small_sv
+    from unfazed_amd.hostpath import vartype_code
+    ds = make_small_sv(SvConfig(seed=91, n_svs=8))
+    sites = SitesTable.from_records(ds.sites, ds.samples)
+    P = abi.make_params()
+    sv = abi.sites_view(sites)
+    kid = "kid1"
+    rt = ReadsTable.from_segments(ds.reads[kid], ds.contigs)
+    ped = ds.pedigrees[kid]
+    fv = abi.family_view(*sites.family_columns(kid, ped["dad"], ped["mom"]))
+    rv = abi.reads_view(rt)
+    dn = ds.dnms
+    n = len(dn)
+    dv = abi.dnms_view([sites.contig_index[d["chrom"]] for d in dn], [rt.contig_index[d["chrom"]] for d in dn],
+                       [d["start"] for d in dn], [d["end"] for d in dn], [vartype_code(d["vartype"]) for d in dn],
+                       [b""] * n, [b""] * n, concordant_cutoff(rt.tlen, P.readlen, 3))
+    found = orc.find(P, sv, fv, dv, abi.FIND_SECOND_WINDOW)
+    want = orc.phase(P, sv, rv, dv, found, keep_lists=True)
+    got = emu.phase(P, sv, rv, dv, found)
+    for k in ("status", "counts", "origin", "evidence"):
+        assert np.array_equal(want[k], got[k]), k
+    vo, vv = want["vote_off"], want["vote_val"]
+    for d in range(n):
+        for j in range(4):
+            assert np.array_equal(vv[vo[4 * d + j]: vo[4 * d + j + 1]], got["lists"][d][j])
+    assert int((want["status"] == abi.ST_OK).sum()) >= 2

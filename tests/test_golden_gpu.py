@@ -18,3 +18,11 @@ def test_phase_snvs_golden_gpu(engine, path):
 
 def test_cnv_allele_balance_golden_gpu(engine):
     check_cnv_golden(engine)
+
+
+from test_oracle_golden import SV, check_sv_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("path", SV, ids=[os.path.basename(p)[3:-5] for p in SV])
+def test_phase_svs_golden_gpu(engine, path):
+    check_sv_golden(engine, path)

@@ -125,3 +125,52 @@ def check_cnv_golden(backend):
 
 def test_cnv_allele_balance_golden():
     check_cnv_golden(OracleBackend())
+
+
+SV = sorted(glob.glob(os.path.join(GOLD, "sv_*.json")))
+
+
+def check_sv_golden(backend, path):
+    import contextlib
+    import copy
+    import io
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import dataset_digest
+    from helpers import RUN_DEFAULTS
+    from synth.small_sv import SvConfig, make_small_sv
+    from unfazed_amd import session
+    from unfazed_amd.sv_phaser import phase_svs
+    g = json.load(open(path))
+    ds = make_small_sv(SvConfig(**g["config"]))
+    assert dataset_digest(ds) == g["digest"]
+    sites, reads = tables(ds)
+    session.set_backend(backend)
+    try:
+        session.register_sites("mem://svsites", sites)
+        for k, t in reads.items():
+            session.register_reads(k, t)
+        a = dict(RUN_DEFAULTS)
+        a.update(g["run"])
+        dn = copy.deepcopy(ds.dnms)
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            recs = phase_svs(dn, list(ds.pedigrees), ds.pedigrees, "mem://svsites", a["threads"], a["build"],
+                             a["no_extended"], a["multithread_proc_min"], a["quiet_mode"], a["ab_homref"], a["ab_homalt"],
+                             a["ab_het"], a["min_gt_qual"], a["min_depth"], a["search_dist"], a["insert_size_max_sample"],
+                             a["stdevs"], a["min_map_qual"], a["readlen"], a["split_error_margin"])
+    finally:
+        session.set_backend(None)
+    assert list(recs.keys()) == g["record_order"]
+    assert json.loads(json.dumps(norm_records(recs))) == g["records"]
+    assert err.getvalue().splitlines() == g["stderr"]
+    for d, r in zip(dn, g["dnms"]):
+        assert d.get("candidate_sites") == r.get("candidate_sites")
+        assert d.get("het_sites") == r.get("het_sites")
+    for k, r in recs.items():
+        assert summarize.summarize_record(r, True, False, 10) == g["summaries"][k]
+
+
+@pytest.mark.parametrize("path", SV, ids=[os.path.basename(p)[3:-5] for p in SV])
+def test_phase_svs_golden(path):
+    check_sv_golden(OracleBackend(), path)

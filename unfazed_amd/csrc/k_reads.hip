@@ -156,18 +156,18 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     memset(&a, 0, sizeof(a));
     a.n = n;
     a.min_gt_qual = c->P.min_gt_qual; a.readlen = c->P.readlen; a.no_extended = c->P.no_extended;
-    a.read_goal = c->P.read_goal; a.evidence_min_ratio = c->P.evidence_min_ratio;
+    a.read_goal = c->P.read_goal; a.evidence_min_ratio = c->P.evidence_min_ratio; a.split_error_margin = c->P.split_error_margin;
     a.cutoff = c->dn.cutoff;
     a.spos = s.pos; a.sref = s.ref_base; a.salt = s.alt_base;
     a.cand_off = c->cand_off.p; a.het_off = c->het_off.p;
     a.cand_idx = c->cand_idx.p; a.het_idx = c->het_idx.p; a.cand_flags = c->cand_flags.p;
-    a.rcontig = c->dn.rcontig.p; a.dstart = c->dn.start.p; a.dflags = c->dn.dflags.p;
+    a.rcontig = c->dn.rcontig.p; a.dstart = c->dn.start.p; a.dend = c->dn.end.p; a.dflags = c->dn.dflags.p; a.vartype = c->dn.vartype.p;
     a.allele_off = c->dn.allele_off.p; a.alleles = c->dn.alleles.p;
     a.R = make_rd(r);
 
     // sizing pass -> scratch capacities (max over the batch)
     st->bounds.ensure((size_t)5 * n);
-    st->pre_win.ensure((size_t)2 * n); st->pre_ha.ensure((size_t)c->n_het + 1); st->pre_hl.ensure((size_t)c->n_het + 1);
+    st->pre_win.ensure((size_t)4 * n); st->pre_ha.ensure((size_t)c->n_het + 1); st->pre_hl.ensure((size_t)c->n_het + 1);
     a.pre_win = st->pre_win.p; a.pre_ha = st->pre_ha.p; a.pre_hl = st->pre_hl.p;
     {
         const unsigned nb = (unsigned)((n + 255) / 256);

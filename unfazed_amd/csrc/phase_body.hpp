@@ -162,7 +162,7 @@ UZ_DEV void ar_reset(Arena &ar) { ar.tmp = ar.pers; }
 
 struct PhaseArgs {
     int32_t n;
-    int32_t min_gt_qual, readlen, no_extended, read_goal, evidence_min_ratio;
+    int32_t min_gt_qual, readlen, no_extended, read_goal, evidence_min_ratio, split_error_margin;
     double cutoff;
     // sites + window lists
     const int32_t *spos;
@@ -171,8 +171,8 @@ struct PhaseArgs {
     const int32_t *cand_idx, *het_idx;
     const uint8_t *cand_flags;
     // DNMs
-    const int32_t *rcontig, *dstart;
-    const uint8_t *dflags;
+    const int32_t *rcontig, *dstart, *dend;
+    const uint8_t *dflags, *vartype;
     const uint32_t *allele_off;
     const uint8_t *alleles;
     RD R;
@@ -193,7 +193,7 @@ struct PhaseArgs {
     int32_t lds_arena_bytes;
     // fetch ranges found by the sizing pass (one lane per DNM, all DNMs in flight at once, so the
     // binary searches overlap instead of serialising inside the per-DNM workgroup)
-    int32_t *pre_win; // [2n]   first / one-past-last record of the DNM fetch
+    int32_t *pre_win; // [4n]   first / one-past-last record of the DNM fetch (SVs: of both breakpoint fetches)
     int32_t *pre_ha;  // [n_het] first record of every het-site fetch range
     int32_t *pre_hl;  // [n_het] its length
     unsigned long long *timing; // diagnostic builds only
@@ -381,6 +381,76 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long l
     return 0;
 }
 
+// collect_reads_sv (:499-586) for one record fetched around a breakpoint `position`:
+// 0 nothing, 1 supporting [read, mate] (split read), 2 supporting [mate, read] (discordant pair or
+// clipped read), 3 the record bans its query name (:520-522)
+UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long position, long long lo, long long sv_start,
+                          long long sv_end) {
+    if (!((long long)R.end[i] > lo)) return 0;
+    if (!(R.qc[i] & UZ_QC_GOOD_DISC)) return 0;  // goodread(read, True) :503
+    const int mate = R.mate[i];                  // :507-510
+    if (mate < 0) return 0;
+    if (!(R.qc[mate] & UZ_QC_GOOD_DISC)) return 0; // :512
+    const uint32_t *c = R.cigar + R.cigar_off[i];
+    const int nc = R.n_cigar[i];
+    long long total = 0;
+    for (int k = 0; k < nc; k++) total += (long long)(c[k] >> 4);
+    int start_m = 0, end_m = 0, lead = 0, trail = 0;
+    {
+        long long o = 0;
+        const long long t0 = total - 10 > 0 ? total - 10 : 0;
+        bool in_lead = true;
+        for (int k = 0; k < nc; k++) { // M/= among the first / last 10 entries of the per-base expansion of all ops :515-519
+            const int op = c[k] & 15;
+            const long long l = (long long)(c[k] >> 4), s0 = o, s1 = o + l;
+            if (op == UZ_OP_M || op == UZ_OP_EQ) {
+                const long long x1 = s1 < 10 ? s1 : 10;
+                if (x1 > s0) start_m += (int)(x1 - s0);
+                const long long y0 = s0 > t0 ? s0 : t0;
+                if (s1 > y0) end_m += (int)(s1 - y0);
+            }
+            if (in_lead) {
+                if (op == UZ_OP_S || op == UZ_OP_I) lead += (int)l;
+                else if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X) in_lead = false;
+            }
+            o = s1;
+        }
+        for (int k = nc - 1; k >= 0; k--) {
+            const int op = c[k] & 15;
+            if (op == UZ_OP_S || op == UZ_OP_I) trail += (int)(c[k] >> 4);
+            else if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X) break;
+        }
+    }
+    if (end_m < 7 && start_m < 7) return 3;
+    const long long rs = R.start[i], re = R.end[i];
+    if (R.aux[i] & UZ_AUX_HAS_SA) { // :524-533
+        const long long m = a.split_error_margin;
+        return ((position - m <= rs && rs <= position + m) || (position - m <= re && re <= position + m)) ? 1 : 0;
+    }
+    long long ins = (long long)R.tlen[i] - 2LL * a.readlen;
+    if (ins < 0) ins = -ins;
+    const double var_len = (double)sv_end - (double)sv_start < 0 ? (double)sv_start - (double)sv_end : (double)sv_end - (double)sv_start;
+    bool disc = (double)ins > a.cutoff;
+    if (disc) {
+        double ratio = var_len / (double)ins;
+        if (ratio < 0) ratio = -ratio;
+        disc = 0.7 < ratio && ratio < 1.3; // :534-536
+    }
+    if (disc) {
+        const long long ms = R.start[mate];
+        const long long left0 = ms < rs ? ms : rs, right0 = ms > rs ? ms : rs;
+        const long long wig = (long long)a.cutoff; // :551
+        return ((sv_start - wig) < left0 && left0 < (sv_start + wig) && (sv_end - wig) < right0 && right0 < (sv_end + wig)) ? 2 : 0;
+    }
+    int rp = uz_qidx(R, i, position); // :565-573
+    if (rp < 0) rp = uz_qidx(R, i, position - 1);
+    if (rp < 0) rp = uz_qidx(R, i, position + 1);
+    if (rp < 0) return 0;
+    const int len = uz_refpos_len(R, i);
+    if (rp < 2 || rp > len - 4) return 0;
+    return (lead >= rp - 1 || trail >= len - (rp + 1)) ? 2 : 0; // :576-586
+}
+
 // ------------------------------------------------------------------ one DNM
 UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_t *lds_arena, int d) {
     const RD &R = a.R;
@@ -416,8 +486,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     WG_FOR(k, nh) s.hpos[k] = a.spos[a.het_idx[h0 + k]];
 
     // ---- A: DNM reads -> ordered "ref" / "alt" lists (each hit contributes read, mate)
-    const long long fa = a.pre_win[2 * d], fb = a.pre_win[2 * d + 1];
-    const int nA = (int)(fb - fa);
+    const bool is_sv = a.vartype[d] != UZ_VT_POINT;
+    const long long fa = a.pre_win[4 * d], fb = a.pre_win[4 * d + 1];
+    const long long fa2 = a.pre_win[4 * d + 2], fb2 = a.pre_win[4 * d + 3];
+    const int n0 = (int)(fb - fa);
+    const int nA = n0 + (int)(fb2 - fa2);
     if (nA > a.caps.A) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
     {
         const size_t ni = 2 * (size_t)nA + 2; // at most two list elements per fetched record
@@ -426,30 +499,103 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         ar_t(ar, s.a_cls, nA + 1); ar_t(ar, s.a_flag[0], nA + 1); ar_t(ar, s.a_flag[1], nA + 1);
         ar_t(ar, s.LR, ni); ar_t(ar, s.LA, ni);
     }
-    WG_FOR(i, nA) {
-        const int cl = uz_classify_dnm_read(R, a, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
-        s.a_cls[i] = (uint8_t)cl;
-        s.a_flag[0][i] = cl == 1;
-        s.a_flag[1][i] = cl == 2;
-    }
-    WG_SYNC();
-    const int n_ref = wg_exscan(s.a_flag[0], nA, sh);
-    const int n_alt = wg_exscan(s.a_flag[1], nA, sh);
-    WG_FOR(i, nA) {
-        const int cl = s.a_cls[i];
-        if (cl) {
-            int32_t *L = cl == 1 ? s.LR : s.LA;
-            const int k = s.a_flag[cl - 1][i];
-            L[2 * k] = (int)(fa + i);
-            L[2 * k + 1] = R.mate[fa + i];
+    int nre = 0, nae = 0; // elements of the "ref" / "alt" lists
+    if (!is_sv) {
+        WG_FOR(i, nA) {
+            const int cl = uz_classify_dnm_read(R, a, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
+            s.a_cls[i] = (uint8_t)cl;
+            s.a_flag[0][i] = cl == 1;
+            s.a_flag[1][i] = cl == 2;
         }
+        WG_SYNC();
+        const int n_ref = wg_exscan(s.a_flag[0], nA, sh);
+        const int n_alt = wg_exscan(s.a_flag[1], nA, sh);
+        WG_FOR(i, nA) {
+            const int cl = s.a_cls[i];
+            if (cl) {
+                int32_t *L = cl == 1 ? s.LR : s.LA;
+                const int k = s.a_flag[cl - 1][i];
+                L[2 * k] = (int)(fa + i);
+                L[2 * k + 1] = R.mate[fa + i];
+            }
+        }
+        WG_SYNC();
+        nre = 2 * n_ref; nae = 2 * n_alt;
+    } else {
+        // ---- A (SV): collect_reads_sv :476-596 around both breakpoints -> "alt" list only
+        const long long sv_start = a.dstart[d], sv_end = a.dend[d];
+        const long long icut = (long long)a.cutoff;
+        WG_FOR(t, nA) {
+            const bool w1 = t >= n0;
+            const int i = (int)(w1 ? fa2 + (t - n0) : fa + t);
+            const long long bp = w1 ? sv_end : sv_start;
+            long long lo = bp - icut;
+            if (lo < 0) lo = 0;
+            const int code = uz_sv_classify(R, a, i, bp, lo, sv_start, sv_end);
+            s.a_cls[t] = (uint8_t)code;
+            s.a_flag[0][t] = code == 3;
+        }
+        WG_SYNC();
+        const int nban = wg_exscan(s.a_flag[0], nA, sh);
+        WG_FOR(t, nA) { // the banned names, in fetch order: (item, name)
+            if (s.a_cls[t] == 3) {
+                const int k = s.a_flag[0][t];
+                const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
+                s.i_qp[k] = t;
+                s.i_L[k] = (int32_t)R.qname[i];
+            }
+        }
+        WG_SYNC();
+        WG_FOR(t, nA) { // a record is skipped once an EARLIER record of the same breakpoint banned its name (:501-502)
+            int code = s.a_cls[t];
+            if (code == 1 || code == 2) {
+                const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
+                const int32_t q = (int32_t)R.qname[i];
+                for (int k = 0; k < nban; k++) {
+                    const int tb = s.i_qp[k];
+                    if (tb < t && ((tb >= n0) == (t >= n0)) && s.i_L[k] == q) { code = 0; break; }
+                }
+            } else code = 0;
+            s.a_cls[t] = (uint8_t)code;
+            s.a_flag[1][t] = code ? 2 : 0;
+        }
+        WG_SYNC();
+        const int nsup = wg_exscan(s.a_flag[1], nA, sh);
+        WG_FOR(t, nA) {
+            const int code = s.a_cls[t];
+            if (code) {
+                const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
+                const int k = s.a_flag[1][t];
+                const int m = R.mate[i];
+                s.LR[k] = code == 1 ? i : m;      // :532-533
+                s.LR[k + 1] = code == 1 ? m : i;  // :562-563, :585-586
+            }
+        }
+        WG_SYNC();
+        WG_FOR(k, nsup) { // :588-591 filter by the names banned at the LAST breakpoint only
+            const int32_t q = (int32_t)R.qname[s.LR[k]];
+            int keep = 1;
+            for (int j = 0; j < nban; j++)
+                if (s.i_qp[j] >= n0 && s.i_L[j] == q) { keep = 0; break; }
+            s.i_R[k] = keep;
+        }
+        WG_SYNC();
+        const int nfil = wg_exscan(s.i_R, nsup, sh);
+        if (nfil >= 2) { // :594-595
+            WG_FOR(k, nsup) {
+                const bool last = k + 1 == nsup;
+                const int nxt = last ? nfil : s.i_R[k + 1];
+                if (nxt > s.i_R[k]) s.LA[s.i_R[k]] = s.LR[k];
+            }
+            nae = nfil;
+        }
+        WG_SYNC();
     }
-    WG_SYNC();
     // init elements in seeding order: "ref" list then "alt" list (:226)
-    const int nI = 2 * (n_ref + n_alt);
+    const int nI = nre + nae;
     WG_FOR(m, nI) {
-        const bool is_ref = m < 2 * n_ref;
-        s.i_seg[m] = is_ref ? s.LR[m] : s.LA[m - 2 * n_ref];
+        const bool is_ref = m < nre;
+        s.i_seg[m] = is_ref ? s.LR[m] : s.LA[m - nre];
         s.i_hb[m] = is_ref ? 0 : 1;
     }
     WG_SYNC();
@@ -704,8 +850,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             ar_t(ar, s.o_flag, P + 2);
         }
         WG_FOR(e, nI) {
-            const int na = 2 * n_alt;
-            const int m = e < na ? (2 * n_ref + e) : (e - na);
+            const int na = nae;
+            const int m = e < na ? (nre + e) : (e - na);
             s.fr_pair[0][e] = s.i_pair[m];
             s.fr_pos[0][e] = -1;
             s.fr_hap[0][e] = s.i_hb[m];
@@ -923,7 +1069,7 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
     const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - h0);
     b[0] = b[1] = b[4] = 0;
     b[2] = nh; b[3] = nc;
-    a.pre_win[2 * d] = a.pre_win[2 * d + 1] = 0;
+    for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
     if (nc <= 0) return;
     const int tid = a.rcontig[d];
     const long long position = a.dstart[d];
@@ -931,8 +1077,19 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
     long long wa, wb, fa, fb;
     uz_dnm_window(a, d, wa, wb);
     uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
-    b[0] = (int32_t)(fb - fa);
-    a.pre_win[2 * d] = (int32_t)fa; a.pre_win[2 * d + 1] = (int32_t)fb;
+    long long fa2 = 0, fb2 = 0;
+    if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
+        const long long icut = (long long)a.cutoff;
+        long long lo = (long long)a.dstart[d] - icut;
+        if (lo < 0) lo = 0;
+        uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);
+        lo = (long long)a.dend[d] - icut;
+        if (lo < 0) lo = 0;
+        uz_fetch_range(R, tid, lo, (long long)a.dend[d] + icut, fa2, fb2);
+    }
+    b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
+    a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
+    a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
     if (a.no_extended) return;
     long long T = 0;
     const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;

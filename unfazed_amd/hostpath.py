@@ -350,8 +350,11 @@ class PhasingHost:
         stdevs,
         readlen,
         want_lists=True,
+        sv=False,
     ):
-        """reference snv_phaser.py:206-299 (+ multithread_read_phasing :87-203)."""
+        """reference snv_phaser.py:206-299 (+ multithread_read_phasing :87-203); with sv=True the
+        SV variant sv_phaser.py:176-266 (+ :88-173): no REF/ALT lookup, reads collected by
+        collect_reads_sv, and autophase that does not short-circuit (quirk Q18)."""
         log = _Log(quiet_mode)
         params.no_extended = 1 if no_extended else 0
         params.read_goal = int(insert_size_max_sample)
@@ -374,7 +377,9 @@ class PhasingHost:
             dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
             if autophaseable(dn, pedigrees, build):  # snv_phaser.py:251, :302-352
                 plan.append((i, "auto"))
-                continue
+                if not sv:
+                    continue
+                # sv_phaser.autophase writes the record but returns None (sv_phaser.py:353-354): fall through
             f = found.get(i)
             if f is None or len(f["cand_idx"]) == 0:  # :254-262
                 plan.append((i, "nocand"))
@@ -382,13 +387,16 @@ class PhasingHost:
             if dn["kid"] not in sample_set:  # :109-110
                 plan.append((i, "silent"))
                 continue
-            ref, alts = self.get_refalt(dn["chrom"], dn["start"])  # :111-116
-            if len(alts) < 1:
-                plan.append((i, "nogt"))
-                continue
-            if len(alts) > 1:
-                plan.append((i, "manygt"))
-                continue
+            if sv:
+                ref, alts = "", [""]
+            else:
+                ref, alts = self.get_refalt(dn["chrom"], dn["start"])  # :111-116
+                if len(alts) < 1:
+                    plan.append((i, "nogt"))
+                    continue
+                if len(alts) > 1:
+                    plan.append((i, "manygt"))
+                    continue
             rt = self.reads_by_bam[dn["bam"]]
             tid, fl = self.resolve_reads_contig(rt, dn["chrom"])
             if tid < 0:
@@ -438,7 +446,11 @@ class PhasingHost:
                     "dad_reads": [], "mom_reads": [],
                 }
             elif action == "nocand":
-                log("No usable informative sites for variant {}:{}-{}".format(dn["chrom"], dn["start"], dn["end"]))
+                if sv:  # sv_phaser.py:227-229
+                    log("No usable informative sites for read-based phasing of variant {}:{}-{}".format(
+                        dn["chrom"], dn["start"], dn["end"]))
+                else:
+                    log("No usable informative sites for variant {}:{}-{}".format(dn["chrom"], dn["start"], dn["end"]))
             elif action == "nogt":
                 log("No usable genotype for variant {chrom}:{start}-{end}".format(**region))
             elif action == "manygt":

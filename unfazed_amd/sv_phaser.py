@@ -1,11 +1,7 @@
-"""phase_svs -- same call surface as reference unfazed/sv_phaser.py:427-493.
-
-Allele-balance phasing of DEL / DUP (run_cnv_phasing, :357-423) runs on the device
-(K1 CNV class codes + K2 whole-region window emit).  The read-backed half for SVs
-(run_read_phasing -> collect_reads_sv, read_collector.py:435-602: split / discordant /
-clipped read evidence) is the first "next" row of SURVEY.md 8(f) and is NOT built yet:
-requesting it raises instead of silently returning allele-balance evidence only, unless the
-caller opts in with `allele_balance_only=True`."""
+"""phase_svs -- same call surface as reference unfazed/sv_phaser.py:427-493: allele-balance
+phasing of DEL / DUP (run_cnv_phasing, :357-423) merged with read-backed phasing of the SV
+breakpoints (run_read_phasing, :176-266 -> collect_reads_sv, read_collector.py:435-602: split,
+discordant and clipped read evidence), both through the C ABI."""
 from __future__ import annotations
 
 from . import abi, session
@@ -24,9 +20,17 @@ def phase_svs(
         ab_homref=ab_homref, ab_homalt=ab_homalt, ab_het=ab_het,
     )
     cnv_records = host.run_cnv_phasing(dnms, pedigrees, threads, build, multiread_proc_min, quiet_mode, params)
-    if not allele_balance_only:
-        raise NotImplementedError(
-            "read-backed SV phasing (collect_reads_sv) is not built yet; pass allele_balance_only=True "
-            "to get the allele-balance records of DEL/DUP events only"
-        )
-    return cnv_records
+    if allele_balance_only:
+        return cnv_records
+    read_records = host.run_read_phasing(
+        dnms, pedigrees, threads, build, no_extended, multiread_proc_min, quiet_mode, params,
+        search_dist, insert_size_max_sample, stdevs, readlen, sv=True,
+    )
+    for key in cnv_records:  # sv_phaser.py:484-492
+        if key not in read_records:
+            read_records[key] = cnv_records[key]
+        else:
+            read_records[key]["cnv_dad_sites"] = cnv_records[key]["cnv_dad_sites"]
+            read_records[key]["cnv_mom_sites"] = cnv_records[key]["cnv_mom_sites"]
+            read_records[key]["evidence_type"] += "," + cnv_records[key]["cnv_evidence_type"]
+    return read_records
