@@ -22,7 +22,8 @@ extern "C" {
 #define UZ_GT_UNKNOWN 2
 #define UZ_HOM_ALT 3
 
-#define UZ_U16_MISSING 0xFFFFu /* cyvcf2's -1 (missing depth / GQ) in the 16-bit columns */
+#define UZ_U16_MISSING 0xFFFFu /* cyvcf2's -1 (missing depth / GQ) in the 16-bit columns, which hold 0..32767
+                                * otherwise (the kernels read them as signed halfwords) */
 
 /* site flags */
 #define UZ_SF_COMPLEX 1u /* reference informative_site_finder.py:239-243 */

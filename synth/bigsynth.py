@@ -17,9 +17,15 @@ READLEN, ROW, MAXOPS = 151, 160, 3
 
 def _build(target, cmd):
     deps = [os.path.join(_HERE, "uzsynth.h")] + [c for c in cmd if c.endswith((".c", ".hip"))]
-    if not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(cmd + ["-o", target + ".tmp"])
-        os.replace(target + ".tmp", target)
+    def stale():
+        return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(d) for d in deps)
+    if stale():
+        import fcntl
+        with open(target + ".lock", "w") as lock:  # ranks of one node may build at once
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                subprocess.check_call(cmd + ["-o", target + ".tmp"])
+                os.replace(target + ".tmp", target)
     return target
 
 

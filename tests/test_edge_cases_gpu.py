@@ -1,0 +1,109 @@
+"""Edge cases of the C ABI on the device: empty batches and tables, DNMs on contigs that the
+sites file or the BAM do not have, windows clipped at a contig start, DNMs without any read, call
+order errors.  Everything is compared with the oracle where there is something to compare."""
+import numpy as np
+import pytest
+
+from helpers import tables
+from oracle import oracle as orc
+from synth.small import SmallConfig, make_small
+from unfazed_amd import abi
+from unfazed_amd.engine import UnfazedHipError
+from unfazed_amd.hostpath import concordant_cutoff
+from unfazed_amd.model import ReadsTable, SitesTable
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    ds = make_small(SmallConfig(seed=321, n_dnms=6))
+    sites, reads = tables(ds)
+    return ds, sites, list(reads.values())[0]
+
+
+def _dv(sites, rt, dn, contig=None, rcontig=None, start=None):
+    refs, alts = [], []
+    for d in dn:
+        j = int(sites.query(d["chrom"], d["start"], d["start"] + 1)[-1])
+        refs.append(sites.ref_str[j].encode())
+        alts.append(sites.alt_strs[j][0].encode())
+    n = len(dn)
+    return abi.dnms_view(
+        contig if contig is not None else [sites.contig_index[d["chrom"]] for d in dn],
+        rcontig if rcontig is not None else [rt.contig_index[d["chrom"]] for d in dn],
+        start if start is not None else [d["start"] for d in dn], [d["end"] for d in dn], [0] * n, refs, alts,
+        concordant_cutoff(rt.tlen, 151, 3))
+
+
+def _compare(engine, P, sites, rt, dv, fid, rid):
+    sv, rv = abi.sites_view(sites), abi.reads_view(rt)
+    fam = None
+    got = engine.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+    return got
+
+
+def test_empty_and_missing_inputs(engine, small):
+    ds, sites, rt = small
+    P = abi.make_params()
+    kid = ds.dnms[0]["kid"]
+    ped = ds.pedigrees[kid]
+    cols = sites.family_columns(kid, ped["dad"], ped["mom"])
+    sid = engine.upload_sites(sites)
+    fid = engine.add_family(sid, *cols)
+    rid = engine.upload_reads(rt)
+    sv, fv, rv = abi.sites_view(sites), abi.family_view(*cols), abi.reads_view(rt)
+    dn = ds.dnms
+
+    # 1. empty DNM batch
+    dv0 = _dv(sites, rt, [])
+    r = engine.phase_raw(fid, rid, dv0, P, abi.FIND_SECOND_WINDOW)
+    assert r["status"].shape == (0,)
+    co, ci, cf, ho, hi = engine.find(fid, dv0, P, abi.FIND_SECOND_WINDOW)
+    assert co.tolist() == [0] and ho.tolist() == [0]
+
+    # 2. contig missing from the sites file / from the BAM, window clipped at the contig start
+    n = len(dn)
+    contig = [sites.contig_index[d["chrom"]] for d in dn]
+    rcontig = [rt.contig_index[d["chrom"]] for d in dn]
+    start = [d["start"] for d in dn]
+    contig[0] = -1
+    rcontig[1] = -1
+    dv = _dv(sites, rt, dn, contig=contig, rcontig=rcontig, start=start)
+    found = orc.find(P, sv, fv, dv, abi.FIND_SECOND_WINDOW)
+    want = orc.phase(P, sv, rv, dv, found, keep_lists=False)
+    got = engine.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+    for k in ("status", "counts", "origin", "evidence"):
+        assert np.array_equal(want[k], got[k]), k
+    assert got["status"][0] == abi.ST_NO_CAND
+
+    # 3. a reads table without any record
+    empty = ReadsTable.from_segments([], ds.contigs)
+    rid0 = engine.upload_reads(empty)
+    dvn = _dv(sites, rt, dn)
+    got = engine.phase_raw(fid, rid0, dvn, P, abi.FIND_SECOND_WINDOW)
+    found = orc.find(P, sv, fv, dvn, abi.FIND_SECOND_WINDOW)
+    want = orc.phase(P, sv, abi.reads_view(empty), dvn, found, keep_lists=False)
+    assert np.array_equal(want["status"], got["status"])
+    assert not (got["status"] == abi.ST_OK).any()
+    engine.free_reads(rid0)
+
+    # 4. a sites table without any record
+    s0 = SitesTable.from_records([], ds.samples)
+    sid0 = engine.upload_sites(s0)
+    z = np.zeros((3, 0), np.uint16)
+    fid0 = engine.add_family(sid0, np.zeros(0, np.uint8), z, z, z)
+    dvz = abi.dnms_view([-1] * n, rcontig, start, [d["end"] for d in dn], [0] * n, [b"A"] * n, [b"C"] * n, 800.0)
+    got = engine.phase_raw(fid0, rid, dvz, P, abi.FIND_SECOND_WINDOW)
+    assert (got["status"] == abi.ST_NO_CAND).all()
+    engine.free_sites(sid0)
+
+    # 5. call-order and handle errors are loud
+    with pytest.raises(UnfazedHipError):
+        engine.phase_raw(fid, 12345, dvn, P, abi.FIND_SECOND_WINDOW)
+    with pytest.raises(UnfazedHipError):
+        engine.classify(999, P, 1)
+    engine.free_reads(rid)
+    engine.free_sites(sid)
+    with pytest.raises(UnfazedHipError):
+        engine.site_scan(fid)  # the family went away with its sites table

@@ -6,6 +6,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = ["abi.hip", "k_sites.hip", "k_reads.hip"]
+DEFAULT_FLAGS = []
 LIB = os.path.join(_HERE, "libunfazed_hip.so")
 
 
@@ -23,9 +24,23 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     lib = out or LIB
     if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
         return lib
+    # several ranks of one node may get here at once (bench.py --gpus N): build under a file lock
+    import fcntl
+    lock = open(lib + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
+            return lib
+        return _compile(lib, srcs, inc, csrc, extra_flags, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _compile(lib, srcs, inc, csrc, extra_flags, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-parameter", "-I", inc, "-I", csrc] + list(extra_flags) + srcs + ["-o", lib + ".tmp"]
+           "-Wall", "-Wno-unused-parameter", "-I", inc, "-I", csrc] + (list(extra_flags) if extra_flags else DEFAULT_FLAGS) + srcs + ["-o", lib + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -195,7 +195,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
     hipDeviceProp_t prop;
     UZ_HIP(hipGetDeviceProperties(&prop, c->device));
-    static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 20) * 1024; }();
+    static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 16) * 1024; }();
     static const int wgs_per_cu = [] {
         const char *e = getenv("UZ_PHASE_WGS_PER_CU");
         if (e) return atoi(e);

@@ -22,83 +22,106 @@ struct SiteParams {
     double lo_ref, hi_ref, lo_het, hi_het, lo_alt, hi_alt; // allele-balance windows per genotype
 };
 
-__device__ __forceinline__ int dec16(uint32_t v) { return v == UZ_U16_MISSING ? -1 : (int)v; }
+// The 16-bit columns hold 0..32767, or 0xFFFF for cyvcf2's -1 (missing): read as SIGNED halfwords the
+// sentinel decodes itself (one v_bfe_i32 / v_ashrrev per value instead of and + compare + select).
+__device__ __forceinline__ int dec16(uint32_t v) { return (int)(int16_t)(uint16_t)v; }
 
 // Allele-balance window test without a division on the hot path.  For a fixed total depth t the
 // correctly rounded quotient RN(a / t) is monotone in the integer a, so the set of alt depths a with
 //     lo <= RN(a / t) <= hi
 // is an interval [amin[t], amax[t]].  k_build_ab_lut finds it once per parameter set with the SAME
 // IEEE f64 division the reference's numpy expression performs (informative_site_finder.py:69-71),
-// for every total the 16-bit columns can produce: t = rd + ad in [-2, 131068] (-1 = missing).
-// t == 0 (0/0 -> NaN, +-1/0 -> +-inf) is not an interval in general and keeps two pass bits instead.
-// A 30x genome touches a few hundred bytes of the table (L1-resident); the table is 3 MiB.
+// for every total the columns can produce: t = rd + ad in [-2, 65534].  The table has one row per
+// genotype code (row 2 = unknown genotype: always empty, :62-63) and already folds in the depth test
+// (t < min_depth -> empty, :66), so is_high_quality_site is  gq >= min  &  amin <= ad <= amax.
+// t == 0 (0/0 -> NaN, +-1/0 -> +-inf) is an interval unless BOTH infinities pass (only with infinite
+// thresholds); that case is flagged and served by the kernel variant with an explicit t == 0 test.
+// A 30x genome touches a few hundred bytes of the 2 MiB table (L1-resident).
 #define UZ_AB_T_MIN (-2)
-#define UZ_AB_T_MAX 131068
+#define UZ_AB_T_MAX 65534
 #define UZ_AB_LUT_N (UZ_AB_T_MAX - UZ_AB_T_MIN + 1)
+#define UZ_AB_A_MIN (-1)
+#define UZ_AB_A_MAX 32767
 __device__ __forceinline__ double ab_lo(const SiteParams &P, int gt) { return gt == UZ_HOM_REF ? P.lo_ref : (gt == UZ_HOM_ALT ? P.lo_alt : P.lo_het); }
 __device__ __forceinline__ double ab_hi(const SiteParams &P, int gt) { return gt == UZ_HOM_REF ? P.hi_ref : (gt == UZ_HOM_ALT ? P.hi_alt : P.hi_het); }
 
-__global__ void k_build_ab_lut(SiteParams P, int2 *lut) {
+#define UZ_AB_LDS_T 512 // totals below this (minus UZ_AB_T_MIN) are served from the LDS copy of the table
+__global__ void k_build_ab_lut(SiteParams P, int2 *lut, uint32_t *small, int *t0_special) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * UZ_AB_LUT_N) return;
-    const int cls = i / UZ_AB_LUT_N, t = i % UZ_AB_LUT_N + UZ_AB_T_MIN;
-    const int gt = cls == 0 ? UZ_HOM_REF : (cls == 1 ? UZ_HET : UZ_HOM_ALT);
+    if (i >= 4 * UZ_AB_LUT_N) return;
+    const int gt = i / UZ_AB_LUT_N, t = i % UZ_AB_LUT_N + UZ_AB_T_MIN;
     const double lo = ab_lo(P, gt), hi = ab_hi(P, gt);
     int2 r = make_int2(0x7FFFFFFF, -0x7FFFFFFF); // empty interval
-    if (t > 0) {
-        // a over every decodable depth: -1 (missing) .. 65534; a/t is increasing in a
-        int l = -1, h = 65535; // smallest a with lo <= RN(a/t); 65535 = none
-        while (l < h) { const int m = l + ((h - l) >> 1); if (lo <= (double)m / (double)t) h = m; else l = m + 1; }
-        const int amin = l;
-        l = -2; h = 65534; // largest a with RN(a/t) <= hi; -2 = none
-        while (l < h) { const int m = l + ((h - l + 1) >> 1); if ((double)m / (double)t <= hi) l = m; else h = m - 1; }
-        if (amin <= 65534 && l >= -1) r = make_int2(amin, l);
-    } else if (t < 0) {
-        // only a in {-1, 0} can give a negative total (one or both depths missing)
-        int amin = 0x7FFFFFFF, amax = -0x7FFFFFFF;
-        for (int a = -1; a <= 0; a++) {
-            const double ab = (double)a / (double)t;
-            if (lo <= ab && ab <= hi) { if (a < amin) amin = a; if (a > amax) amax = a; }
+    if (gt != UZ_GT_UNKNOWN && t >= P.min_depth) {
+        if (t > 0) {
+            // a/t is increasing in a
+            int l = UZ_AB_A_MIN, h = UZ_AB_A_MAX + 1; // smallest a with lo <= RN(a/t); A_MAX + 1 = none
+            while (l < h) { const int m = l + ((h - l) >> 1); if (lo <= (double)m / (double)t) h = m; else l = m + 1; }
+            const int amin = l;
+            l = UZ_AB_A_MIN - 1; h = UZ_AB_A_MAX; // largest a with RN(a/t) <= hi; A_MIN - 1 = none
+            while (l < h) { const int m = l + ((h - l + 1) >> 1); if ((double)m / (double)t <= hi) l = m; else h = m - 1; }
+            if (amin <= UZ_AB_A_MAX && l >= UZ_AB_A_MIN) r = make_int2(amin, l);
+        } else if (t < 0) {
+            // only a in {-1, 0} can give a negative total (one or both depths missing)
+            int amin = 0x7FFFFFFF, amax = -0x7FFFFFFF;
+            for (int a = -1; a <= 0; a++) {
+                const double ab = (double)a / (double)t;
+                if (lo <= ab && ab <= hi) { if (a < amin) amin = a; if (a > amax) amax = a; }
+            }
+            r = make_int2(amin, amax); // any subset of {-1, 0} is an interval
+        } else {
+            // t == 0: a = 0 -> NaN (never passes), a = +-1 -> +-inf
+            const double pinf = 1.0 / 0.0, ninf = -1.0 / 0.0;
+            const bool neg = lo <= ninf && ninf <= hi, pos = lo <= pinf && pinf <= hi;
+            if (neg && pos) { r = make_int2(-1, 1); atomicOr(t0_special, 1); } // not an interval: a = 0 must fail
+            else if (neg) r = make_int2(-1, -1);
+            else if (pos) r = make_int2(1, 1);
         }
-        r = make_int2(amin, amax); // any subset of {-1, 0} is an interval
-    } else {
-        // t == 0: a = 0 -> NaN (never passes), a = +-1 -> +-inf.  x = pass bit of a = -1, y = of a = +1
-        const double pinf = 1.0 / 0.0, ninf = -1.0 / 0.0;
-        r = make_int2((lo <= ninf && ninf <= hi) ? 1 : 0, (lo <= pinf && pinf <= hi) ? 1 : 0);
     }
     lut[i] = r;
+    if (t - UZ_AB_T_MIN < UZ_AB_LDS_T) { // packed copy for LDS: amin | amax << 16 as signed halfwords
+        const int lo16 = r.x > 32767 ? 32767 : r.x, hi16 = r.y < -32768 ? -32768 : r.y;
+        small[gt * UZ_AB_LDS_T + (t - UZ_AB_T_MIN)] = ((uint32_t)lo16 & 0xFFFFu) | ((uint32_t)hi16 << 16);
+    }
 }
 
 // is_high_quality_site (:46-73)
-__device__ __forceinline__ bool hq(const SiteParams &P, const int2 *__restrict__ lut, int gt, int rd, int ad, int gq) {
+template <bool T0>
+__device__ __forceinline__ bool hq(const SiteParams &P, const int2 *__restrict__ lut, const uint32_t *lds, int gt, int rd, int ad, int gq) {
     const int t = rd + ad;
-    const bool ok = (gt != UZ_GT_UNKNOWN) & (gq >= P.min_gt_qual) & (t >= P.min_depth);
-    const int cls = gt == UZ_HOM_REF ? 0 : (gt == UZ_HOM_ALT ? 2 : 1);
-    const int2 b = lut[cls * UZ_AB_LUT_N + (t - UZ_AB_T_MIN)];
-    const bool in_iv = (ad >= b.x) & (ad <= b.y);
-    const bool in_t0 = ((ad == 1) & (b.y != 0)) | ((ad == -1) & (b.x != 0));
-    return ok & (t != 0 ? in_iv : in_t0);
+    const uint32_t ti = (uint32_t)(t - UZ_AB_T_MIN);
+    int amin, amax;
+    if (ti < UZ_AB_LDS_T) { // the common case: a conflict-light LDS read instead of a 64-address gather through L1
+        const uint32_t e = lds[gt * UZ_AB_LDS_T + ti];
+        amin = (int)(int16_t)(e & 0xFFFFu);
+        amax = (int)(int16_t)(e >> 16);
+    } else {
+        const int2 b = lut[gt * UZ_AB_LUT_N + ti];
+        amin = b.x; amax = b.y;
+    }
+    bool ok = (gq >= P.min_gt_qual) & (ad >= amin) & (ad <= amax);
+    if (T0) ok &= !((t == 0) & (ad == 0));
+    return ok;
 }
+
+// parental pattern (:307-320) as a 16 x 2-bit table indexed by dad | mom << 2: 1 = alt_parent is dad, 2 = mom
+#define UZ_PATTERN_TABLE ((1u << 2) | (1u << 6) | (2u << 8) | (2u << 24) | (1u << 14) | (2u << 26))
 
 // CNV = false: SNV / breakpoint mode only (class bits HET, CAND, ALT_DAD) -- what find(...,
 // whole_region=False) evaluates (:292-295); CNV = true adds the DEL / DUP codes of get_kid_allele,
 // which only find(..., whole_region=True) reaches (:286-291).
-template <bool CNV>
-__device__ __forceinline__ uint8_t classify_site(const SiteParams &P, const int2 *__restrict__ lut, uint32_t g, int rdk,
+template <bool CNV, bool T0>
+__device__ __forceinline__ uint8_t classify_site(const SiteParams &P, const int2 *__restrict__ lut, const uint32_t *lds, uint32_t g, int rdk,
                                                  int adk, int gqk, int rdd, int add, int gqd, int rdm, int adm, int gqm) {
     const int kid = g & 3, dad = (g >> 2) & 3, mom = (g >> 4) & 3;
-    const bool hqk = hq(P, lut, kid, rdk, adk, gqk);
-    const bool hqd = hq(P, lut, dad, rdd, add, gqd);
-    const bool hqm = hq(P, lut, mom, rdm, adm, gqm);
+    const bool hqk = hq<T0>(P, lut, lds, kid, rdk, adk, gqk);
+    const bool hqd = hq<T0>(P, lut, lds, dad, rdd, add, gqd);
+    const bool hqm = hq<T0>(P, lut, lds, mom, rdm, adm, gqm);
+    const uint32_t pcode = (UZ_PATTERN_TABLE >> (((g >> 2) & 15u) * 2)) & 3u;
+    const bool pattern = pcode != 0, alt_dad = pcode == 1;
     uint32_t c = 0;
     if (kid == UZ_HET && hqd && hqm) c |= UZ_CL_HET; // :268-284
-    // parental pattern :307-320
-    bool pattern = false, alt_dad = false;
-    if ((dad == UZ_HET || dad == UZ_HOM_ALT) && mom == UZ_HOM_REF) { pattern = true; alt_dad = true; }
-    else if ((mom == UZ_HET || mom == UZ_HOM_ALT) && dad == UZ_HOM_REF) { pattern = true; alt_dad = false; }
-    else if (mom == UZ_HET && dad == UZ_HOM_ALT) { pattern = true; alt_dad = true; }
-    else if (dad == UZ_HET && mom == UZ_HOM_ALT) { pattern = true; alt_dad = false; }
-    if (pattern && alt_dad) c |= UZ_CL_ALT_DAD;
+    if (alt_dad) c |= UZ_CL_ALT_DAD;
     if (hqd && hqm && pattern) {
         if (kid == UZ_HET && hqk) c |= UZ_CL_CAND; // :292-295
         if constexpr (CNV) {
@@ -167,15 +190,21 @@ struct FamPtrs {
     const uint16_t *rd[3], *ad[3], *gq[3];
 };
 
-template <int SPT, bool CNV>
-__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restrict__ cls, int64_t n, SiteParams Pk, const int2 *__restrict__ lut) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t base = t * SPT;
-    if (base >= n) return;
+template <int SPT, bool CNV, bool T0>
+__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restrict__ cls, int64_t n, SiteParams Pk, const int2 *__restrict__ lut,
+                                                   const uint32_t *__restrict__ small) {
+    // every workgroup keeps the low-depth part of the threshold table in LDS (8 KiB) and walks the
+    // site chunks grid-stride, so the fill is paid once per workgroup, not per chunk
+    __shared__ uint32_t lds_lut[4 * UZ_AB_LDS_T];
+    for (int i = threadIdx.x; i < 4 * UZ_AB_LDS_T; i += 256) lds_lut[i] = small[i];
+    __syncthreads();
     // Read the thresholds into registers up front.  Left in the kernarg struct, `c ? P.a : P.b` is
-    // compiled as a select of ADDRESSES followed by a per-lane global load (6 extra vector loads and
-    // waits per site); on copies it is a v_cndmask between SGPR pairs.
+    // compiled as a select of ADDRESSES followed by a per-lane global load; on copies it is a v_cndmask.
     const SiteParams P = {Pk.min_gt_qual, Pk.min_depth, Pk.lo_ref, Pk.hi_ref, Pk.lo_het, Pk.hi_het, Pk.lo_alt, Pk.hi_alt};
+    const int64_t n_chunks = (n + 256 * SPT - 1) / (256 * SPT);
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const int64_t base = (chunk * 256 + threadIdx.x) * SPT;
+    if (base >= n) continue;
     if (base + SPT <= n) {
         // issue all 19-20 vector loads before the first use
         ColVec<SPT> c[9];
@@ -203,7 +232,7 @@ __global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restric
                 const uint32_t g = (gw[w] >> (8 * b)) & 0xFFu;
                 uint32_t cl = 0;
                 if (!(g & 0x40u)) // bit 6: complex record (:239-244)
-                    cl = classify_site<CNV>(P, lut, g, dec16(c[0].get(i)), dec16(c[3].get(i)), dec16(c[6].get(i)),
+                    cl = classify_site<CNV, T0>(P, lut, lds_lut, g, dec16(c[0].get(i)), dec16(c[3].get(i)), dec16(c[6].get(i)),
                                        dec16(c[1].get(i)), dec16(c[4].get(i)), dec16(c[7].get(i)),
                                        dec16(c[2].get(i)), dec16(c[5].get(i)), dec16(c[8].get(i)));
                 o |= cl << (8 * b);
@@ -219,12 +248,13 @@ __global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restric
             const uint32_t g = f.gt[i];
             uint8_t cl = 0;
             if (!(g & 0x40u))
-                cl = classify_site<CNV>(P, lut, g, dec16(f.rd[0][i]), dec16(f.ad[0][i]), dec16(f.gq[0][i]), dec16(f.rd[1][i]),
+                cl = classify_site<CNV, T0>(P, lut, lds_lut, g, dec16(f.rd[0][i]), dec16(f.ad[0][i]), dec16(f.gq[0][i]), dec16(f.rd[1][i]),
                                    dec16(f.ad[1][i]), dec16(f.gq[1][i]), dec16(f.rd[2][i]), dec16(f.ad[2][i]),
                                    dec16(f.gq[2][i]));
             cls[i] = cl;
         }
     }
+    } // chunk loop
 }
 
 __device__ __forceinline__ int64_t lower_bound(const int32_t *a, int64_t lo, int64_t hi, int64_t v) {
@@ -388,21 +418,36 @@ void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_c
         for (int m = 0; m < 3; m++) { fp.rd[m] = f.rd[m]; fp.ad[m] = f.ad[m]; fp.gq[m] = f.gq[m]; }
         const SiteParams sp = make_site_params(c->P);
         if (!(c->ab_lut_valid && site_params_equal(c->ab_lut_params, c->P))) {
-            c->ab_lut.ensure((size_t)3 * UZ_AB_LUT_N * 2);
-            hipLaunchKernelGGL(k_build_ab_lut, dim3((3 * UZ_AB_LUT_N + 255) / 256), dim3(256), 0, c->stream, sp, (int2 *)c->ab_lut.p);
+            c->ab_lut.ensure((size_t)4 * UZ_AB_LUT_N * 2 + 4 + 4 * UZ_AB_LDS_T);
+            int *flag = c->ab_lut.p + (size_t)4 * UZ_AB_LUT_N * 2;
+            UZ_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+            hipLaunchKernelGGL(k_build_ab_lut, dim3((4 * UZ_AB_LUT_N + 255) / 256), dim3(256), 0, c->stream, sp, (int2 *)c->ab_lut.p,
+                               (uint32_t *)(flag + 4), flag);
             UZ_HIP(hipGetLastError());
+            int special = 0;
+            UZ_HIP(hipMemcpyAsync(&special, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipStreamSynchronize(c->stream));
+            c->ab_lut_t0_special = special != 0;
             c->ab_lut_valid = true;
             c->ab_lut_params = c->P;
         }
         static const int spt = [] { const char *e = getenv("UZ_SITE_SPT"); return e ? atoi(e) : UZ_SITE_SPT; }();
         ProfScope ps(c, UZ_K_SITE_SCAN);
         auto launch = [&](auto kern, int SPT) {
-            const int64_t nthreads = (s.n + SPT - 1) / SPT;
-            const int64_t nb = (nthreads + 255) / 256;
-            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), 0, c->stream, fp, f.cls, s.n, sp, (const int2 *)c->ab_lut.p);
+            const int64_t n_chunks = (s.n + 256 * SPT - 1) / (256 * SPT);
+            static const int wgs = [] { const char *e = getenv("UZ_SITE_WGS"); return e ? atoi(e) : 4096; }();
+            const int64_t nb = n_chunks < wgs ? n_chunks : wgs; // 256 CUs x 8 resident workgroups, grid-stride over the chunks
+            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), 0, c->stream, fp, f.cls, s.n, sp, (const int2 *)c->ab_lut.p,
+                               (const uint32_t *)(c->ab_lut.p + (size_t)4 * UZ_AB_LUT_N * 2 + 4));
         };
-        if (spt == 16) { if (with_cnv) launch(k_site_scan<16, true>, 16); else launch(k_site_scan<16, false>, 16); }
-        else { if (with_cnv) launch(k_site_scan<8, true>, 8); else launch(k_site_scan<8, false>, 8); }
+        const bool t0 = c->ab_lut_t0_special;
+        if (spt == 16) {
+            if (with_cnv) { if (t0) launch(k_site_scan<16, true, true>, 16); else launch(k_site_scan<16, true, false>, 16); }
+            else { if (t0) launch(k_site_scan<16, false, true>, 16); else launch(k_site_scan<16, false, false>, 16); }
+        } else {
+            if (with_cnv) { if (t0) launch(k_site_scan<8, true, true>, 8); else launch(k_site_scan<8, true, false>, 8); }
+            else { if (t0) launch(k_site_scan<8, false, true>, 8); else launch(k_site_scan<8, false, false>, 8); }
+        }
         UZ_HIP(hipGetLastError());
     }
     f.cls_has_cnv = with_cnv;

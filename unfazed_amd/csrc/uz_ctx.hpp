@@ -127,6 +127,7 @@ struct uz_ctx {
     // allele-balance threshold table of K1 (k_sites.hip), rebuilt when the thresholds change
     DevBuf<int32_t> ab_lut;
     bool ab_lut_valid = false;
+    bool ab_lut_t0_special = false;
     uz_params ab_lut_params;
 
     // last find

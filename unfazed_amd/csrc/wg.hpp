@@ -33,7 +33,7 @@ UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long l
 #define UZ_DEV __device__ __forceinline__
 #define UZ_HD __host__ __device__ inline
 #ifndef UZ_WG_NT
-#define UZ_WG_NT 256
+#define UZ_WG_NT 128 // lanes per DNM workgroup: 128 with a 16 KiB LDS arena measured best on MI355X
 #endif
 #define WG_NT UZ_WG_NT
 #define WG_TID ((int)threadIdx.x)
@@ -49,7 +49,7 @@ UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long l
 #endif
 
 #ifndef WG_SORT_LDS_CAP
-#define WG_SORT_LDS_CAP 512 // u64 keys copied into the 4 KiB LDS sort buffer; larger sorts run in place (LDS arena or HBM scratch)
+#define WG_SORT_LDS_CAP 256 // u64 keys copied into the 2 KiB LDS sort buffer; larger sorts run in place (LDS arena or HBM scratch)
 #endif
 
 struct WgShared {

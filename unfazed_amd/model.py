@@ -30,7 +30,7 @@ import numpy as np
 HOM_REF, HET, GT_UNKNOWN, HOM_ALT = 0, 1, 2, 3  # reference utils.py:2-5
 
 U16_MISSING = 0xFFFF
-U16_MAX_VALUE = 0xFFFE
+U16_MAX_VALUE = 0x7FFF  # the device reads the 16-bit columns as signed halfwords (0xFFFF = -1)
 
 # BAM flag bits
 FPAIRED, FPROPER, FUNMAP, FMUNMAP, FREVERSE, FMREVERSE = 1, 2, 4, 8, 16, 32
@@ -194,7 +194,8 @@ class SitesTable:
         (reference informative_site_finder.py:64) with the integer threshold of
         ``--min-gt-qual`` (reference __main__.py:146-151) has the same truth value
         for GQ and floor(GQ).  Missing (-1, or any negative) -> 0xFFFF.
-        A depth above 65534 does not fit the 16-bit columns: fail loudly.
+        A depth above 32767 does not fit the 16-bit columns (read as signed halfwords on the
+        device): fail loudly.
         """
         cols = [self.samples.index(s) for s in (kid, dad, mom)]
         gtp = (
@@ -204,7 +205,7 @@ class SitesTable:
         def depth16(a):
             a = a[cols]
             if a.size and a.max() > U16_MAX_VALUE:
-                raise OverflowError("allele depth above 65534 does not fit the device columns")
+                raise OverflowError("allele depth above 32767 does not fit the 16-bit device columns")
             if a.size and a.min() < -1:
                 raise ValueError("negative allele depth other than the missing marker -1")
             out = a.astype(np.int64)
