@@ -17,7 +17,8 @@ namespace {
 // threshold (151 bytes per record): a workgroup takes 256 consecutive records and walks their
 // quality rows as 16-byte chunks, consecutive lanes on consecutive chunks, so the loads are
 // full-width and coalesced (rows are 16-byte aligned); per-record counts are combined in LDS.
-__global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qual, int min_base_qual, uint8_t *qc) {
+__global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qual, int min_base_qual, const uint8_t *__restrict__ need,
+                                                uint8_t *qc) {
     __shared__ int low[256];
     __shared__ uint32_t row16[256]; // quality row offset (16-byte units) of each record of the block
     __shared__ int len[256];        // bases to examine (0 for records without qualities)
@@ -29,7 +30,8 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qua
     if (t == 0) maxch = 0;
     int ls = 0;
     uint32_t ro = 0;
-    if (mine < n && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) { ls = R.l_seq[mine]; ro = R.sq_off16[mine]; }
+    const bool wanted = mine < n && need[mine]; // only records some fetch of this batch can reach
+    if (wanted && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) { ls = R.l_seq[mine]; ro = R.sq_off16[mine]; }
     row16[t] = ro;
     len[t] = ls;
     __syncthreads();
@@ -52,7 +54,25 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qua
         if (c) atomicAdd(&low[rl], c);
     }
     __syncthreads();
-    if (mine < n) qc[mine] = uz_seg_qc_flags(R, (int)mine, min_map_qual, low[t]);
+    if (wanted) qc[mine] = uz_seg_qc_flags(R, (int)mine, min_map_qual, low[t]);
+}
+
+// Marks the records a batch can touch: every record of every fetch range and its mate.  One wave per
+// range, lanes on consecutive records (ranges are tens of records long).
+__global__ __launch_bounds__(256) void k_mark_ranges(const int32_t *__restrict__ first, const int32_t *__restrict__ len_or_end,
+                                                     int end_stride, int64_t n_ranges, const int32_t *__restrict__ mate,
+                                                     uint8_t *need) {
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (w >= n_ranges) return;
+    // end_stride == 0: (first[w], len[w]); otherwise ranges are [first[w * stride], first[w * stride + 1])
+    const int64_t a = end_stride ? first[w * end_stride] : first[w];
+    const int64_t b = end_stride ? first[w * end_stride + 1] : a + len_or_end[w];
+    for (int64_t i = a + lane; i < b; i += 64) {
+        need[i] = 1;
+        const int m = mate[i];
+        if (m >= 0) need[m] = 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {
@@ -60,7 +80,10 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
     if (d < a.n) uz_phase_bounds(a, d, bounds + 5 * (size_t)d);
 }
 
-__global__ __launch_bounds__(WG_NT) void k_phase(PhaseArgs a) {
+#ifndef UZ_PHASE_MIN_WAVES
+#define UZ_PHASE_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(WG_NT, UZ_PHASE_MIN_WAVES) void k_phase(PhaseArgs a) {
     __shared__ WgShared sh;
     extern __shared__ __attribute__((aligned(16))) uint8_t uz_lds_arena[];
     Scr s;
@@ -139,19 +162,6 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     c->phase_n = n;
     if (n <= 0) { c->phase_valid = true; return; }
 
-    // K3a: per-segment QC bits for the current thresholds
-    if (!(r.qc_valid && r.qc_params.min_map_qual == c->P.min_map_qual && r.qc_params.min_gt_qual == c->P.min_gt_qual)) {
-        if (r.n > 0) {
-            ProfScope ps(c, UZ_K_SEG_QC);
-            const unsigned nb = (unsigned)((r.n + 255) / 256);
-            hipLaunchKernelGGL(k_seg_qc, dim3(nb), dim3(256), 0, c->stream, make_rd(r), r.n, c->P.min_map_qual,
-                               c->P.min_gt_qual, r.qc);
-            UZ_HIP(hipGetLastError());
-        }
-        r.qc_valid = true;
-        r.qc_params = c->P;
-    }
-
     PhaseArgs a;
     memset(&a, 0, sizeof(a));
     a.n = n;
@@ -169,6 +179,9 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     st->bounds.ensure((size_t)5 * n);
     st->pre_win.ensure((size_t)4 * n); st->pre_ha.ensure((size_t)c->n_het + 1); st->pre_hl.ensure((size_t)c->n_het + 1);
     a.pre_win = st->pre_win.p; a.pre_ha = st->pre_ha.p; a.pre_hl = st->pre_hl.p;
+    // DNMs without candidates leave their het ranges untouched: they must read as empty
+    UZ_HIP(hipMemsetAsync(st->pre_ha.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
+    UZ_HIP(hipMemsetAsync(st->pre_hl.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
     {
         const unsigned nb = (unsigned)((n + 255) / 256);
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
@@ -228,6 +241,25 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     UZ_HIP(hipMemsetAsync(timing.p, 0, 16 * sizeof(unsigned long long), c->stream));
     a.timing = timing.p;
 #endif
+    // K3a, lazily: QC bits only for the records some fetch range of this batch (or a mate) can reach
+    if (r.n > 0) {
+        UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n, c->stream));
+        ProfScope ps(c, UZ_K_SEG_QC);
+        const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
+        hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const int32_t *)r.mate, r.need);
+        UZ_HIP(hipGetLastError());
+        if (!c->P.no_extended && c->n_het > 0) {
+            hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                               (const int32_t *)st->pre_ha.p, (const int32_t *)st->pre_hl.p, 0, (int64_t)c->n_het,
+                               (const int32_t *)r.mate, r.need);
+            UZ_HIP(hipGetLastError());
+        }
+        const unsigned nb = (unsigned)((r.n + 255) / 256);
+        hipLaunchKernelGGL(k_seg_qc, dim3(nb), dim3(256), 0, c->stream, make_rd(r), r.n, c->P.min_map_qual, c->P.min_gt_qual,
+                           (const uint8_t *)r.need, r.qc);
+        UZ_HIP(hipGetLastError());
+    }
     for (int attempt = 0; attempt < 4; attempt++) {
         UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
         UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));

@@ -91,6 +91,7 @@ struct ReadsDev {
     uint8_t *seq = nullptr, *qual = nullptr;
     // K3a output: per-segment QC bits for the parameters in qc_params
     uint8_t *qc = nullptr;
+    uint8_t *need = nullptr; // records reachable by the current batch (lazy K3a)
     int32_t *coarse = nullptr; // start[] of every 4096th record
     bool qc_valid = false;
     uz_params qc_params;
