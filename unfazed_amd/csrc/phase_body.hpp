@@ -507,7 +507,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.a_flag[0][i] = cl == 1;
             s.a_flag[1][i] = cl == 2;
         }
-        WG_SYNC();
         const int n_ref = wg_exscan(s.a_flag[0], nA, sh);
         const int n_alt = wg_exscan(s.a_flag[1], nA, sh);
         WG_FOR(i, nA) {
@@ -535,7 +534,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.a_cls[t] = (uint8_t)code;
             s.a_flag[0][t] = code == 3;
         }
-        WG_SYNC();
         const int nban = wg_exscan(s.a_flag[0], nA, sh);
         WG_FOR(t, nA) { // the banned names, in fetch order: (item, name)
             if (s.a_cls[t] == 3) {
@@ -559,7 +557,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.a_cls[t] = (uint8_t)code;
             s.a_flag[1][t] = code ? 2 : 0;
         }
-        WG_SYNC();
         const int nsup = wg_exscan(s.a_flag[1], nA, sh);
         WG_FOR(t, nA) {
             const int code = s.a_cls[t];
@@ -579,7 +576,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 if (s.i_qp[j] >= n0 && s.i_L[j] == q) { keep = 0; break; }
             s.i_R[k] = keep;
         }
-        WG_SYNC();
         const int nfil = wg_exscan(s.i_R, nsup, sh);
         if (nfil >= 2) { // :594-595
             WG_FOR(k, nsup) {
@@ -631,12 +627,10 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             const int h = lo;
             const int seg = s.h_a[h] + (t - s.h_off[h]);
             s.reg_h[t] = h; // provisional: het index of work item t
-            s.t_ov[t] = (long long)R.end[seg] > (long long)s.hpos[h];
+            const int ov = (long long)R.end[seg] > (long long)s.hpos[h];
+            s.t_ov[t] = ov;
+            s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
         }
-        WG_SYNC();
-        // enumerate index of the fetch iterator = overlapping records before this one at the same site
-        WG_FOR(t, T) s.t_pass[t] = s.t_ov[t];
-        WG_SYNC();
         (void)wg_exscan(s.t_pass, T, sh);
         WG_FOR(t, T) {
             const int h = s.reg_h[t];
@@ -648,15 +642,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             }
             if (ok) ok = uz_pair_ok(R, a, seg) >= 0 && (R.qc[seg] & UZ_QC_NM5);
             s.t_ov[t] = ok;
+            s.reg_pair[t] = ok; // scanned below: position in the registration list (reg_pair is free until phase S)
         }
-        WG_SYNC();
-        WG_FOR(t, T) s.t_pass[t] = s.t_ov[t];
-        WG_SYNC();
-        E = wg_exscan(s.t_pass, T, sh);
+        E = wg_exscan(s.reg_pair, T, sh);
         // compacting in place is unsafe across lanes: stage, then copy
         WG_FOR(t, T) {
             if (s.t_ov[t]) {
-                const int k = s.t_pass[t];
+                const int k = s.reg_pair[t];
                 const int h = s.reg_h[t];
                 stg1[k] = h;
                 stg2[k] = s.h_a[h] + (t - s.h_off[h]);
@@ -665,7 +657,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         WG_SYNC();
         WG_FOR(k, E) { s.reg_h[k] = stg1[k]; s.reg_seg[k] = stg2[k]; }
         // site_reads range of het index h: entries [sr_off[h], sr_off[h+1])
-        WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.t_pass[s.h_off[h]] : E) : E;
+        WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.reg_pair[s.h_off[h]] : E) : E;
         WG_SYNC();
         WG_FOR(h, nh) {
             // a canonical site exists in site_reads once any of its duplicates registered a read (:217-218)
@@ -680,7 +672,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.i_qp[m] = qp; s.i_L[m] = L; s.i_R[m] = Rr;
             s.i_soff[m] = nm;
         }
-        WG_SYNC();
         S = wg_exscan(s.i_soff, nI, sh);
         WG_T0 s.i_soff[nI] = S;
         WG_SYNC();
@@ -743,7 +734,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
             WG_SYNC();
             WG_FOR(x, M) wg_atomic_add(&s.q_cnt[(int)(s.keys[x] >> 24) - qmin], 1);
-            WG_SYNC();
             (void)wg_exscan(s.q_cnt, qrange, sh);
             WG_FOR(x, M) {
                 const int b = (int)(s.keys[x] >> 24) - qmin;
@@ -769,10 +759,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             wg_sort64(s.keys, M, sh);
     }
     UZ_TICK(3); // sort
-    WG_FOR(x, M) s.srt_flag[x] = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
-    WG_SYNC();
-    WG_FOR(x, M) s.srt_pid[x] = s.srt_flag[x];
-    WG_SYNC();
+    WG_FOR(x, M) {
+        const int st = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
+        s.srt_flag[x] = st;
+        s.srt_pid[x] = st;
+    }
     P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1
     WG_FOR(x, M) {
         const int pid = s.srt_pid[x] + s.srt_flag[x] - 1;
@@ -897,7 +888,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
             WG_FOR(p, P) s.o_flag[p] = (!s.assigned[p] && s.key[p] != ~0ULL) ? 1 : 0;
-            WG_SYNC();
             const int W = wg_exscan(s.o_flag, P, sh);
             WG_FOR(p, P) {
                 if (!s.assigned[p] && s.key[p] != ~0ULL) {
@@ -1018,7 +1008,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             else v = (s.grp[i] >> (k - 4)) & 1;
             fl[i] = v;
         }
-        WG_SYNC();
         cnt[k] = (k < 4 || a.want_lists) ? wg_exscan(fl, n, sh) : 0;
         if (a.want_lists) {
             // one bump allocation per DNM, made when the first list is known: reserve the upper bound 2P + 2nc + 2P
