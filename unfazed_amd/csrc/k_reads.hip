@@ -17,20 +17,86 @@ namespace {
 // threshold (151 bytes per record): a workgroup takes 256 consecutive records and walks their
 // quality rows as 16-byte chunks, consecutive lanes on consecutive chunks, so the loads are
 // full-width and coalesced (rows are 16-byte aligned); per-record counts are combined in LDS.
-__global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qual, int min_base_qual, const uint8_t *__restrict__ need,
-                                                uint8_t *qc) {
+// K3a runs over a compact list of the records the batch can reach (about a quarter of the records
+// inside the DNM windows): every lane of the quality pass then has a 16-byte chunk to count.
+// k_compact_need turns the byte map written by k_mark_ranges into that list; the order of the list is
+// irrelevant (each entry writes its own qc byte), so a wave reserves its slice with one atomic.
+__global__ __launch_bounds__(256) void k_compact_need(const uint8_t *__restrict__ need, int64_t n, int chunks_per_block,
+                                                      int32_t *__restrict__ list, unsigned int *__restrict__ count) {
+    // A block owns chunks_per_block consecutive 4096-record chunks: it counts them, reserves its slice
+    // of the list with ONE atomic (a single hot counter serialises at ~10 ns per atomic), then fills it.
+    __shared__ int wsum[4];
+    __shared__ unsigned int slice;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t first = (int64_t)blockIdx.x * chunks_per_block * 4096;
+    int mine = 0;
+    for (int ch = 0; ch < chunks_per_block; ch++) {
+        const int64_t base = first + (int64_t)ch * 4096 + (int64_t)t * 16;
+        if (base >= n) break; // the map is allocated with a 64-byte pad and zeroed up to it
+        const uint4 v = *reinterpret_cast<const uint4 *>(need + base);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) mine += ((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0 && base + k < n;
+    }
+    int tot = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    if (lane == 0) wsum[wv] = tot;
+    __syncthreads();
+    if (t == 0) {
+        const int all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        slice = all ? atomicAdd(count, (unsigned int)all) : 0u;
+    }
+    __syncthreads();
+    unsigned int run = slice;
+    for (int ch = 0; ch < chunks_per_block; ch++) {
+        const int64_t cbase = first + (int64_t)ch * 4096;
+        if (cbase >= n) break; // block-uniform
+        const int64_t base = cbase + (int64_t)t * 16;
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (base < n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(need + base);
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        }
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) c += ((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0 && base + k < n;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        __syncthreads(); // wsum of the previous round has been read
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        unsigned int o = run + (unsigned int)(incl - c);
+        for (int k = 0; k < wv; k++) o += (unsigned int)wsum[k];
+        run += (unsigned int)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        if (c) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if ((((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0) && base + k < n) list[o++] = (int32_t)(base + k);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict__ list, const unsigned int *__restrict__ count,
+                                                int min_map_qual, int min_base_qual, uint8_t *qc) {
     __shared__ int low[256];
     __shared__ uint32_t row16[256]; // quality row offset (16-byte units) of each record of the block
     __shared__ int len[256];        // bases to examine (0 for records without qualities)
     __shared__ int maxch;
+    const int64_t m = (int64_t)*count;
     const int64_t r0 = (int64_t)blockIdx.x * 256;
+    if (r0 >= m) return; // the grid is sized for the host's upper bound of the list
     const int t = threadIdx.x;
-    const int64_t mine = r0 + t;
+    const bool wanted = r0 + t < m;
+    const int mine = wanted ? list[r0 + t] : 0;
     low[t] = 0;
     if (t == 0) maxch = 0;
     int ls = 0;
     uint32_t ro = 0;
-    const bool wanted = mine < n && need[mine]; // only records some fetch of this batch can reach
     if (wanted && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) { ls = R.l_seq[mine]; ro = R.sq_off16[mine]; }
     row16[t] = ro;
     len[t] = ls;
@@ -39,22 +105,34 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, int64_t n, int min_map_qua
     __syncthreads();
     const int nch = maxch;
     const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
-    for (int it = t; it < 256 * nch; it += 256) {
-        const int rl = it / nch, ch = it - rl * nch;
-        const int l = len[rl] - 16 * ch;
-        if (l <= 0) continue;
-        const uint4 v = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl] + ch) << 4));
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        int c = 0;
+    // five independent 16-byte loads in flight per lane before any of them is counted
+    for (int j0 = 0; j0 < nch; j0 += 5) {
+        uint4 v[5];
+        int rl[5], l[5];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            c += (k < l) & (q < thr);
+        for (int u = 0; u < 5; u++) {
+            const int it = t + 256 * (j0 + u);
+            rl[u] = it / nch;
+            const int ch = it - rl[u] * nch;
+            l[u] = (j0 + u < nch) ? len[rl[u]] - 16 * ch : 0;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (l[u] > 0) v[u] = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl[u]] + ch) << 4));
         }
-        if (c) atomicAdd(&low[rl], c);
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            if (l[u] <= 0) continue;
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            int c = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                c += (k < l[u]) & (q < thr);
+            }
+            if (c) atomicAdd(&low[rl[u]], c);
+        }
     }
     __syncthreads();
-    if (wanted) qc[mine] = uz_seg_qc_flags(R, (int)mine, min_map_qual, low[t]);
+    if (wanted) qc[mine] = uz_seg_qc_flags(R, mine, min_map_qual, low[t]);
 }
 
 // Marks the records a batch can touch: every record of every fetch range and its mate.  One wave per
@@ -103,6 +181,8 @@ struct PhaseState {
     DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len, pre_win, pre_ha, pre_hl;
     DevBuf<long long> list_start;
     DevBuf<unsigned long long> pool_cursor;
+    DevBuf<int32_t> need_list;
+    DevBuf<unsigned int> need_count;
     std::vector<long long> list_start_h;
     std::vector<int32_t> list_len_h;
     bool have_lists = false;
@@ -190,7 +270,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     std::vector<int32_t> bh((size_t)5 * n);
     UZ_HIP(hipMemcpyAsync(bh.data(), st->bounds.p, bh.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     UZ_HIP(hipStreamSynchronize(c->stream));
-    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
+    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
     for (int32_t d = 0; d < n; d++) {
         const int32_t *b = &bh[(size_t)5 * d];
         mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
@@ -198,6 +278,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         const long long I = 4LL * b[0];
         const long long M = (long long)b[1] + I * (b[4] + 1);
         mM = std::max(mM, M);
+        reach += 2LL * ((long long)b[0] + b[1]); // every fetched record and its mate
         sumP += std::min<long long>(M, 4096) + b[3];
     }
     Caps caps;
@@ -237,13 +318,13 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
 
 #ifdef UZ_PHASE_TIMING
     static DevBuf<unsigned long long> timing;
-    timing.ensure(16);
-    UZ_HIP(hipMemsetAsync(timing.p, 0, 16 * sizeof(unsigned long long), c->stream));
+    timing.ensure(32);
+    UZ_HIP(hipMemsetAsync(timing.p, 0, 32 * sizeof(unsigned long long), c->stream));
     a.timing = timing.p;
 #endif
     // K3a, lazily: QC bits only for the records some fetch range of this batch (or a mate) can reach
     if (r.n > 0) {
-        UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n, c->stream));
+        UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n + 64, c->stream));
         ProfScope ps(c, UZ_K_SEG_QC);
         const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
         hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 64 + 255) / 256)), dim3(256), 0, c->stream,
@@ -255,10 +336,23 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                                (const int32_t *)r.mate, r.need);
             UZ_HIP(hipGetLastError());
         }
-        const unsigned nb = (unsigned)((r.n + 255) / 256);
-        hipLaunchKernelGGL(k_seg_qc, dim3(nb), dim3(256), 0, c->stream, make_rd(r), r.n, c->P.min_map_qual, c->P.min_gt_qual,
-                           (const uint8_t *)r.need, r.qc);
+        const int64_t list_cap = std::min<long long>(reach, (long long)r.n);
+        st->need_list.ensure((size_t)list_cap + 16); st->need_count.ensure(4);
+        UZ_HIP(hipMemsetAsync(st->need_count.p, 0, 4 * sizeof(unsigned int), c->stream));
+        {
+            const int64_t chunks = (r.n + 4095) / 4096;
+            const int64_t blocks = std::min<int64_t>(chunks, 4096);
+            const int cpb = (int)((chunks + blocks - 1) / blocks);
+            hipLaunchKernelGGL(k_compact_need, dim3((unsigned)((chunks + cpb - 1) / cpb)), dim3(256), 0, c->stream,
+                               (const uint8_t *)r.need, (int64_t)r.n, cpb, st->need_list.p, st->need_count.p);
+        }
         UZ_HIP(hipGetLastError());
+        if (list_cap > 0) {
+            hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, c->stream, make_rd(r),
+                               (const int32_t *)st->need_list.p, (const unsigned int *)st->need_count.p, c->P.min_map_qual,
+                               c->P.min_gt_qual, r.qc);
+            UZ_HIP(hipGetLastError());
+        }
     }
     for (int attempt = 0; attempt < 4; attempt++) {
         UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
@@ -279,13 +373,15 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     }
 #ifdef UZ_PHASE_TIMING
     {
-        unsigned long long t[16];
+        unsigned long long t[32];
         UZ_HIP(hipMemcpy(t, timing.p, sizeof(t), hipMemcpyDeviceToHost));
-        const char *nm[8] = {"A", "B", "C", "sort", "pairs", "D", "E", "F"};
+        const char *nm[22] = {"A.classify", "A.rest", "B.het", "B.overlap", "B.scan1", "B.pair_ok", "B.scan2", "B.compact",
+                              "C", "S.keys", "S.sort", "P.scan", "P.scatter", "P.pairs", "D.finder", "D.cbase",
+                              "E.expand", "E.scan", "E.frontier", "E.setup", "F.join", "F.count"};
         unsigned long long tot = 0;
-        for (int k = 0; k < 8; k++) tot += t[k];
+        for (int k = 0; k < 22; k++) tot += t[k];
         fprintf(stderr, "[phase timing]");
-        for (int k = 0; k < 8; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)t[k] / (double)(tot ? tot : 1));
+        for (int k = 0; k < 22; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)t[k] / (double)(tot ? tot : 1));
         fprintf(stderr, " | ticks/DNM %.0f\n", (double)tot / n);
     }
 #endif

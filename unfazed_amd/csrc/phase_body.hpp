@@ -507,6 +507,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.a_flag[0][i] = cl == 1;
             s.a_flag[1][i] = cl == 2;
         }
+        UZ_TICK(0); // A.classify
         const int n_ref = wg_exscan(s.a_flag[0], nA, sh);
         const int n_alt = wg_exscan(s.a_flag[1], nA, sh);
         WG_FOR(i, nA) {
@@ -596,7 +597,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     }
     WG_SYNC();
 
-    UZ_TICK(0); // A
+    UZ_TICK(1); // A.rest
     int E = 0, S = 0, P = 0;
     bool exception = false;
     if (!a.no_extended) {
@@ -614,6 +615,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.hcanon[h] = c;
         }
         const int T = wg_exscan(s.h_off, nh, sh);
+        UZ_TICK(2); // B.het
         if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
         ar_reset(ar);
         ar_p(ar, s.reg_h, T + 1); ar_p(ar, s.reg_seg, T + 1); ar_p(ar, s.reg_pair, T + 1); ar_p(ar, s.cbase, T + 1);
@@ -631,7 +633,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.t_ov[t] = ov;
             s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
         }
+        UZ_TICK(3); // B.overlap
         (void)wg_exscan(s.t_pass, T, sh);
+        UZ_TICK(4); // B.scan1
         WG_FOR(t, T) {
             const int h = s.reg_h[t];
             const int seg = s.h_a[h] + (t - s.h_off[h]);
@@ -644,7 +648,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.t_ov[t] = ok;
             s.reg_pair[t] = ok; // scanned below: position in the registration list (reg_pair is free until phase S)
         }
+        UZ_TICK(5); // B.pair_ok
         E = wg_exscan(s.reg_pair, T, sh);
+        UZ_TICK(6); // B.scan2
         // compacting in place is unsafe across lanes: stage, then copy
         WG_FOR(t, T) {
             if (s.t_ov[t]) {
@@ -663,7 +669,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // a canonical site exists in site_reads once any of its duplicates registered a read (:217-218)
             if (s.sr_off[h + 1] > s.sr_off[h]) s.sr_exists[s.hcanon[h]] = 1;
         }
-        UZ_TICK(1); // B
+        UZ_TICK(7); // B.compact
         // ---- C: seeding (:226-249): matches of every init element among the het sites
         WG_FOR(m, nI) {
             const int seg = s.i_seg[m];
@@ -684,7 +690,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
         WG_SYNC();
     }
-    UZ_TICK(2); // C
+    UZ_TICK(8); // C
     // ---- S: pair table.  Keys (qname << 24 | seq): registrations seq < E, seeds, then one
     // presence entry per init element (seq >= E + S) so that every grouped pair has an id.
     const int M = E + S + nI;
@@ -714,6 +720,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
     }
     WG_SYNC();
+    UZ_TICK(9); // S.keys
     // Sort by (query-name id, sequence).  Name ids are interned in file order, so the names met
     // around one locus span a short id range: a counting sort over that range (stable order inside
     // a bucket restored by a tiny insertion sort) replaces the 60+ barrier stages of a bitonic sort.
@@ -758,13 +765,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         } else
             wg_sort64(s.keys, M, sh);
     }
-    UZ_TICK(3); // sort
+    UZ_TICK(10); // S.sort
     WG_FOR(x, M) {
         const int st = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
         s.srt_flag[x] = st;
         s.srt_pid[x] = st;
     }
     P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1
+    UZ_TICK(11); // P.scan
     WG_FOR(x, M) {
         const int pid = s.srt_pid[x] + s.srt_flag[x] - 1;
         s.srt_pid[x] = pid;
@@ -776,6 +784,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     }
     WG_T0 s.rs_off[P] = M;
     WG_SYNC();
+    UZ_TICK(12); // P.scatter
     WG_FOR(p, P) {
         const int x0 = s.rs_off[p], x1 = s.rs_off[p + 1];
         int len = 0, f0 = -1, f1 = -1;
@@ -804,7 +813,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     uz_emu_stats[0] += E; uz_emu_stats[1] += S; uz_emu_stats[2] += nI; uz_emu_stats[3] += P; uz_emu_stats[7] += nh; uz_emu_stats[8] += nc; uz_emu_stats[9]++;
     { int T_ = 0; if (!a.no_extended) T_ = s.h_off[nh]; uz_emu_stats[10] += T_; }
 #endif
-    UZ_TICK(4); // pair table
+    UZ_TICK(13); // P.pairs
     if (!a.no_extended) {
         // ---- D: static allele tables
         WG_FOR(x, M) {
@@ -820,6 +829,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             }
             s.srt_fb[x] = fbv;
         }
+        UZ_TICK(14); // D.finder
         WG_FOR(k, E) {
             uint8_t cb = 0;
             const int p = s.reg_pair[k];
@@ -831,7 +841,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.cbase[k] = cb;
         }
         WG_SYNC();
-        UZ_TICK(5); // D
+        UZ_TICK(15); // D.cbase
         // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
         int F = nI, cur = 0;
         {
@@ -884,11 +894,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 }
             }
             WG_SYNC();
+            UZ_TICK(16); // E.expand
             // winners in the order the reference appends them: "ref" targets by rank, then "alt"
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
             WG_FOR(p, P) s.o_flag[p] = (!s.assigned[p] && s.key[p] != ~0ULL) ? 1 : 0;
             const int W = wg_exscan(s.o_flag, P, sh);
+            UZ_TICK(17); // E.scan
             WG_FOR(p, P) {
                 if (!s.assigned[p] && s.key[p] != ~0ULL) {
                     const unsigned long long k = s.key[p];
@@ -926,10 +938,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
 #ifdef UZ_EMU_STATS
             uz_emu_stats[4]++; if (W > uz_emu_stats[5]) uz_emu_stats[5] = W; uz_emu_stats[6] += W;
 #endif
+            UZ_TICK(18); // E.frontier
             F = W;
             cur ^= 1;
         }
-        UZ_TICK(6); // E
+        UZ_TICK(19); // E.setup
         exception = s.misc[0] != 0;
     }
     WG_SYNC();
@@ -978,6 +991,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
     }
     WG_SYNC();
+    UZ_TICK(20); // F.join
     const int n_match = s.misc[1];
     WG_SYNC();
     if (n_match <= 0) {
@@ -1035,7 +1049,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             WG_SYNC();
         }
     }
-    UZ_TICK(7); // F
+    UZ_TICK(21); // F.count
     WG_T0 {
         a.status[d] = UZ_ST_OK;
         for (int k = 0; k < 4; k++) a.counts[4 * d + k] = cnt[k];
