@@ -83,6 +83,7 @@ struct Scr {
     int32_t *LR, *LA;
     int32_t *hpos, *hcanon, *h_a, *h_off, *sr_off;
     uint8_t *sr_exists;
+    uint8_t *href, *halt; // REF / ALT base of every het site of the DNM
     int32_t *cpos;
     uint32_t *cvote;
     int32_t *t_ov, *t_pass;
@@ -121,6 +122,7 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.LR, 2 * A); uz_carve(base, o, s.LA, 2 * A);
     uz_carve(base, o, s.hpos, H); uz_carve(base, o, s.hcanon, H); uz_carve(base, o, s.h_a, H);
     uz_carve(base, o, s.h_off, H); uz_carve(base, o, s.sr_off, H); uz_carve(base, o, s.sr_exists, H);
+    uz_carve(base, o, s.href, H); uz_carve(base, o, s.halt, H);
     uz_carve(base, o, s.cpos, C); uz_carve(base, o, s.cvote, C);
     uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T);
     uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
@@ -472,6 +474,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     ar_p(ar, s.cpos, nc + 1); ar_p(ar, s.cvote, nc + 1);
     ar_p(ar, s.hpos, nh + 1); ar_p(ar, s.hcanon, nh + 1); ar_p(ar, s.h_a, nh + 1);
     ar_p(ar, s.h_off, nh + 2); ar_p(ar, s.sr_off, nh + 2); ar_p(ar, s.sr_exists, nh + 1);
+    ar_p(ar, s.href, nh + 1); ar_p(ar, s.halt, nh + 1);
     WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
     (void)a.rcontig;
     const long long position = a.dstart[d];
@@ -483,7 +486,10 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
 
     UZ_TICK_INIT;
     WG_FOR(k, nc) { s.cpos[k] = a.spos[a.cand_idx[c0 + k]]; s.cvote[k] = 0; }
-    WG_FOR(k, nh) s.hpos[k] = a.spos[a.het_idx[h0 + k]];
+    WG_FOR(k, nh) {
+        const int si = a.het_idx[h0 + k];
+        s.hpos[k] = a.spos[si]; s.href[k] = a.sref[si]; s.halt[k] = a.salt[si];
+    }
 
     // ---- A: DNM reads -> ordered "ref" / "alt" lists (each hit contributes read, mate)
     const bool is_sv = a.vartype[d] != UZ_VT_POINT;
@@ -702,12 +708,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         ar_reset(ar);
         int mp2 = 2;
         while (mp2 < M) mp2 <<= 1;
-        ar_p(ar, s.keys, mp2 + 1); ar_p(ar, s.key, M + 1);
+        ar_p(ar, s.keys, mp2 + 1); ar_p(ar, s.key, mp2 + 1);
         ar_p(ar, s.srt_h, M + 1); ar_p(ar, s.srt_pid, M + 1); ar_p(ar, s.srt_fb, M + 1);
         ar_p(ar, s.rs_off, M + 2); ar_p(ar, s.rs_len, M + 1); ar_p(ar, s.fet0, M + 1); ar_p(ar, s.fet1, M + 1);
         ar_p(ar, s.grp, M + 1); ar_p(ar, s.pvote, M + 1); ar_p(ar, s.pq, M + 1); ar_p(ar, s.assigned, M + 1);
         ar_t(ar, s.srt_flag, M + 1);
     }
+    int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path)
     WG_FOR(x, M) {
         uint32_t q;
         if (x < E) q = R.qname[s.reg_seg[x]];
@@ -718,6 +725,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             q = R.qname[s.i_seg[lo]];
         } else q = R.qname[s.i_seg[x - E - S]];
         s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
+        lmin = (int)q < lmin ? (int)q : lmin;
+        lmax = (int)q > lmax ? (int)q : lmax;
     }
     WG_SYNC();
     UZ_TICK(9); // S.keys
@@ -726,16 +735,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     // a bucket restored by a tiny insertion sort) replaces the 60+ barrier stages of a bitonic sort.
     // Wider ranges fall back to the bitonic sort; both give the same array.
     {
-        WG_T0 { sh->bcast[1] = 0x7FFFFFFF; sh->bcast[2] = -1; }
-        WG_SYNC();
-        WG_FOR(x, M) {
-            const int q = (int)(s.keys[x] >> 24);
-            wg_atomic_min32(&sh->bcast[1], q);
-            wg_atomic_max32(&sh->bcast[2], q);
-        }
-        WG_SYNC();
-        const int qmin = sh->bcast[1], qrange = M > 0 ? sh->bcast[2] - sh->bcast[1] + 1 : 0;
-        WG_SYNC();
+        int qmin, qmax;
+        wg_minmax(lmin, lmax, qmin, qmax, sh);
+        const int qrange = M > 0 ? qmax - qmin + 1 : 0;
         if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
             ar_t(ar, s.q_cnt, qrange + 2); ar_t(ar, s.q_fill, qrange + 2);
             WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
@@ -760,8 +762,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 }
             }
             WG_SYNC();
-            WG_FOR(x, M) s.keys[x] = s.key[x];
-            WG_SYNC();
+            { unsigned long long *sorted = s.key; s.key = s.keys; s.keys = sorted; } // both hold mp2 + 1 entries
         } else
             wg_sort64(s.keys, M, sh);
     }
@@ -822,10 +823,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             if (h >= 0) {
                 const int p = s.srt_pid[x];
                 const uint8_t *al = s.fet0[p] >= 0 ? uz_allele_at(R, a.readlen, s.fet0[p], s.fet1[p], s.hpos[h], 1) : nullptr; // :91-96
-                if (al) {
-                    const int si = a.het_idx[h0 + h];
-                    if (*al == a.sref[si] || *al == a.salt[si]) fbv = *al; // :98-105
-                }
+                if (al && (*al == s.href[h] || *al == s.halt[h])) fbv = *al; // :98-105
             }
             s.srt_fb[x] = fbv;
         }
@@ -848,7 +846,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             ar_reset(ar);
             const size_t fr = (size_t)(P > nI ? P : nI) + 2;
             for (int k = 0; k < 2; k++) { ar_t(ar, s.fr_pair[k], fr); ar_t(ar, s.fr_pos[k], fr); ar_t(ar, s.fr_hap[k], fr); }
-            ar_t(ar, s.o_flag, P + 2);
         }
         WG_FOR(e, nI) {
             const int na = nae;
@@ -873,8 +870,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                     if (!fbv) continue;                          // :104-105
                     const int canon = s.hcanon[h];
                     if (!s.sr_exists[canon]) { s.misc[0] = 1; continue; } // :106 KeyError
-                    const int si = a.het_idx[h0 + h];
-                    const uint8_t nonf = fbv == a.sref[si] ? a.salt[si] : a.sref[si];
+                    const uint8_t nonf = fbv == s.href[h] ? s.halt[h] : s.href[h];
                     int hl = canon; // last het index of the run of equal positions
                     while (hl + 1 < nh && s.hpos[hl + 1] == s.hpos[canon]) hl++;
                     const int k0 = s.sr_off[canon], k1 = s.sr_off[hl + 1];
@@ -898,16 +894,23 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // winners in the order the reference appends them: "ref" targets by rank, then "alt"
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
-            WG_FOR(p, P) s.o_flag[p] = (!s.assigned[p] && s.key[p] != ~0ULL) ? 1 : 0;
-            const int W = wg_exscan(s.o_flag, P, sh);
-            UZ_TICK(17); // E.scan
-            WG_FOR(p, P) {
-                if (!s.assigned[p] && s.key[p] != ~0ULL) {
-                    const unsigned long long k = s.key[p];
-                    s.keys[s.o_flag[p]] = ((k & 1ULL) << 63) | (k >> 1);
+            int W;
+            {
+                int plo, phi, c1[1] = {0}, o1[1], t1[1];
+                wg_chunk(P, plo, phi);
+                for (int p = plo; p < phi; p++) c1[0] += (!s.assigned[p] && s.key[p] != ~0ULL) ? 1 : 0;
+                wg_lane_exscan<1>(c1, o1, t1, sh);
+                W = t1[0];
+                int o = o1[0];
+                for (int p = plo; p < phi; p++) {
+                    if (!s.assigned[p] && s.key[p] != ~0ULL) {
+                        const unsigned long long k = s.key[p];
+                        s.keys[o++] = ((k & 1ULL) << 63) | (k >> 1);
+                    }
                 }
             }
             WG_SYNC();
+            UZ_TICK(17); // E.scan
             // position in the next frontier = rank of the (target, rank) key among the winners: counted
             // directly while a level has few winners (one barrier), sorted otherwise
             const bool by_count = W <= 96;
@@ -926,12 +929,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 s.fr_pair[cur ^ 1][posn] = p;
                 s.fr_pos[cur ^ 1][posn] = s.hpos[h];
                 s.fr_hap[cur ^ 1][posn] = (uint8_t)(ok >> 63);
-            }
-            WG_SYNC();
-            WG_FOR(w, W) {
-                const int p = s.fr_pair[cur ^ 1][w];
+                // every winner key names a different pair: mark it here
                 s.assigned[p] = 1;
-                s.grp[p] |= s.fr_hap[cur ^ 1][w] ? 2u : 1u;
+                s.grp[p] |= (ok >> 63) ? 2u : 1u;
                 s.key[p] = ~0ULL;
             }
             WG_SYNC();
@@ -954,8 +954,6 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     // ---- F: join + vote.  Items: extended -> both fetched segments of every grouped pair per
     // haplotype (:254-263); --no-extended -> the init list elements themselves.
     ar_reset(ar);
-    s.o_flag = sg.o_flag;
-    ar_t(ar, s.o_flag, (size_t)(P > nc ? P : nc) + 2);
     const int n_items = a.no_extended ? nI : 4 * P;
     WG_FOR(it, n_items) {
         int seg, hb, p;
@@ -998,55 +996,62 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         WG_T0 a.status[d] = UZ_ST_NO_OVERLAP; // snv_phaser.py:158-166
         return;
     }
-    // unique positions: fold the votes of records sharing a position onto the first of the run
-    WG_FOR(ci, nc) {
-        if (ci == 0 || s.cpos[ci - 1] != s.cpos[ci]) {
-            uint32_t v = 0;
-            for (int k = ci; k < nc && s.cpos[k] == s.cpos[ci]; k++) v |= s.cvote[k];
-            s.o_flag[ci] = (int)v;
-        } else s.o_flag[ci] = 0;
-    }
-    WG_SYNC();
-    WG_FOR(ci, nc) s.cvote[ci] = (uint32_t)s.o_flag[ci];
-    WG_SYNC();
-    // counts (and optional lists) through four flag scans; pairs are in ascending qname order
+    // unique positions: the votes of records sharing a position count once, at the first of the run
+    auto cvote_at = [&](int ci) -> uint32_t {
+        if (ci > 0 && s.cpos[ci - 1] == s.cpos[ci]) return 0u;
+        uint32_t v = 0;
+        for (int k = ci; k < nc && s.cpos[k] == s.cpos[ci]; k++) v |= s.cvote[k];
+        return v;
+    };
+    // counts (and optional lists): a lane owns one contiguous slice of the pairs and one of the
+    // candidates, so a single six-way scan ACROSS LANES yields every list offset; pairs are in
+    // ascending qname order, candidates in position order, and slices keep that order
     int cnt[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        const int n = k < 2 ? P : (k < 4 ? nc : P);
-        int32_t *fl = s.o_flag;
-        WG_FOR(i, n) {
-            int v;
-            if (k < 2) v = (s.pvote[i] >> k) & 1;
-            else if (k < 4) v = (s.cvote[i] >> (k - 2)) & 1;
-            else v = (s.grp[i] >> (k - 4)) & 1;
-            fl[i] = v;
+    {
+        int plo, phi, clo, chi;
+        wg_chunk(P, plo, phi);
+        wg_chunk(nc, clo, chi);
+        int c6[6] = {0, 0, 0, 0, 0, 0}, off[6], tot[6];
+        for (int i = plo; i < phi; i++) {
+            const uint32_t v = s.pvote[i], g = s.grp[i];
+            c6[0] += (int)(v & 1u); c6[1] += (int)((v >> 1) & 1u);
+            c6[4] += (int)(g & 1u); c6[5] += (int)((g >> 1) & 1u);
         }
-        cnt[k] = (k < 4 || a.want_lists) ? wg_exscan(fl, n, sh) : 0;
+        for (int i = clo; i < chi; i++) {
+            const uint32_t v = cvote_at(i);
+            c6[2] += (int)(v & 1u); c6[3] += (int)((v >> 1) & 1u);
+        }
+        wg_lane_exscan<6>(c6, off, tot, sh);
+#pragma unroll
+        for (int k = 0; k < 6; k++) cnt[k] = (k < 4 || a.want_lists) ? tot[k] : 0;
         if (a.want_lists) {
-            // one bump allocation per DNM, made when the first list is known: reserve the upper bound 2P + 2nc + 2P
-            if (k == 0) {
-                WG_T0 {
-                    const unsigned long long need = (unsigned long long)(4 * P + 2 * nc);
-                    const unsigned long long at = wg_atomic_add64(a.pool_cursor, need);
-                    a.list_start[d] = (at + need <= a.pool_cap) ? (long long)at : -1;
-                }
-                WG_SYNC();
+            // one bump allocation per DNM: the upper bound 2P + 2nc + 2P
+            WG_T0 {
+                const unsigned long long need = (unsigned long long)(4 * P + 2 * nc);
+                const unsigned long long at = wg_atomic_add64(a.pool_cursor, need);
+                a.list_start[d] = (at + need <= a.pool_cap) ? (long long)at : -1;
+                for (int k = 0; k < 6; k++) a.list_len[6 * d + k] = cnt[k];
             }
+            WG_SYNC();
             const long long base = a.list_start[d];
             if (base >= 0) {
-                long long off = base;
-                for (int kk = 0; kk < k; kk++) off += cnt[kk];
-                WG_FOR(i, n) {
-                    int v;
-                    if (k < 2) v = (s.pvote[i] >> k) & 1;
-                    else if (k < 4) v = (s.cvote[i] >> (k - 2)) & 1;
-                    else v = (s.grp[i] >> (k - 4)) & 1;
-                    if (v) a.pool[off + fl[i]] = (k < 2 || k >= 4) ? (int32_t)s.pq[i] : s.cpos[i];
+                long long o[6], run = base;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { o[k] = run + off[k]; run += tot[k]; }
+                for (int i = plo; i < phi; i++) {
+                    const uint32_t v = s.pvote[i], g = s.grp[i];
+                    const int32_t name = (int32_t)s.pq[i];
+                    if (v & 1u) a.pool[o[0]++] = name;
+                    if (v & 2u) a.pool[o[1]++] = name;
+                    if (g & 1u) a.pool[o[4]++] = name;
+                    if (g & 2u) a.pool[o[5]++] = name;
+                }
+                for (int i = clo; i < chi; i++) {
+                    const uint32_t v = cvote_at(i);
+                    if (v & 1u) a.pool[o[2]++] = s.cpos[i];
+                    if (v & 2u) a.pool[o[3]++] = s.cpos[i];
                 }
             }
-            WG_T0 a.list_len[6 * d + k] = cnt[k];
-            WG_SYNC();
         }
     }
     UZ_TICK(21); // F.count

@@ -97,6 +97,84 @@ UZ_DEV int wg_exscan(int *a, int n, WgShared *sh) {
 #endif
 }
 
+// Lane-chunk helpers: lane t of the workgroup owns the contiguous slice [lo, hi) of 0..n.
+UZ_DEV void wg_chunk(int n, int &lo, int &hi) {
+#ifdef UZ_EMU
+    lo = 0; hi = n;
+#else
+    const int chunk = (n + WG_NT - 1) / WG_NT;
+    lo = (int)threadIdx.x * chunk; if (lo > n) lo = n;
+    hi = lo + chunk; if (hi > n) hi = n;
+#endif
+}
+
+// Exclusive scan ACROSS LANES of K per-lane values at once (one pair of barriers for all K):
+// off[k] = sum of c[k] over lower lanes, tot[k] = sum over all lanes.  Block-uniform call.
+template <int K>
+UZ_DEV void wg_lane_exscan(const int (&c)[K], int (&off)[K], int (&tot)[K], WgShared *sh) {
+#ifdef UZ_EMU
+    for (int k = 0; k < K; k++) { off[k] = 0; tot[k] = c[k]; }
+#else
+    static_assert(K * (WG_NT / 64) <= WG_NT + 1, "part[] too small");
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int incl[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        int v = c[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
+        }
+        incl[k] = v;
+    }
+    __syncthreads(); // part[] may still be read by a previous scan
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < K; k++) sh->part[k * (WG_NT / 64) + wv] = incl[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        int pre = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < WG_NT / 64; w++) {
+            const int v = sh->part[k * (WG_NT / 64) + w];
+            if (w < wv) pre += v;
+            all += v;
+        }
+        off[k] = pre + incl[k] - c[k];
+        tot[k] = all;
+    }
+#endif
+}
+
+// Block-wide minimum and maximum of per-lane partial results (two barriers, no atomics).
+UZ_DEV void wg_minmax(int lmin, int lmax, int &mn, int &mx, WgShared *sh) {
+#ifdef UZ_EMU
+    mn = lmin; mx = lmax;
+#else
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(lmin, o, 64), b = __shfl_xor(lmax, o, 64);
+        lmin = a < lmin ? a : lmin;
+        lmax = b > lmax ? b : lmax;
+    }
+    __syncthreads();
+    if (lane == 0) { sh->part[wv] = lmin; sh->part[WG_NT / 64 + wv] = lmax; }
+    __syncthreads();
+    mn = sh->part[0]; mx = sh->part[WG_NT / 64];
+#pragma unroll
+    for (int w = 1; w < WG_NT / 64; w++) {
+        const int a = sh->part[w], b = sh->part[WG_NT / 64 + w];
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __syncthreads();
+#endif
+}
+
 // Ascending sort of a[0..n) (distinct keys).  a must have room for the next power of two.
 UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh) {
 #ifdef UZ_EMU
