@@ -84,6 +84,7 @@ struct Scr {
     int32_t *hpos, *hcanon, *h_a, *h_off, *sr_off;
     uint8_t *sr_exists;
     uint8_t *href, *halt; // REF / ALT base of every het site of the DNM
+    uint32_t *site_best;  // chaining: first frontier element (e << 12 | j) finding an allele at a het index
     int32_t *cpos;
     uint32_t *cvote;
     int32_t *t_ov, *t_pass;
@@ -122,7 +123,7 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.LR, 2 * A); uz_carve(base, o, s.LA, 2 * A);
     uz_carve(base, o, s.hpos, H); uz_carve(base, o, s.hcanon, H); uz_carve(base, o, s.h_a, H);
     uz_carve(base, o, s.h_off, H); uz_carve(base, o, s.sr_off, H); uz_carve(base, o, s.sr_exists, H);
-    uz_carve(base, o, s.href, H); uz_carve(base, o, s.halt, H);
+    uz_carve(base, o, s.href, H); uz_carve(base, o, s.halt, H); uz_carve(base, o, s.site_best, H);
     uz_carve(base, o, s.cpos, C); uz_carve(base, o, s.cvote, C);
     uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T);
     uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
@@ -474,7 +475,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     ar_p(ar, s.cpos, nc + 1); ar_p(ar, s.cvote, nc + 1);
     ar_p(ar, s.hpos, nh + 1); ar_p(ar, s.hcanon, nh + 1); ar_p(ar, s.h_a, nh + 1);
     ar_p(ar, s.h_off, nh + 2); ar_p(ar, s.sr_off, nh + 2); ar_p(ar, s.sr_exists, nh + 1);
-    ar_p(ar, s.href, nh + 1); ar_p(ar, s.halt, nh + 1);
+    ar_p(ar, s.href, nh + 1); ar_p(ar, s.halt, nh + 1); ar_p(ar, s.site_best, nh + 1);
     WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
     (void)a.rcontig;
     const long long position = a.dstart[d];
@@ -856,44 +857,56 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
         WG_SYNC();
         WG_FOR(p, P) if (s.grp[p]) s.assigned[p] = 1;
+        WG_FOR(h, nh) s.site_best[h] = 0xFFFFFFFFu;
         WG_SYNC();
         while (F > 0) {
+            // (i) per het index, the first frontier element (in visiting order e, then read_sites
+            // index j) that finds a usable allele there.  Every element finding REF or ALT at a het
+            // index claims the same entries of its site_reads list, so only that first one can win.
             WG_FOR(e, F) {
                 const int p = s.fr_pair[cur][e];
                 const int fpos = s.fr_pos[cur][e];
-                const int hap = s.fr_hap[cur][e];
                 const int x0 = s.rs_off[p], len = s.rs_len[p];
                 for (int j = 0; j < len; j++) {
                     const int h = s.srt_h[x0 + j];
                     if (s.hpos[h] == fpos) continue;            // :89-90
-                    const uint8_t fbv = s.srt_fb[x0 + j];
-                    if (!fbv) continue;                          // :104-105
-                    const int canon = s.hcanon[h];
-                    if (!s.sr_exists[canon]) { s.misc[0] = 1; continue; } // :106 KeyError
-                    const uint8_t nonf = fbv == s.href[h] ? s.halt[h] : s.href[h];
-                    int hl = canon; // last het index of the run of equal positions
-                    while (hl + 1 < nh && s.hpos[hl + 1] == s.hpos[canon]) hl++;
-                    const int k0 = s.sr_off[canon], k1 = s.sr_off[hl + 1];
-                    for (int k = k0; k < k1; k++) {
-                        const int p2 = s.reg_pair[k];
-                        if (s.assigned[p2]) continue;            // :108-110 (assigned before this level)
-                        const uint8_t cb = s.cbase[k];
-                        if (!cb) continue;
-                        int target;
-                        if (cb == fbv) target = hap;             // :134-136
-                        else if (cb == nonf) target = hap ^ 1;   // :137-141
-                        else continue;
-                        const unsigned long long key =
-                            ((((unsigned long long)e << 12 | (unsigned long long)j) << 20 | (unsigned long long)(k - k0)) << 1) | (unsigned long long)target;
-                        wg_atomic_min64(&s.key[p2], key);
-                    }
+                    if (!s.srt_fb[x0 + j]) continue;             // :104-105
+                    if (!s.sr_exists[s.hcanon[h]]) { s.misc[0] = 1; continue; } // :106 KeyError
+                    wg_atomic_min32u(&s.site_best[h], ((uint32_t)e << 12) | (uint32_t)j);
                 }
+            }
+            WG_SYNC();
+            // (ii) every still-unassigned registration looks up the finder(s) of its site
+            WG_FOR(k, E) {
+                const int p2 = s.reg_pair[k];
+                if (s.assigned[p2]) continue;                    // :108-110 (assigned before this level)
+                const uint8_t cb = s.cbase[k];
+                if (!cb) continue;
+                const int canon = s.hcanon[s.reg_h[k]];
+                const int krel = k - s.sr_off[canon];
+                unsigned long long best = ~0ULL;
+                for (int h = canon; h < nh && s.hpos[h] == s.hpos[canon]; h++) { // het indices sharing the position
+                    const uint32_t b = s.site_best[h];
+                    if (b == 0xFFFFFFFFu) continue;
+                    const int e = (int)(b >> 12), j = (int)(b & 0xFFFu);
+                    const uint8_t fbv = s.srt_fb[s.rs_off[s.fr_pair[cur][e]] + j];
+                    const uint8_t nonf = fbv == s.href[h] ? s.halt[h] : s.href[h];
+                    const int hap = s.fr_hap[cur][e];
+                    int target;
+                    if (cb == fbv) target = hap;                 // :134-136
+                    else if (cb == nonf) target = hap ^ 1;       // :137-141
+                    else continue;
+                    const unsigned long long key = ((((unsigned long long)b) << 20 | (unsigned long long)krel) << 1) | (unsigned long long)target;
+                    best = key < best ? key : best;
+                }
+                if (best != ~0ULL) wg_atomic_min64(&s.key[p2], best);
             }
             WG_SYNC();
             UZ_TICK(16); // E.expand
             // winners in the order the reference appends them: "ref" targets by rank, then "alt"
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
+            WG_FOR(h, nh) s.site_best[h] = 0xFFFFFFFFu; // for the next level
             int W;
             {
                 int plo, phi, c1[1] = {0}, o1[1], t1[1];
