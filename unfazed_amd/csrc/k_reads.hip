@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
 }
 
 #ifndef UZ_PHASE_MIN_WAVES
-#define UZ_PHASE_MIN_WAVES 1
+#define UZ_PHASE_MIN_WAVES 4 // <= 128 VGPRs: four waves per SIMD, the occupancy the LDS arena allows anyway
 #endif
 __global__ __launch_bounds__(WG_NT, UZ_PHASE_MIN_WAVES) void k_phase(PhaseArgs a) {
     __shared__ WgShared sh;

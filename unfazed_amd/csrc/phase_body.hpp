@@ -736,10 +736,17 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     // a bucket restored by a tiny insertion sort) replaces the 60+ barrier stages of a bitonic sort.
     // Wider ranges fall back to the bitonic sort; both give the same array.
     {
-        int qmin, qmax;
-        wg_minmax(lmin, lmax, qmin, qmax, sh);
-        const int qrange = M > 0 ? qmax - qmin + 1 : 0;
-        if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
+        int qmin = -1, qmax = -1, qrange = 0;
+        // keys that sit in the LDS arena sort fastest in place (bitonic, ~45 short stages for 512 keys);
+        // the counting sort walks the whole id range, which lives in HBM scratch
+        const bool keys_in_lds = (uint8_t *)s.keys >= ar.base && (uint8_t *)s.keys < ar.base + ar.cap;
+        const bool small = keys_in_lds && M <= 4 * WG_NT;
+        if (!small) { // block-uniform
+            wg_minmax(lmin, lmax, qmin, qmax, sh);
+            qrange = M > 0 ? qmax - qmin + 1 : 0;
+        }
+        if (small || (keys_in_lds && M <= 1024)) wg_sort64(s.keys, M, sh, true);
+        else if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
             ar_t(ar, s.q_cnt, qrange + 2); ar_t(ar, s.q_fill, qrange + 2);
             WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
             WG_SYNC();
@@ -817,29 +824,43 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
 #endif
     UZ_TICK(13); // P.pairs
     if (!a.no_extended) {
-        // ---- D: static allele tables
+        // ---- D: static allele tables.  One pass over the sorted entries: the pair-level finder allele
+        // at the entry's het site (get_allele_at, :91-105) and, for registrations, the base the
+        // pair's primary segment shows there (:114-124).  Both start from the same index into the
+        // primary segment, computed once.
         WG_FOR(x, M) {
-            uint8_t fbv = 0;
+            uint8_t fbv = 0, cb = 0;
             const int h = s.srt_h[x];
+            const int seq = (int)(s.keys[x] & 0xFFFFFF);
             if (h >= 0) {
                 const int p = s.srt_pid[x];
-                const uint8_t *al = s.fet0[p] >= 0 ? uz_allele_at(R, a.readlen, s.fet0[p], s.fet1[p], s.hpos[h], 1) : nullptr; // :91-96
-                if (al && (*al == s.href[h] || *al == s.halt[h])) fbv = *al; // :98-105
+                const int f0 = s.fet0[p];
+                if (f0 >= 0) {
+                    const long long hp = s.hpos[h];
+                    const int i = uz_qidx(R, f0, hp);
+                    if (i >= 0) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
+                        if (i >= 4 && i <= a.readlen - 4 && (int)R.l_seq[f0] > i + 1) {
+                            const uint8_t al = uz_seq(R, f0)[i];
+                            if (al == s.href[h] || al == s.halt[h]) fbv = al; // :98-105
+                            if (seq < E && (int)uz_qual(R, f0)[i] >= a.min_gt_qual) cb = al; // :114-124
+                        }
+                    } else {
+                        const int f1 = s.fet1[p];
+                        if (f1 >= 0) {
+                            const int j = uz_qidx(R, f1, hp);
+                            if (j >= 4 && j <= a.readlen - 4 && (int)R.l_seq[f1] > j + 1) {
+                                const uint8_t al = uz_seq(R, f1)[j];
+                                if (al == s.href[h] || al == s.halt[h]) fbv = al;
+                            }
+                        }
+                    }
+                }
             }
             s.srt_fb[x] = fbv;
-        }
-        UZ_TICK(14); // D.finder
-        WG_FOR(k, E) {
-            uint8_t cb = 0;
-            const int p = s.reg_pair[k];
-            const int prim = s.fet0[p];
-            const long long hp = s.hpos[s.reg_h[k]];
-            const int rp = uz_qidx(R, prim, hp); // :114-124 -- the primary segment must cover the site
-            if (rp >= 4 && rp <= a.readlen - 4 && (int)R.l_seq[prim] > rp + 1 && (int)uz_qual(R, prim)[rp] >= a.min_gt_qual)
-                cb = uz_seq(R, prim)[rp];
-            s.cbase[k] = cb;
+            if (seq < E) s.cbase[seq] = cb;
         }
         WG_SYNC();
+        UZ_TICK(14); // D.finder
         UZ_TICK(15); // D.cbase
         // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
         int F = nI, cur = 0;

@@ -178,23 +178,11 @@ UZ_DEV void wg_minmax(int lmin, int lmax, int &mn, int &mx, WgShared *sh) {
 }
 
 // Ascending sort of a[0..n) (distinct keys).  a must have room for the next power of two.
-UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh) {
-#ifdef UZ_EMU
-    std::sort(a, a + n);
-#else
-    __syncthreads();
-    if (n <= 1) return;
-    int N = 1;
-    while (N < n) N <<= 1;
-    unsigned long long *w = a;
-    const bool in_lds = N <= WG_SORT_LDS_CAP;
-    if (in_lds) {
-        w = sh->sortbuf;
-        for (int i = threadIdx.x; i < N; i += WG_NT) w[i] = i < n ? a[i] : ~0ULL;
-    } else {
-        for (int i = n + (int)threadIdx.x; i < N; i += WG_NT) w[i] = ~0ULL;
-    }
-    __syncthreads();
+// a_in_lds: the caller knows a[] lies in the workgroup's LDS arena; the stages then run on an
+// LDS-typed pointer (ds_read/ds_write) instead of flat accesses.
+#ifndef UZ_EMU
+template <typename P>
+UZ_DEV void wg_bitonic_stages(P w, int N) {
     for (int k = 2; k <= N; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < N; i += WG_NT) {
@@ -208,9 +196,83 @@ UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh) {
             __syncthreads();
         }
     }
-    if (in_lds) {
-        for (int i = threadIdx.x; i < n; i += WG_NT) a[i] = w[i];
-        __syncthreads();
+}
+#endif
+#ifndef UZ_EMU
+// Bitonic sort with the keys held in registers: lane t owns elements t + WG_NT * r.  Partners at
+// distance >= WG_NT are other registers of the same lane, partners at distance < 64 are reached by a
+// wave shuffle; only the distances in between (64 for a 128-lane workgroup) go through LDS and a
+// barrier.  buf: LDS, N entries.  N = R * WG_NT.
+template <int R>
+UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) unsigned long long *buf, unsigned long long *a, int n) {
+    const int t = threadIdx.x;
+    unsigned long long v[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int i = t + WG_NT * r; v[r] = i < n ? a[i] : ~0ULL; }
+    const int N = R * WG_NT;
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int rr = R / 2; rr >= 1; rr >>= 1) {
+            if (rr * WG_NT < k) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (!(r & rr)) {
+                        const bool up = ((t + WG_NT * r) & k) == 0;
+                        const unsigned long long x = v[r], y = v[r | rr];
+                        if ((x > y) == up) { v[r] = y; v[r | rr] = x; }
+                    }
+                }
+            }
+        }
+        for (int j = (k >> 1) < (WG_NT >> 1) ? (k >> 1) : (WG_NT >> 1); j >= 64; j >>= 1) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; r++) buf[t + WG_NT * r] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned long long y = buf[(t ^ j) + WG_NT * r];
+                const bool up = ((t + WG_NT * r) & k) == 0, lower = (t & j) == 0;
+                const unsigned long long x = v[r];
+                v[r] = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
+            }
+        }
+        for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const unsigned long long x = v[r];
+                const unsigned long long y = __shfl_xor(x, j, 64);
+                const bool up = ((t + WG_NT * r) & k) == 0, lower = (t & j) == 0;
+                v[r] = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
+            }
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; r++) { const int i = t + WG_NT * r; if (i < n) a[i] = v[r]; }
+    __syncthreads();
+}
+#endif
+UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh, bool a_in_lds = false) {
+#ifdef UZ_EMU
+    (void)sh; (void)a_in_lds;
+    std::sort(a, a + n);
+#else
+    typedef __attribute__((address_space(3))) unsigned long long *lds_u64;
+    __syncthreads();
+    if (n <= 1) return;
+    int N = 1;
+    while (N < n) N <<= 1;
+    if (N <= WG_SORT_LDS_CAP || (a_in_lds && N <= 4 * WG_NT)) { // 8 keys per lane would push the kernel past 128 VGPRs
+        lds_u64 buf = N <= WG_SORT_LDS_CAP ? (lds_u64)sh->sortbuf : (lds_u64)a;
+        if (N <= WG_NT) wg_bitonic_regs<1>(buf, a, n);
+        else if (N <= 2 * WG_NT) wg_bitonic_regs<2>(buf, a, n);
+        else wg_bitonic_regs<4>(buf, a, n);
+        return;
+    }
+    for (int i = n + (int)threadIdx.x; i < N; i += WG_NT) a[i] = ~0ULL;
+    __syncthreads();
+    if (a_in_lds) wg_bitonic_stages((lds_u64)a, N);
+    else wg_bitonic_stages(a, N);
 #endif
 }
