@@ -47,7 +47,11 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 2;
     for (int d = 0; d < D->n; d++) {
         int32_t b[5];
-        uz_phase_bounds(a, d, b);
+        long long tp = 0;
+        int mhp = 0;
+        uz_phase_bounds(a, d, b, 0, 1, tp, mhp);
+        b[1] = (int32_t)(tp > 0x7FFFFFF0LL ? 0x7FFFFFF0LL : tp);
+        b[4] = mhp;
         if (b[0] > mA) mA = b[0];
         if (b[1] > mT) mT = b[1];
         if (b[2] > mH) mH = b[2];

@@ -153,9 +153,25 @@ __global__ __launch_bounds__(256) void k_mark_ranges(const int32_t *__restrict__
     }
 }
 
+// one 16-lane group per DNM (a DNM has about ten het sites, each costing two binary searches)
 __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d < a.n) uz_phase_bounds(a, d, bounds + 5 * (size_t)d);
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 15;
+    const int d = g < a.n ? (int)g : a.n - 1; // whole groups stay converged for the shuffles below
+    long long tp = 0;
+    int mh = 0;
+    int32_t *b = bounds + 5 * (size_t)d;
+    if (g < a.n) uz_phase_bounds(a, d, b, lane, 16, tp, mh);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        tp += __shfl_xor(tp, o, 16);
+        const int m2 = __shfl_xor(mh, o, 16);
+        mh = m2 > mh ? m2 : mh;
+    }
+    if (g < a.n && lane == 0) {
+        b[1] = (int32_t)(tp > 0x7FFFFFF0LL ? 0x7FFFFFF0LL : tp);
+        b[4] = mh;
+    }
 }
 
 #ifndef UZ_PHASE_MIN_WAVES
@@ -263,7 +279,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     UZ_HIP(hipMemsetAsync(st->pre_ha.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
     UZ_HIP(hipMemsetAsync(st->pre_hl.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
     {
-        const unsigned nb = (unsigned)((n + 255) / 256);
+        const unsigned nb = (unsigned)(((int64_t)n * 16 + 255) / 256);
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
         UZ_HIP(hipGetLastError());
     }

@@ -347,29 +347,47 @@ __global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32
     if (!FILL) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
 }
 
-// exclusive scan of two count arrays into int64 offsets (n+1 entries); one workgroup
+// exclusive scan of two count arrays into int64 offsets (n+1 entries); one workgroup walks the
+// arrays in tiles of 4096 counts (coalesced 16-byte loads, wave-shuffle scan, int64 carry)
 __global__ __launch_bounds__(1024) void k_scan2(int32_t n, const int32_t *c0, const int32_t *c1, int64_t *o0, int64_t *o1) {
-    __shared__ int64_t part[2][1024];
-    const int t = threadIdx.x, nt = blockDim.x;
-    const int32_t chunk = (n + nt - 1) / nt;
-    const int32_t lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
-    int64_t s0 = 0, s1 = 0;
-    for (int32_t i = lo; i < hi; i++) { s0 += c0[i]; s1 += c1[i]; }
-    part[0][t] = s0; part[1][t] = s1;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {
-        int64_t a0 = 0, a1 = 0;
-        if (t >= off) { a0 = part[0][t - off]; a1 = part[1][t - off]; }
+    __shared__ int wsum[2][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int64_t carry0 = 0, carry1 = 0;
+    for (int32_t base = 0; base < n; base += 4096) {
+        const int32_t i0 = base + 4 * t;
+        int v0[4] = {0, 0, 0, 0}, v1[4] = {0, 0, 0, 0};
+        if (i0 + 3 < n) {
+            const int4 a = *reinterpret_cast<const int4 *>(c0 + i0), b = *reinterpret_cast<const int4 *>(c1 + i0);
+            v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v0[3] = a.w;
+            v1[0] = b.x; v1[1] = b.y; v1[2] = b.z; v1[3] = b.w;
+        } else {
+            for (int k = 0; k < 4; k++) if (i0 + k < n) { v0[k] = c0[i0 + k]; v1[k] = c1[i0 + k]; }
+        }
+        const int s0 = v0[0] + v0[1] + v0[2] + v0[3], s1 = v1[0] + v1[1] + v1[2] + v1[3];
+        int in0 = s0, in1 = s1;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u0 = __shfl_up(in0, off, 64), u1 = __shfl_up(in1, off, 64);
+            if (lane >= off) { in0 += u0; in1 += u1; }
+        }
+        __syncthreads(); // wsum of the previous tile has been read
+        if (lane == 63) { wsum[0][wv] = in0; wsum[1][wv] = in1; }
         __syncthreads();
-        part[0][t] += a0; part[1][t] += a1;
-        __syncthreads();
+        int64_t p0 = carry0, p1 = carry1, t0 = 0, t1 = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int a = wsum[0][w], b = wsum[1][w];
+            if (w < wv) { p0 += a; p1 += b; }
+            t0 += a; t1 += b;
+        }
+        p0 += in0 - s0; p1 += in1 - s1;
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < n) { o0[i0 + k] = p0; o1[i0 + k] = p1; }
+            p0 += v0[k]; p1 += v1[k];
+        }
+        carry0 += t0; carry1 += t1;
     }
-    int64_t r0 = part[0][t] - s0, r1 = part[1][t] - s1; // exclusive prefix of this thread's chunk
-    for (int32_t i = lo; i < hi; i++) {
-        o0[i] = r0; o1[i] = r1;
-        r0 += c0[i]; r1 += c1[i];
-    }
-    if (t == nt - 1) { o0[n] = part[0][t]; o1[n] = part[1][t]; }
+    if (t == 0) { o0[n] = carry0; o1[n] = carry1; }
 }
 
 SiteParams make_site_params(const uz_params &p) {

@@ -1105,48 +1105,53 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
 //   b[0] records in the DNM fetch range, b[1] sum of the het-site fetch ranges, b[2] het sites,
 //   b[3] candidates, b[4] max het sites inside any window of max_span+1 bases (bounds the
 //   seeding matches of one init element).
-UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b) {
+// Lanes lane, lane + nlanes, ... share the het sites of DNM d; lane 0 also does the per-DNM part.
+// The caller reduces (t_part: sum, mh_part: max) over the lanes and stores them as b[1], b[4].
+UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part) {
     const RD &R = a.R;
     const long long h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - h0);
-    b[0] = b[1] = b[4] = 0;
-    b[2] = nh; b[3] = nc;
-    for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
+    t_part = 0; mh_part = 0;
+    if (lane == 0) {
+        b[0] = b[1] = b[4] = 0;
+        b[2] = nh; b[3] = nc;
+        for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
+    }
     if (nc <= 0) return;
     const int tid = a.rcontig[d];
-    const long long position = a.dstart[d];
-    const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
-    long long wa, wb, fa, fb;
+    long long wa, wb;
     uz_dnm_window(a, d, wa, wb);
-    uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
-    long long fa2 = 0, fb2 = 0;
-    if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
-        const long long icut = (long long)a.cutoff;
-        long long lo = (long long)a.dstart[d] - icut;
-        if (lo < 0) lo = 0;
-        uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);
-        lo = (long long)a.dend[d] - icut;
-        if (lo < 0) lo = 0;
-        uz_fetch_range(R, tid, lo, (long long)a.dend[d] + icut, fa2, fb2);
+    if (lane == 0) {
+        const long long position = a.dstart[d];
+        const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
+        long long fa, fb;
+        uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
+        long long fa2 = 0, fb2 = 0;
+        if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
+            const long long icut = (long long)a.cutoff;
+            long long lo = (long long)a.dstart[d] - icut;
+            if (lo < 0) lo = 0;
+            uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);
+            lo = (long long)a.dend[d] - icut;
+            if (lo < 0) lo = 0;
+            uz_fetch_range(R, tid, lo, (long long)a.dend[d] + icut, fa2, fb2);
+        }
+        b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
+        a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
+        a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
     }
-    b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
-    a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
-    a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
     if (a.no_extended) return;
-    long long T = 0;
     const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;
-    int mh = 0, left = 0;
-    for (int h = 0; h < nh; h++) {
+    for (int h = lane; h < nh; h += nlanes) {
         const long long hp = a.spos[a.het_idx[h0 + h]];
         long long ha, hb;
         uz_fetch_range_in(R, tid, wa, wb, hp, hp + 1, ha, hb);
         a.pre_ha[h0 + h] = (int32_t)ha; a.pre_hl[h0 + h] = (int32_t)(hb - ha);
-        T += hb - ha;
-        while ((long long)a.spos[a.het_idx[h0 + left]] < hp - span - 1) left++;
-        if (h - left + 1 > mh) mh = h - left + 1;
+        t_part += hb - ha;
+        int left = h; // first het site (the list is sorted) a record ending at hp could still reach back to
+        while (left > 0 && (long long)a.spos[a.het_idx[h0 + left - 1]] >= hp - span - 1) left--;
+        if (h - left + 1 > mh_part) mh_part = h - left + 1;
     }
-    b[1] = (int32_t)(T > 0x7FFFFFF0LL ? 0x7FFFFFF0LL : T);
-    b[4] = mh;
 }
 
 // per-segment QC bits (K3a): goodread (:28-53) and the two CIGAR counts of :190-203, given the
