@@ -1,0 +1,96 @@
+/* unfazed_io.h -- C ABI of the native input decoders (host only, no GPU needed).
+ *
+ * "native decode throughput".  These entry points replace what the
+ * reference obtains from pysam / cyvcf2 on the way INTO the hot path:
+ *
+ *   uz_bam_decode      pysam.AlignmentFile(bam) + the per-read accessors used in
+ *                      unfazed/read_collector.py:11-25 (first tlen values), :372-392 (open, fetch),
+ *                      :28-53 / :56-73 / :394-425 (flag, mapq, cigar, sequence, qualities, SA tag)
+ *                      and bamfile.mate(read) (:402, :186, :509).  One multi-threaded pass turns the
+ *                      whole BGZF file into the column table `uz_reads_upload` takes
+ *                      (include/unfazed_hip.h), so region fetches and mate look-ups become index
+ *                      arithmetic on the device.
+ *   uz_vcf_decode      cyvcf2.VCF(sites) + Variant.start/end/REF/ALT/gt_types/gt_ref_depths/
+ *                      gt_alt_depths/gt_quals (unfazed/informative_site_finder.py:213-339, :571-600):
+ *                      text VCF (plain or gzip/bgzip) -> site columns for all samples.
+ *
+ * Error convention: 0 = success, negative = failure with a message in uz_io_last_error()
+ * (thread local).  Nothing is written to stdout / stderr.  Handles own their memory; the views they
+ * hand out stay valid until the handle is freed.
+ */
+#ifndef UNFAZED_IO_H
+#define UNFAZED_IO_H
+#include <stdint.h>
+#include "uz_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UZ_IO_OK 0
+#define UZ_IO_E_OPEN (-1)     /* file missing / unreadable */
+#define UZ_IO_E_FORMAT (-2)   /* not BGZF / BAM / VCF, truncated or corrupt (CRC, sizes) */
+#define UZ_IO_E_UNSORTED (-3) /* records not coordinate sorted / not grouped by contig */
+#define UZ_IO_E_RANGE (-4)    /* a value does not fit the column types (l_seq > 65535, > 2^31 records ...) */
+#define UZ_IO_E_ARG (-5)
+
+const char *uz_io_last_error(void);
+
+/* ------------------------------------------------------------------ BAM */
+typedef struct uz_bam uz_bam;
+
+/* Decode a whole BAM with `threads` worker threads (<= 0: all hardware threads). */
+int uz_bam_decode(const char *path, int threads, uz_bam **out);
+void uz_bam_free(uz_bam *h);
+
+int32_t uz_bam_n_contigs(const uz_bam *h);
+const char *uz_bam_contig_name(const uz_bam *h, int32_t i);
+int32_t uz_bam_contig_length(const uz_bam *h, int32_t i);
+/* records in the file / records kept in the table (reference id >= 0) */
+int64_t uz_bam_n_file_records(const uz_bam *h);
+int64_t uz_bam_n_records(const uz_bam *h);
+/* borrowed pointers into the handle: exactly the struct uz_reads_upload() takes */
+int uz_bam_view(const uz_bam *h, uz_reads_view *out);
+/* query name of an interned id (ids are assigned in order of first appearance in the file) */
+const char *uz_bam_qname(const uz_bam *h, uint32_t id, int32_t *len);
+/* template lengths of the first `cap` records of the FILE (estimate_concordant_insert_len reads the
+ * head of the file, read_collector.py:11-25); returns the number written */
+int64_t uz_bam_tlen_head(const uz_bam *h, int32_t *out, int64_t cap);
+/* wall-clock seconds of the stages of the last decode: [0] read, [1] inflate, [2] columns, [3] names + mates */
+void uz_bam_timing(const uz_bam *h, double out[4]);
+
+/* ------------------------------------------------------------------ VCF */
+typedef struct uz_vcf uz_vcf;
+
+typedef struct uz_vcf_view {
+    int64_t n_sites;
+    int32_t n_samples;
+    int32_t n_contigs;
+    const int64_t *contig_off; /* [n_contigs+1] */
+    const int32_t *pos;        /* 0-based start */
+    const int32_t *end;        /* INFO/END when present, else start + len(REF) */
+    const uint8_t *sflags;     /* UZ_SF_COMPLEX */
+    const uint8_t *ref_base;   /* 0 for complex records */
+    const uint8_t *alt_base;
+    const uint8_t *gt;         /* [n_samples][n_sites] cyvcf2 gt_types codes 0/1/2/3 */
+    const int32_t *ref_depth;  /* [n_samples][n_sites], -1 = missing */
+    const int32_t *alt_depth;
+    const double *gq;          /* [n_samples][n_sites], -1 = missing */
+} uz_vcf_view;
+
+int uz_vcf_decode(const char *path, int threads, uz_vcf **out);
+void uz_vcf_free(uz_vcf *h);
+int uz_vcf_view_get(const uz_vcf *h, uz_vcf_view *out);
+const char *uz_vcf_sample(const uz_vcf *h, int32_t i);
+const char *uz_vcf_contig(const uz_vcf *h, int32_t i);
+/* REF string and comma-joined ALT string of record i (get_refalt, snv_phaser.py:73-84) */
+const char *uz_vcf_ref(const uz_vcf *h, int64_t i, int32_t *len);
+const char *uz_vcf_alt(const uz_vcf *h, int64_t i, int32_t *len);
+/* header lines (incl. #CHROM) joined by '\n' and the raw text line of record i (VCF writer) */
+const char *uz_vcf_header(const uz_vcf *h, int64_t *len);
+const char *uz_vcf_line(const uz_vcf *h, int64_t i, int32_t *len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNFAZED_IO_H */

@@ -27,6 +27,18 @@ def test_binding_lists_the_same_symbols(hip_lib):
     engine.load_library()
 
 
+def test_io_library_exports_every_declared_symbol():
+    """include/unfazed_io.h (native BAM / VCF decoders) against libunfazed_io.so and its binding."""
+    from unfazed_amd import io_native
+    txt = open(os.path.join(ROOT, "include", "unfazed_io.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(uz_[a-z_0-9]+)\s*\(", txt)))
+    assert sorted(io_native.IO_EXPORTS) == syms
+    L = io_native.load()
+    for s in syms:
+        assert hasattr(L, s), "missing export " + s
+
+
 def test_no_device_is_a_loud_error(hip_lib):
     """Without a GPU uz_create must fail with a code, and the Python engine must raise."""
     import torch

@@ -1,0 +1,204 @@
+"""Native decoders (libunfazed_io.so, include/unfazed_io.h) against the Python decoders that state
+the formats (unfazed_amd/io_bam.py, io_vcf.py): every column of the two tables must be equal, on
+the synthetic trio files, on hand-made edge cases, and on the VCFs the reference ships under
+test/data when this container has them.  CPU only."""
+import ctypes as C
+import gzip
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from synth.small import SmallConfig, make_small
+from synth.small_sv import SvConfig, make_small_sv
+from tests.filesio import dump_dataset
+from unfazed_amd import io_native
+from unfazed_amd.io_bam import _bgzf_block, read_bam, write_bam
+from unfazed_amd.io_vcf import read_vcf
+from unfazed_amd.model import (FMREVERSE, FPAIRED, FPROPER, FREAD1, FREAD2, FREVERSE, FSUPP, FUNMAP, OP_D, OP_I, OP_M, OP_S,
+                               ReadsTable, Segment, SitesTable)
+
+READ_COLS = ["contig_off", "max_span", "start", "end", "flag", "mapq", "aux", "tlen", "qname", "mate", "cigar_off",
+             "n_cigar", "cigar", "l_seq", "sq_off16", "seq", "qual"]
+SITE_COLS = ["contig_off", "pos", "end", "sflags", "ref_base", "alt_base", "gt", "ref_depth", "alt_depth"]
+
+
+def _same_reads(path, threads):
+    contigs, segs = read_bam(path)
+    want = ReadsTable.from_segments(segs, contigs)
+    got = io_native.read_bam_table(path, threads=threads, insert_size_max_sample=50)
+    assert got.contigs == want.contigs
+    for c in READ_COLS:
+        a, b = getattr(got, c), getattr(want, c)
+        assert a.dtype == b.dtype, c
+        assert np.array_equal(a, b), c
+    assert list(got.qnames) == list(want.qnames)
+    assert np.array_equal(got.tlen_head, np.array([s.tlen for s in segs[:51]], dtype=np.int32))
+    return got
+
+
+def _same_sites(path, threads):
+    samples, recs, header = read_vcf(path)
+    want = SitesTable.from_records(recs, samples)
+    got = io_native.read_vcf_table(path, threads=threads)
+    assert got.samples == want.samples and got.contigs == want.contigs
+    for c in SITE_COLS:
+        a, b = getattr(got, c), getattr(want, c)
+        assert a.shape == b.shape, c
+        assert np.array_equal(a, b), c
+    assert np.array_equal(got.gq, want.gq, equal_nan=True)
+    assert list(got.ref_str) == list(want.ref_str)
+    assert list(got.alt_strs) == list(want.alt_strs)
+    assert got.header == header
+    assert [ln.split("\t") for ln in got.lines] == [r.raw for r in recs]
+    return got
+
+
+def test_exports():
+    lib = io_native.load()
+    for name in io_native.IO_EXPORTS:
+        assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_synthetic_trio_files(tmp_path, threads):
+    ds = make_small(SmallConfig(seed=5, n_dnms=12))
+    paths = dump_dataset(ds, str(tmp_path))
+    for bam in paths["bams"].values():
+        t = _same_reads(bam, threads)
+        assert t.n_segs > 1000
+    _same_sites(paths["sites"], threads)
+    _same_sites(paths["dnm_vcf"], threads)
+
+
+def test_sv_reads_with_sa_tags_and_supplementary(tmp_path):
+    ds = make_small_sv(SvConfig(seed=3, n_svs=4))
+    paths = dump_dataset(ds, str(tmp_path))
+    for bam in paths["bams"].values():
+        t = _same_reads(bam, 4)
+        assert (t.aux & 2).any()  # SA tags seen
+
+
+def _seg(name, flag, tid, pos, cigar, mtid, mpos, tlen, seq, qual, mapq=60, sa=False):
+    return Segment(name, flag, tid, pos, mapq, cigar, mtid, mpos, tlen, seq, qual, has_sa=sa)
+
+
+def test_bam_edge_cases(tmp_path):
+    q = [30] * 10
+    segs = [
+        _seg("a", FPAIRED | FREAD1 | FMREVERSE, 0, 100, [(OP_M, 10)], 0, 300, 210, "ACGTACGTAC", q),
+        _seg("dup", FPAIRED | FREAD1, 0, 100, [(OP_S, 2), (OP_M, 5), (OP_I, 1), (OP_M, 2)], 0, 100, 0, "ACGTACGTAC", q),
+        _seg("dup", FPAIRED | FREAD2, 0, 100, [(OP_M, 4), (OP_D, 3), (OP_M, 6)], 0, 100, 0, "ACGTACGTAN", q),
+        _seg("noqual", FPAIRED | FREAD1, 0, 120, [(OP_M, 10)], 0, 500, 0, "ACGTACGTAC", None),  # 0xFF qualities
+        _seg("noseq", 0, 0, 130, [(OP_M, 10)], -1, -1, 0, "", None),
+        _seg("nocigar", FUNMAP | FPAIRED | FREAD2, 0, 140, [], 0, 140, 0, "ACGTA", [20] * 5),
+        _seg("a", FPAIRED | FREAD2 | FREVERSE, 0, 300, [(OP_M, 10)], 0, 100, -210, "TTTTTTTTTT", q),
+        _seg("a", FPAIRED | FREAD2 | FSUPP, 0, 305, [(OP_S, 5), (OP_M, 5)], 0, 100, -210, "TTTTTGGGGG", q, sa=True),
+        _seg("odd", FPAIRED | FREAD1, 1, 5, [(OP_M, 7)], 0, 100, 0, "ACGTACG", [1, 2, 3, 4, 5, 6, 7]),  # mate on another contig
+        _seg("solo", 0, 2, 9, [(OP_M, 3)], -1, -1, 0, "AAA", [9, 9, 9]),
+        _seg("unplaced", FUNMAP, -1, -1, [], -1, -1, 0, "ACGT", [5, 5, 5, 5]),  # dropped from the table, kept in tlen_head
+    ]
+    path = str(tmp_path / "edge.bam")
+    write_bam(path, [("1", 1000), ("2", 1000), ("3", 1000), ("empty", 50)], segs)
+    t = _same_reads(path, 2)
+    assert t.n_segs == 10 and len(t.qnames) == 7
+    assert t.mate[0] == 6 and t.mate[6] == 0  # pysam mate(): first record of the name that fits
+
+
+def test_bam_errors(tmp_path):
+    lib = io_native.load()
+    with pytest.raises(io_native.IoError) as e:
+        io_native.read_bam_table(str(tmp_path / "missing.bam"))
+    assert e.value.code == -1
+    bad = tmp_path / "bad.bam"
+    bad.write_bytes(_bgzf_block(b"NOTABAMFILE....") + _bgzf_block(b""))
+    with pytest.raises(io_native.IoError) as e:
+        io_native.read_bam_table(str(bad))
+    assert e.value.code == -2
+    q = [30] * 4
+    unsorted = [_seg("x", 0, 0, 50, [(OP_M, 4)], -1, -1, 0, "ACGT", q), _seg("y", 0, 0, 10, [(OP_M, 4)], -1, -1, 0, "ACGT", q)]
+    p2 = str(tmp_path / "unsorted.bam")
+    write_bam(p2, [("1", 1000)], unsorted)
+    with pytest.raises(io_native.IoError) as e:
+        io_native.read_bam_table(p2)
+    assert e.value.code == -3
+    with pytest.raises(ValueError):
+        contigs, segs = read_bam(p2)
+        ReadsTable.from_segments(segs, contigs)
+    # a flipped payload byte fails the block CRC
+    data = bytearray(open(p2, "rb").read())
+    data[40] ^= 0x55
+    p3 = tmp_path / "crc.bam"
+    p3.write_bytes(bytes(data))
+    with pytest.raises(io_native.IoError) as e:
+        io_native.read_bam_table(str(p3))
+    assert e.value.code == -2
+    assert lib.uz_io_last_error()
+
+
+VCF_EDGE = """##fileformat=VCFv4.2
+##source=edge cases
+#CHROM	POS	ID	REF	ALT	QUAL	FILTER	INFO	FORMAT	kid	dad	mom
+1	10	.	A	G	.	.	.	GT:AD:GQ	0/1:10,12:99	0|0:20,0:45.5	1/1:0,31:.
+1	10	.	A	G,T	.	.	X=1;END=55;Y	GT:AD:GQ	1/2:1,2,3:7	./.:.:.	0/0:9:3
+1	11	.	AT	A	.	.	END=abc	GT:GQ:AD	0/1:50:5,6	.:.:.	./1:12:.,4
+1	11	.	C	*	.	.	SVTYPE=DEL	GT:RO:AO:GQ	0/1:7:8,9:20	1:3:4:1e1	0:.:.:nan
+1	12	.	C	.	.	.	.	GT	0/0	0/1
+1	13	.	G	<DEL>	.	.	SVTYPE=DEL;END=400	GT:AD	0/1	1/.	2/2:1,2
+
+2	5	.	T	C	.	.	.	AD:GT:GQ:AD	1,1:0/1:5:30,40	.,.:0/0:-1:.	7:1|1:0:.
+2	5	.	T	C
+"""
+
+
+def test_vcf_edge_cases(tmp_path):
+    for name, opener in (("edge.vcf", open), ("edge.vcf.gz", gzip.open)):
+        p = str(tmp_path / name)
+        with opener(p, "wt") as fh:
+            fh.write(VCF_EDGE)
+        t = _same_sites(p, 2)
+        assert t.n_sites == 8 and t.contigs == ["1", "2"]
+    # bgzip framing of the same text (several blocks)
+    raw = VCF_EDGE.encode()
+    p = tmp_path / "edge.bgz.vcf.gz"
+    p.write_bytes(b"".join(_bgzf_block(raw[i:i + 97]) for i in range(0, len(raw), 97)) + _bgzf_block(b""))
+    _same_sites(str(p), 3)
+
+
+def test_vcf_errors(tmp_path):
+    p = tmp_path / "ungrouped.vcf"
+    p.write_text("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n1\t5\t.\tA\tC\t.\t.\t.\n2\t5\t.\tA\tC\t.\t.\t.\n1\t9\t.\tA\tC\t.\t.\t.\n")
+    with pytest.raises(io_native.IoError) as e:
+        io_native.read_vcf_table(str(p))
+    assert e.value.code == -3
+    p2 = tmp_path / "unsorted.vcf"
+    p2.write_text("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n1\t9\t.\tA\tC\t.\t.\t.\n1\t5\t.\tA\tC\t.\t.\t.\n")
+    with pytest.raises(io_native.IoError) as e:
+        io_native.read_vcf_table(str(p2))
+    assert e.value.code == -3
+
+
+REF_DATA = "/root/reference/test/data"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference's test data is only present in the authoring container")
+@pytest.mark.parametrize("name", ["trio_hets_snvs_chr22.vcf.gz", "trio_hets_svs_chr22.vcf.gz", "trio_svs_chr22.vcf.gz"])
+def test_reference_vcfs(name):
+    path = os.path.join(REF_DATA, name)
+    if not os.path.exists(path):
+        pytest.skip("absent")
+    t = _same_sites(path, 4)
+    assert t.n_sites > 0
+
+
+def test_family_columns_agree(tmp_path):
+    ds = make_small(SmallConfig(seed=9, n_dnms=6))
+    paths = dump_dataset(ds, str(tmp_path))
+    samples, recs, _ = read_vcf(paths["sites"])
+    want = SitesTable.from_records(recs, samples)
+    got = io_native.read_vcf_table(paths["sites"], threads=2)
+    kid = list(ds.pedigrees)[0]
+    p = ds.pedigrees[kid]
+    for a, b in zip(got.family_columns(kid, p["dad"], p["mom"]), want.family_columns(kid, p["dad"], p["mom"])):
+        assert np.array_equal(a, b)

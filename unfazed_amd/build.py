@@ -1,5 +1,7 @@
-"""Builds unfazed_amd/libunfazed_hip.so in-tree with hipcc for gfx950.
-(hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the tree.)"""
+"""Builds the in-tree native libraries:
+  unfazed_amd/libunfazed_hip.so  the HIP kernels + C ABI, hipcc for gfx950 (cross-compiles without a GPU)
+  unfazed_amd/libunfazed_io.so   the host-side BAM / VCF decoders (g++, zlib, threads)
+Both are git-ignored but travel with the tree."""
 import os
 import subprocess
 import sys
@@ -48,5 +50,37 @@ def _compile(lib, srcs, inc, csrc, extra_flags, verbose):
     return lib
 
 
+IO_SRC = ["io_bam.cpp", "io_vcf.cpp"]
+IO_LIB = os.path.join(_HERE, "libunfazed_io.so")
+
+
+def build_io(force=False, verbose=False, out=None):
+    csrc = os.path.join(_HERE, "csrc")
+    inc = os.path.join(_HERE, "..", "include")
+    srcs = [os.path.join(csrc, s) for s in IO_SRC]
+    deps = srcs + [os.path.join(csrc, "io_common.hpp"), os.path.join(inc, "uz_types.h"), os.path.join(inc, "unfazed_io.h")]
+    lib = out or IO_LIB
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
+        return lib
+    import fcntl
+    lock = open(lib + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
+            return lib
+        cxx = os.environ.get("CXX", "g++")
+        cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-parameter",
+               "-I", inc, "-I", csrc] + srcs + ["-lz", "-o", lib + ".tmp"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        os.replace(lib + ".tmp", lib)
+        return lib
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_io(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,226 @@
+"""ctypes binding of libunfazed_io.so (include/unfazed_io.h): the native, multi-threaded BAM and
+sites-VCF decoders.  They produce the same column tables as the Python decoders in io_bam.py /
+io_vcf.py (kept as the readable statement of the formats and as the checker in
+tests/test_io_native.py); the columns are numpy views of the memory the handle owns.
+
+SURVEY.md section 8(f)-2.  Reference seams: pysam.AlignmentFile / .mate() in
+unfazed/read_collector.py:11-25, :372-392, :402 and cyvcf2.VCF in
+unfazed/informative_site_finder.py:213, :571.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Sequence
+
+import numpy as np
+
+from . import abi
+from .model import ReadsTable, SitesTable
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+IO_EXPORTS = [
+    "uz_io_last_error", "uz_bam_decode", "uz_bam_free", "uz_bam_n_contigs", "uz_bam_contig_name",
+    "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
+    "uz_bam_tlen_head", "uz_bam_timing", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
+    "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line",
+]
+
+
+class VcfView(C.Structure):
+    _fields_ = [
+        ("n_sites", C.c_int64), ("n_samples", C.c_int32), ("n_contigs", C.c_int32),
+        ("contig_off", C.c_void_p), ("pos", C.c_void_p), ("end", C.c_void_p), ("sflags", C.c_void_p),
+        ("ref_base", C.c_void_p), ("alt_base", C.c_void_p), ("gt", C.c_void_p), ("ref_depth", C.c_void_p),
+        ("alt_depth", C.c_void_p), ("gq", C.c_void_p),
+    ]
+
+
+def lib_path() -> str:
+    return os.environ.get("UZ_IO_LIB", os.path.join(_HERE, "libunfazed_io.so"))
+
+
+def load():
+    """The decoder library; built on first use when the tree has no copy yet (g++ and zlib only)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        from . import build
+        build.build_io()
+    lib = C.CDLL(path)
+    lib.uz_io_last_error.restype = C.c_char_p
+    lib.uz_bam_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.uz_bam_free.argtypes = [C.c_void_p]
+    lib.uz_bam_free.restype = None
+    lib.uz_bam_n_contigs.argtypes = [C.c_void_p]
+    lib.uz_bam_contig_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.uz_bam_contig_name.restype = C.c_char_p
+    lib.uz_bam_contig_length.argtypes = [C.c_void_p, C.c_int32]
+    lib.uz_bam_n_file_records.argtypes = [C.c_void_p]
+    lib.uz_bam_n_file_records.restype = C.c_int64
+    lib.uz_bam_n_records.argtypes = [C.c_void_p]
+    lib.uz_bam_n_records.restype = C.c_int64
+    lib.uz_bam_view.argtypes = [C.c_void_p, C.POINTER(abi.ReadsView)]
+    lib.uz_bam_qname.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
+    lib.uz_bam_qname.restype = C.c_void_p
+    lib.uz_bam_tlen_head.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.uz_bam_tlen_head.restype = C.c_int64
+    lib.uz_bam_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.uz_bam_timing.restype = None
+    lib.uz_vcf_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.uz_vcf_free.argtypes = [C.c_void_p]
+    lib.uz_vcf_free.restype = None
+    lib.uz_vcf_view_get.argtypes = [C.c_void_p, C.POINTER(VcfView)]
+    lib.uz_vcf_sample.argtypes = [C.c_void_p, C.c_int32]
+    lib.uz_vcf_sample.restype = C.c_char_p
+    lib.uz_vcf_contig.argtypes = [C.c_void_p, C.c_int32]
+    lib.uz_vcf_contig.restype = C.c_char_p
+    for fn in (lib.uz_vcf_ref, lib.uz_vcf_alt, lib.uz_vcf_line):
+        fn.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+        fn.restype = C.c_void_p
+    lib.uz_vcf_header.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_vcf_header.restype = C.c_void_p
+    _LIB = lib
+    return lib
+
+
+class IoError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("%s (code %d)" % (msg, code))
+        self.code = code
+
+
+def _check(lib, rc: int) -> None:
+    if rc != 0:
+        raise IoError(rc, (lib.uz_io_last_error() or b"").decode(errors="replace"))
+
+
+def _arr(ptr, n: int, dtype) -> np.ndarray:
+    dtype = np.dtype(dtype)
+    if n <= 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (n * dtype.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype, count=n)
+
+
+class _Handle:
+    def __init__(self, ptr, free):
+        self.ptr, self._free = ptr, free
+
+    def __del__(self):
+        if self.ptr:
+            self._free(self.ptr)
+            self.ptr = None
+
+
+class _Names(Sequence):
+    """id -> query name, read from the decoded file on demand (no list of 10^8 Python strings)"""
+
+    def __init__(self, lib, handle: _Handle, n: int):
+        self._lib, self._h, self._n = lib, handle, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        ln = C.c_int32(0)
+        p = self._lib.uz_bam_qname(self._h.ptr, i, C.byref(ln))
+        return C.string_at(p, ln.value).decode()
+
+
+def read_bam_table(path: str, threads: int = 0, insert_size_max_sample: int = 1000000) -> ReadsTable:
+    """BAM -> ReadsTable (columns are views into the native handle, kept alive by the table)."""
+    lib = load()
+    hp = C.c_void_p()
+    _check(lib, lib.uz_bam_decode(os.fsencode(path), int(threads), C.byref(hp)))
+    h = _Handle(hp.value, lib.uz_bam_free)
+    nc = lib.uz_bam_n_contigs(h.ptr)
+    t = ReadsTable([lib.uz_bam_contig_name(h.ptr, i).decode() for i in range(nc)])
+    v = abi.ReadsView()
+    _check(lib, lib.uz_bam_view(h.ptr, C.byref(v)))
+    n = int(v.n_segs)
+
+    def col(name, dtype, count=n):
+        return _arr(C.cast(getattr(v, name), C.c_void_p).value, count, dtype)
+
+    t.contig_off = col("contig_off", np.int64, nc + 1).copy()
+    t.max_span = col("max_span", np.int32, nc).copy()
+    t.start, t.end, t.tlen, t.mate = (col(k, np.int32) for k in ("start", "end", "tlen", "mate"))
+    t.flag, t.n_cigar, t.l_seq = (col(k, np.uint16) for k in ("flag", "n_cigar", "l_seq"))
+    t.mapq, t.aux = col("mapq", np.uint8), col("aux", np.uint8)
+    t.qname, t.cigar_off, t.sq_off16 = (col(k, np.uint32) for k in ("qname", "cigar_off", "sq_off16"))
+    t.cigar = col("cigar", np.uint32, int(v.n_cigar_total))
+    t.seq = col("seq", np.uint8, int(v.n_sq_bytes))
+    t.qual = col("qual", np.uint8, int(v.n_sq_bytes))
+    t.qnames = _Names(lib, h, int(v.n_qnames))
+    cap = max(int(insert_size_max_sample) + 1, 0)
+    k = min(cap, int(lib.uz_bam_n_file_records(h.ptr)))
+    head = np.zeros(k, dtype=np.int32)
+    if k:
+        lib.uz_bam_tlen_head(h.ptr, head.ctypes.data, k)
+    t.tlen_head = head
+    tm = (C.c_double * 4)()
+    lib.uz_bam_timing(h.ptr, tm)
+    t.decode_seconds = dict(zip(("read", "inflate", "columns", "names+mates"), (float(x) for x in tm)))
+    t._native = h  # owns the memory behind the views
+    return t
+
+
+class _Strings(Sequence):
+    def __init__(self, fn, handle: _Handle, n: int, post):
+        self._fn, self._h, self._n, self._post = fn, handle, n, post
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        ln = C.c_int32(0)
+        p = self._fn(self._h.ptr, i, C.byref(ln))
+        return self._post(C.string_at(p, ln.value).decode())
+
+
+def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
+    """sites VCF -> SitesTable; `.header` (list of lines) and `.lines[i]` (raw record text) ride along
+    for the VCF writer."""
+    lib = load()
+    hp = C.c_void_p()
+    _check(lib, lib.uz_vcf_decode(os.fsencode(path), int(threads), C.byref(hp)))
+    h = _Handle(hp.value, lib.uz_vcf_free)
+    v = VcfView()
+    _check(lib, lib.uz_vcf_view_get(h.ptr, C.byref(v)))
+    n, ns, nc = int(v.n_sites), int(v.n_samples), int(v.n_contigs)
+    t = SitesTable([lib.uz_vcf_sample(h.ptr, i).decode() for i in range(ns)],
+                   [lib.uz_vcf_contig(h.ptr, i).decode() for i in range(nc)])
+    t.contig_off = _arr(v.contig_off, nc + 1, np.int64).copy()
+    t.pos, t.end = _arr(v.pos, n, np.int32), _arr(v.end, n, np.int32)
+    t.sflags, t.ref_base, t.alt_base = (_arr(getattr(v, k), n, np.uint8) for k in ("sflags", "ref_base", "alt_base"))
+    t.gt = _arr(v.gt, ns * n, np.uint8).reshape(ns, n)
+    t.ref_depth = _arr(v.ref_depth, ns * n, np.int32).reshape(ns, n)
+    t.alt_depth = _arr(v.alt_depth, ns * n, np.int32).reshape(ns, n)
+    t.gq = _arr(v.gq, ns * n, np.float64).reshape(ns, n)
+    t.ref_str = _Strings(lib.uz_vcf_ref, h, n, lambda s: s)
+    t.alt_strs = _Strings(lib.uz_vcf_alt, h, n, lambda s: [] if s == "." else s.split(","))
+    t.lines = _Strings(lib.uz_vcf_line, h, n, lambda s: s)
+    ln = C.c_int64(0)
+    hp2 = lib.uz_vcf_header(h.ptr, C.byref(ln))
+    t.header = C.string_at(hp2, ln.value).decode().split("\n") if ln.value else []
+    t._native = h
+    return t

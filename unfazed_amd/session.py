@@ -6,6 +6,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import numpy as np
 
 from .hostpath import PhasingHost
@@ -43,15 +45,29 @@ def get_backend():
     return _BACKEND
 
 
+def _python_io() -> bool:
+    """UZ_IO=python selects the pure-Python decoders (io_bam.py / io_vcf.py: the readable statement of the
+    formats, orders of magnitude slower); the default is the native library (io_native.py)."""
+    return os.environ.get("UZ_IO", "native").lower() == "python"
+
+
+def _io_threads() -> int:
+    return int(os.environ.get("UZ_IO_THREADS", "0"))
+
+
 def load_sites(name_or_table) -> (str, SitesTable):
     if isinstance(name_or_table, SitesTable):
         key = "table@%d" % id(name_or_table)
         _SITES[key] = name_or_table
         return key, name_or_table
     if name_or_table not in _SITES:
-        from .io_vcf import read_vcf
-        samples, recs, _ = read_vcf(name_or_table)
-        _SITES[name_or_table] = SitesTable.from_records(recs, samples)
+        if _python_io():
+            from .io_vcf import read_vcf
+            samples, recs, _ = read_vcf(name_or_table)
+            _SITES[name_or_table] = SitesTable.from_records(recs, samples)
+        else:
+            from .io_native import read_vcf_table
+            _SITES[name_or_table] = read_vcf_table(name_or_table, threads=_io_threads())
     return name_or_table, _SITES[name_or_table]
 
 
@@ -59,10 +75,14 @@ def load_reads(name: str, insert_size_max_sample: int = 1000000) -> ReadsTable:
     if name not in _READS:
         if name[-4:] == "cram":
             raise NotImplementedError("CRAM input is not decoded by this build (BAM only)")
-        from .io_bam import read_bam
-        contigs, segs = read_bam(name)
-        t = ReadsTable.from_segments(segs, contigs)
-        t.tlen_head = np.array([s.tlen for s in segs[: int(insert_size_max_sample) + 1]], dtype=np.int32)
+        if _python_io():
+            from .io_bam import read_bam
+            contigs, segs = read_bam(name)
+            t = ReadsTable.from_segments(segs, contigs)
+            t.tlen_head = np.array([s.tlen for s in segs[: int(insert_size_max_sample) + 1]], dtype=np.int32)
+        else:
+            from .io_native import read_bam_table
+            t = read_bam_table(name, threads=_io_threads(), insert_size_max_sample=insert_size_max_sample)
         _READS[name] = t
     return _READS[name]
 
