@@ -18,13 +18,13 @@ namespace uzio {
 
 thread_local std::string last_error;
 
-std::vector<uint8_t> read_file(const char *path) {
+Bytes read_file(const char *path) {
     FILE *f = fopen(path, "rb");
     if (!f) fail(UZ_IO_E_OPEN, "cannot open %s", path);
-    std::vector<uint8_t> data;
+    Bytes data;
     if (fseek(f, 0, SEEK_END) == 0) {
         const long sz = ftell(f);
-        if (sz > 0) data.resize((size_t)sz);
+        data.alloc(sz > 0 ? (size_t)sz : 0);
         fseek(f, 0, SEEK_SET);
     }
     size_t got = 0;
@@ -47,7 +47,7 @@ struct Block {
 };
 
 // the BGZF framing: every gzip member carries its own compressed size in a "BC" extra subfield
-bool scan_bgzf(const std::vector<uint8_t> &f, std::vector<Block> &blocks, size_t &total) {
+bool scan_bgzf(const Bytes &f, std::vector<Block> &blocks, size_t &total) {
     size_t p = 0;
     total = 0;
     while (p < f.size()) {
@@ -79,7 +79,7 @@ bool scan_bgzf(const std::vector<uint8_t> &f, std::vector<Block> &blocks, size_t
     return true;
 }
 
-std::vector<uint8_t> inflate_stream(const std::vector<uint8_t> &f) { // any gzip stream, member after member
+Bytes inflate_stream(const Bytes &f) { // any gzip stream, member after member
     std::vector<uint8_t> out;
     size_t p = 0;
     std::vector<uint8_t> chunk(1 << 20);
@@ -109,22 +109,24 @@ std::vector<uint8_t> inflate_stream(const std::vector<uint8_t> &f) { // any gzip
         if (used == 0) break;
         p += used;
     }
-    return out;
+    Bytes b(out.size());
+    if (!out.empty()) memcpy(b.p, out.data(), out.size());
+    return b;
 }
 
 } // namespace
 
-std::vector<uint8_t> inflate_all(const std::vector<uint8_t> &f, int threads, bool *was_gzip) {
+Bytes inflate_all(Bytes &f, int threads, bool *was_gzip) {
     if (f.size() < 2 || f[0] != 0x1f || f[1] != 0x8b) {
         if (was_gzip) *was_gzip = false;
-        return f;
+        return std::move(f);
     }
     if (was_gzip) *was_gzip = true;
     std::vector<Block> blocks;
     size_t total = 0;
     if (!scan_bgzf(f, blocks, total)) return inflate_stream(f);
-    std::vector<uint8_t> out(total);
-    parallel_slices((int64_t)blocks.size(), threads, [&](int64_t lo, int64_t hi, int) {
+    Bytes out(total);
+    parallel_slices((int64_t)blocks.size(), workers_for((int64_t)blocks.size(), threads, 8), [&](int64_t lo, int64_t hi, int) {
         z_stream z;
         memset(&z, 0, sizeof(z));
         if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
@@ -182,7 +184,7 @@ inline uint64_t hash_bytes(const uint8_t *s, size_t n) { // FNV-1a with a final 
 } // namespace
 
 struct uz_bam {
-    std::vector<uint8_t> data; // inflated file (query names are referenced in place)
+    Bytes data; // inflated file (query names are referenced in place)
     std::vector<std::string> contigs;
     std::vector<int32_t> contig_len;
     int64_t n_file = 0, n = 0;
@@ -238,15 +240,15 @@ bool has_tag(const uint8_t *p, const uint8_t *end, char t0, char t1) {
 
 void decode(uz_bam &B, const char *path, int threads) {
     double t0 = now_s();
-    std::vector<uint8_t> file = read_file(path);
+    Bytes file = read_file(path);
     double t1 = now_s();
     B.timing[0] = t1 - t0;
     bool gz = false;
     B.data = inflate_all(file, threads, &gz);
-    std::vector<uint8_t>().swap(file);
+    file.release();
     double t2 = now_s();
     B.timing[1] = t2 - t1;
-    const std::vector<uint8_t> &d = B.data;
+    const Bytes &d = B.data;
     const size_t N = d.size();
     if (N < 12 || memcmp(d.data(), "BAM\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAM file", path);
     size_t off = 8 + (size_t)rdi32(d.data() + 4);
@@ -274,6 +276,7 @@ void decode(uz_bam &B, const char *path, int threads) {
         B.n_file++;
     }
     const int64_t n = (int64_t)rec.size();
+    threads = workers_for(n, threads, 16384); // a thread per 16k records at most
     if (n >= ((int64_t)1 << 31)) fail(UZ_IO_E_RANGE, "more than 2^31 - 1 alignment records");
     B.n = n;
     const size_t un = (size_t)n;

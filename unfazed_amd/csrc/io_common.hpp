@@ -42,6 +42,12 @@ inline int resolve_threads(int threads) {
     return threads > 256 ? 256 : threads;
 }
 
+// workers worth starting for n items when one worker should get at least `grain` of them
+inline int workers_for(int64_t n, int threads, int64_t grain) {
+    const int64_t by_work = (n + grain - 1) / grain;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(threads, by_work));
+}
+
 // fn(lo, hi, worker) over [0, n) cut into one contiguous slice per worker; the first exception wins
 template <typename F>
 void parallel_slices(int64_t n, int threads, F fn) {
@@ -64,11 +70,35 @@ inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v;
 inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
 inline int32_t rdi32(const uint8_t *p) { int32_t v; memcpy(&v, p, 4); return v; }
 
+// malloc-backed byte buffer: no zero fill of memory that is about to be overwritten
+struct Bytes {
+    uint8_t *p = nullptr;
+    size_t n = 0;
+    Bytes() = default;
+    explicit Bytes(size_t count) { alloc(count); }
+    Bytes(const Bytes &) = delete;
+    Bytes &operator=(const Bytes &) = delete;
+    Bytes(Bytes &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    Bytes &operator=(Bytes &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~Bytes() { free(p); }
+    void alloc(size_t count) {
+        free(p);
+        p = (uint8_t *)malloc(count ? count : 1);
+        n = count;
+        if (!p) fail(UZ_IO_E_RANGE, "out of memory for %zu bytes", count);
+    }
+    void release() { free(p); p = nullptr; n = 0; }
+    size_t size() const { return n; }
+    const uint8_t *data() const { return p; }
+    uint8_t *data() { return p; }
+    const uint8_t &operator[](size_t i) const { return p[i]; }
+};
+
 // whole file -> memory
-std::vector<uint8_t> read_file(const char *path);
+Bytes read_file(const char *path);
 // gzip / BGZF stream -> bytes.  BGZF blocks (BC extra field) are inflated in parallel, any other
-// gzip stream sequentially, member after member.  Not gzip at all -> returned unchanged with
-// *was_gzip = false.
-std::vector<uint8_t> inflate_all(const std::vector<uint8_t> &file, int threads, bool *was_gzip);
+// gzip stream sequentially, member after member.  Not gzip at all -> the input itself is handed
+// back (moved) with *was_gzip = false.
+Bytes inflate_all(Bytes &file, int threads, bool *was_gzip);
 
 } // namespace uzio

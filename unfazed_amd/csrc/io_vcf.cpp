@@ -17,7 +17,7 @@
 using namespace uzio;
 
 struct uz_vcf {
-    std::vector<uint8_t> text;
+    Bytes text;
     std::vector<std::string> samples, contigs;
     std::string header; // header lines joined by '\n'
     int64_t n = 0;
@@ -113,7 +113,7 @@ int parse_gt(Str g) {
 
 void decode(uz_vcf &V, const char *path, int threads) {
     {
-        std::vector<uint8_t> file = read_file(path);
+        Bytes file = read_file(path);
         bool gz = false;
         V.text = inflate_all(file, threads, &gz);
     }
@@ -171,6 +171,7 @@ void decode(uz_vcf &V, const char *path, int threads) {
     }
     const int64_t n = (int64_t)V.line_at.size();
     V.n = n;
+    threads = workers_for(n, threads, 2048);
     const size_t un = (size_t)n, ns = V.samples.size();
     V.line_len.resize(un); V.ref_at.resize(un); V.ref_len.resize(un); V.alt_at.resize(un); V.alt_len.resize(un);
     V.chrom_len.resize(un);
