@@ -87,6 +87,7 @@ struct Scr {
     uint32_t *site_best;  // chaining: first frontier element (e << 12 | j) finding an allele at a het index
     int32_t *cpos;
     uint32_t *cvote;
+    uint8_t *cflag, *cref, *calt; // per candidate: UZ_CF_* flags, REF and ALT base
     int32_t *t_ov, *t_pass;
     int32_t *reg_h, *reg_seg, *reg_pair;
     uint8_t *cbase;
@@ -125,6 +126,7 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.h_off, H); uz_carve(base, o, s.sr_off, H); uz_carve(base, o, s.sr_exists, H);
     uz_carve(base, o, s.href, H); uz_carve(base, o, s.halt, H); uz_carve(base, o, s.site_best, H);
     uz_carve(base, o, s.cpos, C); uz_carve(base, o, s.cvote, C);
+    uz_carve(base, o, s.cflag, C); uz_carve(base, o, s.cref, C); uz_carve(base, o, s.calt, C);
     uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T);
     uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
     uz_carve(base, o, s.i_seg, I); uz_carve(base, o, s.i_qp, I); uz_carve(base, o, s.i_L, I); uz_carve(base, o, s.i_R, I);
@@ -271,6 +273,32 @@ UZ_DEV int uz_qidx(const RD &R, int seg, long long pos) {
     }
     return -1;
 }
+// The fixed-width fields a base lookup needs, fetched together (one memory round trip) before the
+// CIGAR walk instead of one by one along it.
+struct SegHdr {
+    int32_t start, n_cigar, l_seq;
+    uint32_t cigar_off, sq_off16;
+};
+UZ_DEV SegHdr uz_hdr(const RD &R, int seg) {
+    SegHdr h;
+    h.start = R.start[seg]; h.n_cigar = R.n_cigar[seg]; h.l_seq = R.l_seq[seg];
+    h.cigar_off = R.cigar_off[seg]; h.sq_off16 = R.sq_off16[seg];
+    return h;
+}
+UZ_DEV int uz_qidx_h(const RD &R, const SegHdr &h, long long pos) {
+    const uint32_t *c = R.cigar + h.cigar_off;
+    long long r = h.start;
+    int q = 0;
+    for (int k = 0; k < h.n_cigar; k++) {
+        const int op = c[k] & 15, l = (int)(c[k] >> 4);
+        if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X) {
+            if (pos >= r && pos < r + l) return q + (int)(pos - r);
+            q += l; r += l;
+        } else if (op == UZ_OP_I || op == UZ_OP_S) q += l;
+        else if (op == UZ_OP_D || op == UZ_OP_N) r += l;
+    }
+    return -1;
+}
 UZ_DEV int uz_refpos_len(const RD &R, int seg) {
     const uint32_t *c = R.cigar + R.cigar_off[seg];
     int q = 0;
@@ -286,16 +314,17 @@ UZ_DEV const uint8_t *uz_qual(const RD &R, int seg) { return R.qual + ((size_t)R
 
 // get_allele_at :56-73 -> pointer to n bases or nullptr (False)
 UZ_DEV const uint8_t *uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n) {
-    const int i = uz_qidx(R, read, pos);
+    const SegHdr hr = uz_hdr(R, read), hm = uz_hdr(R, mate >= 0 ? mate : read); // both requested up front
+    const int i = uz_qidx_h(R, hr, pos);
     if (i >= 0) {
         if (i < 4 || i > readlen - 4) return nullptr;
-        if ((int)R.l_seq[read] > i + n) return uz_seq(R, read) + i;
+        if (hr.l_seq > i + n) return R.seq + ((size_t)hr.sq_off16 << 4) + i;
         return nullptr; // the mate is not consulted (quirk Q10)
     } else if (mate >= 0) {
-        const int j = uz_qidx(R, mate, pos);
+        const int j = uz_qidx_h(R, hm, pos);
         if (j >= 0) {
             if (j < 4 || j > readlen - 4) return nullptr;
-            if ((int)R.l_seq[mate] > j + n) return uz_seq(R, mate) + j;
+            if (hm.l_seq > j + n) return R.seq + ((size_t)hm.sq_off16 << 4) + j;
         }
     }
     return nullptr;
@@ -330,17 +359,21 @@ UZ_DEV int uz_bsearch_nth(int m, int qp, int L, int Rr) {
 
 // the filters shared by the DNM fetch and the het-site fetch (:395-418 / :181-214), without the
 // site-specific parts.  Returns the mate or -1.
+// All fields of the record are requested together, then all fields of its mate (two memory round
+// trips instead of one per test); the tests keep the reference's order.
 UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, int seg) {
     const uint32_t qc = R.qc[seg];
+    const int mate = R.mate[seg];
     long long ins = (long long)R.tlen[seg] - 2LL * a.readlen;
+    const long long rs = R.start[seg], re = R.end[seg];
+    const int mi = mate >= 0 ? mate : seg; // a safe index: unused without a mate
+    const uint32_t qm = R.qc[mi];
+    const long long ms = R.start[mi], me = R.end[mi];
     if (ins < 0) ins = -ins;
     if (!(qc & UZ_QC_GOOD) || (double)ins > a.cutoff) return -1;
-    const int mate = R.mate[seg];
     if (mate < 0) return -1;
-    const uint32_t qm = R.qc[mate];
     if (!(qm & UZ_QC_GOOD)) return -1;
     if (!(qc & UZ_QC_NONE5) || !(qm & UZ_QC_NONE5)) return -1;
-    const long long rs = R.start[seg], re = R.end[seg], ms = R.start[mate], me = R.end[mate];
     if ((ms <= rs && rs <= me) || (ms <= re && re <= me)) return -1; // mates overlap
     return mate;
 }
@@ -473,6 +506,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     if (nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
     ar_p(ar, s.misc, 8);
     ar_p(ar, s.cpos, nc + 1); ar_p(ar, s.cvote, nc + 1);
+    ar_p(ar, s.cflag, nc + 1); ar_p(ar, s.cref, nc + 1); ar_p(ar, s.calt, nc + 1);
     ar_p(ar, s.hpos, nh + 1); ar_p(ar, s.hcanon, nh + 1); ar_p(ar, s.h_a, nh + 1);
     ar_p(ar, s.h_off, nh + 2); ar_p(ar, s.sr_off, nh + 2); ar_p(ar, s.sr_exists, nh + 1);
     ar_p(ar, s.href, nh + 1); ar_p(ar, s.halt, nh + 1); ar_p(ar, s.site_best, nh + 1);
@@ -486,7 +520,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
 
     UZ_TICK_INIT;
-    WG_FOR(k, nc) { s.cpos[k] = a.spos[a.cand_idx[c0 + k]]; s.cvote[k] = 0; }
+    WG_FOR(k, nc) {
+        const int si = a.cand_idx[c0 + k];
+        s.cpos[k] = a.spos[si]; s.cvote[k] = 0;
+        s.cflag[k] = a.cand_flags[c0 + k]; s.cref[k] = a.sref[si]; s.calt[k] = a.salt[si];
+    }
     WG_FOR(k, nh) {
         const int si = a.het_idx[h0 + k];
         s.hpos[k] = a.spos[si]; s.href[k] = a.sref[si]; s.halt[k] = a.salt[si];
@@ -834,24 +872,24 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             const int seq = (int)(s.keys[x] & 0xFFFFFF);
             if (h >= 0) {
                 const int p = s.srt_pid[x];
-                const int f0 = s.fet0[p];
+                const int f0 = s.fet0[p], f1 = s.fet1[p];
                 if (f0 >= 0) {
                     const long long hp = s.hpos[h];
-                    const int i = uz_qidx(R, f0, hp);
+                    const SegHdr h0 = uz_hdr(R, f0);
+                    const int i = uz_qidx_h(R, h0, hp);
                     if (i >= 0) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
-                        if (i >= 4 && i <= a.readlen - 4 && (int)R.l_seq[f0] > i + 1) {
-                            const uint8_t al = uz_seq(R, f0)[i];
+                        if (i >= 4 && i <= a.readlen - 4 && h0.l_seq > i + 1) {
+                            const size_t at = ((size_t)h0.sq_off16 << 4) + (size_t)i;
+                            const uint8_t al = R.seq[at], ql = R.qual[at];
                             if (al == s.href[h] || al == s.halt[h]) fbv = al; // :98-105
-                            if (seq < E && (int)uz_qual(R, f0)[i] >= a.min_gt_qual) cb = al; // :114-124
+                            if (seq < E && (int)ql >= a.min_gt_qual) cb = al; // :114-124
                         }
-                    } else {
-                        const int f1 = s.fet1[p];
-                        if (f1 >= 0) {
-                            const int j = uz_qidx(R, f1, hp);
-                            if (j >= 4 && j <= a.readlen - 4 && (int)R.l_seq[f1] > j + 1) {
-                                const uint8_t al = uz_seq(R, f1)[j];
-                                if (al == s.href[h] || al == s.halt[h]) fbv = al;
-                            }
+                    } else if (f1 >= 0) {
+                        const SegHdr h1 = uz_hdr(R, f1);
+                        const int j = uz_qidx_h(R, h1, hp);
+                        if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) {
+                            const uint8_t al = R.seq[((size_t)h1.sq_off16 << 4) + (size_t)j];
+                            if (al == s.href[h] || al == s.halt[h]) fbv = al;
                         }
                     }
                 }
@@ -998,24 +1036,24 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             seg = (it & 1) ? s.fet1[p] : s.fet0[p];
         }
         int qp, L, Rr;
-        const int nm = uz_bsearch(R.start[seg], R.end[seg], s.cpos, nc, qp, L, Rr);
+        const SegHdr hd = uz_hdr(R, seg);
+        const int nm = uz_bsearch(hd.start, R.end[seg], s.cpos, nc, qp, L, Rr);
         if (nm <= 0) continue;
         bool dad_alt = false, mom_alt = false;
         for (int ci = L; ci <= Rr; ci++) {
-            if (a.cand_flags[c0 + ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
+            if (s.cflag[ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
         }
         if (dad_alt && mom_alt) continue; // site_searcher.py:74-75
         wg_atomic_add(&s.misc[1], 1);
         for (int ci = L; ci <= Rr; ci++) {
-            const int rp = uz_qidx(R, seg, s.cpos[ci]); // snv_phaser.py:28-33
-            if (rp < 0 || rp >= (int)R.l_seq[seg]) continue;
-            const uint8_t b = uz_seq(R, seg)[rp];
-            const int si = a.cand_idx[c0 + ci];
+            const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
+            if (rp < 0 || rp >= hd.l_seq) continue;
+            const uint8_t b = R.seq[((size_t)hd.sq_off16 << 4) + (size_t)rp];
             bool from_ref;
-            if (b == a.sref[si]) from_ref = true;       // :41-42
-            else if (b == a.salt[si]) from_ref = false; // :43-44
+            if (b == s.cref[ci]) from_ref = true;       // :41-42
+            else if (b == s.calt[ci]) from_ref = false; // :43-44
             else continue;
-            const bool alt_is_dad = (a.cand_flags[c0 + ci] & UZ_CF_ALT_DAD) != 0;
+            const bool alt_is_dad = (s.cflag[ci] & UZ_CF_ALT_DAD) != 0;
             const bool to_alt_parent = (from_ref && hb == 0) || (!from_ref && hb == 1); // :52-69
             const bool to_dad = to_alt_parent ? alt_is_dad : !alt_is_dad;
             wg_atomic_or(&s.pvote[p], to_dad ? 1u : 2u);
