@@ -84,6 +84,9 @@ int uz_reads_free(uz_ctx *ctx, int reads_id);
 /* uz_site_scan / uz_site_classes compute every class bit; uz_find / uz_phase in SNV / breakpoint
  * mode run the variant without the DEL / DUP codes, which only whole_region=True reads (:286-291). */
 int uz_site_scan(uz_ctx *ctx, int fam_id);
+/* Cohort form (many kids / families in one sites VCF, README.md:208): classify n_fam
+ * families of the SAME sites table in one launch.  Same result as n_fam calls of uz_site_scan. */
+int uz_site_scan_many(uz_ctx *ctx, const int32_t *fam_ids, int32_t n_fam);
 int uz_site_classes(uz_ctx *ctx, int fam_id, uint8_t *cls_out /* [n_sites] */);
 
 /* K2: per-DNM window emit.  Replaces get_position (:10-43) / get_close_vars

@@ -89,3 +89,30 @@ def test_window_emit_matches_oracle(engine, mode):
         assert np.array_equal(a, b), name
     assert want[0][-1] > 100 and want[3][-1] > 100
     engine.free_sites(sid)
+
+
+@pytest.mark.parametrize("n_sites,n_fam", [(4097, 1), (50_003, 5), (300_001, 3)])
+def test_cohort_scan_matches_per_family_scans(engine, n_sites, n_fam):
+    """uz_site_scan_many (one launch over the families of a sites table) gives every
+    family the class bytes of its own uz_site_scan, and those match the oracle."""
+    from oracle import oracle as orc
+    base = make_sites(n_sites, seed=91, contig_lens=[4e6, 2e6], weird_frac=0.05, complex_frac=0.04)
+    sid = engine.upload_sites(_Sites(base))
+    fams, cols = [], []
+    for k in range(n_fam):  # other trios of the same table: the table's records, other genotype columns
+        sc = base if k == 0 else make_sites(n_sites, seed=91 + 7 * k, contig_lens=[4e6, 2e6], weird_frac=0.05, complex_frac=0.04)
+        cols.append((sc.gt, sc.rd, sc.ad, sc.gq))
+        fams.append(engine.add_family(sid, sc.gt, sc.rd, sc.ad, sc.gq))
+    P = abi.make_params(min_gt_qual=15)
+    engine.set_params(P)
+    engine.site_scan_many(fams)
+    got_many = [engine.classify(f, P, n_sites).copy() for f in fams]  # classes are fresh: no rescan
+    for f, (gt, rd, ad, gq), gm in zip(fams, cols, got_many):
+        engine.site_scan(f)
+        assert np.array_equal(gm, engine.classify(f, P, n_sites))
+        sh, _ = _views(base)
+        want = orc.classify(P, sh, abi.family_view(gt, rd, ad, gq))
+        assert np.array_equal(want, gm)
+    with pytest.raises(Exception):
+        engine.site_scan_many([fams[0], fams[0]])
+    engine.free_sites(sid)

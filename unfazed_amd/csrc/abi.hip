@@ -375,6 +375,21 @@ int uz_site_scan(uz_ctx *c, int fam_id) {
     });
 }
 
+int uz_site_scan_many(uz_ctx *c, const int32_t *fam_ids, int32_t n_fam) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(n_fam >= 0 && (n_fam == 0 || fam_ids != nullptr), UZ_E_ARG, "bad family list");
+        if (n_fam == 0) return;
+        std::vector<FamilyDev *> fams;
+        for (int32_t k = 0; k < n_fam; k++) {
+            FamilyDev &f = fam_of(c, fam_ids[k]);
+            UZ_REQUIRE(f.sites_id == fam_of(c, fam_ids[0]).sites_id, UZ_E_ARG, "the families of one cohort scan must share a sites table");
+            for (int32_t j = 0; j < k; j++) UZ_REQUIRE(fam_ids[j] != fam_ids[k], UZ_E_ARG, "family listed twice");
+            fams.push_back(&f);
+        }
+        uz_launch_site_scan_many(c, fams.data(), n_fam, sites_of(c, fams[0]->sites_id), true);
+    });
+}
+
 int uz_site_classes(uz_ctx *c, int fam_id, uint8_t *out) {
     return guarded(c, [&] {
         FamilyDev &f = fam_of(c, fam_id);

@@ -13,7 +13,9 @@
 // :442-543) and get_position (:10-43).  No MFMA: there is no contraction here.
 #include "uz_ctx.hpp"
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 
@@ -190,9 +192,19 @@ struct FamPtrs {
     const uint16_t *rd[3], *ad[3], *gq[3];
 };
 
-template <int SPT, bool CNV, bool T0>
-__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f, uint8_t *__restrict__ cls, int64_t n, SiteParams Pk, const int2 *__restrict__ lut,
-                                                   const uint32_t *__restrict__ small) {
+// A cohort scan (BATCH) classifies many trios of one sites table in a single launch: blockIdx.y picks
+// the family, so one pass of 288 GB-class genotype columns costs one launch ramp instead of hundreds.
+struct FamBatchItem {
+    FamPtrs f;
+    uint8_t *cls;
+};
+
+template <int SPT, bool CNV, bool T0, bool BATCH>
+__global__ __launch_bounds__(256) void k_site_scan(FamPtrs f1, uint8_t *cls1, int64_t n, SiteParams Pk, const int2 *__restrict__ lut,
+                                                   const uint32_t *__restrict__ small, const FamBatchItem *__restrict__ batch) {
+    FamPtrs f = f1;
+    uint8_t *__restrict__ cls = cls1;
+    if constexpr (BATCH) { f = batch[blockIdx.y].f; cls = batch[blockIdx.y].cls; }
     // every workgroup keeps the low-depth part of the threshold table in LDS (8 KiB) and walks the
     // site chunks grid-stride, so the fill is paid once per workgroup, not per chunk
     __shared__ uint32_t lds_lut[4 * UZ_AB_LDS_T];
@@ -429,48 +441,84 @@ bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv) {
 #define UZ_SITE_SPT 8
 #endif
 
+namespace {
+
+void ensure_ab_lut(uz_ctx *c, const SiteParams &sp) {
+    if (c->ab_lut_valid && site_params_equal(c->ab_lut_params, c->P)) return;
+    c->ab_lut.ensure((size_t)4 * UZ_AB_LUT_N * 2 + 4 + 4 * UZ_AB_LDS_T);
+    int *flag = c->ab_lut.p + (size_t)4 * UZ_AB_LUT_N * 2;
+    UZ_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_build_ab_lut, dim3((4 * UZ_AB_LUT_N + 255) / 256), dim3(256), 0, c->stream, sp, (int2 *)c->ab_lut.p,
+                       (uint32_t *)(flag + 4), flag);
+    UZ_HIP(hipGetLastError());
+    int special = 0;
+    UZ_HIP(hipMemcpyAsync(&special, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    UZ_HIP(hipStreamSynchronize(c->stream));
+    c->ab_lut_t0_special = special != 0;
+    c->ab_lut_valid = true;
+    c->ab_lut_params = c->P;
+}
+
+FamPtrs fam_ptrs(const FamilyDev &f) {
+    FamPtrs fp;
+    fp.gt = f.gt;
+    for (int m = 0; m < 3; m++) { fp.rd[m] = f.rd[m]; fp.ad[m] = f.ad[m]; fp.gq[m] = f.gq[m]; }
+    return fp;
+}
+
+// one family (batch == nullptr) or n_fam families of the same sites table
+void launch_site_scan(uz_ctx *c, const FamPtrs &fp, uint8_t *cls, int64_t n, bool with_cnv, const FamBatchItem *batch, int n_fam) {
+    const SiteParams sp = make_site_params(c->P);
+    ensure_ab_lut(c, sp);
+    static const int spt = [] { const char *e = getenv("UZ_SITE_SPT"); return e ? atoi(e) : UZ_SITE_SPT; }();
+    ProfScope ps(c, UZ_K_SITE_SCAN);
+    auto launch = [&](auto kern, int SPT) {
+        const int64_t n_chunks = (n + 256 * SPT - 1) / (256 * SPT);
+        static const int wgs = [] { const char *e = getenv("UZ_SITE_WGS"); return e ? atoi(e) : 4096; }();
+        int64_t nb = n_chunks < wgs ? n_chunks : wgs; // 256 CUs x 8 resident workgroups, grid-stride over the chunks
+        if (batch && n_fam > 1) { // the families fill the chip together
+            const int64_t per = (wgs + n_fam - 1) / n_fam;
+            nb = std::max<int64_t>(1, std::min<int64_t>(n_chunks, std::max<int64_t>(per, 16)));
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)nb, (unsigned)(batch ? n_fam : 1)), dim3(256), 0, c->stream, fp, cls, n, sp,
+                           (const int2 *)c->ab_lut.p, (const uint32_t *)(c->ab_lut.p + (size_t)4 * UZ_AB_LUT_N * 2 + 4), batch);
+    };
+    const bool t0 = c->ab_lut_t0_special;
+#define UZ_K1_PICK(SPTV, BATCHV)                                                                                              \
+    do {                                                                                                                        \
+        if (with_cnv) { if (t0) launch(k_site_scan<SPTV, true, true, BATCHV>, SPTV); else launch(k_site_scan<SPTV, true, false, BATCHV>, SPTV); } \
+        else { if (t0) launch(k_site_scan<SPTV, false, true, BATCHV>, SPTV); else launch(k_site_scan<SPTV, false, false, BATCHV>, SPTV); }        \
+    } while (0)
+    if (batch) { if (spt == 16) UZ_K1_PICK(16, true); else UZ_K1_PICK(8, true); }
+    else { if (spt == 16) UZ_K1_PICK(16, false); else UZ_K1_PICK(8, false); }
+#undef UZ_K1_PICK
+    UZ_HIP(hipGetLastError());
+}
+
+} // namespace
+
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv) {
-    if (s.n > 0) {
-        FamPtrs fp;
-        fp.gt = f.gt;
-        for (int m = 0; m < 3; m++) { fp.rd[m] = f.rd[m]; fp.ad[m] = f.ad[m]; fp.gq[m] = f.gq[m]; }
-        const SiteParams sp = make_site_params(c->P);
-        if (!(c->ab_lut_valid && site_params_equal(c->ab_lut_params, c->P))) {
-            c->ab_lut.ensure((size_t)4 * UZ_AB_LUT_N * 2 + 4 + 4 * UZ_AB_LDS_T);
-            int *flag = c->ab_lut.p + (size_t)4 * UZ_AB_LUT_N * 2;
-            UZ_HIP(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
-            hipLaunchKernelGGL(k_build_ab_lut, dim3((4 * UZ_AB_LUT_N + 255) / 256), dim3(256), 0, c->stream, sp, (int2 *)c->ab_lut.p,
-                               (uint32_t *)(flag + 4), flag);
-            UZ_HIP(hipGetLastError());
-            int special = 0;
-            UZ_HIP(hipMemcpyAsync(&special, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            UZ_HIP(hipStreamSynchronize(c->stream));
-            c->ab_lut_t0_special = special != 0;
-            c->ab_lut_valid = true;
-            c->ab_lut_params = c->P;
-        }
-        static const int spt = [] { const char *e = getenv("UZ_SITE_SPT"); return e ? atoi(e) : UZ_SITE_SPT; }();
-        ProfScope ps(c, UZ_K_SITE_SCAN);
-        auto launch = [&](auto kern, int SPT) {
-            const int64_t n_chunks = (s.n + 256 * SPT - 1) / (256 * SPT);
-            static const int wgs = [] { const char *e = getenv("UZ_SITE_WGS"); return e ? atoi(e) : 4096; }();
-            const int64_t nb = n_chunks < wgs ? n_chunks : wgs; // 256 CUs x 8 resident workgroups, grid-stride over the chunks
-            hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(256), 0, c->stream, fp, f.cls, s.n, sp, (const int2 *)c->ab_lut.p,
-                               (const uint32_t *)(c->ab_lut.p + (size_t)4 * UZ_AB_LUT_N * 2 + 4));
-        };
-        const bool t0 = c->ab_lut_t0_special;
-        if (spt == 16) {
-            if (with_cnv) { if (t0) launch(k_site_scan<16, true, true>, 16); else launch(k_site_scan<16, true, false>, 16); }
-            else { if (t0) launch(k_site_scan<16, false, true>, 16); else launch(k_site_scan<16, false, false>, 16); }
-        } else {
-            if (with_cnv) { if (t0) launch(k_site_scan<8, true, true>, 8); else launch(k_site_scan<8, true, false>, 8); }
-            else { if (t0) launch(k_site_scan<8, false, true>, 8); else launch(k_site_scan<8, false, false>, 8); }
-        }
-        UZ_HIP(hipGetLastError());
-    }
+    if (s.n > 0) launch_site_scan(c, fam_ptrs(f), f.cls, s.n, with_cnv, nullptr, 1);
     f.cls_has_cnv = with_cnv;
     f.cls_valid = true;
     f.cls_params = c->P;
+}
+
+void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv) {
+    if (n_fam <= 0) return;
+    if (s.n > 0) {
+        std::vector<FamBatchItem> items((size_t)n_fam);
+        for (int k = 0; k < n_fam; k++) { items[(size_t)k].f = fam_ptrs(*fams[k]); items[(size_t)k].cls = fams[k]->cls; }
+        c->fam_batch.ensure((size_t)n_fam * sizeof(FamBatchItem));
+        UZ_HIP(hipMemcpyAsync(c->fam_batch.p, items.data(), items.size() * sizeof(FamBatchItem), hipMemcpyHostToDevice, c->stream));
+        UZ_HIP(hipStreamSynchronize(c->stream)); // `items` is pageable host memory
+        launch_site_scan(c, items[0].f, items[0].cls, s.n, with_cnv, (const FamBatchItem *)c->fam_batch.p, n_fam);
+    }
+    for (int k = 0; k < n_fam; k++) {
+        fams[k]->cls_has_cnv = with_cnv;
+        fams[k]->cls_valid = true;
+        fams[k]->cls_params = c->P;
+    }
 }
 
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode) {

@@ -127,6 +127,7 @@ struct uz_ctx {
 
     // allele-balance threshold table of K1 (k_sites.hip), rebuilt when the thresholds change
     DevBuf<int32_t> ab_lut;
+    DevBuf<uint8_t> fam_batch; // cohort scan: per-family column pointers
     bool ab_lut_valid = false;
     bool ab_lut_t0_special = false;
     uz_params ab_lut_params;
@@ -169,6 +170,7 @@ struct ProfScope {
 
 // stage launchers
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
+void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode);
 void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d);
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,

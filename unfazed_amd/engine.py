@@ -21,7 +21,7 @@ EXPORTS = [
     "uz_sites_upload", "uz_family_upload", "uz_reads_upload",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
-    "uz_site_scan", "uz_site_classes", "uz_find", "uz_find_fetch",
+    "uz_site_scan", "uz_site_scan_many", "uz_site_classes", "uz_find", "uz_find_fetch",
     "uz_phase", "uz_phase_votes", "uz_phase_groups",
     "uz_prof_enable", "uz_prof_reset", "uz_prof_get",
 ]
@@ -61,6 +61,7 @@ def load_library(path: Optional[str] = None):
     L.uz_sites_free.argtypes = [vp, C.c_int]
     L.uz_reads_free.argtypes = [vp, C.c_int]
     L.uz_site_scan.argtypes = [vp, C.c_int]
+    L.uz_site_scan_many.argtypes = [vp, vp, C.c_int32]
     L.uz_site_classes.argtypes = [vp, C.c_int, vp]
     L.uz_find.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
     L.uz_find_fetch.argtypes = [vp, vp, vp, vp]
@@ -165,6 +166,11 @@ class HipEngine:
     # ----------------------------------------------------------- site stage
     def site_scan(self, fam: int):
         self._ck(self.L.uz_site_scan(self.h, int(fam)), "uz_site_scan")
+
+    def site_scan_many(self, fams):
+        """cohort form: all the families (of one sites table) in one launch"""
+        ids = np.ascontiguousarray(np.asarray(list(fams), dtype=np.int32))
+        self._ck(self.L.uz_site_scan_many(self.h, ids.ctypes.data, int(ids.size)), "uz_site_scan_many")
 
     def classify(self, fam: int, params: abi.Params, n_sites: int) -> np.ndarray:
         self.set_params(params)
