@@ -66,7 +66,8 @@ def main():
     from synth import bigsynth
     from synth.sites_np import make_sites, place_dnms_full
     from unfazed_amd import abi, build
-    from unfazed_amd.engine import HipEngine, K_PHASE, K_SEG_QC, K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL
+    from unfazed_amd.engine import (HipEngine, K_PHASE, K_SEG_QC, K_SEG_QC_PASS, K_SITE_SCAN, K_SIZING, K_WINDOW_COUNT,
+                                    K_WINDOW_FILL)
 
     build.build()
     t_gen = time.time()
@@ -113,7 +114,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE)}
+    prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING)}
+    qc_records = eng.prof_units(K_SEG_QC_PASS)
     eng.prof_enable(False)
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -141,6 +143,16 @@ def main():
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
                 "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n)}
 
+    # The kernel that moves the most bytes per step is K3a's quality pass, not K1: per examined record it
+    # reads the quality row (readlen B) + 20 B of fixed fields and list id + one CIGAR word, writes 1 B.
+    qc_ms, qc_n = prof[K_SEG_QC_PASS]
+    qc_us = qc_ms / max(1, qc_n) * 1e3
+    qc_bytes = qc_records * (int(P.readlen) + 25.0)
+    roofline_k3a = {"bound": "hbm", "kernel": "k_seg_qc", "achieved": round(qc_bytes / (qc_us * 1e-6) / 1e9, 1) if qc_n else 0.0,
+                    "peak": 8000.0, "unit": "GB/s", "frac": round(qc_bytes / (qc_us * 1e-6) / 1e9 / 8000.0, 4) if qc_n else 0.0,
+                    "traffic": None, "avg_launch_us": round(qc_us, 1), "records_examined": int(qc_records),
+                    "algorithmic_bytes_per_launch": int(qc_bytes)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
         cpu = cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, res)
@@ -156,11 +168,13 @@ def main():
                        "dnms_per_gpu": n, "sites": sc.n, "coverage": "30x", "search_dist": 5000, "pairs_per_dnm": cfg.n_pairs,
                        "alignment_records": wl.n_segs, "parallelism": "dnm-shard x%d, no collective" % world},
             "roofline": roofline,
+            "roofline_k3a": roofline_k3a,
             "cpu_baseline": cpu,
             "kernels_ms_per_step": {
                 "site_scan": round(prof[K_SITE_SCAN][0] / args.steps, 3),
                 "window_count+scan": round(prof[K_WINDOW_COUNT][0] / args.steps, 3),
                 "window_fill": round(prof[K_WINDOW_FILL][0] / args.steps, 3),
+                "sizing": round(prof[K_SIZING][0] / args.steps, 3),
                 "seg_qc": round(prof[K_SEG_QC][0] / args.steps, 3),
                 "phase": round(prof[K_PHASE][0] / args.steps, 3),
             },

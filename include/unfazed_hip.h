@@ -42,6 +42,8 @@ extern "C" {
 #define UZ_K_WINDOW_FILL 2
 #define UZ_K_SEG_QC 3
 #define UZ_K_PHASE 4
+#define UZ_K_SEG_QC_PASS 5 /* the quality / CIGAR pass of K3a alone (k_seg_qc), inside UZ_K_SEG_QC */
+#define UZ_K_SIZING 6      /* fetch-range sizing pass */
 #define UZ_K_COUNT 8
 
 typedef struct uz_ctx uz_ctx;
@@ -123,6 +125,8 @@ int uz_phase_groups(uz_ctx *ctx, int64_t *grp_off /* [2n+1] */, int32_t *grp_q);
 int uz_prof_enable(uz_ctx *ctx, int on);
 int uz_prof_reset(uz_ctx *ctx);
 int uz_prof_get(uz_ctx *ctx, int kernel, double *total_ms, int64_t *launches);
+/* Units the last launch of a kernel processed (K3a ids: alignment records examined; 0 when unknown). */
+int uz_prof_units(uz_ctx *ctx, int kernel, int64_t *units);
 
 #ifdef __cplusplus
 }

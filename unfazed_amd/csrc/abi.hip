@@ -484,5 +484,11 @@ int uz_prof_get(uz_ctx *c, int kernel, double *total_ms, int64_t *launches) {
         if (launches) *launches = c->prof[kernel].launches;
     });
 }
+int uz_prof_units(uz_ctx *c, int kernel, int64_t *units) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(kernel >= 0 && kernel < UZ_K_COUNT && units != nullptr, UZ_E_ARG, "bad kernel id");
+        *units = c->prof[kernel].last_units;
+    });
+}
 
 } // extern "C"

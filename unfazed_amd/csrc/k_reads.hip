@@ -95,13 +95,22 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict_
     const int mine = wanted ? list[r0 + t] : 0;
     low[t] = 0;
     if (t == 0) maxch = 0;
-    int ls = 0;
-    uint32_t ro = 0;
-    if (wanted && !(R.aux[mine] & UZ_AUX_DECODE_BAD)) { ls = R.l_seq[mine]; ro = R.sq_off16[mine]; }
+    int ls = 0, ncg = 0, mq = 0;
+    uint32_t ro = 0, fl = 0, ax = UZ_AUX_DECODE_BAD, coff = 0;
+    if (wanted) { // every fixed-width field of the record in one round trip
+        ax = R.aux[mine]; fl = R.flag[mine]; mq = R.mapq[mine]; coff = R.cigar_off[mine]; ncg = R.n_cigar[mine];
+        ls = R.l_seq[mine]; ro = R.sq_off16[mine];
+        if (ax & UZ_AUX_DECODE_BAD) { ls = 0; ro = 0; }
+    }
+    // the first CIGAR operation (usually the only one) is requested now and used after the quality pass
+    const uint32_t c0 = (wanted && ncg > 0) ? R.cigar[coff] : 0u;
     row16[t] = ro;
     len[t] = ls;
+    int mc = (ls + 15) >> 4; // most chunks of any record of the block: wave maximum first, one LDS atomic per wave
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mc, o, 64); mc = v > mc ? v : mc; }
     __syncthreads();
-    if (ls) atomicMax(&maxch, (ls + 15) >> 4);
+    if ((t & 63) == 0 && mc) atomicMax(&maxch, mc);
     __syncthreads();
     const int nch = maxch;
     const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
@@ -132,7 +141,12 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict_
         }
     }
     __syncthreads();
-    if (wanted) qc[mine] = uz_seg_qc_flags(R, mine, min_map_qual, low[t]);
+    if (wanted) {
+        int nonmatch = 0, none = 0;
+        if (ncg > 0) uz_cigar_op_counts(c0, nonmatch, none);
+        for (int k = 1; k < ncg; k++) uz_cigar_op_counts(R.cigar[coff + k], nonmatch, none);
+        qc[mine] = uz_seg_qc_combine(fl, ax, mq, min_map_qual, low[t], ncg, nonmatch, none);
+    }
 }
 
 // Marks the records a batch can touch: every record of every fetch range and its mate.  One wave per
@@ -280,6 +294,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     UZ_HIP(hipMemsetAsync(st->pre_hl.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
     {
         const unsigned nb = (unsigned)(((int64_t)n * 16 + 255) / 256);
+        ProfScope ps(c, UZ_K_SIZING);
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
         UZ_HIP(hipGetLastError());
     }
@@ -364,6 +379,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         UZ_HIP(hipGetLastError());
         if (list_cap > 0) {
+            ProfScope ps2(c, UZ_K_SEG_QC_PASS);
             hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, c->stream, make_rd(r),
                                (const int32_t *)st->need_list.p, (const unsigned int *)st->need_count.p, c->P.min_map_qual,
                                c->P.min_gt_qual, r.qc);
@@ -406,6 +422,11 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     if (origin) UZ_HIP(hipMemcpyAsync(origin, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (evidence) UZ_HIP(hipMemcpyAsync(evidence, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     UZ_HIP(hipStreamSynchronize(c->stream));
+    if (r.n > 0) {
+        unsigned int m = 0;
+        UZ_HIP(hipMemcpy(&m, st->need_count.p, sizeof(m), hipMemcpyDeviceToHost));
+        c->prof[UZ_K_SEG_QC].last_units = c->prof[UZ_K_SEG_QC_PASS].last_units = (int64_t)m;
+    }
     st->have_lists = a.want_lists != 0;
     c->phase_valid = true;
 }

@@ -1194,20 +1194,15 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int
 
 // per-segment QC bits (K3a): goodread (:28-53) and the two CIGAR counts of :190-203, given the
 // number of base qualities below the threshold
-UZ_DEV uint8_t uz_seg_qc_flags(const RD &R, int seg, int min_map_qual, int low) {
-    const uint32_t f = R.flag[seg];
-    const uint32_t aux = R.aux[seg];
+UZ_DEV void uz_cigar_op_counts(uint32_t c, int &nonmatch, int &none) {
+    const int op = c & 15, l = (int)(c >> 4);
+    if (op != UZ_OP_M && op != UZ_OP_EQ) nonmatch++;
+    if (op == UZ_OP_I || op == UZ_OP_S) none += l;
+}
+UZ_DEV uint8_t uz_seg_qc_combine(uint32_t f, uint32_t aux, int mapq, int min_map_qual, int low, int nc, int nonmatch, int none) {
     if (aux & UZ_AUX_DECODE_BAD) return 0; // no CIGAR / SEQ / QUAL: never a good read (unpinned)
-    const bool base_ok = !((f & 512u) || (f & 4u) || (f & 1024u) || (int)R.mapq[seg] < min_map_qual || (f & 256u) ||
+    const bool base_ok = !((f & 512u) || (f & 4u) || (f & 1024u) || mapq < min_map_qual || (f & 256u) ||
                            (f & 2048u) || (f & 8u) || !(aux & UZ_AUX_MATE_SAME_TID)); // :31-41
-    const uint32_t *c = R.cigar + R.cigar_off[seg];
-    const int nc = R.n_cigar[seg];
-    int nonmatch = 0, none = 0;
-    for (int k = 0; k < nc; k++) {
-        const int op = c[k] & 15, l = (int)(c[k] >> 4);
-        if (op != UZ_OP_M && op != UZ_OP_EQ) nonmatch++;
-        if (op == UZ_OP_I || op == UZ_OP_S) none += l;
-    }
     uint8_t qc = 0;
     if (base_ok) {
         qc |= UZ_QC_GOOD_DISC;
@@ -1216,6 +1211,16 @@ UZ_DEV uint8_t uz_seg_qc_flags(const RD &R, int seg, int min_map_qual, int low) 
     if (nonmatch <= 5) qc |= UZ_QC_NM5;
     if (none <= 5) qc |= UZ_QC_NONE5;
     return qc;
+}
+UZ_DEV uint8_t uz_seg_qc_flags(const RD &R, int seg, int min_map_qual, int low) {
+    const uint32_t f = R.flag[seg];
+    const uint32_t aux = R.aux[seg];
+    if (aux & UZ_AUX_DECODE_BAD) return 0;
+    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    const int nc = R.n_cigar[seg];
+    int nonmatch = 0, none = 0;
+    for (int k = 0; k < nc; k++) uz_cigar_op_counts(c[k], nonmatch, none);
+    return uz_seg_qc_combine(f, aux, (int)R.mapq[seg], min_map_qual, low, nc, nonmatch, none);
 }
 UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual, int min_base_qual) {
     int low = 0;

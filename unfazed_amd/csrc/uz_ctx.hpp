@@ -110,6 +110,7 @@ struct DnmsDev {
 struct ProfSlot {
     double total_ms = 0;
     int64_t launches = 0;
+    int64_t last_units = 0;
 };
 struct ProfPending {
     int kernel;

@@ -14,7 +14,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UZ_HIP_LIB", os.path.join(_HERE, "libunfazed_hip.so"))
 
-K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE = 0, 1, 2, 3, 4
+K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING = 0, 1, 2, 3, 4, 5, 6
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
@@ -23,7 +23,7 @@ EXPORTS = [
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
     "uz_site_scan", "uz_site_scan_many", "uz_site_classes", "uz_find", "uz_find_fetch",
     "uz_phase", "uz_phase_votes", "uz_phase_groups",
-    "uz_prof_enable", "uz_prof_reset", "uz_prof_get",
+    "uz_prof_enable", "uz_prof_reset", "uz_prof_get", "uz_prof_units",
 ]
 
 _lib = None
@@ -71,6 +71,7 @@ def load_library(path: Optional[str] = None):
     L.uz_prof_enable.argtypes = [vp, C.c_int]
     L.uz_prof_reset.argtypes = [vp]
     L.uz_prof_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.uz_prof_units.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("uz_destroy", "uz_last_error"):
@@ -250,3 +251,8 @@ class HipEngine:
         n = C.c_int64(0)
         self._ck(self.L.uz_prof_get(self.h, int(kernel), C.byref(ms), C.byref(n)), "uz_prof_get")
         return ms.value, n.value
+
+    def prof_units(self, kernel: int) -> int:
+        u = C.c_int64(0)
+        self._ck(self.L.uz_prof_units(self.h, int(kernel), C.byref(u)), "uz_prof_units")
+        return int(u.value)
