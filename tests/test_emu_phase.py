@@ -16,6 +16,9 @@ CASES = [
     dict(no_extended=True),
     dict(base_err=0.02, cluster_prob=1.0, lowq_prob=0.06),
     dict(kids=["kidA", "kidB"], odd_read_prob=0.15, softclip_prob=0.1, indel_prob=0.08, indel_dnm_frac=0.5),
+    dict(coverage_per_hap=45.0, n_dnms=3),                                          # pair tables beyond 1024 entries
+    dict(coverage_per_hap=30.0, site_rate=1 / 80.0, cluster_prob=1.0, n_dnms=3),    # dense het sites
+    dict(coverage_per_hap=22.0, base_err=0.03, lowq_prob=0.05, n_dnms=4),            # noisy
 ]
 
 
@@ -23,7 +26,7 @@ CASES = [
 def test_kernel_body_matches_oracle(ci):
     kw = dict(CASES[ci])
     no_ext = kw.pop("no_extended", False)
-    ds = make_small(SmallConfig(seed=700 + ci, n_dnms=8, **kw))
+    ds = make_small(SmallConfig(seed=700 + ci, **dict(dict(n_dnms=8), **kw)))
     sites = SitesTable.from_records(ds.sites, ds.samples)
     P = abi.make_params(no_extended=no_ext)
     sv = abi.sites_view(sites)

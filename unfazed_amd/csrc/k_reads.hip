@@ -81,6 +81,9 @@ __global__ __launch_bounds__(256) void k_compact_need(const uint8_t *__restrict_
     }
 }
 
+#ifndef UZ_QC_BATCH
+#define UZ_QC_BATCH 5
+#endif
 __global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict__ list, const unsigned int *__restrict__ count,
                                                 int min_map_qual, int min_base_qual, uint8_t *qc) {
     __shared__ int low[256];
@@ -114,12 +117,12 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict_
     __syncthreads();
     const int nch = maxch;
     const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
-    // five independent 16-byte loads in flight per lane before any of them is counted
-    for (int j0 = 0; j0 < nch; j0 += 5) {
-        uint4 v[5];
-        int rl[5], l[5];
+    // UZ_QC_BATCH independent 16-byte loads in flight per lane before any of them is counted
+    for (int j0 = 0; j0 < nch; j0 += UZ_QC_BATCH) {
+        uint4 v[UZ_QC_BATCH];
+        int rl[UZ_QC_BATCH], l[UZ_QC_BATCH];
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
+        for (int u = 0; u < UZ_QC_BATCH; u++) {
             const int it = t + 256 * (j0 + u);
             rl[u] = it / nch;
             const int ch = it - rl[u] * nch;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict_
             if (l[u] > 0) v[u] = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl[u]] + ch) << 4));
         }
 #pragma unroll
-        for (int u = 0; u < 5; u++) {
+        for (int u = 0; u < UZ_QC_BATCH; u++) {
             if (l[u] <= 0) continue;
             const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
             int c = 0;
