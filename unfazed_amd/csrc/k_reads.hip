@@ -216,6 +216,10 @@ struct PhaseState {
     DevBuf<unsigned long long> pool_cursor;
     DevBuf<int32_t> need_list;
     DevBuf<unsigned int> need_count;
+    int32_t *bounds_h = nullptr; // pinned: the copy back must not block the host, the marking kernels follow it
+    size_t bounds_h_cap = 0;
+    hipEvent_t bounds_ready = nullptr;
+    int n_cus = 0;
     std::vector<long long> list_start_h;
     std::vector<int32_t> list_len_h;
     bool have_lists = false;
@@ -258,7 +262,9 @@ void uz_phase_state_free(uz_ctx *c) {
     if (!st) return;
     st->scratch.release(); st->bounds.release(); st->status.release(); st->counts.release(); st->origin.release();
     st->evidence.release(); st->cursor.release(); st->pre_win.release(); st->pre_ha.release(); st->pre_hl.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
-    st->pool_cursor.release();
+    st->pool_cursor.release(); st->need_list.release(); st->need_count.release();
+    if (st->bounds_ready) (void)hipEventDestroy(st->bounds_ready);
+    if (st->bounds_h) (void)hipHostFree(st->bounds_h);
     delete st;
     c->phase_state = nullptr;
 }
@@ -301,9 +307,35 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
         UZ_HIP(hipGetLastError());
     }
-    std::vector<int32_t> bh((size_t)5 * n);
-    UZ_HIP(hipMemcpyAsync(bh.data(), st->bounds.p, bh.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    UZ_HIP(hipStreamSynchronize(c->stream));
+    if (st->bounds_h_cap < (size_t)5 * n) {
+        if (st->bounds_h) (void)hipHostFree(st->bounds_h);
+        st->bounds_h = nullptr;
+        st->bounds_h_cap = (size_t)5 * n + (size_t)n;
+        UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
+    }
+    const int32_t *bh = st->bounds_h;
+    UZ_HIP(hipMemcpyAsync(st->bounds_h, st->bounds.p, (size_t)5 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (!st->bounds_ready) UZ_HIP(hipEventCreateWithFlags(&st->bounds_ready, hipEventDisableTiming));
+    UZ_HIP(hipEventRecord(st->bounds_ready, c->stream));
+    // K3a, lazily: QC bits only for the records some fetch range of this batch (or a mate) can reach.
+    // The marking only needs the fetch ranges, so it runs while the host sizes the scratch below.
+    hipEvent_t qc_a = nullptr, qc_b = nullptr;
+    if (r.n > 0) {
+        uz_prof_begin(c, UZ_K_SEG_QC, &qc_a, &qc_b);
+        UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n + 64, c->stream));
+        const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
+        hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                           (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const int32_t *)r.mate,
+                           r.need);
+        UZ_HIP(hipGetLastError());
+        if (!c->P.no_extended && c->n_het > 0) {
+            hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 64 + 255) / 256)), dim3(256), 0, c->stream,
+                               (const int32_t *)st->pre_ha.p, (const int32_t *)st->pre_hl.p, 0, (int64_t)c->n_het,
+                               (const int32_t *)r.mate, r.need);
+            UZ_HIP(hipGetLastError());
+        }
+    }
+    UZ_HIP(hipEventSynchronize(st->bounds_ready)); // the copy only: the marking kernels keep running
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
     for (int32_t d = 0; d < n; d++) {
         const int32_t *b = &bh[(size_t)5 * d];
@@ -321,8 +353,11 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
     Scr dummy;
     const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
-    hipDeviceProp_t prop;
-    UZ_HIP(hipGetDeviceProperties(&prop, c->device));
+    if (st->n_cus <= 0) { // asked once: the query is not cheap
+        hipDeviceProp_t prop;
+        UZ_HIP(hipGetDeviceProperties(&prop, c->device));
+        st->n_cus = prop.multiProcessorCount;
+    }
     static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 16) * 1024; }();
     static const int wgs_per_cu = [] {
         const char *e = getenv("UZ_PHASE_WGS_PER_CU");
@@ -332,7 +367,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         return by_lds < by_threads ? (by_lds > 0 ? by_lds : 1) : by_threads;
     }();
     a.lds_arena_bytes = arena_bytes;
-    int grid = prop.multiProcessorCount * wgs_per_cu;
+    int grid = st->n_cus * wgs_per_cu;
     if (grid > n) grid = n;
     const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
     while (grid > 1 && (size_t)grid * per_wg > budget) grid /= 2;
@@ -356,20 +391,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     UZ_HIP(hipMemsetAsync(timing.p, 0, 32 * sizeof(unsigned long long), c->stream));
     a.timing = timing.p;
 #endif
-    // K3a, lazily: QC bits only for the records some fetch range of this batch (or a mate) can reach
     if (r.n > 0) {
-        UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n + 64, c->stream));
-        ProfScope ps(c, UZ_K_SEG_QC);
-        const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
-        hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 64 + 255) / 256)), dim3(256), 0, c->stream,
-                           (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const int32_t *)r.mate, r.need);
-        UZ_HIP(hipGetLastError());
-        if (!c->P.no_extended && c->n_het > 0) {
-            hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 64 + 255) / 256)), dim3(256), 0, c->stream,
-                               (const int32_t *)st->pre_ha.p, (const int32_t *)st->pre_hl.p, 0, (int64_t)c->n_het,
-                               (const int32_t *)r.mate, r.need);
-            UZ_HIP(hipGetLastError());
-        }
         const int64_t list_cap = std::min<long long>(reach, (long long)r.n);
         st->need_list.ensure((size_t)list_cap + 16); st->need_count.ensure(4);
         UZ_HIP(hipMemsetAsync(st->need_count.p, 0, 4 * sizeof(unsigned int), c->stream));
@@ -379,8 +401,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             const int cpb = (int)((chunks + blocks - 1) / blocks);
             hipLaunchKernelGGL(k_compact_need, dim3((unsigned)((chunks + cpb - 1) / cpb)), dim3(256), 0, c->stream,
                                (const uint8_t *)r.need, (int64_t)r.n, cpb, st->need_list.p, st->need_count.p);
+            UZ_HIP(hipGetLastError());
         }
-        UZ_HIP(hipGetLastError());
         if (list_cap > 0) {
             ProfScope ps2(c, UZ_K_SEG_QC_PASS);
             hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, c->stream, make_rd(r),
@@ -388,6 +410,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                                c->P.min_gt_qual, r.qc);
             UZ_HIP(hipGetLastError());
         }
+        uz_prof_end(c, UZ_K_SEG_QC, qc_a, qc_b);
     }
     for (int attempt = 0; attempt < 4; attempt++) {
         UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
