@@ -84,7 +84,7 @@ struct Scr {
     int32_t *hpos, *hcanon, *h_a, *h_off, *sr_off;
     uint8_t *sr_exists;
     uint8_t *href, *halt; // REF / ALT base of every het site of the DNM
-    uint32_t *site_best;  // chaining: first frontier element (e << 12 | j) finding an allele at a het index
+    unsigned long long *site_best; // chaining: first frontier element finding an allele at a het index: (e << 12 | j) << 16 | allele << 8 | haplotype
     int32_t *cpos;
     uint32_t *cvote;
     uint8_t *cflag, *cref, *calt; // per candidate: UZ_CF_* flags, REF and ALT base
@@ -99,7 +99,9 @@ struct Scr {
     uint8_t *srt_fb;
     int32_t *rs_off, *rs_len, *fet0, *fet1;
     uint32_t *grp, *pvote, *pq;
-    unsigned long long *key;
+    unsigned long long *key;  // second buffer of the counting sort
+    unsigned long long *pkey; // per pair: smallest claim rank of the current chaining level
+    unsigned long long *win;  // winners of a chaining level
     uint8_t *assigned;
     int32_t *fr_pair[2], *fr_pos[2];
     uint8_t *fr_hap[2];
@@ -136,6 +138,7 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.rs_off, M); uz_carve(base, o, s.rs_len, M); uz_carve(base, o, s.fet0, M); uz_carve(base, o, s.fet1, M);
     uz_carve(base, o, s.grp, M); uz_carve(base, o, s.pvote, M); uz_carve(base, o, s.pq, M);
     uz_carve(base, o, s.key, M); uz_carve(base, o, s.assigned, M);
+    uz_carve(base, o, s.pkey, M); uz_carve(base, o, s.win, M);
     for (int k = 0; k < 2; k++) { uz_carve(base, o, s.fr_pair[k], FR); uz_carve(base, o, s.fr_pos[k], FR); uz_carve(base, o, s.fr_hap[k], FR); }
     uz_carve(base, o, s.o_flag, M + C + 2);
     uz_carve(base, o, s.q_cnt, 2 * M + 1026); uz_carve(base, o, s.q_fill, 2 * M + 1026);
@@ -149,21 +152,21 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
 // Arrays are placed in the workgroup's LDS arena in the order they are requested, with their ACTUAL
 // sizes; whatever does not fit keeps its pointer into the HBM scratch (the code is address-space
 // agnostic).  "Temporary" arrays live above the persistent ones and are recycled at phase boundaries.
-struct Arena {
+struct Arena { // two-ended: persistent arrays grow from the bottom, temporaries from the top
     uint8_t *base;
-    int cap, pers, tmp;
+    int cap, pers, top;
 };
 template <typename T>
 UZ_DEV void ar_p(Arena &ar, T *&ptr, size_t n) { // persistent for the rest of the DNM
     const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
-    if (ar.pers + b <= ar.cap) { ptr = reinterpret_cast<T *>(ar.base + ar.pers); ar.pers += b; ar.tmp = ar.pers; }
+    if (ar.pers + b <= ar.top) { ptr = reinterpret_cast<T *>(ar.base + ar.pers); ar.pers += b; }
 }
 template <typename T>
 UZ_DEV void ar_t(Arena &ar, T *&ptr, size_t n) { // until the next ar_reset
     const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
-    if (ar.tmp + b <= ar.cap) { ptr = reinterpret_cast<T *>(ar.base + ar.tmp); ar.tmp += b; }
+    if (ar.pers + b <= ar.top) { ar.top -= b; ptr = reinterpret_cast<T *>(ar.base + ar.top); }
 }
-UZ_DEV void ar_reset(Arena &ar) { ar.tmp = ar.pers; }
+UZ_DEV void ar_reset(Arena &ar) { ar.top = ar.cap; }
 
 struct PhaseArgs {
     int32_t n;
@@ -491,7 +494,7 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long posi
 UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_t *lds_arena, int d) {
     const RD &R = a.R;
     Scr s = sg; // pointers into the HBM scratch; re-pointed into LDS below where the arrays fit
-    Arena ar = {lds_arena, lds_arena ? a.lds_arena_bytes : 0, 0, 0};
+    Arena ar = {lds_arena, lds_arena ? a.lds_arena_bytes : 0, 0, lds_arena ? a.lds_arena_bytes : 0};
     int32_t *stg1 = sg.seq_h, *stg2 = sg.srt_h; // staging of the ordered compaction in phase B
     const long long c0 = a.cand_off[d], h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);
@@ -539,8 +542,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     if (nA > a.caps.A) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
     {
         const size_t ni = 2 * (size_t)nA + 2; // at most two list elements per fetched record
-        ar_p(ar, s.i_seg, ni); ar_p(ar, s.i_hb, ni); ar_p(ar, s.i_pair, ni); ar_p(ar, s.i_soff, ni);
-        ar_p(ar, s.i_qp, ni); ar_p(ar, s.i_L, ni); ar_p(ar, s.i_R, ni);
+        // (i_soff / i_qp / i_L / i_R are written and read once, in the seeding step: they stay in HBM scratch)
+        ar_p(ar, s.i_seg, ni); ar_p(ar, s.i_hb, ni); ar_p(ar, s.i_pair, ni);
         ar_t(ar, s.a_cls, nA + 1); ar_t(ar, s.a_flag[0], nA + 1); ar_t(ar, s.a_flag[1], nA + 1);
         ar_t(ar, s.LR, ni); ar_t(ar, s.LA, ni);
     }
@@ -663,7 +666,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         UZ_TICK(2); // B.het
         if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
         ar_reset(ar);
-        ar_p(ar, s.reg_h, T + 1); ar_p(ar, s.reg_seg, T + 1); ar_p(ar, s.reg_pair, T + 1); ar_p(ar, s.cbase, T + 1);
+        // LDS goes to what the chaining levels read over and over; reg_seg is read twice (keys, pair table)
+        ar_p(ar, s.reg_h, T + 1); ar_p(ar, s.reg_pair, T + 1); ar_p(ar, s.cbase, T + 1);
         ar_t(ar, s.t_ov, T + 1); ar_t(ar, s.t_pass, T + 1); ar_t(ar, stg1, T + 1); ar_t(ar, stg2, T + 1);
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
@@ -743,15 +747,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         WG_T0 a.status[d] = UZ_ST_CAPACITY;
         return;
     }
+    int mp2 = 2;
+    while (mp2 < M) mp2 <<= 1;
     {
         ar_reset(ar);
-        int mp2 = 2;
-        while (mp2 < M) mp2 <<= 1;
-        ar_p(ar, s.keys, mp2 + 1); ar_p(ar, s.key, mp2 + 1);
-        ar_p(ar, s.srt_h, M + 1); ar_p(ar, s.srt_pid, M + 1); ar_p(ar, s.srt_fb, M + 1);
-        ar_p(ar, s.rs_off, M + 2); ar_p(ar, s.rs_len, M + 1); ar_p(ar, s.fet0, M + 1); ar_p(ar, s.fet1, M + 1);
-        ar_p(ar, s.grp, M + 1); ar_p(ar, s.pvote, M + 1); ar_p(ar, s.pq, M + 1); ar_p(ar, s.assigned, M + 1);
-        ar_t(ar, s.srt_flag, M + 1);
+        // persistent (read by every chaining level): assigned, srt_h, srt_fb; the sorted keys and the pair ids
+        // of the entries die with the allele tables (phase D), so they are temporaries
+        ar_p(ar, s.assigned, M + 1); ar_p(ar, s.srt_h, M + 1); ar_p(ar, s.srt_fb, M + 1);
+        ar_t(ar, s.keys, mp2 + 1); ar_t(ar, s.srt_pid, M + 1); ar_t(ar, s.srt_flag, M + 1);
     }
     int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path)
     WG_FOR(x, M) {
@@ -785,7 +788,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
         if (small || (keys_in_lds && M <= 1024)) wg_sort64(s.keys, M, sh, true);
         else if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
-            ar_t(ar, s.q_cnt, qrange + 2); ar_t(ar, s.q_fill, qrange + 2);
+            ar_t(ar, s.key, mp2 + 1); ar_t(ar, s.q_cnt, qrange + 2); ar_t(ar, s.q_fill, qrange + 2);
             WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
             WG_SYNC();
             WG_FOR(x, M) wg_atomic_add(&s.q_cnt[(int)(s.keys[x] >> 24) - qmin], 1);
@@ -819,6 +822,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         s.srt_pid[x] = st;
     }
     P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1
+    // per-pair arrays, now that the number of pairs is known; the chaining arrays first
+    ar_p(ar, s.pkey, P + 1); ar_p(ar, s.rs_off, P + 2); ar_p(ar, s.rs_len, P + 1); ar_p(ar, s.grp, P + 1);
+    ar_p(ar, s.fet0, P + 1); ar_p(ar, s.fet1, P + 1); ar_p(ar, s.pvote, P + 1); ar_p(ar, s.pq, P + 1);
     UZ_TICK(11); // P.scan
     WG_FOR(x, M) {
         const int pid = s.srt_pid[x] + s.srt_flag[x] - 1;
@@ -848,7 +854,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         s.rs_len[p] = len;
         s.fet0[p] = f0; s.fet1[p] = f1;
         s.grp[p] = 0; s.pvote[p] = 0;
-        s.key[p] = ~0ULL;
+        s.pkey[p] = ~0ULL;
         s.assigned[p] = 0;
     }
     WG_SYNC();
@@ -905,7 +911,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         {
             ar_reset(ar);
             const size_t fr = (size_t)(P > nI ? P : nI) + 2;
-            for (int k = 0; k < 2; k++) { ar_t(ar, s.fr_pair[k], fr); ar_t(ar, s.fr_pos[k], fr); ar_t(ar, s.fr_hap[k], fr); }
+            for (int k = 0; k < 2; k++) { ar_t(ar, s.fr_pair[k], fr); ar_t(ar, s.fr_hap[k], fr); }
+            for (int k = 0; k < 2; k++) ar_t(ar, s.fr_pos[k], fr);
+            int wp2 = 2; // the winners are sorted in place: room for the next power of two
+            while (wp2 < P) wp2 <<= 1;
+            ar_t(ar, s.win, (size_t)wp2 + 1);
         }
         WG_FOR(e, nI) {
             const int na = nae;
@@ -916,7 +926,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
         WG_SYNC();
         WG_FOR(p, P) if (s.grp[p]) s.assigned[p] = 1;
-        WG_FOR(h, nh) s.site_best[h] = 0xFFFFFFFFu;
+        WG_FOR(h, nh) s.site_best[h] = ~0ULL;
         WG_SYNC();
         while (F > 0) {
             // (i) per het index, the first frontier element (in visiting order e, then read_sites
@@ -925,13 +935,17 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             WG_FOR(e, F) {
                 const int p = s.fr_pair[cur][e];
                 const int fpos = s.fr_pos[cur][e];
+                const unsigned long long hap = s.fr_hap[cur][e];
                 const int x0 = s.rs_off[p], len = s.rs_len[p];
                 for (int j = 0; j < len; j++) {
                     const int h = s.srt_h[x0 + j];
                     if (s.hpos[h] == fpos) continue;            // :89-90
-                    if (!s.srt_fb[x0 + j]) continue;             // :104-105
+                    const unsigned long long fbv = s.srt_fb[x0 + j];
+                    if (!fbv) continue;                          // :104-105
                     if (!s.sr_exists[s.hcanon[h]]) { s.misc[0] = 1; continue; } // :106 KeyError
-                    wg_atomic_min32u(&s.site_best[h], ((uint32_t)e << 12) | (uint32_t)j);
+                    // the allele and haplotype of the finder ride along below the rank, so the
+                    // registrations can use them without going back to the frontier arrays
+                    wg_atomic_min64(&s.site_best[h], ((((unsigned long long)e << 12) | (unsigned long long)j) << 16) | (fbv << 8) | hap);
                 }
             }
             WG_SYNC();
@@ -945,39 +959,39 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 const int krel = k - s.sr_off[canon];
                 unsigned long long best = ~0ULL;
                 for (int h = canon; h < nh && s.hpos[h] == s.hpos[canon]; h++) { // het indices sharing the position
-                    const uint32_t b = s.site_best[h];
-                    if (b == 0xFFFFFFFFu) continue;
-                    const int e = (int)(b >> 12), j = (int)(b & 0xFFFu);
-                    const uint8_t fbv = s.srt_fb[s.rs_off[s.fr_pair[cur][e]] + j];
+                    const unsigned long long sb = s.site_best[h];
+                    if (sb == ~0ULL) continue;
+                    const unsigned long long b = sb >> 16; // (e << 12) | j
+                    const uint8_t fbv = (uint8_t)(sb >> 8);
                     const uint8_t nonf = fbv == s.href[h] ? s.halt[h] : s.href[h];
-                    const int hap = s.fr_hap[cur][e];
+                    const int hap = (int)(sb & 1ULL);
                     int target;
                     if (cb == fbv) target = hap;                 // :134-136
                     else if (cb == nonf) target = hap ^ 1;       // :137-141
                     else continue;
-                    const unsigned long long key = ((((unsigned long long)b) << 20 | (unsigned long long)krel) << 1) | (unsigned long long)target;
+                    const unsigned long long key = (((b << 20) | (unsigned long long)krel) << 1) | (unsigned long long)target;
                     best = key < best ? key : best;
                 }
-                if (best != ~0ULL) wg_atomic_min64(&s.key[p2], best);
+                if (best != ~0ULL) wg_atomic_min64(&s.pkey[p2], best);
             }
             WG_SYNC();
             UZ_TICK(16); // E.expand
             // winners in the order the reference appends them: "ref" targets by rank, then "alt"
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
-            WG_FOR(h, nh) s.site_best[h] = 0xFFFFFFFFu; // for the next level
+            WG_FOR(h, nh) s.site_best[h] = ~0ULL; // for the next level
             int W;
             {
                 int plo, phi, c1[1] = {0}, o1[1], t1[1];
                 wg_chunk(P, plo, phi);
-                for (int p = plo; p < phi; p++) c1[0] += (!s.assigned[p] && s.key[p] != ~0ULL) ? 1 : 0;
+                for (int p = plo; p < phi; p++) c1[0] += (!s.assigned[p] && s.pkey[p] != ~0ULL) ? 1 : 0;
                 wg_lane_exscan<1>(c1, o1, t1, sh);
                 W = t1[0];
                 int o = o1[0];
                 for (int p = plo; p < phi; p++) {
-                    if (!s.assigned[p] && s.key[p] != ~0ULL) {
-                        const unsigned long long k = s.key[p];
-                        s.keys[o++] = ((k & 1ULL) << 63) | (k >> 1);
+                    if (!s.assigned[p] && s.pkey[p] != ~0ULL) {
+                        const unsigned long long k = s.pkey[p];
+                        s.win[o++] = ((k & 1ULL) << 63) | (k >> 1);
                     }
                 }
             }
@@ -986,13 +1000,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // position in the next frontier = rank of the (target, rank) key among the winners: counted
             // directly while a level has few winners (one barrier), sorted otherwise
             const bool by_count = W <= 96;
-            if (!by_count) wg_sort64(s.keys, W, sh);
+            if (!by_count) wg_sort64(s.win, W, sh, (uint8_t *)s.win >= ar.base && (uint8_t *)s.win < ar.base + ar.cap);
             WG_FOR(w, W) {
-                const unsigned long long ok = s.keys[w];
+                const unsigned long long ok = s.win[w];
                 int posn = w;
                 if (by_count) {
                     posn = 0;
-                    for (int v = 0; v < W; v++) posn += s.keys[v] < ok;
+                    for (int v = 0; v < W; v++) posn += s.win[v] < ok;
                 }
                 const int e = (int)((ok >> 32) & 0xFFFFF), j = (int)((ok >> 20) & 0xFFF), krel = (int)(ok & 0xFFFFF);
                 const int pe = s.fr_pair[cur][e];
@@ -1004,7 +1018,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 // every winner key names a different pair: mark it here
                 s.assigned[p] = 1;
                 s.grp[p] |= (ok >> 63) ? 2u : 1u;
-                s.key[p] = ~0ULL;
+                s.pkey[p] = ~0ULL;
             }
             WG_SYNC();
 #ifdef UZ_EMU_STATS
