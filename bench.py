@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dnms", type=int, default=int(os.environ.get("UZ_BENCH_DNMS", 100000)), help="DNMs per GPU")
     ap.add_argument("--sites", type=int, default=int(os.environ.get("UZ_BENCH_SITES", 20000000)))
-    ap.add_argument("--cpu-dnms", type=int, default=4000, help="DNMs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-dnms", type=int, default=12000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
@@ -249,20 +249,33 @@ def cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, gpu_res):
             st[a:b], cnt[a:b], org[a:b], ev[a:b] = p["status"][a:b], p["counts"][a:b], p["origin"][a:b], p["evidence"][a:b]
         return dt, dict(status=st, counts=cnt, origin=org, evidence=ev)
 
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     dt1, r1 = run(1)
     dt2, _ = run(2)
-    dtc, rc = run(cores)
+    # the port does not scale to every hardware thread (allocator / page-fault contention between
+    # threads of one process): try a ladder of thread counts and report the best
+    ladder = sorted({t for t in (8, 16, 32, 64, 128, ncpu) if 2 < t <= ncpu})
+    best = None
+    sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
+    for t in ladder:
+        dtt, rt = run(t)
+        sweep[str(t)] = round(m / dtt, 1)
+        if best is None or dtt < best[0]:
+            best = (dtt, rt, t)
+    if best is None:
+        best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
+    dtc, rc, cores = best
     mism = 0
     for k in ("status", "counts", "origin", "evidence"):
         mism += int(np.any(np.asarray(gpu_res[k][:m]) != r1[k], axis=None if r1[k].ndim == 1 else 1).sum()) if r1[k].ndim > 1 \
             else int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
         mism += int((rc[k] != r1[k]).sum())
     return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",
-            "sample": "first %d DNMs of the GPU batch (read blocks copied back from HBM), oracle find+phase, %d threads over DNM ranges"
+            "sample": "first %d DNMs of the GPU batch (read blocks copied back from HBM), oracle find+phase, threads over DNM ranges (best of a ladder of thread counts: %d)"
                       % (m, cores),
             "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
             "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
+            "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu,
             "parity_mismatches_vs_gpu": mism}
 
 
