@@ -79,7 +79,7 @@ struct Caps { // per-workgroup scratch capacities (elements)
 
 struct Scr {
     uint8_t *a_cls;
-    int32_t *a_flag[2];
+    int32_t *a_flag0, *a_flag1; // (no pointer arrays in this struct: a dynamically indexed member would pin it in private memory)
     int32_t *LR, *LA;
     int32_t *hpos, *hcanon, *h_a, *h_off, *sr_off;
     uint8_t *sr_exists;
@@ -90,6 +90,10 @@ struct Scr {
     uint8_t *cflag, *cref, *calt; // per candidate: UZ_CF_* flags, REF and ALT base
     int32_t *t_ov, *t_pass;
     int32_t *reg_h, *reg_seg, *reg_pair;
+    uint32_t *reg_q, *t_q; // query-name id of every registration (and of every fetched record, before compaction)
+    int32_t *reg_mate, *t_mate;
+    uint32_t *i_q;         // per init element: name id, mate, span -- fetched once, when the list is built
+    int32_t *i_mate, *i_st, *i_en;
     uint8_t *cbase;
     int32_t *i_seg, *i_qp, *i_L, *i_R, *i_soff, *i_pair;
     uint8_t *i_hb;
@@ -103,8 +107,8 @@ struct Scr {
     unsigned long long *pkey; // per pair: smallest claim rank of the current chaining level
     unsigned long long *win;  // winners of a chaining level
     uint8_t *assigned;
-    int32_t *fr_pair[2], *fr_pos[2];
-    uint8_t *fr_hap[2];
+    int32_t *fr_pair0, *fr_pair1, *fr_pos0, *fr_pos1;
+    uint8_t *fr_hap0, *fr_hap1;
     int32_t *o_flag;
     int32_t *q_cnt, *q_fill; // counting sort of the pair-table keys over the query-name id range
     int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
@@ -122,7 +126,7 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     const size_t A = (size_t)c.A + 1, T = (size_t)c.T + 1, H = (size_t)c.H + 2, C = (size_t)c.C + 1, I = (size_t)c.I + 2, M = (size_t)c.M + 2;
     const size_t FR = (M > I ? M : I) + 1;
     uz_carve(base, o, s.a_cls, A);
-    uz_carve(base, o, s.a_flag[0], A); uz_carve(base, o, s.a_flag[1], A);
+    uz_carve(base, o, s.a_flag0, A); uz_carve(base, o, s.a_flag1, A);
     uz_carve(base, o, s.LR, 2 * A); uz_carve(base, o, s.LA, 2 * A);
     uz_carve(base, o, s.hpos, H); uz_carve(base, o, s.hcanon, H); uz_carve(base, o, s.h_a, H);
     uz_carve(base, o, s.h_off, H); uz_carve(base, o, s.sr_off, H); uz_carve(base, o, s.sr_exists, H);
@@ -131,6 +135,8 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.cflag, C); uz_carve(base, o, s.cref, C); uz_carve(base, o, s.calt, C);
     uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T);
     uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
+    uz_carve(base, o, s.reg_q, T); uz_carve(base, o, s.t_q, T); uz_carve(base, o, s.reg_mate, T); uz_carve(base, o, s.t_mate, T);
+    uz_carve(base, o, s.i_q, I); uz_carve(base, o, s.i_mate, I); uz_carve(base, o, s.i_st, I); uz_carve(base, o, s.i_en, I);
     uz_carve(base, o, s.i_seg, I); uz_carve(base, o, s.i_qp, I); uz_carve(base, o, s.i_L, I); uz_carve(base, o, s.i_R, I);
     uz_carve(base, o, s.i_soff, I); uz_carve(base, o, s.i_pair, I); uz_carve(base, o, s.i_hb, I);
     uz_carve(base, o, s.keys, M); uz_carve(base, o, s.seq_h, M);
@@ -139,7 +145,8 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.grp, M); uz_carve(base, o, s.pvote, M); uz_carve(base, o, s.pq, M);
     uz_carve(base, o, s.key, M); uz_carve(base, o, s.assigned, M);
     uz_carve(base, o, s.pkey, M); uz_carve(base, o, s.win, M);
-    for (int k = 0; k < 2; k++) { uz_carve(base, o, s.fr_pair[k], FR); uz_carve(base, o, s.fr_pos[k], FR); uz_carve(base, o, s.fr_hap[k], FR); }
+    uz_carve(base, o, s.fr_pair0, FR); uz_carve(base, o, s.fr_pos0, FR); uz_carve(base, o, s.fr_hap0, FR);
+    uz_carve(base, o, s.fr_pair1, FR); uz_carve(base, o, s.fr_pos1, FR); uz_carve(base, o, s.fr_hap1, FR);
     uz_carve(base, o, s.o_flag, M + C + 2);
     uz_carve(base, o, s.q_cnt, 2 * M + 1026); uz_carve(base, o, s.q_fill, 2 * M + 1026);
     uz_carve(base, o, s.misc, 8);
@@ -544,7 +551,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         const size_t ni = 2 * (size_t)nA + 2; // at most two list elements per fetched record
         // (i_soff / i_qp / i_L / i_R are written and read once, in the seeding step: they stay in HBM scratch)
         ar_p(ar, s.i_seg, ni); ar_p(ar, s.i_hb, ni); ar_p(ar, s.i_pair, ni);
-        ar_t(ar, s.a_cls, nA + 1); ar_t(ar, s.a_flag[0], nA + 1); ar_t(ar, s.a_flag[1], nA + 1);
+        ar_t(ar, s.a_cls, nA + 1); ar_t(ar, s.a_flag0, nA + 1); ar_t(ar, s.a_flag1, nA + 1);
         ar_t(ar, s.LR, ni); ar_t(ar, s.LA, ni);
     }
     int nre = 0, nae = 0; // elements of the "ref" / "alt" lists
@@ -552,17 +559,17 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         WG_FOR(i, nA) {
             const int cl = uz_classify_dnm_read(R, a, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
             s.a_cls[i] = (uint8_t)cl;
-            s.a_flag[0][i] = cl == 1;
-            s.a_flag[1][i] = cl == 2;
+            s.a_flag0[i] = cl == 1;
+            s.a_flag1[i] = cl == 2;
         }
         UZ_TICK(0); // A.classify
-        const int n_ref = wg_exscan(s.a_flag[0], nA, sh);
-        const int n_alt = wg_exscan(s.a_flag[1], nA, sh);
+        const int n_ref = wg_exscan(s.a_flag0, nA, sh);
+        const int n_alt = wg_exscan(s.a_flag1, nA, sh);
         WG_FOR(i, nA) {
             const int cl = s.a_cls[i];
             if (cl) {
                 int32_t *L = cl == 1 ? s.LR : s.LA;
-                const int k = s.a_flag[cl - 1][i];
+                const int k = cl == 1 ? s.a_flag0[i] : s.a_flag1[i];
                 L[2 * k] = (int)(fa + i);
                 L[2 * k + 1] = R.mate[fa + i];
             }
@@ -581,12 +588,12 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             if (lo < 0) lo = 0;
             const int code = uz_sv_classify(R, a, i, bp, lo, sv_start, sv_end);
             s.a_cls[t] = (uint8_t)code;
-            s.a_flag[0][t] = code == 3;
+            s.a_flag0[t] = code == 3;
         }
-        const int nban = wg_exscan(s.a_flag[0], nA, sh);
+        const int nban = wg_exscan(s.a_flag0, nA, sh);
         WG_FOR(t, nA) { // the banned names, in fetch order: (item, name)
             if (s.a_cls[t] == 3) {
-                const int k = s.a_flag[0][t];
+                const int k = s.a_flag0[t];
                 const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
                 s.i_qp[k] = t;
                 s.i_L[k] = (int32_t)R.qname[i];
@@ -604,14 +611,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 }
             } else code = 0;
             s.a_cls[t] = (uint8_t)code;
-            s.a_flag[1][t] = code ? 2 : 0;
+            s.a_flag1[t] = code ? 2 : 0;
         }
-        const int nsup = wg_exscan(s.a_flag[1], nA, sh);
+        const int nsup = wg_exscan(s.a_flag1, nA, sh);
         WG_FOR(t, nA) {
             const int code = s.a_cls[t];
             if (code) {
                 const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
-                const int k = s.a_flag[1][t];
+                const int k = s.a_flag1[t];
                 const int m = R.mate[i];
                 s.LR[k] = code == 1 ? i : m;      // :532-533
                 s.LR[k + 1] = code == 1 ? m : i;  // :562-563, :585-586
@@ -640,8 +647,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     const int nI = nre + nae;
     WG_FOR(m, nI) {
         const bool is_ref = m < nre;
-        s.i_seg[m] = is_ref ? s.LR[m] : s.LA[m - nre];
+        const int seg = is_ref ? s.LR[m] : s.LA[m - nre];
+        s.i_seg[m] = seg;
         s.i_hb[m] = is_ref ? 0 : 1;
+        // everything the later steps need of this record, in one round trip
+        s.i_q[m] = R.qname[seg]; s.i_mate[m] = R.mate[seg]; s.i_st[m] = R.start[seg]; s.i_en[m] = R.end[seg];
     }
     WG_SYNC();
 
@@ -678,8 +688,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             const int h = lo;
             const int seg = s.h_a[h] + (t - s.h_off[h]);
             s.reg_h[t] = h; // provisional: het index of work item t
+            // the record's fields are requested together: overlap test, pair filters (pure: evaluated for every
+            // overlapping record, the enumerate cut-off below only masks them), name id for the pair table
             const int ov = (long long)R.end[seg] > (long long)s.hpos[h];
-            s.t_ov[t] = ov;
+            const int mate = uz_pair_ok(R, a, seg);
+            const bool pok = ov && mate >= 0 && (R.qc[seg] & UZ_QC_NM5);
+            s.t_q[t] = R.qname[seg];
+            s.t_mate[t] = mate;
+            s.t_ov[t] = ov | (pok ? 2 : 0);
             s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
         }
         UZ_TICK(3); // B.overlap
@@ -687,13 +703,11 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         UZ_TICK(4); // B.scan1
         WG_FOR(t, T) {
             const int h = s.reg_h[t];
-            const int seg = s.h_a[h] + (t - s.h_off[h]);
-            bool ok = s.t_ov[t] != 0;
+            bool ok = (s.t_ov[t] & 2) != 0;
             if (ok) {
                 const int ei = s.t_pass[t] - s.t_pass[s.h_off[h]];
                 ok = !(ei > a.read_goal); // :179
             }
-            if (ok) ok = uz_pair_ok(R, a, seg) >= 0 && (R.qc[seg] & UZ_QC_NM5);
             s.t_ov[t] = ok;
             s.reg_pair[t] = ok; // scanned below: position in the registration list (reg_pair is free until phase S)
         }
@@ -707,6 +721,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 const int h = s.reg_h[t];
                 stg1[k] = h;
                 stg2[k] = s.h_a[h] + (t - s.h_off[h]);
+                s.reg_q[k] = s.t_q[t];
+                s.reg_mate[k] = s.t_mate[t];
             }
         }
         WG_SYNC();
@@ -721,9 +737,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         UZ_TICK(7); // B.compact
         // ---- C: seeding (:226-249): matches of every init element among the het sites
         WG_FOR(m, nI) {
-            const int seg = s.i_seg[m];
             int nm = 0, qp = 0, L = 0, Rr = -1;
-            if (R.mate[seg] >= 0) nm = uz_bsearch(R.start[seg], R.end[seg], s.hpos, nh, qp, L, Rr);
+            if (s.i_mate[m] >= 0) nm = uz_bsearch(s.i_st[m], s.i_en[m], s.hpos, nh, qp, L, Rr);
             s.i_qp[m] = qp; s.i_L[m] = L; s.i_R[m] = Rr;
             s.i_soff[m] = nm;
         }
@@ -759,13 +774,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path)
     WG_FOR(x, M) {
         uint32_t q;
-        if (x < E) q = R.qname[s.reg_seg[x]];
+        if (x < E) q = s.reg_q[x];
         else if (x < E + S) {
             int lo = 0, hi = nI; // init element owning seed x - E
             const int sx = x - E;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.i_soff[mid] <= sx) lo = mid; else hi = mid; }
-            q = R.qname[s.i_seg[lo]];
-        } else q = R.qname[s.i_seg[x - E - S]];
+            q = s.i_q[lo];
+        } else q = s.i_q[x - E - S];
         s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
         lmin = (int)q < lmin ? (int)q : lmin;
         lmax = (int)q > lmax ? (int)q : lmax;
@@ -844,10 +859,10 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         for (int x = x0; x < x1; x++) { // ascending sequence = the reference's time order
             const int seq = (int)(s.keys[x] & 0xFFFFFF);
             if (seq < E + S) len++;
-            if (seq < E) { f0 = s.reg_seg[seq]; f1 = R.mate[f0]; }          // :222
+            if (seq < E) { f0 = s.reg_seg[seq]; f1 = s.reg_mate[seq]; }     // :222
             else if (seq >= E + S) {                                        // :233-234
-                const int sg = s.i_seg[seq - E - S];
-                if (R.mate[sg] >= 0) { f0 = sg; f1 = R.mate[sg]; }
+                const int mt = s.i_mate[seq - E - S];
+                if (mt >= 0) { f0 = s.i_seg[seq - E - S]; f1 = mt; }
             }
         }
         if (len >= 4096) s.misc[2] = 1; // rank key: 12 bits for the read_sites index
@@ -911,8 +926,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         {
             ar_reset(ar);
             const size_t fr = (size_t)(P > nI ? P : nI) + 2;
-            for (int k = 0; k < 2; k++) { ar_t(ar, s.fr_pair[k], fr); ar_t(ar, s.fr_hap[k], fr); }
-            for (int k = 0; k < 2; k++) ar_t(ar, s.fr_pos[k], fr);
+            ar_t(ar, s.fr_pair0, fr); ar_t(ar, s.fr_hap0, fr); ar_t(ar, s.fr_pair1, fr); ar_t(ar, s.fr_hap1, fr);
+            ar_t(ar, s.fr_pos0, fr); ar_t(ar, s.fr_pos1, fr);
             int wp2 = 2; // the winners are sorted in place: room for the next power of two
             while (wp2 < P) wp2 <<= 1;
             ar_t(ar, s.win, (size_t)wp2 + 1);
@@ -920,22 +935,25 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         WG_FOR(e, nI) {
             const int na = nae;
             const int m = e < na ? (nre + e) : (e - na);
-            s.fr_pair[0][e] = s.i_pair[m];
-            s.fr_pos[0][e] = -1;
-            s.fr_hap[0][e] = s.i_hb[m];
+            s.fr_pair0[e] = s.i_pair[m];
+            s.fr_pos0[e] = -1;
+            s.fr_hap0[e] = s.i_hb[m];
         }
         WG_SYNC();
         WG_FOR(p, P) if (s.grp[p]) s.assigned[p] = 1;
         WG_FOR(h, nh) s.site_best[h] = ~0ULL;
         WG_SYNC();
         while (F > 0) {
+            int32_t *const fr_pair_c = cur ? s.fr_pair1 : s.fr_pair0, *const fr_pair_n = cur ? s.fr_pair0 : s.fr_pair1;
+            int32_t *const fr_pos_c = cur ? s.fr_pos1 : s.fr_pos0, *const fr_pos_n = cur ? s.fr_pos0 : s.fr_pos1;
+            uint8_t *const fr_hap_c = cur ? s.fr_hap1 : s.fr_hap0, *const fr_hap_n = cur ? s.fr_hap0 : s.fr_hap1;
             // (i) per het index, the first frontier element (in visiting order e, then read_sites
             // index j) that finds a usable allele there.  Every element finding REF or ALT at a het
             // index claims the same entries of its site_reads list, so only that first one can win.
             WG_FOR(e, F) {
-                const int p = s.fr_pair[cur][e];
-                const int fpos = s.fr_pos[cur][e];
-                const unsigned long long hap = s.fr_hap[cur][e];
+                const int p = fr_pair_c[e];
+                const int fpos = fr_pos_c[e];
+                const unsigned long long hap = fr_hap_c[e];
                 const int x0 = s.rs_off[p], len = s.rs_len[p];
                 for (int j = 0; j < len; j++) {
                     const int h = s.srt_h[x0 + j];
@@ -1009,12 +1027,12 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                     for (int v = 0; v < W; v++) posn += s.win[v] < ok;
                 }
                 const int e = (int)((ok >> 32) & 0xFFFFF), j = (int)((ok >> 20) & 0xFFF), krel = (int)(ok & 0xFFFFF);
-                const int pe = s.fr_pair[cur][e];
+                const int pe = fr_pair_c[e];
                 const int h = s.srt_h[s.rs_off[pe] + j];
                 const int p = s.reg_pair[s.sr_off[s.hcanon[h]] + krel];
-                s.fr_pair[cur ^ 1][posn] = p;
-                s.fr_pos[cur ^ 1][posn] = s.hpos[h];
-                s.fr_hap[cur ^ 1][posn] = (uint8_t)(ok >> 63);
+                fr_pair_n[posn] = p;
+                fr_pos_n[posn] = s.hpos[h];
+                fr_hap_n[posn] = (uint8_t)(ok >> 63);
                 // every winner key names a different pair: mark it here
                 s.assigned[p] = 1;
                 s.grp[p] |= (ok >> 63) ? 2u : 1u;
