@@ -502,7 +502,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     const RD &R = a.R;
     Scr s = sg; // pointers into the HBM scratch; re-pointed into LDS below where the arrays fit
     Arena ar = {lds_arena, lds_arena ? a.lds_arena_bytes : 0, 0, lds_arena ? a.lds_arena_bytes : 0};
-    int32_t *stg1 = sg.seq_h, *stg2 = sg.srt_h; // staging of the ordered compaction in phase B
+    int32_t *t_h = sg.seq_h; // het index of every fetched record before the ordered compaction of phase B
     const long long c0 = a.cand_off[d], h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);
     WG_SYNC();
@@ -678,7 +678,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         ar_reset(ar);
         // LDS goes to what the chaining levels read over and over; reg_seg is read twice (keys, pair table)
         ar_p(ar, s.reg_h, T + 1); ar_p(ar, s.reg_pair, T + 1); ar_p(ar, s.cbase, T + 1);
-        ar_t(ar, s.t_ov, T + 1); ar_t(ar, s.t_pass, T + 1); ar_t(ar, stg1, T + 1); ar_t(ar, stg2, T + 1);
+        ar_t(ar, s.t_ov, T + 1); ar_t(ar, s.t_pass, T + 1); ar_t(ar, t_h, T + 1);
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
         WG_FOR(t, T) {
@@ -687,7 +687,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // skip empty ranges that share the same offset
             const int h = lo;
             const int seg = s.h_a[h] + (t - s.h_off[h]);
-            s.reg_h[t] = h; // provisional: het index of work item t
+            t_h[t] = h;
             // the record's fields are requested together: overlap test, pair filters (pure: evaluated for every
             // overlapping record, the enumerate cut-off below only masks them), name id for the pair table
             const int ov = (long long)R.end[seg] > (long long)s.hpos[h];
@@ -702,7 +702,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         (void)wg_exscan(s.t_pass, T, sh);
         UZ_TICK(4); // B.scan1
         WG_FOR(t, T) {
-            const int h = s.reg_h[t];
+            const int h = t_h[t];
             bool ok = (s.t_ov[t] & 2) != 0;
             if (ok) {
                 const int ei = s.t_pass[t] - s.t_pass[s.h_off[h]];
@@ -714,19 +714,17 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         UZ_TICK(5); // B.pair_ok
         E = wg_exscan(s.reg_pair, T, sh);
         UZ_TICK(6); // B.scan2
-        // compacting in place is unsafe across lanes: stage, then copy
+        // ordered compaction (inputs are the per-record temporaries, outputs the registration arrays)
         WG_FOR(t, T) {
             if (s.t_ov[t]) {
                 const int k = s.reg_pair[t];
-                const int h = s.reg_h[t];
-                stg1[k] = h;
-                stg2[k] = s.h_a[h] + (t - s.h_off[h]);
+                const int h = t_h[t];
+                s.reg_h[k] = h;
+                s.reg_seg[k] = s.h_a[h] + (t - s.h_off[h]);
                 s.reg_q[k] = s.t_q[t];
                 s.reg_mate[k] = s.t_mate[t];
             }
         }
-        WG_SYNC();
-        WG_FOR(k, E) { s.reg_h[k] = stg1[k]; s.reg_seg[k] = stg2[k]; }
         // site_reads range of het index h: entries [sr_off[h], sr_off[h+1])
         WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.reg_pair[s.h_off[h]] : E) : E;
         WG_SYNC();
