@@ -24,6 +24,12 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     R.start = Rv->start; R.end = Rv->end; R.flag = Rv->flag; R.mapq = Rv->mapq; R.aux = Rv->aux; R.tlen = Rv->tlen;
     R.qname = Rv->qname; R.mate = Rv->mate; R.cigar_off = Rv->cigar_off; R.n_cigar = Rv->n_cigar; R.cigar = Rv->cigar;
     R.l_seq = Rv->l_seq; R.sq_off16 = Rv->sq_off16; R.seq = Rv->seq; R.qual = Rv->qual; R.qc = qc.data();
+    std::vector<RecA> ra((size_t)Rv->n_segs + 1);
+    std::vector<RecB> rb((size_t)Rv->n_segs + 1);
+    for (int64_t i = 0; i < Rv->n_segs; i++)
+        uz_pack_rec(ra[i], rb[i], Rv->start[i], Rv->end[i], Rv->cigar_off[i], Rv->sq_off16[i], Rv->mate[i], Rv->qname[i],
+                    Rv->l_seq[i], Rv->n_cigar[i], Rv->tlen[i]);
+    R.ra = ra.data(); R.rb = rb.data();
     std::vector<int32_t> coarse((size_t)(Rv->n_segs >> 12) + 2);
     for (int64_t k = 0; (k << 12) < Rv->n_segs; k++) coarse[k] = Rv->start[k << 12];
     R.coarse = coarse.data();

@@ -90,7 +90,7 @@ void free_reads(ReadsDev &r) {
         (void)hipFree(r.n_cigar); (void)hipFree(r.cigar); (void)hipFree(r.l_seq); (void)hipFree(r.sq_off16);
         (void)hipFree(r.seq); (void)hipFree(r.qual);
     }
-    (void)hipFree(r.contig_off); (void)hipFree(r.max_span); (void)hipFree(r.qc); (void)hipFree(r.need); (void)hipFree(r.coarse);
+    (void)hipFree(r.contig_off); (void)hipFree(r.max_span); (void)hipFree(r.qc); (void)hipFree(r.need); (void)hipFree(r.coarse); (void)hipFree(r.rec_a); (void)hipFree(r.rec_b);
     r = ReadsDev();
 }
 
@@ -319,6 +319,7 @@ static void reads_fill(uz_ctx *c, const uz_reads_view *v, ReadsDev &r, bool copy
     UZ_HIP(hipMalloc((void **)&r.need, n + 64));
     UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, c->stream));
     uz_build_coarse(c, r);
+    uz_build_rec_headers(c, r);
     UZ_HIP(hipStreamSynchronize(c->stream));
 }
 

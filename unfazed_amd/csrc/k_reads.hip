@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#define UZ_TRACE(name) do { if (getenv("UZ_TRACE")) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[uz] before %s\n", name); fflush(stderr); } } while (0)
+
 namespace {
 
 // K3a: per-record QC bits.  The only heavy part is counting the base qualities below the
@@ -237,8 +239,22 @@ __global__ void k_build_coarse(const int32_t *start, int64_t n, int32_t *coarse)
     if ((k << 12) < n) coarse[k] = start[k << 12];
 }
 
+__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, const int32_t *start, const int32_t *end, const uint32_t *cigar_off,
+                                                  const uint32_t *sq_off16, const int32_t *mate, const uint32_t *qname,
+                                                  const uint16_t *l_seq, const uint16_t *n_cigar, const int32_t *tlen, RecA *ra,
+                                                  RecB *rb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    RecA A;
+    RecB B;
+    uz_pack_rec(A, B, start[i], end[i], cigar_off[i], sq_off16[i], mate[i], qname[i], l_seq[i], n_cigar[i], tlen[i]);
+    ra[i] = A;
+    rb[i] = B;
+}
+
 RD make_rd(const ReadsDev &r) {
     RD R;
+    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
     R.start = r.start; R.end = r.end; R.flag = r.flag; R.mapq = r.mapq; R.aux = r.aux; R.tlen = r.tlen;
     R.qname = r.qname; R.mate = r.mate; R.cigar_off = r.cigar_off; R.n_cigar = r.n_cigar; R.cigar = r.cigar;
@@ -253,6 +269,20 @@ int next_pow2(long long v) {
 }
 
 } // namespace
+
+void uz_build_rec_headers(uz_ctx *c, ReadsDev &r) {
+    static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "packed record headers are two 16-byte words");
+    UZ_HIP(hipMalloc(&r.rec_a, ((size_t)r.n + 4) * sizeof(RecA)));
+    UZ_HIP(hipMalloc(&r.rec_b, ((size_t)r.n + 4) * sizeof(RecB)));
+    if (r.n > 0) {
+        hipLaunchKernelGGL(k_pack_rec, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)r.n,
+                           (const int32_t *)r.start, (const int32_t *)r.end, (const uint32_t *)r.cigar_off,
+                           (const uint32_t *)r.sq_off16, (const int32_t *)r.mate, (const uint32_t *)r.qname,
+                           (const uint16_t *)r.l_seq, (const uint16_t *)r.n_cigar, (const int32_t *)r.tlen, (RecA *)r.rec_a,
+                           (RecB *)r.rec_b);
+        UZ_HIP(hipGetLastError());
+    }
+}
 
 void uz_build_coarse(uz_ctx *c, ReadsDev &r) {
     const int64_t nk = (r.n >> 12) + 2;
@@ -310,6 +340,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     {
         const unsigned nb = (unsigned)(((int64_t)n * 16 + 255) / 256);
         ProfScope ps(c, UZ_K_SIZING);
+        UZ_TRACE("k_phase_bounds");
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
         UZ_HIP(hipGetLastError());
     }
@@ -406,12 +437,14 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             const int64_t chunks = (r.n + 4095) / 4096;
             const int64_t blocks = std::min<int64_t>(chunks, 4096);
             const int cpb = (int)((chunks + blocks - 1) / blocks);
+            UZ_TRACE("k_compact_need");
             hipLaunchKernelGGL(k_compact_need, dim3((unsigned)((chunks + cpb - 1) / cpb)), dim3(256), 0, c->stream,
                                (const uint8_t *)r.need, (int64_t)r.n, cpb, st->need_list.p, st->need_count.p);
             UZ_HIP(hipGetLastError());
         }
         if (list_cap > 0) {
             ProfScope ps2(c, UZ_K_SEG_QC_PASS);
+            UZ_TRACE("k_seg_qc");
             hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, c->stream, make_rd(r),
                                (const int32_t *)st->need_list.p, (const unsigned int *)st->need_count.p, c->P.min_map_qual,
                                c->P.min_gt_qual, r.qc);
@@ -424,9 +457,11 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
         {
             ProfScope ps(c, UZ_K_PHASE);
+            UZ_TRACE("k_phase");
             hipLaunchKernelGGL(k_phase, dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
             UZ_HIP(hipGetLastError());
         }
+        UZ_TRACE("after k_phase");
         unsigned long long used = 0;
         UZ_HIP(hipMemcpyAsync(&used, st->pool_cursor.p, sizeof(used), hipMemcpyDeviceToHost, c->stream));
         UZ_HIP(hipStreamSynchronize(c->stream));

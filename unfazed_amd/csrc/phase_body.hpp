@@ -53,7 +53,21 @@
 #ifdef UZ_EMU_STATS
 extern "C" long long uz_emu_stats[16];
 #endif
+// Packed per-record headers (built once from the columns when a reads table is uploaded / adopted):
+// the per-DNM kernel GATHERS records (mates, last registrations, init elements), and a gather that finds
+// start / end / offsets / lengths in one or two 16-byte words touches one or two cache lines instead
+// of five to eight.  The streaming kernels keep reading the plain columns.
+struct RecA { int32_t start, end; uint32_t cigar_off, sq_off16; };
+struct RecB { int32_t mate; uint32_t qname; uint16_t l_seq, n_cigar; int32_t tlen; };
+UZ_HD void uz_pack_rec(RecA &A, RecB &B, int32_t start, int32_t end, uint32_t cigar_off, uint32_t sq_off16, int32_t mate,
+                       uint32_t qname, uint16_t l_seq, uint16_t n_cigar, int32_t tlen) {
+    A.start = start; A.end = end; A.cigar_off = cigar_off; A.sq_off16 = sq_off16;
+    B.mate = mate; B.qname = qname; B.l_seq = l_seq; B.n_cigar = n_cigar; B.tlen = tlen;
+}
+
 struct RD { // alignment-record columns (device pointers)
+    const RecA *ra;
+    const RecB *rb;
     const int64_t *contig_off;
     const int32_t *max_span;
     int32_t n_contigs;
@@ -286,13 +300,15 @@ UZ_DEV int uz_qidx(const RD &R, int seg, long long pos) {
 // The fixed-width fields a base lookup needs, fetched together (one memory round trip) before the
 // CIGAR walk instead of one by one along it.
 struct SegHdr {
-    int32_t start, n_cigar, l_seq;
+    int32_t start, end, n_cigar, l_seq;
     uint32_t cigar_off, sq_off16;
 };
 UZ_DEV SegHdr uz_hdr(const RD &R, int seg) {
+    const RecA A = R.ra[seg];
+    const RecB B = R.rb[seg];
     SegHdr h;
-    h.start = R.start[seg]; h.n_cigar = R.n_cigar[seg]; h.l_seq = R.l_seq[seg];
-    h.cigar_off = R.cigar_off[seg]; h.sq_off16 = R.sq_off16[seg];
+    h.start = A.start; h.end = A.end; h.n_cigar = B.n_cigar; h.l_seq = B.l_seq;
+    h.cigar_off = A.cigar_off; h.sq_off16 = A.sq_off16;
     return h;
 }
 UZ_DEV int uz_qidx_h(const RD &R, const SegHdr &h, long long pos) {
@@ -371,14 +387,15 @@ UZ_DEV int uz_bsearch_nth(int m, int qp, int L, int Rr) {
 // site-specific parts.  Returns the mate or -1.
 // All fields of the record are requested together, then all fields of its mate (two memory round
 // trips instead of one per test); the tests keep the reference's order.
-UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, int seg) {
+UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, int seg, const RecA &A, const RecB &B) {
     const uint32_t qc = R.qc[seg];
-    const int mate = R.mate[seg];
-    long long ins = (long long)R.tlen[seg] - 2LL * a.readlen;
-    const long long rs = R.start[seg], re = R.end[seg];
+    const int mate = B.mate;
+    long long ins = (long long)B.tlen - 2LL * a.readlen;
+    const long long rs = A.start, re = A.end;
     const int mi = mate >= 0 ? mate : seg; // a safe index: unused without a mate
     const uint32_t qm = R.qc[mi];
-    const long long ms = R.start[mi], me = R.end[mi];
+    const RecA M = R.ra[mi];
+    const long long ms = M.start, me = M.end;
     if (ins < 0) ins = -ins;
     if (!(qc & UZ_QC_GOOD) || (double)ins > a.cutoff) return -1;
     if (mate < 0) return -1;
@@ -387,11 +404,12 @@ UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, int seg) {
     if ((ms <= rs && rs <= me) || (ms <= re && re <= me)) return -1; // mates overlap
     return mate;
 }
+UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, int seg) { return uz_pair_ok_ab(R, a, seg, R.ra[seg], R.rb[seg]); }
 
 // Phase A classification of one record fetched at the DNM: 0 none, 1 "ref", 2 "alt"
 UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long long flo, long long position,
                                 const uint8_t *ref, int ref_len, const uint8_t *alt, int alt_len) {
-    if (!((long long)R.end[seg] > flo)) return 0;
+    if (!((long long)R.ra[seg].end > flo)) return 0;
     const int mate = uz_pair_ok(R, a, seg);
     if (mate < 0) return 0;
     if (ref_len == alt_len) { // snv_match_alleles :296-336
@@ -651,7 +669,9 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         s.i_seg[m] = seg;
         s.i_hb[m] = is_ref ? 0 : 1;
         // everything the later steps need of this record, in one round trip
-        s.i_q[m] = R.qname[seg]; s.i_mate[m] = R.mate[seg]; s.i_st[m] = R.start[seg]; s.i_en[m] = R.end[seg];
+        const RecA A = R.ra[seg];
+        const RecB B = R.rb[seg];
+        s.i_q[m] = B.qname; s.i_mate[m] = B.mate; s.i_st[m] = A.start; s.i_en[m] = A.end;
     }
     WG_SYNC();
 
@@ -690,10 +710,12 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             t_h[t] = h;
             // the record's fields are requested together: overlap test, pair filters (pure: evaluated for every
             // overlapping record, the enumerate cut-off below only masks them), name id for the pair table
-            const int ov = (long long)R.end[seg] > (long long)s.hpos[h];
-            const int mate = uz_pair_ok(R, a, seg);
+            const RecA A = R.ra[seg];
+            const RecB B = R.rb[seg];
+            const int ov = (long long)A.end > (long long)s.hpos[h];
+            const int mate = uz_pair_ok_ab(R, a, seg, A, B);
             const bool pok = ov && mate >= 0 && (R.qc[seg] & UZ_QC_NM5);
-            s.t_q[t] = R.qname[seg];
+            s.t_q[t] = B.qname;
             s.t_mate[t] = mate;
             s.t_ov[t] = ov | (pok ? 2 : 0);
             s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
@@ -1067,7 +1089,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
         int qp, L, Rr;
         const SegHdr hd = uz_hdr(R, seg);
-        const int nm = uz_bsearch(hd.start, R.end[seg], s.cpos, nc, qp, L, Rr);
+        const int nm = uz_bsearch(hd.start, hd.end, s.cpos, nc, qp, L, Rr);
         if (nm <= 0) continue;
         bool dad_alt = false, mom_alt = false;
         for (int ci = L; ci <= Rr; ci++) {

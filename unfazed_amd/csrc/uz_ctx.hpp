@@ -92,6 +92,7 @@ struct ReadsDev {
     // K3a output: per-segment QC bits for the parameters in qc_params
     uint8_t *qc = nullptr;
     uint8_t *need = nullptr; // records reachable by the current batch (lazy K3a)
+    void *rec_a = nullptr, *rec_b = nullptr; // packed 16-byte record headers for the gathers of k_phase (RecA / RecB)
     int32_t *coarse = nullptr; // start[] of every 4096th record
     bool qc_valid = false;
     uz_params qc_params;
@@ -170,6 +171,7 @@ struct ProfScope {
 };
 
 // stage launchers
+void uz_build_rec_headers(uz_ctx *c, ReadsDev &r);
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode);

@@ -38,7 +38,15 @@ UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long l
 #endif
 #define WG_NT UZ_WG_NT
 #define WG_TID ((int)threadIdx.x)
-#define WG_FOR(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += WG_NT)
+// The lane index is re-read through an opaque move at every loop: otherwise the compiler hoists the
+// per-lane address of every array (`base + 4 * tid`, a 64-bit VGPR pair each) out of ALL the phases that
+// use it and keeps dozens of them alive across the whole kernel (150 VGPRs instead of < 128).
+__device__ __forceinline__ int wg_lane_opaque() {
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#define WG_FOR(i, n) for (int i = wg_lane_opaque(); i < (int)(n); i += WG_NT)
 #define WG_SYNC() __syncthreads()
 #define WG_T0 if (threadIdx.x == 0)
 UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
