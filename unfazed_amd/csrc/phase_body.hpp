@@ -970,6 +970,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // (i) per het index, the first frontier element (in visiting order e, then read_sites
             // index j) that finds a usable allele there.  Every element finding REF or ALT at a het
             // index claims the same entries of its site_reads list, so only that first one can win.
+            WG_T0 s.misc[3] = 0; // winners of this level (read back after the barriers below)
             WG_FOR(e, F) {
                 const int p = fr_pair_c[e];
                 const int fpos = fr_pos_c[e];
@@ -1018,22 +1019,16 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
             WG_FOR(h, nh) s.site_best[h] = ~0ULL; // for the next level
-            int W;
-            {
-                int plo, phi, c1[1] = {0}, o1[1], t1[1];
-                wg_chunk(P, plo, phi);
-                for (int p = plo; p < phi; p++) c1[0] += (!s.assigned[p] && s.pkey[p] != ~0ULL) ? 1 : 0;
-                wg_lane_exscan<1>(c1, o1, t1, sh);
-                W = t1[0];
-                int o = o1[0];
-                for (int p = plo; p < phi; p++) {
-                    if (!s.assigned[p] && s.pkey[p] != ~0ULL) {
-                        const unsigned long long k = s.pkey[p];
-                        s.win[o++] = ((k & 1ULL) << 63) | (k >> 1);
-                    }
+            // the winners are appended in any order (one LDS counter): their place in the next frontier is
+            // decided below by the RANK of their key, so the order of this list does not matter
+            WG_FOR(p, P) {
+                if (!s.assigned[p] && s.pkey[p] != ~0ULL) {
+                    const unsigned long long k = s.pkey[p];
+                    s.win[wg_atomic_add(&s.misc[3], 1)] = ((k & 1ULL) << 63) | (k >> 1);
                 }
             }
             WG_SYNC();
+            const int W = s.misc[3];
             UZ_TICK(17); // E.scan
             // position in the next frontier = rank of the (target, rank) key among the winners: counted
             // directly while a level has few winners (one barrier), sorted otherwise
