@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
 }
 
 #ifndef UZ_PHASE_MIN_WAVES
-#define UZ_PHASE_MIN_WAVES 4 // <= 128 VGPRs: four waves per SIMD, the occupancy the LDS arena allows anyway
+#define UZ_PHASE_MIN_WAVES 5 // <= 96 VGPRs (the kernel needs 94, no spills): five waves per SIMD = five 256-lane workgroups per CU
 #endif
 __global__ __launch_bounds__(WG_NT, UZ_PHASE_MIN_WAVES) void k_phase(PhaseArgs a) {
     __shared__ WgShared sh;
@@ -396,7 +396,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         UZ_HIP(hipGetDeviceProperties(&prop, c->device));
         st->n_cus = prop.multiProcessorCount;
     }
-    static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 16) * 1024; }();
+    static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 28) * 1024; }();
     static const int wgs_per_cu = [] {
         const char *e = getenv("UZ_PHASE_WGS_PER_CU");
         if (e) return atoi(e);

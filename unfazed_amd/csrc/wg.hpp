@@ -3,7 +3,7 @@
 // The per-DNM read stage is written as a sequence of block-parallel phases
 // (WG_FOR loops separated by barriers) over arrays in a per-workgroup scratch
 // region.  The same source compiles two ways:
-//   * hipcc, gfx950: WG_FOR strides the loop over the 256 lanes of the workgroup,
+//   * hipcc, gfx950: WG_FOR strides the loop over the lanes of the workgroup (a power of two),
 //     WG_SYNC is __syncthreads(), scans/sorts go through LDS;
 //   * -DUZ_EMU (g++, tests/emu only): one lane, loops run sequentially.  This is
 //     a debugging aid for the authoring container, which has no GPU; it is never
@@ -34,7 +34,7 @@ UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long l
 #define UZ_DEV __device__ __forceinline__
 #define UZ_HD __host__ __device__ inline
 #ifndef UZ_WG_NT
-#define UZ_WG_NT 128 // lanes per DNM workgroup: 128 with a 16 KiB LDS arena measured best on MI355X
+#define UZ_WG_NT 256 // lanes per DNM workgroup: 256 lanes, 28 KiB LDS arena, 5 workgroups per CU measured best on MI355X
 #endif
 #define WG_NT UZ_WG_NT
 #define WG_TID ((int)threadIdx.x)
