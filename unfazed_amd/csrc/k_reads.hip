@@ -19,138 +19,106 @@ namespace {
 // threshold (151 bytes per record): a workgroup takes 256 consecutive records and walks their
 // quality rows as 16-byte chunks, consecutive lanes on consecutive chunks, so the loads are
 // full-width and coalesced (rows are 16-byte aligned); per-record counts are combined in LDS.
-// K3a runs over a compact list of the records the batch can reach (about a quarter of the records
-// inside the DNM windows): every lane of the quality pass then has a 16-byte chunk to count.
-// k_compact_need turns the byte map written by k_mark_ranges into that list; the order of the list is
-// irrelevant (each entry writes its own qc byte), so a wave reserves its slice with one atomic.
-__global__ __launch_bounds__(256) void k_compact_need(const uint8_t *__restrict__ need, int64_t n, int chunks_per_block,
-                                                      int32_t *__restrict__ list, unsigned int *__restrict__ count) {
-    // A block owns chunks_per_block consecutive 4096-record chunks: it counts them, reserves its slice
-    // of the list with ONE atomic (a single hot counter serialises at ~10 ns per atomic), then fills it.
-    __shared__ int wsum[4];
-    __shared__ unsigned int slice;
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t first = (int64_t)blockIdx.x * chunks_per_block * 4096;
-    int mine = 0;
-    for (int ch = 0; ch < chunks_per_block; ch++) {
-        const int64_t base = first + (int64_t)ch * 4096 + (int64_t)t * 16;
-        if (base >= n) break; // the map is allocated with a 64-byte pad and zeroed up to it
-        const uint4 v = *reinterpret_cast<const uint4 *>(need + base);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 16; k++) mine += ((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0 && base + k < n;
-    }
-    int tot = mine;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off, 64);
-    if (lane == 0) wsum[wv] = tot;
-    __syncthreads();
-    if (t == 0) {
-        const int all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        slice = all ? atomicAdd(count, (unsigned int)all) : 0u;
-    }
-    __syncthreads();
-    unsigned int run = slice;
-    for (int ch = 0; ch < chunks_per_block; ch++) {
-        const int64_t cbase = first + (int64_t)ch * 4096;
-        if (cbase >= n) break; // block-uniform
-        const int64_t base = cbase + (int64_t)t * 16;
-        uint32_t w[4] = {0, 0, 0, 0};
-        if (base < n) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(need + base);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-        }
-        int c = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) c += ((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0 && base + k < n;
-        int incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        __syncthreads(); // wsum of the previous round has been read
-        if (lane == 63) wsum[wv] = incl;
-        __syncthreads();
-        unsigned int o = run + (unsigned int)(incl - c);
-        for (int k = 0; k < wv; k++) o += (unsigned int)wsum[k];
-        run += (unsigned int)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
-        if (c) {
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                if ((((w[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0) && base + k < n) list[o++] = (int32_t)(base + k);
-        }
-    }
-}
-
+// K3a: the quality / CIGAR pass over the records the batch can reach (about a third of the records inside
+// the DNM windows), marked in a byte map by k_mark_ranges.
 #ifndef UZ_QC_BATCH
 #define UZ_QC_BATCH 5
 #endif
-__global__ __launch_bounds__(256) void k_seg_qc(RD R, const int32_t *__restrict__ list, const unsigned int *__restrict__ count,
-                                                int min_map_qual, int min_base_qual, uint8_t *qc) {
+// A block owns UZ_QC_SPAN consecutive records of the table: it compacts the ones the byte map marks into
+// an LDS list (ascending), then runs the quality / CIGAR pass over that list 256 records at a time.  No
+// global list, no global counter on the data path (count, when given, only feeds the profiling read-out).
+#define UZ_QC_SPAN 4096
+__global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict__ need, int64_t n, int min_map_qual, int min_base_qual,
+                                                uint8_t *qc, unsigned int *count) {
+    __shared__ int lst[UZ_QC_SPAN];
+    __shared__ int wsum[4];
     __shared__ int low[256];
-    __shared__ uint32_t row16[256]; // quality row offset (16-byte units) of each record of the block
+    __shared__ uint32_t row16[256]; // quality row offset (16-byte units) of each record of the round
     __shared__ int len[256];        // bases to examine (0 for records without qualities)
     __shared__ int maxch;
-    const int64_t m = (int64_t)*count;
-    const int64_t r0 = (int64_t)blockIdx.x * 256;
-    if (r0 >= m) return; // the grid is sized for the host's upper bound of the list
-    const int t = threadIdx.x;
-    const bool wanted = r0 + t < m;
-    const int mine = wanted ? list[r0 + t] : 0;
-    low[t] = 0;
-    if (t == 0) maxch = 0;
-    int ls = 0, ncg = 0, mq = 0;
-    uint32_t ro = 0, fl = 0, ax = UZ_AUX_DECODE_BAD, coff = 0;
-    if (wanted) { // every fixed-width field of the record in one round trip
-        ax = R.aux[mine]; fl = R.flag[mine]; mq = R.mapq[mine]; coff = R.cigar_off[mine]; ncg = R.n_cigar[mine];
-        ls = R.l_seq[mine]; ro = R.sq_off16[mine];
-        if (ax & UZ_AUX_DECODE_BAD) { ls = 0; ro = 0; }
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t base = (int64_t)blockIdx.x * UZ_QC_SPAN + (int64_t)t * 16;
+    uint32_t w4[4] = {0, 0, 0, 0};
+    if (base < n) { // the map is allocated with a 64-byte pad and zeroed up to it
+        const uint4 v = *reinterpret_cast<const uint4 *>(need + base);
+        w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w;
     }
-    // the first CIGAR operation (usually the only one) is requested now and used after the quality pass
-    const uint32_t c0 = (wanted && ncg > 0) ? R.cigar[coff] : 0u;
-    row16[t] = ro;
-    len[t] = ls;
-    int mc = (ls + 15) >> 4; // most chunks of any record of the block: wave maximum first, one LDS atomic per wave
+    int c16 = 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(mc, o, 64); mc = v > mc ? v : mc; }
+    for (int k = 0; k < 16; k++) c16 += ((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0 && base + k < n;
+    int incl = c16;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    if ((t & 63) == 0 && mc) atomicMax(&maxch, mc);
-    __syncthreads();
-    const int nch = maxch;
+    int o = incl - c16;
+    for (int k = 0; k < wv; k++) o += wsum[k];
+    const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if ((((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0) && base + k < n) lst[o++] = (int32_t)(base + k);
+    if (t == 0 && count && m) atomicAdd(count, (unsigned int)m);
     const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
-    // UZ_QC_BATCH independent 16-byte loads in flight per lane before any of them is counted
-    for (int j0 = 0; j0 < nch; j0 += UZ_QC_BATCH) {
-        uint4 v[UZ_QC_BATCH];
-        int rl[UZ_QC_BATCH], l[UZ_QC_BATCH];
-#pragma unroll
-        for (int u = 0; u < UZ_QC_BATCH; u++) {
-            const int it = t + 256 * (j0 + u);
-            rl[u] = it / nch;
-            const int ch = it - rl[u] * nch;
-            l[u] = (j0 + u < nch) ? len[rl[u]] - 16 * ch : 0;
-            v[u] = make_uint4(0, 0, 0, 0);
-            if (l[u] > 0) v[u] = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl[u]] + ch) << 4));
+    for (int r0 = 0; r0 < m; r0 += 256) { // block-uniform
+        __syncthreads(); // lst complete (first round) / previous round done with low, row16, len, maxch
+        const bool wanted = r0 + t < m;
+        const int mine = wanted ? lst[r0 + t] : 0;
+        low[t] = 0;
+        if (t == 0) maxch = 0;
+        int ls = 0, ncg = 0, mq = 0;
+        uint32_t ro = 0, fl = 0, ax = UZ_AUX_DECODE_BAD, coff = 0;
+        if (wanted) { // every fixed-width field of the record in one round trip
+            ax = R.aux[mine]; fl = R.flag[mine]; mq = R.mapq[mine]; coff = R.cigar_off[mine]; ncg = R.n_cigar[mine];
+            ls = R.l_seq[mine]; ro = R.sq_off16[mine];
+            if (ax & UZ_AUX_DECODE_BAD) { ls = 0; ro = 0; }
         }
+        // the first CIGAR operation (usually the only one) is requested now and used after the quality pass
+        const uint32_t c0 = (wanted && ncg > 0) ? R.cigar[coff] : 0u;
+        row16[t] = ro;
+        len[t] = ls;
+        int mc = (ls + 15) >> 4; // most chunks of any record of the round: wave maximum first, one LDS atomic per wave
 #pragma unroll
-        for (int u = 0; u < UZ_QC_BATCH; u++) {
-            if (l[u] <= 0) continue;
-            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-            int c = 0;
+        for (int s = 32; s > 0; s >>= 1) { const int v = __shfl_xor(mc, s, 64); mc = v > mc ? v : mc; }
+        __syncthreads();
+        if (lane == 0 && mc) atomicMax(&maxch, mc);
+        __syncthreads();
+        const int nch = maxch;
+        // UZ_QC_BATCH independent 16-byte loads in flight per lane before any of them is counted
+        for (int j0 = 0; j0 < nch; j0 += UZ_QC_BATCH) {
+            uint4 v[UZ_QC_BATCH];
+            int rl[UZ_QC_BATCH], l[UZ_QC_BATCH];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                c += (k < l[u]) & (q < thr);
+            for (int u = 0; u < UZ_QC_BATCH; u++) {
+                const int it = t + 256 * (j0 + u);
+                rl[u] = it / nch;
+                const int ch = it - rl[u] * nch;
+                l[u] = (j0 + u < nch) ? len[rl[u]] - 16 * ch : 0;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (l[u] > 0) v[u] = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl[u]] + ch) << 4));
             }
-            if (c) atomicAdd(&low[rl[u]], c);
+#pragma unroll
+            for (int u = 0; u < UZ_QC_BATCH; u++) {
+                if (l[u] <= 0) continue;
+                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                int c = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    c += (k < l[u]) & (q < thr);
+                }
+                if (c) atomicAdd(&low[rl[u]], c);
+            }
         }
-    }
-    __syncthreads();
-    if (wanted) {
-        int nonmatch = 0, none = 0;
-        if (ncg > 0) uz_cigar_op_counts(c0, nonmatch, none);
-        for (int k = 1; k < ncg; k++) uz_cigar_op_counts(R.cigar[coff + k], nonmatch, none);
-        qc[mine] = uz_seg_qc_combine(fl, ax, mq, min_map_qual, low[t], ncg, nonmatch, none);
+        __syncthreads();
+        if (wanted) {
+            int nonmatch = 0, none = 0;
+            if (ncg > 0) uz_cigar_op_counts(c0, nonmatch, none);
+            for (int k = 1; k < ncg; k++) uz_cigar_op_counts(R.cigar[coff + k], nonmatch, none);
+            qc[mine] = uz_seg_qc_combine(fl, ax, mq, min_map_qual, low[t], ncg, nonmatch, none);
+        }
     }
 }
 
@@ -222,7 +190,6 @@ struct PhaseState {
     DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len, pre_win, pre_ha, pre_hl;
     DevBuf<long long> list_start;
     DevBuf<unsigned long long> pool_cursor;
-    DevBuf<int32_t> need_list;
     DevBuf<unsigned int> need_count;
     int32_t *bounds_h = nullptr; // pinned: the copy back must not block the host, the marking kernels follow it
     size_t bounds_h_cap = 0;
@@ -298,7 +265,7 @@ void uz_phase_state_free(uz_ctx *c) {
     if (!st) return;
     st->scratch.release(); st->bounds.release(); st->status.release(); st->counts.release(); st->origin.release();
     st->evidence.release(); st->cursor.release(); st->pre_win.release(); st->pre_ha.release(); st->pre_hl.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
-    st->pool_cursor.release(); st->need_list.release(); st->need_count.release();
+    st->pool_cursor.release(); st->need_count.release();
     if (st->bounds_ready) (void)hipEventDestroy(st->bounds_ready);
     if (st->bounds_h) (void)hipHostFree(st->bounds_h);
     delete st;
@@ -430,24 +397,15 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.timing = timing.p;
 #endif
     if (r.n > 0) {
-        const int64_t list_cap = std::min<long long>(reach, (long long)r.n);
-        st->need_list.ensure((size_t)list_cap + 16); st->need_count.ensure(4);
+        (void)reach;
+        st->need_count.ensure(4);
         UZ_HIP(hipMemsetAsync(st->need_count.p, 0, 4 * sizeof(unsigned int), c->stream));
         {
-            const int64_t chunks = (r.n + 4095) / 4096;
-            const int64_t blocks = std::min<int64_t>(chunks, 4096);
-            const int cpb = (int)((chunks + blocks - 1) / blocks);
-            UZ_TRACE("k_compact_need");
-            hipLaunchKernelGGL(k_compact_need, dim3((unsigned)((chunks + cpb - 1) / cpb)), dim3(256), 0, c->stream,
-                               (const uint8_t *)r.need, (int64_t)r.n, cpb, st->need_list.p, st->need_count.p);
-            UZ_HIP(hipGetLastError());
-        }
-        if (list_cap > 0) {
             ProfScope ps2(c, UZ_K_SEG_QC_PASS);
             UZ_TRACE("k_seg_qc");
-            hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((list_cap + 255) / 256)), dim3(256), 0, c->stream, make_rd(r),
-                               (const int32_t *)st->need_list.p, (const unsigned int *)st->need_count.p, c->P.min_map_qual,
-                               c->P.min_gt_qual, r.qc);
+            hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((r.n + UZ_QC_SPAN - 1) / UZ_QC_SPAN)), dim3(256), 0, c->stream, make_rd(r),
+                               (const uint8_t *)r.need, (int64_t)r.n, c->P.min_map_qual, c->P.min_gt_qual, r.qc,
+                               c->prof_on ? st->need_count.p : (unsigned int *)nullptr);
             UZ_HIP(hipGetLastError());
         }
         uz_prof_end(c, UZ_K_SEG_QC, qc_a, qc_b);
