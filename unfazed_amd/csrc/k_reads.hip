@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+// development aid: UZ_TRACE=1 in the environment names every kernel of the read stage before its launch (after a
+// stream sync), so a device fault can be attributed
 #define UZ_TRACE(name) do { if (getenv("UZ_TRACE")) { (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[uz] before %s\n", name); fflush(stderr); } } while (0)
 
 namespace {

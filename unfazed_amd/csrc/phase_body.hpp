@@ -123,7 +123,6 @@ struct Scr {
     uint8_t *assigned;
     int32_t *fr_pair0, *fr_pair1, *fr_pos0, *fr_pos1;
     uint8_t *fr_hap0, *fr_hap1;
-    int32_t *o_flag;
     int32_t *q_cnt, *q_fill; // counting sort of the pair-table keys over the query-name id range
     int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
 };
@@ -161,7 +160,6 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.pkey, M); uz_carve(base, o, s.win, M);
     uz_carve(base, o, s.fr_pair0, FR); uz_carve(base, o, s.fr_pos0, FR); uz_carve(base, o, s.fr_hap0, FR);
     uz_carve(base, o, s.fr_pair1, FR); uz_carve(base, o, s.fr_pos1, FR); uz_carve(base, o, s.fr_hap1, FR);
-    uz_carve(base, o, s.o_flag, M + C + 2);
     uz_carve(base, o, s.q_cnt, 2 * M + 1026); uz_carve(base, o, s.q_fill, 2 * M + 1026);
     uz_carve(base, o, s.misc, 8);
     return (o + 255) & ~(size_t)255;
@@ -335,7 +333,6 @@ UZ_DEV int uz_refpos_len(const RD &R, int seg) {
     }
     return q;
 }
-UZ_DEV const uint8_t *uz_seq(const RD &R, int seg) { return R.seq + ((size_t)R.sq_off16[seg] << 4); }
 UZ_DEV const uint8_t *uz_qual(const RD &R, int seg) { return R.qual + ((size_t)R.sq_off16[seg] << 4); }
 
 // get_allele_at :56-73 -> pointer to n bases or nullptr (False)

@@ -24,9 +24,6 @@
 #define WG_T0 if (true)
 UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p |= v; return o; }
 UZ_DEV int wg_atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
-UZ_DEV void wg_atomic_min32(int *p, int v) { if (v < *p) *p = v; }
-UZ_DEV void wg_atomic_max32(int *p, int v) { if (v > *p) *p = v; }
-UZ_DEV void wg_atomic_min32u(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
 #else
@@ -51,9 +48,6 @@ __device__ __forceinline__ int wg_lane_opaque() {
 #define WG_T0 if (threadIdx.x == 0)
 UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 UZ_DEV int wg_atomic_add(int *p, int v) { return atomicAdd(p, v); }
-UZ_DEV void wg_atomic_min32(int *p, int v) { atomicMin(p, v); }
-UZ_DEV void wg_atomic_max32(int *p, int v) { atomicMax(p, v); }
-UZ_DEV void wg_atomic_min32u(uint32_t *p, uint32_t v) { atomicMin(p, v); }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
 #endif
