@@ -444,7 +444,7 @@ int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int fin
         c->phase_valid = false;
         uz_stage_dnms(c, d);
         if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
-        uz_launch_find(c, f, s, find_mode);
+        uz_launch_find(c, f, s, find_mode, false);
         c->find_fam = fam_id;
         uz_launch_phase(c, f, s, r, status, counts, origin, evidence);
     });

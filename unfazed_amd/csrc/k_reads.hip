@@ -450,7 +450,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     if (origin) UZ_HIP(hipMemcpyAsync(origin, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     if (evidence) UZ_HIP(hipMemcpyAsync(evidence, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     UZ_HIP(hipStreamSynchronize(c->stream));
-    if (r.n > 0) {
+    if (r.n > 0 && c->prof_on) {
         unsigned int m = 0;
         UZ_HIP(hipMemcpy(&m, st->need_count.p, sizeof(m), hipMemcpyDeviceToHost));
         c->prof[UZ_K_SEG_QC].last_units = c->prof[UZ_K_SEG_QC_PASS].last_units = (int64_t)m;

@@ -521,7 +521,7 @@ void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, cons
     }
 }
 
-void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode) {
+void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool host_offsets) {
     const int32_t n = c->dn.n;
     c->cnt_c.ensure((size_t)n + 1);
     c->cnt_h.ensure((size_t)n + 1);
@@ -550,11 +550,17 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode) {
                                c->het_off.p);
             UZ_HIP(hipGetLastError());
         }
-        UZ_HIP(hipMemcpyAsync(c->cand_off_h.data(), c->cand_off.p, ((size_t)n + 1) * sizeof(int64_t),
-                              hipMemcpyDeviceToHost, c->stream));
-        UZ_HIP(hipMemcpyAsync(c->het_off_h.data(), c->het_off.p, ((size_t)n + 1) * sizeof(int64_t),
-                              hipMemcpyDeviceToHost, c->stream));
-        UZ_HIP(hipStreamSynchronize(c->stream));
+        if (host_offsets) {
+            UZ_HIP(hipMemcpyAsync(c->cand_off_h.data(), c->cand_off.p, ((size_t)n + 1) * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipMemcpyAsync(c->het_off_h.data(), c->het_off.p, ((size_t)n + 1) * sizeof(int64_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipStreamSynchronize(c->stream));
+        } else { // the read stage only needs the two totals to size the lists
+            UZ_HIP(hipMemcpyAsync(&c->cand_off_h[n], c->cand_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipMemcpyAsync(&c->het_off_h[n], c->het_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipStreamSynchronize(c->stream));
+        }
         c->n_cand = c->cand_off_h[n];
         c->n_het = c->het_off_h[n];
         c->cand_idx.ensure((size_t)c->n_cand + 1);

@@ -174,7 +174,7 @@ struct ProfScope {
 void uz_build_rec_headers(uz_ctx *c, ReadsDev &r);
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
-void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode);
+void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool host_offsets = true);
 void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d);
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
                      int32_t *origin, int32_t *evidence);
