@@ -128,16 +128,33 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d) {
     UZ_REQUIRE(d != nullptr && d->n >= 0, UZ_E_ARG, "bad DNM view");
     const size_t n = (size_t)d->n;
     c->dn.n = d->n;
-    stage(c, c->dn.contig, d->contig, n);
-    stage(c, c->dn.rcontig, d->rcontig, n);
-    stage(c, c->dn.start, d->start, n);
-    stage(c, c->dn.end, d->end, n);
-    stage(c, c->dn.vartype, d->vartype, n);
-    stage(c, c->dn.dflags, d->dflags, n);
-    stage(c, c->dn.mult, d->mult, n);
-    stage(c, c->dn.allele_off, d->allele_off, 2 * n + 1);
+    UZ_REQUIRE(n == 0 || (d->contig && d->rcontig && d->start && d->end && d->vartype && d->dflags && d->mult && d->allele_off),
+               UZ_E_ARG, "null DNM column pointer");
     const size_t nb = n ? (size_t)d->allele_off[2 * n] : 0;
-    stage(c, c->dn.alleles, d->alleles, nb);
+    UZ_REQUIRE(nb == 0 || d->alleles != nullptr, UZ_E_ARG, "null DNM column pointer");
+    // The nine small columns go through ONE pinned staging buffer: copies from pageable memory are staged
+    // by the runtime one call at a time (~40 us each with the gaps between them, ~0.4 ms per batch).
+    const size_t sizes[9] = {n * 4, n * 4, n * 4, n * 4, n, n, n, (2 * n + 1) * 4, nb};
+    size_t off[10];
+    off[0] = 0;
+    for (int k = 0; k < 9; k++) off[k + 1] = (off[k] + sizes[k] + 63) & ~(size_t)63;
+    if (c->dn_stage_cap < off[9]) {
+        if (c->dn_stage) (void)hipHostFree(c->dn_stage);
+        c->dn_stage = nullptr;
+        c->dn_stage_cap = off[9] + off[9] / 4 + 4096;
+        UZ_HIP(hipHostMalloc((void **)&c->dn_stage, c->dn_stage_cap, hipHostMallocDefault));
+    }
+    // an earlier batch's copies out of this buffer have completed: every entry point ends with a stream sync
+    const void *src[9] = {d->contig, d->rcontig, d->start, d->end, d->vartype, d->dflags, d->mult, d->allele_off, d->alleles};
+    for (int k = 0; k < 9; k++)
+        if (sizes[k]) memcpy(c->dn_stage + off[k], src[k], sizes[k]);
+    c->dn.contig.ensure(n + 1); c->dn.rcontig.ensure(n + 1); c->dn.start.ensure(n + 1); c->dn.end.ensure(n + 1);
+    c->dn.vartype.ensure(n + 1); c->dn.dflags.ensure(n + 1); c->dn.mult.ensure(n + 1);
+    c->dn.allele_off.ensure(2 * n + 2); c->dn.alleles.ensure(nb + 1);
+    void *dst[9] = {c->dn.contig.p, c->dn.rcontig.p, c->dn.start.p, c->dn.end.p, c->dn.vartype.p, c->dn.dflags.p, c->dn.mult.p,
+                    c->dn.allele_off.p, c->dn.alleles.p};
+    for (int k = 0; k < 9; k++)
+        if (sizes[k]) UZ_HIP(hipMemcpyAsync(dst[k], c->dn_stage + off[k], sizes[k], hipMemcpyHostToDevice, c->stream));
     c->dn.cutoff = d->cutoff;
 }
 
@@ -174,6 +191,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.contig.release(); c->dn.rcontig.release(); c->dn.start.release(); c->dn.end.release();
     c->dn.vartype.release(); c->dn.dflags.release(); c->dn.mult.release(); c->dn.allele_off.release();
     c->dn.alleles.release();
+    if (c->dn_stage) (void)hipHostFree(c->dn_stage);
     c->ab_lut.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release();

@@ -445,11 +445,25 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         fprintf(stderr, " | ticks/DNM %.0f\n", (double)tot / n);
     }
 #endif
-    if (status) UZ_HIP(hipMemcpyAsync(status, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (counts) UZ_HIP(hipMemcpyAsync(counts, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (origin) UZ_HIP(hipMemcpyAsync(origin, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    if (evidence) UZ_HIP(hipMemcpyAsync(evidence, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    UZ_HIP(hipStreamSynchronize(c->stream));
+    { // results come back through the pinned buffer (copies into pageable memory are staged one call at a time)
+        const size_t need = (size_t)7 * n + 16;
+        if (st->bounds_h_cap < need) {
+            if (st->bounds_h) (void)hipHostFree(st->bounds_h);
+            st->bounds_h = nullptr;
+            st->bounds_h_cap = need + (size_t)n;
+            UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
+        }
+        int32_t *h = st->bounds_h;
+        if (status) UZ_HIP(hipMemcpyAsync(h, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (counts) UZ_HIP(hipMemcpyAsync(h + n, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (origin) UZ_HIP(hipMemcpyAsync(h + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (evidence) UZ_HIP(hipMemcpyAsync(h + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        if (status) memcpy(status, h, (size_t)n * sizeof(int32_t));
+        if (counts) memcpy(counts, h + n, (size_t)4 * n * sizeof(int32_t));
+        if (origin) memcpy(origin, h + (size_t)5 * n, (size_t)n * sizeof(int32_t));
+        if (evidence) memcpy(evidence, h + (size_t)6 * n, (size_t)n * sizeof(int32_t));
+    }
     if (r.n > 0 && c->prof_on) {
         unsigned int m = 0;
         UZ_HIP(hipMemcpy(&m, st->need_count.p, sizeof(m), hipMemcpyDeviceToHost));

@@ -138,6 +138,8 @@ struct uz_ctx {
     bool find_valid = false;
     int find_fam = -1, find_mode = 0;
     DnmsDev dn;
+    uint8_t *dn_stage = nullptr; // pinned staging of a DNM batch
+    size_t dn_stage_cap = 0;
     DevBuf<int32_t> cnt_c, cnt_h;
     DevBuf<int64_t> cand_off, het_off;
     DevBuf<int32_t> cand_idx, het_idx;
