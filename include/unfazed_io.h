@@ -12,7 +12,7 @@
  *                      arithmetic on the device.
  *   uz_vcf_decode      cyvcf2.VCF(sites) + Variant.start/end/REF/ALT/gt_types/gt_ref_depths/
  *                      gt_alt_depths/gt_quals (unfazed/informative_site_finder.py:213-339, :571-600):
- *                      text VCF (plain or gzip/bgzip) -> site columns for all samples.
+ *                      text VCF (plain or gzip/bgzip) or BCF2 -> site columns for all samples.
  *
  * Error convention: 0 = success, negative = failure with a message in uz_io_last_error()
  * (thread local).  Nothing is written to stdout / stderr.  Handles own their memory; the views they
@@ -89,6 +89,11 @@ const char *uz_vcf_alt(const uz_vcf *h, int64_t i, int32_t *len);
 /* header lines (incl. #CHROM) joined by '\n' and the raw text line of record i (VCF writer) */
 const char *uz_vcf_header(const uz_vcf *h, int64_t *len);
 const char *uz_vcf_line(const uz_vcf *h, int64_t i, int32_t *len);
+/* text value of INFO/<key> of record i (e.g. SVTYPE: `unfazed.py:67-83` reads it through
+ * variant.INFO.get); NULL when the key is absent or a flag; for BCF only string-typed values are returned */
+const char *uz_vcf_info(const uz_vcf *h, int64_t i, const char *key, int32_t *len);
+/* 1 when the file was BCF (no text lines: uz_vcf_line is empty) */
+int uz_vcf_is_bcf(const uz_vcf *h);
 
 #ifdef __cplusplus
 }

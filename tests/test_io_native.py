@@ -202,3 +202,49 @@ def test_family_columns_agree(tmp_path):
     p = ds.pedigrees[kid]
     for a, b in zip(got.family_columns(kid, p["dad"], p["mom"]), want.family_columns(kid, p["dad"], p["mom"])):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("use_idx,int16", [(False, False), (True, True)])
+def test_bcf_matches_the_text_form(tmp_path, use_idx, int16):
+    """BCF2 input (the reference opens .bcf through cyvcf2, utils.py:7): the native decoder must give the same
+    columns for the binary form as for the text form of the same records."""
+    import gzip as gz
+    from tests.bcfio import write_bcf
+    from tests.filesio import vcf_text
+    ds = make_small(SmallConfig(seed=21, n_dnms=8))
+    sv = make_small_sv(SvConfig(seed=4, n_svs=3))
+    for k, d in enumerate((ds, sv)):
+        recs = list(d.sites)
+        for j, r in enumerate(recs[:20]):  # give some records INFO fields
+            if j % 3 == 0:
+                r.info = {"SVTYPE": "DEL", "END": r.start + 50}
+                r.end = r.start + 50
+        text_path = str(tmp_path / ("t%d.vcf.gz" % k))
+        with gz.open(text_path, "wt") as fh:
+            fh.write(vcf_text(d.samples, recs, d.contigs))
+        bcf_path = str(tmp_path / ("t%d.bcf" % k))
+        write_bcf(bcf_path, d.samples, recs, d.contigs, use_idx=use_idx, int16_depths=int16)
+        a = io_native.read_vcf_table(text_path, threads=2)
+        b = io_native.read_vcf_table(bcf_path, threads=3)
+        assert b.is_bcf and not a.is_bcf
+        assert a.samples == b.samples and a.contigs == b.contigs
+        for c in SITE_COLS:
+            assert np.array_equal(getattr(a, c), getattr(b, c)), c
+        assert np.array_equal(a.gq, b.gq)
+        assert list(a.ref_str) == list(b.ref_str)
+        assert list(a.alt_strs) == list(b.alt_strs)
+        for j in range(min(25, a.n_sites)):
+            assert a.info(j, "SVTYPE") == b.info(j, "SVTYPE")
+        assert a.info(0, "SVTYPE") == "DEL" and a.info(1, "SVTYPE") is None
+
+
+def test_bcf_dnm_input_gives_the_same_variants(tmp_path):
+    from tests.bcfio import write_bcf
+    from unfazed_amd.unfazed import read_vars_vcf
+    ds = make_small(SmallConfig(seed=3, n_dnms=6, kids=["kidA", "kidB"]))
+    paths = dump_dataset(ds, str(tmp_path))
+    smp, recs, _ = read_vcf(paths["dnm_vcf"])
+    bcf = str(tmp_path / "dnms.bcf")
+    write_bcf(bcf, smp, recs, ds.contigs)
+    a, b = list(read_vars_vcf(paths["dnm_vcf"])), list(read_vars_vcf(bcf))
+    assert len(a) >= 6 and a == b

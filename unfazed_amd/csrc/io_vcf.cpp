@@ -8,7 +8,8 @@
 // HET 1, UNKNOWN 2, HOM_ALT 3; half-missing calls count with their called allele, haploid calls as
 // homozygous; depths from FORMAT/AD (first ALT) falling back to RO / AO, missing -> -1; GQ as a
 // float, missing -> -1; end = INFO/END when it parses as an integer, else start + len(REF).
-// BCF is not decoded.
+// BCF2 (the binary form, `.bcf`) is decoded into the same columns (decode_bcf below); it has no text lines,
+// so uz_vcf_line() is empty for such a file.
 #include "io_common.hpp"
 
 #include <cmath>
@@ -30,6 +31,12 @@ struct uz_vcf {
     std::vector<uint64_t> line_at;
     std::vector<uint32_t> line_len, ref_at, ref_len, alt_at, alt_len; // REF / ALT relative to the line start
     std::vector<uint32_t> chrom_len;
+    bool is_bcf = false;
+    std::string pool;                 // BCF: comma-joined ALT strings (REF is used in place)
+    std::vector<uint64_t> alt_pool_at; // BCF: offset of record i's ALT text in `pool`
+    std::vector<uint64_t> info_at;     // BCF: offset of the INFO section of record i in `text`
+    std::vector<uint32_t> n_info;
+    std::vector<std::string> dict;     // BCF: FILTER / INFO / FORMAT string dictionary
 };
 
 namespace {
@@ -111,6 +118,263 @@ int parse_gt(Str g) {
     return a == 0 ? 0 : 3;
 }
 
+
+// ------------------------------------------------------------------ BCF2
+struct BcfVal { // one typed value: `n` elements of `type` at `p`
+    int type = 0; // 1 int8, 2 int16, 3 int32, 5 float, 7 char, 0 missing / flag
+    uint32_t n = 0;
+    const uint8_t *p = nullptr;
+};
+const int BCF_SZ[8] = {0, 1, 2, 4, 0, 4, 0, 1};
+
+const uint8_t *bcf_typed(const uint8_t *p, const uint8_t *end, BcfVal &v) {
+    if (p >= end) fail(UZ_IO_E_FORMAT, "truncated BCF record");
+    const uint8_t b = *p++;
+    v.type = b & 15;
+    v.n = b >> 4;
+    if (v.n == 15) { // the length follows as a typed integer
+        if (p >= end) fail(UZ_IO_E_FORMAT, "truncated BCF record");
+        const uint8_t b2 = *p++;
+        const int t2 = b2 & 15;
+        if (t2 == 1) { v.n = *p; p += 1; } else if (t2 == 2) { v.n = rd16(p); p += 2; } else if (t2 == 3) { v.n = rd32(p); p += 4; }
+        else fail(UZ_IO_E_FORMAT, "bad BCF length descriptor");
+    }
+    if (v.type > 7 || (v.type != 0 && BCF_SZ[v.type] == 0)) fail(UZ_IO_E_FORMAT, "bad BCF value type %d", v.type);
+    v.p = p;
+    p += (size_t)v.n * BCF_SZ[v.type];
+    if (p > end) fail(UZ_IO_E_FORMAT, "BCF value overruns its record");
+    return p;
+}
+// k-th element of an integer vector: value, or missing / end-of-vector
+enum { BCF_OK = 0, BCF_MISSING = 1, BCF_EOV = 2 };
+int bcf_int(int type, const uint8_t *p, uint32_t k, long long &out) {
+    if (type == 1) { const int8_t x = (int8_t)p[k]; if (x == INT8_MIN) return BCF_MISSING; if (x == INT8_MIN + 1) return BCF_EOV; out = x; return BCF_OK; }
+    if (type == 2) { int16_t x; memcpy(&x, p + 2 * k, 2); if (x == INT16_MIN) return BCF_MISSING; if (x == INT16_MIN + 1) return BCF_EOV; out = x; return BCF_OK; }
+    if (type == 3) { int32_t x; memcpy(&x, p + 4 * k, 4); if (x == INT32_MIN) return BCF_MISSING; if (x == INT32_MIN + 1) return BCF_EOV; out = x; return BCF_OK; }
+    return BCF_MISSING;
+}
+long long bcf_scalar_int(const BcfVal &v) {
+    long long x = 0;
+    if (v.n == 0 || bcf_int(v.type, v.p, 0, x) != BCF_OK) fail(UZ_IO_E_FORMAT, "bad BCF dictionary key");
+    return x;
+}
+
+void decode_bcf(uz_vcf &V, int threads) {
+    V.is_bcf = true;
+    const uint8_t *D = V.text.data();
+    const size_t N = V.text.size();
+    if (N < 9 || D[4] != 2) fail(UZ_IO_E_FORMAT, "unsupported BCF version");
+    const size_t l_text = rd32(D + 5);
+    if (9 + l_text > N) fail(UZ_IO_E_FORMAT, "truncated BCF header");
+    // header text: dictionaries (IDX= when present, else order of appearance; PASS is 0), contigs, samples
+    std::vector<std::string> &dict = V.dict;
+    auto dict_set = [&](std::vector<std::string> &d, long idx, const std::string &name) {
+        if (idx < 0) { for (auto &x : d) if (x == name) return; idx = (long)d.size(); }
+        if ((size_t)idx >= d.size()) d.resize((size_t)idx + 1);
+        d[(size_t)idx] = name;
+    };
+    dict_set(dict, 0, "PASS");
+    const char *H = (const char *)D + 9;
+    size_t p = 0;
+    while (p < l_text) {
+        const char *nl = (const char *)memchr(H + p, '\n', l_text - p);
+        size_t e = nl ? (size_t)(nl - H) : l_text;
+        while (e > p && (H[e - 1] == 0 || H[e - 1] == '\r')) e--;
+        if (e > p) {
+            const std::string line(H + p, e - p);
+            if (!V.header.empty()) V.header.push_back('\n');
+            V.header += line;
+            auto field = [&](const char *key) -> std::string {
+                const std::string k = std::string(key) + "=";
+                size_t a = line.find("<" + k);
+                if (a == std::string::npos) a = line.find("," + k);
+                if (a == std::string::npos) return "";
+                a += 1 + k.size();
+                size_t b = a;
+                while (b < line.size() && line[b] != ',' && line[b] != '>') b++;
+                return line.substr(a, b - a);
+            };
+            const bool is_dict = line.rfind("##INFO=<", 0) == 0 || line.rfind("##FORMAT=<", 0) == 0 || line.rfind("##FILTER=<", 0) == 0;
+            if (is_dict || line.rfind("##contig=<", 0) == 0) {
+                const std::string id = field("ID"), ix = field("IDX");
+                long idx = -1;
+                if (!ix.empty()) idx = strtol(ix.c_str(), nullptr, 10);
+                if (!id.empty()) dict_set(is_dict ? dict : V.contigs, idx, id);
+            } else if (line[0] == '#' && line.size() > 1 && line[1] != '#') {
+                size_t a = 0;
+                int col = 0;
+                while (a <= line.size()) {
+                    size_t b = line.find('\t', a);
+                    if (b == std::string::npos) b = line.size();
+                    if (col >= 9) V.samples.emplace_back(line.substr(a, b - a));
+                    col++;
+                    a = b + 1;
+                }
+            }
+        }
+        p = (nl ? (size_t)(nl - H) : l_text) + 1;
+    }
+    std::vector<std::string> header_contigs;
+    header_contigs.swap(V.contigs); // the table's contigs are those that carry records, in order of appearance
+    int k_gt = -1, k_ad = -1, k_ro = -1, k_ao = -1, k_gq = -1;
+    for (size_t k = 0; k < dict.size(); k++) {
+        if (dict[k] == "GT") k_gt = (int)k; else if (dict[k] == "AD") k_ad = (int)k; else if (dict[k] == "RO") k_ro = (int)k;
+        else if (dict[k] == "AO") k_ao = (int)k; else if (dict[k] == "GQ") k_gq = (int)k;
+    }
+    // record boundaries
+    std::vector<uint64_t> rec;
+    size_t off = 9 + l_text;
+    while (off + 8 <= N) {
+        const size_t ls = rd32(D + off), li = rd32(D + off + 4);
+        if (ls < 24 || off + 8 + ls + li > N) fail(UZ_IO_E_FORMAT, "truncated BCF record at byte %zu", off);
+        rec.push_back(off);
+        off += 8 + ls + li;
+    }
+    const int64_t n = (int64_t)rec.size();
+    V.n = n;
+    const size_t un = (size_t)n, ns = V.samples.size();
+    V.line_at.assign(un, 0); V.line_len.assign(un, 0);
+    V.ref_at.resize(un); V.ref_len.resize(un); V.alt_at.assign(un, 0); V.alt_len.resize(un);
+    V.chrom_len.assign(un, 0); V.alt_pool_at.resize(un); V.info_at.resize(un); V.n_info.resize(un);
+    V.pos.resize(un); V.end.resize(un); V.sflags.resize(un); V.ref_base.resize(un); V.alt_base.resize(un);
+    V.gt.assign(ns * un, UZ_GT_UNKNOWN);
+    V.ref_depth.assign(ns * un, -1); V.alt_depth.assign(ns * un, -1);
+    V.gq.assign(ns * un, -1.0);
+    std::vector<int32_t> chrom(un);
+    std::vector<std::string> alts(un);
+    threads = workers_for(n, threads, 2048);
+    parallel_slices(n, threads, [&](int64_t lo, int64_t hi, int) {
+        for (int64_t i = lo; i < hi; i++) {
+            const uint8_t *r = D + rec[(size_t)i];
+            const size_t ls = rd32(r), li = rd32(r + 4);
+            const uint8_t *q = r + 8, *send = r + 8 + ls, *iend = send + li;
+            chrom[(size_t)i] = rdi32(q);
+            const int32_t pos = rdi32(q + 4), rlen = rdi32(q + 8);
+            const uint32_t nai = rd32(q + 16), nfs = rd32(q + 20);
+            const uint32_t n_allele = nai >> 16, n_inf = nai & 0xFFFFu, n_fmt = nfs >> 24, n_smp = nfs & 0xFFFFFFu;
+            if (chrom[(size_t)i] < 0 || (size_t)chrom[(size_t)i] >= header_contigs.size()) fail(UZ_IO_E_FORMAT, "BCF contig id out of range");
+            if (n_smp != ns && n_fmt) fail(UZ_IO_E_FORMAT, "BCF record with %u samples, header has %zu", n_smp, ns);
+            q += 24;
+            BcfVal v;
+            q = bcf_typed(q, send, v); // ID
+            std::string &alt = alts[(size_t)i];
+            size_t ref_n = 0, n_alt = 0, alt0_n = 0;
+            bool star = false;
+            for (uint32_t a = 0; a < n_allele; a++) {
+                q = bcf_typed(q, send, v);
+                if (a == 0) { V.ref_at[(size_t)i] = (uint32_t)(v.p - r); V.ref_len[(size_t)i] = v.n; ref_n = v.n; V.line_at[(size_t)i] = rec[(size_t)i]; }
+                else {
+                    if (a > 1) alt.push_back(',');
+                    alt.append((const char *)v.p, v.n);
+                    if (a == 1) alt0_n = v.n;
+                    if (v.n == 1 && v.p[0] == '*') star = true;
+                    n_alt++;
+                }
+            }
+            if (n_alt == 0) alt = ".";
+            V.alt_len[(size_t)i] = (uint32_t)alt.size();
+            q = bcf_typed(q, send, v); // FILTER
+            V.info_at[(size_t)i] = (uint64_t)(q - D);
+            V.n_info[(size_t)i] = n_inf;
+            V.pos[(size_t)i] = pos;
+            V.end[(size_t)i] = pos + rlen; // htslib keeps rlen = END - POS when INFO/END is present
+            const bool cx = n_alt != 1 || ref_n > 1 || star || alt0_n > 1;
+            V.sflags[(size_t)i] = cx ? UZ_SF_COMPLEX : 0;
+            V.ref_base[(size_t)i] = cx || ref_n != 1 ? 0 : D[rec[(size_t)i] + V.ref_at[(size_t)i]];
+            V.alt_base[(size_t)i] = cx || alt0_n != 1 ? 0 : (uint8_t)alt[0];
+            // FORMAT fields
+            const uint8_t *f = send;
+            BcfVal fv[5]; // GT, AD, RO, AO, GQ
+            for (uint32_t k = 0; k < n_fmt; k++) {
+                BcfVal key;
+                f = bcf_typed(f, iend, key);
+                const long long kid = bcf_scalar_int(key);
+                if (f >= iend) fail(UZ_IO_E_FORMAT, "truncated BCF FORMAT block");
+                BcfVal d; // descriptor: type and per-sample length; the data of all samples follows
+                const uint8_t b = *f++;
+                d.type = b & 15; d.n = b >> 4;
+                if (d.n == 15) { BcfVal L; f = bcf_typed(f, iend, L); d.n = (uint32_t)bcf_scalar_int(L); }
+                if (d.type > 7 || (d.type != 0 && BCF_SZ[d.type] == 0)) fail(UZ_IO_E_FORMAT, "bad BCF FORMAT type");
+                d.p = f;
+                f += (size_t)d.n * BCF_SZ[d.type] * n_smp;
+                if (f > iend) fail(UZ_IO_E_FORMAT, "BCF FORMAT data overruns its record");
+                if (kid == k_gt) fv[0] = d; else if (kid == k_ad) fv[1] = d; else if (kid == k_ro) fv[2] = d;
+                else if (kid == k_ao) fv[3] = d; else if (kid == k_gq) fv[4] = d;
+            }
+            for (size_t s = 0; s < ns && n_fmt; s++) {
+                const size_t o = s * un + (size_t)i;
+                auto at = [&](const BcfVal &d) { return d.p + s * (size_t)d.n * BCF_SZ[d.type]; };
+                if (fv[0].p && fv[0].n) { // GT: (allele + 1) << 1 | phased; 0 = missing allele
+                    long long al[2] = {-1, -1};
+                    int na = 0;
+                    for (uint32_t k = 0; k < fv[0].n; k++) {
+                        long long x;
+                        const int st = bcf_int(fv[0].type, at(fv[0]), k, x);
+                        if (st == BCF_EOV) break;
+                        if (na < 2) al[na] = st == BCF_OK ? (x >> 1) - 1 : -1;
+                        na++;
+                    }
+                    int code = UZ_GT_UNKNOWN;
+                    if (na == 1) code = al[0] < 0 ? UZ_GT_UNKNOWN : (al[0] == 0 ? 0 : 3);
+                    else if (na >= 2) {
+                        const long long a = al[0], b = al[1];
+                        if (a < 0 && b < 0) code = UZ_GT_UNKNOWN;
+                        else if (a < 0 || b < 0) code = (b < 0 ? a : b) == 0 ? 0 : 1;
+                        else if (a != b) code = 1;
+                        else code = a == 0 ? 0 : 3;
+                    }
+                    V.gt[o] = (uint8_t)code;
+                }
+                bool ad_done = false;
+                if (fv[1].p && fv[1].n) { // AD: "." (all missing) falls through to RO / AO, as in the text form
+                    long long x0 = -1, x1 = -1;
+                    const int s0 = bcf_int(fv[1].type, at(fv[1]), 0, x0);
+                    const int s1 = fv[1].n > 1 ? bcf_int(fv[1].type, at(fv[1]), 1, x1) : BCF_EOV;
+                    if (!(s0 != BCF_OK && s1 == BCF_EOV)) {
+                        V.ref_depth[o] = s0 == BCF_OK ? (int32_t)x0 : -1;
+                        V.alt_depth[o] = s1 == BCF_OK ? (int32_t)x1 : -1;
+                        ad_done = true;
+                    }
+                }
+                if (!ad_done && fv[2].p && fv[3].p && fv[2].n && fv[3].n) {
+                    long long x;
+                    V.ref_depth[o] = bcf_int(fv[2].type, at(fv[2]), 0, x) == BCF_OK ? (int32_t)x : -1;
+                    V.alt_depth[o] = bcf_int(fv[3].type, at(fv[3]), 0, x) == BCF_OK ? (int32_t)x : -1;
+                }
+                if (fv[4].p && fv[4].n) {
+                    if (fv[4].type == 5) {
+                        uint32_t bits;
+                        memcpy(&bits, at(fv[4]), 4);
+                        float fl;
+                        memcpy(&fl, &bits, 4);
+                        V.gq[o] = (bits == 0x7F800001u || bits == 0x7F800002u) ? -1.0 : (double)fl;
+                    } else {
+                        long long x;
+                        V.gq[o] = bcf_int(fv[4].type, at(fv[4]), 0, x) == BCF_OK ? (double)x : -1.0;
+                    }
+                }
+            }
+        }
+    });
+    for (int64_t i = 0; i < n; i++) { V.alt_pool_at[(size_t)i] = V.pool.size(); V.pool += alts[(size_t)i]; V.pool.push_back('\0'); }
+    // contigs in order of appearance; records must be grouped by contig and sorted inside one
+    V.contig_off.clear();
+    int32_t last = -1;
+    std::vector<uint8_t> seen(header_contigs.size(), 0);
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t c = chrom[(size_t)i];
+        if (c != last) {
+            if (seen[(size_t)c]) fail(UZ_IO_E_UNSORTED, "sites records are not grouped by contig: %s", header_contigs[(size_t)c].c_str());
+            seen[(size_t)c] = 1;
+            V.contigs.push_back(header_contigs[(size_t)c]);
+            V.contig_off.push_back(i);
+            last = c;
+        } else if (V.pos[(size_t)i] < V.pos[(size_t)i - 1])
+            fail(UZ_IO_E_UNSORTED, "sites records are not sorted by position on %s", header_contigs[(size_t)c].c_str());
+    }
+    V.contig_off.push_back(n);
+}
+
 void decode(uz_vcf &V, const char *path, int threads) {
     {
         Bytes file = read_file(path);
@@ -119,6 +383,7 @@ void decode(uz_vcf &V, const char *path, int threads) {
     }
     const char *T = (const char *)V.text.data();
     const size_t N = V.text.size();
+    if (N >= 5 && memcmp(T, "BCF\2", 4) == 0) { decode_bcf(V, threads); return; }
     // line starts: header first (serial, short), then records
     size_t p = 0;
     bool have_chrom_line = false;
@@ -359,6 +624,7 @@ const char *uz_vcf_ref(const uz_vcf *h, int64_t i, int32_t *len) {
 const char *uz_vcf_alt(const uz_vcf *h, int64_t i, int32_t *len) {
     if (!h || i < 0 || i >= h->n) return nullptr;
     if (len) *len = (int32_t)h->alt_len[(size_t)i];
+    if (h->is_bcf) return h->pool.data() + h->alt_pool_at[(size_t)i];
     return (const char *)h->text.data() + h->line_at[(size_t)i] + h->alt_at[(size_t)i];
 }
 const char *uz_vcf_header(const uz_vcf *h, int64_t *len) {
@@ -366,6 +632,55 @@ const char *uz_vcf_header(const uz_vcf *h, int64_t *len) {
     if (len) *len = (int64_t)h->header.size();
     return h->header.c_str();
 }
+int uz_vcf_is_bcf(const uz_vcf *h) { return h && h->is_bcf ? 1 : 0; }
+
+const char *uz_vcf_info(const uz_vcf *h, int64_t i, const char *key, int32_t *len) {
+    if (!h || !key || i < 0 || i >= h->n) return nullptr;
+    const size_t kl = strlen(key);
+    if (h->is_bcf) {
+        const uint8_t *D = h->text.data();
+        const uint8_t *r = D + h->line_at[(size_t)i];
+        const uint8_t *q = D + h->info_at[(size_t)i], *send = r + 8 + rd32(r);
+        try {
+            for (uint32_t k = 0; k < h->n_info[(size_t)i]; k++) {
+                BcfVal kv, v;
+                q = bcf_typed(q, send, kv);
+                q = bcf_typed(q, send, v);
+                const long long id = bcf_scalar_int(kv);
+                if (id >= 0 && (size_t)id < h->dict.size() && h->dict[(size_t)id].size() == kl && memcmp(h->dict[(size_t)id].data(), key, kl) == 0) {
+                    if (v.type != 7) return nullptr;
+                    uint32_t n = v.n;
+                    while (n > 0 && v.p[n - 1] == 0) n--; // strings may be NUL padded
+                    if (len) *len = (int32_t)n;
+                    return (const char *)v.p;
+                }
+            }
+        } catch (const IoError &) {
+        }
+        return nullptr;
+    }
+    // text: column 8 of the line, `key=value` separated by ';' (the last occurrence wins, as in a dict)
+    const char *L = (const char *)h->text.data() + h->line_at[(size_t)i];
+    const char *E = L + h->line_len[(size_t)i];
+    const char *f = L;
+    for (int col = 0; col < 7 && f; col++) { f = (const char *)memchr(f, '\t', (size_t)(E - f)); if (f) f++; }
+    if (!f) return nullptr;
+    const char *fe = (const char *)memchr(f, '\t', (size_t)(E - f));
+    if (!fe) fe = E;
+    const char *best = nullptr;
+    int32_t best_len = 0;
+    for (const char *q = f; q <= fe;) {
+        const char *sc = (const char *)memchr(q, ';', (size_t)(fe - q));
+        const char *stop = sc ? sc : fe;
+        if ((size_t)(stop - q) > kl && memcmp(q, key, kl) == 0 && q[kl] == '=') { best = q + kl + 1; best_len = (int32_t)(stop - best); }
+        else if ((size_t)(stop - q) == kl && memcmp(q, key, kl) == 0) { best = nullptr; best_len = 0; } // a flag
+        if (!sc) break;
+        q = sc + 1;
+    }
+    if (best && len) *len = best_len;
+    return best;
+}
+
 const char *uz_vcf_line(const uz_vcf *h, int64_t i, int32_t *len) {
     if (!h || i < 0 || i >= h->n) return nullptr;
     if (len) *len = (int32_t)h->line_len[(size_t)i];

@@ -25,7 +25,7 @@ IO_EXPORTS = [
     "uz_io_last_error", "uz_bam_decode", "uz_bam_free", "uz_bam_n_contigs", "uz_bam_contig_name",
     "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
     "uz_bam_tlen_head", "uz_bam_timing", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
-    "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line",
+    "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
 ]
 
 
@@ -82,6 +82,9 @@ def load():
     for fn in (lib.uz_vcf_ref, lib.uz_vcf_alt, lib.uz_vcf_line):
         fn.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
         fn.restype = C.c_void_p
+    lib.uz_vcf_info.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.POINTER(C.c_int32)]
+    lib.uz_vcf_info.restype = C.c_void_p
+    lib.uz_vcf_is_bcf.argtypes = [C.c_void_p]
     lib.uz_vcf_header.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.uz_vcf_header.restype = C.c_void_p
     _LIB = lib
@@ -222,5 +225,13 @@ def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
     ln = C.c_int64(0)
     hp2 = lib.uz_vcf_header(h.ptr, C.byref(ln))
     t.header = C.string_at(hp2, ln.value).decode().split("\n") if ln.value else []
+    t.is_bcf = bool(lib.uz_vcf_is_bcf(h.ptr))
+
+    def info(i: int, key: str):
+        ln2 = C.c_int32(0)
+        p = lib.uz_vcf_info(h.ptr, int(i), key.encode(), C.byref(ln2))
+        return C.string_at(p, ln2.value).decode() if p else None
+
+    t.info = info
     t._native = h
     return t

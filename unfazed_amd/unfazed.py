@@ -7,6 +7,8 @@ from __future__ import annotations
 import gzip
 import os
 import sys
+
+import numpy as np
 from glob import glob
 
 from . import __reference_version__
@@ -48,7 +50,30 @@ def read_vars_bedzip(bedzipname):
         yield from _bed_rows(fh)
 
 
+def _is_bcf(name):
+    import gzip
+    try:
+        with gzip.open(name, "rb") as fh:
+            return fh.read(4) == b"BCF\x02"
+    except OSError:
+        return False
+
+
 def read_vars_vcf(vcfname):
+    if vcfname.endswith("bcf") or _is_bcf(vcfname):
+        # binary form: through the native decoder (io_native); same fields as the text path below
+        from .io_native import read_vcf_table
+        t = read_vcf_table(vcfname)
+        chrom_of = np.repeat(np.arange(len(t.contigs)), np.diff(t.contig_off))
+        for j in range(t.n_sites):
+            vartype = t.info(j, "SVTYPE")
+            if vartype is None:
+                vartype = SNV_TYPES[0]
+            for i in range(len(t.samples)):
+                if int(t.gt[i, j]) in [HET, HOM_ALT]:
+                    yield {"chrom": t.contigs[int(chrom_of[j])], "start": int(t.pos[j]), "end": int(t.end[j]),
+                           "kid": t.samples[i], "vartype": vartype, "bam": ""}
+        return
     samples, records, _ = read_vcf(vcfname)
     for r in records:
         vartype = r.info.get("SVTYPE")
@@ -131,6 +156,9 @@ def uet_code(evidence_types):
 
 
 def write_vcf_output(in_vcf_name, read_records, include_ambiguous, verbose, outfile, evidence_min_ratio):
+    if in_vcf_name.endswith("bcf") or _is_bcf(in_vcf_name):
+        sys.exit("annotated VCF output needs a text VCF as --dnms (BCF input carries no text records): "
+                 "rerun with `--output-type bed`")
     """reference unfazed.py:337-441: GT of a phased sample becomes 1|0 (paternal) / 0|1 (maternal),
     every sample gets UOPS and UET appended."""
     samples, records, header = read_vcf(in_vcf_name)
