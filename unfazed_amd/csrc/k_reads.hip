@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
     }
 }
 
-// Marks the records a batch can touch: every record of every fetch range and its mate.  One wave per
-// range, lanes on consecutive records (ranges are tens of records long).
+// Marks the records a batch can touch: every record of every fetch range and its mate.  Sixteen lanes per
+// range, on consecutive records (ranges are tens of records long).
 // For het-site ranges (rec_end != nullptr) records that end at or before the site are skipped: a fetch
 // range holds every record STARTING within max_span of the site, the kernel only registers those that
 // reach it (`end > pos`, phase B), so the others' QC bits are never read.
@@ -133,14 +133,15 @@ __global__ __launch_bounds__(256) void k_mark_ranges(const int32_t *__restrict__
                                                      int end_stride, int64_t n_ranges, const int32_t *__restrict__ mate,
                                                      uint8_t *need, const int32_t *__restrict__ rec_end,
                                                      const int32_t *__restrict__ spos, const int32_t *__restrict__ het_idx) {
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    // sixteen lanes per range (a het-site range holds ~30 records): four ranges in flight per wave
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 15;
     if (w >= n_ranges) return;
     // end_stride == 0: (first[w], len[w]); otherwise ranges are [first[w * stride], first[w * stride + 1])
     const int64_t a = end_stride ? first[w * end_stride] : first[w];
     const int64_t b = end_stride ? first[w * end_stride + 1] : a + len_or_end[w];
     const int32_t hp = rec_end ? spos[het_idx[w]] : 0;
-    for (int64_t i = a + lane; i < b; i += 64) {
+    for (int64_t i = a + lane; i < b; i += 16) {
         if (rec_end && !(rec_end[i] > hp)) continue;
         need[i] = 1;
         const int m = mate[i];
@@ -330,12 +331,12 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         uz_prof_begin(c, UZ_K_SEG_QC, &qc_a, &qc_b);
         UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n + 64, c->stream));
         const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
-        hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 64 + 255) / 256)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 16 + 255) / 256)), dim3(256), 0, c->stream,
                            (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const int32_t *)r.mate,
                            r.need, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
         UZ_HIP(hipGetLastError());
         if (!c->P.no_extended && c->n_het > 0) {
-            hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 64 + 255) / 256)), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 16 + 255) / 256)), dim3(256), 0, c->stream,
                                (const int32_t *)st->pre_ha.p, (const int32_t *)st->pre_hl.p, 0, (int64_t)c->n_het,
                                (const int32_t *)r.mate, r.need, (const int32_t *)r.end, (const int32_t *)s.pos,
                                (const int32_t *)c->het_idx.p);
