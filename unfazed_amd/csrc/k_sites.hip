@@ -527,8 +527,8 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
     c->cnt_h.ensure((size_t)n + 1);
     c->cand_off.ensure((size_t)n + 1);
     c->het_off.ensure((size_t)n + 1);
-    c->cand_off_h.assign((size_t)n + 1, 0);
-    c->het_off_h.assign((size_t)n + 1, 0);
+    if (host_offsets || n <= 0) { c->cand_off_h.assign((size_t)n + 1, 0); c->het_off_h.assign((size_t)n + 1, 0); }
+    else { c->cand_off_h.resize((size_t)n + 1); c->het_off_h.resize((size_t)n + 1); } // only the totals are read back
     c->n_cand = c->n_het = 0;
     if (n > 0) {
         WinArgs a;
