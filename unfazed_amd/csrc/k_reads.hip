@@ -413,6 +413,18 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         uz_prof_end(c, UZ_K_SEG_QC, qc_a, qc_b);
     }
+    // pinned staging of the per-DNM results (+ the list-pool fill level): everything comes back behind ONE sync
+    {
+        const size_t need = (size_t)7 * n + 16;
+        if (st->bounds_h_cap < need) {
+            if (st->bounds_h) (void)hipHostFree(st->bounds_h);
+            st->bounds_h = nullptr;
+            st->bounds_h_cap = need + (size_t)n;
+            UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
+        }
+    }
+    int32_t *const hres = st->bounds_h;
+    unsigned long long *const hused = (unsigned long long *)(hres + (size_t)7 * n + ((7 * (size_t)n) & 1)); // 8-byte aligned slot
     for (int attempt = 0; attempt < 4; attempt++) {
         UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
         UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
@@ -423,9 +435,14 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             UZ_HIP(hipGetLastError());
         }
         UZ_TRACE("after k_phase");
-        unsigned long long used = 0;
-        UZ_HIP(hipMemcpyAsync(&used, st->pool_cursor.p, sizeof(used), hipMemcpyDeviceToHost, c->stream));
+        *hused = 0;
+        UZ_HIP(hipMemcpyAsync(hused, st->pool_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        if (status) UZ_HIP(hipMemcpyAsync(hres, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (counts) UZ_HIP(hipMemcpyAsync(hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (origin) UZ_HIP(hipMemcpyAsync(hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if (evidence) UZ_HIP(hipMemcpyAsync(hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         UZ_HIP(hipStreamSynchronize(c->stream));
+        const unsigned long long used = *hused;
         if (!a.want_lists || used <= a.pool_cap) break;
         // list pool too small: grow to the exact demand and run again
         pool_cap = (size_t)used + 1024;
@@ -446,25 +463,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         fprintf(stderr, " | ticks/DNM %.0f\n", (double)tot / n);
     }
 #endif
-    { // results come back through the pinned buffer (copies into pageable memory are staged one call at a time)
-        const size_t need = (size_t)7 * n + 16;
-        if (st->bounds_h_cap < need) {
-            if (st->bounds_h) (void)hipHostFree(st->bounds_h);
-            st->bounds_h = nullptr;
-            st->bounds_h_cap = need + (size_t)n;
-            UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
-        }
-        int32_t *h = st->bounds_h;
-        if (status) UZ_HIP(hipMemcpyAsync(h, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (counts) UZ_HIP(hipMemcpyAsync(h + n, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (origin) UZ_HIP(hipMemcpyAsync(h + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (evidence) UZ_HIP(hipMemcpyAsync(h + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        UZ_HIP(hipStreamSynchronize(c->stream));
-        if (status) memcpy(status, h, (size_t)n * sizeof(int32_t));
-        if (counts) memcpy(counts, h + n, (size_t)4 * n * sizeof(int32_t));
-        if (origin) memcpy(origin, h + (size_t)5 * n, (size_t)n * sizeof(int32_t));
-        if (evidence) memcpy(evidence, h + (size_t)6 * n, (size_t)n * sizeof(int32_t));
-    }
+    if (status) memcpy(status, hres, (size_t)n * sizeof(int32_t));
+    if (counts) memcpy(counts, hres + n, (size_t)4 * n * sizeof(int32_t));
+    if (origin) memcpy(origin, hres + (size_t)5 * n, (size_t)n * sizeof(int32_t));
+    if (evidence) memcpy(evidence, hres + (size_t)6 * n, (size_t)n * sizeof(int32_t));
     if (r.n > 0 && c->prof_on) {
         unsigned int m = 0;
         UZ_HIP(hipMemcpy(&m, st->need_count.p, sizeof(m), hipMemcpyDeviceToHost));
