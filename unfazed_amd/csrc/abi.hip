@@ -192,7 +192,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.vartype.release(); c->dn.dflags.release(); c->dn.mult.release(); c->dn.allele_off.release();
     c->dn.alleles.release();
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
-    c->ab_lut.release();
+    c->ab_lut.release(); c->win_range.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);

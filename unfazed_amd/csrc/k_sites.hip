@@ -287,6 +287,7 @@ struct WinArgs {
     const uint8_t *cls;
     int64_t sd;
     int mode;
+    int64_t *range; // [2n] site index range of every DNM's windows: found by the count pass, reused by the fill pass
 };
 
 // One lane per DNM, sites visited in the reference's order: by position, window-1 copy before
@@ -316,8 +317,13 @@ __global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32
         const int vt = a.vartype[d];
         const int mult = a.mult[d];
         const bool small_event = (en - st) < 20;
-        int64_t i = lower_bound(a.pos, clo, chi, w[0][0] - 1);
-        const int64_t hi_all = lower_bound(a.pos, clo, chi, w[nw - 1][1]);
+        int64_t i, hi_all;
+        if (FILL) { i = a.range[2 * (int64_t)d]; hi_all = a.range[2 * (int64_t)d + 1]; }
+        else {
+            i = lower_bound(a.pos, clo, chi, w[0][0] - 1);
+            hi_all = lower_bound(a.pos, clo, chi, w[nw - 1][1]);
+            a.range[2 * (int64_t)d] = i; a.range[2 * (int64_t)d + 1] = hi_all;
+        }
         while (i < hi_all) {
             const int32_t p = a.pos[i];
             int64_t j = i + 1;
@@ -539,6 +545,8 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         a.pos = s.pos; a.cls = f.cls;
         a.sd = c->P.search_dist;
         a.mode = mode;
+        c->win_range.ensure((size_t)2 * n + 2);
+        a.range = c->win_range.p;
         const unsigned nb = (unsigned)((n + 255) / 256);
         {
             ProfScope ps(c, UZ_K_WINDOW_COUNT);

@@ -141,6 +141,7 @@ struct uz_ctx {
     uint8_t *dn_stage = nullptr; // pinned staging of a DNM batch
     size_t dn_stage_cap = 0;
     DevBuf<int32_t> cnt_c, cnt_h;
+    DevBuf<int64_t> win_range;
     DevBuf<int64_t> cand_off, het_off;
     DevBuf<int32_t> cand_idx, het_idx;
     DevBuf<uint8_t> cand_flags;
