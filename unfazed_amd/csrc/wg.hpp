@@ -203,7 +203,7 @@ UZ_DEV void wg_bitonic_stages(P w, int N) {
 #ifndef UZ_EMU
 // Bitonic sort with the keys held in registers: lane t owns elements t + WG_NT * r.  Partners at
 // distance >= WG_NT are other registers of the same lane, partners at distance < 64 are reached by a
-// wave shuffle; only the distances in between (64 for a 128-lane workgroup) go through LDS and a
+// wave shuffle; only the distances in between (64 and 128 for a 256-lane workgroup) go through LDS and a
 // barrier.  buf: LDS, N entries.  N = R * WG_NT.
 template <int R>
 UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) unsigned long long *buf, unsigned long long *a, int n) {
