@@ -10,7 +10,7 @@ import numpy as np
 from .model import ReadsTable, SitesTable
 
 # status / origin codes (include/uz_types.h)
-ST_OK, ST_NO_CAND, ST_NO_OVERLAP, ST_REF_EXCEPTION, ST_SKIPPED = 0, 1, 2, 3, 4
+ST_OK, ST_NO_CAND, ST_NO_OVERLAP, ST_REF_EXCEPTION, ST_SKIPPED, ST_CAPACITY = 0, 1, 2, 3, 4, 5
 OR_NONE, OR_DAD, OR_MOM, OR_AMBIGUOUS = 0, 1, 2, 3
 VT_POINT, VT_DEL, VT_DUP, VT_OTHER_SV = 0, 1, 2, 3
 DF_FETCH_FALLBACK = 1

@@ -2,6 +2,7 @@
   unfazed_amd/libunfazed_hip.so  the HIP kernels + C ABI, hipcc for gfx950 (cross-compiles without a GPU)
   unfazed_amd/libunfazed_io.so   the host-side BAM / VCF decoders (g++, zlib, threads)
 Both are git-ignored but travel with the tree."""
+import glob
 import os
 import subprocess
 import sys
@@ -20,9 +21,8 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     csrc = os.path.join(_HERE, "csrc")
     inc = os.path.join(_HERE, "..", "include")
     srcs = [os.path.join(csrc, s) for s in SRC]
-    deps = srcs + [os.path.join(csrc, "uz_ctx.hpp"), os.path.join(csrc, "wg.hpp"),
-                   os.path.join(inc, "uz_types.h"), os.path.join(inc, "unfazed_hip.h")]
-    deps = [d for d in deps if os.path.exists(d)]
+    # every header a source can include: editing phase_body.hpp (the k_phase body) must rebuild the library
+    deps = srcs + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(inc, "*.h"))
     lib = out or LIB
     if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
         return lib
@@ -58,7 +58,7 @@ def build_io(force=False, verbose=False, out=None):
     csrc = os.path.join(_HERE, "csrc")
     inc = os.path.join(_HERE, "..", "include")
     srcs = [os.path.join(csrc, s) for s in IO_SRC]
-    deps = srcs + [os.path.join(csrc, "io_common.hpp"), os.path.join(inc, "uz_types.h"), os.path.join(inc, "unfazed_io.h")]
+    deps = srcs + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(inc, "*.h"))
     lib = out or IO_LIB
     if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest(deps):
         return lib

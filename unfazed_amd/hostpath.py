@@ -97,6 +97,7 @@ class PhasingHost:
         self._fam_h: Dict[tuple, object] = {}
         self._reads_h: Dict[str, object] = {}
         self.cutoffs: Dict[str, float] = {}  # reference snv_phaser.py:14 concordant_upper_lens
+        self.capacity_skipped: List[str] = []  # record keys the device refused (UZ_ST_CAPACITY)
 
     # ------------------------------------------------------------ handles
     def family(self, kid: str, dad: str, mom: str):
@@ -461,7 +462,16 @@ class PhasingHost:
                 if st == abi.ST_NO_OVERLAP:
                     log("No reads overlap informative sites for variant {chrom}:{start}-{end}".format(**region))
                     continue
+                if st == abi.ST_CAPACITY:
+                    # include/uz_types.h: reported, never silently dropped -- printed even under --quiet
+                    msg = ("variant {chrom}:{start}-{end} of %s exceeds the device layout of the read stage "
+                           "(UZ_ST_CAPACITY): NOT phased" % dn["kid"]).format(**region)
+                    print(msg, file=sys.stderr)
+                    self.capacity_skipped.append(key)
+                    continue
                 if st != abi.ST_OK:
+                    # ST_REF_EXCEPTION: the reference's worker raises (KeyError in connect_reads) and the default
+                    # thread pool swallows it: no record, no message
                     continue
                 rt = self.reads_by_bam[dn["bam"]]
                 lists = res.get("lists")

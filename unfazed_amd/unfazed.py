@@ -84,48 +84,80 @@ def read_vars_vcf(vcfname):
                 yield {"chrom": r.chrom, "start": r.start, "end": r.end, "kid": samples[i], "vartype": vartype, "bam": ""}
 
 
-def get_bam_names(bam_dir, bam_pairs, cram_ref):
-    bam_dict = {}
-    cram_found = False
-    if bam_dir is not None:
-        for ext in ("*.bam", "*.cram"):
-            for path in glob(os.path.join(bam_dir, ext)):
-                cram_found = cram_found or ext == "*.cram"
-                bam_dict.setdefault(os.path.splitext(os.path.basename(path))[0], set()).add(path)
-    if bam_pairs is not None:
-        for sample_id, bam in bam_pairs:
-            if not os.path.exists(bam) or not os.path.isfile(bam):
-                sys.exit("invalid filename " + bam)
-            bam_dict[sample_id] = {bam}  # one file per id: overrides the directory scan
-            if bam[-4:] == "cram":
-                cram_found = True
-    if cram_found:
+class AlignmentFiles:
+    """sample id -> alignment file(s): the directory scan (`{sample_id}.bam` / `.cram`) overlaid by explicit
+    `id:path` pairs, which win.  Same outcomes and messages as reference unfazed.py:93-126."""
+
+    def __init__(self):
+        self.by_sample = {}
+        self.saw_cram = False
+
+    def scan_dir(self, directory):
+        for path in sorted(glob(os.path.join(directory, "*.bam"))) + sorted(glob(os.path.join(directory, "*.cram"))):
+            stem, ext = os.path.splitext(os.path.basename(path))
+            self.by_sample.setdefault(stem, set()).add(path)
+            self.saw_cram |= ext == ".cram"
+
+    def pin(self, sample_id, path):
+        if not os.path.isfile(path):
+            sys.exit("invalid filename " + path)
+        self.by_sample[sample_id] = {path}
+        self.saw_cram |= path.endswith("cram")
+
+    def check_cram_reference(self, cram_ref):
+        if not self.saw_cram:
+            return
         if cram_ref is None:
             sys.exit("Missing reference file for CRAM")
-        elif not os.path.isfile(cram_ref):
+        if not os.path.isfile(cram_ref):
             sys.exit("Reference file is not valid")
-    return bam_dict
+
+    def lookup(self, sample):
+        """-> (path, None) or (None, why) with why in {"missing", "multiple"}"""
+        files = self.by_sample.get(sample)
+        if files is None:
+            return None, "missing"
+        if len(files) != 1:
+            return None, "multiple"
+        return next(iter(files)), None
+
+
+def get_bam_names(bam_dir, bam_pairs, cram_ref):
+    files = AlignmentFiles()
+    if bam_dir is not None:
+        files.scan_dir(bam_dir)
+    for sample_id, path in (bam_pairs or []):
+        files.pin(sample_id, path)
+    files.check_cram_reference(cram_ref)
+    return files.by_sample
 
 
 def parse_ped(ped, kids):
-    labels = ["kid", "dad", "mom", "sex"]
-    kid_entries = {}
-    missing_parents = []
-    with open(ped, "r") as pedfile:
-        for line in pedfile:
-            fields = line.strip().split()
-            if fields[1] in kids:
-                if fields[2] == "0" or fields[3] == "0":
-                    if not QUIET_MODE:
-                        print("Parent of sample {} missing from pedigree file, will be skipped".format(fields[1]),
-                              file=sys.stderr)
-                    missing_parents.append(fields[1])
-                    continue
-                kid_entries[fields[1]] = dict(zip(labels, fields[1:5]))
+    """kid id -> {kid, dad, mom, sex} (strings) for the kids that have DNMs; kids with a parent coded `0`
+    and kids absent from the file are reported and skipped (reference unfazed.py:129-159)."""
+    wanted = set(kids)
+    entries, parentless = {}, set()
+    with open(ped, "r") as fh:
+        rows = [ln.split() for ln in fh]
+    for row in rows:
+        sample = row[1]
+        if sample not in wanted:
+            continue
+        dad, mom = row[2], row[3]
+        if "0" in (dad, mom):
+            _say("Parent of sample {} missing from pedigree file, will be skipped".format(sample))
+            parentless.add(sample)
+        else:
+            entries[sample] = {"kid": sample, "dad": dad, "mom": mom, "sex": row[4]}
     for sample in kids:
-        if (sample not in kid_entries) and (sample not in missing_parents) and not QUIET_MODE:
-            print("{} missing from pedigree file, will be skipped".format(sample), file=sys.stderr)
-    return kid_entries
+        if sample not in entries and sample not in parentless:
+            _say("{} missing from pedigree file, will be skipped".format(sample))
+    return entries
+
+
+def _say(*words):
+    if not QUIET_MODE:
+        print(*words, file=sys.stderr)
 
 
 UOPS_HEADER = ('##FORMAT=<ID=UOPS,Number=1,Type=Float,Description="Count of pieces of evidence supporting the '
@@ -134,6 +166,10 @@ UET_HEADER = ('##FORMAT=<ID=UET,Number=1,Type=Float,Description="Unfazed evidenc
               '`1` (allele-balance, for CNVs only), `2` (both), `3` (ambiguous readbacked), '
               '`4` (ambiguous allele-balance), `5` (ambiguous both), '
               '`6` (auto-phased sex-chromosome variant in male), or `-1` (missing)">')
+
+
+BCF_OUTPUT_MESSAGE = ("annotated VCF output needs a text VCF as --dnms (BCF input carries no text records): "
+                      "rerun with `--output-type bed`")
 
 
 def uet_code(evidence_types):
@@ -156,11 +192,10 @@ def uet_code(evidence_types):
 
 
 def write_vcf_output(in_vcf_name, read_records, include_ambiguous, verbose, outfile, evidence_min_ratio):
-    if in_vcf_name.endswith("bcf") or _is_bcf(in_vcf_name):
-        sys.exit("annotated VCF output needs a text VCF as --dnms (BCF input carries no text records): "
-                 "rerun with `--output-type bed`")
     """reference unfazed.py:337-441: GT of a phased sample becomes 1|0 (paternal) / 0|1 (maternal),
     every sample gets UOPS and UET appended."""
+    if in_vcf_name.endswith("bcf") or _is_bcf(in_vcf_name):
+        sys.exit(BCF_OUTPUT_MESSAGE)
     samples, records, header = read_vcf(in_vcf_name)
     out = []
     out.extend(header[:-1])
@@ -177,6 +212,8 @@ def write_vcf_output(in_vcf_name, read_records, include_ambiguous, verbose, outf
         for i, gt in enumerate(r.gt_types):
             uops, uet = -1, -1
             col = f[9 + i].split(":")
+            # VCF lets a sample drop trailing FORMAT fields (`./.`): pad, so UOPS / UET land in their own columns
+            col += ["."] * (len(fmt) - len(col))
             if gt in [HET, HOM_ALT]:
                 vartype = r.info.get("SVTYPE")
                 if vartype is None:
@@ -202,67 +239,83 @@ def write_vcf_output(in_vcf_name, read_records, include_ambiguous, verbose, outf
             fh.write(text)
 
 
+def _dnm_reader(path):
+    if path.endswith(".bed"):
+        return read_vars_bed, "bed"
+    if path.endswith(".bed.gz"):
+        return read_vars_bedzip, "bed"
+    if any(path.endswith(t) for t in VCF_TYPES):
+        return read_vars_vcf, "vcf"
+    sys.exit("dnms file type is unrecognized. Must be bed, bed.gz, vcf, vcf.gz, or bcf")
+
+
+def _route_variants(variants, bam_names, cram_ref):
+    """Attach the kid's alignment file to every DNM and split the list into point variants and SVs.  A kid
+    without exactly one alignment file is reported once and its DNMs are dropped."""
+    snvs, svs, kids, reported = [], [], set(), set()
+    for var in variants:
+        sample = var["kid"]
+        files = bam_names.get(sample)
+        if files is None or len(files) != 1:
+            if sample not in reported:
+                reported.add(sample)
+                if files is None:
+                    _say("missing alignment file for", sample)
+                else:
+                    _say("multiple alignment files for", sample + ".",
+                         "Please specify correct alignment file using --bam-pairs")
+            continue
+        kids.add(sample)
+        var["bam"] = next(iter(files))
+        var["cram_ref"] = cram_ref
+        kind = var["vartype"].upper()
+        if kind in SV_TYPES:
+            svs.append(var)
+        elif kind in SNV_TYPES:
+            snvs.append(var)
+    return snvs, svs, kids
+
+
 def unfazed(args):
+    """reference unfazed.py:518-667: read the DNMs, find each kid's alignment file and pedigree entry, phase
+    SVs and point variants through the two phasers, write BED or annotated VCF."""
     global QUIET_MODE
-    bam_names_dict = get_bam_names(args.bam_dir, args.bam_pairs, args.reference)
-    snvs, svs = [], []
-    if args.dnms.endswith(".bed"):
-        reader, input_type = read_vars_bed, "bed"
-    elif args.dnms.endswith(".bed.gz"):
-        reader, input_type = read_vars_bedzip, "bed"
-    elif True in [args.dnms.endswith(t) for t in VCF_TYPES]:
-        reader, input_type = read_vars_vcf, "vcf"
-    else:
-        sys.exit("dnms file type is unrecognized. Must be bed, bed.gz, vcf, vcf.gz, or bcf")
+    bam_names = get_bam_names(args.bam_dir, args.bam_pairs, args.reference)
+    reader, input_type = _dnm_reader(args.dnms)
     QUIET_MODE = args.quiet
-    output_type = args.output_type if args.output_type is not None else input_type
+    output_type = args.output_type or input_type
     if output_type == "vcf" and input_type != "vcf":
         print("Invalid option: --output-type is vcf, but input is not a vcf type. "
               + "Rerun with `--output-type bed` or input dnms as one of the following:", ", ".join(VCF_TYPES),
               file=sys.stderr)
         sys.exit(1)
-    kids = set()
-    missing_samples, duplicated_samples = set(), set()
-    for var_fields in reader(args.dnms):
-        sample = var_fields["kid"]
-        if sample not in bam_names_dict:
-            if sample not in missing_samples:
-                if not QUIET_MODE:
-                    print("missing alignment file for", sample, file=sys.stderr)
-                missing_samples.add(sample)
-            continue
-        elif len(bam_names_dict[sample]) != 1:
-            if sample not in duplicated_samples:
-                if not QUIET_MODE:
-                    print("multiple alignment files for", sample + ".",
-                          "Please specify correct alignment file using --bam-pairs", file=sys.stderr)
-                duplicated_samples.add(sample)
-            continue
-        kids.add(sample)
-        var_fields["bam"] = list(bam_names_dict[sample])[0]
-        var_fields["cram_ref"] = args.reference
-        if var_fields["vartype"].upper() in SV_TYPES:
-            svs.append(var_fields)
-        elif var_fields["vartype"].upper() in SNV_TYPES:
-            snvs.append(var_fields)
+    if output_type == "vcf" and (args.dnms.endswith("bcf") or _is_bcf(args.dnms)):
+        sys.exit(BCF_OUTPUT_MESSAGE)  # known before any phasing is done
+    snvs, svs, kids = _route_variants(reader(args.dnms), bam_names, args.reference)
+    crams = sorted({v["bam"] for v in snvs + svs if v["bam"].endswith("cram")})
+    if crams:
+        # the reference reads CRAM through pysam/htslib; this build decodes BAM only -- say so before any work
+        sys.exit("CRAM input is not decoded by this build (BAM only): convert %s with `samtools view -b`" % crams[0])
     pedigrees = parse_ped(args.ped, kids)
-    kids = list(pedigrees.keys())
-    snvs = [v for v in snvs if v["kid"] in kids]
-    svs = [v for v in svs if v["kid"] in kids]
-    phased_svs, phased_snvs = {}, {}
-    if (len(snvs) + len(svs)) == 0:
+    kids = list(pedigrees)
+    snvs = [v for v in snvs if v["kid"] in pedigrees]
+    svs = [v for v in svs if v["kid"] in pedigrees]
+    if not snvs and not svs:
         sys.exit("No phaseable variants")
-    common = (args.threads, args.build, args.no_extended, args.multiread_proc_min, args.quiet, args.ab_homref,
-              args.ab_homalt, args.ab_het, args.min_gt_qual, args.min_depth, args.search_dist,
-              args.insert_size_max_sample, args.stdevs, args.min_map_qual, args.readlen, args.split_error_margin)
-    if len(svs) > 0:
-        phased_svs = phase_svs(svs, kids, pedigrees, args.sites, *common, evidence_min_ratio=args.evidence_min_ratio,
+    thresholds = (args.threads, args.build, args.no_extended, args.multiread_proc_min, args.quiet, args.ab_homref,
+                  args.ab_homalt, args.ab_het, args.min_gt_qual, args.min_depth, args.search_dist,
+                  args.insert_size_max_sample, args.stdevs, args.min_map_qual, args.readlen, args.split_error_margin)
+    # SVs first, as the reference does (:601-646): the order of the per-variant messages on stderr is part of
+    # the surface; on a key collision the SV record wins (its final merge, :648-649)
+    sv_records, snv_records = {}, {}
+    if svs:
+        sv_records = phase_svs(svs, kids, pedigrees, args.sites, *thresholds, evidence_min_ratio=args.evidence_min_ratio,
                                allele_balance_only=getattr(args, "sv_allele_balance_only", False))
-    if len(snvs) > 0:
-        phased_snvs = phase_snvs(snvs, kids, pedigrees, args.sites, *common, evidence_min_ratio=args.evidence_min_ratio)
-    all_phased = phased_snvs
-    all_phased.update(phased_svs)
+    if snvs:
+        snv_records = phase_snvs(snvs, kids, pedigrees, args.sites, *thresholds, evidence_min_ratio=args.evidence_min_ratio)
+    records = dict(snv_records)
+    records.update(sv_records)
     if output_type == "vcf":
-        write_vcf_output(args.dnms, all_phased, args.include_ambiguous, args.verbose, args.outfile, args.evidence_min_ratio)
-    elif output_type == "bed":
-        write_bed_output(all_phased, args.include_ambiguous, args.verbose, args.outfile, args.evidence_min_ratio)
+        write_vcf_output(args.dnms, records, args.include_ambiguous, args.verbose, args.outfile, args.evidence_min_ratio)
+    else:
+        write_bed_output(records, args.include_ambiguous, args.verbose, args.outfile, args.evidence_min_ratio)
