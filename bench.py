@@ -1,29 +1,35 @@
 #!/usr/bin/env python
 """bench.py -- phased DNMs/s of the per-DNM phasing path on MI355X (BASELINE.json metric).
 
-One "step" = one whole pass of the hot path over one batch of synthetic DNMs with every
-input column already resident in HBM: K1 site scan over the whole sites table, K2 window
-emit, K3a per-record QC, the per-DNM collect / chain / join / vote kernel, and the copy of
-the per-DNM results (status, 4 counts, origin, evidence) back to the host.
+Metric 1: input DNMs / wall time of { H2D of the pre-decoded SoA, K1-K5, D2H, decision }.
+One "step" is one whole pass of the hot path over one batch of synthetic DNMs, and `value` is measured with the
+staging INSIDE the timed region:
+    sites + genotype columns: pinned host -> HBM, K1 site scan, K2 window emit, het lists back to the host
+    (they tell the decoder which fetches the read stage makes), then per chunk of DNMs: the alignment records those
+    fetches can return, in the staged (packed) form, pinned host -> HBM on the copy stream while the previous
+    chunk's K3a + per-DNM kernel run on the compute stream; per-DNM results back to the host.
+What is NOT timed is decode: producing the pinned columns (here: the synthetic generator + the host-side
+fetch-reach selection of libunfazed_io), reported as `decode_s`.  `value_resident` is the same pass with every
+input already in HBM (kernel-pass throughput; the round-1 headline).
 
-Workload (BASELINE.json configs[2]): N synthetic SNV/INDEL DNMs
-(90/10) of one trio, whole-genome-like sites table (default 20 M sites, 24 contigs), 30x
-paired-end pile-up within +-6 kb of every DNM, extended read-backed phasing on.  The data
-are generated in place in HBM by synth/uzsynth_hip.hip (no host copy of the read table).
+Workload (BASELINE.json configs[2]): N synthetic SNV/INDEL DNMs (90/10) of one trio placed
+UNIFORMLY over a whole-genome-like sites table (default 20 M sites, 24 contigs) -- about a third of the +-6 kb read
+windows overlap a neighbour's and share its records -- 30x paired-end pile-up, extended read-backed phasing on.
 
-Multi-GPU: DNMs shard embarrassingly, one process per GPU, no collective on the data path;
-every rank phases its own batch (weak scaling); the only communication is the barrier and
-the max-over-ranks of the elapsed time.
+Multi-GPU: DNMs shard embarrassingly, one process per GPU, no collective on the data path; the only
+communication is the barrier and the max-over-ranks of the elapsed time.  `--scaling weak` (default): every rank
+phases its own N DNMs; `--scaling strong` (config 4): the SAME N DNMs cut into contiguous shards.
+`python bench.py --gpus N` without a launcher starts the N ranks itself.
 
-Extra objects on the JSON line: `roofline` for the K1 site-scan kernel (HBM-bound;
-algorithmic bytes = 20 B/site: 19 read + 1 written) measured with HIP events on
-the library's stream, and `cpu_baseline`: the CPU oracle (a C port of the reference's
-algorithm, oracle/) timed on this box's host cores on a bounded sample of the same DNMs,
-whose results are also compared with the GPU's (parity at bench scale).
+Extra objects on the JSON line: `roofline` for the K1 site-scan kernel (HBM-bound; algorithmic bytes = 20 B/site),
+`roofline_k3a` for the QC pass, `link` (achieved host-link GB/s of the staged pass), and `cpu_baseline`: the CPU
+oracle (a C port of the reference's algorithm, oracle/) timed on this box's host cores on a bounded sample of the
+same DNMs, whose results are also compared with the GPU's (parity at bench scale).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import threading
 import time
@@ -40,19 +46,53 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dnms", type=int, default=int(os.environ.get("UZ_BENCH_DNMS", 100000)), help="DNMs per GPU")
+    ap.add_argument("--dnms", type=int, default=int(os.environ.get("UZ_BENCH_DNMS", 100000)),
+                    help="DNMs per GPU (weak scaling) / in total (strong scaling)")
     ap.add_argument("--sites", type=int, default=int(os.environ.get("UZ_BENCH_SITES", 20000000)))
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--chunks", type=int, default=8, help="DNM chunks of the staged pass (uploads overlap the kernels)")
     ap.add_argument("--cpu-dnms", type=int, default=12000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-staged", action="store_true", help="resident pass only (profiling runs)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as children BEFORE anything touches the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
+
+
+def pinned_copy(pool, a):
+    a = np.ascontiguousarray(a)
+    out = pool.alloc(max(64, a.nbytes))[: a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
 
 
 def main():
     args = parse()
-    import torch
+    world = int(os.environ.get("WORLD_SIZE", 0))
+    if world == 0:
+        if args.gpus > 1:
+            spawn_ranks(args)
+        world = 1
+    elif world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X GPU: there is no CPU fallback for the phasing path")
     torch.cuda.set_device(local_rank)
@@ -60,21 +100,35 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from synth import bigsynth
-    from synth.sites_np import make_sites, place_dnms_full
-    from unfazed_amd import abi, build
+    from synth.sites_np import make_clusters, make_sites, place_dnms_full
+    from unfazed_amd import abi, build, io_native, shard
     from unfazed_amd.engine import (HipEngine, K_PHASE, K_SEG_QC, K_SEG_QC_PASS, K_SITE_SCAN, K_SIZING, K_WINDOW_COUNT,
-                                    K_WINDOW_FILL)
+                                    K_WINDOW_FILL, PinnedPool)
+    from unfazed_amd.hostpath import concordant_cutoff
+    from unfazed_amd.staging import fetch_points
 
     build.build()
+    build.build_io()
     t_gen = time.time()
     sc = make_sites(args.sites, seed=202)
-    dn = place_dnms_full(sc, args.dnms, seed=201 + 1000 * rank)
-    cfg = bigsynth.make_cfg(seed=203 + 1000 * rank, n_pairs=1200, half_width=6000, n_dnms=dn.n)
-    wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, device=local_rank)
+    if args.scaling == "strong":
+        # config 4: the same DNM list on every rank, cut into contiguous shards (sites replicated per GPU)
+        allv = place_dnms_full(sc, args.dnms, seed=201)
+        b = shard.shard_bounds(allv.n, world)
+        lo, hi = b[rank], b[rank + 1]
+        from synth.sites_np import DnmColumns
+        dn = DnmColumns(allv.site_idx[lo:hi], allv.contig[lo:hi], allv.start[lo:hi], allv.end[lo:hi], allv.kind[lo:hi],
+                        allv.length[lo:hi], allv.origin[lo:hi], allv.refs[lo:hi], allv.alts[lo:hi])
+        read_seed = 203
+    else:
+        dn = place_dnms_full(sc, args.dnms, seed=201 + 1000 * rank)
+        read_seed = 203 + 1000 * rank
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=read_seed)
+    wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, cl, device=local_rank)
     t_gen = time.time() - t_gen
 
     eng = HipEngine(local_rank)
@@ -84,15 +138,10 @@ def main():
     fid = eng.adopt_family(sid, wl.family_view())
     rid = eng.adopt_reads(wl.reads_view())
     # concordant insert cutoff: host scalar per kid (read_collector.py:11-25) from the first records
-    head = wl.dev.get(wl.out_ptrs["tlen"], (min(wl.n_segs, 1000001),), np.int32)
-    from unfazed_amd.hostpath import concordant_cutoff
-    cutoff = concordant_cutoff(head, P.readlen, 3)
+    cutoff = concordant_cutoff(wl.tlen_head(), P.readlen, 3)
     n = dn.n
+    mode = abi.FIND_SECOND_WINDOW
     dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
-
-    def step():
-        eng.drop_derived()
-        return eng.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
 
     def barrier():
         if dist is not None:
@@ -100,33 +149,115 @@ def main():
         torch.cuda.synchronize()
         eng.sync()
 
-    for _ in range(args.warmup):
-        res = step()
-    eng.prof_enable(True)
-    eng.prof_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING)}
-    qc_records = eng.prof_units(K_SEG_QC_PASS)
-    eng.prof_enable(False)
+    def timed(step):
+        for _ in range(args.warmup):
+            res = step()
+        eng.prof_enable(True)
+        eng.prof_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING)}
+        units = eng.prof_units(K_SEG_QC_PASS)
+        eng.prof_enable(False)
+        return res, elapsed, prof, units
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * n * args.steps / elapsed
+    # ---------------------------------------------------------------- resident pass
+    def step_resident():
+        eng.drop_derived()
+        return eng.phase_raw(fid, rid, dv, P, mode)
+
+    res_r, el_r, prof_r, qc_records = timed(step_resident)
+
+    # ---------------------------------------------------------------- staged pass
+    staged = None
+    if not args.no_staged:
+        t_dec = time.time()
+        pool = PinnedPool()
+        # what the decoders would leave in pinned memory: sites / genotype columns ...
+        hs = {k: pinned_copy(pool, getattr(sc, k)) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
+        hs["contig_off"] = pinned_copy(pool, np.ascontiguousarray(sc.contig_off, np.int64))
+        hg = {k: [pinned_copy(pool, getattr(sc, k)[m]) for m in range(3)] for k in ("rd", "ad", "gq")}
+        sv = abi.SitesView()
+        sv.n_sites, sv.n_contigs = sc.n, len(sc.contig_off) - 1
+        for k in ("contig_off", "pos", "sflags", "ref_base", "alt_base"):
+            setattr(sv, k, hs[k].ctypes.data)
+        sites_h = abi.Held(sv, hs)
+        # ... and, per chunk of DNMs (whole clusters), the records the chunk's fetches return + their mates
+        co, ci, cf, ho, hi = eng.find(fid, dv, P, mode)
+        nchunk = max(1, min(args.chunks, cl.n))
+        cuts = [cl.n * k // nchunk for k in range(nchunk + 1)]
+        chunks, staged_bytes, staged_records = [], 0, 0
+        for k in range(nchunk):
+            c0, c1 = cuts[k], cuts[k + 1]
+            a, b = int(cl.d0[c0]), int(cl.d0[c1 - 1] + cl.nd[c1 - 1])
+            part_full = wl.download(c0, c1)
+            src = io_native.ReadsSource(part_full)
+            fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
+            part = src.select(fc, flo, fhi, alloc=pool.alloc)
+            del src, part_full
+            dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
+                                dn.refs[a:b], dn.alts[a:b], cutoff)
+            chunks.append((a, b, part, dvc))
+            staged_records += int(part.view.n_segs)
+            staged_bytes += int(part.view.n_segs) * 28 + int(part.view.n_cigar_total) * 4 + int(part.view.n_row_units) * 20
+        site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
+        t_dec = time.time() - t_dec
+
+        def step_staged():
+            s2 = eng.upload_sites_view(sites_h)
+            f2 = eng.add_family(s2, hs["gt"], hg["rd"], hg["ad"], hg["gq"])
+            eng.find(f2, dv, P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
+            rids = [eng.upload_reads_packed(part) for (_, _, part, _) in chunks]  # queued behind one another on the copy stream
+            out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32),
+                       evidence=np.empty(n, np.int32))
+            for (a, b, _, dvc), r in zip(chunks, rids):
+                rr = eng.phase_raw(f2, r, dvc, P, mode)
+                for key in out:
+                    out[key][a:b] = rr[key]
+            for r in rids:
+                eng.free_reads(r)
+            eng.free_sites(s2)
+            return out
+
+        res_s, el_s, prof_s, _ = timed(step_staged)
+        mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in ("status", "counts", "origin", "evidence"))
+        staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records,
+                      decode_s=t_dec, mismatches_vs_resident=mism, chunks=nchunk)
+        res = res_s
+    else:
+        res = res_r
+
+    n_total = n * world if args.scaling == "weak" else sum(np.diff(shard.shard_bounds(args.dnms, world)))
+    value_resident = n_total * args.steps / el_r
+    ms_resident = el_r / args.steps * 1e3
+    if staged:
+        value = n_total * args.steps / staged["elapsed"]
+        ms_per_step = staged["elapsed"] / args.steps * 1e3
+    else:
+        value, ms_per_step = value_resident, ms_resident
     status = res["status"]
-    phased = int(((status == abi.ST_OK) & ((res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM))).sum())
-    truth = np.where(dn.origin == 0, abi.OR_DAD, abi.OR_MOM)
     called = (status == abi.ST_OK) & ((res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM))
+    phased = int(called.sum())
+    truth = np.where(dn.origin == 0, abi.OR_DAD, abi.OR_MOM)
     correct = int((res["origin"][called] == truth[called]).sum())
 
-    k1_ms, k1_n = prof[K_SITE_SCAN]
+    def kern_ms(prof):
+        return {"site_scan": round(prof[K_SITE_SCAN][0] / args.steps, 3),
+                "window_count+scan": round(prof[K_WINDOW_COUNT][0] / args.steps, 3),
+                "window_fill": round(prof[K_WINDOW_FILL][0] / args.steps, 3),
+                "sizing": round(prof[K_SIZING][0] / args.steps, 3),
+                "seg_qc": round(prof[K_SEG_QC][0] / args.steps, 3),
+                "phase": round(prof[K_PHASE][0] / args.steps, 3)}
+
+    k1_ms, k1_n = prof_r[K_SITE_SCAN]
     k1_us = k1_ms / max(1, k1_n) * 1e3
     bytes_per_site = 20.0  # 19 B read (packed trio GT + 9 x u16) + 1 B class written; DESIGN.md "K1"
     achieved = bytes_per_site * sc.n / (k1_us * 1e-6) / 1e9 if k1_n else 0.0
@@ -143,74 +274,74 @@ def main():
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
                 "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n)}
 
-    # The kernel that moves the most bytes per step is K3a's quality pass, not K1: per examined record it
-    # reads the quality row (readlen B) + 20 B of fixed fields and list id + one CIGAR word, writes 1 B.
-    qc_ms, qc_n = prof[K_SEG_QC_PASS]
+    # K3a per examined record: two 16-byte headers + the flag word + the first CIGAR word + the quality plane
+    # (4 B per 32 bases) read, 1 B written
+    qc_ms, qc_n = prof_r[K_SEG_QC_PASS]
     qc_us = qc_ms / max(1, qc_n) * 1e3
-    qc_bytes = qc_records * (int(P.readlen) + 25.0)
+    qc_bytes = qc_records * (16 + 16 + 4 + 4 + 4.0 * ((int(P.readlen) + 31) // 32) + 1)
+    k3a_traffic = None
+    tpath = os.path.join(ROOT, "profiles", "k3a_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if int(tj.get("records_examined", -1)) == int(qc_records):
+                k3a_traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            k3a_traffic = None
     roofline_k3a = {"bound": "hbm", "kernel": "k_seg_qc", "achieved": round(qc_bytes / (qc_us * 1e-6) / 1e9, 1) if qc_n else 0.0,
                     "peak": 8000.0, "unit": "GB/s", "frac": round(qc_bytes / (qc_us * 1e-6) / 1e9 / 8000.0, 4) if qc_n else 0.0,
-                    "traffic": None, "avg_launch_us": round(qc_us, 1), "records_examined": int(qc_records),
+                    "traffic": k3a_traffic, "avg_launch_us": round(qc_us, 1), "records_examined": int(qc_records),
                     "algorithmic_bytes_per_launch": int(qc_bytes)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
-        cpu = cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, res)
+        cpu = cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, res)
 
     if rank == 0:
         out = {
             "metric": "phased DNMs/sec", "value": round(value, 1), "unit": "DNMs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32 (+f64 allele balance)",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int32 (+f64 allele balance)",
             "data": "synthetic",
-            "config": {"workload": "100k synthetic SNV/INDEL DNMs, whole-genome sites VCF, --no-extended off (BASELINE configs[2])"
-                       if n == 100000 else "%d synthetic SNV/INDEL DNMs per GPU, extended on" % n,
-                       "dnms_per_gpu": n, "sites": sc.n, "coverage": "30x", "search_dist": 5000, "pairs_per_dnm": cfg.n_pairs,
+            "config": {"workload": ("100k synthetic SNV/INDEL DNMs, whole-genome sites VCF, --no-extended off (BASELINE configs[2])"
+                                    if args.dnms == 100000 else "%d synthetic SNV/INDEL DNMs, extended on" % args.dnms)
+                       + ("; staged: H2D of the pre-decoded columns inside the timed region" if staged else "; inputs resident in HBM"),
+                       "dnms_per_gpu": n, "sites": sc.n, "coverage": "30x", "search_dist": 5000, "dnm_placement": "uniform",
+                       "read_clusters": cl.n, "dnms_sharing_a_cluster": int(cl.nd[cl.nd > 1].sum()),
                        "alignment_records": wl.n_segs, "parallelism": "dnm-shard x%d, no collective" % world},
+            "value_resident": round(value_resident, 1), "ms_per_step_resident": round(ms_resident, 3),
             "roofline": roofline,
             "roofline_k3a": roofline_k3a,
             "cpu_baseline": cpu,
-            "kernels_ms_per_step": {
-                "site_scan": round(prof[K_SITE_SCAN][0] / args.steps, 3),
-                "window_count+scan": round(prof[K_WINDOW_COUNT][0] / args.steps, 3),
-                "window_fill": round(prof[K_WINDOW_FILL][0] / args.steps, 3),
-                "sizing": round(prof[K_SIZING][0] / args.steps, 3),
-                "seg_qc": round(prof[K_SEG_QC][0] / args.steps, 3),
-                "phase": round(prof[K_PHASE][0] / args.steps, 3),
-            },
-            "calls": {"phased": phased, "correct_vs_truth": correct,
-                      "status_counts": np.bincount(status, minlength=6).tolist()},
+            "kernels_ms_per_step": kern_ms(prof_r),
+            "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist()},
             "generate_s": round(t_gen, 1),
         }
+        if staged:
+            out["link"] = {"bytes_per_step": int(staged["bytes"]), "read_records_staged": int(staged["records"]),
+                           "bytes_per_dnm": round(staged["bytes"] / n, 1),
+                           "achieved_GBps": round(staged["bytes"] * args.steps / staged["elapsed"] / 1e9, 2), "peak_GBps": 64.0,
+                           "chunks": staged["chunks"], "decode_s": round(staged["decode_s"], 1),
+                           "result_mismatches_vs_resident": staged["mismatches_vs_resident"]}
+            out["kernels_ms_per_step_staged"] = kern_ms(staged["prof"])
         print(json.dumps(out))
     wl.free()
     if dist is not None:
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, gpu_res):
-    """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first
-    `cpu_dnms` DNMs of the GPU's batch (their read blocks are copied back from HBM), 1, 2 and all
-    cores (threads over DNM ranges, as the reference's thread pool over DNMs); its results are
-    compared with the GPU's."""
+def cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, gpu_res):
+    """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first `cpu_dnms` DNMs of the
+    GPU's batch (whole clusters; their records regenerated on the host by the gcc build of the generator), 1, 2 and
+    more threads over DNM ranges, as the reference's thread pool over DNMs; its results are compared with the GPU's."""
     from oracle import oracle as orc
     from synth import bigsynth
     from unfazed_amd import abi
-    m = min(args.cpu_dnms, dn.n)
-    cols = wl.download_block(0, m)
-    nseg = 2 * cfg.n_pairs
+    ncpu = os.cpu_count() or 1
+    c_hi = cl.of_dnm(min(args.cpu_dnms, dn.n) - 1) + 1
+    m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1])
+    rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, c_hi, threads=min(ncpu, 128))
     nc = len(sc.contig_off) - 1
-    cols["contig_off"] = bigsynth._reads_contig_off(dn.contig, 0, m, nc, nseg)
-    cols["max_span"] = np.full(nc, bigsynth.READLEN + 12, dtype=np.int32)
-    rv = abi.ReadsView()
-    rv.n_segs = m * nseg
-    rv.n_contigs = nc
-    for k, a in cols.items():
-        setattr(rv, k, a.ctypes.data)
-    rv.n_cigar_total = m * nseg * bigsynth.MAXOPS
-    rv.n_sq_bytes = m * nseg * bigsynth.ROW
-    rv.n_qnames = m * cfg.n_pairs
-    rh = abi.Held(rv, cols)
     sv = abi.SitesView()
     keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags,
                 ref_base=sc.ref_base, alt_base=sc.alt_base)
@@ -249,7 +380,6 @@ def cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, gpu_res):
             st[a:b], cnt[a:b], org[a:b], ev[a:b] = p["status"][a:b], p["counts"][a:b], p["origin"][a:b], p["evidence"][a:b]
         return dt, dict(status=st, counts=cnt, origin=org, evidence=ev)
 
-    ncpu = os.cpu_count() or 1
     dt1, r1 = run(1)
     dt2, _ = run(2)
     # the port does not scale to every hardware thread (allocator / page-fault contention between
@@ -267,11 +397,10 @@ def cpu_baseline(args, wl, sc, dn, cfg, P, cutoff, gpu_res):
     dtc, rc, cores = best
     mism = 0
     for k in ("status", "counts", "origin", "evidence"):
-        mism += int(np.any(np.asarray(gpu_res[k][:m]) != r1[k], axis=None if r1[k].ndim == 1 else 1).sum()) if r1[k].ndim > 1 \
-            else int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
+        mism += int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
         mism += int((rc[k] != r1[k]).sum())
     return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",
-            "sample": "first %d DNMs of the GPU batch (read blocks copied back from HBM), oracle find+phase, threads over DNM ranges (best of a ladder of thread counts: %d)"
+            "sample": "first %d DNMs of the GPU batch (whole read clusters, regenerated on the host), oracle find+phase, threads over DNM ranges (best of a ladder of thread counts: %d)"
                       % (m, cores),
             "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
             "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},

@@ -95,6 +95,34 @@ const char *uz_vcf_info(const uz_vcf *h, int64_t i, const char *key, int32_t *le
 /* 1 when the file was BCF (no text lines: uz_vcf_line is empty) */
 int uz_vcf_is_bcf(const uz_vcf *h);
 
+/* ------------------------------------------------------------------ staged (packed) records
+ * uz_reads_packed_view (uz_types.h) is what crosses the host link.  The caller owns the output buffers (pinned
+ * memory from uz_pinned_alloc for the upload): the `out` view arrives with every pointer set to a WRITABLE
+ * buffer of the right size -- [n] for the per-record columns, n_cigar_total words, n_row_units * 16 / * 4 bytes
+ * for seq4 / qlow, [n_contigs + 1] / [n_contigs] for the contig tables -- and the scalar fields are filled in. */
+/* sizes of the packed form of an ASCII table */
+int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t *n_row_units);
+/* ASCII table -> packed columns for the base-quality threshold `min_base_qual` (= --min-gt-qual);
+ * out->n_cigar_total / n_row_units must hold the sizes the buffers were made for */
+int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_reads_packed_view *out);
+
+/* Fetch-reach selection: the records `bamfile.fetch(contig, lo, hi)` returns for a list of fetches (start <
+ * hi and end > lo: read_collector.py:385, :167) plus the records `bamfile.mate()` returns for them (:400,
+ * :185) -- everything of an alignment file the reference can ever look at for those fetches.  Record order and
+ * query-name ids are kept, mate links are renumbered, max_span is recomputed. */
+typedef struct uz_psrc uz_psrc;     /* a packed table opened as the source of selections (host pointers, borrowed) */
+typedef struct uz_select uz_select; /* one selection */
+int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc **out);
+void uz_reads_source_close(uz_psrc *src);
+int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int threads,
+                         uz_select **out);
+int64_t uz_select_n_records(const uz_select *s);
+int64_t uz_select_n_cigar_total(const uz_select *s);
+int64_t uz_select_n_row_units(const uz_select *s);
+/* orig_index (optional, [n_records]): index of every kept record in the source table */
+int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *out, int32_t *orig_index);
+void uz_select_free(uz_select *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,50 @@ typedef struct uz_reads_view {
     uint32_t reserved1;
 } uz_reads_view;
 
+/* ---- packed alignment records: the STAGED ("pre-decoded") form, and the only form kept in HBM -------------
+ *
+ * What crosses the host link per record is what the path can ever look at:
+ *   - bases stay in BAM's own 4-bit codes ("=ACMGRSVTWYHKDBN", high nibble first): the decoder does not expand
+ *     them, and every use is an equality test against a REF / ALT character (read_collector.py:56-73, :98-141,
+ *     snv_phaser.py:28-44);
+ *   - base qualities are reduced to the one comparison the reference ever makes with them, `qual <
+ *     MIN_BASE_QUAL` (= --min-gt-qual: goodread read_collector.py:43-46, connect_reads :123,
+ *     indel_match_alleles :281-284): one bit per base, built by the decoder for the threshold of the run;
+ *   - CIGAR words and rows lie back to back in record order, so their offsets are prefix sums the device
+ *     computes itself (no offset columns on the link).
+ * 132 bytes per 151-base record instead of 370 for the ASCII form (uz_reads_view).
+ * Row geometry: a record of l_seq bases owns UZ_ROW_UNITS(l_seq) units of 32 bases = 16 bytes of seq4 and
+ * 4 bytes of qlow per unit; bits / nibbles beyond l_seq are zero.  A record without SEQ / QUAL / CIGAR
+ * (UZ_AUX_DECODE_BAD) has l_seq = 0 and n_cigar = 0. */
+#define UZ_ROW_UNITS(l_seq) (((uint32_t)(l_seq) + 31u) >> 5)
+#define UZ_SEQ4_UNIT_BYTES 16
+#define UZ_QLOW_UNIT_BYTES 4
+
+typedef struct uz_reads_packed_view {
+    int64_t n_segs; /* < 2^31 */
+    int32_t n_contigs;
+    int32_t min_base_qual;     /* threshold qlow was built with; uz_phase refuses a different --min-gt-qual */
+    const int64_t *contig_off; /* [n_contigs+1] */
+    const int32_t *max_span;   /* [n_contigs] */
+    const int32_t *start;
+    const int32_t *end;
+    const int32_t *tlen;
+    const int32_t *mate;
+    const uint32_t *qname;
+    const uint16_t *flag;
+    const uint16_t *l_seq;
+    const uint16_t *n_cigar;
+    const uint8_t *mapq;
+    const uint8_t *aux;
+    const uint32_t *cigar; /* [n_cigar_total] record i owns the next n_cigar[i] words */
+    const uint8_t *seq4;   /* [n_row_units * 16] base k of a row: byte k>>1, high nibble when k is even */
+    const uint8_t *qlow;   /* [n_row_units * 4]  base k of a row: bit k&7 of byte k>>3, set iff qual[k] < min_base_qual */
+    int64_t n_cigar_total; /* = sum n_cigar, < 2^32 */
+    int64_t n_row_units;   /* = sum UZ_ROW_UNITS(l_seq), < 2^32 */
+    uint32_t n_qnames;
+    uint32_t reserved1;
+} uz_reads_packed_view;
+
 /* one batch of DNMs of one kid (one family, one BAM) */
 typedef struct uz_dnms_view {
     int32_t n;

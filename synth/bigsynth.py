@@ -1,22 +1,25 @@
-"""Python side of the benchmark-scale generator (synth/uzsynth.h): builds the two
-generator libraries and exposes
-  * reads_cpu(...)  -> numpy columns of the read blocks of a DNM range (for the oracle)
-  * ReadsOnGpu(...) -> the same columns generated in place in HBM (device pointers)
+"""Python side of the benchmark-scale generator (synth/uzsynth.h): builds the two generator libraries and exposes
+  * reads_cpu(...)     -> the ASCII columns (uz_reads_view) of a cluster range, generated on the host (for the oracle)
+  * WorkloadOnGpu(...) -> sites, family and the whole reads table generated in place in HBM in the staged format
+                          (uz_reads_packed_view; device pointers)
 Test / bench infrastructure only."""
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
 from unfazed_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-READLEN, ROW, MAXOPS = 151, 160, 3
+READLEN, ROW, MAXOPS, UNITS, MAXSEG = 151, 160, 3, 5, 16384
+HALF_WIDTH = 6000
 
 
 def _build(target, cmd):
     deps = [os.path.join(_HERE, "uzsynth.h")] + [c for c in cmd if c.endswith((".c", ".hip"))]
+
     def stale():
         return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(d) for d in deps)
     if stale():
@@ -41,8 +44,7 @@ def build_hip():
 
 
 class Cfg(C.Structure):
-    _fields_ = [("seed", C.c_uint64), ("n_pairs", C.c_int32), ("half_width", C.c_int32), ("n_dnms", C.c_int32),
-                ("reserved", C.c_int32)]
+    _fields_ = [("seed", C.c_uint64), ("n_clusters", C.c_int32), ("min_base_qual", C.c_int32)]
 
 
 class SitesS(C.Structure):
@@ -51,68 +53,125 @@ class SitesS(C.Structure):
 
 
 class DnmsS(C.Structure):
-    _fields_ = [("contig", C.c_void_p), ("pos", C.c_void_p), ("site_idx", C.c_void_p), ("kind", C.c_void_p),
-                ("len", C.c_void_p), ("origin", C.c_void_p)]
+    _fields_ = [("pos", C.c_void_p), ("site_idx", C.c_void_p), ("kind", C.c_void_p), ("len", C.c_void_p), ("origin", C.c_void_p)]
 
 
-OUT_COLS = [("start", np.int32, 1), ("end", np.int32, 1), ("flag", np.uint16, 1), ("mapq", np.uint8, 1),
-            ("aux", np.uint8, 1), ("tlen", np.int32, 1), ("qname", np.uint32, 1), ("mate", np.int32, 1),
-            ("cigar_off", np.uint32, 1), ("n_cigar", np.uint16, 1), ("cigar", np.uint32, MAXOPS),
-            ("l_seq", np.uint16, 1), ("sq_off16", np.uint32, 1), ("seq", np.uint8, ROW), ("qual", np.uint8, ROW)]
+class ClustersS(C.Structure):
+    _fields_ = [("contig", C.c_void_p), ("lo", C.c_void_p), ("hi", C.c_void_p), ("d0", C.c_void_p), ("nd", C.c_void_p),
+                ("pair_off", C.c_void_p), ("cigar_off", C.c_void_p)]
 
 
-class OutS(C.Structure):
-    _fields_ = [(name, C.c_void_p) for name, _, _ in OUT_COLS]
+# packed output (GPU): per-record columns, then cigar / seq4 / qlow
+PACKED_COLS = abi.PACKED_RECORD_COLS
 
 
-def make_cfg(seed=203, n_pairs=1200, half_width=6000, n_dnms=0):
+class OutPackedS(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("start", "end", "tlen", "mate", "qname", "flag", "l_seq", "n_cigar", "mapq", "aux",
+                                          "cigar", "seq4", "qlow")]
+
+
+ASCII_COLS = [("start", np.int32, 1), ("end", np.int32, 1), ("flag", np.uint16, 1), ("mapq", np.uint8, 1),
+              ("aux", np.uint8, 1), ("tlen", np.int32, 1), ("qname", np.uint32, 1), ("mate", np.int32, 1),
+              ("cigar_off", np.uint32, 1), ("n_cigar", np.uint16, 1), ("cigar", np.uint32, 0),
+              ("l_seq", np.uint16, 1), ("sq_off16", np.uint32, 1), ("seq", np.uint8, ROW), ("qual", np.uint8, ROW)]
+
+
+class OutAsciiS(C.Structure):
+    _fields_ = [(name, C.c_void_p) for name, _, _ in ASCII_COLS]
+
+
+def make_cfg(seed=203, n_clusters=0, min_base_qual=20):
     c = Cfg()
-    c.seed, c.n_pairs, c.half_width, c.n_dnms = seed, n_pairs, half_width, n_dnms
+    c.seed, c.n_clusters, c.min_base_qual = seed, n_clusters, min_base_qual
     return c
 
 
-def _reads_contig_off(dn_contig, d0, d1, n_contigs, nseg):
-    cnt = np.bincount(dn_contig[d0:d1], minlength=n_contigs).astype(np.int64)
+def reads_contig_off(cl, c0, c1, n_contigs):
+    """contig_off of the reads table made of clusters [c0, c1) (records relative to cluster c0)"""
+    recs = 2 * np.diff(cl.pair_off[c0: c1 + 1])
+    cnt = np.bincount(cl.contig[c0:c1], weights=recs, minlength=n_contigs).astype(np.int64)
     off = np.zeros(n_contigs + 1, dtype=np.int64)
-    off[1:] = np.cumsum(cnt) * nseg
+    off[1:] = np.cumsum(cnt)
     return off
 
 
-def reads_cpu(cfg, sc, dn, d0, d1):
-    """Generate the read blocks of DNMs [d0, d1) on the host.  Returns (abi.Held view, dict of arrays).
-    Record indices / qname ids are relative to d0."""
-    L = C.CDLL(build_cpu())
-    L.uzs_gen_reads_cpu.restype = C.c_int
-    nseg = 2 * cfg.n_pairs
-    n = (d1 - d0) * nseg
+def _host_structs(cfg, sc, dn, cl):
+    keep = []
+
+    def ptr(a, dt):
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data
     S = SitesS()
-    keep = [np.ascontiguousarray(sc.contig_off, np.int64), np.ascontiguousarray(sc.pos, np.int32),
-            np.ascontiguousarray(sc.ref_base), np.ascontiguousarray(sc.alt_base), np.ascontiguousarray(sc.khap)]
-    S.contig_off, S.pos, S.ref_base, S.alt_base, S.khap = [a.ctypes.data for a in keep]
+    S.contig_off, S.pos = ptr(sc.contig_off, np.int64), ptr(sc.pos, np.int32)
+    S.ref_base, S.alt_base, S.khap = ptr(sc.ref_base, np.uint8), ptr(sc.alt_base, np.uint8), ptr(sc.khap, np.uint8)
     S.n_contigs = len(sc.contig_off) - 1
     D = DnmsS()
-    dk = [np.ascontiguousarray(dn.contig, np.int32), np.ascontiguousarray(dn.start, np.int32),
-          np.ascontiguousarray(dn.site_idx, np.int32), np.ascontiguousarray(dn.kind, np.uint8),
-          np.ascontiguousarray(dn.length, np.uint8), np.ascontiguousarray(dn.origin, np.uint8)]
-    D.contig, D.pos, D.site_idx, D.kind, D.len, D.origin = [a.ctypes.data for a in dk]
-    O = OutS()
+    D.pos, D.site_idx = ptr(dn.start, np.int32), ptr(dn.site_idx, np.int32)
+    D.kind, D.len, D.origin = ptr(dn.kind, np.uint8), ptr(dn.length, np.uint8), ptr(dn.origin, np.uint8)
+    K = ClustersS()
+    K.contig, K.lo, K.hi = ptr(cl.contig, np.int32), ptr(cl.lo, np.int32), ptr(cl.hi, np.int32)
+    K.d0, K.nd, K.pair_off = ptr(cl.d0, np.int32), ptr(cl.nd, np.int32), ptr(cl.pair_off, np.int64)
+    K.cigar_off = 0
+    return S, D, K, keep
+
+
+def reads_cpu(cfg, sc, dn, cl, c0, c1, threads=1):
+    """Generate the record blocks of clusters [c0, c1) on the host in the ASCII form.  Returns (abi.Held view, dict of
+    arrays).  Record indices / qname ids / CIGAR offsets are relative to cluster c0."""
+    L = C.CDLL(build_cpu())
+    L.uzs_gen_reads_cpu.restype = C.c_int
+    L.uzs_count_ops_cpu.restype = C.c_int64
+    S, D, K, keep = _host_structs(cfg, sc, dn, cl)
+    n = int(2 * (cl.pair_off[c1] - cl.pair_off[c0]))
+    # slices of clusters, one worker each (ctypes releases the GIL)
+    threads = max(1, min(threads, c1 - c0))
+    cuts = [c0 + (c1 - c0) * k // threads for k in range(threads + 1)]
+    ops = [0] * threads
+
+    def count(k):
+        ops[k] = L.uzs_count_ops_cpu(C.byref(cfg), C.byref(K), C.byref(D), C.c_int32(cuts[k]), C.c_int32(cuts[k + 1]))
+    th = [threading.Thread(target=count, args=(k,)) for k in range(threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    n_ops = int(sum(ops))
     arrs = {}
-    for name, dt, w in OUT_COLS:
-        arrs[name] = np.zeros(max(1, n * w), dtype=dt)
-        setattr(O, name, arrs[name].ctypes.data)
-    rc = L.uzs_gen_reads_cpu(C.byref(cfg), C.byref(S), C.byref(D), C.c_int32(d0), C.c_int32(d1), C.byref(O))
-    assert rc == 0
+    for name, dt, w in ASCII_COLS:
+        arrs[name] = np.zeros(max(1, n * w if w else n_ops), dtype=dt)
+    rc = [0] * threads
+
+    def gen(k):
+        r0 = int(2 * (cl.pair_off[cuts[k]] - cl.pair_off[c0]))
+        g0 = int(sum(ops[:k]))
+        O = OutAsciiS()
+        for name, dt, w in ASCII_COLS:
+            off = (r0 * w if w else g0) * np.dtype(dt).itemsize
+            setattr(O, name, arrs[name].ctypes.data + off)
+        rc[k] = L.uzs_gen_reads_cpu(C.byref(cfg), C.byref(S), C.byref(D), C.byref(K), C.c_int32(cuts[k]), C.c_int32(cuts[k + 1]),
+                                    C.byref(O))
+    th = [threading.Thread(target=gen, args=(k,)) for k in range(threads)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(r == 0 for r in rc), rc
+    # the workers numbered records / pairs / CIGAR words from their own first cluster: shift to the range's
+    for k in range(1, threads):
+        r0 = int(2 * (cl.pair_off[cuts[k]] - cl.pair_off[c0]))
+        r1 = int(2 * (cl.pair_off[cuts[k + 1]] - cl.pair_off[c0]))
+        arrs["mate"][r0:r1] += r0
+        arrs["qname"][r0:r1] += r0 // 2
+        arrs["cigar_off"][r0:r1] += int(sum(ops[:k]))
+        arrs["sq_off16"][r0:r1] += r0 * (ROW // 16)
     nc = len(sc.contig_off) - 1
-    arrs["contig_off"] = _reads_contig_off(dn.contig, d0, d1, nc, nseg)
+    arrs["contig_off"] = reads_contig_off(cl, c0, c1, nc)
     arrs["max_span"] = np.full(nc, READLEN + 12, dtype=np.int32)
     v = abi.ReadsView()
     v.n_segs = n
     v.n_contigs = nc
     for name in list(arrs):
         setattr(v, name, arrs[name].ctypes.data)
-    v.n_cigar_total = n * MAXOPS
+    v.n_cigar_total = n_ops
     v.n_sq_bytes = n * ROW
-    v.n_qnames = (d1 - d0) * cfg.n_pairs
+    v.n_qnames = n // 2
     return abi.Held(v, arrs), arrs
 
 
@@ -149,6 +208,11 @@ class DeviceArrays:
             assert self.L.uzs_d2h(out.ctypes.data, ptr, out.nbytes) == 0
         return out
 
+    def get_into(self, out, ptr):
+        if out.nbytes:
+            assert self.L.uzs_d2h(out.ctypes.data, ptr, out.nbytes) == 0
+        return out
+
     def free_all(self):
         for p in self.ptrs:
             self.L.uzs_dev_free(p)
@@ -156,14 +220,17 @@ class DeviceArrays:
 
 
 class WorkloadOnGpu:
-    """Sites table + family columns + read blocks of all DNMs, resident in HBM."""
+    """Sites table + family columns + the reads table of all clusters, resident in HBM (staged format)."""
 
-    def __init__(self, cfg, sc, dn, device=0):
-        self.cfg, self.sc, self.dn = cfg, sc, dn
+    def __init__(self, cfg, sc, dn, cl, device=0):
+        self.cfg, self.sc, self.dn, self.cl = cfg, sc, dn, cl
+        cfg.n_clusters = cl.n
         dev = self.dev = DeviceArrays(device)
-        nseg = 2 * cfg.n_pairs
-        n = dn.n * nseg
+        n = int(2 * cl.pair_off[-1])
         self.n_segs = n
+        nseg = 2 * np.diff(cl.pair_off)
+        if nseg.max() > MAXSEG:
+            raise ValueError("a cluster holds %d records (> %d)" % (nseg.max(), MAXSEG))
         S = SitesS()
         self.d_contig_off = dev.put(np.ascontiguousarray(sc.contig_off, np.int64))
         self.d_pos = dev.put(np.ascontiguousarray(sc.pos, np.int32))
@@ -178,24 +245,50 @@ class WorkloadOnGpu:
         self.d_ad = [dev.put(sc.ad[m]) for m in range(3)]
         self.d_gq = [dev.put(sc.gq[m]) for m in range(3)]
         D = DnmsS()
-        D.contig = dev.put(np.ascontiguousarray(dn.contig, np.int32))
         D.pos = dev.put(np.ascontiguousarray(dn.start, np.int32))
         D.site_idx = dev.put(np.ascontiguousarray(dn.site_idx, np.int32))
-        D.kind = dev.put(dn.kind)
-        D.len = dev.put(dn.length)
-        D.origin = dev.put(dn.origin)
-        O = OutS()
+        D.kind, D.len, D.origin = dev.put(dn.kind), dev.put(dn.length), dev.put(dn.origin)
+        K = ClustersS()
+        K.contig, K.lo, K.hi = dev.put(cl.contig), dev.put(cl.lo), dev.put(cl.hi)
+        K.d0, K.nd, K.pair_off = dev.put(cl.d0), dev.put(cl.nd), dev.put(np.ascontiguousarray(cl.pair_off, np.int64))
+        # pass 1: CIGAR words per cluster -> offsets
+        d_ops = dev.alloc(8 * max(1, cl.n))
+        K.cigar_off = 0
+        dev.L.uzs_count_ops_hip.restype = C.c_int
+        dev.L.uzs_count_ops_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        if dev.L.uzs_count_ops_hip(C.byref(cfg), C.byref(K), C.byref(D), d_ops) != 0:
+            raise RuntimeError("uzs_count_ops_hip failed")
+        ops = dev.get(d_ops, (cl.n,), np.int64)
+        cigar_off = np.zeros(cl.n + 1, np.int64)
+        cigar_off[1:] = np.cumsum(ops)
+        self.n_cigar_total = int(cigar_off[-1])
+        self.n_row_units = n * UNITS
+        K.cigar_off = self._d_cigar_off = dev.put(cigar_off)
+        # pass 2: the records
+        O = OutPackedS()
         self.out_ptrs = {}
-        for name, dt, w in OUT_COLS:
-            self.out_ptrs[name] = dev.alloc(max(16, n * w * np.dtype(dt).itemsize))
+        for name, dt in PACKED_COLS:
+            self.out_ptrs[name] = dev.alloc(max(64, n * np.dtype(dt).itemsize + 64))
+        self.out_ptrs["cigar"] = dev.alloc(4 * self.n_cigar_total + 64)
+        self.out_ptrs["seq4"] = dev.alloc(16 * self.n_row_units + 64)
+        self.out_ptrs["qlow"] = dev.alloc(4 * self.n_row_units + 64)
+        for name in self.out_ptrs:
             setattr(O, name, self.out_ptrs[name])
+        small = np.nonzero(nseg <= 4096)[0].astype(np.int32)
+        big = np.nonzero(nseg > 4096)[0].astype(np.int32)
+        d_small, d_big = dev.put(small if small.size else np.zeros(1, np.int32)), dev.put(big if big.size else np.zeros(1, np.int32))
         dev.L.uzs_gen_reads_hip.restype = C.c_int
-        rc = dev.L.uzs_gen_reads_hip(C.byref(cfg), C.byref(S), C.byref(D), C.c_int32(0), C.c_int32(dn.n), C.byref(O))
+        dev.L.uzs_gen_reads_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                            C.c_int32, C.c_void_p]
+        rc = dev.L.uzs_gen_reads_hip(C.byref(cfg), C.byref(S), C.byref(D), C.byref(K), d_small, int(small.size), d_big, int(big.size),
+                                     C.byref(O))
         if rc != 0:
             raise RuntimeError("uzs_gen_reads_hip failed: %d" % rc)
         nc = len(sc.contig_off) - 1
-        self.d_rcontig_off = dev.put(_reads_contig_off(dn.contig, 0, dn.n, nc, nseg))
-        self.d_max_span = dev.put(np.full(nc, READLEN + 12, dtype=np.int32))
+        self.contig_off = reads_contig_off(cl, 0, cl.n, nc)
+        self.max_span = np.full(nc, READLEN + 12, dtype=np.int32)
+        self.d_rcontig_off = dev.put(self.contig_off)
+        self.d_max_span = dev.put(self.max_span)
 
     def sites_view(self):
         v = abi.SitesView()
@@ -211,26 +304,52 @@ class WorkloadOnGpu:
             v.ref_depth[m], v.alt_depth[m], v.gq[m] = self.d_rd[m], self.d_ad[m], self.d_gq[m]
         return v
 
-    def reads_view(self):
-        v = abi.ReadsView()
+    def _fill_view(self, v):
         v.n_segs = self.n_segs
         v.n_contigs = len(self.sc.contig_off) - 1
-        v.contig_off, v.max_span = self.d_rcontig_off, self.d_max_span
-        for name, _, _ in OUT_COLS:
-            setattr(v, name, self.out_ptrs[name])
-        v.n_cigar_total = self.n_segs * MAXOPS
-        v.n_sq_bytes = self.n_segs * ROW
-        v.n_qnames = self.dn.n * self.cfg.n_pairs
+        v.min_base_qual = self.cfg.min_base_qual
+        v.n_cigar_total, v.n_row_units = self.n_cigar_total, self.n_row_units
+        v.n_qnames = self.n_segs // 2
         return v
 
-    def download_block(self, d0, d1):
-        """Columns of DNM blocks [d0, d1) copied back to the host (tests: GPU vs CPU generator)."""
-        nseg = 2 * self.cfg.n_pairs
-        out = {}
-        for name, dt, w in OUT_COLS:
+    def reads_view(self):
+        """uz_reads_packed_view over the DEVICE columns (uz_reads_adopt_device)"""
+        v = self._fill_view(abi.ReadsPackedView())
+        v.contig_off, v.max_span = self.d_rcontig_off, self.d_max_span
+        for name in self.out_ptrs:
+            setattr(v, name, self.out_ptrs[name])
+        return v
+
+    def download(self, c0=0, c1=None, alloc=None):
+        """The records of clusters [c0, c1) copied back to the host as a self-contained packed view (abi.Held): record
+        numbers (mate links) are relative to the first record of c0, query-name ids stay global."""
+        cl = self.cl
+        c1 = cl.n if c1 is None else c1
+        nc = len(self.sc.contig_off) - 1
+        r0, r1 = int(2 * cl.pair_off[c0]), int(2 * cl.pair_off[c1])
+        if not hasattr(self, "_cigar_off_h"):
+            self._cigar_off_h = self.dev.get(self._d_cigar_off, (cl.n + 1,), np.int64)
+        g0, g1 = int(self._cigar_off_h[c0]), int(self._cigar_off_h[c1])
+        n = r1 - r0
+        h = abi.packed_view_alloc(n, nc, g1 - g0, n * UNITS, alloc)
+        v = h.view
+        v.min_base_qual = self.cfg.min_base_qual
+        v.n_qnames = self.n_segs // 2
+        h.arrays["contig_off"][:] = reads_contig_off(cl, c0, c1, nc)
+        h.arrays["max_span"][:] = self.max_span
+        for name, dt in PACKED_COLS:
             isz = np.dtype(dt).itemsize
-            out[name] = self.dev.get(self.out_ptrs[name] + d0 * nseg * w * isz, ((d1 - d0) * nseg * w,), dt)
-        return out
+            self.dev.get_into(h.arrays[name][:n], self.out_ptrs[name] + r0 * isz)
+        if g1 > g0:
+            self.dev.get_into(h.arrays["cigar"][: g1 - g0], self.out_ptrs["cigar"] + 4 * g0)
+        if n:
+            self.dev.get_into(h.arrays["seq4"][: 16 * n * UNITS], self.out_ptrs["seq4"] + 16 * r0 * UNITS)
+            self.dev.get_into(h.arrays["qlow"][: 4 * n * UNITS], self.out_ptrs["qlow"] + 4 * r0 * UNITS)
+            h.arrays["mate"][:n] -= r0
+        return h
+
+    def tlen_head(self, cap=1000001):
+        return self.dev.get(self.out_ptrs["tlen"], (min(self.n_segs, cap),), np.int32)
 
     def free(self):
         self.dev.free_all()

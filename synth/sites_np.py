@@ -114,22 +114,61 @@ class DnmColumns:
         return int(self.start.shape[0])
 
 
-def place_dnms_full(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1, min_gap=13500) -> DnmColumns:
-    """place_dnms plus the DNM kinds (90 % SNV, 10 % small INDEL),
-    the origin haplotype and the REF/ALT strings; checks that read windows cannot overlap."""
-    idx, contig, start, _ = place_dnms(sc, n_dnms, seed=seed, indel_frac=0.0)
-    rng = np.random.default_rng(seed + 7)
+def place_dnms_full(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1, half_width=6000, max_cluster_len=80000,
+                    uniform=True) -> DnmColumns:
+    """The DNM list of SURVEY.md 8(d) config 3: positions UNIFORM over the genome (so the +-search_dist windows of
+    neighbours overlap as often as they do for real DNMs), 90 % SNV / 10 % small INDEL, an origin haplotype and the
+    REF/ALT strings.  Every DNM sits on a record of the sites table which becomes the DNM's own record (kid het,
+    parents hom-ref).  A DNM that would stretch a chain of overlapping read windows beyond max_cluster_len is
+    re-drawn (the generator sorts one cluster's records in LDS)."""
+    rng = np.random.default_rng(seed)
+    S = sc.n
+    contig_of = (np.searchsorted(sc.contig_off, np.arange(S), side="right") - 1).astype(np.int32)
+    ok = sc.pos.astype(np.int64) - half_width - 64 > 0  # no read starts left of the contig
+    cand = np.nonzero(ok)[0]
+    if uniform:
+        idx = np.sort(rng.choice(cand, size=n_dnms, replace=False))
+    else:  # stratified (no overlapping windows when the table is sparse enough)
+        step = cand.size / n_dnms
+        idx = cand[np.minimum((np.arange(n_dnms) * step + rng.random(n_dnms) * step * 0.5).astype(np.int64), cand.size - 1)]
+    for _ in range(50):  # thin out chains of overlapping windows that would grow beyond max_cluster_len
+        pos = sc.pos[idx].astype(np.int64)
+        cg = contig_of[idx]
+        brk = np.ones(idx.size, bool)
+        brk[1:] = (cg[1:] != cg[:-1]) | (pos[1:] - half_width >= pos[:-1] + half_width)
+        cid = np.cumsum(brk) - 1
+        lo = np.minimum.reduceat(pos, np.nonzero(brk)[0]) - half_width
+        hi = np.maximum.reduceat(pos, np.nonzero(brk)[0]) + half_width
+        too_long = (hi - lo) > max_cluster_len
+        if not too_long.any():
+            break
+        # drop the last DNM of every over-long cluster and draw replacements elsewhere
+        last_of = np.zeros(idx.size, bool)
+        last_of[np.r_[np.nonzero(brk)[0][1:] - 1, idx.size - 1]] = True
+        drop = last_of & too_long[cid]
+        keep = idx[~drop]
+        pool = np.setdiff1d(cand, keep, assume_unique=False)
+        idx = np.sort(np.concatenate([keep, rng.choice(pool, size=int(drop.sum()), replace=False)]))
+    else:
+        raise ValueError("could not place %d DNMs with clusters <= %d bp" % (n_dnms, max_cluster_len))
     n = n_dnms
+    sc.gt[idx] = 1  # kid het, dad/mom hom-ref
+    sc.sflags[idx] = 0
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    sc.ref_base[idx] = bases[rng.integers(0, 4, n)]
+    sc.alt_base[idx] = bases[(np.searchsorted(bases, sc.ref_base[idx]) + 1) % 4]
+    for m in range(3):
+        sc.rd[m][idx] = 30 if m else 15
+        sc.ad[m][idx] = 0 if m else 15
+        sc.gq[m][idx] = 99
+    sc.khap[idx] = 0
+    contig = contig_of[idx].astype(np.int32)
+    start = sc.pos[idx].astype(np.int32)
     is_indel = rng.random(n) < indel_frac
     kind = np.where(is_indel, rng.integers(1, 3, n), 0).astype(np.uint8)
     length = np.where(is_indel, rng.integers(1, 11, n), 0).astype(np.uint8)
     origin = rng.integers(0, 2, n).astype(np.uint8)
     end = (start + 1 + np.where(kind == 2, length, 0)).astype(np.int32)
-    same = contig[1:] == contig[:-1]
-    gaps = (start[1:] - start[:-1])[same]
-    if gaps.size and gaps.min() < min_gap:
-        raise ValueError("synthetic DNMs closer than %d bp (%d): lower n_dnms or raise n_sites" % (min_gap, gaps.min()))
-    sc.khap[idx] = 0
     refs, alts = [], []
     for i in range(n):
         r = bytes([sc.ref_base[idx[i]]])
@@ -142,6 +181,40 @@ def place_dnms_full(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0
         refs.append(r)
         alts.append(a)
     return DnmColumns(idx.astype(np.int32), contig, start, end, kind, length, origin, refs, alts)
+
+
+@dataclass
+class Clusters:
+    """Merged read windows of neighbouring DNMs: one pile-up each (synth/uzsynth.h)."""
+    contig: np.ndarray  # int32
+    lo: np.ndarray  # int32 reads are laid out within [lo, hi)
+    hi: np.ndarray
+    d0: np.ndarray  # int32 DNMs [d0, d0 + nd)
+    nd: np.ndarray
+    pair_off: np.ndarray  # int64 [n+1]
+
+    @property
+    def n(self):
+        return int(self.lo.shape[0])
+
+    def of_dnm(self, d):
+        """cluster holding DNM d"""
+        return int(np.searchsorted(self.d0, d, side="right") - 1)
+
+
+def make_clusters(dn: DnmColumns, half_width=6000, pairs_per_bp=0.1) -> Clusters:
+    pos = dn.start.astype(np.int64)
+    brk = np.ones(dn.n, bool)
+    brk[1:] = (dn.contig[1:] != dn.contig[:-1]) | (pos[1:] - half_width >= pos[:-1] + half_width)
+    first = np.nonzero(brk)[0]
+    lo = np.minimum.reduceat(pos, first) - half_width
+    hi = np.maximum.reduceat(pos, first) + half_width
+    nd = np.diff(np.r_[first, dn.n])
+    per_hap = np.maximum(1, np.round((hi - lo - 900) * pairs_per_bp / 2).astype(np.int64))
+    pair_off = np.zeros(first.size + 1, np.int64)
+    pair_off[1:] = np.cumsum(2 * per_hap)
+    return Clusters(dn.contig[first].astype(np.int32), lo.astype(np.int32), hi.astype(np.int32), first.astype(np.int32),
+                    nd.astype(np.int32), pair_off)
 
 
 def place_dnms(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1):

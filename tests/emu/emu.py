@@ -14,7 +14,8 @@ _LIB = None
 def build():
     so = os.path.join(_HERE, "libemu_phase.so")
     deps = [os.path.join(_HERE, "emu_phase.cpp"), os.path.join(_ROOT, "unfazed_amd", "csrc", "phase_body.hpp"),
-            os.path.join(_ROOT, "unfazed_amd", "csrc", "wg.hpp"), os.path.join(_ROOT, "include", "uz_types.h")]
+            os.path.join(_ROOT, "unfazed_amd", "csrc", "wg.hpp"), os.path.join(_ROOT, "unfazed_amd", "csrc", "pack.hpp"),
+            os.path.join(_ROOT, "include", "uz_types.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall",
                                "-Wno-unused-function", "-Wno-unused-variable",

@@ -18,22 +18,38 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                          const int64_t *het_off, const int32_t *het_idx, int32_t *status, int32_t *counts,
                          int32_t *origin, int32_t *evidence, long long *list_start, int32_t *list_len, int32_t *pool,
                          long long pool_cap, long long *pool_used) {
-    std::vector<uint8_t> qc((size_t)Rv->n_segs + 1);
+    // the table in the packed form the device holds (built here on the host from the ASCII view)
+    const int64_t n = Rv->n_segs;
+    std::vector<uint8_t> qc((size_t)n + 1);
+    std::vector<RecA> ra((size_t)n + 1);
+    std::vector<RecB> rb((size_t)n + 1);
+    std::vector<uint32_t> fm((size_t)n + 1), cigar;
+    std::vector<uint8_t> seq4, qlow;
+    uint64_t coff = 0, uoff = 0;
+    for (int64_t i = 0; i < n; i++) {
+        uz_pack_rec(ra[i], rb[i], Rv->start[i], Rv->end[i], (uint32_t)coff, (uint32_t)uoff, Rv->mate[i], Rv->qname[i], Rv->l_seq[i],
+                    Rv->n_cigar[i], Rv->tlen[i]);
+        fm[i] = uz_pack_fm(Rv->flag[i], Rv->mapq[i], Rv->aux[i]);
+        for (int k = 0; k < (int)Rv->n_cigar[i]; k++) cigar.push_back(Rv->cigar[(size_t)Rv->cigar_off[i] + k]);
+        const uint32_t units = UZ_ROW_UNITS(Rv->l_seq[i]);
+        seq4.resize((size_t)(uoff + units) * UZ_SEQ4_UNIT_BYTES);
+        qlow.resize((size_t)(uoff + units) * UZ_QLOW_UNIT_BYTES);
+        if (uz_pack_rows_host(Rv->seq + ((size_t)Rv->sq_off16[i] << 4), Rv->qual + ((size_t)Rv->sq_off16[i] << 4), Rv->l_seq[i],
+                              P->min_gt_qual, seq4.data() + (size_t)uoff * UZ_SEQ4_UNIT_BYTES,
+                              qlow.data() + (size_t)uoff * UZ_QLOW_UNIT_BYTES) != 0)
+            return -2;
+        coff += Rv->n_cigar[i];
+        uoff += units;
+    }
+    cigar.push_back(0); seq4.resize(seq4.size() + 64); qlow.resize(qlow.size() + 64);
     RD R;
     R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
-    R.start = Rv->start; R.end = Rv->end; R.flag = Rv->flag; R.mapq = Rv->mapq; R.aux = Rv->aux; R.tlen = Rv->tlen;
-    R.qname = Rv->qname; R.mate = Rv->mate; R.cigar_off = Rv->cigar_off; R.n_cigar = Rv->n_cigar; R.cigar = Rv->cigar;
-    R.l_seq = Rv->l_seq; R.sq_off16 = Rv->sq_off16; R.seq = Rv->seq; R.qual = Rv->qual; R.qc = qc.data();
-    std::vector<RecA> ra((size_t)Rv->n_segs + 1);
-    std::vector<RecB> rb((size_t)Rv->n_segs + 1);
-    for (int64_t i = 0; i < Rv->n_segs; i++)
-        uz_pack_rec(ra[i], rb[i], Rv->start[i], Rv->end[i], Rv->cigar_off[i], Rv->sq_off16[i], Rv->mate[i], Rv->qname[i],
-                    Rv->l_seq[i], Rv->n_cigar[i], Rv->tlen[i]);
-    R.ra = ra.data(); R.rb = rb.data();
-    std::vector<int32_t> coarse((size_t)(Rv->n_segs >> 12) + 2);
-    for (int64_t k = 0; (k << 12) < Rv->n_segs; k++) coarse[k] = Rv->start[k << 12];
+    R.ra = ra.data(); R.rb = rb.data(); R.fm = fm.data(); R.cigar = cigar.data(); R.seq4 = seq4.data(); R.qlow = qlow.data();
+    R.qc = qc.data();
+    std::vector<int32_t> coarse((size_t)(n >> 12) + 2);
+    for (int64_t k = 0; (k << 12) < n; k++) coarse[k] = Rv->start[k << 12];
     R.coarse = coarse.data();
-    for (int64_t i = 0; i < Rv->n_segs; i++) qc[i] = uz_seg_qc(R, (int)i, P->min_map_qual, P->min_gt_qual);
+    for (int64_t i = 0; i < n; i++) qc[i] = uz_seg_qc(R, (int)i, P->min_map_qual);
     PhaseArgs a;
     memset(&a, 0, sizeof(a));
     a.n = D->n;

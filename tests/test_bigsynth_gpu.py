@@ -1,14 +1,18 @@
 """Benchmark-scale generator and pipeline on the GPU:
- * the HIP build of synth/uzsynth.h writes the same columns as the gcc build;
- * the whole path on HBM-resident (adopted) columns equals the CPU oracle on the host copy;
- * size-independent properties at a larger size: calls agree with the simulated truth,
-   a second pass is idempotent, and phasing a sub-batch gives the same per-DNM results."""
+ * the HIP build of synth/uzsynth.h (staged format, written in place in HBM) equals the gcc build (ASCII form)
+   packed by the host library;
+ * the whole path on HBM-resident (adopted) columns equals the CPU oracle on the host copy -- DNMs placed
+   uniformly, so neighbouring DNMs share alignment records;
+ * the STAGED path (fetch-reach selection on the host, asynchronous packed upload, chunks of DNMs) gives the
+   same per-DNM results as the resident table;
+ * size-independent properties at a larger size: calls agree with the simulated truth, a second pass is
+   idempotent, and phasing a sub-batch gives the same per-DNM results."""
 import numpy as np
 import pytest
 
 from synth import bigsynth
-from synth.sites_np import make_sites, place_dnms_full
-from unfazed_amd import abi
+from synth.sites_np import make_clusters, make_sites, place_dnms_full
+from unfazed_amd import abi, io_native
 from unfazed_amd.hostpath import concordant_cutoff
 
 pytestmark = pytest.mark.gpu
@@ -27,44 +31,56 @@ def _host_views(sc):
 @pytest.fixture(scope="module")
 def workload():
     sc = make_sites(400_000, seed=31, contig_lens=[6e7, 4e7, 2e7])
-    dn = place_dnms_full(sc, 1500, seed=32, indel_frac=0.2)
-    cfg = bigsynth.make_cfg(seed=33, n_pairs=1200, half_width=6000, n_dnms=dn.n)
-    wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, device=0)
-    yield sc, dn, cfg, wl
+    dn = place_dnms_full(sc, 3000, seed=32, indel_frac=0.2)  # dense: about a third of the DNMs share a cluster
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=33)
+    wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, cl, device=0)
+    yield sc, dn, cl, cfg, wl
     wl.free()
 
 
 def test_gpu_generator_equals_cpu_generator(workload):
-    sc, dn, cfg, wl = workload
-    m = 40
-    _, cpu = bigsynth.reads_cpu(cfg, sc, dn, 0, m)
-    gpu = wl.download_block(0, m)
-    for name, _, _ in bigsynth.OUT_COLS:
-        assert np.array_equal(cpu[name], gpu[name]), name
+    sc, dn, cl, cfg, wl = workload
+    assert (cl.nd > 1).sum() > 50
+    full = wl.download()
+    c1 = 60
+    rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, c1, threads=4)
+    want = io_native.pack_reads(rh, cfg.min_base_qual)
+    n = int(want.view.n_segs)
+    for name, _ in abi.PACKED_RECORD_COLS:
+        assert np.array_equal(want.arrays[name][:n], full.arrays[name][:n]), name
+    assert np.array_equal(want.arrays["cigar"][: want.view.n_cigar_total], full.arrays["cigar"][: want.view.n_cigar_total])
+    for name, unit in (("seq4", 16), ("qlow", 4)):
+        k = int(want.view.n_row_units) * unit
+        assert np.array_equal(want.arrays[name][:k], full.arrays[name][:k]), name
+
+
+def _oracle(sc, dn, cl, cfg, P, cutoff, d_hi):
+    from oracle import oracle as orc
+    c_hi = cl.of_dnm(d_hi - 1) + 1
+    m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1])  # whole clusters
+    rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, c_hi, threads=4)
+    sh, fh = _host_views(sc)
+    dvm = abi.dnms_view(dn.contig[:m], dn.contig[:m], dn.start[:m], dn.end[:m], np.zeros(m, np.uint8), dn.refs[:m],
+                        dn.alts[:m], cutoff)
+    found = orc.find(P, sh, fh, dvm, abi.FIND_SECOND_WINDOW)
+    return m, orc.phase(P, sh, rh, dvm, found, keep_lists=True)
 
 
 def test_resident_pipeline_matches_oracle(workload, engine):
-    from oracle import oracle as orc
-    sc, dn, cfg, wl = workload
+    sc, dn, cl, cfg, wl = workload
     P = abi.make_params()
     engine.set_params(P)
     sid = engine.adopt_sites(wl.sites_view())
     fid = engine.adopt_family(sid, wl.family_view())
     rid = engine.adopt_reads(wl.reads_view())
     n = dn.n
-    head = wl.dev.get(wl.out_ptrs["tlen"], (wl.n_segs,), np.int32)
-    cutoff = concordant_cutoff(head, P.readlen, 3)
+    cutoff = concordant_cutoff(wl.tlen_head(), P.readlen, 3)
     dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
     got = engine.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
     vo, vv = engine.votes(n)
-    # oracle on the first m DNMs, reads regenerated on the CPU
-    m = 300
-    rh, _ = bigsynth.reads_cpu(cfg, sc, dn, 0, m)
-    sh, fh = _host_views(sc)
-    dvm = abi.dnms_view(dn.contig[:m], dn.contig[:m], dn.start[:m], dn.end[:m], np.zeros(m, np.uint8), dn.refs[:m],
-                        dn.alts[:m], cutoff)
-    found = orc.find(P, sh, fh, dvm, abi.FIND_SECOND_WINDOW)
-    want = orc.phase(P, sh, rh, dvm, found, keep_lists=True)
+    # oracle on the first clusters, reads regenerated on the CPU (query-name ids = pair numbers: the same in both)
+    m, want = _oracle(sc, dn, cl, cfg, P, cutoff, 400)
     for k in ("status", "counts", "origin", "evidence"):
         assert np.array_equal(want[k], got[k][:m]), k
     wo, wv = want["vote_off"], want["vote_val"]
@@ -89,5 +105,35 @@ def test_resident_pipeline_matches_oracle(workload, engine):
     sub = engine.phase_raw(fid, rid, dvs, P, abi.FIND_SECOND_WINDOW)
     for k in ("status", "counts", "origin", "evidence"):
         assert np.array_equal(sub[k], got[k][sel]), k
+
+    # the staged path: per chunk of DNMs, the records their fetches can reach (host selection), uploaded
+    # asynchronously in the packed form; chunk boundaries fall INSIDE clusters, so records are duplicated across chunks
+    from unfazed_amd.engine import PinnedPool
+    from unfazed_amd.staging import fetch_points
+    full = wl.download()
+    src = io_native.ReadsSource(full)
+    co, ci, cf, ho, hi = engine.find(fid, dv, P, abi.FIND_SECOND_WINDOW)
+    pool = PinnedPool()
+    bounds = [0, 701, 1399, 2222, n]
+    rids, staged_bytes = [], 0
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
+        part = src.select(fc, flo, fhi, alloc=pool.alloc)
+        staged_bytes += sum(x.nbytes for x in part.arrays.values())
+        rids.append(engine.upload_reads_packed(part))
+    assert staged_bytes < 0.6 * sum(x.nbytes for x in full.arrays.values())
+    for (a, b), r in zip(zip(bounds[:-1], bounds[1:]), rids):
+        dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
+                            dn.refs[a:b], dn.alts[a:b], cutoff)
+        res = engine.phase_raw(fid, r, dvc, P, abi.FIND_SECOND_WINDOW)
+        for k in ("status", "counts", "origin", "evidence"):
+            assert np.array_equal(res[k], got[k][a:b]), (k, a, b)
+        so, sv_ = engine.votes(b - a)
+        for d in range(0, b - a, 7):
+            for j in range(4):
+                assert np.array_equal(sv_[so[4 * d + j]: so[4 * d + j + 1]],
+                                      vv[vo[4 * (a + d) + j]: vo[4 * (a + d) + j + 1]]), (a + d, j)
+        engine.free_reads(r)
+    pool.free_all()
     engine.free_reads(rid)
     engine.free_sites(sid)

@@ -1,0 +1,160 @@
+"""Host side of the staged record format (libunfazed_io: uz_reads_pack, uz_reads_select_*; staging.fetch_points):
+ * the packed columns say what the ASCII columns say (independent numpy unpacking);
+ * a selection holds exactly the records the fetches return plus the closure under `mate`, in order, with mate
+   links renumbered;
+ * the read stage sees nothing else: the oracle on the selected records gives, per DNM, what it gives on the whole
+   table (benchmark-scale generator, DNM chunks cut inside clusters)."""
+import numpy as np
+
+from oracle import oracle as orc
+from synth import bigsynth
+from synth.sites_np import make_clusters, make_sites, place_dnms_full
+from unfazed_amd import abi, io_native
+from unfazed_amd.hostpath import concordant_cutoff
+from unfazed_amd.staging import fetch_points
+
+LUT = np.frombuffer(b"=ACMGRSVTWYHKDBN", np.uint8)
+
+
+def _workload(n_dnms=260, seed=7):
+    sc = make_sites(40_000, seed=seed, contig_lens=[6e6, 4e6, 2e6])
+    dn = place_dnms_full(sc, n_dnms, seed=seed + 1, indel_frac=0.2)
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=seed + 2)
+    cfg.n_clusters = cl.n
+    rh, arrs = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, cl.n, threads=4)
+    return sc, dn, cl, rh, arrs
+
+
+def _sites_views(sc):
+    sv = abi.SitesView()
+    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags,
+                ref_base=sc.ref_base, alt_base=sc.alt_base)
+    sv.n_sites, sv.n_contigs = sc.n, len(sc.contig_off) - 1
+    for k, a in keep.items():
+        setattr(sv, k, a.ctypes.data)
+    return abi.Held(sv, keep), abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
+
+
+def _unpack_row(pk, uoff, i, ls):
+    u = int(abi.row_units(ls))
+    row = pk.arrays["seq4"][uoff[i] * 16: (uoff[i] + u) * 16]
+    seq = LUT[np.stack([row >> 4, row & 15], 1).ravel()[:ls]]
+    low = np.unpackbits(pk.arrays["qlow"][uoff[i] * 4: (uoff[i] + u) * 4], bitorder="little")[:ls]
+    return seq, low
+
+
+def test_pack_matches_ascii_columns():
+    sc, dn, cl, rh, arrs = _workload(60)
+    for thr in (20, 13, 0, 300):
+        pk = io_native.pack_reads(rh, thr)
+        n = int(rh.view.n_segs)
+        assert pk.view.n_segs == n and pk.view.min_base_qual == thr
+        for name, _ in abi.PACKED_RECORD_COLS:
+            assert np.array_equal(pk.arrays[name][:n], arrs[name][:n]), name
+        uoff = np.concatenate([[0], np.cumsum(abi.row_units(arrs["l_seq"][:n]))])
+        coff = np.concatenate([[0], np.cumsum(arrs["n_cigar"][:n].astype(np.int64))])
+        assert pk.view.n_row_units == uoff[-1] and pk.view.n_cigar_total == coff[-1]
+        rng = np.random.default_rng(thr)
+        for i in rng.integers(0, n, 300):
+            ls = int(arrs["l_seq"][i])
+            r0 = int(arrs["sq_off16"][i]) * 16
+            seq, low = _unpack_row(pk, uoff, i, ls)
+            assert np.array_equal(seq, arrs["seq"][r0: r0 + ls])
+            assert np.array_equal(low, (arrs["qual"][r0: r0 + ls].astype(np.int64) < min(max(thr, 0), 256)).astype(np.uint8))
+            c0 = int(arrs["cigar_off"][i])
+            assert np.array_equal(pk.arrays["cigar"][coff[i]: coff[i + 1]], arrs["cigar"][c0: c0 + int(arrs["n_cigar"][i])])
+
+
+def test_pack_rejects_foreign_characters():
+    sc, dn, cl, rh, arrs = _workload(20)
+    arrs["seq"][5] = ord("a")
+    try:
+        io_native.pack_reads(rh, 20)
+    except io_native.IoError as e:
+        assert "alphabet" in str(e)
+    else:
+        raise AssertionError("a lowercase base must be refused, not folded")
+
+
+def _subset_ascii(arrs, idx, n_contigs):
+    """ASCII view of the records idx (ascending) of the table `arrs`, mates renumbered"""
+    new = np.full(arrs["start"].shape[0], -1, np.int64)
+    new[idx] = np.arange(idx.size)
+    out = {}
+    for k in ("start", "end", "flag", "mapq", "aux", "tlen", "qname", "cigar_off", "n_cigar", "l_seq", "sq_off16"):
+        out[k] = np.ascontiguousarray(arrs[k][idx])
+    mt = arrs["mate"][idx]
+    out["mate"] = np.where(mt >= 0, new[np.maximum(mt, 0)], -1).astype(np.int32)
+    out["cigar"], out["seq"], out["qual"] = arrs["cigar"], arrs["seq"], arrs["qual"]  # rows stay where they are
+    co = np.searchsorted(idx, arrs["contig_off"]).astype(np.int64)
+    out["contig_off"] = co
+    span = np.zeros(n_contigs, np.int32)
+    for c in range(n_contigs):
+        if co[c + 1] > co[c]:
+            span[c] = (out["end"][co[c]: co[c + 1]] - out["start"][co[c]: co[c + 1]]).max()
+    out["max_span"] = span
+    v = abi.ReadsView()
+    v.n_segs, v.n_contigs = idx.size, n_contigs
+    for k, a in out.items():
+        setattr(v, k, a.ctypes.data)
+    v.n_cigar_total, v.n_sq_bytes = arrs["cigar"].shape[0], arrs["seq"].shape[0]
+    v.n_qnames = int(arrs["qname"].max()) + 1
+    return abi.Held(v, out)
+
+
+def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else():
+    sc, dn, cl, rh, arrs = _workload(260)
+    n, nc = dn.n, len(sc.contig_off) - 1
+    P = abi.make_params()
+    sh, fh = _sites_views(sc)
+    cutoff = concordant_cutoff(arrs["tlen"], P.readlen, 3)
+    dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
+    found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+    co, ci, cf, ho, hi = found
+    want = orc.phase(P, sh, rh, dv, found, keep_lists=True)
+    assert (want["status"] == abi.ST_OK).sum() > 30
+    pk = io_native.pack_reads(rh, P.min_gt_qual)
+    src = io_native.ReadsSource(pk)
+    N = int(rh.view.n_segs)
+    contig_of_rec = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    bounds = [0, 37, 111, 200, n]  # inside clusters
+    total = 0
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
+        part, idx = src.select(fc, flo, fhi, want_index=True)
+        # brute force: overlap of any fetch, then the closure under mate
+        keep = np.zeros(N, bool)
+        for c, lo, h in zip(fc, flo, fhi):
+            keep |= (contig_of_rec == c) & (arrs["start"][:N] < h) & (arrs["end"][:N] > lo)
+        for _ in range(4):
+            m = arrs["mate"][:N][keep]
+            keep[m[m >= 0]] = True
+        assert np.array_equal(np.nonzero(keep)[0], idx)
+        total += idx.size
+        # packed columns of the selection = the packed columns of those records
+        for name, _ in abi.PACKED_RECORD_COLS:
+            if name != "mate":
+                assert np.array_equal(part.arrays[name][: idx.size], pk.arrays[name][idx]), name
+        mt = part.arrays["mate"][: idx.size]
+        assert np.array_equal(idx[mt[mt >= 0]], pk.arrays["mate"][idx][mt >= 0])
+        uoff_f = np.concatenate([[0], np.cumsum(abi.row_units(pk.arrays["l_seq"][:N]))])
+        uoff_p = np.concatenate([[0], np.cumsum(abi.row_units(part.arrays["l_seq"][: idx.size]))])
+        for k in np.random.default_rng(a).integers(0, idx.size, 50):
+            ls = int(part.arrays["l_seq"][k])
+            s1, q1 = _unpack_row(part, uoff_p, k, ls)
+            s2, q2 = _unpack_row(pk, uoff_f, idx[k], ls)
+            assert np.array_equal(s1, s2) and np.array_equal(q1, q2)
+        # the oracle on the selected records only
+        sub = _subset_ascii(arrs, idx, nc)
+        dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
+                            dn.refs[a:b], dn.alts[a:b], cutoff)
+        fsub = orc.find(P, sh, fh, dvc, abi.FIND_SECOND_WINDOW)
+        got = orc.phase(P, sh, sub, dvc, fsub, keep_lists=True)
+        for k in ("status", "counts", "origin", "evidence"):
+            assert np.array_equal(got[k], want[k][a:b]), (k, a, b)
+        wo, wv, go, gv = want["vote_off"], want["vote_val"], got["vote_off"], got["vote_val"]
+        for d in range(b - a):
+            for j in range(4):
+                assert np.array_equal(gv[go[4 * d + j]: go[4 * d + j + 1]], wv[wo[4 * (a + d) + j]: wo[4 * (a + d) + j + 1]])
+    assert total < 0.6 * N  # about a third of the records inside the windows is reachable

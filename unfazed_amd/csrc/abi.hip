@@ -4,7 +4,6 @@
 
 void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n);
 bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv);
-void uz_build_coarse(uz_ctx *c, ReadsDev &r);
 
 namespace {
 
@@ -83,18 +82,55 @@ void free_sites(SitesDev &s) {
     (void)hipFree(s.contig_off);
     s = SitesDev();
 }
-void free_reads(ReadsDev &r) {
-    if (r.owned) {
-        (void)hipFree(r.start); (void)hipFree(r.end); (void)hipFree(r.flag); (void)hipFree(r.mapq); (void)hipFree(r.aux);
-        (void)hipFree(r.tlen); (void)hipFree(r.qname); (void)hipFree(r.mate); (void)hipFree(r.cigar_off);
-        (void)hipFree(r.n_cigar); (void)hipFree(r.cigar); (void)hipFree(r.l_seq); (void)hipFree(r.sq_off16);
-        (void)hipFree(r.seq); (void)hipFree(r.qual);
-    }
-    (void)hipFree(r.contig_off); (void)hipFree(r.max_span); (void)hipFree(r.qc); (void)hipFree(r.need); (void)hipFree(r.coarse); (void)hipFree(r.rec_a); (void)hipFree(r.rec_b);
+void free_reads(uz_ctx *c, ReadsDev &r) {
+    if (r.ready) (void)hipEventDestroy(r.ready);
+    uz_block_put(c, r.block);
     r = ReadsDev();
 }
 
+// carve arrays out of a table's block
+struct Carver {
+    uint8_t *base;
+    size_t off = 0;
+    explicit Carver(uint8_t *b) : base(b) {}
+    template <typename T>
+    T *take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += (n ? n : 1) * sizeof(T) + 64; // +64: vector tail reads stay in-bounds
+        return p;
+    }
+};
+
 } // namespace
+
+// ---------------------------------------------------------------- device block pool
+DevBlock uz_block_get(uz_ctx *c, size_t bytes) {
+    int best = -1;
+    for (size_t i = 0; i < c->block_pool.size(); i++)
+        if (c->block_pool[i].cap >= bytes && (best < 0 || c->block_pool[i].cap < c->block_pool[best].cap)) best = (int)i;
+    if (best >= 0 && c->block_pool[best].cap <= 2 * bytes + (1 << 20)) {
+        DevBlock b = c->block_pool[best];
+        c->block_pool.erase(c->block_pool.begin() + best);
+        return b;
+    }
+    DevBlock b;
+    b.cap = bytes + bytes / 16 + 4096;
+    UZ_HIP(hipMalloc((void **)&b.p, b.cap));
+    return b;
+}
+void uz_block_put(uz_ctx *c, DevBlock b) {
+    if (!b.p) return;
+    c->block_pool.push_back(b);
+    // keep the parked memory bounded: beyond 64 blocks the smallest ones are returned to the driver
+    while (c->block_pool.size() > 64) {
+        size_t k = 0;
+        for (size_t i = 1; i < c->block_pool.size(); i++)
+            if (c->block_pool[i].cap < c->block_pool[k].cap) k = i;
+        (void)hipFree(c->block_pool[k].p);
+        c->block_pool.erase(c->block_pool.begin() + k);
+    }
+}
 
 // ---------------------------------------------------------------- profiling
 void uz_prof_begin(uz_ctx *c, int kernel, hipEvent_t *a, hipEvent_t *b) {
@@ -171,10 +207,13 @@ int uz_create(int device, uz_ctx **out) {
     uz_ctx *c = new uz_ctx();
     c->device = device;
     memset(&c->P, 0, sizeof(c->P));
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&c->hflags, 64, hipHostMallocMapped) != hipSuccess) {
         delete c;
         return UZ_E_HIP;
     }
+    memset(c->hflags, 0, 64);
     *out = c;
     return 0;
 }
@@ -187,7 +226,10 @@ void uz_destroy(uz_ctx *c) {
     uz_phase_state_free(c);
     for (auto &f : c->fams) if (f.live) free_family(f);
     for (auto &s : c->sites) if (s.live) free_sites(s);
-    for (auto &r : c->reads) if (r.live) free_reads(r);
+    for (auto &r : c->reads) if (r.live) free_reads(c, r);
+    for (auto &b : c->block_pool) (void)hipFree(b.p);
+    if (c->hflags) (void)hipHostFree(c->hflags);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     c->dn.contig.release(); c->dn.rcontig.release(); c->dn.start.release(); c->dn.end.release();
     c->dn.vartype.release(); c->dn.dflags.release(); c->dn.mult.release(); c->dn.allele_off.release();
     c->dn.alleles.release();
@@ -302,64 +344,221 @@ int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int
     });
 }
 
-static void reads_fill(uz_ctx *c, const uz_reads_view *v, ReadsDev &r, bool copy) {
-    UZ_REQUIRE(v->n_segs >= 0 && v->n_segs < (int64_t)0x7FFFFFF0, UZ_E_RANGE, "more than 2^31 alignment records");
-    r.live = true; r.owned = copy;
-    r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
-    r.n_cigar_total = v->n_cigar_total; r.n_sq_bytes = v->n_sq_bytes;
+} // extern "C"
+
+// ---- alignment records -> HBM ---------------------------------------------------------------------------
+// Layout of a table's block: [record headers | flag word | qc | need | coarse | contig tables] then, for
+// uploads, [cigar | seq4 | qlow] (+ the full qualities of an ASCII upload) and the staged fixed-width columns
+// the headers are built from.
+static void carve_common(Carver &cv, ReadsDev &r) {
     const size_t n = (size_t)r.n;
-    if (copy) {
-        r.contig_off = upload(c, v->contig_off, (size_t)v->n_contigs + 1);
-        r.max_span = upload(c, v->max_span, (size_t)v->n_contigs);
-        r.start = upload(c, v->start, n); r.end = upload(c, v->end, n);
-        r.flag = upload(c, v->flag, n); r.mapq = upload(c, v->mapq, n); r.aux = upload(c, v->aux, n);
-        r.tlen = upload(c, v->tlen, n); r.qname = upload(c, v->qname, n); r.mate = upload(c, v->mate, n);
-        r.cigar_off = upload(c, v->cigar_off, n); r.n_cigar = upload(c, v->n_cigar, n);
-        r.cigar = upload(c, v->cigar, (size_t)v->n_cigar_total);
-        r.l_seq = upload(c, v->l_seq, n); r.sq_off16 = upload(c, v->sq_off16, n);
-        r.seq = upload(c, v->seq, (size_t)v->n_sq_bytes); r.qual = upload(c, v->qual, (size_t)v->n_sq_bytes);
-    } else {
-        std::vector<int64_t> co((size_t)v->n_contigs + 1);
-        std::vector<int32_t> ms((size_t)v->n_contigs + 1);
-        UZ_HIP(hipMemcpy(co.data(), v->contig_off, co.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (v->n_contigs) UZ_HIP(hipMemcpy(ms.data(), v->max_span, (size_t)v->n_contigs * sizeof(int32_t), hipMemcpyDeviceToHost));
-        r.contig_off = upload(c, co.data(), co.size());
-        r.max_span = upload(c, ms.data(), (size_t)v->n_contigs);
-        r.start = const_cast<int32_t *>(v->start); r.end = const_cast<int32_t *>(v->end);
-        r.flag = const_cast<uint16_t *>(v->flag); r.mapq = const_cast<uint8_t *>(v->mapq); r.aux = const_cast<uint8_t *>(v->aux);
-        r.tlen = const_cast<int32_t *>(v->tlen); r.qname = const_cast<uint32_t *>(v->qname); r.mate = const_cast<int32_t *>(v->mate);
-        r.cigar_off = const_cast<uint32_t *>(v->cigar_off); r.n_cigar = const_cast<uint16_t *>(v->n_cigar);
-        r.cigar = const_cast<uint32_t *>(v->cigar); r.l_seq = const_cast<uint16_t *>(v->l_seq);
-        r.sq_off16 = const_cast<uint32_t *>(v->sq_off16);
-        r.seq = const_cast<uint8_t *>(v->seq); r.qual = const_cast<uint8_t *>(v->qual);
-    }
-    UZ_HIP(hipMalloc((void **)&r.qc, n + 64));
-    UZ_HIP(hipMalloc((void **)&r.need, n + 64));
-    UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, c->stream));
-    uz_build_coarse(c, r);
-    uz_build_rec_headers(c, r);
-    UZ_HIP(hipStreamSynchronize(c->stream));
+    r.rec_a = cv.take<uint8_t>(n * 16);
+    r.rec_b = cv.take<uint8_t>(n * 16);
+    r.fm = cv.take<uint32_t>(n);
+    r.qc = cv.take<uint8_t>(n);
+    r.need = cv.take<uint8_t>(n);
+    r.coarse = cv.take<int32_t>((n >> 12) + 2);
+    r.contig_off = cv.take<int64_t>((size_t)r.n_contigs + 1);
+    r.max_span = cv.take<int32_t>((size_t)r.n_contigs + 1);
 }
+
+template <typename T>
+static const T *h2d(hipStream_t st, T *dst, const T *host, size_t n) {
+    if (n) {
+        UZ_REQUIRE(host != nullptr, UZ_E_ARG, "null column pointer");
+        UZ_HIP(hipMemcpyAsync(dst, host, n * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    return dst;
+}
+
+static void check_packed_view(const uz_reads_packed_view *v) {
+    UZ_REQUIRE(v->n_segs >= 0 && v->n_segs < (int64_t)0x7FFFFFF0, UZ_E_RANGE, "more than 2^31 alignment records");
+    UZ_REQUIRE(v->n_contigs >= 0, UZ_E_ARG, "bad reads view");
+    UZ_REQUIRE(v->n_cigar_total >= 0 && v->n_cigar_total < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
+    UZ_REQUIRE(v->n_row_units >= 0 && v->n_row_units < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 row units (2^37 bases)");
+}
+
+// packed columns in HOST memory -> one block; every command goes to stream `st`
+static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_packed_view *v, ReadsDev &r) {
+    check_packed_view(v);
+    r.live = true;
+    r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
+    r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units;
+    const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units;
+    uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr;
+    int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
+    void *scratch = nullptr;
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv(pass ? r.block.p : nullptr);
+        carve_common(cv, r);
+        cigar = cv.take<uint32_t>(nc);
+        seq4 = cv.take<uint8_t>(nu * UZ_SEQ4_UNIT_BYTES);
+        qlow = cv.take<uint8_t>(nu * UZ_QLOW_UNIT_BYTES);
+        start = cv.take<int32_t>(n); end = cv.take<int32_t>(n); tlen = cv.take<int32_t>(n); mate = cv.take<int32_t>(n);
+        qname = cv.take<uint32_t>(n); flag = cv.take<uint16_t>(n); l_seq = cv.take<uint16_t>(n); n_cigar = cv.take<uint16_t>(n);
+        mapq = cv.take<uint8_t>(n); aux = cv.take<uint8_t>(n);
+        scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
+        if (!pass) r.block = uz_block_get(c, cv.off + 256);
+    }
+    h2d(st, r.contig_off, v->contig_off, (size_t)v->n_contigs + 1);
+    h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs);
+    RecColumns col;
+    col.start = h2d(st, start, v->start, n); col.end = h2d(st, end, v->end, n); col.tlen = h2d(st, tlen, v->tlen, n);
+    col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n); col.flag = h2d(st, flag, v->flag, n);
+    col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
+    col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
+    r.cigar = h2d(st, cigar, v->cigar, nc);
+    r.seq4 = h2d(st, seq4, v->seq4, nu * UZ_SEQ4_UNIT_BYTES);
+    r.qlow = qlow;
+    h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
+    r.qlow_thr = v->min_base_qual;
+    r.qlow_valid = true;
+    UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, st));
+    uz_build_records(c, st, r, col, scratch);
+}
+
+int uz_reads_upload_impl(uz_ctx *c, const uz_reads_view *v, ReadsDev &r) {
+    // the ASCII form (uz_reads_view): the fixed-width columns are staged as they are, the CIGAR words and
+    // the bases are re-laid in the packed geometry on the device, the qualities are kept for the plane
+    UZ_REQUIRE(v->n_segs >= 0 && v->n_segs < (int64_t)0x7FFFFFF0, UZ_E_RANGE, "more than 2^31 alignment records");
+    hipStream_t st = c->stream;
+    r.live = true;
+    r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
+    const size_t n = (size_t)r.n;
+    // totals of the packed geometry from the host columns
+    int64_t tot_c = 0, tot_u = 0;
+    for (size_t i = 0; i < n; i++) { tot_c += v->n_cigar[i]; tot_u += UZ_ROW_UNITS(v->l_seq[i]); }
+    r.n_cigar_total = tot_c; r.n_row_units = tot_u;
+    UZ_REQUIRE(tot_c < ((int64_t)1 << 32) && tot_u < ((int64_t)1 << 32), UZ_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets");
+    const size_t nc = (size_t)tot_c, nu = (size_t)tot_u, nci = (size_t)v->n_cigar_total, nsq = (size_t)v->n_sq_bytes;
+    uint32_t *cigar = nullptr, *cigar_in = nullptr, *cigar_off_in = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq_in = nullptr;
+    int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
+    void *scratch = nullptr;
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv(pass ? r.block.p : nullptr);
+        carve_common(cv, r);
+        cigar = cv.take<uint32_t>(nc);
+        seq4 = cv.take<uint8_t>(nu * UZ_SEQ4_UNIT_BYTES);
+        qlow = cv.take<uint8_t>(nu * UZ_QLOW_UNIT_BYTES);
+        r.qual8 = cv.take<uint8_t>(nsq);
+        r.qual_off16 = cv.take<uint32_t>(n);
+        start = cv.take<int32_t>(n); end = cv.take<int32_t>(n); tlen = cv.take<int32_t>(n); mate = cv.take<int32_t>(n);
+        qname = cv.take<uint32_t>(n); flag = cv.take<uint16_t>(n); l_seq = cv.take<uint16_t>(n); n_cigar = cv.take<uint16_t>(n);
+        mapq = cv.take<uint8_t>(n); aux = cv.take<uint8_t>(n);
+        cigar_in = cv.take<uint32_t>(nci); cigar_off_in = cv.take<uint32_t>(n); seq_in = cv.take<uint8_t>(nsq);
+        scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
+        if (!pass) r.block = uz_block_get(c, cv.off + 256);
+    }
+    h2d(st, r.contig_off, v->contig_off, (size_t)v->n_contigs + 1);
+    h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs);
+    RecColumns col;
+    col.start = h2d(st, start, v->start, n); col.end = h2d(st, end, v->end, n); col.tlen = h2d(st, tlen, v->tlen, n);
+    col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n); col.flag = h2d(st, flag, v->flag, n);
+    col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
+    col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
+    h2d(st, cigar_in, v->cigar, nci); h2d(st, cigar_off_in, v->cigar_off, n);
+    h2d(st, seq_in, v->seq, nsq); h2d(st, r.qual8, v->qual, nsq); h2d(st, r.qual_off16, v->sq_off16, n);
+    r.cigar = cigar; r.seq4 = seq4; r.qlow = qlow;
+    r.qlow_valid = false; // built for the threshold of the first uz_phase
+    UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, st));
+    uz_build_records(c, st, r, col, scratch);
+    uz_pack_ascii_rows(c, st, r, cigar_in, cigar_off_in, seq_in, r.qual_off16, cigar, seq4);
+    UZ_HIP(hipStreamSynchronize(st));
+    if (c->hflags[0]) {
+        const int f = c->hflags[0];
+        c->hflags[0] = 0;
+        throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet" : "inconsistent reads view"};
+    }
+    return 0;
+}
+
+extern "C" {
 
 int uz_reads_upload(uz_ctx *c, const uz_reads_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
         ReadsDev r;
-        reads_fill(c, v, r, true);
+        try { uz_reads_upload_impl(c, v, r); } catch (...) { uz_block_put(c, r.block); throw; }
         const int k = new_slot(c->reads);
         c->reads[k] = r;
         *id = k;
     });
 }
-int uz_reads_adopt_device(uz_ctx *c, const uz_reads_view *v, int *id) {
+
+int uz_reads_upload_packed(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
         ReadsDev r;
-        reads_fill(c, v, r, false);
+        try {
+            reads_from_packed_host(c, c->copy_stream, v, r);
+            UZ_HIP(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
+            UZ_HIP(hipEventRecord(r.ready, c->copy_stream));
+            r.pending = true;
+        } catch (...) { uz_block_put(c, r.block); throw; }
         const int k = new_slot(c->reads);
         c->reads[k] = r;
         *id = k;
     });
+}
+
+int uz_reads_wait(uz_ctx *c, int reads_id) {
+    return guarded(c, [&] {
+        ReadsDev &r = reads_of(c, reads_id);
+        if (r.ready) UZ_HIP(hipEventSynchronize(r.ready));
+        if (c->hflags[0]) {
+            c->hflags[0] = 0;
+            throw UzError{UZ_E_RANGE, "n_cigar_total / n_row_units of the reads view do not match its columns"};
+        }
+    });
+}
+
+int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
+        check_packed_view(v);
+        UZ_REQUIRE(((uintptr_t)v->qlow | (uintptr_t)v->seq4 | (uintptr_t)v->cigar) % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
+        ReadsDev r;
+        r.live = true;
+        r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
+        r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units;
+        void *scratch = nullptr;
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? r.block.p : nullptr);
+            carve_common(cv, r);
+            scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
+            if (!pass) r.block = uz_block_get(c, cv.off + 256);
+        }
+        try {
+            hipStream_t st = c->stream;
+            UZ_HIP(hipMemcpyAsync(r.contig_off, v->contig_off, ((size_t)v->n_contigs + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+            if (v->n_contigs) UZ_HIP(hipMemcpyAsync(r.max_span, v->max_span, (size_t)v->n_contigs * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            RecColumns col;
+            col.start = v->start; col.end = v->end; col.tlen = v->tlen; col.mate = v->mate; col.qname = v->qname;
+            col.flag = v->flag; col.l_seq = v->l_seq; col.n_cigar = v->n_cigar; col.mapq = v->mapq; col.aux = v->aux;
+            r.cigar = v->cigar; r.seq4 = v->seq4; r.qlow = const_cast<uint8_t *>(v->qlow);
+            r.qlow_thr = v->min_base_qual;
+            r.qlow_valid = true;
+            UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, st));
+            uz_build_records(c, st, r, col, scratch);
+            UZ_HIP(hipStreamSynchronize(st));
+            if (c->hflags[0]) {
+                c->hflags[0] = 0;
+                throw UzError{UZ_E_RANGE, "n_cigar_total / n_row_units of the reads view do not match its columns"};
+            }
+        } catch (...) { uz_block_put(c, r.block); throw; }
+        const int k = new_slot(c->reads);
+        c->reads[k] = r;
+        *id = k;
+    });
+}
+
+int uz_pinned_alloc(size_t bytes, void **out) {
+    if (!out) return UZ_E_ARG;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault) == hipSuccess ? 0 : UZ_E_HIP;
+}
+void uz_pinned_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int uz_drop_derived(uz_ctx *c) {
@@ -382,8 +581,10 @@ int uz_sites_free(uz_ctx *c, int sites_id) {
 int uz_reads_free(uz_ctx *c, int reads_id) {
     return guarded(c, [&] {
         ReadsDev &r = reads_of(c, reads_id);
+        // the block goes back to the pool: whatever still reads or fills it must have finished
+        if (r.ready) UZ_HIP(hipEventSynchronize(r.ready));
         UZ_HIP(hipStreamSynchronize(c->stream));
-        free_reads(r);
+        free_reads(c, r);
     });
 }
 

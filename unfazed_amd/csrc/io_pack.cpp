@@ -1,0 +1,253 @@
+// io_pack.cpp -- host side of the staged record format (uz_reads_packed_view, include/uz_types.h):
+//   uz_reads_pack      ASCII table -> packed columns (4-bit bases, quality-below-threshold plane, CIGAR words
+//                      back to back), into buffers the caller owns (pinned memory for the upload)
+//   uz_reads_select_*  the records a list of fetches can return plus their mates -- what
+//                      `bamfile.fetch(chrom, lo, hi)` + `bamfile.mate(read)` hand the reference
+//                      (read_collector.py:385, :167, :400, :185): nothing else of an alignment file is ever
+//                      looked at, so nothing else needs to be staged.
+// Host only (g++), threads over records.
+#include <atomic>
+
+#include "io_common.hpp"
+#include "pack.hpp"
+
+using namespace uzio;
+
+namespace {
+
+template <typename F>
+int guarded(F &&fn) {
+    try {
+        fn();
+        return UZ_IO_OK;
+    } catch (const IoError &e) {
+        last_error = e.msg;
+        return e.code;
+    } catch (const std::exception &e) {
+        last_error = e.what();
+        return UZ_IO_E_FORMAT;
+    }
+}
+
+// writable aliases of the fields of an output view
+template <typename T>
+T *w(const T *p) { return const_cast<T *>(p); }
+
+// exclusive prefix sums of n_cigar / row units over [0, n): off arrays have n + 1 entries
+void offsets(int64_t n, const uint16_t *n_cigar, const uint16_t *l_seq, int threads, std::vector<uint64_t> &coff, std::vector<uint64_t> &uoff) {
+    coff.assign((size_t)n + 1, 0);
+    uoff.assign((size_t)n + 1, 0);
+    const int wk = workers_for(n, threads, 1 << 16);
+    std::vector<uint64_t> ca((size_t)wk + 1, 0), ua((size_t)wk + 1, 0);
+    parallel_slices(n, wk, [&](int64_t lo, int64_t hi, int k) {
+        uint64_t a = 0, b = 0;
+        for (int64_t i = lo; i < hi; i++) { a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); }
+        ca[(size_t)k + 1] = a; ua[(size_t)k + 1] = b;
+    });
+    for (int k = 0; k < wk; k++) { ca[(size_t)k + 1] += ca[k]; ua[(size_t)k + 1] += ua[k]; }
+    parallel_slices(n, wk, [&](int64_t lo, int64_t hi, int k) {
+        uint64_t a = ca[k], b = ua[k];
+        for (int64_t i = lo; i < hi; i++) { coff[i] = a; uoff[i] = b; a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); }
+    });
+    coff[n] = ca[wk]; uoff[n] = ua[wk];
+}
+
+} // namespace
+
+// a packed table opened as the source of selections: the CIGAR / row offsets of its records, computed once
+struct uz_psrc {
+    uz_reads_packed_view v;
+    std::vector<uint32_t> coff, uoff; // [n + 1]
+};
+
+struct uz_select {
+    const uz_psrc *src = nullptr;
+    int64_t n_sel = 0;
+    uint64_t n_cigar = 0, n_units = 0;
+    std::vector<int32_t> index; // kept records, ascending (indices into the source table)
+};
+
+extern "C" {
+
+int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t *n_row_units) {
+    return guarded([&] {
+        if (!in || !n_cigar_total || !n_row_units) fail(UZ_IO_E_ARG, "null argument");
+        uint64_t a = 0, b = 0;
+        for (int64_t i = 0; i < in->n_segs; i++) { a += in->n_cigar[i]; b += UZ_ROW_UNITS(in->l_seq[i]); }
+        *n_cigar_total = (int64_t)a; *n_row_units = (int64_t)b;
+    });
+}
+
+int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_reads_packed_view *out) {
+    return guarded([&] {
+        if (!in || !out) fail(UZ_IO_E_ARG, "null argument");
+        const int64_t n = in->n_segs;
+        threads = resolve_threads(threads);
+        std::vector<uint64_t> coff, uoff;
+        offsets(n, in->n_cigar, in->l_seq, threads, coff, uoff);
+        if (coff[n] >= ((uint64_t)1 << 32) || uoff[n] >= ((uint64_t)1 << 32)) fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets");
+        if ((int64_t)coff[n] != out->n_cigar_total || (int64_t)uoff[n] != out->n_row_units)
+            fail(UZ_IO_E_ARG, "output view sized for %lld / %lld CIGAR words / row units, the table has %llu / %llu", (long long)out->n_cigar_total,
+                 (long long)out->n_row_units, (unsigned long long)coff[n], (unsigned long long)uoff[n]);
+        out->n_segs = n; out->n_contigs = in->n_contigs; out->min_base_qual = min_base_qual; out->n_qnames = in->n_qnames;
+        memcpy(w(out->contig_off), in->contig_off, ((size_t)in->n_contigs + 1) * sizeof(int64_t));
+        if (in->n_contigs) memcpy(w(out->max_span), in->max_span, (size_t)in->n_contigs * sizeof(int32_t));
+        const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
+        std::atomic<int> bad{0};
+        parallel_slices(n, workers_for(n, threads, 4096), [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; i++) {
+                w(out->start)[i] = in->start[i]; w(out->end)[i] = in->end[i]; w(out->tlen)[i] = in->tlen[i];
+                w(out->mate)[i] = in->mate[i]; w(out->qname)[i] = in->qname[i]; w(out->flag)[i] = in->flag[i];
+                w(out->l_seq)[i] = in->l_seq[i]; w(out->n_cigar)[i] = in->n_cigar[i]; w(out->mapq)[i] = in->mapq[i];
+                w(out->aux)[i] = in->aux[i];
+                for (int k = 0; k < (int)in->n_cigar[i]; k++) w(out->cigar)[coff[i] + k] = in->cigar[(size_t)in->cigar_off[i] + k];
+                const size_t row = (size_t)in->sq_off16[i] << 4;
+                if (uz_pack_rows_host(in->seq + row, in->qual + row, in->l_seq[i], thr, w(out->seq4) + uoff[i] * UZ_SEQ4_UNIT_BYTES,
+                                      w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES) != 0)
+                    bad.store(1);
+            }
+        });
+        if (bad.load()) fail(UZ_IO_E_RANGE, "SEQ holds a character outside BAM's 16-code alphabet");
+    });
+}
+
+int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc **out) {
+    return guarded([&] {
+        if (!full || !out) fail(UZ_IO_E_ARG, "null argument");
+        threads = resolve_threads(threads);
+        auto src = new uz_psrc();
+        src->v = *full;
+        std::vector<uint64_t> coff, uoff;
+        offsets(full->n_segs, full->n_cigar, full->l_seq, threads, coff, uoff);
+        if (coff.back() >= ((uint64_t)1 << 32) || uoff.back() >= ((uint64_t)1 << 32)) { delete src; fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets"); }
+        src->coff.assign(coff.begin(), coff.end());
+        src->uoff.assign(uoff.begin(), uoff.end());
+        *out = src;
+    });
+}
+void uz_reads_source_close(uz_psrc *s) { delete s; }
+
+int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int threads,
+                         uz_select **out) {
+    return guarded([&] {
+        if (!src || !out || (n_fetch > 0 && (!contig || !lo || !hi))) fail(UZ_IO_E_ARG, "null argument");
+        threads = resolve_threads(threads);
+        const uz_reads_packed_view *full = &src->v;
+        const int64_t n = full->n_segs;
+        std::vector<uint8_t> keep((size_t)n + 1, 0);
+        uint8_t *kp = keep.data();
+        std::atomic<int64_t> rmin{n}, rmax{0}; // record range the marks fall into
+        auto widen = [&](int64_t a, int64_t b) {
+            int64_t cur = rmin.load();
+            while (a < cur && !rmin.compare_exchange_weak(cur, a)) {}
+            cur = rmax.load();
+            while (b > cur && !rmax.compare_exchange_weak(cur, b)) {}
+        };
+        // pysam fetch(contig, lo, hi): records with start < hi and end > lo; their starts lie in [lo - max_span, hi)
+        parallel_slices(n_fetch, workers_for(n_fetch, threads, 256), [&](int64_t f0, int64_t f1, int) {
+            int64_t a = n, b = 0;
+            for (int64_t f = f0; f < f1; f++) {
+                const int tid = contig[f];
+                if (tid < 0 || tid >= full->n_contigs) continue;
+                const int64_t c0 = full->contig_off[tid], c1 = full->contig_off[tid + 1];
+                const int64_t from = (int64_t)lo[f] - full->max_span[tid];
+                const int32_t *p = std::lower_bound(full->start + c0, full->start + c1, from,
+                                                    [](int32_t v, int64_t key) { return (int64_t)v < key; });
+                for (int64_t i = p - full->start; i < c1 && full->start[i] < hi[f]; i++)
+                    if (full->end[i] > lo[f]) {
+                        __atomic_store_n(&kp[i], (uint8_t)1, __ATOMIC_RELAXED);
+                        a = std::min(a, i); b = std::max(b, i + 1);
+                    }
+            }
+            if (a < b) widen(a, b);
+        });
+        // mates, and the mates of those (mate() is not an involution when secondary / supplementary records
+        // share a name): closed under `mate` after a few rounds
+        for (int round = 0; round < 8; round++) {
+            std::atomic<int64_t> added{0};
+            const int64_t r0 = rmin.load(), r1 = rmax.load();
+            if (r0 >= r1) break;
+            parallel_slices(r1 - r0, workers_for(r1 - r0, threads, 1 << 16), [&](int64_t a, int64_t b, int) {
+                int64_t mine = 0, lo2 = n, hi2 = 0;
+                for (int64_t i = r0 + a; i < r0 + b; i++) {
+                    if (!__atomic_load_n(&kp[i], __ATOMIC_RELAXED)) continue;
+                    const int32_t m = full->mate[i];
+                    if (m >= 0 && m < n && !__atomic_load_n(&kp[m], __ATOMIC_RELAXED)) {
+                        __atomic_store_n(&kp[m], (uint8_t)1, __ATOMIC_RELAXED);
+                        mine++;
+                        lo2 = std::min<int64_t>(lo2, m); hi2 = std::max<int64_t>(hi2, (int64_t)m + 1);
+                    }
+                }
+                if (lo2 < hi2) widen(lo2, hi2);
+                added += mine;
+            });
+            if (added.load() == 0) break;
+        }
+        auto sel = new uz_select();
+        sel->src = src;
+        for (int64_t i = rmin.load(); i < rmax.load(); i++)
+            if (kp[i]) {
+                sel->index.push_back((int32_t)i);
+                sel->n_cigar += full->n_cigar[i]; sel->n_units += UZ_ROW_UNITS(full->l_seq[i]);
+            }
+        sel->n_sel = (int64_t)sel->index.size();
+        *out = sel;
+    });
+}
+
+int64_t uz_select_n_records(const uz_select *s) { return s ? s->n_sel : 0; }
+int64_t uz_select_n_cigar_total(const uz_select *s) { return s ? (int64_t)s->n_cigar : 0; }
+int64_t uz_select_n_row_units(const uz_select *s) { return s ? (int64_t)s->n_units : 0; }
+void uz_select_free(uz_select *s) { delete s; }
+
+int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *out, int32_t *orig_index) {
+    return guarded([&] {
+        if (!s || !out) fail(UZ_IO_E_ARG, "null argument");
+        const uz_psrc *src = s->src;
+        const uz_reads_packed_view *full = &src->v;
+        threads = resolve_threads(threads);
+        const int64_t m = s->n_sel;
+        out->n_segs = m; out->n_contigs = full->n_contigs; out->min_base_qual = full->min_base_qual; out->n_qnames = full->n_qnames;
+        out->n_cigar_total = (int64_t)s->n_cigar; out->n_row_units = (int64_t)s->n_units;
+        for (int c = 0; c <= full->n_contigs; c++)
+            w(out->contig_off)[c] = std::lower_bound(s->index.begin(), s->index.end(), full->contig_off[c],
+                                                     [](int32_t v, int64_t key) { return (int64_t)v < key; }) - s->index.begin();
+        for (int c = 0; c < full->n_contigs; c++) {
+            int32_t span = 0;
+            for (int64_t k = out->contig_off[c]; k < out->contig_off[c + 1]; k++) {
+                const int64_t i = s->index[k];
+                span = std::max(span, full->end[i] - full->start[i]);
+            }
+            w(out->max_span)[c] = span;
+        }
+        // offsets of the kept records in the OUTPUT: prefix sums over the selection
+        std::vector<uint64_t> oc((size_t)m + 1, 0), ou((size_t)m + 1, 0);
+        for (int64_t k = 0; k < m; k++) {
+            const int64_t i = s->index[k];
+            oc[k + 1] = oc[k] + full->n_cigar[i];
+            ou[k + 1] = ou[k] + UZ_ROW_UNITS(full->l_seq[i]);
+        }
+        parallel_slices(m, workers_for(m, threads, 4096), [&](int64_t a, int64_t b, int) {
+            for (int64_t k = a; k < b; k++) {
+                const int64_t i = s->index[k];
+                w(out->start)[k] = full->start[i]; w(out->end)[k] = full->end[i]; w(out->tlen)[k] = full->tlen[i];
+                const int32_t mt = full->mate[i];
+                int32_t nm = -1;
+                if (mt >= 0 && mt < full->n_segs) { // new index of the mate: its rank in the (sorted) selection
+                    auto it = std::lower_bound(s->index.begin(), s->index.end(), mt);
+                    if (it != s->index.end() && *it == mt) nm = (int32_t)(it - s->index.begin());
+                }
+                w(out->mate)[k] = nm;
+                w(out->qname)[k] = full->qname[i]; w(out->flag)[k] = full->flag[i]; w(out->l_seq)[k] = full->l_seq[i];
+                w(out->n_cigar)[k] = full->n_cigar[i]; w(out->mapq)[k] = full->mapq[i]; w(out->aux)[k] = full->aux[i];
+                memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
+                const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
+                memcpy(w(out->seq4) + ou[k] * UZ_SEQ4_UNIT_BYTES, full->seq4 + (size_t)src->uoff[i] * UZ_SEQ4_UNIT_BYTES, units * UZ_SEQ4_UNIT_BYTES);
+                memcpy(w(out->qlow) + ou[k] * UZ_QLOW_UNIT_BYTES, full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES, units * UZ_QLOW_UNIT_BYTES);
+                if (orig_index) orig_index[k] = (int32_t)i;
+            }
+        });
+    });
+}
+
+} // extern "C"

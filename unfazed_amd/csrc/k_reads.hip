@@ -17,27 +17,19 @@
 
 namespace {
 
-// K3a: per-record QC bits.  The only heavy part is counting the base qualities below the
-// threshold (151 bytes per record): a workgroup takes 256 consecutive records and walks their
-// quality rows as 16-byte chunks, consecutive lanes on consecutive chunks, so the loads are
-// full-width and coalesced (rows are 16-byte aligned); per-record counts are combined in LDS.
-// K3a: the quality / CIGAR pass over the records the batch can reach (about a third of the records inside
-// the DNM windows), marked in a byte map by k_mark_ranges.
-#ifndef UZ_QC_BATCH
-#define UZ_QC_BATCH 5
-#endif
+// K3a: per-record QC bits (goodread read_collector.py:28-53 and the two CIGAR counts of :190-203, :405-408) for
+// the records the batch can reach, marked in a byte map by k_mark_ranges.  With the packed format the count of
+// low-quality bases is a popcount over the record's qlow words (20 bytes for a 151-base read), so one lane
+// takes one record: two header words, the flag word, the first CIGAR word and the quality words are requested
+// together.
 // A block owns UZ_QC_SPAN consecutive records of the table: it compacts the ones the byte map marks into
-// an LDS list (ascending), then runs the quality / CIGAR pass over that list 256 records at a time.  No
-// global list, no global counter on the data path (count, when given, only feeds the profiling read-out).
+// an LDS list (ascending), then runs over that list 256 records at a time.  No global list, no global
+// counter on the data path (count, when given, only feeds the profiling read-out).
 #define UZ_QC_SPAN 4096
-__global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict__ need, int64_t n, int min_map_qual, int min_base_qual,
+__global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict__ need, int64_t n, int min_map_qual,
                                                 uint8_t *qc, unsigned int *count) {
     __shared__ int lst[UZ_QC_SPAN];
     __shared__ int wsum[4];
-    __shared__ int low[256];
-    __shared__ uint32_t row16[256]; // quality row offset (16-byte units) of each record of the round
-    __shared__ int len[256];        // bases to examine (0 for records without qualities)
-    __shared__ int maxch;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t base = (int64_t)blockIdx.x * UZ_QC_SPAN + (int64_t)t * 16;
     uint32_t w4[4] = {0, 0, 0, 0};
@@ -63,75 +55,50 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
     for (int k = 0; k < 16; k++)
         if ((((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0) && base + k < n) lst[o++] = (int32_t)(base + k);
     if (t == 0 && count && m) atomicAdd(count, (unsigned int)m);
-    const uint32_t thr = (uint32_t)(min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual));
-    for (int r0 = 0; r0 < m; r0 += 256) { // block-uniform
-        __syncthreads(); // lst complete (first round) / previous round done with low, row16, len, maxch
-        const bool wanted = r0 + t < m;
-        const int mine = wanted ? lst[r0 + t] : 0;
-        low[t] = 0;
-        if (t == 0) maxch = 0;
-        int ls = 0, ncg = 0, mq = 0;
-        uint32_t ro = 0, fl = 0, ax = UZ_AUX_DECODE_BAD, coff = 0;
-        if (wanted) { // every fixed-width field of the record in one round trip
-            ax = R.aux[mine]; fl = R.flag[mine]; mq = R.mapq[mine]; coff = R.cigar_off[mine]; ncg = R.n_cigar[mine];
-            ls = R.l_seq[mine]; ro = R.sq_off16[mine];
-            if (ax & UZ_AUX_DECODE_BAD) { ls = 0; ro = 0; }
+    __syncthreads();
+    const uint32_t *__restrict__ qw = reinterpret_cast<const uint32_t *>(R.qlow); // rows start on 4-byte units
+    for (int r0 = t; r0 < m; r0 += 256) {
+        const int mine = lst[r0];
+        const RecA A = R.ra[mine];
+        const RecB B = R.rb[mine];
+        const uint32_t fm = R.fm[mine];
+        const uint32_t ax = fm >> 24;
+        const int ncg = B.n_cigar, ls = (ax & UZ_AUX_DECODE_BAD) ? 0 : (int)B.l_seq;
+        const uint32_t c0 = ncg > 0 ? R.cigar[A.cigar_off] : 0u;
+        const int units = (int)UZ_ROW_UNITS(ls);
+        int low = 0;
+        // five words cover a 151-base read: requested together, longer reads loop on
+        uint32_t w[5];
+#pragma unroll
+        for (int u = 0; u < 5; u++) w[u] = u < units ? qw[(size_t)A.sq_off + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 5; u++) {
+            const int valid = ls - 32 * u;
+            uint32_t x = w[u];
+            if (valid < 32) x &= valid > 0 ? ((1u << valid) - 1u) : 0u;
+            low += __popc(x);
         }
-        // the first CIGAR operation (usually the only one) is requested now and used after the quality pass
-        const uint32_t c0 = (wanted && ncg > 0) ? R.cigar[coff] : 0u;
-        row16[t] = ro;
-        len[t] = ls;
-        int mc = (ls + 15) >> 4; // most chunks of any record of the round: wave maximum first, one LDS atomic per wave
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) { const int v = __shfl_xor(mc, s, 64); mc = v > mc ? v : mc; }
-        __syncthreads();
-        if (lane == 0 && mc) atomicMax(&maxch, mc);
-        __syncthreads();
-        const int nch = maxch;
-        // UZ_QC_BATCH independent 16-byte loads in flight per lane before any of them is counted
-        for (int j0 = 0; j0 < nch; j0 += UZ_QC_BATCH) {
-            uint4 v[UZ_QC_BATCH];
-            int rl[UZ_QC_BATCH], l[UZ_QC_BATCH];
-#pragma unroll
-            for (int u = 0; u < UZ_QC_BATCH; u++) {
-                const int it = t + 256 * (j0 + u);
-                rl[u] = it / nch;
-                const int ch = it - rl[u] * nch;
-                l[u] = (j0 + u < nch) ? len[rl[u]] - 16 * ch : 0;
-                v[u] = make_uint4(0, 0, 0, 0);
-                if (l[u] > 0) v[u] = *reinterpret_cast<const uint4 *>(R.qual + (((size_t)row16[rl[u]] + ch) << 4));
-            }
-#pragma unroll
-            for (int u = 0; u < UZ_QC_BATCH; u++) {
-                if (l[u] <= 0) continue;
-                const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                int c = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const uint32_t q = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                    c += (k < l[u]) & (q < thr);
-                }
-                if (c) atomicAdd(&low[rl[u]], c);
-            }
+        for (int u = 5; u < units; u++) {
+            const int valid = ls - 32 * u;
+            uint32_t x = qw[(size_t)A.sq_off + u];
+            if (valid < 32) x &= (1u << valid) - 1u;
+            low += __popc(x);
         }
-        __syncthreads();
-        if (wanted) {
-            int nonmatch = 0, none = 0;
-            if (ncg > 0) uz_cigar_op_counts(c0, nonmatch, none);
-            for (int k = 1; k < ncg; k++) uz_cigar_op_counts(R.cigar[coff + k], nonmatch, none);
-            qc[mine] = uz_seg_qc_combine(fl, ax, mq, min_map_qual, low[t], ncg, nonmatch, none);
-        }
+        int nonmatch = 0, none = 0;
+        if (ncg > 0) uz_cigar_op_counts(c0, nonmatch, none);
+        for (int k = 1; k < ncg; k++) uz_cigar_op_counts(R.cigar[A.cigar_off + k], nonmatch, none);
+        qc[mine] = uz_seg_qc_combine(fm & 0xFFFFu, ax, (int)((fm >> 16) & 0xFFu), min_map_qual, low, ncg, nonmatch, none);
     }
 }
 
 // Marks the records a batch can touch: every record of every fetch range and its mate.  Sixteen lanes per
 // range, on consecutive records (ranges are tens of records long).
-// For het-site ranges (rec_end != nullptr) records that end at or before the site are skipped: a fetch
+// For het-site ranges (spos != nullptr) records that end at or before the site are skipped: a fetch
 // range holds every record STARTING within max_span of the site, the kernel only registers those that
 // reach it (`end > pos`, phase B), so the others' QC bits are never read.
 __global__ __launch_bounds__(256) void k_mark_ranges(const int32_t *__restrict__ first, const int32_t *__restrict__ len_or_end,
-                                                     int end_stride, int64_t n_ranges, const int32_t *__restrict__ mate,
-                                                     uint8_t *need, const int32_t *__restrict__ rec_end,
+                                                     int end_stride, int64_t n_ranges, const RecA *__restrict__ ra,
+                                                     const RecB *__restrict__ rb, uint8_t *need,
                                                      const int32_t *__restrict__ spos, const int32_t *__restrict__ het_idx) {
     // sixteen lanes per range (a het-site range holds ~30 records): four ranges in flight per wave
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -140,11 +107,11 @@ __global__ __launch_bounds__(256) void k_mark_ranges(const int32_t *__restrict__
     // end_stride == 0: (first[w], len[w]); otherwise ranges are [first[w * stride], first[w * stride + 1])
     const int64_t a = end_stride ? first[w * end_stride] : first[w];
     const int64_t b = end_stride ? first[w * end_stride + 1] : a + len_or_end[w];
-    const int32_t hp = rec_end ? spos[het_idx[w]] : 0;
+    const int32_t hp = spos ? spos[het_idx[w]] : 0;
     for (int64_t i = a + lane; i < b; i += 16) {
-        if (rec_end && !(rec_end[i] > hp)) continue;
+        if (spos && !(ra[i].end > hp)) continue;
         need[i] = 1;
-        const int m = mate[i];
+        const int m = rb[i].mate;
         if (m >= 0) need[m] = 1;
     }
 }
@@ -204,31 +171,143 @@ struct PhaseState {
     int32_t n = 0;
 };
 
-__global__ void k_build_coarse(const int32_t *start, int64_t n, int32_t *coarse) {
+__global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((k << 12) < n) coarse[k] = start[k << 12];
+    if ((k << 12) < n) coarse[k] = ra[k << 12].start;
 }
 
-__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, const int32_t *start, const int32_t *end, const uint32_t *cigar_off,
-                                                  const uint32_t *sq_off16, const int32_t *mate, const uint32_t *qname,
-                                                  const uint16_t *l_seq, const uint16_t *n_cigar, const int32_t *tlen, RecA *ra,
-                                                  RecB *rb) {
+// ---- record headers from the staged columns -------------------------------------------------------------
+// cigar_off / sq_off are the exclusive prefix sums of n_cigar / UZ_ROW_UNITS(l_seq) over the records: block
+// sums, one scan of the block sums, then the pack kernel scans inside its block and writes the headers.
+#define UZ_PK_SPAN 4096
+__global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_t *__restrict__ n_cigar, const uint16_t *__restrict__ l_seq,
+                                                        unsigned long long *sums /* [2 nb] */) {
+    __shared__ unsigned long long part[2][4];
+    const int t = threadIdx.x;
+    unsigned long long a = 0, b = 0;
+    for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
+        const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
+        if (i < n) { a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    if ((t & 63) == 0) { part[0][t >> 6] = a; part[1][t >> 6] = b; }
+    __syncthreads();
+    if (t == 0) {
+        sums[2 * (size_t)blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        sums[2 * (size_t)blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    }
+}
+// one workgroup: exclusive scan of the block sums in place; the totals are checked against what the view declared
+__global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
+                                                        unsigned long long want_units, int32_t *hflags) {
+    __shared__ unsigned long long part[2][1024];
+    const int t = threadIdx.x;
+    const int64_t chunk = (nb + 1023) / 1024;
+    const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
+    unsigned long long a = 0, b = 0;
+    for (int64_t i = lo; i < hi; i++) { a += sums[2 * i]; b += sums[2 * i + 1]; }
+    part[0][t] = a; part[1][t] = b;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long ra = 0, rb = 0;
+        for (int k = 0; k < 1024; k++) {
+            const unsigned long long va = part[0][k], vb = part[1][k];
+            part[0][k] = ra; part[1][k] = rb;
+            ra += va; rb += vb;
+        }
+        if (ra != want_cigar || rb != want_units || ra > 0xFFFFFFFFULL || rb > 0xFFFFFFFFULL) hflags[0] = 1;
+    }
+    __syncthreads();
+    a = part[0][t]; b = part[1][t];
+    for (int64_t i = lo; i < hi; i++) {
+        const unsigned long long va = sums[2 * i], vb = sums[2 * i + 1];
+        sums[2 * i] = a; sums[2 * i + 1] = b;
+        a += va; b += vb;
+    }
+}
+__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
+                                                  uint32_t *fm) {
+    __shared__ uint32_t wsum[2][4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t run_a = (uint32_t)sums[2 * (size_t)blockIdx.x], run_b = (uint32_t)sums[2 * (size_t)blockIdx.x + 1];
+    for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
+        const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
+        const bool in = i < n;
+        const uint32_t nc = in ? c.n_cigar[i] : 0u, ls = in ? c.l_seq[i] : 0u;
+        const uint32_t va = nc, vb = UZ_ROW_UNITS(ls);
+        uint32_t ia = va, ib = vb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64);
+            if (lane >= o) { ia += ua; ib += ub; }
+        }
+        __syncthreads(); // wsum of the previous round has been read
+        if (lane == 63) { wsum[0][wv] = ia; wsum[1][wv] = ib; }
+        __syncthreads();
+        uint32_t pa = 0, pb = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            if (w < wv) { pa += wsum[0][w]; pb += wsum[1][w]; }
+            ta += wsum[0][w]; tb += wsum[1][w];
+        }
+        if (in) {
+            RecA A;
+            RecB B;
+            uz_pack_rec(A, B, c.start[i], c.end[i], run_a + pa + ia - va, run_b + pb + ib - vb, c.mate[i], c.qname[i], (uint16_t)ls,
+                        (uint16_t)nc, c.tlen[i]);
+            ra[i] = A;
+            rb[i] = B;
+            fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], c.aux[i]);
+        }
+        run_a += ta; run_b += tb;
+    }
+}
+
+// ---- ASCII uploads (uz_reads_upload): rows re-laid in the packed geometry ---------------------------------
+__global__ __launch_bounds__(256) void k_pack_ascii(int64_t n, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
+                                                    const uint32_t *__restrict__ cigar_in, const uint32_t *__restrict__ cigar_off_in,
+                                                    const uint8_t *__restrict__ seq_in, const uint32_t *__restrict__ sq_off16_in,
+                                                    uint32_t *cigar_out, uint8_t *seq4_out, int32_t *hflags) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    RecA A;
-    RecB B;
-    uz_pack_rec(A, B, start[i], end[i], cigar_off[i], sq_off16[i], mate[i], qname[i], l_seq[i], n_cigar[i], tlen[i]);
-    ra[i] = A;
-    rb[i] = B;
+    const RecA A = ra[i];
+    const RecB B = rb[i];
+    for (int k = 0; k < (int)B.n_cigar; k++) cigar_out[(size_t)A.cigar_off + k] = cigar_in[(size_t)cigar_off_in[i] + k];
+    const uint8_t *src = seq_in + ((size_t)sq_off16_in[i] << 4);
+    uint8_t *dst = seq4_out + (size_t)A.sq_off * UZ_SEQ4_UNIT_BYTES;
+    const int ls = B.l_seq, nb = (int)UZ_ROW_UNITS(ls) * UZ_SEQ4_UNIT_BYTES;
+    bool bad = false;
+    for (int b = 0; b < nb; b++) {
+        uint32_t hi = 0, lo = 0;
+        if (2 * b < ls) { hi = uz_ascii_nt16(src[2 * b]); bad |= hi == 0xFFu; }
+        if (2 * b + 1 < ls) { lo = uz_ascii_nt16(src[2 * b + 1]); bad |= lo == 0xFFu; }
+        dst[b] = (uint8_t)(((hi & 15u) << 4) | (lo & 15u));
+    }
+    if (bad) hflags[0] = 2;
+}
+__global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
+                                                    const uint8_t *__restrict__ qual8, const uint32_t *__restrict__ qual_off16, int thr,
+                                                    uint8_t *qlow) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const RecA A = ra[i];
+    const int ls = rb[i].l_seq;
+    const uint8_t *src = qual8 + ((size_t)qual_off16[i] << 4);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(qlow) + (size_t)A.sq_off;
+    const int units = (int)UZ_ROW_UNITS(ls);
+    for (int u = 0; u < units; u++) {
+        uint32_t w = 0;
+        for (int k = 0; k < 32 && 32 * u + k < ls; k++) w |= (uint32_t)((int)src[32 * u + k] < thr) << k;
+        dst[u] = w;
+    }
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
-    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b;
+    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
-    R.start = r.start; R.end = r.end; R.flag = r.flag; R.mapq = r.mapq; R.aux = r.aux; R.tlen = r.tlen;
-    R.qname = r.qname; R.mate = r.mate; R.cigar_off = r.cigar_off; R.n_cigar = r.n_cigar; R.cigar = r.cigar;
-    R.l_seq = r.l_seq; R.sq_off16 = r.sq_off16; R.seq = r.seq; R.qual = r.qual; R.qc = r.qc; R.coarse = r.coarse;
+    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qc = r.qc; R.coarse = r.coarse;
     return R;
 }
 
@@ -240,27 +319,41 @@ int next_pow2(long long v) {
 
 } // namespace
 
-void uz_build_rec_headers(uz_ctx *c, ReadsDev &r) {
-    static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "packed record headers are two 16-byte words");
-    UZ_HIP(hipMalloc(&r.rec_a, ((size_t)r.n + 4) * sizeof(RecA)));
-    UZ_HIP(hipMalloc(&r.rec_b, ((size_t)r.n + 4) * sizeof(RecB)));
-    if (r.n > 0) {
-        hipLaunchKernelGGL(k_pack_rec, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, c->stream, (int64_t)r.n,
-                           (const int32_t *)r.start, (const int32_t *)r.end, (const uint32_t *)r.cigar_off,
-                           (const uint32_t *)r.sq_off16, (const int32_t *)r.mate, (const uint32_t *)r.qname,
-                           (const uint16_t *)r.l_seq, (const uint16_t *)r.n_cigar, (const int32_t *)r.tlen, (RecA *)r.rec_a,
-                           (RecB *)r.rec_b);
-        UZ_HIP(hipGetLastError());
-    }
+size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * 2 * sizeof(unsigned long long); }
+
+void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col, void *off_scratch) {
+    static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
+    if (r.n <= 0) return;
+    const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
+    unsigned long long *sums = (unsigned long long *)off_scratch;
+    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, sums);
+    hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
+                       (unsigned long long)r.n_row_units, c->hflags);
+    hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
+                       (RecB *)r.rec_b, r.fm);
+    const int64_t nk = (r.n >> 12) + 2;
+    hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
+    UZ_HIP(hipGetLastError());
 }
 
-void uz_build_coarse(uz_ctx *c, ReadsDev &r) {
-    const int64_t nk = (r.n >> 12) + 2;
-    UZ_HIP(hipMalloc((void **)&r.coarse, (size_t)nk * sizeof(int32_t)));
+void uz_pack_ascii_rows(uz_ctx *c, hipStream_t st, ReadsDev &r, const uint32_t *cigar_in, const uint32_t *cigar_off_in,
+                        const uint8_t *seq_in, const uint32_t *sq_off16_in, uint32_t *cigar_out, uint8_t *seq4_out) {
+    if (r.n <= 0) return;
+    hipLaunchKernelGGL(k_pack_ascii, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, (const RecA *)r.rec_a,
+                       (const RecB *)r.rec_b, cigar_in, cigar_off_in, seq_in, sq_off16_in, cigar_out, seq4_out, c->hflags);
+    UZ_HIP(hipGetLastError());
+}
+
+void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual) {
+    const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
     if (r.n > 0) {
-        hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, c->stream, r.start, r.n, r.coarse);
+        hipLaunchKernelGGL(k_build_qlow, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, (const RecA *)r.rec_a,
+                           (const RecB *)r.rec_b, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow);
         UZ_HIP(hipGetLastError());
     }
+    r.qlow_thr = min_base_qual;
+    r.qlow_valid = true;
+    r.qc_valid = false;
 }
 
 void uz_phase_state_free(uz_ctx *c) {
@@ -286,6 +379,19 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     st->have_lists = false;
     c->phase_n = n;
     if (n <= 0) { c->phase_valid = true; return; }
+    // an asynchronous upload of this table must have landed before the first kernel reads it
+    if (r.pending) {
+        UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0));
+        r.pending = false;
+    }
+    // the quality plane holds ONE threshold: tables that kept their full qualities are re-thresholded, the others
+    // were decoded for a threshold and refuse another
+    if (!r.qlow_valid || r.qlow_thr != c->P.min_gt_qual) {
+        UZ_REQUIRE(r.qual8 != nullptr, UZ_E_STATE,
+                   "the reads table was packed for --min-gt-qual " + std::to_string(r.qlow_thr) + ", the parameters say " +
+                       std::to_string(c->P.min_gt_qual) + ": decode it again for this threshold");
+        uz_build_qlow(c, c->stream, r, c->P.min_gt_qual);
+    }
 
     PhaseArgs a;
     memset(&a, 0, sizeof(a));
@@ -332,18 +438,24 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n + 64, c->stream));
         const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
         hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 16 + 255) / 256)), dim3(256), 0, c->stream,
-                           (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const int32_t *)r.mate,
-                           r.need, (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr);
+                           (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const RecA *)r.rec_a,
+                           (const RecB *)r.rec_b, r.need, (const int32_t *)nullptr, (const int32_t *)nullptr);
         UZ_HIP(hipGetLastError());
         if (!c->P.no_extended && c->n_het > 0) {
             hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 16 + 255) / 256)), dim3(256), 0, c->stream,
                                (const int32_t *)st->pre_ha.p, (const int32_t *)st->pre_hl.p, 0, (int64_t)c->n_het,
-                               (const int32_t *)r.mate, r.need, (const int32_t *)r.end, (const int32_t *)s.pos,
+                               (const RecA *)r.rec_a, (const RecB *)r.rec_b, r.need, (const int32_t *)s.pos,
                                (const int32_t *)c->het_idx.p);
             UZ_HIP(hipGetLastError());
         }
     }
     UZ_HIP(hipEventSynchronize(st->bounds_ready)); // the copy only: the marking kernels keep running
+    if (c->hflags[0]) { // set by the header build of an upload (abi.hip) whose commands have now run
+        const int f = c->hflags[0];
+        c->hflags[0] = 0;
+        throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
+                                         : "n_cigar_total / n_row_units of the reads view do not match its columns"};
+    }
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
     for (int32_t d = 0; d < n; d++) {
         const int32_t *b = &bh[(size_t)5 * d];
@@ -407,7 +519,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             ProfScope ps2(c, UZ_K_SEG_QC_PASS);
             UZ_TRACE("k_seg_qc");
             hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((r.n + UZ_QC_SPAN - 1) / UZ_QC_SPAN)), dim3(256), 0, c->stream, make_rd(r),
-                               (const uint8_t *)r.need, (int64_t)r.n, c->P.min_map_qual, c->P.min_gt_qual, r.qc,
+                               (const uint8_t *)r.need, (int64_t)r.n, c->P.min_map_qual, r.qc,
                                c->prof_on ? st->need_count.p : (unsigned int *)nullptr);
             UZ_HIP(hipGetLastError());
         }

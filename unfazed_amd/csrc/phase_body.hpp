@@ -17,6 +17,7 @@
 // (file names relative to reference unfazed/; read_collector.py unless stated)
 #pragma once
 #include "uz_types.h"
+#include "pack.hpp"
 #include "wg.hpp"
 
 // Diagnostic build only (-DUZ_PHASE_TIMING): lane 0 adds the shader-clock ticks spent between
@@ -53,38 +54,33 @@
 #ifdef UZ_EMU_STATS
 extern "C" long long uz_emu_stats[16];
 #endif
-// Packed per-record headers (built once from the columns when a reads table is uploaded / adopted):
-// the per-DNM kernel GATHERS records (mates, last registrations, init elements), and a gather that finds
-// start / end / offsets / lengths in one or two 16-byte words touches one or two cache lines instead
-// of five to eight.  The streaming kernels keep reading the plain columns.
-struct RecA { int32_t start, end; uint32_t cigar_off, sq_off16; };
+// Record headers: the form the fixed-width fields of the staged columns (uz_reads_packed_view) take in HBM,
+// built on the device when a table is uploaded / adopted.  The per-DNM kernel GATHERS records (mates, last
+// registrations, init elements), and a gather that finds start / end / offsets / lengths in one or two
+// 16-byte words touches one or two cache lines instead of five to eight.  cigar_off / sq_off are the prefix
+// sums of n_cigar / UZ_ROW_UNITS(l_seq) (rows and CIGAR words lie back to back in record order).
+struct RecA { int32_t start, end; uint32_t cigar_off, sq_off; }; // sq_off in row units (32 bases)
 struct RecB { int32_t mate; uint32_t qname; uint16_t l_seq, n_cigar; int32_t tlen; };
-UZ_HD void uz_pack_rec(RecA &A, RecB &B, int32_t start, int32_t end, uint32_t cigar_off, uint32_t sq_off16, int32_t mate,
+UZ_HD void uz_pack_rec(RecA &A, RecB &B, int32_t start, int32_t end, uint32_t cigar_off, uint32_t sq_off, int32_t mate,
                        uint32_t qname, uint16_t l_seq, uint16_t n_cigar, int32_t tlen) {
-    A.start = start; A.end = end; A.cigar_off = cigar_off; A.sq_off16 = sq_off16;
+    A.start = start; A.end = end; A.cigar_off = cigar_off; A.sq_off = sq_off;
     B.mate = mate; B.qname = qname; B.l_seq = l_seq; B.n_cigar = n_cigar; B.tlen = tlen;
 }
+// flag | mapq << 16 | aux << 24
+UZ_HD uint32_t uz_pack_fm(uint32_t flag, uint32_t mapq, uint32_t aux) { return (flag & 0xFFFFu) | ((mapq & 0xFFu) << 16) | ((aux & 0xFFu) << 24); }
 
-struct RD { // alignment-record columns (device pointers)
+struct RD { // alignment records of one table (device pointers)
     const RecA *ra;
     const RecB *rb;
+    const uint32_t *fm; // flag | mapq << 16 | aux << 24
     const int64_t *contig_off;
     const int32_t *max_span;
     int32_t n_contigs;
-    const int32_t *start, *end;
-    const uint16_t *flag;
-    const uint8_t *mapq, *aux;
-    const int32_t *tlen;
-    const uint32_t *qname;
-    const int32_t *mate;
-    const uint32_t *cigar_off;
-    const uint16_t *n_cigar;
-    const uint32_t *cigar;
-    const uint16_t *l_seq;
-    const uint32_t *sq_off16;
-    const uint8_t *seq, *qual;
+    const uint32_t *cigar; // BAM encoding, back to back in record order
+    const uint8_t *seq4;   // 4-bit bases, 16 bytes per row unit
+    const uint8_t *qlow;   // 1 bit per base (quality below the threshold), 4 bytes per row unit
     const uint8_t *qc;
-    const int32_t *coarse; // start[] of every 4096th record (L2-resident search index), may be null
+    const int32_t *coarse; // start of every 4096th record (L2-resident search index), may be null
 };
 
 struct Caps { // per-workgroup scratch capacities (elements)
@@ -234,6 +230,14 @@ UZ_DEV long long uz_lower_bound(const int32_t *a, long long lo, long long hi, lo
     }
     return lo;
 }
+// the same over the start field of the record headers
+UZ_DEV long long uz_lower_bound_start(const RecA *ra, long long lo, long long hi, long long v) {
+    while (lo < hi) {
+        const long long mid = lo + ((hi - lo) >> 1);
+        if ((long long)ra[mid].start < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 
 // lower bound on the start column with the first steps taken on the coarse index: a plain binary
 // search over a 1 GB column is ~25 dependent HBM misses; the index keeps all but the last dozen in L2.
@@ -249,7 +253,7 @@ UZ_DEV long long uz_lower_bound_c(const RD &R, long long lo, long long hi, long 
         const long long nhi = a < kh ? (a << 12) : hi;
         lo = nlo; hi = nhi;
     }
-    return uz_lower_bound(R.start, lo, hi, v);
+    return uz_lower_bound_start(R.ra, lo, hi, v);
 }
 
 // pysam fetch(contig, lo, hi): candidates are records with start in [lo - max_span, hi);
@@ -263,8 +267,8 @@ UZ_DEV void uz_fetch_range(const RD &R, int tid, long long lo, long long hi, lon
 // the same inside a record range [wa, wb) already known to contain the answer (the DNM's window)
 UZ_DEV void uz_fetch_range_in(const RD &R, int tid, long long wa, long long wb, long long lo, long long hi, long long &a, long long &b) {
     if (tid < 0 || tid >= R.n_contigs) { a = b = 0; return; }
-    a = uz_lower_bound(R.start, wa, wb, lo - R.max_span[tid]);
-    b = uz_lower_bound(R.start, a, wb, hi);
+    a = uz_lower_bound_start(R.ra, wa, wb, lo - R.max_span[tid]);
+    b = uz_lower_bound_start(R.ra, a, wb, hi);
 }
 // record range covering every fetch of one DNM: the DNM position and all of its het sites
 UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &wb) {
@@ -280,36 +284,26 @@ UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &w
 }
 
 // index of `pos` in get_reference_positions(full_length=True), -1 if absent
-UZ_DEV int uz_qidx(const RD &R, int seg, long long pos) {
-    const uint32_t *c = R.cigar + R.cigar_off[seg];
-    long long r = R.start[seg];
-    int q = 0;
-    const int nc = R.n_cigar[seg];
-    for (int k = 0; k < nc; k++) {
-        const int op = c[k] & 15, l = (int)(c[k] >> 4);
-        if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X) {
-            if (pos >= r && pos < r + l) return q + (int)(pos - r);
-            q += l; r += l;
-        } else if (op == UZ_OP_I || op == UZ_OP_S) q += l;
-        else if (op == UZ_OP_D || op == UZ_OP_N) r += l;
-    }
-    return -1;
-}
 // The fixed-width fields a base lookup needs, fetched together (one memory round trip) before the
 // CIGAR walk instead of one by one along it.
 struct SegHdr {
     int32_t start, end, n_cigar, l_seq;
-    uint32_t cigar_off, sq_off16;
+    uint32_t cigar_off, sq_off;
 };
 UZ_DEV SegHdr uz_hdr(const RD &R, int seg) {
     const RecA A = R.ra[seg];
     const RecB B = R.rb[seg];
     SegHdr h;
     h.start = A.start; h.end = A.end; h.n_cigar = B.n_cigar; h.l_seq = B.l_seq;
-    h.cigar_off = A.cigar_off; h.sq_off16 = A.sq_off16;
+    h.cigar_off = A.cigar_off; h.sq_off = A.sq_off;
     return h;
 }
 UZ_DEV int uz_qidx_h(const RD &R, const SegHdr &h, long long pos) {
+    // one operation spanning the whole read and as many reference bases as read bases can only be M / = / X
+    // (the only operations that consume both; l_seq > 1 because an operation without reference bases still
+    // gives end = start + 1): the index follows from the header, no CIGAR word is fetched
+    if (h.n_cigar == 1 && h.l_seq > 1 && h.end - h.start == h.l_seq)
+        return (pos >= h.start && pos < h.end) ? (int)(pos - h.start) : -1;
     const uint32_t *c = R.cigar + h.cigar_off;
     long long r = h.start;
     int q = 0;
@@ -323,34 +317,36 @@ UZ_DEV int uz_qidx_h(const RD &R, const SegHdr &h, long long pos) {
     }
     return -1;
 }
+UZ_DEV int uz_qidx(const RD &R, int seg, long long pos) { return uz_qidx_h(R, uz_hdr(R, seg), pos); }
 UZ_DEV int uz_refpos_len(const RD &R, int seg) {
-    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    const uint32_t *c = R.cigar + R.ra[seg].cigar_off;
     int q = 0;
-    const int nc = R.n_cigar[seg];
+    const int nc = R.rb[seg].n_cigar;
     for (int k = 0; k < nc; k++) {
         const int op = c[k] & 15, l = (int)(c[k] >> 4);
         if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X || op == UZ_OP_I || op == UZ_OP_S) q += l;
     }
     return q;
 }
-UZ_DEV const uint8_t *uz_qual(const RD &R, int seg) { return R.qual + ((size_t)R.sq_off16[seg] << 4); }
+UZ_DEV uint8_t uz_base(const RD &R, uint32_t sq_off, int k) { return uz_seq4_base(R.seq4, sq_off, k); }
+UZ_DEV bool uz_qual_low(const RD &R, uint32_t sq_off, int k) { return uz_qlow_bit(R.qlow, sq_off, k) != 0; }
 
-// get_allele_at :56-73 -> pointer to n bases or nullptr (False)
-UZ_DEV const uint8_t *uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n) {
+// get_allele_at :56-73 -> the n bases start at query index `idx` of the row `sq_off`; false = the reference's False
+UZ_DEV bool uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n, uint32_t &sq_off, int &idx) {
     const SegHdr hr = uz_hdr(R, read), hm = uz_hdr(R, mate >= 0 ? mate : read); // both requested up front
     const int i = uz_qidx_h(R, hr, pos);
     if (i >= 0) {
-        if (i < 4 || i > readlen - 4) return nullptr;
-        if (hr.l_seq > i + n) return R.seq + ((size_t)hr.sq_off16 << 4) + i;
-        return nullptr; // the mate is not consulted (quirk Q10)
+        if (i < 4 || i > readlen - 4) return false;
+        if (hr.l_seq > i + n) { sq_off = hr.sq_off; idx = i; return true; }
+        return false; // the mate is not consulted (quirk Q10)
     } else if (mate >= 0) {
         const int j = uz_qidx_h(R, hm, pos);
         if (j >= 0) {
-            if (j < 4 || j > readlen - 4) return nullptr;
-            if (hm.l_seq > j + n) return R.seq + ((size_t)hm.sq_off16 << 4) + j;
+            if (j < 4 || j > readlen - 4) return false;
+            if (hm.l_seq > j + n) { sq_off = hm.sq_off; idx = j; return true; }
         }
     }
-    return nullptr;
+    return false;
 }
 
 // binary_search (site_searcher.py:6-47): the result list is [qp, qp+1..R, qp-1..L]; returns its length
@@ -410,33 +406,34 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long l
     const int mate = uz_pair_ok(R, a, seg);
     if (mate < 0) return 0;
     if (ref_len == alt_len) { // snv_match_alleles :296-336
-        const uint8_t *al = uz_allele_at(R, a.readlen, seg, mate, position, ref_len);
-        if (!al) return 0;
+        uint32_t row = 0;
+        int at = 0;
+        if (!uz_allele_at(R, a.readlen, seg, mate, position, ref_len, row, at)) return 0;
         bool eq = true;
-        for (int k = 0; k < ref_len; k++) eq &= al[k] == ref[k];
+        for (int k = 0; k < ref_len; k++) eq &= uz_base(R, row, at + k) == ref[k];
         if (eq) return 1;
         eq = true;
-        for (int k = 0; k < alt_len; k++) eq &= al[k] == alt[k];
+        for (int k = 0; k < alt_len; k++) eq &= uz_base(R, row, at + k) == alt[k];
         return eq ? 2 : 0;
     }
     // indel_match_alleles :266-293
     const int var_len = ref_len > alt_len ? ref_len : alt_len;
-    const int rp = uz_qidx(R, seg, position);
+    const SegHdr hs = uz_hdr(R, seg);
+    const int rp = uz_qidx_h(R, hs, position);
     if (rp < 0) return 0;
-    const uint32_t *c = R.cigar + R.cigar_off[seg];
+    const uint32_t *c = R.cigar + hs.cigar_off;
     bool has_id = false;
     int oi = 0;
-    const int nc = R.n_cigar[seg];
+    const int nc = hs.n_cigar;
     for (int k = 0; k < nc && oi < rp + var_len; k++) { // per-op expansion indexed by the query index (quirk Q16)
         const int op = c[k] & 15, l = (int)(c[k] >> 4);
         const int a0 = oi > rp ? oi : rp, a1 = (oi + l) < (rp + var_len) ? (oi + l) : (rp + var_len);
         if (a0 < a1 && (op == UZ_OP_I || op == UZ_OP_D)) has_id = true;
         oi += l;
     }
-    const uint8_t *ql = uz_qual(R, seg);
-    const int ls = R.l_seq[seg];
+    const int ls = hs.l_seq;
     for (int k = rp; k < rp + var_len && k < ls; k++)
-        if ((int)ql[k] < a.min_gt_qual) return 0;
+        if (uz_qual_low(R, hs.sq_off, k)) return 0;
     if (has_id) return 2;
     if (7 < rp && rp < uz_refpos_len(R, seg) - 7) return 1;
     return 0;
@@ -447,13 +444,15 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long l
 // clipped read), 3 the record bans its query name (:520-522)
 UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long position, long long lo, long long sv_start,
                           long long sv_end) {
-    if (!((long long)R.end[i] > lo)) return 0;
+    const RecA A = R.ra[i];
+    const RecB B = R.rb[i];
+    if (!((long long)A.end > lo)) return 0;
     if (!(R.qc[i] & UZ_QC_GOOD_DISC)) return 0;  // goodread(read, True) :503
-    const int mate = R.mate[i];                  // :507-510
+    const int mate = B.mate;                     // :507-510
     if (mate < 0) return 0;
     if (!(R.qc[mate] & UZ_QC_GOOD_DISC)) return 0; // :512
-    const uint32_t *c = R.cigar + R.cigar_off[i];
-    const int nc = R.n_cigar[i];
+    const uint32_t *c = R.cigar + A.cigar_off;
+    const int nc = B.n_cigar;
     long long total = 0;
     for (int k = 0; k < nc; k++) total += (long long)(c[k] >> 4);
     int start_m = 0, end_m = 0, lead = 0, trail = 0;
@@ -483,12 +482,12 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long posi
         }
     }
     if (end_m < 7 && start_m < 7) return 3;
-    const long long rs = R.start[i], re = R.end[i];
-    if (R.aux[i] & UZ_AUX_HAS_SA) { // :524-533
+    const long long rs = A.start, re = A.end;
+    if ((R.fm[i] >> 24) & UZ_AUX_HAS_SA) { // :524-533
         const long long m = a.split_error_margin;
         return ((position - m <= rs && rs <= position + m) || (position - m <= re && re <= position + m)) ? 1 : 0;
     }
-    long long ins = (long long)R.tlen[i] - 2LL * a.readlen;
+    long long ins = (long long)B.tlen - 2LL * a.readlen;
     if (ins < 0) ins = -ins;
     const double var_len = (double)sv_end - (double)sv_start < 0 ? (double)sv_start - (double)sv_end : (double)sv_end - (double)sv_start;
     bool disc = (double)ins > a.cutoff;
@@ -498,7 +497,7 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long posi
         disc = 0.7 < ratio && ratio < 1.3; // :534-536
     }
     if (disc) {
-        const long long ms = R.start[mate];
+        const long long ms = R.ra[mate].start;
         const long long left0 = ms < rs ? ms : rs, right0 = ms > rs ? ms : rs;
         const long long wig = (long long)a.cutoff; // :551
         return ((sv_start - wig) < left0 && left0 < (sv_start + wig) && (sv_end - wig) < right0 && right0 < (sv_end + wig)) ? 2 : 0;
@@ -586,7 +585,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 int32_t *L = cl == 1 ? s.LR : s.LA;
                 const int k = cl == 1 ? s.a_flag0[i] : s.a_flag1[i];
                 L[2 * k] = (int)(fa + i);
-                L[2 * k + 1] = R.mate[fa + i];
+                L[2 * k + 1] = R.rb[fa + i].mate;
             }
         }
         WG_SYNC();
@@ -611,7 +610,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 const int k = s.a_flag0[t];
                 const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
                 s.i_qp[k] = t;
-                s.i_L[k] = (int32_t)R.qname[i];
+                s.i_L[k] = (int32_t)R.rb[i].qname;
             }
         }
         WG_SYNC();
@@ -619,7 +618,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             int code = s.a_cls[t];
             if (code == 1 || code == 2) {
                 const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
-                const int32_t q = (int32_t)R.qname[i];
+                const int32_t q = (int32_t)R.rb[i].qname;
                 for (int k = 0; k < nban; k++) {
                     const int tb = s.i_qp[k];
                     if (tb < t && ((tb >= n0) == (t >= n0)) && s.i_L[k] == q) { code = 0; break; }
@@ -634,14 +633,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             if (code) {
                 const int i = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
                 const int k = s.a_flag1[t];
-                const int m = R.mate[i];
+                const int m = R.rb[i].mate;
                 s.LR[k] = code == 1 ? i : m;      // :532-533
                 s.LR[k + 1] = code == 1 ? m : i;  // :562-563, :585-586
             }
         }
         WG_SYNC();
         WG_FOR(k, nsup) { // :588-591 filter by the names banned at the LAST breakpoint only
-            const int32_t q = (int32_t)R.qname[s.LR[k]];
+            const int32_t q = (int32_t)R.rb[s.LR[k]].qname;
             int keep = 1;
             for (int j = 0; j < nban; j++)
                 if (s.i_qp[j] >= n0 && s.i_L[j] == q) { keep = 0; break; }
@@ -917,16 +916,16 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                     const int i = uz_qidx_h(R, h0, hp);
                     if (i >= 0) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
                         if (i >= 4 && i <= a.readlen - 4 && h0.l_seq > i + 1) {
-                            const size_t at = ((size_t)h0.sq_off16 << 4) + (size_t)i;
-                            const uint8_t al = R.seq[at], ql = R.qual[at];
+                            const uint8_t al = uz_base(R, h0.sq_off, i);
+                            const bool low = uz_qual_low(R, h0.sq_off, i);
                             if (al == s.href[h] || al == s.halt[h]) fbv = al; // :98-105
-                            if (seq < E && (int)ql >= a.min_gt_qual) cb = al; // :114-124
+                            if (seq < E && !low) cb = al;                     // :114-124
                         }
                     } else if (f1 >= 0) {
                         const SegHdr h1 = uz_hdr(R, f1);
                         const int j = uz_qidx_h(R, h1, hp);
                         if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) {
-                            const uint8_t al = R.seq[((size_t)h1.sq_off16 << 4) + (size_t)j];
+                            const uint8_t al = uz_base(R, h1.sq_off, j);
                             if (al == s.href[h] || al == s.halt[h]) fbv = al;
                         }
                     }
@@ -1092,7 +1091,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         for (int ci = L; ci <= Rr; ci++) {
             const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
             if (rp < 0 || rp >= hd.l_seq) continue;
-            const uint8_t b = R.seq[((size_t)hd.sq_off16 << 4) + (size_t)rp];
+            const uint8_t b = uz_base(R, hd.sq_off, rp);
             bool from_ref;
             if (b == s.cref[ci]) from_ref = true;       // :41-42
             else if (b == s.calt[ci]) from_ref = false; // :43-44
@@ -1256,22 +1255,33 @@ UZ_DEV uint8_t uz_seg_qc_combine(uint32_t f, uint32_t aux, int mapq, int min_map
     if (none <= 5) qc |= UZ_QC_NONE5;
     return qc;
 }
-UZ_DEV uint8_t uz_seg_qc_flags(const RD &R, int seg, int min_map_qual, int low) {
-    const uint32_t f = R.flag[seg];
-    const uint32_t aux = R.aux[seg];
-    if (aux & UZ_AUX_DECODE_BAD) return 0;
-    const uint32_t *c = R.cigar + R.cigar_off[seg];
-    const int nc = R.n_cigar[seg];
-    int nonmatch = 0, none = 0;
-    for (int k = 0; k < nc; k++) uz_cigar_op_counts(c[k], nonmatch, none);
-    return uz_seg_qc_combine(f, aux, (int)R.mapq[seg], min_map_qual, low, nc, nonmatch, none);
-}
-UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual, int min_base_qual) {
+// number of bases of a row whose quality is below the threshold: the set bits of its qlow words up to l_seq
+UZ_DEV int uz_row_low_count(const RD &R, uint32_t sq_off, int l_seq) {
     int low = 0;
-    if (!(R.aux[seg] & UZ_AUX_DECODE_BAD)) {
-        const uint8_t *q = uz_qual(R, seg);
-        const int ls = R.l_seq[seg];
-        for (int k = 0; k < ls; k++) low += (int)q[k] < min_base_qual; // :43-46
+    const uint32_t units = UZ_ROW_UNITS(l_seq);
+    for (uint32_t u = 0; u < units; u++) {
+        const uint8_t *b = R.qlow + (size_t)(sq_off + u) * UZ_QLOW_UNIT_BYTES;
+        uint32_t w = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
+        const int valid = l_seq - 32 * (int)u;
+        if (valid < 32) w &= (1u << valid) - 1u;
+#ifdef UZ_EMU
+        low += __builtin_popcount(w);
+#else
+        low += __popc(w);
+#endif
     }
-    return uz_seg_qc_flags(R, seg, min_map_qual, low);
+    return low;
+}
+// whole QC byte of one record, sequentially (the CPU twin and small tables; K3a proper is k_seg_qc)
+UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual) {
+    const RecA A = R.ra[seg];
+    const RecB B = R.rb[seg];
+    const uint32_t fm = R.fm[seg];
+    const uint32_t aux = fm >> 24;
+    if (aux & UZ_AUX_DECODE_BAD) return 0;
+    const uint32_t *c = R.cigar + A.cigar_off;
+    int nonmatch = 0, none = 0;
+    for (int k = 0; k < (int)B.n_cigar; k++) uz_cigar_op_counts(c[k], nonmatch, none);
+    const int low = uz_row_low_count(R, A.sq_off, B.l_seq); // :43-46
+    return uz_seg_qc_combine(fm & 0xFFFFu, aux, (int)((fm >> 16) & 0xFFu), min_map_qual, low, B.n_cigar, nonmatch, none);
 }

@@ -69,31 +69,37 @@ struct FamilyDev {
     uz_params cls_params;
 };
 
+// one device allocation out of the context's pool (tables come and go every staged pass: hipFree
+// synchronises the device, so freed blocks are parked and handed out again)
+struct DevBlock {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+};
+
 struct ReadsDev {
-    bool live = false, owned = false;
+    bool live = false;
     int64_t n = 0;
     int32_t n_contigs = 0;
     uint32_t n_qnames = 0;
-    int64_t n_cigar_total = 0, n_sq_bytes = 0;
+    int64_t n_cigar_total = 0, n_row_units = 0;
+    DevBlock block;            // everything the library owns for this table lives in this one block
     int64_t *contig_off = nullptr;
     int32_t *max_span = nullptr;
-    int32_t *start = nullptr, *end = nullptr;
-    uint16_t *flag = nullptr;
-    uint8_t *mapq = nullptr, *aux = nullptr;
-    int32_t *tlen = nullptr;
-    uint32_t *qname = nullptr;
-    int32_t *mate = nullptr;
-    uint32_t *cigar_off = nullptr;
-    uint16_t *n_cigar = nullptr;
-    uint32_t *cigar = nullptr;
-    uint16_t *l_seq = nullptr;
-    uint32_t *sq_off16 = nullptr;
-    uint8_t *seq = nullptr, *qual = nullptr;
-    // K3a output: per-segment QC bits for the parameters in qc_params
-    uint8_t *qc = nullptr;
-    uint8_t *need = nullptr; // records reachable by the current batch (lazy K3a)
-    void *rec_a = nullptr, *rec_b = nullptr; // packed 16-byte record headers for the gathers of k_phase (RecA / RecB)
-    int32_t *coarse = nullptr; // start[] of every 4096th record
+    void *rec_a = nullptr, *rec_b = nullptr; // RecA / RecB headers (phase_body.hpp)
+    uint32_t *fm = nullptr;    // flag | mapq << 16 | aux << 24
+    const uint32_t *cigar = nullptr;
+    const uint8_t *seq4 = nullptr;
+    uint8_t *qlow = nullptr;   // caller's memory for adopted tables (then never written)
+    int32_t qlow_thr = 0;      // threshold the qlow plane holds
+    bool qlow_valid = false;
+    // ASCII uploads (uz_reads_upload) keep the full qualities so that the plane can be rebuilt for another threshold
+    uint8_t *qual8 = nullptr;
+    uint32_t *qual_off16 = nullptr;
+    uint8_t *qc = nullptr;     // K3a output: per-record QC bits for the parameters in qc_params
+    uint8_t *need = nullptr;   // records reachable by the current batch (lazy K3a)
+    int32_t *coarse = nullptr; // start of every 4096th record
+    hipEvent_t ready = nullptr; // asynchronous uploads: recorded behind the last command of the upload
+    bool pending = false;
     bool qc_valid = false;
     uz_params qc_params;
 };
@@ -120,7 +126,10 @@ struct ProfPending {
 
 struct uz_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // compute (and the synchronous uploads)
+    hipStream_t copy_stream = nullptr; // asynchronous uploads of packed tables: H2D + header build
+    int32_t *hflags = nullptr;         // pinned, device-visible: [0] upload consistency error (totals / alphabet)
+    std::vector<DevBlock> block_pool;
     uz_params P;
     std::string err;
     std::vector<SitesDev> sites;
@@ -173,8 +182,26 @@ struct ProfScope {
     ~ProfScope() { uz_prof_end(c, k, a, b); }
 };
 
+// device block pool (abi.hip)
+DevBlock uz_block_get(uz_ctx *c, size_t bytes);
+void uz_block_put(uz_ctx *c, DevBlock b);
+
+// the fixed-width columns of a table as DEVICE pointers (staged by an upload, or the caller's for an adopted table)
+struct RecColumns {
+    const int32_t *start, *end, *tlen, *mate;
+    const uint32_t *qname;
+    const uint16_t *flag, *l_seq, *n_cigar;
+    const uint8_t *mapq, *aux;
+};
 // stage launchers
-void uz_build_rec_headers(uz_ctx *c, ReadsDev &r);
+// offsets (prefix sums of n_cigar / row units), RecA / RecB / fm and the coarse index, on stream `st`;
+// off_scratch: >= uz_rec_scratch_bytes(n) bytes of device memory
+size_t uz_rec_scratch_bytes(int64_t n);
+void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col, void *off_scratch);
+// ASCII upload: CIGAR words gathered back to back, bases packed to 4 bits (sets hflags[0] on a character outside the alphabet)
+void uz_pack_ascii_rows(uz_ctx *c, hipStream_t st, ReadsDev &r, const uint32_t *cigar_in, const uint32_t *cigar_off_in,
+                        const uint8_t *seq_in, const uint32_t *sq_off16_in, uint32_t *cigar_out, uint8_t *seq4_out);
+void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual);
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool host_offsets = true);

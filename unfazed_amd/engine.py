@@ -18,7 +18,8 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_reads_upload",
+    "uz_sites_upload", "uz_family_upload", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait",
+    "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
     "uz_site_scan", "uz_site_scan_many", "uz_site_classes", "uz_find", "uz_find_fetch",
@@ -53,7 +54,11 @@ def load_library(path: Optional[str] = None):
     L.uz_last_error.restype = C.c_char_p
     L.uz_sync.argtypes = [vp]
     L.uz_set_params.argtypes = [vp, vp]
-    for f in ("uz_sites_upload", "uz_reads_upload", "uz_sites_adopt_device", "uz_reads_adopt_device"):
+    L.uz_reads_wait.argtypes = [vp, C.c_int]
+    L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.uz_pinned_free.argtypes = [vp]
+    L.uz_pinned_free.restype = None
+    for f in ("uz_sites_upload", "uz_reads_upload", "uz_reads_upload_packed", "uz_sites_adopt_device", "uz_reads_adopt_device"):
         getattr(L, f).argtypes = [vp, vp, C.POINTER(C.c_int)]
     for f in ("uz_family_upload", "uz_family_adopt_device"):
         getattr(L, f).argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
@@ -74,7 +79,7 @@ def load_library(path: Optional[str] = None):
     L.uz_prof_units.argtypes = [vp, C.c_int, C.POINTER(C.c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("uz_destroy", "uz_last_error"):
+        if name not in ("uz_destroy", "uz_last_error", "uz_pinned_free"):
             fn.restype = C.c_int
     if path is None:
         _lib = L
@@ -96,6 +101,7 @@ class HipEngine:
         self.h = h
         self.device = device
         self._keep: List[object] = []
+        self._staged = {}
         self._params = None
 
     def close(self):
@@ -125,6 +131,12 @@ class HipEngine:
         self._ck(self.L.uz_sites_upload(self.h, v.ref(), C.byref(sid)), "uz_sites_upload")
         return sid.value
 
+    def upload_sites_view(self, held: abi.Held) -> int:
+        """the same from a prepared view (e.g. columns in pinned memory)"""
+        sid = C.c_int(-1)
+        self._ck(self.L.uz_sites_upload(self.h, held.ref(), C.byref(sid)), "uz_sites_upload")
+        return sid.value
+
     def add_family(self, sites_h: int, gt, rd, ad, gq) -> int:
         v = abi.family_view(gt, rd, ad, gq)
         fid = C.c_int(-1)
@@ -137,6 +149,17 @@ class HipEngine:
         self._ck(self.L.uz_reads_upload(self.h, v.ref(), C.byref(rid)), "uz_reads_upload")
         return rid.value
 
+    def upload_reads_packed(self, packed: abi.Held) -> int:
+        """Staged form, asynchronous: the arrays of `packed` must stay alive and untouched until wait_reads() or
+        a phase on the table has returned (they are kept referenced here until the table is freed)."""
+        rid = C.c_int(-1)
+        self._ck(self.L.uz_reads_upload_packed(self.h, packed.ref(), C.byref(rid)), "uz_reads_upload_packed")
+        self._staged[rid.value] = packed
+        return rid.value
+
+    def wait_reads(self, rid: int):
+        self._ck(self.L.uz_reads_wait(self.h, int(rid)), "uz_reads_wait")
+
     def adopt_sites(self, view: abi.SitesView) -> int:
         sid = C.c_int(-1)
         self._ck(self.L.uz_sites_adopt_device(self.h, C.byref(view), C.byref(sid)), "uz_sites_adopt_device")
@@ -147,7 +170,7 @@ class HipEngine:
         self._ck(self.L.uz_family_adopt_device(self.h, int(sites_h), C.byref(view), C.byref(fid)), "uz_family_adopt_device")
         return fid.value
 
-    def adopt_reads(self, view: abi.ReadsView) -> int:
+    def adopt_reads(self, view: abi.ReadsPackedView) -> int:
         rid = C.c_int(-1)
         self._ck(self.L.uz_reads_adopt_device(self.h, C.byref(view), C.byref(rid)), "uz_reads_adopt_device")
         return rid.value
@@ -157,6 +180,7 @@ class HipEngine:
 
     def free_reads(self, rid: int):
         self._ck(self.L.uz_reads_free(self.h, int(rid)), "uz_reads_free")
+        self._staged.pop(int(rid), None)
 
     def drop_derived(self):
         self._ck(self.L.uz_drop_derived(self.h), "uz_drop_derived")
@@ -256,3 +280,26 @@ class HipEngine:
         u = C.c_int64(0)
         self._ck(self.L.uz_prof_units(self.h, int(kernel), C.byref(u)), "uz_prof_units")
         return int(u.value)
+
+
+class PinnedPool:
+    """Page-locked host memory for the staged columns (uz_pinned_alloc), handed out as numpy uint8 arrays.
+    alloc() is the `alloc` callback of abi.packed_view_alloc / io_native.pack_reads / ReadsSource.select."""
+
+    def __init__(self):
+        self.L = load_library()
+        self._blocks = []
+
+    def alloc(self, nbytes: int) -> np.ndarray:
+        nbytes = max(64, int(nbytes))
+        p = C.c_void_p()
+        if self.L.uz_pinned_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+            raise MemoryError("uz_pinned_alloc(%d) failed" % nbytes)
+        self._blocks.append(p.value)
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8, count=nbytes)
+
+    def free_all(self):
+        for p in self._blocks:
+            self.L.uz_pinned_free(C.c_void_p(p))
+        self._blocks = []

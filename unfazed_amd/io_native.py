@@ -26,6 +26,8 @@ IO_EXPORTS = [
     "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
     "uz_bam_tlen_head", "uz_bam_timing", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
+    "uz_reads_pack_sizes", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_reads_select_fill", "uz_select_free",
 ]
 
 
@@ -87,6 +89,18 @@ def load():
     lib.uz_vcf_is_bcf.argtypes = [C.c_void_p]
     lib.uz_vcf_header.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.uz_vcf_header.restype = C.c_void_p
+    lib.uz_reads_pack_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.uz_reads_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.uz_reads_source_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.uz_reads_source_close.argtypes = [C.c_void_p]
+    lib.uz_reads_source_close.restype = None
+    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units):
+        fn.argtypes = [C.c_void_p]
+        fn.restype = C.c_int64
+    lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.uz_select_free.argtypes = [C.c_void_p]
+    lib.uz_select_free.restype = None
     _LIB = lib
     return lib
 
@@ -235,3 +249,46 @@ def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
     t.info = info
     t._native = h
     return t
+
+
+# ---------------------------------------------------------------------------- staged (packed) records
+def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=None) -> "abi.Held":
+    """ASCII table (abi.reads_view / a decoder's view) -> the packed form uz_reads_upload_packed takes, for the
+    base-quality threshold of the run.  alloc(nbytes) -> uint8 array chooses the memory (pinned for the upload)."""
+    lib = load()
+    nc, nu = C.c_int64(0), C.c_int64(0)
+    _check(lib, lib.uz_reads_pack_sizes(reads.ref(), C.byref(nc), C.byref(nu)))
+    out = abi.packed_view_alloc(int(reads.view.n_segs), int(reads.view.n_contigs), nc.value, nu.value, alloc)
+    _check(lib, lib.uz_reads_pack(reads.ref(), int(min_base_qual), int(threads), out.ref()))
+    return out
+
+
+class ReadsSource:
+    """A packed table in host memory opened for fetch-reach selections (uz_reads_source_open)."""
+
+    def __init__(self, packed: "abi.Held", threads: int = 0):
+        self.lib = load()
+        self.packed = packed  # keeps the arrays alive
+        h = C.c_void_p()
+        _check(self.lib, self.lib.uz_reads_source_open(packed.ref(), int(threads), C.byref(h)))
+        self._h = _Handle(h, self.lib.uz_reads_source_close)
+        self.threads = threads
+
+    def select(self, contig, lo, hi, alloc=None, want_index=False):
+        """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table."""
+        contig = np.ascontiguousarray(contig, np.int32)
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        sel = C.c_void_p()
+        _check(self.lib, self.lib.uz_reads_select_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data,
+                                                       hi.ctypes.data, int(self.threads), C.byref(sel)))
+        try:
+            n = self.lib.uz_select_n_records(sel)
+            out = abi.packed_view_alloc(n, int(self.packed.view.n_contigs), self.lib.uz_select_n_cigar_total(sel),
+                                        self.lib.uz_select_n_row_units(sel), alloc)
+            idx = np.zeros(max(1, n), np.int32) if want_index else None
+            _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
+                                                           idx.ctypes.data if want_index else None))
+        finally:
+            self.lib.uz_select_free(sel)
+        return (out, idx[:n]) if want_index else out
