@@ -293,6 +293,29 @@ def main():
                     "traffic": k3a_traffic, "avg_launch_us": round(qc_us, 1), "records_examined": int(qc_records),
                     "algorithmic_bytes_per_launch": int(qc_bytes)}
 
+    # k_phase is latency-bound integer work (no GB/s figure): per-wave dependent reads x the time a wave is parked per
+    # read (rocprofv3 SQ counters of the same workload, profiles/phase_latency.json) against this run's kernel time
+    latency_model = None
+    tpath = os.path.join(ROOT, "profiles", "phase_latency.json")
+    ph_ms, ph_n = prof_r[K_PHASE]
+    if os.path.exists(tpath) and ph_n:
+        try:
+            tj = json.load(open(tpath))
+            if int(tj.get("dnms", -1)) == n:
+                clock_ghz = 2.1  # effective shader clock under this load (GRBM_GUI_ACTIVE / 8 / wall), DESIGN.md
+                modelled = tj["vmem_read_instructions_per_wave"] * tj["parked_cycles_per_read_instruction"] / (clock_ghz * 1e6)
+                latency_model = {"kernel": "k_phase", "bound": "latency (dependent reads per wave)",
+                                 "reads_per_wave": round(tj["vmem_read_instructions_per_wave"], 1),
+                                 "reads_per_wave_per_dnm": round(tj["vmem_read_instructions_per_wave"] * tj["waves_resident"] / 4.0 / n, 1),
+                                 "parked_cycles_per_read": round(tj["parked_cycles_per_read_instruction"], 1),
+                                 "l1_miss_latency_cycles": round(tj["l1_miss_latency_cycles"], 1),
+                                 "wave_cycles_parked_frac": round(tj["wave_cycles_parked_frac"], 4),
+                                 "l2_hit_rate": round(tj["l2_hit_rate"], 4), "waves_in_flight": int(tj["waves_resident"]),
+                                 "modelled_ms": round(modelled, 3), "measured_ms": round(ph_ms / ph_n, 3),
+                                 "source": "profiles/phase_latency.json"}
+        except Exception:
+            latency_model = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
         cpu = cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, res)
@@ -312,6 +335,7 @@ def main():
             "value_resident": round(value_resident, 1), "ms_per_step_resident": round(ms_resident, 3),
             "roofline": roofline,
             "roofline_k3a": roofline_k3a,
+            "latency_model": latency_model,
             "cpu_baseline": cpu,
             "kernels_ms_per_step": kern_ms(prof_r),
             "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist()},

@@ -1,0 +1,74 @@
+"""Copy the judged summaries of a profiling round (scripts/profile_round.sh TAG, run on the GPU box) from gpurun_out/TAG
+into profiles/ (tracked): kernel statistics, the per-kernel PMC means, and the derived files bench.py reads
+(k1_traffic.json, k3a_traffic.json, phase_latency.json).   usage: make_profiles.py TAG ROUND [K3A_FETCH_FACTOR]"""
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+k3a_factor = float(sys.argv[3]) if len(sys.argv) > 3 else None
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_bench_kernel_stats.csv" % rnd))
+shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "%s_pmc_summary.json" % rnd))
+line = json.loads([x for x in open(os.path.join(src, "stats.log")) if x.startswith("{")][-1])
+json.dump(line, open(os.path.join(dst, "%s_bench_under_rocprof.json" % rnd), "w"), indent=1)
+pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
+stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv")))}
+
+
+def avg_ns(pat):
+    for k, r in stats.items():
+        if pat in k:
+            return float(r["AverageNs"]), int(r["Calls"])
+    return None, 0
+
+
+def c(kernel, name):
+    return pmc[kernel]["counters_per_launch"][name]["mean"]
+
+
+how = ("rocprofv3 --kernel-trace --pmc <counters> in separate passes (scripts/profile_round.sh) over `bench.py --no-staged --no-cpu "
+       "--steps 3 --warmup 1` (100 k DNMs, 20 M sites); per launch, mean over the launches of the run")
+# K1: pure 16-byte streams -> the guide's x2 correction of FETCH_SIZE applies (MI355X_MICROARCH.md, HBM)
+f, w = c("k_site_scan", "FETCH_SIZE") * 1024, c("k_site_scan", "WRITE_SIZE") * 1024
+n_sites = line["config"]["sites"]
+json.dump({"kernel": pmc["k_site_scan"]["full_name"], "n_sites": n_sites, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
+           "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": int(2 * f + w),
+           "algorithmic_bytes_per_launch": 20 * n_sites, "avg_ns_rocprof": avg_ns("k_site_scan")[0], "how": how,
+           "source": "profiles/%s_pmc_summary.json" % rnd}, open(os.path.join(dst, "k1_traffic.json"), "w"), indent=1)
+# K3a: 16-byte header loads and 4-byte words; the factor between FETCH_SIZE and bytes is CALIBRATED on this kernel's own
+# access pattern with every record marked (known byte count), see DESIGN.md
+f, w = c("k_seg_qc", "FETCH_SIZE") * 1024, c("k_seg_qc", "WRITE_SIZE") * 1024
+rec = line["roofline_k3a"]["records_examined"]
+d = {"kernel": "k_seg_qc", "records_examined": rec, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
+     "algorithmic_bytes_per_launch": line["roofline_k3a"]["algorithmic_bytes_per_launch"], "avg_ns_rocprof": avg_ns("k_seg_qc")[0],
+     "how": how, "source": "profiles/%s_pmc_summary.json" % rnd}
+if k3a_factor:
+    d["fetch_factor_calibrated"] = k3a_factor
+    d["hbm_bytes_per_launch"] = int(k3a_factor * f + w)
+json.dump(d, open(os.path.join(dst, "k3a_traffic.json"), "w"), indent=1)
+# k_phase: latency model from the SQ / TCP counters
+waves = c("k_phase", "SQ_WAVES")
+loads = c("k_phase", "SQ_INSTS_VMEM_RD")
+wait_q = c("k_phase", "SQ_WAIT_ANY")
+wave_q = c("k_phase", "SQ_WAVE_CYCLES")
+ns, calls = avg_ns("k_phase(")
+json.dump({"kernel": "k_phase", "dnms": line["config"]["dnms_per_gpu"], "waves_resident": waves,
+           "vmem_read_instructions_per_wave": loads / waves,
+           "wave_cycles_parked_frac": wait_q / wave_q, "active_frac": c("k_phase", "SQ_ACTIVE_INST_ANY") / wave_q,
+           "issue_stall_frac": c("k_phase", "SQ_WAIT_INST_ANY") / wave_q,
+           "parked_cycles_per_read_instruction": 4 * wait_q / loads,
+           "l1_miss_latency_cycles": c("k_phase", "TCP_TCC_READ_REQ_LATENCY_sum") / c("k_phase", "TCP_TCC_READ_REQ_sum"),
+           "l1_accesses_per_dnm": c("k_phase", "TCP_TOTAL_CACHE_ACCESSES_sum") / line["config"]["dnms_per_gpu"],
+           "l2_requests_per_dnm": c("k_phase", "TCC_REQ_sum") / line["config"]["dnms_per_gpu"],
+           "l2_hit_rate": c("k_phase", "TCC_HIT_sum") / (c("k_phase", "TCC_HIT_sum") + c("k_phase", "TCC_MISS_sum")),
+           "fetch_KB_raw_per_dnm": c("k_phase", "FETCH_SIZE") / line["config"]["dnms_per_gpu"],
+           "lds_instructions_per_wave": c("k_phase", "SQ_INSTS_LDS") / waves,
+           "avg_ns_rocprof": ns, "vgpr": pmc["k_phase"]["vgpr"], "lds_static_bytes": pmc["k_phase"]["lds"], "scratch": pmc["k_phase"]["scratch"],
+           "how": how + "; SQ_* in quad-cycles (x4 = shader cycles)", "source": "profiles/%s_pmc_summary.json" % rnd},
+          open(os.path.join(dst, "phase_latency.json"), "w"), indent=1)
+print(open(os.path.join(dst, "phase_latency.json")).read())

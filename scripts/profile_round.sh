@@ -1,0 +1,22 @@
+#!/bin/bash
+# One profiling round on the GPU box (run through gpurun): kernel statistics and the PMC passes the bench line and DESIGN.md quote.
+# usage: scripts/profile_round.sh TAG   -> gpurun_out/TAG/{stats,sq,tcp,tcc,fetch,write}/..., summaries in gpurun_out/TAG/
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="$ROOT/bench.py --no-staged --no-cpu --steps 3 --warmup 1"
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $ARGS > $OUT/stats.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_LDS -d $OUT/sq -o run -- python3 $ARGS > $OUT/sq.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum -d $OUT/tcp -o run -- python3 $ARGS > $OUT/tcp.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/tcc -o run -- python3 $ARGS > $OUT/tcc.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o run -- python3 $ARGS > $OUT/fetch.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o run -- python3 $ARGS > $OUT/write.log 2>&1
+cd $ROOT
+python3 scripts/pmc_summary.py $OUT/pmc_summary.json $OUT/sq $OUT/tcp $OUT/tcc $OUT/fetch $OUT/write > $OUT/pmc_summary.txt 2>&1
+find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+grep "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
+# keep the merged output small: the raw traces are not needed
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+du -sh $OUT
