@@ -50,6 +50,9 @@ def parse():
                     help="DNMs per GPU (weak scaling) / in total (strong scaling)")
     ap.add_argument("--sites", type=int, default=int(os.environ.get("UZ_BENCH_SITES", 20000000)))
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--workload", choices=["snv", "cnv"], default="snv",
+                    help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
+                         "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=8, help="DNM chunks of the staged pass (uploads overlap the kernels)")
     ap.add_argument("--cpu-dnms", type=int, default=12000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -83,6 +86,8 @@ def pinned_copy(pool, a):
 
 def main():
     args = parse()
+    if args.workload == "cnv" and "--dnms" not in " ".join(sys.argv) and "UZ_BENCH_DNMS" not in os.environ:
+        args.dnms = 10000
     world = int(os.environ.get("WORLD_SIZE", 0))
     if world == 0:
         if args.gpus > 1:
@@ -103,10 +108,10 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from synth import bigsynth
-    from synth.sites_np import make_clusters, make_sites, place_dnms_full
+    from synth.sites_np import DnmColumns, breakpoint_dnms, make_clusters, make_sites, place_cnvs, place_dnms_full
     from unfazed_amd import abi, build, io_native, shard
     from unfazed_amd.engine import (HipEngine, K_PHASE, K_SEG_QC, K_SEG_QC_PASS, K_SITE_SCAN, K_SIZING, K_WINDOW_COUNT,
-                                    K_WINDOW_FILL, PinnedPool)
+                                    K_WINDOW_FILL, K_CNV, PinnedPool)
     from unfazed_amd.hostpath import concordant_cutoff
     from unfazed_amd.staging import fetch_points
 
@@ -114,18 +119,27 @@ def main():
     build.build_io()
     t_gen = time.time()
     sc = make_sites(args.sites, seed=202)
-    if args.scaling == "strong":
-        # config 4: the same DNM list on every rank, cut into contiguous shards (sites replicated per GPU)
-        allv = place_dnms_full(sc, args.dnms, seed=201)
-        b = shard.shard_bounds(allv.n, world)
-        lo, hi = b[rank], b[rank + 1]
-        from synth.sites_np import DnmColumns
-        dn = DnmColumns(allv.site_idx[lo:hi], allv.contig[lo:hi], allv.start[lo:hi], allv.end[lo:hi], allv.kind[lo:hi],
-                        allv.length[lo:hi], allv.origin[lo:hi], allv.refs[lo:hi], allv.alts[lo:hi])
-        read_seed = 203
+    cnv = args.workload == "cnv"
+    seed_off = 0 if args.scaling == "strong" else 1000 * rank
+    if cnv:
+        ev = place_cnvs(sc, args.dnms, seed=501 + seed_off, redraw_seed=502 + seed_off)
     else:
-        dn = place_dnms_full(sc, args.dnms, seed=201 + 1000 * rank)
-        read_seed = 203 + 1000 * rank
+        ev = place_dnms_full(sc, args.dnms, seed=201 + seed_off)
+    if args.scaling == "strong":
+        # config 4: the same list on every rank, cut into contiguous shards (sites replicated per GPU)
+        b = shard.shard_bounds(ev.n, world)
+        lo, hi = b[rank], b[rank + 1]
+        if cnv:
+            from synth.sites_np import CnvColumns
+            ev = CnvColumns(ev.contig[lo:hi], ev.start[lo:hi], ev.end[lo:hi], ev.vartype[lo:hi], ev.origin[lo:hi])
+        else:
+            ev = DnmColumns(ev.site_idx[lo:hi], ev.contig[lo:hi], ev.start[lo:hi], ev.end[lo:hi], ev.kind[lo:hi], ev.length[lo:hi],
+                            ev.origin[lo:hi], ev.refs[lo:hi], ev.alts[lo:hi])
+    read_seed = 203 + seed_off
+    # dn: the list the read generator lays its pile-ups around (the DNMs themselves / the breakpoints of the events);
+    # gen_of(k): index of event k's first entry in it
+    dn = breakpoint_dnms(ev) if cnv else ev
+    per_ev = 2 if cnv else 1
     cl = make_clusters(dn)
     cfg = bigsynth.make_cfg(seed=read_seed)
     wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, cl, device=local_rank)
@@ -139,9 +153,24 @@ def main():
     rid = eng.adopt_reads(wl.reads_view())
     # concordant insert cutoff: host scalar per kid (read_collector.py:11-25) from the first records
     cutoff = concordant_cutoff(wl.tlen_head(), P.readlen, 3)
-    n = dn.n
+    n = ev.n
     mode = abi.FIND_SECOND_WINDOW
-    dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
+    ev_vt = ev.vartype if cnv else np.zeros(n, np.uint8)
+    ev_refs = [b""] * n if cnv else ev.refs
+    ev_alts = [b""] * n if cnv else ev.alts
+
+    def view_of(a, b):
+        return abi.dnms_view(ev.contig[a:b], ev.contig[a:b], ev.start[a:b], ev.end[a:b], ev_vt[a:b], ev_refs[a:b], ev_alts[a:b], cutoff)
+
+    dv = view_of(0, n)
+
+    def with_cnv(f, r):
+        """config 5: K6 over the batch, merged with the read-backed counts as summarize_record merges them"""
+        if not cnv:
+            return r
+        k = eng.phase_cnv(f, dv, P, rb_counts=r["counts"], want_lists=False)
+        return dict(status=r["status"], counts=r["counts"], origin=k["origin"], evidence=k["evidence"], etype=k["etype"],
+                    cnv_counts=k["cnv_counts"])
 
     def barrier():
         if dist is not None:
@@ -164,7 +193,7 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING)}
+        prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING, K_CNV)}
         units = eng.prof_units(K_SEG_QC_PASS)
         eng.prof_enable(False)
         return res, elapsed, prof, units
@@ -172,7 +201,7 @@ def main():
     # ---------------------------------------------------------------- resident pass
     def step_resident():
         eng.drop_derived()
-        return eng.phase_raw(fid, rid, dv, P, mode)
+        return with_cnv(fid, eng.phase_raw(fid, rid, dv, P, mode))
 
     res_r, el_r, prof_r, qc_records = timed(step_resident)
 
@@ -192,20 +221,21 @@ def main():
         sites_h = abi.Held(sv, hs)
         # ... and, per chunk of DNMs (whole clusters), the records the chunk's fetches return + their mates
         co, ci, cf, ho, hi = eng.find(fid, dv, P, mode)
-        nchunk = max(1, min(args.chunks, cl.n))
-        cuts = [cl.n * k // nchunk for k in range(nchunk + 1)]
+        nchunk = max(1, min(args.chunks, n))
         chunks, staged_bytes, staged_records = [], 0, 0
+        ecuts = [n * k // nchunk for k in range(nchunk + 1)]  # chunks of events; their records: the clusters of their generator entries
         for k in range(nchunk):
-            c0, c1 = cuts[k], cuts[k + 1]
-            a, b = int(cl.d0[c0]), int(cl.d0[c1 - 1] + cl.nd[c1 - 1])
+            a, b = ecuts[k], ecuts[k + 1]
+            if b <= a:
+                continue
+            c0, c1 = cl.of_dnm(per_ev * a), cl.of_dnm(per_ev * b - 1) + 1
             part_full = wl.download(c0, c1)
             src = io_native.ReadsSource(part_full)
-            fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
+            fc, flo, fhi = fetch_points(ev.contig[a:b], ev.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P,
+                                        vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff)
             part = src.select(fc, flo, fhi, alloc=pool.alloc)
             del src, part_full
-            dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
-                                dn.refs[a:b], dn.alts[a:b], cutoff)
-            chunks.append((a, b, part, dvc))
+            chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
             staged_bytes += int(part.view.n_segs) * 28 + int(part.view.n_cigar_total) * 4 + int(part.view.n_row_units) * 20
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
@@ -222,15 +252,16 @@ def main():
                 rr = eng.phase_raw(f2, r, dvc, P, mode)
                 for key in out:
                     out[key][a:b] = rr[key]
+            out = with_cnv(f2, out)
             for r in rids:
                 eng.free_reads(r)
             eng.free_sites(s2)
             return out
 
         res_s, el_s, prof_s, _ = timed(step_staged)
-        mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in ("status", "counts", "origin", "evidence"))
+        mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
         staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records,
-                      decode_s=t_dec, mismatches_vs_resident=mism, chunks=nchunk)
+                      decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks))
         res = res_s
     else:
         res = res_r
@@ -244,9 +275,10 @@ def main():
     else:
         value, ms_per_step = value_resident, ms_resident
     status = res["status"]
-    called = (status == abi.ST_OK) & ((res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM))
+    called = (res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM)
+    called &= ((res["etype"] & abi.ET_AMBIG_FLAG) == 0) if cnv else (status == abi.ST_OK)
     phased = int(called.sum())
-    truth = np.where(dn.origin == 0, abi.OR_DAD, abi.OR_MOM)
+    truth = np.where(ev.origin == 0, abi.OR_DAD, abi.OR_MOM)
     correct = int((res["origin"][called] == truth[called]).sum())
 
     def kern_ms(prof):
@@ -255,7 +287,8 @@ def main():
                 "window_fill": round(prof[K_WINDOW_FILL][0] / args.steps, 3),
                 "sizing": round(prof[K_SIZING][0] / args.steps, 3),
                 "seg_qc": round(prof[K_SEG_QC][0] / args.steps, 3),
-                "phase": round(prof[K_PHASE][0] / args.steps, 3)}
+                "phase": round(prof[K_PHASE][0] / args.steps, 3),
+                "cnv_count": round(prof[K_CNV][0] / args.steps, 3)}
 
     k1_ms, k1_n = prof_r[K_SITE_SCAN]
     k1_us = k1_ms / max(1, k1_n) * 1e3
@@ -318,7 +351,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
-        cpu = cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, res)
+        cpu = cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, res, ev_vt, ev_refs, ev_alts, cnv)
 
     if rank == 0:
         out = {
@@ -326,8 +359,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int32 (+f64 allele balance)",
             "data": "synthetic",
-            "config": {"workload": ("100k synthetic SNV/INDEL DNMs, whole-genome sites VCF, --no-extended off (BASELINE configs[2])"
-                                    if args.dnms == 100000 else "%d synthetic SNV/INDEL DNMs, extended on" % args.dnms)
+            "config": {"workload": (("10k CNV (DEL/DUP) DNMs exercising the allele-balance sv_phaser path (BASELINE configs[4]): K6 + SV read-backed stage"
+                                     if args.dnms == 10000 else "%d synthetic DEL/DUP events, allele balance + SV read-backed stage" % args.dnms) if cnv else
+                                    ("100k synthetic SNV/INDEL DNMs, whole-genome sites VCF, --no-extended off (BASELINE configs[2])"
+                                     if args.dnms == 100000 else "%d synthetic SNV/INDEL DNMs, extended on" % args.dnms))
                        + ("; staged: H2D of the pre-decoded columns inside the timed region" if staged else "; inputs resident in HBM"),
                        "dnms_per_gpu": n, "sites": sc.n, "coverage": "30x", "search_dist": 5000, "dnm_placement": "uniform",
                        "read_clusters": cl.n, "dnms_sharing_a_cluster": int(cl.nd[cl.nd > 1].sum()),
@@ -354,7 +389,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, gpu_res):
+def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):
     """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first `cpu_dnms` DNMs of the
     GPU's batch (whole clusters; their records regenerated on the host by the gcc build of the generator), 1, 2 and
     more threads over DNM ranges, as the reference's thread pool over DNMs; its results are compared with the GPU's."""
@@ -362,8 +397,8 @@ def cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, gpu_res):
     from synth import bigsynth
     from unfazed_amd import abi
     ncpu = os.cpu_count() or 1
-    c_hi = cl.of_dnm(min(args.cpu_dnms, dn.n) - 1) + 1
-    m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1])
+    c_hi = cl.of_dnm(per_ev * min(args.cpu_dnms, ev.n) - 1) + 1
+    m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1]) // per_ev  # whole clusters (an event whose second breakpoint lies beyond them is left out)
     rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, c_hi, threads=min(ncpu, 128))
     nc = len(sc.contig_off) - 1
     sv = abi.SitesView()
@@ -375,8 +410,7 @@ def cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, gpu_res):
     sh = abi.Held(sv, keep)
     # the GPU folded the complex flag into bit 6 of its own copy of gt; the host copy is untouched
     fh = abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
-    dv = abi.dnms_view(dn.contig[:m], dn.contig[:m], dn.start[:m], dn.end[:m], np.zeros(m, np.uint8), dn.refs[:m],
-                       dn.alts[:m], cutoff)
+    dv = abi.dnms_view(ev.contig[:m], ev.contig[:m], ev.start[:m], ev.end[:m], ev_vt[:m], ev_refs[:m], ev_alts[:m], cutoff)
     orc.lib()
 
     def run(threads):
@@ -394,15 +428,19 @@ def cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, gpu_res):
             t.start()
         for t in th:
             t.join()
-        dt = time.perf_counter() - t0
         st = np.full(m, abi.ST_SKIPPED, np.int32)
         cnt = np.zeros((m, 4), np.int32)
         org = np.zeros(m, np.int32)
-        ev = np.zeros(m, np.int32)
+        evd = np.zeros(m, np.int32)
         for i, p in enumerate(parts):
             a, b = int(bounds[i]), int(bounds[i + 1])
-            st[a:b], cnt[a:b], org[a:b], ev[a:b] = p["status"][a:b], p["counts"][a:b], p["origin"][a:b], p["evidence"][a:b]
-        return dt, dict(status=st, counts=cnt, origin=org, evidence=ev)
+            st[a:b], cnt[a:b], org[a:b], evd[a:b] = p["status"][a:b], p["counts"][a:b], p["origin"][a:b], p["evidence"][a:b]
+        out = dict(status=st, counts=cnt, origin=org, evidence=evd)
+        if cnv:
+            k = orc.phase_cnv(P, sh, fh, dv, rb_counts=cnt)
+            out = dict(status=st, counts=cnt, origin=k["origin"], evidence=k["evidence"], etype=k["etype"], cnv_counts=k["cnv_counts"])
+        dt = time.perf_counter() - t0
+        return dt, out
 
     dt1, r1 = run(1)
     dt2, _ = run(2)
@@ -420,7 +458,7 @@ def cpu_baseline(args, wl, sc, dn, cl, cfg, P, cutoff, gpu_res):
         best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
     dtc, rc, cores = best
     mism = 0
-    for k in ("status", "counts", "origin", "evidence"):
+    for k in r1:
         mism += int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
         mism += int((rc[k] != r1[k]).sum())
     return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",

@@ -45,6 +45,7 @@ extern "C" {
 #define UZ_K_PHASE 4
 #define UZ_K_SEG_QC_PASS 5 /* the quality / CIGAR pass of K3a alone (k_seg_qc), inside UZ_K_SEG_QC */
 #define UZ_K_SIZING 6      /* fetch-range sizing pass */
+#define UZ_K_CNV 7         /* K6 allele-balance count + decision */
 #define UZ_K_COUNT 8
 
 typedef struct uz_ctx uz_ctx;
@@ -133,6 +134,22 @@ int uz_phase_votes(uz_ctx *ctx, int64_t *vote_off /* [4n+1] */, int32_t *vote_va
 /* Haplotype groups after connect_reads of the last uz_phase (diagnostics / tests):
  * grp_off[2n+1] then grp_q: "ref" set then "alt" set (qname ids, ascending). */
 int uz_phase_groups(uz_ctx *ctx, int64_t *grp_off /* [2n+1] */, int32_t *grp_q);
+
+/* ---- allele-balance (CNV) stage ---------------------------------------- */
+/* K6.  Everything run_cnv_phasing does after its find (sv_phaser.py:357-423: phase_by_snvs :71-85,
+ * multithread_cnv_phasing :269-301) and the decision of summarize_record (unfazed.py:193-298): runs the window
+ * emit for the batch in UZ_FIND_WHOLE_REGION mode (search_dist 0, whole_region=True, :375-389), lets every candidate
+ * of a DEL / DUP vote for the parent its kid_allele names, and decides.
+ * rb_counts: optional [4n] read-backed counts of the same DNMs (dad_reads, mom_reads, dad_sites, mom_sites, e.g. the
+ * `counts` of uz_phase): merged as summarize_record merges them (READBACKED + ALLELE-BALANCE, AMBIGUOUS_BOTH, ...);
+ * NULL = allele-balance evidence only.
+ * cnv_counts [2n] = cnv_dad_sites, cnv_mom_sites; origin UZ_OR_* (AMBIGUOUS = "dad|mom"); evidence = evidence_count;
+ * etype = UZ_ET_* mask. */
+int uz_phase_cnv(uz_ctx *ctx, int fam_id, const uz_dnms_view *dnms, const int32_t *rb_counts, int32_t *cnv_counts /* [2n] */,
+                 int32_t *origin /* [n] */, int32_t *evidence /* [n] */, int32_t *etype /* [n] */);
+/* Site lists of the last uz_phase_cnv: off[2n+1], then pos: cnv_dad_sites, cnv_mom_sites per DNM (positions in
+ * candidate-list order).  pos == NULL: offsets only. */
+int uz_phase_cnv_sites(uz_ctx *ctx, int64_t *off /* [2n+1] */, int32_t *pos);
 
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event timing of the kernels launched on the context's stream since the

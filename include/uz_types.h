@@ -70,6 +70,14 @@ extern "C" {
 #define UZ_OR_MOM 2
 #define UZ_OR_AMBIGUOUS 3
 
+/* evidence types of summarize_record (unfazed.py:190-334), as a bit mask in list order */
+#define UZ_ET_READBACKED 1
+#define UZ_ET_ALLELE_BALANCE 2
+#define UZ_ET_AMBIGUOUS_READBACKED 4
+#define UZ_ET_AMBIGUOUS_ALLELE_BALANCE 8
+#define UZ_ET_AMBIGUOUS_BOTH 16
+#define UZ_ET_AMBIG_FLAG 32 /* the `ambig` variable: the call is dropped unless --include-ambiguous */
+
 typedef struct uz_params {
     int32_t search_dist;        /* --search-dist */
     int32_t min_gt_qual;        /* --min-gt-qual: GQ threshold AND base-quality threshold (read_collector.py:361-362) */

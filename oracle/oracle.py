@@ -53,6 +53,10 @@ def lib():
         L.uzo_concordant_cutoff.restype = C.c_double
         L.uzo_bsearch.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]
         L.uzo_bsearch.restype = C.c_int
+        L.uzo_phase_cnv.argtypes = [C.c_void_p] * 12
+        L.uzo_phase_cnv.restype = None
+        L.uzo_summarize_counts.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.uzo_summarize_counts.restype = None
         _LIB = L
     return _LIB
 
@@ -128,3 +132,34 @@ def bsearch(start, end, pos):
     out = np.zeros(max(1, len(p)), dtype=np.int32)
     n = lib().uzo_bsearch(int(start), int(end), p.ctypes.data if len(p) else None, len(p), out.ctypes.data)
     return out[:n].tolist()
+
+
+def phase_cnv(params, sites, fam, dnms, rb_counts=None):
+    """Allele-balance stage: find(whole_region, search_dist 0) + phase_by_snvs + summarize_record's decision."""
+    import copy
+    p0 = copy.copy(params)
+    p0.search_dist = 0
+    co, ci, cf, ho, hi = find(p0, sites, fam, dnms, abi.FIND_WHOLE_REGION)
+    n = dnms.view.n
+    ci = np.ascontiguousarray(ci if ci.size else np.zeros(1, np.int32))
+    cf = np.ascontiguousarray(cf if cf.size else np.zeros(1, np.uint8))
+    cnt = np.zeros(max(1, 2 * n), np.int32)
+    pos = np.zeros(max(1, int(co[n])), np.int32)
+    origin, evidence, etype = (np.zeros(max(1, n), np.int32) for _ in range(3))
+    rb = np.ascontiguousarray(rb_counts, np.int32).reshape(-1) if rb_counts is not None else None
+    lib().uzo_phase_cnv(C.byref(params), sites.ref(), dnms.ref(), co.ctypes.data, ci.ctypes.data, cf.ctypes.data,
+                        rb.ctypes.data if rb is not None else None, cnt.ctypes.data, pos.ctypes.data, origin.ctypes.data,
+                        evidence.ctypes.data, etype.ctypes.data)
+    cnt = cnt[: 2 * n].reshape(n, 2)
+    lists = [(pos[co[k]: co[k] + cnt[k, 0]], pos[co[k] + cnt[k, 0]: co[k] + cnt[k, 0] + cnt[k, 1]]) for k in range(n)]
+    return dict(cnv_counts=cnt, origin=origin[:n], evidence=evidence[:n], etype=etype[:n], lists=lists)
+
+
+def summarize_counts(rb_counts, cnv_counts, ratio):
+    n = len(cnv_counts)
+    rb = np.ascontiguousarray(rb_counts, np.int32).reshape(-1) if rb_counts is not None else None
+    cv = np.ascontiguousarray(cnv_counts, np.int32).reshape(-1)
+    origin, evidence, etype = (np.zeros(max(1, n), np.int32) for _ in range(3))
+    lib().uzo_summarize_counts(n, rb.ctypes.data if rb is not None else None, cv.ctypes.data, int(ratio), origin.ctypes.data,
+                               evidence.ctypes.data, etype.ctypes.data)
+    return origin[:n], evidence[:n], etype[:n]

@@ -899,3 +899,71 @@ double uzo_concordant_cutoff(const int32_t *tlen, int64_t n, int32_t readlen) {
     free(x);
     return (double)(int64_t)v; /* int(np.mean(scalar)) + 0*stdevs */
 }
+
+/* ------------------------------------------------------------------ allele-balance (CNV) stage
+ * phase_by_snvs (sv_phaser.py:71-85) over the whole-region candidate list of uzo_find(UZ_FIND_WHOLE_REGION, search_dist 0):
+ * every candidate votes for the parent its kid_allele names (site[site["kid_allele"]]); only DEL / DUP are phased (:401).
+ * Then summarize_record (unfazed.py:193-298) on the read-backed counts rb[4] (NULL: none) and the CNV counts.
+ * cnv_pos: [cand_off[n]] per DNM slice: dad's positions, then mom's, in list order. */
+static void summarize_counts(long long dr, long long mr, long long ds, long long ms, long long cd, long long cm, long long r,
+                             int32_t *origin, int32_t *evidence, int32_t *etype) {
+    int org = UZ_OR_NONE, et = 0, ambig = 0;
+    long long ev = 0;
+    if (dr > 0 && dr >= r * mr) { org = UZ_OR_DAD; ev = ds; et = UZ_ET_READBACKED; }            /* :206-215 */
+    else if (mr > 0 && mr >= r * dr) { org = UZ_OR_MOM; ev = ms; et = UZ_ET_READBACKED; }       /* :216-226 */
+    else if (dr > 0 && mr > 0) { org = UZ_OR_AMBIGUOUS; ev = dr + mr; et = UZ_ET_AMBIGUOUS_READBACKED; ambig = 1; } /* :227-234 */
+    if (cd > 0 && cd >= r * cm) {                                                                /* :239-262 */
+        if (org == UZ_OR_MOM && !(et & UZ_ET_READBACKED)) { org = UZ_OR_NONE; ev += cd + cm; et = UZ_ET_AMBIGUOUS_BOTH; ambig = 1; }
+        else {
+            org = UZ_OR_DAD; ev = cd;
+            if (et & UZ_ET_AMBIGUOUS_READBACKED) { et &= ~UZ_ET_AMBIGUOUS_READBACKED; ambig = 0; }
+            et |= UZ_ET_ALLELE_BALANCE;
+        }
+    } else if (cm > 0 && cm >= r * cd) {                                                         /* :264-289 */
+        if (org == UZ_OR_DAD && !(et & UZ_ET_READBACKED)) { org = UZ_OR_NONE; ev += cd + cm; et = UZ_ET_AMBIGUOUS_BOTH; ambig = 1; }
+        else {
+            org = UZ_OR_MOM; ev = cm;
+            if (et & UZ_ET_AMBIGUOUS_READBACKED) et &= ~UZ_ET_AMBIGUOUS_READBACKED; /* ambig is NOT cleared here (:286-288) */
+            et |= UZ_ET_ALLELE_BALANCE;
+        }
+    } else if (cd + cm > 0 && !(et & UZ_ET_READBACKED)) {                                        /* :290-298 */
+        org = UZ_OR_NONE; ev += cd + cm; et |= UZ_ET_AMBIGUOUS_ALLELE_BALANCE; ambig = 1;
+    }
+    if (ambig) et |= UZ_ET_AMBIG_FLAG;
+    *origin = org; *evidence = (int32_t)ev; *etype = et;
+}
+
+void uzo_summarize_counts(int32_t n, const int32_t *rb_counts, const int32_t *cnv_counts, int32_t ratio, int32_t *origin, int32_t *evidence,
+                          int32_t *etype) {
+    for (int32_t d = 0; d < n; d++) {
+        const int32_t *rb = rb_counts ? rb_counts + 4 * (int64_t)d : NULL;
+        summarize_counts(rb ? rb[0] : 0, rb ? rb[1] : 0, rb ? rb[2] : 0, rb ? rb[3] : 0, cnv_counts[2 * d], cnv_counts[2 * d + 1], ratio,
+                         origin + d, evidence + d, etype + d);
+    }
+}
+
+void uzo_phase_cnv(const uz_params *P, const uz_sites_view *S, const uz_dnms_view *D, const int64_t *cand_off, const int32_t *cand_idx,
+                   const uint8_t *cand_flags, const int32_t *rb_counts, int32_t *cnv_counts, int32_t *cnv_pos, int32_t *origin,
+                   int32_t *evidence, int32_t *etype) {
+    for (int32_t d = 0; d < D->n; d++) {
+        int64_t nd = 0, nm = 0;
+        const int vt = D->vartype[d];
+        if (vt == UZ_VT_DEL || vt == UZ_VT_DUP) {
+            for (int pass = 0; pass < 2; pass++) { /* count, then fill dad's positions followed by mom's */
+                int64_t od = cand_off[d], om = cand_off[d] + nd;
+                for (int64_t j = cand_off[d]; j < cand_off[d + 1]; j++) {
+                    const int ka = (cand_flags[j] >> UZ_CF_KA_SHIFT) & 3;
+                    if (!ka) continue;
+                    const int alt_dad = (cand_flags[j] & UZ_CF_ALT_DAD) != 0;
+                    const int is_dad = (ka == UZ_KA_ALT_PARENT) == alt_dad;
+                    if (!pass) { if (is_dad) nd++; else nm++; }
+                    else if (cnv_pos) { if (is_dad) cnv_pos[od++] = S->pos[cand_idx[j]]; else cnv_pos[om++] = S->pos[cand_idx[j]]; }
+                }
+            }
+        }
+        cnv_counts[2 * d] = (int32_t)nd; cnv_counts[2 * d + 1] = (int32_t)nm;
+        const int32_t *rb = rb_counts ? rb_counts + 4 * (int64_t)d : NULL;
+        summarize_counts(rb ? rb[0] : 0, rb ? rb[1] : 0, rb ? rb[2] : 0, rb ? rb[3] : 0, nd, nm, P->evidence_min_ratio, origin + d, evidence + d,
+                         etype + d);
+    }
+}

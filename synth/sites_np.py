@@ -239,3 +239,83 @@ def place_dnms(sc: SitesColumns, n_dnms: int, seed: int = 201, indel_frac=0.1):
     start = sc.pos[idx].astype(np.int32)
     dlen = np.where(rng.random(n_dnms) < indel_frac, rng.integers(2, 11, n_dnms), 1).astype(np.int32)
     return idx, contig, start, start + dlen
+
+
+@dataclass
+class CnvColumns:
+    """DEL / DUP events for the allele-balance path."""
+    contig: np.ndarray  # int32
+    start: np.ndarray  # int32 0-based
+    end: np.ndarray
+    vartype: np.ndarray  # uint8 1 DEL, 2 DUP (UZ_VT_*)
+    origin: np.ndarray  # uint8 0 = the event is on the paternal chromosome (dad), 1 = maternal
+
+    @property
+    def n(self):
+        return int(self.start.shape[0])
+
+
+def place_cnvs(sc: SitesColumns, n_events: int, seed: int = 501, redraw_seed: int = 502, min_len=1000, max_len=300000) -> CnvColumns:
+    """n_events DEL / DUP (50 / 50), length log-uniform in [min_len, max_len], stratified over the genome so that events
+    do not overlap; the kid's genotype / depths at the interior sites are re-drawn for a hemizygous kid (DEL: only the
+    other parent's allele, half the depth) or a 2:1 allele balance (DUP: two copies of the origin parent's allele, 1.5x
+    depth).  Modifies sc.gt / sc.rd[0] / sc.ad[0] in place."""
+    rng = np.random.default_rng(seed)
+    nc = len(sc.contig_off) - 1
+    clen = np.array([int(sc.pos[sc.contig_off[c + 1] - 1]) if sc.contig_off[c + 1] > sc.contig_off[c] else 0 for c in range(nc)], np.int64)
+    per = np.floor(clen / clen.sum() * n_events).astype(np.int64)
+    per[np.argmax(clen)] += n_events - per.sum()
+    contig, start, end = [], [], []
+    for c in range(nc):
+        k = int(per[c])
+        if k == 0:
+            continue
+        cell = clen[c] / k
+        ln = np.exp(rng.uniform(np.log(min_len), np.log(max_len), k)).astype(np.int64)
+        ln = np.minimum(ln, max(int(cell) - 2000, min_len))
+        st = (np.arange(k) * cell + 1000 + rng.random(k) * np.maximum(cell - ln - 2000, 1)).astype(np.int64)
+        contig.append(np.full(k, c, np.int32)); start.append(st); end.append(st + ln)
+    contig = np.concatenate(contig); start = np.concatenate(start).astype(np.int32); end = np.concatenate(end).astype(np.int32)
+    n = contig.size
+    vartype = np.where(rng.random(n) < 0.5, 1, 2).astype(np.uint8)
+    origin = rng.integers(0, 2, n).astype(np.uint8)
+    # interior sites: 1-based POS in [start, end]  <=>  0-based pos in [start - 1, end - 1]
+    r2 = np.random.default_rng(redraw_seed)
+    a = np.empty(n, np.int64); b = np.empty(n, np.int64)
+    for c in range(nc):
+        m = contig == c
+        seg = sc.pos[sc.contig_off[c]: sc.contig_off[c + 1]]
+        a[m] = sc.contig_off[c] + np.searchsorted(seg, start[m] - 1, side="left")
+        b[m] = sc.contig_off[c] + np.searchsorted(seg, end[m] - 1, side="right")
+    cnt = (b - a).astype(np.int64)
+    ev = np.repeat(np.arange(n), cnt)
+    si = (np.repeat(a, cnt) + (np.arange(cnt.sum()) - np.repeat(np.cumsum(cnt) - cnt, cnt))).astype(np.int64)
+    pat, mat = (sc.khap[si] & 1).astype(np.int64), ((sc.khap[si] >> 1) & 1).astype(np.int64)
+    o = origin[ev].astype(np.int64)
+    is_del = vartype[ev] == 1
+    kept = np.where(o == 0, mat, pat)           # DEL: the allele of the chromosome that is left
+    dup, oth = np.where(o == 0, pat, mat), np.where(o == 0, mat, pat)
+    n_alt = np.where(is_del, kept, 2 * dup + oth)
+    copies = np.where(is_del, 1, 3)
+    gt_kid = np.where(n_alt == 0, 0, np.where(n_alt == copies, 3, 1)).astype(np.uint8)
+    depth = r2.poisson(np.where(is_del, 15.0, 45.0))
+    p_alt = np.clip(n_alt / copies, 0.01, 0.99)
+    ad = r2.binomial(depth, p_alt)
+    real = sc.sflags[si] == 0
+    si, gt_kid, ad, depth = si[real], gt_kid[real], ad[real], depth[real]
+    sc.gt[si] = (sc.gt[si] & 0xFC) | gt_kid
+    sc.ad[0][si] = ad.astype(np.uint16)
+    sc.rd[0][si] = (depth - ad).astype(np.uint16)
+    return CnvColumns(contig, start, end, vartype, origin)
+
+
+def breakpoint_dnms(cv: CnvColumns) -> DnmColumns:
+    """The breakpoints of the events as a sorted pseudo-DNM list for the read generator (no site of their own: plain
+    30x pile-ups around both ends, i.e. no split / discordant support for the read-backed branch)."""
+    contig = np.concatenate([cv.contig, cv.contig])
+    pos = np.concatenate([cv.start, cv.end])
+    order = np.lexsort((pos, contig))
+    k = order.size
+    z8 = np.zeros(k, np.uint8)
+    return DnmColumns(np.full(k, -1, np.int32), contig[order].astype(np.int32), pos[order].astype(np.int32), (pos[order] + 1).astype(np.int32),
+                      z8, z8.copy(), z8.copy(), [b""] * k, [b""] * k)

@@ -43,3 +43,7 @@ class OracleBackend:
             lists.append(tuple(vv[vo[4 * k + j]: vo[4 * k + j + 1]] for j in range(4)))
         r["lists"] = lists if want_lists else None
         return r
+
+    def phase_cnv(self, fam, dv, params, rb_counts=None, want_lists=True):
+        sites_h, fv = fam
+        return orc.phase_cnv(params, sites_h, fv, dv, rb_counts)

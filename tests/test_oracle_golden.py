@@ -174,3 +174,31 @@ def check_sv_golden(backend, path):
 @pytest.mark.parametrize("path", SV, ids=[os.path.basename(p)[3:-5] for p in SV])
 def test_phase_svs_golden(path):
     check_sv_golden(OracleBackend(), path)
+
+
+def test_oracle_count_decision_is_summarize_record():
+    """The integer decision the oracle (and K6 on the device) makes from the four read-backed and two CNV counts is
+    summarize_record's (the host restatement pinned by the 1160 reference cases of summarize.json), `ambig` quirk included."""
+    rng = np.random.default_rng(3)
+    vals = [0, 0, 0, 1, 2, 3, 9, 10, 11, 20, 25, 100]
+    rows = []
+    for _ in range(4000):
+        dr, mr, cd, cm = (int(rng.choice(vals)) for _ in range(4))
+        ds = int(rng.integers(0, 4)) if dr else 0
+        ms = int(rng.integers(0, 4)) if mr else 0
+        rows.append((dr, mr, ds, ms, cd, cm))
+    rows = np.array(rows, np.int32)
+    for ratio in (10, 1, 2):
+        org, ev, et = orc.summarize_counts(rows[:, :4], rows[:, 4:], ratio)
+        for k, (dr, mr, ds, ms, cd, cm) in enumerate(rows.tolist()):
+            rec = dict(region=dict(chrom="1", start=5, end=9), vartype="DEL", kid="k", dad="D", mom="M", evidence_type="readbacked",
+                       dad_reads=["r%d" % i for i in range(dr)], mom_reads=["q%d" % i for i in range(mr)],
+                       dad_sites=[str(i) for i in range(ds)], mom_sites=[str(100 + i) for i in range(ms)],
+                       cnv_dad_sites=[str(200 + i) for i in range(cd)], cnv_mom_sites=[str(300 + i) for i in range(cm)], cnv_evidence_type="")
+            full = summarize.summarize_record(rec, True, False, ratio)
+            strict = summarize.summarize_record(rec, False, False, ratio)
+            want_org = {None: abi.OR_NONE, "D": abi.OR_DAD, "M": abi.OR_MOM, "D|M": abi.OR_AMBIGUOUS}[full["origin_parent"]]
+            assert org[k] == want_org and ev[k] == full["evidence_count"], (rows[k], ratio)
+            assert [nm for bit, nm in abi.ET_NAMES if et[k] & bit] == full["evidence_types"], (rows[k], ratio, et[k])
+            dropped = bool(et[k] & abi.ET_AMBIG_FLAG) or org[k] == abi.OR_NONE
+            assert (strict is None) == dropped, (rows[k], ratio)

@@ -18,6 +18,9 @@ CF_ALT_DAD = 1
 CF_KA_SHIFT = 1
 CL_HET, CL_CAND, CL_ALT_DAD = 1, 2, 4
 CL_DEL_SHIFT, CL_DUP_SHIFT = 3, 5
+ET_READBACKED, ET_ALLELE_BALANCE, ET_AMBIGUOUS_READBACKED, ET_AMBIGUOUS_ALLELE_BALANCE, ET_AMBIGUOUS_BOTH, ET_AMBIG_FLAG = 1, 2, 4, 8, 16, 32
+ET_NAMES = [(ET_READBACKED, "READBACKED"), (ET_AMBIGUOUS_READBACKED, "AMBIGUOUS_READBACKED"), (ET_ALLELE_BALANCE, "ALLELE-BALANCE"),
+            (ET_AMBIGUOUS_ALLELE_BALANCE, "AMBIGUOUS_ALLELE-BALANCE"), (ET_AMBIGUOUS_BOTH, "AMBIGUOUS_BOTH")]  # list order of summarize_record
 FIND_WHOLE_REGION = 1
 FIND_SECOND_WINDOW = 2
 

@@ -235,6 +235,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.alleles.release();
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
     c->ab_lut.release(); c->win_range.release();
+    c->cnv_counts.release(); c->cnv_pos.release(); c->cnv_origin.release(); c->cnv_evidence.release(); c->cnv_etype.release(); c->cnv_rb.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release();
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
@@ -666,6 +667,68 @@ int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int fin
         uz_launch_find(c, f, s, find_mode, false);
         c->find_fam = fam_id;
         uz_launch_phase(c, f, s, r, status, counts, origin, evidence);
+    });
+}
+
+int uz_phase_cnv(uz_ctx *c, int fam_id, const uz_dnms_view *d, const int32_t *rb_counts, int32_t *cnv_counts, int32_t *origin,
+                 int32_t *evidence, int32_t *etype) {
+    return guarded(c, [&] {
+        FamilyDev &f = fam_of(c, fam_id);
+        SitesDev &s = sites_of(c, f.sites_id);
+        UZ_REQUIRE(d != nullptr, UZ_E_ARG, "null DNM view");
+        c->find_valid = false; c->phase_valid = false; c->cnv_valid = false;
+        uz_stage_dnms(c, d);
+        const size_t n = (size_t)d->n;
+        if (!uz_site_scan_fresh(c, f, true)) uz_launch_site_scan(c, f, s, true);
+        const int32_t sd = c->P.search_dist;
+        c->P.search_dist = 0; // run_cnv_phasing calls find(..., search_dist=0, whole_region=True), sv_phaser.py:375-389
+        try { uz_launch_find(c, f, s, UZ_FIND_WHOLE_REGION, false); } catch (...) { c->P.search_dist = sd; throw; }
+        c->P.search_dist = sd;
+        c->find_fam = fam_id;
+        c->cnv_n = d->n;
+        c->cnv_counts.ensure(2 * n + 2); c->cnv_pos.ensure((size_t)c->n_cand + 1); c->cnv_origin.ensure(n + 1);
+        c->cnv_evidence.ensure(n + 1); c->cnv_etype.ensure(n + 1);
+        const int32_t *rb = nullptr;
+        if (rb_counts && n) {
+            c->cnv_rb.ensure(4 * n);
+            UZ_HIP(hipMemcpyAsync(c->cnv_rb.p, rb_counts, 4 * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            rb = c->cnv_rb.p;
+        }
+        uz_launch_cnv(c, s, rb, c->cnv_counts.p, c->cnv_pos.p, c->cnv_origin.p, c->cnv_evidence.p, c->cnv_etype.p);
+        c->cnv_counts_h.resize(2 * n + 2);
+        if (n) {
+            UZ_HIP(hipMemcpyAsync(c->cnv_counts_h.data(), c->cnv_counts.p, 2 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            if (origin) UZ_HIP(hipMemcpyAsync(origin, c->cnv_origin.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            if (evidence) UZ_HIP(hipMemcpyAsync(evidence, c->cnv_evidence.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+            if (etype) UZ_HIP(hipMemcpyAsync(etype, c->cnv_etype.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        }
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        if (cnv_counts && n) memcpy(cnv_counts, c->cnv_counts_h.data(), 2 * n * sizeof(int32_t));
+        c->cnv_valid = true;
+    });
+}
+
+int uz_phase_cnv_sites(uz_ctx *c, int64_t *off, int32_t *pos) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(c->cnv_valid && c->find_valid, UZ_E_STATE, "uz_phase_cnv_sites before uz_phase_cnv");
+        UZ_REQUIRE(off != nullptr, UZ_E_ARG, "null output");
+        const size_t n = (size_t)c->cnv_n;
+        // the lists keep the layout of the device array: the DNM's slice of the candidate list, dad's sites then mom's
+        std::vector<int64_t> co(n + 1);
+        if (n) UZ_HIP(hipMemcpy(co.data(), c->cand_off.p, (n + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+        int64_t total = 0;
+        for (size_t d = 0; d < n; d++) {
+            off[2 * d] = total; total += c->cnv_counts_h[2 * d];
+            off[2 * d + 1] = total; total += c->cnv_counts_h[2 * d + 1];
+        }
+        off[2 * n] = total;
+        if (!pos || total == 0) return;
+        std::vector<int32_t> all((size_t)c->n_cand + 1);
+        UZ_HIP(hipMemcpy(all.data(), c->cnv_pos.p, (size_t)c->n_cand * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t d = 0; d < n; d++) {
+            const int64_t len = off[2 * d + 2] - off[2 * d];
+            if (len) memcpy(pos + off[2 * d], all.data() + co[d], (size_t)len * sizeof(int32_t));
+        }
     });
 }
 

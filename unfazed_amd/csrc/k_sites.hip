@@ -408,6 +408,91 @@ __global__ __launch_bounds__(1024) void k_scan2(int32_t n, const int32_t *c0, co
     if (t == 0) { o0[n] = carry0; o1[n] = carry1; }
 }
 
+// K6: allele-balance phasing of a DEL / DUP from the whole-region candidate list (phase_by_snvs, sv_phaser.py:71-85:
+// every candidate votes for the parent its kid_allele names) and the decision of summarize_record (unfazed.py:193-298:
+// the read-backed branch on the counts handed in, then the CNV branch with its AMBIGUOUS_BOTH / ambiguous merges).
+// One wave per DNM; the ordered position lists come from ballots (dad's sites first, then mom's, inside the DNM's
+// slice of the candidate list).
+__global__ __launch_bounds__(256) void k_cnv_count(int32_t n, const int64_t *__restrict__ cand_off, const int32_t *__restrict__ cand_idx,
+                                                   const uint8_t *__restrict__ cand_flags, const int32_t *__restrict__ spos,
+                                                   const uint8_t *__restrict__ vartype, const int32_t *__restrict__ rb_counts, int ratio,
+                                                   int32_t *cnv_counts, int32_t *cnv_pos, int32_t *origin, int32_t *evidence, int32_t *etype) {
+    const int32_t d = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (d >= n) return;
+    const int64_t c0 = cand_off[d], c1 = cand_off[d + 1];
+    const int vt = vartype[d];
+    const bool cnv = vt == UZ_VT_DEL || vt == UZ_VT_DUP; // sv_phaser.py:401
+    int n_dad = 0, n_mom = 0;
+    if (cnv) {
+        for (int64_t b = c0; b < c1; b += 64) { // count
+            const int64_t i = b + lane;
+            bool dad = false, mom = false;
+            if (i < c1) {
+                const uint32_t fl = cand_flags[i];
+                const uint32_t ka = (fl >> UZ_CF_KA_SHIFT) & 3u;
+                const bool alt_dad = (fl & UZ_CF_ALT_DAD) != 0;
+                const bool is_dad = (ka == UZ_KA_ALT_PARENT) == alt_dad; // site[site["kid_allele"]] is the dad
+                dad = ka != 0 && is_dad; mom = ka != 0 && !is_dad;
+            }
+            n_dad += __popcll(__ballot(dad)); n_mom += __popcll(__ballot(mom));
+        }
+        int o_dad = 0, o_mom = 0;
+        for (int64_t b = c0; b < c1; b += 64) { // ordered fill
+            const int64_t i = b + lane;
+            bool dad = false, mom = false;
+            int32_t p = 0;
+            if (i < c1) {
+                const uint32_t fl = cand_flags[i];
+                const uint32_t ka = (fl >> UZ_CF_KA_SHIFT) & 3u;
+                const bool alt_dad = (fl & UZ_CF_ALT_DAD) != 0;
+                const bool is_dad = (ka == UZ_KA_ALT_PARENT) == alt_dad;
+                dad = ka != 0 && is_dad; mom = ka != 0 && !is_dad;
+                p = spos[cand_idx[i]];
+            }
+            const unsigned long long bd = __ballot(dad), bm = __ballot(mom);
+            const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+            if (dad) cnv_pos[c0 + o_dad + __popcll(bd & below)] = p;
+            if (mom) cnv_pos[c0 + n_dad + o_mom + __popcll(bm & below)] = p;
+            o_dad += __popcll(bd); o_mom += __popcll(bm);
+        }
+    }
+    if (lane != 0) return;
+    cnv_counts[2 * d] = n_dad; cnv_counts[2 * d + 1] = n_mom;
+    // summarize_record: 1 dad, 2 mom, 3 "dad|mom", 0 None
+    long long dr = 0, mr = 0, ds = 0, ms = 0;
+    if (rb_counts) { dr = rb_counts[4 * d]; mr = rb_counts[4 * d + 1]; ds = rb_counts[4 * d + 2]; ms = rb_counts[4 * d + 3]; }
+    const long long r = ratio;
+    int org = UZ_OR_NONE, et = 0;
+    long long ev = 0;
+    bool ambig = false;
+    if (dr > 0 && dr >= r * mr) { org = UZ_OR_DAD; ev = ds; et = UZ_ET_READBACKED; }
+    else if (mr > 0 && mr >= r * dr) { org = UZ_OR_MOM; ev = ms; et = UZ_ET_READBACKED; }
+    else if (dr > 0 && mr > 0) { org = UZ_OR_AMBIGUOUS; ev = dr + mr; et = UZ_ET_AMBIGUOUS_READBACKED; ambig = true; }
+    const long long cd = n_dad, cm = n_mom;
+    if (cd > 0 && cd >= r * cm) {
+        if (org == UZ_OR_MOM && !(et & UZ_ET_READBACKED)) { // unreachable with these branches (kept as written, :241-248)
+            org = UZ_OR_NONE; ev += cd + cm; et = UZ_ET_AMBIGUOUS_BOTH; ambig = true;
+        } else {
+            org = UZ_OR_DAD; ev = cd;
+            if (et & UZ_ET_AMBIGUOUS_READBACKED) { et &= ~UZ_ET_AMBIGUOUS_READBACKED; ambig = false; }
+            et |= UZ_ET_ALLELE_BALANCE;
+        }
+    } else if (cm > 0 && cm >= r * cd) {
+        if (org == UZ_OR_DAD && !(et & UZ_ET_READBACKED)) {
+            org = UZ_OR_NONE; ev += cd + cm; et = UZ_ET_AMBIGUOUS_BOTH; ambig = true;
+        } else {
+            org = UZ_OR_MOM; ev = cm;
+            if (et & UZ_ET_AMBIGUOUS_READBACKED) et &= ~UZ_ET_AMBIGUOUS_READBACKED; // `ambig` stays set: the reference forgets to clear it here (:277-278)
+            et |= UZ_ET_ALLELE_BALANCE;
+        }
+    } else if (cd + cm > 0 && !(et & UZ_ET_READBACKED)) {
+        org = UZ_OR_NONE; ev += cd + cm; et |= UZ_ET_AMBIGUOUS_ALLELE_BALANCE; ambig = true;
+    }
+    if (ambig) et |= UZ_ET_AMBIG_FLAG;
+    origin[d] = org; evidence[d] = (int32_t)ev; etype[d] = et;
+}
+
 SiteParams make_site_params(const uz_params &p) {
     SiteParams s;
     s.min_gt_qual = p.min_gt_qual;
@@ -584,4 +669,15 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
     }
     c->find_valid = true;
     c->find_mode = mode;
+}
+
+void uz_launch_cnv(uz_ctx *c, const SitesDev &s, const int32_t *rb_counts_dev, int32_t *cnv_counts, int32_t *cnv_pos, int32_t *origin,
+                   int32_t *evidence, int32_t *etype) {
+    const int32_t n = c->dn.n;
+    if (n <= 0) return;
+    ProfScope ps(c, UZ_K_CNV);
+    hipLaunchKernelGGL(k_cnv_count, dim3((unsigned)(((int64_t)n * 64 + 255) / 256)), dim3(256), 0, c->stream, n, (const int64_t *)c->cand_off.p,
+                       (const int32_t *)c->cand_idx.p, (const uint8_t *)c->cand_flags.p, (const int32_t *)s.pos, (const uint8_t *)c->dn.vartype.p,
+                       rb_counts_dev, (int)c->P.evidence_min_ratio, cnv_counts, cnv_pos, origin, evidence, etype);
+    UZ_HIP(hipGetLastError());
 }

@@ -157,6 +157,12 @@ struct uz_ctx {
     int64_t n_cand = 0, n_het = 0;
     std::vector<int64_t> cand_off_h, het_off_h;
 
+    // last CNV stage (K6)
+    bool cnv_valid = false;
+    int32_t cnv_n = 0;
+    DevBuf<int32_t> cnv_counts, cnv_pos, cnv_origin, cnv_evidence, cnv_etype, cnv_rb;
+    std::vector<int32_t> cnv_counts_h;
+
     // last phase (k_reads.hip)
     bool phase_valid = false;
     int32_t phase_n = 0;
@@ -206,6 +212,8 @@ void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_c
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool host_offsets = true);
 void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d);
+void uz_launch_cnv(uz_ctx *c, const SitesDev &s, const int32_t *rb_counts_dev, int32_t *cnv_counts, int32_t *cnv_pos, int32_t *origin,
+                   int32_t *evidence, int32_t *etype);
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
                      int32_t *origin, int32_t *evidence);
 int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);

@@ -14,7 +14,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UZ_HIP_LIB", os.path.join(_HERE, "libunfazed_hip.so"))
 
-K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING = 0, 1, 2, 3, 4, 5, 6
+K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING, K_CNV = 0, 1, 2, 3, 4, 5, 6, 7
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
@@ -23,7 +23,7 @@ EXPORTS = [
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
     "uz_site_scan", "uz_site_scan_many", "uz_site_classes", "uz_find", "uz_find_fetch",
-    "uz_phase", "uz_phase_votes", "uz_phase_groups",
+    "uz_phase", "uz_phase_votes", "uz_phase_groups", "uz_phase_cnv", "uz_phase_cnv_sites",
     "uz_prof_enable", "uz_prof_reset", "uz_prof_get", "uz_prof_units",
 ]
 
@@ -71,6 +71,8 @@ def load_library(path: Optional[str] = None):
     L.uz_find.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
     L.uz_find_fetch.argtypes = [vp, vp, vp, vp]
     L.uz_phase.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.uz_phase_cnv.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.uz_phase_cnv_sites.argtypes = [vp, vp, vp]
     L.uz_phase_votes.argtypes = [vp, vp, vp]
     L.uz_phase_groups.argtypes = [vp, vp, vp]
     L.uz_prof_enable.argtypes = [vp, C.c_int]
@@ -261,6 +263,31 @@ class HipEngine:
             r["lists"] = [tuple(vv[vo[4 * k + j]: vo[4 * k + j + 1]] for j in range(4)) for k in range(n)]
         else:
             r["lists"] = None
+        return r
+
+    # ------------------------------------------------------------ CNV stage
+    def phase_cnv(self, fam: int, dv: abi.Held, params: abi.Params, rb_counts=None, want_lists: bool = True):
+        """K6: allele-balance phasing of the DEL / DUP of the batch + summarize_record's decision (merged with the
+        read-backed counts when given).  -> dict(cnv_counts [n,2], origin, evidence, etype[, lists: (dad, mom) positions])"""
+        self.set_params(params)
+        n = dv.view.n
+        cnt = np.zeros(max(1, 2 * n), np.int32)
+        origin = np.zeros(max(1, n), np.int32)
+        evidence = np.zeros(max(1, n), np.int32)
+        etype = np.zeros(max(1, n), np.int32)
+        rb = None
+        if rb_counts is not None:
+            rb = np.ascontiguousarray(rb_counts, np.int32).reshape(-1)
+            assert rb.size == 4 * n
+        self._ck(self.L.uz_phase_cnv(self.h, int(fam), dv.ref(), rb.ctypes.data if rb is not None else None, cnt.ctypes.data,
+                                     origin.ctypes.data, evidence.ctypes.data, etype.ctypes.data), "uz_phase_cnv")
+        r = dict(cnv_counts=cnt[: 2 * n].reshape(n, 2), origin=origin[:n], evidence=evidence[:n], etype=etype[:n], lists=None)
+        if want_lists:
+            off = np.zeros(2 * n + 1, np.int64)
+            self._ck(self.L.uz_phase_cnv_sites(self.h, off.ctypes.data, None), "uz_phase_cnv_sites")
+            pos = np.zeros(max(1, int(off[-1])), np.int32)
+            self._ck(self.L.uz_phase_cnv_sites(self.h, off.ctypes.data, pos.ctypes.data), "uz_phase_cnv_sites")
+            r["lists"] = [(pos[off[2 * k]: off[2 * k + 1]], pos[off[2 * k + 1]: off[2 * k + 2]]) for k in range(n)]
         return r
 
     # ---------------------------------------------------------- measurement

@@ -125,6 +125,7 @@ class PhasingHost:
         params: abi.Params,
         whole_region: bool = True,
         attach: bool = True,
+        fetch: bool = True,
     ):
         """informative_site_finder.find: annotates the DNM dicts in place with
         `candidate_sites` / `het_sites` and returns the list in the reference's order.
@@ -196,6 +197,8 @@ class PhasingHost:
                 cutoff=0.0,
                 mult=[mult_of[i] for i in idxs],
             )
+            if not fetch and not attach:
+                continue  # the caller runs its own device stage over the batch (K6): no lists on the host
             co, ci, cf, ho, hi = self.backend.find(fam, dv, params, mode)
             for k, i in enumerate(idxs):
                 found[i] = dict(
@@ -222,7 +225,7 @@ class PhasingHost:
                     dn["het_sites"] = hets
         ret = [dnms[i] for i in order] + [dnms[i] for i in auto_tail]
         ret_idx = order + auto_tail
-        return ret, {"order": ret_idx, "found": found, "many": many, "mode": mode}
+        return ret, {"order": ret_idx, "found": found, "many": many, "mode": mode, "scanned": scan, "contig_of": contig_of}
 
     def _site_dicts(self, idx, flags, dad, mom, with_kid_allele):
         s = self.sites
@@ -494,16 +497,39 @@ class PhasingHost:
         return records
 
     # ------------------------------------------------------- CNV phasing
-    def run_cnv_phasing(self, dnms, pedigrees, threads, build, multithread_proc_min, quiet_mode, params):
+    def run_cnv_phasing(self, dnms, pedigrees, threads, build, multithread_proc_min, quiet_mode, params, annotate=True):
         """reference sv_phaser.py:357-423 with phase_by_snvs (:71-85) and
         multithread_cnv_phasing (:269-301): allele-balance phasing of DEL/DUP."""
         log = _Log(quiet_mode)
+        many = len(dnms) >= multithread_proc_min
+        # find_many's whole-region mode is the quirk path (Q7: KeyError / appended lists): it keeps the annotated site
+        # dicts; the per-DNM path (every realistic CNV batch) takes the counts and ordered site lists from K6.
+        # annotate: write `candidate_sites` into the DNM dicts as the reference's find does (informative_site_finder.py:
+        # 341-343); phase_svs turns it off -- its read-backed find overwrites the lists before anyone can see them
         ret, info = self.find(
-            dnms, pedigrees, 0, threads, build, multithread_proc_min, quiet_mode, params, whole_region=True
+            dnms, pedigrees, 0, threads, build, multithread_proc_min, quiet_mode, params, whole_region=True,
+            attach=many or annotate, fetch=many or annotate,
         )
         records: Dict[str, dict] = {}
         if ret is None:
             return records
+        device_lists: Dict[int, tuple] = {}
+        if not many:
+            by_kid: Dict[str, List[int]] = {}
+            for i in info["scanned"]:
+                if dnms[i]["vartype"] in ["DEL", "DUP"]:
+                    by_kid.setdefault(dnms[i]["kid"], []).append(i)
+            for kid, idxs in by_kid.items():
+                fam = self.family(kid, pedigrees[kid]["dad"], pedigrees[kid]["mom"])
+                n = len(idxs)
+                dv = abi.dnms_view(
+                    contig=[info["contig_of"][i] for i in idxs], rcontig=[-1] * n,
+                    start=[int(dnms[i]["start"]) for i in idxs], end=[int(dnms[i]["end"]) for i in idxs],
+                    vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs], refs=[b""] * n, alts=[b""] * n, cutoff=0.0,
+                )
+                res = self.backend.phase_cnv(fam, dv, params)
+                for k, i in enumerate(idxs):
+                    device_lists[i] = res["lists"][k]
         for i in info["order"]:
             dn = dnms[i]
             dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
@@ -519,21 +545,30 @@ class PhasingHost:
                 }
             if dn["vartype"] not in ["DEL", "DUP"]:  # :401
                 continue
-            if "candidate_sites" not in dn or len(dn["candidate_sites"]) == 0:  # :404-412
+            if many:
+                cs = dn.get("candidate_sites") or []
+                ev = {dad_id: [], mom_id: []}
+                if cs:
+                    origin = {cs[0]["ref_parent"]: [], cs[0]["alt_parent"]: []}  # :75-78
+                    for s in cs:
+                        origin[s[s["kid_allele"]]].append(s)  # :81-84
+                    for parent in ev:
+                        if parent in origin and len(origin[parent]) > 0:
+                            ev[parent] = [str(o["pos"]) for o in origin[parent]]
+                n_cand = len(cs)
+                dad_sites, mom_sites = ev[dad_id], ev[mom_id]
+            else:
+                dl = device_lists.get(i)
+                dad_sites = [str(int(p)) for p in dl[0]] if dl is not None else []
+                mom_sites = [str(int(p)) for p in dl[1]] if dl is not None else []
+                n_cand = len(dad_sites) + len(mom_sites)
+            if n_cand == 0:  # :404-412
                 log("No usable informative sites for allele-balance phasing of variant {}:{}-{}".format(
                     dn["chrom"], dn["start"], dn["end"]))
                 continue
-            cs = dn["candidate_sites"]
-            origin = {cs[0]["ref_parent"]: [], cs[0]["alt_parent"]: []}  # :75-78
-            for s in cs:
-                origin[s[s["kid_allele"]]].append(s)  # :81-84
-            ev = {dad_id: [], mom_id: []}
-            for parent in ev:
-                if parent in origin and len(origin[parent]) > 0:
-                    ev[parent] = [str(o["pos"]) for o in origin[parent]]
             records[key] = {
                 "region": region, "vartype": dn["vartype"], "kid": dn["kid"], "dad": dad_id, "mom": mom_id,
-                "cnv_dad_sites": ev[dad_id], "cnv_mom_sites": ev[mom_id], "cnv_evidence_type": "ALLELE-BALANCE",
+                "cnv_dad_sites": dad_sites, "cnv_mom_sites": mom_sites, "cnv_evidence_type": "ALLELE-BALANCE",
                 "dad_sites": "", "mom_sites": "", "evidence_type": "",
                 "dad_reads": [], "mom_reads": [],
             }

@@ -19,7 +19,8 @@ def phase_svs(
         insert_size_max_sample=insert_size_max_sample, evidence_min_ratio=evidence_min_ratio,
         ab_homref=ab_homref, ab_homalt=ab_homalt, ab_het=ab_het,
     )
-    cnv_records = host.run_cnv_phasing(dnms, pedigrees, threads, build, multiread_proc_min, quiet_mode, params)
+    cnv_records = host.run_cnv_phasing(dnms, pedigrees, threads, build, multiread_proc_min, quiet_mode, params,
+                                       annotate=allele_balance_only)
     if allele_balance_only:
         return cnv_records
     read_records = host.run_read_phasing(
