@@ -241,24 +241,40 @@ def main():
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
         t_dec = time.time() - t_dec
 
+        trace = [] if os.environ.get("UZ_BENCH_TRACE") else None
+
         def step_staged():
+            t = [time.perf_counter()]
+
+            def tick():
+                if trace is not None:
+                    t.append(time.perf_counter())
             s2 = eng.upload_sites_view(sites_h)
             f2 = eng.add_family(s2, hs["gt"], hg["rd"], hg["ad"], hg["gq"])
+            tick()
             eng.find(f2, dv, P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
+            tick()
             rids = [eng.upload_reads_packed(part) for (_, _, part, _) in chunks]  # queued behind one another on the copy stream
+            tick()
             out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32),
                        evidence=np.empty(n, np.int32))
             for (a, b, _, dvc), r in zip(chunks, rids):
                 rr = eng.phase_raw(f2, r, dvc, P, mode)
                 for key in out:
                     out[key][a:b] = rr[key]
+            tick()
             out = with_cnv(f2, out)
             for r in rids:
                 eng.free_reads(r)
             eng.free_sites(s2)
+            tick()
+            if trace is not None:
+                trace.append([round((t[i + 1] - t[i]) * 1e3, 2) for i in range(len(t) - 1)])
             return out
 
         res_s, el_s, prof_s, _ = timed(step_staged)
+        if trace:
+            print("[staged step, ms] sites+family upload | find | enqueue read uploads | phase chunks | cnv + frees:", trace, file=sys.stderr)
         mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
         staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records,
                       decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks))

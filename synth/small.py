@@ -15,6 +15,7 @@ between gcc and hipcc); this one favours coverage of edge cases over speed.
 """
 from __future__ import annotations
 
+import functools
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -46,6 +47,7 @@ from unfazed_amd.model import (
 BASES = "ACGT"
 
 
+@functools.lru_cache(maxsize=1 << 21)
 def refbase(tid: int, pos: int) -> str:
     x = (pos * 0x9E3779B1 + tid * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
     x ^= x >> 15
@@ -272,6 +274,10 @@ def make_small(cfg: SmallConfig) -> SmallDataset:
         lo, hi = p - W, p + W
         n_pairs = int(round(cfg.coverage_per_hap * (hi - lo) / (2.0 * L)))
         out = reads[m["kid"]]
+        # both haplotypes over everything a read of this DNM can touch, computed once (a speed-up only: _make_read
+        # slices these strings instead of calling hap_base per base and falls back to hap_base outside them)
+        c0, c1 = lo - 950, hi + 1100
+        hap_base.cache = (c0, c1, ["".join(hap_base(d, tid, q, hh, sites_by_pos) for q in range(c0, c1)) for hh in (0, 1)])
         for h in (0, 1):
             for _ in range(n_pairs):
                 ins = int(np.clip(rng.normal(cfg.ins_mean, cfg.ins_sd), 2 * L, 900))
@@ -385,8 +391,17 @@ def _make_read(rng, cfg, d, m, tid, a, h, carries_dnm, sites_by_pos, hap_base, o
             ops = [(OP_M, L)]
     # --- bases ---------------------------------------------------------
     q = start
+    c0, c1, hapstr = getattr(hap_base, "cache", (0, 0, None))
     for op, l in ops:
         if op in (OP_M, OP_EQ, OP_X):
+            if c0 <= q and q + l <= c1:
+                chunk = list(hapstr[h][q - c0: q - c0 + l])
+                if carries_dnm and kind in ("snv", "mnp"):
+                    for qq in range(max(q, p), min(q + l, p + len(m["alt"]))):
+                        chunk[qq - q] = m["alt"][qq - p]
+                seq.extend(chunk)
+                q += l
+                continue
             for j in range(l):
                 b = hap_base(d, tid, q, h, sites_by_pos)
                 if carries_dnm and kind in ("snv", "mnp") and p <= q < p + len(m["alt"]):

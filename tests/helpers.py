@@ -70,3 +70,45 @@ def norm_records(recs):
 
 def dnm_sites(dnms):
     return [(d["chrom"], d["start"], d["end"], d["kid"], d.get("candidate_sites"), d.get("het_sites")) for d in dnms]
+
+
+# ---------------------------------------------------------------- compact golden form (tests/golden/make_golden_wide.py)
+def _sha(obj):
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps(obj, sort_keys=True).encode()).hexdigest()[:24]
+
+
+def compact_records(recs):
+    """Records with the read-name lists replaced by (count, digest of the sorted names); everything else kept."""
+    out = {}
+    for k, r in recs.items():
+        c = {}
+        for kk, v in r.items():
+            if kk in ("dad_reads", "mom_reads"):
+                c[kk] = {"n": len(v), "sha": _sha(sorted(v))}
+            else:
+                c[kk] = sorted(v) if isinstance(v, list) else v
+        out[k] = c
+    return out
+
+
+def compact_dnms(dnms):
+    """Per returned DNM: identity + counts and digests of the annotated site lists (order included)."""
+    out = []
+    for d in dnms:
+        cs, hs = d.get("candidate_sites"), d.get("het_sites")
+        out.append(dict(chrom=d["chrom"], start=d["start"], end=d["end"], kid=d["kid"],
+                        cand=None if cs is None else {"n": len(cs), "sha": _sha(cs)},
+                        het=None if hs is None else {"n": len(hs), "sha": _sha(hs)}))
+    return out
+
+
+def reverse_ties(ds):
+    """The same records with the order of records sharing (contig, position) reversed: the reference's chaining is
+    first-come (connect_reads, read_collector.py:76-152), so the fetch order of ties is part of the input."""
+    for kid in ds.reads:
+        segs = list(reversed(ds.reads[kid]))
+        segs.sort(key=lambda s: (s.tid if s.tid >= 0 else 1 << 30, s.pos))
+        ds.reads[kid] = segs
+    return ds

@@ -1,7 +1,8 @@
 """Runs the REFERENCE (/root/reference, imported through tests/refshim stand-ins
 for cyvcf2/pysam) on a synth.small dataset.  Only usable in the authoring
-container; used by tests/golden/make_golden.py to produce the committed vectors
-and by the optional live cross-check tests (skipped when /root/reference is absent)."""
+container; used by tests/golden/make_golden.py and make_golden_wide.py to produce the
+committed vectors and by tests/golden/crosscheck.py (a script, not a test: the reference
+against the oracle on fresh seeds)."""
 import contextlib
 import copy
 import io

@@ -26,3 +26,26 @@ from test_oracle_golden import SV, check_sv_golden  # noqa: E402
 @pytest.mark.parametrize("path", SV, ids=[os.path.basename(p)[3:-5] for p in SV])
 def test_phase_svs_golden_gpu(engine, path):
     check_sv_golden(engine, path)
+
+
+# the wide sets (>= 200 DNMs / DEL-DUP / SVs, tie order, autophase): tests/golden/make_golden_wide.py
+from test_oracle_golden import (WIDE_SNV, WIDE_SV, check_autophase, check_wide_cnv, check_wide_snv,  # noqa: E402
+                                check_wide_sv)
+
+
+@pytest.mark.parametrize("name", WIDE_SNV, ids=[n[9:-8] for n in WIDE_SNV])
+def test_wide_phase_snvs_golden_gpu(engine, name):
+    check_wide_snv(engine, name)
+
+
+def test_wide_cnv_golden_gpu(engine):
+    check_wide_cnv(engine)
+
+
+@pytest.mark.parametrize("name", WIDE_SV, ids=[n[8:-8] for n in WIDE_SV])
+def test_wide_phase_svs_golden_gpu(engine, name):
+    check_wide_sv(engine, name)
+
+
+def test_autophase_golden_gpu(engine):
+    check_autophase(engine)

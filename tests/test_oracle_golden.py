@@ -202,3 +202,168 @@ def test_oracle_count_decision_is_summarize_record():
             assert [nm for bit, nm in abi.ET_NAMES if et[k] & bit] == full["evidence_types"], (rows[k], ratio, et[k])
             dropped = bool(et[k] & abi.ET_AMBIG_FLAG) or org[k] == abi.OR_NONE
             assert (strict is None) == dropped, (rows[k], ratio)
+
+
+# ------------------------------------------------------------------ the wide sets (tests/golden/make_golden_wide.py)
+def _load_gz(name):
+    import gzip
+    return json.loads(gzip.open(os.path.join(GOLD, name), "rb").read().decode())
+
+
+WIDE_SNV = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "wide_snv_*.json.gz")))
+WIDE_SV = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLD, "wide_sv_*.json.gz")))
+
+
+def _digest_of(ds):
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import dataset_digest
+    return dataset_digest(ds)
+
+
+def check_wide_snv(backend, name):
+    from helpers import compact_dnms, compact_records, reverse_ties
+    g = _load_gz(name)
+    ds = make_small(SmallConfig(**g["config"]))
+    if g["reverse_ties"]:
+        reverse_ties(ds)
+    assert _digest_of(ds) == g["digest"], "synthetic generator drifted from the fixture inputs"
+    recs, dnms, err = run_host(backend, ds, **g["run"])
+    assert list(recs.keys()) == g["record_order"]
+    assert json.loads(json.dumps(compact_records(recs))) == g["records"]
+    assert json.loads(json.dumps(compact_dnms(dnms))) == g["dnms"]
+    assert err.splitlines() == g["stderr"]
+    return g, recs
+
+
+@pytest.mark.parametrize("name", WIDE_SNV, ids=[n[9:-8] for n in WIDE_SNV])
+def test_wide_phase_snvs_golden(name):
+    g, recs = check_wide_snv(OracleBackend(), name)
+    if "ties" not in name:
+        assert len(g["dnms"]) >= 200
+
+
+def test_tie_order_is_part_of_the_input():
+    """connect_reads is first-come: the same records with the ties of the coordinate order reversed give the reference
+    (and therefore the goldens) different haplotype groups for some DNMs -- the two fixtures must differ, and each is
+    reproduced exactly above."""
+    a, b = _load_gz("wide_snv_ties_forward.json.gz"), _load_gz("wide_snv_ties_reversed.json.gz")
+    assert a["record_order"] == b["record_order"]
+    assert a["records"] != b["records"]
+
+
+def check_wide_cnv(backend):
+    import sys
+    sys.path.insert(0, GOLD)
+    from helpers import compact_dnms
+    from make_golden import make_cnv_dataset
+    g = _load_gz("wide_cnv.json.gz")
+    ds = make_cnv_dataset(seed=g["seed"], n=g["n"])
+    assert _digest_of(ds) == g["digest"]
+    assert sum(d["vartype"] in ("DEL", "DUP") for d in ds.dnms) >= 160
+    for c in g["cases"]:
+        recs, dn, err = run_cnv(backend, ds, c["params"])
+        assert list(recs.keys()) == c["record_order"]
+        assert json.loads(json.dumps(recs)) == c["records"]
+        assert err.splitlines() == c["stderr"]
+        assert json.loads(json.dumps(compact_dnms(dn))) == c["dnms"]
+        for k, r in recs.items():
+            assert summarize.summarize_record(r, True, True, 10) == c["summaries"][k]
+
+
+def test_wide_cnv_golden():
+    check_wide_cnv(OracleBackend())
+
+
+def _phase_svs_through(backend, ds, run):
+    import contextlib
+    import copy
+    import io
+    from helpers import RUN_DEFAULTS
+    from unfazed_amd import session
+    from unfazed_amd.sv_phaser import phase_svs
+    sites, reads = tables(ds)
+    session.set_backend(backend)
+    try:
+        session.register_sites("mem://svsites", sites)
+        for k, t in reads.items():
+            session.register_reads(k, t)
+        a = dict(RUN_DEFAULTS)
+        a.update(run)
+        dn = copy.deepcopy(ds.dnms)
+        for d in dn:
+            d["bam"] = "mem://%s.bam" % d["kid"]
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            recs = phase_svs(dn, list(ds.pedigrees), ds.pedigrees, "mem://svsites", a["threads"], a["build"],
+                             a["no_extended"], a["multithread_proc_min"], a["quiet_mode"], a["ab_homref"], a["ab_homalt"],
+                             a["ab_het"], a["min_gt_qual"], a["min_depth"], a["search_dist"], a["insert_size_max_sample"],
+                             a["stdevs"], a["min_map_qual"], a["readlen"], a["split_error_margin"])
+    finally:
+        session.set_backend(None)
+    return recs, dn, err.getvalue()
+
+
+def check_wide_sv(backend, name):
+    from helpers import compact_dnms, compact_records
+    from synth.small_sv import SvConfig, make_small_sv
+    g = _load_gz(name)
+    ds = make_small_sv(SvConfig(**g["config"]))
+    assert _digest_of(ds) == g["digest"]
+    recs, dn, err = _phase_svs_through(backend, ds, g["run"])
+    assert list(recs.keys()) == g["record_order"]
+    assert json.loads(json.dumps(compact_records(recs))) == g["records"]
+    assert err.splitlines() == g["stderr"]
+    assert json.loads(json.dumps(compact_dnms(dn))) == g["dnms"]
+    for k, r in recs.items():
+        assert summarize.summarize_record(r, True, False, 10) == g["summaries"][k]
+
+
+@pytest.mark.parametrize("name", WIDE_SV, ids=[n[8:-8] for n in WIDE_SV])
+def test_wide_phase_svs_golden(name):
+    check_wide_sv(OracleBackend(), name)
+
+
+def _norm_summary(s):
+    """verbose read-name lists come out in Python set order (quirk Q19): compare them sorted"""
+    if s is None:
+        return None
+    s = dict(s)
+    for k in ("origin_parent_reads", "other_parent_reads"):
+        if k in s and s[k] != "-":
+            s[k] = ",".join(sorted(s[k].split(",")))
+    return s
+
+
+def check_autophase(backend):
+    """chrX / chrY DNMs x kid sex x build 37 / 38 / na x every PAR edge, through phase_snvs (per-DNM find and
+    find_many) and phase_svs (quirk Q18: the SV driver falls through after writing the SEX-CHROM record)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from helpers import compact_dnms, compact_records
+    from make_golden_wide import autophase_dataset
+    g = json.load(open(os.path.join(GOLD, "autophase.json")))
+    n_auto = 0
+    for run in g["runs"]:
+        ds = autophase_dataset(run["prefix"])
+        if run["kind"] == "sv":
+            for i, d in enumerate(ds.dnms):
+                d["vartype"] = ["DEL", "DUP", "INV"][i % 3]
+                d["end"] = d["start"] + 700 + 50 * (i % 7)
+        assert _digest_of(ds) == run["digest"]
+        if run["kind"] == "snv":
+            recs, dn, err = run_host(backend, ds, **run["run"])
+        else:
+            recs, dn, err = _phase_svs_through(backend, ds, run["run"])
+        assert list(recs.keys()) == run["record_order"], run["run"]
+        assert json.loads(json.dumps(compact_records(recs))) == run["records"]
+        assert err.splitlines() == run["stderr"]
+        assert json.loads(json.dumps(compact_dnms(dn))) == run["dnms"]
+        for k, r in recs.items():
+            assert _norm_summary(summarize.summarize_record(r, True, True, 10)) == _norm_summary(run["summaries"][k])
+        n_auto += sum(1 for r in recs.values() if r["evidence_type"].startswith("SEX-CHROM"))
+    assert n_auto > 150
+
+
+def test_autophase_golden():
+    check_autophase(OracleBackend())

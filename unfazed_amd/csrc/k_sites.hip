@@ -365,6 +365,68 @@ __global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32
     if (!FILL) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
 }
 
+// Whole-region mode (CNV interior, sv_phaser.py:375-389) visits hundreds to thousands of sites per event: one WAVE per
+// DNM, 64 consecutive sites per round, list positions from ballots.  One window, so the visiting order is the table
+// order and every site of the index range lies inside the window (the range comes from the two lower bounds).
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_window_region(WinArgs a, int32_t *cnt_c, int32_t *cnt_h, const int64_t *off_c, const int64_t *off_h,
+                                                       int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx) {
+    const int32_t d = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (d >= a.n) return;
+    int64_t nc = 0, nh = 0;
+    const int32_t c = a.contig[d];
+    if (c >= 0 && c < a.n_contigs) {
+        const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
+        const int64_t st = a.start[d], en = a.end[d];
+        int64_t w0 = st - a.sd;
+        const int64_t w1 = en + a.sd;
+        if (w0 < 1) w0 = 1;
+        const int vt = a.vartype[d];
+        const int mult = a.mult[d];
+        const bool small_event = (en - st) < 20;
+        int64_t lo, hi;
+        if (FILL) { lo = a.range[2 * (int64_t)d]; hi = a.range[2 * (int64_t)d + 1]; }
+        else {
+            lo = lower_bound(a.pos, clo, chi, w0 - 1);
+            hi = lower_bound(a.pos, clo, chi, w1);
+            if (lane == 0) { a.range[2 * (int64_t)d] = lo; a.range[2 * (int64_t)d + 1] = hi; }
+        }
+        const int64_t oc = FILL ? off_c[d] : 0, oh = FILL ? off_h[d] : 0;
+        const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+        for (int64_t b = lo; b < hi; b += 64) {
+            const int64_t sidx = b + lane;
+            bool is_c = false, is_h = false;
+            uint32_t cl = 0, ka = 0;
+            if (sidx < hi) {
+                cl = a.cls[sidx];
+                const int32_t p = a.pos[sidx];
+                if (cl && !(small_event && p >= st && p < en)) { // :253-256
+                    if (vt == UZ_VT_DEL) ka = (cl >> UZ_CL_DEL_SHIFT) & 3;
+                    else if (vt == UZ_VT_DUP) ka = (cl >> UZ_CL_DUP_SHIFT) & 3;
+                    is_c = ka != 0;
+                    is_h = (cl & UZ_CL_HET) != 0;
+                }
+            }
+            const unsigned long long bc = __ballot(is_c), bh = __ballot(is_h);
+            if (FILL) {
+                if (is_h) for (int r = 0; r < mult; r++) het_idx[oh + (nh + __popcll(bh & below)) * mult + r] = (int32_t)sidx;
+                if (is_c) {
+                    const uint8_t fl = (uint8_t)(((cl & UZ_CL_ALT_DAD) ? UZ_CF_ALT_DAD : 0) | (ka << UZ_CF_KA_SHIFT));
+                    for (int r = 0; r < mult; r++) {
+                        const int64_t at = oc + (nc + __popcll(bc & below)) * mult + r;
+                        cand_idx[at] = (int32_t)sidx;
+                        cand_flags[at] = fl;
+                    }
+                }
+            }
+            nc += __popcll(bc); nh += __popcll(bh);
+        }
+        nc *= mult; nh *= mult;
+    }
+    if (!FILL && lane == 0) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
+}
+
 // exclusive scan of two count arrays into int64 offsets (n+1 entries); one workgroup walks the
 // arrays in tiles of 4096 counts (coalesced 16-byte loads, wave-shuffle scan, int64 carry)
 __global__ __launch_bounds__(1024) void k_scan2(int32_t n, const int32_t *c0, const int32_t *c1, int64_t *o0, int64_t *o1) {
@@ -633,11 +695,17 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         c->win_range.ensure((size_t)2 * n + 2);
         a.range = c->win_range.p;
         const unsigned nb = (unsigned)((n + 255) / 256);
+        const unsigned nbw = (unsigned)(((int64_t)n * 64 + 255) / 256); // one wave per DNM
         {
             ProfScope ps(c, UZ_K_WINDOW_COUNT);
-            hipLaunchKernelGGL(k_window<false>, dim3(nb), dim3(256), 0, c->stream, a, c->cnt_c.p, c->cnt_h.p,
-                               (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr,
-                               (uint8_t *)nullptr, (int32_t *)nullptr);
+            if (mode & UZ_FIND_WHOLE_REGION)
+                hipLaunchKernelGGL(k_window_region<false>, dim3(nbw), dim3(256), 0, c->stream, a, c->cnt_c.p, c->cnt_h.p,
+                                   (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr, (uint8_t *)nullptr,
+                                   (int32_t *)nullptr);
+            else
+                hipLaunchKernelGGL(k_window<false>, dim3(nb), dim3(256), 0, c->stream, a, c->cnt_c.p, c->cnt_h.p,
+                                   (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr,
+                                   (uint8_t *)nullptr, (int32_t *)nullptr);
             UZ_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, c->stream, n, c->cnt_c.p, c->cnt_h.p, c->cand_off.p,
                                c->het_off.p);
@@ -661,9 +729,14 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         c->het_idx.ensure((size_t)c->n_het + 1);
         {
             ProfScope ps(c, UZ_K_WINDOW_FILL);
-            hipLaunchKernelGGL(k_window<true>, dim3(nb), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
-                               (int32_t *)nullptr, (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p,
-                               c->cand_idx.p, c->cand_flags.p, c->het_idx.p);
+            if (mode & UZ_FIND_WHOLE_REGION)
+                hipLaunchKernelGGL(k_window_region<true>, dim3(nbw), dim3(256), 0, c->stream, a, (int32_t *)nullptr, (int32_t *)nullptr,
+                                   (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p, c->cand_idx.p, c->cand_flags.p,
+                                   c->het_idx.p);
+            else
+                hipLaunchKernelGGL(k_window<true>, dim3(nb), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
+                                   (int32_t *)nullptr, (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p,
+                                   c->cand_idx.p, c->cand_flags.p, c->het_idx.p);
             UZ_HIP(hipGetLastError());
         }
     }
