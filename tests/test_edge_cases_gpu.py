@@ -107,3 +107,38 @@ def test_empty_and_missing_inputs(engine, small):
     engine.free_sites(sid)
     with pytest.raises(UnfazedHipError):
         engine.site_scan(fid)  # the family went away with its sites table
+
+
+def test_capacity_overflow_is_reported_not_dropped(engine, monkeypatch):
+    """A DNM the device layout cannot hold comes back as UZ_ST_CAPACITY: the host prints it (even under --quiet) and
+    lists it; it is never a silently missing record.  The overflow is forced by capping the registration scratch."""
+    import contextlib
+    import copy
+    import io
+    from helpers import RUN_DEFAULTS, params_from, tables
+    from synth.small import SmallConfig, make_small
+    from unfazed_amd.hostpath import PhasingHost
+    ds = make_small(SmallConfig(seed=4141, n_dnms=8, cluster_prob=0.7))
+    sites, reads = tables(ds)
+    a = dict(RUN_DEFAULTS, quiet_mode=True)
+
+    def run():
+        host = PhasingHost(engine, sites, reads)
+        dn = copy.deepcopy(ds.dnms)
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            recs = host.run_read_phasing(dn, ds.pedigrees, 1, "38", False, 1000, True, params_from(a), 5000, 1000000, 3, 151)
+        return recs, err.getvalue(), host
+
+    full, err0, _ = run()
+    assert err0 == "" and len(full) >= 2
+    monkeypatch.setenv("UZ_TEST_CAP_T", "150")
+    part, err1, host = run()
+    monkeypatch.delenv("UZ_TEST_CAP_T")
+    assert len(host.capacity_skipped) >= 1
+    assert err1.count("UZ_ST_CAPACITY") == len(host.capacity_skipped)
+    for k in host.capacity_skipped:
+        assert k not in part
+    for k, r in part.items():  # the others are untouched
+        assert r == full[k]
+    assert set(full) - set(part) <= set(host.capacity_skipped)

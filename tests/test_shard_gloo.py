@@ -64,3 +64,64 @@ def test_shard_bounds_cover_everything():
     dn = [dict(chrom=str(c), start=s, end=s + 1, kid="k") for c in (2, 1) for s in (5, 3, 9)]
     got = [d for r in range(3) for d in shard_dnms(dn, r, 3)]
     assert sorted((d["chrom"], d["start"]) for d in got) == sorted((d["chrom"], d["start"]) for d in dn)
+
+
+# ---- config 4: the SAME DNM list cut into contiguous shards, each shard's alignment records
+# routed from the one coordinate-sorted table (fetch-reach selection), no collective on the data path
+def _strong_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as orc
+    from synth import bigsynth
+    from synth.sites_np import make_clusters, make_sites, place_dnms_full
+    from test_pack_select import _sites_views, _subset_ascii
+    from unfazed_amd import abi, io_native
+    from unfazed_amd.hostpath import concordant_cutoff
+    from unfazed_amd.shard import shard_bounds
+    from unfazed_amd.staging import fetch_points
+    # every rank holds the same inputs (the sites table is replicated per GPU; here also the reads table it selects from)
+    sc = make_sites(40_000, seed=61, contig_lens=[6e6, 4e6, 2e6])
+    dn = place_dnms_full(sc, 150, seed=62, indel_frac=0.2)
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=63)
+    cfg.n_clusters = cl.n
+    rh, arrs = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, cl.n, threads=2)
+    P = abi.make_params()
+    sh, fh = _sites_views(sc)
+    cutoff = concordant_cutoff(arrs["tlen"], P.readlen, 3)  # the per-kid scalar every shard is handed
+    b = shard_bounds(dn.n, world)
+    lo, hi = b[rank], b[rank + 1]
+    dv = abi.dnms_view(dn.contig[lo:hi], dn.contig[lo:hi], dn.start[lo:hi], dn.end[lo:hi], np.zeros(hi - lo, np.uint8),
+                       dn.refs[lo:hi], dn.alts[lo:hi], cutoff)
+    found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+    if world == 1:
+        reads = rh
+    else:  # route this shard's records: what its fetches return + mates, out of the one table
+        src = io_native.ReadsSource(io_native.pack_reads(rh, P.min_gt_qual))
+        fc, flo, fhi = fetch_points(dn.contig[lo:hi], dn.start[lo:hi], np.zeros(hi - lo, np.uint8), sc.pos, found[3], found[4], P)
+        _, idx = src.select(fc, flo, fhi, want_index=True)
+        reads = _subset_ascii(arrs, idx, len(sc.contig_off) - 1)
+    r = orc.phase(P, sh, reads, dv, found, keep_lists=False)
+    mine = {k: r[k].tolist() for k in ("status", "counts", "origin", "evidence")}
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(mine, gathered, dst=0)  # host objects only: per-shard results concatenated on rank 0
+    if rank == 0:
+        merged = {k: sum((g[k] for g in gathered), []) for k in mine}
+        json.dump(merged, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_split_two_ranks_equal_one_rank(tmp_path):
+    outs = []
+    for world, port in ((1, 29741), (2, 29742)):
+        out = os.path.join(str(tmp_path), "s%d.json" % world)
+        mp.spawn(_strong_worker, args=(world, port, out), nprocs=world, join=True)
+        outs.append(json.load(open(out)))
+    assert outs[0] == outs[1]
+    assert sum(1 for s in outs[0]["status"] if s == 0) >= 20

@@ -471,6 +471,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     caps.A = (int32_t)mA; caps.T = (int32_t)mT; caps.H = (int32_t)mH; caps.C = (int32_t)mC;
     caps.I = (int32_t)(4 * mA);
     caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
+    if (const char *e = getenv("UZ_TEST_CAP_T")) { // test hook: a scratch too small for some DNMs -> they must come back as UZ_ST_CAPACITY
+        const int32_t t = (int32_t)atoi(e);
+        if (t < caps.T) caps.T = t;
+    }
     Scr dummy;
     const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
     if (st->n_cus <= 0) { // asked once: the query is not cheap
