@@ -41,6 +41,17 @@ typedef struct uz_bam uz_bam;
 
 /* Decode a whole BAM with `threads` worker threads (<= 0: all hardware threads). */
 int uz_bam_decode(const char *path, int threads, uz_bam **out);
+/* Region decode through the BAI index (`bai_path` NULL: NAME.bam.bai, then NAME.bai): only the BGZF blocks the index
+ * names for the intervals are read and inflated.  The table holds the records `fetch(contig, lo, hi)` returns for the
+ * intervals (start < hi and end > lo; read_collector.py:385, :167, :478-497) and, closed under it, the records `mate()`
+ * returns for them (:400, :185: overlap of the mate position, same name) -- everything of the file the read stage can
+ * look at -- in file order, with the same columns, name ids in order of first appearance and mate links as a whole-file
+ * decode restricted to those records.  head_records: how many template lengths of the START of the file to keep for
+ * uz_bam_tlen_head (estimate_concordant_insert_len, :11-25). */
+int uz_bam_decode_regions(const char *path, const char *bai_path, int64_t n_iv, const int32_t *tid, const int32_t *lo, const int32_t *hi,
+                          int64_t head_records, int threads, uz_bam **out);
+/* what the last decode touched: [0] compressed file bytes read, [1] BGZF blocks inflated, [2] records walked, [3] records kept */
+void uz_bam_io_stats(const uz_bam *h, int64_t out[4]);
 void uz_bam_free(uz_bam *h);
 
 int32_t uz_bam_n_contigs(const uz_bam *h);

@@ -69,3 +69,98 @@ def dump_dataset(ds, outdir, contig_len=10_000_000):
         paths["bams"][kid] = os.path.join(outdir, "%s.bam" % kid)
         write_bam(paths["bams"][kid], [(c, contig_len) for c in ds.contigs], segs)
     return paths
+
+
+# ---------------------------------------------------------------------------- BAI writer (tests)
+def _reg2bin(beg, end):
+    end -= 1
+    if beg >> 14 == end >> 14:
+        return ((1 << 15) - 1) // 7 + (beg >> 14)
+    if beg >> 17 == end >> 17:
+        return ((1 << 12) - 1) // 7 + (beg >> 17)
+    if beg >> 20 == end >> 20:
+        return ((1 << 9) - 1) // 7 + (beg >> 20)
+    if beg >> 23 == end >> 23:
+        return ((1 << 6) - 1) // 7 + (beg >> 23)
+    if beg >> 26 == end >> 26:
+        return ((1 << 3) - 1) // 7 + (beg >> 26)
+    return 0
+
+
+def write_bai(bam_path, bai_path=None):
+    """A BAI for a coordinate-sorted BAM, built the way samtools index does (SAM spec 5.2): bins with merged chunks and
+    the 16 kb linear index (empty windows take the following window's offset).  Reads the BAM back with the Python reader."""
+    import struct
+    import zlib
+    raw = open(bam_path, "rb").read()
+    # BGZF blocks: compressed offset and inflated size of each
+    blocks, p, u = [], 0, 0
+    data = bytearray()
+    while p < len(raw):
+        xlen = struct.unpack_from("<H", raw, p + 10)[0]
+        bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1  # the writer puts BC first
+        payload = zlib.decompress(raw[p + 12 + xlen: p + bsize - 8], -15)
+        blocks.append((p, u, len(payload)))
+        data += payload
+        p += bsize
+        u += len(payload)
+
+    def voff(uo):  # virtual offset of the byte at inflated offset uo
+        import bisect
+        k = bisect.bisect_right([b[1] for b in blocks], uo) - 1
+        while k + 1 < len(blocks) and blocks[k][2] == 0:
+            k += 1
+        if uo - blocks[k][1] >= blocks[k][2] and k + 1 < len(blocks):  # the end of a block is the start of the next
+            k += 1
+        return (blocks[k][0] << 16) | (uo - blocks[k][1])
+
+    l_text = struct.unpack_from("<i", data, 4)[0]
+    off = 8 + l_text
+    n_ref = struct.unpack_from("<i", data, off)[0]
+    off += 4
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", data, off)[0]
+        off += 4 + ln + 4
+    bins = [dict() for _ in range(n_ref)]
+    linear = [dict() for _ in range(n_ref)]
+    while off + 4 <= len(data):
+        bs = struct.unpack_from("<i", data, off)[0]
+        tid, pos, l_name, mapq, bn, ncig, flag, l_seq = struct.unpack_from("<iiBBHHHi", data, off + 4)
+        q = off + 4 + 32 + l_name
+        rl = 0
+        for k in range(ncig):
+            v = struct.unpack_from("<I", data, q + 4 * k)[0]
+            if (v & 15) in (0, 2, 3, 7, 8):
+                rl += v >> 4
+        end = pos + 1 if (flag & 4) or ncig == 0 else pos + max(rl, 1)
+        v0, v1 = voff(off), voff(off + 4 + bs)
+        if tid >= 0:
+            b = _reg2bin(pos, end)
+            ch = bins[tid].setdefault(b, [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            for w in range(pos >> 14, ((end - 1) >> 14) + 1):
+                if w not in linear[tid]:
+                    linear[tid][w] = v0
+        off += 4 + bs
+    out = bytearray(b"BAI\x01" + struct.pack("<i", n_ref))
+    for t in range(n_ref):
+        out += struct.pack("<i", len(bins[t]))
+        for b in sorted(bins[t]):
+            out += struct.pack("<Ii", b, len(bins[t][b]))
+            for v0, v1 in bins[t][b]:
+                out += struct.pack("<QQ", v0, v1)
+        n_intv = (max(linear[t]) + 1) if linear[t] else 0
+        lin = [linear[t].get(w, 0) for w in range(n_intv)]
+        for w in range(n_intv - 2, -1, -1):
+            if lin[w] == 0:
+                lin[w] = lin[w + 1]
+        out += struct.pack("<i", n_intv)
+        for v in lin:
+            out += struct.pack("<Q", v)
+    bai_path = bai_path or bam_path + ".bai"
+    with open(bai_path, "wb") as fh:
+        fh.write(bytes(out))
+    return bai_path

@@ -67,13 +67,22 @@ def _check(run, text, n_samples):
             assert float(col[-2]) == w["uops"][i] and float(col[-1]) == w["uet"][i]
 
 
-def test_cli_matches_reference_driver(tmp_path):
+@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "bai_regions"])
+def test_cli_matches_reference_driver(tmp_path, indexed):
+    """indexed: a BAI sits next to every BAM, so the session decodes only the regions each batch fetches (through
+    uz_bam_decode_regions) instead of the whole file -- the output must not change."""
     from oracle_backend import OracleBackend
     from unfazed_amd import session
     from unfazed_amd.__main__ import setup_args
     from unfazed_amd.unfazed import unfazed
     g, ds, paths = _inputs(tmp_path)
+    if indexed:
+        from filesio import write_bai
+        for b in paths["bams"].values():
+            write_bai(b)
     session.set_backend(OracleBackend())
+    session._READS.clear()
+    session._HOSTS.clear()
     try:
         for run in g["runs"]:
             args = setup_args().parse_args(_argv(paths, run))
@@ -86,8 +95,13 @@ def test_cli_matches_reference_driver(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cli_on_device_matches_reference_driver(tmp_path, hip_lib):
+@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "bai_regions"])
+def test_cli_on_device_matches_reference_driver(tmp_path, hip_lib, indexed):
     g, ds, paths = _inputs(tmp_path)
+    if indexed:
+        from filesio import write_bai
+        for b in paths["bams"].values():
+            write_bai(b)
     for run in g["runs"]:
         out = subprocess.run([sys.executable, "-m", "unfazed_amd"] + _argv(paths, run), cwd=ROOT, check=True,
                              capture_output=True, text=True)

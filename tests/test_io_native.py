@@ -248,3 +248,71 @@ def test_bcf_dnm_input_gives_the_same_variants(tmp_path):
     write_bcf(bcf, smp, recs, ds.contigs)
     a, b = list(read_vars_vcf(paths["dnm_vcf"])), list(read_vars_vcf(bcf))
     assert len(a) >= 6 and a == b
+
+
+# ---------------------------------------------------------------------------- index-driven region decode
+def _restrict_whole(t, tid, lo, hi):
+    """indices of the records of a whole-file table the fetches return, closed under mate()"""
+    n = t.n_segs
+    contig_of = np.searchsorted(t.contig_off, np.arange(n), side="right") - 1
+    keep = np.zeros(n, bool)
+    for c, a, b in zip(tid, lo, hi):
+        keep |= (contig_of == c) & (t.start < b) & (t.end > a)
+    for _ in range(6):
+        m = t.mate[keep]
+        before = keep.sum()
+        keep[m[m >= 0]] = True
+        if keep.sum() == before:
+            break
+    return np.nonzero(keep)[0]
+
+
+def test_region_decode_equals_whole_file_decode_restricted(tmp_path):
+    """uz_bam_decode_regions through a BAI: same records, columns, names and mate links as the whole-file decode
+    restricted to what the fetches return + mates -- and only a fraction of the file is inflated."""
+    from filesio import dump_dataset, write_bai
+    from synth.small import SmallConfig, make_small
+    ds = make_small(SmallConfig(seed=515, n_dnms=14, kids=["kidA"], odd_read_prob=0.2, softclip_prob=0.05, indel_prob=0.05))
+    paths = dump_dataset(ds, str(tmp_path))
+    bam = paths["bams"]["kidA"]
+    write_bai(bam)
+    whole = io_native.read_bam_table(bam)
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        # fetch points around a few DNMs: single bases and a wider window, on both contigs
+        pick = rng.choice(len(ds.dnms), size=3 + trial, replace=False)
+        tid, lo, hi = [], [], []
+        for k in pick:
+            d = ds.dnms[k]
+            c = whole.contig_index[d["chrom"]]
+            for off in (0, -700, 1300, 2500):
+                tid.append(c); lo.append(d["start"] + off); hi.append(d["start"] + off + 1)
+            tid.append(c); lo.append(d["start"] - 1500); hi.append(d["start"] - 1100)
+        part = io_native.read_bam_regions(bam, tid, lo, hi)
+        idx = _restrict_whole(whole, tid, lo, hi)
+        assert part.n_segs == idx.size and idx.size > 50
+        for col in ("start", "end", "tlen", "flag", "mapq", "aux", "n_cigar", "l_seq"):
+            assert np.array_equal(getattr(part, col), getattr(whole, col)[idx]), col
+        # names: ids are interned per table, the strings must agree record by record
+        assert [part.qnames[int(q)] for q in part.qname] == [whole.qnames[int(q)] for q in whole.qname[idx]]
+        new = np.full(whole.n_segs, -1, np.int64)
+        new[idx] = np.arange(idx.size)
+        wm = whole.mate[idx]
+        assert np.array_equal(part.mate, np.where(wm >= 0, new[np.maximum(wm, 0)], -1))
+        for i in rng.integers(0, idx.size, 60):
+            j = int(idx[i])
+            assert np.array_equal(part.cigar[part.cigar_off[i]: part.cigar_off[i] + part.n_cigar[i]],
+                                  whole.cigar[whole.cigar_off[j]: whole.cigar_off[j] + whole.n_cigar[j]])
+            ls = int(part.l_seq[i])
+            assert np.array_equal(part.seq[int(part.sq_off16[i]) * 16: int(part.sq_off16[i]) * 16 + ls],
+                                  whole.seq[int(whole.sq_off16[j]) * 16: int(whole.sq_off16[j]) * 16 + ls])
+            assert np.array_equal(part.qual[int(part.sq_off16[i]) * 16: int(part.sq_off16[i]) * 16 + ls],
+                                  whole.qual[int(whole.sq_off16[j]) * 16: int(whole.sq_off16[j]) * 16 + ls])
+        assert np.array_equal(part.contig_off, np.searchsorted(idx, whole.contig_off))
+        assert np.array_equal(part.tlen_head, whole.tlen_head)
+        st = part.io_stats
+        assert st["records_kept"] == idx.size
+        assert st["records_walked"] < 0.7 * whole.n_segs  # (head excluded: it is read for the insert-size estimate)
+    # no fetch at all: an empty table with the header and the head
+    empty = io_native.read_bam_regions(bam, [], [], [])
+    assert empty.n_segs == 0 and empty.contigs == whole.contigs

@@ -12,6 +12,10 @@
 // Stages: read file -> inflate BGZF blocks (parallel) -> walk record boundaries (serial, a pointer
 // chase) -> fixed-width columns + CIGAR / SEQ / QUAL payloads (parallel over records) -> query-name
 // interning in order of first appearance (hash-sharded, parallel) -> mate links (parallel).
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "io_common.hpp"
 
 namespace uzio {
@@ -198,6 +202,7 @@ struct uz_bam {
     std::vector<uint64_t> name_at; // per id: offset of the name in `data`
     std::vector<uint8_t> name_len;
     std::vector<int32_t> tlen_file;
+    int64_t io_stats[4] = {0, 0, 0, 0}; // file bytes read, BGZF blocks inflated, records walked, records kept
     mutable std::string name_tmp;
     double timing[4] = {0, 0, 0, 0};
 };
@@ -238,11 +243,34 @@ bool has_tag(const uint8_t *p, const uint8_t *end, char t0, char t1) {
     return false;
 }
 
+// BAM header at the start of the inflated stream d[0, N): fills the contig tables, returns the offset of the first record
+size_t parse_header(uz_bam &B, const uint8_t *d, size_t N, const char *path, int32_t &n_ref, bool allow_short = false) {
+    if (N < 12 || memcmp(d, "BAM\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAM file", path);
+    size_t off = 8 + (size_t)rdi32(d + 4);
+    if (off + 4 > N) { if (allow_short) return 0; fail(UZ_IO_E_FORMAT, "truncated BAM header"); }
+    n_ref = rdi32(d + off);
+    off += 4;
+    B.contigs.clear(); B.contig_len.clear();
+    for (int32_t r = 0; r < n_ref; r++) {
+        if (off + 4 > N) { if (allow_short) return 0; fail(UZ_IO_E_FORMAT, "truncated BAM header"); }
+        const int32_t l_name = rdi32(d + off);
+        if (l_name < 1) fail(UZ_IO_E_FORMAT, "bad BAM header");
+        if (off + 4 + (size_t)l_name + 4 > N) { if (allow_short) return 0; fail(UZ_IO_E_FORMAT, "truncated BAM header"); }
+        B.contigs.emplace_back((const char *)d + off + 4, (size_t)l_name - 1);
+        B.contig_len.push_back(rdi32(d + off + 4 + l_name));
+        off += 4 + (size_t)l_name + 4;
+    }
+    return off;
+}
+
+void build_table(uz_bam &B, std::vector<uint64_t> &rec, std::vector<uint32_t> &rec_end32, int32_t n_ref, int threads, double t2);
+
 void decode(uz_bam &B, const char *path, int threads) {
     double t0 = now_s();
     Bytes file = read_file(path);
     double t1 = now_s();
     B.timing[0] = t1 - t0;
+    B.io_stats[0] = (int64_t)file.size();
     bool gz = false;
     B.data = inflate_all(file, threads, &gz);
     file.release();
@@ -250,19 +278,8 @@ void decode(uz_bam &B, const char *path, int threads) {
     B.timing[1] = t2 - t1;
     const Bytes &d = B.data;
     const size_t N = d.size();
-    if (N < 12 || memcmp(d.data(), "BAM\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAM file", path);
-    size_t off = 8 + (size_t)rdi32(d.data() + 4);
-    if (off + 4 > N) fail(UZ_IO_E_FORMAT, "truncated BAM header");
-    const int32_t n_ref = rdi32(d.data() + off);
-    off += 4;
-    for (int32_t r = 0; r < n_ref; r++) {
-        if (off + 4 > N) fail(UZ_IO_E_FORMAT, "truncated BAM header");
-        const int32_t l_name = rdi32(d.data() + off);
-        if (l_name < 1 || off + 4 + (size_t)l_name + 4 > N) fail(UZ_IO_E_FORMAT, "truncated BAM header");
-        B.contigs.emplace_back((const char *)d.data() + off + 4, (size_t)l_name - 1);
-        B.contig_len.push_back(rdi32(d.data() + off + 4 + l_name));
-        off += 4 + (size_t)l_name + 4;
-    }
+    int32_t n_ref = 0;
+    size_t off = parse_header(B, d.data(), N, path, n_ref);
     // record boundaries (file order); kept records have a reference id
     std::vector<uint64_t> rec; // offsets of the kept records' fixed part (after block_size)
     std::vector<uint32_t> rec_end32; // block_size of the kept records
@@ -270,11 +287,18 @@ void decode(uz_bam &B, const char *path, int threads) {
         const int32_t bs = rdi32(d.data() + off);
         if (bs < 32 || off + 4 + (size_t)bs > N) fail(UZ_IO_E_FORMAT, "truncated alignment record at byte %zu", off);
         const uint8_t *p = d.data() + off + 4;
-        B.tlen_file.push_back(rdi32(p + 28));
+        if (B.tlen_file.size() < ((size_t)1 << 24)) B.tlen_file.push_back(rdi32(p + 28)); // the head of the file only (insert-size estimate)
         if (rdi32(p) >= 0) { rec.push_back(off + 4); rec_end32.push_back((uint32_t)bs); }
         off += 4 + (size_t)bs;
         B.n_file++;
     }
+    B.io_stats[2] = B.n_file;
+    build_table(B, rec, rec_end32, n_ref, threads, t2);
+}
+
+// columns, names and mate links of the records rec[] (offsets into B.data, file order)
+void build_table(uz_bam &B, std::vector<uint64_t> &rec, std::vector<uint32_t> &rec_end32, int32_t n_ref, int threads, double t2) {
+    const Bytes &d = B.data;
     const int64_t n = (int64_t)rec.size();
     threads = workers_for(n, threads, 16384); // a thread per 16k records at most
     if (n >= ((int64_t)1 << 31)) fail(UZ_IO_E_RANGE, "more than 2^31 - 1 alignment records");
@@ -470,6 +494,439 @@ void decode(uz_bam &B, const char *path, int threads) {
         }
     });
     B.timing[3] = now_s() - t3;
+    B.io_stats[3] = n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Region decode through the BAI index: what `bamfile.fetch(contig, lo, hi)` (read_collector.py:385, :167, :478-497)
+// and `bamfile.mate(read)` (:400, :185) hand the reference, without inflating the rest of the file.
+struct Chunk { uint64_t beg, end; }; // virtual file offsets (coffset << 16 | uoffset)
+
+struct BaiRef {
+    std::vector<std::pair<uint32_t, std::vector<Chunk>>> bins; // sorted by bin number
+    std::vector<uint64_t> linear;                              // 16 kb windows
+};
+
+std::vector<BaiRef> read_bai(const char *path) {
+    Bytes f = read_file(path);
+    const uint8_t *d = f.data();
+    const size_t N = f.size();
+    if (N < 8 || memcmp(d, "BAI\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAI index", path);
+    size_t off = 4;
+    auto need = [&](size_t k) { if (off + k > N) fail(UZ_IO_E_FORMAT, "truncated BAI index %s", path); };
+    need(4);
+    const int32_t n_ref = rdi32(d + off); off += 4;
+    std::vector<BaiRef> refs((size_t)std::max(n_ref, 0));
+    for (int32_t r = 0; r < n_ref; r++) {
+        need(4);
+        const int32_t n_bin = rdi32(d + off); off += 4;
+        for (int32_t b = 0; b < n_bin; b++) {
+            need(8);
+            const uint32_t bin = rd32(d + off);
+            const int32_t n_chunk = rdi32(d + off + 4);
+            off += 8;
+            need((size_t)n_chunk * 16);
+            std::vector<Chunk> cs;
+            if (bin != 37450) { // the pseudo-bin holds counts, not chunks
+                for (int32_t k = 0; k < n_chunk; k++) {
+                    Chunk c;
+                    memcpy(&c.beg, d + off + 16 * (size_t)k, 8);
+                    memcpy(&c.end, d + off + 16 * (size_t)k + 8, 8);
+                    cs.push_back(c);
+                }
+                refs[(size_t)r].bins.emplace_back(bin, std::move(cs));
+            }
+            off += (size_t)n_chunk * 16;
+        }
+        std::sort(refs[(size_t)r].bins.begin(), refs[(size_t)r].bins.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+        need(4);
+        const int32_t n_intv = rdi32(d + off); off += 4;
+        need((size_t)n_intv * 8);
+        refs[(size_t)r].linear.resize((size_t)n_intv);
+        if (n_intv) memcpy(refs[(size_t)r].linear.data(), d + off, (size_t)n_intv * 8);
+        off += (size_t)n_intv * 8;
+    }
+    return refs;
+}
+
+// bins a region [beg, end) may have records in (SAM spec, reg2bins)
+void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &out) {
+    out.clear();
+    if (beg < 0) beg = 0;
+    if (end <= beg) end = beg + 1;
+    --end;
+    out.push_back(0);
+    for (uint32_t k = 1 + (uint32_t)(beg >> 26); k <= 1 + (uint32_t)(end >> 26); ++k) out.push_back(k);
+    for (uint32_t k = 9 + (uint32_t)(beg >> 23); k <= 9 + (uint32_t)(end >> 23); ++k) out.push_back(k);
+    for (uint32_t k = 73 + (uint32_t)(beg >> 20); k <= 73 + (uint32_t)(end >> 20); ++k) out.push_back(k);
+    for (uint32_t k = 585 + (uint32_t)(beg >> 17); k <= 585 + (uint32_t)(end >> 17); ++k) out.push_back(k);
+    for (uint32_t k = 4681 + (uint32_t)(beg >> 14); k <= 4681 + (uint32_t)(end >> 14); ++k) out.push_back(k);
+}
+
+struct Iv { int32_t lo, hi; };
+
+// file access for the region reader
+struct FileRd {
+    int fd = -1;
+    int64_t size = 0;
+    explicit FileRd(const char *path) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) fail(UZ_IO_E_OPEN, "cannot open %s", path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) { close(fd); fail(UZ_IO_E_OPEN, "cannot stat %s", path); }
+        size = (int64_t)st.st_size;
+    }
+    ~FileRd() { if (fd >= 0) close(fd); }
+    // bytes [off, off + len) clipped to the file; returns the count read
+    size_t read_at(int64_t off, uint8_t *dst, size_t len) const {
+        size_t got = 0;
+        while (got < len && off + (int64_t)got < size) {
+            const ssize_t k = pread(fd, dst + got, len - got, (off_t)(off + (int64_t)got));
+            if (k <= 0) break;
+            got += (size_t)k;
+        }
+        return got;
+    }
+};
+
+// Inflates consecutive BGZF blocks starting at compressed offset `coff` until the block holding the virtual offset
+// `vend` has been inflated AND the bytes needed by `more()` are there.  out: the inflated bytes of those blocks;
+// block_at: (compressed offset, offset in out) per block.
+struct Inflated {
+    std::vector<uint8_t> bytes;
+    std::vector<std::pair<int64_t, size_t>> block_at;
+    int64_t next_coff = 0;
+};
+
+bool inflate_one(const FileRd &f, int64_t coff, Inflated &o, z_stream &z, std::vector<uint8_t> &cbuf, int64_t *file_bytes, int64_t *blocks) {
+    uint8_t h[18];
+    if (f.read_at(coff, h, 18) != 18) return false; // end of file
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) fail(UZ_IO_E_FORMAT, "not a BGZF block at byte %lld", (long long)coff);
+    const size_t xlen = rd16(h + 10);
+    cbuf.resize(12 + xlen);
+    if (f.read_at(coff, cbuf.data(), 12 + xlen) != 12 + xlen) fail(UZ_IO_E_FORMAT, "truncated BGZF block");
+    size_t q = 12, bsize = 0;
+    bool found = false;
+    while (q + 4 <= 12 + xlen) {
+        const size_t slen = rd16(cbuf.data() + q + 2);
+        if (cbuf[q] == 'B' && cbuf[q + 1] == 'C' && slen == 2) { bsize = rd16(cbuf.data() + q + 4); found = true; }
+        q += 4 + slen;
+    }
+    if (!found) fail(UZ_IO_E_FORMAT, "BGZF block without a BC field at byte %lld", (long long)coff);
+    const size_t blen = bsize + 1;
+    cbuf.resize(blen);
+    if (f.read_at(coff, cbuf.data(), blen) != blen) fail(UZ_IO_E_FORMAT, "truncated BGZF block at byte %lld", (long long)coff);
+    const uint32_t crc = rd32(cbuf.data() + blen - 8), isize = rd32(cbuf.data() + blen - 4);
+    const size_t at = o.bytes.size();
+    o.block_at.emplace_back(coff, at);
+    o.bytes.resize(at + isize);
+    if (isize) {
+        inflateReset(&z);
+        z.next_in = cbuf.data() + 12 + xlen;
+        z.avail_in = (uInt)(blen - 12 - xlen - 8);
+        z.next_out = o.bytes.data() + at;
+        z.avail_out = isize;
+        const int rc = inflate(&z, Z_FINISH);
+        if (rc != Z_STREAM_END || z.avail_out != 0) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
+        if ((uint32_t)crc32(0L, o.bytes.data() + at, isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
+    }
+    o.next_coff = coff + (int64_t)blen;
+    if (file_bytes) *file_bytes += (int64_t)blen;
+    if (blocks) *blocks += 1;
+    return true;
+}
+
+struct Kept { // one kept record: where it starts in the file, its bytes (block_size word included)
+    uint64_t voff;
+    std::vector<uint8_t> bytes;
+    bool direct = false; // returned by one of the fetches (not only as a mate candidate)
+};
+
+// walks the records of one chunk [beg, end) and keeps those `want(tid, pos, end, record)` accepts
+template <typename W>
+void walk_chunk(const FileRd &f, Chunk ck, W &&want, std::vector<Kept> &out, int64_t *file_bytes, int64_t *blocks, int64_t *walked) {
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
+    std::vector<uint8_t> cbuf;
+    Inflated inf;
+    try {
+        int64_t coff = (int64_t)(ck.beg >> 16);
+        if (!inflate_one(f, coff, inf, z, cbuf, file_bytes, blocks)) { inflateEnd(&z); return; }
+        size_t at = (size_t)(ck.beg & 0xFFFF); // offset in inf.bytes of the next record
+        size_t blk = 0;                        // block the next record starts in
+        for (;;) {
+            // virtual offset of the record at `at`
+            while (blk + 1 < inf.block_at.size() && inf.block_at[blk + 1].second <= at) blk++;
+            // a record starting exactly at the end of the last inflated block starts in the NEXT block
+            while (at >= inf.bytes.size()) {
+                if (!inflate_one(f, inf.next_coff, inf, z, cbuf, file_bytes, blocks)) { inflateEnd(&z); return; }
+                while (blk + 1 < inf.block_at.size() && inf.block_at[blk + 1].second <= at) blk++;
+            }
+            const uint64_t voff = ((uint64_t)inf.block_at[blk].first << 16) | (uint64_t)(at - inf.block_at[blk].second);
+            if (voff >= ck.end) break;
+            while (at + 4 > inf.bytes.size())
+                if (!inflate_one(f, inf.next_coff, inf, z, cbuf, file_bytes, blocks)) fail(UZ_IO_E_FORMAT, "truncated alignment record");
+            const int32_t bs = rdi32(inf.bytes.data() + at);
+            if (bs < 32) fail(UZ_IO_E_FORMAT, "bad alignment record at virtual offset %llu", (unsigned long long)voff);
+            while (at + 4 + (size_t)bs > inf.bytes.size())
+                if (!inflate_one(f, inf.next_coff, inf, z, cbuf, file_bytes, blocks)) fail(UZ_IO_E_FORMAT, "truncated alignment record");
+            const uint8_t *p = inf.bytes.data() + at + 4;
+            if (walked) *walked += 1;
+            const int32_t tid = rdi32(p), pos = rdi32(p + 4);
+            const uint32_t l_name = p[8], ncig = rd16(p + 12);
+            const uint16_t fl = rd16(p + 14);
+            int64_t rl = 0;
+            const uint8_t *q = p + 32 + l_name;
+            if (32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
+            for (uint32_t k = 0; k < ncig; k++) {
+                const uint32_t v = rd32(q + 4 * k), op = v & 15;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += v >> 4;
+            }
+            const int32_t end = (fl & FUNMAP) || ncig == 0 ? pos + 1 : (int32_t)(pos + (rl > 0 ? rl : 1));
+            if (tid >= 0 && want(tid, pos, end, p, (uint32_t)bs)) {
+                Kept k;
+                k.voff = voff;
+                k.bytes.assign(inf.bytes.data() + at, inf.bytes.data() + at + 4 + (size_t)bs);
+                out.push_back(std::move(k));
+            }
+            at += 4 + (size_t)bs;
+        }
+    } catch (...) { inflateEnd(&z); throw; }
+    inflateEnd(&z);
+}
+
+// chunks of the file that can hold records overlapping the intervals of one contig (sorted, merged)
+void chunks_for(const BaiRef &ref, const std::vector<Iv> &ivs, std::vector<Chunk> &out) {
+    std::vector<uint32_t> bins;
+    std::vector<Chunk> cs;
+    for (const Iv &iv : ivs) {
+        reg2bins(iv.lo, iv.hi, bins);
+        uint64_t min_off = 0;
+        const size_t w = (size_t)(std::max<int64_t>(iv.lo, 0) >> 14);
+        if (!ref.linear.empty()) min_off = ref.linear[std::min(w, ref.linear.size() - 1)];
+        if (w >= ref.linear.size() && !ref.linear.empty()) min_off = ref.linear.back();
+        for (uint32_t b : bins) {
+            auto it = std::lower_bound(ref.bins.begin(), ref.bins.end(), b, [](const auto &a, uint32_t key) { return a.first < key; });
+            if (it == ref.bins.end() || it->first != b) continue;
+            for (const Chunk &c : it->second)
+                if (c.end > min_off) cs.push_back(Chunk{std::max(c.beg, min_off), c.end});
+        }
+    }
+    std::sort(cs.begin(), cs.end(), [](const Chunk &a, const Chunk &b) { return a.beg < b.beg || (a.beg == b.beg && a.end < b.end); });
+    for (const Chunk &c : cs) {
+        // merge chunks that touch or lie in the same compressed block neighbourhood: no record is walked twice
+        if (!out.empty() && c.beg <= out.back().end) out.back().end = std::max(out.back().end, c.end);
+        else out.push_back(c);
+    }
+}
+
+void decode_regions(uz_bam &B, const char *path, const char *bai_path, int64_t n_iv, const int32_t *iv_tid, const int32_t *iv_lo,
+                    const int32_t *iv_hi, int64_t head_records, int threads) {
+    double t0 = now_s();
+    threads = resolve_threads(threads);
+    FileRd f(path);
+    std::string bai = bai_path ? std::string(bai_path) : std::string(path) + ".bai";
+    if (!bai_path) { // NAME.bam.bai or NAME.bai
+        FILE *t = fopen(bai.c_str(), "rb");
+        if (t) fclose(t);
+        else { std::string alt(path); if (alt.size() > 4) alt = alt.substr(0, alt.size() - 4) + ".bai"; bai = alt; }
+    }
+    const std::vector<BaiRef> refs = read_bai(bai.c_str());
+    int64_t file_bytes = 0, blocks = 0, walked_n = 0;
+    // header: inflate from the start of the file until it parses
+    int32_t n_ref = 0;
+    std::vector<uint8_t> header;
+    {
+        z_stream z;
+        memset(&z, 0, sizeof(z));
+        if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
+        std::vector<uint8_t> cbuf;
+        Inflated inf;
+        size_t off = 0;
+        try {
+            int64_t coff = 0;
+            for (;;) {
+                if (!inflate_one(f, coff, inf, z, cbuf, &file_bytes, &blocks)) fail(UZ_IO_E_FORMAT, "truncated BAM header");
+                coff = inf.next_coff;
+                off = parse_header(B, inf.bytes.data(), inf.bytes.size(), path, n_ref, true);
+                if (off) break;
+            }
+            // the first records of the FILE: estimate_concordant_insert_len reads them (read_collector.py:11-25)
+            size_t at = off;
+            while ((int64_t)B.tlen_file.size() < head_records) {
+                bool eof = false;
+                while (at + 4 > inf.bytes.size() && !eof) eof = !inflate_one(f, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks);
+                if (at + 4 > inf.bytes.size()) break;
+                const int32_t bs = rdi32(inf.bytes.data() + at);
+                if (bs < 32) fail(UZ_IO_E_FORMAT, "bad alignment record in the head of the file");
+                while (at + 4 + (size_t)bs > inf.bytes.size() && !eof) eof = !inflate_one(f, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks);
+                if (at + 4 + (size_t)bs > inf.bytes.size()) break;
+                B.tlen_file.push_back(rdi32(inf.bytes.data() + at + 4 + 28));
+                at += 4 + (size_t)bs;
+            }
+        } catch (...) { inflateEnd(&z); throw; }
+        inflateEnd(&z);
+        header.assign(inf.bytes.begin(), inf.bytes.begin() + (ptrdiff_t)off);
+    }
+    if ((size_t)n_ref != refs.size()) fail(UZ_IO_E_FORMAT, "the index %s holds %zu references, the BAM header %d", bai.c_str(), refs.size(), n_ref);
+
+    // The pool: every record of every chunk walked so far (file order).  Chunks are walked at most once: `walked` holds
+    // the merged virtual-offset ranges already read, and a later request only reads what lies outside them.
+    struct TidIvs { std::vector<Iv> ivs; int32_t max_len = 0; };
+    std::vector<Kept> pool;
+    std::vector<Chunk> walked;
+    auto ensure_walked = [&](std::vector<TidIvs> &per_tid) {
+        std::vector<Chunk> want;
+        for (int32_t t = 0; t < n_ref; t++) {
+            auto &ivs = per_tid[(size_t)t].ivs;
+            if (ivs.empty()) continue;
+            std::sort(ivs.begin(), ivs.end(), [](const Iv &x, const Iv &y) { return x.lo < y.lo || (x.lo == y.lo && x.hi < y.hi); });
+            for (const Iv &iv : ivs) per_tid[(size_t)t].max_len = std::max(per_tid[(size_t)t].max_len, iv.hi - iv.lo);
+            chunks_for(refs[(size_t)t], ivs, want);
+        }
+        std::sort(want.begin(), want.end(), [](const Chunk &x, const Chunk &y) { return x.beg < y.beg; });
+        std::vector<Chunk> merged;
+        for (const Chunk &c : want) {
+            if (!merged.empty() && c.beg <= merged.back().end) merged.back().end = std::max(merged.back().end, c.end);
+            else merged.push_back(c);
+        }
+        // minus what has been walked
+        std::vector<Chunk> work;
+        size_t w = 0;
+        for (Chunk c : merged) {
+            while (w < walked.size() && walked[w].end <= c.beg) w++;
+            size_t k = w;
+            while (c.beg < c.end) {
+                if (k >= walked.size() || walked[k].beg >= c.end) { work.push_back(c); break; }
+                if (walked[k].beg > c.beg) work.push_back(Chunk{c.beg, walked[k].beg});
+                c.beg = std::max(c.beg, walked[k].end);
+                k++;
+            }
+        }
+        if (work.empty()) return;
+        std::vector<std::vector<Kept>> found(work.size());
+        const int wk = workers_for((int64_t)work.size(), threads, 1);
+        std::vector<int64_t> fb((size_t)wk, 0), bl((size_t)wk, 0), wa((size_t)wk, 0);
+        parallel_slices((int64_t)work.size(), wk, [&](int64_t lo, int64_t hi, int wi) {
+            for (int64_t k = lo; k < hi; k++)
+                walk_chunk(f, work[(size_t)k], [](int32_t, int32_t, int32_t, const uint8_t *, uint32_t) { return true; }, found[(size_t)k],
+                           &fb[(size_t)wi], &bl[(size_t)wi], &wa[(size_t)wi]);
+        });
+        for (int k = 0; k < wk; k++) { file_bytes += fb[(size_t)k]; blocks += bl[(size_t)k]; walked_n += wa[(size_t)k]; }
+        for (auto &v : found) for (auto &k : v) pool.push_back(std::move(k));
+        std::sort(pool.begin(), pool.end(), [](const Kept &x, const Kept &y) { return x.voff < y.voff; });
+        for (const Chunk &c : work) walked.push_back(c);
+        std::sort(walked.begin(), walked.end(), [](const Chunk &x, const Chunk &y) { return x.beg < y.beg; });
+        std::vector<Chunk> m2;
+        for (const Chunk &c : walked) {
+            if (!m2.empty() && c.beg <= m2.back().end) m2.back().end = std::max(m2.back().end, c.end);
+            else m2.push_back(c);
+        }
+        walked.swap(m2);
+    };
+    struct Info { int32_t tid, pos, end, mtid, mpos; uint16_t flag; uint64_t h; };
+    auto info_of = [](const Kept &k) {
+        const uint8_t *p = k.bytes.data() + 4;
+        const uint32_t l_name = p[8], ncig = rd16(p + 12);
+        Info x;
+        x.tid = rdi32(p); x.pos = rdi32(p + 4); x.flag = rd16(p + 14); x.mtid = rdi32(p + 20); x.mpos = rdi32(p + 24);
+        int64_t rl = 0;
+        const uint8_t *q = p + 32 + l_name;
+        for (uint32_t c = 0; c < ncig; c++) { const uint32_t v = rd32(q + 4 * c), op = v & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += v >> 4; }
+        x.end = (x.flag & FUNMAP) || ncig == 0 ? x.pos + 1 : (int32_t)(x.pos + (rl > 0 ? rl : 1));
+        x.h = hash_bytes(p + 32, (size_t)l_name - 1);
+        return x;
+    };
+
+    // the fetches themselves
+    std::vector<TidIvs> per_tid((size_t)n_ref);
+    for (int64_t k = 0; k < n_iv; k++)
+        if (iv_tid[k] >= 0 && iv_tid[k] < n_ref && iv_hi[k] > iv_lo[k]) per_tid[(size_t)iv_tid[k]].ivs.push_back(Iv{iv_lo[k], iv_hi[k]});
+    ensure_walked(per_tid);
+    // members of the result, by virtual offset; frontier: members whose mate has not been looked up yet
+    std::vector<uint64_t> member, frontier;
+    for (const Kept &k : pool) {
+        const uint8_t *p = k.bytes.data() + 4;
+        const int32_t tid = rdi32(p);
+        if (tid < 0 || tid >= n_ref) continue;
+        const auto &ivs = per_tid[(size_t)tid].ivs;
+        if (ivs.empty()) continue;
+        const Info x = info_of(k);
+        auto a = std::lower_bound(ivs.begin(), ivs.end(), (int64_t)x.pos - per_tid[(size_t)tid].max_len,
+                                  [](const Iv &v, int64_t key) { return (int64_t)v.lo < key; });
+        bool hit = false;
+        for (; a != ivs.end() && a->lo < x.end && !hit; ++a) hit = a->hi > x.pos;
+        if (hit) { member.push_back(k.voff); frontier.push_back(k.voff); }
+    }
+    // mate(): the FIRST record in file order with the name that overlaps the mate position on the mate's contig and carries
+    // the other read-of-pair flag (it may be a secondary / supplementary record).  Transitively: the kernel follows
+    // mate(mate(r)) for the reads at the DNM.  Generation by generation, so that the chunks a generation needs are
+    // read together.
+    for (int gen = 0; gen < 64 && !frontier.empty(); gen++) {
+        auto at = [&](uint64_t voff) { return (size_t)(std::lower_bound(pool.begin(), pool.end(), voff, [](const Kept &k, uint64_t key) { return k.voff < key; }) - pool.begin()); };
+        std::vector<TidIvs> mate_iv((size_t)n_ref);
+        for (uint64_t v : frontier) {
+            const Info x = info_of(pool[at(v)]);
+            if ((x.flag & FPAIRED) && !(x.flag & FMUNMAP) && x.mtid >= 0 && x.mtid < n_ref) mate_iv[(size_t)x.mtid].ivs.push_back(Iv{x.mpos, x.mpos + 1});
+        }
+        ensure_walked(mate_iv); // the pool may grow (and re-sort): look positions up again below
+        std::vector<std::pair<uint64_t, int32_t>> by_name(pool.size());
+        std::vector<Info> info(pool.size());
+        for (size_t i = 0; i < pool.size(); i++) { info[i] = info_of(pool[i]); by_name[i] = {info[i].h, (int32_t)i}; }
+        std::sort(by_name.begin(), by_name.end());
+        std::vector<uint64_t> next;
+        for (uint64_t v : frontier) {
+            const size_t i = at(v);
+            const Info &x = info[i];
+            if (!(x.flag & FPAIRED) || (x.flag & FMUNMAP) || x.mtid < 0 || x.mtid >= n_ref) continue;
+            const uint16_t want = (uint16_t)((x.flag ^ (FREAD1 | FREAD2)) & (FREAD1 | FREAD2));
+            const uint8_t *pi = pool[i].bytes.data() + 4;
+            auto it = std::lower_bound(by_name.begin(), by_name.end(), std::make_pair(x.h, (int32_t)-1));
+            for (; it != by_name.end() && it->first == x.h; ++it) {
+                const size_t j = (size_t)it->second;
+                const Info &y = info[j];
+                const uint8_t *pj = pool[j].bytes.data() + 4;
+                if (pj[8] != pi[8] || memcmp(pj + 32, pi + 32, (size_t)pi[8] - 1) != 0) continue;
+                if (y.tid != x.mtid) continue;
+                if (!((int64_t)y.pos < (int64_t)x.mpos + 1 && (int64_t)y.end > (int64_t)x.mpos)) continue;
+                if (y.flag & want) { next.push_back(pool[j].voff); break; }
+            }
+        }
+        std::sort(member.begin(), member.end());
+        std::sort(next.begin(), next.end());
+        next.erase(std::unique(next.begin(), next.end()), next.end());
+        frontier.clear();
+        for (uint64_t v : next)
+            if (!std::binary_search(member.begin(), member.end(), v)) frontier.push_back(v);
+        for (uint64_t v : frontier) member.push_back(v);
+    }
+    std::sort(member.begin(), member.end());
+    std::vector<Kept> kept;
+    for (Kept &k : pool)
+        if (std::binary_search(member.begin(), member.end(), k.voff)) kept.push_back(std::move(k));
+    pool.clear();
+    double t1 = now_s();
+    B.timing[0] = 0;
+    B.timing[1] = t1 - t0;
+    // the table is built from a stream holding the header and the kept records only
+    size_t total = header.size();
+    for (const Kept &k : kept) total += k.bytes.size();
+    B.data.alloc(total);
+    memcpy(B.data.data(), header.data(), header.size());
+    std::vector<uint64_t> rec;
+    std::vector<uint32_t> rec_end32;
+    size_t at = header.size();
+    for (const Kept &k : kept) {
+        memcpy(B.data.data() + at, k.bytes.data(), k.bytes.size());
+        rec.push_back(at + 4);
+        rec_end32.push_back((uint32_t)(k.bytes.size() - 4));
+        at += k.bytes.size();
+    }
+    B.n_file = (int64_t)B.tlen_file.size();
+    B.io_stats[0] = file_bytes; B.io_stats[1] = blocks; B.io_stats[2] = walked_n;
+    kept.clear();
+    build_table(B, rec, rec_end32, n_ref, threads, t1);
 }
 
 template <typename F>
@@ -506,6 +963,21 @@ int uz_bam_decode(const char *path, int threads, uz_bam **out) {
     if (rc != UZ_IO_OK) { delete h; return rc; }
     *out = h;
     return UZ_IO_OK;
+}
+
+int uz_bam_decode_regions(const char *path, const char *bai_path, int64_t n_iv, const int32_t *tid, const int32_t *lo, const int32_t *hi,
+                          int64_t head_records, int threads, uz_bam **out) {
+    if (!path || !out || (n_iv > 0 && (!tid || !lo || !hi))) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    *out = nullptr;
+    uz_bam *b = new uz_bam();
+    const int rc = guarded([&] { decode_regions(*b, path, bai_path, n_iv, tid, lo, hi, head_records, threads); });
+    if (rc != UZ_IO_OK) { delete b; return rc; }
+    *out = b;
+    return UZ_IO_OK;
+}
+
+void uz_bam_io_stats(const uz_bam *h, int64_t out[4]) {
+    for (int k = 0; k < 4; k++) out[k] = h ? h->io_stats[k] : 0;
 }
 
 void uz_bam_free(uz_bam *h) { delete h; }

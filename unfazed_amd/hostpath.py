@@ -107,10 +107,23 @@ class PhasingHost:
             self._fam_h[key] = self.backend.add_family(self._sites_h, gt, rd, ad, gq)
         return self._fam_h[key]
 
-    def reads(self, bam: str):
-        if bam not in self._reads_h:
-            self._reads_h[bam] = self.backend.upload_reads(self.reads_by_bam[bam])
-        return self._reads_h[bam]
+    def reads(self, bam: str, min_base_qual: int):
+        """device handle of the whole table of a BAM (kept for the life of the host), staged for this base-quality threshold"""
+        key = (bam, int(min_base_qual))
+        if key not in self._reads_h:
+            self._reads_h[key] = self.backend.upload_reads(self.reads_by_bam[bam], min_base_qual=int(min_base_qual))
+        return self._reads_h[key]
+
+    def _indexed(self, bam: str) -> bool:
+        """does the reads source decode regions of this file through an index (session._LazyReads)?"""
+        f = getattr(self.reads_by_bam, "indexed", None)
+        return bool(f and f(bam))
+
+    def reads_header(self, bam: str) -> ReadsTable:
+        """what the host logic needs before any record is decoded: contig names and the head of the file (insert cutoff)"""
+        if self._indexed(bam):
+            return self.reads_by_bam.header(bam)
+        return self.reads_by_bam[bam]
 
     # --------------------------------------------------------------- find
     def find(
@@ -321,7 +334,7 @@ class PhasingHost:
 
     def kid_cutoff(self, kid: str, bam: str, readlen: int, stdevs: int, insert_size_max_sample: int) -> float:
         if kid not in self.cutoffs or not self.cutoffs[kid]:  # snv_phaser.py:133-135, read_collector.py:377
-            rt = self.reads_by_bam[bam]
+            rt = self.reads_header(bam)
             head = getattr(rt, "tlen_head", None)
             if head is None:
                 head = rt.tlen
@@ -401,7 +414,7 @@ class PhasingHost:
                 if len(alts) > 1:
                     plan.append((i, "manygt"))
                     continue
-            rt = self.reads_by_bam[dn["bam"]]
+            rt = self.reads_header(dn["bam"])
             tid, fl = self.resolve_reads_contig(rt, dn["chrom"])
             if tid < 0:
                 plan.append((i, "silent"))  # ValueError out of the worker: no record
@@ -414,8 +427,24 @@ class PhasingHost:
         for (kid, bam), idxs in batch.items():
             dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
             fam = self.family(kid, dad_id, mom_id)
-            rh = self.reads(bam)
             cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
+            region_table = None
+            if self._indexed(bam):
+                # decode only what the batch's fetches can return (+ mates) through the index: the read stage looks at
+                # nothing else (read_collector.py:385, :167, :400), so nothing else is inflated, staged or uploaded
+                from .staging import fetch_points
+                het_off = np.zeros(len(idxs) + 1, np.int64)
+                for k, i in enumerate(idxs):
+                    het_off[k + 1] = het_off[k] + len(found[i]["het_idx"])
+                het_idx = np.concatenate([found[i]["het_idx"] for i in idxs] + [np.zeros(0, np.int32)]).astype(np.int64)
+                fc, flo, fhi = fetch_points(
+                    [prep[i]["tid"] for i in idxs], [int(dnms[i]["start"]) for i in idxs], [prep[i]["dflags"] for i in idxs],
+                    self.sites.pos, het_off, het_idx, params, vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
+                    end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff)
+                region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
+                rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual))
+            else:
+                rh = self.reads(bam, params.min_gt_qual)
             name_of = {}
             for i in idxs:
                 nm = self.prefix + dnms[i]["chrom"].strip("chr")
@@ -434,6 +463,11 @@ class PhasingHost:
             )
             fl = [found[i] for i in idxs]
             res = self.backend.phase(fam, rh, dv, params, fl, want_lists, find_mode=info["mode"])
+            if region_table is not None:
+                res["table"] = region_table  # query names of the vote lists are ids of THIS table
+                free = getattr(self.backend, "free_reads", None)
+                if free:
+                    free(rh)
             for k, i in enumerate(idxs):
                 results[i] = (res, k)
         # pass 3: records, in the reference's order
@@ -476,7 +510,7 @@ class PhasingHost:
                     # ST_REF_EXCEPTION: the reference's worker raises (KeyError in connect_reads) and the default
                     # thread pool swallows it: no record, no message
                     continue
-                rt = self.reads_by_bam[dn["bam"]]
+                rt = res.get("table") or self.reads_by_bam[dn["bam"]]
                 lists = res.get("lists")
                 if lists is not None:
                     dr, mr, ds, ms = lists[k]

@@ -24,7 +24,7 @@ _LIB = None
 IO_EXPORTS = [
     "uz_io_last_error", "uz_bam_decode", "uz_bam_free", "uz_bam_n_contigs", "uz_bam_contig_name",
     "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
-    "uz_bam_tlen_head", "uz_bam_timing", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
+    "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
     "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_reads_select_fill", "uz_select_free",
@@ -58,6 +58,10 @@ def load():
     lib.uz_bam_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_bam_free.argtypes = [C.c_void_p]
     lib.uz_bam_free.restype = None
+    lib.uz_bam_decode_regions.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                          C.POINTER(C.c_void_p)]
+    lib.uz_bam_io_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_bam_io_stats.restype = None
     lib.uz_bam_n_contigs.argtypes = [C.c_void_p]
     lib.uz_bam_contig_name.argtypes = [C.c_void_p, C.c_int32]
     lib.uz_bam_contig_name.restype = C.c_char_p
@@ -156,12 +160,7 @@ class _Names(Sequence):
         return C.string_at(p, ln.value).decode()
 
 
-def read_bam_table(path: str, threads: int = 0, insert_size_max_sample: int = 1000000) -> ReadsTable:
-    """BAM -> ReadsTable (columns are views into the native handle, kept alive by the table)."""
-    lib = load()
-    hp = C.c_void_p()
-    _check(lib, lib.uz_bam_decode(os.fsencode(path), int(threads), C.byref(hp)))
-    h = _Handle(hp.value, lib.uz_bam_free)
+def _table_from_handle(lib, h, insert_size_max_sample: int) -> ReadsTable:
     nc = lib.uz_bam_n_contigs(h.ptr)
     t = ReadsTable([lib.uz_bam_contig_name(h.ptr, i).decode() for i in range(nc)])
     v = abi.ReadsView()
@@ -190,8 +189,40 @@ def read_bam_table(path: str, threads: int = 0, insert_size_max_sample: int = 10
     tm = (C.c_double * 4)()
     lib.uz_bam_timing(h.ptr, tm)
     t.decode_seconds = dict(zip(("read", "inflate", "columns", "names+mates"), (float(x) for x in tm)))
+    st = (C.c_int64 * 4)()
+    lib.uz_bam_io_stats(h.ptr, st)
+    t.io_stats = dict(zip(("file_bytes_read", "blocks_inflated", "records_walked", "records_kept"), (int(x) for x in st)))
     t._native = h  # owns the memory behind the views
     return t
+
+
+def read_bam_table(path: str, threads: int = 0, insert_size_max_sample: int = 1000000) -> ReadsTable:
+    """BAM -> ReadsTable (columns are views into the native handle, kept alive by the table)."""
+    lib = load()
+    hp = C.c_void_p()
+    _check(lib, lib.uz_bam_decode(os.fsencode(path), int(threads), C.byref(hp)))
+    return _table_from_handle(lib, _Handle(hp.value, lib.uz_bam_free), insert_size_max_sample)
+
+
+def bam_index_path(path: str):
+    """the BAI next to a BAM (NAME.bam.bai or NAME.bai), or None"""
+    for cand in (path + ".bai", path[:-4] + ".bai" if path.endswith(".bam") else None):
+        if cand and os.path.isfile(cand):
+            return cand
+    return None
+
+
+def read_bam_regions(path: str, tid, lo, hi, threads: int = 0, insert_size_max_sample: int = 1000000, bai: str = None) -> ReadsTable:
+    """Index-driven decode: the records the fetches (tid[k], lo[k], hi[k]) return plus, closed under mate(), their mates
+    (uz_bam_decode_regions) -- what pysam's fetch() / mate() hand the reference, without inflating the rest of the file."""
+    lib = load()
+    tid = np.ascontiguousarray(tid, np.int32)
+    lo = np.ascontiguousarray(lo, np.int32)
+    hi = np.ascontiguousarray(hi, np.int32)
+    hp = C.c_void_p()
+    _check(lib, lib.uz_bam_decode_regions(os.fsencode(path), os.fsencode(bai) if bai else None, int(tid.size), tid.ctypes.data,
+                                          lo.ctypes.data, hi.ctypes.data, int(insert_size_max_sample) + 1, int(threads), C.byref(hp)))
+    return _table_from_handle(lib, _Handle(hp.value, lib.uz_bam_free), insert_size_max_sample)
 
 
 class _Strings(Sequence):

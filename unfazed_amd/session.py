@@ -88,15 +88,35 @@ def load_reads(name: str, insert_size_max_sample: int = 1000000) -> ReadsTable:
 
 
 class _LazyReads(dict):
-    """reads_by_bam mapping that decodes a BAM on first use"""
+    """reads_by_bam mapping of the session.  A BAM with a BAI next to it is never decoded whole: `header` gives the
+    contig names and the head of the file, `regions` decodes what a batch's fetches return (+ mates) through the index
+    (UZ_IO_INDEX=0 turns that off).  Anything else (no index, tables registered in memory) is decoded / taken whole on
+    first use."""
 
     def __init__(self, insert_size_max_sample):
         super().__init__()
         self.cap = insert_size_max_sample
+        self._headers: Dict[str, ReadsTable] = {}
 
     def __missing__(self, key):
         self[key] = load_reads(key, self.cap)
         return self[key]
+
+    def indexed(self, bam: str) -> bool:
+        if bam in _READS or bam in self or _python_io() or os.environ.get("UZ_IO_INDEX", "1") == "0":
+            return False
+        from .io_native import bam_index_path
+        return bam.endswith(".bam") and os.path.isfile(bam) and bam_index_path(bam) is not None
+
+    def header(self, bam: str) -> ReadsTable:
+        if bam not in self._headers:
+            from .io_native import read_bam_regions
+            self._headers[bam] = read_bam_regions(bam, [], [], [], threads=_io_threads(), insert_size_max_sample=self.cap)
+        return self._headers[bam]
+
+    def regions(self, bam: str, tid, lo, hi) -> ReadsTable:
+        from .io_native import read_bam_regions
+        return read_bam_regions(bam, tid, lo, hi, threads=_io_threads(), insert_size_max_sample=0)
 
 
 def host_for(sites, insert_size_max_sample: int = 1000000) -> PhasingHost:
