@@ -126,6 +126,15 @@ int uz_find_fetch(uz_ctx *ctx, int32_t *cand_idx, uint8_t *cand_flags, int32_t *
 int uz_phase(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode,
              int32_t *status /* [n] UZ_ST_* */, int32_t *counts /* [4n] */,
              int32_t *origin /* [n] UZ_OR_* */, int32_t *evidence /* [n] */);
+/* Cohort form (603 samples in one run, README.md:208; one alignment file per kid, unfazed.py:574-575): the
+ * DNMs of many kids -- each with its own trio columns, its own alignment records and its own insert cutoff -- in ONE
+ * launch sequence instead of one per kid.  `dnms` holds all groups' DNMs back to back; `rcontig` refers to the group's
+ * own reads table and dnms->cutoff is ignored.  All families must belong to one sites table.  The kids' tables are laid
+ * end to end in HBM as one table (virtual contigs = kid x contig; rebuilt only when the list of reads_ids changes), the
+ * window emit reads every DNM's own family column, the read stage every DNM's own cutoff.  Results as uz_phase, in DNM
+ * order; uz_phase_votes / uz_phase_groups afterwards give query-name ids of the group's own table. */
+int uz_phase_cohort(uz_ctx *ctx, const uz_cohort_group *groups, int32_t n_groups, const uz_dnms_view *dnms, int find_mode,
+                    int32_t *status, int32_t *counts, int32_t *origin, int32_t *evidence);
 /* Vote lists of the last uz_phase (for --verbose and the records dict):
  * vote_off[4n+1] then vote_val: dad_reads (qname ids, ascending), mom_reads,
  * dad_sites (positions, ascending), mom_sites.  Call with vote_val == NULL to get

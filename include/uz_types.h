@@ -202,6 +202,15 @@ typedef struct uz_dnms_view {
     double cutoff;              /* concordant_upper_len of this kid (read_collector.py:11-25) */
 } uz_dnms_view;
 
+/* one kid of a cohort batch (uz_phase_cohort) */
+typedef struct uz_cohort_group {
+    int32_t fam_id;    /* the kid's trio columns (uz_family_upload) */
+    int32_t reads_id;  /* the kid's alignment records */
+    int32_t dnm_first; /* its DNMs: [dnm_first, dnm_first + dnm_count) of the batch */
+    int32_t dnm_count;
+    double cutoff;     /* concordant_upper_len of the kid (read_collector.py:11-25) */
+} uz_cohort_group;
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,3 +47,23 @@ class OracleBackend:
     def phase_cnv(self, fam, dv, params, rb_counts=None, want_lists=True):
         sites_h, fv = fam
         return orc.phase_cnv(params, sites_h, fv, dv, rb_counts)
+
+    def phase_cohort(self, groups, dv, params, found_list, want_lists=True, find_mode=2):
+        """the cohort batch kid by kid (the oracle has no notion of a batch)"""
+        n = dv.view.n
+        out = dict(status=np.zeros(n, np.int32), counts=np.zeros((n, 4), np.int32), origin=np.zeros(n, np.int32),
+                   evidence=np.zeros(n, np.int32), lists=[None] * n if want_lists else None)
+        a = dv.arrays
+        for fam, rh, first, count, cutoff in groups:
+            sl = slice(first, first + count)
+            off = a["allele_off"]
+            refs = [bytes(a["alleles"][off[2 * k]: off[2 * k + 1]]) for k in range(first, first + count)]
+            alts = [bytes(a["alleles"][off[2 * k + 1]: off[2 * k + 2]]) for k in range(first, first + count)]
+            sub = abi.dnms_view(a["contig"][sl], a["rcontig"][sl], a["start"][sl], a["end"][sl], a["vartype"][sl], refs, alts, cutoff,
+                                dflags=a["dflags"][sl], mult=a["mult"][sl])
+            r = self.phase(fam, rh, sub, params, found_list[first: first + count], want_lists, find_mode)
+            for k in ("status", "counts", "origin", "evidence"):
+                out[k][sl] = r[k]
+            if want_lists:
+                out["lists"][sl] = r["lists"]
+        return out

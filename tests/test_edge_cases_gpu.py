@@ -118,7 +118,7 @@ def test_capacity_overflow_is_reported_not_dropped(engine, monkeypatch):
     from helpers import RUN_DEFAULTS, params_from, tables
     from synth.small import SmallConfig, make_small
     from unfazed_amd.hostpath import PhasingHost
-    ds = make_small(SmallConfig(seed=4141, n_dnms=8, cluster_prob=0.7))
+    ds = make_small(SmallConfig(seed=4141, n_dnms=24, cluster_prob=0.8))
     sites, reads = tables(ds)
     a = dict(RUN_DEFAULTS, quiet_mode=True)
 
@@ -132,8 +132,11 @@ def test_capacity_overflow_is_reported_not_dropped(engine, monkeypatch):
 
     full, err0, _ = run()
     assert err0 == "" and len(full) >= 2
-    monkeypatch.setenv("UZ_TEST_CAP_T", "150")
-    part, err1, host = run()
+    for cap in (600, 400, 250, 150, 80):  # shrink the registration scratch until some DNM of this dataset no longer fits
+        monkeypatch.setenv("UZ_TEST_CAP_T", str(cap))
+        part, err1, host = run()
+        if host.capacity_skipped:
+            break
     monkeypatch.delenv("UZ_TEST_CAP_T")
     assert len(host.capacity_skipped) >= 1
     assert err1.count("UZ_ST_CAPACITY") == len(host.capacity_skipped)

@@ -184,6 +184,12 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None) -> "
     return Held(v, arrs)
 
 
+class CohortGroup(C.Structure):
+    """uz_cohort_group: one kid of a cohort batch"""
+    _fields_ = [("fam_id", C.c_int32), ("reads_id", C.c_int32), ("dnm_first", C.c_int32), ("dnm_count", C.c_int32),
+                ("cutoff", C.c_double)]
+
+
 class DnmsView(C.Structure):
     _fields_ = [
         ("n", C.c_int32),

@@ -2,6 +2,8 @@
 // the decoded columns into HBM, and the launch sequence of the stages.
 #include "uz_ctx.hpp"
 
+#include <algorithm>
+
 void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n);
 bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv);
 
@@ -235,6 +237,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.alleles.release();
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
     c->ab_lut.release(); c->win_range.release();
+    c->dn_fam.release(); c->dn_cutoff.release(); c->fam_cls.release();
     c->cnv_counts.release(); c->cnv_pos.release(); c->cnv_origin.release(); c->cnv_evidence.release(); c->cnv_etype.release(); c->cnv_rb.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release();
@@ -585,6 +588,14 @@ int uz_reads_free(uz_ctx *c, int reads_id) {
         // the block goes back to the pool: whatever still reads or fills it must have finished
         if (r.ready) UZ_HIP(hipEventSynchronize(r.ready));
         UZ_HIP(hipStreamSynchronize(c->stream));
+        // a merged cohort table built from this table (or the merged table itself) is forgotten with it
+        const bool member = std::find(c->cohort_ids.begin(), c->cohort_ids.end(), reads_id) != c->cohort_ids.end();
+        if (reads_id == c->cohort_reads) { c->cohort_reads = -1; c->cohort_ids.clear(); }
+        else if (member && c->cohort_reads >= 0) {
+            free_reads(c, c->reads[(size_t)c->cohort_reads]);
+            c->cohort_reads = -1;
+            c->cohort_ids.clear();
+        }
         free_reads(c, r);
     });
 }
@@ -662,11 +673,139 @@ int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int fin
         // the read stage consumes the lists of a find over the same batch in SNV / breakpoint mode
         c->find_valid = false;
         c->phase_valid = false;
+        c->phase_qbase.clear();
         uz_stage_dnms(c, d);
         if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
         uz_launch_find(c, f, s, find_mode, false);
         c->find_fam = fam_id;
         uz_launch_phase(c, f, s, r, status, counts, origin, evidence);
+    });
+}
+
+int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, const uz_dnms_view *d, int find_mode, int32_t *status,
+                    int32_t *counts, int32_t *origin, int32_t *evidence) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(groups && n_groups > 0 && d, UZ_E_ARG, "bad cohort batch");
+        UZ_REQUIRE(!(find_mode & UZ_FIND_WHOLE_REGION), UZ_E_ARG, "the read stage runs on SNV / breakpoint windows");
+        const int32_t n = d->n;
+        FamilyDev &f0 = fam_of(c, groups[0].fam_id);
+        SitesDev &s = sites_of(c, f0.sites_id);
+        // ---- the kids' tables end to end as one table
+        std::vector<int> ids;
+        int64_t tot_n = 0, tot_c = 0, tot_u = 0, tot_contigs = 0;
+        uint64_t tot_q = 0;
+        for (int32_t g = 0; g < n_groups; g++) {
+            UZ_REQUIRE(groups[g].dnm_first >= 0 && groups[g].dnm_count >= 0 && groups[g].dnm_first + groups[g].dnm_count <= n, UZ_E_ARG,
+                       "cohort group outside the DNM batch");
+            UZ_REQUIRE(fam_of(c, groups[g].fam_id).sites_id == f0.sites_id, UZ_E_ARG, "the families of a cohort batch must share a sites table");
+            ReadsDev &r = reads_of(c, groups[g].reads_id);
+            UZ_REQUIRE(groups[g].reads_id != c->cohort_reads, UZ_E_ARG, "the merged cohort table cannot be a member of a cohort");
+            if (r.pending) { UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0)); r.pending = false; }
+            if (!r.qlow_valid || r.qlow_thr != c->P.min_gt_qual) {
+                UZ_REQUIRE(r.qual8 != nullptr, UZ_E_STATE, "a reads table of the cohort was packed for another --min-gt-qual");
+                uz_build_qlow(c, c->stream, r, c->P.min_gt_qual);
+            }
+            ids.push_back(groups[g].reads_id);
+            tot_n += r.n; tot_c += r.n_cigar_total; tot_u += r.n_row_units; tot_contigs += r.n_contigs; tot_q += r.n_qnames;
+        }
+        UZ_REQUIRE(tot_n < (int64_t)0x7FFFFFF0 && tot_c < ((int64_t)1 << 32) && tot_u < ((int64_t)1 << 32) && tot_q < ((uint64_t)1 << 32), UZ_E_RANGE,
+                   "the cohort's alignment records exceed one table's index ranges");
+        std::vector<int64_t> rec_base((size_t)n_groups), contig_base((size_t)n_groups);
+        std::vector<uint32_t> q_base((size_t)n_groups);
+        {
+            int64_t rb = 0, cb = 0;
+            uint32_t qb = 0;
+            for (int32_t g = 0; g < n_groups; g++) {
+                const ReadsDev &r = reads_of(c, groups[g].reads_id);
+                rec_base[(size_t)g] = rb; contig_base[(size_t)g] = cb; q_base[(size_t)g] = qb;
+                rb += r.n; cb += r.n_contigs; qb += r.n_qnames;
+            }
+        }
+        if (c->cohort_reads < 0 || !c->reads[(size_t)c->cohort_reads].live || c->cohort_ids != ids) {
+            if (c->cohort_reads >= 0 && c->reads[(size_t)c->cohort_reads].live) {
+                UZ_HIP(hipStreamSynchronize(c->stream));
+                free_reads(c, c->reads[(size_t)c->cohort_reads]);
+            }
+            ReadsDev m;
+            m.live = true;
+            m.n = tot_n; m.n_contigs = (int32_t)tot_contigs; m.n_qnames = (uint32_t)tot_q; m.n_cigar_total = tot_c; m.n_row_units = tot_u;
+            uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr;
+            for (int pass = 0; pass < 2; pass++) {
+                Carver cv(pass ? m.block.p : nullptr);
+                carve_common(cv, m);
+                cigar = cv.take<uint32_t>((size_t)tot_c);
+                seq4 = cv.take<uint8_t>((size_t)tot_u * UZ_SEQ4_UNIT_BYTES);
+                qlow = cv.take<uint8_t>((size_t)tot_u * UZ_QLOW_UNIT_BYTES);
+                if (!pass) m.block = uz_block_get(c, cv.off + 256);
+            }
+            m.cigar = cigar; m.seq4 = seq4; m.qlow = qlow;
+            m.qlow_thr = c->P.min_gt_qual; m.qlow_valid = true;
+            try {
+                std::vector<int64_t> co((size_t)tot_contigs + 1, 0);
+                std::vector<int32_t> ms((size_t)tot_contigs + 1, 0);
+                int64_t cg = 0, un = 0;
+                for (int32_t g = 0; g < n_groups; g++) {
+                    const ReadsDev &r = reads_of(c, groups[g].reads_id);
+                    std::vector<int64_t> rco((size_t)r.n_contigs + 1);
+                    std::vector<int32_t> rms((size_t)r.n_contigs + 1);
+                    UZ_HIP(hipMemcpyAsync(rco.data(), r.contig_off, rco.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+                    if (r.n_contigs) UZ_HIP(hipMemcpyAsync(rms.data(), r.max_span, (size_t)r.n_contigs * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+                    UZ_HIP(hipStreamSynchronize(c->stream));
+                    for (int32_t k = 0; k < r.n_contigs; k++) {
+                        co[(size_t)contig_base[(size_t)g] + k] = rec_base[(size_t)g] + rco[(size_t)k];
+                        ms[(size_t)contig_base[(size_t)g] + k] = rms[(size_t)k];
+                    }
+                    uz_concat_table(c, c->stream, m, r, rec_base[(size_t)g], cg, un, q_base[(size_t)g]);
+                    cg += r.n_cigar_total; un += r.n_row_units;
+                }
+                co[(size_t)tot_contigs] = tot_n;
+                UZ_HIP(hipMemcpyAsync(m.contig_off, co.data(), co.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+                UZ_HIP(hipMemcpyAsync(m.max_span, ms.data(), ms.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+                UZ_HIP(hipMemsetAsync(m.qc, 0, (size_t)tot_n + 64, c->stream));
+                uz_finish_table(c, c->stream, m);
+                UZ_HIP(hipStreamSynchronize(c->stream)); // co / ms are stack-local
+            } catch (...) { uz_block_put(c, m.block); throw; }
+            const int k = new_slot(c->reads);
+            c->reads[(size_t)k] = m;
+            c->cohort_reads = k;
+            c->cohort_ids = ids;
+        }
+        ReadsDev &R = c->reads[(size_t)c->cohort_reads];
+        // ---- the batch: reads contigs renumbered into the merged table, family / cutoff / name base per DNM
+        std::vector<int32_t> rc((size_t)n), fam_h((size_t)n, 0);
+        std::vector<double> cut_h((size_t)n, 0.0);
+        c->phase_qbase.assign((size_t)n, 0);
+        for (int32_t k = 0; k < n; k++) rc[(size_t)k] = -1;
+        std::vector<uint8_t *> cls_h((size_t)n_groups);
+        for (int32_t g = 0; g < n_groups; g++) {
+            FamilyDev &f = fam_of(c, groups[g].fam_id);
+            if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
+            cls_h[(size_t)g] = f.cls;
+            const int32_t nc_g = reads_of(c, groups[g].reads_id).n_contigs;
+            for (int32_t k = groups[g].dnm_first; k < groups[g].dnm_first + groups[g].dnm_count; k++) {
+                const int32_t t = d->rcontig[k];
+                rc[(size_t)k] = (t >= 0 && t < nc_g) ? (int32_t)(contig_base[(size_t)g] + t) : -1;
+                fam_h[(size_t)k] = g; cut_h[(size_t)k] = groups[g].cutoff; c->phase_qbase[(size_t)k] = q_base[(size_t)g];
+            }
+        }
+        uz_dnms_view dv = *d;
+        dv.rcontig = rc.data();
+        c->find_valid = false; c->phase_valid = false;
+        uz_stage_dnms(c, &dv);
+        c->dn_fam.ensure((size_t)n + 1); c->dn_cutoff.ensure((size_t)n + 1); c->fam_cls.ensure((size_t)n_groups + 1);
+        if (n) {
+            UZ_HIP(hipMemcpyAsync(c->dn_fam.p, fam_h.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            UZ_HIP(hipMemcpyAsync(c->dn_cutoff.p, cut_h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        }
+        UZ_HIP(hipMemcpyAsync(c->fam_cls.p, cls_h.data(), (size_t)n_groups * sizeof(uint8_t *), hipMemcpyHostToDevice, c->stream));
+        UZ_HIP(hipStreamSynchronize(c->stream)); // the staging vectors above are locals
+        c->cohort_on = true;
+        try {
+            uz_launch_find(c, f0, s, find_mode, false);
+            c->find_fam = groups[0].fam_id;
+            uz_launch_phase(c, f0, s, R, status, counts, origin, evidence);
+        } catch (...) { c->cohort_on = false; throw; }
+        c->cohort_on = false;
     });
 }
 

@@ -303,6 +303,20 @@ __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__res
     }
 }
 
+// cohort batches: the headers of one kid's table copied into the merged table with its bases added
+__global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
+                                                    RecA *da, RecB *db, uint32_t *dfm, int32_t rec_base, uint32_t cigar_base, uint32_t unit_base,
+                                                    uint32_t qname_base) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    RecA A = sa[i];
+    RecB B = sb[i];
+    A.cigar_off += cigar_base; A.sq_off += unit_base;
+    if (B.mate >= 0) B.mate += rec_base;
+    B.qname += qname_base;
+    da[i] = A; db[i] = B; dfm[i] = sfm[i];
+}
+
 RD make_rd(const ReadsDev &r) {
     RD R;
     R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm;
@@ -331,6 +345,30 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
                        (unsigned long long)r.n_row_units, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
                        (RecB *)r.rec_b, r.fm);
+    const int64_t nk = (r.n >> 12) + 2;
+    hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
+    UZ_HIP(hipGetLastError());
+}
+
+void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &src, int64_t rec_base, int64_t cigar_base, int64_t unit_base,
+                     uint32_t qname_base) {
+    if (src.n <= 0) return;
+    hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
+                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base,
+                       dst.fm + rec_base, (int32_t)rec_base, (uint32_t)cigar_base, (uint32_t)unit_base, qname_base);
+    UZ_HIP(hipGetLastError());
+    if (src.n_cigar_total)
+        UZ_HIP(hipMemcpyAsync(const_cast<uint32_t *>(dst.cigar) + cigar_base, src.cigar, (size_t)src.n_cigar_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    if (src.n_row_units) {
+        UZ_HIP(hipMemcpyAsync(const_cast<uint8_t *>(dst.seq4) + (size_t)unit_base * UZ_SEQ4_UNIT_BYTES, src.seq4, (size_t)src.n_row_units * UZ_SEQ4_UNIT_BYTES,
+                              hipMemcpyDeviceToDevice, st));
+        UZ_HIP(hipMemcpyAsync(dst.qlow + (size_t)unit_base * UZ_QLOW_UNIT_BYTES, src.qlow, (size_t)src.n_row_units * UZ_QLOW_UNIT_BYTES,
+                              hipMemcpyDeviceToDevice, st));
+    }
+}
+
+void uz_finish_table(uz_ctx *c, hipStream_t st, ReadsDev &r) {
+    if (r.n <= 0) return;
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     UZ_HIP(hipGetLastError());
@@ -399,6 +437,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.min_gt_qual = c->P.min_gt_qual; a.readlen = c->P.readlen; a.no_extended = c->P.no_extended;
     a.read_goal = c->P.read_goal; a.evidence_min_ratio = c->P.evidence_min_ratio; a.split_error_margin = c->P.split_error_margin;
     a.cutoff = c->dn.cutoff;
+    a.cutoff_d = c->cohort_on ? c->dn_cutoff.p : nullptr;
     a.spos = s.pos; a.sref = s.ref_base; a.salt = s.alt_base;
     a.cand_off = c->cand_off.p; a.het_off = c->het_off.p;
     a.cand_idx = c->cand_idx.p; a.het_idx = c->het_idx.p; a.cand_flags = c->cand_flags.p;
@@ -626,7 +665,13 @@ static int gather_lists(uz_ctx *c, int k0, int k1, int64_t *off, int32_t *val) {
         long long src = st->list_start_h[d];
         for (int k = 0; k < 6; k++) {
             const int len = st->list_len_h[(size_t)6 * d + k];
-            if (k >= k0 && k < k1 && len) memcpy(val + off[(size_t)nk * d + (k - k0)], pool.data() + src, (size_t)len * sizeof(int32_t));
+            if (k >= k0 && k < k1 && len) {
+                int32_t *out = val + off[(size_t)nk * d + (k - k0)];
+                memcpy(out, pool.data() + src, (size_t)len * sizeof(int32_t));
+                // cohort batches: query-name ids (lists 0, 1, 4, 5) are handed back relative to the kid's own table
+                if (k != 2 && k != 3 && !c->phase_qbase.empty())
+                    for (int x = 0; x < len; x++) out[x] -= (int32_t)c->phase_qbase[(size_t)d];
+            }
             src += len;
         }
     }

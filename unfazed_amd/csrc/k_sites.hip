@@ -285,6 +285,8 @@ struct WinArgs {
     int32_t n_contigs;
     const int32_t *pos;
     const uint8_t *cls;
+    const uint8_t *const *cls_of; // cohort batches: class column per family ...
+    const int32_t *fam_idx;       // ... and the family of every DNM (null: `cls` for all)
     int64_t sd;
     int mode;
     int64_t *range; // [2n] site index range of every DNM's windows: found by the count pass, reused by the fill pass
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32
     int64_t oc = 0, oh = 0;
     if (FILL) { oc = off_c[d]; oh = off_h[d]; }
     const int32_t c = a.contig[d];
+    const uint8_t *__restrict__ cls = a.fam_idx ? a.cls_of[a.fam_idx[d]] : a.cls;
     if (c >= 0 && c < a.n_contigs) {
         const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
         const int64_t st = a.start[d], en = a.end[d];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32
                 for (int k = 0; k < nw; k++) {
                     if (pos1 < w[k][0] || pos1 > w[k][1]) continue;
                     for (int64_t s = i; s < j; s++) {
-                        const uint32_t cl = a.cls[s];
+                        const uint32_t cl = cls[s];
                         if (!cl) continue;
                         uint32_t ka = 0;
                         bool is_c;
@@ -376,6 +379,7 @@ __global__ __launch_bounds__(256) void k_window_region(WinArgs a, int32_t *cnt_c
     if (d >= a.n) return;
     int64_t nc = 0, nh = 0;
     const int32_t c = a.contig[d];
+    const uint8_t *__restrict__ cls = a.fam_idx ? a.cls_of[a.fam_idx[d]] : a.cls;
     if (c >= 0 && c < a.n_contigs) {
         const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
         const int64_t st = a.start[d], en = a.end[d];
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(256) void k_window_region(WinArgs a, int32_t *cnt_c
             bool is_c = false, is_h = false;
             uint32_t cl = 0, ka = 0;
             if (sidx < hi) {
-                cl = a.cls[sidx];
+                cl = cls[sidx];
                 const int32_t p = a.pos[sidx];
                 if (cl && !(small_event && p >= st && p < en)) { // :253-256
                     if (vt == UZ_VT_DEL) ka = (cl >> UZ_CL_DEL_SHIFT) & 3;
@@ -690,6 +694,8 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         a.vartype = c->dn.vartype.p; a.mult = c->dn.mult.p;
         a.contig_off = s.contig_off; a.n_contigs = s.n_contigs;
         a.pos = s.pos; a.cls = f.cls;
+        a.cls_of = c->cohort_on ? (const uint8_t *const *)c->fam_cls.p : nullptr;
+        a.fam_idx = c->cohort_on ? c->dn_fam.p : nullptr;
         a.sd = c->P.search_dist;
         a.mode = mode;
         c->win_range.ensure((size_t)2 * n + 2);

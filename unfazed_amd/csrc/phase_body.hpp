@@ -186,7 +186,8 @@ UZ_DEV void ar_reset(Arena &ar) { ar.top = ar.cap; }
 struct PhaseArgs {
     int32_t n;
     int32_t min_gt_qual, readlen, no_extended, read_goal, evidence_min_ratio, split_error_margin;
-    double cutoff;
+    double cutoff;           // concordant insert cutoff of the kid (read_collector.py:11-25) ...
+    const double *cutoff_d;  // ... or one per DNM (cohort batches: DNMs of several kids, uz_phase_cohort); null = the scalar
     // sites + window lists
     const int32_t *spos;
     const uint8_t *sref, *salt;
@@ -223,6 +224,8 @@ struct PhaseArgs {
 };
 
 // ------------------------------------------------------------------ helpers
+UZ_DEV double uz_cutoff(const PhaseArgs &a, int d) { return a.cutoff_d ? a.cutoff_d[d] : a.cutoff; }
+
 UZ_DEV long long uz_lower_bound(const int32_t *a, long long lo, long long hi, long long v) {
     while (lo < hi) {
         const long long mid = lo + ((hi - lo) >> 1);
@@ -380,7 +383,7 @@ UZ_DEV int uz_bsearch_nth(int m, int qp, int L, int Rr) {
 // site-specific parts.  Returns the mate or -1.
 // All fields of the record are requested together, then all fields of its mate (two memory round
 // trips instead of one per test); the tests keep the reference's order.
-UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, int seg, const RecA &A, const RecB &B) {
+UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, double cutoff, int seg, const RecA &A, const RecB &B) {
     const uint32_t qc = R.qc[seg];
     const int mate = B.mate;
     long long ins = (long long)B.tlen - 2LL * a.readlen;
@@ -390,20 +393,20 @@ UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, int seg, const RecA &A
     const RecA M = R.ra[mi];
     const long long ms = M.start, me = M.end;
     if (ins < 0) ins = -ins;
-    if (!(qc & UZ_QC_GOOD) || (double)ins > a.cutoff) return -1;
+    if (!(qc & UZ_QC_GOOD) || (double)ins > cutoff) return -1;
     if (mate < 0) return -1;
     if (!(qm & UZ_QC_GOOD)) return -1;
     if (!(qc & UZ_QC_NONE5) || !(qm & UZ_QC_NONE5)) return -1;
     if ((ms <= rs && rs <= me) || (ms <= re && re <= me)) return -1; // mates overlap
     return mate;
 }
-UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, int seg) { return uz_pair_ok_ab(R, a, seg, R.ra[seg], R.rb[seg]); }
+UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, double cutoff, int seg) { return uz_pair_ok_ab(R, a, cutoff, seg, R.ra[seg], R.rb[seg]); }
 
 // Phase A classification of one record fetched at the DNM: 0 none, 1 "ref", 2 "alt"
-UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long long flo, long long position,
+UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, int seg, long long flo, long long position,
                                 const uint8_t *ref, int ref_len, const uint8_t *alt, int alt_len) {
     if (!((long long)R.ra[seg].end > flo)) return 0;
-    const int mate = uz_pair_ok(R, a, seg);
+    const int mate = uz_pair_ok(R, a, cutoff, seg);
     if (mate < 0) return 0;
     if (ref_len == alt_len) { // snv_match_alleles :296-336
         uint32_t row = 0;
@@ -442,7 +445,7 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, int seg, long l
 // collect_reads_sv (:499-586) for one record fetched around a breakpoint `position`:
 // 0 nothing, 1 supporting [read, mate] (split read), 2 supporting [mate, read] (discordant pair or
 // clipped read), 3 the record bans its query name (:520-522)
-UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long position, long long lo, long long sv_start,
+UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i, long long position, long long lo, long long sv_start,
                           long long sv_end) {
     const RecA A = R.ra[i];
     const RecB B = R.rb[i];
@@ -490,7 +493,7 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long posi
     long long ins = (long long)B.tlen - 2LL * a.readlen;
     if (ins < 0) ins = -ins;
     const double var_len = (double)sv_end - (double)sv_start < 0 ? (double)sv_start - (double)sv_end : (double)sv_end - (double)sv_start;
-    bool disc = (double)ins > a.cutoff;
+    bool disc = (double)ins > cutoff;
     if (disc) {
         double ratio = var_len / (double)ins;
         if (ratio < 0) ratio = -ratio;
@@ -499,7 +502,7 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, int i, long long posi
     if (disc) {
         const long long ms = R.ra[mate].start;
         const long long left0 = ms < rs ? ms : rs, right0 = ms > rs ? ms : rs;
-        const long long wig = (long long)a.cutoff; // :551
+        const long long wig = (long long)cutoff; // :551
         return ((sv_start - wig) < left0 && left0 < (sv_start + wig) && (sv_end - wig) < right0 && right0 < (sv_end + wig)) ? 2 : 0;
     }
     int rp = uz_qidx(R, i, position); // :565-573
@@ -537,6 +540,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
     (void)a.rcontig;
     const long long position = a.dstart[d];
+    const double cutoff = uz_cutoff(a, d);
     const uint8_t *ref = a.alleles + a.allele_off[2 * d];
     const int ref_len = (int)(a.allele_off[2 * d + 1] - a.allele_off[2 * d]);
     const uint8_t *alt = a.alleles + a.allele_off[2 * d + 1];
@@ -571,7 +575,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     int nre = 0, nae = 0; // elements of the "ref" / "alt" lists
     if (!is_sv) {
         WG_FOR(i, nA) {
-            const int cl = uz_classify_dnm_read(R, a, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
+            const int cl = uz_classify_dnm_read(R, a, cutoff, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
             s.a_cls[i] = (uint8_t)cl;
             s.a_flag0[i] = cl == 1;
             s.a_flag1[i] = cl == 2;
@@ -593,14 +597,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     } else {
         // ---- A (SV): collect_reads_sv :476-596 around both breakpoints -> "alt" list only
         const long long sv_start = a.dstart[d], sv_end = a.dend[d];
-        const long long icut = (long long)a.cutoff;
+        const long long icut = (long long)cutoff;
         WG_FOR(t, nA) {
             const bool w1 = t >= n0;
             const int i = (int)(w1 ? fa2 + (t - n0) : fa + t);
             const long long bp = w1 ? sv_end : sv_start;
             long long lo = bp - icut;
             if (lo < 0) lo = 0;
-            const int code = uz_sv_classify(R, a, i, bp, lo, sv_start, sv_end);
+            const int code = uz_sv_classify(R, a, cutoff, i, bp, lo, sv_start, sv_end);
             s.a_cls[t] = (uint8_t)code;
             s.a_flag0[t] = code == 3;
         }
@@ -709,7 +713,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             const RecA A = R.ra[seg];
             const RecB B = R.rb[seg];
             const int ov = (long long)A.end > (long long)s.hpos[h];
-            const int mate = uz_pair_ok_ab(R, a, seg, A, B);
+            const int mate = uz_pair_ok_ab(R, a, cutoff, seg, A, B);
             const bool pok = ov && mate >= 0 && (R.qc[seg] & UZ_QC_NM5);
             s.t_q[t] = B.qname;
             s.t_mate[t] = mate;
@@ -1209,7 +1213,7 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int
         uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
         long long fa2 = 0, fb2 = 0;
         if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
-            const long long icut = (long long)a.cutoff;
+            const long long icut = (long long)uz_cutoff(a, d);
             long long lo = (long long)a.dstart[d] - icut;
             if (lo < 0) lo = 0;
             uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);

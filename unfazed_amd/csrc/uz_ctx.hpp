@@ -157,6 +157,16 @@ struct uz_ctx {
     int64_t n_cand = 0, n_het = 0;
     std::vector<int64_t> cand_off_h, het_off_h;
 
+    // cohort batch (uz_phase_cohort): per-DNM family / insert cutoff / query-name base, the class column of every family, and
+    // the reads tables of the kids laid end to end as ONE table (virtual contigs = kid x contig)
+    bool cohort_on = false;
+    DevBuf<int32_t> dn_fam;
+    DevBuf<double> dn_cutoff;
+    DevBuf<uint8_t *> fam_cls;
+    std::vector<uint32_t> phase_qbase; // per DNM: first query-name id of its kid in the merged table (empty: no offset)
+    int cohort_reads = -1;             // slot in `reads` holding the merged table
+    std::vector<int> cohort_ids;       // the tables it was built from
+
     // last CNV stage (K6)
     bool cnv_valid = false;
     int32_t cnv_n = 0;
@@ -208,6 +218,10 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
 void uz_pack_ascii_rows(uz_ctx *c, hipStream_t st, ReadsDev &r, const uint32_t *cigar_in, const uint32_t *cigar_off_in,
                         const uint8_t *seq_in, const uint32_t *sq_off16_in, uint32_t *cigar_out, uint8_t *seq4_out);
 void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual);
+// appends table `src` to the merged table `dst` at the given bases (records, CIGAR words, row units, query names)
+void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &src, int64_t rec_base, int64_t cigar_base, int64_t unit_base,
+                     uint32_t qname_base);
+void uz_finish_table(uz_ctx *c, hipStream_t st, ReadsDev &r); // coarse index of a table whose headers are in place
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool host_offsets = true);

@@ -23,7 +23,7 @@ EXPORTS = [
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
     "uz_site_scan", "uz_site_scan_many", "uz_site_classes", "uz_find", "uz_find_fetch",
-    "uz_phase", "uz_phase_votes", "uz_phase_groups", "uz_phase_cnv", "uz_phase_cnv_sites",
+    "uz_phase", "uz_phase_cohort", "uz_phase_votes", "uz_phase_groups", "uz_phase_cnv", "uz_phase_cnv_sites",
     "uz_prof_enable", "uz_prof_reset", "uz_prof_get", "uz_prof_units",
 ]
 
@@ -71,6 +71,7 @@ def load_library(path: Optional[str] = None):
     L.uz_find.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
     L.uz_find_fetch.argtypes = [vp, vp, vp, vp]
     L.uz_phase.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.uz_phase_cohort.argtypes = [vp, vp, C.c_int32, vp, C.c_int, vp, vp, vp, vp]
     L.uz_phase_cnv.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.uz_phase_cnv_sites.argtypes = [vp, vp, vp]
     L.uz_phase_votes.argtypes = [vp, vp, vp]
@@ -248,6 +249,28 @@ class HipEngine:
             "uz_phase",
         )
         return dict(status=status[:n], counts=counts[: 4 * n].reshape(n, 4), origin=origin[:n], evidence=evidence[:n])
+
+    def phase_cohort(self, groups, dv: abi.Held, params: abi.Params, found_list=None, want_lists: bool = True,
+                     find_mode: int = abi.FIND_SECOND_WINDOW):
+        """Cohort form of phase(): groups = [(fam, reads_h, first, count, cutoff)] over the DNMs of `dv` (several kids, each
+        with its own family columns / alignment records / insert cutoff), one launch sequence.  Same result layout as
+        phase(); the query-name ids of the lists are those of each group's own table."""
+        self.set_params(params)
+        n = dv.view.n
+        arr = (abi.CohortGroup * len(groups))()
+        for k, (fam, rh, first, count, cutoff) in enumerate(groups):
+            arr[k].fam_id, arr[k].reads_id, arr[k].dnm_first, arr[k].dnm_count, arr[k].cutoff = int(fam), int(rh), int(first), int(count), float(cutoff)
+        status = np.zeros(max(1, n), dtype=np.int32)
+        counts = np.zeros(max(1, 4 * n), dtype=np.int32)
+        origin = np.zeros(max(1, n), dtype=np.int32)
+        evidence = np.zeros(max(1, n), dtype=np.int32)
+        self._ck(self.L.uz_phase_cohort(self.h, arr, len(groups), dv.ref(), int(find_mode), status.ctypes.data, counts.ctypes.data,
+                                        origin.ctypes.data, evidence.ctypes.data), "uz_phase_cohort")
+        r = dict(status=status[:n], counts=counts[: 4 * n].reshape(n, 4), origin=origin[:n], evidence=evidence[:n], lists=None)
+        if want_lists:
+            vo, vv = self.votes(n)
+            r["lists"] = [tuple(vv[vo[4 * k + j]: vo[4 * k + j + 1]] for j in range(4)) for k in range(n)]
+        return r
 
     def votes(self, n: int):
         vo = np.zeros(4 * n + 1, dtype=np.int64)

@@ -422,8 +422,10 @@ class PhasingHost:
             prep[i] = dict(ref=ref.encode("ascii"), alt=alts[0].encode("ascii"), tid=tid, dflags=fl)
             batch.setdefault((dn["kid"], dn["bam"]), []).append(i)
             plan.append((i, "phase"))
-        # pass 2: device
+        # pass 2: device.  One batch per kid (its own family columns, alignment file and insert cutoff); several kids go
+        # to the device as ONE cohort batch (uz_phase_cohort), not as one launch sequence per kid
         results: Dict[int, dict] = {}
+        groups, order_all, tables, handles = [], [], [], []
         for (kid, bam), idxs in batch.items():
             dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
             fam = self.family(kid, dad_id, mom_id)
@@ -443,33 +445,41 @@ class PhasingHost:
                     end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff)
                 region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
                 rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual))
+                handles.append(rh)
             else:
                 rh = self.reads(bam, params.min_gt_qual)
+            groups.append((fam, rh, len(order_all), len(idxs), cutoff))
+            tables.append(region_table if region_table is not None else self.reads_by_bam[bam])
+            order_all.extend(idxs)
+        if order_all:
             name_of = {}
-            for i in idxs:
+            for i in order_all:
                 nm = self.prefix + dnms[i]["chrom"].strip("chr")
                 name_of[i] = self.sites.contig_index.get(nm, -1)
             dv = abi.dnms_view(
-                contig=[name_of[i] for i in idxs],
-                rcontig=[prep[i]["tid"] for i in idxs],
-                start=[int(dnms[i]["start"]) for i in idxs],
-                end=[int(dnms[i]["end"]) for i in idxs],
-                vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
-                refs=[prep[i]["ref"] for i in idxs],
-                alts=[prep[i]["alt"] for i in idxs],
-                cutoff=cutoff,
-                dflags=[prep[i]["dflags"] for i in idxs],
-                mult=[found[i]["mult"] for i in idxs],
+                contig=[name_of[i] for i in order_all],
+                rcontig=[prep[i]["tid"] for i in order_all],
+                start=[int(dnms[i]["start"]) for i in order_all],
+                end=[int(dnms[i]["end"]) for i in order_all],
+                vartype=[vartype_code(dnms[i]["vartype"]) for i in order_all],
+                refs=[prep[i]["ref"] for i in order_all],
+                alts=[prep[i]["alt"] for i in order_all],
+                cutoff=groups[0][4],
+                dflags=[prep[i]["dflags"] for i in order_all],
+                mult=[found[i]["mult"] for i in order_all],
             )
-            fl = [found[i] for i in idxs]
-            res = self.backend.phase(fam, rh, dv, params, fl, want_lists, find_mode=info["mode"])
-            if region_table is not None:
-                res["table"] = region_table  # query names of the vote lists are ids of THIS table
-                free = getattr(self.backend, "free_reads", None)
+            fl = [found[i] for i in order_all]
+            if len(groups) == 1:
+                res = self.backend.phase(groups[0][0], groups[0][1], dv, params, fl, want_lists, find_mode=info["mode"])
+            else:
+                res = self.backend.phase_cohort(groups, dv, params, fl, want_lists, find_mode=info["mode"])
+            free = getattr(self.backend, "free_reads", None)
+            for rh in handles:  # region tables live for one batch
                 if free:
                     free(rh)
-            for k, i in enumerate(idxs):
-                results[i] = (res, k)
+            for g, (fam, rh, first, count, cutoff) in enumerate(groups):
+                for k in range(first, first + count):
+                    results[order_all[k]] = (res, k, tables[g])
         # pass 3: records, in the reference's order
         for i, action in plan:
             dn = dnms[i]
@@ -494,7 +504,7 @@ class PhasingHost:
             elif action == "manygt":
                 log("Too many genotypes for variant {chrom}:{start}-{end}".format(**region))
             elif action == "phase":
-                res, k = results[i]
+                res, k, rt = results[i]
                 st = int(res["status"][k])
                 if st == abi.ST_NO_OVERLAP:
                     log("No reads overlap informative sites for variant {chrom}:{start}-{end}".format(**region))
@@ -510,7 +520,6 @@ class PhasingHost:
                     # ST_REF_EXCEPTION: the reference's worker raises (KeyError in connect_reads) and the default
                     # thread pool swallows it: no record, no message
                     continue
-                rt = res.get("table") or self.reads_by_bam[dn["bam"]]
                 lists = res.get("lists")
                 if lists is not None:
                     dr, mr, ds, ms = lists[k]
