@@ -233,11 +233,12 @@ def main():
             src = io_native.ReadsSource(part_full)
             fc, flo, fhi = fetch_points(ev.contig[a:b], ev.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P,
                                         vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff)
-            part = src.select(fc, flo, fhi, alloc=pool.alloc)
+            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended))
             del src, part_full
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
-            staged_bytes += int(part.view.n_segs) * 28 + int(part.view.n_cigar_total) * 4 + int(part.view.n_row_units) * 20
+            staged_bytes += (int(part.view.n_segs) * 28 + int(part.view.n_cigar_total) * 4 + int(part.view.n_row_units) * 4
+                             + int(part.view.n_seq_units) * 16)
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
         t_dec = time.time() - t_dec
 

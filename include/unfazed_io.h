@@ -125,8 +125,13 @@ typedef struct uz_psrc uz_psrc;     /* a packed table opened as the source of se
 typedef struct uz_select uz_select; /* one selection */
 int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc **out);
 void uz_reads_source_close(uz_psrc *src);
-int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int threads,
-                         uz_select **out);
+/* all_bases = 0: a record a fetch returns keeps its bases, a record reachable only as a mate is staged WITHOUT them
+ * (UZ_AUX_NO_SEQ: quality-plane row, no seq4 row) -- every base the extended read stage reads lies at a fetch point the
+ * record overlaps.  all_bases = 1 (--no-extended: the join reads the mates of the DNM reads at candidate sites nobody
+ * fetched): every kept record keeps its bases. */
+int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
+                         int threads, uz_select **out);
+int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_records(const uz_select *s);
 int64_t uz_select_n_cigar_total(const uz_select *s);
 int64_t uz_select_n_row_units(const uz_select *s);

@@ -55,6 +55,8 @@ extern "C" {
 #define UZ_AUX_MATE_SAME_TID 1u
 #define UZ_AUX_HAS_SA 2u
 #define UZ_AUX_DECODE_BAD 4u
+#define UZ_AUX_NO_SEQ 8u /* packed form only: the record was staged WITHOUT its bases (reachable only as a mate: nothing ever
+                          * reads them); it has a quality-plane row but no seq4 row.  A kernel that asks for its bases fails loudly. */
 
 /* per-DNM status of the read stage */
 #define UZ_ST_OK 0             /* a record exists */
@@ -178,10 +180,11 @@ typedef struct uz_reads_packed_view {
     const uint8_t *mapq;
     const uint8_t *aux;
     const uint32_t *cigar; /* [n_cigar_total] record i owns the next n_cigar[i] words */
-    const uint8_t *seq4;   /* [n_row_units * 16] base k of a row: byte k>>1, high nibble when k is even */
-    const uint8_t *qlow;   /* [n_row_units * 4]  base k of a row: bit k&7 of byte k>>3, set iff qual[k] < min_base_qual */
+    const uint8_t *seq4;   /* [n_seq_units * 16] rows of the records WITHOUT UZ_AUX_NO_SEQ, back to back; base k of a row: byte k>>1, high nibble when k is even */
+    const uint8_t *qlow;   /* [n_row_units * 4]  rows of ALL records; base k of a row: bit k&7 of byte k>>3, set iff qual[k] < min_base_qual */
     int64_t n_cigar_total; /* = sum n_cigar, < 2^32 */
-    int64_t n_row_units;   /* = sum UZ_ROW_UNITS(l_seq), < 2^32 */
+    int64_t n_row_units;   /* = sum UZ_ROW_UNITS(l_seq) over all records, < 2^32 */
+    int64_t n_seq_units;   /* = the same sum over the records that carry bases (= n_row_units when none is UZ_AUX_NO_SEQ) */
     uint32_t n_qnames;
     uint32_t reserved1;
 } uz_reads_packed_view;

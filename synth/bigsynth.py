@@ -308,7 +308,7 @@ class WorkloadOnGpu:
         v.n_segs = self.n_segs
         v.n_contigs = len(self.sc.contig_off) - 1
         v.min_base_qual = self.cfg.min_base_qual
-        v.n_cigar_total, v.n_row_units = self.n_cigar_total, self.n_row_units
+        v.n_cigar_total, v.n_row_units, v.n_seq_units = self.n_cigar_total, self.n_row_units, self.n_row_units
         v.n_qnames = self.n_segs // 2
         return v
 

@@ -17,19 +17,21 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                          const int64_t *cand_off, const int32_t *cand_idx, const uint8_t *cand_flags,
                          const int64_t *het_off, const int32_t *het_idx, int32_t *status, int32_t *counts,
                          int32_t *origin, int32_t *evidence, long long *list_start, int32_t *list_len, int32_t *pool,
-                         long long pool_cap, long long *pool_used) {
+                         long long pool_cap, long long *pool_used, const uint8_t *no_seq /* optional: records staged without bases */,
+                         int32_t *base_err_out /* optional: 1 when the bases of such a record were requested */) {
     // the table in the packed form the device holds (built here on the host from the ASCII view)
     const int64_t n = Rv->n_segs;
     std::vector<uint8_t> qc((size_t)n + 1);
     std::vector<RecA> ra((size_t)n + 1);
     std::vector<RecB> rb((size_t)n + 1);
-    std::vector<uint32_t> fm((size_t)n + 1), cigar;
+    std::vector<uint32_t> fm((size_t)n + 1), qoff((size_t)n + 1), cigar;
     std::vector<uint8_t> seq4, qlow;
     uint64_t coff = 0, uoff = 0;
     for (int64_t i = 0; i < n; i++) {
-        uz_pack_rec(ra[i], rb[i], Rv->start[i], Rv->end[i], (uint32_t)coff, (uint32_t)uoff, Rv->mate[i], Rv->qname[i], Rv->l_seq[i],
-                    Rv->n_cigar[i], Rv->tlen[i]);
+        uz_pack_rec(ra[i], rb[i], Rv->start[i], Rv->end[i], (uint32_t)coff, (no_seq && no_seq[i]) ? UZ_NO_SEQ_OFF : (uint32_t)uoff, Rv->mate[i],
+                    Rv->qname[i], Rv->l_seq[i], Rv->n_cigar[i], Rv->tlen[i]);
         fm[i] = uz_pack_fm(Rv->flag[i], Rv->mapq[i], Rv->aux[i]);
+        qoff[i] = (uint32_t)uoff;
         for (int k = 0; k < (int)Rv->n_cigar[i]; k++) cigar.push_back(Rv->cigar[(size_t)Rv->cigar_off[i] + k]);
         const uint32_t units = UZ_ROW_UNITS(Rv->l_seq[i]);
         seq4.resize((size_t)(uoff + units) * UZ_SEQ4_UNIT_BYTES);
@@ -45,7 +47,9 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     RD R;
     R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
     R.ra = ra.data(); R.rb = rb.data(); R.fm = fm.data(); R.cigar = cigar.data(); R.seq4 = seq4.data(); R.qlow = qlow.data();
-    R.qc = qc.data();
+    R.qc = qc.data(); R.qoff = qoff.data();
+    int32_t base_err = 0;
+    R.err = &base_err;
     std::vector<int32_t> coarse((size_t)(n >> 12) + 2);
     for (int64_t k = 0; (k << 12) < n; k++) coarse[k] = Rv->start[k << 12];
     R.coarse = coarse.data();
@@ -99,5 +103,6 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
         uz_phase_dnm(a, s, &sh, a.lds_arena_bytes ? arena.data() : nullptr, d);
     }
     *pool_used = (long long)cursor;
+    if (base_err_out) *base_err_out = base_err;
     return 0;
 }

@@ -120,8 +120,9 @@ def test_resident_pipeline_matches_oracle(workload, engine):
         fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
         part = src.select(fc, flo, fhi, alloc=pool.alloc)
         staged_bytes += sum(x.nbytes for x in part.arrays.values())
+        assert 0.3 < (part.arrays["aux"][: part.view.n_segs] & abi.AUX_NO_SEQ).astype(bool).mean() < 0.6  # mates travel without bases
         rids.append(engine.upload_reads_packed(part))
-    assert staged_bytes < 0.6 * sum(x.nbytes for x in full.arrays.values())
+    assert staged_bytes < 0.3 * sum(x.nbytes for x in full.arrays.values())
     for (a, b), r in zip(zip(bounds[:-1], bounds[1:]), rids):
         dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
                             dn.refs[a:b], dn.alts[a:b], cutoff)

@@ -36,10 +36,15 @@ def _sites_views(sc):
     return abi.Held(sv, keep), abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
 
 
-def _unpack_row(pk, uoff, i, ls):
+def _unpack_row(pk, uoff, i, ls, soff=None):
+    """bases (None for a record staged without them) and quality bits of record i; uoff / soff: quality-plane / seq4 row
+    offsets in units (the same when every record carries its bases)"""
     u = int(abi.row_units(ls))
-    row = pk.arrays["seq4"][uoff[i] * 16: (uoff[i] + u) * 16]
-    seq = LUT[np.stack([row >> 4, row & 15], 1).ravel()[:ls]]
+    soff = uoff if soff is None else soff
+    seq = None
+    if not (pk.arrays["aux"][i] & abi.AUX_NO_SEQ):
+        row = pk.arrays["seq4"][soff[i] * 16: (soff[i] + u) * 16]
+        seq = LUT[np.stack([row >> 4, row & 15], 1).ravel()[:ls]]
     low = np.unpackbits(pk.arrays["qlow"][uoff[i] * 4: (uoff[i] + u) * 4], bitorder="little")[:ls]
     return seq, low
 
@@ -127,24 +132,35 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
         keep = np.zeros(N, bool)
         for c, lo, h in zip(fc, flo, fhi):
             keep |= (contig_of_rec == c) & (arrs["start"][:N] < h) & (arrs["end"][:N] > lo)
+        direct = keep.copy()
         for _ in range(4):
             m = arrs["mate"][:N][keep]
             keep[m[m >= 0]] = True
         assert np.array_equal(np.nonzero(keep)[0], idx)
         total += idx.size
-        # packed columns of the selection = the packed columns of those records
+        # packed columns of the selection = the packed columns of those records; a record no fetch returns (reachable
+        # only as a mate) travels without its bases
         for name, _ in abi.PACKED_RECORD_COLS:
-            if name != "mate":
+            if name not in ("mate", "aux"):
                 assert np.array_equal(part.arrays[name][: idx.size], pk.arrays[name][idx]), name
+        no_seq = (part.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ) != 0
+        assert np.array_equal(no_seq, ~direct[idx]) and 0.3 < no_seq.mean() < 0.6
+        assert np.array_equal(part.arrays["aux"][: idx.size] & ~np.uint8(abi.AUX_NO_SEQ), pk.arrays["aux"][idx])
+        assert part.view.n_seq_units == int(abi.row_units(part.arrays["l_seq"][: idx.size])[~no_seq].sum())
+        everything, _ = src.select(fc, flo, fhi, want_index=True, all_bases=True)
+        assert everything.view.n_seq_units == everything.view.n_row_units and not (everything.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ).any()
         mt = part.arrays["mate"][: idx.size]
         assert np.array_equal(idx[mt[mt >= 0]], pk.arrays["mate"][idx][mt >= 0])
         uoff_f = np.concatenate([[0], np.cumsum(abi.row_units(pk.arrays["l_seq"][:N]))])
-        uoff_p = np.concatenate([[0], np.cumsum(abi.row_units(part.arrays["l_seq"][: idx.size]))])
-        for k in np.random.default_rng(a).integers(0, idx.size, 50):
+        units_p = abi.row_units(part.arrays["l_seq"][: idx.size])
+        uoff_p = np.concatenate([[0], np.cumsum(units_p)])
+        soff_p = np.concatenate([[0], np.cumsum(np.where(no_seq, 0, units_p))])
+        for k in np.random.default_rng(a).integers(0, idx.size, 80):
             ls = int(part.arrays["l_seq"][k])
-            s1, q1 = _unpack_row(part, uoff_p, k, ls)
+            s1, q1 = _unpack_row(part, uoff_p, k, ls, soff_p)
             s2, q2 = _unpack_row(pk, uoff_f, idx[k], ls)
-            assert np.array_equal(s1, s2) and np.array_equal(q1, q2)
+            assert np.array_equal(q1, q2)
+            assert (s1 is None) == bool(no_seq[k]) and (s1 is None or np.array_equal(s1, s2))
         # the oracle on the selected records only
         sub = _subset_ascii(arrs, idx, nc)
         dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
@@ -158,3 +174,38 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
             for j in range(4):
                 assert np.array_equal(gv[go[4 * d + j]: go[4 * d + j + 1]], wv[wo[4 * (a + d) + j]: wo[4 * (a + d) + j + 1]])
     assert total < 0.6 * N  # about a third of the records inside the windows is reachable
+
+
+def test_kernel_body_never_reads_the_bases_of_a_mate_only_record():
+    """The rule behind UZ_AUX_NO_SEQ, checked on the kernel body itself (CPU twin, tests/emu): with every record that no
+    fetch returns stripped of its bases, the extended read stage gives the oracle's results and never asks for a
+    stripped record's bases; with --no-extended (no het-site fetches) the join DOES read mates at candidate sites, which
+    is why such batches are staged with all_bases."""
+    from emu import emu
+    sc, dn, cl, rh, arrs = _workload(200, seed=17)
+    n = dn.n
+    sh, fh = _sites_views(sc)
+    N = int(rh.view.n_segs)
+    contig_of_rec = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    cutoff = concordant_cutoff(arrs["tlen"], 151, 3)
+    dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
+    tripped = {}
+    for no_ext in (False, True):
+        P = abi.make_params(no_extended=no_ext)
+        found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+        want = orc.phase(P, sh, rh, dv, found, keep_lists=False)
+        fc, flo, fhi = fetch_points(dn.contig, dn.start, np.zeros(n, np.uint8), sc.pos, found[3], found[4], P)
+        direct = np.zeros(N, bool)
+        for c in np.unique(fc):
+            m = fc == c
+            los = np.sort(flo[m])  # single-base fetches, plus [pos-1, pos+1) at the DNMs
+            r0, r1 = arrs["contig_off"][c], arrs["contig_off"][c + 1]
+            k = np.searchsorted(los, arrs["start"][r0:r1] - 1, side="left")
+            direct[r0:r1] = (k < los.size) & (los[np.minimum(k, los.size - 1)] < arrs["end"][r0:r1])
+        got = emu.phase(P, sh, rh, dv, found, no_seq=~direct)
+        tripped[no_ext] = got["base_err"]
+        if not no_ext:
+            for k in ("status", "counts", "origin", "evidence"):
+                assert np.array_equal(want[k], got[k]), k
+            assert (want["status"] == abi.ST_OK).sum() > 20 and (~direct).mean() > 0.5
+    assert tripped == {False: 0, True: 1}

@@ -150,11 +150,13 @@ class ReadsPackedView(C.Structure):
         ("qlow", _p),
         ("n_cigar_total", C.c_int64),
         ("n_row_units", C.c_int64),
+        ("n_seq_units", C.c_int64),
         ("n_qnames", C.c_uint32),
         ("reserved1", C.c_uint32),
     ]
 
 
+AUX_NO_SEQ = 8
 # per-record columns of the packed view and their element types
 PACKED_RECORD_COLS = [("start", np.int32), ("end", np.int32), ("tlen", np.int32), ("mate", np.int32), ("qname", np.uint32),
                       ("flag", np.uint16), ("l_seq", np.uint16), ("n_cigar", np.uint16), ("mapq", np.uint8), ("aux", np.uint8)]
@@ -165,8 +167,11 @@ def row_units(l_seq):
     return (np.asarray(l_seq).astype(np.int64) + 31) >> 5
 
 
-def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None) -> "Held":
-    """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy)."""
+def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None) -> "Held":
+    """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
+    n_seq_units: row units of the records that carry bases (default: all of them)."""
+    if n_seq_units is None:
+        n_seq_units = n_row_units
     if alloc is None:
         alloc = lambda nbytes: np.zeros(max(16, nbytes), dtype=np.uint8)  # noqa: E731
     arrs = {}
@@ -175,10 +180,10 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None) -> "
     arrs["contig_off"] = alloc(8 * (n_contigs + 1))[: 8 * (n_contigs + 1)].view(np.int64)
     arrs["max_span"] = alloc(4 * max(1, n_contigs))[: 4 * max(1, n_contigs)].view(np.int32)
     arrs["cigar"] = alloc(4 * max(1, n_cigar_total))[: 4 * max(1, n_cigar_total)].view(np.uint32)
-    arrs["seq4"] = alloc(SEQ4_UNIT_BYTES * max(1, n_row_units))[: SEQ4_UNIT_BYTES * max(1, n_row_units)]
+    arrs["seq4"] = alloc(SEQ4_UNIT_BYTES * max(1, n_seq_units))[: SEQ4_UNIT_BYTES * max(1, n_seq_units)]
     arrs["qlow"] = alloc(QLOW_UNIT_BYTES * max(1, n_row_units))[: QLOW_UNIT_BYTES * max(1, n_row_units)]
     v = ReadsPackedView()
-    v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units = n, n_contigs, n_cigar_total, n_row_units
+    v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units, v.n_seq_units = n, n_contigs, n_cigar_total, n_row_units, n_seq_units
     for k, a in arrs.items():
         setattr(v, k, a.ctypes.data)
     return Held(v, arrs)

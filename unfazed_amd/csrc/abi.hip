@@ -359,6 +359,7 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.rec_a = cv.take<uint8_t>(n * 16);
     r.rec_b = cv.take<uint8_t>(n * 16);
     r.fm = cv.take<uint32_t>(n);
+    r.qoff = cv.take<uint32_t>(n);
     r.qc = cv.take<uint8_t>(n);
     r.need = cv.take<uint8_t>(n);
     r.coarse = cv.take<int32_t>((n >> 12) + 2);
@@ -380,6 +381,7 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_contigs >= 0, UZ_E_ARG, "bad reads view");
     UZ_REQUIRE(v->n_cigar_total >= 0 && v->n_cigar_total < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
     UZ_REQUIRE(v->n_row_units >= 0 && v->n_row_units < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 row units (2^37 bases)");
+    UZ_REQUIRE(v->n_seq_units >= 0 && v->n_seq_units <= v->n_row_units, UZ_E_ARG, "n_seq_units must lie in [0, n_row_units]");
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
@@ -387,8 +389,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     check_packed_view(v);
     r.live = true;
     r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
-    r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units;
-    const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units;
+    r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
+    const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units, ns = (size_t)r.n_seq_units;
     uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr;
     int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
     void *scratch = nullptr;
@@ -396,7 +398,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         Carver cv(pass ? r.block.p : nullptr);
         carve_common(cv, r);
         cigar = cv.take<uint32_t>(nc);
-        seq4 = cv.take<uint8_t>(nu * UZ_SEQ4_UNIT_BYTES);
+        seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
         qlow = cv.take<uint8_t>(nu * UZ_QLOW_UNIT_BYTES);
         start = cv.take<int32_t>(n); end = cv.take<int32_t>(n); tlen = cv.take<int32_t>(n); mate = cv.take<int32_t>(n);
         qname = cv.take<uint32_t>(n); flag = cv.take<uint16_t>(n); l_seq = cv.take<uint16_t>(n); n_cigar = cv.take<uint16_t>(n);
@@ -412,7 +414,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
     col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
     r.cigar = h2d(st, cigar, v->cigar, nc);
-    r.seq4 = h2d(st, seq4, v->seq4, nu * UZ_SEQ4_UNIT_BYTES);
+    r.seq4 = h2d(st, seq4, v->seq4, ns * UZ_SEQ4_UNIT_BYTES);
     r.qlow = qlow;
     h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
     r.qlow_thr = v->min_base_qual;
@@ -432,7 +434,7 @@ int uz_reads_upload_impl(uz_ctx *c, const uz_reads_view *v, ReadsDev &r) {
     // totals of the packed geometry from the host columns
     int64_t tot_c = 0, tot_u = 0;
     for (size_t i = 0; i < n; i++) { tot_c += v->n_cigar[i]; tot_u += UZ_ROW_UNITS(v->l_seq[i]); }
-    r.n_cigar_total = tot_c; r.n_row_units = tot_u;
+    r.n_cigar_total = tot_c; r.n_row_units = tot_u; r.n_seq_units = tot_u; // the ASCII form carries every record's bases
     UZ_REQUIRE(tot_c < ((int64_t)1 << 32) && tot_u < ((int64_t)1 << 32), UZ_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets");
     const size_t nc = (size_t)tot_c, nu = (size_t)tot_u, nci = (size_t)v->n_cigar_total, nsq = (size_t)v->n_sq_bytes;
     uint32_t *cigar = nullptr, *cigar_in = nullptr, *cigar_off_in = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq_in = nullptr;
@@ -524,7 +526,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
         ReadsDev r;
         r.live = true;
         r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
-        r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units;
+        r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
         void *scratch = nullptr;
         for (int pass = 0; pass < 2; pass++) {
             Carver cv(pass ? r.block.p : nullptr);
@@ -692,7 +694,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
         SitesDev &s = sites_of(c, f0.sites_id);
         // ---- the kids' tables end to end as one table
         std::vector<int> ids;
-        int64_t tot_n = 0, tot_c = 0, tot_u = 0, tot_contigs = 0;
+        int64_t tot_n = 0, tot_c = 0, tot_u = 0, tot_s = 0, tot_contigs = 0;
         uint64_t tot_q = 0;
         for (int32_t g = 0; g < n_groups; g++) {
             UZ_REQUIRE(groups[g].dnm_first >= 0 && groups[g].dnm_count >= 0 && groups[g].dnm_first + groups[g].dnm_count <= n, UZ_E_ARG,
@@ -706,7 +708,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
                 uz_build_qlow(c, c->stream, r, c->P.min_gt_qual);
             }
             ids.push_back(groups[g].reads_id);
-            tot_n += r.n; tot_c += r.n_cigar_total; tot_u += r.n_row_units; tot_contigs += r.n_contigs; tot_q += r.n_qnames;
+            tot_n += r.n; tot_c += r.n_cigar_total; tot_u += r.n_row_units; tot_s += r.n_seq_units; tot_contigs += r.n_contigs; tot_q += r.n_qnames;
         }
         UZ_REQUIRE(tot_n < (int64_t)0x7FFFFFF0 && tot_c < ((int64_t)1 << 32) && tot_u < ((int64_t)1 << 32) && tot_q < ((uint64_t)1 << 32), UZ_E_RANGE,
                    "the cohort's alignment records exceed one table's index ranges");
@@ -729,12 +731,13 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
             ReadsDev m;
             m.live = true;
             m.n = tot_n; m.n_contigs = (int32_t)tot_contigs; m.n_qnames = (uint32_t)tot_q; m.n_cigar_total = tot_c; m.n_row_units = tot_u;
+            m.n_seq_units = tot_s;
             uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr;
             for (int pass = 0; pass < 2; pass++) {
                 Carver cv(pass ? m.block.p : nullptr);
                 carve_common(cv, m);
                 cigar = cv.take<uint32_t>((size_t)tot_c);
-                seq4 = cv.take<uint8_t>((size_t)tot_u * UZ_SEQ4_UNIT_BYTES);
+                seq4 = cv.take<uint8_t>((size_t)tot_s * UZ_SEQ4_UNIT_BYTES);
                 qlow = cv.take<uint8_t>((size_t)tot_u * UZ_QLOW_UNIT_BYTES);
                 if (!pass) m.block = uz_block_get(c, cv.off + 256);
             }
@@ -743,7 +746,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
             try {
                 std::vector<int64_t> co((size_t)tot_contigs + 1, 0);
                 std::vector<int32_t> ms((size_t)tot_contigs + 1, 0);
-                int64_t cg = 0, un = 0;
+                int64_t cg = 0, un = 0, sn = 0;
                 for (int32_t g = 0; g < n_groups; g++) {
                     const ReadsDev &r = reads_of(c, groups[g].reads_id);
                     std::vector<int64_t> rco((size_t)r.n_contigs + 1);
@@ -755,8 +758,8 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
                         co[(size_t)contig_base[(size_t)g] + k] = rec_base[(size_t)g] + rco[(size_t)k];
                         ms[(size_t)contig_base[(size_t)g] + k] = rms[(size_t)k];
                     }
-                    uz_concat_table(c, c->stream, m, r, rec_base[(size_t)g], cg, un, q_base[(size_t)g]);
-                    cg += r.n_cigar_total; un += r.n_row_units;
+                    uz_concat_table(c, c->stream, m, r, rec_base[(size_t)g], cg, un, sn, q_base[(size_t)g]);
+                    cg += r.n_cigar_total; un += r.n_row_units; sn += r.n_seq_units;
                 }
                 co[(size_t)tot_contigs] = tot_n;
                 UZ_HIP(hipMemcpyAsync(m.contig_off, co.data(), co.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));

@@ -33,23 +33,30 @@ int guarded(F &&fn) {
 template <typename T>
 T *w(const T *p) { return const_cast<T *>(p); }
 
-// exclusive prefix sums of n_cigar / row units over [0, n): off arrays have n + 1 entries
-void offsets(int64_t n, const uint16_t *n_cigar, const uint16_t *l_seq, int threads, std::vector<uint64_t> &coff, std::vector<uint64_t> &uoff) {
+// exclusive prefix sums over [0, n) of n_cigar, of the quality-plane units (every record) and of the seq4 units (records
+// that carry bases: aux == nullptr means all); the arrays have n + 1 entries
+void offsets(int64_t n, const uint16_t *n_cigar, const uint16_t *l_seq, const uint8_t *aux, int threads, std::vector<uint64_t> &coff,
+             std::vector<uint64_t> &uoff, std::vector<uint64_t> &soff) {
     coff.assign((size_t)n + 1, 0);
     uoff.assign((size_t)n + 1, 0);
+    soff.assign((size_t)n + 1, 0);
     const int wk = workers_for(n, threads, 1 << 16);
-    std::vector<uint64_t> ca((size_t)wk + 1, 0), ua((size_t)wk + 1, 0);
+    std::vector<uint64_t> ca((size_t)wk + 1, 0), ua((size_t)wk + 1, 0), sa((size_t)wk + 1, 0);
+    auto seq_units = [&](int64_t i) -> uint64_t { return (aux && (aux[i] & UZ_AUX_NO_SEQ)) ? 0 : UZ_ROW_UNITS(l_seq[i]); };
     parallel_slices(n, wk, [&](int64_t lo, int64_t hi, int k) {
-        uint64_t a = 0, b = 0;
-        for (int64_t i = lo; i < hi; i++) { a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); }
-        ca[(size_t)k + 1] = a; ua[(size_t)k + 1] = b;
+        uint64_t a = 0, b = 0, c = 0;
+        for (int64_t i = lo; i < hi; i++) { a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); c += seq_units(i); }
+        ca[(size_t)k + 1] = a; ua[(size_t)k + 1] = b; sa[(size_t)k + 1] = c;
     });
-    for (int k = 0; k < wk; k++) { ca[(size_t)k + 1] += ca[k]; ua[(size_t)k + 1] += ua[k]; }
+    for (int k = 0; k < wk; k++) { ca[(size_t)k + 1] += ca[k]; ua[(size_t)k + 1] += ua[k]; sa[(size_t)k + 1] += sa[k]; }
     parallel_slices(n, wk, [&](int64_t lo, int64_t hi, int k) {
-        uint64_t a = ca[k], b = ua[k];
-        for (int64_t i = lo; i < hi; i++) { coff[i] = a; uoff[i] = b; a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); }
+        uint64_t a = ca[k], b = ua[k], c = sa[k];
+        for (int64_t i = lo; i < hi; i++) {
+            coff[i] = a; uoff[i] = b; soff[i] = c;
+            a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); c += seq_units(i);
+        }
     });
-    coff[n] = ca[wk]; uoff[n] = ua[wk];
+    coff[n] = ca[wk]; uoff[n] = ua[wk]; soff[n] = sa[wk];
 }
 
 } // namespace
@@ -57,14 +64,15 @@ void offsets(int64_t n, const uint16_t *n_cigar, const uint16_t *l_seq, int thre
 // a packed table opened as the source of selections: the CIGAR / row offsets of its records, computed once
 struct uz_psrc {
     uz_reads_packed_view v;
-    std::vector<uint32_t> coff, uoff; // [n + 1]
+    std::vector<uint32_t> coff, uoff, soff; // [n + 1]: CIGAR words, quality-plane units, seq4 units
 };
 
 struct uz_select {
     const uz_psrc *src = nullptr;
     int64_t n_sel = 0;
-    uint64_t n_cigar = 0, n_units = 0;
+    uint64_t n_cigar = 0, n_units = 0, n_seq = 0;
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
+    std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
 };
 
 extern "C" {
@@ -83,13 +91,14 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
         if (!in || !out) fail(UZ_IO_E_ARG, "null argument");
         const int64_t n = in->n_segs;
         threads = resolve_threads(threads);
-        std::vector<uint64_t> coff, uoff;
-        offsets(n, in->n_cigar, in->l_seq, threads, coff, uoff);
+        std::vector<uint64_t> coff, uoff, soff;
+        offsets(n, in->n_cigar, in->l_seq, nullptr, threads, coff, uoff, soff);
         if (coff[n] >= ((uint64_t)1 << 32) || uoff[n] >= ((uint64_t)1 << 32)) fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets");
         if ((int64_t)coff[n] != out->n_cigar_total || (int64_t)uoff[n] != out->n_row_units)
             fail(UZ_IO_E_ARG, "output view sized for %lld / %lld CIGAR words / row units, the table has %llu / %llu", (long long)out->n_cigar_total,
                  (long long)out->n_row_units, (unsigned long long)coff[n], (unsigned long long)uoff[n]);
         out->n_segs = n; out->n_contigs = in->n_contigs; out->min_base_qual = min_base_qual; out->n_qnames = in->n_qnames;
+        out->n_seq_units = out->n_row_units; // the ASCII form carries every record's bases
         memcpy(w(out->contig_off), in->contig_off, ((size_t)in->n_contigs + 1) * sizeof(int64_t));
         if (in->n_contigs) memcpy(w(out->max_span), in->max_span, (size_t)in->n_contigs * sizeof(int32_t));
         const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
@@ -117,18 +126,20 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
         threads = resolve_threads(threads);
         auto src = new uz_psrc();
         src->v = *full;
-        std::vector<uint64_t> coff, uoff;
-        offsets(full->n_segs, full->n_cigar, full->l_seq, threads, coff, uoff);
+        std::vector<uint64_t> coff, uoff, soff;
+        offsets(full->n_segs, full->n_cigar, full->l_seq, full->aux, threads, coff, uoff, soff);
         if (coff.back() >= ((uint64_t)1 << 32) || uoff.back() >= ((uint64_t)1 << 32)) { delete src; fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets"); }
+        if ((int64_t)soff.back() != full->n_seq_units) { delete src; fail(UZ_IO_E_ARG, "n_seq_units does not match the aux column"); }
         src->coff.assign(coff.begin(), coff.end());
         src->uoff.assign(uoff.begin(), uoff.end());
+        src->soff.assign(soff.begin(), soff.end());
         *out = src;
     });
 }
 void uz_reads_source_close(uz_psrc *s) { delete s; }
 
-int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int threads,
-                         uz_select **out) {
+int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
+                         int threads, uz_select **out) {
     return guarded([&] {
         if (!src || !out || (n_fetch > 0 && (!contig || !lo || !hi))) fail(UZ_IO_E_ARG, "null argument");
         threads = resolve_threads(threads);
@@ -155,7 +166,7 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                                                     [](int32_t v, int64_t key) { return (int64_t)v < key; });
                 for (int64_t i = p - full->start; i < c1 && full->start[i] < hi[f]; i++)
                     if (full->end[i] > lo[f]) {
-                        __atomic_store_n(&kp[i], (uint8_t)1, __ATOMIC_RELAXED);
+                        __atomic_store_n(&kp[i], (uint8_t)2, __ATOMIC_RELAXED); // 2: returned by a fetch, 1: reachable only as a mate
                         a = std::min(a, i); b = std::max(b, i + 1);
                     }
             }
@@ -187,8 +198,14 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
         sel->src = src;
         for (int64_t i = rmin.load(); i < rmax.load(); i++)
             if (kp[i]) {
+                // bases travel with a record a fetch returns (every base the read stage reads lies at a fetch point the
+                // record overlaps: DNM position, het site, candidate = het site); with --no-extended the join reads the
+                // mates of the DNM reads at candidate sites nobody fetched, so the caller asks for all of them
+                const bool bases = (kp[i] == 2 || all_bases) && !(full->aux[i] & UZ_AUX_NO_SEQ);
                 sel->index.push_back((int32_t)i);
+                sel->bases.push_back(bases ? 1 : 0);
                 sel->n_cigar += full->n_cigar[i]; sel->n_units += UZ_ROW_UNITS(full->l_seq[i]);
+                if (bases) sel->n_seq += UZ_ROW_UNITS(full->l_seq[i]);
             }
         sel->n_sel = (int64_t)sel->index.size();
         *out = sel;
@@ -198,6 +215,7 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
 int64_t uz_select_n_records(const uz_select *s) { return s ? s->n_sel : 0; }
 int64_t uz_select_n_cigar_total(const uz_select *s) { return s ? (int64_t)s->n_cigar : 0; }
 int64_t uz_select_n_row_units(const uz_select *s) { return s ? (int64_t)s->n_units : 0; }
+int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq : 0; }
 void uz_select_free(uz_select *s) { delete s; }
 
 int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *out, int32_t *orig_index) {
@@ -208,7 +226,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         threads = resolve_threads(threads);
         const int64_t m = s->n_sel;
         out->n_segs = m; out->n_contigs = full->n_contigs; out->min_base_qual = full->min_base_qual; out->n_qnames = full->n_qnames;
-        out->n_cigar_total = (int64_t)s->n_cigar; out->n_row_units = (int64_t)s->n_units;
+        out->n_cigar_total = (int64_t)s->n_cigar; out->n_row_units = (int64_t)s->n_units; out->n_seq_units = (int64_t)s->n_seq;
         for (int c = 0; c <= full->n_contigs; c++)
             w(out->contig_off)[c] = std::lower_bound(s->index.begin(), s->index.end(), full->contig_off[c],
                                                      [](int32_t v, int64_t key) { return (int64_t)v < key; }) - s->index.begin();
@@ -221,11 +239,12 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
             w(out->max_span)[c] = span;
         }
         // offsets of the kept records in the OUTPUT: prefix sums over the selection
-        std::vector<uint64_t> oc((size_t)m + 1, 0), ou((size_t)m + 1, 0);
+        std::vector<uint64_t> oc((size_t)m + 1, 0), ou((size_t)m + 1, 0), os((size_t)m + 1, 0);
         for (int64_t k = 0; k < m; k++) {
             const int64_t i = s->index[k];
             oc[k + 1] = oc[k] + full->n_cigar[i];
             ou[k + 1] = ou[k] + UZ_ROW_UNITS(full->l_seq[i]);
+            os[k + 1] = os[k] + (s->bases[k] ? UZ_ROW_UNITS(full->l_seq[i]) : 0);
         }
         parallel_slices(m, workers_for(m, threads, 4096), [&](int64_t a, int64_t b, int) {
             for (int64_t k = a; k < b; k++) {
@@ -239,10 +258,11 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 }
                 w(out->mate)[k] = nm;
                 w(out->qname)[k] = full->qname[i]; w(out->flag)[k] = full->flag[i]; w(out->l_seq)[k] = full->l_seq[i];
-                w(out->n_cigar)[k] = full->n_cigar[i]; w(out->mapq)[k] = full->mapq[i]; w(out->aux)[k] = full->aux[i];
+                w(out->n_cigar)[k] = full->n_cigar[i]; w(out->mapq)[k] = full->mapq[i];
+                w(out->aux)[k] = (uint8_t)(s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ));
                 memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
                 const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
-                memcpy(w(out->seq4) + ou[k] * UZ_SEQ4_UNIT_BYTES, full->seq4 + (size_t)src->uoff[i] * UZ_SEQ4_UNIT_BYTES, units * UZ_SEQ4_UNIT_BYTES);
+                if (s->bases[k]) memcpy(w(out->seq4) + os[k] * UZ_SEQ4_UNIT_BYTES, full->seq4 + (size_t)src->soff[i] * UZ_SEQ4_UNIT_BYTES, units * UZ_SEQ4_UNIT_BYTES);
                 memcpy(w(out->qlow) + ou[k] * UZ_QLOW_UNIT_BYTES, full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES, units * UZ_QLOW_UNIT_BYTES);
                 if (orig_index) orig_index[k] = (int32_t)i;
             }

@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
         int low = 0;
         // five words cover a 151-base read: requested together, longer reads loop on
         uint32_t w[5];
+        const size_t qo = R.qoff[mine];
 #pragma unroll
-        for (int u = 0; u < 5; u++) w[u] = u < units ? qw[(size_t)A.sq_off + u] : 0u;
+        for (int u = 0; u < 5; u++) w[u] = u < units ? qw[qo + u] : 0u;
 #pragma unroll
         for (int u = 0; u < 5; u++) {
             const int valid = ls - 32 * u;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
         }
         for (int u = 5; u < units; u++) {
             const int valid = ls - 32 * u;
-            uint32_t x = qw[(size_t)A.sq_off + u];
+            uint32_t x = qw[qo + u];
             if (valid < 32) x &= (1u << valid) - 1u;
             low += __popc(x);
         }
@@ -180,87 +181,87 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 // cigar_off / sq_off are the exclusive prefix sums of n_cigar / UZ_ROW_UNITS(l_seq) over the records: block
 // sums, one scan of the block sums, then the pack kernel scans inside its block and writes the headers.
 #define UZ_PK_SPAN 4096
+// three running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases)
+__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, uint32_t &a, uint32_t &b, uint32_t &s) {
+    a = nc; b = UZ_ROW_UNITS(ls); s = (aux & UZ_AUX_NO_SEQ) ? 0u : b;
+}
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_t *__restrict__ n_cigar, const uint16_t *__restrict__ l_seq,
-                                                        unsigned long long *sums /* [2 nb] */) {
-    __shared__ unsigned long long part[2][4];
+                                                        const uint8_t *__restrict__ aux, unsigned long long *sums /* [3 nb] */) {
+    __shared__ unsigned long long part[3][4];
     const int t = threadIdx.x;
-    unsigned long long a = 0, b = 0;
+    unsigned long long a = 0, b = 0, sq = 0;
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
-        if (i < n) { a += n_cigar[i]; b += UZ_ROW_UNITS(l_seq[i]); }
+        if (i < n) { uint32_t x, y, z; pk_vals(n_cigar[i], l_seq[i], aux[i], x, y, z); a += x; b += y; sq += z; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    if ((t & 63) == 0) { part[0][t >> 6] = a; part[1][t >> 6] = b; }
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); sq += __shfl_xor(sq, o, 64); }
+    if ((t & 63) == 0) { part[0][t >> 6] = a; part[1][t >> 6] = b; part[2][t >> 6] = sq; }
     __syncthreads();
-    if (t == 0) {
-        sums[2 * (size_t)blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
-        sums[2 * (size_t)blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
-    }
+    if (t == 0)
+        for (int k = 0; k < 3; k++) sums[3 * (size_t)blockIdx.x + k] = part[k][0] + part[k][1] + part[k][2] + part[k][3];
 }
 // one workgroup: exclusive scan of the block sums in place; the totals are checked against what the view declared
 __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
-                                                        unsigned long long want_units, int32_t *hflags) {
-    __shared__ unsigned long long part[2][1024];
+                                                        unsigned long long want_units, unsigned long long want_seq, int32_t *hflags) {
+    __shared__ unsigned long long part[3][1024];
     const int t = threadIdx.x;
     const int64_t chunk = (nb + 1023) / 1024;
     const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long a = 0, b = 0;
-    for (int64_t i = lo; i < hi; i++) { a += sums[2 * i]; b += sums[2 * i + 1]; }
-    part[0][t] = a; part[1][t] = b;
+    unsigned long long v[3] = {0, 0, 0};
+    for (int64_t i = lo; i < hi; i++)
+        for (int k = 0; k < 3; k++) v[k] += sums[3 * i + k];
+    for (int k = 0; k < 3; k++) part[k][t] = v[k];
     __syncthreads();
     if (t == 0) {
-        unsigned long long ra = 0, rb = 0;
-        for (int k = 0; k < 1024; k++) {
-            const unsigned long long va = part[0][k], vb = part[1][k];
-            part[0][k] = ra; part[1][k] = rb;
-            ra += va; rb += vb;
-        }
-        if (ra != want_cigar || rb != want_units || ra > 0xFFFFFFFFULL || rb > 0xFFFFFFFFULL) hflags[0] = 1;
+        unsigned long long r[3] = {0, 0, 0};
+        for (int j = 0; j < 1024; j++)
+            for (int k = 0; k < 3; k++) { const unsigned long long x = part[k][j]; part[k][j] = r[k]; r[k] += x; }
+        if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL) hflags[0] = 1;
     }
     __syncthreads();
-    a = part[0][t]; b = part[1][t];
-    for (int64_t i = lo; i < hi; i++) {
-        const unsigned long long va = sums[2 * i], vb = sums[2 * i + 1];
-        sums[2 * i] = a; sums[2 * i + 1] = b;
-        a += va; b += vb;
-    }
+    for (int k = 0; k < 3; k++) v[k] = part[k][t];
+    for (int64_t i = lo; i < hi; i++)
+        for (int k = 0; k < 3; k++) { const unsigned long long x = sums[3 * i + k]; sums[3 * i + k] = v[k]; v[k] += x; }
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
-                                                  uint32_t *fm) {
-    __shared__ uint32_t wsum[2][4];
+                                                  uint32_t *fm, uint32_t *qoff) {
+    __shared__ uint32_t wsum[3][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t run_a = (uint32_t)sums[2 * (size_t)blockIdx.x], run_b = (uint32_t)sums[2 * (size_t)blockIdx.x + 1];
+    uint32_t run[3] = {(uint32_t)sums[3 * (size_t)blockIdx.x], (uint32_t)sums[3 * (size_t)blockIdx.x + 1], (uint32_t)sums[3 * (size_t)blockIdx.x + 2]};
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         const bool in = i < n;
-        const uint32_t nc = in ? c.n_cigar[i] : 0u, ls = in ? c.l_seq[i] : 0u;
-        const uint32_t va = nc, vb = UZ_ROW_UNITS(ls);
-        uint32_t ia = va, ib = vb;
+        const uint32_t nc = in ? c.n_cigar[i] : 0u, ls = in ? c.l_seq[i] : 0u, ax = in ? c.aux[i] : 0u;
+        uint32_t v[3], inc[3];
+        pk_vals(nc, ls, ax, v[0], v[1], v[2]);
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t ua = __shfl_up(ia, o, 64), ub = __shfl_up(ib, o, 64);
-            if (lane >= o) { ia += ua; ib += ub; }
+        for (int k = 0; k < 3; k++) {
+            uint32_t x = v[k];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
+            inc[k] = x;
         }
         __syncthreads(); // wsum of the previous round has been read
-        if (lane == 63) { wsum[0][wv] = ia; wsum[1][wv] = ib; }
+        if (lane == 63) { wsum[0][wv] = inc[0]; wsum[1][wv] = inc[1]; wsum[2][wv] = inc[2]; }
         __syncthreads();
-        uint32_t pa = 0, pb = 0, ta = 0, tb = 0;
+        uint32_t pre[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            if (w < wv) { pa += wsum[0][w]; pb += wsum[1][w]; }
-            ta += wsum[0][w]; tb += wsum[1][w];
-        }
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) { if (w < wv) pre[k] += wsum[k][w]; tot[k] += wsum[k][w]; }
         if (in) {
             RecA A;
             RecB B;
-            uz_pack_rec(A, B, c.start[i], c.end[i], run_a + pa + ia - va, run_b + pb + ib - vb, c.mate[i], c.qname[i], (uint16_t)ls,
-                        (uint16_t)nc, c.tlen[i]);
+            const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : run[2] + pre[2] + inc[2] - v[2];
+            uz_pack_rec(A, B, c.start[i], c.end[i], run[0] + pre[0] + inc[0] - v[0], sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
             ra[i] = A;
             rb[i] = B;
-            fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], c.aux[i]);
+            fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);
+            qoff[i] = run[1] + pre[1] + inc[1] - v[1];
         }
-        run_a += ta; run_b += tb;
+#pragma unroll
+        for (int k = 0; k < 3; k++) run[k] += tot[k];
     }
 }
 
@@ -287,14 +288,13 @@ __global__ __launch_bounds__(256) void k_pack_ascii(int64_t n, const RecA *__res
     if (bad) hflags[0] = 2;
 }
 __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
-                                                    const uint8_t *__restrict__ qual8, const uint32_t *__restrict__ qual_off16, int thr,
-                                                    uint8_t *qlow) {
+                                                    const uint32_t *__restrict__ qoff, const uint8_t *__restrict__ qual8,
+                                                    const uint32_t *__restrict__ qual_off16, int thr, uint8_t *qlow) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const RecA A = ra[i];
     const int ls = rb[i].l_seq;
     const uint8_t *src = qual8 + ((size_t)qual_off16[i] << 4);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(qlow) + (size_t)A.sq_off;
+    uint32_t *dst = reinterpret_cast<uint32_t *>(qlow) + (size_t)qoff[i];
     const int units = (int)UZ_ROW_UNITS(ls);
     for (int u = 0; u < units; u++) {
         uint32_t w = 0;
@@ -305,23 +305,25 @@ __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__res
 
 // cohort batches: the headers of one kid's table copied into the merged table with its bases added
 __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
-                                                    RecA *da, RecB *db, uint32_t *dfm, int32_t rec_base, uint32_t cigar_base, uint32_t unit_base,
-                                                    uint32_t qname_base) {
+                                                    const uint32_t *__restrict__ sqo, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, int32_t rec_base,
+                                                    uint32_t cigar_base, uint32_t unit_base, uint32_t seq_base, uint32_t qname_base) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     RecA A = sa[i];
     RecB B = sb[i];
-    A.cigar_off += cigar_base; A.sq_off += unit_base;
+    A.cigar_off += cigar_base;
+    if (A.sq_off != UZ_NO_SEQ_OFF) A.sq_off += seq_base;
     if (B.mate >= 0) B.mate += rec_base;
     B.qname += qname_base;
-    da[i] = A; db[i] = B; dfm[i] = sfm[i];
+    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] + unit_base;
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
     R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
-    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qc = r.qc; R.coarse = r.coarse;
+    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.qc = r.qc; R.coarse = r.coarse;
+    R.err = nullptr; // set by the launcher of the per-DNM kernel
     return R;
 }
 
@@ -333,35 +335,37 @@ int next_pow2(long long v) {
 
 } // namespace
 
-size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * 2 * sizeof(unsigned long long); }
+size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * 3 * sizeof(unsigned long long); }
 
 void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col, void *off_scratch) {
     static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
     if (r.n <= 0) return;
     const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
     unsigned long long *sums = (unsigned long long *)off_scratch;
-    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, sums);
+    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
-                       (unsigned long long)r.n_row_units, c->hflags);
+                       (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm);
+                       (RecB *)r.rec_b, r.fm, r.qoff);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     UZ_HIP(hipGetLastError());
 }
 
 void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &src, int64_t rec_base, int64_t cigar_base, int64_t unit_base,
-                     uint32_t qname_base) {
+                     int64_t seq_base, uint32_t qname_base) {
     if (src.n <= 0) return;
     hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
-                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base,
-                       dst.fm + rec_base, (int32_t)rec_base, (uint32_t)cigar_base, (uint32_t)unit_base, qname_base);
+                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (RecA *)dst.rec_a + rec_base,
+                       (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base, (int32_t)rec_base, (uint32_t)cigar_base,
+                       (uint32_t)unit_base, (uint32_t)seq_base, qname_base);
     UZ_HIP(hipGetLastError());
     if (src.n_cigar_total)
         UZ_HIP(hipMemcpyAsync(const_cast<uint32_t *>(dst.cigar) + cigar_base, src.cigar, (size_t)src.n_cigar_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    if (src.n_row_units) {
-        UZ_HIP(hipMemcpyAsync(const_cast<uint8_t *>(dst.seq4) + (size_t)unit_base * UZ_SEQ4_UNIT_BYTES, src.seq4, (size_t)src.n_row_units * UZ_SEQ4_UNIT_BYTES,
+    if (src.n_seq_units)
+        UZ_HIP(hipMemcpyAsync(const_cast<uint8_t *>(dst.seq4) + (size_t)seq_base * UZ_SEQ4_UNIT_BYTES, src.seq4, (size_t)src.n_seq_units * UZ_SEQ4_UNIT_BYTES,
                               hipMemcpyDeviceToDevice, st));
+    if (src.n_row_units) {
         UZ_HIP(hipMemcpyAsync(dst.qlow + (size_t)unit_base * UZ_QLOW_UNIT_BYTES, src.qlow, (size_t)src.n_row_units * UZ_QLOW_UNIT_BYTES,
                               hipMemcpyDeviceToDevice, st));
     }
@@ -386,7 +390,7 @@ void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual) {
     const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
     if (r.n > 0) {
         hipLaunchKernelGGL(k_build_qlow, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, (const RecA *)r.rec_a,
-                           (const RecB *)r.rec_b, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow);
+                           (const RecB *)r.rec_b, (const uint32_t *)r.qoff, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow);
         UZ_HIP(hipGetLastError());
     }
     r.qlow_thr = min_base_qual;
@@ -444,6 +448,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.rcontig = c->dn.rcontig.p; a.dstart = c->dn.start.p; a.dend = c->dn.end.p; a.dflags = c->dn.dflags.p; a.vartype = c->dn.vartype.p;
     a.allele_off = c->dn.allele_off.p; a.alleles = c->dn.alleles.p;
     a.R = make_rd(r);
+    a.R.err = c->hflags + 1;
 
     // sizing pass -> scratch capacities (max over the batch)
     st->bounds.ensure((size_t)5 * n);
@@ -597,6 +602,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         if (origin) UZ_HIP(hipMemcpyAsync(hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         if (evidence) UZ_HIP(hipMemcpyAsync(hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         UZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->hflags[1]) {
+            c->hflags[1] = 0;
+            throw UzError{UZ_E_STATE, "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
+        }
         const unsigned long long used = *hused;
         if (!a.want_lists || used <= a.pool_cap) break;
         // list pool too small: grow to the exact demand and run again

@@ -59,7 +59,8 @@ extern "C" long long uz_emu_stats[16];
 // registrations, init elements), and a gather that finds start / end / offsets / lengths in one or two
 // 16-byte words touches one or two cache lines instead of five to eight.  cigar_off / sq_off are the prefix
 // sums of n_cigar / UZ_ROW_UNITS(l_seq) (rows and CIGAR words lie back to back in record order).
-struct RecA { int32_t start, end; uint32_t cigar_off, sq_off; }; // sq_off in row units (32 bases)
+struct RecA { int32_t start, end; uint32_t cigar_off, sq_off; }; // sq_off: seq4 row, in row units (32 bases); UZ_NO_SEQ_OFF = staged without bases
+#define UZ_NO_SEQ_OFF 0xFFFFFFFFu
 struct RecB { int32_t mate; uint32_t qname; uint16_t l_seq, n_cigar; int32_t tlen; };
 UZ_HD void uz_pack_rec(RecA &A, RecB &B, int32_t start, int32_t end, uint32_t cigar_off, uint32_t sq_off, int32_t mate,
                        uint32_t qname, uint16_t l_seq, uint16_t n_cigar, int32_t tlen) {
@@ -79,6 +80,8 @@ struct RD { // alignment records of one table (device pointers)
     const uint32_t *cigar; // BAM encoding, back to back in record order
     const uint8_t *seq4;   // 4-bit bases, 16 bytes per row unit
     const uint8_t *qlow;   // 1 bit per base (quality below the threshold), 4 bytes per row unit
+    const uint32_t *qoff;  // quality-plane row of every record, in row units (every record has one; seq4 rows only the records with bases)
+    int32_t *err;          // [0] set when the bases of a record staged without them are requested (must never happen)
     const uint8_t *qc;
     const int32_t *coarse; // start of every 4096th record (L2-resident search index), may be null
 };
@@ -331,8 +334,11 @@ UZ_DEV int uz_refpos_len(const RD &R, int seg) {
     }
     return q;
 }
-UZ_DEV uint8_t uz_base(const RD &R, uint32_t sq_off, int k) { return uz_seq4_base(R.seq4, sq_off, k); }
-UZ_DEV bool uz_qual_low(const RD &R, uint32_t sq_off, int k) { return uz_qlow_bit(R.qlow, sq_off, k) != 0; }
+UZ_DEV uint8_t uz_base(const RD &R, uint32_t sq_off, int k) {
+    if (sq_off == UZ_NO_SEQ_OFF) { *R.err = 1; return 0; } // the host left the bases out: its reach rule and the kernel disagree
+    return uz_seq4_base(R.seq4, sq_off, k);
+}
+UZ_DEV bool uz_qual_low(const RD &R, uint32_t q_off, int k) { return uz_qlow_bit(R.qlow, q_off, k) != 0; }
 
 // get_allele_at :56-73 -> the n bases start at query index `idx` of the row `sq_off`; false = the reference's False
 UZ_DEV bool uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n, uint32_t &sq_off, int &idx) {
@@ -435,8 +441,9 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, 
         oi += l;
     }
     const int ls = hs.l_seq;
+    const uint32_t q_off = R.qoff[seg];
     for (int k = rp; k < rp + var_len && k < ls; k++)
-        if (uz_qual_low(R, hs.sq_off, k)) return 0;
+        if (uz_qual_low(R, q_off, k)) return 0;
     if (has_id) return 2;
     if (7 < rp && rp < uz_refpos_len(R, seg) - 7) return 1;
     return 0;
@@ -917,11 +924,12 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 if (f0 >= 0) {
                     const long long hp = s.hpos[h];
                     const SegHdr h0 = uz_hdr(R, f0);
+                    const uint32_t q0 = R.qoff[f0]; // requested with the header
                     const int i = uz_qidx_h(R, h0, hp);
                     if (i >= 0) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
                         if (i >= 4 && i <= a.readlen - 4 && h0.l_seq > i + 1) {
                             const uint8_t al = uz_base(R, h0.sq_off, i);
-                            const bool low = uz_qual_low(R, h0.sq_off, i);
+                            const bool low = uz_qual_low(R, q0, i);
                             if (al == s.href[h] || al == s.halt[h]) fbv = al; // :98-105
                             if (seq < E && !low) cb = al;                     // :114-124
                         }
@@ -1260,11 +1268,11 @@ UZ_DEV uint8_t uz_seg_qc_combine(uint32_t f, uint32_t aux, int mapq, int min_map
     return qc;
 }
 // number of bases of a row whose quality is below the threshold: the set bits of its qlow words up to l_seq
-UZ_DEV int uz_row_low_count(const RD &R, uint32_t sq_off, int l_seq) {
+UZ_DEV int uz_row_low_count(const RD &R, uint32_t q_off, int l_seq) {
     int low = 0;
     const uint32_t units = UZ_ROW_UNITS(l_seq);
     for (uint32_t u = 0; u < units; u++) {
-        const uint8_t *b = R.qlow + (size_t)(sq_off + u) * UZ_QLOW_UNIT_BYTES;
+        const uint8_t *b = R.qlow + (size_t)(q_off + u) * UZ_QLOW_UNIT_BYTES;
         uint32_t w = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
         const int valid = l_seq - 32 * (int)u;
         if (valid < 32) w &= (1u << valid) - 1u;
@@ -1286,6 +1294,6 @@ UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual) {
     const uint32_t *c = R.cigar + A.cigar_off;
     int nonmatch = 0, none = 0;
     for (int k = 0; k < (int)B.n_cigar; k++) uz_cigar_op_counts(c[k], nonmatch, none);
-    const int low = uz_row_low_count(R, A.sq_off, B.l_seq); // :43-46
+    const int low = uz_row_low_count(R, R.qoff[seg], B.l_seq); // :43-46
     return uz_seg_qc_combine(fm & 0xFFFFu, aux, (int)((fm >> 16) & 0xFFu), min_map_qual, low, B.n_cigar, nonmatch, none);
 }

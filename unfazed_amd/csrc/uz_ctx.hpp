@@ -81,12 +81,13 @@ struct ReadsDev {
     int64_t n = 0;
     int32_t n_contigs = 0;
     uint32_t n_qnames = 0;
-    int64_t n_cigar_total = 0, n_row_units = 0;
+    int64_t n_cigar_total = 0, n_row_units = 0, n_seq_units = 0;
     DevBlock block;            // everything the library owns for this table lives in this one block
     int64_t *contig_off = nullptr;
     int32_t *max_span = nullptr;
     void *rec_a = nullptr, *rec_b = nullptr; // RecA / RecB headers (phase_body.hpp)
     uint32_t *fm = nullptr;    // flag | mapq << 16 | aux << 24
+    uint32_t *qoff = nullptr;  // quality-plane row of every record (row units)
     const uint32_t *cigar = nullptr;
     const uint8_t *seq4 = nullptr;
     uint8_t *qlow = nullptr;   // caller's memory for adopted tables (then never written)
@@ -128,7 +129,7 @@ struct uz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // compute (and the synchronous uploads)
     hipStream_t copy_stream = nullptr; // asynchronous uploads of packed tables: H2D + header build
-    int32_t *hflags = nullptr;         // pinned, device-visible: [0] upload consistency error (totals / alphabet)
+    int32_t *hflags = nullptr;         // pinned, device-visible: [0] upload consistency error (totals / alphabet), [1] bases of a row-less record requested
     std::vector<DevBlock> block_pool;
     uz_params P;
     std::string err;
@@ -220,7 +221,7 @@ void uz_pack_ascii_rows(uz_ctx *c, hipStream_t st, ReadsDev &r, const uint32_t *
 void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual);
 // appends table `src` to the merged table `dst` at the given bases (records, CIGAR words, row units, query names)
 void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &src, int64_t rec_base, int64_t cigar_base, int64_t unit_base,
-                     uint32_t qname_base);
+                     int64_t seq_base, uint32_t qname_base);
 void uz_finish_table(uz_ctx *c, hipStream_t st, ReadsDev &r); // coarse index of a table whose headers are in place
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);

@@ -27,7 +27,8 @@ IO_EXPORTS = [
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_reads_select_fill", "uz_select_free",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_reads_select_fill",
+    "uz_select_free",
 ]
 
 
@@ -98,8 +99,8 @@ def load():
     lib.uz_reads_source_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_reads_source_close.argtypes = [C.c_void_p]
     lib.uz_reads_source_close.restype = None
-    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
-    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units):
+    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units):
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int64
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -305,18 +306,19 @@ class ReadsSource:
         self._h = _Handle(h, self.lib.uz_reads_source_close)
         self.threads = threads
 
-    def select(self, contig, lo, hi, alloc=None, want_index=False):
-        """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table."""
+    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False):
+        """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
+        are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them)."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
         sel = C.c_void_p()
         _check(self.lib, self.lib.uz_reads_select_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data,
-                                                       hi.ctypes.data, int(self.threads), C.byref(sel)))
+                                                       hi.ctypes.data, 1 if all_bases else 0, int(self.threads), C.byref(sel)))
         try:
             n = self.lib.uz_select_n_records(sel)
             out = abi.packed_view_alloc(n, int(self.packed.view.n_contigs), self.lib.uz_select_n_cigar_total(sel),
-                                        self.lib.uz_select_n_row_units(sel), alloc)
+                                        self.lib.uz_select_n_row_units(sel), alloc, n_seq_units=self.lib.uz_select_n_seq_units(sel))
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
