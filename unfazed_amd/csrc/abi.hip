@@ -40,6 +40,15 @@ T *upload(uz_ctx *c, const T *host, size_t n) {
 }
 
 template <typename T>
+const T *h2d(hipStream_t st, T *dst, const T *host, size_t n) {
+    if (n) {
+        UZ_REQUIRE(host != nullptr, UZ_E_ARG, "null column pointer");
+        UZ_HIP(hipMemcpyAsync(dst, host, n * sizeof(T), hipMemcpyHostToDevice, st));
+    }
+    return dst;
+}
+
+template <typename T>
 void stage(uz_ctx *c, DevBuf<T> &b, const T *host, size_t n) {
     b.ensure(n + 1);
     if (n) {
@@ -69,19 +78,12 @@ ReadsDev &reads_of(uz_ctx *c, int id) {
     return c->reads[id];
 }
 
-void free_family(FamilyDev &f) {
-    if (f.owned) {
-        (void)hipFree(f.gt);
-        for (int m = 0; m < 3; m++) { (void)hipFree(f.rd[m]); (void)hipFree(f.ad[m]); (void)hipFree(f.gq[m]); }
-    }
-    (void)hipFree(f.cls);
+void free_family(uz_ctx *c, FamilyDev &f) {
+    uz_block_put(c, f.block);
     f = FamilyDev();
 }
-void free_sites(SitesDev &s) {
-    if (s.owned) {
-        (void)hipFree(s.pos); (void)hipFree(s.sflags); (void)hipFree(s.ref_base); (void)hipFree(s.alt_base);
-    }
-    (void)hipFree(s.contig_off);
+void free_sites(uz_ctx *c, SitesDev &s) {
+    uz_block_put(c, s.block);
     s = SitesDev();
 }
 void free_reads(uz_ctx *c, ReadsDev &r) {
@@ -105,6 +107,21 @@ struct Carver {
 };
 
 } // namespace
+
+// ---------------------------------------------------------------- copy kernel (see uz_ctx.hpp)
+template <typename W>
+__global__ __launch_bounds__(256) void k_copy(W *__restrict__ dst, const W *__restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void uz_kcopy(uz_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    const uintptr_t a = (uintptr_t)dst | (uintptr_t)src | (uintptr_t)bytes;
+    auto grid = [](size_t n) { return dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)); };
+    if (a % 16 == 0) hipLaunchKernelGGL(k_copy<uint4>, grid(bytes / 16), dim3(256), 0, c->stream, (uint4 *)dst, (const uint4 *)src, bytes / 16);
+    else if (a % 4 == 0) hipLaunchKernelGGL(k_copy<uint32_t>, grid(bytes / 4), dim3(256), 0, c->stream, (uint32_t *)dst, (const uint32_t *)src, bytes / 4);
+    else hipLaunchKernelGGL(k_copy<uint8_t>, grid(bytes), dim3(256), 0, c->stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
+    UZ_HIP(hipGetLastError());
+}
 
 // ---------------------------------------------------------------- device block pool
 DevBlock uz_block_get(uz_ctx *c, size_t bytes) {
@@ -192,7 +209,7 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d) {
     void *dst[9] = {c->dn.contig.p, c->dn.rcontig.p, c->dn.start.p, c->dn.end.p, c->dn.vartype.p, c->dn.dflags.p, c->dn.mult.p,
                     c->dn.allele_off.p, c->dn.alleles.p};
     for (int k = 0; k < 9; k++)
-        if (sizes[k]) UZ_HIP(hipMemcpyAsync(dst[k], c->dn_stage + off[k], sizes[k], hipMemcpyHostToDevice, c->stream));
+        if (sizes[k]) uz_kcopy(c, dst[k], c->dn_stage + off[k], sizes[k]); // out of the pinned staging buffer, by a kernel
     c->dn.cutoff = d->cutoff;
 }
 
@@ -226,8 +243,8 @@ void uz_destroy(uz_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     uz_prof_drain(c);
     uz_phase_state_free(c);
-    for (auto &f : c->fams) if (f.live) free_family(f);
-    for (auto &s : c->sites) if (s.live) free_sites(s);
+    for (auto &f : c->fams) if (f.live) free_family(c, f);
+    for (auto &s : c->sites) if (s.live) free_sites(c, s);
     for (auto &r : c->reads) if (r.live) free_reads(c, r);
     for (auto &b : c->block_pool) (void)hipFree(b.p);
     if (c->hflags) (void)hipHostFree(c->hflags);
@@ -268,12 +285,19 @@ int uz_sites_upload(uz_ctx *c, const uz_sites_view *v, int *id) {
         s.live = true; s.owned = true;
         s.n = v->n_sites; s.n_contigs = v->n_contigs;
         s.contig_off_h.assign(v->contig_off, v->contig_off + v->n_contigs + 1);
-        s.contig_off = upload(c, v->contig_off, (size_t)v->n_contigs + 1);
-        s.pos = upload(c, v->pos, (size_t)s.n);
-        s.sflags = upload(c, v->sflags, (size_t)s.n);
-        s.ref_base = upload(c, v->ref_base, (size_t)s.n);
-        s.alt_base = upload(c, v->alt_base, (size_t)s.n);
-        UZ_HIP(hipStreamSynchronize(c->stream));
+        const size_t n = (size_t)s.n;
+        for (int pass = 0; pass < 2; pass++) { // one pooled block for the table: no hipMalloc / hipFree per staged pass
+            Carver cv(pass ? s.block.p : nullptr);
+            s.contig_off = cv.take<int64_t>((size_t)v->n_contigs + 1);
+            s.pos = cv.take<int32_t>(n); s.sflags = cv.take<uint8_t>(n); s.ref_base = cv.take<uint8_t>(n); s.alt_base = cv.take<uint8_t>(n);
+            if (!pass) s.block = uz_block_get(c, cv.off + 256);
+        }
+        try {
+            h2d(c->stream, s.contig_off, v->contig_off, (size_t)v->n_contigs + 1);
+            h2d(c->stream, s.pos, v->pos, n); h2d(c->stream, s.sflags, v->sflags, n);
+            h2d(c->stream, s.ref_base, v->ref_base, n); h2d(c->stream, s.alt_base, v->alt_base, n);
+            UZ_HIP(hipStreamSynchronize(c->stream));
+        } catch (...) { uz_block_put(c, s.block); throw; }
         c->sites[k] = s;
         *id = k;
     });
@@ -288,7 +312,12 @@ int uz_sites_adopt_device(uz_ctx *c, const uz_sites_view *v, int *id) {
         s.n = v->n_sites; s.n_contigs = v->n_contigs;
         s.contig_off_h.resize((size_t)v->n_contigs + 1);
         UZ_HIP(hipMemcpy(s.contig_off_h.data(), v->contig_off, ((size_t)v->n_contigs + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
-        s.contig_off = upload(c, s.contig_off_h.data(), (size_t)v->n_contigs + 1);
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? s.block.p : nullptr);
+            s.contig_off = cv.take<int64_t>((size_t)v->n_contigs + 1);
+            if (!pass) s.block = uz_block_get(c, cv.off + 256);
+        }
+        h2d(c->stream, s.contig_off, (const int64_t *)s.contig_off_h.data(), (size_t)v->n_contigs + 1);
         s.pos = const_cast<int32_t *>(v->pos);
         s.sflags = const_cast<uint8_t *>(v->sflags);
         s.ref_base = const_cast<uint8_t *>(v->ref_base);
@@ -303,7 +332,6 @@ static void family_common(uz_ctx *c, int sites_id, FamilyDev &f) {
     SitesDev &s = sites_of(c, sites_id);
     f.live = true;
     f.sites_id = sites_id;
-    UZ_HIP(hipMalloc((void **)&f.cls, (size_t)(s.n ? s.n : 1) + 64));
     uz_fold_complex(c, f.gt, s.sflags, s.n);
     UZ_HIP(hipStreamSynchronize(c->stream));
 }
@@ -314,13 +342,21 @@ int uz_family_upload(uz_ctx *c, int sites_id, const uz_family_view *v, int *id) 
         SitesDev &s = sites_of(c, sites_id);
         FamilyDev f;
         f.owned = true;
-        f.gt = upload(c, v->gt, (size_t)s.n);
-        for (int m = 0; m < 3; m++) {
-            f.rd[m] = upload(c, v->ref_depth[m], (size_t)s.n);
-            f.ad[m] = upload(c, v->alt_depth[m], (size_t)s.n);
-            f.gq[m] = upload(c, v->gq[m], (size_t)s.n);
+        const size_t n = (size_t)s.n;
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? f.block.p : nullptr);
+            f.cls = cv.take<uint8_t>(n);
+            f.gt = cv.take<uint8_t>(n);
+            for (int m = 0; m < 3; m++) { f.rd[m] = cv.take<uint16_t>(n); f.ad[m] = cv.take<uint16_t>(n); f.gq[m] = cv.take<uint16_t>(n); }
+            if (!pass) f.block = uz_block_get(c, cv.off + 256);
         }
-        family_common(c, sites_id, f);
+        try {
+            h2d(c->stream, f.gt, v->gt, n);
+            for (int m = 0; m < 3; m++) {
+                h2d(c->stream, f.rd[m], v->ref_depth[m], n); h2d(c->stream, f.ad[m], v->alt_depth[m], n); h2d(c->stream, f.gq[m], v->gq[m], n);
+            }
+            family_common(c, sites_id, f);
+        } catch (...) { uz_block_put(c, f.block); throw; }
         const int k = new_slot(c->fams);
         c->fams[k] = f;
         *id = k;
@@ -341,7 +377,15 @@ int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int
                        "device columns must be 16-byte aligned");
         }
         UZ_REQUIRE((uintptr_t)f.gt % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
-        family_common(c, sites_id, f);
+        {
+            SitesDev &s = sites_of(c, sites_id);
+            for (int pass = 0; pass < 2; pass++) {
+                Carver cv(pass ? f.block.p : nullptr);
+                f.cls = cv.take<uint8_t>((size_t)s.n);
+                if (!pass) f.block = uz_block_get(c, cv.off + 256);
+            }
+        }
+        try { family_common(c, sites_id, f); } catch (...) { uz_block_put(c, f.block); throw; }
         const int k = new_slot(c->fams);
         c->fams[k] = f;
         *id = k;
@@ -367,15 +411,6 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.max_span = cv.take<int32_t>((size_t)r.n_contigs + 1);
 }
 
-template <typename T>
-static const T *h2d(hipStream_t st, T *dst, const T *host, size_t n) {
-    if (n) {
-        UZ_REQUIRE(host != nullptr, UZ_E_ARG, "null column pointer");
-        UZ_HIP(hipMemcpyAsync(dst, host, n * sizeof(T), hipMemcpyHostToDevice, st));
-    }
-    return dst;
-}
-
 static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_segs >= 0 && v->n_segs < (int64_t)0x7FFFFFF0, UZ_E_RANGE, "more than 2^31 alignment records");
     UZ_REQUIRE(v->n_contigs >= 0, UZ_E_ARG, "bad reads view");
@@ -385,7 +420,7 @@ static void check_packed_view(const uz_reads_packed_view *v) {
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
-static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_packed_view *v, ReadsDev &r) {
+static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_packed_view *v, ReadsDev &r, bool defer_build) {
     check_packed_view(v);
     r.live = true;
     r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
@@ -419,8 +454,27 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
+    if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
+        const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
+        for (int k = 0; k < 10; k++) r.col_ptrs[k] = p[k];
+        r.build_scratch = scratch;
+        return;
+    }
     UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, st));
     uz_build_records(c, st, r, col, scratch);
+}
+
+void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
+    if (!r.pending) return;
+    UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0));
+    RecColumns col;
+    col.start = (const int32_t *)r.col_ptrs[0]; col.end = (const int32_t *)r.col_ptrs[1]; col.tlen = (const int32_t *)r.col_ptrs[2];
+    col.mate = (const int32_t *)r.col_ptrs[3]; col.qname = (const uint32_t *)r.col_ptrs[4]; col.flag = (const uint16_t *)r.col_ptrs[5];
+    col.l_seq = (const uint16_t *)r.col_ptrs[6]; col.n_cigar = (const uint16_t *)r.col_ptrs[7]; col.mapq = (const uint8_t *)r.col_ptrs[8];
+    col.aux = (const uint8_t *)r.col_ptrs[9];
+    UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, c->stream));
+    uz_build_records(c, c->stream, r, col, r.build_scratch);
+    r.pending = false;
 }
 
 int uz_reads_upload_impl(uz_ctx *c, const uz_reads_view *v, ReadsDev &r) {
@@ -496,7 +550,7 @@ int uz_reads_upload_packed(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
         ReadsDev r;
         try {
-            reads_from_packed_host(c, c->copy_stream, v, r);
+            reads_from_packed_host(c, c->copy_stream, v, r, true);
             UZ_HIP(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
             UZ_HIP(hipEventRecord(r.ready, c->copy_stream));
             r.pending = true;
@@ -510,7 +564,8 @@ int uz_reads_upload_packed(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
 int uz_reads_wait(uz_ctx *c, int reads_id) {
     return guarded(c, [&] {
         ReadsDev &r = reads_of(c, reads_id);
-        if (r.ready) UZ_HIP(hipEventSynchronize(r.ready));
+        uz_reads_make_ready(c, r);
+        UZ_HIP(hipStreamSynchronize(c->stream));
         if (c->hflags[0]) {
             c->hflags[0] = 0;
             throw UzError{UZ_E_RANGE, "n_cigar_total / n_row_units of the reads view do not match its columns"};
@@ -579,8 +634,8 @@ int uz_sites_free(uz_ctx *c, int sites_id) {
         SitesDev &s = sites_of(c, sites_id);
         UZ_HIP(hipStreamSynchronize(c->stream));
         for (auto &f : c->fams)
-            if (f.live && f.sites_id == sites_id) free_family(f);
-        free_sites(s);
+            if (f.live && f.sites_id == sites_id) free_family(c, f);
+        free_sites(c, s);
         c->find_valid = false;
     });
 }
@@ -702,7 +757,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
             UZ_REQUIRE(fam_of(c, groups[g].fam_id).sites_id == f0.sites_id, UZ_E_ARG, "the families of a cohort batch must share a sites table");
             ReadsDev &r = reads_of(c, groups[g].reads_id);
             UZ_REQUIRE(groups[g].reads_id != c->cohort_reads, UZ_E_ARG, "the merged cohort table cannot be a member of a cohort");
-            if (r.pending) { UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0)); r.pending = false; }
+            uz_reads_make_ready(c, r);
             if (!r.qlow_valid || r.qlow_thr != c->P.min_gt_qual) {
                 UZ_REQUIRE(r.qual8 != nullptr, UZ_E_STATE, "a reads table of the cohort was packed for another --min-gt-qual");
                 uz_build_qlow(c, c->stream, r, c->P.min_gt_qual);

@@ -422,10 +422,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     c->phase_n = n;
     if (n <= 0) { c->phase_valid = true; return; }
     // an asynchronous upload of this table must have landed before the first kernel reads it
-    if (r.pending) {
-        UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0));
-        r.pending = false;
-    }
+    uz_reads_make_ready(c, r);
     // the quality plane holds ONE threshold: tables that kept their full qualities are re-thresholded, the others
     // were decoded for a threshold and refuse another
     if (!r.qlow_valid || r.qlow_thr != c->P.min_gt_qual) {
@@ -471,7 +468,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
     }
     const int32_t *bh = st->bounds_h;
-    UZ_HIP(hipMemcpyAsync(st->bounds_h, st->bounds.p, (size_t)5 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    uz_kcopy(c, st->bounds_h, st->bounds.p, (size_t)5 * n * sizeof(int32_t));
     if (!st->bounds_ready) UZ_HIP(hipEventCreateWithFlags(&st->bounds_ready, hipEventDisableTiming));
     UZ_HIP(hipEventRecord(st->bounds_ready, c->stream));
     // K3a, lazily: QC bits only for the records some fetch range of this batch (or a mate) can reach.
@@ -596,11 +593,11 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         UZ_TRACE("after k_phase");
         *hused = 0;
-        UZ_HIP(hipMemcpyAsync(hused, st->pool_cursor.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-        if (status) UZ_HIP(hipMemcpyAsync(hres, st->status.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (counts) UZ_HIP(hipMemcpyAsync(hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (origin) UZ_HIP(hipMemcpyAsync(hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-        if (evidence) UZ_HIP(hipMemcpyAsync(hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        uz_kcopy(c, hused, st->pool_cursor.p, sizeof(unsigned long long));
+        if (status) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
+        if (counts) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
+        if (origin) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
+        if (evidence) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
         UZ_HIP(hipStreamSynchronize(c->stream));
         if (c->hflags[1]) {
             c->hflags[1] = 0;

@@ -723,10 +723,13 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
             UZ_HIP(hipMemcpyAsync(c->het_off_h.data(), c->het_off.p, ((size_t)n + 1) * sizeof(int64_t),
                                   hipMemcpyDeviceToHost, c->stream));
             UZ_HIP(hipStreamSynchronize(c->stream));
-        } else { // the read stage only needs the two totals to size the lists
-            UZ_HIP(hipMemcpyAsync(&c->cand_off_h[n], c->cand_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-            UZ_HIP(hipMemcpyAsync(&c->het_off_h[n], c->het_off.p + n, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        } else { // the read stage only needs the two totals to size the lists: into the pinned mailbox, by a kernel
+            int64_t *box = reinterpret_cast<int64_t *>(c->hflags + 4);
+            uz_kcopy(c, box, c->cand_off.p + n, sizeof(int64_t));
+            uz_kcopy(c, box + 1, c->het_off.p + n, sizeof(int64_t));
             UZ_HIP(hipStreamSynchronize(c->stream));
+            c->cand_off_h[n] = box[0];
+            c->het_off_h[n] = box[1];
         }
         c->n_cand = c->cand_off_h[n];
         c->n_het = c->het_off_h[n];

@@ -46,8 +46,16 @@ struct DevBuf {
     }
 };
 
+// one device allocation out of the context's pool (tables come and go every staged pass: hipFree
+// synchronises the device, so freed blocks are parked and handed out again)
+struct DevBlock {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+};
+
 struct SitesDev {
     bool live = false, owned = false;
+    DevBlock block; // owned tables: every column in one pooled block
     int64_t n = 0;
     int32_t n_contigs = 0;
     std::vector<int64_t> contig_off_h;
@@ -58,6 +66,7 @@ struct SitesDev {
 
 struct FamilyDev {
     bool live = false, owned = false;
+    DevBlock block; // the class column and, for owned tables, the genotype columns
     int sites_id = -1;
     uint8_t *gt = nullptr; // bits 0-5 genotypes; bit 6 = the site's complex flag, folded in at upload
     uint16_t *rd[3] = {nullptr, nullptr, nullptr};
@@ -67,13 +76,6 @@ struct FamilyDev {
     bool cls_valid = false;
     bool cls_has_cnv = false; // DEL / DUP codes (bits 3-6) computed
     uz_params cls_params;
-};
-
-// one device allocation out of the context's pool (tables come and go every staged pass: hipFree
-// synchronises the device, so freed blocks are parked and handed out again)
-struct DevBlock {
-    uint8_t *p = nullptr;
-    size_t cap = 0;
 };
 
 struct ReadsDev {
@@ -99,8 +101,12 @@ struct ReadsDev {
     uint8_t *qc = nullptr;     // K3a output: per-record QC bits for the parameters in qc_params
     uint8_t *need = nullptr;   // records reachable by the current batch (lazy K3a)
     int32_t *coarse = nullptr; // start of every 4096th record
-    hipEvent_t ready = nullptr; // asynchronous uploads: recorded behind the last command of the upload
-    bool pending = false;
+    hipEvent_t ready = nullptr; // asynchronous uploads: recorded behind the last copy of the upload
+    bool pending = false;       // the copies may still be in flight, and the headers are not built yet
+    // the header build of an asynchronous upload runs on the COMPUTE stream at first use: kernels queued on the copy stream
+    // would wait behind the persistent per-DNM grid and hold up the next table's copies
+    const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *build_scratch = nullptr;
     bool qc_valid = false;
     uz_params qc_params;
 };
@@ -129,7 +135,8 @@ struct uz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // compute (and the synchronous uploads)
     hipStream_t copy_stream = nullptr; // asynchronous uploads of packed tables: H2D + header build
-    int32_t *hflags = nullptr;         // pinned, device-visible: [0] upload consistency error (totals / alphabet), [1] bases of a row-less record requested
+    int32_t *hflags = nullptr;         // pinned, device-visible: [0] upload consistency error (totals / alphabet), [1] bases of a row-less
+                                       // record requested; [4..7] two int64 mailboxes (list totals of the window emit)
     std::vector<DevBlock> block_pool;
     uz_params P;
     std::string err;
@@ -210,6 +217,13 @@ struct RecColumns {
     const uint16_t *flag, *l_seq, *n_cigar;
     const uint8_t *mapq, *aux;
 };
+// Small transfers on the COMPUTE path go through a copy kernel, one side in pinned host memory, never through
+// hipMemcpyAsync: the DMA engine is in order, and a 2 KB result copy queued behind gigabytes of staged uploads would hold
+// the kernels of the current table back until every later table has landed (measured: copies and kernels did not
+// overlap at all).  dst / src: device memory or pinned host memory.
+void uz_kcopy(uz_ctx *c, void *dst, const void *src, size_t bytes);
+// waits for an asynchronous upload and builds its headers, on the compute stream (no-op for a table that is ready)
+void uz_reads_make_ready(uz_ctx *c, ReadsDev &r);
 // stage launchers
 // offsets (prefix sums of n_cigar / row units), RecA / RecB / fm and the coarse index, on stream `st`;
 // off_scratch: >= uz_rec_scratch_bytes(n) bytes of device memory
