@@ -337,11 +337,11 @@ def main():
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
                 "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n)}
 
-    # K3a per examined record: two 16-byte headers + the flag word + the first CIGAR word + the quality plane
-    # (4 B per 32 bases) read, 1 B written
+    # K3a per examined record: the length word, the flag word, the quality-plane offset (4 B each) + the quality plane
+    # (4 B per 32 bases) read, 1 B written; the ~2 % of records with a real CIGAR also fetch a header and their words
     qc_ms, qc_n = prof_r[K_SEG_QC_PASS]
     qc_us = qc_ms / max(1, qc_n) * 1e3
-    qc_bytes = qc_records * (16 + 16 + 4 + 4 + 4.0 * ((int(P.readlen) + 31) // 32) + 1)
+    qc_bytes = qc_records * (4 + 4 + 4 + 4.0 * ((int(P.readlen) + 31) // 32) + 1)
     k3a_traffic = None
     tpath = os.path.join(ROOT, "profiles", "k3a_traffic.json")
     if os.path.exists(tpath):

@@ -404,6 +404,7 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.rec_b = cv.take<uint8_t>(n * 16);
     r.fm = cv.take<uint32_t>(n);
     r.qoff = cv.take<uint32_t>(n);
+    r.k3 = cv.take<uint32_t>(n);
     r.qc = cv.take<uint8_t>(n);
     r.need = cv.take<uint8_t>(n);
     r.coarse = cv.take<int32_t>((n >> 12) + 2);

@@ -59,17 +59,17 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
     const uint32_t *__restrict__ qw = reinterpret_cast<const uint32_t *>(R.qlow); // rows start on 4-byte units
     for (int r0 = t; r0 < m; r0 += 256) {
         const int mine = lst[r0];
-        const RecA A = R.ra[mine];
-        const RecB B = R.rb[mine];
+        // three words per record instead of its two 16-byte headers: lengths + "simple" flag, flags, quality-plane row
+        const uint32_t k3 = R.k3[mine];
         const uint32_t fm = R.fm[mine];
+        const size_t qo = R.qoff[mine];
         const uint32_t ax = fm >> 24;
-        const int ncg = B.n_cigar, ls = (ax & UZ_AUX_DECODE_BAD) ? 0 : (int)B.l_seq;
-        const uint32_t c0 = ncg > 0 ? R.cigar[A.cigar_off] : 0u;
+        const int ncg = (int)((k3 >> 16) & 0x7FFFu), ls = (ax & UZ_AUX_DECODE_BAD) ? 0 : (int)(k3 & 0xFFFFu);
+        const bool simple = (k3 >> 31) != 0;
         const int units = (int)UZ_ROW_UNITS(ls);
         int low = 0;
         // five words cover a 151-base read: requested together, longer reads loop on
         uint32_t w[5];
-        const size_t qo = R.qoff[mine];
 #pragma unroll
         for (int u = 0; u < 5; u++) w[u] = u < units ? qw[qo + u] : 0u;
 #pragma unroll
@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
             low += __popc(x);
         }
         int nonmatch = 0, none = 0;
-        if (ncg > 0) uz_cigar_op_counts(c0, nonmatch, none);
-        for (int k = 1; k < ncg; k++) uz_cigar_op_counts(R.cigar[A.cigar_off + k], nonmatch, none);
+        if (!simple && ncg > 0) { // the few records with a real CIGAR: soft clips, indels, ...
+            const uint32_t coff = R.ra[mine].cigar_off;
+            const int nc_all = (int)R.rb[mine].n_cigar; // the word saturates at 32767
+            for (int k = 0; k < nc_all; k++) uz_cigar_op_counts(R.cigar[coff + k], nonmatch, none);
+        }
         qc[mine] = uz_seg_qc_combine(fm & 0xFFFFu, ax, (int)((fm >> 16) & 0xFFu), min_map_qual, low, ncg, nonmatch, none);
     }
 }
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
         for (int k = 0; k < 3; k++) { const unsigned long long x = sums[3 * i + k]; sums[3 * i + k] = v[k]; v[k] += x; }
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
-                                                  uint32_t *fm, uint32_t *qoff) {
+                                                  uint32_t *fm, uint32_t *qoff, uint32_t *k3) {
     __shared__ uint32_t wsum[3][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     uint32_t run[3] = {(uint32_t)sums[3 * (size_t)blockIdx.x], (uint32_t)sums[3 * (size_t)blockIdx.x + 1], (uint32_t)sums[3 * (size_t)blockIdx.x + 2]};
@@ -259,6 +262,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             rb[i] = B;
             fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);
             qoff[i] = run[1] + pre[1] + inc[1] - v[1];
+            k3[i] = uz_pack_k3(ls, nc, A.start, A.end);
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) run[k] += tot[k];
@@ -305,7 +309,8 @@ __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__res
 
 // cohort batches: the headers of one kid's table copied into the merged table with its bases added
 __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
-                                                    const uint32_t *__restrict__ sqo, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, int32_t rec_base,
+                                                    const uint32_t *__restrict__ sqo, const uint32_t *__restrict__ sk3, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3,
+                                                    int32_t rec_base,
                                                     uint32_t cigar_base, uint32_t unit_base, uint32_t seq_base, uint32_t qname_base) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -315,12 +320,12 @@ __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__res
     if (A.sq_off != UZ_NO_SEQ_OFF) A.sq_off += seq_base;
     if (B.mate >= 0) B.mate += rec_base;
     B.qname += qname_base;
-    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] + unit_base;
+    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] + unit_base; dk3[i] = sk3[i];
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
-    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm;
+    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm; R.k3 = r.k3;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
     R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.qc = r.qc; R.coarse = r.coarse;
     R.err = nullptr; // set by the launcher of the per-DNM kernel
@@ -346,7 +351,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
                        (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm, r.qoff);
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     UZ_HIP(hipGetLastError());
@@ -356,8 +361,9 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
                      int64_t seq_base, uint32_t qname_base) {
     if (src.n <= 0) return;
     hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
-                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (RecA *)dst.rec_a + rec_base,
-                       (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base, (int32_t)rec_base, (uint32_t)cigar_base,
+                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint32_t *)src.k3,
+                       (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base, dst.k3 + rec_base,
+                       (int32_t)rec_base, (uint32_t)cigar_base,
                        (uint32_t)unit_base, (uint32_t)seq_base, qname_base);
     UZ_HIP(hipGetLastError());
     if (src.n_cigar_total)

@@ -90,6 +90,7 @@ struct ReadsDev {
     void *rec_a = nullptr, *rec_b = nullptr; // RecA / RecB headers (phase_body.hpp)
     uint32_t *fm = nullptr;    // flag | mapq << 16 | aux << 24
     uint32_t *qoff = nullptr;  // quality-plane row of every record (row units)
+    uint32_t *k3 = nullptr;    // l_seq | n_cigar << 16 | simple << 31 (uz_pack_k3): the lengths K3a needs in one word
     const uint32_t *cigar = nullptr;
     const uint8_t *seq4 = nullptr;
     uint8_t *qlow = nullptr;   // caller's memory for adopted tables (then never written)
