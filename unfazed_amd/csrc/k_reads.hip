@@ -141,6 +141,9 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
     }
 }
 
+#ifndef UZ_PHASE_PARTS
+#define UZ_PHASE_PARTS 8 // XCDs of an MI355X
+#endif
 #ifndef UZ_PHASE_MIN_WAVES
 #define UZ_PHASE_MIN_WAVES 5 // <= 96 VGPRs (the kernel needs 94, no spills): five waves per SIMD = five 256-lane workgroups per CU
 #endif
@@ -149,12 +152,27 @@ __global__ __launch_bounds__(WG_NT, UZ_PHASE_MIN_WAVES) void k_phase(PhaseArgs a
     extern __shared__ __attribute__((aligned(16))) uint8_t uz_lds_arena[];
     Scr s;
     uz_scratch_carve(a.scratch + (size_t)blockIdx.x * a.scratch_per_wg, a.caps, s);
+    // Work distribution: the batch is cut into UZ_PHASE_PARTS contiguous DNM ranges, one cursor each, and a workgroup
+    // starts on the range of (blockIdx % PARTS) -- with the usual round-robin placement of workgroups over the 8 XCDs that is
+    // "its XCD's range".  DNMs are sorted by position and neighbours share window sites and alignment records, so the lines
+    // one of them pulls into the XCD's L2 serve the next (each XCD has its own L2).  A workgroup whose range is exhausted
+    // goes on to the other ranges; nothing depends on where a workgroup really runs.
+    int part = (int)(blockIdx.x % UZ_PHASE_PARTS);
+    int tried = 0;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) sh.bcast[0] = atomicAdd(a.work_cursor, 1);
+        if (threadIdx.x == 0) {
+            const int lo = (int)((long long)a.n * part / UZ_PHASE_PARTS), hi = (int)((long long)a.n * (part + 1) / UZ_PHASE_PARTS);
+            const int k = atomicAdd(a.work_cursor + 16 * part, 1); // cursors on separate cache lines
+            sh.bcast[0] = lo + k < hi ? lo + k : -1;
+        }
         __syncthreads();
         const int d = sh.bcast[0];
-        if (d >= a.n) break;
+        if (d < 0) {
+            if (++tried >= UZ_PHASE_PARTS) break;
+            part = (part + 1) % UZ_PHASE_PARTS;
+            continue;
+        }
         uz_phase_dnm(a, s, &sh, a.lds_arena_bytes > 0 ? uz_lds_arena : nullptr, d);
     }
 }
@@ -546,7 +564,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.scratch = st->scratch.p; a.scratch_per_wg = per_wg; a.caps = caps;
 
     st->status.ensure(n); st->counts.ensure((size_t)4 * n); st->origin.ensure(n); st->evidence.ensure(n);
-    st->cursor.ensure(4);
+    st->cursor.ensure(16 * UZ_PHASE_PARTS);
     a.status = st->status.p; a.counts = st->counts.p; a.origin = st->origin.p; a.evidence = st->evidence.p;
     a.work_cursor = st->cursor.p;
     a.want_lists = uz_want_lists;
@@ -589,7 +607,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     int32_t *const hres = st->bounds_h;
     unsigned long long *const hused = (unsigned long long *)(hres + (size_t)7 * n + ((7 * (size_t)n) & 1)); // 8-byte aligned slot
     for (int attempt = 0; attempt < 4; attempt++) {
-        UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 4 * sizeof(int32_t), c->stream));
+        UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * UZ_PHASE_PARTS * sizeof(int32_t), c->stream));
         UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
         {
             ProfScope ps(c, UZ_K_PHASE);

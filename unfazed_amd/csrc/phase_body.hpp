@@ -397,15 +397,11 @@ UZ_DEV int uz_bsearch_nth(int m, int qp, int L, int Rr) {
 // site-specific parts.  Returns the mate or -1.
 // All fields of the record are requested together, then all fields of its mate (two memory round
 // trips instead of one per test); the tests keep the reference's order.
-UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, double cutoff, int seg, const RecA &A, const RecB &B) {
-    const uint32_t qc = R.qc[seg];
+// the same on values already fetched: the record's headers and QC byte, its mate's first header and QC byte
+UZ_DEV int uz_pair_ok_vals(const PhaseArgs &a, double cutoff, const RecA &A, const RecB &B, uint32_t qc, const RecA &M, uint32_t qm) {
     const int mate = B.mate;
     long long ins = (long long)B.tlen - 2LL * a.readlen;
-    const long long rs = A.start, re = A.end;
-    const int mi = mate >= 0 ? mate : seg; // a safe index: unused without a mate
-    const uint32_t qm = R.qc[mi];
-    const RecA M = R.ra[mi];
-    const long long ms = M.start, me = M.end;
+    const long long rs = A.start, re = A.end, ms = M.start, me = M.end;
     if (ins < 0) ins = -ins;
     if (!(qc & UZ_QC_GOOD) || (double)ins > cutoff) return -1;
     if (mate < 0) return -1;
@@ -413,6 +409,10 @@ UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, double cutoff, int seg
     if (!(qc & UZ_QC_NONE5) || !(qm & UZ_QC_NONE5)) return -1;
     if ((ms <= rs && rs <= me) || (ms <= re && re <= me)) return -1; // mates overlap
     return mate;
+}
+UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, double cutoff, int seg, const RecA &A, const RecB &B) {
+    const int mi = B.mate >= 0 ? B.mate : seg; // a safe index: unused without a mate
+    return uz_pair_ok_vals(a, cutoff, A, B, R.qc[seg], R.ra[mi], R.qc[mi]);
 }
 UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, double cutoff, int seg) { return uz_pair_ok_ab(R, a, cutoff, seg, R.ra[seg], R.rb[seg]); }
 
@@ -716,24 +716,41 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         ar_t(ar, s.t_ov, T + 1); ar_t(ar, s.t_pass, T + 1); ar_t(ar, t_h, T + 1);
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
-        WG_FOR(t, T) {
-            int lo = 0, hi = nh; // last h with h_off[h] <= t
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.h_off[mid] <= t) lo = mid; else hi = mid; }
-            // skip empty ranges that share the same offset
-            const int h = lo;
-            const int seg = s.h_a[h] + (t - s.h_off[h]);
-            t_h[t] = h;
-            // the record's fields are requested together: overlap test, pair filters (pure: evaluated for every
-            // overlapping record, the enumerate cut-off below only masks them), name id for the pair table
-            const RecA A = R.ra[seg];
-            const RecB B = R.rb[seg];
-            const int ov = (long long)A.end > (long long)s.hpos[h];
-            const int mate = uz_pair_ok_ab(R, a, cutoff, seg, A, B);
-            const bool pok = ov && mate >= 0 && (R.qc[seg] & UZ_QC_NM5);
-            s.t_q[t] = B.qname;
-            s.t_mate[t] = mate;
-            s.t_ov[t] = ov | (pok ? 2 : 0);
-            s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
+        // Two work items per lane and round: the loads of both (record headers and QC byte, then the mates' header and QC
+        // byte) are in flight together before either is used -- a wave keeps twice the requests outstanding.
+        for (int t0 = wg_lane_opaque(); t0 < T; t0 += 2 * WG_NT) {
+            int tt[2], hh[2], sg[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                tt[u] = t0 + u * WG_NT;
+                const int t = tt[u] < T ? tt[u] : t0;
+                int lo = 0, hi = nh; // last h with h_off[h] <= t
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.h_off[mid] <= t) lo = mid; else hi = mid; }
+                hh[u] = lo; // (empty ranges share an offset: the last of them is the one that holds t)
+                sg[u] = s.h_a[lo] + (t - s.h_off[lo]);
+            }
+            RecA A[2], M[2];
+            RecB B[2];
+            uint32_t q[2], qm[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) { A[u] = R.ra[sg[u]]; B[u] = R.rb[sg[u]]; q[u] = R.qc[sg[u]]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) { const int mi = B[u].mate >= 0 ? B[u].mate : sg[u]; M[u] = R.ra[mi]; qm[u] = R.qc[mi]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (tt[u] >= T) continue;
+                const int t = tt[u], h = hh[u];
+                t_h[t] = h;
+                // overlap test, pair filters (pure: evaluated for every overlapping record, the enumerate cut-off below only
+                // masks them), name id for the pair table
+                const int ov = (long long)A[u].end > (long long)s.hpos[h];
+                const int mate = uz_pair_ok_vals(a, cutoff, A[u], B[u], q[u], M[u], qm[u]);
+                const bool pok = ov && mate >= 0 && (q[u] & UZ_QC_NM5);
+                s.t_q[t] = B[u].qname;
+                s.t_mate[t] = mate;
+                s.t_ov[t] = ov | (pok ? 2 : 0);
+                s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
+            }
         }
         UZ_TICK(3); // B.overlap
         (void)wg_exscan(s.t_pass, T, sh);
@@ -922,37 +939,62 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         // at the entry's het site (get_allele_at, :91-105) and, for registrations, the base the
         // pair's primary segment shows there (:114-124).  Both start from the same index into the
         // primary segment, computed once.
-        WG_FOR(x, M) {
-            uint8_t fbv = 0, cb = 0;
-            const int h = s.srt_h[x];
-            const int seq = (int)(s.keys[x] & 0xFFFFFF);
-            if (h >= 0) {
+        // Two entries per lane and round, staged: (i) both entries' primary-segment headers and quality-plane offsets,
+        // (ii) the mates' headers where the primary segment does not cover the site, (iii) the base / quality bit --
+        // each stage's loads of both entries are in flight together.
+        for (int x0 = wg_lane_opaque(); x0 < M; x0 += 2 * WG_NT) {
+            int xx[2], hh[2], sq[2], f1v[2], qi[2];
+            uint32_t row[2], q0[2];
+            bool live[2], own[2];
+            SegHdr h0[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                xx[u] = x0 + u * WG_NT;
+                const int x = xx[u] < M ? xx[u] : x0;
+                hh[u] = s.srt_h[x];
+                sq[u] = (int)(s.keys[x] & 0xFFFFFF);
                 const int p = s.srt_pid[x];
-                const int f0 = s.fet0[p], f1 = s.fet1[p];
-                if (f0 >= 0) {
-                    const long long hp = s.hpos[h];
-                    const SegHdr h0 = uz_hdr(R, f0);
-                    const uint32_t q0 = R.qoff[f0]; // requested with the header
-                    const int i = uz_qidx_h(R, h0, hp);
-                    if (i >= 0) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
-                        if (i >= 4 && i <= a.readlen - 4 && h0.l_seq > i + 1) {
-                            const uint8_t al = uz_base(R, h0.sq_off, i);
-                            const bool low = uz_qual_low(R, q0, i);
-                            if (al == s.href[h] || al == s.halt[h]) fbv = al; // :98-105
-                            if (seq < E && !low) cb = al;                     // :114-124
-                        }
-                    } else if (f1 >= 0) {
-                        const SegHdr h1 = uz_hdr(R, f1);
-                        const int j = uz_qidx_h(R, h1, hp);
-                        if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) {
-                            const uint8_t al = uz_base(R, h1.sq_off, j);
-                            if (al == s.href[h] || al == s.halt[h]) fbv = al;
-                        }
-                    }
+                const int f0 = s.fet0[p];
+                f1v[u] = s.fet1[p];
+                live[u] = xx[u] < M && hh[u] >= 0 && f0 >= 0;
+                const int f = live[u] ? f0 : 0;
+                h0[u] = uz_hdr(R, f);
+                q0[u] = R.qoff[f];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
+                qi[u] = -1; row[u] = 0; own[u] = false;
+                if (!live[u]) continue;
+                const long long hp = s.hpos[hh[u]];
+                const int i = uz_qidx_h(R, h0[u], hp);
+                if (i >= 0) {
+                    own[u] = true;
+                    if (i >= 4 && i <= a.readlen - 4 && h0[u].l_seq > i + 1) { qi[u] = i; row[u] = h0[u].sq_off; }
+                } else if (f1v[u] >= 0) {
+                    const SegHdr h1 = uz_hdr(R, f1v[u]);
+                    const int j = uz_qidx_h(R, h1, hp);
+                    if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) { qi[u] = j; row[u] = h1.sq_off; }
                 }
             }
-            s.srt_fb[x] = fbv;
-            if (seq < E) s.cbase[seq] = cb;
+            uint8_t al[2];
+            bool low[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                al[u] = qi[u] >= 0 ? uz_base(R, row[u], qi[u]) : (uint8_t)0;
+                low[u] = (qi[u] >= 0 && own[u]) ? uz_qual_low(R, q0[u], qi[u]) : true;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (xx[u] >= M) continue;
+                uint8_t fbv = 0, cb = 0;
+                if (qi[u] >= 0) {
+                    const int h = hh[u];
+                    if (al[u] == s.href[h] || al[u] == s.halt[h]) fbv = al[u]; // :98-105
+                    if (own[u] && sq[u] < E && !low[u]) cb = al[u];           // :114-124
+                }
+                s.srt_fb[xx[u]] = fbv;
+                if (sq[u] < E) s.cbase[sq[u]] = cb;
+            }
         }
         WG_SYNC();
         UZ_TICK(14); // D.finder
@@ -1090,37 +1132,54 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     // haplotype (:254-263); --no-extended -> the init list elements themselves.
     ar_reset(ar);
     const int n_items = a.no_extended ? nI : 4 * P;
-    WG_FOR(it, n_items) {
-        int seg, hb, p;
-        if (a.no_extended) { seg = s.i_seg[it]; hb = s.i_hb[it]; p = s.i_pair[it]; }
-        else {
-            p = it >> 2; hb = (it >> 1) & 1;
-            if (!(s.grp[p] & (1u << hb)) || s.fet0[p] < 0) continue;
-            seg = (it & 1) ? s.fet1[p] : s.fet0[p];
+    // two items per lane and round: both segments' headers are requested before either is used
+    for (int it0 = wg_lane_opaque(); it0 < n_items; it0 += 2 * WG_NT) {
+        int sg[2], hbv[2], pv[2];
+        bool act[2];
+        SegHdr hdv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int it = it0 + u * WG_NT;
+            act[u] = it < n_items;
+            sg[u] = 0; hbv[u] = 0; pv[u] = 0;
+            if (act[u]) {
+                if (a.no_extended) { sg[u] = s.i_seg[it]; hbv[u] = s.i_hb[it]; pv[u] = s.i_pair[it]; }
+                else {
+                    pv[u] = it >> 2; hbv[u] = (it >> 1) & 1;
+                    if (!(s.grp[pv[u]] & (1u << hbv[u])) || s.fet0[pv[u]] < 0) act[u] = false;
+                    else sg[u] = (it & 1) ? s.fet1[pv[u]] : s.fet0[pv[u]];
+                }
+            }
+            hdv[u] = uz_hdr(R, act[u] ? sg[u] : 0);
         }
-        int qp, L, Rr;
-        const SegHdr hd = uz_hdr(R, seg);
-        const int nm = uz_bsearch(hd.start, hd.end, s.cpos, nc, qp, L, Rr);
-        if (nm <= 0) continue;
-        bool dad_alt = false, mom_alt = false;
-        for (int ci = L; ci <= Rr; ci++) {
-            if (s.cflag[ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
-        }
-        if (dad_alt && mom_alt) continue; // site_searcher.py:74-75
-        wg_atomic_add(&s.misc[1], 1);
-        for (int ci = L; ci <= Rr; ci++) {
-            const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
-            if (rp < 0 || rp >= hd.l_seq) continue;
-            const uint8_t b = uz_base(R, hd.sq_off, rp);
-            bool from_ref;
-            if (b == s.cref[ci]) from_ref = true;       // :41-42
-            else if (b == s.calt[ci]) from_ref = false; // :43-44
-            else continue;
-            const bool alt_is_dad = (s.cflag[ci] & UZ_CF_ALT_DAD) != 0;
-            const bool to_alt_parent = (from_ref && hb == 0) || (!from_ref && hb == 1); // :52-69
-            const bool to_dad = to_alt_parent ? alt_is_dad : !alt_is_dad;
-            wg_atomic_or(&s.pvote[p], to_dad ? 1u : 2u);
-            wg_atomic_or(&s.cvote[ci], to_dad ? 1u : 2u);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (!act[u]) continue;
+            const SegHdr &hd = hdv[u];
+            const int hb = hbv[u], p = pv[u];
+            int qp, L, Rr;
+            const int nm = uz_bsearch(hd.start, hd.end, s.cpos, nc, qp, L, Rr);
+            if (nm <= 0) continue;
+            bool dad_alt = false, mom_alt = false;
+            for (int ci = L; ci <= Rr; ci++) {
+                if (s.cflag[ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
+            }
+            if (dad_alt && mom_alt) continue; // site_searcher.py:74-75
+            wg_atomic_add(&s.misc[1], 1);
+            for (int ci = L; ci <= Rr; ci++) {
+                const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
+                if (rp < 0 || rp >= hd.l_seq) continue;
+                const uint8_t b = uz_base(R, hd.sq_off, rp);
+                bool from_ref;
+                if (b == s.cref[ci]) from_ref = true;       // :41-42
+                else if (b == s.calt[ci]) from_ref = false; // :43-44
+                else continue;
+                const bool alt_is_dad = (s.cflag[ci] & UZ_CF_ALT_DAD) != 0;
+                const bool to_alt_parent = (from_ref && hb == 0) || (!from_ref && hb == 1); // :52-69
+                const bool to_dad = to_alt_parent ? alt_is_dad : !alt_is_dad;
+                wg_atomic_or(&s.pvote[p], to_dad ? 1u : 2u);
+                wg_atomic_or(&s.cvote[ci], to_dad ? 1u : 2u);
+            }
         }
     }
     WG_SYNC();

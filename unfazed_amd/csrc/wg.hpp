@@ -19,6 +19,7 @@
 #define UZ_HD static inline
 #define WG_NT 1
 #define WG_TID 0
+static inline int wg_lane_opaque() { return 0; }
 #define WG_FOR(i, n) for (int i = 0; i < (int)(n); ++i)
 #define WG_SYNC() ((void)0)
 #define WG_T0 if (true)
