@@ -47,6 +47,16 @@ rec = line["roofline_k3a"]["records_examined"]
 d = {"kernel": "k_seg_qc", "records_examined": rec, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
      "algorithmic_bytes_per_launch": line["roofline_k3a"]["algorithmic_bytes_per_launch"], "avg_ns_rocprof": avg_ns("k_seg_qc")[0],
      "how": how, "source": "profiles/%s_pmc_summary.json" % rnd}
+cal_path = os.path.join(src, "pmc_cal.json")
+if os.path.exists(cal_path) and not k3a_factor:
+    # calibration pass (UZ_TEST_QC_MARK_ALL): every record examined, bytes known exactly -> what one raw FETCH_SIZE byte is worth
+    # for this kernel's access widths (4-byte words; the guide's x2 holds for 16-byte streams only)
+    cal = json.load(open(cal_path))["k_seg_qc"]["counters_per_launch"]
+    n_all = line["config"]["alignment_records"]
+    known_read = n_all * (4 + 4 + 4 + 20 + 1)  # length word, flag word, plane offset, plane row, the reach-map byte
+    k3a_factor = known_read / (cal["FETCH_SIZE"]["mean"] * 1024)
+    d["calibration"] = {"records": n_all, "known_read_bytes": known_read, "FETCH_SIZE_KB_raw": cal["FETCH_SIZE"]["mean"],
+                        "WRITE_SIZE_KB_raw": cal["WRITE_SIZE"]["mean"], "known_write_bytes": n_all}
 if k3a_factor:
     d["fetch_factor_calibrated"] = k3a_factor
     d["hbm_bytes_per_launch"] = int(k3a_factor * f + w)

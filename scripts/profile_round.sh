@@ -13,7 +13,11 @@ rocprofv3 --output-format csv --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum 
 rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/tcc -o run -- python3 $ARGS > $OUT/tcc.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o run -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o run -- python3 $ARGS > $OUT/write.log 2>&1
+# K3a calibration: every record marked -> a pure stream over known bytes (4+4+4+20 read, 1 written per record)
+UZ_TEST_QC_MARK_ALL=1 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/cal_fetch -o run -- python3 $ARGS > $OUT/cal_fetch.log 2>&1
+UZ_TEST_QC_MARK_ALL=1 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/cal_write -o run -- python3 $ARGS > $OUT/cal_write.log 2>&1
 cd $ROOT
+python3 scripts/pmc_summary.py $OUT/pmc_cal.json $OUT/cal_fetch $OUT/cal_write > /dev/null 2>&1
 python3 scripts/pmc_summary.py $OUT/pmc_summary.json $OUT/sq $OUT/tcp $OUT/tcc $OUT/fetch $OUT/write > $OUT/pmc_summary.txt 2>&1
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 grep "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json

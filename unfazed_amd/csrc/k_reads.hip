@@ -500,7 +500,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     hipEvent_t qc_a = nullptr, qc_b = nullptr;
     if (r.n > 0) {
         uz_prof_begin(c, UZ_K_SEG_QC, &qc_a, &qc_b);
-        UZ_HIP(hipMemsetAsync(r.need, 0, (size_t)r.n + 64, c->stream));
+        // UZ_TEST_QC_MARK_ALL (measurement hook): every record marked, so K3a becomes a pure stream over known bytes -- the
+        // calibration run for its FETCH_SIZE counter (profiles/k3a_traffic.json)
+        static const bool mark_all = getenv("UZ_TEST_QC_MARK_ALL") != nullptr;
+        UZ_HIP(hipMemsetAsync(r.need, mark_all ? 1 : 0, (size_t)r.n + 64, c->stream));
         const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
         hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 16 + 255) / 256)), dim3(256), 0, c->stream,
                            (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const RecA *)r.rec_a,
