@@ -54,7 +54,7 @@ def parse():
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=8, help="DNM chunks of the staged pass (uploads overlap the kernels)")
-    ap.add_argument("--cpu-dnms", type=int, default=12000, help="DNMs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-dnms", type=int, default=30000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-staged", action="store_true", help="resident pass only (profiling runs)")
     return ap.parse_args()
@@ -195,6 +195,7 @@ def main():
             elapsed = float(t.item())
         prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING, K_CNV)}
         units = eng.prof_units(K_SEG_QC_PASS)
+        timed.hbm_build_dnms = int(eng.prof_units(K_PHASE))
         eng.prof_enable(False)
         return res, elapsed, prof, units
 
@@ -403,7 +404,8 @@ def main():
             "latency_model": latency_model,
             "cpu_baseline": cpu,
             "kernels_ms_per_step": kern_ms(prof_r),
-            "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist()},
+            "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist(),
+                      "dnms_redone_by_hbm_build_of_k_phase": getattr(timed, "hbm_build_dnms", None)},
             "generate_s": round(t_gen, 1),
         }
         if staged:
@@ -476,7 +478,7 @@ def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_v
     dt2, _ = run(2)
     # the port does not scale to every hardware thread (allocator / page-fault contention between
     # threads of one process): try a ladder of thread counts and report the best
-    ladder = sorted({t for t in (8, 16, 32, 64, 128, ncpu) if 2 < t <= ncpu})
+    ladder = sorted({t for t in (8, 32, 128, ncpu) if 2 < t <= ncpu})
     best = None
     sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
     for t in ladder:

@@ -8,7 +8,7 @@ import glob
 import json
 import sys
 
-KERNELS = {"k_phase": "k_phase(", "k_seg_qc": "k_seg_qc(", "k_site_scan": "k_site_scan<", "k_mark_ranges": "k_mark_ranges(",
+KERNELS = {"k_phase": "k_phase<true>(", "k_phase_hbm": "k_phase<false>(", "k_phase_r1": "k_phase(", "k_seg_qc": "k_seg_qc(", "k_site_scan": "k_site_scan<", "k_mark_ranges": "k_mark_ranges(",
            "k_phase_bounds": "k_phase_bounds(", "k_window": "k_window<", "k_pack_rec": "k_pack_rec("}
 
 

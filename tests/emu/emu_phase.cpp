@@ -10,7 +10,7 @@
 
 #include "phase_body.hpp"
 #ifdef UZ_EMU_STATS
-extern "C" { long long uz_emu_stats[16]; }
+extern "C" { long long uz_emu_stats[16]; long long *uz_emu_log = nullptr; }
 #endif
 
 extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *Rv, const uz_dnms_view *D,
@@ -95,12 +95,15 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     uz_scratch_carve(scratch.data(), caps, s);
     a.scratch = scratch.data(); a.scratch_per_wg = bytes; a.caps = caps;
     WgShared sh;
-    // exercise all placements: no LDS arena, a tiny one (mixed LDS / HBM arrays), a roomy one
+    // exercise both builds of the body: the HBM build alone, the arena build with a tiny arena (gives most DNMs up at one
+    // of its checks -> they are redone by the HBM build, as the device does), the arena build with a roomy arena
     static const int arena_sizes[3] = {0, 3072, 65536};
     std::vector<uint8_t> arena(65536 + 64);
     for (int d = 0; d < D->n; d++) {
         a.lds_arena_bytes = arena_sizes[d % 3];
-        uz_phase_dnm(a, s, &sh, a.lds_arena_bytes ? arena.data() : nullptr, d);
+        int given_up = 1;
+        if (a.lds_arena_bytes) given_up = uz_phase_dnm<true>(a, s, &sh, arena.data(), d);
+        if (given_up) uz_phase_dnm<false>(a, s, &sh, nullptr, d);
     }
     *pool_used = (long long)cursor;
     if (base_err_out) *base_err_out = base_err;

@@ -145,3 +145,42 @@ def test_capacity_overflow_is_reported_not_dropped(engine, monkeypatch):
     for k, r in part.items():  # the others are untouched
         assert r == full[k]
     assert set(full) - set(part) <= set(host.capacity_skipped)
+
+
+@pytest.mark.parametrize("arena", [0, 2048, 6000, 12000])
+def test_both_builds_of_the_read_stage_agree(engine, monkeypatch, arena):
+    """k_phase runs as two kernels: one keeps a DNM's working arrays in its workgroup's LDS arena and gives up the DNMs that do
+    not fit, the other redoes those in HBM scratch.  With the arena capped (test hook) every mix of the two must give the
+    records of the uncapped run: none, some, most DNMs fitting."""
+    import contextlib
+    import copy
+    import io
+    from helpers import RUN_DEFAULTS, dnm_sites, norm_records, params_from, tables
+    from synth.small import SmallConfig, make_small
+    from unfazed_amd.engine import K_PHASE
+    from unfazed_amd.hostpath import PhasingHost
+    ds = make_small(SmallConfig(seed=5151, n_dnms=30, cluster_prob=0.5))
+    sites, reads = tables(ds)
+    a = dict(RUN_DEFAULTS, quiet_mode=True)
+
+    def run():
+        host = PhasingHost(engine, sites, reads)
+        dn = copy.deepcopy(ds.dnms)
+        err = io.StringIO()
+        engine.prof_enable(True)
+        with contextlib.redirect_stderr(err):
+            recs = host.run_read_phasing(dn, ds.pedigrees, 1, "38", False, 1000, True, params_from(a), 5000, 1000000, 3, 151)
+        redone = engine.prof_units(K_PHASE)
+        engine.prof_enable(False)
+        return recs, dn, err.getvalue(), redone
+
+    full, dn0, err0, redone0 = run()
+    assert len(full) >= 4
+    monkeypatch.setenv("UZ_TEST_PHASE_ARENA", str(arena))
+    part, dn1, err1, redone1 = run()
+    monkeypatch.delenv("UZ_TEST_PHASE_ARENA")
+    assert norm_records(part) == norm_records(full) and list(part) == list(full)
+    assert dnm_sites(dn0) == dnm_sites(dn1) and err0 == err1
+    assert redone1 >= redone0
+    if arena <= 2048:
+        assert redone1 >= 1  # (count of the last batch) nothing with candidates fits: redone in HBM scratch

@@ -19,6 +19,8 @@ CASES = [
     dict(coverage_per_hap=45.0, n_dnms=3),                                          # pair tables beyond 1024 entries
     dict(coverage_per_hap=30.0, site_rate=1 / 80.0, cluster_prob=1.0, n_dnms=3),    # dense het sites
     dict(coverage_per_hap=22.0, base_err=0.03, lowq_prob=0.05, n_dnms=4),            # noisy
+    dict(read_goal=7),       # the enumerate cut-off of the fetch loop (:178-179) bites at every het site
+    dict(read_goal=0, coverage_per_hap=8.0),
 ]
 
 
@@ -26,9 +28,12 @@ CASES = [
 def test_kernel_body_matches_oracle(ci):
     kw = dict(CASES[ci])
     no_ext = kw.pop("no_extended", False)
+    read_goal = kw.pop("read_goal", None)
     ds = make_small(SmallConfig(seed=700 + ci, **dict(dict(n_dnms=8), **kw)))
     sites = SitesTable.from_records(ds.sites, ds.samples)
     P = abi.make_params(no_extended=no_ext)
+    if read_goal is not None:
+        P.read_goal = read_goal
     sv = abi.sites_view(sites)
     n_ok = 0
     for kid in ds.reads:

@@ -22,6 +22,7 @@ SHAPES = [
     dict(coverage_per_hap=4.0, n_dnms=10),                                   # thin coverage: many empty outcomes
     dict(coverage_per_hap=35.0, indel_dnm_frac=0.5, indel_prob=0.05, softclip_prob=0.08, n_dnms=5),
     dict(coverage_per_hap=28.0, no_extended=True, n_dnms=6),
+    dict(insert_size_max_sample=6, n_dnms=6),   # doubles as the enumerate cut-off of the het-site fetch loop (:178-179): it bites everywhere
 ]
 
 

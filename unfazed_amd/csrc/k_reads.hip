@@ -145,13 +145,30 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
 #define UZ_PHASE_PARTS 8 // XCDs of an MI355X
 #endif
 #ifndef UZ_PHASE_MIN_WAVES
-#define UZ_PHASE_MIN_WAVES 5 // <= 96 VGPRs (the kernel needs 94, no spills): five waves per SIMD = five 256-lane workgroups per CU
+#define UZ_PHASE_MIN_WAVES 7 // LDS build: <= 72 VGPRs (16 dwords of spill), up to seven 256-lane workgroups per CU; measured 5 / 6 / 7: 4.70 / 4.33 / 4.15 ms
 #endif
-__global__ __launch_bounds__(WG_NT, UZ_PHASE_MIN_WAVES) void k_phase(PhaseArgs a) {
-    __shared__ WgShared sh;
+// Two builds of the per-DNM body (phase_body.hpp): k_phase<true> keeps the working arrays of a DNM in its workgroup's LDS
+// arena and hands the DNMs that do not fit to k_phase<false>, launched right behind it, which keeps them in HBM scratch.
+template <bool LDS>
+__global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(PhaseArgs a) {
+    __shared__ WgSharedT<LDS ? 1 : WG_SORT_LDS_CAP> sh;
     extern __shared__ __attribute__((aligned(16))) uint8_t uz_lds_arena[];
     Scr s;
     uz_scratch_carve(a.scratch + (size_t)blockIdx.x * a.scratch_per_wg, a.caps, s);
+    if (!LDS) { // the list the first kernel left behind, one cursor
+        for (;;) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int k = atomicAdd(a.work_cursor + 16 * UZ_PHASE_PARTS, 1);
+                sh.bcast[0] = k < *a.retry_count ? a.retry_list[k] : -1;
+            }
+            __syncthreads();
+            const int d = sh.bcast[0];
+            if (d < 0) break;
+            (void)uz_phase_dnm<false>(a, s, &sh, nullptr, d);
+        }
+        return;
+    }
     // Work distribution: the batch is cut into UZ_PHASE_PARTS contiguous DNM ranges, one cursor each, and a workgroup
     // starts on the range of (blockIdx % PARTS) -- with the usual round-robin placement of workgroups over the 8 XCDs that is
     // "its XCD's range".  DNMs are sorted by position and neighbours share window sites and alignment records, so the lines
@@ -173,13 +190,15 @@ __global__ __launch_bounds__(WG_NT, UZ_PHASE_MIN_WAVES) void k_phase(PhaseArgs a
             part = (part + 1) % UZ_PHASE_PARTS;
             continue;
         }
-        uz_phase_dnm(a, s, &sh, a.lds_arena_bytes > 0 ? uz_lds_arena : nullptr, d);
+        if (uz_phase_dnm<LDS>(a, s, &sh, uz_lds_arena, d)) { // (block-uniform)
+            if (threadIdx.x == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = d;
+        }
     }
 }
 
 struct PhaseState {
     DevBuf<uint8_t> scratch;
-    DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len, pre_win, pre_ha, pre_hl;
+    DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len, pre_win, pre_ha, pre_hl, retry;
     DevBuf<long long> list_start;
     DevBuf<unsigned long long> pool_cursor;
     DevBuf<unsigned int> need_count;
@@ -550,15 +569,47 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         UZ_HIP(hipGetDeviceProperties(&prop, c->device));
         st->n_cus = prop.multiProcessorCount;
     }
-    static const int arena_bytes = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return (e ? atoi(e) : 28) * 1024; }();
-    static const int wgs_per_cu = [] {
-        const char *e = getenv("UZ_PHASE_WGS_PER_CU");
-        if (e) return atoi(e);
-        const int by_lds = (160 * 1024) / (arena_bytes + (int)sizeof(WgShared) + 512);
-        const int by_threads = 2048 / WG_NT;
-        return by_lds < by_threads ? (by_lds > 0 ? by_lds : 1) : by_threads;
-    }();
-    a.lds_arena_bytes = arena_bytes;
+    // LDS arena of k_phase<true>, sized for THIS batch: a DNM needs about 20 bytes per record its het-site fetches return
+    // plus 7 KiB (fit over the bench workload).  The 99th percentile of that estimate over the batch
+    // decides how many workgroups share a CU's 160 KiB (at most UZ_PHASE_MIN_WAVES: registers), and the arena is then the
+    // largest that this many workgroups leave room for.  A shallow batch runs 7 workgroups per CU on 21 KiB arenas, a deep
+    // one fewer on larger arenas -- instead of handing most of its DNMs to the slower HBM build.
+    static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
+    int arena_used = arena_env;
+    if (arena_used < 0) {
+        std::vector<int32_t> hist(64, 0); // estimate in KiB
+        int32_t active = 0;
+        for (int32_t d = 0; d < n; d++) {
+            const int32_t *b = &bh[(size_t)5 * d];
+            if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
+            const long long est = (20LL * b[1] + 7168 + 1023) >> 10;
+            hist[(size_t)std::min<long long>(est, 63)]++;
+            active++;
+        }
+        int kb = 12, seen = 0;
+        for (int k = 0; k < 64; k++) {
+            seen += hist[k];
+            if (hist[k]) kb = std::max(kb, k);
+            if ((long long)seen * 100 >= (long long)active * 99) break;
+        }
+        arena_used = std::min(kb, 62) * 1024;
+    }
+    if (const char *e = getenv("UZ_TEST_PHASE_ARENA")) { // test hook: an arena (bytes) too small for most DNMs -> they take the HBM build of k_phase
+        const int t = atoi(e);
+        if (t >= 0 && t < arena_used) arena_used = t;
+    }
+    int wgs_per_cu;
+    {
+        static const int wgs_env = [] { const char *e = getenv("UZ_PHASE_WGS_PER_CU"); return e ? atoi(e) : 0; }();
+        const int by_lds = (160 * 1024) / (arena_used + (int)sizeof(WgSharedT<1>) + 512);
+        const int by_regs = UZ_PHASE_MIN_WAVES; // waves per SIMD = workgroups per CU (four waves, four SIMDs)
+        wgs_per_cu = wgs_env > 0 ? wgs_env : std::max(1, std::min(by_lds, by_regs));
+        if (arena_env < 0 && wgs_env <= 0) { // all the room this occupancy leaves
+            const int room = ((160 * 1024) / wgs_per_cu - (int)sizeof(WgSharedT<1>) - 512) & ~255;
+            if (room > arena_used && !getenv("UZ_TEST_PHASE_ARENA")) arena_used = std::min(room, 62 * 1024);
+        }
+    }
+    a.lds_arena_bytes = arena_used;
     int grid = st->n_cus * wgs_per_cu;
     if (grid > n) grid = n;
     const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
@@ -567,7 +618,9 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.scratch = st->scratch.p; a.scratch_per_wg = per_wg; a.caps = caps;
 
     st->status.ensure(n); st->counts.ensure((size_t)4 * n); st->origin.ensure(n); st->evidence.ensure(n);
-    st->cursor.ensure(16 * UZ_PHASE_PARTS);
+    st->cursor.ensure(16 * (UZ_PHASE_PARTS + 1));
+    st->retry.ensure((size_t)n + 16);
+    a.retry_count = st->retry.p; a.retry_list = st->retry.p + 16;
     a.status = st->status.p; a.counts = st->counts.p; a.origin = st->origin.p; a.evidence = st->evidence.p;
     a.work_cursor = st->cursor.p;
     a.want_lists = uz_want_lists;
@@ -610,17 +663,23 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     int32_t *const hres = st->bounds_h;
     unsigned long long *const hused = (unsigned long long *)(hres + (size_t)7 * n + ((7 * (size_t)n) & 1)); // 8-byte aligned slot
     for (int attempt = 0; attempt < 4; attempt++) {
-        UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * UZ_PHASE_PARTS * sizeof(int32_t), c->stream));
+        UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 1) * sizeof(int32_t), c->stream));
+        UZ_HIP(hipMemsetAsync(st->retry.p, 0, 16 * sizeof(int32_t), c->stream));
         UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
         {
             ProfScope ps(c, UZ_K_PHASE);
             UZ_TRACE("k_phase");
-            hipLaunchKernelGGL(k_phase, dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
+            hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
+            UZ_HIP(hipGetLastError());
+            hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)grid), dim3(WG_NT), 0, c->stream, a);
             UZ_HIP(hipGetLastError());
         }
         UZ_TRACE("after k_phase");
         *hused = 0;
         uz_kcopy(c, hused, st->pool_cursor.p, sizeof(unsigned long long));
+        int32_t *const hretry = (int32_t *)(hused + 1);
+        *hretry = 0;
+        uz_kcopy(c, hretry, st->retry.p, sizeof(int32_t));
         if (status) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
         if (counts) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
         if (origin) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
@@ -631,6 +690,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             throw UzError{UZ_E_STATE, "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
         }
         const unsigned long long used = *hused;
+        c->prof[UZ_K_PHASE].last_units = (int64_t)*(const int32_t *)(hused + 1); // DNMs that took the HBM build
         if (!a.want_lists || used <= a.pool_cap) break;
         // list pool too small: grow to the exact demand and run again
         pool_cap = (size_t)used + 1024;

@@ -53,6 +53,7 @@
 
 #ifdef UZ_EMU_STATS
 extern "C" long long uz_emu_stats[16];
+extern "C" long long *uz_emu_log; // optional: 12 values per DNM (sizes of its working set)
 #endif
 // Record headers: the form the fixed-width fields of the staged columns (uz_reads_packed_view) take in HBM,
 // built on the device when a table is uploaded / adopted.  The per-DNM kernel GATHERS records (mates, last
@@ -98,7 +99,19 @@ struct Caps { // per-workgroup scratch capacities (elements)
     int32_t A, T, H, C, I, M;
 };
 
-struct Scr {
+// Element types of the working arrays that differ between the two builds of the per-DNM body (see Arena below): the
+// HBM build must take any DNM the capacities admit (32-bit indices); a DNM that fits an LDS arena has fewer than
+// 32 k het sites and 64 k pair-table entries, and 16-bit indices nearly halve its footprint (more workgroups per CU).
+template <bool LDS> struct ScrTy { typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t flg; };
+template <> struct ScrTy<true> { typedef int16_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t flg; };
+
+template <bool LDS>
+struct ScrT {
+    typedef typename ScrTy<LDS>::hidx hidx; // het index of the DNM (-1 = none)
+    typedef typename ScrTy<LDS>::pidx pidx; // pair id
+    typedef typename ScrTy<LDS>::xidx xidx; // index into the sorted pair-table entries
+    typedef typename ScrTy<LDS>::flg flg;
+    // ---- arrays the LDS build places in the arena (uz_scr_make lists them once more)
     uint8_t *a_cls;
     int32_t *a_flag0, *a_flag1; // (no pointer arrays in this struct: a dynamically indexed member would pin it in private memory)
     int32_t *LR, *LA;
@@ -109,30 +122,43 @@ struct Scr {
     int32_t *cpos;
     uint32_t *cvote;
     uint8_t *cflag, *cref, *calt; // per candidate: UZ_CF_* flags, REF and ALT base
-    int32_t *t_ov, *t_pass;
-    int32_t *reg_h, *reg_seg, *reg_pair;
+    flg *t_ov;
+    int32_t *t_pass, *t_scan; // the two scans of phase B
+    hidx *t_h;                // het index of every fetched record before the ordered compaction of phase B
+    hidx *reg_h;
+    pidx *reg_pair;
+    uint8_t *cbase;
+    int32_t *i_seg;
+    pidx *i_pair;
+    uint8_t *i_hb;
+    unsigned long long *keys;
+    int32_t *seq_h;
+    hidx *srt_h;
+    int32_t *srt_pid;
+    flg *srt_flag;
+    xidx *srt_seq; // sequence number of every sorted entry (the low 24 bits of its key)
+    uint8_t *srt_fb;
+    xidx *rs_off, *rs_len;
+    uint32_t *grp, *pvote;
+    unsigned long long *pkey; // per pair: smallest claim rank of the current chaining level
+    unsigned long long *win;  // winners of a chaining level
+    pidx *fr_pair0, *fr_pair1;
+    hidx *fr_pos0, *fr_pos1; // canonical het index of the site a frontier element was claimed at (-1: an init element)
+    uint8_t *fr_hap0, *fr_hap1;
+    int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
+    // ---- arrays that stay in the HBM scratch in both builds: written once and read once or twice
+    int32_t *fet0, *fet1; // the two records of every pair ("last writer wins", quirk Q11): read once per entry in D, once per item in F
+    int32_t *reg_seg;
     uint32_t *reg_q, *t_q; // query-name id of every registration (and of every fetched record, before compaction)
     int32_t *reg_mate, *t_mate;
     uint32_t *i_q;         // per init element: name id, mate, span -- fetched once, when the list is built
     int32_t *i_mate, *i_st, *i_en;
-    uint8_t *cbase;
-    int32_t *i_seg, *i_qp, *i_L, *i_R, *i_soff, *i_pair;
-    uint8_t *i_hb;
-    unsigned long long *keys;
-    int32_t *seq_h;
-    int32_t *srt_h, *srt_pid, *srt_flag;
-    uint8_t *srt_fb;
-    int32_t *rs_off, *rs_len, *fet0, *fet1;
-    uint32_t *grp, *pvote, *pq;
-    unsigned long long *key;  // second buffer of the counting sort
-    unsigned long long *pkey; // per pair: smallest claim rank of the current chaining level
-    unsigned long long *win;  // winners of a chaining level
-    uint8_t *assigned;
-    int32_t *fr_pair0, *fr_pair1, *fr_pos0, *fr_pos1;
-    uint8_t *fr_hap0, *fr_hap1;
-    int32_t *q_cnt, *q_fill; // counting sort of the pair-table keys over the query-name id range
-    int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
+    int32_t *i_qp, *i_L, *i_R, *i_soff;
+    uint32_t *pq;             // name id of every pair (the optional lists)
+    unsigned long long *key;  // second buffer of the counting sort (HBM build)
+    int32_t *q_cnt, *q_fill;  // counting sort of the pair-table keys over the query-name id range (HBM build)
 };
+typedef ScrT<false> Scr; // the layout of the HBM scratch region
 
 // carve the scratch region; with base == nullptr it only measures (returns bytes)
 template <typename T>
@@ -153,17 +179,17 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     uz_carve(base, o, s.href, H); uz_carve(base, o, s.halt, H); uz_carve(base, o, s.site_best, H);
     uz_carve(base, o, s.cpos, C); uz_carve(base, o, s.cvote, C);
     uz_carve(base, o, s.cflag, C); uz_carve(base, o, s.cref, C); uz_carve(base, o, s.calt, C);
-    uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T);
+    uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T); uz_carve(base, o, s.t_scan, T); uz_carve(base, o, s.t_h, T);
     uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
     uz_carve(base, o, s.reg_q, T); uz_carve(base, o, s.t_q, T); uz_carve(base, o, s.reg_mate, T); uz_carve(base, o, s.t_mate, T);
     uz_carve(base, o, s.i_q, I); uz_carve(base, o, s.i_mate, I); uz_carve(base, o, s.i_st, I); uz_carve(base, o, s.i_en, I);
     uz_carve(base, o, s.i_seg, I); uz_carve(base, o, s.i_qp, I); uz_carve(base, o, s.i_L, I); uz_carve(base, o, s.i_R, I);
     uz_carve(base, o, s.i_soff, I); uz_carve(base, o, s.i_pair, I); uz_carve(base, o, s.i_hb, I);
     uz_carve(base, o, s.keys, M); uz_carve(base, o, s.seq_h, M);
-    uz_carve(base, o, s.srt_h, M); uz_carve(base, o, s.srt_pid, M); uz_carve(base, o, s.srt_flag, M); uz_carve(base, o, s.srt_fb, M);
+    uz_carve(base, o, s.srt_h, M); uz_carve(base, o, s.srt_pid, M); uz_carve(base, o, s.srt_flag, M); uz_carve(base, o, s.srt_fb, M); uz_carve(base, o, s.srt_seq, M);
     uz_carve(base, o, s.rs_off, M); uz_carve(base, o, s.rs_len, M); uz_carve(base, o, s.fet0, M); uz_carve(base, o, s.fet1, M);
     uz_carve(base, o, s.grp, M); uz_carve(base, o, s.pvote, M); uz_carve(base, o, s.pq, M);
-    uz_carve(base, o, s.key, M); uz_carve(base, o, s.assigned, M);
+    uz_carve(base, o, s.key, M);
     uz_carve(base, o, s.pkey, M); uz_carve(base, o, s.win, M);
     uz_carve(base, o, s.fr_pair0, FR); uz_carve(base, o, s.fr_pos0, FR); uz_carve(base, o, s.fr_hap0, FR);
     uz_carve(base, o, s.fr_pair1, FR); uz_carve(base, o, s.fr_pos1, FR); uz_carve(base, o, s.fr_hap1, FR);
@@ -172,27 +198,46 @@ UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
     return (o + 255) & ~(size_t)255;
 }
 
-// Per-DNM placement of the working arrays: LDS first.  The scratch region in HBM has room for the
-// largest DNM of the batch, but a typical DNM needs a few tens of KB, and every phase boundary waits
-// for its outstanding stores: in LDS that wait is ~100 cycles instead of a round trip to memory.
-// Arrays are placed in the workgroup's LDS arena in the order they are requested, with their ACTUAL
-// sizes; whatever does not fit keeps its pointer into the HBM scratch (the code is address-space
-// agnostic).  "Temporary" arrays live above the persistent ones and are recycled at phase boundaries.
+// Per-DNM placement of the working arrays.  The scratch region in HBM has room for the largest DNM of the
+// batch, but a typical DNM needs a few tens of KB, and every phase boundary waits for its outstanding stores:
+// in LDS that wait is ~100 cycles instead of a round trip to memory.  The per-DNM body is compiled twice:
+//   LDS build  the arrays the phases read over and over are placed in the workgroup's LDS arena in the order
+//              they are requested, with their ACTUAL sizes ("temporary" arrays live above the persistent ones
+//              and are recycled at phase boundaries); a DNM whose arrays do not fit is given up (return 1)
+//              before anything of it is published and queued for the
+//   HBM build  where every array keeps its place in the HBM scratch.
+// Two builds instead of one address-space-agnostic body: a pointer that may hold either kind of address costs
+// a 64-bit flat access (two address registers, both memory counters waited on); a pointer that can only hold an
+// LDS address is a 32-bit ds_* access -- a third fewer instructions over the whole body.
 struct Arena { // two-ended: persistent arrays grow from the bottom, temporaries from the top
     uint8_t *base;
     int cap, pers, top;
+    int fail; // a request did not fit: the DNM is handed to the other build of the kernel (see uz_phase_dnm)
 };
-template <typename T>
+// LDS build: EVERY array requested here lies in the arena (its pointer never holds anything but an LDS address, so
+// the compiler addresses it with 32-bit ds_* instructions); a request that does not fit sets `fail` and the caller
+// gives the DNM up before the array is touched.  HBM build: the arrays keep their place in the HBM scratch.
+template <bool LDS, typename T>
 UZ_DEV void ar_p(Arena &ar, T *&ptr, size_t n) { // persistent for the rest of the DNM
+    if (!LDS) return;
     const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
-    if (ar.pers + b <= ar.top) { ptr = reinterpret_cast<T *>(ar.base + ar.pers); ar.pers += b; }
+    int at = ar.pers;
+    if (ar.pers + b <= ar.top) ar.pers += b; else { ar.fail = 1; at = 0; }
+    ptr = reinterpret_cast<T *>(ar.base + at);
 }
-template <typename T>
+template <bool LDS, typename T>
 UZ_DEV void ar_t(Arena &ar, T *&ptr, size_t n) { // until the next ar_reset
+    if (!LDS) return;
     const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
-    if (ar.pers + b <= ar.top) { ar.top -= b; ptr = reinterpret_cast<T *>(ar.base + ar.top); }
+    int at = 0;
+    if (ar.pers + b <= ar.top) { ar.top -= b; at = ar.top; } else ar.fail = 1;
+    ptr = reinterpret_cast<T *>(ar.base + at);
 }
 UZ_DEV void ar_reset(Arena &ar) { ar.top = ar.cap; }
+template <bool LDS, typename T>
+UZ_DEV void ar_pop(Arena &ar, T *, size_t n) { // gives back the temporary requested LAST (same element type and count)
+    if (LDS) ar.top += (int)((n * sizeof(T) + 15) & ~(size_t)15);
+}
 
 struct PhaseArgs {
     int32_t n;
@@ -222,6 +267,8 @@ struct PhaseArgs {
     int32_t *list_len;     // [6n] dad_reads, mom_reads, dad_sites, mom_sites, ref group, alt group
     // scheduling + scratch
     int32_t *work_cursor;
+    int32_t *retry_count; // DNMs the LDS build of the kernel gave up ...
+    int32_t *retry_list;  // ... and their indices: the work list of the HBM build
     uint8_t *scratch;
     unsigned long long scratch_per_wg;
     Caps caps;
@@ -530,11 +577,37 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i,
 }
 
 // ------------------------------------------------------------------ one DNM
-UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_t *lds_arena, int d) {
+// The working arrays of one build.  HBM build: the scratch layout as it is.  LDS build: the arrays that stay in HBM keep
+// their scratch pointers; the arena arrays are pointed at the arena before any request, so that none of them ever holds
+// an HBM address in that build (the compiler then proves the address space of every access).
+template <bool LDS>
+UZ_DEV ScrT<LDS> uz_scr_make(const Scr &sg, uint8_t *b) {
+    if constexpr (!LDS) return sg;
+    else {
+        ScrT<true> s;
+#define UZ_AT(f) s.f = reinterpret_cast<decltype(s.f)>(b)
+        UZ_AT(misc); UZ_AT(cpos); UZ_AT(cvote); UZ_AT(cflag); UZ_AT(cref); UZ_AT(calt);
+        UZ_AT(hpos); UZ_AT(hcanon); UZ_AT(h_a); UZ_AT(h_off); UZ_AT(sr_off); UZ_AT(sr_exists); UZ_AT(href); UZ_AT(halt); UZ_AT(site_best);
+        UZ_AT(i_seg); UZ_AT(i_hb); UZ_AT(i_pair); UZ_AT(a_cls); UZ_AT(a_flag0); UZ_AT(a_flag1); UZ_AT(LR); UZ_AT(LA);
+        UZ_AT(reg_h); UZ_AT(reg_pair); UZ_AT(cbase); UZ_AT(t_ov); UZ_AT(t_pass); UZ_AT(t_scan); UZ_AT(t_h); UZ_AT(seq_h);
+        UZ_AT(srt_h); UZ_AT(srt_fb); UZ_AT(keys); UZ_AT(srt_pid); UZ_AT(srt_flag); UZ_AT(srt_seq);
+        UZ_AT(pkey); UZ_AT(rs_off); UZ_AT(rs_len); UZ_AT(grp); UZ_AT(pvote);
+        UZ_AT(fr_pair0); UZ_AT(fr_hap0); UZ_AT(fr_pair1); UZ_AT(fr_hap1); UZ_AT(fr_pos0); UZ_AT(fr_pos1); UZ_AT(win);
+#undef UZ_AT
+#define UZ_CP(f) s.f = sg.f
+        UZ_CP(fet0); UZ_CP(fet1); UZ_CP(reg_seg); UZ_CP(reg_q); UZ_CP(t_q); UZ_CP(reg_mate); UZ_CP(t_mate); UZ_CP(i_q); UZ_CP(i_mate); UZ_CP(i_st); UZ_CP(i_en);
+        UZ_CP(i_qp); UZ_CP(i_L); UZ_CP(i_R); UZ_CP(i_soff); UZ_CP(pq); UZ_CP(key); UZ_CP(q_cnt); UZ_CP(q_fill);
+#undef UZ_CP
+        return s;
+    }
+}
+
+// returns 0 when the DNM is done (its status and results are written), 1 when the LDS build gives it up
+template <bool LDS, typename SH>
+UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_arena, int d) {
     const RD &R = a.R;
-    Scr s = sg; // pointers into the HBM scratch; re-pointed into LDS below where the arrays fit
-    Arena ar = {lds_arena, lds_arena ? a.lds_arena_bytes : 0, 0, lds_arena ? a.lds_arena_bytes : 0};
-    int32_t *t_h = sg.seq_h; // het index of every fetched record before the ordered compaction of phase B
+    ScrT<LDS> s = uz_scr_make<LDS>(sg, lds_arena);
+    Arena ar = {lds_arena, LDS ? a.lds_arena_bytes : 0, 0, LDS ? a.lds_arena_bytes : 0, 0};
     const long long c0 = a.cand_off[d], h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);
     WG_SYNC();
@@ -544,14 +617,15 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         for (int k = 0; k < 4; k++) a.counts[4 * d + k] = 0;
         if (a.want_lists) { a.list_start[d] = -1; for (int k = 0; k < 6; k++) a.list_len[6 * d + k] = 0; }
     }
-    if (nc <= 0) return; // snv_phaser.py:254-262
-    if (nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
-    ar_p(ar, s.misc, 8);
-    ar_p(ar, s.cpos, nc + 1); ar_p(ar, s.cvote, nc + 1);
-    ar_p(ar, s.cflag, nc + 1); ar_p(ar, s.cref, nc + 1); ar_p(ar, s.calt, nc + 1);
-    ar_p(ar, s.hpos, nh + 1); ar_p(ar, s.hcanon, nh + 1); ar_p(ar, s.h_a, nh + 1);
-    ar_p(ar, s.h_off, nh + 2); ar_p(ar, s.sr_off, nh + 2); ar_p(ar, s.sr_exists, nh + 1);
-    ar_p(ar, s.href, nh + 1); ar_p(ar, s.halt, nh + 1); ar_p(ar, s.site_best, nh + 1);
+    if (nc <= 0) return 0; // snv_phaser.py:254-262
+    if (nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
+    ar_p<LDS>(ar, s.misc, 8);
+    ar_p<LDS>(ar, s.cpos, nc + 1); ar_p<LDS>(ar, s.cvote, nc + 1);
+    ar_p<LDS>(ar, s.cflag, nc + 1); ar_p<LDS>(ar, s.cref, nc + 1); ar_p<LDS>(ar, s.calt, nc + 1);
+    ar_p<LDS>(ar, s.hpos, nh + 1); ar_p<LDS>(ar, s.hcanon, nh + 1); ar_p<LDS>(ar, s.h_a, nh + 1);
+    ar_p<LDS>(ar, s.h_off, nh + 2); ar_p<LDS>(ar, s.sr_off, nh + 2); ar_p<LDS>(ar, s.sr_exists, nh + 1);
+    ar_p<LDS>(ar, s.href, nh + 1); ar_p<LDS>(ar, s.halt, nh + 1); ar_p<LDS>(ar, s.site_best, nh + 1);
+    if (LDS && ar.fail) return 1;
     WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
     (void)a.rcontig;
     const long long position = a.dstart[d];
@@ -579,14 +653,12 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     const long long fa2 = a.pre_win[4 * d + 2], fb2 = a.pre_win[4 * d + 3];
     const int n0 = (int)(fb - fa);
     const int nA = n0 + (int)(fb2 - fa2);
-    if (nA > a.caps.A) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
-    {
-        const size_t ni = 2 * (size_t)nA + 2; // at most two list elements per fetched record
-        // (i_soff / i_qp / i_L / i_R are written and read once, in the seeding step: they stay in HBM scratch)
-        ar_p(ar, s.i_seg, ni); ar_p(ar, s.i_hb, ni); ar_p(ar, s.i_pair, ni);
-        ar_t(ar, s.a_cls, nA + 1); ar_t(ar, s.a_flag0, nA + 1); ar_t(ar, s.a_flag1, nA + 1);
-        ar_t(ar, s.LR, ni); ar_t(ar, s.LA, ni);
-    }
+    if (nA > a.caps.A) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
+    // per fetched record: class and two scan arrays; the lists and the init elements are requested once their lengths are
+    // known (an SV fetches hundreds of records around its breakpoints and keeps a handful)
+    // (i_soff / i_qp / i_L / i_R are written and read once, in the seeding step: they stay in HBM scratch)
+    ar_t<LDS>(ar, s.a_cls, nA + 1); ar_t<LDS>(ar, s.a_flag0, nA + 1); ar_t<LDS>(ar, s.a_flag1, nA + 1);
+    if (LDS && ar.fail) return 1;
     int nre = 0, nae = 0; // elements of the "ref" / "alt" lists
     if (!is_sv) {
         WG_FOR(i, nA) {
@@ -598,6 +670,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         UZ_TICK(0); // A.classify
         const int n_ref = wg_exscan(s.a_flag0, nA, sh);
         const int n_alt = wg_exscan(s.a_flag1, nA, sh);
+        ar_t<LDS>(ar, s.LR, 2 * (size_t)n_ref + 2); ar_t<LDS>(ar, s.LA, 2 * (size_t)n_alt + 2);
+        if (LDS && ar.fail) return 1;
         WG_FOR(i, nA) {
             const int cl = s.a_cls[i];
             if (cl) {
@@ -647,6 +721,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.a_flag1[t] = code ? 2 : 0;
         }
         const int nsup = wg_exscan(s.a_flag1, nA, sh);
+        ar_t<LDS>(ar, s.LR, (size_t)nsup + 2); ar_t<LDS>(ar, s.LA, (size_t)nsup + 2);
+        if (LDS && ar.fail) return 1;
         WG_FOR(t, nA) {
             const int code = s.a_cls[t];
             if (code) {
@@ -678,6 +754,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     }
     // init elements in seeding order: "ref" list then "alt" list (:226)
     const int nI = nre + nae;
+    ar_p<LDS>(ar, s.i_seg, (size_t)nI + 2); ar_p<LDS>(ar, s.i_hb, (size_t)nI + 2); ar_p<LDS>(ar, s.i_pair, (size_t)nI + 2);
+    if (LDS && ar.fail) return 1;
     WG_FOR(m, nI) {
         const bool is_ref = m < nre;
         const int seg = is_ref ? s.LR[m] : s.LA[m - nre];
@@ -709,11 +787,14 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         }
         const int T = wg_exscan(s.h_off, nh, sh);
         UZ_TICK(2); // B.het
-        if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+        if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
         ar_reset(ar);
-        // LDS goes to what the chaining levels read over and over; reg_seg is read twice (keys, pair table)
-        ar_p(ar, s.reg_h, T + 1); ar_p(ar, s.reg_pair, T + 1); ar_p(ar, s.cbase, T + 1);
-        ar_t(ar, s.t_ov, T + 1); ar_t(ar, s.t_pass, T + 1); ar_t(ar, t_h, T + 1);
+        // the enumerate cut-off (:178-179) can only bite when a fetch returns more than read_goal + 1 records: otherwise the
+        // per-site running count (one array, one scan, one pass) is not needed
+        const bool need_ei = (long long)T > (long long)a.read_goal + 1;
+        ar_t<LDS>(ar, s.t_ov, T + 1); ar_t<LDS>(ar, s.t_scan, T + 1); ar_t<LDS>(ar, s.t_h, T + 1);
+        if (need_ei) ar_t<LDS>(ar, s.t_pass, T + 1);
+        if (LDS && ar.fail) return 1;
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
         // Two work items per lane and round: the loads of both (record headers and QC byte, then the mates' header and QC
@@ -740,7 +821,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             for (int u = 0; u < 2; u++) {
                 if (tt[u] >= T) continue;
                 const int t = tt[u], h = hh[u];
-                t_h[t] = h;
+                s.t_h[t] = (typename ScrT<LDS>::hidx)h;
                 // overlap test, pair filters (pure: evaluated for every overlapping record, the enumerate cut-off below only
                 // masks them), name id for the pair table
                 const int ov = (long long)A[u].end > (long long)s.hpos[h];
@@ -748,39 +829,49 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 const bool pok = ov && mate >= 0 && (q[u] & UZ_QC_NM5);
                 s.t_q[t] = B[u].qname;
                 s.t_mate[t] = mate;
-                s.t_ov[t] = ov | (pok ? 2 : 0);
-                s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
+                if (need_ei) {
+                    s.t_ov[t] = (typename ScrT<LDS>::flg)(ov | (pok ? 2 : 0));
+                    s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
+                } else {
+                    s.t_ov[t] = pok;
+                    s.t_scan[t] = pok; // scanned below: position in the registration list
+                }
             }
         }
         UZ_TICK(3); // B.overlap
-        (void)wg_exscan(s.t_pass, T, sh);
-        UZ_TICK(4); // B.scan1
-        WG_FOR(t, T) {
-            const int h = t_h[t];
-            bool ok = (s.t_ov[t] & 2) != 0;
-            if (ok) {
-                const int ei = s.t_pass[t] - s.t_pass[s.h_off[h]];
-                ok = !(ei > a.read_goal); // :179
+        if (need_ei) {
+            (void)wg_exscan(s.t_pass, T, sh);
+            UZ_TICK(4); // B.scan1
+            WG_FOR(t, T) {
+                const int h = s.t_h[t];
+                bool ok = (s.t_ov[t] & 2) != 0;
+                if (ok) {
+                    const int ei = s.t_pass[t] - s.t_pass[s.h_off[h]];
+                    ok = !(ei > a.read_goal); // :179
+                }
+                s.t_ov[t] = ok;
+                s.t_scan[t] = ok;
             }
-            s.t_ov[t] = ok;
-            s.reg_pair[t] = ok; // scanned below: position in the registration list (reg_pair is free until phase S)
         }
         UZ_TICK(5); // B.pair_ok
-        E = wg_exscan(s.reg_pair, T, sh);
+        E = wg_exscan(s.t_scan, T, sh);
         UZ_TICK(6); // B.scan2
+        // LDS goes to what the chaining levels read over and over; reg_seg is read twice (keys, pair table)
+        ar_p<LDS>(ar, s.reg_h, E + 1); ar_p<LDS>(ar, s.reg_pair, E + 1); ar_p<LDS>(ar, s.cbase, E + 1);
+        if (LDS && ar.fail) return 1;
         // ordered compaction (inputs are the per-record temporaries, outputs the registration arrays)
         WG_FOR(t, T) {
             if (s.t_ov[t]) {
-                const int k = s.reg_pair[t];
-                const int h = t_h[t];
-                s.reg_h[k] = h;
+                const int k = s.t_scan[t];
+                const int h = s.t_h[t];
+                s.reg_h[k] = (typename ScrT<LDS>::hidx)h;
                 s.reg_seg[k] = s.h_a[h] + (t - s.h_off[h]);
                 s.reg_q[k] = s.t_q[t];
                 s.reg_mate[k] = s.t_mate[t];
             }
         }
         // site_reads range of het index h: entries [sr_off[h], sr_off[h+1])
-        WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.reg_pair[s.h_off[h]] : E) : E;
+        WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.t_scan[s.h_off[h]] : E) : E;
         WG_SYNC();
         WG_FOR(h, nh) {
             // a canonical site exists in site_reads once any of its duplicates registered a read (:217-218)
@@ -798,7 +889,8 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         WG_T0 s.i_soff[nI] = S;
         WG_SYNC();
         ar_reset(ar);
-        ar_p(ar, s.seq_h, S + 1); // het index of every seed entry
+        ar_p<LDS>(ar, s.seq_h, S + 1); // het index of every seed entry
+        if (LDS && ar.fail) return 1;
         if (S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
         WG_FOR(m, nI) {
             const int nm = s.i_soff[m + 1] - s.i_soff[m];
@@ -812,17 +904,22 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     const int M = E + S + nI;
     if (M >= (1 << 20) || M > a.caps.M || nI > a.caps.I) { // rank-key field widths / scratch: loud, never silent
         WG_T0 a.status[d] = UZ_ST_CAPACITY;
-        return;
+        return 0;
     }
+    if (LDS && (M > 65535 || nh > 32767)) return 1; // 16-bit indices of the arena build
     int mp2 = 2;
     while (mp2 < M) mp2 <<= 1;
+    // the arena build sorts in place, and the register sort exchanges whole rounds of WG_NT keys through the array
+    if (LDS && mp2 < WG_NT) mp2 = WG_NT;
     {
         ar_reset(ar);
-        // persistent (read by every chaining level): assigned, srt_h, srt_fb; the sorted keys and the pair ids
+        // persistent (read by every chaining level): srt_h, srt_fb; the sorted keys and the pair ids
         // of the entries die with the allele tables (phase D), so they are temporaries
-        ar_p(ar, s.assigned, M + 1); ar_p(ar, s.srt_h, M + 1); ar_p(ar, s.srt_fb, M + 1);
-        ar_t(ar, s.keys, mp2 + 1); ar_t(ar, s.srt_pid, M + 1); ar_t(ar, s.srt_flag, M + 1);
+        ar_p<LDS>(ar, s.srt_h, M + 1); ar_p<LDS>(ar, s.srt_fb, M + 1);
+        ar_t<LDS>(ar, s.srt_pid, M + 1); ar_t<LDS>(ar, s.srt_flag, M + 1); ar_t<LDS>(ar, s.srt_seq, M + 1);
+        ar_t<LDS>(ar, s.keys, mp2 + 1); // requested last: given back as soon as the sorted order is taken down (below)
     }
+    if (LDS && ar.fail) return 1;
     int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path)
     WG_FOR(x, M) {
         uint32_t q;
@@ -839,65 +936,77 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     }
     WG_SYNC();
     UZ_TICK(9); // S.keys
-    // Sort by (query-name id, sequence).  Name ids are interned in file order, so the names met
-    // around one locus span a short id range: a counting sort over that range (stable order inside
-    // a bucket restored by a tiny insertion sort) replaces the 60+ barrier stages of a bitonic sort.
-    // Wider ranges fall back to the bitonic sort; both give the same array.
+    // Sort by (query-name id, sequence).
     {
-        int qmin = -1, qmax = -1, qrange = 0;
-        // keys that sit in the LDS arena sort fastest in place (bitonic, ~45 short stages for 512 keys);
-        // the counting sort walks the whole id range, which lives in HBM scratch
-        const bool keys_in_lds = (uint8_t *)s.keys >= ar.base && (uint8_t *)s.keys < ar.base + ar.cap;
-        const bool small = keys_in_lds && M <= 4 * WG_NT;
-        if (!small) { // block-uniform
+        if constexpr (LDS) {
+            // the keys sit in the arena: bitonic sort in registers / in place (wg_sort64; ~45 short stages for 512 keys)
+            wg_sort64(s.keys, M, sh, true);
+        } else {
+            // keys in HBM scratch.  Name ids are interned in file order, so the names met around one locus span a short
+            // id range: a counting sort over that range (stable order inside a bucket restored by a tiny insertion
+            // sort) replaces the 60+ barrier stages of a bitonic sort; wider ranges fall back to it.  Same array.
+            int qmin = -1, qmax = -1, qrange = 0;
             wg_minmax(lmin, lmax, qmin, qmax, sh);
             qrange = M > 0 ? qmax - qmin + 1 : 0;
-        }
-        if (small || (keys_in_lds && M <= 1024)) wg_sort64(s.keys, M, sh, true);
-        else if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
-            ar_t(ar, s.key, mp2 + 1); ar_t(ar, s.q_cnt, qrange + 2); ar_t(ar, s.q_fill, qrange + 2);
-            WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
-            WG_SYNC();
-            WG_FOR(x, M) wg_atomic_add(&s.q_cnt[(int)(s.keys[x] >> 24) - qmin], 1);
-            (void)wg_exscan(s.q_cnt, qrange, sh);
-            WG_FOR(x, M) {
-                const int b = (int)(s.keys[x] >> 24) - qmin;
-                s.key[s.q_cnt[b] + wg_atomic_add(&s.q_fill[b], 1)] = s.keys[x];
-            }
-            WG_SYNC();
-            WG_FOR(b, qrange) {
-                const int n_b = s.q_fill[b];
-                if (n_b > 1) {
-                    unsigned long long *v = s.key + s.q_cnt[b];
-                    for (int i = 1; i < n_b; i++) {
-                        const unsigned long long kx = v[i];
-                        int j = i - 1;
-                        while (j >= 0 && v[j] > kx) { v[j + 1] = v[j]; j--; }
-                        v[j + 1] = kx;
+            if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
+                WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
+                WG_SYNC();
+                WG_FOR(x, M) wg_atomic_add(&s.q_cnt[(int)(s.keys[x] >> 24) - qmin], 1);
+                (void)wg_exscan(s.q_cnt, qrange, sh);
+                WG_FOR(x, M) {
+                    const int b = (int)(s.keys[x] >> 24) - qmin;
+                    s.key[s.q_cnt[b] + wg_atomic_add(&s.q_fill[b], 1)] = s.keys[x];
+                }
+                WG_SYNC();
+                WG_FOR(b, qrange) {
+                    const int n_b = s.q_fill[b];
+                    if (n_b > 1) {
+                        unsigned long long *v = s.key + s.q_cnt[b];
+                        for (int i = 1; i < n_b; i++) {
+                            const unsigned long long kx = v[i];
+                            int j = i - 1;
+                            while (j >= 0 && v[j] > kx) { v[j + 1] = v[j]; j--; }
+                            v[j + 1] = kx;
+                        }
                     }
                 }
-            }
-            WG_SYNC();
-            { unsigned long long *sorted = s.key; s.key = s.keys; s.keys = sorted; } // both hold mp2 + 1 entries
-        } else
-            wg_sort64(s.keys, M, sh);
+                WG_SYNC();
+                { unsigned long long *sorted = s.key; s.key = s.keys; s.keys = sorted; } // both hold mp2 + 1 entries
+            } else
+                wg_sort64(s.keys, M, sh);
+        }
     }
     UZ_TICK(10); // S.sort
     WG_FOR(x, M) {
         const int st = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
         s.srt_flag[x] = st;
         s.srt_pid[x] = st;
+        s.srt_seq[x] = (typename ScrT<LDS>::xidx)(s.keys[x] & 0xFFFFFF);
     }
-    P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1
+    P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1 (its first barrier ends the reads of keys)
+    ar_pop<LDS>(ar, s.keys, mp2 + 1); // the 8-byte keys are the largest array of the DNM: their room goes to the per-pair arrays
     // per-pair arrays, now that the number of pairs is known; the chaining arrays first
-    ar_p(ar, s.pkey, P + 1); ar_p(ar, s.rs_off, P + 2); ar_p(ar, s.rs_len, P + 1); ar_p(ar, s.grp, P + 1);
-    ar_p(ar, s.fet0, P + 1); ar_p(ar, s.fet1, P + 1); ar_p(ar, s.pvote, P + 1); ar_p(ar, s.pq, P + 1);
+    ar_p<LDS>(ar, s.pkey, P + 1); ar_p<LDS>(ar, s.rs_off, P + 2); ar_p<LDS>(ar, s.rs_len, P + 1); ar_p<LDS>(ar, s.grp, P + 1);
+    if (LDS && ar.fail) return 1;
     UZ_TICK(11); // P.scan
     WG_FOR(x, M) {
         const int pid = s.srt_pid[x] + s.srt_flag[x] - 1;
         s.srt_pid[x] = pid;
-        const int seq = (int)(s.keys[x] & 0xFFFFFF);
-        if (s.srt_flag[x]) { s.rs_off[pid] = x; s.pq[pid] = (uint32_t)(s.keys[x] >> 24); }
+        const int seq = s.srt_seq[x];
+        if (s.srt_flag[x]) {
+            s.rs_off[pid] = (typename ScrT<LDS>::xidx)x;
+            if (a.want_lists) { // name id of the pair = that of its first entry (the optional lists)
+                uint32_t q;
+                if (seq < E) q = s.reg_q[seq];
+                else if (seq < E + S) {
+                    int lo = 0, hi = nI;
+                    const int sx = seq - E;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.i_soff[mid] <= sx) lo = mid; else hi = mid; }
+                    q = s.i_q[lo];
+                } else q = s.i_q[seq - E - S];
+                s.pq[pid] = q;
+            }
+        }
         if (seq < E) s.reg_pair[seq] = pid;
         else if (seq >= E + S) s.i_pair[seq - E - S] = pid;
         s.srt_h[x] = seq < E ? s.reg_h[seq] : (seq < E + S ? s.seq_h[seq - E] : -1);
@@ -909,7 +1018,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         const int x0 = s.rs_off[p], x1 = s.rs_off[p + 1];
         int len = 0, f0 = -1, f1 = -1;
         for (int x = x0; x < x1; x++) { // ascending sequence = the reference's time order
-            const int seq = (int)(s.keys[x] & 0xFFFFFF);
+            const int seq = s.srt_seq[x];
             if (seq < E + S) len++;
             if (seq < E) { f0 = s.reg_seg[seq]; f1 = s.reg_mate[seq]; }     // :222
             else if (seq >= E + S) {                                        // :233-234
@@ -920,18 +1029,18 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         if (len >= 4096) s.misc[2] = 1; // rank key: 12 bits for the read_sites index
         s.rs_len[p] = len;
         s.fet0[p] = f0; s.fet1[p] = f1;
-        s.grp[p] = 0; s.pvote[p] = 0;
+        s.grp[p] = 0;
         s.pkey[p] = ~0ULL;
-        s.assigned[p] = 0;
     }
     WG_SYNC();
     WG_FOR(m, nI) wg_atomic_or(&s.grp[s.i_pair[m]], s.i_hb[m] ? 2u : 1u); // :230
     WG_SYNC();
-    if (s.misc[2]) { WG_SYNC(); WG_T0 a.status[d] = UZ_ST_CAPACITY; return; }
+    if (s.misc[2]) { WG_SYNC(); WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
 
 #ifdef UZ_EMU_STATS
     uz_emu_stats[0] += E; uz_emu_stats[1] += S; uz_emu_stats[2] += nI; uz_emu_stats[3] += P; uz_emu_stats[7] += nh; uz_emu_stats[8] += nc; uz_emu_stats[9]++;
-    { int T_ = 0; if (!a.no_extended) T_ = s.h_off[nh]; uz_emu_stats[10] += T_; }
+    { int T_ = 0; if (!a.no_extended) T_ = s.h_off[nh]; uz_emu_stats[10] += T_;
+      if (uz_emu_log) { long long *r = uz_emu_log + 12 * (long long)d; r[0] = nc; r[1] = nh; r[2] = nA; r[3] = T_; r[4] = nI; r[5] = E; r[6] = S; r[7] = M; r[8] = P; } }
 #endif
     UZ_TICK(13); // P.pairs
     if (!a.no_extended) {
@@ -952,7 +1061,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 xx[u] = x0 + u * WG_NT;
                 const int x = xx[u] < M ? xx[u] : x0;
                 hh[u] = s.srt_h[x];
-                sq[u] = (int)(s.keys[x] & 0xFFFFFF);
+                sq[u] = s.srt_seq[x];
                 const int p = s.srt_pid[x];
                 const int f0 = s.fet0[p];
                 f1v[u] = s.fet1[p];
@@ -1001,15 +1110,20 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         UZ_TICK(15); // D.cbase
         // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
         int F = nI, cur = 0;
+        // winners of one level: at most P.  The arena build sets room aside for 256 (a level rarely has more than a few
+        // dozen) and gives the DNM up if a level overflows it.
+        const int wcap = (LDS && P > 256) ? 256 : P;
         {
             ar_reset(ar);
-            const size_t fr = (size_t)(P > nI ? P : nI) + 2;
-            ar_t(ar, s.fr_pair0, fr); ar_t(ar, s.fr_hap0, fr); ar_t(ar, s.fr_pair1, fr); ar_t(ar, s.fr_hap1, fr);
-            ar_t(ar, s.fr_pos0, fr); ar_t(ar, s.fr_pos1, fr);
+            const size_t fr = (size_t)(wcap > nI ? wcap : nI) + 2;
+            ar_t<LDS>(ar, s.fr_pair0, fr); ar_t<LDS>(ar, s.fr_hap0, fr); ar_t<LDS>(ar, s.fr_pair1, fr); ar_t<LDS>(ar, s.fr_hap1, fr);
+            ar_t<LDS>(ar, s.fr_pos0, fr); ar_t<LDS>(ar, s.fr_pos1, fr);
             int wp2 = 2; // the winners are sorted in place: room for the next power of two
-            while (wp2 < P) wp2 <<= 1;
-            ar_t(ar, s.win, (size_t)wp2 + 1);
+            while (wp2 < wcap) wp2 <<= 1;
+            if (LDS && wcap > 96 && wp2 < WG_NT) wp2 = WG_NT; // (levels with more than 96 winners are sorted in place, see mp2)
+            ar_t<LDS>(ar, s.win, (size_t)wp2 + 1);
         }
+        if (LDS && ar.fail) return 1;
         WG_FOR(e, nI) {
             const int na = nae;
             const int m = e < na ? (nre + e) : (e - na);
@@ -1018,12 +1132,13 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             s.fr_hap0[e] = s.i_hb[m];
         }
         WG_SYNC();
-        WG_FOR(p, P) if (s.grp[p]) s.assigned[p] = 1;
+        // (a pair is "assigned" exactly when it carries a haplotype bit in grp: the init pairs from the start, the winners of a
+        // level from its end)
         WG_FOR(h, nh) s.site_best[h] = ~0ULL;
         WG_SYNC();
         while (F > 0) {
-            int32_t *const fr_pair_c = cur ? s.fr_pair1 : s.fr_pair0, *const fr_pair_n = cur ? s.fr_pair0 : s.fr_pair1;
-            int32_t *const fr_pos_c = cur ? s.fr_pos1 : s.fr_pos0, *const fr_pos_n = cur ? s.fr_pos0 : s.fr_pos1;
+            auto *const fr_pair_c = cur ? s.fr_pair1 : s.fr_pair0, *const fr_pair_n = cur ? s.fr_pair0 : s.fr_pair1;
+            auto *const fr_pos_c = cur ? s.fr_pos1 : s.fr_pos0, *const fr_pos_n = cur ? s.fr_pos0 : s.fr_pos1;
             uint8_t *const fr_hap_c = cur ? s.fr_hap1 : s.fr_hap0, *const fr_hap_n = cur ? s.fr_hap0 : s.fr_hap1;
             // (i) per het index, the first frontier element (in visiting order e, then read_sites
             // index j) that finds a usable allele there.  Every element finding REF or ALT at a het
@@ -1031,12 +1146,12 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             WG_T0 s.misc[3] = 0; // winners of this level (read back after the barriers below)
             WG_FOR(e, F) {
                 const int p = fr_pair_c[e];
-                const int fpos = fr_pos_c[e];
+                const int fcanon = fr_pos_c[e]; // canonical het index of the site this element was claimed at
                 const unsigned long long hap = fr_hap_c[e];
                 const int x0 = s.rs_off[p], len = s.rs_len[p];
                 for (int j = 0; j < len; j++) {
                     const int h = s.srt_h[x0 + j];
-                    if (s.hpos[h] == fpos) continue;            // :89-90
+                    if (s.hcanon[h] == fcanon) continue;        // :89-90 (same position <=> same canonical index)
                     const unsigned long long fbv = s.srt_fb[x0 + j];
                     if (!fbv) continue;                          // :104-105
                     if (!s.sr_exists[s.hcanon[h]]) { s.misc[0] = 1; continue; } // :106 KeyError
@@ -1049,7 +1164,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // (ii) every still-unassigned registration looks up the finder(s) of its site
             WG_FOR(k, E) {
                 const int p2 = s.reg_pair[k];
-                if (s.assigned[p2]) continue;                    // :108-110 (assigned before this level)
+                if (s.grp[p2]) continue;                         // :108-110 (assigned before this level)
                 const uint8_t cb = s.cbase[k];
                 if (!cb) continue;
                 const int canon = s.hcanon[s.reg_h[k]];
@@ -1080,18 +1195,20 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
             // the winners are appended in any order (one LDS counter): their place in the next frontier is
             // decided below by the RANK of their key, so the order of this list does not matter
             WG_FOR(p, P) {
-                if (!s.assigned[p] && s.pkey[p] != ~0ULL) {
+                if (!s.grp[p] && s.pkey[p] != ~0ULL) {
                     const unsigned long long k = s.pkey[p];
-                    s.win[wg_atomic_add(&s.misc[3], 1)] = ((k & 1ULL) << 63) | (k >> 1);
+                    const int wi = wg_atomic_add(&s.misc[3], 1);
+                    if (wi < wcap) s.win[wi] = ((k & 1ULL) << 63) | (k >> 1);
                 }
             }
             WG_SYNC();
             const int W = s.misc[3];
+            if (LDS && W > wcap) return 1; // (block-uniform)
             UZ_TICK(17); // E.scan
             // position in the next frontier = rank of the (target, rank) key among the winners: counted
             // directly while a level has few winners (one barrier), sorted otherwise
             const bool by_count = W <= 96;
-            if (!by_count) wg_sort64(s.win, W, sh, (uint8_t *)s.win >= ar.base && (uint8_t *)s.win < ar.base + ar.cap);
+            if (!by_count) wg_sort64(s.win, W, sh, LDS);
             WG_FOR(w, W) {
                 const unsigned long long ok = s.win[w];
                 int posn = w;
@@ -1103,17 +1220,17 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
                 const int pe = fr_pair_c[e];
                 const int h = s.srt_h[s.rs_off[pe] + j];
                 const int p = s.reg_pair[s.sr_off[s.hcanon[h]] + krel];
-                fr_pair_n[posn] = p;
-                fr_pos_n[posn] = s.hpos[h];
+                fr_pair_n[posn] = (typename ScrT<LDS>::pidx)p;
+                fr_pos_n[posn] = (typename ScrT<LDS>::hidx)s.hcanon[h];
                 fr_hap_n[posn] = (uint8_t)(ok >> 63);
                 // every winner key names a different pair: mark it here
-                s.assigned[p] = 1;
                 s.grp[p] |= (ok >> 63) ? 2u : 1u;
                 s.pkey[p] = ~0ULL;
             }
             WG_SYNC();
 #ifdef UZ_EMU_STATS
             uz_emu_stats[4]++; if (W > uz_emu_stats[5]) uz_emu_stats[5] = W; uz_emu_stats[6] += W;
+            if (uz_emu_log) { long long *r = uz_emu_log + 12 * (long long)d; if (W > r[9]) r[9] = W; r[10]++; }
 #endif
             UZ_TICK(18); // E.frontier
             F = W;
@@ -1125,12 +1242,16 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     WG_SYNC();
     if (exception) {
         WG_T0 a.status[d] = UZ_ST_REF_EXCEPTION;
-        return;
+        return 0;
     }
 
     // ---- F: join + vote.  Items: extended -> both fetched segments of every grouped pair per
     // haplotype (:254-263); --no-extended -> the init list elements themselves.
     ar_reset(ar);
+    ar_p<LDS>(ar, s.pvote, P + 1);
+    if (LDS && ar.fail) return 1;
+    WG_FOR(p, P) s.pvote[p] = 0;
+    WG_SYNC();
     const int n_items = a.no_extended ? nI : 4 * P;
     // two items per lane and round: both segments' headers are requested before either is used
     for (int it0 = wg_lane_opaque(); it0 < n_items; it0 += 2 * WG_NT) {
@@ -1188,7 +1309,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
     WG_SYNC();
     if (n_match <= 0) {
         WG_T0 a.status[d] = UZ_ST_NO_OVERLAP; // snv_phaser.py:158-166
-        return;
+        return 0;
     }
     // unique positions: the votes of records sharing a position count once, at the first of the run
     auto cvote_at = [&](int ci) -> uint32_t {
@@ -1258,6 +1379,7 @@ UZ_DEV void uz_phase_dnm(const PhaseArgs &a, const Scr &sg, WgShared *sh, uint8_
         else if (mr > 0 && mr >= r * dr) { a.origin[d] = UZ_OR_MOM; a.evidence[d] = cnt[3]; }
         else if (dr > 0 && mr > 0) { a.origin[d] = UZ_OR_AMBIGUOUS; a.evidence[d] = (int32_t)(dr + mr); }
     }
+    return 0;
 }
 
 // ------------------------------------------------------------------ sizing

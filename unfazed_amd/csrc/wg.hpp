@@ -57,16 +57,21 @@ UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long l
 #define WG_SORT_LDS_CAP 256 // u64 keys copied into the 2 KiB LDS sort buffer; larger sorts run in place (LDS arena or HBM scratch)
 #endif
 
-struct WgShared {
+// SORT_CAP: room for the keys of a small sort whose array is NOT in LDS (wg_sort64); the kernel build whose arrays all are
+// in LDS sorts in place and keeps the 2 KiB for its arena
+template <int SORT_CAP>
+struct WgSharedT {
     int part[WG_NT + 1];
-    unsigned long long sortbuf[WG_SORT_LDS_CAP];
+    unsigned long long sortbuf[SORT_CAP];
     int bcast[4];
 };
+typedef WgSharedT<WG_SORT_LDS_CAP> WgShared;
 
 // In-place exclusive scan of a[0..n) -> returns the total.  Block-uniform call.
 // Each lane sums a contiguous chunk, lanes are combined with wave shuffles (no barrier) and the
 // waves through WG_NT/64 words of LDS: three barriers per call.
-UZ_DEV int wg_exscan(int *a, int n, WgShared *sh) {
+template <typename SH>
+UZ_DEV int wg_exscan(int *a, int n, SH *sh) {
 #ifdef UZ_EMU
     int s = 0;
     for (int i = 0; i < n; i++) { int v = a[i]; a[i] = s; s += v; }
@@ -115,8 +120,8 @@ UZ_DEV void wg_chunk(int n, int &lo, int &hi) {
 
 // Exclusive scan ACROSS LANES of K per-lane values at once (one pair of barriers for all K):
 // off[k] = sum of c[k] over lower lanes, tot[k] = sum over all lanes.  Block-uniform call.
-template <int K>
-UZ_DEV void wg_lane_exscan(const int (&c)[K], int (&off)[K], int (&tot)[K], WgShared *sh) {
+template <int K, typename SH>
+UZ_DEV void wg_lane_exscan(const int (&c)[K], int (&off)[K], int (&tot)[K], SH *sh) {
 #ifdef UZ_EMU
     for (int k = 0; k < K; k++) { off[k] = 0; tot[k] = c[k]; }
 #else
@@ -155,7 +160,8 @@ UZ_DEV void wg_lane_exscan(const int (&c)[K], int (&off)[K], int (&tot)[K], WgSh
 }
 
 // Block-wide minimum and maximum of per-lane partial results (two barriers, no atomics).
-UZ_DEV void wg_minmax(int lmin, int lmax, int &mn, int &mx, WgShared *sh) {
+template <typename SH>
+UZ_DEV void wg_minmax(int lmin, int lmax, int &mn, int &mx, SH *sh) {
 #ifdef UZ_EMU
     mn = lmin; mx = lmax;
 #else
@@ -256,7 +262,8 @@ UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) unsigned long long
     __syncthreads();
 }
 #endif
-UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh, bool a_in_lds = false) {
+template <typename SH>
+UZ_DEV void wg_sort64(unsigned long long *a, int n, SH *sh, bool a_in_lds = false) {
 #ifdef UZ_EMU
     (void)sh; (void)a_in_lds;
     std::sort(a, a + n);
@@ -266,8 +273,10 @@ UZ_DEV void wg_sort64(unsigned long long *a, int n, WgShared *sh, bool a_in_lds 
     if (n <= 1) return;
     int N = 1;
     while (N < n) N <<= 1;
-    if (N <= WG_SORT_LDS_CAP || (a_in_lds && N <= 4 * WG_NT)) { // 8 keys per lane would push the kernel past 128 VGPRs
-        lds_u64 buf = N <= WG_SORT_LDS_CAP ? (lds_u64)sh->sortbuf : (lds_u64)a;
+    constexpr int sort_cap = (int)(sizeof(sh->sortbuf) / sizeof(unsigned long long));
+    const bool in_buf = !a_in_lds && N <= sort_cap;
+    if (in_buf || (a_in_lds && N <= 4 * WG_NT)) { // 8 keys per lane would push the kernel past 128 VGPRs
+        lds_u64 buf = in_buf ? (lds_u64)sh->sortbuf : (lds_u64)a;
         if (N <= WG_NT) wg_bitonic_regs<1>(buf, a, n);
         else if (N <= 2 * WG_NT) wg_bitonic_regs<2>(buf, a, n);
         else wg_bitonic_regs<4>(buf, a, n);
