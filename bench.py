@@ -357,28 +357,27 @@ def main():
                     "traffic": k3a_traffic, "avg_launch_us": round(qc_us, 1), "records_examined": int(qc_records),
                     "algorithmic_bytes_per_launch": int(qc_bytes)}
 
-    # k_phase is latency-bound integer work (no GB/s figure): per-wave dependent reads x the time a wave is parked per
-    # read (rocprofv3 SQ counters of the same workload, profiles/phase_latency.json) against this run's kernel time
-    latency_model = None
-    tpath = os.path.join(ROOT, "profiles", "phase_latency.json")
+    # k_phase has no GB/s figure: it is bound by instruction issue (integer VALU work) with memory latency on top.  The
+    # counters of the same workload (profiles/phase_issue.json, scripts/profile_round.sh) give the floor: VALU
+    # wave-instructions x 4 cycles / 1024 SIMDs at the measured shader clock; frac = floor / this run's kernel time.
+    issue_model = None
+    tpath = os.path.join(ROOT, "profiles", "phase_issue.json")
     ph_ms, ph_n = prof_r[K_PHASE]
     if os.path.exists(tpath) and ph_n:
         try:
             tj = json.load(open(tpath))
             if int(tj.get("dnms", -1)) == n:
-                clock_ghz = 2.1  # effective shader clock under this load (GRBM_GUI_ACTIVE / 8 / wall), DESIGN.md
-                modelled = tj["vmem_read_instructions_per_wave"] * tj["parked_cycles_per_read_instruction"] / (clock_ghz * 1e6)
-                latency_model = {"kernel": "k_phase", "bound": "latency (dependent reads per wave)",
-                                 "reads_per_wave": round(tj["vmem_read_instructions_per_wave"], 1),
-                                 "reads_per_wave_per_dnm": round(tj["vmem_read_instructions_per_wave"] * tj["waves_resident"] / 4.0 / n, 1),
-                                 "parked_cycles_per_read": round(tj["parked_cycles_per_read_instruction"], 1),
-                                 "l1_miss_latency_cycles": round(tj["l1_miss_latency_cycles"], 1),
-                                 "wave_cycles_parked_frac": round(tj["wave_cycles_parked_frac"], 4),
-                                 "l2_hit_rate": round(tj["l2_hit_rate"], 4), "waves_in_flight": int(tj["waves_resident"]),
-                                 "modelled_ms": round(modelled, 3), "measured_ms": round(ph_ms / ph_n, 3),
-                                 "source": "profiles/phase_latency.json"}
+                measured = ph_ms / ph_n
+                issue_model = {"kernel": "k_phase", "bound": "instruction issue (VALU), memory latency hidden by 7 waves per SIMD",
+                               "valu_wave_instructions_per_dnm": round(tj["valu_wave_instructions_per_dnm_with_candidates"], 0),
+                               "valu_pipe_busy_frac_profiled": round(tj["valu_pipe_busy_frac"], 4),
+                               "valu_lane_utilisation": round(tj["valu_lane_utilisation"], 4),
+                               "wave_cycles_parked_frac": round(tj["wave_cycles_parked_frac"], 4),
+                               "waves_per_simd": round(tj["waves_per_simd"], 2), "shader_clock_GHz": round(tj["shader_clock_GHz"], 3),
+                               "valu_floor_ms": round(tj["valu_floor_ms"], 3), "measured_ms": round(measured, 3),
+                               "frac": round(tj["valu_floor_ms"] / measured, 4), "source": "profiles/phase_issue.json"}
         except Exception:
-            latency_model = None
+            issue_model = None
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
@@ -401,7 +400,7 @@ def main():
             "value_resident": round(value_resident, 1), "ms_per_step_resident": round(ms_resident, 3),
             "roofline": roofline,
             "roofline_k3a": roofline_k3a,
-            "latency_model": latency_model,
+            "issue_model": issue_model,
             "cpu_baseline": cpu,
             "kernels_ms_per_step": kern_ms(prof_r),
             "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist(),

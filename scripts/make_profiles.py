@@ -66,7 +66,9 @@ waves = c("k_phase", "SQ_WAVES")
 loads = c("k_phase", "SQ_INSTS_VMEM_RD")
 wait_q = c("k_phase", "SQ_WAIT_ANY")
 wave_q = c("k_phase", "SQ_WAVE_CYCLES")
-ns, calls = avg_ns("k_phase(")
+ns, calls = avg_ns("k_phase<true>(")
+if ns is None:
+    ns, calls = avg_ns("k_phase(")
 json.dump({"kernel": "k_phase", "dnms": line["config"]["dnms_per_gpu"], "waves_resident": waves,
            "vmem_read_instructions_per_wave": loads / waves,
            "wave_cycles_parked_frac": wait_q / wave_q, "active_frac": c("k_phase", "SQ_ACTIVE_INST_ANY") / wave_q,
@@ -82,3 +84,31 @@ json.dump({"kernel": "k_phase", "dnms": line["config"]["dnms_per_gpu"], "waves_r
            "how": how + "; SQ_* in quad-cycles (x4 = shader cycles)", "source": "profiles/%s_pmc_summary.json" % rnd},
           open(os.path.join(dst, "phase_latency.json"), "w"), indent=1)
 print(open(os.path.join(dst, "phase_latency.json")).read())
+# k_phase: what bounds it.  Instruction issue: wave-instructions by class, the share of the VALU pipes' cycles they take (a
+# wave64 VALU instruction occupies its SIMD's 16-lane pipe for 4 cycles; 1024 SIMDs), lane utilisation, instruction cache.
+cp = pmc["k_phase"]["counters_per_launch"]
+if "SQ_INSTS_VALU" in cp and "GRBM_GUI_ACTIVE" in cp:
+    cyc = c("k_phase", "GRBM_GUI_ACTIVE") / 8.0  # summed over the 8 XCDs
+    n_simd = 1024
+    valu, salu = c("k_phase", "SQ_INSTS_VALU"), c("k_phase", "SQ_INSTS_SALU")
+    dn = line["config"]["dnms_per_gpu"]
+    st = line["calls"]["status_counts"]
+    busy = dn - st[2] if len(st) > 2 else dn  # DNMs with candidate sites: the others end at once
+    issue = {"kernel": "k_phase<true> (LDS build)", "dnms": dn, "dnms_with_candidates": busy,
+             "dnms_redone_by_hbm_build": line["calls"].get("dnms_redone_by_hbm_build_of_k_phase"),
+             "wave_instructions_per_launch": {"valu": valu, "salu": salu, "branch": c("k_phase", "SQ_INSTS_BRANCH"),
+                                              "vmem": c("k_phase", "SQ_INSTS_VMEM"), "lds": c("k_phase", "SQ_INSTS_LDS"),
+                                              "smem": c("k_phase", "SQ_INSTS_SMEM")},
+             "valu_wave_instructions_per_dnm_with_candidates": valu / busy,
+             "shader_cycles_per_launch": cyc, "shader_clock_GHz": cyc / ns, "waves_resident": waves, "waves_per_simd": waves / n_simd,
+             "valu_pipe_busy_frac": 4.0 * valu / (n_simd * cyc), "scalar_pipe_busy_frac": 4.0 * salu / (n_simd * cyc),
+             "valu_lane_utilisation": c("k_phase", "SQ_THREAD_CYCLES_VALU") / (64.0 * c("k_phase", "SQ_ACTIVE_INST_VALU")),
+             "wave_cycles_parked_frac": wait_q / wave_q, "wave_active_frac": c("k_phase", "SQ_ACTIVE_INST_ANY") / wave_q,
+             "icache_miss_rate": c("k_phase", "SQC_ICACHE_MISSES") / max(1.0, c("k_phase", "SQC_ICACHE_REQ")),
+             "ta_busy_frac": c("k_phase", "TA_TA_BUSY_sum") / (256.0 * cyc),
+             "valu_floor_ms": 4.0 * valu / n_simd / (cyc / ns) / 1e6, "avg_ms_rocprof": ns / 1e6,
+             "vgpr": pmc["k_phase"]["vgpr"], "scratch": pmc["k_phase"]["scratch"],
+             "how": how + "; SQ_INSTS_* count wave-instructions, SQ_ACTIVE_* / SQ_WAIT_* are in quad-cycles",
+             "source": "profiles/%s_pmc_summary.json" % rnd}
+    json.dump(issue, open(os.path.join(dst, "phase_issue.json"), "w"), indent=1)
+    print(json.dumps(issue, indent=1))

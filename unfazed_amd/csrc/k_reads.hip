@@ -671,7 +671,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             UZ_TRACE("k_phase");
             hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
             UZ_HIP(hipGetLastError());
-            hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)grid), dim3(WG_NT), 0, c->stream, a);
+            // (the DNMs the first kernel gave up: usually a handful -- two workgroups per CU pull them from the list)
+            hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 2 * st->n_cus)), dim3(WG_NT), 0, c->stream, a);
             UZ_HIP(hipGetLastError());
         }
         UZ_TRACE("after k_phase");
