@@ -239,7 +239,7 @@ def main():
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
             staged_bytes += (int(part.view.n_segs) * 28 + int(part.view.n_cigar_total) * 4 + int(part.view.n_row_units) * 4
-                             + int(part.view.n_seq_units) * 16)
+                             + (int(part.view.n_seq_units) * 8 + int(part.view.n_exc) * 7 if part.view.seq2 else int(part.view.n_seq_units) * 16))
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
         t_dec = time.time() - t_dec
 

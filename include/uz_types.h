@@ -161,6 +161,7 @@ typedef struct uz_reads_view {
  * (UZ_AUX_DECODE_BAD) has l_seq = 0 and n_cigar = 0. */
 #define UZ_ROW_UNITS(l_seq) (((uint32_t)(l_seq) + 31u) >> 5)
 #define UZ_SEQ4_UNIT_BYTES 16
+#define UZ_SEQ2_UNIT_BYTES 8
 #define UZ_QLOW_UNIT_BYTES 4
 
 typedef struct uz_reads_packed_view {
@@ -187,6 +188,16 @@ typedef struct uz_reads_packed_view {
     int64_t n_seq_units;   /* = the same sum over the records that carry bases (= n_row_units when none is UZ_AUX_NO_SEQ) */
     uint32_t n_qnames;
     uint32_t reserved1;
+    /* The bases in TWO bits -- an alternative to seq4 for the host link (exactly one of seq4 / seq2 is non-null when
+     * n_seq_units > 0).  Aligned reads are A/C/G/T but for the odd N: a row stores 2-bit codes (A 0, C 1, G 2, T 3; base k of
+     * a row: byte k>>2, bits 7-6 for k&3 == 0 down to bits 1-0; 8 bytes per unit of 32 bases) and every base that is not one
+     * of the four is listed apart with its BAM 4-bit code (its 2-bit field is 0).  The device expands the rows to seq4 and
+     * patches the listed bases in: lossless, half the bytes of the largest column. */
+    const uint8_t *seq2;      /* [n_seq_units * 8] rows of the records WITHOUT UZ_AUX_NO_SEQ, back to back */
+    const uint32_t *exc_rec;  /* [n_exc] record index, ascending (ties: ascending exc_pos) */
+    const uint16_t *exc_pos;  /* [n_exc] base index within the record */
+    const uint8_t *exc_code;  /* [n_exc] BAM 4-bit code of that base ("=ACMGRSVTWYHKDBN") */
+    int64_t n_exc;
 } uz_reads_packed_view;
 
 /* one batch of DNMs of one kid (one family, one BAM) */

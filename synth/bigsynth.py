@@ -61,13 +61,13 @@ class ClustersS(C.Structure):
                 ("pair_off", C.c_void_p), ("cigar_off", C.c_void_p)]
 
 
-# packed output (GPU): per-record columns, then cigar / seq4 / qlow
+# packed output (GPU): per-record columns, then cigar / seq2 (two-bit base rows) / qlow
 PACKED_COLS = abi.PACKED_RECORD_COLS
 
 
 class OutPackedS(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("start", "end", "tlen", "mate", "qname", "flag", "l_seq", "n_cigar", "mapq", "aux",
-                                          "cigar", "seq4", "qlow")]
+                                          "cigar", "seq2", "qlow")]
 
 
 ASCII_COLS = [("start", np.int32, 1), ("end", np.int32, 1), ("flag", np.uint16, 1), ("mapq", np.uint8, 1),
@@ -270,7 +270,7 @@ class WorkloadOnGpu:
         for name, dt in PACKED_COLS:
             self.out_ptrs[name] = dev.alloc(max(64, n * np.dtype(dt).itemsize + 64))
         self.out_ptrs["cigar"] = dev.alloc(4 * self.n_cigar_total + 64)
-        self.out_ptrs["seq4"] = dev.alloc(16 * self.n_row_units + 64)
+        self.out_ptrs["seq2"] = dev.alloc(8 * self.n_row_units + 64)
         self.out_ptrs["qlow"] = dev.alloc(4 * self.n_row_units + 64)
         for name in self.out_ptrs:
             setattr(O, name, self.out_ptrs[name])
@@ -331,7 +331,7 @@ class WorkloadOnGpu:
             self._cigar_off_h = self.dev.get(self._d_cigar_off, (cl.n + 1,), np.int64)
         g0, g1 = int(self._cigar_off_h[c0]), int(self._cigar_off_h[c1])
         n = r1 - r0
-        h = abi.packed_view_alloc(n, nc, g1 - g0, n * UNITS, alloc)
+        h = abi.packed_view_alloc(n, nc, g1 - g0, n * UNITS, alloc, n_exc=0)
         v = h.view
         v.min_base_qual = self.cfg.min_base_qual
         v.n_qnames = self.n_segs // 2
@@ -343,7 +343,7 @@ class WorkloadOnGpu:
         if g1 > g0:
             self.dev.get_into(h.arrays["cigar"][: g1 - g0], self.out_ptrs["cigar"] + 4 * g0)
         if n:
-            self.dev.get_into(h.arrays["seq4"][: 16 * n * UNITS], self.out_ptrs["seq4"] + 16 * r0 * UNITS)
+            self.dev.get_into(h.arrays["seq2"][: 8 * n * UNITS], self.out_ptrs["seq2"] + 8 * r0 * UNITS)
             self.dev.get_into(h.arrays["qlow"][: 4 * n * UNITS], self.out_ptrs["qlow"] + 4 * r0 * UNITS)
             h.arrays["mate"][:n] -= r0
         return h

@@ -69,7 +69,7 @@ typedef struct uzs_out_packed { /* uz_reads_packed_view columns */
     uint16_t *flag, *l_seq, *n_cigar;
     uint8_t *mapq, *aux;
     uint32_t *cigar; /* back to back */
-    uint8_t *seq4;   /* UZS_UNITS * 16 bytes per record */
+    uint8_t *seq2;   /* UZS_UNITS * 8 bytes per record: two-bit base rows (the generator writes A/C/G/T only: no listed bases) */
     uint8_t *qlow;   /* UZS_UNITS * 4 bytes per record */
 } uzs_out_packed;
 

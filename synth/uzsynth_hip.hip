@@ -26,17 +26,18 @@ __global__ __launch_bounds__(UZS_NT) void k_count_ops(uzs_cfg cf, uzs_clusters C
     }
 }
 
-// pack 32 bases / qualities (n valid) into 16 + 4 bytes of the staged format
-__device__ __forceinline__ void pack_unit(const uint8_t *sq, const uint8_t *ql, int n, int thr, uint4 *seq4, uint32_t *qlow) {
-    uint32_t w[4] = {0, 0, 0, 0}, qw = 0;
+// pack 32 bases / qualities (n valid) into 8 + 4 bytes of the staged format (two-bit base rows: A 0, C 1, G 2, T 3, the
+// first base of a byte in its top bits; uzs_fill writes nothing else)
+__device__ __forceinline__ void pack_unit(const uint8_t *sq, const uint8_t *ql, int n, int thr, uint2 *seq2, uint32_t *qlow) {
+    uint32_t w[2] = {0, 0}, qw = 0;
     for (int k = 0; k < n; k++) {
         const uint8_t b = sq[k];
-        const uint32_t code = b == 'A' ? 1u : (b == 'C' ? 2u : (b == 'G' ? 4u : (b == 'T' ? 8u : 15u)));
-        const int byte = k >> 1; // byte `byte` of the 16: high nibble first
-        w[byte >> 2] |= (code << ((k & 1) ? 0 : 4)) << (8 * (byte & 3));
+        const uint32_t code = b == 'C' ? 1u : (b == 'G' ? 2u : (b == 'T' ? 3u : 0u));
+        const int byte = k >> 2;
+        w[byte >> 2] |= (code << (6 - 2 * (k & 3))) << (8 * (byte & 3));
         qw |= (uint32_t)((int)ql[k] < thr) << k;
     }
-    *seq4 = make_uint4(w[0], w[1], w[2], w[3]);
+    *seq2 = make_uint2(w[0], w[1]);
     *qlow = qw;
 }
 
@@ -131,11 +132,11 @@ __global__ __launch_bounds__(UZS_NT) void k_gen_clusters(uzs_cfg cf, uzs_sites S
             int i1 = i0 + 32;
             if (i1 > UZS_READLEN) i1 = UZS_READLEN;
             uzs_fill(&S, &C, &D, c, &s, win[0], win[1], i0, i1, sq, ql);
-            uint4 a;
+            uint2 a;
             uint32_t b;
             pack_unit(sq, ql, i1 - i0, cf.min_base_qual, &a, &b);
             const int64_t unit = (rec0 + p) * UZS_UNITS + u;
-            *reinterpret_cast<uint4 *>(o.seq4 + unit * 16) = a;
+            *reinterpret_cast<uint2 *>(o.seq2 + unit * 8) = a;
             *reinterpret_cast<uint32_t *>(o.qlow + unit * 4) = b;
         }
     }

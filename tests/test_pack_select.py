@@ -5,6 +5,7 @@
  * the read stage sees nothing else: the oracle on the selected records gives, per DNM, what it gives on the whole
    table (benchmark-scale generator, DNM chunks cut inside clusters)."""
 import numpy as np
+import pytest
 
 from oracle import oracle as orc
 from synth import bigsynth
@@ -23,6 +24,13 @@ def _workload(n_dnms=260, seed=7):
     cfg = bigsynth.make_cfg(seed=seed + 2)
     cfg.n_clusters = cl.n
     rh, arrs = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, cl.n, threads=4)
+    # the generator writes A/C/G/T only: sprinkle the other BAM codes (the two-bit rows list them apart)
+    rng = np.random.default_rng(seed + 3)
+    n = int(rh.view.n_segs)
+    for i in rng.integers(0, n, max(4, n // 40)):
+        ls, r0 = int(arrs["l_seq"][i]), int(arrs["sq_off16"][i]) * 16
+        for k in rng.integers(0, ls, int(rng.integers(1, 4))):
+            arrs["seq"][r0 + k] = LUT[int(rng.choice([15, 15, 15, 5, 0, 14]))]
     return sc, dn, cl, rh, arrs
 
 
@@ -43,16 +51,30 @@ def _unpack_row(pk, uoff, i, ls, soff=None):
     soff = uoff if soff is None else soff
     seq = None
     if not (pk.arrays["aux"][i] & abi.AUX_NO_SEQ):
-        row = pk.arrays["seq4"][soff[i] * 16: (soff[i] + u) * 16]
-        seq = LUT[np.stack([row >> 4, row & 15], 1).ravel()[:ls]]
+        if "seq4" in pk.arrays:
+            row = pk.arrays["seq4"][soff[i] * 16: (soff[i] + u) * 16]
+            seq = LUT[np.stack([row >> 4, row & 15], 1).ravel()[:ls]]
+        else:  # two-bit rows (first base in the top bits of a byte) + the listed bases
+            row = pk.arrays["seq2"][soff[i] * 8: (soff[i] + u) * 8]
+            codes = np.stack([row >> 6, (row >> 4) & 3, (row >> 2) & 3, row & 3], 1).ravel()[:ls]
+            seq = LUT[1 << codes].copy()
+            ne = int(pk.view.n_exc)
+            er = pk.arrays["exc_rec"][:ne]
+            a, b = np.searchsorted(er, i, "left"), np.searchsorted(er, i, "right")
+            assert (codes[pk.arrays["exc_pos"][a:b]] == 0).all()
+            seq[pk.arrays["exc_pos"][a:b]] = LUT[pk.arrays["exc_code"][a:b]]
     low = np.unpackbits(pk.arrays["qlow"][uoff[i] * 4: (uoff[i] + u) * 4], bitorder="little")[:ls]
     return seq, low
 
 
-def test_pack_matches_ascii_columns():
+@pytest.mark.parametrize("two_bit", [True, False])
+def test_pack_matches_ascii_columns(two_bit):
     sc, dn, cl, rh, arrs = _workload(60)
     for thr in (20, 13, 0, 300):
-        pk = io_native.pack_reads(rh, thr)
+        pk = io_native.pack_reads(rh, thr, two_bit=two_bit)
+        if two_bit:
+            n_other = int((~np.isin(arrs["seq"], LUT[[1, 2, 4, 8]])).sum())  # (rows are written back to back: every byte is a base)
+            assert pk.view.n_exc >= 4 and pk.view.n_exc <= n_other and np.all(np.diff(pk.arrays["exc_rec"][: pk.view.n_exc].astype(np.int64)) >= 0)
         n = int(rh.view.n_segs)
         assert pk.view.n_segs == n and pk.view.min_base_qual == thr
         for name, _ in abi.PACKED_RECORD_COLS:
@@ -108,7 +130,8 @@ def _subset_ascii(arrs, idx, n_contigs):
     return abi.Held(v, out)
 
 
-def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else():
+@pytest.mark.parametrize("two_bit", [True, False])
+def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(two_bit):
     sc, dn, cl, rh, arrs = _workload(260)
     n, nc = dn.n, len(sc.contig_off) - 1
     P = abi.make_params()
@@ -119,7 +142,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
     co, ci, cf, ho, hi = found
     want = orc.phase(P, sh, rh, dv, found, keep_lists=True)
     assert (want["status"] == abi.ST_OK).sum() > 30
-    pk = io_native.pack_reads(rh, P.min_gt_qual)
+    pk = io_native.pack_reads(rh, P.min_gt_qual, two_bit=two_bit)
     src = io_native.ReadsSource(pk)
     N = int(rh.view.n_segs)
     contig_of_rec = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1

@@ -153,6 +153,12 @@ class ReadsPackedView(C.Structure):
         ("n_seq_units", C.c_int64),
         ("n_qnames", C.c_uint32),
         ("reserved1", C.c_uint32),
+        # two-bit base rows for the host link (instead of seq4) + the listed bases that are not A/C/G/T
+        ("seq2", _p),
+        ("exc_rec", _p),
+        ("exc_pos", _p),
+        ("exc_code", _p),
+        ("n_exc", C.c_int64),
     ]
 
 
@@ -160,16 +166,17 @@ AUX_NO_SEQ = 8
 # per-record columns of the packed view and their element types
 PACKED_RECORD_COLS = [("start", np.int32), ("end", np.int32), ("tlen", np.int32), ("mate", np.int32), ("qname", np.uint32),
                       ("flag", np.uint16), ("l_seq", np.uint16), ("n_cigar", np.uint16), ("mapq", np.uint8), ("aux", np.uint8)]
-SEQ4_UNIT_BYTES, QLOW_UNIT_BYTES = 16, 4
+SEQ4_UNIT_BYTES, QLOW_UNIT_BYTES, SEQ2_UNIT_BYTES = 16, 4, 8
 
 
 def row_units(l_seq):
     return (np.asarray(l_seq).astype(np.int64) + 31) >> 5
 
 
-def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None) -> "Held":
+def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
-    n_seq_units: row units of the records that carry bases (default: all of them)."""
+    n_seq_units: row units of the records that carry bases (default: all of them).
+    n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*)."""
     if n_seq_units is None:
         n_seq_units = n_row_units
     if alloc is None:
@@ -180,10 +187,17 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     arrs["contig_off"] = alloc(8 * (n_contigs + 1))[: 8 * (n_contigs + 1)].view(np.int64)
     arrs["max_span"] = alloc(4 * max(1, n_contigs))[: 4 * max(1, n_contigs)].view(np.int32)
     arrs["cigar"] = alloc(4 * max(1, n_cigar_total))[: 4 * max(1, n_cigar_total)].view(np.uint32)
-    arrs["seq4"] = alloc(SEQ4_UNIT_BYTES * max(1, n_seq_units))[: SEQ4_UNIT_BYTES * max(1, n_seq_units)]
+    if n_exc is None:
+        arrs["seq4"] = alloc(SEQ4_UNIT_BYTES * max(1, n_seq_units))[: SEQ4_UNIT_BYTES * max(1, n_seq_units)]
+    else:
+        arrs["seq2"] = alloc(SEQ2_UNIT_BYTES * max(1, n_seq_units))[: SEQ2_UNIT_BYTES * max(1, n_seq_units)]
+        arrs["exc_rec"] = alloc(4 * max(1, n_exc))[: 4 * max(1, n_exc)].view(np.uint32)
+        arrs["exc_pos"] = alloc(2 * max(1, n_exc))[: 2 * max(1, n_exc)].view(np.uint16)
+        arrs["exc_code"] = alloc(max(1, n_exc))[: max(1, n_exc)]
     arrs["qlow"] = alloc(QLOW_UNIT_BYTES * max(1, n_row_units))[: QLOW_UNIT_BYTES * max(1, n_row_units)]
     v = ReadsPackedView()
     v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units, v.n_seq_units = n, n_contigs, n_cigar_total, n_row_units, n_seq_units
+    v.n_exc = 0 if n_exc is None else n_exc
     for k, a in arrs.items():
         setattr(v, k, a.ctypes.data)
     return Held(v, arrs)

@@ -418,6 +418,9 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_cigar_total >= 0 && v->n_cigar_total < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
     UZ_REQUIRE(v->n_row_units >= 0 && v->n_row_units < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 row units (2^37 bases)");
     UZ_REQUIRE(v->n_seq_units >= 0 && v->n_seq_units <= v->n_row_units, UZ_E_ARG, "n_seq_units must lie in [0, n_row_units]");
+    UZ_REQUIRE(!(v->seq2 && v->seq4), UZ_E_ARG, "a packed table has four-bit (seq4) OR two-bit (seq2) base rows, not both");
+    UZ_REQUIRE(v->n_seq_units == 0 || v->seq2 || v->seq4, UZ_E_ARG, "n_seq_units > 0 but neither seq4 nor seq2 is set");
+    if (v->seq2) UZ_REQUIRE(v->n_exc >= 0 && (v->n_exc == 0 || (v->exc_rec && v->exc_pos && v->exc_code)), UZ_E_ARG, "bad exc_* columns");
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
@@ -427,7 +430,10 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
     r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
     const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units, ns = (size_t)r.n_seq_units;
-    uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr;
+    const bool two_bit = v->seq2 != nullptr;
+    const size_t ne = two_bit ? (size_t)v->n_exc : 0;
+    uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq2 = nullptr;
+    uint32_t *exc_rec = nullptr; uint16_t *exc_pos = nullptr; uint8_t *exc_code = nullptr;
     int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
     void *scratch = nullptr;
     for (int pass = 0; pass < 2; pass++) {
@@ -436,6 +442,10 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         cigar = cv.take<uint32_t>(nc);
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
         qlow = cv.take<uint8_t>(nu * UZ_QLOW_UNIT_BYTES);
+        if (two_bit) {
+            seq2 = cv.take<uint8_t>(ns * UZ_SEQ2_UNIT_BYTES);
+            exc_rec = cv.take<uint32_t>(ne); exc_pos = cv.take<uint16_t>(ne); exc_code = cv.take<uint8_t>(ne);
+        }
         start = cv.take<int32_t>(n); end = cv.take<int32_t>(n); tlen = cv.take<int32_t>(n); mate = cv.take<int32_t>(n);
         qname = cv.take<uint32_t>(n); flag = cv.take<uint16_t>(n); l_seq = cv.take<uint16_t>(n); n_cigar = cv.take<uint16_t>(n);
         mapq = cv.take<uint8_t>(n); aux = cv.take<uint8_t>(n);
@@ -450,7 +460,13 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
     col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
     r.cigar = h2d(st, cigar, v->cigar, nc);
-    r.seq4 = h2d(st, seq4, v->seq4, ns * UZ_SEQ4_UNIT_BYTES);
+    if (two_bit) { // half the bytes over the link; the header build expands them into seq4
+        r.seq4 = seq4;
+        r.seq2_staged = h2d(st, seq2, v->seq2, ns * UZ_SEQ2_UNIT_BYTES);
+        r.n_exc = (int64_t)ne;
+        r.exc_rec = h2d(st, exc_rec, v->exc_rec, ne); r.exc_pos = h2d(st, exc_pos, v->exc_pos, ne); r.exc_code = h2d(st, exc_code, v->exc_code, ne);
+    } else
+        r.seq4 = h2d(st, seq4, v->seq4, ns * UZ_SEQ4_UNIT_BYTES);
     r.qlow = qlow;
     h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
     r.qlow_thr = v->min_base_qual;
@@ -578,15 +594,17 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
         check_packed_view(v);
-        UZ_REQUIRE(((uintptr_t)v->qlow | (uintptr_t)v->seq4 | (uintptr_t)v->cigar) % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
+        UZ_REQUIRE(((uintptr_t)v->qlow | (uintptr_t)v->seq4 | (uintptr_t)v->seq2 | (uintptr_t)v->cigar) % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
         ReadsDev r;
         r.live = true;
         r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
         r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
         void *scratch = nullptr;
+        uint8_t *seq4_own = nullptr; // two-bit rows are expanded into the library's own block
         for (int pass = 0; pass < 2; pass++) {
             Carver cv(pass ? r.block.p : nullptr);
             carve_common(cv, r);
+            if (v->seq2) seq4_own = cv.take<uint8_t>((size_t)r.n_seq_units * UZ_SEQ4_UNIT_BYTES);
             scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
             if (!pass) r.block = uz_block_get(c, cv.off + 256);
         }
@@ -598,14 +616,21 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             col.start = v->start; col.end = v->end; col.tlen = v->tlen; col.mate = v->mate; col.qname = v->qname;
             col.flag = v->flag; col.l_seq = v->l_seq; col.n_cigar = v->n_cigar; col.mapq = v->mapq; col.aux = v->aux;
             r.cigar = v->cigar; r.seq4 = v->seq4; r.qlow = const_cast<uint8_t *>(v->qlow);
+            if (v->seq2) {
+                r.seq4 = seq4_own; r.seq2_staged = v->seq2;
+                r.n_exc = v->n_exc; r.exc_rec = v->exc_rec; r.exc_pos = v->exc_pos; r.exc_code = v->exc_code;
+            }
             r.qlow_thr = v->min_base_qual;
             r.qlow_valid = true;
             UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, st));
             uz_build_records(c, st, r, col, scratch);
             UZ_HIP(hipStreamSynchronize(st));
+            r.exc_rec = nullptr; r.exc_pos = nullptr; r.exc_code = nullptr; r.n_exc = 0; // (the caller's memory: not kept)
             if (c->hflags[0]) {
+                const int f = c->hflags[0];
                 c->hflags[0] = 0;
-                throw UzError{UZ_E_RANGE, "n_cigar_total / n_row_units of the reads view do not match its columns"};
+                throw UzError{UZ_E_RANGE, f == 3 ? "exc_* columns: an entry names a record without bases, a base beyond l_seq or a code above 15"
+                                                 : "n_cigar_total / n_row_units of the reads view do not match its columns"};
             }
         } catch (...) { uz_block_put(c, r.block); throw; }
         const int k = new_slot(c->reads);

@@ -73,6 +73,8 @@ struct uz_select {
     uint64_t n_cigar = 0, n_units = 0, n_seq = 0;
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
     std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
+    std::vector<int64_t> exc_lo, exc_n; // seq2 sources: per kept record, its slice of the source's exception list (0 entries without bases)
+    int64_t n_exc = 0;
 };
 
 extern "C" {
@@ -83,6 +85,27 @@ int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t
         uint64_t a = 0, b = 0;
         for (int64_t i = 0; i < in->n_segs; i++) { a += in->n_cigar[i]; b += UZ_ROW_UNITS(in->l_seq[i]); }
         *n_cigar_total = (int64_t)a; *n_row_units = (int64_t)b;
+    });
+}
+
+int uz_reads_pack_exceptions(const uz_reads_view *in, int threads, int64_t *n_exc) {
+    return guarded([&] {
+        if (!in || !n_exc) fail(UZ_IO_E_ARG, "null argument");
+        threads = resolve_threads(threads);
+        const int64_t n = in->n_segs;
+        const int wk = workers_for(n, threads, 4096);
+        std::vector<int64_t> part((size_t)wk + 1, 0);
+        parallel_slices(n, wk, [&](int64_t lo, int64_t hi, int k) {
+            int64_t c = 0;
+            for (int64_t i = lo; i < hi; i++) {
+                const uint8_t *sq = in->seq + ((size_t)in->sq_off16[i] << 4);
+                for (int b = 0; b < (int)in->l_seq[i]; b++) c += uz_ascii_seq2(sq[b]) == 0xFF;
+            }
+            part[(size_t)k] = c;
+        });
+        int64_t tot = 0;
+        for (int k = 0; k < wk; k++) tot += part[(size_t)k];
+        *n_exc = tot;
     });
 }
 
@@ -103,7 +126,13 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
         if (in->n_contigs) memcpy(w(out->max_span), in->max_span, (size_t)in->n_contigs * sizeof(int32_t));
         const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
         std::atomic<int> bad{0};
-        parallel_slices(n, workers_for(n, threads, 4096), [&](int64_t lo, int64_t hi, int) {
+        const bool two_bit = out->seq2 != nullptr;
+        const int wk_pack = workers_for(n, threads, 4096);
+        // two-bit rows: the bases that are not A/C/G/T, per slice (slices are contiguous record ranges, so their lists joined in
+        // slice order are sorted by record)
+        struct Exc { uint32_t rec; uint16_t pos; uint8_t code; };
+        std::vector<std::vector<Exc>> exc((size_t)wk_pack);
+        parallel_slices(n, wk_pack, [&](int64_t lo, int64_t hi, int slice) {
             for (int64_t i = lo; i < hi; i++) {
                 w(out->start)[i] = in->start[i]; w(out->end)[i] = in->end[i]; w(out->tlen)[i] = in->tlen[i];
                 w(out->mate)[i] = in->mate[i]; w(out->qname)[i] = in->qname[i]; w(out->flag)[i] = in->flag[i];
@@ -111,12 +140,27 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
                 w(out->aux)[i] = in->aux[i];
                 for (int k = 0; k < (int)in->n_cigar[i]; k++) w(out->cigar)[coff[i] + k] = in->cigar[(size_t)in->cigar_off[i] + k];
                 const size_t row = (size_t)in->sq_off16[i] << 4;
-                if (uz_pack_rows_host(in->seq + row, in->qual + row, in->l_seq[i], thr, w(out->seq4) + uoff[i] * UZ_SEQ4_UNIT_BYTES,
-                                      w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES) != 0)
-                    bad.store(1);
+                int rc;
+                if (two_bit)
+                    rc = uz_pack_rows_host2(in->seq + row, in->qual + row, in->l_seq[i], thr, w(out->seq2) + uoff[i] * UZ_SEQ2_UNIT_BYTES,
+                                            w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES,
+                                            [&](int pos, uint8_t code) { exc[(size_t)slice].push_back(Exc{(uint32_t)i, (uint16_t)pos, code}); });
+                else
+                    rc = uz_pack_rows_host(in->seq + row, in->qual + row, in->l_seq[i], thr, w(out->seq4) + uoff[i] * UZ_SEQ4_UNIT_BYTES,
+                                           w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES);
+                if (rc != 0) bad.store(1);
             }
         });
         if (bad.load()) fail(UZ_IO_E_RANGE, "SEQ holds a character outside BAM's 16-code alphabet");
+        if (two_bit) {
+            int64_t tot = 0;
+            for (auto &e : exc) tot += (int64_t)e.size();
+            if (tot != out->n_exc) fail(UZ_IO_E_ARG, "output view sized for %lld listed bases, the table has %lld (uz_reads_pack_exceptions)", (long long)out->n_exc, (long long)tot);
+            int64_t at = 0;
+            for (auto &e : exc)
+                for (const Exc &x : e) { w(out->exc_rec)[at] = x.rec; w(out->exc_pos)[at] = x.pos; w(out->exc_code)[at] = x.code; at++; }
+        } else
+            out->n_exc = 0;
     });
 }
 
@@ -130,6 +174,9 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
         offsets(full->n_segs, full->n_cigar, full->l_seq, full->aux, threads, coff, uoff, soff);
         if (coff.back() >= ((uint64_t)1 << 32) || uoff.back() >= ((uint64_t)1 << 32)) { delete src; fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets"); }
         if ((int64_t)soff.back() != full->n_seq_units) { delete src; fail(UZ_IO_E_ARG, "n_seq_units does not match the aux column"); }
+        if (full->seq2 && full->n_exc > 0)
+            for (int64_t e = 1; e < full->n_exc; e++)
+                if (full->exc_rec[e] < full->exc_rec[e - 1]) { delete src; fail(UZ_IO_E_ARG, "exc_rec is not ascending"); }
         src->coff.assign(coff.begin(), coff.end());
         src->uoff.assign(uoff.begin(), uoff.end());
         src->soff.assign(soff.begin(), soff.end());
@@ -208,6 +255,18 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 if (bases) sel->n_seq += UZ_ROW_UNITS(full->l_seq[i]);
             }
         sel->n_sel = (int64_t)sel->index.size();
+        if (full->seq2) { // the listed bases of the kept records that keep their bases
+            sel->exc_lo.assign((size_t)sel->n_sel, 0);
+            sel->exc_n.assign((size_t)sel->n_sel, 0);
+            const uint32_t *er = full->exc_rec;
+            for (int64_t k = 0; k < sel->n_sel && full->n_exc > 0; k++) {
+                if (!sel->bases[(size_t)k]) continue;
+                const uint32_t i = (uint32_t)sel->index[(size_t)k];
+                const uint32_t *a = std::lower_bound(er, er + full->n_exc, i), *b = std::upper_bound(a, er + full->n_exc, i);
+                sel->exc_lo[(size_t)k] = a - er; sel->exc_n[(size_t)k] = b - a;
+                sel->n_exc += b - a;
+            }
+        }
         *out = sel;
     });
 }
@@ -216,6 +275,7 @@ int64_t uz_select_n_records(const uz_select *s) { return s ? s->n_sel : 0; }
 int64_t uz_select_n_cigar_total(const uz_select *s) { return s ? (int64_t)s->n_cigar : 0; }
 int64_t uz_select_n_row_units(const uz_select *s) { return s ? (int64_t)s->n_units : 0; }
 int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq : 0; }
+int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
 void uz_select_free(uz_select *s) { delete s; }
 
 int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *out, int32_t *orig_index) {
@@ -227,6 +287,15 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         const int64_t m = s->n_sel;
         out->n_segs = m; out->n_contigs = full->n_contigs; out->min_base_qual = full->min_base_qual; out->n_qnames = full->n_qnames;
         out->n_cigar_total = (int64_t)s->n_cigar; out->n_row_units = (int64_t)s->n_units; out->n_seq_units = (int64_t)s->n_seq;
+        const bool two_bit = full->seq2 != nullptr;
+        if (two_bit && !out->seq2) fail(UZ_IO_E_ARG, "the source table has two-bit base rows: the output view needs seq2 (and the exc_* columns)");
+        if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
+        out->n_exc = two_bit ? s->n_exc : 0;
+        std::vector<int64_t> oe;
+        if (two_bit) {
+            oe.assign((size_t)m + 1, 0);
+            for (int64_t k = 0; k < m; k++) oe[(size_t)k + 1] = oe[(size_t)k] + s->exc_n[(size_t)k];
+        }
         for (int c = 0; c <= full->n_contigs; c++)
             w(out->contig_off)[c] = std::lower_bound(s->index.begin(), s->index.end(), full->contig_off[c],
                                                      [](int32_t v, int64_t key) { return (int64_t)v < key; }) - s->index.begin();
@@ -262,7 +331,16 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 w(out->aux)[k] = (uint8_t)(s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ));
                 memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
                 const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
-                if (s->bases[k]) memcpy(w(out->seq4) + os[k] * UZ_SEQ4_UNIT_BYTES, full->seq4 + (size_t)src->soff[i] * UZ_SEQ4_UNIT_BYTES, units * UZ_SEQ4_UNIT_BYTES);
+                if (s->bases[k]) {
+                    if (two_bit) {
+                        memcpy(w(out->seq2) + os[k] * UZ_SEQ2_UNIT_BYTES, full->seq2 + (size_t)src->soff[i] * UZ_SEQ2_UNIT_BYTES, units * UZ_SEQ2_UNIT_BYTES);
+                        for (int64_t e = 0; e < s->exc_n[(size_t)k]; e++) {
+                            const int64_t from = s->exc_lo[(size_t)k] + e, to = oe[(size_t)k] + e;
+                            w(out->exc_rec)[to] = (uint32_t)k; w(out->exc_pos)[to] = full->exc_pos[from]; w(out->exc_code)[to] = full->exc_code[from];
+                        }
+                    } else
+                        memcpy(w(out->seq4) + os[k] * UZ_SEQ4_UNIT_BYTES, full->seq4 + (size_t)src->soff[i] * UZ_SEQ4_UNIT_BYTES, units * UZ_SEQ4_UNIT_BYTES);
+                }
                 memcpy(w(out->qlow) + ou[k] * UZ_QLOW_UNIT_BYTES, full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES, units * UZ_QLOW_UNIT_BYTES);
                 if (orig_index) orig_index[k] = (int32_t)i;
             }

@@ -377,6 +377,38 @@ int next_pow2(long long v) {
 
 } // namespace
 
+namespace {
+// two-bit base rows of the host link -> the four-bit rows the kernels read: one lane per 8 staged bytes (32 bases),
+// a pure streaming map (8 B in, 16 B out); the padding of a record's last unit expands to code 1 and is never read
+__global__ __launch_bounds__(256) void k_expand_seq2(const unsigned long long *__restrict__ in, uint4 *__restrict__ out, size_t n_units) {
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < n_units; u += (size_t)gridDim.x * 256) {
+        const unsigned long long w = in[u]; // little-endian: byte b of the row = bits 8b..8b+7
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t lo = uz_seq2_expand_byte((uint32_t)(w >> (16 * q)) & 0xFFu), hi = uz_seq2_expand_byte((uint32_t)(w >> (16 * q + 8)) & 0xFFu);
+            o[q] = lo | (hi << 16);
+        }
+        out[u] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+// the listed bases (not A/C/G/T): their BAM codes written over the expanded rows; every entry owns its nibble
+__global__ __launch_bounds__(256) void k_patch_exc(int64_t n_exc, const uint32_t *__restrict__ rec, const uint16_t *__restrict__ pos,
+                                                   const uint8_t *__restrict__ code, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
+                                                   int64_t n, uint32_t *seq4_words, int32_t *hflags) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_exc) return;
+    const uint32_t i = rec[e];
+    const uint32_t k = pos[e];
+    if ((int64_t)i >= n || k >= rb[i].l_seq || ra[i].sq_off == UZ_NO_SEQ_OFF || code[e] > 15) { hflags[0] = 3; return; }
+    const size_t byte = (size_t)ra[i].sq_off * UZ_SEQ4_UNIT_BYTES + (k >> 1);
+    const int sh = (int)(8 * (byte & 3)) + ((k & 1) ? 0 : 4);
+    uint32_t *wd = seq4_words + (byte >> 2);
+    atomicAnd(wd, ~(15u << sh));
+    atomicOr(wd, (uint32_t)code[e] << sh);
+}
+} // namespace
+
 size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * 3 * sizeof(unsigned long long); }
 
 void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col, void *off_scratch) {
@@ -391,6 +423,17 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
                        (RecB *)r.rec_b, r.fm, r.qoff, r.k3);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
+    if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
+        if (r.n_seq_units > 0) {
+            const size_t nu = (size_t)r.n_seq_units;
+            hipLaunchKernelGGL(k_expand_seq2, dim3((unsigned)std::min<size_t>((nu + 255) / 256, 16384)), dim3(256), 0, st,
+                               (const unsigned long long *)r.seq2_staged, (uint4 *)const_cast<uint8_t *>(r.seq4), nu);
+            if (r.n_exc > 0)
+                hipLaunchKernelGGL(k_patch_exc, dim3((unsigned)((r.n_exc + 255) / 256)), dim3(256), 0, st, r.n_exc, r.exc_rec, r.exc_pos, r.exc_code,
+                                   (const RecA *)r.rec_a, (const RecB *)r.rec_b, (int64_t)r.n, (uint32_t *)const_cast<uint8_t *>(r.seq4), c->hflags);
+        }
+        r.seq2_staged = nullptr;
+    }
     UZ_HIP(hipGetLastError());
 }
 
@@ -541,7 +584,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         const int f = c->hflags[0];
         c->hflags[0] = 0;
         throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
-                                         : "n_cigar_total / n_row_units of the reads view do not match its columns"};
+                                  : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
+                                           : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
     for (int32_t d = 0; d < n; d++) {

@@ -43,6 +43,26 @@ UZP_HD uint32_t uz_qlow_bit(const uint8_t *qlow, uint32_t unit, int k) {
     return (uint32_t)(qlow[(size_t)unit * UZ_QLOW_UNIT_BYTES + (size_t)(k >> 3)] >> (k & 7)) & 1u;
 }
 
+// ---- the two-bit rows of the host link (uz_reads_packed_view.seq2)
+// A 0, C 1, G 2, T 3; 0xFF for any other character
+UZP_HD uint8_t uz_ascii_seq2(uint8_t ch) {
+    switch (ch) {
+    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+    default: return 0xFF;
+    }
+}
+// one byte of a seq2 row (four bases, first base in bits 7-6) -> the two bytes of the seq4 row that hold them
+// (little-endian 16 bits: low byte = bases 0 and 1).  Code c becomes the BAM code 1 << c (A 1, C 2, G 4, T 8).
+UZP_HD uint32_t uz_seq2_expand_byte(uint32_t v) {
+    const uint32_t n0 = 1u << ((v >> 6) & 3u), n1 = 1u << ((v >> 4) & 3u), n2 = 1u << ((v >> 2) & 3u), n3 = 1u << (v & 3u);
+    return ((n0 << 4) | n1) | (((n2 << 4) | n3) << 8);
+}
+// base k of the seq2 row that starts at unit `unit` (ASCII; a listed exception is NOT applied here)
+UZP_HD uint8_t uz_seq2_base(const uint8_t *seq2, uint32_t unit, int k) {
+    const uint8_t b = seq2[(size_t)unit * UZ_SEQ2_UNIT_BYTES + (size_t)(k >> 2)];
+    return uz_nt16_ascii(1u << ((b >> (6 - 2 * (k & 3))) & 3u));
+}
+
 // Host-side packing of one record's rows (decoders, tests, the CPU twin).  seq: ASCII, qual: bytes; dst rows
 // hold UZ_ROW_UNITS(l_seq) units and are fully written (padding zero).  Returns 0, or -1 for a character
 // outside the alphabet.
@@ -56,6 +76,27 @@ static inline int uz_pack_rows_host(const uint8_t *seq, const uint8_t *qual, int
         const uint8_t c = uz_ascii_nt16(seq[k]);
         if (c == 0xFF) bad = -1;
         seq4_row[k >> 1] |= (uint8_t)((c & 15u) << ((k & 1) ? 0 : 4));
+        if ((int)qual[k] < min_base_qual) qlow_row[k >> 3] |= (uint8_t)(1u << (k & 7));
+    }
+    return bad;
+}
+
+// The same with two-bit base rows: bases other than A/C/G/T are handed to `exc(pos, code)` (code = BAM 4-bit) and stored as 0.
+// Returns 0, or -1 for a character outside BAM's alphabet.
+template <typename F>
+static inline int uz_pack_rows_host2(const uint8_t *seq, const uint8_t *qual, int l_seq, int min_base_qual, uint8_t *seq2_row,
+                                     uint8_t *qlow_row, F &&exc) {
+    const uint32_t units = UZ_ROW_UNITS(l_seq);
+    for (uint32_t b = 0; b < units * UZ_SEQ2_UNIT_BYTES; b++) seq2_row[b] = 0;
+    for (uint32_t b = 0; b < units * UZ_QLOW_UNIT_BYTES; b++) qlow_row[b] = 0;
+    int bad = 0;
+    for (int k = 0; k < l_seq; k++) {
+        const uint8_t c2 = uz_ascii_seq2(seq[k]);
+        if (c2 != 0xFF) seq2_row[k >> 2] |= (uint8_t)(c2 << (6 - 2 * (k & 3)));
+        else {
+            const uint8_t c4 = uz_ascii_nt16(seq[k]);
+            if (c4 == 0xFF) bad = -1; else exc(k, c4);
+        }
         if ((int)qual[k] < min_base_qual) qlow_row[k >> 3] |= (uint8_t)(1u << (k & 7));
     }
     return bad;

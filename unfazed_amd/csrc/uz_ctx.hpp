@@ -108,6 +108,13 @@ struct ReadsDev {
     // would wait behind the persistent per-DNM grid and hold up the next table's copies
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
+    // a table that arrived with two-bit base rows (uz_reads_packed_view.seq2): the staged rows and the listed bases, expanded
+    // into seq4 by the header build (uz_build_records); null afterwards / for four-bit tables
+    const uint8_t *seq2_staged = nullptr;
+    const uint32_t *exc_rec = nullptr;
+    const uint16_t *exc_pos = nullptr;
+    const uint8_t *exc_code = nullptr;
+    int64_t n_exc = 0;
     bool qc_valid = false;
     uz_params qc_params;
 };

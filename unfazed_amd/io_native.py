@@ -26,9 +26,9 @@ IO_EXPORTS = [
     "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
-    "uz_reads_pack_sizes", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_reads_select_fill",
-    "uz_select_free",
+    "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc",
+    "uz_reads_select_fill", "uz_select_free",
 ]
 
 
@@ -100,7 +100,8 @@ def load():
     lib.uz_reads_source_close.argtypes = [C.c_void_p]
     lib.uz_reads_source_close.restype = None
     lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
-    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units):
+    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units,
+               lib.uz_select_n_exc):
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int64
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -284,13 +285,20 @@ def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
 
 
 # ---------------------------------------------------------------------------- staged (packed) records
-def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=None) -> "abi.Held":
+def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=None, two_bit: bool = True) -> "abi.Held":
     """ASCII table (abi.reads_view / a decoder's view) -> the packed form uz_reads_upload_packed takes, for the
-    base-quality threshold of the run.  alloc(nbytes) -> uint8 array chooses the memory (pinned for the upload)."""
+    base-quality threshold of the run.  alloc(nbytes) -> uint8 array chooses the memory (pinned for the upload).
+    two_bit: base rows in two bits + the listed bases that are not A/C/G/T (half the bytes of the largest column on the
+    host link; the device expands them); False = BAM's four-bit codes."""
     lib = load()
     nc, nu = C.c_int64(0), C.c_int64(0)
     _check(lib, lib.uz_reads_pack_sizes(reads.ref(), C.byref(nc), C.byref(nu)))
-    out = abi.packed_view_alloc(int(reads.view.n_segs), int(reads.view.n_contigs), nc.value, nu.value, alloc)
+    n_exc = None
+    if two_bit:
+        ne = C.c_int64(0)
+        _check(lib, lib.uz_reads_pack_exceptions(reads.ref(), int(threads), C.byref(ne)))
+        n_exc = int(ne.value)
+    out = abi.packed_view_alloc(int(reads.view.n_segs), int(reads.view.n_contigs), nc.value, nu.value, alloc, n_exc=n_exc)
     _check(lib, lib.uz_reads_pack(reads.ref(), int(min_base_qual), int(threads), out.ref()))
     return out
 
@@ -317,8 +325,10 @@ class ReadsSource:
                                                        hi.ctypes.data, 1 if all_bases else 0, int(self.threads), C.byref(sel)))
         try:
             n = self.lib.uz_select_n_records(sel)
+            two_bit = bool(self.packed.view.seq2)  # a selection keeps the base-row form of its source
             out = abi.packed_view_alloc(n, int(self.packed.view.n_contigs), self.lib.uz_select_n_cigar_total(sel),
-                                        self.lib.uz_select_n_row_units(sel), alloc, n_seq_units=self.lib.uz_select_n_seq_units(sel))
+                                        self.lib.uz_select_n_row_units(sel), alloc, n_seq_units=self.lib.uz_select_n_seq_units(sel),
+                                        n_exc=int(self.lib.uz_select_n_exc(sel)) if two_bit else None)
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
