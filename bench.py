@@ -234,12 +234,15 @@ def main():
             src = io_native.ReadsSource(part_full)
             fc, flo, fhi = fetch_points(ev.contig[a:b], ev.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P,
                                         vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff)
-            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended))
+            # qualities as counts + short lists for the point-variant batch; the SV batch needs the plane (uz_types.h)
+            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=not cnv)
             del src, part_full
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
-            staged_bytes += (int(part.view.n_segs) * 28 + int(part.view.n_cigar_total) * 4 + int(part.view.n_row_units) * 4
-                             + (int(part.view.n_seq_units) * 8 + int(part.view.n_exc) * 7 if part.view.seq2 else int(part.view.n_seq_units) * 16))
+            pv = part.view
+            staged_bytes += (int(pv.n_segs) * 28 + int(pv.n_cigar_total) * 4
+                             + (int(pv.n_segs) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if pv.n_low else int(pv.n_row_units) * 4)
+                             + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
         t_dec = time.time() - t_dec
 

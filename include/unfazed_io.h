@@ -111,14 +111,19 @@ int uz_vcf_is_bcf(const uz_vcf *h);
  * memory from uz_pinned_alloc for the upload): the `out` view arrives with every pointer set to a WRITABLE
  * buffer of the right size -- [n] for the per-record columns, n_cigar_total words, n_row_units * 16 / * 4 bytes
  * for seq4 / qlow (or n_row_units * 8 for seq2 and n_exc entries of exc_*), [n_contigs + 1] / [n_contigs] for the contig
- * tables -- and the scalar fields are filled in.  A selection keeps the base-row form of its source. */
+ * tables -- and the scalar fields are filled in.  A selection keeps the base-row form of its source; its qualities are
+ * lists when out->n_low is set (from either form of the source), the plane otherwise (plane sources only). */
 /* sizes of the packed form of an ASCII table */
 int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t *n_row_units);
+/* the quality plane as lists (uz_types.h): entries of qlow_pos for the threshold, and whether a read is longer than 256 bases */
+int uz_reads_pack_lists(const uz_reads_view *in, int min_base_qual, int threads, int64_t *n_qlow_pos, int32_t *wide);
 /* number of bases that are not A/C/G/T: the length of the exc_* columns of the two-bit form */
 int uz_reads_pack_exceptions(const uz_reads_view *in, int threads, int64_t *n_exc);
 /* ASCII table -> packed columns for the base-quality threshold `min_base_qual` (= --min-gt-qual);
  * out->n_cigar_total / n_row_units must hold the sizes the buffers were made for.  Base rows: two-bit (out->seq2 set,
- * n_row_units * 8 bytes, plus exc_rec / exc_pos / exc_code of out->n_exc entries) or four-bit (out->seq2 null: out->seq4) */
+ * n_row_units * 8 bytes, plus exc_rec / exc_pos / exc_code of out->n_exc entries) or four-bit (out->seq2 null: out->seq4).
+ * Qualities: lists (out->n_low set: [n], plus qlow_pos of out->n_qlow_pos entries, out->qlow_pos_wide as uz_reads_pack_lists
+ * says) or the plane (out->n_low null: out->qlow, n_row_units * 4 bytes) */
 int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_reads_packed_view *out);
 
 /* Fetch-reach selection: the records `bamfile.fetch(contig, lo, hi)` returns for a list of fetches (start <
@@ -137,6 +142,8 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                          int threads, uz_select **out);
 int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
+int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */
+int uz_select_qlow_pos_wide(const uz_select *s);  /* 1 when a kept read is longer than 256 bases */
 int64_t uz_select_n_records(const uz_select *s);
 int64_t uz_select_n_cigar_total(const uz_select *s);
 int64_t uz_select_n_row_units(const uz_select *s);

@@ -162,6 +162,7 @@ typedef struct uz_reads_view {
 #define UZ_ROW_UNITS(l_seq) (((uint32_t)(l_seq) + 31u) >> 5)
 #define UZ_SEQ4_UNIT_BYTES 16
 #define UZ_SEQ2_UNIT_BYTES 8
+#define UZ_QLOW_LIST_MAX 10 /* = the constant of goodread (read_collector.py:46) */
 #define UZ_QLOW_UNIT_BYTES 4
 
 typedef struct uz_reads_packed_view {
@@ -198,6 +199,23 @@ typedef struct uz_reads_packed_view {
     const uint16_t *exc_pos;  /* [n_exc] base index within the record */
     const uint8_t *exc_code;  /* [n_exc] BAM 4-bit code of that base ("=ACMGRSVTWYHKDBN") */
     int64_t n_exc;
+    /* The quality plane as lists -- an alternative to qlow for the host link (exactly one of qlow / n_low is non-null).
+     * The path asks two things of the base qualities: HOW MANY bases of a record lie below the threshold (goodread,
+     * read_collector.py:43-46: more than 10 and the record is never "good"), and, for a good record that carries its bases,
+     * WHETHER base k does (:123, :281-284).  So: the count of every record (saturated at 255), and the positions themselves
+     * only for the records that carry bases (not UZ_AUX_NO_SEQ) and have at most UZ_QLOW_LIST_MAX of them -- ascending, back to
+     * back in record order, one byte each (two, little-endian, when qlow_pos_wide: reads longer than 256 bases).  A 151-base
+     * read costs 1 + ~5 bytes instead of 20.  The device rebuilds plane rows for the listed records; a kernel that asks for a
+     * bit of any other record raises UZ_E_STATE (it would contradict goodread).
+     * For tables that serve batches of POINT variants only: collect_reads_snv takes "good" records on both ends (:397-404), so
+     * every pair the chaining can reach is good.  collect_reads_sv takes its evidence under goodread(read, True) (:503, :512),
+     * which does not count qualities, and connect_reads may then test a base of such a record (:114-124): an SV batch needs the
+     * plane (qlow). */
+    const uint8_t *n_low;     /* [n_segs] */
+    const uint8_t *qlow_pos;  /* [n_qlow_pos] (* 2 bytes when qlow_pos_wide) */
+    int64_t n_qlow_pos;
+    int32_t qlow_pos_wide;
+    int32_t reserved2;
 } uz_reads_packed_view;
 
 /* one batch of DNMs of one kid (one family, one BAM) */

@@ -21,7 +21,7 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                          int32_t *base_err_out /* optional: 1 when the bases of such a record were requested */) {
     // the table in the packed form the device holds (built here on the host from the ASCII view)
     const int64_t n = Rv->n_segs;
-    std::vector<uint8_t> qc((size_t)n + 1);
+    std::vector<uint8_t> qc((size_t)n + 1), nlow((size_t)n + 1);
     std::vector<RecA> ra((size_t)n + 1);
     std::vector<RecB> rb((size_t)n + 1);
     std::vector<uint32_t> fm((size_t)n + 1), qoff((size_t)n + 1), cigar;
@@ -40,6 +40,14 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                               P->min_gt_qual, seq4.data() + (size_t)uoff * UZ_SEQ4_UNIT_BYTES,
                               qlow.data() + (size_t)uoff * UZ_QLOW_UNIT_BYTES) != 0)
             return -2;
+        {   // as the staged form has it (list form of the quality plane): the count of every record; a quality row only for a record
+            // that carries its bases and has at most UZ_QLOW_LIST_MAX low ones -- asking for a bit of any other sets base_err = 2
+            int low = 0;
+            const uint8_t *ql = Rv->qual + ((size_t)Rv->sq_off16[i] << 4);
+            for (int k = 0; k < (int)Rv->l_seq[i]; k++) low += (int)ql[k] < P->min_gt_qual;
+            nlow[i] = (uint8_t)(low > 255 ? 255 : low);
+            if ((no_seq && no_seq[i]) || low > UZ_QLOW_LIST_MAX) qoff[i] = UZ_NO_QLOW_OFF;
+        }
         coff += Rv->n_cigar[i];
         uoff += units;
     }
@@ -47,7 +55,7 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     RD R;
     R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
     R.ra = ra.data(); R.rb = rb.data(); R.fm = fm.data(); R.cigar = cigar.data(); R.seq4 = seq4.data(); R.qlow = qlow.data();
-    R.qc = qc.data(); R.qoff = qoff.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
+    R.qc = qc.data(); R.qoff = qoff.data(); R.nlow = nlow.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
     int32_t base_err = 0;
     R.err = &base_err;
     std::vector<int32_t> coarse((size_t)(n >> 12) + 2);

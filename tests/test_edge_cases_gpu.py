@@ -184,3 +184,26 @@ def test_both_builds_of_the_read_stage_agree(engine, monkeypatch, arena):
     assert redone1 >= redone0
     if arena <= 2048:
         assert redone1 >= 1  # (count of the last batch) nothing with candidates fits: redone in HBM scratch
+
+
+def test_sv_batches_on_a_point_only_table_match_or_fail_loudly(engine, monkeypatch):
+    """The list form of the quality plane (counts + the positions of "good" records) is argued for point-variant batches; the
+    host stages SV batches with the plane because collect_reads_sv takes its evidence under goodread(read, True).  Forced onto
+    the SV goldens anyway, the list form must either reproduce them or be refused by the kernel's guard (a bit of a record
+    without a quality row was asked for) -- never answer with a made-up bit."""
+    from test_oracle_golden import SV, check_sv_golden
+    from unfazed_amd import session
+    from unfazed_amd.engine import HipEngine, UnfazedHipError
+    real = HipEngine.upload_reads
+
+    def forced(self, reads, min_base_qual=None, point_only=False):
+        return real(self, reads, min_base_qual=min_base_qual, point_only=True)
+
+    monkeypatch.setattr(HipEngine, "upload_reads", forced)
+    for path in SV:
+        session._READS.clear(); session._HOSTS.clear()  # (hosts keep their uploaded tables)
+        try:
+            check_sv_golden(engine, path)
+        except UnfazedHipError as e:
+            assert "base-quality bit" in str(e)
+    session._READS.clear(); session._HOSTS.clear()

@@ -53,6 +53,9 @@ def test_kernel_body_matches_oracle(ci):
         found = orc.find(P, sv, fv, dv, abi.FIND_SECOND_WINDOW)
         want = orc.phase(P, sv, rv, dv, found, keep_lists=True)
         got = emu.phase(P, sv, rv, dv, found)
+        # the twin holds the qualities as the staged form does: a bit of a record with more than 10 low-quality bases (never
+        # "good") must never be asked for
+        assert got["base_err"] == 0
         for k in ("status", "counts", "origin", "evidence"):
             assert np.array_equal(want[k], got[k]), k
         vo, vv, go, gq = want["vote_off"], want["vote_val"], want["grp_off"], want["grp_q"]

@@ -63,15 +63,38 @@ def _unpack_row(pk, uoff, i, ls, soff=None):
             a, b = np.searchsorted(er, i, "left"), np.searchsorted(er, i, "right")
             assert (codes[pk.arrays["exc_pos"][a:b]] == 0).all()
             seq[pk.arrays["exc_pos"][a:b]] = LUT[pk.arrays["exc_code"][a:b]]
-    low = np.unpackbits(pk.arrays["qlow"][uoff[i] * 4: (uoff[i] + u) * 4], bitorder="little")[:ls]
+    if "qlow" in pk.arrays:
+        low = np.unpackbits(pk.arrays["qlow"][uoff[i] * 4: (uoff[i] + u) * 4], bitorder="little")[:ls]
+    else:  # list form: the count of every record, the positions of the records with bases and at most QLOW_LIST_MAX of them
+        n = int(pk.view.n_segs)
+        nl = pk.arrays["n_low"][:n].astype(np.int64)
+        listed = ((pk.arrays["aux"][:n] & abi.AUX_NO_SEQ) == 0) & (nl <= abi.QLOW_LIST_MAX)
+        loff = np.concatenate([[0], np.cumsum(np.where(listed, nl, 0))])
+        assert loff[-1] == pk.view.n_qlow_pos and not pk.view.qlow_pos_wide
+        low = (int(nl[i]), None)
+        if listed[i]:
+            bits = np.zeros(ls, np.uint8)
+            bits[pk.arrays["qlow_pos"][loff[i]: loff[i + 1]]] = 1
+            assert bits.sum() == nl[i]
+            low = (int(nl[i]), bits)
     return seq, low
+
+
+def _same_low(low, bits):
+    """quality bits of a record in either form against the expected 0/1 vector"""
+    if isinstance(low, tuple):
+        cnt, got = low
+        assert cnt == min(int(bits.sum()), 255)
+        assert got is None or np.array_equal(got, bits)
+        return True
+    return np.array_equal(low, bits)
 
 
 @pytest.mark.parametrize("two_bit", [True, False])
 def test_pack_matches_ascii_columns(two_bit):
     sc, dn, cl, rh, arrs = _workload(60)
     for thr in (20, 13, 0, 300):
-        pk = io_native.pack_reads(rh, thr, two_bit=two_bit)
+        pk = io_native.pack_reads(rh, thr, two_bit=two_bit, lists=two_bit)
         if two_bit:
             n_other = int((~np.isin(arrs["seq"], LUT[[1, 2, 4, 8]])).sum())  # (rows are written back to back: every byte is a base)
             assert pk.view.n_exc >= 4 and pk.view.n_exc <= n_other and np.all(np.diff(pk.arrays["exc_rec"][: pk.view.n_exc].astype(np.int64)) >= 0)
@@ -88,7 +111,7 @@ def test_pack_matches_ascii_columns(two_bit):
             r0 = int(arrs["sq_off16"][i]) * 16
             seq, low = _unpack_row(pk, uoff, i, ls)
             assert np.array_equal(seq, arrs["seq"][r0: r0 + ls])
-            assert np.array_equal(low, (arrs["qual"][r0: r0 + ls].astype(np.int64) < min(max(thr, 0), 256)).astype(np.uint8))
+            assert _same_low(low, (arrs["qual"][r0: r0 + ls].astype(np.int64) < min(max(thr, 0), 256)).astype(np.uint8))
             c0 = int(arrs["cigar_off"][i])
             assert np.array_equal(pk.arrays["cigar"][coff[i]: coff[i + 1]], arrs["cigar"][c0: c0 + int(arrs["n_cigar"][i])])
 
@@ -130,8 +153,8 @@ def _subset_ascii(arrs, idx, n_contigs):
     return abi.Held(v, out)
 
 
-@pytest.mark.parametrize("two_bit", [True, False])
-def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(two_bit):
+@pytest.mark.parametrize("two_bit,src_lists,out_lists", [(True, True, True), (False, False, False), (True, False, True)])
+def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(two_bit, src_lists, out_lists):
     sc, dn, cl, rh, arrs = _workload(260)
     n, nc = dn.n, len(sc.contig_off) - 1
     P = abi.make_params()
@@ -142,7 +165,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
     co, ci, cf, ho, hi = found
     want = orc.phase(P, sh, rh, dv, found, keep_lists=True)
     assert (want["status"] == abi.ST_OK).sum() > 30
-    pk = io_native.pack_reads(rh, P.min_gt_qual, two_bit=two_bit)
+    pk = io_native.pack_reads(rh, P.min_gt_qual, two_bit=two_bit, lists=src_lists)
     src = io_native.ReadsSource(pk)
     N = int(rh.view.n_segs)
     contig_of_rec = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
@@ -150,7 +173,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
     total = 0
     for a, b in zip(bounds[:-1], bounds[1:]):
         fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
-        part, idx = src.select(fc, flo, fhi, want_index=True)
+        part, idx = src.select(fc, flo, fhi, want_index=True, lists=out_lists)
         # brute force: overlap of any fetch, then the closure under mate
         keep = np.zeros(N, bool)
         for c, lo, h in zip(fc, flo, fhi):
@@ -170,7 +193,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
         assert np.array_equal(no_seq, ~direct[idx]) and 0.3 < no_seq.mean() < 0.6
         assert np.array_equal(part.arrays["aux"][: idx.size] & ~np.uint8(abi.AUX_NO_SEQ), pk.arrays["aux"][idx])
         assert part.view.n_seq_units == int(abi.row_units(part.arrays["l_seq"][: idx.size])[~no_seq].sum())
-        everything, _ = src.select(fc, flo, fhi, want_index=True, all_bases=True)
+        everything, _ = src.select(fc, flo, fhi, want_index=True, all_bases=True, lists=out_lists)
         assert everything.view.n_seq_units == everything.view.n_row_units and not (everything.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ).any()
         mt = part.arrays["mate"][: idx.size]
         assert np.array_equal(idx[mt[mt >= 0]], pk.arrays["mate"][idx][mt >= 0])
@@ -182,7 +205,11 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
             ls = int(part.arrays["l_seq"][k])
             s1, q1 = _unpack_row(part, uoff_p, k, ls, soff_p)
             s2, q2 = _unpack_row(pk, uoff_f, idx[k], ls)
-            assert np.array_equal(q1, q2)
+            r0 = int(arrs["sq_off16"][idx[k]]) * 16
+            bits = (arrs["qual"][r0: r0 + ls].astype(np.int64) < P.min_gt_qual).astype(np.uint8)
+            assert _same_low(q1, bits) and _same_low(q2, bits)
+            if isinstance(q1, tuple):  # positions travel exactly with the records that can need them
+                assert (q1[1] is not None) == (not no_seq[k] and q1[0] <= abi.QLOW_LIST_MAX)
             assert (s1 is None) == bool(no_seq[k]) and (s1 is None or np.array_equal(s1, s2))
         # the oracle on the selected records only
         sub = _subset_ascii(arrs, idx, nc)

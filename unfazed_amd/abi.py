@@ -159,6 +159,13 @@ class ReadsPackedView(C.Structure):
         ("exc_pos", _p),
         ("exc_code", _p),
         ("n_exc", C.c_int64),
+        # the quality plane as lists for the host link (instead of qlow): count per record, positions for the records that
+        # carry bases and have at most QLOW_LIST_MAX low bases
+        ("n_low", _p),
+        ("qlow_pos", _p),
+        ("n_qlow_pos", C.c_int64),
+        ("qlow_pos_wide", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -167,16 +174,19 @@ AUX_NO_SEQ = 8
 PACKED_RECORD_COLS = [("start", np.int32), ("end", np.int32), ("tlen", np.int32), ("mate", np.int32), ("qname", np.uint32),
                       ("flag", np.uint16), ("l_seq", np.uint16), ("n_cigar", np.uint16), ("mapq", np.uint8), ("aux", np.uint8)]
 SEQ4_UNIT_BYTES, QLOW_UNIT_BYTES, SEQ2_UNIT_BYTES = 16, 4, 8
+QLOW_LIST_MAX = 10
 
 
 def row_units(l_seq):
     return (np.asarray(l_seq).astype(np.int64) + 31) >> 5
 
 
-def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None) -> "Held":
+def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
+                      qlow_pos_wide=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
-    n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*)."""
+    n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
+    n_qlow_pos: None = the quality plane (qlow); a number = per-record counts (n_low) + that many listed positions (qlow_pos)."""
     if n_seq_units is None:
         n_seq_units = n_row_units
     if alloc is None:
@@ -194,10 +204,17 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
         arrs["exc_rec"] = alloc(4 * max(1, n_exc))[: 4 * max(1, n_exc)].view(np.uint32)
         arrs["exc_pos"] = alloc(2 * max(1, n_exc))[: 2 * max(1, n_exc)].view(np.uint16)
         arrs["exc_code"] = alloc(max(1, n_exc))[: max(1, n_exc)]
-    arrs["qlow"] = alloc(QLOW_UNIT_BYTES * max(1, n_row_units))[: QLOW_UNIT_BYTES * max(1, n_row_units)]
+    if n_qlow_pos is None:
+        arrs["qlow"] = alloc(QLOW_UNIT_BYTES * max(1, n_row_units))[: QLOW_UNIT_BYTES * max(1, n_row_units)]
+    else:
+        arrs["n_low"] = alloc(max(1, n))[: max(1, n)]
+        w = 2 if qlow_pos_wide else 1
+        arrs["qlow_pos"] = alloc(w * max(1, n_qlow_pos))[: w * max(1, n_qlow_pos)]
     v = ReadsPackedView()
     v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units, v.n_seq_units = n, n_contigs, n_cigar_total, n_row_units, n_seq_units
     v.n_exc = 0 if n_exc is None else n_exc
+    v.n_qlow_pos = 0 if n_qlow_pos is None else n_qlow_pos
+    v.qlow_pos_wide = 1 if qlow_pos_wide else 0
     for k, a in arrs.items():
         setattr(v, k, a.ctypes.data)
     return Held(v, arrs)

@@ -405,6 +405,7 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.fm = cv.take<uint32_t>(n);
     r.qoff = cv.take<uint32_t>(n);
     r.k3 = cv.take<uint32_t>(n);
+    r.nlow = cv.take<uint8_t>(n);
     r.qc = cv.take<uint8_t>(n);
     r.need = cv.take<uint8_t>(n);
     r.coarse = cv.take<int32_t>((n >> 12) + 2);
@@ -421,6 +422,9 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(!(v->seq2 && v->seq4), UZ_E_ARG, "a packed table has four-bit (seq4) OR two-bit (seq2) base rows, not both");
     UZ_REQUIRE(v->n_seq_units == 0 || v->seq2 || v->seq4, UZ_E_ARG, "n_seq_units > 0 but neither seq4 nor seq2 is set");
     if (v->seq2) UZ_REQUIRE(v->n_exc >= 0 && (v->n_exc == 0 || (v->exc_rec && v->exc_pos && v->exc_code)), UZ_E_ARG, "bad exc_* columns");
+    UZ_REQUIRE(!(v->qlow && v->n_low), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form (n_low / qlow_pos), not both");
+    UZ_REQUIRE(v->n_segs == 0 || v->qlow || v->n_low, UZ_E_ARG, "neither qlow nor n_low is set");
+    if (v->n_low) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
@@ -432,6 +436,11 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units, ns = (size_t)r.n_seq_units;
     const bool two_bit = v->seq2 != nullptr;
     const size_t ne = two_bit ? (size_t)v->n_exc : 0;
+    const bool lists = v->n_low != nullptr; // quality rows only for the records with bases (at their base-row position), written by the header build
+    const size_t nql = lists ? (size_t)v->n_qlow_pos * (v->qlow_pos_wide ? 2 : 1) : 0;
+    uint8_t *n_low = nullptr, *qpos = nullptr;
+    r.n_qlow_pos = lists ? v->n_qlow_pos : 0;
+    r.n_plane_units = lists ? v->n_seq_units : v->n_row_units;
     uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq2 = nullptr;
     uint32_t *exc_rec = nullptr; uint16_t *exc_pos = nullptr; uint8_t *exc_code = nullptr;
     int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
@@ -441,7 +450,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         carve_common(cv, r);
         cigar = cv.take<uint32_t>(nc);
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
-        qlow = cv.take<uint8_t>(nu * UZ_QLOW_UNIT_BYTES);
+        qlow = cv.take<uint8_t>((lists ? ns : nu) * UZ_QLOW_UNIT_BYTES);
+        if (lists) { n_low = cv.take<uint8_t>(n); qpos = cv.take<uint8_t>(nql); }
         if (two_bit) {
             seq2 = cv.take<uint8_t>(ns * UZ_SEQ2_UNIT_BYTES);
             exc_rec = cv.take<uint32_t>(ne); exc_pos = cv.take<uint16_t>(ne); exc_code = cv.take<uint8_t>(ne);
@@ -468,9 +478,17 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     } else
         r.seq4 = h2d(st, seq4, v->seq4, ns * UZ_SEQ4_UNIT_BYTES);
     r.qlow = qlow;
-    h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
+    if (lists) {
+        col.n_low = h2d(st, n_low, v->n_low, n);
+        col.qlow_pos = h2d(st, qpos, v->qlow_pos, nql);
+        col.qpos_wide = v->qlow_pos_wide;
+    } else {
+        h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
+        col.plane_in = reinterpret_cast<const uint32_t *>(qlow);
+    }
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
+    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_qwide = col.qpos_wide;
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
         for (int k = 0; k < 10; k++) r.col_ptrs[k] = p[k];
@@ -489,6 +507,8 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.mate = (const int32_t *)r.col_ptrs[3]; col.qname = (const uint32_t *)r.col_ptrs[4]; col.flag = (const uint16_t *)r.col_ptrs[5];
     col.l_seq = (const uint16_t *)r.col_ptrs[6]; col.n_cigar = (const uint16_t *)r.col_ptrs[7]; col.mapq = (const uint8_t *)r.col_ptrs[8];
     col.aux = (const uint8_t *)r.col_ptrs[9];
+    col.plane_in = (const uint32_t *)r.col_q[0]; col.n_low = (const uint8_t *)r.col_q[1]; col.qlow_pos = (const uint8_t *)r.col_q[2];
+    col.qpos_wide = r.col_qwide;
     UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, c->stream));
     uz_build_records(c, c->stream, r, col, r.build_scratch);
     r.pending = false;
@@ -506,6 +526,7 @@ int uz_reads_upload_impl(uz_ctx *c, const uz_reads_view *v, ReadsDev &r) {
     int64_t tot_c = 0, tot_u = 0;
     for (size_t i = 0; i < n; i++) { tot_c += v->n_cigar[i]; tot_u += UZ_ROW_UNITS(v->l_seq[i]); }
     r.n_cigar_total = tot_c; r.n_row_units = tot_u; r.n_seq_units = tot_u; // the ASCII form carries every record's bases
+    r.n_plane_units = tot_u;
     UZ_REQUIRE(tot_c < ((int64_t)1 << 32) && tot_u < ((int64_t)1 << 32), UZ_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets");
     const size_t nc = (size_t)tot_c, nu = (size_t)tot_u, nci = (size_t)v->n_cigar_total, nsq = (size_t)v->n_sq_bytes;
     uint32_t *cigar = nullptr, *cigar_in = nullptr, *cigar_off_in = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq_in = nullptr;
@@ -601,10 +622,14 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
         r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
         void *scratch = nullptr;
         uint8_t *seq4_own = nullptr; // two-bit rows are expanded into the library's own block
+        uint8_t *qlow_own = nullptr; // the list form of the quality plane likewise
+        r.n_qlow_pos = v->n_low ? v->n_qlow_pos : 0;
+        r.n_plane_units = v->n_low ? v->n_seq_units : v->n_row_units;
         for (int pass = 0; pass < 2; pass++) {
             Carver cv(pass ? r.block.p : nullptr);
             carve_common(cv, r);
             if (v->seq2) seq4_own = cv.take<uint8_t>((size_t)r.n_seq_units * UZ_SEQ4_UNIT_BYTES);
+            if (v->n_low) qlow_own = cv.take<uint8_t>((size_t)r.n_seq_units * UZ_QLOW_UNIT_BYTES);
             scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
             if (!pass) r.block = uz_block_get(c, cv.off + 256);
         }
@@ -620,6 +645,8 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
                 r.seq4 = seq4_own; r.seq2_staged = v->seq2;
                 r.n_exc = v->n_exc; r.exc_rec = v->exc_rec; r.exc_pos = v->exc_pos; r.exc_code = v->exc_code;
             }
+            if (v->n_low) { r.qlow = qlow_own; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; }
+            else col.plane_in = reinterpret_cast<const uint32_t *>(v->qlow);
             r.qlow_thr = v->min_base_qual;
             r.qlow_valid = true;
             UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, st));
@@ -629,7 +656,8 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             if (c->hflags[0]) {
                 const int f = c->hflags[0];
                 c->hflags[0] = 0;
-                throw UzError{UZ_E_RANGE, f == 3 ? "exc_* columns: an entry names a record without bases, a base beyond l_seq or a code above 15"
+                throw UzError{UZ_E_RANGE, f == 4 ? "qlow_pos: positions of a record are not ascending or lie beyond l_seq"
+                                          : f == 3 ? "exc_* columns: an entry names a record without bases, a base beyond l_seq or a code above 15"
                                                  : "n_cigar_total / n_row_units of the reads view do not match its columns"};
             }
         } catch (...) { uz_block_put(c, r.block); throw; }
@@ -775,7 +803,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
         SitesDev &s = sites_of(c, f0.sites_id);
         // ---- the kids' tables end to end as one table
         std::vector<int> ids;
-        int64_t tot_n = 0, tot_c = 0, tot_u = 0, tot_s = 0, tot_contigs = 0;
+        int64_t tot_n = 0, tot_c = 0, tot_u = 0, tot_s = 0, tot_p = 0, tot_contigs = 0;
         uint64_t tot_q = 0;
         for (int32_t g = 0; g < n_groups; g++) {
             UZ_REQUIRE(groups[g].dnm_first >= 0 && groups[g].dnm_count >= 0 && groups[g].dnm_first + groups[g].dnm_count <= n, UZ_E_ARG,
@@ -789,7 +817,8 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
                 uz_build_qlow(c, c->stream, r, c->P.min_gt_qual);
             }
             ids.push_back(groups[g].reads_id);
-            tot_n += r.n; tot_c += r.n_cigar_total; tot_u += r.n_row_units; tot_s += r.n_seq_units; tot_contigs += r.n_contigs; tot_q += r.n_qnames;
+            tot_n += r.n; tot_c += r.n_cigar_total; tot_u += r.n_row_units; tot_s += r.n_seq_units; tot_p += r.n_plane_units;
+            tot_contigs += r.n_contigs; tot_q += r.n_qnames;
         }
         UZ_REQUIRE(tot_n < (int64_t)0x7FFFFFF0 && tot_c < ((int64_t)1 << 32) && tot_u < ((int64_t)1 << 32) && tot_q < ((uint64_t)1 << 32), UZ_E_RANGE,
                    "the cohort's alignment records exceed one table's index ranges");
@@ -812,14 +841,14 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
             ReadsDev m;
             m.live = true;
             m.n = tot_n; m.n_contigs = (int32_t)tot_contigs; m.n_qnames = (uint32_t)tot_q; m.n_cigar_total = tot_c; m.n_row_units = tot_u;
-            m.n_seq_units = tot_s;
+            m.n_seq_units = tot_s; m.n_plane_units = tot_p;
             uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr;
             for (int pass = 0; pass < 2; pass++) {
                 Carver cv(pass ? m.block.p : nullptr);
                 carve_common(cv, m);
                 cigar = cv.take<uint32_t>((size_t)tot_c);
                 seq4 = cv.take<uint8_t>((size_t)tot_s * UZ_SEQ4_UNIT_BYTES);
-                qlow = cv.take<uint8_t>((size_t)tot_u * UZ_QLOW_UNIT_BYTES);
+                qlow = cv.take<uint8_t>((size_t)tot_p * UZ_QLOW_UNIT_BYTES);
                 if (!pass) m.block = uz_block_get(c, cv.off + 256);
             }
             m.cigar = cigar; m.seq4 = seq4; m.qlow = qlow;
@@ -840,7 +869,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
                         ms[(size_t)contig_base[(size_t)g] + k] = rms[(size_t)k];
                     }
                     uz_concat_table(c, c->stream, m, r, rec_base[(size_t)g], cg, un, sn, q_base[(size_t)g]);
-                    cg += r.n_cigar_total; un += r.n_row_units; sn += r.n_seq_units;
+                    cg += r.n_cigar_total; un += r.n_plane_units; sn += r.n_seq_units;
                 }
                 co[(size_t)tot_contigs] = tot_n;
                 UZ_HIP(hipMemcpyAsync(m.contig_off, co.data(), co.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));

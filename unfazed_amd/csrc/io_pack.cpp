@@ -65,7 +65,18 @@ void offsets(int64_t n, const uint16_t *n_cigar, const uint16_t *l_seq, const ui
 struct uz_psrc {
     uz_reads_packed_view v;
     std::vector<uint32_t> coff, uoff, soff; // [n + 1]: CIGAR words, quality-plane units, seq4 units
+    std::vector<uint64_t> loff;             // [n + 1] list-form sources: first entry of every record in qlow_pos (listed records own n_low entries)
 };
+// low-quality bases of record i of a source table, and whether its positions are / can be listed
+static inline int src_low_count(const uz_psrc *src, int64_t i) {
+    const uz_reads_packed_view *f = &src->v;
+    if (f->n_low) return f->n_low[i];
+    int c = 0;
+    const uint8_t *row = f->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES;
+    const int ls = f->l_seq[i];
+    for (int k = 0; k < ls; k++) c += (row[k >> 3] >> (k & 7)) & 1;
+    return c > 255 ? 255 : c;
+}
 
 struct uz_select {
     const uz_psrc *src = nullptr;
@@ -73,6 +84,8 @@ struct uz_select {
     uint64_t n_cigar = 0, n_units = 0, n_seq = 0;
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
     std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
+    std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
+    int64_t n_qpos = 0;                 // entries of the output's qlow_pos
     std::vector<int64_t> exc_lo, exc_n; // seq2 sources: per kept record, its slice of the source's exception list (0 entries without bases)
     int64_t n_exc = 0;
 };
@@ -85,6 +98,31 @@ int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t
         uint64_t a = 0, b = 0;
         for (int64_t i = 0; i < in->n_segs; i++) { a += in->n_cigar[i]; b += UZ_ROW_UNITS(in->l_seq[i]); }
         *n_cigar_total = (int64_t)a; *n_row_units = (int64_t)b;
+    });
+}
+
+int uz_reads_pack_lists(const uz_reads_view *in, int min_base_qual, int threads, int64_t *n_qlow_pos, int32_t *wide) {
+    return guarded([&] {
+        if (!in || !n_qlow_pos || !wide) fail(UZ_IO_E_ARG, "null argument");
+        threads = resolve_threads(threads);
+        const int64_t n = in->n_segs;
+        const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
+        const int wk = workers_for(n, threads, 4096);
+        std::vector<int64_t> part((size_t)wk + 1, 0), wd((size_t)wk + 1, 0);
+        parallel_slices(n, wk, [&](int64_t lo, int64_t hi, int k) {
+            int64_t c = 0, w2 = 0;
+            for (int64_t i = lo; i < hi; i++) {
+                const uint8_t *q = in->qual + ((size_t)in->sq_off16[i] << 4);
+                int low = 0;
+                for (int b = 0; b < (int)in->l_seq[i]; b++) low += (int)q[b] < thr;
+                if (low <= UZ_QLOW_LIST_MAX) c += low;
+                if (in->l_seq[i] > 256) w2 = 1;
+            }
+            part[(size_t)k] = c; wd[(size_t)k] = w2;
+        });
+        int64_t tot = 0, w2 = 0;
+        for (int k = 0; k < wk; k++) { tot += part[(size_t)k]; w2 |= wd[(size_t)k]; }
+        *n_qlow_pos = tot; *wide = (int32_t)w2;
     });
 }
 
@@ -127,6 +165,25 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
         const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
         std::atomic<int> bad{0};
         const bool two_bit = out->seq2 != nullptr;
+        const bool lists = out->n_low != nullptr;
+        std::vector<uint64_t> loff;
+        if (lists) { // counts first, then the offsets of the lists
+            parallel_slices(n, workers_for(n, threads, 4096), [&](int64_t lo, int64_t hi, int) {
+                for (int64_t i = lo; i < hi; i++) {
+                    const uint8_t *q = in->qual + ((size_t)in->sq_off16[i] << 4);
+                    int low = 0;
+                    for (int b = 0; b < (int)in->l_seq[i]; b++) low += (int)q[b] < thr;
+                    w(out->n_low)[i] = (uint8_t)(low > 255 ? 255 : low);
+                    if (in->l_seq[i] > 256 && !out->qlow_pos_wide) bad.store(2);
+                }
+            });
+            if (bad.load() == 2) fail(UZ_IO_E_ARG, "reads longer than 256 bases need qlow_pos_wide (uz_reads_pack_lists)");
+            loff.assign((size_t)n + 1, 0);
+            for (int64_t i = 0; i < n; i++) loff[(size_t)i + 1] = loff[(size_t)i] + (out->n_low[i] <= UZ_QLOW_LIST_MAX ? out->n_low[i] : 0);
+            if ((int64_t)loff[(size_t)n] != out->n_qlow_pos)
+                fail(UZ_IO_E_ARG, "output view sized for %lld listed positions, the table has %llu (uz_reads_pack_lists)", (long long)out->n_qlow_pos,
+                     (unsigned long long)loff[(size_t)n]);
+        }
         const int wk_pack = workers_for(n, threads, 4096);
         // two-bit rows: the bases that are not A/C/G/T, per slice (slices are contiguous record ranges, so their lists joined in
         // slice order are sorted by record)
@@ -143,12 +200,22 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
                 int rc;
                 if (two_bit)
                     rc = uz_pack_rows_host2(in->seq + row, in->qual + row, in->l_seq[i], thr, w(out->seq2) + uoff[i] * UZ_SEQ2_UNIT_BYTES,
-                                            w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES,
+                                            lists ? (uint8_t *)nullptr : w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES,
                                             [&](int pos, uint8_t code) { exc[(size_t)slice].push_back(Exc{(uint32_t)i, (uint16_t)pos, code}); });
                 else
                     rc = uz_pack_rows_host(in->seq + row, in->qual + row, in->l_seq[i], thr, w(out->seq4) + uoff[i] * UZ_SEQ4_UNIT_BYTES,
-                                           w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES);
+                                           lists ? (uint8_t *)nullptr : w(out->qlow) + uoff[i] * UZ_QLOW_UNIT_BYTES);
                 if (rc != 0) bad.store(1);
+                if (lists && out->n_low[i] <= UZ_QLOW_LIST_MAX) {
+                    uint64_t at = loff[(size_t)i];
+                    const uint8_t *q = in->qual + row;
+                    for (int b = 0; b < (int)in->l_seq[i]; b++)
+                        if ((int)q[b] < thr) {
+                            if (out->qlow_pos_wide) { w(out->qlow_pos)[2 * at] = (uint8_t)(b & 255); w(out->qlow_pos)[2 * at + 1] = (uint8_t)(b >> 8); }
+                            else w(out->qlow_pos)[at] = (uint8_t)b;
+                            at++;
+                        }
+                }
             }
         });
         if (bad.load()) fail(UZ_IO_E_RANGE, "SEQ holds a character outside BAM's 16-code alphabet");
@@ -174,6 +241,15 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
         offsets(full->n_segs, full->n_cigar, full->l_seq, full->aux, threads, coff, uoff, soff);
         if (coff.back() >= ((uint64_t)1 << 32) || uoff.back() >= ((uint64_t)1 << 32)) { delete src; fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets"); }
         if ((int64_t)soff.back() != full->n_seq_units) { delete src; fail(UZ_IO_E_ARG, "n_seq_units does not match the aux column"); }
+        if (!full->qlow && !full->n_low) { delete src; fail(UZ_IO_E_ARG, "the table has neither the quality plane nor its list form"); }
+        if (full->n_low) {
+            src->loff.assign((size_t)full->n_segs + 1, 0);
+            for (int64_t i = 0; i < full->n_segs; i++) {
+                const bool listed = !(full->aux[i] & UZ_AUX_NO_SEQ) && full->n_low[i] <= UZ_QLOW_LIST_MAX;
+                src->loff[(size_t)i + 1] = src->loff[(size_t)i] + (listed ? full->n_low[i] : 0);
+            }
+            if ((int64_t)src->loff.back() != full->n_qlow_pos) { delete src; fail(UZ_IO_E_ARG, "n_qlow_pos does not match the n_low / aux columns"); }
+        }
         if (full->seq2 && full->n_exc > 0)
             for (int64_t e = 1; e < full->n_exc; e++)
                 if (full->exc_rec[e] < full->exc_rec[e - 1]) { delete src; fail(UZ_IO_E_ARG, "exc_rec is not ascending"); }
@@ -255,6 +331,22 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 if (bases) sel->n_seq += UZ_ROW_UNITS(full->l_seq[i]);
             }
         sel->n_sel = (int64_t)sel->index.size();
+        sel->n_low.assign((size_t)sel->n_sel, 0);
+        {
+            std::vector<int64_t> part;
+            const int wk = workers_for(sel->n_sel, threads, 4096);
+            part.assign((size_t)wk + 1, 0);
+            parallel_slices(sel->n_sel, wk, [&](int64_t a, int64_t b, int slice) {
+                int64_t c = 0;
+                for (int64_t k = a; k < b; k++) {
+                    const int low = src_low_count(src, sel->index[(size_t)k]);
+                    sel->n_low[(size_t)k] = (uint8_t)low;
+                    if (sel->bases[(size_t)k] && low <= UZ_QLOW_LIST_MAX) c += low;
+                }
+                part[(size_t)slice] = c;
+            });
+            for (int k = 0; k < wk; k++) sel->n_qpos += part[(size_t)k];
+        }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
             sel->exc_n.assign((size_t)sel->n_sel, 0);
@@ -276,6 +368,15 @@ int64_t uz_select_n_cigar_total(const uz_select *s) { return s ? (int64_t)s->n_c
 int64_t uz_select_n_row_units(const uz_select *s) { return s ? (int64_t)s->n_units : 0; }
 int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq : 0; }
 int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
+int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
+int uz_select_qlow_pos_wide(const uz_select *s) {
+    if (!s) return 0;
+    const uz_reads_packed_view *f = &s->src->v;
+    if (f->n_low) return f->qlow_pos_wide;
+    for (size_t k = 0; k < s->index.size(); k++)
+        if (f->l_seq[s->index[k]] > 256) return 1;
+    return 0;
+}
 void uz_select_free(uz_select *s) { delete s; }
 
 int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *out, int32_t *orig_index) {
@@ -291,6 +392,16 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (two_bit && !out->seq2) fail(UZ_IO_E_ARG, "the source table has two-bit base rows: the output view needs seq2 (and the exc_* columns)");
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
         out->n_exc = two_bit ? s->n_exc : 0;
+        const bool lists = out->n_low != nullptr;
+        if (!lists && !full->qlow) fail(UZ_IO_E_ARG, "the source table has the quality plane as lists: the output view needs n_low / qlow_pos");
+        if (lists && !out->qlow_pos_wide && uz_select_qlow_pos_wide(s)) fail(UZ_IO_E_ARG, "reads longer than 256 bases need qlow_pos_wide");
+        out->n_qlow_pos = lists ? s->n_qpos : 0;
+        std::vector<int64_t> ol;
+        if (lists) {
+            ol.assign((size_t)m + 1, 0);
+            for (int64_t k = 0; k < m; k++)
+                ol[(size_t)k + 1] = ol[(size_t)k] + ((s->bases[(size_t)k] && s->n_low[(size_t)k] <= UZ_QLOW_LIST_MAX) ? s->n_low[(size_t)k] : 0);
+        }
         std::vector<int64_t> oe;
         if (two_bit) {
             oe.assign((size_t)m + 1, 0);
@@ -341,7 +452,29 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                     } else
                         memcpy(w(out->seq4) + os[k] * UZ_SEQ4_UNIT_BYTES, full->seq4 + (size_t)src->soff[i] * UZ_SEQ4_UNIT_BYTES, units * UZ_SEQ4_UNIT_BYTES);
                 }
-                memcpy(w(out->qlow) + ou[k] * UZ_QLOW_UNIT_BYTES, full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES, units * UZ_QLOW_UNIT_BYTES);
+                if (!lists)
+                    memcpy(w(out->qlow) + ou[k] * UZ_QLOW_UNIT_BYTES, full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES, units * UZ_QLOW_UNIT_BYTES);
+                else {
+                    w(out->n_low)[k] = s->n_low[(size_t)k];
+                    if (s->bases[(size_t)k] && s->n_low[(size_t)k] <= UZ_QLOW_LIST_MAX) {
+                        int64_t at = ol[(size_t)k];
+                        auto put = [&](int b) {
+                            if (out->qlow_pos_wide) { w(out->qlow_pos)[2 * at] = (uint8_t)(b & 255); w(out->qlow_pos)[2 * at + 1] = (uint8_t)(b >> 8); }
+                            else w(out->qlow_pos)[at] = (uint8_t)b;
+                            at++;
+                        };
+                        if (full->n_low) { // list -> list
+                            for (int e = 0; e < (int)s->n_low[(size_t)k]; e++) {
+                                const uint64_t from = src->loff[(size_t)i] + (uint64_t)e;
+                                put(full->qlow_pos_wide ? (int)full->qlow_pos[2 * from] | ((int)full->qlow_pos[2 * from + 1] << 8) : (int)full->qlow_pos[from]);
+                            }
+                        } else { // plane -> list
+                            const uint8_t *row = full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES;
+                            for (int b = 0; b < (int)full->l_seq[i]; b++)
+                                if ((row[b >> 3] >> (b & 7)) & 1) put(b);
+                        }
+                    }
+                }
                 if (orig_index) orig_index[k] = (int32_t)i;
             }
         });

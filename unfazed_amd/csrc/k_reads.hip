@@ -56,35 +56,16 @@ __global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict_
         if ((((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0) && base + k < n) lst[o++] = (int32_t)(base + k);
     if (t == 0 && count && m) atomicAdd(count, (unsigned int)m);
     __syncthreads();
-    const uint32_t *__restrict__ qw = reinterpret_cast<const uint32_t *>(R.qlow); // rows start on 4-byte units
     for (int r0 = t; r0 < m; r0 += 256) {
         const int mine = lst[r0];
-        // three words per record instead of its two 16-byte headers: lengths + "simple" flag, flags, quality-plane row
+        // nine bytes per record instead of its two 16-byte headers and its quality rows: lengths + "simple" flag, flags, and
+        // the number of low-quality bases (counted once, when the table was built)
         const uint32_t k3 = R.k3[mine];
         const uint32_t fm = R.fm[mine];
-        const size_t qo = R.qoff[mine];
+        const int low = R.nlow[mine];
         const uint32_t ax = fm >> 24;
-        const int ncg = (int)((k3 >> 16) & 0x7FFFu), ls = (ax & UZ_AUX_DECODE_BAD) ? 0 : (int)(k3 & 0xFFFFu);
+        const int ncg = (int)((k3 >> 16) & 0x7FFFu);
         const bool simple = (k3 >> 31) != 0;
-        const int units = (int)UZ_ROW_UNITS(ls);
-        int low = 0;
-        // five words cover a 151-base read: requested together, longer reads loop on
-        uint32_t w[5];
-#pragma unroll
-        for (int u = 0; u < 5; u++) w[u] = u < units ? qw[qo + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 5; u++) {
-            const int valid = ls - 32 * u;
-            uint32_t x = w[u];
-            if (valid < 32) x &= valid > 0 ? ((1u << valid) - 1u) : 0u;
-            low += __popc(x);
-        }
-        for (int u = 5; u < units; u++) {
-            const int valid = ls - 32 * u;
-            uint32_t x = qw[qo + u];
-            if (valid < 32) x &= (1u << valid) - 1u;
-            low += __popc(x);
-        }
         int nonmatch = 0, none = 0;
         if (!simple && ncg > 0) { // the few records with a real CIGAR: soft clips, indels, ...
             const uint32_t coff = R.ra[mine].cigar_off;
@@ -221,88 +202,149 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 // cigar_off / sq_off are the exclusive prefix sums of n_cigar / UZ_ROW_UNITS(l_seq) over the records: block
 // sums, one scan of the block sums, then the pack kernel scans inside its block and writes the headers.
 #define UZ_PK_SPAN 4096
-// three running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases)
-__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, uint32_t &a, uint32_t &b, uint32_t &s) {
-    a = nc; b = UZ_ROW_UNITS(ls); s = (aux & UZ_AUX_NO_SEQ) ? 0u : b;
+// four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
+// low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
+#define UZ_PK_SUMS 4
+__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t (&v)[UZ_PK_SUMS]) {
+    v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : v[1];
+    v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_t *__restrict__ n_cigar, const uint16_t *__restrict__ l_seq,
-                                                        const uint8_t *__restrict__ aux, unsigned long long *sums /* [3 nb] */) {
-    __shared__ unsigned long long part[3][4];
+                                                        const uint8_t *__restrict__ aux, const uint8_t *__restrict__ n_low,
+                                                        unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
+    __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
-    unsigned long long a = 0, b = 0, sq = 0;
+    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0};
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
-        if (i < n) { uint32_t x, y, z; pk_vals(n_cigar[i], l_seq[i], aux[i], x, y, z); a += x; b += y; sq += z; }
+        if (i < n) {
+            uint32_t v[UZ_PK_SUMS];
+            pk_vals(n_cigar[i], l_seq[i], aux[i], n_low ? (int)n_low[i] : -1, v);
+#pragma unroll
+            for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); sq += __shfl_xor(sq, o, 64); }
-    if ((t & 63) == 0) { part[0][t >> 6] = a; part[1][t >> 6] = b; part[2][t >> 6] = sq; }
+    for (int k = 0; k < UZ_PK_SUMS; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+        if ((t & 63) == 0) part[k][t >> 6] = acc[k];
+    }
     __syncthreads();
     if (t == 0)
-        for (int k = 0; k < 3; k++) sums[3 * (size_t)blockIdx.x + k] = part[k][0] + part[k][1] + part[k][2] + part[k][3];
+        for (int k = 0; k < UZ_PK_SUMS; k++) sums[UZ_PK_SUMS * (size_t)blockIdx.x + k] = part[k][0] + part[k][1] + part[k][2] + part[k][3];
 }
 // one workgroup: exclusive scan of the block sums in place; the totals are checked against what the view declared
 __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
-                                                        unsigned long long want_units, unsigned long long want_seq, int32_t *hflags) {
-    __shared__ unsigned long long part[3][1024];
+                                                        unsigned long long want_units, unsigned long long want_seq, unsigned long long want_qpos,
+                                                        int32_t *hflags) {
+    __shared__ unsigned long long part[UZ_PK_SUMS][1024];
     const int t = threadIdx.x;
     const int64_t chunk = (nb + 1023) / 1024;
     const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long v[3] = {0, 0, 0};
+    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0};
     for (int64_t i = lo; i < hi; i++)
-        for (int k = 0; k < 3; k++) v[k] += sums[3 * i + k];
-    for (int k = 0; k < 3; k++) part[k][t] = v[k];
+        for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
+    for (int k = 0; k < UZ_PK_SUMS; k++) part[k][t] = v[k];
     __syncthreads();
     if (t == 0) {
-        unsigned long long r[3] = {0, 0, 0};
+        unsigned long long r[UZ_PK_SUMS] = {0, 0, 0, 0};
         for (int j = 0; j < 1024; j++)
-            for (int k = 0; k < 3; k++) { const unsigned long long x = part[k][j]; part[k][j] = r[k]; r[k] += x; }
-        if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL) hflags[0] = 1;
+            for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = part[k][j]; part[k][j] = r[k]; r[k] += x; }
+        if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[3] != want_qpos || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL)
+            hflags[0] = 1;
     }
     __syncthreads();
-    for (int k = 0; k < 3; k++) v[k] = part[k][t];
+    for (int k = 0; k < UZ_PK_SUMS; k++) v[k] = part[k][t];
     for (int64_t i = lo; i < hi; i++)
-        for (int k = 0; k < 3; k++) { const unsigned long long x = sums[3 * i + k]; sums[3 * i + k] = v[k]; v[k] += x; }
+        for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = sums[UZ_PK_SUMS * i + k]; sums[UZ_PK_SUMS * i + k] = v[k]; v[k] += x; }
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
-                                                  uint32_t *fm, uint32_t *qoff, uint32_t *k3) {
-    __shared__ uint32_t wsum[3][4];
+                                                  uint32_t *fm, uint32_t *qoff, uint32_t *k3, uint8_t *nlow, uint32_t *plane_out, int32_t *hflags) {
+    __shared__ uint32_t wsum[UZ_PK_SUMS][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    uint32_t run[3] = {(uint32_t)sums[3 * (size_t)blockIdx.x], (uint32_t)sums[3 * (size_t)blockIdx.x + 1], (uint32_t)sums[3 * (size_t)blockIdx.x + 2]};
+    unsigned long long run[UZ_PK_SUMS];
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SUMS; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         const bool in = i < n;
         const uint32_t nc = in ? c.n_cigar[i] : 0u, ls = in ? c.l_seq[i] : 0u, ax = in ? c.aux[i] : 0u;
-        uint32_t v[3], inc[3];
-        pk_vals(nc, ls, ax, v[0], v[1], v[2]);
+        const int nl = c.n_low ? (in ? (int)c.n_low[i] : 0) : -1;
+        uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
+        pk_vals(nc, ls, ax, nl, v);
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < UZ_PK_SUMS; k++) {
             uint32_t x = v[k];
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
             inc[k] = x;
         }
         __syncthreads(); // wsum of the previous round has been read
-        if (lane == 63) { wsum[0][wv] = inc[0]; wsum[1][wv] = inc[1]; wsum[2][wv] = inc[2]; }
-        __syncthreads();
-        uint32_t pre[3] = {0, 0, 0}, tot[3] = {0, 0, 0};
+        if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < 3; k++)
+            for (int k = 0; k < UZ_PK_SUMS; k++) wsum[k][wv] = inc[k];
+        }
+        __syncthreads();
+        uint32_t pre[UZ_PK_SUMS] = {0, 0, 0, 0}, tot[UZ_PK_SUMS] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SUMS; k++)
 #pragma unroll
             for (int w = 0; w < 4; w++) { if (w < wv) pre[k] += wsum[k][w]; tot[k] += wsum[k][w]; }
         if (in) {
             RecA A;
             RecB B;
-            const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : run[2] + pre[2] + inc[2] - v[2];
-            uz_pack_rec(A, B, c.start[i], c.end[i], run[0] + pre[0] + inc[0] - v[0], sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
+            const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : (uint32_t)(run[2] + pre[2] + inc[2] - v[2]);
+            uz_pack_rec(A, B, c.start[i], c.end[i], (uint32_t)(run[0] + pre[0] + inc[0] - v[0]), sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
             ra[i] = A;
             rb[i] = B;
             fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);
-            qoff[i] = run[1] + pre[1] + inc[1] - v[1];
             k3[i] = uz_pack_k3(ls, nc, A.start, A.end);
+            const int units = (int)UZ_ROW_UNITS(ls);
+            if (nl >= 0) {
+                // list form of the staged plane: the count as it is; a quality row (at the record's base-row position) only for a
+                // record whose bits can be asked for, written here from its listed positions
+                nlow[i] = (uint8_t)nl;
+                const bool listed = v[3] == (uint32_t)nl && !(ax & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX;
+                qoff[i] = listed ? sq : UZ_NO_QLOW_OFF;
+                if (listed) {
+                    const unsigned long long at = run[3] + pre[3] + inc[3] - v[3];
+                    int pos[UZ_QLOW_LIST_MAX];
+                    bool bad = false;
+#pragma unroll
+                    for (int e = 0; e < UZ_QLOW_LIST_MAX; e++) {
+                        pos[e] = -1;
+                        if (e < nl) {
+                            pos[e] = c.qpos_wide ? ((int)c.qlow_pos[2 * (at + e)] | ((int)c.qlow_pos[2 * (at + e) + 1] << 8)) : (int)c.qlow_pos[at + e];
+                            bad |= pos[e] >= (int)ls || (e > 0 && pos[e] <= pos[e - 1]);
+                        }
+                    }
+                    if (bad) hflags[0] = 4;
+                    for (int u = 0; u < units; u++) {
+                        uint32_t w = 0;
+#pragma unroll
+                        for (int e = 0; e < UZ_QLOW_LIST_MAX; e++)
+                            if (pos[e] >= 0 && (pos[e] >> 5) == u) w |= 1u << (pos[e] & 31);
+                        plane_out[(size_t)sq + u] = w;
+                    }
+                }
+            } else {
+                const uint32_t qo = (uint32_t)(run[1] + pre[1] + inc[1] - v[1]);
+                qoff[i] = qo;
+                if (c.plane_in) { // the plane itself was staged: count its bits once
+                    int low = 0;
+                    for (int u = 0; u < units; u++) {
+                        uint32_t w = c.plane_in[(size_t)qo + u];
+                        const int valid = (int)ls - 32 * u;
+                        if (valid < 32) w &= valid > 0 ? ((1u << valid) - 1u) : 0u;
+                        low += __popc(w);
+                    }
+                    nlow[i] = (uint8_t)(low > 255 ? 255 : low);
+                }
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 3; k++) run[k] += tot[k];
+        for (int k = 0; k < UZ_PK_SUMS; k++) run[k] += tot[k];
     }
 }
 
@@ -330,23 +372,27 @@ __global__ __launch_bounds__(256) void k_pack_ascii(int64_t n, const RecA *__res
 }
 __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
                                                     const uint32_t *__restrict__ qoff, const uint8_t *__restrict__ qual8,
-                                                    const uint32_t *__restrict__ qual_off16, int thr, uint8_t *qlow) {
+                                                    const uint32_t *__restrict__ qual_off16, int thr, uint8_t *qlow, uint8_t *nlow) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int ls = rb[i].l_seq;
     const uint8_t *src = qual8 + ((size_t)qual_off16[i] << 4);
     uint32_t *dst = reinterpret_cast<uint32_t *>(qlow) + (size_t)qoff[i];
     const int units = (int)UZ_ROW_UNITS(ls);
+    int low = 0;
     for (int u = 0; u < units; u++) {
         uint32_t w = 0;
         for (int k = 0; k < 32 && 32 * u + k < ls; k++) w |= (uint32_t)((int)src[32 * u + k] < thr) << k;
         dst[u] = w;
+        low += __popc(w);
     }
+    nlow[i] = (uint8_t)(low > 255 ? 255 : low);
 }
 
 // cohort batches: the headers of one kid's table copied into the merged table with its bases added
 __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
-                                                    const uint32_t *__restrict__ sqo, const uint32_t *__restrict__ sk3, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3,
+                                                    const uint32_t *__restrict__ sqo, const uint32_t *__restrict__ sk3, const uint8_t *__restrict__ snl,
+                                                    RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3, uint8_t *dnl,
                                                     int32_t rec_base,
                                                     uint32_t cigar_base, uint32_t unit_base, uint32_t seq_base, uint32_t qname_base) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -357,14 +403,14 @@ __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__res
     if (A.sq_off != UZ_NO_SEQ_OFF) A.sq_off += seq_base;
     if (B.mate >= 0) B.mate += rec_base;
     B.qname += qname_base;
-    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] + unit_base; dk3[i] = sk3[i];
+    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dk3[i] = sk3[i]; dnl[i] = snl[i];
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
     R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm; R.k3 = r.k3;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
-    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.qc = r.qc; R.coarse = r.coarse;
+    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.qc = r.qc; R.coarse = r.coarse;
     R.err = nullptr; // set by the launcher of the per-DNM kernel
     return R;
 }
@@ -409,18 +455,18 @@ __global__ __launch_bounds__(256) void k_patch_exc(int64_t n_exc, const uint32_t
 }
 } // namespace
 
-size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * 3 * sizeof(unsigned long long); }
+size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * UZ_PK_SUMS * sizeof(unsigned long long); }
 
 void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col, void *off_scratch) {
     static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
     if (r.n <= 0) return;
     const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
     unsigned long long *sums = (unsigned long long *)off_scratch;
-    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, sums);
+    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, col.n_low, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
-                       (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, c->hflags);
+                       (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3);
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, reinterpret_cast<uint32_t *>(r.qlow), c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
@@ -441,8 +487,8 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
                      int64_t seq_base, uint32_t qname_base) {
     if (src.n <= 0) return;
     hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
-                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint32_t *)src.k3,
-                       (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base, dst.k3 + rec_base,
+                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint32_t *)src.k3, (const uint8_t *)src.nlow,
+                       (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base, dst.k3 + rec_base, dst.nlow + rec_base,
                        (int32_t)rec_base, (uint32_t)cigar_base,
                        (uint32_t)unit_base, (uint32_t)seq_base, qname_base);
     UZ_HIP(hipGetLastError());
@@ -451,8 +497,8 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
     if (src.n_seq_units)
         UZ_HIP(hipMemcpyAsync(const_cast<uint8_t *>(dst.seq4) + (size_t)seq_base * UZ_SEQ4_UNIT_BYTES, src.seq4, (size_t)src.n_seq_units * UZ_SEQ4_UNIT_BYTES,
                               hipMemcpyDeviceToDevice, st));
-    if (src.n_row_units) {
-        UZ_HIP(hipMemcpyAsync(dst.qlow + (size_t)unit_base * UZ_QLOW_UNIT_BYTES, src.qlow, (size_t)src.n_row_units * UZ_QLOW_UNIT_BYTES,
+    if (src.n_plane_units) {
+        UZ_HIP(hipMemcpyAsync(dst.qlow + (size_t)unit_base * UZ_QLOW_UNIT_BYTES, src.qlow, (size_t)src.n_plane_units * UZ_QLOW_UNIT_BYTES,
                               hipMemcpyDeviceToDevice, st));
     }
 }
@@ -476,7 +522,7 @@ void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual) {
     const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
     if (r.n > 0) {
         hipLaunchKernelGGL(k_build_qlow, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, (const RecA *)r.rec_a,
-                           (const RecB *)r.rec_b, (const uint32_t *)r.qoff, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow);
+                           (const RecB *)r.rec_b, (const uint32_t *)r.qoff, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow, r.nlow);
         UZ_HIP(hipGetLastError());
     }
     r.qlow_thr = min_base_qual;
@@ -585,6 +631,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         c->hflags[0] = 0;
         throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
                                   : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
+                                  : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
                                            : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
@@ -731,8 +778,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         if (evidence) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
         UZ_HIP(hipStreamSynchronize(c->stream));
         if (c->hflags[1]) {
+            const int f = c->hflags[1];
             c->hflags[1] = 0;
-            throw UzError{UZ_E_STATE, "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
+            throw UzError{UZ_E_STATE, f == 2 ? "the read stage asked for a base-quality bit of a record staged without its quality row (more than 10 low-quality bases, or no bases): such a record can never pass goodread -- the staging rule and the kernel disagree"
+                                             : "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
         }
         const unsigned long long used = *hused;
         c->prof[UZ_K_PHASE].last_units = (int64_t)*(const int32_t *)(hused + 1); // DNMs that took the HBM build

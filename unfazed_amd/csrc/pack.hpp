@@ -70,13 +70,13 @@ static inline int uz_pack_rows_host(const uint8_t *seq, const uint8_t *qual, int
                                     uint8_t *qlow_row) {
     const uint32_t units = UZ_ROW_UNITS(l_seq);
     for (uint32_t b = 0; b < units * UZ_SEQ4_UNIT_BYTES; b++) seq4_row[b] = 0;
-    for (uint32_t b = 0; b < units * UZ_QLOW_UNIT_BYTES; b++) qlow_row[b] = 0;
+    for (uint32_t b = 0; qlow_row && b < units * UZ_QLOW_UNIT_BYTES; b++) qlow_row[b] = 0;
     int bad = 0;
     for (int k = 0; k < l_seq; k++) {
         const uint8_t c = uz_ascii_nt16(seq[k]);
         if (c == 0xFF) bad = -1;
         seq4_row[k >> 1] |= (uint8_t)((c & 15u) << ((k & 1) ? 0 : 4));
-        if ((int)qual[k] < min_base_qual) qlow_row[k >> 3] |= (uint8_t)(1u << (k & 7));
+        if (qlow_row && (int)qual[k] < min_base_qual) qlow_row[k >> 3] |= (uint8_t)(1u << (k & 7));
     }
     return bad;
 }
@@ -88,7 +88,7 @@ static inline int uz_pack_rows_host2(const uint8_t *seq, const uint8_t *qual, in
                                      uint8_t *qlow_row, F &&exc) {
     const uint32_t units = UZ_ROW_UNITS(l_seq);
     for (uint32_t b = 0; b < units * UZ_SEQ2_UNIT_BYTES; b++) seq2_row[b] = 0;
-    for (uint32_t b = 0; b < units * UZ_QLOW_UNIT_BYTES; b++) qlow_row[b] = 0;
+    for (uint32_t b = 0; qlow_row && b < units * UZ_QLOW_UNIT_BYTES; b++) qlow_row[b] = 0;
     int bad = 0;
     for (int k = 0; k < l_seq; k++) {
         const uint8_t c2 = uz_ascii_seq2(seq[k]);
@@ -97,7 +97,7 @@ static inline int uz_pack_rows_host2(const uint8_t *seq, const uint8_t *qual, in
             const uint8_t c4 = uz_ascii_nt16(seq[k]);
             if (c4 == 0xFF) bad = -1; else exc(k, c4);
         }
-        if ((int)qual[k] < min_base_qual) qlow_row[k >> 3] |= (uint8_t)(1u << (k & 7));
+        if (qlow_row && (int)qual[k] < min_base_qual) qlow_row[k >> 3] |= (uint8_t)(1u << (k & 7));
     }
     return bad;
 }

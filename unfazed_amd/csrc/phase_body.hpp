@@ -62,6 +62,7 @@ extern "C" long long *uz_emu_log; // optional: 12 values per DNM (sizes of its w
 // sums of n_cigar / UZ_ROW_UNITS(l_seq) (rows and CIGAR words lie back to back in record order).
 struct RecA { int32_t start, end; uint32_t cigar_off, sq_off; }; // sq_off: seq4 row, in row units (32 bases); UZ_NO_SEQ_OFF = staged without bases
 #define UZ_NO_SEQ_OFF 0xFFFFFFFFu
+#define UZ_NO_QLOW_OFF 0xFFFFFFFFu
 struct RecB { int32_t mate; uint32_t qname; uint16_t l_seq, n_cigar; int32_t tlen; };
 UZ_HD void uz_pack_rec(RecA &A, RecB &B, int32_t start, int32_t end, uint32_t cigar_off, uint32_t sq_off, int32_t mate,
                        uint32_t qname, uint16_t l_seq, uint16_t n_cigar, int32_t tlen) {
@@ -89,7 +90,9 @@ struct RD { // alignment records of one table (device pointers)
     const uint32_t *cigar; // BAM encoding, back to back in record order
     const uint8_t *seq4;   // 4-bit bases, 16 bytes per row unit
     const uint8_t *qlow;   // 1 bit per base (quality below the threshold), 4 bytes per row unit
-    const uint32_t *qoff;  // quality-plane row of every record, in row units (every record has one; seq4 rows only the records with bases)
+    const uint32_t *qoff;  // quality-plane row of every record, in row units; UZ_NO_QLOW_OFF = no row (the list form of the staged plane keeps
+                           // rows only for the records whose bits can be asked for: bases staged and at most UZ_QLOW_LIST_MAX low ones)
+    const uint8_t *nlow;   // number of low-quality bases of every record, saturated at 255
     int32_t *err;          // [0] set when the bases of a record staged without them are requested (must never happen)
     const uint8_t *qc;
     const int32_t *coarse; // start of every 4096th record (L2-resident search index), may be null
@@ -393,7 +396,10 @@ UZ_DEV uint8_t uz_base(const RD &R, uint32_t sq_off, int k) {
     if (sq_off == UZ_NO_SEQ_OFF) { *R.err = 1; return 0; } // the host left the bases out: its reach rule and the kernel disagree
     return uz_seq4_base(R.seq4, sq_off, k);
 }
-UZ_DEV bool uz_qual_low(const RD &R, uint32_t q_off, int k) { return uz_qlow_bit(R.qlow, q_off, k) != 0; }
+UZ_DEV bool uz_qual_low(const RD &R, uint32_t q_off, int k) {
+    if (q_off == UZ_NO_QLOW_OFF) { *R.err = 2; return false; } // a bit of a record that cannot be "good": the staging rule and the kernel disagree
+    return uz_qlow_bit(R.qlow, q_off, k) != 0;
+}
 
 // get_allele_at :56-73 -> the n bases start at query index `idx` of the row `sq_off`; false = the reference's False
 UZ_DEV bool uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n, uint32_t &sq_off, int &idx) {
@@ -1090,7 +1096,7 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 al[u] = qi[u] >= 0 ? uz_base(R, row[u], qi[u]) : (uint8_t)0;
-                low[u] = (qi[u] >= 0 && own[u]) ? uz_qual_low(R, q0[u], qi[u]) : true;
+                low[u] = (qi[u] >= 0 && own[u] && sq[u] < E) ? uz_qual_low(R, q0[u], qi[u]) : true; // (only a registration uses it, below)
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -1483,6 +1489,6 @@ UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual) {
     const uint32_t *c = R.cigar + A.cigar_off;
     int nonmatch = 0, none = 0;
     for (int k = 0; k < (int)B.n_cigar; k++) uz_cigar_op_counts(c[k], nonmatch, none);
-    const int low = uz_row_low_count(R, R.qoff[seg], B.l_seq); // :43-46
+    const int low = R.nlow[seg]; // :43-46 (only compared with 10: the saturation at 255 does not matter)
     return uz_seg_qc_combine(fm & 0xFFFFu, aux, (int)((fm >> 16) & 0xFFu), min_map_qual, low, B.n_cigar, nonmatch, none);
 }

@@ -89,7 +89,10 @@ struct ReadsDev {
     int32_t *max_span = nullptr;
     void *rec_a = nullptr, *rec_b = nullptr; // RecA / RecB headers (phase_body.hpp)
     uint32_t *fm = nullptr;    // flag | mapq << 16 | aux << 24
-    uint32_t *qoff = nullptr;  // quality-plane row of every record (row units)
+    uint32_t *qoff = nullptr;  // quality-plane row of every record (row units); UZ_NO_QLOW_OFF: none (its bits can never be asked for)
+    uint8_t *nlow = nullptr;   // low-quality bases of every record, saturated at 255 (what K3a needs of the qualities)
+    int64_t n_qlow_pos = 0;    // list form of the staged plane: entries (checked against the columns by the header build)
+    int64_t n_plane_units = 0; // units the quality-plane store holds: n_row_units (plane / ASCII form: every record has a row), n_seq_units (list form)
     uint32_t *k3 = nullptr;    // l_seq | n_cigar << 16 | simple << 31 (uz_pack_k3): the lengths K3a needs in one word
     const uint32_t *cigar = nullptr;
     const uint8_t *seq4 = nullptr;
@@ -108,6 +111,8 @@ struct ReadsDev {
     // would wait behind the persistent per-DNM grid and hold up the next table's copies
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
+    const void *col_q[3] = {nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos of RecColumns, for the deferred header build
+    int32_t col_qwide = 0;
     // a table that arrived with two-bit base rows (uz_reads_packed_view.seq2): the staged rows and the listed bases, expanded
     // into seq4 by the header build (uz_build_records); null afterwards / for four-bit tables
     const uint8_t *seq2_staged = nullptr;
@@ -224,6 +229,12 @@ struct RecColumns {
     const uint32_t *qname;
     const uint16_t *flag, *l_seq, *n_cigar;
     const uint8_t *mapq, *aux;
+    // qualities of the staged form: the plane itself (plane_in: the header build counts its bits into nlow) or its list
+    // form (n_low + qlow_pos: the header build copies the counts and writes the plane rows of the listed records); both
+    // null for an ASCII upload, whose plane and counts are built from the quality bytes (uz_build_qlow)
+    const uint32_t *plane_in = nullptr;
+    const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
+    int32_t qpos_wide = 0;
 };
 // Small transfers on the COMPUTE path go through a copy kernel, one side in pinned host memory, never through
 // hipMemcpyAsync: the DMA engine is in order, and a 2 KB result copy queued behind gigabytes of staged uploads would hold

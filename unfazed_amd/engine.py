@@ -146,15 +146,18 @@ class HipEngine:
         self._ck(self.L.uz_family_upload(self.h, int(sites_h), v.ref(), C.byref(fid)), "uz_family_upload")
         return fid.value
 
-    def upload_reads(self, reads, min_base_qual=None) -> int:
+    def upload_reads(self, reads, min_base_qual=None, point_only=False) -> int:
         """A decoded table -> HBM.  With the base-quality threshold of the run (min_base_qual = --min-gt-qual) the table
-        goes over the link in the staged form (packed on the host into pinned memory, 2.8x fewer bytes); without it in the
-        ASCII form, which the device packs and which then serves any threshold."""
+        goes over the link in the staged form (packed on the host into pinned memory, several times fewer bytes); without it
+        in the ASCII form, which the device packs and which then serves any threshold.
+        point_only: the table will only serve batches of point variants (SNV / indel) -- the qualities then travel as
+        per-record counts + short position lists instead of the one-bit plane (uz_types.h: the list form is exact for "good"
+        records, and a point-variant batch never looks at the bits of any other; an SV batch does)."""
         v = abi.reads_view(reads)
         if min_base_qual is not None:
             from . import io_native
             pool = PinnedPool()
-            rid = self.upload_reads_packed(io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc))
+            rid = self.upload_reads_packed(io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only)))
             self.wait_reads(rid)  # the pinned buffers go back right away: the caller may drop the table
             self._staged.pop(rid, None)
             pool.free_all()

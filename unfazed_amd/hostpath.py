@@ -444,7 +444,10 @@ class PhasingHost:
                     self.sites.pos, het_off, het_idx, params, vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
                     end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff)
                 region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
-                rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual))
+                # (a batch of point variants only ever asks for the quality bits of "good" records: the qualities travel as counts
+                # + short lists; SV evidence is collected under goodread(read, True), which does not count them: the plane)
+                point_only = all(vartype_code(dnms[i]["vartype"]) == abi.VT_POINT for i in idxs)
+                rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=point_only)
                 handles.append(rh)
             else:
                 rh = self.reads(bam, params.min_gt_qual)
