@@ -54,7 +54,7 @@ def parse():
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=8, help="DNM chunks of the staged pass (uploads overlap the kernels)")
-    ap.add_argument("--cpu-dnms", type=int, default=30000, help="DNMs in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-staged", action="store_true", help="resident pass only (profiling runs)")
     return ap.parse_args()
@@ -240,7 +240,7 @@ def main():
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
             pv = part.view
-            staged_bytes += (int(pv.n_segs) * 28 + int(pv.n_cigar_total) * 4
+            staged_bytes += (int(pv.n_segs) * (28 if pv.end else 24) + int(pv.n_cigar_total) * 4
                              + (int(pv.n_segs) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if pv.n_low else int(pv.n_row_units) * 4)
                              + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
@@ -424,6 +424,106 @@ def main():
 
 
 def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):
+    """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first `cpu_dnms` DNMs of the GPU's batch
+    (whole clusters).  The sample is cut into contiguous cluster ranges, each with its OWN records table (regenerated on the
+    host by the gcc build of the generator, outside the timing -- as separate workers each reading their own regions of the
+    alignment file would hold it); T threads take the ranges round-robin, one oracle call (find + phase) per range.  The
+    oracle's per-call set-up is proportional to the table it is handed, so one shared table does not scale past a few
+    threads; per-range tables do.  Results are compared with the GPU's."""
+    if cnv:  # the two breakpoints of an event lie in different clusters: one table for the whole sample
+        return cpu_baseline_shared_table(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv)
+    from oracle import oracle as orc
+    from synth import bigsynth
+    from unfazed_amd import abi
+    ncpu = os.cpu_count() or 1
+    c_hi = cl.of_dnm(per_ev * min(args.cpu_dnms, ev.n) - 1) + 1
+    m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1]) // per_ev  # whole clusters
+    nc = len(sc.contig_off) - 1
+    sv = abi.SitesView()
+    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags,
+                ref_base=sc.ref_base, alt_base=sc.alt_base)
+    sv.n_sites, sv.n_contigs = sc.n, nc
+    for k, a in keep.items():
+        setattr(sv, k, a.ctypes.data)
+    sh = abi.Held(sv, keep)
+    # the GPU folded the complex flag into bit 6 of its own copy of gt; the host copy is untouched
+    fh = abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
+    orc.lib()
+    # ranges: cluster boundaries nearest to an even split of the sample's entries of `dn` (DNMs / breakpoints)
+    n_ranges = max(1, min(4 * ncpu, c_hi))
+    ends = cl.d0[:c_hi] + cl.nd[:c_hi]
+    cuts = sorted({int(np.searchsorted(ends, per_ev * m * (k + 1) / n_ranges, side="left")) + 1 for k in range(n_ranges)} | {c_hi})
+    cuts = [c for c in cuts if c <= c_hi]
+    ranges, c0 = [], 0
+    for c1 in cuts:
+        if c1 > c0:
+            ranges.append((c0, c1))
+            c0 = c1
+    jobs = []
+    for (a, b) in ranges:
+        e0 = int(cl.d0[a]) // per_ev
+        e1 = min(m, int(cl.d0[b - 1] + cl.nd[b - 1]) // per_ev)
+        if e1 <= e0:
+            continue
+        rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, a, b, threads=min(ncpu, 64))
+        dv = abi.dnms_view(ev.contig[e0:e1], ev.contig[e0:e1], ev.start[e0:e1], ev.end[e0:e1], ev_vt[e0:e1], ev_refs[e0:e1], ev_alts[e0:e1], cutoff)
+        jobs.append((e0, e1, rh, dv))
+
+    def run(threads):
+        out = dict(status=np.full(m, abi.ST_SKIPPED, np.int32), counts=np.zeros((m, 4), np.int32), origin=np.zeros(m, np.int32),
+                   evidence=np.zeros(m, np.int32))
+        if cnv:
+            out["etype"] = np.zeros(m, np.int32)
+            out["cnv_counts"] = np.zeros((m, 2), np.int32)
+        t0 = time.perf_counter()
+
+        def work(t):
+            for j in range(t, len(jobs), threads):
+                e0, e1, rh, dv = jobs[j]
+                found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+                p = orc.phase(P, sh, rh, dv, found, keep_lists=False)
+                out["status"][e0:e1], out["counts"][e0:e1] = p["status"], p["counts"]
+                if cnv:
+                    k = orc.phase_cnv(P, sh, fh, dv, rb_counts=p["counts"])
+                    for name in ("origin", "evidence", "etype", "cnv_counts"):
+                        out[name][e0:e1] = k[name]
+                else:
+                    out["origin"][e0:e1], out["evidence"][e0:e1] = p["origin"], p["evidence"]
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0, out
+
+    dt1, r1 = run(1)
+    dt2, _ = run(2)
+    ladder = sorted({t for t in (8, 32, 64, 128, ncpu) if 2 < t <= ncpu})
+    best = None
+    sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
+    for t in ladder:
+        dtt, rt = run(t)
+        sweep[str(t)] = round(m / dtt, 1)
+        if best is None or dtt < best[0]:
+            best = (dtt, rt, t)
+    if best is None:
+        best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
+    dtc, rc, cores = best
+    mism = 0
+    for k in r1:
+        mism += int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
+        mism += int((rc[k] != r1[k]).sum())
+    return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",
+            "sample": "first %d DNMs of the GPU batch (whole read clusters) in %d cluster ranges, each with its own records table regenerated on the host "
+                      "before the timing; oracle find+phase per range, threads over ranges (best of a ladder of thread counts: %d)" % (m, len(jobs), cores),
+            "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
+            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
+            "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu,
+            "parity_mismatches_vs_gpu": mism}
+
+
+def cpu_baseline_shared_table(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):
     """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first `cpu_dnms` DNMs of the
     GPU's batch (whole clusters; their records regenerated on the host by the gcc build of the generator), 1, 2 and
     more threads over DNM ranges, as the reference's thread pool over DNMs; its results are compared with the GPU's."""

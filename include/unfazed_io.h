@@ -115,6 +115,9 @@ int uz_vcf_is_bcf(const uz_vcf *h);
  * lists when out->n_low is set (from either form of the source), the plane otherwise (plane sources only). */
 /* sizes of the packed form of an ASCII table */
 int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t *n_row_units);
+/* 1 when every record's `end` is what htslib's bam_endpos gives for its CIGAR (true of a BAM decoder's table): the packed form
+ * may then leave the column out (out->end = NULL) and the device derives it */
+int uz_reads_pack_end_derivable(const uz_reads_view *in, int threads, int32_t *yes);
 /* the quality plane as lists (uz_types.h): entries of qlow_pos for the threshold, and whether a read is longer than 256 bases */
 int uz_reads_pack_lists(const uz_reads_view *in, int min_base_qual, int threads, int64_t *n_qlow_pos, int32_t *wide);
 /* number of bases that are not A/C/G/T: the length of the exc_* columns of the two-bit form */
@@ -144,6 +147,7 @@ int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */
 int uz_select_qlow_pos_wide(const uz_select *s);  /* 1 when a kept read is longer than 256 bases */
+int uz_select_end_derivable(const uz_select *s);  /* 1: the output may leave `end` out (NULL) */
 int64_t uz_select_n_records(const uz_select *s);
 int64_t uz_select_n_cigar_total(const uz_select *s);
 int64_t uz_select_n_row_units(const uz_select *s);

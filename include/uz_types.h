@@ -172,7 +172,8 @@ typedef struct uz_reads_packed_view {
     const int64_t *contig_off; /* [n_contigs+1] */
     const int32_t *max_span;   /* [n_contigs] */
     const int32_t *start;
-    const int32_t *end;
+    const int32_t *end;        /* may be NULL: the device then derives it as htslib's bam_endpos does -- start + 1 for an unmapped record or one
+                                * without CIGAR, else start + max(1, reference bases of the CIGAR) -- which is what a BAM decoder fills in */
     const int32_t *tlen;
     const int32_t *mate;
     const uint32_t *qname;

@@ -94,14 +94,16 @@ def _same_low(low, bits):
 def test_pack_matches_ascii_columns(two_bit):
     sc, dn, cl, rh, arrs = _workload(60)
     for thr in (20, 13, 0, 300):
-        pk = io_native.pack_reads(rh, thr, two_bit=two_bit, lists=two_bit)
+        pk = io_native.pack_reads(rh, thr, two_bit=two_bit, lists=two_bit, with_end=None if two_bit else True)
+        assert ("end" in pk.arrays) == (not two_bit)  # the generator's `end` is what the CIGAR gives: the column can stay home
         if two_bit:
             n_other = int((~np.isin(arrs["seq"], LUT[[1, 2, 4, 8]])).sum())  # (rows are written back to back: every byte is a base)
             assert pk.view.n_exc >= 4 and pk.view.n_exc <= n_other and np.all(np.diff(pk.arrays["exc_rec"][: pk.view.n_exc].astype(np.int64)) >= 0)
         n = int(rh.view.n_segs)
         assert pk.view.n_segs == n and pk.view.min_base_qual == thr
         for name, _ in abi.PACKED_RECORD_COLS:
-            assert np.array_equal(pk.arrays[name][:n], arrs[name][:n]), name
+            if name in pk.arrays:
+                assert np.array_equal(pk.arrays[name][:n], arrs[name][:n]), name
         uoff = np.concatenate([[0], np.cumsum(abi.row_units(arrs["l_seq"][:n]))])
         coff = np.concatenate([[0], np.cumsum(arrs["n_cigar"][:n].astype(np.int64))])
         assert pk.view.n_row_units == uoff[-1] and pk.view.n_cigar_total == coff[-1]
@@ -165,7 +167,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
     co, ci, cf, ho, hi = found
     want = orc.phase(P, sh, rh, dv, found, keep_lists=True)
     assert (want["status"] == abi.ST_OK).sum() > 30
-    pk = io_native.pack_reads(rh, P.min_gt_qual, two_bit=two_bit, lists=src_lists)
+    pk = io_native.pack_reads(rh, P.min_gt_qual, two_bit=two_bit, lists=src_lists, with_end=True)  # (a source of selections keeps `end`)
     src = io_native.ReadsSource(pk)
     N = int(rh.view.n_segs)
     contig_of_rec = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
@@ -173,7 +175,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
     total = 0
     for a, b in zip(bounds[:-1], bounds[1:]):
         fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
-        part, idx = src.select(fc, flo, fhi, want_index=True, lists=out_lists)
+        part, idx = src.select(fc, flo, fhi, want_index=True, lists=out_lists, with_end=None if out_lists else True)
         # brute force: overlap of any fetch, then the closure under mate
         keep = np.zeros(N, bool)
         for c, lo, h in zip(fc, flo, fhi):
@@ -186,8 +188,9 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
         total += idx.size
         # packed columns of the selection = the packed columns of those records; a record no fetch returns (reachable
         # only as a mate) travels without its bases
+        assert ("end" in part.arrays) == (not out_lists)  # (left out by default; the plane-form case below asks for it)
         for name, _ in abi.PACKED_RECORD_COLS:
-            if name not in ("mate", "aux"):
+            if name not in ("mate", "aux") and name in part.arrays:
                 assert np.array_equal(part.arrays[name][: idx.size], pk.arrays[name][idx]), name
         no_seq = (part.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ) != 0
         assert np.array_equal(no_seq, ~direct[idx]) and 0.3 < no_seq.mean() < 0.6

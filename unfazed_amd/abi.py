@@ -182,17 +182,20 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False) -> "Held":
+                      qlow_pos_wide=False, with_end=True) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
-    n_qlow_pos: None = the quality plane (qlow); a number = per-record counts (n_low) + that many listed positions (qlow_pos)."""
+    n_qlow_pos: None = the quality plane (qlow); a number = per-record counts (n_low) + that many listed positions (qlow_pos).
+    with_end: False leaves the `end` column out (the device derives it from the CIGAR, as a BAM decoder did)."""
     if n_seq_units is None:
         n_seq_units = n_row_units
     if alloc is None:
         alloc = lambda nbytes: np.zeros(max(16, nbytes), dtype=np.uint8)  # noqa: E731
     arrs = {}
     for name, dt in PACKED_RECORD_COLS:
+        if name == "end" and not with_end:
+            continue
         arrs[name] = alloc(max(1, n) * np.dtype(dt).itemsize)[: max(1, n) * np.dtype(dt).itemsize].view(dt)
     arrs["contig_off"] = alloc(8 * (n_contigs + 1))[: 8 * (n_contigs + 1)].view(np.int64)
     arrs["max_span"] = alloc(4 * max(1, n_contigs))[: 4 * max(1, n_contigs)].view(np.int32)

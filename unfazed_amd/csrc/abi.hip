@@ -465,11 +465,12 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     h2d(st, r.contig_off, v->contig_off, (size_t)v->n_contigs + 1);
     h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs);
     RecColumns col;
-    col.start = h2d(st, start, v->start, n); col.end = h2d(st, end, v->end, n); col.tlen = h2d(st, tlen, v->tlen, n);
+    col.start = h2d(st, start, v->start, n); col.end = v->end ? h2d(st, end, v->end, n) : nullptr; col.tlen = h2d(st, tlen, v->tlen, n);
     col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n); col.flag = h2d(st, flag, v->flag, n);
     col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
     col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
     r.cigar = h2d(st, cigar, v->cigar, nc);
+    col.cigar_in = r.cigar;
     if (two_bit) { // half the bytes over the link; the header build expands them into seq4
         r.seq4 = seq4;
         r.seq2_staged = h2d(st, seq2, v->seq2, ns * UZ_SEQ2_UNIT_BYTES);
@@ -488,7 +489,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     }
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
-    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_qwide = col.qpos_wide;
+    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_qwide = col.qpos_wide;
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
         for (int k = 0; k < 10; k++) r.col_ptrs[k] = p[k];
@@ -508,6 +509,7 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.l_seq = (const uint16_t *)r.col_ptrs[6]; col.n_cigar = (const uint16_t *)r.col_ptrs[7]; col.mapq = (const uint8_t *)r.col_ptrs[8];
     col.aux = (const uint8_t *)r.col_ptrs[9];
     col.plane_in = (const uint32_t *)r.col_q[0]; col.n_low = (const uint8_t *)r.col_q[1]; col.qlow_pos = (const uint8_t *)r.col_q[2];
+    col.cigar_in = (const uint32_t *)r.col_q[3];
     col.qpos_wide = r.col_qwide;
     UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, c->stream));
     uz_build_records(c, c->stream, r, col, r.build_scratch);
@@ -641,6 +643,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             col.start = v->start; col.end = v->end; col.tlen = v->tlen; col.mate = v->mate; col.qname = v->qname;
             col.flag = v->flag; col.l_seq = v->l_seq; col.n_cigar = v->n_cigar; col.mapq = v->mapq; col.aux = v->aux;
             r.cigar = v->cigar; r.seq4 = v->seq4; r.qlow = const_cast<uint8_t *>(v->qlow);
+            col.cigar_in = v->cigar;
             if (v->seq2) {
                 r.seq4 = seq4_own; r.seq2_staged = v->seq2;
                 r.n_exc = v->n_exc; r.exc_rec = v->exc_rec; r.exc_pos = v->exc_pos; r.exc_code = v->exc_code;

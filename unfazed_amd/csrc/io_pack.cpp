@@ -84,6 +84,7 @@ struct uz_select {
     uint64_t n_cigar = 0, n_units = 0, n_seq = 0;
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
     std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
+    int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
     int64_t n_qpos = 0;                 // entries of the output's qlow_pos
     std::vector<int64_t> exc_lo, exc_n; // seq2 sources: per kept record, its slice of the source's exception list (0 entries without bases)
@@ -123,6 +124,19 @@ int uz_reads_pack_lists(const uz_reads_view *in, int min_base_qual, int threads,
         int64_t tot = 0, w2 = 0;
         for (int k = 0; k < wk; k++) { tot += part[(size_t)k]; w2 |= wd[(size_t)k]; }
         *n_qlow_pos = tot; *wide = (int32_t)w2;
+    });
+}
+
+int uz_reads_pack_end_derivable(const uz_reads_view *in, int threads, int32_t *yes) {
+    return guarded([&] {
+        if (!in || !yes) fail(UZ_IO_E_ARG, "null argument");
+        threads = resolve_threads(threads);
+        std::atomic<int> bad{0};
+        parallel_slices(in->n_segs, workers_for(in->n_segs, threads, 1 << 14), [&](int64_t lo, int64_t hi, int) {
+            for (int64_t i = lo; i < hi; i++)
+                if (in->end[i] != uz_bam_endpos(in->start[i], in->flag[i], in->n_cigar[i], in->cigar + in->cigar_off[i])) { bad.store(1); return; }
+        });
+        *yes = bad.load() ? 0 : 1;
     });
 }
 
@@ -191,7 +205,9 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
         std::vector<std::vector<Exc>> exc((size_t)wk_pack);
         parallel_slices(n, wk_pack, [&](int64_t lo, int64_t hi, int slice) {
             for (int64_t i = lo; i < hi; i++) {
-                w(out->start)[i] = in->start[i]; w(out->end)[i] = in->end[i]; w(out->tlen)[i] = in->tlen[i];
+                w(out->start)[i] = in->start[i]; w(out->tlen)[i] = in->tlen[i];
+                if (out->end) w(out->end)[i] = in->end[i];
+                else if (in->end[i] != uz_bam_endpos(in->start[i], in->flag[i], in->n_cigar[i], in->cigar + in->cigar_off[i])) bad.store(3);
                 w(out->mate)[i] = in->mate[i]; w(out->qname)[i] = in->qname[i]; w(out->flag)[i] = in->flag[i];
                 w(out->l_seq)[i] = in->l_seq[i]; w(out->n_cigar)[i] = in->n_cigar[i]; w(out->mapq)[i] = in->mapq[i];
                 w(out->aux)[i] = in->aux[i];
@@ -218,6 +234,7 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
                 }
             }
         });
+        if (bad.load() == 3) fail(UZ_IO_E_ARG, "the `end` column was left out but a record's end is not what its CIGAR gives (uz_reads_pack_end_derivable)");
         if (bad.load()) fail(UZ_IO_E_RANGE, "SEQ holds a character outside BAM's 16-code alphabet");
         if (two_bit) {
             int64_t tot = 0;
@@ -241,6 +258,7 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
         offsets(full->n_segs, full->n_cigar, full->l_seq, full->aux, threads, coff, uoff, soff);
         if (coff.back() >= ((uint64_t)1 << 32) || uoff.back() >= ((uint64_t)1 << 32)) { delete src; fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets"); }
         if ((int64_t)soff.back() != full->n_seq_units) { delete src; fail(UZ_IO_E_ARG, "n_seq_units does not match the aux column"); }
+        if (!full->end) { delete src; fail(UZ_IO_E_ARG, "a source of selections needs the `end` column"); }
         if (!full->qlow && !full->n_low) { delete src; fail(UZ_IO_E_ARG, "the table has neither the quality plane nor its list form"); }
         if (full->n_low) {
             src->loff.assign((size_t)full->n_segs + 1, 0);
@@ -339,6 +357,9 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
             parallel_slices(sel->n_sel, wk, [&](int64_t a, int64_t b, int slice) {
                 int64_t c = 0;
                 for (int64_t k = a; k < b; k++) {
+                    const int64_t i = sel->index[(size_t)k];
+                    if (full->end[i] != uz_bam_endpos(full->start[i], full->flag[i], full->n_cigar[i], full->cigar + src->coff[(size_t)i]))
+                        __atomic_store_n(&sel->end_derivable, 0, __ATOMIC_RELAXED);
                     const int low = src_low_count(src, sel->index[(size_t)k]);
                     sel->n_low[(size_t)k] = (uint8_t)low;
                     if (sel->bases[(size_t)k] && low <= UZ_QLOW_LIST_MAX) c += low;
@@ -369,6 +390,7 @@ int64_t uz_select_n_row_units(const uz_select *s) { return s ? (int64_t)s->n_uni
 int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq : 0; }
 int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
 int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
+int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
     if (!s) return 0;
     const uz_reads_packed_view *f = &s->src->v;
@@ -392,6 +414,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (two_bit && !out->seq2) fail(UZ_IO_E_ARG, "the source table has two-bit base rows: the output view needs seq2 (and the exc_* columns)");
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
         out->n_exc = two_bit ? s->n_exc : 0;
+        if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
         const bool lists = out->n_low != nullptr;
         if (!lists && !full->qlow) fail(UZ_IO_E_ARG, "the source table has the quality plane as lists: the output view needs n_low / qlow_pos");
         if (lists && !out->qlow_pos_wide && uz_select_qlow_pos_wide(s)) fail(UZ_IO_E_ARG, "reads longer than 256 bases need qlow_pos_wide");
@@ -429,7 +452,8 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         parallel_slices(m, workers_for(m, threads, 4096), [&](int64_t a, int64_t b, int) {
             for (int64_t k = a; k < b; k++) {
                 const int64_t i = s->index[k];
-                w(out->start)[k] = full->start[i]; w(out->end)[k] = full->end[i]; w(out->tlen)[k] = full->tlen[i];
+                w(out->start)[k] = full->start[i]; w(out->tlen)[k] = full->tlen[i];
+                if (out->end) w(out->end)[k] = full->end[i];
                 const int32_t mt = full->mate[i];
                 int32_t nm = -1;
                 if (mt >= 0 && mt < full->n_segs) { // new index of the mate: its rank in the (sorted) selection

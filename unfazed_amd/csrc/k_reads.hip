@@ -295,7 +295,10 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             RecA A;
             RecB B;
             const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : (uint32_t)(run[2] + pre[2] + inc[2] - v[2]);
-            uz_pack_rec(A, B, c.start[i], c.end[i], (uint32_t)(run[0] + pre[0] + inc[0] - v[0]), sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
+            const uint32_t cg = (uint32_t)(run[0] + pre[0] + inc[0] - v[0]);
+            const int32_t st0 = c.start[i];
+            const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, c.flag[i], nc, c.cigar_in + cg); // (column left out: as bam_endpos)
+            uz_pack_rec(A, B, st0, en0, cg, sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
             ra[i] = A;
             rb[i] = B;
             fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);

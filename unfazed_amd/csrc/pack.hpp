@@ -43,6 +43,18 @@ UZP_HD uint32_t uz_qlow_bit(const uint8_t *qlow, uint32_t unit, int k) {
     return (uint32_t)(qlow[(size_t)unit * UZ_QLOW_UNIT_BYTES + (size_t)(k >> 3)] >> (k & 7)) & 1u;
 }
 
+// end of an alignment as htslib's bam_endpos gives it: what a BAM decoder writes into the `end` column, and what the device
+// derives when the staged form leaves the column out
+UZP_HD int32_t uz_bam_endpos(int32_t start, uint32_t flag, uint32_t n_cigar, const uint32_t *cigar) {
+    if ((flag & 4u) || n_cigar == 0) return start + 1;
+    int64_t rl = 0;
+    for (uint32_t k = 0; k < n_cigar; k++) {
+        const uint32_t op = cigar[k] & 15u;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += (int64_t)(cigar[k] >> 4); // M D N = X
+    }
+    return (int32_t)(start + (rl > 0 ? rl : 1));
+}
+
 // ---- the two-bit rows of the host link (uz_reads_packed_view.seq2)
 // A 0, C 1, G 2, T 3; 0xFF for any other character
 UZP_HD uint8_t uz_ascii_seq2(uint8_t ch) {

@@ -111,7 +111,7 @@ struct ReadsDev {
     // would wait behind the persistent per-DNM grid and hold up the next table's copies
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
-    const void *col_q[3] = {nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos of RecColumns, for the deferred header build
+    const void *col_q[4] = {nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in of RecColumns, for the deferred header build
     int32_t col_qwide = 0;
     // a table that arrived with two-bit base rows (uz_reads_packed_view.seq2): the staged rows and the listed bases, expanded
     // into seq4 by the header build (uz_build_records); null afterwards / for four-bit tables
@@ -232,6 +232,7 @@ struct RecColumns {
     // qualities of the staged form: the plane itself (plane_in: the header build counts its bits into nlow) or its list
     // form (n_low + qlow_pos: the header build copies the counts and writes the plane rows of the listed records); both
     // null for an ASCII upload, whose plane and counts are built from the quality bytes (uz_build_qlow)
+    const uint32_t *cigar_in = nullptr; // the record's CIGAR words (at its cigar offset): `end` is derived from them when the column is left out (end == nullptr)
     const uint32_t *plane_in = nullptr;
     const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
     int32_t qpos_wide = 0;

@@ -157,7 +157,7 @@ class HipEngine:
         if min_base_qual is not None:
             from . import io_native
             pool = PinnedPool()
-            rid = self.upload_reads_packed(io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only)))
+            rid = self.upload_reads_packed(io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None))
             self.wait_reads(rid)  # the pinned buffers go back right away: the caller may drop the table
             self._staged.pop(rid, None)
             pool.free_all()

@@ -26,8 +26,8 @@ IO_EXPORTS = [
     "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
-    "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide",
+    "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable",
     "uz_reads_select_fill", "uz_select_free",
 ]
 
@@ -98,6 +98,8 @@ def load():
     lib.uz_reads_pack_exceptions.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
     lib.uz_reads_pack_lists.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.uz_select_qlow_pos_wide.argtypes = [C.c_void_p]
+    lib.uz_select_end_derivable.argtypes = [C.c_void_p]
+    lib.uz_reads_pack_end_derivable.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
     lib.uz_reads_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.uz_reads_source_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_reads_source_close.argtypes = [C.c_void_p]
@@ -288,14 +290,17 @@ def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
 
 
 # ---------------------------------------------------------------------------- staged (packed) records
-def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=None, two_bit: bool = True, lists: bool = True) -> "abi.Held":
+def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=None, two_bit: bool = True, lists: bool = True,
+               with_end=True) -> "abi.Held":
     """ASCII table (abi.reads_view / a decoder's view) -> the packed form uz_reads_upload_packed takes, for the
     base-quality threshold of the run.  alloc(nbytes) -> uint8 array chooses the memory (pinned for the upload).
     two_bit: base rows in two bits + the listed bases that are not A/C/G/T (half the bytes of the largest column on the
     host link; the device expands them); False = BAM's four-bit codes.
     lists: the quality plane as per-record counts + the positions of the records that can need them (a quarter of the plane's
     bytes; the device rebuilds the rows) -- for tables that serve batches of point variants only (uz_types.h); False = the plane
-    itself."""
+    itself.
+    with_end: True keeps the `end` column (a table that will be the source of selections needs it); None = leave it out when every
+    record's end is what its CIGAR gives (a BAM decoder's table) -- the device derives it."""
     lib = load()
     nc, nu = C.c_int64(0), C.c_int64(0)
     _check(lib, lib.uz_reads_pack_sizes(reads.ref(), C.byref(nc), C.byref(nu)))
@@ -309,8 +314,12 @@ def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=No
         nq, wd = C.c_int64(0), C.c_int32(0)
         _check(lib, lib.uz_reads_pack_lists(reads.ref(), int(min_base_qual), int(threads), C.byref(nq), C.byref(wd)))
         n_qpos, wide = int(nq.value), bool(wd.value)
+    if with_end is None:
+        yes = C.c_int32(0)
+        _check(lib, lib.uz_reads_pack_end_derivable(reads.ref(), int(threads), C.byref(yes)))
+        with_end = not yes.value
     out = abi.packed_view_alloc(int(reads.view.n_segs), int(reads.view.n_contigs), nc.value, nu.value, alloc, n_exc=n_exc,
-                                n_qlow_pos=n_qpos, qlow_pos_wide=wide)
+                                n_qlow_pos=n_qpos, qlow_pos_wide=wide, with_end=bool(with_end))
     _check(lib, lib.uz_reads_pack(reads.ref(), int(min_base_qual), int(threads), out.ref()))
     return out
 
@@ -326,7 +335,7 @@ class ReadsSource:
         self._h = _Handle(h, self.lib.uz_reads_source_close)
         self.threads = threads
 
-    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True):
+    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only)."""
@@ -343,7 +352,8 @@ class ReadsSource:
                                         self.lib.uz_select_n_row_units(sel), alloc, n_seq_units=self.lib.uz_select_n_seq_units(sel),
                                         n_exc=int(self.lib.uz_select_n_exc(sel)) if two_bit else None,
                                         n_qlow_pos=int(self.lib.uz_select_n_qlow_pos(sel)) if lists else None,
-                                        qlow_pos_wide=bool(self.lib.uz_select_qlow_pos_wide(sel)) if lists else False)
+                                        qlow_pos_wide=bool(self.lib.uz_select_qlow_pos_wide(sel)) if lists else False,
+                                        with_end=(not self.lib.uz_select_end_derivable(sel)) if with_end is None else bool(with_end))
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
