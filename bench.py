@@ -232,15 +232,17 @@ def main():
             c0, c1 = cl.of_dnm(per_ev * a), cl.of_dnm(per_ev * b - 1) + 1
             part_full = wl.download(c0, c1)
             src = io_native.ReadsSource(part_full)
-            fc, flo, fhi = fetch_points(ev.contig[a:b], ev.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P,
-                                        vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff)
-            # qualities as counts + short lists for the point-variant batch; the SV batch needs the plane (uz_types.h)
-            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=not cnv)
+            alen = np.array([max(len(r), len(x)) for r, x in zip(ev_refs[a:b], ev_alts[a:b])], np.int64)
+            fc, flo, fhi, fex = fetch_points(ev.contig[a:b], ev.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P,
+                                             vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff, allele_len=alen)
+            # point-variant batch: qualities as counts + short lists, and of every record's rows only the 32-base units that hold
+            # a fetched position; the SV batch needs the plane and whole rows (uz_types.h)
+            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=not cnv, extra=None if cnv else fex)
             del src, part_full
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
             pv = part.view
-            staged_bytes += (int(pv.n_segs) * (28 if pv.end else 24) + int(pv.n_cigar_total) * 4
+            staged_bytes += (int(pv.n_segs) * ((28 if pv.end else 24) + (2 if pv.umask else 0)) + int(pv.n_cigar_total) * 4
                              + (int(pv.n_segs) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if pv.n_low else int(pv.n_row_units) * 4)
                              + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
         site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
@@ -341,11 +343,11 @@ def main():
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
                 "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n)}
 
-    # K3a per examined record: the length word, the flag word, the quality-plane offset (4 B each) + the quality plane
-    # (4 B per 32 bases) read, 1 B written; the ~2 % of records with a real CIGAR also fetch a header and their words
+    # K3a per examined record: the length word, the flag word (4 B each), the count of low-quality bases and the reach-map byte
+    # (1 B each) read, 1 B written; the ~2 % of records with a real CIGAR also fetch a header and their words
     qc_ms, qc_n = prof_r[K_SEG_QC_PASS]
     qc_us = qc_ms / max(1, qc_n) * 1e3
-    qc_bytes = qc_records * (4 + 4 + 4 + 4.0 * ((int(P.readlen) + 31) // 32) + 1)
+    qc_bytes = qc_records * (4 + 4 + 1 + 1 + 1)
     k3a_traffic = None
     tpath = os.path.join(ROOT, "profiles", "k3a_traffic.json")
     if os.path.exists(tpath):

@@ -141,8 +141,12 @@ void uz_reads_source_close(uz_psrc *src);
  * (UZ_AUX_NO_SEQ: quality-plane row, no seq4 row) -- every base the extended read stage reads lies at a fetch point the
  * record overlaps.  all_bases = 1 (--no-extended: the join reads the mates of the DNM reads at candidate sites nobody
  * fetched): every kept record keeps its bases. */
+/* unit_masks = 1 (ignored with all_bases): a record whose single CIGAR operation spans the read keeps only the 32-base units
+ * of its rows that hold a fetched position -- position hi - 1 of a one- or two-base fetch, and extra[f] bases on (extra: NULL
+ * = 0; for the fetch at a DNM the length of its longer allele) -- see uz_reads_packed_view.umask; the output then needs
+ * the umask column and the list form of the qualities. */
 int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
-                         int threads, uz_select **out);
+                         int unit_masks, const uint16_t *extra, int threads, uz_select **out);
 int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */

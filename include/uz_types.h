@@ -217,7 +217,16 @@ typedef struct uz_reads_packed_view {
     int64_t n_qlow_pos;
     int32_t qlow_pos_wide;
     int32_t reserved2;
+    /* Which 32-base units of a record's base row were staged (NULL: every unit of every record; needs the list form of the
+     * qualities).  The read stage reads the bases of a record only at the fetch points it overlaps -- the DNM position (plus
+     * the length of the longer allele) and the het sites of the window -- so a selection made from those fetches can leave the
+     * other units of a 151-base read (usually four of its five) at home.  Bit u = unit u (bases 32u .. 32u+31) for a read of up
+     * to 480 bases; UZ_UMASK_ALL (0xFFFF) = every unit (any length; what a record with a multi-operation CIGAR gets).  The base
+     * row then holds the staged units back to back; n_seq_units counts staged units; exc_* entries in other units are ignored.
+     * A kernel that asks for a base of a unit that stayed home raises UZ_E_STATE. */
+    const uint16_t *umask;    /* [n_segs] */
 } uz_reads_packed_view;
+#define UZ_UMASK_ALL 0xFFFFu
 
 /* one batch of DNMs of one kid (one family, one BAM) */
 typedef struct uz_dnms_view {

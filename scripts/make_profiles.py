@@ -53,7 +53,7 @@ if os.path.exists(cal_path) and not k3a_factor:
     # for this kernel's access widths (4-byte words; the guide's x2 holds for 16-byte streams only)
     cal = json.load(open(cal_path))["k_seg_qc"]["counters_per_launch"]
     n_all = line["config"]["alignment_records"]
-    known_read = n_all * (4 + 4 + 4 + 20 + 1)  # length word, flag word, plane offset, plane row, the reach-map byte
+    known_read = n_all * (4 + 4 + 1 + 1)  # length word, flag word, low-quality count, the reach-map byte
     k3a_factor = known_read / (cal["FETCH_SIZE"]["mean"] * 1024)
     d["calibration"] = {"records": n_all, "known_read_bytes": known_read, "FETCH_SIZE_KB_raw": cal["FETCH_SIZE"]["mean"],
                         "WRITE_SIZE_KB_raw": cal["WRITE_SIZE"]["mean"], "known_write_bytes": n_all}

@@ -24,7 +24,7 @@ def build():
     return so
 
 
-def phase(params, sites, reads, dnms, found, no_seq=None):
+def phase(params, sites, reads, dnms, found, no_seq=None, umask=None):
     """Same result layout as oracle.phase(..., keep_lists=True) plus groups."""
     global _LIB
     if _LIB is None:
@@ -47,12 +47,15 @@ def phase(params, sites, reads, dnms, found, no_seq=None):
     base_err = C.c_int32(0)
     if no_seq is not None:
         no_seq = np.ascontiguousarray(no_seq, np.uint8)
+    if umask is not None:
+        umask = np.ascontiguousarray(umask, np.uint16)
     vp = C.c_void_p
     rc = _LIB.emu_phase(C.byref(params), sites.ref(), reads.ref(), dnms.ref(), vp(co.ctypes.data), vp(ci.ctypes.data),
                         vp(cf.ctypes.data), vp(ho.ctypes.data), vp(hi.ctypes.data), vp(status.ctypes.data),
                         vp(counts.ctypes.data), vp(origin.ctypes.data), vp(evidence.ctypes.data),
                         vp(lstart.ctypes.data), vp(llen.ctypes.data), vp(pool.ctypes.data), C.c_longlong(cap),
-                        C.byref(used), vp(no_seq.ctypes.data) if no_seq is not None else None, C.byref(base_err))
+                        C.byref(used), vp(no_seq.ctypes.data) if no_seq is not None else None, C.byref(base_err),
+                        vp(umask.ctypes.data) if umask is not None else None)
     assert rc == 0 and used.value <= cap
     llen = llen[: 6 * n].reshape(n, 6)
     lists = []

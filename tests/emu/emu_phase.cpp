@@ -18,10 +18,12 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                          const int64_t *het_off, const int32_t *het_idx, int32_t *status, int32_t *counts,
                          int32_t *origin, int32_t *evidence, long long *list_start, int32_t *list_len, int32_t *pool,
                          long long pool_cap, long long *pool_used, const uint8_t *no_seq /* optional: records staged without bases */,
-                         int32_t *base_err_out /* optional: 1 when the bases of such a record were requested */) {
+                         int32_t *base_err_out /* optional: 1 when the bases of such a record were requested */,
+                         const uint16_t *umask_in /* optional: staged 32-base units per record (UZ_UMASK_ALL: all) -- the others are left out of the rows */) {
     // the table in the packed form the device holds (built here on the host from the ASCII view)
     const int64_t n = Rv->n_segs;
     std::vector<uint8_t> qc((size_t)n + 1), nlow((size_t)n + 1);
+    std::vector<uint16_t> umask((size_t)n + 1, (uint16_t)UZ_UMASK_ALL); // every unit of every row
     std::vector<RecA> ra((size_t)n + 1);
     std::vector<RecB> rb((size_t)n + 1);
     std::vector<uint32_t> fm((size_t)n + 1), qoff((size_t)n + 1), cigar;
@@ -40,6 +42,17 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                               P->min_gt_qual, seq4.data() + (size_t)uoff * UZ_SEQ4_UNIT_BYTES,
                               qlow.data() + (size_t)uoff * UZ_QLOW_UNIT_BYTES) != 0)
             return -2;
+        uint32_t kept = units;
+        if (umask_in && umask_in[i] != UZ_UMASK_ALL) { // keep the staged units only, back to back (as the device's rows are)
+            umask[i] = umask_in[i];
+            kept = 0;
+            for (uint32_t u = 0; u < units; u++)
+                if ((umask_in[i] >> u) & 1u) {
+                    memmove(seq4.data() + (size_t)(uoff + kept) * UZ_SEQ4_UNIT_BYTES, seq4.data() + (size_t)(uoff + u) * UZ_SEQ4_UNIT_BYTES, UZ_SEQ4_UNIT_BYTES);
+                    memmove(qlow.data() + (size_t)(uoff + kept) * UZ_QLOW_UNIT_BYTES, qlow.data() + (size_t)(uoff + u) * UZ_QLOW_UNIT_BYTES, UZ_QLOW_UNIT_BYTES);
+                    kept++;
+                }
+        }
         {   // as the staged form has it (list form of the quality plane): the count of every record; a quality row only for a record
             // that carries its bases and has at most UZ_QLOW_LIST_MAX low ones -- asking for a bit of any other sets base_err = 2
             int low = 0;
@@ -49,13 +62,13 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
             if ((no_seq && no_seq[i]) || low > UZ_QLOW_LIST_MAX) qoff[i] = UZ_NO_QLOW_OFF;
         }
         coff += Rv->n_cigar[i];
-        uoff += units;
+        uoff += kept;
     }
     cigar.push_back(0); seq4.resize(seq4.size() + 64); qlow.resize(qlow.size() + 64);
     RD R;
     R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
     R.ra = ra.data(); R.rb = rb.data(); R.fm = fm.data(); R.cigar = cigar.data(); R.seq4 = seq4.data(); R.qlow = qlow.data();
-    R.qc = qc.data(); R.qoff = qoff.data(); R.nlow = nlow.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
+    R.qc = qc.data(); R.qoff = qoff.data(); R.nlow = nlow.data(); R.umask = umask.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
     int32_t base_err = 0;
     R.err = &base_err;
     std::vector<int32_t> coarse((size_t)(n >> 12) + 2);

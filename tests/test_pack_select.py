@@ -262,3 +262,49 @@ def test_kernel_body_never_reads_the_bases_of_a_mate_only_record():
                 assert np.array_equal(want[k], got[k]), k
             assert (want["status"] == abi.ST_OK).sum() > 20 and (~direct).mean() > 0.5
     assert tripped == {False: 0, True: 1}
+
+
+def test_kernel_body_stays_inside_the_staged_units():
+    """Unit masks (uz_reads_packed_view.umask): the selection keeps, of a record's rows, only the 32-base units that hold a fetched
+    position (and the alleles of a DNM).  The kernel body (CPU twin) run on rows cut down by exactly those masks must give the
+    oracle's results and never ask for a base of a unit that stayed home; with the masks of the het-site fetches alone (the DNM
+    fetches left out) it must trip the guard instead."""
+    from emu import emu
+    sc, dn, cl, rh, arrs = _workload(220, seed=23)
+    n = dn.n
+    sh, fh = _sites_views(sc)
+    N = int(rh.view.n_segs)
+    P = abi.make_params()
+    cutoff = concordant_cutoff(arrs["tlen"], 151, 3)
+    dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
+    found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+    want = orc.phase(P, sh, rh, dv, found, keep_lists=False)
+    assert (want["status"] == abi.ST_OK).sum() > 20
+    alen = np.array([max(len(r), len(x)) for r, x in zip(dn.refs, dn.alts)], np.int64)
+    assert alen.max() > 1  # indel DNMs: the alleles reach past the fetched position
+    fc, flo, fhi, fex = fetch_points(dn.contig, dn.start, np.zeros(n, np.uint8), sc.pos, found[3], found[4], P, allele_len=alen)
+    src = io_native.ReadsSource(io_native.pack_reads(rh, P.min_gt_qual, with_end=True))
+
+    def masks_of(sel):
+        part, idx = src.select(fc[sel], flo[sel], fhi[sel], want_index=True, extra=fex[sel])
+        m = part.view.n_segs
+        um = np.zeros(N, np.uint16)
+        um[idx] = part.arrays["umask"][:m]
+        no_seq = np.ones(N, bool)
+        no_seq[idx] = (part.arrays["aux"][:m] & abi.AUX_NO_SEQ) != 0
+        # the rows of the selection hold exactly the masked units of the source rows
+        with_b = ~no_seq[idx]
+        units = abi.row_units(part.arrays["l_seq"][:m])
+        kept = np.where(part.arrays["umask"][:m] == abi.UMASK_ALL, units, [bin(int(x)).count("1") for x in part.arrays["umask"][:m]])
+        assert part.view.n_seq_units == int(kept[with_b].sum()) < 0.5 * int(units[with_b].sum())
+        return um, no_seq
+
+    um, no_seq = masks_of(np.ones(fc.size, bool))
+    got = emu.phase(P, sh, rh, dv, found, no_seq=no_seq, umask=um)
+    assert got["base_err"] == 0
+    for k in ("status", "counts", "origin", "evidence"):
+        assert np.array_equal(want[k], got[k]), k
+    # masks that ignore the DNM fetches: the DNM-position units of most reads stay home -> the guard fires (err 3), loudly
+    um2, _ = masks_of(np.arange(fc.size) >= n)  # (fetch_points lists the n DNM fetches first)
+    got2 = emu.phase(P, sh, rh, dv, found, no_seq=no_seq, umask=np.where(no_seq, um, um2))
+    assert got2["base_err"] == 3

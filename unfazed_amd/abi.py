@@ -166,6 +166,7 @@ class ReadsPackedView(C.Structure):
         ("n_qlow_pos", C.c_int64),
         ("qlow_pos_wide", C.c_int32),
         ("reserved2", C.c_int32),
+        ("umask", _p),  # staged 32-base units per record (NULL: all)
     ]
 
 
@@ -175,6 +176,7 @@ PACKED_RECORD_COLS = [("start", np.int32), ("end", np.int32), ("tlen", np.int32)
                       ("flag", np.uint16), ("l_seq", np.uint16), ("n_cigar", np.uint16), ("mapq", np.uint8), ("aux", np.uint8)]
 SEQ4_UNIT_BYTES, QLOW_UNIT_BYTES, SEQ2_UNIT_BYTES = 16, 4, 8
 QLOW_LIST_MAX = 10
+UMASK_ALL = 0xFFFF
 
 
 def row_units(l_seq):
@@ -182,12 +184,13 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False, with_end=True) -> "Held":
+                      qlow_pos_wide=False, with_end=True, with_umask=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
     n_qlow_pos: None = the quality plane (qlow); a number = per-record counts (n_low) + that many listed positions (qlow_pos).
-    with_end: False leaves the `end` column out (the device derives it from the CIGAR, as a BAM decoder did)."""
+    with_end: False leaves the `end` column out (the device derives it from the CIGAR, as a BAM decoder did).
+    with_umask: a per-record mask of the staged 32-base units (n_seq_units then counts staged units)."""
     if n_seq_units is None:
         n_seq_units = n_row_units
     if alloc is None:
@@ -197,6 +200,8 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
         if name == "end" and not with_end:
             continue
         arrs[name] = alloc(max(1, n) * np.dtype(dt).itemsize)[: max(1, n) * np.dtype(dt).itemsize].view(dt)
+    if with_umask:
+        arrs["umask"] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.uint16)
     arrs["contig_off"] = alloc(8 * (n_contigs + 1))[: 8 * (n_contigs + 1)].view(np.int64)
     arrs["max_span"] = alloc(4 * max(1, n_contigs))[: 4 * max(1, n_contigs)].view(np.int32)
     arrs["cigar"] = alloc(4 * max(1, n_cigar_total))[: 4 * max(1, n_cigar_total)].view(np.uint32)

@@ -406,6 +406,7 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.qoff = cv.take<uint32_t>(n);
     r.k3 = cv.take<uint32_t>(n);
     r.nlow = cv.take<uint8_t>(n);
+    r.umask = cv.take<uint16_t>(n);
     r.qc = cv.take<uint8_t>(n);
     r.need = cv.take<uint8_t>(n);
     r.coarse = cv.take<int32_t>((n >> 12) + 2);
@@ -425,6 +426,7 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(!(v->qlow && v->n_low), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form (n_low / qlow_pos), not both");
     UZ_REQUIRE(v->n_segs == 0 || v->qlow || v->n_low, UZ_E_ARG, "neither qlow nor n_low is set");
     if (v->n_low) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
+    UZ_REQUIRE(!v->umask || v->n_low, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
@@ -439,6 +441,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     const bool lists = v->n_low != nullptr; // quality rows only for the records with bases (at their base-row position), written by the header build
     const size_t nql = lists ? (size_t)v->n_qlow_pos * (v->qlow_pos_wide ? 2 : 1) : 0;
     uint8_t *n_low = nullptr, *qpos = nullptr;
+    uint16_t *umask_in = nullptr;
     r.n_qlow_pos = lists ? v->n_qlow_pos : 0;
     r.n_plane_units = lists ? v->n_seq_units : v->n_row_units;
     uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq2 = nullptr;
@@ -452,6 +455,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
         qlow = cv.take<uint8_t>((lists ? ns : nu) * UZ_QLOW_UNIT_BYTES);
         if (lists) { n_low = cv.take<uint8_t>(n); qpos = cv.take<uint8_t>(nql); }
+        if (v->umask) umask_in = cv.take<uint16_t>(n);
         if (two_bit) {
             seq2 = cv.take<uint8_t>(ns * UZ_SEQ2_UNIT_BYTES);
             exc_rec = cv.take<uint32_t>(ne); exc_pos = cv.take<uint16_t>(ne); exc_code = cv.take<uint8_t>(ne);
@@ -483,13 +487,14 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         col.n_low = h2d(st, n_low, v->n_low, n);
         col.qlow_pos = h2d(st, qpos, v->qlow_pos, nql);
         col.qpos_wide = v->qlow_pos_wide;
+        if (v->umask) col.umask = h2d(st, umask_in, v->umask, n);
     } else {
         h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
         col.plane_in = reinterpret_cast<const uint32_t *>(qlow);
     }
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
-    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_qwide = col.qpos_wide;
+    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_q[4] = col.umask; r.col_qwide = col.qpos_wide;
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
         for (int k = 0; k < 10; k++) r.col_ptrs[k] = p[k];
@@ -509,7 +514,7 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.l_seq = (const uint16_t *)r.col_ptrs[6]; col.n_cigar = (const uint16_t *)r.col_ptrs[7]; col.mapq = (const uint8_t *)r.col_ptrs[8];
     col.aux = (const uint8_t *)r.col_ptrs[9];
     col.plane_in = (const uint32_t *)r.col_q[0]; col.n_low = (const uint8_t *)r.col_q[1]; col.qlow_pos = (const uint8_t *)r.col_q[2];
-    col.cigar_in = (const uint32_t *)r.col_q[3];
+    col.cigar_in = (const uint32_t *)r.col_q[3]; col.umask = (const uint16_t *)r.col_q[4];
     col.qpos_wide = r.col_qwide;
     UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, c->stream));
     uz_build_records(c, c->stream, r, col, r.build_scratch);
@@ -648,7 +653,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
                 r.seq4 = seq4_own; r.seq2_staged = v->seq2;
                 r.n_exc = v->n_exc; r.exc_rec = v->exc_rec; r.exc_pos = v->exc_pos; r.exc_code = v->exc_code;
             }
-            if (v->n_low) { r.qlow = qlow_own; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; }
+            if (v->n_low) { r.qlow = qlow_own; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; col.umask = v->umask; }
             else col.plane_in = reinterpret_cast<const uint32_t *>(v->qlow);
             r.qlow_thr = v->min_base_qual;
             r.qlow_valid = true;
@@ -659,7 +664,8 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             if (c->hflags[0]) {
                 const int f = c->hflags[0];
                 c->hflags[0] = 0;
-                throw UzError{UZ_E_RANGE, f == 4 ? "qlow_pos: positions of a record are not ascending or lie beyond l_seq"
+                throw UzError{UZ_E_RANGE, f == 5 ? "umask: a unit beyond the read's length, or a mask on a read longer than 480 bases"
+                                          : f == 4 ? "qlow_pos: positions of a record are not ascending or lie beyond l_seq"
                                           : f == 3 ? "exc_* columns: an entry names a record without bases, a base beyond l_seq or a code above 15"
                                                  : "n_cigar_total / n_row_units of the reads view do not match its columns"};
             }

@@ -84,6 +84,7 @@ struct uz_select {
     uint64_t n_cigar = 0, n_units = 0, n_seq = 0;
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
     std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
+    std::vector<uint16_t> umask;        // per kept record: staged 32-base units of its rows (UZ_UMASK_ALL: every unit; empty vector: no masks asked for)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
     int64_t n_qpos = 0;                 // entries of the output's qlow_pos
@@ -280,7 +281,7 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
 void uz_reads_source_close(uz_psrc *s) { delete s; }
 
 int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
-                         int threads, uz_select **out) {
+                         int unit_masks, const uint16_t *extra, int threads, uz_select **out) {
     return guarded([&] {
         if (!src || !out || (n_fetch > 0 && (!contig || !lo || !hi))) fail(UZ_IO_E_ARG, "null argument");
         threads = resolve_threads(threads);
@@ -288,6 +289,13 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
         const int64_t n = full->n_segs;
         std::vector<uint8_t> keep((size_t)n + 1, 0);
         uint8_t *kp = keep.data();
+        // unit masks: the read stage reads the bases of a record at the fetched position (and `extra` bases on: the alleles of a
+        // DNM) only -- position hi - 1 of a one- or two-base fetch.  For a record whose single CIGAR operation spans the read the
+        // query index is position - start; every other record (and every record of a wider fetch: SV breakpoints) keeps all units.
+        const bool masks = unit_masks && !all_bases;
+        std::vector<uint16_t> um;
+        if (masks) um.assign((size_t)n + 1, 0);
+        uint16_t *ump = um.data();
         std::atomic<int64_t> rmin{n}, rmax{0}; // record range the marks fall into
         auto widen = [&](int64_t a, int64_t b) {
             int64_t cur = rmin.load();
@@ -309,6 +317,23 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                     if (full->end[i] > lo[f]) {
                         __atomic_store_n(&kp[i], (uint8_t)2, __ATOMIC_RELAXED); // 2: returned by a fetch, 1: reachable only as a mate
                         a = std::min(a, i); b = std::max(b, i + 1);
+                        if (masks) {
+                            uint16_t bits = (uint16_t)UZ_UMASK_ALL;
+                            const int ls = full->l_seq[i];
+                            const uint32_t cw = full->n_cigar[i] == 1 ? full->cigar[src->coff[(size_t)i]] : 0u;
+                            const uint32_t op = cw & 15u;
+                            const bool simple = full->n_cigar[i] == 1 && (op == 0 || op == 7 || op == 8) && (int)(cw >> 4) == ls && ls > 1 &&
+                                                full->end[i] - full->start[i] == ls;
+                            if (simple && ls <= 480 && hi[f] - lo[f] <= 2) {
+                                const int64_t q0 = (int64_t)hi[f] - 1 - full->start[i];
+                                bits = 0;
+                                if (q0 >= 0 && q0 < ls) {
+                                    const int64_t q1 = std::min<int64_t>(q0 + (extra ? extra[f] : 0), ls - 1);
+                                    for (int64_t u = q0 >> 5; u <= (q1 >> 5); u++) bits |= (uint16_t)(1u << u);
+                                }
+                            }
+                            __atomic_fetch_or(&ump[i], bits, __ATOMIC_RELAXED);
+                        }
                     }
             }
             if (a < b) widen(a, b);
@@ -346,7 +371,13 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 sel->index.push_back((int32_t)i);
                 sel->bases.push_back(bases ? 1 : 0);
                 sel->n_cigar += full->n_cigar[i]; sel->n_units += UZ_ROW_UNITS(full->l_seq[i]);
-                if (bases) sel->n_seq += UZ_ROW_UNITS(full->l_seq[i]);
+                uint16_t m16 = (uint16_t)UZ_UMASK_ALL;
+                if (masks) { // (a record with bases that no fetched position falls into keeps none of its units: a zero mask)
+                    m16 = bases ? ump[i] : (uint16_t)0;
+                    if (m16 != UZ_UMASK_ALL && (uint32_t)__builtin_popcount(m16) == UZ_ROW_UNITS(full->l_seq[i])) m16 = (uint16_t)UZ_UMASK_ALL;
+                    sel->umask.push_back(m16);
+                }
+                if (bases) sel->n_seq += m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16);
             }
         sel->n_sel = (int64_t)sel->index.size();
         sel->n_low.assign((size_t)sel->n_sel, 0);
@@ -376,7 +407,7 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 if (!sel->bases[(size_t)k]) continue;
                 const uint32_t i = (uint32_t)sel->index[(size_t)k];
                 const uint32_t *a = std::lower_bound(er, er + full->n_exc, i), *b = std::upper_bound(a, er + full->n_exc, i);
-                sel->exc_lo[(size_t)k] = a - er; sel->exc_n[(size_t)k] = b - a;
+                sel->exc_lo[(size_t)k] = a - er; sel->exc_n[(size_t)k] = b - a; // (entries in units that stay home travel along: the device skips them)
                 sel->n_exc += b - a;
             }
         }
@@ -415,6 +446,9 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
         out->n_exc = two_bit ? s->n_exc : 0;
         if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
+        const bool masks = !s->umask.empty();
+        if (masks && !out->umask) fail(UZ_IO_E_ARG, "the selection was planned with unit masks: the output view needs umask");
+        if (masks && !out->n_low) fail(UZ_IO_E_ARG, "unit masks need the list form of the qualities in the output (n_low / qlow_pos)");
         const bool lists = out->n_low != nullptr;
         if (!lists && !full->qlow) fail(UZ_IO_E_ARG, "the source table has the quality plane as lists: the output view needs n_low / qlow_pos");
         if (lists && !out->qlow_pos_wide && uz_select_qlow_pos_wide(s)) fail(UZ_IO_E_ARG, "reads longer than 256 bases need qlow_pos_wide");
@@ -447,7 +481,8 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
             const int64_t i = s->index[k];
             oc[k + 1] = oc[k] + full->n_cigar[i];
             ou[k + 1] = ou[k] + UZ_ROW_UNITS(full->l_seq[i]);
-            os[k + 1] = os[k] + (s->bases[k] ? UZ_ROW_UNITS(full->l_seq[i]) : 0);
+            const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
+            os[k + 1] = os[k] + (s->bases[k] ? (m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16)) : 0);
         }
         parallel_slices(m, workers_for(m, threads, 4096), [&](int64_t a, int64_t b, int) {
             for (int64_t k = a; k < b; k++) {
@@ -466,7 +501,20 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 w(out->aux)[k] = (uint8_t)(s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ));
                 memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
                 const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
-                if (s->bases[k]) {
+                const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
+                if (out->umask) w(out->umask)[k] = m16;
+                if (s->bases[k] && m16 != UZ_UMASK_ALL) { // the staged units only, back to back
+                    const size_t ub = two_bit ? UZ_SEQ2_UNIT_BYTES : UZ_SEQ4_UNIT_BYTES;
+                    const uint8_t *from = (two_bit ? full->seq2 : full->seq4) + (size_t)src->soff[i] * ub;
+                    uint8_t *to = w(two_bit ? out->seq2 : out->seq4) + os[k] * ub;
+                    for (size_t u = 0; u < units; u++)
+                        if ((m16 >> u) & 1u) { memcpy(to, from + u * ub, ub); to += ub; }
+                    if (two_bit)
+                        for (int64_t e = 0; e < s->exc_n[(size_t)k]; e++) {
+                            const int64_t fr = s->exc_lo[(size_t)k] + e, t2 = oe[(size_t)k] + e;
+                            w(out->exc_rec)[t2] = (uint32_t)k; w(out->exc_pos)[t2] = full->exc_pos[fr]; w(out->exc_code)[t2] = full->exc_code[fr];
+                        }
+                } else if (s->bases[k]) {
                     if (two_bit) {
                         memcpy(w(out->seq2) + os[k] * UZ_SEQ2_UNIT_BYTES, full->seq2 + (size_t)src->soff[i] * UZ_SEQ2_UNIT_BYTES, units * UZ_SEQ2_UNIT_BYTES);
                         for (int64_t e = 0; e < s->exc_n[(size_t)k]; e++) {

@@ -205,13 +205,14 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 // four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
 // low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
 #define UZ_PK_SUMS 4
-__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t (&v)[UZ_PK_SUMS]) {
-    v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : v[1];
+// um: which units of the record's rows were staged (UZ_UMASK_ALL: all of them)
+__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t (&v)[UZ_PK_SUMS]) {
+    v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? v[1] : (uint32_t)__popc(um));
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_t *__restrict__ n_cigar, const uint16_t *__restrict__ l_seq,
                                                         const uint8_t *__restrict__ aux, const uint8_t *__restrict__ n_low,
-                                                        unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
+                                                        const uint16_t *__restrict__ umask, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
     unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0};
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         if (i < n) {
             uint32_t v[UZ_PK_SUMS];
-            pk_vals(n_cigar[i], l_seq[i], aux[i], n_low ? (int)n_low[i] : -1, v);
+            pk_vals(n_cigar[i], l_seq[i], aux[i], n_low ? (int)n_low[i] : -1, umask ? (uint32_t)umask[i] : UZ_UMASK_ALL, v);
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -260,7 +261,8 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
         for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = sums[UZ_PK_SUMS * i + k]; sums[UZ_PK_SUMS * i + k] = v[k]; v[k] += x; }
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
-                                                  uint32_t *fm, uint32_t *qoff, uint32_t *k3, uint8_t *nlow, uint32_t *plane_out, int32_t *hflags) {
+                                                  uint32_t *fm, uint32_t *qoff, uint32_t *k3, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
+                                                  int32_t *hflags) {
     __shared__ uint32_t wsum[UZ_PK_SUMS][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     unsigned long long run[UZ_PK_SUMS];
@@ -271,8 +273,9 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         const bool in = i < n;
         const uint32_t nc = in ? c.n_cigar[i] : 0u, ls = in ? c.l_seq[i] : 0u, ax = in ? c.aux[i] : 0u;
         const int nl = c.n_low ? (in ? (int)c.n_low[i] : 0) : -1;
+        const uint32_t um = (c.umask && in) ? (uint32_t)c.umask[i] : UZ_UMASK_ALL;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
-        pk_vals(nc, ls, ax, nl, v);
+        pk_vals(nc, ls, ax, nl, um, v);
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++) {
             uint32_t x = v[k];
@@ -304,6 +307,8 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);
             k3[i] = uz_pack_k3(ls, nc, A.start, A.end);
             const int units = (int)UZ_ROW_UNITS(ls);
+            umask_out[i] = (uint16_t)um;
+            if (um != UZ_UMASK_ALL && (units > 15 || (um >> units) != 0u)) hflags[0] = 5; // a unit beyond the read, or a read too long for a mask
             if (nl >= 0) {
                 // list form of the staged plane: the count as it is; a quality row (at the record's base-row position) only for a
                 // record whose bits can be asked for, written here from its listed positions
@@ -323,12 +328,14 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                         }
                     }
                     if (bad) hflags[0] = 4;
+                    uint32_t at_row = sq; // the quality row holds the same units as the base row: the staged ones
                     for (int u = 0; u < units; u++) {
+                        if (um != UZ_UMASK_ALL && !((um >> u) & 1u)) continue;
                         uint32_t w = 0;
 #pragma unroll
                         for (int e = 0; e < UZ_QLOW_LIST_MAX; e++)
                             if (pos[e] >= 0 && (pos[e] >> 5) == u) w |= 1u << (pos[e] & 31);
-                        plane_out[(size_t)sq + u] = w;
+                        plane_out[(size_t)at_row++] = w;
                     }
                 }
             } else {
@@ -395,7 +402,8 @@ __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__res
 // cohort batches: the headers of one kid's table copied into the merged table with its bases added
 __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
                                                     const uint32_t *__restrict__ sqo, const uint32_t *__restrict__ sk3, const uint8_t *__restrict__ snl,
-                                                    RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3, uint8_t *dnl,
+                                                    const uint16_t *__restrict__ sum_, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3, uint8_t *dnl,
+                                                    uint16_t *dum,
                                                     int32_t rec_base,
                                                     uint32_t cigar_base, uint32_t unit_base, uint32_t seq_base, uint32_t qname_base) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -406,14 +414,14 @@ __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__res
     if (A.sq_off != UZ_NO_SEQ_OFF) A.sq_off += seq_base;
     if (B.mate >= 0) B.mate += rec_base;
     B.qname += qname_base;
-    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dk3[i] = sk3[i]; dnl[i] = snl[i];
+    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dk3[i] = sk3[i]; dnl[i] = snl[i]; dum[i] = sum_[i];
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
     R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm; R.k3 = r.k3;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
-    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.qc = r.qc; R.coarse = r.coarse;
+    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.umask = r.umask; R.qc = r.qc; R.coarse = r.coarse;
     R.err = nullptr; // set by the launcher of the per-DNM kernel
     return R;
 }
@@ -444,13 +452,19 @@ __global__ __launch_bounds__(256) void k_expand_seq2(const unsigned long long *_
 // the listed bases (not A/C/G/T): their BAM codes written over the expanded rows; every entry owns its nibble
 __global__ __launch_bounds__(256) void k_patch_exc(int64_t n_exc, const uint32_t *__restrict__ rec, const uint16_t *__restrict__ pos,
                                                    const uint8_t *__restrict__ code, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
-                                                   int64_t n, uint32_t *seq4_words, int32_t *hflags) {
+                                                   const uint16_t *__restrict__ umask, int64_t n, uint32_t *seq4_words, int32_t *hflags) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n_exc) return;
     const uint32_t i = rec[e];
     const uint32_t k = pos[e];
     if ((int64_t)i >= n || k >= rb[i].l_seq || ra[i].sq_off == UZ_NO_SEQ_OFF || code[e] > 15) { hflags[0] = 3; return; }
-    const size_t byte = (size_t)ra[i].sq_off * UZ_SEQ4_UNIT_BYTES + (k >> 1);
+    uint32_t unit = k >> 5;
+    const uint32_t um = umask[i];
+    if (um != UZ_UMASK_ALL) {
+        if (unit > 14u || !((um >> unit) & 1u)) return; // the unit stayed home: nothing to patch
+        unit = (uint32_t)__popc(um & ((1u << unit) - 1u));
+    }
+    const size_t byte = ((size_t)ra[i].sq_off + unit) * UZ_SEQ4_UNIT_BYTES + ((k & 31u) >> 1);
     const int sh = (int)(8 * (byte & 3)) + ((k & 1) ? 0 : 4);
     uint32_t *wd = seq4_words + (byte >> 2);
     atomicAnd(wd, ~(15u << sh));
@@ -465,11 +479,11 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     if (r.n <= 0) return;
     const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
     unsigned long long *sums = (unsigned long long *)off_scratch;
-    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, col.n_low, sums);
+    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, col.n_low, col.umask, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
                        (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, reinterpret_cast<uint32_t *>(r.qlow), c->hflags);
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
@@ -479,7 +493,8 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
                                (const unsigned long long *)r.seq2_staged, (uint4 *)const_cast<uint8_t *>(r.seq4), nu);
             if (r.n_exc > 0)
                 hipLaunchKernelGGL(k_patch_exc, dim3((unsigned)((r.n_exc + 255) / 256)), dim3(256), 0, st, r.n_exc, r.exc_rec, r.exc_pos, r.exc_code,
-                                   (const RecA *)r.rec_a, (const RecB *)r.rec_b, (int64_t)r.n, (uint32_t *)const_cast<uint8_t *>(r.seq4), c->hflags);
+                                   (const RecA *)r.rec_a, (const RecB *)r.rec_b, (const uint16_t *)r.umask, (int64_t)r.n,
+                                   (uint32_t *)const_cast<uint8_t *>(r.seq4), c->hflags);
         }
         r.seq2_staged = nullptr;
     }
@@ -491,7 +506,8 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
     if (src.n <= 0) return;
     hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
                        (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint32_t *)src.k3, (const uint8_t *)src.nlow,
-                       (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base, dst.k3 + rec_base, dst.nlow + rec_base,
+                       (const uint16_t *)src.umask, (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base,
+                       dst.k3 + rec_base, dst.nlow + rec_base, dst.umask + rec_base,
                        (int32_t)rec_base, (uint32_t)cigar_base,
                        (uint32_t)unit_base, (uint32_t)seq_base, qname_base);
     UZ_HIP(hipGetLastError());
@@ -635,6 +651,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
                                   : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
                                   : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
+                                  : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
                                            : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
@@ -783,7 +800,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         if (c->hflags[1]) {
             const int f = c->hflags[1];
             c->hflags[1] = 0;
-            throw UzError{UZ_E_STATE, f == 2 ? "the read stage asked for a base-quality bit of a record staged without its quality row (more than 10 low-quality bases, or no bases): such a record can never pass goodread -- the staging rule and the kernel disagree"
+            throw UzError{UZ_E_STATE, f == 3 ? "the read stage asked for a base (or its quality bit) in a 32-base unit that was not staged (umask): the fetch points that staged the table do not cover this batch"
+                                    : f == 2 ? "the read stage asked for a base-quality bit of a record staged without its quality row (more than 10 low-quality bases, or no bases): such a record can never pass goodread -- the staging rule and the kernel disagree"
                                              : "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
         }
         const unsigned long long used = *hused;

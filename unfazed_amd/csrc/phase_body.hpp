@@ -93,6 +93,8 @@ struct RD { // alignment records of one table (device pointers)
     const uint32_t *qoff;  // quality-plane row of every record, in row units; UZ_NO_QLOW_OFF = no row (the list form of the staged plane keeps
                            // rows only for the records whose bits can be asked for: bases staged and at most UZ_QLOW_LIST_MAX low ones)
     const uint8_t *nlow;   // number of low-quality bases of every record, saturated at 255
+    const uint16_t *umask; // which 32-base units of a record's rows were staged: bit u = unit u, UZ_UMASK_ALL = every unit (rows hold the
+                           // staged units back to back); a base or a quality bit of a unit that stayed home sets err = 3
     int32_t *err;          // [0] set when the bases of a record staged without them are requested (must never happen)
     const uint8_t *qc;
     const int32_t *coarse; // start of every 4096th record (L2-resident search index), may be null
@@ -352,15 +354,30 @@ UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &w
 // CIGAR walk instead of one by one along it.
 struct SegHdr {
     int32_t start, end, n_cigar, l_seq;
-    uint32_t cigar_off, sq_off;
+    uint32_t cigar_off, sq_off, umask;
 };
+// a record's rows: first staged unit + which units were staged
+struct RowRef { uint32_t off, umask; };
 UZ_DEV SegHdr uz_hdr(const RD &R, int seg) {
     const RecA A = R.ra[seg];
     const RecB B = R.rb[seg];
     SegHdr h;
     h.start = A.start; h.end = A.end; h.n_cigar = B.n_cigar; h.l_seq = B.l_seq;
-    h.cigar_off = A.cigar_off; h.sq_off = A.sq_off;
+    h.cigar_off = A.cigar_off; h.sq_off = A.sq_off; h.umask = R.umask[seg];
     return h;
+}
+// position of base k inside the staged units of a row: false when its unit stayed home
+UZ_DEV bool uz_unit_of(uint32_t umask, int k, uint32_t &unit) {
+    const uint32_t u = (uint32_t)k >> 5;
+    if (umask == UZ_UMASK_ALL) { unit = u; return true; }
+    if (u > 14u || !((umask >> u) & 1u)) return false;
+    const uint32_t below = umask & ((1u << u) - 1u);
+#ifdef UZ_EMU
+    unit = (uint32_t)__builtin_popcount(below);
+#else
+    unit = (uint32_t)__popc(below);
+#endif
+    return true;
 }
 UZ_DEV int uz_qidx_h(const RD &R, const SegHdr &h, long long pos) {
     // one operation spanning the whole read and as many reference bases as read bases can only be M / = / X
@@ -392,28 +409,32 @@ UZ_DEV int uz_refpos_len(const RD &R, int seg) {
     }
     return q;
 }
-UZ_DEV uint8_t uz_base(const RD &R, uint32_t sq_off, int k) {
-    if (sq_off == UZ_NO_SEQ_OFF) { *R.err = 1; return 0; } // the host left the bases out: its reach rule and the kernel disagree
-    return uz_seq4_base(R.seq4, sq_off, k);
+UZ_DEV uint8_t uz_base(const RD &R, RowRef row, int k) {
+    if (row.off == UZ_NO_SEQ_OFF) { *R.err = 1; return 0; } // the host left the bases out: its reach rule and the kernel disagree
+    uint32_t u;
+    if (!uz_unit_of(row.umask, k, u)) { *R.err = 3; return 0; } // ... or this 32-base unit of them
+    return uz_seq4_base(R.seq4, row.off + u, k & 31);
 }
-UZ_DEV bool uz_qual_low(const RD &R, uint32_t q_off, int k) {
-    if (q_off == UZ_NO_QLOW_OFF) { *R.err = 2; return false; } // a bit of a record that cannot be "good": the staging rule and the kernel disagree
-    return uz_qlow_bit(R.qlow, q_off, k) != 0;
+UZ_DEV bool uz_qual_low(const RD &R, RowRef row, int k) {
+    if (row.off == UZ_NO_QLOW_OFF) { *R.err = 2; return false; } // a bit of a record that cannot be "good": the staging rule and the kernel disagree
+    uint32_t u;
+    if (!uz_unit_of(row.umask, k, u)) { *R.err = 3; return false; }
+    return uz_qlow_bit(R.qlow, row.off + u, k & 31) != 0;
 }
 
 // get_allele_at :56-73 -> the n bases start at query index `idx` of the row `sq_off`; false = the reference's False
-UZ_DEV bool uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n, uint32_t &sq_off, int &idx) {
+UZ_DEV bool uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n, RowRef &row, int &idx) {
     const SegHdr hr = uz_hdr(R, read), hm = uz_hdr(R, mate >= 0 ? mate : read); // both requested up front
     const int i = uz_qidx_h(R, hr, pos);
     if (i >= 0) {
         if (i < 4 || i > readlen - 4) return false;
-        if (hr.l_seq > i + n) { sq_off = hr.sq_off; idx = i; return true; }
+        if (hr.l_seq > i + n) { row.off = hr.sq_off; row.umask = hr.umask; idx = i; return true; }
         return false; // the mate is not consulted (quirk Q10)
     } else if (mate >= 0) {
         const int j = uz_qidx_h(R, hm, pos);
         if (j >= 0) {
             if (j < 4 || j > readlen - 4) return false;
-            if (hm.l_seq > j + n) { sq_off = hm.sq_off; idx = j; return true; }
+            if (hm.l_seq > j + n) { row.off = hm.sq_off; row.umask = hm.umask; idx = j; return true; }
         }
     }
     return false;
@@ -476,7 +497,7 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, 
     const int mate = uz_pair_ok(R, a, cutoff, seg);
     if (mate < 0) return 0;
     if (ref_len == alt_len) { // snv_match_alleles :296-336
-        uint32_t row = 0;
+        RowRef row = {0, UZ_UMASK_ALL};
         int at = 0;
         if (!uz_allele_at(R, a.readlen, seg, mate, position, ref_len, row, at)) return 0;
         bool eq = true;
@@ -502,9 +523,9 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, 
         oi += l;
     }
     const int ls = hs.l_seq;
-    const uint32_t q_off = R.qoff[seg];
+    const RowRef qrow = {R.qoff[seg], hs.umask};
     for (int k = rp; k < rp + var_len && k < ls; k++)
-        if (uz_qual_low(R, q_off, k)) return 0;
+        if (uz_qual_low(R, qrow, k)) return 0;
     if (has_id) return 2;
     if (7 < rp && rp < uz_refpos_len(R, seg) - 7) return 1;
     return 0;
@@ -1059,7 +1080,8 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
         // each stage's loads of both entries are in flight together.
         for (int x0 = wg_lane_opaque(); x0 < M; x0 += 2 * WG_NT) {
             int xx[2], hh[2], sq[2], f1v[2], qi[2];
-            uint32_t row[2], q0[2];
+            RowRef row[2];
+            uint32_t q0[2];
             bool live[2], own[2];
             SegHdr h0[2];
 #pragma unroll
@@ -1078,17 +1100,17 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
-                qi[u] = -1; row[u] = 0; own[u] = false;
+                qi[u] = -1; row[u].off = 0; row[u].umask = UZ_UMASK_ALL; own[u] = false;
                 if (!live[u]) continue;
                 const long long hp = s.hpos[hh[u]];
                 const int i = uz_qidx_h(R, h0[u], hp);
                 if (i >= 0) {
                     own[u] = true;
-                    if (i >= 4 && i <= a.readlen - 4 && h0[u].l_seq > i + 1) { qi[u] = i; row[u] = h0[u].sq_off; }
+                    if (i >= 4 && i <= a.readlen - 4 && h0[u].l_seq > i + 1) { qi[u] = i; row[u].off = h0[u].sq_off; row[u].umask = h0[u].umask; }
                 } else if (f1v[u] >= 0) {
                     const SegHdr h1 = uz_hdr(R, f1v[u]);
                     const int j = uz_qidx_h(R, h1, hp);
-                    if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) { qi[u] = j; row[u] = h1.sq_off; }
+                    if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) { qi[u] = j; row[u].off = h1.sq_off; row[u].umask = h1.umask; }
                 }
             }
             uint8_t al[2];
@@ -1096,7 +1118,7 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 al[u] = qi[u] >= 0 ? uz_base(R, row[u], qi[u]) : (uint8_t)0;
-                low[u] = (qi[u] >= 0 && own[u] && sq[u] < E) ? uz_qual_low(R, q0[u], qi[u]) : true; // (only a registration uses it, below)
+                low[u] = (qi[u] >= 0 && own[u] && sq[u] < E) ? uz_qual_low(R, RowRef{q0[u], h0[u].umask}, qi[u]) : true; // (only a registration uses it, below)
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
@@ -1296,7 +1318,7 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
             for (int ci = L; ci <= Rr; ci++) {
                 const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
                 if (rp < 0 || rp >= hd.l_seq) continue;
-                const uint8_t b = uz_base(R, hd.sq_off, rp);
+                const uint8_t b = uz_base(R, RowRef{hd.sq_off, hd.umask}, rp);
                 bool from_ref;
                 if (b == s.cref[ci]) from_ref = true;       // :41-42
                 else if (b == s.calt[ci]) from_ref = false; // :43-44
@@ -1461,23 +1483,6 @@ UZ_DEV uint8_t uz_seg_qc_combine(uint32_t f, uint32_t aux, int mapq, int min_map
     if (nonmatch <= 5) qc |= UZ_QC_NM5;
     if (none <= 5) qc |= UZ_QC_NONE5;
     return qc;
-}
-// number of bases of a row whose quality is below the threshold: the set bits of its qlow words up to l_seq
-UZ_DEV int uz_row_low_count(const RD &R, uint32_t q_off, int l_seq) {
-    int low = 0;
-    const uint32_t units = UZ_ROW_UNITS(l_seq);
-    for (uint32_t u = 0; u < units; u++) {
-        const uint8_t *b = R.qlow + (size_t)(q_off + u) * UZ_QLOW_UNIT_BYTES;
-        uint32_t w = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24);
-        const int valid = l_seq - 32 * (int)u;
-        if (valid < 32) w &= (1u << valid) - 1u;
-#ifdef UZ_EMU
-        low += __builtin_popcount(w);
-#else
-        low += __popc(w);
-#endif
-    }
-    return low;
 }
 // whole QC byte of one record, sequentially (the CPU twin and small tables; K3a proper is k_seg_qc)
 UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual) {

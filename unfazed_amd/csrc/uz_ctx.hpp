@@ -90,6 +90,7 @@ struct ReadsDev {
     void *rec_a = nullptr, *rec_b = nullptr; // RecA / RecB headers (phase_body.hpp)
     uint32_t *fm = nullptr;    // flag | mapq << 16 | aux << 24
     uint32_t *qoff = nullptr;  // quality-plane row of every record (row units); UZ_NO_QLOW_OFF: none (its bits can never be asked for)
+    uint16_t *umask = nullptr; // staged 32-base units of every record's rows (UZ_UMASK_ALL: every unit)
     uint8_t *nlow = nullptr;   // low-quality bases of every record, saturated at 255 (what K3a needs of the qualities)
     int64_t n_qlow_pos = 0;    // list form of the staged plane: entries (checked against the columns by the header build)
     int64_t n_plane_units = 0; // units the quality-plane store holds: n_row_units (plane / ASCII form: every record has a row), n_seq_units (list form)
@@ -111,7 +112,7 @@ struct ReadsDev {
     // would wait behind the persistent per-DNM grid and hold up the next table's copies
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
-    const void *col_q[4] = {nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in of RecColumns, for the deferred header build
+    const void *col_q[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask of RecColumns, for the deferred header build
     int32_t col_qwide = 0;
     // a table that arrived with two-bit base rows (uz_reads_packed_view.seq2): the staged rows and the listed bases, expanded
     // into seq4 by the header build (uz_build_records); null afterwards / for four-bit tables
@@ -233,6 +234,7 @@ struct RecColumns {
     // form (n_low + qlow_pos: the header build copies the counts and writes the plane rows of the listed records); both
     // null for an ASCII upload, whose plane and counts are built from the quality bytes (uz_build_qlow)
     const uint32_t *cigar_in = nullptr; // the record's CIGAR words (at its cigar offset): `end` is derived from them when the column is left out (end == nullptr)
+    const uint16_t *umask = nullptr;    // staged units per record (null: every unit)
     const uint32_t *plane_in = nullptr;
     const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
     int32_t qpos_wide = 0;

@@ -104,7 +104,8 @@ def load():
     lib.uz_reads_source_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_reads_source_close.argtypes = [C.c_void_p]
     lib.uz_reads_source_close.restype = None
-    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                         C.POINTER(C.c_void_p)]
     for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units,
                lib.uz_select_n_exc, lib.uz_select_n_qlow_pos):
         fn.argtypes = [C.c_void_p]
@@ -335,16 +336,23 @@ class ReadsSource:
         self._h = _Handle(h, self.lib.uz_reads_source_close)
         self.threads = threads
 
-    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None):
+    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
-        lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only)."""
+        lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
+        extra (uint16 per fetch, staging.fetch_points(..., allele_len=)): stage only the 32-base units of a record's rows that
+        the read stage can read -- the fetched position and `extra` bases on (needs lists; ignored with all_bases)."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
         sel = C.c_void_p()
+        masks = extra is not None and lists and not all_bases
+        if masks:
+            extra = np.ascontiguousarray(extra, np.uint16)
+            assert extra.size == contig.size
         _check(self.lib, self.lib.uz_reads_select_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data,
-                                                       hi.ctypes.data, 1 if all_bases else 0, int(self.threads), C.byref(sel)))
+                                                       hi.ctypes.data, 1 if all_bases else 0, 1 if masks else 0,
+                                                       extra.ctypes.data if masks else None, int(self.threads), C.byref(sel)))
         try:
             n = self.lib.uz_select_n_records(sel)
             two_bit = bool(self.packed.view.seq2)  # a selection keeps the base-row form of its source
@@ -353,7 +361,8 @@ class ReadsSource:
                                         n_exc=int(self.lib.uz_select_n_exc(sel)) if two_bit else None,
                                         n_qlow_pos=int(self.lib.uz_select_n_qlow_pos(sel)) if lists else None,
                                         qlow_pos_wide=bool(self.lib.uz_select_qlow_pos_wide(sel)) if lists else False,
-                                        with_end=(not self.lib.uz_select_end_derivable(sel)) if with_end is None else bool(with_end))
+                                        with_end=(not self.lib.uz_select_end_derivable(sel)) if with_end is None else bool(with_end),
+                                        with_umask=masks)
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
