@@ -211,12 +211,26 @@ def main():
     if not args.no_staged:
         t_dec = time.time()
         pool = PinnedPool()
-        # what the decoders would leave in pinned memory: sites / genotype columns ...
-        hs = {k: pinned_copy(pool, getattr(sc, k)) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
-        hs["contig_off"] = pinned_copy(pool, np.ascontiguousarray(sc.contig_off, np.int64))
-        hg = {k: [pinned_copy(pool, getattr(sc, k)[m]) for m in range(3)] for k in ("rd", "ad", "gq")}
+        # what the decoders would leave in pinned memory: the sites / genotype columns of the DNMs' windows (the reference queries
+        # the indexed VCF per DNM region, informative_site_finder.py:399-420: no site outside a window is ever decoded) ...
+        sd = int(P.search_dist) + 2
+        keep_site = np.zeros(sc.n + 1, np.int32)
+        co_s = np.asarray(sc.contig_off, np.int64)
+        for c in np.unique(ev.contig):
+            if c < 0:
+                continue
+            m = ev.contig == c
+            pc = sc.pos[co_s[c]: co_s[c + 1]]
+            lo_i = np.searchsorted(pc, ev.start[m].astype(np.int64) - sd, "left") + co_s[c]
+            hi_i = np.searchsorted(pc, ev.end[m].astype(np.int64) + sd, "right") + co_s[c]
+            np.add.at(keep_site, lo_i, 1)
+            np.add.at(keep_site, hi_i, -1)
+        site_sel = np.nonzero(np.cumsum(keep_site[:-1]) > 0)[0]
+        hs = {k: pinned_copy(pool, getattr(sc, k)[site_sel]) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
+        hs["contig_off"] = pinned_copy(pool, np.searchsorted(site_sel, co_s).astype(np.int64))
+        hg = {k: [pinned_copy(pool, getattr(sc, k)[m][site_sel]) for m in range(3)] for k in ("rd", "ad", "gq")}
         sv = abi.SitesView()
-        sv.n_sites, sv.n_contigs = sc.n, len(sc.contig_off) - 1
+        sv.n_sites, sv.n_contigs = int(site_sel.size), len(sc.contig_off) - 1
         for k in ("contig_off", "pos", "sflags", "ref_base", "alt_base"):
             setattr(sv, k, hs[k].ctypes.data)
         sites_h = abi.Held(sv, hs)
@@ -245,7 +259,7 @@ def main():
             staged_bytes += (int(pv.n_segs) * ((28 if pv.end else 24) + (2 if pv.umask else 0)) + int(pv.n_cigar_total) * 4
                              + (int(pv.n_segs) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if pv.n_low else int(pv.n_row_units) * 4)
                              + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
-        site_bytes = sc.n * (4 + 1 + 1 + 1 + 1 + 18)
+        site_bytes = int(site_sel.size) * (4 + 1 + 1 + 1 + 1 + 18)
         t_dec = time.time() - t_dec
 
         trace = [] if os.environ.get("UZ_BENCH_TRACE") else None
@@ -296,7 +310,7 @@ def main():
             print("[staged, ms] copies + header builds alone %.1f (%.1f GB/s) | kernels alone %.1f" %
                   ((t1 - t0) * 1e3, staged_bytes / (t1 - t0) / 1e9, (t2 - t1) * 1e3), file=sys.stderr)
         mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
-        staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records,
+        staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records, sites=int(site_sel.size),
                       decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks))
         res = res_s
     else:
@@ -413,7 +427,7 @@ def main():
             "generate_s": round(t_gen, 1),
         }
         if staged:
-            out["link"] = {"bytes_per_step": int(staged["bytes"]), "read_records_staged": int(staged["records"]),
+            out["link"] = {"bytes_per_step": int(staged["bytes"]), "read_records_staged": int(staged["records"]), "sites_staged": staged["sites"],
                            "bytes_per_dnm": round(staged["bytes"] / n, 1),
                            "achieved_GBps": round(staged["bytes"] * args.steps / staged["elapsed"] / 1e9, 2), "peak_GBps": 64.0,
                            "chunks": staged["chunks"], "decode_s": round(staged["decode_s"], 1),
