@@ -146,18 +146,30 @@ class HipEngine:
         self._ck(self.L.uz_family_upload(self.h, int(sites_h), v.ref(), C.byref(fid)), "uz_family_upload")
         return fid.value
 
-    def upload_reads(self, reads, min_base_qual=None, point_only=False) -> int:
+    def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False) -> int:
         """A decoded table -> HBM.  With the base-quality threshold of the run (min_base_qual = --min-gt-qual) the table
         goes over the link in the staged form (packed on the host into pinned memory, several times fewer bytes); without it
         in the ASCII form, which the device packs and which then serves any threshold.
         point_only: the table will only serve batches of point variants (SNV / indel) -- the qualities then travel as
         per-record counts + short position lists instead of the one-bit plane (uz_types.h: the list form is exact for "good"
-        records, and a point-variant batch never looks at the bits of any other; an SV batch does)."""
+        records, and a point-variant batch never looks at the bits of any other; an SV batch does).
+        fetches = (contig, lo, hi, extra) of staging.fetch_points for the ONE batch the table will serve (point_only): records no
+        fetch returns travel without bases, of the others' rows only the 32-base units that hold a fetched position (all_bases:
+        --no-extended batches read mates at candidate sites nobody fetched -- every record keeps its rows)."""
         v = abi.reads_view(reads)
         if min_base_qual is not None:
             from . import io_native
             pool = PinnedPool()
-            rid = self.upload_reads_packed(io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None))
+            if fetches is not None and point_only:
+                full = io_native.pack_reads(v, int(min_base_qual), lists=True, with_end=True)
+                fc, flo, fhi, fex = fetches
+                packed, idx = io_native.ReadsSource(full).select(fc, flo, fhi, alloc=pool.alloc, want_index=True, all_bases=bool(all_bases),
+                                                                 extra=fex)
+                if idx.size != int(v.view.n_segs):  # record numbers are the caller's: the table must be the fetches' own reach
+                    raise UnfazedHipError("upload_reads(fetches=...): the table holds records the fetches cannot reach")
+            else:
+                packed = io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None)
+            rid = self.upload_reads_packed(packed)
             self.wait_reads(rid)  # the pinned buffers go back right away: the caller may drop the table
             self._staged.pop(rid, None)
             pool.free_all()

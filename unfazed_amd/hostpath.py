@@ -439,15 +439,19 @@ class PhasingHost:
                 for k, i in enumerate(idxs):
                     het_off[k + 1] = het_off[k] + len(found[i]["het_idx"])
                 het_idx = np.concatenate([found[i]["het_idx"] for i in idxs] + [np.zeros(0, np.int32)]).astype(np.int64)
-                fc, flo, fhi = fetch_points(
+                fc, flo, fhi, fex = fetch_points(
                     [prep[i]["tid"] for i in idxs], [int(dnms[i]["start"]) for i in idxs], [prep[i]["dflags"] for i in idxs],
                     self.sites.pos, het_off, het_idx, params, vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
-                    end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff)
+                    end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff,
+                    allele_len=[max(len(prep[i]["ref"]), len(prep[i]["alt"])) for i in idxs])
                 region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
                 # (a batch of point variants only ever asks for the quality bits of "good" records: the qualities travel as counts
                 # + short lists; SV evidence is collected under goodread(read, True), which does not count them: the plane)
                 point_only = all(vartype_code(dnms[i]["vartype"]) == abi.VT_POINT for i in idxs)
-                rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=point_only)
+                # with the fetches at hand the table travels as the bench stages it: mates without bases, of the other records' rows
+                # only the 32-base units that hold a fetched position (uz_types.h: umask)
+                rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=point_only,
+                                               fetches=(fc, flo, fhi, fex) if point_only else None, all_bases=bool(params.no_extended))
                 handles.append(rh)
             else:
                 rh = self.reads(bam, params.min_gt_qual)
