@@ -115,6 +115,9 @@ int uz_vcf_is_bcf(const uz_vcf *h);
  * lists when out->n_low is set (from either form of the source), the plane otherwise (plane sources only). */
 /* sizes of the packed form of an ASCII table */
 int uz_reads_pack_sizes(const uz_reads_view *in, int64_t *n_cigar_total, int64_t *n_row_units);
+/* records whose CIGAR is one M / = / X operation spanning the read: with out->cigar_compact their words stay home (out->n_cigar_total
+ * then is the plain total minus this, out->n_cigar_omitted this) */
+int uz_reads_pack_cigar_omitted(const uz_reads_view *in, int threads, int64_t *n_omitted);
 /* 1 when every record's `end` is what htslib's bam_endpos gives for its CIGAR (true of a BAM decoder's table): the packed form
  * may then leave the column out (out->end = NULL) and the device derives it */
 int uz_reads_pack_end_derivable(const uz_reads_view *in, int threads, int32_t *yes);
@@ -152,6 +155,8 @@ int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */
 int uz_select_qlow_pos_wide(const uz_select *s);  /* 1 when a kept read is longer than 256 bases */
 int uz_select_end_derivable(const uz_select *s);  /* 1: the output may leave `end` out (NULL) */
+int64_t uz_select_n_cigar_omitted(const uz_select *s); /* words that stay home when the output sets cigar_compact (its `cigar` then holds
+                                                        * uz_select_n_cigar_total - this many words) */
 int64_t uz_select_n_records(const uz_select *s);
 int64_t uz_select_n_cigar_total(const uz_select *s);
 int64_t uz_select_n_row_units(const uz_select *s);

@@ -55,6 +55,8 @@ extern "C" {
 #define UZ_AUX_MATE_SAME_TID 1u
 #define UZ_AUX_HAS_SA 2u
 #define UZ_AUX_DECODE_BAD 4u
+#define UZ_AUX_SIMPLE_SHIFT 4 /* packed form with cigar_compact, two bits: 0 = the CIGAR words are in `cigar`; 1 / 2 / 3 = one M / = / X over l_seq bases */
+#define UZ_AUX_SIMPLE_MASK 48u
 #define UZ_AUX_NO_SEQ 8u /* packed form only: the record was staged WITHOUT its bases (reachable only as a mate: nothing ever
                           * reads them); it has a quality-plane row but no seq4 row.  A kernel that asks for its bases fails loudly. */
 
@@ -216,7 +218,9 @@ typedef struct uz_reads_packed_view {
     const uint8_t *qlow_pos;  /* [n_qlow_pos] (* 2 bytes when qlow_pos_wide) */
     int64_t n_qlow_pos;
     int32_t qlow_pos_wide;
-    int32_t reserved2;
+    int32_t cigar_compact;    /* 1: a record whose CIGAR is one M / = / X operation spanning the read (98 % of a short-read file) carries the
+                               * operation in its aux byte (UZ_AUX_SIMPLE_*) and owns NO word in `cigar`; n_cigar_total counts the words that
+                               * are there, n_cigar_omitted the ones that are not; the device writes them back (len = l_seq) */
     /* Which 32-base units of a record's base row were staged (NULL: every unit of every record; needs the list form of the
      * qualities).  The read stage reads the bases of a record only at the fetch points it overlaps -- the DNM position (plus
      * the length of the longer allele) and the het sites of the window -- so a selection made from those fetches can leave the
@@ -225,6 +229,7 @@ typedef struct uz_reads_packed_view {
      * row then holds the staged units back to back; n_seq_units counts staged units; exc_* entries in other units are ignored.
      * A kernel that asks for a base of a unit that stayed home raises UZ_E_STATE. */
     const uint16_t *umask;    /* [n_segs] */
+    int64_t n_cigar_omitted;  /* cigar_compact: records with a simple code (each stands for one word) */
 } uz_reads_packed_view;
 #define UZ_UMASK_ALL 0xFFFFu
 

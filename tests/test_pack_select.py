@@ -194,7 +194,19 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
                 assert np.array_equal(part.arrays[name][: idx.size], pk.arrays[name][idx]), name
         no_seq = (part.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ) != 0
         assert np.array_equal(no_seq, ~direct[idx]) and 0.3 < no_seq.mean() < 0.6
-        assert np.array_equal(part.arrays["aux"][: idx.size] & ~np.uint8(abi.AUX_NO_SEQ), pk.arrays["aux"][idx])
+        SIMPLE = np.uint8(48)  # cigar_compact: a record that is one M / = / X over the read names the operation in its aux byte
+        assert np.array_equal(part.arrays["aux"][: idx.size] & ~np.uint8(abi.AUX_NO_SEQ) & ~SIMPLE, pk.arrays["aux"][idx])
+        code = (part.arrays["aux"][: idx.size] & SIMPLE) >> 4
+        assert part.view.cigar_compact == 1 and part.view.n_cigar_omitted == int((code != 0).sum()) > 0.9 * idx.size
+        coff_f = np.concatenate([[0], np.cumsum(pk.arrays["n_cigar"][:N].astype(np.int64))])
+        coff_p = np.concatenate([[0], np.cumsum(np.where(code != 0, 0, part.arrays["n_cigar"][: idx.size].astype(np.int64)))])
+        assert coff_p[-1] == part.view.n_cigar_total
+        for k in np.random.default_rng(a + 1).integers(0, idx.size, 200):
+            words = pk.arrays["cigar"][coff_f[idx[k]]: coff_f[idx[k] + 1]]
+            if code[k]:
+                assert words.size == 1 and words[0] == (int(part.arrays["l_seq"][k]) << 4 | {1: 0, 2: 7, 3: 8}[int(code[k])])
+            else:
+                assert np.array_equal(part.arrays["cigar"][coff_p[k]: coff_p[k + 1]], words)
         assert part.view.n_seq_units == int(abi.row_units(part.arrays["l_seq"][: idx.size])[~no_seq].sum())
         everything, _ = src.select(fc, flo, fhi, want_index=True, all_bases=True, lists=out_lists)
         assert everything.view.n_seq_units == everything.view.n_row_units and not (everything.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ).any()

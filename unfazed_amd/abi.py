@@ -165,8 +165,9 @@ class ReadsPackedView(C.Structure):
         ("qlow_pos", _p),
         ("n_qlow_pos", C.c_int64),
         ("qlow_pos_wide", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("cigar_compact", C.c_int32),  # 1: simple records (one M / = / X over the read) own no CIGAR word, their aux byte names the operation
         ("umask", _p),  # staged 32-base units per record (NULL: all)
+        ("n_cigar_omitted", C.c_int64),
     ]
 
 
@@ -184,13 +185,15 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False, with_end=True, with_umask=False) -> "Held":
+                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
     n_qlow_pos: None = the quality plane (qlow); a number = per-record counts (n_low) + that many listed positions (qlow_pos).
     with_end: False leaves the `end` column out (the device derives it from the CIGAR, as a BAM decoder did).
-    with_umask: a per-record mask of the staged 32-base units (n_seq_units then counts staged units)."""
+    with_umask: a per-record mask of the staged 32-base units (n_seq_units then counts staged units).
+    cigar_omitted: None = every CIGAR word; a number = cigar_compact with that many simple records (n_cigar_total is the plain total:
+    the words that stay home are taken off here)."""
     if n_seq_units is None:
         n_seq_units = n_row_units
     if alloc is None:
@@ -204,6 +207,8 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
         arrs["umask"] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.uint16)
     arrs["contig_off"] = alloc(8 * (n_contigs + 1))[: 8 * (n_contigs + 1)].view(np.int64)
     arrs["max_span"] = alloc(4 * max(1, n_contigs))[: 4 * max(1, n_contigs)].view(np.int32)
+    if cigar_omitted is not None:
+        n_cigar_total = n_cigar_total - cigar_omitted
     arrs["cigar"] = alloc(4 * max(1, n_cigar_total))[: 4 * max(1, n_cigar_total)].view(np.uint32)
     if n_exc is None:
         arrs["seq4"] = alloc(SEQ4_UNIT_BYTES * max(1, n_seq_units))[: SEQ4_UNIT_BYTES * max(1, n_seq_units)]
@@ -221,6 +226,8 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     v = ReadsPackedView()
     v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units, v.n_seq_units = n, n_contigs, n_cigar_total, n_row_units, n_seq_units
     v.n_exc = 0 if n_exc is None else n_exc
+    v.cigar_compact = 0 if cigar_omitted is None else 1
+    v.n_cigar_omitted = 0 if cigar_omitted is None else cigar_omitted
     v.n_qlow_pos = 0 if n_qlow_pos is None else n_qlow_pos
     v.qlow_pos_wide = 1 if qlow_pos_wide else 0
     for k, a in arrs.items():

@@ -427,6 +427,8 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_segs == 0 || v->qlow || v->n_low, UZ_E_ARG, "neither qlow nor n_low is set");
     if (v->n_low) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
     UZ_REQUIRE(!v->umask || v->n_low, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
+    UZ_REQUIRE(v->cigar_compact ? v->n_cigar_omitted >= 0 && v->n_cigar_omitted <= v->n_segs : v->n_cigar_omitted == 0, UZ_E_ARG, "bad n_cigar_omitted");
+    UZ_REQUIRE(v->n_cigar_total + v->n_cigar_omitted < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
@@ -434,8 +436,12 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     check_packed_view(v);
     r.live = true;
     r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
-    r.n_cigar_total = v->n_cigar_total; r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
-    const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units, ns = (size_t)r.n_seq_units;
+    r.n_cigar_total = v->n_cigar_total + v->n_cigar_omitted; // the device's store holds every record's words
+    r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
+    r.n_cigar_staged = v->n_cigar_total;
+    const bool ccompact = v->cigar_compact != 0;
+    const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units, ns = (size_t)r.n_seq_units, ncs = (size_t)v->n_cigar_total;
+    uint32_t *cigar_staged = nullptr;
     const bool two_bit = v->seq2 != nullptr;
     const size_t ne = two_bit ? (size_t)v->n_exc : 0;
     const bool lists = v->n_low != nullptr; // quality rows only for the records with bases (at their base-row position), written by the header build
@@ -452,6 +458,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         Carver cv(pass ? r.block.p : nullptr);
         carve_common(cv, r);
         cigar = cv.take<uint32_t>(nc);
+        if (ccompact) cigar_staged = cv.take<uint32_t>(ncs);
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
         qlow = cv.take<uint8_t>((lists ? ns : nu) * UZ_QLOW_UNIT_BYTES);
         if (lists) { n_low = cv.take<uint8_t>(n); qpos = cv.take<uint8_t>(nql); }
@@ -473,7 +480,12 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n); col.flag = h2d(st, flag, v->flag, n);
     col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
     col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
-    r.cigar = h2d(st, cigar, v->cigar, nc);
+    if (ccompact) { // the travelled words land in a staging area; the header build writes the store
+        r.cigar = cigar;
+        col.cigar_staged = h2d(st, cigar_staged, v->cigar, ncs);
+        col.cigar_out = cigar;
+    } else
+        r.cigar = h2d(st, cigar, v->cigar, nc);
     col.cigar_in = r.cigar;
     if (two_bit) { // half the bytes over the link; the header build expands them into seq4
         r.seq4 = seq4;
@@ -494,7 +506,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     }
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
-    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_q[4] = col.umask; r.col_qwide = col.qpos_wide;
+    r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_q[4] = col.umask; r.col_q[5] = col.cigar_staged; r.col_q[6] = col.cigar_out; r.col_qwide = col.qpos_wide;
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
         for (int k = 0; k < 10; k++) r.col_ptrs[k] = p[k];
@@ -515,6 +527,7 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.aux = (const uint8_t *)r.col_ptrs[9];
     col.plane_in = (const uint32_t *)r.col_q[0]; col.n_low = (const uint8_t *)r.col_q[1]; col.qlow_pos = (const uint8_t *)r.col_q[2];
     col.cigar_in = (const uint32_t *)r.col_q[3]; col.umask = (const uint16_t *)r.col_q[4];
+    col.cigar_staged = (const uint32_t *)r.col_q[5]; col.cigar_out = (uint32_t *)const_cast<void *>(r.col_q[6]);
     col.qpos_wide = r.col_qwide;
     UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, c->stream));
     uz_build_records(c, c->stream, r, col, r.build_scratch);
@@ -622,6 +635,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
         check_packed_view(v);
+        UZ_REQUIRE(!v->cigar_compact, UZ_E_ARG, "uz_reads_adopt_device takes every CIGAR word (cigar_compact = 0): the caller's column IS the device's store");
         UZ_REQUIRE(((uintptr_t)v->qlow | (uintptr_t)v->seq4 | (uintptr_t)v->seq2 | (uintptr_t)v->cigar) % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
         ReadsDev r;
         r.live = true;

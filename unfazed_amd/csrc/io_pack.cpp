@@ -85,6 +85,7 @@ struct uz_select {
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
     std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
     std::vector<uint16_t> umask;        // per kept record: staged 32-base units of its rows (UZ_UMASK_ALL: every unit; empty vector: no masks asked for)
+    int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
     int64_t n_qpos = 0;                 // entries of the output's qlow_pos
@@ -125,6 +126,24 @@ int uz_reads_pack_lists(const uz_reads_view *in, int min_base_qual, int threads,
         int64_t tot = 0, w2 = 0;
         for (int k = 0; k < wk; k++) { tot += part[(size_t)k]; w2 |= wd[(size_t)k]; }
         *n_qlow_pos = tot; *wide = (int32_t)w2;
+    });
+}
+
+int uz_reads_pack_cigar_omitted(const uz_reads_view *in, int threads, int64_t *n_omitted) {
+    return guarded([&] {
+        if (!in || !n_omitted) fail(UZ_IO_E_ARG, "null argument");
+        threads = resolve_threads(threads);
+        const int wk = workers_for(in->n_segs, threads, 1 << 14);
+        std::vector<int64_t> part((size_t)wk + 1, 0);
+        parallel_slices(in->n_segs, wk, [&](int64_t lo, int64_t hi, int k) {
+            int64_t c = 0;
+            for (int64_t i = lo; i < hi; i++)
+                c += uz_cigar_simple_code(in->n_cigar[i], in->n_cigar[i] ? in->cigar[in->cigar_off[i]] : 0u, in->l_seq[i]) != 0;
+            part[(size_t)k] = c;
+        });
+        int64_t tot = 0;
+        for (int k = 0; k < wk; k++) tot += part[(size_t)k];
+        *n_omitted = tot;
     });
 }
 
@@ -170,6 +189,20 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
         std::vector<uint64_t> coff, uoff, soff;
         offsets(n, in->n_cigar, in->l_seq, nullptr, threads, coff, uoff, soff);
         if (coff[n] >= ((uint64_t)1 << 32) || uoff[n] >= ((uint64_t)1 << 32)) fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets");
+        std::vector<uint8_t> scode;
+        if (out->cigar_compact) { // words of the simple records stay home: offsets over the others
+            scode.assign((size_t)n + 1, 0);
+            uint64_t at = 0, om = 0;
+            for (int64_t i = 0; i < n; i++) {
+                const uint32_t code = uz_cigar_simple_code(in->n_cigar[i], in->n_cigar[i] ? in->cigar[in->cigar_off[i]] : 0u, in->l_seq[i]);
+                scode[(size_t)i] = (uint8_t)code;
+                coff[(size_t)i] = at;
+                if (code) om++; else at += in->n_cigar[i];
+            }
+            coff[(size_t)n] = at;
+            if ((int64_t)om != out->n_cigar_omitted) fail(UZ_IO_E_ARG, "output view sized for %lld omitted CIGAR words, the table has %llu (uz_reads_pack_cigar_omitted)", (long long)out->n_cigar_omitted, (unsigned long long)om);
+        } else
+            out->n_cigar_omitted = 0;
         if ((int64_t)coff[n] != out->n_cigar_total || (int64_t)uoff[n] != out->n_row_units)
             fail(UZ_IO_E_ARG, "output view sized for %lld / %lld CIGAR words / row units, the table has %llu / %llu", (long long)out->n_cigar_total,
                  (long long)out->n_row_units, (unsigned long long)coff[n], (unsigned long long)uoff[n]);
@@ -212,7 +245,9 @@ int uz_reads_pack(const uz_reads_view *in, int min_base_qual, int threads, uz_re
                 w(out->mate)[i] = in->mate[i]; w(out->qname)[i] = in->qname[i]; w(out->flag)[i] = in->flag[i];
                 w(out->l_seq)[i] = in->l_seq[i]; w(out->n_cigar)[i] = in->n_cigar[i]; w(out->mapq)[i] = in->mapq[i];
                 w(out->aux)[i] = in->aux[i];
-                for (int k = 0; k < (int)in->n_cigar[i]; k++) w(out->cigar)[coff[i] + k] = in->cigar[(size_t)in->cigar_off[i] + k];
+                if (!scode.empty() && scode[(size_t)i]) w(out->aux)[i] = (uint8_t)(in->aux[i] | (scode[(size_t)i] << UZ_AUX_SIMPLE_SHIFT));
+                else
+                    for (int k = 0; k < (int)in->n_cigar[i]; k++) w(out->cigar)[coff[i] + k] = in->cigar[(size_t)in->cigar_off[i] + k];
                 const size_t row = (size_t)in->sq_off16[i] << 4;
                 int rc;
                 if (two_bit)
@@ -260,6 +295,7 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
         if (coff.back() >= ((uint64_t)1 << 32) || uoff.back() >= ((uint64_t)1 << 32)) { delete src; fail(UZ_IO_E_RANGE, "table exceeds the 32-bit CIGAR / row offsets"); }
         if ((int64_t)soff.back() != full->n_seq_units) { delete src; fail(UZ_IO_E_ARG, "n_seq_units does not match the aux column"); }
         if (!full->end) { delete src; fail(UZ_IO_E_ARG, "a source of selections needs the `end` column"); }
+        if (full->cigar_compact) { delete src; fail(UZ_IO_E_ARG, "a source of selections needs every CIGAR word (cigar_compact = 0)"); }
         if (!full->qlow && !full->n_low) { delete src; fail(UZ_IO_E_ARG, "the table has neither the quality plane nor its list form"); }
         if (full->n_low) {
             src->loff.assign((size_t)full->n_segs + 1, 0);
@@ -380,6 +416,10 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 if (bases) sel->n_seq += m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16);
             }
         sel->n_sel = (int64_t)sel->index.size();
+        for (int64_t k = 0; k < sel->n_sel; k++) {
+            const int64_t i = sel->index[(size_t)k];
+            sel->n_cigar_simple += uz_cigar_simple_code(full->n_cigar[i], full->n_cigar[i] ? full->cigar[src->coff[(size_t)i]] : 0u, full->l_seq[i]) != 0;
+        }
         sel->n_low.assign((size_t)sel->n_sel, 0);
         {
             std::vector<int64_t> part;
@@ -422,6 +462,7 @@ int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq
 int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
 int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
 int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
+int64_t uz_select_n_cigar_omitted(const uz_select *s) { return s ? s->n_cigar_simple : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
     if (!s) return 0;
     const uz_reads_packed_view *f = &s->src->v;
@@ -440,7 +481,9 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         threads = resolve_threads(threads);
         const int64_t m = s->n_sel;
         out->n_segs = m; out->n_contigs = full->n_contigs; out->min_base_qual = full->min_base_qual; out->n_qnames = full->n_qnames;
-        out->n_cigar_total = (int64_t)s->n_cigar; out->n_row_units = (int64_t)s->n_units; out->n_seq_units = (int64_t)s->n_seq;
+        const bool ccompact = out->cigar_compact != 0;
+        out->n_cigar_omitted = ccompact ? s->n_cigar_simple : 0;
+        out->n_cigar_total = (int64_t)s->n_cigar - out->n_cigar_omitted; out->n_row_units = (int64_t)s->n_units; out->n_seq_units = (int64_t)s->n_seq;
         const bool two_bit = full->seq2 != nullptr;
         if (two_bit && !out->seq2) fail(UZ_IO_E_ARG, "the source table has two-bit base rows: the output view needs seq2 (and the exc_* columns)");
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
@@ -479,7 +522,8 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         std::vector<uint64_t> oc((size_t)m + 1, 0), ou((size_t)m + 1, 0), os((size_t)m + 1, 0);
         for (int64_t k = 0; k < m; k++) {
             const int64_t i = s->index[k];
-            oc[k + 1] = oc[k] + full->n_cigar[i];
+            const bool smp = ccompact && uz_cigar_simple_code(full->n_cigar[i], full->n_cigar[i] ? full->cigar[src->coff[(size_t)i]] : 0u, full->l_seq[i]) != 0;
+            oc[k + 1] = oc[k] + (smp ? 0 : full->n_cigar[i]);
             ou[k + 1] = ou[k] + UZ_ROW_UNITS(full->l_seq[i]);
             const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
             os[k + 1] = os[k] + (s->bases[k] ? (m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16)) : 0);
@@ -498,8 +542,9 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 w(out->mate)[k] = nm;
                 w(out->qname)[k] = full->qname[i]; w(out->flag)[k] = full->flag[i]; w(out->l_seq)[k] = full->l_seq[i];
                 w(out->n_cigar)[k] = full->n_cigar[i]; w(out->mapq)[k] = full->mapq[i];
-                w(out->aux)[k] = (uint8_t)(s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ));
-                memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
+                const uint32_t scode = ccompact ? uz_cigar_simple_code(full->n_cigar[i], full->n_cigar[i] ? full->cigar[src->coff[(size_t)i]] : 0u, full->l_seq[i]) : 0u;
+                w(out->aux)[k] = (uint8_t)((s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ)) | (scode << UZ_AUX_SIMPLE_SHIFT));
+                if (!scode) memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
                 const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
                 const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
                 if (out->umask) w(out->umask)[k] = m16;

@@ -204,9 +204,11 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 #define UZ_PK_SPAN 4096
 // four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
 // low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
-#define UZ_PK_SUMS 4
+// ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none)
+#define UZ_PK_SUMS 5
 // um: which units of the record's rows were staged (UZ_UMASK_ALL: all of them)
 __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t (&v)[UZ_PK_SUMS]) {
+    v[4] = (aux & UZ_AUX_SIMPLE_MASK) ? 0u : nc;
     v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? v[1] : (uint32_t)__popc(um));
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_
                                                         const uint16_t *__restrict__ umask, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
-    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0};
+    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         if (i < n) {
@@ -238,21 +240,22 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_
 // one workgroup: exclusive scan of the block sums in place; the totals are checked against what the view declared
 __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
                                                         unsigned long long want_units, unsigned long long want_seq, unsigned long long want_qpos,
-                                                        int32_t *hflags) {
+                                                        unsigned long long want_staged /* ~0: not compact */, int32_t *hflags) {
     __shared__ unsigned long long part[UZ_PK_SUMS][1024];
     const int t = threadIdx.x;
     const int64_t chunk = (nb + 1023) / 1024;
     const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0};
+    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
     for (int64_t i = lo; i < hi; i++)
         for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
     for (int k = 0; k < UZ_PK_SUMS; k++) part[k][t] = v[k];
     __syncthreads();
     if (t == 0) {
-        unsigned long long r[UZ_PK_SUMS] = {0, 0, 0, 0};
+        unsigned long long r[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
         for (int j = 0; j < 1024; j++)
             for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = part[k][j]; part[k][j] = r[k]; r[k] += x; }
-        if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[3] != want_qpos || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL)
+        if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[3] != want_qpos || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL ||
+            (want_staged != ~0ULL && r[4] != want_staged))
             hflags[0] = 1;
     }
     __syncthreads();
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             for (int k = 0; k < UZ_PK_SUMS; k++) wsum[k][wv] = inc[k];
         }
         __syncthreads();
-        uint32_t pre[UZ_PK_SUMS] = {0, 0, 0, 0}, tot[UZ_PK_SUMS] = {0, 0, 0, 0};
+        uint32_t pre[UZ_PK_SUMS] = {0, 0, 0, 0, 0}, tot[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++)
 #pragma unroll
@@ -300,7 +303,19 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : (uint32_t)(run[2] + pre[2] + inc[2] - v[2]);
             const uint32_t cg = (uint32_t)(run[0] + pre[0] + inc[0] - v[0]);
             const int32_t st0 = c.start[i];
-            const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, c.flag[i], nc, c.cigar_in + cg); // (column left out: as bam_endpos)
+            const uint32_t *words = c.cigar_in + cg;
+            if (c.cigar_out) { // cigar_compact: this record's words into the store -- the travelled ones, or the one its aux byte names
+                const uint32_t code = (ax & UZ_AUX_SIMPLE_MASK) >> UZ_AUX_SIMPLE_SHIFT;
+                if (code) {
+                    if (nc != 1) hflags[0] = 6;
+                    c.cigar_out[cg] = uz_cigar_simple_word(code, ls);
+                } else {
+                    const unsigned long long so = run[4] + pre[4] + inc[4] - v[4];
+                    for (uint32_t k = 0; k < nc; k++) c.cigar_out[cg + k] = c.cigar_staged[so + k];
+                }
+                words = c.cigar_out + cg;
+            }
+            const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, c.flag[i], nc, words); // (column left out: as bam_endpos)
             uz_pack_rec(A, B, st0, en0, cg, sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
             ra[i] = A;
             rb[i] = B;
@@ -481,7 +496,8 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     unsigned long long *sums = (unsigned long long *)off_scratch;
     hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, col.n_low, col.umask, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
-                       (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos, c->hflags);
+                       (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos,
+                       col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
                        (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
@@ -652,6 +668,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                                   : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
                                   : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
                                   : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
+                                  : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
                                            : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;

@@ -55,6 +55,14 @@ UZP_HD int32_t uz_bam_endpos(int32_t start, uint32_t flag, uint32_t n_cigar, con
     return (int32_t)(start + (rl > 0 ? rl : 1));
 }
 
+// a CIGAR of one M / = / X operation spanning the read -> 1 / 2 / 3 (UZ_AUX_SIMPLE_*), 0 otherwise; and back to its word
+UZP_HD uint32_t uz_cigar_simple_code(uint32_t n_cigar, uint32_t word, uint32_t l_seq) {
+    if (n_cigar != 1 || (word >> 4) != l_seq) return 0;
+    const uint32_t op = word & 15u;
+    return op == 0 ? 1u : (op == 7 ? 2u : (op == 8 ? 3u : 0u));
+}
+UZP_HD uint32_t uz_cigar_simple_word(uint32_t code, uint32_t l_seq) { return (l_seq << 4) | (code == 1 ? 0u : (code == 2 ? 7u : 8u)); }
+
 // ---- the two-bit rows of the host link (uz_reads_packed_view.seq2)
 // A 0, C 1, G 2, T 3; 0xFF for any other character
 UZP_HD uint8_t uz_ascii_seq2(uint8_t ch) {

@@ -112,7 +112,8 @@ struct ReadsDev {
     // would wait behind the persistent per-DNM grid and hold up the next table's copies
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
-    const void *col_q[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask of RecColumns, for the deferred header build
+    const void *col_q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask / cigar_staged / cigar_out of RecColumns, for the deferred header build
+    int64_t n_cigar_staged = 0; // cigar_compact: words that travelled (checked by the header build)
     int32_t col_qwide = 0;
     // a table that arrived with two-bit base rows (uz_reads_packed_view.seq2): the staged rows and the listed bases, expanded
     // into seq4 by the header build (uz_build_records); null afterwards / for four-bit tables
@@ -233,6 +234,8 @@ struct RecColumns {
     // qualities of the staged form: the plane itself (plane_in: the header build counts its bits into nlow) or its list
     // form (n_low + qlow_pos: the header build copies the counts and writes the plane rows of the listed records); both
     // null for an ASCII upload, whose plane and counts are built from the quality bytes (uz_build_qlow)
+    const uint32_t *cigar_staged = nullptr; // cigar_compact: the words that travelled (records with a simple code own none); the header build writes
+    uint32_t *cigar_out = nullptr;          // ... every record's words here (the device's CIGAR store).  Both null: `cigar_in` is the store itself
     const uint32_t *cigar_in = nullptr; // the record's CIGAR words (at its cigar offset): `end` is derived from them when the column is left out (end == nullptr)
     const uint16_t *umask = nullptr;    // staged units per record (null: every unit)
     const uint32_t *plane_in = nullptr;

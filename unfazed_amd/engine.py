@@ -168,7 +168,7 @@ class HipEngine:
                 if idx.size != int(v.view.n_segs):  # record numbers are the caller's: the table must be the fetches' own reach
                     raise UnfazedHipError("upload_reads(fetches=...): the table holds records the fetches cannot reach")
             else:
-                packed = io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None)
+                packed = io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None, cigar_compact=True)
             rid = self.upload_reads_packed(packed)
             self.wait_reads(rid)  # the pinned buffers go back right away: the caller may drop the table
             self._staged.pop(rid, None)

@@ -26,8 +26,8 @@ IO_EXPORTS = [
     "uz_bam_contig_length", "uz_bam_n_file_records", "uz_bam_n_records", "uz_bam_view", "uz_bam_qname",
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
-    "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable",
+    "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted",
     "uz_reads_select_fill", "uz_select_free",
 ]
 
@@ -100,6 +100,7 @@ def load():
     lib.uz_select_qlow_pos_wide.argtypes = [C.c_void_p]
     lib.uz_select_end_derivable.argtypes = [C.c_void_p]
     lib.uz_reads_pack_end_derivable.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int32)]
+    lib.uz_reads_pack_cigar_omitted.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64)]
     lib.uz_reads_pack.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.uz_reads_source_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_reads_source_close.argtypes = [C.c_void_p]
@@ -107,7 +108,7 @@ def load():
     lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                          C.POINTER(C.c_void_p)]
     for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units,
-               lib.uz_select_n_exc, lib.uz_select_n_qlow_pos):
+               lib.uz_select_n_exc, lib.uz_select_n_qlow_pos, lib.uz_select_n_cigar_omitted):
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int64
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -292,7 +293,7 @@ def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
 
 # ---------------------------------------------------------------------------- staged (packed) records
 def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=None, two_bit: bool = True, lists: bool = True,
-               with_end=True) -> "abi.Held":
+               with_end=True, cigar_compact: bool = False) -> "abi.Held":
     """ASCII table (abi.reads_view / a decoder's view) -> the packed form uz_reads_upload_packed takes, for the
     base-quality threshold of the run.  alloc(nbytes) -> uint8 array chooses the memory (pinned for the upload).
     two_bit: base rows in two bits + the listed bases that are not A/C/G/T (half the bytes of the largest column on the
@@ -301,7 +302,9 @@ def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=No
     bytes; the device rebuilds the rows) -- for tables that serve batches of point variants only (uz_types.h); False = the plane
     itself.
     with_end: True keeps the `end` column (a table that will be the source of selections needs it); None = leave it out when every
-    record's end is what its CIGAR gives (a BAM decoder's table) -- the device derives it."""
+    record's end is what its CIGAR gives (a BAM decoder's table) -- the device derives it.
+    cigar_compact: the CIGAR word of a record that is one M / = / X over the read stays home (its aux byte names the operation; not
+    for a table that will be the source of selections)."""
     lib = load()
     nc, nu = C.c_int64(0), C.c_int64(0)
     _check(lib, lib.uz_reads_pack_sizes(reads.ref(), C.byref(nc), C.byref(nu)))
@@ -319,8 +322,13 @@ def pack_reads(reads: "abi.Held", min_base_qual: int, threads: int = 0, alloc=No
         yes = C.c_int32(0)
         _check(lib, lib.uz_reads_pack_end_derivable(reads.ref(), int(threads), C.byref(yes)))
         with_end = not yes.value
+    omitted = None
+    if cigar_compact:
+        om = C.c_int64(0)
+        _check(lib, lib.uz_reads_pack_cigar_omitted(reads.ref(), int(threads), C.byref(om)))
+        omitted = int(om.value)
     out = abi.packed_view_alloc(int(reads.view.n_segs), int(reads.view.n_contigs), nc.value, nu.value, alloc, n_exc=n_exc,
-                                n_qlow_pos=n_qpos, qlow_pos_wide=wide, with_end=bool(with_end))
+                                n_qlow_pos=n_qpos, qlow_pos_wide=wide, with_end=bool(with_end), cigar_omitted=omitted)
     _check(lib, lib.uz_reads_pack(reads.ref(), int(min_base_qual), int(threads), out.ref()))
     return out
 
@@ -336,7 +344,7 @@ class ReadsSource:
         self._h = _Handle(h, self.lib.uz_reads_source_close)
         self.threads = threads
 
-    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None):
+    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
@@ -362,7 +370,7 @@ class ReadsSource:
                                         n_qlow_pos=int(self.lib.uz_select_n_qlow_pos(sel)) if lists else None,
                                         qlow_pos_wide=bool(self.lib.uz_select_qlow_pos_wide(sel)) if lists else False,
                                         with_end=(not self.lib.uz_select_end_derivable(sel)) if with_end is None else bool(with_end),
-                                        with_umask=masks)
+                                        with_umask=masks, cigar_omitted=int(self.lib.uz_select_n_cigar_omitted(sel)) if cigar_compact else None)
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
