@@ -89,23 +89,64 @@ def make_small_sv(cfg: SvConfig) -> SmallDataset:
     reads: List[Segment] = []
     qn = 0
 
+    BASE_ARR = np.frombuffer(BASES.encode(), np.uint8)
+
+    def ref_codes(tid, a, n):  # refbase(tid, q) for q in [a, a + n), as 0..3 (the same integer hash, vectorised)
+        q = np.arange(a, a + n, dtype=np.int64)
+        x = (q * 0x9E3779B1 + tid * 0x85EBCA6B + 0x1234567) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+        x ^= x >> 12
+        return (x & 3).astype(np.int64)
+
+    site_keys = [np.array(sorted(d.keys()), np.int64) for d in ev_sites]
+
+    bitgen = rng._bit_generator  # the MT19937 behind the legacy RandomState: rand() and randint() are functions of its raw words
+
     def bases(ev_i, tid, a, n, h):
-        out = []
-        for q in range(a, a + n):
-            st = ev_sites[ev_i].get(q)
-            b = refbase(tid, q)
-            if st is not None:
-                b = st[1] if st[2 + h] else st[0]
-            if rng.rand() < cfg.base_err:
-                b = otherbase(b, int(rng.randint(0, 3)))
-            out.append(b)
-        return "".join(out)
+        """n bases from a: the haplotype's allele at the event's sites, the reference elsewhere, with base errors.  The random
+        draws are those of the plain loop -- one rand() per base, a randint(0, 3) right after a draw below base_err -- read off
+        the generator's raw 32-bit words in blocks (rand() = two words, randint(0, 3) = words & 3 until one is not 3), so a
+        read costs a few numpy calls instead of 151 Python-level draws and the stream stays word for word the same."""
+        code = ref_codes(tid, a, n)
+        ks = site_keys[ev_i]
+        for q in ks[np.searchsorted(ks, a): np.searchsorted(ks, a + n)]:
+            st = ev_sites[ev_i][int(q)]
+            code[int(q) - a] = BASES.index(st[1] if st[2 + h] else st[0])
+        raw = bitgen.random_raw(2 * n)
+        at, i = 0, 0  # next unread word, next base
+        while i < n:
+            m = n - i
+            short = 2 * m - (raw.size - at)
+            if short > 0:
+                raw = np.concatenate([raw[at:], bitgen.random_raw(short)])
+                at = 0
+            blk = raw[at: at + 2 * m]
+            d = ((blk[0::2] >> np.uint64(5)) * np.uint64(67108864) + (blk[1::2] >> np.uint64(6))).astype(np.float64) / 9007199254740992.0
+            hit = np.nonzero(d < cfg.base_err)[0]
+            if hit.size == 0:
+                at += 2 * m
+                break
+            j = int(hit[0])
+            at += 2 * (j + 1)
+            while True:  # randint(0, 3)
+                if at >= raw.size:
+                    raw = bitgen.random_raw(1)
+                    at = 0
+                v = int(raw[at]) & 3
+                at += 1
+                if v <= 2:
+                    break
+            code[i + j] = (code[i + j] + 1 + (v % 3)) % 4  # otherbase
+            i += j + 1
+        assert at == raw.size  # every word drawn was used: the generator stands where the plain loop would leave it
+        return BASE_ARR[code].tobytes().decode()
 
     def rnd(n):
         return "".join(BASES[int(x)] for x in rng.randint(0, 4, size=n))
 
     def qual(n):
-        return [12 if rng.rand() < 0.03 else 37 for _ in range(n)]
+        return np.where(rng.rand(n) < 0.03, 12, 37).tolist()
 
     for ei, ev in enumerate(events):
         tid, s, e = ev["tid"], ev["start"], ev["end"]
