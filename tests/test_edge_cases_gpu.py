@@ -207,3 +207,32 @@ def test_sv_batches_on_a_point_only_table_match_or_fail_loudly(engine, monkeypat
         except UnfazedHipError as e:
             assert "base-quality bit" in str(e)
     session._READS.clear(); session._HOSTS.clear()
+
+
+@pytest.mark.parametrize("shape", [dict(n_dnms=8), dict(readlen=300, ins_mean=800.0, ins_sd=60.0, coverage_per_hap=18.0, n_dnms=6),
+                                   dict(readlen=76, ins_mean=250.0, ins_sd=30.0, n_dnms=8, lowq_prob=0.08),
+                                   dict(indel_dnm_frac=0.6, indel_prob=0.06, softclip_prob=0.1, n_dnms=8)])
+def test_link_form_of_a_point_variant_table_matches_oracle(engine, monkeypatch, shape):
+    """The drop-in host uploads whole-file tables with the quality plane (they serve SV batches too); here every table is forced
+    into the form a point-variant region table travels in -- two-bit bases, qualities as counts + position lists (two-byte
+    positions for reads longer than 256 bases), `end` derived, compact CIGAR -- and the records must equal the oracle's."""
+    from helpers import dnm_sites, norm_records, run_host, split_kwargs, tables
+    from oracle_backend import OracleBackend
+    from synth.small import SmallConfig, make_small
+    from unfazed_amd.engine import HipEngine
+    real = HipEngine.upload_reads
+
+    def forced(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False):
+        return real(self, reads, min_base_qual=min_base_qual, point_only=True)
+
+    monkeypatch.setattr(HipEngine, "upload_reads", forced)
+    cfgkw, runkw = split_kwargs(dict(shape))
+    if "readlen" in cfgkw:
+        runkw["readlen"] = cfgkw["readlen"]
+    ds = make_small(SmallConfig(seed=6262, **cfgkw))
+    sites, reads = tables(ds)
+    want, dn_w, err_w = run_host(OracleBackend(), ds, sites, reads, **runkw)
+    got, dn_g, err_g = run_host(engine, ds, sites, reads, **runkw)
+    assert dnm_sites(dn_w) == dnm_sites(dn_g)
+    assert norm_records(want) == norm_records(got) and list(want.keys()) == list(got.keys())
+    assert err_w == err_g and len(want) >= 2
