@@ -277,6 +277,24 @@ __device__ __forceinline__ int64_t lower_bound(const int32_t *a, int64_t lo, int
     return lo;
 }
 
+// lower bound by a whole wave: 64 probes per round (a 64-ary search: four rounds over 20 M sites instead of 24 dependent
+// loads); every lane of the wave must call it with the same arguments
+__device__ __forceinline__ int64_t lower_bound_wave(const int32_t *__restrict__ a, int64_t lo, int64_t hi, int64_t v, int lane) {
+    while (hi - lo > 64) {
+        const int64_t step = (hi - lo + 63) >> 6;
+        const int64_t idx = lo + (int64_t)lane * step;
+        const bool lt = idx < hi && (int64_t)a[idx] < v; // sorted: true for a prefix of the lanes
+        const int k = __popcll(__ballot(lt));
+        if (k == 0) return lo;
+        const int64_t nhi = lo + (int64_t)k * step;
+        lo = lo + (int64_t)(k - 1) * step + 1;
+        hi = nhi < hi ? nhi : hi;
+    }
+    const int64_t idx = lo + lane;
+    const bool lt = idx < hi && (int64_t)a[idx] < v;
+    return lo + __popcll(__ballot(lt));
+}
+
 struct WinArgs {
     int32_t n;
     const int32_t *contig, *start, *end;
@@ -289,83 +307,128 @@ struct WinArgs {
     const int32_t *fam_idx;       // ... and the family of every DNM (null: `cls` for all)
     int64_t sd;
     int mode;
-    int64_t *range; // [2n] site index range of every DNM's windows: found by the count pass, reused by the fill pass
+    int64_t *range; // [4n] site index range of each of a DNM's (up to two) windows: found by the count pass, reused by the fill pass
 };
 
-// One lane per DNM, sites visited in the reference's order: by position, window-1 copy before
-// window-2 copy (= stable sort of the concatenated windows, :341-342), each entry `mult` times.
+// One lane walks the sites of one DNM in the reference's order: by position, window-1 copy before
+// window-2 copy (= stable sort of the concatenated windows, :341-342), each entry `mult` times.  Only the rare DNM whose
+// two windows overlap still goes this way (k_window_wave below takes every other).
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_window(WinArgs a, int32_t *cnt_c, int32_t *cnt_h, const int64_t *off_c,
-                                                const int64_t *off_h, int32_t *cand_idx, uint8_t *cand_flags,
-                                                int32_t *het_idx) {
-    const int32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ void window_serial(const WinArgs &a, int32_t d, const uint8_t *__restrict__ cls, int64_t clo, int64_t chi, int64_t w[2][2], int nw,
+                              int64_t oc, int64_t oh, int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx, int64_t &nc, int64_t &nh) {
+    const int64_t st = a.start[d], en = a.end[d];
+    const bool whole = a.mode & UZ_FIND_WHOLE_REGION;
+    const int vt = a.vartype[d];
+    const int mult = a.mult[d];
+    const bool small_event = (en - st) < 20;
+    int64_t i = lower_bound(a.pos, clo, chi, w[0][0] - 1);
+    const int64_t hi_all = lower_bound(a.pos, clo, chi, w[nw - 1][1]);
+    while (i < hi_all) {
+        const int32_t p = a.pos[i];
+        int64_t j = i + 1;
+        while (j < hi_all && a.pos[j] == p) j++;
+        const int64_t pos1 = (int64_t)p + 1;
+        if (!(small_event && p >= st && p < en)) { // :253-256
+            for (int k = 0; k < nw; k++) {
+                if (pos1 < w[k][0] || pos1 > w[k][1]) continue;
+                for (int64_t s = i; s < j; s++) {
+                    const uint32_t cl = cls[s];
+                    if (!cl) continue;
+                    uint32_t ka = 0;
+                    bool is_c;
+                    if (whole) {
+                        if (vt == UZ_VT_DEL) ka = (cl >> UZ_CL_DEL_SHIFT) & 3;
+                        else if (vt == UZ_VT_DUP) ka = (cl >> UZ_CL_DUP_SHIFT) & 3;
+                        is_c = ka != 0;
+                    } else is_c = (cl & UZ_CL_CAND) != 0;
+                    const bool is_h = (cl & UZ_CL_HET) != 0;
+                    for (int r = 0; r < mult; r++) {
+                        if (is_h) {
+                            if (FILL) het_idx[oh + nh] = (int32_t)s;
+                            nh++;
+                        }
+                        if (is_c) {
+                            if (FILL) {
+                                cand_idx[oc + nc] = (int32_t)s;
+                                cand_flags[oc + nc] = (uint8_t)(((cl & UZ_CL_ALT_DAD) ? UZ_CF_ALT_DAD : 0) | (ka << UZ_CF_KA_SHIFT));
+                            }
+                            nc++;
+                        }
+                    }
+                }
+            }
+        }
+        i = j;
+    }
+}
+
+// Breakpoint / point mode: one WAVE per DNM.  A window is a contiguous index range of the sites table (two lower bounds), walked
+// 64 sites per round with the list positions from ballots; a DNM with two windows (an event longer than search_dist) has
+// them one after the other -- window 1 lies wholly before window 2 unless they overlap, and then the reference's order
+// (window-1 copy before window-2 copy of the same position) is kept by lane 0 walking the sites alone.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_window_wave(WinArgs a, int32_t *cnt_c, int32_t *cnt_h, const int64_t *off_c, const int64_t *off_h,
+                                                     int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx) {
+    const int32_t d = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
     if (d >= a.n) return;
     int64_t nc = 0, nh = 0;
-    int64_t oc = 0, oh = 0;
-    if (FILL) { oc = off_c[d]; oh = off_h[d]; }
     const int32_t c = a.contig[d];
     const uint8_t *__restrict__ cls = a.fam_idx ? a.cls_of[a.fam_idx[d]] : a.cls;
     if (c >= 0 && c < a.n_contigs) {
         const int64_t clo = a.contig_off[c], chi = a.contig_off[c + 1];
         const int64_t st = a.start[d], en = a.end[d];
-        const bool whole = a.mode & UZ_FIND_WHOLE_REGION;
         int64_t w[2][2];
         int nw = 1;
-        if (whole) { w[0][0] = st - a.sd; w[0][1] = en + a.sd; }
-        else {
-            w[0][0] = st - a.sd; w[0][1] = st + a.sd; // 1-based POS window built from the 0-based start (:24-31)
-            if ((a.mode & UZ_FIND_SECOND_WINDOW) && (en - st) > a.sd) { w[1][0] = en - a.sd; w[1][1] = en + a.sd; nw = 2; }
-        }
+        w[0][0] = st - a.sd; w[0][1] = st + a.sd; // 1-based POS window built from the 0-based start (:24-31)
+        if ((a.mode & UZ_FIND_SECOND_WINDOW) && (en - st) > a.sd) { w[1][0] = en - a.sd; w[1][1] = en + a.sd; nw = 2; }
         for (int k = 0; k < nw; k++) if (w[k][0] < 1) w[k][0] = 1;
-        const int vt = a.vartype[d];
-        const int mult = a.mult[d];
-        const bool small_event = (en - st) < 20;
-        int64_t i, hi_all;
-        if (FILL) { i = a.range[2 * (int64_t)d]; hi_all = a.range[2 * (int64_t)d + 1]; }
-        else {
-            i = lower_bound(a.pos, clo, chi, w[0][0] - 1);
-            hi_all = lower_bound(a.pos, clo, chi, w[nw - 1][1]);
-            a.range[2 * (int64_t)d] = i; a.range[2 * (int64_t)d + 1] = hi_all;
-        }
-        while (i < hi_all) {
-            const int32_t p = a.pos[i];
-            int64_t j = i + 1;
-            while (j < hi_all && a.pos[j] == p) j++;
-            const int64_t pos1 = (int64_t)p + 1;
-            if (!(small_event && p >= st && p < en)) { // :253-256
-                for (int k = 0; k < nw; k++) {
-                    if (pos1 < w[k][0] || pos1 > w[k][1]) continue;
-                    for (int64_t s = i; s < j; s++) {
-                        const uint32_t cl = cls[s];
-                        if (!cl) continue;
-                        uint32_t ka = 0;
-                        bool is_c;
-                        if (whole) {
-                            if (vt == UZ_VT_DEL) ka = (cl >> UZ_CL_DEL_SHIFT) & 3;
-                            else if (vt == UZ_VT_DUP) ka = (cl >> UZ_CL_DUP_SHIFT) & 3;
-                            is_c = ka != 0;
-                        } else is_c = (cl & UZ_CL_CAND) != 0;
-                        const bool is_h = (cl & UZ_CL_HET) != 0;
-                        for (int r = 0; r < mult; r++) {
-                            if (is_h) {
-                                if (FILL) het_idx[oh + nh] = (int32_t)s;
-                                nh++;
-                            }
-                            if (is_c) {
-                                if (FILL) {
-                                    cand_idx[oc + nc] = (int32_t)s;
-                                    cand_flags[oc + nc] = (uint8_t)(((cl & UZ_CL_ALT_DAD) ? UZ_CF_ALT_DAD : 0) | (ka << UZ_CF_KA_SHIFT));
-                                }
-                                nc++;
+        const int64_t oc = FILL ? off_c[d] : 0, oh = FILL ? off_h[d] : 0;
+        if (nw == 2 && w[1][0] <= w[0][1]) { // overlapping windows: a site can be listed twice, in the reference's order
+            if (lane == 0) window_serial<FILL>(a, d, cls, clo, chi, w, nw, oc, oh, cand_idx, cand_flags, het_idx, nc, nh);
+        } else {
+            const int mult = a.mult[d];
+            const bool small_event = (en - st) < 20;
+            const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
+            for (int k = 0; k < nw; k++) {
+                int64_t lo, hi;
+                if (FILL) { lo = a.range[4 * (int64_t)d + 2 * k]; hi = a.range[4 * (int64_t)d + 2 * k + 1]; }
+                else {
+                    lo = lower_bound_wave(a.pos, clo, chi, w[k][0] - 1, lane);
+                    hi = lower_bound_wave(a.pos, lo, chi, w[k][1], lane);
+                    if (lane == 0) { a.range[4 * (int64_t)d + 2 * k] = lo; a.range[4 * (int64_t)d + 2 * k + 1] = hi; }
+                }
+                for (int64_t b = lo; b < hi; b += 64) {
+                    const int64_t sidx = b + lane;
+                    bool is_c = false, is_h = false;
+                    uint32_t cl = 0;
+                    if (sidx < hi) {
+                        cl = cls[sidx];
+                        const int32_t p = a.pos[sidx];
+                        if (cl && !(small_event && p >= st && p < en)) { // :253-256
+                            is_c = (cl & UZ_CL_CAND) != 0;
+                            is_h = (cl & UZ_CL_HET) != 0;
+                        }
+                    }
+                    const unsigned long long bc = __ballot(is_c), bh = __ballot(is_h);
+                    if (FILL) {
+                        if (is_h) for (int r = 0; r < mult; r++) het_idx[oh + (nh + __popcll(bh & below)) * mult + r] = (int32_t)sidx;
+                        if (is_c) {
+                            const uint8_t fl = (uint8_t)((cl & UZ_CL_ALT_DAD) ? UZ_CF_ALT_DAD : 0);
+                            for (int r = 0; r < mult; r++) {
+                                const int64_t at = oc + (nc + __popcll(bc & below)) * mult + r;
+                                cand_idx[at] = (int32_t)sidx;
+                                cand_flags[at] = fl;
                             }
                         }
                     }
+                    nc += __popcll(bc); nh += __popcll(bh);
                 }
             }
-            i = j;
+            nc *= mult; nh *= mult;
         }
     }
-    if (!FILL) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
+    if (!FILL && lane == 0) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
 }
 
 // Whole-region mode (CNV interior, sv_phaser.py:375-389) visits hundreds to thousands of sites per event: one WAVE per
@@ -390,11 +453,11 @@ __global__ __launch_bounds__(256) void k_window_region(WinArgs a, int32_t *cnt_c
         const int mult = a.mult[d];
         const bool small_event = (en - st) < 20;
         int64_t lo, hi;
-        if (FILL) { lo = a.range[2 * (int64_t)d]; hi = a.range[2 * (int64_t)d + 1]; }
+        if (FILL) { lo = a.range[4 * (int64_t)d]; hi = a.range[4 * (int64_t)d + 1]; }
         else {
-            lo = lower_bound(a.pos, clo, chi, w0 - 1);
-            hi = lower_bound(a.pos, clo, chi, w1);
-            if (lane == 0) { a.range[2 * (int64_t)d] = lo; a.range[2 * (int64_t)d + 1] = hi; }
+            lo = lower_bound_wave(a.pos, clo, chi, w0 - 1, lane);
+            hi = lower_bound_wave(a.pos, lo, chi, w1, lane);
+            if (lane == 0) { a.range[4 * (int64_t)d] = lo; a.range[4 * (int64_t)d + 1] = hi; }
         }
         const int64_t oc = FILL ? off_c[d] : 0, oh = FILL ? off_h[d] : 0;
         const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
@@ -698,9 +761,8 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         a.fam_idx = c->cohort_on ? c->dn_fam.p : nullptr;
         a.sd = c->P.search_dist;
         a.mode = mode;
-        c->win_range.ensure((size_t)2 * n + 2);
+        c->win_range.ensure((size_t)4 * n + 4);
         a.range = c->win_range.p;
-        const unsigned nb = (unsigned)((n + 255) / 256);
         const unsigned nbw = (unsigned)(((int64_t)n * 64 + 255) / 256); // one wave per DNM
         {
             ProfScope ps(c, UZ_K_WINDOW_COUNT);
@@ -709,7 +771,7 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
                                    (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr, (uint8_t *)nullptr,
                                    (int32_t *)nullptr);
             else
-                hipLaunchKernelGGL(k_window<false>, dim3(nb), dim3(256), 0, c->stream, a, c->cnt_c.p, c->cnt_h.p,
+                hipLaunchKernelGGL(k_window_wave<false>, dim3(nbw), dim3(256), 0, c->stream, a, c->cnt_c.p, c->cnt_h.p,
                                    (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr,
                                    (uint8_t *)nullptr, (int32_t *)nullptr);
             UZ_HIP(hipGetLastError());
@@ -743,7 +805,7 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
                                    (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p, c->cand_idx.p, c->cand_flags.p,
                                    c->het_idx.p);
             else
-                hipLaunchKernelGGL(k_window<true>, dim3(nb), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
+                hipLaunchKernelGGL(k_window_wave<true>, dim3(nbw), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
                                    (int32_t *)nullptr, (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p,
                                    c->cand_idx.p, c->cand_flags.p, c->het_idx.p);
             UZ_HIP(hipGetLastError());
