@@ -40,27 +40,29 @@ json.dump({"kernel": pmc["k_site_scan"]["full_name"], "n_sites": n_sites, "FETCH
            "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": int(2 * f + w),
            "algorithmic_bytes_per_launch": 20 * n_sites, "avg_ns_rocprof": avg_ns("k_site_scan")[0], "how": how,
            "source": "profiles/%s_pmc_summary.json" % rnd}, open(os.path.join(dst, "k1_traffic.json"), "w"), indent=1)
-# K3a: 16-byte header loads and 4-byte words; the factor between FETCH_SIZE and bytes is CALIBRATED on this kernel's own
-# access pattern with every record marked (known byte count), see DESIGN.md
-f, w = c("k_seg_qc", "FETCH_SIZE") * 1024, c("k_seg_qc", "WRITE_SIZE") * 1024
-rec = line["roofline_k3a"]["records_examined"]
-d = {"kernel": "k_seg_qc", "records_examined": rec, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
-     "algorithmic_bytes_per_launch": line["roofline_k3a"]["algorithmic_bytes_per_launch"], "avg_ns_rocprof": avg_ns("k_seg_qc")[0],
-     "how": how, "source": "profiles/%s_pmc_summary.json" % rnd}
-cal_path = os.path.join(src, "pmc_cal.json")
-if os.path.exists(cal_path) and not k3a_factor:
-    # calibration pass (UZ_TEST_QC_MARK_ALL): every record examined, bytes known exactly -> what one raw FETCH_SIZE byte is worth
-    # for this kernel's access widths (4-byte words; the guide's x2 holds for 16-byte streams only)
-    cal = json.load(open(cal_path))["k_seg_qc"]["counters_per_launch"]
-    n_all = line["config"]["alignment_records"]
-    known_read = n_all * (4 + 4 + 1 + 1)  # length word, flag word, low-quality count, the reach-map byte
-    k3a_factor = known_read / (cal["FETCH_SIZE"]["mean"] * 1024)
-    d["calibration"] = {"records": n_all, "known_read_bytes": known_read, "FETCH_SIZE_KB_raw": cal["FETCH_SIZE"]["mean"],
-                        "WRITE_SIZE_KB_raw": cal["WRITE_SIZE"]["mean"], "known_write_bytes": n_all}
-if k3a_factor:
-    d["fetch_factor_calibrated"] = k3a_factor
-    d["hbm_bytes_per_launch"] = int(k3a_factor * f + w)
-json.dump(d, open(os.path.join(dst, "k3a_traffic.json"), "w"), indent=1)
+if "k_seg_qc" in pmc:  # (rounds that still had the pass)
+    # K3a: 16-byte header loads and 4-byte words; the factor between FETCH_SIZE and bytes is CALIBRATED on this kernel's own
+    # access pattern with every record marked (known byte count), see DESIGN.md
+    f, w = c("k_seg_qc", "FETCH_SIZE") * 1024, c("k_seg_qc", "WRITE_SIZE") * 1024
+    rec = line["roofline_k3a"]["records_examined"]
+    d = {"kernel": "k_seg_qc", "records_examined": rec, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
+         "algorithmic_bytes_per_launch": line["roofline_k3a"]["algorithmic_bytes_per_launch"], "avg_ns_rocprof": avg_ns("k_seg_qc")[0],
+         "how": how, "source": "profiles/%s_pmc_summary.json" % rnd}
+    cal_path = os.path.join(src, "pmc_cal.json")
+    if os.path.exists(cal_path) and not k3a_factor:
+        # calibration pass (UZ_TEST_QC_MARK_ALL): every record examined, bytes known exactly -> what one raw FETCH_SIZE byte is worth
+        # for this kernel's access widths (4-byte words; the guide's x2 holds for 16-byte streams only)
+        cal = json.load(open(cal_path))["k_seg_qc"]["counters_per_launch"]
+        n_all = line["config"]["alignment_records"]
+        known_read = n_all * (4 + 4 + 1 + 1)  # length word, flag word, low-quality count, the reach-map byte
+        k3a_factor = known_read / (cal["FETCH_SIZE"]["mean"] * 1024)
+        d["calibration"] = {"records": n_all, "known_read_bytes": known_read, "FETCH_SIZE_KB_raw": cal["FETCH_SIZE"]["mean"],
+                            "WRITE_SIZE_KB_raw": cal["WRITE_SIZE"]["mean"], "known_write_bytes": n_all}
+    if k3a_factor:
+        d["fetch_factor_calibrated"] = k3a_factor
+        d["hbm_bytes_per_launch"] = int(k3a_factor * f + w)
+    json.dump(d, open(os.path.join(dst, "k3a_traffic.json"), "w"), indent=1)
+
 # k_phase: latency model from the SQ / TCP counters
 waves = c("k_phase", "SQ_WAVES")
 loads = c("k_phase", "SQ_INSTS_VMEM_RD")

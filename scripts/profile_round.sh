@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --no-staged --no-cpu --steps 3 --warmup 1"
 # counters only for the product's kernels (the synthetic generator's launches would be serialised and counted too)
-ONLY='--kernel-include-regex k_phase|k_seg_qc|k_site_scan|k_mark_ranges|k_window|k_pack_rec|k_cnv'
+ONLY='--kernel-include-regex k_phase|k_site_scan|k_window|k_pack_rec|k_expand_seq2|k_cnv'
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_LDS -d $OUT/sq -o run -- python3 $ARGS > $OUT/sq.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU -d $OUT/insts -o run -- python3 $ARGS > $OUT/insts.log 2>&1
@@ -17,11 +17,7 @@ rocprofv3 $ONLY --output-format csv --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSE
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/tcc -o run -- python3 $ARGS > $OUT/tcc.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o run -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o run -- python3 $ARGS > $OUT/write.log 2>&1
-# K3a calibration: every record marked -> a pure stream over known bytes (4+4+4+20 read, 1 written per record)
-UZ_TEST_QC_MARK_ALL=1 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/cal_fetch -o run -- python3 $ARGS > $OUT/cal_fetch.log 2>&1
-UZ_TEST_QC_MARK_ALL=1 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/cal_write -o run -- python3 $ARGS > $OUT/cal_write.log 2>&1
 cd $ROOT
-python3 scripts/pmc_summary.py $OUT/pmc_cal.json $OUT/cal_fetch $OUT/cal_write > /dev/null 2>&1
 python3 scripts/pmc_summary.py $OUT/pmc_summary.json $OUT/sq $OUT/insts $OUT/misc $OUT/tcp $OUT/tcc $OUT/fetch $OUT/write > $OUT/pmc_summary.txt 2>&1
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 grep "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json

@@ -22,7 +22,8 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                          const uint16_t *umask_in /* optional: staged 32-base units per record (UZ_UMASK_ALL: all) -- the others are left out of the rows */) {
     // the table in the packed form the device holds (built here on the host from the ASCII view)
     const int64_t n = Rv->n_segs;
-    std::vector<uint8_t> qc((size_t)n + 1), nlow((size_t)n + 1);
+    std::vector<uint8_t> nlow((size_t)n + 1);
+    std::vector<uint16_t> qs((size_t)n + 1);
     std::vector<uint16_t> umask((size_t)n + 1, (uint16_t)UZ_UMASK_ALL); // every unit of every row
     std::vector<RecA> ra((size_t)n + 1);
     std::vector<RecB> rb((size_t)n + 1);
@@ -68,13 +69,17 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     RD R;
     R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
     R.ra = ra.data(); R.rb = rb.data(); R.fm = fm.data(); R.cigar = cigar.data(); R.seq4 = seq4.data(); R.qlow = qlow.data();
-    R.qc = qc.data(); R.qoff = qoff.data(); R.nlow = nlow.data(); R.umask = umask.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
+    R.qs = qs.data(); R.min_map_qual = P->min_map_qual; R.qoff = qoff.data(); R.nlow = nlow.data(); R.umask = umask.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
     int32_t base_err = 0;
     R.err = &base_err;
     std::vector<int32_t> coarse((size_t)(n >> 12) + 2);
     for (int64_t k = 0; (k << 12) < n; k++) coarse[k] = Rv->start[k << 12];
     R.coarse = coarse.data();
-    for (int64_t i = 0; i < n; i++) qc[i] = uz_seg_qc(R, (int)i, P->min_map_qual);
+    for (int64_t i = 0; i < n; i++) { // the QC word as the header build makes it
+        int nonmatch = 0, none = 0;
+        for (int k = 0; k < (int)rb[i].n_cigar; k++) uz_cigar_op_counts(cigar[(size_t)ra[i].cigar_off + k], nonmatch, none);
+        qs[i] = uz_qs_word(fm[i] & 0xFFFFu, fm[i] >> 24, (fm[i] >> 16) & 0xFFu, nlow[i], rb[i].n_cigar, nonmatch, none);
+    }
     PhaseArgs a;
     memset(&a, 0, sizeof(a));
     a.n = D->n;

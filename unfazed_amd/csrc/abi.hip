@@ -395,7 +395,7 @@ int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int
 } // extern "C"
 
 // ---- alignment records -> HBM ---------------------------------------------------------------------------
-// Layout of a table's block: [record headers | flag word | qc | need | coarse | contig tables] then, for
+// Layout of a table's block: [record headers | flag word | QC word | coarse | contig tables] then, for
 // uploads, [cigar | seq4 | qlow] (+ the full qualities of an ASCII upload) and the staged fixed-width columns
 // the headers are built from.
 static void carve_common(Carver &cv, ReadsDev &r) {
@@ -407,8 +407,7 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.k3 = cv.take<uint32_t>(n);
     r.nlow = cv.take<uint8_t>(n);
     r.umask = cv.take<uint16_t>(n);
-    r.qc = cv.take<uint8_t>(n);
-    r.need = cv.take<uint8_t>(n);
+    r.qs = cv.take<uint16_t>(n);
     r.coarse = cv.take<int32_t>((n >> 12) + 2);
     r.contig_off = cv.take<int64_t>((size_t)r.n_contigs + 1);
     r.max_span = cv.take<int32_t>((size_t)r.n_contigs + 1);
@@ -513,7 +512,6 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         r.build_scratch = scratch;
         return;
     }
-    UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, st));
     uz_build_records(c, st, r, col, scratch);
 }
 
@@ -529,7 +527,6 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.cigar_in = (const uint32_t *)r.col_q[3]; col.umask = (const uint16_t *)r.col_q[4];
     col.cigar_staged = (const uint32_t *)r.col_q[5]; col.cigar_out = (uint32_t *)const_cast<void *>(r.col_q[6]);
     col.qpos_wide = r.col_qwide;
-    UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, c->stream));
     uz_build_records(c, c->stream, r, col, r.build_scratch);
     r.pending = false;
 }
@@ -578,7 +575,6 @@ int uz_reads_upload_impl(uz_ctx *c, const uz_reads_view *v, ReadsDev &r) {
     h2d(st, seq_in, v->seq, nsq); h2d(st, r.qual8, v->qual, nsq); h2d(st, r.qual_off16, v->sq_off16, n);
     r.cigar = cigar; r.seq4 = seq4; r.qlow = qlow;
     r.qlow_valid = false; // built for the threshold of the first uz_phase
-    UZ_HIP(hipMemsetAsync(r.qc, 0, n + 64, st));
     uz_build_records(c, st, r, col, scratch);
     uz_pack_ascii_rows(c, st, r, cigar_in, cigar_off_in, seq_in, r.qual_off16, cigar, seq4);
     UZ_HIP(hipStreamSynchronize(st));
@@ -671,7 +667,6 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             else col.plane_in = reinterpret_cast<const uint32_t *>(v->qlow);
             r.qlow_thr = v->min_base_qual;
             r.qlow_valid = true;
-            UZ_HIP(hipMemsetAsync(r.qc, 0, (size_t)r.n + 64, st));
             uz_build_records(c, st, r, col, scratch);
             UZ_HIP(hipStreamSynchronize(st));
             r.exc_rec = nullptr; r.exc_pos = nullptr; r.exc_code = nullptr; r.n_exc = 0; // (the caller's memory: not kept)
@@ -702,7 +697,6 @@ void uz_pinned_free(void *p) {
 int uz_drop_derived(uz_ctx *c) {
     return guarded(c, [&] {
         for (auto &f : c->fams) f.cls_valid = false;
-        for (auto &r : c->reads) r.qc_valid = false;
     });
 }
 
@@ -897,7 +891,6 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
                 co[(size_t)tot_contigs] = tot_n;
                 UZ_HIP(hipMemcpyAsync(m.contig_off, co.data(), co.size() * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
                 UZ_HIP(hipMemcpyAsync(m.max_span, ms.data(), ms.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-                UZ_HIP(hipMemsetAsync(m.qc, 0, (size_t)tot_n + 64, c->stream));
                 uz_finish_table(c, c->stream, m);
                 UZ_HIP(hipStreamSynchronize(c->stream)); // co / ms are stack-local
             } catch (...) { uz_block_put(c, m.block); throw; }

@@ -17,89 +17,9 @@
 
 namespace {
 
-// K3a: per-record QC bits (goodread read_collector.py:28-53 and the two CIGAR counts of :190-203, :405-408) for
-// the records the batch can reach, marked in a byte map by k_mark_ranges.  With the packed format the count of
-// low-quality bases is a popcount over the record's qlow words (20 bytes for a 151-base read), so one lane
-// takes one record: two header words, the flag word, the first CIGAR word and the quality words are requested
-// together.
-// A block owns UZ_QC_SPAN consecutive records of the table: it compacts the ones the byte map marks into
-// an LDS list (ascending), then runs over that list 256 records at a time.  No global list, no global
-// counter on the data path (count, when given, only feeds the profiling read-out).
-#define UZ_QC_SPAN 4096
-__global__ __launch_bounds__(256) void k_seg_qc(RD R, const uint8_t *__restrict__ need, int64_t n, int min_map_qual,
-                                                uint8_t *qc, unsigned int *count) {
-    __shared__ int lst[UZ_QC_SPAN];
-    __shared__ int wsum[4];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t base = (int64_t)blockIdx.x * UZ_QC_SPAN + (int64_t)t * 16;
-    uint32_t w4[4] = {0, 0, 0, 0};
-    if (base < n) { // the map is allocated with a 64-byte pad and zeroed up to it
-        const uint4 v = *reinterpret_cast<const uint4 *>(need + base);
-        w4[0] = v.x; w4[1] = v.y; w4[2] = v.z; w4[3] = v.w;
-    }
-    int c16 = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) c16 += ((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0 && base + k < n;
-    int incl = c16;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += u;
-    }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    int o = incl - c16;
-    for (int k = 0; k < wv; k++) o += wsum[k];
-    const int m = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if ((((w4[k >> 2] >> (8 * (k & 3))) & 0xFFu) != 0) && base + k < n) lst[o++] = (int32_t)(base + k);
-    if (t == 0 && count && m) atomicAdd(count, (unsigned int)m);
-    __syncthreads();
-    for (int r0 = t; r0 < m; r0 += 256) {
-        const int mine = lst[r0];
-        // nine bytes per record instead of its two 16-byte headers and its quality rows: lengths + "simple" flag, flags, and
-        // the number of low-quality bases (counted once, when the table was built)
-        const uint32_t k3 = R.k3[mine];
-        const uint32_t fm = R.fm[mine];
-        const int low = R.nlow[mine];
-        const uint32_t ax = fm >> 24;
-        const int ncg = (int)((k3 >> 16) & 0x7FFFu);
-        const bool simple = (k3 >> 31) != 0;
-        int nonmatch = 0, none = 0;
-        if (!simple && ncg > 0) { // the few records with a real CIGAR: soft clips, indels, ...
-            const uint32_t coff = R.ra[mine].cigar_off;
-            const int nc_all = (int)R.rb[mine].n_cigar; // the word saturates at 32767
-            for (int k = 0; k < nc_all; k++) uz_cigar_op_counts(R.cigar[coff + k], nonmatch, none);
-        }
-        qc[mine] = uz_seg_qc_combine(fm & 0xFFFFu, ax, (int)((fm >> 16) & 0xFFu), min_map_qual, low, ncg, nonmatch, none);
-    }
-}
-
-// Marks the records a batch can touch: every record of every fetch range and its mate.  Sixteen lanes per
-// range, on consecutive records (ranges are tens of records long).
-// For het-site ranges (spos != nullptr) records that end at or before the site are skipped: a fetch
-// range holds every record STARTING within max_span of the site, the kernel only registers those that
-// reach it (`end > pos`, phase B), so the others' QC bits are never read.
-__global__ __launch_bounds__(256) void k_mark_ranges(const int32_t *__restrict__ first, const int32_t *__restrict__ len_or_end,
-                                                     int end_stride, int64_t n_ranges, const RecA *__restrict__ ra,
-                                                     const RecB *__restrict__ rb, uint8_t *need,
-                                                     const int32_t *__restrict__ spos, const int32_t *__restrict__ het_idx) {
-    // sixteen lanes per range (a het-site range holds ~30 records): four ranges in flight per wave
-    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int lane = threadIdx.x & 15;
-    if (w >= n_ranges) return;
-    // end_stride == 0: (first[w], len[w]); otherwise ranges are [first[w * stride], first[w * stride + 1])
-    const int64_t a = end_stride ? first[w * end_stride] : first[w];
-    const int64_t b = end_stride ? first[w * end_stride + 1] : a + len_or_end[w];
-    const int32_t hp = spos ? spos[het_idx[w]] : 0;
-    for (int64_t i = a + lane; i < b; i += 16) {
-        if (spos && !(ra[i].end > hp)) continue;
-        need[i] = 1;
-        const int m = rb[i].mate;
-        if (m >= 0) need[m] = 1;
-    }
-}
+// K3a (per-record QC bits) has no kernel of its own any more: with the count of low-quality bases a column of the table, a
+// record's QC bits depend on nothing but the record -- the header build (k_pack_rec) writes them once, as a word that
+// keeps the mapping quality beside the parameter-independent bits, and the readers apply --min-map-qual (uz_qc_of).
 
 // one 16-lane group per DNM (a DNM has about ten het sites, each costing two binary searches)
 __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {
@@ -265,7 +185,7 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint32_t *k3, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
-                                                  int32_t *hflags) {
+                                                  uint16_t *qs, int32_t *hflags) {
     __shared__ uint32_t wsum[UZ_PK_SUMS][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     unsigned long long run[UZ_PK_SUMS];
@@ -316,6 +236,10 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                 words = c.cigar_out + cg;
             }
             const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, c.flag[i], nc, words); // (column left out: as bam_endpos)
+            int cig_nonmatch = 0, cig_none = 0; // the two CIGAR counts of the QC word
+            if (!(ax & UZ_AUX_DECODE_BAD) && c.cigar_in) // (an ASCII upload lays the words out after this kernel: k_pack_ascii sets the two bits)
+                for (uint32_t k = 0; k < nc; k++) uz_cigar_op_counts(words[k], cig_nonmatch, cig_none);
+            int low_for_qc = 0; // (an ASCII upload has no counts yet: uz_build_qlow sets the bit that depends on them)
             uz_pack_rec(A, B, st0, en0, cg, sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
             ra[i] = A;
             rb[i] = B;
@@ -328,6 +252,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                 // list form of the staged plane: the count as it is; a quality row (at the record's base-row position) only for a
                 // record whose bits can be asked for, written here from its listed positions
                 nlow[i] = (uint8_t)nl;
+                low_for_qc = nl;
                 const bool listed = v[3] == (uint32_t)nl && !(ax & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX;
                 qoff[i] = listed ? sq : UZ_NO_QLOW_OFF;
                 if (listed) {
@@ -365,8 +290,10 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                         low += __popc(w);
                     }
                     nlow[i] = (uint8_t)(low > 255 ? 255 : low);
+                    low_for_qc = low;
                 }
             }
+            qs[i] = uz_qs_word(c.flag[i], ax, c.mapq[i], low_for_qc, (int)nc, cig_nonmatch, cig_none);
         }
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++) run[k] += tot[k];
@@ -377,12 +304,22 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
 __global__ __launch_bounds__(256) void k_pack_ascii(int64_t n, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
                                                     const uint32_t *__restrict__ cigar_in, const uint32_t *__restrict__ cigar_off_in,
                                                     const uint8_t *__restrict__ seq_in, const uint32_t *__restrict__ sq_off16_in,
-                                                    uint32_t *cigar_out, uint8_t *seq4_out, int32_t *hflags) {
+                                                    uint32_t *cigar_out, uint8_t *seq4_out, uint16_t *qs, int32_t *hflags) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const RecA A = ra[i];
     const RecB B = rb[i];
-    for (int k = 0; k < (int)B.n_cigar; k++) cigar_out[(size_t)A.cigar_off + k] = cigar_in[(size_t)cigar_off_in[i] + k];
+    int nonmatch = 0, none = 0;
+    for (int k = 0; k < (int)B.n_cigar; k++) {
+        const uint32_t w = cigar_in[(size_t)cigar_off_in[i] + k];
+        cigar_out[(size_t)A.cigar_off + k] = w;
+        uz_cigar_op_counts(w, nonmatch, none);
+    }
+    { // the two CIGAR bits of the QC word (the header build ran before the words were here); a record without CIGAR / SEQ / QUAL keeps 0
+        const uint32_t w = qs[i];
+        if (w & 0xFF0Fu || B.n_cigar) // (uz_qs_word gave 0 for UZ_AUX_DECODE_BAD: such a record has no operations)
+            qs[i] = (uint16_t)((w & ~(UZ_QC_NM5 | UZ_QC_NONE5)) | (nonmatch <= 5 ? UZ_QC_NM5 : 0u) | (none <= 5 ? UZ_QC_NONE5 : 0u));
+    }
     const uint8_t *src = seq_in + ((size_t)sq_off16_in[i] << 4);
     uint8_t *dst = seq4_out + (size_t)A.sq_off * UZ_SEQ4_UNIT_BYTES;
     const int ls = B.l_seq, nb = (int)UZ_ROW_UNITS(ls) * UZ_SEQ4_UNIT_BYTES;
@@ -397,7 +334,7 @@ __global__ __launch_bounds__(256) void k_pack_ascii(int64_t n, const RecA *__res
 }
 __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__restrict__ ra, const RecB *__restrict__ rb,
                                                     const uint32_t *__restrict__ qoff, const uint8_t *__restrict__ qual8,
-                                                    const uint32_t *__restrict__ qual_off16, int thr, uint8_t *qlow, uint8_t *nlow) {
+                                                    const uint32_t *__restrict__ qual_off16, int thr, uint8_t *qlow, uint8_t *nlow, uint16_t *qs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int ls = rb[i].l_seq;
@@ -412,13 +349,16 @@ __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__res
         low += __popc(w);
     }
     nlow[i] = (uint8_t)(low > 255 ? 255 : low);
+    // the one bit of the QC word that depends on the threshold: goodread's count of low-quality bases (:43-52)
+    const uint32_t w = qs[i];
+    qs[i] = (uint16_t)((w & ~UZ_QC_GOOD) | (((w & UZ_QC_GOOD_DISC) && low <= 10 && rb[i].n_cigar <= 10) ? UZ_QC_GOOD : 0u));
 }
 
 // cohort batches: the headers of one kid's table copied into the merged table with its bases added
 __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
                                                     const uint32_t *__restrict__ sqo, const uint32_t *__restrict__ sk3, const uint8_t *__restrict__ snl,
-                                                    const uint16_t *__restrict__ sum_, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3, uint8_t *dnl,
-                                                    uint16_t *dum,
+                                                    const uint16_t *__restrict__ sum_, const uint16_t *__restrict__ sqs, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3,
+                                                    uint8_t *dnl, uint16_t *dum, uint16_t *dqs,
                                                     int32_t rec_base,
                                                     uint32_t cigar_base, uint32_t unit_base, uint32_t seq_base, uint32_t qname_base) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -429,14 +369,14 @@ __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__res
     if (A.sq_off != UZ_NO_SEQ_OFF) A.sq_off += seq_base;
     if (B.mate >= 0) B.mate += rec_base;
     B.qname += qname_base;
-    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dk3[i] = sk3[i]; dnl[i] = snl[i]; dum[i] = sum_[i];
+    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dk3[i] = sk3[i]; dnl[i] = snl[i]; dum[i] = sum_[i]; dqs[i] = sqs[i];
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
     R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm; R.k3 = r.k3;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
-    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.umask = r.umask; R.qc = r.qc; R.coarse = r.coarse;
+    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.umask = r.umask; R.qs = r.qs; R.min_map_qual = 0; R.coarse = r.coarse;
     R.err = nullptr; // set by the launcher of the per-DNM kernel
     return R;
 }
@@ -499,7 +439,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
                        (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos,
                        col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), c->hflags);
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
@@ -522,8 +462,8 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
     if (src.n <= 0) return;
     hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
                        (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint32_t *)src.k3, (const uint8_t *)src.nlow,
-                       (const uint16_t *)src.umask, (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base, dst.qoff + rec_base,
-                       dst.k3 + rec_base, dst.nlow + rec_base, dst.umask + rec_base,
+                       (const uint16_t *)src.umask, (const uint16_t *)src.qs, (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base,
+                       dst.qoff + rec_base, dst.k3 + rec_base, dst.nlow + rec_base, dst.umask + rec_base, dst.qs + rec_base,
                        (int32_t)rec_base, (uint32_t)cigar_base,
                        (uint32_t)unit_base, (uint32_t)seq_base, qname_base);
     UZ_HIP(hipGetLastError());
@@ -549,7 +489,7 @@ void uz_pack_ascii_rows(uz_ctx *c, hipStream_t st, ReadsDev &r, const uint32_t *
                         const uint8_t *seq_in, const uint32_t *sq_off16_in, uint32_t *cigar_out, uint8_t *seq4_out) {
     if (r.n <= 0) return;
     hipLaunchKernelGGL(k_pack_ascii, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, (const RecA *)r.rec_a,
-                       (const RecB *)r.rec_b, cigar_in, cigar_off_in, seq_in, sq_off16_in, cigar_out, seq4_out, c->hflags);
+                       (const RecB *)r.rec_b, cigar_in, cigar_off_in, seq_in, sq_off16_in, cigar_out, seq4_out, r.qs, c->hflags);
     UZ_HIP(hipGetLastError());
 }
 
@@ -557,12 +497,11 @@ void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual) {
     const int thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
     if (r.n > 0) {
         hipLaunchKernelGGL(k_build_qlow, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, (const RecA *)r.rec_a,
-                           (const RecB *)r.rec_b, (const uint32_t *)r.qoff, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow, r.nlow);
+                           (const RecB *)r.rec_b, (const uint32_t *)r.qoff, (const uint8_t *)r.qual8, (const uint32_t *)r.qual_off16, thr, r.qlow, r.nlow, r.qs);
         UZ_HIP(hipGetLastError());
     }
     r.qlow_thr = min_base_qual;
     r.qlow_valid = true;
-    r.qc_valid = false;
 }
 
 void uz_phase_state_free(uz_ctx *c) {
@@ -613,6 +552,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.allele_off = c->dn.allele_off.p; a.alleles = c->dn.alleles.p;
     a.R = make_rd(r);
     a.R.err = c->hflags + 1;
+    a.R.min_map_qual = c->P.min_map_qual;
 
     // sizing pass -> scratch capacities (max over the batch)
     st->bounds.ensure((size_t)5 * n);
@@ -638,29 +578,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     uz_kcopy(c, st->bounds_h, st->bounds.p, (size_t)5 * n * sizeof(int32_t));
     if (!st->bounds_ready) UZ_HIP(hipEventCreateWithFlags(&st->bounds_ready, hipEventDisableTiming));
     UZ_HIP(hipEventRecord(st->bounds_ready, c->stream));
-    // K3a, lazily: QC bits only for the records some fetch range of this batch (or a mate) can reach.
-    // The marking only needs the fetch ranges, so it runs while the host sizes the scratch below.
-    hipEvent_t qc_a = nullptr, qc_b = nullptr;
-    if (r.n > 0) {
-        uz_prof_begin(c, UZ_K_SEG_QC, &qc_a, &qc_b);
-        // UZ_TEST_QC_MARK_ALL (measurement hook): every record marked, so K3a becomes a pure stream over known bytes -- the
-        // calibration run for its FETCH_SIZE counter (profiles/k3a_traffic.json)
-        static const bool mark_all = getenv("UZ_TEST_QC_MARK_ALL") != nullptr;
-        UZ_HIP(hipMemsetAsync(r.need, mark_all ? 1 : 0, (size_t)r.n + 64, c->stream));
-        const int64_t n_dnm_ranges = 2 * (int64_t)n; // pre_win = (fa, fb, fa2, fb2) per DNM
-        hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)((n_dnm_ranges * 16 + 255) / 256)), dim3(256), 0, c->stream,
-                           (const int32_t *)st->pre_win.p, (const int32_t *)nullptr, 2, n_dnm_ranges, (const RecA *)r.rec_a,
-                           (const RecB *)r.rec_b, r.need, (const int32_t *)nullptr, (const int32_t *)nullptr);
-        UZ_HIP(hipGetLastError());
-        if (!c->P.no_extended && c->n_het > 0) {
-            hipLaunchKernelGGL(k_mark_ranges, dim3((unsigned)(((int64_t)c->n_het * 16 + 255) / 256)), dim3(256), 0, c->stream,
-                               (const int32_t *)st->pre_ha.p, (const int32_t *)st->pre_hl.p, 0, (int64_t)c->n_het,
-                               (const RecA *)r.rec_a, (const RecB *)r.rec_b, r.need, (const int32_t *)s.pos,
-                               (const int32_t *)c->het_idx.p);
-            UZ_HIP(hipGetLastError());
-        }
-    }
-    UZ_HIP(hipEventSynchronize(st->bounds_ready)); // the copy only: the marking kernels keep running
+    UZ_HIP(hipEventSynchronize(st->bounds_ready));
     if (c->hflags[0]) { // set by the header build of an upload (abi.hip) whose commands have now run
         const int f = c->hflags[0];
         c->hflags[0] = 0;
@@ -764,20 +682,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     UZ_HIP(hipMemsetAsync(timing.p, 0, 32 * sizeof(unsigned long long), c->stream));
     a.timing = timing.p;
 #endif
-    if (r.n > 0) {
-        (void)reach;
-        st->need_count.ensure(4);
-        UZ_HIP(hipMemsetAsync(st->need_count.p, 0, 4 * sizeof(unsigned int), c->stream));
-        {
-            ProfScope ps2(c, UZ_K_SEG_QC_PASS);
-            UZ_TRACE("k_seg_qc");
-            hipLaunchKernelGGL(k_seg_qc, dim3((unsigned)((r.n + UZ_QC_SPAN - 1) / UZ_QC_SPAN)), dim3(256), 0, c->stream, make_rd(r),
-                               (const uint8_t *)r.need, (int64_t)r.n, c->P.min_map_qual, r.qc,
-                               c->prof_on ? st->need_count.p : (unsigned int *)nullptr);
-            UZ_HIP(hipGetLastError());
-        }
-        uz_prof_end(c, UZ_K_SEG_QC, qc_a, qc_b);
-    }
+    (void)reach;
     // pinned staging of the per-DNM results (+ the list-pool fill level): everything comes back behind ONE sync
     {
         const size_t need = (size_t)7 * n + 16;
@@ -847,11 +752,6 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     if (counts) memcpy(counts, hres + n, (size_t)4 * n * sizeof(int32_t));
     if (origin) memcpy(origin, hres + (size_t)5 * n, (size_t)n * sizeof(int32_t));
     if (evidence) memcpy(evidence, hres + (size_t)6 * n, (size_t)n * sizeof(int32_t));
-    if (r.n > 0 && c->prof_on) {
-        unsigned int m = 0;
-        UZ_HIP(hipMemcpy(&m, st->need_count.p, sizeof(m), hipMemcpyDeviceToHost));
-        c->prof[UZ_K_SEG_QC].last_units = c->prof[UZ_K_SEG_QC_PASS].last_units = (int64_t)m;
-    }
     st->have_lists = a.want_lists != 0;
     c->phase_valid = true;
 }

@@ -96,9 +96,37 @@ struct RD { // alignment records of one table (device pointers)
     const uint16_t *umask; // which 32-base units of a record's rows were staged: bit u = unit u, UZ_UMASK_ALL = every unit (rows hold the
                            // staged units back to back); a base or a quality bit of a unit that stayed home sets err = 3
     int32_t *err;          // [0] set when the bases of a record staged without them are requested (must never happen)
-    const uint8_t *qc;
+    const uint16_t *qs;    // per-record QC word, built with the headers: bits 0-3 the parameter-independent part of the QC bits (UZ_QC_*:
+                           // GOOD / GOOD_DISC as they are when the mapping quality passes), bits 8-15 the mapping quality (uz_qc applies
+                           // --min-map-qual where the bits are used: no per-batch QC pass)
+    int32_t min_map_qual;
     const int32_t *coarse; // start of every 4096th record (L2-resident search index), may be null
 };
+
+// ---- per-record QC (goodread read_collector.py:28-53 and the two CIGAR counts of :190-203, :405-408)
+UZ_HD void uz_cigar_op_counts(uint32_t c, int &nonmatch, int &none) {
+    const int op = c & 15, l = (int)(c >> 4);
+    if (op != UZ_OP_M && op != UZ_OP_EQ) nonmatch++;
+    if (op == UZ_OP_I || op == UZ_OP_S) none += l;
+}
+// the QC word of a record: everything but the comparison with --min-map-qual, which the readers of the bits apply
+// (low: bases below the base-quality threshold; nc: CIGAR operations; nonmatch / none: the two counts above)
+UZ_HD uint16_t uz_qs_word(uint32_t f, uint32_t aux, uint32_t mapq, int low, int nc, int nonmatch, int none) {
+    if (aux & UZ_AUX_DECODE_BAD) return 0; // no CIGAR / SEQ / QUAL: never a good read (unpinned, DESIGN.md)
+    const bool flags_ok = !((f & 512u) || (f & 4u) || (f & 1024u) || (f & 256u) || (f & 2048u) || (f & 8u) || !(aux & UZ_AUX_MATE_SAME_TID)); // :31-41
+    uint32_t q = 0;
+    if (flags_ok) {
+        q |= UZ_QC_GOOD_DISC;
+        if (low <= 10 && nc <= 10) q |= UZ_QC_GOOD; // :43-52; "mismatches" counts every CIGAR op (quirk Q9)
+    }
+    if (nonmatch <= 5) q |= UZ_QC_NM5;
+    if (none <= 5) q |= UZ_QC_NONE5;
+    return (uint16_t)(q | ((mapq & 0xFFu) << 8));
+}
+// QC bits of a record for the run's --min-map-qual
+UZ_HD uint32_t uz_qc_of(uint32_t w, int min_map_qual) {
+    return ((int)(w >> 8) < min_map_qual) ? (w & (UZ_QC_NM5 | UZ_QC_NONE5)) : (w & 15u);
+}
 
 struct Caps { // per-workgroup scratch capacities (elements)
     int32_t A, T, H, C, I, M;
@@ -486,7 +514,7 @@ UZ_DEV int uz_pair_ok_vals(const PhaseArgs &a, double cutoff, const RecA &A, con
 }
 UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, double cutoff, int seg, const RecA &A, const RecB &B) {
     const int mi = B.mate >= 0 ? B.mate : seg; // a safe index: unused without a mate
-    return uz_pair_ok_vals(a, cutoff, A, B, R.qc[seg], R.ra[mi], R.qc[mi]);
+    return uz_pair_ok_vals(a, cutoff, A, B, uz_qc_of(R.qs[seg], R.min_map_qual), R.ra[mi], uz_qc_of(R.qs[mi], R.min_map_qual));
 }
 UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, double cutoff, int seg) { return uz_pair_ok_ab(R, a, cutoff, seg, R.ra[seg], R.rb[seg]); }
 
@@ -539,10 +567,10 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i,
     const RecA A = R.ra[i];
     const RecB B = R.rb[i];
     if (!((long long)A.end > lo)) return 0;
-    if (!(R.qc[i] & UZ_QC_GOOD_DISC)) return 0;  // goodread(read, True) :503
+    if (!(uz_qc_of(R.qs[i], R.min_map_qual) & UZ_QC_GOOD_DISC)) return 0;  // goodread(read, True) :503
     const int mate = B.mate;                     // :507-510
     if (mate < 0) return 0;
-    if (!(R.qc[mate] & UZ_QC_GOOD_DISC)) return 0; // :512
+    if (!(uz_qc_of(R.qs[mate], R.min_map_qual) & UZ_QC_GOOD_DISC)) return 0; // :512
     const uint32_t *c = R.cigar + A.cigar_off;
     const int nc = B.n_cigar;
     long long total = 0;
@@ -841,9 +869,9 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
             RecB B[2];
             uint32_t q[2], qm[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) { A[u] = R.ra[sg[u]]; B[u] = R.rb[sg[u]]; q[u] = R.qc[sg[u]]; }
+            for (int u = 0; u < 2; u++) { A[u] = R.ra[sg[u]]; B[u] = R.rb[sg[u]]; q[u] = uz_qc_of(R.qs[sg[u]], R.min_map_qual); }
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const int mi = B[u].mate >= 0 ? B[u].mate : sg[u]; M[u] = R.ra[mi]; qm[u] = R.qc[mi]; }
+            for (int u = 0; u < 2; u++) { const int mi = B[u].mate >= 0 ? B[u].mate : sg[u]; M[u] = R.ra[mi]; qm[u] = uz_qc_of(R.qs[mi], R.min_map_qual); }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 if (tt[u] >= T) continue;
@@ -1464,36 +1492,3 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int
     }
 }
 
-// per-segment QC bits (K3a): goodread (:28-53) and the two CIGAR counts of :190-203, given the
-// number of base qualities below the threshold
-UZ_DEV void uz_cigar_op_counts(uint32_t c, int &nonmatch, int &none) {
-    const int op = c & 15, l = (int)(c >> 4);
-    if (op != UZ_OP_M && op != UZ_OP_EQ) nonmatch++;
-    if (op == UZ_OP_I || op == UZ_OP_S) none += l;
-}
-UZ_DEV uint8_t uz_seg_qc_combine(uint32_t f, uint32_t aux, int mapq, int min_map_qual, int low, int nc, int nonmatch, int none) {
-    if (aux & UZ_AUX_DECODE_BAD) return 0; // no CIGAR / SEQ / QUAL: never a good read (unpinned, DESIGN.md)
-    const bool base_ok = !((f & 512u) || (f & 4u) || (f & 1024u) || mapq < min_map_qual || (f & 256u) ||
-                           (f & 2048u) || (f & 8u) || !(aux & UZ_AUX_MATE_SAME_TID)); // :31-41
-    uint8_t qc = 0;
-    if (base_ok) {
-        qc |= UZ_QC_GOOD_DISC;
-        if (low <= 10 && nc <= 10) qc |= UZ_QC_GOOD; // :43-52; "mismatches" counts every CIGAR op (quirk Q9)
-    }
-    if (nonmatch <= 5) qc |= UZ_QC_NM5;
-    if (none <= 5) qc |= UZ_QC_NONE5;
-    return qc;
-}
-// whole QC byte of one record, sequentially (the CPU twin and small tables; K3a proper is k_seg_qc)
-UZ_DEV uint8_t uz_seg_qc(const RD &R, int seg, int min_map_qual) {
-    const RecA A = R.ra[seg];
-    const RecB B = R.rb[seg];
-    const uint32_t fm = R.fm[seg];
-    const uint32_t aux = fm >> 24;
-    if (aux & UZ_AUX_DECODE_BAD) return 0;
-    const uint32_t *c = R.cigar + A.cigar_off;
-    int nonmatch = 0, none = 0;
-    for (int k = 0; k < (int)B.n_cigar; k++) uz_cigar_op_counts(c[k], nonmatch, none);
-    const int low = R.nlow[seg]; // :43-46 (only compared with 10: the saturation at 255 does not matter)
-    return uz_seg_qc_combine(fm & 0xFFFFu, aux, (int)((fm >> 16) & 0xFFu), min_map_qual, low, B.n_cigar, nonmatch, none);
-}

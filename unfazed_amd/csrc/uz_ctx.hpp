@@ -103,8 +103,7 @@ struct ReadsDev {
     // ASCII uploads (uz_reads_upload) keep the full qualities so that the plane can be rebuilt for another threshold
     uint8_t *qual8 = nullptr;
     uint32_t *qual_off16 = nullptr;
-    uint8_t *qc = nullptr;     // K3a output: per-record QC bits for the parameters in qc_params
-    uint8_t *need = nullptr;   // records reachable by the current batch (lazy K3a)
+    uint16_t *qs = nullptr;    // per-record QC word (phase_body.hpp: uz_qs_word), written by the header build
     int32_t *coarse = nullptr; // start of every 4096th record
     hipEvent_t ready = nullptr; // asynchronous uploads: recorded behind the last copy of the upload
     bool pending = false;       // the copies may still be in flight, and the headers are not built yet
@@ -122,8 +121,7 @@ struct ReadsDev {
     const uint16_t *exc_pos = nullptr;
     const uint8_t *exc_code = nullptr;
     int64_t n_exc = 0;
-    bool qc_valid = false;
-    uz_params qc_params;
+
 };
 
 // DNM batch staged on the device
