@@ -69,7 +69,7 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     RD R;
     R.contig_off = Rv->contig_off; R.max_span = Rv->max_span; R.n_contigs = Rv->n_contigs;
     R.ra = ra.data(); R.rb = rb.data(); R.fm = fm.data(); R.cigar = cigar.data(); R.seq4 = seq4.data(); R.qlow = qlow.data();
-    R.qs = qs.data(); R.min_map_qual = P->min_map_qual; R.qoff = qoff.data(); R.nlow = nlow.data(); R.umask = umask.data(); R.k3 = nullptr; // (only the device's K3a reads k3)
+    R.qs = qs.data(); R.min_map_qual = P->min_map_qual; R.qoff = qoff.data(); R.nlow = nlow.data(); R.umask = umask.data();
     int32_t base_err = 0;
     R.err = &base_err;
     std::vector<int32_t> coarse((size_t)(n >> 12) + 2);

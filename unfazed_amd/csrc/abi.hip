@@ -404,7 +404,6 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.rec_b = cv.take<uint8_t>(n * 16);
     r.fm = cv.take<uint32_t>(n);
     r.qoff = cv.take<uint32_t>(n);
-    r.k3 = cv.take<uint32_t>(n);
     r.nlow = cv.take<uint8_t>(n);
     r.umask = cv.take<uint16_t>(n);
     r.qs = cv.take<uint16_t>(n);

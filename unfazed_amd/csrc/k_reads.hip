@@ -184,7 +184,7 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
         for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = sums[UZ_PK_SUMS * i + k]; sums[UZ_PK_SUMS * i + k] = v[k]; v[k] += x; }
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
-                                                  uint32_t *fm, uint32_t *qoff, uint32_t *k3, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
+                                                  uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
                                                   uint16_t *qs, int32_t *hflags) {
     __shared__ uint32_t wsum[UZ_PK_SUMS][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -244,7 +244,6 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             ra[i] = A;
             rb[i] = B;
             fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);
-            k3[i] = uz_pack_k3(ls, nc, A.start, A.end);
             const int units = (int)UZ_ROW_UNITS(ls);
             umask_out[i] = (uint16_t)um;
             if (um != UZ_UMASK_ALL && (units > 15 || (um >> units) != 0u)) hflags[0] = 5; // a unit beyond the read, or a read too long for a mask
@@ -356,8 +355,8 @@ __global__ __launch_bounds__(256) void k_build_qlow(int64_t n, const RecA *__res
 
 // cohort batches: the headers of one kid's table copied into the merged table with its bases added
 __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__restrict__ sa, const RecB *__restrict__ sb, const uint32_t *__restrict__ sfm,
-                                                    const uint32_t *__restrict__ sqo, const uint32_t *__restrict__ sk3, const uint8_t *__restrict__ snl,
-                                                    const uint16_t *__restrict__ sum_, const uint16_t *__restrict__ sqs, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo, uint32_t *dk3,
+                                                    const uint32_t *__restrict__ sqo, const uint8_t *__restrict__ snl,
+                                                    const uint16_t *__restrict__ sum_, const uint16_t *__restrict__ sqs, RecA *da, RecB *db, uint32_t *dfm, uint32_t *dqo,
                                                     uint8_t *dnl, uint16_t *dum, uint16_t *dqs,
                                                     int32_t rec_base,
                                                     uint32_t cigar_base, uint32_t unit_base, uint32_t seq_base, uint32_t qname_base) {
@@ -369,12 +368,12 @@ __global__ __launch_bounds__(256) void k_concat_rec(int64_t n, const RecA *__res
     if (A.sq_off != UZ_NO_SEQ_OFF) A.sq_off += seq_base;
     if (B.mate >= 0) B.mate += rec_base;
     B.qname += qname_base;
-    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dk3[i] = sk3[i]; dnl[i] = snl[i]; dum[i] = sum_[i]; dqs[i] = sqs[i];
+    da[i] = A; db[i] = B; dfm[i] = sfm[i]; dqo[i] = sqo[i] == UZ_NO_QLOW_OFF ? UZ_NO_QLOW_OFF : sqo[i] + unit_base; dnl[i] = snl[i]; dum[i] = sum_[i]; dqs[i] = sqs[i];
 }
 
 RD make_rd(const ReadsDev &r) {
     RD R;
-    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm; R.k3 = r.k3;
+    R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
     R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.umask = r.umask; R.qs = r.qs; R.min_map_qual = 0; R.coarse = r.coarse;
     R.err = nullptr; // set by the launcher of the per-DNM kernel
@@ -439,7 +438,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
                        (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos,
                        col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.k3, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, c->hflags);
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
@@ -461,9 +460,9 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
                      int64_t seq_base, uint32_t qname_base) {
     if (src.n <= 0) return;
     hipLaunchKernelGGL(k_concat_rec, dim3((unsigned)((src.n + 255) / 256)), dim3(256), 0, st, (int64_t)src.n, (const RecA *)src.rec_a,
-                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint32_t *)src.k3, (const uint8_t *)src.nlow,
+                       (const RecB *)src.rec_b, (const uint32_t *)src.fm, (const uint32_t *)src.qoff, (const uint8_t *)src.nlow,
                        (const uint16_t *)src.umask, (const uint16_t *)src.qs, (RecA *)dst.rec_a + rec_base, (RecB *)dst.rec_b + rec_base, dst.fm + rec_base,
-                       dst.qoff + rec_base, dst.k3 + rec_base, dst.nlow + rec_base, dst.umask + rec_base, dst.qs + rec_base,
+                       dst.qoff + rec_base, dst.nlow + rec_base, dst.umask + rec_base, dst.qs + rec_base,
                        (int32_t)rec_base, (uint32_t)cigar_base,
                        (uint32_t)unit_base, (uint32_t)seq_base, qname_base);
     UZ_HIP(hipGetLastError());

@@ -69,13 +69,6 @@ UZ_HD void uz_pack_rec(RecA &A, RecB &B, int32_t start, int32_t end, uint32_t ci
     A.start = start; A.end = end; A.cigar_off = cigar_off; A.sq_off = sq_off;
     B.mate = mate; B.qname = qname; B.l_seq = l_seq; B.n_cigar = n_cigar; B.tlen = tlen;
 }
-// l_seq | min(n_cigar, 32767) << 16 | simple << 31.  simple: one operation spanning the read and as many reference bases, i.e.
-// M, = or X (see uz_qidx_h).  For such a record the two CIGAR counts of K3a are (0 or 1, 0) whichever of the three it is,
-// so its QC bits (<= 5 non-M/= operations, <= 5 bases without a reference position, <= 10 operations) need no CIGAR word.
-UZ_HD uint32_t uz_pack_k3(uint32_t l_seq, uint32_t n_cigar, int32_t start, int32_t end) {
-    const uint32_t simple = (n_cigar == 1 && l_seq > 1 && (uint32_t)(end - start) == l_seq) ? 1u : 0u;
-    return (l_seq & 0xFFFFu) | ((n_cigar > 32767u ? 32767u : n_cigar) << 16) | (simple << 31);
-}
 // flag | mapq << 16 | aux << 24
 UZ_HD uint32_t uz_pack_fm(uint32_t flag, uint32_t mapq, uint32_t aux) { return (flag & 0xFFFFu) | ((mapq & 0xFFu) << 16) | ((aux & 0xFFu) << 24); }
 
@@ -83,7 +76,6 @@ struct RD { // alignment records of one table (device pointers)
     const RecA *ra;
     const RecB *rb;
     const uint32_t *fm; // flag | mapq << 16 | aux << 24
-    const uint32_t *k3; // what K3a needs of the lengths in one word: l_seq | min(n_cigar, 32767) << 16 | simple << 31 (uz_pack_k3)
     const int64_t *contig_off;
     const int32_t *max_span;
     int32_t n_contigs;

@@ -94,7 +94,6 @@ struct ReadsDev {
     uint8_t *nlow = nullptr;   // low-quality bases of every record, saturated at 255 (what K3a needs of the qualities)
     int64_t n_qlow_pos = 0;    // list form of the staged plane: entries (checked against the columns by the header build)
     int64_t n_plane_units = 0; // units the quality-plane store holds: n_row_units (plane / ASCII form: every record has a row), n_seq_units (list form)
-    uint32_t *k3 = nullptr;    // l_seq | n_cigar << 16 | simple << 31 (uz_pack_k3): the lengths K3a needs in one word
     const uint32_t *cigar = nullptr;
     const uint8_t *seq4 = nullptr;
     uint8_t *qlow = nullptr;   // caller's memory for adopted tables (then never written)
