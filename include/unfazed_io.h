@@ -148,8 +148,12 @@ void uz_reads_source_close(uz_psrc *src);
  * of its rows that hold a fetched position -- position hi - 1 of a one- or two-base fetch, and extra[f] bases on (extra: NULL
  * = 0; for the fetch at a DNM the length of its longer allele) -- see uz_reads_packed_view.umask; the output then needs
  * the umask column and the list form of the qualities. */
+/* tuples: 0, or 1 (build the dictionary of the small columns, uz_reads_packed_view.tup) | 2 (the output will set cigar_compact) | 4 (the
+ * output will take the qualities as lists: n_low joins the combination); uz_select_n_tuples then gives the table length, or -1
+ * when the selection holds more than 65536 combinations (the output keeps the plain columns) */
 int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
-                         int unit_masks, const uint16_t *extra, int threads, uz_select **out);
+                         int unit_masks, const uint16_t *extra, int tuples, int threads, uz_select **out);
+int64_t uz_select_n_tuples(const uz_select *s);
 int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */

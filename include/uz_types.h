@@ -230,6 +230,19 @@ typedef struct uz_reads_packed_view {
      * A kernel that asks for a base of a unit that stayed home raises UZ_E_STATE. */
     const uint16_t *umask;    /* [n_segs] */
     int64_t n_cigar_omitted;  /* cigar_compact: records with a simple code (each stands for one word) */
+    /* The small columns as a dictionary (NULL: the plain columns).  flag, l_seq, n_cigar, mapq, aux and n_low take a few hundred
+     * distinct combinations in a whole alignment file (four pairing flags x a handful of mapping qualities and low-quality
+     * counts, one read length, one CIGAR operation): a record then carries a 16-bit index into a table of the combinations it
+     * uses instead of the nine bytes (tup set => flag, l_seq, n_cigar, mapq, aux and n_low are NULL; tup_n_low is NULL when the
+     * qualities travel as the plane).  At most 65536 combinations per table: a packer that meets more keeps the columns. */
+    const uint16_t *tup;         /* [n_segs] */
+    const uint16_t *tup_flag;    /* [n_tup] */
+    const uint16_t *tup_l_seq;
+    const uint16_t *tup_n_cigar;
+    const uint8_t *tup_mapq;
+    const uint8_t *tup_aux;
+    const uint8_t *tup_n_low;
+    int64_t n_tup;
 } uz_reads_packed_view;
 #define UZ_UMASK_ALL 0xFFFFu
 

@@ -168,6 +168,9 @@ class ReadsPackedView(C.Structure):
         ("cigar_compact", C.c_int32),  # 1: simple records (one M / = / X over the read) own no CIGAR word, their aux byte names the operation
         ("umask", _p),  # staged 32-base units per record (NULL: all)
         ("n_cigar_omitted", C.c_int64),
+        # the small columns (flag, l_seq, n_cigar, mapq, aux, n_low) as a 16-bit index into a table of their combinations
+        ("tup", _p), ("tup_flag", _p), ("tup_l_seq", _p), ("tup_n_cigar", _p), ("tup_mapq", _p), ("tup_aux", _p), ("tup_n_low", _p),
+        ("n_tup", C.c_int64),
     ]
 
 
@@ -185,13 +188,15 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None) -> "Held":
+                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
     n_qlow_pos: None = the quality plane (qlow); a number = per-record counts (n_low) + that many listed positions (qlow_pos).
     with_end: False leaves the `end` column out (the device derives it from the CIGAR, as a BAM decoder did).
     with_umask: a per-record mask of the staged 32-base units (n_seq_units then counts staged units).
+    n_tup: None = the plain small columns; a number = the dictionary form with that many combinations (tup + tup_* instead of flag,
+    l_seq, n_cigar, mapq, aux and n_low).
     cigar_omitted: None = every CIGAR word; a number = cigar_compact with that many simple records (n_cigar_total is the plain total:
     the words that stay home are taken off here)."""
     if n_seq_units is None:
@@ -199,8 +204,11 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     if alloc is None:
         alloc = lambda nbytes: np.zeros(max(16, nbytes), dtype=np.uint8)  # noqa: E731
     arrs = {}
+    TUP_COLS = ("flag", "l_seq", "n_cigar", "mapq", "aux")
     for name, dt in PACKED_RECORD_COLS:
         if name == "end" and not with_end:
+            continue
+        if n_tup is not None and name in TUP_COLS:
             continue
         arrs[name] = alloc(max(1, n) * np.dtype(dt).itemsize)[: max(1, n) * np.dtype(dt).itemsize].view(dt)
     if with_umask:
@@ -220,12 +228,19 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     if n_qlow_pos is None:
         arrs["qlow"] = alloc(QLOW_UNIT_BYTES * max(1, n_row_units))[: QLOW_UNIT_BYTES * max(1, n_row_units)]
     else:
-        arrs["n_low"] = alloc(max(1, n))[: max(1, n)]
+        if n_tup is None:
+            arrs["n_low"] = alloc(max(1, n))[: max(1, n)]
         w = 2 if qlow_pos_wide else 1
         arrs["qlow_pos"] = alloc(w * max(1, n_qlow_pos))[: w * max(1, n_qlow_pos)]
     v = ReadsPackedView()
     v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units, v.n_seq_units = n, n_contigs, n_cigar_total, n_row_units, n_seq_units
     v.n_exc = 0 if n_exc is None else n_exc
+    if n_tup is not None:
+        arrs["tup"] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.uint16)
+        for name, dt in (("tup_flag", np.uint16), ("tup_l_seq", np.uint16), ("tup_n_cigar", np.uint16), ("tup_mapq", np.uint8),
+                         ("tup_aux", np.uint8)) + ((("tup_n_low", np.uint8),) if n_qlow_pos is not None else ()):
+            arrs[name] = alloc(np.dtype(dt).itemsize * max(1, n_tup))[: np.dtype(dt).itemsize * max(1, n_tup)].view(dt)
+        v.n_tup = n_tup
     v.cigar_compact = 0 if cigar_omitted is None else 1
     v.n_cigar_omitted = 0 if cigar_omitted is None else cigar_omitted
     v.n_qlow_pos = 0 if n_qlow_pos is None else n_qlow_pos
@@ -233,6 +248,18 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     for k, a in arrs.items():
         setattr(v, k, a.ctypes.data)
     return Held(v, arrs)
+
+
+def small_columns(held: "Held") -> dict:
+    """flag, l_seq, n_cigar, mapq, aux (and n_low) of a packed view as plain per-record arrays, whichever way it carries them
+    (the dictionary form keeps a 16-bit index per record and a table of the combinations)."""
+    a, n = held.arrays, int(held.view.n_segs)
+    names = ["flag", "l_seq", "n_cigar", "mapq", "aux"] + (["n_low"] if ("n_low" in a or "tup_n_low" in a) else [])
+    if "tup" not in a:
+        return {k: a[k][:n] for k in names}
+    t = a["tup"][:n].astype(np.int64)
+    assert n == 0 or t.max() < int(held.view.n_tup)
+    return {k: a["tup_" + k][t] for k in names}
 
 
 class CohortGroup(C.Structure):

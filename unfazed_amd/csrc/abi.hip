@@ -422,9 +422,15 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_seq_units == 0 || v->seq2 || v->seq4, UZ_E_ARG, "n_seq_units > 0 but neither seq4 nor seq2 is set");
     if (v->seq2) UZ_REQUIRE(v->n_exc >= 0 && (v->n_exc == 0 || (v->exc_rec && v->exc_pos && v->exc_code)), UZ_E_ARG, "bad exc_* columns");
     UZ_REQUIRE(!(v->qlow && v->n_low), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form (n_low / qlow_pos), not both");
-    UZ_REQUIRE(v->n_segs == 0 || v->qlow || v->n_low, UZ_E_ARG, "neither qlow nor n_low is set");
-    if (v->n_low) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
-    UZ_REQUIRE(!v->umask || v->n_low, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
+    const bool v_lists = v->n_low != nullptr || (v->tup && v->tup_n_low);
+    UZ_REQUIRE(v->n_segs == 0 || v->qlow || v_lists, UZ_E_ARG, "neither qlow nor n_low is set");
+    UZ_REQUIRE(!(v->qlow && v_lists), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form, not both");
+    if (v_lists) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
+    UZ_REQUIRE(!v->umask || v_lists, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
+    if (v->tup) {
+        UZ_REQUIRE(v->n_tup >= 1 && v->n_tup <= 65536 && v->tup_flag && v->tup_l_seq && v->tup_n_cigar && v->tup_mapq && v->tup_aux, UZ_E_ARG, "bad tup_* table");
+        UZ_REQUIRE(!v->flag && !v->l_seq && !v->n_cigar && !v->mapq && !v->aux && !v->n_low, UZ_E_ARG, "tup is set: flag / l_seq / n_cigar / mapq / aux / n_low must be NULL");
+    }
     UZ_REQUIRE(v->cigar_compact ? v->n_cigar_omitted >= 0 && v->n_cigar_omitted <= v->n_segs : v->n_cigar_omitted == 0, UZ_E_ARG, "bad n_cigar_omitted");
     UZ_REQUIRE(v->n_cigar_total + v->n_cigar_omitted < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
 }
@@ -442,7 +448,10 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     uint32_t *cigar_staged = nullptr;
     const bool two_bit = v->seq2 != nullptr;
     const size_t ne = two_bit ? (size_t)v->n_exc : 0;
-    const bool lists = v->n_low != nullptr; // quality rows only for the records with bases (at their base-row position), written by the header build
+    const bool lists = v->n_low != nullptr || (v->tup && v->tup_n_low); // quality rows only for the records with bases (at their base-row position), written by the header build
+    const bool tupf = v->tup != nullptr;
+    const size_t nt = tupf ? (size_t)v->n_tup : 0;
+    uint16_t *tup = nullptr, *t_flag = nullptr, *t_ls = nullptr, *t_nc = nullptr; uint8_t *t_mq = nullptr, *t_ax = nullptr, *t_nl = nullptr;
     const size_t nql = lists ? (size_t)v->n_qlow_pos * (v->qlow_pos_wide ? 2 : 1) : 0;
     uint8_t *n_low = nullptr, *qpos = nullptr;
     uint16_t *umask_in = nullptr;
@@ -459,15 +468,21 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         if (ccompact) cigar_staged = cv.take<uint32_t>(ncs);
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
         qlow = cv.take<uint8_t>((lists ? ns : nu) * UZ_QLOW_UNIT_BYTES);
-        if (lists) { n_low = cv.take<uint8_t>(n); qpos = cv.take<uint8_t>(nql); }
+        if (lists) { n_low = cv.take<uint8_t>(tupf ? 0 : n); qpos = cv.take<uint8_t>(nql); }
+        if (tupf) {
+            tup = cv.take<uint16_t>(n); t_flag = cv.take<uint16_t>(nt); t_ls = cv.take<uint16_t>(nt); t_nc = cv.take<uint16_t>(nt);
+            t_mq = cv.take<uint8_t>(nt); t_ax = cv.take<uint8_t>(nt); t_nl = cv.take<uint8_t>(nt);
+        }
         if (v->umask) umask_in = cv.take<uint16_t>(n);
         if (two_bit) {
             seq2 = cv.take<uint8_t>(ns * UZ_SEQ2_UNIT_BYTES);
             exc_rec = cv.take<uint32_t>(ne); exc_pos = cv.take<uint16_t>(ne); exc_code = cv.take<uint8_t>(ne);
         }
         start = cv.take<int32_t>(n); end = cv.take<int32_t>(n); tlen = cv.take<int32_t>(n); mate = cv.take<int32_t>(n);
-        qname = cv.take<uint32_t>(n); flag = cv.take<uint16_t>(n); l_seq = cv.take<uint16_t>(n); n_cigar = cv.take<uint16_t>(n);
-        mapq = cv.take<uint8_t>(n); aux = cv.take<uint8_t>(n);
+        qname = cv.take<uint32_t>(n);
+        const size_t npl = tupf ? 0 : n; // the plain small columns
+        flag = cv.take<uint16_t>(npl); l_seq = cv.take<uint16_t>(npl); n_cigar = cv.take<uint16_t>(npl);
+        mapq = cv.take<uint8_t>(npl); aux = cv.take<uint8_t>(npl);
         scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
         if (!pass) r.block = uz_block_get(c, cv.off + 256);
     }
@@ -475,9 +490,18 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs);
     RecColumns col;
     col.start = h2d(st, start, v->start, n); col.end = v->end ? h2d(st, end, v->end, n) : nullptr; col.tlen = h2d(st, tlen, v->tlen, n);
-    col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n); col.flag = h2d(st, flag, v->flag, n);
-    col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
-    col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
+    col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n);
+    if (tupf) { // a 16-bit index per record + the table of combinations instead of nine bytes of small columns
+        col.tup = h2d(st, tup, v->tup, n);
+        col.tup_flag = h2d(st, t_flag, v->tup_flag, nt); col.tup_l_seq = h2d(st, t_ls, v->tup_l_seq, nt); col.tup_n_cigar = h2d(st, t_nc, v->tup_n_cigar, nt);
+        col.tup_mapq = h2d(st, t_mq, v->tup_mapq, nt); col.tup_aux = h2d(st, t_ax, v->tup_aux, nt);
+        if (v->tup_n_low) col.tup_n_low = h2d(st, t_nl, v->tup_n_low, nt);
+    } else {
+        col.flag = h2d(st, flag, v->flag, n);
+        col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
+        col.mapq = h2d(st, mapq, v->mapq, n); col.aux = h2d(st, aux, v->aux, n);
+    }
+    col.lists = lists ? 1 : 0;
     if (ccompact) { // the travelled words land in a staging area; the header build writes the store
         r.cigar = cigar;
         col.cigar_staged = h2d(st, cigar_staged, v->cigar, ncs);
@@ -494,7 +518,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         r.seq4 = h2d(st, seq4, v->seq4, ns * UZ_SEQ4_UNIT_BYTES);
     r.qlow = qlow;
     if (lists) {
-        col.n_low = h2d(st, n_low, v->n_low, n);
+        if (!tupf) col.n_low = h2d(st, n_low, v->n_low, n);
         col.qlow_pos = h2d(st, qpos, v->qlow_pos, nql);
         col.qpos_wide = v->qlow_pos_wide;
         if (v->umask) col.umask = h2d(st, umask_in, v->umask, n);
@@ -505,6 +529,11 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
     r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_q[4] = col.umask; r.col_q[5] = col.cigar_staged; r.col_q[6] = col.cigar_out; r.col_qwide = col.qpos_wide;
+    {
+        const void *t[7] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low};
+        for (int k = 0; k < 7; k++) r.col_t[k] = t[k];
+        r.col_lists = col.lists;
+    }
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
         for (int k = 0; k < 10; k++) r.col_ptrs[k] = p[k];
@@ -525,6 +554,9 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.plane_in = (const uint32_t *)r.col_q[0]; col.n_low = (const uint8_t *)r.col_q[1]; col.qlow_pos = (const uint8_t *)r.col_q[2];
     col.cigar_in = (const uint32_t *)r.col_q[3]; col.umask = (const uint16_t *)r.col_q[4];
     col.cigar_staged = (const uint32_t *)r.col_q[5]; col.cigar_out = (uint32_t *)const_cast<void *>(r.col_q[6]);
+    col.tup = (const uint16_t *)r.col_t[0]; col.tup_flag = (const uint16_t *)r.col_t[1]; col.tup_l_seq = (const uint16_t *)r.col_t[2];
+    col.tup_n_cigar = (const uint16_t *)r.col_t[3]; col.tup_mapq = (const uint8_t *)r.col_t[4]; col.tup_aux = (const uint8_t *)r.col_t[5];
+    col.tup_n_low = (const uint8_t *)r.col_t[6]; col.lists = r.col_lists;
     col.qpos_wide = r.col_qwide;
     uz_build_records(c, c->stream, r, col, r.build_scratch);
     r.pending = false;
@@ -639,13 +671,14 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
         void *scratch = nullptr;
         uint8_t *seq4_own = nullptr; // two-bit rows are expanded into the library's own block
         uint8_t *qlow_own = nullptr; // the list form of the quality plane likewise
-        r.n_qlow_pos = v->n_low ? v->n_qlow_pos : 0;
-        r.n_plane_units = v->n_low ? v->n_seq_units : v->n_row_units;
+        const bool a_lists = v->n_low != nullptr || (v->tup && v->tup_n_low);
+        r.n_qlow_pos = a_lists ? v->n_qlow_pos : 0;
+        r.n_plane_units = a_lists ? v->n_seq_units : v->n_row_units;
         for (int pass = 0; pass < 2; pass++) {
             Carver cv(pass ? r.block.p : nullptr);
             carve_common(cv, r);
             if (v->seq2) seq4_own = cv.take<uint8_t>((size_t)r.n_seq_units * UZ_SEQ4_UNIT_BYTES);
-            if (v->n_low) qlow_own = cv.take<uint8_t>((size_t)r.n_seq_units * UZ_QLOW_UNIT_BYTES);
+            if (a_lists) qlow_own = cv.take<uint8_t>((size_t)r.n_seq_units * UZ_QLOW_UNIT_BYTES);
             scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
             if (!pass) r.block = uz_block_get(c, cv.off + 256);
         }
@@ -662,7 +695,11 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
                 r.seq4 = seq4_own; r.seq2_staged = v->seq2;
                 r.n_exc = v->n_exc; r.exc_rec = v->exc_rec; r.exc_pos = v->exc_pos; r.exc_code = v->exc_code;
             }
-            if (v->n_low) { r.qlow = qlow_own; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; col.umask = v->umask; }
+            if (v->tup) {
+                col.tup = v->tup; col.tup_flag = v->tup_flag; col.tup_l_seq = v->tup_l_seq; col.tup_n_cigar = v->tup_n_cigar;
+                col.tup_mapq = v->tup_mapq; col.tup_aux = v->tup_aux; col.tup_n_low = v->tup_n_low;
+            }
+            if (v->n_low || (v->tup && v->tup_n_low)) { r.qlow = qlow_own; col.lists = 1; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; col.umask = v->umask; }
             else col.plane_in = reinterpret_cast<const uint32_t *>(v->qlow);
             r.qlow_thr = v->min_base_qual;
             r.qlow_valid = true;

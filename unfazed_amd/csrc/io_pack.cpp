@@ -7,6 +7,7 @@
 //                      looked at, so nothing else needs to be staged.
 // Host only (g++), threads over records.
 #include <atomic>
+#include <unordered_map>
 
 #include "io_common.hpp"
 #include "pack.hpp"
@@ -85,6 +86,11 @@ struct uz_select {
     std::vector<int32_t> index; // kept records, ascending (indices into the source table)
     std::vector<uint8_t> bases; // per kept record: 1 = its bases are staged (a fetch returns it), 0 = reachable only as a mate
     std::vector<uint16_t> umask;        // per kept record: staged 32-base units of its rows (UZ_UMASK_ALL: every unit; empty vector: no masks asked for)
+    // dictionary form of the small columns (uz_reads_packed_view.tup): built by the plan when asked for
+    int tuples = 0;                     // 0 none; else bit 0 set, bit 1: aux carries the simple-CIGAR code, bit 2: n_low is part of the combination
+    std::vector<uint16_t> tup_idx;      // per kept record
+    std::vector<uint64_t> tup_key;      // per combination: flag | l_seq << 16 | n_cigar << 32 | mapq << 48 | aux << 56
+    std::vector<uint8_t> tup_low;
     int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
@@ -317,7 +323,7 @@ int uz_reads_source_open(const uz_reads_packed_view *full, int threads, uz_psrc 
 void uz_reads_source_close(uz_psrc *s) { delete s; }
 
 int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
-                         int unit_masks, const uint16_t *extra, int threads, uz_select **out) {
+                         int unit_masks, const uint16_t *extra, int tuples, int threads, uz_select **out) {
     return guarded([&] {
         if (!src || !out || (n_fetch > 0 && (!contig || !lo || !hi))) fail(UZ_IO_E_ARG, "null argument");
         threads = resolve_threads(threads);
@@ -439,6 +445,30 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
             });
             for (int k = 0; k < wk; k++) sel->n_qpos += part[(size_t)k];
         }
+        if (tuples & 1) { // the small columns as a dictionary: combinations numbered in order of first appearance
+            struct KeyHash { size_t operator()(const std::pair<uint64_t, uint8_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second); } };
+            std::unordered_map<std::pair<uint64_t, uint8_t>, uint32_t, KeyHash> dict;
+            sel->tup_idx.assign((size_t)sel->n_sel, 0);
+            bool ok = true;
+            for (int64_t k = 0; k < sel->n_sel && ok; k++) {
+                const int64_t i = sel->index[(size_t)k];
+                uint32_t aux = sel->bases[(size_t)k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ);
+                if (tuples & 2)
+                    aux |= uz_cigar_simple_code(full->n_cigar[i], full->n_cigar[i] ? full->cigar[src->coff[(size_t)i]] : 0u, full->l_seq[i]) << UZ_AUX_SIMPLE_SHIFT;
+                const uint64_t key = (uint64_t)full->flag[i] | ((uint64_t)full->l_seq[i] << 16) | ((uint64_t)full->n_cigar[i] << 32) |
+                                     ((uint64_t)full->mapq[i] << 48) | ((uint64_t)(aux & 0xFFu) << 56);
+                const uint8_t low = (tuples & 4) ? sel->n_low[(size_t)k] : (uint8_t)0;
+                auto it = dict.find({key, low});
+                if (it == dict.end()) {
+                    if (dict.size() >= 65536) { ok = false; break; }
+                    it = dict.emplace(std::make_pair(key, low), (uint32_t)dict.size()).first;
+                    sel->tup_key.push_back(key); sel->tup_low.push_back(low);
+                }
+                sel->tup_idx[(size_t)k] = (uint16_t)it->second;
+            }
+            if (ok) sel->tuples = tuples;
+            else { sel->tup_idx.clear(); sel->tup_key.clear(); sel->tup_low.clear(); } // more than 65536 combinations: the plain columns
+        }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
             sel->exc_n.assign((size_t)sel->n_sel, 0);
@@ -462,6 +492,7 @@ int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq
 int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
 int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
 int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
+int64_t uz_select_n_tuples(const uz_select *s) { return (s && s->tuples) ? (int64_t)s->tup_key.size() : -1; }
 int64_t uz_select_n_cigar_omitted(const uz_select *s) { return s ? s->n_cigar_simple : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
     if (!s) return 0;
@@ -489,10 +520,24 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
         out->n_exc = two_bit ? s->n_exc : 0;
         if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
+        const bool tup = out->tup != nullptr;
+        if (tup) {
+            if (!s->tuples) fail(UZ_IO_E_ARG, "the output view asks for the dictionary form (tup) but the selection was planned without it (or met more than 65536 combinations: uz_select_n_tuples)");
+            if (((s->tuples & 2) != 0) != (out->cigar_compact != 0) || ((s->tuples & 4) != 0) != (out->tup_n_low != nullptr) || (out->tup_n_low && !out->qlow_pos))
+                fail(UZ_IO_E_ARG, "the dictionary of the selection was planned for another output form (cigar_compact / qualities as lists)");
+            out->n_tup = (int64_t)s->tup_key.size();
+            for (size_t t = 0; t < s->tup_key.size(); t++) {
+                const uint64_t key = s->tup_key[t];
+                w(out->tup_flag)[t] = (uint16_t)key; w(out->tup_l_seq)[t] = (uint16_t)(key >> 16); w(out->tup_n_cigar)[t] = (uint16_t)(key >> 32);
+                w(out->tup_mapq)[t] = (uint8_t)(key >> 48); w(out->tup_aux)[t] = (uint8_t)(key >> 56);
+                if (out->tup_n_low) w(out->tup_n_low)[t] = s->tup_low[t];
+            }
+        } else
+            out->n_tup = 0;
         const bool masks = !s->umask.empty();
         if (masks && !out->umask) fail(UZ_IO_E_ARG, "the selection was planned with unit masks: the output view needs umask");
-        if (masks && !out->n_low) fail(UZ_IO_E_ARG, "unit masks need the list form of the qualities in the output (n_low / qlow_pos)");
-        const bool lists = out->n_low != nullptr;
+        const bool lists = out->n_low != nullptr || (tup && out->tup_n_low != nullptr);
+        if (masks && !lists) fail(UZ_IO_E_ARG, "unit masks need the list form of the qualities in the output (n_low / qlow_pos)");
         if (!lists && !full->qlow) fail(UZ_IO_E_ARG, "the source table has the quality plane as lists: the output view needs n_low / qlow_pos");
         if (lists && !out->qlow_pos_wide && uz_select_qlow_pos_wide(s)) fail(UZ_IO_E_ARG, "reads longer than 256 bases need qlow_pos_wide");
         out->n_qlow_pos = lists ? s->n_qpos : 0;
@@ -540,10 +585,14 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                     if (it != s->index.end() && *it == mt) nm = (int32_t)(it - s->index.begin());
                 }
                 w(out->mate)[k] = nm;
-                w(out->qname)[k] = full->qname[i]; w(out->flag)[k] = full->flag[i]; w(out->l_seq)[k] = full->l_seq[i];
-                w(out->n_cigar)[k] = full->n_cigar[i]; w(out->mapq)[k] = full->mapq[i];
+                w(out->qname)[k] = full->qname[i];
+                if (tup) w(out->tup)[k] = s->tup_idx[(size_t)k];
+                else {
+                    w(out->flag)[k] = full->flag[i]; w(out->l_seq)[k] = full->l_seq[i];
+                    w(out->n_cigar)[k] = full->n_cigar[i]; w(out->mapq)[k] = full->mapq[i];
+                }
                 const uint32_t scode = ccompact ? uz_cigar_simple_code(full->n_cigar[i], full->n_cigar[i] ? full->cigar[src->coff[(size_t)i]] : 0u, full->l_seq[i]) : 0u;
-                w(out->aux)[k] = (uint8_t)((s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ)) | (scode << UZ_AUX_SIMPLE_SHIFT));
+                if (!tup) w(out->aux)[k] = (uint8_t)((s->bases[k] ? full->aux[i] : (full->aux[i] | UZ_AUX_NO_SEQ)) | (scode << UZ_AUX_SIMPLE_SHIFT));
                 if (!scode) memcpy(w(out->cigar) + oc[k], full->cigar + src->coff[i], (size_t)full->n_cigar[i] * sizeof(uint32_t));
                 const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
                 const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
@@ -572,7 +621,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 if (!lists)
                     memcpy(w(out->qlow) + ou[k] * UZ_QLOW_UNIT_BYTES, full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES, units * UZ_QLOW_UNIT_BYTES);
                 else {
-                    w(out->n_low)[k] = s->n_low[(size_t)k];
+                    if (!tup) w(out->n_low)[k] = s->n_low[(size_t)k];
                     if (s->bases[(size_t)k] && s->n_low[(size_t)k] <= UZ_QLOW_LIST_MAX) {
                         int64_t at = ol[(size_t)k];
                         auto put = [&](int b) {

@@ -132,9 +132,21 @@ __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, 
     v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? v[1] : (uint32_t)__popc(um));
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
-__global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_t *__restrict__ n_cigar, const uint16_t *__restrict__ l_seq,
-                                                        const uint8_t *__restrict__ aux, const uint8_t *__restrict__ n_low,
-                                                        const uint16_t *__restrict__ umask, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
+// the small columns of record i, plain or through the dictionary (uz_reads_packed_view.tup)
+struct RecSmall { uint32_t flag, ls, nc, mapq, aux; int nl; };
+__device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
+    RecSmall r;
+    if (c.tup) {
+        const uint32_t t = c.tup[i];
+        r.flag = c.tup_flag[t]; r.ls = c.tup_l_seq[t]; r.nc = c.tup_n_cigar[t]; r.mapq = c.tup_mapq[t]; r.aux = c.tup_aux[t];
+        r.nl = c.lists ? (int)c.tup_n_low[t] : -1;
+    } else {
+        r.flag = c.flag[i]; r.ls = c.l_seq[i]; r.nc = c.n_cigar[i]; r.mapq = c.mapq[i]; r.aux = c.aux[i];
+        r.nl = c.lists ? (int)c.n_low[i] : -1;
+    }
+    return r;
+}
+__global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
     unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
@@ -142,7 +154,8 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, const uint16_
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         if (i < n) {
             uint32_t v[UZ_PK_SUMS];
-            pk_vals(n_cigar[i], l_seq[i], aux[i], n_low ? (int)n_low[i] : -1, umask ? (uint32_t)umask[i] : UZ_UMASK_ALL, v);
+            const RecSmall r = rec_small(c, i);
+            pk_vals(r.nc, r.ls, r.aux, r.nl, c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL, v);
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -194,8 +207,10 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         const bool in = i < n;
-        const uint32_t nc = in ? c.n_cigar[i] : 0u, ls = in ? c.l_seq[i] : 0u, ax = in ? c.aux[i] : 0u;
-        const int nl = c.n_low ? (in ? (int)c.n_low[i] : 0) : -1;
+        RecSmall rs = {0u, 0u, 0u, 0u, 0u, c.lists ? 0 : -1};
+        if (in) rs = rec_small(c, i);
+        const uint32_t nc = rs.nc, ls = rs.ls, ax = rs.aux;
+        const int nl = rs.nl;
         const uint32_t um = (c.umask && in) ? (uint32_t)c.umask[i] : UZ_UMASK_ALL;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
         pk_vals(nc, ls, ax, nl, um, v);
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                 }
                 words = c.cigar_out + cg;
             }
-            const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, c.flag[i], nc, words); // (column left out: as bam_endpos)
+            const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, rs.flag, nc, words); // (column left out: as bam_endpos)
             int cig_nonmatch = 0, cig_none = 0; // the two CIGAR counts of the QC word
             if (!(ax & UZ_AUX_DECODE_BAD) && c.cigar_in) // (an ASCII upload lays the words out after this kernel: k_pack_ascii sets the two bits)
                 for (uint32_t k = 0; k < nc; k++) uz_cigar_op_counts(words[k], cig_nonmatch, cig_none);
@@ -243,7 +258,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             uz_pack_rec(A, B, st0, en0, cg, sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
             ra[i] = A;
             rb[i] = B;
-            fm[i] = uz_pack_fm(c.flag[i], c.mapq[i], ax);
+            fm[i] = uz_pack_fm(rs.flag, rs.mapq, ax);
             const int units = (int)UZ_ROW_UNITS(ls);
             umask_out[i] = (uint16_t)um;
             if (um != UZ_UMASK_ALL && (units > 15 || (um >> units) != 0u)) hflags[0] = 5; // a unit beyond the read, or a read too long for a mask
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                     low_for_qc = low;
                 }
             }
-            qs[i] = uz_qs_word(c.flag[i], ax, c.mapq[i], low_for_qc, (int)nc, cig_nonmatch, cig_none);
+            qs[i] = uz_qs_word(rs.flag, ax, rs.mapq, low_for_qc, (int)nc, cig_nonmatch, cig_none);
         }
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++) run[k] += tot[k];
@@ -433,7 +448,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     if (r.n <= 0) return;
     const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
     unsigned long long *sums = (unsigned long long *)off_scratch;
-    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col.n_cigar, col.l_seq, col.aux, col.n_low, col.umask, sums);
+    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
                        (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos,
                        col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, c->hflags);

@@ -27,7 +27,7 @@ IO_EXPORTS = [
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples",
     "uz_reads_select_fill", "uz_select_free",
 ]
 
@@ -105,10 +105,10 @@ def load():
     lib.uz_reads_source_open.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_reads_source_close.argtypes = [C.c_void_p]
     lib.uz_reads_source_close.restype = None
-    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+    lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)]
     for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units,
-               lib.uz_select_n_exc, lib.uz_select_n_qlow_pos, lib.uz_select_n_cigar_omitted):
+               lib.uz_select_n_exc, lib.uz_select_n_qlow_pos, lib.uz_select_n_cigar_omitted, lib.uz_select_n_tuples):
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int64
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -344,12 +344,15 @@ class ReadsSource:
         self._h = _Handle(h, self.lib.uz_reads_source_close)
         self.threads = threads
 
-    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True):
+    def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True,
+               tuples=True):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
         extra (uint16 per fetch, staging.fetch_points(..., allele_len=)): stage only the 32-base units of a record's rows that
-        the read stage can read -- the fetched position and `extra` bases on (needs lists; ignored with all_bases)."""
+        the read stage can read -- the fetched position and `extra` bases on (needs lists; ignored with all_bases).
+        tuples: flag, l_seq, n_cigar, mapq, aux (and n_low) as a 16-bit index into a table of their combinations (falls back to the
+        plain columns when the selection holds more than 65536 of them)."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -360,17 +363,21 @@ class ReadsSource:
             assert extra.size == contig.size
         _check(self.lib, self.lib.uz_reads_select_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data,
                                                        hi.ctypes.data, 1 if all_bases else 0, 1 if masks else 0,
-                                                       extra.ctypes.data if masks else None, int(self.threads), C.byref(sel)))
+                                                       extra.ctypes.data if masks else None,
+                                                       (1 | (2 if cigar_compact else 0) | (4 if lists else 0)) if tuples else 0,
+                                                       int(self.threads), C.byref(sel)))
         try:
             n = self.lib.uz_select_n_records(sel)
             two_bit = bool(self.packed.view.seq2)  # a selection keeps the base-row form of its source
+            n_tup = int(self.lib.uz_select_n_tuples(sel)) if tuples else -1
             out = abi.packed_view_alloc(n, int(self.packed.view.n_contigs), self.lib.uz_select_n_cigar_total(sel),
                                         self.lib.uz_select_n_row_units(sel), alloc, n_seq_units=self.lib.uz_select_n_seq_units(sel),
                                         n_exc=int(self.lib.uz_select_n_exc(sel)) if two_bit else None,
                                         n_qlow_pos=int(self.lib.uz_select_n_qlow_pos(sel)) if lists else None,
                                         qlow_pos_wide=bool(self.lib.uz_select_qlow_pos_wide(sel)) if lists else False,
                                         with_end=(not self.lib.uz_select_end_derivable(sel)) if with_end is None else bool(with_end),
-                                        with_umask=masks, cigar_omitted=int(self.lib.uz_select_n_cigar_omitted(sel)) if cigar_compact else None)
+                                        with_umask=masks, cigar_omitted=int(self.lib.uz_select_n_cigar_omitted(sel)) if cigar_compact else None,
+                                        n_tup=n_tup if n_tup >= 0 else None)
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
