@@ -243,6 +243,7 @@ typedef struct uz_reads_packed_view {
     const uint8_t *tup_aux;
     const uint8_t *tup_n_low;
     int64_t n_tup;
+    const uint16_t *tup_umask;   /* [n_tup] optional: the unit mask joins the combination too (umask is then NULL) */
 } uz_reads_packed_view;
 #define UZ_UMASK_ALL 0xFFFFu
 

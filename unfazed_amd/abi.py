@@ -171,6 +171,7 @@ class ReadsPackedView(C.Structure):
         # the small columns (flag, l_seq, n_cigar, mapq, aux, n_low) as a 16-bit index into a table of their combinations
         ("tup", _p), ("tup_flag", _p), ("tup_l_seq", _p), ("tup_n_cigar", _p), ("tup_mapq", _p), ("tup_aux", _p), ("tup_n_low", _p),
         ("n_tup", C.c_int64),
+        ("tup_umask", _p),
     ]
 
 
@@ -211,7 +212,7 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
         if n_tup is not None and name in TUP_COLS:
             continue
         arrs[name] = alloc(max(1, n) * np.dtype(dt).itemsize)[: max(1, n) * np.dtype(dt).itemsize].view(dt)
-    if with_umask:
+    if with_umask and n_tup is None:
         arrs["umask"] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.uint16)
     arrs["contig_off"] = alloc(8 * (n_contigs + 1))[: 8 * (n_contigs + 1)].view(np.int64)
     arrs["max_span"] = alloc(4 * max(1, n_contigs))[: 4 * max(1, n_contigs)].view(np.int32)
@@ -238,7 +239,8 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     if n_tup is not None:
         arrs["tup"] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.uint16)
         for name, dt in (("tup_flag", np.uint16), ("tup_l_seq", np.uint16), ("tup_n_cigar", np.uint16), ("tup_mapq", np.uint8),
-                         ("tup_aux", np.uint8)) + ((("tup_n_low", np.uint8),) if n_qlow_pos is not None else ()):
+                         ("tup_aux", np.uint8)) + ((("tup_n_low", np.uint8),) if n_qlow_pos is not None else ()) + (
+                                 (("tup_umask", np.uint16),) if with_umask else ()):
             arrs[name] = alloc(np.dtype(dt).itemsize * max(1, n_tup))[: np.dtype(dt).itemsize * max(1, n_tup)].view(dt)
         v.n_tup = n_tup
     v.cigar_compact = 0 if cigar_omitted is None else 1
@@ -254,7 +256,8 @@ def small_columns(held: "Held") -> dict:
     """flag, l_seq, n_cigar, mapq, aux (and n_low) of a packed view as plain per-record arrays, whichever way it carries them
     (the dictionary form keeps a 16-bit index per record and a table of the combinations)."""
     a, n = held.arrays, int(held.view.n_segs)
-    names = ["flag", "l_seq", "n_cigar", "mapq", "aux"] + (["n_low"] if ("n_low" in a or "tup_n_low" in a) else [])
+    names = ["flag", "l_seq", "n_cigar", "mapq", "aux"] + (["n_low"] if ("n_low" in a or "tup_n_low" in a) else []) + (
+        ["umask"] if ("umask" in a or "tup_umask" in a) else [])
     if "tup" not in a:
         return {k: a[k][:n] for k in names}
     t = a["tup"][:n].astype(np.int64)

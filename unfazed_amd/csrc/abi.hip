@@ -426,7 +426,8 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_segs == 0 || v->qlow || v_lists, UZ_E_ARG, "neither qlow nor n_low is set");
     UZ_REQUIRE(!(v->qlow && v_lists), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form, not both");
     if (v_lists) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
-    UZ_REQUIRE(!v->umask || v_lists, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
+    UZ_REQUIRE(!(v->umask || v->tup_umask) || v_lists, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
+    UZ_REQUIRE(!v->tup_umask || (v->tup && !v->umask), UZ_E_ARG, "tup_umask needs tup, and umask NULL");
     if (v->tup) {
         UZ_REQUIRE(v->n_tup >= 1 && v->n_tup <= 65536 && v->tup_flag && v->tup_l_seq && v->tup_n_cigar && v->tup_mapq && v->tup_aux, UZ_E_ARG, "bad tup_* table");
         UZ_REQUIRE(!v->flag && !v->l_seq && !v->n_cigar && !v->mapq && !v->aux && !v->n_low, UZ_E_ARG, "tup is set: flag / l_seq / n_cigar / mapq / aux / n_low must be NULL");
@@ -451,7 +452,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     const bool lists = v->n_low != nullptr || (v->tup && v->tup_n_low); // quality rows only for the records with bases (at their base-row position), written by the header build
     const bool tupf = v->tup != nullptr;
     const size_t nt = tupf ? (size_t)v->n_tup : 0;
-    uint16_t *tup = nullptr, *t_flag = nullptr, *t_ls = nullptr, *t_nc = nullptr; uint8_t *t_mq = nullptr, *t_ax = nullptr, *t_nl = nullptr;
+    uint16_t *tup = nullptr, *t_flag = nullptr, *t_ls = nullptr, *t_nc = nullptr, *t_um = nullptr; uint8_t *t_mq = nullptr, *t_ax = nullptr, *t_nl = nullptr;
     const size_t nql = lists ? (size_t)v->n_qlow_pos * (v->qlow_pos_wide ? 2 : 1) : 0;
     uint8_t *n_low = nullptr, *qpos = nullptr;
     uint16_t *umask_in = nullptr;
@@ -471,7 +472,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         if (lists) { n_low = cv.take<uint8_t>(tupf ? 0 : n); qpos = cv.take<uint8_t>(nql); }
         if (tupf) {
             tup = cv.take<uint16_t>(n); t_flag = cv.take<uint16_t>(nt); t_ls = cv.take<uint16_t>(nt); t_nc = cv.take<uint16_t>(nt);
-            t_mq = cv.take<uint8_t>(nt); t_ax = cv.take<uint8_t>(nt); t_nl = cv.take<uint8_t>(nt);
+            t_mq = cv.take<uint8_t>(nt); t_ax = cv.take<uint8_t>(nt); t_nl = cv.take<uint8_t>(nt); t_um = cv.take<uint16_t>(nt);
         }
         if (v->umask) umask_in = cv.take<uint16_t>(n);
         if (two_bit) {
@@ -496,6 +497,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         col.tup_flag = h2d(st, t_flag, v->tup_flag, nt); col.tup_l_seq = h2d(st, t_ls, v->tup_l_seq, nt); col.tup_n_cigar = h2d(st, t_nc, v->tup_n_cigar, nt);
         col.tup_mapq = h2d(st, t_mq, v->tup_mapq, nt); col.tup_aux = h2d(st, t_ax, v->tup_aux, nt);
         if (v->tup_n_low) col.tup_n_low = h2d(st, t_nl, v->tup_n_low, nt);
+        if (v->tup_umask) col.tup_umask = h2d(st, t_um, v->tup_umask, nt);
     } else {
         col.flag = h2d(st, flag, v->flag, n);
         col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
@@ -530,8 +532,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     r.qlow_valid = true;
     r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_q[4] = col.umask; r.col_q[5] = col.cigar_staged; r.col_q[6] = col.cigar_out; r.col_qwide = col.qpos_wide;
     {
-        const void *t[7] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low};
-        for (int k = 0; k < 7; k++) r.col_t[k] = t[k];
+        const void *t[8] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low, col.tup_umask};
+        for (int k = 0; k < 8; k++) r.col_t[k] = t[k];
         r.col_lists = col.lists;
     }
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
@@ -556,7 +558,7 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.cigar_staged = (const uint32_t *)r.col_q[5]; col.cigar_out = (uint32_t *)const_cast<void *>(r.col_q[6]);
     col.tup = (const uint16_t *)r.col_t[0]; col.tup_flag = (const uint16_t *)r.col_t[1]; col.tup_l_seq = (const uint16_t *)r.col_t[2];
     col.tup_n_cigar = (const uint16_t *)r.col_t[3]; col.tup_mapq = (const uint8_t *)r.col_t[4]; col.tup_aux = (const uint8_t *)r.col_t[5];
-    col.tup_n_low = (const uint8_t *)r.col_t[6]; col.lists = r.col_lists;
+    col.tup_n_low = (const uint8_t *)r.col_t[6]; col.tup_umask = (const uint16_t *)r.col_t[7]; col.lists = r.col_lists;
     col.qpos_wide = r.col_qwide;
     uz_build_records(c, c->stream, r, col, r.build_scratch);
     r.pending = false;
@@ -697,7 +699,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             }
             if (v->tup) {
                 col.tup = v->tup; col.tup_flag = v->tup_flag; col.tup_l_seq = v->tup_l_seq; col.tup_n_cigar = v->tup_n_cigar;
-                col.tup_mapq = v->tup_mapq; col.tup_aux = v->tup_aux; col.tup_n_low = v->tup_n_low;
+                col.tup_mapq = v->tup_mapq; col.tup_aux = v->tup_aux; col.tup_n_low = v->tup_n_low; col.tup_umask = v->tup_umask;
             }
             if (v->n_low || (v->tup && v->tup_n_low)) { r.qlow = qlow_own; col.lists = 1; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; col.umask = v->umask; }
             else col.plane_in = reinterpret_cast<const uint32_t *>(v->qlow);

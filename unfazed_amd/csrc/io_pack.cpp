@@ -91,6 +91,7 @@ struct uz_select {
     std::vector<uint16_t> tup_idx;      // per kept record
     std::vector<uint64_t> tup_key;      // per combination: flag | l_seq << 16 | n_cigar << 32 | mapq << 48 | aux << 56
     std::vector<uint8_t> tup_low;
+    std::vector<uint16_t> tup_um;       // (unit mask of the combination when the selection has masks)
     int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
@@ -446,8 +447,9 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
             for (int k = 0; k < wk; k++) sel->n_qpos += part[(size_t)k];
         }
         if (tuples & 1) { // the small columns as a dictionary: combinations numbered in order of first appearance
-            struct KeyHash { size_t operator()(const std::pair<uint64_t, uint8_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second); } };
-            std::unordered_map<std::pair<uint64_t, uint8_t>, uint32_t, KeyHash> dict;
+            struct KeyHash { size_t operator()(const std::pair<uint64_t, uint32_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second * 0xC2B2AE3D27D4EB4FULL); } };
+            std::unordered_map<std::pair<uint64_t, uint32_t>, uint32_t, KeyHash> dict;
+            const bool with_um = !sel->umask.empty();
             sel->tup_idx.assign((size_t)sel->n_sel, 0);
             bool ok = true;
             for (int64_t k = 0; k < sel->n_sel && ok; k++) {
@@ -458,16 +460,18 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 const uint64_t key = (uint64_t)full->flag[i] | ((uint64_t)full->l_seq[i] << 16) | ((uint64_t)full->n_cigar[i] << 32) |
                                      ((uint64_t)full->mapq[i] << 48) | ((uint64_t)(aux & 0xFFu) << 56);
                 const uint8_t low = (tuples & 4) ? sel->n_low[(size_t)k] : (uint8_t)0;
-                auto it = dict.find({key, low});
+                const uint16_t um16 = with_um ? sel->umask[(size_t)k] : (uint16_t)0;
+                const uint32_t k2 = (uint32_t)low | ((uint32_t)um16 << 8);
+                auto it = dict.find({key, k2});
                 if (it == dict.end()) {
                     if (dict.size() >= 65536) { ok = false; break; }
-                    it = dict.emplace(std::make_pair(key, low), (uint32_t)dict.size()).first;
-                    sel->tup_key.push_back(key); sel->tup_low.push_back(low);
+                    it = dict.emplace(std::make_pair(key, k2), (uint32_t)dict.size()).first;
+                    sel->tup_key.push_back(key); sel->tup_low.push_back(low); sel->tup_um.push_back(um16);
                 }
                 sel->tup_idx[(size_t)k] = (uint16_t)it->second;
             }
             if (ok) sel->tuples = tuples;
-            else { sel->tup_idx.clear(); sel->tup_key.clear(); sel->tup_low.clear(); } // more than 65536 combinations: the plain columns
+            else { sel->tup_idx.clear(); sel->tup_key.clear(); sel->tup_low.clear(); sel->tup_um.clear(); } // more than 65536 combinations: the plain columns
         }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
@@ -531,11 +535,13 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 w(out->tup_flag)[t] = (uint16_t)key; w(out->tup_l_seq)[t] = (uint16_t)(key >> 16); w(out->tup_n_cigar)[t] = (uint16_t)(key >> 32);
                 w(out->tup_mapq)[t] = (uint8_t)(key >> 48); w(out->tup_aux)[t] = (uint8_t)(key >> 56);
                 if (out->tup_n_low) w(out->tup_n_low)[t] = s->tup_low[t];
+                if (out->tup_umask) w(out->tup_umask)[t] = s->tup_um[t];
             }
+            if (!s->umask.empty() && !out->tup_umask) fail(UZ_IO_E_ARG, "the selection has unit masks and a dictionary: the output view needs tup_umask");
         } else
             out->n_tup = 0;
         const bool masks = !s->umask.empty();
-        if (masks && !out->umask) fail(UZ_IO_E_ARG, "the selection was planned with unit masks: the output view needs umask");
+        if (masks && !out->umask && !(tup && out->tup_umask)) fail(UZ_IO_E_ARG, "the selection was planned with unit masks: the output view needs umask");
         const bool lists = out->n_low != nullptr || (tup && out->tup_n_low != nullptr);
         if (masks && !lists) fail(UZ_IO_E_ARG, "unit masks need the list form of the qualities in the output (n_low / qlow_pos)");
         if (!lists && !full->qlow) fail(UZ_IO_E_ARG, "the source table has the quality plane as lists: the output view needs n_low / qlow_pos");

@@ -133,16 +133,18 @@ __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, 
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
 // the small columns of record i, plain or through the dictionary (uz_reads_packed_view.tup)
-struct RecSmall { uint32_t flag, ls, nc, mapq, aux; int nl; };
+struct RecSmall { uint32_t flag, ls, nc, mapq, aux, um; int nl; };
 __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
     RecSmall r;
     if (c.tup) {
         const uint32_t t = c.tup[i];
         r.flag = c.tup_flag[t]; r.ls = c.tup_l_seq[t]; r.nc = c.tup_n_cigar[t]; r.mapq = c.tup_mapq[t]; r.aux = c.tup_aux[t];
         r.nl = c.lists ? (int)c.tup_n_low[t] : -1;
+        r.um = c.tup_umask ? (uint32_t)c.tup_umask[t] : (c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL);
     } else {
         r.flag = c.flag[i]; r.ls = c.l_seq[i]; r.nc = c.n_cigar[i]; r.mapq = c.mapq[i]; r.aux = c.aux[i];
         r.nl = c.lists ? (int)c.n_low[i] : -1;
+        r.um = c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL;
     }
     return r;
 }
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
         if (i < n) {
             uint32_t v[UZ_PK_SUMS];
             const RecSmall r = rec_small(c, i);
-            pk_vals(r.nc, r.ls, r.aux, r.nl, c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL, v);
+            pk_vals(r.nc, r.ls, r.aux, r.nl, r.um, v);
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -207,11 +209,11 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         const bool in = i < n;
-        RecSmall rs = {0u, 0u, 0u, 0u, 0u, c.lists ? 0 : -1};
+        RecSmall rs = {0u, 0u, 0u, 0u, 0u, UZ_UMASK_ALL, c.lists ? 0 : -1};
         if (in) rs = rec_small(c, i);
         const uint32_t nc = rs.nc, ls = rs.ls, ax = rs.aux;
         const int nl = rs.nl;
-        const uint32_t um = (c.umask && in) ? (uint32_t)c.umask[i] : UZ_UMASK_ALL;
+        const uint32_t um = rs.um;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
         pk_vals(nc, ls, ax, nl, um, v);
 #pragma unroll

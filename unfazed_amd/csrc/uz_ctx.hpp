@@ -110,7 +110,7 @@ struct ReadsDev {
     // would wait behind the persistent per-DNM grid and hold up the next table's copies
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
-    const void *col_t[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low
+    const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
     int32_t col_lists = 0;
     const void *col_q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask / cigar_staged / cigar_out of RecColumns, for the deferred header build
     int64_t n_cigar_staged = 0; // cigar_compact: words that travelled (checked by the header build)
@@ -240,6 +240,7 @@ struct RecColumns {
     // dictionary form of the small columns (tup set: flag / l_seq / n_cigar / mapq / aux / n_low are read through the table)
     const uint16_t *tup = nullptr, *tup_flag = nullptr, *tup_l_seq = nullptr, *tup_n_cigar = nullptr;
     const uint8_t *tup_mapq = nullptr, *tup_aux = nullptr, *tup_n_low = nullptr;
+    const uint16_t *tup_umask = nullptr;
     int32_t lists = 0; // the qualities came as counts (+ positions): n_low, or tup_n_low through the table
     const uint32_t *plane_in = nullptr;
     const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
