@@ -154,6 +154,7 @@ void uz_reads_source_close(uz_psrc *src);
 int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *contig, const int32_t *lo, const int32_t *hi, int all_bases,
                          int unit_masks, const uint16_t *extra, int tuples, int threads, uz_select **out);
 int64_t uz_select_n_tuples(const uz_select *s);
+int64_t uz_select_n_esc16(const uz_select *s); /* entries of esc16_* when the output takes start / tlen / mate / qname as 16-bit differences */
 int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */

@@ -244,7 +244,23 @@ typedef struct uz_reads_packed_view {
     const uint8_t *tup_n_low;
     int64_t n_tup;
     const uint16_t *tup_umask;   /* [n_tup] optional: the unit mask joins the combination too (umask is then NULL) */
+    /* The four wide columns as 16-bit differences (NULL: the plain columns; set all four or none, and then start / tlen / mate / qname
+     * are NULL).  In a coordinate-sorted table a record starts within a few bases of the one before it, its name id lies a few
+     * hundred from its neighbour's, its mate a few hundred records away, and a template is a few hundred bases long:
+     *   start_d[i] = start[i] - start[i-1], qname_d[i] = qname[i] - qname[i-1] (modulo 2^32; the values before record 0 are 0),
+     *   mate_d[i] = mate[i] - i (UZ_D16_NONE: no mate), tlen_s[i] = tlen[i].
+     * A value that does not fit is UZ_D16_ESC in the column and stands in the escape list: key = record << 2 | column (0 start,
+     * 1 tlen, 2 mate, 3 qname), ascending; value = what the 16 bits could not hold (the same difference / tlen / mate index). */
+    const int16_t *start_d;
+    const int16_t *tlen_s;
+    const int16_t *mate_d;
+    const int16_t *qname_d;
+    const uint64_t *esc16_key;   /* [n_esc16] */
+    const int32_t *esc16_val;
+    int64_t n_esc16;
 } uz_reads_packed_view;
+#define UZ_D16_ESC (-32768)
+#define UZ_D16_NONE (-32767)
 #define UZ_UMASK_ALL 0xFFFFu
 
 /* one batch of DNMs of one kid (one family, one BAM) */

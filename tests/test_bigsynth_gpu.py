@@ -123,7 +123,7 @@ def test_resident_pipeline_matches_oracle(workload, engine):
         # chunks alternate between whole rows and the fetched 32-base units only (unit masks)
         part = src.select(fc, flo, fhi, alloc=pool.alloc, extra=fex if (a // 700) % 2 == 0 else None, tuples=(a // 700) % 3 != 2)
         staged_bytes += sum(x.nbytes for x in part.arrays.values())
-        part.arrays.update(abi.small_columns(part))  # (plain views for the checks below; not staged)
+        part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))  # (plain views for the checks below; not staged)
         if "umask" in part.arrays:
             um = part.arrays["umask"][: part.view.n_segs]
             with_bases = (part.arrays["aux"][: part.view.n_segs] & abi.AUX_NO_SEQ) == 0

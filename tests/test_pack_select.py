@@ -177,7 +177,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
         fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
         part, idx = src.select(fc, flo, fhi, want_index=True, lists=out_lists, with_end=None if out_lists else True)
         assert ("tup" in part.arrays) and part.view.n_tup < 2000  # the small columns travel as a dictionary
-        part.arrays.update(abi.small_columns(part))
+        part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))
         # brute force: overlap of any fetch, then the closure under mate
         keep = np.zeros(N, bool)
         for c, lo, h in zip(fc, flo, fhi):
@@ -211,7 +211,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
                 assert np.array_equal(part.arrays["cigar"][coff_p[k]: coff_p[k + 1]], words)
         assert part.view.n_seq_units == int(abi.row_units(part.arrays["l_seq"][: idx.size])[~no_seq].sum())
         everything, _ = src.select(fc, flo, fhi, want_index=True, all_bases=True, lists=out_lists)
-        everything.arrays.update(abi.small_columns(everything))
+        everything.arrays.update(abi.small_columns(everything)); everything.arrays.update(abi.wide_columns(everything))
         assert everything.view.n_seq_units == everything.view.n_row_units and not (everything.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ).any()
         mt = part.arrays["mate"][: idx.size]
         assert np.array_equal(idx[mt[mt >= 0]], pk.arrays["mate"][idx][mt >= 0])
@@ -302,7 +302,7 @@ def test_kernel_body_stays_inside_the_staged_units():
 
     def masks_of(sel):
         part, idx = src.select(fc[sel], flo[sel], fhi[sel], want_index=True, extra=fex[sel])
-        part.arrays.update(abi.small_columns(part))
+        part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))
         m = part.view.n_segs
         um = np.zeros(N, np.uint16)
         um[idx] = part.arrays["umask"][:m]

@@ -172,6 +172,8 @@ class ReadsPackedView(C.Structure):
         ("tup", _p), ("tup_flag", _p), ("tup_l_seq", _p), ("tup_n_cigar", _p), ("tup_mapq", _p), ("tup_aux", _p), ("tup_n_low", _p),
         ("n_tup", C.c_int64),
         ("tup_umask", _p),
+        # start / tlen / mate / qname as 16-bit differences + an escape list
+        ("start_d", _p), ("tlen_s", _p), ("mate_d", _p), ("qname_d", _p), ("esc16_key", _p), ("esc16_val", _p), ("n_esc16", C.c_int64),
     ]
 
 
@@ -189,7 +191,7 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None) -> "Held":
+                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -198,6 +200,7 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     with_umask: a per-record mask of the staged 32-base units (n_seq_units then counts staged units).
     n_tup: None = the plain small columns; a number = the dictionary form with that many combinations (tup + tup_* instead of flag,
     l_seq, n_cigar, mapq, aux and n_low).
+    n_esc16: None = start / tlen / mate / qname as 32-bit columns; a number = as 16-bit differences with that many escapes.
     cigar_omitted: None = every CIGAR word; a number = cigar_compact with that many simple records (n_cigar_total is the plain total:
     the words that stay home are taken off here)."""
     if n_seq_units is None:
@@ -210,6 +213,8 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
         if name == "end" and not with_end:
             continue
         if n_tup is not None and name in TUP_COLS:
+            continue
+        if n_esc16 is not None and name in ("start", "tlen", "mate", "qname"):
             continue
         arrs[name] = alloc(max(1, n) * np.dtype(dt).itemsize)[: max(1, n) * np.dtype(dt).itemsize].view(dt)
     if with_umask and n_tup is None:
@@ -243,6 +248,12 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
                                  (("tup_umask", np.uint16),) if with_umask else ()):
             arrs[name] = alloc(np.dtype(dt).itemsize * max(1, n_tup))[: np.dtype(dt).itemsize * max(1, n_tup)].view(dt)
         v.n_tup = n_tup
+    if n_esc16 is not None:
+        for name in ("start_d", "tlen_s", "mate_d", "qname_d"):
+            arrs[name] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.int16)
+        arrs["esc16_key"] = alloc(8 * max(1, n_esc16))[: 8 * max(1, n_esc16)].view(np.uint64)
+        arrs["esc16_val"] = alloc(4 * max(1, n_esc16))[: 4 * max(1, n_esc16)].view(np.int32)
+        v.n_esc16 = n_esc16
     v.cigar_compact = 0 if cigar_omitted is None else 1
     v.n_cigar_omitted = 0 if cigar_omitted is None else cigar_omitted
     v.n_qlow_pos = 0 if n_qlow_pos is None else n_qlow_pos
@@ -250,6 +261,32 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     for k, a in arrs.items():
         setattr(v, k, a.ctypes.data)
     return Held(v, arrs)
+
+
+def wide_columns(held: "Held") -> dict:
+    """start, tlen, mate, qname of a packed view as plain per-record arrays, whichever way it carries them."""
+    a, n = held.arrays, int(held.view.n_segs)
+    if "start_d" not in a:
+        return {k: a[k][:n] for k in ("start", "tlen", "mate", "qname")}
+    ne = int(held.view.n_esc16)
+    key, val = a["esc16_key"][:ne], a["esc16_val"][:ne].astype(np.int64)
+    assert np.all(np.diff(key.astype(np.int64)) > 0)
+    out = {}
+    for col, (name, src) in enumerate((("start", "start_d"), ("tlen", "tlen_s"), ("mate", "mate_d"), ("qname", "qname_d"))):
+        v = a[src][:n].astype(np.int64)
+        sel = (key & np.uint64(3)) == col
+        rec = (key[sel] >> np.uint64(2)).astype(np.int64)
+        assert np.array_equal(np.nonzero(v == -32768)[0], rec)
+        v[rec] = val[sel]
+        if name in ("start", "qname"):
+            v = np.cumsum(v) & 0xFFFFFFFF
+        elif name == "mate":
+            none = a[src][:n] == -32767
+            esc = np.zeros(n, bool)
+            esc[rec] = True
+            v = np.where(none, -1, np.where(esc, v, v + np.arange(n)))
+        out[name] = v.astype(np.uint32 if name == "qname" else np.int32)
+    return out
 
 
 def small_columns(held: "Held") -> dict:

@@ -92,6 +92,7 @@ struct uz_select {
     std::vector<uint64_t> tup_key;      // per combination: flag | l_seq << 16 | n_cigar << 32 | mapq << 48 | aux << 56
     std::vector<uint8_t> tup_low;
     std::vector<uint16_t> tup_um;       // (unit mask of the combination when the selection has masks)
+    int64_t n_esc16 = 0;                // escapes of the 16-bit difference form of start / tlen / mate / qname (uz_d16_of)
     int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
@@ -99,6 +100,33 @@ struct uz_select {
     std::vector<int64_t> exc_lo, exc_n; // seq2 sources: per kept record, its slice of the source's exception list (0 entries without bases)
     int64_t n_exc = 0;
 };
+
+// start / tlen / mate / qname of kept record k as 16-bit differences (uz_reads_packed_view.start_d ...): v[c] the column values,
+// e[c] the escape value where v[c] == UZ_D16_ESC (columns 0 start, 1 tlen, 2 mate, 3 qname); returns the number of escapes
+static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t e[4]) {
+    const uz_reads_packed_view *f = &s->src->v;
+    const int64_t i = s->index[(size_t)k];
+    const int64_t ip = k > 0 ? s->index[(size_t)k - 1] : -1;
+    int n = 0;
+    auto put = [&](int c, int64_t d, int64_t esc_val) {
+        if (d > -32767 && d <= 32767) v[c] = (int16_t)d;
+        else { v[c] = (int16_t)UZ_D16_ESC; e[c] = (int32_t)esc_val; n++; }
+    };
+    const int64_t ds = (int64_t)f->start[i] - (ip >= 0 ? (int64_t)f->start[ip] : 0);
+    put(0, ds, ds);
+    put(1, f->tlen[i], f->tlen[i]);
+    const int32_t mt = f->mate[i];
+    int64_t nm = -1;
+    if (mt >= 0 && mt < f->n_segs) { // new index of the mate: its rank in the (sorted) selection
+        auto it = std::lower_bound(s->index.begin(), s->index.end(), mt);
+        if (it != s->index.end() && *it == mt) nm = it - s->index.begin();
+    }
+    if (nm < 0) v[2] = (int16_t)UZ_D16_NONE;
+    else put(2, nm - k, nm);
+    const int32_t dq = (int32_t)(f->qname[i] - (ip >= 0 ? f->qname[ip] : 0u)); // modulo 2^32
+    put(3, dq, dq);
+    return n;
+}
 
 extern "C" {
 
@@ -473,6 +501,18 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
             if (ok) sel->tuples = tuples;
             else { sel->tup_idx.clear(); sel->tup_key.clear(); sel->tup_low.clear(); sel->tup_um.clear(); } // more than 65536 combinations: the plain columns
         }
+        { // escapes of the 16-bit difference form (counted whether or not the output will use it: cheap)
+            const int wk = workers_for(sel->n_sel, threads, 1 << 14);
+            std::vector<int64_t> part((size_t)wk + 1, 0);
+            parallel_slices(sel->n_sel, wk, [&](int64_t a, int64_t b, int slice) {
+                int64_t c = 0;
+                int16_t v[4];
+                int32_t e[4];
+                for (int64_t k = a; k < b; k++) c += uz_d16_of(sel, k, v, e);
+                part[(size_t)slice] = c;
+            });
+            for (int k = 0; k < wk; k++) sel->n_esc16 += part[(size_t)k];
+        }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
             sel->exc_n.assign((size_t)sel->n_sel, 0);
@@ -496,6 +536,7 @@ int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq
 int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
 int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
 int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
+int64_t uz_select_n_esc16(const uz_select *s) { return s ? s->n_esc16 : 0; }
 int64_t uz_select_n_tuples(const uz_select *s) { return (s && s->tuples) ? (int64_t)s->tup_key.size() : -1; }
 int64_t uz_select_n_cigar_omitted(const uz_select *s) { return s ? s->n_cigar_simple : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
@@ -524,6 +565,24 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
         out->n_exc = two_bit ? s->n_exc : 0;
         if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
+        const bool d16 = out->start_d != nullptr;
+        if (d16 && (!out->tlen_s || !out->mate_d || !out->qname_d || (s->n_esc16 && (!out->esc16_key || !out->esc16_val))))
+            fail(UZ_IO_E_ARG, "the 16-bit difference form needs start_d, tlen_s, mate_d, qname_d and the esc16_* list");
+        out->n_esc16 = d16 ? s->n_esc16 : 0;
+        std::vector<int64_t> esc_at; // first escape of every slice of the fill loop below
+        const int wk_fill = workers_for(m, threads, 4096);
+        if (d16) {
+            std::vector<int64_t> part((size_t)wk_fill + 1, 0);
+            parallel_slices(m, wk_fill, [&](int64_t a, int64_t b, int slice) {
+                int64_t c = 0;
+                int16_t v[4];
+                int32_t e[4];
+                for (int64_t k = a; k < b; k++) c += uz_d16_of(s, k, v, e);
+                part[(size_t)slice + 1] = c;
+            });
+            for (int k = 0; k < wk_fill; k++) part[(size_t)k + 1] += part[(size_t)k];
+            esc_at = part;
+        }
         const bool tup = out->tup != nullptr;
         if (tup) {
             if (!s->tuples) fail(UZ_IO_E_ARG, "the output view asks for the dictionary form (tup) but the selection was planned without it (or met more than 65536 combinations: uz_select_n_tuples)");
@@ -579,19 +638,33 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
             const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
             os[k + 1] = os[k] + (s->bases[k] ? (m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16)) : 0);
         }
-        parallel_slices(m, workers_for(m, threads, 4096), [&](int64_t a, int64_t b, int) {
+        parallel_slices(m, wk_fill, [&](int64_t a, int64_t b, int slice) {
+            int64_t esc_next = d16 ? esc_at[(size_t)slice] : 0;
             for (int64_t k = a; k < b; k++) {
                 const int64_t i = s->index[k];
-                w(out->start)[k] = full->start[i]; w(out->tlen)[k] = full->tlen[i];
                 if (out->end) w(out->end)[k] = full->end[i];
-                const int32_t mt = full->mate[i];
-                int32_t nm = -1;
-                if (mt >= 0 && mt < full->n_segs) { // new index of the mate: its rank in the (sorted) selection
-                    auto it = std::lower_bound(s->index.begin(), s->index.end(), mt);
-                    if (it != s->index.end() && *it == mt) nm = (int32_t)(it - s->index.begin());
+                if (d16) {
+                    int16_t v[4];
+                    int32_t e[4];
+                    uz_d16_of(s, k, v, e);
+                    w(out->start_d)[k] = v[0]; w(out->tlen_s)[k] = v[1]; w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3];
+                    for (int c = 0; c < 4; c++)
+                        if (v[c] == (int16_t)UZ_D16_ESC) {
+                            w(out->esc16_key)[esc_next] = ((uint64_t)k << 2) | (uint64_t)c;
+                            w(out->esc16_val)[esc_next] = e[c];
+                            esc_next++;
+                        }
+                } else {
+                    w(out->start)[k] = full->start[i]; w(out->tlen)[k] = full->tlen[i];
+                    const int32_t mt = full->mate[i];
+                    int32_t nm = -1;
+                    if (mt >= 0 && mt < full->n_segs) { // new index of the mate: its rank in the (sorted) selection
+                        auto it = std::lower_bound(s->index.begin(), s->index.end(), mt);
+                        if (it != s->index.end() && *it == mt) nm = (int32_t)(it - s->index.begin());
+                    }
+                    w(out->mate)[k] = nm;
+                    w(out->qname)[k] = full->qname[i];
                 }
-                w(out->mate)[k] = nm;
-                w(out->qname)[k] = full->qname[i];
                 if (tup) w(out->tup)[k] = s->tup_idx[(size_t)k];
                 else {
                     w(out->flag)[k] = full->flag[i]; w(out->l_seq)[k] = full->l_seq[i];

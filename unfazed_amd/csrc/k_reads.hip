@@ -124,11 +124,14 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 #define UZ_PK_SPAN 4096
 // four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
 // low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
-// ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none)
-#define UZ_PK_SUMS 5
+// ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none); sixth and seventh, the
+// differences of start and of the name id to the record before (16-bit difference form: the columns are their running sums,
+// modulo 2^32)
+#define UZ_PK_SUMS 7
 // um: which units of the record's rows were staged (UZ_UMASK_ALL: all of them)
 __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t (&v)[UZ_PK_SUMS]) {
     v[4] = (aux & UZ_AUX_SIMPLE_MASK) ? 0u : nc;
+    v[5] = 0u; v[6] = 0u; // (set by the callers from the difference columns)
     v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? v[1] : (uint32_t)__popc(um));
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
@@ -148,16 +151,28 @@ __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
     }
     return r;
 }
+// the escape list of the 16-bit difference columns: value of (record, column)
+__device__ __forceinline__ int32_t esc16_of(const RecColumns &c, int64_t i, int col) {
+    const unsigned long long key = ((unsigned long long)i << 2) | (unsigned long long)col;
+    int64_t lo = 0, hi = c.n_esc16;
+    while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (c.esc16_key[mid] < key) lo = mid + 1; else hi = mid; }
+    return (lo < c.n_esc16 && c.esc16_key[lo] == key) ? c.esc16_val[lo] : 0; // (a missing entry is caught by the totals / the mate check)
+}
+__device__ __forceinline__ uint32_t d16_val(const RecColumns &c, const int16_t *col, int64_t i, int k) {
+    const int v = col[i];
+    return (uint32_t)(v == UZ_D16_ESC ? esc16_of(c, i, k) : v);
+}
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
-    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
+    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         if (i < n) {
             uint32_t v[UZ_PK_SUMS];
             const RecSmall r = rec_small(c, i);
             pk_vals(r.nc, r.ls, r.aux, r.nl, r.um, v);
+            if (c.start_d) { v[5] = d16_val(c, c.start_d, i, 0); v[6] = d16_val(c, c.qname_d, i, 3); }
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -180,13 +195,13 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
     const int t = threadIdx.x;
     const int64_t chunk = (nb + 1023) / 1024;
     const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
+    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
     for (int64_t i = lo; i < hi; i++)
         for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
     for (int k = 0; k < UZ_PK_SUMS; k++) part[k][t] = v[k];
     __syncthreads();
     if (t == 0) {
-        unsigned long long r[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
+        unsigned long long r[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
         for (int j = 0; j < 1024; j++)
             for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = part[k][j]; part[k][j] = r[k]; r[k] += x; }
         if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[3] != want_qpos || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL ||
@@ -216,6 +231,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         const uint32_t um = rs.um;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
         pk_vals(nc, ls, ax, nl, um, v);
+        if (c.start_d && in) { v[5] = d16_val(c, c.start_d, i, 0); v[6] = d16_val(c, c.qname_d, i, 3); }
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++) {
             uint32_t x = v[k];
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             for (int k = 0; k < UZ_PK_SUMS; k++) wsum[k][wv] = inc[k];
         }
         __syncthreads();
-        uint32_t pre[UZ_PK_SUMS] = {0, 0, 0, 0, 0}, tot[UZ_PK_SUMS] = {0, 0, 0, 0, 0};
+        uint32_t pre[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0}, tot[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++)
 #pragma unroll
@@ -239,7 +255,17 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             RecB B;
             const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : (uint32_t)(run[2] + pre[2] + inc[2] - v[2]);
             const uint32_t cg = (uint32_t)(run[0] + pre[0] + inc[0] - v[0]);
-            const int32_t st0 = c.start[i];
+            // the four wide columns: plain, or from their 16-bit differences (start and name id: running sums, this record included)
+            int32_t st0, tl0, mt0;
+            uint32_t qn0;
+            if (c.start_d) {
+                st0 = (int32_t)(uint32_t)(run[5] + pre[5] + inc[5]);
+                qn0 = (uint32_t)(run[6] + pre[6] + inc[6]);
+                tl0 = (int32_t)d16_val(c, c.tlen_s, i, 1);
+                const int md = c.mate_d[i];
+                mt0 = md == UZ_D16_NONE ? -1 : (md == UZ_D16_ESC ? esc16_of(c, i, 2) : (int32_t)(i + md));
+                if (mt0 < -1 || mt0 >= n) { hflags[0] = 7; mt0 = -1; }
+            } else { st0 = c.start[i]; tl0 = c.tlen[i]; mt0 = c.mate[i]; qn0 = c.qname[i]; }
             const uint32_t *words = c.cigar_in + cg;
             if (c.cigar_out) { // cigar_compact: this record's words into the store -- the travelled ones, or the one its aux byte names
                 const uint32_t code = (ax & UZ_AUX_SIMPLE_MASK) >> UZ_AUX_SIMPLE_SHIFT;
@@ -257,7 +283,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             if (!(ax & UZ_AUX_DECODE_BAD) && c.cigar_in) // (an ASCII upload lays the words out after this kernel: k_pack_ascii sets the two bits)
                 for (uint32_t k = 0; k < nc; k++) uz_cigar_op_counts(words[k], cig_nonmatch, cig_none);
             int low_for_qc = 0; // (an ASCII upload has no counts yet: uz_build_qlow sets the bit that depends on them)
-            uz_pack_rec(A, B, st0, en0, cg, sq, c.mate[i], c.qname[i], (uint16_t)ls, (uint16_t)nc, c.tlen[i]);
+            uz_pack_rec(A, B, st0, en0, cg, sq, mt0, qn0, (uint16_t)ls, (uint16_t)nc, tl0);
             ra[i] = A;
             rb[i] = B;
             fm[i] = uz_pack_fm(rs.flag, rs.mapq, ax);
@@ -603,6 +629,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                                   : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
                                   : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
                                   : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
+                                  : f == 7 ? "mate_d / esc16_* of the reads view: a mate index outside the table"
                                            : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;

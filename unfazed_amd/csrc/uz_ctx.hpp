@@ -112,6 +112,8 @@ struct ReadsDev {
     void *build_scratch = nullptr;
     const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
     int32_t col_lists = 0;
+    const void *col_d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val
+    int64_t col_nesc = 0;
     const void *col_q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask / cigar_staged / cigar_out of RecColumns, for the deferred header build
     int64_t n_cigar_staged = 0; // cigar_compact: words that travelled (checked by the header build)
     int32_t col_qwide = 0;
@@ -226,10 +228,10 @@ void uz_block_put(uz_ctx *c, DevBlock b);
 
 // the fixed-width columns of a table as DEVICE pointers (staged by an upload, or the caller's for an adopted table)
 struct RecColumns {
-    const int32_t *start, *end, *tlen, *mate;
-    const uint32_t *qname;
-    const uint16_t *flag, *l_seq, *n_cigar;
-    const uint8_t *mapq, *aux;
+    const int32_t *start = nullptr, *end = nullptr, *tlen = nullptr, *mate = nullptr;
+    const uint32_t *qname = nullptr;
+    const uint16_t *flag = nullptr, *l_seq = nullptr, *n_cigar = nullptr;
+    const uint8_t *mapq = nullptr, *aux = nullptr;
     // qualities of the staged form: the plane itself (plane_in: the header build counts its bits into nlow) or its list
     // form (n_low + qlow_pos: the header build copies the counts and writes the plane rows of the listed records); both
     // null for an ASCII upload, whose plane and counts are built from the quality bytes (uz_build_qlow)
@@ -241,6 +243,11 @@ struct RecColumns {
     const uint16_t *tup = nullptr, *tup_flag = nullptr, *tup_l_seq = nullptr, *tup_n_cigar = nullptr;
     const uint8_t *tup_mapq = nullptr, *tup_aux = nullptr, *tup_n_low = nullptr;
     const uint16_t *tup_umask = nullptr;
+    // 16-bit difference form of start / tlen / mate / qname (start_d set: the plain four are null)
+    const int16_t *start_d = nullptr, *tlen_s = nullptr, *mate_d = nullptr, *qname_d = nullptr;
+    const unsigned long long *esc16_key = nullptr;
+    const int32_t *esc16_val = nullptr;
+    int64_t n_esc16 = 0;
     int32_t lists = 0; // the qualities came as counts (+ positions): n_low, or tup_n_low through the table
     const uint32_t *plane_in = nullptr;
     const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
