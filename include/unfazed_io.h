@@ -70,6 +70,13 @@ int64_t uz_bam_tlen_head(const uz_bam *h, int32_t *out, int64_t cap);
 /* wall-clock seconds of the stages of the last decode: [0] read, [1] inflate, [2] columns, [3] names + mates */
 void uz_bam_timing(const uz_bam *h, double out[4]);
 
+/* ------------------------------------------------------------------ CRAM (block codec; the container / slice / record
+ * layer is unfazed_amd/io_cram.py -- what pysam.AlignmentFile(path, "rc", reference_filename=...) does for the reference,
+ * read_collector.py:372-373) */
+/* rANS 4x8 (CRAM 3.0 block method 4), order 0 and 1: `in` is the whole block payload (order byte, two sizes, tables,
+ * states, stream); `n_out` must equal the size the payload declares. */
+int uz_rans4x8_decode(const uint8_t *in, int64_t n_in, uint8_t *out, int64_t n_out);
+
 /* ------------------------------------------------------------------ VCF */
 typedef struct uz_vcf uz_vcf;
 

@@ -1,0 +1,288 @@
+"""CRAM 3.0 input (unfazed_amd/io_cram.py; the reference opens CRAMs through pysam, read_collector.py:372-373).
+
+The image has no htslib and the reference ships no CRAM, so these are round trips through the test-side writer
+(tests/cramio.py): the same records written as BAM and as CRAM must decode to the same columns, by whole-file decode and
+through the .crai; and the whole driver on CRAM input must print what the REFERENCE's driver printed for the BAM
+(tests/golden/cli.json)."""
+import contextlib
+import io
+import os
+import random
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cramio
+from filesio import write_bai
+from synth.small import SmallConfig, make_small, refbase
+from synth.small_sv import SvConfig, make_small_sv
+from unfazed_amd import io_cram, io_native
+from unfazed_amd.io_bam import read_bam, write_bam
+from unfazed_amd.model import ReadsTable, Segment
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _norm(a: Segment):
+    cg = []
+    for op, ln in a.cigar:
+        op = 0 if op in (7, 8) else op  # CRAM keeps no = / X: htslib gives M as well
+        if cg and cg[-1][0] == op:
+            cg[-1] = (op, cg[-1][1] + ln)
+        else:
+            cg.append((op, ln))
+    return (a.qname, a.flag, a.tid, a.pos, a.mapq, cg, a.mtid, a.mpos, a.tlen, a.seq, None if a.qual is None else list(a.qual), a.has_sa)
+
+
+def _reference_for(segs, names):
+    hi = {}
+    for s in segs:
+        if s.tid >= 0:
+            hi[s.tid] = max(hi.get(s.tid, 0), s.endpos + 300)
+    return {c: "".join(refbase(i, p) for p in range(hi.get(i, 50))).encode() for i, c in enumerate(names)}
+
+
+def _write(tmp, segs, names, fai=True, **kw):
+    ref = _reference_for(segs, names)
+    fa = os.path.join(tmp, "ref.fa")
+    cramio.write_fasta(fa, ref, names, index=fai)
+    path = os.path.join(tmp, "a.cram")
+    cramio.write_cram(path, [(c, len(ref[c])) for c in names], segs, ref, **kw)
+    return path, fa
+
+
+@pytest.fixture(scope="module")
+def small():
+    ds = make_small(SmallConfig(seed=5))
+    return ds.contigs, next(iter(ds.reads.values()))[:6000]
+
+
+def test_integers_round_trip():
+    rng = random.Random(3)
+    vals = [0, 1, 127, 128, 16383, 16384, 2097151, 2097152, 268435455, 268435456, 2 ** 31 - 1, -1, -2, -2 ** 31] + \
+        [rng.randrange(-2 ** 31, 2 ** 31) for _ in range(200)]
+    inp = io_cram._In(b"".join(cramio.itf8(v) for v in vals))
+    assert [inp.itf8() for _ in vals] == vals
+    big = [0, 127, 128, 2 ** 14, 2 ** 21, 2 ** 28, 2 ** 35, 2 ** 42, 2 ** 49, 2 ** 56 - 1, 2 ** 56, 2 ** 63 - 1, -1, -2 ** 63] + \
+        [rng.randrange(-2 ** 63, 2 ** 63) for _ in range(200)]
+    inp = io_cram._In(b"".join(cramio.ltf8(v) for v in big))
+    assert [inp.ltf8() for _ in big] == big
+
+
+def test_rans_python_and_native_decoders_agree():
+    rng = random.Random(1)
+    for n in (0, 1, 2, 3, 4, 5, 7, 8, 63, 64, 1000, 4099):
+        for kind in range(3):
+            if kind == 0:
+                d = bytes(rng.randrange(256) for _ in range(n))
+            elif kind == 1:
+                d = bytes(rng.choice(b"ACGT") if rng.random() < 0.97 else rng.randrange(256) for _ in range(n))
+            else:
+                d = bytes([7]) * n
+            for order in (0, 1):
+                e = cramio.rans4x8_encode(d, order)
+                assert io_cram.rans4x8_decode(e) == d, (n, kind, order)
+                assert io_native.rans4x8_decode(e) == d, (n, kind, order)
+    e = cramio.rans4x8_encode(b"ACGT" * 50, 0)
+    with pytest.raises(io_native.IoError):
+        io_native.rans4x8_decode(e[:-30] + b"\0")  # sizes no longer match the header
+    with pytest.raises(io_native.IoError):
+        io_native.rans4x8_decode(bytes([2]) + e[1:])  # unknown order
+
+
+VARIANTS = {
+    "default": {},
+    "small_slices": dict(records_per_slice=97, slices_per_container=3),  # mates fall into other slices: detached
+    "generated_names": dict(keep_names=False),
+    "embedded_reference": dict(embed_ref=True),
+    "multi_reference_slices": dict(multi_ref_slices=True, records_per_slice=5000),
+    "base_stretches_other_matrix": dict(base_stretches=True, sm=cramio.SM_OTHER),
+    "rans_only": dict(methods=(cramio.RANS0, cramio.RANS1)),
+    "no_fai": dict(fai=False),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_cram_decodes_to_the_records_it_was_written_from(tmp_path, small, variant):
+    names, segs = small
+    kw = dict(VARIANTS[variant])
+    path, fa = _write(str(tmp_path), segs, names, **kw)
+    got_names, got = io_cram.read_cram(path, None if kw.get("embed_ref") else fa)
+    assert got_names == names and len(got) == len(segs)
+    first = 0 if kw.get("keep_names", True) else 1
+    for a, b in zip(segs, got):
+        assert _norm(a)[first:] == _norm(b)[first:]
+    if first:  # generated names still tie the records of a mate chain together, and nothing else
+        by = {}
+        for a, b in zip(segs, got):
+            by.setdefault(b.qname, set()).add(a.qname)
+        assert all(len(v) == 1 for v in by.values())
+        assert len(by) > 0.4 * len({s.qname for s in segs})
+
+
+def test_sv_reads_and_odd_records(tmp_path):
+    sv = make_small_sv(SvConfig(seed=3))
+    segs = next(iter(sv.reads.values()))[:8000]
+    assert sum(s.has_sa for s in segs) > 100
+    path, fa = _write(str(tmp_path), segs, sv.contigs)
+    _, got = io_cram.read_cram(path, fa)
+    assert [_norm(a) for a in segs] == [_norm(b) for b in got]
+    seq51 = "".join("ACGT"[(i * 7) % 4] for i in range(51))
+    odd = [
+        # hard + soft clips, insertions of 1 and 4 bases, a deletion, a reference skip, an SA tag, per-base qualities
+        Segment("m0", 0, 0, 100, 60, [(5, 3), (4, 2), (0, 20), (1, 1), (0, 5), (2, 7), (0, 10), (3, 50), (0, 5), (1, 4), (0, 3), (4, 1)],
+                -1, -1, 0, seq51, [20 + i % 20 for i in range(51)], True),
+        Segment("m1", 16, 0, 120, 0, [(0, 30)], -1, -1, 0, "", None, False),  # no bases stored
+        Segment("m2", 1 | 64 | 32, 0, 130, 13, [(0, 10)], 1, 5, 0, "ACGTRYACGT", None, False),  # IUPAC codes: base + quality features
+        Segment("m3", 4 | 1 | 128, 0, 130, 0, [], 0, 130, 0, "ACGTACGTAA", [5] * 10, False),  # placed unmapped mate
+        Segment("m2", 1 | 128 | 16, 1, 5, 13, [(0, 10)], 0, 130, 0, "ACGTACGTAC", None, False),  # mate on another contig
+        Segment("u1", 4 | 1 | 8 | 64, -1, -1, 0, [], -1, -1, 0, "ACGTNACGT", [30] * 9, False),
+        Segment("u2", 4, -1, -1, 0, [], -1, -1, 0, "ACG", None, False),
+    ]
+    for kw in ({}, dict(multi_ref_slices=True)):
+        path, fa = _write(str(tmp_path), odd, sv.contigs, **kw)
+        _, got = io_cram.read_cram(path, fa)
+        assert [_norm(a) for a in odd] == [_norm(b) for b in got]
+
+
+def test_what_is_not_decoded_fails_loudly(tmp_path, small):
+    names, segs = small
+    segs = segs[:300]
+    path, fa = _write(str(tmp_path), segs, names)
+    with pytest.raises(io_cram.CramError, match="reference FASTA"):
+        io_cram.read_cram(path, None)
+    # a reference that is not the one the file was written against (slice MD5)
+    ref = _reference_for(segs, names)
+    wrong = {k: v[:50] + (b"A" if v[50:51] != b"A" else b"C") + v[51:] if False else bytes(reversed(v)) for k, v in ref.items()}
+    fb = os.path.join(str(tmp_path), "wrong.fa")
+    cramio.write_fasta(fb, wrong, names)
+    with pytest.raises(io_cram.CramError, match="does not match"):
+        io_cram.read_cram(path, fb)
+    raw = bytearray(open(path, "rb").read())
+    v2 = os.path.join(str(tmp_path), "v2.cram")
+    open(v2, "wb").write(bytes(raw[:4]) + b"\x02\x01" + bytes(raw[6:]))
+    with pytest.raises(io_cram.CramError, match="only CRAM 3.0"):
+        io_cram.read_cram(v2, fa)
+    open(v2, "wb").write(b"BAM\x01" + bytes(raw[4:]))
+    with pytest.raises(io_cram.CramError, match="not a CRAM"):
+        io_cram.read_cram(v2, fa)
+    # a block with a CRAM 3.1 codec
+    blk = cramio.block(cramio.RAW, 4, 7, b"abc")
+    bad = bytes([5]) + blk[1:-4]
+    import zlib
+    bad += struct.pack("<I", zlib.crc32(bad) & 0xFFFFFFFF)
+    with pytest.raises(io_cram.CramError, match="3.1"):
+        io_cram._read_block(io_cram._In(bad))
+    # a flipped bit inside a block is caught by its checksum
+    raw[len(raw) // 2] ^= 0x10
+    open(v2, "wb").write(bytes(raw))
+    with pytest.raises((io_cram.CramError, Exception)):
+        io_cram.read_cram(v2, fa)
+
+
+def _table_columns(t: ReadsTable):
+    names = [t.qnames[int(i)] for i in t.qname]
+    return dict(start=t.start, end=t.end, flag=t.flag, mapq=t.mapq, tlen=t.tlen, names=names, l_seq=t.l_seq, n_cigar=t.n_cigar,
+                cigar=t.cigar, aux=t.aux)
+
+
+def test_region_decode_through_the_crai_equals_the_bam_region_decode(tmp_path):
+    """the same records as BAM + BAI through uz_bam_decode_regions and as CRAM + CRAI through read_cram_regions: the same table"""
+    ds = make_small(SmallConfig(seed=9))
+    names = ds.contigs
+    segs = [s for s in next(iter(ds.reads.values()))]
+    for s in segs:  # (the BAM keeps = / X; make both sides M)
+        s.cigar = _norm(s)[5]
+    path, fa = _write(str(tmp_path), segs, names, records_per_slice=400, slices_per_container=2)
+    bam = os.path.join(str(tmp_path), "a.bam")
+    ref = _reference_for(segs, names)
+    write_bam(bam, [(c, len(ref[c])) for c in names], segs)
+    write_bai(bam)
+    rng = np.random.default_rng(4)
+    pos = np.array([s.pos for s in segs if s.tid == 0])
+    lo = np.sort(rng.choice(pos, 25)) + rng.integers(-300, 300, 25)
+    tid = np.zeros(25, np.int32)
+    hi = lo + rng.integers(1, 700, 25)
+    want = io_native.read_bam_regions(bam, tid, lo, hi, insert_size_max_sample=0)
+    stats = {}
+    got_names, got = io_cram.read_cram_regions(path, fa, tid, lo, hi, stats=stats)
+    t = ReadsTable.from_segments(got, got_names)
+    assert want.start.size > 200 and stats["records_walked"] < 0.7 * len(segs) and stats["records_kept"] == want.start.size
+    a, b = _table_columns(want), _table_columns(t)
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    # and against the definition: fetched records + their mates, from the whole-file decode
+    _, whole = io_cram.read_cram(path, fa)
+    ivs = list(zip(tid.tolist(), lo.tolist(), hi.tolist()))
+    fetched = [s for s in whole if any(s.tid == t_ and s.pos < b_ and s.endpos > a_ for t_, a_, b_ in ivs)]
+    assert {(s.qname, s.flag, s.pos) for s in fetched} <= {(s.qname, s.flag, s.pos) for s in got}
+    assert len(got) > len(fetched)  # mates outside the intervals came along
+
+
+def _cli_inputs(tmp_path):
+    """the files of the CLI golden with every kid's BAM rewritten twice: as a BAM whose CIGARs say M where they said = / X
+    (a CRAM cannot keep the difference, and the read filter counts CIGAR operations) and as a CRAM of the same records"""
+    from test_cli_golden import _inputs
+    g, ds, paths = _inputs(tmp_path)
+    decoded = {kid: read_bam(bam) for kid, bam in paths["bams"].items()}
+    names = next(iter(decoded.values()))[0]
+    ref = _reference_for([s for _, segs in decoded.values() for s in segs], names)
+    fa = os.path.join(str(tmp_path), "ref.fa")
+    cramio.write_fasta(fa, ref, names)
+    crams = {}
+    for kid, (_, segs) in decoded.items():
+        for s in segs:
+            s.cigar = _norm(s)[5]
+        write_bam(paths["bams"][kid], [(c, len(ref[c])) for c in names], segs)
+        crams[kid] = os.path.join(str(tmp_path), "%s.cram" % kid)
+        cramio.write_cram(crams[kid], [(c, len(ref[c])) for c in names], segs, ref, records_per_slice=500)
+    return g, ds, paths, dict(paths, bams=crams), fa
+
+
+def _drive(argv):
+    from unfazed_amd import session
+    from unfazed_amd.__main__ import setup_args
+    from unfazed_amd.unfazed import unfazed
+    session._READS.clear()
+    session._HOSTS.clear()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+        unfazed(setup_args().parse_args(argv))
+    return buf.getvalue()
+
+
+@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "crai_regions"])
+def test_cli_on_cram_prints_what_it_prints_on_the_bam(tmp_path, indexed):
+    """`-r ref.fa` + a CRAM per kid through the whole driver (the reference: unfazed.py:97-126, read_collector.py:372-373)"""
+    from oracle_backend import OracleBackend
+    from test_cli_golden import _argv
+    from unfazed_amd import session
+    g, ds, bam_paths, cram_paths, fa = _cli_inputs(tmp_path)
+    if not indexed:
+        for c in cram_paths["bams"].values():
+            os.remove(c + ".crai")
+    session.set_backend(OracleBackend())
+    try:
+        for run in g["runs"][:2]:
+            want = _drive(_argv(bam_paths, run))
+            got = _drive(_argv(cram_paths, run) + ["-r", fa])
+            assert got == want and len(want.splitlines()) > 5
+        with pytest.raises(SystemExit, match="Missing reference file for CRAM"):
+            _drive(_argv(cram_paths, g["runs"][0]))
+    finally:
+        session.set_backend(None)
+        session._READS.clear()
+        session._HOSTS.clear()
+
+
+@pytest.mark.gpu
+def test_cli_on_cram_on_device(tmp_path, hip_lib):
+    from test_cli_golden import _argv
+    g, ds, bam_paths, cram_paths, fa = _cli_inputs(tmp_path)
+    run = g["runs"][0]
+    outs = [subprocess.run([sys.executable, "-m", "unfazed_amd"] + argv, cwd=ROOT, check=True, capture_output=True, text=True).stdout
+            for argv in (_argv(bam_paths, run), _argv(cram_paths, run) + ["-r", fa])]
+    assert outs[0] == outs[1] and len(outs[0].splitlines()) > 5

@@ -691,7 +691,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     {
         static const int wgs_env = [] { const char *e = getenv("UZ_PHASE_WGS_PER_CU"); return e ? atoi(e) : 0; }();
         const int by_lds = (160 * 1024) / (arena_used + (int)sizeof(WgSharedT<1>) + 512);
-        const int by_regs = UZ_PHASE_MIN_WAVES; // waves per SIMD = workgroups per CU (four waves, four SIMDs)
+        const int by_regs = UZ_PHASE_MIN_WAVES * 4 / (WG_NT / 64); // waves per SIMD x four SIMDs / waves per workgroup
         wgs_per_cu = wgs_env > 0 ? wgs_env : std::max(1, std::min(by_lds, by_regs));
         if (arena_env < 0 && wgs_env <= 0) { // all the room this occupancy leaves
             const int room = ((160 * 1024) / wgs_per_cu - (int)sizeof(WgSharedT<1>) - 512) & ~255;

@@ -28,7 +28,7 @@ IO_EXPORTS = [
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
     "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16",
-    "uz_reads_select_fill", "uz_select_free",
+    "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode",
 ]
 
 
@@ -76,6 +76,7 @@ def load():
     lib.uz_bam_qname.restype = C.c_void_p
     lib.uz_bam_tlen_head.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.uz_bam_tlen_head.restype = C.c_int64
+    lib.uz_rans4x8_decode.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
     lib.uz_bam_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.uz_bam_timing.restype = None
     lib.uz_vcf_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -127,6 +128,18 @@ class IoError(RuntimeError):
 def _check(lib, rc: int) -> None:
     if rc != 0:
         raise IoError(rc, (lib.uz_io_last_error() or b"").decode(errors="replace"))
+
+
+def rans4x8_decode(data: bytes) -> bytes:
+    """payload of a CRAM block compressed with rANS 4x8 -> its bytes (uz_rans4x8_decode)"""
+    import struct
+    lib = load()
+    if len(data) < 9:
+        raise IoError(-2, "rANS block shorter than its header")
+    (n_out,) = struct.unpack_from("<I", data, 5)
+    out = C.create_string_buffer(max(1, n_out))
+    _check(lib, lib.uz_rans4x8_decode(data, len(data), out, n_out))
+    return out.raw[:n_out]
 
 
 def _arr(ptr, n: int, dtype) -> np.ndarray:

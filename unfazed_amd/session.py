@@ -71,11 +71,23 @@ def load_sites(name_or_table) -> (str, SitesTable):
     return name_or_table, _SITES[name_or_table]
 
 
+_CRAM_REF: Dict[str, str] = {}
+
+
+def set_cram_reference(name: str, fasta: Optional[str]) -> None:
+    """the FASTA a CRAM is decoded against (`-r / --reference`; read_collector.py:372-373 passes it to pysam)"""
+    if fasta:
+        _CRAM_REF[name] = fasta
+
+
 def load_reads(name: str, insert_size_max_sample: int = 1000000) -> ReadsTable:
     if name not in _READS:
         if name[-4:] == "cram":
-            raise NotImplementedError("CRAM input is not decoded by this build (BAM only)")
-        if _python_io():
+            from .io_cram import read_cram
+            contigs, segs = read_cram(name, _CRAM_REF.get(name))
+            t = ReadsTable.from_segments(segs, contigs)
+            t.tlen_head = np.array([s.tlen for s in segs[: int(insert_size_max_sample) + 1]], dtype=np.int32)
+        elif _python_io():
             from .io_bam import read_bam
             contigs, segs = read_bam(name)
             t = ReadsTable.from_segments(segs, contigs)
@@ -103,18 +115,35 @@ class _LazyReads(dict):
         return self[key]
 
     def indexed(self, bam: str) -> bool:
-        if bam in _READS or bam in self or _python_io() or os.environ.get("UZ_IO_INDEX", "1") == "0":
+        if bam in _READS or bam in self or os.environ.get("UZ_IO_INDEX", "1") == "0" or not os.path.isfile(bam):
+            return False
+        if bam.endswith(".cram"):
+            from .io_cram import crai_path
+            return crai_path(bam) is not None
+        if _python_io():
             return False
         from .io_native import bam_index_path
-        return bam.endswith(".bam") and os.path.isfile(bam) and bam_index_path(bam) is not None
+        return bam.endswith(".bam") and bam_index_path(bam) is not None
 
     def header(self, bam: str) -> ReadsTable:
         if bam not in self._headers:
-            from .io_native import read_bam_regions
-            self._headers[bam] = read_bam_regions(bam, [], [], [], threads=_io_threads(), insert_size_max_sample=self.cap)
+            if bam.endswith(".cram"):
+                # the head of the file: whole slices until insert_size_max_sample + 1 records are there
+                from .io_cram import read_cram
+                contigs, segs = read_cram(bam, _CRAM_REF.get(bam), max_records=int(self.cap) + 1)
+                t = ReadsTable(contigs)
+                t.tlen_head = np.array([s.tlen for s in segs[: int(self.cap) + 1]], dtype=np.int32)
+                self._headers[bam] = t
+            else:
+                from .io_native import read_bam_regions
+                self._headers[bam] = read_bam_regions(bam, [], [], [], threads=_io_threads(), insert_size_max_sample=self.cap)
         return self._headers[bam]
 
     def regions(self, bam: str, tid, lo, hi) -> ReadsTable:
+        if bam.endswith(".cram"):
+            from .io_cram import read_cram_regions
+            contigs, segs = read_cram_regions(bam, _CRAM_REF.get(bam), tid, lo, hi)
+            return ReadsTable.from_segments(segs, contigs)
         from .io_native import read_bam_regions
         return read_bam_regions(bam, tid, lo, hi, threads=_io_threads(), insert_size_max_sample=0)
 

@@ -12,6 +12,8 @@ def phase_snvs(
     ab_homref, ab_homalt, ab_het, min_gt_qual, min_depth, search_dist, insert_size_max_sample,
     stdevs, min_map_qual, readlen, split_error_margin, evidence_min_ratio=10,
 ):
+    for dn in dnms:  # a CRAM is decoded against the FASTA its DNMs carry (unfazed.py:270, read_collector.py:372-373)
+        session.set_cram_reference(dn.get("bam", ""), dn.get("cram_ref"))
     host = session.host_for(sites, insert_size_max_sample)
     params = abi.make_params(
         search_dist=search_dist, min_gt_qual=min_gt_qual, min_depth=min_depth, min_map_qual=min_map_qual,

@@ -292,10 +292,6 @@ def unfazed(args):
     if output_type == "vcf" and (args.dnms.endswith("bcf") or _is_bcf(args.dnms)):
         sys.exit(BCF_OUTPUT_MESSAGE)  # known before any phasing is done
     snvs, svs, kids = _route_variants(reader(args.dnms), bam_names, args.reference)
-    crams = sorted({v["bam"] for v in snvs + svs if v["bam"].endswith("cram")})
-    if crams:
-        # the reference reads CRAM through pysam/htslib; this build decodes BAM only -- say so before any work
-        sys.exit("CRAM input is not decoded by this build (BAM only): convert %s with `samtools view -b`" % crams[0])
     pedigrees = parse_ped(args.ped, kids)
     kids = list(pedigrees)
     snvs = [v for v in snvs if v["kid"] in pedigrees]
