@@ -97,6 +97,18 @@ typedef struct uz_vcf_view {
 } uz_vcf_view;
 
 int uz_vcf_decode(const char *path, int threads, uz_vcf **out);
+/* Region decode through the tabix index (`tbi_path` NULL: NAME.tbi next to the file): only the BGZF blocks the index names
+ * for the intervals are read and inflated.  The table holds the header and, in file order, the records that overlap an
+ * interval [lo, hi) (0-based) of reference `ref[k]` (an index into uz_vcf_index_names) -- what `vcf(region)` hands the
+ * reference per DNM (informative_site_finder.py:42, :399-420, :566); a record is kept once however many intervals it
+ * overlaps.  Text VCF only (BCF carries a CSI index: decoded whole). */
+int uz_vcf_decode_regions(const char *path, const char *tbi_path, int64_t n_iv, const int32_t *ref, const int32_t *lo, const int32_t *hi,
+                          int threads, uz_vcf **out);
+/* sequence names of the tabix index, in the order of their first record in the file, each NUL-terminated, into buf; returns the
+ * bytes needed (call with cap 0 first) or a negative UZ_IO_E_* */
+int64_t uz_vcf_index_names(const char *path, const char *tbi_path, char *buf, int64_t cap);
+/* what the last decode touched: [0] compressed file bytes read, [1] BGZF blocks inflated (region decode), [2] lines walked, [3] records kept */
+void uz_vcf_io_stats(const uz_vcf *h, int64_t out[4]);
 void uz_vcf_free(uz_vcf *h);
 int uz_vcf_view_get(const uz_vcf *h, uz_vcf_view *out);
 const char *uz_vcf_sample(const uz_vcf *h, int32_t i);

@@ -164,3 +164,98 @@ def write_bai(bam_path, bai_path=None):
     with open(bai_path, "wb") as fh:
         fh.write(bytes(out))
     return bai_path
+
+
+# ---------------------------------------------------------------------------- BGZF text + tabix index writer (tests)
+def write_bgzf_text(path, text: str, block_bytes=6000):
+    """text -> BGZF file (small blocks, so that a region touches few of many)"""
+    from unfazed_amd.io_bam import _bgzf_block
+    data = text.encode()
+    with open(path, "wb") as fh:
+        for i in range(0, len(data), block_bytes):
+            fh.write(_bgzf_block(data[i: i + block_bytes]))
+        fh.write(_bgzf_block(b""))
+
+
+def write_tbi(vcf_gz_path, tbi_path=None):
+    """A tabix index for a BGZF-compressed, position-sorted VCF, built the way `tabix -p vcf` does (the binning scheme and
+    linear index of the SAM spec; the end of a record is POS + len(REF) - 1, or INFO/END when it reaches further)."""
+    import struct
+    import zlib
+    from unfazed_amd.io_bam import _bgzf_block
+    raw = open(vcf_gz_path, "rb").read()
+    blocks, p, u = [], 0, 0
+    data = bytearray()
+    while p < len(raw):
+        xlen = struct.unpack_from("<H", raw, p + 10)[0]
+        bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+        payload = zlib.decompress(raw[p + 12 + xlen: p + bsize - 8], -15)
+        blocks.append((p, u, len(payload)))
+        data += payload
+        p += bsize
+        u += len(payload)
+    starts = [b[1] for b in blocks]
+
+    def voff(uo):
+        import bisect
+        k = bisect.bisect_right(starts, uo) - 1
+        while k + 1 < len(blocks) and uo - blocks[k][1] >= blocks[k][2]:
+            k += 1
+        return (blocks[k][0] << 16) | (uo - blocks[k][1])
+
+    names, bins, linear = [], [], []
+    off = 0
+    n = len(data)
+    while off < n:
+        e = data.find(b"\n", off)
+        if e < 0:
+            e = n
+        line = bytes(data[off:e])
+        if line and not line.startswith(b"#"):
+            f = line.split(b"\t")
+            chrom, pos0 = f[0].decode(), int(f[1]) - 1
+            end = pos0 + max(1, len(f[3]))
+            if len(f) > 7:
+                for kv in f[7].split(b";"):
+                    if kv.startswith(b"END="):
+                        try:
+                            end = max(end, int(kv[4:]))
+                        except ValueError:
+                            pass
+            if not names or names[-1] != chrom:
+                assert chrom not in names, "records are not grouped by contig"
+                names.append(chrom)
+                bins.append({})
+                linear.append({})
+            v0, v1 = voff(off), voff(min(e + 1, n))
+            ch = bins[-1].setdefault(_reg2bin(pos0, end), [])
+            if ch and ch[-1][1] == v0:
+                ch[-1][1] = v1
+            else:
+                ch.append([v0, v1])
+            for w in range(pos0 >> 14, ((end - 1) >> 14) + 1):
+                linear[-1].setdefault(w, v0)
+        off = e + 1
+    nm = b"".join(x.encode() + b"\0" for x in names)
+    out = bytearray(b"TBI\x01" + struct.pack("<iiiiiiii", len(names), 2, 1, 2, 0, ord("#"), 0, len(nm)) + nm)
+    for t in range(len(names)):
+        out += struct.pack("<i", len(bins[t]))
+        for b in sorted(bins[t]):
+            out += struct.pack("<Ii", b, len(bins[t][b]))
+            for v0, v1 in bins[t][b]:
+                out += struct.pack("<QQ", v0, v1)
+        n_intv = (max(linear[t]) + 1) if linear[t] else 0
+        lin = [linear[t].get(w, 0) for w in range(n_intv)]
+        for w in range(n_intv - 2, -1, -1):
+            if lin[w] == 0:
+                lin[w] = lin[w + 1]
+        out += struct.pack("<i", n_intv)
+        for v in lin:
+            out += struct.pack("<Q", v)
+    tbi_path = tbi_path or vcf_gz_path + ".tbi"
+    with open(tbi_path, "wb") as fh:
+        blob = bytes(out)
+        for i in range(0, len(blob), 60000):
+            fh.write(_bgzf_block(blob[i: i + 60000]))
+        fh.write(_bgzf_block(b""))
+    return tbi_path

@@ -67,19 +67,28 @@ def _check(run, text, n_samples):
             assert float(col[-2]) == w["uops"][i] and float(col[-1]) == w["uet"][i]
 
 
-@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "bai_regions"])
+def _index_inputs(paths):
+    """a BAI next to every BAM, and the sites VCF rewritten as BGZF with a tabix index next to it"""
+    import gzip
+    from filesio import write_bai, write_bgzf_text, write_tbi
+    for b in paths["bams"].values():
+        write_bai(b)
+    text = gzip.open(paths["sites"], "rt").read()
+    write_bgzf_text(paths["sites"], text)
+    write_tbi(paths["sites"])
+
+
+@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "bai_tbi_regions"])
 def test_cli_matches_reference_driver(tmp_path, indexed):
-    """indexed: a BAI sits next to every BAM, so the session decodes only the regions each batch fetches (through
-    uz_bam_decode_regions) instead of the whole file -- the output must not change."""
+    """indexed: a BAI sits next to every BAM and a tabix index next to the sites VCF, so the session decodes only the regions
+    each batch looks at (uz_bam_decode_regions, uz_vcf_decode_regions) instead of the whole files -- the output must not change."""
     from oracle_backend import OracleBackend
     from unfazed_amd import session
     from unfazed_amd.__main__ import setup_args
     from unfazed_amd.unfazed import unfazed
     g, ds, paths = _inputs(tmp_path)
     if indexed:
-        from filesio import write_bai
-        for b in paths["bams"].values():
-            write_bai(b)
+        _index_inputs(paths)
     session.set_backend(OracleBackend())
     session._READS.clear()
     session._HOSTS.clear()
@@ -90,18 +99,20 @@ def test_cli_matches_reference_driver(tmp_path, indexed):
             with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
                 unfazed(args)
             _check(run, buf.getvalue(), len(ds.samples))
+        # (the sites really came through the tabix index: region tables are cached under NAME@batch)
+        assert any("@" in k for k in session._SITES) == indexed
     finally:
         session.set_backend(None)
+        for k in [k for k in session._SITES if "@" in k]:
+            del session._SITES[k]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "bai_regions"])
+@pytest.mark.parametrize("indexed", [False, True], ids=["whole_file", "bai_tbi_regions"])
 def test_cli_on_device_matches_reference_driver(tmp_path, hip_lib, indexed):
     g, ds, paths = _inputs(tmp_path)
     if indexed:
-        from filesio import write_bai
-        for b in paths["bams"].values():
-            write_bai(b)
+        _index_inputs(paths)
     for run in g["runs"]:
         out = subprocess.run([sys.executable, "-m", "unfazed_amd"] + _argv(paths, run), cwd=ROOT, check=True,
                              capture_output=True, text=True)

@@ -316,3 +316,72 @@ def test_region_decode_equals_whole_file_decode_restricted(tmp_path):
     # no fetch at all: an empty table with the header and the head
     empty = io_native.read_bam_regions(bam, [], [], [])
     assert empty.n_segs == 0 and empty.contigs == whole.contigs
+
+
+def _big_vcf_text(n_per_contig=30000, contigs=("chr1", "chr2", "chrX"), seed=3):
+    """position-sorted sites on several contigs, with a few long deletions and INFO/END records reaching into later windows"""
+    rng = np.random.default_rng(seed)
+    lines = ["##fileformat=VCFv4.2"] + ["##contig=<ID=%s>" % c for c in contigs] + [
+        '##INFO=<ID=END,Number=1,Type=Integer,Description="end">', '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+        '##FORMAT=<ID=AD,Number=R,Type=Integer,Description="Allelic depths">', '##FORMAT=<ID=GQ,Number=1,Type=Float,Description="Genotype quality">',
+        "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tkid\tdad\tmom"]
+    gts = ["0/0", "0/1", "1/1", "./."]
+    for c in contigs:
+        pos = np.cumsum(rng.integers(1, 400, n_per_contig)) + 1000
+        for k, p in enumerate(pos.tolist()):
+            ref, alt, info = "ACGT"[k % 4], "CGTA"[k % 4], "."
+            if k % 997 == 0:
+                ref = "A" * int(rng.integers(50, 3000))  # a long deletion
+                alt = "A"
+            elif k % 1013 == 0:
+                info = "SVTYPE=DEL;END=%d" % (p + int(rng.integers(1000, 20000)))
+                alt = "<DEL>"
+            cols = ["%s:%d,%d:%d" % (gts[int(g)], int(a), int(b), int(q)) for g, a, b, q in
+                    zip(rng.integers(0, 4, 3), rng.integers(0, 40, 3), rng.integers(0, 40, 3), rng.integers(0, 99, 3))]
+            lines.append("\t".join([c, str(p), ".", ref, alt, "50", "PASS", info, "GT:AD:GQ"] + cols))
+    return "\n".join(lines) + "\n"
+
+
+def test_vcf_region_decode_through_the_tabix_index(tmp_path):
+    """uz_vcf_decode_regions: the header and the records overlapping the intervals, read through NAME.tbi -- the same columns,
+    strings and raw lines as the whole-file decode restricted to those records, from a fraction of the file"""
+    from filesio import write_bgzf_text, write_tbi
+    path = os.path.join(str(tmp_path), "sites.vcf.gz")
+    write_bgzf_text(path, _big_vcf_text(), block_bytes=20000)
+    write_tbi(path)
+    assert io_native.tabix_index_path(path) == path + ".tbi"
+    names = io_native.tabix_contigs(path)
+    assert names == ["chr1", "chr2", "chrX"]
+    whole = io_native.read_vcf_table(path)
+    rng = np.random.default_rng(8)
+    pick = np.sort(rng.choice(whole.pos.size, 40, replace=False))
+    ref = np.searchsorted(whole.contig_off, pick, "right") - 1
+    lo, hi = whole.pos[pick] - 5002, whole.pos[pick] + 5002
+    t = io_native.read_vcf_table_regions(path, [names.index(whole.contigs[r]) for r in ref], lo, hi)
+    keep = np.zeros(whole.pos.size, bool)
+    for r, a, b in zip(ref, lo, hi):
+        c0, c1 = int(whole.contig_off[r]), int(whole.contig_off[r + 1])
+        keep[c0:c1] |= (whole.pos[c0:c1] < b) & (whole.end[c0:c1] > a)
+    idx = np.nonzero(keep)[0]
+    assert 1000 < idx.size < 0.2 * whole.pos.size and t.pos.size == idx.size
+    assert (whole.end[idx] - whole.pos[idx]).max() > 1000  # long records reaching into a window came along
+    for k in ("pos", "end", "sflags", "ref_base", "alt_base"):
+        assert np.array_equal(getattr(whole, k)[idx], getattr(t, k)), k
+    for k in ("gt", "ref_depth", "alt_depth", "gq"):
+        assert np.array_equal(getattr(whole, k)[:, idx], getattr(t, k)), k
+    assert t.samples == whole.samples and t.header == whole.header
+    assert [c for c in whole.contigs if c in t.contigs] == t.contigs
+    for j in range(0, idx.size, 37):
+        i = int(idx[j])
+        assert whole.lines[i] == t.lines[j] and whole.ref_str[i] == t.ref_str[j] and whole.alt_strs[i] == t.alt_strs[j]
+    # only a fraction of the file was read and inflated
+    assert t.io_stats[0] < 0.35 * os.path.getsize(path) and t.io_stats[3] == idx.size and t.io_stats[2] < 0.35 * whole.pos.size
+    # no interval, an interval past the end of a contig, a reference the index does not have
+    empty = io_native.read_vcf_table_regions(path, [], [], [])
+    assert empty.pos.size == 0 and empty.samples == whole.samples
+    far = io_native.read_vcf_table_regions(path, [2], [2_000_000_000 - 10], [2_000_000_000])
+    assert far.pos.size == 0
+    with pytest.raises(io_native.IoError):
+        io_native.read_vcf_table_regions(path, [7], [0], [10])
+    with pytest.raises(io_native.IoError):
+        io_native.read_vcf_table_regions(path, [0], [0], [10], tbi=path)  # not a tabix index

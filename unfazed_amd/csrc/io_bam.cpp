@@ -17,6 +17,7 @@
 #include <unistd.h>
 
 #include "io_common.hpp"
+#include "io_index.hpp"
 
 namespace uzio {
 
@@ -500,142 +501,6 @@ void build_table(uz_bam &B, std::vector<uint64_t> &rec, std::vector<uint32_t> &r
 // ---------------------------------------------------------------------------------------------------------
 // Region decode through the BAI index: what `bamfile.fetch(contig, lo, hi)` (read_collector.py:385, :167, :478-497)
 // and `bamfile.mate(read)` (:400, :185) hand the reference, without inflating the rest of the file.
-struct Chunk { uint64_t beg, end; }; // virtual file offsets (coffset << 16 | uoffset)
-
-struct BaiRef {
-    std::vector<std::pair<uint32_t, std::vector<Chunk>>> bins; // sorted by bin number
-    std::vector<uint64_t> linear;                              // 16 kb windows
-};
-
-std::vector<BaiRef> read_bai(const char *path) {
-    Bytes f = read_file(path);
-    const uint8_t *d = f.data();
-    const size_t N = f.size();
-    if (N < 8 || memcmp(d, "BAI\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAI index", path);
-    size_t off = 4;
-    auto need = [&](size_t k) { if (off + k > N) fail(UZ_IO_E_FORMAT, "truncated BAI index %s", path); };
-    need(4);
-    const int32_t n_ref = rdi32(d + off); off += 4;
-    std::vector<BaiRef> refs((size_t)std::max(n_ref, 0));
-    for (int32_t r = 0; r < n_ref; r++) {
-        need(4);
-        const int32_t n_bin = rdi32(d + off); off += 4;
-        for (int32_t b = 0; b < n_bin; b++) {
-            need(8);
-            const uint32_t bin = rd32(d + off);
-            const int32_t n_chunk = rdi32(d + off + 4);
-            off += 8;
-            need((size_t)n_chunk * 16);
-            std::vector<Chunk> cs;
-            if (bin != 37450) { // the pseudo-bin holds counts, not chunks
-                for (int32_t k = 0; k < n_chunk; k++) {
-                    Chunk c;
-                    memcpy(&c.beg, d + off + 16 * (size_t)k, 8);
-                    memcpy(&c.end, d + off + 16 * (size_t)k + 8, 8);
-                    cs.push_back(c);
-                }
-                refs[(size_t)r].bins.emplace_back(bin, std::move(cs));
-            }
-            off += (size_t)n_chunk * 16;
-        }
-        std::sort(refs[(size_t)r].bins.begin(), refs[(size_t)r].bins.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-        need(4);
-        const int32_t n_intv = rdi32(d + off); off += 4;
-        need((size_t)n_intv * 8);
-        refs[(size_t)r].linear.resize((size_t)n_intv);
-        if (n_intv) memcpy(refs[(size_t)r].linear.data(), d + off, (size_t)n_intv * 8);
-        off += (size_t)n_intv * 8;
-    }
-    return refs;
-}
-
-// bins a region [beg, end) may have records in (SAM spec, reg2bins)
-void reg2bins(int64_t beg, int64_t end, std::vector<uint32_t> &out) {
-    out.clear();
-    if (beg < 0) beg = 0;
-    if (end <= beg) end = beg + 1;
-    --end;
-    out.push_back(0);
-    for (uint32_t k = 1 + (uint32_t)(beg >> 26); k <= 1 + (uint32_t)(end >> 26); ++k) out.push_back(k);
-    for (uint32_t k = 9 + (uint32_t)(beg >> 23); k <= 9 + (uint32_t)(end >> 23); ++k) out.push_back(k);
-    for (uint32_t k = 73 + (uint32_t)(beg >> 20); k <= 73 + (uint32_t)(end >> 20); ++k) out.push_back(k);
-    for (uint32_t k = 585 + (uint32_t)(beg >> 17); k <= 585 + (uint32_t)(end >> 17); ++k) out.push_back(k);
-    for (uint32_t k = 4681 + (uint32_t)(beg >> 14); k <= 4681 + (uint32_t)(end >> 14); ++k) out.push_back(k);
-}
-
-struct Iv { int32_t lo, hi; };
-
-// file access for the region reader
-struct FileRd {
-    int fd = -1;
-    int64_t size = 0;
-    explicit FileRd(const char *path) {
-        fd = open(path, O_RDONLY);
-        if (fd < 0) fail(UZ_IO_E_OPEN, "cannot open %s", path);
-        struct stat st;
-        if (fstat(fd, &st) != 0) { close(fd); fail(UZ_IO_E_OPEN, "cannot stat %s", path); }
-        size = (int64_t)st.st_size;
-    }
-    ~FileRd() { if (fd >= 0) close(fd); }
-    // bytes [off, off + len) clipped to the file; returns the count read
-    size_t read_at(int64_t off, uint8_t *dst, size_t len) const {
-        size_t got = 0;
-        while (got < len && off + (int64_t)got < size) {
-            const ssize_t k = pread(fd, dst + got, len - got, (off_t)(off + (int64_t)got));
-            if (k <= 0) break;
-            got += (size_t)k;
-        }
-        return got;
-    }
-};
-
-// Inflates consecutive BGZF blocks starting at compressed offset `coff` until the block holding the virtual offset
-// `vend` has been inflated AND the bytes needed by `more()` are there.  out: the inflated bytes of those blocks;
-// block_at: (compressed offset, offset in out) per block.
-struct Inflated {
-    std::vector<uint8_t> bytes;
-    std::vector<std::pair<int64_t, size_t>> block_at;
-    int64_t next_coff = 0;
-};
-
-bool inflate_one(const FileRd &f, int64_t coff, Inflated &o, z_stream &z, std::vector<uint8_t> &cbuf, int64_t *file_bytes, int64_t *blocks) {
-    uint8_t h[18];
-    if (f.read_at(coff, h, 18) != 18) return false; // end of file
-    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) fail(UZ_IO_E_FORMAT, "not a BGZF block at byte %lld", (long long)coff);
-    const size_t xlen = rd16(h + 10);
-    cbuf.resize(12 + xlen);
-    if (f.read_at(coff, cbuf.data(), 12 + xlen) != 12 + xlen) fail(UZ_IO_E_FORMAT, "truncated BGZF block");
-    size_t q = 12, bsize = 0;
-    bool found = false;
-    while (q + 4 <= 12 + xlen) {
-        const size_t slen = rd16(cbuf.data() + q + 2);
-        if (cbuf[q] == 'B' && cbuf[q + 1] == 'C' && slen == 2) { bsize = rd16(cbuf.data() + q + 4); found = true; }
-        q += 4 + slen;
-    }
-    if (!found) fail(UZ_IO_E_FORMAT, "BGZF block without a BC field at byte %lld", (long long)coff);
-    const size_t blen = bsize + 1;
-    cbuf.resize(blen);
-    if (f.read_at(coff, cbuf.data(), blen) != blen) fail(UZ_IO_E_FORMAT, "truncated BGZF block at byte %lld", (long long)coff);
-    const uint32_t crc = rd32(cbuf.data() + blen - 8), isize = rd32(cbuf.data() + blen - 4);
-    const size_t at = o.bytes.size();
-    o.block_at.emplace_back(coff, at);
-    o.bytes.resize(at + isize);
-    if (isize) {
-        inflateReset(&z);
-        z.next_in = cbuf.data() + 12 + xlen;
-        z.avail_in = (uInt)(blen - 12 - xlen - 8);
-        z.next_out = o.bytes.data() + at;
-        z.avail_out = isize;
-        const int rc = inflate(&z, Z_FINISH);
-        if (rc != Z_STREAM_END || z.avail_out != 0) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
-        if ((uint32_t)crc32(0L, o.bytes.data() + at, isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
-    }
-    o.next_coff = coff + (int64_t)blen;
-    if (file_bytes) *file_bytes += (int64_t)blen;
-    if (blocks) *blocks += 1;
-    return true;
-}
-
 struct Kept { // one kept record: where it starts in the file, its bytes (block_size word included)
     uint64_t voff;
     std::vector<uint8_t> bytes;
@@ -694,31 +559,6 @@ void walk_chunk(const FileRd &f, Chunk ck, W &&want, std::vector<Kept> &out, int
         }
     } catch (...) { inflateEnd(&z); throw; }
     inflateEnd(&z);
-}
-
-// chunks of the file that can hold records overlapping the intervals of one contig (sorted, merged)
-void chunks_for(const BaiRef &ref, const std::vector<Iv> &ivs, std::vector<Chunk> &out) {
-    std::vector<uint32_t> bins;
-    std::vector<Chunk> cs;
-    for (const Iv &iv : ivs) {
-        reg2bins(iv.lo, iv.hi, bins);
-        uint64_t min_off = 0;
-        const size_t w = (size_t)(std::max<int64_t>(iv.lo, 0) >> 14);
-        if (!ref.linear.empty()) min_off = ref.linear[std::min(w, ref.linear.size() - 1)];
-        if (w >= ref.linear.size() && !ref.linear.empty()) min_off = ref.linear.back();
-        for (uint32_t b : bins) {
-            auto it = std::lower_bound(ref.bins.begin(), ref.bins.end(), b, [](const auto &a, uint32_t key) { return a.first < key; });
-            if (it == ref.bins.end() || it->first != b) continue;
-            for (const Chunk &c : it->second)
-                if (c.end > min_off) cs.push_back(Chunk{std::max(c.beg, min_off), c.end});
-        }
-    }
-    std::sort(cs.begin(), cs.end(), [](const Chunk &a, const Chunk &b) { return a.beg < b.beg || (a.beg == b.beg && a.end < b.end); });
-    for (const Chunk &c : cs) {
-        // merge chunks that touch or lie in the same compressed block neighbourhood: no record is walked twice
-        if (!out.empty() && c.beg <= out.back().end) out.back().end = std::max(out.back().end, c.end);
-        else out.push_back(c);
-    }
 }
 
 void decode_regions(uz_bam &B, const char *path, const char *bai_path, int64_t n_iv, const int32_t *iv_tid, const int32_t *iv_lo,

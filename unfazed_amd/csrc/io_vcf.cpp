@@ -10,7 +10,10 @@
 // float, missing -> -1; end = INFO/END when it parses as an integer, else start + len(REF).
 // BCF2 (the binary form, `.bcf`) is decoded into the same columns (decode_bcf below); it has no text lines,
 // so uz_vcf_line() is empty for such a file.
+#include <memory>
+
 #include "io_common.hpp"
+#include "io_index.hpp"
 
 #include <cmath>
 #include <cstdlib>
@@ -37,6 +40,7 @@ struct uz_vcf {
     std::vector<uint64_t> info_at;     // BCF: offset of the INFO section of record i in `text`
     std::vector<uint32_t> n_info;
     std::vector<std::string> dict;     // BCF: FILTER / INFO / FORMAT string dictionary
+    int64_t io_stats[4] = {0, 0, 0, 0}; // compressed bytes read, BGZF blocks inflated (region decode), lines walked, records kept
 };
 
 namespace {
@@ -375,12 +379,177 @@ void decode_bcf(uz_vcf &V, int threads) {
     V.contig_off.push_back(n);
 }
 
+void decode_text(uz_vcf &V, int threads);
+
 void decode(uz_vcf &V, const char *path, int threads) {
     {
         Bytes file = read_file(path);
         bool gz = false;
         V.text = inflate_all(file, threads, &gz);
+        V.io_stats[0] = (int64_t)file.size();
     }
+    decode_text(V, threads);
+    V.io_stats[2] = V.io_stats[3] = V.n;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Region decode through the tabix index (NAME.vcf.gz.tbi): what `vcf(region)` hands the reference per DNM
+// (informative_site_finder.py:42, :399-420, :566) -- only the BGZF blocks the index names for the intervals are read and
+// inflated; the table holds the header and, in file order, the records that overlap an interval.
+struct Tbi {
+    std::vector<std::string> names;
+    std::vector<BaiRef> refs;
+};
+
+Tbi read_tbi(const char *path, int threads) {
+    Bytes f = read_file(path);
+    bool gz = false;
+    Bytes raw = inflate_all(f, threads, &gz);
+    const uint8_t *d = raw.data();
+    const size_t N = raw.size();
+    if (N < 36 || memcmp(d, "TBI\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a tabix index", path);
+    const int32_t n_ref = rdi32(d + 4), format = rdi32(d + 8), l_nm = rdi32(d + 32);
+    if ((format & 0xFFFF) != 2) fail(UZ_IO_E_FORMAT, "%s indexes a file that is not VCF (format %d)", path, format);
+    if (n_ref < 0 || l_nm < 0 || 36 + (size_t)l_nm > N) fail(UZ_IO_E_FORMAT, "truncated tabix index %s", path);
+    Tbi t;
+    size_t a = 36;
+    const size_t stop = 36 + (size_t)l_nm;
+    while (a < stop && (int32_t)t.names.size() < n_ref) {
+        const void *z = memchr(d + a, 0, stop - a);
+        const size_t e = z ? (size_t)((const uint8_t *)z - d) : stop;
+        t.names.emplace_back((const char *)d + a, e - a);
+        a = e + 1;
+    }
+    if ((int32_t)t.names.size() != n_ref) fail(UZ_IO_E_FORMAT, "tabix index %s: %d names for %d references", path, (int)t.names.size(), n_ref);
+    t.refs = parse_index_refs(d, N, stop, n_ref, path);
+    return t;
+}
+
+std::string tbi_path_for(const char *path, const char *tbi_path) {
+    if (tbi_path && *tbi_path) return tbi_path;
+    return std::string(path) + ".tbi";
+}
+
+void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n_iv, const int32_t *iv_ref, const int32_t *iv_lo,
+                    const int32_t *iv_hi, int threads) {
+    const std::string tp = tbi_path_for(path, tbi_path);
+    const Tbi tbi = read_tbi(tp.c_str(), threads);
+    const int32_t n_ref = (int32_t)tbi.names.size();
+    std::vector<std::vector<Iv>> ivs((size_t)n_ref);
+    for (int64_t k = 0; k < n_iv; k++) {
+        if (iv_ref[k] < 0 || iv_ref[k] >= n_ref) fail(UZ_IO_E_ARG, "interval %lld names reference %d of %d", (long long)k, iv_ref[k], n_ref);
+        if (iv_hi[k] > iv_lo[k]) ivs[(size_t)iv_ref[k]].push_back(Iv{std::max(iv_lo[k], 0), iv_hi[k]});
+    }
+    FileRd file(path);
+    z_stream z;
+    memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
+    std::vector<uint8_t> cbuf;
+    std::string text;
+    int64_t file_bytes = 0, blocks = 0, walked = 0, kept = 0;
+    try {
+        // header: blocks from the start of the file until a line that does not start with '#'
+        {
+            Inflated inf;
+            size_t at = 0;
+            bool done = false;
+            while (!done) {
+                while (!memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at)) {
+                    const int64_t next = inf.block_at.empty() ? 0 : inf.next_coff;
+                    if (!inflate_one(file, next, inf, z, cbuf, &file_bytes, &blocks)) { done = true; break; }
+                }
+                if (done) break;
+                const uint8_t *nl = (const uint8_t *)memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at);
+                const size_t e = (size_t)(nl - inf.bytes.data());
+                if (e > at && inf.bytes[at] != '#') break;
+                text.append((const char *)inf.bytes.data() + at, e + 1 - at);
+                at = e + 1;
+            }
+        }
+        for (int32_t r = 0; r < n_ref; r++) {
+            std::vector<Iv> &v = ivs[(size_t)r];
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end(), [](const Iv &a, const Iv &b) { return a.lo < b.lo || (a.lo == b.lo && a.hi < b.hi); });
+            std::vector<Iv> merged;
+            for (const Iv &iv : v) {
+                if (!merged.empty() && iv.lo <= merged.back().hi) merged.back().hi = std::max(merged.back().hi, iv.hi);
+                else merged.push_back(iv);
+            }
+            std::vector<Chunk> chunks;
+            chunks_for(tbi.refs[(size_t)r], merged, chunks);
+            const std::string &name = tbi.names[(size_t)r];
+            for (const Chunk &ck : chunks) {
+                Inflated inf;
+                if (!inflate_one(file, (int64_t)(ck.beg >> 16), inf, z, cbuf, &file_bytes, &blocks)) continue;
+                size_t at = (size_t)(ck.beg & 0xFFFF), blk = 0;
+                for (;;) {
+                    while (at >= inf.bytes.size())
+                        if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) goto chunk_done;
+                    while (blk + 1 < inf.block_at.size() && inf.block_at[blk + 1].second <= at) blk++;
+                    {
+                        const uint64_t voff = ((uint64_t)inf.block_at[blk].first << 16) | (uint64_t)(at - inf.block_at[blk].second);
+                        if (voff >= ck.end) break;
+                    }
+                    const uint8_t *nl;
+                    bool eof = false;
+                    while (!(nl = (const uint8_t *)memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at)))
+                        if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) { eof = true; break; }
+                    const size_t e = eof ? inf.bytes.size() : (size_t)(nl - inf.bytes.data());
+                    const char *L = (const char *)inf.bytes.data() + at;
+                    const size_t len = e - at;
+                    walked++;
+                    if (len && L[0] != '#') {
+                        // CHROM, POS, REF (columns 1, 2, 4) and INFO/END (column 8)
+                        const char *c1 = (const char *)memchr(L, '\t', len);
+                        const char *c2 = c1 ? (const char *)memchr(c1 + 1, '\t', len - (size_t)(c1 + 1 - L)) : nullptr;
+                        if (c1 && c2 && (size_t)(c1 - L) == name.size() && memcmp(L, name.data(), name.size()) == 0) {
+                            long long pos1 = 0;
+                            if (parse_int(Str{c1 + 1, (size_t)(c2 - c1 - 1)}, pos1)) {
+                                const long long pos0 = pos1 - 1;
+                                long long end = pos0 + 1;
+                                const char *c3 = (const char *)memchr(c2 + 1, '\t', len - (size_t)(c2 + 1 - L));
+                                const char *c4 = c3 ? (const char *)memchr(c3 + 1, '\t', len - (size_t)(c3 + 1 - L)) : nullptr;
+                                if (c3 && c4) end = pos0 + std::max<long long>(1, (long long)(c4 - c3 - 1));
+                                // (INFO/END may reach further: looked for anywhere in the rest of the line -- a superset is fine)
+                                for (const char *q = c4 ? c4 : L + len; q && q + 4 < L + len;) {
+                                    const char *h = (const char *)memmem(q, (size_t)(L + len - q), "END=", 4);
+                                    if (!h) break;
+                                    if (h[-1] == ';' || h[-1] == '\t') {
+                                        long long ev = 0;
+                                        const char *s0 = h + 4, *s1 = s0;
+                                        while (s1 < L + len && *s1 >= '0' && *s1 <= '9') s1++;
+                                        if (s1 > s0 && parse_int(Str{s0, (size_t)(s1 - s0)}, ev)) end = std::max(end, ev);
+                                    }
+                                    q = h + 4;
+                                }
+                                bool hit = false;
+                                for (const Iv &iv : merged) {
+                                    if ((long long)iv.lo >= end) break;
+                                    if (pos0 < iv.hi && end > iv.lo) { hit = true; break; }
+                                }
+                                if (hit) {
+                                    text.append(L, len);
+                                    text.push_back('\n');
+                                    kept++;
+                                }
+                            }
+                        }
+                    }
+                    if (eof) break;
+                    at = e + 1;
+                }
+            chunk_done:;
+            }
+        }
+    } catch (...) { inflateEnd(&z); throw; }
+    inflateEnd(&z);
+    V.text.alloc(text.size());
+    memcpy(V.text.data(), text.data(), text.size());
+    decode_text(V, threads);
+    V.io_stats[0] = file_bytes; V.io_stats[1] = blocks; V.io_stats[2] = walked; V.io_stats[3] = kept;
+}
+
+void decode_text(uz_vcf &V, int threads) {
     const char *T = (const char *)V.text.data();
     const size_t N = V.text.size();
     if (N >= 5 && memcmp(T, "BCF\2", 4) == 0) { decode_bcf(V, threads); return; }
@@ -593,6 +762,33 @@ int uz_vcf_decode(const char *path, int threads, uz_vcf **out) {
     if (rc != UZ_IO_OK) { delete h; return rc; }
     *out = h;
     return UZ_IO_OK;
+}
+
+int uz_vcf_decode_regions(const char *path, const char *tbi_path, int64_t n_iv, const int32_t *ref, const int32_t *lo, const int32_t *hi,
+                          int threads, uz_vcf **out) {
+    return guarded([&] {
+        if (!path || !out || n_iv < 0 || (n_iv && (!ref || !lo || !hi))) fail(UZ_IO_E_ARG, "uz_vcf_decode_regions: bad arguments");
+        std::unique_ptr<uz_vcf> V(new uz_vcf());
+        decode_regions(*V, path, tbi_path, n_iv, ref, lo, hi, resolve_threads(threads));
+        *out = V.release();
+    });
+}
+
+int64_t uz_vcf_index_names(const char *path, const char *tbi_path, char *buf, int64_t cap) {
+    int64_t total = -1;
+    const int rc = guarded([&] {
+        if (!path) fail(UZ_IO_E_ARG, "uz_vcf_index_names: bad arguments");
+        const Tbi t = read_tbi(tbi_path_for(path, tbi_path).c_str(), 1);
+        std::string all;
+        for (const std::string &n : t.names) { all += n; all.push_back('\0'); }
+        if (buf && cap >= (int64_t)all.size()) memcpy(buf, all.data(), all.size());
+        total = (int64_t)all.size();
+    });
+    return rc == UZ_IO_OK ? total : (int64_t)rc;
+}
+
+void uz_vcf_io_stats(const uz_vcf *h, int64_t out[4]) {
+    for (int k = 0; k < 4; k++) out[k] = h ? h->io_stats[k] : 0;
 }
 
 void uz_vcf_free(uz_vcf *h) { delete h; }

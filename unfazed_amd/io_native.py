@@ -28,7 +28,7 @@ IO_EXPORTS = [
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
     "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16",
-    "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode",
+    "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
 ]
 
 
@@ -80,6 +80,11 @@ def load():
     lib.uz_bam_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.uz_bam_timing.restype = None
     lib.uz_vcf_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.uz_vcf_decode_regions.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    lib.uz_vcf_index_names.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.uz_vcf_index_names.restype = C.c_int64
+    lib.uz_vcf_io_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_vcf_io_stats.restype = None
     lib.uz_vcf_free.argtypes = [C.c_void_p]
     lib.uz_vcf_free.restype = None
     lib.uz_vcf_view_get.argtypes = [C.c_void_p, C.POINTER(VcfView)]
@@ -267,13 +272,47 @@ class _Strings(Sequence):
         return self._post(C.string_at(p, ln.value).decode())
 
 
+def tabix_index_path(path: str):
+    """the .tbi next to a BGZF-compressed VCF, or None"""
+    cand = path + ".tbi"
+    return cand if path.endswith(".gz") and os.path.isfile(cand) else None
+
+
+def tabix_contigs(path: str, tbi: str = None) -> list:
+    """sequence names of the tabix index, in the order of their first record in the file"""
+    lib = load()
+    n = lib.uz_vcf_index_names(os.fsencode(path), os.fsencode(tbi) if tbi else None, None, 0)
+    if n < 0:
+        _check(lib, int(n))
+    buf = C.create_string_buffer(max(1, int(n)))
+    lib.uz_vcf_index_names(os.fsencode(path), os.fsencode(tbi) if tbi else None, buf, int(n))
+    return [x.decode() for x in buf.raw[: int(n)].split(b"\0")[:-1]]
+
+
+def read_vcf_table_regions(path: str, ref, lo, hi, threads: int = 0, tbi: str = None) -> SitesTable:
+    """Index-driven decode: the records overlapping the intervals [lo[k], hi[k]) (0-based) of sequence ref[k] (an index into
+    tabix_contigs) -- what cyvcf2's vcf(region) hands the reference, without inflating the rest of the file.  `.io_stats`:
+    compressed bytes read, BGZF blocks inflated, lines walked, records kept."""
+    lib = load()
+    ref = np.ascontiguousarray(ref, np.int32)
+    lo = np.ascontiguousarray(lo, np.int32)
+    hi = np.ascontiguousarray(hi, np.int32)
+    hp = C.c_void_p()
+    _check(lib, lib.uz_vcf_decode_regions(os.fsencode(path), os.fsencode(tbi) if tbi else None, int(ref.size), ref.ctypes.data,
+                                          lo.ctypes.data, hi.ctypes.data, int(threads), C.byref(hp)))
+    return _vcf_table_from_handle(lib, _Handle(hp.value, lib.uz_vcf_free))
+
+
 def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
     """sites VCF -> SitesTable; `.header` (list of lines) and `.lines[i]` (raw record text) ride along
     for the VCF writer."""
     lib = load()
     hp = C.c_void_p()
     _check(lib, lib.uz_vcf_decode(os.fsencode(path), int(threads), C.byref(hp)))
-    h = _Handle(hp.value, lib.uz_vcf_free)
+    return _vcf_table_from_handle(lib, _Handle(hp.value, lib.uz_vcf_free))
+
+
+def _vcf_table_from_handle(lib, h) -> SitesTable:
     v = VcfView()
     _check(lib, lib.uz_vcf_view_get(h.ptr, C.byref(v)))
     n, ns, nc = int(v.n_sites), int(v.n_samples), int(v.n_contigs)
@@ -300,6 +339,9 @@ def read_vcf_table(path: str, threads: int = 0) -> SitesTable:
         return C.string_at(p, ln2.value).decode() if p else None
 
     t.info = info
+    st = (C.c_int64 * 4)()
+    lib.uz_vcf_io_stats(h.ptr, st)
+    t.io_stats = [int(x) for x in st]
     t._native = h
     return t
 

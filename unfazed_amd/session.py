@@ -55,11 +55,43 @@ def _io_threads() -> int:
     return int(os.environ.get("UZ_IO_THREADS", "0"))
 
 
-def load_sites(name_or_table) -> (str, SitesTable):
+def site_regions(name, dnms, search_dist):
+    """The intervals of a tabix-indexed sites file a batch of DNMs can look at -- its windows of +-search_dist and, for
+    whole-region (CNV) lookups, the events themselves: what the reference asks the index for DNM by DNM
+    (informative_site_finder.py:399-420, :566).  None: no index (or UZ_IO_INDEX=0, or the Python decoders): decode the file."""
+    if dnms is None or search_dist is None or not isinstance(name, str) or name in _SITES or _python_io():
+        return None
+    if os.environ.get("UZ_IO_INDEX", "1") == "0" or not os.path.isfile(name):
+        return None
+    from .io_native import tabix_contigs, tabix_index_path
+    if tabix_index_path(name) is None:
+        return None
+    names = tabix_contigs(name)
+    if not names:
+        return None
+    prefix = names[0][:3] if "chr" in names[0].lower() else ""  # utils.py:46-52: the first record of the file decides
+    index = {n: i for i, n in enumerate(names)}
+    sd = int(search_dist) + 2
+    out = set()
+    for dn in dnms:
+        k = index.get(prefix + str(dn["chrom"]).strip("chr"))
+        if k is not None:
+            out.add((k, max(0, int(dn["start"]) - sd), int(dn["end"]) + sd))
+    return tuple(sorted(out))
+
+
+def load_sites(name_or_table, regions=None) -> (str, SitesTable):
     if isinstance(name_or_table, SitesTable):
         key = "table@%d" % id(name_or_table)
         _SITES[key] = name_or_table
         return key, name_or_table
+    if regions is not None:
+        key = "%s@%x" % (name_or_table, hash(regions) & 0xFFFFFFFFFFFF)
+        if key not in _SITES:
+            from .io_native import read_vcf_table_regions
+            _SITES[key] = read_vcf_table_regions(name_or_table, [r[0] for r in regions], [r[1] for r in regions],
+                                                 [r[2] for r in regions], threads=_io_threads())
+        return key, _SITES[key]
     if name_or_table not in _SITES:
         if _python_io():
             from .io_vcf import read_vcf
@@ -148,8 +180,10 @@ class _LazyReads(dict):
         return read_bam_regions(bam, tid, lo, hi, threads=_io_threads(), insert_size_max_sample=0)
 
 
-def host_for(sites, insert_size_max_sample: int = 1000000) -> PhasingHost:
-    key, table = load_sites(sites)
+def host_for(sites, insert_size_max_sample: int = 1000000, dnms=None, search_dist=None) -> PhasingHost:
+    """dnms + search_dist: the batch the host will serve -- a sites file with a tabix index next to it is then decoded through
+    the index for the batch's windows only (one table, one host per distinct batch)"""
+    key, table = load_sites(sites, site_regions(sites, dnms, search_dist))
     backend = get_backend()
     hk = (key, id(backend))
     if hk not in _HOSTS:

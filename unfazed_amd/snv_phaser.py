@@ -14,7 +14,7 @@ def phase_snvs(
 ):
     for dn in dnms:  # a CRAM is decoded against the FASTA its DNMs carry (unfazed.py:270, read_collector.py:372-373)
         session.set_cram_reference(dn.get("bam", ""), dn.get("cram_ref"))
-    host = session.host_for(sites, insert_size_max_sample)
+    host = session.host_for(sites, insert_size_max_sample, dnms=dnms, search_dist=search_dist)
     params = abi.make_params(
         search_dist=search_dist, min_gt_qual=min_gt_qual, min_depth=min_depth, min_map_qual=min_map_qual,
         readlen=readlen, split_error_margin=split_error_margin, no_extended=no_extended,
