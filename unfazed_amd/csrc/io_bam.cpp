@@ -266,6 +266,8 @@ size_t parse_header(uz_bam &B, const uint8_t *d, size_t N, const char *path, int
 
 void build_table(uz_bam &B, std::vector<uint64_t> &rec, std::vector<uint32_t> &rec_end32, int32_t n_ref, int threads, double t2);
 
+void decode_stream(uz_bam &B, const char *path, int threads, double t2);
+
 void decode(uz_bam &B, const char *path, int threads) {
     double t0 = now_s();
     Bytes file = read_file(path);
@@ -277,6 +279,11 @@ void decode(uz_bam &B, const char *path, int threads) {
     file.release();
     double t2 = now_s();
     B.timing[1] = t2 - t1;
+    decode_stream(B, path, threads, t2);
+}
+
+// the table of an uncompressed BAM stream held in B.data
+void decode_stream(uz_bam &B, const char *path, int threads, double t2) {
     const Bytes &d = B.data;
     const size_t N = d.size();
     int32_t n_ref = 0;
@@ -799,6 +806,21 @@ int uz_bam_decode(const char *path, int threads, uz_bam **out) {
     const int rc = guarded([&] {
         h = new uz_bam();
         decode(*h, path, resolve_threads(threads));
+    });
+    if (rc != UZ_IO_OK) { delete h; return rc; }
+    *out = h;
+    return UZ_IO_OK;
+}
+
+int uz_bam_decode_memory(const uint8_t *stream, int64_t n, int threads, uz_bam **out) {
+    if (!stream || n < 0 || !out) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    *out = nullptr;
+    uz_bam *h = nullptr;
+    const int rc = guarded([&] {
+        h = new uz_bam();
+        h->data.alloc((size_t)n);
+        memcpy(h->data.data(), stream, (size_t)n);
+        decode_stream(*h, "<memory>", resolve_threads(threads), now_s());
     });
     if (rc != UZ_IO_OK) { delete h; return rc; }
     *out = h;

@@ -641,8 +641,9 @@ class CramFile:
             off = c.body_off + c.length
 
     # ---- slices
-    def decode_container(self, c: _Container, only_slices: Optional[Sequence[int]] = None) -> List[Tuple[int, List[Segment]]]:
-        """-> [(slice offset within the container, records)]"""
+    def decode_container(self, c: _Container, only_slices: Optional[Sequence[int]] = None, as_bam: bool = False):
+        """-> [(slice offset within the container, records)]; as_bam: the records of a slice as uncompressed BAM records
+        (bytes) from the native record layer (uz_cram_slice_to_bam) instead of Segment objects"""
         if c.n_records == 0:
             return []
         body = self._body(c)
@@ -655,10 +656,10 @@ class CramFile:
         for lm in c.landmarks:
             if only_slices is not None and lm not in only_slices:
                 continue
-            out.append((lm, self._decode_slice(ch, _In(body, lm))))
+            out.append((lm, self._decode_slice(ch, _In(body, lm), ch_block.data if as_bam else None)))
         return out
 
-    def _decode_slice(self, ch: CompressionHeader, inp: _In) -> List[Segment]:
+    def _decode_slice(self, ch: CompressionHeader, inp: _In, ch_raw: Optional[bytes] = None):
         hb = _read_block(inp)
         if hb.ctype != 2:
             raise CramError("slice does not start with a slice header block")
@@ -671,10 +672,60 @@ class CramFile:
             elif b.ctype == 4:
                 ext[b.cid] = b.data
         self.slices_decoded += 1
+        if ch_raw is not None and sh.ref != -2:
+            from . import io_native
+            ref, ref0 = None, 0
+            if sh.embedded >= 0:
+                if sh.embedded not in ext:
+                    raise CramError("slice names a missing embedded reference block")
+                ref, ref0 = bytes(ext[sh.embedded]).upper(), sh.start - 1
+            elif sh.ref >= 0 and self.fasta is not None:
+                ref0 = max(0, sh.start - 1)
+                ref = self.fasta.fetch(self.contigs[sh.ref], ref0, sh.start - 1 + sh.span + 1000)
+                _check_slice_md5(self, sh, ref[sh.start - 1 - ref0: sh.start - 1 - ref0 + sh.span], ch)
+            elif sh.ref >= 0 and ch.rr:
+                raise CramError("this CRAM needs its reference FASTA (-r / --reference)")
+            try:
+                return io_native.cram_slice_to_bam(ch_raw, sh.ref, sh.start, sh.span, sh.n_records, sh.counter, core, ext, ref, ref0)
+            except io_native.IoError as e:
+                raise CramError("%s: %s" % (self.path, e))
         try:
-            return _decode_records(ch, sh, _SliceStreams(core, ext), self)
+            recs = _decode_records(ch, sh, _SliceStreams(core, ext), self)
         except IndexError:
             raise CramError("a data series of %s runs past the end of its block" % self.path)
+        return b"".join(bam_record(s) for s in recs) if ch_raw is not None else recs  # (multi-reference slice: packed here)
+
+
+def _check_slice_md5(cf: "CramFile", sh: "_SliceHeader", seq: bytes, ch: "CompressionHeader") -> None:
+    if ch.rr and any(sh.md5) and hashlib.md5(seq).digest() != sh.md5:
+        raise CramError("the reference FASTA does not match the one %s was written against (contig %s, %d-%d)"
+                        % (cf.path, cf.contigs[sh.ref], sh.start, sh.start + sh.span - 1))
+
+
+_SEQ16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+
+
+def bam_record(s: Segment) -> bytes:
+    """one Segment as an uncompressed BAM record (block_size word included; an SA:Z:* tag when the record carries one)"""
+    name = s.qname.encode("latin1") + b"\0"
+    l_seq = len(s.seq) if s.seq else 0
+    sq = bytearray((l_seq + 1) // 2)
+    for i, ch in enumerate(s.seq or ""):
+        sq[i >> 1] |= _SEQ16.get(ch.upper(), 15) << (4 if i % 2 == 0 else 0)
+    qual = bytes(s.qual[:l_seq]) if (s.qual is not None and l_seq) else b"\xff" * l_seq
+    body = struct.pack("<iiBBHHHiiii", s.tid, s.pos, len(name), s.mapq & 0xFF, 4680, len(s.cigar), s.flag & 0xFFFF, l_seq, s.mtid, s.mpos,
+                       s.tlen) + name + b"".join(struct.pack("<I", (ln << 4) | op) for op, ln in s.cigar) + bytes(sq) + qual + \
+        (b"SAZ*\0" if s.has_sa else b"")
+    return struct.pack("<i", len(body)) + body
+
+
+def bam_stream_header(cf: "CramFile") -> bytes:
+    text = cf.text.encode("latin1")
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(cf.contigs)))
+    for name, ln in zip(cf.contigs, cf.contig_len):
+        nm = name.encode("latin1") + b"\0"
+        out += struct.pack("<i", len(nm)) + nm + struct.pack("<i", ln)
+    return bytes(out)
 
 
 def _decode_records(ch: CompressionHeader, sh: _SliceHeader, st: _SliceStreams, cf: CramFile) -> List[Segment]:
@@ -698,10 +749,7 @@ def _decode_records(ch: CompressionHeader, sh: _SliceHeader, st: _SliceStreams, 
             raise CramError("slice names a missing embedded reference block")
         ref.set_embedded(sh.ref, sh.start - 1, st.ext[sh.embedded].b)
     elif sh.ref >= 0 and ch.rr and cf.fasta is not None and any(sh.md5):
-        seq = ref.get(sh.ref, sh.start - 1, sh.start - 1 + sh.span)
-        if hashlib.md5(seq).digest() != sh.md5:
-            raise CramError("the reference FASTA does not match the one %s was written against (contig %s, %d-%d)"
-                            % (cf.path, cf.contigs[sh.ref], sh.start, sh.start + sh.span - 1))
+        _check_slice_md5(cf, sh, ref.get(sh.ref, sh.start - 1, sh.start - 1 + sh.span), ch)
     n = sh.n_records
     recs = [None] * n  # [flag, cf, tid, pos1, aend1, mapq, cigar, seq, qual, name, mate_line, mtid, mpos1, tlen, has_sa]
     last_pos = sh.start
@@ -889,7 +937,9 @@ def _decode_records(ch: CompressionHeader, sh: _SliceHeader, st: _SliceStreams, 
                 rk[13] = 0
             if mate[0] & FREVERSE:
                 rk[0] |= FMREVERSE
-            if rk[9] is None:
+            if rk[9] is None:  # (names not kept: the records of a chain share the name generated for its first record)
+                if recs[chain[0]][9] is None:
+                    recs[chain[0]][9] = b"cram:%d" % (sh.counter + chain[0])
                 rk[9] = recs[chain[0]][9]
             rk[10] = -2  # resolved
     out = []
@@ -935,8 +985,63 @@ def _overlaps(seg: Segment, tid: int, lo: int, hi: int) -> bool:
     return seg.tid == tid and seg.pos < hi and seg.endpos > lo
 
 
+class _Lite:
+    """what the region selection looks at, read off an uncompressed BAM record (native record layer)"""
+    __slots__ = ("raw", "tid", "pos", "endpos", "flag", "mtid", "mpos", "qname")
+
+
+def _lite_records(buf: bytes) -> List[_Lite]:
+    out = []
+    off, n = 0, len(buf)
+    unpack = struct.Struct("<iiiBBHHHiii").unpack_from
+    while off + 4 <= n:
+        bs, tid, pos, l_name, _mq, _bin, n_cig, flag, _l_seq, mtid, mpos = unpack(buf, off)
+        r = _Lite()
+        r.raw = buf[off: off + 4 + bs]
+        r.tid, r.pos, r.flag, r.mtid, r.mpos = tid, pos, flag, mtid, mpos
+        p = off + 36
+        r.qname = buf[p: p + l_name - 1]
+        p += l_name
+        rl = 0
+        if n_cig:
+            for v in struct.unpack_from("<%dI" % n_cig, buf, p):
+                if (v & 15) in (0, 2, 3, 7, 8):
+                    rl += v >> 4
+        r.endpos = pos + 1 if (flag & FUNMAP or not n_cig) else pos + (rl if rl > 0 else 1)
+        out.append(r)
+        off += 4 + bs
+    return out
+
+
+def read_cram_table(path: str, reference: Optional[str] = None, max_records: Optional[int] = None, threads: int = 0,
+                    insert_size_max_sample: int = 1000000):
+    """whole file (or its head: whole slices until max_records) -> model.ReadsTable through the native record layer and the
+    BAM table builder (uz_cram_slice_to_bam, uz_bam_decode_memory)"""
+    from . import io_native
+    cf = CramFile(path, reference)
+    try:
+        parts, n = [bam_stream_header(cf)], 0
+        for c in cf.containers():
+            for _, part in cf.decode_container(c, as_bam=True):
+                parts.append(part)
+            n += c.n_records
+            if max_records is not None and n >= max_records:
+                break
+        return io_native.read_bam_stream_table(b"".join(parts), threads=threads, insert_size_max_sample=insert_size_max_sample)
+    finally:
+        cf.close()
+
+
+def read_cram_regions_table(path: str, reference: Optional[str], tid, lo, hi, crai: Optional[str] = None, stats: Optional[dict] = None,
+                            threads: int = 0):
+    """read_cram_regions through the native record layer -> model.ReadsTable"""
+    from . import io_native
+    header, kept = read_cram_regions(path, reference, tid, lo, hi, crai=crai, stats=stats, as_bam=True)
+    return io_native.read_bam_stream_table(header + b"".join(r.raw for r in kept), threads=threads, insert_size_max_sample=0)
+
+
 def read_cram_regions(path: str, reference: Optional[str], tid: Sequence[int], lo: Sequence[int], hi: Sequence[int],
-                      crai: Optional[str] = None, stats: Optional[dict] = None) -> Tuple[List[str], List[Segment]]:
+                      crai: Optional[str] = None, stats: Optional[dict] = None, as_bam: bool = False):
     """What `fetch(contig, lo, hi)` returns for the intervals (start < hi and end > lo, 0-based half open) and, closed under
     it, what `mate()` returns for those records (same name at the mate position) -- the same contract as
     uz_bam_decode_regions (include/unfazed_io.h) -- in file order.  Only slices the index names for the intervals (and for
@@ -960,8 +1065,8 @@ def read_cram_regions(path: str, reference: Optional[str], tid: Sequence[int], l
                         want.setdefault(e[3], set()).add(e[4])
             for coff in sorted(want):
                 c = cf._container_at(coff)
-                for lm, part in cf.decode_container(c, only_slices=want[coff]):
-                    decoded[(coff, lm)] = part
+                for lm, part in cf.decode_container(c, only_slices=want[coff], as_bam=as_bam):
+                    decoded[(coff, lm)] = _lite_records(part) if as_bam else part
 
         ivs = sorted(set(zip((int(x) for x in tid), (int(x) for x in lo), (int(x) for x in hi))))
         slices_for(ivs)
@@ -1017,6 +1122,6 @@ def read_cram_regions(path: str, reference: Optional[str], tid: Sequence[int], l
         if stats is not None:
             stats.update(slices_decoded=cf.slices_decoded, bytes_read=cf.bytes_read, records_walked=sum(len(v) for v in decoded.values()),
                          records_kept=len(keep))
-        return cf.contigs, [keep[k] for k in sorted(keep)]
+        return (bam_stream_header(cf) if as_bam else cf.contigs), [keep[k] for k in sorted(keep)]
     finally:
         cf.close()

@@ -114,7 +114,10 @@ def set_cram_reference(name: str, fasta: Optional[str]) -> None:
 
 def load_reads(name: str, insert_size_max_sample: int = 1000000) -> ReadsTable:
     if name not in _READS:
-        if name[-4:] == "cram":
+        if name[-4:] == "cram" and not _python_io():
+            from .io_cram import read_cram_table
+            t = read_cram_table(name, _CRAM_REF.get(name), threads=_io_threads(), insert_size_max_sample=insert_size_max_sample)
+        elif name[-4:] == "cram":
             from .io_cram import read_cram
             contigs, segs = read_cram(name, _CRAM_REF.get(name))
             t = ReadsTable.from_segments(segs, contigs)
@@ -159,8 +162,15 @@ class _LazyReads(dict):
 
     def header(self, bam: str) -> ReadsTable:
         if bam not in self._headers:
-            if bam.endswith(".cram"):
+            if bam.endswith(".cram") and not _python_io():
                 # the head of the file: whole slices until insert_size_max_sample + 1 records are there
+                from .io_cram import read_cram_table
+                full = read_cram_table(bam, _CRAM_REF.get(bam), max_records=int(self.cap) + 1, threads=_io_threads(),
+                                       insert_size_max_sample=self.cap)
+                t = ReadsTable(full.contigs)
+                t.tlen_head = full.tlen_head
+                self._headers[bam] = t
+            elif bam.endswith(".cram"):
                 from .io_cram import read_cram
                 contigs, segs = read_cram(bam, _CRAM_REF.get(bam), max_records=int(self.cap) + 1)
                 t = ReadsTable(contigs)
@@ -172,6 +182,9 @@ class _LazyReads(dict):
         return self._headers[bam]
 
     def regions(self, bam: str, tid, lo, hi) -> ReadsTable:
+        if bam.endswith(".cram") and not _python_io():
+            from .io_cram import read_cram_regions_table
+            return read_cram_regions_table(bam, _CRAM_REF.get(bam), tid, lo, hi, threads=_io_threads())
         if bam.endswith(".cram"):
             from .io_cram import read_cram_regions
             contigs, segs = read_cram_regions(bam, _CRAM_REF.get(bam), tid, lo, hi)
