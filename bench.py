@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--workload", choices=["snv", "cnv"], default="snv",
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
-    ap.add_argument("--chunks", type=int, default=8, help="DNM chunks of the staged pass (uploads overlap the kernels)")
+    ap.add_argument("--chunks", type=int, default=12, help="DNM chunks of the staged pass (uploads overlap the kernels)")
+    ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-staged", action="store_true", help="resident pass only (profiling runs)")
@@ -238,6 +239,7 @@ def main():
         co, ci, cf, ho, hi = eng.find(fid, dv, P, mode)
         nchunk = max(1, min(args.chunks, n))
         chunks, staged_bytes, staged_records = [], 0, 0
+        slab_hint = 768 << 20
         ecuts = [n * k // nchunk for k in range(nchunk + 1)]  # chunks of events; their records: the clusters of their generator entries
         for k in range(nchunk):
             a, b = ecuts[k], ecuts[k + 1]
@@ -251,7 +253,10 @@ def main():
                                              vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff, allele_len=alen)
             # point-variant batch: qualities as counts + short lists, and of every record's rows only the 32-base units that hold
             # a fetched position; the SV batch needs the plane and whole rows (uz_types.h)
+            # (the chunk's columns back to back in one pinned block: they cross the link as one copy)
+            pool.new_slab(slab_hint)
             part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=not cnv, extra=None if cnv else fex)
+            slab_hint = max(64 << 20, int(pool.end_slab() * 1.3))
             del src, part_full
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)
@@ -262,11 +267,85 @@ def main():
                              + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
                              + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
         site_bytes = int(site_sel.size) * (4 + 1 + 1 + 1 + 1 + 18)
+        # The same site columns cut per chunk (the windows of the chunk's DNMs): the site stage of chunk k + 1 then runs while the
+        # records of chunk k are still on the link, instead of one site stage for the whole batch in front of everything.
+        # (config 5 keeps the single table: its allele-balance kernel runs once over the whole batch.)
+        chunk_sites = []
+        if not cnv and not args.one_site_table:
+            for (a, b, _, _) in chunks:
+                kk = np.zeros(sc.n + 1, np.int32)
+                for c in np.unique(ev.contig[a:b]):
+                    if c < 0:
+                        continue
+                    m = ev.contig[a:b] == c
+                    pc = sc.pos[co_s[c]: co_s[c + 1]]
+                    lo_i = np.searchsorted(pc, ev.start[a:b][m].astype(np.int64) - sd, "left") + co_s[c]
+                    hi_i = np.searchsorted(pc, ev.end[a:b][m].astype(np.int64) + sd, "right") + co_s[c]
+                    np.add.at(kk, lo_i, 1)
+                    np.add.at(kk, hi_i, -1)
+                sel = np.nonzero(np.cumsum(kk[:-1]) > 0)[0]
+                pool.new_slab(int(sel.size) * 28 + (1 << 20))
+                hs_k = {k: pinned_copy(pool, getattr(sc, k)[sel]) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
+                hs_k["contig_off"] = pinned_copy(pool, np.searchsorted(sel, co_s).astype(np.int64))
+                hg_k = {k: [pinned_copy(pool, getattr(sc, k)[m][sel]) for m in range(3)] for k in ("rd", "ad", "gq")}
+                svk = abi.SitesView()
+                svk.n_sites, svk.n_contigs = int(sel.size), len(sc.contig_off) - 1
+                for k in ("contig_off", "pos", "sflags", "ref_base", "alt_base"):
+                    setattr(svk, k, hs_k[k].ctypes.data)
+                pool.end_slab()
+                chunk_sites.append((abi.Held(svk, hs_k), hs_k, hg_k, int(sel.size)))
+            site_bytes = sum(x[3] for x in chunk_sites) * (4 + 1 + 1 + 1 + 1 + 18)
         t_dec = time.time() - t_dec
 
         trace = [] if os.environ.get("UZ_BENCH_TRACE") else None
 
+        def step_pipelined():
+            """chunk k: site stage (its windows' site columns up, K1 + K2, het lists back) -> its records queued on the copy stream
+            -> the read stage of chunk k - 1; the site columns of chunk k + 1 go up before the records of chunk k"""
+            out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32),
+                       evidence=np.empty(n, np.int32))
+            K = len(chunks)
+            sids, fids, rids = [None] * K, [None] * K, [None] * K
+
+            def site_stage(k):  # queued on the copy stream (in front of the records of chunk k - 1 ... k): no host wait
+                held, hs_k, hg_k, _ = chunk_sites[k]
+                sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"])
+
+            def read_stage(k):
+                a, b, _, dvc = chunks[k]
+                rr = eng.phase_raw(fids[k], rids[k], dvc, P, mode)
+                for key in out:
+                    out[key][a:b] = rr[key]
+                eng.free_reads(rids[k])
+                eng.free_sites(sids[k])
+
+            tr = [time.perf_counter()] if trace is not None else None
+
+            def tick():
+                if tr is not None:
+                    tr.append(time.perf_counter())
+            site_stage(0)
+            tick()
+            for k in range(K):
+                eng.find(fids[k], chunks[k][3], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
+                tick()
+                if k + 1 < K:
+                    site_stage(k + 1)
+                tick()
+                rids[k] = eng.upload_reads_packed(chunks[k][2])
+                tick()
+                if k >= 1:
+                    read_stage(k - 1)
+                tick()
+            read_stage(K - 1)
+            tick()
+            if tr is not None:
+                trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
+            return out
+
         def step_staged():
+            if chunk_sites:
+                return step_pipelined()
             t = [time.perf_counter()]
 
             def tick():
@@ -296,7 +375,9 @@ def main():
             return out
 
         res_s, el_s, prof_s, _ = timed(step_staged)
-        if trace:
+        if trace and chunk_sites:
+            print("[staged step, ms] site stage 0, then per chunk: find | next site stage | enqueue records | read stage of the chunk before; last read stage:", trace[-2:], file=sys.stderr)
+        elif trace:
             print("[staged step, ms] sites+family upload | find | enqueue read uploads | phase chunks | cnv + frees:", trace, file=sys.stderr)
             # where the link time goes: the copies alone, the kernels alone (tables already in HBM), both overlapped
             t0 = time.perf_counter()
@@ -312,8 +393,9 @@ def main():
             print("[staged, ms] copies + header builds alone %.1f (%.1f GB/s) | kernels alone %.1f" %
                   ((t1 - t0) * 1e3, staged_bytes / (t1 - t0) / 1e9, (t2 - t1) * 1e3), file=sys.stderr)
         mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
-        staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records, sites=int(site_sel.size),
-                      decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks))
+        staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records,
+                      decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks),
+                      sites=sum(x[3] for x in chunk_sites) if chunk_sites else int(site_sel.size), site_stage="per chunk" if chunk_sites else "whole batch")
         res = res_s
     else:
         res = res_r
@@ -416,7 +498,7 @@ def main():
             "generate_s": round(t_gen, 1),
         }
         if staged:
-            out["link"] = {"bytes_per_step": int(staged["bytes"]), "read_records_staged": int(staged["records"]), "sites_staged": staged["sites"],
+            out["link"] = {"bytes_per_step": int(staged["bytes"]), "read_records_staged": int(staged["records"]), "sites_staged": staged["sites"], "site_stage": staged["site_stage"],
                            "bytes_per_dnm": round(staged["bytes"] / n, 1),
                            "achieved_GBps": round(staged["bytes"] * args.steps / staged["elapsed"] / 1e9, 2), "peak_GBps": 64.0,
                            "chunks": staged["chunks"], "decode_s": round(staged["decode_s"], 1),

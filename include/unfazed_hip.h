@@ -66,6 +66,12 @@ int uz_sites_upload(uz_ctx *ctx, const uz_sites_view *sites, int *sites_id);
 /* Genotype columns of one trio -> HBM (gt_types / gt_ref_depths / gt_alt_depths /
  * gt_quals of informative_site_finder.py:257-260). */
 int uz_family_upload(uz_ctx *ctx, int sites_id, const uz_family_view *fam, int *fam_id);
+/* Both at once, asynchronously: the copies are queued on the library's copy stream (behind whatever uz_reads_upload_packed
+ * queued before) and the call returns; the first call that uses the family or the sites makes the compute stream wait for
+ * them.  The host arrays (pinned memory for link speed, uz_pinned_alloc) must stay untouched until such a call has returned.
+ * This is how a batch is streamed in sub-batches: the site stage of sub-batch k + 1 rides the link between the record
+ * tables of sub-batches k - 1 and k instead of stopping it. */
+int uz_sites_family_upload_async(uz_ctx *ctx, const uz_sites_view *sites, const uz_family_view *fam, int *sites_id, int *fam_id);
 /* Alignment records of one BAM -> HBM.  Replaces pysam.AlignmentFile + fetch +
  * mate (read_collector.py:372-385, :400, :167, :185).  Whatever form a table arrives in, HBM holds the packed
  * one (uz_reads_packed_view in uz_types.h).

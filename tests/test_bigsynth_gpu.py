@@ -120,8 +120,12 @@ def test_resident_pipeline_matches_oracle(workload, engine):
     for a, b in zip(bounds[:-1], bounds[1:]):
         alen = np.array([max(len(r), len(x)) for r, x in zip(dn.refs[a:b], dn.alts[a:b])], np.int64)
         fc, flo, fhi, fex = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P, allele_len=alen)
-        # chunks alternate between whole rows and the fetched 32-base units only (unit masks)
+        # chunks alternate between whole rows and the fetched 32-base units only (unit masks); every other chunk is carved from
+        # one pinned block, so its columns cross the link as ONE copy into a mirror block instead of one copy per column
+        if (a // 700) % 2 == 1:
+            pool.new_slab(256 << 20)
         part = src.select(fc, flo, fhi, alloc=pool.alloc, extra=fex if (a // 700) % 2 == 0 else None, tuples=(a // 700) % 3 != 2)
+        pool.end_slab()
         staged_bytes += sum(x.nbytes for x in part.arrays.values())
         part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))  # (plain views for the checks below; not staged)
         if "umask" in part.arrays:

@@ -116,3 +116,47 @@ def test_cohort_scan_matches_per_family_scans(engine, n_sites, n_fam):
     with pytest.raises(Exception):
         engine.site_scan_many([fams[0], fams[0]])
     engine.free_sites(sid)
+
+
+@pytest.mark.parametrize("slab", [False, True], ids=["column_copies", "one_slab_copy"])
+def test_asynchronous_site_stage_equals_the_synchronous_one(engine, slab):
+    """uz_sites_family_upload_async: sites + genotype columns queued on the copy stream, the first use waits for them and folds
+    the complex flag -- the same classes and the same windows as the synchronous uploads.  slab: the host columns sit back to
+    back in one pinned block and cross the link as ONE copy into a mirror block (abi.hip: SlabPlan)."""
+    from unfazed_amd.engine import PinnedPool
+    sc = make_sites(200_000, seed=21, contig_lens=[4e7, 2e7], weird_frac=0.03)
+    idx, contig, start, end = place_dnms(sc, 1500, seed=6)
+    n = len(start)
+    P = abi.make_params()
+    dv = abi.dnms_view(contig, [-1] * n, start, end, np.zeros(n, np.uint8), [b""] * n, [b""] * n, 0.0)
+    sid = engine.upload_sites(_Sites(sc))
+    fid = engine.add_family(sid, sc.gt, sc.rd, sc.ad, sc.gq)
+    want = engine.find(fid, dv, P, 0)
+    want_cls = engine.classify(fid, P, sc.n)
+    engine.free_sites(sid)
+    pool = PinnedPool()
+    if slab:
+        pool.new_slab(sc.n * 40 + (1 << 20))
+
+    def pin(a):
+        a = np.ascontiguousarray(a)
+        out = pool.alloc(max(64, a.nbytes))[: a.nbytes].view(a.dtype).reshape(a.shape)
+        out[...] = a
+        return out
+    cols = {k: pin(getattr(sc, k)) for k in ("pos", "sflags", "ref_base", "alt_base")}
+    cols["contig_off"] = pin(np.asarray(sc.contig_off, np.int64))
+    gt = pin(sc.gt)
+    rd, ad, gq = ([pin(x[m]) for m in range(3)] for x in (sc.rd, sc.ad, sc.gq))
+    sv = abi.SitesView()
+    sv.n_sites, sv.n_contigs = sc.n, len(sc.contig_off) - 1
+    for k, a in cols.items():
+        setattr(sv, k, a.ctypes.data)
+    for _ in range(2):  # twice: blocks (and the mirror) go back to the pool and are reused
+        sid2, fid2 = engine.upload_sites_family_async(abi.Held(sv, cols), gt, rd, ad, gq)
+        got = engine.find(fid2, dv, P, 0)
+        for a, b, name in zip(want, got, ("cand_off", "cand_idx", "cand_flags", "het_off", "het_idx")):
+            assert np.array_equal(a, b), name
+        assert np.array_equal(want_cls, engine.classify(fid2, P, sc.n))
+        engine.free_sites(sid2)
+    assert np.array_equal(gt, sc.gt)  # the host copy is never written (the complex flag is folded into the device's copy)
+    pool.free_all()

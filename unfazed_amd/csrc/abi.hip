@@ -39,13 +39,58 @@ T *upload(uz_ctx *c, const T *host, size_t n) {
     return d;
 }
 
+// One copy instead of one per column: when the host columns of a table sit back to back in one slab of (pinned) memory --
+// a decoder that carves its output from one allocation -- the slab goes over the link as a whole into a mirror block and
+// the columns' device addresses follow from their offsets in it.  Every separate copy costs the link ~8 us of set-up, and
+// a staged table has about twenty columns, half of them tiny.  A staging routine runs its h2d() calls twice: a planning
+// pass that only looks at the host addresses, then -- mirrored or not -- the pass that yields the device pointers.
+struct SlabPlan {
+    int mode = 1; // 1 planning, 2 mirrored
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    size_t sum = 0;
+    std::vector<const uint8_t *> at;
+    uint8_t *dev = nullptr;
+    void add(const void *p, size_t bytes) {
+        const uint8_t *q = (const uint8_t *)p;
+        if (!lo || q < lo) lo = q;
+        if (!hi || q + bytes > hi) hi = q + bytes;
+        sum += bytes;
+        at.push_back(q);
+    }
+    size_t span() const { return (size_t)(hi - lo); }
+    bool worth() const {
+        if (at.size() < 2 || span() > sum + sum / 8 + 1024 * at.size()) return false;
+        for (const uint8_t *q : at)
+            if ((size_t)(q - lo) % 256) return false; // the kernels' vector loads want the carver's alignment
+        return true;
+    }
+};
+static thread_local SlabPlan *g_slab = nullptr;
+struct SlabScope {
+    explicit SlabScope(SlabPlan *p) { g_slab = p; }
+    ~SlabScope() { g_slab = nullptr; }
+};
+static const bool g_slab_off = getenv("UZ_NO_SLAB_COPY") != nullptr;
+
 template <typename T>
 const T *h2d(hipStream_t st, T *dst, const T *host, size_t n) {
     if (n) {
         UZ_REQUIRE(host != nullptr, UZ_E_ARG, "null column pointer");
+        if (g_slab && g_slab->mode == 1) { g_slab->add(host, n * sizeof(T)); return dst; }
+        if (g_slab && g_slab->mode == 2) return reinterpret_cast<const T *>(g_slab->dev + ((const uint8_t *)host - g_slab->lo));
         UZ_HIP(hipMemcpyAsync(dst, host, n * sizeof(T), hipMemcpyHostToDevice, st));
     }
     return dst;
+}
+// after the planning pass: ship the slab (mirror: the device block that receives it) or fall back to column copies
+static void slab_commit(uz_ctx *c, hipStream_t st, SlabPlan &plan, DevBlock &mirror) {
+    if (!g_slab_off && plan.worth()) {
+        mirror = uz_block_get(c, plan.span() + 512);
+        UZ_HIP(hipMemcpyAsync(mirror.p, plan.lo, plan.span(), hipMemcpyHostToDevice, st));
+        plan.dev = mirror.p;
+        plan.mode = 2;
+    } else
+        g_slab = nullptr;
 }
 
 template <typename T>
@@ -67,11 +112,23 @@ int new_slot(std::vector<V> &v) {
 
 SitesDev &sites_of(uz_ctx *c, int id) {
     UZ_REQUIRE(id >= 0 && id < (int)c->sites.size() && c->sites[id].live, UZ_E_ARG, "unknown sites handle");
-    return c->sites[id];
+    SitesDev &s = c->sites[id];
+    if (s.pending) { // queued by uz_sites_family_upload_async
+        s.pending = false;
+        UZ_HIP(hipStreamWaitEvent(c->stream, s.ready, 0));
+    }
+    return s;
 }
 FamilyDev &fam_of(uz_ctx *c, int id) {
     UZ_REQUIRE(id >= 0 && id < (int)c->fams.size() && c->fams[id].live, UZ_E_ARG, "unknown family handle");
-    return c->fams[id];
+    FamilyDev &f = c->fams[id];
+    if (f.pending) { // queued by uz_sites_family_upload_async: the compute stream waits for the copies, then folds the complex flag
+        f.pending = false;
+        UZ_HIP(hipStreamWaitEvent(c->stream, f.ready, 0));
+        SitesDev &s = sites_of(c, f.sites_id);
+        uz_fold_complex(c, f.gt, s.sflags, s.n);
+    }
+    return f;
 }
 ReadsDev &reads_of(uz_ctx *c, int id) {
     UZ_REQUIRE(id >= 0 && id < (int)c->reads.size() && c->reads[id].live, UZ_E_ARG, "unknown reads handle");
@@ -79,16 +136,21 @@ ReadsDev &reads_of(uz_ctx *c, int id) {
 }
 
 void free_family(uz_ctx *c, FamilyDev &f) {
+    if (f.ready) { (void)hipEventSynchronize(f.ready); (void)hipEventDestroy(f.ready); f.ready = nullptr; }
+    f.pending = false;
     uz_block_put(c, f.block);
     f = FamilyDev();
 }
 void free_sites(uz_ctx *c, SitesDev &s) {
+    if (s.ready) { (void)hipEventSynchronize(s.ready); (void)hipEventDestroy(s.ready); }
     uz_block_put(c, s.block);
+    uz_block_put(c, s.mirror);
     s = SitesDev();
 }
 void free_reads(uz_ctx *c, ReadsDev &r) {
     if (r.ready) (void)hipEventDestroy(r.ready);
     uz_block_put(c, r.block);
+    uz_block_put(c, r.mirror);
     r = ReadsDev();
 }
 
@@ -363,6 +425,61 @@ int uz_family_upload(uz_ctx *c, int sites_id, const uz_family_view *v, int *id) 
     });
 }
 
+int uz_sites_family_upload_async(uz_ctx *c, const uz_sites_view *v, const uz_family_view *fv, int *sites_id, int *fam_id) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(v && fv && sites_id && fam_id && v->n_sites >= 0 && v->n_contigs >= 0, UZ_E_ARG, "bad sites / family view");
+        UZ_REQUIRE(v->n_sites < (int64_t)0x7FFFFFF0, UZ_E_RANGE, "more than 2^31 sites");
+        SitesDev s;
+        s.live = true; s.owned = true;
+        s.n = v->n_sites; s.n_contigs = v->n_contigs;
+        s.contig_off_h.assign(v->contig_off, v->contig_off + v->n_contigs + 1);
+        const size_t n = (size_t)s.n;
+        FamilyDev f;
+        f.owned = true;
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? s.block.p : nullptr);
+            s.contig_off = cv.take<int64_t>((size_t)v->n_contigs + 1);
+            s.pos = cv.take<int32_t>(n); s.sflags = cv.take<uint8_t>(n); s.ref_base = cv.take<uint8_t>(n); s.alt_base = cv.take<uint8_t>(n);
+            if (!pass) s.block = uz_block_get(c, cv.off + 256);
+        }
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? f.block.p : nullptr);
+            f.cls = cv.take<uint8_t>(n);
+            f.gt = cv.take<uint8_t>(n);
+            for (int m = 0; m < 3; m++) { f.rd[m] = cv.take<uint16_t>(n); f.ad[m] = cv.take<uint16_t>(n); f.gq[m] = cv.take<uint16_t>(n); }
+            if (!pass) f.block = uz_block_get(c, cv.off + 256);
+        }
+        try {
+            hipStream_t st = c->copy_stream;
+            SlabPlan plan;
+            SlabScope slab_scope(&plan);
+            for (int stage_pass = 0; stage_pass < 2; stage_pass++) {
+                if (stage_pass) slab_commit(c, st, plan, s.mirror);
+                s.contig_off = const_cast<int64_t *>(h2d(st, s.contig_off, v->contig_off, (size_t)v->n_contigs + 1));
+                s.pos = const_cast<int32_t *>(h2d(st, s.pos, v->pos, n)); s.sflags = const_cast<uint8_t *>(h2d(st, s.sflags, v->sflags, n));
+                s.ref_base = const_cast<uint8_t *>(h2d(st, s.ref_base, v->ref_base, n)); s.alt_base = const_cast<uint8_t *>(h2d(st, s.alt_base, v->alt_base, n));
+                f.gt = const_cast<uint8_t *>(h2d(st, f.gt, fv->gt, n)); // (bit 6 is written by the library: the mirror is the library's own memory)
+                for (int m = 0; m < 3; m++) {
+                    f.rd[m] = const_cast<uint16_t *>(h2d(st, f.rd[m], fv->ref_depth[m], n));
+                    f.ad[m] = const_cast<uint16_t *>(h2d(st, f.ad[m], fv->alt_depth[m], n));
+                    f.gq[m] = const_cast<uint16_t *>(h2d(st, f.gq[m], fv->gq[m], n));
+                }
+            }
+            UZ_HIP(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming));
+            UZ_HIP(hipEventRecord(f.ready, st));
+            UZ_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+            UZ_HIP(hipEventRecord(s.ready, st));
+            s.pending = true;
+        } catch (...) { uz_block_put(c, s.block); uz_block_put(c, s.mirror); uz_block_put(c, f.block); throw; }
+        const int ks = new_slot(c->sites);
+        c->sites[ks] = s;
+        f.live = true; f.sites_id = ks; f.pending = true;
+        const int kf = new_slot(c->fams);
+        c->fams[kf] = f;
+        *sites_id = ks; *fam_id = kf;
+    });
+}
+
 int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad family view");
@@ -500,9 +617,14 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
         if (!pass) r.block = uz_block_get(c, cv.off + 256);
     }
-    h2d(st, r.contig_off, v->contig_off, (size_t)v->n_contigs + 1);
-    h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs);
     RecColumns col;
+    SlabPlan plan;
+    SlabScope slab_scope(&plan);
+    for (int stage_pass = 0; stage_pass < 2; stage_pass++) {
+    if (stage_pass) slab_commit(c, st, plan, r.mirror);
+    col = RecColumns();
+    r.contig_off = const_cast<int64_t *>(h2d(st, r.contig_off, v->contig_off, (size_t)v->n_contigs + 1));
+    r.max_span = const_cast<int32_t *>(h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs));
     col.end = v->end ? h2d(st, end, v->end, n) : nullptr;
     if (d16) { // 16-bit differences + the escape list instead of four 32-bit columns
         col.start_d = h2d(st, d_start, v->start_d, n); col.tlen_s = h2d(st, d_tlen, v->tlen_s, n);
@@ -547,9 +669,10 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         col.qpos_wide = v->qlow_pos_wide;
         if (v->umask) col.umask = h2d(st, umask_in, v->umask, n);
     } else {
-        h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES);
-        col.plane_in = reinterpret_cast<const uint32_t *>(qlow);
+        r.qlow = const_cast<uint8_t *>(h2d(st, qlow, v->qlow, nu * UZ_QLOW_UNIT_BYTES));
+        col.plane_in = reinterpret_cast<const uint32_t *>(r.qlow);
     }
+    } // stage_pass
     r.qlow_thr = v->min_base_qual;
     r.qlow_valid = true;
     r.col_q[0] = col.plane_in; r.col_q[1] = col.n_low; r.col_q[2] = col.qlow_pos; r.col_q[3] = col.cigar_in; r.col_q[4] = col.umask; r.col_q[5] = col.cigar_staged; r.col_q[6] = col.cigar_out; r.col_qwide = col.qpos_wide;
@@ -669,7 +792,7 @@ int uz_reads_upload_packed(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             UZ_HIP(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
             UZ_HIP(hipEventRecord(r.ready, c->copy_stream));
             r.pending = true;
-        } catch (...) { uz_block_put(c, r.block); throw; }
+        } catch (...) { uz_block_put(c, r.block); uz_block_put(c, r.mirror); throw; }
         const int k = new_slot(c->reads);
         c->reads[k] = r;
         *id = k;
@@ -748,7 +871,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
                                           : f == 3 ? "exc_* columns: an entry names a record without bases, a base beyond l_seq or a code above 15"
                                                  : "n_cigar_total / n_row_units of the reads view do not match its columns"};
             }
-        } catch (...) { uz_block_put(c, r.block); throw; }
+        } catch (...) { uz_block_put(c, r.block); uz_block_put(c, r.mirror); throw; }
         const int k = new_slot(c->reads);
         c->reads[k] = r;
         *id = k;

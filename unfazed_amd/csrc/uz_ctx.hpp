@@ -56,12 +56,15 @@ struct DevBlock {
 struct SitesDev {
     bool live = false, owned = false;
     DevBlock block; // owned tables: every column in one pooled block
+    DevBlock mirror; // asynchronous upload of a slab of host columns: its image (sites + genotype columns; abi.hip: SlabPlan)
     int64_t n = 0;
     int32_t n_contigs = 0;
     std::vector<int64_t> contig_off_h;
     int64_t *contig_off = nullptr;
     int32_t *pos = nullptr;
     uint8_t *sflags = nullptr, *ref_base = nullptr, *alt_base = nullptr;
+    hipEvent_t ready = nullptr; // asynchronous upload: end of the copies on the copy stream; the first use waits for it
+    bool pending = false;
 };
 
 struct FamilyDev {
@@ -73,6 +76,10 @@ struct FamilyDev {
     uint16_t *ad[3] = {nullptr, nullptr, nullptr};
     uint16_t *gq[3] = {nullptr, nullptr, nullptr};
     uint8_t *cls = nullptr;
+    // asynchronous upload (uz_sites_family_upload_async): the copies are queued on the copy stream; `ready` marks their end and
+    // the first use of the family makes the compute stream wait for it and folds the complex flag (family_make_ready)
+    hipEvent_t ready = nullptr;
+    bool pending = false;
     bool cls_valid = false;
     bool cls_has_cnv = false; // DEL / DUP codes (bits 3-6) computed
     uz_params cls_params;
@@ -85,6 +92,7 @@ struct ReadsDev {
     uint32_t n_qnames = 0;
     int64_t n_cigar_total = 0, n_row_units = 0, n_seq_units = 0;
     DevBlock block;            // everything the library owns for this table lives in this one block
+    DevBlock mirror;           // ... except, when the host columns came over the link as one slab, the slab's image (abi.hip: SlabPlan)
     int64_t *contig_off = nullptr;
     int32_t *max_span = nullptr;
     void *rec_a = nullptr, *rec_b = nullptr; // RecA / RecB headers (phase_body.hpp)

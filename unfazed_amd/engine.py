@@ -18,7 +18,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait",
+    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -62,6 +62,7 @@ def load_library(path: Optional[str] = None):
         getattr(L, f).argtypes = [vp, vp, C.POINTER(C.c_int)]
     for f in ("uz_family_upload", "uz_family_adopt_device"):
         getattr(L, f).argtypes = [vp, C.c_int, vp, C.POINTER(C.c_int)]
+    L.uz_sites_family_upload_async.argtypes = [vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.uz_drop_derived.argtypes = [vp]
     L.uz_sites_free.argtypes = [vp, C.c_int]
     L.uz_reads_free.argtypes = [vp, C.c_int]
@@ -105,6 +106,7 @@ class HipEngine:
         self.device = device
         self._keep: List[object] = []
         self._staged = {}
+        self._staged_sites = {}
         self._params = None
 
     def close(self):
@@ -146,6 +148,15 @@ class HipEngine:
         self._ck(self.L.uz_family_upload(self.h, int(sites_h), v.ref(), C.byref(fid)), "uz_family_upload")
         return fid.value
 
+    def upload_sites_family_async(self, held: abi.Held, gt, rd, ad, gq):
+        """sites + one trio's genotype columns queued on the copy stream (uz_sites_family_upload_async) -> (sites id, family id);
+        the arrays (pinned) must stay alive until a call using the family has returned: the engine keeps them"""
+        v = abi.family_view(gt, rd, ad, gq)
+        sid, fid = C.c_int(-1), C.c_int(-1)
+        self._ck(self.L.uz_sites_family_upload_async(self.h, held.ref(), v.ref(), C.byref(sid), C.byref(fid)), "uz_sites_family_upload_async")
+        self._staged_sites[sid.value] = (held, v)
+        return sid.value, fid.value
+
     def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False) -> int:
         """A decoded table -> HBM.  With the base-quality threshold of the run (min_base_qual = --min-gt-qual) the table
         goes over the link in the staged form (packed on the host into pinned memory, several times fewer bytes); without it
@@ -160,6 +171,9 @@ class HipEngine:
         if min_base_qual is not None:
             from . import io_native
             pool = PinnedPool()
+            # the staged columns back to back in one pinned block (they cross the link as one copy); the packed form is at most half
+            # the size of the ASCII table, usually a small fraction
+            pool.new_slab(sum(int(getattr(x, "nbytes", 0)) for x in v.arrays.values()) // 2 + (1 << 20))
             if fetches is not None and point_only:
                 full = io_native.pack_reads(v, int(min_base_qual), lists=True, with_end=True)
                 fc, flo, fhi, fex = fetches
@@ -206,6 +220,7 @@ class HipEngine:
 
     def free_sites(self, sid: int):
         self._ck(self.L.uz_sites_free(self.h, int(sid)), "uz_sites_free")
+        self._staged_sites.pop(int(sid), None)
 
     def free_reads(self, rid: int):
         self._ck(self.L.uz_reads_free(self.h, int(rid)), "uz_reads_free")
@@ -365,9 +380,34 @@ class PinnedPool:
     def __init__(self):
         self.L = load_library()
         self._blocks = []
+        self._slab = None  # [base address, capacity, used]: alloc() carves from it while it lasts
+        self.last_slab_used = 0
+
+    def new_slab(self, nbytes: int):
+        """The allocations that follow come back to back (256-byte aligned) out of ONE page-locked block of `nbytes`: the
+        columns of a table staged this way cross the link as one copy (abi.hip: SlabPlan).  What does not fit any more gets
+        a block of its own, as without a slab."""
+        nbytes = max(1 << 20, int(nbytes))
+        p = C.c_void_p()
+        if self.L.uz_pinned_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+            raise MemoryError("uz_pinned_alloc(%d) failed" % nbytes)
+        self._blocks.append(p.value)
+        self.last_slab_used = self._slab[2] if self._slab else 0
+        self._slab = [p.value, nbytes, 0]
+
+    def end_slab(self) -> int:
+        used = self._slab[2] if self._slab else 0
+        self._slab = None
+        return used
 
     def alloc(self, nbytes: int) -> np.ndarray:
         nbytes = max(64, int(nbytes))
+        if self._slab is not None:
+            at = (self._slab[2] + 255) & ~255
+            if at + nbytes <= self._slab[1]:
+                self._slab[2] = at + nbytes
+                buf = (C.c_uint8 * nbytes).from_address(self._slab[0] + at)
+                return np.frombuffer(buf, dtype=np.uint8, count=nbytes)
         p = C.c_void_p()
         if self.L.uz_pinned_alloc(nbytes, C.byref(p)) != 0 or not p.value:
             raise MemoryError("uz_pinned_alloc(%d) failed" % nbytes)
@@ -379,3 +419,4 @@ class PinnedPool:
         for p in self._blocks:
             self.L.uz_pinned_free(C.c_void_p(p))
         self._blocks = []
+        self._slab = None
