@@ -257,6 +257,10 @@ def main():
             pool.new_slab(slab_hint)
             part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=not cnv, extra=None if cnv else fex)
             slab_hint = max(64 << 20, int(pool.end_slab() * 1.3))
+            if os.environ.get("UZ_BENCH_LINK_BYTES") and not chunks:  # development aid: the first chunk, column by column
+                nrec = int(part.view.n_segs)
+                print("[link bytes] %d records for %d DNMs:" % (nrec, b - a), {k: (int(x.nbytes), round(x.nbytes / max(1, b - a), 1)) for k, x in part.arrays.items()},
+                      file=sys.stderr)
             del src, part_full
             chunks.append((a, b, part, view_of(a, b)))
             staged_records += int(part.view.n_segs)

@@ -227,7 +227,12 @@ typedef struct uz_reads_packed_view {
      * other units of a 151-base read (usually four of its five) at home.  Bit u = unit u (bases 32u .. 32u+31) for a read of up
      * to 480 bases; UZ_UMASK_ALL (0xFFFF) = every unit (any length; what a record with a multi-operation CIGAR gets).  The base
      * row then holds the staged units back to back; n_seq_units counts staged units; exc_* entries in other units are ignored.
-     * A kernel that asks for a base of a unit that stayed home raises UZ_E_STATE. */
+     * A kernel that asks for a base of a unit that stayed home raises UZ_E_STATE.
+     * The quality lists follow the mask: of a listed record only the positions INSIDE its staged units need to travel (the
+     * quality row the device rebuilds has no other units), and n_low of such a record may be the length of that shorter
+     * list instead of the full count -- all the read filter asks of the count is "at most UZ_QLOW_LIST_MAX", which a
+     * subset keeps true (uz_reads_select_* stages them so; a record with more than UZ_QLOW_LIST_MAX keeps its full,
+     * saturated count and no list). */
     const uint16_t *umask;    /* [n_segs] */
     int64_t n_cigar_omitted;  /* cigar_compact: records with a simple code (each stands for one word) */
     /* The small columns as a dictionary (NULL: the plain columns).  flag, l_seq, n_cigar, mapq, aux and n_low take a few hundred

@@ -313,6 +313,26 @@ def test_kernel_body_stays_inside_the_staged_units():
         units = abi.row_units(part.arrays["l_seq"][:m])
         kept = np.where(part.arrays["umask"][:m] == abi.UMASK_ALL, units, [bin(int(x)).count("1") for x in part.arrays["umask"][:m]])
         assert part.view.n_seq_units == int(kept[with_b].sum()) < 0.5 * int(units[with_b].sum())
+        # the listed low-quality positions: only those inside the staged units travel, and the count that travels with a listed
+        # record is the length of that list (a record with more than ten keeps its full, saturated count and no list)
+        full = src.packed
+        true_low = full.arrays["n_low"][idx]
+        n_low = part.arrays["n_low"][:m]
+        listed = with_b & (true_low <= abi.QLOW_LIST_MAX)
+        assert np.array_equal(n_low[~listed], true_low[~listed])
+        off = np.concatenate([[0], np.cumsum(np.where(listed, n_low, 0).astype(np.int64))]).astype(np.int64)
+        assert off[-1] == part.view.n_qlow_pos
+        foff = np.concatenate([[0], np.cumsum(np.where(((full.arrays["aux"][:N] & abi.AUX_NO_SEQ) == 0) & (full.arrays["n_low"][:N] <= abi.QLOW_LIST_MAX),
+                                                        full.arrays["n_low"][:N], 0).astype(np.int64))]).astype(np.int64)
+        total_true = 0
+        for k in np.nonzero(listed)[0][::7]:
+            i = int(idx[k])
+            all_pos = full.arrays["qlow_pos"][int(foff[i]): int(foff[i + 1])].astype(np.int64)
+            mk = int(part.arrays["umask"][k])
+            want_pos = all_pos if mk == abi.UMASK_ALL else all_pos[((mk >> (all_pos >> 5)) & 1) == 1]
+            assert np.array_equal(part.arrays["qlow_pos"][int(off[k]): int(off[k + 1])].astype(np.int64), want_pos)
+            total_true += all_pos.size
+        assert off[-1] < 0.6 * int(true_low[listed].sum())
         return um, no_seq
 
     um, no_seq = masks_of(np.ones(fc.size, bool))

@@ -79,6 +79,26 @@ static inline int src_low_count(const uz_psrc *src, int64_t i) {
     return c > 255 ? 255 : c;
 }
 
+// the low-quality positions of record i (ascending), each handed to fn -- from the source's lists or its plane
+template <typename F>
+static inline void src_low_positions(const uz_psrc *src, int64_t i, F &&fn) {
+    const uz_reads_packed_view *f = &src->v;
+    if (f->n_low) {
+        if ((f->aux[i] & UZ_AUX_NO_SEQ) || f->n_low[i] > UZ_QLOW_LIST_MAX) return; // (no list)
+        for (int e = 0; e < (int)f->n_low[i]; e++) {
+            const uint64_t from = src->loff[(size_t)i] + (uint64_t)e;
+            fn(f->qlow_pos_wide ? (int)f->qlow_pos[2 * from] | ((int)f->qlow_pos[2 * from + 1] << 8) : (int)f->qlow_pos[from]);
+        }
+        return;
+    }
+    const uint8_t *row = f->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES;
+    const int ls = f->l_seq[i];
+    for (int b = 0; b < ls; b++)
+        if ((row[b >> 3] >> (b & 7)) & 1) fn(b);
+}
+// is base b of a record inside the 32-base units the mask keeps?
+static inline bool unit_kept(uint16_t m16, int b) { return m16 == UZ_UMASK_ALL || ((m16 >> (b >> 5)) & 1); }
+
 struct uz_select {
     const uz_psrc *src = nullptr;
     int64_t n_sel = 0;
@@ -466,9 +486,20 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                     const int64_t i = sel->index[(size_t)k];
                     if (full->end[i] != uz_bam_endpos(full->start[i], full->flag[i], full->n_cigar[i], full->cigar + src->coff[(size_t)i]))
                         __atomic_store_n(&sel->end_derivable, 0, __ATOMIC_RELAXED);
-                    const int low = src_low_count(src, sel->index[(size_t)k]);
+                    int low = src_low_count(src, sel->index[(size_t)k]);
+                    if (sel->bases[(size_t)k] && low <= UZ_QLOW_LIST_MAX) {
+                        // a listed record: with unit masks only the positions inside the staged units travel -- no bit of any
+                        // other unit can be asked for (uz_types.h) -- and the count that travels is the length of that list;
+                        // "at most UZ_QLOW_LIST_MAX low-quality bases", all the read filter wants of the count, stays true
+                        if (!sel->umask.empty() && sel->umask[(size_t)k] != UZ_UMASK_ALL) {
+                            const uint16_t m16 = sel->umask[(size_t)k];
+                            int kept = 0;
+                            src_low_positions(src, i, [&](int b) { kept += unit_kept(m16, b); });
+                            low = kept;
+                        }
+                        c += low;
+                    }
                     sel->n_low[(size_t)k] = (uint8_t)low;
-                    if (sel->bases[(size_t)k] && low <= UZ_QLOW_LIST_MAX) c += low;
                 }
                 part[(size_t)slice] = c;
             });
@@ -638,6 +669,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
             const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
             os[k + 1] = os[k] + (s->bases[k] ? (m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16)) : 0);
         }
+        int list_mismatch = 0;
         parallel_slices(m, wk_fill, [&](int64_t a, int64_t b, int slice) {
             int64_t esc_next = d16 ? esc_at[(size_t)slice] : 0;
             for (int64_t k = a; k < b; k++) {
@@ -708,21 +740,15 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                             else w(out->qlow_pos)[at] = (uint8_t)b;
                             at++;
                         };
-                        if (full->n_low) { // list -> list
-                            for (int e = 0; e < (int)s->n_low[(size_t)k]; e++) {
-                                const uint64_t from = src->loff[(size_t)i] + (uint64_t)e;
-                                put(full->qlow_pos_wide ? (int)full->qlow_pos[2 * from] | ((int)full->qlow_pos[2 * from + 1] << 8) : (int)full->qlow_pos[from]);
-                            }
-                        } else { // plane -> list
-                            const uint8_t *row = full->qlow + (size_t)src->uoff[i] * UZ_QLOW_UNIT_BYTES;
-                            for (int b = 0; b < (int)full->l_seq[i]; b++)
-                                if ((row[b >> 3] >> (b & 7)) & 1) put(b);
-                        }
+                        const uint16_t keep16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
+                        src_low_positions(src, i, [&](int b) { if (unit_kept(keep16, b)) put(b); }); // (the staged units only)
+                        if (at != ol[(size_t)k + 1]) __atomic_store_n(&list_mismatch, 1, __ATOMIC_RELAXED);
                     }
                 }
                 if (orig_index) orig_index[k] = (int32_t)i;
             }
         });
+        if (list_mismatch) fail(UZ_IO_E_FORMAT, "listed low-quality positions of the source do not add up to the planned counts");
     });
 }
 
