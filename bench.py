@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--workload", choices=["snv", "cnv"], default="snv",
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
-    ap.add_argument("--chunks", type=int, default=12, help="DNM chunks of the staged pass (uploads overlap the kernels)")
+    ap.add_argument("--chunks", type=int, default=10, help="DNM chunks of the staged pass (uploads overlap the kernels)")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -266,7 +266,7 @@ def main():
             staged_records += int(part.view.n_segs)
             pv = part.view
             lists_f = bool(pv.n_low) or bool(pv.tup and pv.tup_n_low)
-            fixed = (8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
+            fixed = (7 if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
             staged_bytes += (int(pv.n_segs) * fixed + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
                              + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
                              + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))

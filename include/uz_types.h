@@ -263,7 +263,12 @@ typedef struct uz_reads_packed_view {
     const uint64_t *esc16_key;   /* [n_esc16] */
     const int32_t *esc16_val;
     int64_t n_esc16;
+    /* start_d in eight bits (then start_d is NULL; tlen_s / mate_d / qname_d as above): consecutive records of a pile-up start a
+     * few bases apart, so the difference is 0 .. 254 for all but the first record of a region; UZ_D8_ESC (255) = in the escape
+     * list (column 0), as for start_d. */
+    const uint8_t *start_d8;
 } uz_reads_packed_view;
+#define UZ_D8_ESC 255
 #define UZ_D16_ESC (-32768)
 #define UZ_D16_NONE (-32767)
 #define UZ_UMASK_ALL 0xFFFFu

@@ -124,7 +124,8 @@ def test_resident_pipeline_matches_oracle(workload, engine):
         # one pinned block, so its columns cross the link as ONE copy into a mirror block instead of one copy per column
         if (a // 700) % 2 == 1:
             pool.new_slab(256 << 20)
-        part = src.select(fc, flo, fhi, alloc=pool.alloc, extra=fex if (a // 700) % 2 == 0 else None, tuples=(a // 700) % 3 != 2)
+        part = src.select(fc, flo, fhi, alloc=pool.alloc, extra=fex if (a // 700) % 2 == 0 else None, tuples=(a // 700) % 3 != 2,
+                          start8=(a // 700) % 2 == 1)  # (start differences in eight / sixteen bits)
         pool.end_slab()
         staged_bytes += sum(x.nbytes for x in part.arrays.values())
         part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))  # (plain views for the checks below; not staged)

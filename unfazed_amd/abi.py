@@ -174,6 +174,7 @@ class ReadsPackedView(C.Structure):
         ("tup_umask", _p),
         # start / tlen / mate / qname as 16-bit differences + an escape list
         ("start_d", _p), ("tlen_s", _p), ("mate_d", _p), ("qname_d", _p), ("esc16_key", _p), ("esc16_val", _p), ("n_esc16", C.c_int64),
+        ("start_d8", _p),  # the start differences in eight bits (start_d then NULL)
     ]
 
 
@@ -191,7 +192,7 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None) -> "Held":
+                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -249,7 +250,9 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
             arrs[name] = alloc(np.dtype(dt).itemsize * max(1, n_tup))[: np.dtype(dt).itemsize * max(1, n_tup)].view(dt)
         v.n_tup = n_tup
     if n_esc16 is not None:
-        for name in ("start_d", "tlen_s", "mate_d", "qname_d"):
+        if start8:
+            arrs["start_d8"] = alloc(max(1, n))[: max(1, n)]
+        for name in ("tlen_s", "mate_d", "qname_d") if start8 else ("start_d", "tlen_s", "mate_d", "qname_d"):
             arrs[name] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.int16)
         arrs["esc16_key"] = alloc(8 * max(1, n_esc16))[: 8 * max(1, n_esc16)].view(np.uint64)
         arrs["esc16_val"] = alloc(4 * max(1, n_esc16))[: 4 * max(1, n_esc16)].view(np.int32)
@@ -266,17 +269,17 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
 def wide_columns(held: "Held") -> dict:
     """start, tlen, mate, qname of a packed view as plain per-record arrays, whichever way it carries them."""
     a, n = held.arrays, int(held.view.n_segs)
-    if "start_d" not in a:
+    if "start_d" not in a and "start_d8" not in a:
         return {k: a[k][:n] for k in ("start", "tlen", "mate", "qname")}
     ne = int(held.view.n_esc16)
     key, val = a["esc16_key"][:ne], a["esc16_val"][:ne].astype(np.int64)
     assert np.all(np.diff(key.astype(np.int64)) > 0)
     out = {}
-    for col, (name, src) in enumerate((("start", "start_d"), ("tlen", "tlen_s"), ("mate", "mate_d"), ("qname", "qname_d"))):
+    for col, (name, src) in enumerate((("start", "start_d8" if "start_d8" in a else "start_d"), ("tlen", "tlen_s"), ("mate", "mate_d"), ("qname", "qname_d"))):
         v = a[src][:n].astype(np.int64)
         sel = (key & np.uint64(3)) == col
         rec = (key[sel] >> np.uint64(2)).astype(np.int64)
-        assert np.array_equal(np.nonzero(v == -32768)[0], rec)
+        assert np.array_equal(np.nonzero(v == (255 if src == "start_d8" else -32768))[0], rec)
         v[rec] = val[sel]
         if name in ("start", "qname"):
             v = np.cumsum(v) & 0xFFFFFFFF

@@ -113,6 +113,7 @@ struct uz_select {
     std::vector<uint8_t> tup_low;
     std::vector<uint16_t> tup_um;       // (unit mask of the combination when the selection has masks)
     int64_t n_esc16 = 0;                // escapes of the 16-bit difference form of start / tlen / mate / qname (uz_d16_of)
+    int64_t n_esc16_start8 = 0;         // ... when the start differences travel in eight bits (start_d8)
     int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
@@ -123,7 +124,8 @@ struct uz_select {
 
 // start / tlen / mate / qname of kept record k as 16-bit differences (uz_reads_packed_view.start_d ...): v[c] the column values,
 // e[c] the escape value where v[c] == UZ_D16_ESC (columns 0 start, 1 tlen, 2 mate, 3 qname); returns the number of escapes
-static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t e[4]) {
+// start8: the start difference is to fit EIGHT bits (0 .. 254; uz_reads_packed_view.start_d8): anything else escapes
+static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t e[4], bool start8 = false) {
     const uz_reads_packed_view *f = &s->src->v;
     const int64_t i = s->index[(size_t)k];
     const int64_t ip = k > 0 ? s->index[(size_t)k - 1] : -1;
@@ -133,7 +135,9 @@ static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t
         else { v[c] = (int16_t)UZ_D16_ESC; e[c] = (int32_t)esc_val; n++; }
     };
     const int64_t ds = (int64_t)f->start[i] - (ip >= 0 ? (int64_t)f->start[ip] : 0);
-    put(0, ds, ds);
+    if (!start8) put(0, ds, ds);
+    else if (ds >= 0 && ds <= 254) v[0] = (int16_t)ds;
+    else { v[0] = (int16_t)UZ_D16_ESC; e[0] = (int32_t)ds; n++; }
     put(1, f->tlen[i], f->tlen[i]);
     const int32_t mt = f->mate[i];
     int64_t nm = -1;
@@ -535,14 +539,16 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
         { // escapes of the 16-bit difference form (counted whether or not the output will use it: cheap)
             const int wk = workers_for(sel->n_sel, threads, 1 << 14);
             std::vector<int64_t> part((size_t)wk + 1, 0);
+            std::vector<int64_t> part8((size_t)wk + 1, 0);
             parallel_slices(sel->n_sel, wk, [&](int64_t a, int64_t b, int slice) {
-                int64_t c = 0;
+                int64_t c = 0, c8 = 0;
                 int16_t v[4];
                 int32_t e[4];
-                for (int64_t k = a; k < b; k++) c += uz_d16_of(sel, k, v, e);
+                for (int64_t k = a; k < b; k++) { c += uz_d16_of(sel, k, v, e); c8 += uz_d16_of(sel, k, v, e, true); }
                 part[(size_t)slice] = c;
+                part8[(size_t)slice] = c8;
             });
-            for (int k = 0; k < wk; k++) sel->n_esc16 += part[(size_t)k];
+            for (int k = 0; k < wk; k++) { sel->n_esc16 += part[(size_t)k]; sel->n_esc16_start8 += part8[(size_t)k]; }
         }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
@@ -568,6 +574,7 @@ int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
 int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
 int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
 int64_t uz_select_n_esc16(const uz_select *s) { return s ? s->n_esc16 : 0; }
+int64_t uz_select_n_esc16_start8(const uz_select *s) { return s ? s->n_esc16_start8 : 0; }
 int64_t uz_select_n_tuples(const uz_select *s) { return (s && s->tuples) ? (int64_t)s->tup_key.size() : -1; }
 int64_t uz_select_n_cigar_omitted(const uz_select *s) { return s ? s->n_cigar_simple : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
@@ -596,10 +603,13 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (!two_bit && !out->seq4 && s->n_seq) fail(UZ_IO_E_ARG, "the source table has four-bit base rows: the output view needs seq4");
         out->n_exc = two_bit ? s->n_exc : 0;
         if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
-        const bool d16 = out->start_d != nullptr;
-        if (d16 && (!out->tlen_s || !out->mate_d || !out->qname_d || (s->n_esc16 && (!out->esc16_key || !out->esc16_val))))
-            fail(UZ_IO_E_ARG, "the 16-bit difference form needs start_d, tlen_s, mate_d, qname_d and the esc16_* list");
-        out->n_esc16 = d16 ? s->n_esc16 : 0;
+        const bool start8 = out->start_d8 != nullptr;
+        const bool d16 = out->start_d != nullptr || start8;
+        if (start8 && out->start_d) fail(UZ_IO_E_ARG, "start_d and start_d8 are both set");
+        const int64_t n_esc = start8 ? s->n_esc16_start8 : s->n_esc16;
+        if (d16 && (!out->tlen_s || !out->mate_d || !out->qname_d || (n_esc && (!out->esc16_key || !out->esc16_val))))
+            fail(UZ_IO_E_ARG, "the 16-bit difference form needs start_d (or start_d8), tlen_s, mate_d, qname_d and the esc16_* list");
+        out->n_esc16 = d16 ? n_esc : 0;
         std::vector<int64_t> esc_at; // first escape of every slice of the fill loop below
         const int wk_fill = workers_for(m, threads, 4096);
         if (d16) {
@@ -608,7 +618,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 int64_t c = 0;
                 int16_t v[4];
                 int32_t e[4];
-                for (int64_t k = a; k < b; k++) c += uz_d16_of(s, k, v, e);
+                for (int64_t k = a; k < b; k++) c += uz_d16_of(s, k, v, e, start8);
                 part[(size_t)slice + 1] = c;
             });
             for (int k = 0; k < wk_fill; k++) part[(size_t)k + 1] += part[(size_t)k];
@@ -678,8 +688,10 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 if (d16) {
                     int16_t v[4];
                     int32_t e[4];
-                    uz_d16_of(s, k, v, e);
-                    w(out->start_d)[k] = v[0]; w(out->tlen_s)[k] = v[1]; w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3];
+                    uz_d16_of(s, k, v, e, start8);
+                    if (start8) w(out->start_d8)[k] = v[0] == (int16_t)UZ_D16_ESC ? (uint8_t)UZ_D8_ESC : (uint8_t)v[0];
+                    else w(out->start_d)[k] = v[0];
+                    w(out->tlen_s)[k] = v[1]; w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3];
                     for (int c = 0; c < 4; c++)
                         if (v[c] == (int16_t)UZ_D16_ESC) {
                             w(out->esc16_key)[esc_next] = ((uint64_t)k << 2) | (uint64_t)c;

@@ -162,6 +162,14 @@ __device__ __forceinline__ uint32_t d16_val(const RecColumns &c, const int16_t *
     const int v = col[i];
     return (uint32_t)(v == UZ_D16_ESC ? esc16_of(c, i, k) : v);
 }
+// the start difference of record i: sixteen bits, or eight (start_d8)
+__device__ __forceinline__ uint32_t start_diff(const RecColumns &c, int64_t i) {
+    if (c.start_d8) {
+        const uint32_t x = c.start_d8[i];
+        return x == UZ_D8_ESC ? (uint32_t)esc16_of(c, i, 0) : x;
+    }
+    return d16_val(c, c.start_d, i, 0);
+}
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
             uint32_t v[UZ_PK_SUMS];
             const RecSmall r = rec_small(c, i);
             pk_vals(r.nc, r.ls, r.aux, r.nl, r.um, v);
-            if (c.start_d) { v[5] = d16_val(c, c.start_d, i, 0); v[6] = d16_val(c, c.qname_d, i, 3); }
+            if (c.tlen_s) { v[5] = start_diff(c, i); v[6] = d16_val(c, c.qname_d, i, 3); }
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -231,7 +239,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         const uint32_t um = rs.um;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
         pk_vals(nc, ls, ax, nl, um, v);
-        if (c.start_d && in) { v[5] = d16_val(c, c.start_d, i, 0); v[6] = d16_val(c, c.qname_d, i, 3); }
+        if (c.tlen_s && in) { v[5] = start_diff(c, i); v[6] = d16_val(c, c.qname_d, i, 3); }
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++) {
             uint32_t x = v[k];
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             // the four wide columns: plain, or from their 16-bit differences (start and name id: running sums, this record included)
             int32_t st0, tl0, mt0;
             uint32_t qn0;
-            if (c.start_d) {
+            if (c.tlen_s) {
                 st0 = (int32_t)(uint32_t)(run[5] + pre[5] + inc[5]);
                 qn0 = (uint32_t)(run[6] + pre[6] + inc[6]);
                 tl0 = (int32_t)d16_val(c, c.tlen_s, i, 1);
