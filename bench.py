@@ -85,6 +85,32 @@ def pinned_copy(pool, a):
     return out
 
 
+def bind_near_gpu(torch, local_rank):
+    """Run (and allocate the pinned staging memory: first touch) on the CPUs of the GPU's own NUMA node: a host-to-device copy
+    out of the other socket's memory crosses the socket link first.  Best effort (sysfs); UZ_BENCH_NO_NUMA=1 leaves the process
+    where the launcher put it.  -> the node, or None"""
+    if os.environ.get("UZ_BENCH_NO_NUMA"):
+        return None
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        bind_near_gpu.before = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     if args.workload == "cnv" and "--dnms" not in " ".join(sys.argv) and "UZ_BENCH_DNMS" not in os.environ:
@@ -102,6 +128,7 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X GPU: there is no CPU fallback for the phasing path")
     torch.cuda.set_device(local_rank)
+    numa = bind_near_gpu(torch, local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -475,6 +502,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
+        if getattr(bind_near_gpu, "before", None):  # the CPU baseline gets every core of the box back
+            os.sched_setaffinity(0, bind_near_gpu.before)
         cpu = cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, res, ev_vt, ev_refs, ev_alts, cnv)
 
     if rank == 0:
@@ -499,7 +528,7 @@ def main():
             "kernels_ms_per_step": kern_ms(prof_r),
             "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist(),
                       "dnms_redone_by_hbm_build_of_k_phase": getattr(timed, "hbm_build_dnms", None)},
-            "generate_s": round(t_gen, 1),
+            "generate_s": round(t_gen, 1), "numa_node": numa,
         }
         if staged:
             out["link"] = {"bytes_per_step": int(staged["bytes"]), "read_records_staged": int(staged["records"]), "sites_staged": staged["sites"], "site_stage": staged["site_stage"],
