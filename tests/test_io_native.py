@@ -385,3 +385,26 @@ def test_vcf_region_decode_through_the_tabix_index(tmp_path):
         io_native.read_vcf_table_regions(path, [7], [0], [10])
     with pytest.raises(io_native.IoError):
         io_native.read_vcf_table_regions(path, [0], [0], [10], tbi=path)  # not a tabix index
+
+
+def test_session_asks_the_tabix_index_for_the_batch_windows(tmp_path, monkeypatch):
+    """session.site_regions: DNM windows (+- search_dist, whole events) in the index's own sequence names -- the chr prefix is
+    decided by the FIRST sequence of the index (= the first record of the file, utils.py:46-52), DNMs on sequences the file does
+    not have ask for nothing; no index, UZ_IO_INDEX=0 or the Python decoders: None (decode the file)."""
+    from filesio import write_bgzf_text, write_tbi
+    from unfazed_amd import session
+    path = os.path.join(str(tmp_path), "sites.vcf.gz")
+    write_bgzf_text(path, _big_vcf_text(n_per_contig=300), block_bytes=20000)
+    dnms = [dict(chrom="1", start=50_000, end=50_001), dict(chrom="chrX", start=1200, end=90_000), dict(chrom="7", start=5, end=6),
+            dict(chrom="chr2", start=100, end=101)]
+    assert session.site_regions(path, dnms, 5000) is None  # no index yet
+    write_tbi(path)
+    got = session.site_regions(path, dnms, 5000)
+    assert got == ((0, 44_998, 55_003), (1, 0, 5_103), (2, 0, 95_002))
+    monkeypatch.setenv("UZ_IO_INDEX", "0")
+    assert session.site_regions(path, dnms, 5000) is None
+    monkeypatch.delenv("UZ_IO_INDEX")
+    key, table = session.load_sites(path, got)
+    whole = io_native.read_vcf_table(path)
+    assert "@" in key and 0 < table.pos.size < whole.pos.size and table.contigs == whole.contigs
+    del session._SITES[key]
