@@ -54,6 +54,7 @@ def parse():
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=10, help="DNM chunks of the staged pass (uploads overlap the kernels)")
+    ap.add_argument("--last-chunk", type=float, default=0.5, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -267,7 +268,11 @@ def main():
         nchunk = max(1, min(args.chunks, n))
         chunks, staged_bytes, staged_records = [], 0, 0
         slab_hint = 768 << 20
-        ecuts = [n * k // nchunk for k in range(nchunk + 1)]  # chunks of events; their records: the clusters of their generator entries
+        # chunks of events (their records: the clusters of their generator entries); the last one smaller (--last-chunk): its read
+        # stage is the only one nothing hides -- the link is idle by then
+        f_last = min(1.0, max(0.05, args.last_chunk))
+        unit = n / (nchunk - 1 + f_last)
+        ecuts = [min(n, int(round(unit * k))) for k in range(nchunk)] + [n]
         for k in range(nchunk):
             a, b = ecuts[k], ecuts[k + 1]
             if b <= a:
