@@ -18,7 +18,7 @@ HALF_WIDTH = 6000
 
 
 def _build(target, cmd):
-    deps = [os.path.join(_HERE, "uzsynth.h")] + [c for c in cmd if c.endswith((".c", ".hip"))]
+    deps = [os.path.join(_HERE, "uzsynth.h")] + [c for c in cmd if c.endswith((".c", ".hip", ".cpp"))]
 
     def stale():
         return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(d) for d in deps)
@@ -41,6 +41,12 @@ def build_hip():
     return _build(os.path.join(_HERE, "libuzsynth_hip.so"),
                   [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
                    "-shared", "-I", _HERE, os.path.join(_HERE, "uzsynth_hip.hip")])
+
+
+def build_files():
+    """the file writer (synth/uzfiles.cpp): BAM + BAI, BGZF VCF + TBI"""
+    return _build(os.path.join(_HERE, "libuzsynth_files.so"),
+                  ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", _HERE, os.path.join(_HERE, "uzfiles.cpp"), "-lz"])
 
 
 class Cfg(C.Structure):
@@ -173,6 +179,65 @@ def reads_cpu(cfg, sc, dn, cl, c0, c1, threads=1):
     v.n_sq_bytes = n * ROW
     v.n_qnames = n // 2
     return abi.Held(v, arrs), arrs
+
+
+def qname_of(pair: int) -> str:
+    """query name the file writer gives global pair number `pair` (uzs_qname)"""
+    return "UZSYN:30X:1:%03d:%07d" % (pair % 997, pair // 997)
+
+
+def _names_array(names):
+    arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    return arr
+
+
+def write_bam(path, cfg, sc, dn, cl, c0=0, c1=None, contig_len=None, level=6, tags=True, threads=0, bai=True):
+    """Clusters [c0, c1) as a coordinate-sorted BAM (+ BAI next to it): the records reads_cpu() generates for the same range,
+    query names qname_of(global pair).  -> dict(records, raw_bytes, file_bytes, blocks)"""
+    L = C.CDLL(build_files())
+    c1 = cl.n if c1 is None else c1
+    S, D, K, keep = _host_structs(cfg, sc, dn, cl)
+    nc = len(sc.contig_off) - 1
+    if contig_len is None:
+        from .sites_np import GRCH38_LEN
+        contig_len = GRCH38_LEN[:nc] if nc <= len(GRCH38_LEN) else [int(sc.pos.max()) + 100000] * nc
+    lens = np.ascontiguousarray(contig_len, np.int32)
+    names = _names_array(sc.contig_names)
+    stats = (C.c_int64 * 4)()
+    err = C.create_string_buffer(256)
+    L.uzs_write_bam.restype = C.c_int
+    rc = L.uzs_write_bam(os.fsencode(path), os.fsencode(path + ".bai") if bai else None, C.byref(cfg), C.byref(S), C.byref(D), C.byref(K),
+                         C.c_int32(c0), C.c_int32(c1), names, C.c_void_p(lens.ctypes.data), C.c_int(level), C.c_int(1 if tags else 0),
+                         C.c_int(threads), stats, err, C.c_int(256))
+    if rc != 0:
+        raise RuntimeError("uzs_write_bam: " + err.value.decode())
+    return dict(zip(("records", "raw_bytes", "file_bytes", "blocks"), (int(x) for x in stats)))
+
+
+def write_vcf(path, sc, samples=("kid", "dad", "mom"), contig_len=None, level=6, threads=0, tbi=True):
+    """The sites table as a BGZF-compressed VCF (+ tabix index next to it).  -> dict(records, raw_bytes, file_bytes, blocks)"""
+    L = C.CDLL(build_files())
+    nc = len(sc.contig_off) - 1
+    if contig_len is None:
+        from .sites_np import GRCH38_LEN
+        contig_len = GRCH38_LEN[:nc] if nc <= len(GRCH38_LEN) else [int(sc.pos.max()) + 100000] * nc
+    lens = np.ascontiguousarray(contig_len, np.int32)
+    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=np.ascontiguousarray(sc.pos, np.int32),
+                sflags=np.ascontiguousarray(sc.sflags, np.uint8), ref=np.ascontiguousarray(sc.ref_base, np.uint8),
+                alt=np.ascontiguousarray(sc.alt_base, np.uint8), gt=np.ascontiguousarray(sc.gt, np.uint8))
+    cols = {k: [np.ascontiguousarray(getattr(sc, k)[m], np.uint16) for m in range(3)] for k in ("rd", "ad", "gq")}
+    ptrs = {k: (C.c_void_p * 3)(*[a.ctypes.data for a in v]) for k, v in cols.items()}
+    stats = (C.c_int64 * 4)()
+    err = C.create_string_buffer(256)
+    L.uzs_write_vcf.restype = C.c_int
+    rc = L.uzs_write_vcf(os.fsencode(path), os.fsencode(path + ".tbi") if tbi else None, C.c_int64(sc.n), C.c_int32(nc),
+                         C.c_void_p(keep["contig_off"].ctypes.data), _names_array(sc.contig_names), C.c_void_p(lens.ctypes.data),
+                         C.c_void_p(keep["pos"].ctypes.data), C.c_void_p(keep["sflags"].ctypes.data), C.c_void_p(keep["ref"].ctypes.data),
+                         C.c_void_p(keep["alt"].ctypes.data), C.c_void_p(keep["gt"].ctypes.data), ptrs["rd"], ptrs["ad"], ptrs["gq"],
+                         _names_array(list(samples)), C.c_int(level), C.c_int(threads), stats, err, C.c_int(256))
+    if rc != 0:
+        raise RuntimeError("uzs_write_vcf: " + err.value.decode())
+    return dict(zip(("records", "raw_bytes", "file_bytes", "blocks"), (int(x) for x in stats)))
 
 
 class DeviceArrays:
