@@ -213,6 +213,42 @@ int64_t uz_select_n_row_units(const uz_select *s);
 int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *out, int32_t *orig_index);
 void uz_select_free(uz_select *s);
 
+/* ------------------------------------------------------------------ BAM file -> staged records in one pass
+ * What uz_bam_decode_regions + uz_reads_pack + uz_reads_select_* produce for one batch -- the records the batch's fetches return
+ * (read_collector.py:385, :167, :478-497) and, closed under it, the records mate() returns for them (:400, :185), in the form the
+ * host link carries (uz_reads_packed_view: two-bit bases of the 32-base units a fetch point falls into, qualities as lists,
+ * dictionary + difference columns, no `end`, simple CIGARs left home) -- built straight from the inflated BGZF blocks of the
+ * batch's reach, with no table in between.  Byte for byte the same columns as the three-step path (tests/test_io_stage.py). */
+typedef struct uz_bamsrc uz_bamsrc; /* an opened BAM + its BAI (mapped; header and the head of the file read once) */
+typedef struct uz_stage uz_stage;   /* one batch planned: sizes known, columns not written yet */
+int uz_bamsrc_open(const char *path, const char *bai_path, int64_t head_records, uz_bamsrc **out);
+void uz_bamsrc_close(uz_bamsrc *s);
+int32_t uz_bamsrc_n_contigs(const uz_bamsrc *s);
+const char *uz_bamsrc_contig_name(const uz_bamsrc *s, int32_t i);
+int32_t uz_bamsrc_contig_length(const uz_bamsrc *s, int32_t i);
+int64_t uz_bamsrc_tlen_head(const uz_bamsrc *s, int32_t *out, int64_t cap); /* as uz_bam_tlen_head */
+const char *uz_inflate_backend(void); /* "libdeflate" (found at run time) or "zlib" */
+#define UZ_STAGE_ALL_BASES 1  /* --no-extended batches: every kept record keeps its bases (uz_reads_select_plan: all_bases) */
+#define UZ_STAGE_UNIT_MASKS 2 /* only the 32-base units that hold a fetched position (+ extra[f] bases on) are staged */
+#define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (SV batches; no unit masks then) */
+/* fetches (tid, lo, hi[, extra]) as staging.fetch_points lists them; min_base_qual = --min-gt-qual.  UZ_IO_E_RANGE when the batch
+ * holds more than 65536 combinations of the small columns (stage it through the table form then). */
+int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra,
+                      int flags, int min_base_qual, int threads, uz_stage **out);
+/* [0] records, [1] CIGAR words that travel, [2] words left home (simple records), [3] row units, [4] staged base units, [5] listed
+ * bases (exc_*), [6] listed low-quality positions, [7] qlow_pos_wide, [8] dictionary entries, [9] escapes, [10] query names,
+ * [11] 1 when the dictionary carries unit masks */
+void uz_stage_sizes(const uz_stage *s, int64_t out[12]);
+/* [0] compressed bytes read, [1] BGZF blocks inflated, [2] records walked, [3] records kept, [4] reach intervals, [5] mates looked
+ * up through the index */
+void uz_stage_io_stats(const uz_stage *s, int64_t out[8]);
+/* seconds: [0] file spans from the index, [1] inflate + walk, [2] mates, [3] numbering, [4] the last fill */
+void uz_stage_timing(const uz_stage *s, double out[6]);
+/* writes the columns into the caller's buffers (sized from uz_stage_sizes; every pointer of the form described above set) */
+int uz_stage_fill(const uz_stage *s, int threads, uz_reads_packed_view *out);
+const char *uz_stage_qname(const uz_stage *s, uint32_t id, int32_t *len);
+void uz_stage_free(uz_stage *s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,107 @@
+"""uz_bam_stage_* (BAM file -> staged records in one pass) against the three-step path it replaces -- uz_bam_decode_regions
+(ASCII table) -> uz_reads_pack -> uz_reads_select_* -- on the same fetches: every column byte for byte."""
+import numpy as np
+import pytest
+
+from synth import bigsynth
+from synth.sites_np import make_clusters, make_sites, place_dnms_full
+from unfazed_amd import abi, io_native
+
+
+def three_step(bam, fc, flo, fhi, fex, mbq, all_bases=False, lists=True):
+    table = io_native.read_bam_regions(bam, fc, flo, fhi, threads=2, insert_size_max_sample=0)
+    v = abi.reads_view(table)
+    full = io_native.pack_reads(v, mbq, lists=True, with_end=True)
+    return io_native.ReadsSource(full).select(fc, flo, fhi, all_bases=all_bases, lists=lists, extra=fex), table
+
+
+def assert_same(a, b):
+    va, vb = a.view, b.view
+    for f, _ in abi.ReadsPackedView._fields_:
+        x, y = getattr(va, f), getattr(vb, f)
+        if isinstance(x, int) and not f.startswith(("contig_off", "max_span")) and f not in a.arrays and f not in b.arrays:
+            assert x == y, f
+    assert set(a.arrays) == set(b.arrays), (sorted(a.arrays), sorted(b.arrays))
+    n = int(va.n_segs)
+    sizes = {"cigar": int(va.n_cigar_total), "seq2": 8 * int(va.n_seq_units), "exc_rec": int(va.n_exc), "exc_pos": int(va.n_exc), "exc_code": int(va.n_exc),
+             "qlow_pos": int(va.n_qlow_pos) * (2 if va.qlow_pos_wide else 1), "esc16_key": int(va.n_esc16), "esc16_val": int(va.n_esc16),
+             "qlow": 4 * int(va.n_row_units), "contig_off": int(va.n_contigs) + 1, "max_span": int(va.n_contigs)}
+    for k in a.arrays:
+        m = sizes.get(k, int(va.n_tup) if k.startswith("tup_") else n)
+        assert np.array_equal(a.arrays[k][:m], b.arrays[k][:m]), k
+
+
+@pytest.fixture(scope="module")
+def workload(tmp_path_factory):
+    d = tmp_path_factory.mktemp("stage")
+    lens = [3_000_000, 2_000_000, 1_000_000]
+    sc = make_sites(12000, seed=177, contig_lens=lens)
+    dn = place_dnms_full(sc, 60, seed=178)
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=179)
+    cfg.n_clusters = cl.n
+    bam = str(d / "kid.bam")
+    bigsynth.write_bam(bam, cfg, sc, dn, cl, contig_len=lens, level=1, threads=3)
+    return dict(sc=sc, dn=dn, cl=cl, bam=bam)
+
+
+def fetches_of(w, stride=1, spread=5):
+    """fetch points as staging.fetch_points lists them: the DNM ([start - 1, start + 1), extra = allele length) and a few
+    one-base fetches at 'het sites' of its window"""
+    dn = w["dn"]
+    rng = np.random.default_rng(5)
+    c, lo, hi, ex = [], [], [], []
+    for i in range(0, dn.n, stride):
+        c.append(dn.contig[i]); lo.append(dn.start[i] - 1); hi.append(dn.start[i] + 1); ex.append(max(len(dn.refs[i]), len(dn.alts[i])))
+        for p in np.sort(rng.integers(dn.start[i] - 5000, dn.start[i] + 5000, spread)):
+            c.append(dn.contig[i]); lo.append(int(p)); hi.append(int(p) + 1); ex.append(0)
+    return (np.array(c, np.int32), np.array(lo, np.int32), np.array(hi, np.int32), np.array(ex, np.uint16))
+
+
+@pytest.mark.parametrize("stride,spread", [(1, 5), (3, 9), (7, 0)])
+def test_unit_masked_lists_equal_three_step(workload, stride, spread):
+    fc, flo, fhi, fex = fetches_of(workload, stride, spread)
+    want, table = three_step(workload["bam"], fc, flo, fhi, fex, 20)
+    src = io_native.BamSource(workload["bam"], threads=3)
+    got = src.select(fc, flo, fhi, 20, extra=fex)
+    assert_same(got, want)
+    # names by id
+    n = int(got.view.n_segs)
+    q = abi.wide_columns(got)["qname"]
+    for i in range(0, n, max(1, n // 200)):
+        assert got.qnames[int(q[i])] == table.qnames[int(table.qname[i])]
+    assert got.io_stats["records_kept"] == n
+    assert np.array_equal(src.tlen_head[:100], io_native.read_bam_table(workload["bam"], threads=2).tlen_head[:100])
+
+
+def test_all_bases_and_other_thresholds(workload):
+    fc, flo, fhi, fex = fetches_of(workload, 2, 4)
+    src = io_native.BamSource(workload["bam"], threads=2)
+    for mbq in (13, 38):
+        want, _ = three_step(workload["bam"], fc, flo, fhi, fex, mbq)
+        assert_same(src.select(fc, flo, fhi, mbq, extra=fex), want)
+    want, _ = three_step(workload["bam"], fc, flo, fhi, fex, 20, all_bases=True)
+    assert_same(src.select(fc, flo, fhi, 20, extra=fex, all_bases=True), want)
+    want, _ = three_step(workload["bam"], fc, flo, fhi, None, 20)
+    assert_same(src.select(fc, flo, fhi, 20), want)
+
+
+def test_wide_fetches_keep_every_unit(workload):
+    """SV-style fetches (+-cutoff around a breakpoint): no unit masks for their records"""
+    dn = workload["dn"]
+    fc = dn.contig[::4].astype(np.int32)
+    flo = (dn.start[::4] - 700).astype(np.int32)
+    fhi = (dn.start[::4] + 700).astype(np.int32)
+    fex = np.zeros(fc.size, np.uint16)
+    want, _ = three_step(workload["bam"], fc, flo, fhi, fex, 20)
+    got = io_native.BamSource(workload["bam"], threads=2).select(fc, flo, fhi, 20, extra=fex)
+    assert_same(got, want)
+
+
+def test_empty_and_absent(workload):
+    src = io_native.BamSource(workload["bam"], threads=2)
+    got = src.select(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32), 20)
+    assert int(got.view.n_segs) == 0
+    # a fetch where the file has no records, a contig id out of range
+    got = src.select(np.array([2, 7], np.int32), np.array([900_000, 5], np.int32), np.array([900_001, 6], np.int32), 20)
+    assert int(got.view.n_segs) == 0

@@ -50,7 +50,7 @@ def _compile(lib, srcs, inc, csrc, extra_flags, verbose):
     return lib
 
 
-IO_SRC = ["io_bam.cpp", "io_vcf.cpp", "io_pack.cpp", "io_cram.cpp"]
+IO_SRC = ["io_bam.cpp", "io_vcf.cpp", "io_pack.cpp", "io_cram.cpp", "io_stage.cpp"]
 IO_LIB = os.path.join(_HERE, "libunfazed_io.so")
 
 
@@ -70,7 +70,7 @@ def build_io(force=False, verbose=False, out=None):
             return lib
         cxx = os.environ.get("CXX", "g++")
         cmd = [cxx, "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wall", "-Wno-unused-parameter",
-               "-I", inc, "-I", csrc] + srcs + ["-lz", "-o", lib + ".tmp"]
+               "-I", inc, "-I", csrc] + srcs + ["-lz", "-ldl", "-o", lib + ".tmp"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

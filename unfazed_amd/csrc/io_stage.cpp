@@ -1,0 +1,1213 @@
+// io_stage.cpp -- BAM file -> the staged (link) form of the alignment records in ONE pass (uz_bam_stage_*).
+//
+// What it replaces: the three passes the session used to make per batch -- uz_bam_decode_regions (BAI-driven decode
+// into the ASCII column table: one byte per base and per quality), uz_reads_pack (ASCII -> packed table) and
+// uz_reads_select_* (fetch reach + link-form columns) -- i.e. what `bamfile.fetch(chrom, lo, hi)` and
+// `bamfile.mate(read)` hand the reference per DNM (read_collector.py:385, :167, :400, :185), delivered as the columns
+// uz_reads_upload_packed takes.  Here a batch's fetch points are merged into reach intervals, each interval's BGZF
+// blocks (BAI bins + linear index) are inflated once by one worker, and the worker turns the records it walks
+// straight into what the link carries: 2-bit bases of the 32-base units a fetch point falls into, the low-quality
+// positions inside those units, CIGAR words of the records that are not one M / = / X over the read, and the small
+// fixed columns.  No intermediate table; what is not needed is never copied out of the inflate buffer.
+//
+// Equivalence: the output is byte for byte what ReadsSource(pack_reads(read_bam_regions(...))).select(...) builds for
+// the same fetches (tests/test_io_stage.py) -- same records (fetched + closed under mate()), same order, same name
+// ids (order of first appearance), same dictionary / escape / exception lists.
+//
+// Inflate: libdeflate when the system has it (dlopen, no headers needed: three functions of its stable ABI), else
+// zlib.  UZ_INFLATE=zlib forces zlib.
+#include <dlfcn.h>
+#include <sys/mman.h>
+
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
+#include "io_common.hpp"
+#include "io_index.hpp"
+#include "pack.hpp"
+
+using namespace uzio;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ inflate
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+};
+
+const LibDeflate &libdeflate() {
+    static LibDeflate L;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("UZ_INFLATE");
+        if (e && strcmp(e, "zlib") == 0) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        L.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        L.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        L.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        L.crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        L.ok = L.alloc && L.decompress && L.release && L.crc;
+    });
+    return L;
+}
+
+struct Inflater {
+    void *ld = nullptr;
+    z_stream z;
+    bool z_init = false;
+    Inflater() {
+        const LibDeflate &L = libdeflate();
+        if (L.ok) ld = L.alloc();
+        if (!ld) {
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
+            z_init = true;
+        }
+    }
+    ~Inflater() {
+        if (ld) libdeflate().release(ld);
+        if (z_init) inflateEnd(&z);
+    }
+    Inflater(const Inflater &) = delete;
+    void block(const uint8_t *c, size_t clen, uint8_t *dst, size_t isize, uint32_t crc, int64_t coff) {
+        if (isize == 0) return;
+        if (ld) {
+            size_t got = 0;
+            if (libdeflate().decompress(ld, c, clen, dst, isize, &got) != 0 || got != isize) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
+            if (libdeflate().crc(0, dst, isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
+            return;
+        }
+        inflateReset(&z);
+        z.next_in = const_cast<Bytef *>(c);
+        z.avail_in = (uInt)clen;
+        z.next_out = dst;
+        z.avail_out = (uInt)isize;
+        if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
+        if ((uint32_t)crc32(0L, dst, (uInt)isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
+    }
+};
+
+template <typename F>
+void parallel_dynamic(int64_t n, int threads, F fn) { // fn(item, worker): items handed out one by one (uneven costs)
+    if (n <= 0) return;
+    const int w = (int)std::min<int64_t>(std::max(1, threads), n);
+    if (w <= 1) { for (int64_t i = 0; i < n; i++) fn(i, 0); return; }
+    std::atomic<int64_t> next{0};
+    std::vector<std::thread> pool;
+    std::vector<IoError> errs((size_t)w, IoError{0, ""});
+    for (int k = 0; k < w; k++)
+        pool.emplace_back([&, k] {
+            try {
+                for (;;) {
+                    const int64_t i = next.fetch_add(1);
+                    if (i >= n) break;
+                    fn(i, k);
+                }
+            } catch (const IoError &e) { errs[(size_t)k] = e; next.store(n); } catch (const std::exception &e) { errs[(size_t)k] = IoError{UZ_IO_E_FORMAT, e.what()}; next.store(n); }
+        });
+    for (auto &t : pool) t.join();
+    for (auto &e : errs) if (e.code) throw e;
+}
+
+inline uint64_t hash_name(const uint8_t *s, size_t n) { // FNV-1a with a final mix
+    uint64_t h = 1469598103934665603ULL;
+    for (size_t i = 0; i < n; i++) { h ^= s[i]; h *= 1099511628211ULL; }
+    h ^= h >> 32; h *= 0x9E3779B97F4A7C15ULL; h ^= h >> 29;
+    return h;
+}
+
+const uint16_t FPAIRED = 1, FUNMAP = 4, FMUNMAP = 8, FREAD1 = 64, FREAD2 = 128;
+const int32_t REACH_SLACK = 1000; // a reach interval extends this far beyond its fetch points: the mates of a pile-up lie inside it
+
+bool has_sa_tag(const uint8_t *p, const uint8_t *end) {
+    while (p + 3 <= end) {
+        const uint8_t a = p[0], b = p[1], typ = p[2];
+        p += 3;
+        if (a == 'S' && b == 'A') return true;
+        size_t sz = 0;
+        switch (typ) {
+        case 'A': case 'c': case 'C': sz = 1; break;
+        case 's': case 'S': sz = 2; break;
+        case 'i': case 'I': case 'f': sz = 4; break;
+        case 'Z': case 'H': {
+            const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(end - p));
+            if (!z) return false;
+            p = z + 1;
+            continue;
+        }
+        case 'B': {
+            if (p + 5 > end) return false;
+            size_t es = 0;
+            switch (p[0]) { case 'c': case 'C': es = 1; break; case 's': case 'S': es = 2; break; case 'i': case 'I': case 'f': es = 4; break; default: return false; }
+            const int32_t cnt = rdi32(p + 1);
+            if (cnt < 0) return false;
+            p += 5 + (size_t)cnt * es;
+            continue;
+        }
+        default: return false;
+        }
+        p += sz;
+    }
+    return false;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ the opened file
+struct uz_bamsrc {
+    std::string path;
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t size = 0;
+    std::vector<BaiRef> refs;
+    std::vector<std::string> contigs;
+    std::vector<int32_t> contig_len;
+    std::vector<int32_t> tlen_head;
+    ~uz_bamsrc() {
+        if (map && size) munmap(const_cast<uint8_t *>(map), size);
+        if (fd >= 0) close(fd);
+    }
+};
+
+namespace {
+
+struct BlockHdr { size_t cdata, clen, blen; uint32_t crc, isize; };
+
+// header of the BGZF block at compressed offset coff; false at the end of the file
+bool block_at(const uz_bamsrc &S, int64_t coff, BlockHdr &b) {
+    if (coff < 0 || (size_t)coff + 18 > S.size) return false;
+    const uint8_t *h = S.map + coff;
+    if (h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) fail(UZ_IO_E_FORMAT, "not a BGZF block at byte %lld", (long long)coff);
+    const size_t xlen = rd16(h + 10);
+    if ((size_t)coff + 12 + xlen > S.size) fail(UZ_IO_E_FORMAT, "truncated BGZF block");
+    size_t q = 12, bsize = 0;
+    bool found = false;
+    while (q + 4 <= 12 + xlen) {
+        const size_t slen = rd16(h + q + 2);
+        if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) { bsize = rd16(h + q + 4); found = true; }
+        q += 4 + slen;
+    }
+    if (!found) fail(UZ_IO_E_FORMAT, "BGZF block without a BC field at byte %lld", (long long)coff);
+    b.blen = bsize + 1;
+    if (b.blen < 12 + xlen + 8 || (size_t)coff + b.blen > S.size) fail(UZ_IO_E_FORMAT, "truncated BGZF block at byte %lld", (long long)coff);
+    b.cdata = (size_t)coff + 12 + xlen;
+    b.clen = b.blen - 12 - xlen - 8;
+    b.crc = rd32(h + b.blen - 8);
+    b.isize = rd32(h + b.blen - 4);
+    return true;
+}
+
+// A sequential reader of the inflated stream from a virtual offset on: inflates block after block into a rolling buffer and
+// hands out whole records with their virtual offsets.
+struct Stream {
+    const uz_bamsrc &S;
+    Inflater &inf;
+    std::vector<uint8_t> buf;
+    struct Blk { int64_t coff; size_t at, isize; };
+    std::vector<Blk> blks; // blocks held in buf (buffer offsets)
+    size_t cur = 0;        // next unread byte of buf
+    size_t blk = 0;        // block holding `cur`
+    int64_t next_coff = 0;
+    int64_t file_bytes = 0, n_blocks = 0;
+    bool eof = false;
+    Stream(const uz_bamsrc &s, Inflater &i) : S(s), inf(i) {}
+    void seek(uint64_t voff) {
+        buf.clear(); blks.clear(); cur = 0; blk = 0; eof = false;
+        next_coff = (int64_t)(voff >> 16);
+        if (!more()) return;
+        cur = (size_t)(voff & 0xFFFF);
+        if (cur > blks[0].isize) fail(UZ_IO_E_FORMAT, "virtual offset beyond its block");
+    }
+    bool more() { // one more block; false at the end of the file
+        if (eof) return false;
+        if (cur > (1u << 20)) { // drop what has been consumed
+            size_t b0 = blk;
+            while (b0 > 0 && blks[b0].at > cur) b0--;
+            const size_t cut = blks[b0].at;
+            if (cut) {
+                memmove(buf.data(), buf.data() + cut, buf.size() - cut);
+                buf.resize(buf.size() - cut);
+                cur -= cut;
+                blks.erase(blks.begin(), blks.begin() + (ptrdiff_t)b0);
+                for (auto &x : blks) x.at -= cut;
+                blk -= b0;
+            }
+        }
+        BlockHdr h;
+        if (!block_at(S, next_coff, h)) { eof = true; return false; }
+        const size_t at = buf.size();
+        buf.resize(at + h.isize);
+        inf.block(S.map + h.cdata, h.clen, buf.data() + at, h.isize, h.crc, next_coff);
+        blks.push_back(Blk{next_coff, at, h.isize});
+        next_coff += (int64_t)h.blen;
+        file_bytes += (int64_t)h.blen;
+        n_blocks++;
+        return true;
+    }
+    // the record at the cursor: false at the end of the file.  *voff: where it starts; p: its fixed part; bs: its block_size
+    bool next(uint64_t &voff, const uint8_t *&p, uint32_t &bs) {
+        for (;;) { // the cursor at the end of a block is the start of the next one
+            while (blk + 1 < blks.size() && cur >= blks[blk].at + blks[blk].isize) blk++;
+            if (cur < blks[blk].at + blks[blk].isize) break;
+            if (!more()) return false;
+        }
+        voff = ((uint64_t)blks[blk].coff << 16) | (uint64_t)(cur - blks[blk].at);
+        while (cur + 4 > buf.size()) if (!more()) fail(UZ_IO_E_FORMAT, "truncated alignment record");
+        const int32_t n = rdi32(buf.data() + cur);
+        if (n < 32) fail(UZ_IO_E_FORMAT, "bad alignment record at virtual offset %llu", (unsigned long long)voff);
+        while (cur + 4 + (size_t)n > buf.size()) if (!more()) fail(UZ_IO_E_FORMAT, "truncated alignment record");
+        p = buf.data() + cur + 4;
+        bs = (uint32_t)n;
+        return true;
+    }
+    void advance(uint32_t bs) { cur += 4 + (size_t)bs; }
+    Stream(const Stream &) = delete;
+};
+
+void open_source(uz_bamsrc &S, const char *path, const char *bai_path, int64_t head_records) {
+    S.path = path;
+    S.fd = open(path, O_RDONLY);
+    if (S.fd < 0) fail(UZ_IO_E_OPEN, "cannot open %s", path);
+    struct stat st;
+    if (fstat(S.fd, &st) != 0) fail(UZ_IO_E_OPEN, "cannot stat %s", path);
+    S.size = (size_t)st.st_size;
+    if (S.size) {
+        void *m = mmap(nullptr, S.size, PROT_READ, MAP_SHARED, S.fd, 0);
+        if (m == MAP_FAILED) fail(UZ_IO_E_OPEN, "cannot map %s", path);
+        S.map = (const uint8_t *)m;
+    }
+    std::string bai = bai_path ? std::string(bai_path) : std::string(path) + ".bai";
+    if (!bai_path) { // NAME.bam.bai or NAME.bai
+        FILE *t = fopen(bai.c_str(), "rb");
+        if (t) fclose(t);
+        else { std::string alt(path); if (alt.size() > 4) alt = alt.substr(0, alt.size() - 4) + ".bai"; bai = alt; }
+    }
+    S.refs = read_bai(bai.c_str());
+    // header + the head of the file (estimate_concordant_insert_len reads the first records, read_collector.py:11-25)
+    Inflater inf;
+    Stream s(S, inf);
+    s.seek(0);
+    for (;;) {
+        if (s.buf.size() >= 12) {
+            if (memcmp(s.buf.data(), "BAM\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAM file", path);
+            const int32_t l_text = rdi32(s.buf.data() + 4);
+            if (l_text < 0) fail(UZ_IO_E_FORMAT, "bad BAM header");
+            size_t off = 8 + (size_t)l_text;
+            bool short_ = off + 4 > s.buf.size();
+            int32_t n_ref = 0;
+            if (!short_) {
+                n_ref = rdi32(s.buf.data() + off);
+                if (n_ref < 0) fail(UZ_IO_E_FORMAT, "bad BAM header");
+                off += 4;
+                S.contigs.clear(); S.contig_len.clear();
+                for (int32_t r = 0; r < n_ref && !short_; r++) {
+                    if (off + 4 > s.buf.size()) { short_ = true; break; }
+                    const int32_t l_name = rdi32(s.buf.data() + off);
+                    if (l_name < 1) fail(UZ_IO_E_FORMAT, "bad BAM header");
+                    if (off + 4 + (size_t)l_name + 4 > s.buf.size()) { short_ = true; break; }
+                    S.contigs.emplace_back((const char *)s.buf.data() + off + 4, (size_t)l_name - 1);
+                    S.contig_len.push_back(rdi32(s.buf.data() + off + 4 + (size_t)l_name));
+                    off += 4 + (size_t)l_name + 4;
+                }
+            }
+            if (!short_) { s.cur = off; break; }
+        }
+        if (!s.more()) fail(UZ_IO_E_FORMAT, "truncated BAM header");
+    }
+    if (S.contigs.size() != S.refs.size()) fail(UZ_IO_E_FORMAT, "the index %s holds %zu references, the BAM header %zu", bai.c_str(), S.refs.size(), S.contigs.size());
+    s.blk = 0;
+    while ((int64_t)S.tlen_head.size() < head_records) {
+        uint64_t voff;
+        const uint8_t *p;
+        uint32_t bs;
+        if (!s.next(voff, p, bs)) break;
+        S.tlen_head.push_back(rdi32(p + 28));
+        s.advance(bs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the plan
+struct Fx { int32_t lo, hi; uint16_t extra; };
+
+struct WRec { // one walked record that may be kept
+    uint64_t voff, nhash;
+    int64_t mate_ref;  // (task << 32 | index) of the record mate() returns, -1 none, -2 not looked up yet
+    int32_t pos, end, tlen, mpos, mtid;
+    uint32_t name_at, cigar_at, pay_at;
+    uint32_t gidx, qid;
+    uint16_t flag, l_seq, n_cigar, umask, n_exc, tup;
+    uint8_t mapq, aux, n_low_full, l_name, n_qpos, n_low, simple, keep, n_units, has_pay;
+};
+
+struct Task { // one reach interval of one reference: its file spans, and what its walk kept
+    int32_t tid = 0, a = 0, b = 0;   // reach interval [a, b)
+    size_t f0 = 0, f1 = 0;           // its fetches: [f0, f1) of the reference's sorted list
+    std::vector<Chunk> spans;
+    std::vector<WRec> recs;          // file order
+    std::vector<uint8_t> names;      // name bytes (no terminator)
+    std::vector<uint32_t> cigars;    // words of the records that are not simple
+    std::vector<uint8_t> pay;        // per record with has_pay: seq2 units | exceptions (pos u16, code u8, pad) | positions (u16) | plane row
+    int64_t n_walked = 0, file_bytes = 0, n_blocks = 0;
+    // sizes of the kept records (filled by the numbering pass)
+    int64_t n_keep = 0, k0 = 0;
+};
+
+struct Opt { bool all_bases, masks, lists; int thr; };
+
+inline uint8_t sat255(int v) { return (uint8_t)(v > 255 ? 255 : v); }
+
+// everything the link can need of one record, extracted while its bytes are in the inflate buffer
+void extract(Task &T, WRec &r, const uint8_t *p, uint32_t bs, const Opt &o, bool bases) {
+    const uint32_t l_name = p[8], ncig = r.n_cigar, L = r.l_seq;
+    const uint8_t *q = p + 32 + l_name;
+    const uint8_t *sq = q + 4 * (size_t)ncig;
+    const uint8_t *ql = sq + ((size_t)L + 1) / 2;
+    const uint8_t *tags = ql + L;
+    if (l_name < 1 || tags > p + bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
+    r.name_at = (uint32_t)T.names.size();
+    r.l_name = (uint8_t)(l_name - 1);
+    T.names.insert(T.names.end(), p + 32, p + 32 + l_name - 1);
+    uint8_t a = 0;
+    if (r.mtid == T.tid) a |= UZ_AUX_MATE_SAME_TID;
+    if (has_sa_tag(tags, p + bs)) a |= UZ_AUX_HAS_SA;
+    const bool noqual = L > 0 && ql[0] == 0xFF;
+    if (ncig == 0 || L == 0 || noqual) a |= UZ_AUX_DECODE_BAD;
+    r.aux = a;
+    r.simple = (uint8_t)uz_cigar_simple_code(ncig, ncig ? rd32(q) : 0u, L);
+    r.cigar_at = (uint32_t)T.cigars.size();
+    if (!r.simple)
+        for (uint32_t k = 0; k < ncig; k++) T.cigars.push_back(rd32(q + 4 * k));
+    // low-quality bases: the count of every record (a record without qualities decodes to zeros: every base is below a positive threshold)
+    int low = 0;
+    if (noqual) low = o.thr > 0 ? (int)L : 0;
+    else for (uint32_t k = 0; k < L; k++) low += (int)ql[k] < o.thr;
+    r.n_low_full = sat255(low);
+    r.n_low = r.n_low_full;
+    r.has_pay = 0; r.n_units = 0; r.n_exc = 0; r.n_qpos = 0;
+    r.pay_at = (uint32_t)T.pay.size();
+    const uint32_t units = UZ_ROW_UNITS(L);
+    if (bases) {
+        r.has_pay = 1;
+        // the staged units: two bits per base, first base of a byte in bits 7-6; a base that is not A/C/G/T is 0 here and listed
+        static const struct Tab { uint8_t t[256]; Tab() { for (int v = 0; v < 256; v++) { auto c = [](int n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : 0; }; t[v] = (uint8_t)((c(v >> 4) << 2) | c(v & 15)); } } } two;
+        const uint16_t m16 = r.umask;
+        for (uint32_t u = 0; u < units; u++) {
+            if (m16 != UZ_UMASK_ALL && !((m16 >> u) & 1u)) continue;
+            uint8_t row[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const uint32_t b0 = 32 * u, b1 = std::min<uint32_t>(L, b0 + 32);
+            const uint32_t nb = (b1 - b0 + 1) / 2; // BAM bytes of the unit
+            const uint8_t *s = sq + b0 / 2;
+            for (uint32_t j = 0; j < nb; j++) {
+                uint8_t v = s[j];
+                if (b0 + 2 * j + 1 >= L) v &= 0xF0; // the pad nibble of an odd length
+                row[j >> 1] |= (uint8_t)(two.t[v] << ((j & 1) ? 0 : 4));
+            }
+            T.pay.insert(T.pay.end(), row, row + 8);
+            r.n_units++;
+        }
+        // every base of the record that is not A/C/G/T (entries in units that stay home travel along: the device skips them)
+        for (uint32_t k = 0; k < L; k++) {
+            const uint32_t c = (k & 1) ? (uint32_t)(sq[k >> 1] & 15u) : (uint32_t)(sq[k >> 1] >> 4);
+            if (c == 1 || c == 2 || c == 4 || c == 8) continue;
+            const uint16_t pos16 = (uint16_t)k;
+            const uint8_t e[4] = {(uint8_t)(pos16 & 255), (uint8_t)(pos16 >> 8), (uint8_t)c, 0};
+            T.pay.insert(T.pay.end(), e, e + 4);
+            r.n_exc++;
+        }
+        if (o.lists && low <= UZ_QLOW_LIST_MAX) { // the listed positions, inside the staged units only
+            int kept = 0;
+            for (uint32_t k = 0; k < L; k++) {
+                const bool lowq = noqual ? o.thr > 0 : (int)ql[k] < o.thr;
+                if (!lowq) continue;
+                if (m16 != UZ_UMASK_ALL && !((m16 >> (k >> 5)) & 1u)) continue;
+                const uint8_t e[2] = {(uint8_t)(k & 255), (uint8_t)(k >> 8)};
+                T.pay.insert(T.pay.end(), e, e + 2);
+                kept++;
+            }
+            r.n_qpos = (uint8_t)kept;
+            r.n_low = (uint8_t)kept;
+        }
+    }
+    if (!o.lists) { // the plane row of every record
+        r.has_pay = 1;
+        const size_t at = T.pay.size();
+        T.pay.resize(at + (size_t)units * UZ_QLOW_UNIT_BYTES, 0);
+        for (uint32_t k = 0; k < L; k++)
+            if (noqual ? o.thr > 0 : (int)ql[k] < o.thr) T.pay[at + (k >> 3)] |= (uint8_t)(1u << (k & 7));
+    }
+}
+
+inline int32_t endpos_of(const uint8_t *p, int32_t pos, uint16_t fl, uint32_t ncig, uint32_t l_name) {
+    if ((fl & FUNMAP) || ncig == 0) return pos + 1;
+    int64_t rl = 0;
+    const uint8_t *q = p + 32 + l_name;
+    for (uint32_t k = 0; k < ncig; k++) {
+        const uint32_t v = rd32(q + 4 * k), op = v & 15;
+        if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rl += v >> 4;
+    }
+    return (int32_t)(pos + (rl > 0 ? rl : 1));
+}
+
+// the unit-mask bits one fetch contributes to a record it returns (uz_reads_select_plan states the rule)
+inline uint16_t mask_bits(const Fx &f, int32_t pos, int32_t end, uint32_t ncig, uint32_t cw, uint32_t L) {
+    const uint32_t op = cw & 15u;
+    const bool simple = ncig == 1 && (op == 0 || op == 7 || op == 8) && (cw >> 4) == L && L > 1 && (uint32_t)(end - pos) == L;
+    if (!(simple && L <= 480 && f.hi - f.lo <= 2)) return (uint16_t)UZ_UMASK_ALL;
+    const int64_t q0 = (int64_t)f.hi - 1 - pos;
+    uint16_t bits = 0;
+    if (q0 >= 0 && q0 < (int64_t)L) {
+        const int64_t q1 = std::min<int64_t>(q0 + f.extra, (int64_t)L - 1);
+        for (int64_t u = q0 >> 5; u <= (q1 >> 5); u++) bits |= (uint16_t)(1u << u);
+    }
+    return bits;
+}
+
+} // namespace
+
+struct SliceBase { // running totals of the variable-length columns in front of a slice of the output order
+    int64_t cig = 0, omitted = 0, units = 0, seq = 0, exc = 0, qpos = 0, esc = 0;
+    void add(const SliceBase &o) { cig += o.cig; omitted += o.omitted; units += o.units; seq += o.seq; exc += o.exc; qpos += o.qpos; esc += o.esc; }
+};
+
+struct uz_stage {
+    const uz_bamsrc *src = nullptr;
+    Opt opt{};
+    std::vector<Task> tasks;
+    std::vector<std::vector<Fx>> fx;       // per reference, sorted by lo
+    std::vector<int32_t> fx_max_len;
+    std::vector<int64_t> order;            // the kept records in file order: (task << 32 | record)
+    std::unordered_map<int64_t, int64_t> folded; // a record kept by two tasks: duplicate -> survivor
+    std::vector<int64_t> cut;              // slices of `order`
+    std::vector<SliceBase> base;           // [slices + 1]: totals in front of every slice; the last entry holds the sizes
+    int64_t n = 0, n_tup = 0, n_qnames = 0;
+    int wide = 0;
+    std::vector<uint64_t> tup_key;
+    std::vector<uint32_t> tup_k2;
+    std::vector<int64_t> name_of_id;       // id -> record
+    std::vector<int64_t> contig_off;
+    std::vector<int32_t> max_span;
+    int64_t io_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // file bytes read, blocks inflated, records walked, records kept, reach intervals, mates looked up through the index
+    double timing[6] = {0, 0, 0, 0, 0, 0};          // file spans, walk, mates, numbering, fill
+    mutable std::string name_tmp;
+};
+
+namespace {
+
+inline WRec &rec_of(uz_stage &P, int64_t ref) { return P.tasks[(size_t)(ref >> 32)].recs[(size_t)(ref & 0xFFFFFFFF)]; }
+inline const WRec &rec_of(const uz_stage &P, int64_t ref) { return P.tasks[(size_t)(ref >> 32)].recs[(size_t)(ref & 0xFFFFFFFF)]; }
+
+inline int64_t final_ref(const uz_stage &P, int64_t m) { // a mate that was folded away stands for its survivor
+    for (int hop = 0; hop < 4 && m >= 0 && !P.folded.empty(); hop++) {
+        auto it = P.folded.find(m);
+        if (it == P.folded.end()) break;
+        m = it->second;
+    }
+    return m;
+}
+
+// start / tlen / mate / qname of output record k as differences (uz_types.h: start in eight bits, the others in sixteen): v[c] the
+// column values, e[c] the escape value where v[c] == UZ_D16_ESC; returns the number of escapes
+inline int d16_of(const uz_stage &P, int64_t k, int16_t v[4], int32_t e[4]) {
+    const WRec &x = rec_of(P, P.order[(size_t)k]);
+    int n = 0;
+    auto put = [&](int c, int64_t d, int64_t esc_val) {
+        if (d > -32767 && d <= 32767) v[c] = (int16_t)d;
+        else { v[c] = (int16_t)UZ_D16_ESC; e[c] = (int32_t)esc_val; n++; }
+    };
+    const WRec *px = k > 0 ? &rec_of(P, P.order[(size_t)k - 1]) : nullptr;
+    const int64_t ds = (int64_t)x.pos - (px ? (int64_t)px->pos : 0);
+    if (ds >= 0 && ds <= 254) v[0] = (int16_t)ds;
+    else { v[0] = (int16_t)UZ_D16_ESC; e[0] = (int32_t)ds; n++; }
+    put(1, x.tlen, x.tlen);
+    const int64_t m = final_ref(P, x.mate_ref);
+    if (m < 0) v[2] = (int16_t)UZ_D16_NONE;
+    else { const int64_t nm = rec_of(P, m).gidx; put(2, nm - k, nm); }
+    const int32_t dq = (int32_t)(x.qid - (px ? px->qid : 0u));
+    put(3, dq, dq);
+    return n;
+}
+
+// file spans holding every record that overlaps [a, b) of reference `ref` (bins + linear index); sorted, merged per block
+void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out) {
+    std::vector<uint32_t> bins;
+    reg2bins(a, b, bins);
+    uint64_t min_off = 0;
+    const size_t w = (size_t)(std::max<int64_t>(a, 0) >> 14);
+    if (!ref.linear.empty()) min_off = ref.linear[std::min(w, ref.linear.size() - 1)];
+    std::vector<Chunk> cs;
+    for (uint32_t bn : bins) {
+        auto it = std::lower_bound(ref.bins.begin(), ref.bins.end(), bn, [](const auto &x, uint32_t key) { return x.first < key; });
+        if (it == ref.bins.end() || it->first != bn) continue;
+        for (const Chunk &c : it->second)
+            if (c.end > min_off) cs.push_back(Chunk{std::max(c.beg, min_off), c.end});
+    }
+    std::sort(cs.begin(), cs.end(), [](const Chunk &x, const Chunk &y) { return x.beg < y.beg || (x.beg == y.beg && x.end < y.end); });
+    out.clear();
+    for (const Chunk &c : cs) {
+        // spans that touch, overlap or meet in one BGZF block are walked as one: no block is inflated twice
+        if (!out.empty() && (c.beg >> 16) <= (out.back().end >> 16)) out.back().end = std::max(out.back().end, c.end);
+        else out.push_back(c);
+    }
+}
+
+// walks the spans of a task: direct records (a fetch returns them) and every other record, of which only those that share a
+// name with a direct one are kept as mate candidates
+void walk_task(const uz_stage &P, Task &T, Inflater &inf) {
+    const uz_bamsrc &S = *P.src;
+    const Opt &o = P.opt;
+    const std::vector<Fx> &fx = P.fx[(size_t)T.tid];
+    const int32_t max_len = P.fx_max_len[(size_t)T.tid];
+    Stream s(S, inf);
+    std::vector<WRec> all;
+    Task tmp; // pools of every walked record; the survivors are copied over
+    tmp.tid = T.tid;
+    bool stop = false;
+    for (size_t ci = 0; ci < T.spans.size() && !stop; ci++) {
+        s.seek(T.spans[ci].beg);
+        for (;;) {
+            uint64_t voff;
+            const uint8_t *p;
+            uint32_t bs;
+            if (!s.next(voff, p, bs)) { stop = true; break; } // end of the file
+            if (voff >= T.spans[ci].end) break;
+            const int32_t tid = rdi32(p), pos = rdi32(p + 4);
+            if (tid != T.tid) {
+                if (tid < 0 || tid > T.tid) { stop = true; break; }
+                s.advance(bs);
+                continue;
+            }
+            if (pos >= T.b) { stop = true; break; }
+            const uint32_t l_name = p[8], ncig = rd16(p + 12);
+            const uint16_t fl = rd16(p + 14);
+            const int32_t lseq = rdi32(p + 16);
+            if (lseq < 0 || lseq > 0xFFFF) fail(UZ_IO_E_RANGE, "record too long for the 16-bit length columns (l_seq %d)", lseq);
+            if (32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
+            const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
+            T.n_walked++;
+            WRec r;
+            memset(&r, 0, sizeof(r));
+            r.voff = voff; r.pos = pos; r.end = end; r.flag = fl; r.mapq = p[9];
+            r.n_cigar = (uint16_t)ncig; r.l_seq = (uint16_t)lseq;
+            r.mtid = rdi32(p + 20); r.mpos = rdi32(p + 24); r.tlen = rdi32(p + 28);
+            r.mate_ref = -2;
+            r.nhash = hash_name(p + 32, (size_t)l_name - 1);
+            // does a fetch return it?  (start < hi and end > lo: read_collector.py:385, :167)
+            bool direct = false;
+            uint16_t um = 0;
+            {
+                auto it = std::lower_bound(fx.begin() + (ptrdiff_t)T.f0, fx.begin() + (ptrdiff_t)T.f1, (int64_t)pos - max_len,
+                                           [](const Fx &f, int64_t key) { return (int64_t)f.lo < key; });
+                const uint32_t cw = ncig == 1 ? rd32(p + 32 + l_name) : 0u;
+                for (; it != fx.begin() + (ptrdiff_t)T.f1 && it->lo < end; ++it)
+                    if (it->hi > pos) {
+                        direct = true;
+                        if (o.masks) um |= mask_bits(*it, pos, end, ncig, cw, (uint32_t)lseq);
+                    }
+            }
+            r.keep = direct ? 2 : 0;
+            const bool bases = direct || o.all_bases;
+            r.umask = (uint16_t)UZ_UMASK_ALL;
+            if (o.masks) {
+                uint16_t m16 = bases ? um : (uint16_t)0;
+                if (m16 != UZ_UMASK_ALL && (uint32_t)__builtin_popcount(m16) == UZ_ROW_UNITS(lseq)) m16 = (uint16_t)UZ_UMASK_ALL;
+                r.umask = m16;
+            }
+            extract(tmp, r, p, bs, o, bases);
+            all.push_back(r);
+            s.advance(bs);
+        }
+    }
+    T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks;
+    // mate candidates: the records that share a name with a direct one
+    std::vector<uint64_t> dn;
+    for (const WRec &r : all) if (r.keep == 2) dn.push_back(r.nhash);
+    std::sort(dn.begin(), dn.end());
+    dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
+    for (const WRec &r0 : all) {
+        if (r0.keep != 2 && !std::binary_search(dn.begin(), dn.end(), r0.nhash)) continue;
+        WRec r = r0;
+        r.name_at = (uint32_t)T.names.size();
+        T.names.insert(T.names.end(), tmp.names.begin() + r0.name_at, tmp.names.begin() + r0.name_at + r0.l_name);
+        r.cigar_at = (uint32_t)T.cigars.size();
+        if (!r0.simple) T.cigars.insert(T.cigars.end(), tmp.cigars.begin() + r0.cigar_at, tmp.cigars.begin() + r0.cigar_at + r0.n_cigar);
+        r.pay_at = (uint32_t)T.pay.size();
+        if (r0.has_pay) {
+            const size_t len = (size_t)r0.n_units * 8 + (size_t)r0.n_exc * 4 + (size_t)r0.n_qpos * 2 + (o.lists ? 0 : (size_t)UZ_ROW_UNITS(r0.l_seq) * UZ_QLOW_UNIT_BYTES);
+            T.pay.insert(T.pay.end(), tmp.pay.begin() + r0.pay_at, tmp.pay.begin() + r0.pay_at + (ptrdiff_t)len);
+        }
+        T.recs.push_back(r);
+    }
+}
+
+inline bool same_name(const Task &A, const WRec &a, const Task &B, const WRec &b) {
+    return a.nhash == b.nhash && a.l_name == b.l_name && memcmp(A.names.data() + a.name_at, B.names.data() + b.name_at, a.l_name) == 0;
+}
+
+// mate(): the first record in file order with the name, on the mate's reference, overlapping the mate position, carrying the
+// other read-of-pair flag (pysam's AlignmentFile.mate; it may be a secondary / supplementary record)
+inline bool is_mate_of(const WRec &x, const WRec &y, int32_t y_tid) {
+    if (y_tid != x.mtid) return false;
+    if (!((int64_t)y.pos < (int64_t)x.mpos + 1 && (int64_t)y.end > (int64_t)x.mpos)) return false;
+    const uint16_t want = (uint16_t)((x.flag ^ (FREAD1 | FREAD2)) & (FREAD1 | FREAD2));
+    return (y.flag & want) != 0;
+}
+
+inline bool wants_mate(const WRec &x, int32_t n_ref) { return (x.flag & FPAIRED) && !(x.flag & FMUNMAP) && x.mtid >= 0 && x.mtid < n_ref; }
+
+// a mate looked up through the index: the records overlapping [mpos, mpos + 1) of the mate's reference, walked like a fetch
+struct Lookup { int64_t who; int32_t mtid, mpos; };
+
+void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int threads) {
+    const uz_bamsrc &S = *P.src;
+    const int32_t n_ref = (int32_t)S.contigs.size();
+    double t0 = now_s();
+    threads = resolve_threads(threads);
+    // ---- the fetches per reference, sorted; reach intervals = fetches grown by the slack, merged
+    P.fx.assign((size_t)n_ref, {});
+    P.fx_max_len.assign((size_t)n_ref, 0);
+    for (int64_t k = 0; k < n_fetch; k++)
+        if (tid[k] >= 0 && tid[k] < n_ref && hi[k] > lo[k]) P.fx[(size_t)tid[k]].push_back(Fx{lo[k], hi[k], extra ? extra[k] : (uint16_t)0});
+    for (int32_t t = 0; t < n_ref; t++) {
+        auto &v = P.fx[(size_t)t];
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end(), [](const Fx &x, const Fx &y) { return x.lo < y.lo || (x.lo == y.lo && x.hi < y.hi); });
+        for (const Fx &f : v) P.fx_max_len[(size_t)t] = std::max(P.fx_max_len[(size_t)t], f.hi - f.lo);
+        size_t f0 = 0;
+        int64_t a = (int64_t)v[0].lo - REACH_SLACK, b = (int64_t)v[0].hi + REACH_SLACK;
+        for (size_t k = 1; k <= v.size(); k++) {
+            if (k < v.size() && (int64_t)v[k].lo - REACH_SLACK <= b) { b = std::max(b, (int64_t)v[k].hi + REACH_SLACK); continue; }
+            Task T;
+            T.tid = t; T.a = (int32_t)std::max<int64_t>(a, 0); T.b = (int32_t)std::min<int64_t>(b, INT32_MAX); T.f0 = f0; T.f1 = k;
+            P.tasks.push_back(std::move(T));
+            if (k < v.size()) { f0 = k; a = (int64_t)v[k].lo - REACH_SLACK; b = (int64_t)v[k].hi + REACH_SLACK; }
+        }
+    }
+    parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; i++) spans_for(S.refs[(size_t)P.tasks[(size_t)i].tid], P.tasks[(size_t)i].a, P.tasks[(size_t)i].b, P.tasks[(size_t)i].spans);
+    });
+    double t1 = now_s();
+    P.timing[0] = t1 - t0;
+    // ---- the walk
+    {
+        const int w = (int)std::min<int64_t>(threads, std::max<int64_t>(1, (int64_t)P.tasks.size()));
+        std::vector<std::unique_ptr<Inflater>> infs((size_t)w);
+        for (auto &p : infs) p.reset(new Inflater());
+        parallel_dynamic((int64_t)P.tasks.size(), w, [&](int64_t i, int k) { walk_task(P, P.tasks[(size_t)i], *infs[(size_t)k]); });
+    }
+    double t2 = now_s();
+    P.timing[1] = t2 - t1;
+    // ---- mates.  In-task look-ups are exact for mate positions inside the task's reach interval (every record overlapping
+    // such a position was walked); anything else goes through the index.
+    const size_t n_tasks0 = P.tasks.size();
+    // per task a name index would pay for deep pile-ups; the candidates are grouped by name hash first
+    struct ByName { std::vector<std::pair<uint64_t, uint32_t>> v; };
+    std::vector<ByName> by_name(P.tasks.size());
+    parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 16), [&](int64_t i0, int64_t i1, int) {
+        for (int64_t i = i0; i < i1; i++) {
+            auto &v = by_name[(size_t)i].v;
+            const Task &T = P.tasks[(size_t)i];
+            v.resize(T.recs.size());
+            for (size_t j = 0; j < T.recs.size(); j++) v[j] = {T.recs[j].nhash, (uint32_t)j};
+            std::sort(v.begin(), v.end());
+        }
+    });
+    // the task of the first walk whose reach interval holds position `pos` of reference `tid` (they are sorted and disjoint), or -1
+    auto covering = [&](int32_t tid_q, int32_t pos_q) -> int64_t {
+        size_t lo_i = 0, hi_i = n_tasks0;
+        while (lo_i < hi_i) {
+            const size_t mid = (lo_i + hi_i) / 2;
+            const Task &M = P.tasks[mid];
+            if (M.tid < tid_q || (M.tid == tid_q && M.b <= pos_q)) lo_i = mid + 1; else hi_i = mid;
+        }
+        if (lo_i < n_tasks0 && P.tasks[lo_i].tid == tid_q && P.tasks[lo_i].a <= pos_q && pos_q < P.tasks[lo_i].b) return (int64_t)lo_i;
+        return -1;
+    };
+    // A task of the first walk walked EVERY record overlapping a position inside its reach interval and kept all records of a name
+    // as soon as one of them is a fetched one: when it holds the name at all, its answer is the index's answer.
+    auto resolve_fast = [&](size_t ti, size_t ri) -> int { // 1: mate_ref set; 0: needs the index
+        WRec &x = P.tasks[ti].recs[ri];
+        if (!wants_mate(x, n_ref)) { x.mate_ref = -1; return 1; }
+        const int64_t tc = covering(x.mtid, x.mpos);
+        if (tc < 0) return 0;
+        const Task &T = P.tasks[(size_t)tc];
+        const auto &v = by_name[(size_t)tc].v;
+        auto it = std::lower_bound(v.begin(), v.end(), std::make_pair(x.nhash, (uint32_t)0));
+        bool seen = false;
+        for (; it != v.end() && it->first == x.nhash; ++it) { // ascending record index = file order
+            const WRec &y = T.recs[it->second];
+            if (!same_name(P.tasks[ti], x, T, y)) continue;
+            seen = true;
+            if (is_mate_of(x, y, T.tid)) { x.mate_ref = (tc << 32) | (int64_t)it->second; return 1; }
+        }
+        if (!seen) return 0;
+        x.mate_ref = -1;
+        return 1;
+    };
+    // generation by generation: the members whose mate has not been looked up; a found mate becomes a member
+    std::vector<int64_t> frontier;
+    for (size_t ti = 0; ti < P.tasks.size(); ti++)
+        for (size_t ri = 0; ri < P.tasks[ti].recs.size(); ri++)
+            if (P.tasks[ti].recs[ri].keep == 2) frontier.push_back(((int64_t)ti << 32) | (int64_t)ri);
+    int64_t n_lookups = 0;
+    for (int gen = 0; gen < 64 && !frontier.empty(); gen++) {
+        std::vector<Lookup> need;
+        {
+            const int w = workers_for((int64_t)frontier.size(), threads, 4096);
+            std::vector<std::vector<Lookup>> part((size_t)w);
+            parallel_slices((int64_t)frontier.size(), w, [&](int64_t i0, int64_t i1, int k) {
+                for (int64_t i = i0; i < i1; i++) {
+                    const int64_t ref = frontier[(size_t)i];
+                    WRec &x = rec_of(P, ref);
+                    if (x.mate_ref != -2) continue;
+                    if (!resolve_fast((size_t)(ref >> 32), (size_t)(ref & 0xFFFFFFFF))) part[(size_t)k].push_back(Lookup{ref, x.mtid, x.mpos});
+                }
+            });
+            for (auto &v : part) need.insert(need.end(), v.begin(), v.end());
+        }
+        if (!need.empty()) { // through the index: one extra task per look-up position (walked like a one-base fetch)
+            std::sort(need.begin(), need.end(), [](const Lookup &x, const Lookup &y) { return x.mtid < y.mtid || (x.mtid == y.mtid && (x.mpos < y.mpos || (x.mpos == y.mpos && x.who < y.who))); });
+            n_lookups += (int64_t)need.size();
+            std::vector<size_t> first; // look-ups of one position share a task
+            for (size_t k = 0; k < need.size(); k++)
+                if (k == 0 || need[k].mtid != need[k - 1].mtid || need[k].mpos != need[k - 1].mpos) first.push_back(k);
+            const size_t base = P.tasks.size();
+            P.tasks.resize(base + first.size());
+            const int w = (int)std::min<int64_t>(threads, (int64_t)first.size());
+            std::vector<std::unique_ptr<Inflater>> infs((size_t)std::max(1, w));
+            for (auto &p : infs) p.reset(new Inflater());
+            parallel_dynamic((int64_t)first.size(), std::max(1, w), [&](int64_t g, int k) {
+                Task &T = P.tasks[base + (size_t)g];
+                const Lookup &q = need[first[(size_t)g]];
+                T.tid = q.mtid; T.a = q.mpos; T.b = q.mpos + 1; T.f0 = T.f1 = 0;
+                spans_for(S.refs[(size_t)q.mtid], T.a, T.b, T.spans);
+                // walk: every record overlapping the position, no fetch (nothing is direct), keep those whose name is asked for
+                Inflater &inf = *infs[(size_t)k];
+                Stream s(S, inf);
+                const size_t k1 = (size_t)g + 1 < first.size() ? first[(size_t)g + 1] : need.size();
+                bool stop = false;
+                for (size_t ci = 0; ci < T.spans.size() && !stop; ci++) {
+                    s.seek(T.spans[ci].beg);
+                    for (;;) {
+                        uint64_t voff;
+                        const uint8_t *p;
+                        uint32_t bs;
+                        if (!s.next(voff, p, bs)) { stop = true; break; }
+                        if (voff >= T.spans[ci].end) break;
+                        const int32_t tid2 = rdi32(p), pos = rdi32(p + 4);
+                        if (tid2 != T.tid) { if (tid2 < 0 || tid2 > T.tid) { stop = true; break; } s.advance(bs); continue; }
+                        if (pos > q.mpos) { stop = true; break; }
+                        const uint32_t l_name = p[8], ncig = rd16(p + 12);
+                        const uint16_t fl = rd16(p + 14);
+                        const int32_t lseq = rdi32(p + 16);
+                        if (lseq < 0 || lseq > 0xFFFF) fail(UZ_IO_E_RANGE, "record too long for the 16-bit length columns (l_seq %d)", lseq);
+                        if (32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
+                        const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
+                        T.n_walked++;
+                        if (end > q.mpos) {
+                            const uint64_t h = hash_name(p + 32, (size_t)l_name - 1);
+                            bool asked = false;
+                            for (size_t u = first[(size_t)g]; u < k1 && !asked; u++) {
+                                const WRec &x = rec_of(P, need[u].who);
+                                const Task &TX = P.tasks[(size_t)(need[u].who >> 32)];
+                                asked = x.nhash == h && x.l_name == l_name - 1 && memcmp(TX.names.data() + x.name_at, p + 32, x.l_name) == 0;
+                            }
+                            if (asked) {
+                                WRec r;
+                                memset(&r, 0, sizeof(r));
+                                r.voff = voff; r.pos = pos; r.end = end; r.flag = fl; r.mapq = p[9];
+                                r.n_cigar = (uint16_t)ncig; r.l_seq = (uint16_t)lseq;
+                                r.mtid = rdi32(p + 20); r.mpos = rdi32(p + 24); r.tlen = rdi32(p + 28);
+                                r.mate_ref = -2; r.nhash = h; r.keep = 0;
+                                r.umask = P.opt.masks ? (uint16_t)0 : (uint16_t)UZ_UMASK_ALL;
+                                extract(T, r, p, bs, P.opt, P.opt.all_bases);
+                                T.recs.push_back(r);
+                            }
+                        }
+                        s.advance(bs);
+                    }
+                }
+                T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks;
+            });
+            // answers: first match in file order
+            for (size_t g = 0; g < first.size(); g++) {
+                const size_t k1 = g + 1 < first.size() ? first[g + 1] : need.size();
+                Task &T = P.tasks[base + g];
+                for (size_t u = first[g]; u < k1; u++) {
+                    WRec &x = rec_of(P, need[u].who);
+                    const Task &TX = P.tasks[(size_t)(need[u].who >> 32)];
+                    x.mate_ref = -1;
+                    for (size_t j = 0; j < T.recs.size(); j++)
+                        if (same_name(TX, x, T, T.recs[j]) && is_mate_of(x, T.recs[j], T.tid)) { x.mate_ref = ((int64_t)(base + g) << 32) | (int64_t)j; break; }
+                }
+            }
+        }
+        // the mates found become members; those that were not members yet are the next generation
+        std::vector<int64_t> next;
+        for (int64_t ref : frontier) {
+            const int64_t m = rec_of(P, ref).mate_ref;
+            if (m < 0) continue;
+            WRec &y = rec_of(P, m);
+            if (y.keep == 0) { y.keep = 1; next.push_back(m); }
+        }
+        frontier.swap(next);
+    }
+    double t3 = now_s();
+    P.timing[2] = t3 - t2;
+    P.io_stats[5] = n_lookups;
+
+    // ---- file order across tasks.  The tasks of the first walk are sorted and their kept records normally do not interleave; a
+    // record found through the index (or walked by two tasks: reads longer than the slack) can lie anywhere: then the kept
+    // records are sorted by virtual offset and duplicates folded.
+    std::vector<int64_t> &order = P.order;
+    {
+        std::vector<int64_t> t_first(P.tasks.size() + 1, 0);
+        for (size_t ti = 0; ti < P.tasks.size(); ti++) {
+            int64_t c = 0;
+            for (const WRec &r : P.tasks[ti].recs) c += r.keep != 0;
+            t_first[ti + 1] = t_first[ti] + c;
+        }
+        order.resize((size_t)t_first.back());
+        parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
+            for (int64_t ti = i0; ti < i1; ti++) {
+                int64_t at = t_first[(size_t)ti];
+                const auto &recs = P.tasks[(size_t)ti].recs;
+                for (size_t ri = 0; ri < recs.size(); ri++)
+                    if (recs[ri].keep) order[(size_t)at++] = ((int64_t)ti << 32) | (int64_t)ri;
+            }
+        });
+        bool sorted = true;
+        for (size_t ti = 0; ti + 1 < P.tasks.size() && sorted; ti++) { // kept records of consecutive tasks must ascend
+            if (t_first[ti + 1] == t_first[ti]) continue;
+            size_t tj = ti + 1;
+            while (tj < P.tasks.size() && t_first[tj + 1] == t_first[tj]) tj++;
+            if (tj < P.tasks.size() && rec_of(P, order[(size_t)t_first[ti + 1] - 1]).voff >= rec_of(P, order[(size_t)t_first[tj]]).voff) sorted = false;
+        }
+        if (!sorted) {
+            std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return rec_of(P, x).voff < rec_of(P, y).voff; });
+            std::vector<int64_t> uniq;
+            for (int64_t e : order) {
+                if (!uniq.empty() && rec_of(P, uniq.back()).voff == rec_of(P, e).voff) { // the same record kept twice: the one a fetch returned survives
+                    WRec &a = rec_of(P, uniq.back()), &b = rec_of(P, e);
+                    if (b.keep > a.keep) { P.folded[uniq.back()] = e; a.keep = 0; uniq.back() = e; }
+                    else { P.folded[e] = uniq.back(); b.keep = 0; }
+                    continue;
+                }
+                uniq.push_back(e);
+            }
+            order.swap(uniq);
+        }
+    }
+    const int64_t n = (int64_t)order.size();
+    if (n >= ((int64_t)1 << 31)) fail(UZ_IO_E_RANGE, "more than 2^31 - 1 alignment records");
+    P.n = n;
+    // slices of the output order: every later pass (and the fill) runs over them in parallel, with a serial step over the slices
+    const int W = workers_for(n, threads, 8192);
+    P.cut.assign((size_t)W + 1, 0);
+    for (int k = 0; k <= W; k++) P.cut[(size_t)k] = n * k / W;
+    auto slices = [&](auto fn) { parallel_slices(W, W, [&](int64_t s0, int64_t s1, int) { for (int64_t sl = s0; sl < s1; sl++) fn((int)sl, P.cut[(size_t)sl], P.cut[(size_t)sl + 1]); }); };
+    slices([&](int, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) rec_of(P, order[(size_t)k]).gidx = (uint32_t)k; });
+    // ---- names -> ids in order of first appearance (hash-sharded, as the table builder of the whole-file decoder does)
+    {
+        const int SH = 256;
+        std::vector<std::vector<int64_t>> hist((size_t)W, std::vector<int64_t>(SH, 0));
+        slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) hist[(size_t)sl][rec_of(P, order[(size_t)k]).nhash >> 56]++; });
+        std::vector<int64_t> sh_off(SH + 1, 0);
+        int64_t run = 0;
+        for (int sft = 0; sft < SH; sft++) {
+            sh_off[(size_t)sft] = run;
+            for (int w = 0; w < W; w++) { const int64_t c = hist[(size_t)w][(size_t)sft]; hist[(size_t)w][(size_t)sft] = run; run += c; }
+        }
+        sh_off[SH] = run;
+        std::vector<uint32_t> by_shard((size_t)n), first_of((size_t)n);
+        slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) by_shard[(size_t)hist[(size_t)sl][rec_of(P, order[(size_t)k]).nhash >> 56]++] = (uint32_t)k; });
+        parallel_slices(SH, workers_for(SH, threads, 1), [&](int64_t s0, int64_t s1, int) {
+            std::vector<int32_t> tab;
+            for (int64_t sft = s0; sft < s1; sft++) {
+                const int64_t a = sh_off[(size_t)sft], b = sh_off[(size_t)sft + 1];
+                size_t cap = 16;
+                while (cap < 2 * (size_t)(b - a)) cap <<= 1;
+                tab.assign(cap, -1);
+                for (int64_t e = a; e < b; e++) { // ascending k inside a shard: the first record met for a name is its first in the file
+                    const uint32_t k = by_shard[(size_t)e];
+                    const int64_t ref = order[k];
+                    const WRec &x = rec_of(P, ref);
+                    const Task &TX = P.tasks[(size_t)(ref >> 32)];
+                    size_t slot = (size_t)(x.nhash * 0x9E3779B97F4A7C15ULL >> 20) & (cap - 1);
+                    for (;;) {
+                        const int32_t f = tab[slot];
+                        if (f < 0) { tab[slot] = (int32_t)k; first_of[k] = k; break; }
+                        const int64_t rf = order[(size_t)f];
+                        if (same_name(TX, x, P.tasks[(size_t)(rf >> 32)], rec_of(P, rf))) { first_of[k] = (uint32_t)f; break; }
+                        slot = (slot + 1) & (cap - 1);
+                    }
+                }
+            }
+        });
+        std::vector<int64_t> nfirst((size_t)W + 1, 0);
+        slices([&](int sl, int64_t k0, int64_t k1) { int64_t c = 0; for (int64_t k = k0; k < k1; k++) c += first_of[(size_t)k] == (uint32_t)k; nfirst[(size_t)sl + 1] = c; });
+        for (int w = 0; w < W; w++) nfirst[(size_t)w + 1] += nfirst[(size_t)w];
+        P.name_of_id.assign((size_t)nfirst[(size_t)W], 0);
+        slices([&](int sl, int64_t k0, int64_t k1) {
+            int64_t id = nfirst[(size_t)sl];
+            for (int64_t k = k0; k < k1; k++)
+                if (first_of[(size_t)k] == (uint32_t)k) { rec_of(P, order[(size_t)k]).qid = (uint32_t)id; P.name_of_id[(size_t)id] = order[(size_t)k]; id++; }
+        });
+        slices([&](int, int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++)
+                if (first_of[(size_t)k] != (uint32_t)k) rec_of(P, order[(size_t)k]).qid = rec_of(P, order[first_of[(size_t)k]]).qid;
+        });
+        P.n_qnames = nfirst[(size_t)W];
+    }
+    // ---- the dictionary of the small columns: combinations numbered in order of first appearance (per slice, then joined in order)
+    const Opt &o = P.opt;
+    auto tup_of = [&](const WRec &x, uint64_t &key, uint32_t &k2) {
+        const bool bases = (x.keep == 2 || o.all_bases);
+        uint32_t aux = bases ? x.aux : (x.aux | UZ_AUX_NO_SEQ);
+        aux |= (uint32_t)x.simple << UZ_AUX_SIMPLE_SHIFT;
+        key = (uint64_t)x.flag | ((uint64_t)x.l_seq << 16) | ((uint64_t)x.n_cigar << 32) | ((uint64_t)x.mapq << 48) | ((uint64_t)(aux & 0xFFu) << 56);
+        k2 = (uint32_t)(o.lists ? x.n_low : (uint8_t)0) | ((uint32_t)(o.masks ? x.umask : (uint16_t)0) << 8);
+    };
+    {
+        struct KeyHash { size_t operator()(const std::pair<uint64_t, uint32_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second * 0xC2B2AE3D27D4EB4FULL); } };
+        typedef std::unordered_map<std::pair<uint64_t, uint32_t>, uint32_t, KeyHash> Dict;
+        std::vector<std::vector<std::pair<uint64_t, uint32_t>>> local((size_t)W);
+        std::vector<std::vector<uint32_t>> lidx((size_t)W);
+        slices([&](int sl, int64_t k0, int64_t k1) {
+            Dict d;
+            lidx[(size_t)sl].resize((size_t)(k1 - k0));
+            uint64_t lk = ~0ULL; uint32_t lk2 = ~0u, li = 0; // the combination of the record before: most records repeat it
+            for (int64_t k = k0; k < k1; k++) {
+                uint64_t key; uint32_t k2;
+                tup_of(rec_of(P, order[(size_t)k]), key, k2);
+                if (key != lk || k2 != lk2) {
+                    auto it = d.find({key, k2});
+                    if (it == d.end()) { it = d.emplace(std::make_pair(key, k2), (uint32_t)local[(size_t)sl].size()).first; local[(size_t)sl].push_back({key, k2}); }
+                    lk = key; lk2 = k2; li = it->second;
+                }
+                lidx[(size_t)sl][(size_t)(k - k0)] = li;
+            }
+        });
+        Dict dict;
+        std::vector<std::vector<uint32_t>> remap((size_t)W);
+        for (int w = 0; w < W; w++)
+            for (const auto &e : local[(size_t)w]) {
+                auto it = dict.find(e);
+                if (it == dict.end()) {
+                    if (dict.size() >= 65536) fail(UZ_IO_E_RANGE, "more than 65536 combinations of the small columns: stage this batch through the table form");
+                    it = dict.emplace(e, (uint32_t)dict.size()).first;
+                    P.tup_key.push_back(e.first);
+                    P.tup_k2.push_back(e.second);
+                }
+                remap[(size_t)w].push_back(it->second);
+            }
+        slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) rec_of(P, order[(size_t)k]).tup = (uint16_t)remap[(size_t)sl][lidx[(size_t)sl][(size_t)(k - k0)]]; });
+        P.n_tup = (int64_t)P.tup_key.size();
+    }
+    // ---- sizes: per slice, then the slices' first offsets
+    P.base.assign((size_t)W + 1, SliceBase());
+    std::vector<std::vector<int64_t>> cnt((size_t)W, std::vector<int64_t>((size_t)n_ref, 0));
+    std::vector<std::vector<int32_t>> span((size_t)W, std::vector<int32_t>((size_t)n_ref, 0));
+    std::vector<int> wides((size_t)W, 0);
+    slices([&](int sl, int64_t k0, int64_t k1) {
+        SliceBase b;
+        for (int64_t k = k0; k < k1; k++) {
+            const int64_t ref = order[(size_t)k];
+            WRec &x = rec_of(P, ref);
+            const int32_t tid_k = P.tasks[(size_t)(ref >> 32)].tid;
+            b.omitted += x.simple != 0;
+            b.cig += x.simple ? 0 : x.n_cigar;
+            b.units += UZ_ROW_UNITS(x.l_seq);
+            b.seq += x.n_units; b.exc += x.n_exc; b.qpos += x.n_qpos;
+            if (x.l_seq > 256) wides[(size_t)sl] = 1;
+            cnt[(size_t)sl][(size_t)tid_k]++;
+            span[(size_t)sl][(size_t)tid_k] = std::max(span[(size_t)sl][(size_t)tid_k], x.end - x.pos);
+            int16_t v[4];
+            int32_t e[4];
+            b.esc += d16_of(P, k, v, e);
+        }
+        P.base[(size_t)sl + 1] = b;
+    });
+    for (int w = 0; w < W; w++) P.base[(size_t)w + 1].add(P.base[(size_t)w]);
+    P.contig_off.assign((size_t)n_ref + 1, 0);
+    P.max_span.assign((size_t)n_ref, 0);
+    for (int w = 0; w < W; w++)
+        for (int32_t c = 0; c < n_ref; c++) {
+            P.contig_off[(size_t)c + 1] += cnt[(size_t)w][(size_t)c];
+            P.max_span[(size_t)c] = std::max(P.max_span[(size_t)c], span[(size_t)w][(size_t)c]);
+            P.wide |= wides[(size_t)w];
+        }
+    for (int32_t c = 0; c < n_ref; c++) P.contig_off[(size_t)c + 1] += P.contig_off[(size_t)c];
+    for (const Task &T : P.tasks) { P.io_stats[0] += T.file_bytes; P.io_stats[1] += T.n_blocks; P.io_stats[2] += T.n_walked; }
+    P.io_stats[3] = n;
+    P.io_stats[4] = (int64_t)n_tasks0;
+    P.timing[3] = now_s() - t3;
+}
+
+void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
+    const Opt &o = P.opt;
+    const int64_t n = P.n;
+    const SliceBase &tot = P.base.back();
+    auto need = [&](bool ok, const char *what) { if (!ok) fail(UZ_IO_E_ARG, "uz_stage_fill: the output view %s", what); };
+    need(out->seq2 || tot.seq == 0, "needs seq2 (two-bit base rows)");
+    need(!out->seq4, "must not set seq4 (the staged form carries two-bit rows)");
+    need(out->tup && out->tup_flag && out->tup_l_seq && out->tup_n_cigar && out->tup_mapq && out->tup_aux, "needs the dictionary form (tup, tup_*)");
+    need(out->start_d8 && out->tlen_s && out->mate_d && out->qname_d && !out->start_d, "needs the difference form with eight-bit starts (start_d8, tlen_s, mate_d, qname_d)");
+    need(tot.esc == 0 || (out->esc16_key && out->esc16_val), "needs the esc16_* list");
+    need(!out->end, "must leave `end` out (a BAM record's end is what its CIGAR gives)");
+    need(out->cigar_compact != 0, "must set cigar_compact");
+    if (o.lists) need(out->tup_n_low && (out->qlow_pos || tot.qpos == 0) && !out->qlow, "needs the list form of the qualities (tup_n_low, qlow_pos)");
+    else need(out->qlow && !out->tup_n_low, "needs the quality plane (qlow)");
+    if (o.masks) need(out->tup_umask != nullptr, "needs tup_umask");
+    need(!P.wide || out->qlow_pos_wide || !o.lists, "needs qlow_pos_wide (reads longer than 256 bases)");
+    if (tot.exc) need(out->exc_rec && out->exc_pos && out->exc_code, "needs the exc_* columns");
+    const uz_bamsrc &S = *P.src;
+    const int32_t n_ref = (int32_t)S.contigs.size();
+    out->n_segs = n; out->n_contigs = n_ref; out->min_base_qual = o.thr; out->n_qnames = (uint32_t)P.n_qnames;
+    out->n_cigar_total = tot.cig; out->n_cigar_omitted = tot.omitted; out->n_row_units = tot.units; out->n_seq_units = tot.seq;
+    out->n_exc = tot.exc; out->n_qlow_pos = o.lists ? tot.qpos : 0; out->n_tup = P.n_tup; out->n_esc16 = tot.esc;
+    auto w = [](const auto *p) { return const_cast<typename std::remove_const<typename std::remove_pointer<decltype(p)>::type>::type *>(p); };
+    for (int32_t c = 0; c <= n_ref; c++) w(out->contig_off)[c] = P.contig_off[(size_t)c];
+    for (int32_t c = 0; c < n_ref; c++) w(out->max_span)[c] = P.max_span[(size_t)c];
+    for (size_t t = 0; t < P.tup_key.size(); t++) {
+        const uint64_t key = P.tup_key[t];
+        w(out->tup_flag)[t] = (uint16_t)key; w(out->tup_l_seq)[t] = (uint16_t)(key >> 16); w(out->tup_n_cigar)[t] = (uint16_t)(key >> 32);
+        w(out->tup_mapq)[t] = (uint8_t)(key >> 48); w(out->tup_aux)[t] = (uint8_t)(key >> 56);
+        if (out->tup_n_low) w(out->tup_n_low)[t] = (uint8_t)(P.tup_k2[t] & 0xFF);
+        if (out->tup_umask) w(out->tup_umask)[t] = (uint16_t)(P.tup_k2[t] >> 8);
+    }
+    const bool wide = out->qlow_pos_wide != 0;
+    const int W = (int)P.cut.size() - 1;
+    parallel_slices(W, std::min(W, resolve_threads(threads)), [&](int64_t s0, int64_t s1, int) {
+        for (int64_t sl = s0; sl < s1; sl++) {
+            SliceBase at = P.base[(size_t)sl];
+            for (int64_t k = P.cut[(size_t)sl]; k < P.cut[(size_t)sl + 1]; k++) {
+                const int64_t ref = P.order[(size_t)k];
+                const Task &T = P.tasks[(size_t)(ref >> 32)];
+                const WRec &x = T.recs[(size_t)(ref & 0xFFFFFFFF)];
+                int16_t v[4];
+                int32_t e[4];
+                d16_of(P, k, v, e);
+                w(out->start_d8)[k] = v[0] == (int16_t)UZ_D16_ESC ? (uint8_t)UZ_D8_ESC : (uint8_t)v[0];
+                w(out->tlen_s)[k] = v[1]; w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3];
+                for (int c = 0; c < 4; c++)
+                    if (v[c] == (int16_t)UZ_D16_ESC) { w(out->esc16_key)[at.esc] = ((uint64_t)k << 2) | (uint64_t)c; w(out->esc16_val)[at.esc] = e[c]; at.esc++; }
+                w(out->tup)[k] = x.tup;
+                if (!x.simple) { memcpy(w(out->cigar) + at.cig, T.cigars.data() + x.cigar_at, (size_t)x.n_cigar * 4); at.cig += x.n_cigar; }
+                const uint8_t *pay = T.pay.data() + x.pay_at;
+                if (x.n_units) { memcpy(w(out->seq2) + (size_t)at.seq * UZ_SEQ2_UNIT_BYTES, pay, (size_t)x.n_units * 8); at.seq += x.n_units; }
+                pay += (size_t)x.n_units * 8;
+                for (int j = 0; j < (int)x.n_exc; j++) {
+                    w(out->exc_rec)[at.exc] = (uint32_t)k; w(out->exc_pos)[at.exc] = (uint16_t)(pay[4 * j] | (pay[4 * j + 1] << 8)); w(out->exc_code)[at.exc] = pay[4 * j + 2];
+                    at.exc++;
+                }
+                pay += (size_t)x.n_exc * 4;
+                for (int j = 0; j < (int)x.n_qpos; j++) {
+                    if (wide) { w(out->qlow_pos)[2 * at.qpos] = pay[2 * j]; w(out->qlow_pos)[2 * at.qpos + 1] = pay[2 * j + 1]; }
+                    else w(out->qlow_pos)[at.qpos] = pay[2 * j];
+                    at.qpos++;
+                }
+                pay += (size_t)x.n_qpos * 2;
+                if (!o.lists) { const size_t ub = (size_t)UZ_ROW_UNITS(x.l_seq) * UZ_QLOW_UNIT_BYTES; memcpy(w(out->qlow) + (size_t)at.units * UZ_QLOW_UNIT_BYTES, pay, ub); }
+                at.units += UZ_ROW_UNITS(x.l_seq);
+            }
+        }
+    });
+}
+
+template <typename F>
+int guarded(F &&fn) {
+    try {
+        fn();
+        return UZ_IO_OK;
+    } catch (const IoError &e) {
+        last_error = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        last_error = "out of memory";
+        return UZ_IO_E_RANGE;
+    } catch (const std::exception &e) {
+        last_error = e.what();
+        return UZ_IO_E_FORMAT;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int uz_bamsrc_open(const char *path, const char *bai_path, int64_t head_records, uz_bamsrc **out) {
+    if (!path || !out) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    *out = nullptr;
+    uz_bamsrc *s = new uz_bamsrc();
+    const int rc = guarded([&] { open_source(*s, path, bai_path, head_records); });
+    if (rc != UZ_IO_OK) { delete s; return rc; }
+    *out = s;
+    return UZ_IO_OK;
+}
+void uz_bamsrc_close(uz_bamsrc *s) { delete s; }
+int32_t uz_bamsrc_n_contigs(const uz_bamsrc *s) { return s ? (int32_t)s->contigs.size() : 0; }
+const char *uz_bamsrc_contig_name(const uz_bamsrc *s, int32_t i) { return (s && i >= 0 && (size_t)i < s->contigs.size()) ? s->contigs[(size_t)i].c_str() : nullptr; }
+int32_t uz_bamsrc_contig_length(const uz_bamsrc *s, int32_t i) { return (s && i >= 0 && (size_t)i < s->contig_len.size()) ? s->contig_len[(size_t)i] : -1; }
+int64_t uz_bamsrc_tlen_head(const uz_bamsrc *s, int32_t *out, int64_t cap) {
+    if (!s || !out || cap <= 0) return 0;
+    const int64_t k = std::min<int64_t>(cap, (int64_t)s->tlen_head.size());
+    memcpy(out, s->tlen_head.data(), (size_t)k * sizeof(int32_t));
+    return k;
+}
+const char *uz_inflate_backend(void) { return libdeflate().ok ? "libdeflate" : "zlib"; }
+
+int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int flags,
+                      int min_base_qual, int threads, uz_stage **out) {
+    if (!src || !out || (n_fetch > 0 && (!tid || !lo || !hi))) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    *out = nullptr;
+    uz_stage *P = new uz_stage();
+    P->src = src;
+    P->opt.all_bases = (flags & UZ_STAGE_ALL_BASES) != 0;
+    P->opt.lists = !(flags & UZ_STAGE_PLANE);
+    P->opt.masks = (flags & UZ_STAGE_UNIT_MASKS) && !P->opt.all_bases && P->opt.lists;
+    P->opt.thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
+    const int rc = guarded([&] { plan(*P, n_fetch, tid, lo, hi, extra, threads); });
+    if (rc != UZ_IO_OK) { delete P; return rc; }
+    *out = P;
+    return UZ_IO_OK;
+}
+
+void uz_stage_sizes(const uz_stage *P, int64_t out[12]) {
+    memset(out, 0, 12 * sizeof(int64_t));
+    if (!P) return;
+    const SliceBase &t = P->base.back();
+    out[0] = P->n; out[1] = t.cig; out[2] = t.omitted; out[3] = t.units; out[4] = t.seq; out[5] = t.exc; out[6] = t.qpos; out[7] = P->wide;
+    out[8] = P->n_tup; out[9] = t.esc; out[10] = P->n_qnames; out[11] = P->opt.masks ? 1 : 0;
+}
+void uz_stage_io_stats(const uz_stage *P, int64_t out[8]) { for (int k = 0; k < 8; k++) out[k] = P ? P->io_stats[k] : 0; }
+void uz_stage_timing(const uz_stage *P, double out[6]) { for (int k = 0; k < 6; k++) out[k] = P ? P->timing[k] : 0.0; }
+
+int uz_stage_fill(const uz_stage *P, int threads, uz_reads_packed_view *out) {
+    if (!P || !out) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    const double t0 = now_s();
+    const int rc = guarded([&] { fill(*P, threads, out); });
+    const_cast<uz_stage *>(P)->timing[4] = now_s() - t0;
+    return rc;
+}
+
+const char *uz_stage_qname(const uz_stage *P, uint32_t id, int32_t *len) {
+    if (!P || id >= P->name_of_id.size()) return nullptr;
+    const int64_t ref = P->name_of_id[id];
+    const Task &T = P->tasks[(size_t)(ref >> 32)];
+    const WRec &x = T.recs[(size_t)(ref & 0xFFFFFFFF)];
+    P->name_tmp.assign((const char *)T.names.data() + x.name_at, x.l_name);
+    if (len) *len = x.l_name;
+    return P->name_tmp.c_str();
+}
+
+void uz_stage_free(uz_stage *P) { delete P; }
+
+} // extern "C"

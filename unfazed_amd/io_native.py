@@ -30,6 +30,9 @@ IO_EXPORTS = [
     "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16", "uz_select_n_esc16_start8",
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
+    "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
+    "uz_inflate_backend", "uz_bam_stage_plan", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
+    "uz_stage_free",
 ]
 
 
@@ -136,6 +139,29 @@ def load():
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.uz_select_free.argtypes = [C.c_void_p]
     lib.uz_select_free.restype = None
+    lib.uz_bamsrc_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.uz_bamsrc_close.argtypes = [C.c_void_p]
+    lib.uz_bamsrc_close.restype = None
+    lib.uz_bamsrc_n_contigs.argtypes = [C.c_void_p]
+    lib.uz_bamsrc_contig_name.argtypes = [C.c_void_p, C.c_int32]
+    lib.uz_bamsrc_contig_name.restype = C.c_char_p
+    lib.uz_bamsrc_contig_length.argtypes = [C.c_void_p, C.c_int32]
+    lib.uz_bamsrc_tlen_head.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.uz_bamsrc_tlen_head.restype = C.c_int64
+    lib.uz_inflate_backend.restype = C.c_char_p
+    lib.uz_bam_stage_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]
+    lib.uz_stage_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_stage_sizes.restype = None
+    lib.uz_stage_io_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_stage_io_stats.restype = None
+    lib.uz_stage_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.uz_stage_timing.restype = None
+    lib.uz_stage_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.uz_stage_qname.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
+    lib.uz_stage_qname.restype = C.c_void_p
+    lib.uz_stage_free.argtypes = [C.c_void_p]
+    lib.uz_stage_free.restype = None
     _LIB = lib
     return lib
 
@@ -490,3 +516,84 @@ class ReadsSource:
         finally:
             self.lib.uz_select_free(sel)
         return (out, idx[:n]) if want_index else out
+
+
+# ---------------------------------------------------------------------------- BAM file -> staged records in one pass
+STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE = 1, 2, 4
+
+
+def inflate_backend() -> str:
+    return load().uz_inflate_backend().decode()
+
+
+class _StageNames(Sequence):
+    """id -> query name of a staged batch (uz_stage_qname)"""
+
+    def __init__(self, lib, handle: _Handle, n: int):
+        self._lib, self._h, self._n = lib, handle, n
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        i = int(i)
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        ln = C.c_int32(0)
+        p = self._lib.uz_stage_qname(self._h.ptr, i, C.byref(ln))
+        return C.string_at(p, ln.value).decode()
+
+
+class BamSource:
+    """An indexed BAM opened for staging (uz_bamsrc_open): `select` turns the fetches of one batch straight into the packed table
+    uz_reads_upload_packed takes -- what read_bam_regions + pack_reads + ReadsSource.select build in three passes, in one."""
+
+    def __init__(self, path: str, bai: str = None, insert_size_max_sample: int = 1000000, threads: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.uz_bamsrc_open(os.fsencode(path), os.fsencode(bai) if bai else None, int(insert_size_max_sample) + 1, C.byref(h)))
+        self._h = _Handle(h.value, self.lib.uz_bamsrc_close)
+        self.path, self.threads = path, threads
+        nc = self.lib.uz_bamsrc_n_contigs(h)
+        self.contigs = [self.lib.uz_bamsrc_contig_name(h, i).decode() for i in range(nc)]
+        self.contig_len = [self.lib.uz_bamsrc_contig_length(h, i) for i in range(nc)]
+        head = np.zeros(int(insert_size_max_sample) + 1, np.int32)
+        k = self.lib.uz_bamsrc_tlen_head(h, head.ctypes.data, head.size)
+        self.tlen_head = head[: int(k)].copy()
+
+    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None):
+        """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
+        `.io_stats` / `.timing` / `.qnames` ride on the returned object."""
+        contig = np.ascontiguousarray(contig, np.int32)
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        masks = extra is not None and lists and not all_bases
+        if extra is not None:
+            extra = np.ascontiguousarray(extra, np.uint16)
+            assert extra.size == contig.size
+        flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_UNIT_MASKS if masks else 0) | (0 if lists else STAGE_PLANE)
+        st = C.c_void_p()
+        _check(self.lib, self.lib.uz_bam_stage_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                                    extra.ctypes.data if extra is not None else None, flags, int(min_base_qual), int(self.threads),
+                                                    C.byref(st)))
+        sh = _Handle(st.value, self.lib.uz_stage_free)
+        z = (C.c_int64 * 12)()
+        self.lib.uz_stage_sizes(sh.ptr, z)
+        n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um = (int(x) for x in z)
+        out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
+                                    n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
+                                    cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True)
+        _check(self.lib, self.lib.uz_stage_fill(sh.ptr, int(self.threads), out.ref()))
+        io = (C.c_int64 * 8)()
+        self.lib.uz_stage_io_stats(sh.ptr, io)
+        tm = (C.c_double * 6)()
+        self.lib.uz_stage_timing(sh.ptr, tm)
+        out.io_stats = dict(zip(("file_bytes_read", "blocks_inflated", "records_walked", "records_kept", "reach_intervals", "index_mate_lookups"),
+                                (int(x) for x in io)))
+        out.timing = dict(zip(("spans", "walk", "mates", "numbering", "fill"), (float(x) for x in tm)))
+        out.qnames = _StageNames(self.lib, sh, n_names)
+        return out
