@@ -3,6 +3,8 @@
 #include "uz_ctx.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n);
 bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv);
@@ -44,6 +46,19 @@ T *upload(uz_ctx *c, const T *host, size_t n) {
 // the columns' device addresses follow from their offsets in it.  Every separate copy costs the link ~8 us of set-up, and
 // a staged table has about twenty columns, half of them tiny.  A staging routine runs its h2d() calls twice: a planning
 // pass that only looks at the host addresses, then -- mirrored or not -- the pass that yields the device pointers.
+// the page-locked blocks this library handed out (uz_pinned_alloc): the one-copy path ships a span of host memory as a whole, so the
+// span must lie inside ONE block the caller really owns -- never a guess from address density (columns of separate allocations
+// that happen to sit close together, with unmapped or foreign memory between them)
+static std::mutex g_pinned_mu;
+static std::map<uintptr_t, size_t> g_pinned;
+static bool inside_one_pinned_block(const uint8_t *lo, const uint8_t *hi) {
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    auto it = g_pinned.upper_bound((uintptr_t)lo);
+    if (it == g_pinned.begin()) return false;
+    --it;
+    return (uintptr_t)lo >= it->first && (uintptr_t)hi <= it->first + it->second;
+}
+
 struct SlabPlan {
     int mode = 1; // 1 planning, 2 mirrored
     const uint8_t *lo = nullptr, *hi = nullptr;
@@ -62,7 +77,7 @@ struct SlabPlan {
         if (at.size() < 2 || span() > sum + sum / 8 + 1024 * at.size()) return false;
         for (const uint8_t *q : at)
             if ((size_t)(q - lo) % 256) return false; // the kernels' vector loads want the carver's alignment
-        return true;
+        return inside_one_pinned_block(lo, hi);
     }
 };
 static thread_local SlabPlan *g_slab = nullptr;
@@ -888,10 +903,18 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
 int uz_pinned_alloc(size_t bytes, void **out) {
     if (!out) return UZ_E_ARG;
     *out = nullptr;
-    return hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault) == hipSuccess ? 0 : UZ_E_HIP;
+    if (hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocDefault) != hipSuccess) return UZ_E_HIP;
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    g_pinned[(uintptr_t)*out] = bytes ? bytes : 64;
+    return 0;
 }
 void uz_pinned_free(void *p) {
-    if (p) (void)hipHostFree(p);
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        g_pinned.erase((uintptr_t)p);
+    }
+    (void)hipHostFree(p);
 }
 
 int uz_drop_derived(uz_ctx *c) {

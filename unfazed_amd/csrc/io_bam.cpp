@@ -132,28 +132,12 @@ Bytes inflate_all(Bytes &f, int threads, bool *was_gzip) {
     if (!scan_bgzf(f, blocks, total)) return inflate_stream(f);
     Bytes out(total);
     parallel_slices((int64_t)blocks.size(), workers_for((int64_t)blocks.size(), threads, 8), [&](int64_t lo, int64_t hi, int) {
-        z_stream z;
-        memset(&z, 0, sizeof(z));
-        if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
+        Inflater inf;
         for (int64_t k = lo; k < hi; k++) {
             const Block &b = blocks[(size_t)k];
             if (b.isize == 0 && b.clen <= 2) continue; // EOF marker
-            inflateReset(&z);
-            z.next_in = const_cast<Bytef *>(f.data() + b.cdata);
-            z.avail_in = (uInt)b.clen;
-            z.next_out = out.data() + b.out_off;
-            z.avail_out = b.isize;
-            const int rc = inflate(&z, Z_FINISH);
-            if (rc != Z_STREAM_END || z.avail_out != 0) {
-                inflateEnd(&z);
-                fail(UZ_IO_E_FORMAT, "corrupt BGZF block %lld", (long long)k);
-            }
-            if ((uint32_t)crc32(0L, out.data() + b.out_off, b.isize) != b.crc) {
-                inflateEnd(&z);
-                fail(UZ_IO_E_FORMAT, "CRC mismatch in BGZF block %lld", (long long)k);
-            }
+            inf.block(f.data() + b.cdata, b.clen, out.data() + b.out_off, b.isize, b.crc, (int64_t)b.cdata);
         }
-        inflateEnd(&z);
     });
     return out;
 }
@@ -247,9 +231,11 @@ bool has_tag(const uint8_t *p, const uint8_t *end, char t0, char t1) {
 // BAM header at the start of the inflated stream d[0, N): fills the contig tables, returns the offset of the first record
 size_t parse_header(uz_bam &B, const uint8_t *d, size_t N, const char *path, int32_t &n_ref, bool allow_short = false) {
     if (N < 12 || memcmp(d, "BAM\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a BAM file", path);
+    if (rdi32(d + 4) < 0) fail(UZ_IO_E_FORMAT, "bad BAM header (negative l_text)");
     size_t off = 8 + (size_t)rdi32(d + 4);
     if (off + 4 > N) { if (allow_short) return 0; fail(UZ_IO_E_FORMAT, "truncated BAM header"); }
     n_ref = rdi32(d + off);
+    if (n_ref < 0) fail(UZ_IO_E_FORMAT, "bad BAM header (negative n_ref)");
     off += 4;
     B.contigs.clear(); B.contig_len.clear();
     for (int32_t r = 0; r < n_ref; r++) {

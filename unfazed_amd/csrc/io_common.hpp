@@ -11,6 +11,13 @@
 #include <thread>
 #include <vector>
 #include <zlib.h>
+#include <dlfcn.h>
+#include <sched.h>
+#include <unistd.h>
+#include <new>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 
 #include "unfazed_io.h"
 
@@ -37,7 +44,12 @@ inline double now_s() {
 }
 
 inline int resolve_threads(int threads) {
-    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) { // the CPUs this process may run on (an affinity mask narrower than the machine counts), not the machine's
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) threads = CPU_COUNT(&set);
+        if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    }
     if (threads <= 0) threads = 1;
     return threads > 256 ? 256 : threads;
 }
@@ -48,22 +60,104 @@ inline int workers_for(int64_t n, int threads, int64_t grain) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(threads, by_work));
 }
 
+// The library's worker threads: created once and parked between jobs (a staged batch runs a dozen short parallel passes; starting
+// 256 threads for each costs more than the passes).  One job at a time (callers on other threads queue); a job started from inside a
+// job runs inline.  The pool follows the caller's CPU affinity: when that changes it is rebuilt.
+class ThreadPool {
+  public:
+    static ThreadPool &get() { static ThreadPool p; return p; }
+    // fn(worker) on `w` workers (the caller is worker 0); the first exception wins
+    template <typename F>
+    void run(int w, F &&fn) {
+        if (w <= 1 || in_job()) { fn(0); return; }
+        std::lock_guard<std::mutex> submit(submit_mu_);
+        ensure(w - 1);
+        w = std::min<int>(w, (int)th_.size() + 1);
+        std::vector<IoError> errs((size_t)w, IoError{0, ""});
+        std::function<void(int)> job = [&](int k) {
+            try { fn(k); } catch (const IoError &e) { errs[(size_t)k] = e; } catch (const std::exception &e) { errs[(size_t)k] = IoError{UZ_IO_E_FORMAT, e.what()}; }
+        };
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            job_ = &job; want_ = w - 1; active_ = w - 1; gen_++;
+        }
+        cv_job_.notify_all();
+        in_job() = true;
+        job(0);
+        in_job() = false;
+        {
+            std::unique_lock<std::mutex> g(mu_);
+            cv_done_.wait(g, [&] { return active_ == 0; });
+            job_ = nullptr;
+        }
+        for (auto &e : errs) if (e.code) throw e;
+    }
+    ~ThreadPool() { shutdown(); }
+
+  private:
+    static bool &in_job() { static thread_local bool f = false; return f; }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true; gen_++;
+        }
+        cv_job_.notify_all();
+        for (auto &t : th_) t.join();
+        th_.clear();
+        stop_ = false;
+    }
+    void ensure(int n) {
+        if (pid_ != getpid()) { // a forked child: the parent's workers do not exist here -- forget them (never join or destroy)
+            new (&th_) std::vector<std::thread>();
+            pid_ = getpid();
+        }
+        cpu_set_t now;
+        CPU_ZERO(&now);
+        sched_getaffinity(0, sizeof(now), &now);
+        if (!th_.empty() && !CPU_EQUAL(&now, &mask_)) shutdown();
+        mask_ = now;
+        n = std::min(n, 1023);
+        while ((int)th_.size() < n) {
+            const int k = (int)th_.size() + 1;
+            const int gen0 = gen_;
+            th_.emplace_back([this, k, gen0] {
+                in_job() = true;
+                int seen = gen0;
+                for (;;) {
+                    std::function<void(int)> *job = nullptr;
+                    {
+                        std::unique_lock<std::mutex> g(mu_);
+                        cv_job_.wait(g, [&] { return gen_ != seen; });
+                        seen = gen_;
+                        if (stop_) return;
+                        if (k <= want_) job = job_;
+                    }
+                    if (job) {
+                        (*job)(k);
+                        std::lock_guard<std::mutex> g(mu_);
+                        if (--active_ == 0) cv_done_.notify_all();
+                    }
+                }
+            });
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_, submit_mu_;
+    std::condition_variable cv_job_, cv_done_;
+    std::function<void(int)> *job_ = nullptr;
+    int gen_ = 0, want_ = 0, active_ = 0;
+    bool stop_ = false;
+    cpu_set_t mask_;
+    pid_t pid_ = getpid();
+};
+
 // fn(lo, hi, worker) over [0, n) cut into one contiguous slice per worker; the first exception wins
 template <typename F>
 void parallel_slices(int64_t n, int threads, F fn) {
     if (n <= 0) return;
-    int w = (int)std::min<int64_t>(threads, n);
+    const int w = (int)std::min<int64_t>(threads, n);
     if (w <= 1) { fn((int64_t)0, n, 0); return; }
-    std::vector<std::thread> pool;
-    std::vector<IoError> errs(w, IoError{0, ""});
-    for (int k = 0; k < w; k++) {
-        const int64_t lo = n * k / w, hi = n * (k + 1) / w;
-        pool.emplace_back([&, lo, hi, k] {
-            try { fn(lo, hi, k); } catch (const IoError &e) { errs[k] = e; } catch (const std::exception &e) { errs[k] = IoError{UZ_IO_E_FORMAT, e.what()}; }
-        });
-    }
-    for (auto &t : pool) t.join();
-    for (auto &e : errs) if (e.code) throw e;
+    ThreadPool::get().run(w, [&](int k) { fn(n * k / w, n * (k + 1) / w, k); });
 }
 
 inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
@@ -93,6 +187,86 @@ struct Bytes {
     uint8_t *data() { return p; }
     const uint8_t &operator[](size_t i) const { return p[i]; }
 };
+
+// ------------------------------------------------------------------------------------------------ inflate
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+};
+
+inline const LibDeflate &libdeflate() {
+    static LibDeflate L;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("UZ_INFLATE");
+        if (e && strcmp(e, "zlib") == 0) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        L.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        L.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        L.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        L.crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        L.ok = L.alloc && L.decompress && L.release && L.crc;
+    });
+    return L;
+}
+
+struct Inflater {
+    void *ld = nullptr;
+    z_stream z;
+    bool z_init = false;
+    Inflater() {
+        const LibDeflate &L = libdeflate();
+        if (L.ok) ld = L.alloc();
+        if (!ld) {
+            memset(&z, 0, sizeof(z));
+            if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
+            z_init = true;
+        }
+    }
+    ~Inflater() {
+        if (ld) libdeflate().release(ld);
+        if (z_init) inflateEnd(&z);
+    }
+    Inflater(const Inflater &) = delete;
+    void block(const uint8_t *c, size_t clen, uint8_t *dst, size_t isize, uint32_t crc, int64_t coff) {
+        if (isize == 0) return;
+        if (ld) {
+            size_t got = 0;
+            if (libdeflate().decompress(ld, c, clen, dst, isize, &got) != 0 || got != isize) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
+            if (libdeflate().crc(0, dst, isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
+            return;
+        }
+        inflateReset(&z);
+        z.next_in = const_cast<Bytef *>(c);
+        z.avail_in = (uInt)clen;
+        z.next_out = dst;
+        z.avail_out = (uInt)isize;
+        if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
+        if ((uint32_t)crc32(0L, dst, (uInt)isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
+    }
+};
+
+template <typename F>
+void parallel_dynamic(int64_t n, int threads, F fn) { // fn(item, worker): items handed out one by one (uneven costs)
+    if (n <= 0) return;
+    const int w = (int)std::min<int64_t>(std::max(1, threads), n);
+    if (w <= 1) { for (int64_t i = 0; i < n; i++) fn(i, 0); return; }
+    std::atomic<int64_t> next{0};
+    ThreadPool::get().run(w, [&](int k) {
+        try {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i, k);
+            }
+        } catch (...) { next.store(n); throw; }
+    });
+}
 
 // whole file -> memory
 Bytes read_file(const char *path);

@@ -20,15 +20,21 @@ struct BaiRef {
 // the per-reference part of a BAI / TBI: n_ref x { bins { chunks }, linear index }, starting at d[off]
 inline std::vector<BaiRef> parse_index_refs(const uint8_t *d, size_t N, size_t off, int32_t n_ref, const char *path) {
     auto need = [&](size_t k) { if (off + k > N) fail(UZ_IO_E_FORMAT, "truncated index %s", path); };
-    std::vector<BaiRef> refs((size_t)std::max(n_ref, 0));
+    // counts are signed in the file: a negative one (a corrupt index) must not wrap into a huge size or move `off` backwards
+    auto count = [&](int32_t v, size_t each, const char *what) {
+        if (v < 0 || (size_t)v > (N - std::min(off, N)) / each) fail(UZ_IO_E_FORMAT, "corrupt index %s: bad %s count %d", path, what, v);
+        return (size_t)v;
+    };
+    if (n_ref < 0 || (size_t)n_ref > N) fail(UZ_IO_E_FORMAT, "corrupt index %s: bad reference count %d", path, n_ref);
+    std::vector<BaiRef> refs((size_t)n_ref);
     for (int32_t r = 0; r < n_ref; r++) {
         need(4);
-        const int32_t n_bin = rdi32(d + off); off += 4;
+        const int32_t n_bin = (int32_t)count(rdi32(d + off), 8, "bin"); off += 4;
         for (int32_t b = 0; b < n_bin; b++) {
             need(8);
             const uint32_t bin = rd32(d + off);
-            const int32_t n_chunk = rdi32(d + off + 4);
             off += 8;
+            const int32_t n_chunk = (int32_t)count(rdi32(d + off - 4), 16, "chunk");
             need((size_t)n_chunk * 16);
             std::vector<Chunk> cs;
             if (bin != 37450) { // the pseudo-bin holds counts, not chunks
@@ -44,7 +50,8 @@ inline std::vector<BaiRef> parse_index_refs(const uint8_t *d, size_t N, size_t o
         }
         std::sort(refs[(size_t)r].bins.begin(), refs[(size_t)r].bins.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
         need(4);
-        const int32_t n_intv = rdi32(d + off); off += 4;
+        off += 4;
+        const int32_t n_intv = (int32_t)count(rdi32(d + off - 4), 8, "interval");
         need((size_t)n_intv * 8);
         refs[(size_t)r].linear.resize((size_t)n_intv);
         if (n_intv) memcpy(refs[(size_t)r].linear.data(), d + off, (size_t)n_intv * 8);
@@ -133,14 +140,9 @@ inline bool inflate_one(const FileRd &f, int64_t coff, Inflated &o, z_stream &z,
     o.block_at.emplace_back(coff, at);
     o.bytes.resize(at + isize);
     if (isize) {
-        inflateReset(&z);
-        z.next_in = cbuf.data() + 12 + xlen;
-        z.avail_in = (uInt)(blen - 12 - xlen - 8);
-        z.next_out = o.bytes.data() + at;
-        z.avail_out = isize;
-        const int rc = inflate(&z, Z_FINISH);
-        if (rc != Z_STREAM_END || z.avail_out != 0) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
-        if ((uint32_t)crc32(0L, o.bytes.data() + at, isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
+        (void)z; // (the caller's zlib stream is not used any more: the thread's own inflater -- libdeflate when the system has it)
+        static thread_local Inflater tl_inf;
+        tl_inf.block(cbuf.data() + 12 + xlen, blen - 12 - xlen - 8, o.bytes.data() + at, isize, crc, coff);
     }
     o.next_coff = coff + (int64_t)blen;
     if (file_bytes) *file_bytes += (int64_t)blen;

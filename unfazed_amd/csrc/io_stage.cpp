@@ -16,7 +16,6 @@
 //
 // Inflate: libdeflate when the system has it (dlopen, no headers needed: three functions of its stable ABI), else
 // zlib.  UZ_INFLATE=zlib forces zlib.
-#include <dlfcn.h>
 #include <sys/mman.h>
 
 #include <atomic>
@@ -31,91 +30,6 @@
 using namespace uzio;
 
 namespace {
-
-// ------------------------------------------------------------------------------------------------ inflate
-struct LibDeflate {
-    void *(*alloc)() = nullptr;
-    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
-    void (*release)(void *) = nullptr;
-    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
-    bool ok = false;
-};
-
-const LibDeflate &libdeflate() {
-    static LibDeflate L;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char *e = getenv("UZ_INFLATE");
-        if (e && strcmp(e, "zlib") == 0) return;
-        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
-        if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
-        if (!h) return;
-        L.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
-        L.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
-        L.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
-        L.crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
-        L.ok = L.alloc && L.decompress && L.release && L.crc;
-    });
-    return L;
-}
-
-struct Inflater {
-    void *ld = nullptr;
-    z_stream z;
-    bool z_init = false;
-    Inflater() {
-        const LibDeflate &L = libdeflate();
-        if (L.ok) ld = L.alloc();
-        if (!ld) {
-            memset(&z, 0, sizeof(z));
-            if (inflateInit2(&z, -15) != Z_OK) fail(UZ_IO_E_FORMAT, "zlib init failed");
-            z_init = true;
-        }
-    }
-    ~Inflater() {
-        if (ld) libdeflate().release(ld);
-        if (z_init) inflateEnd(&z);
-    }
-    Inflater(const Inflater &) = delete;
-    void block(const uint8_t *c, size_t clen, uint8_t *dst, size_t isize, uint32_t crc, int64_t coff) {
-        if (isize == 0) return;
-        if (ld) {
-            size_t got = 0;
-            if (libdeflate().decompress(ld, c, clen, dst, isize, &got) != 0 || got != isize) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
-            if (libdeflate().crc(0, dst, isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
-            return;
-        }
-        inflateReset(&z);
-        z.next_in = const_cast<Bytef *>(c);
-        z.avail_in = (uInt)clen;
-        z.next_out = dst;
-        z.avail_out = (uInt)isize;
-        if (inflate(&z, Z_FINISH) != Z_STREAM_END || z.avail_out != 0) fail(UZ_IO_E_FORMAT, "corrupt BGZF block at byte %lld", (long long)coff);
-        if ((uint32_t)crc32(0L, dst, (uInt)isize) != crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the BGZF block at byte %lld", (long long)coff);
-    }
-};
-
-template <typename F>
-void parallel_dynamic(int64_t n, int threads, F fn) { // fn(item, worker): items handed out one by one (uneven costs)
-    if (n <= 0) return;
-    const int w = (int)std::min<int64_t>(std::max(1, threads), n);
-    if (w <= 1) { for (int64_t i = 0; i < n; i++) fn(i, 0); return; }
-    std::atomic<int64_t> next{0};
-    std::vector<std::thread> pool;
-    std::vector<IoError> errs((size_t)w, IoError{0, ""});
-    for (int k = 0; k < w; k++)
-        pool.emplace_back([&, k] {
-            try {
-                for (;;) {
-                    const int64_t i = next.fetch_add(1);
-                    if (i >= n) break;
-                    fn(i, k);
-                }
-            } catch (const IoError &e) { errs[(size_t)k] = e; next.store(n); } catch (const std::exception &e) { errs[(size_t)k] = IoError{UZ_IO_E_FORMAT, e.what()}; next.store(n); }
-        });
-    for (auto &t : pool) t.join();
-    for (auto &e : errs) if (e.code) throw e;
-}
 
 inline uint64_t hash_name(const uint8_t *s, size_t n) { // FNV-1a with a final mix
     uint64_t h = 1469598103934665603ULL;

@@ -466,81 +466,110 @@ void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n
                 at = e + 1;
             }
         }
+        // work items: (reference, chunk) in file order; every item is walked by one worker into its own text
+        struct Item { int32_t r; Chunk ck; };
+        std::vector<Item> items;
+        std::vector<std::vector<Iv>> merged_of((size_t)n_ref);
         for (int32_t r = 0; r < n_ref; r++) {
             std::vector<Iv> &v = ivs[(size_t)r];
             if (v.empty()) continue;
             std::sort(v.begin(), v.end(), [](const Iv &a, const Iv &b) { return a.lo < b.lo || (a.lo == b.lo && a.hi < b.hi); });
-            std::vector<Iv> merged;
+            std::vector<Iv> &merged = merged_of[(size_t)r];
             for (const Iv &iv : v) {
                 if (!merged.empty() && iv.lo <= merged.back().hi) merged.back().hi = std::max(merged.back().hi, iv.hi);
                 else merged.push_back(iv);
             }
+            // chunks per merged interval, then joined per BGZF block: a window costs its own blocks, not the rest of its 16 kb bin
             std::vector<Chunk> chunks;
-            chunks_for(tbi.refs[(size_t)r], merged, chunks);
+            for (const Iv &iv : merged) {
+                std::vector<Chunk> one;
+                chunks_for(tbi.refs[(size_t)r], std::vector<Iv>{iv}, one);
+                chunks.insert(chunks.end(), one.begin(), one.end());
+            }
+            std::sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.beg < b.beg || (a.beg == b.beg && a.end < b.end); });
+            std::vector<Chunk> joined;
+            for (const Chunk &c : chunks) {
+                if (!joined.empty() && (c.beg >> 16) <= (joined.back().end >> 16)) joined.back().end = std::max(joined.back().end, c.end);
+                else joined.push_back(c);
+            }
+            for (const Chunk &c : joined) items.push_back(Item{r, c});
+        }
+        std::vector<std::string> texts(items.size());
+        std::vector<int64_t> st_bytes(items.size(), 0), st_blocks(items.size(), 0), st_walked(items.size(), 0), st_kept(items.size(), 0);
+        parallel_dynamic((int64_t)items.size(), threads, [&](int64_t it, int) {
+            const int32_t r = items[(size_t)it].r;
+            const Chunk ck = items[(size_t)it].ck;
+            const std::vector<Iv> &merged = merged_of[(size_t)r];
             const std::string &name = tbi.names[(size_t)r];
-            for (const Chunk &ck : chunks) {
-                Inflated inf;
-                if (!inflate_one(file, (int64_t)(ck.beg >> 16), inf, z, cbuf, &file_bytes, &blocks)) continue;
-                size_t at = (size_t)(ck.beg & 0xFFFF), blk = 0;
-                for (;;) {
-                    while (at >= inf.bytes.size())
-                        if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) goto chunk_done;
-                    while (blk + 1 < inf.block_at.size() && inf.block_at[blk + 1].second <= at) blk++;
-                    {
-                        const uint64_t voff = ((uint64_t)inf.block_at[blk].first << 16) | (uint64_t)(at - inf.block_at[blk].second);
-                        if (voff >= ck.end) break;
-                    }
-                    const uint8_t *nl;
-                    bool eof = false;
-                    while (!(nl = (const uint8_t *)memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at)))
-                        if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) { eof = true; break; }
-                    const size_t e = eof ? inf.bytes.size() : (size_t)(nl - inf.bytes.data());
-                    const char *L = (const char *)inf.bytes.data() + at;
-                    const size_t len = e - at;
-                    walked++;
-                    if (len && L[0] != '#') {
-                        // CHROM, POS, REF (columns 1, 2, 4) and INFO/END (column 8)
-                        const char *c1 = (const char *)memchr(L, '\t', len);
-                        const char *c2 = c1 ? (const char *)memchr(c1 + 1, '\t', len - (size_t)(c1 + 1 - L)) : nullptr;
-                        if (c1 && c2 && (size_t)(c1 - L) == name.size() && memcmp(L, name.data(), name.size()) == 0) {
-                            long long pos1 = 0;
-                            if (parse_int(Str{c1 + 1, (size_t)(c2 - c1 - 1)}, pos1)) {
-                                const long long pos0 = pos1 - 1;
-                                long long end = pos0 + 1;
-                                const char *c3 = (const char *)memchr(c2 + 1, '\t', len - (size_t)(c2 + 1 - L));
-                                const char *c4 = c3 ? (const char *)memchr(c3 + 1, '\t', len - (size_t)(c3 + 1 - L)) : nullptr;
-                                if (c3 && c4) end = pos0 + std::max<long long>(1, (long long)(c4 - c3 - 1));
-                                // (INFO/END may reach further: looked for anywhere in the rest of the line -- a superset is fine)
-                                for (const char *q = c4 ? c4 : L + len; q && q + 4 < L + len;) {
-                                    const char *h = (const char *)memmem(q, (size_t)(L + len - q), "END=", 4);
-                                    if (!h) break;
-                                    if (h[-1] == ';' || h[-1] == '\t') {
-                                        long long ev = 0;
-                                        const char *s0 = h + 4, *s1 = s0;
-                                        while (s1 < L + len && *s1 >= '0' && *s1 <= '9') s1++;
-                                        if (s1 > s0 && parse_int(Str{s0, (size_t)(s1 - s0)}, ev)) end = std::max(end, ev);
-                                    }
-                                    q = h + 4;
+            const int32_t last_hi = merged.back().hi;
+            std::string &text = texts[(size_t)it];
+            int64_t &file_bytes = st_bytes[(size_t)it], &blocks = st_blocks[(size_t)it], &walked = st_walked[(size_t)it], &kept = st_kept[(size_t)it];
+            std::vector<uint8_t> cbuf;
+            z_stream z; // (unused by inflate_one: kept for its signature)
+            Inflated inf;
+            if (!inflate_one(file, (int64_t)(ck.beg >> 16), inf, z, cbuf, &file_bytes, &blocks)) return;
+            size_t at = (size_t)(ck.beg & 0xFFFF), blk = 0;
+            for (;;) {
+                while (at >= inf.bytes.size())
+                    if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) return;
+                while (blk + 1 < inf.block_at.size() && inf.block_at[blk + 1].second <= at) blk++;
+                {
+                    const uint64_t voff = ((uint64_t)inf.block_at[blk].first << 16) | (uint64_t)(at - inf.block_at[blk].second);
+                    if (voff >= ck.end) break;
+                }
+                const uint8_t *nl;
+                bool eof = false;
+                while (!(nl = (const uint8_t *)memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at)))
+                    if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) { eof = true; break; }
+                const size_t e = eof ? inf.bytes.size() : (size_t)(nl - inf.bytes.data());
+                const char *L = (const char *)inf.bytes.data() + at;
+                const size_t len = e - at;
+                walked++;
+                if (len && L[0] != '#') {
+                    // CHROM, POS, REF (columns 1, 2, 4) and INFO/END (column 8)
+                    const char *c1 = (const char *)memchr(L, '\t', len);
+                    const char *c2 = c1 ? (const char *)memchr(c1 + 1, '\t', len - (size_t)(c1 + 1 - L)) : nullptr;
+                    if (c1 && c2 && (size_t)(c1 - L) == name.size() && memcmp(L, name.data(), name.size()) == 0) {
+                        long long pos1 = 0;
+                        if (parse_int(Str{c1 + 1, (size_t)(c2 - c1 - 1)}, pos1)) {
+                            const long long pos0 = pos1 - 1;
+                            if (pos0 >= (long long)last_hi) break; // sorted by position: nothing further on can overlap an interval
+                            long long end = pos0 + 1;
+                            const char *c3 = (const char *)memchr(c2 + 1, '\t', len - (size_t)(c2 + 1 - L));
+                            const char *c4 = c3 ? (const char *)memchr(c3 + 1, '\t', len - (size_t)(c3 + 1 - L)) : nullptr;
+                            if (c3 && c4) end = pos0 + std::max<long long>(1, (long long)(c4 - c3 - 1));
+                            // (INFO/END may reach further: looked for in the INFO column)
+                            const char *c5 = c4 ? (const char *)memchr(c4 + 1, '\t', len - (size_t)(c4 + 1 - L)) : nullptr;
+                            const char *c6 = c5 ? (const char *)memchr(c5 + 1, '\t', len - (size_t)(c5 + 1 - L)) : nullptr;
+                            const char *c7 = c6 ? (const char *)memchr(c6 + 1, '\t', len - (size_t)(c6 + 1 - L)) : nullptr;
+                            const char *c8 = c7 ? (const char *)memchr(c7 + 1, '\t', len - (size_t)(c7 + 1 - L)) : nullptr;
+                            const char *ie = c8 ? c8 : L + len;
+                            for (const char *q = c7 ? c7 : L + len; q && q + 4 < ie;) {
+                                const char *h = (const char *)memmem(q, (size_t)(ie - q), "END=", 4);
+                                if (!h) break;
+                                if (h[-1] == ';' || h[-1] == '\t') {
+                                    long long ev = 0;
+                                    const char *s0 = h + 4, *s1 = s0;
+                                    while (s1 < ie && *s1 >= '0' && *s1 <= '9') s1++;
+                                    if (s1 > s0 && parse_int(Str{s0, (size_t)(s1 - s0)}, ev)) end = std::max(end, ev);
                                 }
-                                bool hit = false;
-                                for (const Iv &iv : merged) {
-                                    if ((long long)iv.lo >= end) break;
-                                    if (pos0 < iv.hi && end > iv.lo) { hit = true; break; }
-                                }
-                                if (hit) {
-                                    text.append(L, len);
-                                    text.push_back('\n');
-                                    kept++;
-                                }
+                                q = h + 4;
+                            }
+                            // the merged intervals are disjoint and ascending: the first one that ends beyond the record's start decides
+                            auto iv = std::upper_bound(merged.begin(), merged.end(), pos0, [](long long key, const Iv &x) { return key < (long long)x.hi; });
+                            if (iv != merged.end() && (long long)iv->lo < end) {
+                                text.append(L, len);
+                                text.push_back('\n');
+                                kept++;
                             }
                         }
                     }
-                    if (eof) break;
-                    at = e + 1;
                 }
-            chunk_done:;
+                if (eof) break;
+                at = e + 1;
             }
-        }
+        });
+        for (size_t k = 0; k < items.size(); k++) { text += texts[k]; file_bytes += st_bytes[k]; blocks += st_blocks[k]; walked += st_walked[k]; kept += st_kept[k]; }
     } catch (...) { inflateEnd(&z); throw; }
     inflateEnd(&z);
     V.text.alloc(text.size());

@@ -171,26 +171,54 @@ class HipEngine:
         if min_base_qual is not None:
             from . import io_native
             pool = PinnedPool()
-            # the staged columns back to back in one pinned block (they cross the link as one copy); the packed form is at most half
-            # the size of the ASCII table, usually a small fraction
-            pool.new_slab(sum(int(getattr(x, "nbytes", 0)) for x in v.arrays.values()) // 2 + (1 << 20))
-            if fetches is not None and point_only:
-                full = io_native.pack_reads(v, int(min_base_qual), lists=True, with_end=True)
-                fc, flo, fhi, fex = fetches
-                packed, idx = io_native.ReadsSource(full).select(fc, flo, fhi, alloc=pool.alloc, want_index=True, all_bases=bool(all_bases),
-                                                                 extra=fex)
-                if idx.size != int(v.view.n_segs):  # record numbers are the caller's: the table must be the fetches' own reach
-                    raise UnfazedHipError("upload_reads(fetches=...): the table holds records the fetches cannot reach")
-            else:
-                packed = io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None, cigar_compact=True)
-            rid = self.upload_reads_packed(packed)
-            self.wait_reads(rid)  # the pinned buffers go back right away: the caller may drop the table
-            self._staged.pop(rid, None)
-            pool.free_all()
+            rid = None
+            try:
+                # the staged columns back to back in one pinned block (they cross the link as one copy); the packed form is at most
+                # half the size of the ASCII table, usually a small fraction
+                pool.new_slab(sum(int(getattr(x, "nbytes", 0)) for x in v.arrays.values()) // 2 + (1 << 20))
+                if fetches is not None and point_only:
+                    full = io_native.pack_reads(v, int(min_base_qual), lists=True, with_end=True)
+                    fc, flo, fhi, fex = fetches
+                    packed, idx = io_native.ReadsSource(full).select(fc, flo, fhi, alloc=pool.alloc, want_index=True, all_bases=bool(all_bases),
+                                                                     extra=fex)
+                    if idx.size != int(v.view.n_segs):  # record numbers are the caller's: the table must be the fetches' own reach
+                        raise UnfazedHipError("upload_reads(fetches=...): the table holds records the fetches cannot reach")
+                else:
+                    packed = io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None, cigar_compact=True)
+                rid = self.upload_reads_packed(packed)
+                self.wait_reads(rid)  # the pinned buffers go back right away: the caller may drop the table
+                self._staged.pop(rid, None)
+            except BaseException:
+                if rid is not None:  # the copy may still be reading the pinned block: let it finish before the block goes back
+                    try:
+                        self.wait_reads(rid)
+                    except UnfazedHipError:
+                        pass
+                raise
+            finally:
+                pool.free_all()
             return rid
         rid = C.c_int(-1)
         self._ck(self.L.uz_reads_upload(self.h, v.ref(), C.byref(rid)), "uz_reads_upload")
         return rid.value
+
+    def upload_reads_staged(self, src, fc, flo, fhi, fex, min_base_qual: int, all_bases: bool = False):
+        """One batch straight from an indexed BAM (io_native.BamSource): the records its fetches return + their mates, built in the
+        link form in pinned memory by one pass over the file's blocks (uz_bam_stage_*), uploaded as one table.
+        -> (reads id, the staged view: `.qnames` maps the name ids of the result lists back to strings)"""
+        pool = PinnedPool()
+        try:
+            pool.new_slab(max(1 << 20, int(len(fc)) * 4096))
+            packed = src.select(fc, flo, fhi, int(min_base_qual), alloc=pool.alloc, all_bases=bool(all_bases), extra=fex)
+            pool.end_slab()
+            rid = self.upload_reads_packed(packed)
+            self.wait_reads(rid)  # the pinned buffers go back right away
+            self._staged.pop(rid, None)
+        finally:
+            pool.free_all()
+        names = type("StagedNames", (), {})()
+        names.qnames, names.io_stats, names.timing = packed.qnames, packed.io_stats, packed.timing
+        return rid, names
 
     def upload_reads_packed(self, packed: abi.Held) -> int:
         """Staged form, asynchronous: the arrays of `packed` must stay alive and untouched until wait_reads() or
@@ -394,6 +422,22 @@ class PinnedPool:
         self._blocks.append(p.value)
         self.last_slab_used = self._slab[2] if self._slab else 0
         self._slab = [p.value, nbytes, 0]
+
+    def rewind(self, nbytes: int) -> bool:
+        """Start over in the current slab when it holds at least `nbytes` (a staging loop re-uses its page-locked block chunk after
+        chunk instead of pinning a new one); the overflow blocks of the last use are freed.  False: no slab of that size."""
+        if self._slab is None or self._slab[1] < int(nbytes):
+            return False
+        keep = self._slab[0]
+        for p in self._blocks:
+            if p != keep:
+                self.L.uz_pinned_free(C.c_void_p(p))
+        self._blocks = [keep]
+        self._slab[2] = 0
+        return True
+
+    def slab_used(self) -> int:
+        return self._slab[2] if self._slab else 0
 
     def end_slab(self) -> int:
         used = self._slab[2] if self._slab else 0

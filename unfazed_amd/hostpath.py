@@ -31,7 +31,12 @@ grch38_par2 = {"x": [154931044, 155260560], "y": [59034050, 59363566]}
 
 
 def get_prefix(sites: SitesTable) -> str:
-    """reference utils.py:46-52 -- decided by the first record of the sites file."""
+    """reference utils.py:46-52 -- decided by the first record of the sites FILE: a table decoded through the tabix index for a
+    batch's windows carries the file-level answer (`file_prefix`, from the index's first sequence name) instead of guessing it
+    from the subset it happens to hold."""
+    fp = getattr(sites, "file_prefix", None)
+    if fp is not None:
+        return fp
     if sites.n_sites == 0:
         return ""
     chrom = sites.contigs[0]
@@ -444,14 +449,21 @@ class PhasingHost:
                     self.sites.pos, het_off, het_idx, params, vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
                     end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff,
                     allele_len=[max(len(prep[i]["ref"]), len(prep[i]["alt"])) for i in idxs])
-                region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
                 # (a batch of point variants only ever asks for the quality bits of "good" records: the qualities travel as counts
                 # + short lists; SV evidence is collected under goodread(read, True), which does not count them: the plane)
                 point_only = all(vartype_code(dnms[i]["vartype"]) == abi.VT_POINT for i in idxs)
-                # with the fetches at hand the table travels as the bench stages it: mates without bases, of the other records' rows
-                # only the 32-base units that hold a fetched position (uz_types.h: umask)
-                rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=point_only,
-                                               fetches=(fc, flo, fhi, fex) if point_only else None, all_bases=bool(params.no_extended))
+                stager = getattr(self.reads_by_bam, "stager", None)
+                src = stager(bam) if (stager and point_only and hasattr(self.backend, "upload_reads_staged")) else None
+                if src is not None:
+                    # BAM + BAI -> the link form in one pass (uz_bam_stage_*): no table in between
+                    rh, region_table = self.backend.upload_reads_staged(src, fc, flo, fhi, fex, int(params.min_gt_qual),
+                                                                        all_bases=bool(params.no_extended))
+                else:
+                    region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
+                    # with the fetches at hand the table travels as the bench stages it: mates without bases, of the other records'
+                    # rows only the 32-base units that hold a fetched position (uz_types.h: umask)
+                    rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=point_only,
+                                                   fetches=(fc, flo, fhi, fex) if point_only else None, all_bases=bool(params.no_extended))
                 handles.append(rh)
             else:
                 rh = self.reads(bam, params.min_gt_qual)

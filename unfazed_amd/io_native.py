@@ -373,7 +373,11 @@ def read_vcf_table_regions(path: str, ref, lo, hi, threads: int = 0, tbi: str = 
     hp = C.c_void_p()
     _check(lib, lib.uz_vcf_decode_regions(os.fsencode(path), os.fsencode(tbi) if tbi else None, int(ref.size), ref.ctypes.data,
                                           lo.ctypes.data, hi.ctypes.data, int(threads), C.byref(hp)))
-    return _vcf_table_from_handle(lib, _Handle(hp.value, lib.uz_vcf_free))
+    t = _vcf_table_from_handle(lib, _Handle(hp.value, lib.uz_vcf_free))
+    names = tabix_contigs(path, tbi)
+    # utils.py:46-52 get_prefix: the first record of the FILE decides, not the first record of this subset
+    t.file_prefix = (names[0][:3] if "chr" in names[0].lower() else "") if names else ""
+    return t
 
 
 def read_vcf_table(path: str, threads: int = 0) -> SitesTable:

@@ -144,6 +144,7 @@ class _LazyReads(dict):
         super().__init__()
         self.cap = insert_size_max_sample
         self._headers: Dict[str, ReadsTable] = {}
+        self._stagers: Dict[str, object] = {}
 
     def __missing__(self, key):
         self[key] = load_reads(key, self.cap)
@@ -176,10 +177,25 @@ class _LazyReads(dict):
                 t = ReadsTable(contigs)
                 t.tlen_head = np.array([s.tlen for s in segs[: int(self.cap) + 1]], dtype=np.int32)
                 self._headers[bam] = t
+            elif self.stager(bam) is not None:
+                src = self.stager(bam)
+                t = ReadsTable(src.contigs)
+                t.tlen_head = src.tlen_head
+                self._headers[bam] = t
             else:
                 from .io_native import read_bam_regions
                 self._headers[bam] = read_bam_regions(bam, [], [], [], threads=_io_threads(), insert_size_max_sample=self.cap)
         return self._headers[bam]
+
+    def stager(self, bam: str):
+        """the file opened for one-pass staging (io_native.BamSource: BAM + BAI -> link-form columns), or None: CRAM, the Python
+        decoders, UZ_IO_STAGE=0"""
+        if not bam.endswith(".bam") or _python_io() or os.environ.get("UZ_IO_STAGE", "1") == "0":
+            return None
+        if bam not in self._stagers:
+            from .io_native import BamSource
+            self._stagers[bam] = BamSource(bam, insert_size_max_sample=self.cap, threads=_io_threads())
+        return self._stagers[bam]
 
     def regions(self, bam: str, tid, lo, hi) -> ReadsTable:
         if bam.endswith(".cram") and not _python_io():
