@@ -524,6 +524,8 @@ def main():
 
     feed = None
     if rank == 0 and world == 1 and not cnv and args.feed_dnms > 0:
+        if getattr(bind_near_gpu, "before", None):  # the files -> results pass is host work: it gets every core of the box
+            os.sched_setaffinity(0, bind_near_gpu.before)
         feed = feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool)
 
     cpu = None

@@ -46,7 +46,7 @@ def build_hip():
 def build_files():
     """the file writer (synth/uzfiles.cpp): BAM + BAI, BGZF VCF + TBI"""
     return _build(os.path.join(_HERE, "libuzsynth_files.so"),
-                  ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", _HERE, os.path.join(_HERE, "uzfiles.cpp"), "-lz"])
+                  ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", _HERE, os.path.join(_HERE, "uzfiles.cpp"), "-lz", "-ldl"])
 
 
 class Cfg(C.Structure):

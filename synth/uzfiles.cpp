@@ -7,6 +7,7 @@
 //
 // Layout: workers own contiguous ranges of clusters (BAM) / sites (VCF); each deflates its own BGZF blocks and keeps a
 // partial index in offsets relative to its own first block; the parts are joined by adding the workers' file offsets.
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -52,6 +53,28 @@ struct RefIndex {
     }
 };
 
+// libdeflate when the system has it (three functions of its stable ABI, no headers needed): several times faster than zlib at the
+// same level; the blocks it writes are plain deflate either way
+struct LibDeflateC {
+    void *(*alloc)(int) = nullptr;
+    size_t (*compress)(void *, const void *, size_t, void *, size_t) = nullptr;
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+    LibDeflateC() {
+        const char *e = getenv("UZ_INFLATE");
+        if (e && strcmp(e, "zlib") == 0) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = (void *(*)(int))dlsym(h, "libdeflate_alloc_compressor");
+        compress = (size_t (*)(void *, const void *, size_t, void *, size_t))dlsym(h, "libdeflate_deflate_compress");
+        release = (void (*)(void *))dlsym(h, "libdeflate_free_compressor");
+        crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        ok = alloc && compress && release && crc;
+    }
+};
+const LibDeflateC &libdeflate_c() { static LibDeflateC L; return L; }
+
 // one worker's output: BGZF blocks back to back + its partial index
 struct Part {
     std::vector<uint8_t> cdata;
@@ -65,18 +88,23 @@ struct Part {
     uint64_t last_v1 = 0;
     bool tail_at_block_end = false;
     z_stream z;
+    void *ld = nullptr;
     int level = 6;
     bool z_ok = false;
     std::string err;
 
     void init(int lvl) {
         level = lvl;
+        if (libdeflate_c().ok) ld = libdeflate_c().alloc(lvl);
         memset(&z, 0, sizeof(z));
         z_ok = deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
         if (!z_ok) err = "deflateInit2 failed";
         cur.reserve(BGZF_MAX_IN);
     }
-    ~Part() { if (z_ok) deflateEnd(&z); }
+    ~Part() {
+        if (z_ok) deflateEnd(&z);
+        if (ld) libdeflate_c().release(ld);
+    }
     uint64_t tell() const { return ((uint64_t)cdata.size() << 16) | (uint64_t)cur.size(); }
     void flush() {
         if (cur.empty()) return;
@@ -90,18 +118,22 @@ struct Part {
         uint8_t *h = cdata.data() + at;
         static const uint8_t head[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
         memcpy(h, head, 16);
-        deflateReset(&z);
-        z.next_in = const_cast<Bytef *>(raw);
-        z.avail_in = (uInt)n;
-        z.next_out = h + 18;
-        z.avail_out = (uInt)(cdata.size() - at - 18 - 8);
-        if (deflate(&z, Z_FINISH) != Z_STREAM_END) { err = "deflate failed"; return; }
-        const size_t clen = (size_t)z.total_out;
+        size_t clen = 0;
+        if (ld && n) clen = libdeflate_c().compress(ld, raw, n, h + 18, cdata.size() - at - 18 - 8);
+        if (!clen) {
+            deflateReset(&z);
+            z.next_in = const_cast<Bytef *>(raw);
+            z.avail_in = (uInt)n;
+            z.next_out = h + 18;
+            z.avail_out = (uInt)(cdata.size() - at - 18 - 8);
+            if (deflate(&z, Z_FINISH) != Z_STREAM_END) { err = "deflate failed"; return; }
+            clen = (size_t)z.total_out;
+        }
         const size_t blen = 18 + clen + 8;
         if (blen > 0x10000) { err = "BGZF block does not fit 64 KiB"; return; }
         const uint16_t bsize = (uint16_t)(blen - 1);
         memcpy(h + 16, &bsize, 2);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), raw, (uInt)n), isize = (uint32_t)n;
+        const uint32_t crc = ld ? libdeflate_c().crc(0, raw, n) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), raw, (uInt)n), isize = (uint32_t)n;
         memcpy(h + 18 + clen, &crc, 4);
         memcpy(h + 18 + clen + 4, &isize, 4);
         cdata.resize(at + blen);

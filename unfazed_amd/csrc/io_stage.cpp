@@ -261,8 +261,9 @@ struct WRec { // one walked record that may be kept
     uint8_t mapq, aux, n_low_full, l_name, n_qpos, n_low, simple, keep, n_units, has_pay;
 };
 
-struct Task { // one reach interval of one reference: its file spans, and what its walk kept
-    int32_t tid = 0, a = 0, b = 0;   // reach interval [a, b)
+struct Task { // reach intervals of one reference whose file spans meet (walked as one: no block is inflated twice), and what the walk kept
+    int32_t tid = 0, a = 0, b = 0;   // first start / last end of the reach intervals
+    std::vector<std::pair<int32_t, int32_t>> reach; // the intervals [a_i, b_i), ascending, disjoint
     size_t f0 = 0, f1 = 0;           // its fetches: [f0, f1) of the reference's sorted list
     std::vector<Chunk> spans;
     std::vector<WRec> recs;          // file order
@@ -474,15 +475,24 @@ void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out)
 
 // walks the spans of a task: direct records (a fetch returns them) and every other record, of which only those that share a
 // name with a direct one are kept as mate candidates
-void walk_task(const uz_stage &P, Task &T, Inflater &inf) {
+struct Scratch { // a worker's buffers, kept from task to task
+    Inflater inf;
+    std::vector<WRec> all;
+    Task tmp;
+    std::vector<uint64_t> dn;
+};
+
+void walk_task(const uz_stage &P, Task &T, Scratch &W) {
     const uz_bamsrc &S = *P.src;
     const Opt &o = P.opt;
     const std::vector<Fx> &fx = P.fx[(size_t)T.tid];
     const int32_t max_len = P.fx_max_len[(size_t)T.tid];
-    Stream s(S, inf);
-    std::vector<WRec> all;
-    Task tmp; // pools of every walked record; the survivors are copied over
+    Stream s(S, W.inf);
+    std::vector<WRec> &all = W.all;
+    Task &tmp = W.tmp; // pools of every walked record; the survivors are copied over
+    all.clear(); tmp.names.clear(); tmp.cigars.clear(); tmp.pay.clear();
     tmp.tid = T.tid;
+    size_t ri = 0; // the reach interval the walk is in or in front of
     bool stop = false;
     for (size_t ci = 0; ci < T.spans.size() && !stop; ci++) {
         s.seek(T.spans[ci].beg);
@@ -506,6 +516,9 @@ void walk_task(const uz_stage &P, Task &T, Inflater &inf) {
             if (32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
             const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
             T.n_walked++;
+            // between two reach intervals: nothing there can be fetched, and a mate position there is looked up through the index
+            while (ri < T.reach.size() && pos >= T.reach[ri].second) ri++;
+            if (ri < T.reach.size() && end <= T.reach[ri].first) { s.advance(bs); continue; }
             WRec r;
             memset(&r, 0, sizeof(r));
             r.voff = voff; r.pos = pos; r.end = end; r.flag = fl; r.mapq = p[9];
@@ -541,7 +554,8 @@ void walk_task(const uz_stage &P, Task &T, Inflater &inf) {
     }
     T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks;
     // mate candidates: the records that share a name with a direct one
-    std::vector<uint64_t> dn;
+    std::vector<uint64_t> &dn = W.dn;
+    dn.clear();
     for (const WRec &r : all) if (r.keep == 2) dn.push_back(r.nhash);
     std::sort(dn.begin(), dn.end());
     dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
@@ -600,6 +614,7 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
             if (k < v.size() && (int64_t)v[k].lo - REACH_SLACK <= b) { b = std::max(b, (int64_t)v[k].hi + REACH_SLACK); continue; }
             Task T;
             T.tid = t; T.a = (int32_t)std::max<int64_t>(a, 0); T.b = (int32_t)std::min<int64_t>(b, INT32_MAX); T.f0 = f0; T.f1 = k;
+            T.reach.push_back({T.a, T.b});
             P.tasks.push_back(std::move(T));
             if (k < v.size()) { f0 = k; a = (int64_t)v[k].lo - REACH_SLACK; b = (int64_t)v[k].hi + REACH_SLACK; }
         }
@@ -607,14 +622,41 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
         for (int64_t i = i0; i < i1; i++) spans_for(S.refs[(size_t)P.tasks[(size_t)i].tid], P.tasks[(size_t)i].a, P.tasks[(size_t)i].b, P.tasks[(size_t)i].spans);
     });
+    P.io_stats[4] = (int64_t)P.tasks.size();
+    { // reach intervals whose file spans meet in a BGZF block (the same 16 kb bin, neighbouring windows) are walked as one task
+        std::vector<Task> merged;
+        for (Task &T : P.tasks) {
+            if (T.spans.empty()) continue; // the index knows no record there
+            Task *L = merged.empty() ? nullptr : &merged.back();
+            // (up to a size: a file that holds nothing but the fetched windows would chain into one task per reference)
+            const uint64_t MAX_TASK_BYTES = 768 << 10; // compressed
+            if (L && L->tid == T.tid && (T.spans.front().beg >> 16) <= (L->spans.back().end >> 16) &&
+                (T.spans.back().end >> 16) - (L->spans.front().beg >> 16) <= MAX_TASK_BYTES) {
+                std::vector<Chunk> all(L->spans);
+                all.insert(all.end(), T.spans.begin(), T.spans.end());
+                std::sort(all.begin(), all.end(), [](const Chunk &x, const Chunk &y) { return x.beg < y.beg || (x.beg == y.beg && x.end < y.end); });
+                L->spans.clear();
+                for (const Chunk &c : all) {
+                    if (!L->spans.empty() && (c.beg >> 16) <= (L->spans.back().end >> 16)) L->spans.back().end = std::max(L->spans.back().end, c.end);
+                    else L->spans.push_back(c);
+                }
+                L->b = T.b; L->f1 = T.f1;
+                L->reach.push_back({T.a, T.b});
+            } else
+                merged.push_back(std::move(T));
+        }
+        P.tasks.swap(merged);
+    }
     double t1 = now_s();
     P.timing[0] = t1 - t0;
     // ---- the walk
     {
         const int w = (int)std::min<int64_t>(threads, std::max<int64_t>(1, (int64_t)P.tasks.size()));
-        std::vector<std::unique_ptr<Inflater>> infs((size_t)w);
-        for (auto &p : infs) p.reset(new Inflater());
-        parallel_dynamic((int64_t)P.tasks.size(), w, [&](int64_t i, int k) { walk_task(P, P.tasks[(size_t)i], *infs[(size_t)k]); });
+        std::vector<std::unique_ptr<Scratch>> scr((size_t)w);
+        parallel_dynamic((int64_t)P.tasks.size(), w, [&](int64_t i, int k) {
+            if (!scr[(size_t)k]) scr[(size_t)k].reset(new Scratch());
+            walk_task(P, P.tasks[(size_t)i], *scr[(size_t)k]);
+        });
     }
     double t2 = now_s();
     P.timing[1] = t2 - t1;
@@ -641,7 +683,11 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
             const Task &M = P.tasks[mid];
             if (M.tid < tid_q || (M.tid == tid_q && M.b <= pos_q)) lo_i = mid + 1; else hi_i = mid;
         }
-        if (lo_i < n_tasks0 && P.tasks[lo_i].tid == tid_q && P.tasks[lo_i].a <= pos_q && pos_q < P.tasks[lo_i].b) return (int64_t)lo_i;
+        if (lo_i < n_tasks0 && P.tasks[lo_i].tid == tid_q && P.tasks[lo_i].a <= pos_q && pos_q < P.tasks[lo_i].b) {
+            const auto &rv = P.tasks[lo_i].reach; // inside one of its reach intervals?
+            auto it = std::upper_bound(rv.begin(), rv.end(), pos_q, [](int32_t key, const std::pair<int32_t, int32_t> &x) { return key < x.second; });
+            if (it != rv.end() && it->first <= pos_q) return (int64_t)lo_i;
+        }
         return -1;
     };
     // A task of the first walk walked EVERY record overlapping a position inside its reach interval and kept all records of a name
@@ -667,9 +713,23 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     };
     // generation by generation: the members whose mate has not been looked up; a found mate becomes a member
     std::vector<int64_t> frontier;
-    for (size_t ti = 0; ti < P.tasks.size(); ti++)
-        for (size_t ri = 0; ri < P.tasks[ti].recs.size(); ri++)
-            if (P.tasks[ti].recs[ri].keep == 2) frontier.push_back(((int64_t)ti << 32) | (int64_t)ri);
+    {
+        std::vector<int64_t> at(P.tasks.size() + 1, 0);
+        for (size_t ti = 0; ti < P.tasks.size(); ti++) {
+            int64_t c = 0;
+            for (const WRec &r : P.tasks[ti].recs) c += r.keep == 2;
+            at[ti + 1] = at[ti] + c;
+        }
+        frontier.resize((size_t)at.back());
+        parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
+            for (int64_t ti = i0; ti < i1; ti++) {
+                int64_t k = at[(size_t)ti];
+                const auto &recs = P.tasks[(size_t)ti].recs;
+                for (size_t ri = 0; ri < recs.size(); ri++)
+                    if (recs[ri].keep == 2) frontier[(size_t)k++] = ((int64_t)ti << 32) | (int64_t)ri;
+            }
+        });
+    }
     int64_t n_lookups = 0;
     for (int gen = 0; gen < 64 && !frontier.empty(); gen++) {
         std::vector<Lookup> need;
@@ -765,11 +825,18 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
         }
         // the mates found become members; those that were not members yet are the next generation
         std::vector<int64_t> next;
-        for (int64_t ref : frontier) {
-            const int64_t m = rec_of(P, ref).mate_ref;
-            if (m < 0) continue;
-            WRec &y = rec_of(P, m);
-            if (y.keep == 0) { y.keep = 1; next.push_back(m); }
+        {
+            const int w = workers_for((int64_t)frontier.size(), threads, 8192);
+            std::vector<std::vector<int64_t>> part((size_t)w);
+            parallel_slices((int64_t)frontier.size(), w, [&](int64_t i0, int64_t i1, int k) {
+                for (int64_t i = i0; i < i1; i++) {
+                    const int64_t m = rec_of(P, frontier[(size_t)i]).mate_ref;
+                    if (m < 0) continue;
+                    uint8_t zero = 0; // two members can name the same mate: the first to flip its flag lists it
+                    if (__atomic_compare_exchange_n(&rec_of(P, m).keep, &zero, (uint8_t)1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) part[(size_t)k].push_back(m);
+                }
+            });
+            for (auto &v : part) next.insert(next.end(), v.begin(), v.end());
         }
         frontier.swap(next);
     }
@@ -961,7 +1028,6 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     for (int32_t c = 0; c < n_ref; c++) P.contig_off[(size_t)c + 1] += P.contig_off[(size_t)c];
     for (const Task &T : P.tasks) { P.io_stats[0] += T.file_bytes; P.io_stats[1] += T.n_blocks; P.io_stats[2] += T.n_walked; }
     P.io_stats[3] = n;
-    P.io_stats[4] = (int64_t)n_tasks0;
     P.timing[3] = now_s() - t3;
 }
 
