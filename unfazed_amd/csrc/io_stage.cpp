@@ -124,7 +124,8 @@ bool block_at(const uz_bamsrc &S, int64_t coff, BlockHdr &b) {
 struct Stream {
     const uz_bamsrc &S;
     Inflater &inf;
-    std::vector<uint8_t> buf;
+    std::vector<uint8_t> own_buf;
+    std::vector<uint8_t> &buf; // (a worker hands in its own buffer, kept from task to task: no fresh pages per task)
     struct Blk { int64_t coff; size_t at, isize; };
     std::vector<Blk> blks; // blocks held in buf (buffer offsets)
     size_t cur = 0;        // next unread byte of buf
@@ -132,7 +133,8 @@ struct Stream {
     int64_t next_coff = 0;
     int64_t file_bytes = 0, n_blocks = 0;
     bool eof = false;
-    Stream(const uz_bamsrc &s, Inflater &i) : S(s), inf(i) {}
+    Stream(const uz_bamsrc &s, Inflater &i) : S(s), inf(i), buf(own_buf) {}
+    Stream(const uz_bamsrc &s, Inflater &i, std::vector<uint8_t> &b) : S(s), inf(i), buf(b) {}
     void seek(uint64_t voff) {
         buf.clear(); blks.clear(); cur = 0; blk = 0; eof = false;
         next_coff = (int64_t)(voff >> 16);
@@ -266,6 +268,7 @@ struct Task { // reach intervals of one reference whose file spans meet (walked 
     std::vector<std::pair<int32_t, int32_t>> reach; // the intervals [a_i, b_i), ascending, disjoint
     size_t f0 = 0, f1 = 0;           // its fetches: [f0, f1) of the reference's sorted list
     std::vector<Chunk> spans;
+    uint64_t est_end = 0;            // where the walk will probably stop (linear index of the window behind b): the spans of the wide bins reach much further
     std::vector<WRec> recs;          // file order
     std::vector<uint8_t> names;      // name bytes (no terminator)
     std::vector<uint32_t> cigars;    // words of the records that are not simple
@@ -451,7 +454,7 @@ inline int d16_of(const uz_stage &P, int64_t k, int16_t v[4], int32_t e[4]) {
 }
 
 // file spans holding every record that overlaps [a, b) of reference `ref` (bins + linear index); sorted, merged per block
-void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out) {
+void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out, uint64_t *est_end = nullptr) {
     std::vector<uint32_t> bins;
     reg2bins(a, b, bins);
     uint64_t min_off = 0;
@@ -471,12 +474,18 @@ void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out)
         if (!out.empty() && (c.beg >> 16) <= (out.back().end >> 16)) out.back().end = std::max(out.back().end, c.end);
         else out.push_back(c);
     }
+    if (est_end) {
+        *est_end = out.empty() ? 0 : out.back().end;
+        const size_t wb = (size_t)(std::max<int64_t>((int64_t)b - 1, 0) >> 14) + 1; // first record overlapping the window behind b
+        if (!out.empty() && wb < ref.linear.size() && ref.linear[wb] > out.front().beg) *est_end = std::min(*est_end, ref.linear[wb]);
+    }
 }
 
 // walks the spans of a task: direct records (a fetch returns them) and every other record, of which only those that share a
 // name with a direct one are kept as mate candidates
 struct Scratch { // a worker's buffers, kept from task to task
     Inflater inf;
+    std::vector<uint8_t> buf;
     std::vector<WRec> all;
     Task tmp;
     std::vector<uint64_t> dn;
@@ -487,7 +496,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W) {
     const Opt &o = P.opt;
     const std::vector<Fx> &fx = P.fx[(size_t)T.tid];
     const int32_t max_len = P.fx_max_len[(size_t)T.tid];
-    Stream s(S, W.inf);
+    Stream s(S, W.inf, W.buf);
     std::vector<WRec> &all = W.all;
     Task &tmp = W.tmp; // pools of every walked record; the survivors are copied over
     all.clear(); tmp.names.clear(); tmp.cigars.clear(); tmp.pay.clear();
@@ -620,7 +629,7 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
         }
     }
     parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
-        for (int64_t i = i0; i < i1; i++) spans_for(S.refs[(size_t)P.tasks[(size_t)i].tid], P.tasks[(size_t)i].a, P.tasks[(size_t)i].b, P.tasks[(size_t)i].spans);
+        for (int64_t i = i0; i < i1; i++) spans_for(S.refs[(size_t)P.tasks[(size_t)i].tid], P.tasks[(size_t)i].a, P.tasks[(size_t)i].b, P.tasks[(size_t)i].spans, &P.tasks[(size_t)i].est_end);
     });
     P.io_stats[4] = (int64_t)P.tasks.size();
     { // reach intervals whose file spans meet in a BGZF block (the same 16 kb bin, neighbouring windows) are walked as one task
@@ -630,8 +639,8 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
             Task *L = merged.empty() ? nullptr : &merged.back();
             // (up to a size: a file that holds nothing but the fetched windows would chain into one task per reference)
             const uint64_t MAX_TASK_BYTES = 768 << 10; // compressed
-            if (L && L->tid == T.tid && (T.spans.front().beg >> 16) <= (L->spans.back().end >> 16) &&
-                (T.spans.back().end >> 16) - (L->spans.front().beg >> 16) <= MAX_TASK_BYTES) {
+            if (L && L->tid == T.tid && (T.spans.front().beg >> 16) <= (L->est_end >> 16) &&
+                (std::max(T.est_end, L->est_end) >> 16) - (L->spans.front().beg >> 16) <= MAX_TASK_BYTES) {
                 std::vector<Chunk> all(L->spans);
                 all.insert(all.end(), T.spans.begin(), T.spans.end());
                 std::sort(all.begin(), all.end(), [](const Chunk &x, const Chunk &y) { return x.beg < y.beg || (x.beg == y.beg && x.end < y.end); });
@@ -641,6 +650,7 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
                     else L->spans.push_back(c);
                 }
                 L->b = T.b; L->f1 = T.f1;
+                L->est_end = std::max(L->est_end, T.est_end);
                 L->reach.push_back({T.a, T.b});
             } else
                 merged.push_back(std::move(T));
@@ -715,11 +725,14 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     std::vector<int64_t> frontier;
     {
         std::vector<int64_t> at(P.tasks.size() + 1, 0);
-        for (size_t ti = 0; ti < P.tasks.size(); ti++) {
-            int64_t c = 0;
-            for (const WRec &r : P.tasks[ti].recs) c += r.keep == 2;
-            at[ti + 1] = at[ti] + c;
-        }
+        parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
+            for (int64_t ti = i0; ti < i1; ti++) {
+                int64_t c = 0;
+                for (const WRec &r : P.tasks[(size_t)ti].recs) c += r.keep == 2;
+                at[(size_t)ti + 1] = c;
+            }
+        });
+        for (size_t ti = 0; ti < P.tasks.size(); ti++) at[ti + 1] += at[ti];
         frontier.resize((size_t)at.back());
         parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
             for (int64_t ti = i0; ti < i1; ti++) {
@@ -850,11 +863,14 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     std::vector<int64_t> &order = P.order;
     {
         std::vector<int64_t> t_first(P.tasks.size() + 1, 0);
-        for (size_t ti = 0; ti < P.tasks.size(); ti++) {
-            int64_t c = 0;
-            for (const WRec &r : P.tasks[ti].recs) c += r.keep != 0;
-            t_first[ti + 1] = t_first[ti] + c;
-        }
+        parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
+            for (int64_t ti = i0; ti < i1; ti++) {
+                int64_t c = 0;
+                for (const WRec &r : P.tasks[(size_t)ti].recs) c += r.keep != 0;
+                t_first[(size_t)ti + 1] = c;
+            }
+        });
+        for (size_t ti = 0; ti < P.tasks.size(); ti++) t_first[ti + 1] += t_first[ti];
         order.resize((size_t)t_first.back());
         parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
             for (int64_t ti = i0; ti < i1; ti++) {
