@@ -710,7 +710,8 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         raw_per_rec = st_b["raw_bytes"] / max(1, st_b["records"])
         return {
             "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "result_mismatches_vs_resident": mism,
-            "inflate": io_native.inflate_backend(), "host_threads": os.cpu_count(),
+            "inflate": io_native.inflate_backend(), "host_threads": io_native.default_threads(), "host_cpu_quota": io_native.cpu_quota() or None,
+            "host_processors": os.cpu_count(),
             "bam": {"records": st_b["records"], "file_GB": round(st_b["file_bytes"] / 1e9, 3), "raw_GB": round(st_b["raw_bytes"] / 1e9, 3), "blocks": st_b["blocks"],
                     "write_s": round(t1 - t0, 1), "deflate_level": args.feed_level},
             "vcf": {"records": st_v["records"], "file_GB": round(st_v["file_bytes"] / 1e9, 3), "write_s": round(t2 - t1, 1)},
@@ -828,8 +829,17 @@ def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_v
                       "before the timing; oracle find+phase per range, threads over ranges (best of a ladder of thread counts: %d)" % (m, len(jobs), cores),
             "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
             "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
-            "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu,
+            "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu, "host_cpu_quota": _cpu_quota(),
             "parity_mismatches_vs_gpu": mism}
+
+
+def _cpu_quota():
+    """CPUs the container's cgroup grants (cpu.max), None = unlimited: a pod that lists 256 processors may be held to 16"""
+    try:
+        a, b = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if a == "max" else round(int(a) / int(b), 2)
+    except Exception:
+        return None
 
 
 def cpu_baseline_shared_table(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):

@@ -228,6 +228,8 @@ const char *uz_bamsrc_contig_name(const uz_bamsrc *s, int32_t i);
 int32_t uz_bamsrc_contig_length(const uz_bamsrc *s, int32_t i);
 int64_t uz_bamsrc_tlen_head(const uz_bamsrc *s, int32_t *out, int64_t cap); /* as uz_bam_tlen_head */
 const char *uz_inflate_backend(void); /* "libdeflate" (found at run time) or "zlib" */
+int uz_io_default_threads(void);      /* what `threads <= 0` means: CPUs of the affinity mask, held to twice the cgroup CPU quota */
+int uz_io_cpu_quota(void);            /* CPUs the container's cgroup grants (cpu.max), 0 = unlimited */
 #define UZ_STAGE_ALL_BASES 1  /* --no-extended batches: every kept record keeps its bases (uz_reads_select_plan: all_bases) */
 #define UZ_STAGE_UNIT_MASKS 2 /* only the 32-base units that hold a fetched position (+ extra[f] bases on) are staged */
 #define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (SV batches; no unit masks then) */

@@ -169,6 +169,19 @@ struct Part {
     }
 };
 
+// threads <= 0: the machine's, held to twice the cgroup's CPU quota (a pod that shows 256 processors may be granted 16)
+int default_threads() {
+    int t = (int)std::thread::hardware_concurrency();
+    long long quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64] = {0};
+        if (fscanf(f, "%63s %lld", a, &period) >= 1 && strcmp(a, "max") != 0) quota = atoll(a);
+        fclose(f);
+    }
+    if (quota > 0 && period > 0) t = std::min<int>(t, (int)(2 * ((quota + period - 1) / period)));
+    return std::max(1, t);
+}
+
 template <typename F>
 void run_workers(int w, F fn) {
     std::vector<std::thread> th;
@@ -241,7 +254,7 @@ int uzs_write_bam(const char *bam_path, const char *bai_path, const uzs_cfg *cf,
                   int64_t *stats, char *err, int cap) {
     auto fail = [&](const char *m) { if (err && cap > 0) snprintf(err, (size_t)cap, "%s", m); return -1; };
     if (!bam_path || !cf || !S || !D || !C || c1 < c0) return fail("bad argument");
-    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = default_threads();
     const int64_t pairs = C->pair_off[c1] - C->pair_off[c0];
     int W = (int)std::max<int64_t>(1, std::min<int64_t>(threads, pairs / 2048 + 1));
     W = std::min<int>(W, std::max(1, c1 - c0));
@@ -376,7 +389,7 @@ int uzs_write_vcf(const char *vcf_path, const char *tbi_path, int64_t n_sites, i
                   const char *const *samples, int level, int threads, int64_t *stats, char *err, int cap) {
     auto fail = [&](const char *m) { if (err && cap > 0) snprintf(err, (size_t)cap, "%s", m); return -1; };
     if (!vcf_path || !contig_off || !pos || !gt || !rd || !ad || !gq) return fail("bad argument");
-    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    if (threads <= 0) threads = default_threads();
     const int W = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n_sites / 4096 + 1));
     std::vector<Part> parts((size_t)W + 2);
     for (auto &p : parts) p.init(level);

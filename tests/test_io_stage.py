@@ -105,3 +105,15 @@ def test_empty_and_absent(workload):
     # a fetch where the file has no records, a contig id out of range
     got = src.select(np.array([2, 7], np.int32), np.array([900_000, 5], np.int32), np.array([900_001, 6], np.int32), 20)
     assert int(got.view.n_segs) == 0
+
+
+@pytest.mark.parametrize("slack", ["0", "40", "300"])
+def test_mates_outside_the_reach_go_through_the_index(workload, slack, monkeypatch):
+    """with a small slack around the fetch points most mates lie outside every reach interval: they are answered by another
+    task or looked up through the index -- the table must not change"""
+    fc, flo, fhi, fex = fetches_of(workload, 2, 3)
+    want, _ = three_step(workload["bam"], fc, flo, fhi, fex, 20)
+    monkeypatch.setenv("UZ_STAGE_SLACK", slack)
+    got = io_native.BamSource(workload["bam"], threads=3).select(fc, flo, fhi, 20, extra=fex)
+    assert got.io_stats["index_mate_lookups"] > 0
+    assert_same(got, want)

@@ -43,12 +43,35 @@ inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// CPUs' worth of run time the container's cgroup grants per period (cpu.max / cfs_quota), 0 = no limit.  A pod that shows 256
+// processors can be held to 16 of them: threads beyond about twice the quota only get throttled (measured on the MI355X boxes:
+// cpu.max = 1600000 100000, a spin loop scales to 16 threads and not one further).
+inline int cgroup_cpu_quota() {
+    static const int q = [] {
+        long long quota = -1, period = 100000;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char a[64] = {0};
+            if (fscanf(f, "%63s %lld", a, &period) >= 1 && strcmp(a, "max") != 0) quota = atoll(a);
+            fclose(f);
+        } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+            fclose(g);
+            if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &period) != 1) period = 100000; fclose(h); }
+        }
+        if (quota <= 0 || period <= 0) return 0;
+        return (int)std::max<long long>(1, (quota + period - 1) / period);
+    }();
+    return q;
+}
+
 inline int resolve_threads(int threads) {
     if (threads <= 0) { // the CPUs this process may run on (an affinity mask narrower than the machine counts), not the machine's
         cpu_set_t set;
         CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof(set), &set) == 0) threads = CPU_COUNT(&set);
         if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+        const int q = cgroup_cpu_quota();
+        if (q > 0) threads = std::min(threads, 2 * q);
     }
     if (threads <= 0) threads = 1;
     return threads > 256 ? 256 : threads;

@@ -39,7 +39,7 @@ inline uint64_t hash_name(const uint8_t *s, size_t n) { // FNV-1a with a final m
 }
 
 const uint16_t FPAIRED = 1, FUNMAP = 4, FMUNMAP = 8, FREAD1 = 64, FREAD2 = 128;
-const int32_t REACH_SLACK = 1000; // a reach interval extends this far beyond its fetch points: the mates of a pile-up lie inside it
+const int32_t REACH_SLACK_DEFAULT = 1000; // a reach interval extends this far beyond its fetch points: the mates of a pile-up lie inside it
 
 bool has_sa_tag(const uint8_t *p, const uint8_t *end) {
     while (p + 3 <= end) {
@@ -483,15 +483,31 @@ void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out,
 
 // walks the spans of a task: direct records (a fetch returns them) and every other record, of which only those that share a
 // name with a direct one are kept as mate candidates
+inline bool same_name(const Task &A, const WRec &a, const Task &B, const WRec &b) {
+    return a.nhash == b.nhash && a.l_name == b.l_name && memcmp(A.names.data() + a.name_at, B.names.data() + b.name_at, a.l_name) == 0;
+}
+
+// mate(): the first record in file order with the name, on the mate's reference, overlapping the mate position, carrying the
+// other read-of-pair flag (pysam's AlignmentFile.mate; it may be a secondary / supplementary record)
+inline bool is_mate_of(const WRec &x, const WRec &y, int32_t y_tid) {
+    if (y_tid != x.mtid) return false;
+    if (!((int64_t)y.pos < (int64_t)x.mpos + 1 && (int64_t)y.end > (int64_t)x.mpos)) return false;
+    const uint16_t want = (uint16_t)((x.flag ^ (FREAD1 | FREAD2)) & (FREAD1 | FREAD2));
+    return (y.flag & want) != 0;
+}
+
+inline bool wants_mate(const WRec &x, int32_t n_ref) { return (x.flag & FPAIRED) && !(x.flag & FMUNMAP) && x.mtid >= 0 && x.mtid < n_ref; }
+
 struct Scratch { // a worker's buffers, kept from task to task
     Inflater inf;
     std::vector<uint8_t> buf;
     std::vector<WRec> all;
     Task tmp;
     std::vector<uint64_t> dn;
+    std::vector<int32_t> tab, stack;
 };
 
-void walk_task(const uz_stage &P, Task &T, Scratch &W) {
+void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
     const uz_bamsrc &S = *P.src;
     const Opt &o = P.opt;
     const std::vector<Fx> &fx = P.fx[(size_t)T.tid];
@@ -582,22 +598,43 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W) {
         }
         T.recs.push_back(r);
     }
+    // mates inside the task, while its records are hot: exact for a mate position inside one of the task's reach intervals (every
+    // record overlapping such a position was walked, and the task holds ALL records of a name it holds at all).  Generation by
+    // generation: a mate found becomes a member and has its own mate looked up.  What is left (mate_ref -2) goes through the
+    // other tasks / the index afterwards.
+    const int32_t n_ref = (int32_t)S.contigs.size();
+    const size_t nr = T.recs.size();
+    size_t cap = 16;
+    while (cap < 2 * nr) cap <<= 1;
+    std::vector<int32_t> &tab = W.tab, &stack = W.stack;
+    tab.assign(cap, -1);
+    for (size_t j = 0; j < nr; j++) { // linear probing, inserted in file order: equal names are met in file order along a probe chain
+        size_t slot = (size_t)(T.recs[j].nhash * 0x9E3779B97F4A7C15ULL >> 20) & (cap - 1);
+        while (tab[slot] >= 0) slot = (slot + 1) & (cap - 1);
+        tab[slot] = (int32_t)j;
+    }
+    auto in_reach = [&](int32_t pos_q) {
+        auto it = std::upper_bound(T.reach.begin(), T.reach.end(), pos_q, [](int32_t key, const std::pair<int32_t, int32_t> &x) { return key < x.second; });
+        return it != T.reach.end() && it->first <= pos_q;
+    };
+    stack.clear();
+    for (size_t j = nr; j-- > 0;) if (T.recs[j].keep == 2) stack.push_back((int32_t)j);
+    while (!stack.empty()) {
+        WRec &x = T.recs[(size_t)stack.back()];
+        stack.pop_back();
+        if (x.mate_ref != -2) continue;
+        if (!wants_mate(x, n_ref)) { x.mate_ref = -1; continue; }
+        if (!(x.mtid == T.tid && in_reach(x.mpos))) continue; // not this task's to answer
+        x.mate_ref = -1;
+        for (size_t slot = (size_t)(x.nhash * 0x9E3779B97F4A7C15ULL >> 20) & (cap - 1); tab[slot] >= 0; slot = (slot + 1) & (cap - 1)) {
+            WRec &y = T.recs[(size_t)tab[slot]];
+            if (y.nhash != x.nhash || !same_name(T, x, T, y) || !is_mate_of(x, y, T.tid)) continue;
+            x.mate_ref = ((int64_t)ti << 32) | (int64_t)tab[slot];
+            if (y.keep == 0) { y.keep = 1; stack.push_back(tab[slot]); }
+            break;
+        }
+    }
 }
-
-inline bool same_name(const Task &A, const WRec &a, const Task &B, const WRec &b) {
-    return a.nhash == b.nhash && a.l_name == b.l_name && memcmp(A.names.data() + a.name_at, B.names.data() + b.name_at, a.l_name) == 0;
-}
-
-// mate(): the first record in file order with the name, on the mate's reference, overlapping the mate position, carrying the
-// other read-of-pair flag (pysam's AlignmentFile.mate; it may be a secondary / supplementary record)
-inline bool is_mate_of(const WRec &x, const WRec &y, int32_t y_tid) {
-    if (y_tid != x.mtid) return false;
-    if (!((int64_t)y.pos < (int64_t)x.mpos + 1 && (int64_t)y.end > (int64_t)x.mpos)) return false;
-    const uint16_t want = (uint16_t)((x.flag ^ (FREAD1 | FREAD2)) & (FREAD1 | FREAD2));
-    return (y.flag & want) != 0;
-}
-
-inline bool wants_mate(const WRec &x, int32_t n_ref) { return (x.flag & FPAIRED) && !(x.flag & FMUNMAP) && x.mtid >= 0 && x.mtid < n_ref; }
 
 // a mate looked up through the index: the records overlapping [mpos, mpos + 1) of the mate's reference, walked like a fetch
 struct Lookup { int64_t who; int32_t mtid, mpos; };
@@ -607,6 +644,8 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     const int32_t n_ref = (int32_t)S.contigs.size();
     double t0 = now_s();
     threads = resolve_threads(threads);
+    // (UZ_STAGE_SLACK: a test hook -- a small slack pushes the mates outside the reach intervals, onto the cross-task / index path)
+    const int32_t REACH_SLACK = getenv("UZ_STAGE_SLACK") ? std::max(0, atoi(getenv("UZ_STAGE_SLACK"))) : REACH_SLACK_DEFAULT;
     // ---- the fetches per reference, sorted; reach intervals = fetches grown by the slack, merged
     P.fx.assign((size_t)n_ref, {});
     P.fx_max_len.assign((size_t)n_ref, 0);
@@ -665,7 +704,7 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
         std::vector<std::unique_ptr<Scratch>> scr((size_t)w);
         parallel_dynamic((int64_t)P.tasks.size(), w, [&](int64_t i, int k) {
             if (!scr[(size_t)k]) scr[(size_t)k].reset(new Scratch());
-            walk_task(P, P.tasks[(size_t)i], *scr[(size_t)k]);
+            walk_task(P, P.tasks[(size_t)i], *scr[(size_t)k], (size_t)i);
         });
     }
     double t2 = now_s();
@@ -675,16 +714,18 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
     const size_t n_tasks0 = P.tasks.size();
     // per task a name index would pay for deep pile-ups; the candidates are grouped by name hash first
     struct ByName { std::vector<std::pair<uint64_t, uint32_t>> v; };
-    std::vector<ByName> by_name(P.tasks.size());
-    parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 16), [&](int64_t i0, int64_t i1, int) {
-        for (int64_t i = i0; i < i1; i++) {
-            auto &v = by_name[(size_t)i].v;
-            const Task &T = P.tasks[(size_t)i];
-            v.resize(T.recs.size());
-            for (size_t j = 0; j < T.recs.size(); j++) v[j] = {T.recs[j].nhash, (uint32_t)j};
-            std::sort(v.begin(), v.end());
-        }
-    });
+    std::vector<ByName> by_name(P.tasks.size()); // (filled only when a mate is left to look up outside its own task)
+    auto build_by_name = [&] {
+        parallel_slices((int64_t)n_tasks0, workers_for((int64_t)n_tasks0, threads, 16), [&](int64_t i0, int64_t i1, int) {
+            for (int64_t i = i0; i < i1; i++) {
+                auto &v = by_name[(size_t)i].v;
+                const Task &T = P.tasks[(size_t)i];
+                v.resize(T.recs.size());
+                for (size_t j = 0; j < T.recs.size(); j++) v[j] = {T.recs[j].nhash, (uint32_t)j};
+                std::sort(v.begin(), v.end());
+            }
+        });
+    };
     // the task of the first walk whose reach interval holds position `pos` of reference `tid` (they are sorted and disjoint), or -1
     auto covering = [&](int32_t tid_q, int32_t pos_q) -> int64_t {
         size_t lo_i = 0, hi_i = n_tasks0;
@@ -728,7 +769,7 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
         parallel_slices((int64_t)P.tasks.size(), workers_for((int64_t)P.tasks.size(), threads, 64), [&](int64_t i0, int64_t i1, int) {
             for (int64_t ti = i0; ti < i1; ti++) {
                 int64_t c = 0;
-                for (const WRec &r : P.tasks[(size_t)ti].recs) c += r.keep == 2;
+                for (const WRec &r : P.tasks[(size_t)ti].recs) c += r.keep != 0 && r.mate_ref == -2;
                 at[(size_t)ti + 1] = c;
             }
         });
@@ -739,11 +780,12 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
                 int64_t k = at[(size_t)ti];
                 const auto &recs = P.tasks[(size_t)ti].recs;
                 for (size_t ri = 0; ri < recs.size(); ri++)
-                    if (recs[ri].keep == 2) frontier[(size_t)k++] = ((int64_t)ti << 32) | (int64_t)ri;
+                    if (recs[ri].keep != 0 && recs[ri].mate_ref == -2) frontier[(size_t)k++] = ((int64_t)ti << 32) | (int64_t)ri;
             }
         });
     }
     int64_t n_lookups = 0;
+    if (!frontier.empty()) build_by_name();
     for (int gen = 0; gen < 64 && !frontier.empty(); gen++) {
         std::vector<Lookup> need;
         {
@@ -1159,6 +1201,8 @@ int64_t uz_bamsrc_tlen_head(const uz_bamsrc *s, int32_t *out, int64_t cap) {
     return k;
 }
 const char *uz_inflate_backend(void) { return libdeflate().ok ? "libdeflate" : "zlib"; }
+int uz_io_default_threads(void) { return resolve_threads(0); }
+int uz_io_cpu_quota(void) { return cgroup_cpu_quota(); }
 
 int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int flags,
                       int min_base_qual, int threads, uz_stage **out) {

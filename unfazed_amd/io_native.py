@@ -31,7 +31,7 @@ IO_EXPORTS = [
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
-    "uz_inflate_backend", "uz_bam_stage_plan", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
+    "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
     "uz_stage_free",
 ]
 
@@ -528,6 +528,16 @@ STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE = 1, 2, 4
 
 def inflate_backend() -> str:
     return load().uz_inflate_backend().decode()
+
+
+def default_threads() -> int:
+    """worker threads the library uses for `threads=0`: CPUs of the affinity mask, held to twice the cgroup's CPU quota"""
+    return int(load().uz_io_default_threads())
+
+
+def cpu_quota() -> int:
+    """CPUs the container's cgroup grants (cpu.max); 0 = no limit"""
+    return int(load().uz_io_cpu_quota())
 
 
 class _StageNames(Sequence):
