@@ -481,18 +481,25 @@ def main():
     k1_us = k1_ms / max(1, k1_n) * 1e3
     bytes_per_site = 20.0  # 19 B read (packed trio GT + 9 x u16) + 1 B class written; DESIGN.md "K1"
     achieved = bytes_per_site * sc.n / (k1_us * 1e-6) / 1e9 if k1_n else 0.0
-    traffic = None
+    # counters come from a committed profile (separate --pmc passes, scripts/profile_round.sh) and are quoted only while that profile
+    # measured THIS build's kernels (it records the hash of the device sources); otherwise null + where to look
+    ksha = build.kernel_source_hash()
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "k1_traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if int(tj.get("n_sites", -1)) == sc.n:
+            if int(tj.get("n_sites", -1)) == sc.n and tj.get("kernel_source_sha") == ksha:
                 traffic = tj.get("hbm_bytes_per_launch")
+            else:
+                traffic_note = "profiles/k1_traffic.json was collected on other kernel sources (%s) or another table size: not quoted" % tj.get("kernel_source_sha")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_site_scan", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
-                "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n)}
+                "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n), "kernel_source_sha": ksha}
+    if traffic_note:
+        roofline["traffic_note"] = traffic_note
 
     # K3a (per-record QC bits) has no pass of its own any more: the header build writes a QC word per record at upload and the
     # readers apply --min-map-qual; the object stays in the line so that round-to-round readers find it
@@ -509,7 +516,10 @@ def main():
     if os.path.exists(tpath) and ph_n:
         try:
             tj = json.load(open(tpath))
-            if int(tj.get("dnms", -1)) == n:
+            if int(tj.get("dnms", -1)) == n and tj.get("kernel_source_sha") != ksha:
+                issue_model = {"kernel": "k_phase", "stale": True, "source": "profiles/phase_issue.json",
+                               "note": "collected on other kernel sources (%s): not quoted for this build (%s)" % (tj.get("kernel_source_sha"), ksha)}
+            elif int(tj.get("dnms", -1)) == n:
                 measured = ph_ms / ph_n
                 issue_model = {"kernel": "k_phase", "bound": "instruction issue (VALU), memory latency hidden by 7 waves per SIMD",
                                "valu_wave_instructions_per_dnm": round(tj["valu_wave_instructions_per_dnm_with_candidates"], 0),

@@ -131,6 +131,10 @@ int uz_vcf_decode_regions(const char *path, const char *tbi_path, int64_t n_iv, 
 /* sequence names of the tabix index, in the order of their first record in the file, each NUL-terminated, into buf; returns the
  * bytes needed (call with cap 0 first) or a negative UZ_IO_E_* */
 int64_t uz_vcf_index_names(const char *path, const char *tbi_path, char *buf, int64_t cap);
+/* What the index readers make of a BAI (kind 0) or TBI (kind 1) file, for checks against an independent reader: per reference six
+ * numbers -- bins (the 37450 pseudo-bin left out), chunks in them, linear-index entries, sum of the chunks' begins, of their ends, of
+ * the linear entries (each modulo 2^62).  Returns the number of references (fills at most cap_refs of them) or a negative UZ_IO_E_*. */
+int64_t uz_index_summary(const char *path, int kind, int64_t *out, int64_t cap_refs);
 /* what the last decode touched: [0] compressed file bytes read, [1] BGZF blocks inflated (region decode), [2] lines walked, [3] records kept */
 void uz_vcf_io_stats(const uz_vcf *h, int64_t out[4]);
 void uz_vcf_free(uz_vcf *h);

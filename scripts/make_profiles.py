@@ -8,13 +8,20 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from unfazed_amd.build import kernel_source_hash  # noqa: E402
+
 tag, rnd = sys.argv[1], sys.argv[2]
+# the device sources the profile was collected on: the bench line records it (roofline.kernel_source_sha); bench.py quotes these
+# counters only while it equals the hash of the build it runs
+KSHA = None
 k3a_factor = float(sys.argv[3]) if len(sys.argv) > 3 else None
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_bench_kernel_stats.csv" % rnd))
 shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "%s_pmc_summary.json" % rnd))
 line = json.loads([x for x in open(os.path.join(src, "stats.log")) if x.startswith("{")][-1])
+KSHA = (line.get("roofline") or {}).get("kernel_source_sha") or kernel_source_hash()
 json.dump(line, open(os.path.join(dst, "%s_bench_under_rocprof.json" % rnd), "w"), indent=1)
 pmc = json.load(open(os.path.join(src, "pmc_summary.json")))
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "kernel_stats.csv")))}
@@ -38,7 +45,7 @@ f, w = c("k_site_scan", "FETCH_SIZE") * 1024, c("k_site_scan", "WRITE_SIZE") * 1
 n_sites = line["config"]["sites"]
 json.dump({"kernel": pmc["k_site_scan"]["full_name"], "n_sites": n_sites, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
            "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": int(2 * f + w),
-           "algorithmic_bytes_per_launch": 20 * n_sites, "avg_ns_rocprof": avg_ns("k_site_scan")[0], "how": how,
+           "algorithmic_bytes_per_launch": 20 * n_sites, "avg_ns_rocprof": avg_ns("k_site_scan")[0], "how": how, "kernel_source_sha": KSHA,
            "source": "profiles/%s_pmc_summary.json" % rnd}, open(os.path.join(dst, "k1_traffic.json"), "w"), indent=1)
 if "k_seg_qc" in pmc:  # (rounds that still had the pass)
     # K3a: 16-byte header loads and 4-byte words; the factor between FETCH_SIZE and bytes is CALIBRATED on this kernel's own
@@ -112,5 +119,6 @@ if "SQ_INSTS_VALU" in cp and "GRBM_GUI_ACTIVE" in cp:
              "vgpr": pmc["k_phase"]["vgpr"], "scratch": pmc["k_phase"]["scratch"],
              "how": how + "; SQ_INSTS_* count wave-instructions, SQ_ACTIVE_* / SQ_WAIT_* are in quad-cycles",
              "source": "profiles/%s_pmc_summary.json" % rnd}
+    issue["kernel_source_sha"] = KSHA
     json.dump(issue, open(os.path.join(dst, "phase_issue.json"), "w"), indent=1)
     print(json.dumps(issue, indent=1))

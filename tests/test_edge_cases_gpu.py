@@ -36,13 +36,6 @@ def _dv(sites, rt, dn, contig=None, rcontig=None, start=None):
         concordant_cutoff(rt.tlen, 151, 3))
 
 
-def _compare(engine, P, sites, rt, dv, fid, rid):
-    sv, rv = abi.sites_view(sites), abi.reads_view(rt)
-    fam = None
-    got = engine.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
-    return got
-
-
 def test_empty_and_missing_inputs(engine, small):
     ds, sites, rt = small
     P = abi.make_params()

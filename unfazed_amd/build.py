@@ -13,6 +13,22 @@ DEFAULT_FLAGS = []
 LIB = os.path.join(_HERE, "libunfazed_hip.so")
 
 
+def kernel_source_hash() -> str:
+    """sha256 (16 hex digits) over the device sources (csrc/*.hip, *.hpp, include/*.h): profiles record it, and bench.py quotes a
+    profile's counters only while the kernels it measured are the kernels of this build"""
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    inc = os.path.join(_HERE, "..", "include")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(inc, "uz_types.h")) +
+                    glob.glob(os.path.join(inc, "unfazed_hip.h"))):
+        if os.path.basename(f).startswith("io_"):
+            continue  # host-only decoders
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 

@@ -10,6 +10,7 @@
 // float, missing -> -1; end = INFO/END when it parses as an integer, else start + len(REF).
 // BCF2 (the binary form, `.bcf`) is decoded into the same columns (decode_bcf below); it has no text lines,
 // so uz_vcf_line() is empty for such a file.
+#include <map>
 #include <memory>
 
 #include "io_common.hpp"
@@ -401,7 +402,29 @@ struct Tbi {
     std::vector<BaiRef> refs;
 };
 
-Tbi read_tbi(const char *path, int threads) {
+Tbi read_tbi_file(const char *path, int threads);
+
+// The parsed index of a file is kept for the next call (a session decodes the windows of batch after batch from one sites file; the
+// index of a 20 M-site VCF takes longer to inflate and parse than a batch's windows take to decode): keyed by path, size and mtime.
+std::shared_ptr<const Tbi> read_tbi(const char *path, int threads) {
+    static std::mutex mu;
+    static std::map<std::string, std::pair<std::pair<int64_t, int64_t>, std::shared_ptr<const Tbi>>> cache;
+    struct stat st;
+    if (stat(path, &st) != 0) fail(UZ_IO_E_OPEN, "cannot open %s", path);
+    const std::pair<int64_t, int64_t> stamp{(int64_t)st.st_size, (int64_t)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec};
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(path);
+        if (it != cache.end() && it->second.first == stamp) return it->second.second;
+    }
+    auto t = std::make_shared<const Tbi>(read_tbi_file(path, threads));
+    std::lock_guard<std::mutex> g(mu);
+    if (cache.size() >= 8) cache.clear();
+    cache[path] = {stamp, t};
+    return t;
+}
+
+Tbi read_tbi_file(const char *path, int threads) {
     Bytes f = read_file(path);
     bool gz = false;
     Bytes raw = inflate_all(f, threads, &gz);
@@ -433,7 +456,8 @@ std::string tbi_path_for(const char *path, const char *tbi_path) {
 void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n_iv, const int32_t *iv_ref, const int32_t *iv_lo,
                     const int32_t *iv_hi, int threads) {
     const std::string tp = tbi_path_for(path, tbi_path);
-    const Tbi tbi = read_tbi(tp.c_str(), threads);
+    const std::shared_ptr<const Tbi> tbi_p = read_tbi(tp.c_str(), threads);
+    const Tbi &tbi = *tbi_p;
     const int32_t n_ref = (int32_t)tbi.names.size();
     std::vector<std::vector<Iv>> ivs((size_t)n_ref);
     for (int64_t k = 0; k < n_iv; k++) {
@@ -807,13 +831,37 @@ int64_t uz_vcf_index_names(const char *path, const char *tbi_path, char *buf, in
     int64_t total = -1;
     const int rc = guarded([&] {
         if (!path) fail(UZ_IO_E_ARG, "uz_vcf_index_names: bad arguments");
-        const Tbi t = read_tbi(tbi_path_for(path, tbi_path).c_str(), 1);
+        const std::shared_ptr<const Tbi> tp = read_tbi(tbi_path_for(path, tbi_path).c_str(), 1);
+        const Tbi &t = *tp;
         std::string all;
         for (const std::string &n : t.names) { all += n; all.push_back('\0'); }
         if (buf && cap >= (int64_t)all.size()) memcpy(buf, all.data(), all.size());
         total = (int64_t)all.size();
     });
     return rc == UZ_IO_OK ? total : (int64_t)rc;
+}
+
+int64_t uz_index_summary(const char *path, int kind, int64_t *out, int64_t cap_refs) {
+    int64_t n = -1;
+    const int rc = guarded([&] {
+        if (!path || (cap_refs > 0 && !out)) fail(UZ_IO_E_ARG, "uz_index_summary: bad arguments");
+        std::vector<BaiRef> refs;
+        if (kind == 0) refs = read_bai(path);
+        else refs = read_tbi_file(path, 1).refs;
+        for (size_t r = 0; r < refs.size() && (int64_t)r < cap_refs; r++) {
+            uint64_t nb = 0, nc = 0, sb = 0, se = 0, sl = 0;
+            for (const auto &b : refs[r].bins) {
+                nb++;
+                for (const Chunk &c : b.second) { nc++; sb += c.beg; se += c.end; }
+            }
+            for (uint64_t v : refs[r].linear) sl += v;
+            const uint64_t m = (1ULL << 62) - 1;
+            int64_t *o = out + 6 * r;
+            o[0] = (int64_t)nb; o[1] = (int64_t)nc; o[2] = (int64_t)refs[r].linear.size(); o[3] = (int64_t)(sb & m); o[4] = (int64_t)(se & m); o[5] = (int64_t)(sl & m);
+        }
+        n = (int64_t)refs.size();
+    });
+    return rc == UZ_IO_OK ? n : (int64_t)rc;
 }
 
 void uz_vcf_io_stats(const uz_vcf *h, int64_t out[4]) {

@@ -31,7 +31,7 @@ IO_EXPORTS = [
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
-    "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
+    "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
     "uz_stage_free",
 ]
 
@@ -139,6 +139,8 @@ def load():
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.uz_select_free.argtypes = [C.c_void_p]
     lib.uz_select_free.restype = None
+    lib.uz_index_summary.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64]
+    lib.uz_index_summary.restype = C.c_int64
     lib.uz_bamsrc_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p)]
     lib.uz_bamsrc_close.argtypes = [C.c_void_p]
     lib.uz_bamsrc_close.restype = None
@@ -524,6 +526,18 @@ class ReadsSource:
 
 # ---------------------------------------------------------------------------- BAM file -> staged records in one pass
 STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE = 1, 2, 4
+
+
+def index_summary(path: str, kind: str) -> np.ndarray:
+    """what the native BAI / TBI reader makes of an index file (uz_index_summary): int64 [n_ref, 6]"""
+    lib = load()
+    k = {"bai": 0, "tbi": 1}[kind]
+    n = lib.uz_index_summary(os.fsencode(path), k, None, 0)
+    if n < 0:
+        _check(lib, int(n))
+    out = np.zeros((max(1, int(n)), 6), np.int64)
+    lib.uz_index_summary(os.fsencode(path), k, out.ctypes.data, int(n))
+    return out[: int(n)]
 
 
 def inflate_backend() -> str:
