@@ -49,11 +49,13 @@ def parse():
     ap.add_argument("--dnms", type=int, default=int(os.environ.get("UZ_BENCH_DNMS", 100000)),
                     help="DNMs per GPU (weak scaling) / in total (strong scaling)")
     ap.add_argument("--sites", type=int, default=int(os.environ.get("UZ_BENCH_SITES", 20000000)))
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when --gpus > 1 (BASELINE configs[3]: the SAME 100 k DNMs cut into contiguous shards), weak = every rank its own --dnms")
     ap.add_argument("--workload", choices=["snv", "cnv"], default="snv",
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
-    ap.add_argument("--chunks", type=int, default=10, help="DNM chunks of the staged pass (uploads overlap the kernels)")
+    ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
+                    "(shard.chunk_plan: >= 10 k DNMs per chunk, at least 2)")
     ap.add_argument("--last-chunk", type=float, default=0.5, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
@@ -131,6 +133,8 @@ def bind_near_gpu(torch, local_rank):
 
 def main():
     args = parse()
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.workload == "cnv" and "--dnms" not in " ".join(sys.argv) and "UZ_BENCH_DNMS" not in os.environ:
         args.dnms = 10000
     world = int(os.environ.get("WORLD_SIZE", 0))
@@ -235,10 +239,13 @@ def main():
             res = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        timed.per_rank = [elapsed]
         if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64, device="cuda")
+            t[rank] = elapsed
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            timed.per_rank = [float(x) for x in t.tolist()]
+            elapsed = max(timed.per_rank)
         prof = {k: eng.prof_get(k) for k in (K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING, K_CNV)}
         units = eng.prof_units(K_SEG_QC_PASS)
         timed.hbm_build_dnms = int(eng.prof_units(K_PHASE))
@@ -251,6 +258,7 @@ def main():
         return with_cnv(fid, eng.phase_raw(fid, rid, dv, P, mode))
 
     res_r, el_r, prof_r, qc_records = timed(step_resident)
+    per_rank_r = list(timed.per_rank)
 
     # ---------------------------------------------------------------- staged pass
     staged = None
@@ -282,14 +290,12 @@ def main():
         sites_h = abi.Held(sv, hs)
         # ... and, per chunk of DNMs (whole clusters), the records the chunk's fetches return + their mates
         co, ci, cf, ho, hi = eng.find(fid, dv, P, mode)
-        nchunk = max(1, min(args.chunks, n))
         chunks, staged_bytes, staged_records = [], 0, 0
         slab_hint = 768 << 20
         # chunks of events (their records: the clusters of their generator entries); the last one smaller (--last-chunk): its read
         # stage is the only one nothing hides -- the link is idle by then
-        f_last = min(1.0, max(0.05, args.last_chunk))
-        unit = n / (nchunk - 1 + f_last)
-        ecuts = [min(n, int(round(unit * k))) for k in range(nchunk)] + [n]
+        ecuts = shard.chunk_plan(n, args.chunks or None, args.last_chunk)
+        nchunk = len(ecuts) - 1
         for k in range(nchunk):
             a, b = ecuts[k], ecuts[k + 1]
             if b <= a:
@@ -428,6 +434,7 @@ def main():
             return out
 
         res_s, el_s, prof_s, _ = timed(step_staged)
+        per_rank_s = list(timed.per_rank)
         if trace and chunk_sites:
             print("[staged step, ms] site stage 0, then per chunk: find | next site stage | enqueue records | read stage of the chunk before; last read stage:", trace[-2:], file=sys.stderr)
         elif trace:
@@ -567,6 +574,8 @@ def main():
                        "read_clusters": cl.n, "dnms_sharing_a_cluster": int(cl.nd[cl.nd > 1].sum()),
                        "alignment_records": wl.n_segs, "parallelism": "dnm-shard x%d, no collective" % world},
             "value_resident": round(value_resident, 1), "ms_per_step_resident": round(ms_resident, 3),
+            "ms_per_step_by_rank": [round(x / args.steps * 1e3, 3) for x in (per_rank_s if staged else per_rank_r)],
+            "ms_per_step_resident_by_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_r],
             "roofline": roofline,
             "roofline_k3a": roofline_k3a,
             "issue_model": issue_model,

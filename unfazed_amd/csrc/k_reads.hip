@@ -105,6 +105,14 @@ struct PhaseState {
     DevBuf<unsigned int> need_count;
     int32_t *bounds_h = nullptr; // pinned: the copy back must not block the host, the marking kernels follow it
     size_t bounds_h_cap = 0;
+    int32_t *res_h = nullptr;    // pinned staging of the per-DNM results
+    size_t res_h_cap = 0;
+    // the sizes of the batch before this one (with head room): what a batch is first run on (uz_launch_phase)
+    bool spec_valid = false;
+    Caps spec_caps = {0, 0, 0, 0, 0, 0};
+    int spec_arena = 0;
+    double spec_sumP_per_dnm = 0.0;
+    long long spec_runs = 0, spec_misses = 0;
     hipEvent_t bounds_ready = nullptr;
     int n_cus = 0;
     std::vector<long long> list_start_h;
@@ -624,96 +632,80 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         st->bounds_h_cap = (size_t)5 * n + (size_t)n;
         UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
     }
-    const int32_t *bh = st->bounds_h;
-    uz_kcopy(c, st->bounds_h, st->bounds.p, (size_t)5 * n * sizeof(int32_t));
+    // The sizes of the batch (k_phase_bounds) decide the scratch capacities, the LDS arena and the grid.  Waiting for them costs a
+    // host round trip per batch -- a staged pass makes one per chunk.  So a batch is first run SPECULATIVELY on the capacities of the
+    // batch before it (with head room): the kernels refuse what does not fit (UZ_ST_CAPACITY, never a write out of bounds), the
+    // bounds come back with the results, and only when they exceed what was assumed is the batch run again on its own sizes.
+    // (UZ_PHASE_NO_SPEC=1, the capacity / arena test hooks and the first batch of a context take the exact path.)
+    int32_t *const bh_own = st->bounds_h; // [5n] bounds (kept apart from the result staging below: both are read after the run)
+    uz_kcopy(c, bh_own, st->bounds.p, (size_t)5 * n * sizeof(int32_t));
     if (!st->bounds_ready) UZ_HIP(hipEventCreateWithFlags(&st->bounds_ready, hipEventDisableTiming));
     UZ_HIP(hipEventRecord(st->bounds_ready, c->stream));
-    UZ_HIP(hipEventSynchronize(st->bounds_ready));
-    if (c->hflags[0]) { // set by the header build of an upload (abi.hip) whose commands have now run
-        const int f = c->hflags[0];
-        c->hflags[0] = 0;
-        throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
-                                  : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
-                                  : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
-                                  : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
-                                  : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
-                                  : f == 7 ? "mate_d / esc16_* of the reads view: a mate index outside the table"
-                                           : "n_cigar_total / n_row_units of the reads view do not match its columns"};
-    }
-    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, reach = 0;
-    for (int32_t d = 0; d < n; d++) {
-        const int32_t *b = &bh[(size_t)5 * d];
-        mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
-        mH = std::max<long long>(mH, b[2]); mC = std::max<long long>(mC, b[3]);
-        const long long I = 4LL * b[0];
-        const long long M = (long long)b[1] + I * (b[4] + 1);
-        mM = std::max(mM, M);
-        reach += 2LL * ((long long)b[0] + b[1]); // every fetched record and its mate
-        sumP += std::min<long long>(M, 4096) + b[3];
-    }
-    Caps caps;
-    caps.A = (int32_t)mA; caps.T = (int32_t)mT; caps.H = (int32_t)mH; caps.C = (int32_t)mC;
-    caps.I = (int32_t)(4 * mA);
-    caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
-    if (const char *e = getenv("UZ_TEST_CAP_T")) { // test hook: a scratch too small for some DNMs -> they must come back as UZ_ST_CAPACITY
-        const int32_t t = (int32_t)atoi(e);
-        if (t < caps.T) caps.T = t;
-    }
-    Scr dummy;
-    const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
+    auto check_upload_flags = [&] {
+        if (c->hflags[0]) { // set by the header build of an upload (abi.hip) whose commands have now run
+            const int f = c->hflags[0];
+            c->hflags[0] = 0;
+            throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
+                                      : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
+                                      : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
+                                      : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
+                                      : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
+                                      : f == 7 ? "mate_d / esc16_* of the reads view: a mate index outside the table"
+                                               : "n_cigar_total / n_row_units of the reads view do not match its columns"};
+        }
+    };
+    struct Sizes { Caps caps; int arena; long long sumP; };
+    static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
+    auto exact_sizes = [&](const int32_t *bh) {
+        long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
+        for (int32_t d = 0; d < n; d++) {
+            const int32_t *b = &bh[(size_t)5 * d];
+            mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
+            mH = std::max<long long>(mH, b[2]); mC = std::max<long long>(mC, b[3]);
+            const long long I = 4LL * b[0];
+            const long long M = (long long)b[1] + I * (b[4] + 1);
+            mM = std::max(mM, M);
+            sumP += std::min<long long>(M, 4096) + b[3];
+        }
+        Sizes z;
+        z.caps.A = (int32_t)mA; z.caps.T = (int32_t)mT; z.caps.H = (int32_t)mH; z.caps.C = (int32_t)mC;
+        z.caps.I = (int32_t)(4 * mA);
+        z.caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
+        z.sumP = sumP;
+        // LDS arena of k_phase<true>, sized for THIS batch: a DNM needs about 20 bytes per record its het-site fetches return
+        // plus 7 KiB (fit over the bench workload).  The 99th percentile of that estimate over the batch
+        // decides how many workgroups share a CU's 160 KiB (at most UZ_PHASE_MIN_WAVES: registers), and the arena is then the
+        // largest that this many workgroups leave room for.  A shallow batch runs 7 workgroups per CU on 21 KiB arenas, a deep
+        // one fewer on larger arenas -- instead of handing most of its DNMs to the slower HBM build.
+        z.arena = arena_env;
+        if (z.arena < 0) {
+            std::vector<int32_t> hist(64, 0); // estimate in KiB
+            int32_t active = 0;
+            for (int32_t d = 0; d < n; d++) {
+                const int32_t *b = &bh[(size_t)5 * d];
+                if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
+                const long long est = (20LL * b[1] + 7168 + 1023) >> 10;
+                hist[(size_t)std::min<long long>(est, 63)]++;
+                active++;
+            }
+            int kb = 12, seen = 0;
+            for (int k = 0; k < 64; k++) {
+                seen += hist[k];
+                if (hist[k]) kb = std::max(kb, k);
+                if ((long long)seen * 100 >= (long long)active * 99) break;
+            }
+            z.arena = std::min(kb, 62) * 1024;
+        }
+        return z;
+    };
     if (st->n_cus <= 0) { // asked once: the query is not cheap
         hipDeviceProp_t prop;
         UZ_HIP(hipGetDeviceProperties(&prop, c->device));
         st->n_cus = prop.multiProcessorCount;
     }
-    // LDS arena of k_phase<true>, sized for THIS batch: a DNM needs about 20 bytes per record its het-site fetches return
-    // plus 7 KiB (fit over the bench workload).  The 99th percentile of that estimate over the batch
-    // decides how many workgroups share a CU's 160 KiB (at most UZ_PHASE_MIN_WAVES: registers), and the arena is then the
-    // largest that this many workgroups leave room for.  A shallow batch runs 7 workgroups per CU on 21 KiB arenas, a deep
-    // one fewer on larger arenas -- instead of handing most of its DNMs to the slower HBM build.
-    static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
-    int arena_used = arena_env;
-    if (arena_used < 0) {
-        std::vector<int32_t> hist(64, 0); // estimate in KiB
-        int32_t active = 0;
-        for (int32_t d = 0; d < n; d++) {
-            const int32_t *b = &bh[(size_t)5 * d];
-            if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
-            const long long est = (20LL * b[1] + 7168 + 1023) >> 10;
-            hist[(size_t)std::min<long long>(est, 63)]++;
-            active++;
-        }
-        int kb = 12, seen = 0;
-        for (int k = 0; k < 64; k++) {
-            seen += hist[k];
-            if (hist[k]) kb = std::max(kb, k);
-            if ((long long)seen * 100 >= (long long)active * 99) break;
-        }
-        arena_used = std::min(kb, 62) * 1024;
-    }
-    if (const char *e = getenv("UZ_TEST_PHASE_ARENA")) { // test hook: an arena (bytes) too small for most DNMs -> they take the HBM build of k_phase
-        const int t = atoi(e);
-        if (t >= 0 && t < arena_used) arena_used = t;
-    }
-    int wgs_per_cu;
-    {
-        static const int wgs_env = [] { const char *e = getenv("UZ_PHASE_WGS_PER_CU"); return e ? atoi(e) : 0; }();
-        const int by_lds = (160 * 1024) / (arena_used + (int)sizeof(WgSharedT<1>) + 512);
-        const int by_regs = UZ_PHASE_MIN_WAVES * 4 / (WG_NT / 64); // waves per SIMD x four SIMDs / waves per workgroup
-        wgs_per_cu = wgs_env > 0 ? wgs_env : std::max(1, std::min(by_lds, by_regs));
-        if (arena_env < 0 && wgs_env <= 0) { // all the room this occupancy leaves
-            const int room = ((160 * 1024) / wgs_per_cu - (int)sizeof(WgSharedT<1>) - 512) & ~255;
-            if (room > arena_used && !getenv("UZ_TEST_PHASE_ARENA")) arena_used = std::min(room, 62 * 1024);
-        }
-    }
-    a.lds_arena_bytes = arena_used;
-    int grid = st->n_cus * wgs_per_cu;
-    if (grid > n) grid = n;
-    const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
-    while (grid > 1 && (size_t)grid * per_wg > budget) grid /= 2;
-    st->scratch.ensure((size_t)grid * per_wg);
-    a.scratch = st->scratch.p; a.scratch_per_wg = per_wg; a.caps = caps;
-
+    static const bool no_spec = getenv("UZ_PHASE_NO_SPEC") != nullptr;
+    const bool hooks = getenv("UZ_TEST_CAP_T") || getenv("UZ_TEST_PHASE_ARENA");
+    bool speculative = st->spec_valid && !no_spec && !hooks;
     st->status.ensure(n); st->counts.ensure((size_t)4 * n); st->origin.ensure(n); st->evidence.ensure(n);
     st->cursor.ensure(16 * (UZ_PHASE_PARTS + 1));
     st->retry.ensure((size_t)n + 16);
@@ -721,69 +713,125 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     a.status = st->status.p; a.counts = st->counts.p; a.origin = st->origin.p; a.evidence = st->evidence.p;
     a.work_cursor = st->cursor.p;
     a.want_lists = uz_want_lists;
-    size_t pool_cap = (size_t)std::min<long long>(4 * sumP + 1024, (long long)1 << 31);
-    st->pool.ensure(pool_cap);
     st->pool_cursor.ensure(2); st->list_start.ensure(n); st->list_len.ensure((size_t)6 * n);
-    a.pool = st->pool.p; a.pool_cap = pool_cap; a.pool_cursor = st->pool_cursor.p;
+    a.pool_cursor = st->pool_cursor.p;
     a.list_start = st->list_start.p; a.list_len = st->list_len.p;
-
 #ifdef UZ_PHASE_TIMING
     static DevBuf<unsigned long long> timing;
     timing.ensure(32);
     UZ_HIP(hipMemsetAsync(timing.p, 0, 32 * sizeof(unsigned long long), c->stream));
     a.timing = timing.p;
 #endif
-    (void)reach;
     // pinned staging of the per-DNM results (+ the list-pool fill level): everything comes back behind ONE sync
     {
         const size_t need = (size_t)7 * n + 16;
-        if (st->bounds_h_cap < need) {
-            if (st->bounds_h) (void)hipHostFree(st->bounds_h);
-            st->bounds_h = nullptr;
-            st->bounds_h_cap = need + (size_t)n;
-            UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
+        if (st->res_h_cap < need) {
+            if (st->res_h) (void)hipHostFree(st->res_h);
+            st->res_h = nullptr;
+            st->res_h_cap = need + (size_t)n;
+            UZ_HIP(hipHostMalloc((void **)&st->res_h, st->res_h_cap * sizeof(int32_t), hipHostMallocDefault));
         }
     }
-    int32_t *const hres = st->bounds_h;
+    int32_t *const hres = st->res_h;
     unsigned long long *const hused = (unsigned long long *)(hres + (size_t)7 * n + ((7 * (size_t)n) & 1)); // 8-byte aligned slot
-    for (int attempt = 0; attempt < 4; attempt++) {
-        UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 1) * sizeof(int32_t), c->stream));
-        UZ_HIP(hipMemsetAsync(st->retry.p, 0, 16 * sizeof(int32_t), c->stream));
-        UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
+    for (int round = 0; round < 2; round++) {
+        Sizes z;
+        if (speculative) {
+            z.caps = st->spec_caps; z.arena = st->spec_arena;
+            z.sumP = (long long)(st->spec_sumP_per_dnm * (double)n) + 4096;
+        } else {
+            UZ_HIP(hipEventSynchronize(st->bounds_ready));
+            check_upload_flags();
+            z = exact_sizes(bh_own);
+            if (const char *e = getenv("UZ_TEST_CAP_T")) { // test hook: a scratch too small for some DNMs -> they must come back as UZ_ST_CAPACITY
+                const int32_t t = (int32_t)atoi(e);
+                if (t < z.caps.T) z.caps.T = t;
+            }
+        }
+        const Caps caps = z.caps;
+        int arena_used = z.arena;
+        Scr dummy;
+        const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
+        if (const char *e = getenv("UZ_TEST_PHASE_ARENA")) { // test hook: an arena (bytes) too small for most DNMs -> they take the HBM build of k_phase
+            const int t = atoi(e);
+            if (t >= 0 && t < arena_used) arena_used = t;
+        }
+        int wgs_per_cu;
         {
-            ProfScope ps(c, UZ_K_PHASE);
-            UZ_TRACE("k_phase");
-            hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
-            UZ_HIP(hipGetLastError());
-            // (the DNMs the first kernel gave up: usually a handful -- two workgroups per CU pull them from the list)
-            hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 2 * st->n_cus)), dim3(WG_NT), 0, c->stream, a);
-            UZ_HIP(hipGetLastError());
+            static const int wgs_env = [] { const char *e = getenv("UZ_PHASE_WGS_PER_CU"); return e ? atoi(e) : 0; }();
+            const int by_lds = (160 * 1024) / (arena_used + (int)sizeof(WgSharedT<1>) + 512);
+            const int by_regs = UZ_PHASE_MIN_WAVES * 4 / (WG_NT / 64); // waves per SIMD x four SIMDs / waves per workgroup
+            wgs_per_cu = wgs_env > 0 ? wgs_env : std::max(1, std::min(by_lds, by_regs));
+            if (arena_env < 0 && wgs_env <= 0) { // all the room this occupancy leaves
+                const int room = ((160 * 1024) / wgs_per_cu - (int)sizeof(WgSharedT<1>) - 512) & ~255;
+                if (room > arena_used && !getenv("UZ_TEST_PHASE_ARENA")) arena_used = std::min(room, 62 * 1024);
+            }
         }
-        UZ_TRACE("after k_phase");
-        *hused = 0;
-        uz_kcopy(c, hused, st->pool_cursor.p, sizeof(unsigned long long));
-        int32_t *const hretry = (int32_t *)(hused + 1);
-        *hretry = 0;
-        uz_kcopy(c, hretry, st->retry.p, sizeof(int32_t));
-        if (status) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
-        if (counts) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
-        if (origin) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
-        if (evidence) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
-        UZ_HIP(hipStreamSynchronize(c->stream));
-        if (c->hflags[1]) {
-            const int f = c->hflags[1];
-            c->hflags[1] = 0;
-            throw UzError{UZ_E_STATE, f == 3 ? "the read stage asked for a base (or its quality bit) in a 32-base unit that was not staged (umask): the fetch points that staged the table do not cover this batch"
-                                    : f == 2 ? "the read stage asked for a base-quality bit of a record staged without its quality row (more than 10 low-quality bases, or no bases): such a record can never pass goodread -- the staging rule and the kernel disagree"
-                                             : "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
-        }
-        const unsigned long long used = *hused;
-        c->prof[UZ_K_PHASE].last_units = (int64_t)*(const int32_t *)(hused + 1); // DNMs that took the HBM build
-        if (!a.want_lists || used <= a.pool_cap) break;
-        // list pool too small: grow to the exact demand and run again
-        pool_cap = (size_t)used + 1024;
+        a.lds_arena_bytes = arena_used;
+        int grid = st->n_cus * wgs_per_cu;
+        if (grid > n) grid = n;
+        const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
+        while (grid > 1 && (size_t)grid * per_wg > budget) grid /= 2;
+        st->scratch.ensure((size_t)grid * per_wg);
+        a.scratch = st->scratch.p; a.scratch_per_wg = per_wg; a.caps = caps;
+        size_t pool_cap = (size_t)std::min<long long>(4 * z.sumP + 1024, (long long)1 << 31);
         st->pool.ensure(pool_cap);
         a.pool = st->pool.p; a.pool_cap = pool_cap;
+        for (int attempt = 0; attempt < 4; attempt++) {
+            UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 1) * sizeof(int32_t), c->stream));
+            UZ_HIP(hipMemsetAsync(st->retry.p, 0, 16 * sizeof(int32_t), c->stream));
+            UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
+            {
+                ProfScope ps(c, UZ_K_PHASE);
+                UZ_TRACE("k_phase");
+                hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
+                UZ_HIP(hipGetLastError());
+                // (the DNMs the first kernel gave up: usually a handful -- two workgroups per CU pull them from the list)
+                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 2 * st->n_cus)), dim3(WG_NT), 0, c->stream, a);
+                UZ_HIP(hipGetLastError());
+            }
+            UZ_TRACE("after k_phase");
+            *hused = 0;
+            uz_kcopy(c, hused, st->pool_cursor.p, sizeof(unsigned long long));
+            int32_t *const hretry = (int32_t *)(hused + 1);
+            *hretry = 0;
+            uz_kcopy(c, hretry, st->retry.p, sizeof(int32_t));
+            if (status) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
+            if (counts) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
+            if (origin) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
+            if (evidence) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
+            UZ_HIP(hipStreamSynchronize(c->stream));
+            if (speculative) check_upload_flags();
+            if (c->hflags[1]) {
+                const int f = c->hflags[1];
+                c->hflags[1] = 0;
+                throw UzError{UZ_E_STATE, f == 3 ? "the read stage asked for a base (or its quality bit) in a 32-base unit that was not staged (umask): the fetch points that staged the table do not cover this batch"
+                                        : f == 2 ? "the read stage asked for a base-quality bit of a record staged without its quality row (more than 10 low-quality bases, or no bases): such a record can never pass goodread -- the staging rule and the kernel disagree"
+                                                 : "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
+            }
+            const unsigned long long used = *hused;
+            c->prof[UZ_K_PHASE].last_units = (int64_t)*(const int32_t *)(hused + 1); // DNMs that took the HBM build
+            if (!a.want_lists || used <= a.pool_cap) break;
+            // list pool too small: grow to the exact demand and run again
+            pool_cap = (size_t)used + 1024;
+            st->pool.ensure(pool_cap);
+            a.pool = st->pool.p; a.pool_cap = pool_cap;
+        }
+        // what the batch really needed: the next batch's assumption -- and the verdict on this one's
+        const Sizes real = exact_sizes(bh_own);
+        auto room = [](int32_t v) { return (int32_t)std::min<long long>((long long)v + v / 4 + 16, 0x3FFFFFFF); };
+        st->spec_caps.A = room(real.caps.A); st->spec_caps.T = room(real.caps.T); st->spec_caps.H = room(real.caps.H); st->spec_caps.C = room(real.caps.C);
+        st->spec_caps.I = 4 * st->spec_caps.A;
+        st->spec_caps.M = next_pow2(std::min<long long>(2LL * real.caps.M, 1 << 20));
+        st->spec_arena = real.arena;
+        st->spec_sumP_per_dnm = 1.25 * (double)real.sumP / (double)n;
+        st->spec_valid = true;
+        if (!speculative) break;
+        const bool fits = real.caps.A <= caps.A && real.caps.T <= caps.T && real.caps.H <= caps.H && real.caps.C <= caps.C && real.caps.M <= caps.M;
+        st->spec_runs++;
+        if (fits) break;
+        st->spec_misses++;
+        speculative = false; // the batch outgrew the assumption: once more, on its own sizes
     }
 #ifdef UZ_PHASE_TIMING
     {

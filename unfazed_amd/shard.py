@@ -13,6 +13,25 @@ def shard_bounds(n: int, world: int) -> List[int]:
     return [(n * r) // world for r in range(world + 1)]
 
 
+def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, min_per_chunk: int = 10000) -> List[int]:
+    """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k, so a shard wants at
+    least two chunks, and chunks of at least ~min_per_chunk DNMs (a chunk's copy should outlast the host's work per chunk).  The
+    last chunk is smaller (last_chunk x the others): its read stage is the only one nothing hides.
+    chunks=None: from the shard size -- 100 k DNMs -> 10 chunks, a 12.5 k shard of an 8-GPU run -> 2.  -> [0, ..., n]"""
+    if n <= 0:
+        return [0, 0]
+    k = int(chunks) if chunks else max(2, n // int(min_per_chunk))
+    k = max(1, min(k, n))
+    f = min(1.0, max(0.05, float(last_chunk)))
+    unit = n / (k - 1 + f)
+    cuts = [min(n, int(round(unit * j))) for j in range(k)] + [n]
+    out = [0]
+    for c in cuts[1:]:
+        if c > out[-1]:
+            out.append(c)
+    return out
+
+
 def shard_dnms(dnms: List[dict], rank: int, world: int) -> List[dict]:
     """Sort by (chrom, start, end, kid) -- neighbours share site windows and read blocks -- and
     take this rank's contiguous slice."""
