@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-staged", action="store_true", help="resident pass only (profiling runs)")
+    ap.add_argument("--no-config5", action="store_true", help="default snv run: do not also run BASELINE configs[4] (10 k DEL/DUP) as a child process for the `config5` object")
     ap.add_argument("--feed-dnms", type=int, default=int(os.environ.get("UZ_BENCH_FEED_DNMS", 20000)),
                     help="DNMs of the files -> results pass (`feed` / `value_e2e`): their pile-ups are written as a real BAM + BAI, the sites table as "
                          "a BGZF VCF + TBI, and decoded back through the indexes inside the timed region (0 = skip)")
@@ -135,6 +136,8 @@ def main():
     args = parse()
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
+    if args.workload == "cnv" and not args.chunks:
+        args.chunks = 10  # (the events of a chunk bring the pile-ups of both breakpoints: many small chunks keep the link busy)
     if args.workload == "cnv" and "--dnms" not in " ".join(sys.argv) and "UZ_BENCH_DNMS" not in os.environ:
         args.dnms = 10000
     world = int(os.environ.get("WORLD_SIZE", 0))
@@ -559,6 +562,24 @@ def main():
             cpu["e2e"] = ("files -> results for the %d DNMs of the feed pass: %.2f s decode (uz_bam_decode of the same BAM, %d records, + uz_vcf_decode_regions of "
                           "the same windows, all host threads) + %.2f s oracle at its best thread count" % (m_f, feed["cpu_decode_s"], feed["cpu_decode_records"], m_f / cpu["value"]))
 
+    config5 = None
+    if rank == 0 and world == 1 and not cnv and not args.no_config5 and args.dnms == 100000:
+        # BASELINE configs[4] in the same driver-run line: the 10 k DEL/DUP workload as a child process (its own generator state and
+        # contexts; this process has let go of nothing it needs and waits)
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", "cnv", "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-config5",
+                   "--cpu-dnms", "10000" if not args.no_cpu else "0"] + (["--no-cpu"] if args.no_cpu else [])
+            cp = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=900)
+            line5 = [x for x in cp.stdout.decode().splitlines() if x.startswith("{")]
+            j5 = json.loads(line5[-1]) if line5 else None
+            if j5:
+                config5 = {k: j5.get(k) for k in ("value", "unit", "ms_per_step", "value_resident", "ms_per_step_resident", "kernels_ms_per_step", "calls", "cpu_baseline")}
+                config5["workload"] = j5["config"]["workload"]
+                config5["link"] = j5.get("link")
+                config5["metric"] = "phased events/sec (DEL/DUP: allele balance K6 merged with the SV read-backed stage)"
+        except Exception as e:  # the headline line must not die with the side run
+            config5 = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "phased DNMs/sec", "value": round(value, 1), "unit": "DNMs/s", "n_gpus": world,
@@ -582,6 +603,7 @@ def main():
             "cpu_baseline": cpu,
             "value_e2e": feed["value_e2e"] if feed else None,
             "feed": feed,
+            "config5": config5,
             "kernels_ms_per_step": kern_ms(prof_r),
             "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist(),
                       "dnms_redone_by_hbm_build_of_k_phase": getattr(timed, "hbm_build_dnms", None)},
@@ -759,8 +781,8 @@ def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_v
     alignment file would hold it); T threads take the ranges round-robin, one oracle call (find + phase) per range.  The
     oracle's per-call set-up is proportional to the table it is handed, so one shared table does not scale past a few
     threads; per-range tables do.  Results are compared with the GPU's."""
-    if cnv:  # the two breakpoints of an event lie in different clusters: one table for the whole sample
-        return cpu_baseline_shared_table(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv)
+    if cnv:  # the two breakpoints of an event lie in different clusters
+        return cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res)
     from oracle import oracle as orc
     from synth import bigsynth
     from unfazed_amd import abi
@@ -859,6 +881,94 @@ def _cpu_quota():
         return None if a == "max" else round(int(a) / int(b), 2)
     except Exception:
         return None
+
+
+def cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res):
+    """Config 5 on the CPU oracle with per-range tables, as the SNV baseline has them: the breakpoint list (sorted by position) is cut
+    into contiguous cluster ranges, each with its own records table regenerated on the host before the timing; the sample is the
+    events whose BOTH breakpoints fall into one range (an event that straddles a cut is left out: a few per cent); T threads take the
+    ranges round-robin, one oracle pass (find + read stage + allele balance) per range.  Results are compared with the GPU's."""
+    from oracle import oracle as orc
+    from synth import bigsynth
+    from unfazed_amd import abi
+    ncpu = os.cpu_count() or 1
+    want = min(args.cpu_dnms, ev.n)
+    n_ranges = max(1, min(4 * ncpu, cl.n // 8))
+    ends = cl.d0 + cl.nd
+    cuts = sorted({int(np.searchsorted(ends, dn.n * (k + 1) / n_ranges, side="left")) + 1 for k in range(n_ranges)} | {cl.n})
+    cuts = [c for c in cuts if c <= cl.n]
+    c_of_start = np.searchsorted(cl.d0, dn.bp_start, side="right") - 1
+    c_of_end = np.searchsorted(cl.d0, dn.bp_end, side="right") - 1
+    nc = len(sc.contig_off) - 1
+    sv = abi.SitesView()
+    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags, ref_base=sc.ref_base, alt_base=sc.alt_base)
+    sv.n_sites, sv.n_contigs = sc.n, nc
+    for k, a in keep.items():
+        setattr(sv, k, a.ctypes.data)
+    sh = abi.Held(sv, keep)
+    fh = abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
+    orc.lib()
+    jobs, c0, taken = [], 0, 0
+    for c1 in cuts:
+        if c1 <= c0:
+            continue
+        inside = np.nonzero((c_of_start >= c0) & (c_of_start < c1) & (c_of_end >= c0) & (c_of_end < c1))[0]
+        if inside.size and taken < want:
+            inside = inside[: want - taken]
+            rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, c0, c1, threads=min(ncpu, 32))
+            dv = abi.dnms_view(ev.contig[inside], ev.contig[inside], ev.start[inside], ev.end[inside], ev.vartype[inside], [b""] * inside.size, [b""] * inside.size, cutoff)
+            jobs.append((inside, rh, dv))
+            taken += int(inside.size)
+        c0 = c1
+    idx_all = np.concatenate([j[0] for j in jobs]) if jobs else np.zeros(0, np.int64)
+    m = int(idx_all.size)
+
+    def run(threads):
+        out = {k: {} for k in ("status", "counts", "origin", "evidence", "etype", "cnv_counts")}
+        t0 = time.perf_counter()
+
+        def work(t):
+            for j in range(t, len(jobs), threads):
+                inside, rh, dv = jobs[j]
+                found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+                p = orc.phase(P, sh, rh, dv, found, keep_lists=False)
+                k = orc.phase_cnv(P, sh, fh, dv, rb_counts=p["counts"])
+                out["status"][j], out["counts"][j] = p["status"], p["counts"]
+                for name in ("origin", "evidence", "etype", "cnv_counts"):
+                    out[name][j] = k[name]
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        return dt, {k: np.concatenate([v[j] for j in range(len(jobs))]) for k, v in out.items()}
+
+    dt1, r1 = run(1)
+    dt2, _ = run(2)
+    ladder = sorted({t for t in (8, 32, 64, 128, ncpu) if 2 < t <= ncpu})
+    best = None
+    sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
+    for t in ladder:
+        dtt, rt = run(t)
+        sweep[str(t)] = round(m / dtt, 1)
+        if best is None or dtt < best[0]:
+            best = (dtt, rt, t)
+    if best is None:
+        best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
+    dtc, rc, cores = best
+    mism = 0
+    for k in r1:
+        mism += int((np.asarray(gpu_res[k])[idx_all] != r1[k]).sum())
+        mism += int((rc[k] != r1[k]).sum())
+    return {"value": round(m / dtc, 1), "unit": "events/s", "cores": cores, "kind": "port",
+            "sample": "%d events of the GPU batch whose two breakpoints fall into one of %d cluster ranges (each range with its own records table, regenerated on the "
+                      "host before the timing); oracle find + read stage + allele balance per range, threads over ranges (best of a ladder: %d)" % (m, len(jobs), cores),
+            "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
+            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
+            "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu, "host_cpu_quota": _cpu_quota(),
+            "parity_mismatches_vs_gpu": mism}
 
 
 def cpu_baseline_shared_table(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):

@@ -317,5 +317,9 @@ def breakpoint_dnms(cv: CnvColumns) -> DnmColumns:
     order = np.lexsort((pos, contig))
     k = order.size
     z8 = np.zeros(k, np.uint8)
-    return DnmColumns(np.full(k, -1, np.int32), contig[order].astype(np.int32), pos[order].astype(np.int32), (pos[order] + 1).astype(np.int32),
-                      z8, z8.copy(), z8.copy(), [b""] * k, [b""] * k)
+    out = DnmColumns(np.full(k, -1, np.int32), contig[order].astype(np.int32), pos[order].astype(np.int32), (pos[order] + 1).astype(np.int32),
+                     z8, z8.copy(), z8.copy(), [b""] * k, [b""] * k)
+    inv = np.empty(k, np.int64)
+    inv[order] = np.arange(k)
+    out.bp_start, out.bp_end = inv[: cv.contig.size], inv[cv.contig.size:]  # entry of every event's start / end breakpoint in the list
+    return out
