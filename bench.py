@@ -256,11 +256,24 @@ def main():
         return res, elapsed, prof, units
 
     # ---------------------------------------------------------------- resident pass
+    rtrace = [] if os.environ.get("UZ_BENCH_TRACE") else None
+
     def step_resident():
+        if rtrace is None:
+            eng.drop_derived()
+            return with_cnv(fid, eng.phase_raw(fid, rid, dv, P, mode))
+        t0 = time.perf_counter()
         eng.drop_derived()
-        return with_cnv(fid, eng.phase_raw(fid, rid, dv, P, mode))
+        t1 = time.perf_counter()
+        r = eng.phase_raw(fid, rid, dv, P, mode)
+        t2 = time.perf_counter()
+        r = with_cnv(fid, r)
+        rtrace.append([round((b - a) * 1e3, 2) for a, b in ((t0, t1), (t1, t2), (t2, time.perf_counter()))])
+        return r
 
     res_r, el_r, prof_r, qc_records = timed(step_resident)
+    if rtrace:
+        print("[resident step, ms] drop_derived | read stage | allele balance:", rtrace, file=sys.stderr)
     per_rank_r = list(timed.per_rank)
 
     # ---------------------------------------------------------------- staged pass

@@ -819,13 +819,19 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         // what the batch really needed: the next batch's assumption -- and the verdict on this one's
         const Sizes real = exact_sizes(bh_own);
-        auto room = [](int32_t v) { return (int32_t)std::min<long long>((long long)v + v / 4 + 16, 0x3FFFFFFF); };
+        // (head room costs scratch, and a scratch that outgrows its budget halves the grid: an eighth on the linear sizes, none on the
+        // pair table -- its capacity is a power of two already)
+        auto room = [](int32_t v) { return (int32_t)std::min<long long>((long long)v + v / 8 + 8, 0x3FFFFFFF); };
         st->spec_caps.A = room(real.caps.A); st->spec_caps.T = room(real.caps.T); st->spec_caps.H = room(real.caps.H); st->spec_caps.C = room(real.caps.C);
         st->spec_caps.I = 4 * st->spec_caps.A;
-        st->spec_caps.M = next_pow2(std::min<long long>(2LL * real.caps.M, 1 << 20));
+        st->spec_caps.M = real.caps.M;
         st->spec_arena = real.arena;
         st->spec_sumP_per_dnm = 1.25 * (double)real.sumP / (double)n;
         st->spec_valid = true;
+        static const bool spec_log = getenv("UZ_PHASE_SPEC_LOG") != nullptr; // development aid
+        if (spec_log)
+            fprintf(stderr, "[uz_launch_phase] n %d speculative %d caps A %d T %d H %d C %d M %d arena %d grid %d per_wg %zu pool %zu | real A %d T %d H %d C %d M %d arena %d\n", n,
+                    (int)speculative, caps.A, caps.T, caps.H, caps.C, caps.M, arena_used, grid, per_wg, pool_cap, real.caps.A, real.caps.T, real.caps.H, real.caps.C, real.caps.M, real.arena);
         if (!speculative) break;
         const bool fits = real.caps.A <= caps.A && real.caps.T <= caps.T && real.caps.H <= caps.H && real.caps.C <= caps.C && real.caps.M <= caps.M;
         st->spec_runs++;

@@ -30,6 +30,9 @@ grch38_par1 = {"x": [60001, 2699520], "y": [10001, 2649520]}
 grch38_par2 = {"x": [154931044, 155260560], "y": [59034050, 59363566]}
 
 
+_CHR = [chr(v) for v in range(256)]
+
+
 def get_prefix(sites: SitesTable) -> str:
     """reference utils.py:46-52 -- decided by the first record of the sites FILE: a table decoded through the tabix index for a
     batch's windows carries the file-level answer (`file_prefix`, from the index's first sequence name) instead of guessing it
@@ -247,18 +250,23 @@ class PhasingHost:
 
     def _site_dicts(self, idx, flags, dad, mom, with_kid_allele):
         s = self.sites
+        if len(idx) == 0:
+            return []
+        # columns of the few sites as Python values in one go (tolist), then one dict display per site
+        pos = s.pos[idx].tolist()
+        ref = [_CHR[v] for v in s.ref_base[idx].tolist()]
+        alt = [_CHR[v] for v in s.alt_base[idx].tolist()]
+        if flags is None:
+            return [{"pos": p, "ref_allele": r, "alt_allele": a} for p, r, a in zip(pos, ref, alt)]
         out = []
-        for k, j in enumerate(idx):
-            j = int(j)
-            d = {"pos": int(s.pos[j]), "ref_allele": chr(s.ref_base[j]), "alt_allele": chr(s.alt_base[j])}
-            if flags is not None:
-                fl = int(flags[k])
-                if with_kid_allele:
-                    d["kid_allele"] = ("ref_parent", "alt_parent")[((fl >> abi.CF_KA_SHIFT) & 3) - 1]
-                if fl & abi.CF_ALT_DAD:
-                    d["alt_parent"], d["ref_parent"] = dad, mom
-                else:
-                    d["alt_parent"], d["ref_parent"] = mom, dad
+        for p, r, a, fl in zip(pos, ref, alt, flags.tolist()):
+            d = {"pos": p, "ref_allele": r, "alt_allele": a}
+            if with_kid_allele:
+                d["kid_allele"] = ("ref_parent", "alt_parent")[((fl >> abi.CF_KA_SHIFT) & 3) - 1]
+            if fl & abi.CF_ALT_DAD:
+                d["alt_parent"], d["ref_parent"] = dad, mom
+            else:
+                d["alt_parent"], d["ref_parent"] = mom, dad
             out.append(d)
         return out
 
@@ -337,6 +345,38 @@ class PhasingHost:
             alts.extend(self.sites.alt_strs[int(j)])
         return ref, alts
 
+    def batch_refalt(self, dnms, idxs):
+        """get_refalt for many DNMs at once: the look-ups (two binary searches per DNM in the reference's per-DNM VCF query) as
+        vectorised searches per contig; the strings only for the one or two records each DNM really overlaps.  -> {i: (ref, alts)}"""
+        s = self.sites
+        out = {}
+        by_contig = {}
+        for i in idxs:
+            name = self.prefix + dnms[i]["chrom"].strip("chr")
+            c = s.contig_index.get(name, -1)
+            if c < 0:
+                out[i] = (None, [])
+            else:
+                by_contig.setdefault(c, []).append(i)
+        lim = np.iinfo(s.pos.dtype)
+        for c, members in by_contig.items():
+            lo, hi = int(s.contig_off[c]), int(s.contig_off[c + 1])
+            seg = s.pos[lo:hi]
+            st = np.fromiter((int(dnms[i]["start"]) for i in members), np.int64, len(members))
+            span = s._max_span(c)
+            # 1-based [pos, pos + 1]: records with start + 1 <= pos + 1 and end >= pos
+            k_lo = lo + np.searchsorted(seg, np.clip(st - span, lim.min, lim.max).astype(s.pos.dtype), side="left")
+            k_hi = lo + np.searchsorted(seg, np.clip(st, lim.min, lim.max).astype(s.pos.dtype), side="right")
+            for i, a, b, p in zip(members, k_lo.tolist(), k_hi.tolist(), st.tolist()):
+                ref, alts = None, []
+                for j in range(a, b):
+                    if s.end[j] >= p:
+                        if ref is None:
+                            ref = s.ref_str[j]
+                        alts.extend(s.alt_strs[j])
+                out[i] = (ref, alts)
+        return out
+
     def kid_cutoff(self, kid: str, bam: str, readlen: int, stdevs: int, insert_size_max_sample: int) -> float:
         if kid not in self.cutoffs or not self.cutoffs[kid]:  # snv_phaser.py:133-135, read_collector.py:377
             rt = self.reads_header(bam)
@@ -394,6 +434,7 @@ class PhasingHost:
         batch: Dict[tuple, List[int]] = {}
         prep: Dict[int, dict] = {}
         sample_set = set(self.sites.samples)
+        refalt = {} if sv else self.batch_refalt(dnms, [i for i in info["order"] if found.get(i) is not None and len(found[i]["cand_idx"])])
         for i in info["order"]:
             dn = dnms[i]
             dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
@@ -412,7 +453,7 @@ class PhasingHost:
             if sv:
                 ref, alts = "", [""]
             else:
-                ref, alts = self.get_refalt(dn["chrom"], dn["start"])  # :111-116
+                ref, alts = refalt[i] if i in refalt else self.get_refalt(dn["chrom"], dn["start"])  # :111-116
                 if len(alts) < 1:
                     plan.append((i, "nogt"))
                     continue

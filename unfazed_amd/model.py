@@ -230,12 +230,26 @@ class SitesTable:
             return np.zeros(0, dtype=np.int64)
         c = self.contig_index[chrom]
         lo, hi = int(self.contig_off[c]), int(self.contig_off[c + 1])
-        # record covers 1-based [start+1, end]; overlap: start+1 <= end1 and end >= beg1
-        k_hi = lo + int(np.searchsorted(self.pos[lo:hi], end1 - 1, side="right"))
-        idx = np.arange(lo, k_hi, dtype=np.int64)
+        # record covers 1-based [start+1, end]; overlap: start+1 <= end1 and end >= beg1.  A record that reaches beg1 starts within
+        # the longest record of the contig before it: the scan is a few records, not the contig up to the position
+        span = self._max_span(c)
+        # (keys in the column's own type: a Python int would make numpy convert the whole column for every look-up)
+        key = self.pos.dtype.type
+        lim = np.iinfo(self.pos.dtype)
+        k_lo = lo + int(np.searchsorted(self.pos[lo:hi], key(min(max(beg1 - span, lim.min), lim.max)), side="left"))
+        k_hi = lo + int(np.searchsorted(self.pos[lo:hi], key(min(max(end1 - 1, lim.min), lim.max)), side="right"))
+        idx = np.arange(k_lo, k_hi, dtype=np.int64)
         if idx.size == 0:
             return idx
-        return idx[self.end[lo:k_hi] >= beg1]
+        return idx[self.end[k_lo:k_hi] >= beg1]
+
+    def _max_span(self, c: int) -> int:
+        """longest record (end - start) of contig c, cached"""
+        cache = self.__dict__.setdefault("_span_cache", {})
+        if c not in cache:
+            lo, hi = int(self.contig_off[c]), int(self.contig_off[c + 1])
+            cache[c] = int((np.asarray(self.end[lo:hi], np.int64) - np.asarray(self.pos[lo:hi], np.int64)).max()) if hi > lo else 1
+        return cache[c]
 
 
 class ReadsTable:
