@@ -143,3 +143,65 @@ def test_chunk_plan_of_the_eight_gpu_strong_split():
     assert min(y - x for x, y in zip(one[:-1], one[1:-1])) >= 10000
     assert shard.chunk_plan(0) == [0, 0] and shard.chunk_plan(1) == [0, 1] and shard.chunk_plan(3, 8)[-1] == 3
     assert shard.chunk_plan(100000, 16)[-1] == 100000 and len(shard.chunk_plan(100000, 16)) == 17
+
+
+# ---- the product's own multi-GPU entry: `python -m unfazed_amd --gpus N` / torchrun -> unfazed() reads RANK / WORLD_SIZE, phases
+# its shard, rank 0 writes the merged output.  Here: two gloo ranks drive unfazed() through the oracle backend (the test sets it; the
+# product never does) on the files of the CLI golden, and the text rank 0 writes must be the single-process text.
+def _cli_worker(rank, world, port, argv, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import contextlib
+    import io
+    from oracle_backend import OracleBackend
+    from unfazed_amd import session
+    from unfazed_amd.__main__ import setup_args
+    from unfazed_amd.unfazed import unfazed
+    session.set_backend(OracleBackend())
+    args = setup_args().parse_args(argv + ["--outfile", out_path if rank == 0 else os.devnull])
+    with contextlib.redirect_stderr(io.StringIO()):
+        unfazed(args)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cli_sharded_over_ranks_writes_the_single_process_output(tmp_path, world):
+    import contextlib
+    import io
+    from filesio import dump_dataset
+    from oracle_backend import OracleBackend
+    from synth.small import SmallConfig, make_small
+    from unfazed_amd import session
+    from unfazed_amd.__main__ import setup_args
+    from unfazed_amd.unfazed import unfazed
+    ds = make_small(SmallConfig(seed=515, n_dnms=14, kids=["kidA", "kidB"], cluster_prob=0.5))
+    paths = dump_dataset(ds, str(tmp_path))
+    for out_type, dnm in (("bed", "dnm_bed"), ("vcf", "dnm_vcf")):
+        argv = ["-d", paths[dnm], "-s", paths["sites"], "-p", paths["ped"], "--build", "38", "-t", "1", "-q", "-o", out_type, "--verbose",
+                "--include-ambiguous", "--bam-pairs"] + ["%s:%s" % (k, v) for k, v in paths["bams"].items()]
+        one = os.path.join(str(tmp_path), "one." + out_type)
+        session.set_backend(OracleBackend())
+        session._READS.clear(); session._HOSTS.clear()
+        try:
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                os.environ.pop(k, None)
+            with contextlib.redirect_stderr(io.StringIO()):
+                unfazed(setup_args().parse_args(argv + ["--outfile", one]))
+        finally:
+            session.set_backend(None)
+        many = os.path.join(str(tmp_path), "many%d.%s" % (world, out_type))
+        mp.spawn(_cli_worker, args=(world, 29741 + world + (10 if out_type == "vcf" else 0), argv + ["--gpus", str(world)], many), nprocs=world, join=True)
+        a, b = open(one).read(), open(many).read()
+        assert len(a.splitlines()) > 3
+        if out_type == "bed":  # verbose read-name lists come out of sets: order-free comparison of those two columns (quirk Q19)
+            def norm(t):
+                rows = []
+                for line in t.splitlines():
+                    f = line.split("\t")
+                    if len(f) > 12:
+                        f[10], f[12] = ",".join(sorted(f[10].split(","))), ",".join(sorted(f[12].split(",")))
+                    rows.append(f)
+                return rows
+            assert norm(a) == norm(b)
+        else:
+            assert a == b

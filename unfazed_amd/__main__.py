@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import argparse
+import os
 import sys
 
 from . import __reference_version__, __version__
@@ -67,6 +68,9 @@ def setup_args():
                    help="margin of error for the location of split read clipping in bases")
     p.add_argument("--max-reads", type=int, default=100,
                    help="maximum number of reads to collect for phasing a single variant")
+    p.add_argument("--gpus", type=int, default=1,
+                   help="(unfazed_amd) GPUs of this node to phase on: the DNM list is cut into contiguous shards, one process per GPU, no collective "
+                        "on the data path; rank 0 writes the output.  Under torchrun the launcher's WORLD_SIZE decides")
     p.add_argument("--sv-allele-balance-only", action="store_true", default=False,
                    help="(unfazed_amd) phase DEL/DUP by allele balance only; read-backed SV evidence is not built yet")
     return p
@@ -80,7 +84,37 @@ def main():
     if args.bam_dir is None and args.bam_pairs is None:
         print("\nMissing required argument: --bam-dir or --bam-pairs must be set\n", file=sys.stderr)
         sys.exit(parser.print_help())
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # before anything touches a GPU: the ranks are children of this process
     unfazed(args)
+
+
+def spawn_ranks(n: int) -> int:
+    """`python -m unfazed_amd --gpus N` without a launcher: the N ranks as child processes (same command line, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment); rank 0 writes the output.  All are ended when one fails."""
+    import socket
+    import subprocess
+    import time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-m", "unfazed_amd"] + sys.argv[1:], env=env))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.1)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0:
+                rc = max(rc, abs(r))
+                for q in live:
+                    q.terminate()
+    return rc
 
 
 if __name__ == "__main__":

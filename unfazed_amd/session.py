@@ -37,11 +37,20 @@ def set_backend(backend) -> None:
     _HOSTS.clear()
 
 
+_DEVICE = 0
+
+
+def set_device(device: int) -> None:
+    """the GPU the lazily created default backend lives on (one process per GPU: its LOCAL_RANK)"""
+    global _DEVICE
+    _DEVICE = int(device)
+
+
 def get_backend():
     global _BACKEND
     if _BACKEND is None:
         from .engine import HipEngine  # raises without libunfazed_hip.so / a gfx950 device
-        _BACKEND = HipEngine(0)
+        _BACKEND = HipEngine(_DEVICE)
     return _BACKEND
 
 

@@ -33,11 +33,17 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, mi
 
 
 def shard_dnms(dnms: List[dict], rank: int, world: int) -> List[dict]:
-    """Sort by (chrom, start, end, kid) -- neighbours share site windows and read blocks -- and
-    take this rank's contiguous slice."""
-    order = sorted(range(len(dnms)), key=lambda i: (str(dnms[i]["chrom"]), int(dnms[i]["start"]),
-                                                    int(dnms[i]["end"]), str(dnms[i]["kid"])))
+    """Sort by (chrom, start, end) -- neighbours share site windows and read blocks; ties keep the input order, as the single
+    process meets them -- and take this rank's contiguous slice."""
+    order = sorted(range(len(dnms)), key=lambda i: (str(dnms[i]["chrom"]), int(dnms[i]["start"]), int(dnms[i]["end"]), i))
     b = shard_bounds(len(order), world)
+    # DNMs that share a chromosome and a start stay in one shard: the many-variant path counts them together (find_many's
+    # per-position lists, informative_site_finder.py:385-395)
+    same = lambda x, y: (str(dnms[x]["chrom"]), int(dnms[x]["start"])) == (str(dnms[y]["chrom"]), int(dnms[y]["start"]))  # noqa: E731
+    for r in range(1, world):
+        while 0 < b[r] < len(order) and same(order[b[r] - 1], order[b[r]]):
+            b[r] += 1
+        b[r] = max(b[r], b[r - 1])
     return [dnms[i] for i in order[b[rank]: b[rank + 1]]]
 
 

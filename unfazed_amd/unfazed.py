@@ -276,6 +276,22 @@ def _route_variants(variants, bam_names, cram_ref):
     return snvs, svs, kids
 
 
+def _ranks(args):
+    """(rank, world, torch.distributed or None): more than one rank when a launcher (torchrun, or `--gpus N` which starts the ranks
+    itself, __main__.spawn_ranks) put RANK / WORLD_SIZE into the environment.  The only communication is the gather of the per-shard
+    records (host objects) on rank 0: gloo, whatever the ranks compute on."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, None
+    import datetime
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(hours=12))
+    return rank, world, dist
+
+
 def unfazed(args):
     """reference unfazed.py:518-667: read the DNMs, find each kid's alignment file and pedigree entry, phase
     SVs and point variants through the two phasers, write BED or annotated VCF."""
@@ -304,11 +320,35 @@ def unfazed(args):
     # SVs first, as the reference does (:601-646): the order of the per-variant messages on stderr is part of
     # the surface; on a key collision the SV record wins (its final merge, :648-649)
     sv_records, snv_records = {}, {}
-    if svs:
-        sv_records = phase_svs(svs, kids, pedigrees, args.sites, *thresholds, evidence_min_ratio=args.evidence_min_ratio,
-                               allele_balance_only=getattr(args, "sv_allele_balance_only", False))
-    if snvs:
-        snv_records = phase_snvs(snvs, kids, pedigrees, args.sites, *thresholds, evidence_min_ratio=args.evidence_min_ratio)
+    rank, world, dist = _ranks(args)
+    if world > 1:
+        # one process per GPU, contiguous DNM shards, no collective on the data path: the reference's task pool
+        # over DNMs (snv_phaser.py:244-298) as shards; the records are gathered on rank 0, which writes the output.  A batch that
+        # takes the many-variant path as a whole (--multiread-proc-min) takes it in every shard.
+        from . import session, shard
+        session.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        mpm = args.multiread_proc_min
+
+        def shard_thresholds(batch):
+            return (args.threads, args.build, args.no_extended, 0 if len(batch) >= mpm else 1 << 60) + thresholds[4:]
+        if svs:
+            sv_records = shard.phase_sharded(phase_svs, svs, kids, pedigrees, args.sites, *shard_thresholds(svs), rank=rank, world=world, dist=dist,
+                                             evidence_min_ratio=args.evidence_min_ratio,
+                                             allele_balance_only=getattr(args, "sv_allele_balance_only", False))
+        if snvs:
+            snv_records = shard.phase_sharded(phase_snvs, snvs, kids, pedigrees, args.sites, *shard_thresholds(snvs), rank=rank, world=world, dist=dist,
+                                              evidence_min_ratio=args.evidence_min_ratio)
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+        sv_records, snv_records = sv_records or {}, snv_records or {}
+    else:
+        if svs:
+            sv_records = phase_svs(svs, kids, pedigrees, args.sites, *thresholds, evidence_min_ratio=args.evidence_min_ratio,
+                                   allele_balance_only=getattr(args, "sv_allele_balance_only", False))
+        if snvs:
+            snv_records = phase_snvs(snvs, kids, pedigrees, args.sites, *thresholds, evidence_min_ratio=args.evidence_min_ratio)
     records = dict(snv_records)
     records.update(sv_records)
     if output_type == "vcf":
