@@ -116,6 +116,14 @@ typedef struct uz_family_view {
     const uint16_t *ref_depth[3]; /* [S] each; UZ_U16_MISSING = -1 */
     const uint16_t *alt_depth[3];
     const uint16_t *gq[3];        /* floor(GQ); UZ_U16_MISSING = -1 */
+    /* Sites with an allele depth the 16-bit columns cannot hold (> 32767: the reference takes any depth,
+     * informative_site_finder.py:46-73): listed apart with their depths in 32 bits, all three members, -1 = missing.  The 16-bit
+     * columns may hold anything there; the class of such a site is computed from these (same rule, the same f64 division).
+     * HOST pointers, also for uz_family_adopt_device; n_wide = 0 / NULL: none.  wide_site ascending. */
+    int64_t n_wide;
+    const int64_t *wide_site;        /* [n_wide] site index */
+    const int32_t *wide_ref_depth[3]; /* [n_wide] each; values up to 2^30 */
+    const int32_t *wide_alt_depth[3];
 } uz_family_view;
 
 /* alignment records of one BAM in file (coordinate) order */

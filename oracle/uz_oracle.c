@@ -114,15 +114,27 @@ uint8_t uzo_classify_one(const uz_params *P, uint8_t sflags, uint8_t gtp, const 
     return c;
 }
 
+/* depths and GQ of site i: from the 16-bit columns, or -- a site listed as too deep for them (uz_family_view.wide_*) -- the
+ * 32-bit depths of the list */
+static void fam_values(const uz_family_view *F, int64_t i, int rd[3], int ad[3], int gq[3]) {
+    for (int m = 0; m < 3; m++) {
+        rd[m] = dec16(F->ref_depth[m][i]);
+        ad[m] = dec16(F->alt_depth[m][i]);
+        gq[m] = dec16(F->gq[m][i]);
+    }
+    if (F->n_wide > 0) {
+        int64_t lo = 0, hi = F->n_wide;
+        while (lo < hi) { int64_t mid = lo + ((hi - lo) >> 1); if (F->wide_site[mid] < i) lo = mid + 1; else hi = mid; }
+        if (lo < F->n_wide && F->wide_site[lo] == i)
+            for (int m = 0; m < 3; m++) { rd[m] = F->wide_ref_depth[m][lo]; ad[m] = F->wide_alt_depth[m][lo]; }
+    }
+}
+
 void uzo_classify(const uz_params *P, const uz_sites_view *S, const uz_family_view *F, int64_t lo, int64_t hi,
                   uint8_t *cls) {
     for (int64_t i = lo; i < hi; i++) {
         int rd[3], ad[3], gq[3];
-        for (int m = 0; m < 3; m++) {
-            rd[m] = dec16(F->ref_depth[m][i]);
-            ad[m] = dec16(F->alt_depth[m][i]);
-            gq[m] = dec16(F->gq[m][i]);
-        }
+        fam_values(F, i, rd, ad, gq);
         cls[i] = uzo_classify_one(P, S->sflags[i], F->gt[i], rd, ad, gq);
     }
 }
@@ -176,11 +188,7 @@ int uzo_find(const uz_params *P, const uz_sites_view *S, const uz_family_view *F
                     uint8_t cl;
                     {
                         int rd[3], ad[3], gq[3];
-                        for (int m = 0; m < 3; m++) {
-                            rd[m] = dec16(F->ref_depth[m][s]);
-                            ad[m] = dec16(F->alt_depth[m][s]);
-                            gq[m] = dec16(F->gq[m][s]);
-                        }
+                        fam_values(F, s, rd, ad, gq);
                         cl = uzo_classify_one(P, S->sflags[s], F->gt[s], rd, ad, gq);
                     }
                     if (!cl) continue;

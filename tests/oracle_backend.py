@@ -11,8 +11,8 @@ class OracleBackend:
     def upload_sites(self, sites):
         return abi.sites_view(sites)
 
-    def add_family(self, sites_h, gt, rd, ad, gq):
-        return (sites_h, abi.family_view(gt, rd, ad, gq))
+    def add_family(self, sites_h, gt, rd, ad, gq, wide=None):
+        return (sites_h, abi.family_view(gt, rd, ad, gq, wide))
 
     def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False):
         return abi.reads_view(reads)

@@ -49,3 +49,13 @@ def test_wide_phase_svs_golden_gpu(engine, name):
 
 def test_autophase_golden_gpu(engine):
     check_autophase(engine)
+
+
+from test_oracle_golden import check_find_grid  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["find_grid.json", "find_grid_deep.json"])
+def test_find_grid_golden_gpu(engine, name):
+    """the reference's find() over the genotype x depth grids -- the deep one holds allele depths of 32768, 70000, 10^6 ... that the
+    16-bit device columns cannot hold: their classes come from the family's side table (k_site_scan_wide)"""
+    check_find_grid(engine, name)

@@ -48,12 +48,14 @@ def test_phase_snvs_golden(path):
     check_against_golden(OracleBackend(), g, ds)
 
 
-def test_find_grid_golden():
-    g = json.load(open(os.path.join(GOLD, "find_grid.json")))
+def check_find_grid(backend, name):
+    """find_grid_deep: every record holds an allele depth beyond 16 bits (32768, 70000, 10^6 ...) in at least one member -- the
+    reference takes any depth (informative_site_finder.py:46-73); such sites travel on the side table of the family view"""
+    g = json.load(open(os.path.join(GOLD, name)))
     recs = [SiteRecord("1", s["start"], s["ref"], s["alts"], s["gt"], s["rd"], s["ad"], s["gq"]) for s in g["sites"]]
     sites = SitesTable.from_records(recs, g["samples"])
     ped = {"kid": {"kid": "kid", "dad": "dad", "mom": "mom", "sex": "2"}}
-    host = PhasingHost(OracleBackend(), sites, {})
+    host = PhasingHost(backend, sites, {})
     n_c = 0
     for c in g["cases"]:
         ps = c["params"]
@@ -66,6 +68,13 @@ def test_find_grid_golden():
         assert dn[0]["het_sites"] == c["het_sites"]
         n_c += len(c["candidate_sites"])
     assert n_c > 150
+    if "deep" in name:
+        assert sites.wide_depths is not None and len(sites.wide_depths[0]) >= 600
+
+
+@pytest.mark.parametrize("name", ["find_grid.json", "find_grid_deep.json"])
+def test_find_grid_golden(name):
+    check_find_grid(OracleBackend(), name)
 
 
 def test_binary_search_golden():

@@ -95,6 +95,10 @@ class FamilyView(C.Structure):
         ("ref_depth", _p * 3),
         ("alt_depth", _p * 3),
         ("gq", _p * 3),
+        ("n_wide", C.c_int64),
+        ("wide_site", _p),
+        ("wide_ref_depth", _p * 3),
+        ("wide_alt_depth", _p * 3),
     ]
 
 
@@ -363,8 +367,9 @@ def sites_view(t: SitesTable) -> Held:
     return Held(v, arrs)
 
 
-def family_view(gt: np.ndarray, rd: np.ndarray, ad: np.ndarray, gq: np.ndarray) -> Held:
-    """gt u8[S]; rd/ad/gq u16[3][S] in kid, dad, mom order."""
+def family_view(gt: np.ndarray, rd: np.ndarray, ad: np.ndarray, gq: np.ndarray, wide=None) -> Held:
+    """gt u8[S]; rd/ad/gq u16[3][S] in kid, dad, mom order.  wide = (site int64[W], ref_depth int32[3][W], alt_depth int32[3][W]): the
+    sites whose depths do not fit the 16-bit columns (model.SitesTable.family_columns lists them), or None."""
     gt = _c(gt, np.uint8)
     rd = [_c(rd[m], np.uint16) for m in range(3)]
     ad = [_c(ad[m], np.uint16) for m in range(3)]
@@ -375,7 +380,16 @@ def family_view(gt: np.ndarray, rd: np.ndarray, ad: np.ndarray, gq: np.ndarray) 
         v.ref_depth[m] = _ptr(rd[m])
         v.alt_depth[m] = _ptr(ad[m])
         v.gq[m] = _ptr(gq[m])
-    return Held(v, dict(gt=gt, rd=rd, ad=ad, gq=gq))
+    keep = dict(gt=gt, rd=rd, ad=ad, gq=gq)
+    if wide is not None and len(wide[0]):
+        ws = _c(wide[0], np.int64)
+        wr = [_c(wide[1][m], np.int32) for m in range(3)]
+        wa = [_c(wide[2][m], np.int32) for m in range(3)]
+        v.n_wide, v.wide_site = int(ws.size), _ptr(ws)
+        for m in range(3):
+            v.wide_ref_depth[m], v.wide_alt_depth[m] = _ptr(wr[m]), _ptr(wa[m])
+        keep.update(wide_site=ws, wide_rd=wr, wide_ad=wa)
+    return Held(v, keep)
 
 
 def reads_view(t: ReadsTable) -> Held:

@@ -154,6 +154,7 @@ void free_family(uz_ctx *c, FamilyDev &f) {
     if (f.ready) { (void)hipEventSynchronize(f.ready); (void)hipEventDestroy(f.ready); f.ready = nullptr; }
     f.pending = false;
     uz_block_put(c, f.block);
+    uz_block_put(c, f.wide_block);
     f = FamilyDev();
 }
 void free_sites(uz_ctx *c, SitesDev &s) {
@@ -405,6 +406,37 @@ int uz_sites_adopt_device(uz_ctx *c, const uz_sites_view *v, int *id) {
     });
 }
 
+// the too-deep sites of a family view (host pointers) -> the family's side table on the device
+static void family_wide(uz_ctx *c, hipStream_t st, const uz_family_view *v, FamilyDev &f, int64_t n_sites) {
+    f.n_wide = 0;
+    if (!v || v->n_wide <= 0) return;
+    UZ_REQUIRE(v->wide_site != nullptr, UZ_E_ARG, "n_wide set but wide_site is null");
+    const size_t w = (size_t)v->n_wide;
+    std::vector<int32_t> dep(6 * w);
+    for (int m = 0; m < 3; m++) {
+        UZ_REQUIRE(v->wide_ref_depth[m] && v->wide_alt_depth[m], UZ_E_ARG, "null wide depth column");
+        for (size_t k = 0; k < w; k++) {
+            const int32_t r = v->wide_ref_depth[m][k], a = v->wide_alt_depth[m][k];
+            UZ_REQUIRE(r >= -1 && a >= -1 && r <= (1 << 30) && a <= (1 << 30), UZ_E_RANGE, "wide depth outside [-1, 2^30]");
+            dep[(size_t)m * w + k] = r; dep[(size_t)(3 + m) * w + k] = a;
+        }
+    }
+    for (size_t k = 0; k < w; k++) {
+        UZ_REQUIRE(v->wide_site[k] >= 0 && v->wide_site[k] < n_sites && (k == 0 || v->wide_site[k] > v->wide_site[k - 1]), UZ_E_ARG,
+                   "wide_site must be ascending site indices of the table");
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        Carver cv(pass ? f.wide_block.p : nullptr);
+        f.wide_site = cv.take<int64_t>(w);
+        f.wide_depth = cv.take<int32_t>(6 * w);
+        if (!pass) f.wide_block = uz_block_get(c, cv.off + 256);
+    }
+    UZ_HIP(hipMemcpyAsync(f.wide_site, v->wide_site, w * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    UZ_HIP(hipMemcpyAsync(f.wide_depth, dep.data(), 6 * w * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    UZ_HIP(hipStreamSynchronize(st)); // `dep` is a local (a handful of sites)
+    f.n_wide = (int64_t)w;
+}
+
 static void family_common(uz_ctx *c, int sites_id, FamilyDev &f) {
     SitesDev &s = sites_of(c, sites_id);
     f.live = true;
@@ -432,8 +464,9 @@ int uz_family_upload(uz_ctx *c, int sites_id, const uz_family_view *v, int *id) 
             for (int m = 0; m < 3; m++) {
                 h2d(c->stream, f.rd[m], v->ref_depth[m], n); h2d(c->stream, f.ad[m], v->alt_depth[m], n); h2d(c->stream, f.gq[m], v->gq[m], n);
             }
+            family_wide(c, c->stream, v, f, s.n);
             family_common(c, sites_id, f);
-        } catch (...) { uz_block_put(c, f.block); throw; }
+        } catch (...) { uz_block_put(c, f.block); uz_block_put(c, f.wide_block); throw; }
         const int k = new_slot(c->fams);
         c->fams[k] = f;
         *id = k;
@@ -480,12 +513,13 @@ int uz_sites_family_upload_async(uz_ctx *c, const uz_sites_view *v, const uz_fam
                     f.gq[m] = const_cast<uint16_t *>(h2d(st, f.gq[m], fv->gq[m], n));
                 }
             }
+            family_wide(c, st, fv, f, s.n);
             UZ_HIP(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming));
             UZ_HIP(hipEventRecord(f.ready, st));
             UZ_HIP(hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
             UZ_HIP(hipEventRecord(s.ready, st));
             s.pending = true;
-        } catch (...) { uz_block_put(c, s.block); uz_block_put(c, s.mirror); uz_block_put(c, f.block); throw; }
+        } catch (...) { uz_block_put(c, s.block); uz_block_put(c, s.mirror); uz_block_put(c, f.block); uz_block_put(c, f.wide_block); throw; }
         const int ks = new_slot(c->sites);
         c->sites[ks] = s;
         f.live = true; f.sites_id = ks; f.pending = true;
@@ -517,7 +551,10 @@ int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int
                 if (!pass) f.block = uz_block_get(c, cv.off + 256);
             }
         }
-        try { family_common(c, sites_id, f); } catch (...) { uz_block_put(c, f.block); throw; }
+        try {
+            family_wide(c, c->stream, v, f, sites_of(c, sites_id).n);
+            family_common(c, sites_id, f);
+        } catch (...) { uz_block_put(c, f.block); uz_block_put(c, f.wide_block); throw; }
         const int k = new_slot(c->fams);
         c->fams[k] = f;
         *id = k;

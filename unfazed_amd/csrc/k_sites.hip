@@ -106,19 +106,29 @@ __device__ __forceinline__ bool hq(const SiteParams &P, const int2 *__restrict__
     return ok;
 }
 
+// the same test on depths of any size, evaluated directly (the sites the 16-bit columns cannot hold: uz_family_view.wide_*): the
+// reference's own order -- genotype, GQ, depth, then the f64 quotient against the interval (:62-71)
+__device__ __forceinline__ bool hq_wide(const SiteParams &P, int gt, int rd, int ad, int gq) {
+    if (gt == UZ_GT_UNKNOWN) return false;
+    const long long t = (long long)rd + (long long)ad;
+    if (gq < P.min_gt_qual || t < (long long)P.min_depth) return false;
+    const double ab = (double)ad / (double)t; // 0 / 0 -> NaN (fails both comparisons), x / 0 -> +-inf: what numpy gives the reference
+    return ab_lo(P, gt) <= ab && ab <= ab_hi(P, gt);
+}
+
 // parental pattern (:307-320) as a 16 x 2-bit table indexed by dad | mom << 2: 1 = alt_parent is dad, 2 = mom
 #define UZ_PATTERN_TABLE ((1u << 2) | (1u << 6) | (2u << 8) | (2u << 24) | (1u << 14) | (2u << 26))
 
 // CNV = false: SNV / breakpoint mode only (class bits HET, CAND, ALT_DAD) -- what find(...,
 // whole_region=False) evaluates (:292-295); CNV = true adds the DEL / DUP codes of get_kid_allele,
 // which only find(..., whole_region=True) reaches (:286-291).
-template <bool CNV, bool T0>
+template <bool CNV, bool T0, bool WIDE = false>
 __device__ __forceinline__ uint8_t classify_site(const SiteParams &P, const int2 *__restrict__ lut, const uint32_t *lds, uint32_t g, int rdk,
                                                  int adk, int gqk, int rdd, int add, int gqd, int rdm, int adm, int gqm) {
     const int kid = g & 3, dad = (g >> 2) & 3, mom = (g >> 4) & 3;
-    const bool hqk = hq<T0>(P, lut, lds, kid, rdk, adk, gqk);
-    const bool hqd = hq<T0>(P, lut, lds, dad, rdd, add, gqd);
-    const bool hqm = hq<T0>(P, lut, lds, mom, rdm, adm, gqm);
+    const bool hqk = WIDE ? hq_wide(P, kid, rdk, adk, gqk) : hq<T0>(P, lut, lds, kid, rdk, adk, gqk);
+    const bool hqd = WIDE ? hq_wide(P, dad, rdd, add, gqd) : hq<T0>(P, lut, lds, dad, rdd, add, gqd);
+    const bool hqm = WIDE ? hq_wide(P, mom, rdm, adm, gqm) : hq<T0>(P, lut, lds, mom, rdm, adm, gqm);
     const uint32_t pcode = (UZ_PATTERN_TABLE >> (((g >> 2) & 15u) * 2)) & 3u;
     const bool pattern = pcode != 0, alt_dad = pcode == 1;
     uint32_t c = 0;
@@ -267,6 +277,21 @@ __global__ __launch_bounds__(256) void k_site_scan(FamPtrs f1, uint8_t *cls1, in
         }
     }
     } // chunk loop
+}
+
+// the sites listed as too deep for the 16-bit columns: their class bytes again, from the 32-bit depths (one lane per site; a handful)
+template <bool CNV>
+__global__ void k_site_scan_wide(FamPtrs f, uint8_t *cls, int64_t n_wide, const int64_t *__restrict__ site, const int32_t *__restrict__ dep,
+                                 SiteParams P) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_wide) return;
+    const int64_t i = site[k];
+    const uint32_t g = f.gt[i];
+    uint8_t cl = 0;
+    if (!(g & 0x40u))
+        cl = classify_site<CNV, false, true>(P, nullptr, nullptr, g, dep[k], dep[3 * n_wide + k], dec16(f.gq[0][i]), dep[n_wide + k], dep[4 * n_wide + k],
+                                             dec16(f.gq[1][i]), dep[2 * n_wide + k], dep[5 * n_wide + k], dec16(f.gq[2][i]));
+    cls[i] = cl;
 }
 
 __device__ __forceinline__ int64_t lower_bound(const int32_t *a, int64_t lo, int64_t hi, int64_t v) {
@@ -717,8 +742,17 @@ void launch_site_scan(uz_ctx *c, const FamPtrs &fp, uint8_t *cls, int64_t n, boo
 
 } // namespace
 
+static void launch_site_scan_wide(uz_ctx *c, FamilyDev &f, bool with_cnv) {
+    if (f.n_wide <= 0) return;
+    const SiteParams P = make_site_params(c->P);
+    const unsigned nb = (unsigned)((f.n_wide + 255) / 256);
+    if (with_cnv) hipLaunchKernelGGL(k_site_scan_wide<true>, dim3(nb), dim3(256), 0, c->stream, fam_ptrs(f), f.cls, f.n_wide, f.wide_site, f.wide_depth, P);
+    else hipLaunchKernelGGL(k_site_scan_wide<false>, dim3(nb), dim3(256), 0, c->stream, fam_ptrs(f), f.cls, f.n_wide, f.wide_site, f.wide_depth, P);
+    UZ_HIP(hipGetLastError());
+}
+
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv) {
-    if (s.n > 0) launch_site_scan(c, fam_ptrs(f), f.cls, s.n, with_cnv, nullptr, 1);
+    if (s.n > 0) { launch_site_scan(c, fam_ptrs(f), f.cls, s.n, with_cnv, nullptr, 1); launch_site_scan_wide(c, f, with_cnv); }
     f.cls_has_cnv = with_cnv;
     f.cls_valid = true;
     f.cls_params = c->P;
@@ -733,6 +767,7 @@ void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, cons
         UZ_HIP(hipMemcpyAsync(c->fam_batch.p, items.data(), items.size() * sizeof(FamBatchItem), hipMemcpyHostToDevice, c->stream));
         UZ_HIP(hipStreamSynchronize(c->stream)); // `items` is pageable host memory
         launch_site_scan(c, items[0].f, items[0].cls, s.n, with_cnv, (const FamBatchItem *)c->fam_batch.p, n_fam);
+        for (int k = 0; k < n_fam; k++) launch_site_scan_wide(c, *fams[k], with_cnv);
     }
     for (int k = 0; k < n_fam; k++) {
         fams[k]->cls_has_cnv = with_cnv;

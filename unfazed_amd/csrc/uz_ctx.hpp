@@ -76,6 +76,12 @@ struct FamilyDev {
     uint16_t *ad[3] = {nullptr, nullptr, nullptr};
     uint16_t *gq[3] = {nullptr, nullptr, nullptr};
     uint8_t *cls = nullptr;
+    // sites whose depths the 16-bit columns cannot hold (uz_family_view.wide_*): index + six 32-bit depths each, in a small block of
+    // their own; their class bytes are rewritten after every site scan (k_site_scan_wide)
+    int64_t n_wide = 0;
+    int64_t *wide_site = nullptr;
+    int32_t *wide_depth = nullptr; // [6][n_wide]: rd kid, dad, mom, ad kid, dad, mom
+    DevBlock wide_block;
     // asynchronous upload (uz_sites_family_upload_async): the copies are queued on the copy stream; `ready` marks their end and
     // the first use of the family makes the compute stream wait for it and folds the complex flag (family_make_ready)
     hipEvent_t ready = nullptr;

@@ -142,8 +142,8 @@ class HipEngine:
         self._ck(self.L.uz_sites_upload(self.h, held.ref(), C.byref(sid)), "uz_sites_upload")
         return sid.value
 
-    def add_family(self, sites_h: int, gt, rd, ad, gq) -> int:
-        v = abi.family_view(gt, rd, ad, gq)
+    def add_family(self, sites_h: int, gt, rd, ad, gq, wide=None) -> int:
+        v = abi.family_view(gt, rd, ad, gq, wide)
         fid = C.c_int(-1)
         self._ck(self.L.uz_family_upload(self.h, int(sites_h), v.ref(), C.byref(fid)), "uz_family_upload")
         return fid.value

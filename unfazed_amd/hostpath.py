@@ -112,7 +112,9 @@ class PhasingHost:
         key = (kid, dad, mom)
         if key not in self._fam_h:
             gt, rd, ad, gq = self.sites.family_columns(kid, dad, mom)
-            self._fam_h[key] = self.backend.add_family(self._sites_h, gt, rd, ad, gq)
+            wide = getattr(self.sites, "wide_depths", None)  # sites deeper than the 16-bit columns hold: their 32-bit depths
+            self._fam_h[key] = self.backend.add_family(self._sites_h, gt, rd, ad, gq, wide=wide) if wide is not None else \
+                self.backend.add_family(self._sites_h, gt, rd, ad, gq)
         return self._fam_h[key]
 
     def reads(self, bam: str, min_base_qual: int):

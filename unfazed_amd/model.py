@@ -195,7 +195,9 @@ class SitesTable:
         ``--min-gt-qual`` (reference __main__.py:146-151) has the same truth value
         for GQ and floor(GQ).  Missing (-1, or any negative) -> 0xFFFF.
         A depth above 32767 does not fit the 16-bit columns (read as signed halfwords on the
-        device): fail loudly.
+        device): such sites are listed apart with their 32-bit depths (`wide_depths`, what
+        abi.family_view / the engines take as `wide`) -- the reference takes any depth
+        (informative_site_finder.py:46-73).  The 16-bit columns hold 32767 there.
         """
         cols = [self.samples.index(s) for s in (kid, dad, mom)]
         gtp = (
@@ -204,13 +206,19 @@ class SitesTable:
 
         def depth16(a):
             a = a[cols]
-            if a.size and a.max() > U16_MAX_VALUE:
-                raise OverflowError("allele depth above 32767 does not fit the 16-bit device columns")
             if a.size and a.min() < -1:
                 raise ValueError("negative allele depth other than the missing marker -1")
-            out = a.astype(np.int64)
+            if a.size and a.max() > (1 << 30):
+                raise OverflowError("allele depth above 2^30")
+            out = np.minimum(a.astype(np.int64), U16_MAX_VALUE)
             out[out < 0] = U16_MISSING
             return np.ascontiguousarray(out.astype(np.uint16))
+
+        rdc, adc = self.ref_depth[cols], self.alt_depth[cols]
+        wide_sites = np.nonzero((rdc > U16_MAX_VALUE).any(axis=0) | (adc > U16_MAX_VALUE).any(axis=0))[0].astype(np.int64) if self.n_sites else np.zeros(0, np.int64)
+        self.wide_depths = None
+        if wide_sites.size:
+            self.wide_depths = (wide_sites, np.ascontiguousarray(rdc[:, wide_sites].astype(np.int32)), np.ascontiguousarray(adc[:, wide_sites].astype(np.int32)))
 
         g = np.floor(self.gq[cols])
         g = np.where(np.isnan(g), -1.0, g)
