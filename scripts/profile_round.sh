@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$ROOT/bench.py --no-staged --no-cpu --steps 3 --warmup 1"
+ARGS="$ROOT/bench.py --no-staged --no-cpu --steps 3 --warmup 1 --feed-dnms 0 --no-config5"
 # counters only for the product's kernels (the synthetic generator's launches would be serialised and counted too)
 ONLY='--kernel-include-regex k_phase|k_site_scan|k_window|k_pack_rec|k_expand_seq2|k_cnv'
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $ARGS > $OUT/stats.log 2>&1
@@ -24,3 +24,10 @@ grep "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
 # keep the merged output small: the raw traces are not needed
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
+# the staged pass (the headline `value`): kernel statistics of the command the driver runs, without the CPU legs
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/staged -o run -- python3 $ROOT/bench.py --no-cpu --feed-dnms 0 --no-config5 --steps 5 --warmup 1 > $OUT/staged.log 2>&1
+cd $ROOT
+find $OUT/staged -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/staged_kernel_stats.csv
+grep "^{" $OUT/staged.log | tail -1 > $OUT/bench_staged_under_rocprof.json
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
