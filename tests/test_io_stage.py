@@ -117,3 +117,58 @@ def test_mates_outside_the_reach_go_through_the_index(workload, slack, monkeypat
     got = io_native.BamSource(workload["bam"], threads=3).select(fc, flo, fhi, 20, extra=fex)
     assert got.io_stats["index_mate_lookups"] > 0
     assert_same(got, want)
+
+
+@pytest.mark.parametrize("seed,readlen", [(31, 151), (32, 100), (33, 301)])
+def test_odd_records_from_a_python_written_bam(tmp_path, seed, readlen):
+    """The other writer, the other kind of data: synth.small's pile-ups (duplicates, QC failures, secondary and supplementary
+    records with SA tags, mates on other contigs or unmapped, overlapping mates, many-operation CIGARs, low-quality runs, reads
+    of 100 and 301 bases) written by the Python BAM writer + write_bai, staged in one pass and through the three steps."""
+    from filesio import dump_dataset, write_bai
+    from synth.small import SmallConfig, make_small
+    ds = make_small(SmallConfig(seed=seed, n_dnms=10, odd_read_prob=0.25, lowq_prob=0.08, softclip_prob=0.05, indel_prob=0.03, readlen=readlen, cluster_prob=0.6))
+    paths = dump_dataset(ds, str(tmp_path))
+    bam = list(paths["bams"].values())[0]
+    write_bai(bam)
+    full = io_native.read_bam_table(bam, threads=2)
+    assert (np.asarray(full.flag) & 0x900).any() and (np.asarray(full.flag) & 0x8).any()  # secondary / supplementary, mate unmapped
+    rng = np.random.default_rng(seed)
+    c, lo, hi, ex = [], [], [], []
+    for d in ds.dnms:
+        tid = full.contig_index[d["chrom"]]
+        c.append(tid); lo.append(d["start"] - 1); hi.append(d["start"] + 1); ex.append(max(1, d["end"] - d["start"]))
+        for p in np.sort(rng.integers(d["start"] - 5000, d["start"] + 5000, 8)):
+            c.append(tid); lo.append(int(p)); hi.append(int(p) + 1); ex.append(0)
+    fc, flo, fhi, fex = np.array(c, np.int32), np.array(lo, np.int32), np.array(hi, np.int32), np.array(ex, np.uint16)
+    src = io_native.BamSource(bam, threads=3)
+    for kw in (dict(extra=fex), dict(extra=fex, all_bases=True), dict()):
+        want, _ = three_step(bam, fc, flo, fhi, kw.get("extra"), 20, all_bases=kw.get("all_bases", False))
+        assert_same(src.select(fc, flo, fhi, 20, **kw), want)
+    # wide (SV-style) fetches over the same file
+    wc, wlo, whi = fc[::9], (flo[::9] - 600).astype(np.int32), (fhi[::9] + 600).astype(np.int32)
+    want, _ = three_step(bam, wc, wlo, whi, np.zeros(wc.size, np.uint16), 20)
+    assert_same(src.select(wc, wlo, whi, 20, extra=np.zeros(wc.size, np.uint16)), want)
+
+
+def test_reads_longer_than_the_reach_slack(tmp_path):
+    """2.5 kb reads: a record can overlap the fetch points of two reach intervals and a mate lies beyond any slack -- the kept
+    records of neighbouring tasks interleave in the file (sorted and folded by virtual offset), mates go through the index"""
+    from filesio import dump_dataset, write_bai
+    from synth.small import SmallConfig, make_small
+    ds = make_small(SmallConfig(seed=41, n_dnms=6, odd_read_prob=0.1, readlen=2500, coverage_per_hap=4.0, ins_mean=7500, ins_sd=100))
+    paths = dump_dataset(ds, str(tmp_path))
+    bam = list(paths["bams"].values())[0]
+    write_bai(bam)
+    full = io_native.read_bam_table(bam, threads=2)
+    rng = np.random.default_rng(5)
+    c, lo, hi, ex = [], [], [], []
+    for d in ds.dnms:
+        tid = full.contig_index[d["chrom"]]
+        c.append(tid); lo.append(d["start"] - 1); hi.append(d["start"] + 1); ex.append(1)
+        for p in np.sort(rng.integers(d["start"] - 5000, d["start"] + 5000, 3)):
+            c.append(tid); lo.append(int(p)); hi.append(int(p) + 1); ex.append(0)
+    fc, flo, fhi, fex = np.array(c, np.int32), np.array(lo, np.int32), np.array(hi, np.int32), np.array(ex, np.uint16)
+    want, _ = three_step(bam, fc, flo, fhi, fex, 20)
+    got = io_native.BamSource(bam, threads=3).select(fc, flo, fhi, 20, extra=fex)
+    assert got.io_stats["index_mate_lookups"] > 0
+    assert_same(got, want)
