@@ -208,8 +208,7 @@ class HipEngine:
         -> (reads id, the staged view: `.qnames` maps the name ids of the result lists back to strings)"""
         pool = PinnedPool()
         try:
-            pool.new_slab(max(1 << 20, int(len(fc)) * 4096))
-            packed = src.select(fc, flo, fhi, int(min_base_qual), alloc=pool.alloc, all_bases=bool(all_bases), extra=fex)
+            packed = src.select(fc, flo, fhi, int(min_base_qual), pool=pool, all_bases=bool(all_bases), extra=fex)
             pool.end_slab()
             rid = self.upload_reads_packed(packed)
             self.wait_reads(rid)  # the pinned buffers go back right away

@@ -593,9 +593,11 @@ class BamSource:
         k = self.lib.uz_bamsrc_tlen_head(h, head.ctypes.data, head.size)
         self.tlen_head = head[: int(k)].copy()
 
-    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None):
+    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
-        `.io_stats` / `.timing` / `.qnames` ride on the returned object."""
+        `.io_stats` / `.timing` / `.qnames` ride on the returned object.
+        pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
+        as one copy); alloc: any other allocator of the columns."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -612,6 +614,11 @@ class BamSource:
         z = (C.c_int64 * 12)()
         self.lib.uz_stage_sizes(sh.ptr, z)
         n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um = (int(x) for x in z)
+        if pool is not None:  # the sizes are known now: one block for all the columns (each 256-byte aligned)
+            total = (n * 9 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 12 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
+                     + 40 * 256 + 4096)
+            pool.new_slab(total)
+            alloc = pool.alloc
         out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
                                     n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
                                     cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True)
