@@ -326,7 +326,9 @@ def main():
             # a fetched position; the SV batch needs the plane and whole rows (uz_types.h)
             # (the chunk's columns back to back in one pinned block: they cross the link as one copy)
             pool.new_slab(slab_hint)
-            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=not cnv, extra=None if cnv else fex)
+            # (SV batches the same way: their +-cutoff fetches stage no base unit -- collect_reads_sv reads none -- and the read stage asks
+            # for quality bits of records that pass goodread only, which the lists hold)
+            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=True, extra=fex, wide_no_units=cnv)
             slab_hint = max(64 << 20, int(pool.end_slab() * 1.3))
             if os.environ.get("UZ_BENCH_LINK_BYTES") and not chunks:  # development aid: the first chunk, column by column
                 nrec = int(part.view.n_segs)

@@ -194,7 +194,11 @@ void uz_reads_source_close(uz_psrc *src);
 /* unit_masks = 1 (ignored with all_bases): a record whose single CIGAR operation spans the read keeps only the 32-base units
  * of its rows that hold a fetched position -- position hi - 1 of a one- or two-base fetch, and extra[f] bases on (extra: NULL
  * = 0; for the fetch at a DNM the length of its longer allele) -- see uz_reads_packed_view.umask; the output then needs
- * the umask column and the list form of the qualities. */
+ * the umask column and the list form of the qualities.
+ * unit_masks = 3 (SV batches): as 1, and a fetch wider than two bases stages NO unit of the records it returns: collect_reads_sv
+ * (read_collector.py:476-596) looks at flags, CIGARs and mates only; the bases of its records are read at the het sites they overlap
+ * -- one-base fetches of the same batch -- and the only quality bits the read stage ever asks for are those of records that pass
+ * goodread (:43-46) at such sites, so the list form serves SV batches too. */
 /* tuples: 0, or 1 (build the dictionary of the small columns, uz_reads_packed_view.tup) | 2 (the output will set cigar_compact) | 4 (the
  * output will take the qualities as lists: n_low joins the combination); uz_select_n_tuples then gives the table length, or -1
  * when the selection holds more than 65536 combinations (the output keeps the plain columns) */
@@ -236,7 +240,8 @@ int uz_io_default_threads(void);      /* what `threads <= 0` means: CPUs of the 
 int uz_io_cpu_quota(void);            /* CPUs the container's cgroup grants (cpu.max), 0 = unlimited */
 #define UZ_STAGE_ALL_BASES 1  /* --no-extended batches: every kept record keeps its bases (uz_reads_select_plan: all_bases) */
 #define UZ_STAGE_UNIT_MASKS 2 /* only the 32-base units that hold a fetched position (+ extra[f] bases on) are staged */
-#define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (SV batches; no unit masks then) */
+#define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (no unit masks then) */
+#define UZ_STAGE_WIDE_NO_UNITS 8 /* with unit masks: a fetch wider than two bases stages no unit (SV batches; uz_reads_select_plan: unit_masks = 3) */
 /* fetches (tid, lo, hi[, extra]) as staging.fetch_points lists them; min_base_qual = --min-gt-qual.  UZ_IO_E_RANGE when the batch
  * holds more than 65536 combinations of the small columns (stage it through the table form then). */
 int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra,

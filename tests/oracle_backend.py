@@ -14,7 +14,7 @@ class OracleBackend:
     def add_family(self, sites_h, gt, rd, ad, gq, wide=None):
         return (sites_h, abi.family_view(gt, rd, ad, gq, wide))
 
-    def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False):
+    def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False, wide_no_units=False):
         return abi.reads_view(reads)
 
     def classify(self, fam, params):

@@ -1,6 +1,8 @@
 """Edge cases of the C ABI on the device: empty batches and tables, DNMs on contigs that the
 sites file or the BAM do not have, windows clipped at a contig start, DNMs without any read, call
 order errors.  Everything is compared with the oracle where there is something to compare."""
+import os
+
 import numpy as np
 import pytest
 
@@ -179,27 +181,75 @@ def test_both_builds_of_the_read_stage_agree(engine, monkeypatch, arena):
         assert redone1 >= 1  # (count of the last batch) nothing with candidates fits: redone in HBM scratch
 
 
-def test_sv_batches_on_a_point_only_table_match_or_fail_loudly(engine, monkeypatch):
-    """The list form of the quality plane (counts + the positions of "good" records) is argued for point-variant batches; the
-    host stages SV batches with the plane because collect_reads_sv takes its evidence under goodread(read, True).  Forced onto
-    the SV goldens anyway, the list form must either reproduce them or be refused by the kernel's guard (a bit of a record
-    without a quality row was asked for) -- never answer with a made-up bit."""
-    from test_oracle_golden import SV, check_sv_golden
+def test_sv_batches_on_a_list_form_table_reproduce_the_goldens(engine, monkeypatch):
+    """The list form of the quality plane (counts + the positions of "good" records) serves SV batches too: collect_reads_sv takes
+    its evidence under goodread(read, True) from flags, CIGARs and mates alone, and the only quality bits the read stage asks for are
+    those of records that pass goodread at het sites.  Forced onto every table of the SV goldens, it must reproduce them -- the
+    kernel's guard (a bit of a record without a quality row was asked for) would fail the call loudly otherwise."""
+    from test_oracle_golden import SV, WIDE_SV, check_sv_golden, check_wide_sv
     from unfazed_amd import session
-    from unfazed_amd.engine import HipEngine, UnfazedHipError
+    from unfazed_amd.engine import HipEngine
     real = HipEngine.upload_reads
 
-    def forced(self, reads, min_base_qual=None, point_only=False):
+    def forced(self, reads, min_base_qual=None, point_only=False, **kw):
         return real(self, reads, min_base_qual=min_base_qual, point_only=True)
 
     monkeypatch.setattr(HipEngine, "upload_reads", forced)
     for path in SV:
         session._READS.clear(); session._HOSTS.clear()  # (hosts keep their uploaded tables)
-        try:
-            check_sv_golden(engine, path)
-        except UnfazedHipError as e:
-            assert "base-quality bit" in str(e)
+        check_sv_golden(engine, path)
+    for name in WIDE_SV:
+        session._READS.clear(); session._HOSTS.clear()
+        check_wide_sv(engine, name)
     session._READS.clear(); session._HOSTS.clear()
+
+
+@pytest.mark.parametrize("route", ["stage", "table"])
+def test_sv_goldens_from_indexed_files(engine, tmp_path, monkeypatch, route):
+    """The SV goldens from FILES with a BAI next to every BAM: the batch travels in the link form of an SV batch -- qualities as lists,
+    unit masks from the one-base fetches, no unit for the +-cutoff fetches around the breakpoints -- built in one pass from the file
+    (stage) or out of the region table (table: UZ_IO_STAGE=0); the records must be the reference's."""
+    import contextlib
+    import copy
+    import io
+    import json
+    import sys
+    from filesio import dump_dataset, write_bai
+    from helpers import RUN_DEFAULTS, norm_records
+    from test_oracle_golden import GOLD, SV
+    sys.path.insert(0, GOLD)
+    from make_golden import dataset_digest
+    from synth.small_sv import SvConfig, make_small_sv
+    from unfazed_amd import session
+    from unfazed_amd.sv_phaser import phase_svs
+    if route == "table":
+        monkeypatch.setenv("UZ_IO_STAGE", "0")
+    for path in SV:
+        g = json.load(open(path))
+        ds = make_small_sv(SvConfig(**g["config"]))
+        assert dataset_digest(ds) == g["digest"]
+        d = tmp_path / (os.path.basename(path)[:-5] + "_" + route)
+        paths = dump_dataset(ds, str(d))
+        for b in paths["bams"].values():
+            write_bai(b)
+        session.set_backend(engine)
+        session._READS.clear(); session._HOSTS.clear()
+        try:
+            a = dict(RUN_DEFAULTS)
+            a.update(g["run"])
+            dn = copy.deepcopy(ds.dnms)
+            for x in dn:
+                x["bam"] = paths["bams"][x["kid"]]
+            err = io.StringIO()
+            with contextlib.redirect_stderr(err):
+                recs = phase_svs(dn, list(ds.pedigrees), ds.pedigrees, paths["sites"], a["threads"], a["build"], a["no_extended"], a["multithread_proc_min"],
+                                 a["quiet_mode"], a["ab_homref"], a["ab_homalt"], a["ab_het"], a["min_gt_qual"], a["min_depth"], a["search_dist"],
+                                 a["insert_size_max_sample"], a["stdevs"], a["min_map_qual"], a["readlen"], a["split_error_margin"])
+        finally:
+            session.set_backend(None)
+        assert list(recs.keys()) == g["record_order"]
+        assert json.loads(json.dumps(norm_records(recs))) == g["records"]
+        assert err.getvalue().splitlines() == g["stderr"]
 
 
 @pytest.mark.parametrize("shape", [dict(n_dnms=8), dict(readlen=300, ins_mean=800.0, ins_sd=60.0, coverage_per_hap=18.0, n_dnms=6),
@@ -215,7 +265,7 @@ def test_link_form_of_a_point_variant_table_matches_oracle(engine, monkeypatch, 
     from unfazed_amd.engine import HipEngine
     real = HipEngine.upload_reads
 
-    def forced(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False):
+    def forced(self, reads, min_base_qual=None, point_only=False, **kw):
         return real(self, reads, min_base_qual=min_base_qual, point_only=True)
 
     monkeypatch.setattr(HipEngine, "upload_reads", forced)

@@ -8,11 +8,11 @@ from synth.sites_np import make_clusters, make_sites, place_dnms_full
 from unfazed_amd import abi, io_native
 
 
-def three_step(bam, fc, flo, fhi, fex, mbq, all_bases=False, lists=True):
+def three_step(bam, fc, flo, fhi, fex, mbq, all_bases=False, lists=True, wide_no_units=False):
     table = io_native.read_bam_regions(bam, fc, flo, fhi, threads=2, insert_size_max_sample=0)
     v = abi.reads_view(table)
     full = io_native.pack_reads(v, mbq, lists=True, with_end=True)
-    return io_native.ReadsSource(full).select(fc, flo, fhi, all_bases=all_bases, lists=lists, extra=fex), table
+    return io_native.ReadsSource(full).select(fc, flo, fhi, all_bases=all_bases, lists=lists, extra=fex, wide_no_units=wide_no_units), table
 
 
 def assert_same(a, b):
@@ -172,3 +172,24 @@ def test_reads_longer_than_the_reach_slack(tmp_path):
     got = io_native.BamSource(bam, threads=3).select(fc, flo, fhi, 20, extra=fex)
     assert got.io_stats["index_mate_lookups"] > 0
     assert_same(got, want)
+
+
+def test_sv_batch_form_wide_fetches_stage_no_units(workload):
+    """an SV batch: +-cutoff fetches around two breakpoints (no base unit for what only they return) mixed with the one-base fetches at
+    het sites of the windows (their units, also on records a wide fetch returns too)"""
+    dn = workload["dn"]
+    rng = np.random.default_rng(8)
+    c, lo, hi, ex = [], [], [], []
+    for i in range(0, dn.n, 3):
+        for bp in (int(dn.start[i]), int(dn.start[i]) + 3000):
+            c.append(dn.contig[i]); lo.append(max(bp - 500, 0)); hi.append(bp + 500); ex.append(0)
+        for p in np.sort(rng.integers(dn.start[i] - 5000, dn.start[i] + 5000, 6)):
+            c.append(dn.contig[i]); lo.append(int(p)); hi.append(int(p) + 1); ex.append(0)
+    fc, flo, fhi, fex = np.array(c, np.int32), np.array(lo, np.int32), np.array(hi, np.int32), np.array(ex, np.uint16)
+    want, _ = three_step(workload["bam"], fc, flo, fhi, fex, 20, wide_no_units=True)
+    got = io_native.BamSource(workload["bam"], threads=3).select(fc, flo, fhi, 20, extra=fex, wide_no_units=True)
+    assert_same(got, want)
+    plain, _ = three_step(workload["bam"], fc, flo, fhi, fex, 20)
+    assert int(got.view.n_seq_units) < int(plain.view.n_seq_units) // 2  # most of the records only a wide fetch returns keep no unit
+    um = got.arrays["tup_umask"][got.arrays["tup"][: int(got.view.n_segs)]]
+    assert (um == 0).sum() > int(got.view.n_segs) // 3

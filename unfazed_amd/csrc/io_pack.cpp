@@ -387,7 +387,11 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
         // unit masks: the read stage reads the bases of a record at the fetched position (and `extra` bases on: the alleles of a
         // DNM) only -- position hi - 1 of a one- or two-base fetch.  For a record whose single CIGAR operation spans the read the
         // query index is position - start; every other record (and every record of a wider fetch: SV breakpoints) keeps all units.
-        const bool masks = unit_masks && !all_bases;
+        const bool masks = (unit_masks & 1) && !all_bases;
+        // unit_masks & 2: a fetch wider than two bases (the +-cutoff fetches around an SV's breakpoints) stages NO unit of the records
+        // it returns -- collect_reads_sv looks at flags, CIGARs and mates only (read_collector.py:476-596); the bases of such a record
+        // are read at the het sites it overlaps, which have one-base fetches of their own
+        const bool wide_none = (unit_masks & 2) != 0;
         std::vector<uint16_t> um;
         if (masks) um.assign((size_t)n + 1, 0);
         uint16_t *ump = um.data();
@@ -419,7 +423,8 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                             const uint32_t op = cw & 15u;
                             const bool simple = full->n_cigar[i] == 1 && (op == 0 || op == 7 || op == 8) && (int)(cw >> 4) == ls && ls > 1 &&
                                                 full->end[i] - full->start[i] == ls;
-                            if (simple && ls <= 480 && hi[f] - lo[f] <= 2) {
+                            if (hi[f] - lo[f] > 2 && wide_none) bits = 0;
+                            else if (simple && ls <= 480 && hi[f] - lo[f] <= 2) {
                                 const int64_t q0 = (int64_t)hi[f] - 1 - full->start[i];
                                 bits = 0;
                                 if (q0 >= 0 && q0 < ls) {

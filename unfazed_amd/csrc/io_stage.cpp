@@ -278,7 +278,7 @@ struct Task { // reach intervals of one reference whose file spans meet (walked 
     int64_t n_keep = 0, k0 = 0;
 };
 
-struct Opt { bool all_bases, masks, lists; int thr; };
+struct Opt { bool all_bases, masks, lists, wide_none; int thr; };
 
 inline uint8_t sat255(int v) { return (uint8_t)(v > 255 ? 255 : v); }
 
@@ -375,7 +375,8 @@ inline int32_t endpos_of(const uint8_t *p, int32_t pos, uint16_t fl, uint32_t nc
 }
 
 // the unit-mask bits one fetch contributes to a record it returns (uz_reads_select_plan states the rule)
-inline uint16_t mask_bits(const Fx &f, int32_t pos, int32_t end, uint32_t ncig, uint32_t cw, uint32_t L) {
+inline uint16_t mask_bits(const Fx &f, int32_t pos, int32_t end, uint32_t ncig, uint32_t cw, uint32_t L, bool wide_none) {
+    if (wide_none && f.hi - f.lo > 2) return 0;
     const uint32_t op = cw & 15u;
     const bool simple = ncig == 1 && (op == 0 || op == 7 || op == 8) && (cw >> 4) == L && L > 1 && (uint32_t)(end - pos) == L;
     if (!(simple && L <= 480 && f.hi - f.lo <= 2)) return (uint16_t)UZ_UMASK_ALL;
@@ -561,7 +562,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
                 for (; it != fx.begin() + (ptrdiff_t)T.f1 && it->lo < end; ++it)
                     if (it->hi > pos) {
                         direct = true;
-                        if (o.masks) um |= mask_bits(*it, pos, end, ncig, cw, (uint32_t)lseq);
+                        if (o.masks) um |= mask_bits(*it, pos, end, ncig, cw, (uint32_t)lseq, o.wide_none);
                     }
             }
             r.keep = direct ? 2 : 0;
@@ -1213,6 +1214,7 @@ int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid,
     P->opt.all_bases = (flags & UZ_STAGE_ALL_BASES) != 0;
     P->opt.lists = !(flags & UZ_STAGE_PLANE);
     P->opt.masks = (flags & UZ_STAGE_UNIT_MASKS) && !P->opt.all_bases && P->opt.lists;
+    P->opt.wide_none = P->opt.masks && (flags & UZ_STAGE_WIDE_NO_UNITS);
     P->opt.thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
     const int rc = guarded([&] { plan(*P, n_fetch, tid, lo, hi, extra, threads); });
     if (rc != UZ_IO_OK) { delete P; return rc; }

@@ -157,7 +157,7 @@ class HipEngine:
         self._staged_sites[sid.value] = (held, v)
         return sid.value, fid.value
 
-    def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False) -> int:
+    def upload_reads(self, reads, min_base_qual=None, point_only=False, fetches=None, all_bases=False, wide_no_units=False) -> int:
         """A decoded table -> HBM.  With the base-quality threshold of the run (min_base_qual = --min-gt-qual) the table
         goes over the link in the staged form (packed on the host into pinned memory, several times fewer bytes); without it
         in the ASCII form, which the device packs and which then serves any threshold.
@@ -166,7 +166,9 @@ class HipEngine:
         records, and a point-variant batch never looks at the bits of any other; an SV batch does).
         fetches = (contig, lo, hi, extra) of staging.fetch_points for the ONE batch the table will serve (point_only): records no
         fetch returns travel without bases, of the others' rows only the 32-base units that hold a fetched position (all_bases:
-        --no-extended batches read mates at candidate sites nobody fetched -- every record keeps its rows)."""
+        --no-extended batches read mates at candidate sites nobody fetched -- every record keeps its rows).
+        wide_no_units: the batch holds SVs -- their +-cutoff fetches stage no base unit (collect_reads_sv reads none); the list form of
+        the qualities serves them too: the read stage asks for quality bits of records that pass goodread only (uz_types.h)."""
         v = abi.reads_view(reads)
         if min_base_qual is not None:
             from . import io_native
@@ -180,7 +182,7 @@ class HipEngine:
                     full = io_native.pack_reads(v, int(min_base_qual), lists=True, with_end=True)
                     fc, flo, fhi, fex = fetches
                     packed, idx = io_native.ReadsSource(full).select(fc, flo, fhi, alloc=pool.alloc, want_index=True, all_bases=bool(all_bases),
-                                                                     extra=fex)
+                                                                     extra=fex, wide_no_units=bool(wide_no_units))
                     if idx.size != int(v.view.n_segs):  # record numbers are the caller's: the table must be the fetches' own reach
                         raise UnfazedHipError("upload_reads(fetches=...): the table holds records the fetches cannot reach")
                 else:
@@ -202,13 +204,13 @@ class HipEngine:
         self._ck(self.L.uz_reads_upload(self.h, v.ref(), C.byref(rid)), "uz_reads_upload")
         return rid.value
 
-    def upload_reads_staged(self, src, fc, flo, fhi, fex, min_base_qual: int, all_bases: bool = False):
+    def upload_reads_staged(self, src, fc, flo, fhi, fex, min_base_qual: int, all_bases: bool = False, wide_no_units: bool = False):
         """One batch straight from an indexed BAM (io_native.BamSource): the records its fetches return + their mates, built in the
         link form in pinned memory by one pass over the file's blocks (uz_bam_stage_*), uploaded as one table.
         -> (reads id, the staged view: `.qnames` maps the name ids of the result lists back to strings)"""
         pool = PinnedPool()
         try:
-            packed = src.select(fc, flo, fhi, int(min_base_qual), pool=pool, all_bases=bool(all_bases), extra=fex)
+            packed = src.select(fc, flo, fhi, int(min_base_qual), pool=pool, all_bases=bool(all_bases), extra=fex, wide_no_units=bool(wide_no_units))
             pool.end_slab()
             rid = self.upload_reads_packed(packed)
             self.wait_reads(rid)  # the pinned buffers go back right away

@@ -492,21 +492,22 @@ class PhasingHost:
                     self.sites.pos, het_off, het_idx, params, vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
                     end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff,
                     allele_len=[max(len(prep[i]["ref"]), len(prep[i]["alt"])) for i in idxs])
-                # (a batch of point variants only ever asks for the quality bits of "good" records: the qualities travel as counts
-                # + short lists; SV evidence is collected under goodread(read, True), which does not count them: the plane)
-                point_only = all(vartype_code(dnms[i]["vartype"]) == abi.VT_POINT for i in idxs)
+                # (the read stage asks for the quality bits of "good" records only -- the DNM reads of a point variant and the records
+                # registered at het sites, both under goodread, read_collector.py:43-46; SV evidence is collected under
+                # goodread(read, True) from flags, CIGARs and mates alone, :476-596 -- so every batch travels with the qualities as
+                # counts + short lists and, of the rows, the 32-base units that hold a one-base fetch; the +-cutoff fetches around an
+                # SV's breakpoints stage no unit)
+                has_sv = any(vartype_code(dnms[i]["vartype"]) != abi.VT_POINT for i in idxs)
                 stager = getattr(self.reads_by_bam, "stager", None)
-                src = stager(bam) if (stager and point_only and hasattr(self.backend, "upload_reads_staged")) else None
+                src = stager(bam) if (stager and hasattr(self.backend, "upload_reads_staged")) else None
                 if src is not None:
                     # BAM + BAI -> the link form in one pass (uz_bam_stage_*): no table in between
                     rh, region_table = self.backend.upload_reads_staged(src, fc, flo, fhi, fex, int(params.min_gt_qual),
-                                                                        all_bases=bool(params.no_extended))
+                                                                        all_bases=bool(params.no_extended), wide_no_units=has_sv)
                 else:
                     region_table = self.reads_by_bam.regions(bam, fc, flo, fhi)
-                    # with the fetches at hand the table travels as the bench stages it: mates without bases, of the other records'
-                    # rows only the 32-base units that hold a fetched position (uz_types.h: umask)
-                    rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=point_only,
-                                                   fetches=(fc, flo, fhi, fex) if point_only else None, all_bases=bool(params.no_extended))
+                    rh = self.backend.upload_reads(region_table, min_base_qual=int(params.min_gt_qual), point_only=True,
+                                                   fetches=(fc, flo, fhi, fex), all_bases=bool(params.no_extended), wide_no_units=has_sv)
                 handles.append(rh)
             else:
                 rh = self.reads(bam, params.min_gt_qual)

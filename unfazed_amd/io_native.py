@@ -479,7 +479,7 @@ class ReadsSource:
         self.threads = threads
 
     def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True,
-               tuples=True, d16=True, start8=True):
+               tuples=True, d16=True, start8=True, wide_no_units=False):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
@@ -488,7 +488,8 @@ class ReadsSource:
         tuples: flag, l_seq, n_cigar, mapq, aux (and n_low) as a 16-bit index into a table of their combinations (falls back to the
         plain columns when the selection holds more than 65536 of them).
         d16: start, tlen, mate and qname as 16-bit differences (to the record before / to the record's own index) + an escape list.
-        start8: ... the start differences in eight bits (records of a pile-up start a few bases apart)."""
+        start8: ... the start differences in eight bits (records of a pile-up start a few bases apart).
+        wide_no_units (SV batches, with extra): a fetch wider than two bases stages no unit of the records it returns."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -498,7 +499,7 @@ class ReadsSource:
             extra = np.ascontiguousarray(extra, np.uint16)
             assert extra.size == contig.size
         _check(self.lib, self.lib.uz_reads_select_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data,
-                                                       hi.ctypes.data, 1 if all_bases else 0, 1 if masks else 0,
+                                                       hi.ctypes.data, 1 if all_bases else 0, (3 if wide_no_units else 1) if masks else 0,
                                                        extra.ctypes.data if masks else None,
                                                        (1 | (2 if cigar_compact else 0) | (4 if lists else 0)) if tuples else 0,
                                                        int(self.threads), C.byref(sel)))
@@ -593,7 +594,7 @@ class BamSource:
         k = self.lib.uz_bamsrc_tlen_head(h, head.ctypes.data, head.size)
         self.tlen_head = head[: int(k)].copy()
 
-    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None):
+    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
         `.io_stats` / `.timing` / `.qnames` ride on the returned object.
         pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
@@ -605,7 +606,7 @@ class BamSource:
         if extra is not None:
             extra = np.ascontiguousarray(extra, np.uint16)
             assert extra.size == contig.size
-        flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_UNIT_MASKS if masks else 0) | (0 if lists else STAGE_PLANE)
+        flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_UNIT_MASKS if masks else 0) | (0 if lists else STAGE_PLANE) | (8 if wide_no_units and masks else 0)
         st = C.c_void_p()
         _check(self.lib, self.lib.uz_bam_stage_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
                                                     extra.ctypes.data if extra is not None else None, flags, int(min_base_qual), int(self.threads),
