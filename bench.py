@@ -137,7 +137,8 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.workload == "cnv" and not args.chunks:
-        args.chunks = 10  # (the events of a chunk bring the pile-ups of both breakpoints: many small chunks keep the link busy)
+        args.chunks = 2  # (measured: 2 / 4 / 6 / 10 chunks = 7.9 / 8.5 / 9.4 / 12.2 ms -- since the SV batch travels at 29 KB per event the step is
+        # bound by the per-chunk host work, not by the link)
     if args.workload == "cnv" and "--dnms" not in " ".join(sys.argv) and "UZ_BENCH_DNMS" not in os.environ:
         args.dnms = 10000
     world = int(os.environ.get("WORLD_SIZE", 0))
