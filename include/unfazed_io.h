@@ -207,6 +207,7 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
 int64_t uz_select_n_tuples(const uz_select *s);
 int64_t uz_select_n_esc16(const uz_select *s); /* entries of esc16_* when the output takes start / tlen / mate / qname as 16-bit differences */
 int64_t uz_select_n_esc16_start8(const uz_select *s); /* ... when it takes the start differences in eight bits (start_d8) */
+int64_t uz_select_n_esc16_narrow8(const uz_select *s); /* ... and the mate / name-id differences in eight bits too (mate_d8, qname_d8) */
 int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */

@@ -275,7 +275,14 @@ typedef struct uz_reads_packed_view {
      * few bases apart, so the difference is 0 .. 254 for all but the first record of a region; UZ_D8_ESC (255) = in the escape
      * list (column 0), as for start_d. */
     const uint8_t *start_d8;
+    /* mate_d and qname_d in eight bits (then mate_d / qname_d are NULL; set both or none, with start_d8): a selection keeps about a
+     * third of a pile-up, so a mate lies within +-75 kept records and a name id within +-40 of the record's before it -- signed
+     * bytes, UZ_D8S_ESC (-128) = in the escape list (columns 2 / 3, as for the 16-bit form), UZ_D8S_NONE (-127) = no mate. */
+    const int8_t *mate_d8;
+    const int8_t *qname_d8;
 } uz_reads_packed_view;
+#define UZ_D8S_ESC (-128)
+#define UZ_D8S_NONE (-127)
 #define UZ_D8_ESC 255
 #define UZ_D16_ESC (-32768)
 #define UZ_D16_NONE (-32767)

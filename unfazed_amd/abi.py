@@ -179,6 +179,7 @@ class ReadsPackedView(C.Structure):
         # start / tlen / mate / qname as 16-bit differences + an escape list
         ("start_d", _p), ("tlen_s", _p), ("mate_d", _p), ("qname_d", _p), ("esc16_key", _p), ("esc16_val", _p), ("n_esc16", C.c_int64),
         ("start_d8", _p),  # the start differences in eight bits (start_d then NULL)
+        ("mate_d8", _p), ("qname_d8", _p),  # mate / name-id differences in eight bits (mate_d / qname_d then NULL)
     ]
 
 
@@ -196,7 +197,8 @@ def row_units(l_seq):
 
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
-                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False) -> "Held":
+                      qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False,
+                      narrow8=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -256,7 +258,11 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     if n_esc16 is not None:
         if start8:
             arrs["start_d8"] = alloc(max(1, n))[: max(1, n)]
-        for name in ("tlen_s", "mate_d", "qname_d") if start8 else ("start_d", "tlen_s", "mate_d", "qname_d"):
+        if narrow8:  # (with start8) mate / name-id differences as signed bytes
+            assert start8
+            for name in ("mate_d8", "qname_d8"):
+                arrs[name] = alloc(max(1, n))[: max(1, n)].view(np.int8)
+        for name in (("tlen_s",) if narrow8 else ("tlen_s", "mate_d", "qname_d")) if start8 else ("start_d", "tlen_s", "mate_d", "qname_d"):
             arrs[name] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.int16)
         arrs["esc16_key"] = alloc(8 * max(1, n_esc16))[: 8 * max(1, n_esc16)].view(np.uint64)
         arrs["esc16_val"] = alloc(4 * max(1, n_esc16))[: 4 * max(1, n_esc16)].view(np.int32)
@@ -279,16 +285,17 @@ def wide_columns(held: "Held") -> dict:
     key, val = a["esc16_key"][:ne], a["esc16_val"][:ne].astype(np.int64)
     assert np.all(np.diff(key.astype(np.int64)) > 0)
     out = {}
-    for col, (name, src) in enumerate((("start", "start_d8" if "start_d8" in a else "start_d"), ("tlen", "tlen_s"), ("mate", "mate_d"), ("qname", "qname_d"))):
+    for col, (name, src) in enumerate((("start", "start_d8" if "start_d8" in a else "start_d"), ("tlen", "tlen_s"),
+                                       ("mate", "mate_d8" if "mate_d8" in a else "mate_d"), ("qname", "qname_d8" if "qname_d8" in a else "qname_d"))):
         v = a[src][:n].astype(np.int64)
         sel = (key & np.uint64(3)) == col
         rec = (key[sel] >> np.uint64(2)).astype(np.int64)
-        assert np.array_equal(np.nonzero(v == (255 if src == "start_d8" else -32768))[0], rec)
+        assert np.array_equal(np.nonzero(v == (255 if src == "start_d8" else -128 if src.endswith("_d8") else -32768))[0], rec)
         v[rec] = val[sel]
         if name in ("start", "qname"):
             v = np.cumsum(v) & 0xFFFFFFFF
         elif name == "mate":
-            none = a[src][:n] == -32767
+            none = a[src][:n] == (-127 if src == "mate_d8" else -32767)
             esc = np.zeros(n, bool)
             esc[rec] = True
             v = np.where(none, -1, np.where(esc, v, v + np.arange(n)))

@@ -599,7 +599,9 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(!v->tup_umask || (v->tup && !v->umask), UZ_E_ARG, "tup_umask needs tup, and umask NULL");
     if (v->start_d || v->start_d8) {
         UZ_REQUIRE(!(v->start_d && v->start_d8), UZ_E_ARG, "start_d and start_d8 are both set");
-        UZ_REQUIRE(v->tlen_s && v->mate_d && v->qname_d && v->n_esc16 >= 0 && (v->n_esc16 == 0 || (v->esc16_key && v->esc16_val)), UZ_E_ARG, "bad 16-bit difference columns");
+        const bool n8 = v->mate_d8 != nullptr || v->qname_d8 != nullptr;
+        UZ_REQUIRE(!n8 || (v->start_d8 && v->mate_d8 && v->qname_d8 && !v->mate_d && !v->qname_d), UZ_E_ARG, "mate_d8 and qname_d8 come together, with start_d8, instead of mate_d / qname_d");
+        UZ_REQUIRE(v->tlen_s && (n8 || (v->mate_d && v->qname_d)) && v->n_esc16 >= 0 && (v->n_esc16 == 0 || (v->esc16_key && v->esc16_val)), UZ_E_ARG, "bad 16-bit difference columns");
         UZ_REQUIRE(!v->start && !v->tlen && !v->mate && !v->qname, UZ_E_ARG, "start_d / start_d8 is set: start / tlen / mate / qname must be NULL");
     }
     if (v->tup) {
@@ -636,10 +638,12 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     uint32_t *exc_rec = nullptr; uint16_t *exc_pos = nullptr; uint8_t *exc_code = nullptr;
     int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
     const bool d8 = v->start_d8 != nullptr;
+    const bool n8 = v->mate_d8 != nullptr;
     const bool d16 = v->start_d != nullptr || d8;
     const size_t nes = d16 ? (size_t)v->n_esc16 : 0;
     int16_t *d_start = nullptr, *d_tlen = nullptr, *d_mate = nullptr, *d_qname = nullptr;
     uint8_t *d_start8 = nullptr;
+    int8_t *d_mate8 = nullptr, *d_qname8 = nullptr;
     unsigned long long *e_key = nullptr; int32_t *e_val = nullptr;
     void *scratch = nullptr;
     for (int pass = 0; pass < 2; pass++) {
@@ -649,7 +653,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         if (ccompact) cigar_staged = cv.take<uint32_t>(ncs);
         if (d16) {
             d_start = cv.take<int16_t>(d8 ? 0 : n); d_start8 = cv.take<uint8_t>(d8 ? n : 0);
-            d_tlen = cv.take<int16_t>(n); d_mate = cv.take<int16_t>(n); d_qname = cv.take<int16_t>(n);
+            d_tlen = cv.take<int16_t>(n); d_mate = cv.take<int16_t>(n8 ? 0 : n); d_qname = cv.take<int16_t>(n8 ? 0 : n);
+            d_mate8 = cv.take<int8_t>(n8 ? n : 0); d_qname8 = cv.take<int8_t>(n8 ? n : 0);
             e_key = cv.take<unsigned long long>(nes); e_val = cv.take<int32_t>(nes);
         }
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
@@ -686,7 +691,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         if (d8) col.start_d8 = h2d(st, d_start8, v->start_d8, n);
         else col.start_d = h2d(st, d_start, v->start_d, n);
         col.tlen_s = h2d(st, d_tlen, v->tlen_s, n);
-        col.mate_d = h2d(st, d_mate, v->mate_d, n); col.qname_d = h2d(st, d_qname, v->qname_d, n);
+        if (n8) { col.mate_d8 = h2d(st, d_mate8, v->mate_d8, n); col.qname_d8 = h2d(st, d_qname8, v->qname_d8, n); }
+        else { col.mate_d = h2d(st, d_mate, v->mate_d, n); col.qname_d = h2d(st, d_qname, v->qname_d, n); }
         col.esc16_key = h2d(st, e_key, (const unsigned long long *)v->esc16_key, nes); col.esc16_val = h2d(st, e_val, v->esc16_val, nes);
         col.n_esc16 = (int64_t)nes;
         col.start = nullptr; col.tlen = nullptr; col.mate = nullptr; col.qname = nullptr;
@@ -738,8 +744,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         const void *t[8] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low, col.tup_umask};
         for (int k = 0; k < 8; k++) r.col_t[k] = t[k];
         r.col_lists = col.lists;
-        const void *dd[7] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8};
-        for (int k = 0; k < 7; k++) r.col_d[k] = dd[k];
+        const void *dd[9] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8, col.mate_d8, col.qname_d8};
+        for (int k = 0; k < 9; k++) r.col_d[k] = dd[k];
         r.col_nesc = col.n_esc16;
     }
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
@@ -768,6 +774,7 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.start_d = (const int16_t *)r.col_d[0]; col.tlen_s = (const int16_t *)r.col_d[1]; col.mate_d = (const int16_t *)r.col_d[2];
     col.qname_d = (const int16_t *)r.col_d[3]; col.esc16_key = (const unsigned long long *)r.col_d[4]; col.esc16_val = (const int32_t *)r.col_d[5];
     col.start_d8 = (const uint8_t *)r.col_d[6];
+    col.mate_d8 = (const int8_t *)r.col_d[7]; col.qname_d8 = (const int8_t *)r.col_d[8];
     col.n_esc16 = r.col_nesc;
     col.qpos_wide = r.col_qwide;
     uz_build_records(c, c->stream, r, col, r.build_scratch);
@@ -902,6 +909,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             col.start = v->start; col.end = v->end; col.tlen = v->tlen; col.mate = v->mate; col.qname = v->qname;
             if (v->start_d || v->start_d8) {
                 col.start_d = v->start_d; col.start_d8 = v->start_d8; col.tlen_s = v->tlen_s; col.mate_d = v->mate_d; col.qname_d = v->qname_d;
+                col.mate_d8 = v->mate_d8; col.qname_d8 = v->qname_d8;
                 col.esc16_key = (const unsigned long long *)v->esc16_key; col.esc16_val = v->esc16_val; col.n_esc16 = v->n_esc16;
             }
             col.flag = v->flag; col.l_seq = v->l_seq; col.n_cigar = v->n_cigar; col.mapq = v->mapq; col.aux = v->aux;

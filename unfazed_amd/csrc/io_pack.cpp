@@ -114,6 +114,7 @@ struct uz_select {
     std::vector<uint16_t> tup_um;       // (unit mask of the combination when the selection has masks)
     int64_t n_esc16 = 0;                // escapes of the 16-bit difference form of start / tlen / mate / qname (uz_d16_of)
     int64_t n_esc16_start8 = 0;         // ... when the start differences travel in eight bits (start_d8)
+    int64_t n_esc16_narrow8 = 0;        // ... and the mate / name-id differences too (mate_d8, qname_d8)
     int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
@@ -125,12 +126,18 @@ struct uz_select {
 // start / tlen / mate / qname of kept record k as 16-bit differences (uz_reads_packed_view.start_d ...): v[c] the column values,
 // e[c] the escape value where v[c] == UZ_D16_ESC (columns 0 start, 1 tlen, 2 mate, 3 qname); returns the number of escapes
 // start8: the start difference is to fit EIGHT bits (0 .. 254; uz_reads_packed_view.start_d8): anything else escapes
-static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t e[4], bool start8 = false) {
+// narrow8: mate and name-id differences are to fit a signed byte (-126 .. 127; UZ_D8S_ESC / UZ_D8S_NONE); v[] then holds those codes
+static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t e[4], bool start8 = false, bool narrow8 = false) {
     const uz_reads_packed_view *f = &s->src->v;
     const int64_t i = s->index[(size_t)k];
     const int64_t ip = k > 0 ? s->index[(size_t)k - 1] : -1;
     int n = 0;
     auto put = [&](int c, int64_t d, int64_t esc_val) {
+        if (narrow8 && c >= 2) {
+            if (d > -127 && d <= 127) v[c] = (int16_t)d;
+            else { v[c] = (int16_t)UZ_D8S_ESC; e[c] = (int32_t)esc_val; n++; }
+            return;
+        }
         if (d > -32767 && d <= 32767) v[c] = (int16_t)d;
         else { v[c] = (int16_t)UZ_D16_ESC; e[c] = (int32_t)esc_val; n++; }
     };
@@ -145,7 +152,7 @@ static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t
         auto it = std::lower_bound(s->index.begin(), s->index.end(), mt);
         if (it != s->index.end() && *it == mt) nm = it - s->index.begin();
     }
-    if (nm < 0) v[2] = (int16_t)UZ_D16_NONE;
+    if (nm < 0) v[2] = narrow8 ? (int16_t)UZ_D8S_NONE : (int16_t)UZ_D16_NONE;
     else put(2, nm - k, nm);
     const int32_t dq = (int32_t)(f->qname[i] - (ip >= 0 ? f->qname[ip] : 0u)); // modulo 2^32
     put(3, dq, dq);
@@ -544,16 +551,17 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
         { // escapes of the 16-bit difference form (counted whether or not the output will use it: cheap)
             const int wk = workers_for(sel->n_sel, threads, 1 << 14);
             std::vector<int64_t> part((size_t)wk + 1, 0);
-            std::vector<int64_t> part8((size_t)wk + 1, 0);
+            std::vector<int64_t> part8((size_t)wk + 1, 0), partn((size_t)wk + 1, 0);
             parallel_slices(sel->n_sel, wk, [&](int64_t a, int64_t b, int slice) {
-                int64_t c = 0, c8 = 0;
+                int64_t c = 0, c8 = 0, cn = 0;
                 int16_t v[4];
                 int32_t e[4];
-                for (int64_t k = a; k < b; k++) { c += uz_d16_of(sel, k, v, e); c8 += uz_d16_of(sel, k, v, e, true); }
+                for (int64_t k = a; k < b; k++) { c += uz_d16_of(sel, k, v, e); c8 += uz_d16_of(sel, k, v, e, true); cn += uz_d16_of(sel, k, v, e, true, true); }
                 part[(size_t)slice] = c;
                 part8[(size_t)slice] = c8;
+                partn[(size_t)slice] = cn;
             });
-            for (int k = 0; k < wk; k++) { sel->n_esc16 += part[(size_t)k]; sel->n_esc16_start8 += part8[(size_t)k]; }
+            for (int k = 0; k < wk; k++) { sel->n_esc16 += part[(size_t)k]; sel->n_esc16_start8 += part8[(size_t)k]; sel->n_esc16_narrow8 += partn[(size_t)k]; }
         }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
@@ -580,6 +588,7 @@ int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
 int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
 int64_t uz_select_n_esc16(const uz_select *s) { return s ? s->n_esc16 : 0; }
 int64_t uz_select_n_esc16_start8(const uz_select *s) { return s ? s->n_esc16_start8 : 0; }
+int64_t uz_select_n_esc16_narrow8(const uz_select *s) { return s ? s->n_esc16_narrow8 : 0; }
 int64_t uz_select_n_tuples(const uz_select *s) { return (s && s->tuples) ? (int64_t)s->tup_key.size() : -1; }
 int64_t uz_select_n_cigar_omitted(const uz_select *s) { return s ? s->n_cigar_simple : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
@@ -609,11 +618,14 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         out->n_exc = two_bit ? s->n_exc : 0;
         if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
         const bool start8 = out->start_d8 != nullptr;
+        const bool narrow8 = out->mate_d8 != nullptr || out->qname_d8 != nullptr;
         const bool d16 = out->start_d != nullptr || start8;
         if (start8 && out->start_d) fail(UZ_IO_E_ARG, "start_d and start_d8 are both set");
-        const int64_t n_esc = start8 ? s->n_esc16_start8 : s->n_esc16;
-        if (d16 && (!out->tlen_s || !out->mate_d || !out->qname_d || (n_esc && (!out->esc16_key || !out->esc16_val))))
-            fail(UZ_IO_E_ARG, "the 16-bit difference form needs start_d (or start_d8), tlen_s, mate_d, qname_d and the esc16_* list");
+        if (narrow8 && (!start8 || !out->mate_d8 || !out->qname_d8 || out->mate_d || out->qname_d))
+            fail(UZ_IO_E_ARG, "mate_d8 and qname_d8 come together, with start_d8, instead of mate_d / qname_d");
+        const int64_t n_esc = narrow8 ? s->n_esc16_narrow8 : start8 ? s->n_esc16_start8 : s->n_esc16;
+        if (d16 && (!out->tlen_s || (!narrow8 && (!out->mate_d || !out->qname_d)) || (n_esc && (!out->esc16_key || !out->esc16_val))))
+            fail(UZ_IO_E_ARG, "the 16-bit difference form needs start_d (or start_d8), tlen_s, mate_d, qname_d (or mate_d8, qname_d8) and the esc16_* list");
         out->n_esc16 = d16 ? n_esc : 0;
         std::vector<int64_t> esc_at; // first escape of every slice of the fill loop below
         const int wk_fill = workers_for(m, threads, 4096);
@@ -623,7 +635,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 int64_t c = 0;
                 int16_t v[4];
                 int32_t e[4];
-                for (int64_t k = a; k < b; k++) c += uz_d16_of(s, k, v, e, start8);
+                for (int64_t k = a; k < b; k++) c += uz_d16_of(s, k, v, e, start8, narrow8);
                 part[(size_t)slice + 1] = c;
             });
             for (int k = 0; k < wk_fill; k++) part[(size_t)k + 1] += part[(size_t)k];
@@ -693,12 +705,14 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 if (d16) {
                     int16_t v[4];
                     int32_t e[4];
-                    uz_d16_of(s, k, v, e, start8);
+                    uz_d16_of(s, k, v, e, start8, narrow8);
                     if (start8) w(out->start_d8)[k] = v[0] == (int16_t)UZ_D16_ESC ? (uint8_t)UZ_D8_ESC : (uint8_t)v[0];
                     else w(out->start_d)[k] = v[0];
-                    w(out->tlen_s)[k] = v[1]; w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3];
+                    w(out->tlen_s)[k] = v[1];
+                    if (narrow8) { w(out->mate_d8)[k] = (int8_t)v[2]; w(out->qname_d8)[k] = (int8_t)v[3]; }
+                    else { w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3]; }
                     for (int c = 0; c < 4; c++)
-                        if (v[c] == (int16_t)UZ_D16_ESC) {
+                        if (v[c] == (int16_t)((narrow8 && c >= 2) ? UZ_D8S_ESC : UZ_D16_ESC)) {
                             w(out->esc16_key)[esc_next] = ((uint64_t)k << 2) | (uint64_t)c;
                             w(out->esc16_val)[esc_next] = e[c];
                             esc_next++;

@@ -438,6 +438,11 @@ inline int d16_of(const uz_stage &P, int64_t k, int16_t v[4], int32_t e[4]) {
     const WRec &x = rec_of(P, P.order[(size_t)k]);
     int n = 0;
     auto put = [&](int c, int64_t d, int64_t esc_val) {
+        if (c >= 2) { // mate and name id: signed bytes (mate_d8 / qname_d8)
+            if (d > -127 && d <= 127) v[c] = (int16_t)d;
+            else { v[c] = (int16_t)UZ_D8S_ESC; e[c] = (int32_t)esc_val; n++; }
+            return;
+        }
         if (d > -32767 && d <= 32767) v[c] = (int16_t)d;
         else { v[c] = (int16_t)UZ_D16_ESC; e[c] = (int32_t)esc_val; n++; }
     };
@@ -447,7 +452,7 @@ inline int d16_of(const uz_stage &P, int64_t k, int16_t v[4], int32_t e[4]) {
     else { v[0] = (int16_t)UZ_D16_ESC; e[0] = (int32_t)ds; n++; }
     put(1, x.tlen, x.tlen);
     const int64_t m = final_ref(P, x.mate_ref);
-    if (m < 0) v[2] = (int16_t)UZ_D16_NONE;
+    if (m < 0) v[2] = (int16_t)UZ_D8S_NONE;
     else { const int64_t nm = rec_of(P, m).gidx; put(2, nm - k, nm); }
     const int32_t dq = (int32_t)(x.qid - (px ? px->qid : 0u));
     put(3, dq, dq);
@@ -1098,7 +1103,8 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
     need(out->seq2 || tot.seq == 0, "needs seq2 (two-bit base rows)");
     need(!out->seq4, "must not set seq4 (the staged form carries two-bit rows)");
     need(out->tup && out->tup_flag && out->tup_l_seq && out->tup_n_cigar && out->tup_mapq && out->tup_aux, "needs the dictionary form (tup, tup_*)");
-    need(out->start_d8 && out->tlen_s && out->mate_d && out->qname_d && !out->start_d, "needs the difference form with eight-bit starts (start_d8, tlen_s, mate_d, qname_d)");
+    need(out->start_d8 && out->tlen_s && out->mate_d8 && out->qname_d8 && !out->start_d && !out->mate_d && !out->qname_d,
+         "needs the difference form with eight-bit starts, mates and name ids (start_d8, tlen_s, mate_d8, qname_d8)");
     need(tot.esc == 0 || (out->esc16_key && out->esc16_val), "needs the esc16_* list");
     need(!out->end, "must leave `end` out (a BAM record's end is what its CIGAR gives)");
     need(out->cigar_compact != 0, "must set cigar_compact");
@@ -1135,9 +1141,9 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
                 int32_t e[4];
                 d16_of(P, k, v, e);
                 w(out->start_d8)[k] = v[0] == (int16_t)UZ_D16_ESC ? (uint8_t)UZ_D8_ESC : (uint8_t)v[0];
-                w(out->tlen_s)[k] = v[1]; w(out->mate_d)[k] = v[2]; w(out->qname_d)[k] = v[3];
+                w(out->tlen_s)[k] = v[1]; w(out->mate_d8)[k] = (int8_t)v[2]; w(out->qname_d8)[k] = (int8_t)v[3];
                 for (int c = 0; c < 4; c++)
-                    if (v[c] == (int16_t)UZ_D16_ESC) { w(out->esc16_key)[at.esc] = ((uint64_t)k << 2) | (uint64_t)c; w(out->esc16_val)[at.esc] = e[c]; at.esc++; }
+                    if (v[c] == (int16_t)(c >= 2 ? UZ_D8S_ESC : UZ_D16_ESC)) { w(out->esc16_key)[at.esc] = ((uint64_t)k << 2) | (uint64_t)c; w(out->esc16_val)[at.esc] = e[c]; at.esc++; }
                 w(out->tup)[k] = x.tup;
                 if (!x.simple) { memcpy(w(out->cigar) + at.cig, T.cigars.data() + x.cigar_at, (size_t)x.n_cigar * 4); at.cig += x.n_cigar; }
                 const uint8_t *pay = T.pay.data() + x.pay_at;

@@ -170,6 +170,14 @@ __device__ __forceinline__ uint32_t d16_val(const RecColumns &c, const int16_t *
     const int v = col[i];
     return (uint32_t)(v == UZ_D16_ESC ? esc16_of(c, i, k) : v);
 }
+// the name-id difference of record i: sixteen bits, or eight (qname_d8)
+__device__ __forceinline__ uint32_t qname_diff(const RecColumns &c, int64_t i) {
+    if (c.qname_d8) {
+        const int v = c.qname_d8[i];
+        return (uint32_t)(v == UZ_D8S_ESC ? esc16_of(c, i, 3) : v);
+    }
+    return d16_val(c, c.qname_d, i, 3);
+}
 // the start difference of record i: sixteen bits, or eight (start_d8)
 __device__ __forceinline__ uint32_t start_diff(const RecColumns &c, int64_t i) {
     if (c.start_d8) {
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
             uint32_t v[UZ_PK_SUMS];
             const RecSmall r = rec_small(c, i);
             pk_vals(r.nc, r.ls, r.aux, r.nl, r.um, v);
-            if (c.tlen_s) { v[5] = start_diff(c, i); v[6] = d16_val(c, c.qname_d, i, 3); }
+            if (c.tlen_s) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         const uint32_t um = rs.um;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
         pk_vals(nc, ls, ax, nl, um, v);
-        if (c.tlen_s && in) { v[5] = start_diff(c, i); v[6] = d16_val(c, c.qname_d, i, 3); }
+        if (c.tlen_s && in) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
 #pragma unroll
         for (int k = 0; k < UZ_PK_SUMS; k++) {
             uint32_t x = v[k];
@@ -278,8 +286,13 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                 st0 = (int32_t)(uint32_t)(run[5] + pre[5] + inc[5]);
                 qn0 = (uint32_t)(run[6] + pre[6] + inc[6]);
                 tl0 = (int32_t)d16_val(c, c.tlen_s, i, 1);
-                const int md = c.mate_d[i];
-                mt0 = md == UZ_D16_NONE ? -1 : (md == UZ_D16_ESC ? esc16_of(c, i, 2) : (int32_t)(i + md));
+                if (c.mate_d8) {
+                    const int md = c.mate_d8[i];
+                    mt0 = md == UZ_D8S_NONE ? -1 : (md == UZ_D8S_ESC ? esc16_of(c, i, 2) : (int32_t)(i + md));
+                } else {
+                    const int md = c.mate_d[i];
+                    mt0 = md == UZ_D16_NONE ? -1 : (md == UZ_D16_ESC ? esc16_of(c, i, 2) : (int32_t)(i + md));
+                }
                 if (mt0 < -1 || mt0 >= n) { hflags[0] = 7; mt0 = -1; }
             } else { st0 = c.start[i]; tl0 = c.tlen[i]; mt0 = c.mate[i]; qn0 = c.qname[i]; }
             const uint32_t *words = c.cigar_in + cg;

@@ -126,7 +126,7 @@ struct ReadsDev {
     void *build_scratch = nullptr;
     const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
     int32_t col_lists = 0;
-    const void *col_d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val, start_d8
+    const void *col_d[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val, start_d8
     int64_t col_nesc = 0;
     const void *col_q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask / cigar_staged / cigar_out of RecColumns, for the deferred header build
     int64_t n_cigar_staged = 0; // cigar_compact: words that travelled (checked by the header build)
@@ -260,6 +260,7 @@ struct RecColumns {
     // 16-bit difference form of start / tlen / mate / qname (start_d set: the plain four are null)
     const int16_t *start_d = nullptr, *tlen_s = nullptr, *mate_d = nullptr, *qname_d = nullptr;
     const uint8_t *start_d8 = nullptr; // the start differences in eight bits (then start_d is null)
+    const int8_t *mate_d8 = nullptr, *qname_d8 = nullptr; // mate / name-id differences in eight bits (then mate_d / qname_d are null)
     const unsigned long long *esc16_key = nullptr;
     const int32_t *esc16_val = nullptr;
     int64_t n_esc16 = 0;
