@@ -340,7 +340,7 @@ def main():
             staged_records += int(part.view.n_segs)
             pv = part.view
             lists_f = bool(pv.n_low) or bool(pv.tup and pv.tup_n_low)
-            fixed = ((5 if pv.mate_d8 else 7) if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
+            fixed = ((2 if pv.pair_d8 else 5 if pv.mate_d8 else 7) if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
             staged_bytes += (int(pv.n_segs) * fixed + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
                              + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
                              + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
@@ -389,9 +389,12 @@ def main():
                 held, hs_k, hg_k, _ = chunk_sites[k]
                 sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"])
 
-            def read_stage(k):
+            def read_stage_begin(k):  # queued on the compute stream (waits there for the chunk's records): no host wait
+                eng.phase_begin(fids[k], rids[k], chunks[k][3], P, mode)
+
+            def read_stage_end(k):
                 a, b, _, dvc = chunks[k]
-                rr = eng.phase_raw(fids[k], rids[k], dvc, P, mode)
+                rr = eng.phase_end(fids[k], rids[k], dvc, P, mode)
                 for key in out:
                     out[key][a:b] = rr[key]
                 eng.free_reads(rids[k])
@@ -402,20 +405,28 @@ def main():
             def tick():
                 if tr is not None:
                     tr.append(time.perf_counter())
+            # The read stage of chunk k - 1 is queued (uz_phase_begin) before the host waits for the het lists of chunk k + 1: that wait
+            # -- the ONE host round trip per chunk -- then runs behind the read stage's kernels instead of beside an idle device, and the
+            # read stage's results are there when it returns (uz_phase_end).
             site_stage(0)
             tick()
             for k in range(K):
                 eng.find(fids[k], chunks[k][3], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
                 tick()
+                if k >= 2:
+                    read_stage_end(k - 2)
                 if k + 1 < K:
                     site_stage(k + 1)
                 tick()
                 rids[k] = eng.upload_reads_packed(chunks[k][2])
                 tick()
                 if k >= 1:
-                    read_stage(k - 1)
+                    read_stage_begin(k - 1)
                 tick()
-            read_stage(K - 1)
+            if K >= 2:
+                read_stage_end(K - 2)
+            read_stage_begin(K - 1)
+            read_stage_end(K - 1)
             tick()
             if tr is not None:
                 trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
@@ -455,7 +466,7 @@ def main():
         res_s, el_s, prof_s, _ = timed(step_staged)
         per_rank_s = list(timed.per_rank)
         if trace and chunk_sites:
-            print("[staged step, ms] site stage 0, then per chunk: find | next site stage | enqueue records | read stage of the chunk before; last read stage:", trace[-2:], file=sys.stderr)
+            print("[staged step, ms] site stage 0, then per chunk: find (behind the read stage of chunk k - 2) | its results, next site stage | enqueue records | queue the read stage of chunk k - 1; last read stages:", trace[-2:], file=sys.stderr)
         elif trace:
             print("[staged step, ms] sites+family upload | find | enqueue read uploads | phase chunks | cnv + frees:", trace, file=sys.stderr)
             # where the link time goes: the copies alone, the kernels alone (tables already in HBM), both overlapped

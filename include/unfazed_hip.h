@@ -86,6 +86,10 @@ int uz_reads_upload(uz_ctx *ctx, const uz_reads_view *reads, int *reads_id);
  * kernels of the current one. */
 int uz_reads_upload_packed(uz_ctx *ctx, const uz_reads_packed_view *reads, int *reads_id);
 int uz_reads_wait(uz_ctx *ctx, int reads_id);
+/* what the device made of a table's fixed-width columns, whatever form they travelled in (plain, 16- / 8-bit differences, the pair
+ * form; `end` derived from the CIGAR when it was left out): [n_segs] each, any pointer may be NULL.  For parity tests of the
+ * upload forms; waits for the table like uz_reads_wait. */
+int uz_reads_headers(uz_ctx *ctx, int reads_id, int32_t *start, int32_t *end, int32_t *tlen, int32_t *mate, uint32_t *qname);
 /* page-locked host memory for the staged columns (plain hipHostMalloc; no context needed) */
 int uz_pinned_alloc(size_t bytes, void **out);
 void uz_pinned_free(void *p);
@@ -132,6 +136,15 @@ int uz_find_fetch(uz_ctx *ctx, int32_t *cand_idx, uint8_t *cand_flags, int32_t *
 int uz_phase(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode,
              int32_t *status /* [n] UZ_ST_* */, int32_t *counts /* [4n] */,
              int32_t *origin /* [n] UZ_OR_* */, int32_t *evidence /* [n] */);
+/* uz_phase in two halves, for a caller that has the next batch's work ready: uz_phase_begin queues the window emit and the read
+ * stage and returns without waiting (a first batch, whose sizes nothing predicts yet, runs to its end instead); uz_phase_end -- same
+ * batch, same arguments -- waits and hands out the results of uz_phase.  Between the two the caller may upload tables and run
+ * uz_site_scan / uz_find for OTHER batches (they queue up behind the read stage: the device does not idle through the host's round
+ * trips); not another uz_phase*, and not uz_find_fetch / uz_phase_votes of this batch before uz_phase_end has returned.  After an
+ * intervening uz_find the window lists of the context are that batch's: uz_find_fetch then returns those. */
+int uz_phase_begin(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode);
+int uz_phase_end(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode,
+                 int32_t *status, int32_t *counts, int32_t *origin, int32_t *evidence);
 /* Cohort form (603 samples in one run, README.md:208; one alignment file per kid, unfazed.py:574-575): the
  * DNMs of many kids -- each with its own trio columns, its own alignment records and its own insert cutoff -- in ONE
  * launch sequence instead of one per kid.  `dnms` holds all groups' DNMs back to back; `rcontig` refers to the group's

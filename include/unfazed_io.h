@@ -208,6 +208,14 @@ int64_t uz_select_n_tuples(const uz_select *s);
 int64_t uz_select_n_esc16(const uz_select *s); /* entries of esc16_* when the output takes start / tlen / mate / qname as 16-bit differences */
 int64_t uz_select_n_esc16_start8(const uz_select *s); /* ... when it takes the start differences in eight bits (start_d8) */
 int64_t uz_select_n_esc16_narrow8(const uz_select *s); /* ... and the mate / name-id differences in eight bits too (mate_d8, qname_d8) */
+/* The pair form (uz_reads_packed_view.pair_d8: tlen, mate and name id in one byte).  It numbers the names of the selection by first
+ * appearance, which keeps the order of the source's ids only when those ascend by first appearance too (any decoder's table):
+ * uz_select_pair8_ok says whether the plan found it so; n_esc16_pair8 = entries of esc16_* for that form (-1: not available);
+ * n_new_names = the output's n_qnames; qname_map[output id] = source id. */
+int uz_select_pair8_ok(const uz_select *s);
+int64_t uz_select_n_esc16_pair8(const uz_select *s);
+int64_t uz_select_n_new_names(const uz_select *s);
+int uz_select_qname_map(const uz_select *s, uint32_t *out /* [n_new_names] */);
 int64_t uz_select_n_seq_units(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */

@@ -280,7 +280,26 @@ typedef struct uz_reads_packed_view {
      * bytes, UZ_D8S_ESC (-128) = in the escape list (columns 2 / 3, as for the 16-bit form), UZ_D8S_NONE (-127) = no mate. */
     const int8_t *mate_d8;
     const int8_t *qname_d8;
+    /* tlen, mate and name id of a record in ONE byte -- the pair form (with start_d8; then tlen_s / mate_d / qname_d / mate_d8 /
+     * qname_d8 are NULL).  Nearly every record of a short-read file is one of two mates that name each other, carry one query name
+     * nobody before them carried, and a template length that is the span of the pair; and name ids are handed out by first
+     * appearance, so a new name's id is the number of new names before it.  pair_d8[i]:
+     *   1 .. UZ_P8_MAX_DIST  FIRST of such a pair: mate = i + pair_d8[i]; a new name; tlen = max(end[i], end[mate]) - start[i]
+     *   UZ_P8_SECOND (0)     SECOND of such a pair: the record naming it as its mate is its mate; the same name id; tlen = -(its mate's)
+     *   UZ_P8_SECOND_TLEN (253)  the same, of a pair whose template lengths are +-t for some other t (soft clips, another aligner's
+     *                        convention): its own tlen stands in the escape list (column 1), its mate's is the negative
+     *   UZ_P8_NEW (254)      any other record with a new name: tlen and mate stand in the escape list (columns 1 and 2; mate -1 = none)
+     *   UZ_P8_OLD (255)      any other record: tlen, mate and name id stand in the escape list (columns 1, 2 and 3: the id itself)
+     * A packer gives a pair the first two codes only when every one of those statements holds for it (both directions of the mate
+     * link, the distance, both template lengths), so the form is lossless; the device checks that every SECOND is named by exactly one
+     * FIRST (UZ_E_STATE otherwise).  A 151-base pair costs 2 bytes here instead of 8. */
+    const uint8_t *pair_d8;
 } uz_reads_packed_view;
+#define UZ_P8_SECOND 0
+#define UZ_P8_MAX_DIST 252
+#define UZ_P8_SECOND_TLEN 253
+#define UZ_P8_NEW 254
+#define UZ_P8_OLD 255
 #define UZ_D8S_ESC (-128)
 #define UZ_D8S_NONE (-127)
 #define UZ_D8_ESC 255

@@ -30,11 +30,12 @@ int uzs_gen_reads_cpu(const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, 
                       const uzs_out_ascii *o) {
     uint32_t *keys = (uint32_t *)malloc((size_t)UZS_MAXSEG * sizeof(uint32_t));
     int32_t *inv = (int32_t *)malloc((size_t)UZS_MAXSEG * sizeof(int32_t));
+    int32_t *fid = (int32_t *)malloc((size_t)UZS_MAXSEG * sizeof(int32_t));
     const int64_t pair0 = C->pair_off[c0];
     int64_t cig = 0;
     for (int32_t c = c0; c < c1; c++) {
         const int nseg = (int)(2 * (C->pair_off[c + 1] - C->pair_off[c]));
-        if (nseg > UZS_MAXSEG) { free(keys); free(inv); return -2; }
+        if (nseg > UZS_MAXSEG) { free(keys); free(inv); free(fid); return -2; }
         for (int slot = 0; slot < nseg; slot++) {
             uzs_seg s;
             uzs_segment(cf, C, D, c, slot >> 1, slot & 1, &s);
@@ -42,6 +43,8 @@ int uzs_gen_reads_cpu(const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, 
         }
         qsort(keys, (size_t)nseg, sizeof(uint32_t), cmp_u32);
         for (int p = 0; p < nseg; p++) inv[keys[p] & 0x3FFF] = p;
+        /* name ids as a decoder hands them out: in order of first appearance (a pair's id = pairs that start before it in the block) */
+        for (int p = 0, run = 0; p < nseg; p++) { fid[p] = run; run += inv[(keys[p] & 0x3FFF) ^ 1] > p; }
         int64_t s_lo, s_hi;
         uzs_site_window(S, C, c, &s_lo, &s_hi);
         const int64_t rec0 = 2 * (C->pair_off[c] - pair0);
@@ -52,7 +55,7 @@ int uzs_gen_reads_cpu(const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, 
             const int64_t i = rec0 + p;
             o->start[i] = s.start; o->end[i] = s.end; o->flag[i] = s.flag; o->mapq[i] = s.mapq; o->aux[i] = 1;
             o->tlen[i] = s.tlen;
-            o->qname[i] = (uint32_t)(C->pair_off[c] - pair0 + (slot >> 1));
+            o->qname[i] = (uint32_t)(C->pair_off[c] - pair0 + fid[inv[slot ^ 1] > p ? p : inv[slot ^ 1]]);
             o->mate[i] = (int32_t)(rec0 + inv[slot ^ 1]);
             o->cigar_off[i] = (uint32_t)cig;
             o->n_cigar[i] = s.n_ops;
@@ -67,5 +70,6 @@ int uzs_gen_reads_cpu(const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, 
     }
     free(keys);
     free(inv);
+    free(fid);
     return 0;
 }

@@ -108,6 +108,27 @@ __global__ __launch_bounds__(UZS_NT) void k_gen_clusters(uzs_cfg cf, uzs_sites S
             for (int p = lo; p < hi; p++) { pre[p] = (unsigned short)run; run += nops[p]; }
             __syncthreads();
         }
+        { // name ids as a decoder hands them out: in order of first appearance (a pair's id = pairs that start before it in the block)
+            const int chunk = (nseg + UZS_NT - 1) / UZS_NT;
+            int lo = threadIdx.x * chunk; if (lo > nseg) lo = nseg;
+            int hi = lo + chunk; if (hi > nseg) hi = nseg;
+            int sum = 0;
+            for (int p = lo; p < hi; p++) sum += (int)inv[(keys[p] & 0x3FFF) ^ 1] > p;
+            part[threadIdx.x] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int run = 0;
+                for (int t = 0; t < UZS_NT; t++) { const int v = part[t]; part[t] = run; run += v; }
+            }
+            __syncthreads();
+            int run = part[threadIdx.x];
+            for (int p = lo; p < hi; p++) { // (the sort is done: the key's upper bits now hold the rank, its low 14 the slot)
+                const uint32_t slot = keys[p] & 0x3FFF;
+                keys[p] = slot | ((uint32_t)run << 14);
+                run += (int)inv[slot ^ 1] > p;
+            }
+            __syncthreads();
+        }
         const int64_t rec0 = 2 * C.pair_off[c];
         for (int p = threadIdx.x; p < nseg; p += UZS_NT) {
             const int slot = (int)(keys[p] & 0x3FFF);
@@ -115,8 +136,9 @@ __global__ __launch_bounds__(UZS_NT) void k_gen_clusters(uzs_cfg cf, uzs_sites S
             uzs_segment(&cf, &C, &D, c, slot >> 1, slot & 1, &s);
             const int64_t i = rec0 + p;
             o.start[i] = s.start; o.end[i] = s.end; o.tlen[i] = s.tlen;
-            o.mate[i] = (int32_t)(rec0 + inv[slot ^ 1]);
-            o.qname[i] = (uint32_t)(C.pair_off[c] + (slot >> 1));
+            const int pm = (int)inv[slot ^ 1];
+            o.mate[i] = (int32_t)(rec0 + pm);
+            o.qname[i] = (uint32_t)(C.pair_off[c] + (keys[pm > p ? p : pm] >> 14));
             o.flag[i] = s.flag; o.l_seq[i] = (uint16_t)uzs_query_len(&s); o.n_cigar[i] = s.n_ops;
             o.mapq[i] = s.mapq; o.aux[i] = 1; /* mate on the same contig */
             for (int j = 0; j < s.n_ops; j++) o.cigar[C.cigar_off[c] + pre[p] + j] = s.ops[j];

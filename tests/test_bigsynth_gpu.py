@@ -116,7 +116,7 @@ def test_resident_pipeline_matches_oracle(workload, engine):
     co, ci, cf, ho, hi = engine.find(fid, dv, P, abi.FIND_SECOND_WINDOW)
     pool = PinnedPool()
     bounds = [0, 701, 1399, 2222, n]
-    rids, staged_bytes = [], 0
+    rids, staged_bytes, maps = [], 0, []
     for a, b in zip(bounds[:-1], bounds[1:]):
         alen = np.array([max(len(r), len(x)) for r, x in zip(dn.refs[a:b], dn.alts[a:b])], np.int64)
         fc, flo, fhi, fex = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P, allele_len=alen)
@@ -125,8 +125,11 @@ def test_resident_pipeline_matches_oracle(workload, engine):
         if (a // 700) % 2 == 1:
             pool.new_slab(256 << 20)
         part = src.select(fc, flo, fhi, alloc=pool.alloc, extra=fex if (a // 700) % 2 == 0 else None, tuples=(a // 700) % 3 != 2,
-                          start8=(a // 700) % 2 == 1)  # (start differences in eight / sixteen bits)
+                          start8=(a // 700) % 2 == 1,  # (start differences in eight / sixteen bits)
+                          pair8=(a // 700) == 1)       # (tlen / mate / name id in the pair form's one byte, or as eight- / sixteen-bit differences)
         pool.end_slab()
+        assert ("pair_d8" in part.arrays) == ((a // 700) == 1) and ("mate_d8" in part.arrays) == ((a // 700) == 3)
+        maps.append(part.qname_map)
         staged_bytes += sum(x.nbytes for x in part.arrays.values())
         part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))  # (plain views for the checks below; not staged)
         if "umask" in part.arrays:
@@ -136,7 +139,7 @@ def test_resident_pipeline_matches_oracle(workload, engine):
         assert 0.3 < (part.arrays["aux"][: part.view.n_segs] & abi.AUX_NO_SEQ).astype(bool).mean() < 0.6  # mates travel without bases
         rids.append(engine.upload_reads_packed(part))
     assert staged_bytes < 0.3 * sum(x.nbytes for x in full.arrays.values())
-    for (a, b), r in zip(zip(bounds[:-1], bounds[1:]), rids):
+    for (a, b), r, qmap in zip(zip(bounds[:-1], bounds[1:]), rids, maps):
         dvc = abi.dnms_view(dn.contig[a:b], dn.contig[a:b], dn.start[a:b], dn.end[a:b], np.zeros(b - a, np.uint8),
                             dn.refs[a:b], dn.alts[a:b], cutoff)
         res = engine.phase_raw(fid, r, dvc, P, abi.FIND_SECOND_WINDOW)
@@ -145,9 +148,57 @@ def test_resident_pipeline_matches_oracle(workload, engine):
         so, sv_ = engine.votes(b - a)
         for d in range(0, b - a, 7):
             for j in range(4):
-                assert np.array_equal(sv_[so[4 * d + j]: so[4 * d + j + 1]],
-                                      vv[vo[4 * (a + d) + j]: vo[4 * (a + d) + j + 1]]), (a + d, j)
+                mine = sv_[so[4 * d + j]: so[4 * d + j + 1]]
+                if j < 2 and qmap is not None:  # read lists hold name ids: the pair form numbered the chunk's names itself
+                    mine = qmap[mine]
+                assert np.array_equal(mine, vv[vo[4 * (a + d) + j]: vo[4 * (a + d) + j + 1]]), (a + d, j)
         engine.free_reads(r)
     pool.free_all()
+    engine.free_reads(rid)
+    engine.free_sites(sid)
+
+
+def test_read_stage_in_two_halves(workload, engine):
+    """uz_phase_begin / uz_phase_end: the batch queued, another batch's window emit run in between, the results handed out afterwards
+    -- the same as uz_phase's; a batch that outgrows the sizes it was queued on (those of the batch before it) is run again inside
+    uz_phase_end, with the same results."""
+    sc, dn, cl, cfg, wl = workload
+    P = abi.make_params()
+    engine.set_params(P)
+    sid = engine.adopt_sites(wl.sites_view())
+    fid = engine.adopt_family(sid, wl.family_view())
+    rid = engine.adopt_reads(wl.reads_view())
+    n = dn.n
+    cutoff = concordant_cutoff(wl.tlen_head(), P.readlen, 3)
+
+    def view(sel):
+        return abi.dnms_view(dn.contig[sel], dn.contig[sel], dn.start[sel], dn.end[sel], np.zeros(len(sel), np.uint8),
+                             [dn.refs[i] for i in sel], [dn.alts[i] for i in sel], cutoff)
+    everything = np.arange(n)
+    dv = view(everything)
+    got = engine.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+    a, b = everything[::2], everything[1::2]
+    dva, dvb = view(a), view(b)
+    want_a = engine.phase_raw(fid, rid, dva, P, abi.FIND_SECOND_WINDOW)
+    va = engine.votes(len(a))
+    engine.phase_begin(fid, rid, dva, P, abi.FIND_SECOND_WINDOW)
+    co, ci, cf, ho, hi = engine.find(fid, dvb, P, abi.FIND_SECOND_WINDOW)  # another batch's window lists, queued behind the read stage
+    assert co[-1] > 0
+    res = engine.phase_end(fid, rid, dva, P, abi.FIND_SECOND_WINDOW)
+    vb = engine.votes(len(a))
+    for k in ("status", "counts", "origin", "evidence"):
+        assert np.array_equal(res[k], want_a[k]) and np.array_equal(res[k], got[k][a]), k
+    assert np.array_equal(va[0], vb[0]) and np.array_equal(va[1], vb[1])
+    with pytest.raises(Exception):
+        engine.phase_end(fid, rid, dva, P, abi.FIND_SECOND_WINDOW)  # no batch is open
+    # a batch of DNMs without candidate sites leaves tiny sizes behind: the whole batch queued on those cannot fit
+    none = np.nonzero(got["status"] == abi.ST_NO_CAND)[0]
+    assert none.size >= 3
+    engine.phase_raw(fid, rid, view(none[:3]), P, abi.FIND_SECOND_WINDOW)
+    engine.phase_begin(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+    engine.find(fid, dvb, P, abi.FIND_SECOND_WINDOW)
+    again = engine.phase_end(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+    for k in ("status", "counts", "origin", "evidence"):
+        assert np.array_equal(again[k], got[k]), k
     engine.free_reads(rid)
     engine.free_sites(sid)

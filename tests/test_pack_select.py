@@ -192,8 +192,11 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
         # only as a mate) travels without its bases
         assert ("end" in part.arrays) == (not out_lists)  # (left out by default; the plane-form case below asks for it)
         for name, _ in abi.PACKED_RECORD_COLS:
-            if name not in ("mate", "aux") and name in part.arrays:
+            if name not in ("mate", "aux", "qname") and name in part.arrays:
                 assert np.array_equal(part.arrays[name][: idx.size], pk.arrays[name][idx]), name
+        # the pair form numbers the names of the selection by first appearance; qname_map leads back to the source's ids
+        assert "pair_d8" in part.arrays and part.view.n_qnames == part.qname_map.size and np.all(np.diff(part.qname_map.astype(np.int64)) > 0)
+        assert np.array_equal(part.qname_map[part.arrays["qname"][: idx.size]], pk.arrays["qname"][idx])
         no_seq = (part.arrays["aux"][: idx.size] & abi.AUX_NO_SEQ) != 0
         assert np.array_equal(no_seq, ~direct[idx]) and 0.3 < no_seq.mean() < 0.6
         SIMPLE = np.uint8(48)  # cigar_compact: a record that is one M / = / X over the read names the operation in its aux byte
@@ -344,3 +347,44 @@ def test_kernel_body_stays_inside_the_staged_units():
     um2, _ = masks_of(np.arange(fc.size) >= n)  # (fetch_points lists the n DNM fetches first)
     got2 = emu.phase(P, sh, rh, dv, found, no_seq=no_seq, umask=np.where(no_seq, um, um2))
     assert got2["base_err"] == 3
+
+
+def test_pair_form_codes_and_its_fallback():
+    """tlen / mate / name id in one byte (uz_types.h, pair_d8): every code of the form on a table with odd records -- a pair whose
+    template lengths are not its span, a record without a mate, a name carried by three records, mates further apart than a byte
+    reaches -- decodes to the source's columns; a source whose name ids do not ascend by first appearance keeps the eight-bit
+    differences (the pair form would renumber the names out of order)."""
+    sc, dn, cl, rh, arrs = _workload(40)
+    N = int(rh.view.n_segs)
+    mate, tlen, qname = arrs["mate"], arrs["tlen"], arrs["qname"]
+    firsts = np.nonzero(mate[:N] > np.arange(N))[0]
+    a, b, c, d = (int(firsts[k]) for k in (3, 40, 90, 150))
+    tlen[a] += 9; tlen[mate[a]] -= 9           # +-t for another t: the SECOND carries it
+    tlen[b] += 5                               # not even symmetric: both records spelled out
+    m = int(mate[c]); mate[c] = -1; mate[m] = -1  # no mates: a new name, then an old one
+    qname[d + 1 if mate[d] != d + 1 else d + 2] = qname[d]  # a third record with the name (and its own pair broken by that)
+    pk = io_native.pack_reads(rh, 20, with_end=True)
+    src = io_native.ReadsSource(pk)
+    contig_of = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    fc = np.unique(contig_of).astype(np.int32)
+    part, idx = src.select(fc, np.zeros(fc.size, np.int32), np.full(fc.size, 2 ** 31 - 1, np.int32), want_index=True)  # everything
+    assert idx.size == N and "pair_d8" in part.arrays
+    p = part.arrays["pair_d8"][:N]
+    assert p[a] <= 252 and p[mate[a]] == 253 and {int(p[b]), int(p[mate[b]])} == {254, 255} and p[c] == 254 and p[m] == 255
+    assert (p == 0).sum() > 0.9 * N / 2 and ((p >= 1) & (p <= 252)).sum() == ((p == 0) | (p == 253)).sum()
+    w = abi.wide_columns(part)
+    assert np.array_equal(w["start"], pk.arrays["start"][:N]) and np.array_equal(w["tlen"], tlen[:N]) and np.array_equal(w["mate"], mate[:N])
+    assert np.array_equal(part.qname_map[w["qname"]], qname[:N])
+    # far mates: keep one record in three of the source -- and shuffle nothing: the form still holds; then ids out of order
+    far = np.arange(N)
+    lo = pk.arrays["start"][:N][far[::97]].astype(np.int32)
+    part2, idx2 = src.select(contig_of[::97].astype(np.int32), lo, lo + 1, want_index=True)
+    w2 = abi.wide_columns(part2)
+    assert np.array_equal(w2["tlen"], tlen[idx2]) and np.array_equal(part2.qname_map[w2["qname"]], qname[idx2])
+    perm = np.random.default_rng(5).permutation(int(qname[:N].max()) + 1).astype(np.uint32)
+    arrs["qname"][:N] = perm[qname[:N]]
+    src3 = io_native.ReadsSource(io_native.pack_reads(rh, 20, with_end=True))
+    part3, idx3 = src3.select(contig_of[::97].astype(np.int32), lo, lo + 1, want_index=True)
+    assert "pair_d8" not in part3.arrays and "mate_d8" in part3.arrays and part3.qname_map is None
+    w3 = abi.wide_columns(part3)
+    assert np.array_equal(idx3, idx2) and np.array_equal(w3["qname"], arrs["qname"][idx3]) and np.array_equal(w3["tlen"], tlen[idx3])

@@ -1,0 +1,113 @@
+"""What the device makes of a table's fixed-width columns (uz_reads_headers) equals the source's columns in every form they can
+travel in: plain, 16-bit differences, 8-bit start / mate / name-id differences, the pair form (one byte for tlen, mate and name id)
+with every one of its codes -- FIRST / SECOND, a SECOND that brings its own template length, records spelled out in the escape list,
+with a new or an old name -- and straight from an indexed BAM (uz_bam_stage_*).  A pair form that contradicts itself is refused."""
+import numpy as np
+import pytest
+
+from test_pack_select import _workload
+from unfazed_amd import abi, io_native
+from unfazed_amd.engine import UnfazedHipError
+
+pytestmark = pytest.mark.gpu
+
+
+def _odd_table(n_dnms=40):
+    sc, dn, cl, rh, arrs = _workload(n_dnms)
+    N = int(rh.view.n_segs)
+    mate, tlen, qname = arrs["mate"], arrs["tlen"], arrs["qname"]
+    firsts = np.nonzero(mate[:N] > np.arange(N))[0]
+    a, b, c, d = (int(firsts[k]) for k in (3, 40, 90, 150))
+    tlen[a] += 9; tlen[mate[a]] -= 9
+    tlen[b] += 5
+    m = int(mate[c]); mate[c] = -1; mate[m] = -1
+    qname[d + 1 if mate[d] != d + 1 else d + 2] = qname[d]
+    return rh, arrs, N
+
+
+def test_every_form_decodes_to_the_source_columns(engine):
+    rh, arrs, N = _odd_table()
+    pk = io_native.pack_reads(rh, 20, with_end=True)
+    src = io_native.ReadsSource(pk)
+    contig_of = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    fc = np.unique(contig_of).astype(np.int32)
+    everything = (fc, np.zeros(fc.size, np.int32), np.full(fc.size, 2 ** 31 - 1, np.int32))
+    lo = arrs["start"][:N][::53].astype(np.int32)
+    some = (contig_of[::53].astype(np.int32), lo, lo + 1)
+    seen = set()
+    for fetches in (everything, some):
+        for kw in (dict(d16=False), dict(start8=False), dict(pair8=False, narrow8=False), dict(pair8=False), dict()):
+            part, idx = src.select(*fetches, want_index=True, **kw)
+            seen.add(tuple(sorted(k for k in part.arrays if k.endswith(("_d", "_d8", "_s")))))
+            rid = engine.upload_reads_packed(part)
+            got = engine.reads_headers(rid, idx.size)
+            engine.free_reads(rid)
+            new_of = np.full(N, -1, np.int64)
+            new_of[idx] = np.arange(idx.size)
+            m = arrs["mate"][:N][idx]
+            want_mate = np.where(m >= 0, new_of[np.maximum(m, 0)], -1)
+            assert np.array_equal(got["start"], arrs["start"][:N][idx]) and np.array_equal(got["end"], arrs["end"][:N][idx]), kw
+            assert np.array_equal(got["tlen"], arrs["tlen"][:N][idx]), kw
+            assert np.array_equal(got["mate"], want_mate), kw
+            q = got["qname"] if part.qname_map is None else part.qname_map[got["qname"]]
+            assert np.array_equal(q, arrs["qname"][:N][idx]), kw
+            if "pair_d8" in part.arrays:
+                p = part.arrays["pair_d8"][: idx.size]
+                assert set(np.unique(p[(p == 0) | (p > 252)]).tolist()) >= ({0, 253, 254, 255} if idx.size == N else {0})
+    assert len(seen) == 5
+
+
+def test_a_pair_form_that_contradicts_itself_is_refused(engine):
+    rh, arrs, N = _odd_table(20)
+    src = io_native.ReadsSource(io_native.pack_reads(rh, 20, with_end=True))
+    contig_of = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    fc = np.unique(contig_of).astype(np.int32)
+    for breakage in ("second_named_twice", "orphan_second", "first_names_a_first"):
+        part = src.select(fc, np.zeros(fc.size, np.int32), np.full(fc.size, 2 ** 31 - 1, np.int32))
+        p = part.arrays["pair_d8"]
+        f = np.nonzero((p[:N] >= 1) & (p[:N] <= 252))[0]
+        if breakage == "second_named_twice":  # two FIRST records name one SECOND (and another SECOND is left over)
+            i, j = int(f[5]), int(f[5]) + int(p[f[5]])
+            k = next(int(x) for x in f if x != i and 0 < j - int(x) <= 252)
+            p[k] = j - k
+        elif breakage == "orphan_second":     # a FIRST turned into a spelled-out record would need escapes: turn it into a SECOND instead
+            p[int(f[7])] = 0
+        else:
+            i = int(f[9])
+            k = next(int(x) for x in f if 0 < int(x) - i <= 252 and int(x) != i + int(p[i]))
+            p[i] = k - i
+        with pytest.raises(UnfazedHipError):
+            rid = engine.upload_reads_packed(part)
+            engine.wait_reads(rid)
+
+
+def test_staged_from_an_indexed_bam(engine, tmp_path):
+    from synth import bigsynth
+    from synth.sites_np import make_clusters, make_sites, place_dnms_full
+    sc = make_sites(40_000, seed=7, contig_lens=[6e6, 4e6, 2e6])
+    dn = place_dnms_full(sc, 60, seed=8, indel_frac=0.2)
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=9)
+    cfg.n_clusters = cl.n
+    bam = str(tmp_path / "kid.bam")
+    bigsynth.write_bam(bam, cfg, sc, dn, cl, 0, cl.n, level=1)
+    table = io_native.read_bam_table(bam, threads=2)
+    srcb = io_native.BamSource(bam, threads=2)
+    tid = dn.contig[::2].astype(np.int32)
+    lo = (dn.start[::2] - 1).astype(np.int32)
+    got = srcb.select(tid, lo, lo + 2, 20, extra=np.zeros(tid.size, np.uint16))
+    n = int(got.view.n_segs)
+    assert "pair_d8" in got.arrays and n > 1000
+    rid = engine.upload_reads_packed(got)
+    dev = engine.reads_headers(rid, n)
+    engine.free_reads(rid)
+    w = abi.wide_columns(got)
+    for k in ("start", "tlen", "mate", "qname"):
+        assert np.array_equal(dev[k], w[k]), k
+    assert np.array_equal(dev["end"], abi.record_ends(got, w["start"].astype(np.int64)))
+    # ... and those are the file's records: names and template lengths by name
+    by_name = {}
+    for i in range(table.start.size):
+        by_name.setdefault(table.qnames[int(table.qname[i])], []).append((int(table.start[i]), int(table.tlen[i])))
+    for i in range(0, n, 37):
+        assert (int(dev["start"][i]), int(dev["tlen"][i])) in by_name[got.qnames[int(dev["qname"][i])]]

@@ -180,10 +180,12 @@ class ReadsPackedView(C.Structure):
         ("start_d", _p), ("tlen_s", _p), ("mate_d", _p), ("qname_d", _p), ("esc16_key", _p), ("esc16_val", _p), ("n_esc16", C.c_int64),
         ("start_d8", _p),  # the start differences in eight bits (start_d then NULL)
         ("mate_d8", _p), ("qname_d8", _p),  # mate / name-id differences in eight bits (mate_d / qname_d then NULL)
+        ("pair_d8", _p),  # the pair form: tlen, mate and name id in one byte (with start_d8; the other difference columns then NULL)
     ]
 
 
 AUX_NO_SEQ = 8
+AUX_SIMPLE_MASK = 48  # cigar_compact: the record's one M / = / X operation is named by its aux byte
 # per-record columns of the packed view and their element types
 PACKED_RECORD_COLS = [("start", np.int32), ("end", np.int32), ("tlen", np.int32), ("mate", np.int32), ("qname", np.uint32),
                       ("flag", np.uint16), ("l_seq", np.uint16), ("n_cigar", np.uint16), ("mapq", np.uint8), ("aux", np.uint8)]
@@ -198,7 +200,7 @@ def row_units(l_seq):
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
                       qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False,
-                      narrow8=False) -> "Held":
+                      narrow8=False, pair8=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -208,6 +210,7 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     n_tup: None = the plain small columns; a number = the dictionary form with that many combinations (tup + tup_* instead of flag,
     l_seq, n_cigar, mapq, aux and n_low).
     n_esc16: None = start / tlen / mate / qname as 32-bit columns; a number = as 16-bit differences with that many escapes.
+    pair8 (with start8): tlen, mate and name id in the pair form's one byte (pair_d8) instead of tlen_s / mate_d* / qname_d*.
     cigar_omitted: None = every CIGAR word; a number = cigar_compact with that many simple records (n_cigar_total is the plain total:
     the words that stay home are taken off here)."""
     if n_seq_units is None:
@@ -258,11 +261,14 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     if n_esc16 is not None:
         if start8:
             arrs["start_d8"] = alloc(max(1, n))[: max(1, n)]
+        if pair8:
+            assert start8 and not narrow8
+            arrs["pair_d8"] = alloc(max(1, n))[: max(1, n)]
         if narrow8:  # (with start8) mate / name-id differences as signed bytes
             assert start8
             for name in ("mate_d8", "qname_d8"):
                 arrs[name] = alloc(max(1, n))[: max(1, n)].view(np.int8)
-        for name in (("tlen_s",) if narrow8 else ("tlen_s", "mate_d", "qname_d")) if start8 else ("start_d", "tlen_s", "mate_d", "qname_d"):
+        for name in (() if pair8 else ("tlen_s",) if narrow8 else ("tlen_s", "mate_d", "qname_d")) if start8 else ("start_d", "tlen_s", "mate_d", "qname_d"):
             arrs[name] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.int16)
         arrs["esc16_key"] = alloc(8 * max(1, n_esc16))[: 8 * max(1, n_esc16)].view(np.uint64)
         arrs["esc16_val"] = alloc(4 * max(1, n_esc16))[: 4 * max(1, n_esc16)].view(np.int32)
@@ -285,6 +291,8 @@ def wide_columns(held: "Held") -> dict:
     key, val = a["esc16_key"][:ne], a["esc16_val"][:ne].astype(np.int64)
     assert np.all(np.diff(key.astype(np.int64)) > 0)
     out = {}
+    if "pair_d8" in a:
+        return _pair_columns(held, key, val)
     for col, (name, src) in enumerate((("start", "start_d8" if "start_d8" in a else "start_d"), ("tlen", "tlen_s"),
                                        ("mate", "mate_d8" if "mate_d8" in a else "mate_d"), ("qname", "qname_d8" if "qname_d8" in a else "qname_d"))):
         v = a[src][:n].astype(np.int64)
@@ -301,6 +309,61 @@ def wide_columns(held: "Held") -> dict:
             v = np.where(none, -1, np.where(esc, v, v + np.arange(n)))
         out[name] = v.astype(np.uint32 if name == "qname" else np.int32)
     return out
+
+
+def record_ends(held: "Held", start: np.ndarray) -> np.ndarray:
+    """`end` of every record of a packed view: the column, or what the device derives when it was left out (htslib's bam_endpos)"""
+    a, n = held.arrays, int(held.view.n_segs)
+    if "end" in a:
+        return a["end"][:n].astype(np.int64)
+    sm = small_columns(held)
+    flag, ncig, lseq, aux = (sm[k].astype(np.int64) for k in ("flag", "n_cigar", "l_seq", "aux"))
+    compact = bool(held.view.cigar_compact)
+    simple = ((aux & AUX_SIMPLE_MASK) != 0) if compact else np.zeros(n, bool)
+    words_of = np.where(simple, 0, ncig)
+    off = np.concatenate([[0], np.cumsum(words_of)])
+    cig = a["cigar"]
+    ref_len = np.where(simple, lseq, 0).astype(np.int64)
+    for i in np.nonzero(~simple & (ncig > 0))[0]:
+        w = cig[off[i]: off[i] + ncig[i]].astype(np.int64)
+        op = w & 15
+        ref_len[i] = int((w >> 4)[(op == 0) | (op == 2) | (op == 3) | (op == 7) | (op == 8)].sum())
+    unmapped = (flag & 4) != 0
+    return np.where(unmapped | (ncig == 0), start + 1, start + np.maximum(ref_len, 1))
+
+
+def _pair_columns(held: "Held", key, val) -> dict:
+    """the pair form (uz_types.h, pair_d8) back to start / tlen / mate / qname, as the device rebuilds them"""
+    a, n = held.arrays, int(held.view.n_segs)
+    def esc(col):
+        sel = (key & np.uint64(3)) == col
+        return (key[sel] >> np.uint64(2)).astype(np.int64), val[sel]
+    sd = a["start_d8"][:n].astype(np.int64)
+    rec, v = esc(0)
+    assert np.array_equal(np.nonzero(sd == 255)[0], rec)
+    sd[rec] = v
+    start = (np.cumsum(sd) & 0xFFFFFFFF).astype(np.uint32).view(np.int32).astype(np.int64)
+    p = a["pair_d8"][:n].astype(np.int64)
+    first, second, given, new, old = (p >= 1) & (p <= 252), (p == 0) | (p == 253), p == 253, p == 254, p == 255
+    other = new | old
+    assert np.array_equal(np.nonzero(other | given)[0], esc(1)[0]) and np.array_equal(np.nonzero(other)[0], esc(2)[0])
+    rec3, v3 = esc(3)
+    assert np.array_equal(np.nonzero(old)[0], rec3)
+    qname = np.cumsum(first | new) - 1
+    qname[rec3] = v3
+    mate = np.full(n, -1, np.int64)
+    tlen = np.zeros(n, np.int64)
+    tlen[other | given] = esc(1)[1]
+    mate[other] = esc(2)[1]
+    fi = np.nonzero(first)[0]
+    fj = fi + p[fi]
+    assert fi.size == int(second.sum()) and (fj.size == 0 or fj.max() < n) and np.all(second[fj]) and np.unique(fj).size == fj.size
+    end = record_ends(held, start)
+    span = np.where(given[fj], -tlen[fj], np.maximum(end[fi], end[fj]) - start[fi])
+    mate[fi], mate[fj] = fj, fi
+    tlen[fi], tlen[fj] = span, -span
+    qname[fj] = qname[fi]
+    return {"start": start.astype(np.int32), "tlen": tlen.astype(np.int32), "mate": mate.astype(np.int32), "qname": qname.astype(np.uint32)}
 
 
 def small_columns(held: "Held") -> dict:

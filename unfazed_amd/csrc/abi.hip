@@ -271,13 +271,14 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d) {
     size_t off[10];
     off[0] = 0;
     for (int k = 0; k < 9; k++) off[k + 1] = (off[k] + sizes[k] + 63) & ~(size_t)63;
+    // (an earlier batch's copies out of the buffer are usually long done -- every entry point but uz_phase_begin ends with a stream sync)
+    if (c->dn_stage_done) UZ_HIP(hipEventSynchronize(c->dn_stage_done));
     if (c->dn_stage_cap < off[9]) {
         if (c->dn_stage) (void)hipHostFree(c->dn_stage);
         c->dn_stage = nullptr;
         c->dn_stage_cap = off[9] + off[9] / 4 + 4096;
         UZ_HIP(hipHostMalloc((void **)&c->dn_stage, c->dn_stage_cap, hipHostMallocDefault));
     }
-    // an earlier batch's copies out of this buffer have completed: every entry point ends with a stream sync
     const void *src[9] = {d->contig, d->rcontig, d->start, d->end, d->vartype, d->dflags, d->mult, d->allele_off, d->alleles};
     for (int k = 0; k < 9; k++)
         if (sizes[k]) memcpy(c->dn_stage + off[k], src[k], sizes[k]);
@@ -288,6 +289,8 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d) {
                     c->dn.allele_off.p, c->dn.alleles.p};
     for (int k = 0; k < 9; k++)
         if (sizes[k]) uz_kcopy(c, dst[k], c->dn_stage + off[k], sizes[k]); // out of the pinned staging buffer, by a kernel
+    if (!c->dn_stage_done) UZ_HIP(hipEventCreateWithFlags(&c->dn_stage_done, hipEventDisableTiming));
+    UZ_HIP(hipEventRecord(c->dn_stage_done, c->stream));
     c->dn.cutoff = d->cutoff;
 }
 
@@ -330,6 +333,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.contig.release(); c->dn.rcontig.release(); c->dn.start.release(); c->dn.end.release();
     c->dn.vartype.release(); c->dn.dflags.release(); c->dn.mult.release(); c->dn.allele_off.release();
     c->dn.alleles.release();
+    if (c->dn_stage_done) (void)hipEventDestroy(c->dn_stage_done);
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
     c->ab_lut.release(); c->win_range.release();
     c->dn_fam.release(); c->dn_cutoff.release(); c->fam_cls.release();
@@ -601,7 +605,9 @@ static void check_packed_view(const uz_reads_packed_view *v) {
         UZ_REQUIRE(!(v->start_d && v->start_d8), UZ_E_ARG, "start_d and start_d8 are both set");
         const bool n8 = v->mate_d8 != nullptr || v->qname_d8 != nullptr;
         UZ_REQUIRE(!n8 || (v->start_d8 && v->mate_d8 && v->qname_d8 && !v->mate_d && !v->qname_d), UZ_E_ARG, "mate_d8 and qname_d8 come together, with start_d8, instead of mate_d / qname_d");
-        UZ_REQUIRE(v->tlen_s && (n8 || (v->mate_d && v->qname_d)) && v->n_esc16 >= 0 && (v->n_esc16 == 0 || (v->esc16_key && v->esc16_val)), UZ_E_ARG, "bad 16-bit difference columns");
+        if (v->pair_d8)
+            UZ_REQUIRE(v->start_d8 && !v->tlen_s && !v->mate_d && !v->qname_d && !n8, UZ_E_ARG, "pair_d8 comes with start_d8, instead of tlen_s / mate_d* / qname_d*");
+        UZ_REQUIRE((v->pair_d8 || (v->tlen_s && (n8 || (v->mate_d && v->qname_d)))) && v->n_esc16 >= 0 && (v->n_esc16 == 0 || (v->esc16_key && v->esc16_val)), UZ_E_ARG, "bad 16-bit difference columns");
         UZ_REQUIRE(!v->start && !v->tlen && !v->mate && !v->qname, UZ_E_ARG, "start_d / start_d8 is set: start / tlen / mate / qname must be NULL");
     }
     if (v->tup) {
@@ -639,11 +645,13 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
     const bool d8 = v->start_d8 != nullptr;
     const bool n8 = v->mate_d8 != nullptr;
+    const bool p8 = v->pair_d8 != nullptr;
     const bool d16 = v->start_d != nullptr || d8;
     const size_t nes = d16 ? (size_t)v->n_esc16 : 0;
     int16_t *d_start = nullptr, *d_tlen = nullptr, *d_mate = nullptr, *d_qname = nullptr;
     uint8_t *d_start8 = nullptr;
     int8_t *d_mate8 = nullptr, *d_qname8 = nullptr;
+    uint8_t *d_pair8 = nullptr;
     unsigned long long *e_key = nullptr; int32_t *e_val = nullptr;
     void *scratch = nullptr;
     for (int pass = 0; pass < 2; pass++) {
@@ -653,8 +661,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         if (ccompact) cigar_staged = cv.take<uint32_t>(ncs);
         if (d16) {
             d_start = cv.take<int16_t>(d8 ? 0 : n); d_start8 = cv.take<uint8_t>(d8 ? n : 0);
-            d_tlen = cv.take<int16_t>(n); d_mate = cv.take<int16_t>(n8 ? 0 : n); d_qname = cv.take<int16_t>(n8 ? 0 : n);
-            d_mate8 = cv.take<int8_t>(n8 ? n : 0); d_qname8 = cv.take<int8_t>(n8 ? n : 0);
+            d_tlen = cv.take<int16_t>(p8 ? 0 : n); d_mate = cv.take<int16_t>(n8 || p8 ? 0 : n); d_qname = cv.take<int16_t>(n8 || p8 ? 0 : n);
+            d_mate8 = cv.take<int8_t>(n8 ? n : 0); d_qname8 = cv.take<int8_t>(n8 ? n : 0); d_pair8 = cv.take<uint8_t>(p8 ? n : 0);
             e_key = cv.take<unsigned long long>(nes); e_val = cv.take<int32_t>(nes);
         }
         seq4 = cv.take<uint8_t>(ns * UZ_SEQ4_UNIT_BYTES);
@@ -690,9 +698,12 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     if (d16) { // 16-bit differences + the escape list instead of four 32-bit columns
         if (d8) col.start_d8 = h2d(st, d_start8, v->start_d8, n);
         else col.start_d = h2d(st, d_start, v->start_d, n);
-        col.tlen_s = h2d(st, d_tlen, v->tlen_s, n);
-        if (n8) { col.mate_d8 = h2d(st, d_mate8, v->mate_d8, n); col.qname_d8 = h2d(st, d_qname8, v->qname_d8, n); }
-        else { col.mate_d = h2d(st, d_mate, v->mate_d, n); col.qname_d = h2d(st, d_qname, v->qname_d, n); }
+        if (p8) col.pair_d8 = h2d(st, d_pair8, v->pair_d8, n);
+        else {
+            col.tlen_s = h2d(st, d_tlen, v->tlen_s, n);
+            if (n8) { col.mate_d8 = h2d(st, d_mate8, v->mate_d8, n); col.qname_d8 = h2d(st, d_qname8, v->qname_d8, n); }
+            else { col.mate_d = h2d(st, d_mate, v->mate_d, n); col.qname_d = h2d(st, d_qname, v->qname_d, n); }
+        }
         col.esc16_key = h2d(st, e_key, (const unsigned long long *)v->esc16_key, nes); col.esc16_val = h2d(st, e_val, v->esc16_val, nes);
         col.n_esc16 = (int64_t)nes;
         col.start = nullptr; col.tlen = nullptr; col.mate = nullptr; col.qname = nullptr;
@@ -744,8 +755,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         const void *t[8] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low, col.tup_umask};
         for (int k = 0; k < 8; k++) r.col_t[k] = t[k];
         r.col_lists = col.lists;
-        const void *dd[9] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8, col.mate_d8, col.qname_d8};
-        for (int k = 0; k < 9; k++) r.col_d[k] = dd[k];
+        const void *dd[10] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8, col.mate_d8, col.qname_d8, col.pair_d8};
+        for (int k = 0; k < 10; k++) r.col_d[k] = dd[k];
         r.col_nesc = col.n_esc16;
     }
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
@@ -774,7 +785,7 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.start_d = (const int16_t *)r.col_d[0]; col.tlen_s = (const int16_t *)r.col_d[1]; col.mate_d = (const int16_t *)r.col_d[2];
     col.qname_d = (const int16_t *)r.col_d[3]; col.esc16_key = (const unsigned long long *)r.col_d[4]; col.esc16_val = (const int32_t *)r.col_d[5];
     col.start_d8 = (const uint8_t *)r.col_d[6];
-    col.mate_d8 = (const int8_t *)r.col_d[7]; col.qname_d8 = (const int8_t *)r.col_d[8];
+    col.mate_d8 = (const int8_t *)r.col_d[7]; col.qname_d8 = (const int8_t *)r.col_d[8]; col.pair_d8 = (const uint8_t *)r.col_d[9];
     col.n_esc16 = r.col_nesc;
     col.qpos_wide = r.col_qwide;
     uz_build_records(c, c->stream, r, col, r.build_scratch);
@@ -877,6 +888,34 @@ int uz_reads_wait(uz_ctx *c, int reads_id) {
     });
 }
 
+int uz_reads_headers(uz_ctx *c, int reads_id, int32_t *start, int32_t *end, int32_t *tlen, int32_t *mate, uint32_t *qname) {
+    return guarded(c, [&] {
+        ReadsDev &r = reads_of(c, reads_id);
+        uz_reads_make_ready(c, r);
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        if (c->hflags[0]) {
+            c->hflags[0] = 0;
+            throw UzError{UZ_E_RANGE, "inconsistent reads view"};
+        }
+        struct HA { int32_t start, end; uint32_t cigar_off, sq_off; }; // the record headers (RecA / RecB of phase_body.hpp)
+        struct HB { int32_t mate; uint32_t qname; uint16_t l_seq, n_cigar; int32_t tlen; };
+        const size_t n = (size_t)r.n;
+        std::vector<HA> a(n);
+        std::vector<HB> b(n);
+        if (n) {
+            UZ_HIP(hipMemcpy(a.data(), r.rec_a, n * sizeof(HA), hipMemcpyDeviceToHost));
+            UZ_HIP(hipMemcpy(b.data(), r.rec_b, n * sizeof(HB), hipMemcpyDeviceToHost));
+        }
+        for (size_t i = 0; i < n; i++) {
+            if (start) start[i] = a[i].start;
+            if (end) end[i] = a[i].end;
+            if (tlen) tlen[i] = b[i].tlen;
+            if (mate) mate[i] = b[i].mate;
+            if (qname) qname[i] = b[i].qname;
+        }
+    });
+}
+
 int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
@@ -909,7 +948,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             col.start = v->start; col.end = v->end; col.tlen = v->tlen; col.mate = v->mate; col.qname = v->qname;
             if (v->start_d || v->start_d8) {
                 col.start_d = v->start_d; col.start_d8 = v->start_d8; col.tlen_s = v->tlen_s; col.mate_d = v->mate_d; col.qname_d = v->qname_d;
-                col.mate_d8 = v->mate_d8; col.qname_d8 = v->qname_d8;
+                col.mate_d8 = v->mate_d8; col.qname_d8 = v->qname_d8; col.pair_d8 = v->pair_d8;
                 col.esc16_key = (const unsigned long long *)v->esc16_key; col.esc16_val = v->esc16_val; col.n_esc16 = v->n_esc16;
             }
             col.flag = v->flag; col.l_seq = v->l_seq; col.n_cigar = v->n_cigar; col.mapq = v->mapq; col.aux = v->aux;
@@ -1075,6 +1114,42 @@ int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int fin
         uz_launch_find(c, f, s, find_mode, false);
         c->find_fam = fam_id;
         uz_launch_phase(c, f, s, r, status, counts, origin, evidence);
+    });
+}
+
+// uz_phase in two halves (unfazed_hip.h)
+static void phase_whole(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode, int32_t *status, int32_t *counts, int32_t *origin,
+                        int32_t *evidence, bool defer) {
+    FamilyDev &f = fam_of(c, fam_id);
+    SitesDev &s = sites_of(c, f.sites_id);
+    ReadsDev &r = reads_of(c, reads_id);
+    UZ_REQUIRE(d != nullptr, UZ_E_ARG, "null DNM view");
+    UZ_REQUIRE(!(find_mode & UZ_FIND_WHOLE_REGION), UZ_E_ARG, "the read stage runs on SNV / breakpoint windows");
+    c->find_valid = false;
+    c->phase_valid = false;
+    c->phase_qbase.clear();
+    uz_stage_dnms(c, d);
+    if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
+    uz_launch_find(c, f, s, find_mode, false);
+    c->find_fam = fam_id;
+    uz_launch_phase(c, f, s, r, status, counts, origin, evidence, defer);
+}
+int uz_phase_begin(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(!c->phase_open, UZ_E_STATE, "uz_phase_begin: the batch before this one is still open (uz_phase_end)");
+        phase_whole(c, fam_id, reads_id, d, find_mode, nullptr, nullptr, nullptr, nullptr, true);
+        c->phase_open = true;
+    });
+}
+int uz_phase_end(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode, int32_t *status, int32_t *counts, int32_t *origin,
+                 int32_t *evidence) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(c->phase_open, UZ_E_STATE, "uz_phase_end without uz_phase_begin");
+        c->phase_open = false;
+        if (uz_finish_phase(c, status, counts, origin, evidence)) return;
+        // the batch outgrew the sizes it was run on: once more, whole, on its own sizes (the DNMs and the window lists of the
+        // context may be another batch's by now)
+        phase_whole(c, fam_id, reads_id, d, find_mode, status, counts, origin, evidence, false);
     });
 }
 

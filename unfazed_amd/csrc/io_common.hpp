@@ -291,6 +291,40 @@ void parallel_dynamic(int64_t n, int threads, F fn) { // fn(item, worker): items
     });
 }
 
+// ---- the pair form of tlen / mate / name id (uz_reads_packed_view.pair_d8): what both packers ask of one output record
+struct PairRec {
+    int64_t mate;   // output index of the record mate() returns, -1 = none
+    int32_t start, end, tlen;
+    uint32_t qid;   // name id as the output numbers it (first appearance)
+    bool is_new;    // the first record of the output carrying its name
+};
+// code of output record k; get(j) -> PairRec of output record j.  A pair gets the FIRST / SECOND codes only when every statement
+// the device rebuilds it from holds: the two name each other, lie at most UZ_P8_MAX_DIST records apart, the earlier one brings the
+// name, and the template lengths are +-t (t = the span of the pair, or the SECOND carries its own).
+template <typename Get>
+inline uint8_t pair8_code(int64_t k, Get &&get) {
+    const PairRec x = get(k);
+    if (x.mate >= 0 && x.mate != k) {
+        const int64_t a = std::min(k, x.mate), b = std::max(k, x.mate);
+        if (b - a <= UZ_P8_MAX_DIST) {
+            const PairRec A = a == k ? x : get(a), B = b == k ? x : get(b);
+            const int64_t span = (int64_t)std::max(A.end, B.end) - (int64_t)A.start;
+            if (A.mate == b && B.mate == a && A.is_new && !B.is_new && B.qid == A.qid && (int64_t)B.tlen == -(int64_t)A.tlen && span < 0x7FFFFFFFLL)
+                return a == k ? (uint8_t)(b - a) : ((int64_t)A.tlen == span ? (uint8_t)UZ_P8_SECOND : (uint8_t)UZ_P8_SECOND_TLEN);
+        }
+    }
+    return x.is_new ? (uint8_t)UZ_P8_NEW : (uint8_t)UZ_P8_OLD;
+}
+// the escape-list entries a record of the pair form owns besides its start: e[1] tlen, e[2] mate, e[3] name id; returns how many (0 .. 3)
+inline int pair8_escapes(uint8_t code, const PairRec &x, int32_t e[4], bool has[4]) {
+    has[1] = has[2] = has[3] = false;
+    if (code == UZ_P8_SECOND_TLEN) { has[1] = true; e[1] = x.tlen; return 1; }
+    if (code != UZ_P8_NEW && code != UZ_P8_OLD) return 0;
+    has[1] = has[2] = true; e[1] = x.tlen; e[2] = (int32_t)x.mate;
+    if (code == UZ_P8_OLD) { has[3] = true; e[3] = (int32_t)x.qid; }
+    return code == UZ_P8_OLD ? 3 : 2;
+}
+
 // whole file -> memory
 Bytes read_file(const char *path);
 // gzip / BGZF stream -> bytes.  BGZF blocks (BC extra field) are inflated in parallel, any other

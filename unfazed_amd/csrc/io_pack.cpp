@@ -115,6 +115,13 @@ struct uz_select {
     int64_t n_esc16 = 0;                // escapes of the 16-bit difference form of start / tlen / mate / qname (uz_d16_of)
     int64_t n_esc16_start8 = 0;         // ... when the start differences travel in eight bits (start_d8)
     int64_t n_esc16_narrow8 = 0;        // ... and the mate / name-id differences too (mate_d8, qname_d8)
+    // the pair form (pair_d8): a new name's id is the number of new names before it, so the output numbers the names of the selection
+    // by first appearance; that keeps the ORDER of the source's ids (what the read stage sorts pairs by) only when the source's ids
+    // ascend by first appearance too -- checked by the plan
+    int pair8_ok = 0;
+    int64_t n_esc16_pair8 = 0;
+    std::vector<uint8_t> is_new;        // per kept record: the first of the selection with its name
+    std::vector<uint32_t> new_ids;      // source id of every new name, ascending = in order of appearance: output id -> source id
     int64_t n_cigar_simple = 0;         // kept records whose CIGAR is one M / = / X over the read (their words can stay home)
     int end_derivable = 1;              // every kept record's end is what its CIGAR gives (the output may leave the column out)
     std::vector<uint8_t> n_low;         // per kept record: low-quality bases (saturated), for the list form of the output
@@ -157,6 +164,35 @@ static inline int uz_d16_of(const uz_select *s, int64_t k, int16_t v[4], int32_t
     const int32_t dq = (int32_t)(f->qname[i] - (ip >= 0 ? f->qname[ip] : 0u)); // modulo 2^32
     put(3, dq, dq);
     return n;
+}
+
+// the pair form's view of kept record k (io_common.hpp)
+static inline int64_t sel_rank(const uz_select *s, int64_t src_index) {
+    auto it = std::lower_bound(s->index.begin(), s->index.end(), src_index, [](int32_t v, int64_t key) { return (int64_t)v < key; });
+    return (it != s->index.end() && *it == src_index) ? (int64_t)(it - s->index.begin()) : -1;
+}
+static inline PairRec sel_pair_rec(const uz_select *s, int64_t k) {
+    const uz_reads_packed_view *f = &s->src->v;
+    const int64_t i = s->index[(size_t)k];
+    PairRec r;
+    const int32_t mt = f->mate[i];
+    r.mate = (mt >= 0 && mt < f->n_segs) ? sel_rank(s, mt) : -1;
+    r.start = f->start[i]; r.end = f->end[i]; r.tlen = f->tlen[i];
+    r.is_new = s->is_new[(size_t)k] != 0;
+    r.qid = (uint32_t)(std::lower_bound(s->new_ids.begin(), s->new_ids.end(), f->qname[i]) - s->new_ids.begin()); // rank of the source id = output id
+    return r;
+}
+static inline int sel_link_of(const uz_select *s, int64_t k, uint8_t &start8, uint8_t &pair, int32_t e[4], bool has[4]) {
+    const uz_reads_packed_view *f = &s->src->v;
+    const int64_t i = s->index[(size_t)k];
+    const int64_t ip = k > 0 ? s->index[(size_t)k - 1] : -1;
+    const int64_t ds = (int64_t)f->start[i] - (ip >= 0 ? (int64_t)f->start[ip] : 0);
+    int n = 0;
+    has[0] = !(ds >= 0 && ds <= 254);
+    if (has[0]) { start8 = (uint8_t)UZ_D8_ESC; e[0] = (int32_t)ds; n++; }
+    else start8 = (uint8_t)ds;
+    pair = pair8_code(k, [&](int64_t j) { return sel_pair_rec(s, j); });
+    return n + pair8_escapes(pair, sel_pair_rec(s, k), e, has);
 }
 
 extern "C" {
@@ -563,6 +599,51 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
             });
             for (int k = 0; k < wk; k++) { sel->n_esc16 += part[(size_t)k]; sel->n_esc16_start8 += part8[(size_t)k]; sel->n_esc16_narrow8 += partn[(size_t)k]; }
         }
+        { // the pair form: new names by the running maximum of the ids, then every other record's id must be one of them
+            const int64_t m = sel->n_sel;
+            const int wk = workers_for(m, threads, 1 << 14);
+            std::vector<int64_t> smax((size_t)wk + 1, -1), cnt((size_t)wk + 1, 0);
+            parallel_slices(m, wk, [&](int64_t a, int64_t b, int slice) {
+                int64_t mx = -1;
+                for (int64_t k = a; k < b; k++) mx = std::max(mx, (int64_t)full->qname[sel->index[(size_t)k]]);
+                smax[(size_t)slice + 1] = mx;
+            });
+            for (int k = 0; k < wk; k++) smax[(size_t)k + 1] = std::max(smax[(size_t)k + 1], smax[(size_t)k]);
+            sel->is_new.assign((size_t)m, 0);
+            parallel_slices(m, wk, [&](int64_t a, int64_t b, int slice) {
+                int64_t mx = smax[(size_t)slice], c = 0;
+                for (int64_t k = a; k < b; k++) {
+                    const int64_t q = full->qname[sel->index[(size_t)k]];
+                    if (q > mx) { sel->is_new[(size_t)k] = 1; mx = q; c++; }
+                }
+                cnt[(size_t)slice + 1] = c;
+            });
+            for (int k = 0; k < wk; k++) cnt[(size_t)k + 1] += cnt[(size_t)k];
+            sel->new_ids.assign((size_t)cnt[(size_t)wk], 0);
+            parallel_slices(m, wk, [&](int64_t a, int64_t b, int slice) {
+                int64_t at = cnt[(size_t)slice];
+                for (int64_t k = a; k < b; k++)
+                    if (sel->is_new[(size_t)k]) sel->new_ids[(size_t)at++] = full->qname[sel->index[(size_t)k]];
+            });
+            std::atomic<int> ok{1};
+            std::vector<int64_t> part((size_t)wk + 1, 0);
+            parallel_slices(m, wk, [&](int64_t a, int64_t b, int) {
+                for (int64_t k = a; k < b && ok.load(std::memory_order_relaxed); k++)
+                    if (!sel->is_new[(size_t)k] && !std::binary_search(sel->new_ids.begin(), sel->new_ids.end(), full->qname[sel->index[(size_t)k]])) ok.store(0);
+            });
+            sel->pair8_ok = ok.load();
+            if (sel->pair8_ok) {
+                parallel_slices(m, wk, [&](int64_t a, int64_t b, int slice) {
+                    int64_t c = 0;
+                    uint8_t s8, p8;
+                    int32_t e[4];
+                    bool has[4];
+                    for (int64_t k = a; k < b; k++) c += sel_link_of(sel, k, s8, p8, e, has);
+                    part[(size_t)slice] = c;
+                });
+                for (int k = 0; k < wk; k++) sel->n_esc16_pair8 += part[(size_t)k];
+            }
+        }
         if (full->seq2) { // the listed bases of the kept records that keep their bases
             sel->exc_lo.assign((size_t)sel->n_sel, 0);
             sel->exc_n.assign((size_t)sel->n_sel, 0);
@@ -589,6 +670,14 @@ int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 
 int64_t uz_select_n_esc16(const uz_select *s) { return s ? s->n_esc16 : 0; }
 int64_t uz_select_n_esc16_start8(const uz_select *s) { return s ? s->n_esc16_start8 : 0; }
 int64_t uz_select_n_esc16_narrow8(const uz_select *s) { return s ? s->n_esc16_narrow8 : 0; }
+int uz_select_pair8_ok(const uz_select *s) { return s ? s->pair8_ok : 0; }
+int64_t uz_select_n_esc16_pair8(const uz_select *s) { return (s && s->pair8_ok) ? s->n_esc16_pair8 : -1; }
+int64_t uz_select_n_new_names(const uz_select *s) { return s ? (int64_t)s->new_ids.size() : 0; }
+int uz_select_qname_map(const uz_select *s, uint32_t *out) {
+    if (!s || !out) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    if (!s->new_ids.empty()) memcpy(out, s->new_ids.data(), s->new_ids.size() * sizeof(uint32_t));
+    return UZ_IO_OK;
+}
 int64_t uz_select_n_tuples(const uz_select *s) { return (s && s->tuples) ? (int64_t)s->tup_key.size() : -1; }
 int64_t uz_select_n_cigar_omitted(const uz_select *s) { return s ? s->n_cigar_simple : 0; }
 int uz_select_qlow_pos_wide(const uz_select *s) {
@@ -619,12 +708,18 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
         if (!out->end && !s->end_derivable) fail(UZ_IO_E_ARG, "the `end` column was left out but a kept record's end is not what its CIGAR gives (uz_select_end_derivable)");
         const bool start8 = out->start_d8 != nullptr;
         const bool narrow8 = out->mate_d8 != nullptr || out->qname_d8 != nullptr;
+        const bool pair8 = out->pair_d8 != nullptr;
         const bool d16 = out->start_d != nullptr || start8;
+        if (pair8) {
+            if (!s->pair8_ok) fail(UZ_IO_E_ARG, "the pair form (pair_d8) is not available for this selection: the name ids of the source do not ascend by first appearance (uz_select_pair8_ok)");
+            if (!start8 || narrow8 || out->tlen_s || out->mate_d || out->qname_d) fail(UZ_IO_E_ARG, "pair_d8 comes with start_d8, instead of tlen_s / mate_d* / qname_d*");
+            out->n_qnames = (uint32_t)s->new_ids.size(); // the names of the selection, numbered by first appearance (uz_select_qname_map)
+        }
         if (start8 && out->start_d) fail(UZ_IO_E_ARG, "start_d and start_d8 are both set");
         if (narrow8 && (!start8 || !out->mate_d8 || !out->qname_d8 || out->mate_d || out->qname_d))
             fail(UZ_IO_E_ARG, "mate_d8 and qname_d8 come together, with start_d8, instead of mate_d / qname_d");
-        const int64_t n_esc = narrow8 ? s->n_esc16_narrow8 : start8 ? s->n_esc16_start8 : s->n_esc16;
-        if (d16 && (!out->tlen_s || (!narrow8 && (!out->mate_d || !out->qname_d)) || (n_esc && (!out->esc16_key || !out->esc16_val))))
+        const int64_t n_esc = pair8 ? s->n_esc16_pair8 : narrow8 ? s->n_esc16_narrow8 : start8 ? s->n_esc16_start8 : s->n_esc16;
+        if (d16 && ((!pair8 && (!out->tlen_s || (!narrow8 && (!out->mate_d || !out->qname_d)))) || (n_esc && (!out->esc16_key || !out->esc16_val))))
             fail(UZ_IO_E_ARG, "the 16-bit difference form needs start_d (or start_d8), tlen_s, mate_d, qname_d (or mate_d8, qname_d8) and the esc16_* list");
         out->n_esc16 = d16 ? n_esc : 0;
         std::vector<int64_t> esc_at; // first escape of every slice of the fill loop below
@@ -635,7 +730,9 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 int64_t c = 0;
                 int16_t v[4];
                 int32_t e[4];
-                for (int64_t k = a; k < b; k++) c += uz_d16_of(s, k, v, e, start8, narrow8);
+                uint8_t s8, p8;
+                bool has[4];
+                for (int64_t k = a; k < b; k++) c += pair8 ? sel_link_of(s, k, s8, p8, e, has) : uz_d16_of(s, k, v, e, start8, narrow8);
                 part[(size_t)slice + 1] = c;
             });
             for (int k = 0; k < wk_fill; k++) part[(size_t)k + 1] += part[(size_t)k];
@@ -702,7 +799,20 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
             for (int64_t k = a; k < b; k++) {
                 const int64_t i = s->index[k];
                 if (out->end) w(out->end)[k] = full->end[i];
-                if (d16) {
+                if (pair8) {
+                    uint8_t s8, p8;
+                    int32_t e[4];
+                    bool has[4];
+                    sel_link_of(s, k, s8, p8, e, has);
+                    w(out->start_d8)[k] = s8;
+                    w(out->pair_d8)[k] = p8;
+                    for (int c = 0; c < 4; c++)
+                        if (has[c]) {
+                            w(out->esc16_key)[esc_next] = ((uint64_t)k << 2) | (uint64_t)c;
+                            w(out->esc16_val)[esc_next] = e[c];
+                            esc_next++;
+                        }
+                } else if (d16) {
                     int16_t v[4];
                     int32_t e[4];
                     uz_d16_of(s, k, v, e, start8, narrow8);

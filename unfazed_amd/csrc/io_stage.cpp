@@ -432,31 +432,29 @@ inline int64_t final_ref(const uz_stage &P, int64_t m) { // a mate that was fold
     return m;
 }
 
-// start / tlen / mate / qname of output record k as differences (uz_types.h: start in eight bits, the others in sixteen): v[c] the
-// column values, e[c] the escape value where v[c] == UZ_D16_ESC; returns the number of escapes
-inline int d16_of(const uz_stage &P, int64_t k, int16_t v[4], int32_t e[4]) {
+// start / tlen / mate / qname of output record k in the link form (uz_types.h: the start difference in eight bits, the rest as the
+// pair form's one byte): start8 / pair the column values, e[c] / has[c] the escape-list entries (columns 0 start, 1 tlen, 2 mate,
+// 3 name id); returns their number
+inline PairRec pair_rec(const uz_stage &P, int64_t k) {
+    const int64_t ref = P.order[(size_t)k];
+    const WRec &x = rec_of(P, ref);
+    const int64_t m = final_ref(P, x.mate_ref);
+    PairRec r;
+    r.mate = m < 0 ? -1 : (int64_t)rec_of(P, m).gidx;
+    r.start = x.pos; r.end = x.end; r.tlen = x.tlen; r.qid = x.qid;
+    r.is_new = P.name_of_id[(size_t)x.qid] == ref;
+    return r;
+}
+inline int link_of(const uz_stage &P, int64_t k, uint8_t &start8, uint8_t &pair, int32_t e[4], bool has[4]) {
     const WRec &x = rec_of(P, P.order[(size_t)k]);
-    int n = 0;
-    auto put = [&](int c, int64_t d, int64_t esc_val) {
-        if (c >= 2) { // mate and name id: signed bytes (mate_d8 / qname_d8)
-            if (d > -127 && d <= 127) v[c] = (int16_t)d;
-            else { v[c] = (int16_t)UZ_D8S_ESC; e[c] = (int32_t)esc_val; n++; }
-            return;
-        }
-        if (d > -32767 && d <= 32767) v[c] = (int16_t)d;
-        else { v[c] = (int16_t)UZ_D16_ESC; e[c] = (int32_t)esc_val; n++; }
-    };
     const WRec *px = k > 0 ? &rec_of(P, P.order[(size_t)k - 1]) : nullptr;
     const int64_t ds = (int64_t)x.pos - (px ? (int64_t)px->pos : 0);
-    if (ds >= 0 && ds <= 254) v[0] = (int16_t)ds;
-    else { v[0] = (int16_t)UZ_D16_ESC; e[0] = (int32_t)ds; n++; }
-    put(1, x.tlen, x.tlen);
-    const int64_t m = final_ref(P, x.mate_ref);
-    if (m < 0) v[2] = (int16_t)UZ_D8S_NONE;
-    else { const int64_t nm = rec_of(P, m).gidx; put(2, nm - k, nm); }
-    const int32_t dq = (int32_t)(x.qid - (px ? px->qid : 0u));
-    put(3, dq, dq);
-    return n;
+    int n = 0;
+    has[0] = !(ds >= 0 && ds <= 254);
+    if (has[0]) { start8 = (uint8_t)UZ_D8_ESC; e[0] = (int32_t)ds; n++; }
+    else start8 = (uint8_t)ds;
+    pair = pair8_code(k, [&](int64_t j) { return pair_rec(P, j); });
+    return n + pair8_escapes(pair, pair_rec(P, k), e, has);
 }
 
 // file spans holding every record that overlaps [a, b) of reference `ref` (bins + linear index); sorted, merged per block
@@ -1074,9 +1072,10 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
             if (x.l_seq > 256) wides[(size_t)sl] = 1;
             cnt[(size_t)sl][(size_t)tid_k]++;
             span[(size_t)sl][(size_t)tid_k] = std::max(span[(size_t)sl][(size_t)tid_k], x.end - x.pos);
-            int16_t v[4];
+            uint8_t s8, p8;
             int32_t e[4];
-            b.esc += d16_of(P, k, v, e);
+            bool has[4];
+            b.esc += link_of(P, k, s8, p8, e, has);
         }
         P.base[(size_t)sl + 1] = b;
     });
@@ -1103,8 +1102,8 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
     need(out->seq2 || tot.seq == 0, "needs seq2 (two-bit base rows)");
     need(!out->seq4, "must not set seq4 (the staged form carries two-bit rows)");
     need(out->tup && out->tup_flag && out->tup_l_seq && out->tup_n_cigar && out->tup_mapq && out->tup_aux, "needs the dictionary form (tup, tup_*)");
-    need(out->start_d8 && out->tlen_s && out->mate_d8 && out->qname_d8 && !out->start_d && !out->mate_d && !out->qname_d,
-         "needs the difference form with eight-bit starts, mates and name ids (start_d8, tlen_s, mate_d8, qname_d8)");
+    need(out->start_d8 && out->pair_d8 && !out->tlen_s && !out->mate_d8 && !out->qname_d8 && !out->start_d && !out->mate_d && !out->qname_d,
+         "needs the difference form with eight-bit starts and the pair form of tlen / mate / name id (start_d8, pair_d8)");
     need(tot.esc == 0 || (out->esc16_key && out->esc16_val), "needs the esc16_* list");
     need(!out->end, "must leave `end` out (a BAM record's end is what its CIGAR gives)");
     need(out->cigar_compact != 0, "must set cigar_compact");
@@ -1137,13 +1136,14 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
                 const int64_t ref = P.order[(size_t)k];
                 const Task &T = P.tasks[(size_t)(ref >> 32)];
                 const WRec &x = T.recs[(size_t)(ref & 0xFFFFFFFF)];
-                int16_t v[4];
+                uint8_t s8, p8;
                 int32_t e[4];
-                d16_of(P, k, v, e);
-                w(out->start_d8)[k] = v[0] == (int16_t)UZ_D16_ESC ? (uint8_t)UZ_D8_ESC : (uint8_t)v[0];
-                w(out->tlen_s)[k] = v[1]; w(out->mate_d8)[k] = (int8_t)v[2]; w(out->qname_d8)[k] = (int8_t)v[3];
+                bool has[4];
+                link_of(P, k, s8, p8, e, has);
+                w(out->start_d8)[k] = s8;
+                w(out->pair_d8)[k] = p8;
                 for (int c = 0; c < 4; c++)
-                    if (v[c] == (int16_t)(c >= 2 ? UZ_D8S_ESC : UZ_D16_ESC)) { w(out->esc16_key)[at.esc] = ((uint64_t)k << 2) | (uint64_t)c; w(out->esc16_val)[at.esc] = e[c]; at.esc++; }
+                    if (has[c]) { w(out->esc16_key)[at.esc] = ((uint64_t)k << 2) | (uint64_t)c; w(out->esc16_val)[at.esc] = e[c]; at.esc++; }
                 w(out->tup)[k] = x.tup;
                 if (!x.simple) { memcpy(w(out->cigar) + at.cig, T.cigars.data() + x.cigar_at, (size_t)x.n_cigar * 4); at.cig += x.n_cigar; }
                 const uint8_t *pay = T.pay.data() + x.pay_at;

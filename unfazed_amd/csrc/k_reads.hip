@@ -119,6 +119,12 @@ struct PhaseState {
     std::vector<int32_t> list_len_h;
     bool have_lists = false;
     int32_t n = 0;
+    // uz_phase_begin left a speculative run in flight: what uz_finish_phase needs to judge it
+    bool pending = false;
+    Caps pend_caps = {0, 0, 0, 0, 0, 0};
+    size_t pend_pool_cap = 0;
+    int pend_want_lists = 0;
+    bool force_exact = false; // the next run skips the speculative sizing (a batch that outgrew it is run again on its own sizes)
 };
 
 __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
@@ -129,17 +135,20 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 // ---- record headers from the staged columns -------------------------------------------------------------
 // cigar_off / sq_off are the exclusive prefix sums of n_cigar / UZ_ROW_UNITS(l_seq) over the records: block
 // sums, one scan of the block sums, then the pack kernel scans inside its block and writes the headers.
+#ifndef UZ_PK_SPAN
 #define UZ_PK_SPAN 4096
+#endif
 // four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
 // low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
 // ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none); sixth and seventh, the
 // differences of start and of the name id to the record before (16-bit difference form: the columns are their running sums,
-// modulo 2^32)
-#define UZ_PK_SUMS 7
+// modulo 2^32; pair form: the sixth counts the NEW names, a new name's id being the number of new names before it); eighth and
+// ninth, the FIRST and SECOND records of the pair form (their totals must agree)
+#define UZ_PK_SUMS 9
 // um: which units of the record's rows were staged (UZ_UMASK_ALL: all of them)
 __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t (&v)[UZ_PK_SUMS]) {
     v[4] = (aux & UZ_AUX_SIMPLE_MASK) ? 0u : nc;
-    v[5] = 0u; v[6] = 0u; // (set by the callers from the difference columns)
+    v[5] = 0u; v[6] = 0u; v[7] = 0u; v[8] = 0u; // (set by the callers from the difference columns)
     v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? v[1] : (uint32_t)__popc(um));
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
@@ -159,19 +168,35 @@ __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
     }
     return r;
 }
-// the escape list of the 16-bit difference columns: value of (record, column)
+// the escape list of the 16-bit difference columns: value of (record, column).  The list is sorted by record, and esc_off (one entry
+// per UZ_PK_SPAN records, k_esc_block_off) bounds the search to the handful of entries of the record's own span: a lane that meets
+// an escape costs its wave two or three loads instead of a binary search over the whole list
 __device__ __forceinline__ int32_t esc16_of(const RecColumns &c, int64_t i, int col) {
     const unsigned long long key = ((unsigned long long)i << 2) | (unsigned long long)col;
     int64_t lo = 0, hi = c.n_esc16;
+    if (c.esc_off) { lo = c.esc_off[i / UZ_PK_SPAN]; hi = c.esc_off[i / UZ_PK_SPAN + 1]; }
     while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (c.esc16_key[mid] < key) lo = mid + 1; else hi = mid; }
     return (lo < c.n_esc16 && c.esc16_key[lo] == key) ? c.esc16_val[lo] : 0; // (a missing entry is caught by the totals / the mate check)
+}
+// first escape entry of every span of UZ_PK_SPAN records (and the end of the list)
+__global__ __launch_bounds__(256) void k_esc_block_off(int64_t nb, const unsigned long long *__restrict__ key, int64_t n_esc, int64_t *off) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b > nb) return;
+    const unsigned long long want = (unsigned long long)(b * UZ_PK_SPAN) << 2;
+    int64_t lo = 0, hi = n_esc;
+    while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (key[mid] < want) lo = mid + 1; else hi = mid; }
+    off[b] = lo;
 }
 __device__ __forceinline__ uint32_t d16_val(const RecColumns &c, const int16_t *col, int64_t i, int k) {
     const int v = col[i];
     return (uint32_t)(v == UZ_D16_ESC ? esc16_of(c, i, k) : v);
 }
-// the name-id difference of record i: sixteen bits, or eight (qname_d8)
+// the name-id difference of record i: sixteen bits, or eight (qname_d8); pair form: 1 for a record that brings a new name
 __device__ __forceinline__ uint32_t qname_diff(const RecColumns &c, int64_t i) {
+    if (c.pair_d8) {
+        const uint32_t p = c.pair_d8[i];
+        return (p != UZ_P8_SECOND && p != UZ_P8_SECOND_TLEN && p != UZ_P8_OLD) ? 1u : 0u;
+    }
     if (c.qname_d8) {
         const int v = c.qname_d8[i];
         return (uint32_t)(v == UZ_D8S_ESC ? esc16_of(c, i, 3) : v);
@@ -189,14 +214,15 @@ __device__ __forceinline__ uint32_t start_diff(const RecColumns &c, int64_t i) {
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
-    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         if (i < n) {
             uint32_t v[UZ_PK_SUMS];
             const RecSmall r = rec_small(c, i);
             pk_vals(r.nc, r.ls, r.aux, r.nl, r.um, v);
-            if (c.tlen_s) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
+            if (c.diff_form()) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
+            if (c.pair_d8) { const uint32_t p = c.pair_d8[i]; v[7] = (p >= 1u && p <= UZ_P8_MAX_DIST) ? 1u : 0u; v[8] = (p == UZ_P8_SECOND || p == UZ_P8_SECOND_TLEN) ? 1u : 0u; }
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -215,36 +241,47 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
 __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
                                                         unsigned long long want_units, unsigned long long want_seq, unsigned long long want_qpos,
                                                         unsigned long long want_staged /* ~0: not compact */, int32_t *hflags) {
-    __shared__ unsigned long long part[UZ_PK_SUMS][1024];
-    const int t = threadIdx.x;
+    __shared__ unsigned long long wpart[UZ_PK_SUMS][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t chunk = (nb + 1023) / 1024;
     const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, inc[UZ_PK_SUMS];
     for (int64_t i = lo; i < hi; i++)
         for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
-    for (int k = 0; k < UZ_PK_SUMS; k++) part[k][t] = v[k];
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long r[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
-        for (int j = 0; j < 1024; j++)
-            for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = part[k][j]; part[k][j] = r[k]; r[k] += x; }
-        if (r[0] != want_cigar || r[1] != want_units || r[2] != want_seq || r[3] != want_qpos || r[0] > 0xFFFFFFFFULL || r[1] > 0xFFFFFFFFULL ||
-            (want_staged != ~0ULL && r[4] != want_staged))
-            hflags[0] = 1;
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SUMS; k++) { // inclusive scan inside the wave, then across the sixteen waves
+        unsigned long long x = v[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
+        inc[k] = x;
+        if (lane == 63) wpart[k][wv] = x;
     }
     __syncthreads();
-    for (int k = 0; k < UZ_PK_SUMS; k++) v[k] = part[k][t];
+    unsigned long long tot[UZ_PK_SUMS];
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SUMS; k++) {
+        unsigned long long pre = 0, all = 0;
+        for (int w = 0; w < 16; w++) { const unsigned long long x = wpart[k][w]; if (w < wv) pre += x; all += x; }
+        v[k] = pre + inc[k] - v[k]; // exclusive prefix of this thread's blocks
+        tot[k] = all;
+    }
+    if (t == 0) {
+        if (tot[0] != want_cigar || tot[1] != want_units || tot[2] != want_seq || tot[3] != want_qpos || tot[0] > 0xFFFFFFFFULL || tot[1] > 0xFFFFFFFFULL ||
+            (want_staged != ~0ULL && tot[4] != want_staged))
+            hflags[0] = 1;
+        if (tot[7] != tot[8]) hflags[0] = 8; // pair form: as many SECOND records as FIRST ones (k_pair_link checks that they are each other's)
+    }
     for (int64_t i = lo; i < hi; i++)
         for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = sums[UZ_PK_SUMS * i + k]; sums[UZ_PK_SUMS * i + k] = v[k]; v[k] += x; }
 }
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
                                                   uint16_t *qs, int32_t *hflags) {
-    __shared__ uint32_t wsum[UZ_PK_SUMS][4];
+    __shared__ uint32_t wsum[7][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    unsigned long long run[UZ_PK_SUMS];
+    unsigned long long run[7];
 #pragma unroll
-    for (int k = 0; k < UZ_PK_SUMS; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
+    for (int k = 0; k < 7; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         const bool in = i < n;
@@ -255,9 +292,9 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         const uint32_t um = rs.um;
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
         pk_vals(nc, ls, ax, nl, um, v);
-        if (c.tlen_s && in) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
+        if (c.diff_form() && in) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
 #pragma unroll
-        for (int k = 0; k < UZ_PK_SUMS; k++) {
+        for (int k = 0; k < 7; k++) { // (the eighth and ninth sum are totals only)
             uint32_t x = v[k];
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
@@ -266,12 +303,12 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         __syncthreads(); // wsum of the previous round has been read
         if (lane == 63) {
 #pragma unroll
-            for (int k = 0; k < UZ_PK_SUMS; k++) wsum[k][wv] = inc[k];
+            for (int k = 0; k < 7; k++) wsum[k][wv] = inc[k];
         }
         __syncthreads();
-        uint32_t pre[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0}, tot[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0};
+        uint32_t pre[7] = {0, 0, 0, 0, 0, 0, 0}, tot[7] = {0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int k = 0; k < UZ_PK_SUMS; k++)
+        for (int k = 0; k < 7; k++)
 #pragma unroll
             for (int w = 0; w < 4; w++) { if (w < wv) pre[k] += wsum[k][w]; tot[k] += wsum[k][w]; }
         if (in) {
@@ -282,7 +319,25 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             // the four wide columns: plain, or from their 16-bit differences (start and name id: running sums, this record included)
             int32_t st0, tl0, mt0;
             uint32_t qn0;
-            if (c.tlen_s) {
+            if (c.pair_d8) {
+                // pair form: a FIRST record knows its mate and its (new) name id, and gets its template length from k_pair_link once
+                // every `end` is there; a SECOND record gets all three from the FIRST that names it (mate -2 until then)
+                st0 = (int32_t)(uint32_t)(run[5] + pre[5] + inc[5]);
+                const uint32_t p = c.pair_d8[i];
+                qn0 = (uint32_t)(run[6] + pre[6] + inc[6]) - 1u; // a new name's id = new names before it
+                tl0 = 0;
+                if (p == UZ_P8_SECOND) { mt0 = -2; qn0 = 0u; }
+                else if (p == UZ_P8_SECOND_TLEN) { mt0 = -2; qn0 = 0u; tl0 = esc16_of(c, i, 1); }
+                else if (p <= UZ_P8_MAX_DIST) {
+                    mt0 = (int32_t)(i + p);
+                    if (mt0 >= n) { hflags[0] = 7; mt0 = -1; }
+                } else {
+                    tl0 = esc16_of(c, i, 1);
+                    mt0 = esc16_of(c, i, 2);
+                    if (p == UZ_P8_OLD) qn0 = (uint32_t)esc16_of(c, i, 3);
+                    if (mt0 < -1 || mt0 >= n) { hflags[0] = 7; mt0 = -1; }
+                }
+            } else if (c.tlen_s) {
                 st0 = (int32_t)(uint32_t)(run[5] + pre[5] + inc[5]);
                 qn0 = (uint32_t)(run[6] + pre[6] + inc[6]);
                 tl0 = (int32_t)d16_val(c, c.tlen_s, i, 1);
@@ -295,22 +350,33 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                 }
                 if (mt0 < -1 || mt0 >= n) { hflags[0] = 7; mt0 = -1; }
             } else { st0 = c.start[i]; tl0 = c.tlen[i]; mt0 = c.mate[i]; qn0 = c.qname[i]; }
-            const uint32_t *words = c.cigar_in + cg;
-            if (c.cigar_out) { // cigar_compact: this record's words into the store -- the travelled ones, or the one its aux byte names
-                const uint32_t code = (ax & UZ_AUX_SIMPLE_MASK) >> UZ_AUX_SIMPLE_SHIFT;
-                if (code) {
-                    if (nc != 1) hflags[0] = 6;
-                    c.cigar_out[cg] = uz_cigar_simple_word(code, ls);
-                } else {
-                    const unsigned long long so = run[4] + pre[4] + inc[4] - v[4];
-                    for (uint32_t k = 0; k < nc; k++) c.cigar_out[cg + k] = c.cigar_staged[so + k];
-                }
-                words = c.cigar_out + cg;
+            // The record's CIGAR words, fetched ONCE and all together (the first four in one round trip; a short read has one to
+            // three): its end and the two counts of the QC word come from registers, and the device's store gets the words -- the
+            // travelled ones, or the one a simple record's aux byte names (cigar_compact).
+            const uint32_t code = c.cigar_out ? (ax & UZ_AUX_SIMPLE_MASK) >> UZ_AUX_SIMPLE_SHIFT : 0u;
+            if (code && nc != 1) hflags[0] = 6;
+            const uint32_t *src_w = c.cigar_out ? c.cigar_staged + (run[4] + pre[4] + inc[4] - v[4]) : c.cigar_in + cg;
+            const bool have_words = c.cigar_in != nullptr; // (an ASCII upload lays the words out after this kernel: k_pack_ascii sets the two bits)
+            uint32_t w4[4] = {0u, 0u, 0u, 0u};
+            if (code) w4[0] = uz_cigar_simple_word(code, ls);
+            else if (have_words) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) if (k < nc) w4[k] = src_w[k];
             }
-            const int32_t en0 = c.end ? c.end[i] : uz_bam_endpos(st0, rs.flag, nc, words); // (column left out: as bam_endpos)
+            int64_t ref_len = 0;
             int cig_nonmatch = 0, cig_none = 0; // the two CIGAR counts of the QC word
-            if (!(ax & UZ_AUX_DECODE_BAD) && c.cigar_in) // (an ASCII upload lays the words out after this kernel: k_pack_ascii sets the two bits)
-                for (uint32_t k = 0; k < nc; k++) uz_cigar_op_counts(words[k], cig_nonmatch, cig_none);
+            auto take = [&](uint32_t w) {
+                const uint32_t op = w & 15u;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += (int64_t)(w >> 4); // M D N = X
+                if (!(ax & UZ_AUX_DECODE_BAD)) uz_cigar_op_counts(w, cig_nonmatch, cig_none);
+            };
+            if (have_words) {
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) if (k < nc) { take(w4[k]); if (c.cigar_out) c.cigar_out[cg + k] = w4[k]; }
+                for (uint32_t k = 4; k < nc; k++) { const uint32_t w = src_w[k]; take(w); if (c.cigar_out) c.cigar_out[cg + k] = w; }
+            }
+            // (column left out: as htslib's bam_endpos -- uz_bam_endpos in pack.hpp states it for the host)
+            const int32_t en0 = c.end ? c.end[i] : (((rs.flag & 4u) || nc == 0 || !have_words) ? st0 + 1 : (int32_t)(st0 + (ref_len > 0 ? ref_len : 1)));
             int low_for_qc = 0; // (an ASCII upload has no counts yet: uz_build_qlow sets the bit that depends on them)
             uz_pack_rec(A, B, st0, en0, cg, sq, mt0, qn0, (uint16_t)ls, (uint16_t)nc, tl0);
             ra[i] = A;
@@ -367,8 +433,27 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             qs[i] = uz_qs_word(rs.flag, ax, rs.mapq, low_for_qc, (int)nc, cig_nonmatch, cig_none);
         }
 #pragma unroll
-        for (int k = 0; k < UZ_PK_SUMS; k++) run[k] += tot[k];
+        for (int k = 0; k < 7; k++) run[k] += tot[k];
     }
+}
+
+// pair form: every FIRST record hands its mate (the SECOND it names) the link back, the name id and the template length
+__global__ __launch_bounds__(256) void k_pair_link(int64_t n, const uint8_t *__restrict__ pair, const RecA *__restrict__ ra, RecB *rb, int32_t *hflags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pair[i];
+    if (p < 1u || p > UZ_P8_MAX_DIST) return;
+    const int64_t j = i + p;
+    if (j >= n) return; // (flagged by the header build)
+    if (atomicExch(&rb[j].mate, (int32_t)i) != -2) { hflags[0] = 8; return; } // not a SECOND record, or named twice
+    const RecA A = ra[i], M = ra[j];
+    if (pair[j] == UZ_P8_SECOND_TLEN) rb[i].tlen = -rb[j].tlen; // (the SECOND brought its own)
+    else {
+        const int32_t tl = (A.end > M.end ? A.end : M.end) - A.start;
+        rb[i].tlen = tl;
+        rb[j].tlen = -tl;
+    }
+    rb[j].qname = rb[i].qname;
 }
 
 // ---- ASCII uploads (uz_reads_upload): rows re-laid in the packed geometry ---------------------------------
@@ -498,19 +583,28 @@ __global__ __launch_bounds__(256) void k_patch_exc(int64_t n_exc, const uint32_t
 }
 } // namespace
 
-size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 1) * UZ_PK_SUMS * sizeof(unsigned long long); }
+size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 2) * (UZ_PK_SUMS + 1) * sizeof(unsigned long long); }
 
-void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col, void *off_scratch) {
+void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col_in, void *off_scratch) {
     static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
     if (r.n <= 0) return;
     const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
     unsigned long long *sums = (unsigned long long *)off_scratch;
+    RecColumns col = col_in;
+    if (col.n_esc16 > 0) { // the escape list cut at the spans of the passes below
+        int64_t *off = (int64_t *)(sums + (size_t)(nb + 1) * UZ_PK_SUMS);
+        hipLaunchKernelGGL(k_esc_block_off, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (int64_t)nb, col.esc16_key, col.n_esc16, off);
+        col.esc_off = off;
+    }
     hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
                        (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos,
                        col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
                        (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, c->hflags);
+    if (col.pair_d8)
+        hipLaunchKernelGGL(k_pair_link, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, col.pair_d8, (const RecA *)r.rec_a, (RecB *)r.rec_b,
+                           c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
@@ -589,13 +683,73 @@ void uz_phase_state_free(uz_ctx *c) {
 
 int uz_want_lists = 1; // uz_phase always keeps the lists available for uz_phase_votes / uz_phase_groups
 
+static void phase_check_upload_flags(uz_ctx *c) {
+    if (c->hflags[0]) { // set by the header build of an upload (abi.hip) whose commands have now run
+        const int f = c->hflags[0];
+        c->hflags[0] = 0;
+        throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
+                                  : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
+                                  : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
+                                  : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
+                                  : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
+                                  : f == 7 ? "mate_d / esc16_* of the reads view: a mate index outside the table"
+                                  : f == 8 ? "pair_d8 of the reads view: a SECOND record that no FIRST record names, or one that two of them name"
+                                           : "n_cigar_total / n_row_units of the reads view do not match its columns"};
+    }
+}
+struct Sizes { Caps caps; int arena; long long sumP; };
+static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
+static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
+    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
+    for (int32_t d = 0; d < n; d++) {
+        const int32_t *b = &bh[(size_t)5 * d];
+        mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
+        mH = std::max<long long>(mH, b[2]); mC = std::max<long long>(mC, b[3]);
+        const long long I = 4LL * b[0];
+        const long long M = (long long)b[1] + I * (b[4] + 1);
+        mM = std::max(mM, M);
+        sumP += std::min<long long>(M, 4096) + b[3];
+    }
+    Sizes z;
+    z.caps.A = (int32_t)mA; z.caps.T = (int32_t)mT; z.caps.H = (int32_t)mH; z.caps.C = (int32_t)mC;
+    z.caps.I = (int32_t)(4 * mA);
+    z.caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
+    z.sumP = sumP;
+    // LDS arena of k_phase<true>, sized for THIS batch: a DNM needs about 20 bytes per record its het-site fetches return
+    // plus 7 KiB (fit over the bench workload).  The 99th percentile of that estimate over the batch
+    // decides how many workgroups share a CU's 160 KiB (at most UZ_PHASE_MIN_WAVES: registers), and the arena is then the
+    // largest that this many workgroups leave room for.  A shallow batch runs 7 workgroups per CU on 21 KiB arenas, a deep
+    // one fewer on larger arenas -- instead of handing most of its DNMs to the slower HBM build.
+    z.arena = arena_env;
+    if (z.arena < 0) {
+        std::vector<int32_t> hist(64, 0); // estimate in KiB
+        int32_t active = 0;
+        for (int32_t d = 0; d < n; d++) {
+            const int32_t *b = &bh[(size_t)5 * d];
+            if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
+            const long long est = (20LL * b[1] + 7168 + 1023) >> 10;
+            hist[(size_t)std::min<long long>(est, 63)]++;
+            active++;
+        }
+        int kb = 12, seen = 0;
+        for (int k = 0; k < 64; k++) {
+            seen += hist[k];
+            if (hist[k]) kb = std::max(kb, k);
+            if ((long long)seen * 100 >= (long long)active * 99) break;
+        }
+        z.arena = std::min(kb, 62) * 1024;
+    }
+    return z;
+}
+
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
-                     int32_t *origin, int32_t *evidence) {
+                     int32_t *origin, int32_t *evidence, bool defer) {
     if (!c->phase_state) c->phase_state = new PhaseState();
     PhaseState *st = (PhaseState *)c->phase_state;
     const int32_t n = c->dn.n;
     st->n = n;
     st->have_lists = false;
+    st->pending = false;
     c->phase_n = n;
     if (n <= 0) { c->phase_valid = true; return; }
     // an asynchronous upload of this table must have landed before the first kernel reads it
@@ -654,63 +808,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     uz_kcopy(c, bh_own, st->bounds.p, (size_t)5 * n * sizeof(int32_t));
     if (!st->bounds_ready) UZ_HIP(hipEventCreateWithFlags(&st->bounds_ready, hipEventDisableTiming));
     UZ_HIP(hipEventRecord(st->bounds_ready, c->stream));
-    auto check_upload_flags = [&] {
-        if (c->hflags[0]) { // set by the header build of an upload (abi.hip) whose commands have now run
-            const int f = c->hflags[0];
-            c->hflags[0] = 0;
-            throw UzError{UZ_E_RANGE, f == 2 ? "SEQ holds a character outside BAM's 16-code alphabet"
-                                      : f == 3 ? "exc_* columns of the reads view: an entry names a record without bases, a base beyond l_seq or a code above 15"
-                                      : f == 4 ? "qlow_pos of the reads view: positions of a record are not ascending or lie beyond l_seq"
-                                      : f == 5 ? "umask of the reads view: a unit beyond the read's length, or a mask on a read longer than 480 bases"
-                                      : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
-                                      : f == 7 ? "mate_d / esc16_* of the reads view: a mate index outside the table"
-                                               : "n_cigar_total / n_row_units of the reads view do not match its columns"};
-        }
-    };
-    struct Sizes { Caps caps; int arena; long long sumP; };
-    static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
-    auto exact_sizes = [&](const int32_t *bh) {
-        long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
-        for (int32_t d = 0; d < n; d++) {
-            const int32_t *b = &bh[(size_t)5 * d];
-            mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
-            mH = std::max<long long>(mH, b[2]); mC = std::max<long long>(mC, b[3]);
-            const long long I = 4LL * b[0];
-            const long long M = (long long)b[1] + I * (b[4] + 1);
-            mM = std::max(mM, M);
-            sumP += std::min<long long>(M, 4096) + b[3];
-        }
-        Sizes z;
-        z.caps.A = (int32_t)mA; z.caps.T = (int32_t)mT; z.caps.H = (int32_t)mH; z.caps.C = (int32_t)mC;
-        z.caps.I = (int32_t)(4 * mA);
-        z.caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
-        z.sumP = sumP;
-        // LDS arena of k_phase<true>, sized for THIS batch: a DNM needs about 20 bytes per record its het-site fetches return
-        // plus 7 KiB (fit over the bench workload).  The 99th percentile of that estimate over the batch
-        // decides how many workgroups share a CU's 160 KiB (at most UZ_PHASE_MIN_WAVES: registers), and the arena is then the
-        // largest that this many workgroups leave room for.  A shallow batch runs 7 workgroups per CU on 21 KiB arenas, a deep
-        // one fewer on larger arenas -- instead of handing most of its DNMs to the slower HBM build.
-        z.arena = arena_env;
-        if (z.arena < 0) {
-            std::vector<int32_t> hist(64, 0); // estimate in KiB
-            int32_t active = 0;
-            for (int32_t d = 0; d < n; d++) {
-                const int32_t *b = &bh[(size_t)5 * d];
-                if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
-                const long long est = (20LL * b[1] + 7168 + 1023) >> 10;
-                hist[(size_t)std::min<long long>(est, 63)]++;
-                active++;
-            }
-            int kb = 12, seen = 0;
-            for (int k = 0; k < 64; k++) {
-                seen += hist[k];
-                if (hist[k]) kb = std::max(kb, k);
-                if ((long long)seen * 100 >= (long long)active * 99) break;
-            }
-            z.arena = std::min(kb, 62) * 1024;
-        }
-        return z;
-    };
+    auto check_upload_flags = [&] { phase_check_upload_flags(c); };
+    auto exact_sizes = [&](const int32_t *bh) { return phase_exact_sizes(bh, n); };
     if (st->n_cus <= 0) { // asked once: the query is not cheap
         hipDeviceProp_t prop;
         UZ_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -718,7 +817,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     }
     static const bool no_spec = getenv("UZ_PHASE_NO_SPEC") != nullptr;
     const bool hooks = getenv("UZ_TEST_CAP_T") || getenv("UZ_TEST_PHASE_ARENA");
-    bool speculative = st->spec_valid && !no_spec && !hooks;
+    bool speculative = st->spec_valid && !no_spec && !hooks && !st->force_exact;
+    st->force_exact = false;
     st->status.ensure(n); st->counts.ensure((size_t)4 * n); st->origin.ensure(n); st->evidence.ensure(n);
     st->cursor.ensure(16 * (UZ_PHASE_PARTS + 1));
     st->retry.ensure((size_t)n + 16);
@@ -809,10 +909,15 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             int32_t *const hretry = (int32_t *)(hused + 1);
             *hretry = 0;
             uz_kcopy(c, hretry, st->retry.p, sizeof(int32_t));
-            if (status) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
-            if (counts) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
-            if (origin) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
-            if (evidence) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
+            if (status || defer) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
+            if (counts || defer) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
+            if (origin || defer) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
+            if (evidence || defer) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
+            if (defer && speculative) { // uz_phase_begin: the run stays in flight; uz_finish_phase waits for it and judges it
+                st->pending = true;
+                st->pend_caps = caps; st->pend_pool_cap = a.pool_cap; st->pend_want_lists = a.want_lists;
+                return;
+            }
             UZ_HIP(hipStreamSynchronize(c->stream));
             if (speculative) check_upload_flags();
             if (c->hflags[1]) {
@@ -872,6 +977,49 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     if (evidence) memcpy(evidence, hres + (size_t)6 * n, (size_t)n * sizeof(int32_t));
     st->have_lists = a.want_lists != 0;
     c->phase_valid = true;
+}
+
+// second half of uz_phase_begin / uz_phase_end: waits for the run uz_launch_phase(defer) left in flight (or finds the results of a run
+// that had to be synchronous) and hands the results out.  false: the batch outgrew the sizes it was run on (or its list pool) and
+// must be run again, whole -- the caller does that with PhaseState::force_exact set.
+bool uz_finish_phase(uz_ctx *c, int32_t *status, int32_t *counts, int32_t *origin, int32_t *evidence) {
+    PhaseState *st = (PhaseState *)c->phase_state;
+    UZ_REQUIRE(st != nullptr, UZ_E_STATE, "uz_phase_end without uz_phase_begin");
+    const int32_t n = st->n;
+    if (n <= 0) { c->phase_valid = true; return true; }
+    int32_t *const hres = st->res_h;
+    if (st->pending) {
+        st->pending = false;
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        phase_check_upload_flags(c);
+        if (c->hflags[1]) {
+            c->hflags[1] = 0;
+            st->force_exact = true; // (the whole run states the error in full)
+            return false;
+        }
+        unsigned long long *const hused = (unsigned long long *)(hres + (size_t)7 * n + ((7 * (size_t)n) & 1));
+        const unsigned long long used = *hused;
+        c->prof[UZ_K_PHASE].last_units = (int64_t)*(const int32_t *)(hused + 1);
+        const Sizes real = phase_exact_sizes(st->bounds_h, n);
+        auto room = [](int32_t v) { return (int32_t)std::min<long long>((long long)v + v / 8 + 8, 0x3FFFFFFF); };
+        st->spec_caps.A = room(real.caps.A); st->spec_caps.T = room(real.caps.T); st->spec_caps.H = room(real.caps.H); st->spec_caps.C = room(real.caps.C);
+        st->spec_caps.I = 4 * st->spec_caps.A;
+        st->spec_caps.M = real.caps.M;
+        st->spec_arena = real.arena;
+        st->spec_sumP_per_dnm = 1.25 * (double)real.sumP / (double)n;
+        const Caps &caps = st->pend_caps;
+        const bool fits = real.caps.A <= caps.A && real.caps.T <= caps.T && real.caps.H <= caps.H && real.caps.C <= caps.C && real.caps.M <= caps.M;
+        st->spec_runs++;
+        if (!fits) st->spec_misses++;
+        if (!fits || (st->pend_want_lists && used > st->pend_pool_cap)) { st->force_exact = true; return false; }
+        st->have_lists = st->pend_want_lists != 0;
+    }
+    if (status) memcpy(status, hres, (size_t)n * sizeof(int32_t));
+    if (counts) memcpy(counts, hres + n, (size_t)4 * n * sizeof(int32_t));
+    if (origin) memcpy(origin, hres + (size_t)5 * n, (size_t)n * sizeof(int32_t));
+    if (evidence) memcpy(evidence, hres + (size_t)6 * n, (size_t)n * sizeof(int32_t));
+    c->phase_valid = true;
+    return true;
 }
 
 static void fetch_list_index(uz_ctx *c, PhaseState *st) {

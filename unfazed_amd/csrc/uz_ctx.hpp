@@ -126,7 +126,7 @@ struct ReadsDev {
     void *build_scratch = nullptr;
     const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
     int32_t col_lists = 0;
-    const void *col_d[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val, start_d8
+    const void *col_d[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val, start_d8, mate_d8, qname_d8, pair_d8
     int64_t col_nesc = 0;
     const void *col_q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask / cigar_staged / cigar_out of RecColumns, for the deferred header build
     int64_t n_cigar_staged = 0; // cigar_compact: words that travelled (checked by the header build)
@@ -187,6 +187,7 @@ struct uz_ctx {
     DnmsDev dn;
     uint8_t *dn_stage = nullptr; // pinned staging of a DNM batch
     size_t dn_stage_cap = 0;
+    hipEvent_t dn_stage_done = nullptr; // behind the copies out of dn_stage: a batch queued by uz_phase_begin may still be reading it
     DevBuf<int32_t> cnt_c, cnt_h;
     DevBuf<int64_t> win_range;
     DevBuf<int64_t> cand_off, het_off;
@@ -213,6 +214,7 @@ struct uz_ctx {
 
     // last phase (k_reads.hip)
     bool phase_valid = false;
+    bool phase_open = false; // uz_phase_begin without its uz_phase_end
     int32_t phase_n = 0;
     void *phase_state = nullptr;
 
@@ -261,9 +263,12 @@ struct RecColumns {
     const int16_t *start_d = nullptr, *tlen_s = nullptr, *mate_d = nullptr, *qname_d = nullptr;
     const uint8_t *start_d8 = nullptr; // the start differences in eight bits (then start_d is null)
     const int8_t *mate_d8 = nullptr, *qname_d8 = nullptr; // mate / name-id differences in eight bits (then mate_d / qname_d are null)
+    const uint8_t *pair_d8 = nullptr; // the pair form: tlen, mate and name id in one byte (then tlen_s and the four above are null)
+    __host__ __device__ bool diff_form() const { return tlen_s != nullptr || pair_d8 != nullptr; } // start (and the rest) travel as differences
     const unsigned long long *esc16_key = nullptr;
     const int32_t *esc16_val = nullptr;
     int64_t n_esc16 = 0;
+    const int64_t *esc_off = nullptr; // set by the header build: first escape entry of every span of records
     int32_t lists = 0; // the qualities came as counts (+ positions): n_low, or tup_n_low through the table
     const uint32_t *plane_in = nullptr;
     const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
@@ -296,7 +301,8 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d);
 void uz_launch_cnv(uz_ctx *c, const SitesDev &s, const int32_t *rb_counts_dev, int32_t *cnv_counts, int32_t *cnv_pos, int32_t *origin,
                    int32_t *evidence, int32_t *etype);
 void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, int32_t *status, int32_t *counts,
-                     int32_t *origin, int32_t *evidence);
+                     int32_t *origin, int32_t *evidence, bool defer = false);
+bool uz_finish_phase(uz_ctx *c, int32_t *status, int32_t *counts, int32_t *origin, int32_t *evidence);
 int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);
 int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q);
 void uz_phase_state_free(uz_ctx *c);

@@ -18,12 +18,12 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait",
+    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
     "uz_site_scan", "uz_site_scan_many", "uz_site_classes", "uz_find", "uz_find_fetch",
-    "uz_phase", "uz_phase_cohort", "uz_phase_votes", "uz_phase_groups", "uz_phase_cnv", "uz_phase_cnv_sites",
+    "uz_phase", "uz_phase_begin", "uz_phase_end", "uz_phase_cohort", "uz_phase_votes", "uz_phase_groups", "uz_phase_cnv", "uz_phase_cnv_sites",
     "uz_prof_enable", "uz_prof_reset", "uz_prof_get", "uz_prof_units",
 ]
 
@@ -55,6 +55,7 @@ def load_library(path: Optional[str] = None):
     L.uz_sync.argtypes = [vp]
     L.uz_set_params.argtypes = [vp, vp]
     L.uz_reads_wait.argtypes = [vp, C.c_int]
+    L.uz_reads_headers.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -72,6 +73,8 @@ def load_library(path: Optional[str] = None):
     L.uz_find.argtypes = [vp, C.c_int, vp, C.c_int, vp, vp]
     L.uz_find_fetch.argtypes = [vp, vp, vp, vp]
     L.uz_phase.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
+    L.uz_phase_begin.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.uz_phase_end.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp, vp]
     L.uz_phase_cohort.argtypes = [vp, vp, C.c_int32, vp, C.c_int, vp, vp, vp, vp]
     L.uz_phase_cnv.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.uz_phase_cnv_sites.argtypes = [vp, vp, vp]
@@ -185,6 +188,11 @@ class HipEngine:
                                                                      extra=fex, wide_no_units=bool(wide_no_units))
                     if idx.size != int(v.view.n_segs):  # record numbers are the caller's: the table must be the fetches' own reach
                         raise UnfazedHipError("upload_reads(fetches=...): the table holds records the fetches cannot reach")
+                    if packed.qname_map is not None and not np.array_equal(packed.qname_map, np.arange(packed.qname_map.size, dtype=np.uint32)):
+                        # name ids are the caller's too: the pair form renumbers them unless they already count first appearances
+                        pool.rewind(0)
+                        packed, idx = io_native.ReadsSource(full).select(fc, flo, fhi, alloc=pool.alloc, want_index=True, all_bases=bool(all_bases),
+                                                                         extra=fex, wide_no_units=bool(wide_no_units), pair8=False)
                 else:
                     packed = io_native.pack_reads(v, int(min_base_qual), alloc=pool.alloc, lists=bool(point_only), with_end=None, cigar_compact=True)
                 rid = self.upload_reads_packed(packed)
@@ -231,6 +239,12 @@ class HipEngine:
 
     def wait_reads(self, rid: int):
         self._ck(self.L.uz_reads_wait(self.h, int(rid)), "uz_reads_wait")
+
+    def reads_headers(self, rid: int, n: int) -> dict:
+        """start / end / tlen / mate / qname of a table as the device holds them (uz_reads_headers)"""
+        out = {k: np.zeros(max(1, int(n)), np.uint32 if k == "qname" else np.int32) for k in ("start", "end", "tlen", "mate", "qname")}
+        self._ck(self.L.uz_reads_headers(self.h, int(rid), *(out[k].ctypes.data for k in ("start", "end", "tlen", "mate", "qname"))), "uz_reads_headers")
+        return {k: v[: int(n)] for k, v in out.items()}
 
     def adopt_sites(self, view: abi.SitesView) -> int:
         sid = C.c_int(-1)
@@ -307,6 +321,22 @@ class HipEngine:
                             counts.ctypes.data, origin.ctypes.data, evidence.ctypes.data),
             "uz_phase",
         )
+        return dict(status=status[:n], counts=counts[: 4 * n].reshape(n, 4), origin=origin[:n], evidence=evidence[:n])
+
+    def phase_begin(self, fam: int, reads_h: int, dv: abi.Held, params: abi.Params, find_mode: int):
+        """first half of phase_raw (uz_phase_begin): queues the batch and returns; phase_end -- same arguments -- hands out the results.
+        Uploads and find() of OTHER batches may run in between: they queue up behind this batch's kernels."""
+        self.set_params(params)
+        self._ck(self.L.uz_phase_begin(self.h, int(fam), int(reads_h), dv.ref(), int(find_mode)), "uz_phase_begin")
+
+    def phase_end(self, fam: int, reads_h: int, dv: abi.Held, params: abi.Params, find_mode: int):
+        n = dv.view.n
+        status = np.zeros(max(1, n), dtype=np.int32)
+        counts = np.zeros(max(1, 4 * n), dtype=np.int32)
+        origin = np.zeros(max(1, n), dtype=np.int32)
+        evidence = np.zeros(max(1, n), dtype=np.int32)
+        self._ck(self.L.uz_phase_end(self.h, int(fam), int(reads_h), dv.ref(), int(find_mode), status.ctypes.data, counts.ctypes.data,
+                                     origin.ctypes.data, evidence.ctypes.data), "uz_phase_end")
         return dict(status=status[:n], counts=counts[: 4 * n].reshape(n, 4), origin=origin[:n], evidence=evidence[:n])
 
     def phase_cohort(self, groups, dv: abi.Held, params: abi.Params, found_list=None, want_lists: bool = True,

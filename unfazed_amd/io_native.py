@@ -27,7 +27,7 @@ IO_EXPORTS = [
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16", "uz_select_n_esc16_start8", "uz_select_n_esc16_narrow8",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16", "uz_select_n_esc16_start8", "uz_select_n_esc16_narrow8", "uz_select_pair8_ok", "uz_select_n_esc16_pair8", "uz_select_n_new_names", "uz_select_qname_map",
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
@@ -133,10 +133,12 @@ def load():
     lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)]
     for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units,
-               lib.uz_select_n_exc, lib.uz_select_n_qlow_pos, lib.uz_select_n_cigar_omitted, lib.uz_select_n_tuples, lib.uz_select_n_esc16, lib.uz_select_n_esc16_start8, lib.uz_select_n_esc16_narrow8):
+               lib.uz_select_n_exc, lib.uz_select_n_qlow_pos, lib.uz_select_n_cigar_omitted, lib.uz_select_n_tuples, lib.uz_select_n_esc16, lib.uz_select_n_esc16_start8, lib.uz_select_n_esc16_narrow8, lib.uz_select_n_esc16_pair8, lib.uz_select_n_new_names):
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int64
     lib.uz_reads_select_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.uz_select_pair8_ok.argtypes = [C.c_void_p]
+    lib.uz_select_qname_map.argtypes = [C.c_void_p, C.c_void_p]
     lib.uz_select_free.argtypes = [C.c_void_p]
     lib.uz_select_free.restype = None
     lib.uz_index_summary.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64]
@@ -479,7 +481,7 @@ class ReadsSource:
         self.threads = threads
 
     def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True,
-               tuples=True, d16=True, start8=True, wide_no_units=False, narrow8=True):
+               tuples=True, d16=True, start8=True, wide_no_units=False, narrow8=True, pair8=True):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
@@ -491,7 +493,10 @@ class ReadsSource:
         start8: ... the start differences in eight bits (records of a pile-up start a few bases apart).
         wide_no_units (SV batches, with extra): a fetch wider than two bases stages no unit of the records it returns.
         narrow8 (with start8): ... and the mate / name-id differences in eight bits (a selection keeps a third of a pile-up: a mate lies
-        within +-75 kept records)."""
+        within +-75 kept records).
+        pair8 (with start8): tlen, mate and name id in the pair form's ONE byte (uz_types.h, pair_d8) when the source's name ids ascend
+        by first appearance (any decoder's table; else the narrow8 form).  The output then numbers the names of the selection by first
+        appearance: `.qname_map[output id]` = the source's id."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -509,6 +514,8 @@ class ReadsSource:
             n = self.lib.uz_select_n_records(sel)
             two_bit = bool(self.packed.view.seq2)  # a selection keeps the base-row form of its source
             n_tup = int(self.lib.uz_select_n_tuples(sel)) if tuples else -1
+            pair8 = bool(pair8 and d16 and start8 and self.lib.uz_select_pair8_ok(sel))
+            narrow8 = bool(narrow8 and not pair8)
             out = abi.packed_view_alloc(n, int(self.packed.view.n_contigs), self.lib.uz_select_n_cigar_total(sel),
                                         self.lib.uz_select_n_row_units(sel), alloc, n_seq_units=self.lib.uz_select_n_seq_units(sel),
                                         n_exc=int(self.lib.uz_select_n_exc(sel)) if two_bit else None,
@@ -517,12 +524,17 @@ class ReadsSource:
                                         with_end=(not self.lib.uz_select_end_derivable(sel)) if with_end is None else bool(with_end),
                                         with_umask=masks, cigar_omitted=int(self.lib.uz_select_n_cigar_omitted(sel)) if cigar_compact else None,
                                         n_tup=n_tup if n_tup >= 0 else None,
-                                        n_esc16=int((self.lib.uz_select_n_esc16_narrow8 if (start8 and narrow8) else self.lib.uz_select_n_esc16_start8 if start8
-                                                     else self.lib.uz_select_n_esc16)(sel)) if d16 else None,
-                                        start8=bool(d16 and start8), narrow8=bool(d16 and start8 and narrow8))
+                                        n_esc16=int((self.lib.uz_select_n_esc16_pair8 if pair8 else self.lib.uz_select_n_esc16_narrow8 if (start8 and narrow8)
+                                                     else self.lib.uz_select_n_esc16_start8 if start8 else self.lib.uz_select_n_esc16)(sel)) if d16 else None,
+                                        start8=bool(d16 and start8), narrow8=bool(d16 and start8 and narrow8), pair8=pair8)
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
+            out.qname_map = None
+            if pair8:
+                out.qname_map = np.zeros(max(1, int(self.lib.uz_select_n_new_names(sel))), np.uint32)
+                _check(self.lib, self.lib.uz_select_qname_map(sel, out.qname_map.ctypes.data))
+                out.qname_map = out.qname_map[: int(self.lib.uz_select_n_new_names(sel))]
         finally:
             self.lib.uz_select_free(sel)
         return (out, idx[:n]) if want_index else out
@@ -619,13 +631,13 @@ class BamSource:
         self.lib.uz_stage_sizes(sh.ptr, z)
         n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um = (int(x) for x in z)
         if pool is not None:  # the sizes are known now: one block for all the columns (each 256-byte aligned)
-            total = (n * 9 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 12 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
+            total = (n * 5 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 12 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
                      + 40 * 256 + 4096)
             pool.new_slab(total)
             alloc = pool.alloc
         out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
                                     n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
-                                    cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True, narrow8=True)
+                                    cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True, pair8=True)
         _check(self.lib, self.lib.uz_stage_fill(sh.ptr, int(self.threads), out.ref()))
         io = (C.c_int64 * 8)()
         self.lib.uz_stage_io_stats(sh.ptr, io)
