@@ -98,9 +98,8 @@ void uz_pinned_free(void *p);
 int uz_sites_adopt_device(uz_ctx *ctx, const uz_sites_view *sites, int *sites_id);
 int uz_family_adopt_device(uz_ctx *ctx, int sites_id, const uz_family_view *fam, int *fam_id);
 int uz_reads_adopt_device(uz_ctx *ctx, const uz_reads_packed_view *reads, int *reads_id);
-/* Forget the derived columns (site classes of every family, per-record QC bits) so that the
- * next uz_find / uz_phase recomputes them: a timed "whole job" pass starts from the staged
- * inputs only. */
+/* Forget the derived columns (site classes of every family, per-record QC bits, the window lists of the last finds) so that
+ * the next uz_find / uz_phase recomputes them: a timed "whole job" pass starts from the staged inputs only. */
 int uz_drop_derived(uz_ctx *ctx);
 int uz_sites_free(uz_ctx *ctx, int sites_id); /* also frees its families */
 int uz_reads_free(uz_ctx *ctx, int reads_id);
@@ -124,6 +123,9 @@ int uz_site_classes(uz_ctx *ctx, int fam_id, uint8_t *cls_out /* [n_sites] */);
 int uz_find(uz_ctx *ctx, int fam_id, const uz_dnms_view *dnms, int mode,
             int64_t *cand_off /* [n+1] */, int64_t *het_off /* [n+1] */);
 int uz_find_fetch(uz_ctx *ctx, int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx);
+/* (The lists of the last TWO finds stay in HBM: a uz_phase / uz_phase_begin over a batch -- same family, DNMs, mode and parameters --
+ * that one of them covered takes its lists instead of running the window emit again.  A staged pass calls uz_find for chunk k + 1,
+ * whose het lists tell the decoder what to stage, before it queues the read stage of chunk k.) */
 
 /* ---- read stage ------------------------------------------------------- */
 /* Everything multithread_read_phasing does after get_refalt (snv_phaser.py:131-203):

@@ -282,16 +282,67 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d) {
     const void *src[9] = {d->contig, d->rcontig, d->start, d->end, d->vartype, d->dflags, d->mult, d->allele_off, d->alleles};
     for (int k = 0; k < 9; k++)
         if (sizes[k]) memcpy(c->dn_stage + off[k], src[k], sizes[k]);
-    c->dn.contig.ensure(n + 1); c->dn.rcontig.ensure(n + 1); c->dn.start.ensure(n + 1); c->dn.end.ensure(n + 1);
-    c->dn.vartype.ensure(n + 1); c->dn.dflags.ensure(n + 1); c->dn.mult.ensure(n + 1);
-    c->dn.allele_off.ensure(2 * n + 2); c->dn.alleles.ensure(nb + 1);
-    void *dst[9] = {c->dn.contig.p, c->dn.rcontig.p, c->dn.start.p, c->dn.end.p, c->dn.vartype.p, c->dn.dflags.p, c->dn.mult.p,
-                    c->dn.allele_off.p, c->dn.alleles.p};
-    for (int k = 0; k < 9; k++)
-        if (sizes[k]) uz_kcopy(c, dst[k], c->dn_stage + off[k], sizes[k]); // out of the pinned staging buffer, by a kernel
+    c->dn.block.ensure(off[9] + 64);
+    uint8_t *const b = c->dn.block.p;
+    c->dn.contig.p = (int32_t *)(b + off[0]); c->dn.rcontig.p = (int32_t *)(b + off[1]); c->dn.start.p = (int32_t *)(b + off[2]);
+    c->dn.end.p = (int32_t *)(b + off[3]); c->dn.vartype.p = b + off[4]; c->dn.dflags.p = b + off[5]; c->dn.mult.p = b + off[6];
+    c->dn.allele_off.p = (uint32_t *)(b + off[7]); c->dn.alleles.p = b + off[8];
+    if (off[9]) uz_kcopy(c, b, c->dn_stage, off[9]); // out of the pinned staging buffer, by ONE kernel (the offsets are multiples of 64)
     if (!c->dn_stage_done) UZ_HIP(hipEventCreateWithFlags(&c->dn_stage_done, hipEventDisableTiming));
     UZ_HIP(hipEventRecord(c->dn_stage_done, c->stream));
     c->dn.cutoff = d->cutoff;
+}
+
+// ---------------------------------------------------------------- window lists of the last two finds (uz_ctx.hpp: find_key, find_alt)
+static FindKey find_key_of(const uz_ctx *c, int fam_id, int mode, const uz_dnms_view *d) {
+    FindKey k;
+    k.valid = d != nullptr && d->n >= 0;
+    k.fam = fam_id; k.mode = mode; k.n = d ? d->n : -1; k.cohort = c->cohort_on;
+    k.P = c->P;
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+    auto mix = [&](const void *p, size_t bytes) {
+        if (!p) return;
+        const uint8_t *b = (const uint8_t *)p;
+        size_t i = 0;
+        for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001B3ULL; h ^= h >> 29; }
+        for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001B3ULL;
+    };
+    if (k.valid && d->n > 0) {
+        const size_t n = (size_t)d->n;
+        mix(d->contig, n * 4); mix(d->start, n * 4); mix(d->end, n * 4); mix(d->vartype, n); mix(d->mult, n);
+    }
+    k.hash = h;
+    return k;
+}
+static bool find_key_eq(const FindKey &a, const FindKey &b) {
+    return a.valid && b.valid && a.fam == b.fam && a.mode == b.mode && a.n == b.n && a.cohort == b.cohort && a.hash == b.hash &&
+           memcmp(&a.P, &b.P, sizeof(uz_params)) == 0;
+}
+static void find_swap(uz_ctx *c) { // the parked lists become the context's, and the other way round (pointers only)
+    FindSlot &a = c->find_alt;
+    std::swap(c->cnt_c, a.cnt_c); std::swap(c->cnt_h, a.cnt_h); std::swap(c->win_range, a.win_range);
+    std::swap(c->cand_off, a.cand_off); std::swap(c->het_off, a.het_off);
+    std::swap(c->cand_idx, a.cand_idx); std::swap(c->het_idx, a.het_idx); std::swap(c->cand_flags, a.cand_flags);
+    std::swap(c->n_cand, a.n_cand); std::swap(c->n_het, a.n_het);
+    c->cand_off_h.swap(a.cand_off_h); c->het_off_h.swap(a.het_off_h);
+    std::swap(c->find_key, a.key); std::swap(c->find_stamp, a.stamp);
+}
+// a new find overwrites the OLDER of the two sets (kernels still reading it are ahead of the new ones on the stream)
+static void find_target(uz_ctx *c) {
+    if (c->find_key.valid && (!c->find_alt.key.valid || c->find_alt.stamp < c->find_stamp)) find_swap(c);
+    c->find_key.valid = false;
+    c->find_valid = false;
+}
+static void find_done(uz_ctx *c, const FindKey &k) { c->find_key = k; c->find_stamp = ++c->find_counter; }
+// the context's lists become those of batch `k` if either set holds them; false: they must be computed
+static bool find_recall(uz_ctx *c, const FindKey &k) {
+    if (find_key_eq(c->find_key, k)) { c->find_valid = true; c->find_mode = k.mode; return true; }
+    if (find_key_eq(c->find_alt.key, k)) { find_swap(c); c->find_valid = true; c->find_mode = k.mode; return true; }
+    return false;
+}
+static void find_forget(uz_ctx *c, int fam_id /* -1: everything */) {
+    if (fam_id < 0 || c->find_key.fam == fam_id) { c->find_key.valid = false; c->find_valid = false; }
+    if (fam_id < 0 || c->find_alt.key.fam == fam_id) c->find_alt.key.valid = false;
 }
 
 extern "C" {
@@ -330,9 +381,7 @@ void uz_destroy(uz_ctx *c) {
     for (auto &b : c->block_pool) (void)hipFree(b.p);
     if (c->hflags) (void)hipHostFree(c->hflags);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    c->dn.contig.release(); c->dn.rcontig.release(); c->dn.start.release(); c->dn.end.release();
-    c->dn.vartype.release(); c->dn.dflags.release(); c->dn.mult.release(); c->dn.allele_off.release();
-    c->dn.alleles.release();
+    c->dn.block.release();
     if (c->dn_stage_done) (void)hipEventDestroy(c->dn_stage_done);
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
     c->ab_lut.release(); c->win_range.release();
@@ -1004,6 +1053,7 @@ void uz_pinned_free(void *p) {
 int uz_drop_derived(uz_ctx *c) {
     return guarded(c, [&] {
         for (auto &f : c->fams) f.cls_valid = false;
+        find_forget(c, -1);
     });
 }
 
@@ -1011,10 +1061,9 @@ int uz_sites_free(uz_ctx *c, int sites_id) {
     return guarded(c, [&] {
         SitesDev &s = sites_of(c, sites_id);
         UZ_HIP(hipStreamSynchronize(c->stream));
-        for (auto &f : c->fams)
-            if (f.live && f.sites_id == sites_id) free_family(c, f);
+        for (size_t k = 0; k < c->fams.size(); k++)
+            if (c->fams[k].live && c->fams[k].sites_id == sites_id) { find_forget(c, (int)k); free_family(c, c->fams[k]); }
         free_sites(c, s);
-        c->find_valid = false;
     });
 }
 int uz_reads_free(uz_ctx *c, int reads_id) {
@@ -1072,12 +1121,16 @@ int uz_find(uz_ctx *c, int fam_id, const uz_dnms_view *d, int mode, int64_t *can
     return guarded(c, [&] {
         FamilyDev &f = fam_of(c, fam_id);
         SitesDev &s = sites_of(c, f.sites_id);
-        c->find_valid = false;
+        UZ_REQUIRE(d != nullptr && d->n >= 0, UZ_E_ARG, "bad DNM view");
+        c->cohort_on = false;
+        const FindKey key = find_key_of(c, fam_id, mode, d);
+        find_target(c);
         c->phase_valid = false;
         uz_stage_dnms(c, d);
         const bool cnv = (mode & UZ_FIND_WHOLE_REGION) != 0;
         if (!uz_site_scan_fresh(c, f, cnv)) uz_launch_site_scan(c, f, s, cnv);
         uz_launch_find(c, f, s, mode);
+        find_done(c, key);
         c->find_fam = fam_id;
         if (cand_off) memcpy(cand_off, c->cand_off_h.data(), ((size_t)d->n + 1) * sizeof(int64_t));
         if (het_off) memcpy(het_off, c->het_off_h.data(), ((size_t)d->n + 1) * sizeof(int64_t));
@@ -1097,26 +1150,6 @@ int uz_find_fetch(uz_ctx *c, int32_t *cand_idx, uint8_t *cand_flags, int32_t *he
     });
 }
 
-int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode, int32_t *status,
-             int32_t *counts, int32_t *origin, int32_t *evidence) {
-    return guarded(c, [&] {
-        FamilyDev &f = fam_of(c, fam_id);
-        SitesDev &s = sites_of(c, f.sites_id);
-        ReadsDev &r = reads_of(c, reads_id);
-        UZ_REQUIRE(d != nullptr, UZ_E_ARG, "null DNM view");
-        UZ_REQUIRE(!(find_mode & UZ_FIND_WHOLE_REGION), UZ_E_ARG, "the read stage runs on SNV / breakpoint windows");
-        // the read stage consumes the lists of a find over the same batch in SNV / breakpoint mode
-        c->find_valid = false;
-        c->phase_valid = false;
-        c->phase_qbase.clear();
-        uz_stage_dnms(c, d);
-        if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
-        uz_launch_find(c, f, s, find_mode, false);
-        c->find_fam = fam_id;
-        uz_launch_phase(c, f, s, r, status, counts, origin, evidence);
-    });
-}
-
 // uz_phase in two halves (unfazed_hip.h)
 static void phase_whole(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode, int32_t *status, int32_t *counts, int32_t *origin,
                         int32_t *evidence, bool defer) {
@@ -1125,14 +1158,29 @@ static void phase_whole(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view 
     ReadsDev &r = reads_of(c, reads_id);
     UZ_REQUIRE(d != nullptr, UZ_E_ARG, "null DNM view");
     UZ_REQUIRE(!(find_mode & UZ_FIND_WHOLE_REGION), UZ_E_ARG, "the read stage runs on SNV / breakpoint windows");
-    c->find_valid = false;
+    c->cohort_on = false;
     c->phase_valid = false;
     c->phase_qbase.clear();
+    // the read stage consumes the window lists of this batch in SNV / breakpoint mode: those of the caller's own uz_find, if one of
+    // the last two finds was over this batch; else computed here
+    const FindKey key = find_key_of(c, fam_id, find_mode, d);
+    const bool have = find_recall(c, key);
+    if (!have) find_target(c);
     uz_stage_dnms(c, d);
     if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
-    uz_launch_find(c, f, s, find_mode, false);
+    if (!have) {
+        uz_launch_find(c, f, s, find_mode, false);
+        find_done(c, key);
+    }
     c->find_fam = fam_id;
     uz_launch_phase(c, f, s, r, status, counts, origin, evidence, defer);
+}
+int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode, int32_t *status,
+             int32_t *counts, int32_t *origin, int32_t *evidence) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(!c->phase_open, UZ_E_STATE, "uz_phase: a batch is still open (uz_phase_end)");
+        phase_whole(c, fam_id, reads_id, d, find_mode, status, counts, origin, evidence, false);
+    });
 }
 int uz_phase_begin(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode) {
     return guarded(c, [&] {
@@ -1262,7 +1310,7 @@ int uz_phase_cohort(uz_ctx *c, const uz_cohort_group *groups, int32_t n_groups, 
         }
         uz_dnms_view dv = *d;
         dv.rcontig = rc.data();
-        c->find_valid = false; c->phase_valid = false;
+        find_target(c); c->phase_valid = false; // (the cohort's lists take the place of the older set, under no key)
         uz_stage_dnms(c, &dv);
         c->dn_fam.ensure((size_t)n + 1); c->dn_cutoff.ensure((size_t)n + 1); c->fam_cls.ensure((size_t)n_groups + 1);
         if (n) {
@@ -1287,7 +1335,7 @@ int uz_phase_cnv(uz_ctx *c, int fam_id, const uz_dnms_view *d, const int32_t *rb
         FamilyDev &f = fam_of(c, fam_id);
         SitesDev &s = sites_of(c, f.sites_id);
         UZ_REQUIRE(d != nullptr, UZ_E_ARG, "null DNM view");
-        c->find_valid = false; c->phase_valid = false; c->cnv_valid = false;
+        find_target(c); c->phase_valid = false; c->cnv_valid = false;
         uz_stage_dnms(c, d);
         const size_t n = (size_t)d->n;
         if (!uz_site_scan_fresh(c, f, true)) uz_launch_site_scan(c, f, s, true);

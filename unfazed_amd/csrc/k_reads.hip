@@ -99,9 +99,11 @@ __global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(P
 
 struct PhaseState {
     DevBuf<uint8_t> scratch;
-    DevBuf<int32_t> bounds, status, counts, origin, evidence, cursor, pool, list_len, pre_win, pre_ha, pre_hl, retry;
+    // res: the per-DNM results as they go back to the host in ONE copy -- status [n], counts [4n], origin [n], evidence [n], then (8-byte
+    // aligned) the fill level of the list pool; pre_h: first record and length of every het-site fetch range, [2 (n_het + 1)]
+    DevBuf<int32_t> bounds, res, cursor, pool, list_len, pre_win, pre_h, retry;
     DevBuf<long long> list_start;
-    DevBuf<unsigned long long> pool_cursor;
+    unsigned long long *pool_cursor = nullptr; // (inside res)
     DevBuf<unsigned int> need_count;
     int32_t *bounds_h = nullptr; // pinned: the copy back must not block the host, the marking kernels follow it
     size_t bounds_h_cap = 0;
@@ -672,9 +674,9 @@ void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual) {
 void uz_phase_state_free(uz_ctx *c) {
     PhaseState *st = (PhaseState *)c->phase_state;
     if (!st) return;
-    st->scratch.release(); st->bounds.release(); st->status.release(); st->counts.release(); st->origin.release();
-    st->evidence.release(); st->cursor.release(); st->pre_win.release(); st->pre_ha.release(); st->pre_hl.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
-    st->pool_cursor.release(); st->need_count.release();
+    st->scratch.release(); st->bounds.release(); st->res.release();
+    st->cursor.release(); st->pre_win.release(); st->pre_h.release(); st->pool.release(); st->list_len.release(); st->list_start.release();
+    st->pool_cursor = nullptr; st->need_count.release();
     if (st->bounds_ready) (void)hipEventDestroy(st->bounds_ready);
     if (st->bounds_h) (void)hipHostFree(st->bounds_h);
     delete st;
@@ -781,11 +783,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
 
     // sizing pass -> scratch capacities (max over the batch)
     st->bounds.ensure((size_t)5 * n);
-    st->pre_win.ensure((size_t)4 * n); st->pre_ha.ensure((size_t)c->n_het + 1); st->pre_hl.ensure((size_t)c->n_het + 1);
-    a.pre_win = st->pre_win.p; a.pre_ha = st->pre_ha.p; a.pre_hl = st->pre_hl.p;
+    st->pre_win.ensure((size_t)4 * n); st->pre_h.ensure(2 * ((size_t)c->n_het + 1));
+    a.pre_win = st->pre_win.p; a.pre_ha = st->pre_h.p; a.pre_hl = st->pre_h.p + (size_t)c->n_het + 1;
     // DNMs without candidates leave their het ranges untouched: they must read as empty
-    UZ_HIP(hipMemsetAsync(st->pre_ha.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
-    UZ_HIP(hipMemsetAsync(st->pre_hl.p, 0, ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
+    UZ_HIP(hipMemsetAsync(st->pre_h.p, 0, 2 * ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
     {
         const unsigned nb = (unsigned)(((int64_t)n * 16 + 255) / 256);
         ProfScope ps(c, UZ_K_SIZING);
@@ -819,15 +820,17 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     const bool hooks = getenv("UZ_TEST_CAP_T") || getenv("UZ_TEST_PHASE_ARENA");
     bool speculative = st->spec_valid && !no_spec && !hooks && !st->force_exact;
     st->force_exact = false;
-    st->status.ensure(n); st->counts.ensure((size_t)4 * n); st->origin.ensure(n); st->evidence.ensure(n);
+    const size_t res_ints = (size_t)7 * n + ((7 * (size_t)n) & 1); // the results, padded to eight bytes; the pool's fill level behind them
+    st->res.ensure(res_ints + 4);
+    st->pool_cursor = (unsigned long long *)(st->res.p + res_ints);
     st->cursor.ensure(16 * (UZ_PHASE_PARTS + 1));
     st->retry.ensure((size_t)n + 16);
     a.retry_count = st->retry.p; a.retry_list = st->retry.p + 16;
-    a.status = st->status.p; a.counts = st->counts.p; a.origin = st->origin.p; a.evidence = st->evidence.p;
+    a.status = st->res.p; a.counts = st->res.p + n; a.origin = st->res.p + (size_t)5 * n; a.evidence = st->res.p + (size_t)6 * n;
     a.work_cursor = st->cursor.p;
     a.want_lists = uz_want_lists;
-    st->pool_cursor.ensure(2); st->list_start.ensure(n); st->list_len.ensure((size_t)6 * n);
-    a.pool_cursor = st->pool_cursor.p;
+    st->list_start.ensure(n); st->list_len.ensure((size_t)6 * n);
+    a.pool_cursor = st->pool_cursor;
     a.list_start = st->list_start.p; a.list_len = st->list_len.p;
 #ifdef UZ_PHASE_TIMING
     static DevBuf<unsigned long long> timing;
@@ -893,7 +896,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         for (int attempt = 0; attempt < 4; attempt++) {
             UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 1) * sizeof(int32_t), c->stream));
             UZ_HIP(hipMemsetAsync(st->retry.p, 0, 16 * sizeof(int32_t), c->stream));
-            UZ_HIP(hipMemsetAsync(st->pool_cursor.p, 0, 2 * sizeof(unsigned long long), c->stream));
+            UZ_HIP(hipMemsetAsync(st->pool_cursor, 0, 2 * sizeof(unsigned long long), c->stream));
             {
                 ProfScope ps(c, UZ_K_PHASE);
                 UZ_TRACE("k_phase");
@@ -905,14 +908,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             }
             UZ_TRACE("after k_phase");
             *hused = 0;
-            uz_kcopy(c, hused, st->pool_cursor.p, sizeof(unsigned long long));
+            uz_kcopy(c, hres, st->res.p, res_ints * sizeof(int32_t) + sizeof(unsigned long long)); // the results and the pool's fill level: one copy
             int32_t *const hretry = (int32_t *)(hused + 1);
             *hretry = 0;
             uz_kcopy(c, hretry, st->retry.p, sizeof(int32_t));
-            if (status || defer) uz_kcopy(c, hres, st->status.p, (size_t)n * sizeof(int32_t));
-            if (counts || defer) uz_kcopy(c, hres + n, st->counts.p, (size_t)4 * n * sizeof(int32_t));
-            if (origin || defer) uz_kcopy(c, hres + (size_t)5 * n, st->origin.p, (size_t)n * sizeof(int32_t));
-            if (evidence || defer) uz_kcopy(c, hres + (size_t)6 * n, st->evidence.p, (size_t)n * sizeof(int32_t));
             if (defer && speculative) { // uz_phase_begin: the run stays in flight; uz_finish_phase waits for it and judges it
                 st->pending = true;
                 st->pend_caps = caps; st->pend_pool_cap = a.pool_cap; st->pend_want_lists = a.want_lists;
@@ -1048,7 +1047,7 @@ static int gather_lists(uz_ctx *c, int k0, int k1, int64_t *off, int32_t *val) {
     if (!val || total == 0) return 0;
     // copy the used part of the pool once, then slice on the host
     unsigned long long used = 0;
-    UZ_HIP(hipMemcpy(&used, st->pool_cursor.p, sizeof(used), hipMemcpyDeviceToHost));
+    UZ_HIP(hipMemcpy(&used, st->pool_cursor, sizeof(used), hipMemcpyDeviceToHost));
     std::vector<int32_t> pool((size_t)used);
     if (used) UZ_HIP(hipMemcpy(pool.data(), st->pool.p, (size_t)used * sizeof(int32_t), hipMemcpyDeviceToHost));
     for (int32_t d = 0; d < st->n; d++) {

@@ -46,6 +46,27 @@ struct DevBuf {
     }
 };
 
+// what a set of window lists was computed for
+struct FindKey {
+    bool valid = false;
+    int fam = -1, mode = 0;
+    int32_t n = -1;
+    bool cohort = false;
+    uint64_t hash = 0; // of the DNM columns the window emit reads
+    uz_params P;
+};
+struct FindSlot { // the window lists of one uz_find, parked
+    FindKey key;
+    unsigned long long stamp = 0;
+    DevBuf<int32_t> cnt_c, cnt_h;
+    DevBuf<int64_t> win_range;
+    DevBuf<int64_t> cand_off, het_off;
+    DevBuf<int32_t> cand_idx, het_idx;
+    DevBuf<uint8_t> cand_flags;
+    int64_t n_cand = 0, n_het = 0;
+    std::vector<int64_t> cand_off_h, het_off_h;
+};
+
 // one device allocation out of the context's pool (tables come and go every staged pass: hipFree
 // synchronises the device, so freed blocks are parked and handed out again)
 struct DevBlock {
@@ -142,12 +163,15 @@ struct ReadsDev {
 };
 
 // DNM batch staged on the device
-struct DnmsDev {
+template <typename T>
+struct DevPtr { T *p = nullptr; };
+struct DnmsDev { // the columns of a DNM batch: one block in HBM, laid out like its pinned staging copy (ONE copy brings a batch over)
     int32_t n = 0;
-    DevBuf<int32_t> contig, rcontig, start, end;
-    DevBuf<uint8_t> vartype, dflags, mult;
-    DevBuf<uint32_t> allele_off;
-    DevBuf<uint8_t> alleles;
+    DevBuf<uint8_t> block;
+    DevPtr<int32_t> contig, rcontig, start, end;
+    DevPtr<uint8_t> vartype, dflags, mult;
+    DevPtr<uint32_t> allele_off;
+    DevPtr<uint8_t> alleles;
     double cutoff = 0;
 };
 
@@ -195,6 +219,12 @@ struct uz_ctx {
     DevBuf<uint8_t> cand_flags;
     int64_t n_cand = 0, n_het = 0;
     std::vector<int64_t> cand_off_h, het_off_h;
+    // Whose window lists these are, and the lists of the find BEFORE the last one, kept aside (find_alt): a staged pass asks for the
+    // lists of chunk k + 1 (uz_find: the decoder's input) before it queues the read stage of chunk k, whose own uz_find ran one call
+    // earlier -- the read stage then takes those lists instead of running the window emit (and its host round trip) again.
+    FindKey find_key;
+    unsigned long long find_stamp = 0, find_counter = 0;
+    FindSlot find_alt;
 
     // cohort batch (uz_phase_cohort): per-DNM family / insert cutoff / query-name base, the class column of every family, and
     // the reads tables of the kids laid end to end as ONE table (virtual contigs = kid x contig)
