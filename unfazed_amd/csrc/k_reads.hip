@@ -156,6 +156,14 @@ __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, 
 }
 // the small columns of record i, plain or through the dictionary (uz_reads_packed_view.tup)
 struct RecSmall { uint32_t flag, ls, nc, mapq, aux, um; int nl; };
+// ... of record i whose dictionary index is already at hand
+__device__ __forceinline__ RecSmall rec_small_of(const RecColumns &c, int64_t i, uint32_t t) {
+    RecSmall r;
+    r.flag = c.tup_flag[t]; r.ls = c.tup_l_seq[t]; r.nc = c.tup_n_cigar[t]; r.mapq = c.tup_mapq[t]; r.aux = c.tup_aux[t];
+    r.nl = c.lists ? (int)c.tup_n_low[t] : -1;
+    r.um = c.tup_umask ? (uint32_t)c.tup_umask[t] : (c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL);
+    return r;
+}
 __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
     RecSmall r;
     if (c.tup) {
@@ -217,14 +225,41 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
     unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
-        const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
-        if (i < n) {
+    // four records per lane at a time: their column bytes are requested together, then their dictionary entries, then the sums --
+    // three round trips to memory for four records instead of three for each
+    constexpr int U = 4;
+    static_assert((UZ_PK_SPAN / 256) % U == 0, "UZ_PK_SPAN is a multiple of 1024");
+    for (int it = 0; it < UZ_PK_SPAN / 256; it += U) {
+        int64_t idx[U];
+        bool in[U];
+        RecSmall r[U];
+        uint32_t sd[U], pd[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            idx[u] = (int64_t)blockIdx.x * UZ_PK_SPAN + (it + u) * 256 + t;
+            in[u] = idx[u] < n;
+            if (!in[u]) idx[u] = n - 1; // (n > 0: the kernel is not launched on an empty table)
+        }
+        uint32_t tp[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            tp[u] = c.tup ? (uint32_t)c.tup[idx[u]] : 0u;
+            sd[u] = c.start_d8 ? (uint32_t)c.start_d8[idx[u]] : 0u;
+            pd[u] = c.pair_d8 ? (uint32_t)c.pair_d8[idx[u]] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) r[u] = c.tup ? rec_small_of(c, idx[u], tp[u]) : rec_small(c, idx[u]);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!in[u]) continue;
+            const int64_t i = idx[u];
             uint32_t v[UZ_PK_SUMS];
-            const RecSmall r = rec_small(c, i);
-            pk_vals(r.nc, r.ls, r.aux, r.nl, r.um, v);
-            if (c.diff_form()) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
-            if (c.pair_d8) { const uint32_t p = c.pair_d8[i]; v[7] = (p >= 1u && p <= UZ_P8_MAX_DIST) ? 1u : 0u; v[8] = (p == UZ_P8_SECOND || p == UZ_P8_SECOND_TLEN) ? 1u : 0u; }
+            pk_vals(r[u].nc, r[u].ls, r[u].aux, r[u].nl, r[u].um, v);
+            if (c.diff_form()) {
+                v[5] = c.start_d8 ? (sd[u] == UZ_D8_ESC ? (uint32_t)esc16_of(c, i, 0) : sd[u]) : start_diff(c, i);
+                v[6] = c.pair_d8 ? ((pd[u] != UZ_P8_SECOND && pd[u] != UZ_P8_SECOND_TLEN && pd[u] != UZ_P8_OLD) ? 1u : 0u) : qname_diff(c, i);
+            }
+            if (c.pair_d8) { v[7] = (pd[u] >= 1u && pd[u] <= UZ_P8_MAX_DIST) ? 1u : 0u; v[8] = (pd[u] == UZ_P8_SECOND || pd[u] == UZ_P8_SECOND_TLEN) ? 1u : 0u; }
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -284,11 +319,20 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
     unsigned long long run[7];
 #pragma unroll
     for (int k = 0; k < 7; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
+    // the dictionary index of the NEXT round's record is requested a round ahead: its table entries can then be fetched as soon as
+    // the round begins, instead of after a round trip of their own
+    uint32_t tp_next = 0;
+    {
+        const int64_t i0 = (int64_t)blockIdx.x * UZ_PK_SPAN + t;
+        if (c.tup && i0 < n) tp_next = c.tup[i0];
+    }
     for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
         const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
         const bool in = i < n;
+        const uint32_t tp = tp_next;
+        if (c.tup && it + 1 < UZ_PK_SPAN / 256 && i + 256 < n) tp_next = c.tup[i + 256];
         RecSmall rs = {0u, 0u, 0u, 0u, 0u, UZ_UMASK_ALL, c.lists ? 0 : -1};
-        if (in) rs = rec_small(c, i);
+        if (in) rs = c.tup ? rec_small_of(c, i, tp) : rec_small(c, i);
         const uint32_t nc = rs.nc, ls = rs.ls, ax = rs.aux;
         const int nl = rs.nl;
         const uint32_t um = rs.um;
@@ -408,14 +452,25 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
                     }
                     if (bad) hflags[0] = 4;
                     uint32_t at_row = sq; // the quality row holds the same units as the base row: the staged ones
-                    for (int u = 0; u < units; u++) {
-                        if (um != UZ_UMASK_ALL && !((um >> u) & 1u)) continue;
-                        uint32_t w = 0;
+                    if (um != UZ_UMASK_ALL) { // (usually one or two of a read's five: one round per staged unit)
+                        uint32_t m = um;
+                        while (m) {
+                            const int u = __ffs((int)m) - 1;
+                            m &= m - 1u;
+                            uint32_t w = 0;
 #pragma unroll
-                        for (int e = 0; e < UZ_QLOW_LIST_MAX; e++)
-                            if (pos[e] >= 0 && (pos[e] >> 5) == u) w |= 1u << (pos[e] & 31);
-                        plane_out[(size_t)at_row++] = w;
-                    }
+                            for (int e = 0; e < UZ_QLOW_LIST_MAX; e++)
+                                if (pos[e] >= 0 && (pos[e] >> 5) == u) w |= 1u << (pos[e] & 31);
+                            plane_out[(size_t)at_row++] = w;
+                        }
+                    } else
+                        for (int u = 0; u < units; u++) {
+                            uint32_t w = 0;
+#pragma unroll
+                            for (int e = 0; e < UZ_QLOW_LIST_MAX; e++)
+                                if (pos[e] >= 0 && (pos[e] >> 5) == u) w |= 1u << (pos[e] & 31);
+                            plane_out[(size_t)at_row++] = w;
+                        }
                 }
             } else {
                 const uint32_t qo = (uint32_t)(run[1] + pre[1] + inc[1] - v[1]);
