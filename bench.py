@@ -137,8 +137,8 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.workload == "cnv" and not args.chunks:
-        args.chunks = 2  # (measured: 2 / 4 / 6 / 10 chunks = 7.9 / 8.5 / 9.4 / 12.2 ms -- since the SV batch travels at 29 KB per event the step is
-        # bound by the per-chunk host work, not by the link)
+        args.chunks = 3  # (measured: 2 / 3 / 4 / 6 chunks = 6.6 / 6.2 / 7.4 / 8.1 ms: 214 MB cross the link in 3.9 ms; the read stage of an SV chunk
+        # is as long as its slowest event -- a breakpoint pile-up of a thousand records in one workgroup -- so small chunks cost more in total)
     if args.workload == "cnv" and "--dnms" not in " ".join(sys.argv) and "UZ_BENCH_DNMS" not in os.environ:
         args.dnms = 10000
     world = int(os.environ.get("WORLD_SIZE", 0))
@@ -347,9 +347,9 @@ def main():
         site_bytes = int(site_sel.size) * (4 + 1 + 1 + 1 + 1 + 18)
         # The same site columns cut per chunk (the windows of the chunk's DNMs): the site stage of chunk k + 1 then runs while the
         # records of chunk k are still on the link, instead of one site stage for the whole batch in front of everything.
-        # (config 5 keeps the single table: its allele-balance kernel runs once over the whole batch.)
+        # (config 5 the same way: the allele-balance stage of a chunk runs on the chunk's own site windows, behind its read stage.)
         chunk_sites = []
-        if not cnv and not args.one_site_table:
+        if not args.one_site_table:
             for (a, b, _, _) in chunks:
                 kk = np.zeros(sc.n + 1, np.int32)
                 for c in np.unique(ev.contig[a:b]):
@@ -382,6 +382,8 @@ def main():
             -> the read stage of chunk k - 1; the site columns of chunk k + 1 go up before the records of chunk k"""
             out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32),
                        evidence=np.empty(n, np.int32))
+            if cnv:
+                out.update(etype=np.empty(n, np.int32), cnv_counts=np.empty((n, 2), np.int32))
             K = len(chunks)
             sids, fids, rids = [None] * K, [None] * K, [None] * K
 
@@ -392,9 +394,23 @@ def main():
             def read_stage_begin(k):  # queued on the compute stream (waits there for the chunk's records): no host wait
                 eng.phase_begin(fids[k], rids[k], chunks[k][3], P, mode)
 
+            pending = {}
+
             def read_stage_end(k):
-                a, b, _, dvc = chunks[k]
-                rr = eng.phase_end(fids[k], rids[k], dvc, P, mode)
+                pending[k] = eng.phase_end(fids[k], rids[k], chunks[k][3], P, mode)
+                if not cnv:
+                    finish(k)
+
+            def cnv_stage(k):  # config 5: K6 over the chunk's events, merged with their read-backed counts as summarize_record merges them
+                rr = pending[k]
+                kk = eng.phase_cnv(fids[k], chunks[k][3], P, rb_counts=rr["counts"], want_lists=False)
+                pending[k] = dict(status=rr["status"], counts=rr["counts"], origin=kk["origin"], evidence=kk["evidence"], etype=kk["etype"],
+                                  cnv_counts=kk["cnv_counts"])
+                finish(k)
+
+            def finish(k):
+                a, b = chunks[k][0], chunks[k][1]
+                rr = pending.pop(k)
                 for key in out:
                     out[key][a:b] = rr[key]
                 eng.free_reads(rids[k])
@@ -407,26 +423,36 @@ def main():
                     tr.append(time.perf_counter())
             # The read stage of chunk k - 1 is queued (uz_phase_begin) before the host waits for the het lists of chunk k + 1: that wait
             # -- the ONE host round trip per chunk -- then runs behind the read stage's kernels instead of beside an idle device, and the
-            # read stage's results are there when it returns (uz_phase_end).
+            # read stage's results are there when it returns (uz_phase_end).  The site windows travel two chunks ahead of their find, so
+            # the link does not idle through that round trip either.  (config 5: the allele-balance stage of chunk k - 2 is queued behind
+            # the read stage of chunk k - 1, and waited for there.)
             site_stage(0)
+            if K > 1:
+                site_stage(1)
             tick()
             for k in range(K):
                 eng.find(fids[k], chunks[k][3], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
                 tick()
                 if k >= 2:
                     read_stage_end(k - 2)
-                if k + 1 < K:
-                    site_stage(k + 1)
                 tick()
                 rids[k] = eng.upload_reads_packed(chunks[k][2])
+                if k + 2 < K:
+                    site_stage(k + 2)
                 tick()
                 if k >= 1:
                     read_stage_begin(k - 1)
+                if cnv and k >= 2:
+                    cnv_stage(k - 2)
                 tick()
             if K >= 2:
                 read_stage_end(K - 2)
             read_stage_begin(K - 1)
+            if cnv and K >= 2:
+                cnv_stage(K - 2)
             read_stage_end(K - 1)
+            if cnv:
+                cnv_stage(K - 1)
             tick()
             if tr is not None:
                 trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
@@ -466,7 +492,7 @@ def main():
         res_s, el_s, prof_s, _ = timed(step_staged)
         per_rank_s = list(timed.per_rank)
         if trace and chunk_sites:
-            print("[staged step, ms] site stage 0, then per chunk: find (behind the read stage of chunk k - 2) | its results, next site stage | enqueue records | queue the read stage of chunk k - 1; last read stages:", trace[-2:], file=sys.stderr)
+            print("[staged step, ms] site stage 0, then per chunk: find (behind the read stage of chunk k - 2) | its results | enqueue records, the site windows of chunk k + 2 | queue the read stage of chunk k - 1 (config 5: + allele balance of chunk k - 2); last read stages:", trace[-2:], file=sys.stderr)
         elif trace:
             print("[staged step, ms] sites+family upload | find | enqueue read uploads | phase chunks | cnv + frees:", trace, file=sys.stderr)
             # where the link time goes: the copies alone, the kernels alone (tables already in HBM), both overlapped

@@ -123,7 +123,7 @@ int uz_site_classes(uz_ctx *ctx, int fam_id, uint8_t *cls_out /* [n_sites] */);
 int uz_find(uz_ctx *ctx, int fam_id, const uz_dnms_view *dnms, int mode,
             int64_t *cand_off /* [n+1] */, int64_t *het_off /* [n+1] */);
 int uz_find_fetch(uz_ctx *ctx, int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx);
-/* (The lists of the last TWO finds stay in HBM: a uz_phase / uz_phase_begin over a batch -- same family, DNMs, mode and parameters --
+/* (The lists of the last THREE finds stay in HBM: a uz_phase / uz_phase_begin over a batch -- same family, DNMs, mode and parameters --
  * that one of them covered takes its lists instead of running the window emit again.  A staged pass calls uz_find for chunk k + 1,
  * whose het lists tell the decoder what to stage, before it queues the read stage of chunk k.) */
 
@@ -141,8 +141,9 @@ int uz_phase(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, in
 /* uz_phase in two halves, for a caller that has the next batch's work ready: uz_phase_begin queues the window emit and the read
  * stage and returns without waiting (a first batch, whose sizes nothing predicts yet, runs to its end instead); uz_phase_end -- same
  * batch, same arguments -- waits and hands out the results of uz_phase.  Between the two the caller may upload tables and run
- * uz_site_scan / uz_find for OTHER batches (they queue up behind the read stage: the device does not idle through the host's round
- * trips); not another uz_phase*, and not uz_find_fetch / uz_phase_votes of this batch before uz_phase_end has returned.  After an
+ * uz_site_scan / uz_find / uz_phase_cnv for OTHER batches (they queue up behind the read stage: the device does not idle through the
+ * host's round trips); not another uz_phase / uz_phase_begin / uz_phase_cohort, and not uz_find_fetch / uz_phase_votes of this batch
+ * before uz_phase_end has returned.  After an
  * intervening uz_find the window lists of the context are that batch's: uz_find_fetch then returns those. */
 int uz_phase_begin(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode);
 int uz_phase_end(uz_ctx *ctx, int fam_id, int reads_id, const uz_dnms_view *dnms, int find_mode,

@@ -293,7 +293,7 @@ void uz_stage_dnms(uz_ctx *c, const uz_dnms_view *d) {
     c->dn.cutoff = d->cutoff;
 }
 
-// ---------------------------------------------------------------- window lists of the last two finds (uz_ctx.hpp: find_key, find_alt)
+// ---------------------------------------------------------------- window lists of the last finds (uz_ctx.hpp: find_key, find_alt)
 static FindKey find_key_of(const uz_ctx *c, int fam_id, int mode, const uz_dnms_view *d) {
     FindKey k;
     k.valid = d != nullptr && d->n >= 0;
@@ -318,8 +318,8 @@ static bool find_key_eq(const FindKey &a, const FindKey &b) {
     return a.valid && b.valid && a.fam == b.fam && a.mode == b.mode && a.n == b.n && a.cohort == b.cohort && a.hash == b.hash &&
            memcmp(&a.P, &b.P, sizeof(uz_params)) == 0;
 }
-static void find_swap(uz_ctx *c) { // the parked lists become the context's, and the other way round (pointers only)
-    FindSlot &a = c->find_alt;
+static void find_swap(uz_ctx *c, int which) { // a parked set becomes the context's, and the other way round (pointers only)
+    FindSlot &a = c->find_alt[which];
     std::swap(c->cnt_c, a.cnt_c); std::swap(c->cnt_h, a.cnt_h); std::swap(c->win_range, a.win_range);
     std::swap(c->cand_off, a.cand_off); std::swap(c->het_off, a.het_off);
     std::swap(c->cand_idx, a.cand_idx); std::swap(c->het_idx, a.het_idx); std::swap(c->cand_flags, a.cand_flags);
@@ -327,22 +327,33 @@ static void find_swap(uz_ctx *c) { // the parked lists become the context's, and
     c->cand_off_h.swap(a.cand_off_h); c->het_off_h.swap(a.het_off_h);
     std::swap(c->find_key, a.key); std::swap(c->find_stamp, a.stamp);
 }
-// a new find overwrites the OLDER of the two sets (kernels still reading it are ahead of the new ones on the stream)
+// a new find overwrites the OLDEST set, or one that holds nothing (kernels still reading it are ahead of the new ones on the stream)
 static void find_target(uz_ctx *c) {
-    if (c->find_key.valid && (!c->find_alt.key.valid || c->find_alt.stamp < c->find_stamp)) find_swap(c);
+    if (c->find_key.valid) {
+        int best = -1;
+        unsigned long long best_stamp = c->find_stamp;
+        for (int k = 0; k < UZ_FIND_ALTS; k++) {
+            const FindSlot &a = c->find_alt[k];
+            if (!a.key.valid) { best = k; break; }
+            if (a.stamp < best_stamp) { best = k; best_stamp = a.stamp; }
+        }
+        if (best >= 0) find_swap(c, best);
+    }
     c->find_key.valid = false;
     c->find_valid = false;
 }
 static void find_done(uz_ctx *c, const FindKey &k) { c->find_key = k; c->find_stamp = ++c->find_counter; }
-// the context's lists become those of batch `k` if either set holds them; false: they must be computed
+// the context's lists become those of batch `k` if one of the sets holds them; false: they must be computed
 static bool find_recall(uz_ctx *c, const FindKey &k) {
     if (find_key_eq(c->find_key, k)) { c->find_valid = true; c->find_mode = k.mode; return true; }
-    if (find_key_eq(c->find_alt.key, k)) { find_swap(c); c->find_valid = true; c->find_mode = k.mode; return true; }
+    for (int a = 0; a < UZ_FIND_ALTS; a++)
+        if (find_key_eq(c->find_alt[a].key, k)) { find_swap(c, a); c->find_valid = true; c->find_mode = k.mode; return true; }
     return false;
 }
 static void find_forget(uz_ctx *c, int fam_id /* -1: everything */) {
     if (fam_id < 0 || c->find_key.fam == fam_id) { c->find_key.valid = false; c->find_valid = false; }
-    if (fam_id < 0 || c->find_alt.key.fam == fam_id) c->find_alt.key.valid = false;
+    for (int a = 0; a < UZ_FIND_ALTS; a++)
+        if (fam_id < 0 || c->find_alt[a].key.fam == fam_id) c->find_alt[a].key.valid = false;
 }
 
 extern "C" {
@@ -388,7 +399,11 @@ void uz_destroy(uz_ctx *c) {
     c->dn_fam.release(); c->dn_cutoff.release(); c->fam_cls.release();
     c->cnv_counts.release(); c->cnv_pos.release(); c->cnv_origin.release(); c->cnv_evidence.release(); c->cnv_etype.release(); c->cnv_rb.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
-    c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release();
+    c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release(); c->win_range.release();
+    for (FindSlot &a : c->find_alt) {
+        a.cnt_c.release(); a.cnt_h.release(); a.win_range.release(); a.cand_off.release(); a.het_off.release();
+        a.cand_idx.release(); a.het_idx.release(); a.cand_flags.release();
+    }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;

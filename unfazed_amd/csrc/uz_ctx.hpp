@@ -55,6 +55,7 @@ struct FindKey {
     uint64_t hash = 0; // of the DNM columns the window emit reads
     uz_params P;
 };
+#define UZ_FIND_ALTS 2
 struct FindSlot { // the window lists of one uz_find, parked
     FindKey key;
     unsigned long long stamp = 0;
@@ -219,12 +220,13 @@ struct uz_ctx {
     DevBuf<uint8_t> cand_flags;
     int64_t n_cand = 0, n_het = 0;
     std::vector<int64_t> cand_off_h, het_off_h;
-    // Whose window lists these are, and the lists of the find BEFORE the last one, kept aside (find_alt): a staged pass asks for the
-    // lists of chunk k + 1 (uz_find: the decoder's input) before it queues the read stage of chunk k, whose own uz_find ran one call
-    // earlier -- the read stage then takes those lists instead of running the window emit (and its host round trip) again.
+    // Whose window lists these are, and the lists of the two finds BEFORE the last one, kept aside (find_alt): a staged pass asks for
+    // the lists of chunk k + 1 (uz_find: the decoder's input) before it queues the read stage of chunk k, whose own uz_find ran one
+    // call earlier -- the read stage then takes those lists instead of running the window emit (and its host round trip) again; the
+    // third set leaves room for the whole-region lists of an allele-balance stage in between.
     FindKey find_key;
     unsigned long long find_stamp = 0, find_counter = 0;
-    FindSlot find_alt;
+    FindSlot find_alt[UZ_FIND_ALTS];
 
     // cohort batch (uz_phase_cohort): per-DNM family / insert cutoff / query-name base, the class column of every family, and
     // the reads tables of the kids laid end to end as ONE table (virtual contigs = kid x contig)
