@@ -127,8 +127,8 @@ struct Caps { // per-workgroup scratch capacities (elements)
 // Element types of the working arrays that differ between the two builds of the per-DNM body (see Arena below): the
 // HBM build must take any DNM the capacities admit (32-bit indices); a DNM that fits an LDS arena has fewer than
 // 32 k het sites and 64 k pair-table entries, and 16-bit indices nearly halve its footprint (more workgroups per CU).
-template <bool LDS> struct ScrTy { typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t flg; };
-template <> struct ScrTy<true> { typedef int16_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t flg; };
+template <bool LDS> struct ScrTy { typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t flg; typedef unsigned long long skey; };
+template <> struct ScrTy<true> { typedef int16_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t flg; typedef uint32_t skey; };
 
 template <bool LDS>
 struct ScrT {
@@ -136,6 +136,10 @@ struct ScrT {
     typedef typename ScrTy<LDS>::pidx pidx; // pair id
     typedef typename ScrTy<LDS>::xidx xidx; // index into the sorted pair-table entries
     typedef typename ScrTy<LDS>::flg flg;
+    // pair-table sort key: (name id, sequence number).  HBM build: id << 24 | sequence in 64 bits.  Arena build: the ids a DNM meets lie
+    // close together (they are handed out in file order), so (id - smallest id of the DNM) and the sequence number share 32 bits -- a DNM
+    // whose ids do not fit is given up to the HBM build
+    typedef typename ScrTy<LDS>::skey skey;
     // ---- arrays the LDS build places in the arena (uz_scr_make lists them once more)
     uint8_t *a_cls;
     int32_t *a_flag0, *a_flag1; // (no pointer arrays in this struct: a dynamically indexed member would pin it in private memory)
@@ -156,7 +160,7 @@ struct ScrT {
     int32_t *i_seg;
     pidx *i_pair;
     uint8_t *i_hb;
-    unsigned long long *keys;
+    skey *keys;
     int32_t *seq_h;
     hidx *srt_h;
     int32_t *srt_pid;
@@ -967,7 +971,9 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
         ar_t<LDS>(ar, s.keys, mp2 + 1); // requested last: given back as soon as the sorted order is taken down (below)
     }
     if (LDS && ar.fail) return 1;
-    int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path)
+    int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path / the HBM build)
+    int SB = 24; // bits of a key that hold the sequence number
+    if constexpr (LDS) { SB = 1; while ((1 << SB) < M) SB++; }
     WG_FOR(x, M) {
         uint32_t q;
         if (x < E) q = s.reg_q[x];
@@ -977,7 +983,8 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.i_soff[mid] <= sx) lo = mid; else hi = mid; }
             q = s.i_q[lo];
         } else q = s.i_q[x - E - S];
-        s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
+        if constexpr (LDS) s.keys[x] = q; // (shifted below, once the smallest id is known)
+        else s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
         lmin = (int)q < lmin ? (int)q : lmin;
         lmax = (int)q > lmax ? (int)q : lmax;
     }
@@ -986,8 +993,13 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
     // Sort by (query-name id, sequence).
     {
         if constexpr (LDS) {
-            // the keys sit in the arena: bitonic sort in registers / in place (wg_sort64; ~45 short stages for 512 keys)
-            wg_sort64(s.keys, M, sh, true);
+            // the keys sit in the arena, packed into 32 bits: bitonic sort in registers / in place (~45 short stages for 512 keys)
+            int qmin = -1, qmax = -1;
+            wg_minmax(lmin, lmax, qmin, qmax, sh);
+            if (qmin < 0 || (((unsigned)(qmax - qmin)) >> (32 - SB)) != 0u) return 1; // (block-uniform) the HBM build sorts 64-bit keys
+            WG_FOR(x, M) s.keys[x] = ((s.keys[x] - (uint32_t)qmin) << SB) | (uint32_t)x;
+            WG_SYNC();
+            wg_sort32_lds(s.keys, M);
         } else {
             // keys in HBM scratch.  Name ids are interned in file order, so the names met around one locus span a short
             // id range: a counting sort over that range (stable order inside a bucket restored by a tiny insertion
@@ -1025,10 +1037,10 @@ UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_
     }
     UZ_TICK(10); // S.sort
     WG_FOR(x, M) {
-        const int st = (x == 0 || (s.keys[x] >> 24) != (s.keys[x - 1] >> 24)) ? 1 : 0;
+        const int st = (x == 0 || (s.keys[x] >> SB) != (s.keys[x - 1] >> SB)) ? 1 : 0;
         s.srt_flag[x] = st;
         s.srt_pid[x] = st;
-        s.srt_seq[x] = (typename ScrT<LDS>::xidx)(s.keys[x] & 0xFFFFFF);
+        s.srt_seq[x] = (typename ScrT<LDS>::xidx)(s.keys[x] & (typename ScrT<LDS>::skey)((1u << SB) - 1u));
     }
     P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1 (its first barrier ends the reads of keys)
     ar_pop<LDS>(ar, s.keys, mp2 + 1); // the 8-byte keys are the largest array of the DNM: their room goes to the per-pair arrays

@@ -197,7 +197,7 @@ UZ_DEV void wg_bitonic_stages(P w, int N) {
             for (int i = threadIdx.x; i < N; i += WG_NT) {
                 const int x = i ^ j;
                 if (x > i) {
-                    const unsigned long long u = w[i], v = w[x];
+                    const auto u = w[i], v = w[x];
                     const bool up = (i & k) == 0;
                     if ((u > v) == up) { w[i] = v; w[x] = u; }
                 }
@@ -212,12 +212,12 @@ UZ_DEV void wg_bitonic_stages(P w, int N) {
 // distance >= WG_NT are other registers of the same lane, partners at distance < 64 are reached by a
 // wave shuffle; only the distances in between (64 and 128 for a 256-lane workgroup) go through LDS and a
 // barrier.  buf: LDS, N entries.  N = R * WG_NT.
-template <int R>
-UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) unsigned long long *buf, unsigned long long *a, int n) {
+template <int R, typename T = unsigned long long>
+UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) T *buf, T *a, int n) {
     const int t = threadIdx.x;
-    unsigned long long v[R];
+    T v[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) { const int i = t + WG_NT * r; v[r] = i < n ? a[i] : ~0ULL; }
+    for (int r = 0; r < R; r++) { const int i = t + WG_NT * r; v[r] = i < n ? a[i] : (T) ~(T)0; }
     const int N = R * WG_NT;
     for (int k = 2; k <= N; k <<= 1) {
 #pragma unroll
@@ -227,7 +227,7 @@ UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) unsigned long long
                 for (int r = 0; r < R; r++) {
                     if (!(r & rr)) {
                         const bool up = ((t + WG_NT * r) & k) == 0;
-                        const unsigned long long x = v[r], y = v[r | rr];
+                        const T x = v[r], y = v[r | rr];
                         if ((x > y) == up) { v[r] = y; v[r | rr] = x; }
                     }
                 }
@@ -240,17 +240,17 @@ UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) unsigned long long
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const unsigned long long y = buf[(t ^ j) + WG_NT * r];
+                const T y = buf[(t ^ j) + WG_NT * r];
                 const bool up = ((t + WG_NT * r) & k) == 0, lower = (t & j) == 0;
-                const unsigned long long x = v[r];
+                const T x = v[r];
                 v[r] = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
             }
         }
         for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {
 #pragma unroll
             for (int r = 0; r < R; r++) {
-                const unsigned long long x = v[r];
-                const unsigned long long y = __shfl_xor(x, j, 64);
+                const T x = v[r];
+                const T y = __shfl_xor(x, j, 64);
                 const bool up = ((t + WG_NT * r) & k) == 0, lower = (t & j) == 0;
                 v[r] = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
             }
@@ -286,5 +286,28 @@ UZ_DEV void wg_sort64(unsigned long long *a, int n, SH *sh, bool a_in_lds = fals
     __syncthreads();
     if (a_in_lds) wg_bitonic_stages((lds_u64)a, N);
     else wg_bitonic_stages(a, N);
+#endif
+}
+
+// The same for 32-bit keys that lie in the workgroup's LDS arena (the arena build of the per-DNM kernel packs its pair-table keys into
+// 32 bits: half the shuffles and one min / max per exchange instead of a 64-bit compare and two selects).
+UZ_DEV void wg_sort32_lds(uint32_t *a, int n) {
+#ifdef UZ_EMU
+    std::sort(a, a + n);
+#else
+    typedef __attribute__((address_space(3))) uint32_t *lds_u32;
+    __syncthreads();
+    if (n <= 1) return;
+    int N = 1;
+    while (N < n) N <<= 1;
+    if (N <= 4 * WG_NT) {
+        if (N <= WG_NT) wg_bitonic_regs<1, uint32_t>((lds_u32)a, a, n);
+        else if (N <= 2 * WG_NT) wg_bitonic_regs<2, uint32_t>((lds_u32)a, a, n);
+        else wg_bitonic_regs<4, uint32_t>((lds_u32)a, a, n);
+        return;
+    }
+    for (int i = n + (int)threadIdx.x; i < N; i += WG_NT) a[i] = ~0u;
+    __syncthreads();
+    wg_bitonic_stages((lds_u32)a, N);
 #endif
 }
