@@ -55,7 +55,7 @@ def parse():
                     help="snv: BASELINE configs[2] (100k SNV/INDEL DNMs, read-backed); cnv: configs[4] (10k DEL/DUP: allele-balance "
                          "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
-                    "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 2)")
+                    "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 3)")
     ap.add_argument("--last-chunk", type=float, default=0.5, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")

@@ -15,13 +15,14 @@ def shard_bounds(n: int, world: int) -> List[int]:
 
 def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, min_per_chunk: int = 12500) -> List[int]:
     """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k, so a shard wants at
-    least two chunks, and chunks of at least ~min_per_chunk DNMs (a chunk's copy should outlast the host's work per chunk).  The
-    last chunk is smaller (last_chunk x the others): its read stage is the only one nothing hides.
-    chunks=None: from the shard size -- 100 k DNMs -> 8 chunks (measured at 9.1 KB per DNM: 6 / 8 / 10 / 12 chunks = 19.1 / 18.9 / 19.9 /
-    21.3 ms), a 12.5 k shard of an 8-GPU run -> 2.  -> [0, ..., n]"""
+    least three chunks (the first chunk's upload and the last chunk's read stage are the two things nothing hides), and chunks of at
+    least ~min_per_chunk DNMs (every chunk costs a host round trip and ~40 kernel launches).  The last chunk is smaller (last_chunk x
+    the others).
+    chunks=None: from the shard size -- 100 k DNMs -> 8 chunks (measured at 7.3 KB per DNM: 5 / 6 / 8 / 10 / 12 chunks = 15.9 / 15.6 /
+    15.7 / 16.5 / 17.3 ms), a 12.5 k shard of an 8-GPU run -> 3 (1 / 2 / 3 chunks = 3.69 / 3.54 / 3.35 ms).  -> [0, ..., n]"""
     if n <= 0:
         return [0, 0]
-    k = int(chunks) if chunks else max(2, n // int(min_per_chunk))
+    k = int(chunks) if chunks else max(3, n // int(min_per_chunk))
     k = max(1, min(k, n))
     f = min(1.0, max(0.05, float(last_chunk)))
     unit = n / (k - 1 + f)
