@@ -436,12 +436,12 @@ def main():
                 if k >= 2:
                     read_stage_end(k - 2)
                 tick()
+                if k >= 1:
+                    read_stage_begin(k - 1)
+                tick()
                 rids[k] = eng.upload_reads_packed(chunks[k][2])
                 if k + 2 < K:
                     site_stage(k + 2)
-                tick()
-                if k >= 1:
-                    read_stage_begin(k - 1)
                 if cnv and k >= 2:
                     cnv_stage(k - 2)
                 tick()
