@@ -279,3 +279,51 @@ def test_link_form_of_a_point_variant_table_matches_oracle(engine, monkeypatch, 
     assert dnm_sites(dn_w) == dnm_sites(dn_g)
     assert norm_records(want) == norm_records(got) and list(want.keys()) == list(got.keys())
     assert err_w == err_g and len(want) >= 2
+
+
+def test_window_lists_are_reused_only_for_the_batch_they_were_made_for(engine, small):
+    """The lists of the last finds stay in HBM and a read stage over a batch one of them covered takes them (uz_find_fetch's note in
+    unfazed_hip.h).  Whatever changes what a find would give must not meet stale lists: other parameters, another family under a
+    recycled id, other DNMs of the same number -- each result is held against the oracle's for ITS inputs."""
+    ds, sites, rt = small
+    kid = ds.dnms[0]["kid"]
+    ped = ds.pedigrees[kid]
+    cols = sites.family_columns(kid, ped["dad"], ped["mom"])
+    swapped = sites.family_columns(kid, ped["mom"], ped["dad"])  # the parents change places: every candidate's ALT parent flips
+    sv, rv = abi.sites_view(sites), abi.reads_view(rt)
+    rid = engine.upload_reads(rt)
+    dn = ds.dnms
+
+    def check(fid, fam_cols, dv, P):
+        fv = abi.family_view(*fam_cols)
+        engine.find(fid, dv, P, abi.FIND_SECOND_WINDOW)  # the caller's own find: the read stage below may take its lists
+        got = engine.phase_raw(fid, rid, dv, P, abi.FIND_SECOND_WINDOW)
+        want = orc.phase(P, sv, rv, dv, orc.find(P, sv, fv, dv, abi.FIND_SECOND_WINDOW), keep_lists=False)
+        for k in ("status", "counts", "origin", "evidence"):
+            assert np.array_equal(want[k], got[k]), k
+        return got
+
+    P = abi.make_params()
+    dv = _dv(sites, rt, dn)
+    sid = engine.upload_sites(sites)
+    fid = engine.add_family(sid, *cols)
+    a = check(fid, cols, dv, P)
+    assert (a["status"] == abi.ST_OK).any()
+    # other parameters: a window that holds nothing but the DNM itself
+    P2 = abi.make_params(search_dist=1)
+    b = check(fid, cols, dv, P2)
+    assert not (b["status"] == abi.ST_OK).any()
+    # other DNMs, as many: the first shifted off its site
+    dv2 = _dv(sites, rt, dn, start=[dn[0]["start"] + 3000] + [d["start"] for d in dn[1:]])
+    check(fid, cols, dv2, P)
+    # another family under the same ids
+    check(fid, cols, dv, P)
+    engine.free_sites(sid)
+    sid2 = engine.upload_sites(sites)
+    fid2 = engine.add_family(sid2, *swapped)
+    assert fid2 == fid  # (the id is recycled: the lists kept for it must be gone)
+    c = check(fid2, swapped, dv, P)
+    ok = (a["status"] == abi.ST_OK) & (a["origin"] != abi.OR_AMBIGUOUS) & (a["origin"] != abi.OR_NONE)
+    assert ok.any() and np.all(c["origin"][ok] != a["origin"][ok])
+    engine.free_reads(rid)
+    engine.free_sites(sid2)
