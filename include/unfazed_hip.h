@@ -90,6 +90,14 @@ int uz_reads_wait(uz_ctx *ctx, int reads_id);
  * form; `end` derived from the CIGAR when it was left out): [n_segs] each, any pointer may be NULL.  For parity tests of the
  * upload forms; waits for the table like uz_reads_wait. */
 int uz_reads_headers(uz_ctx *ctx, int reads_id, int32_t *start, int32_t *end, int32_t *tlen, int32_t *mate, uint32_t *qname);
+/* BGZF blocks inflated on the device (csrc/k_inflate.hip: one wavefront per block; fixed, dynamic and stored DEFLATE blocks).  The
+ * building block of a decode stage that no longer passes through the host's cores -- today a measured kernel
+ * with its parity test, not yet part of the session's path.  comp: the compressed bytes (host); in_off[k]: where the DEFLATE stream
+ * of block k starts in them (behind its gzip header and BC field); out_off[k] .. out_off[k+1]: where its ISIZE bytes go in `out`
+ * (host, [out_off[n_blocks]]).  repeat > 0: the kernel is run that many more times and *kernel_ms is their mean duration (HIP events).
+ * A stream that does not decode to exactly its declared size fails the call (UZ_E_RANGE, the block named). */
+int uz_bgzf_inflate(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off,
+                    uint8_t *out, int repeat, double *kernel_ms);
 /* page-locked host memory for the staged columns (plain hipHostMalloc; no context needed) */
 int uz_pinned_alloc(size_t bytes, void **out);
 void uz_pinned_free(void *p);

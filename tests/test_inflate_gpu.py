@@ -1,0 +1,91 @@
+"""BGZF blocks inflated on the device (uz_bgzf_inflate, csrc/k_inflate.hip) against zlib on the host: stored, fixed and dynamic DEFLATE
+blocks, matches that overlap their own output (runs), codes longer than the direct tables, blocks that end exactly at 64 KiB, empty
+blocks (the EOF marker), the generator's BAM (libdeflate's compressor) -- and streams that do not decode are refused, the block named."""
+import gzip
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from unfazed_amd.engine import UnfazedHipError
+
+pytestmark = pytest.mark.gpu
+
+
+def bgzf_block(payload: bytes, level=6, strategy=zlib.Z_DEFAULT_STRATEGY) -> bytes:
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+    body = c.compress(payload) + c.flush()
+    bsize = len(body) + 25
+    assert bsize <= 65536 + 25
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + body
+            + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+
+
+def payloads():
+    rng = np.random.default_rng(17)
+    text = (b"ACGTTGCAAGCT" * 40 + b"\n@read/1 151M * 0 0 " + bytes(rng.integers(33, 74, 151, dtype=np.uint8))) * 60
+    out = [b"", b"A", bytes(range(256)) * 3, b"\x00" * 65280, text[:65280], text[:30000],
+           bytes(rng.integers(0, 256, 40000, dtype=np.uint8)),          # incompressible: long codes / stored
+           bytes(rng.integers(0, 4, 65280, dtype=np.uint8)),            # two-bit entropy: short codes, many matches
+           b"ab" * 20000 + b"abc" * 5000 + b"x" * 3000,                 # distances shorter than the match lengths
+           bytes(rng.choice(np.arange(256, dtype=np.uint8), 50000, p=np.r_[0.5, np.full(255, 0.5 / 255)]))]  # one cheap symbol, 255 dear ones
+    return out
+
+
+def test_every_block_type_equals_zlib(engine):
+    blocks, want = [], []
+    for p in payloads():
+        for level, strategy in ((0, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)):
+            if level == 0 and len(p) > 65000:
+                continue  # (a stored block of 64 KiB does not fit a BGZF block with its framing)
+            blocks.append(bgzf_block(p, level, strategy))
+            want.append(p)
+    data = b"".join(blocks)
+    assert gzip.decompress(data) == b"".join(want)  # (the blocks are what htslib would call a BGZF file)
+    got, nb, _ = engine.bgzf_inflate(data)
+    assert nb == len(blocks)
+    assert bytes(got) == b"".join(want)
+    # one block alone, at every alignment of its first byte inside the buffer
+    one = bgzf_block(payloads()[4], 6)
+    for shift in range(4):
+        got, nb, _ = engine.bgzf_inflate(bgzf_block(b"x" * shift, 1) + one) if shift else engine.bgzf_inflate(one)
+        assert bytes(got)[-len(payloads()[4]):] == payloads()[4]
+
+
+def test_the_generators_bam(engine, tmp_path):
+    from synth import bigsynth
+    from synth.sites_np import make_clusters, make_sites, place_dnms_full
+    sc = make_sites(40_000, seed=7, contig_lens=[6e6, 4e6, 2e6])
+    dn = place_dnms_full(sc, 40, seed=8, indel_frac=0.2)
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=9)
+    cfg.n_clusters = cl.n
+    for level in (1, 6):
+        bam = str(tmp_path / ("kid%d.bam" % level))
+        bigsynth.write_bam(bam, cfg, sc, dn, cl, 0, cl.n, level=level)
+        data = open(bam, "rb").read()
+        got, nb, ms = engine.bgzf_inflate(data, repeat=3)
+        want = gzip.decompress(data)
+        assert nb > 50 and bytes(got) == want
+        print("BAM level %d: %d blocks, %.1f MB -> %.1f MB, %.3f ms per launch = %.1f GB/s of output" % (
+            level, nb, len(data) / 1e6, len(want) / 1e6, ms, len(want) / ms / 1e6))
+
+
+def test_broken_streams_are_refused(engine):
+    good = bgzf_block(payloads()[5], 6)
+    for breakage in ("flip", "size", "truncated_code"):
+        b = bytearray(good)
+        if breakage == "flip":
+            b[18 + len(b) // 3] ^= 0x55
+        elif breakage == "size":
+            b[-4:] = struct.pack("<I", len(payloads()[5]) - 7)
+        else:
+            b[18:22] = b"\xff\xff\xff\xff"  # block type 3 / nonsense lengths
+        try:
+            got, _, _ = engine.bgzf_inflate(bytes(b))
+        except UnfazedHipError as e:
+            assert "block 0" in str(e)
+            continue
+        assert breakage == "flip" and bytes(got) != payloads()[5]  # (a flipped bit can still be a valid stream of the same size: only then)

@@ -980,6 +980,56 @@ int uz_reads_headers(uz_ctx *c, int reads_id, int32_t *start, int32_t *end, int3
     });
 }
 
+int uz_bgzf_inflate(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off, uint8_t *out,
+                    int repeat, double *kernel_ms) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(comp && in_off && out_off && out && n_blocks >= 0 && comp_bytes >= 0, UZ_E_ARG, "bad arguments");
+        if (kernel_ms) *kernel_ms = 0;
+        if (n_blocks == 0) return;
+        const int64_t out_bytes = out_off[n_blocks];
+        for (int64_t k = 0; k < n_blocks; k++)
+            UZ_REQUIRE(in_off[k] >= 0 && in_off[k] < comp_bytes && out_off[k] <= out_off[k + 1] && out_off[k + 1] - out_off[k] <= 65536, UZ_E_ARG,
+                       "bad block table (a BGZF block inflates to at most 64 KiB)");
+        uint8_t *d_comp = nullptr, *d_out = nullptr;
+        int64_t *d_in = nullptr, *d_off = nullptr;
+        int32_t *d_flags = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        auto cleanup = [&] {
+            (void)hipFree(d_comp); (void)hipFree(d_out); (void)hipFree(d_in); (void)hipFree(d_off); (void)hipFree(d_flags);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        };
+        try {
+            UZ_HIP(hipMalloc((void **)&d_comp, (size_t)comp_bytes + 1024));
+            UZ_HIP(hipMalloc((void **)&d_out, (size_t)out_bytes + 64));
+            UZ_HIP(hipMalloc((void **)&d_in, (size_t)n_blocks * 8));
+            UZ_HIP(hipMalloc((void **)&d_off, (size_t)(n_blocks + 1) * 8));
+            UZ_HIP(hipMalloc((void **)&d_flags, 64));
+            UZ_HIP(hipMemsetAsync(d_comp + comp_bytes, 0, 1024, c->stream));
+            UZ_HIP(hipMemcpyAsync(d_comp, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, c->stream));
+            UZ_HIP(hipMemcpyAsync(d_in, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, c->stream));
+            UZ_HIP(hipMemcpyAsync(d_off, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, c->stream));
+            UZ_HIP(hipEventCreate(&e0));
+            UZ_HIP(hipEventCreate(&e1));
+            uz_launch_inflate(c, c->stream, n_blocks, d_comp, d_in, d_off, d_out, d_flags); // (warm-up and the run that is checked)
+            UZ_HIP(hipEventRecord(e0, c->stream));
+            for (int r = 0; r < std::max(repeat, 0); r++) uz_launch_inflate(c, c->stream, n_blocks, d_comp, d_in, d_off, d_out, d_flags);
+            UZ_HIP(hipEventRecord(e1, c->stream));
+            int32_t flags[2] = {0, 0};
+            UZ_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipMemcpyAsync(out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, c->stream));
+            UZ_HIP(hipStreamSynchronize(c->stream));
+            if (kernel_ms && repeat > 0) {
+                float ms = 0;
+                UZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+                *kernel_ms = (double)ms / repeat;
+            }
+            if (flags[1]) throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(flags[1] >> 4) + ": not a valid DEFLATE stream of the declared size (code " + std::to_string(flags[1] & 15) + ")"};
+        } catch (...) { cleanup(); throw; }
+        cleanup();
+    });
+}
+
 int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");

@@ -1,0 +1,291 @@
+// k_inflate.hip -- BGZF blocks inflated on the device (DEFLATE, RFC 1951), one wavefront per block.
+//
+// Why: from files to results the host is the bound -- the box's 16 CPUs inflate 17 GB/s (libdeflate) while the compressed
+// windows of a batch would cross the link at 55 GB/s and the device phases what comes out of them two orders of magnitude
+// faster.  A BGZF block is an independent DEFLATE stream of at most 64 KiB of output whose LZ77
+// window never leaves the block: a batch's windows are tens of thousands of such blocks, enough for every wave slot of
+// the chip.
+//
+// How: the 64 lanes of a wave run the decoder in lockstep on the SAME state (bit buffer, positions: every lane holds a
+// copy, so there is no divergence and no broadcast), and differ only where there is parallel work:
+//   * input: the wave reads 64 consecutive dwords of the stream with one coalesced load and hands them out with
+//     v_readlane as the bit buffer drains (one memory round trip per 256 bytes of input, the next one already in flight);
+//   * Huffman tables in LDS: a direct table for codes of up to 10 (literal / length) or 8 (distance) bits, filled by all
+//     lanes; the rare longer codes are resolved the canonical way (count / first code per length);
+//   * a match is copied by all lanes at once (lane k takes byte k, modulo the distance when source and destination
+//     overlap); literals are stored by lane 0.
+// The output lies in HBM, not in LDS (64 KiB per block would leave two waves per CU): a match reads bytes this wave
+// stored earlier, so its loads bypass the L1 (agent-scope loads) and wait for the wave's outstanding stores only when
+// the source reaches into bytes stored since the last such wait -- most matches of alignment records point hundreds of
+// bytes back and wait for nothing.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include "uz_ctx.hpp"
+
+namespace {
+
+#define UZI_LIT_BITS 10
+#define UZI_DIST_BITS 8
+
+struct InflateLds {
+    uint16_t lit_tab[1 << UZI_LIT_BITS];   // (symbol << 4) | length; 0: a longer code
+    uint16_t dist_tab[1 << UZI_DIST_BITS];
+    uint16_t lit_sorted[288], dist_sorted[32]; // symbols in canonical order (by length, then value)
+    uint16_t lit_cnt[16], dist_cnt[16];        // codes per length
+    uint8_t lens[320];                          // code lengths of the block being set up: literal / length code at 0, distance code at 288
+    uint8_t cl_lens[32];                        // ... and of the code they are written in
+    uint16_t code_of[288];                      // bit-reversed canonical code of every symbol (table fill)
+};
+
+__device__ __constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__device__ __constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__device__ __constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__device__ __constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__device__ __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+// the input stream of one block, seen through two registers per lane: dwords [cbase, cbase + 64) and the 64 after them
+struct BitIn {
+    const uint32_t *w;  // aligned dwords of the compressed buffer
+    long long cbase;    // dword index held by lane 0 of `cur`
+    uint32_t cur, nxt;  // lane l: w[cbase + l], w[cbase + 64 + l]
+    long long widx;     // next dword to take
+    unsigned long long buf;
+    int bits;
+};
+__device__ __forceinline__ uint32_t lane_word(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
+__device__ __forceinline__ void bi_open(BitIn &b, const uint8_t *base, long long byte_off, int lane) {
+    b.w = reinterpret_cast<const uint32_t *>(base);
+    const long long first = byte_off >> 2;
+    b.cbase = first;
+    b.cur = b.w[first + lane];
+    b.nxt = b.w[first + 64 + lane];
+    b.widx = first + 1;
+    const int skip = (int)(byte_off & 3) * 8;
+    b.buf = (unsigned long long)(lane_word(b.cur, 0) >> skip);
+    b.bits = 32 - skip;
+}
+__device__ __forceinline__ void bi_refill(BitIn &b, int lane) { // afterwards: at least 33 bits
+    if (b.bits <= 32) {
+        long long k = b.widx - b.cbase;
+        if (k >= 64) {
+            b.cur = b.nxt;
+            b.cbase += 64;
+            b.nxt = b.w[b.cbase + 64 + lane];
+            k -= 64;
+        }
+        b.buf |= (unsigned long long)lane_word(b.cur, (int)k) << b.bits;
+        b.bits += 32;
+        b.widx++;
+    }
+}
+__device__ __forceinline__ uint32_t bi_peek(const BitIn &b, int n) { return (uint32_t)(b.buf & ((1ULL << n) - 1ULL)); }
+__device__ __forceinline__ void bi_drop(BitIn &b, int n) { b.buf >>= n; b.bits -= n; }
+__device__ __forceinline__ uint32_t bi_take(BitIn &b, int n) { const uint32_t v = bi_peek(b, n); bi_drop(b, n); return v; }
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+
+// canonical Huffman set-up from lens[0 .. n): counts, symbols in canonical order, the direct table for codes of <= tb bits.
+// false: an over-subscribed or (but for the one-code case) incomplete set of lengths
+// (complete: a literal / length or code-length code must use its code space up; a distance code need not -- the fixed one does not,
+// and a block without matches has none -- an unused code then decodes to "no symbol")
+__device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int lane, bool complete) {
+    // (every lane runs the serial part on the same values; lane 0 stores)
+    int count[16];
+#pragma unroll
+    for (int l = 0; l < 16; l++) count[l] = 0;
+    for (int s = 0; s < n; s++) count[lens[s]]++;
+    count[0] = 0;
+    int left = 1;
+    for (int l = 1; l < 16; l++) {
+        left = (left << 1) - count[l];
+        if (left < 0) return false;
+    }
+    if (left > 0 && complete) return false;
+    int offs[16], next[16];
+    offs[1] = 0; next[1] = 0;
+    for (int l = 1; l < 15; l++) { offs[l + 1] = offs[l] + count[l]; next[l + 1] = (next[l] + count[l]) << 1; }
+    __syncthreads();
+    if (lane == 0) {
+        for (int l = 0; l < 16; l++) cnt[l] = (uint16_t)count[l];
+    }
+    for (int s = 0; s < n; s++) {
+        const int l = lens[s];
+        if (l) {
+            if (lane == 0) { sorted[offs[l]] = (uint16_t)s; code_of[s] = (uint16_t)bitrev((uint32_t)next[l], l); }
+            offs[l]++; next[l]++;
+        }
+    }
+    for (int k = lane; k < (1 << tb); k += 64) tab[k] = 0;
+    __syncthreads();
+    for (int s = lane; s < n; s += 64) { // every lane fills the replicas of its symbols' codes
+        const int l = lens[s];
+        if (l && l <= tb) {
+            const uint16_t e = (uint16_t)((s << 4) | l);
+            for (int k = code_of[s]; k < (1 << tb); k += 1 << l) tab[k] = e;
+        }
+    }
+    __syncthreads();
+    return true;
+}
+// one symbol: the direct table, or the canonical walk for a code longer than the table's index (rare)
+__device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb, const uint16_t *sorted, const uint16_t *cnt) {
+    const uint32_t e = tab[bi_peek(b, tb)];
+    if (e) { bi_drop(b, (int)(e & 15u)); return (int)(e >> 4); }
+    int code = 0, first = 0, index = 0;
+    unsigned long long v = b.buf;
+    for (int l = 1; l <= 15; l++) {
+        code |= (int)(v & 1ULL);
+        v >>= 1;
+        const int c = cnt[l];
+        if (code - c < first) { bi_drop(b, l); return sorted[index + (code - first)]; }
+        index += c; first += c;
+        first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+// err: 1 bad block type / stored length, 2 bad code lengths, 3 bad symbol, 4 output overrun or distance before the block, 5 wrong size
+__global__ __launch_bounds__(64) void k_bgzf_inflate(int64_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ in_off,
+                                                     const int64_t *__restrict__ out_off, uint8_t *out, int32_t *cursor, int32_t *err) {
+    __shared__ InflateLds L;
+    __shared__ int next_block;
+    const int lane = threadIdx.x;
+    for (;;) {
+        __syncthreads();
+        if (lane == 0) next_block = atomicAdd(cursor, 1);
+        __syncthreads();
+        const int64_t blk = next_block;
+        if (blk >= n_blocks) return;
+        uint8_t *o = out + out_off[blk];
+        const int64_t osize = out_off[blk + 1] - out_off[blk];
+        BitIn b;
+        bi_open(b, comp, in_off[blk], lane);
+        int64_t pos = 0, safe = 0; // bytes written; bytes whose stores are known to have landed
+        int bad = 0;
+        for (int last = 0; !last && !bad;) {
+            bi_refill(b, lane);
+            last = (int)bi_take(b, 1);
+            const int type = (int)bi_take(b, 2);
+            if (type == 0) { // stored: to the byte boundary, LEN, NLEN, then the bytes
+                bi_drop(b, b.bits & 7);
+                bi_refill(b, lane);
+                const uint32_t len = bi_take(b, 16);
+                bi_refill(b, lane);
+                const uint32_t nlen = bi_take(b, 16);
+                if ((len ^ nlen) != 0xFFFFu || pos + (int64_t)len > osize) { bad = 1; break; }
+                // the bytes: drain what the bit buffer holds (whole bytes), then dword by dword through the same window
+                uint32_t done = 0;
+                while (done < len) {
+                    bi_refill(b, lane);
+                    const int nb = min(b.bits >> 3, (int)min(len - done, 4u));
+                    const uint32_t v = bi_take(b, 8 * nb);
+                    if (lane < nb) o[pos + done + lane] = (uint8_t)(v >> (8 * lane));
+                    done += (uint32_t)nb;
+                }
+                pos += len;
+                continue;
+            }
+            if (type == 3) { bad = 1; break; }
+            int nlit, ndist;
+            if (type == 1) { // fixed code
+                for (int s = lane; s < 288; s += 64) L.lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
+                if (lane < 32) L.lens[288 + lane] = 5;
+                nlit = 288; ndist = 30;
+                __syncthreads();
+            } else { // dynamic code: the code-length code, then the lengths of both codes
+                bi_refill(b, lane);
+                nlit = (int)bi_take(b, 5) + 257;
+                ndist = (int)bi_take(b, 5) + 1;
+                const int ncl = (int)bi_take(b, 4) + 4;
+                if (nlit > 286 || ndist > 30) { bad = 2; break; }
+                __syncthreads();
+                if (lane < 19) L.cl_lens[lane] = 0;
+                __syncthreads();
+                for (int k = 0; k < ncl; k++) {
+                    bi_refill(b, lane);
+                    const uint32_t v = bi_take(b, 3);
+                    if (lane == 0) L.cl_lens[kClOrder[k]] = (uint8_t)v;
+                }
+                __syncthreads();
+                // (the code-length code sits where the distance code will be: 7-bit direct table, canonical arrays)
+                if (!build_table(L.cl_lens, 19, L.dist_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, lane, true)) { bad = 2; break; }
+                int n = 0, prev = 0;
+                while (n < nlit + ndist) {
+                    bi_refill(b, lane);
+                    const int s = decode_sym(b, L.dist_tab, 7, L.dist_sorted, L.dist_cnt);
+                    if (s < 0) { bad = 2; break; }
+                    int rep = 1, val = s;
+                    if (s == 16) { if (n == 0) { bad = 2; break; } val = prev; rep = 3 + (int)bi_take(b, 2); }
+                    else if (s == 17) { val = 0; rep = 3 + (int)bi_take(b, 3); }
+                    else if (s == 18) { val = 0; rep = 11 + (int)bi_take(b, 7); }
+                    if (n + rep > nlit + ndist) { bad = 2; break; }
+                    for (int k = lane; k < rep; k += 64) { // entry n + k: a literal / length code's length, or a distance code's
+                        const int at = n + k;
+                        L.lens[at < nlit ? at : 288 + (at - nlit)] = (uint8_t)val;
+                    }
+                    n += rep;
+                    prev = val;
+                }
+                if (bad) break;
+                __syncthreads();
+                if (L.lens[256] == 0) { bad = 2; break; } // no end-of-block code
+            }
+            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, lane, true)) { bad = 2; break; }
+            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, lane, false)) { bad = 2; break; }
+            // ---- the symbols of the block
+            for (;;) {
+                bi_refill(b, lane);
+                const int s = decode_sym(b, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt);
+                if (s < 256) {
+                    if (s < 0) { bad = 3; break; }
+                    if (pos >= osize) { bad = 4; break; }
+                    if (lane == 0) o[pos] = (uint8_t)s;
+                    pos++;
+                    continue;
+                }
+                if (s == 256) break;
+                if (s > 285) { bad = 3; break; }
+                bi_refill(b, lane);
+                const int len = (int)kLenBase[s - 257] + (int)bi_take(b, kLenExtra[s - 257]);
+                bi_refill(b, lane);
+                const int ds = decode_sym(b, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt);
+                if (ds < 0 || ds > 29) { bad = 3; break; }
+                bi_refill(b, lane);
+                const int dist = (int)kDistBase[ds] + (int)bi_take(b, kDistExtra[ds]);
+                if ((int64_t)dist > pos || pos + len > osize) { bad = 4; break; }
+                const int64_t src = pos - dist;
+                if (src + (len < dist ? len : dist) > safe) { // the source reaches into bytes whose stores may still be in flight
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+                    asm volatile("" ::: "memory");
+                    safe = pos;
+                }
+                for (int k = lane; k < len; k += 64) {
+                    const int sk = dist >= len ? k : k % dist;
+                    o[pos + k] = __hip_atomic_load(o + src + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (past the L1: see the head of the file)
+                }
+                pos += len;
+            }
+        }
+        if (!bad && pos != osize) bad = 5;
+        if (bad && lane == 0) atomicCAS(err, 0, bad | ((int)blk << 4));
+    }
+}
+
+} // namespace
+
+// comp / in_off / out_off / out: device memory (comp padded by 1 KiB past its last byte); out_off[n_blocks] = total bytes
+void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, const int64_t *in_off, const int64_t *out_off, uint8_t *out,
+                       int32_t *cursor_and_err /* [2], zeroed here */) {
+    if (n_blocks <= 0) return;
+    UZ_HIP(hipMemsetAsync(cursor_and_err, 0, 2 * sizeof(int32_t), st));
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    const int64_t grid = std::min<int64_t>(n_blocks, (int64_t)cus * 32); // every wave slot of the chip: a wave is one block's decoder
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)grid), dim3(64), 0, st, n_blocks, comp, in_off, out_off, out, cursor_and_err, cursor_and_err + 1);
+    UZ_HIP(hipGetLastError());
+}

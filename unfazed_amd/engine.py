@@ -18,7 +18,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers",
+    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -56,6 +56,7 @@ def load_library(path: Optional[str] = None):
     L.uz_set_params.argtypes = [vp, vp]
     L.uz_reads_wait.argtypes = [vp, C.c_int]
     L.uz_reads_headers.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.uz_bgzf_inflate.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -245,6 +246,35 @@ class HipEngine:
         out = {k: np.zeros(max(1, int(n)), np.uint32 if k == "qname" else np.int32) for k in ("start", "end", "tlen", "mate", "qname")}
         self._ck(self.L.uz_reads_headers(self.h, int(rid), *(out[k].ctypes.data for k in ("start", "end", "tlen", "mate", "qname"))), "uz_reads_headers")
         return {k: v[: int(n)] for k, v in out.items()}
+
+    def bgzf_inflate(self, data, repeat: int = 0):
+        """Every BGZF block of `data` (bytes / uint8 array: a BGZF file or a run of its blocks) inflated on the device (uz_bgzf_inflate).
+        -> (uint8 array of the inflated bytes, block count, mean kernel ms over `repeat` extra runs or None)"""
+        buf = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+        n, at, ins, sizes = buf.size, 0, [], []
+        while at + 18 <= n:
+            if not (buf[at] == 0x1F and buf[at + 1] == 0x8B and buf[at + 2] == 8 and (buf[at + 3] & 4)):
+                raise UnfazedHipError("not a BGZF block at byte %d" % at)
+            xlen = int(buf[at + 10]) | (int(buf[at + 11]) << 8)
+            bsize, p = None, at + 12
+            while p + 4 <= at + 12 + xlen:
+                slen = int(buf[p + 2]) | (int(buf[p + 3]) << 8)
+                if buf[p] == 66 and buf[p + 1] == 67 and slen == 2:
+                    bsize = (int(buf[p + 4]) | (int(buf[p + 5]) << 8)) + 1
+                p += 4 + slen
+            if bsize is None or at + bsize > n:
+                raise UnfazedHipError("BGZF block at byte %d: no BC field, or the block overruns the data" % at)
+            ins.append(at + 12 + xlen)
+            sizes.append(int(buf[at + bsize - 4]) | (int(buf[at + bsize - 3]) << 8) | (int(buf[at + bsize - 2]) << 16) | (int(buf[at + bsize - 1]) << 24))
+            at += bsize
+        nb = len(ins)
+        in_off = np.asarray(ins, np.int64)
+        out_off = np.concatenate([[0], np.cumsum(np.asarray(sizes, np.int64))]).astype(np.int64)
+        out = np.zeros(max(1, int(out_off[-1])), np.uint8)
+        ms = C.c_double(0.0)
+        self._ck(self.L.uz_bgzf_inflate(self.h, buf.ctypes.data, int(n), nb, in_off.ctypes.data if nb else None, out_off.ctypes.data, out.ctypes.data,
+                                        int(repeat), C.byref(ms)) if nb else 0, "uz_bgzf_inflate")
+        return out[: int(out_off[-1])], nb, (ms.value if repeat > 0 else None)
 
     def adopt_sites(self, view: abi.SitesView) -> int:
         sid = C.c_int(-1)
