@@ -98,6 +98,12 @@ int uz_reads_headers(uz_ctx *ctx, int reads_id, int32_t *start, int32_t *end, in
  * A stream that does not decode to exactly its declared size fails the call (UZ_E_RANGE, the block named). */
 int uz_bgzf_inflate(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off,
                     uint8_t *out, int repeat, double *kernel_ms);
+/* The working form: the same kernel on buffers the context keeps from call to call and on a stream of its own; comp and out in pinned
+ * host memory for full link speed (uz_pinned_alloc).  This is what io_native.BamSource.select(inflate=...) calls between
+ * uz_bam_stage_begin and uz_bam_stage_finish (unfazed_io.h): the blocks a batch's walk will read are gathered, inflated here, and handed
+ * back; the host then copies records out of them instead of inflating (and still holds every block against its CRC-32). */
+int uz_bgzf_inflate_to_host(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off,
+                            uint8_t *out);
 /* page-locked host memory for the staged columns (plain hipHostMalloc; no context needed) */
 int uz_pinned_alloc(size_t bytes, void **out);
 void uz_pinned_free(void *p);

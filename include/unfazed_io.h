@@ -255,12 +255,24 @@ int uz_io_cpu_quota(void);            /* CPUs the container's cgroup grants (cpu
  * holds more than 65536 combinations of the small columns (stage it through the table form then). */
 int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra,
                       int flags, int min_base_qual, int threads, uz_stage **out);
+/* The plan in two halves, for a caller that can inflate BGZF blocks faster than the host's cores (the device: uz_bgzf_inflate in
+ * unfazed_hip.h): uz_bam_stage_begin = fetches -> reach intervals -> tasks with their file spans; uz_stage_gather_blocks copies the
+ * blocks the walk will read back to back (whole blocks) and says where each DEFLATE stream starts and where its bytes belong in an
+ * inflated buffer (call it with comp == NULL for the sizes first); uz_stage_set_inflated hands that buffer back (it must stay valid until
+ * uz_bam_stage_finish returns); uz_bam_stage_finish = walk (listed blocks are copied from the buffer and held against their CRC-32, any
+ * other block goes through the host's inflate), mates, numbering.  uz_bam_stage_plan = begin + finish. */
+int uz_bam_stage_begin(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int flags,
+                       int min_base_qual, int threads, uz_stage **out);
+int uz_stage_gather_blocks(uz_stage *s, uint8_t *comp, int64_t cap, int64_t *in_off /* [n_blocks] */, int64_t *out_off /* [n_blocks + 1] */,
+                           int64_t *n_blocks, int64_t *comp_bytes, int64_t *out_bytes);
+int uz_stage_set_inflated(uz_stage *s, const uint8_t *inflated);
+int uz_bam_stage_finish(uz_stage *s);
 /* [0] records, [1] CIGAR words that travel, [2] words left home (simple records), [3] row units, [4] staged base units, [5] listed
  * bases (exc_*), [6] listed low-quality positions, [7] qlow_pos_wide, [8] dictionary entries, [9] escapes, [10] query names,
  * [11] 1 when the dictionary carries unit masks */
 void uz_stage_sizes(const uz_stage *s, int64_t out[12]);
-/* [0] compressed bytes read, [1] BGZF blocks inflated, [2] records walked, [3] records kept, [4] reach intervals, [5] mates looked
- * up through the index */
+/* [0] compressed bytes read, [1] BGZF blocks read, [2] records walked, [3] records kept, [4] reach intervals, [5] mates looked
+ * up through the index, [6] blocks taken from the pre-inflated buffer, [7] compressed bytes of the gathered blocks */
 void uz_stage_io_stats(const uz_stage *s, int64_t out[8]);
 /* seconds: [0] file spans from the index, [1] inflate + walk, [2] mates, [3] numbering, [4] the last fill */
 void uz_stage_timing(const uz_stage *s, double out[6]);

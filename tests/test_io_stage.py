@@ -193,3 +193,41 @@ def test_sv_batch_form_wide_fetches_stage_no_units(workload):
     assert int(got.view.n_seq_units) < int(plain.view.n_seq_units) // 2  # most of the records only a wide fetch returns keep no unit
     um = got.arrays["tup_umask"][got.arrays["tup"][: int(got.view.n_segs)]]
     assert (um == 0).sum() > int(got.view.n_segs) // 3
+
+
+def test_blocks_inflated_elsewhere_give_the_same_batch(workload, monkeypatch):
+    """uz_bam_stage_begin / uz_stage_gather_blocks / uz_stage_set_inflated / uz_bam_stage_finish: the blocks the walk will read, gathered
+    and inflated by somebody else (here zlib, block by block; in the product the device, tests/test_inflate_gpu.py), give the same batch
+    byte for byte; blocks the gather did not list (mates through the index) still go through the host's inflate; a block that comes
+    back wrong is refused by its CRC-32."""
+    import zlib
+    w = workload
+    fc, flo, fhi, fex = fetches_of(w, 2, 4)
+    src = io_native.BamSource(w["bam"], threads=2)
+    plain = src.select(fc, flo, fhi, 20, extra=fex)
+    calls = []
+
+    def host_inflate(comp, comp_bytes, in_off, out_off, out, spoil=False):
+        calls.append((int(in_off.size), int(comp_bytes), int(out_off[-1])))
+        for k in range(in_off.size):
+            n = int(out_off[k + 1] - out_off[k])
+            data = zlib.decompressobj(-15).decompress(bytes(comp[int(in_off[k]): int(comp_bytes)]), n) if n else b""
+            assert len(data) == n
+            out[int(out_off[k]): int(out_off[k]) + n] = np.frombuffer(data, np.uint8)
+        if spoil:
+            out[int(out_off[-1]) // 2] ^= 1
+
+    got = src.select(fc, flo, fhi, 20, extra=fex, inflate=host_inflate)
+    assert_same(got, plain)
+    assert calls and calls[0][0] > 10 and got.io_stats["blocks_from_the_device"] >= 0.9 * got.io_stats["blocks_inflated"] > 0
+    assert got.pre_inflate["blocks"] == calls[0][0] and got.pre_inflate["out_bytes"] == calls[0][2]
+    # mates outside the reach: looked up through the index, in blocks the gather does not list
+    monkeypatch.setenv("UZ_STAGE_SLACK", "50")
+    far = io_native.BamSource(w["bam"], threads=2)
+    a = far.select(fc, flo, fhi, 20, extra=fex)
+    b = far.select(fc, flo, fhi, 20, extra=fex, inflate=host_inflate)
+    assert_same(a, b)
+    assert b.io_stats["index_mate_lookups"] > 0 and b.io_stats["blocks_from_the_device"] < b.io_stats["blocks_inflated"]
+    monkeypatch.delenv("UZ_STAGE_SLACK")
+    with pytest.raises(io_native.IoError, match="CRC mismatch in the pre-inflated"):
+        src.select(fc, flo, fhi, 20, extra=fex, inflate=lambda *x: host_inflate(*x, spoil=True))

@@ -400,6 +400,8 @@ void uz_destroy(uz_ctx *c) {
     c->cnv_counts.release(); c->cnv_pos.release(); c->cnv_origin.release(); c->cnv_evidence.release(); c->cnv_etype.release(); c->cnv_rb.release();
     c->cnt_c.release(); c->cnt_h.release(); c->cand_off.release(); c->het_off.release();
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release(); c->win_range.release();
+    c->inf_comp.release(); c->inf_out.release(); c->inf_in.release(); c->inf_off.release(); c->inf_flags.release();
+    if (c->inf_stream) (void)hipStreamDestroy(c->inf_stream);
     for (FindSlot &a : c->find_alt) {
         a.cnt_c.release(); a.cnt_h.release(); a.win_range.release(); a.cand_off.release(); a.het_off.release();
         a.cand_idx.release(); a.het_idx.release(); a.cand_flags.release();
@@ -1027,6 +1029,30 @@ int uz_bgzf_inflate(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t 
             if (flags[1]) throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(flags[1] >> 4) + ": not a valid DEFLATE stream of the declared size (code " + std::to_string(flags[1] & 15) + ")"};
         } catch (...) { cleanup(); throw; }
         cleanup();
+    });
+}
+
+int uz_bgzf_inflate_to_host(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off,
+                            uint8_t *out) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(n_blocks >= 0 && comp_bytes >= 0 && (n_blocks == 0 || (comp && in_off && out_off && out)), UZ_E_ARG, "bad arguments");
+        if (n_blocks == 0) return;
+        const int64_t out_bytes = out_off[n_blocks];
+        UZ_REQUIRE(out_bytes >= 0, UZ_E_ARG, "bad block table");
+        if (!c->inf_stream) UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
+        hipStream_t st = c->inf_stream;
+        c->inf_comp.ensure((size_t)comp_bytes + 1024); c->inf_out.ensure((size_t)out_bytes + 64);
+        c->inf_in.ensure((size_t)n_blocks); c->inf_off.ensure((size_t)n_blocks + 1); c->inf_flags.ensure(16);
+        UZ_HIP(hipMemsetAsync(c->inf_comp.p + comp_bytes, 0, 1024, st));
+        UZ_HIP(hipMemcpyAsync(c->inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+        UZ_HIP(hipMemcpyAsync(c->inf_in.p, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
+        UZ_HIP(hipMemcpyAsync(c->inf_off.p, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
+        uz_launch_inflate(c, st, n_blocks, c->inf_comp.p, c->inf_in.p, c->inf_off.p, c->inf_out.p, c->inf_flags.p);
+        int32_t flags[2] = {0, 0};
+        UZ_HIP(hipMemcpyAsync(flags, c->inf_flags.p, sizeof(flags), hipMemcpyDeviceToHost, st));
+        UZ_HIP(hipMemcpyAsync(out, c->inf_out.p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
+        UZ_HIP(hipStreamSynchronize(st));
+        if (flags[1]) throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(flags[1] >> 4) + " of the batch: not a valid DEFLATE stream of the declared size (code " + std::to_string(flags[1] & 15) + ")"};
     });
 }
 

@@ -256,6 +256,7 @@ struct Inflater {
         if (z_init) inflateEnd(&z);
     }
     Inflater(const Inflater &) = delete;
+    uint32_t crc_of(const uint8_t *p, size_t n) const { return ld ? libdeflate().crc(0, p, n) : (uint32_t)crc32(0L, p, (uInt)n); }
     void block(const uint8_t *c, size_t clen, uint8_t *dst, size_t isize, uint32_t crc, int64_t coff) {
         if (isize == 0) return;
         if (ld) {

@@ -121,9 +121,27 @@ bool block_at(const uz_bamsrc &S, int64_t coff, BlockHdr &b) {
 
 // A sequential reader of the inflated stream from a virtual offset on: inflates block after block into a rolling buffer and
 // hands out whole records with their virtual offsets.
+// blocks somebody else has inflated already (uz_stage_set_inflated: the device): where block `coff` lies in that buffer
+struct PreBlk { int64_t coff; int64_t at; uint32_t isize, crc; };
+struct PreDir {
+    const std::vector<PreBlk> *blks = nullptr; // ascending coff
+    const uint8_t *base = nullptr;
+    size_t hint = 0;
+    const PreBlk *find(int64_t coff) {
+        if (!blks || !base) return nullptr;
+        const std::vector<PreBlk> &v = *blks;
+        if (hint < v.size() && v[hint].coff == coff) return &v[hint++];
+        auto it = std::lower_bound(v.begin(), v.end(), coff, [](const PreBlk &b, int64_t key) { return b.coff < key; });
+        if (it == v.end() || it->coff != coff) return nullptr;
+        hint = (size_t)(it - v.begin()) + 1;
+        return &*it;
+    }
+};
+
 struct Stream {
     const uz_bamsrc &S;
     Inflater &inf;
+    PreDir pre;
     std::vector<uint8_t> own_buf;
     std::vector<uint8_t> &buf; // (a worker hands in its own buffer, kept from task to task: no fresh pages per task)
     struct Blk { int64_t coff; size_t at, isize; };
@@ -131,7 +149,7 @@ struct Stream {
     size_t cur = 0;        // next unread byte of buf
     size_t blk = 0;        // block holding `cur`
     int64_t next_coff = 0;
-    int64_t file_bytes = 0, n_blocks = 0;
+    int64_t file_bytes = 0, n_blocks = 0, n_pre = 0;
     bool eof = false;
     Stream(const uz_bamsrc &s, Inflater &i) : S(s), inf(i), buf(own_buf) {}
     Stream(const uz_bamsrc &s, Inflater &i, std::vector<uint8_t> &b) : S(s), inf(i), buf(b) {}
@@ -161,7 +179,15 @@ struct Stream {
         if (!block_at(S, next_coff, h)) { eof = true; return false; }
         const size_t at = buf.size();
         buf.resize(at + h.isize);
-        inf.block(S.map + h.cdata, h.clen, buf.data() + at, h.isize, h.crc, next_coff);
+        if (const PreBlk *pb = pre.find(next_coff)) { // inflated elsewhere: its bytes are copied in and held against the block's checksum
+            if (pb->isize != h.isize) fail(UZ_IO_E_FORMAT, "pre-inflated BGZF block at byte %lld has another size", (long long)next_coff);
+            if (h.isize) {
+                memcpy(buf.data() + at, pre.base + pb->at, h.isize);
+                if (inf.crc_of(buf.data() + at, h.isize) != h.crc) fail(UZ_IO_E_FORMAT, "CRC mismatch in the pre-inflated BGZF block at byte %lld", (long long)next_coff);
+            }
+            n_pre++;
+        } else
+            inf.block(S.map + h.cdata, h.clen, buf.data() + at, h.isize, h.crc, next_coff);
         blks.push_back(Blk{next_coff, at, h.isize});
         next_coff += (int64_t)h.blen;
         file_bytes += (int64_t)h.blen;
@@ -273,7 +299,8 @@ struct Task { // reach intervals of one reference whose file spans meet (walked 
     std::vector<uint8_t> names;      // name bytes (no terminator)
     std::vector<uint32_t> cigars;    // words of the records that are not simple
     std::vector<uint8_t> pay;        // per record with has_pay: seq2 units | exceptions (pos u16, code u8, pad) | positions (u16) | plane row
-    int64_t n_walked = 0, file_bytes = 0, n_blocks = 0;
+    int64_t n_walked = 0, file_bytes = 0, n_blocks = 0, n_pre = 0;
+    std::vector<PreBlk> pre;         // blocks of this task inflated elsewhere (uz_stage_gather_blocks / uz_stage_set_inflated)
     // sizes of the kept records (filled by the numbering pass)
     int64_t n_keep = 0, k0 = 0;
 };
@@ -408,6 +435,12 @@ struct uz_stage {
     std::vector<SliceBase> base;           // [slices + 1]: totals in front of every slice; the last entry holds the sizes
     int64_t n = 0, n_tup = 0, n_qnames = 0;
     int wide = 0;
+    // the plan in two halves (uz_bam_stage_begin / uz_bam_stage_finish): between them the blocks the walk will read can be inflated
+    // elsewhere -- on the device -- and handed back
+    int threads = 0;
+    bool begun = false, finished = false;
+    const uint8_t *inflated = nullptr;
+    int64_t n_pre_blocks = 0, pre_bytes = 0;
     std::vector<uint64_t> tup_key;
     std::vector<uint32_t> tup_k2;
     std::vector<int64_t> name_of_id;       // id -> record
@@ -517,6 +550,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
     const std::vector<Fx> &fx = P.fx[(size_t)T.tid];
     const int32_t max_len = P.fx_max_len[(size_t)T.tid];
     Stream s(S, W.inf, W.buf);
+    if (P.inflated && !T.pre.empty()) { s.pre.blks = &T.pre; s.pre.base = P.inflated; }
     std::vector<WRec> &all = W.all;
     Task &tmp = W.tmp; // pools of every walked record; the survivors are copied over
     all.clear(); tmp.names.clear(); tmp.cigars.clear(); tmp.pay.clear();
@@ -581,7 +615,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
             s.advance(bs);
         }
     }
-    T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks;
+    T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks; T.n_pre = s.n_pre;
     // mate candidates: the records that share a name with a direct one
     std::vector<uint64_t> &dn = W.dn;
     dn.clear();
@@ -643,7 +677,8 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
 // a mate looked up through the index: the records overlapping [mpos, mpos + 1) of the mate's reference, walked like a fetch
 struct Lookup { int64_t who; int32_t mtid, mpos; };
 
-void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int threads) {
+// first half of the plan: fetches -> reach intervals -> tasks with their file spans
+void plan_begin(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int threads) {
     const uz_bamsrc &S = *P.src;
     const int32_t n_ref = (int32_t)S.contigs.size();
     double t0 = now_s();
@@ -700,8 +735,17 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
         }
         P.tasks.swap(merged);
     }
+    P.timing[0] = now_s() - t0;
+    P.threads = threads;
+    P.begun = true;
+}
+
+// second half of the plan: walk, mates, numbering
+void plan_finish(uz_stage &P) {
+    const uz_bamsrc &S = *P.src;
+    const int32_t n_ref = (int32_t)S.contigs.size();
+    const int threads = P.threads;
     double t1 = now_s();
-    P.timing[0] = t1 - t0;
     // ---- the walk
     {
         const int w = (int)std::min<int64_t>(threads, std::max<int64_t>(1, (int64_t)P.tasks.size()));
@@ -1089,7 +1133,7 @@ void plan(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, c
             P.wide |= wides[(size_t)w];
         }
     for (int32_t c = 0; c < n_ref; c++) P.contig_off[(size_t)c + 1] += P.contig_off[(size_t)c];
-    for (const Task &T : P.tasks) { P.io_stats[0] += T.file_bytes; P.io_stats[1] += T.n_blocks; P.io_stats[2] += T.n_walked; }
+    for (const Task &T : P.tasks) { P.io_stats[0] += T.file_bytes; P.io_stats[1] += T.n_blocks; P.io_stats[2] += T.n_walked; P.io_stats[6] += T.n_pre; }
     P.io_stats[3] = n;
     P.timing[3] = now_s() - t3;
 }
@@ -1211,8 +1255,8 @@ const char *uz_inflate_backend(void) { return libdeflate().ok ? "libdeflate" : "
 int uz_io_default_threads(void) { return resolve_threads(0); }
 int uz_io_cpu_quota(void) { return cgroup_cpu_quota(); }
 
-int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int flags,
-                      int min_base_qual, int threads, uz_stage **out) {
+int uz_bam_stage_begin(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int flags,
+                       int min_base_qual, int threads, uz_stage **out) {
     if (!src || !out || (n_fetch > 0 && (!tid || !lo || !hi))) { last_error = "null argument"; return UZ_IO_E_ARG; }
     *out = nullptr;
     uz_stage *P = new uz_stage();
@@ -1222,9 +1266,90 @@ int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid,
     P->opt.masks = (flags & UZ_STAGE_UNIT_MASKS) && !P->opt.all_bases && P->opt.lists;
     P->opt.wide_none = P->opt.masks && (flags & UZ_STAGE_WIDE_NO_UNITS);
     P->opt.thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
-    const int rc = guarded([&] { plan(*P, n_fetch, tid, lo, hi, extra, threads); });
+    const int rc = guarded([&] { plan_begin(*P, n_fetch, tid, lo, hi, extra, threads); });
     if (rc != UZ_IO_OK) { delete P; return rc; }
     *out = P;
+    return UZ_IO_OK;
+}
+int uz_bam_stage_finish(uz_stage *P) {
+    if (!P || !P->begun || P->finished) { last_error = "uz_bam_stage_finish: no plan that was begun and not yet finished"; return UZ_IO_E_ARG; }
+    P->finished = true;
+    return guarded([&] { plan_finish(*P); });
+}
+int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int flags,
+                      int min_base_qual, int threads, uz_stage **out) {
+    const int rc = uz_bam_stage_begin(src, n_fetch, tid, lo, hi, extra, flags, min_base_qual, threads, out);
+    if (rc != UZ_IO_OK) return rc;
+    const int rc2 = uz_bam_stage_finish(*out);
+    if (rc2 != UZ_IO_OK) { delete *out; *out = nullptr; }
+    return rc2;
+}
+
+// The blocks the walk of a begun plan will read -- every task's spans from their first block to the block the linear index puts the end
+// of the task's reach in -- copied back to back (whole blocks, framing included) into `comp` (cap bytes; NULL: sizes only).
+// n_blocks / comp_bytes / out_bytes: how many, their compressed and inflated size; in_off [n_blocks]: where each block's DEFLATE stream
+// starts in comp; out_off [n_blocks + 1]: where its bytes belong in the inflated buffer (uz_stage_set_inflated).
+int uz_stage_gather_blocks(uz_stage *P, uint8_t *comp, int64_t cap, int64_t *in_off, int64_t *out_off, int64_t *n_blocks, int64_t *comp_bytes,
+                           int64_t *out_bytes) {
+    if (!P || !P->begun || P->finished) { last_error = "uz_stage_gather_blocks: between uz_bam_stage_begin and uz_bam_stage_finish"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        const uz_bamsrc &S = *P->src;
+        if (P->n_pre_blocks == 0 && P->pre_bytes == 0) { // list them once
+            parallel_slices((int64_t)P->tasks.size(), workers_for((int64_t)P->tasks.size(), resolve_threads(P->threads), 16), [&](int64_t i0, int64_t i1, int) {
+                for (int64_t i = i0; i < i1; i++) {
+                    Task &T = P->tasks[(size_t)i];
+                    T.pre.clear();
+                    int64_t last = -1;
+                    for (const Chunk &c : T.spans) {
+                        int64_t coff = (int64_t)(c.beg >> 16);
+                        const int64_t stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16); // (inclusive: the block that holds the end)
+                        while (coff <= stop) {
+                            BlockHdr h;
+                            if (!block_at(S, coff, h)) break;
+                            if (coff > last) { T.pre.push_back(PreBlk{coff, (int64_t)h.blen /* for now: its length in the file */, h.isize, h.crc}); last = coff; }
+                            coff += (int64_t)h.blen;
+                        }
+                    }
+                }
+            });
+            int64_t nb = 0, cb = 0, ob = 0;
+            for (Task &T : P->tasks)
+                for (PreBlk &b : T.pre) { const int64_t blen = b.at; b.at = ob; ob += b.isize; cb += blen; nb++; }
+            P->n_pre_blocks = nb; P->pre_bytes = ob;
+            P->io_stats[7] = cb;
+        }
+        if (n_blocks) *n_blocks = P->n_pre_blocks;
+        if (comp_bytes) *comp_bytes = P->io_stats[7];
+        if (out_bytes) *out_bytes = P->pre_bytes;
+        if (!comp) return;
+        if (cap < P->io_stats[7] || !in_off || !out_off) fail(UZ_IO_E_ARG, "uz_stage_gather_blocks: buffer too small, or null offset arrays");
+        // the first block of every task in comp / in the block list
+        std::vector<int64_t> c0(P->tasks.size() + 1, 0), b0(P->tasks.size() + 1, 0);
+        for (size_t i = 0; i < P->tasks.size(); i++) {
+            int64_t cb = 0;
+            for (const PreBlk &b : P->tasks[i].pre) { BlockHdr h; block_at(S, b.coff, h); cb += (int64_t)h.blen; }
+            c0[i + 1] = c0[i] + cb; b0[i + 1] = b0[i] + (int64_t)P->tasks[i].pre.size();
+        }
+        parallel_dynamic((int64_t)P->tasks.size(), resolve_threads(P->threads), [&](int64_t i, int) {
+            const Task &T = P->tasks[(size_t)i];
+            int64_t at = c0[(size_t)i], k = b0[(size_t)i];
+            for (const PreBlk &b : T.pre) {
+                BlockHdr h;
+                block_at(S, b.coff, h);
+                memcpy(comp + at, S.map + b.coff, h.blen);
+                in_off[k] = at + (int64_t)(h.cdata - (size_t)b.coff);
+                out_off[k] = b.at;
+                at += (int64_t)h.blen; k++;
+            }
+        });
+        out_off[P->n_pre_blocks] = P->pre_bytes;
+    });
+}
+// the blocks of uz_stage_gather_blocks, inflated (out_off of that call says where each lies); must stay valid until uz_bam_stage_finish
+// has returned, which copies the blocks in as it walks and holds each against its CRC-32
+int uz_stage_set_inflated(uz_stage *P, const uint8_t *inflated) {
+    if (!P || !P->begun || P->finished) { last_error = "uz_stage_set_inflated: between uz_bam_stage_begin and uz_bam_stage_finish"; return UZ_IO_E_ARG; }
+    P->inflated = inflated;
     return UZ_IO_OK;
 }
 

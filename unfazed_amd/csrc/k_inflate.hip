@@ -13,7 +13,7 @@
 //   * Huffman tables in LDS: a direct table for codes of up to 10 (literal / length) or 8 (distance) bits, filled by all
 //     lanes; the rare longer codes are resolved the canonical way (count / first code per length);
 //   * a match is copied by all lanes at once (lane k takes byte k, modulo the distance when source and destination
-//     overlap); literals are stored by lane 0.
+//     overlap); literals gather in a register window, one byte per lane, and leave it as one coalesced store.
 // The output lies in HBM, not in LDS (64 KiB per block would leave two waves per CU): a match reads bytes this wave
 // stored earlier, so its loads bypass the L1 (agent-scope loads) and wait for the wave's outstanding stores only when
 // the source reaches into bytes stored since the last such wait -- most matches of alignment records point hundreds of
@@ -38,43 +38,38 @@ struct InflateLds {
     uint16_t code_of[288];                      // bit-reversed canonical code of every symbol (table fill)
 };
 
-__device__ __constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ __constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // the input stream of one block, seen through two registers per lane: dwords [cbase, cbase + 64) and the 64 after them
 struct BitIn {
-    const uint32_t *w;  // aligned dwords of the compressed buffer
-    long long cbase;    // dword index held by lane 0 of `cur`
+    const uint32_t *w;  // aligned dwords of the compressed buffer, from the dword that holds the stream's first byte
+    int cbase;          // dword index held by lane 0 of `cur`
     uint32_t cur, nxt;  // lane l: w[cbase + l], w[cbase + 64 + l]
-    long long widx;     // next dword to take
+    int widx;           // next dword to take
     unsigned long long buf;
     int bits;
 };
 __device__ __forceinline__ uint32_t lane_word(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
 __device__ __forceinline__ void bi_open(BitIn &b, const uint8_t *base, long long byte_off, int lane) {
-    b.w = reinterpret_cast<const uint32_t *>(base);
-    const long long first = byte_off >> 2;
-    b.cbase = first;
-    b.cur = b.w[first + lane];
-    b.nxt = b.w[first + 64 + lane];
-    b.widx = first + 1;
+    b.w = reinterpret_cast<const uint32_t *>(base) + (byte_off >> 2);
+    b.cbase = 0;
+    b.cur = b.w[lane];
+    b.nxt = b.w[64 + lane];
+    b.widx = 1;
     const int skip = (int)(byte_off & 3) * 8;
     b.buf = (unsigned long long)(lane_word(b.cur, 0) >> skip);
     b.bits = 32 - skip;
 }
 __device__ __forceinline__ void bi_refill(BitIn &b, int lane) { // afterwards: at least 33 bits
     if (b.bits <= 32) {
-        long long k = b.widx - b.cbase;
+        int k = b.widx - b.cbase;
         if (k >= 64) {
             b.cur = b.nxt;
             b.cbase += 64;
             b.nxt = b.w[b.cbase + 64 + lane];
             k -= 64;
         }
-        b.buf |= (unsigned long long)lane_word(b.cur, (int)k) << b.bits;
+        b.buf |= (unsigned long long)lane_word(b.cur, k) << b.bits;
         b.bits += 32;
         b.widx++;
     }
@@ -146,7 +141,10 @@ __device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb,
 }
 
 // err: 1 bad block type / stored length, 2 bad code lengths, 3 bad symbol, 4 output overrun or distance before the block, 5 wrong size
-__global__ __launch_bounds__(64) void k_bgzf_inflate(int64_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ in_off,
+#ifndef UZI_WAVES_PER_EU
+#define UZI_WAVES_PER_EU 8
+#endif
+__global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ in_off,
                                                      const int64_t *__restrict__ out_off, uint8_t *out, int32_t *cursor, int32_t *err) {
     __shared__ InflateLds L;
     __shared__ int next_block;
@@ -162,6 +160,8 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(int64_t n_blocks, const uin
         BitIn b;
         bi_open(b, comp, in_off[blk], lane);
         int64_t pos = 0, safe = 0; // bytes written; bytes whose stores are known to have landed
+        int64_t wbase = 0;         // first position of the literal window (pos - wbase bytes wait in it)
+        uint32_t wbyte = 0;
         int bad = 0;
         for (int last = 0; !last && !bad;) {
             bi_refill(b, lane);
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(int64_t n_blocks, const uin
                     done += (uint32_t)nb;
                 }
                 pos += len;
+                wbase = pos;
                 continue;
             }
             if (type == 3) { bad = 1; break; }
@@ -233,26 +234,38 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(int64_t n_blocks, const uin
             }
             if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, lane, true)) { bad = 2; break; }
             if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, lane, false)) { bad = 2; break; }
-            // ---- the symbols of the block
+            // ---- the symbols of the block.  Literals gather in a register window -- lane l holds the byte for position wbase + l -- and
+            // leave it as one coalesced store when it is full or a match needs them in memory.
             for (;;) {
                 bi_refill(b, lane);
                 const int s = decode_sym(b, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt);
                 if (s < 256) {
                     if (s < 0) { bad = 3; break; }
                     if (pos >= osize) { bad = 4; break; }
-                    if (lane == 0) o[pos] = (uint8_t)s;
+                    wbyte = (lane == (int)(pos - wbase)) ? (uint32_t)s : wbyte;
                     pos++;
+                    if (pos - wbase == 64) { o[wbase + lane] = (uint8_t)wbyte; wbase = pos; }
                     continue;
                 }
-                if (s == 256) break;
+                if (pos > wbase) { // the window's bytes into memory, in front of whatever comes next
+                    if (lane < (int)(pos - wbase)) o[wbase + lane] = (uint8_t)wbyte;
+                }
+                if (s == 256) { wbase = pos; break; }
                 if (s > 285) { bad = 3; break; }
                 bi_refill(b, lane);
-                const int len = (int)kLenBase[s - 257] + (int)bi_take(b, kLenExtra[s - 257]);
+                // (length and distance from their symbols: RFC 1951's tables are arithmetic -- four codes per extra bit / two per extra bit)
+                const int ls = s - 257;
+                int len;
+                if (ls < 8) len = 3 + ls;
+                else if (ls == 28) len = 258;
+                else { const int e = (ls >> 2) - 1; len = ((4 + (ls & 3)) << e) + 3 + (int)bi_take(b, e); }
                 bi_refill(b, lane);
                 const int ds = decode_sym(b, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt);
                 if (ds < 0 || ds > 29) { bad = 3; break; }
                 bi_refill(b, lane);
-                const int dist = (int)kDistBase[ds] + (int)bi_take(b, kDistExtra[ds]);
+                int dist;
+                if (ds < 4) dist = 1 + ds;
+                else { const int e = (ds >> 1) - 1; dist = ((2 + (ds & 1)) << e) + 1 + (int)bi_take(b, e); }
                 if ((int64_t)dist > pos || pos + len > osize) { bad = 4; break; }
                 const int64_t src = pos - dist;
                 if (src + (len < dist ? len : dist) > safe) { // the source reaches into bytes whose stores may still be in flight
@@ -266,6 +279,7 @@ __global__ __launch_bounds__(64) void k_bgzf_inflate(int64_t n_blocks, const uin
                     o[pos + k] = __hip_atomic_load(o + src + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (past the L1: see the head of the file)
                 }
                 pos += len;
+                wbase = pos;
             }
         }
         if (!bad && pos != osize) bad = 5;

@@ -244,6 +244,13 @@ struct uz_ctx {
     DevBuf<int32_t> cnv_counts, cnv_pos, cnv_origin, cnv_evidence, cnv_etype, cnv_rb;
     std::vector<int32_t> cnv_counts_h;
 
+    // BGZF inflate (k_inflate.hip, uz_bgzf_inflate_to_host): buffers kept from call to call, a stream of its own (a batch's blocks can
+    // be inflated while the read stage of the batch before is still queued on the compute stream)
+    DevBuf<uint8_t> inf_comp, inf_out;
+    DevBuf<int64_t> inf_in, inf_off;
+    DevBuf<int32_t> inf_flags;
+    hipStream_t inf_stream = nullptr;
+
     // last phase (k_reads.hip)
     bool phase_valid = false;
     bool phase_open = false; // uz_phase_begin without its uz_phase_end

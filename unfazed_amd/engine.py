@@ -18,7 +18,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate",
+    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -57,6 +57,7 @@ def load_library(path: Optional[str] = None):
     L.uz_reads_wait.argtypes = [vp, C.c_int]
     L.uz_reads_headers.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.uz_bgzf_inflate.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
+    L.uz_bgzf_inflate_to_host.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -275,6 +276,12 @@ class HipEngine:
         self._ck(self.L.uz_bgzf_inflate(self.h, buf.ctypes.data, int(n), nb, in_off.ctypes.data if nb else None, out_off.ctypes.data, out.ctypes.data,
                                         int(repeat), C.byref(ms)) if nb else 0, "uz_bgzf_inflate")
         return out[: int(out_off[-1])], nb, (ms.value if repeat > 0 else None)
+
+    def inflate_blocks(self, comp: np.ndarray, comp_bytes: int, in_off: np.ndarray, out_off: np.ndarray, out: np.ndarray):
+        """The gathered BGZF blocks of a staged batch (io_native.BamSource.select(inflate=engine.inflate_blocks)) inflated on the device:
+        comp[:comp_bytes] -> out[:out_off[-1]] (both best in pinned memory)."""
+        self._ck(self.L.uz_bgzf_inflate_to_host(self.h, comp.ctypes.data, int(comp_bytes), int(in_off.size), in_off.ctypes.data, out_off.ctypes.data,
+                                                out.ctypes.data), "uz_bgzf_inflate_to_host")
 
     def adopt_sites(self, view: abi.SitesView) -> int:
         sid = C.c_int(-1)

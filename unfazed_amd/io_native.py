@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 from typing import List, Sequence
 
 import numpy as np
@@ -31,7 +32,7 @@ IO_EXPORTS = [
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
-    "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
+    "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
     "uz_stage_free",
 ]
 
@@ -155,6 +156,11 @@ def load():
     lib.uz_inflate_backend.restype = C.c_char_p
     lib.uz_bam_stage_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_void_p)]
+    lib.uz_bam_stage_begin.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_void_p)]
+    lib.uz_bam_stage_finish.argtypes = [C.c_void_p]
+    lib.uz_stage_gather_blocks.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.uz_stage_set_inflated.argtypes = [C.c_void_p, C.c_void_p]
     lib.uz_stage_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.uz_stage_sizes.restype = None
     lib.uz_stage_io_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -609,11 +615,16 @@ class BamSource:
         k = self.lib.uz_bamsrc_tlen_head(h, head.ctypes.data, head.size)
         self.tlen_head = head[: int(k)].copy()
 
-    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False):
+    def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False,
+               inflate=None, inflate_alloc=None):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
         `.io_stats` / `.timing` / `.qnames` ride on the returned object.
         pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
-        as one copy); alloc: any other allocator of the columns."""
+        as one copy); alloc: any other allocator of the columns.
+        inflate(comp, comp_bytes, in_off, out_off, out): somebody who inflates BGZF blocks faster than this host's cores
+        (HipEngine.inflate_blocks: the device) -- the blocks the walk will read are gathered and handed to it between the two halves of the
+        plan, and the walk copies records out of what comes back (each block still held against its CRC-32) instead of inflating;
+        inflate_alloc(nbytes) -> uint8 array: where the gathered and the inflated bytes go (pinned memory for full link speed)."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -623,10 +634,32 @@ class BamSource:
             assert extra.size == contig.size
         flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_UNIT_MASKS if masks else 0) | (0 if lists else STAGE_PLANE) | (8 if wide_no_units and masks else 0)
         st = C.c_void_p()
-        _check(self.lib, self.lib.uz_bam_stage_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
-                                                    extra.ctypes.data if extra is not None else None, flags, int(min_base_qual), int(self.threads),
-                                                    C.byref(st)))
-        sh = _Handle(st.value, self.lib.uz_stage_free)
+        pre = None
+        if inflate is None:
+            _check(self.lib, self.lib.uz_bam_stage_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                                        extra.ctypes.data if extra is not None else None, flags, int(min_base_qual), int(self.threads),
+                                                        C.byref(st)))
+            sh = _Handle(st.value, self.lib.uz_stage_free)
+        else:
+            _check(self.lib, self.lib.uz_bam_stage_begin(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                                         extra.ctypes.data if extra is not None else None, flags, int(min_base_qual), int(self.threads),
+                                                         C.byref(st)))
+            sh = _Handle(st.value, self.lib.uz_stage_free)
+            nb, cb, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            _check(self.lib, self.lib.uz_stage_gather_blocks(sh.ptr, None, 0, None, None, C.byref(nb), C.byref(cb), C.byref(ob)))
+            if nb.value:
+                ia = inflate_alloc or (lambda nbytes: np.empty(max(16, nbytes), np.uint8))
+                comp = ia(int(cb.value) + 64)
+                inflated = ia(int(ob.value) + 64)
+                in_off, out_off = np.zeros(nb.value, np.int64), np.zeros(nb.value + 1, np.int64)
+                t_g = time.perf_counter()
+                _check(self.lib, self.lib.uz_stage_gather_blocks(sh.ptr, comp.ctypes.data, int(cb.value), in_off.ctypes.data, out_off.ctypes.data, None, None, None))
+                t_i = time.perf_counter()
+                inflate(comp, int(cb.value), in_off, out_off, inflated)
+                t_e = time.perf_counter()
+                _check(self.lib, self.lib.uz_stage_set_inflated(sh.ptr, inflated.ctypes.data))
+                pre = dict(blocks=int(nb.value), comp_bytes=int(cb.value), out_bytes=int(ob.value), gather_s=t_i - t_g, inflate_s=t_e - t_i, keep=(comp, inflated))
+            _check(self.lib, self.lib.uz_bam_stage_finish(sh.ptr))
         z = (C.c_int64 * 12)()
         self.lib.uz_stage_sizes(sh.ptr, z)
         n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um = (int(x) for x in z)
@@ -643,8 +676,9 @@ class BamSource:
         self.lib.uz_stage_io_stats(sh.ptr, io)
         tm = (C.c_double * 6)()
         self.lib.uz_stage_timing(sh.ptr, tm)
-        out.io_stats = dict(zip(("file_bytes_read", "blocks_inflated", "records_walked", "records_kept", "reach_intervals", "index_mate_lookups"),
-                                (int(x) for x in io)))
+        out.io_stats = dict(zip(("file_bytes_read", "blocks_inflated", "records_walked", "records_kept", "reach_intervals", "index_mate_lookups",
+                                 "blocks_from_the_device", "gathered_bytes"), (int(x) for x in io)))
+        out.pre_inflate = None if pre is None else {k: v for k, v in pre.items() if k != "keep"}
         out.timing = dict(zip(("spans", "walk", "mates", "numbering", "fill"), (float(x) for x in tm)))
         out.qnames = _StageNames(self.lib, sh, n_names)
         return out
