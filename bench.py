@@ -66,6 +66,8 @@ def parse():
                     help="DNMs of the files -> results pass (`feed` / `value_e2e`): their pile-ups are written as a real BAM + BAI, the sites table as "
                          "a BGZF VCF + TBI, and decoded back through the indexes inside the timed region (0 = skip)")
     ap.add_argument("--feed-chunk", type=int, default=2500, help="DNMs per chunk of the files -> results pass")
+    ap.add_argument("--feed-inflate", choices=("device", "host"), default="device",
+                    help="feed pass: who inflates the BGZF blocks of the BAM -- the device (uz_bgzf_inflate_to_host) or the host's cores")
     ap.add_argument("--feed-level", type=int, default=6, help="deflate level of the files written for the feed pass (samtools / bgzip default: 6)")
     ap.add_argument("--feed-dir", default=None, help="where the files of the feed pass go (default: a temporary directory in /dev/shm, else /tmp)")
     return ap.parse_args()
@@ -715,9 +717,15 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         cuts = list(range(0, m, max(1, args.feed_chunk))) + [m]
         K = len(cuts) - 1
         pools = [PinnedPool() for _ in range(3)]  # chunk k stages into pools[k % 3]: its block is rewound, not re-pinned
+        from unfazed_amd.engine import PinnedPair
+        on_device = args.feed_inflate == "device"
+        ipairs = [PinnedPair() for _ in range(3)] if on_device else None  # ... and its gathered / inflated BGZF blocks through ipairs[k % 3]
         slab_bytes = [0, 0, 0]
         acc = dict(vcf_s=0.0, bam_s=0.0, site_records=0, walked=0, kept=0, file_bytes=0, blocks=0, spans=0.0, walk=0.0, mates=0.0, numbering=0.0, fill=0.0,
-                   link_bytes=0, lookups=0)
+                   link_bytes=0, lookups=0, dev_blocks=0, dev_out_bytes=0, dev_inflate_s=0.0, gather_s=0.0, blocks_dev=0)
+
+        def io_dev(packed):
+            return packed.io_stats.get("blocks_from_the_device", 0)
         out = dict(status=np.empty(m, np.int32), counts=np.empty((m, 4), np.int32), origin=np.empty(m, np.int32), evidence=np.empty(m, np.int32))
 
         def stage_a(k):  # the chunk's windows of the sites file -> columns
@@ -749,7 +757,14 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
             if not pool.rewind(want):
                 pool.free_all()
                 pool.new_slab(want)
-            packed = src.select(f[0], f[1], f[2], int(P.min_gt_qual), alloc=pool.alloc, extra=f[3])
+            if on_device:
+                ipairs[k % 3].start()
+            packed = src.select(f[0], f[1], f[2], int(P.min_gt_qual), alloc=pool.alloc, extra=f[3],
+                                inflate=eng.inflate_blocks if on_device else None, inflate_alloc=ipairs[k % 3].alloc if on_device else None)
+            if packed.pre_inflate:
+                acc["dev_blocks"] += packed.pre_inflate["blocks"]; acc["dev_out_bytes"] += packed.pre_inflate["out_bytes"]
+                acc["dev_inflate_s"] += packed.pre_inflate["inflate_s"]; acc["gather_s"] += packed.pre_inflate["gather_s"]
+                acc["blocks_dev"] += io_dev(packed)
             slab_bytes[k % 3] = max(slab_bytes[k % 3], pool.slab_used())
             acc["bam_s"] += time.perf_counter() - t
             io, tm = packed.io_stats, packed.timing
@@ -792,6 +807,8 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         el = run_pass()
         for pool in pools:
             pool.free_all()
+        for ip in ipairs or []:
+            ip.free_all()
         mism = sum(int((np.asarray(out[k]) != np.asarray(res_r[k][:m])).sum()) for k in out)
         # the CPU path's decode of the same files: the whole BAM (it holds only these pile-ups) + the same windows of the VCF
         t = time.perf_counter()
@@ -804,7 +821,15 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         raw_per_rec = st_b["raw_bytes"] / max(1, st_b["records"])
         return {
             "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "result_mismatches_vs_resident": mism,
-            "inflate": io_native.inflate_backend(), "host_threads": io_native.default_threads(), "host_cpu_quota": io_native.cpu_quota() or None,
+            "inflate": ("device (k_bgzf_inflate: one wavefront per BGZF block; blocks the walk did not announce: " + io_native.inflate_backend() + ")") if on_device
+                       else io_native.inflate_backend(),
+            "device_inflate": None if not on_device else {
+                "blocks": acc["dev_blocks"], "blocks_used_by_the_walk": acc["blocks_dev"], "out_GB": round(acc["dev_out_bytes"] / 1e9, 3),
+                "seconds_busy": round(acc["dev_inflate_s"], 3), "gather_seconds_busy": round(acc["gather_s"], 3),
+                "GBps_incl_both_copies": round(acc["dev_out_bytes"] / max(acc["dev_inflate_s"], 1e-9) / 1e9, 1),
+                "note": "per chunk: the blocks the walk will read gathered into pinned memory (host), host -> device, kernel, device -> host, all "
+                        "inside seconds_busy; the walk then copies records out of the inflated blocks and holds each block against its CRC-32"},
+            "host_threads": io_native.default_threads(), "host_cpu_quota": io_native.cpu_quota() or None,
             "host_processors": os.cpu_count(),
             "bam": {"records": st_b["records"], "file_GB": round(st_b["file_bytes"] / 1e9, 3), "raw_GB": round(st_b["raw_bytes"] / 1e9, 3), "blocks": st_b["blocks"],
                     "write_s": round(t1 - t0, 1), "deflate_level": args.feed_level},
@@ -813,9 +838,9 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                                "inflated_GBps": round(acc["walked"] * raw_per_rec / max(acc["walk"], 1e-9) / 1e9, 2),
                                "records_walked": acc["walked"], "blocks_inflated": acc["blocks"], "file_bytes_read": acc["file_bytes"],
                                "index_mate_lookups": acc["lookups"]},
-            "select": {"seconds_busy": round(acc["spans"] + acc["mates"], 3), "records_kept": acc["kept"],
+            "select": {"seconds_busy": round(acc["spans"] + acc["mates"], 3), "spans_s": round(acc["spans"], 3), "mates_s": round(acc["mates"], 3), "records_kept": acc["kept"],
                        "records_per_s": round(acc["kept"] / max(acc["spans"] + acc["mates"], 1e-9), 0)},
-            "pack": {"seconds_busy": round(acc["numbering"] + acc["fill"], 3), "records_per_s": round(acc["kept"] / max(acc["numbering"] + acc["fill"], 1e-9), 0),
+            "pack": {"seconds_busy": round(acc["numbering"] + acc["fill"], 3), "numbering_s": round(acc["numbering"], 3), "fill_s": round(acc["fill"], 3), "records_per_s": round(acc["kept"] / max(acc["numbering"] + acc["fill"], 1e-9), 0),
                      "link_bytes_per_dnm": round(acc["link_bytes"] / m, 1)},
             "sites_decode": {"seconds_busy": round(acc["vcf_s"], 3), "records": acc["site_records"], "records_per_s": round(acc["site_records"] / max(acc["vcf_s"], 1e-9), 0)},
             "bam_stage_seconds_busy": round(acc["bam_s"], 3),

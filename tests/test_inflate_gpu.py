@@ -89,3 +89,32 @@ def test_broken_streams_are_refused(engine):
             assert "block 0" in str(e)
             continue
         assert breakage == "flip" and bytes(got) != payloads()[5]  # (a flipped bit can still be a valid stream of the same size: only then)
+
+
+def test_a_staged_batch_with_its_blocks_inflated_on_the_device(engine, tmp_path):
+    """BamSource.select(inflate=engine.inflate_blocks): the blocks a batch's walk reads come back from the device, and the batch is the
+    one the host's inflate gives, byte for byte"""
+    from synth import bigsynth
+    from synth.sites_np import make_clusters, make_sites, place_dnms_full
+    from unfazed_amd import io_native
+    from unfazed_amd.engine import PinnedPair
+    from test_io_stage import assert_same
+    sc = make_sites(40_000, seed=7, contig_lens=[6e6, 4e6, 2e6])
+    dn = place_dnms_full(sc, 80, seed=8, indel_frac=0.2)
+    cl = make_clusters(dn)
+    cfg = bigsynth.make_cfg(seed=9)
+    cfg.n_clusters = cl.n
+    bam = str(tmp_path / "kid.bam")
+    bigsynth.write_bam(bam, cfg, sc, dn, cl, 0, cl.n, level=6)
+    src = io_native.BamSource(bam, threads=2)
+    tid = dn.contig[::2].astype(np.int32)
+    lo = (dn.start[::2] - 1).astype(np.int32)
+    ex = np.zeros(tid.size, np.uint16)
+    plain = src.select(tid, lo, lo + 2, 20, extra=ex)
+    pair = PinnedPair()
+    for _ in range(2):  # (the second batch re-uses the pinned pair)
+        pair.start()
+        got = src.select(tid, lo, lo + 2, 20, extra=ex, inflate=engine.inflate_blocks, inflate_alloc=pair.alloc)
+        assert_same(got, plain)
+        assert got.io_stats["blocks_from_the_device"] == got.io_stats["blocks_inflated"] > 20
+    pair.free_all()

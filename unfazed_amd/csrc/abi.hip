@@ -1039,6 +1039,7 @@ int uz_bgzf_inflate_to_host(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, 
         if (n_blocks == 0) return;
         const int64_t out_bytes = out_off[n_blocks];
         UZ_REQUIRE(out_bytes >= 0, UZ_E_ARG, "bad block table");
+        UZ_HIP(hipSetDevice(c->device)); // (a decoder's worker thread calls this: the current device is per thread)
         if (!c->inf_stream) UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
         hipStream_t st = c->inf_stream;
         c->inf_comp.ensure((size_t)comp_bytes + 1024); c->inf_out.ensure((size_t)out_bytes + 64);

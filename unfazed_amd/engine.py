@@ -113,8 +113,14 @@ class HipEngine:
         self._staged = {}
         self._staged_sites = {}
         self._params = None
+        import threading
+        self._inflate_lock = threading.Lock()
+        self._inflate_bufs = None  # PinnedPair of upload_reads_staged
 
     def close(self):
+        if getattr(self, "_inflate_bufs", None) is not None:
+            self._inflate_bufs.free_all()
+            self._inflate_bufs = None
         if getattr(self, "h", None):
             self.L.uz_destroy(self.h)
             self.h = None
@@ -220,7 +226,14 @@ class HipEngine:
         -> (reads id, the staged view: `.qnames` maps the name ids of the result lists back to strings)"""
         pool = PinnedPool()
         try:
-            packed = src.select(fc, flo, fhi, int(min_base_qual), pool=pool, all_bases=bool(all_bases), extra=fex, wide_no_units=bool(wide_no_units))
+            inflate = inflate_alloc = None
+            if os.environ.get("UZ_INFLATE", "device") == "device":  # the batch's BGZF blocks inflated on the device (UZ_INFLATE=host: by the host's cores)
+                if self._inflate_bufs is None:
+                    self._inflate_bufs = PinnedPair()
+                self._inflate_bufs.start()
+                inflate, inflate_alloc = self.inflate_blocks, self._inflate_bufs.alloc
+            packed = src.select(fc, flo, fhi, int(min_base_qual), pool=pool, all_bases=bool(all_bases), extra=fex, wide_no_units=bool(wide_no_units),
+                                inflate=inflate, inflate_alloc=inflate_alloc)
             pool.end_slab()
             rid = self.upload_reads_packed(packed)
             self.wait_reads(rid)  # the pinned buffers go back right away
@@ -279,9 +292,13 @@ class HipEngine:
 
     def inflate_blocks(self, comp: np.ndarray, comp_bytes: int, in_off: np.ndarray, out_off: np.ndarray, out: np.ndarray):
         """The gathered BGZF blocks of a staged batch (io_native.BamSource.select(inflate=engine.inflate_blocks)) inflated on the device:
-        comp[:comp_bytes] -> out[:out_off[-1]] (both best in pinned memory)."""
-        self._ck(self.L.uz_bgzf_inflate_to_host(self.h, comp.ctypes.data, int(comp_bytes), int(in_off.size), in_off.ctypes.data, out_off.ctypes.data,
-                                                out.ctypes.data), "uz_bgzf_inflate_to_host")
+        comp[:comp_bytes] -> out[:out_off[-1]] (both best in pinned memory: PinnedPair).  May be called from a decoder's worker thread
+        beside the main thread's calls (its own stream and buffers; one call at a time)."""
+        with self._inflate_lock:
+            rc = self.L.uz_bgzf_inflate_to_host(self.h, comp.ctypes.data, int(comp_bytes), int(in_off.size), in_off.ctypes.data, out_off.ctypes.data,
+                                                out.ctypes.data)
+            if rc != 0:
+                raise UnfazedHipError("uz_bgzf_inflate_to_host: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
 
     def adopt_sites(self, view: abi.SitesView) -> int:
         sid = C.c_int(-1)
@@ -467,6 +484,31 @@ class HipEngine:
         u = C.c_int64(0)
         self._ck(self.L.uz_prof_units(self.h, int(kernel), C.byref(u)), "uz_prof_units")
         return int(u.value)
+
+
+class PinnedPair:
+    """The two page-locked buffers a staged batch needs when the device inflates its blocks (gathered bytes, inflated bytes), kept and
+    grown from batch to batch: `alloc` is BamSource.select's inflate_alloc (called twice per batch, after start())."""
+
+    def __init__(self):
+        self.pool = PinnedPool()
+        self.bufs = []
+        self.k = 0
+
+    def start(self):
+        self.k = 0
+
+    def alloc(self, nbytes: int) -> np.ndarray:
+        i, self.k = self.k, self.k + 1
+        while len(self.bufs) <= i:
+            self.bufs.append(None)
+        if self.bufs[i] is None or self.bufs[i].size < nbytes:
+            self.bufs[i] = self.pool.alloc(int(nbytes) + int(nbytes) // 4 + (1 << 20))  # (the block it outgrew stays until free_all)
+        return self.bufs[i][: max(64, int(nbytes))]
+
+    def free_all(self):
+        self.bufs = []
+        self.pool.free_all()
 
 
 class PinnedPool:
