@@ -33,6 +33,27 @@ try:
     e = HipEngine(0)
     got, nb, ms = e.bgzf_inflate(data, repeat=5)
     print("device: %d blocks, %.2f ms per launch = %.1f GB/s of output (%.1f GB/s of input)" % (nb, ms, got.size / ms / 1e6, data.size / ms / 1e6), flush=True)
+    # the working form: pinned buffers, both copies inside the call (uz_bgzf_inflate_to_host), as a staged batch uses it
+    from unfazed_amd.engine import PinnedPair
+    pair = PinnedPair()
+    blocks = []
+    at = 0
+    while at + 18 <= data.size:
+        bsize = (int(data[at + 16]) | (int(data[at + 17]) << 8)) + 1
+        blocks.append((at + 18, int(data[at + bsize - 4]) | (int(data[at + bsize - 3]) << 8) | (int(data[at + bsize - 2]) << 16) | (int(data[at + bsize - 1]) << 24)))
+        at += bsize
+    in_off = np.array([b[0] for b in blocks], np.int64)
+    out_off = np.concatenate([[0], np.cumsum([b[1] for b in blocks])]).astype(np.int64)
+    comp = pair.alloc(data.size + 64)
+    comp[: data.size] = data
+    outp = pair.alloc(int(out_off[-1]) + 64)
+    for rep in range(3):
+        t = time.time()
+        e.inflate_blocks(comp, data.size, in_off, out_off, outp)
+        dt = time.time() - t
+    print("device, pinned host -> pinned host (both copies inside): %.1f ms = %.1f GB/s of output" % (dt * 1e3, out_off[-1] / dt / 1e9), flush=True)
+    assert np.array_equal(outp[: int(out_off[-1])], got)
+    pair.free_all()
     t = time.time()
     want = np.frombuffer(gzip.decompress(data.tobytes()), np.uint8)
     print("python gzip (one thread): %.2f s = %.2f GB/s" % (time.time() - t, want.size / (time.time() - t) / 1e9))

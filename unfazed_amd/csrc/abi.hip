@@ -402,6 +402,8 @@ void uz_destroy(uz_ctx *c) {
     c->cand_idx.release(); c->het_idx.release(); c->cand_flags.release(); c->win_range.release();
     c->inf_comp.release(); c->inf_out.release(); c->inf_in.release(); c->inf_off.release(); c->inf_flags.release();
     if (c->inf_stream) (void)hipStreamDestroy(c->inf_stream);
+    if (c->inf_stream2) (void)hipStreamDestroy(c->inf_stream2);
+    if (c->inf_ready) (void)hipEventDestroy(c->inf_ready);
     for (FindSlot &a : c->find_alt) {
         a.cnt_c.release(); a.cnt_h.release(); a.win_range.release(); a.cand_off.release(); a.het_off.release();
         a.cand_idx.release(); a.het_idx.release(); a.cand_flags.release();
@@ -1040,20 +1042,46 @@ int uz_bgzf_inflate_to_host(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, 
         const int64_t out_bytes = out_off[n_blocks];
         UZ_REQUIRE(out_bytes >= 0, UZ_E_ARG, "bad block table");
         UZ_HIP(hipSetDevice(c->device)); // (a decoder's worker thread calls this: the current device is per thread)
-        if (!c->inf_stream) UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
-        hipStream_t st = c->inf_stream;
+        if (!c->inf_stream) {
+            UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
+            UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream2, hipStreamNonBlocking));
+            UZ_HIP(hipEventCreateWithFlags(&c->inf_ready, hipEventDisableTiming));
+        }
+        // The batch in slices of ~8 k blocks, alternating between two streams: the blocks of slice i + 1 go up and are inflated
+        // while the bytes of slice i come down (the two directions of the link and the kernel overlap: the call takes about as long as
+        // its slowest leg, the way down).  The blocks lie in `comp` in the order of the table, so a slice is a contiguous piece of it.
+        std::vector<int64_t> cut{0};
+        {
+            const int64_t SLICE = 8192; // blocks: a wave is one block's decoder, and the chip holds 6 000 ... 8 000 waves -- a smaller launch leaves slots idle
+            for (int64_t k = 1; k <= n_blocks; k++)
+                if (k == n_blocks || (k - cut.back() >= SLICE && n_blocks - k >= SLICE / 2)) cut.push_back(k);
+        }
+        const size_t ns = cut.size() - 1;
         c->inf_comp.ensure((size_t)comp_bytes + 1024); c->inf_out.ensure((size_t)out_bytes + 64);
-        c->inf_in.ensure((size_t)n_blocks); c->inf_off.ensure((size_t)n_blocks + 1); c->inf_flags.ensure(16);
-        UZ_HIP(hipMemsetAsync(c->inf_comp.p + comp_bytes, 0, 1024, st));
-        UZ_HIP(hipMemcpyAsync(c->inf_comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
-        UZ_HIP(hipMemcpyAsync(c->inf_in.p, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
-        UZ_HIP(hipMemcpyAsync(c->inf_off.p, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
-        uz_launch_inflate(c, st, n_blocks, c->inf_comp.p, c->inf_in.p, c->inf_off.p, c->inf_out.p, c->inf_flags.p);
-        int32_t flags[2] = {0, 0};
-        UZ_HIP(hipMemcpyAsync(flags, c->inf_flags.p, sizeof(flags), hipMemcpyDeviceToHost, st));
-        UZ_HIP(hipMemcpyAsync(out, c->inf_out.p, (size_t)out_bytes, hipMemcpyDeviceToHost, st));
-        UZ_HIP(hipStreamSynchronize(st));
-        if (flags[1]) throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(flags[1] >> 4) + " of the batch: not a valid DEFLATE stream of the declared size (code " + std::to_string(flags[1] & 15) + ")"};
+        c->inf_in.ensure((size_t)n_blocks); c->inf_off.ensure((size_t)n_blocks + 1); c->inf_flags.ensure(2 * ns + 2);
+        hipStream_t st[2] = {c->inf_stream, c->inf_stream2};
+        UZ_HIP(hipMemsetAsync(c->inf_comp.p + comp_bytes, 0, 1024, st[0]));
+        UZ_HIP(hipMemcpyAsync(c->inf_in.p, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st[0]));
+        UZ_HIP(hipMemcpyAsync(c->inf_off.p, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, st[0]));
+        UZ_HIP(hipEventRecord(c->inf_ready, st[0]));
+        UZ_HIP(hipStreamWaitEvent(st[1], c->inf_ready, 0));
+        std::vector<int32_t> flags(2 * ns, 0);
+        for (size_t i = 0; i < ns; i++) {
+            hipStream_t s = st[i & 1];
+            const int64_t b0 = cut[i], b1 = cut[i + 1];
+            // (whole blocks travel: a slice's bytes run from the framing of its first block to the start of the next slice's)
+            const int64_t c0 = i == 0 ? 0 : in_off[b0] - 18 < 0 ? 0 : in_off[b0] - 18, c1 = i + 1 == ns ? comp_bytes : std::max<int64_t>(in_off[b1] - 18, c0);
+            UZ_HIP(hipMemcpyAsync(c->inf_comp.p + c0, comp + c0, (size_t)(c1 - c0), hipMemcpyHostToDevice, s));
+            uz_launch_inflate(c, s, b1 - b0, c->inf_comp.p, c->inf_in.p + b0, c->inf_off.p + b0, c->inf_out.p, c->inf_flags.p + 2 * i);
+            UZ_HIP(hipMemcpyAsync(flags.data() + 2 * i, c->inf_flags.p + 2 * i, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            UZ_HIP(hipMemcpyAsync(out + out_off[b0], c->inf_out.p + out_off[b0], (size_t)(out_off[b1] - out_off[b0]), hipMemcpyDeviceToHost, s));
+        }
+        UZ_HIP(hipStreamSynchronize(st[0]));
+        UZ_HIP(hipStreamSynchronize(st[1]));
+        for (size_t i = 0; i < ns; i++)
+            if (flags[2 * i + 1])
+                throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(cut[i] + (flags[2 * i + 1] >> 4)) + " of the batch: not a valid DEFLATE stream of the declared size (code " +
+                                              std::to_string(flags[2 * i + 1] & 15) + ")"};
     });
 }
 

@@ -944,6 +944,8 @@ void plan_finish(uz_stage &P) {
         frontier.swap(next);
     }
     double t3 = now_s();
+    static const bool sub_timing = getenv("UZ_STAGE_TIMING") != nullptr; // development aid: where the numbering pass spends its time
+    double tn[5] = {t3, 0, 0, 0, 0};
     P.timing[2] = t3 - t2;
     P.io_stats[5] = n_lookups;
 
@@ -1001,11 +1003,17 @@ void plan_finish(uz_stage &P) {
     for (int k = 0; k <= W; k++) P.cut[(size_t)k] = n * k / W;
     auto slices = [&](auto fn) { parallel_slices(W, W, [&](int64_t s0, int64_t s1, int) { for (int64_t sl = s0; sl < s1; sl++) fn((int)sl, P.cut[(size_t)sl], P.cut[(size_t)sl + 1]); }); };
     slices([&](int, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) rec_of(P, order[(size_t)k]).gidx = (uint32_t)k; });
+    tn[1] = now_s();
     // ---- names -> ids in order of first appearance (hash-sharded, as the table builder of the whole-file decoder does)
     {
         const int SH = 256;
         std::vector<std::vector<int64_t>> hist((size_t)W, std::vector<int64_t>(SH, 0));
-        slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) hist[(size_t)sl][rec_of(P, order[(size_t)k]).nhash >> 56]++; });
+        // (the name hashes side by side: the passes below look at nothing else of a record until two hashes are equal, and the records
+        // themselves are ~100 bytes apiece behind two indirections)
+        std::vector<uint64_t> nh((size_t)n);
+        slices([&](int sl, int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; k++) { const uint64_t h = rec_of(P, order[(size_t)k]).nhash; nh[(size_t)k] = h; hist[(size_t)sl][h >> 56]++; }
+        });
         std::vector<int64_t> sh_off(SH + 1, 0);
         int64_t run = 0;
         for (int sft = 0; sft < SH; sft++) {
@@ -1014,7 +1022,7 @@ void plan_finish(uz_stage &P) {
         }
         sh_off[SH] = run;
         std::vector<uint32_t> by_shard((size_t)n), first_of((size_t)n);
-        slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) by_shard[(size_t)hist[(size_t)sl][rec_of(P, order[(size_t)k]).nhash >> 56]++] = (uint32_t)k; });
+        slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) by_shard[(size_t)hist[(size_t)sl][nh[(size_t)k] >> 56]++] = (uint32_t)k; });
         parallel_slices(SH, workers_for(SH, threads, 1), [&](int64_t s0, int64_t s1, int) {
             std::vector<int32_t> tab;
             for (int64_t sft = s0; sft < s1; sft++) {
@@ -1024,15 +1032,15 @@ void plan_finish(uz_stage &P) {
                 tab.assign(cap, -1);
                 for (int64_t e = a; e < b; e++) { // ascending k inside a shard: the first record met for a name is its first in the file
                     const uint32_t k = by_shard[(size_t)e];
-                    const int64_t ref = order[k];
-                    const WRec &x = rec_of(P, ref);
-                    const Task &TX = P.tasks[(size_t)(ref >> 32)];
-                    size_t slot = (size_t)(x.nhash * 0x9E3779B97F4A7C15ULL >> 20) & (cap - 1);
+                    const uint64_t hk = nh[k];
+                    size_t slot = (size_t)(hk * 0x9E3779B97F4A7C15ULL >> 20) & (cap - 1);
                     for (;;) {
                         const int32_t f = tab[slot];
                         if (f < 0) { tab[slot] = (int32_t)k; first_of[k] = k; break; }
-                        const int64_t rf = order[(size_t)f];
-                        if (same_name(TX, x, P.tasks[(size_t)(rf >> 32)], rec_of(P, rf))) { first_of[k] = (uint32_t)f; break; }
+                        if (nh[(size_t)f] == hk) { // (then, and only then, the names themselves)
+                            const int64_t ref = order[k], rf = order[(size_t)f];
+                            if (same_name(P.tasks[(size_t)(ref >> 32)], rec_of(P, ref), P.tasks[(size_t)(rf >> 32)], rec_of(P, rf))) { first_of[k] = (uint32_t)f; break; }
+                        }
                         slot = (slot + 1) & (cap - 1);
                     }
                 }
@@ -1053,6 +1061,7 @@ void plan_finish(uz_stage &P) {
         });
         P.n_qnames = nfirst[(size_t)W];
     }
+    tn[2] = now_s();
     // ---- the dictionary of the small columns: combinations numbered in order of first appearance (per slice, then joined in order)
     const Opt &o = P.opt;
     auto tup_of = [&](const WRec &x, uint64_t &key, uint32_t &k2) {
@@ -1098,6 +1107,7 @@ void plan_finish(uz_stage &P) {
         slices([&](int sl, int64_t k0, int64_t k1) { for (int64_t k = k0; k < k1; k++) rec_of(P, order[(size_t)k]).tup = (uint16_t)remap[(size_t)sl][lidx[(size_t)sl][(size_t)(k - k0)]]; });
         P.n_tup = (int64_t)P.tup_key.size();
     }
+    tn[3] = now_s();
     // ---- sizes: per slice, then the slices' first offsets
     P.base.assign((size_t)W + 1, SliceBase());
     std::vector<std::vector<int64_t>> cnt((size_t)W, std::vector<int64_t>((size_t)n_ref, 0));
@@ -1136,6 +1146,9 @@ void plan_finish(uz_stage &P) {
     for (const Task &T : P.tasks) { P.io_stats[0] += T.file_bytes; P.io_stats[1] += T.n_blocks; P.io_stats[2] += T.n_walked; P.io_stats[6] += T.n_pre; }
     P.io_stats[3] = n;
     P.timing[3] = now_s() - t3;
+    if (sub_timing)
+        fprintf(stderr, "[uz_stage numbering] %lld records: order %.1f ms | names %.1f ms | dictionary %.1f ms | sizes %.1f ms\n", (long long)n,
+                (tn[1] - tn[0]) * 1e3, (tn[2] - tn[1]) * 1e3, (tn[3] - tn[2]) * 1e3, (now_s() - tn[3]) * 1e3);
 }
 
 void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {

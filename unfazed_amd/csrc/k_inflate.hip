@@ -142,7 +142,7 @@ __device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb,
 
 // err: 1 bad block type / stored length, 2 bad code lengths, 3 bad symbol, 4 output overrun or distance before the block, 5 wrong size
 #ifndef UZI_WAVES_PER_EU
-#define UZI_WAVES_PER_EU 8
+#define UZI_WAVES_PER_EU 6 // (measured 4 / 6 / 8 waves per SIMD: 63 / 86 / 76 GB/s of output -- at 8 the 64 registers spill)
 #endif
 __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ in_off,
                                                      const int64_t *__restrict__ out_off, uint8_t *out, int32_t *cursor, int32_t *err) {
@@ -294,11 +294,10 @@ void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_
                        int32_t *cursor_and_err /* [2], zeroed here */) {
     if (n_blocks <= 0) return;
     UZ_HIP(hipMemsetAsync(cursor_and_err, 0, 2 * sizeof(int32_t), st));
-    int cus = 256;
-    {
+    static const int cus = [&] { // (asked once: the query is not cheap; one kind of device per process)
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) cus = prop.multiProcessorCount;
-    }
+        return hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 256;
+    }();
     const int64_t grid = std::min<int64_t>(n_blocks, (int64_t)cus * 32); // every wave slot of the chip: a wave is one block's decoder
     hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)grid), dim3(64), 0, st, n_blocks, comp, in_off, out_off, out, cursor_and_err, cursor_and_err + 1);
     UZ_HIP(hipGetLastError());

@@ -249,7 +249,8 @@ struct uz_ctx {
     DevBuf<uint8_t> inf_comp, inf_out;
     DevBuf<int64_t> inf_in, inf_off;
     DevBuf<int32_t> inf_flags;
-    hipStream_t inf_stream = nullptr;
+    hipStream_t inf_stream = nullptr, inf_stream2 = nullptr;
+    hipEvent_t inf_ready = nullptr;
 
     // last phase (k_reads.hip)
     bool phase_valid = false;
