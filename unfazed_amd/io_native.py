@@ -616,7 +616,7 @@ class BamSource:
         self.tlen_head = head[: int(k)].copy()
 
     def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False,
-               inflate=None, inflate_alloc=None):
+               inflate=None, inflate_alloc=None, inflate_max_bytes=8 << 30):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
         `.io_stats` / `.timing` / `.qnames` ride on the returned object.
         pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
@@ -624,7 +624,8 @@ class BamSource:
         inflate(comp, comp_bytes, in_off, out_off, out): somebody who inflates BGZF blocks faster than this host's cores
         (HipEngine.inflate_blocks: the device) -- the blocks the walk will read are gathered and handed to it between the two halves of the
         plan, and the walk copies records out of what comes back (each block still held against its CRC-32) instead of inflating;
-        inflate_alloc(nbytes) -> uint8 array: where the gathered and the inflated bytes go (pinned memory for full link speed)."""
+        inflate_alloc(nbytes) -> uint8 array: where the gathered and the inflated bytes go (pinned memory for full link speed); a batch whose
+        blocks inflate to more than inflate_max_bytes stays with the host's inflate (that much memory would have to be page-locked)."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -647,7 +648,7 @@ class BamSource:
             sh = _Handle(st.value, self.lib.uz_stage_free)
             nb, cb, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
             _check(self.lib, self.lib.uz_stage_gather_blocks(sh.ptr, None, 0, None, None, C.byref(nb), C.byref(cb), C.byref(ob)))
-            if nb.value:
+            if nb.value and ob.value <= int(inflate_max_bytes):
                 ia = inflate_alloc or (lambda nbytes: np.empty(max(16, nbytes), np.uint8))
                 comp = ia(int(cb.value) + 64)
                 inflated = ia(int(ob.value) + 64)
