@@ -616,7 +616,7 @@ class BamSource:
         self.tlen_head = head[: int(k)].copy()
 
     def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False,
-               inflate=None, inflate_alloc=None, inflate_max_bytes=8 << 30):
+               inflate=None, inflate_alloc=None, inflate_max_bytes=16 << 30):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
         `.io_stats` / `.timing` / `.qnames` ride on the returned object.
         pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
