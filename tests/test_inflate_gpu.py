@@ -118,3 +118,36 @@ def test_a_staged_batch_with_its_blocks_inflated_on_the_device(engine, tmp_path)
         assert_same(got, plain)
         assert got.io_stats["blocks_from_the_device"] == got.io_stats["blocks_inflated"] > 20
     pair.free_all()
+
+
+def test_random_blocks_against_zlib(engine):
+    """three hundred blocks of mixed statistics (alphabet size, run lengths, copies of earlier stretches at every distance up to the
+    window, sizes from one byte to the 64 KiB limit), every zlib level and strategy in turn"""
+    rng = np.random.default_rng(2024)
+    blocks, want = [], []
+    strategies = (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED)
+    for k in range(300):
+        n = int(rng.choice([1, 2, 3, 17, 255, 256, 257, 4000, 33000, 65280])) if k % 3 == 0 else int(rng.integers(1, 65281))
+        alpha = int(rng.choice([1, 2, 4, 20, 64, 256]))
+        p = bytearray(rng.integers(0, alpha, n, dtype=np.uint8).tobytes())
+        for _ in range(int(rng.integers(0, 40))):  # copies of earlier stretches: matches at chosen distances, some overlapping their own output
+            if n < 8:
+                break
+            ln = int(rng.integers(3, min(300, n)))
+            dst = int(rng.integers(1, n - ln + 1)) if n - ln >= 1 else 0
+            dist = int(rng.integers(1, min(dst, 32768) + 1)) if dst >= 1 else 0
+            if dist:
+                for i in range(ln):
+                    p[dst + i] = p[dst + i - dist]
+        p = bytes(p)
+        level = int(rng.integers(0, 10))
+        if level == 0 and n > 65000:
+            level = 1
+        blocks.append(bgzf_block(p, level, strategies[k % len(strategies)]))
+        want.append(p)
+    got, nb, _ = engine.bgzf_inflate(b"".join(blocks))
+    assert nb == 300
+    off = 0
+    for k, p in enumerate(want):
+        assert bytes(got[off: off + len(p)]) == p, (k, len(p))
+        off += len(p)
