@@ -801,7 +801,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 if (out->end) w(out->end)[k] = full->end[i];
                 if (pair8) {
                     uint8_t s8, p8;
-                    int32_t e[4];
+                    int32_t e[4] = {0, 0, 0, 0};
                     bool has[4];
                     sel_link_of(s, k, s8, p8, e, has);
                     w(out->start_d8)[k] = s8;
