@@ -56,6 +56,7 @@ def parse():
                          "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
                     "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 3)")
+    ap.add_argument("--first-chunk", type=float, default=1.0, help="size of the first chunk of the staged pass relative to the others")
     ap.add_argument("--last-chunk", type=float, default=0.5, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
@@ -313,7 +314,7 @@ def main():
         slab_hint = 768 << 20
         # chunks of events (their records: the clusters of their generator entries); the last one smaller (--last-chunk): its read
         # stage is the only one nothing hides -- the link is idle by then
-        ecuts = shard.chunk_plan(n, args.chunks or None, args.last_chunk)
+        ecuts = shard.chunk_plan(n, args.chunks or None, args.last_chunk, first_chunk=args.first_chunk)
         nchunk = len(ecuts) - 1
         for k in range(nchunk):
             a, b = ecuts[k], ecuts[k + 1]

@@ -13,7 +13,7 @@ def shard_bounds(n: int, world: int) -> List[int]:
     return [(n * r) // world for r in range(world + 1)]
 
 
-def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, min_per_chunk: int = 12500) -> List[int]:
+def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, min_per_chunk: int = 12500, first_chunk: float = 1.0) -> List[int]:
     """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k, so a shard wants at
     least three chunks (the first chunk's upload and the last chunk's read stage are the two things nothing hides), and chunks of at
     least ~min_per_chunk DNMs (every chunk costs a host round trip and ~40 kernel launches).  The last chunk is smaller (last_chunk x
@@ -25,8 +25,9 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, mi
     k = int(chunks) if chunks else max(3, n // int(min_per_chunk))
     k = max(1, min(k, n))
     f = min(1.0, max(0.05, float(last_chunk)))
-    unit = n / (k - 1 + f)
-    cuts = [min(n, int(round(unit * j))) for j in range(k)] + [n]
+    g = min(1.0, max(0.05, float(first_chunk))) if k >= 3 else 1.0
+    unit = n / (k - 2 + g + f) if k >= 2 else float(n)
+    cuts = [0] + [min(n, int(round(unit * (g + j)))) for j in range(k - 1)] + [n] if k >= 2 else [0, n]
     out = [0]
     for c in cuts[1:]:
         if c > out[-1]:
