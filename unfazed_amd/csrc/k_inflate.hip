@@ -36,6 +36,7 @@ struct InflateLds {
     uint8_t lens[320];                          // code lengths of the block being set up: literal / length code at 0, distance code at 288
     uint8_t cl_lens[32];                        // ... and of the code they are written in
     uint16_t code_of[288];                      // bit-reversed canonical code of every symbol (table fill)
+    int work[48];                               // per-length counters of the table set-up
 };
 
 __device__ __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -81,34 +82,39 @@ __device__ __forceinline__ uint32_t bi_take(BitIn &b, int n) { const uint32_t v 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
 // canonical Huffman set-up from lens[0 .. n): counts, symbols in canonical order, the direct table for codes of <= tb bits.
-// false: an over-subscribed or (but for the one-code case) incomplete set of lengths
+// false: an over-subscribed or (where it matters) incomplete set of lengths
 // (complete: a literal / length or code-length code must use its code space up; a distance code need not -- the fixed one does not,
 // and a block without matches has none -- an unused code then decodes to "no symbol")
-__device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int lane, bool complete) {
-    // (every lane runs the serial part on the same values; lane 0 stores)
-    int count[16];
-#pragma unroll
-    for (int l = 0; l < 16; l++) count[l] = 0;
-    for (int s = 0; s < n; s++) count[lens[s]]++;
-    count[0] = 0;
+// The per-length counters live in LDS (work[48]): indexed by a code length, they would otherwise sit in scratch memory or pin 48 registers
+// (the kernel then needs 80 registers and runs 6 waves per SIMD at 86 GB/s instead of 8 at 97).
+__device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int *work, int lane,
+                            bool complete) {
+    int *count = work, *offs = work + 16, *next = work + 32;
+    __syncthreads();
+    if (lane < 16) count[lane] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        for (int s = 0; s < n; s++) count[lens[s]]++;
+        count[0] = 0;
+        offs[1] = 0; next[1] = 0;
+        for (int l = 1; l < 15; l++) { offs[l + 1] = offs[l] + count[l]; next[l + 1] = (next[l] + count[l]) << 1; }
+    }
+    __syncthreads();
     int left = 1;
     for (int l = 1; l < 16; l++) {
         left = (left << 1) - count[l];
         if (left < 0) return false;
     }
     if (left > 0 && complete) return false;
-    int offs[16], next[16];
-    offs[1] = 0; next[1] = 0;
-    for (int l = 1; l < 15; l++) { offs[l + 1] = offs[l] + count[l]; next[l + 1] = (next[l] + count[l]) << 1; }
-    __syncthreads();
+    if (lane < 16) cnt[lane] = (uint16_t)count[lane];
     if (lane == 0) {
-        for (int l = 0; l < 16; l++) cnt[l] = (uint16_t)count[l];
-    }
-    for (int s = 0; s < n; s++) {
-        const int l = lens[s];
-        if (l) {
-            if (lane == 0) { sorted[offs[l]] = (uint16_t)s; code_of[s] = (uint16_t)bitrev((uint32_t)next[l], l); }
-            offs[l]++; next[l]++;
+        for (int s = 0; s < n; s++) {
+            const int l = lens[s];
+            if (l) {
+                sorted[offs[l]] = (uint16_t)s;
+                code_of[s] = (uint16_t)bitrev((uint32_t)next[l], l);
+                offs[l]++; next[l]++;
+            }
         }
     }
     for (int k = lane; k < (1 << tb); k += 64) tab[k] = 0;
@@ -142,7 +148,7 @@ __device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb,
 
 // err: 1 bad block type / stored length, 2 bad code lengths, 3 bad symbol, 4 output overrun or distance before the block, 5 wrong size
 #ifndef UZI_WAVES_PER_EU
-#define UZI_WAVES_PER_EU 6 // (measured 4 / 6 / 8 waves per SIMD: 63 / 86 / 76 GB/s of output -- at 8 the 64 registers spill)
+#define UZI_WAVES_PER_EU 8 // (measured 6 / 8 waves per SIMD: 86 / 97 GB/s of output; the decoder state fits 64 registers)
 #endif
 __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ in_off,
                                                      const int64_t *__restrict__ out_off, uint8_t *out, int32_t *cursor, int32_t *err) {
@@ -210,7 +216,7 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 }
                 __syncthreads();
                 // (the code-length code sits where the distance code will be: 7-bit direct table, canonical arrays)
-                if (!build_table(L.cl_lens, 19, L.dist_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, lane, true)) { bad = 2; break; }
+                if (!build_table(L.cl_lens, 19, L.dist_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, true)) { bad = 2; break; }
                 int n = 0, prev = 0;
                 while (n < nlit + ndist) {
                     bi_refill(b, lane);
@@ -232,8 +238,8 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 __syncthreads();
                 if (L.lens[256] == 0) { bad = 2; break; } // no end-of-block code
             }
-            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, lane, true)) { bad = 2; break; }
-            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, lane, false)) { bad = 2; break; }
+            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, true)) { bad = 2; break; }
+            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, false)) { bad = 2; break; }
             // ---- the symbols of the block.  Literals gather in a register window -- lane l holds the byte for position wbase + l -- and
             // leave it as one coalesced store when it is full or a match needs them in memory.
             for (;;) {
