@@ -56,6 +56,7 @@ def parse():
                          "K6 + the SV read-backed stage around both breakpoints)")
     ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
                     "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 3)")
+    ap.add_argument("--sites16", action="store_true", help="staged pass: the genotype columns of the site windows in 16 bits (default: the eight-bit link form)")
     ap.add_argument("--first-chunk", type=float, default=1.0, help="size of the first chunk of the staged pass relative to the others")
     ap.add_argument("--last-chunk", type=float, default=0.5, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
@@ -368,14 +369,19 @@ def main():
                 pool.new_slab(int(sel.size) * 28 + (1 << 20))
                 hs_k = {k: pinned_copy(pool, getattr(sc, k)[sel]) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
                 hs_k["contig_off"] = pinned_copy(pool, np.searchsorted(sel, co_s).astype(np.int64))
-                hg_k = {k: [pinned_copy(pool, getattr(sc, k)[m][sel]) for m in range(3)] for k in ("rd", "ad", "gq")}
+                hg_k = {k: [getattr(sc, k)[m][sel] for m in range(3)] for k in ("rd", "ad", "gq")}
+                wide_k = None
+                if not args.sites16:  # the nine genotype columns in eight bits (uz_types.h: depths of 255 and more, or missing, through the wide list)
+                    r8, a8, g8, wide_k = abi.family_columns8(hg_k["rd"], hg_k["ad"], hg_k["gq"])
+                    hg_k = dict(rd=list(r8), ad=list(a8), gq=list(g8))
+                hg_k = {k: [pinned_copy(pool, x) for x in v] for k, v in hg_k.items()}
                 svk = abi.SitesView()
                 svk.n_sites, svk.n_contigs = int(sel.size), len(sc.contig_off) - 1
                 for k in ("contig_off", "pos", "sflags", "ref_base", "alt_base"):
                     setattr(svk, k, hs_k[k].ctypes.data)
                 pool.end_slab()
-                chunk_sites.append((abi.Held(svk, hs_k), hs_k, hg_k, int(sel.size)))
-            site_bytes = sum(x[3] for x in chunk_sites) * (4 + 1 + 1 + 1 + 1 + 18)
+                chunk_sites.append((abi.Held(svk, hs_k), hs_k, hg_k, int(sel.size), wide_k))
+            site_bytes = sum(x[3] * (4 + 1 + 1 + 1 + 1 + (18 if args.sites16 else 9)) + (0 if x[4] is None else len(x[4][0]) * 32) for x in chunk_sites)
         t_dec = time.time() - t_dec
 
         trace = [] if os.environ.get("UZ_BENCH_TRACE") else None
@@ -391,8 +397,8 @@ def main():
             sids, fids, rids = [None] * K, [None] * K, [None] * K
 
             def site_stage(k):  # queued on the copy stream (in front of the records of chunk k - 1 ... k): no host wait
-                held, hs_k, hg_k, _ = chunk_sites[k]
-                sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"])
+                held, hs_k, hg_k, _, wide_k = chunk_sites[k]
+                sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"], wide_k)
 
             def read_stage_begin(k):  # queued on the compute stream (waits there for the chunk's records): no host wait
                 eng.phase_begin(fids[k], rids[k], chunks[k][3], P, mode)

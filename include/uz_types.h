@@ -124,7 +124,19 @@ typedef struct uz_family_view {
     const int64_t *wide_site;        /* [n_wide] site index */
     const int32_t *wide_ref_depth[3]; /* [n_wide] each; values up to 2^30 */
     const int32_t *wide_alt_depth[3];
+    /* The nine columns in EIGHT bits for the host link (set all nine; ref_depth / alt_depth / gq are then NULL): a trio sequenced to
+     * 30x has depths of a few dozen and genotype qualities of at most 99.  A depth byte below 254 is the depth; UZ_U8_MISSING (254) =
+     * missing; UZ_U8_SEE_WIDE (255) = the site stands in the wide list above with its exact depths (any member's depth of 254 or more puts
+     * it there).  A quality byte below 255 is min(floor(GQ), 254); 255 = missing --
+     * the site tests compare GQ with --min-gt-qual only, so the clamp is exact for thresholds up to 254 (a family staged this way refuses
+     * a larger one, UZ_E_STATE).  The device widens the columns to the 16-bit ones its kernels read: 10 bytes per site cross the link
+     * instead of 19. */
+    const uint8_t *ref_depth8[3];
+    const uint8_t *alt_depth8[3];
+    const uint8_t *gq8[3];
 } uz_family_view;
+#define UZ_U8_MISSING 254u
+#define UZ_U8_SEE_WIDE 255u
 
 /* alignment records of one BAM in file (coordinate) order */
 typedef struct uz_reads_view {

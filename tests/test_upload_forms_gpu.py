@@ -111,3 +111,43 @@ def test_staged_from_an_indexed_bam(engine, tmp_path):
         by_name.setdefault(table.qnames[int(table.qname[i])], []).append((int(table.start[i]), int(table.tlen[i])))
     for i in range(0, n, 37):
         assert (int(dev["start"][i]), int(dev["tlen"][i])) in by_name[got.qnames[int(dev["qname"][i])]]
+
+
+def test_family_columns_in_eight_bits_give_the_same_classes(engine):
+    """The nine genotype columns of a trio in the eight-bit link form (uz_family_view.ref_depth8 ...: depths below 254, 254 = missing,
+    255 = the site stands in the wide list; qualities clamped at 254, 255 = missing) against the 16-bit columns: the same class byte at
+    every site, on both upload routes and for several threshold sets; a --min-gt-qual the clamp cannot serve is refused."""
+    from synth.sites_np import make_sites
+    from test_site_stage_gpu import PARAM_SETS, _Sites
+    from test_pack_select import _sites_views  # noqa: F401  (shared helpers live there)
+    sc = make_sites(60_001, seed=91)
+    rd, ad, gq = (np.array(x, np.uint16, copy=True) for x in (sc.rd, sc.ad, sc.gq))
+    rng = np.random.default_rng(3)
+    deep = rng.choice(sc.n, 300, replace=False)
+    rd[0, deep[:100]] = rng.integers(254, 2000, 100)     # depths the bytes cannot hold: through the wide list
+    ad[1, deep[100:200]] = rng.integers(254, 30000, 100)
+    ad[2, deep[200:]] = 254
+    gq[1, deep[:50]] = rng.integers(255, 1000, 50)       # qualities beyond the clamp
+    assert (rd == 0xFFFF).any() and (gq == 0xFFFF).any()  # missing values are part of the table
+    r8, a8, g8, wide = abi.family_columns8(rd, ad, gq)
+    assert r8.dtype == np.uint8 and len(wide[0]) >= 290 and (r8 == 254).sum() == (rd == 0xFFFF).sum() - int((rd[:, wide[0]] == 0xFFFF).sum())
+    sid = engine.upload_sites(_Sites(sc))
+    f16 = engine.add_family(sid, sc.gt, rd, ad, gq)
+    f8 = engine.add_family(sid, sc.gt, r8, a8, g8, wide)
+    sv = abi.SitesView()
+    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags, ref_base=sc.ref_base, alt_base=sc.alt_base)
+    sv.n_sites, sv.n_contigs = sc.n, len(sc.contig_off) - 1
+    for k, a in keep.items():
+        setattr(sv, k, a.ctypes.data)
+    sid2, f8a = engine.upload_sites_family_async(abi.Held(sv, keep), sc.gt, list(r8), list(a8), list(g8), wide)
+    for kw in PARAM_SETS:
+        P = abi.make_params(**kw)
+        want = engine.classify(f16, P, sc.n)
+        assert np.array_equal(engine.classify(f8, P, sc.n), want), kw
+        assert np.array_equal(engine.classify(f8a, P, sc.n), want), kw
+    assert len(np.unique(want)) > 3
+    with pytest.raises(UnfazedHipError, match="eight-bit genotype qualities"):
+        engine.classify(f8, abi.make_params(min_gt_qual=300), sc.n)
+    engine.classify(f16, abi.make_params(min_gt_qual=300), sc.n)  # (the 16-bit columns serve any threshold)
+    engine.free_sites(sid)
+    engine.free_sites(sid2)

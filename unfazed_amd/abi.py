@@ -99,6 +99,9 @@ class FamilyView(C.Structure):
         ("wide_site", _p),
         ("wide_ref_depth", _p * 3),
         ("wide_alt_depth", _p * 3),
+        ("ref_depth8", _p * 3),  # the nine columns in eight bits for the host link (then ref_depth / alt_depth / gq are NULL)
+        ("alt_depth8", _p * 3),
+        ("gq8", _p * 3),
     ]
 
 
@@ -441,15 +444,18 @@ def family_view(gt: np.ndarray, rd: np.ndarray, ad: np.ndarray, gq: np.ndarray, 
     """gt u8[S]; rd/ad/gq u16[3][S] in kid, dad, mom order.  wide = (site int64[W], ref_depth int32[3][W], alt_depth int32[3][W]): the
     sites whose depths do not fit the 16-bit columns (model.SitesTable.family_columns lists them), or None."""
     gt = _c(gt, np.uint8)
-    rd = [_c(rd[m], np.uint16) for m in range(3)]
-    ad = [_c(ad[m], np.uint16) for m in range(3)]
-    gq = [_c(gq[m], np.uint16) for m in range(3)]
+    eight = all(np.asarray(x[m]).dtype == np.uint8 for x in (rd, ad, gq) for m in range(3))  # the link form of family_columns8
+    dt = np.uint8 if eight else np.uint16
+    rd = [_c(rd[m], dt) for m in range(3)]
+    ad = [_c(ad[m], dt) for m in range(3)]
+    gq = [_c(gq[m], dt) for m in range(3)]
     v = FamilyView()
     v.gt = _ptr(gt)
     for m in range(3):
-        v.ref_depth[m] = _ptr(rd[m])
-        v.alt_depth[m] = _ptr(ad[m])
-        v.gq[m] = _ptr(gq[m])
+        if eight:
+            v.ref_depth8[m], v.alt_depth8[m], v.gq8[m] = _ptr(rd[m]), _ptr(ad[m]), _ptr(gq[m])
+        else:
+            v.ref_depth[m], v.alt_depth[m], v.gq[m] = _ptr(rd[m]), _ptr(ad[m]), _ptr(gq[m])
     keep = dict(gt=gt, rd=rd, ad=ad, gq=gq)
     if wide is not None and len(wide[0]):
         ws = _c(wide[0], np.int64)
@@ -460,6 +466,35 @@ def family_view(gt: np.ndarray, rd: np.ndarray, ad: np.ndarray, gq: np.ndarray, 
             v.wide_ref_depth[m], v.wide_alt_depth[m] = _ptr(wr[m]), _ptr(wa[m])
         keep.update(wide_site=ws, wide_rd=wr, wide_ad=wa)
     return Held(v, keep)
+
+
+def family_columns8(rd, ad, gq, wide=None):
+    """The 16-bit family columns (rd / ad / gq u16[3][S], 0xFFFF = missing; wide as family_view takes it) in the eight-bit link form of
+    uz_family_view: -> (rd8, ad8, gq8 as uint8 [3][S], wide) -- depth bytes: 0 .. 253 the depth, 254 missing, 255 = the site is in the wide
+    list with its exact depths (any member's depth of 254 or more puts it there); quality bytes: min(gq, 254), 255 missing."""
+    rd = np.asarray(rd, np.uint16)
+    ad = np.asarray(ad, np.uint16)
+    gq = np.asarray(gq, np.uint16)
+    S = rd.shape[1]
+    big = (((rd >= 254) & (rd != 0xFFFF)) | ((ad >= 254) & (ad != 0xFFFF))).any(axis=0)
+    listed = np.zeros(S, bool)
+    w_site = np.zeros(0, np.int64)
+    if wide is not None and len(wide[0]):
+        w_site = np.asarray(wide[0], np.int64)
+        listed[w_site] = True
+    new = np.nonzero(big & ~listed)[0]
+    exact = lambda col: np.where(col == 0xFFFF, -1, col.astype(np.int64)).astype(np.int32)  # noqa: E731
+    if new.size or w_site.size:
+        sites = np.concatenate([w_site, new])
+        order = np.argsort(sites, kind="stable")
+        wr = [np.concatenate([np.asarray(wide[1][m], np.int32) if w_site.size else np.zeros(0, np.int32), exact(rd[m][new])])[order] for m in range(3)]
+        wa = [np.concatenate([np.asarray(wide[2][m], np.int32) if w_site.size else np.zeros(0, np.int32), exact(ad[m][new])])[order] for m in range(3)]
+        wide = (sites[order], wr, wa)
+        listed[new] = True
+    rd8 = np.where(listed[None, :], 255, np.where(rd == 0xFFFF, 254, rd)).astype(np.uint8)
+    ad8 = np.where(listed[None, :], 255, np.where(ad == 0xFFFF, 254, ad)).astype(np.uint8)
+    gq8 = np.where(gq == 0xFFFF, 255, np.minimum(gq, 254)).astype(np.uint8)
+    return rd8, ad8, gq8, wide
 
 
 def reads_view(t: ReadsTable) -> Held:

@@ -141,6 +141,7 @@ FamilyDev &fam_of(uz_ctx *c, int id) {
         f.pending = false;
         UZ_HIP(hipStreamWaitEvent(c->stream, f.ready, 0));
         SitesDev &s = sites_of(c, f.sites_id);
+        uz_family_widen(c, f, s.n);
         uz_fold_complex(c, f.gt, s.sflags, s.n);
     }
     return f;
@@ -478,13 +479,25 @@ int uz_sites_adopt_device(uz_ctx *c, const uz_sites_view *v, int *id) {
     });
 }
 
+// which form the nine columns of a family view come in: true = eight bits (all nine of ref_depth8 / alt_depth8 / gq8 set, the 16-bit ones null)
+static bool family_view_eight(const uz_family_view *v) {
+    int n8 = 0, n16 = 0;
+    for (int m = 0; m < 3; m++) {
+        n8 += (v->ref_depth8[m] != nullptr) + (v->alt_depth8[m] != nullptr) + (v->gq8[m] != nullptr);
+        n16 += (v->ref_depth[m] != nullptr) + (v->alt_depth[m] != nullptr) + (v->gq[m] != nullptr);
+    }
+    UZ_REQUIRE((n8 == 9 && n16 == 0) || (n8 == 0 && n16 == 9), UZ_E_ARG, "a family view carries its nine columns in 16 bits OR in 8 bits (ref_depth8 / alt_depth8 / gq8), all nine");
+    return n8 == 9;
+}
+
 // the too-deep sites of a family view (host pointers) -> the family's side table on the device
 static void family_wide(uz_ctx *c, hipStream_t st, const uz_family_view *v, FamilyDev &f, int64_t n_sites) {
     f.n_wide = 0;
     if (!v || v->n_wide <= 0) return;
     UZ_REQUIRE(v->wide_site != nullptr, UZ_E_ARG, "n_wide set but wide_site is null");
     const size_t w = (size_t)v->n_wide;
-    std::vector<int32_t> dep(6 * w);
+    f.wide_host = std::make_shared<std::vector<int32_t>>(6 * w);
+    std::vector<int32_t> &dep = *f.wide_host;
     for (int m = 0; m < 3; m++) {
         UZ_REQUIRE(v->wide_ref_depth[m] && v->wide_alt_depth[m], UZ_E_ARG, "null wide depth column");
         for (size_t k = 0; k < w; k++) {
@@ -504,8 +517,7 @@ static void family_wide(uz_ctx *c, hipStream_t st, const uz_family_view *v, Fami
         if (!pass) f.wide_block = uz_block_get(c, cv.off + 256);
     }
     UZ_HIP(hipMemcpyAsync(f.wide_site, v->wide_site, w * sizeof(int64_t), hipMemcpyHostToDevice, st));
-    UZ_HIP(hipMemcpyAsync(f.wide_depth, dep.data(), 6 * w * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    UZ_HIP(hipStreamSynchronize(st)); // `dep` is a local (a handful of sites)
+    UZ_HIP(hipMemcpyAsync(f.wide_depth, dep.data(), 6 * w * sizeof(int32_t), hipMemcpyHostToDevice, st)); // (`dep` lives as long as the family)
     f.n_wide = (int64_t)w;
 }
 
@@ -524,18 +536,29 @@ int uz_family_upload(uz_ctx *c, int sites_id, const uz_family_view *v, int *id) 
         FamilyDev f;
         f.owned = true;
         const size_t n = (size_t)s.n;
+        const bool eight = family_view_eight(v);
+        uint8_t *st8[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (int pass = 0; pass < 2; pass++) {
             Carver cv(pass ? f.block.p : nullptr);
             f.cls = cv.take<uint8_t>(n);
             f.gt = cv.take<uint8_t>(n);
             for (int m = 0; m < 3; m++) { f.rd[m] = cv.take<uint16_t>(n); f.ad[m] = cv.take<uint16_t>(n); f.gq[m] = cv.take<uint16_t>(n); }
+            if (eight) for (int k = 0; k < 9; k++) st8[k] = cv.take<uint8_t>(n);
             if (!pass) f.block = uz_block_get(c, cv.off + 256);
         }
         try {
             h2d(c->stream, f.gt, v->gt, n);
-            for (int m = 0; m < 3; m++) {
-                h2d(c->stream, f.rd[m], v->ref_depth[m], n); h2d(c->stream, f.ad[m], v->alt_depth[m], n); h2d(c->stream, f.gq[m], v->gq[m], n);
-            }
+            if (eight) {
+                for (int m = 0; m < 3; m++) {
+                    f.stage8[m] = h2d(c->stream, st8[m], v->ref_depth8[m], n); f.stage8[3 + m] = h2d(c->stream, st8[3 + m], v->alt_depth8[m], n);
+                    f.stage8[6 + m] = h2d(c->stream, st8[6 + m], v->gq8[m], n);
+                }
+                f.widen_pending = true; f.gq_clamped = true;
+                uz_family_widen(c, f, s.n);
+            } else
+                for (int m = 0; m < 3; m++) {
+                    h2d(c->stream, f.rd[m], v->ref_depth[m], n); h2d(c->stream, f.ad[m], v->alt_depth[m], n); h2d(c->stream, f.gq[m], v->gq[m], n);
+                }
             family_wide(c, c->stream, v, f, s.n);
             family_common(c, sites_id, f);
         } catch (...) { uz_block_put(c, f.block); uz_block_put(c, f.wide_block); throw; }
@@ -556,6 +579,8 @@ int uz_sites_family_upload_async(uz_ctx *c, const uz_sites_view *v, const uz_fam
         const size_t n = (size_t)s.n;
         FamilyDev f;
         f.owned = true;
+        const bool eight = family_view_eight(fv);
+        uint8_t *st8[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         for (int pass = 0; pass < 2; pass++) {
             Carver cv(pass ? s.block.p : nullptr);
             s.contig_off = cv.take<int64_t>((size_t)v->n_contigs + 1);
@@ -567,6 +592,7 @@ int uz_sites_family_upload_async(uz_ctx *c, const uz_sites_view *v, const uz_fam
             f.cls = cv.take<uint8_t>(n);
             f.gt = cv.take<uint8_t>(n);
             for (int m = 0; m < 3; m++) { f.rd[m] = cv.take<uint16_t>(n); f.ad[m] = cv.take<uint16_t>(n); f.gq[m] = cv.take<uint16_t>(n); }
+            if (eight) for (int k = 0; k < 9; k++) st8[k] = cv.take<uint8_t>(n);
             if (!pass) f.block = uz_block_get(c, cv.off + 256);
         }
         try {
@@ -579,12 +605,19 @@ int uz_sites_family_upload_async(uz_ctx *c, const uz_sites_view *v, const uz_fam
                 s.pos = const_cast<int32_t *>(h2d(st, s.pos, v->pos, n)); s.sflags = const_cast<uint8_t *>(h2d(st, s.sflags, v->sflags, n));
                 s.ref_base = const_cast<uint8_t *>(h2d(st, s.ref_base, v->ref_base, n)); s.alt_base = const_cast<uint8_t *>(h2d(st, s.alt_base, v->alt_base, n));
                 f.gt = const_cast<uint8_t *>(h2d(st, f.gt, fv->gt, n)); // (bit 6 is written by the library: the mirror is the library's own memory)
-                for (int m = 0; m < 3; m++) {
-                    f.rd[m] = const_cast<uint16_t *>(h2d(st, f.rd[m], fv->ref_depth[m], n));
-                    f.ad[m] = const_cast<uint16_t *>(h2d(st, f.ad[m], fv->alt_depth[m], n));
-                    f.gq[m] = const_cast<uint16_t *>(h2d(st, f.gq[m], fv->gq[m], n));
-                }
+                if (eight) { // (the staged bytes may end up in the mirror block: the 16-bit columns are always the family's own)
+                    for (int m = 0; m < 3; m++) {
+                        f.stage8[m] = h2d(st, st8[m], fv->ref_depth8[m], n); f.stage8[3 + m] = h2d(st, st8[3 + m], fv->alt_depth8[m], n);
+                        f.stage8[6 + m] = h2d(st, st8[6 + m], fv->gq8[m], n);
+                    }
+                } else
+                    for (int m = 0; m < 3; m++) {
+                        f.rd[m] = const_cast<uint16_t *>(h2d(st, f.rd[m], fv->ref_depth[m], n));
+                        f.ad[m] = const_cast<uint16_t *>(h2d(st, f.ad[m], fv->alt_depth[m], n));
+                        f.gq[m] = const_cast<uint16_t *>(h2d(st, f.gq[m], fv->gq[m], n));
+                    }
             }
+            if (eight) { f.widen_pending = true; f.gq_clamped = true; }
             family_wide(c, st, fv, f, s.n);
             UZ_HIP(hipEventCreateWithFlags(&f.ready, hipEventDisableTiming));
             UZ_HIP(hipEventRecord(f.ready, st));
@@ -604,6 +637,7 @@ int uz_sites_family_upload_async(uz_ctx *c, const uz_sites_view *v, const uz_fam
 int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int *id) {
     return guarded(c, [&] {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad family view");
+        UZ_REQUIRE(!family_view_eight(v), UZ_E_ARG, "uz_family_adopt_device takes the 16-bit columns (the kernels read them in place)");
         FamilyDev f;
         f.owned = false;
         f.gt = const_cast<uint8_t *>(v->gt); // bit 6 is written by the library (complex flag)

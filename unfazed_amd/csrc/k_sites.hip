@@ -671,6 +671,29 @@ __global__ void k_fold_complex(uint8_t *gt, const uint8_t *sflags, int64_t n) {
     if (i < n) gt[i] = (uint8_t)((gt[i] & 0x3Fu) | ((sflags[i] & UZ_SF_COMPLEX) ? 0x40u : 0u));
 }
 
+// the nine eight-bit columns of the link form (uz_family_view.ref_depth8 ...) into the 16-bit ones the kernels read.  `missing`: the
+// byte that stands for a missing value (254 in a depth column -- 255 there is "see the wide list": any value will do, the site's class is
+// rewritten from the list -- 255 in a quality column)
+__global__ __launch_bounds__(256) void k_widen8(int64_t n, const uint8_t *__restrict__ s0, const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
+                                                uint16_t *d0, uint16_t *d1, uint16_t *d2, uint32_t missing) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = s0[i], b = s1[i], c = s2[i];
+    d0[i] = (uint16_t)(a == missing ? 0xFFFFu : a);
+    d1[i] = (uint16_t)(b == missing ? 0xFFFFu : b);
+    d2[i] = (uint16_t)(c == missing ? 0xFFFFu : c);
+}
+void uz_family_widen(uz_ctx *c, FamilyDev &f, int64_t n) {
+    if (!f.widen_pending) return;
+    f.widen_pending = false;
+    if (n <= 0) return;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, f.stage8[0], f.stage8[1], f.stage8[2], f.rd[0], f.rd[1], f.rd[2], UZ_U8_MISSING);
+    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, f.stage8[3], f.stage8[4], f.stage8[5], f.ad[0], f.ad[1], f.ad[2], UZ_U8_MISSING);
+    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, f.stage8[6], f.stage8[7], f.stage8[8], f.gq[0], f.gq[1], f.gq[2], 255u);
+    UZ_HIP(hipGetLastError());
+}
+
 void uz_fold_complex(uz_ctx *c, uint8_t *gt, const uint8_t *sflags, int64_t n) {
     if (n <= 0) return;
     const int64_t nb = (n + 255) / 256;
@@ -751,7 +774,12 @@ static void launch_site_scan_wide(uz_ctx *c, FamilyDev &f, bool with_cnv) {
     UZ_HIP(hipGetLastError());
 }
 
+static void check_gq_clamp(const uz_ctx *c, const FamilyDev &f) {
+    UZ_REQUIRE(!f.gq_clamped || c->P.min_gt_qual <= 254, UZ_E_STATE,
+               "this family was staged with eight-bit genotype qualities (clamped at 254): --min-gt-qual above 254 needs the 16-bit columns");
+}
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv) {
+    check_gq_clamp(c, f);
     if (s.n > 0) { launch_site_scan(c, fam_ptrs(f), f.cls, s.n, with_cnv, nullptr, 1); launch_site_scan_wide(c, f, with_cnv); }
     f.cls_has_cnv = with_cnv;
     f.cls_valid = true;
@@ -760,6 +788,7 @@ void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_c
 
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv) {
     if (n_fam <= 0) return;
+    for (int k = 0; k < n_fam; k++) check_gq_clamp(c, *fams[k]);
     if (s.n > 0) {
         std::vector<FamBatchItem> items((size_t)n_fam);
         for (int k = 0; k < n_fam; k++) { items[(size_t)k].f = fam_ptrs(*fams[k]); items[(size_t)k].cls = fams[k]->cls; }

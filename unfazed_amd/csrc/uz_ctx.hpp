@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "unfazed_hip.h"
@@ -104,10 +105,14 @@ struct FamilyDev {
     int64_t *wide_site = nullptr;
     int32_t *wide_depth = nullptr; // [6][n_wide]: rd kid, dad, mom, ad kid, dad, mom
     DevBlock wide_block;
+    std::shared_ptr<std::vector<int32_t>> wide_host; // the host copy the (asynchronous) upload of wide_depth reads: kept with the family
     // asynchronous upload (uz_sites_family_upload_async): the copies are queued on the copy stream; `ready` marks their end and
     // the first use of the family makes the compute stream wait for it and folds the complex flag (family_make_ready)
     hipEvent_t ready = nullptr;
     bool pending = false;
+    // eight-bit link form (uz_family_view.ref_depth8 ...): the staged bytes, widened into rd / ad / gq at first use; gq was clamped at 254
+    const uint8_t *stage8[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool widen_pending = false, gq_clamped = false;
     bool cls_valid = false;
     bool cls_has_cnv = false; // DEL / DUP codes (bits 3-6) computed
     uz_params cls_params;
@@ -334,6 +339,7 @@ void uz_build_qlow(uz_ctx *c, hipStream_t st, ReadsDev &r, int min_base_qual);
 void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &src, int64_t rec_base, int64_t cigar_base, int64_t unit_base,
                      int64_t seq_base, uint32_t qname_base);
 void uz_finish_table(uz_ctx *c, hipStream_t st, ReadsDev &r); // coarse index of a table whose headers are in place
+void uz_family_widen(uz_ctx *c, FamilyDev &f, int64_t n_sites); // eight-bit link columns -> the 16-bit ones, on the compute stream (once)
 void uz_launch_site_scan(uz_ctx *c, FamilyDev &f, const SitesDev &s, bool with_cnv);
 void uz_launch_site_scan_many(uz_ctx *c, FamilyDev *const *fams, int n_fam, const SitesDev &s, bool with_cnv);
 void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool host_offsets = true);

@@ -159,10 +159,11 @@ class HipEngine:
         self._ck(self.L.uz_family_upload(self.h, int(sites_h), v.ref(), C.byref(fid)), "uz_family_upload")
         return fid.value
 
-    def upload_sites_family_async(self, held: abi.Held, gt, rd, ad, gq):
+    def upload_sites_family_async(self, held: abi.Held, gt, rd, ad, gq, wide=None):
         """sites + one trio's genotype columns queued on the copy stream (uz_sites_family_upload_async) -> (sites id, family id);
-        the arrays (pinned) must stay alive until a call using the family has returned: the engine keeps them"""
-        v = abi.family_view(gt, rd, ad, gq)
+        the arrays (pinned) must stay alive until a call using the family has returned: the engine keeps them.
+        rd / ad / gq as uint8 arrays = the eight-bit link form (abi.family_columns8, which also extends `wide`)."""
+        v = abi.family_view(gt, rd, ad, gq, wide)
         sid, fid = C.c_int(-1), C.c_int(-1)
         self._ck(self.L.uz_sites_family_upload_async(self.h, held.ref(), v.ref(), C.byref(sid), C.byref(fid)), "uz_sites_family_upload_async")
         self._staged_sites[sid.value] = (held, v)
