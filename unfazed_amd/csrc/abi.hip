@@ -486,7 +486,9 @@ static bool family_view_eight(const uz_family_view *v) {
         n8 += (v->ref_depth8[m] != nullptr) + (v->alt_depth8[m] != nullptr) + (v->gq8[m] != nullptr);
         n16 += (v->ref_depth[m] != nullptr) + (v->alt_depth[m] != nullptr) + (v->gq[m] != nullptr);
     }
-    UZ_REQUIRE((n8 == 9 && n16 == 0) || (n8 == 0 && n16 == 9), UZ_E_ARG, "a family view carries its nine columns in 16 bits OR in 8 bits (ref_depth8 / alt_depth8 / gq8), all nine");
+    // (a table without sites may leave every pointer null)
+    UZ_REQUIRE((n8 == 9 && n16 == 0) || (n8 == 0 && n16 == 9) || (n8 == 0 && n16 == 0), UZ_E_ARG,
+               "a family view carries its nine columns in 16 bits OR in 8 bits (ref_depth8 / alt_depth8 / gq8), all nine");
     return n8 == 9;
 }
 
