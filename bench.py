@@ -44,8 +44,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # (the second step of a run still allocates: lists of three finds, table blocks; measured 1 / 2 / 3 warm-up steps: 16.7 / 15.3 / 15.4 ms)
     ap.add_argument("--dnms", type=int, default=int(os.environ.get("UZ_BENCH_DNMS", 100000)),
                     help="DNMs per GPU (weak scaling) / in total (strong scaling)")
     ap.add_argument("--sites", type=int, default=int(os.environ.get("UZ_BENCH_SITES", 20000000)))
