@@ -151,3 +151,20 @@ def test_random_blocks_against_zlib(engine):
     for k, p in enumerate(want):
         assert bytes(got[off: off + len(p)]) == p, (k, len(p))
         off += len(p)
+
+
+def test_a_stream_that_never_ends_is_stopped(engine):
+    """empty stored blocks without end (BFINAL never set), the last one of block A stepping over A's trailer and B's header into B's
+    body, which goes on the same way: the decoder gives up once it has read more than a BGZF block can hold (error 6) -- it does not
+    walk on through the buffer and out of it"""
+    def frame(body, isize):
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(body) + 25) + body + struct.pack("<II", 0, isize))
+    empty = b"\x00\x00\x00\xff\xff"
+    a = frame(empty * 13101 + b"\x00" + struct.pack("<HH", 26, 26 ^ 0xFFFF), 100)  # the last stored block: 26 bytes = A's trailer + B's header
+    assert len(a) == 65536
+    b = frame(empty * 4000, 100)
+    good = bgzf_block(b"hello" * 100, 6)
+    with pytest.raises(UnfazedHipError, match="block"):
+        engine.bgzf_inflate(good + a + b + good * 3)
+    out, nb, _ = engine.bgzf_inflate(good * 4)  # and the context is fine afterwards
+    assert nb == 4 and out.tobytes() == b"hello" * 400

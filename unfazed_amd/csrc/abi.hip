@@ -1027,6 +1027,7 @@ int uz_bgzf_inflate(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t 
         if (kernel_ms) *kernel_ms = 0;
         if (n_blocks == 0) return;
         const int64_t out_bytes = out_off[n_blocks];
+        UZ_REQUIRE(out_off[0] >= 0, UZ_E_ARG, "bad block table");
         for (int64_t k = 0; k < n_blocks; k++)
             UZ_REQUIRE(in_off[k] >= 0 && in_off[k] < comp_bytes && out_off[k] <= out_off[k + 1] && out_off[k + 1] - out_off[k] <= 65536, UZ_E_ARG,
                        "bad block table (a BGZF block inflates to at most 64 KiB)");
@@ -1051,9 +1052,9 @@ int uz_bgzf_inflate(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t 
             UZ_HIP(hipMemcpyAsync(d_off, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, c->stream));
             UZ_HIP(hipEventCreate(&e0));
             UZ_HIP(hipEventCreate(&e1));
-            uz_launch_inflate(c, c->stream, n_blocks, d_comp, d_in, d_off, d_out, d_flags); // (warm-up and the run that is checked)
+            uz_launch_inflate(c, c->stream, n_blocks, d_comp, (comp_bytes + 1024) & ~(int64_t)3, d_in, d_off, d_out, d_flags); // (warm-up and the run that is checked)
             UZ_HIP(hipEventRecord(e0, c->stream));
-            for (int r = 0; r < std::max(repeat, 0); r++) uz_launch_inflate(c, c->stream, n_blocks, d_comp, d_in, d_off, d_out, d_flags);
+            for (int r = 0; r < std::max(repeat, 0); r++) uz_launch_inflate(c, c->stream, n_blocks, d_comp, (comp_bytes + 1024) & ~(int64_t)3, d_in, d_off, d_out, d_flags);
             UZ_HIP(hipEventRecord(e1, c->stream));
             int32_t flags[2] = {0, 0};
             UZ_HIP(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
@@ -1076,7 +1077,11 @@ int uz_bgzf_inflate_to_host(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, 
         UZ_REQUIRE(n_blocks >= 0 && comp_bytes >= 0 && (n_blocks == 0 || (comp && in_off && out_off && out)), UZ_E_ARG, "bad arguments");
         if (n_blocks == 0) return;
         const int64_t out_bytes = out_off[n_blocks];
-        UZ_REQUIRE(out_bytes >= 0, UZ_E_ARG, "bad block table");
+        UZ_REQUIRE(out_bytes >= 0 && out_off[0] >= 0, UZ_E_ARG, "bad block table");
+        for (int64_t k = 0; k < n_blocks; k++)
+            UZ_REQUIRE(in_off[k] >= 0 && in_off[k] < comp_bytes && (k == 0 || in_off[k] > in_off[k - 1]) && out_off[k] <= out_off[k + 1] &&
+                           out_off[k + 1] - out_off[k] <= 65536,
+                       UZ_E_ARG, "bad block table (blocks in the order they lie in `comp`; a BGZF block inflates to at most 64 KiB)");
         UZ_HIP(hipSetDevice(c->device)); // (a decoder's worker thread calls this: the current device is per thread)
         if (!c->inf_stream) {
             UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
@@ -1108,7 +1113,7 @@ int uz_bgzf_inflate_to_host(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, 
             // (whole blocks travel: a slice's bytes run from the framing of its first block to the start of the next slice's)
             const int64_t c0 = i == 0 ? 0 : in_off[b0] - 18 < 0 ? 0 : in_off[b0] - 18, c1 = i + 1 == ns ? comp_bytes : std::max<int64_t>(in_off[b1] - 18, c0);
             UZ_HIP(hipMemcpyAsync(c->inf_comp.p + c0, comp + c0, (size_t)(c1 - c0), hipMemcpyHostToDevice, s));
-            uz_launch_inflate(c, s, b1 - b0, c->inf_comp.p, c->inf_in.p + b0, c->inf_off.p + b0, c->inf_out.p, c->inf_flags.p + 2 * i);
+            uz_launch_inflate(c, s, b1 - b0, c->inf_comp.p, (comp_bytes + 1024) & ~(int64_t)3, c->inf_in.p + b0, c->inf_off.p + b0, c->inf_out.p, c->inf_flags.p + 2 * i);
             UZ_HIP(hipMemcpyAsync(flags.data() + 2 * i, c->inf_flags.p + 2 * i, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             UZ_HIP(hipMemcpyAsync(out + out_off[b0], c->inf_out.p + out_off[b0], (size_t)(out_off[b1] - out_off[b0]), hipMemcpyDeviceToHost, s));
         }

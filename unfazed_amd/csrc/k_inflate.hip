@@ -47,15 +47,20 @@ struct BitIn {
     int cbase;          // dword index held by lane 0 of `cur`
     uint32_t cur, nxt;  // lane l: w[cbase + l], w[cbase + 64 + l]
     int widx;           // next dword to take
+    int last_word;      // the last dword of the compressed buffer (its padding included): no load goes beyond it
     unsigned long long buf;
     int bits;
 };
+// a BGZF block is at most 64 KiB long, framing included: a decoder that has taken more dwords than that is not reading a block any more
+// (an endless run of empty stored blocks, say) and is stopped before it walks out of the buffer
+#define UZI_MAX_WORDS (65536 / 4 + 8)
 __device__ __forceinline__ uint32_t lane_word(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
-__device__ __forceinline__ void bi_open(BitIn &b, const uint8_t *base, long long byte_off, int lane) {
+__device__ __forceinline__ void bi_open(BitIn &b, const uint8_t *base, long long byte_off, long long buffer_words, int lane) {
     b.w = reinterpret_cast<const uint32_t *>(base) + (byte_off >> 2);
+    b.last_word = (int)(buffer_words - 1 - (byte_off >> 2) < 0x7FFFFFFF ? buffer_words - 1 - (byte_off >> 2) : 0x7FFFFFFF);
     b.cbase = 0;
-    b.cur = b.w[lane];
-    b.nxt = b.w[64 + lane];
+    b.cur = b.w[lane < b.last_word ? lane : b.last_word];
+    b.nxt = b.w[64 + lane < b.last_word ? 64 + lane : b.last_word];
     b.widx = 1;
     const int skip = (int)(byte_off & 3) * 8;
     b.buf = (unsigned long long)(lane_word(b.cur, 0) >> skip);
@@ -67,7 +72,8 @@ __device__ __forceinline__ void bi_refill(BitIn &b, int lane) { // afterwards: a
         if (k >= 64) {
             b.cur = b.nxt;
             b.cbase += 64;
-            b.nxt = b.w[b.cbase + 64 + lane];
+            const int at = b.cbase + 64 + lane;
+            b.nxt = b.w[at < b.last_word ? at : b.last_word];
             k -= 64;
         }
         b.buf |= (unsigned long long)lane_word(b.cur, k) << b.bits;
@@ -146,12 +152,14 @@ __device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb,
     return -1;
 }
 
-// err: 1 bad block type / stored length, 2 bad code lengths, 3 bad symbol, 4 output overrun or distance before the block, 5 wrong size
+// err: 1 bad block type / stored length, 2 bad code lengths, 3 bad symbol, 4 output overrun or distance before the block, 5 wrong size,
+// 6 the stream runs on past the longest possible BGZF block
 #ifndef UZI_WAVES_PER_EU
 #define UZI_WAVES_PER_EU 8 // (measured 6 / 8 waves per SIMD: 86 / 97 GB/s of output; the decoder state fits 64 registers)
 #endif
 __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n_blocks, const uint8_t *__restrict__ comp, const int64_t *__restrict__ in_off,
-                                                     const int64_t *__restrict__ out_off, uint8_t *out, int32_t *cursor, int32_t *err) {
+                                                     const int64_t *__restrict__ out_off, uint8_t *out, int64_t comp_words, int32_t *cursor,
+                                                     int32_t *err) {
     __shared__ InflateLds L;
     __shared__ int next_block;
     const int lane = threadIdx.x;
@@ -164,12 +172,13 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
         uint8_t *o = out + out_off[blk];
         const int64_t osize = out_off[blk + 1] - out_off[blk];
         BitIn b;
-        bi_open(b, comp, in_off[blk], lane);
+        bi_open(b, comp, in_off[blk], comp_words, lane);
         int64_t pos = 0, safe = 0; // bytes written; bytes whose stores are known to have landed
         int64_t wbase = 0;         // first position of the literal window (pos - wbase bytes wait in it)
         uint32_t wbyte = 0;
         int bad = 0;
         for (int last = 0; !last && !bad;) {
+            if (b.widx > UZI_MAX_WORDS) { bad = 6; break; }
             bi_refill(b, lane);
             last = (int)bi_take(b, 1);
             const int type = (int)bi_take(b, 2);
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
             // ---- the symbols of the block.  Literals gather in a register window -- lane l holds the byte for position wbase + l -- and
             // leave it as one coalesced store when it is full or a match needs them in memory.
             for (;;) {
+                if (b.widx > UZI_MAX_WORDS) { bad = 6; break; }
                 bi_refill(b, lane);
                 const int s = decode_sym(b, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt);
                 if (s < 256) {
@@ -296,8 +306,8 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
 } // namespace
 
 // comp / in_off / out_off / out: device memory (comp padded by 1 KiB past its last byte); out_off[n_blocks] = total bytes
-void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, const int64_t *in_off, const int64_t *out_off, uint8_t *out,
-                       int32_t *cursor_and_err /* [2], zeroed here */) {
+void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, int64_t comp_bytes_padded, const int64_t *in_off,
+                       const int64_t *out_off, uint8_t *out, int32_t *cursor_and_err /* [2], zeroed here */) {
     if (n_blocks <= 0) return;
     UZ_HIP(hipMemsetAsync(cursor_and_err, 0, 2 * sizeof(int32_t), st));
     static const int cus = [&] { // (asked once: the query is not cheap; one kind of device per process)
@@ -305,6 +315,6 @@ void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_
         return hipGetDeviceProperties(&prop, c->device) == hipSuccess ? prop.multiProcessorCount : 256;
     }();
     const int64_t grid = std::min<int64_t>(n_blocks, (int64_t)cus * 32); // every wave slot of the chip: a wave is one block's decoder
-    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)grid), dim3(64), 0, st, n_blocks, comp, in_off, out_off, out, cursor_and_err, cursor_and_err + 1);
+    hipLaunchKernelGGL(k_bgzf_inflate, dim3((unsigned)grid), dim3(64), 0, st, n_blocks, comp, in_off, out_off, out, comp_bytes_padded / 4, cursor_and_err, cursor_and_err + 1);
     UZ_HIP(hipGetLastError());
 }

@@ -350,8 +350,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                      int32_t *origin, int32_t *evidence, bool defer = false);
 bool uz_finish_phase(uz_ctx *c, int32_t *status, int32_t *counts, int32_t *origin, int32_t *evidence);
 // BGZF blocks inflated on the device (k_inflate.hip): device pointers; comp padded by 1 KiB; cursor_and_err: two int32 of device memory
-void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, const int64_t *in_off, const int64_t *out_off, uint8_t *out,
-                       int32_t *cursor_and_err);
+void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, int64_t comp_bytes_padded, const int64_t *in_off,
+                       const int64_t *out_off, uint8_t *out, int32_t *cursor_and_err);
 int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);
 int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q);
 void uz_phase_state_free(uz_ctx *c);
