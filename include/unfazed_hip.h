@@ -198,7 +198,10 @@ int uz_phase_cnv_sites(uz_ctx *ctx, int64_t *off /* [2n+1] */, int32_t *pos);
 
 /* ---- measurement ------------------------------------------------------ */
 /* HIP-event timing of the kernels launched on the context's stream since the
- * last reset: total milliseconds and launch count per UZ_K_* id. */
+ * last reset: total milliseconds and launch count per UZ_K_* id.
+ * on: 0 none, 1 every id, otherwise a set of ids -- (1 << (id + 1)) for each id
+ * wanted (two event records per timed launch are host work in front of the
+ * launch: a caller that times a whole pass keeps the set small). */
 int uz_prof_enable(uz_ctx *ctx, int on);
 int uz_prof_reset(uz_ctx *ctx);
 int uz_prof_get(uz_ctx *ctx, int kernel, double *total_ms, int64_t *launches);

@@ -233,7 +233,7 @@ void uz_block_put(uz_ctx *c, DevBlock b) {
 // ---------------------------------------------------------------- profiling
 void uz_prof_begin(uz_ctx *c, int kernel, hipEvent_t *a, hipEvent_t *b) {
     *a = *b = nullptr;
-    if (!c->prof_on) return;
+    if (!(c->prof_mask >> kernel & 1u)) return;
     for (hipEvent_t *e : {a, b}) {
         if (!c->event_pool.empty()) { *e = c->event_pool.back(); c->event_pool.pop_back(); }
         else UZ_HIP(hipEventCreate(e));
@@ -1570,7 +1570,7 @@ int uz_phase_groups(uz_ctx *c, int64_t *grp_off, int32_t *grp_q) {
 }
 
 int uz_prof_enable(uz_ctx *c, int on) {
-    return guarded(c, [&] { c->prof_on = on != 0; });
+    return guarded(c, [&] { c->prof_mask = on == 0 ? 0u : on == 1 ? ~0u : (uint32_t)on >> 1; });
 }
 int uz_prof_reset(uz_ctx *c) {
     return guarded(c, [&] {

@@ -264,7 +264,7 @@ struct uz_ctx {
     void *phase_state = nullptr;
 
     // profiling
-    bool prof_on = false;
+    uint32_t prof_mask = 0; // bit k: kernel id k is timed (uz_prof_enable)
     ProfSlot prof[UZ_K_COUNT];
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> event_pool;

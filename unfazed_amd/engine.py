@@ -469,8 +469,10 @@ class HipEngine:
         return r
 
     # ---------------------------------------------------------- measurement
-    def prof_enable(self, on: bool = True):
-        self._ck(self.L.uz_prof_enable(self.h, 1 if on else 0), "uz_prof_enable")
+    def prof_enable(self, on=True):
+        """on: False / True, or the kernel ids (abi.K_*) to time -- an empty list is False"""
+        v = (1 if on else 0) if isinstance(on, (bool, int)) else sum(1 << (int(k) + 1) for k in set(on))
+        self._ck(self.L.uz_prof_enable(self.h, int(v)), "uz_prof_enable")
 
     def prof_reset(self):
         self._ck(self.L.uz_prof_reset(self.h), "uz_prof_reset")
