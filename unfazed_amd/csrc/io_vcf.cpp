@@ -478,7 +478,7 @@ void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n
             size_t at = 0;
             bool done = false;
             while (!done) {
-                while (!memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at)) {
+                while (inf.bytes.size() <= at || !memchr(inf.bytes.data() + at, '\n', inf.bytes.size() - at)) { // (nothing inflated yet: no pointer to hand to memchr)
                     const int64_t next = inf.block_at.empty() ? 0 : inf.next_coff;
                     if (!inflate_one(file, next, inf, z, cbuf, &file_bytes, &blocks)) { done = true; break; }
                 }
