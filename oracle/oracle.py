@@ -13,6 +13,8 @@ _LIB = None
 
 
 def build(force=False):
+    if os.environ.get("UZ_ORACLE_LIB"):  # a sanitizer build of the same source (scripts/sanitize_io.sh)
+        return os.environ["UZ_ORACLE_LIB"]
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "uz_oracle.c")
     hdr = os.path.join(_HERE, "..", "include", "uz_types.h")

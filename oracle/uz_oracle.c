@@ -791,7 +791,7 @@ int uzo_phase(const uz_params *P, const uz_sites_view *S, const uz_reads_view *R
                             uint32_t q = (uint32_t)Q.touched.v[t];
                             if (Q.grp[q] & (1 << hb)) iv_push(&grp_all, (int32_t)q);
                         }
-                        qsort(grp_all.v + s0, (size_t)(grp_all.n - s0), sizeof(int32_t), cmp_i32);
+                        if (grp_all.n > s0) qsort(grp_all.v + s0, (size_t)(grp_all.n - s0), sizeof(int32_t), cmp_i32); /* (an empty list may have no storage yet) */
                         if (hb == 0) res->grp_off[2 * d + 1] = grp_all.n;
                     }
                 }

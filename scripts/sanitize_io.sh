@@ -18,3 +18,8 @@ TESTS=${@:-tests/test_io_native.py tests/test_io_stage.py tests/test_pack_select
 LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 \
 UBSAN_OPTIONS=print_stacktrace=1 UZ_IO_LIB=$OUT/libunfazed_io_san.so python3 -m pytest $TESTS -x -q -s -m "not gpu" -p no:cacheprovider 2>&1 | tee $OUT/log.txt | grep -v "^    #" | tail -40
 echo "sanitizer findings:"; grep -c "runtime error\|ERROR: AddressSanitizer" $OUT/log.txt || true
+# the oracle (the checker every parity test trusts) the same way, on its golden vectors
+gcc -O1 -g -fPIC -std=c11 -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include -shared -o $OUT/liboracle_san.so $ROOT/oracle/uz_oracle.c -lm
+LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 \
+UBSAN_OPTIONS=print_stacktrace=1 UZ_ORACLE_LIB=$OUT/liboracle_san.so python3 -m pytest tests/test_oracle_golden.py -x -q -s -p no:cacheprovider 2>&1 | tee $OUT/log_oracle.txt | grep -v "^    #" | tail -5
+echo "sanitizer findings (oracle):"; grep -c "runtime error\|ERROR: AddressSanitizer" $OUT/log_oracle.txt || true
