@@ -88,6 +88,26 @@ def test_window_emit_matches_oracle(engine, mode):
     for a, b, name in zip(want, got, ("cand_off", "cand_idx", "cand_flags", "het_off", "het_idx")):
         assert np.array_equal(a, b), name
     assert want[0][-1] > 100 and want[3][-1] > 100
+    # the fill pass first runs on the room the lists already have (no host wait for the totals in front of it): the same batch again
+    # -- now the room is there --, with a room that holds only some of the DNMs' slices (test hook: the second fill must repair it),
+    # and a smaller batch behind a larger one (stale entries beyond its totals must not leak)
+    import os
+    engine.drop_derived()
+    again = engine.find(fid, dv, P, mode)
+    os.environ["UZ_TEST_FIND_CAP"] = str(int(want[3][-1]) // 3)
+    try:
+        engine.drop_derived()
+        short = engine.find(fid, dv, P, mode)
+    finally:
+        del os.environ["UZ_TEST_FIND_CAP"]
+    m = n // 2
+    dv2 = abi.dnms_view(contig[:m], [-1] * m, start[:m], end[:m], vt[:m], [b""] * m, [b""] * m, 0.0, mult=mult[:m])
+    want2 = orc.find(P, sh, fh, dv2, mode)
+    half = engine.find(fid, dv2, P, mode)
+    for name, a, b, c2, w2, h2 in zip(("cand_off", "cand_idx", "cand_flags", "het_off", "het_idx"), want, again, short, want2, half):
+        assert np.array_equal(a, b), name + " (second run)"
+        assert np.array_equal(a, c2), name + " (room too small)"
+        assert np.array_equal(w2, h2), name + " (smaller batch)"
     engine.free_sites(sid)
 
 

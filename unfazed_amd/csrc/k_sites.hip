@@ -333,6 +333,7 @@ struct WinArgs {
     int64_t sd;
     int mode;
     int64_t *range; // [4n] site index range of each of a DNM's (up to two) windows: found by the count pass, reused by the fill pass
+    int64_t cap_c, cap_h; // fill pass: what the candidate / het lists hold -- a DNM whose slice ends beyond it writes nothing (uz_launch_find's first try)
 };
 
 // One lane walks the sites of one DNM in the reference's order: by position, window-1 copy before
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) void k_window_wave(WinArgs a, int32_t *cnt_c, 
     const int32_t d = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (d >= a.n) return;
+    if (FILL && (off_c[d + 1] > a.cap_c || off_h[d + 1] > a.cap_h)) return;
     int64_t nc = 0, nh = 0;
     const int32_t c = a.contig[d];
     const uint8_t *__restrict__ cls = a.fam_idx ? a.cls_of[a.fam_idx[d]] : a.cls;
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(256) void k_window_region(WinArgs a, int32_t *cnt_c
     const int32_t d = (int32_t)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (d >= a.n) return;
+    if (FILL && (off_c[d + 1] > a.cap_c || off_h[d + 1] > a.cap_h)) return;
     int64_t nc = 0, nh = 0;
     const int32_t c = a.contig[d];
     const uint8_t *__restrict__ cls = a.fam_idx ? a.cls_of[a.fam_idx[d]] : a.cls;
@@ -843,6 +846,28 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
                                c->het_off.p);
             UZ_HIP(hipGetLastError());
         }
+        auto fill = [&](int64_t cap_c, int64_t cap_h) {
+            a.cap_c = cap_c; a.cap_h = cap_h;
+            ProfScope ps(c, UZ_K_WINDOW_FILL);
+            if (mode & UZ_FIND_WHOLE_REGION)
+                hipLaunchKernelGGL(k_window_region<true>, dim3(nbw), dim3(256), 0, c->stream, a, (int32_t *)nullptr, (int32_t *)nullptr,
+                                   (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p, c->cand_idx.p, c->cand_flags.p,
+                                   c->het_idx.p);
+            else
+                hipLaunchKernelGGL(k_window_wave<true>, dim3(nbw), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
+                                   (int32_t *)nullptr, (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p,
+                                   c->cand_idx.p, c->cand_flags.p, c->het_idx.p);
+            UZ_HIP(hipGetLastError());
+        };
+        // The lists are sized by the totals, and the totals are on the device: waiting for them in front of the fill pass is a host
+        // round trip with an idle device (two per chunk of a staged pass, one more in the allele-balance stage).  So the fill pass
+        // first runs on the lists AS THEY ARE -- a set of lists keeps the room of the batches it held before -- with the room as a
+        // bound (a DNM whose slice would end beyond it writes nothing), the totals come back behind it, and only a batch that
+        // outgrew the room is filled again after the lists have grown.  (UZ_TEST_FIND_CAP: test hook, a room too small.)
+        int64_t room_c = (int64_t)std::min(c->cand_idx.cap, c->cand_flags.cap) - 1, room_h = (int64_t)c->het_idx.cap - 1;
+        if (const char *e = getenv("UZ_TEST_FIND_CAP")) { room_c = std::min<int64_t>(room_c, atoll(e)); room_h = std::min<int64_t>(room_h, atoll(e)); }
+        const bool tried = room_c > 0 && room_h > 0;
+        if (tried) fill(room_c, room_h);
         if (host_offsets) {
             UZ_HIP(hipMemcpyAsync(c->cand_off_h.data(), c->cand_off.p, ((size_t)n + 1) * sizeof(int64_t),
                                   hipMemcpyDeviceToHost, c->stream));
@@ -859,20 +884,11 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         }
         c->n_cand = c->cand_off_h[n];
         c->n_het = c->het_off_h[n];
-        c->cand_idx.ensure((size_t)c->n_cand + 1);
-        c->cand_flags.ensure((size_t)c->n_cand + 1);
-        c->het_idx.ensure((size_t)c->n_het + 1);
-        {
-            ProfScope ps(c, UZ_K_WINDOW_FILL);
-            if (mode & UZ_FIND_WHOLE_REGION)
-                hipLaunchKernelGGL(k_window_region<true>, dim3(nbw), dim3(256), 0, c->stream, a, (int32_t *)nullptr, (int32_t *)nullptr,
-                                   (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p, c->cand_idx.p, c->cand_flags.p,
-                                   c->het_idx.p);
-            else
-                hipLaunchKernelGGL(k_window_wave<true>, dim3(nbw), dim3(256), 0, c->stream, a, (int32_t *)nullptr,
-                                   (int32_t *)nullptr, (const int64_t *)c->cand_off.p, (const int64_t *)c->het_off.p,
-                                   c->cand_idx.p, c->cand_flags.p, c->het_idx.p);
-            UZ_HIP(hipGetLastError());
+        if (!tried || c->n_cand > room_c || c->n_het > room_h) {
+            c->cand_idx.ensure((size_t)c->n_cand + 1);
+            c->cand_flags.ensure((size_t)c->n_cand + 1);
+            c->het_idx.ensure((size_t)c->n_het + 1);
+            fill(INT64_MAX, INT64_MAX);
         }
     }
     c->find_valid = true;
