@@ -137,9 +137,13 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 // ---- record headers from the staged columns -------------------------------------------------------------
 // cigar_off / sq_off are the exclusive prefix sums of n_cigar / UZ_ROW_UNITS(l_seq) over the records: block
 // sums, one scan of the block sums, then the pack kernel scans inside its block and writes the headers.
-#ifndef UZ_PK_SPAN
-#define UZ_PK_SPAN 4096
-#endif
+// A span of records is one workgroup's share of the two passes below.  4096 for a table that fills the chip with such spans (a chunk
+// of the 100 k-DNM pass: 23 M records, 5.6 k spans; 1024 / 2048 measured slower there: more sums to scan), 1024 for a smaller one --
+// the 5 M records of a config-5 chunk are 1.2 k spans of 4096, five 256-lane workgroups per CU, and the pack pass ran at a third of
+// its rate per record.
+#define UZ_PK_SHIFT_LARGE 12
+#define UZ_PK_SHIFT_SMALL 10
+static inline int uz_pk_shift(int64_t n) { return (n >> UZ_PK_SHIFT_LARGE) >= 4096 ? UZ_PK_SHIFT_LARGE : UZ_PK_SHIFT_SMALL; }
 // four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
 // low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
 // ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none); sixth and seventh, the
@@ -179,20 +183,20 @@ __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
     return r;
 }
 // the escape list of the 16-bit difference columns: value of (record, column).  The list is sorted by record, and esc_off (one entry
-// per UZ_PK_SPAN records, k_esc_block_off) bounds the search to the handful of entries of the record's own span: a lane that meets
+// per span of records, k_esc_block_off) bounds the search to the handful of entries of the record's own span: a lane that meets
 // an escape costs its wave two or three loads instead of a binary search over the whole list
 __device__ __forceinline__ int32_t esc16_of(const RecColumns &c, int64_t i, int col) {
     const unsigned long long key = ((unsigned long long)i << 2) | (unsigned long long)col;
     int64_t lo = 0, hi = c.n_esc16;
-    if (c.esc_off) { lo = c.esc_off[i / UZ_PK_SPAN]; hi = c.esc_off[i / UZ_PK_SPAN + 1]; }
+    if (c.esc_off) { lo = c.esc_off[i >> c.pk_shift]; hi = c.esc_off[(i >> c.pk_shift) + 1]; }
     while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (c.esc16_key[mid] < key) lo = mid + 1; else hi = mid; }
     return (lo < c.n_esc16 && c.esc16_key[lo] == key) ? c.esc16_val[lo] : 0; // (a missing entry is caught by the totals / the mate check)
 }
-// first escape entry of every span of UZ_PK_SPAN records (and the end of the list)
-__global__ __launch_bounds__(256) void k_esc_block_off(int64_t nb, const unsigned long long *__restrict__ key, int64_t n_esc, int64_t *off) {
+// first escape entry of every span of records (and the end of the list)
+__global__ __launch_bounds__(256) void k_esc_block_off(int64_t nb, int pk_shift, const unsigned long long *__restrict__ key, int64_t n_esc, int64_t *off) {
     const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (b > nb) return;
-    const unsigned long long want = (unsigned long long)(b * UZ_PK_SPAN) << 2;
+    const unsigned long long want = (unsigned long long)(b << pk_shift) << 2;
     int64_t lo = 0, hi = n_esc;
     while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (key[mid] < want) lo = mid + 1; else hi = mid; }
     off[b] = lo;
@@ -228,15 +232,16 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
     // four records per lane at a time: their column bytes are requested together, then their dictionary entries, then the sums --
     // three round trips to memory for four records instead of three for each
     constexpr int U = 4;
-    static_assert((UZ_PK_SPAN / 256) % U == 0, "UZ_PK_SPAN is a multiple of 1024");
-    for (int it = 0; it < UZ_PK_SPAN / 256; it += U) {
+    static_assert(((1 << UZ_PK_SHIFT_SMALL) / 256) % U == 0, "a span is a multiple of 1024 records");
+    const int rounds = (1 << c.pk_shift) / 256;
+    for (int it = 0; it < rounds; it += U) {
         int64_t idx[U];
         bool in[U];
         RecSmall r[U];
         uint32_t sd[U], pd[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            idx[u] = (int64_t)blockIdx.x * UZ_PK_SPAN + (it + u) * 256 + t;
+            idx[u] = ((int64_t)blockIdx.x << c.pk_shift) + (it + u) * 256 + t;
             in[u] = idx[u] < n;
             if (!in[u]) idx[u] = n - 1; // (n > 0: the kernel is not launched on an empty table)
         }
@@ -323,14 +328,15 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
     // the round begins, instead of after a round trip of their own
     uint32_t tp_next = 0;
     {
-        const int64_t i0 = (int64_t)blockIdx.x * UZ_PK_SPAN + t;
+        const int64_t i0 = ((int64_t)blockIdx.x << c.pk_shift) + t;
         if (c.tup && i0 < n) tp_next = c.tup[i0];
     }
-    for (int it = 0; it < UZ_PK_SPAN / 256; it++) {
-        const int64_t i = (int64_t)blockIdx.x * UZ_PK_SPAN + it * 256 + t;
+    const int rounds = (1 << c.pk_shift) / 256;
+    for (int it = 0; it < rounds; it++) {
+        const int64_t i = ((int64_t)blockIdx.x << c.pk_shift) + it * 256 + t;
         const bool in = i < n;
         const uint32_t tp = tp_next;
-        if (c.tup && it + 1 < UZ_PK_SPAN / 256 && i + 256 < n) tp_next = c.tup[i + 256];
+        if (c.tup && it + 1 < rounds && i + 256 < n) tp_next = c.tup[i + 256];
         RecSmall rs = {0u, 0u, 0u, 0u, 0u, UZ_UMASK_ALL, c.lists ? 0 : -1};
         if (in) rs = c.tup ? rec_small_of(c, i, tp) : rec_small(c, i);
         const uint32_t nc = rs.nc, ls = rs.ls, ax = rs.aux;
@@ -640,17 +646,19 @@ __global__ __launch_bounds__(256) void k_patch_exc(int64_t n_exc, const uint32_t
 }
 } // namespace
 
-size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)((n + UZ_PK_SPAN - 1) / UZ_PK_SPAN + 2) * (UZ_PK_SUMS + 1) * sizeof(unsigned long long); }
+// (sized for the short spans whatever the table gets: 80 bytes per 1024 records)
+size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)(((n + (1 << UZ_PK_SHIFT_SMALL) - 1) >> UZ_PK_SHIFT_SMALL) + 2) * (UZ_PK_SUMS + 1) * sizeof(unsigned long long); }
 
 void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col_in, void *off_scratch) {
     static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
     if (r.n <= 0) return;
-    const unsigned nb = (unsigned)((r.n + UZ_PK_SPAN - 1) / UZ_PK_SPAN);
-    unsigned long long *sums = (unsigned long long *)off_scratch;
     RecColumns col = col_in;
+    col.pk_shift = uz_pk_shift(r.n);
+    const unsigned nb = (unsigned)((r.n + (1 << col.pk_shift) - 1) >> col.pk_shift);
+    unsigned long long *sums = (unsigned long long *)off_scratch;
     if (col.n_esc16 > 0) { // the escape list cut at the spans of the passes below
         int64_t *off = (int64_t *)(sums + (size_t)(nb + 1) * UZ_PK_SUMS);
-        hipLaunchKernelGGL(k_esc_block_off, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (int64_t)nb, col.esc16_key, col.n_esc16, off);
+        hipLaunchKernelGGL(k_esc_block_off, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (int64_t)nb, col.pk_shift, col.esc16_key, col.n_esc16, off);
         col.esc_off = off;
     }
     hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
