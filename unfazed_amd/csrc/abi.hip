@@ -165,6 +165,7 @@ void free_sites(uz_ctx *c, SitesDev &s) {
     s = SitesDev();
 }
 void free_reads(uz_ctx *c, ReadsDev &r) {
+    if (r.built) { (void)hipEventSynchronize(r.built); (void)hipEventDestroy(r.built); } // (a table freed before its first use: its build may still run)
     if (r.ready) (void)hipEventDestroy(r.ready);
     uz_block_put(c, r.block);
     uz_block_put(c, r.mirror);
@@ -393,6 +394,7 @@ void uz_destroy(uz_ctx *c) {
     for (auto &b : c->block_pool) (void)hipFree(b.p);
     if (c->hflags) (void)hipHostFree(c->hflags);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->build_stream) (void)hipStreamDestroy(c->build_stream);
     c->dn.block.release();
     if (c->dn_stage_done) (void)hipEventDestroy(c->dn_stage_done);
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
@@ -872,9 +874,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     uz_build_records(c, st, r, col, scratch);
 }
 
-void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
-    if (!r.pending) return;
-    UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0));
+// the header build of an asynchronously uploaded table, from the staged columns the upload left in its block
+static void build_staged(uz_ctx *c, hipStream_t st, ReadsDev &r) {
     RecColumns col;
     col.start = (const int32_t *)r.col_ptrs[0]; col.end = (const int32_t *)r.col_ptrs[1]; col.tlen = (const int32_t *)r.col_ptrs[2];
     col.mate = (const int32_t *)r.col_ptrs[3]; col.qname = (const uint32_t *)r.col_ptrs[4]; col.flag = (const uint16_t *)r.col_ptrs[5];
@@ -892,7 +893,15 @@ void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
     col.mate_d8 = (const int8_t *)r.col_d[7]; col.qname_d8 = (const int8_t *)r.col_d[8]; col.pair_d8 = (const uint8_t *)r.col_d[9];
     col.n_esc16 = r.col_nesc;
     col.qpos_wide = r.col_qwide;
-    uz_build_records(c, c->stream, r, col, r.build_scratch);
+    uz_build_records(c, st, r, col, r.build_scratch);
+}
+void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
+    if (!r.pending) return;
+    if (r.built) UZ_HIP(hipStreamWaitEvent(c->stream, r.built, 0)); // built beside whatever the compute stream was doing
+    else {
+        UZ_HIP(hipStreamWaitEvent(c->stream, r.ready, 0));
+        build_staged(c, c->stream, r);
+    }
     r.pending = false;
 }
 
@@ -973,7 +982,19 @@ int uz_reads_upload_packed(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             UZ_HIP(hipEventCreateWithFlags(&r.ready, hipEventDisableTiming));
             UZ_HIP(hipEventRecord(r.ready, c->copy_stream));
             r.pending = true;
-        } catch (...) { uz_block_put(c, r.block); uz_block_put(c, r.mirror); throw; }
+            static const bool lazy = getenv("UZ_BUILD_LAZY") != nullptr; // development aid: the header build at first use, on the compute stream
+            if (!lazy) {
+                if (!c->build_stream) UZ_HIP(hipStreamCreateWithFlags(&c->build_stream, hipStreamNonBlocking));
+                UZ_HIP(hipStreamWaitEvent(c->build_stream, r.ready, 0));
+                build_staged(c, c->build_stream, r);
+                UZ_HIP(hipEventCreateWithFlags(&r.built, hipEventDisableTiming));
+                UZ_HIP(hipEventRecord(r.built, c->build_stream));
+            }
+        } catch (...) {
+            if (r.built) { (void)hipEventSynchronize(r.built); (void)hipEventDestroy(r.built); }
+            if (r.ready) { (void)hipEventSynchronize(r.ready); (void)hipEventDestroy(r.ready); }
+            uz_block_put(c, r.block); uz_block_put(c, r.mirror); throw;
+        }
         const int k = new_slot(c->reads);
         c->reads[k] = r;
         *id = k;
@@ -1232,6 +1253,7 @@ int uz_reads_free(uz_ctx *c, int reads_id) {
         ReadsDev &r = reads_of(c, reads_id);
         // the block goes back to the pool: whatever still reads or fills it must have finished
         if (r.ready) UZ_HIP(hipEventSynchronize(r.ready));
+        if (r.built) UZ_HIP(hipEventSynchronize(r.built));
         UZ_HIP(hipStreamSynchronize(c->stream));
         // a merged cohort table built from this table (or the merged table itself) is forgotten with it
         const bool member = std::find(c->cohort_ids.begin(), c->cohort_ids.end(), reads_id) != c->cohort_ids.end();

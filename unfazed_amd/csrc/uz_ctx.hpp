@@ -146,9 +146,12 @@ struct ReadsDev {
     uint16_t *qs = nullptr;    // per-record QC word (phase_body.hpp: uz_qs_word), written by the header build
     int32_t *coarse = nullptr; // start of every 4096th record
     hipEvent_t ready = nullptr; // asynchronous uploads: recorded behind the last copy of the upload
-    bool pending = false;       // the copies may still be in flight, and the headers are not built yet
-    // the header build of an asynchronous upload runs on the COMPUTE stream at first use: kernels queued on the copy stream
-    // would wait behind the persistent per-DNM grid and hold up the next table's copies
+    bool pending = false;       // the copies may still be in flight and the headers not built yet: the first use waits (uz_reads_make_ready)
+    // The header build of an asynchronous upload is queued with the upload on a stream of its own (uz_ctx::build_stream), behind the
+    // copies' event: on the copy stream it would hold up the next table's copies, on the compute stream (where it ran at first use) it
+    // sat in the chain of every chunk's read stage.  `built` marks its end; null: no build queued yet, the first use runs it
+    // (UZ_BUILD_LAZY=1).
+    hipEvent_t built = nullptr;
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
     const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
@@ -194,7 +197,8 @@ struct ProfPending {
 struct uz_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // compute (and the synchronous uploads)
-    hipStream_t copy_stream = nullptr; // asynchronous uploads of packed tables: H2D + header build
+    hipStream_t copy_stream = nullptr; // asynchronous uploads of packed tables: the copies
+    hipStream_t build_stream = nullptr; // ... and their header builds (created at the first asynchronous upload)
     int32_t *hflags = nullptr;         // pinned, device-visible: [0] upload consistency error (totals / alphabet), [1] bases of a row-less
                                        // record requested; [4..7] two int64 mailboxes (list totals of the window emit)
     std::vector<DevBlock> block_pool;
