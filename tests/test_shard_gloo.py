@@ -129,7 +129,7 @@ def test_strong_split_two_ranks_equal_one_rank(tmp_path):
 
 def test_chunk_plan_of_the_eight_gpu_strong_split():
     """BASELINE configs[3]: 100 k DNMs over 8 GPUs = 12.5 k per rank; the staged pass of a shard that small runs THREE chunks (the
-    upload of the first and the read stage of the last are what nothing hides: measured 1 / 2 / 3 chunks = 3.69 / 3.54 / 3.35 ms),
+    upload of the first and the read stage of the last are what nothing hides: measured 2 / 3 / 4 chunks = 3.03 / 2.91 / 3.02 ms),
     the single-GPU pass eight"""
     from unfazed_amd import shard
     b = shard.shard_bounds(100000, 8)

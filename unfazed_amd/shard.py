@@ -19,7 +19,7 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.5, mi
     least ~min_per_chunk DNMs (every chunk costs a host round trip and ~40 kernel launches).  The last chunk is smaller (last_chunk x
     the others).
     chunks=None: from the shard size -- 100 k DNMs -> 8 chunks (measured at 7.3 KB per DNM: 5 / 6 / 8 / 10 / 12 chunks = 15.9 / 15.6 /
-    15.7 / 16.5 / 17.3 ms), a 12.5 k shard of an 8-GPU run -> 3 (1 / 2 / 3 chunks = 3.69 / 3.54 / 3.35 ms).  -> [0, ..., n]"""
+    15.7 / 16.5 / 17.3 ms), a 12.5 k shard of an 8-GPU run -> 3 (2 / 3 / 4 / 5 chunks = 3.03 / 2.91 / 3.02 / 3.19 ms; 100 k: 6 / 8 / 10 / 12 / 16 = 14.5 / 14.2 / 14.3 / 14.6 / 15.5 ms with the header build on its own stream).  -> [0, ..., n]"""
     if n <= 0:
         return [0, 0]
     k = int(chunks) if chunks else max(3, n // int(min_per_chunk))
