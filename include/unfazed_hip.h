@@ -79,11 +79,12 @@ int uz_sites_family_upload_async(uz_ctx *ctx, const uz_sites_view *sites, const 
  * device and the qualities are kept, so the table serves any --min-gt-qual.  Returns when the copy is done. */
 int uz_reads_upload(uz_ctx *ctx, const uz_reads_view *reads, int *reads_id);
 /* uz_reads_upload_packed: the staged form a decoder emits directly (4-bit bases, the quality-below-threshold
- * plane, no offset columns) -- 2.8x fewer bytes over the host link.  ASYNCHRONOUS: the copies and the header
- * build are queued on the context's copy stream and the call returns; the host buffers (pinned memory for full
- * link speed, uz_pinned_alloc) must stay untouched until uz_reads_wait or a uz_phase on the table has returned.
- * uz_phase on the table waits for the upload on the device, so the upload of the next table overlaps the
- * kernels of the current one. */
+ * plane, no offset columns) -- 2.8x fewer bytes over the host link.  ASYNCHRONOUS: the copies are queued on the
+ * context's copy stream, the header build behind them on a stream of its own (neither the next table's copies
+ * nor the kernels of the table before wait for it), and the call returns; the host buffers (pinned memory for
+ * full link speed, uz_pinned_alloc) must stay untouched until uz_reads_wait or a uz_phase on the table has
+ * returned.  uz_phase on the table waits for the build on the device, so the upload and the build of the next
+ * table overlap the kernels of the current one. */
 int uz_reads_upload_packed(uz_ctx *ctx, const uz_reads_packed_view *reads, int *reads_id);
 int uz_reads_wait(uz_ctx *ctx, int reads_id);
 /* what the device made of a table's fixed-width columns, whatever form they travelled in (plain, 16- / 8-bit differences, the pair
