@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--feed-dnms", type=int, default=int(os.environ.get("UZ_BENCH_FEED_DNMS", 20000)),
                     help="DNMs of the files -> results pass (`feed` / `value_e2e`): their pile-ups are written as a real BAM + BAI, the sites table as "
                          "a BGZF VCF + TBI, and decoded back through the indexes inside the timed region (0 = skip)")
-    ap.add_argument("--feed-chunk", type=int, default=2500, help="DNMs per chunk of the files -> results pass")
+    ap.add_argument("--feed-chunk", type=int, default=3400, help="DNMs per chunk of the files -> results pass (scripts/feed_sweep.sh, two boxes: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)")
     ap.add_argument("--feed-inflate", choices=("device", "host"), default="device",
                     help="feed pass: who inflates the BGZF blocks of the BAM -- the device (uz_bgzf_inflate_to_host) or the host's cores")
     ap.add_argument("--feed-level", type=int, default=6, help="deflate level of the files written for the feed pass (samtools / bgzip default: 6)")
