@@ -137,7 +137,7 @@ def test_chunk_plan_of_the_eight_gpu_strong_split():
     for r in range(8):
         cuts = shard.chunk_plan(b[r + 1] - b[r])
         assert cuts[0] == 0 and cuts[-1] == 12500 and len(cuts) == 4
-        assert cuts[1] - cuts[0] == cuts[2] - cuts[1] > cuts[3] - cuts[2]  # the last chunk is the small one: nothing hides its read stage
+        assert abs((cuts[1] - cuts[0]) - (cuts[2] - cuts[1])) <= 1 and cuts[2] - cuts[1] > cuts[3] - cuts[2]  # the last chunk is the small one: nothing hides its read stage
     one = shard.chunk_plan(100000)
     assert len(one) == 9 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))
     assert min(y - x for x, y in zip(one[:-1], one[1:-1])) >= 10000
