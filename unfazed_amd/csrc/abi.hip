@@ -11,6 +11,13 @@ bool uz_site_scan_fresh(const uz_ctx *c, const FamilyDev &f, bool need_cnv);
 
 namespace {
 
+// The message of a failed call.  uz_bgzf_inflate_to_host may run on a decoder's worker thread beside the owner's calls, so the
+// context's message is written under a lock, and uz_last_error hands out a copy that belongs to the calling thread.
+void set_error(uz_ctx *c, const std::string &msg) {
+    std::lock_guard<std::mutex> lk(c->err_mu);
+    c->err = msg;
+}
+
 template <typename F>
 int guarded(uz_ctx *c, F &&fn) {
     if (!c) return UZ_E_ARG;
@@ -19,13 +26,13 @@ int guarded(uz_ctx *c, F &&fn) {
         fn();
         return 0;
     } catch (const UzError &e) {
-        c->err = e.msg;
+        set_error(c, e.msg);
         return e.code;
     } catch (const std::exception &e) {
-        c->err = e.what();
+        set_error(c, e.what());
         return UZ_E_ARG;
     } catch (...) {
-        c->err = "unknown error";
+        set_error(c, "unknown error");
         return UZ_E_ARG;
     }
 }
@@ -416,7 +423,15 @@ void uz_destroy(uz_ctx *c) {
     delete c;
 }
 
-const char *uz_last_error(const uz_ctx *c) { return c ? c->err.c_str() : "null context"; }
+const char *uz_last_error(const uz_ctx *c) {
+    if (!c) return "null context";
+    static thread_local std::string mine; // valid until this thread's next uz_last_error
+    {
+        std::lock_guard<std::mutex> lk(const_cast<uz_ctx *>(c)->err_mu);
+        mine = c->err;
+    }
+    return mine.c_str();
+}
 
 int uz_sync(uz_ctx *c) {
     return guarded(c, [&] { UZ_HIP(hipStreamSynchronize(c->stream)); });

@@ -13,6 +13,7 @@
 #include <zlib.h>
 #include <dlfcn.h>
 #include <sched.h>
+#include <pthread.h>
 #include <unistd.h>
 #include <new>
 #include <atomic>
@@ -88,7 +89,17 @@ inline int workers_for(int64_t n, int threads, int64_t grain) {
 // job runs inline.  The pool follows the caller's CPU affinity: when that changes it is rebuilt.
 class ThreadPool {
   public:
-    static ThreadPool &get() { static ThreadPool p; return p; }
+    // One pool per process, on the heap and never destroyed: no join at exit (a destructor that ran in a forked child would join the
+    // PARENT's thread handles), and a forked child gets a fresh pool -- the atfork handler builds one over the inherited bytes, whose
+    // mutexes may have been copied in a locked state and whose workers do not exist on this side of the fork.
+    static ThreadPool &get() {
+        static ThreadPool *p = [] {
+            ThreadPool *q = new ThreadPool();
+            pthread_atfork(nullptr, nullptr, [] { new (&ThreadPool::get()) ThreadPool(); });
+            return q;
+        }();
+        return *p;
+    }
     // fn(worker) on `w` workers (the caller is worker 0); the first exception wins
     template <typename F>
     void run(int w, F &&fn) {
@@ -115,9 +126,9 @@ class ThreadPool {
         }
         for (auto &e : errs) if (e.code) throw e;
     }
-    ~ThreadPool() { shutdown(); }
 
   private:
+    ThreadPool() = default;
     static bool &in_job() { static thread_local bool f = false; return f; }
     void shutdown() {
         {
@@ -130,10 +141,6 @@ class ThreadPool {
         stop_ = false;
     }
     void ensure(int n) {
-        if (pid_ != getpid()) { // a forked child: the parent's workers do not exist here -- forget them (never join or destroy)
-            new (&th_) std::vector<std::thread>();
-            pid_ = getpid();
-        }
         cpu_set_t now;
         CPU_ZERO(&now);
         sched_getaffinity(0, sizeof(now), &now);
@@ -171,7 +178,6 @@ class ThreadPool {
     int gen_ = 0, want_ = 0, active_ = 0;
     bool stop_ = false;
     cpu_set_t mask_;
-    pid_t pid_ = getpid();
 };
 
 // fn(lo, hi, worker) over [0, n) cut into one contiguous slice per worker; the first exception wins

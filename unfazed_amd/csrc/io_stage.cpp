@@ -106,6 +106,7 @@ bool block_at(const uz_bamsrc &S, int64_t coff, BlockHdr &b) {
     bool found = false;
     while (q + 4 <= 12 + xlen) {
         const size_t slen = rd16(h + q + 2);
+        if (q + 4 + slen > 12 + xlen) fail(UZ_IO_E_FORMAT, "BGZF extra subfield overruns the extra field at byte %lld", (long long)coff);
         if (h[q] == 'B' && h[q + 1] == 'C' && slen == 2) { bsize = rd16(h + q + 4); found = true; }
         q += 4 + slen;
     }
@@ -156,7 +157,10 @@ struct Stream {
     void seek(uint64_t voff) {
         buf.clear(); blks.clear(); cur = 0; blk = 0; eof = false;
         next_coff = (int64_t)(voff >> 16);
-        if (!more()) return;
+        if (!more()) { // exactly the end of the file: an empty stream (next() says so); anywhere else the index does not belong to this file
+            if ((voff >> 16) != (uint64_t)S.size || (voff & 0xFFFF)) fail(UZ_IO_E_FORMAT, "virtual offset %llu points past the end of the file (a stale or truncated index?)", (unsigned long long)voff);
+            return;
+        }
         cur = (size_t)(voff & 0xFFFF);
         if (cur > blks[0].isize) fail(UZ_IO_E_FORMAT, "virtual offset beyond its block");
     }
@@ -177,6 +181,7 @@ struct Stream {
         }
         BlockHdr h;
         if (!block_at(S, next_coff, h)) { eof = true; return false; }
+        if (h.isize > 65536u) fail(UZ_IO_E_FORMAT, "BGZF block at byte %lld declares %u inflated bytes (a block holds at most 65536)", (long long)next_coff, h.isize);
         const size_t at = buf.size();
         buf.resize(at + h.isize);
         if (const PreBlk *pb = pre.find(next_coff)) { // inflated elsewhere: its bytes are copied in and held against the block's checksum
@@ -197,6 +202,7 @@ struct Stream {
     // the record at the cursor: false at the end of the file.  *voff: where it starts; p: its fixed part; bs: its block_size
     bool next(uint64_t &voff, const uint8_t *&p, uint32_t &bs) {
         for (;;) { // the cursor at the end of a block is the start of the next one
+            if (blks.empty()) { if (!more()) return false; continue; }
             while (blk + 1 < blks.size() && cur >= blks[blk].at + blks[blk].isize) blk++;
             if (cur < blks[blk].at + blks[blk].isize) break;
             if (!more()) return false;
@@ -576,7 +582,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
             const uint16_t fl = rd16(p + 14);
             const int32_t lseq = rdi32(p + 16);
             if (lseq < 0 || lseq > 0xFFFF) fail(UZ_IO_E_RANGE, "record too long for the 16-bit length columns (l_seq %d)", lseq);
-            if (32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
+            if (l_name < 1 || 32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block (or has no read name)");
             const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
             T.n_walked++;
             // between two reach intervals: nothing there can be fetched, and a mate position there is looked up through the index
@@ -885,7 +891,7 @@ void plan_finish(uz_stage &P) {
                         const uint16_t fl = rd16(p + 14);
                         const int32_t lseq = rdi32(p + 16);
                         if (lseq < 0 || lseq > 0xFFFF) fail(UZ_IO_E_RANGE, "record too long for the 16-bit length columns (l_seq %d)", lseq);
-                        if (32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block");
+                        if (l_name < 1 || 32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block (or has no read name)");
                         const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
                         T.n_walked++;
                         if (end > q.mpos) {

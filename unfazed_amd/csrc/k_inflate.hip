@@ -89,12 +89,13 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v)
 
 // canonical Huffman set-up from lens[0 .. n): counts, symbols in canonical order, the direct table for codes of <= tb bits.
 // false: an over-subscribed or (where it matters) incomplete set of lengths
-// (complete: a literal / length or code-length code must use its code space up; a distance code need not -- the fixed one does not,
-// and a block without matches has none -- an unused code then decodes to "no symbol")
+// (complete 2: a code-length code must use its code space up; 1: so must a literal / length code, unless it is ONE code of one bit -- zlib's
+// inftrees.c rule ("incomplete set ... max != 1"), which the host inflaters follow; 0: a distance code need not -- the fixed one does not,
+// and a block without matches has none.  An unused code then decodes to "no symbol")
 // The per-length counters live in LDS (work[48]): indexed by a code length, they would otherwise sit in scratch memory or pin 48 registers
 // (the kernel then needs 80 registers and runs 6 waves per SIMD at 86 GB/s instead of 8 at 97).
 __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int *work, int lane,
-                            bool complete) {
+                            int complete) {
     int *count = work, *offs = work + 16, *next = work + 32;
     __syncthreads();
     if (lane < 16) count[lane] = 0;
@@ -106,12 +107,13 @@ __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, u
         for (int l = 1; l < 15; l++) { offs[l + 1] = offs[l] + count[l]; next[l + 1] = (next[l] + count[l]) << 1; }
     }
     __syncthreads();
-    int left = 1;
+    int left = 1, total = 0;
     for (int l = 1; l < 16; l++) {
         left = (left << 1) - count[l];
+        total += count[l];
         if (left < 0) return false;
     }
-    if (left > 0 && complete) return false;
+    if (left > 0 && (complete == 2 || (complete == 1 && !(total == 1 && count[1] == 1)))) return false;
     if (lane < 16) cnt[lane] = (uint16_t)count[lane];
     if (lane == 0) {
         for (int s = 0; s < n; s++) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 }
                 __syncthreads();
                 // (the code-length code sits where the distance code will be: 7-bit direct table, canonical arrays)
-                if (!build_table(L.cl_lens, 19, L.dist_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, true)) { bad = 2; break; }
+                if (!build_table(L.cl_lens, 19, L.dist_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 2)) { bad = 2; break; }
                 int n = 0, prev = 0;
                 while (n < nlit + ndist) {
                     bi_refill(b, lane);
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 __syncthreads();
                 if (L.lens[256] == 0) { bad = 2; break; } // no end-of-block code
             }
-            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, true)) { bad = 2; break; }
-            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, false)) { bad = 2; break; }
+            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, 1)) { bad = 2; break; }
+            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 0)) { bad = 2; break; }
             // ---- the symbols of the block.  Literals gather in a register window -- lane l holds the byte for position wbase + l -- and
             // leave it as one coalesced store when it is full or a match needs them in memory.
             for (;;) {

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <memory>
 #include <vector>
@@ -204,6 +205,7 @@ struct uz_ctx {
     std::vector<DevBlock> block_pool;
     uz_params P;
     std::string err;
+    std::mutex err_mu; // (err is written by whichever thread's call failed: abi.hip set_error)
     std::vector<SitesDev> sites;
     std::vector<FamilyDev> fams;
     std::vector<ReadsDev> reads;

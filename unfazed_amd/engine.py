@@ -213,6 +213,7 @@ class HipEngine:
                         self.wait_reads(rid)
                     except UnfazedHipError:
                         pass
+                    self._staged.pop(rid, None)
                 raise
             finally:
                 pool.free_all()
@@ -226,6 +227,7 @@ class HipEngine:
         link form in pinned memory by one pass over the file's blocks (uz_bam_stage_*), uploaded as one table.
         -> (reads id, the staged view: `.qnames` maps the name ids of the result lists back to strings)"""
         pool = PinnedPool()
+        rid = None
         try:
             inflate = inflate_alloc = None
             if os.environ.get("UZ_INFLATE", "device") == "device":  # the batch's BGZF blocks inflated on the device (UZ_INFLATE=host: by the host's cores)
@@ -239,6 +241,14 @@ class HipEngine:
             rid = self.upload_reads_packed(packed)
             self.wait_reads(rid)  # the pinned buffers go back right away
             self._staged.pop(rid, None)
+        except BaseException:
+            if rid is not None:  # the copy may still be reading the pinned block: let it finish before the block goes back
+                try:
+                    self.wait_reads(rid)
+                except UnfazedHipError:
+                    pass
+                self._staged.pop(rid, None)
+            raise
         finally:
             pool.free_all()
         names = type("StagedNames", (), {})()
