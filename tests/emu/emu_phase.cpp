@@ -115,10 +115,8 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     caps.A = (int)mA; caps.T = (int)mT; caps.H = (int)mH; caps.C = (int)mC; caps.I = (int)(4 * mA);
     long long p2 = 1; while (p2 < mM) p2 <<= 1;
     caps.M = (int)p2;
-    Scr s;
-    const size_t bytes = uz_scratch_carve(nullptr, caps, s);
+    const size_t bytes = uz_scratch_layout(caps, a.so);
     std::vector<uint8_t> scratch(bytes + 256, 0xCD);
-    uz_scratch_carve(scratch.data(), caps, s);
     a.scratch = scratch.data(); a.scratch_per_wg = bytes; a.caps = caps;
     WgShared sh;
     // exercise both builds of the body: the HBM build alone, the arena build with a tiny arena (gives most DNMs up at one
@@ -128,8 +126,8 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     for (int d = 0; d < D->n; d++) {
         a.lds_arena_bytes = arena_sizes[d % 3];
         int given_up = 1;
-        if (a.lds_arena_bytes) given_up = uz_phase_dnm<true>(a, s, &sh, arena.data(), d);
-        if (given_up) uz_phase_dnm<false>(a, s, &sh, nullptr, d);
+        if (a.lds_arena_bytes) given_up = uz_phase_dnm<true>(&a, scratch.data(), &sh, arena.data(), d);
+        if (given_up) uz_phase_dnm<false>(&a, scratch.data(), &sh, nullptr, d);
     }
     *pool_used = (long long)cursor;
     if (base_err_out) *base_err_out = base_err;

@@ -51,22 +51,25 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
 // Two builds of the per-DNM body (phase_body.hpp): k_phase<true> keeps the working arrays of a DNM in its workgroup's LDS
 // arena and hands the DNMs that do not fit to k_phase<false>, launched right behind it, which keeps them in HBM scratch.
 template <bool LDS>
-__global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(PhaseArgs a) {
+__global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(PhaseArgs a_by_value) {
     __shared__ WgSharedT<LDS ? 1 : WG_SORT_LDS_CAP> sh;
     extern __shared__ __attribute__((aligned(16))) uint8_t uz_lds_arena[];
-    Scr s;
-    uz_scratch_carve(a.scratch + (size_t)blockIdx.x * a.scratch_per_wg, a.caps, s);
+    // the arguments are read where they lie, phase by phase (phase_body.hpp: uz_args_load); the by-value parameter only gives the kernarg
+    // segment its layout (PhaseArgs is the kernel's first and only explicit argument: offset 0)
+    (void)a_by_value;
+    const PhaseArgsK ap = (PhaseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+    uint8_t *const scr_base = uz_g(ap->scratch) + (size_t)blockIdx.x * ap->scratch_per_wg;
     if (!LDS) { // the list the first kernel left behind, one cursor
         for (;;) {
             __syncthreads();
             if (threadIdx.x == 0) {
-                const int k = atomicAdd(a.work_cursor + 16 * UZ_PHASE_PARTS, 1);
-                sh.bcast[0] = k < *a.retry_count ? a.retry_list[k] : -1;
+                const int k = atomicAdd(uz_g(ap->work_cursor) + 16 * UZ_PHASE_PARTS, 1);
+                sh.bcast[0] = k < *uz_g(ap->retry_count) ? uz_g(ap->retry_list)[k] : -1;
             }
             __syncthreads();
             const int d = sh.bcast[0];
             if (d < 0) break;
-            (void)uz_phase_dnm<false>(a, s, &sh, nullptr, d);
+            (void)uz_phase_dnm<false>(ap, scr_base, &sh, nullptr, d);
         }
         return;
     }
@@ -80,8 +83,9 @@ __global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(P
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int lo = (int)((long long)a.n * part / UZ_PHASE_PARTS), hi = (int)((long long)a.n * (part + 1) / UZ_PHASE_PARTS);
-            const int k = atomicAdd(a.work_cursor + 16 * part, 1); // cursors on separate cache lines
+            const int n = ap->n;
+            const int lo = (int)((long long)n * part / UZ_PHASE_PARTS), hi = (int)((long long)n * (part + 1) / UZ_PHASE_PARTS);
+            const int k = atomicAdd(uz_g(ap->work_cursor) + 16 * part, 1); // cursors on separate cache lines
             sh.bcast[0] = lo + k < hi ? lo + k : -1;
         }
         __syncthreads();
@@ -91,8 +95,8 @@ __global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(P
             part = (part + 1) % UZ_PHASE_PARTS;
             continue;
         }
-        if (uz_phase_dnm<LDS>(a, s, &sh, uz_lds_arena, d)) { // (block-uniform)
-            if (threadIdx.x == 0) a.retry_list[atomicAdd(a.retry_count, 1)] = d;
+        if (uz_phase_dnm<LDS>(ap, scr_base, &sh, uz_lds_arena, d)) { // (block-uniform)
+            if (threadIdx.x == 0) uz_g(ap->retry_list)[atomicAdd(uz_g(ap->retry_count), 1)] = d;
         }
     }
 }
@@ -929,8 +933,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         const Caps caps = z.caps;
         int arena_used = z.arena;
-        Scr dummy;
-        const size_t per_wg = uz_scratch_carve(nullptr, caps, dummy);
+        const size_t per_wg = uz_scratch_layout(caps, a.so);
         if (const char *e = getenv("UZ_TEST_PHASE_ARENA")) { // test hook: an arena (bytes) too small for most DNMs -> they take the HBM build of k_phase
             const int t = atoi(e);
             if (t >= 0 && t < arena_used) arena_used = t;

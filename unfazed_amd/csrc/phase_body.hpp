@@ -20,12 +20,14 @@
 #include "pack.hpp"
 #include "wg.hpp"
 
-// Diagnostic build only (-DUZ_PHASE_TIMING): lane 0 adds the shader-clock ticks spent between
-// phase boundaries into a.timing[k]; never compiled into the product library.
+// UZ_TICK(k) marks the boundary between two phases of the body: the arguments and scratch pointers of the next phase are read afresh there
+// (UZ_PHASE_ARGS, below).  Diagnostic build only (-DUZ_PHASE_TIMING): lane 0 also adds the shader-clock ticks spent since the last
+// boundary into a.timing[k]; never compiled into the product library.
 #if defined(UZ_PHASE_TIMING) && !defined(UZ_EMU)
 #define UZ_TICK(k)                                                                     \
     do {                                                                               \
         __syncthreads();                                                               \
+        UZ_PHASE_ARGS();                                                               \
         if (threadIdx.x == 0) {                                                        \
             const unsigned long long now__ = __builtin_amdgcn_s_memtime();             \
             atomicAdd(&a.timing[k], now__ - tick__);                                   \
@@ -34,7 +36,7 @@
     } while (0)
 #define UZ_TICK_INIT unsigned long long tick__ = __builtin_amdgcn_s_memtime()
 #else
-#define UZ_TICK(k) ((void)0)
+#define UZ_TICK(k) UZ_PHASE_ARGS()
 #define UZ_TICK_INIT ((void)0)
 #endif
 
@@ -130,6 +132,40 @@ struct Caps { // per-workgroup scratch capacities (elements)
 template <bool LDS> struct ScrTy { typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t flg; typedef unsigned long long skey; };
 template <> struct ScrTy<true> { typedef int16_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t flg; typedef uint32_t skey; };
 
+// The working arrays of one DNM, listed once: X(element type, name, capacity in elements).  cA .. cFR are the capacities of the scratch
+// layout (uz_scratch_layout); the element types hidx / pidx / xidx / flg / skey are those of the build (ScrTy).
+// ---- arrays the LDS build places in its arena (uz_scr_make points them at the arena before any request)
+#define UZ_SCR_ARENA(X)                                                                                                                   \
+    X(uint8_t, a_cls, cA) X(int32_t, a_flag0, cA) X(int32_t, a_flag1, cA) X(int32_t, LR, 2 * cA) X(int32_t, LA, 2 * cA)                    \
+    X(int32_t, hpos, cH) X(int32_t, hcanon, cH) X(int32_t, h_a, cH) X(int32_t, h_off, cH) X(int32_t, sr_off, cH) X(uint8_t, sr_exists, cH) \
+    X(uint8_t, href, cH) X(uint8_t, halt, cH) /* REF / ALT base of every het site of the DNM */                                            \
+    X(unsigned long long, site_best, cH) /* chaining: first frontier element finding an allele at a het index: (e << 12 | j) << 16 | allele << 8 | haplotype */ \
+    X(int32_t, cpos, cC) X(uint32_t, cvote, cC) X(uint8_t, cflag, cC) X(uint8_t, cref, cC) X(uint8_t, calt, cC) /* per candidate: UZ_CF_* flags, REF and ALT base */ \
+    X(flg, t_ov, cT) X(int32_t, t_pass, cT) X(int32_t, t_scan, cT) /* the two scans of phase B */                                          \
+    X(hidx, t_h, cT) /* het index of every fetched record before the ordered compaction of phase B */                                      \
+    X(hidx, reg_h, cT) X(pidx, reg_pair, cT) X(uint8_t, cbase, cT)                                                                          \
+    X(int32_t, i_seg, cI) X(pidx, i_pair, cI) X(uint8_t, i_hb, cI)                                                                          \
+    X(skey, keys, cM) X(int32_t, seq_h, cM) X(hidx, srt_h, cM) X(int32_t, srt_pid, cM) X(flg, srt_flag, cM)                                \
+    X(xidx, srt_seq, cM) /* sequence number of every sorted entry (the low bits of its key) */                                             \
+    X(uint8_t, srt_fb, cM) X(xidx, rs_off, cM) X(xidx, rs_len, cM) X(uint32_t, grp, cM) X(uint32_t, pvote, cM)                             \
+    X(unsigned long long, pkey, cM) /* per pair: smallest claim rank of the current chaining level */                                      \
+    X(unsigned long long, win, cM)  /* winners of a chaining level */                                                                      \
+    X(pidx, fr_pair0, cFR) X(pidx, fr_pair1, cFR)                                                                                          \
+    X(hidx, fr_pos0, cFR) X(hidx, fr_pos1, cFR) /* canonical het index of the site a frontier element was claimed at (-1: an init element) */ \
+    X(uint8_t, fr_hap0, cFR) X(uint8_t, fr_hap1, cFR)                                                                                      \
+    X(int32_t, misc, 8) /* [0] KeyError seen, [1] match_info count, [2] capacity exceeded */
+// ---- arrays that stay in the HBM scratch in both builds: written once and read once or twice
+#define UZ_SCR_HBM(X)                                                                                                                     \
+    X(int32_t, fet0, cM) X(int32_t, fet1, cM) /* the two records of every pair ("last writer wins", quirk Q11): read once per entry in D, once per item in F */ \
+    X(int32_t, reg_seg, cT)                                                                                                                \
+    X(uint32_t, reg_q, cT) X(uint32_t, t_q, cT) /* query-name id of every registration (and of every fetched record, before compaction) */ \
+    X(int32_t, reg_mate, cT) X(int32_t, t_mate, cT)                                                                                        \
+    X(uint32_t, i_q, cI) X(int32_t, i_mate, cI) X(int32_t, i_st, cI) X(int32_t, i_en, cI) /* per init element: name id, mate, span -- fetched once, when the list is built */ \
+    X(int32_t, i_qp, cI) X(int32_t, i_L, cI) X(int32_t, i_R, cI) X(int32_t, i_soff, cI)                                                    \
+    X(uint32_t, pq, cM)            /* name id of every pair (the optional lists) */                                                        \
+    X(unsigned long long, key, cM) /* second buffer of the counting sort (HBM build) */                                                    \
+    X(int32_t, q_cnt, 2 * cM + 1026) X(int32_t, q_fill, 2 * cM + 1026) /* counting sort of the pair-table keys over the query-name id range (HBM build) */
+
 template <bool LDS>
 struct ScrT {
     typedef typename ScrTy<LDS>::hidx hidx; // het index of the DNM (-1 = none)
@@ -140,91 +176,51 @@ struct ScrT {
     // close together (they are handed out in file order), so (id - smallest id of the DNM) and the sequence number share 32 bits -- a DNM
     // whose ids do not fit is given up to the HBM build
     typedef typename ScrTy<LDS>::skey skey;
-    // ---- arrays the LDS build places in the arena (uz_scr_make lists them once more)
-    uint8_t *a_cls;
-    int32_t *a_flag0, *a_flag1; // (no pointer arrays in this struct: a dynamically indexed member would pin it in private memory)
-    int32_t *LR, *LA;
-    int32_t *hpos, *hcanon, *h_a, *h_off, *sr_off;
-    uint8_t *sr_exists;
-    uint8_t *href, *halt; // REF / ALT base of every het site of the DNM
-    unsigned long long *site_best; // chaining: first frontier element finding an allele at a het index: (e << 12 | j) << 16 | allele << 8 | haplotype
-    int32_t *cpos;
-    uint32_t *cvote;
-    uint8_t *cflag, *cref, *calt; // per candidate: UZ_CF_* flags, REF and ALT base
-    flg *t_ov;
-    int32_t *t_pass, *t_scan; // the two scans of phase B
-    hidx *t_h;                // het index of every fetched record before the ordered compaction of phase B
-    hidx *reg_h;
-    pidx *reg_pair;
-    uint8_t *cbase;
-    int32_t *i_seg;
-    pidx *i_pair;
-    uint8_t *i_hb;
-    skey *keys;
-    int32_t *seq_h;
-    hidx *srt_h;
-    int32_t *srt_pid;
-    flg *srt_flag;
-    xidx *srt_seq; // sequence number of every sorted entry (the low 24 bits of its key)
-    uint8_t *srt_fb;
-    xidx *rs_off, *rs_len;
-    uint32_t *grp, *pvote;
-    unsigned long long *pkey; // per pair: smallest claim rank of the current chaining level
-    unsigned long long *win;  // winners of a chaining level
-    pidx *fr_pair0, *fr_pair1;
-    hidx *fr_pos0, *fr_pos1; // canonical het index of the site a frontier element was claimed at (-1: an init element)
-    uint8_t *fr_hap0, *fr_hap1;
-    int32_t *misc; // [0] KeyError seen, [1] match_info count, [2] capacity exceeded
-    // ---- arrays that stay in the HBM scratch in both builds: written once and read once or twice
-    int32_t *fet0, *fet1; // the two records of every pair ("last writer wins", quirk Q11): read once per entry in D, once per item in F
-    int32_t *reg_seg;
-    uint32_t *reg_q, *t_q; // query-name id of every registration (and of every fetched record, before compaction)
-    int32_t *reg_mate, *t_mate;
-    uint32_t *i_q;         // per init element: name id, mate, span -- fetched once, when the list is built
-    int32_t *i_mate, *i_st, *i_en;
-    int32_t *i_qp, *i_L, *i_R, *i_soff;
-    uint32_t *pq;             // name id of every pair (the optional lists)
-    unsigned long long *key;  // second buffer of the counting sort (HBM build)
-    int32_t *q_cnt, *q_fill;  // counting sort of the pair-table keys over the query-name id range (HBM build)
+    // (no pointer arrays in this struct: a dynamically indexed member would pin it in private memory)
+#define UZ_X(TY, NAME, CNT) TY *NAME;
+    UZ_SCR_ARENA(UZ_X)
+    UZ_SCR_HBM(UZ_X)
+#undef UZ_X
 };
-typedef ScrT<false> Scr; // the layout of the HBM scratch region
+typedef ScrT<false> Scr; // the layout of the HBM scratch region: every array at its place
 
-// carve the scratch region; with base == nullptr it only measures (returns bytes)
-template <typename T>
-UZ_HD void uz_carve(uint8_t *base, size_t &off, T *&p, size_t n) {
-    off = (off + 15) & ~(size_t)15;
-    p = reinterpret_cast<T *>(base + off);
-    off += n * sizeof(T);
+// Where every array starts inside a workgroup's scratch region (bytes).  The host works the layout out once per launch
+// (uz_scratch_layout) and hands it to the kernel with its arguments; the kernel adds an offset to its region's base at the phase that
+// uses the array -- a scalar load and a scalar add -- instead of carving ~75 pointers at its start and keeping them (two scalar registers
+// each) alive across the whole body: that, with the ~100 scalar registers of the arguments themselves, was 430 spilled scalar registers
+// and a third of the body's vector instructions moving them in and out of vector-register lanes (round 3's ISA).
+struct ScrOff {
+#define UZ_X(TY, NAME, CNT) unsigned long long NAME;
+    UZ_SCR_ARENA(UZ_X)
+    UZ_SCR_HBM(UZ_X)
+#undef UZ_X
+};
+// fills `o`, returns the bytes of one workgroup's region
+UZ_HD size_t uz_scratch_layout(const Caps &c, ScrOff &o) {
+    typedef Scr::hidx hidx; typedef Scr::pidx pidx; typedef Scr::xidx xidx; typedef Scr::flg flg; typedef Scr::skey skey;
+    const size_t cA = (size_t)c.A + 1, cT = (size_t)c.T + 1, cH = (size_t)c.H + 2, cC = (size_t)c.C + 1, cI = (size_t)c.I + 2, cM = (size_t)c.M + 2;
+    const size_t cFR = (cM > cI ? cM : cI) + 1;
+    size_t at = 0;
+#define UZ_X(TY, NAME, CNT) at = (at + 15) & ~(size_t)15; o.NAME = at; at += (size_t)(CNT) * sizeof(TY);
+    UZ_SCR_ARENA(UZ_X)
+    UZ_SCR_HBM(UZ_X)
+#undef UZ_X
+    return (at + 255) & ~(size_t)255;
 }
-UZ_HD size_t uz_scratch_carve(uint8_t *base, const Caps &c, Scr &s) {
-    size_t o = 0;
-    const size_t A = (size_t)c.A + 1, T = (size_t)c.T + 1, H = (size_t)c.H + 2, C = (size_t)c.C + 1, I = (size_t)c.I + 2, M = (size_t)c.M + 2;
-    const size_t FR = (M > I ? M : I) + 1;
-    uz_carve(base, o, s.a_cls, A);
-    uz_carve(base, o, s.a_flag0, A); uz_carve(base, o, s.a_flag1, A);
-    uz_carve(base, o, s.LR, 2 * A); uz_carve(base, o, s.LA, 2 * A);
-    uz_carve(base, o, s.hpos, H); uz_carve(base, o, s.hcanon, H); uz_carve(base, o, s.h_a, H);
-    uz_carve(base, o, s.h_off, H); uz_carve(base, o, s.sr_off, H); uz_carve(base, o, s.sr_exists, H);
-    uz_carve(base, o, s.href, H); uz_carve(base, o, s.halt, H); uz_carve(base, o, s.site_best, H);
-    uz_carve(base, o, s.cpos, C); uz_carve(base, o, s.cvote, C);
-    uz_carve(base, o, s.cflag, C); uz_carve(base, o, s.cref, C); uz_carve(base, o, s.calt, C);
-    uz_carve(base, o, s.t_ov, T); uz_carve(base, o, s.t_pass, T); uz_carve(base, o, s.t_scan, T); uz_carve(base, o, s.t_h, T);
-    uz_carve(base, o, s.reg_h, T); uz_carve(base, o, s.reg_seg, T); uz_carve(base, o, s.reg_pair, T); uz_carve(base, o, s.cbase, T);
-    uz_carve(base, o, s.reg_q, T); uz_carve(base, o, s.t_q, T); uz_carve(base, o, s.reg_mate, T); uz_carve(base, o, s.t_mate, T);
-    uz_carve(base, o, s.i_q, I); uz_carve(base, o, s.i_mate, I); uz_carve(base, o, s.i_st, I); uz_carve(base, o, s.i_en, I);
-    uz_carve(base, o, s.i_seg, I); uz_carve(base, o, s.i_qp, I); uz_carve(base, o, s.i_L, I); uz_carve(base, o, s.i_R, I);
-    uz_carve(base, o, s.i_soff, I); uz_carve(base, o, s.i_pair, I); uz_carve(base, o, s.i_hb, I);
-    uz_carve(base, o, s.keys, M); uz_carve(base, o, s.seq_h, M);
-    uz_carve(base, o, s.srt_h, M); uz_carve(base, o, s.srt_pid, M); uz_carve(base, o, s.srt_flag, M); uz_carve(base, o, s.srt_fb, M); uz_carve(base, o, s.srt_seq, M);
-    uz_carve(base, o, s.rs_off, M); uz_carve(base, o, s.rs_len, M); uz_carve(base, o, s.fet0, M); uz_carve(base, o, s.fet1, M);
-    uz_carve(base, o, s.grp, M); uz_carve(base, o, s.pvote, M); uz_carve(base, o, s.pq, M);
-    uz_carve(base, o, s.key, M);
-    uz_carve(base, o, s.pkey, M); uz_carve(base, o, s.win, M);
-    uz_carve(base, o, s.fr_pair0, FR); uz_carve(base, o, s.fr_pos0, FR); uz_carve(base, o, s.fr_hap0, FR);
-    uz_carve(base, o, s.fr_pair1, FR); uz_carve(base, o, s.fr_pos1, FR); uz_carve(base, o, s.fr_hap1, FR);
-    uz_carve(base, o, s.q_cnt, 2 * M + 1026); uz_carve(base, o, s.q_fill, 2 * M + 1026);
-    uz_carve(base, o, s.misc, 8);
-    return (o + 255) & ~(size_t)255;
+// the arrays that stay in the HBM scratch, from the layout and the region's base: called at every phase boundary of the body (the pointers
+// then live for a phase, not for the kernel)
+template <bool LDS>
+UZ_DEV void uz_scr_hbm(ScrT<LDS> &s, const ScrOff &o, uint8_t *base) {
+#define UZ_X(TY, NAME, CNT) s.NAME = reinterpret_cast<decltype(s.NAME)>(base + o.NAME);
+    UZ_SCR_HBM(UZ_X)
+#undef UZ_X
+}
+// HBM build: the other arrays too, once per DNM (the body swaps `keys` and `key` after its counting sort: they are not set again)
+UZ_DEV void uz_scr_all(Scr &s, const ScrOff &o, uint8_t *base) {
+#define UZ_X(TY, NAME, CNT) s.NAME = reinterpret_cast<decltype(s.NAME)>(base + o.NAME);
+    UZ_SCR_ARENA(UZ_X)
+    UZ_SCR_HBM(UZ_X)
+#undef UZ_X
 }
 
 // Per-DNM placement of the working arrays.  The scratch region in HBM has room for the largest DNM of the
@@ -301,6 +297,7 @@ struct PhaseArgs {
     uint8_t *scratch;
     unsigned long long scratch_per_wg;
     Caps caps;
+    ScrOff so; // where every working array starts inside a workgroup's scratch region (uz_scratch_layout)
     int32_t lds_arena_bytes;
     // fetch ranges found by the sizing pass (one lane per DNM, all DNMs in flight at once, so the
     // binary searches overlap instead of serialising inside the per-DNM workgroup)
@@ -628,36 +625,68 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i,
 }
 
 // ------------------------------------------------------------------ one DNM
-// The working arrays of one build.  HBM build: the scratch layout as it is.  LDS build: the arrays that stay in HBM keep
-// their scratch pointers; the arena arrays are pointed at the arena before any request, so that none of them ever holds
-// an HBM address in that build (the compiler then proves the address space of every access).
+// The arguments of the kernel, read where they are used.  A by-value kernel argument is loaded whole at the kernel's entry: PhaseArgs
+// is ~120 scalar registers of pointers and sizes, all alive across a 16 k-instruction body that has ~100 to give -- the compiler parked
+// them in vector-register lanes and fetched them back one v_readlane at a time (round 3: 430 spilled scalar registers, 2 150 v_readlane
+// among 8 138 vector instructions).  The body therefore takes the ADDRESS of the arguments in the kernarg segment (constant address
+// space: every read is a scalar load) and re-reads what a phase uses at the phase's start, through a copy of the address the compiler
+// cannot see through -- so nothing loaded for one phase stays alive into the next.  Pointers come back typed as global memory (a
+// pointer loaded from memory would otherwise be generic: flat_* instead of global_* accesses).
+#ifdef UZ_EMU
+typedef const PhaseArgs *PhaseArgsK;
+UZ_DEV void uz_args_load(PhaseArgs &a, PhaseArgsK &ap) { a = *ap; }
+#else
+typedef const __attribute__((address_space(4))) PhaseArgs *PhaseArgsK;
+template <typename T>
+UZ_DEV T *uz_g(T *p) { return (T *)(__attribute__((address_space(1))) T *)p; }
+UZ_DEV void uz_args_load(PhaseArgs &a, PhaseArgsK &ap) {
+    asm volatile("" : "+s"(ap)); // a fresh copy of the address: loads through it cannot be merged with (or hoisted above) earlier ones
+#define UZ_V(f) a.f = ap->f;
+#define UZ_P(f) a.f = uz_g(ap->f);
+    UZ_V(n) UZ_V(min_gt_qual) UZ_V(readlen) UZ_V(no_extended) UZ_V(read_goal) UZ_V(evidence_min_ratio) UZ_V(split_error_margin) UZ_V(cutoff)
+    UZ_P(cutoff_d) UZ_P(spos) UZ_P(sref) UZ_P(salt) UZ_P(cand_off) UZ_P(het_off) UZ_P(cand_idx) UZ_P(het_idx) UZ_P(cand_flags)
+    UZ_P(rcontig) UZ_P(dstart) UZ_P(dend) UZ_P(dflags) UZ_P(vartype) UZ_P(allele_off) UZ_P(alleles)
+    UZ_P(R.ra) UZ_P(R.rb) UZ_P(R.fm) UZ_P(R.contig_off) UZ_P(R.max_span) UZ_V(R.n_contigs) UZ_P(R.cigar) UZ_P(R.seq4) UZ_P(R.qlow) UZ_P(R.qoff)
+    UZ_P(R.nlow) UZ_P(R.umask) UZ_P(R.err) UZ_P(R.qs) UZ_V(R.min_map_qual) UZ_P(R.coarse)
+    UZ_P(status) UZ_P(counts) UZ_P(origin) UZ_P(evidence) UZ_V(want_lists) UZ_P(pool) UZ_V(pool_cap) UZ_P(pool_cursor) UZ_P(list_start) UZ_P(list_len)
+    UZ_P(work_cursor) UZ_P(retry_count) UZ_P(retry_list) UZ_P(scratch) UZ_V(scratch_per_wg)
+    UZ_V(caps.A) UZ_V(caps.T) UZ_V(caps.H) UZ_V(caps.C) UZ_V(caps.I) UZ_V(caps.M) UZ_V(lds_arena_bytes)
+    UZ_P(pre_win) UZ_P(pre_ha) UZ_P(pre_hl) UZ_P(timing)
+#define UZ_X(TY, NAME, CNT) UZ_V(so.NAME)
+    UZ_SCR_ARENA(UZ_X)
+    UZ_SCR_HBM(UZ_X)
+#undef UZ_X
+#undef UZ_V
+#undef UZ_P
+}
+#endif
+// a phase boundary of the body: the arguments and the HBM scratch pointers of the next phase are read afresh
+#define UZ_PHASE_ARGS() do { uz_args_load(a, ap); uz_scr_hbm<LDS>(s, a.so, scr_base); } while (0)
+
+// The working arrays of one build.  HBM build: every array at its place in the scratch region.  LDS build: the arrays that stay in HBM
+// come from the scratch layout (uz_scr_hbm, at every phase boundary); the arena arrays are pointed at the arena before any request, so
+// that none of them ever holds an HBM address in that build (the compiler then proves the address space of every access).
 template <bool LDS>
-UZ_DEV ScrT<LDS> uz_scr_make(const Scr &sg, uint8_t *b) {
-    if constexpr (!LDS) return sg;
+UZ_DEV ScrT<LDS> uz_scr_make(const ScrOff &o, uint8_t *scr_base, uint8_t *b) {
+    ScrT<LDS> s;
+    if constexpr (!LDS) uz_scr_all(s, o, scr_base);
     else {
-        ScrT<true> s;
-#define UZ_AT(f) s.f = reinterpret_cast<decltype(s.f)>(b)
-        UZ_AT(misc); UZ_AT(cpos); UZ_AT(cvote); UZ_AT(cflag); UZ_AT(cref); UZ_AT(calt);
-        UZ_AT(hpos); UZ_AT(hcanon); UZ_AT(h_a); UZ_AT(h_off); UZ_AT(sr_off); UZ_AT(sr_exists); UZ_AT(href); UZ_AT(halt); UZ_AT(site_best);
-        UZ_AT(i_seg); UZ_AT(i_hb); UZ_AT(i_pair); UZ_AT(a_cls); UZ_AT(a_flag0); UZ_AT(a_flag1); UZ_AT(LR); UZ_AT(LA);
-        UZ_AT(reg_h); UZ_AT(reg_pair); UZ_AT(cbase); UZ_AT(t_ov); UZ_AT(t_pass); UZ_AT(t_scan); UZ_AT(t_h); UZ_AT(seq_h);
-        UZ_AT(srt_h); UZ_AT(srt_fb); UZ_AT(keys); UZ_AT(srt_pid); UZ_AT(srt_flag); UZ_AT(srt_seq);
-        UZ_AT(pkey); UZ_AT(rs_off); UZ_AT(rs_len); UZ_AT(grp); UZ_AT(pvote);
-        UZ_AT(fr_pair0); UZ_AT(fr_hap0); UZ_AT(fr_pair1); UZ_AT(fr_hap1); UZ_AT(fr_pos0); UZ_AT(fr_pos1); UZ_AT(win);
-#undef UZ_AT
-#define UZ_CP(f) s.f = sg.f
-        UZ_CP(fet0); UZ_CP(fet1); UZ_CP(reg_seg); UZ_CP(reg_q); UZ_CP(t_q); UZ_CP(reg_mate); UZ_CP(t_mate); UZ_CP(i_q); UZ_CP(i_mate); UZ_CP(i_st); UZ_CP(i_en);
-        UZ_CP(i_qp); UZ_CP(i_L); UZ_CP(i_R); UZ_CP(i_soff); UZ_CP(pq); UZ_CP(key); UZ_CP(q_cnt); UZ_CP(q_fill);
-#undef UZ_CP
-        return s;
+#define UZ_X(TY, NAME, CNT) s.NAME = reinterpret_cast<decltype(s.NAME)>(b);
+        UZ_SCR_ARENA(UZ_X)
+#undef UZ_X
+        uz_scr_hbm<true>(s, o, scr_base);
     }
+    return s;
 }
 
 // returns 0 when the DNM is done (its status and results are written), 1 when the LDS build gives it up
+// ap: the kernel's arguments where they lie (device: the kernarg segment); scr_base: this workgroup's scratch region
 template <bool LDS, typename SH>
-UZ_DEV int uz_phase_dnm(const PhaseArgs &a, const Scr &sg, SH *sh, uint8_t *lds_arena, int d) {
+UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_arena, int d) {
+    PhaseArgs a;
+    uz_args_load(a, ap);
     const RD &R = a.R;
-    ScrT<LDS> s = uz_scr_make<LDS>(sg, lds_arena);
+    ScrT<LDS> s = uz_scr_make<LDS>(a.so, scr_base, lds_arena);
     Arena ar = {lds_arena, LDS ? a.lds_arena_bytes : 0, 0, LDS ? a.lds_arena_bytes : 0, 0};
     const long long c0 = a.cand_off[d], h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);

@@ -46,11 +46,103 @@ __device__ __forceinline__ int wg_lane_opaque() {
 }
 #define WG_FOR(i, n) for (int i = wg_lane_opaque(); i < (int)(n); i += WG_NT)
 #define WG_SYNC() __syncthreads()
-#define WG_T0 if (threadIdx.x == 0)
+#define WG_T0 if (wg_lane_opaque() == 0) // (opaque: the mask `lane 0` is made where it is used -- hoisted, it is one more pair of scalar registers kept for the whole kernel)
 UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 UZ_DEV int wg_atomic_add(int *p, int v) { return atomicAdd(p, v); }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+#endif
+
+#ifndef UZ_EMU
+// ---- cross-lane steps of a 64-lane wave without LDS traffic (gfx950) ------------------------------------------------------------
+// __shfl_up / __shfl_xor compile to ds_bpermute_b32: an LDS-pipe instruction, an address computation and -- for the scans -- a lane
+// predicate (`lane >= off`) per step, which the compiler computes once at the kernel's entry for every step of every inlined scan and
+// sort and then keeps: in round 3's k_phase that was ~100 lane masks (200 scalar registers) spilled before the first DNM was read.
+// DPP operands read another lane of the same 16-lane row inside the vector instruction itself (v_add_u32_dpp: one instruction per
+// scan step, lanes without a source add 0); rows are joined by row_bcast:15 / :31, and lanes 16 / 32 apart by the gfx950 lane swaps.
+#define WV_QUAD(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+#define WV_ROW_SL(n) (0x100 | (n)) // lane i reads lane i + n of its row
+#define WV_ROW_SR(n) (0x110 | (n)) // lane i reads lane i - n of its row
+#define WV_ROW_RR(n) (0x120 | (n)) // ... lane (i - n) mod 16
+#define WV_ROW_MIRROR 0x140        // lane i reads lane 15 - i of its row
+#define WV_ROW_HALF_MIRROR 0x141   // lane i reads lane 7 - i of its half row
+#define WV_ROW_BCAST15 0x142       // lane 15 of every row to the next row
+#define WV_ROW_BCAST31 0x143       // lane 31 to the upper half
+// lanes without a source (beyond the row, or masked out by row / bank mask) keep `old`
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+UZ_DEV uint32_t wv_dpp(uint32_t old, uint32_t src) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+// inclusive prefix sum over the 64 lanes: six vector instructions
+UZ_DEV uint32_t wv_incl_scan(uint32_t x) {
+    x += wv_dpp<WV_ROW_SR(1)>(0u, x);
+    x += wv_dpp<WV_ROW_SR(2)>(0u, x);
+    x += wv_dpp<WV_ROW_SR(4)>(0u, x);
+    x += wv_dpp<WV_ROW_SR(8)>(0u, x);
+    x += wv_dpp<WV_ROW_BCAST15, 0xa>(0u, x); // rows 1 and 3 take the total of rows 0 and 2
+    x += wv_dpp<WV_ROW_BCAST31, 0xc>(0u, x); // the upper half takes the total of the lower
+    return x;
+}
+UZ_DEV int wv_incl_scan(int x) { return (int)wv_incl_scan((uint32_t)x); }
+// the value of lane (i ^ J), J a power of two below 64
+template <int J>
+UZ_DEV uint32_t wv_xor(uint32_t x, int lane) {
+    if constexpr (J == 1) return wv_dpp<WV_QUAD(1, 0, 3, 2)>(x, x);
+    else if constexpr (J == 2) return wv_dpp<WV_QUAD(2, 3, 0, 1)>(x, x);
+    else if constexpr (J == 4) return wv_dpp<WV_ROW_SR(4), 0xf, 0xa>(wv_dpp<WV_ROW_SL(4), 0xf, 0x5>(x, x), x); // banks 0, 2 from the right, 1, 3 from the left
+    else if constexpr (J == 8) return wv_dpp<WV_ROW_RR(8)>(x, x);
+    else if constexpr (J == 16) { // v_permlane16_swap: the odd rows of the first operand change places with the even rows of the second
+        const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        return (lane & 16) ? p[0] : p[1];
+    } else {                      // v_permlane32_swap: the upper half of the first operand with the lower half of the second
+        static_assert(J == 32, "a power of two below 64");
+        const auto p = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        return (lane & 32) ? p[0] : p[1];
+    }
+}
+template <int J>
+UZ_DEV unsigned long long wv_xor(unsigned long long x, int lane) {
+    return ((unsigned long long)wv_xor<J>((uint32_t)(x >> 32), lane) << 32) | (unsigned long long)wv_xor<J>((uint32_t)x, lane);
+}
+// smaller and larger of a lane's value and that of lane (i ^ J): for 32-bit values and J = 16 / 32 both fall out of the swap itself
+template <int J>
+UZ_DEV void wv_minmax_xor(uint32_t x, int lane, uint32_t &mn, uint32_t &mx) {
+    if constexpr (J == 16) {
+        const auto p = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        mn = p[0] < p[1] ? p[0] : p[1]; mx = p[0] < p[1] ? p[1] : p[0];
+    } else if constexpr (J == 32) {
+        const auto p = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        mn = p[0] < p[1] ? p[0] : p[1]; mx = p[0] < p[1] ? p[1] : p[0];
+    } else {
+        const uint32_t y = wv_xor<J>(x, lane);
+        mn = x < y ? x : y; mx = x < y ? y : x;
+    }
+}
+template <int J>
+UZ_DEV void wv_minmax_xor(unsigned long long x, int lane, unsigned long long &mn, unsigned long long &mx) {
+    const unsigned long long y = wv_xor<J>(x, lane);
+    mn = x < y ? x : y; mx = x < y ? y : x;
+}
+// minimum and maximum over the 64 lanes, in every lane (uniform: the last step reads the four row results with v_readlane)
+UZ_DEV void wv_allminmax(int &mn, int &mx) {
+    uint32_t a = (uint32_t)mn, b = (uint32_t)mx;
+#define WV_STEP(CTRL)                                                           \
+    {                                                                           \
+        const int a2 = (int)wv_dpp<CTRL>(a, a), b2 = (int)wv_dpp<CTRL>(b, b);   \
+        a = (uint32_t)(a2 < (int)a ? a2 : (int)a);                              \
+        b = (uint32_t)(b2 > (int)b ? b2 : (int)b);                              \
+    }
+    WV_STEP(WV_QUAD(1, 0, 3, 2)) WV_STEP(WV_QUAD(2, 3, 0, 1)) WV_STEP(WV_ROW_HALF_MIRROR) WV_STEP(WV_ROW_MIRROR)
+#undef WV_STEP
+    int lo = __builtin_amdgcn_readlane((int)a, 0), hi = __builtin_amdgcn_readlane((int)b, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const int a2 = __builtin_amdgcn_readlane((int)a, r), b2 = __builtin_amdgcn_readlane((int)b, r);
+        lo = a2 < lo ? a2 : lo;
+        hi = b2 > hi ? b2 : hi;
+    }
+    mn = lo; mx = hi;
+}
 #endif
 
 #ifndef WG_SORT_LDS_CAP
@@ -78,20 +170,14 @@ UZ_DEV int wg_exscan(int *a, int n, SH *sh) {
     return s;
 #else
     __syncthreads();
-    const int t = threadIdx.x;
+    const int t = wg_lane_opaque();
     const int chunk = (n + WG_NT - 1) / WG_NT;
     int lo = t * chunk; if (lo > n) lo = n;
     int hi = lo + chunk; if (hi > n) hi = n;
     int s = 0;
     for (int i = lo; i < hi; i++) s += a[i];
-    int incl = s;
-    const int lane = t & 63;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) sh->part[t >> 6] = incl;
+    const int incl = wv_incl_scan(s);
+    if ((t & 63) == 63) sh->part[t >> 6] = incl;
     __syncthreads();
     int wave_prefix = 0, total = 0;
 #pragma unroll
@@ -126,18 +212,10 @@ UZ_DEV void wg_lane_exscan(const int (&c)[K], int (&off)[K], int (&tot)[K], SH *
     for (int k = 0; k < K; k++) { off[k] = 0; tot[k] = c[k]; }
 #else
     static_assert(K * (WG_NT / 64) <= WG_NT + 1, "part[] too small");
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = wg_lane_opaque(), lane = t & 63, wv = t >> 6;
     int incl[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        int v = c[k];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(v, o, 64);
-            if (lane >= o) v += u;
-        }
-        incl[k] = v;
-    }
+    for (int k = 0; k < K; k++) incl[k] = wv_incl_scan(c[k]);
     __syncthreads(); // part[] may still be read by a previous scan
     if (lane == 63) {
 #pragma unroll
@@ -165,13 +243,8 @@ UZ_DEV void wg_minmax(int lmin, int lmax, int &mn, int &mx, SH *sh) {
 #ifdef UZ_EMU
     mn = lmin; mx = lmax;
 #else
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int a = __shfl_xor(lmin, o, 64), b = __shfl_xor(lmax, o, 64);
-        lmin = a < lmin ? a : lmin;
-        lmax = b > lmax ? b : lmax;
-    }
+    const int t = wg_lane_opaque(), lane = t & 63, wv = t >> 6;
+    wv_allminmax(lmin, lmax);
     __syncthreads();
     if (lane == 0) { sh->part[wv] = lmin; sh->part[WG_NT / 64 + wv] = lmax; }
     __syncthreads();
@@ -209,24 +282,44 @@ UZ_DEV void wg_bitonic_stages(P w, int N) {
 #endif
 #ifndef UZ_EMU
 // Bitonic sort with the keys held in registers: lane t owns elements t + WG_NT * r.  Partners at
-// distance >= WG_NT are other registers of the same lane, partners at distance < 64 are reached by a
-// wave shuffle; only the distances in between (64 and 128 for a 256-lane workgroup) go through LDS and a
-// barrier.  buf: LDS, N entries.  N = R * WG_NT.
+// distance >= WG_NT are other registers of the same lane; partners at distance < 64 are other lanes of the wave, reached by DPP
+// operands (1, 2, 4, 8) and the gfx950 lane swaps (16, 32) -- no LDS traffic; only the distances in between (64 and 128 for a 256-lane
+// workgroup) go through LDS and a barrier.  buf: LDS, N entries.  N = R * WG_NT.
+// The loop over the merge sizes k is NOT unrolled and re-reads the lane index through an opaque move: unrolled, every one of the 45
+// stages of a 1024-key sort owns a pair of lane masks ("lower half of the exchange", "ascending block") that the compiler computes at the
+// kernel's entry and keeps -- for three inlined sorts that was ~100 masks in 200 spilled scalar registers, fetched back with
+// v_readlane in front of every exchange.  Rolled, a merge's masks are made where they are used (two instructions) and the body is a
+// sixth of the code.
+template <int J, int R, typename T>
+UZ_DEV void wg_bitonic_wave_stage(T (&v)[R], const int (&kdesc)[R], int t) {
+    const bool lower = (t & J) == 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        T mn, mx;
+        wv_minmax_xor<J>(v[r], t, mn, mx);
+        v[r] = (lower == (kdesc[r] == 0)) ? mn : mx;
+    }
+}
 template <int R, typename T = unsigned long long>
 UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) T *buf, T *a, int n) {
-    const int t = threadIdx.x;
+    int t = threadIdx.x;
     T v[R];
 #pragma unroll
     for (int r = 0; r < R; r++) { const int i = t + WG_NT * r; v[r] = i < n ? a[i] : (T) ~(T)0; }
-    const int N = R * WG_NT;
+    constexpr int N = R * WG_NT;
+#pragma nounroll
     for (int k = 2; k <= N; k <<= 1) {
+        asm volatile("" : "+v"(t)); // (see above)
+        int kdesc[R]; // element r lies in a descending block of this merge
+#pragma unroll
+        for (int r = 0; r < R; r++) kdesc[r] = (t + WG_NT * r) & k;
 #pragma unroll
         for (int rr = R / 2; rr >= 1; rr >>= 1) {
             if (rr * WG_NT < k) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     if (!(r & rr)) {
-                        const bool up = ((t + WG_NT * r) & k) == 0;
+                        const bool up = kdesc[r] == 0;
                         const T x = v[r], y = v[r | rr];
                         if ((x > y) == up) { v[r] = y; v[r | rr] = x; }
                     }
@@ -241,20 +334,17 @@ UZ_DEV void wg_bitonic_regs(__attribute__((address_space(3))) T *buf, T *a, int 
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const T y = buf[(t ^ j) + WG_NT * r];
-                const bool up = ((t + WG_NT * r) & k) == 0, lower = (t & j) == 0;
+                const bool up = kdesc[r] == 0, lower = (t & j) == 0;
                 const T x = v[r];
                 v[r] = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
             }
         }
-        for (int j = (k >> 1) < 32 ? (k >> 1) : 32; j >= 1; j >>= 1) {
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const T x = v[r];
-                const T y = __shfl_xor(x, j, 64);
-                const bool up = ((t + WG_NT * r) & k) == 0, lower = (t & j) == 0;
-                v[r] = (lower == up) ? (x < y ? x : y) : (x > y ? x : y);
-            }
-        }
+        if (k > 32) wg_bitonic_wave_stage<32, R, T>(v, kdesc, t);
+        if (k > 16) wg_bitonic_wave_stage<16, R, T>(v, kdesc, t);
+        if (k > 8) wg_bitonic_wave_stage<8, R, T>(v, kdesc, t);
+        if (k > 4) wg_bitonic_wave_stage<4, R, T>(v, kdesc, t);
+        if (k > 2) wg_bitonic_wave_stage<2, R, T>(v, kdesc, t);
+        wg_bitonic_wave_stage<1, R, T>(v, kdesc, t);
     }
     __syncthreads();
 #pragma unroll
