@@ -22,7 +22,7 @@ phases its own N DNMs; `--scaling strong` (config 4): the SAME N DNMs cut into c
 `python bench.py --gpus N` without a launcher starts the N ranks itself.
 
 Extra objects on the JSON line: `roofline` for the K1 site-scan kernel (HBM-bound; algorithmic bytes = 20 B/site),
-`roofline_k3a` for the QC pass, `link` (achieved host-link GB/s of the staged pass), and `cpu_baseline`: the CPU
+`issue_model` for the read stage, `link` (achieved host-link GB/s of the staged pass), and `cpu_baseline`: the CPU
 oracle (a C port of the reference's algorithm, oracle/) timed on this box's host cores on a bounded sample of the
 same DNMs, whose results are also compared with the GPU's (parity at bench scale).
 """
@@ -103,13 +103,6 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
-def pinned_copy(pool, a):
-    a = np.ascontiguousarray(a)
-    out = pool.alloc(max(64, a.nbytes))[: a.nbytes].view(a.dtype).reshape(a.shape)
-    out[...] = a
-    return out
-
-
 def bind_near_gpu(torch, local_rank):
     """Run (and allocate the pinned staging memory: first touch) on the CPUs of the GPU's own NUMA node: a host-to-device copy
     out of the other socket's memory crosses the socket link first.  Best effort (sysfs); UZ_BENCH_NO_NUMA=1 leaves the process
@@ -170,62 +163,33 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from synth import bigsynth
-    from synth.sites_np import DnmColumns, breakpoint_dnms, make_clusters, make_sites, place_cnvs, place_dnms_full
-    from unfazed_amd import abi, build, io_native, shard
-    from unfazed_amd.engine import (HipEngine, K_PHASE, K_SEG_QC, K_SEG_QC_PASS, K_SITE_SCAN, K_SIZING, K_WINDOW_COUNT,
-                                    K_WINDOW_FILL, K_CNV, PinnedPool)
-    from unfazed_amd.hostpath import concordant_cutoff
-    from unfazed_amd.staging import fetch_points
+    from synth.benchload import BenchLoad
+    from unfazed_amd import abi, build, io_native, pipeline, shard
+    from unfazed_amd.engine import (HipEngine, K_PHASE, K_SITE_SCAN, K_SIZING, K_WINDOW_COUNT, K_WINDOW_FILL, K_CNV, PinnedPool)
 
     build.build()
     build.build_io()
     t_gen = time.time()
-    sc = make_sites(args.sites, seed=202)
     cnv = args.workload == "cnv"
     seed_off = 0 if args.scaling == "strong" else 1000 * rank
-    if cnv:
-        ev = place_cnvs(sc, args.dnms, seed=501 + seed_off, redraw_seed=502 + seed_off)
-    else:
-        ev = place_dnms_full(sc, args.dnms, seed=201 + seed_off)
+    lo = hi = None
     if args.scaling == "strong":
         # config 4: the same list on every rank, cut into contiguous shards (sites replicated per GPU)
-        b = shard.shard_bounds(ev.n, world)
+        b = shard.shard_bounds(args.dnms, world)
         lo, hi = b[rank], b[rank + 1]
-        if cnv:
-            from synth.sites_np import CnvColumns
-            ev = CnvColumns(ev.contig[lo:hi], ev.start[lo:hi], ev.end[lo:hi], ev.vartype[lo:hi], ev.origin[lo:hi])
-        else:
-            ev = DnmColumns(ev.site_idx[lo:hi], ev.contig[lo:hi], ev.start[lo:hi], ev.end[lo:hi], ev.kind[lo:hi], ev.length[lo:hi],
-                            ev.origin[lo:hi], ev.refs[lo:hi], ev.alts[lo:hi])
-    read_seed = 203 + seed_off
-    # dn: the list the read generator lays its pile-ups around (the DNMs themselves / the breakpoints of the events);
-    # gen_of(k): index of event k's first entry in it
-    dn = breakpoint_dnms(ev) if cnv else ev
-    per_ev = 2 if cnv else 1
-    cl = make_clusters(dn)
-    cfg = bigsynth.make_cfg(seed=read_seed)
-    wl = bigsynth.WorkloadOnGpu(cfg, sc, dn, cl, device=local_rank)
+    load = BenchLoad(args.dnms, args.sites, workload=args.workload, seed_off=seed_off, lo=lo, hi=hi, device=local_rank)
+    sc, ev, dn, cl, cfg, wl, per_ev = load.sc, load.ev, load.dn, load.cl, load.cfg, load.wl, load.per_ev
     t_gen = time.time() - t_gen
 
     eng = HipEngine(local_rank)
     P = abi.make_params()  # the reference's CLI defaults
     eng.set_params(P)
-    sid = eng.adopt_sites(wl.sites_view())
-    fid = eng.adopt_family(sid, wl.family_view())
-    rid = eng.adopt_reads(wl.reads_view())
-    # concordant insert cutoff: host scalar per kid (read_collector.py:11-25) from the first records
-    cutoff = concordant_cutoff(wl.tlen_head(), P.readlen, 3)
+    sid, fid, rid = load.adopt(eng, P)
+    cutoff = load.cutoff
     n = ev.n
     mode = abi.FIND_SECOND_WINDOW
-    ev_vt = ev.vartype if cnv else np.zeros(n, np.uint8)
-    ev_refs = [b""] * n if cnv else ev.refs
-    ev_alts = [b""] * n if cnv else ev.alts
-
-    def view_of(a, b):
-        return abi.dnms_view(ev.contig[a:b], ev.contig[a:b], ev.start[a:b], ev.end[a:b], ev_vt[a:b], ev_refs[a:b], ev_alts[a:b], cutoff)
-
-    dv = view_of(0, n)
+    ev_vt, ev_refs, ev_alts = load.ev_vt, load.ev_refs, load.ev_alts
+    dv = load.view_of(0, n)
 
     def with_cnv(f, r):
         """config 5: K6 over the batch, merged with the read-backed counts as summarize_record merges them"""
@@ -270,12 +234,11 @@ def main():
             step()
         eng.sync()
         # (totals scaled to the timed region's step count: the readers below divide by args.steps)
-        prof = {k: tuple(x * args.steps / extra for x in eng.prof_get(k)) for k in (K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING, K_CNV)}
+        prof = {k: tuple(x * args.steps / extra for x in eng.prof_get(k)) for k in (K_WINDOW_COUNT, K_WINDOW_FILL, K_PHASE, K_SIZING, K_CNV)}
         prof[K_SITE_SCAN] = k1
-        units = eng.prof_units(K_SEG_QC_PASS)
         timed.hbm_build_dnms = int(eng.prof_units(K_PHASE))
         eng.prof_enable(False)
-        return res, elapsed, prof, units
+        return res, elapsed, prof
 
     # ---------------------------------------------------------------- resident pass
     rtrace = [] if os.environ.get("UZ_BENCH_TRACE") else None
@@ -293,251 +256,43 @@ def main():
         rtrace.append([round((b - a) * 1e3, 2) for a, b in ((t0, t1), (t1, t2), (t2, time.perf_counter()))])
         return r
 
-    res_r, el_r, prof_r, qc_records = timed(step_resident)
+    res_r, el_r, prof_r = timed(step_resident)
     if rtrace:
         print("[resident step, ms] drop_derived | read stage | allele balance:", rtrace, file=sys.stderr)
     per_rank_r = list(timed.per_rank)
 
     # ---------------------------------------------------------------- staged pass
+    # (the pass itself is the product's: unfazed_amd/pipeline.py; what the decoders would leave in pinned memory -- the site windows and the
+    # records of every chunk in the link form -- comes from synth/benchload.py, outside the timing: `decode_s`)
     staged = None
     if not args.no_staged:
         t_dec = time.time()
         pool = PinnedPool()
-        # what the decoders would leave in pinned memory: the sites / genotype columns of the DNMs' windows (the reference queries
-        # the indexed VCF per DNM region, informative_site_finder.py:399-420: no site outside a window is ever decoded) ...
-        sd = int(P.search_dist) + 2
-        keep_site = np.zeros(sc.n + 1, np.int32)
-        co_s = np.asarray(sc.contig_off, np.int64)
-        for c in np.unique(ev.contig):
-            if c < 0:
-                continue
-            m = ev.contig == c
-            pc = sc.pos[co_s[c]: co_s[c + 1]]
-            lo_i = np.searchsorted(pc, ev.start[m].astype(np.int64) - sd, "left") + co_s[c]
-            hi_i = np.searchsorted(pc, ev.end[m].astype(np.int64) + sd, "right") + co_s[c]
-            np.add.at(keep_site, lo_i, 1)
-            np.add.at(keep_site, hi_i, -1)
-        site_sel = np.nonzero(np.cumsum(keep_site[:-1]) > 0)[0]
-        hs = {k: pinned_copy(pool, getattr(sc, k)[site_sel]) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
-        hs["contig_off"] = pinned_copy(pool, np.searchsorted(site_sel, co_s).astype(np.int64))
-        hg = {k: [pinned_copy(pool, getattr(sc, k)[m][site_sel]) for m in range(3)] for k in ("rd", "ad", "gq")}
-        sv = abi.SitesView()
-        sv.n_sites, sv.n_contigs = int(site_sel.size), len(sc.contig_off) - 1
-        for k in ("contig_off", "pos", "sflags", "ref_base", "alt_base"):
-            setattr(sv, k, hs[k].ctypes.data)
-        sites_h = abi.Held(sv, hs)
-        # ... and, per chunk of DNMs (whole clusters), the records the chunk's fetches return + their mates
-        co, ci, cf, ho, hi = eng.find(fid, dv, P, mode)
-        chunks, staged_bytes, staged_records = [], 0, 0
-        slab_hint = 768 << 20
-        # chunks of events (their records: the clusters of their generator entries); the last one smaller (--last-chunk): its read
-        # stage is the only one nothing hides -- the link is idle by then
-        ecuts = shard.chunk_plan(n, args.chunks or None, args.last_chunk, first_chunk=args.first_chunk)
-        nchunk = len(ecuts) - 1
-        for k in range(nchunk):
-            a, b = ecuts[k], ecuts[k + 1]
-            if b <= a:
-                continue
-            c0, c1 = cl.of_dnm(per_ev * a), cl.of_dnm(per_ev * b - 1) + 1
-            part_full = wl.download(c0, c1)
-            src = io_native.ReadsSource(part_full)
-            alen = np.array([max(len(r), len(x)) for r, x in zip(ev_refs[a:b], ev_alts[a:b])], np.int64)
-            fc, flo, fhi, fex = fetch_points(ev.contig[a:b], ev.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P,
-                                             vartype=ev_vt[a:b], end=ev.end[a:b], cutoff=cutoff, allele_len=alen)
-            # point-variant batch: qualities as counts + short lists, and of every record's rows only the 32-base units that hold
-            # a fetched position; the SV batch needs the plane and whole rows (uz_types.h)
-            # (the chunk's columns back to back in one pinned block: they cross the link as one copy)
-            pool.new_slab(slab_hint)
-            # (SV batches the same way: their +-cutoff fetches stage no base unit -- collect_reads_sv reads none -- and the read stage asks
-            # for quality bits of records that pass goodread only, which the lists hold)
-            part = src.select(fc, flo, fhi, alloc=pool.alloc, all_bases=bool(P.no_extended), lists=True, extra=fex, wide_no_units=cnv)
-            slab_hint = max(64 << 20, int(pool.end_slab() * 1.3))
-            if os.environ.get("UZ_BENCH_LINK_BYTES") and not chunks:  # development aid: the first chunk, column by column
-                nrec = int(part.view.n_segs)
-                print("[link bytes] %d records for %d DNMs:" % (nrec, b - a), {k: (int(x.nbytes), round(x.nbytes / max(1, b - a), 1)) for k, x in part.arrays.items()},
-                      file=sys.stderr)
-            del src, part_full
-            chunks.append((a, b, part, view_of(a, b)))
-            staged_records += int(part.view.n_segs)
-            pv = part.view
-            lists_f = bool(pv.n_low) or bool(pv.tup and pv.tup_n_low)
-            fixed = ((2 if pv.pair_d8 else 5 if pv.mate_d8 else 7) if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
-            staged_bytes += (int(pv.n_segs) * fixed + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
-                             + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
-                             + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
-        site_bytes = int(site_sel.size) * (4 + 1 + 1 + 1 + 1 + 18)
-        # The same site columns cut per chunk (the windows of the chunk's DNMs): the site stage of chunk k + 1 then runs while the
-        # records of chunk k are still on the link, instead of one site stage for the whole batch in front of everything.
-        # (config 5 the same way: the allele-balance stage of a chunk runs on the chunk's own site windows, behind its read stage.)
-        chunk_sites = []
-        if not args.one_site_table:
-            for (a, b, _, _) in chunks:
-                kk = np.zeros(sc.n + 1, np.int32)
-                for c in np.unique(ev.contig[a:b]):
-                    if c < 0:
-                        continue
-                    m = ev.contig[a:b] == c
-                    pc = sc.pos[co_s[c]: co_s[c + 1]]
-                    lo_i = np.searchsorted(pc, ev.start[a:b][m].astype(np.int64) - sd, "left") + co_s[c]
-                    hi_i = np.searchsorted(pc, ev.end[a:b][m].astype(np.int64) + sd, "right") + co_s[c]
-                    np.add.at(kk, lo_i, 1)
-                    np.add.at(kk, hi_i, -1)
-                sel = np.nonzero(np.cumsum(kk[:-1]) > 0)[0]
-                pool.new_slab(int(sel.size) * 28 + (1 << 20))
-                hs_k = {k: pinned_copy(pool, getattr(sc, k)[sel]) for k in ("pos", "sflags", "ref_base", "alt_base", "gt")}
-                hs_k["contig_off"] = pinned_copy(pool, np.searchsorted(sel, co_s).astype(np.int64))
-                hg_k = {k: [getattr(sc, k)[m][sel] for m in range(3)] for k in ("rd", "ad", "gq")}
-                wide_k = None
-                if not args.sites16:  # the nine genotype columns in eight bits (uz_types.h: depths of 255 and more, or missing, through the wide list)
-                    r8, a8, g8, wide_k = abi.family_columns8(hg_k["rd"], hg_k["ad"], hg_k["gq"])
-                    hg_k = dict(rd=list(r8), ad=list(a8), gq=list(g8))
-                hg_k = {k: [pinned_copy(pool, x) for x in v] for k, v in hg_k.items()}
-                svk = abi.SitesView()
-                svk.n_sites, svk.n_contigs = int(sel.size), len(sc.contig_off) - 1
-                for k in ("contig_off", "pos", "sflags", "ref_base", "alt_base"):
-                    setattr(svk, k, hs_k[k].ctypes.data)
-                pool.end_slab()
-                chunk_sites.append((abi.Held(svk, hs_k), hs_k, hg_k, int(sel.size), wide_k))
-            site_bytes = sum(x[3] * (4 + 1 + 1 + 1 + 1 + (18 if args.sites16 else 9)) + (0 if x[4] is None else len(x[4][0]) * 32) for x in chunk_sites)
+        chunks, st = load.stage(eng, P, mode, fid, pool, chunks=args.chunks, last_chunk=args.last_chunk, first_chunk=args.first_chunk,
+                                sites16=args.sites16, per_chunk_sites=not args.one_site_table, log_first=bool(os.environ.get("UZ_BENCH_LINK_BYTES")))
+        f_all = s_all = None
+        if args.one_site_table:  # one site stage for the whole batch in front of the chunks (a measurement aid: the default pipelines it per chunk)
+            held, hs, hg, wide, ns = load.pinned_sites(pool, load.window_sites(0, n, P), eight_bit=not args.sites16)
+            st["sites"], st["site_bytes"] = ns, ns * (4 + 1 + 1 + 1 + 1 + (18 if args.sites16 else 9))
         t_dec = time.time() - t_dec
-
         trace = [] if os.environ.get("UZ_BENCH_TRACE") else None
 
-        def step_pipelined():
-            """chunk k: site stage (its windows' site columns up, K1 + K2, het lists back) -> its records queued on the copy stream
-            -> the read stage of chunk k - 1; the site columns of chunk k + 1 go up before the records of chunk k"""
-            out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32),
-                       evidence=np.empty(n, np.int32))
-            if cnv:
-                out.update(etype=np.empty(n, np.int32), cnv_counts=np.empty((n, 2), np.int32))
-            K = len(chunks)
-            sids, fids, rids = [None] * K, [None] * K, [None] * K
-
-            def site_stage(k):  # queued on the copy stream (in front of the records of chunk k - 1 ... k): no host wait
-                held, hs_k, hg_k, _, wide_k = chunk_sites[k]
-                sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"], wide_k)
-
-            def read_stage_begin(k):  # queued on the compute stream (waits there for the chunk's records): no host wait
-                eng.phase_begin(fids[k], rids[k], chunks[k][3], P, mode)
-
-            pending = {}
-
-            def read_stage_end(k):
-                pending[k] = eng.phase_end(fids[k], rids[k], chunks[k][3], P, mode)
-                if not cnv:
-                    finish(k)
-
-            def cnv_stage(k):  # config 5: K6 over the chunk's events, merged with their read-backed counts as summarize_record merges them
-                rr = pending[k]
-                kk = eng.phase_cnv(fids[k], chunks[k][3], P, rb_counts=rr["counts"], want_lists=False)
-                pending[k] = dict(status=rr["status"], counts=rr["counts"], origin=kk["origin"], evidence=kk["evidence"], etype=kk["etype"],
-                                  cnv_counts=kk["cnv_counts"])
-                finish(k)
-
-            def finish(k):
-                a, b = chunks[k][0], chunks[k][1]
-                rr = pending.pop(k)
-                for key in out:
-                    out[key][a:b] = rr[key]
-                eng.free_reads(rids[k])
-                eng.free_sites(sids[k])
-
-            tr = [time.perf_counter()] if trace is not None else None
-
-            def tick():
-                if tr is not None:
-                    tr.append(time.perf_counter())
-            # The read stage of chunk k - 1 is queued (uz_phase_begin) before the host waits for the het lists of chunk k + 1: that wait
-            # -- the ONE host round trip per chunk -- then runs behind the read stage's kernels instead of beside an idle device, and the
-            # read stage's results are there when it returns (uz_phase_end).  The site windows travel two chunks ahead of their find, so
-            # the link does not idle through that round trip either.  (config 5: the allele-balance stage of chunk k - 2 is queued behind
-            # the read stage of chunk k - 1, and waited for there.)
-            site_stage(0)
-            if K > 1:
-                site_stage(1)
-            tick()
-            for k in range(K):
-                eng.find(fids[k], chunks[k][3], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
-                tick()
-                if k >= 2:
-                    read_stage_end(k - 2)
-                tick()
-                if k >= 1:
-                    read_stage_begin(k - 1)
-                tick()
-                rids[k] = eng.upload_reads_packed(chunks[k][2])
-                if k + 2 < K:
-                    site_stage(k + 2)
-                if cnv and k >= 2:
-                    cnv_stage(k - 2)
-                tick()
-            if K >= 2:
-                read_stage_end(K - 2)
-            read_stage_begin(K - 1)
-            if cnv and K >= 2:
-                cnv_stage(K - 2)
-            read_stage_end(K - 1)
-            if cnv:
-                cnv_stage(K - 1)
-            tick()
-            if tr is not None:
-                trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
-            return out
-
         def step_staged():
-            if chunk_sites:
-                return step_pipelined()
-            t = [time.perf_counter()]
-
-            def tick():
-                if trace is not None:
-                    t.append(time.perf_counter())
-            s2 = eng.upload_sites_view(sites_h)
-            f2 = eng.add_family(s2, hs["gt"], hg["rd"], hg["ad"], hg["gq"])
-            tick()
-            eng.find(f2, dv, P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
-            tick()
-            rids = [eng.upload_reads_packed(part) for (_, _, part, _) in chunks]  # queued behind one another on the copy stream
-            tick()
-            out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32),
-                       evidence=np.empty(n, np.int32))
-            for (a, b, _, dvc), r in zip(chunks, rids):
-                rr = eng.phase_raw(f2, r, dvc, P, mode)
-                for key in out:
-                    out[key][a:b] = rr[key]
-            tick()
-            out = with_cnv(f2, out)
-            for r in rids:
-                eng.free_reads(r)
+            if not args.one_site_table:
+                return pipeline.run_pipelined(eng, P, mode, n, chunks, cnv=cnv, trace=trace)
+            s2, f2 = eng.upload_sites_family_async(held, hs["gt"], hg["rd"], hg["ad"], hg["gq"], wide)
+            out = pipeline.run_pipelined(eng, P, mode, n, chunks, cnv=cnv, fid=f2, trace=trace)
             eng.free_sites(s2)
-            tick()
-            if trace is not None:
-                trace.append([round((t[i + 1] - t[i]) * 1e3, 2) for i in range(len(t) - 1)])
             return out
 
-        res_s, el_s, prof_s, _ = timed(step_staged)
+        res_s, el_s, prof_s = timed(step_staged)
         per_rank_s = list(timed.per_rank)
-        if trace and chunk_sites:
+        if trace:
             print("[staged step, ms] site stage 0, then per chunk: find (behind the read stage of chunk k - 2) | its results | enqueue records, the site windows of chunk k + 2 | queue the read stage of chunk k - 1 (config 5: + allele balance of chunk k - 2); last read stages:", trace[-2:], file=sys.stderr)
-        elif trace:
-            print("[staged step, ms] sites+family upload | find | enqueue read uploads | phase chunks | cnv + frees:", trace, file=sys.stderr)
-            # where the link time goes: the copies alone, the kernels alone (tables already in HBM), both overlapped
-            t0 = time.perf_counter()
-            rids = [eng.upload_reads_packed(part) for (_, _, part, _) in chunks]
-            for r in rids:
-                eng.wait_reads(r)
-            t1 = time.perf_counter()
-            for (a, b, _, dvc), r in zip(chunks, rids):
-                eng.phase_raw(fid, r, dvc, P, mode)
-            t2 = time.perf_counter()
-            for r in rids:
-                eng.free_reads(r)
-            print("[staged, ms] copies + header builds alone %.1f (%.1f GB/s) | kernels alone %.1f" %
-                  ((t1 - t0) * 1e3, staged_bytes / (t1 - t0) / 1e9, (t2 - t1) * 1e3), file=sys.stderr)
         mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
-        staged = dict(elapsed=el_s, prof=prof_s, bytes=staged_bytes + site_bytes, read_bytes=staged_bytes, records=staged_records,
+        staged = dict(elapsed=el_s, prof=prof_s, bytes=st["read_bytes"] + st["site_bytes"], read_bytes=st["read_bytes"], records=st["records"],
                       decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks),
-                      sites=sum(x[3] for x in chunk_sites) if chunk_sites else int(site_sel.size), site_stage="per chunk" if chunk_sites else "whole batch")
+                      sites=st["sites"], site_stage="whole batch" if args.one_site_table else "per chunk")
         res = res_s
     else:
         res = res_r
@@ -562,7 +317,6 @@ def main():
                 "window_count+scan": round(prof[K_WINDOW_COUNT][0] / args.steps, 3),
                 "window_fill": round(prof[K_WINDOW_FILL][0] / args.steps, 3),
                 "sizing": round(prof[K_SIZING][0] / args.steps, 3),
-                "seg_qc": round(prof[K_SEG_QC][0] / args.steps, 3),
                 "phase": round(prof[K_PHASE][0] / args.steps, 3),
                 "cnv_count": round(prof[K_CNV][0] / args.steps, 3)}
 
@@ -584,17 +338,18 @@ def main():
                 traffic_note = "profiles/k1_traffic.json was collected on other kernel sources (%s) or another table size: not quoted" % tj.get("kernel_source_sha")
         except Exception:
             traffic = None
+    # two byte counts: `achieved` / `frac` on the bytes the kernel moves (20 B per site: it does not read `pos`), and the same launch priced at
+    # SURVEY.md 8(d)'s fixed 24 B per site (pos + packed GT + 9 x u16 + class)
+    survey_bytes = 24.0 * sc.n
     roofline = {"bound": "hbm", "kernel": "k_site_scan", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 4), "traffic": traffic, "avg_launch_us": round(k1_us, 2),
-                "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n), "kernel_source_sha": ksha}
+                "algorithmic_bytes_per_launch": int(bytes_per_site * sc.n), "bytes_moved": int(bytes_per_site * sc.n),
+                "algorithmic_bytes_survey": int(survey_bytes),
+                "achieved_on_survey_bytes": round(survey_bytes / (k1_us * 1e-6) / 1e9, 1) if k1_n else 0.0,
+                "frac_on_survey_bytes": round(survey_bytes / (k1_us * 1e-6) / 1e9 / 8000.0, 4) if k1_n else 0.0,
+                "kernel_source_sha": ksha}
     if traffic_note:
         roofline["traffic_note"] = traffic_note
-
-    # K3a (per-record QC bits) has no pass of its own any more: the header build writes a QC word per record at upload and the
-    # readers apply --min-map-qual; the object stays in the line so that round-to-round readers find it
-    qc_ms, qc_n = prof_r[K_SEG_QC_PASS]
-    roofline_k3a = {"kernel": "k_seg_qc", "fused_into": "k_pack_rec (header build at upload): no per-batch QC pass", "ms_per_step": round(qc_ms / args.steps, 3),
-                    "last_standalone_measurement": "profiles/k3a_traffic.json (0.54 ms per pass, 1.42 GB = 2.1x its algorithmic bytes)"}
 
     # k_phase has no GB/s figure: it is bound by instruction issue (integer VALU work) with memory latency on top.  The
     # counters of the same workload (profiles/phase_issue.json, scripts/profile_round.sh) give the floor: VALU
@@ -677,7 +432,6 @@ def main():
             "ms_per_step_by_rank": [round(x / args.steps * 1e3, 3) for x in (per_rank_s if staged else per_rank_r)],
             "ms_per_step_resident_by_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_r],
             "roofline": roofline,
-            "roofline_k3a": roofline_k3a,
             "issue_model": issue_model,
             "cpu_baseline": cpu,
             "value_e2e": feed["value_e2e"] if feed else None,
@@ -876,7 +630,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):
+def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv, parity_only=False):
     """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first `cpu_dnms` DNMs of the GPU's batch
     (whole clusters).  The sample is cut into contiguous cluster ranges, each with its OWN records table (regenerated on the
     host by the gcc build of the generator, outside the timing -- as separate workers each reading their own regions of the
@@ -884,7 +638,7 @@ def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_v
     oracle's per-call set-up is proportional to the table it is handed, so one shared table does not scale past a few
     threads; per-range tables do.  Results are compared with the GPU's."""
     if cnv:  # the two breakpoints of an event lie in different clusters
-        return cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res)
+        return cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res, parity_only=parity_only)
     from oracle import oracle as orc
     from synth import bigsynth
     from unfazed_amd import abi
@@ -903,7 +657,7 @@ def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_v
     fh = abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
     orc.lib()
     # ranges: cluster boundaries nearest to an even split of the sample's entries of `dn` (DNMs / breakpoints)
-    n_ranges = max(1, min(4 * ncpu, c_hi))
+    n_ranges = max(1, min(4 * max(ncpu, 64), c_hi))
     ends = cl.d0[:c_hi] + cl.nd[:c_hi]
     cuts = sorted({int(np.searchsorted(ends, per_ev * m * (k + 1) / n_ranges, side="left")) + 1 for k in range(n_ranges)} | {c_hi})
     cuts = [c for c in cuts if c <= c_hi]
@@ -950,30 +704,47 @@ def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_v
             t.join()
         return time.perf_counter() - t0, out
 
-    dt1, r1 = run(1)
-    dt2, _ = run(2)
-    ladder = sorted({t for t in (8, 32, 64, 128, ncpu) if 2 < t <= ncpu})
-    best = None
-    sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
-    for t in ladder:
-        dtt, rt = run(t)
-        sweep[str(t)] = round(m / dtt, 1)
-        if best is None or dtt < best[0]:
-            best = (dtt, rt, t)
-    if best is None:
-        best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
-    dtc, rc, cores = best
+    if parity_only:  # (tests: one pass on every core the box grants, no timing ladder)
+        dtp, rp = run(_cpus())
+        dt1, r1, dt2 = dtp, rp, dtp
+        best, sweep = (dtp, rp, _cpus()), {str(_cpus()): round(m / dtp, 1)}
+    else:
+        dt1, r1 = run(1)
+        dt2, _ = run(2)
+        # thread counts up to twice the CPUs the cgroup grants (threads beyond the quota only take turns: round 3's "best at 256 threads" on a
+        # 16-CPU quota was noise)
+        ladder = sorted({t for t in (8, _cpus(), 2 * _cpus()) if 2 < t <= ncpu})
+        best = None
+        sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
+        for t in ladder:
+            dtt, rt = run(t)
+            sweep[str(t)] = round(m / dtt, 1)
+            if best is None or dtt < best[0]:
+                best = (dtt, rt, t)
+        if best is None:
+            best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
+    dtc, rc, threads_best = best
+    cores = min(threads_best, _cpus())  # the CPUs those threads really ran on
     mism = 0
     for k in r1:
         mism += int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
         mism += int((rc[k] != r1[k]).sum())
     return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",
+            "threads": threads_best,
             "sample": "first %d DNMs of the GPU batch (whole read clusters) in %d cluster ranges, each with its own records table regenerated on the host "
-                      "before the timing; oracle find+phase per range, threads over ranges (best of a ladder of thread counts: %d)" % (m, len(jobs), cores),
+                      "before the timing; oracle find+phase per range, threads over ranges (best of a ladder of thread counts: %d threads on %d CPUs)" % (m, len(jobs), threads_best, cores),
             "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
-            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
+            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(threads_best): round(dtc, 2)},
             "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu, "host_cpu_quota": _cpu_quota(),
             "parity_mismatches_vs_gpu": mism}
+
+
+def _cpus():
+    """CPUs this process can really run on at once: the cgroup's quota when there is one (a pod that lists 256 processors may be held to 16),
+    else the processors listed"""
+    q = _cpu_quota()
+    n = os.cpu_count() or 1
+    return max(1, min(n, int(q))) if q else n
 
 
 def _cpu_quota():
@@ -985,7 +756,7 @@ def _cpu_quota():
         return None
 
 
-def cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res):
+def cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res, parity_only=False, n_ranges=None):
     """Config 5 on the CPU oracle with per-range tables, as the SNV baseline has them: the breakpoint list (sorted by position) is cut
     into contiguous cluster ranges, each with its own records table regenerated on the host before the timing; the sample is the
     events whose BOTH breakpoints fall into one range (an event that straddles a cut is left out: a few per cent); T threads take the
@@ -995,7 +766,7 @@ def cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res):
     from unfazed_amd import abi
     ncpu = os.cpu_count() or 1
     want = min(args.cpu_dnms, ev.n)
-    n_ranges = max(1, min(4 * ncpu, cl.n // 8))
+    n_ranges = int(n_ranges) if n_ranges else max(1, min(4 * ncpu, cl.n // 8))
     ends = cl.d0 + cl.nd
     cuts = sorted({int(np.searchsorted(ends, dn.n * (k + 1) / n_ranges, side="left")) + 1 for k in range(n_ranges)} | {cl.n})
     cuts = [c for c in cuts if c <= cl.n]
@@ -1047,110 +818,38 @@ def cpu_baseline_cnv_ranges(args, sc, ev, dn, cl, cfg, P, cutoff, gpu_res):
         dt = time.perf_counter() - t0
         return dt, {k: np.concatenate([v[j] for j in range(len(jobs))]) for k, v in out.items()}
 
-    dt1, r1 = run(1)
-    dt2, _ = run(2)
-    ladder = sorted({t for t in (8, 32, 64, 128, ncpu) if 2 < t <= ncpu})
-    best = None
-    sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
-    for t in ladder:
-        dtt, rt = run(t)
-        sweep[str(t)] = round(m / dtt, 1)
-        if best is None or dtt < best[0]:
-            best = (dtt, rt, t)
-    if best is None:
-        best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
-    dtc, rc, cores = best
+    if parity_only:  # (tests: one pass on every core the box grants, no timing ladder)
+        dtp, rp = run(_cpus())
+        dt1, r1, dt2 = dtp, rp, dtp
+        best, sweep = (dtp, rp, _cpus()), {str(_cpus()): round(m / dtp, 1)}
+    else:
+        dt1, r1 = run(1)
+        dt2, _ = run(2)
+        # thread counts up to twice the CPUs the cgroup grants (threads beyond the quota only take turns: round 3's "best at 256 threads" on a
+        # 16-CPU quota was noise)
+        ladder = sorted({t for t in (8, _cpus(), 2 * _cpus()) if 2 < t <= ncpu})
+        best = None
+        sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
+        for t in ladder:
+            dtt, rt = run(t)
+            sweep[str(t)] = round(m / dtt, 1)
+            if best is None or dtt < best[0]:
+                best = (dtt, rt, t)
+        if best is None:
+            best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
+    dtc, rc, threads_best = best
+    cores = min(threads_best, _cpus())  # the CPUs those threads really ran on
     mism = 0
     for k in r1:
         mism += int((np.asarray(gpu_res[k])[idx_all] != r1[k]).sum())
         mism += int((rc[k] != r1[k]).sum())
     return {"value": round(m / dtc, 1), "unit": "events/s", "cores": cores, "kind": "port",
+            "threads": threads_best,
             "sample": "%d events of the GPU batch whose two breakpoints fall into one of %d cluster ranges (each range with its own records table, regenerated on the "
-                      "host before the timing); oracle find + read stage + allele balance per range, threads over ranges (best of a ladder: %d)" % (m, len(jobs), cores),
+                      "host before the timing); oracle find + read stage + allele balance per range, threads over ranges (best of a ladder: %d threads on %d CPUs)" % (m, len(jobs), threads_best, cores),
             "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
-            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
+            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(threads_best): round(dtc, 2)},
             "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu, "host_cpu_quota": _cpu_quota(),
-            "parity_mismatches_vs_gpu": mism}
-
-
-def cpu_baseline_shared_table(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv):
-    """The CPU oracle (C port of the reference's algorithm) timed on this host, on the first `cpu_dnms` DNMs of the
-    GPU's batch (whole clusters; their records regenerated on the host by the gcc build of the generator), 1, 2 and
-    more threads over DNM ranges, as the reference's thread pool over DNMs; its results are compared with the GPU's."""
-    from oracle import oracle as orc
-    from synth import bigsynth
-    from unfazed_amd import abi
-    ncpu = os.cpu_count() or 1
-    c_hi = cl.of_dnm(per_ev * min(args.cpu_dnms, ev.n) - 1) + 1
-    m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1]) // per_ev  # whole clusters (an event whose second breakpoint lies beyond them is left out)
-    rh, _ = bigsynth.reads_cpu(cfg, sc, dn, cl, 0, c_hi, threads=min(ncpu, 128))
-    nc = len(sc.contig_off) - 1
-    sv = abi.SitesView()
-    keep = dict(contig_off=np.ascontiguousarray(sc.contig_off, np.int64), pos=sc.pos, sflags=sc.sflags,
-                ref_base=sc.ref_base, alt_base=sc.alt_base)
-    sv.n_sites, sv.n_contigs = sc.n, nc
-    for k, a in keep.items():
-        setattr(sv, k, a.ctypes.data)
-    sh = abi.Held(sv, keep)
-    # the GPU folded the complex flag into bit 6 of its own copy of gt; the host copy is untouched
-    fh = abi.family_view(sc.gt, sc.rd, sc.ad, sc.gq)
-    dv = abi.dnms_view(ev.contig[:m], ev.contig[:m], ev.start[:m], ev.end[:m], ev_vt[:m], ev_refs[:m], ev_alts[:m], cutoff)
-    orc.lib()
-
-    def run(threads):
-        found = [None]
-        parts = [None] * threads
-        t0 = time.perf_counter()
-        found[0] = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
-        bounds = np.linspace(0, m, threads + 1).astype(int)
-
-        def work(i):
-            parts[i] = orc.phase(P, sh, rh, dv, found[0], d_lo=int(bounds[i]), d_hi=int(bounds[i + 1]), keep_lists=False)
-
-        th = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        st = np.full(m, abi.ST_SKIPPED, np.int32)
-        cnt = np.zeros((m, 4), np.int32)
-        org = np.zeros(m, np.int32)
-        evd = np.zeros(m, np.int32)
-        for i, p in enumerate(parts):
-            a, b = int(bounds[i]), int(bounds[i + 1])
-            st[a:b], cnt[a:b], org[a:b], evd[a:b] = p["status"][a:b], p["counts"][a:b], p["origin"][a:b], p["evidence"][a:b]
-        out = dict(status=st, counts=cnt, origin=org, evidence=evd)
-        if cnv:
-            k = orc.phase_cnv(P, sh, fh, dv, rb_counts=cnt)
-            out = dict(status=st, counts=cnt, origin=k["origin"], evidence=k["evidence"], etype=k["etype"], cnv_counts=k["cnv_counts"])
-        dt = time.perf_counter() - t0
-        return dt, out
-
-    dt1, r1 = run(1)
-    dt2, _ = run(2)
-    # the port does not scale to every hardware thread (allocator / page-fault contention between
-    # threads of one process): try a ladder of thread counts and report the best
-    ladder = sorted({t for t in (8, 32, 128, ncpu) if 2 < t <= ncpu})
-    best = None
-    sweep = {"1": round(m / dt1, 1), "2": round(m / dt2, 1)}
-    for t in ladder:
-        dtt, rt = run(t)
-        sweep[str(t)] = round(m / dtt, 1)
-        if best is None or dtt < best[0]:
-            best = (dtt, rt, t)
-    if best is None:
-        best = (dt2, r1, 2) if dt2 < dt1 else (dt1, r1, 1)
-    dtc, rc, cores = best
-    mism = 0
-    for k in r1:
-        mism += int((np.asarray(gpu_res[k][:m]) != r1[k]).sum())
-        mism += int((rc[k] != r1[k]).sum())
-    return {"value": round(m / dtc, 1), "unit": "DNMs/s", "cores": cores, "kind": "port",
-            "sample": "first %d DNMs of the GPU batch (whole read clusters, regenerated on the host), oracle find+phase, threads over DNM ranges (best of a ladder of thread counts: %d)"
-                      % (m, cores),
-            "value_1thread": round(m / dt1, 1), "value_2threads": round(m / dt2, 1),
-            "seconds": {"1": round(dt1, 2), "2": round(dt2, 2), str(cores): round(dtc, 2)},
-            "dnms_per_s_by_threads": sweep, "host_hw_threads": ncpu,
             "parity_mismatches_vs_gpu": mism}
 
 

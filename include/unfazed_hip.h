@@ -41,12 +41,10 @@ extern "C" {
 #define UZ_K_SITE_SCAN 0   /* K1 site classify (the roofline kernel) */
 #define UZ_K_WINDOW_COUNT 1
 #define UZ_K_WINDOW_FILL 2
-#define UZ_K_SEG_QC 3
-#define UZ_K_PHASE 4
-#define UZ_K_SEG_QC_PASS 5 /* the quality / CIGAR pass of K3a alone (k_seg_qc), inside UZ_K_SEG_QC */
-#define UZ_K_SIZING 6      /* fetch-range sizing pass */
-#define UZ_K_CNV 7         /* K6 allele-balance count + decision */
-#define UZ_K_COUNT 8
+#define UZ_K_PHASE 3       /* the per-DNM read stage (both builds of k_phase) */
+#define UZ_K_SIZING 4      /* fetch-range sizing pass */
+#define UZ_K_CNV 5         /* K6 allele-balance count + decision */
+#define UZ_K_COUNT 6
 
 typedef struct uz_ctx uz_ctx;
 
@@ -91,9 +89,9 @@ int uz_reads_wait(uz_ctx *ctx, int reads_id);
  * form; `end` derived from the CIGAR when it was left out): [n_segs] each, any pointer may be NULL.  For parity tests of the
  * upload forms; waits for the table like uz_reads_wait. */
 int uz_reads_headers(uz_ctx *ctx, int reads_id, int32_t *start, int32_t *end, int32_t *tlen, int32_t *mate, uint32_t *qname);
-/* BGZF blocks inflated on the device (csrc/k_inflate.hip: one wavefront per block; fixed, dynamic and stored DEFLATE blocks).  The
- * building block of a decode stage that no longer passes through the host's cores -- today a measured kernel
- * with its parity test, not yet part of the session's path.  comp: the compressed bytes (host); in_off[k]: where the DEFLATE stream
+/* BGZF blocks inflated on the device (csrc/k_inflate.hip: one wavefront per block; fixed, dynamic and stored DEFLATE blocks).  This
+ * entry is the measured form (repeat / kernel_ms) behind the parity tests; the session's path calls uz_bgzf_inflate_to_host below for
+ * every staged batch (HipEngine.upload_reads_staged).  comp: the compressed bytes (host); in_off[k]: where the DEFLATE stream
  * of block k starts in them (behind its gzip header and BC field); out_off[k] .. out_off[k+1]: where its ISIZE bytes go in `out`
  * (host, [out_off[n_blocks]]).  repeat > 0: the kernel is run that many more times and *kernel_ms is their mean duration (HIP events).
  * A stream that does not decode to exactly its declared size fails the call (UZ_E_RANGE, the block named). */

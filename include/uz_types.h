@@ -306,7 +306,28 @@ typedef struct uz_reads_packed_view {
      * link, the distance, both template lengths), so the form is lossless; the device checks that every SECOND is named by exactly one
      * FIRST (UZ_E_STATE otherwise).  A 151-base pair costs 2 bytes here instead of 8. */
     const uint8_t *pair_d8;
+    /* The bases of a record as a LIST -- per record an alternative to its staged row units (needs umask or tup_umask, and seq2).
+     * The read stage reads a record's bases at the fetch points it overlaps and nowhere else: the DNM position (plus the longer
+     * allele) and the het sites of the window -- one or two bases of a 151-base read, where its staged 32-base unit is 8 bytes.
+     * A record with bl_n[i] = k > 0 (tup_n_bl through the dictionary) sends those k bases instead: their query indices (bl_pos,
+     * ascending within the record, records in order; one byte each, two little-endian when bl_wide) and their two-bit codes
+     * (bl_code: entry e of the table in bits 2 (e & 3) .. 2 (e & 3) + 1 of byte e >> 2; A 0, C 1, G 2, T 3; a base that is none of
+     * the four is 0 here and stands in exc_*).  Such a record owns NO units in seq2; its umask still names the units its bases lie
+     * in, the device lays those units out behind the ones that travelled as rows and writes the listed bases into them
+     * (n_bl_units = sum of popcount(umask) over the records with a list).  A packer lists a record only when every listed position
+     * lies in a unit of its mask, every unit of the mask holds a listed position, and no listed base is '=' (BAM code 0): the device
+     * marks the record, and a kernel that asks for a base of it that was not listed reads code 0 and raises UZ_E_STATE -- the
+     * staging rule and the kernel cannot disagree silently.  k = 0: the record's units travel as rows, as before. */
+    const uint8_t *bl_n;       /* [n_segs], or NULL with tup_n_bl */
+    const uint8_t *tup_n_bl;   /* [n_tup] */
+    const uint8_t *bl_pos;     /* [n_bl] (* 2 bytes when bl_wide) */
+    const uint8_t *bl_code;    /* [(n_bl + 3) / 4] */
+    int64_t n_bl;
+    int64_t n_bl_units;
+    int32_t bl_wide;
+    int32_t reserved2;
 } uz_reads_packed_view;
+#define UZ_UMASK_LISTED 0x8000u /* device only: set in a record's unit mask when its bases came as a list (masks name units 0 .. 14) */
 #define UZ_P8_SECOND 0
 #define UZ_P8_MAX_DIST 252
 #define UZ_P8_SECOND_TLEN 253

@@ -285,13 +285,19 @@ class DeviceArrays:
 
 
 class WorkloadOnGpu:
-    """Sites table + family columns + the reads table of all clusters, resident in HBM (staged format)."""
+    """Sites table + family columns + the reads table of all clusters, resident in HBM (staged format).
+    c0, c1: only clusters [c0, c1) are generated (one rank's shard of a list every rank knows whole: a cluster's records are a function of
+    its number in the WHOLE list, so a shard holds exactly the records the one-GPU table holds for its clusters); record numbers and
+    query-name ids are then relative to the first record / pair of cluster c0."""
 
-    def __init__(self, cfg, sc, dn, cl, device=0):
+    def __init__(self, cfg, sc, dn, cl, device=0, c0=0, c1=None):
         self.cfg, self.sc, self.dn, self.cl = cfg, sc, dn, cl
         cfg.n_clusters = cl.n
+        c1 = cl.n if c1 is None else int(c1)
+        self.c0, self.c1 = int(c0), c1
         dev = self.dev = DeviceArrays(device)
-        n = int(2 * cl.pair_off[-1])
+        p0, p1 = int(cl.pair_off[self.c0]), int(cl.pair_off[c1])
+        n = int(2 * (p1 - p0))
         self.n_segs = n
         nseg = 2 * np.diff(cl.pair_off)
         if nseg.max() > MAXSEG:
@@ -315,7 +321,8 @@ class WorkloadOnGpu:
         D.kind, D.len, D.origin = dev.put(dn.kind), dev.put(dn.length), dev.put(dn.origin)
         K = ClustersS()
         K.contig, K.lo, K.hi = dev.put(cl.contig), dev.put(cl.lo), dev.put(cl.hi)
-        K.d0, K.nd, K.pair_off = dev.put(cl.d0), dev.put(cl.nd), dev.put(np.ascontiguousarray(cl.pair_off, np.int64))
+        # (offsets relative to the first generated cluster; clusters outside [c0, c1) are never touched)
+        K.d0, K.nd, K.pair_off = dev.put(cl.d0), dev.put(cl.nd), dev.put(np.ascontiguousarray(np.clip(cl.pair_off - p0, 0, p1 - p0), np.int64))
         # pass 1: CIGAR words per cluster -> offsets
         d_ops = dev.alloc(8 * max(1, cl.n))
         K.cigar_off = 0
@@ -326,7 +333,8 @@ class WorkloadOnGpu:
         ops = dev.get(d_ops, (cl.n,), np.int64)
         cigar_off = np.zeros(cl.n + 1, np.int64)
         cigar_off[1:] = np.cumsum(ops)
-        self.n_cigar_total = int(cigar_off[-1])
+        cigar_off = np.clip(cigar_off - cigar_off[self.c0], 0, cigar_off[c1] - cigar_off[self.c0])
+        self.n_cigar_total = int(cigar_off[c1])
         self.n_row_units = n * UNITS
         K.cigar_off = self._d_cigar_off = dev.put(cigar_off)
         # pass 2: the records
@@ -339,8 +347,10 @@ class WorkloadOnGpu:
         self.out_ptrs["qlow"] = dev.alloc(4 * self.n_row_units + 64)
         for name in self.out_ptrs:
             setattr(O, name, self.out_ptrs[name])
-        small = np.nonzero(nseg <= 4096)[0].astype(np.int32)
-        big = np.nonzero(nseg > 4096)[0].astype(np.int32)
+        mine = np.zeros(cl.n, bool)
+        mine[self.c0: c1] = True
+        small = np.nonzero((nseg <= 4096) & mine)[0].astype(np.int32)
+        big = np.nonzero((nseg > 4096) & mine)[0].astype(np.int32)
         d_small, d_big = dev.put(small if small.size else np.zeros(1, np.int32)), dev.put(big if big.size else np.zeros(1, np.int32))
         dev.L.uzs_gen_reads_hip.restype = C.c_int
         dev.L.uzs_gen_reads_hip.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
@@ -350,7 +360,7 @@ class WorkloadOnGpu:
         if rc != 0:
             raise RuntimeError("uzs_gen_reads_hip failed: %d" % rc)
         nc = len(sc.contig_off) - 1
-        self.contig_off = reads_contig_off(cl, 0, cl.n, nc)
+        self.contig_off = reads_contig_off(cl, self.c0, c1, nc)
         self.max_span = np.full(nc, READLEN + 12, dtype=np.int32)
         self.d_rcontig_off = dev.put(self.contig_off)
         self.d_max_span = dev.put(self.max_span)
@@ -389,9 +399,13 @@ class WorkloadOnGpu:
         """The records of clusters [c0, c1) copied back to the host as a self-contained packed view (abi.Held): record
         numbers (mate links) are relative to the first record of c0, query-name ids stay global."""
         cl = self.cl
-        c1 = cl.n if c1 is None else c1
+        c1 = self.c1 if c1 is None else c1
+        c0 = max(c0, self.c0)
+        if not (self.c0 <= c0 <= c1 <= self.c1):
+            raise ValueError("clusters [%d, %d) are not in this table ([%d, %d))" % (c0, c1, self.c0, self.c1))
         nc = len(self.sc.contig_off) - 1
-        r0, r1 = int(2 * cl.pair_off[c0]), int(2 * cl.pair_off[c1])
+        pbase = int(cl.pair_off[self.c0])
+        r0, r1 = int(2 * (cl.pair_off[c0] - pbase)), int(2 * (cl.pair_off[c1] - pbase))
         if not hasattr(self, "_cigar_off_h"):
             self._cigar_off_h = self.dev.get(self._d_cigar_off, (cl.n + 1,), np.int64)
         g0, g1 = int(self._cigar_off_h[c0]), int(self._cigar_off_h[c1])

@@ -1,0 +1,198 @@
+"""Every BASELINE.json config at its FULL size, through the C ABI, against the CPU oracle:
+
+  configs[1]  1 k synthetic SNV DNMs, one 40 Mb contig, DNMs at least 12 kb apart, +-5 kb search distance  -> oracle on all 1 000
+  configs[2]  100 k SNV / INDEL DNMs over a 20 M-site whole-genome table, extended on                       -> resident AND staged pass
+              (the product's pipeline, unfazed_amd/pipeline.py), staged == resident on all 100 k, oracle on a >= 20 k-DNM sample of whole
+              read clusters (threads over cluster ranges, as bench.py's cpu_baseline), properties on all 100 k
+  configs[3]  the same 100 k cut by shard.shard_bounds(.., 8): the eight shards one after another on this one GPU through the rank code
+              `bench.py --gpus 8` runs (synth.benchload.BenchLoad(lo, hi) + pipeline.run_pipelined), concatenated == the one-GPU
+              result bit for bit.  This is a stand-in for the split, not a scaling measurement: no 8-GPU node exists in the pool.
+  configs[4]  10 k DEL / DUP events: SV read stage + allele balance (K6)                                      -> oracle on all 10 000
+
+(configs[0], the reference's own test data, is the CPU plumbing case: tests/test_cli_golden.py, tests/test_index_refdata.py.)
+Reference seams: snv_phaser.py:206-299, :244-298 (thread pool over DNMs); sv_phaser.py:357-423."""
+import argparse
+
+import numpy as np
+import pytest
+
+from unfazed_amd import abi, pipeline, shard
+
+pytestmark = pytest.mark.gpu
+
+MODE = abi.FIND_SECOND_WINDOW
+KEYS = ("status", "counts", "origin", "evidence")
+
+
+def _params(engine):
+    P = abi.make_params()  # the reference's CLI defaults
+    engine.set_params(P)
+    return P
+
+
+def _resident(engine, load, P, fid, rid):
+    engine.drop_derived()
+    dv = load.view_of(0, load.n)
+    r = engine.phase_raw(fid, rid, dv, P, MODE)
+    if load.cnv:
+        k = engine.phase_cnv(fid, dv, P, rb_counts=r["counts"], want_lists=False)
+        r = dict(status=r["status"], counts=r["counts"], origin=k["origin"], evidence=k["evidence"], etype=k["etype"], cnv_counts=k["cnv_counts"])
+    return r
+
+
+def _staged(engine, load, P, fid, **kw):
+    from unfazed_amd.engine import PinnedPool
+    pool = PinnedPool()
+    try:
+        chunks, st = load.stage(engine, P, MODE, fid, pool, **kw)
+        out = pipeline.run_pipelined(engine, P, MODE, load.n, chunks, cnv=load.cnv)
+        engine.sync()
+        return out, len(chunks), st
+    finally:
+        pool.free_all()
+
+
+def _oracle_args(cpu_dnms):
+    return argparse.Namespace(cpu_dnms=int(cpu_dnms))
+
+
+def _same(a, b, keys=KEYS, what=""):
+    for k in keys:
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        bad = np.nonzero((x != y).reshape(x.shape[0], -1).any(axis=1))[0]
+        assert bad.size == 0, "%s: `%s` differs for %d DNMs, first %s" % (what, k, bad.size, bad[:5].tolist())
+
+
+# ------------------------------------------------------------------------------------------------ configs[2] and configs[3]
+@pytest.fixture(scope="module")
+def snv100k(engine):
+    from synth.benchload import BenchLoad
+    load = BenchLoad(100_000, 20_000_000, workload="snv")
+    P = _params(engine)
+    sid, fid, rid = load.adopt(engine, P)
+    res = _resident(engine, load, P, fid, rid)
+    yield dict(load=load, P=P, sid=sid, fid=fid, rid=rid, res=res)
+    engine.free_reads(rid)
+    engine.free_sites(sid)
+    load.free()
+
+
+def test_config3_100k_resident_vs_oracle_and_properties(engine, snv100k):
+    import bench
+    w = snv100k
+    load, P, res = w["load"], w["P"], w["res"]
+    assert load.n == 100_000 and load.sc.n == 20_000_000
+    # oracle on the first >= 20 k DNMs (whole read clusters; their records regenerated on the host by the generator's gcc build)
+    cpu = bench.cpu_baseline(_oracle_args(20_000), load.wl, load.sc, load.ev, load.dn, load.per_ev, load.cl, load.cfg, P, load.cutoff, res,
+                             load.ev_vt, load.ev_refs, load.ev_alts, False, parity_only=True)
+    m = int(cpu["sample"].split()[1])
+    assert m >= 20_000
+    assert cpu["parity_mismatches_vs_gpu"] == 0, cpu
+    # properties on all 100 k ---------------------------------------------------------------------
+    status, origin = res["status"], res["origin"]
+    assert set(np.unique(status).tolist()) <= {abi.ST_OK, abi.ST_NO_CAND, abi.ST_NO_OVERLAP, abi.ST_REF_EXCEPTION}  # nothing refused for capacity
+    ok = status == abi.ST_OK
+    called = ok & ((origin == abi.OR_DAD) | (origin == abi.OR_MOM))
+    truth = np.where(load.ev.origin == 0, abi.OR_DAD, abi.OR_MOM)
+    assert called.sum() > 50_000
+    assert (origin[called] == truth[called]).mean() > 0.99  # (simulated truth: the haplotype that carries the DNM)
+    c = res["counts"]
+    assert (c[~ok] == 0).all()  # (an ST_OK DNM may still have no vote at all: reads matched sites, every vote skipped -- quirk Q21)
+    # the integer decision of summarize_record (unfazed.py:206-234) re-derived from the counts on the host
+    r = int(P.evidence_min_ratio)
+    dad = (c[:, 0] > 0) & (c[:, 0] >= r * c[:, 1])
+    mom = ~dad & (c[:, 1] > 0) & (c[:, 1] >= r * c[:, 0])
+    amb = ~dad & ~mom & (c[:, 0] > 0) & (c[:, 1] > 0)
+    want = np.where(dad, abi.OR_DAD, np.where(mom, abi.OR_MOM, np.where(amb, abi.OR_AMBIGUOUS, abi.OR_NONE)))
+    assert np.array_equal(np.where(ok, want, abi.OR_NONE), origin)
+    ev_want = np.where(dad, c[:, 2], np.where(mom, c[:, 3], np.where(amb, c[:, 0] + c[:, 1], 0)))
+    assert np.array_equal(np.where(ok, ev_want, 0), res["evidence"])
+    # a second pass over the same inputs gives the same answers
+    _same(_resident(engine, load, P, w["fid"], w["rid"]), res, what="second resident pass")
+
+
+def test_config3_100k_staged_equals_resident(engine, snv100k):
+    w = snv100k
+    out, n_chunks, st = _staged(engine, w["load"], w["P"], w["fid"])
+    assert n_chunks == 8  # shard.chunk_plan for 100 k DNMs
+    assert st["records"] > 50_000_000
+    _same(out, w["res"], what="staged (pipelined, 8 chunks) vs resident")
+
+
+def test_config4_eight_shards_one_after_another_equal_one_gpu(engine, snv100k):
+    """configs[3] on one GPU: rank r's code path (BenchLoad(lo, hi) -> adopt -> stage -> pipeline) for r = 0 .. 7, concatenated"""
+    from synth.benchload import BenchLoad
+    w = snv100k
+    P = w["P"]
+    b = shard.shard_bounds(100_000, 8)
+    assert b[0] == 0 and b[-1] == 100_000 and all(b[r + 1] - b[r] == 12_500 for r in range(8))
+    got = {k: [] for k in KEYS}
+    for r in range(8):
+        part = BenchLoad(100_000, 20_000_000, workload="snv", lo=b[r], hi=b[r + 1], share=w["load"])
+        try:
+            sid, fid, rid = part.adopt(engine, P)
+            assert part.cutoff == w["load"].cutoff  # every rank estimates the insert cutoff from the head of the same file
+            assert len(shard.chunk_plan(part.n)) - 1 == 3  # three chunks for a 12.5 k shard
+            out, n_chunks, _ = _staged(engine, part, P, fid)
+            assert n_chunks == 3
+            for k in KEYS:
+                got[k].append(out[k])
+            engine.free_reads(rid)
+            engine.free_sites(sid)
+        finally:
+            part.free()
+    merged = {k: np.concatenate(v) for k, v in got.items()}
+    _same(merged, w["res"], what="8 shards concatenated vs one GPU")
+
+
+# ------------------------------------------------------------------------------------------------ configs[4]
+def test_config5_10k_cnv_events_vs_oracle(engine):
+    import bench
+    from synth.benchload import BenchLoad
+    load = BenchLoad(10_000, 20_000_000, workload="cnv")
+    try:
+        P = _params(engine)
+        sid, fid, rid = load.adopt(engine, P)
+        res = _resident(engine, load, P, fid, rid)
+        keys = KEYS + ("etype", "cnv_counts")
+        # the staged pass: SV read stage per chunk + allele balance on the chunk's own site windows
+        out, n_chunks, _ = _staged(engine, load, P, fid, chunks=3, last_chunk=1.0)
+        assert n_chunks == 3
+        _same(out, res, keys, what="config 5 staged vs resident")
+        # oracle on ALL events: one range = the whole breakpoint list with one records table on the host
+        cpu = bench.cpu_baseline_cnv_ranges(_oracle_args(10_000), load.sc, load.ev, load.dn, load.cl, load.cfg, P, load.cutoff, res, parity_only=True, n_ranges=1)
+        assert int(cpu["sample"].split()[0]) == 10_000, cpu["sample"]
+        assert cpu["parity_mismatches_vs_gpu"] == 0, cpu
+        called = ((res["origin"] == abi.OR_DAD) | (res["origin"] == abi.OR_MOM)) & ((res["etype"] & abi.ET_AMBIG_FLAG) == 0)
+        truth = np.where(load.ev.origin == 0, abi.OR_DAD, abi.OR_MOM)
+        assert called.sum() > 8_000 and (res["origin"][called] == truth[called]).mean() > 0.99
+        engine.free_reads(rid)
+        engine.free_sites(sid)
+    finally:
+        load.free()
+
+
+# ------------------------------------------------------------------------------------------------ configs[1]
+def test_config2_1k_spaced_dnms_vs_oracle(engine):
+    """one contig "1" of 40 Mb, 1 k DNMs at least 12 kb apart, sites at 1 / 550 bp, 30x, +-5 kb"""
+    import bench
+    from synth.benchload import BenchLoad
+    load = BenchLoad(1_000, 40_000_000 // 550, workload="snv_spaced", contig_lens=[40_000_000], min_gap=12_000)
+    try:
+        assert len(load.sc.contig_off) == 2 and load.n == 1_000
+        assert (load.cl.nd == 1).all()  # no two read windows meet
+        P = _params(engine)
+        assert int(P.search_dist) == 5000
+        sid, fid, rid = load.adopt(engine, P)
+        res = _resident(engine, load, P, fid, rid)
+        cpu = bench.cpu_baseline(_oracle_args(1_000), load.wl, load.sc, load.ev, load.dn, load.per_ev, load.cl, load.cfg, P, load.cutoff, res,
+                                 load.ev_vt, load.ev_refs, load.ev_alts, False, parity_only=True)
+        assert int(cpu["sample"].split()[1]) == 1_000
+        assert cpu["parity_mismatches_vs_gpu"] == 0, cpu
+        out, n_chunks, _ = _staged(engine, load, P, fid)
+        _same(out, res, what="config 2 staged vs resident")
+        assert (res["status"] == abi.ST_OK).sum() > 300
+        engine.free_reads(rid)
+        engine.free_sites(sid)
+    finally:
+        load.free()

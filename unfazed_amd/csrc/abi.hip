@@ -735,6 +735,14 @@ static void check_packed_view(const uz_reads_packed_view *v) {
         UZ_REQUIRE(v->n_tup >= 1 && v->n_tup <= 65536 && v->tup_flag && v->tup_l_seq && v->tup_n_cigar && v->tup_mapq && v->tup_aux, UZ_E_ARG, "bad tup_* table");
         UZ_REQUIRE(!v->flag && !v->l_seq && !v->n_cigar && !v->mapq && !v->aux && !v->n_low, UZ_E_ARG, "tup is set: flag / l_seq / n_cigar / mapq / aux / n_low must be NULL");
     }
+    if (v->bl_n || v->tup_n_bl) {
+        UZ_REQUIRE(!(v->bl_n && v->tup_n_bl) && (!v->tup_n_bl || v->tup), UZ_E_ARG, "bl_n OR tup_n_bl (the latter with tup)");
+        UZ_REQUIRE((v->umask || v->tup_umask) && v_lists && (v->seq2 || v->n_seq_units == 0) && !v->seq4, UZ_E_ARG,
+                   "the list form of the bases (bl_*) needs unit masks, the list form of the qualities and two-bit rows");
+        UZ_REQUIRE(v->n_bl >= 0 && v->n_bl_units >= 0 && v->n_bl_units <= v->n_bl && (v->n_bl == 0 || (v->bl_pos && v->bl_code)), UZ_E_ARG, "bad bl_* columns");
+        UZ_REQUIRE(v->n_seq_units + v->n_bl_units <= v->n_row_units, UZ_E_ARG, "n_seq_units + n_bl_units must not exceed n_row_units");
+    } else
+        UZ_REQUIRE(v->n_bl == 0 && v->n_bl_units == 0, UZ_E_ARG, "n_bl / n_bl_units without bl_n / tup_n_bl");
     UZ_REQUIRE(v->cigar_compact ? v->n_cigar_omitted >= 0 && v->n_cigar_omitted <= v->n_segs : v->n_cigar_omitted == 0, UZ_E_ARG, "bad n_cigar_omitted");
     UZ_REQUIRE(v->n_cigar_total + v->n_cigar_omitted < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
 }
@@ -745,10 +753,15 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     r.live = true;
     r.n = v->n_segs; r.n_contigs = v->n_contigs; r.n_qnames = v->n_qnames;
     r.n_cigar_total = v->n_cigar_total + v->n_cigar_omitted; // the device's store holds every record's words
-    r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units;
+    const bool blf = v->bl_n != nullptr || v->tup_n_bl != nullptr; // bases of some records as lists: their units exist on the device only, behind the rows that travelled
+    r.n_bl = blf ? v->n_bl : 0; r.n_bl_units = blf ? v->n_bl_units : 0;
+    r.n_row_units = v->n_row_units; r.n_seq_units = v->n_seq_units + r.n_bl_units;
     r.n_cigar_staged = v->n_cigar_total;
     const bool ccompact = v->cigar_compact != 0;
     const size_t n = (size_t)r.n, nc = (size_t)r.n_cigar_total, nu = (size_t)r.n_row_units, ns = (size_t)r.n_seq_units, ncs = (size_t)v->n_cigar_total;
+    const size_t nsl = (size_t)v->n_seq_units; // units on the link
+    const size_t nbl = (size_t)r.n_bl, nblp = nbl * (v->bl_wide ? 2 : 1), nblc = (nbl + 3) / 4;
+    uint8_t *bl_n = nullptr, *t_nbl = nullptr, *bl_pos = nullptr, *bl_code = nullptr;
     uint32_t *cigar_staged = nullptr;
     const bool two_bit = v->seq2 != nullptr;
     const size_t ne = two_bit ? (size_t)v->n_exc : 0;
@@ -760,7 +773,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     uint8_t *n_low = nullptr, *qpos = nullptr;
     uint16_t *umask_in = nullptr;
     r.n_qlow_pos = lists ? v->n_qlow_pos : 0;
-    r.n_plane_units = lists ? v->n_seq_units : v->n_row_units;
+    r.n_plane_units = lists ? r.n_seq_units : v->n_row_units;
     uint32_t *cigar = nullptr; uint8_t *seq4 = nullptr, *qlow = nullptr, *seq2 = nullptr;
     uint32_t *exc_rec = nullptr; uint16_t *exc_pos = nullptr; uint8_t *exc_code = nullptr;
     int32_t *start, *end, *tlen, *mate; uint32_t *qname; uint16_t *flag, *l_seq, *n_cigar; uint8_t *mapq, *aux;
@@ -794,8 +807,9 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
             t_mq = cv.take<uint8_t>(nt); t_ax = cv.take<uint8_t>(nt); t_nl = cv.take<uint8_t>(nt); t_um = cv.take<uint16_t>(nt);
         }
         if (v->umask) umask_in = cv.take<uint16_t>(n);
+        if (blf) { bl_n = cv.take<uint8_t>(v->bl_n ? n : 0); t_nbl = cv.take<uint8_t>(v->tup_n_bl ? nt : 0); bl_pos = cv.take<uint8_t>(nblp); bl_code = cv.take<uint8_t>(nblc + 4); }
         if (two_bit) {
-            seq2 = cv.take<uint8_t>(ns * UZ_SEQ2_UNIT_BYTES);
+            seq2 = cv.take<uint8_t>(nsl * UZ_SEQ2_UNIT_BYTES);
             exc_rec = cv.take<uint32_t>(ne); exc_pos = cv.take<uint16_t>(ne); exc_code = cv.take<uint8_t>(ne);
         }
         const size_t nw = d16 ? 0 : n; // the plain wide columns
@@ -838,6 +852,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         col.tup_mapq = h2d(st, t_mq, v->tup_mapq, nt); col.tup_aux = h2d(st, t_ax, v->tup_aux, nt);
         if (v->tup_n_low) col.tup_n_low = h2d(st, t_nl, v->tup_n_low, nt);
         if (v->tup_umask) col.tup_umask = h2d(st, t_um, v->tup_umask, nt);
+        if (v->tup_n_bl) col.tup_n_bl = h2d(st, t_nbl, v->tup_n_bl, nt);
     } else {
         col.flag = h2d(st, flag, v->flag, n);
         col.l_seq = h2d(st, l_seq, v->l_seq, n); col.n_cigar = h2d(st, n_cigar, v->n_cigar, n);
@@ -853,11 +868,19 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     col.cigar_in = r.cigar;
     if (two_bit) { // half the bytes over the link; the header build expands them into seq4
         r.seq4 = seq4;
-        r.seq2_staged = h2d(st, seq2, v->seq2, ns * UZ_SEQ2_UNIT_BYTES);
+        r.seq2_staged = h2d(st, seq2, v->seq2, nsl * UZ_SEQ2_UNIT_BYTES);
         r.n_exc = (int64_t)ne;
         r.exc_rec = h2d(st, exc_rec, v->exc_rec, ne); r.exc_pos = h2d(st, exc_pos, v->exc_pos, ne); r.exc_code = h2d(st, exc_code, v->exc_code, ne);
     } else
         r.seq4 = h2d(st, seq4, v->seq4, ns * UZ_SEQ4_UNIT_BYTES);
+    if (blf) {
+        if (v->bl_n) col.bl_n = h2d(st, bl_n, v->bl_n, n);
+        col.bl_pos = h2d(st, bl_pos, v->bl_pos, nblp); col.bl_code = h2d(st, bl_code, v->bl_code, nblc);
+        col.bl_wide = v->bl_wide;
+        col.n_seq_link = (int64_t)nsl;
+        col.seq4_out = reinterpret_cast<uint32_t *>(seq4);
+        r.seq4 = seq4;
+    }
     r.qlow = qlow;
     if (lists) {
         if (!tupf) col.n_low = h2d(st, n_low, v->n_low, n);
@@ -879,6 +902,9 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         const void *dd[10] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8, col.mate_d8, col.qname_d8, col.pair_d8};
         for (int k = 0; k < 10; k++) r.col_d[k] = dd[k];
         r.col_nesc = col.n_esc16;
+        const void *bb[4] = {col.bl_n, col.tup_n_bl, col.bl_pos, col.bl_code};
+        for (int k = 0; k < 4; k++) r.col_b[k] = bb[k];
+        r.col_bwide = col.bl_wide;
     }
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
@@ -908,6 +934,9 @@ static void build_staged(uz_ctx *c, hipStream_t st, ReadsDev &r) {
     col.mate_d8 = (const int8_t *)r.col_d[7]; col.qname_d8 = (const int8_t *)r.col_d[8]; col.pair_d8 = (const uint8_t *)r.col_d[9];
     col.n_esc16 = r.col_nesc;
     col.qpos_wide = r.col_qwide;
+    col.bl_n = (const uint8_t *)r.col_b[0]; col.tup_n_bl = (const uint8_t *)r.col_b[1]; col.bl_pos = (const uint8_t *)r.col_b[2]; col.bl_code = (const uint8_t *)r.col_b[3];
+    col.bl_wide = r.col_bwide;
+    if (col.bl_form()) { col.n_seq_link = r.n_seq_units - r.n_bl_units; col.seq4_out = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(r.seq4)); }
     uz_build_records(c, st, r, col, r.build_scratch);
 }
 void uz_reads_make_ready(uz_ctx *c, ReadsDev &r) {
@@ -1167,6 +1196,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
         UZ_REQUIRE(v && id, UZ_E_ARG, "bad reads view");
         check_packed_view(v);
         UZ_REQUIRE(!v->cigar_compact, UZ_E_ARG, "uz_reads_adopt_device takes every CIGAR word (cigar_compact = 0): the caller's column IS the device's store");
+        UZ_REQUIRE(!v->bl_n && !v->tup_n_bl, UZ_E_ARG, "uz_reads_adopt_device takes base rows: the list form of the bases (bl_*) is a form of the host link");
         UZ_REQUIRE(((uintptr_t)v->qlow | (uintptr_t)v->seq4 | (uintptr_t)v->seq2 | (uintptr_t)v->cigar) % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
         ReadsDev r;
         r.live = true;

@@ -153,23 +153,30 @@ static inline int uz_pk_shift(int64_t n) { return (n >> UZ_PK_SHIFT_LARGE) >= 40
 // ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none); sixth and seventh, the
 // differences of start and of the name id to the record before (16-bit difference form: the columns are their running sums,
 // modulo 2^32; pair form: the sixth counts the NEW names, a new name's id being the number of new names before it); eighth and
-// ninth, the FIRST and SECOND records of the pair form (their totals must agree)
-#define UZ_PK_SUMS 9
+// ninth, the row units and the listed bases of the records whose bases came as a list (bl_*: their units are laid out behind the
+// ones that travelled as rows); tenth and eleventh, the FIRST and SECOND records of the pair form (their totals must agree)
+#define UZ_PK_SUMS 11
+#define UZ_PK_SCANNED 9 // the running sums the header build needs per record (the last two are totals only)
 // um: which units of the record's rows were staged (UZ_UMASK_ALL: all of them)
-__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t (&v)[UZ_PK_SUMS]) {
+__device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t nb, uint32_t (&v)[UZ_PK_SUMS]) {
     v[4] = (aux & UZ_AUX_SIMPLE_MASK) ? 0u : nc;
-    v[5] = 0u; v[6] = 0u; v[7] = 0u; v[8] = 0u; // (set by the callers from the difference columns)
-    v[0] = nc; v[1] = UZ_ROW_UNITS(ls); v[2] = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? v[1] : (uint32_t)__popc(um));
+    v[5] = 0u; v[6] = 0u; v[9] = 0u; v[10] = 0u; // (set by the callers from the difference columns)
+    const uint32_t staged = (aux & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? UZ_ROW_UNITS(ls) : (uint32_t)__popc(um));
+    v[0] = nc; v[1] = UZ_ROW_UNITS(ls);
+    v[2] = nb ? 0u : staged; // units that travelled as rows
+    v[7] = nb ? staged : 0u; // units of a record whose bases came as a list
+    v[8] = nb;
     v[3] = (nl >= 0 && !(aux & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
 }
 // the small columns of record i, plain or through the dictionary (uz_reads_packed_view.tup)
-struct RecSmall { uint32_t flag, ls, nc, mapq, aux, um; int nl; };
+struct RecSmall { uint32_t flag, ls, nc, mapq, aux, um; int nl; uint32_t nb; };
 // ... of record i whose dictionary index is already at hand
 __device__ __forceinline__ RecSmall rec_small_of(const RecColumns &c, int64_t i, uint32_t t) {
     RecSmall r;
     r.flag = c.tup_flag[t]; r.ls = c.tup_l_seq[t]; r.nc = c.tup_n_cigar[t]; r.mapq = c.tup_mapq[t]; r.aux = c.tup_aux[t];
     r.nl = c.lists ? (int)c.tup_n_low[t] : -1;
     r.um = c.tup_umask ? (uint32_t)c.tup_umask[t] : (c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL);
+    r.nb = c.tup_n_bl ? (uint32_t)c.tup_n_bl[t] : (c.bl_n ? (uint32_t)c.bl_n[i] : 0u);
     return r;
 }
 __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
@@ -179,10 +186,12 @@ __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
         r.flag = c.tup_flag[t]; r.ls = c.tup_l_seq[t]; r.nc = c.tup_n_cigar[t]; r.mapq = c.tup_mapq[t]; r.aux = c.tup_aux[t];
         r.nl = c.lists ? (int)c.tup_n_low[t] : -1;
         r.um = c.tup_umask ? (uint32_t)c.tup_umask[t] : (c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL);
+        r.nb = c.tup_n_bl ? (uint32_t)c.tup_n_bl[t] : (c.bl_n ? (uint32_t)c.bl_n[i] : 0u);
     } else {
         r.flag = c.flag[i]; r.ls = c.l_seq[i]; r.nc = c.n_cigar[i]; r.mapq = c.mapq[i]; r.aux = c.aux[i];
         r.nl = c.lists ? (int)c.n_low[i] : -1;
         r.um = c.umask ? (uint32_t)c.umask[i] : UZ_UMASK_ALL;
+        r.nb = c.bl_n ? (uint32_t)c.bl_n[i] : 0u;
     }
     return r;
 }
@@ -232,7 +241,7 @@ __device__ __forceinline__ uint32_t start_diff(const RecColumns &c, int64_t i) {
 __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
     const int t = threadIdx.x;
-    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // four records per lane at a time: their column bytes are requested together, then their dictionary entries, then the sums --
     // three round trips to memory for four records instead of three for each
     constexpr int U = 4;
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
             if (!in[u]) continue;
             const int64_t i = idx[u];
             uint32_t v[UZ_PK_SUMS];
-            pk_vals(r[u].nc, r[u].ls, r[u].aux, r[u].nl, r[u].um, v);
+            pk_vals(r[u].nc, r[u].ls, r[u].aux, r[u].nl, r[u].um, r[u].nb, v);
             if (c.diff_form()) {
                 v[5] = c.start_d8 ? (sd[u] == UZ_D8_ESC ? (uint32_t)esc16_of(c, i, 0) : sd[u]) : start_diff(c, i);
                 v[6] = c.pair_d8 ? ((pd[u] != UZ_P8_SECOND && pd[u] != UZ_P8_SECOND_TLEN && pd[u] != UZ_P8_OLD) ? 1u : 0u) : qname_diff(c, i);
             }
-            if (c.pair_d8) { v[7] = (pd[u] >= 1u && pd[u] <= UZ_P8_MAX_DIST) ? 1u : 0u; v[8] = (pd[u] == UZ_P8_SECOND || pd[u] == UZ_P8_SECOND_TLEN) ? 1u : 0u; }
+            if (c.pair_d8) { v[9] = (pd[u] >= 1u && pd[u] <= UZ_P8_MAX_DIST) ? 1u : 0u; v[10] = (pd[u] == UZ_P8_SECOND || pd[u] == UZ_P8_SECOND_TLEN) ? 1u : 0u; }
 #pragma unroll
             for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += v[k];
         }
@@ -286,12 +295,13 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
 // one workgroup: exclusive scan of the block sums in place; the totals are checked against what the view declared
 __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
                                                         unsigned long long want_units, unsigned long long want_seq, unsigned long long want_qpos,
-                                                        unsigned long long want_staged /* ~0: not compact */, int32_t *hflags) {
+                                                        unsigned long long want_staged /* ~0: not compact */, unsigned long long want_bl_units,
+                                                        unsigned long long want_bl, int32_t *hflags) {
     __shared__ unsigned long long wpart[UZ_PK_SUMS][16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int64_t chunk = (nb + 1023) / 1024;
     const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, inc[UZ_PK_SUMS];
+    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, inc[UZ_PK_SUMS];
     for (int64_t i = lo; i < hi; i++)
         for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
 #pragma unroll
@@ -313,9 +323,9 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
     }
     if (t == 0) {
         if (tot[0] != want_cigar || tot[1] != want_units || tot[2] != want_seq || tot[3] != want_qpos || tot[0] > 0xFFFFFFFFULL || tot[1] > 0xFFFFFFFFULL ||
-            (want_staged != ~0ULL && tot[4] != want_staged))
+            (want_staged != ~0ULL && tot[4] != want_staged) || tot[7] != want_bl_units || tot[8] != want_bl || tot[1] + tot[7] > 0xFFFFFFFFULL)
             hflags[0] = 1;
-        if (tot[7] != tot[8]) hflags[0] = 8; // pair form: as many SECOND records as FIRST ones (k_pair_link checks that they are each other's)
+        if (tot[9] != tot[10]) hflags[0] = 8; // pair form: as many SECOND records as FIRST ones (k_pair_link checks that they are each other's)
     }
     for (int64_t i = lo; i < hi; i++)
         for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = sums[UZ_PK_SUMS * i + k]; sums[UZ_PK_SUMS * i + k] = v[k]; v[k] += x; }
@@ -323,11 +333,11 @@ __global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned lon
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
                                                   uint16_t *qs, int32_t *hflags) {
-    __shared__ uint32_t wsum[7][4];
+    __shared__ uint32_t wsum[UZ_PK_SCANNED][4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    unsigned long long run[7];
+    unsigned long long run[UZ_PK_SCANNED];
 #pragma unroll
-    for (int k = 0; k < 7; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
+    for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
     // the dictionary index of the NEXT round's record is requested a round ahead: its table entries can then be fetched as soon as
     // the round begins, instead of after a round trip of their own
     uint32_t tp_next = 0;
@@ -341,36 +351,35 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
         const bool in = i < n;
         const uint32_t tp = tp_next;
         if (c.tup && it + 1 < rounds && i + 256 < n) tp_next = c.tup[i + 256];
-        RecSmall rs = {0u, 0u, 0u, 0u, 0u, UZ_UMASK_ALL, c.lists ? 0 : -1};
+        RecSmall rs = {0u, 0u, 0u, 0u, 0u, UZ_UMASK_ALL, c.lists ? 0 : -1, 0u};
         if (in) rs = c.tup ? rec_small_of(c, i, tp) : rec_small(c, i);
         const uint32_t nc = rs.nc, ls = rs.ls, ax = rs.aux;
         const int nl = rs.nl;
-        const uint32_t um = rs.um;
-        uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SUMS];
-        pk_vals(nc, ls, ax, nl, um, v);
+        const uint32_t um = rs.um, nb = rs.nb;
+        uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SCANNED];
+        pk_vals(nc, ls, ax, nl, um, nb, v);
         if (c.diff_form() && in) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
 #pragma unroll
-        for (int k = 0; k < 7; k++) { // (the eighth and ninth sum are totals only)
-            uint32_t x = v[k];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
-            inc[k] = x;
-        }
+        for (int k = 0; k < UZ_PK_SCANNED; k++) inc[k] = wv_incl_scan(v[k]); // (the last two sums are totals only; DPP scans: wg.hpp)
         __syncthreads(); // wsum of the previous round has been read
         if (lane == 63) {
 #pragma unroll
-            for (int k = 0; k < 7; k++) wsum[k][wv] = inc[k];
+            for (int k = 0; k < UZ_PK_SCANNED; k++) wsum[k][wv] = inc[k];
         }
         __syncthreads();
-        uint32_t pre[7] = {0, 0, 0, 0, 0, 0, 0}, tot[7] = {0, 0, 0, 0, 0, 0, 0};
+        uint32_t pre[UZ_PK_SCANNED], tot[UZ_PK_SCANNED];
 #pragma unroll
-        for (int k = 0; k < 7; k++)
+        for (int k = 0; k < UZ_PK_SCANNED; k++) {
+            pre[k] = 0; tot[k] = 0;
 #pragma unroll
             for (int w = 0; w < 4; w++) { if (w < wv) pre[k] += wsum[k][w]; tot[k] += wsum[k][w]; }
+        }
         if (in) {
             RecA A;
             RecB B;
-            const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : (uint32_t)(run[2] + pre[2] + inc[2] - v[2]);
+            // base rows: the units that travelled as rows in link order, then the units of the records whose bases came as a list
+            const uint32_t sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF
+                                : (nb ? (uint32_t)((unsigned long long)c.n_seq_link + run[7] + pre[7] + inc[7] - v[7]) : (uint32_t)(run[2] + pre[2] + inc[2] - v[2]));
             const uint32_t cg = (uint32_t)(run[0] + pre[0] + inc[0] - v[0]);
             // the four wide columns: plain, or from their 16-bit differences (start and name id: running sums, this record included)
             int32_t st0, tl0, mt0;
@@ -439,8 +448,44 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             rb[i] = B;
             fm[i] = uz_pack_fm(rs.flag, rs.mapq, ax);
             const int units = (int)UZ_ROW_UNITS(ls);
-            umask_out[i] = (uint16_t)um;
+            umask_out[i] = (uint16_t)(nb ? (um | UZ_UMASK_LISTED) : um);
             if (um != UZ_UMASK_ALL && (units > 15 || (um >> units) != 0u)) hflags[0] = 5; // a unit beyond the read, or a read too long for a mask
+            if (nb) {
+                // The listed bases -> the record's rows (one 16-byte row per unit of its mask; bases that were not listed stay code 0, which
+                // the readers of a listed record refuse: phase_body.hpp uz_base).  Positions ascend, so the units come in row order.
+                if (um == UZ_UMASK_ALL || (ax & UZ_AUX_NO_SEQ)) hflags[0] = 9;
+                else {
+                    const unsigned long long at = run[8] + pre[8] + inc[8] - v[8];
+                    uint32_t w4r[4] = {0u, 0u, 0u, 0u};
+                    int cur = -1, last = -1;
+                    uint32_t row = sq, seen = 0u;
+                    bool bad = false;
+                    for (uint32_t e = 0; e < nb; e++) {
+                        const unsigned long long g = at + e;
+                        const int pos = c.bl_wide ? ((int)c.bl_pos[2 * g] | ((int)c.bl_pos[2 * g + 1] << 8)) : (int)c.bl_pos[g];
+                        const uint32_t code = ((uint32_t)c.bl_code[g >> 2] >> (2u * (uint32_t)(g & 3ULL))) & 3u;
+                        const int u = pos >> 5;
+                        bad |= pos <= last || pos >= (int)ls || u > 14 || !((um >> u) & 1u);
+                        last = pos;
+                        if (u != cur) {
+                            if (cur >= 0) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) { c.seq4_out[4 * (size_t)row + q] = w4r[q]; w4r[q] = 0u; }
+                                row++;
+                            }
+                            cur = u;
+                            seen |= 1u << (u & 15);
+                        }
+                        const int k32 = pos & 31; // byte k32 >> 1 of the row, high nibble when k32 is even
+                        w4r[k32 >> 3] |= (1u << code) << (8 * ((k32 >> 1) & 3) + ((k32 & 1) ? 0 : 4));
+                    }
+                    if (cur >= 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) c.seq4_out[4 * (size_t)row + q] = w4r[q];
+                    }
+                    if (bad || seen != um) hflags[0] = 9; // a position outside the mask / not ascending, or a unit of the mask without a listed base
+                }
+            }
             if (nl >= 0) {
                 // list form of the staged plane: the count as it is; a quality row (at the record's base-row position) only for a
                 // record whose bits can be asked for, written here from its listed positions
@@ -500,7 +545,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             qs[i] = uz_qs_word(rs.flag, ax, rs.mapq, low_for_qc, (int)nc, cig_nonmatch, cig_none);
         }
 #pragma unroll
-        for (int k = 0; k < 7; k++) run[k] += tot[k];
+        for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] += tot[k];
     }
 }
 
@@ -667,8 +712,8 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     }
     hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
-                       (unsigned long long)r.n_row_units, (unsigned long long)r.n_seq_units, (unsigned long long)r.n_qlow_pos,
-                       col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, c->hflags);
+                       (unsigned long long)r.n_row_units, (unsigned long long)(r.n_seq_units - r.n_bl_units), (unsigned long long)r.n_qlow_pos,
+                       col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, (unsigned long long)r.n_bl_units, (unsigned long long)r.n_bl, c->hflags);
     hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
                        (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, c->hflags);
     if (col.pair_d8)
@@ -676,18 +721,20 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
                            c->hflags);
     const int64_t nk = (r.n >> 12) + 2;
     hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
-    if (r.seq2_staged) { // the table arrived with two-bit base rows: expand them (and patch the listed bases) into seq4
-        if (r.n_seq_units > 0) {
-            const size_t nu = (size_t)r.n_seq_units;
-            hipLaunchKernelGGL(k_expand_seq2, dim3((unsigned)std::min<size_t>((nu + 255) / 256, 16384)), dim3(256), 0, st,
-                               (const unsigned long long *)r.seq2_staged, (uint4 *)const_cast<uint8_t *>(r.seq4), nu);
-            if (r.n_exc > 0)
-                hipLaunchKernelGGL(k_patch_exc, dim3((unsigned)((r.n_exc + 255) / 256)), dim3(256), 0, st, r.n_exc, r.exc_rec, r.exc_pos, r.exc_code,
-                                   (const RecA *)r.rec_a, (const RecB *)r.rec_b, (const uint16_t *)r.umask, (int64_t)r.n,
-                                   (uint32_t *)const_cast<uint8_t *>(r.seq4), c->hflags);
-        }
-        r.seq2_staged = nullptr;
+    // the table arrived with two-bit base rows: expand them into seq4 (the units of list-form records, behind them, were written by
+    // k_pack_rec); then the listed bases that are not A/C/G/T, of either kind of record
+    if (r.seq2_staged && r.n_seq_units - r.n_bl_units > 0) {
+        const size_t nu = (size_t)(r.n_seq_units - r.n_bl_units);
+        hipLaunchKernelGGL(k_expand_seq2, dim3((unsigned)std::min<size_t>((nu + 255) / 256, 16384)), dim3(256), 0, st,
+                           (const unsigned long long *)r.seq2_staged, (uint4 *)const_cast<uint8_t *>(r.seq4), nu);
     }
+    if (r.n_exc > 0 && r.exc_rec) {
+        hipLaunchKernelGGL(k_patch_exc, dim3((unsigned)((r.n_exc + 255) / 256)), dim3(256), 0, st, r.n_exc, r.exc_rec, r.exc_pos, r.exc_code,
+                           (const RecA *)r.rec_a, (const RecB *)r.rec_b, (const uint16_t *)r.umask, (int64_t)r.n,
+                           (uint32_t *)const_cast<uint8_t *>(r.seq4), c->hflags);
+        r.n_exc = 0;
+    }
+    r.seq2_staged = nullptr;
     UZ_HIP(hipGetLastError());
 }
 
@@ -763,6 +810,7 @@ static void phase_check_upload_flags(uz_ctx *c) {
                                   : f == 6 ? "aux of the reads view: a simple-CIGAR code on a record whose n_cigar is not 1"
                                   : f == 7 ? "mate_d / esc16_* of the reads view: a mate index outside the table"
                                   : f == 8 ? "pair_d8 of the reads view: a SECOND record that no FIRST record names, or one that two of them name"
+                                  : f == 9 ? "bl_* of the reads view: a listed base outside the record's unit mask or its length, positions not ascending, a unit of the mask without a listed base, or a list on a record without a mask / without bases"
                                            : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
 }
@@ -988,7 +1036,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             if (c->hflags[1]) {
                 const int f = c->hflags[1];
                 c->hflags[1] = 0;
-                throw UzError{UZ_E_STATE, f == 3 ? "the read stage asked for a base (or its quality bit) in a 32-base unit that was not staged (umask): the fetch points that staged the table do not cover this batch"
+                throw UzError{UZ_E_STATE, f == 4 ? "the read stage asked for a base of a record whose bases were staged as a list (bl_*), and the list does not hold it: the fetch points that staged the table do not cover this batch"
+                                        : f == 3 ? "the read stage asked for a base (or its quality bit) in a 32-base unit that was not staged (umask): the fetch points that staged the table do not cover this batch"
                                         : f == 2 ? "the read stage asked for a base-quality bit of a record staged without its quality row (more than 10 low-quality bases, or no bases): such a record can never pass goodread -- the staging rule and the kernel disagree"
                                                  : "the read stage asked for the bases of a record staged without them (UZ_AUX_NO_SEQ): the selection that staged the table does not cover this batch's fetches"};
             }

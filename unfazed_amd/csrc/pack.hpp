@@ -33,11 +33,12 @@ UZP_HD uint8_t uz_ascii_nt16(uint8_t ch) {
     }
 }
 
-// base k of the row that starts at unit `unit` (ASCII)
-UZP_HD uint8_t uz_seq4_base(const uint8_t *seq4, uint32_t unit, int k) {
+// base k of the row that starts at unit `unit`: its BAM code / its character
+UZP_HD uint32_t uz_seq4_code(const uint8_t *seq4, uint32_t unit, int k) {
     const uint8_t b = seq4[(size_t)unit * UZ_SEQ4_UNIT_BYTES + (size_t)(k >> 1)];
-    return uz_nt16_ascii((k & 1) ? (uint32_t)(b & 15u) : (uint32_t)(b >> 4));
+    return (k & 1) ? (uint32_t)(b & 15u) : (uint32_t)(b >> 4);
 }
+UZP_HD uint8_t uz_seq4_base(const uint8_t *seq4, uint32_t unit, int k) { return uz_nt16_ascii(uz_seq4_code(seq4, unit, k)); }
 // 1 iff the quality of base k is below the threshold the plane was built with
 UZP_HD uint32_t uz_qlow_bit(const uint8_t *qlow, uint32_t unit, int k) {
     return (uint32_t)(qlow[(size_t)unit * UZ_QLOW_UNIT_BYTES + (size_t)(k >> 3)] >> (k & 7)) & 1u;

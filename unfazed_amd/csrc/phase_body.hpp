@@ -434,7 +434,10 @@ UZ_DEV uint8_t uz_base(const RD &R, RowRef row, int k) {
     if (row.off == UZ_NO_SEQ_OFF) { *R.err = 1; return 0; } // the host left the bases out: its reach rule and the kernel disagree
     uint32_t u;
     if (!uz_unit_of(row.umask, k, u)) { *R.err = 3; return 0; } // ... or this 32-base unit of them
-    return uz_seq4_base(R.seq4, row.off + u, k & 31);
+    const uint32_t code = uz_seq4_code(R.seq4, row.off + u, k & 31);
+    // a record whose bases came as a list (UZ_UMASK_LISTED): a base nobody listed reads as code 0, which a listed base never is
+    if (code == 0u && (row.umask & UZ_UMASK_LISTED) && row.umask != UZ_UMASK_ALL) { *R.err = 4; return 0; }
+    return uz_nt16_ascii(code);
 }
 UZ_DEV bool uz_qual_low(const RD &R, RowRef row, int k) {
     if (row.off == UZ_NO_QLOW_OFF) { *R.err = 2; return false; } // a bit of a record that cannot be "good": the staging rule and the kernel disagree

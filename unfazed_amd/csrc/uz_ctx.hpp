@@ -169,7 +169,11 @@ struct ReadsDev {
     const uint16_t *exc_pos = nullptr;
     const uint8_t *exc_code = nullptr;
     int64_t n_exc = 0;
-
+    // bases as lists (uz_types.h bl_*): the listed bases and the row units of the records that carry them (inside n_seq_units: their units
+    // lie behind the n_seq_units - n_bl_units that travelled as rows); bl_n / tup_n_bl / bl_pos / bl_code for the deferred header build
+    int64_t n_bl = 0, n_bl_units = 0;
+    const void *col_b[4] = {nullptr, nullptr, nullptr, nullptr};
+    int32_t col_bwide = 0;
 };
 
 // DNM batch staged on the device
@@ -310,6 +314,14 @@ struct RecColumns {
     const uint16_t *tup = nullptr, *tup_flag = nullptr, *tup_l_seq = nullptr, *tup_n_cigar = nullptr;
     const uint8_t *tup_mapq = nullptr, *tup_aux = nullptr, *tup_n_low = nullptr;
     const uint16_t *tup_umask = nullptr;
+    // bases as lists (uz_types.h: bl_*): per record the number of listed bases (plain column or through the dictionary), their query indices and
+    // two-bit codes; seq4_out: the device's base rows (the header build writes the units of the listed records, behind the n_seq_link units that
+    // travelled as rows)
+    const uint8_t *bl_n = nullptr, *tup_n_bl = nullptr, *bl_pos = nullptr, *bl_code = nullptr;
+    int32_t bl_wide = 0;
+    int64_t n_seq_link = 0;
+    uint32_t *seq4_out = nullptr;
+    __host__ __device__ bool bl_form() const { return bl_n != nullptr || tup_n_bl != nullptr; }
     // 16-bit difference form of start / tlen / mate / qname (start_d set: the plain four are null)
     const int16_t *start_d = nullptr, *tlen_s = nullptr, *mate_d = nullptr, *qname_d = nullptr;
     const uint8_t *start_d8 = nullptr; // the start differences in eight bits (then start_d is null)

@@ -14,7 +14,7 @@ from . import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UZ_HIP_LIB", os.path.join(_HERE, "libunfazed_hip.so"))
 
-K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_SEG_QC, K_PHASE, K_SEG_QC_PASS, K_SIZING, K_CNV = 0, 1, 2, 3, 4, 5, 6, 7
+K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_PHASE, K_SIZING, K_CNV = 0, 1, 2, 3, 4, 5
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",

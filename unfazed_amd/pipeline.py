@@ -1,0 +1,117 @@
+"""The staged pass of the read stage as a pipeline over chunks of DNMs -- the product's route for a batch larger than one chunk
+(hostpath.run_read_phasing) and the thing bench.py measures.
+
+Reference seam: snv_phaser.py:206-299 / sv_phaser.py:176-266 run one task per DNM on a thread pool; each task opens the sites
+file and the alignment file for its own window.  Here a batch is cut into chunks (shard.chunk_plan) and every chunk goes through
+    site stage   its windows' site + genotype columns up (copy stream), K1 + K2, het lists back: they tell the decoder which fetches the
+                 read stage will make -- the ONE host round trip of a chunk
+    records      the records those fetches return (+ mates), in the link form, queued on the copy stream
+    read stage   queued on the compute stream (uz_phase_begin), picked up later (uz_phase_end)
+    (config 5)   allele balance of the chunk's events on its own windows, merged with the read-backed counts
+with the stages of neighbouring chunks overlapped: the site windows travel two chunks ahead of their find, the read stage of chunk
+k - 1 is queued before the host waits for the het lists of chunk k + 1, and its results are taken when that wait is over.
+
+A chunk is a dict:
+    a, b        its DNMs are [a, b) of the batch (results are written there)
+    dnms        abi.dnms_view of them
+    sites       (held sites view, host site columns incl. "gt", genotype columns {"rd", "ad", "gq"} (8- or 16-bit), wide list or None), all in
+                pinned memory -- or None when the caller's family handle `fid` covers the chunk (one site table for the whole batch)
+    records     the chunk's records in the link form (abi.Held of uz_reads_packed_view, pinned) -- or a callable returning it, called
+                when the chunk's het lists are known: records(k, het_off, het_idx) -> abi.Held   (a decoder working from files)
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None) -> Dict[str, np.ndarray]:
+    """One pass over the batch -> per-DNM status / counts / origin / evidence (+ etype / cnv_counts for cnv)."""
+    out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32), evidence=np.empty(n, np.int32))
+    if cnv:
+        out.update(etype=np.empty(n, np.int32), cnv_counts=np.empty((n, 2), np.int32))
+    K = len(chunks)
+    if K == 0:
+        return out
+    sids, fids, rids = [None] * K, [fid] * K, [None] * K
+    finds = [None] * K
+    own_sites = [c.get("sites") is not None for c in chunks]
+
+    def site_stage(k):  # queued on the copy stream (in front of the records of chunk k - 1 ... k): no host wait
+        if not own_sites[k]:
+            return
+        held, hs_k, hg_k, wide_k = chunks[k]["sites"]
+        sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"], wide_k)
+
+    def read_stage_begin(k):  # queued on the compute stream (waits there for the chunk's records): no host wait
+        eng.phase_begin(fids[k], rids[k], chunks[k]["dnms"], P, mode)
+
+    pending = {}
+
+    def read_stage_end(k):
+        pending[k] = eng.phase_end(fids[k], rids[k], chunks[k]["dnms"], P, mode)
+        if not cnv:
+            finish(k)
+
+    def cnv_stage(k):  # config 5: K6 over the chunk's events, merged with their read-backed counts as summarize_record merges them
+        rr = pending[k]
+        kk = eng.phase_cnv(fids[k], chunks[k]["dnms"], P, rb_counts=rr["counts"], want_lists=False)
+        pending[k] = dict(status=rr["status"], counts=rr["counts"], origin=kk["origin"], evidence=kk["evidence"], etype=kk["etype"], cnv_counts=kk["cnv_counts"])
+        finish(k)
+
+    def finish(k):
+        a, b = chunks[k]["a"], chunks[k]["b"]
+        rr = pending.pop(k)
+        for key in out:
+            out[key][a:b] = rr[key]
+        eng.free_reads(rids[k])
+        if own_sites[k]:
+            eng.free_sites(sids[k])
+
+    tr = [time.perf_counter()] if trace is not None else None
+
+    def tick():
+        if tr is not None:
+            tr.append(time.perf_counter())
+    # The read stage of chunk k - 1 is queued (uz_phase_begin) before the host waits for the het lists of chunk k + 1: that wait
+    # -- the ONE host round trip per chunk -- then runs behind the read stage's kernels instead of beside an idle device, and the
+    # read stage's results are there when it returns (uz_phase_end).  The site windows travel two chunks ahead of their find, so
+    # the link does not idle through that round trip either.  (config 5: the allele-balance stage of chunk k - 2 is queued behind
+    # the read stage of chunk k - 1, and waited for there.)
+    site_stage(0)
+    if K > 1:
+        site_stage(1)
+    tick()
+    for k in range(K):
+        finds[k] = eng.find(fids[k], chunks[k]["dnms"], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
+        tick()
+        if k >= 2:
+            read_stage_end(k - 2)
+        tick()
+        if k >= 1:
+            read_stage_begin(k - 1)
+        tick()
+        rec = chunks[k]["records"]
+        if callable(rec):
+            rec = rec(k, finds[k][3], finds[k][4])
+        finds[k] = None
+        rids[k] = eng.upload_reads_packed(rec)
+        if k + 2 < K:
+            site_stage(k + 2)
+        if cnv and k >= 2:
+            cnv_stage(k - 2)
+        tick()
+    if K >= 2:
+        read_stage_end(K - 2)
+    read_stage_begin(K - 1)
+    if cnv and K >= 2:
+        cnv_stage(K - 2)
+    read_stage_end(K - 1)
+    if cnv:
+        cnv_stage(K - 1)
+    tick()
+    if tr is not None:
+        trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
+    return out
