@@ -217,6 +217,11 @@ int64_t uz_select_n_esc16_pair8(const uz_select *s);
 int64_t uz_select_n_new_names(const uz_select *s);
 int uz_select_qname_map(const uz_select *s, uint32_t *out /* [n_new_names] */);
 int64_t uz_select_n_seq_units(const uz_select *s);
+/* the list form of the bases (uz_types.h bl_*; planned with unit_masks & 4 on a two-bit source): listed bases (-1: planned without), the row units
+ * of the records that travel so (not counted in uz_select_n_seq_units), and whether their positions need two bytes */
+int64_t uz_select_n_bl(const uz_select *s);
+int64_t uz_select_n_bl_units(const uz_select *s);
+int uz_select_bl_wide(const uz_select *s);
 int64_t uz_select_n_exc(const uz_select *s); /* entries of the exc_* columns (0 for a source with four-bit rows) */
 int64_t uz_select_n_qlow_pos(const uz_select *s); /* entries of qlow_pos when the output takes the quality plane as lists */
 int uz_select_qlow_pos_wide(const uz_select *s);  /* 1 when a kept read is longer than 256 bases */
@@ -251,6 +256,8 @@ int uz_io_cpu_quota(void);            /* CPUs the container's cgroup grants (cpu
 #define UZ_STAGE_UNIT_MASKS 2 /* only the 32-base units that hold a fetched position (+ extra[f] bases on) are staged */
 #define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (no unit masks then) */
 #define UZ_STAGE_WIDE_NO_UNITS 8 /* with unit masks: a fetch wider than two bases stages no unit (SV batches; uz_reads_select_plan: unit_masks = 3) */
+#define UZ_STAGE_BASE_LISTS 16  /* with unit masks: a record whose fetches name single positions sends those bases as a list instead of the
+                                 * units they lie in (uz_types.h: bl_*; uz_reads_select_plan: unit_masks & 4) */
 /* fetches (tid, lo, hi[, extra]) as staging.fetch_points lists them; min_base_qual = --min-gt-qual.  UZ_IO_E_RANGE when the batch
  * holds more than 65536 combinations of the small columns (stage it through the table form then). */
 int uz_bam_stage_plan(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra,
@@ -269,8 +276,9 @@ int uz_stage_set_inflated(uz_stage *s, const uint8_t *inflated);
 int uz_bam_stage_finish(uz_stage *s);
 /* [0] records, [1] CIGAR words that travel, [2] words left home (simple records), [3] row units, [4] staged base units, [5] listed
  * bases (exc_*), [6] listed low-quality positions, [7] qlow_pos_wide, [8] dictionary entries, [9] escapes, [10] query names,
- * [11] 1 when the dictionary carries unit masks */
-void uz_stage_sizes(const uz_stage *s, int64_t out[12]);
+ * [11] 1 when the dictionary carries unit masks, [12] 1 when it carries list counts (tup_n_bl), [13] listed bases of the list form (bl_pos),
+ * [14] row units of the records that travel so (n_bl_units) */
+void uz_stage_sizes(const uz_stage *s, int64_t out[16]);
 /* [0] compressed bytes read, [1] BGZF blocks read, [2] records walked, [3] records kept, [4] reach intervals, [5] mates looked
  * up through the index, [6] blocks taken from the pre-inflated buffer, [7] compressed bytes of the gathered blocks */
 void uz_stage_io_stats(const uz_stage *s, int64_t out[8]);

@@ -24,7 +24,7 @@ def build():
     return so
 
 
-def phase(params, sites, reads, dnms, found, no_seq=None, umask=None):
+def phase(params, sites, reads, dnms, found, no_seq=None, umask=None, bl=None):
     """Same result layout as oracle.phase(..., keep_lists=True) plus groups."""
     global _LIB
     if _LIB is None:
@@ -49,13 +49,17 @@ def phase(params, sites, reads, dnms, found, no_seq=None, umask=None):
         no_seq = np.ascontiguousarray(no_seq, np.uint8)
     if umask is not None:
         umask = np.ascontiguousarray(umask, np.uint16)
+    bl_off = bl_pos = None
+    if bl is not None:  # (offsets [n + 1], positions): the listed bases of every record (with umask)
+        bl_off, bl_pos = np.ascontiguousarray(bl[0], np.int64), np.ascontiguousarray(bl[1], np.uint16)
     vp = C.c_void_p
     rc = _LIB.emu_phase(C.byref(params), sites.ref(), reads.ref(), dnms.ref(), vp(co.ctypes.data), vp(ci.ctypes.data),
                         vp(cf.ctypes.data), vp(ho.ctypes.data), vp(hi.ctypes.data), vp(status.ctypes.data),
                         vp(counts.ctypes.data), vp(origin.ctypes.data), vp(evidence.ctypes.data),
                         vp(lstart.ctypes.data), vp(llen.ctypes.data), vp(pool.ctypes.data), C.c_longlong(cap),
                         C.byref(used), vp(no_seq.ctypes.data) if no_seq is not None else None, C.byref(base_err),
-                        vp(umask.ctypes.data) if umask is not None else None)
+                        vp(umask.ctypes.data) if umask is not None else None,
+                        vp(bl_off.ctypes.data) if bl_off is not None else None, vp(bl_pos.ctypes.data) if bl_pos is not None else None)
     assert rc == 0 and used.value <= cap
     llen = llen[: 6 * n].reshape(n, 6)
     lists = []

@@ -19,7 +19,9 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                          int32_t *origin, int32_t *evidence, long long *list_start, int32_t *list_len, int32_t *pool,
                          long long pool_cap, long long *pool_used, const uint8_t *no_seq /* optional: records staged without bases */,
                          int32_t *base_err_out /* optional: 1 when the bases of such a record were requested */,
-                         const uint16_t *umask_in /* optional: staged 32-base units per record (UZ_UMASK_ALL: all) -- the others are left out of the rows */) {
+                         const uint16_t *umask_in /* optional: staged 32-base units per record (UZ_UMASK_ALL: all) -- the others are left out of the rows */,
+                         const int64_t *bl_off /* optional, with umask_in: [n + 1] listed bases per record (uz_types.h bl_*) -- a record with a list keeps, inside its staged units, ONLY those bases (the others read as code 0) and is marked UZ_UMASK_LISTED, as the device's header build leaves it */,
+                         const uint16_t *bl_pos) {
     // the table in the packed form the device holds (built here on the host from the ASCII view)
     const int64_t n = Rv->n_segs;
     std::vector<uint8_t> nlow((size_t)n + 1);
@@ -53,6 +55,17 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
                     memmove(qlow.data() + (size_t)(uoff + kept) * UZ_QLOW_UNIT_BYTES, qlow.data() + (size_t)(uoff + u) * UZ_QLOW_UNIT_BYTES, UZ_QLOW_UNIT_BYTES);
                     kept++;
                 }
+            if (bl_off && bl_off[i + 1] > bl_off[i]) { // only the listed bases survive
+                std::vector<uint8_t> keepn((size_t)kept * UZ_SEQ4_UNIT_BYTES, 0);
+                for (int64_t e = bl_off[i]; e < bl_off[i + 1]; e++) {
+                    const uint32_t q = bl_pos[e], u = q >> 5;
+                    if (u > 14 || !((umask_in[i] >> u) & 1u)) return -3; // a listed base outside the mask
+                    const uint32_t row = (uint32_t)__builtin_popcount(umask_in[i] & ((1u << u) - 1u));
+                    keepn[(size_t)row * UZ_SEQ4_UNIT_BYTES + ((q & 31) >> 1)] |= (uint8_t)((q & 1) ? 0x0F : 0xF0);
+                }
+                for (size_t b = 0; b < keepn.size(); b++) seq4[(size_t)uoff * UZ_SEQ4_UNIT_BYTES + b] &= keepn[b];
+                umask[i] = (uint16_t)(umask_in[i] | UZ_UMASK_LISTED);
+            }
         }
         {   // as the staged form has it (list form of the quality plane): the count of every record; a quality row only for a record
             // that carries its bases and has at most UZ_QLOW_LIST_MAX low ones -- asking for a bit of any other sets base_err = 2

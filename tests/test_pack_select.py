@@ -304,7 +304,7 @@ def test_kernel_body_stays_inside_the_staged_units():
     src = io_native.ReadsSource(io_native.pack_reads(rh, P.min_gt_qual, with_end=True))
 
     def masks_of(sel):
-        part, idx = src.select(fc[sel], flo[sel], fhi[sel], want_index=True, extra=fex[sel])
+        part, idx = src.select(fc[sel], flo[sel], fhi[sel], want_index=True, extra=fex[sel], base_lists=False)  # (every staged unit as a row: the list form has its own test below)
         part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))
         m = part.view.n_segs
         um = np.zeros(N, np.uint16)
@@ -347,6 +347,77 @@ def test_kernel_body_stays_inside_the_staged_units():
     um2, _ = masks_of(np.arange(fc.size) >= n)  # (fetch_points lists the n DNM fetches first)
     got2 = emu.phase(P, sh, rh, dv, found, no_seq=no_seq, umask=np.where(no_seq, um, um2))
     assert got2["base_err"] == 3
+
+
+def test_kernel_body_stays_inside_the_listed_bases():
+    """The list form of the bases (uz_reads_packed_view.bl_*): a record that one- / two-base fetches return sends the bases at those
+    positions (+ the DNM's alleles) instead of the 32-base units they lie in.  The kernel body (CPU twin) run on rows that hold ONLY the
+    listed bases -- every other base of a staged unit reads as code 0, and a listed record refuses code 0 -- must give the oracle's results
+    without tripping the guard; with the lists of the het-site fetches alone it must trip it (err 3 or 4).  And the form must pay:
+    fewer link bytes than the units, codes equal to the source's bases."""
+    from emu import emu
+    sc, dn, cl, rh, arrs = _workload(220, seed=23)
+    n = dn.n
+    sh, fh = _sites_views(sc)
+    N = int(rh.view.n_segs)
+    P = abi.make_params()
+    cutoff = concordant_cutoff(arrs["tlen"], 151, 3)
+    dv = abi.dnms_view(dn.contig, dn.contig, dn.start, dn.end, np.zeros(n, np.uint8), dn.refs, dn.alts, cutoff)
+    found = orc.find(P, sh, fh, dv, abi.FIND_SECOND_WINDOW)
+    want = orc.phase(P, sh, rh, dv, found, keep_lists=False)
+    alen = np.array([max(len(r), len(x)) for r, x in zip(dn.refs, dn.alts)], np.int64)
+    fc, flo, fhi, fex = fetch_points(dn.contig, dn.start, np.zeros(n, np.uint8), sc.pos, found[3], found[4], P, allele_len=alen)
+    src = io_native.ReadsSource(io_native.pack_reads(rh, P.min_gt_qual, with_end=True))
+
+    def lists_of(sel):
+        part, idx = src.select(fc[sel], flo[sel], fhi[sel], want_index=True, extra=fex[sel], base_lists=True)
+        rows, _ = src.select(fc[sel], flo[sel], fhi[sel], want_index=True, extra=fex[sel], base_lists=False)
+        small = abi.small_columns(part)
+        m = int(part.view.n_segs)
+        off, pos, code = abi.base_lists(part)
+        cnt = np.diff(off)
+        listed = cnt > 0
+        assert listed.mean() > 0.3
+        um_k = small["umask"][:m]
+        pop = np.array([bin(int(x)).count("1") for x in um_k])
+        # a listed record owns no row on the link; its units exist on the device only
+        assert int(part.view.n_bl_units) == int(pop[listed].sum())
+        assert int(part.view.n_seq_units) + int(part.view.n_bl_units) == int(rows.view.n_seq_units)
+        assert 8 * int(part.view.n_seq_units) + 1.25 * int(part.view.n_bl) < 0.5 * 8 * int(rows.view.n_seq_units)  # it pays
+        # every unit of a listed record's mask holds a listed base, every listed base lies in the mask, ascending
+        rec_of = np.repeat(np.arange(m), cnt)
+        assert (((um_k[rec_of].astype(np.int64) >> (pos.astype(np.int64) >> 5)) & 1) == 1).all()
+        got_units = np.zeros(m, np.int64)
+        np.bitwise_or.at(got_units, rec_of, 1 << (pos.astype(np.int64) >> 5))
+        assert np.array_equal(got_units[listed], um_k[listed].astype(np.int64))
+        same = rec_of[1:] == rec_of[:-1]
+        assert (np.diff(pos.astype(np.int64))[same] > 0).all()
+        # codes = the source's bases (A C G T -> 0 1 2 3)
+        seq = arrs["seq"].reshape(-1, 160)
+        src_base = seq[idx[rec_of], pos.astype(np.int64)]
+        lut = np.full(256, 0, np.uint8); lut[ord("C")] = 1; lut[ord("G")] = 2; lut[ord("T")] = 3
+        assert np.array_equal(code, lut[src_base])
+        um = np.zeros(N, np.uint16)
+        um[idx] = um_k
+        no_seq = np.ones(N, bool)
+        no_seq[idx] = (small["aux"][:m] & abi.AUX_NO_SEQ) != 0
+        full_off = np.zeros(N + 1, np.int64)
+        full_cnt = np.zeros(N, np.int64)
+        full_cnt[idx] = cnt
+        full_off[1:] = np.cumsum(full_cnt)
+        full_pos = np.zeros(int(full_off[-1]), np.uint16)
+        for k in np.nonzero(listed)[0]:
+            full_pos[full_off[idx[k]]: full_off[idx[k] + 1]] = pos[off[k]: off[k + 1]]
+        return um, no_seq, (full_off, full_pos)
+
+    um, no_seq, bl = lists_of(np.ones(fc.size, bool))
+    got = emu.phase(P, sh, rh, dv, found, no_seq=no_seq, umask=um, bl=bl)
+    assert got["base_err"] == 0
+    for k in ("status", "counts", "origin", "evidence"):
+        assert np.array_equal(want[k], got[k]), k
+    um2, _, bl2 = lists_of(np.arange(fc.size) >= n)  # the DNM fetches left out: their bases are neither staged nor listed
+    got2 = emu.phase(P, sh, rh, dv, found, no_seq=no_seq, umask=np.where(no_seq, um, um2), bl=bl2)
+    assert got2["base_err"] in (3, 4)
 
 
 def test_pair_form_codes_and_its_fallback():

@@ -184,6 +184,10 @@ class ReadsPackedView(C.Structure):
         ("start_d8", _p),  # the start differences in eight bits (start_d then NULL)
         ("mate_d8", _p), ("qname_d8", _p),  # mate / name-id differences in eight bits (mate_d / qname_d then NULL)
         ("pair_d8", _p),  # the pair form: tlen, mate and name id in one byte (with start_d8; the other difference columns then NULL)
+        # the bases of a record as a list (uz_types.h bl_*): per record the number of listed bases (0: its units travel as rows), their query
+        # indices and two-bit codes
+        ("bl_n", _p), ("tup_n_bl", _p), ("bl_pos", _p), ("bl_code", _p), ("n_bl", C.c_int64), ("n_bl_units", C.c_int64), ("bl_wide", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -203,7 +207,7 @@ def row_units(l_seq):
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
                       qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False,
-                      narrow8=False, pair8=False) -> "Held":
+                      narrow8=False, pair8=False, n_bl=None, n_bl_units=0, bl_wide=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -214,6 +218,8 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     l_seq, n_cigar, mapq, aux and n_low).
     n_esc16: None = start / tlen / mate / qname as 32-bit columns; a number = as 16-bit differences with that many escapes.
     pair8 (with start8): tlen, mate and name id in the pair form's one byte (pair_d8) instead of tlen_s / mate_d* / qname_d*.
+    n_bl: None = every record's staged units travel as rows; a number = the list form of the bases for some records (bl_* columns with that many
+    listed bases; the count per record in the dictionary, tup_n_bl, or the plain bl_n column), n_bl_units their row units.
     cigar_omitted: None = every CIGAR word; a number = cigar_compact with that many simple records (n_cigar_total is the plain total:
     the words that stay home are taken off here)."""
     if n_seq_units is None:
@@ -261,6 +267,15 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
                                  (("tup_umask", np.uint16),) if with_umask else ()):
             arrs[name] = alloc(np.dtype(dt).itemsize * max(1, n_tup))[: np.dtype(dt).itemsize * max(1, n_tup)].view(dt)
         v.n_tup = n_tup
+    if n_bl is not None:
+        if n_tup is not None:
+            arrs["tup_n_bl"] = alloc(max(1, n_tup))[: max(1, n_tup)]
+        else:
+            arrs["bl_n"] = alloc(max(1, n))[: max(1, n)]
+        wb = 2 if bl_wide else 1
+        arrs["bl_pos"] = alloc(wb * max(1, n_bl))[: wb * max(1, n_bl)]
+        arrs["bl_code"] = alloc((max(1, n_bl) + 3) // 4 + 4)[: (max(1, n_bl) + 3) // 4]
+        v.n_bl, v.n_bl_units, v.bl_wide = n_bl, n_bl_units, 1 if bl_wide else 0
     if n_esc16 is not None:
         if start8:
             arrs["start_d8"] = alloc(max(1, n))[: max(1, n)]
@@ -376,10 +391,31 @@ def small_columns(held: "Held") -> dict:
     names = ["flag", "l_seq", "n_cigar", "mapq", "aux"] + (["n_low"] if ("n_low" in a or "tup_n_low" in a) else []) + (
         ["umask"] if ("umask" in a or "tup_umask" in a) else [])
     if "tup" not in a:
-        return {k: a[k][:n] for k in names}
+        out = {k: a[k][:n] for k in names}
+        if "bl_n" in a:
+            out["bl_n"] = a["bl_n"][:n]
+        return out
     t = a["tup"][:n].astype(np.int64)
     assert n == 0 or t.max() < int(held.view.n_tup)
-    return {k: a["tup_" + k][t] for k in names}
+    out = {k: a["tup_" + k][t] for k in names}
+    if "tup_n_bl" in a:  # the list form of the bases: listed bases per record (0: its units travel as rows)
+        out["bl_n"] = a["tup_n_bl"][t]
+    return out
+
+
+def base_lists(held: "Held"):
+    """the list form of the bases of a packed view as (offsets [n + 1], query indices, two-bit codes), or None when it has none"""
+    a, n = held.arrays, int(held.view.n_segs)
+    if "bl_pos" not in a:
+        return None
+    cnt = small_columns(held)["bl_n"].astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    m = int(off[-1])
+    assert m == int(held.view.n_bl)
+    pos = a["bl_pos"][: 2 * m].view(np.uint16)[:m] if held.view.bl_wide else a["bl_pos"][:m].astype(np.uint16)
+    e = np.arange(m)
+    code = (a["bl_code"][e >> 2] >> (2 * (e & 3))) & 3 if m else np.zeros(0, np.uint8)
+    return off, pos.astype(np.uint16), code.astype(np.uint8)
 
 
 class CohortGroup(C.Structure):

@@ -128,6 +128,14 @@ struct uz_select {
     int64_t n_qpos = 0;                 // entries of the output's qlow_pos
     std::vector<int64_t> exc_lo, exc_n; // seq2 sources: per kept record, its slice of the source's exception list (0 entries without bases)
     int64_t n_exc = 0;
+    // the list form of the bases (uz_types.h bl_*; planned with unit_masks & 4 on a two-bit source): per kept record the number of listed
+    // bases (0: its staged units travel as rows), the query indices back to back, their first entry per record
+    std::vector<uint8_t> bl_n;
+    std::vector<uint16_t> bl_pos;
+    std::vector<int64_t> bl_off;        // [n_sel + 1]
+    std::vector<uint8_t> tup_nb;        // (list count of the combination)
+    int64_t n_bl_units = 0;             // row units of the listed records (not in n_seq)
+    int bl_wide = 0;
 };
 
 // start / tlen / mate / qname of kept record k as 16-bit differences (uz_reads_packed_view.start_d ...): v[c] the column values,
@@ -557,6 +565,72 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
             });
             for (int k = 0; k < wk; k++) sel->n_qpos += part[(size_t)k];
         }
+        if (full->seq2) { // the listed bases of the kept records that keep their bases
+            sel->exc_lo.assign((size_t)sel->n_sel, 0);
+            sel->exc_n.assign((size_t)sel->n_sel, 0);
+            const uint32_t *er = full->exc_rec;
+            for (int64_t k = 0; k < sel->n_sel && full->n_exc > 0; k++) {
+                if (!sel->bases[(size_t)k]) continue;
+                const uint32_t i = (uint32_t)sel->index[(size_t)k];
+                const uint32_t *a = std::lower_bound(er, er + full->n_exc, i), *b = std::upper_bound(a, er + full->n_exc, i);
+                sel->exc_lo[(size_t)k] = a - er; sel->exc_n[(size_t)k] = b - a; // (entries in units that stay home travel along: the device skips them)
+                sel->n_exc += b - a;
+            }
+        }
+        if (masks && (unit_masks & 4) && full->seq2) {
+            // The bases as lists: a kept record with an explicit unit mask was returned by one- / two-base fetches only and its single CIGAR
+            // operation spans the read, so every base the read stage can ask of it is (fetched position - start) .. + extra.  Those
+            // positions travel instead of the units they lie in when that is fewer bytes and none of them is '=' (uz_types.h).
+            std::vector<int64_t> ford((size_t)n_fetch);
+            for (int64_t f = 0; f < n_fetch; f++) ford[(size_t)f] = f;
+            std::sort(ford.begin(), ford.end(), [&](int64_t a, int64_t b) { return contig[a] != contig[b] ? contig[a] < contig[b] : (lo[a] != lo[b] ? lo[a] < lo[b] : a < b); });
+            std::vector<int64_t> cfirst((size_t)full->n_contigs + 1, n_fetch); // first sorted fetch of every contig
+            for (int64_t j = n_fetch - 1; j >= 0; j--) { const int c = contig[ford[(size_t)j]]; if (c >= 0 && c < full->n_contigs) cfirst[(size_t)c] = j; }
+            sel->bl_n.assign((size_t)sel->n_sel, 0);
+            sel->bl_off.assign((size_t)sel->n_sel + 1, 0);
+            std::vector<uint16_t> v;
+            for (int64_t k = 0; k < sel->n_sel; k++) {
+                sel->bl_off[(size_t)k] = (int64_t)sel->bl_pos.size();
+                const uint16_t m16 = sel->umask[(size_t)k];
+                if (!sel->bases[(size_t)k] || m16 == UZ_UMASK_ALL || m16 == 0) continue;
+                const int64_t i = sel->index[(size_t)k];
+                const int tid = (int)(std::upper_bound(full->contig_off, full->contig_off + full->n_contigs + 1, i) - full->contig_off) - 1;
+                const int32_t st = full->start[i], en = full->end[i], ls = full->l_seq[i];
+                v.clear();
+                int64_t j = cfirst[(size_t)tid];
+                { // first fetch of the contig with lo >= st - 1 (a one- or two-base fetch that overlaps the record starts there or later)
+                    int64_t a = j, b = n_fetch;
+                    while (a < b) { const int64_t mid = (a + b) >> 1; const int64_t f = ford[(size_t)mid]; if (contig[f] < tid || (contig[f] == tid && lo[f] < st - 1)) a = mid + 1; else b = mid; }
+                    j = a;
+                }
+                for (; j < n_fetch; j++) {
+                    const int64_t f = ford[(size_t)j];
+                    if (contig[f] != tid || lo[f] >= en) break;
+                    if (hi[f] - lo[f] > 2 || hi[f] <= st) continue; // (a wider fetch contributes no unit here: wide_none -- or the mask would be "all")
+                    const int64_t q0 = (int64_t)hi[f] - 1 - st;
+                    if (q0 < 0 || q0 >= ls) continue;
+                    const int64_t q1 = std::min<int64_t>(q0 + (extra ? extra[f] : 0), ls - 1);
+                    for (int64_t q = q0; q <= q1; q++) v.push_back((uint16_t)q);
+                }
+                std::sort(v.begin(), v.end());
+                v.erase(std::unique(v.begin(), v.end()), v.end());
+                uint16_t units = 0;
+                for (uint16_t q : v) units |= (uint16_t)(1u << (q >> 5));
+                bool ok = !v.empty() && v.size() <= 255 && units == m16 && 5 * v.size() < 32 * (size_t)__builtin_popcount(m16);
+                for (int64_t e = 0; ok && e < sel->exc_n[(size_t)k]; e++) { // a listed '=' (BAM code 0) would read as "not listed" on the device
+                    const int64_t fr = sel->exc_lo[(size_t)k] + e;
+                    if (full->exc_code[fr] == 0 && std::binary_search(v.begin(), v.end(), full->exc_pos[fr])) ok = false;
+                }
+                if (!ok) continue;
+                sel->bl_n[(size_t)k] = (uint8_t)v.size();
+                sel->bl_pos.insert(sel->bl_pos.end(), v.begin(), v.end());
+                sel->n_bl_units += __builtin_popcount(m16);
+                sel->n_seq -= (uint64_t)__builtin_popcount(m16);
+            }
+            sel->bl_off[(size_t)sel->n_sel] = (int64_t)sel->bl_pos.size();
+            for (int64_t k = 0; k < sel->n_sel && !sel->bl_wide; k++) // (two-byte positions as soon as the table holds a read longer than 256 bases: the rule of qlow_pos_wide)
+                if (full->l_seq[sel->index[(size_t)k]] > 256) sel->bl_wide = 1;
+        }
         if (tuples & 1) { // the small columns as a dictionary: combinations numbered in order of first appearance
             struct KeyHash { size_t operator()(const std::pair<uint64_t, uint32_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second * 0xC2B2AE3D27D4EB4FULL); } };
             std::unordered_map<std::pair<uint64_t, uint32_t>, uint32_t, KeyHash> dict;
@@ -572,17 +646,18 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                                      ((uint64_t)full->mapq[i] << 48) | ((uint64_t)(aux & 0xFFu) << 56);
                 const uint8_t low = (tuples & 4) ? sel->n_low[(size_t)k] : (uint8_t)0;
                 const uint16_t um16 = with_um ? sel->umask[(size_t)k] : (uint16_t)0;
-                const uint32_t k2 = (uint32_t)low | ((uint32_t)um16 << 8);
+                const uint8_t nb = sel->bl_n.empty() ? (uint8_t)0 : sel->bl_n[(size_t)k];
+                const uint32_t k2 = (uint32_t)low | ((uint32_t)um16 << 8) | ((uint32_t)nb << 24);
                 auto it = dict.find({key, k2});
                 if (it == dict.end()) {
                     if (dict.size() >= 65536) { ok = false; break; }
                     it = dict.emplace(std::make_pair(key, k2), (uint32_t)dict.size()).first;
-                    sel->tup_key.push_back(key); sel->tup_low.push_back(low); sel->tup_um.push_back(um16);
+                    sel->tup_key.push_back(key); sel->tup_low.push_back(low); sel->tup_um.push_back(um16); sel->tup_nb.push_back(nb);
                 }
                 sel->tup_idx[(size_t)k] = (uint16_t)it->second;
             }
             if (ok) sel->tuples = tuples;
-            else { sel->tup_idx.clear(); sel->tup_key.clear(); sel->tup_low.clear(); sel->tup_um.clear(); } // more than 65536 combinations: the plain columns
+            else { sel->tup_idx.clear(); sel->tup_key.clear(); sel->tup_low.clear(); sel->tup_um.clear(); sel->tup_nb.clear(); } // more than 65536 combinations: the plain columns
         }
         { // escapes of the 16-bit difference form (counted whether or not the output will use it: cheap)
             const int wk = workers_for(sel->n_sel, threads, 1 << 14);
@@ -644,18 +719,6 @@ int uz_reads_select_plan(const uz_psrc *src, int64_t n_fetch, const int32_t *con
                 for (int k = 0; k < wk; k++) sel->n_esc16_pair8 += part[(size_t)k];
             }
         }
-        if (full->seq2) { // the listed bases of the kept records that keep their bases
-            sel->exc_lo.assign((size_t)sel->n_sel, 0);
-            sel->exc_n.assign((size_t)sel->n_sel, 0);
-            const uint32_t *er = full->exc_rec;
-            for (int64_t k = 0; k < sel->n_sel && full->n_exc > 0; k++) {
-                if (!sel->bases[(size_t)k]) continue;
-                const uint32_t i = (uint32_t)sel->index[(size_t)k];
-                const uint32_t *a = std::lower_bound(er, er + full->n_exc, i), *b = std::upper_bound(a, er + full->n_exc, i);
-                sel->exc_lo[(size_t)k] = a - er; sel->exc_n[(size_t)k] = b - a; // (entries in units that stay home travel along: the device skips them)
-                sel->n_exc += b - a;
-            }
-        }
         *out = sel;
     });
 }
@@ -665,6 +728,9 @@ int64_t uz_select_n_cigar_total(const uz_select *s) { return s ? (int64_t)s->n_c
 int64_t uz_select_n_row_units(const uz_select *s) { return s ? (int64_t)s->n_units : 0; }
 int64_t uz_select_n_seq_units(const uz_select *s) { return s ? (int64_t)s->n_seq : 0; }
 int64_t uz_select_n_exc(const uz_select *s) { return s ? s->n_exc : 0; }
+int64_t uz_select_n_bl(const uz_select *s) { return (s && !s->bl_n.empty()) ? (int64_t)s->bl_pos.size() : -1; } /* -1: planned without the list form of the bases */
+int64_t uz_select_n_bl_units(const uz_select *s) { return s ? s->n_bl_units : 0; }
+int uz_select_bl_wide(const uz_select *s) { return s ? s->bl_wide : 0; }
 int64_t uz_select_n_qlow_pos(const uz_select *s) { return s ? s->n_qpos : 0; }
 int uz_select_end_derivable(const uz_select *s) { return s ? s->end_derivable : 0; }
 int64_t uz_select_n_esc16(const uz_select *s) { return s ? s->n_esc16 : 0; }
@@ -750,12 +816,19 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 w(out->tup_mapq)[t] = (uint8_t)(key >> 48); w(out->tup_aux)[t] = (uint8_t)(key >> 56);
                 if (out->tup_n_low) w(out->tup_n_low)[t] = s->tup_low[t];
                 if (out->tup_umask) w(out->tup_umask)[t] = s->tup_um[t];
+                if (out->tup_n_bl) w(out->tup_n_bl)[t] = s->tup_nb[t];
             }
             if (!s->umask.empty() && !out->tup_umask) fail(UZ_IO_E_ARG, "the selection has unit masks and a dictionary: the output view needs tup_umask");
         } else
             out->n_tup = 0;
         const bool masks = !s->umask.empty();
         if (masks && !out->umask && !(tup && out->tup_umask)) fail(UZ_IO_E_ARG, "the selection was planned with unit masks: the output view needs umask");
+        const bool blf = !s->bl_n.empty();
+        if (blf != (out->bl_n != nullptr || out->tup_n_bl != nullptr) || (blf && (tup ? !out->tup_n_bl || out->bl_n : !out->bl_n)) ||
+            (blf && !s->bl_pos.empty() && (!out->bl_pos || !out->bl_code)) || (blf && s->bl_wide && !out->bl_wide))
+            fail(UZ_IO_E_ARG, "the list form of the bases: the output view needs bl_n (or tup_n_bl with the dictionary), bl_pos and bl_code exactly when the selection was planned with it (uz_select_n_bl)");
+        out->n_bl = blf ? (int64_t)s->bl_pos.size() : 0; out->n_bl_units = blf ? s->n_bl_units : 0;
+        if (blf && out->n_bl) memset(w(out->bl_code), 0, (size_t)(out->n_bl + 3) / 4);
         const bool lists = out->n_low != nullptr || (tup && out->tup_n_low != nullptr);
         if (masks && !lists) fail(UZ_IO_E_ARG, "unit masks need the list form of the qualities in the output (n_low / qlow_pos)");
         if (!lists && !full->qlow) fail(UZ_IO_E_ARG, "the source table has the quality plane as lists: the output view needs n_low / qlow_pos");
@@ -791,7 +864,7 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
             oc[k + 1] = oc[k] + (smp ? 0 : full->n_cigar[i]);
             ou[k + 1] = ou[k] + UZ_ROW_UNITS(full->l_seq[i]);
             const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
-            os[k + 1] = os[k] + (s->bases[k] ? (m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16)) : 0);
+            os[k + 1] = os[k] + ((s->bases[k] && !(blf && s->bl_n[(size_t)k])) ? (m16 == UZ_UMASK_ALL ? UZ_ROW_UNITS(full->l_seq[i]) : (uint32_t)__builtin_popcount(m16)) : 0);
         }
         int list_mismatch = 0;
         parallel_slices(m, wk_fill, [&](int64_t a, int64_t b, int slice) {
@@ -849,7 +922,22 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
                 const size_t units = UZ_ROW_UNITS(full->l_seq[i]);
                 const uint16_t m16 = masks ? s->umask[(size_t)k] : (uint16_t)UZ_UMASK_ALL;
                 if (out->umask) w(out->umask)[k] = m16;
-                if (s->bases[k] && m16 != UZ_UMASK_ALL) { // the staged units only, back to back
+                if (!tup && out->bl_n) w(out->bl_n)[k] = blf ? s->bl_n[(size_t)k] : (uint8_t)0;
+                if (blf && s->bl_n[(size_t)k]) { // the listed bases: query index + two-bit code (a base that is none of the four: 0, and in the exception list)
+                    const uint8_t *row = full->seq2 + (size_t)src->soff[i] * UZ_SEQ2_UNIT_BYTES;
+                    for (int64_t e = 0; e < (int64_t)s->bl_n[(size_t)k]; e++) {
+                        const int64_t at = s->bl_off[(size_t)k] + e;
+                        const uint32_t q = s->bl_pos[(size_t)at];
+                        if (out->bl_wide) { w(out->bl_pos)[2 * at] = (uint8_t)(q & 255); w(out->bl_pos)[2 * at + 1] = (uint8_t)(q >> 8); }
+                        else w(out->bl_pos)[at] = (uint8_t)q;
+                        const uint8_t c2 = (uint8_t)((row[q >> 2] >> (6 - 2 * (q & 3))) & 3u);
+                        if (c2) __atomic_fetch_or(w(out->bl_code) + (at >> 2), (uint8_t)(c2 << (2 * (at & 3))), __ATOMIC_RELAXED);
+                    }
+                    for (int64_t e = 0; e < s->exc_n[(size_t)k]; e++) {
+                        const int64_t fr = s->exc_lo[(size_t)k] + e, t2 = oe[(size_t)k] + e;
+                        w(out->exc_rec)[t2] = (uint32_t)k; w(out->exc_pos)[t2] = full->exc_pos[fr]; w(out->exc_code)[t2] = full->exc_code[fr];
+                    }
+                } else if (s->bases[k] && m16 != UZ_UMASK_ALL) { // the staged units only, back to back
                     const size_t ub = two_bit ? UZ_SEQ2_UNIT_BYTES : UZ_SEQ4_UNIT_BYTES;
                     const uint8_t *from = (two_bit ? full->seq2 : full->seq4) + (size_t)src->soff[i] * ub;
                     uint8_t *to = w(two_bit ? out->seq2 : out->seq4) + os[k] * ub;

@@ -293,6 +293,7 @@ struct WRec { // one walked record that may be kept
     uint32_t gidx, qid;
     uint16_t flag, l_seq, n_cigar, umask, n_exc, tup;
     uint8_t mapq, aux, n_low_full, l_name, n_qpos, n_low, simple, keep, n_units, has_pay;
+    uint8_t n_bl, bl_units; // bases as a list (uz_types.h bl_*): the listed bases and the units of the mask they lie in (n_units is then 0: no rows travel)
 };
 
 struct Task { // reach intervals of one reference whose file spans meet (walked as one: no block is inflated twice), and what the walk kept
@@ -304,19 +305,19 @@ struct Task { // reach intervals of one reference whose file spans meet (walked 
     std::vector<WRec> recs;          // file order
     std::vector<uint8_t> names;      // name bytes (no terminator)
     std::vector<uint32_t> cigars;    // words of the records that are not simple
-    std::vector<uint8_t> pay;        // per record with has_pay: seq2 units | exceptions (pos u16, code u8, pad) | positions (u16) | plane row
+    std::vector<uint8_t> pay;        // per record with has_pay: seq2 units | listed bases (pos u16, two-bit code) | exceptions (pos u16, code u8, pad) | positions (u16) | plane row
     int64_t n_walked = 0, file_bytes = 0, n_blocks = 0, n_pre = 0;
     std::vector<PreBlk> pre;         // blocks of this task inflated elsewhere (uz_stage_gather_blocks / uz_stage_set_inflated)
     // sizes of the kept records (filled by the numbering pass)
     int64_t n_keep = 0, k0 = 0;
 };
 
-struct Opt { bool all_bases, masks, lists, wide_none; int thr; };
+struct Opt { bool all_bases, masks, lists, wide_none, bl; int thr; };
 
 inline uint8_t sat255(int v) { return (uint8_t)(v > 255 ? 255 : v); }
 
 // everything the link can need of one record, extracted while its bytes are in the inflate buffer
-void extract(Task &T, WRec &r, const uint8_t *p, uint32_t bs, const Opt &o, bool bases) {
+void extract(Task &T, WRec &r, const uint8_t *p, uint32_t bs, const Opt &o, bool bases, const std::vector<uint16_t> *bl = nullptr) {
     const uint32_t l_name = p[8], ncig = r.n_cigar, L = r.l_seq;
     const uint8_t *q = p + 32 + l_name;
     const uint8_t *sq = q + 4 * (size_t)ncig;
@@ -342,7 +343,7 @@ void extract(Task &T, WRec &r, const uint8_t *p, uint32_t bs, const Opt &o, bool
     else for (uint32_t k = 0; k < L; k++) low += (int)ql[k] < o.thr;
     r.n_low_full = sat255(low);
     r.n_low = r.n_low_full;
-    r.has_pay = 0; r.n_units = 0; r.n_exc = 0; r.n_qpos = 0;
+    r.has_pay = 0; r.n_units = 0; r.n_exc = 0; r.n_qpos = 0; r.n_bl = 0; r.bl_units = 0;
     r.pay_at = (uint32_t)T.pay.size();
     const uint32_t units = UZ_ROW_UNITS(L);
     if (bases) {
@@ -350,7 +351,16 @@ void extract(Task &T, WRec &r, const uint8_t *p, uint32_t bs, const Opt &o, bool
         // the staged units: two bits per base, first base of a byte in bits 7-6; a base that is not A/C/G/T is 0 here and listed
         static const struct Tab { uint8_t t[256]; Tab() { for (int v = 0; v < 256; v++) { auto c = [](int n) { return n == 1 ? 0 : n == 2 ? 1 : n == 4 ? 2 : n == 8 ? 3 : 0; }; t[v] = (uint8_t)((c(v >> 4) << 2) | c(v & 15)); } } } two;
         const uint16_t m16 = r.umask;
-        for (uint32_t u = 0; u < units; u++) {
+        if (bl) { // the listed bases instead of the units they lie in (a base that is not A/C/G/T: code 0 here, and in the exception list below)
+            for (uint16_t k : *bl) {
+                const uint32_t c = (k & 1) ? (uint32_t)(sq[k >> 1] & 15u) : (uint32_t)(sq[k >> 1] >> 4);
+                const uint8_t e[3] = {(uint8_t)(k & 255), (uint8_t)(k >> 8), (uint8_t)(c == 2 ? 1 : c == 4 ? 2 : c == 8 ? 3 : 0)};
+                T.pay.insert(T.pay.end(), e, e + 3);
+            }
+            r.n_bl = (uint8_t)bl->size();
+            r.bl_units = (uint8_t)__builtin_popcount(m16);
+        }
+        for (uint32_t u = 0; u < units && !bl; u++) {
             if (m16 != UZ_UMASK_ALL && !((m16 >> u) & 1u)) continue;
             uint8_t row[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const uint32_t b0 = 32 * u, b1 = std::min<uint32_t>(L, b0 + 32);
@@ -422,11 +432,26 @@ inline uint16_t mask_bits(const Fx &f, int32_t pos, int32_t end, uint32_t ncig, 
     return bits;
 }
 
+// the bases one fetch asks of a record it returns, as query indices appended to `out`; false: the fetch's rule for this record is
+// "every unit" (mask_bits gives UZ_UMASK_ALL) -- the record cannot travel as a list
+inline bool list_bits(const Fx &f, int32_t pos, int32_t end, uint32_t ncig, uint32_t cw, uint32_t L, bool wide_none, std::vector<uint16_t> &out) {
+    if (wide_none && f.hi - f.lo > 2) return true;
+    const uint32_t op = cw & 15u;
+    const bool simple = ncig == 1 && (op == 0 || op == 7 || op == 8) && (cw >> 4) == L && L > 1 && (uint32_t)(end - pos) == L;
+    if (!(simple && L <= 480 && f.hi - f.lo <= 2)) return false;
+    const int64_t q0 = (int64_t)f.hi - 1 - pos;
+    if (q0 >= 0 && q0 < (int64_t)L) {
+        const int64_t q1 = std::min<int64_t>(q0 + f.extra, (int64_t)L - 1);
+        for (int64_t q = q0; q <= q1; q++) out.push_back((uint16_t)q);
+    }
+    return true;
+}
+
 } // namespace
 
 struct SliceBase { // running totals of the variable-length columns in front of a slice of the output order
-    int64_t cig = 0, omitted = 0, units = 0, seq = 0, exc = 0, qpos = 0, esc = 0;
-    void add(const SliceBase &o) { cig += o.cig; omitted += o.omitted; units += o.units; seq += o.seq; exc += o.exc; qpos += o.qpos; esc += o.esc; }
+    int64_t cig = 0, omitted = 0, units = 0, seq = 0, exc = 0, qpos = 0, esc = 0, bl = 0, blu = 0;
+    void add(const SliceBase &o) { cig += o.cig; omitted += o.omitted; units += o.units; seq += o.seq; exc += o.exc; qpos += o.qpos; esc += o.esc; bl += o.bl; blu += o.blu; }
 };
 
 struct uz_stage {
@@ -548,6 +573,7 @@ struct Scratch { // a worker's buffers, kept from task to task
     Task tmp;
     std::vector<uint64_t> dn;
     std::vector<int32_t> tab, stack;
+    std::vector<uint16_t> blv; // the bases the fetches ask of the record at hand
 };
 
 void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
@@ -561,6 +587,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
     Task &tmp = W.tmp; // pools of every walked record; the survivors are copied over
     all.clear(); tmp.names.clear(); tmp.cigars.clear(); tmp.pay.clear();
     tmp.tid = T.tid;
+    std::vector<uint16_t> &blv = W.blv;
     size_t ri = 0; // the reach interval the walk is in or in front of
     bool stop = false;
     for (size_t ci = 0; ci < T.spans.size() && !stop; ci++) {
@@ -596,8 +623,9 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
             r.mate_ref = -2;
             r.nhash = hash_name(p + 32, (size_t)l_name - 1);
             // does a fetch return it?  (start < hi and end > lo: read_collector.py:385, :167)
-            bool direct = false;
+            bool direct = false, listable = o.bl;
             uint16_t um = 0;
+            blv.clear();
             {
                 auto it = std::lower_bound(fx.begin() + (ptrdiff_t)T.f0, fx.begin() + (ptrdiff_t)T.f1, (int64_t)pos - max_len,
                                            [](const Fx &f, int64_t key) { return (int64_t)f.lo < key; });
@@ -606,17 +634,32 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
                     if (it->hi > pos) {
                         direct = true;
                         if (o.masks) um |= mask_bits(*it, pos, end, ncig, cw, (uint32_t)lseq, o.wide_none);
+                        if (listable) listable = list_bits(*it, pos, end, ncig, cw, (uint32_t)lseq, o.wide_none, blv);
                     }
             }
             r.keep = direct ? 2 : 0;
             const bool bases = direct || o.all_bases;
+            bool use_list = false;
             r.umask = (uint16_t)UZ_UMASK_ALL;
             if (o.masks) {
                 uint16_t m16 = bases ? um : (uint16_t)0;
                 if (m16 != UZ_UMASK_ALL && (uint32_t)__builtin_popcount(m16) == UZ_ROW_UNITS(lseq)) m16 = (uint16_t)UZ_UMASK_ALL;
                 r.umask = m16;
+                // The bases as a list (uz_types.h bl_*): when every fetch names single positions, they are fewer bytes than the units they lie
+                // in, and none of them is '=' (BAM code 0, which the device reads as "not listed").
+                if (listable && bases && m16 != UZ_UMASK_ALL && m16 != 0) {
+                    std::sort(blv.begin(), blv.end());
+                    blv.erase(std::unique(blv.begin(), blv.end()), blv.end());
+                    const uint8_t *sq0 = p + 32 + l_name + 4 * (size_t)ncig;
+                    bool ok = !blv.empty() && blv.size() <= 255 && 5 * blv.size() < 32 * (size_t)__builtin_popcount(m16);
+                    for (size_t j = 0; ok && j < blv.size(); j++) {
+                        const uint32_t k = blv[j];
+                        ok = ((k & 1) ? (uint32_t)(sq0[k >> 1] & 15u) : (uint32_t)(sq0[k >> 1] >> 4)) != 0u;
+                    }
+                    use_list = ok;
+                }
             }
-            extract(tmp, r, p, bs, o, bases);
+            extract(tmp, r, p, bs, o, bases, use_list ? &blv : nullptr);
             all.push_back(r);
             s.advance(bs);
         }
@@ -637,7 +680,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
         if (!r0.simple) T.cigars.insert(T.cigars.end(), tmp.cigars.begin() + r0.cigar_at, tmp.cigars.begin() + r0.cigar_at + r0.n_cigar);
         r.pay_at = (uint32_t)T.pay.size();
         if (r0.has_pay) {
-            const size_t len = (size_t)r0.n_units * 8 + (size_t)r0.n_exc * 4 + (size_t)r0.n_qpos * 2 + (o.lists ? 0 : (size_t)UZ_ROW_UNITS(r0.l_seq) * UZ_QLOW_UNIT_BYTES);
+            const size_t len = (size_t)r0.n_units * 8 + (size_t)r0.n_bl * 3 + (size_t)r0.n_exc * 4 + (size_t)r0.n_qpos * 2 + (o.lists ? 0 : (size_t)UZ_ROW_UNITS(r0.l_seq) * UZ_QLOW_UNIT_BYTES);
             T.pay.insert(T.pay.end(), tmp.pay.begin() + r0.pay_at, tmp.pay.begin() + r0.pay_at + (ptrdiff_t)len);
         }
         T.recs.push_back(r);
@@ -1075,7 +1118,7 @@ void plan_finish(uz_stage &P) {
         uint32_t aux = bases ? x.aux : (x.aux | UZ_AUX_NO_SEQ);
         aux |= (uint32_t)x.simple << UZ_AUX_SIMPLE_SHIFT;
         key = (uint64_t)x.flag | ((uint64_t)x.l_seq << 16) | ((uint64_t)x.n_cigar << 32) | ((uint64_t)x.mapq << 48) | ((uint64_t)(aux & 0xFFu) << 56);
-        k2 = (uint32_t)(o.lists ? x.n_low : (uint8_t)0) | ((uint32_t)(o.masks ? x.umask : (uint16_t)0) << 8);
+        k2 = (uint32_t)(o.lists ? x.n_low : (uint8_t)0) | ((uint32_t)(o.masks ? x.umask : (uint16_t)0) << 8) | ((uint32_t)x.n_bl << 24);
     };
     {
         struct KeyHash { size_t operator()(const std::pair<uint64_t, uint32_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second * 0xC2B2AE3D27D4EB4FULL); } };
@@ -1128,7 +1171,7 @@ void plan_finish(uz_stage &P) {
             b.omitted += x.simple != 0;
             b.cig += x.simple ? 0 : x.n_cigar;
             b.units += UZ_ROW_UNITS(x.l_seq);
-            b.seq += x.n_units; b.exc += x.n_exc; b.qpos += x.n_qpos;
+            b.seq += x.n_units; b.exc += x.n_exc; b.qpos += x.n_qpos; b.bl += x.n_bl; b.blu += x.bl_units;
             if (x.l_seq > 256) wides[(size_t)sl] = 1;
             cnt[(size_t)sl][(size_t)tid_k]++;
             span[(size_t)sl][(size_t)tid_k] = std::max(span[(size_t)sl][(size_t)tid_k], x.end - x.pos);
@@ -1173,6 +1216,8 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
     if (o.lists) need(out->tup_n_low && (out->qlow_pos || tot.qpos == 0) && !out->qlow, "needs the list form of the qualities (tup_n_low, qlow_pos)");
     else need(out->qlow && !out->tup_n_low, "needs the quality plane (qlow)");
     if (o.masks) need(out->tup_umask != nullptr, "needs tup_umask");
+    if (o.bl) need(out->tup_n_bl && !out->bl_n && (tot.bl == 0 || (out->bl_pos && out->bl_code)) && (!P.wide || out->bl_wide), "needs the list form of the bases (tup_n_bl, bl_pos, bl_code; bl_wide for reads longer than 256 bases)");
+    else need(!out->tup_n_bl && !out->bl_n, "must not set bl_n / tup_n_bl (the stage was planned without the list form of the bases)");
     need(!P.wide || out->qlow_pos_wide || !o.lists, "needs qlow_pos_wide (reads longer than 256 bases)");
     if (tot.exc) need(out->exc_rec && out->exc_pos && out->exc_code, "needs the exc_* columns");
     const uz_bamsrc &S = *P.src;
@@ -1180,6 +1225,7 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
     out->n_segs = n; out->n_contigs = n_ref; out->min_base_qual = o.thr; out->n_qnames = (uint32_t)P.n_qnames;
     out->n_cigar_total = tot.cig; out->n_cigar_omitted = tot.omitted; out->n_row_units = tot.units; out->n_seq_units = tot.seq;
     out->n_exc = tot.exc; out->n_qlow_pos = o.lists ? tot.qpos : 0; out->n_tup = P.n_tup; out->n_esc16 = tot.esc;
+    out->n_bl = o.bl ? tot.bl : 0; out->n_bl_units = o.bl ? tot.blu : 0;
     auto w = [](const auto *p) { return const_cast<typename std::remove_const<typename std::remove_pointer<decltype(p)>::type>::type *>(p); };
     for (int32_t c = 0; c <= n_ref; c++) w(out->contig_off)[c] = P.contig_off[(size_t)c];
     for (int32_t c = 0; c < n_ref; c++) w(out->max_span)[c] = P.max_span[(size_t)c];
@@ -1189,8 +1235,11 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
         w(out->tup_mapq)[t] = (uint8_t)(key >> 48); w(out->tup_aux)[t] = (uint8_t)(key >> 56);
         if (out->tup_n_low) w(out->tup_n_low)[t] = (uint8_t)(P.tup_k2[t] & 0xFF);
         if (out->tup_umask) w(out->tup_umask)[t] = (uint16_t)(P.tup_k2[t] >> 8);
+        if (out->tup_n_bl) w(out->tup_n_bl)[t] = (uint8_t)(P.tup_k2[t] >> 24);
     }
     const bool wide = out->qlow_pos_wide != 0;
+    const bool blw = out->bl_wide != 0;
+    if (o.bl && tot.bl) memset(w(out->bl_code), 0, (size_t)(tot.bl + 3) / 4); // (two-bit fields of neighbouring slices share bytes: OR-ed in below)
     const int W = (int)P.cut.size() - 1;
     parallel_slices(W, std::min(W, resolve_threads(threads)), [&](int64_t s0, int64_t s1, int) {
         for (int64_t sl = s0; sl < s1; sl++) {
@@ -1212,6 +1261,13 @@ void fill(const uz_stage &P, int threads, uz_reads_packed_view *out) {
                 const uint8_t *pay = T.pay.data() + x.pay_at;
                 if (x.n_units) { memcpy(w(out->seq2) + (size_t)at.seq * UZ_SEQ2_UNIT_BYTES, pay, (size_t)x.n_units * 8); at.seq += x.n_units; }
                 pay += (size_t)x.n_units * 8;
+                for (int j = 0; j < (int)x.n_bl; j++) {
+                    if (blw) { w(out->bl_pos)[2 * at.bl] = pay[3 * j]; w(out->bl_pos)[2 * at.bl + 1] = pay[3 * j + 1]; }
+                    else w(out->bl_pos)[at.bl] = pay[3 * j];
+                    if (pay[3 * j + 2]) __atomic_fetch_or(w(out->bl_code) + (at.bl >> 2), (uint8_t)(pay[3 * j + 2] << (2 * (at.bl & 3))), __ATOMIC_RELAXED);
+                    at.bl++;
+                }
+                pay += (size_t)x.n_bl * 3;
                 for (int j = 0; j < (int)x.n_exc; j++) {
                     w(out->exc_rec)[at.exc] = (uint32_t)k; w(out->exc_pos)[at.exc] = (uint16_t)(pay[4 * j] | (pay[4 * j + 1] << 8)); w(out->exc_code)[at.exc] = pay[4 * j + 2];
                     at.exc++;
@@ -1284,6 +1340,7 @@ int uz_bam_stage_begin(const uz_bamsrc *src, int64_t n_fetch, const int32_t *tid
     P->opt.lists = !(flags & UZ_STAGE_PLANE);
     P->opt.masks = (flags & UZ_STAGE_UNIT_MASKS) && !P->opt.all_bases && P->opt.lists;
     P->opt.wide_none = P->opt.masks && (flags & UZ_STAGE_WIDE_NO_UNITS);
+    P->opt.bl = P->opt.masks && (flags & UZ_STAGE_BASE_LISTS);
     P->opt.thr = min_base_qual < 0 ? 0 : (min_base_qual > 255 ? 256 : min_base_qual);
     const int rc = guarded([&] { plan_begin(*P, n_fetch, tid, lo, hi, extra, threads); });
     if (rc != UZ_IO_OK) { delete P; return rc; }
@@ -1372,12 +1429,13 @@ int uz_stage_set_inflated(uz_stage *P, const uint8_t *inflated) {
     return UZ_IO_OK;
 }
 
-void uz_stage_sizes(const uz_stage *P, int64_t out[12]) {
-    memset(out, 0, 12 * sizeof(int64_t));
+void uz_stage_sizes(const uz_stage *P, int64_t out[16]) {
+    memset(out, 0, 16 * sizeof(int64_t));
     if (!P) return;
     const SliceBase &t = P->base.back();
     out[0] = P->n; out[1] = t.cig; out[2] = t.omitted; out[3] = t.units; out[4] = t.seq; out[5] = t.exc; out[6] = t.qpos; out[7] = P->wide;
     out[8] = P->n_tup; out[9] = t.esc; out[10] = P->n_qnames; out[11] = P->opt.masks ? 1 : 0;
+    out[12] = P->opt.bl ? 1 : 0; out[13] = t.bl; out[14] = t.blu;
 }
 void uz_stage_io_stats(const uz_stage *P, int64_t out[8]) { for (int k = 0; k < 8; k++) out[k] = P ? P->io_stats[k] : 0; }
 void uz_stage_timing(const uz_stage *P, double out[6]) { for (int k = 0; k < 6; k++) out[k] = P ? P->timing[k] : 0.0; }

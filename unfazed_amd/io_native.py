@@ -28,7 +28,7 @@ IO_EXPORTS = [
     "uz_bam_tlen_head", "uz_bam_timing", "uz_bam_decode_regions", "uz_bam_io_stats", "uz_vcf_decode", "uz_vcf_free", "uz_vcf_view_get", "uz_vcf_sample",
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
-    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16", "uz_select_n_esc16_start8", "uz_select_n_esc16_narrow8", "uz_select_pair8_ok", "uz_select_n_esc16_pair8", "uz_select_n_new_names", "uz_select_qname_map",
+    "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_bl", "uz_select_n_bl_units", "uz_select_bl_wide", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16", "uz_select_n_esc16_start8", "uz_select_n_esc16_narrow8", "uz_select_pair8_ok", "uz_select_n_esc16_pair8", "uz_select_n_new_names", "uz_select_qname_map",
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
@@ -133,7 +133,8 @@ def load():
     lib.uz_reads_source_close.restype = None
     lib.uz_reads_select_plan.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                          C.POINTER(C.c_void_p)]
-    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units,
+    lib.uz_select_bl_wide.argtypes = [C.c_void_p]
+    for fn in (lib.uz_select_n_records, lib.uz_select_n_cigar_total, lib.uz_select_n_row_units, lib.uz_select_n_seq_units, lib.uz_select_n_bl, lib.uz_select_n_bl_units,
                lib.uz_select_n_exc, lib.uz_select_n_qlow_pos, lib.uz_select_n_cigar_omitted, lib.uz_select_n_tuples, lib.uz_select_n_esc16, lib.uz_select_n_esc16_start8, lib.uz_select_n_esc16_narrow8, lib.uz_select_n_esc16_pair8, lib.uz_select_n_new_names):
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int64
@@ -487,7 +488,7 @@ class ReadsSource:
         self.threads = threads
 
     def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True,
-               tuples=True, d16=True, start8=True, wide_no_units=False, narrow8=True, pair8=True):
+               tuples=True, d16=True, start8=True, wide_no_units=False, narrow8=True, pair8=True, base_lists=None):
         """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
@@ -512,7 +513,8 @@ class ReadsSource:
             extra = np.ascontiguousarray(extra, np.uint16)
             assert extra.size == contig.size
         _check(self.lib, self.lib.uz_reads_select_plan(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data,
-                                                       hi.ctypes.data, 1 if all_bases else 0, (3 if wide_no_units else 1) if masks else 0,
+                                                       hi.ctypes.data, 1 if all_bases else 0,
+                                                       ((3 if wide_no_units else 1) | (4 if (os.environ.get("UZ_BASE_LISTS", "1") != "0" if base_lists is None else base_lists) else 0)) if masks else 0,
                                                        extra.ctypes.data if masks else None,
                                                        (1 | (2 if cigar_compact else 0) | (4 if lists else 0)) if tuples else 0,
                                                        int(self.threads), C.byref(sel)))
@@ -520,6 +522,7 @@ class ReadsSource:
             n = self.lib.uz_select_n_records(sel)
             two_bit = bool(self.packed.view.seq2)  # a selection keeps the base-row form of its source
             n_tup = int(self.lib.uz_select_n_tuples(sel)) if tuples else -1
+            n_bl = int(self.lib.uz_select_n_bl(sel))
             pair8 = bool(pair8 and d16 and start8 and self.lib.uz_select_pair8_ok(sel))
             narrow8 = bool(narrow8 and not pair8)
             out = abi.packed_view_alloc(n, int(self.packed.view.n_contigs), self.lib.uz_select_n_cigar_total(sel),
@@ -532,7 +535,8 @@ class ReadsSource:
                                         n_tup=n_tup if n_tup >= 0 else None,
                                         n_esc16=int((self.lib.uz_select_n_esc16_pair8 if pair8 else self.lib.uz_select_n_esc16_narrow8 if (start8 and narrow8)
                                                      else self.lib.uz_select_n_esc16_start8 if start8 else self.lib.uz_select_n_esc16)(sel)) if d16 else None,
-                                        start8=bool(d16 and start8), narrow8=bool(d16 and start8 and narrow8), pair8=pair8)
+                                        start8=bool(d16 and start8), narrow8=bool(d16 and start8 and narrow8), pair8=pair8,
+                                        n_bl=n_bl if n_bl >= 0 else None, n_bl_units=int(self.lib.uz_select_n_bl_units(sel)), bl_wide=bool(self.lib.uz_select_bl_wide(sel)))
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
@@ -547,7 +551,7 @@ class ReadsSource:
 
 
 # ---------------------------------------------------------------------------- BAM file -> staged records in one pass
-STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE = 1, 2, 4
+STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE, STAGE_WIDE_NO_UNITS, STAGE_BASE_LISTS = 1, 2, 4, 8, 16
 
 
 def index_summary(path: str, kind: str) -> np.ndarray:
@@ -616,7 +620,7 @@ class BamSource:
         self.tlen_head = head[: int(k)].copy()
 
     def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False,
-               inflate=None, inflate_alloc=None, inflate_max_bytes=16 << 30):
+               inflate=None, inflate_alloc=None, inflate_max_bytes=16 << 30, base_lists=None):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
         `.io_stats` / `.timing` / `.qnames` ride on the returned object.
         pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
@@ -633,7 +637,10 @@ class BamSource:
         if extra is not None:
             extra = np.ascontiguousarray(extra, np.uint16)
             assert extra.size == contig.size
-        flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_UNIT_MASKS if masks else 0) | (0 if lists else STAGE_PLANE) | (8 if wide_no_units and masks else 0)
+        if base_lists is None:  # (UZ_BASE_LISTS=0: every record's staged units as rows, the form of round 3)
+            base_lists = os.environ.get("UZ_BASE_LISTS", "1") != "0"
+        flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_UNIT_MASKS if masks else 0) | (0 if lists else STAGE_PLANE) | (STAGE_WIDE_NO_UNITS if wide_no_units and masks else 0) \
+            | (STAGE_BASE_LISTS if base_lists and masks else 0)
         st = C.c_void_p()
         pre = None
         if inflate is None:
@@ -661,17 +668,18 @@ class BamSource:
                 _check(self.lib, self.lib.uz_stage_set_inflated(sh.ptr, inflated.ctypes.data))
                 pre = dict(blocks=int(nb.value), comp_bytes=int(cb.value), out_bytes=int(ob.value), gather_s=t_i - t_g, inflate_s=t_e - t_i, keep=(comp, inflated))
             _check(self.lib, self.lib.uz_bam_stage_finish(sh.ptr))
-        z = (C.c_int64 * 12)()
+        z = (C.c_int64 * 16)()
         self.lib.uz_stage_sizes(sh.ptr, z)
-        n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um = (int(x) for x in z)
+        n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um, has_bl, n_bl, n_blu = (int(x) for x in z[:15])
         if pool is not None:  # the sizes are known now: one block for all the columns (each 256-byte aligned)
-            total = (n * 5 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 12 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
-                     + 40 * 256 + 4096)
+            total = (n * 5 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 13 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
+                     + n_bl * 3 + 44 * 256 + 4096)
             pool.new_slab(total)
             alloc = pool.alloc
         out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
                                     n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
-                                    cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True, pair8=True)
+                                    cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True, pair8=True,
+                                    n_bl=n_bl if has_bl else None, n_bl_units=n_blu, bl_wide=bool(wide) and bool(has_bl))
         _check(self.lib, self.lib.uz_stage_fill(sh.ptr, int(self.threads), out.ref()))
         io = (C.c_int64 * 8)()
         self.lib.uz_stage_io_stats(sh.ptr, io)
