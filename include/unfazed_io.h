@@ -287,6 +287,9 @@ void uz_stage_timing(const uz_stage *s, double out[6]);
 /* writes the columns into the caller's buffers (sized from uz_stage_sizes; every pointer of the form described above set) */
 int uz_stage_fill(const uz_stage *s, int threads, uz_reads_packed_view *out);
 const char *uz_stage_qname(const uz_stage *s, uint32_t id, int32_t *len);
+/* many names at once: the bytes of names ids[0 .. n) back to back into buf (no terminators), off[k] .. off[k + 1] the k-th ([n + 1]); returns the
+ * bytes needed (cap = 0: the size only), -1 for an id out of range */
+int64_t uz_stage_qnames(const uz_stage *s, const uint32_t *ids, int64_t n, char *buf, int64_t cap, int64_t *off);
 void uz_stage_free(uz_stage *s);
 
 #ifdef __cplusplus

@@ -190,4 +190,5 @@ def link_bytes(pv) -> int:
     fixed = ((2 if pv.pair_d8 else 5 if pv.mate_d8 else 7) if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
     return (int(pv.n_segs) * fixed + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
             + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
-            + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16))
+            + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16)
+            + (int(pv.n_bl) * (2 if pv.bl_wide else 1) + (int(pv.n_bl) + 3) // 4 + (int(pv.n_tup) if pv.tup_n_bl else int(pv.n_segs) if pv.bl_n else 0)))

@@ -191,7 +191,9 @@ def test_config2_1k_spaced_dnms_vs_oracle(engine):
         assert cpu["parity_mismatches_vs_gpu"] == 0, cpu
         out, n_chunks, _ = _staged(engine, load, P, fid)
         _same(out, res, what="config 2 staged vs resident")
-        assert (res["status"] == abi.ST_OK).sum() > 300
+        # (at one site per 550 bp a +-5 kb window holds ~3 het sites with two good parents: the chain from the DNM reaches a candidate for about one DNM
+        # in eight -- the oracle says the same, DNM by DNM, above)
+        assert (res["status"] == abi.ST_OK).sum() > 50
         engine.free_reads(rid)
         engine.free_sites(sid)
     finally:

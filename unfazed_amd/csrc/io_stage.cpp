@@ -1458,6 +1458,24 @@ const char *uz_stage_qname(const uz_stage *P, uint32_t id, int32_t *len) {
     return P->name_tmp.c_str();
 }
 
+// many names at once: the bytes of names ids[0 .. n) back to back into buf (no terminators), off[k] .. off[k + 1] the k-th; returns the bytes
+// needed (call with cap = 0 for the size), -1 for an id out of range
+int64_t uz_stage_qnames(const uz_stage *P, const uint32_t *ids, int64_t n, char *buf, int64_t cap, int64_t *off) {
+    if (!P || (n > 0 && !ids)) return -1;
+    int64_t at = 0;
+    for (int64_t k = 0; k < n; k++) {
+        if (ids[k] >= P->name_of_id.size()) return -1;
+        const int64_t ref = P->name_of_id[ids[k]];
+        const Task &T = P->tasks[(size_t)(ref >> 32)];
+        const WRec &x = T.recs[(size_t)(ref & 0xFFFFFFFF)];
+        if (off) off[k] = at;
+        if (buf && at + x.l_name <= cap) memcpy(buf + at, T.names.data() + x.name_at, x.l_name);
+        at += x.l_name;
+    }
+    if (off) off[n] = at;
+    return at;
+}
+
 void uz_stage_free(uz_stage *P) { delete P; }
 
 } // extern "C"

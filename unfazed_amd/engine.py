@@ -116,11 +116,15 @@ class HipEngine:
         import threading
         self._inflate_lock = threading.Lock()
         self._inflate_bufs = None  # PinnedPair of upload_reads_staged
+        self._stage_pool = None    # PinnedPool of upload_reads_staged: the staged columns' page-locked block, kept from batch to batch
 
     def close(self):
         if getattr(self, "_inflate_bufs", None) is not None:
             self._inflate_bufs.free_all()
             self._inflate_bufs = None
+        if getattr(self, "_stage_pool", None) is not None:
+            self._stage_pool.free_all()
+            self._stage_pool = None
         if getattr(self, "h", None):
             self.L.uz_destroy(self.h)
             self.h = None
@@ -226,7 +230,12 @@ class HipEngine:
         """One batch straight from an indexed BAM (io_native.BamSource): the records its fetches return + their mates, built in the
         link form in pinned memory by one pass over the file's blocks (uz_bam_stage_*), uploaded as one table.
         -> (reads id, the staged view: `.qnames` maps the name ids of the result lists back to strings)"""
-        pool = PinnedPool()
+        # the page-locked block of the staged columns is kept from batch to batch (pinning a gigabyte takes about a second: round 3's
+        # product route spent 1.2 s of its 2.4 s per 20 k DNMs there): rewound when it is large enough, replaced when not
+        if self._stage_pool is None:
+            self._stage_pool = PinnedPool()
+        pool = self._stage_pool
+        pool.keep = True
         rid = None
         try:
             inflate = inflate_alloc = None
@@ -249,8 +258,6 @@ class HipEngine:
                     pass
                 self._staged.pop(rid, None)
             raise
-        finally:
-            pool.free_all()
         names = type("StagedNames", (), {})()
         names.qnames, names.io_stats, names.timing = packed.qnames, packed.io_stats, packed.timing
         return rid, names
@@ -532,6 +539,8 @@ class PinnedPool:
         self.L = load_library()
         self._blocks = []
         self._slab = None  # [base address, capacity, used]: alloc() carves from it while it lasts
+        self._ended = None  # the slab end_slab() closed (rewind() takes it up again)
+        self.keep = False   # kept from batch to batch by its owner (io_native.BamSource.select rewinds it instead of pinning a new block)
         self.last_slab_used = 0
 
     def new_slab(self, nbytes: int):
@@ -549,6 +558,8 @@ class PinnedPool:
     def rewind(self, nbytes: int) -> bool:
         """Start over in the current slab when it holds at least `nbytes` (a staging loop re-uses its page-locked block chunk after
         chunk instead of pinning a new one); the overflow blocks of the last use are freed.  False: no slab of that size."""
+        if self._slab is None and getattr(self, "_ended", None) is not None:
+            self._slab = self._ended  # (end_slab() closed it: the block is still there)
         if self._slab is None or self._slab[1] < int(nbytes):
             return False
         keep = self._slab[0]
@@ -564,6 +575,7 @@ class PinnedPool:
 
     def end_slab(self) -> int:
         used = self._slab[2] if self._slab else 0
+        self._ended = self._slab
         self._slab = None
         return used
 
@@ -587,3 +599,4 @@ class PinnedPool:
             self.L.uz_pinned_free(C.c_void_p(p))
         self._blocks = []
         self._slab = None
+        self._ended = None

@@ -125,9 +125,16 @@ class PhasingHost:
         return self._reads_h[key]
 
     def _indexed(self, bam: str) -> bool:
-        """does the reads source decode regions of this file through an index (session._LazyReads)?"""
+        """does the reads source decode regions of this file through an index (session._LazyReads)?  (asked once per file and batch: the
+        answer looks at the file system)"""
+        memo = getattr(self, "_indexed_memo", None)
+        if memo is not None and bam in memo:
+            return memo[bam]
         f = getattr(self.reads_by_bam, "indexed", None)
-        return bool(f and f(bam))
+        r = bool(f and f(bam))
+        if memo is not None:
+            memo[bam] = r
+        return r
 
     def reads_header(self, bam: str) -> ReadsTable:
         """what the host logic needs before any record is decoded: contig names and the head of the file (insert cutoff)"""
@@ -420,6 +427,7 @@ class PhasingHost:
         SV variant sv_phaser.py:176-266 (+ :88-173): no REF/ALT lookup, reads collected by
         collect_reads_sv, and autophase that does not short-circuit (quirk Q18)."""
         log = _Log(quiet_mode)
+        self._indexed_memo = {}
         params.no_extended = 1 if no_extended else 0
         params.read_goal = int(insert_size_max_sample)
         params.readlen = int(readlen)
@@ -436,6 +444,7 @@ class PhasingHost:
         batch: Dict[tuple, List[int]] = {}
         prep: Dict[int, dict] = {}
         sample_set = set(self.sites.samples)
+        contig_memo: Dict[tuple, tuple] = {}
         refalt = {} if sv else self.batch_refalt(dnms, [i for i in info["order"] if found.get(i) is not None and len(found[i]["cand_idx"])])
         for i in info["order"]:
             dn = dnms[i]
@@ -462,8 +471,10 @@ class PhasingHost:
                 if len(alts) > 1:
                     plan.append((i, "manygt"))
                     continue
-            rt = self.reads_header(dn["bam"])
-            tid, fl = self.resolve_reads_contig(rt, dn["chrom"])
+            hk = (dn["bam"], dn["chrom"])
+            if hk not in contig_memo:
+                contig_memo[hk] = self.resolve_reads_contig(self.reads_header(dn["bam"]), dn["chrom"])
+            tid, fl = contig_memo[hk]
             if tid < 0:
                 plan.append((i, "silent"))  # ValueError out of the worker: no record
                 continue
@@ -543,7 +554,21 @@ class PhasingHost:
             for g, (fam, rh, first, count, cutoff) in enumerate(groups):
                 for k in range(first, first + count):
                     results[order_all[k]] = (res, k, tables[g])
-        # pass 3: records, in the reference's order
+        self._indexed_memo = None
+        # pass 3: records, in the reference's order.  The names of the reads in the result lists: one look-up per table for the whole batch
+        # (a staged table answers ids through the C ABI: hundreds of thousands of single calls were a third of round 3's host time)
+        names_of: Dict[int, Dict[int, str]] = {}
+        for g_tab in {id(t): t for (_, _, t) in results.values()}.values():
+            take = getattr(getattr(g_tab, "qnames", None), "take", None)
+            if take is None:
+                continue
+            ids = []
+            for (res, k, rt) in results.values():
+                if rt is g_tab and res.get("lists") is not None and int(res["status"][k]) == abi.ST_OK:
+                    ids.append(res["lists"][k][0]); ids.append(res["lists"][k][1])
+            if ids:
+                u = np.unique(np.concatenate(ids + [np.zeros(0, np.int64)]).astype(np.int64))
+                names_of[id(g_tab)] = dict(zip(u.tolist(), take(u)))
         for i, action in plan:
             dn = dnms[i]
             dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
@@ -586,8 +611,13 @@ class PhasingHost:
                 lists = res.get("lists")
                 if lists is not None:
                     dr, mr, ds, ms = lists[k]
-                    dad_reads = [rt.qnames[q] for q in dr]
-                    mom_reads = [rt.qnames[q] for q in mr]
+                    nm = names_of.get(id(rt))
+                    if nm is not None:
+                        dad_reads = [nm[q] for q in dr.tolist()]
+                        mom_reads = [nm[q] for q in mr.tolist()]
+                    else:
+                        dad_reads = [rt.qnames[q] for q in dr]
+                        mom_reads = [rt.qnames[q] for q in mr]
                     dad_sites = [str(p) for p in ds]
                     mom_sites = [str(p) for p in ms]
                 else:

@@ -32,7 +32,7 @@ IO_EXPORTS = [
     "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
-    "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname",
+    "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
     "uz_stage_free",
 ]
 
@@ -171,6 +171,8 @@ def load():
     lib.uz_stage_fill.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.uz_stage_qname.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int32)]
     lib.uz_stage_qname.restype = C.c_void_p
+    lib.uz_stage_qnames.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.uz_stage_qnames.restype = C.c_int64
     lib.uz_stage_free.argtypes = [C.c_void_p]
     lib.uz_stage_free.restype = None
     _LIB = lib
@@ -601,6 +603,22 @@ class _StageNames(Sequence):
         p = self._lib.uz_stage_qname(self._h.ptr, i, C.byref(ln))
         return C.string_at(p, ln.value).decode()
 
+    def take(self, ids) -> list:
+        """the names of many ids in one call (uz_stage_qnames): a batch's result lists name hundreds of thousands of reads"""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = int(ids.size)
+        if n == 0:
+            return []
+        off = np.zeros(n + 1, np.int64)
+        need = int(self._lib.uz_stage_qnames(self._h.ptr, ids.ctypes.data, n, None, 0, off.ctypes.data))
+        if need < 0:
+            raise IndexError("query-name id out of range")
+        buf = np.empty(max(1, need), np.uint8)
+        self._lib.uz_stage_qnames(self._h.ptr, ids.ctypes.data, n, buf.ctypes.data, need, None)
+        text = buf[:need].tobytes().decode()
+        o = off.tolist()
+        return [text[o[k]: o[k + 1]] for k in range(n)]
+
 
 class BamSource:
     """An indexed BAM opened for staging (uz_bamsrc_open): `select` turns the fetches of one batch straight into the packed table
@@ -674,7 +692,11 @@ class BamSource:
         if pool is not None:  # the sizes are known now: one block for all the columns (each 256-byte aligned)
             total = (n * 5 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 13 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
                      + n_bl * 3 + 44 * 256 + 4096)
-            pool.new_slab(total)
+            if not (getattr(pool, "keep", False) and pool.rewind(total)):  # (a kept pool: its block is re-used when it is large enough)
+                if getattr(pool, "keep", False):
+                    pool.free_all()
+                    total += total // 4
+                pool.new_slab(total)
             alloc = pool.alloc
         out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
                                     n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
