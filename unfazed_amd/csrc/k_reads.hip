@@ -200,19 +200,18 @@ __device__ __forceinline__ RecSmall rec_small(const RecColumns &c, int64_t i) {
 // an escape costs its wave two or three loads instead of a binary search over the whole list
 __device__ __forceinline__ int32_t esc16_of(const RecColumns &c, int64_t i, int col) {
     const unsigned long long key = ((unsigned long long)i << 2) | (unsigned long long)col;
-    int64_t lo = 0, hi = c.n_esc16;
-    if (c.esc_off) { lo = c.esc_off[i >> c.pk_shift]; hi = c.esc_off[(i >> c.pk_shift) + 1]; }
+    int64_t lo = c.esc_lo, hi = c.esc_hi; // (the entries of the workgroup's own span: set by the kernels below)
     while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (c.esc16_key[mid] < key) lo = mid + 1; else hi = mid; }
     return (lo < c.n_esc16 && c.esc16_key[lo] == key) ? c.esc16_val[lo] : 0; // (a missing entry is caught by the totals / the mate check)
 }
-// first escape entry of every span of records (and the end of the list)
-__global__ __launch_bounds__(256) void k_esc_block_off(int64_t nb, int pk_shift, const unsigned long long *__restrict__ key, int64_t n_esc, int64_t *off) {
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (b > nb) return;
-    const unsigned long long want = (unsigned long long)(b << pk_shift) << 2;
+// first escape entry at or behind record `rec` (the list is sorted by record): every workgroup of the header build bounds the searches of
+// its span with two of these, kept in LDS (a kernel of its own did that for all spans at once: one more small launch per table that had to
+// wait for room beside the read stage's persistent workgroups)
+__device__ __forceinline__ int64_t esc_lower_bound(const unsigned long long *__restrict__ key, int64_t n_esc, int64_t rec) {
+    const unsigned long long want = (unsigned long long)rec << 2;
     int64_t lo = 0, hi = n_esc;
     while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (key[mid] < want) lo = mid + 1; else hi = mid; }
-    off[b] = lo;
+    return lo;
 }
 __device__ __forceinline__ uint32_t d16_val(const RecColumns &c, const int16_t *col, int64_t i, int k) {
     const int v = col[i];
@@ -238,9 +237,77 @@ __device__ __forceinline__ uint32_t start_diff(const RecColumns &c, int64_t i) {
     }
     return d16_val(c, c.start_d, i, 0);
 }
-__global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
+// The form every packer of the product emits (uz_bam_stage_*, uz_reads_select_* with its defaults): the small columns through the dictionary
+// with unit masks and counts of low-quality bases, eight-bit start differences, the pair form, compact CIGARs, no `end`.  The header-build
+// kernels are compiled once more for exactly that form: the pointers of every other form are known to be null there, their branches fall
+// away, and what stays alive across the record loop fits the scalar registers (the general build of k_pack_rec spills 160 of them).
+__host__ __device__ inline bool uz_link_form(const RecColumns &c) {
+    return c.tup && c.tup_umask && c.tup_n_low && c.lists && c.start_d8 && c.pair_d8 && c.cigar_out && !c.end && !c.plane_in && !c.umask && !c.n_low && !c.bl_n &&
+           !c.start && !c.start_d && !c.tlen_s && !c.mate_d8 && !c.qname_d8 && !c.flag;
+}
+template <bool LINK>
+__device__ __forceinline__ RecColumns uz_columns_of(const RecColumns &in) {
+    RecColumns c = in;
+    if (LINK) {
+        c.start = nullptr; c.end = nullptr; c.tlen = nullptr; c.mate = nullptr; c.qname = nullptr;
+        c.flag = nullptr; c.l_seq = nullptr; c.n_cigar = nullptr; c.mapq = nullptr; c.aux = nullptr;
+        c.umask = nullptr; c.start_d = nullptr; c.tlen_s = nullptr; c.mate_d = nullptr; c.qname_d = nullptr; c.mate_d8 = nullptr; c.qname_d8 = nullptr;
+        c.plane_in = nullptr; c.n_low = nullptr; c.bl_n = nullptr; c.lists = 1;
+        __builtin_assume(c.tup != nullptr); __builtin_assume(c.tup_umask != nullptr); __builtin_assume(c.tup_n_low != nullptr);
+        __builtin_assume(c.start_d8 != nullptr); __builtin_assume(c.pair_d8 != nullptr); __builtin_assume(c.cigar_out != nullptr);
+        __builtin_assume(c.cigar_in != nullptr);
+    }
+    return c;
+}
+// exclusive scan of the block sums in place by ONE workgroup of 256 lanes; the totals are checked against what the view declared
+struct PkWant { unsigned long long cigar, units, seq, qpos, staged /* ~0: not compact */, bl_units, bl; };
+__device__ __forceinline__ void scan_block_sums(int64_t nb, unsigned long long *sums, const PkWant &want, int32_t *hflags) {
+    __shared__ unsigned long long wpart[UZ_PK_SUMS][4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t chunk = (nb + 255) / 256;
+    const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
+    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, inc[UZ_PK_SUMS];
+    for (int64_t i = lo; i < hi; i++)
+        for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SUMS; k++) { // inclusive scan inside the wave, then across the four waves
+        unsigned long long x = v[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
+        inc[k] = x;
+        if (lane == 63) wpart[k][wv] = x;
+    }
+    __syncthreads();
+    unsigned long long tot[UZ_PK_SUMS];
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SUMS; k++) {
+        unsigned long long pre = 0, all = 0;
+        for (int w = 0; w < 4; w++) { const unsigned long long x = wpart[k][w]; if (w < wv) pre += x; all += x; }
+        v[k] = pre + inc[k] - v[k]; // exclusive prefix of this thread's blocks
+        tot[k] = all;
+    }
+    if (t == 0) {
+        if (tot[0] != want.cigar || tot[1] != want.units || tot[2] != want.seq || tot[3] != want.qpos || tot[0] > 0xFFFFFFFFULL || tot[1] > 0xFFFFFFFFULL ||
+            (want.staged != ~0ULL && tot[4] != want.staged) || tot[7] != want.bl_units || tot[8] != want.bl || tot[1] + tot[7] > 0xFFFFFFFFULL)
+            hflags[0] = 1;
+        if (tot[9] != tot[10]) hflags[0] = 8; // pair form: as many SECOND records as FIRST ones (k_pair_link checks that they are each other's)
+    }
+    for (int64_t i = lo; i < hi; i++)
+        for (int k = 0; k < UZ_PK_SUMS; k++) {
+            const unsigned long long x = sums[UZ_PK_SUMS * i + k];
+            sums[UZ_PK_SUMS * i + k] = v[k];
+            v[k] += x;
+        }
+}
+template <bool LINK>
+__global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c_in, unsigned long long *sums /* [UZ_PK_SUMS nb] */) {
+    RecColumns c = uz_columns_of<LINK>(c_in);
     __shared__ unsigned long long part[UZ_PK_SUMS][4];
+    __shared__ int64_t esc_span[2];
     const int t = threadIdx.x;
+    if (c.n_esc16 > 0 && t < 2) esc_span[t] = esc_lower_bound(c.esc16_key, c.n_esc16, ((int64_t)blockIdx.x + t) << c.pk_shift);
+    __syncthreads();
+    c.esc_lo = c.n_esc16 > 0 ? esc_span[0] : 0; c.esc_hi = c.n_esc16 > 0 ? esc_span[1] : 0;
     unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // four records per lane at a time: their column bytes are requested together, then their dictionary entries, then the sums --
     // three round trips to memory for four records instead of three for each
@@ -292,49 +359,21 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c,
     if (t == 0)
         for (int k = 0; k < UZ_PK_SUMS; k++) sums[UZ_PK_SUMS * (size_t)blockIdx.x + k] = part[k][0] + part[k][1] + part[k][2] + part[k][3];
 }
-// one workgroup: exclusive scan of the block sums in place; the totals are checked against what the view declared
-__global__ __launch_bounds__(1024) void k_off_scan_sums(int64_t nb, unsigned long long *sums, unsigned long long want_cigar,
-                                                        unsigned long long want_units, unsigned long long want_seq, unsigned long long want_qpos,
-                                                        unsigned long long want_staged /* ~0: not compact */, unsigned long long want_bl_units,
-                                                        unsigned long long want_bl, int32_t *hflags) {
-    __shared__ unsigned long long wpart[UZ_PK_SUMS][16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int64_t chunk = (nb + 1023) / 1024;
-    const int64_t lo = t * chunk < nb ? t * chunk : nb, hi = lo + chunk < nb ? lo + chunk : nb;
-    unsigned long long v[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, inc[UZ_PK_SUMS];
-    for (int64_t i = lo; i < hi; i++)
-        for (int k = 0; k < UZ_PK_SUMS; k++) v[k] += sums[UZ_PK_SUMS * i + k];
-#pragma unroll
-    for (int k = 0; k < UZ_PK_SUMS; k++) { // inclusive scan inside the wave, then across the sixteen waves
-        unsigned long long x = v[k];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(x, o, 64); if (lane >= o) x += u; }
-        inc[k] = x;
-        if (lane == 63) wpart[k][wv] = x;
-    }
-    __syncthreads();
-    unsigned long long tot[UZ_PK_SUMS];
-#pragma unroll
-    for (int k = 0; k < UZ_PK_SUMS; k++) {
-        unsigned long long pre = 0, all = 0;
-        for (int w = 0; w < 16; w++) { const unsigned long long x = wpart[k][w]; if (w < wv) pre += x; all += x; }
-        v[k] = pre + inc[k] - v[k]; // exclusive prefix of this thread's blocks
-        tot[k] = all;
-    }
-    if (t == 0) {
-        if (tot[0] != want_cigar || tot[1] != want_units || tot[2] != want_seq || tot[3] != want_qpos || tot[0] > 0xFFFFFFFFULL || tot[1] > 0xFFFFFFFFULL ||
-            (want_staged != ~0ULL && tot[4] != want_staged) || tot[7] != want_bl_units || tot[8] != want_bl || tot[1] + tot[7] > 0xFFFFFFFFULL)
-            hflags[0] = 1;
-        if (tot[9] != tot[10]) hflags[0] = 8; // pair form: as many SECOND records as FIRST ones (k_pair_link checks that they are each other's)
-    }
-    for (int64_t i = lo; i < hi; i++)
-        for (int k = 0; k < UZ_PK_SUMS; k++) { const unsigned long long x = sums[UZ_PK_SUMS * i + k]; sums[UZ_PK_SUMS * i + k] = v[k]; v[k] += x; }
-}
-__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
+// (One workgroup.  Tried in round 4 and dropped: the scan done by whichever workgroup of k_off_block_sums finishes last.  The sums then cross
+// between XCDs inside a kernel: with a __threadfence per workgroup every kernel of the step ran 20 - 50 % slower -- two thousand L2
+// write-backs per table -- and with agent-scope accesses instead the lone scanning workgroup sat through ~180 uncached round trips.)
+__global__ __launch_bounds__(256) void k_off_scan_sums(int64_t nb, unsigned long long *sums, PkWant want, int32_t *hflags) { scan_block_sums(nb, sums, want, hflags); }
+template <bool LINK>
+__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
-                                                  uint16_t *qs, int32_t *hflags) {
+                                                  uint16_t *qs, int32_t *coarse, int32_t *hflags) {
+    RecColumns c = uz_columns_of<LINK>(c_in);
     __shared__ uint32_t wsum[UZ_PK_SCANNED][4];
+    __shared__ int64_t esc_span[2];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (c.n_esc16 > 0 && t < 2) esc_span[t] = esc_lower_bound(c.esc16_key, c.n_esc16, ((int64_t)blockIdx.x + t) << c.pk_shift);
+    __syncthreads();
+    c.esc_lo = c.n_esc16 > 0 ? esc_span[0] : 0; c.esc_hi = c.n_esc16 > 0 ? esc_span[1] : 0;
     unsigned long long run[UZ_PK_SCANNED];
 #pragma unroll
     for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
@@ -444,6 +483,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c, const
             const int32_t en0 = c.end ? c.end[i] : (((rs.flag & 4u) || nc == 0 || !have_words) ? st0 + 1 : (int32_t)(st0 + (ref_len > 0 ? ref_len : 1)));
             int low_for_qc = 0; // (an ASCII upload has no counts yet: uz_build_qlow sets the bit that depends on them)
             uz_pack_rec(A, B, st0, en0, cg, sq, mt0, qn0, (uint16_t)ls, (uint16_t)nc, tl0);
+            if ((i & 4095) == 0) coarse[i >> 12] = st0; // the coarse search index: start of every 4096th record
             ra[i] = A;
             rb[i] = B;
             fm[i] = uz_pack_fm(rs.flag, rs.mapq, ax);
@@ -705,22 +745,26 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     col.pk_shift = uz_pk_shift(r.n);
     const unsigned nb = (unsigned)((r.n + (1 << col.pk_shift) - 1) >> col.pk_shift);
     unsigned long long *sums = (unsigned long long *)off_scratch;
-    if (col.n_esc16 > 0) { // the escape list cut at the spans of the passes below
-        int64_t *off = (int64_t *)(sums + (size_t)(nb + 1) * UZ_PK_SUMS);
-        hipLaunchKernelGGL(k_esc_block_off, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (int64_t)nb, col.pk_shift, col.esc16_key, col.n_esc16, off);
-        col.esc_off = off;
-    }
-    hipLaunchKernelGGL(k_off_block_sums, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
-    hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(1024), 0, st, (int64_t)nb, sums, (unsigned long long)r.n_cigar_total,
-                       (unsigned long long)r.n_row_units, (unsigned long long)(r.n_seq_units - r.n_bl_units), (unsigned long long)r.n_qlow_pos,
-                       col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL, (unsigned long long)r.n_bl_units, (unsigned long long)r.n_bl, c->hflags);
-    hipLaunchKernelGGL(k_pack_rec, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, c->hflags);
+    // (the escape list is cut at the spans of the passes below by the workgroups themselves; the coarse search index is written by the second
+    // pass: two launches gone from every table)
+    PkWant want;
+    want.cigar = (unsigned long long)r.n_cigar_total; want.units = (unsigned long long)r.n_row_units; want.seq = (unsigned long long)(r.n_seq_units - r.n_bl_units);
+    want.qpos = (unsigned long long)r.n_qlow_pos; want.staged = col.cigar_out ? (unsigned long long)r.n_cigar_staged : ~0ULL;
+    want.bl_units = (unsigned long long)r.n_bl_units; want.bl = (unsigned long long)r.n_bl;
+    static const bool no_link_build = getenv("UZ_BUILD_GENERIC") != nullptr; // (development aid: the general build of the two kernels for every table)
+    const bool link_form = uz_link_form(col) && col.cigar_in != nullptr && !no_link_build;
+    if (link_form) hipLaunchKernelGGL((k_off_block_sums<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
+    else hipLaunchKernelGGL((k_off_block_sums<false>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
+    hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(256), 0, st, (int64_t)nb, sums, want, c->hflags);
+    if (link_form)
+        hipLaunchKernelGGL((k_pack_rec<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
+                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags);
+    else
+        hipLaunchKernelGGL((k_pack_rec<false>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
+                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags);
     if (col.pair_d8)
         hipLaunchKernelGGL(k_pair_link, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, col.pair_d8, (const RecA *)r.rec_a, (RecB *)r.rec_b,
                            c->hflags);
-    const int64_t nk = (r.n >> 12) + 2;
-    hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
     // the table arrived with two-bit base rows: expand them into seq4 (the units of list-form records, behind them, were written by
     // k_pack_rec); then the listed bases that are not A/C/G/T, of either kind of record
     if (r.seq2_staged && r.n_seq_units - r.n_bl_units > 0) {

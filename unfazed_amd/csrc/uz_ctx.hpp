@@ -331,7 +331,7 @@ struct RecColumns {
     const unsigned long long *esc16_key = nullptr;
     const int32_t *esc16_val = nullptr;
     int64_t n_esc16 = 0;
-    const int64_t *esc_off = nullptr; // set by the header build: first escape entry of every span of records
+    int64_t esc_lo = 0, esc_hi = 0;   // set by the header build's workgroups: the escape entries of their own span of records
     int32_t pk_shift = 12;            // set by the header build: records per span of its passes = 1 << pk_shift (a small table gets shorter spans: more workgroups)
     int32_t lists = 0; // the qualities came as counts (+ positions): n_low, or tup_n_low through the table
     const uint32_t *plane_in = nullptr;

@@ -8,8 +8,9 @@ file and the alignment file for its own window.  Here a batch is cut into chunks
     records      the records those fetches return (+ mates), in the link form, queued on the copy stream
     read stage   queued on the compute stream (uz_phase_begin), picked up later (uz_phase_end)
     (config 5)   allele balance of the chunk's events on its own windows, merged with the read-backed counts
-with the stages of neighbouring chunks overlapped: the site windows travel two chunks ahead of their find, the read stage of chunk
-k - 1 is queued before the host waits for the het lists of chunk k + 1, and its results are taken when that wait is over.
+with the stages of neighbouring chunks overlapped: the site windows travel two chunks ahead of their find, the records of chunk k are
+enqueued as soon as its het lists are back, and its read stage is queued two finds later -- by then its copy and its header build have run
+beside the read stages of the chunks before it; the results are taken one iteration after that.
 
 A chunk is a dict:
     a, b        its DNMs are [a, b) of the batch (results are written there)
@@ -21,13 +22,14 @@ A chunk is a dict:
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
 
 
-def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None) -> Dict[str, np.ndarray]:
+def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None, lag: int = 2) -> Dict[str, np.ndarray]:
     """One pass over the batch -> per-DNM status / counts / origin / evidence (+ etype / cnv_counts for cnv)."""
     out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32), evidence=np.empty(n, np.int32))
     if cnv:
@@ -75,43 +77,42 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
     def tick():
         if tr is not None:
             tr.append(time.perf_counter())
-    # The read stage of chunk k - 1 is queued (uz_phase_begin) before the host waits for the het lists of chunk k + 1: that wait
-    # -- the ONE host round trip per chunk -- then runs behind the read stage's kernels instead of beside an idle device, and the
-    # read stage's results are there when it returns (uz_phase_end).  The site windows travel two chunks ahead of their find, so
-    # the link does not idle through that round trip either.  (config 5: the allele-balance stage of chunk k - 2 is queued behind
-    # the read stage of chunk k - 1, and waited for there.)
+    # Every wait of the host (the het lists of a find, the results of a read stage) sits behind whatever was queued on the compute stream
+    # before it, so the host runs LAG chunks ahead of the read stages: chunk k's records are enqueued as soon as find(k) returns, and its
+    # read stage is queued LAG iterations later -- by then the copy (0.8 ms for 12.5 k DNMs) and the header build on its own stream
+    # (0.85 ms) have run beside the read stages of the chunks before.  With a lag of one the read stage of chunk k had to wait for that
+    # chain (1.65 ms) from the moment the read stage of chunk k - 2 ended: 0.45 ms of idle device per chunk (rocprofv3 timeline of round
+    # 4: scripts/staged_timeline.sh).  The site windows travel two chunks ahead of their find, so the link does not idle through that
+    # round trip either.  The library keeps the window lists of the last three finds: a lag of two is what it serves.
+    # (config 5: the allele-balance stage of a chunk is queued behind the read stage of the next one, and waited for there.)
+    lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid: 1 = the order of round 3)
+    lag = max(1, min(int(lag), 2, K - 1)) if K > 1 else 1
     site_stage(0)
     if K > 1:
         site_stage(1)
     tick()
-    for k in range(K):
-        finds[k] = eng.find(fids[k], chunks[k]["dnms"], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
+    for k in range(K + lag + 1):
+        if k < K:
+            finds[k] = eng.find(fids[k], chunks[k]["dnms"], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
         tick()
-        if k >= 2:
-            read_stage_end(k - 2)
+        e, b = k - lag - 1, k - lag
+        if 0 <= e < K:
+            read_stage_end(e)
         tick()
-        if k >= 1:
-            read_stage_begin(k - 1)
+        if 0 <= b < K:
+            read_stage_begin(b)
         tick()
-        rec = chunks[k]["records"]
-        if callable(rec):
-            rec = rec(k, finds[k][3], finds[k][4])
-        finds[k] = None
-        rids[k] = eng.upload_reads_packed(rec)
-        if k + 2 < K:
-            site_stage(k + 2)
-        if cnv and k >= 2:
-            cnv_stage(k - 2)
+        if k < K:
+            rec = chunks[k]["records"]
+            if callable(rec):
+                rec = rec(k, finds[k][3], finds[k][4])
+            finds[k] = None
+            rids[k] = eng.upload_reads_packed(rec)
+            if k + 2 < K:
+                site_stage(k + 2)
+        if cnv and 0 <= e < K:
+            cnv_stage(e)
         tick()
-    if K >= 2:
-        read_stage_end(K - 2)
-    read_stage_begin(K - 1)
-    if cnv and K >= 2:
-        cnv_stage(K - 2)
-    read_stage_end(K - 1)
-    if cnv:
-        cnv_stage(K - 1)
-    tick()
     if tr is not None:
         trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
     return out
