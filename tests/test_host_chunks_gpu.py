@@ -1,0 +1,70 @@
+"""The product route for a LARGE batch of one kid from an indexed BAM (hostpath._chunked_batch): chunks of DNMs, chunk k + 1 decoded on
+a worker thread while chunk k is uploaded and phased.  The records must be exactly those of the one-table route -- DNMs are independent
+(reference: one task per DNM, snv_phaser.py:244-298) -- and those of the CPU oracle through the same host code."""
+import contextlib
+import io
+import os
+
+import pytest
+
+from helpers import norm_records
+from synth.small import SmallConfig, make_small
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(paths, ds, env):
+    from unfazed_amd import session
+    from unfazed_amd.snv_phaser import phase_snvs
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    session._READS.clear()
+    session._HOSTS.clear()
+    for k in [k for k in session._SITES if "@" in k]:
+        del session._SITES[k]
+    try:
+        kid = ds.dnms[0]["kid"]
+        dnms = [dict(chrom=d["chrom"], start=d["start"], end=d["end"], kid=d["kid"], vartype="POINT", bam=paths["bams"][d["kid"]], cram_ref=None)
+                for d in ds.dnms if d["kid"] == kid]
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            recs = phase_snvs(dnms, [kid], ds.pedigrees, paths["sites"], 2, "38", False, 10 ** 9, False, [0.0, 0.2], [0.8, 1.0], [0.2, 0.8], 20, 10, 5000,
+                              1000000, 3, 1, 151, 5)
+        return norm_records(recs), sorted(err.getvalue().splitlines()), len(dnms)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_chunked_route_equals_one_table_route(tmp_path, hip_lib):
+    import gzip
+    from filesio import dump_dataset, write_bai, write_bgzf_text, write_tbi
+    ds = make_small(SmallConfig(seed=909, n_dnms=46, cluster_prob=0.5))  # (one kid: the chunked route takes a batch of one alignment file)
+    paths = dump_dataset(ds, str(tmp_path))
+    for b in paths["bams"].values():
+        write_bai(b)
+    text = gzip.open(paths["sites"], "rt").read()
+    write_bgzf_text(paths["sites"], text)
+    write_tbi(paths["sites"])
+    whole, err_w, n = _run(paths, ds, {"UZ_HOST_CHUNKS": "0"})
+    assert n >= 40 and len(whole) >= 8
+    from unfazed_amd import hostpath
+    calls = []
+    orig = hostpath.PhasingHost._chunked_batch
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        calls.append(r)
+        return r
+    hostpath.PhasingHost._chunked_batch = spy
+    try:
+        for size in ("5", "13"):
+            got, err_g, _ = _run(paths, ds, {"UZ_HOST_CHUNKS": "1", "UZ_HOST_CHUNK_DNMS": size})
+            assert got == whole, size
+            assert err_g == err_w, size
+    finally:
+        hostpath.PhasingHost._chunked_batch = orig
+    assert calls == [True, True]  # (the chunked route really ran)

@@ -731,6 +731,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     }
 
     // ---- A: DNM reads -> ordered "ref" / "alt" lists (each hit contributes read, mate)
+    UZ_PHASE_ARGS(); // (the site columns of the set-up above are not needed again)
     const bool is_sv = a.vartype[d] != UZ_VT_POINT;
     const long long fa = a.pre_win[4 * d], fb = a.pre_win[4 * d + 1];
     const long long fa2 = a.pre_win[4 * d + 2], fb2 = a.pre_win[4 * d + 3];
@@ -1481,6 +1482,9 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
 //   seeding matches of one init element).
 // Lanes lane, lane + nlanes, ... share the het sites of DNM d; lane 0 also does the per-DNM part.
 // The caller reduces (t_part: sum, mh_part: max) over the lanes and stores them as b[1], b[4].
+// (Tried in round 4 and dropped: the window found by the 16 lanes of a DNM's group together, 16 probes per round -- seven rounds instead of ~24
+// dependent loads.  0.40 -> 0.49 ms for 100 k DNMs: the first rounds of a 16-ary search land all over a 3 GB column, cold in every cache and
+// TLB, where a binary search takes its first twelve steps on the 180 KB coarse index that stays in L2.)
 UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part) {
     const RD &R = a.R;
     const long long h0 = a.het_off[d];

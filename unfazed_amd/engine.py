@@ -117,6 +117,8 @@ class HipEngine:
         self._inflate_lock = threading.Lock()
         self._inflate_bufs = None  # PinnedPair of upload_reads_staged
         self._stage_pool = None    # PinnedPool of upload_reads_staged: the staged columns' page-locked block, kept from batch to batch
+        self._chunk_pools = [None, None]  # stage_reads: two alternating sets of page-locked buffers (columns; gathered / inflated blocks)
+        self._chunk_pairs = [None, None]
 
     def close(self):
         if getattr(self, "_inflate_bufs", None) is not None:
@@ -125,6 +127,11 @@ class HipEngine:
         if getattr(self, "_stage_pool", None) is not None:
             self._stage_pool.free_all()
             self._stage_pool = None
+        for k in range(2):
+            if getattr(self, "_chunk_pools", [None, None])[k] is not None:
+                self._chunk_pools[k].free_all()
+                self._chunk_pairs[k].free_all()
+                self._chunk_pools[k] = self._chunk_pairs[k] = None
         if getattr(self, "h", None):
             self.L.uz_destroy(self.h)
             self.h = None
@@ -261,6 +268,27 @@ class HipEngine:
         names = type("StagedNames", (), {})()
         names.qnames, names.io_stats, names.timing = packed.qnames, packed.io_stats, packed.timing
         return rid, names
+
+    def stage_reads(self, src, fc, flo, fhi, fex, min_base_qual: int, all_bases: bool = False, wide_no_units: bool = False, slot: int = 0):
+        """The first half of upload_reads_staged alone -- the batch's records built in the link form in page-locked memory -- for a caller that
+        overlaps it with the device work of the batch before (hostpath: chunks of a large batch; may be called from a worker thread, the
+        device inflates the BGZF blocks on streams of its own).  slot: 0 / 1, two sets of page-locked buffers that alternate; the block of a
+        slot is re-used by the next stage_reads on it, so the table staged there must have been uploaded AND waited for by then.
+        -> the packed view for upload_reads_packed (`.qnames`, `.io_stats`, `.timing` ride on it)"""
+        slot = int(slot) & 1
+        if self._chunk_pools[slot] is None:
+            self._chunk_pools[slot] = PinnedPool()
+            self._chunk_pools[slot].keep = True
+            self._chunk_pairs[slot] = PinnedPair()
+        pool, pair = self._chunk_pools[slot], self._chunk_pairs[slot]
+        inflate = inflate_alloc = None
+        if os.environ.get("UZ_INFLATE", "device") == "device":
+            pair.start()
+            inflate, inflate_alloc = self.inflate_blocks, pair.alloc
+        packed = src.select(fc, flo, fhi, int(min_base_qual), pool=pool, all_bases=bool(all_bases), extra=fex, wide_no_units=bool(wide_no_units),
+                            inflate=inflate, inflate_alloc=inflate_alloc)
+        pool.end_slab()
+        return packed
 
     def upload_reads_packed(self, packed: abi.Held) -> int:
         """Staged form, asynchronous: the arrays of `packed` must stay alive and untouched until wait_reads() or

@@ -406,6 +406,90 @@ class PhasingHost:
             return rt.contig_index[alt], abi.DF_FETCH_FALLBACK
         return -1, 0
 
+    def _fetches_of(self, idxs, dnms, prep, found, params, cutoff):
+        """the fetches the read stage will make for these DNMs (staging.fetch_points): the DNM position and every het site of its window
+        (read_collector.py:385, :167) -> (contig, lo, hi, extra, the batch holds SVs)"""
+        from .staging import fetch_points
+        het_off = np.zeros(len(idxs) + 1, np.int64)
+        for k, i in enumerate(idxs):
+            het_off[k + 1] = het_off[k] + len(found[i]["het_idx"])
+        het_idx = np.concatenate([found[i]["het_idx"] for i in idxs] + [np.zeros(0, np.int32)]).astype(np.int64)
+        vts = [vartype_code(dnms[i]["vartype"]) for i in idxs]
+        fc, flo, fhi, fex = fetch_points(
+            [prep[i]["tid"] for i in idxs], [int(dnms[i]["start"]) for i in idxs], [prep[i]["dflags"] for i in idxs],
+            self.sites.pos, het_off, het_idx, params, vartype=vts,
+            end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff,
+            allele_len=[max(len(prep[i]["ref"]), len(prep[i]["alt"])) for i in idxs])
+        # (the read stage asks for the quality bits of "good" records only -- the DNM reads of a point variant and the records
+        # registered at het sites, both under goodread, read_collector.py:43-46; SV evidence is collected under
+        # goodread(read, True) from flags, CIGARs and mates alone, :476-596 -- so every batch travels with the qualities as
+        # counts + short lists and, of the rows, the 32-base units that hold a one-base fetch; the +-cutoff fetches around an
+        # SV's breakpoints stage no unit)
+        return fc, flo, fhi, fex, any(v != abi.VT_POINT for v in vts)
+
+    def _dnms_view_of(self, idxs, dnms, prep, found, cutoff):
+        name_of = {}
+        for i in idxs:
+            nm = self.prefix + dnms[i]["chrom"].strip("chr")
+            name_of[i] = self.sites.contig_index.get(nm, -1)
+        return abi.dnms_view(
+            contig=[name_of[i] for i in idxs],
+            rcontig=[prep[i]["tid"] for i in idxs],
+            start=[int(dnms[i]["start"]) for i in idxs],
+            end=[int(dnms[i]["end"]) for i in idxs],
+            vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
+            refs=[prep[i]["ref"] for i in idxs],
+            alts=[prep[i]["alt"] for i in idxs],
+            cutoff=cutoff,
+            dflags=[prep[i]["dflags"] for i in idxs],
+            mult=[found[i]["mult"] for i in idxs],
+        )
+
+    CHUNK_DNMS = 3400  # DNMs per chunk of a large batch (bench.py's files -> results pass: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)
+
+    def _chunked_batch(self, batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, mode, results) -> bool:
+        """A large batch of ONE kid from an indexed BAM as a pipeline over chunks of DNMs -- the reference runs one task per DNM on a thread
+        pool, each opening the alignment file for its own window (snv_phaser.py:244-298); here chunk k + 1 is decoded on a worker thread
+        (BAM blocks through the index straight into the link form, the blocks inflated on the device) while chunk k is uploaded, phased and its
+        result lists are fetched.  Fills `results` and returns True when it took the batch."""
+        import os
+        if len(batch) != 1 or not hasattr(self.backend, "stage_reads") or os.environ.get("UZ_HOST_CHUNKS", "1") == "0":
+            return False
+        (kid, bam), idxs = next(iter(batch.items()))
+        stager = getattr(self.reads_by_bam, "stager", None)
+        chunk = int(os.environ.get("UZ_HOST_CHUNK_DNMS", self.CHUNK_DNMS))
+        if len(idxs) < 2 * chunk or not self._indexed(bam) or stager is None or stager(bam) is None:
+            return False
+        from concurrent.futures import ThreadPoolExecutor
+        src = stager(bam)
+        fam = self.family(kid, pedigrees[kid]["dad"], pedigrees[kid]["mom"])
+        cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
+        cuts = list(range(0, len(idxs), chunk)) + [len(idxs)]
+        if cuts[-1] - cuts[-2] < chunk // 2 and len(cuts) > 2:
+            cuts.pop(-2)  # (a short tail joins the chunk before it)
+        parts = [idxs[cuts[k]: cuts[k + 1]] for k in range(len(cuts) - 1)]
+
+        def stage(k):
+            fc, flo, fhi, fex, has_sv = self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
+            return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k)
+
+        with ThreadPoolExecutor(1) as ex:
+            fut = ex.submit(stage, 0)
+            for k, part in enumerate(parts):
+                packed = fut.result()
+                if k + 1 < len(parts):
+                    fut = ex.submit(stage, k + 1)  # (into the other slot: the table staged there two chunks ago has long landed)
+                rid = self.backend.upload_reads_packed(packed)
+                self.backend.wait_reads(rid)  # (this slot's page-locked block is free again once the copy has landed)
+                dv = self._dnms_view_of(part, dnms, prep, found, cutoff)
+                res = self.backend.phase(fam, rid, dv, params, [found[i] for i in part], want_lists, find_mode=mode)
+                self.backend.free_reads(rid)
+                table = type("StagedNames", (), {})()
+                table.qnames = packed.qnames
+                for j, i in enumerate(part):
+                    results[i] = (res, j, table)
+        return True
+
     def run_read_phasing(
         self,
         dnms,
@@ -485,7 +569,8 @@ class PhasingHost:
         # to the device as ONE cohort batch (uz_phase_cohort), not as one launch sequence per kid
         results: Dict[int, dict] = {}
         groups, order_all, tables, handles = [], [], [], []
-        for (kid, bam), idxs in batch.items():
+        chunked = self._chunked_batch(batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, info["mode"], results)
+        for (kid, bam), idxs in ([] if chunked else batch.items()):
             dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
             fam = self.family(kid, dad_id, mom_id)
             cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
@@ -493,22 +578,7 @@ class PhasingHost:
             if self._indexed(bam):
                 # decode only what the batch's fetches can return (+ mates) through the index: the read stage looks at
                 # nothing else (read_collector.py:385, :167, :400), so nothing else is inflated, staged or uploaded
-                from .staging import fetch_points
-                het_off = np.zeros(len(idxs) + 1, np.int64)
-                for k, i in enumerate(idxs):
-                    het_off[k + 1] = het_off[k] + len(found[i]["het_idx"])
-                het_idx = np.concatenate([found[i]["het_idx"] for i in idxs] + [np.zeros(0, np.int32)]).astype(np.int64)
-                fc, flo, fhi, fex = fetch_points(
-                    [prep[i]["tid"] for i in idxs], [int(dnms[i]["start"]) for i in idxs], [prep[i]["dflags"] for i in idxs],
-                    self.sites.pos, het_off, het_idx, params, vartype=[vartype_code(dnms[i]["vartype"]) for i in idxs],
-                    end=[int(dnms[i]["end"]) for i in idxs], cutoff=cutoff,
-                    allele_len=[max(len(prep[i]["ref"]), len(prep[i]["alt"])) for i in idxs])
-                # (the read stage asks for the quality bits of "good" records only -- the DNM reads of a point variant and the records
-                # registered at het sites, both under goodread, read_collector.py:43-46; SV evidence is collected under
-                # goodread(read, True) from flags, CIGARs and mates alone, :476-596 -- so every batch travels with the qualities as
-                # counts + short lists and, of the rows, the 32-base units that hold a one-base fetch; the +-cutoff fetches around an
-                # SV's breakpoints stage no unit)
-                has_sv = any(vartype_code(dnms[i]["vartype"]) != abi.VT_POINT for i in idxs)
+                fc, flo, fhi, fex, has_sv = self._fetches_of(idxs, dnms, prep, found, params, cutoff)
                 stager = getattr(self.reads_by_bam, "stager", None)
                 src = stager(bam) if (stager and hasattr(self.backend, "upload_reads_staged")) else None
                 if src is not None:
@@ -526,22 +596,7 @@ class PhasingHost:
             tables.append(region_table if region_table is not None else self.reads_by_bam[bam])
             order_all.extend(idxs)
         if order_all:
-            name_of = {}
-            for i in order_all:
-                nm = self.prefix + dnms[i]["chrom"].strip("chr")
-                name_of[i] = self.sites.contig_index.get(nm, -1)
-            dv = abi.dnms_view(
-                contig=[name_of[i] for i in order_all],
-                rcontig=[prep[i]["tid"] for i in order_all],
-                start=[int(dnms[i]["start"]) for i in order_all],
-                end=[int(dnms[i]["end"]) for i in order_all],
-                vartype=[vartype_code(dnms[i]["vartype"]) for i in order_all],
-                refs=[prep[i]["ref"] for i in order_all],
-                alts=[prep[i]["alt"] for i in order_all],
-                cutoff=groups[0][4],
-                dflags=[prep[i]["dflags"] for i in order_all],
-                mult=[found[i]["mult"] for i in order_all],
-            )
+            dv = self._dnms_view_of(order_all, dnms, prep, found, groups[0][4])
             fl = [found[i] for i in order_all]
             if len(groups) == 1:
                 res = self.backend.phase(groups[0][0], groups[0][1], dv, params, fl, want_lists, find_mode=info["mode"])
