@@ -588,6 +588,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         for ip in ipairs or []:
             ip.free_all()
         mism = sum(int((np.asarray(out[k]) != np.asarray(res_r[k][:m])).sum()) for k in out)
+        product = product_e2e(bam, vcf, sc, ev, m, res_r) if not os.environ.get("UZ_BENCH_NO_PRODUCT") else None
         # the CPU path's decode of the same files: the whole BAM (it holds only these pile-ups) + the same windows of the VCF
         t = time.perf_counter()
         full = io_native.read_bam_table(bam, threads=0)
@@ -622,12 +623,45 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                      "link_bytes_per_dnm": round(acc["link_bytes"] / m, 1)},
             "sites_decode": {"seconds_busy": round(acc["vcf_s"], 3), "records": acc["site_records"], "records_per_s": round(acc["site_records"] / max(acc["vcf_s"], 1e-9), 0)},
             "bam_stage_seconds_busy": round(acc["bam_s"], 3),
+            "product": product,
             "cpu_decode_s": round(cpu_decode_s, 3), "cpu_decode_records": cpu_records,
             "note": "files -> BED-ready results with the real dependency find(k) -> fetches(k) -> BAM stage(k) -> upload(k) inside the timer; the BAM holds the "
                     "+-6 kb pile-ups of the DNMs only (no filler between windows), so a window's BGZF blocks carry no lead-in from a 16 kb index bin",
         }
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def product_e2e(bam, vcf, sc, ev, m, res_r):
+    """The same files through the PRODUCT's drop-in call -- phase_snvs(dnms, kids, pedigrees, sites, ...) as the reference's driver makes it
+    (unfazed.py:601-646) -> session -> hostpath (chunks of DNMs, chunk k + 1 decoded while chunk k is phased) -> records dict -- timed on its
+    second call, and its records held against the resident pass (read and site counts of every DNM)."""
+    from unfazed_amd import abi, session
+    from unfazed_amd.snv_phaser import phase_snvs
+    ped = {"kid": {"kid": "kid", "dad": "dad", "mom": "mom", "sex": "2"}}
+    dnms = [dict(chrom=sc.contig_names[int(c)], start=int(s), end=int(e), kid="kid", vartype="POINT", bam=bam, cram_ref=None)
+            for c, s, e in zip(ev.contig[:m], ev.start[:m], ev.end[:m])]
+    argv = (["kid"], ped, vcf, 2, "38", False, 10 ** 9, True, [0.0, 0.2], [0.8, 1.0], [0.2, 0.8], 20, 10, 5000, 1000000, 3, 1, 151, 5)
+    el, recs = 0.0, {}
+    for rep in range(2):
+        session._HOSTS.clear()
+        for k in [k for k in session._SITES if "@" in k]:
+            del session._SITES[k]
+        batch = [dict(x) for x in dnms]
+        t = time.perf_counter()
+        recs = phase_snvs(batch, *argv)
+        el = time.perf_counter() - t
+    bad = 0
+    st, cnt = np.asarray(res_r["status"][:m]), np.asarray(res_r["counts"][:m])
+    for d in range(m):
+        key = "%s_%d_%d_kid_POINT" % (dnms[d]["chrom"], dnms[d]["start"], dnms[d]["end"])
+        r = recs.get(key)
+        if st[d] != abi.ST_OK:
+            bad += r is not None
+        else:
+            bad += r is None or [len(r["dad_reads"]), len(r["mom_reads"]), len(r["dad_sites"]), len(r["mom_sites"])] != cnt[d].tolist()
+    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "records": len(recs), "record_mismatches_vs_resident": int(bad),
+            "route": "phase_snvs -> session -> hostpath._chunked_batch (%d DNMs per chunk) -> HipEngine" % __import__("unfazed_amd.hostpath", fromlist=["x"]).PhasingHost.CHUNK_DNMS}
 
 
 def cpu_baseline(args, wl, sc, ev, dn, per_ev, cl, cfg, P, cutoff, gpu_res, ev_vt, ev_refs, ev_alts, cnv, parity_only=False):

@@ -677,23 +677,27 @@ __global__ void k_fold_complex(uint8_t *gt, const uint8_t *sflags, int64_t n) {
 // the nine eight-bit columns of the link form (uz_family_view.ref_depth8 ...) into the 16-bit ones the kernels read.  `missing`: the
 // byte that stands for a missing value (254 in a depth column -- 255 there is "see the wide list": any value will do, the site's class is
 // rewritten from the list -- 255 in a quality column)
-__global__ __launch_bounds__(256) void k_widen8(int64_t n, const uint8_t *__restrict__ s0, const uint8_t *__restrict__ s1, const uint8_t *__restrict__ s2,
-                                                uint16_t *d0, uint16_t *d1, uint16_t *d2, uint32_t missing) {
+struct Widen8 { const uint8_t *s[9]; uint16_t *d[9]; };
+__global__ __launch_bounds__(256) void k_widen8(int64_t n, Widen8 w) { // (one launch for the nine columns: a chunk of the staged pass makes ~40 launches, each waits for room beside the read stage)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t a = s0[i], b = s1[i], c = s2[i];
-    d0[i] = (uint16_t)(a == missing ? 0xFFFFu : a);
-    d1[i] = (uint16_t)(b == missing ? 0xFFFFu : b);
-    d2[i] = (uint16_t)(c == missing ? 0xFFFFu : c);
+    uint32_t v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = w.s[k][i];
+#pragma unroll
+    for (int k = 0; k < 9; k++) w.d[k][i] = (uint16_t)(v[k] == (k < 6 ? (uint32_t)UZ_U8_MISSING : 255u) ? 0xFFFFu : v[k]);
 }
 void uz_family_widen(uz_ctx *c, FamilyDev &f, int64_t n) {
     if (!f.widen_pending) return;
     f.widen_pending = false;
     if (n <= 0) return;
     const unsigned nb = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, f.stage8[0], f.stage8[1], f.stage8[2], f.rd[0], f.rd[1], f.rd[2], UZ_U8_MISSING);
-    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, f.stage8[3], f.stage8[4], f.stage8[5], f.ad[0], f.ad[1], f.ad[2], UZ_U8_MISSING);
-    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, f.stage8[6], f.stage8[7], f.stage8[8], f.gq[0], f.gq[1], f.gq[2], 255u);
+    Widen8 w;
+    for (int m = 0; m < 3; m++) {
+        w.s[m] = f.stage8[m]; w.s[3 + m] = f.stage8[3 + m]; w.s[6 + m] = f.stage8[6 + m];
+        w.d[m] = f.rd[m]; w.d[3 + m] = f.ad[m]; w.d[6 + m] = f.gq[m];
+    }
+    hipLaunchKernelGGL(k_widen8, dim3(nb), dim3(256), 0, c->stream, n, w);
     UZ_HIP(hipGetLastError());
 }
 
