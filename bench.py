@@ -651,16 +651,21 @@ def product_e2e(bam, vcf, sc, ev, m, res_r):
         t = time.perf_counter()
         recs = phase_snvs(batch, *argv)
         el = time.perf_counter() - t
-    bad = 0
+    # (the sites file spells every DNM's own record as an SNV, so the driver -- which takes REF / ALT from that file, snv_phaser.py:73-84 -- phases
+    # the batch's INDEL DNMs as SNVs: only the SNV DNMs are the same question in both passes)
+    bad, compared = 0, 0
     st, cnt = np.asarray(res_r["status"][:m]), np.asarray(res_r["counts"][:m])
     for d in range(m):
+        if ev.kind[d] != 0:
+            continue
+        compared += 1
         key = "%s_%d_%d_kid_POINT" % (dnms[d]["chrom"], dnms[d]["start"], dnms[d]["end"])
         r = recs.get(key)
         if st[d] != abi.ST_OK:
             bad += r is not None
         else:
             bad += r is None or [len(r["dad_reads"]), len(r["mom_reads"]), len(r["dad_sites"]), len(r["mom_sites"])] != cnt[d].tolist()
-    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "records": len(recs), "record_mismatches_vs_resident": int(bad),
+    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "records": len(recs), "snv_dnms_compared": compared, "record_mismatches_vs_resident": int(bad),
             "route": "phase_snvs -> session -> hostpath._chunked_batch (%d DNMs per chunk) -> HipEngine" % __import__("unfazed_amd.hostpath", fromlist=["x"]).PhasingHost.CHUNK_DNMS}
 
 
