@@ -17,8 +17,10 @@ ph = k[k.nm.str.startswith('k_phase<true>')]
 d = (ph.End_Timestamp - ph.Start_Timestamp).values / 1e6
 idx = ph.index.values
 short = [i for i, x in zip(idx, d) if x < 1.5]
-last8 = short[-8:]
-lo = k.Start_Timestamp[last8[0]] - 3.5e6; hi = k.End_Timestamp[last8[-1]] + 0.2e6
+import os
+K = int(os.environ.get("UZ_TL_CHUNKS", "8"))
+last8 = short[-K:]
+lo = k.Start_Timestamp[last8[0]] - float(os.environ.get("UZ_TL_HEAD_MS", "3.5")) * 1e6; hi = k.End_Timestamp[last8[-1]] + 0.2e6
 ks = k[(k.Start_Timestamp >= lo) & (k.End_Timestamp <= hi)].copy()
 ms = m[(m.Start_Timestamp >= lo) & (m.End_Timestamp <= hi)].copy()
 qcol = 'Queue_Id' if 'Queue_Id' in ks.columns else 'Stream_Id'

@@ -363,8 +363,11 @@ __global__ __launch_bounds__(256) void k_off_block_sums(int64_t n, RecColumns c_
 // between XCDs inside a kernel: with a __threadfence per workgroup every kernel of the step ran 20 - 50 % slower -- two thousand L2
 // write-backs per table -- and with agent-scope accesses instead the lone scanning workgroup sat through ~180 uncached round trips.)
 __global__ __launch_bounds__(256) void k_off_scan_sums(int64_t nb, unsigned long long *sums, PkWant want, int32_t *hflags) { scan_block_sums(nb, sums, want, hflags); }
-template <bool LINK>
-__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, RecA *ra, RecB *rb,
+// SELF: `sums` holds the raw block sums (no scan kernel ran): every workgroup adds up the sums of the blocks before its own -- a table of a
+// few thousand spans costs each workgroup a few microseconds of L2 reads, where the one-workgroup scan kernel between the two passes waited
+// ~100 us for room beside the read stage's persistent workgroups; the last workgroup holds the totals against what the view declared.
+template <bool LINK, bool SELF>
+__global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, PkWant want, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
                                                   uint16_t *qs, int32_t *coarse, int32_t *hflags) {
     RecColumns c = uz_columns_of<LINK>(c_in);
@@ -375,8 +378,45 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
     __syncthreads();
     c.esc_lo = c.n_esc16 > 0 ? esc_span[0] : 0; c.esc_hi = c.n_esc16 > 0 ? esc_span[1] : 0;
     unsigned long long run[UZ_PK_SCANNED];
+    if constexpr (SELF) {
+        __shared__ unsigned long long pre_s[UZ_PK_SUMS][4];
+        unsigned long long acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool last = blockIdx.x + 1 == gridDim.x;
+        const int64_t nbk = (int64_t)blockIdx.x + (last ? 1 : 0); // (the last workgroup adds its own block too: the totals)
+        for (int64_t b = t; b < nbk; b += 256) {
+            unsigned long long row[UZ_PK_SUMS];
 #pragma unroll
-    for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
+            for (int k = 0; k < UZ_PK_SUMS; k++) row[k] = sums[UZ_PK_SUMS * (size_t)b + k];
+#pragma unroll
+            for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += row[k];
+        }
+        // (the last workgroup's own block: part of the totals, not of its prefix)
+        unsigned long long own[UZ_PK_SUMS];
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SUMS; k++) own[k] = last ? sums[UZ_PK_SUMS * (size_t)blockIdx.x + k] : 0ULL;
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SUMS; k++) {
+            unsigned long long x = acc[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+            if (lane == 0) pre_s[k][wv] = x;
+        }
+        __syncthreads();
+        unsigned long long tot[UZ_PK_SUMS];
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SUMS; k++) tot[k] = pre_s[k][0] + pre_s[k][1] + pre_s[k][2] + pre_s[k][3];
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] = tot[k] - own[k];
+        if (last && t == 0) {
+            if (tot[0] != want.cigar || tot[1] != want.units || tot[2] != want.seq || tot[3] != want.qpos || tot[0] > 0xFFFFFFFFULL || tot[1] > 0xFFFFFFFFULL ||
+                (want.staged != ~0ULL && tot[4] != want.staged) || tot[7] != want.bl_units || tot[8] != want.bl || tot[1] + tot[7] > 0xFFFFFFFFULL)
+                hflags[0] = 1;
+            if (tot[9] != tot[10]) hflags[0] = 8; // pair form: as many SECOND records as FIRST ones (k_pair_link checks that they are each other's)
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
+    }
     // the dictionary index of the NEXT round's record is requested a round ahead: its table entries can then be fetched as soon as
     // the round begins, instead of after a round trip of their own
     uint32_t tp_next = 0;
@@ -755,13 +795,17 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     const bool link_form = uz_link_form(col) && col.cigar_in != nullptr && !no_link_build;
     if (link_form) hipLaunchKernelGGL((k_off_block_sums<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     else hipLaunchKernelGGL((k_off_block_sums<false>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
-    hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(256), 0, st, (int64_t)nb, sums, want, c->hflags);
-    if (link_form)
-        hipLaunchKernelGGL((k_pack_rec<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags);
-    else
-        hipLaunchKernelGGL((k_pack_rec<false>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (RecA *)r.rec_a,
-                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags);
+    // a table of up to 4096 spans (a chunk of a staged pass: ~2 k): no scan kernel, every workgroup of the second pass adds up the sums in front
+    // of its own block; a larger table (the resident 187 M-record one: 46 k spans) gets the one-workgroup scan
+    static const bool no_self = getenv("UZ_BUILD_SCAN_KERNEL") != nullptr; // (development aid)
+    const bool self = nb <= 4096 && !no_self;
+    if (!self) hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(256), 0, st, (int64_t)nb, sums, want, c->hflags);
+#define UZ_PACK_LAUNCH(L, S)                                                                                                                              \
+    hipLaunchKernelGGL((k_pack_rec<L, S>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, want, (RecA *)r.rec_a, \
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags)
+    if (link_form) { if (self) UZ_PACK_LAUNCH(true, true); else UZ_PACK_LAUNCH(true, false); }
+    else { if (self) UZ_PACK_LAUNCH(false, true); else UZ_PACK_LAUNCH(false, false); }
+#undef UZ_PACK_LAUNCH
     if (col.pair_d8)
         hipLaunchKernelGGL(k_pair_link, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, col.pair_d8, (const RecA *)r.rec_a, (RecB *)r.rec_b,
                            c->hflags);

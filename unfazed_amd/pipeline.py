@@ -29,7 +29,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 
-def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None, lag: int = 2) -> Dict[str, np.ndarray]:
+def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None, lag: Optional[int] = None) -> Dict[str, np.ndarray]:
     """One pass over the batch -> per-DNM status / counts / origin / evidence (+ etype / cnv_counts for cnv)."""
     out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32), evidence=np.empty(n, np.int32))
     if cnv:
@@ -85,7 +85,11 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
     # 4: scripts/staged_timeline.sh).  The site windows travel two chunks ahead of their find, so the link does not idle through that
     # round trip either.  The library keeps the window lists of the last three finds: a lag of two is what it serves.
     # (config 5: the allele-balance stage of a chunk is queued behind the read stage of the next one, and waited for there.)
-    lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid: 1 = the order of round 3)
+    if lag is None:
+        # two finds ahead pays when a chunk's copy + header build is long (100 k DNMs in 8 chunks: 12.27 -> 11.9 ms; config 5's three heavy
+        # chunks: 4.6 -> 4.5 ms); the three small chunks of a 12.5 k-DNM shard only start their first read stage later (2.45 -> 2.7 ms)
+        lag = 2 if (cnv or n >= 8000 * max(1, K)) else 1
+    lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid)
     lag = max(1, min(int(lag), 2, K - 1)) if K > 1 else 1
     site_stage(0)
     if K > 1:
