@@ -153,6 +153,50 @@ def test_random_blocks_against_zlib(engine):
         off += len(p)
 
 
+class _Bits:
+    def __init__(self):
+        self.v, self.n = 0, 0
+
+    def put(self, val, nbits):  # LSB first, as DEFLATE packs everything but Huffman codes
+        self.v |= (val & ((1 << nbits) - 1)) << self.n
+        self.n += nbits
+
+    def code(self, code, nbits):  # a Huffman code: most significant bit first
+        for b in range(nbits - 1, -1, -1):
+            self.put((code >> b) & 1, 1)
+
+    def bytes(self):
+        return self.v.to_bytes((self.n + 7) // 8, "little")
+
+
+def test_a_literal_code_of_one_single_code_is_taken_as_zlib_takes_it(engine):
+    """inftrees.c lets an INCOMPLETE literal / length code pass when it is ONE code of one bit ("max != 1" is what it refuses): a dynamic block
+    whose only symbol is end-of-block.  No compressor emits it, but the host inflaters decode it -- so must the device (round 3's review)."""
+    payload = b"five!"                  # a stored block first, not final ...
+    body = b"\x00" + struct.pack("<HH", len(payload), 0xFFFF ^ len(payload)) + payload  # (BFINAL 0, BTYPE 00, padded to the byte)
+    w = _Bits()
+    w.put(1, 1); w.put(2, 2)            # ... then the final block, dynamic
+    w.put(0, 5); w.put(0, 5); w.put(14, 4)  # HLIT 257, HDIST 1, HCLEN 18 code-length codes
+    # code-length code, in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1: symbol 18 one bit, symbols 0 and 1 two bits (complete)
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1]
+    cl = {18: 1, 0: 2, 1: 2}
+    for sym in order:
+        w.put(cl.get(sym, 0), 3)
+    # canonical codes: 18 -> 0, 0 -> 10, 1 -> 11
+    w.code(0b0, 1); w.put(127, 7)       # 18: 138 zeros
+    w.code(0b0, 1); w.put(107, 7)       # 18: 118 zeros  (256 literals of length 0)
+    w.code(0b11, 2)                     # symbol 256 (end of block): length 1
+    w.code(0b10, 2)                     # the one distance code: length 0
+    w.code(0b0, 1)                      # the data: end of block
+    stream = body + w.bytes()
+    assert zlib.decompress(stream, -15) == payload  # zlib takes it
+    bsize = len(stream) + 25
+    block = (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + stream
+             + struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload)))
+    got, nb, _ = engine.bgzf_inflate(block + bgzf_block(b"and a normal block behind it", 6))
+    assert nb == 2 and bytes(got) == payload + b"and a normal block behind it"
+
+
 def test_a_stream_that_never_ends_is_stopped(engine):
     """empty stored blocks without end (BFINAL never set), the last one of block A stepping over A's trailer and B's header into B's
     body, which goes on the same way: the decoder gives up once it has read more than a BGZF block can hold (error 6) -- it does not

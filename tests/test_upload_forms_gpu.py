@@ -81,6 +81,45 @@ def test_a_pair_form_that_contradicts_itself_is_refused(engine):
             engine.wait_reads(rid)
 
 
+def test_a_base_list_that_contradicts_its_mask_is_refused(engine):
+    """The list form of the bases (uz_types.h bl_*): the header build lays a listed record's units out from its mask and writes the listed
+    bases into them -- a position outside the mask, positions that do not ascend, or a unit of the mask nobody lists is a table whose
+    columns disagree, refused when the table is first used (never a base written somewhere else)."""
+    sc, dn, cl, rh, arrs = _workload(30, seed=5)
+    N = int(rh.view.n_segs)
+    src = io_native.ReadsSource(io_native.pack_reads(rh, 20, with_end=True))
+    # one-base fetches at every 97th record's 40th base: single positions -> lists
+    idx = np.arange(0, N, 97)
+    contig_of = np.searchsorted(arrs["contig_off"], idx, side="right") - 1
+    lo = (arrs["start"][:N][idx] + 40).astype(np.int32)
+    fetches = (contig_of.astype(np.int32), lo, lo + 1)
+    ex = np.ones(idx.size, np.uint16)  # (+ one base on: two listed bases per record)
+
+    def fresh():
+        part = src.select(*fetches, extra=ex, base_lists=True)
+        off, pos, code = abi.base_lists(part)
+        assert int(part.view.n_bl) > 50 and not part.view.bl_wide
+        return part, off
+    part, off = fresh()
+    rid = engine.upload_reads_packed(part)  # the honest table is taken
+    engine.wait_reads(rid)
+    engine.free_reads(rid)
+    k = int(np.nonzero(np.diff(off) >= 1)[0][3])
+    for breakage in ("outside_the_mask", "not_ascending", "beyond_the_read"):
+        part, off = fresh()
+        bp = part.arrays["bl_pos"]
+        if breakage == "outside_the_mask":
+            bp[off[k]] = (int(bp[off[k]]) + 64) % 150  # two units further: not in the record's mask
+        elif breakage == "not_ascending":
+            kk = int(np.nonzero(np.diff(off) >= 2)[0][0])
+            bp[off[kk] + 1] = bp[off[kk]]
+        else:
+            bp[off[k]] = 200  # l_seq is 151
+        with pytest.raises(UnfazedHipError):
+            rid = engine.upload_reads_packed(part)
+            engine.wait_reads(rid)
+
+
 def test_staged_from_an_indexed_bam(engine, tmp_path):
     from synth import bigsynth
     from synth.sites_np import make_clusters, make_sites, place_dnms_full
