@@ -1,6 +1,6 @@
 """Copy the judged summaries of a profiling round (scripts/profile_round.sh TAG, run on the GPU box) from gpurun_out/TAG
 into profiles/ (tracked): kernel statistics, the per-kernel PMC means, and the derived files bench.py reads
-(k1_traffic.json, k3a_traffic.json, phase_latency.json).   usage: make_profiles.py TAG ROUND [K3A_FETCH_FACTOR]"""
+(k1_traffic.json, phase_latency.json, phase_issue.json).   usage: make_profiles.py TAG ROUND"""
 import csv
 import json
 import os
@@ -15,11 +15,13 @@ tag, rnd = sys.argv[1], sys.argv[2]
 # the device sources the profile was collected on: the bench line records it (roofline.kernel_source_sha); bench.py quotes these
 # counters only while it equals the hash of the build it runs
 KSHA = None
-k3a_factor = float(sys.argv[3]) if len(sys.argv) > 3 else None
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_bench_kernel_stats.csv" % rnd))
 shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "%s_pmc_summary.json" % rnd))
+for extra, name in (("staged_kernel_stats.csv", "%s_bench_staged_kernel_stats.csv"), ("bench_staged_under_rocprof.json", "%s_bench_staged_under_rocprof.json")):
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, name % rnd))
 line = json.loads([x for x in open(os.path.join(src, "stats.log")) if x.startswith("{")][-1])
 KSHA = (line.get("roofline") or {}).get("kernel_source_sha") or kernel_source_hash()
 json.dump(line, open(os.path.join(dst, "%s_bench_under_rocprof.json" % rnd), "w"), indent=1)
@@ -47,29 +49,6 @@ json.dump({"kernel": pmc["k_site_scan"]["full_name"], "n_sites": n_sites, "FETCH
            "fetch_bytes_corrected_x2": 2 * f, "write_bytes": w, "hbm_bytes_per_launch": int(2 * f + w),
            "algorithmic_bytes_per_launch": 20 * n_sites, "avg_ns_rocprof": avg_ns("k_site_scan")[0], "how": how, "kernel_source_sha": KSHA,
            "source": "profiles/%s_pmc_summary.json" % rnd}, open(os.path.join(dst, "k1_traffic.json"), "w"), indent=1)
-if "k_seg_qc" in pmc:  # (rounds that still had the pass)
-    # K3a: 16-byte header loads and 4-byte words; the factor between FETCH_SIZE and bytes is CALIBRATED on this kernel's own
-    # access pattern with every record marked (known byte count), see DESIGN.md
-    f, w = c("k_seg_qc", "FETCH_SIZE") * 1024, c("k_seg_qc", "WRITE_SIZE") * 1024
-    rec = line["roofline_k3a"]["records_examined"]
-    d = {"kernel": "k_seg_qc", "records_examined": rec, "FETCH_SIZE_KB_raw": f / 1024, "WRITE_SIZE_KB_raw": w / 1024,
-         "algorithmic_bytes_per_launch": line["roofline_k3a"]["algorithmic_bytes_per_launch"], "avg_ns_rocprof": avg_ns("k_seg_qc")[0],
-         "how": how, "source": "profiles/%s_pmc_summary.json" % rnd}
-    cal_path = os.path.join(src, "pmc_cal.json")
-    if os.path.exists(cal_path) and not k3a_factor:
-        # calibration pass (UZ_TEST_QC_MARK_ALL): every record examined, bytes known exactly -> what one raw FETCH_SIZE byte is worth
-        # for this kernel's access widths (4-byte words; the guide's x2 holds for 16-byte streams only)
-        cal = json.load(open(cal_path))["k_seg_qc"]["counters_per_launch"]
-        n_all = line["config"]["alignment_records"]
-        known_read = n_all * (4 + 4 + 1 + 1)  # length word, flag word, low-quality count, the reach-map byte
-        k3a_factor = known_read / (cal["FETCH_SIZE"]["mean"] * 1024)
-        d["calibration"] = {"records": n_all, "known_read_bytes": known_read, "FETCH_SIZE_KB_raw": cal["FETCH_SIZE"]["mean"],
-                            "WRITE_SIZE_KB_raw": cal["WRITE_SIZE"]["mean"], "known_write_bytes": n_all}
-    if k3a_factor:
-        d["fetch_factor_calibrated"] = k3a_factor
-        d["hbm_bytes_per_launch"] = int(k3a_factor * f + w)
-    json.dump(d, open(os.path.join(dst, "k3a_traffic.json"), "w"), indent=1)
-
 # k_phase: latency model from the SQ / TCP counters
 waves = c("k_phase", "SQ_WAVES")
 loads = c("k_phase", "SQ_INSTS_VMEM_RD")
