@@ -653,10 +653,18 @@ def product_e2e(bam, vcf, sc, ev, m, res_r):
         el = time.perf_counter() - t
     # (the sites file spells every DNM's own record as an SNV, so the driver -- which takes REF / ALT from that file, snv_phaser.py:73-84 -- phases
     # the batch's INDEL DNMs as SNVs: only the SNV DNMs are the same question in both passes)
-    bad, compared = 0, 0
+    # (and a DNM with a second site record at its position or the base before gets "Too many genotypes" from the driver's REF / ALT look-up over
+    # 1-based [pos, pos + 1], snv_phaser.py:73-84, :117-130 -- the read stage is never asked: not a question both passes answer either)
+    bad, compared, refalt_skips = 0, 0, 0
     st, cnt = np.asarray(res_r["status"][:m]), np.asarray(res_r["counts"][:m])
+    co_s = np.asarray(sc.contig_off, np.int64)
     for d in range(m):
         if ev.kind[d] != 0:
+            continue
+        c, p0 = int(ev.contig[d]), int(ev.start[d])
+        seg = sc.pos[co_s[c]: co_s[c + 1]]
+        if int(np.searchsorted(seg, p0, "right") - np.searchsorted(seg, p0 - 1, "left")) != 1:
+            refalt_skips += 1
             continue
         compared += 1
         key = "%s_%d_%d_kid_POINT" % (dnms[d]["chrom"], dnms[d]["start"], dnms[d]["end"])
@@ -665,7 +673,7 @@ def product_e2e(bam, vcf, sc, ev, m, res_r):
             bad += r is not None
         else:
             bad += r is None or [len(r["dad_reads"]), len(r["mom_reads"]), len(r["dad_sites"]), len(r["mom_sites"])] != cnt[d].tolist()
-    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "records": len(recs), "snv_dnms_compared": compared, "record_mismatches_vs_resident": int(bad),
+    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "records": len(recs), "snv_dnms_compared": compared, "dnms_the_driver_skips_at_its_refalt_lookup": refalt_skips, "record_mismatches_vs_resident": int(bad),
             "route": "phase_snvs -> session -> hostpath._chunked_batch (%d DNMs per chunk) -> HipEngine" % __import__("unfazed_amd.hostpath", fromlist=["x"]).PhasingHost.CHUNK_DNMS}
 
 

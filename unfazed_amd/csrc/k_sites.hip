@@ -178,7 +178,14 @@ struct ColVec; // SPT u16 values
 template <>
 struct ColVec<8> {
     uint4 v;
+#ifdef UZ_K1_NT // (variant build: the columns are read once -- non-temporal loads)
+    __device__ __forceinline__ void load(const uint16_t *p) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        v.x = __builtin_nontemporal_load(q); v.y = __builtin_nontemporal_load(q + 1); v.z = __builtin_nontemporal_load(q + 2); v.w = __builtin_nontemporal_load(q + 3);
+    }
+#else
     __device__ __forceinline__ void load(const uint16_t *p) { v = *reinterpret_cast<const uint4 *>(p); }
+#endif
     __device__ __forceinline__ uint32_t get(int i) const {
         const uint32_t w = (&v.x)[i >> 1];
         return (i & 1) ? (w >> 16) : (w & 0xFFFFu);
