@@ -127,8 +127,8 @@ class HipEngine:
         if getattr(self, "_stage_pool", None) is not None:
             self._stage_pool.free_all()
             self._stage_pool = None
-        for k in range(2):
-            if getattr(self, "_chunk_pools", [None, None])[k] is not None:
+        for k in range(len(getattr(self, "_chunk_pools", []))):
+            if self._chunk_pools[k] is not None:
                 self._chunk_pools[k].free_all()
                 self._chunk_pairs[k].free_all()
                 self._chunk_pools[k] = self._chunk_pairs[k] = None
@@ -272,10 +272,13 @@ class HipEngine:
     def stage_reads(self, src, fc, flo, fhi, fex, min_base_qual: int, all_bases: bool = False, wide_no_units: bool = False, slot: int = 0):
         """The first half of upload_reads_staged alone -- the batch's records built in the link form in page-locked memory -- for a caller that
         overlaps it with the device work of the batch before (hostpath: chunks of a large batch; may be called from a worker thread, the
-        device inflates the BGZF blocks on streams of its own).  slot: 0 / 1, two sets of page-locked buffers that alternate; the block of a
-        slot is re-used by the next stage_reads on it, so the table staged there must have been uploaded AND waited for by then.
+        device inflates the BGZF blocks on streams of its own).  slot: which set of page-locked buffers to use (sets are made as they are asked
+        for); the block of a slot is re-used by the next stage_reads on it, so the table staged there must have landed on the device by then.
         -> the packed view for upload_reads_packed (`.qnames`, `.io_stats`, `.timing` ride on it)"""
-        slot = int(slot) & 1
+        slot = int(slot)
+        while len(self._chunk_pools) <= slot:
+            self._chunk_pools.append(None)
+            self._chunk_pairs.append(None)
         if self._chunk_pools[slot] is None:
             self._chunk_pools[slot] = PinnedPool()
             self._chunk_pools[slot].keep = True

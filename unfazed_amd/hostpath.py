@@ -448,10 +448,11 @@ class PhasingHost:
     CHUNK_DNMS = 3400  # DNMs per chunk of a large batch (bench.py's files -> results pass: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)
 
     def _chunked_batch(self, batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, mode, results) -> bool:
-        """A large batch of ONE kid from an indexed BAM as a pipeline over chunks of DNMs -- the reference runs one task per DNM on a thread
-        pool, each opening the alignment file for its own window (snv_phaser.py:244-298); here chunk k + 1 is decoded on a worker thread
-        (BAM blocks through the index straight into the link form, the blocks inflated on the device) while chunk k is uploaded, phased and its
-        result lists are fetched.  Fills `results` and returns True when it took the batch."""
+        """A large batch of ONE kid from an indexed BAM through the staged pipeline (pipeline.run_pipelined: what bench.py measures) -- the
+        reference runs one task per DNM on a thread pool, each opening the alignment file for its own window (snv_phaser.py:244-298); here chunk
+        k + 1 is decoded on a worker thread (BAM blocks through the index straight into the link form, the blocks inflated on the device) while
+        the read stage of chunk k runs, and the vote lists of a chunk are fetched when its read stage is collected.  Fills `results` and returns
+        True when it took the batch."""
         import os
         if len(batch) != 1 or not hasattr(self.backend, "stage_reads") or os.environ.get("UZ_HOST_CHUNKS", "1") == "0":
             return False
@@ -469,25 +470,40 @@ class PhasingHost:
             cuts.pop(-2)  # (a short tail joins the chunk before it)
         parts = [idxs[cuts[k]: cuts[k + 1]] for k in range(len(cuts) - 1)]
 
+        from . import pipeline
+        lag = 1  # (chunks of a few thousand DNMs: the first read stage should start as early as it can)
+        n_slots = lag + 2  # a slot is staged into again once the read stage of the chunk it held has been collected
+
         def stage(k):
             fc, flo, fhi, fex, has_sv = self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
-            return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k)
+            return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k % n_slots)
 
         with ThreadPoolExecutor(1) as ex:
-            fut = ex.submit(stage, 0)
-            for k, part in enumerate(parts):
-                packed = fut.result()
+            futs = {0: ex.submit(stage, 0)}
+            names = {}
+
+            def records(k, het_off, het_idx):  # (the pipeline's own find has just returned: the fetches were derived from the batch's find already)
+                packed = futs.pop(k).result()
                 if k + 1 < len(parts):
-                    fut = ex.submit(stage, k + 1)  # (into the other slot: the table staged there two chunks ago has long landed)
-                rid = self.backend.upload_reads_packed(packed)
-                self.backend.wait_reads(rid)  # (this slot's page-locked block is free again once the copy has landed)
-                dv = self._dnms_view_of(part, dnms, prep, found, cutoff)
-                res = self.backend.phase(fam, rid, dv, params, [found[i] for i in part], want_lists, find_mode=mode)
-                self.backend.free_reads(rid)
+                    futs[k + 1] = ex.submit(stage, k + 1)  # decoded beside the device work of this chunk
+                names[k] = packed.qnames
+                return packed
+
+            def done(k, rr):
+                part = parts[k]
+                lists = None
+                if want_lists:
+                    vo, vv = self.backend.votes(len(part))
+                    lists = [tuple(vv[vo[4 * j + q]: vo[4 * j + q + 1]] for q in range(4)) for j in range(len(part))]
+                res = dict(status=rr["status"], counts=rr["counts"], origin=rr["origin"], evidence=rr["evidence"], lists=lists)
                 table = type("StagedNames", (), {})()
-                table.qnames = packed.qnames
+                table.qnames = names.pop(k)
                 for j, i in enumerate(part):
                     results[i] = (res, j, table)
+
+            chunks = [dict(a=cuts[k], b=cuts[k + 1], dnms=self._dnms_view_of(parts[k], dnms, prep, found, cutoff), records=records, sites=None)
+                      for k in range(len(parts))]
+            pipeline.run_pipelined(self.backend, params, mode, len(idxs), chunks, fid=fam, lag=lag, on_done=done)
         return True
 
     def run_read_phasing(

@@ -29,8 +29,12 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 
-def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None, lag: Optional[int] = None) -> Dict[str, np.ndarray]:
-    """One pass over the batch -> per-DNM status / counts / origin / evidence (+ etype / cnv_counts for cnv)."""
+def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None, lag: Optional[int] = None,
+                  on_done: Optional[Callable] = None) -> Dict[str, np.ndarray]:
+    """One pass over the batch -> per-DNM status / counts / origin / evidence (+ etype / cnv_counts for cnv).
+    on_done(k, results of chunk k): called when the read stage of chunk k has been collected and before the next one is queued -- the moment its
+    vote lists can still be fetched (uz_phase_votes).  lag: read stages queued this many finds behind (None: from the chunk size); a caller that
+    stages chunk k + 1 while chunk k is on the device needs lag + 2 sets of staging buffers."""
     out = dict(status=np.empty(n, np.int32), counts=np.empty((n, 4), np.int32), origin=np.empty(n, np.int32), evidence=np.empty(n, np.int32))
     if cnv:
         out.update(etype=np.empty(n, np.int32), cnv_counts=np.empty((n, 2), np.int32))
@@ -54,6 +58,8 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
 
     def read_stage_end(k):
         pending[k] = eng.phase_end(fids[k], rids[k], chunks[k]["dnms"], P, mode)
+        if on_done is not None:
+            on_done(k, pending[k])
         if not cnv:
             finish(k)
 
