@@ -139,7 +139,7 @@ def test_chunk_plan_of_the_eight_gpu_strong_split():
         assert cuts[0] == 0 and cuts[-1] == 12500 and len(cuts) == 4
         assert abs((cuts[1] - cuts[0]) - (cuts[2] - cuts[1])) <= 1 and cuts[2] - cuts[1] > cuts[3] - cuts[2]  # the last chunk is the small one: nothing hides its read stage
     one = shard.chunk_plan(100000)
-    assert len(one) == 9 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))
+    assert len(one) == 7 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))  # six chunks for the 100 k of one GPU
     assert min(y - x for x, y in zip(one[:-1], one[1:-1])) >= 10000
     assert shard.chunk_plan(0) == [0, 0] and shard.chunk_plan(1) == [0, 1] and shard.chunk_plan(3, 8)[-1] == 3
     assert shard.chunk_plan(100000, 16)[-1] == 100000 and len(shard.chunk_plan(100000, 16)) == 17

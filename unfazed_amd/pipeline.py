@@ -92,7 +92,7 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
     # round trip either.  The library keeps the window lists of the last three finds: a lag of two is what it serves.
     # (config 5: the allele-balance stage of a chunk is queued behind the read stage of the next one, and waited for there.)
     if lag is None:
-        # two finds ahead pays when a chunk's copy + header build is long (100 k DNMs in 8 chunks: 12.27 -> 11.9 ms; config 5's three heavy
+        # two finds ahead pays when a chunk's copy + header build is long (100 k DNMs in 8 chunks of 12.5 k: 12.27 -> 11.9 ms; config 5's three heavy
         # chunks: 4.6 -> 4.5 ms); the three small chunks of a 12.5 k-DNM shard only start their first read stage later (2.45 -> 2.7 ms)
         lag = 2 if (cnv or n >= 8000 * max(1, K)) else 1
     lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid)
