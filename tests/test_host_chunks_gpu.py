@@ -13,7 +13,7 @@ from synth.small import SmallConfig, make_small
 pytestmark = pytest.mark.gpu
 
 
-def _run(paths, ds, env):
+def _run(paths, ds, env, readlen=151):
     from unfazed_amd import session
     from unfazed_amd.snv_phaser import phase_snvs
     old = {k: os.environ.get(k) for k in env}
@@ -29,7 +29,7 @@ def _run(paths, ds, env):
         err = io.StringIO()
         with contextlib.redirect_stderr(err):
             recs = phase_snvs(dnms, [kid], ds.pedigrees, paths["sites"], 2, "38", False, 10 ** 9, False, [0.0, 0.2], [0.8, 1.0], [0.2, 0.8], 20, 10, 5000,
-                              1000000, 3, 1, 151, 5)
+                              1000000, 3, 1, readlen, 5)
         return norm_records(recs), sorted(err.getvalue().splitlines()), len(dnms)
     finally:
         for k, v in old.items():
@@ -68,3 +68,33 @@ def test_chunked_route_equals_one_table_route(tmp_path, hip_lib):
     finally:
         hostpath.PhasingHost._chunked_batch = orig
     assert calls == [True, True]  # (the chunked route really ran)
+
+
+def test_long_reads_travel_as_lists_with_two_byte_positions(tmp_path, hip_lib):
+    """Reads longer than 256 bases: the listed bases of a record carry two-byte positions (bl_wide).  From files through the product route, with
+    the list form and with every staged unit as a row (UZ_BASE_LISTS=0): the same records."""
+    import gzip
+    from filesio import dump_dataset, write_bai, write_bgzf_text, write_tbi
+    from unfazed_amd import io_native
+    ds = make_small(SmallConfig(seed=77, n_dnms=14, readlen=300, ins_mean=800.0, ins_sd=60.0, coverage_per_hap=18.0, cluster_prob=0.6))
+    paths = dump_dataset(ds, str(tmp_path))
+    for b in paths["bams"].values():
+        write_bai(b)
+    text = gzip.open(paths["sites"], "rt").read()
+    write_bgzf_text(paths["sites"], text)
+    write_tbi(paths["sites"])
+    seen = []
+    orig = io_native.BamSource.select
+
+    def spy(self, *a, **k):
+        r = orig(self, *a, **k)
+        seen.append((int(r.view.n_bl), int(r.view.bl_wide), int(r.view.n_seq_units)))
+        return r
+    io_native.BamSource.select = spy
+    try:
+        rows, err_r, n = _run(paths, ds, {"UZ_BASE_LISTS": "0", "UZ_HOST_CHUNKS": "0"}, readlen=300)
+        lists, err_l, _ = _run(paths, ds, {"UZ_BASE_LISTS": "1", "UZ_HOST_CHUNKS": "0"}, readlen=300)
+    finally:
+        io_native.BamSource.select = orig
+    assert len(rows) >= 3 and lists == rows and err_l == err_r
+    assert seen[0][0] == 0 and seen[1][0] > 100 and seen[1][1] == 1 and seen[1][2] < seen[0][2]
