@@ -152,6 +152,11 @@ def main():
         sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # development aid for a box with ONE GPU: UZ_BENCH_ONE_DEVICE=1 puts every rank on device 0 and runs the barrier / max-over-ranks over gloo (two
+    # ranks cannot share a device under RCCL) -- it exercises the N-rank code path (shards, barrier, reduction, rank 0's line), it measures nothing
+    one_device = bool(os.environ.get("UZ_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     import torch
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X GPU: there is no CPU fallback for the phasing path")
@@ -161,7 +166,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from synth.benchload import BenchLoad
     from unfazed_amd import abi, build, io_native, pipeline, shard
@@ -221,7 +229,7 @@ def main():
         elapsed = time.perf_counter() - t0
         timed.per_rank = [elapsed]
         if dist is not None:
-            t = torch.zeros(world, dtype=torch.float64, device="cuda")
+            t = torch.zeros(world, dtype=torch.float64, device="cpu" if one_device else "cuda")
             t[rank] = elapsed
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             timed.per_rank = [float(x) for x in t.tolist()]
