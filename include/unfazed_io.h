@@ -22,6 +22,7 @@
 #define UNFAZED_IO_H
 #include <stdint.h>
 #include "uz_types.h"
+#include "uz_bamwalk.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -290,6 +291,29 @@ const char *uz_stage_qname(const uz_stage *s, uint32_t id, int32_t *len);
 /* many names at once: the bytes of names ids[0 .. n) back to back into buf (no terminators), off[k] .. off[k + 1] the k-th ([n + 1]); returns the
  * bytes needed (cap = 0: the size only), -1 for an id out of range */
 int64_t uz_stage_qnames(const uz_stage *s, const uint32_t *ids, int64_t n, char *buf, int64_t cap, int64_t *off);
+/* ---- The walk on the device (uz_bamwalk.h; the HIP half is uz_bam_walk / uz_reads_from_bam in unfazed_hip.h).  Between uz_stage_gather_blocks
+ * and the finish: uz_stage_walk_plan writes the plan as flat arrays (sizes first: [0] tasks, [1] spans, [2] reach intervals, [3] fetches,
+ * [4] gathered blocks; layouts in uz_bamwalk.h).  uz_bam_stage_finish_desc finishes the plan from the device's descriptors instead of
+ * walking: d[d_first[t] .. d_first[t + 1]) are task t's records inside its reach intervals in file order, d_flags[t] != 0 marks a task the
+ * device could not finish (its gathered bytes ended early, or a malformed record: the host walks that task itself and reports what it finds),
+ * d_walked[t] the records the device passed.  What the reference's fetch() + mate() return is then listed by uz_stage_kept, record by record
+ * in file order: where the record lies (in the inflated buffer on the device, or -- a task the host walked, a mate found through the index --
+ * in the aux bytes this call hands over), its name id, its mate, and its offsets in the device's stores.  uz_stage_kept_sizes: [0] records,
+ * [1] CIGAR words, [2] row units, [3] base-row units, [4] query names, [5] aux bytes, [6] tasks the host walked itself.
+ * Names are compared by two hashes and the length on this route (no name bytes reach the host); uz_stage_fill / uz_stage_qname(s) refuse
+ * such a plan. */
+void uz_stage_walk_plan_sizes(const uz_stage *s, int64_t out[8]);
+int uz_stage_walk_plan(uz_stage *s, int32_t *task /* [UZ_WALK_TASK_COLS n_tasks] */, int64_t *span /* [UZ_WALK_SPAN_COLS n_spans] */,
+                       int32_t *reach /* [2 n_reach] */, int32_t *fetch /* [3 n_fetch] */, int64_t *blk_coff /* [n_blocks] */);
+int uz_bam_stage_finish_desc(uz_stage *s, const uz_walk_desc *d, const int64_t *d_first /* [n_tasks + 1] */, const int32_t *d_flags /* [n_tasks] or NULL */,
+                             const int64_t *d_walked /* [n_tasks] or NULL */);
+/* the host's twin of the device's walk: the same descriptors from the host's own walk (out == NULL: the counts only) */
+int uz_stage_walk_host(uz_stage *s, uz_walk_desc *out, int64_t cap, int64_t *d_first /* [n_tasks + 1] */, int64_t *d_walked /* [n_tasks] or NULL */);
+void uz_stage_kept_sizes(const uz_stage *s, int64_t out[8]);
+int uz_stage_kept(const uz_stage *s, int threads, uz_kept_rec *out /* [records] */, int64_t *contig_off /* [n_contigs + 1] */, int32_t *max_span /* [n_contigs] */,
+                  uint8_t *aux, int64_t aux_cap);
+/* parity aid: the kept records of any finished plan in output order (any pointer may be NULL) */
+int uz_stage_kept_debug(const uz_stage *s, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases);
 void uz_stage_free(uz_stage *s);
 
 #ifdef __cplusplus

@@ -26,6 +26,7 @@
 #include "io_common.hpp"
 #include "io_index.hpp"
 #include "pack.hpp"
+#include "uz_bamwalk.h"
 
 using namespace uzio;
 
@@ -294,6 +295,10 @@ struct WRec { // one walked record that may be kept
     uint16_t flag, l_seq, n_cigar, umask, n_exc, tup;
     uint8_t mapq, aux, n_low_full, l_name, n_qpos, n_low, simple, keep, n_units, has_pay;
     uint8_t n_bl, bl_units; // bases as a list (uz_types.h bl_*): the listed bases and the units of the mask they lie in (n_units is then 0: no rows travel)
+    // the descriptor route (uz_bam_stage_finish_desc): where the record's fixed part lies (uz_walk_desc.src; a record the HOST walked there keeps its
+    // bytes in Task::raw: pay_at = offset of its block_size field, cigar_at = 4 + block_size) and the second name hash
+    uint64_t src;
+    uint32_t nhash2;
 };
 
 struct Task { // reach intervals of one reference whose file spans meet (walked as one: no block is inflated twice), and what the walk kept
@@ -308,6 +313,8 @@ struct Task { // reach intervals of one reference whose file spans meet (walked 
     std::vector<uint8_t> pay;        // per record with has_pay: seq2 units | listed bases (pos u16, two-bit code) | exceptions (pos u16, code u8, pad) | positions (u16) | plane row
     int64_t n_walked = 0, file_bytes = 0, n_blocks = 0, n_pre = 0;
     std::vector<PreBlk> pre;         // blocks of this task inflated elsewhere (uz_stage_gather_blocks / uz_stage_set_inflated)
+    bool by_hash = false;            // descriptor route: no name bytes on the host, two names are equal when both hashes and the lengths agree
+    std::vector<uint8_t> raw;        // descriptor route: the bytes (block_size field included) of the kept records of a task the host walked itself
     // sizes of the kept records (filled by the numbering pass)
     int64_t n_keep = 0, k0 = 0;
 };
@@ -470,6 +477,8 @@ struct uz_stage {
     // elsewhere -- on the device -- and handed back
     int threads = 0;
     bool begun = false, finished = false;
+    std::vector<std::vector<uz_walk_desc>> twin; // uz_stage_walk_host: the host's twin of the device's walk, task by task
+    bool desc = false; // the descriptor route (uz_bam_stage_finish_desc): the walk ran on the device, the host holds no record bytes
     const uint8_t *inflated = nullptr;
     int64_t n_pre_blocks = 0, pre_bytes = 0;
     std::vector<uint64_t> tup_key;
@@ -552,6 +561,7 @@ void spans_for(const BaiRef &ref, int32_t a, int32_t b, std::vector<Chunk> &out,
 // walks the spans of a task: direct records (a fetch returns them) and every other record, of which only those that share a
 // name with a direct one are kept as mate candidates
 inline bool same_name(const Task &A, const WRec &a, const Task &B, const WRec &b) {
+    if (A.by_hash) return a.nhash == b.nhash && a.nhash2 == b.nhash2 && a.l_name == b.l_name; // (descriptor route: uz_bamwalk.h)
     return a.nhash == b.nhash && a.l_name == b.l_name && memcmp(A.names.data() + a.name_at, B.names.data() + b.name_at, a.l_name) == 0;
 }
 
@@ -576,7 +586,22 @@ struct Scratch { // a worker's buffers, kept from task to task
     std::vector<uint16_t> blv; // the bases the fetches ask of the record at hand
 };
 
-void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
+void finish_task(const uz_stage &P, Task &T, Scratch &W, size_t ti);
+
+// descriptor route: a record the host walked itself keeps its bytes (the device packs it from there: uz_stage_kept hands them over as the
+// batch's aux bytes) instead of the link-form extract
+void keep_raw(Task &T, WRec &r, const uint8_t *p, uint32_t bs) {
+    const uint32_t l_name = p[8];
+    r.l_name = (uint8_t)(l_name - 1);
+    r.nhash2 = uz_name_hash2(p + 32, l_name - 1);
+    r.pay_at = (uint32_t)T.raw.size();
+    r.cigar_at = 4 + bs;
+    T.raw.insert(T.raw.end(), p - 4, p + bs);
+    r.src = 0; // (set when the aux bytes are laid out: uz_stage_kept)
+}
+
+void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti, bool finish = true) {
+    T.n_walked = 0;
     const uz_bamsrc &S = *P.src;
     const Opt &o = P.opt;
     const std::vector<Fx> &fx = P.fx[(size_t)T.tid];
@@ -585,7 +610,7 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
     if (P.inflated && !T.pre.empty()) { s.pre.blks = &T.pre; s.pre.base = P.inflated; }
     std::vector<WRec> &all = W.all;
     Task &tmp = W.tmp; // pools of every walked record; the survivors are copied over
-    all.clear(); tmp.names.clear(); tmp.cigars.clear(); tmp.pay.clear();
+    all.clear(); tmp.names.clear(); tmp.cigars.clear(); tmp.pay.clear(); tmp.raw.clear();
     tmp.tid = T.tid;
     std::vector<uint16_t> &blv = W.blv;
     size_t ri = 0; // the reach interval the walk is in or in front of
@@ -659,12 +684,22 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
                     use_list = ok;
                 }
             }
-            extract(tmp, r, p, bs, o, bases, use_list ? &blv : nullptr);
+            if (P.desc) keep_raw(tmp, r, p, bs);
+            else extract(tmp, r, p, bs, o, bases, use_list ? &blv : nullptr);
             all.push_back(r);
             s.advance(bs);
         }
     }
     T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks; T.n_pre = s.n_pre;
+    if (finish) finish_task(P, T, W, ti);
+}
+
+// the second half of a task's walk, from the records in W.all: the mate candidates, and the mates inside the task
+void finish_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
+    const uz_bamsrc &S = *P.src;
+    const Opt &o = P.opt;
+    std::vector<WRec> &all = W.all;
+    Task &tmp = W.tmp;
     // mate candidates: the records that share a name with a direct one
     std::vector<uint64_t> &dn = W.dn;
     dn.clear();
@@ -674,6 +709,14 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
     for (const WRec &r0 : all) {
         if (r0.keep != 2 && !std::binary_search(dn.begin(), dn.end(), r0.nhash)) continue;
         WRec r = r0;
+        if (P.desc) { // no pools: the record's bytes stay where they are (a host-walked task: in its raw bytes)
+            if (!tmp.raw.empty()) {
+                r.pay_at = (uint32_t)T.raw.size();
+                T.raw.insert(T.raw.end(), tmp.raw.begin() + r0.pay_at, tmp.raw.begin() + r0.pay_at + r0.cigar_at);
+            }
+            T.recs.push_back(r);
+            continue;
+        }
         r.name_at = (uint32_t)T.names.size();
         T.names.insert(T.names.end(), tmp.names.begin() + r0.name_at, tmp.names.begin() + r0.name_at + r0.l_name);
         r.cigar_at = (uint32_t)T.cigars.size();
@@ -790,7 +833,10 @@ void plan_begin(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t 
 }
 
 // second half of the plan: walk, mates, numbering
-void plan_finish(uz_stage &P) {
+// d (descriptor route): the device's walk of every task -- its records inside the reach intervals, file order, task by task
+// (d_first[t] .. d_first[t + 1]); a task flagged there is walked here as well
+void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_first = nullptr, const int32_t *d_flags = nullptr,
+                 const int64_t *d_walked = nullptr) {
     const uz_bamsrc &S = *P.src;
     const int32_t n_ref = (int32_t)S.contigs.size();
     const int threads = P.threads;
@@ -801,7 +847,26 @@ void plan_finish(uz_stage &P) {
         std::vector<std::unique_ptr<Scratch>> scr((size_t)w);
         parallel_dynamic((int64_t)P.tasks.size(), w, [&](int64_t i, int k) {
             if (!scr[(size_t)k]) scr[(size_t)k].reset(new Scratch());
-            walk_task(P, P.tasks[(size_t)i], *scr[(size_t)k], (size_t)i);
+            Task &T = P.tasks[(size_t)i];
+            Scratch &W = *scr[(size_t)k];
+            if (!d || (d_flags && d_flags[i])) { walk_task(P, T, W, (size_t)i); return; }
+            // the device walked it: its records from the descriptors
+            W.all.clear(); W.tmp.names.clear(); W.tmp.cigars.clear(); W.tmp.pay.clear(); W.tmp.raw.clear();
+            W.all.reserve((size_t)(d_first[i + 1] - d_first[i]));
+            for (int64_t j = d_first[i]; j < d_first[i + 1]; j++) {
+                const uz_walk_desc &x = d[j];
+                WRec r;
+                memset(&r, 0, sizeof(r));
+                r.voff = x.voff; r.nhash = x.h1; r.nhash2 = x.h2; r.src = x.src;
+                r.pos = x.pos; r.end = x.end; r.tlen = x.tlen; r.mpos = x.mpos; r.mtid = x.mtid;
+                r.flag = x.flag; r.l_seq = x.l_seq; r.n_cigar = x.n_cigar; r.mapq = x.mapq; r.l_name = x.l_name;
+                r.keep = x.direct ? 2 : 0;
+                r.mate_ref = -2;
+                r.umask = (uint16_t)UZ_UMASK_ALL;
+                W.all.push_back(r);
+            }
+            T.n_walked = d_walked ? d_walked[i] : (int64_t)W.all.size();
+            finish_task(P, T, W, (size_t)i);
         });
     }
     double t2 = now_s();
@@ -913,6 +978,7 @@ void plan_finish(uz_stage &P) {
                 Task &T = P.tasks[base + (size_t)g];
                 const Lookup &q = need[first[(size_t)g]];
                 T.tid = q.mtid; T.a = q.mpos; T.b = q.mpos + 1; T.f0 = T.f1 = 0;
+                T.by_hash = P.desc;
                 spans_for(S.refs[(size_t)q.mtid], T.a, T.b, T.spans);
                 // walk: every record overlapping the position, no fetch (nothing is direct), keep those whose name is asked for
                 Inflater &inf = *infs[(size_t)k];
@@ -939,11 +1005,13 @@ void plan_finish(uz_stage &P) {
                         T.n_walked++;
                         if (end > q.mpos) {
                             const uint64_t h = hash_name(p + 32, (size_t)l_name - 1);
+                            const uint32_t h2 = P.desc ? uz_name_hash2(p + 32, l_name - 1) : 0u;
                             bool asked = false;
                             for (size_t u = first[(size_t)g]; u < k1 && !asked; u++) {
                                 const WRec &x = rec_of(P, need[u].who);
                                 const Task &TX = P.tasks[(size_t)(need[u].who >> 32)];
-                                asked = x.nhash == h && x.l_name == l_name - 1 && memcmp(TX.names.data() + x.name_at, p + 32, x.l_name) == 0;
+                                asked = x.nhash == h && x.l_name == l_name - 1 &&
+                                        (P.desc ? x.nhash2 == h2 : memcmp(TX.names.data() + x.name_at, p + 32, x.l_name) == 0);
                             }
                             if (asked) {
                                 WRec r;
@@ -953,7 +1021,8 @@ void plan_finish(uz_stage &P) {
                                 r.mtid = rdi32(p + 20); r.mpos = rdi32(p + 24); r.tlen = rdi32(p + 28);
                                 r.mate_ref = -2; r.nhash = h; r.keep = 0;
                                 r.umask = P.opt.masks ? (uint16_t)0 : (uint16_t)UZ_UMASK_ALL;
-                                extract(T, r, p, bs, P.opt, P.opt.all_bases);
+                                if (P.desc) keep_raw(T, r, p, bs);
+                                else extract(T, r, p, bs, P.opt, P.opt.all_bases);
                                 T.recs.push_back(r);
                             }
                         }
@@ -1120,7 +1189,7 @@ void plan_finish(uz_stage &P) {
         key = (uint64_t)x.flag | ((uint64_t)x.l_seq << 16) | ((uint64_t)x.n_cigar << 32) | ((uint64_t)x.mapq << 48) | ((uint64_t)(aux & 0xFFu) << 56);
         k2 = (uint32_t)(o.lists ? x.n_low : (uint8_t)0) | ((uint32_t)(o.masks ? x.umask : (uint16_t)0) << 8) | ((uint32_t)x.n_bl << 24);
     };
-    {
+    if (!P.desc) { // (descriptor route: no link form, no dictionary)
         struct KeyHash { size_t operator()(const std::pair<uint64_t, uint32_t> &k) const { return std::hash<uint64_t>()(k.first * 0x9E3779B97F4A7C15ULL + k.second * 0xC2B2AE3D27D4EB4FULL); } };
         typedef std::unordered_map<std::pair<uint64_t, uint32_t>, uint32_t, KeyHash> Dict;
         std::vector<std::vector<std::pair<uint64_t, uint32_t>>> local((size_t)W);
@@ -1168,6 +1237,14 @@ void plan_finish(uz_stage &P) {
             const int64_t ref = order[(size_t)k];
             WRec &x = rec_of(P, ref);
             const int32_t tid_k = P.tasks[(size_t)(ref >> 32)].tid;
+            if (P.desc) { // the device's table: every CIGAR word, a quality row per record, base rows (all units) of the records with bases
+                b.cig += x.n_cigar;
+                b.units += UZ_ROW_UNITS(x.l_seq);
+                if (x.keep == 2 || o.all_bases) b.seq += UZ_ROW_UNITS(x.l_seq);
+                cnt[(size_t)sl][(size_t)tid_k]++;
+                span[(size_t)sl][(size_t)tid_k] = std::max(span[(size_t)sl][(size_t)tid_k], x.end - x.pos);
+                continue;
+            }
             b.omitted += x.simple != 0;
             b.cig += x.simple ? 0 : x.n_cigar;
             b.units += UZ_ROW_UNITS(x.l_seq);
@@ -1442,6 +1519,7 @@ void uz_stage_timing(const uz_stage *P, double out[6]) { for (int k = 0; k < 6; 
 
 int uz_stage_fill(const uz_stage *P, int threads, uz_reads_packed_view *out) {
     if (!P || !out) { last_error = "null argument"; return UZ_IO_E_ARG; }
+    if (P->desc) { last_error = "uz_stage_fill: this plan was finished from the device's walk (uz_bam_stage_finish_desc): its records are listed by uz_stage_kept"; return UZ_IO_E_ARG; }
     const double t0 = now_s();
     const int rc = guarded([&] { fill(*P, threads, out); });
     const_cast<uz_stage *>(P)->timing[4] = now_s() - t0;
@@ -1449,7 +1527,7 @@ int uz_stage_fill(const uz_stage *P, int threads, uz_reads_packed_view *out) {
 }
 
 const char *uz_stage_qname(const uz_stage *P, uint32_t id, int32_t *len) {
-    if (!P || id >= P->name_of_id.size()) return nullptr;
+    if (!P || P->desc || id >= P->name_of_id.size()) return nullptr; // (descriptor route: the name bytes stayed on the device)
     const int64_t ref = P->name_of_id[id];
     const Task &T = P->tasks[(size_t)(ref >> 32)];
     const WRec &x = T.recs[(size_t)(ref & 0xFFFFFFFF)];
@@ -1461,7 +1539,7 @@ const char *uz_stage_qname(const uz_stage *P, uint32_t id, int32_t *len) {
 // many names at once: the bytes of names ids[0 .. n) back to back into buf (no terminators), off[k] .. off[k + 1] the k-th; returns the bytes
 // needed (call with cap = 0 for the size), -1 for an id out of range
 int64_t uz_stage_qnames(const uz_stage *P, const uint32_t *ids, int64_t n, char *buf, int64_t cap, int64_t *off) {
-    if (!P || (n > 0 && !ids)) return -1;
+    if (!P || P->desc || (n > 0 && !ids)) return -1;
     int64_t at = 0;
     for (int64_t k = 0; k < n; k++) {
         if (ids[k] >= P->name_of_id.size()) return -1;
@@ -1474,6 +1552,165 @@ int64_t uz_stage_qnames(const uz_stage *P, const uint32_t *ids, int64_t n, char 
     }
     if (off) off[n] = at;
     return at;
+}
+
+// ---- the descriptor route (uz_bamwalk.h): the walk runs on the device, the batch-wide joins here
+void uz_stage_walk_plan_sizes(const uz_stage *P, int64_t out[8]) {
+    memset(out, 0, 8 * sizeof(int64_t));
+    if (!P) return;
+    out[0] = (int64_t)P->tasks.size();
+    for (const Task &T : P->tasks) { out[1] += (int64_t)T.spans.size(); out[2] += (int64_t)T.reach.size(); }
+    for (const auto &v : P->fx) out[3] += (int64_t)v.size();
+    out[4] = P->n_pre_blocks;
+}
+
+int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach, int32_t *fetch, int64_t *blk_coff) {
+    if (!P || !P->begun || P->finished || !task || !span || !reach || !fetch || !blk_coff) { last_error = "uz_stage_walk_plan: between uz_stage_gather_blocks and the finish, every array set"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        if (P->n_pre_blocks == 0 && P->pre_bytes == 0 && !P->tasks.empty()) fail(UZ_IO_E_ARG, "uz_stage_walk_plan: call uz_stage_gather_blocks first (the block table is laid out there)");
+        std::vector<int64_t> fbase(P->fx.size() + 1, 0);
+        for (size_t t = 0; t < P->fx.size(); t++) {
+            fbase[t + 1] = fbase[t] + (int64_t)P->fx[t].size();
+            for (size_t k = 0; k < P->fx[t].size(); k++) {
+                int32_t *f = fetch + 3 * (fbase[t] + (int64_t)k);
+                f[0] = P->fx[t][k].lo; f[1] = P->fx[t][k].hi; f[2] = (int32_t)P->fx[t][k].extra;
+            }
+        }
+        int64_t si = 0, ri = 0, bi = 0;
+        for (size_t i = 0; i < P->tasks.size(); i++) {
+            const Task &T = P->tasks[i];
+            int32_t *tc = task + UZ_WALK_TASK_COLS * i;
+            tc[0] = T.tid; tc[1] = T.b; tc[2] = (int32_t)si; tc[3] = (int32_t)(si + (int64_t)T.spans.size());
+            tc[4] = (int32_t)ri; tc[5] = (int32_t)(ri + (int64_t)T.reach.size());
+            tc[6] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f0); tc[7] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f1);
+            tc[8] = P->fx_max_len[(size_t)T.tid]; tc[9] = 0;
+            for (const auto &r : T.reach) { reach[2 * ri] = r.first; reach[2 * ri + 1] = r.second; ri++; }
+            for (size_t k = 0; k < T.pre.size(); k++) blk_coff[bi + (int64_t)k] = T.pre[k].coff;
+            for (const Chunk &c : T.spans) {
+                int64_t *sc = span + UZ_WALK_SPAN_COLS * si++;
+                const int64_t c0 = (int64_t)(c.beg >> 16), stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16);
+                auto lo = std::lower_bound(T.pre.begin(), T.pre.end(), c0, [](const PreBlk &b, int64_t key) { return b.coff < key; });
+                auto hi = std::upper_bound(T.pre.begin(), T.pre.end(), stop, [](int64_t key, const PreBlk &b) { return key < b.coff; });
+                sc[0] = (int64_t)c.beg; sc[1] = (int64_t)c.end;
+                if (lo == T.pre.end() || lo->coff != c0 || hi <= lo) { sc[2] = sc[3] = 0; sc[4] = sc[5] = bi; continue; } // (no block there: the walk ends at once, as the host's)
+                sc[2] = lo->at + (int64_t)(c.beg & 0xFFFF);
+                sc[3] = (hi - 1)->at + (int64_t)(hi - 1)->isize;
+                sc[4] = bi + (int64_t)(lo - T.pre.begin()); sc[5] = bi + (int64_t)(hi - T.pre.begin());
+            }
+            bi += (int64_t)T.pre.size();
+        }
+    });
+}
+
+int uz_bam_stage_finish_desc(uz_stage *P, const uz_walk_desc *d, const int64_t *d_first, const int32_t *d_flags, const int64_t *d_walked) {
+    if (!P || !P->begun || P->finished || !d_first) { last_error = "uz_bam_stage_finish_desc: no plan that was begun and not yet finished"; return UZ_IO_E_ARG; }
+    P->finished = true;
+    P->desc = true;
+    for (Task &T : P->tasks) T.by_hash = true;
+    return guarded([&] { plan_finish(*P, d ? d : (const uz_walk_desc *)"", d_first, d_flags, d_walked); });
+}
+
+/* totals: [0] records, [1] CIGAR words, [2] row units, [3] base-row units, [4] query names, [5] aux bytes, [6] tasks the host walked itself */
+void uz_stage_kept_sizes(const uz_stage *P, int64_t out[8]) {
+    memset(out, 0, 8 * sizeof(int64_t));
+    if (!P || !P->desc || P->base.empty()) return;
+    const SliceBase &t = P->base.back();
+    out[0] = P->n; out[1] = t.cig; out[2] = t.units; out[3] = t.seq; out[4] = P->n_qnames;
+    for (const Task &T : P->tasks) { out[5] += (int64_t)T.raw.size(); out[6] += !T.raw.empty(); }
+}
+
+int uz_stage_kept(const uz_stage *P, int threads, uz_kept_rec *out, int64_t *contig_off, int32_t *max_span, uint8_t *aux, int64_t aux_cap) {
+    if (!P || !P->finished || !P->desc || !contig_off || !max_span || (P->n && !out)) { last_error = "uz_stage_kept: a plan finished by uz_bam_stage_finish_desc"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        const int32_t n_ref = (int32_t)P->src->contigs.size();
+        for (int32_t c = 0; c <= n_ref; c++) contig_off[c] = P->contig_off[(size_t)c];
+        for (int32_t c = 0; c < n_ref; c++) max_span[c] = P->max_span[(size_t)c];
+        std::vector<int64_t> abase(P->tasks.size() + 1, 0);
+        for (size_t i = 0; i < P->tasks.size(); i++) abase[i + 1] = abase[i] + (int64_t)P->tasks[i].raw.size();
+        if (abase.back() > aux_cap || (abase.back() && !aux)) fail(UZ_IO_E_ARG, "uz_stage_kept: aux buffer too small");
+        for (size_t i = 0; i < P->tasks.size(); i++)
+            if (!P->tasks[i].raw.empty()) memcpy(aux + abase[i], P->tasks[i].raw.data(), P->tasks[i].raw.size());
+        const int W = (int)P->cut.size() - 1;
+        const bool all_bases = P->opt.all_bases;
+        parallel_slices(W, std::min(W, resolve_threads(threads)), [&](int64_t s0, int64_t s1, int) {
+            for (int64_t sl = s0; sl < s1; sl++) {
+                SliceBase at = P->base[(size_t)sl];
+                for (int64_t k = P->cut[(size_t)sl]; k < P->cut[(size_t)sl + 1]; k++) {
+                    const int64_t ref = P->order[(size_t)k];
+                    const size_t ti = (size_t)(ref >> 32);
+                    const Task &T = P->tasks[ti];
+                    const WRec &x = T.recs[(size_t)(ref & 0xFFFFFFFF)];
+                    uz_kept_rec &o = out[k];
+                    o.src = T.raw.empty() ? x.src : (UZ_WALK_SRC_AUX | (uint64_t)(abase[ti] + (int64_t)x.pay_at + 4));
+                    o.qname = x.qid;
+                    const int64_t m = final_ref(*P, x.mate_ref);
+                    o.mate = m < 0 ? -1 : (int32_t)rec_of(*P, m).gidx;
+                    const uint32_t units = UZ_ROW_UNITS(x.l_seq);
+                    const bool bases = x.keep == 2 || all_bases;
+                    o.cig_off = (uint32_t)at.cig; o.unit_off = (uint32_t)at.units; o.seq_off = bases ? (uint32_t)at.seq : UZ_KEPT_NO_SEQ; o.pad = 0;
+                    at.cig += x.n_cigar; at.units += units; if (bases) at.seq += units;
+                }
+            }
+        });
+    });
+}
+
+/* The host's twin of k_bam_walk (csrc/k_bamwalk.hip): the same descriptors from the host's own walk of every task -- what the device's are held
+ * against (tests/test_bamwalk_gpu.py), and the descriptor route without a device (tests/test_stage_desc.py).  Call it with out == NULL for the
+ * counts (d_first, d_walked), then with the buffer.  src = where the record lies in the buffer uz_stage_gather_blocks lays out. */
+int uz_stage_walk_host(uz_stage *P, uz_walk_desc *out, int64_t cap, int64_t *d_first, int64_t *d_walked) {
+    if (!P || !P->begun || P->finished || !d_first) { last_error = "uz_stage_walk_host: between uz_stage_gather_blocks and the finish"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        const size_t nt = P->tasks.size();
+        if (P->twin.size() != nt) {
+            P->twin.assign(nt, {});
+            P->desc = true;
+            const int w = (int)std::min<int64_t>(std::max(1, P->threads), std::max<int64_t>(1, (int64_t)nt));
+            std::vector<std::unique_ptr<Scratch>> scr((size_t)w);
+            parallel_dynamic((int64_t)nt, w, [&](int64_t i, int k) {
+                if (!scr[(size_t)k]) scr[(size_t)k].reset(new Scratch());
+                Task &T = P->tasks[(size_t)i];
+                Scratch &W = *scr[(size_t)k];
+                walk_task(*P, T, W, (size_t)i, false);
+                auto &v = P->twin[(size_t)i];
+                v.reserve(W.all.size());
+                for (const WRec &r : W.all) {
+                    uz_walk_desc x;
+                    memset(&x, 0, sizeof(x));
+                    x.voff = r.voff; x.h1 = r.nhash; x.h2 = r.nhash2;
+                    const int64_t coff = (int64_t)(r.voff >> 16);
+                    auto it = std::lower_bound(T.pre.begin(), T.pre.end(), coff, [](const PreBlk &b, int64_t key) { return b.coff < key; });
+                    x.src = (it != T.pre.end() && it->coff == coff) ? (uint64_t)(it->at + (int64_t)(r.voff & 0xFFFF) + 4) : ~0ULL; // (a block the gather did not list)
+                    x.pos = r.pos; x.end = r.end; x.tlen = r.tlen; x.mpos = r.mpos; x.mtid = r.mtid;
+                    x.task = (uint32_t)i; x.flag = r.flag; x.l_seq = r.l_seq; x.n_cigar = r.n_cigar; x.mapq = r.mapq; x.l_name = r.l_name;
+                    x.direct = r.keep == 2;
+                    v.push_back(x);
+                }
+                T.raw.clear(); T.recs.clear();
+            });
+        }
+        d_first[0] = 0;
+        for (size_t i = 0; i < nt; i++) { d_first[i + 1] = d_first[i] + (int64_t)P->twin[i].size(); if (d_walked) d_walked[i] = P->tasks[i].n_walked; }
+        if (!out) return;
+        if (cap < d_first[nt]) fail(UZ_IO_E_ARG, "uz_stage_walk_host: descriptor buffer too small");
+        for (size_t i = 0; i < nt; i++)
+            if (!P->twin[i].empty()) memcpy(out + d_first[i], P->twin[i].data(), P->twin[i].size() * sizeof(uz_walk_desc));
+    });
+}
+
+/* parity aid (tests/test_stage_desc.py): the kept records of ANY finished plan, in output order -- virtual offset, name id, mate, 1 when the
+ * record travels with bases */
+int uz_stage_kept_debug(const uz_stage *P, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases) {
+    if (!P || !P->finished) { last_error = "uz_stage_kept_debug: a finished plan"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        for (int64_t k = 0; k < P->n; k++) {
+            const WRec &x = rec_of(*P, P->order[(size_t)k]);
+            if (voff) voff[k] = x.voff;
+            if (qname) qname[k] = x.qid;
+            if (mate) { const int64_t m = final_ref(*P, x.mate_ref); mate[k] = m < 0 ? -1 : (int32_t)rec_of(*P, m).gidx; }
+            if (bases) bases[k] = (x.keep == 2 || P->opt.all_bases) ? 1 : 0;
+        }
+    });
 }
 
 void uz_stage_free(uz_stage *P) { delete P; }

@@ -33,7 +33,7 @@ IO_EXPORTS = [
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
-    "uz_stage_free",
+    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug",
 ]
 
 
@@ -175,6 +175,15 @@ def load():
     lib.uz_stage_qnames.restype = C.c_int64
     lib.uz_stage_free.argtypes = [C.c_void_p]
     lib.uz_stage_free.restype = None
+    lib.uz_stage_walk_plan_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_stage_walk_plan_sizes.restype = None
+    lib.uz_stage_walk_plan.argtypes = [C.c_void_p] * 6
+    lib.uz_bam_stage_finish_desc.argtypes = [C.c_void_p] * 5
+    lib.uz_stage_kept_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.uz_stage_kept_sizes.restype = None
+    lib.uz_stage_kept.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.uz_stage_walk_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.uz_stage_kept_debug.argtypes = [C.c_void_p] * 5
     _LIB = lib
     return lib
 
@@ -620,6 +629,30 @@ class _StageNames(Sequence):
         return [text[o[k]: o[k + 1]] for k in range(n)]
 
 
+# include/uz_bamwalk.h
+WALK_DESC = np.dtype([("voff", "<u8"), ("src", "<u8"), ("h1", "<u8"), ("pos", "<i4"), ("end", "<i4"), ("tlen", "<i4"), ("mpos", "<i4"), ("mtid", "<i4"),
+                      ("h2", "<u4"), ("task", "<u4"), ("flag", "<u2"), ("l_seq", "<u2"), ("n_cigar", "<u2"), ("mapq", "u1"), ("l_name", "u1"), ("direct", "u1"),
+                      ("pad8", "u1"), ("pad16", "<u2")])
+KEPT_REC = np.dtype([("src", "<u8"), ("qname", "<u4"), ("mate", "<i4"), ("cig_off", "<u4"), ("unit_off", "<u4"), ("seq_off", "<u4"), ("pad", "<u4")])
+assert WALK_DESC.itemsize == 64 and KEPT_REC.itemsize == 32
+WALK_TASK_COLS, WALK_SPAN_COLS = 10, 6
+KEPT_NO_SEQ = 0xFFFFFFFF
+WALK_SRC_AUX = 1 << 63
+
+
+def stage_kept_debug(lib, stage_ptr, n: int):
+    """(voff, qname, mate, bases) of the kept records of a finished plan (uz_stage_kept_debug)"""
+    voff, qn, mt, bs = np.zeros(max(1, n), np.uint64), np.zeros(max(1, n), np.uint32), np.zeros(max(1, n), np.int32), np.zeros(max(1, n), np.uint8)
+    _check(lib, lib.uz_stage_kept_debug(stage_ptr, voff.ctypes.data, qn.ctypes.data, mt.ctypes.data, bs.ctypes.data))
+    return voff[:n], qn[:n], mt[:n], bs[:n]
+
+
+class KeptBatch:
+    """What BamSource.select_kept returns: the records fetch() + mate() hand the reference for a batch, as the list the device packs its record
+    table from (uz_kept_rec), with the table's sizes.  `.blocks`: the gathered BGZF blocks (comp, in_off, out_off) the device inflated."""
+    pass
+
+
 class BamSource:
     """An indexed BAM opened for staging (uz_bamsrc_open): `select` turns the fetches of one batch straight into the packed table
     uz_reads_upload_packed takes -- what read_bam_regions + pack_reads + ReadsSource.select build in three passes, in one."""
@@ -712,4 +745,79 @@ class BamSource:
         out.pre_inflate = None if pre is None else {k: v for k, v in pre.items() if k != "keep"}
         out.timing = dict(zip(("spans", "walk", "mates", "numbering", "fill"), (float(x) for x in tm)))
         out.qnames = _StageNames(self.lib, sh, n_names)
+        out._stage = sh
+        return out
+
+    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None) -> "KeptBatch":
+        """The same batch through the device's walk (include/uz_bamwalk.h): the blocks are gathered, `walk(plan)` inflates them in HBM and walks
+        them there (HipEngine.bam_walk -> descriptors, d_first, d_flags, d_walked; None: the host's twin uz_stage_walk_host -- tests), the
+        batch-wide joins run here on the descriptors, and the answer is the list of kept records for uz_reads_from_bam.
+        plan: dict(comp, comp_bytes, in_off, out_off, out_bytes, task, span, reach, fetch, blk_coff)."""
+        contig = np.ascontiguousarray(contig, np.int32)
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        if extra is not None:
+            extra = np.ascontiguousarray(extra, np.uint16)
+        ia = alloc or (lambda nbytes: np.empty(max(16, nbytes), np.uint8))
+        flags = STAGE_ALL_BASES if all_bases else 0
+        st = C.c_void_p()
+        t0 = time.perf_counter()
+        _check(self.lib, self.lib.uz_bam_stage_begin(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                                     extra.ctypes.data if extra is not None else None, flags, int(min_base_qual), int(self.threads), C.byref(st)))
+        sh = _Handle(st.value, self.lib.uz_stage_free)
+        nb, cb, ob = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(self.lib, self.lib.uz_stage_gather_blocks(sh.ptr, None, 0, None, None, C.byref(nb), C.byref(cb), C.byref(ob)))
+        comp = ia(int(cb.value) + 64)
+        in_off, out_off = np.zeros(max(1, nb.value), np.int64), np.zeros(nb.value + 1, np.int64)
+        if nb.value:
+            _check(self.lib, self.lib.uz_stage_gather_blocks(sh.ptr, comp.ctypes.data, int(cb.value), in_off.ctypes.data, out_off.ctypes.data, None, None, None))
+        z = (C.c_int64 * 8)()
+        self.lib.uz_stage_walk_plan_sizes(sh.ptr, z)
+        nt, nsp, nr, nf, nblk = (int(x) for x in z[:5])
+        task = np.zeros((max(1, nt), WALK_TASK_COLS), np.int32)
+        span = np.zeros((max(1, nsp), WALK_SPAN_COLS), np.int64)
+        reach = np.zeros((max(1, nr), 2), np.int32)
+        fetch = np.zeros((max(1, nf), 3), np.int32)
+        blk_coff = np.zeros(max(1, nblk), np.int64)
+        _check(self.lib, self.lib.uz_stage_walk_plan(sh.ptr, task.ctypes.data, span.ctypes.data, reach.ctypes.data, fetch.ctypes.data, blk_coff.ctypes.data))
+        plan = dict(comp=comp, comp_bytes=int(cb.value), in_off=in_off[: nb.value], out_off=out_off, out_bytes=int(ob.value), n_blocks=int(nb.value),
+                    task=task[:nt], span=span[:nsp], reach=reach[:nr], fetch=fetch[:nf], blk_coff=blk_coff[:nblk], n_ref=len(self.contigs))
+        t1 = time.perf_counter()
+        if walk is None:  # the host's twin
+            d_first, d_walked = np.zeros(nt + 1, np.int64), np.zeros(max(1, nt), np.int64)
+            _check(self.lib, self.lib.uz_stage_walk_host(sh.ptr, None, 0, d_first.ctypes.data, d_walked.ctypes.data))
+            desc = np.zeros(max(1, int(d_first[-1])), WALK_DESC)
+            _check(self.lib, self.lib.uz_stage_walk_host(sh.ptr, desc.ctypes.data, int(desc.size), d_first.ctypes.data, d_walked.ctypes.data))
+            desc = desc[: int(d_first[-1])]
+            d_flags, token = np.zeros(max(1, nt), np.int32), None
+        else:
+            desc, d_first, d_flags, d_walked, token = walk(plan)
+        t2 = time.perf_counter()
+        d_first = np.ascontiguousarray(d_first, np.int64)
+        d_flags = np.ascontiguousarray(d_flags, np.int32)
+        d_walked = np.ascontiguousarray(d_walked, np.int64)
+        assert desc.dtype == WALK_DESC and d_first.size == nt + 1
+        _check(self.lib, self.lib.uz_bam_stage_finish_desc(sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data))
+        t3 = time.perf_counter()
+        self.lib.uz_stage_kept_sizes(sh.ptr, z)
+        out = KeptBatch()
+        out.n, out.n_cigar_total, out.n_row_units, out.n_seq_units, out.n_qnames, n_aux, out.host_tasks = (int(x) for x in z[:7])
+        out.kept = (alloc(max(1, out.n) * KEPT_REC.itemsize).view(KEPT_REC) if alloc else np.zeros(max(1, out.n), KEPT_REC))[: out.n]
+        out.contig_off = np.zeros(len(self.contigs) + 1, np.int64)
+        out.max_span = np.zeros(max(1, len(self.contigs)), np.int32)
+        out.aux = ia(n_aux + 64)
+        _check(self.lib, self.lib.uz_stage_kept(sh.ptr, int(self.threads), out.kept.ctypes.data, out.contig_off.ctypes.data, out.max_span.ctypes.data,
+                                                out.aux.ctypes.data, int(n_aux)))
+        out.n_aux = n_aux
+        t4 = time.perf_counter()
+        io = (C.c_int64 * 8)()
+        self.lib.uz_stage_io_stats(sh.ptr, io)
+        out.io_stats = dict(zip(("file_bytes_read", "blocks_inflated", "records_walked", "records_kept", "reach_intervals", "index_mate_lookups",
+                                 "blocks_from_the_device", "gathered_bytes"), (int(x) for x in io)))
+        tm = (C.c_double * 6)()
+        self.lib.uz_stage_timing(sh.ptr, tm)
+        out.timing = dict(plan=t1 - t0, walk=t2 - t1, joins=t3 - t2, kept=t4 - t3, mates=float(tm[2]), numbering=float(tm[3]))
+        out.plan, out.desc, out.d_first, out.d_flags, out.token = plan, desc, d_first, d_flags, token
+        out.min_base_qual, out.n_contigs, out.all_bases = int(min_base_qual), len(self.contigs), bool(all_bases)
+        out._stage = sh
         return out
