@@ -68,6 +68,9 @@ def parse():
                     help="DNMs of the files -> results pass (`feed` / `value_e2e`): their pile-ups are written as a real BAM + BAI, the sites table as "
                          "a BGZF VCF + TBI, and decoded back through the indexes inside the timed region (0 = skip)")
     ap.add_argument("--feed-chunk", type=int, default=3400, help="DNMs per chunk of the files -> results pass (scripts/feed_sweep.sh, two boxes: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)")
+    ap.add_argument("--feed-walk", choices=("device", "host"), default="device",
+                    help="feed pass: where the BAM records are walked -- device: the inflated blocks stay in HBM, k_bam_walk hands the host 64-byte descriptors, "
+                         "the table is unpacked from HBM (include/uz_bamwalk.h); host: uz_bam_stage_* walks them on the host's cores (the link form)")
     ap.add_argument("--feed-inflate", choices=("device", "host"), default="device",
                     help="feed pass: who inflates the BGZF blocks of the BAM -- the device (uz_bgzf_inflate_to_host) or the host's cores")
     ap.add_argument("--feed-level", type=int, default=6, help="deflate level of the files written for the feed pass (samtools / bgzip default: 6)")
@@ -505,10 +508,12 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         pools = [PinnedPool() for _ in range(3)]  # chunk k stages into pools[k % 3]: its block is rewound, not re-pinned
         from unfazed_amd.engine import PinnedPair
         on_device = args.feed_inflate == "device"
+        dev_walk = args.feed_walk == "device" and on_device
         ipairs = [PinnedPair() for _ in range(3)] if on_device else None  # ... and its gathered / inflated BGZF blocks through ipairs[k % 3]
         slab_bytes = [0, 0, 0]
         acc = dict(vcf_s=0.0, bam_s=0.0, site_records=0, walked=0, kept=0, file_bytes=0, blocks=0, spans=0.0, walk=0.0, mates=0.0, numbering=0.0, fill=0.0,
-                   link_bytes=0, lookups=0, dev_blocks=0, dev_out_bytes=0, dev_inflate_s=0.0, gather_s=0.0, blocks_dev=0)
+                   link_bytes=0, lookups=0, dev_blocks=0, dev_out_bytes=0, dev_inflate_s=0.0, gather_s=0.0, blocks_dev=0,
+                   w_plan=0.0, w_walk=0.0, w_joins=0.0, w_kept=0.0, w_desc=0, w_host_tasks=0, w_tasks=0, w_aux=0)
 
         def io_dev(packed):
             return packed.io_stats.get("blocks_from_the_device", 0)
@@ -545,6 +550,19 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 pool.new_slab(want)
             if on_device:
                 ipairs[k % 3].start()
+            if dev_walk:  # the blocks go up, are inflated and walked in HBM; descriptors come back, the joins run here, the kept list goes up
+                pa = ipairs[k % 3].alloc
+                kb = src.select_kept(f[0], f[1], f[2], int(P.min_gt_qual), walk=lambda plan: eng.bam_walk(plan, alloc=pa), alloc=pa)
+                acc["bam_s"] += time.perf_counter() - t
+                io, tm = kb.io_stats, kb.timing
+                acc["walked"] += io["records_walked"]; acc["kept"] += io["records_kept"]; acc["lookups"] += io["index_mate_lookups"]
+                acc["dev_blocks"] += kb.plan["n_blocks"]; acc["dev_out_bytes"] += kb.plan["out_bytes"]; acc["file_bytes"] += kb.plan["comp_bytes"]
+                acc["w_plan"] += tm["plan"]; acc["w_walk"] += tm["walk"]; acc["w_joins"] += tm["joins"]; acc["w_kept"] += tm["kept"]
+                acc["mates"] += tm["mates"]; acc["numbering"] += tm["numbering"]
+                acc["w_desc"] += int(kb.desc.size); acc["w_host_tasks"] += int(kb.host_tasks); acc["w_tasks"] += int(kb.d_first.size - 1); acc["w_aux"] += int(kb.n_aux)
+                acc["link_bytes"] += int(kb.plan["comp_bytes"]) + int(kb.desc.size) * 64 + int(kb.n) * 32 + int(kb.n_aux)
+                kb.plan = kb.desc = None
+                return kb
             packed = src.select(f[0], f[1], f[2], int(P.min_gt_qual), alloc=pool.alloc, extra=f[3],
                                 inflate=eng.inflate_blocks if on_device else None, inflate_alloc=ipairs[k % 3].alloc if on_device else None)
             if packed.pre_inflate:
@@ -564,7 +582,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         def stage_d(k, dev, packed):  # upload + read stage + results
             a, b = cuts[k], cuts[k + 1]
             sid, fid, dv, _ = dev
-            rid = eng.upload_reads_packed(packed)
+            rid = eng.reads_from_bam(packed) if dev_walk else eng.upload_reads_packed(packed)
             rr = eng.phase_raw(fid, rid, dv, P, mode)
             for key in out:
                 out[key][a:b] = rr[key]
@@ -616,6 +634,14 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 "GBps_incl_both_copies": round(acc["dev_out_bytes"] / max(acc["dev_inflate_s"], 1e-9) / 1e9, 1),
                 "note": "per chunk: the blocks the walk will read gathered into pinned memory (host), host -> device, kernel, device -> host, all "
                         "inside seconds_busy; the walk then copies records out of the inflated blocks and holds each block against its CRC-32"},
+            "device_walk": None if not dev_walk else {
+                "kernels": "k_bam_walk (one wavefront per walk task, two passes) + k_bam_extract (csrc/k_bamwalk.hip)", "tasks": acc["w_tasks"],
+                "tasks_walked_by_the_host": acc["w_host_tasks"], "descriptors": acc["w_desc"], "aux_bytes": acc["w_aux"],
+                "seconds_busy": {"plan+gather": round(acc["w_plan"], 3), "upload+inflate+walk+descriptors_down": round(acc["w_walk"], 3),
+                                 "joins_on_the_host": round(acc["w_joins"], 3), "kept_list": round(acc["w_kept"], 3)},
+                "link_bytes_per_dnm": round(acc["link_bytes"] / m, 1),
+                "note": "the inflated bytes (out_GB) never cross the link: up go the compressed blocks and the kept list (32 B per record), down come the "
+                        "descriptors (64 B per record inside a reach interval)"},
             "host_threads": io_native.default_threads(), "host_cpu_quota": io_native.cpu_quota() or None,
             "host_processors": os.cpu_count(),
             "bam": {"records": st_b["records"], "file_GB": round(st_b["file_bytes"] / 1e9, 3), "raw_GB": round(st_b["raw_bytes"] / 1e9, 3), "blocks": st_b["blocks"],

@@ -1661,4 +1661,169 @@ int uz_prof_units(uz_ctx *c, int kernel, int64_t *units) {
     });
 }
 
+// ---- the record walk on the device (include/uz_bamwalk.h, csrc/k_bamwalk.hip)
+int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off, const int64_t *blk_coff,
+                int32_t n_tasks, const int32_t *task, int64_t n_spans, const int64_t *span, int64_t n_reach, const int32_t *reach, int64_t n_fetch,
+                const int32_t *fetch, int *walk_id, int64_t *n_desc) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id && n_desc && n_blocks >= 0 && comp_bytes >= 0 && n_tasks >= 0 && n_spans >= 0 && n_reach >= 0 && n_fetch >= 0, UZ_E_ARG, "bad arguments");
+        UZ_REQUIRE(n_blocks == 0 || (comp && in_off && out_off && blk_coff), UZ_E_ARG, "null block table");
+        UZ_REQUIRE(n_tasks == 0 || (task && span && reach && fetch), UZ_E_ARG, "null walk plan");
+        const int64_t out_bytes = n_blocks ? out_off[n_blocks] : 0;
+        for (int64_t k = 0; k < n_blocks; k++)
+            UZ_REQUIRE(in_off[k] >= 0 && in_off[k] < comp_bytes && (k == 0 || in_off[k] > in_off[k - 1]) && out_off[k] >= 0 && out_off[k] <= out_off[k + 1] &&
+                           out_off[k + 1] - out_off[k] <= 65536,
+                       UZ_E_ARG, "bad block table (blocks in the order they lie in `comp`; a BGZF block inflates to at most 64 KiB)");
+        // the plan is the kernel's only guard: every index it names must lie inside the arrays it names
+        for (int32_t t = 0; t < n_tasks; t++) {
+            const int32_t *tc = task + UZ_WALK_TASK_COLS * (size_t)t;
+            UZ_REQUIRE(tc[2] >= 0 && tc[2] <= tc[3] && tc[3] <= n_spans && tc[4] >= 0 && tc[4] <= tc[5] && tc[5] <= n_reach && tc[6] >= 0 && tc[6] <= tc[7] && tc[7] <= n_fetch,
+                       UZ_E_ARG, "walk plan: a task names spans, reach intervals or fetches outside the arrays");
+        }
+        for (int64_t k = 0; k < n_spans; k++) {
+            const int64_t *sc = span + UZ_WALK_SPAN_COLS * (size_t)k;
+            UZ_REQUIRE(sc[4] >= 0 && sc[4] <= sc[5] && sc[5] <= n_blocks && (sc[4] == sc[5] || (sc[2] >= out_off[sc[4]] && sc[2] <= sc[3] && sc[3] == out_off[sc[5]])),
+                       UZ_E_ARG, "walk plan: a span names blocks or bytes outside the block table");
+        }
+        UZ_HIP(hipSetDevice(c->device));
+        int k = -1;
+        {
+            std::lock_guard<std::mutex> lk(c->err_mu);
+            for (int i = 0; i < 3 && k < 0; i++)
+                if (!c->walk[i].busy) { k = i; c->walk[i].busy = true; }
+        }
+        UZ_REQUIRE(k >= 0, UZ_E_STATE, "three walked batches are waiting for uz_reads_from_bam / uz_bam_walk_release");
+        uz_ctx::WalkSlot &w = c->walk[k];
+        try {
+            if (!c->inf_stream) {
+                UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
+                UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream2, hipStreamNonBlocking));
+                UZ_HIP(hipEventCreateWithFlags(&c->inf_ready, hipEventDisableTiming));
+            }
+            hipStream_t st = c->inf_stream;
+            w.n_blocks = n_blocks; w.out_bytes = out_bytes; w.n_tasks = n_tasks; w.n_desc = 0;
+            w.comp.ensure((size_t)comp_bytes + 1024); w.out.ensure((size_t)out_bytes + uz_bam_walk_pad());
+            w.in_off.ensure((size_t)n_blocks + 1); w.out_off.ensure((size_t)n_blocks + 1); w.blk_coff.ensure((size_t)n_blocks + 1);
+            w.task.ensure((size_t)n_tasks * UZ_WALK_TASK_COLS + 1); w.span.ensure((size_t)n_spans * UZ_WALK_SPAN_COLS + 1);
+            w.reach.ensure((size_t)n_reach * 2 + 1); w.fetch.ensure((size_t)n_fetch * 3 + 1);
+            w.count.ensure((size_t)n_tasks + 1); w.first.ensure((size_t)n_tasks + 2); w.walked.ensure((size_t)n_tasks + 1); w.flags.ensure((size_t)n_tasks + 1);
+            w.iflags.ensure(4);
+            if (n_blocks) {
+                UZ_HIP(hipMemsetAsync(w.comp.p + comp_bytes, 0, 1024, st));
+                UZ_HIP(hipMemsetAsync(w.out.p + out_bytes, 0, uz_bam_walk_pad(), st));
+                UZ_HIP(hipMemcpyAsync(w.comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
+                UZ_HIP(hipMemcpyAsync(w.in_off.p, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
+                UZ_HIP(hipMemcpyAsync(w.out_off.p, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
+                UZ_HIP(hipMemcpyAsync(w.blk_coff.p, blk_coff, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
+                uz_launch_inflate(c, st, n_blocks, w.comp.p, (comp_bytes + 1024) & ~(int64_t)3, w.in_off.p, w.out_off.p, w.out.p, w.iflags.p);
+            }
+            int32_t iflags[2] = {0, 0};
+            int64_t total = 0;
+            if (n_tasks) {
+                UZ_HIP(hipMemcpyAsync(w.task.p, task, (size_t)n_tasks * UZ_WALK_TASK_COLS * 4, hipMemcpyHostToDevice, st));
+                if (n_spans) UZ_HIP(hipMemcpyAsync(w.span.p, span, (size_t)n_spans * UZ_WALK_SPAN_COLS * 8, hipMemcpyHostToDevice, st));
+                if (n_reach) UZ_HIP(hipMemcpyAsync(w.reach.p, reach, (size_t)n_reach * 8, hipMemcpyHostToDevice, st));
+                if (n_fetch) UZ_HIP(hipMemcpyAsync(w.fetch.p, fetch, (size_t)n_fetch * 12, hipMemcpyHostToDevice, st));
+                uz_launch_bam_walk(c, st, false, n_tasks, w.out.p, w.out_off.p, w.blk_coff.p, w.task.p, w.span.p, w.reach.p, w.fetch.p, w.count.p, w.first.p, w.walked.p,
+                                   w.flags.p, nullptr);
+                UZ_HIP(hipMemcpyAsync(&total, w.first.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
+            }
+            if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags, w.iflags.p, 8, hipMemcpyDeviceToHost, st));
+            UZ_HIP(hipStreamSynchronize(st));
+            if (iflags[1])
+                throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(iflags[1] >> 4) + " of the batch: not a valid DEFLATE stream of the declared size (code " +
+                                              std::to_string(iflags[1] & 15) + ")"};
+            w.n_desc = total;
+            *n_desc = total;
+            *walk_id = k;
+        } catch (...) { std::lock_guard<std::mutex> lk(c->err_mu); w.busy = false; throw; }
+    });
+}
+
+int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_first, int32_t *d_flags, int64_t *d_walked) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < 3 && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        uz_ctx::WalkSlot &w = c->walk[walk_id];
+        UZ_REQUIRE(d_first && (w.n_desc == 0 || desc), UZ_E_ARG, "null output");
+        UZ_HIP(hipSetDevice(c->device));
+        hipStream_t st = c->inf_stream;
+        const int32_t nt = w.n_tasks;
+        if (nt == 0) { d_first[0] = 0; return; }
+        w.desc.ensure((size_t)w.n_desc + 1);
+        uz_launch_bam_walk(c, st, true, nt, w.out.p, w.out_off.p, w.blk_coff.p, w.task.p, w.span.p, w.reach.p, w.fetch.p, w.count.p, w.first.p, w.walked.p, w.flags.p,
+                           w.desc.p);
+        if (w.n_desc) UZ_HIP(hipMemcpyAsync(desc, w.desc.p, (size_t)w.n_desc * sizeof(uz_walk_desc), hipMemcpyDeviceToHost, st));
+        UZ_HIP(hipMemcpyAsync(d_first, w.first.p, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
+        if (d_flags) UZ_HIP(hipMemcpyAsync(d_flags, w.flags.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));
+        if (d_walked) UZ_HIP(hipMemcpyAsync(d_walked, w.walked.p, (size_t)nt * 8, hipMemcpyDeviceToHost, st));
+        UZ_HIP(hipStreamSynchronize(st));
+    });
+}
+
+int uz_bam_walk_release(uz_ctx *c, int walk_id) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < 3, UZ_E_ARG, "bad walk id");
+        std::lock_guard<std::mutex> lk(c->err_mu);
+        c->walk[walk_id].busy = false;
+    });
+}
+
+int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n, const uint8_t *aux, int64_t aux_bytes, const int64_t *contig_off,
+                      const int32_t *max_span, int32_t n_contigs, int64_t n_cigar_total, int64_t n_row_units, int64_t n_seq_units, uint32_t n_qnames,
+                      int32_t min_base_qual, int *reads_id) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < 3 && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        UZ_REQUIRE(reads_id && n >= 0 && n < (int64_t)0x7FFFFFF0 && (n == 0 || kept) && aux_bytes >= 0 && (aux_bytes == 0 || aux) && contig_off && max_span && n_contigs >= 0 &&
+                       n_cigar_total >= 0 && n_cigar_total < ((int64_t)1 << 32) && n_row_units >= 0 && n_row_units < ((int64_t)1 << 32) && n_seq_units >= 0 && n_seq_units <= n_row_units,
+                   UZ_E_ARG, "bad arguments");
+        uz_ctx::WalkSlot &w = c->walk[walk_id];
+        // one block for the kept list, the aux bytes and the columns the records are unpacked into; the table adopts the columns in place
+        // (uz_reads_adopt_device: cigar, seq4 and the quality plane ARE the device's stores) and keeps the block as its `mirror`
+        DevBlock blk;
+        uz_kept_rec *d_kept = nullptr;
+        uint8_t *d_aux = nullptr, *mapq = nullptr, *aux_col = nullptr, *seq4 = nullptr;
+        int64_t *d_coff = nullptr;
+        int32_t *d_span = nullptr, *start = nullptr, *tlen = nullptr, *mate = nullptr, *err = nullptr;
+        uint32_t *qname = nullptr, *cigar = nullptr, *plane = nullptr;
+        uint16_t *flag = nullptr, *l_seq = nullptr, *n_cigar = nullptr;
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? blk.p : nullptr);
+            d_kept = cv.take<uz_kept_rec>((size_t)n); d_aux = cv.take<uint8_t>((size_t)aux_bytes + 64);
+            d_coff = cv.take<int64_t>((size_t)n_contigs + 1); d_span = cv.take<int32_t>((size_t)n_contigs + 1); err = cv.take<int32_t>(4);
+            start = cv.take<int32_t>((size_t)n); tlen = cv.take<int32_t>((size_t)n); mate = cv.take<int32_t>((size_t)n); qname = cv.take<uint32_t>((size_t)n);
+            flag = cv.take<uint16_t>((size_t)n); l_seq = cv.take<uint16_t>((size_t)n); n_cigar = cv.take<uint16_t>((size_t)n);
+            mapq = cv.take<uint8_t>((size_t)n); aux_col = cv.take<uint8_t>((size_t)n);
+            cigar = cv.take<uint32_t>((size_t)n_cigar_total); seq4 = cv.take<uint8_t>((size_t)n_seq_units * UZ_SEQ4_UNIT_BYTES);
+            plane = cv.take<uint32_t>((size_t)n_row_units);
+            if (!pass) blk = uz_block_get(c, cv.off + 256);
+        }
+        int id = -1;
+        try {
+            hipStream_t st = c->stream;
+            if (n) UZ_HIP(hipMemcpyAsync(d_kept, kept, (size_t)n * sizeof(uz_kept_rec), hipMemcpyHostToDevice, st));
+            if (aux_bytes) UZ_HIP(hipMemcpyAsync(d_aux, aux, (size_t)aux_bytes, hipMemcpyHostToDevice, st));
+            UZ_HIP(hipMemcpyAsync(d_coff, contig_off, ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice, st));
+            if (n_contigs) UZ_HIP(hipMemcpyAsync(d_span, max_span, (size_t)n_contigs * 4, hipMemcpyHostToDevice, st));
+            UZ_HIP(hipMemsetAsync(err, 0, 16, st));
+            uz_launch_bam_extract(c, st, n, w.out.p, w.out_bytes, d_aux, aux_bytes, d_kept, min_base_qual, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col,
+                                  cigar, seq4, plane, err);
+            int32_t e = 0;
+            UZ_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
+            UZ_HIP(hipStreamSynchronize(st));
+            UZ_REQUIRE(e == 0, UZ_E_RANGE, "uz_reads_from_bam: a kept record lies outside the walked bytes, or overruns its block_size");
+            uz_reads_packed_view v;
+            memset(&v, 0, sizeof(v));
+            v.n_segs = n; v.n_contigs = n_contigs; v.contig_off = d_coff; v.max_span = d_span;
+            v.start = start; v.tlen = tlen; v.mate = mate; v.qname = qname; v.flag = flag; v.l_seq = l_seq; v.n_cigar = n_cigar; v.mapq = mapq; v.aux = aux_col;
+            v.n_cigar_total = n_cigar_total; v.cigar = cigar; v.n_row_units = n_row_units; v.n_seq_units = n_seq_units; v.seq4 = seq4;
+            v.qlow = reinterpret_cast<const uint8_t *>(plane); v.min_base_qual = min_base_qual; v.n_qnames = n_qnames;
+            const int rc = uz_reads_adopt_device(c, &v, &id);
+            if (rc) throw UzError{rc, c->err};
+            c->reads[(size_t)id].mirror = blk;
+        } catch (...) { uz_block_put(c, blk); throw; }
+        { std::lock_guard<std::mutex> lk(c->err_mu); w.busy = false; }
+        *reads_id = id;
+    });
+}
+
 } // extern "C"

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "unfazed_hip.h"
+#include "uz_bamwalk.h"
 
 struct UzError {
     int code;
@@ -267,6 +268,19 @@ struct uz_ctx {
     hipStream_t inf_stream = nullptr, inf_stream2 = nullptr;
     hipEvent_t inf_ready = nullptr;
 
+    // the record walk on the device (k_bamwalk.hip, uz_bam_walk): a batch's inflated blocks stay in HBM from the walk until the batch's table has
+    // been packed from them (uz_reads_from_bam); three batches can be in flight (the staged pipeline decodes two chunks ahead)
+    struct WalkSlot {
+        bool busy = false;
+        DevBuf<uint8_t> comp, out;
+        DevBuf<int64_t> in_off, out_off, blk_coff, span, count, first, walked;
+        DevBuf<int32_t> task, reach, fetch, flags, iflags;
+        DevBuf<uz_walk_desc> desc;
+        int64_t n_blocks = 0, out_bytes = 0, n_desc = 0;
+        int32_t n_tasks = 0;
+    };
+    WalkSlot walk[3];
+
     // last phase (k_reads.hip)
     bool phase_valid = false;
     bool phase_open = false; // uz_phase_begin without its uz_phase_end
@@ -371,6 +385,14 @@ bool uz_finish_phase(uz_ctx *c, int32_t *status, int32_t *counts, int32_t *origi
 // BGZF blocks inflated on the device (k_inflate.hip): device pointers; comp padded by 1 KiB; cursor_and_err: two int32 of device memory
 void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, int64_t comp_bytes_padded, const int64_t *in_off,
                        const int64_t *out_off, uint8_t *out, int32_t *cursor_and_err);
+// the record walk on the device (k_bamwalk.hip): every pointer device memory; fill = false: counts + offsets (count, first, walked, flags), fill = true: the descriptors
+void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uint8_t *buf, const int64_t *blk_at, const int64_t *blk_coff, const int32_t *task,
+                        const int64_t *span, const int32_t *reach, const int32_t *fetch, int64_t *count, int64_t *first, int64_t *walked, int32_t *flags,
+                        uz_walk_desc *out);
+size_t uz_bam_walk_pad(); // bytes the inflated buffer must be padded by (the walk's LDS windows read past the last record)
+void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
+                           int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
+                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err);
 int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);
 int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q);
 void uz_phase_state_free(uz_ctx *c);

@@ -18,7 +18,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_PHASE, K_SIZING, K_CNV = 0, 1, 2, 
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host",
+    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host", "uz_bam_walk", "uz_bam_walk_fetch", "uz_bam_walk_release", "uz_reads_from_bam",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -58,6 +58,10 @@ def load_library(path: Optional[str] = None):
     L.uz_reads_headers.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.uz_bgzf_inflate.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
     L.uz_bgzf_inflate_to_host.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
+    L.uz_bam_walk.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
+    L.uz_bam_walk_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    L.uz_bam_walk_release.argtypes = [vp, C.c_int]
+    L.uz_reads_from_bam.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, vp]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -348,6 +352,42 @@ class HipEngine:
                                                 out.ctypes.data)
             if rc != 0:
                 raise UnfazedHipError("uz_bgzf_inflate_to_host: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
+
+    # ---- the record walk on the device (include/uz_bamwalk.h)
+    def bam_walk(self, plan: dict, alloc=None):
+        """io_native.BamSource.select_kept(walk=engine.bam_walk): the batch's gathered BGZF blocks inflated in HBM and walked there
+        (uz_bam_walk + uz_bam_walk_fetch).  -> (descriptors, d_first, d_flags, d_walked, walk id); the inflated bytes wait on the device for
+        reads_from_bam (or bam_walk_release).  May be called from a decoder's worker thread."""
+        from . import io_native
+        wid, nd = C.c_int(-1), C.c_int64(0)
+        nt = int(plan["task"].shape[0])
+        with self._inflate_lock:
+            rc = self.L.uz_bam_walk(self.h, plan["comp"].ctypes.data, int(plan["comp_bytes"]), int(plan["n_blocks"]), plan["in_off"].ctypes.data,
+                                    plan["out_off"].ctypes.data, plan["blk_coff"].ctypes.data, nt, plan["task"].ctypes.data, int(plan["span"].shape[0]),
+                                    plan["span"].ctypes.data, int(plan["reach"].shape[0]), plan["reach"].ctypes.data, int(plan["fetch"].shape[0]),
+                                    plan["fetch"].ctypes.data, C.byref(wid), C.byref(nd))
+            if rc != 0:
+                raise UnfazedHipError("uz_bam_walk: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
+            n = int(nd.value)
+            desc = (alloc(max(1, n) * 64).view(io_native.WALK_DESC) if alloc else np.zeros(max(1, n), io_native.WALK_DESC))[: max(1, n)]
+            d_first, d_flags, d_walked = np.zeros(nt + 1, np.int64), np.zeros(max(1, nt), np.int32), np.zeros(max(1, nt), np.int64)
+            rc = self.L.uz_bam_walk_fetch(self.h, wid.value, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data)
+            if rc != 0:
+                self.L.uz_bam_walk_release(self.h, wid.value)
+                raise UnfazedHipError("uz_bam_walk_fetch: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
+        return desc[:n], d_first, d_flags[:nt], d_walked[:nt], wid.value
+
+    def bam_walk_release(self, walk_id: int):
+        self._ck(self.L.uz_bam_walk_release(self.h, int(walk_id)), "uz_bam_walk_release")
+
+    def reads_from_bam(self, kb) -> int:
+        """The table of a batch walked on the device (kb: io_native.KeptBatch of select_kept(walk=self.bam_walk)): unpacked from the bytes in HBM."""
+        rid = C.c_int(-1)
+        self._ck(self.L.uz_reads_from_bam(self.h, int(kb.token), kb.kept.ctypes.data, int(kb.n), kb.aux.ctypes.data, int(kb.n_aux), kb.contig_off.ctypes.data,
+                                          kb.max_span.ctypes.data, int(kb.n_contigs), int(kb.n_cigar_total), int(kb.n_row_units), int(kb.n_seq_units),
+                                          int(kb.n_qnames), int(kb.min_base_qual), C.byref(rid)), "uz_reads_from_bam")
+        kb.token = None
+        return rid.value
 
     def adopt_sites(self, view: abi.SitesView) -> int:
         sid = C.c_int(-1)
