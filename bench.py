@@ -592,7 +592,10 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         def run_pass():
             for key in acc:
                 acc[key] = type(acc[key])()
-            with ThreadPoolExecutor(2) as ex:
+            # device walk: the BAM stages of TWO chunks in flight -- the device's share of chunk k (blocks up, inflate, walk, descriptors down) runs
+            # beside the host's joins of chunk k - 1 (three walked batches may wait on the device: uz_bam_walk)
+            lag = 2 if dev_walk else 1
+            with ThreadPoolExecutor(lag + 1) as ex:
                 t = time.perf_counter()
                 fa = {0: ex.submit(stage_a, 0)}
                 fcs, devs = {}, {}
@@ -601,9 +604,10 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                         fa[k + 1] = ex.submit(stage_a, k + 1)
                     devs[k] = stage_b(k, fa.pop(k).result())
                     fcs[k] = ex.submit(stage_c, k, devs[k][3])
-                    if k >= 1:
-                        stage_d(k - 1, devs.pop(k - 1), fcs.pop(k - 1).result())
-                stage_d(K - 1, devs.pop(K - 1), fcs.pop(K - 1).result())
+                    if k >= lag:
+                        stage_d(k - lag, devs.pop(k - lag), fcs.pop(k - lag).result())
+                for k in range(max(0, K - lag), K):
+                    stage_d(k, devs.pop(k), fcs.pop(k).result())
                 eng.sync()
                 return time.perf_counter() - t
 

@@ -70,7 +70,15 @@ struct WalkArgs {
     int64_t *walked;          // [n_tasks]
     int32_t *flags;           // [n_tasks]
     uz_walk_desc *out;
+    // the names of the direct records of a task, as a hash set (open addressing over the task's own slice of `tab`): pass 1 counts them,
+    // pass 2 inserts them; k_desc_filter then drops every descriptor that is neither direct nor shares a name hash with a direct one --
+    // exactly the records the host's walk drops first (io_stage.cpp finish_task: "mate candidates")
+    int64_t *n_direct;        // [n_tasks]  (pass 1)
+    const int64_t *tab_first; // [n_tasks + 1]  (pass 2): the task's slice, a power of two of slots
+    unsigned long long *tab;
 };
+__device__ __forceinline__ unsigned long long tab_key(uint64_t h1) { return (unsigned long long)h1 | 1ULL; } // (never 0 = empty; merging two hashes keeps a record too many, never one too few)
+__device__ __forceinline__ size_t tab_slot(unsigned long long key, int64_t size) { return (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 20) & (size_t)(size - 1); }
 
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
     const int32_t *tc = a.task + UZ_WALK_TASK_COLS * (size_t)t;
     const int32_t tid = tc[0], tb = tc[1], sp0 = tc[2], sp1 = tc[3], r0 = tc[4], r1 = tc[5], f0 = tc[6], f1 = tc[7], max_len = tc[8];
     const uint8_t *win8 = reinterpret_cast<const uint8_t *>(win);
-    int64_t n_out = 0, walked = 0;
+    int64_t n_out = 0, walked = 0, n_dir = 0;
     int flag = 0;
     bool stop = false;
     if (FILL && a.flags[t]) return; // (pass 1 gave this task back to the host: it owns no descriptors)
@@ -168,20 +176,30 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
                 walked += __popcll(__ballot(live && counted));
                 const bool emit = live && kind == K_EMIT;
                 const unsigned long long m = __ballot(emit);
+                // does a fetch return it?  (start < hi and end > lo: read_collector.py:385, :167)
+                bool direct = false;
+                if (emit) {
+                    const int64_t key = (int64_t)pos - max_len;
+                    int lo = f0, hi = f1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)a.fetch[3 * mid] < key) lo = mid + 1; else hi = mid; }
+                    for (; lo < f1 && a.fetch[3 * lo] < end; lo++)
+                        if (a.fetch[3 * lo + 1] > pos) { direct = true; break; }
+                }
+                n_dir += __popcll(__ballot(direct));
                 if (FILL && emit) {
                     const int rank = __popcll(m & ((1ULL << lane) - 1ULL));
-                    // does a fetch return it?  (start < hi and end > lo: read_collector.py:385, :167)
-                    bool direct = false;
-                    {
-                        const int64_t key = (int64_t)pos - max_len;
-                        int lo = f0, hi = f1;
-                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)a.fetch[3 * mid] < key) lo = mid + 1; else hi = mid; }
-                        for (; lo < f1 && a.fetch[3 * lo] < end; lo++)
-                            if (a.fetch[3 * lo + 1] > pos) { direct = true; break; }
-                    }
                     uz_walk_desc d;
                     d.voff = voff; d.src = (uint64_t)(c + 4);
                     d.h1 = name_hash1(p + 32, l_name - 1);
+                    if (direct) {
+                        const int64_t size = a.tab_first[t + 1] - a.tab_first[t];
+                        unsigned long long *tb = a.tab + a.tab_first[t];
+                        const unsigned long long key = tab_key(d.h1);
+                        for (size_t sl = tab_slot(key, size);; sl = (sl + 1) & (size_t)(size - 1)) { // (at most half full: pass 1 counted the direct records)
+                            const unsigned long long was = atomicCAS(&tb[sl], 0ULL, key);
+                            if (was == 0ULL || was == key) break;
+                        }
+                    }
                     d.pos = pos; d.end = end; d.tlen = (int32_t)ld32(p + 28); d.mpos = (int32_t)ld32(p + 24); d.mtid = (int32_t)ld32(p + 20);
                     d.h2 = uz_name_hash2(p + 32, l_name - 1);
                     d.task = (uint32_t)t;
@@ -201,19 +219,27 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
         }
     }
     if (lane == 0) {
-        if (!FILL) { a.count[t] = flag ? 0 : n_out; a.walked[t] = walked; a.flags[t] = flag; }
+        if (!FILL) { a.count[t] = flag ? 0 : n_out; a.n_direct[t] = flag ? 0 : n_dir; a.walked[t] = walked; a.flags[t] = flag; }
         else if (!flag && n_out != a.first[t + 1] - a.first[t]) a.flags[t] = UZ_WALK_TASK_BAD; // (cannot happen: both passes read the same bytes)
     }
 }
 
-// counts -> offsets (one workgroup)
+// counts -> offsets (one workgroup); POW2: the count of task i stands for a hash set of the next power of two >= 2 count + 2 slots
+template <bool POW2>
 __global__ __launch_bounds__(256) void k_walk_scan(int n, const int64_t *count, int64_t *first) {
     __shared__ long long part[256];
     const int t = threadIdx.x;
     const int chunk = (n + 255) / 256;
     const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
+    auto val = [&](int i) -> long long {
+        const long long c = count[i];
+        if (!POW2) return c;
+        long long sz = 4;
+        while (sz < 2 * c + 2) sz <<= 1;
+        return sz;
+    };
     long long s = 0;
-    for (int i = lo; i < hi; i++) s += count[i];
+    for (int i = lo; i < hi; i++) s += val(i);
     part[t] = s;
     __syncthreads();
     if (t == 0) {
@@ -223,7 +249,36 @@ __global__ __launch_bounds__(256) void k_walk_scan(int n, const int64_t *count, 
     }
     __syncthreads();
     long long run = part[t];
-    for (int i = lo; i < hi; i++) { first[i] = run; run += count[i]; }
+    for (int i = lo; i < hi; i++) { first[i] = run; run += val(i); }
+}
+
+// the descriptors of a task that are direct or share a name hash with a direct one, in order (one wavefront per task)
+template <bool FILL>
+__global__ __launch_bounds__(64) void k_desc_filter(const uz_walk_desc *__restrict__ in, const int64_t *__restrict__ first, const int64_t *__restrict__ tab_first,
+                                                    const unsigned long long *__restrict__ tab, int64_t *kcount, const int64_t *__restrict__ kfirst, uz_walk_desc *out) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int64_t a = first[t], b = first[t + 1], size = tab_first[t + 1] - tab_first[t];
+    const unsigned long long *tb = tab + tab_first[t];
+    int64_t n_out = 0;
+    for (int64_t i0 = a; i0 < b; i0 += 64) {
+        const int64_t i = i0 + lane;
+        bool keep = false;
+        if (i < b) {
+            keep = in[i].direct != 0;
+            if (!keep) {
+                const unsigned long long key = tab_key(in[i].h1);
+                for (size_t sl = tab_slot(key, size);; sl = (sl + 1) & (size_t)(size - 1)) {
+                    const unsigned long long x = tb[sl];
+                    if (x == key) { keep = true; break; }
+                    if (x == 0ULL) break;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (FILL && keep) out[kfirst[t] + n_out + __popcll(m & ((1ULL << lane) - 1ULL))] = in[i];
+        n_out += __popcll(m);
+    }
+    if (!FILL && lane == 0) kcount[t] = n_out;
 }
 
 // io_stage.cpp: has_sa_tag
@@ -337,14 +392,26 @@ __global__ __launch_bounds__(256) void k_bam_extract(ExtractArgs a) {
 // ---- launchers (abi.hip: uz_bam_walk / uz_bam_walk_fetch / uz_reads_from_bam)
 void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uint8_t *buf, const int64_t *blk_at, const int64_t *blk_coff, const int32_t *task,
                         const int64_t *span, const int32_t *reach, const int32_t *fetch, int64_t *count, int64_t *first, int64_t *walked, int32_t *flags,
-                        uz_walk_desc *out) {
+                        uz_walk_desc *out, int64_t *n_direct, int64_t *tab_first, unsigned long long *tab) {
     if (n_tasks <= 0) return;
-    WalkArgs a{buf, blk_at, blk_coff, task, span, reach, fetch, count, first, walked, flags, out};
+    WalkArgs a{buf, blk_at, blk_coff, task, span, reach, fetch, count, first, walked, flags, out, n_direct, tab_first, tab};
     if (!fill) {
         hipLaunchKernelGGL((k_bam_walk<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, a);
-        hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)count, first);
+        hipLaunchKernelGGL((k_walk_scan<false>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)count, first);
+        hipLaunchKernelGGL((k_walk_scan<true>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)n_direct, tab_first);
     } else
         hipLaunchKernelGGL((k_bam_walk<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, a);
+    UZ_HIP(hipGetLastError());
+}
+// fill = false: kcount + kfirst; fill = true: the kept descriptors into `out`
+void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uz_walk_desc *in, const int64_t *first, const int64_t *tab_first,
+                           const unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out) {
+    if (n_tasks <= 0) return;
+    if (!fill) {
+        hipLaunchKernelGGL((k_desc_filter<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, tab_first, tab, kcount, (const int64_t *)kfirst, out);
+        hipLaunchKernelGGL((k_walk_scan<false>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)kcount, kfirst);
+    } else
+        hipLaunchKernelGGL((k_desc_filter<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, tab_first, tab, kcount, (const int64_t *)kfirst, out);
     UZ_HIP(hipGetLastError());
 }
 size_t uz_bam_walk_pad() { return (size_t)WIN + 64; }
