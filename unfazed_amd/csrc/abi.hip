@@ -1719,35 +1719,38 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 uz_launch_inflate(c, st, n_blocks, w.comp.p, (comp_bytes + 1024) & ~(int64_t)3, w.in_off.p, w.out_off.p, w.out.p, w.iflags.p);
             }
             int32_t iflags[2] = {0, 0};
-            int64_t total = 0, tab_total = 0;
+            int64_t tab_total = 0, kept = 0;
             if (n_tasks) {
+                // one pass: every task writes its descriptors into a slice sized for the most records its bytes can hold (a record is at least 36 bytes)
+                std::vector<int64_t> first((size_t)n_tasks + 1, 0);
+                for (int32_t t = 0; t < n_tasks; t++) {
+                    const int32_t *tc = task + UZ_WALK_TASK_COLS * (size_t)t;
+                    int64_t cap = 0;
+                    for (int32_t sp = tc[2]; sp < tc[3]; sp++) cap += (span[UZ_WALK_SPAN_COLS * (size_t)sp + 3] - span[UZ_WALK_SPAN_COLS * (size_t)sp + 2]) / 36 + 1;
+                    first[(size_t)t + 1] = first[(size_t)t] + cap;
+                }
+                w.n_desc_all = first.back();
+                w.desc.ensure((size_t)first.back() + 1);
+                UZ_HIP(hipMemcpyAsync(w.first.p, first.data(), ((size_t)n_tasks + 1) * 8, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.task.p, task, (size_t)n_tasks * UZ_WALK_TASK_COLS * 4, hipMemcpyHostToDevice, st));
                 if (n_spans) UZ_HIP(hipMemcpyAsync(w.span.p, span, (size_t)n_spans * UZ_WALK_SPAN_COLS * 8, hipMemcpyHostToDevice, st));
                 if (n_reach) UZ_HIP(hipMemcpyAsync(w.reach.p, reach, (size_t)n_reach * 8, hipMemcpyHostToDevice, st));
                 if (n_fetch) UZ_HIP(hipMemcpyAsync(w.fetch.p, fetch, (size_t)n_fetch * 12, hipMemcpyHostToDevice, st));
-                uz_launch_bam_walk(c, st, false, n_tasks, w.out.p, w.out_off.p, w.blk_coff.p, w.task.p, w.span.p, w.reach.p, w.fetch.p, w.count.p, w.first.p, w.walked.p,
-                                   w.flags.p, nullptr, w.n_direct.p, w.tab_first.p, nullptr);
-                UZ_HIP(hipMemcpyAsync(&total, w.first.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
+                uz_launch_bam_walk(c, st, n_tasks, w.out.p, w.out_off.p, w.blk_coff.p, w.task.p, w.span.p, w.reach.p, w.fetch.p, w.count.p, w.first.p, w.walked.p,
+                                   w.flags.p, w.desc.p, w.n_direct.p, w.tab_first.p);
                 UZ_HIP(hipMemcpyAsync(&tab_total, w.tab_first.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
+                UZ_HIP(hipStreamSynchronize(st)); // (the pageable `first` has been read; the hash sets' size is known)
+                // the descriptors the host's joins can need at all (direct, or sharing a name hash with a direct record of the task) are counted
+                w.tab.ensure((size_t)tab_total + 1);
+                UZ_HIP(hipMemsetAsync(w.tab.p, 0, (size_t)tab_total * 8, st));
+                uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.count.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
+                UZ_HIP(hipMemcpyAsync(&kept, w.kfirst.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
             }
             if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags, w.iflags.p, 8, hipMemcpyDeviceToHost, st));
             UZ_HIP(hipStreamSynchronize(st));
             if (iflags[1])
                 throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(iflags[1] >> 4) + " of the batch: not a valid DEFLATE stream of the declared size (code " +
                                               std::to_string(iflags[1] & 15) + ")"};
-            // second pass: every record inside a reach interval as a descriptor in HBM, the names of the direct ones into the tasks' hash sets; then the
-            // descriptors the host's joins can need at all (direct, or sharing a name hash with a direct record of the task) are counted
-            w.n_desc_all = total;
-            int64_t kept = 0;
-            if (n_tasks) {
-                w.desc.ensure((size_t)total + 1); w.tab.ensure((size_t)tab_total + 1);
-                UZ_HIP(hipMemsetAsync(w.tab.p, 0, (size_t)tab_total * 8, st));
-                uz_launch_bam_walk(c, st, true, n_tasks, w.out.p, w.out_off.p, w.blk_coff.p, w.task.p, w.span.p, w.reach.p, w.fetch.p, w.count.p, w.first.p, w.walked.p,
-                                   w.flags.p, w.desc.p, w.n_direct.p, w.tab_first.p, w.tab.p);
-                uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
-                UZ_HIP(hipMemcpyAsync(&kept, w.kfirst.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
-                UZ_HIP(hipStreamSynchronize(st));
-            }
             w.n_desc = kept;
             *n_desc = kept;
             *walk_id = k;
@@ -1765,7 +1768,7 @@ int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_fir
         const int32_t nt = w.n_tasks;
         if (nt == 0) { d_first[0] = 0; return; }
         w.desc_kept.ensure((size_t)w.n_desc + 1);
-        uz_launch_desc_filter(c, st, true, nt, w.desc.p, w.first.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, w.desc_kept.p);
+        uz_launch_desc_filter(c, st, true, nt, w.desc.p, w.first.p, w.count.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, w.desc_kept.p);
         if (w.n_desc) UZ_HIP(hipMemcpyAsync(desc, w.desc_kept.p, (size_t)w.n_desc * sizeof(uz_walk_desc), hipMemcpyDeviceToHost, st));
         UZ_HIP(hipMemcpyAsync(d_first, w.kfirst.p, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
         if (d_flags) UZ_HIP(hipMemcpyAsync(d_flags, w.flags.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));

@@ -587,6 +587,7 @@ struct Scratch { // a worker's buffers, kept from task to task
 };
 
 void finish_task(const uz_stage &P, Task &T, Scratch &W, size_t ti);
+void mates_in_task(const uz_stage &P, Task &T, Scratch &W, size_t ti);
 
 // descriptor route: a record the host walked itself keeps its bytes (the device packs it from there: uz_stage_kept hands them over as the
 // batch's aux bytes) instead of the link-form extract
@@ -696,7 +697,6 @@ void walk_task(const uz_stage &P, Task &T, Scratch &W, size_t ti, bool finish = 
 
 // the second half of a task's walk, from the records in W.all: the mate candidates, and the mates inside the task
 void finish_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
-    const uz_bamsrc &S = *P.src;
     const Opt &o = P.opt;
     std::vector<WRec> &all = W.all;
     Task &tmp = W.tmp;
@@ -728,6 +728,11 @@ void finish_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
         }
         T.recs.push_back(r);
     }
+    mates_in_task(P, T, W, ti);
+}
+
+void mates_in_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
+    const uz_bamsrc &S = *P.src;
     // mates inside the task, while its records are hot: exact for a mate position inside one of the task's reach intervals (every
     // record overlapping such a position was walked, and the task holds ALL records of a name it holds at all).  Generation by
     // generation: a mate found becomes a member and has its own mate looked up.  What is left (mate_ref -2) goes through the
@@ -850,11 +855,17 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
             Task &T = P.tasks[(size_t)i];
             Scratch &W = *scr[(size_t)k];
             if (!d || (d_flags && d_flags[i])) { walk_task(P, T, W, (size_t)i); return; }
-            // the device walked it: its records from the descriptors
-            W.all.clear(); W.tmp.names.clear(); W.tmp.cigars.clear(); W.tmp.pay.clear(); W.tmp.raw.clear();
-            W.all.reserve((size_t)(d_first[i + 1] - d_first[i]));
+            // the device walked it: its records from the descriptors -- the direct ones and those that share a name hash with one of them
+            // (finish_task's rule; the device has dropped most of the others already)
+            std::vector<uint64_t> &dn = W.dn;
+            dn.clear();
+            for (int64_t j = d_first[i]; j < d_first[i + 1]; j++) if (d[j].direct) dn.push_back(d[j].h1);
+            std::sort(dn.begin(), dn.end());
+            dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
+            T.recs.reserve((size_t)(d_first[i + 1] - d_first[i]));
             for (int64_t j = d_first[i]; j < d_first[i + 1]; j++) {
                 const uz_walk_desc &x = d[j];
+                if (!x.direct && !std::binary_search(dn.begin(), dn.end(), x.h1)) continue;
                 WRec r;
                 memset(&r, 0, sizeof(r));
                 r.voff = x.voff; r.nhash = x.h1; r.nhash2 = x.h2; r.src = x.src;
@@ -863,10 +874,10 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
                 r.keep = x.direct ? 2 : 0;
                 r.mate_ref = -2;
                 r.umask = (uint16_t)UZ_UMASK_ALL;
-                W.all.push_back(r);
+                T.recs.push_back(r);
             }
-            T.n_walked = d_walked ? d_walked[i] : (int64_t)W.all.size();
-            finish_task(P, T, W, (size_t)i);
+            T.n_walked = d_walked ? d_walked[i] : d_first[i + 1] - d_first[i];
+            mates_in_task(P, T, W, (size_t)i);
         });
     }
     double t2 = now_s();
@@ -1129,8 +1140,13 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
         // (the name hashes side by side: the passes below look at nothing else of a record until two hashes are equal, and the records
         // themselves are ~100 bytes apiece behind two indirections)
         std::vector<uint64_t> nh((size_t)n);
+        std::vector<uint64_t> nh2(P.desc ? (size_t)n : 0); // descriptor route: the second hash and the length side by side too -- a name IS that triple there
         slices([&](int sl, int64_t k0, int64_t k1) {
-            for (int64_t k = k0; k < k1; k++) { const uint64_t h = rec_of(P, order[(size_t)k]).nhash; nh[(size_t)k] = h; hist[(size_t)sl][h >> 56]++; }
+            for (int64_t k = k0; k < k1; k++) {
+                const WRec &x = rec_of(P, order[(size_t)k]);
+                const uint64_t h = x.nhash; nh[(size_t)k] = h; hist[(size_t)sl][h >> 56]++;
+                if (P.desc) nh2[(size_t)k] = (uint64_t)x.nhash2 | ((uint64_t)x.l_name << 32);
+            }
         });
         std::vector<int64_t> sh_off(SH + 1, 0);
         int64_t run = 0;
@@ -1155,7 +1171,9 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
                     for (;;) {
                         const int32_t f = tab[slot];
                         if (f < 0) { tab[slot] = (int32_t)k; first_of[k] = k; break; }
-                        if (nh[(size_t)f] == hk) { // (then, and only then, the names themselves)
+                        if (nh[(size_t)f] == hk && P.desc) {
+                            if (nh2[(size_t)f] == nh2[k]) { first_of[k] = (uint32_t)f; break; }
+                        } else if (nh[(size_t)f] == hk) { // (then, and only then, the names themselves)
                             const int64_t ref = order[k], rf = order[(size_t)f];
                             if (same_name(P.tasks[(size_t)(ref >> 32)], rec_of(P, ref), P.tasks[(size_t)(rf >> 32)], rec_of(P, rf))) { first_of[k] = (uint32_t)f; break; }
                         }

@@ -80,8 +80,8 @@ struct WalkArgs {
 __device__ __forceinline__ unsigned long long tab_key(uint64_t h1) { return (unsigned long long)h1 | 1ULL; } // (never 0 = empty; merging two hashes keeps a record too many, never one too few)
 __device__ __forceinline__ size_t tab_slot(unsigned long long key, int64_t size) { return (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 20) & (size_t)(size - 1); }
 
-template <bool FILL>
 __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
+    constexpr bool FILL = true;
     __shared__ uint4 win[WIN / 16];
     __shared__ uint16_t offs[WIN_RECS];
     __shared__ int s_n, s_state;
@@ -93,7 +93,6 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
     int64_t n_out = 0, walked = 0, n_dir = 0;
     int flag = 0;
     bool stop = false;
-    if (FILL && a.flags[t]) return; // (pass 1 gave this task back to the host: it owns no descriptors)
     for (int sp = sp0; sp < sp1 && !stop && !flag; sp++) {
         const int64_t *sc = a.span + UZ_WALK_SPAN_COLS * (size_t)sp;
         const uint64_t span_end = (uint64_t)sc[1];
@@ -191,15 +190,7 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
                     uz_walk_desc d;
                     d.voff = voff; d.src = (uint64_t)(c + 4);
                     d.h1 = name_hash1(p + 32, l_name - 1);
-                    if (direct) {
-                        const int64_t size = a.tab_first[t + 1] - a.tab_first[t];
-                        unsigned long long *tb = a.tab + a.tab_first[t];
-                        const unsigned long long key = tab_key(d.h1);
-                        for (size_t sl = tab_slot(key, size);; sl = (sl + 1) & (size_t)(size - 1)) { // (at most half full: pass 1 counted the direct records)
-                            const unsigned long long was = atomicCAS(&tb[sl], 0ULL, key);
-                            if (was == 0ULL || was == key) break;
-                        }
-                    }
+
                     d.pos = pos; d.end = end; d.tlen = (int32_t)ld32(p + 28); d.mpos = (int32_t)ld32(p + 24); d.mtid = (int32_t)ld32(p + 20);
                     d.h2 = uz_name_hash2(p + 32, l_name - 1);
                     d.task = (uint32_t)t;
@@ -218,9 +209,24 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
             __syncthreads(); // the window is read to the end before the next one lands
         }
     }
-    if (lane == 0) {
-        if (!FILL) { a.count[t] = flag ? 0 : n_out; a.n_direct[t] = flag ? 0 : n_dir; a.walked[t] = walked; a.flags[t] = flag; }
-        else if (!flag && n_out != a.first[t + 1] - a.first[t]) a.flags[t] = UZ_WALK_TASK_BAD; // (cannot happen: both passes read the same bytes)
+    if (lane == 0) { // (a flagged task goes back to the host: what it wrote into its slice is never looked at)
+        a.count[t] = flag ? 0 : n_out; a.n_direct[t] = flag ? 0 : n_dir; a.walked[t] = walked; a.flags[t] = flag;
+    }
+}
+
+// the names of every task's direct records into its hash set (one wavefront per task over its descriptors)
+__global__ __launch_bounds__(64) void k_tab_insert(const uz_walk_desc *__restrict__ in, const int64_t *__restrict__ first, const int64_t *__restrict__ count,
+                                                   const int64_t *__restrict__ tab_first, unsigned long long *tab) {
+    const int t = blockIdx.x;
+    const int64_t a = first[t], b = a + count[t], size = tab_first[t + 1] - tab_first[t];
+    unsigned long long *tb = tab + tab_first[t];
+    for (int64_t i = a + threadIdx.x; i < b; i += 64) {
+        if (!in[i].direct) continue;
+        const unsigned long long key = tab_key(in[i].h1);
+        for (size_t sl = tab_slot(key, size);; sl = (sl + 1) & (size_t)(size - 1)) { // (at most half full: the walk counted the direct records)
+            const unsigned long long was = atomicCAS(&tb[sl], 0ULL, key);
+            if (was == 0ULL || was == key) break;
+        }
     }
 }
 
@@ -254,10 +260,11 @@ __global__ __launch_bounds__(256) void k_walk_scan(int n, const int64_t *count, 
 
 // the descriptors of a task that are direct or share a name hash with a direct one, in order (one wavefront per task)
 template <bool FILL>
-__global__ __launch_bounds__(64) void k_desc_filter(const uz_walk_desc *__restrict__ in, const int64_t *__restrict__ first, const int64_t *__restrict__ tab_first,
-                                                    const unsigned long long *__restrict__ tab, int64_t *kcount, const int64_t *__restrict__ kfirst, uz_walk_desc *out) {
+__global__ __launch_bounds__(64) void k_desc_filter(const uz_walk_desc *__restrict__ in, const int64_t *__restrict__ first, const int64_t *__restrict__ count,
+                                                    const int64_t *__restrict__ tab_first, const unsigned long long *__restrict__ tab, int64_t *kcount,
+                                                    const int64_t *__restrict__ kfirst, uz_walk_desc *out) {
     const int t = blockIdx.x, lane = threadIdx.x;
-    const int64_t a = first[t], b = first[t + 1], size = tab_first[t + 1] - tab_first[t];
+    const int64_t a = first[t], b = a + count[t], size = tab_first[t + 1] - tab_first[t];
     const unsigned long long *tb = tab + tab_first[t];
     int64_t n_out = 0;
     for (int64_t i0 = a; i0 < b; i0 += 64) {
@@ -329,54 +336,84 @@ struct ExtractArgs {
     int32_t *err;
 };
 
+// Eight lanes per record, 32 records per workgroup.  The record's bytes are staged in LDS first -- the eight lanes fetch consecutive 16-byte
+// pieces, so a wave's load touches eight records' lines instead of 64 lanes' worth of scattered bytes -- and every byte-granular read below
+// (BAM fields are unaligned) is an LDS read; a record longer than the stage is read from where it lies.
+constexpr int EX_CAP = 768;
 __global__ __launch_bounds__(256) void k_bam_extract(ExtractArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const uz_kept_rec k = a.kept[i];
-    const bool in_aux = (k.src & UZ_WALK_SRC_AUX) != 0;
-    const uint64_t off = k.src & ~UZ_WALK_SRC_AUX;
-    const int64_t lim = in_aux ? a.aux_bytes : a.buf_bytes;
-    if (off < 4 || (int64_t)off + 32 > lim) { *a.err = 1; return; }
-    const uint8_t *p = (in_aux ? a.aux : a.buf) + off;
-    const uint32_t bs = ld32(p - 4);
+    __shared__ uint4 stage[32][EX_CAP / 16];
+    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    const int64_t i = (int64_t)blockIdx.x * 32 + g;
+    bool ok = i < a.n;
+    uz_kept_rec k = {};
+    const uint8_t *gp = a.buf;
+    int64_t lim = 0;
+    uint64_t off = 0;
+    uint32_t bs = 0;
+    if (ok) {
+        k = a.kept[i];
+        const bool in_aux = (k.src & UZ_WALK_SRC_AUX) != 0;
+        off = k.src & ~UZ_WALK_SRC_AUX;
+        lim = in_aux ? a.aux_bytes : a.buf_bytes;
+        if (off < 4 || (int64_t)off + 32 > lim) { *a.err = 1; ok = false; }
+        else {
+            gp = (in_aux ? a.aux : a.buf) + off;
+            bs = ld32(gp - 4);
+            if (bs < 32 || (int64_t)off + (int64_t)bs > lim) { *a.err = 1; ok = false; }
+        }
+    }
+    const uint8_t *src = gp - 4;
+    const uint32_t d = ok ? (uint32_t)((uintptr_t)src & 15u) : 0u;
+    const uint32_t total = d + 4 + bs;
+    const bool in_lds = ok && total <= (uint32_t)EX_CAP;
+    if (in_lds)
+        for (uint32_t c = (uint32_t)l; 16 * c < total; c += 8) stage[g][c] = *reinterpret_cast<const uint4 *>(src - d + 16 * (size_t)c); // (the buffers are padded: the last piece may reach past the record)
+    __syncthreads();
+    if (!ok) return;
+    const uint8_t *p = in_lds ? reinterpret_cast<const uint8_t *>(stage[g]) + d + 4 : gp;
     const uint32_t l_name = p[8], ncig = ld16(p + 12), fl = ld16(p + 14), L = ld32(p + 16);
-    if ((int64_t)off + (int64_t)bs > lim || L > 0xFFFFu || l_name < 1 ||
-        32 + (uint64_t)l_name + 4 * (uint64_t)ncig + ((uint64_t)L + 1) / 2 + (uint64_t)L > (uint64_t)bs) { *a.err = 1; return; }
+    if (L > 0xFFFFu || l_name < 1 || 32 + (uint64_t)l_name + 4 * (uint64_t)ncig + ((uint64_t)L + 1) / 2 + (uint64_t)L > (uint64_t)bs) { *a.err = 1; return; }
     const uint8_t *q = p + 32 + l_name;
     const uint8_t *sq = q + 4 * (size_t)ncig;
     const uint8_t *ql = sq + ((size_t)L + 1) / 2;
-    const uint8_t *tags = ql + L;
     const bool bases = k.seq_off != UZ_KEPT_NO_SEQ;
     const bool noqual = L > 0 && ql[0] == 0xFF;
-    uint32_t ax = 0;
-    if ((int32_t)ld32(p + 20) == (int32_t)ld32(p)) ax |= UZ_AUX_MATE_SAME_TID;
-    if (has_sa_tag(tags, p + bs)) ax |= UZ_AUX_HAS_SA;
-    if (ncig == 0 || L == 0 || noqual) ax |= UZ_AUX_DECODE_BAD;
-    if (!bases) ax |= UZ_AUX_NO_SEQ;
-    a.start[i] = (int32_t)ld32(p + 4);
-    a.tlen[i] = (int32_t)ld32(p + 28);
-    a.mate[i] = k.mate;
-    a.qname[i] = k.qname;
-    a.flag[i] = (uint16_t)fl; a.l_seq[i] = (uint16_t)L; a.n_cigar[i] = (uint16_t)ncig;
-    a.mapq[i] = p[9]; a.aux_col[i] = (uint8_t)ax;
-    for (uint32_t w = 0; w < ncig; w++) a.cigar[(size_t)k.cig_off + w] = ld32(q + 4 * w);
+    if (l == 0) {
+        uint32_t ax = 0;
+        if ((int32_t)ld32(p + 20) == (int32_t)ld32(p)) ax |= UZ_AUX_MATE_SAME_TID;
+        if (has_sa_tag(ql + L, p + bs)) ax |= UZ_AUX_HAS_SA;
+        if (ncig == 0 || L == 0 || noqual) ax |= UZ_AUX_DECODE_BAD;
+        if (!bases) ax |= UZ_AUX_NO_SEQ;
+        a.start[i] = (int32_t)ld32(p + 4);
+        a.tlen[i] = (int32_t)ld32(p + 28);
+        a.mate[i] = k.mate;
+        a.qname[i] = k.qname;
+        a.flag[i] = (uint16_t)fl; a.l_seq[i] = (uint16_t)L; a.n_cigar[i] = (uint16_t)ncig;
+        a.mapq[i] = p[9]; a.aux_col[i] = (uint8_t)ax;
+    }
+    for (uint32_t w = (uint32_t)l; w < ncig; w += 8) a.cigar[(size_t)k.cig_off + w] = ld32(q + 4 * w);
     const uint32_t units = UZ_ROW_UNITS(L);
     if (bases) { // BAM's own nibbles; the pad nibble of an odd length and the rest of the last unit are zero
-        uint8_t *row = a.seq4 + (size_t)k.seq_off * UZ_SEQ4_UNIT_BYTES;
         const uint32_t nb = (L + 1) / 2;
-        for (uint32_t b = 0; b < units * UZ_SEQ4_UNIT_BYTES; b += 4) {
-            uint32_t w = 0;
+        for (uint32_t u = (uint32_t)l; u < units; u += 8) {
+            uint32_t w4[4];
 #pragma unroll
-            for (uint32_t e = 0; e < 4; e++) {
-                uint32_t v = b + e < nb ? (uint32_t)sq[b + e] : 0u;
-                if (b + e + 1 == nb && (L & 1u)) v &= 0xF0u;
-                w |= v << (8 * e);
+            for (uint32_t qd = 0; qd < 4; qd++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++) {
+                    const uint32_t b = 16 * u + 4 * qd + e;
+                    uint32_t v = b < nb ? (uint32_t)sq[b] : 0u;
+                    if (b + 1 == nb && (L & 1u)) v &= 0xF0u;
+                    w |= v << (8 * e);
+                }
+                w4[qd] = w;
             }
-            *reinterpret_cast<uint32_t *>(row + b) = w;
+            *reinterpret_cast<uint4 *>(a.seq4 + ((size_t)k.seq_off + u) * UZ_SEQ4_UNIT_BYTES) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         }
     }
     // the plane "quality below the threshold" (a record without qualities decodes to zeros: every base is below a positive threshold)
-    for (uint32_t u = 0; u < units; u++) {
+    for (uint32_t u = (uint32_t)l; u < units; u += 8) {
         uint32_t w = 0;
         const uint32_t k0 = 32 * u, k1 = min(L, k0 + 32);
         for (uint32_t b = k0; b < k1; b++) {
@@ -390,28 +427,29 @@ __global__ __launch_bounds__(256) void k_bam_extract(ExtractArgs a) {
 } // namespace
 
 // ---- launchers (abi.hip: uz_bam_walk / uz_bam_walk_fetch / uz_reads_from_bam)
-void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uint8_t *buf, const int64_t *blk_at, const int64_t *blk_coff, const int32_t *task,
-                        const int64_t *span, const int32_t *reach, const int32_t *fetch, int64_t *count, int64_t *first, int64_t *walked, int32_t *flags,
-                        uz_walk_desc *out, int64_t *n_direct, int64_t *tab_first, unsigned long long *tab) {
+// the walk: every record inside a reach interval as a descriptor into its task's slice of `out` (first[t]: where the slice starts -- sized by
+// the caller for the most records the task's bytes can hold), count / n_direct / walked / flags per task; tab_first: the hash sets' slices
+void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, int n_tasks, const uint8_t *buf, const int64_t *blk_at, const int64_t *blk_coff, const int32_t *task,
+                        const int64_t *span, const int32_t *reach, const int32_t *fetch, int64_t *count, const int64_t *first, int64_t *walked, int32_t *flags,
+                        uz_walk_desc *out, int64_t *n_direct, int64_t *tab_first) {
     if (n_tasks <= 0) return;
-    WalkArgs a{buf, blk_at, blk_coff, task, span, reach, fetch, count, first, walked, flags, out, n_direct, tab_first, tab};
-    if (!fill) {
-        hipLaunchKernelGGL((k_bam_walk<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, a);
-        hipLaunchKernelGGL((k_walk_scan<false>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)count, first);
-        hipLaunchKernelGGL((k_walk_scan<true>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)n_direct, tab_first);
-    } else
-        hipLaunchKernelGGL((k_bam_walk<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, a);
+    WalkArgs a{buf, blk_at, blk_coff, task, span, reach, fetch, count, first, walked, flags, out, n_direct, nullptr, nullptr};
+    hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)n_tasks), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((k_walk_scan<true>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)n_direct, tab_first);
     UZ_HIP(hipGetLastError());
 }
-// fill = false: kcount + kfirst; fill = true: the kept descriptors into `out`
-void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uz_walk_desc *in, const int64_t *first, const int64_t *tab_first,
-                           const unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out) {
+// stage 0: the hash sets filled, the kept descriptors counted (kcount, kfirst); stage 1: the kept descriptors into `out`
+void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uz_walk_desc *in, const int64_t *first, const int64_t *count,
+                           const int64_t *tab_first, unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out) {
     if (n_tasks <= 0) return;
     if (!fill) {
-        hipLaunchKernelGGL((k_desc_filter<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, tab_first, tab, kcount, (const int64_t *)kfirst, out);
+        hipLaunchKernelGGL(k_tab_insert, dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, tab_first, tab);
+        hipLaunchKernelGGL((k_desc_filter<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, tab_first, (const unsigned long long *)tab, kcount,
+                           (const int64_t *)kfirst, out);
         hipLaunchKernelGGL((k_walk_scan<false>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)kcount, kfirst);
     } else
-        hipLaunchKernelGGL((k_desc_filter<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, tab_first, tab, kcount, (const int64_t *)kfirst, out);
+        hipLaunchKernelGGL((k_desc_filter<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, tab_first, (const unsigned long long *)tab, kcount,
+                           (const int64_t *)kfirst, out);
     UZ_HIP(hipGetLastError());
 }
 size_t uz_bam_walk_pad() { return (size_t)WIN + 64; }
@@ -421,6 +459,6 @@ void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *
                            uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err) {
     if (n <= 0) return;
     ExtractArgs a{buf, aux, kept, n, buf_bytes, aux_bytes, thr, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col, cigar, seq4, plane, err};
-    hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, a);
     UZ_HIP(hipGetLastError());
 }
