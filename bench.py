@@ -504,13 +504,22 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         cutoff = concordant_cutoff(src.tlen_head, P.readlen, 3)
         sd = int(P.search_dist) + 2
         cuts = list(range(0, m, max(1, args.feed_chunk))) + [m]
+        if args.feed_walk == "device" and args.feed_inflate == "device" and len(cuts) > 3:
+            # device walk: the device's share of a chunk (blocks up, inflate, walk) is the pipeline's longest stage, so the pass is its sum plus what
+            # cannot overlap -- the first chunk's way to the device, the last chunk's joins and read stage: half-size chunks at both ends
+            c = max(1, args.feed_chunk)
+            cuts = [0, c // 2] + list(range(c // 2 + c, m - c // 2, c))
+            if m - cuts[-1] > c // 2 + c // 4:
+                cuts.append(m - c // 2)
+            cuts.append(m)
         K = len(cuts) - 1
-        pools = [PinnedPool() for _ in range(3)]  # chunk k stages into pools[k % 3]: its block is rewound, not re-pinned
+        NB = 4  # sets of page-locked buffers: chunk k uses set k % NB (up to three BAM stages in flight beside the read stage of a fourth chunk)
+        pools = [PinnedPool() for _ in range(NB)]  # chunk k stages into pools[k % NB]: its block is rewound, not re-pinned
         from unfazed_amd.engine import PinnedPair
         on_device = args.feed_inflate == "device"
         dev_walk = args.feed_walk == "device" and on_device
-        ipairs = [PinnedPair() for _ in range(3)] if on_device else None  # ... and its gathered / inflated BGZF blocks through ipairs[k % 3]
-        slab_bytes = [0, 0, 0]
+        ipairs = [PinnedPair() for _ in range(NB)] if on_device else None  # ... and its gathered / inflated BGZF blocks through ipairs[k % NB]
+        slab_bytes = [0] * NB
         acc = dict(vcf_s=0.0, bam_s=0.0, site_records=0, walked=0, kept=0, file_bytes=0, blocks=0, spans=0.0, walk=0.0, mates=0.0, numbering=0.0, fill=0.0,
                    link_bytes=0, lookups=0, dev_blocks=0, dev_out_bytes=0, dev_inflate_s=0.0, gather_s=0.0, blocks_dev=0,
                    w_plan=0.0, w_walk=0.0, w_joins=0.0, w_kept=0.0, w_desc=0, w_host_tasks=0, w_tasks=0, w_aux=0)
@@ -543,16 +552,16 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
 
         def stage_c(k, f):  # the BAM through its index, straight into the link form (pinned)
             t = time.perf_counter()
-            pool = pools[k % 3]
+            pool = pools[k % NB]
             want = max(slab_bytes) * 5 // 4 if max(slab_bytes) else (cuts[k + 1] - cuts[k]) * 16384 + (1 << 20)
             if not pool.rewind(want):
                 pool.free_all()
                 pool.new_slab(want)
             if on_device:
-                ipairs[k % 3].start()
+                ipairs[k % NB].start()
             if dev_walk:  # the blocks go up, are inflated and walked in HBM; descriptors come back, the joins run here, the kept list goes up
-                pa = ipairs[k % 3].alloc
-                kb = src.select_kept(f[0], f[1], f[2], int(P.min_gt_qual), walk=lambda plan: eng.bam_walk(plan, alloc=pa), alloc=pa)
+                pa = ipairs[k % NB].alloc
+                kb = src.select_kept(f[0], f[1], f[2], int(P.min_gt_qual), walk=lambda plan: eng.bam_walk(plan, alloc=pa), alloc=pa, release=eng.bam_walk_release)
                 acc["bam_s"] += time.perf_counter() - t
                 io, tm = kb.io_stats, kb.timing
                 acc["walked"] += io["records_walked"]; acc["kept"] += io["records_kept"]; acc["lookups"] += io["index_mate_lookups"]
@@ -564,12 +573,12 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 kb.plan = kb.desc = None
                 return kb
             packed = src.select(f[0], f[1], f[2], int(P.min_gt_qual), alloc=pool.alloc, extra=f[3],
-                                inflate=eng.inflate_blocks if on_device else None, inflate_alloc=ipairs[k % 3].alloc if on_device else None)
+                                inflate=eng.inflate_blocks if on_device else None, inflate_alloc=ipairs[k % NB].alloc if on_device else None)
             if packed.pre_inflate:
                 acc["dev_blocks"] += packed.pre_inflate["blocks"]; acc["dev_out_bytes"] += packed.pre_inflate["out_bytes"]
                 acc["dev_inflate_s"] += packed.pre_inflate["inflate_s"]; acc["gather_s"] += packed.pre_inflate["gather_s"]
                 acc["blocks_dev"] += io_dev(packed)
-            slab_bytes[k % 3] = max(slab_bytes[k % 3], pool.slab_used())
+            slab_bytes[k % NB] = max(slab_bytes[k % NB], pool.slab_used())
             acc["bam_s"] += time.perf_counter() - t
             io, tm = packed.io_stats, packed.timing
             acc["walked"] += io["records_walked"]; acc["kept"] += io["records_kept"]; acc["file_bytes"] += io["file_bytes_read"]
@@ -592,9 +601,9 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         def run_pass():
             for key in acc:
                 acc[key] = type(acc[key])()
-            # device walk: the BAM stages of TWO chunks in flight -- the device's share of chunk k (blocks up, inflate, walk, descriptors down) runs
-            # beside the host's joins of chunk k - 1 (three walked batches may wait on the device: uz_bam_walk)
-            lag = 2 if dev_walk else 1
+            # device walk: the BAM stages of THREE chunks in flight -- the device's share of chunk k (blocks up, inflate, walk, descriptors down) runs
+            # beside the host's joins of chunks k - 1 and k - 2 (four walked batches may wait on the device: uz_bam_walk)
+            lag = int(os.environ.get("UZ_FEED_LAG", "3")) if dev_walk else 1
             with ThreadPoolExecutor(lag + 1) as ex:
                 t = time.perf_counter()
                 fa = {0: ex.submit(stage_a, 0)}
@@ -630,9 +639,11 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         raw_per_rec = st_b["raw_bytes"] / max(1, st_b["records"])
         return {
             "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "result_mismatches_vs_resident": mism,
+            "walk": "device (k_bam_walk: one wavefront per walk task; the host runs the batch-wide joins on 64-byte descriptors)" if dev_walk else "host (uz_bam_stage_*)",
             "inflate": ("device (k_bgzf_inflate: one wavefront per BGZF block; blocks the walk did not announce: " + io_native.inflate_backend() + ")") if on_device
                        else io_native.inflate_backend(),
-            "device_inflate": None if not on_device else {
+            "device_inflate": None if not on_device else {"blocks": acc["dev_blocks"], "out_GB": round(acc["dev_out_bytes"] / 1e9, 3),
+                                                          "note": "inflated in HBM and walked there: its time is inside device_walk.seconds_busy"} if dev_walk else {
                 "blocks": acc["dev_blocks"], "blocks_used_by_the_walk": acc["blocks_dev"], "out_GB": round(acc["dev_out_bytes"] / 1e9, 3),
                 "seconds_busy": round(acc["dev_inflate_s"], 3), "gather_seconds_busy": round(acc["gather_s"], 3),
                 "GBps_incl_both_copies": round(acc["dev_out_bytes"] / max(acc["dev_inflate_s"], 1e-9) / 1e9, 1),

@@ -108,9 +108,10 @@ int uz_bgzf_inflate_to_host(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes
  * What it replaces: `bamfile.fetch(chrom, lo, hi)` walking the records of a window (read_collector.py:385, :167) -- on the host until round 4, with
  * the inflated blocks crossing the link twice.
  * uz_bam_walk: the gathered BGZF blocks of a batch (uz_stage_gather_blocks: comp / in_off / out_off, blk_coff from uz_stage_walk_plan) go up, are
- * inflated in HBM and stay there; one wavefront per task of the plan walks them and counts the records inside the task's reach intervals.
- * -> *n_desc descriptors wait, *walk_id names the batch (three may be in flight).  Callable from a decoder's worker thread.
- * uz_bam_walk_fetch: the descriptors (second pass of the walk), task by task in file order: desc [n_desc], d_first [n_tasks + 1], d_flags / d_walked
+ * inflated in HBM and stay there; one wavefront per task of the plan walks them (every record inside a reach interval becomes a descriptor in HBM), and the
+ * descriptors the batch-wide joins can need -- the records a fetch returns and those that share a name with one of them -- are counted.
+ * -> *n_desc descriptors wait, *walk_id names the batch (four may be in flight).  Callable from a decoder's worker thread.
+ * uz_bam_walk_fetch: those descriptors, task by task in file order: desc [n_desc], d_first [n_tasks + 1], d_flags / d_walked
  * [n_tasks] (UZ_WALK_TASK_*: a flagged task owns no descriptors -- the host walks it).
  * uz_reads_from_bam: the table of the kept records (uz_stage_kept), unpacked on the device from the bytes the walk left in HBM (and the aux bytes
  * of records only the host has seen) and built like an adopted table (uz_reads_adopt_device); releases the batch.  Owner's thread only.
@@ -122,7 +123,8 @@ int uz_bam_walk_fetch(uz_ctx *ctx, int walk_id, uz_walk_desc *desc, int64_t *d_f
 int uz_bam_walk_release(uz_ctx *ctx, int walk_id);
 int uz_reads_from_bam(uz_ctx *ctx, int walk_id, const uz_kept_rec *kept, int64_t n, const uint8_t *aux, int64_t aux_bytes, const int64_t *contig_off,
                       const int32_t *max_span, int32_t n_contigs, int64_t n_cigar_total, int64_t n_row_units, int64_t n_seq_units, uint32_t n_qnames,
-                      int32_t min_base_qual, int *reads_id);
+                      int32_t min_base_qual, uint8_t *names_out /* NULL, or [names_bytes]: the kept records' read names back to back (uz_kept_rec.name_off) */,
+                      int64_t names_bytes, int *reads_id);
 /* page-locked host memory for the staged columns (plain hipHostMalloc; no context needed) */
 int uz_pinned_alloc(size_t bytes, void **out);
 void uz_pinned_free(void *p);

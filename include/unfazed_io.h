@@ -309,7 +309,9 @@ int uz_bam_stage_finish_desc(uz_stage *s, const uz_walk_desc *d, const int64_t *
                              const int64_t *d_walked /* [n_tasks] or NULL */);
 /* the host's twin of the device's walk: the same descriptors from the host's own walk (out == NULL: the counts only) */
 int uz_stage_walk_host(uz_stage *s, uz_walk_desc *out, int64_t cap, int64_t *d_first /* [n_tasks + 1] */, int64_t *d_walked /* [n_tasks] or NULL */);
-void uz_stage_kept_sizes(const uz_stage *s, int64_t out[8]);
+void uz_stage_kept_sizes(const uz_stage *s, int64_t out[8]); /* ... [7] name bytes of the kept records */
+/* the kept record that brought name id ids[k] first (ids == NULL: ids 0 .. n - 1): its name is the id's (uz_reads_from_bam returns the kept records' names) */
+int uz_stage_name_records(const uz_stage *s, const uint32_t *ids, int64_t n, int64_t *rec);
 int uz_stage_kept(const uz_stage *s, int threads, uz_kept_rec *out /* [records] */, int64_t *contig_off /* [n_contigs + 1] */, int32_t *max_span /* [n_contigs] */,
                   uint8_t *aux, int64_t aux_cap);
 /* parity aid: the kept records of any finished plan in output order (any pointer may be NULL) */

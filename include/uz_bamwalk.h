@@ -51,7 +51,7 @@ typedef struct uz_kept_rec {
     uint32_t cig_off;  /* first CIGAR word in the table's store */
     uint32_t unit_off; /* first row unit of its quality plane (every record has one) */
     uint32_t seq_off;  /* first row unit of its bases, UZ_KEPT_NO_SEQ: the record travels without bases */
-    uint32_t pad;
+    uint32_t name_off; /* first byte of its read name in the batch's name store (names back to back, no terminators, record order) */
 } uz_kept_rec;
 #define UZ_KEPT_NO_SEQ 0xFFFFFFFFu
 

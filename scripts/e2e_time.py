@@ -65,7 +65,18 @@ try:
         r = orig_vcf(*a, **k)
         stats["vcf"].append((time.time() - tt, r.io_stats))
         return r
+    orig_kept = io_native.BamSource.select_kept
+
+    def spy_kept(self, *a, **k):  # the device-walk route (include/uz_bamwalk.h): the blocks are inflated and walked on the device
+        tt = time.time()
+        r = orig_kept(self, *a, **k)
+        io = dict(r.io_stats)
+        io["blocks_inflated"] = r.plan["n_blocks"]
+        io["walked_on_the_device"] = 1
+        stats["bam"].append((time.time() - tt, io, r.timing))
+        return r
     io_native.BamSource.select = spy_sel
+    io_native.BamSource.select_kept = spy_kept
     io_native.read_vcf_table_regions = spy_vcf
     for rep in range(2):
         for v in stats.values():
@@ -92,7 +103,7 @@ try:
           "%d kept | VCF windows %.2f s: %d of %d blocks, %d records | BED %.2f s" % (
               M, t_phase, bam_s, blocks, sb["blocks"], 100.0 * blocks / sb["blocks"], walked, kept, vcf_s, vcf_blocks, sv["blocks"], vcf_kept, t_bed), flush=True)
     print("end to end %.0f DNMs/s from files to BED text (%d records); inflate %s, %d host threads (cgroup quota %s CPUs)" % (
-        M / (t_phase + t_bed), len(recs), ("the device, " if os.environ.get("UZ_INFLATE", "device") == "device" and sum(s[1].get("blocks_from_the_device", 0) for s in stats["bam"]) else "")
+        M / (t_phase + t_bed), len(recs), ("the device (records walked there too), " if sum(s[1].get("walked_on_the_device", 0) for s in stats["bam"]) else "the device, " if os.environ.get("UZ_INFLATE", "device") == "device" and sum(s[1].get("blocks_from_the_device", 0) for s in stats["bam"]) else "")
         + io_native.inflate_backend(), io_native.default_threads(), io_native.cpu_quota() or "no"), flush=True)
     # calls against the simulated truth
     truth = {"%s_%d_%d_kid_POINT" % (sc.contig_names[int(c)], int(s), int(e)): ("dad" if o == 0 else "mom") for c, s, e, o in zip(dn.contig[:M], dn.start[:M], dn.end[:M], dn.origin[:M])}

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from unfazed_amd import abi, io_native
-from test_io_stage import fetches_of, workload  # noqa: F401
+from test_io_stage import fetches_of
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +23,7 @@ def walk_both(engine, bam, fc, flo, fhi, fex, all_bases=False):
 
 
 @pytest.mark.parametrize("stride,spread", [(1, 5), (3, 9), (7, 0)])
-def test_descriptors_equal_the_hosts_walk(engine, workload, stride, spread):  # noqa: F811
+def test_descriptors_equal_the_hosts_walk(engine, workload, stride, spread):
     fc, flo, fhi, fex = fetches_of(workload, stride, spread)
     src, twin, dev = walk_both(engine, workload["bam"], fc, flo, fhi, fex)
     try:
@@ -51,29 +51,35 @@ def test_descriptors_equal_the_hosts_walk(engine, workload, stride, spread):  # 
         assert np.array_equal(dev.kept["src"][same_place], twin.kept["src"][same_place])
     finally:
         engine.bam_walk_release(dev.token)
+        dev.token = None
 
 
 @pytest.mark.parametrize("all_bases", [False, True])
-def test_table_from_hbm_equals_the_staged_table(engine, workload, all_bases):  # noqa: F811
+def test_table_from_hbm_equals_the_staged_table(engine, workload, all_bases):
     fc, flo, fhi, fex = fetches_of(workload, 1, 5)
     src = io_native.BamSource(workload["bam"], threads=3)
     staged = src.select(fc, flo, fhi, 20, extra=fex, all_bases=all_bases)
     rid_a = engine.upload_reads_packed(staged)
     engine.wait_reads(rid_a)
     dev = src.select_kept(fc, flo, fhi, 20, all_bases=all_bases, walk=engine.bam_walk)
-    rid_b = engine.reads_from_bam(dev)
+    rid_b = engine.reads_from_bam(dev, names=True)
     try:
         n = int(staged.view.n_segs)
         assert dev.n == n
         a, b = engine.reads_headers(rid_a, n), engine.reads_headers(rid_b, n)
         for k in ("start", "end", "tlen", "mate", "qname"):
             assert np.array_equal(a[k], b[k]), k
+        # the read names, fetched from HBM: id by id those of the host route
+        ids = np.arange(len(staged.qnames), dtype=np.uint32)
+        assert len(dev.qnames) == ids.size
+        assert dev.qnames.take(ids) == staged.qnames.take(ids)
+        assert dev.qnames[3] == staged.qnames[3]
     finally:
         engine.free_reads(rid_a)
         engine.free_reads(rid_b)
 
 
-def test_mates_through_the_index_and_flagged_tasks(engine, workload, monkeypatch):  # noqa: F811
+def test_mates_through_the_index_and_flagged_tasks(engine, workload, monkeypatch):
     """a small slack: mates outside every reach interval are looked up through the index by the HOST -- their bytes travel as aux bytes"""
     fc, flo, fhi, fex = fetches_of(workload, 2, 3)
     monkeypatch.setenv("UZ_STAGE_SLACK", "40")

@@ -31,20 +31,6 @@ def assert_same(a, b):
         assert np.array_equal(a.arrays[k][:m], b.arrays[k][:m]), k
 
 
-@pytest.fixture(scope="module")
-def workload(tmp_path_factory):
-    d = tmp_path_factory.mktemp("stage")
-    lens = [3_000_000, 2_000_000, 1_000_000]
-    sc = make_sites(12000, seed=177, contig_lens=lens)
-    dn = place_dnms_full(sc, 60, seed=178)
-    cl = make_clusters(dn)
-    cfg = bigsynth.make_cfg(seed=179)
-    cfg.n_clusters = cl.n
-    bam = str(d / "kid.bam")
-    bigsynth.write_bam(bam, cfg, sc, dn, cl, contig_len=lens, level=1, threads=3)
-    return dict(sc=sc, dn=dn, cl=cl, bam=bam)
-
-
 def fetches_of(w, stride=1, spread=5):
     """fetch points as staging.fetch_points lists them: the DNM ([start - 1, start + 1), extra = allele length) and a few
     one-base fetches at 'het sites' of its window"""

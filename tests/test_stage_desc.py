@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from unfazed_amd import io_native
-from test_io_stage import fetches_of, workload  # noqa: F401  (the module's synthetic BAM)
+from test_io_stage import fetches_of
 
 
 def both(bam, fc, flo, fhi, fex, all_bases=False, threads=3):
@@ -44,7 +44,7 @@ def check(ref, want, got):
 
 
 @pytest.mark.parametrize("stride,spread", [(1, 5), (3, 9), (7, 0)])
-def test_kept_list_equals_the_one_pass_stage(workload, stride, spread):  # noqa: F811
+def test_kept_list_equals_the_one_pass_stage(workload, stride, spread):
     fc, flo, fhi, fex = fetches_of(workload, stride, spread)
     ref, want, got, _ = both(workload["bam"], fc, flo, fhi, fex)
     in_aux = check(ref, want, got)
@@ -52,7 +52,7 @@ def test_kept_list_equals_the_one_pass_stage(workload, stride, spread):  # noqa:
     assert got.io_stats["records_walked"] == ref.io_stats["records_walked"]
 
 
-def test_all_bases(workload):  # noqa: F811
+def test_all_bases(workload):
     fc, flo, fhi, fex = fetches_of(workload, 2, 3)
     ref, want, got, _ = both(workload["bam"], fc, flo, fhi, fex, all_bases=True)
     check(ref, want, got)
@@ -60,7 +60,7 @@ def test_all_bases(workload):  # noqa: F811
 
 
 @pytest.mark.parametrize("slack", ["0", "40", "300"])
-def test_mates_through_the_index_travel_as_aux_bytes(workload, slack, monkeypatch):  # noqa: F811
+def test_mates_through_the_index_travel_as_aux_bytes(workload, slack, monkeypatch):
     fc, flo, fhi, fex = fetches_of(workload, 2, 3)
     monkeypatch.setenv("UZ_STAGE_SLACK", slack)
     ref, want, got, _ = both(workload["bam"], fc, flo, fhi, fex)
@@ -75,7 +75,7 @@ def test_mates_through_the_index_travel_as_aux_bytes(workload, slack, monkeypatc
         assert 32 <= bs and o + bs <= got.n_aux
 
 
-def test_a_task_the_device_flags_is_walked_by_the_host(workload):  # noqa: F811
+def test_a_task_the_device_flags_is_walked_by_the_host(workload):
     """d_flags: every third task handed back as `incomplete` -- the host walks those itself, their records travel as aux bytes, the list is the same"""
     fc, flo, fhi, fex = fetches_of(workload, 1, 5)
     src = io_native.BamSource(workload["bam"], threads=3)
@@ -100,7 +100,7 @@ def test_a_task_the_device_flags_is_walked_by_the_host(workload):  # noqa: F811
     assert in_aux.any() and got.host_tasks > 0
 
 
-def test_empty_batch(workload):  # noqa: F811
+def test_empty_batch(workload):
     z = np.zeros(0, np.int32)
     got = io_native.BamSource(workload["bam"], threads=2).select_kept(z, z, z, 20)
     assert got.n == 0 and got.n_qnames == 0

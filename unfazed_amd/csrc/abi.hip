@@ -1689,10 +1689,10 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
         int k = -1;
         {
             std::lock_guard<std::mutex> lk(c->err_mu);
-            for (int i = 0; i < 3 && k < 0; i++)
+            for (int i = 0; i < uz_ctx::WALK_SLOTS && k < 0; i++)
                 if (!c->walk[i].busy) { k = i; c->walk[i].busy = true; }
         }
-        UZ_REQUIRE(k >= 0, UZ_E_STATE, "three walked batches are waiting for uz_reads_from_bam / uz_bam_walk_release");
+        UZ_REQUIRE(k >= 0, UZ_E_STATE, "four walked batches are waiting for uz_reads_from_bam / uz_bam_walk_release");
         uz_ctx::WalkSlot &w = c->walk[k];
         try {
             if (!c->inf_stream) {
@@ -1708,17 +1708,33 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
             w.reach.ensure((size_t)n_reach * 2 + 1); w.fetch.ensure((size_t)n_fetch * 3 + 1);
             w.count.ensure((size_t)n_tasks + 1); w.first.ensure((size_t)n_tasks + 2); w.walked.ensure((size_t)n_tasks + 1); w.flags.ensure((size_t)n_tasks + 1);
             w.n_direct.ensure((size_t)n_tasks + 1); w.tab_first.ensure((size_t)n_tasks + 2); w.kcount.ensure((size_t)n_tasks + 1); w.kfirst.ensure((size_t)n_tasks + 2);
-            w.iflags.ensure(4);
+            // the blocks in slices of ~8 k on two streams, as uz_bgzf_inflate_to_host sends them: slice i + 1 goes up while slice i is inflated
+            std::vector<int64_t> cut{0};
+            for (int64_t b = 1; b <= n_blocks; b++)
+                if (b == n_blocks || (b - cut.back() >= 8192 && n_blocks - b >= 4096)) cut.push_back(b);
+            const size_t ns = cut.size() - 1;
+            w.iflags.ensure(2 * ns + 4);
+            std::vector<int32_t> iflags(2 * ns + 2, 0);
             if (n_blocks) {
+                hipStream_t s2[2] = {c->inf_stream, c->inf_stream2};
                 UZ_HIP(hipMemsetAsync(w.comp.p + comp_bytes, 0, 1024, st));
                 UZ_HIP(hipMemsetAsync(w.out.p + out_bytes, 0, uz_bam_walk_pad(), st));
-                UZ_HIP(hipMemcpyAsync(w.comp.p, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.in_off.p, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.out_off.p, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.blk_coff.p, blk_coff, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
-                uz_launch_inflate(c, st, n_blocks, w.comp.p, (comp_bytes + 1024) & ~(int64_t)3, w.in_off.p, w.out_off.p, w.out.p, w.iflags.p);
+                UZ_HIP(hipEventRecord(c->inf_ready, st));
+                UZ_HIP(hipStreamWaitEvent(s2[1], c->inf_ready, 0));
+                for (size_t i = 0; i < ns; i++) {
+                    const int64_t b0 = cut[i], b1 = cut[i + 1];
+                    const int64_t c0 = i == 0 ? 0 : std::max<int64_t>(in_off[b0] - 18, 0), c1 = i + 1 == ns ? comp_bytes : std::max<int64_t>(in_off[b1] - 18, c0);
+                    UZ_HIP(hipMemcpyAsync(w.comp.p + c0, comp + c0, (size_t)(c1 - c0), hipMemcpyHostToDevice, s2[i & 1]));
+                    uz_launch_inflate(c, s2[i & 1], b1 - b0, w.comp.p, (comp_bytes + 1024) & ~(int64_t)3, w.in_off.p + b0, w.out_off.p + b0, w.out.p, w.iflags.p + 2 * i);
+                }
+                if (ns > 1) { // the walk (first stream) reads what both streams inflated
+                    UZ_HIP(hipEventRecord(c->inf_ready, s2[1]));
+                    UZ_HIP(hipStreamWaitEvent(st, c->inf_ready, 0));
+                }
             }
-            int32_t iflags[2] = {0, 0};
             int64_t tab_total = 0, kept = 0;
             if (n_tasks) {
                 // one pass: every task writes its descriptors into a slice sized for the most records its bytes can hold (a record is at least 36 bytes)
@@ -1746,11 +1762,12 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.count.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
                 UZ_HIP(hipMemcpyAsync(&kept, w.kfirst.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
             }
-            if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags, w.iflags.p, 8, hipMemcpyDeviceToHost, st));
+            if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags.data(), w.iflags.p, 2 * ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             UZ_HIP(hipStreamSynchronize(st));
-            if (iflags[1])
-                throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(iflags[1] >> 4) + " of the batch: not a valid DEFLATE stream of the declared size (code " +
-                                              std::to_string(iflags[1] & 15) + ")"};
+            for (size_t i = 0; i < ns; i++)
+                if (iflags[2 * i + 1])
+                    throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(cut[i] + (iflags[2 * i + 1] >> 4)) + " of the batch: not a valid DEFLATE stream of the declared size (code " +
+                                                  std::to_string(iflags[2 * i + 1] & 15) + ")"};
             w.n_desc = kept;
             *n_desc = kept;
             *walk_id = k;
@@ -1760,7 +1777,7 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
 
 int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_first, int32_t *d_flags, int64_t *d_walked) {
     return guarded(c, [&] {
-        UZ_REQUIRE(walk_id >= 0 && walk_id < 3 && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
         uz_ctx::WalkSlot &w = c->walk[walk_id];
         UZ_REQUIRE(d_first && (w.n_desc == 0 || desc), UZ_E_ARG, "null output");
         UZ_HIP(hipSetDevice(c->device));
@@ -1779,7 +1796,7 @@ int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_fir
 
 int uz_bam_walk_release(uz_ctx *c, int walk_id) {
     return guarded(c, [&] {
-        UZ_REQUIRE(walk_id >= 0 && walk_id < 3, UZ_E_ARG, "bad walk id");
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS, UZ_E_ARG, "bad walk id");
         std::lock_guard<std::mutex> lk(c->err_mu);
         c->walk[walk_id].busy = false;
     });
@@ -1787,9 +1804,10 @@ int uz_bam_walk_release(uz_ctx *c, int walk_id) {
 
 int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n, const uint8_t *aux, int64_t aux_bytes, const int64_t *contig_off,
                       const int32_t *max_span, int32_t n_contigs, int64_t n_cigar_total, int64_t n_row_units, int64_t n_seq_units, uint32_t n_qnames,
-                      int32_t min_base_qual, int *reads_id) {
+                      int32_t min_base_qual, uint8_t *names_out, int64_t names_bytes, int *reads_id) {
     return guarded(c, [&] {
-        UZ_REQUIRE(walk_id >= 0 && walk_id < 3 && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        UZ_REQUIRE(names_bytes >= 0 && (names_out == nullptr || names_bytes < ((int64_t)1 << 32)), UZ_E_ARG, "bad name store size");
         UZ_REQUIRE(reads_id && n >= 0 && n < (int64_t)0x7FFFFFF0 && (n == 0 || kept) && aux_bytes >= 0 && (aux_bytes == 0 || aux) && contig_off && max_span && n_contigs >= 0 &&
                        n_cigar_total >= 0 && n_cigar_total < ((int64_t)1 << 32) && n_row_units >= 0 && n_row_units < ((int64_t)1 << 32) && n_seq_units >= 0 && n_seq_units <= n_row_units,
                    UZ_E_ARG, "bad arguments");
@@ -1798,7 +1816,7 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
         // (uz_reads_adopt_device: cigar, seq4 and the quality plane ARE the device's stores) and keeps the block as its `mirror`
         DevBlock blk;
         uz_kept_rec *d_kept = nullptr;
-        uint8_t *d_aux = nullptr, *mapq = nullptr, *aux_col = nullptr, *seq4 = nullptr;
+        uint8_t *d_aux = nullptr, *mapq = nullptr, *aux_col = nullptr, *seq4 = nullptr, *d_names = nullptr;
         int64_t *d_coff = nullptr;
         int32_t *d_span = nullptr, *start = nullptr, *tlen = nullptr, *mate = nullptr, *err = nullptr;
         uint32_t *qname = nullptr, *cigar = nullptr, *plane = nullptr;
@@ -1812,6 +1830,7 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
             mapq = cv.take<uint8_t>((size_t)n); aux_col = cv.take<uint8_t>((size_t)n);
             cigar = cv.take<uint32_t>((size_t)n_cigar_total); seq4 = cv.take<uint8_t>((size_t)n_seq_units * UZ_SEQ4_UNIT_BYTES);
             plane = cv.take<uint32_t>((size_t)n_row_units);
+            if (names_out) d_names = cv.take<uint8_t>((size_t)names_bytes);
             if (!pass) blk = uz_block_get(c, cv.off + 256);
         }
         int id = -1;
@@ -1823,7 +1842,8 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
             if (n_contigs) UZ_HIP(hipMemcpyAsync(d_span, max_span, (size_t)n_contigs * 4, hipMemcpyHostToDevice, st));
             UZ_HIP(hipMemsetAsync(err, 0, 16, st));
             uz_launch_bam_extract(c, st, n, w.out.p, w.out_bytes, d_aux, aux_bytes, d_kept, min_base_qual, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col,
-                                  cigar, seq4, plane, err);
+                                  cigar, seq4, plane, err, names_out ? d_names : nullptr);
+            if (names_out && names_bytes) UZ_HIP(hipMemcpyAsync(names_out, d_names, (size_t)names_bytes, hipMemcpyDeviceToHost, st));
             int32_t e = 0;
             UZ_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
             UZ_HIP(hipStreamSynchronize(st));

@@ -457,8 +457,8 @@ inline bool list_bits(const Fx &f, int32_t pos, int32_t end, uint32_t ncig, uint
 } // namespace
 
 struct SliceBase { // running totals of the variable-length columns in front of a slice of the output order
-    int64_t cig = 0, omitted = 0, units = 0, seq = 0, exc = 0, qpos = 0, esc = 0, bl = 0, blu = 0;
-    void add(const SliceBase &o) { cig += o.cig; omitted += o.omitted; units += o.units; seq += o.seq; exc += o.exc; qpos += o.qpos; esc += o.esc; bl += o.bl; blu += o.blu; }
+    int64_t cig = 0, omitted = 0, units = 0, seq = 0, exc = 0, qpos = 0, esc = 0, bl = 0, blu = 0, names = 0;
+    void add(const SliceBase &o) { names += o.names; cig += o.cig; omitted += o.omitted; units += o.units; seq += o.seq; exc += o.exc; qpos += o.qpos; esc += o.esc; bl += o.bl; blu += o.blu; }
 };
 
 struct uz_stage {
@@ -1259,6 +1259,7 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
                 b.cig += x.n_cigar;
                 b.units += UZ_ROW_UNITS(x.l_seq);
                 if (x.keep == 2 || o.all_bases) b.seq += UZ_ROW_UNITS(x.l_seq);
+                b.names += x.l_name;
                 cnt[(size_t)sl][(size_t)tid_k]++;
                 span[(size_t)sl][(size_t)tid_k] = std::max(span[(size_t)sl][(size_t)tid_k], x.end - x.pos);
                 continue;
@@ -1628,12 +1629,12 @@ int uz_bam_stage_finish_desc(uz_stage *P, const uz_walk_desc *d, const int64_t *
     return guarded([&] { plan_finish(*P, d ? d : (const uz_walk_desc *)"", d_first, d_flags, d_walked); });
 }
 
-/* totals: [0] records, [1] CIGAR words, [2] row units, [3] base-row units, [4] query names, [5] aux bytes, [6] tasks the host walked itself */
+/* totals: [0] records, [1] CIGAR words, [2] row units, [3] base-row units, [4] query names, [5] aux bytes, [6] tasks the host walked itself, [7] name bytes */
 void uz_stage_kept_sizes(const uz_stage *P, int64_t out[8]) {
     memset(out, 0, 8 * sizeof(int64_t));
     if (!P || !P->desc || P->base.empty()) return;
     const SliceBase &t = P->base.back();
-    out[0] = P->n; out[1] = t.cig; out[2] = t.units; out[3] = t.seq; out[4] = P->n_qnames;
+    out[0] = P->n; out[1] = t.cig; out[2] = t.units; out[3] = t.seq; out[4] = P->n_qnames; out[7] = t.names;
     for (const Task &T : P->tasks) { out[5] += (int64_t)T.raw.size(); out[6] += !T.raw.empty(); }
 }
 
@@ -1665,8 +1666,8 @@ int uz_stage_kept(const uz_stage *P, int threads, uz_kept_rec *out, int64_t *con
                     o.mate = m < 0 ? -1 : (int32_t)rec_of(*P, m).gidx;
                     const uint32_t units = UZ_ROW_UNITS(x.l_seq);
                     const bool bases = x.keep == 2 || all_bases;
-                    o.cig_off = (uint32_t)at.cig; o.unit_off = (uint32_t)at.units; o.seq_off = bases ? (uint32_t)at.seq : UZ_KEPT_NO_SEQ; o.pad = 0;
-                    at.cig += x.n_cigar; at.units += units; if (bases) at.seq += units;
+                    o.cig_off = (uint32_t)at.cig; o.unit_off = (uint32_t)at.units; o.seq_off = bases ? (uint32_t)at.seq : UZ_KEPT_NO_SEQ; o.name_off = (uint32_t)at.names;
+                    at.cig += x.n_cigar; at.units += units; if (bases) at.seq += units; at.names += x.l_name;
                 }
             }
         });
@@ -1729,6 +1730,18 @@ int uz_stage_kept_debug(const uz_stage *P, uint64_t *voff, uint32_t *qname, int3
             if (bases) bases[k] = (x.keep == 2 || P->opt.all_bases) ? 1 : 0;
         }
     });
+}
+
+/* descriptor route: the record (index in the kept list) that brought name id `ids[k]` first -- its name bytes are the id's (uz_reads_from_bam hands the
+ * names of the kept records back in record order); ids == NULL: every id, 0 .. n - 1 */
+int uz_stage_name_records(const uz_stage *P, const uint32_t *ids, int64_t n, int64_t *rec) {
+    if (!P || !P->finished || !rec || n < 0) { last_error = "uz_stage_name_records: a finished plan"; return UZ_IO_E_ARG; }
+    for (int64_t k = 0; k < n; k++) {
+        const uint64_t id = ids ? ids[k] : (uint64_t)k;
+        if (id >= P->name_of_id.size()) { last_error = "uz_stage_name_records: name id out of range"; return UZ_IO_E_ARG; }
+        rec[k] = (int64_t)rec_of(*P, P->name_of_id[id]).gidx;
+    }
+    return 0;
 }
 
 void uz_stage_free(uz_stage *P) { delete P; }

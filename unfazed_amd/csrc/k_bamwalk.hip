@@ -334,6 +334,7 @@ struct ExtractArgs {
     uint8_t *seq4;
     uint32_t *plane;
     int32_t *err;
+    uint8_t *names; // null: the names are not asked for
 };
 
 // Eight lanes per record, 32 records per workgroup.  The record's bytes are staged in LDS first -- the eight lanes fetch consecutive 16-byte
@@ -392,6 +393,8 @@ __global__ __launch_bounds__(256) void k_bam_extract(ExtractArgs a) {
         a.mapq[i] = p[9]; a.aux_col[i] = (uint8_t)ax;
     }
     for (uint32_t w = (uint32_t)l; w < ncig; w += 8) a.cigar[(size_t)k.cig_off + w] = ld32(q + 4 * w);
+    if (a.names)
+        for (uint32_t b = (uint32_t)l; b + 1 < l_name; b += 8) a.names[(size_t)k.name_off + b] = p[32 + b];
     const uint32_t units = UZ_ROW_UNITS(L);
     if (bases) { // BAM's own nibbles; the pad nibble of an odd length and the rest of the last unit are zero
         const uint32_t nb = (L + 1) / 2;
@@ -456,9 +459,9 @@ size_t uz_bam_walk_pad() { return (size_t)WIN + 64; }
 
 void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
                            int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
-                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err) {
+                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names) {
     if (n <= 0) return;
-    ExtractArgs a{buf, aux, kept, n, buf_bytes, aux_bytes, thr, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col, cigar, seq4, plane, err};
+    ExtractArgs a{buf, aux, kept, n, buf_bytes, aux_bytes, thr, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col, cigar, seq4, plane, err, names};
     hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, a);
     UZ_HIP(hipGetLastError());
 }

@@ -269,7 +269,7 @@ struct uz_ctx {
     hipEvent_t inf_ready = nullptr;
 
     // the record walk on the device (k_bamwalk.hip, uz_bam_walk): a batch's inflated blocks stay in HBM from the walk until the batch's table has
-    // been packed from them (uz_reads_from_bam); three batches can be in flight (the staged pipeline decodes two chunks ahead)
+    // been packed from them (uz_reads_from_bam); four batches can be in flight (a feed pipeline walks up to three chunks ahead of the read stage)
     struct WalkSlot {
         bool busy = false;
         DevBuf<uint8_t> comp, out;
@@ -281,7 +281,8 @@ struct uz_ctx {
         int64_t n_blocks = 0, out_bytes = 0, n_desc = 0, n_desc_all = 0;
         int32_t n_tasks = 0;
     };
-    WalkSlot walk[3];
+    static constexpr int WALK_SLOTS = 4;
+    WalkSlot walk[WALK_SLOTS];
 
     // last phase (k_reads.hip)
     bool phase_valid = false;
@@ -396,7 +397,7 @@ void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, co
 size_t uz_bam_walk_pad(); // bytes the inflated buffer must be padded by (the walk's LDS windows read past the last record)
 void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
                            int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
-                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err);
+                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names);
 int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);
 int uz_phase_groups_impl(uz_ctx *c, int64_t *grp_off, int32_t *grp_q);
 void uz_phase_state_free(uz_ctx *c);

@@ -61,7 +61,7 @@ def load_library(path: Optional[str] = None):
     L.uz_bam_walk.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
     L.uz_bam_walk_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.uz_bam_walk_release.argtypes = [vp, C.c_int]
-    L.uz_reads_from_bam.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, vp]
+    L.uz_reads_from_bam.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, vp, C.c_int64, vp]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -289,6 +289,14 @@ class HipEngine:
             self._chunk_pairs[slot] = PinnedPair()
         pool, pair = self._chunk_pools[slot], self._chunk_pairs[slot]
         inflate = inflate_alloc = None
+        if os.environ.get("UZ_INFLATE", "device") == "device" and os.environ.get("UZ_WALK", "device") == "device":
+            # the record walk on the device too (include/uz_bamwalk.h): the batch's blocks are inflated AND walked in HBM, the host runs the joins on
+            # 64-byte descriptors, and upload_reads_packed builds the table from the bytes the walk left on the device (UZ_WALK=host: the link form)
+            from . import io_native
+            pair.start()
+            kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=lambda plan: self.bam_walk(plan, alloc=pair.alloc), all_bases=bool(all_bases),
+                                 alloc=pair.alloc, extra=fex, release=self.bam_walk_release)
+            return kb
         if os.environ.get("UZ_INFLATE", "device") == "device":
             pair.start()
             inflate, inflate_alloc = self.inflate_blocks, pair.alloc
@@ -300,6 +308,8 @@ class HipEngine:
     def upload_reads_packed(self, packed: abi.Held) -> int:
         """Staged form, asynchronous: the arrays of `packed` must stay alive and untouched until wait_reads() or
         a phase on the table has returned (they are kept referenced here until the table is freed)."""
+        if getattr(packed, "token", None) is not None and hasattr(packed, "kept"):  # a batch walked on the device (stage_reads): its table is built from HBM
+            return self.reads_from_bam(packed, names=True)
         rid = C.c_int(-1)
         self._ck(self.L.uz_reads_upload_packed(self.h, packed.ref(), C.byref(rid)), "uz_reads_upload_packed")
         self._staged[rid.value] = packed
@@ -380,13 +390,18 @@ class HipEngine:
     def bam_walk_release(self, walk_id: int):
         self._ck(self.L.uz_bam_walk_release(self.h, int(walk_id)), "uz_bam_walk_release")
 
-    def reads_from_bam(self, kb) -> int:
-        """The table of a batch walked on the device (kb: io_native.KeptBatch of select_kept(walk=self.bam_walk)): unpacked from the bytes in HBM."""
+    def reads_from_bam(self, kb, names: bool = False) -> int:
+        """The table of a batch walked on the device (kb: io_native.KeptBatch of select_kept(walk=self.bam_walk)): unpacked from the bytes in HBM.
+        names: the read names of the kept records come back too (kb.qnames then maps the name ids of the result lists to strings)."""
         rid = C.c_int(-1)
+        nb = int(kb.n_name_bytes) if names else 0
+        buf = np.empty(max(1, nb), np.uint8) if names else None
         self._ck(self.L.uz_reads_from_bam(self.h, int(kb.token), kb.kept.ctypes.data, int(kb.n), kb.aux.ctypes.data, int(kb.n_aux), kb.contig_off.ctypes.data,
                                           kb.max_span.ctypes.data, int(kb.n_contigs), int(kb.n_cigar_total), int(kb.n_row_units), int(kb.n_seq_units),
-                                          int(kb.n_qnames), int(kb.min_base_qual), C.byref(rid)), "uz_reads_from_bam")
+                                          int(kb.n_qnames), int(kb.min_base_qual), buf.ctypes.data if names else None, nb, C.byref(rid)), "uz_reads_from_bam")
         kb.token = None
+        if names:
+            kb.set_names(buf[:nb])
         return rid.value
 
     def adopt_sites(self, view: abi.SitesView) -> int:

@@ -486,7 +486,7 @@ class PhasingHost:
                 packed = futs.pop(k).result()
                 if k + 1 < len(parts):
                     futs[k + 1] = ex.submit(stage, k + 1)  # decoded beside the device work of this chunk
-                names[k] = packed.qnames
+                names[k] = packed  # (its `.qnames`: at once for the link form, once the table is built for a batch walked on the device)
                 return packed
 
             def done(k, rr):
@@ -497,7 +497,7 @@ class PhasingHost:
                     lists = [tuple(vv[vo[4 * j + q]: vo[4 * j + q + 1]] for q in range(4)) for j in range(len(part))]
                 res = dict(status=rr["status"], counts=rr["counts"], origin=rr["origin"], evidence=rr["evidence"], lists=lists)
                 table = type("StagedNames", (), {})()
-                table.qnames = names.pop(k)
+                table.qnames = names.pop(k).qnames
                 for j, i in enumerate(part):
                     results[i] = (res, j, table)
 

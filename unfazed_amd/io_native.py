@@ -33,7 +33,7 @@ IO_EXPORTS = [
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
-    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug",
+    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records",
 ]
 
 
@@ -184,6 +184,7 @@ def load():
     lib.uz_stage_kept.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.uz_stage_walk_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.uz_stage_kept_debug.argtypes = [C.c_void_p] * 5
+    lib.uz_stage_name_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -633,7 +634,7 @@ class _StageNames(Sequence):
 WALK_DESC = np.dtype([("voff", "<u8"), ("src", "<u8"), ("h1", "<u8"), ("pos", "<i4"), ("end", "<i4"), ("tlen", "<i4"), ("mpos", "<i4"), ("mtid", "<i4"),
                       ("h2", "<u4"), ("task", "<u4"), ("flag", "<u2"), ("l_seq", "<u2"), ("n_cigar", "<u2"), ("mapq", "u1"), ("l_name", "u1"), ("direct", "u1"),
                       ("pad8", "u1"), ("pad16", "<u2")])
-KEPT_REC = np.dtype([("src", "<u8"), ("qname", "<u4"), ("mate", "<i4"), ("cig_off", "<u4"), ("unit_off", "<u4"), ("seq_off", "<u4"), ("pad", "<u4")])
+KEPT_REC = np.dtype([("src", "<u8"), ("qname", "<u4"), ("mate", "<i4"), ("cig_off", "<u4"), ("unit_off", "<u4"), ("seq_off", "<u4"), ("name_off", "<u4")])
 assert WALK_DESC.itemsize == 64 and KEPT_REC.itemsize == 32
 WALK_TASK_COLS, WALK_SPAN_COLS = 10, 6
 KEPT_NO_SEQ = 0xFFFFFFFF
@@ -647,10 +648,50 @@ def stage_kept_debug(lib, stage_ptr, n: int):
     return voff[:n], qn[:n], mt[:n], bs[:n]
 
 
+class _KeptNames(Sequence):
+    """name id -> query name of a batch walked on the device: the kept records' names came back from HBM in record order (uz_reads_from_bam), and
+    the id's name is the name of the record that brought it first (uz_stage_name_records)"""
+
+    def __init__(self, buf: np.ndarray, name_off: np.ndarray, rec_of_id: np.ndarray):
+        self._buf, self._off, self._rec = buf, name_off, rec_of_id
+
+    def __len__(self):
+        return int(self._rec.size)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        r = int(self._rec[int(i)])
+        return self._buf[int(self._off[r]): int(self._off[r + 1])].tobytes().decode()
+
+    def take(self, ids) -> list:
+        r = self._rec[np.ascontiguousarray(ids, np.int64)]
+        a, b = self._off[r].tolist(), self._off[r + 1].tolist()
+        raw = self._buf.tobytes()
+        return [raw[x:y].decode() for x, y in zip(a, b)]
+
+
 class KeptBatch:
     """What BamSource.select_kept returns: the records fetch() + mate() hand the reference for a batch, as the list the device packs its record
-    table from (uz_kept_rec), with the table's sizes.  `.blocks`: the gathered BGZF blocks (comp, in_off, out_off) the device inflated."""
-    pass
+    table from (uz_kept_rec), with the table's sizes.  `.plan`: the gathered BGZF blocks and the walk plan the device worked from."""
+    qnames = None
+    token = None
+    _release = None
+
+    def __del__(self):  # (dropped before its table was built -- a failed join, an abandoned pipeline: the inflated bytes on the device are given up)
+        if self.token is not None and self._release is not None:
+            try:
+                self._release(self.token)
+            except Exception:
+                pass
+            self.token = None
+
+    def set_names(self, buf: np.ndarray):
+        lib = load()
+        rec = np.zeros(max(1, self.n_qnames), np.int64)
+        _check(lib, lib.uz_stage_name_records(self._stage.ptr, None, int(self.n_qnames), rec.ctypes.data))
+        off = np.concatenate([self.kept["name_off"].astype(np.int64), [int(self.n_name_bytes)]])
+        self.qnames = _KeptNames(buf, off, rec[: self.n_qnames])
 
 
 class BamSource:
@@ -748,11 +789,13 @@ class BamSource:
         out._stage = sh
         return out
 
-    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None) -> "KeptBatch":
+    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None) -> "KeptBatch":
         """The same batch through the device's walk (include/uz_bamwalk.h): the blocks are gathered, `walk(plan)` inflates them in HBM and walks
         them there (HipEngine.bam_walk -> descriptors, d_first, d_flags, d_walked; None: the host's twin uz_stage_walk_host -- tests), the
         batch-wide joins run here on the descriptors, and the answer is the list of kept records for uz_reads_from_bam.
-        plan: dict(comp, comp_bytes, in_off, out_off, out_bytes, task, span, reach, fetch, blk_coff)."""
+        plan: dict(comp, comp_bytes, in_off, out_off, out_bytes, task, span, reach, fetch, blk_coff).
+        release(token): gives the walked batch on the device up (HipEngine.bam_walk_release) -- called when the joins fail here, or when the returned
+        batch is dropped without its table having been built."""
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -793,6 +836,8 @@ class BamSource:
         else:
             desc, d_first, d_flags, d_walked, token = walk(plan)
         t2 = time.perf_counter()
+        out = KeptBatch()
+        out.token, out._release = token, release
         d_first = np.ascontiguousarray(d_first, np.int64)
         d_flags = np.ascontiguousarray(d_flags, np.int32)
         d_walked = np.ascontiguousarray(d_walked, np.int64)
@@ -800,8 +845,7 @@ class BamSource:
         _check(self.lib, self.lib.uz_bam_stage_finish_desc(sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data))
         t3 = time.perf_counter()
         self.lib.uz_stage_kept_sizes(sh.ptr, z)
-        out = KeptBatch()
-        out.n, out.n_cigar_total, out.n_row_units, out.n_seq_units, out.n_qnames, n_aux, out.host_tasks = (int(x) for x in z[:7])
+        out.n, out.n_cigar_total, out.n_row_units, out.n_seq_units, out.n_qnames, n_aux, out.host_tasks, out.n_name_bytes = (int(x) for x in z[:8])
         out.kept = (alloc(max(1, out.n) * KEPT_REC.itemsize).view(KEPT_REC) if alloc else np.zeros(max(1, out.n), KEPT_REC))[: out.n]
         out.contig_off = np.zeros(len(self.contigs) + 1, np.int64)
         out.max_span = np.zeros(max(1, len(self.contigs)), np.int32)
@@ -817,7 +861,7 @@ class BamSource:
         tm = (C.c_double * 6)()
         self.lib.uz_stage_timing(sh.ptr, tm)
         out.timing = dict(plan=t1 - t0, walk=t2 - t1, joins=t3 - t2, kept=t4 - t3, mates=float(tm[2]), numbering=float(tm[3]))
-        out.plan, out.desc, out.d_first, out.d_flags, out.token = plan, desc, d_first, d_flags, token
+        out.plan, out.desc, out.d_first, out.d_flags = plan, desc, d_first, d_flags
         out.min_base_qual, out.n_contigs, out.all_bases = int(min_base_qual), len(self.contigs), bool(all_bases)
         out._stage = sh
         return out
