@@ -650,7 +650,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 "note": "per chunk: the blocks the walk will read gathered into pinned memory (host), host -> device, kernel, device -> host, all "
                         "inside seconds_busy; the walk then copies records out of the inflated blocks and holds each block against its CRC-32"},
             "device_walk": None if not dev_walk else {
-                "kernels": "k_bam_walk (one wavefront per walk task, two passes) + k_bam_extract (csrc/k_bamwalk.hip)", "tasks": acc["w_tasks"],
+                "kernels": "k_bgzf_inflate + k_bgzf_crc32, k_bam_walk (one wavefront per walk task), k_tab_insert + k_desc_filter, k_bam_extract (csrc/k_inflate.hip, k_bamwalk.hip)", "tasks": acc["w_tasks"],
                 "tasks_walked_by_the_host": acc["w_host_tasks"], "descriptors": acc["w_desc"], "aux_bytes": acc["w_aux"],
                 "seconds_busy": {"plan+gather": round(acc["w_plan"], 3), "upload+inflate+walk+descriptors_down": round(acc["w_walk"], 3),
                                  "joins_on_the_host": round(acc["w_joins"], 3), "kept_list": round(acc["w_kept"], 3)},

@@ -117,8 +117,12 @@ int uz_bgzf_inflate_to_host(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes
  * of records only the host has seen) and built like an adopted table (uz_reads_adopt_device); releases the batch.  Owner's thread only.
  * uz_bam_walk_release: gives a walked batch up without building its table. */
 int uz_bam_walk(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off, const int64_t *blk_coff,
+                const uint32_t *blk_crc /* [n_blocks] the CRC-32 of every block's footer: held against the inflated bytes (k_bgzf_crc32); NULL: not checked */,
                 int32_t n_tasks, const int32_t *task, int64_t n_spans, const int64_t *span, int64_t n_reach, const int32_t *reach, int64_t n_fetch,
                 const int32_t *fetch, int *walk_id, int64_t *n_desc);
+/* k_bgzf_crc32 alone (the parity tests hold it against zlib): blocks data[off[k] .. off[k + 1]) of at most 64 KiB (host memory), want[k] their CRC-32;
+ * *first_bad = -1, or a block whose checksum differs */
+int uz_crc32_blocks(uz_ctx *ctx, const uint8_t *data, int64_t n_blocks, const int64_t *off, const uint32_t *want, int64_t *first_bad);
 int uz_bam_walk_fetch(uz_ctx *ctx, int walk_id, uz_walk_desc *desc, int64_t *d_first, int32_t *d_flags, int64_t *d_walked);
 int uz_bam_walk_release(uz_ctx *ctx, int walk_id);
 int uz_reads_from_bam(uz_ctx *ctx, int walk_id, const uz_kept_rec *kept, int64_t n, const uint8_t *aux, int64_t aux_bytes, const int64_t *contig_off,

@@ -304,7 +304,8 @@ int64_t uz_stage_qnames(const uz_stage *s, const uint32_t *ids, int64_t n, char 
  * such a plan. */
 void uz_stage_walk_plan_sizes(const uz_stage *s, int64_t out[8]);
 int uz_stage_walk_plan(uz_stage *s, int32_t *task /* [UZ_WALK_TASK_COLS n_tasks] */, int64_t *span /* [UZ_WALK_SPAN_COLS n_spans] */,
-                       int32_t *reach /* [2 n_reach] */, int32_t *fetch /* [3 n_fetch] */, int64_t *blk_coff /* [n_blocks] */);
+                       int32_t *reach /* [2 n_reach] */, int32_t *fetch /* [3 n_fetch] */, int64_t *blk_coff /* [n_blocks] */,
+                       uint32_t *blk_crc /* [n_blocks] the CRC-32 in every gathered block's footer, or NULL */);
 int uz_bam_stage_finish_desc(uz_stage *s, const uz_walk_desc *d, const int64_t *d_first /* [n_tasks + 1] */, const int32_t *d_flags /* [n_tasks] or NULL */,
                              const int64_t *d_walked /* [n_tasks] or NULL */);
 /* the host's twin of the device's walk: the same descriptors from the host's own walk (out == NULL: the counts only) */

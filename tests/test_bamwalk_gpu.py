@@ -98,3 +98,22 @@ def test_mates_through_the_index_and_flagged_tasks(engine, workload, monkeypatch
     finally:
         engine.free_reads(rid_a)
         engine.free_reads(rid_b)
+
+
+def test_a_block_that_fails_its_crc_is_refused(engine, workload):
+    """the device holds every inflated block against the CRC-32 of its BGZF footer (k_bgzf_crc32), as htslib's reader does"""
+    from unfazed_amd.engine import UnfazedHipError
+    fc, flo, fhi, fex = fetches_of(workload, 3, 3)
+    src = io_native.BamSource(workload["bam"], threads=3)
+
+    def walk(plan):
+        plan["blk_crc"] = plan["blk_crc"].copy()
+        plan["blk_crc"][5] ^= np.uint32(0x80)
+        return engine.bam_walk(plan)
+
+    with pytest.raises(UnfazedHipError, match="CRC mismatch in BGZF block 5"):
+        src.select_kept(fc, flo, fhi, 20, walk=walk)
+    # ... and the batch after it goes through (the failed walk gave its slot back)
+    dev = src.select_kept(fc, flo, fhi, 20, walk=engine.bam_walk, release=engine.bam_walk_release)
+    assert dev.n > 0
+    del dev

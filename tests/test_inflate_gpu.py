@@ -212,3 +212,24 @@ def test_a_stream_that_never_ends_is_stopped(engine):
         engine.bgzf_inflate(good + a + b + good * 3)
     out, nb, _ = engine.bgzf_inflate(good * 4)  # and the context is fine afterwards
     assert nb == 4 and out.tobytes() == b"hello" * 400
+
+
+def test_crc32_kernel_against_zlib(engine):
+    """k_bgzf_crc32 (one wavefront per block, 64 slices joined with GF(2) shift matrices) == zlib.crc32 on blocks of every awkward size"""
+    import zlib
+    rng = np.random.default_rng(77)
+    sizes = [0, 1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 1000, 4095, 4096, 4097, 65279, 65280, 65535, 65536] + [int(x) for x in rng.integers(0, 65537, 200)]
+    blocks = [rng.integers(0, 256, n, dtype=np.uint8) for n in sizes]
+    blocks[7][:] = 0          # all zeros: the shift matrices alone
+    blocks[8][:] = 255
+    data = np.concatenate(blocks) if blocks else np.zeros(0, np.uint8)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    want = np.array([zlib.crc32(b.tobytes()) & 0xFFFFFFFF for b in blocks], np.uint32)
+    assert engine.crc32_blocks(data, off, want) == -1
+    for k in (0, 7, 19, len(sizes) - 1):  # one wrong value: that block is named
+        w2 = want.copy()
+        w2[k] ^= np.uint32(1 << (k % 32))
+        assert engine.crc32_blocks(data, off, w2) == k
+    d2 = data.copy()  # one flipped bit in the data
+    d2[off[19] + 65535] ^= 0x10
+    assert engine.crc32_blocks(d2, off, want) == 19

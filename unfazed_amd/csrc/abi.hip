@@ -1663,7 +1663,7 @@ int uz_prof_units(uz_ctx *c, int kernel, int64_t *units) {
 
 // ---- the record walk on the device (include/uz_bamwalk.h, csrc/k_bamwalk.hip)
 int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_blocks, const int64_t *in_off, const int64_t *out_off, const int64_t *blk_coff,
-                int32_t n_tasks, const int32_t *task, int64_t n_spans, const int64_t *span, int64_t n_reach, const int32_t *reach, int64_t n_fetch,
+                const uint32_t *blk_crc, int32_t n_tasks, const int32_t *task, int64_t n_spans, const int64_t *span, int64_t n_reach, const int32_t *reach, int64_t n_fetch,
                 const int32_t *fetch, int *walk_id, int64_t *n_desc) {
     return guarded(c, [&] {
         UZ_REQUIRE(walk_id && n_desc && n_blocks >= 0 && comp_bytes >= 0 && n_tasks >= 0 && n_spans >= 0 && n_reach >= 0 && n_fetch >= 0, UZ_E_ARG, "bad arguments");
@@ -1713,8 +1713,8 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
             for (int64_t b = 1; b <= n_blocks; b++)
                 if (b == n_blocks || (b - cut.back() >= 8192 && n_blocks - b >= 4096)) cut.push_back(b);
             const size_t ns = cut.size() - 1;
-            w.iflags.ensure(2 * ns + 4);
-            std::vector<int32_t> iflags(2 * ns + 2, 0);
+            w.iflags.ensure(2 * ns + 8); w.blk_crc.ensure((size_t)n_blocks + 1);
+            std::vector<int32_t> iflags(2 * ns + 4, 0);
             if (n_blocks) {
                 hipStream_t s2[2] = {c->inf_stream, c->inf_stream2};
                 UZ_HIP(hipMemsetAsync(w.comp.p + comp_bytes, 0, 1024, st));
@@ -1733,6 +1733,10 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 if (ns > 1) { // the walk (first stream) reads what both streams inflated
                     UZ_HIP(hipEventRecord(c->inf_ready, s2[1]));
                     UZ_HIP(hipStreamWaitEvent(st, c->inf_ready, 0));
+                }
+                if (blk_crc) { // every block against the CRC-32 of its footer, as htslib's reader (and the host's walk) holds it
+                    UZ_HIP(hipMemcpyAsync(w.blk_crc.p, blk_crc, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
+                    uz_launch_crc32(c, st, n_blocks, w.out.p, w.out_off.p, w.blk_crc.p, w.iflags.p + 2 * ns);
                 }
             }
             int64_t tab_total = 0, kept = 0;
@@ -1762,12 +1766,15 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.count.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
                 UZ_HIP(hipMemcpyAsync(&kept, w.kfirst.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
             }
-            if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags.data(), w.iflags.p, 2 * ns * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags.data(), w.iflags.p, (2 * ns + (blk_crc ? 1 : 0)) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
             UZ_HIP(hipStreamSynchronize(st));
             for (size_t i = 0; i < ns; i++)
                 if (iflags[2 * i + 1])
                     throw UzError{UZ_E_RANGE, "BGZF block " + std::to_string(cut[i] + (iflags[2 * i + 1] >> 4)) + " of the batch: not a valid DEFLATE stream of the declared size (code " +
                                                   std::to_string(iflags[2 * i + 1] & 15) + ")"};
+            if (blk_crc && n_blocks && iflags[2 * ns])
+                throw UzError{UZ_E_RANGE, "CRC mismatch in BGZF block " + std::to_string(iflags[2 * ns] - 1) + " of the batch (file offset " +
+                                              std::to_string((long long)blk_coff[iflags[2 * ns] - 1]) + ")"};
             w.n_desc = kept;
             *n_desc = kept;
             *walk_id = k;
@@ -1860,6 +1867,25 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
         } catch (...) { uz_block_put(c, blk); throw; }
         { std::lock_guard<std::mutex> lk(c->err_mu); w.busy = false; }
         *reads_id = id;
+    });
+}
+
+int uz_crc32_blocks(uz_ctx *c, const uint8_t *data, int64_t n_blocks, const int64_t *off, const uint32_t *want, int64_t *first_bad) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(n_blocks >= 0 && first_bad && (n_blocks == 0 || (data && off && want)), UZ_E_ARG, "bad arguments");
+        *first_bad = -1;
+        if (n_blocks == 0) return;
+        for (int64_t k = 0; k < n_blocks; k++) UZ_REQUIRE(off[k] >= 0 && off[k] <= off[k + 1] && off[k + 1] - off[k] <= 65536, UZ_E_ARG, "bad block table");
+        uint8_t *d = upload(c, data, (size_t)off[n_blocks]);
+        int64_t *d_off = upload(c, off, (size_t)n_blocks + 1);
+        uint32_t *d_want = upload(c, want, (size_t)n_blocks);
+        int32_t *d_err = nullptr, e = 0;
+        UZ_HIP(hipMalloc((void **)&d_err, 64));
+        uz_launch_crc32(c, c->stream, n_blocks, d, d_off, d_want, d_err);
+        UZ_HIP(hipMemcpyAsync(&e, d_err, 4, hipMemcpyDeviceToHost, c->stream));
+        UZ_HIP(hipStreamSynchronize(c->stream));
+        (void)hipFree(d); (void)hipFree(d_off); (void)hipFree(d_want); (void)hipFree(d_err);
+        if (e) *first_bad = e - 1;
     });
 }
 

@@ -1583,7 +1583,7 @@ void uz_stage_walk_plan_sizes(const uz_stage *P, int64_t out[8]) {
     out[4] = P->n_pre_blocks;
 }
 
-int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach, int32_t *fetch, int64_t *blk_coff) {
+int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach, int32_t *fetch, int64_t *blk_coff, uint32_t *blk_crc) {
     if (!P || !P->begun || P->finished || !task || !span || !reach || !fetch || !blk_coff) { last_error = "uz_stage_walk_plan: between uz_stage_gather_blocks and the finish, every array set"; return UZ_IO_E_ARG; }
     return guarded([&] {
         if (P->n_pre_blocks == 0 && P->pre_bytes == 0 && !P->tasks.empty()) fail(UZ_IO_E_ARG, "uz_stage_walk_plan: call uz_stage_gather_blocks first (the block table is laid out there)");
@@ -1604,7 +1604,7 @@ int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach
             tc[6] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f0); tc[7] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f1);
             tc[8] = P->fx_max_len[(size_t)T.tid]; tc[9] = 0;
             for (const auto &r : T.reach) { reach[2 * ri] = r.first; reach[2 * ri + 1] = r.second; ri++; }
-            for (size_t k = 0; k < T.pre.size(); k++) blk_coff[bi + (int64_t)k] = T.pre[k].coff;
+            for (size_t k = 0; k < T.pre.size(); k++) { blk_coff[bi + (int64_t)k] = T.pre[k].coff; if (blk_crc) blk_crc[bi + (int64_t)k] = T.pre[k].crc; }
             for (const Chunk &c : T.spans) {
                 int64_t *sc = span + UZ_WALK_SPAN_COLS * si++;
                 const int64_t c0 = (int64_t)(c.beg >> 16), stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16);

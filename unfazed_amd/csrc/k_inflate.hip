@@ -305,7 +305,60 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
     }
 }
 
+// ---- CRC-32 of every inflated block against the value its BGZF footer carries (what htslib's bgzf reader checks after inflating a block, and
+// what the host's walk checked on blocks the device had inflated: io_stage.cpp Stream::more).  One wavefront per block: the block is cut into 64
+// consecutive slices, lane l runs the byte-wise table CRC over slice l (the 256-entry table in LDS; lane 0 starts from 0xFFFFFFFF, the others
+// from 0 -- the register is linear in its start value), and the slices are joined the way zlib's crc32_combine joins two: the CRC register after
+// m more zero bytes is a 32 x 32 matrix over GF(2) applied to it, the matrices for 2^j zero bytes (j = 0 .. 16) are squared up once per wave in LDS,
+// and lane l applies those its distance from the block's end names.  XOR over the lanes, final inversion, compare.
+__device__ __forceinline__ uint32_t gf2_times(const uint32_t *mat, uint32_t vec) {
+    uint32_t sum = 0;
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) sum ^= ((vec >> i) & 1u) ? mat[i] : 0u;
+    return sum;
+}
+__global__ __launch_bounds__(64) void k_bgzf_crc32(int64_t n_blocks, const uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
+                                                   const uint32_t *__restrict__ want, int32_t *err /* [1]: 0, or 1 + the first bad block seen */) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t mat[19][32]; // [0]: one zero bit, [1]: two, [2]: four; [3 + j]: 2^j zero bytes
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) {
+        uint32_t c = (uint32_t)i;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        tab[i] = c;
+    }
+    if (lane < 32) mat[0][lane] = lane == 0 ? 0xEDB88320u : 1u << (lane - 1);
+    __syncthreads();
+    for (int j = 1; j < 19; j++) { // each squared from the one before
+        if (lane < 32) mat[j][lane] = gf2_times(mat[j - 1], mat[j - 1][lane]);
+        __syncthreads();
+    }
+    for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
+        const int64_t at = out_off[b];
+        const uint32_t n = (uint32_t)(out_off[b + 1] - at);
+        const uint32_t S = (n + 63u) / 64u;
+        const uint32_t lo = min(n, (uint32_t)lane * S), hi = min(n, lo + S);
+        uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
+        const uint8_t *p = out + at;
+        for (uint32_t i = lo; i < hi; i++) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        uint32_t m = n - hi; // zero bytes behind this slice
+        for (int j = 0; m; j++, m >>= 1)
+            if (m & 1u) c = gf2_times(mat[3 + j], c);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c ^= __shfl_xor(c, o, 64);
+        if (lane == 0 && (c ^ 0xFFFFFFFFu) != want[b]) atomicCAS(err, 0, (int32_t)(b + 1 > 0x7FFFFFFF ? 0x7FFFFFFF : b + 1));
+    }
+}
 } // namespace
+
+// out / out_off / want / err: device memory; *err stays 0 when every block's CRC-32 is the one its footer carries
+void uz_launch_crc32(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *out, const int64_t *out_off, const uint32_t *want, int32_t *err) {
+    if (n_blocks <= 0) return;
+    UZ_HIP(hipMemsetAsync(err, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_bgzf_crc32, dim3((unsigned)std::min<int64_t>(n_blocks, 256 * 16)), dim3(64), 0, st, n_blocks, out, out_off, want, err);
+    UZ_HIP(hipGetLastError());
+}
+
 
 // comp / in_off / out_off / out: device memory (comp padded by 1 KiB past its last byte); out_off[n_blocks] = total bytes
 void uz_launch_inflate(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *comp, int64_t comp_bytes_padded, const int64_t *in_off,

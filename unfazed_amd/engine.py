@@ -18,7 +18,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_PHASE, K_SIZING, K_CNV = 0, 1, 2, 
 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
-    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host", "uz_bam_walk", "uz_bam_walk_fetch", "uz_bam_walk_release", "uz_reads_from_bam",
+    "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host", "uz_bam_walk", "uz_crc32_blocks", "uz_bam_walk_fetch", "uz_bam_walk_release", "uz_reads_from_bam",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -58,7 +58,8 @@ def load_library(path: Optional[str] = None):
     L.uz_reads_headers.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.uz_bgzf_inflate.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int, C.POINTER(C.c_double)]
     L.uz_bgzf_inflate_to_host.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
-    L.uz_bam_walk.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
+    L.uz_crc32_blocks.argtypes = [vp, vp, C.c_int64, vp, vp, vp]
+    L.uz_bam_walk.argtypes = [vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
     L.uz_bam_walk_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.uz_bam_walk_release.argtypes = [vp, C.c_int]
     L.uz_reads_from_bam.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, vp, C.c_int64, vp]
@@ -373,7 +374,8 @@ class HipEngine:
         nt = int(plan["task"].shape[0])
         with self._inflate_lock:
             rc = self.L.uz_bam_walk(self.h, plan["comp"].ctypes.data, int(plan["comp_bytes"]), int(plan["n_blocks"]), plan["in_off"].ctypes.data,
-                                    plan["out_off"].ctypes.data, plan["blk_coff"].ctypes.data, nt, plan["task"].ctypes.data, int(plan["span"].shape[0]),
+                                    plan["out_off"].ctypes.data, plan["blk_coff"].ctypes.data,
+                                    plan["blk_crc"].ctypes.data if plan.get("blk_crc") is not None and os.environ.get("UZ_WALK_CRC", "1") != "0" else None, nt, plan["task"].ctypes.data, int(plan["span"].shape[0]),
                                     plan["span"].ctypes.data, int(plan["reach"].shape[0]), plan["reach"].ctypes.data, int(plan["fetch"].shape[0]),
                                     plan["fetch"].ctypes.data, C.byref(wid), C.byref(nd))
             if rc != 0:
@@ -386,6 +388,15 @@ class HipEngine:
                 self.L.uz_bam_walk_release(self.h, wid.value)
                 raise UnfazedHipError("uz_bam_walk_fetch: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
         return desc[:n], d_first, d_flags[:nt], d_walked[:nt], wid.value
+
+    def crc32_blocks(self, data: np.ndarray, off: np.ndarray, want: np.ndarray) -> int:
+        """k_bgzf_crc32 on blocks data[off[k]:off[k+1]] (<= 64 KiB each) against want[k] -> -1, or a block whose CRC-32 differs (uz_crc32_blocks)"""
+        data = np.ascontiguousarray(data, np.uint8)
+        off = np.ascontiguousarray(off, np.int64)
+        want = np.ascontiguousarray(want, np.uint32)
+        bad = C.c_int64(-1)
+        self._ck(self.L.uz_crc32_blocks(self.h, data.ctypes.data, int(off.size) - 1, off.ctypes.data, want.ctypes.data, C.byref(bad)), "uz_crc32_blocks")
+        return int(bad.value)
 
     def bam_walk_release(self, walk_id: int):
         self._ck(self.L.uz_bam_walk_release(self.h, int(walk_id)), "uz_bam_walk_release")

@@ -177,7 +177,7 @@ def load():
     lib.uz_stage_free.restype = None
     lib.uz_stage_walk_plan_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.uz_stage_walk_plan_sizes.restype = None
-    lib.uz_stage_walk_plan.argtypes = [C.c_void_p] * 6
+    lib.uz_stage_walk_plan.argtypes = [C.c_void_p] * 7
     lib.uz_bam_stage_finish_desc.argtypes = [C.c_void_p] * 5
     lib.uz_stage_kept_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.uz_stage_kept_sizes.restype = None
@@ -821,10 +821,11 @@ class BamSource:
         span = np.zeros((max(1, nsp), WALK_SPAN_COLS), np.int64)
         reach = np.zeros((max(1, nr), 2), np.int32)
         fetch = np.zeros((max(1, nf), 3), np.int32)
-        blk_coff = np.zeros(max(1, nblk), np.int64)
-        _check(self.lib, self.lib.uz_stage_walk_plan(sh.ptr, task.ctypes.data, span.ctypes.data, reach.ctypes.data, fetch.ctypes.data, blk_coff.ctypes.data))
+        blk_coff, blk_crc = np.zeros(max(1, nblk), np.int64), np.zeros(max(1, nblk), np.uint32)
+        _check(self.lib, self.lib.uz_stage_walk_plan(sh.ptr, task.ctypes.data, span.ctypes.data, reach.ctypes.data, fetch.ctypes.data, blk_coff.ctypes.data,
+                                                     blk_crc.ctypes.data))
         plan = dict(comp=comp, comp_bytes=int(cb.value), in_off=in_off[: nb.value], out_off=out_off, out_bytes=int(ob.value), n_blocks=int(nb.value),
-                    task=task[:nt], span=span[:nsp], reach=reach[:nr], fetch=fetch[:nf], blk_coff=blk_coff[:nblk], n_ref=len(self.contigs))
+                    task=task[:nt], span=span[:nsp], reach=reach[:nr], fetch=fetch[:nf], blk_coff=blk_coff[:nblk], blk_crc=blk_crc[:nblk], n_ref=len(self.contigs))
         t1 = time.perf_counter()
         if walk is None:  # the host's twin
             d_first, d_walked = np.zeros(nt + 1, np.int64), np.zeros(max(1, nt), np.int64)
