@@ -68,6 +68,7 @@ def parse():
                     help="DNMs of the files -> results pass (`feed` / `value_e2e`): their pile-ups are written as a real BAM + BAI, the sites table as "
                          "a BGZF VCF + TBI, and decoded back through the indexes inside the timed region (0 = skip)")
     ap.add_argument("--feed-chunk", type=int, default=3400, help="DNMs per chunk of the files -> results pass (scripts/feed_sweep.sh, two boxes: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)")
+    ap.add_argument("--feed-reps", type=int, default=3, help="timed passes of the feed leg (the median is reported)")
     ap.add_argument("--feed-walk", choices=("device", "host"), default="device",
                     help="feed pass: where the BAM records are walked -- device: the inflated blocks stay in HBM, k_bam_walk hands the host 64-byte descriptors, "
                          "the table is unpacked from HBM (include/uz_bamwalk.h); host: uz_bam_stage_* walks them on the host's cores (the link form)")
@@ -621,7 +622,8 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 return time.perf_counter() - t
 
         run_pass()  # warm-up: page cache, pinned blocks, code
-        el = run_pass()
+        els = sorted(run_pass() for _ in range(max(1, args.feed_reps)))
+        el = els[len(els) // 2]  # the median pass (the stage statistics below are the last pass's)
         for pool in pools:
             pool.free_all()
         for ip in ipairs or []:
@@ -638,7 +640,8 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         cpu_decode_s = time.perf_counter() - t
         raw_per_rec = st_b["raw_bytes"] / max(1, st_b["records"])
         return {
-            "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "result_mismatches_vs_resident": mism,
+            "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "seconds_of_every_pass": [round(x, 3) for x in els],
+            "result_mismatches_vs_resident": mism,
             "walk": "device (k_bam_walk: one wavefront per walk task; the host runs the batch-wide joins on 64-byte descriptors)" if dev_walk else "host (uz_bam_stage_*)",
             "inflate": ("device (k_bgzf_inflate: one wavefront per BGZF block; blocks the walk did not announce: " + io_native.inflate_backend() + ")") if on_device
                        else io_native.inflate_backend(),

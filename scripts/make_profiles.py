@@ -19,7 +19,9 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_bench_kernel_stats.csv" % rnd))
 shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "%s_pmc_summary.json" % rnd))
-for extra, name in (("staged_kernel_stats.csv", "%s_bench_staged_kernel_stats.csv"), ("bench_staged_under_rocprof.json", "%s_bench_staged_under_rocprof.json")):
+for extra, name in (("staged_kernel_stats.csv", "%s_bench_staged_kernel_stats.csv"), ("bench_staged_under_rocprof.json", "%s_bench_staged_under_rocprof.json"),
+                    ("feed_kernel_stats.csv", "%s_bench_feed_kernel_stats.csv"), ("bench_feed_under_rocprof.json", "%s_bench_feed_under_rocprof.json"),
+                    ("feed_pmc.txt", "%s_feed_pmc.txt")):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, name % rnd))
 line = json.loads([x for x in open(os.path.join(src, "stats.log")) if x.startswith("{")][-1])

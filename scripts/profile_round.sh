@@ -31,3 +31,17 @@ cd $ROOT
 find $OUT/staged -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/staged_kernel_stats.csv
 grep "^{" $OUT/staged.log | tail -1 > $OUT/bench_staged_under_rocprof.json
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
+# the feed pass (files -> results: BGZF inflate, CRC-32, record walk, descriptor filter, extract on the device): kernel statistics, then counters of its kernels
+cd /tmp
+UZ_BENCH_NO_PRODUCT=1 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/feed -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feed.log 2>&1
+cd $ROOT
+find $OUT/feed -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/feed_kernel_stats.csv
+grep "^{" $OUT/feed.log | tail -1 > $OUT/bench_feed_under_rocprof.json
+cd /tmp
+FONLY='--kernel-include-regex k_bam_walk|k_bam_extract|k_desc_filter|k_tab_insert|k_bgzf_crc32|k_bgzf_inflate'
+UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/feedpmc -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feedpmc.log 2>&1
+UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/feedfetch -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feedfetch.log 2>&1
+UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/feedwrite -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feedwrite.log 2>&1
+cd $ROOT
+(python3 scripts/pmc_rows.py $OUT/feedpmc; python3 scripts/pmc_rows.py $OUT/feedfetch; python3 scripts/pmc_rows.py $OUT/feedwrite) > $OUT/feed_pmc.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete

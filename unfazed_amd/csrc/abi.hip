@@ -414,6 +414,11 @@ void uz_destroy(uz_ctx *c) {
     if (c->inf_stream) (void)hipStreamDestroy(c->inf_stream);
     if (c->inf_stream2) (void)hipStreamDestroy(c->inf_stream2);
     if (c->inf_ready) (void)hipEventDestroy(c->inf_ready);
+    for (auto &w : c->walk) {
+        if (w.s0) (void)hipStreamDestroy(w.s0);
+        if (w.s1) (void)hipStreamDestroy(w.s1);
+        if (w.ev) (void)hipEventDestroy(w.ev);
+    }
     for (FindSlot &a : c->find_alt) {
         a.cnt_c.release(); a.cnt_h.release(); a.win_range.release(); a.cand_off.release(); a.het_off.release();
         a.cand_idx.release(); a.het_idx.release(); a.cand_flags.release();
@@ -1695,12 +1700,13 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
         UZ_REQUIRE(k >= 0, UZ_E_STATE, "four walked batches are waiting for uz_reads_from_bam / uz_bam_walk_release");
         uz_ctx::WalkSlot &w = c->walk[k];
         try {
-            if (!c->inf_stream) {
-                UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream, hipStreamNonBlocking));
-                UZ_HIP(hipStreamCreateWithFlags(&c->inf_stream2, hipStreamNonBlocking));
-                UZ_HIP(hipEventCreateWithFlags(&c->inf_ready, hipEventDisableTiming));
+            // streams of the slot's own: the blocks of the next batch go up and are inflated while this one is still walked (two calls may run at once)
+            if (!w.s0) {
+                UZ_HIP(hipStreamCreateWithFlags(&w.s0, hipStreamNonBlocking));
+                UZ_HIP(hipStreamCreateWithFlags(&w.s1, hipStreamNonBlocking));
+                UZ_HIP(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
             }
-            hipStream_t st = c->inf_stream;
+            hipStream_t st = w.s0;
             w.n_blocks = n_blocks; w.out_bytes = out_bytes; w.n_tasks = n_tasks; w.n_desc = 0;
             w.comp.ensure((size_t)comp_bytes + 1024); w.out.ensure((size_t)out_bytes + uz_bam_walk_pad());
             w.in_off.ensure((size_t)n_blocks + 1); w.out_off.ensure((size_t)n_blocks + 1); w.blk_coff.ensure((size_t)n_blocks + 1);
@@ -1716,14 +1722,14 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
             w.iflags.ensure(2 * ns + 8); w.blk_crc.ensure((size_t)n_blocks + 1);
             std::vector<int32_t> iflags(2 * ns + 4, 0);
             if (n_blocks) {
-                hipStream_t s2[2] = {c->inf_stream, c->inf_stream2};
+                hipStream_t s2[2] = {w.s0, w.s1};
                 UZ_HIP(hipMemsetAsync(w.comp.p + comp_bytes, 0, 1024, st));
                 UZ_HIP(hipMemsetAsync(w.out.p + out_bytes, 0, uz_bam_walk_pad(), st));
                 UZ_HIP(hipMemcpyAsync(w.in_off.p, in_off, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.out_off.p, out_off, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.blk_coff.p, blk_coff, (size_t)n_blocks * 8, hipMemcpyHostToDevice, st));
-                UZ_HIP(hipEventRecord(c->inf_ready, st));
-                UZ_HIP(hipStreamWaitEvent(s2[1], c->inf_ready, 0));
+                UZ_HIP(hipEventRecord(w.ev, st));
+                UZ_HIP(hipStreamWaitEvent(s2[1], w.ev, 0));
                 for (size_t i = 0; i < ns; i++) {
                     const int64_t b0 = cut[i], b1 = cut[i + 1];
                     const int64_t c0 = i == 0 ? 0 : std::max<int64_t>(in_off[b0] - 18, 0), c1 = i + 1 == ns ? comp_bytes : std::max<int64_t>(in_off[b1] - 18, c0);
@@ -1731,8 +1737,8 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                     uz_launch_inflate(c, s2[i & 1], b1 - b0, w.comp.p, (comp_bytes + 1024) & ~(int64_t)3, w.in_off.p + b0, w.out_off.p + b0, w.out.p, w.iflags.p + 2 * i);
                 }
                 if (ns > 1) { // the walk (first stream) reads what both streams inflated
-                    UZ_HIP(hipEventRecord(c->inf_ready, s2[1]));
-                    UZ_HIP(hipStreamWaitEvent(st, c->inf_ready, 0));
+                    UZ_HIP(hipEventRecord(w.ev, s2[1]));
+                    UZ_HIP(hipStreamWaitEvent(st, w.ev, 0));
                 }
                 if (blk_crc) { // every block against the CRC-32 of its footer, as htslib's reader (and the host's walk) holds it
                     UZ_HIP(hipMemcpyAsync(w.blk_crc.p, blk_crc, (size_t)n_blocks * 4, hipMemcpyHostToDevice, st));
@@ -1788,7 +1794,7 @@ int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_fir
         uz_ctx::WalkSlot &w = c->walk[walk_id];
         UZ_REQUIRE(d_first && (w.n_desc == 0 || desc), UZ_E_ARG, "null output");
         UZ_HIP(hipSetDevice(c->device));
-        hipStream_t st = c->inf_stream;
+        hipStream_t st = w.s0;
         const int32_t nt = w.n_tasks;
         if (nt == 0) { d_first[0] = 0; return; }
         w.desc_kept.ensure((size_t)w.n_desc + 1);

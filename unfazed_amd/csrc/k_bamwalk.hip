@@ -139,8 +139,10 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
                 const uint8_t *p = a.buf;
                 if (valid) {
                     c = w0 + offs[j];
-                    p = a.buf + c + 4;
                     bs = ld32(win8 + offs[j]);
+                    // the record's own bytes: from the window in LDS when it lies inside it whole (all but the last record or two of a window),
+                    // else from where it lies -- every field below is read byte by byte (BAM fields are unaligned)
+                    p = (uint32_t)offs[j] + 4u + bs <= (uint32_t)WIN ? win8 + offs[j] + 4 : a.buf + c + 4;
                     // the block that holds the record's first byte: the first whose end lies behind it (an empty block holds nothing)
                     int64_t lo = blk0, hi = blk1 - 1;
                     while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.blk_at[mid + 1] > c) hi = mid; else lo = mid + 1; }

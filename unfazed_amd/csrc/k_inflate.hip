@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
 
 // ---- CRC-32 of every inflated block against the value its BGZF footer carries (what htslib's bgzf reader checks after inflating a block, and
 // what the host's walk checked on blocks the device had inflated: io_stage.cpp Stream::more).  One wavefront per block: the block is cut into 64
-// consecutive slices, lane l runs the byte-wise table CRC over slice l (the 256-entry table in LDS; lane 0 starts from 0xFFFFFFFF, the others
+// consecutive slices, lane l runs the table CRC over slice l (slicing by four, 16-byte loads; tables in LDS; lane 0 starts from 0xFFFFFFFF, the others
 // from 0 -- the register is linear in its start value), and the slices are joined the way zlib's crc32_combine joins two: the CRC register after
 // m more zero bytes is a 32 x 32 matrix over GF(2) applied to it, the matrices for 2^j zero bytes (j = 0 .. 16) are squared up once per wave in LDS,
 // and lane l applies those its distance from the block's end names.  XOR over the lanes, final inversion, compare.
@@ -319,28 +319,45 @@ __device__ __forceinline__ uint32_t gf2_times(const uint32_t *mat, uint32_t vec)
 }
 __global__ __launch_bounds__(64) void k_bgzf_crc32(int64_t n_blocks, const uint8_t *__restrict__ out, const int64_t *__restrict__ out_off,
                                                    const uint32_t *__restrict__ want, int32_t *err /* [1]: 0, or 1 + the first bad block seen */) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[4][256]; // slicing by four: tab[k][b] = the register after byte b and k more zero bytes
     __shared__ uint32_t mat[19][32]; // [0]: one zero bit, [1]: two, [2]: four; [3 + j]: 2^j zero bytes
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) {
         uint32_t c = (uint32_t)i;
         for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        tab[i] = c;
+        tab[0][i] = c;
     }
     if (lane < 32) mat[0][lane] = lane == 0 ? 0xEDB88320u : 1u << (lane - 1);
     __syncthreads();
+    for (int k = 1; k < 4; k++) {
+        for (int i = lane; i < 256; i += 64) { const uint32_t c = tab[k - 1][i]; tab[k][i] = tab[0][c & 0xFFu] ^ (c >> 8); }
+        __syncthreads();
+    }
     for (int j = 1; j < 19; j++) { // each squared from the one before
         if (lane < 32) mat[j][lane] = gf2_times(mat[j - 1], mat[j - 1][lane]);
         __syncthreads();
     }
+    auto step4 = [&](uint32_t c, uint32_t w) {
+        c ^= w;
+        return tab[3][c & 0xFFu] ^ tab[2][(c >> 8) & 0xFFu] ^ tab[1][(c >> 16) & 0xFFu] ^ tab[0][c >> 24];
+    };
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         const int64_t at = out_off[b];
         const uint32_t n = (uint32_t)(out_off[b + 1] - at);
-        const uint32_t S = (n + 63u) / 64u;
-        const uint32_t lo = min(n, (uint32_t)lane * S), hi = min(n, lo + S);
-        uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
         const uint8_t *p = out + at;
-        for (uint32_t i = lo; i < hi; i++) c = tab[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+        // slices whose first byte is 16-byte aligned in memory (all but lane 0's): a lane reads its slice with 16-byte loads, eight of them to a
+        // cache line, instead of byte loads 1 KiB apart in every lane
+        const uint32_t a0 = (uint32_t)((uintptr_t)p & 15u);
+        const uint32_t S = ((((n + 15u) + 63u) / 64u) + 15u) & ~15u;
+        uint32_t lo = lane == 0 ? 0u : min(n, (uint32_t)lane * S - a0);
+        const uint32_t hi = min(n, ((uint32_t)lane + 1u) * S - a0);
+        uint32_t c = lane == 0 ? 0xFFFFFFFFu : 0u;
+        while (lo < hi && (((uintptr_t)(p + lo)) & 15u)) { c = tab[0][(c ^ p[lo]) & 0xFFu] ^ (c >> 8); lo++; }
+        for (; lo + 16u <= hi; lo += 16u) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + lo);
+            c = step4(c, v.x); c = step4(c, v.y); c = step4(c, v.z); c = step4(c, v.w);
+        }
+        for (; lo < hi; lo++) c = tab[0][(c ^ p[lo]) & 0xFFu] ^ (c >> 8);
         uint32_t m = n - hi; // zero bytes behind this slice
         for (int j = 0; m; j++, m >>= 1)
             if (m & 1u) c = gf2_times(mat[3 + j], c);

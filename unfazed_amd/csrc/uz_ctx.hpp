@@ -281,6 +281,8 @@ struct uz_ctx {
         DevBuf<unsigned long long> tab;
         int64_t n_blocks = 0, out_bytes = 0, n_desc = 0, n_desc_all = 0;
         int32_t n_tasks = 0;
+        hipStream_t s0 = nullptr, s1 = nullptr; // the slot's own streams (blocks up + inflate in slices on both, the walk on the first)
+        hipEvent_t ev = nullptr;
     };
     static constexpr int WALK_SLOTS = 4;
     WalkSlot walk[WALK_SLOTS];

@@ -120,6 +120,7 @@ class HipEngine:
         self._params = None
         import threading
         self._inflate_lock = threading.Lock()
+        self._walk_sem = threading.BoundedSemaphore(int(os.environ.get("UZ_WALKS_AT_ONCE", "1")))
         self._inflate_bufs = None  # PinnedPair of upload_reads_staged
         self._stage_pool = None    # PinnedPool of upload_reads_staged: the staged columns' page-locked block, kept from batch to batch
         self._chunk_pools = [None, None]  # stage_reads: two alternating sets of page-locked buffers (columns; gathered / inflated blocks)
@@ -372,7 +373,7 @@ class HipEngine:
         from . import io_native
         wid, nd = C.c_int(-1), C.c_int64(0)
         nt = int(plan["task"].shape[0])
-        with self._inflate_lock:
+        with self._walk_sem:  # (one batch at a time by default: two at once -- each on its slot's own streams -- measured 10 % slower, UZ_WALKS_AT_ONCE=2)
             rc = self.L.uz_bam_walk(self.h, plan["comp"].ctypes.data, int(plan["comp_bytes"]), int(plan["n_blocks"]), plan["in_off"].ctypes.data,
                                     plan["out_off"].ctypes.data, plan["blk_coff"].ctypes.data,
                                     plan["blk_crc"].ctypes.data if plan.get("blk_crc") is not None and os.environ.get("UZ_WALK_CRC", "1") != "0" else None, nt, plan["task"].ctypes.data, int(plan["span"].shape[0]),
