@@ -86,10 +86,17 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
     __shared__ uint16_t offs[WIN_RECS];
     __shared__ int s_n, s_state;
     __shared__ long long s_next;
+    // the task's fetches and reach intervals, searched once per record: in LDS when they fit (they do unless a task holds thousands of fetches)
+    constexpr int FCAP = 1024, RCAP = 256;
+    __shared__ int32_t f_lo[FCAP], f_hi[FCAP], r_a[RCAP], r_b[RCAP];
     const int t = blockIdx.x, lane = threadIdx.x;
     const int32_t *tc = a.task + UZ_WALK_TASK_COLS * (size_t)t;
     const int32_t tid = tc[0], tb = tc[1], sp0 = tc[2], sp1 = tc[3], r0 = tc[4], r1 = tc[5], f0 = tc[6], f1 = tc[7], max_len = tc[8];
     const uint8_t *win8 = reinterpret_cast<const uint8_t *>(win);
+    const bool f_lds = f1 - f0 <= FCAP, r_lds = r1 - r0 <= RCAP;
+    if (f_lds) for (int i = lane; i < f1 - f0; i += 64) { f_lo[i] = a.fetch[3 * (f0 + i)]; f_hi[i] = a.fetch[3 * (f0 + i) + 1]; }
+    if (r_lds) for (int i = lane; i < r1 - r0; i += 64) { r_a[i] = a.reach[2 * (r0 + i)]; r_b[i] = a.reach[2 * (r0 + i) + 1]; }
+    __syncthreads();
     int64_t n_out = 0, walked = 0, n_dir = 0;
     int flag = 0;
     bool stop = false;
@@ -100,7 +107,9 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
         const int64_t bend = sc[3], blk0 = sc[4], blk1 = sc[5];
         if (blk0 >= blk1) { stop = true; break; } // no block at the span's start: the end of the file (the host's walk stops there too)
         bool span_done = false;
+        int64_t bi_cur = blk0; // the block that holds `cur` (the cursor only moves forward: a step or none per window)
         while (!span_done) {
+            while (bi_cur + 1 < blk1 && a.blk_at[bi_cur + 1] <= cur) bi_cur++;
             const int64_t w0 = cur & ~(int64_t)15;
 #pragma unroll
             for (int it = 0; it < WIN / 16 / 64; it++) {
@@ -144,8 +153,8 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
                     // else from where it lies -- every field below is read byte by byte (BAM fields are unaligned)
                     p = (uint32_t)offs[j] + 4u + bs <= (uint32_t)WIN ? win8 + offs[j] + 4 : a.buf + c + 4;
                     // the block that holds the record's first byte: the first whose end lies behind it (an empty block holds nothing)
-                    int64_t lo = blk0, hi = blk1 - 1;
-                    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.blk_at[mid + 1] > c) hi = mid; else lo = mid + 1; }
+                    int64_t lo = bi_cur; // (a window reaches into the next block or two at most)
+                    while (lo + 1 < blk1 && a.blk_at[lo + 1] <= c) lo++;
                     voff = ((uint64_t)a.blk_coff[lo] << 16) | (uint64_t)(c - a.blk_at[lo]);
                     if (voff >= span_end) kind = K_BREAK;
                     else {
@@ -162,9 +171,17 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
                                 end = endpos_of(p, pos, fl, ncig, l_name);
                                 counted = true;
                                 // between two reach intervals nothing can be fetched (and a mate position there goes through the index)
-                                int ri = r0;
-                                while (ri < r1 && pos >= a.reach[2 * ri + 1]) ri++;
-                                if (ri < r1 && end <= a.reach[2 * ri]) kind = K_SKIP;
+                                bool gap;
+                                if (r_lds) {
+                                    int ri = 0;
+                                    while (ri < r1 - r0 && pos >= r_b[ri]) ri++;
+                                    gap = ri < r1 - r0 && end <= r_a[ri];
+                                } else {
+                                    int ri = r0;
+                                    while (ri < r1 && pos >= a.reach[2 * ri + 1]) ri++;
+                                    gap = ri < r1 && end <= a.reach[2 * ri];
+                                }
+                                if (gap) kind = K_SKIP;
                                 else if (32 + (uint64_t)l_name + 4 * (uint64_t)ncig + ((uint64_t)lseq + 1) / 2 + (uint64_t)lseq > (uint64_t)bs) kind = K_BAD; // (the host's extract)
                                 else kind = K_EMIT;
                             }
@@ -181,10 +198,17 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
                 bool direct = false;
                 if (emit) {
                     const int64_t key = (int64_t)pos - max_len;
-                    int lo = f0, hi = f1;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)a.fetch[3 * mid] < key) lo = mid + 1; else hi = mid; }
-                    for (; lo < f1 && a.fetch[3 * lo] < end; lo++)
-                        if (a.fetch[3 * lo + 1] > pos) { direct = true; break; }
+                    if (f_lds) {
+                        int lo = 0, hi = f1 - f0;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)f_lo[mid] < key) lo = mid + 1; else hi = mid; }
+                        for (; lo < f1 - f0 && f_lo[lo] < end; lo++)
+                            if (f_hi[lo] > pos) { direct = true; break; }
+                    } else {
+                        int lo = f0, hi = f1;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int64_t)a.fetch[3 * mid] < key) lo = mid + 1; else hi = mid; }
+                        for (; lo < f1 && a.fetch[3 * lo] < end; lo++)
+                            if (a.fetch[3 * lo + 1] > pos) { direct = true; break; }
+                    }
                 }
                 n_dir += __popcll(__ballot(direct));
                 if (FILL && emit) {
