@@ -813,7 +813,7 @@ void plan_begin(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t 
             if (T.spans.empty()) continue; // the index knows no record there
             Task *L = merged.empty() ? nullptr : &merged.back();
             // (up to a size: a file that holds nothing but the fetched windows would chain into one task per reference)
-            const uint64_t MAX_TASK_BYTES = 768 << 10; // compressed
+            static const uint64_t MAX_TASK_BYTES = getenv("UZ_STAGE_MAX_TASK_KB") ? (uint64_t)std::max(16, atoi(getenv("UZ_STAGE_MAX_TASK_KB"))) << 10 : (uint64_t)768 << 10; // compressed (the variable: a development aid)
             if (L && L->tid == T.tid && (T.spans.front().beg >> 16) <= (L->est_end >> 16) &&
                 (std::max(T.est_end, L->est_end) >> 16) - (L->spans.front().beg >> 16) <= MAX_TASK_BYTES) {
                 std::vector<Chunk> all(L->spans);
