@@ -257,6 +257,8 @@ int uz_io_cpu_quota(void);            /* CPUs the container's cgroup grants (cpu
 #define UZ_STAGE_UNIT_MASKS 2 /* only the 32-base units that hold a fetched position (+ extra[f] bases on) are staged */
 #define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (no unit masks then) */
 #define UZ_STAGE_WIDE_NO_UNITS 8 /* with unit masks: a fetch wider than two bases stages no unit (SV batches; uz_reads_select_plan: unit_masks = 3) */
+#define UZ_STAGE_SMALL_TASKS 32 /* the plan is made for the device's walk (uz_stage_walk_plan: one wavefront per task): walk tasks of at most 256 KB of
+                                 * compressed bytes instead of 768 -- more, shorter chains of records */
 #define UZ_STAGE_BASE_LISTS 16  /* with unit masks: a record whose fetches name single positions sends those bases as a list instead of the
                                  * units they lie in (uz_types.h: bl_*; uz_reads_select_plan: unit_masks & 4) */
 /* fetches (tid, lo, hi[, extra]) as staging.fetch_points lists them; min_base_qual = --min-gt-qual.  UZ_IO_E_RANGE when the batch

@@ -81,7 +81,7 @@ def test_a_task_the_device_flags_is_walked_by_the_host(workload):
     src = io_native.BamSource(workload["bam"], threads=3)
     ref = src.select(fc, flo, fhi, 20, extra=fex)
     want = io_native.stage_kept_debug(src.lib, ref._stage.ptr, int(ref.view.n_segs))
-    plain = src.select_kept(fc, flo, fhi, 20)
+    plain = src.select_kept(fc, flo, fhi, 20, small_tasks=True)  # (the plan `walk` below gets: a plan for the device takes smaller tasks)
 
     def walk(plan):
         nt = plan["task"].shape[0]

@@ -563,7 +563,7 @@ class ReadsSource:
 
 
 # ---------------------------------------------------------------------------- BAM file -> staged records in one pass
-STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE, STAGE_WIDE_NO_UNITS, STAGE_BASE_LISTS = 1, 2, 4, 8, 16
+STAGE_ALL_BASES, STAGE_UNIT_MASKS, STAGE_PLANE, STAGE_WIDE_NO_UNITS, STAGE_BASE_LISTS, STAGE_SMALL_TASKS = 1, 2, 4, 8, 16, 32
 
 
 def index_summary(path: str, kind: str) -> np.ndarray:
@@ -789,7 +789,7 @@ class BamSource:
         out._stage = sh
         return out
 
-    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None) -> "KeptBatch":
+    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None, small_tasks=None) -> "KeptBatch":
         """The same batch through the device's walk (include/uz_bamwalk.h): the blocks are gathered, `walk(plan)` inflates them in HBM and walks
         them there (HipEngine.bam_walk -> descriptors, d_first, d_flags, d_walked; None: the host's twin uz_stage_walk_host -- tests), the
         batch-wide joins run here on the descriptors, and the answer is the list of kept records for uz_reads_from_bam.
@@ -802,7 +802,9 @@ class BamSource:
         if extra is not None:
             extra = np.ascontiguousarray(extra, np.uint16)
         ia = alloc or (lambda nbytes: np.empty(max(16, nbytes), np.uint8))
-        flags = STAGE_ALL_BASES if all_bases else 0
+        if small_tasks is None:  # (a plan for the device's walk takes smaller tasks: one wavefront walks a task)
+            small_tasks = walk is not None
+        flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_SMALL_TASKS if small_tasks else 0)
         st = C.c_void_p()
         t0 = time.perf_counter()
         _check(self.lib, self.lib.uz_bam_stage_begin(self._h.ptr, int(contig.size), contig.ctypes.data, lo.ctypes.data, hi.ctypes.data,
