@@ -321,6 +321,11 @@ int uz_stage_kept(const uz_stage *s, int threads, uz_kept_rec *out /* [records] 
 int uz_stage_kept_debug(const uz_stage *s, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases);
 void uz_stage_free(uz_stage *s);
 
+/* The span sums of a packed view (uz_types.h: pk_sums) -- what the device's header build would otherwise compute in a pass of its own (k_off_block_sums +
+ * scan).  *n_spans = the spans of the view; sums: NULL (the count only), or [(n_spans + 1) * UZ_PK_SUMS], row b = the sums over the records in front
+ * of span b, the last row the totals.  Every packer of this library calls it on the view it has just filled (io_native: select / pack_reads). */
+int uz_packed_block_sums(const uz_reads_packed_view *v, int threads, uint64_t *sums, int64_t *n_spans);
+
 #ifdef __cplusplus
 }
 #endif

@@ -326,7 +326,21 @@ typedef struct uz_reads_packed_view {
     int64_t n_bl_units;
     int32_t bl_wide;
     int32_t reserved2;
+    /* Span sums -- optional (NULL: the device computes them itself, one more pass over the small columns and a scan).  The header build lays the
+     * records' variable-length parts out by the running sums of UZ_PK_SUMS per-record quantities: 0 CIGAR words, 1 row units, 2 base-row units
+     * that travelled as rows, 3 listed low-quality positions, 4 CIGAR words that travelled (cigar_compact), 5 start differences and 6 name-id
+     * differences / new names (difference forms; modulo 2^32 where a column is), 7 row units and 8 listed bases of the records whose bases came as a
+     * list, 9 FIRST and 10 SECOND records of the pair form.  A packer knows them as it packs: pk_sums[UZ_PK_SUMS * b + k] = quantity k summed over
+     * the records in front of span b, spans of 1 << UZ_PK_SHIFT(n_segs) records, b = 0 .. n_pk_spans (the last row: the totals).
+     * uz_packed_block_sums (unfazed_io.h) fills it for any view.  The device packs from these offsets and holds every span's own sums against the
+     * next row as it goes (UZ_E_RANGE on a mismatch; no record is laid out beyond its span's share). */
+    const uint64_t *pk_sums;
+    int64_t n_pk_spans;
 } uz_reads_packed_view;
+#define UZ_PK_SUMS 11
+#define UZ_PK_SHIFT_LARGE 12
+#define UZ_PK_SHIFT_SMALL 10
+#define UZ_PK_SHIFT(n) ((((int64_t)(n)) >> UZ_PK_SHIFT_LARGE) >= 4096 ? UZ_PK_SHIFT_LARGE : UZ_PK_SHIFT_SMALL) /* records per span of the header build's passes: 1 << this */
 #define UZ_UMASK_LISTED 0x8000u /* device only: set in a record's unit mask when its bases came as a list (masks name units 0 .. 14) */
 #define UZ_P8_SECOND 0
 #define UZ_P8_MAX_DIST 252

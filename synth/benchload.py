@@ -191,4 +191,5 @@ def link_bytes(pv) -> int:
     return (int(pv.n_segs) * fixed + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
             + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
             + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16)
-            + (int(pv.n_bl) * (2 if pv.bl_wide else 1) + (int(pv.n_bl) + 3) // 4 + (int(pv.n_tup) if pv.tup_n_bl else int(pv.n_segs) if pv.bl_n else 0)))
+            + (int(pv.n_bl) * (2 if pv.bl_wide else 1) + (int(pv.n_bl) + 3) // 4 + (int(pv.n_tup) if pv.tup_n_bl else int(pv.n_segs) if pv.bl_n else 0))
+            + ((int(pv.n_pk_spans) + 1) * 88 if pv.pk_sums else 0))  # (the packer's span sums: uz_types.h pk_sums)

@@ -204,9 +204,9 @@ def test_sv_batches_on_a_list_form_table_reproduce_the_goldens(engine, monkeypat
     session._READS.clear(); session._HOSTS.clear()
 
 
-@pytest.mark.parametrize("route", ["stage", "table"])
+@pytest.mark.parametrize("route", ["walk", "stage", "table"])
 def test_sv_goldens_from_indexed_files(engine, tmp_path, monkeypatch, route):
-    """The SV goldens from FILES with a BAI next to every BAM: the batch travels in the link form of an SV batch -- qualities as lists,
+    """The SV goldens from FILES with a BAI next to every BAM: the batch is walked on the device (walk), or travels in the link form of an SV batch -- qualities as lists,
     unit masks from the one-base fetches, no unit for the +-cutoff fetches around the breakpoints -- built in one pass from the file
     (stage) or out of the region table (table: UZ_IO_STAGE=0); the records must be the reference's."""
     import contextlib
@@ -224,6 +224,9 @@ def test_sv_goldens_from_indexed_files(engine, tmp_path, monkeypatch, route):
     from unfazed_amd.sv_phaser import phase_svs
     if route == "table":
         monkeypatch.setenv("UZ_IO_STAGE", "0")
+    # walk: the session's default since round 4 -- blocks inflated, checked and WALKED on the device, the table unpacked from HBM (include/uz_bamwalk.h);
+    # stage: the link form built by the host's walk (UZ_WALK=host)
+    monkeypatch.setenv("UZ_WALK", "device" if route == "walk" else "host")
     for path in SV:
         g = json.load(open(path))
         ds = make_small_sv(SvConfig(**g["config"]))

@@ -49,8 +49,11 @@ def test_chunked_route_equals_one_table_route(tmp_path, hip_lib):
     text = gzip.open(paths["sites"], "rt").read()
     write_bgzf_text(paths["sites"], text)
     write_tbi(paths["sites"])
-    whole, err_w, n = _run(paths, ds, {"UZ_HOST_CHUNKS": "0"})
+    # the one-table route with the HOST's walk (the link form) is the yardstick; every route below walks the records on the device unless it says otherwise
+    whole, err_w, n = _run(paths, ds, {"UZ_HOST_CHUNKS": "0", "UZ_WALK": "host"})
     assert n >= 40 and len(whole) >= 8
+    dev, err_d, _ = _run(paths, ds, {"UZ_HOST_CHUNKS": "0", "UZ_WALK": "device"})  # one table, walked on the device (include/uz_bamwalk.h)
+    assert dev == whole and err_d == err_w
     from unfazed_amd import hostpath
     calls = []
     orig = hostpath.PhasingHost._chunked_batch
@@ -61,13 +64,13 @@ def test_chunked_route_equals_one_table_route(tmp_path, hip_lib):
         return r
     hostpath.PhasingHost._chunked_batch = spy
     try:
-        for size in ("5", "13"):
-            got, err_g, _ = _run(paths, ds, {"UZ_HOST_CHUNKS": "1", "UZ_HOST_CHUNK_DNMS": size})
-            assert got == whole, size
-            assert err_g == err_w, size
+        for size, walk in (("5", "device"), ("13", "device"), ("13", "host")):
+            got, err_g, _ = _run(paths, ds, {"UZ_HOST_CHUNKS": "1", "UZ_HOST_CHUNK_DNMS": size, "UZ_WALK": walk})
+            assert got == whole, (size, walk)
+            assert err_g == err_w, (size, walk)
     finally:
         hostpath.PhasingHost._chunked_batch = orig
-    assert calls == [True, True]  # (the chunked route really ran)
+    assert calls == [True, True, True]  # (the chunked route really ran)
 
 
 def test_long_reads_travel_as_lists_with_two_byte_positions(tmp_path, hip_lib):
@@ -92,9 +95,11 @@ def test_long_reads_travel_as_lists_with_two_byte_positions(tmp_path, hip_lib):
         return r
     io_native.BamSource.select = spy
     try:
-        rows, err_r, n = _run(paths, ds, {"UZ_BASE_LISTS": "0", "UZ_HOST_CHUNKS": "0"}, readlen=300)
-        lists, err_l, _ = _run(paths, ds, {"UZ_BASE_LISTS": "1", "UZ_HOST_CHUNKS": "0"}, readlen=300)
+        rows, err_r, n = _run(paths, ds, {"UZ_BASE_LISTS": "0", "UZ_HOST_CHUNKS": "0", "UZ_WALK": "host"}, readlen=300)
+        lists, err_l, _ = _run(paths, ds, {"UZ_BASE_LISTS": "1", "UZ_HOST_CHUNKS": "0", "UZ_WALK": "host"}, readlen=300)
+        walked, err_w, _ = _run(paths, ds, {"UZ_HOST_CHUNKS": "0", "UZ_WALK": "device"}, readlen=300)  # (the device's walk: no link form at all)
     finally:
         io_native.BamSource.select = orig
     assert len(rows) >= 3 and lists == rows and err_l == err_r
+    assert walked == rows and err_w == err_r and len(seen) == 2
     assert seen[0][0] == 0 and seen[1][0] > 100 and seen[1][1] == 1 and seen[1][2] < seen[0][2]

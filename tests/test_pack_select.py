@@ -459,3 +459,45 @@ def test_pair_form_codes_and_its_fallback():
     assert "pair_d8" not in part3.arrays and "mate_d8" in part3.arrays and part3.qname_map is None
     w3 = abi.wide_columns(part3)
     assert np.array_equal(idx3, idx2) and np.array_equal(w3["qname"], arrs["qname"][idx3]) and np.array_equal(w3["tlen"], tlen[idx3])
+
+
+def test_span_sums_of_a_packed_view_are_the_running_sums_of_its_columns():
+    """uz_packed_block_sums (uz_types.h pk_sums) against numpy on a link-form selection: per span of 1024 records the running sums of the eleven
+    quantities the device's header build lays the records out by (csrc/k_reads.hip pk_vals)."""
+    from synth.small import SmallConfig, make_small
+    from helpers import tables
+    ds = make_small(SmallConfig(seed=4242, n_dnms=40, cluster_prob=0.7, indel_prob=0.05, softclip_prob=0.05))
+    _, reads = tables(ds)
+    kid = sorted(reads)[0]
+    full = io_native.pack_reads(abi.reads_view(reads[kid]), 20, lists=True, with_end=True)
+    st = np.asarray(reads[kid].start)
+    pts = np.sort(np.random.default_rng(3).choice(st, 400))
+    fc = np.asarray(reads[kid].contig_of(pts) if hasattr(reads[kid], "contig_of") else np.zeros(pts.size), np.int32)
+    sel = io_native.ReadsSource(full).select(fc, pts.astype(np.int32), (pts + 1).astype(np.int32), extra=np.zeros(pts.size, np.uint16))
+    v, a = sel.view, sel.arrays
+    n = int(v.n_segs)
+    assert n > 1500 and "pk_sums" in a and int(v.n_pk_spans) == abi.pk_spans(n) == (n + 1023) // 1024
+    S = a["pk_sums"].reshape(-1, abi.PK_SUMS)
+    t = a["tup"][:n].astype(np.int64)
+    ls, nc, ax = a["tup_l_seq"][t].astype(np.int64), a["tup_n_cigar"][t].astype(np.int64), a["tup_aux"][t].astype(np.int64)
+    nl, um = a["tup_n_low"][t].astype(np.int64), a["tup_umask"][t].astype(np.int64)
+    nb = a["tup_n_bl"][t].astype(np.int64) if "tup_n_bl" in a else np.zeros(n, np.int64)
+    units = (ls + 31) >> 5
+    staged = np.where(ax & abi.AUX_NO_SEQ, 0, np.where(um == abi.UMASK_ALL, units, np.array([bin(int(x)).count("1") for x in um])))
+    pd = a["pair_d8"][:n].astype(np.int64)
+    sd = a["start_d8"][:n].astype(np.int64)
+    key, val = a["esc16_key"][: int(v.n_esc16)], a["esc16_val"][: int(v.n_esc16)]
+    esc0 = {int(k >> 2): int(x) for k, x in zip(key, val) if int(k) & 3 == 0}
+    sdv = np.array([esc0.get(i, 0) if sd[i] == 255 else sd[i] for i in range(n)], np.int64) & 0xFFFFFFFF
+    q = np.zeros((n, abi.PK_SUMS), np.int64)
+    q[:, 0], q[:, 1] = nc, units
+    q[:, 2], q[:, 7], q[:, 8] = np.where(nb > 0, 0, staged), np.where(nb > 0, staged, 0), nb
+    q[:, 3] = np.where((ax & abi.AUX_NO_SEQ) == 0, np.where(nl <= abi.QLOW_LIST_MAX, nl, 0), 0)
+    q[:, 4] = np.where(ax & abi.AUX_SIMPLE_MASK, 0, nc)
+    q[:, 5] = sdv
+    q[:, 6] = ((pd != 0) & (pd != 253) & (pd != 255)).astype(np.int64)
+    q[:, 9], q[:, 10] = ((pd >= 1) & (pd <= 252)).astype(np.int64), ((pd == 0) | (pd == 253)).astype(np.int64)
+    run = np.concatenate([np.zeros((1, abi.PK_SUMS), np.int64), np.cumsum(q, axis=0)])
+    want = run[np.minimum(np.arange(S.shape[0]) * 1024, n)]
+    assert np.array_equal(S.astype(np.int64), want)
+    assert S[-1, 0] == int(v.n_cigar_total) + int(v.n_cigar_omitted) and S[-1, 1] == int(v.n_row_units) and S[-1, 9] == S[-1, 10]

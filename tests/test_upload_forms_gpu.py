@@ -190,3 +190,50 @@ def test_family_columns_in_eight_bits_give_the_same_classes(engine):
     engine.classify(f16, abi.make_params(min_gt_qual=300), sc.n)  # (the 16-bit columns serve any threshold)
     engine.free_sites(sid)
     engine.free_sites(sid2)
+
+
+def test_span_sums_from_the_packer(engine):
+    """uz_types.h pk_sums: the header build packs from the packer's span sums (no k_off_block_sums / scan) and must build the same table as from its
+    own; sums that do not add up -- one span's share moved to its neighbour, or totals that differ from the view's -- are refused."""
+    rh, arrs, N = _odd_table(60)
+    pk = io_native.pack_reads(rh, 20, with_end=True)
+    src = io_native.ReadsSource(pk)
+    contig_of = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    fc = np.unique(contig_of).astype(np.int32)
+    part, idx = src.select(fc, np.zeros(fc.size, np.int32), np.full(fc.size, 2 ** 31 - 1, np.int32), want_index=True)
+    n = idx.size
+    assert "pk_sums" in part.arrays and int(part.view.n_pk_spans) >= 3
+    S = part.arrays["pk_sums"].reshape(-1, abi.PK_SUMS)
+    good = S.copy()
+    rid = engine.upload_reads_packed(part)
+    with_sums = engine.reads_headers(rid, n)
+    engine.free_reads(rid)
+    keep = part.view.pk_sums
+    part.view.pk_sums = None  # the device counts for itself
+    rid = engine.upload_reads_packed(part)
+    own = engine.reads_headers(rid, n)
+    engine.free_reads(rid)
+    for k in ("start", "end", "tlen", "mate", "qname"):
+        assert np.array_equal(with_sums[k], own[k]), k
+    part.view.pk_sums = keep
+    # a CIGAR word moved from span 1 to span 2: the rows still ascend and end at the totals, but span 1 does not add up to its row
+    S[2, 0] -= 1
+    with pytest.raises(UnfazedHipError):
+        rid = engine.upload_reads_packed(part)
+        engine.wait_reads(rid)
+        engine.reads_headers(rid, n)
+    S[:] = good
+    S[2, 2] += 1  # ... one base-row unit the other way
+    with pytest.raises(UnfazedHipError):
+        rid = engine.upload_reads_packed(part)
+        engine.wait_reads(rid)
+        engine.reads_headers(rid, n)
+    S[:] = good
+    S[-1, 1] += 1  # totals that are not the view's: refused before anything is copied
+    with pytest.raises(UnfazedHipError, match="pk_sums"):
+        engine.upload_reads_packed(part)
+    S[:] = good
+    rid = engine.upload_reads_packed(part)  # ... and the untouched sums still go through
+    again = engine.reads_headers(rid, n)
+    engine.free_reads(rid)
+    assert np.array_equal(again["start"], own["start"])

@@ -188,7 +188,18 @@ class ReadsPackedView(C.Structure):
         # indices and two-bit codes
         ("bl_n", _p), ("tup_n_bl", _p), ("bl_pos", _p), ("bl_code", _p), ("n_bl", C.c_int64), ("n_bl_units", C.c_int64), ("bl_wide", C.c_int32),
         ("reserved2", C.c_int32),
+        # span sums (uz_types.h pk_sums): the running sums the device's header build lays the records out by, from the packer
+        ("pk_sums", _p), ("n_pk_spans", C.c_int64),
     ]
+
+
+PK_SUMS = 11
+
+
+def pk_spans(n: int) -> int:
+    """spans of the header build's passes over n records (uz_types.h: UZ_PK_SHIFT)"""
+    shift = 12 if (int(n) >> 12) >= 4096 else 10
+    return (int(n) + (1 << shift) - 1) >> shift
 
 
 AUX_NO_SEQ = 8
@@ -207,7 +218,7 @@ def row_units(l_seq):
 
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
                       qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False,
-                      narrow8=False, pair8=False, n_bl=None, n_bl_units=0, bl_wide=False) -> "Held":
+                      narrow8=False, pair8=False, n_bl=None, n_bl_units=0, bl_wide=False, pk_sums=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -217,6 +228,7 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     n_tup: None = the plain small columns; a number = the dictionary form with that many combinations (tup + tup_* instead of flag,
     l_seq, n_cigar, mapq, aux and n_low).
     n_esc16: None = start / tlen / mate / qname as 32-bit columns; a number = as 16-bit differences with that many escapes.
+    pk_sums: room for the span sums (uz_types.h pk_sums; io_native.block_sums fills them).
     pair8 (with start8): tlen, mate and name id in the pair form's one byte (pair_d8) instead of tlen_s / mate_d* / qname_d*.
     n_bl: None = every record's staged units travel as rows; a number = the list form of the bases for some records (bl_* columns with that many
     listed bases; the count per record in the dictionary, tup_n_bl, or the plain bl_n column), n_bl_units their row units.
@@ -291,6 +303,10 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
         arrs["esc16_key"] = alloc(8 * max(1, n_esc16))[: 8 * max(1, n_esc16)].view(np.uint64)
         arrs["esc16_val"] = alloc(4 * max(1, n_esc16))[: 4 * max(1, n_esc16)].view(np.int32)
         v.n_esc16 = n_esc16
+    if pk_sums:  # the span sums ride along (filled by io_native.block_sums once the columns are)
+        nb = pk_spans(n)
+        arrs["pk_sums"] = alloc(8 * PK_SUMS * (nb + 1))[: 8 * PK_SUMS * (nb + 1)].view(np.uint64)
+        v.n_pk_spans = nb
     v.cigar_compact = 0 if cigar_omitted is None else 1
     v.n_cigar_omitted = 0 if cigar_omitted is None else cigar_omitted
     v.n_qlow_pos = 0 if n_qlow_pos is None else n_qlow_pos

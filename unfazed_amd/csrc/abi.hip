@@ -750,6 +750,22 @@ static void check_packed_view(const uz_reads_packed_view *v) {
         UZ_REQUIRE(v->n_bl == 0 && v->n_bl_units == 0, UZ_E_ARG, "n_bl / n_bl_units without bl_n / tup_n_bl");
     UZ_REQUIRE(v->cigar_compact ? v->n_cigar_omitted >= 0 && v->n_cigar_omitted <= v->n_segs : v->n_cigar_omitted == 0, UZ_E_ARG, "bad n_cigar_omitted");
     UZ_REQUIRE(v->n_cigar_total + v->n_cigar_omitted < ((int64_t)1 << 32), UZ_E_RANGE, "more than 2^32 CIGAR operations");
+    if (v->pk_sums) { // the packer's span sums: rows that ascend from zero to the totals the view declares (the device holds every span against its row)
+        const int shift = UZ_PK_SHIFT(v->n_segs);
+        const int64_t nb = (v->n_segs + ((int64_t)1 << shift) - 1) >> shift;
+        UZ_REQUIRE(v->n_pk_spans == nb, UZ_E_ARG, "pk_sums: n_pk_spans is not the number of spans of n_segs records (UZ_PK_SHIFT)");
+        const uint64_t *S = v->pk_sums, *T = S + (size_t)nb * UZ_PK_SUMS;
+        bool ok = true;
+        for (int k = 0; k < UZ_PK_SUMS; k++) ok &= S[k] == 0;
+        for (int64_t b = 0; b < nb && ok; b++)
+            for (int k = 0; k < UZ_PK_SUMS; k++)
+                if (k != 5 && k != 6) ok &= S[(size_t)(b + 1) * UZ_PK_SUMS + k] >= S[(size_t)b * UZ_PK_SUMS + k];
+        const bool lists_f = v->n_low != nullptr || (v->tup && v->tup_n_low);
+        ok = ok && T[0] == (uint64_t)(v->n_cigar_total + v->n_cigar_omitted) && T[1] == (uint64_t)v->n_row_units && T[2] == (uint64_t)v->n_seq_units &&
+             T[3] == (uint64_t)(lists_f ? v->n_qlow_pos : 0) && (!v->cigar_compact || T[4] == (uint64_t)v->n_cigar_total) && T[7] == (uint64_t)v->n_bl_units &&
+             T[8] == (uint64_t)v->n_bl && T[9] == T[10];
+        UZ_REQUIRE(ok, UZ_E_RANGE, "pk_sums: the span sums do not ascend from zero to the totals the view declares");
+    }
 }
 
 // packed columns in HOST memory -> one block; every command goes to stream `st`
@@ -792,6 +808,8 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     int8_t *d_mate8 = nullptr, *d_qname8 = nullptr;
     uint8_t *d_pair8 = nullptr;
     unsigned long long *e_key = nullptr; int32_t *e_val = nullptr;
+    unsigned long long *pk = nullptr;
+    const size_t npk = v->pk_sums ? ((size_t)v->n_pk_spans + 1) * UZ_PK_SUMS : 0; // the packer's span sums (checked below)
     void *scratch = nullptr;
     for (int pass = 0; pass < 2; pass++) {
         Carver cv(pass ? r.block.p : nullptr);
@@ -823,6 +841,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         const size_t npl = tupf ? 0 : n; // the plain small columns
         flag = cv.take<uint16_t>(npl); l_seq = cv.take<uint16_t>(npl); n_cigar = cv.take<uint16_t>(npl);
         mapq = cv.take<uint8_t>(npl); aux = cv.take<uint8_t>(npl);
+        if (npk) pk = cv.take<unsigned long long>(npk);
         scratch = cv.take<uint8_t>(uz_rec_scratch_bytes(r.n));
         if (!pass) r.block = uz_block_get(c, cv.off + 256);
     }
@@ -835,6 +854,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     r.contig_off = const_cast<int64_t *>(h2d(st, r.contig_off, v->contig_off, (size_t)v->n_contigs + 1));
     r.max_span = const_cast<int32_t *>(h2d(st, r.max_span, v->max_span, (size_t)v->n_contigs));
     col.end = v->end ? h2d(st, end, v->end, n) : nullptr;
+    if (npk) col.pk_sums = h2d(st, pk, (const unsigned long long *)v->pk_sums, npk);
     if (d16) { // 16-bit differences + the escape list instead of four 32-bit columns
         if (d8) col.start_d8 = h2d(st, d_start8, v->start_d8, n);
         else col.start_d = h2d(st, d_start, v->start_d, n);
@@ -910,6 +930,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         const void *bb[4] = {col.bl_n, col.tup_n_bl, col.bl_pos, col.bl_code};
         for (int k = 0; k < 4; k++) r.col_b[k] = bb[k];
         r.col_bwide = col.bl_wide;
+        r.col_pk = col.pk_sums;
     }
     if (defer_build) { // asynchronous upload: copies only on the copy stream, the header build at first use (uz_reads_make_ready)
         const void *p[10] = {col.start, col.end, col.tlen, col.mate, col.qname, col.flag, col.l_seq, col.n_cigar, col.mapq, col.aux};
@@ -941,6 +962,7 @@ static void build_staged(uz_ctx *c, hipStream_t st, ReadsDev &r) {
     col.qpos_wide = r.col_qwide;
     col.bl_n = (const uint8_t *)r.col_b[0]; col.tup_n_bl = (const uint8_t *)r.col_b[1]; col.bl_pos = (const uint8_t *)r.col_b[2]; col.bl_code = (const uint8_t *)r.col_b[3];
     col.bl_wide = r.col_bwide;
+    col.pk_sums = (const unsigned long long *)r.col_pk;
     if (col.bl_form()) { col.n_seq_link = r.n_seq_units - r.n_bl_units; col.seq4_out = reinterpret_cast<uint32_t *>(const_cast<uint8_t *>(r.seq4)); }
     uz_build_records(c, st, r, col, r.build_scratch);
 }

@@ -982,3 +982,78 @@ int uz_reads_select_fill(const uz_select *s, int threads, uz_reads_packed_view *
 }
 
 } // extern "C"
+
+// ---- span sums of a packed view (uz_types.h: pk_sums): the host's statement of csrc/k_reads.hip k_off_block_sums + the scan behind it
+namespace {
+struct SumsView {
+    const uz_reads_packed_view *v;
+    bool lists;
+    int64_t esc_find(int64_t i, int col) const { // value of (record, column) in the escape list, 0 when absent (as the device reads it)
+        const uint64_t key = ((uint64_t)i << 2) | (uint64_t)col;
+        const uint64_t *k0 = v->esc16_key, *k1 = k0 + v->n_esc16;
+        const uint64_t *it = std::lower_bound(k0, k1, key);
+        return (it != k1 && *it == key) ? (int64_t)v->esc16_val[it - k0] : 0;
+    }
+    void vals(int64_t i, uint32_t (&q)[UZ_PK_SUMS]) const {
+        uint32_t ls, nc, ax, um, nb;
+        int nl;
+        if (v->tup) {
+            const uint32_t t = v->tup[i];
+            ls = v->tup_l_seq[t]; nc = v->tup_n_cigar[t]; ax = v->tup_aux[t];
+            nl = lists ? (int)v->tup_n_low[t] : -1;
+            um = v->tup_umask ? (uint32_t)v->tup_umask[t] : (v->umask ? (uint32_t)v->umask[i] : UZ_UMASK_ALL);
+            nb = v->tup_n_bl ? (uint32_t)v->tup_n_bl[t] : (v->bl_n ? (uint32_t)v->bl_n[i] : 0u);
+        } else {
+            ls = v->l_seq[i]; nc = v->n_cigar[i]; ax = v->aux[i];
+            nl = lists ? (int)v->n_low[i] : -1;
+            um = v->umask ? (uint32_t)v->umask[i] : UZ_UMASK_ALL;
+            nb = v->bl_n ? (uint32_t)v->bl_n[i] : 0u;
+        }
+        for (int k = 0; k < UZ_PK_SUMS; k++) q[k] = 0;
+        q[4] = (ax & UZ_AUX_SIMPLE_MASK) ? 0u : nc;
+        const uint32_t staged = (ax & UZ_AUX_NO_SEQ) ? 0u : (um == UZ_UMASK_ALL ? UZ_ROW_UNITS(ls) : (uint32_t)__builtin_popcount(um));
+        q[0] = nc; q[1] = UZ_ROW_UNITS(ls);
+        q[2] = nb ? 0u : staged;
+        q[7] = nb ? staged : 0u;
+        q[8] = nb;
+        q[3] = (nl >= 0 && !(ax & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX) ? (uint32_t)nl : 0u;
+        const bool diff_form = v->tlen_s != nullptr || v->pair_d8 != nullptr;
+        if (diff_form) {
+            if (v->start_d8) { const uint32_t x = v->start_d8[i]; q[5] = x == UZ_D8_ESC ? (uint32_t)esc_find(i, 0) : x; }
+            else { const int x = v->start_d[i]; q[5] = (uint32_t)(x == UZ_D16_ESC ? esc_find(i, 0) : x); }
+            if (v->pair_d8) { const uint32_t p = v->pair_d8[i]; q[6] = (p != UZ_P8_SECOND && p != UZ_P8_SECOND_TLEN && p != UZ_P8_OLD) ? 1u : 0u; }
+            else if (v->qname_d8) { const int x = v->qname_d8[i]; q[6] = (uint32_t)(x == UZ_D8S_ESC ? esc_find(i, 3) : x); }
+            else { const int x = v->qname_d[i]; q[6] = (uint32_t)(x == UZ_D16_ESC ? esc_find(i, 3) : x); }
+        }
+        if (v->pair_d8) { const uint32_t p = v->pair_d8[i]; q[9] = (p >= 1u && p <= UZ_P8_MAX_DIST) ? 1u : 0u; q[10] = (p == UZ_P8_SECOND || p == UZ_P8_SECOND_TLEN) ? 1u : 0u; }
+    }
+};
+} // namespace
+
+int uz_packed_block_sums(const uz_reads_packed_view *v, int threads, uint64_t *sums, int64_t *n_spans) {
+    if (!v || v->n_segs < 0) { last_error = "uz_packed_block_sums: bad view"; return UZ_IO_E_ARG; }
+    const int shift = UZ_PK_SHIFT(v->n_segs);
+    const int64_t nb = (v->n_segs + ((int64_t)1 << shift) - 1) >> shift;
+    if (n_spans) *n_spans = nb;
+    if (!sums) return 0;
+    return guarded([&] {
+        SumsView S{v, v->n_low != nullptr || (v->tup && v->tup_n_low)};
+        if (v->n_segs && !(v->tup ? (v->tup_l_seq && v->tup_n_cigar && v->tup_aux) : (v->l_seq && v->n_cigar && v->aux))) fail(UZ_IO_E_ARG, "uz_packed_block_sums: the small columns are missing");
+        if ((v->tlen_s || v->pair_d8) && !(v->start_d8 || v->start_d)) fail(UZ_IO_E_ARG, "uz_packed_block_sums: a difference form without its start column");
+        parallel_slices(nb, workers_for(nb, resolve_threads(threads), 16), [&](int64_t b0, int64_t b1, int) {
+            for (int64_t b = b0; b < b1; b++) {
+                uint64_t acc[UZ_PK_SUMS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                const int64_t i1 = std::min<int64_t>(v->n_segs, (b + 1) << shift);
+                for (int64_t i = b << shift; i < i1; i++) {
+                    uint32_t q[UZ_PK_SUMS];
+                    S.vals(i, q);
+                    for (int k = 0; k < UZ_PK_SUMS; k++) acc[k] += q[k];
+                }
+                for (int k = 0; k < UZ_PK_SUMS; k++) sums[UZ_PK_SUMS * (b + 1) + k] = acc[k]; // (row b + 1 for now: its own sums; scanned below)
+            }
+        });
+        for (int k = 0; k < UZ_PK_SUMS; k++) sums[k] = 0;
+        for (int64_t b = 1; b <= nb; b++)
+            for (int k = 0; k < UZ_PK_SUMS; k++) sums[UZ_PK_SUMS * b + k] += sums[UZ_PK_SUMS * (b - 1) + k];
+    });
+}

@@ -145,9 +145,7 @@ __global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
 // of the 100 k-DNM pass: 23 M records, 5.6 k spans; 1024 / 2048 measured slower there: more sums to scan), 1024 for a smaller one --
 // the 5 M records of a config-5 chunk are 1.2 k spans of 4096, five 256-lane workgroups per CU, and the pack pass ran at a third of
 // its rate per record.
-#define UZ_PK_SHIFT_LARGE 12
-#define UZ_PK_SHIFT_SMALL 10
-static inline int uz_pk_shift(int64_t n) { return (n >> UZ_PK_SHIFT_LARGE) >= 4096 ? UZ_PK_SHIFT_LARGE : UZ_PK_SHIFT_SMALL; }
+static inline int uz_pk_shift(int64_t n) { return UZ_PK_SHIFT(n); } // (uz_types.h: the packers cut their span sums the same way)
 // four running sums per record: CIGAR words, quality-plane units (every record), seq4 units (records with bases), listed
 // low-quality positions (list form of the staged plane: records with bases and at most UZ_QLOW_LIST_MAX of them; nl < 0: plane form)
 // ... and, fifth, the CIGAR words that travelled (cigar_compact: a record with a simple code owns none); sixth and seventh, the
@@ -155,7 +153,6 @@ static inline int uz_pk_shift(int64_t n) { return (n >> UZ_PK_SHIFT_LARGE) >= 40
 // modulo 2^32; pair form: the sixth counts the NEW names, a new name's id being the number of new names before it); eighth and
 // ninth, the row units and the listed bases of the records whose bases came as a list (bl_*: their units are laid out behind the
 // ones that travelled as rows); tenth and eleventh, the FIRST and SECOND records of the pair form (their totals must agree)
-#define UZ_PK_SUMS 11
 #define UZ_PK_SCANNED 9 // the running sums the header build needs per record (the last two are totals only)
 // um: which units of the record's rows were staged (UZ_UMASK_ALL: all of them)
 __device__ __forceinline__ void pk_vals(uint32_t nc, uint32_t ls, uint32_t aux, int nl, uint32_t um, uint32_t nb, uint32_t (&v)[UZ_PK_SUMS]) {
@@ -369,7 +366,7 @@ __global__ __launch_bounds__(256) void k_off_scan_sums(int64_t nb, unsigned long
 template <bool LINK, bool SELF>
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, PkWant want, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
-                                                  uint16_t *qs, int32_t *coarse, int32_t *hflags) {
+                                                  uint16_t *qs, int32_t *coarse, int32_t *hflags, int host_sums) {
     RecColumns c = uz_columns_of<LINK>(c_in);
     __shared__ uint32_t wsum[UZ_PK_SCANNED][4];
     __shared__ int64_t esc_span[2];
@@ -417,6 +414,12 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
 #pragma unroll
         for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + k];
     }
+    // host_sums: the offsets come from the packer (uz_types.h pk_sums; the host has checked that the rows ascend and end at the declared totals).
+    // Every record's variable-length parts must then end in front of the NEXT span's offsets -- nothing is read or written beyond the span's share
+    // -- and the span's own sums must add up to exactly that row: a packer that counted wrong is refused, whatever it counted.
+    unsigned long long nxt[UZ_PK_SCANNED];
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SCANNED; k++) nxt[k] = host_sums ? sums[UZ_PK_SUMS * ((size_t)blockIdx.x + 1) + k] : ~0ULL;
     // the dictionary index of the NEXT round's record is requested a round ahead: its table entries can then be fetched as soon as
     // the round begins, instead of after a round trip of their own
     uint32_t tp_next = 0;
@@ -453,7 +456,14 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
 #pragma unroll
             for (int w = 0; w < 4; w++) { if (w < wv) pre[k] += wsum[k][w]; tot[k] += wsum[k][w]; }
         }
-        if (in) {
+        bool fits = true;
+        if (host_sums && in) {
+#pragma unroll
+            for (int k = 0; k < UZ_PK_SCANNED; k++)
+                if (k != 5 && k != 6) fits &= run[k] + pre[k] + inc[k] <= nxt[k];
+            if (!fits) hflags[0] = 1;
+        }
+        if (in && fits) {
             RecA A;
             RecB B;
             // base rows: the units that travelled as rows in link order, then the units of the records whose bases came as a list
@@ -627,6 +637,12 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
 #pragma unroll
         for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] += tot[k];
     }
+    if (host_sums && t == 0) {
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < UZ_PK_SCANNED; k++) same &= run[k] == nxt[k];
+        if (!same) hflags[0] = 1;
+    }
 }
 
 // pair form: every FIRST record hands its mate (the SECOND it names) the link back, the name id and the template length
@@ -793,16 +809,21 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     want.bl_units = (unsigned long long)r.n_bl_units; want.bl = (unsigned long long)r.n_bl;
     static const bool no_link_build = getenv("UZ_BUILD_GENERIC") != nullptr; // (development aid: the general build of the two kernels for every table)
     const bool link_form = uz_link_form(col) && col.cigar_in != nullptr && !no_link_build;
-    if (link_form) hipLaunchKernelGGL((k_off_block_sums<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
+    // the span sums: from the packer (uz_types.h pk_sums: the two kernels below are not launched, k_pack_rec packs from the packer's offsets and holds
+    // every span against them), or counted here
+    static const bool no_host_sums = getenv("UZ_BUILD_OWN_SUMS") != nullptr; // (development aid: ignore the packer's)
+    const bool host_sums = col.pk_sums != nullptr && !no_host_sums;
+    if (host_sums) sums = const_cast<unsigned long long *>(col.pk_sums);
+    else if (link_form) hipLaunchKernelGGL((k_off_block_sums<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     else hipLaunchKernelGGL((k_off_block_sums<false>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     // a table of up to 4096 spans (a chunk of a staged pass: ~2 k): no scan kernel, every workgroup of the second pass adds up the sums in front
     // of its own block; a larger table (the resident 187 M-record one: 46 k spans) gets the one-workgroup scan
     static const bool no_self = getenv("UZ_BUILD_SCAN_KERNEL") != nullptr; // (development aid)
-    const bool self = nb <= 4096 && !no_self;
-    if (!self) hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(256), 0, st, (int64_t)nb, sums, want, c->hflags);
+    const bool self = nb <= 4096 && !no_self && !host_sums;
+    if (!self && !host_sums) hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(256), 0, st, (int64_t)nb, sums, want, c->hflags);
 #define UZ_PACK_LAUNCH(L, S)                                                                                                                              \
     hipLaunchKernelGGL((k_pack_rec<L, S>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, want, (RecA *)r.rec_a, \
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags)
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags, host_sums ? 1 : 0)
     if (link_form) { if (self) UZ_PACK_LAUNCH(true, true); else UZ_PACK_LAUNCH(true, false); }
     else { if (self) UZ_PACK_LAUNCH(false, true); else UZ_PACK_LAUNCH(false, false); }
 #undef UZ_PACK_LAUNCH

@@ -173,6 +173,7 @@ struct ReadsDev {
     // bases as lists (uz_types.h bl_*): the listed bases and the row units of the records that carry them (inside n_seq_units: their units
     // lie behind the n_seq_units - n_bl_units that travelled as rows); bl_n / tup_n_bl / bl_pos / bl_code for the deferred header build
     int64_t n_bl = 0, n_bl_units = 0;
+    const void *col_pk = nullptr; // pk_sums of RecColumns, for the deferred header build
     const void *col_b[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t col_bwide = 0;
 };
@@ -357,6 +358,8 @@ struct RecColumns {
     const uint32_t *plane_in = nullptr;
     const uint8_t *n_low = nullptr, *qlow_pos = nullptr;
     int32_t qpos_wide = 0;
+    // the span sums from the packer (uz_types.h pk_sums: [(spans + 1) * UZ_PK_SUMS], exclusive): null -- the header build computes them itself
+    const unsigned long long *pk_sums = nullptr;
 };
 // Small transfers on the COMPUTE path go through a copy kernel, one side in pinned host memory, never through
 // hipMemcpyAsync: the DMA engine is in order, and a 2 KB result copy queued behind gigabytes of staged uploads would hold

@@ -250,6 +250,19 @@ class HipEngine:
         pool = self._stage_pool
         pool.keep = True
         rid = None
+        if os.environ.get("UZ_INFLATE", "device") == "device" and os.environ.get("UZ_WALK", "device") == "device":
+            # the record walk on the device (include/uz_bamwalk.h; stage_reads has the chunked form): blocks inflated, checked and walked in HBM, the
+            # joins here on descriptors, the table unpacked where the records lie.  UZ_WALK=host: the link form below
+            if self._inflate_bufs is None:
+                self._inflate_bufs = PinnedPair()
+            pair = self._inflate_bufs
+            pair.start()
+            kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=lambda plan: self.bam_walk(plan, alloc=pair.alloc), all_bases=bool(all_bases),
+                                 alloc=pair.alloc, extra=fex, release=self.bam_walk_release)
+            rid = self.reads_from_bam(kb, names=True)
+            names = type("StagedNames", (), {})()
+            names.qnames, names.io_stats, names.timing = kb.qnames, kb.io_stats, kb.timing
+            return rid, names
         try:
             inflate = inflate_alloc = None
             if os.environ.get("UZ_INFLATE", "device") == "device":  # the batch's BGZF blocks inflated on the device (UZ_INFLATE=host: by the host's cores)

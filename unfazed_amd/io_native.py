@@ -33,7 +33,7 @@ IO_EXPORTS = [
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
-    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records",
+    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums",
 ]
 
 
@@ -185,6 +185,7 @@ def load():
     lib.uz_stage_walk_host.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.uz_stage_kept_debug.argtypes = [C.c_void_p] * 5
     lib.uz_stage_name_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.uz_packed_block_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _LIB = lib
     return lib
 
@@ -548,10 +549,12 @@ class ReadsSource:
                                         n_esc16=int((self.lib.uz_select_n_esc16_pair8 if pair8 else self.lib.uz_select_n_esc16_narrow8 if (start8 and narrow8)
                                                      else self.lib.uz_select_n_esc16_start8 if start8 else self.lib.uz_select_n_esc16)(sel)) if d16 else None,
                                         start8=bool(d16 and start8), narrow8=bool(d16 and start8 and narrow8), pair8=pair8,
-                                        n_bl=n_bl if n_bl >= 0 else None, n_bl_units=int(self.lib.uz_select_n_bl_units(sel)), bl_wide=bool(self.lib.uz_select_bl_wide(sel)))
+                                        n_bl=n_bl if n_bl >= 0 else None, n_bl_units=int(self.lib.uz_select_n_bl_units(sel)), bl_wide=bool(self.lib.uz_select_bl_wide(sel)),
+                                        pk_sums=_PK_SUMS)
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
+            block_sums(out, self.threads)  # (the span sums the device's header build packs from: uz_types.h pk_sums)
             out.qname_map = None
             if pair8:
                 out.qname_map = np.zeros(max(1, int(self.lib.uz_select_n_new_names(sel))), np.uint32)
@@ -639,6 +642,21 @@ assert WALK_DESC.itemsize == 64 and KEPT_REC.itemsize == 32
 WALK_TASK_COLS, WALK_SPAN_COLS = 10, 6
 KEPT_NO_SEQ = 0xFFFFFFFF
 WALK_SRC_AUX = 1 << 63
+
+
+_PK_SUMS = os.environ.get("UZ_PK_SUMS", "1") != "0"  # the packers hand the device the span sums of what they packed (UZ_PK_SUMS=0: the device computes them)
+
+
+def block_sums(held: "abi.Held", threads: int = 0) -> "abi.Held":
+    """The span sums of a filled packed view (uz_packed_block_sums) into its pk_sums array (abi.packed_view_alloc(pk_sums=True)): the device's header
+    build then packs from them instead of computing them in a pass of its own.  A view without the array is returned as it is."""
+    if "pk_sums" not in held.arrays:
+        return held
+    lib = load()
+    nb = C.c_int64(0)
+    _check(lib, lib.uz_packed_block_sums(held.ref(), int(threads), held.arrays["pk_sums"].ctypes.data, C.byref(nb)))
+    assert int(nb.value) == int(held.view.n_pk_spans)
+    return held
 
 
 def stage_kept_debug(lib, stage_ptr, n: int):
@@ -765,7 +783,7 @@ class BamSource:
         n, n_cig, n_om, n_units, n_seq, n_exc, n_qpos, wide, n_tup, n_esc, n_names, has_um, has_bl, n_bl, n_blu = (int(x) for x in z[:15])
         if pool is not None:  # the sizes are known now: one block for all the columns (each 256-byte aligned)
             total = (n * 5 + n_cig * 4 + n_seq * 8 + n_exc * 7 + n_qpos * 2 + n_esc * 12 + n_tup * 13 + len(self.contigs) * 12 + (0 if lists else n_units * 4)
-                     + n_bl * 3 + 44 * 256 + 4096)
+                     + n_bl * 3 + 44 * 256 + 4096 + (abi.pk_spans(n) + 1) * 8 * abi.PK_SUMS + 256)
             if not (getattr(pool, "keep", False) and pool.rewind(total)):  # (a kept pool: its block is re-used when it is large enough)
                 if getattr(pool, "keep", False):
                     pool.free_all()
@@ -775,8 +793,9 @@ class BamSource:
         out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
                                     n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
                                     cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True, pair8=True,
-                                    n_bl=n_bl if has_bl else None, n_bl_units=n_blu, bl_wide=bool(wide) and bool(has_bl))
+                                    n_bl=n_bl if has_bl else None, n_bl_units=n_blu, bl_wide=bool(wide) and bool(has_bl), pk_sums=_PK_SUMS)
         _check(self.lib, self.lib.uz_stage_fill(sh.ptr, int(self.threads), out.ref()))
+        block_sums(out, self.threads)  # (the span sums the device's header build packs from: uz_types.h pk_sums)
         io = (C.c_int64 * 8)()
         self.lib.uz_stage_io_stats(sh.ptr, io)
         tm = (C.c_double * 6)()
