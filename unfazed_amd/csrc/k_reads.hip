@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
     if (host_sums && t == 0) {
         bool same = true;
 #pragma unroll
-        for (int k = 0; k < UZ_PK_SCANNED; k++) same &= run[k] == nxt[k];
+        for (int k = 0; k < UZ_PK_SCANNED; k++) same &= (k == 5 || k == 6) ? (uint32_t)run[k] == (uint32_t)nxt[k] : run[k] == nxt[k]; // (the two difference columns count modulo 2^32)
         if (!same) hflags[0] = 1;
     }
 }
