@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
                     "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 3)")
     ap.add_argument("--sites16", action="store_true", help="staged pass: the genotype columns of the site windows in 16 bits (default: the eight-bit link form)")
-    ap.add_argument("--first-chunk", type=float, default=1.0, help="size of the first chunk of the staged pass relative to the others")
+    ap.add_argument("--first-chunk", type=float, default=None, help="size of the first chunk of the staged pass relative to the others (default: shard.chunk_plan's 0.5)")
     ap.add_argument("--last-chunk", type=float, default=0.7, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")

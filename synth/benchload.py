@@ -129,7 +129,7 @@ class BenchLoad:
         pool.end_slab()
         return abi.Held(svk, hs_k), hs_k, hg_k, wide_k, int(sel.size)
 
-    def stage(self, eng, P, mode, fid, pool, chunks=None, last_chunk=0.7, first_chunk=1.0, sites16=False, per_chunk_sites=True, log_first=False):
+    def stage(self, eng, P, mode, fid, pool, chunks=None, last_chunk=0.7, first_chunk=None, sites16=False, per_chunk_sites=True, log_first=False):
         """What the decoders would leave in pinned memory for a staged pass: per chunk of DNMs (whole clusters) the records the chunk's fetches
         return + their mates, in the link form (selected on the host out of the generator's table), and the site windows.
         -> (chunks for pipeline.run_pipelined, stats)"""

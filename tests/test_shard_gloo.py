@@ -137,10 +137,11 @@ def test_chunk_plan_of_the_eight_gpu_strong_split():
     for r in range(8):
         cuts = shard.chunk_plan(b[r + 1] - b[r])
         assert cuts[0] == 0 and cuts[-1] == 12500 and len(cuts) == 4
-        assert abs((cuts[1] - cuts[0]) - (cuts[2] - cuts[1])) <= 1 and cuts[2] - cuts[1] > cuts[3] - cuts[2]  # the last chunk is the small one: nothing hides its read stage
+        # the ends are the small ones: nothing hides the first chunk's copy and header build, nor the last chunk's read stage
+        assert cuts[1] - cuts[0] < cuts[2] - cuts[1] > cuts[3] - cuts[2] and abs(2 * (cuts[1] - cuts[0]) - (cuts[2] - cuts[1])) <= 2
     one = shard.chunk_plan(100000)
-    assert len(one) == 7 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))  # six chunks for the 100 k of one GPU
-    assert min(y - x for x, y in zip(one[:-1], one[1:-1])) >= 10000
+    assert len(one) == 8 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))  # seven chunks for the 100 k of one GPU, the first half-size
+    assert min(y - x for x, y in zip(one[1:-1], one[2:-1])) >= 10000 and 2 * one[1] - (one[2] - one[1]) in (-2, -1, 0, 1, 2)
     assert shard.chunk_plan(0) == [0, 0] and shard.chunk_plan(1) == [0, 1] and shard.chunk_plan(3, 8)[-1] == 3
     assert shard.chunk_plan(100000, 16)[-1] == 100000 and len(shard.chunk_plan(100000, 16)) == 17
 

@@ -13,7 +13,7 @@ def shard_bounds(n: int, world: int) -> List[int]:
     return [(n * r) // world for r in range(world + 1)]
 
 
-def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, min_per_chunk: int = 16000, first_chunk: float = 1.0) -> List[int]:
+def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, min_per_chunk: int = 16000, first_chunk: Optional[float] = None) -> List[int]:
     """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k, so a shard wants at
     least three chunks (the first chunk's upload and the last chunk's read stage are the two things nothing hides), and chunks of at
     least ~min_per_chunk DNMs (every chunk costs a host round trip and ~40 kernel launches).  The last chunk is smaller (last_chunk x
@@ -24,7 +24,13 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, mi
     15.7 / 16.5 / 17.3 ms), a 12.5 k shard of an 8-GPU run -> 3 (2 / 3 / 4 / 5 chunks = 3.03 / 2.91 / 3.02 / 3.19 ms; 100 k: 6 / 8 / 10 / 12 / 16 = 14.5 / 14.2 / 14.3 / 14.6 / 15.5 ms with the header build on its own stream).  -> [0, ..., n]"""
     if n <= 0:
         return [0, 0]
-    k = int(chunks) if chunks else max(3, n // int(min_per_chunk))
+    # The first chunk half the size of the others (its copy and header build are what nothing hides; with the span sums from the packer the header
+    # build is short enough for that to pay: 12.5 k shard 2.45 -> 2.36 ms, config 5 4.63 -> 4.53, 100 k: 6 chunks / 1.0 = 11.45, 6 / 0.5 = 11.69,
+    # 7 / 0.5 = 11.07 ms on one box) -- and one chunk more than n / min_per_chunk when there are four or more, so that the others keep their size.
+    k0 = n // int(min_per_chunk)
+    k = int(chunks) if chunks else max(3, k0 + (1 if k0 >= 4 else 0))
+    if first_chunk is None:
+        first_chunk = 0.5
     k = max(1, min(k, n))
     f = min(1.0, max(0.05, float(last_chunk)))
     g = min(1.0, max(0.05, float(first_chunk))) if k >= 3 else 1.0
