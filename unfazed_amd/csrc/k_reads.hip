@@ -363,6 +363,19 @@ __global__ __launch_bounds__(256) void k_off_scan_sums(int64_t nb, unsigned long
 // SELF: `sums` holds the raw block sums (no scan kernel ran): every workgroup adds up the sums of the blocks before its own -- a table of a
 // few thousand spans costs each workgroup a few microseconds of L2 reads, where the one-workgroup scan kernel between the two passes waited
 // ~100 us for room beside the read stage's persistent workgroups; the last workgroup holds the totals against what the view declared.
+// pair form: FIRST record i hands its mate j (the SECOND it names) the link back, the name id and the template length
+__device__ __forceinline__ void uz_pair_link_one(int64_t i, int64_t j, const uint8_t *__restrict__ pair, const RecA *ra, RecB *rb, int32_t *hflags) {
+    if (atomicExch(&rb[j].mate, (int32_t)i) != -2) { hflags[0] = 8; return; } // not a SECOND record, or named twice
+    const RecA A = ra[i], M = ra[j];
+    if (pair[j] == UZ_P8_SECOND_TLEN) rb[i].tlen = -rb[j].tlen; // (the SECOND brought its own)
+    else {
+        const int32_t tl = (A.end > M.end ? A.end : M.end) - A.start;
+        rb[i].tlen = tl;
+        rb[j].tlen = -tl;
+    }
+    rb[j].qname = rb[i].qname;
+}
+
 template <bool LINK, bool SELF>
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, PkWant want, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
@@ -637,6 +650,21 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
 #pragma unroll
         for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] += tot[k];
     }
+    if (c.pair_d8) {
+        // the pairs that lie inside this span are joined here, by the workgroup that has just written both headers (they sit in its L2 lines); a FIRST
+        // whose SECOND belongs to the next span is left to k_pair_link, which then looks at the last 256 records of every span only
+        __syncthreads();
+        const int64_t s0 = (int64_t)blockIdx.x << c.pk_shift, s1 = s0 + ((int64_t)1 << c.pk_shift);
+        for (int it = 0; it < rounds; it++) {
+            const int64_t i = s0 + it * 256 + t;
+            if (i >= n) break;
+            const uint32_t p = c.pair_d8[i];
+            if (p < 1u || p > UZ_P8_MAX_DIST) continue;
+            const int64_t j = i + p;
+            if (j >= n || j >= s1) continue; // (beyond the table: flagged above; in the next span: k_pair_link)
+            uz_pair_link_one(i, j, c.pair_d8, ra, rb, hflags);
+        }
+    }
     if (host_sums && t == 0) {
         bool same = true;
 #pragma unroll
@@ -645,23 +673,17 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
     }
 }
 
-// pair form: every FIRST record hands its mate (the SECOND it names) the link back, the name id and the template length
-__global__ __launch_bounds__(256) void k_pair_link(int64_t n, const uint8_t *__restrict__ pair, const RecA *__restrict__ ra, RecB *rb, int32_t *hflags) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// pair form, across spans: a FIRST among the last 256 records of a span of the header build whose SECOND lies in the next span (the pairs inside a
+// span were joined by k_pack_rec's own workgroups; a mate lies at most UZ_P8_MAX_DIST = 252 records on)
+__global__ __launch_bounds__(256) void k_pair_link(int64_t n, int pk_shift, const uint8_t *__restrict__ pair, const RecA *__restrict__ ra, RecB *rb, int32_t *hflags) {
+    const int64_t s1 = ((int64_t)blockIdx.x + 1) << pk_shift;
+    const int64_t i = s1 - 256 + threadIdx.x;
+    if (i < 0 || i >= n) return;
     const uint32_t p = pair[i];
     if (p < 1u || p > UZ_P8_MAX_DIST) return;
     const int64_t j = i + p;
-    if (j >= n) return; // (flagged by the header build)
-    if (atomicExch(&rb[j].mate, (int32_t)i) != -2) { hflags[0] = 8; return; } // not a SECOND record, or named twice
-    const RecA A = ra[i], M = ra[j];
-    if (pair[j] == UZ_P8_SECOND_TLEN) rb[i].tlen = -rb[j].tlen; // (the SECOND brought its own)
-    else {
-        const int32_t tl = (A.end > M.end ? A.end : M.end) - A.start;
-        rb[i].tlen = tl;
-        rb[j].tlen = -tl;
-    }
-    rb[j].qname = rb[i].qname;
+    if (j >= n || j < s1) return; // (beyond the table: flagged by the header build; inside the span: done there)
+    uz_pair_link_one(i, j, pair, ra, rb, hflags);
 }
 
 // ---- ASCII uploads (uz_reads_upload): rows re-laid in the packed geometry ---------------------------------
@@ -828,7 +850,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     else { if (self) UZ_PACK_LAUNCH(false, true); else UZ_PACK_LAUNCH(false, false); }
 #undef UZ_PACK_LAUNCH
     if (col.pair_d8)
-        hipLaunchKernelGGL(k_pair_link, dim3((unsigned)((r.n + 255) / 256)), dim3(256), 0, st, (int64_t)r.n, col.pair_d8, (const RecA *)r.rec_a, (RecB *)r.rec_b,
+        hipLaunchKernelGGL(k_pair_link, dim3(nb), dim3(256), 0, st, (int64_t)r.n, (int)col.pk_shift, col.pair_d8, (const RecA *)r.rec_a, (RecB *)r.rec_b,
                            c->hflags);
     // the table arrived with two-bit base rows: expand them into seq4 (the units of list-form records, behind them, were written by
     // k_pack_rec); then the listed bases that are not A/C/G/T, of either kind of record
