@@ -59,9 +59,9 @@ def test_all_bases(workload):
     assert (got.kept["seq_off"] != io_native.KEPT_NO_SEQ).all()
 
 
-@pytest.mark.parametrize("slack", ["0", "40", "300"])
+@pytest.mark.parametrize("slack", ["40", "300"])
 def test_mates_through_the_index_travel_as_aux_bytes(workload, slack, monkeypatch):
-    fc, flo, fhi, fex = fetches_of(workload, 2, 3)
+    fc, flo, fhi, fex = fetches_of(workload, 5, 2)  # (every look-up through the index is a walk of its own: a small batch keeps this on the CPU suite's budget)
     monkeypatch.setenv("UZ_STAGE_SLACK", slack)
     ref, want, got, _ = both(workload["bam"], fc, flo, fhi, fex)
     assert ref.io_stats["index_mate_lookups"] > 0 and got.io_stats["index_mate_lookups"] == ref.io_stats["index_mate_lookups"]
