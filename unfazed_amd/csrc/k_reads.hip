@@ -430,9 +430,10 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
     // host_sums: the offsets come from the packer (uz_types.h pk_sums; the host has checked that the rows ascend and end at the declared totals).
     // Every record's variable-length parts must then end in front of the NEXT span's offsets -- nothing is read or written beyond the span's share
     // -- and the span's own sums must add up to exactly that row: a packer that counted wrong is refused, whatever it counted.
-    unsigned long long nxt[UZ_PK_SCANNED];
-#pragma unroll
-    for (int k = 0; k < UZ_PK_SCANNED; k++) nxt[k] = host_sums ? sums[UZ_PK_SUMS * ((size_t)blockIdx.x + 1) + k] : ~0ULL;
+    // (the next row sits in LDS: eighteen registers less across the record loop)
+    __shared__ unsigned long long nxt[UZ_PK_SCANNED];
+    if (t < UZ_PK_SCANNED) nxt[t] = host_sums ? sums[UZ_PK_SUMS * ((size_t)blockIdx.x + 1) + t] : ~0ULL;
+    __syncthreads();
     // the dictionary index of the NEXT round's record is requested a round ahead: its table entries can then be fetched as soon as
     // the round begins, instead of after a round trip of their own
     uint32_t tp_next = 0;
