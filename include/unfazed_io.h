@@ -257,8 +257,8 @@ int uz_io_cpu_quota(void);            /* CPUs the container's cgroup grants (cpu
 #define UZ_STAGE_UNIT_MASKS 2 /* only the 32-base units that hold a fetched position (+ extra[f] bases on) are staged */
 #define UZ_STAGE_PLANE 4      /* qualities as the one-bit plane instead of lists (no unit masks then) */
 #define UZ_STAGE_WIDE_NO_UNITS 8 /* with unit masks: a fetch wider than two bases stages no unit (SV batches; uz_reads_select_plan: unit_masks = 3) */
-#define UZ_STAGE_SMALL_TASKS 32 /* the plan is made for the device's walk (uz_stage_walk_plan: one wavefront per task): walk tasks of at most 256 KB of
-                                 * compressed bytes instead of 768 -- more, shorter chains of records */
+#define UZ_STAGE_SMALL_TASKS 32 /* the plan is made for the device's walk (uz_stage_walk_plan: one wavefront per task): the walk plan cuts the stage's
+                                 * tasks into sub-tasks of ~32 kb of reach (uz_stage_merge_subtasks joins what comes back) */
 #define UZ_STAGE_BASE_LISTS 16  /* with unit masks: a record whose fetches name single positions sends those bases as a list instead of the
                                  * units they lie in (uz_types.h: bl_*; uz_reads_select_plan: unit_masks & 4) */
 /* fetches (tid, lo, hi[, extra]) as staging.fetch_points lists them; min_base_qual = --min-gt-qual.  UZ_IO_E_RANGE when the batch
@@ -308,6 +308,12 @@ void uz_stage_walk_plan_sizes(const uz_stage *s, int64_t out[8]);
 int uz_stage_walk_plan(uz_stage *s, int32_t *task /* [UZ_WALK_TASK_COLS n_tasks] */, int64_t *span /* [UZ_WALK_SPAN_COLS n_spans] */,
                        int32_t *reach /* [2 n_reach] */, int32_t *fetch /* [3 n_fetch] */, int64_t *blk_coff /* [n_blocks] */,
                        uint32_t *blk_crc /* [n_blocks] the CRC-32 in every gathered block's footer, or NULL */);
+/* Under UZ_STAGE_SMALL_TASKS the walk plan's tasks are SUB-TASKS of the stage's own (groups of a task's reach intervals of at most ~32 kb, each starting its
+ * walk where the file's linear index puts the first record of its first 16 kb window: more, shorter chains of records for the device, the same blocks):
+ * uz_stage_walk_plan_sizes [0] counts them ([5]: the stage's tasks), and uz_stage_merge_subtasks joins their descriptors per task of the stage, in place --
+ * a record that two neighbouring sub-tasks met is kept once -- for uz_bam_stage_finish_desc. */
+int uz_stage_merge_subtasks(const uz_stage *s, uz_walk_desc *d, const int64_t *d_first /* [n_sub + 1] */, const int32_t *d_flags, const int64_t *d_walked,
+                            int64_t *h_first /* [n_tasks + 1] */, int32_t *h_flags /* [n_tasks] */, int64_t *h_walked /* [n_tasks] */);
 int uz_bam_stage_finish_desc(uz_stage *s, const uz_walk_desc *d, const int64_t *d_first /* [n_tasks + 1] */, const int32_t *d_flags /* [n_tasks] or NULL */,
                              const int64_t *d_walked /* [n_tasks] or NULL */);
 /* the host's twin of the device's walk: the same descriptors from the host's own walk (out == NULL: the counts only) */

@@ -478,7 +478,14 @@ struct uz_stage {
     int threads = 0;
     bool begun = false, finished = false;
     std::vector<std::vector<uz_walk_desc>> twin; // uz_stage_walk_host: the host's twin of the device's walk, task by task
-    bool small_tasks = false; // UZ_STAGE_SMALL_TASKS: the plan is made for the device's walk
+    // UZ_STAGE_SMALL_TASKS: the plan is made for the device's walk (one wavefront per walk task).  The host's tasks stay as they are -- their blocks are
+    // gathered and inflated once -- but the walk plan cuts each into SUB-TASKS, groups of its reach intervals of at most ~32 kb: a sub-task starts
+    // its walk where the linear index puts the first record of its first window (a record boundary the file's index vouches for) and stops at the
+    // end of its last interval.  More, shorter chains of records for the device, not one more block to inflate.
+    bool small_tasks = false;
+    struct SubTask { int32_t host, r0, r1, s0, tb; uint64_t beg; };
+    std::vector<SubTask> subs;       // built by the walk plan (build_subtasks)
+    std::vector<uint8_t> sub_preflag; // per host task: a sub-task starts in a block the gather did not list -- the host walks the task itself
     bool desc = false; // the descriptor route (uz_bam_stage_finish_desc): the walk ran on the device, the host holds no record bytes
     const uint8_t *inflated = nullptr;
     int64_t n_pre_blocks = 0, pre_bytes = 0;
@@ -814,10 +821,11 @@ void plan_begin(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t 
             if (T.spans.empty()) continue; // the index knows no record there
             Task *L = merged.empty() ? nullptr : &merged.back();
             // (up to a size: a file that holds nothing but the fetched windows would chain into one task per reference)
-            // (compressed bytes.  A plan made for the device's walk -- one wavefront per task -- takes smaller tasks: 64 / 128 / 256 / 768 KB = 43 / 50 / 69 / 66 k
-            // DNMs/s in the feed pass; every cut has the tasks on both sides gather the blocks around it, 22 % more blocks at 256 KB, 78 % at 128)
+            // (compressed bytes.  Smaller tasks for the device's walk -- one wavefront per task -- were tried: 64 / 128 / 256 / 768 KB = 43 / 50 / 69 / 66 k DNMs/s
+            // in the feed pass; every cut has the tasks on both sides gather the blocks around it, 22 % more blocks at 256 KB, 78 % at 128.  The walk plan
+            // cuts the tasks into sub-tasks instead, without touching what is gathered: uz_stage::subs)
             static const int env_kb = getenv("UZ_STAGE_MAX_TASK_KB") ? std::max(16, atoi(getenv("UZ_STAGE_MAX_TASK_KB"))) : 0; // (development aid)
-            const uint64_t MAX_TASK_BYTES = (uint64_t)(env_kb ? env_kb : P.small_tasks ? 256 : 768) << 10;
+            const uint64_t MAX_TASK_BYTES = (uint64_t)(env_kb ? env_kb : 768) << 10;
             if (L && L->tid == T.tid && (T.spans.front().beg >> 16) <= (L->est_end >> 16) &&
                 (std::max(T.est_end, L->est_end) >> 16) - (L->spans.front().beg >> 16) <= MAX_TASK_BYTES) {
                 std::vector<Chunk> all(L->spans);
@@ -1579,19 +1587,61 @@ int64_t uz_stage_qnames(const uz_stage *P, const uint32_t *ids, int64_t n, char 
 }
 
 // ---- the descriptor route (uz_bamwalk.h): the walk runs on the device, the batch-wide joins here
+namespace {
+// The device's walk tasks (uz_stage::subs).  Without UZ_STAGE_SMALL_TASKS: the host's tasks as they are.  With it: every group of a task's reach
+// intervals that spans at most SUB_EXTENT bases is a task of its own.  Its walk starts where the file's linear index puts the first record that
+// overlaps the 16 kb window its first interval begins in -- every record overlapping the group lies at or behind that offset -- and stops at the
+// first record that starts at or behind the end of its last interval, as the host's walk of the whole task would.  A record that reaches from one
+// group into the next is met by both: uz_stage_merge_subtasks drops the later copy (it starts in front of the earlier group's stop).
+void build_subtasks(uz_stage &P) {
+    if (!P.subs.empty() || P.tasks.empty()) return;
+    const int32_t SUB_EXTENT = 32768;
+    P.sub_preflag.assign(P.tasks.size(), 0);
+    for (size_t i = 0; i < P.tasks.size(); i++) {
+        const Task &T = P.tasks[i];
+        const BaiRef &ref = P.src->refs[(size_t)T.tid];
+        const int32_t nr = (int32_t)T.reach.size();
+        int32_t g0 = 0;
+        for (int32_t k = 1; k <= nr; k++) {
+            if (k < nr && (!P.small_tasks || T.reach[(size_t)k].second - T.reach[(size_t)g0].first <= SUB_EXTENT)) continue;
+            uz_stage::SubTask S;
+            S.host = (int32_t)i; S.r0 = g0; S.r1 = k; S.s0 = 0;
+            S.tb = k == nr ? T.b : T.reach[(size_t)k - 1].second;
+            S.beg = T.spans.empty() ? 0 : T.spans.front().beg;
+            if (g0 > 0 && !T.spans.empty()) { // (the task's first group starts where the task starts)
+                const size_t w = (size_t)(std::max<int64_t>(T.reach[(size_t)g0].first, 0) >> 14);
+                uint64_t off = ref.linear.empty() ? 0 : ref.linear[std::min(w, ref.linear.size() - 1)];
+                off = std::max(off, T.spans.front().beg);
+                size_t si = 0;
+                while (si + 1 < T.spans.size() && T.spans[si].end <= off) si++;
+                S.s0 = (int32_t)si;
+                S.beg = std::max(off, T.spans[si].beg);
+            }
+            P.subs.push_back(S);
+            g0 = k;
+        }
+        if (nr == 0) { uz_stage::SubTask S{(int32_t)i, 0, 0, 0, T.b, T.spans.empty() ? 0 : T.spans.front().beg}; P.subs.push_back(S); }
+    }
+}
+} // namespace
+
 void uz_stage_walk_plan_sizes(const uz_stage *P, int64_t out[8]) {
     memset(out, 0, 8 * sizeof(int64_t));
     if (!P) return;
-    out[0] = (int64_t)P->tasks.size();
-    for (const Task &T : P->tasks) { out[1] += (int64_t)T.spans.size(); out[2] += (int64_t)T.reach.size(); }
+    build_subtasks(*const_cast<uz_stage *>(P));
+    out[0] = (int64_t)P->subs.size();
+    for (const auto &S : P->subs) out[1] += (int64_t)P->tasks[(size_t)S.host].spans.size() - S.s0;
+    for (const Task &T : P->tasks) out[2] += (int64_t)T.reach.size();
     for (const auto &v : P->fx) out[3] += (int64_t)v.size();
     out[4] = P->n_pre_blocks;
+    out[5] = (int64_t)P->tasks.size();
 }
 
 int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach, int32_t *fetch, int64_t *blk_coff, uint32_t *blk_crc) {
     if (!P || !P->begun || P->finished || !task || !span || !reach || !fetch || !blk_coff) { last_error = "uz_stage_walk_plan: between uz_stage_gather_blocks and the finish, every array set"; return UZ_IO_E_ARG; }
     return guarded([&] {
         if (P->n_pre_blocks == 0 && P->pre_bytes == 0 && !P->tasks.empty()) fail(UZ_IO_E_ARG, "uz_stage_walk_plan: call uz_stage_gather_blocks first (the block table is laid out there)");
+        build_subtasks(*P);
         std::vector<int64_t> fbase(P->fx.size() + 1, 0);
         for (size_t t = 0; t < P->fx.size(); t++) {
             fbase[t + 1] = fbase[t] + (int64_t)P->fx[t].size();
@@ -1600,29 +1650,72 @@ int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach
                 f[0] = P->fx[t][k].lo; f[1] = P->fx[t][k].hi; f[2] = (int32_t)P->fx[t][k].extra;
             }
         }
-        int64_t si = 0, ri = 0, bi = 0;
+        // per host task: where its reach intervals and its blocks lie in the flat arrays
+        std::vector<int64_t> rbase(P->tasks.size() + 1, 0), bbase(P->tasks.size() + 1, 0);
         for (size_t i = 0; i < P->tasks.size(); i++) {
             const Task &T = P->tasks[i];
-            int32_t *tc = task + UZ_WALK_TASK_COLS * i;
-            tc[0] = T.tid; tc[1] = T.b; tc[2] = (int32_t)si; tc[3] = (int32_t)(si + (int64_t)T.spans.size());
-            tc[4] = (int32_t)ri; tc[5] = (int32_t)(ri + (int64_t)T.reach.size());
-            tc[6] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f0); tc[7] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f1);
-            tc[8] = P->fx_max_len[(size_t)T.tid]; tc[9] = 0;
-            for (const auto &r : T.reach) { reach[2 * ri] = r.first; reach[2 * ri + 1] = r.second; ri++; }
-            for (size_t k = 0; k < T.pre.size(); k++) { blk_coff[bi + (int64_t)k] = T.pre[k].coff; if (blk_crc) blk_crc[bi + (int64_t)k] = T.pre[k].crc; }
-            for (const Chunk &c : T.spans) {
+            rbase[i + 1] = rbase[i] + (int64_t)T.reach.size(); bbase[i + 1] = bbase[i] + (int64_t)T.pre.size();
+            for (size_t k = 0; k < T.reach.size(); k++) { reach[2 * (rbase[i] + (int64_t)k)] = T.reach[k].first; reach[2 * (rbase[i] + (int64_t)k) + 1] = T.reach[k].second; }
+            for (size_t k = 0; k < T.pre.size(); k++) { blk_coff[bbase[i] + (int64_t)k] = T.pre[k].coff; if (blk_crc) blk_crc[bbase[i] + (int64_t)k] = T.pre[k].crc; }
+        }
+        int64_t si = 0;
+        for (size_t u = 0; u < P->subs.size(); u++) {
+            const auto &S = P->subs[u];
+            const Task &T = P->tasks[(size_t)S.host];
+            const int64_t bi = bbase[(size_t)S.host];
+            int32_t *tc = task + UZ_WALK_TASK_COLS * u;
+            tc[0] = T.tid; tc[1] = S.tb; tc[2] = (int32_t)si; tc[3] = (int32_t)(si + (int64_t)T.spans.size() - S.s0);
+            tc[4] = (int32_t)(rbase[(size_t)S.host] + S.r0); tc[5] = (int32_t)(rbase[(size_t)S.host] + S.r1);
+            tc[6] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f0); tc[7] = (int32_t)(fbase[(size_t)T.tid] + (int64_t)T.f1); // (every fetch of the host task: a record of this group may be returned by a neighbour's)
+            tc[8] = P->fx_max_len[(size_t)T.tid]; tc[9] = S.host;
+            for (size_t sp = (size_t)S.s0; sp < T.spans.size(); sp++) {
+                const Chunk &c = T.spans[sp];
+                const uint64_t beg = sp == (size_t)S.s0 ? S.beg : c.beg;
                 int64_t *sc = span + UZ_WALK_SPAN_COLS * si++;
-                const int64_t c0 = (int64_t)(c.beg >> 16), stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16);
+                const int64_t c0 = (int64_t)(beg >> 16), stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16);
                 auto lo = std::lower_bound(T.pre.begin(), T.pre.end(), c0, [](const PreBlk &b, int64_t key) { return b.coff < key; });
                 auto hi = std::upper_bound(T.pre.begin(), T.pre.end(), stop, [](int64_t key, const PreBlk &b) { return key < b.coff; });
-                sc[0] = (int64_t)c.beg; sc[1] = (int64_t)c.end;
-                if (lo == T.pre.end() || lo->coff != c0 || hi <= lo) { sc[2] = sc[3] = 0; sc[4] = sc[5] = bi; continue; } // (no block there: the walk ends at once, as the host's)
-                sc[2] = lo->at + (int64_t)(c.beg & 0xFFFF);
+                sc[0] = (int64_t)beg; sc[1] = (int64_t)c.end;
+                if (lo == T.pre.end() || lo->coff != c0 || hi <= lo) { // no block there: the walk ends at once, as the host's does at the end of the file ...
+                    sc[2] = sc[3] = 0; sc[4] = sc[5] = bi;
+                    if (beg != c.beg) P->sub_preflag[(size_t)S.host] = 1; // ... but a sub-task that starts behind what was gathered says nothing: the host walks the task
+                    continue;
+                }
+                sc[2] = lo->at + (int64_t)(beg & 0xFFFF);
                 sc[3] = (hi - 1)->at + (int64_t)(hi - 1)->isize;
                 sc[4] = bi + (int64_t)(lo - T.pre.begin()); sc[5] = bi + (int64_t)(hi - T.pre.begin());
             }
-            bi += (int64_t)T.pre.size();
         }
+    });
+}
+
+/* The descriptors of the device's walk tasks (sub-tasks of the host's: uz_stage_walk_plan under UZ_STAGE_SMALL_TASKS) joined per host task, in place:
+ * the sub-tasks of a task in order, without the records a later sub-task met again (they start in front of the stop of the one before).  In:
+ * d [d_first[n_sub]], d_first [n_sub + 1], d_flags / d_walked [n_sub]; out: d compacted, h_first [n_tasks + 1], h_flags / h_walked [n_tasks]. */
+int uz_stage_merge_subtasks(const uz_stage *P, uz_walk_desc *d, const int64_t *d_first, const int32_t *d_flags, const int64_t *d_walked, int64_t *h_first,
+                            int32_t *h_flags, int64_t *h_walked) {
+    if (!P || !d_first || !h_first || !h_flags || !h_walked) { last_error = "uz_stage_merge_subtasks: null argument"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        const size_t nt = P->tasks.size();
+        for (size_t i = 0; i < nt; i++) { h_flags[i] = P->sub_preflag.empty() ? 0 : (P->sub_preflag[i] ? UZ_WALK_TASK_INCOMPLETE : 0); h_walked[i] = 0; }
+        for (size_t u = 0; u < P->subs.size(); u++) { h_flags[(size_t)P->subs[u].host] |= d_flags ? d_flags[u] : 0; h_walked[(size_t)P->subs[u].host] += d_walked ? d_walked[u] : 0; }
+        int64_t out = 0;
+        size_t u = 0;
+        for (size_t i = 0; i < nt; i++) {
+            h_first[i] = out;
+            int32_t stop_before = INT32_MIN;
+            for (; u < P->subs.size() && (size_t)P->subs[u].host == i; u++) {
+                if (!h_flags[i])
+                    for (int64_t j = d_first[u]; j < d_first[u + 1]; j++) {
+                        if (d[j].pos < stop_before) continue; // (the sub-task before walked it, and kept it: it overlaps an interval of this one, so it lay in reach there too)
+                        uz_walk_desc x = d[j];
+                        x.task = (uint32_t)i;
+                        d[out++] = x;
+                    }
+                stop_before = P->subs[u].tb;
+            }
+        }
+        h_first[nt] = out;
     });
 }
 
@@ -1687,31 +1780,56 @@ int uz_stage_walk_host(uz_stage *P, uz_walk_desc *out, int64_t cap, int64_t *d_f
     return guarded([&] {
         const size_t nt = P->tasks.size();
         if (P->twin.size() != nt) {
-            P->twin.assign(nt, {});
+            // the device's walk tasks (the host's tasks, or their sub-tasks under UZ_STAGE_SMALL_TASKS), each walked by the host's own walk_task on a task
+            // of its own -- then joined per host task exactly as the device's descriptors are (uz_stage_merge_subtasks)
+            build_subtasks(*P);
+            const size_t ns = P->subs.size();
+            std::vector<std::vector<uz_walk_desc>> part(ns);
+            std::vector<int64_t> walked(ns, 0);
             P->desc = true;
-            const int w = (int)std::min<int64_t>(std::max(1, P->threads), std::max<int64_t>(1, (int64_t)nt));
+            const int w = (int)std::min<int64_t>(std::max(1, P->threads), std::max<int64_t>(1, (int64_t)ns));
             std::vector<std::unique_ptr<Scratch>> scr((size_t)w);
-            parallel_dynamic((int64_t)nt, w, [&](int64_t i, int k) {
+            parallel_dynamic((int64_t)ns, w, [&](int64_t u, int k) {
                 if (!scr[(size_t)k]) scr[(size_t)k].reset(new Scratch());
-                Task &T = P->tasks[(size_t)i];
+                const auto &S = P->subs[(size_t)u];
+                const Task &H = P->tasks[(size_t)S.host];
                 Scratch &W = *scr[(size_t)k];
-                walk_task(*P, T, W, (size_t)i, false);
-                auto &v = P->twin[(size_t)i];
+                Task T; // the sub-task as a task of its own
+                T.tid = H.tid; T.b = S.tb; T.f0 = H.f0; T.f1 = H.f1; T.est_end = H.est_end; T.by_hash = true;
+                T.reach.assign(H.reach.begin() + S.r0, H.reach.begin() + S.r1);
+                T.a = T.reach.empty() ? H.a : T.reach.front().first;
+                for (size_t sp = (size_t)S.s0; sp < H.spans.size(); sp++) T.spans.push_back(Chunk{sp == (size_t)S.s0 ? S.beg : H.spans[sp].beg, H.spans[sp].end});
+                walk_task(*P, T, W, (size_t)S.host, false);
+                walked[(size_t)u] = T.n_walked;
+                auto &v = part[(size_t)u];
                 v.reserve(W.all.size());
                 for (const WRec &r : W.all) {
                     uz_walk_desc x;
                     memset(&x, 0, sizeof(x));
                     x.voff = r.voff; x.h1 = r.nhash; x.h2 = r.nhash2;
                     const int64_t coff = (int64_t)(r.voff >> 16);
-                    auto it = std::lower_bound(T.pre.begin(), T.pre.end(), coff, [](const PreBlk &b, int64_t key) { return b.coff < key; });
-                    x.src = (it != T.pre.end() && it->coff == coff) ? (uint64_t)(it->at + (int64_t)(r.voff & 0xFFFF) + 4) : ~0ULL; // (a block the gather did not list)
+                    auto it = std::lower_bound(H.pre.begin(), H.pre.end(), coff, [](const PreBlk &b, int64_t key) { return b.coff < key; });
+                    x.src = (it != H.pre.end() && it->coff == coff) ? (uint64_t)(it->at + (int64_t)(r.voff & 0xFFFF) + 4) : ~0ULL; // (a block the gather did not list)
                     x.pos = r.pos; x.end = r.end; x.tlen = r.tlen; x.mpos = r.mpos; x.mtid = r.mtid;
-                    x.task = (uint32_t)i; x.flag = r.flag; x.l_seq = r.l_seq; x.n_cigar = r.n_cigar; x.mapq = r.mapq; x.l_name = r.l_name;
+                    x.task = (uint32_t)u; x.flag = r.flag; x.l_seq = r.l_seq; x.n_cigar = r.n_cigar; x.mapq = r.mapq; x.l_name = r.l_name;
                     x.direct = r.keep == 2;
                     v.push_back(x);
                 }
-                T.raw.clear(); T.recs.clear();
             });
+            std::vector<int64_t> sf(ns + 1, 0);
+            for (size_t u = 0; u < ns; u++) sf[u + 1] = sf[u] + (int64_t)part[u].size();
+            std::vector<uz_walk_desc> flat((size_t)sf[ns] + 1);
+            for (size_t u = 0; u < ns; u++)
+                if (!part[u].empty()) memcpy(flat.data() + sf[u], part[u].data(), part[u].size() * sizeof(uz_walk_desc));
+            std::vector<int64_t> hf(nt + 1, 0), hw(nt, 0);
+            std::vector<int32_t> hfl(nt, 0), zero(ns, 0);
+            const std::vector<uint8_t> keep_flags = P->sub_preflag;
+            std::fill(P->sub_preflag.begin(), P->sub_preflag.end(), 0); // (the host's own walk reads any block: nothing is handed back here)
+            const int rc = uz_stage_merge_subtasks(P, flat.data(), sf.data(), zero.data(), walked.data(), hf.data(), hfl.data(), hw.data());
+            P->sub_preflag = keep_flags;
+            if (rc) fail(rc, "%s", last_error.c_str());
+            P->twin.assign(nt, {});
+            for (size_t i = 0; i < nt; i++) { P->twin[i].assign(flat.begin() + hf[i], flat.begin() + hf[i + 1]); P->tasks[i].n_walked = hw[i]; }
         }
         d_first[0] = 0;
         for (size_t i = 0; i < nt; i++) { d_first[i + 1] = d_first[i] + (int64_t)P->twin[i].size(); if (d_walked) d_walked[i] = P->tasks[i].n_walked; }

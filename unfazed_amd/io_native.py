@@ -33,7 +33,7 @@ IO_EXPORTS = [
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
-    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums",
+    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums", "uz_stage_merge_subtasks",
 ]
 
 
@@ -186,6 +186,7 @@ def load():
     lib.uz_stage_kept_debug.argtypes = [C.c_void_p] * 5
     lib.uz_stage_name_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.uz_packed_block_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.uz_stage_merge_subtasks.argtypes = [C.c_void_p] * 8
     _LIB = lib
     return lib
 
@@ -837,7 +838,7 @@ class BamSource:
             _check(self.lib, self.lib.uz_stage_gather_blocks(sh.ptr, comp.ctypes.data, int(cb.value), in_off.ctypes.data, out_off.ctypes.data, None, None, None))
         z = (C.c_int64 * 8)()
         self.lib.uz_stage_walk_plan_sizes(sh.ptr, z)
-        nt, nsp, nr, nf, nblk = (int(x) for x in z[:5])
+        nt, nsp, nr, nf, nblk, n_host = (int(x) for x in z[:6])  # (nt: the device's walk tasks -- sub-tasks of the stage's n_host tasks under small_tasks)
         task = np.zeros((max(1, nt), WALK_TASK_COLS), np.int32)
         span = np.zeros((max(1, nsp), WALK_SPAN_COLS), np.int64)
         reach = np.zeros((max(1, nr), 2), np.int32)
@@ -849,14 +850,30 @@ class BamSource:
                     task=task[:nt], span=span[:nsp], reach=reach[:nr], fetch=fetch[:nf], blk_coff=blk_coff[:nblk], blk_crc=blk_crc[:nblk], n_ref=len(self.contigs))
         t1 = time.perf_counter()
         if walk is None:  # the host's twin
-            d_first, d_walked = np.zeros(nt + 1, np.int64), np.zeros(max(1, nt), np.int64)
+            d_first, d_walked = np.zeros(n_host + 1, np.int64), np.zeros(max(1, n_host), np.int64)
             _check(self.lib, self.lib.uz_stage_walk_host(sh.ptr, None, 0, d_first.ctypes.data, d_walked.ctypes.data))
             desc = np.zeros(max(1, int(d_first[-1])), WALK_DESC)
             _check(self.lib, self.lib.uz_stage_walk_host(sh.ptr, desc.ctypes.data, int(desc.size), d_first.ctypes.data, d_walked.ctypes.data))
             desc = desc[: int(d_first[-1])]
-            d_flags, token = np.zeros(max(1, nt), np.int32), None
+            d_flags, token = np.zeros(max(1, n_host), np.int32), None
         else:
             desc, d_first, d_flags, d_walked, token = walk(plan)
+            # the device walked the plan's tasks: joined per task of the stage (a record two neighbouring sub-tasks met is kept once)
+            d_first = np.ascontiguousarray(d_first, np.int64)
+            d_flags = np.ascontiguousarray(d_flags, np.int32)
+            d_walked = np.ascontiguousarray(d_walked, np.int64)
+            assert d_first.size == nt + 1
+            h_first, h_flags, h_walked = np.zeros(n_host + 1, np.int64), np.zeros(max(1, n_host), np.int32), np.zeros(max(1, n_host), np.int64)
+            desc = np.ascontiguousarray(desc)
+            try:
+                _check(self.lib, self.lib.uz_stage_merge_subtasks(sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data,
+                                                                  h_first.ctypes.data, h_flags.ctypes.data, h_walked.ctypes.data))
+            except BaseException:
+                if release is not None and token is not None:
+                    release(token)
+                raise
+            desc, d_first, d_flags, d_walked = desc[: int(h_first[-1])], h_first, h_flags[:n_host], h_walked[:n_host]
+        nt = n_host
         t2 = time.perf_counter()
         out = KeptBatch()
         out.token, out._release = token, release
