@@ -314,6 +314,8 @@ int uz_stage_walk_plan(uz_stage *s, int32_t *task /* [UZ_WALK_TASK_COLS n_tasks]
  * a record that two neighbouring sub-tasks met is kept once -- for uz_bam_stage_finish_desc. */
 int uz_stage_merge_subtasks(const uz_stage *s, uz_walk_desc *d, const int64_t *d_first /* [n_sub + 1] */, const int32_t *d_flags, const int64_t *d_walked,
                             int64_t *h_first /* [n_tasks + 1] */, int32_t *h_flags /* [n_tasks] */, int64_t *h_walked /* [n_tasks] */);
+int uz_bam_stage_finish_sub(uz_stage *s, const uz_walk_desc *d, const int64_t *d_first /* [n_sub + 1] */, const int32_t *d_flags /* [n_sub] or NULL */,
+                            const int64_t *d_walked /* [n_sub] or NULL */); /* = merge + uz_bam_stage_finish_desc, without the copy */
 int uz_bam_stage_finish_desc(uz_stage *s, const uz_walk_desc *d, const int64_t *d_first /* [n_tasks + 1] */, const int32_t *d_flags /* [n_tasks] or NULL */,
                              const int64_t *d_walked /* [n_tasks] or NULL */);
 /* the host's twin of the device's walk: the same descriptors from the host's own walk (out == NULL: the counts only) */

@@ -18,7 +18,7 @@ FIELDS = ("voff", "src", "h1", "pos", "end", "tlen", "mpos", "mtid", "h2", "task
 def walk_both(engine, bam, fc, flo, fhi, fex, all_bases=False):
     src = io_native.BamSource(bam, threads=3)
     twin = src.select_kept(fc, flo, fhi, 20, all_bases=all_bases, small_tasks=True)
-    dev = src.select_kept(fc, flo, fhi, 20, all_bases=all_bases, walk=engine.bam_walk)
+    dev = src.select_kept(fc, flo, fhi, 20, all_bases=all_bases, walk=engine.bam_walk, merge=True)  # (merge: the descriptors per task of the stage, as the twin's)
     return src, twin, dev
 
 

@@ -102,7 +102,7 @@ def test_a_task_the_device_flags_is_walked_by_the_host(workload):
         d_first = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         return plain.desc[keep].copy(), d_first, flags, np.zeros(nt, np.int64), None
 
-    got = src.select_kept(fc, flo, fhi, 20, walk=walk, small_tasks=False)  # (the stage's own tasks as walk tasks: `walk` hands back what `plain` walked)
+    got = src.select_kept(fc, flo, fhi, 20, walk=walk, small_tasks=False, merge=True)  # (the stage's own tasks as walk tasks: `walk` hands back what `plain` walked)
     in_aux = check(ref, want, got)
     assert in_aux.any() and got.host_tasks > 0
 

@@ -852,8 +852,10 @@ void plan_begin(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t 
 // second half of the plan: walk, mates, numbering
 // d (descriptor route): the device's walk of every task -- its records inside the reach intervals, file order, task by task
 // (d_first[t] .. d_first[t + 1]); a task flagged there is walked here as well
+// by_sub: d_first / d_walked count the walk plan's SUB-tasks (uz_stage::subs; d_flags stays per task of the stage): a task's records are its
+// sub-tasks' in order, without those a later sub-task met again (uz_stage_merge_subtasks states the rule; here nothing is copied)
 void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_first = nullptr, const int32_t *d_flags = nullptr,
-                 const int64_t *d_walked = nullptr) {
+                 const int64_t *d_walked = nullptr, bool by_sub = false) {
     const uz_bamsrc &S = *P.src;
     const int32_t n_ref = (int32_t)S.contigs.size();
     const int threads = P.threads;
@@ -862,6 +864,12 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
     {
         const int w = (int)std::min<int64_t>(threads, std::max<int64_t>(1, (int64_t)P.tasks.size()));
         std::vector<std::unique_ptr<Scratch>> scr((size_t)w);
+        std::vector<size_t> sub_of_task; // by_sub: the first sub-task of every task of the stage (they lie in order)
+        if (by_sub) {
+            sub_of_task.assign(P.tasks.size() + 1, P.subs.size());
+            for (size_t u = P.subs.size(); u-- > 0;) sub_of_task[(size_t)P.subs[u].host] = u;
+            for (size_t i = P.tasks.size(); i-- > 0;) sub_of_task[i] = std::min(sub_of_task[i], sub_of_task[i + 1]);
+        }
         parallel_dynamic((int64_t)P.tasks.size(), w, [&](int64_t i, int k) {
             if (!scr[(size_t)k]) scr[(size_t)k].reset(new Scratch());
             Task &T = P.tasks[(size_t)i];
@@ -871,12 +879,23 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
             // (finish_task's rule; the device has dropped most of the others already)
             std::vector<uint64_t> &dn = W.dn;
             dn.clear();
-            for (int64_t j = d_first[i]; j < d_first[i + 1]; j++) if (d[j].direct) dn.push_back(d[j].h1);
+            // the ranges of descriptors that are this task's: one, or one per sub-task with the stop of the sub-task before it
+            const size_t u0 = by_sub ? sub_of_task[(size_t)i] : (size_t)i, u1 = by_sub ? sub_of_task[(size_t)i + 1] : (size_t)i + 1;
+            int64_t n_desc = 0, n_walk = 0;
+            for (size_t u = u0; u < u1; u++) {
+                const int32_t stop_before = (by_sub && u > u0) ? P.subs[u - 1].tb : INT32_MIN;
+                for (int64_t j = d_first[u]; j < d_first[u + 1]; j++) if (d[j].direct && d[j].pos >= stop_before) dn.push_back(d[j].h1);
+                n_desc += d_first[u + 1] - d_first[u];
+                n_walk += d_walked ? d_walked[u] : d_first[u + 1] - d_first[u];
+            }
             std::sort(dn.begin(), dn.end());
             dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
-            T.recs.reserve((size_t)(d_first[i + 1] - d_first[i]));
-            for (int64_t j = d_first[i]; j < d_first[i + 1]; j++) {
+            T.recs.reserve((size_t)n_desc);
+            for (size_t u = u0; u < u1; u++) {
+              const int32_t stop_before = (by_sub && u > u0) ? P.subs[u - 1].tb : INT32_MIN;
+              for (int64_t j = d_first[u]; j < d_first[u + 1]; j++) {
                 const uz_walk_desc &x = d[j];
+                if (x.pos < stop_before) continue; // (the sub-task before met it too, and kept it)
                 if (!x.direct && !std::binary_search(dn.begin(), dn.end(), x.h1)) continue;
                 WRec r;
                 memset(&r, 0, sizeof(r));
@@ -887,8 +906,9 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
                 r.mate_ref = -2;
                 r.umask = (uint16_t)UZ_UMASK_ALL;
                 T.recs.push_back(r);
+              }
             }
-            T.n_walked = d_walked ? d_walked[i] : d_first[i + 1] - d_first[i];
+            T.n_walked = n_walk;
             mates_in_task(P, T, W, (size_t)i);
         });
     }
@@ -1725,6 +1745,22 @@ int uz_bam_stage_finish_desc(uz_stage *P, const uz_walk_desc *d, const int64_t *
     P->desc = true;
     for (Task &T : P->tasks) T.by_hash = true;
     return guarded([&] { plan_finish(*P, d ? d : (const uz_walk_desc *)"", d_first, d_flags, d_walked); });
+}
+
+/* the same from the descriptors of the walk plan's SUB-tasks as the device hands them back (d_first [n_sub + 1], d_flags / d_walked [n_sub]): joined per
+ * task of the stage as uz_stage_merge_subtasks joins them, without the copy */
+int uz_bam_stage_finish_sub(uz_stage *P, const uz_walk_desc *d, const int64_t *d_first, const int32_t *d_flags, const int64_t *d_walked) {
+    if (!P || !P->begun || P->finished || !d_first) { last_error = "uz_bam_stage_finish_sub: no plan that was begun and not yet finished"; return UZ_IO_E_ARG; }
+    P->finished = true;
+    P->desc = true;
+    for (Task &T : P->tasks) T.by_hash = true;
+    return guarded([&] {
+        build_subtasks(*P);
+        std::vector<int32_t> hfl(P->tasks.size(), 0);
+        for (size_t i = 0; i < P->tasks.size(); i++) hfl[i] = (!P->sub_preflag.empty() && P->sub_preflag[i]) ? UZ_WALK_TASK_INCOMPLETE : 0;
+        for (size_t u = 0; u < P->subs.size(); u++) hfl[(size_t)P->subs[u].host] |= d_flags ? d_flags[u] : 0;
+        plan_finish(*P, d ? d : (const uz_walk_desc *)"", d_first, hfl.data(), d_walked, true);
+    });
 }
 
 /* totals: [0] records, [1] CIGAR words, [2] row units, [3] base-row units, [4] query names, [5] aux bytes, [6] tasks the host walked itself, [7] name bytes */

@@ -33,7 +33,7 @@ IO_EXPORTS = [
     "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
-    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums", "uz_stage_merge_subtasks",
+    "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums", "uz_stage_merge_subtasks", "uz_bam_stage_finish_sub",
 ]
 
 
@@ -187,6 +187,7 @@ def load():
     lib.uz_stage_name_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.uz_packed_block_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.uz_stage_merge_subtasks.argtypes = [C.c_void_p] * 8
+    lib.uz_bam_stage_finish_sub.argtypes = [C.c_void_p] * 5
     _LIB = lib
     return lib
 
@@ -809,11 +810,13 @@ class BamSource:
         out._stage = sh
         return out
 
-    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None, small_tasks=None) -> "KeptBatch":
+    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None, small_tasks=None, merge=False) -> "KeptBatch":
         """The same batch through the device's walk (include/uz_bamwalk.h): the blocks are gathered, `walk(plan)` inflates them in HBM and walks
         them there (HipEngine.bam_walk -> descriptors, d_first, d_flags, d_walked; None: the host's twin uz_stage_walk_host -- tests), the
         batch-wide joins run here on the descriptors, and the answer is the list of kept records for uz_reads_from_bam.
         plan: dict(comp, comp_bytes, in_off, out_off, out_bytes, task, span, reach, fetch, blk_coff).
+        merge: the descriptors of the plan's sub-tasks are joined per task of the stage first (uz_stage_merge_subtasks: `.desc` / `.d_first` are then per
+        task, for the parity tests); default: the joins read them as they came (uz_bam_stage_finish_sub).
         release(token): gives the walked batch on the device up (HipEngine.bam_walk_release) -- called when the joins fail here, or when the returned
         batch is dropped without its table having been built."""
         contig = np.ascontiguousarray(contig, np.int32)
@@ -823,7 +826,7 @@ class BamSource:
             extra = np.ascontiguousarray(extra, np.uint16)
         ia = alloc or (lambda nbytes: np.empty(max(16, nbytes), np.uint8))
         if small_tasks is None:  # (a plan for the device's walk takes smaller tasks: one wavefront walks a task)
-            small_tasks = walk is not None
+            small_tasks = walk is not None and os.environ.get("UZ_STAGE_SUBTASKS", "1") != "0"  # (0: the stage's own tasks as walk tasks -- a development aid)
         flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_SMALL_TASKS if small_tasks else 0)
         st = C.c_void_p()
         t0 = time.perf_counter()
@@ -858,22 +861,23 @@ class BamSource:
             d_flags, token = np.zeros(max(1, n_host), np.int32), None
         else:
             desc, d_first, d_flags, d_walked, token = walk(plan)
-            # the device walked the plan's tasks: joined per task of the stage (a record two neighbouring sub-tasks met is kept once)
             d_first = np.ascontiguousarray(d_first, np.int64)
             d_flags = np.ascontiguousarray(d_flags, np.int32)
             d_walked = np.ascontiguousarray(d_walked, np.int64)
             assert d_first.size == nt + 1
-            h_first, h_flags, h_walked = np.zeros(n_host + 1, np.int64), np.zeros(max(1, n_host), np.int32), np.zeros(max(1, n_host), np.int64)
-            desc = np.ascontiguousarray(desc)
-            try:
-                _check(self.lib, self.lib.uz_stage_merge_subtasks(sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data,
-                                                                  h_first.ctypes.data, h_flags.ctypes.data, h_walked.ctypes.data))
-            except BaseException:
-                if release is not None and token is not None:
-                    release(token)
-                raise
-            desc, d_first, d_flags, d_walked = desc[: int(h_first[-1])], h_first, h_flags[:n_host], h_walked[:n_host]
-        nt = n_host
+            if merge:  # the device walked the plan's tasks: joined per task of the stage (a record two neighbouring sub-tasks met is kept once)
+                h_first, h_flags, h_walked = np.zeros(n_host + 1, np.int64), np.zeros(max(1, n_host), np.int32), np.zeros(max(1, n_host), np.int64)
+                desc = np.ascontiguousarray(desc)
+                try:
+                    _check(self.lib, self.lib.uz_stage_merge_subtasks(sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data,
+                                                                      h_first.ctypes.data, h_flags.ctypes.data, h_walked.ctypes.data))
+                except BaseException:
+                    if release is not None and token is not None:
+                        release(token)
+                    raise
+                desc, d_first, d_flags, d_walked = desc[: int(h_first[-1])], h_first, h_flags[:n_host], h_walked[:n_host]
+        by_sub = walk is not None and not merge  # (the joins read the sub-tasks' descriptors as they came: uz_bam_stage_finish_sub)
+        nt = nt if by_sub else n_host
         t2 = time.perf_counter()
         out = KeptBatch()
         out.token, out._release = token, release
@@ -881,7 +885,8 @@ class BamSource:
         d_flags = np.ascontiguousarray(d_flags, np.int32)
         d_walked = np.ascontiguousarray(d_walked, np.int64)
         assert desc.dtype == WALK_DESC and d_first.size == nt + 1
-        _check(self.lib, self.lib.uz_bam_stage_finish_desc(sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data))
+        _check(self.lib, (self.lib.uz_bam_stage_finish_sub if by_sub else self.lib.uz_bam_stage_finish_desc)(
+            sh.ptr, desc.ctypes.data, d_first.ctypes.data, d_flags.ctypes.data, d_walked.ctypes.data))
         t3 = time.perf_counter()
         self.lib.uz_stage_kept_sizes(sh.ptr, z)
         out.n, out.n_cigar_total, out.n_row_units, out.n_seq_units, out.n_qnames, n_aux, out.host_tasks, out.n_name_bytes = (int(x) for x in z[:8])
