@@ -124,7 +124,7 @@ bool block_at(const uz_bamsrc &S, int64_t coff, BlockHdr &b) {
 // A sequential reader of the inflated stream from a virtual offset on: inflates block after block into a rolling buffer and
 // hands out whole records with their virtual offsets.
 // blocks somebody else has inflated already (uz_stage_set_inflated: the device): where block `coff` lies in that buffer
-struct PreBlk { int64_t coff; int64_t at; uint32_t isize, crc; };
+struct PreBlk { int64_t coff; int64_t at; uint32_t isize, crc; uint32_t blen /* bytes of the block in the file */, hdr /* ... of its header: the DEFLATE stream starts behind them */; };
 struct PreDir {
     const std::vector<PreBlk> *blks = nullptr; // ascending coff
     const uint8_t *base = nullptr;
@@ -1511,7 +1511,7 @@ int uz_stage_gather_blocks(uz_stage *P, uint8_t *comp, int64_t cap, int64_t *in_
                         while (coff <= stop) {
                             BlockHdr h;
                             if (!block_at(S, coff, h)) break;
-                            if (coff > last) { T.pre.push_back(PreBlk{coff, (int64_t)h.blen /* for now: its length in the file */, h.isize, h.crc}); last = coff; }
+                            if (coff > last) { T.pre.push_back(PreBlk{coff, 0, h.isize, h.crc, (uint32_t)h.blen, (uint32_t)(h.cdata - (size_t)coff)}); last = coff; }
                             coff += (int64_t)h.blen;
                         }
                     }
@@ -1519,7 +1519,7 @@ int uz_stage_gather_blocks(uz_stage *P, uint8_t *comp, int64_t cap, int64_t *in_
             });
             int64_t nb = 0, cb = 0, ob = 0;
             for (Task &T : P->tasks)
-                for (PreBlk &b : T.pre) { const int64_t blen = b.at; b.at = ob; ob += b.isize; cb += blen; nb++; }
+                for (PreBlk &b : T.pre) { b.at = ob; ob += b.isize; cb += b.blen; nb++; }
             P->n_pre_blocks = nb; P->pre_bytes = ob;
             P->io_stats[7] = cb;
         }
@@ -1532,19 +1532,17 @@ int uz_stage_gather_blocks(uz_stage *P, uint8_t *comp, int64_t cap, int64_t *in_
         std::vector<int64_t> c0(P->tasks.size() + 1, 0), b0(P->tasks.size() + 1, 0);
         for (size_t i = 0; i < P->tasks.size(); i++) {
             int64_t cb = 0;
-            for (const PreBlk &b : P->tasks[i].pre) { BlockHdr h; block_at(S, b.coff, h); cb += (int64_t)h.blen; }
+            for (const PreBlk &b : P->tasks[i].pre) cb += (int64_t)b.blen;
             c0[i + 1] = c0[i] + cb; b0[i + 1] = b0[i] + (int64_t)P->tasks[i].pre.size();
         }
         parallel_dynamic((int64_t)P->tasks.size(), resolve_threads(P->threads), [&](int64_t i, int) {
             const Task &T = P->tasks[(size_t)i];
             int64_t at = c0[(size_t)i], k = b0[(size_t)i];
-            for (const PreBlk &b : T.pre) {
-                BlockHdr h;
-                block_at(S, b.coff, h);
-                memcpy(comp + at, S.map + b.coff, h.blen);
-                in_off[k] = at + (int64_t)(h.cdata - (size_t)b.coff);
+            for (const PreBlk &b : T.pre) { // (the blocks' headers were read when the blocks were listed)
+                memcpy(comp + at, S.map + b.coff, b.blen);
+                in_off[k] = at + (int64_t)b.hdr;
                 out_off[k] = b.at;
-                at += (int64_t)h.blen; k++;
+                at += (int64_t)b.blen; k++;
             }
         });
         out_off[P->n_pre_blocks] = P->pre_bytes;
