@@ -117,3 +117,20 @@ def test_a_block_that_fails_its_crc_is_refused(engine, workload):
     dev = src.select_kept(fc, flo, fhi, 20, walk=engine.bam_walk, release=engine.bam_walk_release)
     assert dev.n > 0
     del dev
+
+
+def test_a_kept_list_that_points_beyond_its_stores_is_refused(engine, workload):
+    """the kept list is the caller's: k_bam_extract writes no record beyond the totals it came with"""
+    from unfazed_amd.engine import UnfazedHipError
+    fc, flo, fhi, fex = fetches_of(workload, 3, 3)
+    src = io_native.BamSource(workload["bam"], threads=3)
+    for col, val in (("cig_off", 2 ** 31), ("seq_off", 2 ** 31), ("unit_off", 2 ** 31), ("src", np.uint64(2 ** 40))):
+        dev = src.select_kept(fc, flo, fhi, 20, walk=engine.bam_walk, release=engine.bam_walk_release)
+        k = int(np.nonzero(dev.kept["seq_off"] != io_native.KEPT_NO_SEQ)[0][-1])
+        dev.kept[col][k] = val
+        with pytest.raises(UnfazedHipError, match="kept"):
+            engine.reads_from_bam(dev)
+        del dev  # (gives the walked batch up)
+    dev = src.select_kept(fc, flo, fhi, 20, walk=engine.bam_walk, release=engine.bam_walk_release)
+    rid = engine.reads_from_bam(dev)
+    engine.free_reads(rid)

@@ -1877,11 +1877,12 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
             if (n_contigs) UZ_HIP(hipMemcpyAsync(d_span, max_span, (size_t)n_contigs * 4, hipMemcpyHostToDevice, st));
             UZ_HIP(hipMemsetAsync(err, 0, 16, st));
             uz_launch_bam_extract(c, st, n, w.out.p, w.out_bytes, d_aux, aux_bytes, d_kept, min_base_qual, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col,
-                                  cigar, seq4, plane, err, names_out ? d_names : nullptr);
+                                  cigar, seq4, plane, err, names_out ? d_names : nullptr, n_cigar_total, n_row_units, n_seq_units, names_bytes);
             if (names_out && names_bytes) UZ_HIP(hipMemcpyAsync(names_out, d_names, (size_t)names_bytes, hipMemcpyDeviceToHost, st));
             int32_t e = 0;
             UZ_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
             UZ_HIP(hipStreamSynchronize(st));
+            UZ_REQUIRE(e != 2, UZ_E_RANGE, "uz_reads_from_bam: an offset of the kept list points beyond the stores its totals declare");
             UZ_REQUIRE(e == 0, UZ_E_RANGE, "uz_reads_from_bam: a kept record lies outside the walked bytes, or overruns its block_size");
             uz_reads_packed_view v;
             memset(&v, 0, sizeof(v));

@@ -361,6 +361,8 @@ struct ExtractArgs {
     uint32_t *plane;
     int32_t *err;
     uint8_t *names; // null: the names are not asked for
+    // the sizes of the stores the kept list's offsets point into: a record that would be written beyond them is refused (the list is the caller's)
+    int64_t n_cigar_total, n_row_units, n_seq_units, names_bytes;
 };
 
 // Eight lanes per record, 32 records per workgroup.  The record's bytes are staged in LDS first -- the eight lanes fetch consecutive 16-byte
@@ -400,6 +402,11 @@ __global__ __launch_bounds__(256) void k_bam_extract(ExtractArgs a) {
     const uint8_t *p = in_lds ? reinterpret_cast<const uint8_t *>(stage[g]) + d + 4 : gp;
     const uint32_t l_name = p[8], ncig = ld16(p + 12), fl = ld16(p + 14), L = ld32(p + 16);
     if (L > 0xFFFFu || l_name < 1 || 32 + (uint64_t)l_name + 4 * (uint64_t)ncig + ((uint64_t)L + 1) / 2 + (uint64_t)L > (uint64_t)bs) { *a.err = 1; return; }
+    {
+        const int64_t u = (int64_t)UZ_ROW_UNITS(L);
+        if ((int64_t)k.cig_off + (int64_t)ncig > a.n_cigar_total || (int64_t)k.unit_off + u > a.n_row_units ||
+            (k.seq_off != UZ_KEPT_NO_SEQ && (int64_t)k.seq_off + u > a.n_seq_units) || (a.names && (int64_t)k.name_off + (int64_t)l_name - 1 > a.names_bytes)) { *a.err = 2; return; }
+    }
     const uint8_t *q = p + 32 + l_name;
     const uint8_t *sq = q + 4 * (size_t)ncig;
     const uint8_t *ql = sq + ((size_t)L + 1) / 2;
@@ -485,9 +492,11 @@ size_t uz_bam_walk_pad() { return (size_t)WIN + 64; }
 
 void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
                            int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
-                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names) {
+                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names, int64_t n_cigar_total, int64_t n_row_units,
+                           int64_t n_seq_units, int64_t names_bytes) {
     if (n <= 0) return;
-    ExtractArgs a{buf, aux, kept, n, buf_bytes, aux_bytes, thr, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col, cigar, seq4, plane, err, names};
+    ExtractArgs a{buf, aux, kept, n, buf_bytes, aux_bytes, thr, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col, cigar, seq4, plane, err, names,
+                  n_cigar_total, n_row_units, n_seq_units, names_bytes};
     hipLaunchKernelGGL(k_bam_extract, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, a);
     UZ_HIP(hipGetLastError());
 }

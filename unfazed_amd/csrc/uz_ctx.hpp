@@ -403,7 +403,8 @@ void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, co
 size_t uz_bam_walk_pad(); // bytes the inflated buffer must be padded by (the walk's LDS windows read past the last record)
 void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
                            int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
-                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names);
+                           uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names, int64_t n_cigar_total, int64_t n_row_units,
+                           int64_t n_seq_units, int64_t names_bytes);
 // CRC-32 of inflated blocks against their BGZF footers (k_inflate.hip): device pointers; *err: 0, or 1 + a block whose checksum differs
 void uz_launch_crc32(uz_ctx *c, hipStream_t st, int64_t n_blocks, const uint8_t *out, const int64_t *out_off, const uint32_t *want, int32_t *err);
 int uz_phase_votes_impl(uz_ctx *c, int64_t *vote_off, int32_t *vote_val);
