@@ -396,6 +396,14 @@ UZ_DEV void wg_sort32_lds(uint32_t *a, int n) {
         else wg_bitonic_regs<4, uint32_t>((lds_u32)a, a, n);
         return;
     }
+#if WG_NT == 64
+    // one wave per DNM: a lane holds up to 16 keys, so 1024 keys are sorted without touching LDS between the first load and the last store
+    if (N <= 16 * WG_NT) {
+        if (N <= 8 * WG_NT) wg_bitonic_regs<8, uint32_t>((lds_u32)a, a, n);
+        else wg_bitonic_regs<16, uint32_t>((lds_u32)a, a, n);
+        return;
+    }
+#endif
     for (int i = n + (int)threadIdx.x; i < N; i += WG_NT) a[i] = ~0u;
     __syncthreads();
     wg_bitonic_stages((lds_u32)a, N);
