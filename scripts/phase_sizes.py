@@ -49,10 +49,16 @@ emu._LIB.emu_phase.restype = C.c_int
 log = np.zeros((m, 12), np.int64)
 C.c_void_p.in_dll(emu._LIB, "uz_emu_log").value = log.ctypes.data
 r = emu.phase(P, sh, rh, dv, found)
-names = ["nc", "nh", "nA", "T", "nI", "E", "S", "M", "P", "Wmax", "levels"]
+names = ["nc", "nh", "nA", "T", "nI", "E", "S", "M", "P", "Wmax", "levels", "arena_peak_bytes"]
 ok = log[:, 7] > 0
 print("DNMs %d, reaching the pair table %d" % (m, ok.sum()))
 for i, nme in enumerate(names):
     v = log[ok, i]
     print("%-3s mean %8.1f  p50 %6d  p90 %6d  p99 %6d  max %6d" % (nme, v.mean(), *np.percentile(v, [50, 90, 99]).astype(int), v.max()))
 np.save("/tmp/phase_sizes.npy", log)
+# the host's arena estimate (k_reads.hip: phase_exact_sizes) is a line in the records the het-site fetches return (T, known from the sizing pass)
+T, pk = log[ok, 3].astype(float), log[ok, 11].astype(float)
+A = np.vstack([T, np.ones_like(T)]).T
+coef, *_ = np.linalg.lstsq(A, pk, rcond=None)
+res = pk - A @ coef
+print("arena peak ~ %.2f * T + %.0f bytes; residual p50 %.0f p99 %.0f max %.0f" % (coef[0], coef[1], *np.percentile(res, [50, 99]), res.max()))

@@ -138,6 +138,9 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     std::vector<uint8_t> arena(65536 + 64);
     for (int d = 0; d < D->n; d++) {
         a.lds_arena_bytes = arena_sizes[d % 3];
+#ifdef UZ_EMU_STATS
+        a.lds_arena_bytes = 65536; // the statistics are those of the arena build (scripts/phase_sizes.py)
+#endif
         int given_up = 1;
         if (a.lds_arena_bytes) given_up = uz_phase_dnm<true>(&a, scratch.data(), &sh, arena.data(), d);
         if (given_up) uz_phase_dnm<false>(&a, scratch.data(), &sh, nullptr, d);

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *boun
 #define UZ_PHASE_PARTS 8 // XCDs of an MI355X
 #endif
 #ifndef UZ_PHASE_MIN_WAVES
-#define UZ_PHASE_MIN_WAVES 7 // LDS build: <= 72 VGPRs (16 dwords of spill), up to seven 256-lane workgroups per CU; measured 5 / 6 / 7: 4.70 / 4.33 / 4.15 ms
+#define UZ_PHASE_MIN_WAVES 4 // LDS build: a workgroup is ONE wave (wg.hpp), so this is workgroups per SIMD: 4 -> up to 16 DNMs per CU, <= 128 VGPRs (what the LDS arenas leave room for anyway)
 #endif
 // Two builds of the per-DNM body (phase_body.hpp): k_phase<true> keeps the working arrays of a DNM in its workgroup's LDS
 // arena and hands the DNMs that do not fit to k_phase<false>, launched right behind it, which keeps them in HBM scratch.
@@ -59,6 +59,13 @@ __global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(P
     (void)a_by_value;
     const PhaseArgsK ap = (PhaseArgsK)__builtin_amdgcn_kernarg_segment_ptr();
     uint8_t *const scr_base = uz_g(ap->scratch) + (size_t)blockIdx.x * ap->scratch_per_wg;
+#ifdef UZ_PHASE_TIMING
+    if (threadIdx.x < 24) sh.tick[threadIdx.x] = 0;
+    struct TickFlush { // on every way out of the kernel
+        decltype(sh) *s; unsigned long long *t;
+        __device__ ~TickFlush() { __syncthreads(); if (threadIdx.x < 24 && s->tick[threadIdx.x]) atomicAdd(&t[threadIdx.x], s->tick[threadIdx.x]); }
+    } tick_flush{&sh, uz_g(ap->timing)};
+#endif
     if (!LDS) { // the list the first kernel left behind, one cursor
         for (;;) {
             __syncthreads();
@@ -1148,8 +1155,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                 UZ_TRACE("k_phase");
                 hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
                 UZ_HIP(hipGetLastError());
-                // (the DNMs the first kernel gave up: usually a handful -- two workgroups per CU pull them from the list)
-                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 2 * st->n_cus)), dim3(WG_NT), 0, c->stream, a);
+                // (the DNMs the first kernel gave up: usually a handful -- eight waves per CU pull them from the list)
+                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 8 * st->n_cus)), dim3(WG_NT), 0, c->stream, a);
                 UZ_HIP(hipGetLastError());
             }
             UZ_TRACE("after k_phase");
@@ -1207,13 +1214,12 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     {
         unsigned long long t[32];
         UZ_HIP(hipMemcpy(t, timing.p, sizeof(t), hipMemcpyDeviceToHost));
-        const char *nm[22] = {"A.classify", "A.rest", "B.het", "B.overlap", "B.scan1", "B.pair_ok", "B.scan2", "B.compact",
-                              "C", "S.keys", "S.sort", "P.scan", "P.scatter", "P.pairs", "D.finder", "D.cbase",
-                              "E.expand", "E.scan", "E.frontier", "E.setup", "F.join", "F.count"};
+        const char *nm[17] = {"A.classify", "A.lists+C", "-", "B.overlap", "B.finish", "S.keys", "S.sort", "P.count", "P.scatter", "P.pairs", "D.finder",
+                              "E.setup", "E.expand", "E.winners", "E.frontier", "F.join", "F.count"};
         unsigned long long tot = 0;
-        for (int k = 0; k < 22; k++) tot += t[k];
+        for (int k = 0; k < 17; k++) tot += t[k];
         fprintf(stderr, "[phase timing]");
-        for (int k = 0; k < 22; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)t[k] / (double)(tot ? tot : 1));
+        for (int k = 0; k < 17; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)t[k] / (double)(tot ? tot : 1));
         fprintf(stderr, " | ticks/DNM %.0f\n", (double)tot / n);
     }
 #endif

@@ -28,9 +28,9 @@
     do {                                                                               \
         __syncthreads();                                                               \
         UZ_PHASE_ARGS();                                                               \
-        if (threadIdx.x == 0) {                                                        \
+        if (threadIdx.x == 0) { /* summed per wave in LDS, flushed once when the wave exits (k_phase): 17 atomics per DNM on 17 addresses bound the whole kernel */ \
             const unsigned long long now__ = __builtin_amdgcn_s_memtime();             \
-            atomicAdd(&a.timing[k], now__ - tick__);                                   \
+            sh->tick[k] += now__ - tick__;                                             \
             tick__ = now__;                                                            \
         }                                                                              \
     } while (0)
@@ -40,6 +40,9 @@
 #define UZ_TICK_INIT ((void)0)
 #endif
 
+#ifndef UZ_PHASE_K
+#define UZ_PHASE_K 4 // entries a lane works on at once in the finder pass (phase D): their loads are in flight together
+#endif
 #define UZ_QC_GOOD 1u      // goodread(read) :28-53
 #define UZ_QC_GOOD_DISC 2u // goodread(read, True)
 #define UZ_QC_NM5 4u       // <= 5 CIGAR ops other than M/= :190-196
@@ -127,41 +130,77 @@ struct Caps { // per-workgroup scratch capacities (elements)
 };
 
 // Element types of the working arrays that differ between the two builds of the per-DNM body (see Arena below): the
-// HBM build must take any DNM the capacities admit (32-bit indices); a DNM that fits an LDS arena has fewer than
-// 32 k het sites and 64 k pair-table entries, and 16-bit indices nearly halve its footprint (more workgroups per CU).
-template <bool LDS> struct ScrTy { typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t flg; typedef unsigned long long skey; };
-template <> struct ScrTy<true> { typedef int16_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t flg; typedef uint32_t skey; };
+// HBM build must take any DNM the capacities admit (32-bit indices, 64-bit sort and rank keys); a DNM that fits an LDS arena has at
+// most 127 het sites, fewer than 64 k pair-table entries, 8 k registrations and 1 k init elements, and its arrays take the narrowest
+// type that holds them -- the arena of a DNM is what decides how many DNMs a CU works on at once.
+template <bool LDS> struct ScrTy {
+    typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t rlen; typedef uint32_t gflg;
+    typedef unsigned long long skey; typedef unsigned long long rkey;
+};
+template <> struct ScrTy<true> {
+    typedef int8_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t rlen; typedef uint8_t gflg;
+    typedef uint32_t skey; typedef uint32_t rkey;
+};
+// Claim ranks of the chaining levels (phase E).  A claim is (e: frontier element, j: index into its read_sites list, krel: index into the
+// site_reads list of the site, target haplotype); the smallest (e, j, krel) wins a pair, winners are ordered by (target, e, j, krel).
+//   HBM build: 20 + 12 + 20 + 1 bits of a 64-bit word;  arena build: 10 + 8 + 13 + 1 bits of a 32-bit word (the DNM is given up to the HBM
+//   build when a field would not fit: uz_phase_dnm checks nI, the winner room, E and every read_sites length).
+template <bool LDS> struct Rk {
+    typedef unsigned long long T;
+    static constexpr int EB = 20, JB = 12, KB = 20;
+};
+template <> struct Rk<true> {
+    typedef uint32_t T;
+    static constexpr int EB = 10, JB = 8, KB = 13;
+};
+template <bool LDS> UZ_DEV typename Rk<LDS>::T uz_rk_none() { return (typename Rk<LDS>::T) ~(typename Rk<LDS>::T)0; }
+// b = (e << 12) | j as site_best carries it
+template <bool LDS> UZ_DEV typename Rk<LDS>::T uz_rk_make(unsigned long long b, int krel, int target) {
+    typedef typename Rk<LDS>::T T;
+    const T e = (T)(b >> 12), j = (T)(b & 0xFFFu);
+    return (((((e << Rk<LDS>::JB) | j) << Rk<LDS>::KB) | (T)krel) << 1) | (T)target;
+}
+// winner key: target in the top bit, the rank below it
+template <bool LDS> UZ_DEV typename Rk<LDS>::T uz_rk_win(typename Rk<LDS>::T k) {
+    typedef typename Rk<LDS>::T T;
+    return ((k & (T)1) << (8 * sizeof(T) - 1)) | (k >> 1);
+}
+template <bool LDS> UZ_DEV void uz_rk_split(typename Rk<LDS>::T w, int &e, int &j, int &krel, int &target) {
+    typedef typename Rk<LDS>::T T;
+    target = (int)(w >> (8 * sizeof(T) - 1));
+    krel = (int)(w & (((T)1 << Rk<LDS>::KB) - 1));
+    j = (int)((w >> Rk<LDS>::KB) & (((T)1 << Rk<LDS>::JB) - 1));
+    e = (int)((w >> (Rk<LDS>::KB + Rk<LDS>::JB)) & (((T)1 << Rk<LDS>::EB) - 1));
+}
 
 // The working arrays of one DNM, listed once: X(element type, name, capacity in elements).  cA .. cFR are the capacities of the scratch
-// layout (uz_scratch_layout); the element types hidx / pidx / xidx / flg / skey are those of the build (ScrTy).
+// layout (uz_scratch_layout); the element types hidx / pidx / xidx / rlen / gflg / skey / rkey are those of the build (ScrTy).
 // ---- arrays the LDS build places in its arena (uz_scr_make points them at the arena before any request)
 #define UZ_SCR_ARENA(X)                                                                                                                   \
-    X(uint8_t, a_cls, cA) X(int32_t, a_flag0, cA) X(int32_t, a_flag1, cA) X(int32_t, LR, 2 * cA) X(int32_t, LA, 2 * cA)                    \
+    X(uint8_t, a_cls, cA) X(int32_t, a_flag0, cA) X(int32_t, a_flag1, cA) X(int32_t, LR, 2 * cA) X(int32_t, LA, 2 * cA) /* flags + lists: SV evidence only */ \
     X(int32_t, hpos, cH) X(int32_t, hcanon, cH) X(int32_t, h_a, cH) X(int32_t, h_off, cH) X(int32_t, sr_off, cH) X(uint8_t, sr_exists, cH) \
+    X(int32_t, ov0, cH) /* enumerate index of the first record of every het-site fetch (the cut-off of :178-179) */                        \
     X(uint8_t, href, cH) X(uint8_t, halt, cH) /* REF / ALT base of every het site of the DNM */                                            \
     X(unsigned long long, site_best, cH) /* chaining: first frontier element finding an allele at a het index: (e << 12 | j) << 16 | allele << 8 | haplotype */ \
     X(int32_t, cpos, cC) X(uint32_t, cvote, cC) X(uint8_t, cflag, cC) X(uint8_t, cref, cC) X(uint8_t, calt, cC) /* per candidate: UZ_CF_* flags, REF and ALT base */ \
-    X(flg, t_ov, cT) X(int32_t, t_pass, cT) X(int32_t, t_scan, cT) /* the two scans of phase B */                                          \
-    X(hidx, t_h, cT) /* het index of every fetched record before the ordered compaction of phase B */                                      \
-    X(hidx, reg_h, cT) X(pidx, reg_pair, cT) X(uint8_t, cbase, cT)                                                                          \
-    X(int32_t, i_seg, cI) X(pidx, i_pair, cI) X(uint8_t, i_hb, cI)                                                                          \
-    X(skey, keys, cM) X(int32_t, seq_h, cM) X(hidx, srt_h, cM) X(int32_t, srt_pid, cM) X(flg, srt_flag, cM)                                \
-    X(xidx, srt_seq, cM) /* sequence number of every sorted entry (the low bits of its key) */                                             \
-    X(uint8_t, srt_fb, cM) X(xidx, rs_off, cM) X(xidx, rs_len, cM) X(uint32_t, grp, cM) X(uint32_t, pvote, cM)                             \
-    X(unsigned long long, pkey, cM) /* per pair: smallest claim rank of the current chaining level */                                      \
-    X(unsigned long long, win, cM)  /* winners of a chaining level */                                                                      \
+    X(hidx, reg_h, cT) X(xidx, reg_t, cT) X(pidx, reg_pair, cT) X(uint8_t, cbase, cT) /* reg_t: the registration's place in its fetch (its record = h_a[h] + reg_t) */ \
+    X(int32_t, i_seg, cI) X(pidx, i_pair, cI) X(uint8_t, i_hb, cI) /* i_hb: bit 0 haplotype ("alt" list), bit 1 the element has a mate */  \
+    X(uint32_t, i_q, cI) X(int32_t, i_soff, cI) X(uint32_t, i_pk, cI) /* name id; first seed entry; seeding matches qp | L << 8 | (R + 1) << 16 (arena build) */ \
+    X(skey, keys, cM) /* pair table: (name, sequence) keys; after the sort the entries (pair id << SB | sequence) */                        \
+    X(hidx, seq_h, cM) X(hidx, srt_h, cM) X(uint8_t, srt_fb, cM)                                                                           \
+    X(xidx, rs_off, cM) X(rlen, rs_len, cM) X(gflg, grp, cM) X(gflg, pvote, cM)                                                            \
+    X(xidx, plast, cM) /* per pair: 1 + sequence number of the entry whose record is the pair's primary segment ("last writer wins", quirk Q11), 0 = none */ \
+    X(uint32_t, f_item, 2 * cM) /* join: the (pair, haplotype) items of the grouped pairs, compacted */                                      \
+    X(rkey, pkey, cM) /* per pair: smallest claim rank of the current chaining level */                                                    \
+    X(rkey, win, cM)  /* winners of a chaining level */                                                                                    \
     X(pidx, fr_pair0, cFR) X(pidx, fr_pair1, cFR)                                                                                          \
     X(hidx, fr_pos0, cFR) X(hidx, fr_pos1, cFR) /* canonical het index of the site a frontier element was claimed at (-1: an init element) */ \
     X(uint8_t, fr_hap0, cFR) X(uint8_t, fr_hap1, cFR)                                                                                      \
-    X(int32_t, misc, 8) /* [0] KeyError seen, [1] match_info count, [2] capacity exceeded */
-// ---- arrays that stay in the HBM scratch in both builds: written once and read once or twice
+    X(int32_t, misc, 8) /* [0] KeyError seen, [1] match_info count, [2] capacity exceeded, [3] winners of the level */
+// ---- arrays that stay in the HBM scratch in both builds (none of them on the point-variant path of the arena build: since round 5 a pair's
+// records follow from arena arrays alone -- plast -> reg_h / reg_t / h_a or i_seg, and the second record is the first one's mate)
 #define UZ_SCR_HBM(X)                                                                                                                     \
-    X(int32_t, fet0, cM) X(int32_t, fet1, cM) /* the two records of every pair ("last writer wins", quirk Q11): read once per entry in D, once per item in F */ \
-    X(int32_t, reg_seg, cT)                                                                                                                \
-    X(uint32_t, reg_q, cT) X(uint32_t, t_q, cT) /* query-name id of every registration (and of every fetched record, before compaction) */ \
-    X(int32_t, reg_mate, cT) X(int32_t, t_mate, cT)                                                                                        \
-    X(uint32_t, i_q, cI) X(int32_t, i_mate, cI) X(int32_t, i_st, cI) X(int32_t, i_en, cI) /* per init element: name id, mate, span -- fetched once, when the list is built */ \
-    X(int32_t, i_qp, cI) X(int32_t, i_L, cI) X(int32_t, i_R, cI) X(int32_t, i_soff, cI)                                                    \
+    X(int32_t, i_qp, cI) X(int32_t, i_L, cI) X(int32_t, i_R, cI) /* SV evidence: banned names, filter flags; HBM build: the seeding matches */ \
     X(uint32_t, pq, cM)            /* name id of every pair (the optional lists) */                                                        \
     X(unsigned long long, key, cM) /* second buffer of the counting sort (HBM build) */                                                    \
     X(int32_t, q_cnt, 2 * cM + 1026) X(int32_t, q_fill, 2 * cM + 1026) /* counting sort of the pair-table keys over the query-name id range (HBM build) */
@@ -171,7 +210,9 @@ struct ScrT {
     typedef typename ScrTy<LDS>::hidx hidx; // het index of the DNM (-1 = none)
     typedef typename ScrTy<LDS>::pidx pidx; // pair id
     typedef typename ScrTy<LDS>::xidx xidx; // index into the sorted pair-table entries
-    typedef typename ScrTy<LDS>::flg flg;
+    typedef typename ScrTy<LDS>::rlen rlen; // length of a read_sites list
+    typedef typename ScrTy<LDS>::gflg gflg; // per-pair flag sets (haplotype groups, votes)
+    typedef typename ScrTy<LDS>::rkey rkey; // claim rank of a chaining level (Rk)
     // pair-table sort key: (name id, sequence number).  HBM build: id << 24 | sequence in 64 bits.  Arena build: the ids a DNM meets lie
     // close together (they are handed out in file order), so (id - smallest id of the DNM) and the sequence number share 32 bits -- a DNM
     // whose ids do not fit is given up to the HBM build
@@ -197,7 +238,7 @@ struct ScrOff {
 };
 // fills `o`, returns the bytes of one workgroup's region
 UZ_HD size_t uz_scratch_layout(const Caps &c, ScrOff &o) {
-    typedef Scr::hidx hidx; typedef Scr::pidx pidx; typedef Scr::xidx xidx; typedef Scr::flg flg; typedef Scr::skey skey;
+    typedef Scr::hidx hidx; typedef Scr::pidx pidx; typedef Scr::xidx xidx; typedef Scr::rlen rlen; typedef Scr::gflg gflg; typedef Scr::skey skey; typedef Scr::rkey rkey;
     const size_t cA = (size_t)c.A + 1, cT = (size_t)c.T + 1, cH = (size_t)c.H + 2, cC = (size_t)c.C + 1, cI = (size_t)c.I + 2, cM = (size_t)c.M + 2;
     const size_t cFR = (cM > cI ? cM : cI) + 1;
     size_t at = 0;
@@ -238,7 +279,15 @@ struct Arena { // two-ended: persistent arrays grow from the bottom, temporaries
     uint8_t *base;
     int cap, pers, top;
     int fail; // a request did not fit: the DNM is handed to the other build of the kernel (see uz_phase_dnm)
+#ifdef UZ_EMU_STATS
+    int peak; // most bytes in use at once (scripts/phase_sizes.py: what the host's arena estimate is fitted to)
+#endif
 };
+#ifdef UZ_EMU_STATS
+#define UZ_AR_PEAK(ar) do { const int u__ = (ar).pers + ((ar).cap - (ar).top); if (u__ > (ar).peak) (ar).peak = u__; } while (0)
+#else
+#define UZ_AR_PEAK(ar) ((void)0)
+#endif
 // LDS build: EVERY array requested here lies in the arena (its pointer never holds anything but an LDS address, so
 // the compiler addresses it with 32-bit ds_* instructions); a request that does not fit sets `fail` and the caller
 // gives the DNM up before the array is touched.  HBM build: the arrays keep their place in the HBM scratch.
@@ -248,6 +297,7 @@ UZ_DEV void ar_p(Arena &ar, T *&ptr, size_t n) { // persistent for the rest of t
     const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
     int at = ar.pers;
     if (ar.pers + b <= ar.top) ar.pers += b; else { ar.fail = 1; at = 0; }
+    UZ_AR_PEAK(ar);
     ptr = reinterpret_cast<T *>(ar.base + at);
 }
 template <bool LDS, typename T>
@@ -256,6 +306,7 @@ UZ_DEV void ar_t(Arena &ar, T *&ptr, size_t n) { // until the next ar_reset
     const int b = (int)((n * sizeof(T) + 15) & ~(size_t)15);
     int at = 0;
     if (ar.pers + b <= ar.top) { ar.top -= b; at = ar.top; } else ar.fail = 1;
+    UZ_AR_PEAK(ar);
     ptr = reinterpret_cast<T *>(ar.base + at);
 }
 UZ_DEV void ar_reset(Arena &ar) { ar.top = ar.cap; }
@@ -376,6 +427,7 @@ UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &w
 struct SegHdr {
     int32_t start, end, n_cigar, l_seq;
     uint32_t cigar_off, sq_off, umask;
+    int32_t mate;
 };
 // a record's rows: first staged unit + which units were staged
 struct RowRef { uint32_t off, umask; };
@@ -384,7 +436,7 @@ UZ_DEV SegHdr uz_hdr(const RD &R, int seg) {
     const RecB B = R.rb[seg];
     SegHdr h;
     h.start = A.start; h.end = A.end; h.n_cigar = B.n_cigar; h.l_seq = B.l_seq;
-    h.cigar_off = A.cigar_off; h.sq_off = A.sq_off; h.umask = R.umask[seg];
+    h.cigar_off = A.cigar_off; h.sq_off = A.sq_off; h.umask = R.umask[seg]; h.mate = B.mate;
     return h;
 }
 // position of base k inside the staged units of a row: false when its unit stayed home
@@ -446,24 +498,6 @@ UZ_DEV bool uz_qual_low(const RD &R, RowRef row, int k) {
     return uz_qlow_bit(R.qlow, row.off + u, k & 31) != 0;
 }
 
-// get_allele_at :56-73 -> the n bases start at query index `idx` of the row `sq_off`; false = the reference's False
-UZ_DEV bool uz_allele_at(const RD &R, int readlen, int read, int mate, long long pos, int n, RowRef &row, int &idx) {
-    const SegHdr hr = uz_hdr(R, read), hm = uz_hdr(R, mate >= 0 ? mate : read); // both requested up front
-    const int i = uz_qidx_h(R, hr, pos);
-    if (i >= 0) {
-        if (i < 4 || i > readlen - 4) return false;
-        if (hr.l_seq > i + n) { row.off = hr.sq_off; row.umask = hr.umask; idx = i; return true; }
-        return false; // the mate is not consulted (quirk Q10)
-    } else if (mate >= 0) {
-        const int j = uz_qidx_h(R, hm, pos);
-        if (j >= 0) {
-            if (j < 4 || j > readlen - 4) return false;
-            if (hm.l_seq > j + n) { row.off = hm.sq_off; row.umask = hm.umask; idx = j; return true; }
-        }
-    }
-    return false;
-}
-
 // binary_search (site_searcher.py:6-47): the result list is [qp, qp+1..R, qp-1..L]; returns its length
 UZ_DEV int uz_bsearch(long long start, long long end, const int32_t *pos, int n, int &qp_out, int &L, int &Rr) {
     int qs = 0, qe = n - 1, qsp = -1, qep = -1;
@@ -508,22 +542,44 @@ UZ_DEV int uz_pair_ok_vals(const PhaseArgs &a, double cutoff, const RecA &A, con
     if ((ms <= rs && rs <= me) || (ms <= re && re <= me)) return -1; // mates overlap
     return mate;
 }
-UZ_DEV int uz_pair_ok_ab(const RD &R, const PhaseArgs &a, double cutoff, int seg, const RecA &A, const RecB &B) {
-    const int mi = B.mate >= 0 ? B.mate : seg; // a safe index: unused without a mate
-    return uz_pair_ok_vals(a, cutoff, A, B, uz_qc_of(R.qs[seg], R.min_map_qual), R.ra[mi], uz_qc_of(R.qs[mi], R.min_map_qual));
-}
-UZ_DEV int uz_pair_ok(const RD &R, const PhaseArgs &a, double cutoff, int seg) { return uz_pair_ok_ab(R, a, cutoff, seg, R.ra[seg], R.rb[seg]); }
 
-// Phase A classification of one record fetched at the DNM: 0 none, 1 "ref", 2 "alt"
+// everything the filters and the allele look-up read of a record, requested together (one memory round trip)
+struct RecFull { RecA A; RecB B; uint32_t qc, umask; };
+UZ_DEV RecFull uz_rec_full(const RD &R, int seg) {
+    RecFull r;
+    r.A = R.ra[seg]; r.B = R.rb[seg]; r.qc = uz_qc_of(R.qs[seg], R.min_map_qual); r.umask = R.umask[seg];
+    return r;
+}
+UZ_DEV SegHdr uz_hdr_of(const RecFull &r) {
+    SegHdr h;
+    h.start = r.A.start; h.end = r.A.end; h.n_cigar = r.B.n_cigar; h.l_seq = r.B.l_seq;
+    h.cigar_off = r.A.cigar_off; h.sq_off = r.A.sq_off; h.umask = r.umask; h.mate = r.B.mate;
+    return h;
+}
+// Phase A classification of one record fetched at the DNM: 0 none, 1 "ref", 2 "alt".  Two round trips (the record, its mate) before the
+// first test instead of four (filters, then the headers of both again for the allele look-up).
 UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, int seg, long long flo, long long position,
                                 const uint8_t *ref, int ref_len, const uint8_t *alt, int alt_len) {
-    if (!((long long)R.ra[seg].end > flo)) return 0;
-    const int mate = uz_pair_ok(R, a, cutoff, seg);
+    const RecFull r = uz_rec_full(R, seg);
+    const RecFull m = uz_rec_full(R, r.B.mate >= 0 ? r.B.mate : seg); // a safe index: unused without a mate
+    if (!((long long)r.A.end > flo)) return 0;
+    const int mate = uz_pair_ok_vals(a, cutoff, r.A, r.B, r.qc, m.A, m.qc);
     if (mate < 0) return 0;
-    if (ref_len == alt_len) { // snv_match_alleles :296-336
+    const SegHdr hs = uz_hdr_of(r);
+    if (ref_len == alt_len) { // snv_match_alleles :296-336; get_allele_at :56-73
+        const SegHdr hm = uz_hdr_of(m);
         RowRef row = {0, UZ_UMASK_ALL};
-        int at = 0;
-        if (!uz_allele_at(R, a.readlen, seg, mate, position, ref_len, row, at)) return 0;
+        int at = -1;
+        const int i = uz_qidx_h(R, hs, position);
+        if (i >= 0) {
+            if (i < 4 || i > a.readlen - 4) return 0;
+            if (!(hs.l_seq > i + ref_len)) return 0; // the mate is not consulted (quirk Q10)
+            row.off = hs.sq_off; row.umask = hs.umask; at = i;
+        } else {
+            const int j = uz_qidx_h(R, hm, position);
+            if (j < 0 || j < 4 || j > a.readlen - 4 || !(hm.l_seq > j + ref_len)) return 0;
+            row.off = hm.sq_off; row.umask = hm.umask; at = j;
+        }
         bool eq = true;
         for (int k = 0; k < ref_len; k++) eq &= uz_base(R, row, at + k) == ref[k];
         if (eq) return 1;
@@ -533,7 +589,6 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, 
     }
     // indel_match_alleles :266-293
     const int var_len = ref_len > alt_len ? ref_len : alt_len;
-    const SegHdr hs = uz_hdr(R, seg);
     const int rp = uz_qidx_h(R, hs, position);
     if (rp < 0) return 0;
     const uint32_t *c = R.cigar + hs.cigar_off;
@@ -684,13 +739,27 @@ UZ_DEV ScrT<LDS> uz_scr_make(const ScrOff &o, uint8_t *scr_base, uint8_t *b) {
 
 // returns 0 when the DNM is done (its status and results are written), 1 when the LDS build gives it up
 // ap: the kernel's arguments where they lie (device: the kernarg segment); scr_base: this workgroup's scratch region
+//
+// ONE WAVE works through a DNM (wg.hpp): lists are walked in rounds of 64 items, the place of an item in a compacted list is a
+// ballot rank (wg_rank), and nothing waits at a barrier.  Order of the steps: A (DNM reads -> init elements), C (seeding matches of the
+// init elements: before B, so that the pair table's size is known when B fills its keys), B (registrations, written compacted with
+// their names as sort keys), S (sort), P (pair ids: one pass over the sorted keys), D, E, F.
 template <bool LDS, typename SH>
 UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_arena, int d) {
+    typedef typename ScrT<LDS>::hidx hidx;
+    typedef typename ScrT<LDS>::pidx pidx;
+    typedef typename ScrT<LDS>::xidx xidx;
+    typedef typename ScrT<LDS>::rlen rlen;
+    typedef typename ScrT<LDS>::skey skey;
+    typedef typename ScrT<LDS>::rkey rkey;
     PhaseArgs a;
     uz_args_load(a, ap);
     const RD &R = a.R;
     ScrT<LDS> s = uz_scr_make<LDS>(a.so, scr_base, lds_arena);
     Arena ar = {lds_arena, LDS ? a.lds_arena_bytes : 0, 0, LDS ? a.lds_arena_bytes : 0, 0};
+#ifdef UZ_EMU_STATS
+    ar.peak = 0;
+#endif
     const long long c0 = a.cand_off[d], h0 = a.het_off[d];
     const int nc = (int)(a.cand_off[d + 1] - c0), nh = (int)(a.het_off[d + 1] - h0);
     WG_SYNC();
@@ -702,11 +771,12 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     }
     if (nc <= 0) return 0; // snv_phaser.py:254-262
     if (nh > a.caps.H || nc > a.caps.C) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
+    if (LDS && nh > 127) return 1; // 8-bit het indices of the arena build
     ar_p<LDS>(ar, s.misc, 8);
     ar_p<LDS>(ar, s.cpos, nc + 1); ar_p<LDS>(ar, s.cvote, nc + 1);
     ar_p<LDS>(ar, s.cflag, nc + 1); ar_p<LDS>(ar, s.cref, nc + 1); ar_p<LDS>(ar, s.calt, nc + 1);
     ar_p<LDS>(ar, s.hpos, nh + 1); ar_p<LDS>(ar, s.hcanon, nh + 1); ar_p<LDS>(ar, s.h_a, nh + 1);
-    ar_p<LDS>(ar, s.h_off, nh + 2); ar_p<LDS>(ar, s.sr_off, nh + 2); ar_p<LDS>(ar, s.sr_exists, nh + 1);
+    ar_p<LDS>(ar, s.h_off, nh + 2); ar_p<LDS>(ar, s.sr_off, nh + 2); ar_p<LDS>(ar, s.sr_exists, nh + 1); ar_p<LDS>(ar, s.ov0, nh + 1);
     ar_p<LDS>(ar, s.href, nh + 1); ar_p<LDS>(ar, s.halt, nh + 1); ar_p<LDS>(ar, s.site_best, nh + 1);
     if (LDS && ar.fail) return 1;
     WG_T0 { s.misc[0] = 0; s.misc[1] = 0; s.misc[2] = 0; }
@@ -730,7 +800,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         s.hpos[k] = a.spos[si]; s.href[k] = a.sref[si]; s.halt[k] = a.salt[si];
     }
 
-    // ---- A: DNM reads -> ordered "ref" / "alt" lists (each hit contributes read, mate)
+    // ---- A: DNM reads -> init elements in seeding order: the "ref" list, then the "alt" list (:226); each hit contributes read, mate
     UZ_PHASE_ARGS(); // (the site columns of the set-up above are not needed again)
     const bool is_sv = a.vartype[d] != UZ_VT_POINT;
     const long long fa = a.pre_win[4 * d], fb = a.pre_win[4 * d + 1];
@@ -738,37 +808,41 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     const int n0 = (int)(fb - fa);
     const int nA = n0 + (int)(fb2 - fa2);
     if (nA > a.caps.A) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
-    // per fetched record: class and two scan arrays; the lists and the init elements are requested once their lengths are
-    // known (an SV fetches hundreds of records around its breakpoints and keeps a handful)
-    // (i_soff / i_qp / i_L / i_R are written and read once, in the seeding step: they stay in HBM scratch)
-    ar_t<LDS>(ar, s.a_cls, nA + 1); ar_t<LDS>(ar, s.a_flag0, nA + 1); ar_t<LDS>(ar, s.a_flag1, nA + 1);
+    ar_t<LDS>(ar, s.a_cls, nA + 1);
     if (LDS && ar.fail) return 1;
-    int nre = 0, nae = 0; // elements of the "ref" / "alt" lists
+    int nre = 0, nae = 0, nI = 0; // elements of the "ref" / "alt" lists, of both
     if (!is_sv) {
-        WG_FOR(i, nA) {
-            const int cl = uz_classify_dnm_read(R, a, cutoff, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len);
-            s.a_cls[i] = (uint8_t)cl;
-            s.a_flag0[i] = cl == 1;
-            s.a_flag1[i] = cl == 2;
+        int n_ref = 0, n_alt = 0;
+        WG_ROUNDS(i, nA, act) {
+            const int cl = act ? uz_classify_dnm_read(R, a, cutoff, (int)(fa + i), flo, position, ref, ref_len, alt, alt_len) : 0;
+            if (act) s.a_cls[i] = (uint8_t)cl;
+            n_ref += wg_count(cl == 1);
+            n_alt += wg_count(cl == 2);
         }
+        WG_SYNC();
         UZ_TICK(0); // A.classify
-        const int n_ref = wg_exscan(s.a_flag0, nA, sh);
-        const int n_alt = wg_exscan(s.a_flag1, nA, sh);
-        ar_t<LDS>(ar, s.LR, 2 * (size_t)n_ref + 2); ar_t<LDS>(ar, s.LA, 2 * (size_t)n_alt + 2);
+        nre = 2 * n_ref; nae = 2 * n_alt; nI = nre + nae;
+        if (nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
+        ar_p<LDS>(ar, s.i_seg, (size_t)nI + 2); ar_p<LDS>(ar, s.i_hb, (size_t)nI + 2); ar_p<LDS>(ar, s.i_pair, (size_t)nI + 2);
+        ar_p<LDS>(ar, s.i_q, (size_t)nI + 2); ar_p<LDS>(ar, s.i_soff, (size_t)nI + 2);
         if (LDS && ar.fail) return 1;
-        WG_FOR(i, nA) {
-            const int cl = s.a_cls[i];
+        int br = 0, ba = 0;
+        WG_ROUNDS(i, nA, act) { // a hit's place in its list is its rank among the hits of its class
+            const int cl = act ? (int)s.a_cls[i] : 0;
+            const int kr = wg_rank(cl == 1, br), ka = wg_rank(cl == 2, ba);
             if (cl) {
-                int32_t *L = cl == 1 ? s.LR : s.LA;
-                const int k = cl == 1 ? s.a_flag0[i] : s.a_flag1[i];
-                L[2 * k] = (int)(fa + i);
-                L[2 * k + 1] = R.rb[fa + i].mate;
+                const int m = cl == 1 ? 2 * kr : nre + 2 * ka;
+                const int seg = (int)(fa + i);
+                s.i_seg[m] = seg;
+                s.i_seg[m + 1] = R.rb[seg].mate;
+                s.i_hb[m] = s.i_hb[m + 1] = (uint8_t)(cl == 2 ? 1 : 0);
             }
         }
         WG_SYNC();
-        nre = 2 * n_ref; nae = 2 * n_alt;
     } else {
         // ---- A (SV): collect_reads_sv :476-596 around both breakpoints -> "alt" list only
+        ar_t<LDS>(ar, s.a_flag0, nA + 1); ar_t<LDS>(ar, s.a_flag1, nA + 1);
+        if (LDS && ar.fail) return 1;
         const long long sv_start = a.dstart[d], sv_end = a.dend[d];
         const long long icut = (long long)cutoff;
         WG_FOR(t, nA) {
@@ -835,28 +909,20 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             nae = nfil;
         }
         WG_SYNC();
+        UZ_TICK(0); // A.classify
+        nI = nae;
+        if (nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
+        ar_p<LDS>(ar, s.i_seg, (size_t)nI + 2); ar_p<LDS>(ar, s.i_hb, (size_t)nI + 2); ar_p<LDS>(ar, s.i_pair, (size_t)nI + 2);
+        ar_p<LDS>(ar, s.i_q, (size_t)nI + 2); ar_p<LDS>(ar, s.i_soff, (size_t)nI + 2);
+        if (LDS && ar.fail) return 1;
+        WG_FOR(m, nI) { s.i_seg[m] = s.LA[m]; s.i_hb[m] = 1; }
+        WG_SYNC();
     }
-    // init elements in seeding order: "ref" list then "alt" list (:226)
-    const int nI = nre + nae;
-    ar_p<LDS>(ar, s.i_seg, (size_t)nI + 2); ar_p<LDS>(ar, s.i_hb, (size_t)nI + 2); ar_p<LDS>(ar, s.i_pair, (size_t)nI + 2);
-    if (LDS && ar.fail) return 1;
-    WG_FOR(m, nI) {
-        const bool is_ref = m < nre;
-        const int seg = is_ref ? s.LR[m] : s.LA[m - nre];
-        s.i_seg[m] = seg;
-        s.i_hb[m] = is_ref ? 0 : 1;
-        // everything the later steps need of this record, in one round trip
-        const RecA A = R.ra[seg];
-        const RecB B = R.rb[seg];
-        s.i_q[m] = B.qname; s.i_mate[m] = B.mate; s.i_st[m] = A.start; s.i_en[m] = A.end;
-    }
-    WG_SYNC();
+    if (LDS && nI >= (1 << Rk<true>::EB)) return 1; // (a frontier element's index is a field of the 32-bit claim rank)
 
-    UZ_TICK(1); // A.rest
-    int E = 0, S = 0, P = 0;
-    bool exception = false;
+    // ---- het-site set-up of B (before the seeding step: it clears sr_exists, which the seeding step may set)
+    int T = 0;
     if (!a.no_extended) {
-        // ---- B: registration at every het site, in list order
         WG_FOR(h, nh) {
             s.h_a[h] = a.pre_ha[h0 + h];
             s.h_off[h] = a.pre_hl[h0 + h];
@@ -869,177 +935,164 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             while (c > 0 && s.hpos[c - 1] == s.hpos[h]) c--;
             s.hcanon[h] = c;
         }
-        const int T = wg_exscan(s.h_off, nh, sh);
-        UZ_TICK(2); // B.het
-        if (T > a.caps.T || nI > a.caps.I) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
-        ar_reset(ar);
-        // the enumerate cut-off (:178-179) can only bite when a fetch returns more than read_goal + 1 records: otherwise the
-        // per-site running count (one array, one scan, one pass) is not needed
-        const bool need_ei = (long long)T > (long long)a.read_goal + 1;
-        ar_t<LDS>(ar, s.t_ov, T + 1); ar_t<LDS>(ar, s.t_scan, T + 1); ar_t<LDS>(ar, s.t_h, T + 1);
-        if (need_ei) ar_t<LDS>(ar, s.t_pass, T + 1);
-        if (LDS && ar.fail) return 1;
+        T = wg_exscan(s.h_off, nh, sh);
+        if (T > a.caps.T) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
-        // Two work items per lane and round: the loads of both (record headers and QC byte, then the mates' header and QC
-        // byte) are in flight together before either is used -- a wave keeps twice the requests outstanding.
-        for (int t0 = wg_lane_opaque(); t0 < T; t0 += 2 * WG_NT) {
+    }
+    // ---- init elements: name, mate, and (C, :226-249) the matches of every element among the het sites -- one round trip for all of it
+    if (LDS) ar_t<LDS>(ar, s.i_pk, (size_t)nI + 1);
+    if (LDS && ar.fail) return 1;
+    WG_FOR(m, nI) {
+        const int seg = s.i_seg[m];
+        const RecA A = R.ra[seg];
+        const RecB B = R.rb[seg];
+        s.i_q[m] = B.qname;
+        if (B.mate >= 0) s.i_hb[m] |= 2;
+        int nm = 0, qp = 0, L = 0, Rr = -1;
+        if (!a.no_extended && B.mate >= 0) nm = uz_bsearch(A.start, A.end, s.hpos, nh, qp, L, Rr);
+        s.i_soff[m] = nm;
+        if constexpr (LDS) s.i_pk[m] = (uint32_t)qp | ((uint32_t)L << 8) | ((uint32_t)(Rr + 1) << 16);
+        else { s.i_qp[m] = qp; s.i_L[m] = L; s.i_R[m] = Rr; }
+    }
+    WG_SYNC();
+    int E = 0, S = 0, P = 0;
+    bool exception = false;
+    if (!a.no_extended) {
+        S = wg_exscan(s.i_soff, nI, sh);
+        WG_T0 s.i_soff[nI] = S;
+        WG_SYNC();
+        ar_p<LDS>(ar, s.seq_h, (size_t)S + 1); // het index of every seed entry
+        if (LDS && ar.fail) return 1;
+        if (S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
+        WG_FOR(m, nI) {
+            const int nm = s.i_soff[m + 1] - s.i_soff[m];
+            if (nm > 0) {
+                int qp, L, Rr;
+                if constexpr (LDS) { const uint32_t pk = s.i_pk[m]; qp = (int)(pk & 255u); L = (int)((pk >> 8) & 255u); Rr = (int)(pk >> 16) - 1; }
+                else { qp = s.i_qp[m]; L = s.i_L[m]; Rr = s.i_R[m]; }
+                for (int j = 0; j < nm; j++) s.seq_h[s.i_soff[m] + j] = (hidx)uz_bsearch_nth(j, qp, L, Rr);
+            }
+        }
+        WG_SYNC();
+    }
+    UZ_TICK(1); // A.lists + C
+    // ---- pair-table keys (name, sequence): registrations seq < E, then the seeds, then one presence entry per init element
+    // (seq >= E + S) so that every grouped pair has an id.  B writes the registrations' keys as it compacts them.
+    const int Mcap = T + S + nI;
+    if (Mcap >= (1 << 20) || Mcap > a.caps.M) { // rank-key field widths / scratch: loud, never silent
+        WG_T0 a.status[d] = UZ_ST_CAPACITY;
+        return 0;
+    }
+    if (LDS && Mcap > 65535) return 1; // 16-bit indices of the arena build
+    ar_reset(ar);
+    {
+        ar_p<LDS>(ar, s.reg_h, (size_t)T + 1); ar_p<LDS>(ar, s.reg_t, (size_t)T + 1);
+        size_t kcap = (size_t)Mcap + 2; // (a table beyond 1024 entries is sorted in place: room for the next power of two)
+        if (LDS && Mcap > 1024) { kcap = 2048; while (kcap < (size_t)Mcap) kcap <<= 1; kcap += 1; }
+        ar_t<LDS>(ar, s.keys, kcap);
+    }
+    if (LDS && ar.fail) return 1;
+    int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path / the HBM build)
+    auto put_key = [&](int x, uint32_t q) {
+        if constexpr (LDS) s.keys[x] = q; // (shifted below, once the smallest id is known)
+        else s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
+        lmin = (int)q < lmin ? (int)q : lmin;
+        lmax = (int)q > lmax ? (int)q : lmax;
+    };
+    if (!a.no_extended) {
+        // ---- B: registration at every het site, in list order (group_reads_by_haplotype :165-222).  Items = the records of all het-site
+        // fetches end to end; a record that passes is written at its rank among those that pass.
+        // Two items per lane and round: the loads of both (record headers and QC word, then the mates' header and QC word) are in
+        // flight together before either is used.
+        const bool need_ei = (long long)T > (long long)a.read_goal + 1; // the enumerate cut-off (:178-179) can only bite when a fetch returns more than read_goal + 1 records
+        int OV = 0;
+        const int lane = wg_lane_opaque();
+        for (int t0 = 0; t0 < T; t0 += 2 * WG_NT) {
             int tt[2], hh[2], sg[2];
+            bool act[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                tt[u] = t0 + u * WG_NT;
-                const int t = tt[u] < T ? tt[u] : t0;
-                int lo = 0, hi = nh; // last h with h_off[h] <= t
+                tt[u] = t0 + u * WG_NT + lane;
+                act[u] = tt[u] < T;
+                const int t = act[u] ? tt[u] : T - 1;
+                int lo = 0, hi = nh; // last h with h_off[h] <= t (empty ranges share an offset: the last of them is the one that holds t)
                 while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.h_off[mid] <= t) lo = mid; else hi = mid; }
-                hh[u] = lo; // (empty ranges share an offset: the last of them is the one that holds t)
+                hh[u] = lo;
                 sg[u] = s.h_a[lo] + (t - s.h_off[lo]);
             }
-            RecA A[2], M[2];
+            RecA A[2], Mt[2];
             RecB B[2];
             uint32_t q[2], qm[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) { A[u] = R.ra[sg[u]]; B[u] = R.rb[sg[u]]; q[u] = uz_qc_of(R.qs[sg[u]], R.min_map_qual); }
 #pragma unroll
-            for (int u = 0; u < 2; u++) { const int mi = B[u].mate >= 0 ? B[u].mate : sg[u]; M[u] = R.ra[mi]; qm[u] = uz_qc_of(R.qs[mi], R.min_map_qual); }
+            for (int u = 0; u < 2; u++) { const int mi = B[u].mate >= 0 ? B[u].mate : sg[u]; Mt[u] = R.ra[mi]; qm[u] = uz_qc_of(R.qs[mi], R.min_map_qual); }
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                if (tt[u] >= T) continue;
+            for (int u = 0; u < 2; u++) { // (in item order: the 64 items of u = 0 come before those of u = 1)
                 const int t = tt[u], h = hh[u];
-                s.t_h[t] = (typename ScrT<LDS>::hidx)h;
-                // overlap test, pair filters (pure: evaluated for every overlapping record, the enumerate cut-off below only
-                // masks them), name id for the pair table
-                const int ov = (long long)A[u].end > (long long)s.hpos[h];
-                const int mate = uz_pair_ok_vals(a, cutoff, A[u], B[u], q[u], M[u], qm[u]);
-                const bool pok = ov && mate >= 0 && (q[u] & UZ_QC_NM5);
-                s.t_q[t] = B[u].qname;
-                s.t_mate[t] = mate;
-                if (need_ei) {
-                    s.t_ov[t] = (typename ScrT<LDS>::flg)(ov | (pok ? 2 : 0));
-                    s.t_pass[t] = ov; // scanned below: enumerate index of the fetch iterator (:178-179)
-                } else {
-                    s.t_ov[t] = pok;
-                    s.t_scan[t] = pok; // scanned below: position in the registration list
+                const bool first = act[u] && t == s.h_off[h]; // the first record of a fetch
+                // overlap test, pair filters (pure: evaluated for every overlapping record, the enumerate cut-off only masks them)
+                const bool ov = act[u] && (long long)A[u].end > (long long)s.hpos[h];
+                const int mate = uz_pair_ok_vals(a, cutoff, A[u], B[u], q[u], Mt[u], qm[u]);
+                bool ok = ov && mate >= 0 && (q[u] & UZ_QC_NM5);
+                if (need_ei) { // enumerate index of the fetch iterator = overlapping records of this fetch before this one
+                    const int er = wg_rank(ov, OV);
+                    if (first) s.ov0[h] = er;
+                    WG_SYNC();
+                    if (ok) ok = !((er - s.ov0[h]) > a.read_goal); // :179
                 }
-            }
-        }
-        UZ_TICK(3); // B.overlap
-        if (need_ei) {
-            (void)wg_exscan(s.t_pass, T, sh);
-            UZ_TICK(4); // B.scan1
-            WG_FOR(t, T) {
-                const int h = s.t_h[t];
-                bool ok = (s.t_ov[t] & 2) != 0;
+                const int k = wg_rank(ok, E);
+                if (first) // site_reads range of het index h starts here; so do the (empty) ranges in front of it that share its offset
+                    for (int h2 = h; h2 >= 0 && s.h_off[h2] == t; h2--) s.sr_off[h2] = k;
                 if (ok) {
-                    const int ei = s.t_pass[t] - s.t_pass[s.h_off[h]];
-                    ok = !(ei > a.read_goal); // :179
+                    s.reg_h[k] = (hidx)h;
+                    s.reg_t[k] = (xidx)(t - s.h_off[h]);
+                    put_key(k, B[u].qname);
                 }
-                s.t_ov[t] = ok;
-                s.t_scan[t] = ok;
             }
         }
-        UZ_TICK(5); // B.pair_ok
-        E = wg_exscan(s.t_scan, T, sh);
-        UZ_TICK(6); // B.scan2
-        // LDS goes to what the chaining levels read over and over; reg_seg is read twice (keys, pair table)
-        ar_p<LDS>(ar, s.reg_h, E + 1); ar_p<LDS>(ar, s.reg_pair, E + 1); ar_p<LDS>(ar, s.cbase, E + 1);
-        if (LDS && ar.fail) return 1;
-        // ordered compaction (inputs are the per-record temporaries, outputs the registration arrays)
-        WG_FOR(t, T) {
-            if (s.t_ov[t]) {
-                const int k = s.t_scan[t];
-                const int h = s.t_h[t];
-                s.reg_h[k] = (typename ScrT<LDS>::hidx)h;
-                s.reg_seg[k] = s.h_a[h] + (t - s.h_off[h]);
-                s.reg_q[k] = s.t_q[t];
-                s.reg_mate[k] = s.t_mate[t];
-            }
-        }
-        // site_reads range of het index h: entries [sr_off[h], sr_off[h+1])
-        WG_FOR(h, nh + 1) s.sr_off[h] = h < nh ? (s.h_off[h] < T ? s.t_scan[s.h_off[h]] : E) : E;
+        WG_SYNC();
+        UZ_TICK(3); // B.overlap
+        // site_reads range of het index h: entries [sr_off[h], sr_off[h+1]); fetches that start at the end of the item list are empty
+        WG_FOR(h, nh + 1) { if (s.h_off[h] >= T) s.sr_off[h] = E; }
         WG_SYNC();
         WG_FOR(h, nh) {
             // a canonical site exists in site_reads once any of its duplicates registered a read (:217-218)
             if (s.sr_off[h + 1] > s.sr_off[h]) s.sr_exists[s.hcanon[h]] = 1;
         }
-        UZ_TICK(7); // B.compact
-        // ---- C: seeding (:226-249): matches of every init element among the het sites
-        WG_FOR(m, nI) {
-            int nm = 0, qp = 0, L = 0, Rr = -1;
-            if (s.i_mate[m] >= 0) nm = uz_bsearch(s.i_st[m], s.i_en[m], s.hpos, nh, qp, L, Rr);
-            s.i_qp[m] = qp; s.i_L[m] = L; s.i_R[m] = Rr;
-            s.i_soff[m] = nm;
-        }
-        S = wg_exscan(s.i_soff, nI, sh);
-        WG_T0 s.i_soff[nI] = S;
-        WG_SYNC();
-        ar_reset(ar);
-        ar_p<LDS>(ar, s.seq_h, S + 1); // het index of every seed entry
-        if (LDS && ar.fail) return 1;
-        if (S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
-        WG_FOR(m, nI) {
-            const int nm = s.i_soff[m + 1] - s.i_soff[m];
-            for (int j = 0; j < nm; j++) s.seq_h[s.i_soff[m] + j] = uz_bsearch_nth(j, s.i_qp[m], s.i_L[m], s.i_R[m]);
-        }
         WG_SYNC();
     }
-    UZ_TICK(8); // C
-    // ---- S: pair table.  Keys (qname << 24 | seq): registrations seq < E, seeds, then one
-    // presence entry per init element (seq >= E + S) so that every grouped pair has an id.
+    UZ_TICK(4); // B.finish
     const int M = E + S + nI;
-    if (M >= (1 << 20) || M > a.caps.M || nI > a.caps.I) { // rank-key field widths / scratch: loud, never silent
-        WG_T0 a.status[d] = UZ_ST_CAPACITY;
-        return 0;
-    }
-    if (LDS && (M > 65535 || nh > 32767)) return 1; // 16-bit indices of the arena build
-    int mp2 = 2;
-    while (mp2 < M) mp2 <<= 1;
-    // the arena build sorts in place, and the register sort exchanges whole rounds of WG_NT keys through the array
-    if (LDS && mp2 < WG_NT) mp2 = WG_NT;
-    {
-        ar_reset(ar);
-        // persistent (read by every chaining level): srt_h, srt_fb; the sorted keys and the pair ids
-        // of the entries die with the allele tables (phase D), so they are temporaries
-        ar_p<LDS>(ar, s.srt_h, M + 1); ar_p<LDS>(ar, s.srt_fb, M + 1);
-        ar_t<LDS>(ar, s.srt_pid, M + 1); ar_t<LDS>(ar, s.srt_flag, M + 1); ar_t<LDS>(ar, s.srt_seq, M + 1);
-        ar_t<LDS>(ar, s.keys, mp2 + 1); // requested last: given back as soon as the sorted order is taken down (below)
-    }
-    if (LDS && ar.fail) return 1;
-    int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path / the HBM build)
+    if (LDS && E >= (1 << Rk<true>::KB)) return 1; // (an index into a site_reads list is a field of the 32-bit claim rank)
     int SB = 24; // bits of a key that hold the sequence number
     if constexpr (LDS) { SB = 1; while ((1 << SB) < M) SB++; }
-    WG_FOR(x, M) {
-        uint32_t q;
-        if (x < E) q = s.reg_q[x];
-        else if (x < E + S) {
-            int lo = 0, hi = nI; // init element owning seed x - E
-            const int sx = x - E;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.i_soff[mid] <= sx) lo = mid; else hi = mid; }
-            q = s.i_q[lo];
-        } else q = s.i_q[x - E - S];
-        if constexpr (LDS) s.keys[x] = q; // (shifted below, once the smallest id is known)
-        else s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
-        lmin = (int)q < lmin ? (int)q : lmin;
-        lmax = (int)q > lmax ? (int)q : lmax;
+    WG_FOR(m, nI) { // seeds and presence entries of every init element
+        const uint32_t q = s.i_q[m];
+        if (!a.no_extended) {
+            const int o = E + s.i_soff[m], nm = s.i_soff[m + 1] - s.i_soff[m];
+            for (int j = 0; j < nm; j++) put_key(o + j, q);
+        }
+        put_key(E + S + m, q);
     }
     WG_SYNC();
-    UZ_TICK(9); // S.keys
+    UZ_TICK(5); // S.keys
     // Sort by (query-name id, sequence).
+    int qmin = -1, qmax = -1;
     {
+        wg_minmax(lmin, lmax, qmin, qmax, sh);
         if constexpr (LDS) {
-            // the keys sit in the arena, packed into 32 bits: bitonic sort in registers / in place (~45 short stages for 512 keys)
-            int qmin = -1, qmax = -1;
-            wg_minmax(lmin, lmax, qmin, qmax, sh);
-            if (qmin < 0 || (((unsigned)(qmax - qmin)) >> (32 - SB)) != 0u) return 1; // (block-uniform) the HBM build sorts 64-bit keys
+            // the keys sit in the arena, packed into 32 bits: bitonic sort in registers (up to 16 keys per lane)
+            if (qmin < 0 || (((unsigned)(qmax - qmin)) >> (32 - SB)) != 0u) return 1; // (uniform) the HBM build sorts 64-bit keys
             WG_FOR(x, M) s.keys[x] = ((s.keys[x] - (uint32_t)qmin) << SB) | (uint32_t)x;
             WG_SYNC();
             wg_sort32_lds(s.keys, M);
         } else {
             // keys in HBM scratch.  Name ids are interned in file order, so the names met around one locus span a short
             // id range: a counting sort over that range (stable order inside a bucket restored by a tiny insertion
-            // sort) replaces the 60+ barrier stages of a bitonic sort; wider ranges fall back to it.  Same array.
-            int qmin = -1, qmax = -1, qrange = 0;
-            wg_minmax(lmin, lmax, qmin, qmax, sh);
-            qrange = M > 0 ? qmax - qmin + 1 : 0;
+            // sort) replaces the stages of a bitonic sort; wider ranges fall back to it.  Same array.
+            const int qrange = M > 0 ? qmax - qmin + 1 : 0;
             if (M > 1 && qmin >= 0 && qrange > 0 && qrange <= 2 * a.caps.M + 1024) {
                 WG_FOR(i, qrange + 1) { s.q_cnt[i] = 0; s.q_fill[i] = 0; }
                 WG_SYNC();
@@ -1063,172 +1116,196 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
                     }
                 }
                 WG_SYNC();
-                { unsigned long long *sorted = s.key; s.key = s.keys; s.keys = sorted; } // both hold mp2 + 1 entries
+                { unsigned long long *sorted = s.key; s.key = s.keys; s.keys = sorted; } // both hold cM entries
             } else
                 wg_sort64(s.keys, M, sh);
         }
     }
-    UZ_TICK(10); // S.sort
-    WG_FOR(x, M) {
-        const int st = (x == 0 || (s.keys[x] >> SB) != (s.keys[x - 1] >> SB)) ? 1 : 0;
-        s.srt_flag[x] = st;
-        s.srt_pid[x] = st;
-        s.srt_seq[x] = (typename ScrT<LDS>::xidx)(s.keys[x] & (typename ScrT<LDS>::skey)((1u << SB) - 1u));
+    UZ_TICK(6); // S.sort
+    // ---- P: pair ids.  A pair = a run of equal names in the sorted keys; its id = the number of run starts before it.
+    const skey seqmask = (skey)(((skey)1 << SB) - 1);
+    {
+        uint32_t carry = 0;
+        WG_ROUNDS(x, M, act) {
+            const uint32_t nmx = act ? (uint32_t)(s.keys[x] >> SB) : 0u;
+            const uint32_t pv = wg_prev32(nmx, carry);
+            P += wg_count(act && (x == 0 || nmx != pv));
+        }
     }
-    P = wg_exscan(s.srt_pid, M, sh); // exclusive scan of run starts: pid = value + flag - 1 (its first barrier ends the reads of keys)
-    ar_pop<LDS>(ar, s.keys, mp2 + 1); // the 8-byte keys are the largest array of the DNM: their room goes to the per-pair arrays
-    // per-pair arrays, now that the number of pairs is known; the chaining arrays first
-    ar_p<LDS>(ar, s.pkey, P + 1); ar_p<LDS>(ar, s.rs_off, P + 2); ar_p<LDS>(ar, s.rs_len, P + 1); ar_p<LDS>(ar, s.grp, P + 1);
+    // per-entry and per-pair arrays, now that their lengths are known
+    ar_p<LDS>(ar, s.reg_pair, (size_t)E + 1); ar_p<LDS>(ar, s.cbase, (size_t)E + 1);
+    ar_p<LDS>(ar, s.srt_h, (size_t)M + 1); ar_p<LDS>(ar, s.srt_fb, (size_t)M + 1);
+    ar_p<LDS>(ar, s.rs_off, (size_t)P + 2); ar_p<LDS>(ar, s.rs_len, (size_t)P + 1); ar_p<LDS>(ar, s.grp, (size_t)P + 1); ar_p<LDS>(ar, s.plast, (size_t)P + 1);
     if (LDS && ar.fail) return 1;
-    UZ_TICK(11); // P.scan
-    WG_FOR(x, M) {
-        const int pid = s.srt_pid[x] + s.srt_flag[x] - 1;
-        s.srt_pid[x] = pid;
-        const int seq = s.srt_seq[x];
-        if (s.srt_flag[x]) {
-            s.rs_off[pid] = (typename ScrT<LDS>::xidx)x;
-            if (a.want_lists) { // name id of the pair = that of its first entry (the optional lists)
-                uint32_t q;
-                if (seq < E) q = s.reg_q[seq];
-                else if (seq < E + S) {
-                    int lo = 0, hi = nI;
-                    const int sx = seq - E;
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.i_soff[mid] <= sx) lo = mid; else hi = mid; }
-                    q = s.i_q[lo];
-                } else q = s.i_q[seq - E - S];
-                s.pq[pid] = q;
+    UZ_TICK(7); // P.count
+    {
+        uint32_t carry = 0;
+        int pb = 0;
+        WG_ROUNDS(x, M, act) {
+            const skey key = act ? s.keys[x] : (skey)0;
+            const uint32_t nmx = (uint32_t)(key >> SB);
+            const uint32_t pv = wg_prev32(nmx, carry);
+            const bool st = act && (x == 0 || nmx != pv);
+            const int pid = wg_rank(st, pb) + (st ? 1 : 0) - 1; // run starts up to and including this entry, minus one
+            if (act) {
+                const int seq = (int)(key & seqmask);
+                if (st) {
+                    s.rs_off[pid] = (xidx)x;
+                    if (a.want_lists) s.pq[pid] = LDS ? nmx + (uint32_t)qmin : nmx; // name id of the pair (the optional lists)
+                }
+                if (seq < E) s.reg_pair[seq] = (pidx)pid;
+                else if (seq >= E + S) s.i_pair[seq - E - S] = (pidx)pid;
+                s.srt_h[x] = seq < E ? s.reg_h[seq] : (seq < E + S ? s.seq_h[seq - E] : (hidx)-1);
+                s.keys[x] = ((skey)pid << SB) | (skey)seq; // the entry: pair id above its sequence number
             }
         }
-        if (seq < E) s.reg_pair[seq] = pid;
-        else if (seq >= E + S) s.i_pair[seq - E - S] = pid;
-        s.srt_h[x] = seq < E ? s.reg_h[seq] : (seq < E + S ? s.seq_h[seq - E] : -1);
+        WG_T0 s.rs_off[P] = (xidx)M;
+        WG_SYNC();
     }
-    WG_T0 s.rs_off[P] = M;
-    WG_SYNC();
-    UZ_TICK(12); // P.scatter
+    UZ_TICK(8); // P.scatter
     WG_FOR(p, P) {
         const int x0 = s.rs_off[p], x1 = s.rs_off[p + 1];
-        int len = 0, f0 = -1, f1 = -1;
-        for (int x = x0; x < x1; x++) { // ascending sequence = the reference's time order
-            const int seq = s.srt_seq[x];
+        int len = 0, last = -1;
+        for (int x = x0; x < x1; x++) { // ascending sequence = the reference's time order: the last writer of fetched_reads wins (quirk Q11)
+            const int seq = (int)(s.keys[x] & seqmask);
             if (seq < E + S) len++;
-            if (seq < E) { f0 = s.reg_seg[seq]; f1 = s.reg_mate[seq]; }     // :222
-            else if (seq >= E + S) {                                        // :233-234
-                const int mt = s.i_mate[seq - E - S];
-                if (mt >= 0) { f0 = s.i_seg[seq - E - S]; f1 = mt; }
-            }
+            if (seq < E) last = seq;                                          // :222
+            else if (seq >= E + S && (s.i_hb[seq - E - S] & 2)) last = seq;   // :233-234 (an element with a mate)
         }
-        if (len >= 4096) s.misc[2] = 1; // rank key: 12 bits for the read_sites index
-        s.rs_len[p] = len;
-        s.fet0[p] = f0; s.fet1[p] = f1;
+        if (len >= (1 << Rk<LDS>::JB)) s.misc[2] = 1; // rank key: the bits of the read_sites index
+        s.rs_len[p] = (rlen)len;
+        s.plast[p] = (xidx)(last + 1);
         s.grp[p] = 0;
-        s.pkey[p] = ~0ULL;
     }
     WG_SYNC();
-    WG_FOR(m, nI) wg_atomic_or(&s.grp[s.i_pair[m]], s.i_hb[m] ? 2u : 1u); // :230
+    WG_FOR(m, nI) wg_or_flag(s.grp, (int)s.i_pair[m], (s.i_hb[m] & 1) ? 2u : 1u); // :230
     WG_SYNC();
-    if (s.misc[2]) { WG_SYNC(); WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
+    if (s.misc[2]) {
+        if (LDS) return 1; // (the HBM build's rank has room for 4095 sites per pair)
+        WG_SYNC(); WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0;
+    }
 
 #ifdef UZ_EMU_STATS
     uz_emu_stats[0] += E; uz_emu_stats[1] += S; uz_emu_stats[2] += nI; uz_emu_stats[3] += P; uz_emu_stats[7] += nh; uz_emu_stats[8] += nc; uz_emu_stats[9]++;
-    { int T_ = 0; if (!a.no_extended) T_ = s.h_off[nh]; uz_emu_stats[10] += T_;
-      if (uz_emu_log) { long long *r = uz_emu_log + 12 * (long long)d; r[0] = nc; r[1] = nh; r[2] = nA; r[3] = T_; r[4] = nI; r[5] = E; r[6] = S; r[7] = M; r[8] = P; } }
+    uz_emu_stats[10] += T;
+    if (uz_emu_log) { long long *r = uz_emu_log + 12 * (long long)d; r[0] = nc; r[1] = nh; r[2] = nA; r[3] = T; r[4] = nI; r[5] = E; r[6] = S; r[7] = M; r[8] = P; }
 #endif
-    UZ_TICK(13); // P.pairs
+    UZ_TICK(9); // P.pairs
+    // the primary segment of a pair -- fetched_reads[name][0], "last writer wins" (quirk Q11) -- or -1; the second one is its mate
+    // (a registration's mate and an init element's mate both are the record's own mate field).  Arena arrays only.
+    auto primary = [&](int p) -> int {
+        const int l = (int)s.plast[p];
+        if (!l) return -1;
+        const int seq = l - 1;
+        if (seq < E) return s.h_a[s.reg_h[seq]] + (int)s.reg_t[seq];
+        return s.i_seg[seq - E - S];
+    };
     if (!a.no_extended) {
         // ---- D: static allele tables.  One pass over the sorted entries: the pair-level finder allele
         // at the entry's het site (get_allele_at, :91-105) and, for registrations, the base the
         // pair's primary segment shows there (:114-124).  Both start from the same index into the
         // primary segment, computed once.
-        // Two entries per lane and round, staged: (i) both entries' primary-segment headers and quality-plane offsets,
+        // UZ_PHASE_K entries per lane and round, staged: (i) the entries' primary-segment headers and quality-plane offsets,
         // (ii) the mates' headers where the primary segment does not cover the site, (iii) the base / quality bit --
-        // each stage's loads of both entries are in flight together.
-        for (int x0 = wg_lane_opaque(); x0 < M; x0 += 2 * WG_NT) {
-            int xx[2], hh[2], sq[2], f1v[2], qi[2];
-            RowRef row[2];
-            uint32_t q0[2];
-            bool live[2], own[2];
-            SegHdr h0[2];
+        // each stage's loads of all the lane's entries are in flight together (a DNM's ~400 entries: two rounds of three round trips).
+        {
+            constexpr int K = UZ_PHASE_K;
+            const int lane = wg_lane_opaque();
+            for (int xb = 0; xb < M; xb += K * WG_NT) {
+                int xx[K], hh[K], sq[K], qi[K], mt[K];
+                RowRef row[K];
+                uint32_t q0[K], um0[K];
+                bool live[K], own[K], needm[K];
+                {
+                    SegHdr hd0[K];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                xx[u] = x0 + u * WG_NT;
-                const int x = xx[u] < M ? xx[u] : x0;
-                hh[u] = s.srt_h[x];
-                sq[u] = s.srt_seq[x];
-                const int p = s.srt_pid[x];
-                const int f0 = s.fet0[p];
-                f1v[u] = s.fet1[p];
-                live[u] = xx[u] < M && hh[u] >= 0 && f0 >= 0;
-                const int f = live[u] ? f0 : 0;
-                h0[u] = uz_hdr(R, f);
-                q0[u] = R.qoff[f];
-            }
+                    for (int u = 0; u < K; u++) {
+                        xx[u] = xb + u * WG_NT + lane;
+                        const int x = xx[u] < M ? xx[u] : 0;
+                        hh[u] = s.srt_h[x];
+                        const skey ent = s.keys[x];
+                        sq[u] = (int)(ent & seqmask);
+                        const int f0 = primary((int)(ent >> SB));
+                        live[u] = xx[u] < M && hh[u] >= 0 && f0 >= 0;
+                        const int f = live[u] ? f0 : 0;
+                        hd0[u] = uz_hdr(R, f);
+                        q0[u] = R.qoff[f];
+                    }
 #pragma unroll
-            for (int u = 0; u < 2; u++) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
-                qi[u] = -1; row[u].off = 0; row[u].umask = UZ_UMASK_ALL; own[u] = false;
-                if (!live[u]) continue;
-                const long long hp = s.hpos[hh[u]];
-                const int i = uz_qidx_h(R, h0[u], hp);
-                if (i >= 0) {
-                    own[u] = true;
-                    if (i >= 4 && i <= a.readlen - 4 && h0[u].l_seq > i + 1) { qi[u] = i; row[u].off = h0[u].sq_off; row[u].umask = h0[u].umask; }
-                } else if (f1v[u] >= 0) {
-                    const SegHdr h1 = uz_hdr(R, f1v[u]);
-                    const int j = uz_qidx_h(R, h1, hp);
-                    if (j >= 4 && j <= a.readlen - 4 && h1.l_seq > j + 1) { qi[u] = j; row[u].off = h1.sq_off; row[u].umask = h1.umask; }
+                    for (int u = 0; u < K; u++) { // the primary segment covers the site: the mate is not consulted (quirk Q10)
+                        qi[u] = -1; row[u].off = 0; row[u].umask = UZ_UMASK_ALL; own[u] = false; needm[u] = false;
+                        um0[u] = hd0[u].umask; mt[u] = hd0[u].mate;
+                        if (!live[u]) continue;
+                        const int i = uz_qidx_h(R, hd0[u], (long long)s.hpos[hh[u]]);
+                        if (i >= 0) {
+                            own[u] = true;
+                            if (i >= 4 && i <= a.readlen - 4 && hd0[u].l_seq > i + 1) { qi[u] = i; row[u].off = hd0[u].sq_off; row[u].umask = hd0[u].umask; }
+                        } else needm[u] = mt[u] >= 0;
+                    }
                 }
-            }
-            uint8_t al[2];
-            bool low[2];
+                {
+                    SegHdr h1[K];
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                al[u] = qi[u] >= 0 ? uz_base(R, row[u], qi[u]) : (uint8_t)0;
-                low[u] = (qi[u] >= 0 && own[u] && sq[u] < E) ? uz_qual_low(R, RowRef{q0[u], h0[u].umask}, qi[u]) : true; // (only a registration uses it, below)
-            }
+                    for (int u = 0; u < K; u++) h1[u] = uz_hdr(R, needm[u] ? mt[u] : 0);
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                if (xx[u] >= M) continue;
-                uint8_t fbv = 0, cb = 0;
-                if (qi[u] >= 0) {
-                    const int h = hh[u];
-                    if (al[u] == s.href[h] || al[u] == s.halt[h]) fbv = al[u]; // :98-105
-                    if (own[u] && sq[u] < E && !low[u]) cb = al[u];           // :114-124
+                    for (int u = 0; u < K; u++) {
+                        if (!needm[u]) continue;
+                        const int j = uz_qidx_h(R, h1[u], (long long)s.hpos[hh[u]]);
+                        if (j >= 4 && j <= a.readlen - 4 && h1[u].l_seq > j + 1) { qi[u] = j; row[u].off = h1[u].sq_off; row[u].umask = h1[u].umask; }
+                    }
                 }
-                s.srt_fb[xx[u]] = fbv;
-                if (sq[u] < E) s.cbase[sq[u]] = cb;
+                uint8_t al[K];
+                bool low[K];
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    al[u] = qi[u] >= 0 ? uz_base(R, row[u], qi[u]) : (uint8_t)0;
+                    low[u] = (qi[u] >= 0 && own[u] && sq[u] < E) ? uz_qual_low(R, RowRef{q0[u], um0[u]}, qi[u]) : true; // (only a registration uses it, below)
+                }
+#pragma unroll
+                for (int u = 0; u < K; u++) {
+                    if (xx[u] >= M) continue;
+                    uint8_t fbv = 0, cb = 0;
+                    if (qi[u] >= 0) {
+                        const int h = hh[u];
+                        if (al[u] == s.href[h] || al[u] == s.halt[h]) fbv = al[u]; // :98-105
+                        if (own[u] && sq[u] < E && !low[u]) cb = al[u];           // :114-124
+                    }
+                    s.srt_fb[xx[u]] = fbv;
+                    if (sq[u] < E) s.cbase[sq[u]] = cb;
+                }
             }
         }
         WG_SYNC();
-        UZ_TICK(14); // D.finder
-        UZ_TICK(15); // D.cbase
+        UZ_TICK(10); // D.finder
         // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
         int F = nI, cur = 0;
-        // winners of one level: at most P.  The arena build sets room aside for 256 (a level rarely has more than a few
+        // winners of one level: at most P.  The arena build sets room aside for 128 (a level rarely has more than a few
         // dozen) and gives the DNM up if a level overflows it.
-        const int wcap = (LDS && P > 256) ? 256 : P;
+        const int wcap = (LDS && P > 128) ? 128 : P;
         {
-            ar_reset(ar);
+            ar_reset(ar); // (the sorted entries are not read again)
             const size_t fr = (size_t)(wcap > nI ? wcap : nI) + 2;
+            ar_t<LDS>(ar, s.pkey, (size_t)P + 1);
             ar_t<LDS>(ar, s.fr_pair0, fr); ar_t<LDS>(ar, s.fr_hap0, fr); ar_t<LDS>(ar, s.fr_pair1, fr); ar_t<LDS>(ar, s.fr_hap1, fr);
             ar_t<LDS>(ar, s.fr_pos0, fr); ar_t<LDS>(ar, s.fr_pos1, fr);
             int wp2 = 2; // the winners are sorted in place: room for the next power of two
             while (wp2 < wcap) wp2 <<= 1;
-            if (LDS && wcap > 96 && wp2 < WG_NT) wp2 = WG_NT; // (levels with more than 96 winners are sorted in place, see mp2)
             ar_t<LDS>(ar, s.win, (size_t)wp2 + 1);
         }
         if (LDS && ar.fail) return 1;
+        WG_FOR(p, P) s.pkey[p] = uz_rk_none<LDS>();
         WG_FOR(e, nI) {
             const int na = nae;
             const int m = e < na ? (nre + e) : (e - na);
             s.fr_pair0[e] = s.i_pair[m];
-            s.fr_pos0[e] = -1;
-            s.fr_hap0[e] = s.i_hb[m];
+            s.fr_pos0[e] = (hidx)-1;
+            s.fr_hap0[e] = (uint8_t)(s.i_hb[m] & 1);
         }
-        WG_SYNC();
         // (a pair is "assigned" exactly when it carries a haplotype bit in grp: the init pairs from the start, the winners of a
         // level from its end)
         WG_FOR(h, nh) s.site_best[h] = ~0ULL;
         WG_SYNC();
+        UZ_TICK(11); // E.setup
         while (F > 0) {
             auto *const fr_pair_c = cur ? s.fr_pair1 : s.fr_pair0, *const fr_pair_n = cur ? s.fr_pair0 : s.fr_pair1;
             auto *const fr_pos_c = cur ? s.fr_pos1 : s.fr_pos0, *const fr_pos_n = cur ? s.fr_pos0 : s.fr_pos1;
@@ -1236,7 +1313,6 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             // (i) per het index, the first frontier element (in visiting order e, then read_sites
             // index j) that finds a usable allele there.  Every element finding REF or ALT at a het
             // index claims the same entries of its site_reads list, so only that first one can win.
-            WG_T0 s.misc[3] = 0; // winners of this level (read back after the barriers below)
             WG_FOR(e, F) {
                 const int p = fr_pair_c[e];
                 const int fcanon = fr_pos_c[e]; // canonical het index of the site this element was claimed at
@@ -1262,7 +1338,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
                 if (!cb) continue;
                 const int canon = s.hcanon[s.reg_h[k]];
                 const int krel = k - s.sr_off[canon];
-                unsigned long long best = ~0ULL;
+                rkey best = uz_rk_none<LDS>();
                 for (int h = canon; h < nh && s.hpos[h] == s.hpos[canon]; h++) { // het indices sharing the position
                     const unsigned long long sb = s.site_best[h];
                     if (sb == ~0ULL) continue;
@@ -1274,62 +1350,62 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
                     if (cb == fbv) target = hap;                 // :134-136
                     else if (cb == nonf) target = hap ^ 1;       // :137-141
                     else continue;
-                    const unsigned long long key = (((b << 20) | (unsigned long long)krel) << 1) | (unsigned long long)target;
+                    const rkey key = uz_rk_make<LDS>(b, krel, target);
                     best = key < best ? key : best;
                 }
-                if (best != ~0ULL) wg_atomic_min64(&s.pkey[p2], best);
+                if (best != uz_rk_none<LDS>()) wg_atomic_min(&s.pkey[p2], best);
             }
             WG_SYNC();
-            UZ_TICK(16); // E.expand
+            UZ_TICK(12); // E.expand
             // winners in the order the reference appends them: "ref" targets by rank, then "alt"
             // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
             // sorting the keys alone is enough: the pair is recovered from the rank.
             WG_FOR(h, nh) s.site_best[h] = ~0ULL; // for the next level
-            // the winners are appended in any order (one LDS counter): their place in the next frontier is
-            // decided below by the RANK of their key, so the order of this list does not matter
-            WG_FOR(p, P) {
-                if (!s.grp[p] && s.pkey[p] != ~0ULL) {
-                    const unsigned long long k = s.pkey[p];
-                    const int wi = wg_atomic_add(&s.misc[3], 1);
-                    if (wi < wcap) s.win[wi] = ((k & 1ULL) << 63) | (k >> 1);
-                }
+            // the winners in any order: their place in the next frontier is decided below by the RANK of their key
+            int W = 0;
+            WG_ROUNDS(p, P, act) {
+                const bool w = act && !s.grp[p] && s.pkey[p] != uz_rk_none<LDS>();
+                const int wi = wg_rank(w, W);
+                if (w && wi < wcap) s.win[wi] = uz_rk_win<LDS>(s.pkey[p]);
             }
             WG_SYNC();
-            const int W = s.misc[3];
-            if (LDS && W > wcap) return 1; // (block-uniform)
-            UZ_TICK(17); // E.scan
+            if (LDS && W > wcap) return 1; // (uniform)
+            UZ_TICK(13); // E.winners
             // position in the next frontier = rank of the (target, rank) key among the winners: counted
-            // directly while a level has few winners (one barrier), sorted otherwise
+            // directly while a level has few winners, sorted otherwise
             const bool by_count = W <= 96;
-            if (!by_count) wg_sort64(s.win, W, sh, LDS);
+            if (!by_count) {
+                if constexpr (LDS) wg_sort32_lds(s.win, W);
+                else wg_sort64(s.win, W, sh, false);
+            }
             WG_FOR(w, W) {
-                const unsigned long long ok = s.win[w];
+                const rkey ok = s.win[w];
                 int posn = w;
                 if (by_count) {
                     posn = 0;
                     for (int v = 0; v < W; v++) posn += s.win[v] < ok;
                 }
-                const int e = (int)((ok >> 32) & 0xFFFFF), j = (int)((ok >> 20) & 0xFFF), krel = (int)(ok & 0xFFFFF);
+                int e, j, krel, target;
+                uz_rk_split<LDS>(ok, e, j, krel, target);
                 const int pe = fr_pair_c[e];
                 const int h = s.srt_h[s.rs_off[pe] + j];
                 const int p = s.reg_pair[s.sr_off[s.hcanon[h]] + krel];
-                fr_pair_n[posn] = (typename ScrT<LDS>::pidx)p;
-                fr_pos_n[posn] = (typename ScrT<LDS>::hidx)s.hcanon[h];
-                fr_hap_n[posn] = (uint8_t)(ok >> 63);
+                fr_pair_n[posn] = (pidx)p;
+                fr_pos_n[posn] = (hidx)s.hcanon[h];
+                fr_hap_n[posn] = (uint8_t)target;
                 // every winner key names a different pair: mark it here
-                s.grp[p] |= (ok >> 63) ? 2u : 1u;
-                s.pkey[p] = ~0ULL;
+                wg_or_flag(s.grp, p, target ? 2u : 1u);
+                s.pkey[p] = uz_rk_none<LDS>();
             }
             WG_SYNC();
 #ifdef UZ_EMU_STATS
             uz_emu_stats[4]++; if (W > uz_emu_stats[5]) uz_emu_stats[5] = W; uz_emu_stats[6] += W;
             if (uz_emu_log) { long long *r = uz_emu_log + 12 * (long long)d; if (W > r[9]) r[9] = W; r[10]++; }
 #endif
-            UZ_TICK(18); // E.frontier
+            UZ_TICK(14); // E.frontier
             F = W;
             cur ^= 1;
         }
-        UZ_TICK(19); // E.setup
         exception = s.misc[0] != 0;
     }
     WG_SYNC();
@@ -1341,63 +1417,88 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     // ---- F: join + vote.  Items: extended -> both fetched segments of every grouped pair per
     // haplotype (:254-263); --no-extended -> the init list elements themselves.
     ar_reset(ar);
-    ar_p<LDS>(ar, s.pvote, P + 1);
+    ar_t<LDS>(ar, s.pvote, (size_t)P + 1);
     if (LDS && ar.fail) return 1;
+#ifdef UZ_EMU_STATS
+    if (uz_emu_log) uz_emu_log[12 * (long long)d + 11] = ar.peak;
+#endif
     WG_FOR(p, P) s.pvote[p] = 0;
     WG_SYNC();
-    const int n_items = a.no_extended ? nI : 4 * P;
-    // two items per lane and round: both segments' headers are requested before either is used
-    for (int it0 = wg_lane_opaque(); it0 < n_items; it0 += 2 * WG_NT) {
-        int sg[2], hbv[2], pv[2];
-        bool act[2];
-        SegHdr hdv[2];
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int it = it0 + u * WG_NT;
-            act[u] = it < n_items;
-            sg[u] = 0; hbv[u] = 0; pv[u] = 0;
-            if (act[u]) {
-                if (a.no_extended) { sg[u] = s.i_seg[it]; hbv[u] = s.i_hb[it]; pv[u] = s.i_pair[it]; }
-                else {
-                    pv[u] = it >> 2; hbv[u] = (it >> 1) & 1;
-                    if (!(s.grp[pv[u]] & (1u << hbv[u])) || s.fet0[pv[u]] < 0) act[u] = false;
-                    else sg[u] = (it & 1) ? s.fet1[pv[u]] : s.fet0[pv[u]];
-                }
-            }
-            hdv[u] = uz_hdr(R, act[u] ? sg[u] : 0);
+    // one fetched segment against the candidate sites: match_informative_sites (site_searcher.py:50-78) + phase_by_reads (snv_phaser.py:16-70)
+    auto join_seg = [&](const SegHdr &hd, int hb, int p) {
+        int qp, L, Rr;
+        const int nm = uz_bsearch(hd.start, hd.end, s.cpos, nc, qp, L, Rr);
+        if (nm <= 0) return;
+        bool dad_alt = false, mom_alt = false;
+        for (int ci = L; ci <= Rr; ci++) {
+            if (s.cflag[ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
         }
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (!act[u]) continue;
-            const SegHdr &hd = hdv[u];
-            const int hb = hbv[u], p = pv[u];
-            int qp, L, Rr;
-            const int nm = uz_bsearch(hd.start, hd.end, s.cpos, nc, qp, L, Rr);
-            if (nm <= 0) continue;
-            bool dad_alt = false, mom_alt = false;
-            for (int ci = L; ci <= Rr; ci++) {
-                if (s.cflag[ci] & UZ_CF_ALT_DAD) dad_alt = true; else mom_alt = true;
+        if (dad_alt && mom_alt) return; // site_searcher.py:74-75
+        wg_atomic_add(&s.misc[1], 1);
+        for (int ci = L; ci <= Rr; ci++) {
+            const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
+            if (rp < 0 || rp >= hd.l_seq) continue;
+            const uint8_t b = uz_base(R, RowRef{hd.sq_off, hd.umask}, rp);
+            bool from_ref;
+            if (b == s.cref[ci]) from_ref = true;       // :41-42
+            else if (b == s.calt[ci]) from_ref = false; // :43-44
+            else continue;
+            const bool alt_is_dad = (s.cflag[ci] & UZ_CF_ALT_DAD) != 0;
+            const bool to_alt_parent = (from_ref && hb == 0) || (!from_ref && hb == 1); // :52-69
+            const bool to_dad = to_alt_parent ? alt_is_dad : !alt_is_dad;
+            wg_or_flag(s.pvote, p, to_dad ? 1u : 2u);
+            wg_atomic_or(&s.cvote[ci], to_dad ? 1u : 2u);
+        }
+    };
+    if (a.no_extended) {
+        WG_FOR(it, nI) join_seg(uz_hdr(R, s.i_seg[it]), s.i_hb[it] & 1, (int)s.i_pair[it]);
+    } else {
+        // the (pair, haplotype) items of the grouped pairs, compacted first: a DNM has ~330 pairs, a few dozen of them grouped
+        int nF = 0;
+        WG_ROUNDS(it, 2 * P, act) {
+            const int p = it >> 1;
+            nF += wg_count(act && (s.grp[p] & (1u << (it & 1))) && s.plast[p]);
+        }
+        ar_t<LDS>(ar, s.f_item, (size_t)nF + 1);
+        if (LDS && ar.fail) return 1;
+        {
+            int fb = 0;
+            WG_ROUNDS(it, 2 * P, act) {
+                const int p = it >> 1;
+                const bool on = act && (s.grp[p] & (1u << (it & 1))) && s.plast[p];
+                const int k = wg_rank(on, fb);
+                if (on) s.f_item[k] = (uint32_t)it;
             }
-            if (dad_alt && mom_alt) continue; // site_searcher.py:74-75
-            wg_atomic_add(&s.misc[1], 1);
-            for (int ci = L; ci <= Rr; ci++) {
-                const int rp = uz_qidx_h(R, hd, s.cpos[ci]); // snv_phaser.py:28-33
-                if (rp < 0 || rp >= hd.l_seq) continue;
-                const uint8_t b = uz_base(R, RowRef{hd.sq_off, hd.umask}, rp);
-                bool from_ref;
-                if (b == s.cref[ci]) from_ref = true;       // :41-42
-                else if (b == s.calt[ci]) from_ref = false; // :43-44
-                else continue;
-                const bool alt_is_dad = (s.cflag[ci] & UZ_CF_ALT_DAD) != 0;
-                const bool to_alt_parent = (from_ref && hb == 0) || (!from_ref && hb == 1); // :52-69
-                const bool to_dad = to_alt_parent ? alt_is_dad : !alt_is_dad;
-                wg_atomic_or(&s.pvote[p], to_dad ? 1u : 2u);
-                wg_atomic_or(&s.cvote[ci], to_dad ? 1u : 2u);
+        }
+        WG_SYNC();
+        // two items per lane and round: the first segments' headers, then the second segments' (the first ones' mates) beside the
+        // work on the first
+        constexpr int KF = 2;
+        const int lane = wg_lane_opaque();
+        for (int ib = 0; ib < nF; ib += KF * WG_NT) {
+            int pv[KF], hbv[KF];
+            bool act[KF];
+            SegHdr hd0[KF], hd1[KF];
+#pragma unroll
+            for (int u = 0; u < KF; u++) {
+                const int it = ib + u * WG_NT + lane;
+                act[u] = it < nF;
+                const uint32_t v = act[u] ? s.f_item[it] : 0u;
+                pv[u] = (int)(v >> 1); hbv[u] = (int)(v & 1u);
+                hd0[u] = uz_hdr(R, act[u] ? primary(pv[u]) : 0);
+            }
+#pragma unroll
+            for (int u = 0; u < KF; u++) hd1[u] = uz_hdr(R, (act[u] && hd0[u].mate >= 0) ? hd0[u].mate : 0);
+#pragma unroll
+            for (int u = 0; u < KF; u++) {
+                if (!act[u]) continue;
+                join_seg(hd0[u], hbv[u], pv[u]);
+                if (hd0[u].mate >= 0) join_seg(hd1[u], hbv[u], pv[u]);
             }
         }
     }
     WG_SYNC();
-    UZ_TICK(20); // F.join
+    UZ_TICK(15); // F.join
     const int n_match = s.misc[1];
     WG_SYNC();
     if (n_match <= 0) {
@@ -1462,7 +1563,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             }
         }
     }
-    UZ_TICK(21); // F.count
+    UZ_TICK(16); // F.count
     WG_T0 {
         a.status[d] = UZ_ST_OK;
         for (int k = 0; k < 4; k++) a.counts[4 * d + k] = cnt[k];

@@ -27,13 +27,16 @@ UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { uint32_t o = *p; *p |= v
 UZ_DEV int wg_atomic_add(int *p, int v) { int o = *p; *p += v; return o; }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { unsigned long long o = *p; *p += v; return o; }
+UZ_DEV void wg_atomic_min32(uint32_t *p, uint32_t v) { if (v < *p) *p = v; }
 #else
 #include <hip/hip_runtime.h>
 #define UZ_DEV __device__ __forceinline__
 #define UZ_HD __host__ __device__ inline
-#ifndef UZ_WG_NT
-#define UZ_WG_NT 256 // lanes per DNM workgroup: 256 lanes, 28 KiB LDS arena, 5 workgroups per CU measured best on MI355X
-#endif
+// ONE WAVE PER DNM (round 5).  Rounds 1-4 gave a DNM a 256-lane workgroup: ~150 barrier-separated phases per DNM, four waves each paying a
+// phase's scalar set-up, three of them idle whenever a list had fewer than 65 items (most lists of a DNM do).  With a single wavefront per
+// DNM every __syncthreads() is a compiler fence (no s_barrier: the backend drops it for a workgroup that is one wave), scans are ballots,
+// and a CU holds as many DNMs as its LDS has arenas for.
+#define UZ_WG_NT 64
 #define WG_NT UZ_WG_NT
 #define WG_TID ((int)threadIdx.x)
 // The lane index is re-read through an opaque move at every loop: otherwise the compiler hoists the
@@ -51,7 +54,63 @@ UZ_DEV uint32_t wg_atomic_or(uint32_t *p, uint32_t v) { return atomicOr(p, v); }
 UZ_DEV int wg_atomic_add(int *p, int v) { return atomicAdd(p, v); }
 UZ_DEV void wg_atomic_min64(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
 UZ_DEV unsigned long long wg_atomic_add64(unsigned long long *p, unsigned long long v) { return atomicAdd(p, v); }
+UZ_DEV void wg_atomic_min32(uint32_t *p, uint32_t v) { atomicMin(p, v); }
 #endif
+UZ_DEV void wg_atomic_min(unsigned long long *p, unsigned long long v) { wg_atomic_min64(p, v); }
+UZ_DEV void wg_atomic_min(uint32_t *p, uint32_t v) { wg_atomic_min32(p, v); }
+// OR into an element of a flag array: 32-bit elements directly, 8-bit elements through the aligned word that holds them (arrays start
+// 16-byte aligned and are padded to 16 bytes, so the word is inside the array)
+UZ_DEV void wg_or_flag(uint32_t *a, int i, uint32_t v) { wg_atomic_or(&a[i], v); }
+UZ_DEV void wg_or_flag(uint8_t *a, int i, uint32_t v) {
+#ifdef UZ_EMU
+    a[i] = (uint8_t)(a[i] | v);
+#else
+    wg_atomic_or(reinterpret_cast<uint32_t *>(a + (i & ~3)), v << (8 * (i & 3)));
+#endif
+}
+
+// ---- rounds of the wave: every lane takes part in every round (uniform trip count: ballots and lane scans inside the body are
+// legal), `act` says whether the lane holds an item.  WG_FOR stays for loops whose bodies are lane-private.
+#define WG_ROUNDS(i, n, act)                                                                                  \
+    for (int i##_r0 = 0, i = wg_lane_opaque(); i##_r0 < (int)(n); i##_r0 += WG_NT, i += WG_NT)              \
+        if (const bool act = i < (int)(n); true)
+// rank of the lane's item among the items of the pass that satisfy `pred`, in item order: base + the number of lower lanes whose pred is
+// set; base then moves on by the round's total (uniform).  Replaces flag array + scan + compaction pass.
+UZ_DEV int wg_rank(bool pred, int &base) {
+#ifdef UZ_EMU
+    const int r = base;
+    base += pred ? 1 : 0;
+    return r;
+#else
+    const unsigned long long m = __ballot(pred);
+    const int r = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    base += (int)__popcll(m);
+    return r;
+#endif
+}
+// number of lanes of the round whose pred is set (uniform)
+UZ_DEV int wg_count(bool pred) {
+#ifdef UZ_EMU
+    return pred ? 1 : 0;
+#else
+    return (int)__popcll(__ballot(pred));
+#endif
+}
+// the value of the item before the lane's own (lane - 1; lane 0: `carry`, the last item of the round before); carry then becomes the
+// value of the round's last lane
+UZ_DEV uint32_t wg_prev32(uint32_t v, uint32_t &carry) {
+#ifdef UZ_EMU
+    const uint32_t p = carry;
+    carry = v;
+    return p;
+#else
+    const int lane = (int)(threadIdx.x & 63);
+    const uint32_t up = (uint32_t)__shfl_up((int)v, 1, 64);
+    const uint32_t p = lane == 0 ? carry : up;
+    carry = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return p;
+#endif
+}
 
 #ifndef UZ_EMU
 // ---- cross-lane steps of a 64-lane wave without LDS traffic (gfx950) ------------------------------------------------------------
@@ -156,6 +215,9 @@ struct WgSharedT {
     int part[WG_NT + 1];
     unsigned long long sortbuf[SORT_CAP];
     int bcast[4];
+#ifdef UZ_PHASE_TIMING
+    unsigned long long tick[24]; // diagnostic build: shader-clock ticks per phase of this wave's DNMs
+#endif
 };
 typedef WgSharedT<WG_SORT_LDS_CAP> WgShared;
 
