@@ -955,6 +955,8 @@ static void phase_check_upload_flags(uz_ctx *c) {
 }
 struct Sizes { Caps caps; int arena; long long sumP; };
 static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
+// the share of a batch's DNMs (per mille, by the estimate below) the arena is sized to hold; the rest take the HBM build behind it
+static const int arena_permille = [] { const char *e = getenv("UZ_PHASE_ARENA_PERMILLE"); return e ? atoi(e) : 990; }();
 static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
     for (int32_t d = 0; d < n; d++) {
@@ -971,29 +973,32 @@ static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
     z.caps.I = (int32_t)(4 * mA);
     z.caps.M = next_pow2(std::min<long long>(std::max<long long>(mM, 2), 1 << 20));
     z.sumP = sumP;
-    // LDS arena of k_phase<true>, sized for THIS batch: a DNM needs about 20 bytes per record its het-site fetches return
-    // plus 7 KiB (fit over the bench workload).  The 99th percentile of that estimate over the batch
-    // decides how many workgroups share a CU's 160 KiB (at most UZ_PHASE_MIN_WAVES: registers), and the arena is then the
-    // largest that this many workgroups leave room for.  A shallow batch runs 7 workgroups per CU on 21 KiB arenas, a deep
-    // one fewer on larger arenas -- instead of handing most of its DNMs to the slower HBM build.
+    // LDS arena of k_phase<true>, sized for THIS batch.  One wave works on a DNM, so the arena alone decides how many DNMs a CU has in
+    // flight: a DNM needs about 9.2 bytes per record its het-site fetches return plus 3.2 KiB (fit over the bench workload by the CPU twin,
+    // scripts/phase_sizes.py: residual p99 0.4 KiB).  The 99th percentile of that estimate over the batch decides how
+    // many waves share a CU's 160 KiB (at most 4 x UZ_PHASE_MIN_WAVES: registers), and the arena is then the largest that this many leave
+    // room for.  The bench batch runs 15 DNMs per CU on 10 KiB arenas; a deep-coverage batch gets larger arenas and fewer waves instead
+    // of handing most of its DNMs to the slower HBM build.
     z.arena = arena_env;
     if (z.arena < 0) {
-        std::vector<int32_t> hist(64, 0); // estimate in KiB
+        std::vector<int32_t> hist(256, 0); // estimate in units of 256 bytes
         int32_t active = 0;
         for (int32_t d = 0; d < n; d++) {
             const int32_t *b = &bh[(size_t)5 * d];
             if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
-            const long long est = (20LL * b[1] + 7168 + 1023) >> 10;
-            hist[(size_t)std::min<long long>(est, 63)]++;
+            const long long est = ((37LL * b[1]) / 4 + 3584 + 255) >> 8;
+            hist[(size_t)std::min<long long>(est, 255)]++;
             active++;
         }
-        int kb = 12, seen = 0;
-        for (int k = 0; k < 64; k++) {
+        int u = 16, seen = 0, umax = 16;
+        for (int k = 0; k < 256; k++) if (hist[k]) umax = k;
+        for (int k = 0; k < 256; k++) {
             seen += hist[k];
-            if (hist[k]) kb = std::max(kb, k);
-            if ((long long)seen * 100 >= (long long)active * 99) break;
+            if (hist[k]) u = std::max(u, k);
+            if ((long long)seen * 1000 >= (long long)active * arena_permille) break;
         }
-        z.arena = std::min(kb, 62) * 1024;
+        (void)umax;
+        z.arena = std::min(u * 256, 62 * 1024);
     }
     return z;
 }

@@ -41,7 +41,7 @@
 #endif
 
 #ifndef UZ_PHASE_K
-#define UZ_PHASE_K 4 // entries a lane works on at once in the finder pass (phase D): their loads are in flight together
+#define UZ_PHASE_K 3 // entries a lane works on at once in the finder pass (phase D): their loads are in flight together (2 / 3 / 4: 3.02 / 2.97 / 3.09 ms per 100 k DNMs; 4 spills vector registers)
 #endif
 #define UZ_QC_GOOD 1u      // goodread(read) :28-53
 #define UZ_QC_GOOD_DISC 2u // goodread(read, True)
@@ -134,13 +134,33 @@ struct Caps { // per-workgroup scratch capacities (elements)
 // most 127 het sites, fewer than 64 k pair-table entries, 8 k registrations and 1 k init elements, and its arrays take the narrowest
 // type that holds them -- the arena of a DNM is what decides how many DNMs a CU works on at once.
 template <bool LDS> struct ScrTy {
-    typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t rlen; typedef uint32_t gflg;
+    typedef int32_t hidx; typedef int32_t pidx; typedef int32_t xidx; typedef int32_t rlen; typedef uint32_t gflg; typedef int32_t fidx;
     typedef unsigned long long skey; typedef unsigned long long rkey;
 };
 template <> struct ScrTy<true> {
-    typedef int8_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t rlen; typedef uint8_t gflg;
+    typedef int8_t hidx; typedef uint16_t pidx; typedef uint16_t xidx; typedef uint8_t rlen; typedef uint8_t gflg; typedef uint16_t fidx;
     typedef uint32_t skey; typedef uint32_t rkey;
 };
+// A pair-table entry after the sort is ONE word (the array of the sort keys, rewritten in place): its sequence number, its het index, the
+// finder allele the pair shows at that site as a code (0 none, 1 the site's REF, 2 its ALT: get_allele_at :91-105) and the base the pair's
+// primary segment shows there (ASCII, 0 = none: :114-124).  Sequence numbers keep the reference's time order without being dense:
+// registration k has k, seed j has T + j, the presence entry of init element m has T + S + m (T = records the het-site fetches returned).
+template <bool LDS> struct En {
+    typedef unsigned long long W;
+    static constexpr int SEQ_B = 24, H_B = 20; // 24 + 20 + 2 + 8 bits of 64
+};
+template <> struct En<true> {
+    typedef uint32_t W;
+    static constexpr int SEQ_B = 15, H_B = 7; // 15 + 7 + 2 + 8 = 32 (the DNM is given up when T + S + nI or nh would not fit)
+};
+template <bool LDS> UZ_DEV typename En<LDS>::W uz_en_make(int seq, int h) { return (typename En<LDS>::W)seq | ((typename En<LDS>::W)h << En<LDS>::SEQ_B); }
+template <bool LDS> UZ_DEV int uz_en_seq(typename En<LDS>::W w) { return (int)(w & (((typename En<LDS>::W)1 << En<LDS>::SEQ_B) - 1)); }
+template <bool LDS> UZ_DEV int uz_en_h(typename En<LDS>::W w) { return (int)((w >> En<LDS>::SEQ_B) & (((typename En<LDS>::W)1 << En<LDS>::H_B) - 1)); }
+template <bool LDS> UZ_DEV int uz_en_fb(typename En<LDS>::W w) { return (int)((w >> (En<LDS>::SEQ_B + En<LDS>::H_B)) & 3); }
+template <bool LDS> UZ_DEV int uz_en_cb(typename En<LDS>::W w) { return (int)((w >> (En<LDS>::SEQ_B + En<LDS>::H_B + 2)) & 255); }
+template <bool LDS> UZ_DEV typename En<LDS>::W uz_en_alleles(typename En<LDS>::W w, int fb, int cb) {
+    return w | ((typename En<LDS>::W)fb << (En<LDS>::SEQ_B + En<LDS>::H_B)) | ((typename En<LDS>::W)cb << (En<LDS>::SEQ_B + En<LDS>::H_B + 2));
+}
 // Claim ranks of the chaining levels (phase E).  A claim is (e: frontier element, j: index into its read_sites list, krel: index into the
 // site_reads list of the site, target haplotype); the smallest (e, j, krel) wins a pair, winners are ordered by (target, e, j, krel).
 //   HBM build: 20 + 12 + 20 + 1 bits of a 64-bit word;  arena build: 10 + 8 + 13 + 1 bits of a 32-bit word (the DNM is given up to the HBM
@@ -165,13 +185,6 @@ template <bool LDS> UZ_DEV typename Rk<LDS>::T uz_rk_win(typename Rk<LDS>::T k) 
     typedef typename Rk<LDS>::T T;
     return ((k & (T)1) << (8 * sizeof(T) - 1)) | (k >> 1);
 }
-template <bool LDS> UZ_DEV void uz_rk_split(typename Rk<LDS>::T w, int &e, int &j, int &krel, int &target) {
-    typedef typename Rk<LDS>::T T;
-    target = (int)(w >> (8 * sizeof(T) - 1));
-    krel = (int)(w & (((T)1 << Rk<LDS>::KB) - 1));
-    j = (int)((w >> Rk<LDS>::KB) & (((T)1 << Rk<LDS>::JB) - 1));
-    e = (int)((w >> (Rk<LDS>::KB + Rk<LDS>::JB)) & (((T)1 << Rk<LDS>::EB) - 1));
-}
 
 // The working arrays of one DNM, listed once: X(element type, name, capacity in elements).  cA .. cFR are the capacities of the scratch
 // layout (uz_scratch_layout); the element types hidx / pidx / xidx / rlen / gflg / skey / rkey are those of the build (ScrTy).
@@ -183,22 +196,20 @@ template <bool LDS> UZ_DEV void uz_rk_split(typename Rk<LDS>::T w, int &e, int &
     X(uint8_t, href, cH) X(uint8_t, halt, cH) /* REF / ALT base of every het site of the DNM */                                            \
     X(unsigned long long, site_best, cH) /* chaining: first frontier element finding an allele at a het index: (e << 12 | j) << 16 | allele << 8 | haplotype */ \
     X(int32_t, cpos, cC) X(uint32_t, cvote, cC) X(uint8_t, cflag, cC) X(uint8_t, cref, cC) X(uint8_t, calt, cC) /* per candidate: UZ_CF_* flags, REF and ALT base */ \
-    X(hidx, reg_h, cT) X(xidx, reg_t, cT) X(pidx, reg_pair, cT) X(uint8_t, cbase, cT) /* reg_t: the registration's place in its fetch (its record = h_a[h] + reg_t) */ \
     X(int32_t, i_seg, cI) X(pidx, i_pair, cI) X(uint8_t, i_hb, cI) /* i_hb: bit 0 haplotype ("alt" list), bit 1 the element has a mate */  \
-    X(uint32_t, i_q, cI) X(int32_t, i_soff, cI) X(uint32_t, i_pk, cI) /* name id; first seed entry; seeding matches qp | L << 8 | (R + 1) << 16 (arena build) */ \
-    X(skey, keys, cM) /* pair table: (name, sequence) keys; after the sort the entries (pair id << SB | sequence) */                        \
-    X(hidx, seq_h, cM) X(hidx, srt_h, cM) X(uint8_t, srt_fb, cM)                                                                           \
+    X(uint32_t, i_q, cI) X(int32_t, i_soff, cI) X(uint32_t, i_pk, cI) /* (seeding step only) name id; first seed entry; matches qp | L << 8 | (R + 1) << 16 (arena build) */ \
+    X(skey, keys, cM) /* pair table: (name, sequence) keys; after the sort the entry words (En) */                                         \
+    X(xidx, reg_t, cT) /* (B .. P) per registration: the item of the fetch list it came from (its het site and record follow from h_off / h_a) */ \
+    X(fidx, x16, cM)   /* (P .. D) per entry: its own record, then its pair's primary segment (1 + record - rbase, 0 = none) */             \
+    X(hidx, seq_h, cM) /* het index of every seed entry */                                                                                 \
     X(xidx, rs_off, cM) X(rlen, rs_len, cM) X(gflg, grp, cM) X(gflg, pvote, cM)                                                            \
-    X(xidx, plast, cM) /* per pair: 1 + sequence number of the entry whose record is the pair's primary segment ("last writer wins", quirk Q11), 0 = none */ \
+    X(fidx, pf0, cM) /* per pair: its primary segment -- fetched_reads[name][0], "last writer wins" (quirk Q11) -- as 1 + record - rbase, 0 = none */ \
     X(uint32_t, f_item, 2 * cM) /* join: the (pair, haplotype) items of the grouped pairs, compacted */                                      \
-    X(rkey, pkey, cM) /* per pair: smallest claim rank of the current chaining level */                                                    \
-    X(rkey, win, cM)  /* winners of a chaining level */                                                                                    \
-    X(pidx, fr_pair0, cFR) X(pidx, fr_pair1, cFR)                                                                                          \
-    X(hidx, fr_pos0, cFR) X(hidx, fr_pos1, cFR) /* canonical het index of the site a frontier element was claimed at (-1: an init element) */ \
-    X(uint8_t, fr_hap0, cFR) X(uint8_t, fr_hap1, cFR)                                                                                      \
-    X(int32_t, misc, 8) /* [0] KeyError seen, [1] match_info count, [2] capacity exceeded, [3] winners of the level */
+    X(rkey, win, cFR) X(pidx, w_pair, cFR) X(hidx, w_pos, cFR) /* winners of a chaining level: key, pair, canonical het index of the site */ \
+    X(pidx, fr_pair, cFR) X(hidx, fr_pos, cFR) X(uint8_t, fr_hap, cFR) /* the frontier: pair, canonical het index of the site the element was claimed at (-1: an init element), haplotype */ \
+    X(int32_t, misc, 8) /* [0] KeyError seen, [1] match_info count, [2] capacity exceeded */
 // ---- arrays that stay in the HBM scratch in both builds (none of them on the point-variant path of the arena build: since round 5 a pair's
-// records follow from arena arrays alone -- plast -> reg_h / reg_t / h_a or i_seg, and the second record is the first one's mate)
+// records follow from arena arrays alone, and the second record of a pair is the first one's mate)
 #define UZ_SCR_HBM(X)                                                                                                                     \
     X(int32_t, i_qp, cI) X(int32_t, i_L, cI) X(int32_t, i_R, cI) /* SV evidence: banned names, filter flags; HBM build: the seeding matches */ \
     X(uint32_t, pq, cM)            /* name id of every pair (the optional lists) */                                                        \
@@ -213,6 +224,7 @@ struct ScrT {
     typedef typename ScrTy<LDS>::rlen rlen; // length of a read_sites list
     typedef typename ScrTy<LDS>::gflg gflg; // per-pair flag sets (haplotype groups, votes)
     typedef typename ScrTy<LDS>::rkey rkey; // claim rank of a chaining level (Rk)
+    typedef typename ScrTy<LDS>::fidx fidx; // a record relative to the DNM's first one
     // pair-table sort key: (name id, sequence number).  HBM build: id << 24 | sequence in 64 bits.  Arena build: the ids a DNM meets lie
     // close together (they are handed out in file order), so (id - smallest id of the DNM) and the sequence number share 32 bits -- a DNM
     // whose ids do not fit is given up to the HBM build
@@ -238,7 +250,7 @@ struct ScrOff {
 };
 // fills `o`, returns the bytes of one workgroup's region
 UZ_HD size_t uz_scratch_layout(const Caps &c, ScrOff &o) {
-    typedef Scr::hidx hidx; typedef Scr::pidx pidx; typedef Scr::xidx xidx; typedef Scr::rlen rlen; typedef Scr::gflg gflg; typedef Scr::skey skey; typedef Scr::rkey rkey;
+    typedef Scr::hidx hidx; typedef Scr::pidx pidx; typedef Scr::xidx xidx; typedef Scr::rlen rlen; typedef Scr::gflg gflg; typedef Scr::skey skey; typedef Scr::rkey rkey; typedef Scr::fidx fidx;
     const size_t cA = (size_t)c.A + 1, cT = (size_t)c.T + 1, cH = (size_t)c.H + 2, cC = (size_t)c.C + 1, cI = (size_t)c.I + 2, cM = (size_t)c.M + 2;
     const size_t cFR = (cM > cI ? cM : cI) + 1;
     size_t at = 0;
@@ -256,7 +268,7 @@ UZ_DEV void uz_scr_hbm(ScrT<LDS> &s, const ScrOff &o, uint8_t *base) {
     UZ_SCR_HBM(UZ_X)
 #undef UZ_X
 }
-// HBM build: the other arrays too, once per DNM (the body swaps `keys` and `key` after its counting sort: they are not set again)
+// HBM build: the other arrays too, once per DNM
 UZ_DEV void uz_scr_all(Scr &s, const ScrOff &o, uint8_t *base) {
 #define UZ_X(TY, NAME, CNT) s.NAME = reinterpret_cast<decltype(s.NAME)>(base + o.NAME);
     UZ_SCR_ARENA(UZ_X)
@@ -682,6 +694,73 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i,
     return (lead >= rp - 1 || trail >= len - (rp + 1)) ? 2 : 0; // :576-586
 }
 
+// ------------------------------------------------------------------ sizing
+// Upper bounds of the per-DNM working set, computed before the scratch is sized:
+//   b[0] records in the DNM fetch range, b[1] sum of the het-site fetch ranges, b[2] het sites,
+//   b[3] candidates, b[4] max het sites inside any window of max_span+1 bases (bounds the
+//   seeding matches of one init element).
+// Lanes lane, lane + nlanes, ... share the het sites of DNM d; lane 0 also does the per-DNM part.
+// The caller reduces (t_part: sum, mh_part: max) over the lanes and stores them as b[1], b[4].
+// (Tried in round 4 and dropped: the window found by the 16 lanes of a DNM's group together, 16 probes per round -- seven rounds instead of ~24
+// dependent loads.  0.40 -> 0.49 ms for 100 k DNMs: the first rounds of a 16-ary search land all over a 3 GB column, cold in every cache and
+// TLB, where a binary search takes its first twelve steps on the 180 KB coarse index that stays in L2.)
+// (the window [wa, wb) of the DNM -- uz_dnm_window -- is an argument)
+// (Tried in round 5 and dropped: no sizing kernel for a batch run speculatively, every wave of the read stage working out the fetch ranges of
+// its own DNM when it takes the DNM up -- window bounds by the 64 lanes together, the window's start column staged once into the empty
+// arena, every range searched there.  ~25 dependent round trips at ~1 us under load, later ~12: 0.7 ms per 100 k DNMs inside the read stage
+// against 0.42 ms for the kernel below, which has every DNM of the batch in flight at once.)
+UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long wa, long long wb, long long &t_part, int &mh_part) {
+    const RD &R = a.R;
+    const long long h0 = a.het_off[d];
+    const int nh = (int)(a.het_off[d + 1] - h0);
+    t_part = 0; mh_part = 0;
+    const int tid = a.rcontig[d];
+    if (lane == 0) {
+        const long long position = a.dstart[d];
+        const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
+        long long fa, fb;
+        uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
+        long long fa2 = 0, fb2 = 0;
+        if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
+            const long long icut = (long long)uz_cutoff(a, d);
+            long long lo = (long long)a.dstart[d] - icut;
+            if (lo < 0) lo = 0;
+            uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);
+            lo = (long long)a.dend[d] - icut;
+            if (lo < 0) lo = 0;
+            uz_fetch_range(R, tid, lo, (long long)a.dend[d] + icut, fa2, fb2);
+        }
+        b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
+        a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
+        a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
+    }
+    if (a.no_extended) return;
+    const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;
+    for (int h = lane; h < nh; h += nlanes) {
+        const long long hp = a.spos[a.het_idx[h0 + h]];
+        long long ha, hb;
+        uz_fetch_range_in(R, tid, wa, wb, hp, hp + 1, ha, hb);
+        a.pre_ha[h0 + h] = (int32_t)ha; a.pre_hl[h0 + h] = (int32_t)(hb - ha);
+        t_part += hb - ha;
+        int left = h; // first het site (the list is sorted) a record ending at hp could still reach back to
+        while (left > 0 && (long long)a.spos[a.het_idx[h0 + left - 1]] >= hp - span - 1) left--;
+        if (h - left + 1 > mh_part) mh_part = h - left + 1;
+    }
+}
+UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part) {
+    const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - a.het_off[d]);
+    t_part = 0; mh_part = 0;
+    if (lane == 0) {
+        b[0] = b[1] = b[4] = 0;
+        b[2] = nh; b[3] = nc;
+        for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
+    }
+    if (nc <= 0) return;
+    long long wa, wb;
+    uz_dnm_window(a, d, wa, wb);
+    uz_phase_bounds_w(a, d, b, lane, nlanes, wa, wb, t_part, mh_part);
+}
+
 // ------------------------------------------------------------------ one DNM
 // The arguments of the kernel, read where they are used.  A by-value kernel argument is loaded whole at the kernel's entry: PhaseArgs
 // is ~120 scalar registers of pointers and sizes, all alive across a 16 k-instruction body that has ~100 to give -- the compiler parked
@@ -752,6 +831,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     typedef typename ScrT<LDS>::rlen rlen;
     typedef typename ScrT<LDS>::skey skey;
     typedef typename ScrT<LDS>::rkey rkey;
+    typedef typename ScrT<LDS>::fidx fidx;
     PhaseArgs a;
     uz_args_load(a, ap);
     const RD &R = a.R;
@@ -940,7 +1020,25 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         WG_T0 s.h_off[nh] = T;
         WG_SYNC();
     }
+    // rbase: the first record any array of this DNM names -- the arena build keeps records as 16-bit distances from it
+    int rbase = 0;
+    if constexpr (LDS) {
+        int lo = 0x7FFFFFFF, hi = -1;
+        WG_FOR(h, nh) {
+            if (!a.no_extended && s.h_off[h + 1] > s.h_off[h]) {
+                const int f = s.h_a[h], l = f + (s.h_off[h + 1] - s.h_off[h]) - 1;
+                lo = f < lo ? f : lo; hi = l > hi ? l : hi;
+            }
+        }
+        WG_FOR(m, nI) { const int f = s.i_seg[m]; lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
+        int mn, mx;
+        wg_minmax(lo, hi, mn, mx, sh);
+        if (mx >= 0 && (long long)mx - (long long)mn >= 65534) return 1; // (uniform)
+        rbase = mx >= 0 ? mn : 0;
+    }
     // ---- init elements: name, mate, and (C, :226-249) the matches of every element among the het sites -- one round trip for all of it
+    ar_reset(ar); // (the classes and lists of phase A are not read again)
+    ar_t<LDS>(ar, s.i_q, (size_t)nI + 2); ar_t<LDS>(ar, s.i_soff, (size_t)nI + 2);
     if (LDS) ar_t<LDS>(ar, s.i_pk, (size_t)nI + 1);
     if (LDS && ar.fail) return 1;
     WG_FOR(m, nI) {
@@ -962,43 +1060,58 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         S = wg_exscan(s.i_soff, nI, sh);
         WG_T0 s.i_soff[nI] = S;
         WG_SYNC();
-        ar_p<LDS>(ar, s.seq_h, (size_t)S + 1); // het index of every seed entry
-        if (LDS && ar.fail) return 1;
-        if (S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
-        WG_FOR(m, nI) {
-            const int nm = s.i_soff[m + 1] - s.i_soff[m];
-            if (nm > 0) {
-                int qp, L, Rr;
-                if constexpr (LDS) { const uint32_t pk = s.i_pk[m]; qp = (int)(pk & 255u); L = (int)((pk >> 8) & 255u); Rr = (int)(pk >> 16) - 1; }
-                else { qp = s.i_qp[m]; L = s.i_L[m]; Rr = s.i_R[m]; }
-                for (int j = 0; j < nm; j++) s.seq_h[s.i_soff[m] + j] = (hidx)uz_bsearch_nth(j, qp, L, Rr);
-            }
-        }
-        WG_SYNC();
     }
-    UZ_TICK(1); // A.lists + C
-    // ---- pair-table keys (name, sequence): registrations seq < E, then the seeds, then one presence entry per init element
-    // (seq >= E + S) so that every grouped pair has an id.  B writes the registrations' keys as it compacts them.
+    // ---- pair-table keys (name, sequence).  Sequence numbers: registration k -> k, seed j -> T + j, the presence entry of init element
+    // m (every grouped pair needs an id) -> T + S + m: the reference's time order, known before the registrations are counted.  In the key
+    // array the seeds and presence entries come first (S + nI of them), the registrations behind them as B compacts them.
     const int Mcap = T + S + nI;
     if (Mcap >= (1 << 20) || Mcap > a.caps.M) { // rank-key field widths / scratch: loud, never silent
         WG_T0 a.status[d] = UZ_ST_CAPACITY;
         return 0;
     }
-    if (LDS && Mcap > 65535) return 1; // 16-bit indices of the arena build
-    ar_reset(ar);
+    if (LDS && Mcap >= (1 << En<true>::SEQ_B)) return 1; // 15-bit sequence numbers of the arena build
+    if (!LDS && nh >= (1 << En<false>::H_B)) { WG_T0 a.status[d] = UZ_ST_CAPACITY; return 0; }
     {
-        ar_p<LDS>(ar, s.reg_h, (size_t)T + 1); ar_p<LDS>(ar, s.reg_t, (size_t)T + 1);
+        ar_p<LDS>(ar, s.seq_h, (size_t)S + 1);
         size_t kcap = (size_t)Mcap + 2; // (a table beyond 1024 entries is sorted in place: room for the next power of two)
         if (LDS && Mcap > 1024) { kcap = 2048; while (kcap < (size_t)Mcap) kcap <<= 1; kcap += 1; }
-        ar_t<LDS>(ar, s.keys, kcap);
+        ar_p<LDS>(ar, s.keys, kcap);
     }
     if (LDS && ar.fail) return 1;
     int lmin = 0x7FFFFFFF, lmax = -1; // range of the query-name ids met (as int: ids beyond 2^31 take the bitonic path / the HBM build)
-    auto put_key = [&](int x, uint32_t q) {
-        if constexpr (LDS) s.keys[x] = q; // (shifted below, once the smallest id is known)
-        else s.keys[x] = ((unsigned long long)q << 24) | (unsigned long long)x;
+    auto put_key = [&](int pos, int seq, uint32_t q) {
+        if constexpr (LDS) s.keys[pos] = q; // (shifted below, once the smallest id is known; the sequence number follows from the place)
+        else s.keys[pos] = ((unsigned long long)q << 24) | (unsigned long long)seq;
         lmin = (int)q < lmin ? (int)q : lmin;
         lmax = (int)q > lmax ? (int)q : lmax;
+    };
+    if (!a.no_extended && S > 0 && nh > 0) { WG_T0 s.sr_exists[s.hcanon[nh - 1]] = 1; } // stale loop variable, :242-243 (quirk Q13)
+    WG_FOR(m, nI) {
+        const uint32_t q = s.i_q[m];
+        if (!a.no_extended) {
+            const int o = s.i_soff[m], nm = s.i_soff[m + 1] - o;
+            if (nm > 0) {
+                int qp, L, Rr;
+                if constexpr (LDS) { const uint32_t pk = s.i_pk[m]; qp = (int)(pk & 255u); L = (int)((pk >> 8) & 255u); Rr = (int)(pk >> 16) - 1; }
+                else { qp = s.i_qp[m]; L = s.i_L[m]; Rr = s.i_R[m]; }
+                for (int j = 0; j < nm; j++) {
+                    s.seq_h[o + j] = (hidx)uz_bsearch_nth(j, qp, L, Rr);
+                    put_key(o + j, T + o + j, q);
+                }
+            }
+        }
+        put_key(S + m, T + S + m, q);
+    }
+    WG_SYNC();
+    UZ_TICK(1); // A.lists + C
+    ar_reset(ar); // (name ids and matches of the init elements are in the keys now)
+    ar_t<LDS>(ar, s.x16, (size_t)Mcap + 1); ar_t<LDS>(ar, s.reg_t, (size_t)T + 1);
+    if (LDS && ar.fail) return 1;
+    const int kreg = S + nI; // place of registration 0 in the key array
+    auto het_of = [&](int t) { // the fetch an item of the fetch list belongs to: last h with h_off[h] <= t (empty fetches share an offset: the last of them holds t)
+        int lo = 0, hi = nh;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.h_off[mid] <= t) lo = mid; else hi = mid; }
+        return lo;
     };
     if (!a.no_extended) {
         // ---- B: registration at every het site, in list order (group_reads_by_haplotype :165-222).  Items = the records of all het-site
@@ -1016,10 +1129,8 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
                 tt[u] = t0 + u * WG_NT + lane;
                 act[u] = tt[u] < T;
                 const int t = act[u] ? tt[u] : T - 1;
-                int lo = 0, hi = nh; // last h with h_off[h] <= t (empty ranges share an offset: the last of them is the one that holds t)
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s.h_off[mid] <= t) lo = mid; else hi = mid; }
-                hh[u] = lo;
-                sg[u] = s.h_a[lo] + (t - s.h_off[lo]);
+                hh[u] = het_of(t);
+                sg[u] = s.h_a[hh[u]] + (t - s.h_off[hh[u]]);
             }
             RecA A[2], Mt[2];
             RecB B[2];
@@ -1046,9 +1157,8 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
                 if (first) // site_reads range of het index h starts here; so do the (empty) ranges in front of it that share its offset
                     for (int h2 = h; h2 >= 0 && s.h_off[h2] == t; h2--) s.sr_off[h2] = k;
                 if (ok) {
-                    s.reg_h[k] = (hidx)h;
-                    s.reg_t[k] = (xidx)(t - s.h_off[h]);
-                    put_key(k, B[u].qname);
+                    s.reg_t[k] = (xidx)t;
+                    put_key(kreg + k, k, B[u].qname);
                 }
             }
         }
@@ -1067,17 +1177,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     const int M = E + S + nI;
     if (LDS && E >= (1 << Rk<true>::KB)) return 1; // (an index into a site_reads list is a field of the 32-bit claim rank)
     int SB = 24; // bits of a key that hold the sequence number
-    if constexpr (LDS) { SB = 1; while ((1 << SB) < M) SB++; }
-    WG_FOR(m, nI) { // seeds and presence entries of every init element
-        const uint32_t q = s.i_q[m];
-        if (!a.no_extended) {
-            const int o = E + s.i_soff[m], nm = s.i_soff[m + 1] - s.i_soff[m];
-            for (int j = 0; j < nm; j++) put_key(o + j, q);
-        }
-        put_key(E + S + m, q);
-    }
-    WG_SYNC();
-    UZ_TICK(5); // S.keys
+    if constexpr (LDS) { SB = 1; while ((1 << SB) < Mcap) SB++; }
     // Sort by (query-name id, sequence).
     int qmin = -1, qmax = -1;
     {
@@ -1085,8 +1185,9 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         if constexpr (LDS) {
             // the keys sit in the arena, packed into 32 bits: bitonic sort in registers (up to 16 keys per lane)
             if (qmin < 0 || (((unsigned)(qmax - qmin)) >> (32 - SB)) != 0u) return 1; // (uniform) the HBM build sorts 64-bit keys
-            WG_FOR(x, M) s.keys[x] = ((s.keys[x] - (uint32_t)qmin) << SB) | (uint32_t)x;
+            WG_FOR(x, M) s.keys[x] = ((s.keys[x] - (uint32_t)qmin) << SB) | (uint32_t)(x < kreg ? T + x : x - kreg);
             WG_SYNC();
+            UZ_TICK(5); // S.keys
             wg_sort32_lds(s.keys, M);
         } else {
             // keys in HBM scratch.  Name ids are interned in file order, so the names met around one locus span a short
@@ -1116,7 +1217,8 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
                     }
                 }
                 WG_SYNC();
-                { unsigned long long *sorted = s.key; s.key = s.keys; s.keys = sorted; } // both hold cM entries
+                WG_FOR(x, M) s.keys[x] = s.key[x]; // (back into the entry array: `key` is scratch again -- the winners' sorted copy in phase E)
+                WG_SYNC();
             } else
                 wg_sort64(s.keys, M, sh);
         }
@@ -1132,13 +1234,12 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             P += wg_count(act && (x == 0 || nmx != pv));
         }
     }
-    // per-entry and per-pair arrays, now that their lengths are known
-    ar_p<LDS>(ar, s.reg_pair, (size_t)E + 1); ar_p<LDS>(ar, s.cbase, (size_t)E + 1);
-    ar_p<LDS>(ar, s.srt_h, (size_t)M + 1); ar_p<LDS>(ar, s.srt_fb, (size_t)M + 1);
-    ar_p<LDS>(ar, s.rs_off, (size_t)P + 2); ar_p<LDS>(ar, s.rs_len, (size_t)P + 1); ar_p<LDS>(ar, s.grp, (size_t)P + 1); ar_p<LDS>(ar, s.plast, (size_t)P + 1);
+    ar_p<LDS>(ar, s.rs_off, (size_t)P + 2); // (the other per-pair arrays once the registrations' places have been read: their room is reg_t's)
     if (LDS && ar.fail) return 1;
     UZ_TICK(7); // P.count
     {
+        // one pass over the sorted keys: run starts -> pair ids; every key becomes its entry word (sequence number, het index); x16 takes
+        // the entry's own record
         uint32_t carry = 0;
         int pb = 0;
         WG_ROUNDS(x, M, act) {
@@ -1149,32 +1250,45 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             const int pid = wg_rank(st, pb) + (st ? 1 : 0) - 1; // run starts up to and including this entry, minus one
             if (act) {
                 const int seq = (int)(key & seqmask);
+                int h = 0, own = 0;
+                if (seq < T) { // a registration: het site and record from its place in the fetch list
+                    const int t = (int)s.reg_t[seq];
+                    h = het_of(t);
+                    own = s.h_a[h] + (t - s.h_off[h]) - rbase + 1;
+                } else if (seq < T + S) h = s.seq_h[seq - T];
+                else {
+                    own = s.i_seg[seq - T - S] - rbase + 1;
+                    s.i_pair[seq - T - S] = (pidx)pid;
+                }
                 if (st) {
                     s.rs_off[pid] = (xidx)x;
                     if (a.want_lists) s.pq[pid] = LDS ? nmx + (uint32_t)qmin : nmx; // name id of the pair (the optional lists)
                 }
-                if (seq < E) s.reg_pair[seq] = (pidx)pid;
-                else if (seq >= E + S) s.i_pair[seq - E - S] = (pidx)pid;
-                s.srt_h[x] = seq < E ? s.reg_h[seq] : (seq < E + S ? s.seq_h[seq - E] : (hidx)-1);
-                s.keys[x] = ((skey)pid << SB) | (skey)seq; // the entry: pair id above its sequence number
+                s.keys[x] = uz_en_make<LDS>(seq, h);
+                s.x16[x] = (fidx)own;
             }
         }
         WG_T0 s.rs_off[P] = (xidx)M;
         WG_SYNC();
     }
+    ar_pop<LDS>(ar, s.reg_t, (size_t)T + 1);
+    ar_p<LDS>(ar, s.rs_len, (size_t)P + 1); ar_p<LDS>(ar, s.grp, (size_t)P + 1); ar_p<LDS>(ar, s.pf0, (size_t)P + 1);
+    if (LDS && ar.fail) return 1;
     UZ_TICK(8); // P.scatter
     WG_FOR(p, P) {
         const int x0 = s.rs_off[p], x1 = s.rs_off[p + 1];
-        int len = 0, last = -1;
+        int len = 0, lastx = -1;
         for (int x = x0; x < x1; x++) { // ascending sequence = the reference's time order: the last writer of fetched_reads wins (quirk Q11)
-            const int seq = (int)(s.keys[x] & seqmask);
-            if (seq < E + S) len++;
-            if (seq < E) last = seq;                                          // :222
-            else if (seq >= E + S && (s.i_hb[seq - E - S] & 2)) last = seq;   // :233-234 (an element with a mate)
+            const int seq = uz_en_seq<LDS>(s.keys[x]);
+            if (seq < T + S) len++;
+            if (seq < T) lastx = x;                                           // :222
+            else if (seq >= T + S && (s.i_hb[seq - T - S] & 2)) lastx = x;   // :233-234 (an element with a mate)
         }
+        const fidx f = lastx >= 0 ? s.x16[lastx] : (fidx)0;
+        for (int x = x0; x < x1; x++) s.x16[x] = f; // every entry of the pair now names the pair's primary segment
         if (len >= (1 << Rk<LDS>::JB)) s.misc[2] = 1; // rank key: the bits of the read_sites index
         s.rs_len[p] = (rlen)len;
-        s.plast[p] = (xidx)(last + 1);
+        s.pf0[p] = f;
         s.grp[p] = 0;
     }
     WG_SYNC();
@@ -1194,17 +1308,14 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     // the primary segment of a pair -- fetched_reads[name][0], "last writer wins" (quirk Q11) -- or -1; the second one is its mate
     // (a registration's mate and an init element's mate both are the record's own mate field).  Arena arrays only.
     auto primary = [&](int p) -> int {
-        const int l = (int)s.plast[p];
-        if (!l) return -1;
-        const int seq = l - 1;
-        if (seq < E) return s.h_a[s.reg_h[seq]] + (int)s.reg_t[seq];
-        return s.i_seg[seq - E - S];
+        const int f = (int)s.pf0[p];
+        return f ? rbase + f - 1 : -1;
     };
     if (!a.no_extended) {
         // ---- D: static allele tables.  One pass over the sorted entries: the pair-level finder allele
         // at the entry's het site (get_allele_at, :91-105) and, for registrations, the base the
         // pair's primary segment shows there (:114-124).  Both start from the same index into the
-        // primary segment, computed once.
+        // primary segment, computed once; both go into the entry's word.
         // UZ_PHASE_K entries per lane and round, staged: (i) the entries' primary-segment headers and quality-plane offsets,
         // (ii) the mates' headers where the primary segment does not cover the site, (iii) the base / quality bit --
         // each stage's loads of all the lane's entries are in flight together (a DNM's ~400 entries: two rounds of three round trips).
@@ -1212,22 +1323,24 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             constexpr int K = UZ_PHASE_K;
             const int lane = wg_lane_opaque();
             for (int xb = 0; xb < M; xb += K * WG_NT) {
-                int xx[K], hh[K], sq[K], qi[K], mt[K];
+                int xx[K], hh[K], qi[K], mt[K];
+                skey wv[K];
                 RowRef row[K];
                 uint32_t q0[K], um0[K];
-                bool live[K], own[K], needm[K];
+                bool live[K], own[K], needm[K], isreg[K];
                 {
                     SegHdr hd0[K];
 #pragma unroll
                     for (int u = 0; u < K; u++) {
                         xx[u] = xb + u * WG_NT + lane;
                         const int x = xx[u] < M ? xx[u] : 0;
-                        hh[u] = s.srt_h[x];
-                        const skey ent = s.keys[x];
-                        sq[u] = (int)(ent & seqmask);
-                        const int f0 = primary((int)(ent >> SB));
-                        live[u] = xx[u] < M && hh[u] >= 0 && f0 >= 0;
-                        const int f = live[u] ? f0 : 0;
+                        wv[u] = s.keys[x];
+                        const int seq = uz_en_seq<LDS>(wv[u]);
+                        hh[u] = uz_en_h<LDS>(wv[u]);
+                        isreg[u] = seq < T;
+                        const int fx = (int)s.x16[x];
+                        live[u] = xx[u] < M && seq < T + S && fx != 0;
+                        const int f = live[u] ? rbase + fx - 1 : 0;
                         hd0[u] = uz_hdr(R, f);
                         q0[u] = R.qoff[f];
                     }
@@ -1259,47 +1372,38 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
 #pragma unroll
                 for (int u = 0; u < K; u++) {
                     al[u] = qi[u] >= 0 ? uz_base(R, row[u], qi[u]) : (uint8_t)0;
-                    low[u] = (qi[u] >= 0 && own[u] && sq[u] < E) ? uz_qual_low(R, RowRef{q0[u], um0[u]}, qi[u]) : true; // (only a registration uses it, below)
+                    low[u] = (qi[u] >= 0 && own[u] && isreg[u]) ? uz_qual_low(R, RowRef{q0[u], um0[u]}, qi[u]) : true; // (only a registration uses it, below)
                 }
 #pragma unroll
                 for (int u = 0; u < K; u++) {
-                    if (xx[u] >= M) continue;
-                    uint8_t fbv = 0, cb = 0;
-                    if (qi[u] >= 0) {
-                        const int h = hh[u];
-                        if (al[u] == s.href[h] || al[u] == s.halt[h]) fbv = al[u]; // :98-105
-                        if (own[u] && sq[u] < E && !low[u]) cb = al[u];           // :114-124
-                    }
-                    s.srt_fb[xx[u]] = fbv;
-                    if (sq[u] < E) s.cbase[sq[u]] = cb;
+                    if (xx[u] >= M || qi[u] < 0) continue; // (the word was written without alleles)
+                    const int h = hh[u];
+                    const int fbc = al[u] == s.href[h] ? 1 : (al[u] == s.halt[h] ? 2 : 0); // :98-105
+                    const int cb = (own[u] && isreg[u] && !low[u]) ? (int)al[u] : 0;        // :114-124
+                    if (fbc | cb) s.keys[xx[u]] = uz_en_alleles<LDS>(wv[u], fbc, cb);
                 }
             }
         }
         WG_SYNC();
         UZ_TICK(10); // D.finder
         // ---- E: chaining.  Level 0 visits new_reads "alt" then "ref" (:224); deeper levels "ref" then "alt" (:78)
-        int F = nI, cur = 0;
-        // winners of one level: at most P.  The arena build sets room aside for 128 (a level rarely has more than a few
-        // dozen) and gives the DNM up if a level overflows it.
-        const int wcap = (LDS && P > 128) ? 128 : P;
+        int F = nI;
+        // winners of one level: at most P.  The arena build sets room aside for 96 (a level rarely has more than a few
+        // dozen: 19 at the median of the bench workload, 80 at most) and gives the DNM up if a level overflows it.
+        const int wcap = (LDS && P > 96) ? 96 : P;
         {
-            ar_reset(ar); // (the sorted entries are not read again)
+            ar_reset(ar); // (the entries' primary segments are not read again: the join takes them per pair)
             const size_t fr = (size_t)(wcap > nI ? wcap : nI) + 2;
-            ar_t<LDS>(ar, s.pkey, (size_t)P + 1);
-            ar_t<LDS>(ar, s.fr_pair0, fr); ar_t<LDS>(ar, s.fr_hap0, fr); ar_t<LDS>(ar, s.fr_pair1, fr); ar_t<LDS>(ar, s.fr_hap1, fr);
-            ar_t<LDS>(ar, s.fr_pos0, fr); ar_t<LDS>(ar, s.fr_pos1, fr);
-            int wp2 = 2; // the winners are sorted in place: room for the next power of two
-            while (wp2 < wcap) wp2 <<= 1;
-            ar_t<LDS>(ar, s.win, (size_t)wp2 + 1);
+            ar_t<LDS>(ar, s.fr_pair, fr); ar_t<LDS>(ar, s.fr_pos, fr); ar_t<LDS>(ar, s.fr_hap, fr);
+            ar_t<LDS>(ar, s.win, (size_t)wcap + 2); ar_t<LDS>(ar, s.w_pair, (size_t)wcap + 2); ar_t<LDS>(ar, s.w_pos, (size_t)wcap + 2);
         }
         if (LDS && ar.fail) return 1;
-        WG_FOR(p, P) s.pkey[p] = uz_rk_none<LDS>();
         WG_FOR(e, nI) {
             const int na = nae;
             const int m = e < na ? (nre + e) : (e - na);
-            s.fr_pair0[e] = s.i_pair[m];
-            s.fr_pos0[e] = (hidx)-1;
-            s.fr_hap0[e] = (uint8_t)(s.i_hb[m] & 1);
+            s.fr_pair[e] = s.i_pair[m];
+            s.fr_pos[e] = (hidx)-1;
+            s.fr_hap[e] = (uint8_t)(s.i_hb[m] & 1);
         }
         // (a pair is "assigned" exactly when it carries a haplotype bit in grp: the init pairs from the start, the winners of a
         // level from its end)
@@ -1307,95 +1411,97 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         WG_SYNC();
         UZ_TICK(11); // E.setup
         while (F > 0) {
-            auto *const fr_pair_c = cur ? s.fr_pair1 : s.fr_pair0, *const fr_pair_n = cur ? s.fr_pair0 : s.fr_pair1;
-            auto *const fr_pos_c = cur ? s.fr_pos1 : s.fr_pos0, *const fr_pos_n = cur ? s.fr_pos0 : s.fr_pos1;
-            uint8_t *const fr_hap_c = cur ? s.fr_hap1 : s.fr_hap0, *const fr_hap_n = cur ? s.fr_hap0 : s.fr_hap1;
             // (i) per het index, the first frontier element (in visiting order e, then read_sites
             // index j) that finds a usable allele there.  Every element finding REF or ALT at a het
             // index claims the same entries of its site_reads list, so only that first one can win.
             WG_FOR(e, F) {
-                const int p = fr_pair_c[e];
-                const int fcanon = fr_pos_c[e]; // canonical het index of the site this element was claimed at
-                const unsigned long long hap = fr_hap_c[e];
+                const int p = s.fr_pair[e];
+                const int fcanon = s.fr_pos[e]; // canonical het index of the site this element was claimed at
+                const unsigned long long hap = s.fr_hap[e];
                 const int x0 = s.rs_off[p], len = s.rs_len[p];
                 for (int j = 0; j < len; j++) {
-                    const int h = s.srt_h[x0 + j];
+                    const skey w = s.keys[x0 + j];
+                    const int h = uz_en_h<LDS>(w);
                     if (s.hcanon[h] == fcanon) continue;        // :89-90 (same position <=> same canonical index)
-                    const unsigned long long fbv = s.srt_fb[x0 + j];
-                    if (!fbv) continue;                          // :104-105
+                    const int fbc = uz_en_fb<LDS>(w);
+                    if (!fbc) continue;                          // :104-105
                     if (!s.sr_exists[s.hcanon[h]]) { s.misc[0] = 1; continue; } // :106 KeyError
+                    const unsigned long long fbv = fbc == 1 ? s.href[h] : s.halt[h];
                     // the allele and haplotype of the finder ride along below the rank, so the
                     // registrations can use them without going back to the frontier arrays
                     wg_atomic_min64(&s.site_best[h], ((((unsigned long long)e << 12) | (unsigned long long)j) << 16) | (fbv << 8) | hap);
                 }
             }
             WG_SYNC();
-            // (ii) every still-unassigned registration looks up the finder(s) of its site
-            WG_FOR(k, E) {
-                const int p2 = s.reg_pair[k];
-                if (s.grp[p2]) continue;                         // :108-110 (assigned before this level)
-                const uint8_t cb = s.cbase[k];
-                if (!cb) continue;
-                const int canon = s.hcanon[s.reg_h[k]];
-                const int krel = k - s.sr_off[canon];
-                rkey best = uz_rk_none<LDS>();
-                for (int h = canon; h < nh && s.hpos[h] == s.hpos[canon]; h++) { // het indices sharing the position
-                    const unsigned long long sb = s.site_best[h];
-                    if (sb == ~0ULL) continue;
-                    const unsigned long long b = sb >> 16; // (e << 12) | j
-                    const uint8_t fbv = (uint8_t)(sb >> 8);
-                    const uint8_t nonf = fbv == s.href[h] ? s.halt[h] : s.href[h];
-                    const int hap = (int)(sb & 1ULL);
-                    int target;
-                    if (cb == fbv) target = hap;                 // :134-136
-                    else if (cb == nonf) target = hap ^ 1;       // :137-141
-                    else continue;
-                    const rkey key = uz_rk_make<LDS>(b, krel, target);
-                    best = key < best ? key : best;
-                }
-                if (best != uz_rk_none<LDS>()) wg_atomic_min(&s.pkey[p2], best);
-            }
-            WG_SYNC();
-            UZ_TICK(12); // E.expand
-            // winners in the order the reference appends them: "ref" targets by rank, then "alt"
-            // targets by rank.  A rank (e, j, k) names one site_reads entry, hence one pair, so
-            // sorting the keys alone is enough: the pair is recovered from the rank.
-            WG_FOR(h, nh) s.site_best[h] = ~0ULL; // for the next level
-            // the winners in any order: their place in the next frontier is decided below by the RANK of their key
+            // (ii) every still-unassigned pair looks up the finder(s) of the sites its registrations stand at; the smallest claim
+            // (frontier element, its read_sites index, the registration's place in the site's list) takes the pair (:108-141)
             int W = 0;
             WG_ROUNDS(p, P, act) {
-                const bool w = act && !s.grp[p] && s.pkey[p] != uz_rk_none<LDS>();
-                const int wi = wg_rank(w, W);
-                if (w && wi < wcap) s.win[wi] = uz_rk_win<LDS>(s.pkey[p]);
+                rkey best = uz_rk_none<LDS>();
+                int bcanon = 0;
+                if (act && !s.grp[p]) { // :108-110 (assigned before this level)
+                    const int x1 = s.rs_off[p + 1];
+                    for (int x = s.rs_off[p]; x < x1; x++) {
+                        const skey w = s.keys[x];
+                        const int k = uz_en_seq<LDS>(w);
+                        if (k >= T) break; // (the registrations of a pair come first: smallest sequence numbers)
+                        const uint8_t cb = (uint8_t)uz_en_cb<LDS>(w);
+                        if (!cb) continue;
+                        const int canon = s.hcanon[uz_en_h<LDS>(w)];
+                        const int krel = k - s.sr_off[canon];
+                        for (int h = canon; h < nh && s.hpos[h] == s.hpos[canon]; h++) { // het indices sharing the position
+                            const unsigned long long sb = s.site_best[h];
+                            if (sb == ~0ULL) continue;
+                            const unsigned long long b = sb >> 16; // (e << 12) | j
+                            const uint8_t fbv = (uint8_t)(sb >> 8);
+                            const uint8_t nonf = fbv == s.href[h] ? s.halt[h] : s.href[h];
+                            const int hap = (int)(sb & 1ULL);
+                            int target;
+                            if (cb == fbv) target = hap;                 // :134-136
+                            else if (cb == nonf) target = hap ^ 1;       // :137-141
+                            else continue;
+                            const rkey key = uz_rk_make<LDS>(b, krel, target);
+                            if (key < best) { best = key; bcanon = canon; }
+                        }
+                    }
+                }
+                // the winners in any order: their place in the next frontier is decided below by the RANK of their key
+                const bool won = best != uz_rk_none<LDS>();
+                const int wi = wg_rank(won, W);
+                if (won && wi < wcap) { s.win[wi] = uz_rk_win<LDS>(best); s.w_pair[wi] = (pidx)p; s.w_pos[wi] = (hidx)bcanon; }
             }
             WG_SYNC();
             if (LDS && W > wcap) return 1; // (uniform)
-            UZ_TICK(13); // E.winners
-            // position in the next frontier = rank of the (target, rank) key among the winners: counted
-            // directly while a level has few winners, sorted otherwise
-            const bool by_count = W <= 96;
-            if (!by_count) {
-                if constexpr (LDS) wg_sort32_lds(s.win, W);
-                else wg_sort64(s.win, W, sh, false);
+            UZ_TICK(12); // E.expand
+            WG_FOR(h, nh) s.site_best[h] = ~0ULL; // for the next level
+            // winners in the order the reference appends them: "ref" targets by rank, then "alt" targets by rank.  Position in the
+            // next frontier = rank of the (target, rank) key among the winners: counted directly while a level has few winners (the
+            // arena build always: at most 96), looked up in a sorted copy otherwise
+            const bool by_count = LDS || W <= 96;
+            if constexpr (!LDS) {
+                if (!by_count) {
+                    WG_FOR(w, W) s.key[w] = s.win[w];
+                    WG_SYNC();
+                    wg_sort64(s.key, W, sh, false);
+                }
             }
             WG_FOR(w, W) {
                 const rkey ok = s.win[w];
-                int posn = w;
+                int posn = 0;
                 if (by_count) {
-                    posn = 0;
                     for (int v = 0; v < W; v++) posn += s.win[v] < ok;
+                } else if constexpr (!LDS) {
+                    int lo = 0, hi = W;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s.key[mid] < ok) lo = mid + 1; else hi = mid; }
+                    posn = lo;
                 }
-                int e, j, krel, target;
-                uz_rk_split<LDS>(ok, e, j, krel, target);
-                const int pe = fr_pair_c[e];
-                const int h = s.srt_h[s.rs_off[pe] + j];
-                const int p = s.reg_pair[s.sr_off[s.hcanon[h]] + krel];
-                fr_pair_n[posn] = (pidx)p;
-                fr_pos_n[posn] = (hidx)s.hcanon[h];
-                fr_hap_n[posn] = (uint8_t)target;
-                // every winner key names a different pair: mark it here
+                const int target = (int)(ok >> (8 * sizeof(rkey) - 1));
+                const int p = s.w_pair[w];
+                s.fr_pair[posn] = (pidx)p;
+                s.fr_pos[posn] = s.w_pos[w];
+                s.fr_hap[posn] = (uint8_t)target;
+                // every winner is a different pair: mark it here
                 wg_or_flag(s.grp, p, target ? 2u : 1u);
-                s.pkey[p] = uz_rk_none<LDS>();
             }
             WG_SYNC();
 #ifdef UZ_EMU_STATS
@@ -1404,7 +1510,6 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
 #endif
             UZ_TICK(14); // E.frontier
             F = W;
-            cur ^= 1;
         }
         exception = s.misc[0] != 0;
     }
@@ -1457,7 +1562,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         int nF = 0;
         WG_ROUNDS(it, 2 * P, act) {
             const int p = it >> 1;
-            nF += wg_count(act && (s.grp[p] & (1u << (it & 1))) && s.plast[p]);
+            nF += wg_count(act && (s.grp[p] & (1u << (it & 1))) && s.pf0[p]);
         }
         ar_t<LDS>(ar, s.f_item, (size_t)nF + 1);
         if (LDS && ar.fail) return 1;
@@ -1465,7 +1570,7 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
             int fb = 0;
             WG_ROUNDS(it, 2 * P, act) {
                 const int p = it >> 1;
-                const bool on = act && (s.grp[p] & (1u << (it & 1))) && s.plast[p];
+                const bool on = act && (s.grp[p] & (1u << (it & 1))) && s.pf0[p];
                 const int k = wg_rank(on, fb);
                 if (on) s.f_item[k] = (uint32_t)it;
             }
@@ -1575,61 +1680,3 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
     }
     return 0;
 }
-
-// ------------------------------------------------------------------ sizing
-// Upper bounds of the per-DNM working set, computed before the scratch is sized:
-//   b[0] records in the DNM fetch range, b[1] sum of the het-site fetch ranges, b[2] het sites,
-//   b[3] candidates, b[4] max het sites inside any window of max_span+1 bases (bounds the
-//   seeding matches of one init element).
-// Lanes lane, lane + nlanes, ... share the het sites of DNM d; lane 0 also does the per-DNM part.
-// The caller reduces (t_part: sum, mh_part: max) over the lanes and stores them as b[1], b[4].
-// (Tried in round 4 and dropped: the window found by the 16 lanes of a DNM's group together, 16 probes per round -- seven rounds instead of ~24
-// dependent loads.  0.40 -> 0.49 ms for 100 k DNMs: the first rounds of a 16-ary search land all over a 3 GB column, cold in every cache and
-// TLB, where a binary search takes its first twelve steps on the 180 KB coarse index that stays in L2.)
-UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part) {
-    const RD &R = a.R;
-    const long long h0 = a.het_off[d];
-    const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - h0);
-    t_part = 0; mh_part = 0;
-    if (lane == 0) {
-        b[0] = b[1] = b[4] = 0;
-        b[2] = nh; b[3] = nc;
-        for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
-    }
-    if (nc <= 0) return;
-    const int tid = a.rcontig[d];
-    long long wa, wb;
-    uz_dnm_window(a, d, wa, wb);
-    if (lane == 0) {
-        const long long position = a.dstart[d];
-        const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
-        long long fa, fb;
-        uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
-        long long fa2 = 0, fb2 = 0;
-        if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
-            const long long icut = (long long)uz_cutoff(a, d);
-            long long lo = (long long)a.dstart[d] - icut;
-            if (lo < 0) lo = 0;
-            uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);
-            lo = (long long)a.dend[d] - icut;
-            if (lo < 0) lo = 0;
-            uz_fetch_range(R, tid, lo, (long long)a.dend[d] + icut, fa2, fb2);
-        }
-        b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
-        a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
-        a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
-    }
-    if (a.no_extended) return;
-    const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;
-    for (int h = lane; h < nh; h += nlanes) {
-        const long long hp = a.spos[a.het_idx[h0 + h]];
-        long long ha, hb;
-        uz_fetch_range_in(R, tid, wa, wb, hp, hp + 1, ha, hb);
-        a.pre_ha[h0 + h] = (int32_t)ha; a.pre_hl[h0 + h] = (int32_t)(hb - ha);
-        t_part += hb - ha;
-        int left = h; // first het site (the list is sorted) a record ending at hp could still reach back to
-        while (left > 0 && (long long)a.spos[a.het_idx[h0 + left - 1]] >= hp - span - 1) left--;
-        if (h - left + 1 > mh_part) mh_part = h - left + 1;
-    }
-}
-
