@@ -1,9 +1,10 @@
 #!/bin/bash
 # development aid (GPU box): kernel durations of the feed pass (device walk) -- rocprofv3 kernel trace, medians by kernel
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/tlf
-UZ_BENCH_NO_PRODUCT=1 rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $GRAFT_REPO_ROOT/gpurun_out/tlf -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-config5 --steps 1 --warmup 0 "$@" > $GRAFT_REPO_ROOT/gpurun_out/tlf.log 2>&1
-cd $GRAFT_REPO_ROOT
+rm -rf $ROOT/gpurun_out/tlf
+UZ_BENCH_NO_PRODUCT=1 rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $ROOT/gpurun_out/tlf -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --steps 1 --warmup 0 "$@" > $ROOT/gpurun_out/tlf.log 2>&1
+cd $ROOT
 python3 - <<'P'
 import pandas as pd
 k = pd.read_csv('gpurun_out/tlf/run_kernel_trace.csv')

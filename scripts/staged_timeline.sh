@@ -1,11 +1,12 @@
 #!/bin/bash
 # development aid (GPU box): what the device does during ONE staged step of the SNV bench -- kernels per queue and copies, merged into busy
 # spans, with the gaps between them.   scripts/staged_timeline.sh [bench args]
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/stl
+OUT=$ROOT/gpurun_out/stl
 rm -rf $OUT
-rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $OUT -o run -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --feed-dnms 0 --no-config5 --steps 4 --warmup 2 "$@" > $OUT.log 2>&1
-cd $GRAFT_REPO_ROOT
+rocprofv3 --output-format csv --kernel-trace --memory-copy-trace -d $OUT -o run -- python3 $ROOT/bench.py --no-cpu --feed-dnms 0 --no-config5 --steps 4 --warmup 2 "$@" > $OUT.log 2>&1
+cd $ROOT
 python3 - <<'P'
 import pandas as pd, numpy as np, json
 k = pd.read_csv('gpurun_out/stl/run_kernel_trace.csv').sort_values('Start_Timestamp').reset_index(drop=True)

@@ -873,6 +873,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     }
     if (tupf) { // a 16-bit index per record + the table of combinations instead of nine bytes of small columns
         col.tup = h2d(st, tup, v->tup, n);
+        col.n_tup = (int64_t)nt;
         col.tup_flag = h2d(st, t_flag, v->tup_flag, nt); col.tup_l_seq = h2d(st, t_ls, v->tup_l_seq, nt); col.tup_n_cigar = h2d(st, t_nc, v->tup_n_cigar, nt);
         col.tup_mapq = h2d(st, t_mq, v->tup_mapq, nt); col.tup_aux = h2d(st, t_ax, v->tup_aux, nt);
         if (v->tup_n_low) col.tup_n_low = h2d(st, t_nl, v->tup_n_low, nt);
@@ -924,6 +925,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         const void *t[8] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low, col.tup_umask};
         for (int k = 0; k < 8; k++) r.col_t[k] = t[k];
         r.col_lists = col.lists;
+        r.col_ntup = col.n_tup;
         const void *dd[10] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8, col.mate_d8, col.qname_d8, col.pair_d8};
         for (int k = 0; k < 10; k++) r.col_d[k] = dd[k];
         r.col_nesc = col.n_esc16;
@@ -953,7 +955,7 @@ static void build_staged(uz_ctx *c, hipStream_t st, ReadsDev &r) {
     col.cigar_staged = (const uint32_t *)r.col_q[5]; col.cigar_out = (uint32_t *)const_cast<void *>(r.col_q[6]);
     col.tup = (const uint16_t *)r.col_t[0]; col.tup_flag = (const uint16_t *)r.col_t[1]; col.tup_l_seq = (const uint16_t *)r.col_t[2];
     col.tup_n_cigar = (const uint16_t *)r.col_t[3]; col.tup_mapq = (const uint8_t *)r.col_t[4]; col.tup_aux = (const uint8_t *)r.col_t[5];
-    col.tup_n_low = (const uint8_t *)r.col_t[6]; col.tup_umask = (const uint16_t *)r.col_t[7]; col.lists = r.col_lists;
+    col.tup_n_low = (const uint8_t *)r.col_t[6]; col.tup_umask = (const uint16_t *)r.col_t[7]; col.lists = r.col_lists; col.n_tup = r.col_ntup;
     col.start_d = (const int16_t *)r.col_d[0]; col.tlen_s = (const int16_t *)r.col_d[1]; col.mate_d = (const int16_t *)r.col_d[2];
     col.qname_d = (const int16_t *)r.col_d[3]; col.esc16_key = (const unsigned long long *)r.col_d[4]; col.esc16_val = (const int32_t *)r.col_d[5];
     col.start_d8 = (const uint8_t *)r.col_d[6];
@@ -1263,7 +1265,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
             }
             if (v->tup) {
                 col.tup = v->tup; col.tup_flag = v->tup_flag; col.tup_l_seq = v->tup_l_seq; col.tup_n_cigar = v->tup_n_cigar;
-                col.tup_mapq = v->tup_mapq; col.tup_aux = v->tup_aux; col.tup_n_low = v->tup_n_low; col.tup_umask = v->tup_umask;
+                col.tup_mapq = v->tup_mapq; col.tup_aux = v->tup_aux; col.tup_n_low = v->tup_n_low; col.tup_umask = v->tup_umask; col.n_tup = v->n_tup;
             }
             if (v->n_low || (v->tup && v->tup_n_low)) { r.qlow = qlow_own; col.lists = 1; col.n_low = v->n_low; col.qlow_pos = v->qlow_pos; col.qpos_wide = v->qlow_pos_wide; col.umask = v->umask; }
             else col.plane_in = reinterpret_cast<const uint32_t *>(v->qlow);

@@ -66,17 +66,20 @@ __global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(P
         __device__ ~TickFlush() { __syncthreads(); if (threadIdx.x < 24 && s->tick[threadIdx.x]) atomicAdd(&t[threadIdx.x], s->tick[threadIdx.x]); }
     } tick_flush{&sh, uz_g(ap->timing)};
 #endif
-    if (!LDS) { // the list the first kernel left behind, one cursor
+    if (ap->from_list) { // the list the launch before this one left behind, one cursor
+        const int slot = ap->cursor_slot;
         for (;;) {
             __syncthreads();
             if (threadIdx.x == 0) {
-                const int k = atomicAdd(uz_g(ap->work_cursor) + 16 * UZ_PHASE_PARTS, 1);
-                sh.bcast[0] = k < *uz_g(ap->retry_count) ? uz_g(ap->retry_list)[k] : -1;
+                const int k = atomicAdd(uz_g(ap->work_cursor) + 16 * slot, 1);
+                sh.bcast[0] = k < *uz_g(ap->src_count) ? uz_g(ap->src_list)[k] : -1;
             }
             __syncthreads();
             const int d = sh.bcast[0];
             if (d < 0) break;
-            (void)uz_phase_dnm<false>(ap, scr_base, &sh, nullptr, d);
+            if (uz_phase_dnm<LDS>(ap, scr_base, &sh, LDS ? uz_lds_arena : nullptr, d)) { // (uniform; the HBM build never gives a DNM up)
+                if (threadIdx.x == 0) uz_g(ap->retry_list)[atomicAdd(uz_g(ap->retry_count), 1)] = d;
+            }
         }
         return;
     }
@@ -123,7 +126,7 @@ struct PhaseState {
     // the sizes of the batch before this one (with head room): what a batch is first run on (uz_launch_phase)
     bool spec_valid = false;
     Caps spec_caps = {0, 0, 0, 0, 0, 0};
-    int spec_arena = 0;
+    int spec_arena = 0, spec_arena2 = 0;
     double spec_sumP_per_dnm = 0.0;
     long long spec_runs = 0, spec_misses = 0;
     hipEvent_t bounds_ready = nullptr;
@@ -383,6 +386,13 @@ __device__ __forceinline__ void uz_pair_link_one(int64_t i, int64_t j, const uin
     rb[j].qname = rb[i].qname;
 }
 
+// diagnostic build only (-DUZ_PACK_TIMING): shader-clock ticks of lane 0 per section of the header build, summed over the workgroups
+#ifdef UZ_PACK_TIMING
+__device__ unsigned long long uz_pack_ticks[16];
+#define PK_TICK(k) do { if (threadIdx.x == 0) { const unsigned long long now__ = __builtin_amdgcn_s_memtime(); ptk__[k] += now__ - ptl__; ptl__ = now__; } } while (0)
+#else
+#define PK_TICK(k) ((void)0)
+#endif
 template <bool LINK, bool SELF>
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, PkWant want, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
@@ -391,6 +401,9 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
     __shared__ uint32_t wsum[UZ_PK_SCANNED][4];
     __shared__ int64_t esc_span[2];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#ifdef UZ_PACK_TIMING
+    unsigned long long ptk__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ptl__ = __builtin_amdgcn_s_memtime();
+#endif
     if (c.n_esc16 > 0 && t < 2) esc_span[t] = esc_lower_bound(c.esc16_key, c.n_esc16, ((int64_t)blockIdx.x + t) << c.pk_shift);
     __syncthreads();
     c.esc_lo = c.n_esc16 > 0 ? esc_span[0] : 0; c.esc_hi = c.n_esc16 > 0 ? esc_span[1] : 0;
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
         if (c.tup && i0 < n) tp_next = c.tup[i0];
     }
     const int rounds = (1 << c.pk_shift) / 256;
+    PK_TICK(0); // set-up
     for (int it = 0; it < rounds; it++) {
         const int64_t i = ((int64_t)blockIdx.x << c.pk_shift) + it * 256 + t;
         const bool in = i < n;
@@ -462,6 +476,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
         uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SCANNED];
         pk_vals(nc, ls, ax, nl, um, nb, v);
         if (c.diff_form() && in) { v[5] = start_diff(c, i); v[6] = qname_diff(c, i); }
+        PK_TICK(1); // small columns + dictionary + differences
 #pragma unroll
         for (int k = 0; k < UZ_PK_SCANNED; k++) inc[k] = wv_incl_scan(v[k]); // (the last two sums are totals only; DPP scans: wg.hpp)
         __syncthreads(); // wsum of the previous round has been read
@@ -477,6 +492,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
 #pragma unroll
             for (int w = 0; w < 4; w++) { if (w < wv) pre[k] += wsum[k][w]; tot[k] += wsum[k][w]; }
         }
+        PK_TICK(2); // scans
         bool fits = true;
         if (host_sums && in) {
 #pragma unroll
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
                 }
                 if (mt0 < -1 || mt0 >= n) { hflags[0] = 7; mt0 = -1; }
             } else { st0 = c.start[i]; tl0 = c.tlen[i]; mt0 = c.mate[i]; qn0 = c.qname[i]; }
+            PK_TICK(3); // wide columns (pair form / escapes)
             // The record's CIGAR words, fetched ONCE and all together (the first four in one round trip; a short read has one to
             // three): its end and the two counts of the QC word come from registers, and the device's store gets the words -- the
             // travelled ones, or the one a simple record's aux byte names (cigar_compact).
@@ -552,6 +569,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
             }
             // (column left out: as htslib's bam_endpos -- uz_bam_endpos in pack.hpp states it for the host)
             const int32_t en0 = c.end ? c.end[i] : (((rs.flag & 4u) || nc == 0 || !have_words) ? st0 + 1 : (int32_t)(st0 + (ref_len > 0 ? ref_len : 1)));
+            PK_TICK(4); // CIGAR
             int low_for_qc = 0; // (an ASCII upload has no counts yet: uz_build_qlow sets the bit that depends on them)
             uz_pack_rec(A, B, st0, en0, cg, sq, mt0, qn0, (uint16_t)ls, (uint16_t)nc, tl0);
             if ((i & 4095) == 0) coarse[i >> 12] = st0; // the coarse search index: start of every 4096th record
@@ -561,6 +579,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
             const int units = (int)UZ_ROW_UNITS(ls);
             umask_out[i] = (uint16_t)(nb ? (um | UZ_UMASK_LISTED) : um);
             if (um != UZ_UMASK_ALL && (units > 15 || (um >> units) != 0u)) hflags[0] = 5; // a unit beyond the read, or a read too long for a mask
+            PK_TICK(5); // header stores
             if (nb) {
                 // The listed bases -> the record's rows (one 16-byte row per unit of its mask; bases that were not listed stay code 0, which
                 // the readers of a listed record refuse: phase_body.hpp uz_base).  Positions ascend, so the units come in row order.
@@ -597,6 +616,7 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
                     if (bad || seen != um) hflags[0] = 9; // a position outside the mask / not ascending, or a unit of the mask without a listed base
                 }
             }
+            PK_TICK(6); // listed bases
             if (nl >= 0) {
                 // list form of the staged plane: the count as it is; a quality row (at the record's base-row position) only for a
                 // record whose bits can be asked for, written here from its listed positions
@@ -654,10 +674,12 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
                 }
             }
             qs[i] = uz_qs_word(rs.flag, ax, rs.mapq, low_for_qc, (int)nc, cig_nonmatch, cig_none);
+            PK_TICK(7); // quality list + QC word
         }
 #pragma unroll
         for (int k = 0; k < UZ_PK_SCANNED; k++) run[k] += tot[k];
     }
+    PK_TICK(8);
     if (c.pair_d8) {
         // the pairs that lie inside this span are joined here, by the workgroup that has just written both headers (they sit in its L2 lines); a FIRST
         // whose SECOND belongs to the next span is left to k_pair_link, which then looks at the last 256 records of every span only
@@ -673,10 +695,332 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
             uz_pair_link_one(i, j, c.pair_d8, ra, rb, hflags);
         }
     }
+    PK_TICK(9); // pairs inside the span
+#ifdef UZ_PACK_TIMING
+    if (threadIdx.x == 0) for (int k = 0; k < 10; k++) atomicAdd(&uz_pack_ticks[k], ptk__[k]);
+#endif
     if (host_sums && t == 0) {
         bool same = true;
 #pragma unroll
         for (int k = 0; k < UZ_PK_SCANNED; k++) same &= (k == 5 || k == 6) ? (uint32_t)run[k] == (uint32_t)nxt[k] : run[k] == nxt[k]; // (the two difference columns count modulo 2^32)
+        if (!same) hflags[0] = 1;
+    }
+}
+
+// ---- the header build of the link form, from LDS -----------------------------------------------------------------------------------------
+// k_pack_rec reads a record's parts where they lie: per round of 256 records a dozen dependent trips to memory (dictionary entries, escape
+// searches, CIGAR words, listed positions one at a time, quality lists, and a second pass over the span for its pairs) -- 30 k cycles per
+// round, 1.0 ms per 9.9 M-record chunk of the staged pass against a streaming bound of 0.12 ms (profiles/r05: section timing).  The form
+// every packer of the product emits comes with the span sums of the packer (pk_sums): a workgroup knows before it starts where every
+// variable-length list of its span begins and ends.  So it stages ALL of its span's input -- the three byte columns, the dictionary, its
+// share of the quality lists, listed bases, travelled CIGAR words and escapes, ~6 KB -- into LDS with one round of coalesced loads, and
+// decodes from there; the pairs of a span are joined through LDS too (a FIRST record tells its SECOND how far back it stands), so a header is
+// stored once, finished.  Only a FIRST whose SECOND lies in the next span is left to k_pair_link.
+// Taken for: the link form (uz_link_form) with host sums, spans of 1024 records, byte positions.  The dictionary of the small columns (a few
+// thousand combinations of eight values) is packed into one 16-byte entry per combination first (k_pack_dict): a record's small columns are one load.
+// A list of a span that outgrows its LDS room is read from memory by that workgroup (slower, same result).
+#define UZ_PL_SPAN 1024
+#define UZ_PL_QP 4096   // staged quality-list bytes per span
+#define UZ_PL_BL 4096   // staged listed-base positions per span
+#define UZ_PL_CIG 256   // staged CIGAR words per span
+#define UZ_PL_ESC 64    // staged escape entries per span
+// a workgroup barrier that orders LDS traffic only: the round's stores to memory (nobody reads them here) stay in flight across it, where
+// __syncthreads() would have every wave wait for their acknowledgement three times a round
+#define PL_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__global__ __launch_bounds__(256) void k_pack_dict(RecColumns c, int32_t n_tup, uint4 *dict) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_tup) return;
+    uint4 e; // flag | l_seq << 16, n_cigar | umask << 16, mapq | aux << 8 | n_low << 16 | n_bl << 24
+    e.x = (uint32_t)c.tup_flag[k] | ((uint32_t)c.tup_l_seq[k] << 16);
+    e.y = (uint32_t)c.tup_n_cigar[k] | ((uint32_t)c.tup_umask[k] << 16);
+    e.z = (uint32_t)c.tup_mapq[k] | ((uint32_t)c.tup_aux[k] << 8) | ((uint32_t)c.tup_n_low[k] << 16) | ((c.tup_n_bl ? (uint32_t)c.tup_n_bl[k] : 0u) << 24);
+    e.w = 0u;
+    dict[k] = e;
+}
+__global__ __launch_bounds__(256, 3) void k_pack_link(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, int32_t n_tup, const uint4 *__restrict__ dict, RecA *ra, RecB *rb,
+                                                     uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
+                                                     uint16_t *qs, int32_t *coarse, int32_t *hflags) {
+    RecColumns c = uz_columns_of<true>(c_in);
+    __shared__ uint16_t s_tup[UZ_PL_SPAN];
+    __shared__ uint8_t s_sd[UZ_PL_SPAN], s_pd[UZ_PL_SPAN];
+    __shared__ uint8_t s_qp[UZ_PL_QP], s_blp[UZ_PL_BL], s_blc[UZ_PL_BL / 4 + 8];
+    __shared__ uint32_t s_cig[UZ_PL_CIG];
+    __shared__ unsigned long long s_esck[UZ_PL_ESC];
+    __shared__ int32_t s_escv[UZ_PL_ESC];
+    __shared__ RecA s_ra[UZ_PL_SPAN]; // the span's headers: finished here (a SECOND record writes its FIRST's template length), stored once at the end
+    __shared__ RecB s_rb[UZ_PL_SPAN];
+    __shared__ uint8_t s_back[UZ_PL_SPAN];        // how far back a SECOND's FIRST stands (0: not named inside the span)
+    __shared__ uint32_t s_named[UZ_PL_SPAN / 4];  // how often a record was named (a byte each)
+    __shared__ uint32_t wsum[UZ_PK_SCANNED][4];
+    __shared__ unsigned long long s_run[UZ_PK_SUMS], s_nxt[UZ_PK_SUMS];
+    __shared__ int64_t esc_span[2];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#ifdef UZ_PACK_TIMING
+    unsigned long long ptk__[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ptl__ = __builtin_amdgcn_s_memtime();
+#endif
+    const int64_t s0 = (int64_t)blockIdx.x * UZ_PL_SPAN;
+    const int cnt = (int)(n - s0 < UZ_PL_SPAN ? n - s0 : UZ_PL_SPAN);
+    if (t < UZ_PK_SUMS) { s_run[t] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + t]; s_nxt[t] = sums[UZ_PK_SUMS * ((size_t)blockIdx.x + 1) + t]; }
+    if (c.n_esc16 > 0 && t < 2) esc_span[t] = esc_lower_bound(c.esc16_key, c.n_esc16, s0 + (int64_t)t * UZ_PL_SPAN);
+    // the byte columns of the span and the dictionary (independent of the sums: requested beside them)
+    for (int k = t; k < cnt; k += 256) { s_tup[k] = c.tup[s0 + k]; s_sd[k] = c.start_d8[s0 + k]; s_pd[k] = c.pair_d8[s0 + k]; }
+    for (int k = t; k < UZ_PL_SPAN; k += 256) s_back[k] = 0;
+    for (int k = t; k < UZ_PL_SPAN / 4; k += 256) s_named[k] = 0u;
+    __syncthreads();
+    PK_TICK(0); // columns + sums rows
+    // the dictionary entry of a round's record is requested a round ahead (the first one here, beside the lists)
+    auto dict_of = [&](int k) -> uint4 {
+        uint32_t tp = k < cnt ? (uint32_t)s_tup[k] : 0u;
+        if ((int)tp >= n_tup) { hflags[0] = 1; tp = 0u; } // (an index beyond the dictionary)
+        return dict[tp];
+    };
+    uint4 de_next = dict_of(t);
+    // Everything below counts in 32 bits from the span's own base: the running offsets inside the span (rel), the span's share of every
+    // quantity (len: next row - this row; the host has checked that the rows ascend and that the totals fit 32 bits), the bases of the five
+    // quantities that become absolute offsets.  All of it uniform: read back through readfirstlane so that it lives in scalar registers.
+    auto uni64 = [&](unsigned long long x) -> unsigned long long {
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    };
+    uint32_t rel[UZ_PK_SCANNED], len[UZ_PK_SCANNED];
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SCANNED; k++) { rel[k] = 0u; len[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(s_nxt[k] - s_run[k])); }
+    const uint32_t base_cg = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_run[0]), base_sq = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_run[2]);
+    const uint32_t base_st = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_run[5]), base_qn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)s_run[6]);
+    const uint32_t base_sql = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((unsigned long long)c.n_seq_link + s_run[7]));
+    bool len_ok = true; // (a span's share of anything is far below 2^32; a row pair that says otherwise is refused)
+#pragma unroll
+    for (int k = 0; k < UZ_PK_SCANNED; k++) if (k != 5 && k != 6) len_ok &= s_nxt[k] - s_run[k] <= 0xFFFFFFFFULL;
+    if (!len_ok) hflags[0] = 1;
+    // this span's share of the lists, where the packer's sums put it
+    const unsigned long long q0 = uni64(s_run[3]), b0 = uni64(s_run[8]), g0 = uni64(s_run[4]);
+    const uint32_t qn_ = len[3], bn_ = len[8], gn_ = len[4];
+    const bool q_in = qn_ <= UZ_PL_QP, b_in = bn_ <= UZ_PL_BL, g_in = gn_ <= UZ_PL_CIG;
+    const int64_t e0 = c.n_esc16 > 0 ? (int64_t)uni64((unsigned long long)esc_span[0]) : 0, e1 = c.n_esc16 > 0 ? (int64_t)uni64((unsigned long long)esc_span[1]) : 0;
+    const bool e_in = e1 - e0 <= UZ_PL_ESC;
+    const uint32_t b0lo = (uint32_t)(b0 & 3ULL); // (four two-bit codes per byte: the span's first code sits b0lo codes into its first byte)
+    if (q_in) for (int k = t; k < (int)qn_; k += 256) s_qp[k] = c.qlow_pos[q0 + k];
+    if (b_in) {
+        for (int k = t; k < (int)bn_; k += 256) s_blp[k] = c.bl_pos[b0 + k];
+        const int ncb = (int)((b0lo + bn_ + 3u) >> 2);
+        for (int k = t; k < ncb; k += 256) s_blc[k] = c.bl_code[(b0 >> 2) + k];
+    }
+    if (g_in) for (int k = t; k < (int)gn_; k += 256) s_cig[k] = c.cigar_staged[g0 + k];
+    if (e_in) for (int k = t; k < (int)(e1 - e0); k += 256) { s_esck[k] = c.esc16_key[e0 + k]; s_escv[k] = c.esc16_val[e0 + k]; }
+    __syncthreads();
+    PK_TICK(1); // lists
+    auto esc_of = [&](int64_t i, int col) -> int32_t { // value of (record, column) in the escape list, 0 when missing (caught by the totals / the mate check)
+        const unsigned long long key = ((unsigned long long)i << 2) | (unsigned long long)col;
+        if (e_in) {
+            int lo = 0, hi = (int)(e1 - e0);
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_esck[mid] < key) lo = mid + 1; else hi = mid; }
+            return (lo < (int)(e1 - e0) && s_esck[lo] == key) ? s_escv[lo] : 0;
+        }
+        int64_t lo = e0, hi = e1;
+        while (lo < hi) { const int64_t mid = lo + ((hi - lo) >> 1); if (c.esc16_key[mid] < key) lo = mid + 1; else hi = mid; }
+        return (lo < c.n_esc16 && c.esc16_key[lo] == key) ? c.esc16_val[lo] : 0;
+    };
+    // (r: place in the span's share of the list)
+    auto qpos_at = [&](uint32_t r) -> int { return q_in ? (int)s_qp[r] : (int)c.qlow_pos[q0 + r]; };
+    auto blpos_at = [&](uint32_t r) -> int { return b_in ? (int)s_blp[r] : (int)c.bl_pos[b0 + r]; };
+    auto blcode_at = [&](uint32_t r) -> uint32_t {
+        const uint32_t g = b0lo + r;
+        const uint32_t byte = b_in ? (uint32_t)s_blc[g >> 2] : (uint32_t)c.bl_code[(b0 >> 2) + (g >> 2)];
+        return (byte >> (2u * (g & 3u))) & 3u;
+    };
+    auto cig_at = [&](uint32_t r) -> uint32_t { return g_in ? s_cig[r] : c.cigar_staged[g0 + r]; };
+    for (int it = 0; it < UZ_PL_SPAN / 256; it++) {
+        const int k = it * 256 + t; // the record's place in the span
+        const int64_t i = s0 + k;
+        const bool in = k < cnt;
+        uint4 de = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t p = UZ_P8_NEW, sd = 0;
+        if (in) { de = de_next; p = s_pd[k]; sd = s_sd[k]; }
+        if (it + 1 < UZ_PL_SPAN / 256) de_next = dict_of(k + 256);
+        const uint32_t flag = de.x & 0xFFFFu, ls = de.x >> 16, nc = de.y & 0xFFFFu, um = in ? (de.y >> 16) : UZ_UMASK_ALL;
+        const uint32_t mapq = de.z & 0xFFu, ax = (de.z >> 8) & 0xFFu, nb = de.z >> 24;
+        const int nl = (int)((de.z >> 16) & 0xFFu);
+        uint32_t v[UZ_PK_SUMS], inc[UZ_PK_SCANNED];
+        pk_vals(nc, ls, ax, nl, um, nb, v);
+        if (!in) {
+#pragma unroll
+            for (int q = 0; q < UZ_PK_SUMS; q++) v[q] = 0u;
+        } else {
+            v[5] = sd == UZ_D8_ESC ? (uint32_t)esc_of(i, 0) : sd;
+            v[6] = (p != UZ_P8_SECOND && p != UZ_P8_SECOND_TLEN && p != UZ_P8_OLD) ? 1u : 0u;
+        }
+        PK_TICK(2); // dictionary entry + values
+#pragma unroll
+        for (int q = 0; q < UZ_PK_SCANNED; q++) inc[q] = wv_incl_scan(v[q]);
+        PL_BARRIER(); // wsum of the previous round has been read
+        if (lane == 63) {
+#pragma unroll
+            for (int q = 0; q < UZ_PK_SCANNED; q++) wsum[q][wv] = inc[q];
+        }
+        PL_BARRIER();
+        // where the record's parts end, counted from the span's base: the rounds before, the waves before, the lanes before and the record
+        // itself; the running offsets move on at once, so that only the eight offsets below live through the rest of the round.  Nothing
+        // of a record may end beyond the span's share: nothing is read or written outside it.
+        bool fits = in;
+        uint32_t e32[UZ_PK_SCANNED];
+#pragma unroll
+        for (int q = 0; q < UZ_PK_SCANNED; q++) {
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { if (w < wv) pre += wsum[q][w]; tot += wsum[q][w]; }
+            e32[q] = rel[q] + pre + inc[q];
+            if (q != 5 && q != 6) fits &= e32[q] <= len[q] && e32[q] >= inc[q]; // (no wrap)
+            rel[q] += tot;
+        }
+        if (in && !fits) hflags[0] = 1;
+        const uint32_t o_cg = base_cg + e32[0] - v[0], o_sq = base_sq + e32[2] - v[2], o_sql = base_sql + e32[7] - v[7];
+        const uint32_t r_qp = e32[3] - v[3], r_gw = e32[4] - v[4], r_bl = e32[8] - v[8];
+        const uint32_t o_st = base_st + e32[5], o_qn = base_qn + e32[6];
+        const uint32_t v3 = v[3];
+        PK_TICK(3); // scans
+        // ---- first half: everything of the record that does not depend on its mate
+        int32_t st0 = 0, en0 = 0, tl0 = 0, mt0 = -1;
+        uint32_t qn0 = 0, sq = 0, cg = 0;
+        int cig_nonmatch = 0, cig_none = 0;
+        if (fits) {
+            sq = (ax & UZ_AUX_NO_SEQ) ? UZ_NO_SEQ_OFF : (nb ? o_sql : o_sq);
+            cg = o_cg;
+            st0 = (int32_t)o_st;
+            qn0 = o_qn - 1u; // a new name's id = new names before it
+            if (p == UZ_P8_SECOND) { mt0 = -2; qn0 = 0u; }
+            else if (p == UZ_P8_SECOND_TLEN) { mt0 = -2; qn0 = 0u; tl0 = esc_of(i, 1); }
+            else if (p <= UZ_P8_MAX_DIST) {
+                mt0 = (int32_t)(i + p);
+                if (mt0 >= n) { hflags[0] = 7; mt0 = -1; }
+            } else {
+                tl0 = esc_of(i, 1);
+                mt0 = esc_of(i, 2);
+                if (p == UZ_P8_OLD) qn0 = (uint32_t)esc_of(i, 3);
+                if (mt0 < -1 || mt0 >= n) { hflags[0] = 7; mt0 = -1; }
+            }
+            // CIGAR: the word a simple record's aux byte names, or the words that travelled; `end` and the two counts of the QC word from them
+            const uint32_t code = (ax & UZ_AUX_SIMPLE_MASK) >> UZ_AUX_SIMPLE_SHIFT;
+            if (code && nc != 1) hflags[0] = 6;
+            const uint32_t gw = r_gw;
+            int64_t ref_len = 0;
+            for (uint32_t q = 0; q < nc; q++) {
+                const uint32_t w = code ? uz_cigar_simple_word(code, ls) : cig_at(gw + q);
+                const uint32_t op = w & 15u;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) ref_len += (int64_t)(w >> 4); // M D N = X
+                if (!(ax & UZ_AUX_DECODE_BAD)) uz_cigar_op_counts(w, cig_nonmatch, cig_none);
+                c.cigar_out[cg + q] = w;
+            }
+            // (as htslib's bam_endpos -- uz_bam_endpos in pack.hpp states it for the host)
+            en0 = ((flag & 4u) || nc == 0) ? st0 + 1 : (int32_t)(st0 + (ref_len > 0 ? ref_len : 1));
+            {
+                RecA A;
+                RecB B;
+                uz_pack_rec(A, B, st0, en0, cg, sq, mt0, qn0, (uint16_t)ls, (uint16_t)nc, tl0);
+                s_ra[k] = A; s_rb[k] = B;
+            }
+            if (p >= 1u && p <= UZ_P8_MAX_DIST && mt0 >= 0 && k + (int)p < UZ_PL_SPAN) { // a FIRST whose SECOND lies in this span: tell it
+                const int j = k + (int)p;
+                s_back[j] = (uint8_t)p;
+                if ((atomicAdd(&s_named[j >> 2], 1u << (8 * (j & 3))) >> (8 * (j & 3))) & 0xFFu) hflags[0] = 8; // named twice
+            }
+        }
+        PL_BARRIER();
+        PK_TICK(4); // first half (wide columns, CIGAR)
+        // ---- second half: the pair.  A FIRST and its SECOND share name id and template length (+-): tlen = max(end, mate's end) - start of
+        // the FIRST, or the SECOND's own (UZ_P8_SECOND_TLEN).  The SECOND finishes both headers (its FIRST stands in front of it: written, and
+        // behind a barrier).
+        if (fits) {
+            const uint32_t named = (s_named[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            if (p == UZ_P8_SECOND || p == UZ_P8_SECOND_TLEN) {
+                const int d = (int)s_back[k];
+                if (d) { // its FIRST stands d records back, in this span
+                    const int f = k - d;
+                    const RecA FA = s_ra[f];
+                    int32_t tlf; // the FIRST's template length
+                    if (p == UZ_P8_SECOND_TLEN) tlf = -tl0;
+                    else { tlf = (FA.end > en0 ? FA.end : en0) - FA.start; tl0 = -tlf; }
+                    s_rb[f].tlen = tlf;
+                    s_rb[k].mate = (int32_t)(s0 + f);
+                    s_rb[k].qname = s_rb[f].qname;
+                    s_rb[k].tlen = tl0;
+                }
+                // (else: its FIRST lies in the span before this one -- k_pair_link -- or nowhere: the totals of the packer's sums tell)
+            } else if (named) hflags[0] = 8; // named as a mate, but not a SECOND record
+            // (a FIRST whose SECOND lies in the next span: k_pair_link)
+            if ((i & 4095) == 0) coarse[i >> 12] = st0; // the coarse search index: start of every 4096th record
+            fm[i] = uz_pack_fm(flag, mapq, ax);
+            const int units = (int)UZ_ROW_UNITS(ls);
+            umask_out[i] = (uint16_t)(nb ? (um | UZ_UMASK_LISTED) : um);
+            if (um != UZ_UMASK_ALL && (units > 15 || (um >> units) != 0u)) hflags[0] = 5; // a unit beyond the read, or a read too long for a mask
+            PK_TICK(5); // pair + header stores
+            if (nb) {
+                // The listed bases -> the record's rows (one 16-byte row per unit of its mask; bases that were not listed stay code 0, which
+                // the readers of a listed record refuse: phase_body.hpp uz_base).  Positions ascend, so the units come in row order.
+                if (um == UZ_UMASK_ALL || (ax & UZ_AUX_NO_SEQ)) hflags[0] = 9;
+                else {
+                    const uint32_t at = r_bl;
+                    uint32_t w4r[4] = {0u, 0u, 0u, 0u};
+                    int cur = -1, last = -1;
+                    uint32_t row = sq, seen = 0u;
+                    bool bad = false;
+                    for (uint32_t e = 0; e < nb; e++) {
+                        const int pos = blpos_at(at + e);
+                        const uint32_t code = blcode_at(at + e);
+                        const int u = pos >> 5;
+                        bad |= pos <= last || pos >= (int)ls || u > 14 || !((um >> u) & 1u);
+                        last = pos;
+                        if (u != cur) {
+                            if (cur >= 0) {
+                                reinterpret_cast<uint4 *>(c.seq4_out)[row] = make_uint4(w4r[0], w4r[1], w4r[2], w4r[3]);
+                                w4r[0] = w4r[1] = w4r[2] = w4r[3] = 0u;
+                                row++;
+                            }
+                            cur = u;
+                            seen |= 1u << (u & 15);
+                        }
+                        const int k32 = pos & 31; // byte k32 >> 1 of the row, high nibble when k32 is even
+                        w4r[k32 >> 3] |= (1u << code) << (8 * ((k32 >> 1) & 3) + ((k32 & 1) ? 0 : 4));
+                    }
+                    if (cur >= 0) reinterpret_cast<uint4 *>(c.seq4_out)[row] = make_uint4(w4r[0], w4r[1], w4r[2], w4r[3]);
+                    if (bad || seen != um) hflags[0] = 9; // a position outside the mask / not ascending, or a unit of the mask without a listed base
+                }
+            }
+            PK_TICK(6); // listed bases
+            // list form of the staged plane: the count as it is; a quality row (at the record's base-row position) only for a record whose
+            // bits can be asked for, written here from its listed positions
+            nlow[i] = (uint8_t)nl;
+            const bool listed = v3 == (uint32_t)nl && !(ax & UZ_AUX_NO_SEQ) && nl <= UZ_QLOW_LIST_MAX;
+            qoff[i] = listed ? sq : UZ_NO_QLOW_OFF;
+            if (listed) {
+                const uint32_t at = r_qp;
+                bool bad = false;
+                int prev = -1;
+                for (int e = 0; e < nl; e++) { const int ps = qpos_at(at + e); bad |= ps >= (int)ls || ps <= prev; prev = ps; }
+                if (bad) hflags[0] = 4;
+                uint32_t at_row = sq; // the quality row holds the same units as the base row: the staged ones
+                auto row_word = [&](int u) { // the bits of unit u
+                    uint32_t w = 0;
+                    for (int e = 0; e < nl; e++) { const int ps = qpos_at(at + e); if ((ps >> 5) == u) w |= 1u << (ps & 31); }
+                    return w;
+                };
+                if (um != UZ_UMASK_ALL) { // one round per staged unit (usually one or two of a read's five)
+                    uint32_t m = um;
+                    while (m) { const int u = __ffs((int)m) - 1; m &= m - 1u; plane_out[(size_t)at_row++] = row_word(u); }
+                } else
+                    for (int u = 0; u < units; u++) plane_out[(size_t)at_row++] = row_word(u);
+            }
+            qs[i] = uz_qs_word(flag, ax, mapq, nl, (int)nc, cig_nonmatch, cig_none);
+            PK_TICK(7); // quality list
+        }
+    }
+#ifdef UZ_PACK_TIMING
+    if (threadIdx.x == 0) for (int q = 0; q < 10; q++) atomicAdd(&uz_pack_ticks[q], ptk__[q]);
+#endif
+    PL_BARRIER();
+    for (int q = t; q < cnt; q += 256) { ra[s0 + q] = s_ra[q]; rb[s0 + q] = s_rb[q]; }
+    if (t == 0) { // the span's own sums must add up to exactly the packer's next row (the two difference columns modulo 2^32)
+        bool same = true;
+#pragma unroll
+        for (int q = 0; q < UZ_PK_SCANNED; q++) same &= rel[q] == len[q];
         if (!same) hflags[0] = 1;
     }
 }
@@ -854,9 +1198,36 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
 #define UZ_PACK_LAUNCH(L, S)                                                                                                                              \
     hipLaunchKernelGGL((k_pack_rec<L, S>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, want, (RecA *)r.rec_a, \
                        (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags, host_sums ? 1 : 0)
-    if (link_form) { if (self) UZ_PACK_LAUNCH(true, true); else UZ_PACK_LAUNCH(true, false); }
+    static const bool no_lds_build = getenv("UZ_BUILD_FROM_MEMORY") != nullptr; // (development aid: k_pack_rec for every table)
+    // (with host sums the scratch of the span sums is free: it holds the packed dictionary)
+    const bool from_lds = link_form && host_sums && col.pk_shift == UZ_PK_SHIFT_SMALL && col.n_tup >= 1 && (size_t)col.n_tup * sizeof(uint4) <= uz_rec_scratch_bytes(r.n) &&
+                          !col.qpos_wide && !col.bl_wide && (col.tup_n_bl == nullptr || col.bl_pos != nullptr) && !no_lds_build;
+    static const bool build_log = getenv("UZ_BUILD_LOG") != nullptr; // (development aid)
+    if (build_log)
+        fprintf(stderr, "[uz_build_records] n %lld link_form %d host_sums %d pk_shift %d n_tup %lld qpos_wide %d bl_wide %d -> from_lds %d\n", (long long)r.n, (int)link_form,
+                (int)host_sums, (int)col.pk_shift, (long long)col.n_tup, (int)col.qpos_wide, (int)col.bl_wide, (int)from_lds);
+    if (from_lds) {
+        hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((col.n_tup + 255) / 256)), dim3(256), 0, st, col, (int32_t)col.n_tup, (uint4 *)off_scratch);
+        hipLaunchKernelGGL(k_pack_link, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (int32_t)col.n_tup, (const uint4 *)off_scratch, (RecA *)r.rec_a,
+                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags);
+    } else if (link_form) { if (self) UZ_PACK_LAUNCH(true, true); else UZ_PACK_LAUNCH(true, false); }
     else { if (self) UZ_PACK_LAUNCH(false, true); else UZ_PACK_LAUNCH(false, false); }
 #undef UZ_PACK_LAUNCH
+#ifdef UZ_PACK_TIMING
+    {
+        UZ_HIP(hipStreamSynchronize(st));
+        unsigned long long tk[16];
+        UZ_HIP(hipMemcpyFromSymbol(tk, HIP_SYMBOL(uz_pack_ticks), sizeof(tk)));
+        const char *nm[10] = {"s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9"};
+        unsigned long long tot = 0;
+        for (int k = 0; k < 10; k++) tot += tk[k];
+        fprintf(stderr, "[pack timing] n %lld wgs %u", (long long)r.n, nb);
+        for (int k = 0; k < 10; k++) fprintf(stderr, " %s %.1f%%", nm[k], 100.0 * (double)tk[k] / (double)(tot ? tot : 1));
+        fprintf(stderr, " | ticks/wg %.0f\n", (double)tot / nb);
+        unsigned long long z[16] = {0};
+        UZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(uz_pack_ticks), z, sizeof(z)));
+    }
+#endif
     if (col.pair_d8)
         hipLaunchKernelGGL(k_pair_link, dim3(nb), dim3(256), 0, st, (int64_t)r.n, (int)col.pk_shift, col.pair_d8, (const RecA *)r.rec_a, (RecB *)r.rec_b,
                            c->hflags);
@@ -953,10 +1324,11 @@ static void phase_check_upload_flags(uz_ctx *c) {
                                            : "n_cigar_total / n_row_units of the reads view do not match its columns"};
     }
 }
-struct Sizes { Caps caps; int arena; long long sumP; };
+struct Sizes { Caps caps; int arena, arena2; long long sumP; };
 static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); return e ? atoi(e) * 1024 : -1; }();
 // the share of a batch's DNMs (per mille, by the estimate below) the arena is sized to hold; the rest take the HBM build behind it
-static const int arena_permille = [] { const char *e = getenv("UZ_PHASE_ARENA_PERMILLE"); return e ? atoi(e) : 990; }();
+// (1000 / 990 / 940 / 900 on the bench batch: 3.16 / 2.98 / 2.84 / 2.84 ms -- one more wave per CU is worth more than the 1.3 % of the DNMs redone)
+static const int arena_permille = [] { const char *e = getenv("UZ_PHASE_ARENA_PERMILLE"); return e ? atoi(e) : 940; }();
 static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
     for (int32_t d = 0; d < n; d++) {
@@ -975,9 +1347,9 @@ static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
     z.sumP = sumP;
     // LDS arena of k_phase<true>, sized for THIS batch.  One wave works on a DNM, so the arena alone decides how many DNMs a CU has in
     // flight: a DNM needs about 9.2 bytes per record its het-site fetches return plus 3.2 KiB (fit over the bench workload by the CPU twin,
-    // scripts/phase_sizes.py: residual p99 0.4 KiB).  The 99th percentile of that estimate over the batch decides how
+    // scripts/phase_sizes.py: residual p99 0.4 KiB).  The 94th percentile of that estimate over the batch decides how
     // many waves share a CU's 160 KiB (at most 4 x UZ_PHASE_MIN_WAVES: registers), and the arena is then the largest that this many leave
-    // room for.  The bench batch runs 15 DNMs per CU on 10 KiB arenas; a deep-coverage batch gets larger arenas and fewer waves instead
+    // room for.  The bench batch runs 16 DNMs per CU on 9.25 KiB arenas; a deep-coverage batch gets larger arenas and fewer waves instead
     // of handing most of its DNMs to the slower HBM build.
     z.arena = arena_env;
     if (z.arena < 0) {
@@ -997,9 +1369,10 @@ static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
             if (hist[k]) u = std::max(u, k);
             if ((long long)seen * 1000 >= (long long)active * arena_permille) break;
         }
-        (void)umax;
         z.arena = std::min(u * 256, 62 * 1024);
-    }
+        z.arena2 = std::min(std::max(2 * z.arena, umax * 256 + 1024), 62 * 1024);
+    } else
+        z.arena2 = std::min(2 * z.arena, 62 * 1024);
     return z;
 }
 
@@ -1082,9 +1455,12 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     const size_t res_ints = (size_t)7 * n + ((7 * (size_t)n) & 1); // the results, padded to eight bytes; the pool's fill level behind them
     st->res.ensure(res_ints + 4);
     st->pool_cursor = (unsigned long long *)(st->res.p + res_ints);
-    st->cursor.ensure(16 * (UZ_PHASE_PARTS + 1));
-    st->retry.ensure((size_t)n + 16);
-    a.retry_count = st->retry.p; a.retry_list = st->retry.p + 16;
+    st->cursor.ensure(16 * (UZ_PHASE_PARTS + 2));
+    // two lists of given-up DNMs: what the first launch leaves for the second (larger arenas), what the second leaves for the HBM build
+    st->retry.ensure(2 * ((size_t)n + 16));
+    int32_t *const retry1 = st->retry.p, *const retry2 = st->retry.p + (size_t)n + 16;
+    a.retry_count = retry1; a.retry_list = retry1 + 16;
+    a.from_list = 0; a.cursor_slot = 0; a.src_count = nullptr; a.src_list = nullptr;
     a.status = st->res.p; a.counts = st->res.p + n; a.origin = st->res.p + (size_t)5 * n; a.evidence = st->res.p + (size_t)6 * n;
     a.work_cursor = st->cursor.p;
     a.want_lists = uz_want_lists;
@@ -1112,7 +1488,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     for (int round = 0; round < 2; round++) {
         Sizes z;
         if (speculative) {
-            z.caps = st->spec_caps; z.arena = st->spec_arena;
+            z.caps = st->spec_caps; z.arena = st->spec_arena; z.arena2 = st->spec_arena2;
             z.sumP = (long long)(st->spec_sumP_per_dnm * (double)n) + 4096;
         } else {
             UZ_HIP(hipEventSynchronize(st->bounds_ready));
@@ -1152,16 +1528,31 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         st->pool.ensure(pool_cap);
         a.pool = st->pool.p; a.pool_cap = pool_cap;
         for (int attempt = 0; attempt < 4; attempt++) {
-            UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 1) * sizeof(int32_t), c->stream));
-            UZ_HIP(hipMemsetAsync(st->retry.p, 0, 16 * sizeof(int32_t), c->stream));
+            UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 2) * sizeof(int32_t), c->stream));
+            UZ_HIP(hipMemsetAsync(retry1, 0, 16 * sizeof(int32_t), c->stream));
+            UZ_HIP(hipMemsetAsync(retry2, 0, 16 * sizeof(int32_t), c->stream));
             UZ_HIP(hipMemsetAsync(st->pool_cursor, 0, 2 * sizeof(unsigned long long), c->stream));
             {
+                // Three launches.  The arena is sized for most of the batch's DNMs, not all (the more DNMs a CU holds, the faster the batch);
+                // the rest are redone by a second launch of the same build with arenas for the largest estimate -- a DNM's latency in the
+                // arena build is ~100 us, in the HBM build ~450 us, and a list that is worked off behind the main launch costs the batch its
+                // slowest DNM -- and only what that launch gives up too (a field width, a chaining level with more than 96 winners) goes to
+                // the HBM build.
                 ProfScope ps(c, UZ_K_PHASE);
                 UZ_TRACE("k_phase");
                 hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
                 UZ_HIP(hipGetLastError());
-                // (the DNMs the first kernel gave up: usually a handful -- eight waves per CU pull them from the list)
-                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 8 * st->n_cus)), dim3(WG_NT), 0, c->stream, a);
+                PhaseArgs a2 = a;
+                a2.from_list = 1; a2.cursor_slot = UZ_PHASE_PARTS; a2.src_count = retry1; a2.src_list = retry1 + 16;
+                a2.retry_count = retry2; a2.retry_list = retry2 + 16;
+                a2.lds_arena_bytes = getenv("UZ_TEST_PHASE_ARENA") ? arena_used /* test hook: the small arena again, so that the HBM build is what runs */
+                                                                    : std::max(arena_used, std::min(z.arena2, 62 * 1024));
+                const int per_cu2 = std::max(1, (160 * 1024) / (a2.lds_arena_bytes + (int)sizeof(WgSharedT<1>) + 512));
+                hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)std::min(grid, per_cu2 * st->n_cus)), dim3(WG_NT), (size_t)a2.lds_arena_bytes, c->stream, a2);
+                UZ_HIP(hipGetLastError());
+                PhaseArgs a3 = a2;
+                a3.cursor_slot = UZ_PHASE_PARTS + 1; a3.src_count = retry2; a3.src_list = retry2 + 16;
+                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 8 * st->n_cus)), dim3(WG_NT), 0, c->stream, a3);
                 UZ_HIP(hipGetLastError());
             }
             UZ_TRACE("after k_phase");
@@ -1169,7 +1560,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
             uz_kcopy(c, hres, st->res.p, res_ints * sizeof(int32_t) + sizeof(unsigned long long)); // the results and the pool's fill level: one copy
             int32_t *const hretry = (int32_t *)(hused + 1);
             *hretry = 0;
-            uz_kcopy(c, hretry, st->retry.p, sizeof(int32_t));
+            uz_kcopy(c, hretry, retry2, sizeof(int32_t)); // DNMs that took the HBM build
             if (defer && speculative) { // uz_phase_begin: the run stays in flight; uz_finish_phase waits for it and judges it
                 st->pending = true;
                 st->pend_caps = caps; st->pend_pool_cap = a.pool_cap; st->pend_want_lists = a.want_lists;
@@ -1201,7 +1592,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         st->spec_caps.A = room(real.caps.A); st->spec_caps.T = room(real.caps.T); st->spec_caps.H = room(real.caps.H); st->spec_caps.C = room(real.caps.C);
         st->spec_caps.I = 4 * st->spec_caps.A;
         st->spec_caps.M = real.caps.M;
-        st->spec_arena = real.arena;
+        st->spec_arena = real.arena; st->spec_arena2 = real.arena2;
         st->spec_sumP_per_dnm = 1.25 * (double)real.sumP / (double)n;
         st->spec_valid = true;
         static const bool spec_log = getenv("UZ_PHASE_SPEC_LOG") != nullptr; // development aid
@@ -1262,7 +1653,7 @@ bool uz_finish_phase(uz_ctx *c, int32_t *status, int32_t *counts, int32_t *origi
         st->spec_caps.A = room(real.caps.A); st->spec_caps.T = room(real.caps.T); st->spec_caps.H = room(real.caps.H); st->spec_caps.C = room(real.caps.C);
         st->spec_caps.I = 4 * st->spec_caps.A;
         st->spec_caps.M = real.caps.M;
-        st->spec_arena = real.arena;
+        st->spec_arena = real.arena; st->spec_arena2 = real.arena2;
         st->spec_sumP_per_dnm = 1.25 * (double)real.sumP / (double)n;
         const Caps &caps = st->pend_caps;
         const bool fits = real.caps.A <= caps.A && real.caps.T <= caps.T && real.caps.H <= caps.H && real.caps.C <= caps.C && real.caps.M <= caps.M;

@@ -355,8 +355,11 @@ struct PhaseArgs {
     int32_t *list_len;     // [6n] dad_reads, mom_reads, dad_sites, mom_sites, ref group, alt group
     // scheduling + scratch
     int32_t *work_cursor;
-    int32_t *retry_count; // DNMs the LDS build of the kernel gave up ...
-    int32_t *retry_list;  // ... and their indices: the work list of the HBM build
+    int32_t *retry_count; // DNMs this launch of the arena build gave up ...
+    int32_t *retry_list;  // ... and their indices: the work list of the launch behind it
+    // a launch that works through such a list instead of the whole batch (the second arena launch, with larger arenas; the HBM build)
+    int32_t from_list, cursor_slot;
+    const int32_t *src_count, *src_list;
     uint8_t *scratch;
     unsigned long long scratch_per_wg;
     Caps caps;
@@ -786,7 +789,7 @@ UZ_DEV void uz_args_load(PhaseArgs &a, PhaseArgsK &ap) {
     UZ_P(R.ra) UZ_P(R.rb) UZ_P(R.fm) UZ_P(R.contig_off) UZ_P(R.max_span) UZ_V(R.n_contigs) UZ_P(R.cigar) UZ_P(R.seq4) UZ_P(R.qlow) UZ_P(R.qoff)
     UZ_P(R.nlow) UZ_P(R.umask) UZ_P(R.err) UZ_P(R.qs) UZ_V(R.min_map_qual) UZ_P(R.coarse)
     UZ_P(status) UZ_P(counts) UZ_P(origin) UZ_P(evidence) UZ_V(want_lists) UZ_P(pool) UZ_V(pool_cap) UZ_P(pool_cursor) UZ_P(list_start) UZ_P(list_len)
-    UZ_P(work_cursor) UZ_P(retry_count) UZ_P(retry_list) UZ_P(scratch) UZ_V(scratch_per_wg)
+    UZ_P(work_cursor) UZ_P(retry_count) UZ_P(retry_list) UZ_V(from_list) UZ_V(cursor_slot) UZ_P(src_count) UZ_P(src_list) UZ_P(scratch) UZ_V(scratch_per_wg)
     UZ_V(caps.A) UZ_V(caps.T) UZ_V(caps.H) UZ_V(caps.C) UZ_V(caps.I) UZ_V(caps.M) UZ_V(lds_arena_bytes)
     UZ_P(pre_win) UZ_P(pre_ha) UZ_P(pre_hl) UZ_P(timing)
 #define UZ_X(TY, NAME, CNT) UZ_V(so.NAME)

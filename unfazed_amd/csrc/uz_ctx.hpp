@@ -158,6 +158,7 @@ struct ReadsDev {
     void *build_scratch = nullptr;
     const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
     int32_t col_lists = 0;
+    int64_t col_ntup = 0;
     const void *col_d[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val, start_d8, mate_d8, qname_d8, pair_d8
     int64_t col_nesc = 0;
     const void *col_q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // plane_in / n_low / qlow_pos / cigar_in / umask / cigar_staged / cigar_out of RecColumns, for the deferred header build
@@ -335,6 +336,7 @@ struct RecColumns {
     const uint16_t *tup = nullptr, *tup_flag = nullptr, *tup_l_seq = nullptr, *tup_n_cigar = nullptr;
     const uint8_t *tup_mapq = nullptr, *tup_aux = nullptr, *tup_n_low = nullptr;
     const uint16_t *tup_umask = nullptr;
+    int64_t n_tup = 0; // entries of the dictionary (0: not known)
     // bases as lists (uz_types.h: bl_*): per record the number of listed bases (plain column or through the dictionary), their query indices and
     // two-bit codes; seq4_out: the device's base rows (the header build writes the units of the listed records, behind the n_seq_link units that
     // travelled as rows)
