@@ -716,9 +716,18 @@ def product_e2e(bam, vcf, sc, ev, m, res_r):
         for k in [k for k in session._SITES if "@" in k]:
             del session._SITES[k]
         batch = [dict(x) for x in dnms]
+        prof = None
+        if rep == 1 and os.environ.get("UZ_BENCH_PROFILE_PRODUCT"):  # development aid: where the drop-in call's host time goes
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         t = time.perf_counter()
         recs = phase_snvs(batch, *argv)
         el = time.perf_counter() - t
+        if prof is not None:
+            import pstats
+            prof.disable()
+            pstats.Stats(prof, stream=sys.stderr).sort_stats("cumulative").print_stats(40)
     # (the sites file spells every DNM's own record as an SNV, so the driver -- which takes REF / ALT from that file, snv_phaser.py:73-84 -- phases
     # the batch's INDEL DNMs as SNVs: only the SNV DNMs are the same question in both passes)
     # (and a DNM with a second site record at its position or the base before gets "Too many genotypes" from the driver's REF / ALT look-up over

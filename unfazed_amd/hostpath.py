@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import abi
-from .model import ReadsTable, SitesTable
+from .model import SFLAG_COMPLEX, ReadsTable, SitesTable
 
 SEX_KEY = {"male": 1, "female": 2}  # reference utils.py:6
 SV_TYPES = ["DEL", "DUP", "INV", "CNV", "DUP:TANDEM", "DEL:ME", "CPX", "CTX"]  # utils.py:8
@@ -31,6 +31,7 @@ grch38_par2 = {"x": [154931044, 155260560], "y": [59034050, 59363566]}
 
 
 _CHR = [chr(v) for v in range(256)]
+_CHR_OBJ = np.array(_CHR, dtype=object)  # (a column of base bytes -> a list of one-character strings in one fancy index)
 
 
 def get_prefix(sites: SitesTable) -> str:
@@ -91,6 +92,41 @@ class _Log:
     def __call__(self, msg: str):
         if not self.quiet:
             print(msg, file=sys.stderr)
+
+
+class _VoteLists:
+    """The four vote lists of every DNM of a chunk (uz_phase_votes: offsets [4n + 1], values) behind the indexing the host code uses --
+    lists[k] -> (dad_reads, mom_reads, dad_sites, mom_sites) as arrays -- without 4n array slices made up front: the values become ONE Python
+    list, cut per DNM when its record is built."""
+
+    def __init__(self, vo, vv):
+        self.vo, self.vv = vo, vv
+        self._vol = vo.tolist()
+        self._vvl = None
+
+    def __len__(self):
+        return (len(self._vol) - 1) // 4
+
+    def __getitem__(self, k):
+        o = self._vol
+        return tuple(self.vv[o[4 * k + q]: o[4 * k + q + 1]] for q in range(4))
+
+    def py(self, k):
+        if self._vvl is None:
+            self._vvl = self.vv.tolist()
+        o, v = self._vol, self._vvl
+        return v[o[4 * k]: o[4 * k + 1]], v[o[4 * k + 1]: o[4 * k + 2]], v[o[4 * k + 2]: o[4 * k + 3]], v[o[4 * k + 3]: o[4 * k + 4]]
+
+    def read_ids(self, ks):
+        """the distinct name ids in the read lists of DNMs ks"""
+        o = self.vo
+        ks = np.asarray(ks, np.int64)
+        a, b = o[4 * ks], o[4 * ks + 2]  # (the two read lists of a DNM lie end to end)
+        n = (b - a).astype(np.int64)
+        if int(n.sum()) == 0:
+            return np.zeros(0, np.int64)
+        idx = np.repeat(a - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum()))
+        return np.unique(self.vv[idx].astype(np.int64))
 
 
 class PhasingHost:
@@ -230,29 +266,32 @@ class PhasingHost:
             if not fetch and not attach:
                 continue  # the caller runs its own device stage over the batch (K6): no lists on the host
             co, ci, cf, ho, hi = self.backend.find(fam, dv, params, mode)
+            col, hol = co.tolist(), ho.tolist()
             for k, i in enumerate(idxs):
                 found[i] = dict(
                     mult=mult_of[i],
-                    cand_idx=ci[co[k] : co[k + 1]],
-                    cand_flags=cf[co[k] : co[k + 1]],
-                    het_idx=hi[ho[k] : ho[k + 1]],
+                    cand_idx=ci[col[k] : col[k + 1]],
+                    cand_flags=cf[col[k] : col[k + 1]],
+                    het_idx=hi[hol[k] : hol[k + 1]],
                 )
-        if attach:
-            for i in scan:
-                dn = dnms[i]
-                f = found[i]
-                dad, mom = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
-                cands = self._site_dicts(f["cand_idx"], f["cand_flags"], dad, mom, whole_region)
-                hets = self._site_dicts(f["het_idx"], None, dad, mom, False)
-                if many:
-                    # find_many only creates the keys on first append (:481-482, :540-541)
-                    if cands:
-                        dn["candidate_sites"] = cands
-                    if hets:
+            if attach:
+                # the site dicts the reference leaves on every DNM (:262-343): the columns of the whole batch's sites become Python values in
+                # ONE pass each (a fancy index and a tolist per column, not per DNM), then one dict display per site
+                cands_all = self._site_dicts(ci, cf, dad, mom, whole_region)
+                hets_all = self._site_dicts(hi, None, dad, mom, False)
+                for k, i in enumerate(idxs):
+                    dn = dnms[i]
+                    cands = cands_all[col[k] : col[k + 1]]
+                    hets = hets_all[hol[k] : hol[k + 1]]
+                    if many:
+                        # find_many only creates the keys on first append (:481-482, :540-541)
+                        if cands:
+                            dn["candidate_sites"] = cands
+                        if hets:
+                            dn["het_sites"] = hets
+                    else:
+                        dn["candidate_sites"] = cands  # :341-342
                         dn["het_sites"] = hets
-                else:
-                    dn["candidate_sites"] = cands  # :341-342
-                    dn["het_sites"] = hets
         ret = [dnms[i] for i in order] + [dnms[i] for i in auto_tail]
         ret_idx = order + auto_tail
         return ret, {"order": ret_idx, "found": found, "many": many, "mode": mode, "scanned": scan, "contig_of": contig_of}
@@ -263,8 +302,8 @@ class PhasingHost:
             return []
         # columns of the few sites as Python values in one go (tolist), then one dict display per site
         pos = s.pos[idx].tolist()
-        ref = [_CHR[v] for v in s.ref_base[idx].tolist()]
-        alt = [_CHR[v] for v in s.alt_base[idx].tolist()]
+        ref = _CHR_OBJ[s.ref_base[idx]].tolist()
+        alt = _CHR_OBJ[s.alt_base[idx]].tolist()
         if flags is None:
             return [{"pos": p, "ref_allele": r, "alt_allele": a} for p, r, a in zip(pos, ref, alt)]
         out = []
@@ -376,7 +415,17 @@ class PhasingHost:
             # 1-based [pos, pos + 1]: records with start + 1 <= pos + 1 and end >= pos
             k_lo = lo + np.searchsorted(seg, np.clip(st - span, lim.min, lim.max).astype(s.pos.dtype), side="left")
             k_hi = lo + np.searchsorted(seg, np.clip(st, lim.min, lim.max).astype(s.pos.dtype), side="right")
-            for i, a, b, p in zip(members, k_lo.tolist(), k_hi.tolist(), st.tolist()):
+            # the usual case -- exactly one record in the range, overlapping, a plain SNV (not UZ_SF_COMPLEX: one REF base, one one-base ALT) --
+            # takes its two strings from the base columns, for all such DNMs at once; everything else asks the table for the strings
+            one = (k_hi - k_lo) == 1
+            j1 = np.where(one, k_lo, lo).astype(np.int64)
+            one &= (s.end[j1] >= st) & ((s.sflags[j1] & SFLAG_COMPLEX) == 0) & (s.ref_base[j1] != 0) & (s.alt_base[j1] != 0)
+            r1 = _CHR_OBJ[s.ref_base[j1]].tolist()
+            a1 = _CHR_OBJ[s.alt_base[j1]].tolist()
+            for i, a, b, p, fast, r, al in zip(members, k_lo.tolist(), k_hi.tolist(), st.tolist(), one.tolist(), r1, a1):
+                if fast:
+                    out[i] = (r, [al])
+                    continue
                 ref, alts = None, []
                 for j in range(a, b):
                     if s.end[j] >= p:
@@ -472,20 +521,21 @@ class PhasingHost:
 
         from . import pipeline
         lag = 1  # (chunks of a few thousand DNMs: the first read stage should start as early as it can)
-        n_slots = lag + 2  # a slot is staged into again once the read stage of the chunk it held has been collected
+        ahead = 2  # BAM stages in flight beside the chunk on the device (native code: the interpreter lock is released; bench.py's own loop runs three)
+        n_slots = lag + 1 + ahead  # a slot is staged into again once the read stage of the chunk it held has been collected
 
         def stage(k):
             fc, flo, fhi, fex, has_sv = self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
             return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k % n_slots)
 
-        with ThreadPoolExecutor(1) as ex:
-            futs = {0: ex.submit(stage, 0)}
+        with ThreadPoolExecutor(ahead) as ex:
+            futs = {k: ex.submit(stage, k) for k in range(min(ahead, len(parts)))}
             names = {}
 
             def records(k, het_off, het_idx):  # (the pipeline's own find has just returned: the fetches were derived from the batch's find already)
                 packed = futs.pop(k).result()
-                if k + 1 < len(parts):
-                    futs[k + 1] = ex.submit(stage, k + 1)  # decoded beside the device work of this chunk
+                if k + ahead < len(parts):
+                    futs[k + ahead] = ex.submit(stage, k + ahead)  # decoded beside the device work of this chunk and the next
                 names[k] = packed  # (its `.qnames`: at once for the link form, once the table is built for a batch walked on the device)
                 return packed
 
@@ -494,10 +544,14 @@ class PhasingHost:
                 lists = None
                 if want_lists:
                     vo, vv = self.backend.votes(len(part))
-                    lists = [tuple(vv[vo[4 * j + q]: vo[4 * j + q + 1]] for q in range(4)) for j in range(len(part))]
+                    lists = _VoteLists(vo, vv)
                 res = dict(status=rr["status"], counts=rr["counts"], origin=rr["origin"], evidence=rr["evidence"], lists=lists)
                 table = type("StagedNames", (), {})()
                 table.qnames = names.pop(k).qnames
+                if lists is not None:
+                    # the name and position lists of the chunk's records, built HERE -- beside the native decode of the chunks that follow -- and
+                    # not in a pass over the whole batch behind the pipeline
+                    res["built"] = self._evidence_lists(res, range(len(part)), table)
                 for j, i in enumerate(part):
                     results[i] = (res, j, table)
 
@@ -627,19 +681,17 @@ class PhasingHost:
                     results[order_all[k]] = (res, k, tables[g])
         self._indexed_memo = None
         # pass 3: records, in the reference's order.  The names of the reads in the result lists: one look-up per table for the whole batch
-        # (a staged table answers ids through the C ABI: hundreds of thousands of single calls were a third of round 3's host time)
-        names_of: Dict[int, Dict[int, str]] = {}
-        for g_tab in {id(t): t for (_, _, t) in results.values()}.values():
-            take = getattr(getattr(g_tab, "qnames", None), "take", None)
-            if take is None:
-                continue
-            ids = []
-            for (res, k, rt) in results.values():
-                if rt is g_tab and res.get("lists") is not None and int(res["status"][k]) == abi.ST_OK:
-                    ids.append(res["lists"][k][0]); ids.append(res["lists"][k][1])
-            if ids:
-                u = np.unique(np.concatenate(ids + [np.zeros(0, np.int64)]).astype(np.int64))
-                names_of[id(g_tab)] = dict(zip(u.tolist(), take(u)))
+        # (a staged table answers ids through the C ABI: hundreds of thousands of single calls were a third of round 3's host time); the chunks
+        # of a staged batch have built theirs already (res["built"])
+        by_res: Dict[tuple, tuple] = {}
+        for (res, k, rt) in results.values():
+            if "built" not in res and res.get("lists") is not None:
+                by_res.setdefault((id(res), id(rt)), (res, rt, []))[2].append(k)  # (a cohort batch: one result, a table per kid)
+        for res, rt, ks in by_res.values():
+            res.setdefault("built_", {}).update(self._evidence_lists(res, ks, rt))
+        for res, rt, ks in by_res.values():
+            if "built_" in res:
+                res["built"] = res.pop("built_")
         for i, action in plan:
             dn = dnms[i]
             dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
@@ -679,18 +731,8 @@ class PhasingHost:
                     # ST_REF_EXCEPTION: the reference's worker raises (KeyError in connect_reads) and the default
                     # thread pool swallows it: no record, no message
                     continue
-                lists = res.get("lists")
-                if lists is not None:
-                    dr, mr, ds, ms = lists[k]
-                    nm = names_of.get(id(rt))
-                    if nm is not None:
-                        dad_reads = [nm[q] for q in dr.tolist()]
-                        mom_reads = [nm[q] for q in mr.tolist()]
-                    else:
-                        dad_reads = [rt.qnames[q] for q in dr]
-                        mom_reads = [rt.qnames[q] for q in mr]
-                    dad_sites = [str(p) for p in ds]
-                    mom_sites = [str(p) for p in ms]
+                if res.get("lists") is not None:
+                    dad_reads, mom_reads, dad_sites, mom_sites = res["built"][k]
                 else:
                     c = res["counts"][k]
                     dad_reads, mom_reads = [None] * int(c[0]), [None] * int(c[1])
@@ -702,6 +744,40 @@ class PhasingHost:
                     "cnv_dad_sites": "", "cnv_mom_sites": "", "cnv_evidence_type": "",
                 }
         return records
+
+    @staticmethod
+    def _evidence_lists(res, ks, rt) -> dict:
+        """{k: (dad_reads, mom_reads, dad_sites, mom_sites)} of the phased DNMs k of one device result: read names through ONE look-up for all of
+        them (a staged table answers ids through the C ABI), positions as the reference's strings (snv_phaser.py:169-185)"""
+        lists, status = res["lists"], res["status"]
+        st = status.tolist() if hasattr(status, "tolist") else list(status)
+        ok = [k for k in ks if st[k] == abi.ST_OK]
+        out = {}
+        if not ok:
+            return out
+        take = getattr(getattr(rt, "qnames", None), "take", None)
+        fast = isinstance(lists, _VoteLists)
+        nm = None
+        if take is not None:
+            if fast:
+                u = lists.read_ids(ok)
+            else:
+                ids = [lists[k][q] for k in ok for q in (0, 1)]
+                u = np.unique(np.concatenate(ids + [np.zeros(0, np.int64)]).astype(np.int64))
+            nm = dict(zip(u.tolist(), take(u)))
+        for k in ok:
+            if fast:
+                dr, mr, ds, ms = lists.py(k)  # (Python lists already)
+            else:
+                dr, mr, ds, ms = (x.tolist() for x in lists[k])
+            if nm is not None:
+                dad_reads = [nm[q] for q in dr]
+                mom_reads = [nm[q] for q in mr]
+            else:
+                dad_reads = [rt.qnames[q] for q in dr]
+                mom_reads = [rt.qnames[q] for q in mr]
+            out[k] = (dad_reads, mom_reads, list(map(str, ds)), list(map(str, ms)))
+        return out
 
     # ------------------------------------------------------- CNV phasing
     def run_cnv_phasing(self, dnms, pedigrees, threads, build, multithread_proc_min, quiet_mode, params, annotate=True):

@@ -687,8 +687,8 @@ class _KeptNames(Sequence):
     def take(self, ids) -> list:
         r = self._rec[np.ascontiguousarray(ids, np.int64)]
         a, b = self._off[r].tolist(), self._off[r + 1].tolist()
-        raw = self._buf.tobytes()
-        return [raw[x:y].decode() for x, y in zip(a, b)]
+        mv = memoryview(self._buf)  # (not tobytes(): the buffer holds the names of every kept record of the batch, tens of megabytes)
+        return [str(mv[x:y], "utf-8") for x, y in zip(a, b)]
 
 
 class KeptBatch:

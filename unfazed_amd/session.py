@@ -16,6 +16,7 @@ from .model import ReadsTable, SitesTable
 _SITES: Dict[str, SitesTable] = {}
 _READS: Dict[str, ReadsTable] = {}
 _HOSTS: Dict[tuple, PhasingHost] = {}
+_STAGERS: Dict[tuple, object] = {}  # indexed BAMs opened for staging, by (path, size, mtime, insert-size sample)
 _BACKEND = None
 
 
@@ -202,8 +203,15 @@ class _LazyReads(dict):
         if not bam.endswith(".bam") or _python_io() or os.environ.get("UZ_IO_STAGE", "1") == "0":
             return None
         if bam not in self._stagers:
+            # opening reads the index and the first insert_size_max_sample + 1 records (the reference's insert-size estimate,
+            # read_collector.py:11-25): kept for the process, so that the drivers' second call on a file (phase_svs behind phase_snvs:
+            # unfazed.py:601-646) does not pay it again -- as long as the file is the same one
             from .io_native import BamSource
-            self._stagers[bam] = BamSource(bam, insert_size_max_sample=self.cap, threads=_io_threads())
+            st = os.stat(bam)
+            key = (os.path.abspath(bam), st.st_size, st.st_mtime_ns, int(self.cap))
+            if key not in _STAGERS:
+                _STAGERS[key] = BamSource(bam, insert_size_max_sample=self.cap, threads=_io_threads())
+            self._stagers[bam] = _STAGERS[key]
         return self._stagers[bam]
 
     def regions(self, bam: str, tid, lo, hi) -> ReadsTable:
