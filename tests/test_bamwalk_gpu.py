@@ -134,3 +134,56 @@ def test_a_kept_list_that_points_beyond_its_stores_is_refused(engine, workload):
     dev = src.select_kept(fc, flo, fhi, 20, walk=engine.bam_walk, release=engine.bam_walk_release)
     rid = engine.reads_from_bam(dev)
     engine.free_reads(rid)
+
+
+def _long_insert_bam(path):
+    """pairs 3 kb apart (template length far beyond the 1 kb reach slack) tiling 10 kb - 62 kb of one contig: the mate of a record a fetch returns
+    lies in ANOTHER reach interval of the same stage task -- and, where the walk plan cuts that task into sub-tasks of at most 32 kb, in
+    another sub-task"""
+    from filesio import write_bai
+    from unfazed_amd.io_bam import write_bam
+    from unfazed_amd.model import Segment
+    segs = []
+    L = 151
+    for k, p in enumerate(range(10_000, 59_000, 23)):
+        q = "pair%05d" % k
+        m = p + 3000
+        segs.append(Segment(q, 0x1 | 0x2 | 0x20 | 0x40, 0, p, 60, [(0, L)], 0, m, m + L - p, "ACGT" * 37 + "ACG", [37] * L))
+        segs.append(Segment(q, 0x1 | 0x2 | 0x10 | 0x80, 0, m, 60, [(0, L)], 0, p, -(m + L - p), "TGCA" * 37 + "TGC", [37] * L))
+    segs.sort(key=lambda s: s.pos)
+    write_bam(path, [("1", 200_000)], segs)
+    write_bai(path)
+
+
+def test_a_mate_in_another_sub_task_of_the_same_stage_task_is_kept(engine, tmp_path):
+    """the device built its mate-candidate hash set per walk task -- a sub-task of the stage's task -- where the host's rule
+    (finish_task) works per stage task: a non-direct mate walked by sub-task u whose direct partner lay in sub-task u + 1 was dropped on the
+    device route and never looked up through the index.  The set now belongs to the stage task: the device's descriptors are again exactly the
+    host rule's, and every direct record keeps its mate."""
+    bam = str(tmp_path / "long.bam")
+    _long_insert_bam(bam)
+    pts = np.arange(12_000, 58_001, 2_500)  # one-base fetches 2.5 kb apart: reach intervals that do not merge, one stage task, two sub-tasks
+    fc = np.zeros(pts.size, np.int32)
+    flo, fhi, fex = pts.astype(np.int32), (pts + 1).astype(np.int32), np.zeros(pts.size, np.uint16)
+    src = io_native.BamSource(bam, threads=2)
+    twin = src.select_kept(fc, flo, fhi, 20, small_tasks=True)
+    dev = src.select_kept(fc, flo, fhi, 20, walk=engine.bam_walk, merge=True)
+    try:
+        assert dev.plan["task"].reshape(-1, 10).shape[0] > np.unique(dev.plan["task"].reshape(-1, 10)[:, 9]).size, "the plan did not cut a stage task into sub-tasks"
+        assert (dev.d_flags != 0).sum() == 0
+        ok = np.ones(twin.desc.size, bool)
+        for t in range(twin.d_first.size - 1):
+            d = twin.desc[twin.d_first[t]: twin.d_first[t + 1]]
+            keys = np.unique(d["h1"][d["direct"] != 0] | np.uint64(1))
+            ok[twin.d_first[t]: twin.d_first[t + 1]] &= (d["direct"] != 0) | np.isin(d["h1"] | np.uint64(1), keys)
+        want = twin.desc[ok]
+        assert dev.desc.size == want.size
+        for f in FIELDS:
+            assert np.array_equal(dev.desc[f], want[f]), f
+        for f in ("qname", "mate", "cig_off", "unit_off", "seq_off"):
+            assert np.array_equal(dev.kept[f], twin.kept[f]), f
+        # every record a fetch returns has its mate in the kept list (the mates lie 3 kb away: inside the stage task's reach, outside the record's own interval)
+        assert (dev.kept["mate"] >= 0).all()
+    finally:
+        engine.bam_walk_release(dev.token)
+        dev.token = None

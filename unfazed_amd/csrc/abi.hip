@@ -1793,7 +1793,7 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 // the descriptors the host's joins can need at all (direct, or sharing a name hash with a direct record of the task) are counted
                 w.tab.ensure((size_t)tab_total + 1);
                 UZ_HIP(hipMemsetAsync(w.tab.p, 0, (size_t)tab_total * 8, st));
-                uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.count.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
+                uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.count.p, w.task.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
                 UZ_HIP(hipMemcpyAsync(&kept, w.kfirst.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
             }
             if (n_blocks) UZ_HIP(hipMemcpyAsync(iflags.data(), w.iflags.p, (2 * ns + (blk_crc ? 1 : 0)) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1822,7 +1822,7 @@ int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_fir
         const int32_t nt = w.n_tasks;
         if (nt == 0) { d_first[0] = 0; return; }
         w.desc_kept.ensure((size_t)w.n_desc + 1);
-        uz_launch_desc_filter(c, st, true, nt, w.desc.p, w.first.p, w.count.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, w.desc_kept.p);
+        uz_launch_desc_filter(c, st, true, nt, w.desc.p, w.first.p, w.count.p, w.task.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, w.desc_kept.p);
         if (w.n_desc) UZ_HIP(hipMemcpyAsync(desc, w.desc_kept.p, (size_t)w.n_desc * sizeof(uz_walk_desc), hipMemcpyDeviceToHost, st));
         UZ_HIP(hipMemcpyAsync(d_first, w.kfirst.p, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
         if (d_flags) UZ_HIP(hipMemcpyAsync(d_flags, w.flags.p, (size_t)nt * 4, hipMemcpyDeviceToHost, st));

@@ -4,16 +4,16 @@
 // the reference per DNM and het site, read_collector.py:385, :167) and the copy of every record it keeps into the link form.  The blocks of a
 // batch are inflated in HBM by k_bgzf_inflate and stay there.
 //
-//   k_bam_walk<FILL>   one wavefront per walk task.  A BAM stream has no record index: every record starts where the one before ends, so the
+//   k_bam_walk         one wavefront per walk task.  A BAM stream has no record index: every record starts where the one before ends, so the
 //                      chain of block_size fields is inherently serial -- but only per task, and a batch has hundreds to thousands of tasks.
 //                      The wave stages the stream through LDS in 16 KiB windows (64 lanes x 16-byte loads, coalesced); lane 0 follows the
 //                      chain inside the window at LDS latency (~50 records per window) and lists the record starts; then all 64 lanes take
 //                      one record each: virtual offset (block table), refID / pos against the task's stop rules, end from the CIGAR, the
 //                      reach intervals, the fetches (binary search), the two name hashes.  The host's walk is sequential (`break` / `stop`
 //                      at the first record that says so): the lanes vote, the first lane that ends the walk wins, later lanes are dropped.
-//                      Pass 1 (FILL = false) counts the descriptors per task, k_walk_scan turns the counts into offsets, pass 2 writes the
-//                      64-byte descriptors task by task in file order.  HBM-bound by construction (every inflated byte is read once per pass
-//                      through the windows, the lanes' own reads hit the same lines in L2): 2 x the batch's inflated bytes.
+//                      ONE pass: every task writes its 64-byte descriptors in file order into a slice of the output sized for the most records
+//                      its bytes can hold (a record is at least 36 bytes) and counts them; every inflated byte is read once through the windows
+//                      (the lanes' own reads hit the same lines in L2).  Then the mate-candidate filter: k_tab_insert, k_desc_filter.
 //   k_bam_extract      one lane per KEPT record (the host's answer: uz_kept_rec): the plain columns of uz_reads_packed_view from the record's
 //                      bytes -- start, tlen, flag, l_seq, n_cigar, mapq, the aux bits (mate on the same reference, an SA tag, no CIGAR / SEQ /
 //                      QUAL), every CIGAR word, the bases as BAM packs them (four bits: the device's own row format), the one-bit plane
@@ -65,16 +65,16 @@ struct WalkArgs {
     const int64_t *span;      // [UZ_WALK_SPAN_COLS n_spans]
     const int32_t *reach;     // [2 n_reach]
     const int32_t *fetch;     // [3 n_fetch]
-    int64_t *count;           // [n_tasks]  (pass 1)
-    const int64_t *first;     // [n_tasks + 1]  (pass 2)
+    int64_t *count;           // [n_tasks]  out: descriptors written
+    const int64_t *first;     // [n_tasks + 1]  where every task's slice of `out` starts (worst-case sizes: abi.hip uz_bam_walk)
     int64_t *walked;          // [n_tasks]
     int32_t *flags;           // [n_tasks]
     uz_walk_desc *out;
-    // the names of the direct records of a task, as a hash set (open addressing over the task's own slice of `tab`): pass 1 counts them,
-    // pass 2 inserts them; k_desc_filter then drops every descriptor that is neither direct nor shares a name hash with a direct one --
-    // exactly the records the host's walk drops first (io_stage.cpp finish_task: "mate candidates")
-    int64_t *n_direct;        // [n_tasks]  (pass 1)
-    const int64_t *tab_first; // [n_tasks + 1]  (pass 2): the task's slice, a power of two of slots
+    // the names of the direct records of a HOST task (all its sub-tasks), as a hash set (open addressing over a slice of `tab`): the walk
+    // counts them, k_tab_insert inserts them; k_desc_filter then drops every descriptor that is neither direct nor shares a name hash with a
+    // direct one -- exactly the records the host's walk drops first (io_stage.cpp finish_task: "mate candidates")
+    int64_t *n_direct;        // [n_tasks]  out: direct records of the task
+    const int64_t *tab_first; // [n_tasks + 1]  (the kernels behind the walk): the slices, a power of two of slots for the first sub-task of a host task
     unsigned long long *tab;
 };
 __device__ __forceinline__ unsigned long long tab_key(uint64_t h1) { return (unsigned long long)h1 | 1ULL; } // (never 0 = empty; merging two hashes keeps a record too many, never one too few)
@@ -240,12 +240,22 @@ __global__ __launch_bounds__(64) void k_bam_walk(WalkArgs a) {
     }
 }
 
-// the names of every task's direct records into its hash set (one wavefront per task over its descriptors)
+// The hash set of mate candidates belongs to the HOST task (the stage's own task: finish_task in io_stage.cpp keeps the records that share a
+// name with a direct record of the task), and a host task is walked as several sub-tasks here (column 9 of a walk task names its host task;
+// the sub-tasks of one host task stand next to each other): all of them insert into and look up in ONE set, the slice of the first of
+// them.  (Round 4 gave every sub-task a set of its own: a mate that lay in another sub-task's reach than its partner -- a long insert, a
+// discordant pair -- was dropped here and never looked up through the index.)
+__device__ __forceinline__ int walk_leader(const int32_t *__restrict__ task, int t) {
+    const int32_t host = task[UZ_WALK_TASK_COLS * (size_t)t + 9];
+    while (t > 0 && task[UZ_WALK_TASK_COLS * (size_t)(t - 1) + 9] == host) t--;
+    return t;
+}
+// the names of every task's direct records into its host task's hash set (one wavefront per task over its descriptors)
 __global__ __launch_bounds__(64) void k_tab_insert(const uz_walk_desc *__restrict__ in, const int64_t *__restrict__ first, const int64_t *__restrict__ count,
-                                                   const int64_t *__restrict__ tab_first, unsigned long long *tab) {
-    const int t = blockIdx.x;
-    const int64_t a = first[t], b = a + count[t], size = tab_first[t + 1] - tab_first[t];
-    unsigned long long *tb = tab + tab_first[t];
+                                                   const int32_t *__restrict__ task, const int64_t *__restrict__ tab_first, unsigned long long *tab) {
+    const int t = blockIdx.x, L = walk_leader(task, t);
+    const int64_t a = first[t], b = a + count[t], size = tab_first[L + 1] - tab_first[L];
+    unsigned long long *tb = tab + tab_first[L];
     for (int64_t i = a + threadIdx.x; i < b; i += 64) {
         if (!in[i].direct) continue;
         const unsigned long long key = tab_key(in[i].h1);
@@ -256,16 +266,20 @@ __global__ __launch_bounds__(64) void k_tab_insert(const uz_walk_desc *__restric
     }
 }
 
-// counts -> offsets (one workgroup); POW2: the count of task i stands for a hash set of the next power of two >= 2 count + 2 slots
+// counts -> offsets (one workgroup); POW2: the hash sets -- the first sub-task of a host task stands for a set of the next power of two >= 2 c + 2
+// slots, c the direct records of all its sub-tasks; the others for none (walk_leader)
 template <bool POW2>
-__global__ __launch_bounds__(256) void k_walk_scan(int n, const int64_t *count, int64_t *first) {
+__global__ __launch_bounds__(256) void k_walk_scan(int n, const int64_t *count, int64_t *first, const int32_t *__restrict__ task) {
     __shared__ long long part[256];
     const int t = threadIdx.x;
     const int chunk = (n + 255) / 256;
     const int lo = min(t * chunk, n), hi = min(lo + chunk, n);
     auto val = [&](int i) -> long long {
-        const long long c = count[i];
+        long long c = count[i];
         if (!POW2) return c;
+        const int32_t host = task[UZ_WALK_TASK_COLS * (size_t)i + 9];
+        if (i > 0 && task[UZ_WALK_TASK_COLS * (size_t)(i - 1) + 9] == host) return 0;
+        for (int j = i + 1; j < n && task[UZ_WALK_TASK_COLS * (size_t)j + 9] == host; j++) c += count[j];
         long long sz = 4;
         while (sz < 2 * c + 2) sz <<= 1;
         return sz;
@@ -287,11 +301,11 @@ __global__ __launch_bounds__(256) void k_walk_scan(int n, const int64_t *count, 
 // the descriptors of a task that are direct or share a name hash with a direct one, in order (one wavefront per task)
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_desc_filter(const uz_walk_desc *__restrict__ in, const int64_t *__restrict__ first, const int64_t *__restrict__ count,
-                                                    const int64_t *__restrict__ tab_first, const unsigned long long *__restrict__ tab, int64_t *kcount,
-                                                    const int64_t *__restrict__ kfirst, uz_walk_desc *out) {
-    const int t = blockIdx.x, lane = threadIdx.x;
-    const int64_t a = first[t], b = a + count[t], size = tab_first[t + 1] - tab_first[t];
-    const unsigned long long *tb = tab + tab_first[t];
+                                                    const int32_t *__restrict__ task, const int64_t *__restrict__ tab_first, const unsigned long long *__restrict__ tab,
+                                                    int64_t *kcount, const int64_t *__restrict__ kfirst, uz_walk_desc *out) {
+    const int t = blockIdx.x, lane = threadIdx.x, L = walk_leader(task, t);
+    const int64_t a = first[t], b = a + count[t], size = tab_first[L + 1] - tab_first[L];
+    const unsigned long long *tb = tab + tab_first[L];
     int64_t n_out = 0;
     for (int64_t i0 = a; i0 < b; i0 += 64) {
         const int64_t i = i0 + lane;
@@ -471,20 +485,20 @@ void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, int n_tasks, const uint8_t *b
     if (n_tasks <= 0) return;
     WalkArgs a{buf, blk_at, blk_coff, task, span, reach, fetch, count, first, walked, flags, out, n_direct, nullptr, nullptr};
     hipLaunchKernelGGL(k_bam_walk, dim3((unsigned)n_tasks), dim3(64), 0, st, a);
-    hipLaunchKernelGGL((k_walk_scan<true>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)n_direct, tab_first);
+    hipLaunchKernelGGL((k_walk_scan<true>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)n_direct, tab_first, task);
     UZ_HIP(hipGetLastError());
 }
 // stage 0: the hash sets filled, the kept descriptors counted (kcount, kfirst); stage 1: the kept descriptors into `out`
 void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uz_walk_desc *in, const int64_t *first, const int64_t *count,
-                           const int64_t *tab_first, unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out) {
+                           const int32_t *task, const int64_t *tab_first, unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out) {
     if (n_tasks <= 0) return;
     if (!fill) {
-        hipLaunchKernelGGL(k_tab_insert, dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, tab_first, tab);
-        hipLaunchKernelGGL((k_desc_filter<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, tab_first, (const unsigned long long *)tab, kcount,
+        hipLaunchKernelGGL(k_tab_insert, dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, task, tab_first, tab);
+        hipLaunchKernelGGL((k_desc_filter<false>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, task, tab_first, (const unsigned long long *)tab, kcount,
                            (const int64_t *)kfirst, out);
-        hipLaunchKernelGGL((k_walk_scan<false>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)kcount, kfirst);
+        hipLaunchKernelGGL((k_walk_scan<false>), dim3(1), dim3(256), 0, st, n_tasks, (const int64_t *)kcount, kfirst, task);
     } else
-        hipLaunchKernelGGL((k_desc_filter<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, tab_first, (const unsigned long long *)tab, kcount,
+        hipLaunchKernelGGL((k_desc_filter<true>), dim3((unsigned)n_tasks), dim3(64), 0, st, in, first, count, task, tab_first, (const unsigned long long *)tab, kcount,
                            (const int64_t *)kfirst, out);
     UZ_HIP(hipGetLastError());
 }

@@ -401,7 +401,7 @@ void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, int n_tasks, const uint8_t *b
                         const int64_t *span, const int32_t *reach, const int32_t *fetch, int64_t *count, const int64_t *first, int64_t *walked, int32_t *flags,
                         uz_walk_desc *out, int64_t *n_direct, int64_t *tab_first);
 void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uz_walk_desc *in, const int64_t *first, const int64_t *count,
-                           const int64_t *tab_first, unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out);
+                           const int32_t *task, const int64_t *tab_first, unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out);
 size_t uz_bam_walk_pad(); // bytes the inflated buffer must be padded by (the walk's LDS windows read past the last record)
 void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
                            int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
