@@ -187,3 +187,26 @@ def test_a_mate_in_another_sub_task_of_the_same_stage_task_is_kept(engine, tmp_p
     finally:
         engine.bam_walk_release(dev.token)
         dev.token = None
+
+
+def test_a_batch_beyond_the_walk_cap_takes_the_host_route(engine, workload, monkeypatch):
+    """the device walk keeps a batch's inflated bytes and worst-case descriptor slices in HBM with no size cap.  A batch whose blocks
+    inflate to more than UZ_WALK_MAX_BYTES is staged by the host (the link form) instead of failing in hipMalloc: same table either way."""
+    fc, flo, fhi, fex = fetches_of(workload, 2, 4)
+    src = io_native.BamSource(workload["bam"], threads=3)
+    rid_a, names_a = engine.upload_reads_staged(src, fc, flo, fhi, fex, 20)
+    monkeypatch.setenv("UZ_WALK_MAX_BYTES", "1")
+    rid_b, names_b = engine.upload_reads_staged(src, fc, flo, fhi, fex, 20)
+    monkeypatch.delenv("UZ_WALK_MAX_BYTES")
+    try:
+        assert "joins" in names_a.timing and "joins" not in names_b.timing  # (the device walk's timing keys; the host stage's: spans / walk / mates / ...)
+        n = int(names_b.io_stats["records_kept"])
+        assert n == int(names_a.io_stats["records_kept"])
+        a, b = engine.reads_headers(rid_a, n), engine.reads_headers(rid_b, n)
+        for k in ("start", "end", "tlen", "mate", "qname"):
+            assert np.array_equal(a[k], b[k]), k
+        ids = np.arange(len(names_b.qnames), dtype=np.uint32)
+        assert names_a.qnames.take(ids) == names_b.qnames.take(ids)
+    finally:
+        engine.free_reads(rid_a)
+        engine.free_reads(rid_b)

@@ -1808,7 +1808,16 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
             w.n_desc = kept;
             *n_desc = kept;
             *walk_id = k;
-        } catch (...) { std::lock_guard<std::mutex> lk(c->err_mu); w.busy = false; throw; }
+        } catch (...) {
+            // (copies into this frame's locals and kernels on the slot's buffers may still be queued: nothing of the slot is handed on, and the frame
+            // is not left, before both of its streams have drained)
+            if (w.s0) (void)hipStreamSynchronize(w.s0);
+            if (w.s1) (void)hipStreamSynchronize(w.s1);
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lk(c->err_mu);
+            w.busy = false;
+            throw;
+        }
     });
 }
 

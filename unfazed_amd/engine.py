@@ -100,6 +100,10 @@ def load_library(path: Optional[str] = None):
     return L
 
 
+class _WalkTooLarge(Exception):
+    """the blocks of a batch inflate to more than the device walk keeps in HBM (HipEngine.stage_reads falls back to the host route)"""
+
+
 class HipEngine:
     """One context on one GPU.  Backend interface used by hostpath.PhasingHost."""
 
@@ -257,12 +261,22 @@ class HipEngine:
                 self._inflate_bufs = PinnedPair()
             pair = self._inflate_bufs
             pair.start()
-            kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=lambda plan: self.bam_walk(plan, alloc=pair.alloc), all_bases=bool(all_bases),
-                                 alloc=pair.alloc, extra=fex, release=self.bam_walk_release)
-            rid = self.reads_from_bam(kb, names=True)
-            names = type("StagedNames", (), {})()
-            names.qnames, names.io_stats, names.timing = kb.qnames, kb.io_stats, kb.timing
-            return rid, names
+            cap = int(os.environ.get("UZ_WALK_MAX_BYTES", 16 << 30))  # (stage_reads: a batch beyond it takes the host route below)
+
+            def walk(plan):
+                if int(plan["out_bytes"]) > cap:
+                    raise _WalkTooLarge()
+                return self.bam_walk(plan, alloc=pair.alloc)
+            try:
+                kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=walk, all_bases=bool(all_bases), alloc=pair.alloc, extra=fex,
+                                     release=self.bam_walk_release)
+            except _WalkTooLarge:
+                kb = None
+            if kb is not None:
+                rid = self.reads_from_bam(kb, names=True)
+                names = type("StagedNames", (), {})()
+                names.qnames, names.io_stats, names.timing = kb.qnames, kb.io_stats, kb.timing
+                return rid, names
         try:
             inflate = inflate_alloc = None
             if os.environ.get("UZ_INFLATE", "device") == "device":  # the batch's BGZF blocks inflated on the device (UZ_INFLATE=host: by the host's cores)
@@ -309,9 +323,20 @@ class HipEngine:
             # 64-byte descriptors, and upload_reads_packed builds the table from the bytes the walk left on the device (UZ_WALK=host: the link form)
             from . import io_native
             pair.start()
-            kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=lambda plan: self.bam_walk(plan, alloc=pair.alloc), all_bases=bool(all_bases),
-                                 alloc=pair.alloc, extra=fex, release=self.bam_walk_release)
-            return kb
+            # a walked batch keeps its compressed blocks, the inflated bytes and worst-case descriptor slices (64 B per 36 B of inflated data) in
+            # HBM until its table is built, in one of four slots: a batch whose blocks inflate to more than the cap takes the host route below
+            # (the link form: nothing but the packed table reaches the device) instead of failing in hipMalloc
+            cap = int(os.environ.get("UZ_WALK_MAX_BYTES", 16 << 30))
+
+            def walk(plan):
+                if int(plan["out_bytes"]) > cap:
+                    raise _WalkTooLarge()
+                return self.bam_walk(plan, alloc=pair.alloc)
+            try:
+                return src.select_kept(fc, flo, fhi, int(min_base_qual), walk=walk, all_bases=bool(all_bases), alloc=pair.alloc, extra=fex,
+                                       release=self.bam_walk_release)
+            except _WalkTooLarge:
+                pass
         if os.environ.get("UZ_INFLATE", "device") == "device":
             pair.start()
             inflate, inflate_alloc = self.inflate_blocks, pair.alloc
