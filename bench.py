@@ -239,10 +239,12 @@ def main():
         eng.prof_reset()
         barrier()
         t0 = time.perf_counter()
+        c0 = time.process_time()
         for _ in range(args.steps):
             res = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        timed.host_cpu_s = (time.process_time() - c0) / max(1, args.steps)  # CPU seconds of this rank's process per step, all its threads
         timed.per_rank = [elapsed]
         if dist is not None:
             t = torch.zeros(world, dtype=torch.float64, device="cpu" if one_device else "cuda")
@@ -281,6 +283,7 @@ def main():
         return r
 
     res_r, el_r, prof_r = timed(step_resident)
+    host_cpu_resident = timed.host_cpu_s
     if rtrace:
         print("[resident step, ms] drop_derived | read stage | allele balance:", rtrace, file=sys.stderr)
     per_rank_r = list(timed.per_rank)
@@ -311,10 +314,11 @@ def main():
 
         res_s, el_s, prof_s = timed(step_staged)
         per_rank_s = list(timed.per_rank)
+        host_cpu_staged = timed.host_cpu_s
         if trace:
             print("[staged step, ms] site stage 0, then per chunk: find (behind the read stage of chunk k - 2) | its results | enqueue records, the site windows of chunk k + 2 | queue the read stage of chunk k - 1 (config 5: + allele balance of chunk k - 2); last read stages:", trace[-2:], file=sys.stderr)
         mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
-        staged = dict(elapsed=el_s, prof=prof_s, bytes=st["read_bytes"] + st["site_bytes"], read_bytes=st["read_bytes"], records=st["records"],
+        staged = dict(host_cpu_s=host_cpu_staged, elapsed=el_s, prof=prof_s, bytes=st["read_bytes"] + st["site_bytes"], read_bytes=st["read_bytes"], records=st["records"],
                       decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks),
                       sites=st["sites"], site_stage="whole batch" if args.one_site_table else "per chunk")
         res = res_s
@@ -446,7 +450,7 @@ def main():
         out = {
             "metric": "phased DNMs/sec", "value": round(value, 1), "unit": "DNMs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8/int32 (+f64 allele balance)",
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "n/a", "vs_baseline": None, "dtype": "u8/int32 (+f64 allele balance)",
             "data": "synthetic",
             "config": {"workload": (("10k CNV (DEL/DUP) DNMs exercising the allele-balance sv_phaser path (BASELINE configs[4]): K6 + SV read-backed stage"
                                      if args.dnms == 10000 else "%d synthetic DEL/DUP events, allele balance + SV read-backed stage" % args.dnms) if cnv else
@@ -457,6 +461,8 @@ def main():
                        "read_clusters": cl.n, "dnms_sharing_a_cluster": int(cl.nd[cl.nd > 1].sum()),
                        "alignment_records": wl.n_segs, "parallelism": "dnm-shard x%d, no collective" % world},
             "value_resident": round(value_resident, 1), "ms_per_step_resident": round(ms_resident, 3),
+            # CPU seconds of rank 0's process per step (every thread of it): what eight ranks on one node would ask of the host's cores between them
+            "host_cpu_seconds_per_step": {"staged": round(staged["host_cpu_s"], 5) if staged else None, "resident": round(host_cpu_resident, 5)},
             "ms_per_step_by_rank": [round(x / args.steps * 1e3, 3) for x in (per_rank_s if staged else per_rank_r)],
             "ms_per_step_resident_by_rank": [round(x / args.steps * 1e3, 3) for x in per_rank_r],
             "roofline": roofline,
@@ -623,6 +629,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
             lag = int(os.environ.get("UZ_FEED_LAG", "3")) if dev_walk else 1
             with ThreadPoolExecutor(lag + 1) as ex:
                 t = time.perf_counter()
+                c_t = time.process_time()
                 fa = {0: ex.submit(stage_a, 0)}
                 fcs, devs = {}, {}
                 for k in range(K):
@@ -635,6 +642,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 for k in range(max(0, K - lag), K):
                     stage_d(k, devs.pop(k), fcs.pop(k).result())
                 eng.sync()
+                acc["host_cpu_s"] = time.process_time() - c_t  # (the library's worker threads included)
                 return time.perf_counter() - t
 
         run_pass()  # warm-up: page cache, pinned blocks, code
@@ -681,10 +689,12 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
             "bam": {"records": st_b["records"], "file_GB": round(st_b["file_bytes"] / 1e9, 3), "raw_GB": round(st_b["raw_bytes"] / 1e9, 3), "blocks": st_b["blocks"],
                     "write_s": round(t1 - t0, 1), "deflate_level": args.feed_level},
             "vcf": {"records": st_v["records"], "file_GB": round(st_v["file_bytes"] / 1e9, 3), "write_s": round(t2 - t1, 1)},
-            "decode_regions": {"seconds_busy": round(acc["walk"], 3), "records_walked_per_s": round(acc["walked"] / max(acc["walk"], 1e-9), 0),
-                               "inflated_GBps": round(acc["walked"] * raw_per_rec / max(acc["walk"], 1e-9) / 1e9, 2),
-                               "records_walked": acc["walked"], "blocks_inflated": acc["blocks"], "file_bytes_read": acc["file_bytes"],
-                               "index_mate_lookups": acc["lookups"]},
+            # (rates only for a stage that ran on the host: with the walk on the device its time is inside device_walk.seconds_busy)
+            "decode_regions": dict({"seconds_busy": round(acc["walk"], 3), "records_walked": acc["walked"], "blocks_inflated": acc["blocks"],
+                                    "file_bytes_read": acc["file_bytes"], "index_mate_lookups": acc["lookups"]},
+                                   **({"records_walked_per_s": round(acc["walked"] / acc["walk"], 0),
+                                       "inflated_GBps": round(acc["walked"] * raw_per_rec / acc["walk"] / 1e9, 2)} if acc["walk"] > 1e-6 else {})),
+            "host_cpu_seconds_per_pass": round(float(acc.get("host_cpu_s", 0.0)), 3),
             "select": {"seconds_busy": round(acc["spans"] + acc["mates"], 3), "spans_s": round(acc["spans"], 3), "mates_s": round(acc["mates"], 3), "records_kept": acc["kept"],
                        "records_per_s": round(acc["kept"] / max(acc["spans"] + acc["mates"], 1e-9), 0)},
             "pack": {"seconds_busy": round(acc["numbering"] + acc["fill"], 3), "numbering_s": round(acc["numbering"], 3), "fill_s": round(acc["fill"], 3), "records_per_s": round(acc["kept"] / max(acc["numbering"] + acc["fill"], 1e-9), 0),

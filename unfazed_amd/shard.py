@@ -29,6 +29,11 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, mi
     # 7 / 0.5 = 11.07 ms on one box) -- and one chunk more than n / min_per_chunk when there are four or more, so that the others keep their size.
     k0 = n // int(min_per_chunk)
     k = int(chunks) if chunks else max(3, k0 + (1 if k0 >= 4 else 0))
+    if not chunks and k0 < 1:
+        # a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run): two chunks, the second 0.6 x the first -- round 5, with the read
+        # stage and the header build at a third of their round-4 time a chunk's fixed costs (a find, ~40 launches) weigh more than what a
+        # third chunk hides: 1 / 2 equal / 2 with 0.6 / 3 / 4 chunks = 2.75 / 2.88 / 2.57 / 2.75 / 3.10 ms on one box
+        k, last_chunk = 2, min(float(last_chunk), 0.6)
     if first_chunk is None:
         first_chunk = 0.5
     k = max(1, min(k, n))
