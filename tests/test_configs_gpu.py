@@ -132,9 +132,9 @@ def test_config4_eight_shards_one_after_another_equal_one_gpu(engine, snv100k):
         try:
             sid, fid, rid = part.adopt(engine, P)
             assert part.cutoff == w["load"].cutoff  # every rank estimates the insert cutoff from the head of the same file
-            assert len(shard.chunk_plan(part.n)) - 1 == 3  # three chunks for a 12.5 k shard
+            assert len(shard.chunk_plan(part.n)) - 1 == 2  # two chunks for a 12.5 k shard (shard.chunk_plan: round 5)
             out, n_chunks, _ = _staged(engine, part, P, fid)
-            assert n_chunks == 3
+            assert n_chunks == 2
             for k in KEYS:
                 got[k].append(out[k])
             engine.free_reads(rid)
