@@ -66,46 +66,34 @@ __global__ __launch_bounds__(WG_NT, LDS ? UZ_PHASE_MIN_WAVES : 5) void k_phase(P
         __device__ ~TickFlush() { __syncthreads(); if (threadIdx.x < 24 && s->tick[threadIdx.x]) atomicAdd(&t[threadIdx.x], s->tick[threadIdx.x]); }
     } tick_flush{&sh, uz_g(ap->timing)};
 #endif
-    if (ap->from_list) { // the list the launch before this one left behind, one cursor
-        const int slot = ap->cursor_slot;
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int k = atomicAdd(uz_g(ap->work_cursor) + 16 * slot, 1);
-                sh.bcast[0] = k < *uz_g(ap->src_count) ? uz_g(ap->src_list)[k] : -1;
-            }
-            __syncthreads();
-            const int d = sh.bcast[0];
-            if (d < 0) break;
-            if (uz_phase_dnm<LDS>(ap, scr_base, &sh, LDS ? uz_lds_arena : nullptr, d)) { // (uniform; the HBM build never gives a DNM up)
-                if (threadIdx.x == 0) uz_g(ap->retry_list)[atomicAdd(uz_g(ap->retry_count), 1)] = d;
-            }
-        }
-        return;
-    }
-    // Work distribution: the batch is cut into UZ_PHASE_PARTS contiguous DNM ranges, one cursor each, and a workgroup
-    // starts on the range of (blockIdx % PARTS) -- with the usual round-robin placement of workgroups over the 8 XCDs that is
-    // "its XCD's range".  DNMs are sorted by position and neighbours share window sites and alignment records, so the lines
-    // one of them pulls into the XCD's L2 serve the next (each XCD has its own L2).  A workgroup whose range is exhausted
-    // goes on to the other ranges; nothing depends on where a workgroup really runs.
-    int part = (int)(blockIdx.x % UZ_PHASE_PARTS);
+    // Work distribution.  A launch over the whole batch: the batch is cut into UZ_PHASE_PARTS contiguous DNM ranges, one cursor each, and a
+    // workgroup starts on the range of (blockIdx % PARTS) -- with the usual round-robin placement of workgroups over the 8 XCDs that is
+    // "its XCD's range".  DNMs are sorted by position and neighbours share window sites and alignment records, so the lines one of them pulls
+    // into the XCD's L2 serve the next (each XCD has its own L2).  A workgroup whose range is exhausted goes on to the other ranges; nothing
+    // depends on where a workgroup really runs.  A launch over a list (the DNMs the launch before it gave up): one cursor.
+    // (ONE call of the body for both: inlined twice, the kernel was twice the instruction cache's size)
+    const bool from_list = ap->from_list != 0;
+    int part = from_list ? ap->cursor_slot : (int)(blockIdx.x % UZ_PHASE_PARTS);
     int tried = 0;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int n = ap->n;
-            const int lo = (int)((long long)n * part / UZ_PHASE_PARTS), hi = (int)((long long)n * (part + 1) / UZ_PHASE_PARTS);
             const int k = atomicAdd(uz_g(ap->work_cursor) + 16 * part, 1); // cursors on separate cache lines
-            sh.bcast[0] = lo + k < hi ? lo + k : -1;
+            if (from_list) sh.bcast[0] = k < *uz_g(ap->src_count) ? uz_g(ap->src_list)[k] : -1;
+            else {
+                const int n = ap->n;
+                const int lo = (int)((long long)n * part / UZ_PHASE_PARTS), hi = (int)((long long)n * (part + 1) / UZ_PHASE_PARTS);
+                sh.bcast[0] = lo + k < hi ? lo + k : -1;
+            }
         }
         __syncthreads();
         const int d = sh.bcast[0];
         if (d < 0) {
-            if (++tried >= UZ_PHASE_PARTS) break;
+            if (from_list || ++tried >= UZ_PHASE_PARTS) break;
             part = (part + 1) % UZ_PHASE_PARTS;
             continue;
         }
-        if (uz_phase_dnm<LDS>(ap, scr_base, &sh, uz_lds_arena, d)) { // (block-uniform)
+        if (uz_phase_dnm<LDS>(ap, scr_base, &sh, LDS ? uz_lds_arena : nullptr, d)) { // (uniform; the HBM build never gives a DNM up)
             if (threadIdx.x == 0) uz_g(ap->retry_list)[atomicAdd(uz_g(ap->retry_count), 1)] = d;
         }
     }
@@ -1358,7 +1346,7 @@ static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
         for (int32_t d = 0; d < n; d++) {
             const int32_t *b = &bh[(size_t)5 * d];
             if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
-            const long long est = ((37LL * b[1]) / 4 + 3584 + 255) >> 8;
+            const long long est = ((37LL * b[1]) / 4 + 10LL * b[0] + 3328 + 255) >> 8; // (b[0]: records of the DNM's own fetch -- 33 of a point variant, hundreds around an SV's breakpoints: a class byte and two flags each)
             hist[(size_t)std::min<long long>(est, 255)]++;
             active++;
         }
@@ -1501,7 +1489,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         const Caps caps = z.caps;
         int arena_used = z.arena;
-        const size_t per_wg = uz_scratch_layout(caps, a.so);
+        // two layouts of a workgroup's scratch region: the arena build's (what that build keeps in HBM: little) for the two arena launches,
+        // the HBM build's (every array) for the launch behind them; one buffer serves both, the launches run one after the other
+        ScrOff so_hbm;
+        const size_t per_wg = uz_scratch_layout(caps, a.so, true), per_wg_hbm = uz_scratch_layout(caps, so_hbm, false);
         if (const char *e = getenv("UZ_TEST_PHASE_ARENA")) { // test hook: an arena (bytes) too small for most DNMs -> they take the HBM build of k_phase
             const int t = atoi(e);
             if (t >= 0 && t < arena_used) arena_used = t;
@@ -1522,7 +1513,9 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         if (grid > n) grid = n;
         const size_t budget = (size_t)8 << 30; // keep the scratch under 8 GiB
         while (grid > 1 && (size_t)grid * per_wg > budget) grid /= 2;
-        st->scratch.ensure((size_t)grid * per_wg);
+        int grid_hbm = std::min(grid, 8 * st->n_cus); // (the DNMs the arena launches gave up: usually a handful -- eight waves per CU pull them from the list)
+        while (grid_hbm > 1 && (size_t)grid_hbm * per_wg_hbm > budget) grid_hbm /= 2;
+        st->scratch.ensure(std::max((size_t)grid * per_wg, (size_t)grid_hbm * per_wg_hbm));
         a.scratch = st->scratch.p; a.scratch_per_wg = per_wg; a.caps = caps;
         size_t pool_cap = (size_t)std::min<long long>(4 * z.sumP + 1024, (long long)1 << 31);
         st->pool.ensure(pool_cap);
@@ -1552,7 +1545,8 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                 UZ_HIP(hipGetLastError());
                 PhaseArgs a3 = a2;
                 a3.cursor_slot = UZ_PHASE_PARTS + 1; a3.src_count = retry2; a3.src_list = retry2 + 16;
-                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)std::min(grid, 8 * st->n_cus)), dim3(WG_NT), 0, c->stream, a3);
+                a3.so = so_hbm; a3.scratch_per_wg = per_wg_hbm;
+                hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)grid_hbm), dim3(WG_NT), 0, c->stream, a3);
                 UZ_HIP(hipGetLastError());
             }
             UZ_TRACE("after k_phase");

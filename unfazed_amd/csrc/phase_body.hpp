@@ -210,11 +210,14 @@ template <bool LDS> UZ_DEV typename Rk<LDS>::T uz_rk_win(typename Rk<LDS>::T k) 
     X(int32_t, misc, 8) /* [0] KeyError seen, [1] match_info count, [2] capacity exceeded */
 // ---- arrays that stay in the HBM scratch in both builds (none of them on the point-variant path of the arena build: since round 5 a pair's
 // records follow from arena arrays alone, and the second record of a pair is the first one's mate)
-#define UZ_SCR_HBM(X)                                                                                                                     \
+#define UZ_SCR_HBM_BOTH(X)                                                                                                                \
     X(int32_t, i_qp, cI) X(int32_t, i_L, cI) X(int32_t, i_R, cI) /* SV evidence: banned names, filter flags; HBM build: the seeding matches */ \
-    X(uint32_t, pq, cM)            /* name id of every pair (the optional lists) */                                                        \
-    X(unsigned long long, key, cM) /* second buffer of the counting sort (HBM build) */                                                    \
-    X(int32_t, q_cnt, 2 * cM + 1026) X(int32_t, q_fill, 2 * cM + 1026) /* counting sort of the pair-table keys over the query-name id range (HBM build) */
+    X(uint32_t, pq, cM)            /* name id of every pair (the optional lists) */
+// ---- ... and those only the HBM build touches
+#define UZ_SCR_HBM_ONLY(X)                                                                                                                \
+    X(unsigned long long, key, cM) /* second buffer of the counting sort; the winners' sorted copy of a chaining level */                  \
+    X(int32_t, q_cnt, 2 * cM + 1026) X(int32_t, q_fill, 2 * cM + 1026) /* counting sort of the pair-table keys over the query-name id range */
+#define UZ_SCR_HBM(X) UZ_SCR_HBM_BOTH(X) UZ_SCR_HBM_ONLY(X)
 
 template <bool LDS>
 struct ScrT {
@@ -248,15 +251,26 @@ struct ScrOff {
     UZ_SCR_HBM(UZ_X)
 #undef UZ_X
 };
-// fills `o`, returns the bytes of one workgroup's region
-UZ_HD size_t uz_scratch_layout(const Caps &c, ScrOff &o) {
+// fills `o`, returns the bytes of one workgroup's region.  arena_build: the region of a workgroup of the ARENA build -- it holds nothing but the few
+// arrays that build keeps in HBM (UZ_SCR_HBM_BOTH: ~4 bytes per pair-table entry of the largest DNM), where the HBM build's region holds every
+// array (~110 bytes per entry: 3.3 MB per workgroup for an SV batch -- sized like that for every wave of the arena build, a config-5 batch
+// outgrew the 8 GiB scratch budget and ran on half its waves)
+UZ_HD size_t uz_scratch_layout(const Caps &c, ScrOff &o, bool arena_build = false) {
     typedef Scr::hidx hidx; typedef Scr::pidx pidx; typedef Scr::xidx xidx; typedef Scr::rlen rlen; typedef Scr::gflg gflg; typedef Scr::skey skey; typedef Scr::rkey rkey; typedef Scr::fidx fidx;
     const size_t cA = (size_t)c.A + 1, cT = (size_t)c.T + 1, cH = (size_t)c.H + 2, cC = (size_t)c.C + 1, cI = (size_t)c.I + 2, cM = (size_t)c.M + 2;
     const size_t cFR = (cM > cI ? cM : cI) + 1;
     size_t at = 0;
 #define UZ_X(TY, NAME, CNT) at = (at + 15) & ~(size_t)15; o.NAME = at; at += (size_t)(CNT) * sizeof(TY);
-    UZ_SCR_ARENA(UZ_X)
-    UZ_SCR_HBM(UZ_X)
+#define UZ_X0(TY, NAME, CNT) o.NAME = 0;
+    if (arena_build) {
+        UZ_SCR_ARENA(UZ_X0)
+        UZ_SCR_HBM_ONLY(UZ_X0)
+        UZ_SCR_HBM_BOTH(UZ_X)
+    } else {
+        UZ_SCR_ARENA(UZ_X)
+        UZ_SCR_HBM(UZ_X)
+    }
+#undef UZ_X0
 #undef UZ_X
     return (at + 255) & ~(size_t)255;
 }
@@ -628,27 +642,40 @@ UZ_DEV int uz_classify_dnm_read(const RD &R, const PhaseArgs &a, double cutoff, 
 // collect_reads_sv (:499-586) for one record fetched around a breakpoint `position`:
 // 0 nothing, 1 supporting [read, mate] (split read), 2 supporting [mate, read] (discordant pair or
 // clipped read), 3 the record bans its query name (:520-522)
-UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i, long long position, long long lo, long long sv_start,
-                          long long sv_end) {
-    const RecA A = R.ra[i];
-    const RecB B = R.rb[i];
+// What the rule reads of a record comes in two round trips -- uz_sv_fetch1: headers, QC word, flag word; uz_sv_fetch2: its mate's QC word
+// and start, its first CIGAR word (98 % of records have one) -- which the caller issues for TWO records per lane before it decides either:
+// a breakpoint fetch returns hundreds of records, and one wave works through them.
+struct SvIn { RecA A; RecB B; uint32_t qc, fmw, qcm, w0; int32_t mstart; };
+UZ_DEV void uz_sv_fetch1(const RD &R, int i, SvIn &x) { x.A = R.ra[i]; x.B = R.rb[i]; x.qc = uz_qc_of(R.qs[i], R.min_map_qual); x.fmw = R.fm[i]; }
+UZ_DEV void uz_sv_fetch2(const RD &R, int i, SvIn &x) {
+    const int mi = x.B.mate >= 0 ? x.B.mate : i; // a safe index: unused without a mate
+    x.qcm = uz_qc_of(R.qs[mi], R.min_map_qual);
+    x.mstart = R.ra[mi].start;
+    x.w0 = x.B.n_cigar > 0 ? R.cigar[x.A.cigar_off] : 0u;
+}
+UZ_DEV int uz_sv_decide(const RD &R, const PhaseArgs &a, double cutoff, const SvIn &x, long long position, long long lo, long long sv_start,
+                        long long sv_end) {
+    const RecA &A = x.A;
+    const RecB &B = x.B;
     if (!((long long)A.end > lo)) return 0;
-    if (!(uz_qc_of(R.qs[i], R.min_map_qual) & UZ_QC_GOOD_DISC)) return 0;  // goodread(read, True) :503
-    const int mate = B.mate;                     // :507-510
+    if (!(x.qc & UZ_QC_GOOD_DISC)) return 0;  // goodread(read, True) :503
+    const int mate = B.mate;                  // :507-510
     if (mate < 0) return 0;
-    if (!(uz_qc_of(R.qs[mate], R.min_map_qual) & UZ_QC_GOOD_DISC)) return 0; // :512
+    if (!(x.qcm & UZ_QC_GOOD_DISC)) return 0; // :512
     const uint32_t *c = R.cigar + A.cigar_off;
     const int nc = B.n_cigar;
+    auto cw = [&](int k) -> uint32_t { return k == 0 ? x.w0 : c[k]; };
     long long total = 0;
-    for (int k = 0; k < nc; k++) total += (long long)(c[k] >> 4);
+    for (int k = 0; k < nc; k++) total += (long long)(cw(k) >> 4);
     int start_m = 0, end_m = 0, lead = 0, trail = 0;
     {
         long long o = 0;
         const long long t0 = total - 10 > 0 ? total - 10 : 0;
         bool in_lead = true;
         for (int k = 0; k < nc; k++) { // M/= among the first / last 10 entries of the per-base expansion of all ops :515-519
-            const int op = c[k] & 15;
-            const long long l = (long long)(c[k] >> 4), s0 = o, s1 = o + l;
+            const uint32_t w = cw(k);
+            const int op = w & 15;
+            const long long l = (long long)(w >> 4), s0 = o, s1 = o + l;
             if (op == UZ_OP_M || op == UZ_OP_EQ) {
                 const long long x1 = s1 < 10 ? s1 : 10;
                 if (x1 > s0) start_m += (int)(x1 - s0);
@@ -662,14 +689,15 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i,
             o = s1;
         }
         for (int k = nc - 1; k >= 0; k--) {
-            const int op = c[k] & 15;
-            if (op == UZ_OP_S || op == UZ_OP_I) trail += (int)(c[k] >> 4);
+            const uint32_t w = cw(k);
+            const int op = w & 15;
+            if (op == UZ_OP_S || op == UZ_OP_I) trail += (int)(w >> 4);
             else if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X) break;
         }
     }
     if (end_m < 7 && start_m < 7) return 3;
     const long long rs = A.start, re = A.end;
-    if ((R.fm[i] >> 24) & UZ_AUX_HAS_SA) { // :524-533
+    if ((x.fmw >> 24) & UZ_AUX_HAS_SA) { // :524-533
         const long long m = a.split_error_margin;
         return ((position - m <= rs && rs <= position + m) || (position - m <= re && re <= position + m)) ? 1 : 0;
     }
@@ -683,16 +711,23 @@ UZ_DEV int uz_sv_classify(const RD &R, const PhaseArgs &a, double cutoff, int i,
         disc = 0.7 < ratio && ratio < 1.3; // :534-536
     }
     if (disc) {
-        const long long ms = R.ra[mate].start;
+        const long long ms = x.mstart;
         const long long left0 = ms < rs ? ms : rs, right0 = ms > rs ? ms : rs;
         const long long wig = (long long)cutoff; // :551
         return ((sv_start - wig) < left0 && left0 < (sv_start + wig) && (sv_end - wig) < right0 && right0 < (sv_end + wig)) ? 2 : 0;
     }
-    int rp = uz_qidx(R, i, position); // :565-573
-    if (rp < 0) rp = uz_qidx(R, i, position - 1);
-    if (rp < 0) rp = uz_qidx(R, i, position + 1);
+    SegHdr hd; // (the headers are at hand: the index look-ups fetch nothing but CIGAR words, and those only of a multi-operation record)
+    hd.start = A.start; hd.end = A.end; hd.n_cigar = B.n_cigar; hd.l_seq = B.l_seq; hd.cigar_off = A.cigar_off; hd.sq_off = A.sq_off; hd.umask = 0; hd.mate = B.mate;
+    int rp = uz_qidx_h(R, hd, position); // :565-573
+    if (rp < 0) rp = uz_qidx_h(R, hd, position - 1);
+    if (rp < 0) rp = uz_qidx_h(R, hd, position + 1);
     if (rp < 0) return 0;
-    const int len = uz_refpos_len(R, i);
+    int len = 0; // uz_refpos_len
+    for (int k = 0; k < nc; k++) {
+        const uint32_t w = cw(k);
+        const int op = w & 15;
+        if (op == UZ_OP_M || op == UZ_OP_EQ || op == UZ_OP_X || op == UZ_OP_I || op == UZ_OP_S) len += (int)(w >> 4);
+    }
     if (rp < 2 || rp > len - 4) return 0;
     return (lead >= rp - 1 || trail >= len - (rp + 1)) ? 2 : 0; // :576-586
 }
@@ -928,15 +963,29 @@ UZ_DEV int uz_phase_dnm(PhaseArgsK ap, uint8_t *scr_base, SH *sh, uint8_t *lds_a
         if (LDS && ar.fail) return 1;
         const long long sv_start = a.dstart[d], sv_end = a.dend[d];
         const long long icut = (long long)cutoff;
-        WG_FOR(t, nA) {
-            const bool w1 = t >= n0;
-            const int i = (int)(w1 ? fa2 + (t - n0) : fa + t);
-            const long long bp = w1 ? sv_end : sv_start;
-            long long lo = bp - icut;
-            if (lo < 0) lo = 0;
-            const int code = uz_sv_classify(R, a, cutoff, i, bp, lo, sv_start, sv_end);
-            s.a_cls[t] = (uint8_t)code;
-            s.a_flag0[t] = code == 3;
+        for (int tb = wg_lane_opaque(); tb < nA; tb += 2 * WG_NT) { // two records per lane and round: their loads in flight together
+            int tt[2], ii[2];
+            SvIn xin[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                tt[u] = tb + u * WG_NT;
+                const int t = tt[u] < nA ? tt[u] : tb;
+                ii[u] = (int)(t >= n0 ? fa2 + (t - n0) : fa + t);
+                uz_sv_fetch1(R, ii[u], xin[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) uz_sv_fetch2(R, ii[u], xin[u]);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int t = tt[u];
+                if (t >= nA) continue;
+                const long long bp = t >= n0 ? sv_end : sv_start;
+                long long lo = bp - icut;
+                if (lo < 0) lo = 0;
+                const int code = uz_sv_decide(R, a, cutoff, xin[u], bp, lo, sv_start, sv_end);
+                s.a_cls[t] = (uint8_t)code;
+                s.a_flag0[t] = code == 3;
+            }
         }
         const int nban = wg_exscan(s.a_flag0, nA, sh);
         WG_FOR(t, nA) { // the banned names, in fetch order: (item, name)
