@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --no-staged --no-cpu --steps 3 --warmup 1 --feed-dnms 0 --no-config5"
 # counters only for the product's kernels (the synthetic generator's launches would be serialised and counted too)
-ONLY='--kernel-include-regex k_phase|k_site_scan|k_window|k_pack_rec|k_expand_seq2|k_cnv'
+ONLY='--kernel-include-regex k_phase|k_site_scan|k_window|k_pack_rec|k_pack_link|k_expand_seq2|k_cnv'
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_LDS -d $OUT/sq -o run -- python3 $ARGS > $OUT/sq.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU -d $OUT/insts -o run -- python3 $ARGS > $OUT/insts.log 2>&1
@@ -20,6 +20,24 @@ rocprofv3 $ONLY --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/writ
 cd $ROOT
 python3 scripts/pmc_summary.py $OUT/pmc_summary.json $OUT/sq $OUT/insts $OUT/misc $OUT/tcp $OUT/tcc $OUT/fetch $OUT/write > $OUT/pmc_summary.txt 2>&1
 find $OUT/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+# (k_phase<true> is launched twice per batch: the statistics file averages both; the full-size launches alone, from the trace)
+python3 - "$OUT" <<'P'
+import csv, glob, json, sys
+out = sys.argv[1]
+f = glob.glob(out + "/stats/**/*kernel_trace.csv", recursive=True)
+rows = [r for r in csv.DictReader(open(f[0]))] if f else []
+res = {}
+for name, pat in (("k_phase", "k_phase<true>("), ("k_pack_link", "k_pack_link("), ("k_phase_bounds", "k_phase_bounds("), ("k_site_scan", "k_site_scan<")):
+    rr = [r for r in rows if pat in r["Kernel_Name"]]
+    if not rr:
+        continue
+    gcol = "Grid_Size_X" if "Grid_Size_X" in rr[0] else "Grid_Size"
+    gmax = max(int(r[gcol]) for r in rr)
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rr if int(r[gcol]) == gmax]
+    res[name] = {"full_size_launches": len(d), "all_launches": len(rr), "grid": gmax, "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
+json.dump(res, open(out + "/full_size_launches.json", "w"), indent=1)
+print(json.dumps(res))
+P
 grep "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_rocprof.json
 # keep the merged output small: the raw traces are not needed
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
