@@ -393,7 +393,7 @@ def main():
                                "note": "collected on other kernel sources (%s): not quoted for this build (%s)" % (tj.get("kernel_source_sha"), ksha)}
             elif int(tj.get("dnms", -1)) == n:
                 measured = ph_ms / ph_n
-                issue_model = {"kernel": "k_phase", "bound": "instruction issue (VALU), memory latency hidden by 7 waves per SIMD",
+                issue_model = {"kernel": "k_phase", "bound": "instruction issue (one wavefront per DNM, as many DNMs per SIMD as the LDS arenas leave room for: waves_per_simd); measured_ms covers the three launches of a batch (arena build, its larger-arena rerun, HBM build)",
                                "valu_wave_instructions_per_dnm": round(tj["valu_wave_instructions_per_dnm_with_candidates"], 0),
                                "valu_pipe_busy_frac_profiled": round(tj["valu_pipe_busy_frac"], 4),
                                "valu_lane_utilisation": round(tj["valu_lane_utilisation"], 4),
