@@ -2,6 +2,7 @@
 // the decoded columns into HBM, and the launch sequence of the stages.
 #include "uz_ctx.hpp"
 
+#include <chrono>
 #include <algorithm>
 #include <map>
 #include <mutex>
@@ -1858,6 +1859,10 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
                        n_cigar_total >= 0 && n_cigar_total < ((int64_t)1 << 32) && n_row_units >= 0 && n_row_units < ((int64_t)1 << 32) && n_seq_units >= 0 && n_seq_units <= n_row_units,
                    UZ_E_ARG, "bad arguments");
         uz_ctx::WalkSlot &w = c->walk[walk_id];
+        static const bool rfb_log = getenv("UZ_RFB_LOG") != nullptr; // development aid: where the call's time goes
+        const auto t0 = std::chrono::steady_clock::now();
+        auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+        double t_blk = 0, t_enq = 0, t_sync = 0;
         // one block for the kept list, the aux bytes and the columns the records are unpacked into; the table adopts the columns in place
         // (uz_reads_adopt_device: cigar, seq4 and the quality plane ARE the device's stores) and keeps the block as its `mirror`
         DevBlock blk;
@@ -1880,6 +1885,7 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
             if (!pass) blk = uz_block_get(c, cv.off + 256);
         }
         int id = -1;
+        t_blk = since();
         try {
             hipStream_t st = c->stream;
             if (n) UZ_HIP(hipMemcpyAsync(d_kept, kept, (size_t)n * sizeof(uz_kept_rec), hipMemcpyHostToDevice, st));
@@ -1892,7 +1898,9 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
             if (names_out && names_bytes) UZ_HIP(hipMemcpyAsync(names_out, d_names, (size_t)names_bytes, hipMemcpyDeviceToHost, st));
             int32_t e = 0;
             UZ_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
+            t_enq = since();
             UZ_HIP(hipStreamSynchronize(st));
+            t_sync = since();
             UZ_REQUIRE(e != 2, UZ_E_RANGE, "uz_reads_from_bam: an offset of the kept list points beyond the stores its totals declare");
             UZ_REQUIRE(e == 0, UZ_E_RANGE, "uz_reads_from_bam: a kept record lies outside the walked bytes, or overruns its block_size");
             uz_reads_packed_view v;
@@ -1906,6 +1914,7 @@ int uz_reads_from_bam(uz_ctx *c, int walk_id, const uz_kept_rec *kept, int64_t n
             c->reads[(size_t)id].mirror = blk;
         } catch (...) { uz_block_put(c, blk); throw; }
         { std::lock_guard<std::mutex> lk(c->err_mu); w.busy = false; }
+        if (rfb_log) fprintf(stderr, "[uz] reads_from_bam n=%lld kept %.1f MB names %.1f MB: block %.2f, enqueue %.2f, sync %.2f, adopt %.2f ms\n", (long long)n, n * 32 / 1e6, names_bytes / 1e6, t_blk, t_enq - t_blk, t_sync - t_enq, since() - t_sync);
         *reads_id = id;
     });
 }

@@ -54,6 +54,10 @@ struct BitIn {
 // a BGZF block is at most 64 KiB long, framing included: a decoder that has taken more dwords than that is not reading a block any more
 // (an endless run of empty stored blocks, say) and is stopped before it walks out of the buffer
 #define UZI_MAX_WORDS (65536 / 4 + 8)
+// every lane holds the same decoder state; a value read from LDS or memory is uniform too, but the compiler cannot know: uni() says so (the value
+// moves to a scalar register, what depends on it is scalar arithmetic and scalar branches instead of lane masks)
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_word(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(lane)); }
 __device__ __forceinline__ void bi_open(BitIn &b, const uint8_t *base, long long byte_off, long long buffer_words, int lane) {
     b.w = reinterpret_cast<const uint32_t *>(base) + (byte_off >> 2);
@@ -94,8 +98,11 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v)
 // and a block without matches has none.  An unused code then decodes to "no symbol")
 // The per-length counters live in LDS (work[48]): indexed by a code length, they would otherwise sit in scratch memory or pin 48 registers
 // (the kernel then needs 80 registers and runs 6 waves per SIMD at 86 GB/s instead of 8 at 97).
+// lit_form: the table of the literal / length code as the symbol loop reads it -- a literal is (byte << 4) | code length; a length symbol
+// 0x8000 | extra bits << 12 | (base length - 3) << 4 | code length (RFC 1951's length table folded into the entry: 3 ... 258 minus 3 fits eight
+// bits); end of block and the two symbols that stand for nothing: "7 extra bits" with value 0 / 1; a code longer than the table's index: 0x8000
 __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int *work, int lane,
-                            int complete) {
+                            int complete, bool lit_form = false) {
     int *count = work, *offs = work + 16, *next = work + 32;
     __syncthreads();
     if (lane < 16) count[lane] = 0;
@@ -109,11 +116,12 @@ __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, u
     __syncthreads();
     int left = 1, total = 0;
     for (int l = 1; l < 16; l++) {
-        left = (left << 1) - count[l];
-        total += count[l];
+        const int c = uni(count[l]);
+        left = (left << 1) - c;
+        total += c;
         if (left < 0) return false;
     }
-    if (left > 0 && (complete == 2 || (complete == 1 && !(total == 1 && count[1] == 1)))) return false;
+    if (left > 0 && (complete == 2 || (complete == 1 && !(total == 1 && uni(count[1]) == 1)))) return false;
     if (lane < 16) cnt[lane] = (uint16_t)count[lane];
     if (lane == 0) {
         for (int s = 0; s < n; s++) {
@@ -125,12 +133,23 @@ __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, u
             }
         }
     }
-    for (int k = lane; k < (1 << tb); k += 64) tab[k] = 0;
+    for (int k = lane; k < (1 << tb); k += 64) tab[k] = lit_form ? (uint16_t)0x8000 : (uint16_t)0; // (lit form: "not a literal" is bit 15; length 0: a longer code)
     __syncthreads();
     for (int s = lane; s < n; s += 64) { // every lane fills the replicas of its symbols' codes
         const int l = lens[s];
         if (l && l <= tb) {
-            const uint16_t e = (uint16_t)((s << 4) | l);
+            uint16_t e = (uint16_t)((s << 4) | l);
+            if (lit_form && s >= 256) {
+                const int ls = s - 257;
+                int base3 = 0, extra = 7; // end of block (value 0) / a symbol that stands for nothing (286, 287: value 1)
+                if (s > 285) base3 = 1;
+                else if (s > 256) {
+                    if (ls < 8) { base3 = ls; extra = 0; }
+                    else if (ls == 28) { base3 = 255; extra = 0; }
+                    else { extra = (ls >> 2) - 1; base3 = (4 + (ls & 3)) << extra; }
+                }
+                e = (uint16_t)(0x8000 | (extra << 12) | (base3 << 4) | l);
+            }
             for (int k = code_of[s]; k < (1 << tb); k += 1 << l) tab[k] = e;
         }
     }
@@ -138,16 +157,20 @@ __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, u
     return true;
 }
 // one symbol: the direct table, or the canonical walk for a code longer than the table's index (rare)
+__device__ __forceinline__ int decode_long(BitIn &b, const uint16_t *sorted, const uint16_t *cnt);
 __device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb, const uint16_t *sorted, const uint16_t *cnt) {
-    const uint32_t e = tab[bi_peek(b, tb)];
+    const uint32_t e = uni((uint32_t)tab[bi_peek(b, tb)]);
     if (e) { bi_drop(b, (int)(e & 15u)); return (int)(e >> 4); }
+    return decode_long(b, sorted, cnt);
+}
+__device__ __forceinline__ int decode_long(BitIn &b, const uint16_t *sorted, const uint16_t *cnt) {
     int code = 0, first = 0, index = 0;
     unsigned long long v = b.buf;
     for (int l = 1; l <= 15; l++) {
         code |= (int)(v & 1ULL);
         v >>= 1;
-        const int c = cnt[l];
-        if (code - c < first) { bi_drop(b, l); return sorted[index + (code - first)]; }
+        const int c = uni((int)cnt[l]);
+        if (code - c < first) { bi_drop(b, l); return uni((int)sorted[index + (code - first)]); }
         index += c; first += c;
         first <<= 1; code <<= 1;
     }
@@ -169,14 +192,15 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
         __syncthreads();
         if (lane == 0) next_block = atomicAdd(cursor, 1);
         __syncthreads();
-        const int64_t blk = next_block;
+        const int64_t blk = uni(next_block);
         if (blk >= n_blocks) return;
         uint8_t *o = out + out_off[blk];
-        const int64_t osize = out_off[blk + 1] - out_off[blk];
+        const int64_t osize64 = out_off[blk + 1] - out_off[blk];
+        const uint32_t osize = (uint32_t)(osize64 < 0 ? 0 : (osize64 > (1 << 30) ? (1 << 30) : osize64)); // (a BGZF block holds at most 64 KiB: positions are 32-bit)
         BitIn b;
         bi_open(b, comp, in_off[blk], comp_words, lane);
-        int64_t pos = 0, safe = 0; // bytes written; bytes whose stores are known to have landed
-        int64_t wbase = 0;         // first position of the literal window (pos - wbase bytes wait in it)
+        uint32_t pos = 0, safe = 0; // bytes written; bytes whose stores are known to have landed
+        uint32_t wbase = 0;         // first position of the literal window
         uint32_t wbyte = 0;
         int bad = 0;
         for (int last = 0; !last && !bad;) {
@@ -190,7 +214,7 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 const uint32_t len = bi_take(b, 16);
                 bi_refill(b, lane);
                 const uint32_t nlen = bi_take(b, 16);
-                if ((len ^ nlen) != 0xFFFFu || pos + (int64_t)len > osize) { bad = 1; break; }
+                if ((len ^ nlen) != 0xFFFFu || pos + len > osize) { bad = 1; break; }
                 // the bytes: drain what the bit buffer holds (whole bytes), then dword by dword through the same window
                 uint32_t done = 0;
                 while (done < len) {
@@ -247,60 +271,300 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 }
                 if (bad) break;
                 __syncthreads();
-                if (L.lens[256] == 0) { bad = 2; break; } // no end-of-block code
+                if (uni((int)L.lens[256]) == 0) { bad = 2; break; } // no end-of-block code
             }
-            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, 1)) { bad = 2; break; }
+            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, 1, true)) { bad = 2; break; }
             if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 0)) { bad = 2; break; }
             // ---- the symbols of the block.  Literals gather in a register window -- lane l holds the byte for position wbase + l -- and
             // leave it as one coalesced store when it is full or a match needs them in memory.
+            //
+            // The loop is written out by hand (one asm statement).  Why: every lane holds the same decoder state, so the state lives in scalar
+            // registers and the kernel is bound by SCALAR ISSUE -- a SIMD issues one scalar instruction per four cycles whatever its eight waves
+            // do, and the compiler's loop (exits unified, conditions kept as lane masks, 64-bit positions, four refill tests per match) spent ~20
+            // scalar instructions per literal and ~140 per match: 400 k per 64 KiB block = the 12.7 M cycles a wave lived (rocprofv3, round 5; the
+            // generator's BAM is 2.1 k literals + 2.4 k matches per block).  Here: 7 scalar + 6 vector instructions per literal, ~45 + 12 per match
+            // whose codes both sit in the direct tables, whose source does not overlap its destination and which is at most 64 bytes long (nine in
+            // ten); everything else -- longer codes, long or overlapping matches, the input window moving on, errors -- leaves the statement with a
+            // reason (`why`) and whatever it has decoded so far, and is finished by the C++ below.
+            //   why: 1 window full; 2 the next input word lies beyond the 64 the wave holds; 3 end of block (consumed); 4 the symbol at hand is not
+            //   for the fast path (nothing consumed); 5 a match leaves the block (bad 4); 6 length decoded, distance still to come; 7 length and
+            //   distance decoded, window stored, bounds checked: a copy the fast path does not do; 8 a distance symbol beyond 29 (bad 3)
+            // Wait states (gfx940 family): a scalar register a lane select reads (k, wcnt - 1) is written by a scalar instruction; two instructions stand
+            // between v_readlane writing a scalar register and the vector instruction that reads it.  (v_writelane cannot take the byte AND the lane from
+            // scalar registers -- one constant-bus read per instruction -- so a literal enters the window through v_cmp_eq + v_cndmask.)
+            uint32_t wcnt = 0; // literals waiting in the window: pos == wbase + wcnt
+            const uint32_t lit_tab_lds = (uint32_t)(uintptr_t)L.lit_tab, dist_tab_lds = (uint32_t)(uintptr_t)L.dist_tab; // (addresses in LDS)
             for (;;) {
-                if (b.widx > UZI_MAX_WORDS) { bad = 6; break; }
-                bi_refill(b, lane);
-                const int s = decode_sym(b, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt);
-                if (s < 256) {
-                    if (s < 0) { bad = 3; break; }
-                    if (pos >= osize) { bad = 4; break; }
-                    wbyte = (lane == (int)(pos - wbase)) ? (uint32_t)s : wbyte;
-                    pos++;
-                    if (pos - wbase == 64) { o[wbase + lane] = (uint8_t)wbyte; wbase = pos; }
+                if (b.bits <= 32) {
+                    if (b.widx > UZI_MAX_WORDS) { bad = 6; break; }
+                    bi_refill(b, lane);
+                }
+                uint32_t e, why = 0, len_a, dist_a, t_n, t_x, t_t, va, ve;
+                {
+                    unsigned long long buf = b.buf;
+                    int bits = b.bits, widx = b.widx;
+                    asm volatile(
+                        ".Luz_top%=:\n"
+                        "  v_bfe_u32 %[va], s44, 0, 10\n"
+                        "  v_lshl_add_u32 %[va], %[va], 1, %[vlit]\n"
+                        "  ds_read_u16 %[ve], %[va]\n"
+                        "  s_waitcnt lgkmcnt(0)\n"
+                        "  v_readfirstlane_b32 %[e], %[ve]\n"
+                        "  s_bitcmp1_b32 %[e], 15\n"
+                        "  s_cbranch_scc1 .Luz_nonlit%=\n"
+                        // a literal
+                        "  s_and_b32 %[n], %[e], 15\n"
+                        "  v_lshrrev_b32 %[ve], 4, %[ve]\n"
+                        "  v_cmp_eq_u32 vcc, %[wc], %[vlane]\n"
+                        "  s_lshr_b64 s[44:45], s[44:45], %[n]\n"
+                        "  v_cndmask_b32 %[wb], %[wb], %[ve], vcc\n"
+                        "  s_add_u32 %[wc], %[wc], 1\n"
+                        "  s_sub_u32 %[bits], %[bits], %[n]\n"
+                        "  s_cmpk_eq_u32 %[wc], 64\n"
+                        "  s_cbranch_scc1 .Luz_full%=\n"
+                        // the end of a symbol: at least 33 bits for the next one
+                        ".Luz_next%=:\n"
+                        "  s_cmpk_gt_i32 %[bits], 32\n"
+                        "  s_cbranch_scc1 .Luz_top%=\n"
+                        "  s_sub_u32 %[n], %[widx], %[cbase]\n"
+                        "  s_cmpk_ge_u32 %[n], 64\n"
+                        "  s_cbranch_scc1 .Luz_need%=\n"
+                        "  v_readlane_b32 s46, %[cur], %[n]\n"
+                        "  s_mov_b32 s47, 0\n"
+                        "  s_lshl_b64 s[46:47], s[46:47], %[bits]\n"
+                        "  s_or_b64 s[44:45], s[44:45], s[46:47]\n"
+                        "  s_add_u32 %[bits], %[bits], 32\n"
+                        "  s_add_u32 %[widx], %[widx], 1\n"
+                        "  s_branch .Luz_top%=\n"
+                        // not a literal: a length, the end of the block, or a code the table does not hold
+                        ".Luz_nonlit%=:\n"
+                        "  s_and_b32 %[n], %[e], 15\n"
+                        "  s_cmp_eq_u32 %[n], 0\n"
+                        "  s_cbranch_scc1 .Luz_generic%=\n"
+                        "  s_bfe_u32 %[x], %[e], 0x3000c\n"
+                        "  s_bfe_u32 %[len], %[e], 0x80004\n"
+                        "  s_cmpk_eq_u32 %[x], 7\n"
+                        "  s_cbranch_scc1 .Luz_special%=\n"
+                        "  s_lshr_b64 s[44:45], s[44:45], %[n]\n"
+                        "  s_sub_u32 %[bits], %[bits], %[n]\n"
+                        "  s_bfm_b32 %[t], %[x], 0\n"
+                        "  s_and_b32 %[t], s44, %[t]\n"
+                        "  s_add_u32 %[len], %[len], %[t]\n"
+                        "  s_add_u32 %[len], %[len], 3\n"
+                        "  s_lshr_b64 s[44:45], s[44:45], %[x]\n"
+                        "  s_sub_u32 %[bits], %[bits], %[x]\n"
+                        // the distance: up to 15 + 13 bits
+                        "  s_cmpk_gt_i32 %[bits], 32\n"
+                        "  s_cbranch_scc1 .Luz_dist%=\n"
+                        "  s_sub_u32 %[n], %[widx], %[cbase]\n"
+                        "  s_cmpk_ge_u32 %[n], 64\n"
+                        "  s_cbranch_scc1 .Luz_havelen%=\n"
+                        "  v_readlane_b32 s46, %[cur], %[n]\n"
+                        "  s_mov_b32 s47, 0\n"
+                        "  s_lshl_b64 s[46:47], s[46:47], %[bits]\n"
+                        "  s_or_b64 s[44:45], s[44:45], s[46:47]\n"
+                        "  s_add_u32 %[bits], %[bits], 32\n"
+                        "  s_add_u32 %[widx], %[widx], 1\n"
+                        ".Luz_dist%=:\n"
+                        "  v_bfe_u32 %[va], s44, 0, 8\n"
+                        "  v_lshl_add_u32 %[va], %[va], 1, %[vdist]\n"
+                        "  ds_read_u16 %[ve], %[va]\n"
+                        "  s_waitcnt lgkmcnt(0)\n"
+                        "  v_readfirstlane_b32 %[e], %[ve]\n"
+                        "  s_and_b32 %[n], %[e], 15\n"
+                        "  s_cmp_eq_u32 %[n], 0\n"
+                        "  s_cbranch_scc1 .Luz_havelen%=\n"
+                        "  s_lshr_b64 s[44:45], s[44:45], %[n]\n"
+                        "  s_sub_u32 %[bits], %[bits], %[n]\n"
+                        "  s_lshr_b32 %[dist], %[e], 4\n"
+                        "  s_cmpk_gt_u32 %[dist], 29\n"
+                        "  s_cbranch_scc1 .Luz_bad3%=\n"
+                        "  s_cmpk_lt_u32 %[dist], 4\n"
+                        "  s_cbranch_scc1 .Luz_small%=\n"
+                        "  s_lshr_b32 %[x], %[dist], 1\n"
+                        "  s_sub_u32 %[x], %[x], 1\n"
+                        "  s_and_b32 %[t], %[dist], 1\n"
+                        "  s_add_u32 %[t], %[t], 2\n"
+                        "  s_lshl_b32 %[t], %[t], %[x]\n"
+                        "  s_bfm_b32 %[n], %[x], 0\n"
+                        "  s_and_b32 %[n], s44, %[n]\n"
+                        "  s_add_u32 %[dist], %[t], %[n]\n"
+                        "  s_lshr_b64 s[44:45], s[44:45], %[x]\n"
+                        "  s_sub_u32 %[bits], %[bits], %[x]\n"
+                        ".Luz_small%=:\n"
+                        "  s_add_u32 %[dist], %[dist], 1\n"
+                        // the window's literals into memory in front of the match (no lane masked off: the lanes behind the fill store its last byte again)
+                        "  s_cmp_eq_u32 %[wc], 0\n"
+                        "  s_cbranch_scc1 .Luz_noflush%=\n"
+                        "  s_add_u32 %[t], %[wbase], %[wc]\n"
+                        "  s_cmp_gt_u32 %[t], %[osize]\n"
+                        "  s_cbranch_scc1 .Luz_bad4%=\n"
+                        "  s_sub_u32 %[n], %[wc], 1\n"
+                        "  v_readlane_b32 %[x], %[wb], %[n]\n"
+                        "  v_min_u32 %[va], %[n], %[vlane]\n"
+                        "  v_cmp_gt_u32 vcc, %[wc], %[vlane]\n"
+                        "  v_mov_b32 %[ve], %[x]\n"
+                        "  v_cndmask_b32 %[ve], %[ve], %[wb], vcc\n"
+                        "  v_add_u32 %[va], %[wbase], %[va]\n"
+                        "  global_store_byte %[va], %[ve], s[48:49]\n"
+                        "  s_mov_b32 %[wbase], %[t]\n"
+                        "  s_mov_b32 %[wc], 0\n"
+                        ".Luz_noflush%=:\n"
+                        "  s_cmp_gt_u32 %[dist], %[wbase]\n"
+                        "  s_cbranch_scc1 .Luz_bad4%=\n"
+                        "  s_add_u32 %[t], %[wbase], %[len]\n"
+                        "  s_cmp_gt_u32 %[t], %[osize]\n"
+                        "  s_cbranch_scc1 .Luz_bad4%=\n"
+                        "  s_cmp_lt_u32 %[dist], %[len]\n"
+                        "  s_cbranch_scc1 .Luz_copy%=\n"
+                        "  s_cmpk_gt_u32 %[len], 64\n"
+                        "  s_cbranch_scc1 .Luz_copy%=\n"
+                        // the copy: lane k takes byte k (the lanes past the end repeat the last byte); the load goes past the L1 and waits for the wave's
+                        // stores only when the source reaches into bytes stored since the last such wait
+                        "  s_sub_u32 %[n], %[wbase], %[dist]\n"
+                        "  s_add_u32 %[x], %[n], %[len]\n"
+                        "  s_cmp_le_u32 %[x], %[safe]\n"
+                        "  s_cbranch_scc1 .Luz_safe%=\n"
+                        "  s_waitcnt vmcnt(0)\n"
+                        "  s_mov_b32 %[safe], %[wbase]\n"
+                        ".Luz_safe%=:\n"
+                        "  s_sub_u32 %[x], %[len], 1\n"
+                        "  v_min_u32 %[va], %[x], %[vlane]\n"
+                        "  v_add_u32 %[ve], %[n], %[va]\n"
+                        "  global_load_ubyte %[ve], %[ve], s[48:49] sc1\n"
+                        "  v_add_u32 %[va], %[wbase], %[va]\n"
+                        "  s_waitcnt vmcnt(0)\n"
+                        "  global_store_byte %[va], %[ve], s[48:49]\n"
+                        "  s_mov_b32 %[wbase], %[t]\n"
+                        "  s_branch .Luz_next%=\n"
+                        // the ways out
+                        ".Luz_special%=:\n" // (value 0: the end of the block; 1: a symbol that stands for nothing -- the C++ reports it)
+                        "  s_cmp_lg_u32 %[len], 0\n"
+                        "  s_cbranch_scc1 .Luz_generic%=\n"
+                        "  s_lshr_b64 s[44:45], s[44:45], %[n]\n"
+                        "  s_sub_u32 %[bits], %[bits], %[n]\n"
+                        "  s_mov_b32 %[why], 3\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_full%=:\n"
+                        "  s_mov_b32 %[why], 1\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_need%=:\n"
+                        "  s_mov_b32 %[why], 2\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_generic%=:\n"
+                        "  s_mov_b32 %[why], 4\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_bad4%=:\n"
+                        "  s_mov_b32 %[why], 5\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_havelen%=:\n"
+                        "  s_mov_b32 %[why], 6\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_copy%=:\n"
+                        "  s_mov_b32 %[why], 7\n"
+                        "  s_branch .Luz_out%=\n"
+                        ".Luz_bad3%=:\n"
+                        "  s_mov_b32 %[why], 8\n"
+                        ".Luz_out%=:\n"
+                        : "+{s[44:45]}"(buf), [bits] "+s"(bits), [widx] "+s"(widx), [wc] "+s"(wcnt), [wbase] "+s"(wbase), [safe] "+s"(safe), [wb] "+v"(wbyte),
+                          [why] "+s"(why), [e] "=&s"(e), [len] "=&s"(len_a), [dist] "=&s"(dist_a), [n] "=&s"(t_n), [x] "=&s"(t_x), [t] "=&s"(t_t),
+                          [va] "=&v"(va), [ve] "=&v"(ve)
+                        : [vlit] "v"(lit_tab_lds), [vdist] "v"(dist_tab_lds), [cbase] "s"(b.cbase), [cur] "v"(b.cur), [vlane] "v"(lane), [osize] "s"(osize),
+                          "{s[48:49]}"(o)
+                        : "s46", "s47", "scc", "vcc", "memory");
+                    b.buf = buf; b.bits = bits; b.widx = widx;
+                }
+                if (why == 1) { // the window is full: one coalesced store
+                    if (wbase + 64u > osize) { bad = 4; break; }
+                    o[wbase + lane] = (uint8_t)wbyte;
+                    wbase += 64; wcnt = 0;
                     continue;
                 }
-                if (pos > wbase) { // the window's bytes into memory, in front of whatever comes next
-                    if (lane < (int)(pos - wbase)) o[wbase + lane] = (uint8_t)wbyte;
+                if (why == 2) continue; // (the refill at the loop's head moves the input window on)
+                if (why == 5) { bad = 4; break; }
+                if (why == 8) { bad = 3; break; }
+                int len = (int)len_a, dist = (int)dist_a;
+                if (why == 4) { // the symbol at hand the general way (the canonical walk decodes a code of any length)
+                    const int s = decode_long(b, L.lit_sorted, L.lit_cnt);
+                    if (s < 0) { bad = 3; break; }
+                    if (s < 256) {
+                        wbyte = (uint32_t)lane == wcnt ? (uint32_t)s : wbyte;
+                        wcnt++;
+                        if (wcnt == 64) {
+                            if (wbase + 64u > osize) { bad = 4; break; }
+                            o[wbase + lane] = (uint8_t)wbyte;
+                            wbase += 64; wcnt = 0;
+                        }
+                        continue;
+                    }
+                    if (s == 256) why = 3;
+                    else {
+                        if (s > 285) { bad = 3; break; }
+                        bi_refill(b, lane);
+                        // (length and distance from their symbols: RFC 1951's tables are arithmetic -- four codes per extra bit / two per extra bit)
+                        const int ls = s - 257;
+                        if (ls < 8) len = 3 + ls;
+                        else if (ls == 28) len = 258;
+                        else { const int x = (ls >> 2) - 1; len = ((4 + (ls & 3)) << x) + 3 + (int)bi_take(b, x); }
+                    }
                 }
-                if (s == 256) { wbase = pos; break; }
-                if (s > 285) { bad = 3; break; }
-                bi_refill(b, lane);
-                // (length and distance from their symbols: RFC 1951's tables are arithmetic -- four codes per extra bit / two per extra bit)
-                const int ls = s - 257;
-                int len;
-                if (ls < 8) len = 3 + ls;
-                else if (ls == 28) len = 258;
-                else { const int e = (ls >> 2) - 1; len = ((4 + (ls & 3)) << e) + 3 + (int)bi_take(b, e); }
-                bi_refill(b, lane);
-                const int ds = decode_sym(b, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt);
-                if (ds < 0 || ds > 29) { bad = 3; break; }
-                bi_refill(b, lane);
-                int dist;
-                if (ds < 4) dist = 1 + ds;
-                else { const int e = (ds >> 1) - 1; dist = ((2 + (ds & 1)) << e) + 1 + (int)bi_take(b, e); }
-                if ((int64_t)dist > pos || pos + len > osize) { bad = 4; break; }
-                const int64_t src = pos - dist;
-                if (src + (len < dist ? len : dist) > safe) { // the source reaches into bytes whose stores may still be in flight
+                if (wcnt) { // the window's bytes into memory, in front of whatever comes next.  No lane is masked off (a divergent branch here would have
+                    // the compiler restructure the whole symbol loop around lane masks): the lanes behind the window's fill store its last byte again
+                    if (wbase + wcnt > osize) { bad = 4; break; }
+                    const uint32_t last_b = lane_word(wbyte, (int)wcnt - 1);
+                    const uint32_t wl = (uint32_t)lane < wcnt ? (uint32_t)lane : wcnt - 1u;
+                    o[wbase + wl] = (uint8_t)((uint32_t)lane < wcnt ? wbyte : last_b);
+                    wbase += wcnt; wcnt = 0;
+                }
+                if (why == 3) break; // the end of the block
+                const uint32_t pos = wbase;
+                if (why != 7) { // the distance
+                    bi_refill(b, lane);
+                    const int ds = decode_sym(b, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt);
+                    if (ds < 0 || ds > 29) { bad = 3; break; }
+                    bi_refill(b, lane);
+                    if (ds < 4) dist = 1 + ds;
+                    else { const int x = (ds >> 1) - 1; dist = ((2 + (ds & 1)) << x) + 1 + (int)bi_take(b, x); }
+                }
+                if ((uint32_t)dist > pos || pos + (uint32_t)len > osize) { bad = 4; break; }
+                const uint32_t src = pos - (uint32_t)dist;
+                if (src + (uint32_t)(len < dist ? len : dist) > safe) { // the source reaches into bytes whose stores may still be in flight
                     asm volatile("" ::: "memory");
                     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
                     asm volatile("" ::: "memory");
                     safe = pos;
                 }
-                for (int k = lane; k < len; k += 64) {
-                    const int sk = dist >= len ? k : k % dist;
-                    o[pos + k] = __hip_atomic_load(o + src + sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (past the L1: see the head of the file)
+                // lane k takes byte k of the match; where source and destination overlap (a run: quality strings are full of them) the source index
+                // wraps at the distance -- k mod dist through a float reciprocal, exact for k < 512 after one correction (an integer division by a
+                // variable is ~40 instructions).  Uniform loops over 64-byte pieces; the lanes past the match's end repeat its last byte: no lane masks
+                const int lastk = len - 1;
+                if (dist >= len) {
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                    for (int k0 = 0; k0 < len; k0 += 64) {
+                        const int k = min(k0 + lane, lastk);
+                        o[pos + k] = __hip_atomic_load(o + src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (past the L1: see the head of the file)
+                    }
+                } else if (dist == 1) {
+                    const uint8_t v = __hip_atomic_load(o + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                    for (int k0 = 0; k0 < len; k0 += 64) o[pos + min(k0 + lane, lastk)] = v;
+                } else {
+                    const float rd = 1.0f / (float)dist;
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
+                    for (int k0 = 0; k0 < len; k0 += 64) {
+                        const int k = min(k0 + lane, lastk);
+                        const int q = (int)((float)k * rd);
+                        int r = k - q * dist;
+                        r = r < 0 ? r + dist : (r >= dist ? r - dist : r);
+                        o[pos + k] = __hip_atomic_load(o + src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
-                pos += len;
-                wbase = pos;
+                wbase = pos + (uint32_t)len;
             }
+            if (bad) break;
+            pos = wbase;
         }
-        if (!bad && pos != osize) bad = 5;
+        if (!bad && (int64_t)pos != osize64) bad = 5;
         if (bad && lane == 0) atomicCAS(err, 0, bad | ((int)blk << 4));
     }
 }

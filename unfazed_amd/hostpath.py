@@ -94,6 +94,36 @@ class _Log:
             print(msg, file=sys.stderr)
 
 
+class _Sec:
+    """development aid (UZ_HOST_TRACE=1): wall and per-thread CPU seconds of a named section of the host path, summed over calls"""
+    acc: Dict[str, list] = {}
+    on = bool(__import__("os").environ.get("UZ_HOST_TRACE"))
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _Sec.on:
+            import time
+            self.t = (time.perf_counter(), time.thread_time())
+        return self
+
+    def __exit__(self, *exc):
+        if _Sec.on:
+            import time
+            a = _Sec.acc.setdefault(self.name, [0.0, 0.0, 0])
+            a[0] += time.perf_counter() - self.t[0]
+            a[1] += time.thread_time() - self.t[1]
+            a[2] += 1
+        return False
+
+    @staticmethod
+    def report():
+        if _Sec.on and _Sec.acc:
+            print("[uz] host sections (wall s, thread CPU s, calls): " + ", ".join("%s %.3f %.3f %d" % (k, v[0], v[1], v[2]) for k, v in _Sec.acc.items()), file=sys.stderr)
+            _Sec.acc.clear()
+
+
 class _VoteLists:
     """The four vote lists of every DNM of a chunk (uz_phase_votes: offsets [4n + 1], values) behind the indexing the host code uses --
     lists[k] -> (dad_reads, mom_reads, dad_sites, mom_sites) as arrays -- without 4n array slices made up front: the values become ONE Python
@@ -525,8 +555,10 @@ class PhasingHost:
         n_slots = lag + 1 + ahead  # a slot is staged into again once the read stage of the chunk it held has been collected
 
         def stage(k):
-            fc, flo, fhi, fex, has_sv = self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
-            return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k % n_slots)
+            with _Sec("fetches_of"):
+                fc, flo, fhi, fex, has_sv = self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
+            with _Sec("stage_reads"):
+                return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k % n_slots)
 
         with ThreadPoolExecutor(ahead) as ex:
             futs = {k: ex.submit(stage, k) for k in range(min(ahead, len(parts)))}
@@ -540,6 +572,7 @@ class PhasingHost:
                 return packed
 
             def done(k, rr):
+              with _Sec("done"):
                 part = parts[k]
                 lists = None
                 if want_lists:
@@ -557,7 +590,10 @@ class PhasingHost:
 
             chunks = [dict(a=cuts[k], b=cuts[k + 1], dnms=self._dnms_view_of(parts[k], dnms, prep, found, cutoff), records=records, sites=None)
                       for k in range(len(parts))]
-            pipeline.run_pipelined(self.backend, params, mode, len(idxs), chunks, fid=fam, lag=lag, on_done=done)
+            trace = [] if os.environ.get("UZ_HOST_TRACE") else None  # development aid: ms per pipeline step (find, collect, queue, records + upload)
+            pipeline.run_pipelined(self.backend, params, mode, len(idxs), chunks, fid=fam, lag=lag, on_done=done, trace=trace)
+            if trace:
+                print("[uz] chunked batch, ms per step:", trace[0], file=sys.stderr)
         return True
 
     def run_read_phasing(
@@ -585,10 +621,11 @@ class PhasingHost:
         params.no_extended = 1 if no_extended else 0
         params.read_goal = int(insert_size_max_sample)
         params.readlen = int(readlen)
-        ret, info = self.find(
-            dnms, pedigrees, search_dist, threads, build, multithread_proc_min, quiet_mode, params,
-            whole_region=False,
-        )
+        with _Sec("find"):
+            ret, info = self.find(
+                dnms, pedigrees, search_dist, threads, build, multithread_proc_min, quiet_mode, params,
+                whole_region=False,
+            )
         records: Dict[str, dict] = {}
         if ret is None:
             return records
@@ -599,7 +636,9 @@ class PhasingHost:
         prep: Dict[int, dict] = {}
         sample_set = set(self.sites.samples)
         contig_memo: Dict[tuple, tuple] = {}
-        refalt = {} if sv else self.batch_refalt(dnms, [i for i in info["order"] if found.get(i) is not None and len(found[i]["cand_idx"])])
+        with _Sec("refalt"):
+            refalt = {} if sv else self.batch_refalt(dnms, [i for i in info["order"] if found.get(i) is not None and len(found[i]["cand_idx"])])
+        sec_pass1 = _Sec("pass1").__enter__()
         for i in info["order"]:
             dn = dnms[i]
             dad_id, mom_id = pedigrees[dn["kid"]]["dad"], pedigrees[dn["kid"]]["mom"]
@@ -639,7 +678,9 @@ class PhasingHost:
         # to the device as ONE cohort batch (uz_phase_cohort), not as one launch sequence per kid
         results: Dict[int, dict] = {}
         groups, order_all, tables, handles = [], [], [], []
-        chunked = self._chunked_batch(batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, info["mode"], results)
+        sec_pass1.__exit__()
+        with _Sec("chunked"):
+          chunked = self._chunked_batch(batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, info["mode"], results)
         for (kid, bam), idxs in ([] if chunked else batch.items()):
             dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
             fam = self.family(kid, dad_id, mom_id)
@@ -683,6 +724,7 @@ class PhasingHost:
         # pass 3: records, in the reference's order.  The names of the reads in the result lists: one look-up per table for the whole batch
         # (a staged table answers ids through the C ABI: hundreds of thousands of single calls were a third of round 3's host time); the chunks
         # of a staged batch have built theirs already (res["built"])
+        sec_pass3 = _Sec("pass3").__enter__()
         by_res: Dict[tuple, tuple] = {}
         for (res, k, rt) in results.values():
             if "built" not in res and res.get("lists") is not None:
@@ -743,6 +785,8 @@ class PhasingHost:
                     "dad_reads": dad_reads, "mom_reads": mom_reads,
                     "cnv_dad_sites": "", "cnv_mom_sites": "", "cnv_evidence_type": "",
                 }
+        sec_pass3.__exit__()
+        _Sec.report()
         return records
 
     @staticmethod
