@@ -29,14 +29,15 @@ namespace {
 #define UZI_DIST_BITS 8
 
 struct InflateLds {
-    uint16_t lit_tab[1 << UZI_LIT_BITS];   // (symbol << 4) | length; 0: a longer code
-    uint16_t dist_tab[1 << UZI_DIST_BITS];
+    uint16_t lit_tab[1 << UZI_LIT_BITS];   // the literal / length code's direct table (build_table: form 1); before that, the code-length code's (form 0)
+    uint32_t dist_tab[1 << UZI_DIST_BITS]; // the distance code's direct table (form 2)
     uint16_t lit_sorted[288], dist_sorted[32]; // symbols in canonical order (by length, then value)
     uint16_t lit_cnt[16], dist_cnt[16];        // codes per length
     uint8_t lens[320];                          // code lengths of the block being set up: literal / length code at 0, distance code at 288
     uint8_t cl_lens[32];                        // ... and of the code they are written in
-    uint16_t code_of[288];                      // bit-reversed canonical code of every symbol (table fill)
+    uint16_t code_of[288];                      // bit-reversed canonical code of every symbol (table fill); form 1: afterwards every symbol's table entry
     int work[48];                               // per-length counters of the table set-up
+    int lit_walk[2];                            // form 1: the canonical walk's `first` and `index` after length UZI_LIT_BITS (where a longer code's walk starts)
 };
 
 __device__ __constant__ uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
@@ -98,11 +99,17 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v)
 // and a block without matches has none.  An unused code then decodes to "no symbol")
 // The per-length counters live in LDS (work[48]): indexed by a code length, they would otherwise sit in scratch memory or pin 48 registers
 // (the kernel then needs 80 registers and runs 6 waves per SIMD at 86 GB/s instead of 8 at 97).
-// lit_form: the table of the literal / length code as the symbol loop reads it -- a literal is (byte << 4) | code length; a length symbol
+// form 0: 16-bit entries (symbol << 4) | code length, 0 for a longer code (the code-length code).
+// form 1: the literal / length code as the symbol loop reads it -- a literal is (byte << 4) | code length; a length symbol
 // 0x8000 | extra bits << 12 | (base length - 3) << 4 | code length (RFC 1951's length table folded into the entry: 3 ... 258 minus 3 fits eight
-// bits); end of block and the two symbols that stand for nothing: "7 extra bits" with value 0 / 1; a code longer than the table's index: 0x8000
-__device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int *work, int lane,
-                            int complete, bool lit_form = false) {
+// bits); end of block and the two symbols that stand for nothing: "7 extra bits" with value 0 / 1; a code longer than the table's index: 0x8000.
+// code_of[] holds every symbol's entry afterwards (what a longer code's walk ends in), walk[] where that walk starts.
+// form 2: the distance code, 32-bit entries base distance << 8 | extra bits << 4 | code length (RFC 1951's distance table folded in); 0 for a
+// longer code and for the two symbols that stand for nothing.
+__device__ bool build_table(const uint8_t *lens, int n, void *tab_, int tb, uint16_t *sorted, uint16_t *cnt, uint16_t *code_of, int *work, int lane,
+                            int complete, int form = 0, int *walk = nullptr) {
+    uint16_t *tab = static_cast<uint16_t *>(tab_);
+    uint32_t *tab32 = static_cast<uint32_t *>(tab_);
     int *count = work, *offs = work + 16, *next = work + 32;
     __syncthreads();
     if (lane < 16) count[lane] = 0;
@@ -112,6 +119,11 @@ __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, u
         count[0] = 0;
         offs[1] = 0; next[1] = 0;
         for (int l = 1; l < 15; l++) { offs[l + 1] = offs[l] + count[l]; next[l + 1] = (next[l] + count[l]) << 1; }
+        if (walk) { // decode_long's `first` and `index` after its iteration l = tb
+            int first = 0, index = 0;
+            for (int l = 1; l <= tb; l++) { index += count[l]; first += count[l]; first <<= 1; }
+            walk[0] = first; walk[1] = index;
+        }
     }
     __syncthreads();
     int left = 1, total = 0;
@@ -133,25 +145,33 @@ __device__ bool build_table(const uint8_t *lens, int n, uint16_t *tab, int tb, u
             }
         }
     }
-    for (int k = lane; k < (1 << tb); k += 64) tab[k] = lit_form ? (uint16_t)0x8000 : (uint16_t)0; // (lit form: "not a literal" is bit 15; length 0: a longer code)
+    if (form == 2) for (int k = lane; k < (1 << tb); k += 64) tab32[k] = 0;
+    else for (int k = lane; k < (1 << tb); k += 64) tab[k] = form == 1 ? (uint16_t)0x8000 : (uint16_t)0;
     __syncthreads();
     for (int s = lane; s < n; s += 64) { // every lane fills the replicas of its symbols' codes
         const int l = lens[s];
-        if (l && l <= tb) {
-            uint16_t e = (uint16_t)((s << 4) | l);
-            if (lit_form && s >= 256) {
-                const int ls = s - 257;
-                int base3 = 0, extra = 7; // end of block (value 0) / a symbol that stands for nothing (286, 287: value 1)
-                if (s > 285) base3 = 1;
-                else if (s > 256) {
-                    if (ls < 8) { base3 = ls; extra = 0; }
-                    else if (ls == 28) { base3 = 255; extra = 0; }
-                    else { extra = (ls >> 2) - 1; base3 = (4 + (ls & 3)) << extra; }
-                }
-                e = (uint16_t)(0x8000 | (extra << 12) | (base3 << 4) | l);
+        if (!l) continue;
+        uint32_t e = (uint32_t)((s << 4) | l);
+        if (form == 1 && s >= 256) {
+            const int ls = s - 257;
+            int base3 = 0, extra = 7; // end of block (value 0) / a symbol that stands for nothing (286, 287: value 1)
+            if (s > 285) base3 = 1;
+            else if (s > 256) {
+                if (ls < 8) { base3 = ls; extra = 0; }
+                else if (ls == 28) { base3 = 255; extra = 0; }
+                else { extra = (ls >> 2) - 1; base3 = (4 + (ls & 3)) << extra; }
             }
-            for (int k = code_of[s]; k < (1 << tb); k += 1 << l) tab[k] = e;
+            e = (uint32_t)(0x8000 | (extra << 12) | (base3 << 4) | l);
+        } else if (form == 2) {
+            if (s > 29) e = 0;
+            else if (s < 4) e = (uint32_t)(((1 + s) << 8) | l);
+            else { const int x = (s >> 1) - 1; e = (uint32_t)(((((2 + (s & 1)) << x) + 1) << 8) | (x << 4) | l); }
         }
+        if (l <= tb) {
+            if (form == 2) { for (int k = code_of[s]; k < (1 << tb); k += 1 << l) tab32[k] = e; }
+            else for (int k = code_of[s]; k < (1 << tb); k += 1 << l) tab[k] = (uint16_t)e;
+        }
+        if (form == 1) code_of[s] = (uint16_t)e; // (this lane's own symbol: its code has just been read)
     }
     __syncthreads();
     return true;
@@ -250,12 +270,12 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                     if (lane == 0) L.cl_lens[kClOrder[k]] = (uint8_t)v;
                 }
                 __syncthreads();
-                // (the code-length code sits where the distance code will be: 7-bit direct table, canonical arrays)
-                if (!build_table(L.cl_lens, 19, L.dist_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 2)) { bad = 2; break; }
+                // (the code-length code sits where the other two codes will be: 7-bit direct table in the literal table's place, the distance code's canonical arrays)
+                if (!build_table(L.cl_lens, 19, L.lit_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 2)) { bad = 2; break; }
                 int n = 0, prev = 0;
                 while (n < nlit + ndist) {
                     bi_refill(b, lane);
-                    const int s = decode_sym(b, L.dist_tab, 7, L.dist_sorted, L.dist_cnt);
+                    const int s = decode_sym(b, L.lit_tab, 7, L.dist_sorted, L.dist_cnt);
                     if (s < 0) { bad = 2; break; }
                     int rep = 1, val = s;
                     if (s == 16) { if (n == 0) { bad = 2; break; } val = prev; rep = 3 + (int)bi_take(b, 2); }
@@ -273,8 +293,9 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 __syncthreads();
                 if (uni((int)L.lens[256]) == 0) { bad = 2; break; } // no end-of-block code
             }
-            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, 1, true)) { bad = 2; break; }
-            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 0)) { bad = 2; break; }
+            // (the distance code first: the literal / length code's build leaves every symbol's entry in code_of[])
+            if (!build_table(L.lens + 288, ndist, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 0, 2)) { bad = 2; break; }
+            if (!build_table(L.lens, nlit, L.lit_tab, UZI_LIT_BITS, L.lit_sorted, L.lit_cnt, L.code_of, L.work, lane, 1, 1, L.lit_walk)) { bad = 2; break; }
             // ---- the symbols of the block.  Literals gather in a register window -- lane l holds the byte for position wbase + l -- and
             // leave it as one coalesced store when it is full or a match needs them in memory.
             //
@@ -287,34 +308,35 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
             // ten); everything else -- longer codes, long or overlapping matches, the input window moving on, errors -- leaves the statement with a
             // reason (`why`) and whatever it has decoded so far, and is finished by the C++ below.
             //   why: 1 window full; 2 the next input word lies beyond the 64 the wave holds; 3 end of block (consumed); 4 the symbol at hand is not
-            //   for the fast path (nothing consumed); 5 a match leaves the block (bad 4); 6 length decoded, distance still to come; 7 length and
-            //   distance decoded, window stored, bounds checked: a copy the fast path does not do; 8 a distance symbol beyond 29 (bad 3)
+            //   for the fast path (nothing consumed: a symbol that stands for nothing, a code no symbol has); 5 a match leaves the block (bad 4);
+            //   6 length decoded, distance still to come (its code is longer than the table's index, or the input window has to move first)
             // Wait states (gfx940 family): a scalar register a lane select reads (k, wcnt - 1) is written by a scalar instruction; two instructions stand
             // between v_readlane writing a scalar register and the vector instruction that reads it.  (v_writelane cannot take the byte AND the lane from
             // scalar registers -- one constant-bus read per instruction -- so a literal enters the window through v_cmp_eq + v_cndmask.)
             uint32_t wcnt = 0; // literals waiting in the window: pos == wbase + wcnt
-            const uint32_t lit_tab_lds = (uint32_t)(uintptr_t)L.lit_tab, dist_tab_lds = (uint32_t)(uintptr_t)L.dist_tab; // (addresses in LDS)
+            const uint32_t lds_base = (uint32_t)(uintptr_t)&L; // (the tables' address in LDS; the fields are reached through offset: fields of the ds_ instructions)
             for (;;) {
                 if (b.bits <= 32) {
                     if (b.widx > UZI_MAX_WORDS) { bad = 6; break; }
                     bi_refill(b, lane);
                 }
-                uint32_t e, why = 0, len_a, dist_a, t_n, t_x, t_t, va, ve;
+                uint32_t e, why = 0, len_a, dist_a, t_n, t_x, t_t, va, ve, vr, vt, vp0, vp1;
                 {
                     unsigned long long buf = b.buf;
                     int bits = b.bits, widx = b.widx;
                     asm volatile(
                         ".Luz_top%=:\n"
                         "  v_bfe_u32 %[va], s44, 0, 10\n"
-                        "  v_lshl_add_u32 %[va], %[va], 1, %[vlit]\n"
-                        "  ds_read_u16 %[ve], %[va]\n"
+                        "  v_lshl_add_u32 %[va], %[va], 1, %[vL]\n"
+                        "  ds_read_u16 %[ve], %[va] offset:%[o_lit]\n"
                         "  s_waitcnt lgkmcnt(0)\n"
                         "  v_readfirstlane_b32 %[e], %[ve]\n"
+                        ".Luz_entry%=:\n"
                         "  s_bitcmp1_b32 %[e], 15\n"
                         "  s_cbranch_scc1 .Luz_nonlit%=\n"
-                        // a literal
+                        // a literal: into lane wcnt of the window
                         "  s_and_b32 %[n], %[e], 15\n"
-                        "  v_lshrrev_b32 %[ve], 4, %[ve]\n"
+                        "  v_bfe_u32 %[ve], %[ve], 4, 8\n"
                         "  v_cmp_eq_u32 vcc, %[wc], %[vlane]\n"
                         "  s_lshr_b64 s[44:45], s[44:45], %[n]\n"
                         "  v_cndmask_b32 %[wb], %[wb], %[ve], vcc\n"
@@ -340,7 +362,7 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                         ".Luz_nonlit%=:\n"
                         "  s_and_b32 %[n], %[e], 15\n"
                         "  s_cmp_eq_u32 %[n], 0\n"
-                        "  s_cbranch_scc1 .Luz_generic%=\n"
+                        "  s_cbranch_scc1 .Luz_long%=\n"
                         "  s_bfe_u32 %[x], %[e], 0x3000c\n"
                         "  s_bfe_u32 %[len], %[e], 0x80004\n"
                         "  s_cmpk_eq_u32 %[x], 7\n"
@@ -367,8 +389,8 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                         "  s_add_u32 %[widx], %[widx], 1\n"
                         ".Luz_dist%=:\n"
                         "  v_bfe_u32 %[va], s44, 0, 8\n"
-                        "  v_lshl_add_u32 %[va], %[va], 1, %[vdist]\n"
-                        "  ds_read_u16 %[ve], %[va]\n"
+                        "  v_lshl_add_u32 %[va], %[va], 2, %[vL]\n"
+                        "  ds_read_b32 %[ve], %[va] offset:%[o_dist]\n"
                         "  s_waitcnt lgkmcnt(0)\n"
                         "  v_readfirstlane_b32 %[e], %[ve]\n"
                         "  s_and_b32 %[n], %[e], 15\n"
@@ -376,23 +398,13 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                         "  s_cbranch_scc1 .Luz_havelen%=\n"
                         "  s_lshr_b64 s[44:45], s[44:45], %[n]\n"
                         "  s_sub_u32 %[bits], %[bits], %[n]\n"
-                        "  s_lshr_b32 %[dist], %[e], 4\n"
-                        "  s_cmpk_gt_u32 %[dist], 29\n"
-                        "  s_cbranch_scc1 .Luz_bad3%=\n"
-                        "  s_cmpk_lt_u32 %[dist], 4\n"
-                        "  s_cbranch_scc1 .Luz_small%=\n"
-                        "  s_lshr_b32 %[x], %[dist], 1\n"
-                        "  s_sub_u32 %[x], %[x], 1\n"
-                        "  s_and_b32 %[t], %[dist], 1\n"
-                        "  s_add_u32 %[t], %[t], 2\n"
-                        "  s_lshl_b32 %[t], %[t], %[x]\n"
-                        "  s_bfm_b32 %[n], %[x], 0\n"
-                        "  s_and_b32 %[n], s44, %[n]\n"
-                        "  s_add_u32 %[dist], %[t], %[n]\n"
+                        "  s_bfe_u32 %[x], %[e], 0x40004\n"
+                        "  s_lshr_b32 %[dist], %[e], 8\n"
+                        "  s_bfm_b32 %[t], %[x], 0\n"
+                        "  s_and_b32 %[t], s44, %[t]\n"
+                        "  s_add_u32 %[dist], %[dist], %[t]\n"
                         "  s_lshr_b64 s[44:45], s[44:45], %[x]\n"
                         "  s_sub_u32 %[bits], %[bits], %[x]\n"
-                        ".Luz_small%=:\n"
-                        "  s_add_u32 %[dist], %[dist], 1\n"
                         // the window's literals into memory in front of the match (no lane masked off: the lanes behind the fill store its last byte again)
                         "  s_cmp_eq_u32 %[wc], 0\n"
                         "  s_cbranch_scc1 .Luz_noflush%=\n"
@@ -415,28 +427,107 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                         "  s_add_u32 %[t], %[wbase], %[len]\n"
                         "  s_cmp_gt_u32 %[t], %[osize]\n"
                         "  s_cbranch_scc1 .Luz_bad4%=\n"
-                        "  s_cmp_lt_u32 %[dist], %[len]\n"
-                        "  s_cbranch_scc1 .Luz_copy%=\n"
-                        "  s_cmpk_gt_u32 %[len], 64\n"
-                        "  s_cbranch_scc1 .Luz_copy%=\n"
-                        // the copy: lane k takes byte k (the lanes past the end repeat the last byte); the load goes past the L1 and waits for the wave's
-                        // stores only when the source reaches into bytes stored since the last such wait
+                        // the copy.  Lane k takes byte k of a 64-byte piece (the lanes past the match's end repeat its last byte); the loads go past the
+                        // L1 and wait for the wave's stores only when the source reaches into bytes stored since the last wait -- and every piece waits
+                        // for its own load before it stores, so everything in front of the match has landed by then: `safe` moves up to its start
                         "  s_sub_u32 %[n], %[wbase], %[dist]\n"
-                        "  s_add_u32 %[x], %[n], %[len]\n"
+                        "  s_min_u32 %[x], %[len], %[dist]\n"
+                        "  s_add_u32 %[x], %[n], %[x]\n"
                         "  s_cmp_le_u32 %[x], %[safe]\n"
                         "  s_cbranch_scc1 .Luz_safe%=\n"
                         "  s_waitcnt vmcnt(0)\n"
-                        "  s_mov_b32 %[safe], %[wbase]\n"
                         ".Luz_safe%=:\n"
+                        "  s_mov_b32 %[safe], %[wbase]\n"
                         "  s_sub_u32 %[x], %[len], 1\n"
-                        "  v_min_u32 %[va], %[x], %[vlane]\n"
+                        "  s_mov_b32 %[e], 0\n"
+                        "  s_cmp_lt_u32 %[dist], %[len]\n"
+                        "  s_cbranch_scc1 .Luz_mod%=\n"
+                        ".Luz_plain%=:\n"
+                        "  v_add_u32 %[va], %[e], %[vlane]\n"
+                        "  v_min_u32 %[va], %[x], %[va]\n"
                         "  v_add_u32 %[ve], %[n], %[va]\n"
                         "  global_load_ubyte %[ve], %[ve], s[48:49] sc1\n"
                         "  v_add_u32 %[va], %[wbase], %[va]\n"
+                        "  s_add_u32 %[e], %[e], 64\n"
                         "  s_waitcnt vmcnt(0)\n"
                         "  global_store_byte %[va], %[ve], s[48:49]\n"
+                        "  s_cmp_lt_u32 %[e], %[len]\n"
+                        "  s_cbranch_scc1 .Luz_plain%=\n"
                         "  s_mov_b32 %[wbase], %[t]\n"
                         "  s_branch .Luz_next%=\n"
+                        // source and destination overlap (a run): byte k comes from k mod dist -- through a float reciprocal, exact for k < 512 after one
+                        // correction either way
+                        ".Luz_mod%=:\n"
+                        "  v_cvt_f32_u32 %[vr], %[dist]\n"
+                        "  v_rcp_f32 %[vr], %[vr]\n"
+                        ".Luz_modl%=:\n"
+                        "  v_add_u32 %[va], %[e], %[vlane]\n"
+                        "  v_min_u32 %[va], %[x], %[va]\n"
+                        "  v_cvt_f32_u32 %[ve], %[va]\n"
+                        "  v_mul_f32 %[ve], %[ve], %[vr]\n"
+                        "  v_cvt_u32_f32 %[ve], %[ve]\n"
+                        "  v_mul_u32_u24 %[ve], %[dist], %[ve]\n"
+                        "  v_sub_u32 %[ve], %[va], %[ve]\n"
+                        "  v_cmp_gt_i32 vcc, 0, %[ve]\n"
+                        "  v_add_u32 %[vt], %[dist], %[ve]\n"
+                        "  v_cndmask_b32 %[ve], %[ve], %[vt], vcc\n"
+                        "  v_cmp_le_u32 vcc, %[dist], %[ve]\n"
+                        "  v_subrev_u32 %[vt], %[dist], %[ve]\n"
+                        "  v_cndmask_b32 %[ve], %[ve], %[vt], vcc\n"
+                        "  v_add_u32 %[ve], %[n], %[ve]\n"
+                        "  global_load_ubyte %[ve], %[ve], s[48:49] sc1\n"
+                        "  v_add_u32 %[va], %[wbase], %[va]\n"
+                        "  s_add_u32 %[e], %[e], 64\n"
+                        "  s_waitcnt vmcnt(0)\n"
+                        "  global_store_byte %[va], %[ve], s[48:49]\n"
+                        "  s_cmp_lt_u32 %[e], %[len]\n"
+                        "  s_cbranch_scc1 .Luz_modl%=\n"
+                        "  s_mov_b32 %[wbase], %[t]\n"
+                        "  s_branch .Luz_next%=\n"
+                        // a code longer than the table's index: the canonical walk (decode_long) from length 11 on -- its state after length 10 was worked out
+                        // when the table was built -- ends at the symbol's table entry (code_of[]), and the symbol goes the way of all the others
+                        ".Luz_long%=:\n"
+                        "  ds_read_b32 %[vp0], %[vL] offset:%[o_walk]\n"
+                        "  ds_read_b32 %[vp1], %[vL] offset:%[o_walk1]\n"
+                        "  s_brev_b32 %[t], s44\n"
+                        "  s_lshr_b32 %[t], %[t], 22\n"
+                        "  s_lshl_b32 %[t], %[t], 1\n"
+                        "  s_mov_b32 %[n], 10\n"
+                        "  s_waitcnt lgkmcnt(0)\n"
+                        "  v_readfirstlane_b32 %[x], %[vp0]\n"
+                        "  v_readfirstlane_b32 %[len], %[vp1]\n"
+                        ".Luz_walk%=:\n"
+                        "  s_lshr_b32 %[dist], s44, %[n]\n"
+                        "  s_and_b32 %[dist], %[dist], 1\n"
+                        "  s_or_b32 %[t], %[t], %[dist]\n"
+                        "  s_add_u32 %[n], %[n], 1\n"
+                        "  v_mov_b32 %[va], %[n]\n"
+                        "  v_lshl_add_u32 %[va], %[va], 1, %[vL]\n"
+                        "  ds_read_u16 %[ve], %[va] offset:%[o_cnt]\n"
+                        "  s_waitcnt lgkmcnt(0)\n"
+                        "  v_readfirstlane_b32 %[dist], %[ve]\n"
+                        "  s_sub_i32 %[e], %[t], %[dist]\n"
+                        "  s_cmp_lt_i32 %[e], %[x]\n"
+                        "  s_cbranch_scc1 .Luz_found%=\n"
+                        "  s_add_u32 %[len], %[len], %[dist]\n"
+                        "  s_add_u32 %[x], %[x], %[dist]\n"
+                        "  s_lshl_b32 %[x], %[x], 1\n"
+                        "  s_lshl_b32 %[t], %[t], 1\n"
+                        "  s_cmpk_lt_u32 %[n], 15\n"
+                        "  s_cbranch_scc1 .Luz_walk%=\n"
+                        "  s_branch .Luz_generic%=\n"
+                        ".Luz_found%=:\n"
+                        "  s_sub_u32 %[t], %[t], %[x]\n"
+                        "  s_add_u32 %[t], %[t], %[len]\n"
+                        "  v_mov_b32 %[va], %[t]\n"
+                        "  v_lshl_add_u32 %[va], %[va], 1, %[vL]\n"
+                        "  ds_read_u16 %[ve], %[va] offset:%[o_sorted]\n"
+                        "  s_waitcnt lgkmcnt(0)\n"
+                        "  v_lshl_add_u32 %[va], %[ve], 1, %[vL]\n"
+                        "  ds_read_u16 %[ve], %[va] offset:%[o_entry]\n"
+                        "  s_waitcnt lgkmcnt(0)\n"
+                        "  v_readfirstlane_b32 %[e], %[ve]\n"
+                        "  s_branch .Luz_entry%=\n"
                         // the ways out
                         ".Luz_special%=:\n" // (value 0: the end of the block; 1: a symbol that stands for nothing -- the C++ reports it)
                         "  s_cmp_lg_u32 %[len], 0\n"
@@ -459,18 +550,13 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                         "  s_branch .Luz_out%=\n"
                         ".Luz_havelen%=:\n"
                         "  s_mov_b32 %[why], 6\n"
-                        "  s_branch .Luz_out%=\n"
-                        ".Luz_copy%=:\n"
-                        "  s_mov_b32 %[why], 7\n"
-                        "  s_branch .Luz_out%=\n"
-                        ".Luz_bad3%=:\n"
-                        "  s_mov_b32 %[why], 8\n"
                         ".Luz_out%=:\n"
                         : "+{s[44:45]}"(buf), [bits] "+s"(bits), [widx] "+s"(widx), [wc] "+s"(wcnt), [wbase] "+s"(wbase), [safe] "+s"(safe), [wb] "+v"(wbyte),
                           [why] "+s"(why), [e] "=&s"(e), [len] "=&s"(len_a), [dist] "=&s"(dist_a), [n] "=&s"(t_n), [x] "=&s"(t_x), [t] "=&s"(t_t),
-                          [va] "=&v"(va), [ve] "=&v"(ve)
-                        : [vlit] "v"(lit_tab_lds), [vdist] "v"(dist_tab_lds), [cbase] "s"(b.cbase), [cur] "v"(b.cur), [vlane] "v"(lane), [osize] "s"(osize),
-                          "{s[48:49]}"(o)
+                          [va] "=&v"(va), [ve] "=&v"(ve), [vr] "=&v"(vr), [vt] "=&v"(vt), [vp0] "=&v"(vp0), [vp1] "=&v"(vp1)
+                        : [vL] "v"(lds_base), [cbase] "s"(b.cbase), [cur] "v"(b.cur), [vlane] "v"(lane), [osize] "s"(osize), "{s[48:49]}"(o),
+                          [o_lit] "i"(offsetof(InflateLds, lit_tab)), [o_dist] "i"(offsetof(InflateLds, dist_tab)), [o_walk] "i"(offsetof(InflateLds, lit_walk)), [o_walk1] "i"(offsetof(InflateLds, lit_walk) + 4),
+                          [o_cnt] "i"(offsetof(InflateLds, lit_cnt)), [o_sorted] "i"(offsetof(InflateLds, lit_sorted)), [o_entry] "i"(offsetof(InflateLds, code_of))
                         : "s46", "s47", "scc", "vcc", "memory");
                     b.buf = buf; b.bits = bits; b.widx = widx;
                 }
@@ -482,7 +568,6 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 }
                 if (why == 2) continue; // (the refill at the loop's head moves the input window on)
                 if (why == 5) { bad = 4; break; }
-                if (why == 8) { bad = 3; break; }
                 int len = (int)len_a, dist = (int)dist_a;
                 if (why == 4) { // the symbol at hand the general way (the canonical walk decodes a code of any length)
                     const int s = decode_long(b, L.lit_sorted, L.lit_cnt);
@@ -518,9 +603,9 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 }
                 if (why == 3) break; // the end of the block
                 const uint32_t pos = wbase;
-                if (why != 7) { // the distance
+                { // the distance (the canonical walk: the direct table's entries are made for the fast path)
                     bi_refill(b, lane);
-                    const int ds = decode_sym(b, L.dist_tab, UZI_DIST_BITS, L.dist_sorted, L.dist_cnt);
+                    const int ds = decode_long(b, L.dist_sorted, L.dist_cnt);
                     if (ds < 0 || ds > 29) { bad = 3; break; }
                     bi_refill(b, lane);
                     if (ds < 4) dist = 1 + ds;
