@@ -176,13 +176,7 @@ __device__ bool build_table(const uint8_t *lens, int n, void *tab_, int tb, uint
     __syncthreads();
     return true;
 }
-// one symbol: the direct table, or the canonical walk for a code longer than the table's index (rare)
-__device__ __forceinline__ int decode_long(BitIn &b, const uint16_t *sorted, const uint16_t *cnt);
-__device__ __forceinline__ int decode_sym(BitIn &b, const uint16_t *tab, int tb, const uint16_t *sorted, const uint16_t *cnt) {
-    const uint32_t e = uni((uint32_t)tab[bi_peek(b, tb)]);
-    if (e) { bi_drop(b, (int)(e & 15u)); return (int)(e >> 4); }
-    return decode_long(b, sorted, cnt);
-}
+// one symbol the canonical way (count / first code per length): what the C++ around the hand-written loops decodes with -- codes of any length
 __device__ __forceinline__ int decode_long(BitIn &b, const uint16_t *sorted, const uint16_t *cnt) {
     int code = 0, first = 0, index = 0;
     unsigned long long v = b.buf;
@@ -272,22 +266,110 @@ __global__ __launch_bounds__(64, UZI_WAVES_PER_EU) void k_bgzf_inflate(int64_t n
                 __syncthreads();
                 // (the code-length code sits where the other two codes will be: 7-bit direct table in the literal table's place, the distance code's canonical arrays)
                 if (!build_table(L.cl_lens, 19, L.lit_tab, 7, L.dist_sorted, L.dist_cnt, L.code_of, L.work, lane, 2)) { bad = 2; break; }
-                int n = 0, prev = 0;
-                while (n < nlit + ndist) {
-                    bi_refill(b, lane);
-                    const int s = decode_sym(b, L.lit_tab, 7, L.dist_sorted, L.dist_cnt);
-                    if (s < 0) { bad = 2; break; }
-                    int rep = 1, val = s;
-                    if (s == 16) { if (n == 0) { bad = 2; break; } val = prev; rep = 3 + (int)bi_take(b, 2); }
-                    else if (s == 17) { val = 0; rep = 3 + (int)bi_take(b, 3); }
-                    else if (s == 18) { val = 0; rep = 11 + (int)bi_take(b, 7); }
-                    if (n + rep > nlit + ndist) { bad = 2; break; }
-                    for (int k = lane; k < rep; k += 64) { // entry n + k: a literal / length code's length, or a distance code's
-                        const int at = n + k;
-                        L.lens[at < nlit ? at : 288 + (at - nlit)] = (uint8_t)val;
+                // the code lengths of both codes, written out by hand like the symbol loop below (and for the same reason: ~500 of these symbols per
+                // BGZF block at ~80 scalar instructions each in the compiler's loop were a fifth of the kernel's scalar issue; here ~17).  A symbol below
+                // 16 is a length, 16 repeats the one before 3 - 6 times, 17 / 18 write 3 - 10 / 11 - 138 zeros; entry n + k is a literal / length code's
+                // length while n + k < nlit, a distance code's behind it (L.lens + 288).  All lanes store (the lanes past the run's end its last entry again).
+                // why: 0 done; 1 bad lengths; 2 the next input word lies beyond the 64 the wave holds
+                {
+                    uint32_t hn = 0, hprev = 0, hwhy = 0;
+                    const uint32_t htotal = (uint32_t)(nlit + ndist), hnlit = (uint32_t)nlit, hadj = 288u - (uint32_t)nlit;
+                    const uint32_t lds_base = (uint32_t)(uintptr_t)&L;
+                    for (;;) {
+                        if (b.bits <= 32) {
+                            if (b.widx > UZI_MAX_WORDS) { bad = 6; break; }
+                            bi_refill(b, lane);
+                        }
+                        uint32_t e, t_val, t_rep, t_x, t_t, va, ve, vv;
+                        unsigned long long buf = b.buf;
+                        int bits = b.bits, widx = b.widx;
+                        hwhy = 0;
+                        hn = uni(hn); hprev = uni(hprev); // (loop-carried through nothing but the statement below: the compiler would keep them in vector registers)
+                        asm volatile(
+                            ".Luzh_top%=:\n"
+                            "  v_bfe_u32 %[va], s44, 0, 7\n"
+                            "  v_lshl_add_u32 %[va], %[va], 1, %[vL]\n"
+                            "  ds_read_u16 %[ve], %[va] offset:%[o_lit]\n"
+                            "  s_waitcnt lgkmcnt(0)\n"
+                            "  v_readfirstlane_b32 %[e], %[ve]\n"
+                            "  s_and_b32 %[t], %[e], 15\n"
+                            "  s_cmp_eq_u32 %[t], 0\n"
+                            "  s_cbranch_scc1 .Luzh_bad%=\n"
+                            "  s_lshr_b64 s[44:45], s[44:45], %[t]\n"
+                            "  s_sub_u32 %[bits], %[bits], %[t]\n"
+                            "  s_lshr_b32 %[val], %[e], 4\n"
+                            "  s_mov_b32 %[rep], 1\n"
+                            "  s_cmpk_lt_u32 %[val], 16\n"
+                            "  s_cbranch_scc1 .Luzh_store%=\n"
+                            "  s_cmpk_eq_u32 %[val], 16\n"
+                            "  s_cbranch_scc1 .Luzh_16%=\n"
+                            "  s_cmpk_eq_u32 %[val], 17\n"
+                            "  s_cselect_b32 %[x], 3, 7\n"
+                            "  s_cselect_b32 %[rep], 3, 11\n"
+                            "  s_mov_b32 %[val], 0\n"
+                            "  s_branch .Luzh_ext%=\n"
+                            ".Luzh_16%=:\n"
+                            "  s_cmp_eq_u32 %[n], 0\n"
+                            "  s_cbranch_scc1 .Luzh_bad%=\n"
+                            "  s_mov_b32 %[val], %[prev]\n"
+                            "  s_mov_b32 %[x], 2\n"
+                            "  s_mov_b32 %[rep], 3\n"
+                            ".Luzh_ext%=:\n"
+                            "  s_bfm_b32 %[t], %[x], 0\n"
+                            "  s_and_b32 %[t], s44, %[t]\n"
+                            "  s_add_u32 %[rep], %[rep], %[t]\n"
+                            "  s_lshr_b64 s[44:45], s[44:45], %[x]\n"
+                            "  s_sub_u32 %[bits], %[bits], %[x]\n"
+                            ".Luzh_store%=:\n"
+                            "  s_add_u32 %[t], %[n], %[rep]\n"
+                            "  s_cmp_gt_u32 %[t], %[total]\n"
+                            "  s_cbranch_scc1 .Luzh_bad%=\n"
+                            "  s_mov_b32 %[prev], %[val]\n"
+                            "  s_sub_u32 %[x], %[rep], 1\n"
+                            "  s_mov_b32 %[e], 0\n"
+                            "  v_mov_b32 %[vv], %[val]\n"
+                            ".Luzh_w%=:\n"
+                            "  v_add_u32 %[va], %[e], %[vlane]\n"
+                            "  v_min_u32 %[va], %[x], %[va]\n"
+                            "  v_add_u32 %[va], %[n], %[va]\n"
+                            "  v_cmp_gt_u32 vcc, %[nlit], %[va]\n"
+                            "  v_add_u32 %[ve], %[adj], %[va]\n"
+                            "  v_cndmask_b32 %[va], %[ve], %[va], vcc\n"
+                            "  v_add_u32 %[va], %[va], %[vL]\n"
+                            "  ds_write_b8 %[va], %[vv] offset:%[o_lens]\n"
+                            "  s_add_u32 %[e], %[e], 64\n"
+                            "  s_cmp_lt_u32 %[e], %[rep]\n"
+                            "  s_cbranch_scc1 .Luzh_w%=\n"
+                            "  s_mov_b32 %[n], %[t]\n"
+                            "  s_cmp_lt_u32 %[n], %[total]\n"
+                            "  s_cbranch_scc0 .Luzh_out%=\n"
+                            "  s_cmpk_gt_i32 %[bits], 32\n"
+                            "  s_cbranch_scc1 .Luzh_top%=\n"
+                            "  s_sub_u32 %[t], %[widx], %[cbase]\n"
+                            "  s_cmpk_ge_u32 %[t], 64\n"
+                            "  s_cbranch_scc1 .Luzh_need%=\n"
+                            "  v_readlane_b32 s46, %[cur], %[t]\n"
+                            "  s_mov_b32 s47, 0\n"
+                            "  s_lshl_b64 s[46:47], s[46:47], %[bits]\n"
+                            "  s_or_b64 s[44:45], s[44:45], s[46:47]\n"
+                            "  s_add_u32 %[bits], %[bits], 32\n"
+                            "  s_add_u32 %[widx], %[widx], 1\n"
+                            "  s_branch .Luzh_top%=\n"
+                            ".Luzh_bad%=:\n"
+                            "  s_mov_b32 %[why], 1\n"
+                            "  s_branch .Luzh_out%=\n"
+                            ".Luzh_need%=:\n"
+                            "  s_mov_b32 %[why], 2\n"
+                            ".Luzh_out%=:\n"
+                            : "+{s[44:45]}"(buf), [bits] "+s"(bits), [widx] "+s"(widx), [n] "+s"(hn), [prev] "+s"(hprev), [why] "+s"(hwhy), [e] "=&s"(e),
+                              [val] "=&s"(t_val), [rep] "=&s"(t_rep), [x] "=&s"(t_x), [t] "=&s"(t_t), [va] "=&v"(va), [ve] "=&v"(ve), [vv] "=&v"(vv)
+                            : [vL] "v"(lds_base), [cbase] "s"(b.cbase), [cur] "v"(b.cur), [vlane] "v"(lane), [total] "s"(htotal), [nlit] "s"(hnlit), [adj] "s"(hadj),
+                              [o_lit] "i"(offsetof(InflateLds, lit_tab)), [o_lens] "i"(offsetof(InflateLds, lens))
+                            : "s46", "s47", "scc", "vcc", "memory");
+                        b.buf = buf; b.bits = bits; b.widx = widx;
+                        if (hwhy != 2) break;
                     }
-                    n += rep;
-                    prev = val;
+                    if (!bad && hwhy == 1) bad = 2;
                 }
                 if (bad) break;
                 __syncthreads();
