@@ -5,6 +5,8 @@ import gzip
 import struct
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -120,10 +122,11 @@ def test_a_staged_batch_with_its_blocks_inflated_on_the_device(engine, tmp_path)
     pair.free_all()
 
 
-def test_random_blocks_against_zlib(engine):
+@pytest.mark.parametrize("seed", [2024] + [int(x) for x in os.environ.get("UZ_INFLATE_FUZZ_SEEDS", "").split(",") if x])
+def test_random_blocks_against_zlib(engine, seed):
     """three hundred blocks of mixed statistics (alphabet size, run lengths, copies of earlier stretches at every distance up to the
-    window, sizes from one byte to the 64 KiB limit), every zlib level and strategy in turn"""
-    rng = np.random.default_rng(2024)
+    window, sizes from one byte to the 64 KiB limit), every zlib level and strategy in turn (UZ_INFLATE_FUZZ_SEEDS=1,2,...: more seeds)"""
+    rng = np.random.default_rng(seed)
     blocks, want = [], []
     strategies = (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED)
     for k in range(300):

@@ -333,8 +333,10 @@ class HipEngine:
                     raise _WalkTooLarge()
                 return self.bam_walk(plan, alloc=pair.alloc)
             try:
-                return src.select_kept(fc, flo, fhi, int(min_base_qual), walk=walk, all_bases=bool(all_bases), alloc=pair.alloc, extra=fex,
-                                       release=self.bam_walk_release)
+                kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=walk, all_bases=bool(all_bases), alloc=pair.alloc, extra=fex,
+                                     release=self.bam_walk_release)
+                kb._alloc = pair.alloc  # (the names of its records come back into page-locked memory of the same set: reads_from_bam)
+                return kb
             except _WalkTooLarge:
                 pass
         if os.environ.get("UZ_INFLATE", "device") == "device":
@@ -445,7 +447,8 @@ class HipEngine:
         names: the read names of the kept records come back too (kb.qnames then maps the name ids of the result lists to strings)."""
         rid = C.c_int(-1)
         nb = int(kb.n_name_bytes) if names else 0
-        buf = np.empty(max(1, nb), np.uint8) if names else None
+        alloc = getattr(kb, "_alloc", None)
+        buf = (alloc(max(1, nb)) if alloc is not None else np.empty(max(1, nb), np.uint8)) if names else None
         self._ck(self.L.uz_reads_from_bam(self.h, int(kb.token), kb.kept.ctypes.data, int(kb.n), kb.aux.ctypes.data, int(kb.n_aux), kb.contig_off.ctypes.data,
                                           kb.max_span.ctypes.data, int(kb.n_contigs), int(kb.n_cigar_total), int(kb.n_row_units), int(kb.n_seq_units),
                                           int(kb.n_qnames), int(kb.min_base_qual), buf.ctypes.data if names else None, nb, C.byref(rid)), "uz_reads_from_bam")

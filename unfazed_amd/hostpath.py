@@ -147,6 +147,26 @@ class _VoteLists:
         o, v = self._vol, self._vvl
         return v[o[4 * k]: o[4 * k + 1]], v[o[4 * k + 1]: o[4 * k + 2]], v[o[4 * k + 2]: o[4 * k + 3]], v[o[4 * k + 3]: o[4 * k + 4]]
 
+    def strings(self, take):
+        """Every value of the chunk's lists as the string a record carries -- a read's name (take(ids) -> names) or a position's decimal form --
+        in ONE Python list (the lists of a DNM are slices of it): a fancy index over the distinct names and one str() per distinct position
+        instead of a dictionary look-up and an append per list entry"""
+        vo, vv = self.vo, self.vv
+        n4 = vo.size - 1
+        if vv.size == 0:
+            return []
+        is_read = np.repeat((np.arange(n4) & 3) < 2, np.diff(vo))
+        out = np.empty(vv.size, object)
+        ids = vv[is_read].astype(np.int64)
+        if ids.size:
+            u, inv = np.unique(ids, return_inverse=True)
+            out[is_read] = np.array(take(u), object)[inv]
+        pos = vv[~is_read]
+        if pos.size:
+            u, inv = np.unique(pos, return_inverse=True)
+            out[~is_read] = np.array(list(map(str, u.tolist())), object)[inv]
+        return out.tolist()
+
     def read_ids(self, ks):
         """the distinct name ids in the read lists of DNMs ks"""
         o = self.vo
@@ -222,6 +242,7 @@ class PhasingHost:
         whole_region: bool = True,
         attach: bool = True,
         fetch: bool = True,
+        defer_attach: bool = False,
     ):
         """informative_site_finder.find: annotates the DNM dicts in place with
         `candidate_sites` / `het_sites` and returns the list in the reference's order.
@@ -274,6 +295,7 @@ class PhasingHost:
             mult_of[i] = mults[i] if many else 1
 
         found: Dict[int, dict] = {}
+        pending_attach: list = []
         by_kid: Dict[str, List[int]] = {}
         for i in scan:
             by_kid.setdefault(dnms[i]["kid"], []).append(i)
@@ -305,8 +327,12 @@ class PhasingHost:
                     het_idx=hi[hol[k] : hol[k + 1]],
                 )
             if attach:
-                # the site dicts the reference leaves on every DNM (:262-343): the columns of the whole batch's sites become Python values in
-                # ONE pass each (a fancy index and a tolist per column, not per DNM), then one dict display per site
+                pending_attach.append((idxs, ci, cf, hi, col, hol, dad, mom))
+
+        def attach_now():
+            # the site dicts the reference leaves on every DNM (:262-343): the columns of the whole batch's sites become Python values in
+            # ONE pass each (a fancy index and a tolist per column, not per DNM), then one dict display per site
+            for idxs, ci, cf, hi, col, hol, dad, mom in pending_attach:
                 cands_all = self._site_dicts(ci, cf, dad, mom, whole_region)
                 hets_all = self._site_dicts(hi, None, dad, mom, False)
                 for k, i in enumerate(idxs):
@@ -322,9 +348,14 @@ class PhasingHost:
                     else:
                         dn["candidate_sites"] = cands  # :341-342
                         dn["het_sites"] = hets
+            del pending_attach[:]
+        if not defer_attach:
+            attach_now()
         ret = [dnms[i] for i in order] + [dnms[i] for i in auto_tail]
         ret_idx = order + auto_tail
-        return ret, {"order": ret_idx, "found": found, "many": many, "mode": mode, "scanned": scan, "contig_of": contig_of}
+        # (defer_attach: the caller runs info["attach"]() itself -- the read stage needs the index lists, not the dicts, so a staged batch builds
+        # them beside the native decode of its first chunks instead of in front of it)
+        return ret, {"order": ret_idx, "found": found, "many": many, "mode": mode, "scanned": scan, "contig_of": contig_of, "attach": attach_now}
 
     def _site_dicts(self, idx, flags, dad, mom, with_kid_allele):
         s = self.sites
@@ -526,7 +557,8 @@ class PhasingHost:
 
     CHUNK_DNMS = 3400  # DNMs per chunk of a large batch (bench.py's files -> results pass: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)
 
-    def _chunked_batch(self, batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, mode, results) -> bool:
+    def _chunked_batch(self, batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, mode, results,
+                       while_first_stages=None) -> bool:
         """A large batch of ONE kid from an indexed BAM through the staged pipeline (pipeline.run_pipelined: what bench.py measures) -- the
         reference runs one task per DNM on a thread pool, each opening the alignment file for its own window (snv_phaser.py:244-298); here chunk
         k + 1 is decoded on a worker thread (BAM blocks through the index straight into the link form, the blocks inflated on the device) while
@@ -544,14 +576,15 @@ class PhasingHost:
         src = stager(bam)
         fam = self.family(kid, pedigrees[kid]["dad"], pedigrees[kid]["mom"])
         cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
-        cuts = list(range(0, len(idxs), chunk)) + [len(idxs)]
+        # (the first chunk half-size: nothing hides its decode)
+        cuts = [0] + list(range(chunk // 2, len(idxs), chunk)) + [len(idxs)]
         if cuts[-1] - cuts[-2] < chunk // 2 and len(cuts) > 2:
             cuts.pop(-2)  # (a short tail joins the chunk before it)
         parts = [idxs[cuts[k]: cuts[k + 1]] for k in range(len(cuts) - 1)]
 
         from . import pipeline
         lag = 1  # (chunks of a few thousand DNMs: the first read stage should start as early as it can)
-        ahead = 2  # BAM stages in flight beside the chunk on the device (native code: the interpreter lock is released; bench.py's own loop runs three)
+        ahead = int(os.environ.get("UZ_HOST_AHEAD", 3))  # BAM stages in flight beside the chunk on the device (native code: the interpreter lock is released; bench.py's own loop runs three)
         n_slots = lag + 1 + ahead  # a slot is staged into again once the read stage of the chunk it held has been collected
 
         def stage(k):
@@ -588,6 +621,9 @@ class PhasingHost:
                 for j, i in enumerate(part):
                     results[i] = (res, j, table)
 
+            if while_first_stages is not None:
+                with _Sec("attach"):
+                    while_first_stages()  # host work that nothing below waits for, beside the native decode of the first chunks
             chunks = [dict(a=cuts[k], b=cuts[k + 1], dnms=self._dnms_view_of(parts[k], dnms, prep, found, cutoff), records=records, sites=None)
                       for k in range(len(parts))]
             trace = [] if os.environ.get("UZ_HOST_TRACE") else None  # development aid: ms per pipeline step (find, collect, queue, records + upload)
@@ -624,11 +660,12 @@ class PhasingHost:
         with _Sec("find"):
             ret, info = self.find(
                 dnms, pedigrees, search_dist, threads, build, multithread_proc_min, quiet_mode, params,
-                whole_region=False,
+                whole_region=False, defer_attach=True,
             )
         records: Dict[str, dict] = {}
         if ret is None:
             return records
+        attach_sites = info["attach"]
         found = info["found"]
         # pass 1: host-side filters in the reference's order; collect the device batch per kid
         plan = []  # (dnm index, action)
@@ -680,7 +717,9 @@ class PhasingHost:
         groups, order_all, tables, handles = [], [], [], []
         sec_pass1.__exit__()
         with _Sec("chunked"):
-          chunked = self._chunked_batch(batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, info["mode"], results)
+          chunked = self._chunked_batch(batch, dnms, pedigrees, prep, found, params, readlen, stdevs, insert_size_max_sample, want_lists, info["mode"], results,
+                                        while_first_stages=attach_sites)
+        attach_sites()  # (a batch that did not take the chunked route: here; otherwise done already, and this is a no-op)
         for (kid, bam), idxs in ([] if chunked else batch.items()):
             dad_id, mom_id = pedigrees[kid]["dad"], pedigrees[kid]["mom"]
             fam = self.family(kid, dad_id, mom_id)
@@ -801,6 +840,11 @@ class PhasingHost:
             return out
         take = getattr(getattr(rt, "qnames", None), "take", None)
         fast = isinstance(lists, _VoteLists)
+        if fast and take is not None and len(ok) * 2 >= len(lists):  # (a chunk's lists as a whole: its DNMs' lists are slices of one list of strings)
+            sl, o = lists.strings(take), lists._vol
+            for k in ok:
+                out[k] = (sl[o[4 * k]: o[4 * k + 1]], sl[o[4 * k + 1]: o[4 * k + 2]], sl[o[4 * k + 2]: o[4 * k + 3]], sl[o[4 * k + 3]: o[4 * k + 4]])
+            return out
         nm = None
         if take is not None:
             if fast:

@@ -670,25 +670,39 @@ def stage_kept_debug(lib, stage_ptr, n: int):
 
 class _KeptNames(Sequence):
     """name id -> query name of a batch walked on the device: the kept records' names came back from HBM in record order (uz_reads_from_bam), and
-    the id's name is the name of the record that brought it first (uz_stage_name_records)"""
+    the id's name is the name of the record that brought it first (uz_stage_name_records: asked per look-up, for the ids looked up -- a chunk's
+    result lists name a few per cent of its million names)"""
 
-    def __init__(self, buf: np.ndarray, name_off: np.ndarray, rec_of_id: np.ndarray):
-        self._buf, self._off, self._rec = buf, name_off, rec_of_id
+    def __init__(self, buf: np.ndarray, name_off: np.ndarray, total: int, n_names: int, stage):
+        self._buf, self._off, self._total, self._n, self._stage = buf, name_off, int(total), int(n_names), stage
 
     def __len__(self):
-        return int(self._rec.size)
+        return self._n
+
+    def _records(self, ids: np.ndarray) -> np.ndarray:
+        lib = load()
+        ids = np.ascontiguousarray(ids, np.uint32)
+        rec = np.zeros(max(1, ids.size), np.int64)
+        _check(lib, lib.uz_stage_name_records(self._stage.ptr, ids.ctypes.data, int(ids.size), rec.ctypes.data))
+        return rec[: ids.size]
+
+    def _bounds(self, r: np.ndarray):
+        n = self._off.shape[0]
+        a = self._off[r].astype(np.int64)
+        nxt = r + 1
+        b = np.where(nxt < n, self._off[np.minimum(nxt, n - 1)].astype(np.int64), self._total)
+        return a, b
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[k] for k in range(*i.indices(len(self)))]
-        r = int(self._rec[int(i)])
-        return self._buf[int(self._off[r]): int(self._off[r + 1])].tobytes().decode()
+        a, b = self._bounds(self._records(np.array([int(i)], np.int64)))
+        return self._buf[int(a[0]): int(b[0])].tobytes().decode()
 
     def take(self, ids) -> list:
-        r = self._rec[np.ascontiguousarray(ids, np.int64)]
-        a, b = self._off[r].tolist(), self._off[r + 1].tolist()
+        a, b = self._bounds(self._records(np.asarray(ids)))
         mv = memoryview(self._buf)  # (not tobytes(): the buffer holds the names of every kept record of the batch, tens of megabytes)
-        return [str(mv[x:y], "utf-8") for x, y in zip(a, b)]
+        return [str(mv[x:y], "utf-8") for x, y in zip(a.tolist(), b.tolist())]
 
 
 class KeptBatch:
@@ -707,11 +721,7 @@ class KeptBatch:
             self.token = None
 
     def set_names(self, buf: np.ndarray):
-        lib = load()
-        rec = np.zeros(max(1, self.n_qnames), np.int64)
-        _check(lib, lib.uz_stage_name_records(self._stage.ptr, None, int(self.n_qnames), rec.ctypes.data))
-        off = np.concatenate([self.kept["name_off"].astype(np.int64), [int(self.n_name_bytes)]])
-        self.qnames = _KeptNames(buf, off, rec[: self.n_qnames])
+        self.qnames = _KeptNames(buf, self.kept["name_off"], int(self.n_name_bytes), int(self.n_qnames), self._stage)
 
 
 class BamSource:
