@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
                     "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 3)")
     ap.add_argument("--sites16", action="store_true", help="staged pass: the genotype columns of the site windows in 16 bits (default: the eight-bit link form)")
-    ap.add_argument("--first-chunk", type=float, default=None, help="size of the first chunk of the staged pass relative to the others (default: shard.chunk_plan's 0.5)")
+    ap.add_argument("--first-chunk", type=float, default=None, help="size of the first chunk of the staged pass relative to the others (default: shard.chunk_plan's: 1.0 for a batch of four chunks or more, else 0.5)")
     ap.add_argument("--last-chunk", type=float, default=0.7, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
     ap.add_argument("--cpu-dnms", type=int, default=60000, help="DNMs in the CPU-baseline sample (0 = skip)")
@@ -150,6 +150,8 @@ def main():
     if args.scaling is None:
         args.scaling = "strong" if args.gpus > 1 else "weak"
     if args.workload == "cnv" and not args.chunks:
+        if args.first_chunk is None:
+            args.first_chunk = 0.5
         args.chunks = 3  # (measured: 2 / 3 / 4 / 6 chunks = 6.6 / 6.2 / 7.4 / 8.1 ms: 214 MB cross the link in 3.9 ms; the read stage of an SV chunk
         # is as long as its slowest event -- a breakpoint pile-up of a thousand records in one workgroup -- so small chunks cost more in total)
     if args.workload == "cnv" and "--last-chunk" not in " ".join(sys.argv):
@@ -237,6 +239,13 @@ def main():
         # chunk -- on the small chunks of config 5 the host's queueing IS on the critical path)
         eng.prof_enable([K_SITE_SCAN])
         eng.prof_reset()
+        # (the cyclic collector stays out of the timed region, as it stays out of the product's phasing calls -- session.no_gc_pauses: a full
+        # collection walks every container this process holds, the generator's tables' wrappers included, and lands in whichever step crosses
+        # the allocation threshold)
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         c0 = time.process_time()
@@ -244,6 +253,8 @@ def main():
             res = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         timed.host_cpu_s = (time.process_time() - c0) / max(1, args.steps)  # CPU seconds of this rank's process per step, all its threads
         timed.per_rank = [elapsed]
         if dist is not None:

@@ -186,10 +186,12 @@ class BenchLoad:
 
 def link_bytes(pv) -> int:
     """bytes of one table in the link form (uz_reads_packed_view), column by column"""
-    lists_f = bool(pv.n_low) or bool(pv.tup and pv.tup_n_low)
-    fixed = ((2 if pv.pair_d8 else 5 if pv.mate_d8 else 7) if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup or flag .. aux
-    return (int(pv.n_segs) * fixed + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
-            + ((0 if pv.tup else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
+    dic = bool(pv.tup) or bool(pv.tup8)
+    lists_f = bool(pv.n_low) or bool(dic and pv.tup_n_low)
+    fixed = ((2 if pv.pair_d8 else 5 if pv.mate_d8 else 7) if pv.start_d8 else 8 if pv.start_d else 16) + (4 if pv.end else 0) + (2 if pv.umask else 0) + (1 if pv.tup8 else 2 if pv.tup else 8)  # start, tlen, mate, qname | end | umask | tup8 / tup or flag .. aux
+    t8 = (512 + 2 * int(pv.n_tup_esc) + 4 * ((int(pv.n_segs) + 1023) // 1024 + 1)) if pv.tup8 else 0  # hot table, escape list, span offsets
+    return (int(pv.n_segs) * fixed + t8 + int(pv.n_tup) * 11 + int(pv.n_esc16) * 12 + int(pv.n_cigar_total) * 4
+            + ((0 if dic else int(pv.n_segs)) + int(pv.n_qlow_pos) * (2 if pv.qlow_pos_wide else 1) if lists_f else int(pv.n_row_units) * 4)
             + (int(pv.n_seq_units) * 8 + int(pv.n_exc) * 7 if pv.seq2 else int(pv.n_seq_units) * 16)
             + (int(pv.n_bl) * (2 if pv.bl_wide else 1) + (int(pv.n_bl) + 3) // 4 + (int(pv.n_tup) if pv.tup_n_bl else int(pv.n_segs) if pv.bl_n else 0))
             + ((int(pv.n_pk_spans) + 1) * 88 if pv.pk_sums else 0))  # (the packer's span sums: uz_types.h pk_sums)

@@ -114,7 +114,7 @@ def test_config3_100k_resident_vs_oracle_and_properties(engine, snv100k):
 def test_config3_100k_staged_equals_resident(engine, snv100k):
     w = snv100k
     out, n_chunks, st = _staged(engine, w["load"], w["P"], w["fid"])
-    assert n_chunks == 7  # shard.chunk_plan for 100 k DNMs (the first chunk half-size)
+    assert n_chunks == 5  # shard.chunk_plan for 100 k DNMs (round 5: fewer, larger chunks)
     assert st["records"] > 50_000_000
     _same(out, w["res"], what="staged (pipelined, 7 chunks) vs resident")
 

@@ -25,7 +25,8 @@ def assert_same(a, b):
     n = int(va.n_segs)
     sizes = {"cigar": int(va.n_cigar_total), "seq2": 8 * int(va.n_seq_units), "exc_rec": int(va.n_exc), "exc_pos": int(va.n_exc), "exc_code": int(va.n_exc),
              "qlow_pos": int(va.n_qlow_pos) * (2 if va.qlow_pos_wide else 1), "esc16_key": int(va.n_esc16), "esc16_val": int(va.n_esc16),
-             "qlow": 4 * int(va.n_row_units), "contig_off": int(va.n_contigs) + 1, "max_span": int(va.n_contigs)}
+             "qlow": 4 * int(va.n_row_units), "contig_off": int(va.n_contigs) + 1, "max_span": int(va.n_contigs),
+             "tup_hot": 256, "tup_esc": int(va.n_tup_esc), "tup_esc_off": (n + abi.TUP8_SPAN - 1) // abi.TUP8_SPAN + 1}
     for k in a.arrays:
         m = sizes.get(k, int(va.n_tup) if k.startswith("tup_") else n)
         assert np.array_equal(a.arrays[k][:m], b.arrays[k][:m]), k
@@ -177,7 +178,7 @@ def test_sv_batch_form_wide_fetches_stage_no_units(workload):
     assert_same(got, want)
     plain, _ = three_step(workload["bam"], fc, flo, fhi, fex, 20)
     assert int(got.view.n_seq_units) < int(plain.view.n_seq_units) // 2  # most of the records only a wide fetch returns keep no unit
-    um = got.arrays["tup_umask"][got.arrays["tup"][: int(got.view.n_segs)]]
+    um = got.arrays["tup_umask"][abi.tup_column(got)]
     assert (um == 0).sum() > int(got.view.n_segs) // 3
 
 

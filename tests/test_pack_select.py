@@ -176,7 +176,7 @@ def test_selection_is_what_the_fetches_return_and_the_oracle_needs_nothing_else(
     for a, b in zip(bounds[:-1], bounds[1:]):
         fc, flo, fhi = fetch_points(dn.contig[a:b], dn.start[a:b], np.zeros(b - a, np.uint8), sc.pos, ho[a: b + 1], hi, P)
         part, idx = src.select(fc, flo, fhi, want_index=True, lists=out_lists, with_end=None if out_lists else True)
-        assert ("tup" in part.arrays) and part.view.n_tup < 2000  # the small columns travel as a dictionary
+        assert ("tup" in part.arrays or "tup8" in part.arrays) and part.view.n_tup < 2000  # the small columns travel as a dictionary
         part.arrays.update(abi.small_columns(part)); part.arrays.update(abi.wide_columns(part))
         # brute force: overlap of any fetch, then the closure under mate
         keep = np.zeros(N, bool)
@@ -478,7 +478,7 @@ def test_span_sums_of_a_packed_view_are_the_running_sums_of_its_columns():
     n = int(v.n_segs)
     assert n > 1500 and "pk_sums" in a and int(v.n_pk_spans) == abi.pk_spans(n) == (n + 1023) // 1024
     S = a["pk_sums"].reshape(-1, abi.PK_SUMS)
-    t = a["tup"][:n].astype(np.int64)
+    t = abi.tup_column(sel).astype(np.int64)
     ls, nc, ax = a["tup_l_seq"][t].astype(np.int64), a["tup_n_cigar"][t].astype(np.int64), a["tup_aux"][t].astype(np.int64)
     nl, um = a["tup_n_low"][t].astype(np.int64), a["tup_umask"][t].astype(np.int64)
     nb = a["tup_n_bl"][t].astype(np.int64) if "tup_n_bl" in a else np.zeros(n, np.int64)
@@ -501,3 +501,28 @@ def test_span_sums_of_a_packed_view_are_the_running_sums_of_its_columns():
     want = run[np.minimum(np.arange(S.shape[0]) * 1024, n)]
     assert np.array_equal(S.astype(np.int64), want)
     assert S[-1, 0] == int(v.n_cigar_total) + int(v.n_cigar_omitted) and S[-1, 1] == int(v.n_row_units) and S[-1, 9] == S[-1, 10]
+
+
+def test_the_dictionary_index_in_one_byte_round_trips():
+    """abi.compact_tup (uz_types.h tup8): the 255 most frequent combinations by a byte, the rest through the escape list, escapes counted per
+    span of 1 024 records -- rebuilt, the 16-bit index is the one that went in; a table with more than 255 combinations in use escapes some"""
+    rng = np.random.default_rng(11)
+    for n, n_tup, skew in ((0, 1, 1.0), (1, 1, 1.0), (1023, 40, 1.0), (1024, 300, 1.2), (1025, 3000, 1.1), (70001, 5000, 1.05)):
+        p = 1.0 / np.arange(1, n_tup + 1) ** skew
+        tup = rng.choice(n_tup, size=n, p=p / p.sum()).astype(np.uint16)
+        v = abi.ReadsPackedView()
+        arr = np.zeros(max(1, n), np.uint16)
+        arr[:n] = tup
+        v.n_segs, v.n_tup, v.tup = n, n_tup, arr.ctypes.data
+        held = abi.Held(v, {"tup": arr})
+        assert abi.compact_tup(held)
+        a = held.arrays
+        assert "tup" not in a and not held.view.tup and held.view.tup8
+        assert np.array_equal(abi.tup_column(held), tup)
+        n_esc = int(held.view.n_tup_esc)
+        assert (n_esc > 0) == (np.unique(tup).size > 255)
+        nsp = (n + abi.TUP8_SPAN - 1) // abi.TUP8_SPAN
+        off = a["tup_esc_off"][: nsp + 1]
+        assert off[0] == 0 and int(off[-1]) == n_esc and np.all(np.diff(off.astype(np.int64)) >= 0)
+        for b in range(nsp):
+            assert int(off[b + 1] - off[b]) == int((a["tup8"][b * abi.TUP8_SPAN: min(n, (b + 1) * abi.TUP8_SPAN)] == 255).sum())

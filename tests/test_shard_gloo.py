@@ -130,7 +130,7 @@ def test_strong_split_two_ranks_equal_one_rank(tmp_path):
 def test_chunk_plan_of_the_eight_gpu_strong_split():
     """BASELINE configs[3]: 100 k DNMs over 8 GPUs = 12.5 k per rank; the staged pass of a shard that small runs TWO chunks, the second
     0.6 x the first (round 5: 1 / 2 equal / 2 with 0.6 / 3 / 4 chunks = 2.75 / 2.88 / 2.57 / 2.75 / 3.10 ms; round 4, with slower kernels,
-    chose three), the single-GPU pass seven"""
+    chose three), the single-GPU pass five"""
     from unfazed_amd import shard
     b = shard.shard_bounds(100000, 8)
     assert [b[r + 1] - b[r] for r in range(8)] == [12500] * 8
@@ -140,8 +140,11 @@ def test_chunk_plan_of_the_eight_gpu_strong_split():
         # the last chunk is the small one: nothing hides its read stage
         assert abs((cuts[2] - cuts[1]) - 0.6 * (cuts[1] - cuts[0])) <= 2
     one = shard.chunk_plan(100000)
-    assert len(one) == 8 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))  # seven chunks for the 100 k of one GPU, the first half-size
-    assert min(y - x for x, y in zip(one[1:-1], one[2:-1])) >= 10000 and 2 * one[1] - (one[2] - one[1]) in (-2, -1, 0, 1, 2)
+    assert len(one) == 6 and one[-1] == 100000 and all(y > x for x, y in zip(one, one[1:]))  # five chunks for the 100 k of one GPU (round 5), the last 0.7 x the others
+    sizes = [y - x for x, y in zip(one, one[1:])]
+    assert max(sizes[:4]) - min(sizes[:4]) <= 2 and abs(sizes[4] - 0.7 * sizes[0]) <= 2
+    half = shard.chunk_plan(50000)  # (a batch of fewer than four chunks' worth: three chunks, the first half-size)
+    assert len(half) == 4 and abs(2 * half[1] - (half[2] - half[1])) <= 2
     assert shard.chunk_plan(0) == [0, 0] and shard.chunk_plan(1) == [0, 1] and shard.chunk_plan(3, 8)[-1] == 3
     assert shard.chunk_plan(100000, 16)[-1] == 100000 and len(shard.chunk_plan(100000, 16)) == 17
 

@@ -237,3 +237,79 @@ def test_span_sums_from_the_packer(engine):
     again = engine.reads_headers(rid, n)
     engine.free_reads(rid)
     assert np.array_equal(again["start"], own["start"])
+
+
+def test_the_dictionary_index_in_one_byte(engine):
+    """uz_types.h tup8: the device rebuilds the 16-bit index from the byte column, the hot table and the escape list before the header build reads
+    it -- the same table as from `tup` (headers; the read stage's answers are held against the resident pass by every staged test of the suite) --
+    and refuses a form that contradicts itself: escapes that are not where the span offsets say, an index beyond the dictionary."""
+    rh, arrs, N = _odd_table(60)
+    pk = io_native.pack_reads(rh, 20, with_end=True)
+    src = io_native.ReadsSource(pk)
+    contig_of = np.searchsorted(arrs["contig_off"], np.arange(N), side="right") - 1
+    fc = np.unique(contig_of).astype(np.int32)
+    fetches = (fc, np.zeros(fc.size, np.int32), np.full(fc.size, 2 ** 31 - 1, np.int32))
+    plain, idx = src.select(*fetches, want_index=True, tup8=False)
+    n = idx.size
+    assert "tup" in plain.arrays
+    rid = engine.upload_reads_packed(plain)
+    want = engine.reads_headers(rid, n)
+    engine.free_reads(rid)
+
+    def fresh(hot_keep=None):
+        part, _ = src.select(*fetches, want_index=True, tup8=False)
+        if hot_keep is not None:  # (few enough hot entries that the escape list is exercised on this small table)
+            t = part.arrays["tup"][:n]
+            keep = np.argsort(-np.bincount(t, minlength=int(part.view.n_tup)), kind="stable")[:hot_keep]
+            part.arrays["tup"][:n] = t  # unchanged; the cut happens below
+            assert abi.compact_tup(part)
+            a = part.arrays
+            full = abi.tup_column(part)
+            # rebuild the form with only `hot_keep` hot entries
+            lut = np.full(int(part.view.n_tup), 255, np.uint8)
+            lut[keep] = np.arange(keep.size, dtype=np.uint8)
+            a["tup8"][:n] = lut[full]
+            esc = a["tup8"][:n] == 255
+            ne = int(esc.sum())
+            e16 = np.zeros(max(1, ne), np.uint16)
+            e16[:ne] = full[esc]
+            off = np.zeros((n + abi.TUP8_SPAN - 1) // abi.TUP8_SPAN + 1, np.uint32)
+            off[1:] = np.cumsum(np.add.reduceat(esc.astype(np.int64), np.arange(0, n, abi.TUP8_SPAN)))
+            a["tup_hot"][:] = 0
+            a["tup_hot"][: keep.size] = keep
+            a["tup_esc"], a["tup_esc_off"] = e16, off
+            part.view.tup_esc, part.view.tup_esc_off, part.view.n_tup_esc = e16.ctypes.data, off.ctypes.data, ne
+        else:
+            assert abi.compact_tup(part)
+        return part
+    for hot_keep in (None, 3):
+        part = fresh(hot_keep)
+        assert "tup8" in part.arrays and "tup" not in part.arrays and (hot_keep is None or int(part.view.n_tup_esc) > 100)
+        rid = engine.upload_reads_packed(part)
+        got = engine.reads_headers(rid, n)
+        engine.free_reads(rid)
+        for k in ("start", "end", "tlen", "mate", "qname"):
+            assert np.array_equal(got[k], want[k]), (k, hot_keep)
+    # an escape moved from one span to the next: the offsets still ascend to the total, but the spans do not hold what they say
+    part = fresh(3)
+    off = part.arrays["tup_esc_off"]
+    assert off.size >= 3 and off[1] > 0
+    off[1] -= 1
+    with pytest.raises(UnfazedHipError):
+        rid = engine.upload_reads_packed(part)
+        engine.wait_reads(rid)
+        engine.reads_headers(rid, n)
+    part = fresh(3)
+    part.arrays["tup_esc"][0] = 65535  # an index beyond the dictionary
+    with pytest.raises(UnfazedHipError):
+        rid = engine.upload_reads_packed(part)
+        engine.wait_reads(rid)
+        engine.reads_headers(rid, n)
+    part = fresh(3)
+    part.arrays["tup_esc_off"][-1] += 1  # offsets that do not end at the total: refused before anything is copied
+    with pytest.raises(UnfazedHipError):
+        engine.upload_reads_packed(part)
+    part = fresh(3)  # ... and the untouched form still goes through
+    rid = engine.upload_reads_packed(part)
+    engine.wait_reads(rid)
+    engine.free_reads(rid)

@@ -190,6 +190,8 @@ class ReadsPackedView(C.Structure):
         ("reserved2", C.c_int32),
         # span sums (uz_types.h pk_sums): the running sums the device's header build lays the records out by, from the packer
         ("pk_sums", _p), ("n_pk_spans", C.c_int64),
+        # the dictionary index in one byte (uz_types.h tup8): the most frequent 255 combinations + an escape list, instead of `tup`
+        ("tup8", _p), ("tup_hot", _p), ("tup_esc", _p), ("tup_esc_off", _p), ("n_tup_esc", C.c_int64),
     ]
 
 
@@ -216,9 +218,12 @@ def row_units(l_seq):
     return (np.asarray(l_seq).astype(np.int64) + 31) >> 5
 
 
+TUP8_SPAN = 1024  # uz_types.h UZ_TUP8_SPAN
+
+
 def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_seq_units=None, n_exc=None, n_qlow_pos=None,
                       qlow_pos_wide=False, with_end=True, with_umask=False, cigar_omitted=None, n_tup=None, n_esc16=None, start8=False,
-                      narrow8=False, pair8=False, n_bl=None, n_bl_units=0, bl_wide=False, pk_sums=False) -> "Held":
+                      narrow8=False, pair8=False, n_bl=None, n_bl_units=0, bl_wide=False, pk_sums=False, tup_off_link=False) -> "Held":
     """A packed view over freshly allocated, writable arrays (alloc(nbytes) -> uint8 array; default numpy).
     n_seq_units: row units of the records that carry bases (default: all of them).
     n_exc: None = four-bit base rows (seq4); a number = two-bit rows (seq2) with that many listed bases (exc_*).
@@ -273,7 +278,9 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     v.n_segs, v.n_contigs, v.n_cigar_total, v.n_row_units, v.n_seq_units = n, n_contigs, n_cigar_total, n_row_units, n_seq_units
     v.n_exc = 0 if n_exc is None else n_exc
     if n_tup is not None:
-        arrs["tup"] = alloc(2 * max(1, n))[: 2 * max(1, n)].view(np.uint16)
+        # (tup_off_link: the 16-bit index is an intermediate -- compact_tup() replaces it by the one-byte form -- and stays out of the caller's
+        # page-locked block)
+        arrs["tup"] = (np.zeros(2 * max(1, n), np.uint8) if tup_off_link else alloc(2 * max(1, n)))[: 2 * max(1, n)].view(np.uint16)
         for name, dt in (("tup_flag", np.uint16), ("tup_l_seq", np.uint16), ("tup_n_cigar", np.uint16), ("tup_mapq", np.uint8),
                          ("tup_aux", np.uint8)) + ((("tup_n_low", np.uint8),) if n_qlow_pos is not None else ()) + (
                                  (("tup_umask", np.uint16),) if with_umask else ()):
@@ -314,6 +321,43 @@ def packed_view_alloc(n, n_contigs, n_cigar_total, n_row_units, alloc=None, n_se
     for k, a in arrs.items():
         setattr(v, k, a.ctypes.data)
     return Held(v, arrs)
+
+
+def compact_tup(held: "Held", alloc=None) -> bool:
+    """The dictionary index of a packed view from two bytes per record to one (uz_types.h tup8): the 255 most frequent combinations by a byte,
+    the rest through an escape list.  In place: `tup` leaves the view, tup8 / tup_hot / tup_esc / tup_esc_off (from `alloc`) enter it.
+    -> False (view untouched) when it has no dictionary form."""
+    a, v = held.arrays, held.view
+    if "tup" not in a or not v.tup:
+        return False
+    if alloc is None:
+        alloc = lambda nbytes: np.zeros(max(16, nbytes), dtype=np.uint8)  # noqa: E731
+    n, n_tup = int(v.n_segs), int(v.n_tup)
+    tup = a["tup"][:n]
+    cnt = np.bincount(tup, minlength=max(1, n_tup))
+    hot = np.argsort(-cnt, kind="stable")[:255]
+    hot = hot[cnt[hot] > 0]
+    lut = np.full(max(1, cnt.size), 255, np.uint8)
+    lut[hot] = np.arange(hot.size, dtype=np.uint8)
+    t8 = alloc(max(1, n))[: max(1, n)]
+    t8[:n] = lut[tup]
+    esc_mask = t8[:n] == 255
+    n_esc = int(esc_mask.sum())
+    esc = alloc(2 * max(1, n_esc))[: 2 * max(1, n_esc)].view(np.uint16)
+    esc[:n_esc] = tup[esc_mask]
+    nsp = (n + TUP8_SPAN - 1) // TUP8_SPAN
+    off = alloc(4 * (nsp + 1))[: 4 * (nsp + 1)].view(np.uint32)
+    off[0] = 0
+    if nsp:
+        off[1:] = np.cumsum(np.add.reduceat(esc_mask.astype(np.int64), np.arange(0, n, TUP8_SPAN)))
+    hot16 = alloc(512)[:512].view(np.uint16)
+    hot16[:] = 0
+    hot16[: hot.size] = hot.astype(np.uint16)
+    del a["tup"]
+    a.update(tup8=t8, tup_hot=hot16, tup_esc=esc, tup_esc_off=off)
+    v.tup = None
+    v.tup8, v.tup_hot, v.tup_esc, v.tup_esc_off, v.n_tup_esc = t8.ctypes.data, hot16.ctypes.data, esc.ctypes.data, off.ctypes.data, n_esc
+    return True
 
 
 def wide_columns(held: "Held") -> dict:
@@ -400,18 +444,31 @@ def _pair_columns(held: "Held", key, val) -> dict:
     return {"start": start.astype(np.int32), "tlen": tlen.astype(np.int32), "mate": mate.astype(np.int32), "qname": qname.astype(np.uint32)}
 
 
+def tup_column(held: "Held") -> np.ndarray:
+    """the 16-bit dictionary index of every record, from either form (tup, or tup8 + hot table + escape list: what the device rebuilds)"""
+    a, n = held.arrays, int(held.view.n_segs)
+    if "tup" in a:
+        return a["tup"][:n]
+    t8 = a["tup8"][:n]
+    out = a["tup_hot"][t8.astype(np.int64)].astype(np.uint16)
+    esc = t8 == 255
+    assert int(esc.sum()) == int(held.view.n_tup_esc)
+    out[esc] = a["tup_esc"][: int(held.view.n_tup_esc)]
+    return out
+
+
 def small_columns(held: "Held") -> dict:
     """flag, l_seq, n_cigar, mapq, aux (and n_low) of a packed view as plain per-record arrays, whichever way it carries them
     (the dictionary form keeps a 16-bit index per record and a table of the combinations)."""
     a, n = held.arrays, int(held.view.n_segs)
     names = ["flag", "l_seq", "n_cigar", "mapq", "aux"] + (["n_low"] if ("n_low" in a or "tup_n_low" in a) else []) + (
         ["umask"] if ("umask" in a or "tup_umask" in a) else [])
-    if "tup" not in a:
+    if "tup" not in a and "tup8" not in a:
         out = {k: a[k][:n] for k in names}
         if "bl_n" in a:
             out["bl_n"] = a["bl_n"][:n]
         return out
-    t = a["tup"][:n].astype(np.int64)
+    t = tup_column(held).astype(np.int64)
     assert n == 0 or t.max() < int(held.view.n_tup)
     out = {k: a["tup_" + k][t] for k in names}
     if "tup_n_bl" in a:  # the list form of the bases: listed bases per record (0: its units travel as rows)

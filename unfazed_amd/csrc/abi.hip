@@ -722,12 +722,13 @@ static void check_packed_view(const uz_reads_packed_view *v) {
     UZ_REQUIRE(v->n_seq_units == 0 || v->seq2 || v->seq4, UZ_E_ARG, "n_seq_units > 0 but neither seq4 nor seq2 is set");
     if (v->seq2) UZ_REQUIRE(v->n_exc >= 0 && (v->n_exc == 0 || (v->exc_rec && v->exc_pos && v->exc_code)), UZ_E_ARG, "bad exc_* columns");
     UZ_REQUIRE(!(v->qlow && v->n_low), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form (n_low / qlow_pos), not both");
-    const bool v_lists = v->n_low != nullptr || (v->tup && v->tup_n_low);
+    const bool v_dict = v->tup != nullptr || v->tup8 != nullptr;
+    const bool v_lists = v->n_low != nullptr || (v_dict && v->tup_n_low);
     UZ_REQUIRE(v->n_segs == 0 || v->qlow || v_lists, UZ_E_ARG, "neither qlow nor n_low is set");
     UZ_REQUIRE(!(v->qlow && v_lists), UZ_E_ARG, "a packed table has the quality plane (qlow) OR its list form, not both");
     if (v_lists) UZ_REQUIRE(v->n_qlow_pos >= 0 && (v->n_qlow_pos == 0 || v->qlow_pos), UZ_E_ARG, "bad qlow_pos column");
     UZ_REQUIRE(!(v->umask || v->tup_umask) || v_lists, UZ_E_ARG, "umask (staged units) needs the list form of the qualities (n_low / qlow_pos)");
-    UZ_REQUIRE(!v->tup_umask || (v->tup && !v->umask), UZ_E_ARG, "tup_umask needs tup, and umask NULL");
+    UZ_REQUIRE(!v->tup_umask || (v_dict && !v->umask), UZ_E_ARG, "tup_umask needs tup, and umask NULL");
     if (v->start_d || v->start_d8) {
         UZ_REQUIRE(!(v->start_d && v->start_d8), UZ_E_ARG, "start_d and start_d8 are both set");
         const bool n8 = v->mate_d8 != nullptr || v->qname_d8 != nullptr;
@@ -737,12 +738,18 @@ static void check_packed_view(const uz_reads_packed_view *v) {
         UZ_REQUIRE((v->pair_d8 || (v->tlen_s && (n8 || (v->mate_d && v->qname_d)))) && v->n_esc16 >= 0 && (v->n_esc16 == 0 || (v->esc16_key && v->esc16_val)), UZ_E_ARG, "bad 16-bit difference columns");
         UZ_REQUIRE(!v->start && !v->tlen && !v->mate && !v->qname, UZ_E_ARG, "start_d / start_d8 is set: start / tlen / mate / qname must be NULL");
     }
-    if (v->tup) {
+    if (v->tup8) { // the index in one byte: hot table, escape list, escapes in front of every span (ascending from 0 to the total)
+        UZ_REQUIRE(!v->tup && v->tup_hot && v->tup_esc_off && v->n_tup_esc >= 0 && v->n_tup_esc <= v->n_segs && (v->n_tup_esc == 0 || v->tup_esc), UZ_E_ARG, "bad tup8 form");
+        const int64_t nsp = (v->n_segs + UZ_TUP8_SPAN - 1) / UZ_TUP8_SPAN;
+        UZ_REQUIRE(v->tup_esc_off[0] == 0 && (int64_t)v->tup_esc_off[nsp] == v->n_tup_esc, UZ_E_RANGE, "tup_esc_off does not run from 0 to n_tup_esc");
+        for (int64_t b = 0; b < nsp; b++) UZ_REQUIRE(v->tup_esc_off[b] <= v->tup_esc_off[b + 1], UZ_E_RANGE, "tup_esc_off does not ascend");
+    }
+    if (v_dict) {
         UZ_REQUIRE(v->n_tup >= 1 && v->n_tup <= 65536 && v->tup_flag && v->tup_l_seq && v->tup_n_cigar && v->tup_mapq && v->tup_aux, UZ_E_ARG, "bad tup_* table");
         UZ_REQUIRE(!v->flag && !v->l_seq && !v->n_cigar && !v->mapq && !v->aux && !v->n_low, UZ_E_ARG, "tup is set: flag / l_seq / n_cigar / mapq / aux / n_low must be NULL");
     }
     if (v->bl_n || v->tup_n_bl) {
-        UZ_REQUIRE(!(v->bl_n && v->tup_n_bl) && (!v->tup_n_bl || v->tup), UZ_E_ARG, "bl_n OR tup_n_bl (the latter with tup)");
+        UZ_REQUIRE(!(v->bl_n && v->tup_n_bl) && (!v->tup_n_bl || v_dict), UZ_E_ARG, "bl_n OR tup_n_bl (the latter with tup)");
         UZ_REQUIRE((v->umask || v->tup_umask) && v_lists && (v->seq2 || v->n_seq_units == 0) && !v->seq4, UZ_E_ARG,
                    "the list form of the bases (bl_*) needs unit masks, the list form of the qualities and two-bit rows");
         UZ_REQUIRE(v->n_bl >= 0 && v->n_bl_units >= 0 && v->n_bl_units <= v->n_bl && (v->n_bl == 0 || (v->bl_pos && v->bl_code)), UZ_E_ARG, "bad bl_* columns");
@@ -761,7 +768,7 @@ static void check_packed_view(const uz_reads_packed_view *v) {
         for (int64_t b = 0; b < nb && ok; b++)
             for (int k = 0; k < UZ_PK_SUMS; k++)
                 if (k != 5 && k != 6) ok &= S[(size_t)(b + 1) * UZ_PK_SUMS + k] >= S[(size_t)b * UZ_PK_SUMS + k];
-        const bool lists_f = v->n_low != nullptr || (v->tup && v->tup_n_low);
+        const bool lists_f = v->n_low != nullptr || (v_dict && v->tup_n_low);
         ok = ok && T[0] == (uint64_t)(v->n_cigar_total + v->n_cigar_omitted) && T[1] == (uint64_t)v->n_row_units && T[2] == (uint64_t)v->n_seq_units &&
              T[3] == (uint64_t)(lists_f ? v->n_qlow_pos : 0) && (!v->cigar_compact || T[4] == (uint64_t)v->n_cigar_total) && T[7] == (uint64_t)v->n_bl_units &&
              T[8] == (uint64_t)v->n_bl && T[9] == T[10];
@@ -787,9 +794,12 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     uint32_t *cigar_staged = nullptr;
     const bool two_bit = v->seq2 != nullptr;
     const size_t ne = two_bit ? (size_t)v->n_exc : 0;
-    const bool lists = v->n_low != nullptr || (v->tup && v->tup_n_low); // quality rows only for the records with bases (at their base-row position), written by the header build
-    const bool tupf = v->tup != nullptr;
+    const bool t8 = v->tup8 != nullptr; // the dictionary index in one byte: rebuilt into the 16-bit column's place by the header build's first kernel
+    const bool tupf = v->tup != nullptr || t8;
+    const bool lists = v->n_low != nullptr || (tupf && v->tup_n_low); // quality rows only for the records with bases (at their base-row position), written by the header build
     const size_t nt = tupf ? (size_t)v->n_tup : 0;
+    const size_t nte = t8 ? (size_t)v->n_tup_esc : 0, ntsp = t8 ? ((size_t)v->n_segs + UZ_TUP8_SPAN - 1) / UZ_TUP8_SPAN + 1 : 0;
+    uint8_t *d_tup8 = nullptr; uint16_t *t_hot = nullptr, *t_esc = nullptr; uint32_t *t_eoff = nullptr;
     uint16_t *tup = nullptr, *t_flag = nullptr, *t_ls = nullptr, *t_nc = nullptr, *t_um = nullptr; uint8_t *t_mq = nullptr, *t_ax = nullptr, *t_nl = nullptr;
     const size_t nql = lists ? (size_t)v->n_qlow_pos * (v->qlow_pos_wide ? 2 : 1) : 0;
     uint8_t *n_low = nullptr, *qpos = nullptr;
@@ -829,6 +839,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         if (tupf) {
             tup = cv.take<uint16_t>(n); t_flag = cv.take<uint16_t>(nt); t_ls = cv.take<uint16_t>(nt); t_nc = cv.take<uint16_t>(nt);
             t_mq = cv.take<uint8_t>(nt); t_ax = cv.take<uint8_t>(nt); t_nl = cv.take<uint8_t>(nt); t_um = cv.take<uint16_t>(nt);
+            if (t8) { d_tup8 = cv.take<uint8_t>(n); t_hot = cv.take<uint16_t>(256); t_esc = cv.take<uint16_t>(nte); t_eoff = cv.take<uint32_t>(ntsp); }
         }
         if (v->umask) umask_in = cv.take<uint16_t>(n);
         if (blf) { bl_n = cv.take<uint8_t>(v->bl_n ? n : 0); t_nbl = cv.take<uint8_t>(v->tup_n_bl ? nt : 0); bl_pos = cv.take<uint8_t>(nblp); bl_code = cv.take<uint8_t>(nblc + 4); }
@@ -873,7 +884,13 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
         col.mate = h2d(st, mate, v->mate, n); col.qname = h2d(st, qname, v->qname, n);
     }
     if (tupf) { // a 16-bit index per record + the table of combinations instead of nine bytes of small columns
-        col.tup = h2d(st, tup, v->tup, n);
+        if (t8) {
+            col.tup8 = h2d(st, d_tup8, v->tup8, n); col.tup_hot = h2d(st, t_hot, v->tup_hot, (size_t)256);
+            col.tup_esc = nte ? h2d(st, t_esc, v->tup_esc, nte) : t_esc; col.tup_esc_off = h2d(st, t_eoff, v->tup_esc_off, ntsp);
+            col.n_tup_esc = (int64_t)nte;
+            col.tup_out = tup; col.tup = tup; // (k_tup_expand writes it before anything reads it)
+        } else
+            col.tup = h2d(st, tup, v->tup, n);
         col.n_tup = (int64_t)nt;
         col.tup_flag = h2d(st, t_flag, v->tup_flag, nt); col.tup_l_seq = h2d(st, t_ls, v->tup_l_seq, nt); col.tup_n_cigar = h2d(st, t_nc, v->tup_n_cigar, nt);
         col.tup_mapq = h2d(st, t_mq, v->tup_mapq, nt); col.tup_aux = h2d(st, t_ax, v->tup_aux, nt);
@@ -925,6 +942,7 @@ static void reads_from_packed_host(uz_ctx *c, hipStream_t st, const uz_reads_pac
     {
         const void *t[8] = {col.tup, col.tup_flag, col.tup_l_seq, col.tup_n_cigar, col.tup_mapq, col.tup_aux, col.tup_n_low, col.tup_umask};
         for (int k = 0; k < 8; k++) r.col_t[k] = t[k];
+        r.col_t8[0] = col.tup8; r.col_t8[1] = col.tup_hot; r.col_t8[2] = col.tup_esc; r.col_t8[3] = col.tup_esc_off; r.col_ntesc = col.n_tup_esc;
         r.col_lists = col.lists;
         r.col_ntup = col.n_tup;
         const void *dd[10] = {col.start_d, col.tlen_s, col.mate_d, col.qname_d, col.esc16_key, col.esc16_val, col.start_d8, col.mate_d8, col.qname_d8, col.pair_d8};
@@ -957,6 +975,9 @@ static void build_staged(uz_ctx *c, hipStream_t st, ReadsDev &r) {
     col.tup = (const uint16_t *)r.col_t[0]; col.tup_flag = (const uint16_t *)r.col_t[1]; col.tup_l_seq = (const uint16_t *)r.col_t[2];
     col.tup_n_cigar = (const uint16_t *)r.col_t[3]; col.tup_mapq = (const uint8_t *)r.col_t[4]; col.tup_aux = (const uint8_t *)r.col_t[5];
     col.tup_n_low = (const uint8_t *)r.col_t[6]; col.tup_umask = (const uint16_t *)r.col_t[7]; col.lists = r.col_lists; col.n_tup = r.col_ntup;
+    col.tup8 = (const uint8_t *)r.col_t8[0]; col.tup_hot = (const uint16_t *)r.col_t8[1]; col.tup_esc = (const uint16_t *)r.col_t8[2];
+    col.tup_esc_off = (const uint32_t *)r.col_t8[3]; col.n_tup_esc = r.col_ntesc;
+    if (col.tup8) col.tup_out = const_cast<uint16_t *>(col.tup);
     col.start_d = (const int16_t *)r.col_d[0]; col.tlen_s = (const int16_t *)r.col_d[1]; col.mate_d = (const int16_t *)r.col_d[2];
     col.qname_d = (const int16_t *)r.col_d[3]; col.esc16_key = (const unsigned long long *)r.col_d[4]; col.esc16_val = (const int32_t *)r.col_d[5];
     col.start_d8 = (const uint8_t *)r.col_d[6];
@@ -1227,6 +1248,7 @@ int uz_reads_adopt_device(uz_ctx *c, const uz_reads_packed_view *v, int *id) {
         check_packed_view(v);
         UZ_REQUIRE(!v->cigar_compact, UZ_E_ARG, "uz_reads_adopt_device takes every CIGAR word (cigar_compact = 0): the caller's column IS the device's store");
         UZ_REQUIRE(!v->bl_n && !v->tup_n_bl, UZ_E_ARG, "uz_reads_adopt_device takes base rows: the list form of the bases (bl_*) is a form of the host link");
+        UZ_REQUIRE(!v->tup8, UZ_E_ARG, "uz_reads_adopt_device takes the 16-bit dictionary index: the one-byte form (tup8) is a form of the host link");
         UZ_REQUIRE(((uintptr_t)v->qlow | (uintptr_t)v->seq4 | (uintptr_t)v->seq2 | (uintptr_t)v->cigar) % 16 == 0, UZ_E_ARG, "device columns must be 16-byte aligned");
         ReadsDev r;
         r.live = true;

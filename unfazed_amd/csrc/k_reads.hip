@@ -1156,10 +1156,61 @@ __global__ __launch_bounds__(256) void k_patch_exc(int64_t n_exc, const uint32_t
 // (sized for the short spans whatever the table gets: 80 bytes per 1024 records)
 size_t uz_rec_scratch_bytes(int64_t n) { return (size_t)(((n + (1 << UZ_PK_SHIFT_SMALL) - 1) >> UZ_PK_SHIFT_SMALL) + 2) * (UZ_PK_SUMS + 1) * sizeof(unsigned long long); }
 
+// The dictionary index in one byte (uz_types.h tup8) back to the 16-bit column the header build reads: a workgroup per span of UZ_TUP8_SPAN
+// records, four records per lane (one 4-byte load, one 8-byte store); an escaped record's place in the escape list is the span's offset + the
+// escapes in front of it inside the span (a block scan of per-lane counts).  A span whose escapes are not the number its two offsets name, an
+// escape beyond the list, an index beyond the dictionary: hflags[0] (UZ_E_RANGE at the table's first use).  1 byte read + 2 written per record.
+__global__ __launch_bounds__(256) void k_tup_expand(int64_t n, const uint8_t *__restrict__ tup8, const uint16_t *__restrict__ hot, const uint16_t *__restrict__ esc,
+                                                    const uint32_t *__restrict__ esc_off, int64_t n_esc, int32_t n_tup, uint16_t *__restrict__ out, int32_t *hflags) {
+    __shared__ uint16_t s_hot[256];
+    __shared__ uint32_t s_wsum[4];
+    static_assert(UZ_TUP8_SPAN == 4 * 256, "four records per lane");
+    const int t = threadIdx.x;
+    s_hot[t] = hot[t];
+    const int64_t base = (int64_t)blockIdx.x * UZ_TUP8_SPAN + 4 * t;
+    uint32_t w = 0;
+    if (base + 4 <= n) w = *reinterpret_cast<const uint32_t *>(tup8 + base);
+    else for (int k = 0; k < 4; k++) if (base + k < n) w |= (uint32_t)tup8[base + k] << (8 * k);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) cnt += (base + k < n && ((w >> (8 * k)) & 0xFFu) == 255u) ? 1u : 0u;
+    // exclusive scan of cnt over the workgroup: within the wave by DPP-free shuffles, across the four waves through LDS
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o, 64); if ((t & 63) >= o) inc += v; }
+    if ((t & 63) == 63) s_wsum[t >> 6] = inc;
+    __syncthreads();
+    uint32_t before = inc - cnt;
+    for (int k = 0; k < (t >> 6); k++) before += s_wsum[k];
+    const uint32_t e0 = esc_off[blockIdx.x], e1 = esc_off[blockIdx.x + 1];
+    if (t == 255 && before + cnt != e1 - e0) hflags[0] = 1;
+    uint32_t at = e0 + before;
+    uint16_t v4[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t b = (w >> (8 * k)) & 0xFFu;
+        uint32_t val = s_hot[b];
+        if (b == 255u && base + k < n) {
+            if ((int64_t)at < n_esc && at < e1) val = esc[at];
+            else { val = 0; hflags[0] = 1; }
+            at++;
+        }
+        if (val >= (uint32_t)n_tup) { val = 0; if (base + k < n) hflags[0] = 1; }
+        v4[k] = (uint16_t)val;
+    }
+    if (base + 4 <= n) *reinterpret_cast<uint2 *>(out + base) = make_uint2((uint32_t)v4[0] | ((uint32_t)v4[1] << 16), (uint32_t)v4[2] | ((uint32_t)v4[3] << 16));
+    else for (int k = 0; k < 4; k++) if (base + k < n) out[base + k] = v4[k];
+}
+
 void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &col_in, void *off_scratch) {
     static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
     if (r.n <= 0) return;
     RecColumns col = col_in;
+    if (col.tup8) { // the one-byte dictionary index: the 16-bit column first (everything below reads col.tup)
+        hipLaunchKernelGGL(k_tup_expand, dim3((unsigned)((r.n + UZ_TUP8_SPAN - 1) / UZ_TUP8_SPAN)), dim3(256), 0, st, (int64_t)r.n, col.tup8, col.tup_hot, col.tup_esc,
+                           col.tup_esc_off, col.n_tup_esc, (int32_t)col.n_tup, col.tup_out, c->hflags);
+        col.tup = col.tup_out;
+    }
     col.pk_shift = uz_pk_shift(r.n);
     const unsigned nb = (unsigned)((r.n + (1 << col.pk_shift) - 1) >> col.pk_shift);
     unsigned long long *sums = (unsigned long long *)off_scratch;

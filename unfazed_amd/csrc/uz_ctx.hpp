@@ -157,6 +157,8 @@ struct ReadsDev {
     const void *col_ptrs[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void *build_scratch = nullptr;
     const void *col_t[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // tup, tup_flag, tup_l_seq, tup_n_cigar, tup_mapq, tup_aux, tup_n_low, tup_umask
+    const void *col_t8[4] = {nullptr, nullptr, nullptr, nullptr}; // tup8, tup_hot, tup_esc, tup_esc_off (the one-byte index: col_t[0] is then where the 16-bit column is rebuilt)
+    int64_t col_ntesc = 0;
     int32_t col_lists = 0;
     int64_t col_ntup = 0;
     const void *col_d[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // start_d, tlen_s, mate_d, qname_d, esc16_key, esc16_val, start_d8, mate_d8, qname_d8, pair_d8
@@ -337,6 +339,12 @@ struct RecColumns {
     const uint8_t *tup_mapq = nullptr, *tup_aux = nullptr, *tup_n_low = nullptr;
     const uint16_t *tup_umask = nullptr;
     int64_t n_tup = 0; // entries of the dictionary (0: not known)
+    // the index in one byte (uz_types.h tup8): the header build first rebuilds the 16-bit column into tup_out (k_tup_expand) and reads it as `tup`
+    const uint8_t *tup8 = nullptr;
+    const uint16_t *tup_hot = nullptr, *tup_esc = nullptr;
+    const uint32_t *tup_esc_off = nullptr;
+    int64_t n_tup_esc = 0;
+    uint16_t *tup_out = nullptr;
     // bases as lists (uz_types.h: bl_*): per record the number of listed bases (plain column or through the dictionary), their query indices and
     // two-bit codes; seq4_out: the device's base rows (the header build writes the units of the listed records, behind the n_seq_link units that
     // travelled as rows)

@@ -503,8 +503,9 @@ class ReadsSource:
         self.threads = threads
 
     def select(self, contig, lo, hi, alloc=None, want_index=False, all_bases=False, lists=True, with_end=None, extra=None, cigar_compact=True,
-               tuples=True, d16=True, start8=True, wide_no_units=False, narrow8=True, pair8=True, base_lists=None):
-        """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.  Records that
+               tuples=True, d16=True, start8=True, wide_no_units=False, narrow8=True, pair8=True, base_lists=None, tup8=None):
+        """The records the fetches (contig[k], lo[k], hi[k]) return plus their mates, as a packed table.
+        tup8 (default: on, UZ_TUP8=0 turns it off): the dictionary index in one byte (uz_types.h tup8; abi.compact_tup) -- what crosses the link.  Records that
         are reachable only as mates are staged without their bases unless all_bases (--no-extended batches need them).
         lists: the qualities as counts + listed positions (what the host link carries); False keeps the plane (plane sources only).
         extra (uint16 per fetch, staging.fetch_points(..., allele_len=)): stage only the 32-base units of a record's rows that
@@ -522,6 +523,8 @@ class ReadsSource:
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
+        if tup8 is None:
+            tup8 = os.environ.get("UZ_TUP8", "1") != "0"
         sel = C.c_void_p()
         masks = extra is not None and lists and not all_bases
         if masks:
@@ -552,11 +555,13 @@ class ReadsSource:
                                                      else self.lib.uz_select_n_esc16_start8 if start8 else self.lib.uz_select_n_esc16)(sel)) if d16 else None,
                                         start8=bool(d16 and start8), narrow8=bool(d16 and start8 and narrow8), pair8=pair8,
                                         n_bl=n_bl if n_bl >= 0 else None, n_bl_units=int(self.lib.uz_select_n_bl_units(sel)), bl_wide=bool(self.lib.uz_select_bl_wide(sel)),
-                                        pk_sums=_PK_SUMS)
+                                        pk_sums=_PK_SUMS, tup_off_link=bool(tup8 and n_tup >= 0))
             idx = np.zeros(max(1, n), np.int32) if want_index else None
             _check(self.lib, self.lib.uz_reads_select_fill(sel, int(self.threads), out.ref(),
                                                            idx.ctypes.data if want_index else None))
             block_sums(out, self.threads)  # (the span sums the device's header build packs from: uz_types.h pk_sums)
+            if tup8 and n_tup >= 0:
+                abi.compact_tup(out, alloc)
             out.qname_map = None
             if pair8:
                 out.qname_map = np.zeros(max(1, int(self.lib.uz_select_n_new_names(sel))), np.uint32)
@@ -742,7 +747,7 @@ class BamSource:
         self.tlen_head = head[: int(k)].copy()
 
     def select(self, contig, lo, hi, min_base_qual: int, alloc=None, all_bases=False, lists=True, extra=None, pool=None, wide_no_units=False,
-               inflate=None, inflate_alloc=None, inflate_max_bytes=16 << 30, base_lists=None):
+               inflate=None, inflate_alloc=None, inflate_max_bytes=16 << 30, base_lists=None, tup8=None):
         """-> abi.Held packed view (the same columns, byte for byte, as ReadsSource.select's defaults on the region-decoded table).
         `.io_stats` / `.timing` / `.qnames` ride on the returned object.
         pool (engine.PinnedPool): the columns are carved from ONE page-locked block of exactly the planned size (they cross the link
@@ -752,6 +757,8 @@ class BamSource:
         plan, and the walk copies records out of what comes back (each block still held against its CRC-32) instead of inflating;
         inflate_alloc(nbytes) -> uint8 array: where the gathered and the inflated bytes go (pinned memory for full link speed); a batch whose
         blocks inflate to more than inflate_max_bytes stays with the host's inflate (that much memory would have to be page-locked)."""
+        if tup8 is None:
+            tup8 = os.environ.get("UZ_TUP8", "1") != "0"
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
@@ -805,9 +812,12 @@ class BamSource:
         out = abi.packed_view_alloc(n, len(self.contigs), n_cig + n_om, n_units, alloc, n_seq_units=n_seq, n_exc=n_exc,
                                     n_qlow_pos=n_qpos if lists else None, qlow_pos_wide=bool(wide) and lists, with_end=False, with_umask=bool(has_um),
                                     cigar_omitted=n_om, n_tup=n_tup, n_esc16=n_esc, start8=True, pair8=True,
-                                    n_bl=n_bl if has_bl else None, n_bl_units=n_blu, bl_wide=bool(wide) and bool(has_bl), pk_sums=_PK_SUMS)
+                                    n_bl=n_bl if has_bl else None, n_bl_units=n_blu, bl_wide=bool(wide) and bool(has_bl), pk_sums=_PK_SUMS,
+                                    tup_off_link=bool(tup8))
         _check(self.lib, self.lib.uz_stage_fill(sh.ptr, int(self.threads), out.ref()))
         block_sums(out, self.threads)  # (the span sums the device's header build packs from: uz_types.h pk_sums)
+        if tup8:
+            abi.compact_tup(out, alloc)  # (the dictionary index in one byte: uz_types.h tup8)
         io = (C.c_int64 * 8)()
         self.lib.uz_stage_io_stats(sh.ptr, io)
         tm = (C.c_double * 6)()

@@ -13,7 +13,7 @@ def shard_bounds(n: int, world: int) -> List[int]:
     return [(n * r) // world for r in range(world + 1)]
 
 
-def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, min_per_chunk: int = 16000, first_chunk: Optional[float] = None) -> List[int]:
+def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, min_per_chunk: int = 20000, first_chunk: Optional[float] = None) -> List[int]:
     """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k, so a shard wants at
     least three chunks (the first chunk's upload and the last chunk's read stage are the two things nothing hides), and chunks of at
     least ~min_per_chunk DNMs (every chunk costs a host round trip and ~40 kernel launches).  The last chunk is smaller (last_chunk x
@@ -27,15 +27,19 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, mi
     # The first chunk half the size of the others (its copy and header build are what nothing hides; with the span sums from the packer the header
     # build is short enough for that to pay: 12.5 k shard 2.45 -> 2.36 ms, config 5 4.63 -> 4.53, 100 k: 6 chunks / 1.0 = 11.45, 6 / 0.5 = 11.69,
     # 7 / 0.5 = 11.07 ms on one box) -- and one chunk more than n / min_per_chunk when there are four or more, so that the others keep their size.
+    # Round 5 (read stage one wavefront per DNM, header build from LDS, 4.0 KB per DNM): a timeline of the step shows the compute queue busy 80 % of
+    # it and the copies half of it -- what a chunk costs now is the ramp and the tail of its own read stage (a DNM's latency is ~100 us whatever
+    # the chunk's size), so fewer, larger chunks win: 4 / 5 / 6 / 7 / 8 chunks with a half-size first = 11.0 / 10.0 / 9.85 / 10.2 / 10.5 ms, and with
+    # chunks that large a full-size first one: 5 chunks, first 0.5 / 0.7 / 1.0 = 9.99 / 9.83 / 9.69 ms (last 0.5 / 0.7 / 1.0: 9.85 / 9.69 / 9.70).
     k0 = n // int(min_per_chunk)
-    k = int(chunks) if chunks else max(3, k0 + (1 if k0 >= 4 else 0))
+    k = int(chunks) if chunks else max(3, k0)
     if not chunks and k0 < 1:
         # a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run): two chunks, the second 0.6 x the first -- round 5, with the read
         # stage and the header build at a third of their round-4 time a chunk's fixed costs (a find, ~40 launches) weigh more than what a
         # third chunk hides: 1 / 2 equal / 2 with 0.6 / 3 / 4 chunks = 2.75 / 2.88 / 2.57 / 2.75 / 3.10 ms on one box
         k, last_chunk = 2, min(float(last_chunk), 0.6)
     if first_chunk is None:
-        first_chunk = 0.5
+        first_chunk = 1.0 if (not chunks and k0 >= 4) else 0.5
     k = max(1, min(k, n))
     f = min(1.0, max(0.05, float(last_chunk)))
     g = min(1.0, max(0.05, float(first_chunk))) if k >= 3 else 1.0
