@@ -146,7 +146,12 @@ def test_random_blocks_against_zlib(engine, seed):
         level = int(rng.integers(0, 10))
         if level == 0 and n > 65000:
             level = 1
-        blocks.append(bgzf_block(p, level, strategies[k % len(strategies)]))
+        while True:  # (a payload a fixed or Huffman-only code blows up beyond what a BGZF block can hold is cut down)
+            try:
+                blocks.append(bgzf_block(p, level, strategies[k % len(strategies)]))
+                break
+            except AssertionError:
+                p = p[: len(p) // 2]
         want.append(p)
     got, nb, _ = engine.bgzf_inflate(b"".join(blocks))
     assert nb == 300

@@ -14,14 +14,12 @@ def shard_bounds(n: int, world: int) -> List[int]:
 
 
 def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, min_per_chunk: int = 20000, first_chunk: Optional[float] = None) -> List[int]:
-    """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k, so a shard wants at
-    least three chunks (the first chunk's upload and the last chunk's read stage are the two things nothing hides), and chunks of at
-    least ~min_per_chunk DNMs (every chunk costs a host round trip and ~40 kernel launches).  The last chunk is smaller (last_chunk x
-    the others: its read stage is the one nothing hides; 0.5 / 0.7 / 1.0 x, three alternating runs each: 14.56 / 14.15 / 14.31 ms).
-    chunks=None: from the shard size -- 100 k DNMs -> 6 chunks (round 4, 4.5 KB per DNM, the step bound by the device's own time: 4 / 5 / 6 / 7 / 8 / 10
-    chunks = 12.4 / 11.9 / 11.6 / 11.9 / 12.1 / 12.2 ms -- every chunk costs a k_phase<false> launch and ~40 launch gaps; round 3, link-bound, chose 8:
-    measured at 7.3 KB per DNM: 5 / 6 / 8 / 10 / 12 chunks = 15.9 / 15.6 /
-    15.7 / 16.5 / 17.3 ms), a 12.5 k shard of an 8-GPU run -> 3 (2 / 3 / 4 / 5 chunks = 3.03 / 2.91 / 3.02 / 3.19 ms; 100 k: 6 / 8 / 10 / 12 / 16 = 14.5 / 14.2 / 14.3 / 14.6 / 15.5 ms with the header build on its own stream).  -> [0, ..., n]"""
+    """Cut points of a staged pass over n DNMs: the uploads of chunk k + 1 overlap the kernels of chunk k.  Every chunk costs a host round trip,
+    ~40 kernel launches and the ramp and tail of its own read stage; the first chunk's upload and the last chunk's read stage are what nothing
+    hides.  chunks=None: from the shard size -- chunks of at least ~min_per_chunk DNMs, at least three: 100 k DNMs -> five chunks, the last
+    last_chunk x the others (round 5, below; round 4 chose seven with a half-size first, round 3 -- link-bound at 7.3 KB per DNM -- eight); a batch
+    of fewer than four chunks' worth -> three, the first half-size; a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run) -> two.
+    -> [0, ..., n]"""
     if n <= 0:
         return [0, 0]
     # The first chunk half the size of the others (its copy and header build are what nothing hides; with the span sums from the packer the header
