@@ -63,3 +63,36 @@ UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc 
 cd $ROOT
 (python3 scripts/pmc_rows.py $OUT/feedpmc; python3 scripts/pmc_rows.py $OUT/feedfetch; python3 scripts/pmc_rows.py $OUT/feedwrite) > $OUT/feed_pmc.txt 2>&1
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete
+# the BGZF inflate alone (scripts/inflate_probe.py: every block of the feed pass's BAM in one launch): duration and instruction counters of the
+# whole-file launches -> inflate_pmc.json (per 64 KiB block: scalar / vector / branch / LDS / memory instructions; the scalar-issue floor)
+cd /tmp
+rocprofv3 --kernel-include-regex k_bgzf_inflate --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/inflate -o run -- python3 $ROOT/scripts/inflate_probe.py 20000 > $OUT/inflate.log 2>&1
+cd $ROOT
+python3 - "$OUT" <<'P'
+import csv, collections, glob, json, re, sys
+out = sys.argv[1]
+f = glob.glob(out + "/inflate/**/*counter_collection.csv", recursive=True)
+d = collections.defaultdict(dict)
+for r in (csv.DictReader(open(f[0])) if f else []):
+    d[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+    d[r["Dispatch_Id"]]["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+log = open(out + "/inflate.log").read()
+m = re.search(r"BAM: (\d+) records, ([\d.]+) MB -> ([\d.]+) MB, (\d+) blocks", log)
+g = re.search(r"device: (\d+) blocks, ([\d.]+) ms per launch = ([\d.]+) GB/s", log)
+res = {"probe": g.group(0) if g else None}
+if d and m:
+    blocks = int(m.group(4))
+    big = max(v.get("SQ_INSTS_SALU", 0) for v in d.values())
+    full = [v for v in d.values() if v.get("SQ_INSTS_SALU", 0) > 0.9 * big]
+    mean = lambda k: sum(v[k] for v in full) / len(full)
+    per = {k.replace("SQ_INSTS_", "").lower() + "_per_block": round(mean(k) / blocks, 1) for k in ("SQ_INSTS_SALU", "SQ_INSTS_VALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")}
+    ns = mean("ns")
+    cyc_per_simd_block = ns * 1e-9 * 2.35e9 * 1024 / blocks
+    res.update(blocks=blocks, whole_file_launches=len(full), launch_ms_under_counters=round(ns / 1e6, 2), out_GB=float(m.group(3)) / 1e3, **per,
+               simd_cycles_per_block=round(cyc_per_simd_block), scalar_issue_floor_frac=round(per["salu_per_block"] * 4 / cyc_per_simd_block, 3),
+               note="one wavefront per block, 8 per SIMD; a SIMD issues one scalar instruction per four cycles: salu_per_block x 4 against the cycles a SIMD spends per block (2.35 GHz assumed)")
+json.dump(res, open(out + "/inflate_pmc.json", "w"), indent=1)
+print(json.dumps(res))
+P
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete
+
