@@ -524,7 +524,9 @@ class ReadsSource:
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
         if tup8 is None:
-            tup8 = os.environ.get("UZ_TUP8", "1") != "0"
+            # (not for an SV batch: its step is a chain of dependent launches over three heavy chunks, not bytes -- the kernel that rebuilds the
+            # 16-bit column stands in that chain: config 5 4.56 ms with the 16-bit index, 4.64 with the byte)
+            tup8 = os.environ.get("UZ_TUP8", "1") != "0" and not wide_no_units
         sel = C.c_void_p()
         masks = extra is not None and lists and not all_bases
         if masks:
@@ -758,7 +760,7 @@ class BamSource:
         inflate_alloc(nbytes) -> uint8 array: where the gathered and the inflated bytes go (pinned memory for full link speed); a batch whose
         blocks inflate to more than inflate_max_bytes stays with the host's inflate (that much memory would have to be page-locked)."""
         if tup8 is None:
-            tup8 = os.environ.get("UZ_TUP8", "1") != "0"
+            tup8 = os.environ.get("UZ_TUP8", "1") != "0" and not wide_no_units  # (as ReadsSource.select)
         contig = np.ascontiguousarray(contig, np.int32)
         lo = np.ascontiguousarray(lo, np.int32)
         hi = np.ascontiguousarray(hi, np.int32)
