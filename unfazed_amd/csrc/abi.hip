@@ -406,6 +406,7 @@ void uz_destroy(uz_ctx *c) {
     c->dn.block.release();
     if (c->dn_stage_done) (void)hipEventDestroy(c->dn_stage_done);
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
+    if (c->find_pin) (void)hipHostFree(c->find_pin);
     c->ab_lut.release(); c->win_range.release();
     c->dn_fam.release(); c->dn_cutoff.release(); c->fam_cls.release();
     c->cnv_counts.release(); c->cnv_pos.release(); c->cnv_origin.release(); c->cnv_evidence.release(); c->cnv_etype.release(); c->cnv_rb.release();
@@ -1420,6 +1421,17 @@ int uz_find(uz_ctx *c, int fam_id, const uz_dnms_view *d, int mode, int64_t *can
 int uz_find_fetch(uz_ctx *c, int32_t *cand_idx, uint8_t *cand_flags, int32_t *het_idx) {
     return guarded(c, [&] {
         UZ_REQUIRE(c->find_valid, UZ_E_STATE, "uz_find_fetch before uz_find");
+        // destinations in page-locked memory of this library (uz_pinned_alloc): by copy kernels, past the DMA engine's queue (uz_launch_find)
+        const bool pinned = (!cand_idx || !c->n_cand || inside_one_pinned_block((const uint8_t *)cand_idx, (const uint8_t *)(cand_idx + c->n_cand))) &&
+                            (!cand_flags || !c->n_cand || inside_one_pinned_block(cand_flags, cand_flags + c->n_cand)) &&
+                            (!het_idx || !c->n_het || inside_one_pinned_block((const uint8_t *)het_idx, (const uint8_t *)(het_idx + c->n_het)));
+        if (pinned) {
+            if (cand_idx && c->n_cand) uz_kcopy(c, cand_idx, c->cand_idx.p, (size_t)c->n_cand * sizeof(int32_t));
+            if (cand_flags && c->n_cand) uz_kcopy(c, cand_flags, c->cand_flags.p, (size_t)c->n_cand);
+            if (het_idx && c->n_het) uz_kcopy(c, het_idx, c->het_idx.p, (size_t)c->n_het * sizeof(int32_t));
+            UZ_HIP(hipStreamSynchronize(c->stream));
+            return;
+        }
         if (cand_idx && c->n_cand)
             UZ_HIP(hipMemcpyAsync(cand_idx, c->cand_idx.p, (size_t)c->n_cand * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
         if (cand_flags && c->n_cand)

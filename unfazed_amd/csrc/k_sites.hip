@@ -880,11 +880,21 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
         const bool tried = room_c > 0 && room_h > 0;
         if (tried) fill(room_c, room_h);
         if (host_offsets) {
-            UZ_HIP(hipMemcpyAsync(c->cand_off_h.data(), c->cand_off.p, ((size_t)n + 1) * sizeof(int64_t),
-                                  hipMemcpyDeviceToHost, c->stream));
-            UZ_HIP(hipMemcpyAsync(c->het_off_h.data(), c->het_off.p, ((size_t)n + 1) * sizeof(int64_t),
-                                  hipMemcpyDeviceToHost, c->stream));
+            // By a copy kernel into page-locked memory, not by hipMemcpyAsync: the DMA engine is in order, and inside a staged pass these two small
+            // copies would wait behind the records of the chunk before (65 MB: 1.4 ms per chunk of the 100 k pass, round 5's trace) -- the host
+            // sat in uz_find while the link idled, and enqueued the next chunk's records only afterwards
+            const size_t ob = ((size_t)n + 1) * sizeof(int64_t), obr = (ob + 255) & ~(size_t)255;
+            if (c->find_pin_cap < 2 * obr) {
+                if (c->find_pin) (void)hipHostFree(c->find_pin);
+                c->find_pin = nullptr;
+                c->find_pin_cap = 2 * obr + obr / 2 + 4096;
+                UZ_HIP(hipHostMalloc((void **)&c->find_pin, c->find_pin_cap, hipHostMallocDefault));
+            }
+            uz_kcopy(c, c->find_pin, c->cand_off.p, ob);
+            uz_kcopy(c, c->find_pin + obr, c->het_off.p, ob);
             UZ_HIP(hipStreamSynchronize(c->stream));
+            memcpy(c->cand_off_h.data(), c->find_pin, ob);
+            memcpy(c->het_off_h.data(), c->find_pin + obr, ob);
         } else { // the read stage only needs the two totals to size the lists: into the pinned mailbox, by a kernel
             int64_t *box = reinterpret_cast<int64_t *>(c->hflags + 4);
             uz_kcopy(c, box, c->cand_off.p + n, sizeof(int64_t));

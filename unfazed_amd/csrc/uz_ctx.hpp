@@ -231,6 +231,8 @@ struct uz_ctx {
     int find_fam = -1, find_mode = 0;
     DnmsDev dn;
     uint8_t *dn_stage = nullptr; // pinned staging of a DNM batch
+    uint8_t *find_pin = nullptr; // pinned landing place of a find's offsets (copied there by a kernel: see uz_kcopy)
+    size_t find_pin_cap = 0;
     size_t dn_stage_cap = 0;
     hipEvent_t dn_stage_done = nullptr; // behind the copies out of dn_stage: a batch queued by uz_phase_begin may still be reading it
     DevBuf<int32_t> cnt_c, cnt_h;

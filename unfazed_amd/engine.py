@@ -501,7 +501,9 @@ class HipEngine:
         self._ck(self.L.uz_site_classes(self.h, int(fam), out.ctypes.data), "uz_site_classes")
         return out[:n_sites]
 
-    def find(self, fam: int, dv: abi.Held, params: abi.Params, mode: int, fetch: bool = True):
+    def find(self, fam: int, dv: abi.Held, params: abi.Params, mode: int, fetch: bool = True, transient: bool = False):
+        """transient: the index lists come back as views of page-locked buffers this engine re-uses (valid until the find after next) -- what a
+        pipeline that reads them at once wants (pipeline.run_pipelined)"""
         self.set_params(params)
         n = dv.view.n
         co = np.zeros(n + 1, dtype=np.int64)
@@ -509,13 +511,32 @@ class HipEngine:
         self._ck(self.L.uz_find(self.h, int(fam), dv.ref(), int(mode), co.ctypes.data, ho.ctypes.data), "uz_find")
         if not fetch:
             return co, None, None, ho, None
-        ci, cf, hi = self._fetch(int(co[n]), int(ho[n]))
+        ci, cf, hi = self._fetch(int(co[n]), int(ho[n]), transient=transient)
         return co, ci, cf, ho, hi
 
-    def _fetch(self, nc: int, nh: int):
-        ci = np.zeros(max(1, nc), dtype=np.int32)
-        cf = np.zeros(max(1, nc), dtype=np.uint8)
-        hi = np.zeros(max(1, nh), dtype=np.int32)
+    def _fetch(self, nc: int, nh: int, transient: bool = False):
+        if transient:
+            # Into page-locked memory kept from call to call (three sets in turn: the lists of a find are read before the find after next
+            # returns): the library then copies by kernels, past the DMA engine's queue -- inside a staged pass a plain copy back waits
+            # behind the records of the chunk before (abi.hip: uz_find_fetch)
+            if not hasattr(self, "_find_pins"):
+                self._find_pins, self._find_turn = [None, None, None], 0
+            self._find_turn = (self._find_turn + 1) % 3
+            need = 4 * max(1, nc) + 256 + max(1, nc) + 256 + 4 * max(1, nh) + 256
+            pin = self._find_pins[self._find_turn]
+            if pin is None or pin[1].size < need:
+                if pin is not None:
+                    pin[0].free_all()
+                pool = PinnedPool()
+                pin = self._find_pins[self._find_turn] = (pool, pool.alloc(need + need // 4 + (1 << 16)))
+            buf = pin[1]
+            a = (4 * max(1, nc) + 255) & ~255
+            b = a + ((max(1, nc) + 255) & ~255)
+            ci, cf, hi = buf[: 4 * max(1, nc)].view(np.int32), buf[a: a + max(1, nc)], buf[b: b + 4 * max(1, nh)].view(np.int32)
+        else:
+            ci = np.zeros(max(1, nc), dtype=np.int32)
+            cf = np.zeros(max(1, nc), dtype=np.uint8)
+            hi = np.zeros(max(1, nh), dtype=np.int32)
         self._ck(self.L.uz_find_fetch(self.h, ci.ctypes.data, cf.ctypes.data, hi.ctypes.data), "uz_find_fetch")
         return ci[:nc], cf[:nc], hi[:nh]
 

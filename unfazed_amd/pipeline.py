@@ -51,6 +51,17 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
         held, hs_k, hg_k, wide_k = chunks[k]["sites"]
         sids[k], fids[k] = eng.upload_sites_family_async(held, hs_k["gt"], hg_k["rd"], hg_k["ad"], hg_k["gq"], wide_k)
 
+    try:
+        import inspect
+        _transient = "transient" in inspect.signature(eng.find).parameters
+    except (TypeError, ValueError):
+        _transient = False
+
+    def find_of(k):  # K1 + K2 + the het lists back on the host (read at once by the chunk's decoder: into re-used page-locked buffers where the engine offers them)
+        if _transient:
+            return eng.find(fids[k], chunks[k]["dnms"], P, mode, transient=True)
+        return eng.find(fids[k], chunks[k]["dnms"], P, mode)
+
     def read_stage_begin(k):  # queued on the compute stream (waits there for the chunk's records): no host wait
         eng.phase_begin(fids[k], rids[k], chunks[k]["dnms"], P, mode)
 
@@ -96,14 +107,43 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
         # chunks: 4.6 -> 4.5 ms); the three small chunks of a 12.5 k-DNM shard only start their first read stage later (2.45 -> 2.7 ms)
         lag = 2 if (cnv or n >= 8000 * max(1, K)) else 1
     lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid)
-    lag = max(1, min(int(lag), 2, K - 1)) if K > 1 else 1
+    lag = max(0, min(int(lag), 2, K - 1)) if K > 1 else 1
     site_stage(0)
     if K > 1:
         site_stage(1)
     tick()
+    if lag == 0:
+        # No lag: the read stage of chunk k is queued the moment its records are enqueued, and find(k + 1) waits behind it on the compute stream --
+        # copies and kernels of neighbouring chunks do not overlap, but nothing stands between a chunk's records and its read stage.  For a batch
+        # of two small chunks (a 12.5 k-DNM shard of an 8-GPU run) that chain is the shorter one.
+        for k in range(K):
+            finds[k] = find_of(k)
+            tick()
+            if k >= 1:
+                read_stage_end(k - 1)  # (it ran in front of find(k): no wait)
+                if cnv:
+                    cnv_stage(k - 1)
+            tick()
+            rec = chunks[k]["records"]
+            if callable(rec):
+                rec = rec(k, finds[k][3], finds[k][4])
+            finds[k] = None
+            rids[k] = eng.upload_reads_packed(rec)
+            if k + 2 < K:
+                site_stage(k + 2)
+            tick()
+            read_stage_begin(k)
+            tick()
+        read_stage_end(K - 1)
+        if cnv:
+            cnv_stage(K - 1)
+        tick()
+        if tr is not None:
+            trace.append([round((tr[i + 1] - tr[i]) * 1e3, 2) for i in range(len(tr) - 1)])
+        return out
     for k in range(K + lag + 1):
         if k < K:
-            finds[k] = eng.find(fids[k], chunks[k]["dnms"], P, mode)  # K1 + K2 + the het lists back on the host: the decoder's input
+            finds[k] = find_of(k)  # K1 + K2 + the het lists back on the host: the decoder's input
         tick()
         e, b = k - lag - 1, k - lag
         if 0 <= e < K:
