@@ -105,3 +105,61 @@ def test_one_site_table_for_the_whole_batch_and_the_default_lag():
         pipeline.run_pipelined(e, None, 0, n, ch, cnv=cnv, fid=7)
         first_b = e.log.index(("b", 0))
         assert sum(1 for x in e.log[:first_b] if x[0] == "f") == want + 1
+
+
+def test_a_chunks_result_lists_as_strings_in_one_pass_equal_the_lists_built_entry_by_entry():
+    """hostpath._VoteLists.strings (a fancy index over the distinct names, one str() per distinct position) against the per-DNM path of
+    _evidence_lists: the same four lists for every phased DNM, whichever way they are built; the cyclic collector comes back on after a
+    phasing call that switched it off (session.no_gc_pauses)."""
+    import gc
+    import numpy as np
+    from unfazed_amd import abi, session
+    from unfazed_amd.hostpath import PhasingHost, _VoteLists
+    rng = np.random.default_rng(12)
+    n = 200
+    lens = rng.integers(0, 9, 4 * n)
+    lens[rng.random(4 * n) < 0.3] = 0
+    vo = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    vv = np.zeros(int(vo[-1]), np.int32)
+    for k in range(4 * n):
+        a, b = int(vo[k]), int(vo[k + 1])
+        vv[a:b] = rng.integers(0, 500, b - a) if k % 4 < 2 else rng.integers(1, 10 ** 8, b - a)  # read ids / site positions
+    status = np.where(rng.random(n) < 0.8, abi.ST_OK, abi.ST_NO_OVERLAP).astype(np.int32)
+
+    class Names:
+        calls = 0
+
+        def take(self, ids):
+            Names.calls += 1
+            return ["read%05d" % int(i) for i in ids]
+
+        def __getitem__(self, i):
+            return "read%05d" % int(i)
+
+    class Table:
+        qnames = Names()
+
+    res = dict(status=status, lists=_VoteLists(vo, vv))
+    fast = PhasingHost._evidence_lists(res, range(n), Table())
+    assert Names.calls == 1  # one look-up for the whole chunk
+    slow_res = dict(status=status, lists=[tuple(vv[vo[4 * k + q]: vo[4 * k + q + 1]] for q in range(4)) for k in range(n)])
+    slow = PhasingHost._evidence_lists(slow_res, range(n), Table())
+    assert set(fast) == set(slow) == {k for k in range(n) if status[k] == abi.ST_OK}
+    for k in fast:
+        assert tuple(fast[k]) == tuple(slow[k]), k
+        assert all(isinstance(x, str) for part in fast[k] for x in part)
+    # a few DNMs of the chunk only: the per-DNM path of the same object
+    some = PhasingHost._evidence_lists(dict(status=status, lists=_VoteLists(vo, vv)), [k for k in range(n) if k % 7 == 0], Table())
+    for k in some:
+        assert tuple(some[k]) == tuple(slow[k])
+    was = gc.isenabled()
+    gc.enable()
+    with session.no_gc_pauses():
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    gc.disable()
+    with session.no_gc_pauses():
+        assert not gc.isenabled()
+    assert not gc.isenabled()  # (it was off before the call: it stays off)
+    if was:
+        gc.enable()
