@@ -423,20 +423,88 @@ UZ_DEV long long uz_lower_bound_c(const RD &R, long long lo, long long hi, long 
     return uz_lower_bound_start(R.ra, lo, hi, v);
 }
 
-// pysam fetch(contig, lo, hi): candidates are records with start in [lo - max_span, hi);
-// the caller still tests end > lo.
-UZ_DEV void uz_fetch_range(const RD &R, int tid, long long lo, long long hi, long long &a, long long &b) {
-    if (tid < 0 || tid >= R.n_contigs) { a = b = 0; return; }
-    const long long clo = R.contig_off[tid], chi = R.contig_off[tid + 1];
-    a = uz_lower_bound_c(R, clo, chi, lo - R.max_span[tid]);
-    b = uz_lower_bound_c(R, a, chi, hi);
+// N lower bounds over the start field at once: res[s] = the first record of [lo, hi) whose start is not below v[s] (as an offset from lo), chains
+// with on[s] false left at 0.  The N searches advance in lockstep, every step's N loads issued before the first of them is looked at: a binary
+// search is a chain of dependent loads at ~1 us each under load (~110 per DNM taken one search at a time, ~35 with a DNM's searches side by side).
+// Measured (round 5): sizing pass 0.40 -> 0.38 ms per 100 k DNMs, config 5 0.136 -> 0.104 -- less than the chains' lengths promised, because what
+// bounds the pass is the NUMBER of probes: ~1 450 per DNM, every one a 16-byte header in a line of its own for most of a search, and a CU's L1
+// takes one line per cycle (145 M probes over 256 CUs: ~0.2 ms before anything else).  Fewer probes, not shorter chains, is what is left.
+template <int N>
+UZ_DEV void uz_lower_bounds_start(const RecA *ra, long long lo, long long hi, const long long (&v)[N], const bool (&on)[N], int32_t (&res)[N]) {
+    int32_t l[N], h[N];
+    const int32_t n = (int32_t)(hi - lo);
+#pragma unroll
+    for (int s = 0; s < N; s++) { l[s] = 0; h[s] = (on[s] && n > 0) ? n : 0; }
+    if (n > 0) {
+        for (;;) {
+            bool any = false;
+            long long x[N];
+            int32_t mid[N];
+#pragma unroll
+            for (int s = 0; s < N; s++) {
+                const bool act = l[s] < h[s];
+                any |= act;
+                mid[s] = act ? l[s] + ((h[s] - l[s]) >> 1) : 0; // (an idle chain reads the range's first record again: no branch around the load)
+                x[s] = (long long)ra[lo + mid[s]].start;
+            }
+            if (!any) break;
+#pragma unroll
+            for (int s = 0; s < N; s++)
+                if (l[s] < h[s]) { if (x[s] < v[s]) l[s] = mid[s] + 1; else h[s] = mid[s]; }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < N; s++) res[s] = l[s];
 }
-// the same inside a record range [wa, wb) already known to contain the answer (the DNM's window)
-UZ_DEV void uz_fetch_range_in(const RD &R, int tid, long long wa, long long wb, long long lo, long long hi, long long &a, long long &b) {
-    if (tid < 0 || tid >= R.n_contigs) { a = b = 0; return; }
-    a = uz_lower_bound_start(R.ra, wa, wb, lo - R.max_span[tid]);
-    b = uz_lower_bound_start(R.ra, a, wb, hi);
+// ... and N lower bounds over a whole contig's records [clo, chi), the first steps on the coarse index (uz_lower_bound_c), likewise side by side
+template <int N>
+UZ_DEV void uz_lower_bounds_c(const RD &R, long long clo, long long chi, const long long (&v)[N], long long (&res)[N]) {
+    long long lo[N], hi[N];
+#pragma unroll
+    for (int s = 0; s < N; s++) { lo[s] = clo; hi[s] = chi; }
+    if (R.coarse && chi - clo > 8192) {
+        const long long kl = (clo + 4095) >> 12, kh = chi >> 12;
+        long long a[N], b[N];
+#pragma unroll
+        for (int s = 0; s < N; s++) { a[s] = kl; b[s] = kh; }
+        for (;;) {
+            bool any = false;
+            long long x[N], mid[N];
+#pragma unroll
+            for (int s = 0; s < N; s++) {
+                const bool act = a[s] < b[s];
+                any |= act;
+                mid[s] = act ? a[s] + ((b[s] - a[s]) >> 1) : kl;
+                x[s] = (kl < kh) ? (long long)R.coarse[mid[s]] : 0;
+            }
+            if (!any) break;
+#pragma unroll
+            for (int s = 0; s < N; s++)
+                if (a[s] < b[s]) { if (x[s] < v[s]) a[s] = mid[s] + 1; else b[s] = mid[s]; }
+        }
+#pragma unroll
+        for (int s = 0; s < N; s++) { lo[s] = a[s] > kl ? ((a[s] - 1) << 12) : clo; hi[s] = a[s] < kh ? (a[s] << 12) : chi; }
+    }
+    for (;;) { // the last steps: every chain inside its own stretch of the column
+        bool any = false;
+        long long x[N], mid[N];
+#pragma unroll
+        for (int s = 0; s < N; s++) {
+            const bool act = lo[s] < hi[s];
+            any |= act;
+            mid[s] = act ? lo[s] + ((hi[s] - lo[s]) >> 1) : clo;
+            x[s] = (clo < chi) ? (long long)R.ra[mid[s]].start : 0;
+        }
+        if (!any) break;
+#pragma unroll
+        for (int s = 0; s < N; s++)
+            if (lo[s] < hi[s]) { if (x[s] < v[s]) lo[s] = mid[s] + 1; else hi[s] = mid[s]; }
+    }
+#pragma unroll
+    for (int s = 0; s < N; s++) res[s] = lo[s];
 }
+
+// (pysam fetch(contig, lo, hi): candidates are records with start in [lo - max_span, hi); the caller still tests end > lo)
 // record range covering every fetch of one DNM: the DNM position and all of its het sites
 UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &wb) {
     const long long position = a.dstart[d];
@@ -447,7 +515,13 @@ UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &w
         if (p0 < lo) lo = p0;
         if (p1 + 1 > hi) hi = p1 + 1;
     }
-    uz_fetch_range(a.R, a.rcontig[d], lo, hi, wa, wb);
+    // (both bounds side by side; the second over the whole contig instead of from the first on: the same answer, hi > lo - max_span)
+    const int tid = a.rcontig[d];
+    if (tid < 0 || tid >= a.R.n_contigs) { wa = wb = 0; return; }
+    const long long v[2] = {lo - a.R.max_span[tid], hi};
+    long long r[2];
+    uz_lower_bounds_c<2>(a.R, a.R.contig_off[tid], a.R.contig_off[tid + 1], v, r);
+    wa = r[0]; wb = r[1];
 }
 
 // index of `pos` in get_reference_positions(full_length=True), -1 if absent
@@ -753,36 +827,83 @@ UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, i
     const int nh = (int)(a.het_off[d + 1] - h0);
     t_part = 0; mh_part = 0;
     const int tid = a.rcontig[d];
-    if (lane == 0) {
-        const long long position = a.dstart[d];
-        const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
-        long long fa, fb;
-        uz_fetch_range_in(R, tid, wa, wb, flo, position + 1, fa, fb);
-        long long fa2 = 0, fb2 = 0;
-        if (a.vartype[d] != UZ_VT_POINT) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497)
+    const bool tid_ok = tid >= 0 && tid < R.n_contigs;
+    const long long span = tid_ok ? R.max_span[tid] : 0;
+    const bool point = a.vartype[d] == UZ_VT_POINT;
+    if (lane == 0 && !point) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497): four bounds over the contig, side by side
+        long long fa = 0, fb = 0, fa2 = 0, fb2 = 0;
+        if (tid_ok) {
             const long long icut = (long long)uz_cutoff(a, d);
-            long long lo = (long long)a.dstart[d] - icut;
-            if (lo < 0) lo = 0;
-            uz_fetch_range(R, tid, lo, (long long)a.dstart[d] + icut, fa, fb);
-            lo = (long long)a.dend[d] - icut;
-            if (lo < 0) lo = 0;
-            uz_fetch_range(R, tid, lo, (long long)a.dend[d] + icut, fa2, fb2);
+            long long lo1 = (long long)a.dstart[d] - icut, lo2 = (long long)a.dend[d] - icut;
+            if (lo1 < 0) lo1 = 0;
+            if (lo2 < 0) lo2 = 0;
+            const long long v[4] = {lo1 - span, (long long)a.dstart[d] + icut, lo2 - span, (long long)a.dend[d] + icut};
+            long long r[4];
+            uz_lower_bounds_c<4>(R, R.contig_off[tid], R.contig_off[tid + 1], v, r);
+            fa = r[0]; fb = r[1] > r[0] ? r[1] : r[0]; fa2 = r[2]; fb2 = r[3] > r[2] ? r[3] : r[2];
         }
         b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
         a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
         a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
     }
-    if (a.no_extended) return;
-    const long long span = (tid >= 0 && tid < R.n_contigs) ? R.max_span[tid] : 0;
-    for (int h = lane; h < nh; h += nlanes) {
-        const long long hp = a.spos[a.het_idx[h0 + h]];
-        long long ha, hb;
-        uz_fetch_range_in(R, tid, wa, wb, hp, hp + 1, ha, hb);
-        a.pre_ha[h0 + h] = (int32_t)ha; a.pre_hl[h0 + h] = (int32_t)(hb - ha);
-        t_part += hb - ha;
-        int left = h; // first het site (the list is sorted) a record ending at hp could still reach back to
-        while (left > 0 && (long long)a.spos[a.het_idx[h0 + left - 1]] >= hp - span - 1) left--;
-        if (h - left + 1 > mh_part) mh_part = h - left + 1;
+    // The fetch ranges of the het sites, UZ_BW_SITES per lane at a time with their 2 x UZ_BW_SITES searches side by side (uz_lower_bounds_start);
+    // lane 0's first batch carries the two bounds of a point variant's own fetch along.  The walks back to the first het site a record ending at
+    // a site could still reach go side by side too (two dependent loads per step each).
+    constexpr int SITES = 4, NCH = 2 * SITES + 2;
+    bool first = true;
+    for (int hb0 = lane; hb0 < nh || (first && lane == 0 && point); hb0 += nlanes * SITES) {
+        long long v[NCH], hp[SITES];
+        bool on[NCH];
+        int hs[SITES];
+#pragma unroll
+        for (int j = 0; j < SITES; j++) {
+            hs[j] = hb0 + j * nlanes;
+            const bool in = hs[j] < nh && !a.no_extended;
+            hp[j] = in ? (long long)a.spos[a.het_idx[h0 + hs[j]]] : 0;
+            v[2 * j] = hp[j] - span; v[2 * j + 1] = hp[j] + 1;
+            on[2 * j] = on[2 * j + 1] = in && tid_ok;
+        }
+        const bool own = first && lane == 0 && point;
+        const long long position = a.dstart[d];
+        const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
+        v[2 * SITES] = flo - span; v[2 * SITES + 1] = position + 1;
+        on[2 * SITES] = on[2 * SITES + 1] = own && tid_ok;
+        int32_t r[NCH];
+        uz_lower_bounds_start<NCH>(R.ra, wa, wb, v, on, r);
+        if (own) {
+            const long long fa = tid_ok ? wa + r[2 * SITES] : 0, fb = tid_ok ? wa + (r[2 * SITES + 1] > r[2 * SITES] ? r[2 * SITES + 1] : r[2 * SITES]) : 0;
+            b[0] = (int32_t)(fb - fa);
+            a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
+            a.pre_win[4 * d + 2] = 0; a.pre_win[4 * d + 3] = 0;
+        }
+        first = false;
+        if (a.no_extended) break;
+        int left[SITES];
+#pragma unroll
+        for (int j = 0; j < SITES; j++) {
+            left[j] = hs[j];
+            if (hs[j] < nh) {
+                const long long ha = tid_ok ? wa + r[2 * j] : 0, hb = tid_ok ? wa + (r[2 * j + 1] > r[2 * j] ? r[2 * j + 1] : r[2 * j]) : 0;
+                a.pre_ha[h0 + hs[j]] = (int32_t)ha; a.pre_hl[h0 + hs[j]] = (int32_t)(hb - ha);
+                t_part += hb - ha;
+            }
+        }
+        for (;;) { // first het site (the list is sorted) a record ending at hp could still reach back to
+            bool any = false;
+            long long q[SITES];
+#pragma unroll
+            for (int j = 0; j < SITES; j++) {
+                const bool act = hs[j] < nh && left[j] > 0;
+                q[j] = act ? (long long)a.spos[a.het_idx[h0 + left[j] - 1]] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < SITES; j++)
+                if (hs[j] < nh && left[j] > 0 && q[j] >= hp[j] - span - 1) { left[j]--; any = true; }
+            if (!any) break;
+        }
+#pragma unroll
+        for (int j = 0; j < SITES; j++)
+            if (hs[j] < nh && hs[j] - left[j] + 1 > mh_part) mh_part = hs[j] - left[j] + 1;
     }
 }
 UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part) {
