@@ -723,16 +723,16 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
 
 def product_e2e(bam, vcf, sc, ev, m, res_r):
     """The same files through the PRODUCT's drop-in call -- phase_snvs(dnms, kids, pedigrees, sites, ...) as the reference's driver makes it
-    (unfazed.py:601-646) -> session -> hostpath (chunks of DNMs, chunk k + 1 decoded while chunk k is phased) -> records dict -- timed on its
-    second call, and its records held against the resident pass (read and site counts of every DNM)."""
+    (unfazed.py:601-646) -> session -> hostpath (chunks of DNMs, chunk k + 1 decoded while chunk k is phased) -> records dict -- timed on the
+    three calls after a first one (the median is reported), and its records held against the resident pass (read and site counts of every DNM)."""
     from unfazed_amd import abi, session
     from unfazed_amd.snv_phaser import phase_snvs
     ped = {"kid": {"kid": "kid", "dad": "dad", "mom": "mom", "sex": "2"}}
     dnms = [dict(chrom=sc.contig_names[int(c)], start=int(s), end=int(e), kid="kid", vartype="POINT", bam=bam, cram_ref=None)
             for c, s, e in zip(ev.contig[:m], ev.start[:m], ev.end[:m])]
     argv = (["kid"], ped, vcf, 2, "38", False, 10 ** 9, True, [0.0, 0.2], [0.8, 1.0], [0.2, 0.8], 20, 10, 5000, 1000000, 3, 1, 151, 5)
-    el, recs = 0.0, {}
-    for rep in range(2):
+    el, recs, els = 0.0, {}, []
+    for rep in range(4):  # (one warm call, then three timed ones: the median is reported, as for the feed pass)
         session._HOSTS.clear()
         for k in [k for k in session._SITES if "@" in k]:
             del session._SITES[k]
@@ -745,6 +745,8 @@ def product_e2e(bam, vcf, sc, ev, m, res_r):
         t = time.perf_counter()
         recs = phase_snvs(batch, *argv)
         el = time.perf_counter() - t
+        if rep >= 1:
+            els.append(el)
         if prof is not None:
             import pstats
             prof.disable()
@@ -771,7 +773,8 @@ def product_e2e(bam, vcf, sc, ev, m, res_r):
             bad += r is not None
         else:
             bad += r is None or [len(r["dad_reads"]), len(r["mom_reads"]), len(r["dad_sites"]), len(r["mom_sites"])] != cnt[d].tolist()
-    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "records": len(recs), "snv_dnms_compared": compared, "dnms_the_driver_skips_at_its_refalt_lookup": refalt_skips, "record_mismatches_vs_resident": int(bad),
+    el = sorted(els)[len(els) // 2]
+    return {"value_e2e": round(m / el, 1), "seconds": round(el, 3), "seconds_of_every_call": [round(x, 3) for x in els], "records": len(recs), "snv_dnms_compared": compared, "dnms_the_driver_skips_at_its_refalt_lookup": refalt_skips, "record_mismatches_vs_resident": int(bad),
             "route": "phase_snvs -> session -> hostpath._chunked_batch (%d DNMs per chunk) -> HipEngine" % __import__("unfazed_amd.hostpath", fromlist=["x"]).PhasingHost.CHUNK_DNMS}
 
 
