@@ -609,7 +609,8 @@ class PhasingHost:
                 part = parts[k]
                 lists = None
                 if want_lists:
-                    vo, vv = self.backend.votes(len(part))
+                    with _Sec("votes"):
+                        vo, vv = self.backend.votes(len(part))
                     lists = _VoteLists(vo, vv)
                 res = dict(status=rr["status"], counts=rr["counts"], origin=rr["origin"], evidence=rr["evidence"], lists=lists)
                 table = type("StagedNames", (), {})()
@@ -617,7 +618,8 @@ class PhasingHost:
                 if lists is not None:
                     # the name and position lists of the chunk's records, built HERE -- beside the native decode of the chunks that follow -- and
                     # not in a pass over the whole batch behind the pipeline
-                    res["built"] = self._evidence_lists(res, range(len(part)), table)
+                    with _Sec("evidence"):
+                        res["built"] = self._evidence_lists(res, range(len(part)), table)
                 for j, i in enumerate(part):
                     results[i] = (res, j, table)
 
