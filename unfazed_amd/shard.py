@@ -18,7 +18,7 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, mi
     ~40 kernel launches and the ramp and tail of its own read stage; the first chunk's upload and the last chunk's read stage are what nothing
     hides.  chunks=None: from the shard size -- chunks of at least ~min_per_chunk DNMs, at least three: 100 k DNMs -> five chunks, the last
     last_chunk x the others (round 5, below; round 4 chose seven with a half-size first, round 3 -- link-bound at 7.3 KB per DNM -- eight); a batch
-    of fewer than four chunks' worth -> three, the first half-size; a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run) -> two.
+    of fewer than four chunks' worth -> three, the first half-size; a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run) -> two, the second 1.5 x the first.
     -> [0, ..., n]"""
     if n <= 0:
         return [0, 0]
@@ -32,14 +32,17 @@ def chunk_plan(n: int, chunks: Optional[int] = None, last_chunk: float = 0.7, mi
     k0 = n // int(min_per_chunk)
     k = int(chunks) if chunks else max(3, k0)
     if not chunks and k0 < 1:
-        # a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run): two chunks, the second 0.6 x the first -- round 5, with the read
-        # stage and the header build at a third of their round-4 time a chunk's fixed costs (a find, ~40 launches) weigh more than what a
-        # third chunk hides: 1 / 2 equal / 2 with 0.6 / 3 / 4 chunks = 2.75 / 2.88 / 2.57 / 2.75 / 3.10 ms on one box
-        k, last_chunk = 2, min(float(last_chunk), 0.6)
+        # a shard below one chunk's size (the 12.5 k DNMs of an 8-GPU run): two chunks -- round 5, with the read stage and the header build at a
+        # third of their round-4 time a chunk's fixed costs (a find, ~40 launches) weigh more than what a third chunk hides: 1 / 2 / 3 / 4 chunks =
+        # 2.75 / 2.57 / 2.75 / 3.10 ms on one box -- and the FIRST the smaller one, the second 1.5 x it: what nothing hides in so short a pass is the
+        # first chunk's way to the device (find, copy, header build), and since the find's answers no longer wait behind the uploads (uz_find: copy
+        # kernels) the second chunk's copy is done before the first read stage is: second chunk 0.6 / 1.0 / 1.2 / 1.5 / 1.8 / 2.0 x the first =
+        # 2.45 / 2.21 / 2.18 / 2.15 / 2.17 / 2.20 ms
+        k, last_chunk = 2, 1.5
     if first_chunk is None:
         first_chunk = 1.0 if (not chunks and k0 >= 4) else 0.5
     k = max(1, min(k, n))
-    f = min(1.0, max(0.05, float(last_chunk)))
+    f = min(3.0, max(0.05, float(last_chunk)))  # (above 1: a last chunk LARGER than the others -- a two-chunk shard whose first chunk should reach the device early)
     g = min(1.0, max(0.05, float(first_chunk))) if k >= 3 else 1.0
     unit = n / (k - 2 + g + f) if k >= 2 else float(n)
     cuts = [0] + [min(n, int(round(unit * (g + j)))) for j in range(k - 1)] + [n] if k >= 2 else [0, n]
