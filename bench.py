@@ -152,10 +152,11 @@ def main():
     if args.workload == "cnv" and not args.chunks:
         if args.first_chunk is None:
             args.first_chunk = 0.5
-        args.chunks = 3  # (measured: 2 / 3 / 4 / 6 chunks = 6.6 / 6.2 / 7.4 / 8.1 ms: 214 MB cross the link in 3.9 ms; the read stage of an SV chunk
-        # is as long as its slowest event -- a breakpoint pile-up of a thousand records in one workgroup -- so small chunks cost more in total)
+        args.chunks = 2  # (rounds 3 / 4: three -- 2 / 3 / 4 / 6 chunks = 6.6 / 6.2 / 7.4 / 8.1 ms; the read stage of an SV chunk is as long as its slowest
+        # event -- a breakpoint pile-up of a thousand records in one wave -- so small chunks cost more in total.  End of round 5, with the find's answers
+        # past the DMA queue: 2 equal chunks / 2 with the second 1.5 x / 3 with a half-size first = 4.29 / 4.31 / 4.45 ms)
     if args.workload == "cnv" and "--last-chunk" not in " ".join(sys.argv):
-        # three EQUAL chunks: the read stage of an SV chunk is as long as its slowest event, so a smaller last chunk buys nothing and makes
+        # EQUAL chunks: the read stage of an SV chunk is as long as its slowest event, so a smaller last chunk buys nothing and makes
         # the others larger (scripts/cnv_sweep.sh, header build on its own stream: last chunk 0.3 / 0.5 / 0.7 / 1.0 x = 5.44 / 5.25 / 5.06 /
         # 4.95 ms; with that, a first chunk of 0.5 / 0.7 / 1.0 x = 5.03 / 4.90 / 4.93 ms; 2 / 4 equal chunks 4.97 / 5.19 ms)
         args.last_chunk = 1.0
