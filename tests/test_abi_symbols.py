@@ -62,3 +62,16 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dp, fn)).read()
                 assert not bad.search(src), fn
+
+
+def test_the_committed_profiles_belong_to_these_device_sources():
+    """bench.py quotes a profile's counters (roofline.traffic, issue_model) only while the profile's recorded hash of the device sources equals
+    the build's (build.kernel_source_hash): the profiles committed with a round must be the ones of its final kernels."""
+    import json
+    import os
+    from unfazed_amd.build import kernel_source_hash
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = kernel_source_hash()
+    for name in ("k1_traffic.json", "phase_issue.json"):
+        p = os.path.join(root, "profiles", name)
+        assert json.load(open(p)).get("kernel_source_sha") == sha, name
