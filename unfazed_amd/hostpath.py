@@ -576,10 +576,16 @@ class PhasingHost:
         src = stager(bam)
         fam = self.family(kid, pedigrees[kid]["dad"], pedigrees[kid]["mom"])
         cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
-        # (the first chunk half-size: nothing hides its decode)
-        cuts = [0] + list(range(chunk // 2, len(idxs), chunk)) + [len(idxs)]
-        if cuts[-1] - cuts[-2] < chunk // 2 and len(cuts) > 2:
-            cuts.pop(-2)  # (a short tail joins the chunk before it)
+        # The first chunk half-size (nothing hides its decode), the rest in EQUAL chunks of at most `chunk` DNMs.  No chunk larger than the others:
+        # a walked batch keeps its blocks, inflated bytes and descriptors in one of four device slots (abi.hip uz_bam_walk: the first free one), a
+        # slot that meets a larger batch than it has held grows through hipFree + hipMalloc of gigabytes with every stream of the device waiting,
+        # and a tail joined to the last chunk (4 700 DNMs after five of 3 400) did that to the SECOND call of a process, whose timing puts the
+        # large chunk on another slot than the first call's: 1.3 ... 1.7 s instead of 0.6
+        n_all, first = len(idxs), min(len(idxs), chunk // 2)
+        k_rest = max(1, -(-(n_all - first) // chunk))
+        size = -(-(n_all - first) // k_rest)
+        cuts = [0] + [min(n_all, first + j * size) for j in range(k_rest)] + [n_all]
+        cuts = sorted(set(cuts))
         parts = [idxs[cuts[k]: cuts[k + 1]] for k in range(len(cuts) - 1)]
 
         from . import pipeline
