@@ -320,6 +320,18 @@ int uz_bam_stage_finish_desc(uz_stage *s, const uz_walk_desc *d, const int64_t *
                              const int64_t *d_walked /* [n_tasks] or NULL */);
 /* the host's twin of the device's walk: the same descriptors from the host's own walk (out == NULL: the counts only) */
 int uz_stage_walk_host(uz_stage *s, uz_walk_desc *out, int64_t cap, int64_t *d_first /* [n_tasks + 1] */, int64_t *d_walked /* [n_tasks] or NULL */);
+/* The joins on the device (unfazed_hip.h: uz_bam_join -- mate(), the closure over mates of mates, names numbered by first appearance: what
+ * read_collector.py:400, :185 and :226-234 do record by record): the host's share is the records it has to walk itself, handed over as descriptors
+ * whose bytes lie in the batch's aux store (uz_walk_desc.task = UZ_WALK_TASK_JOIN | join task, src = UZ_WALK_SRC_AUX | offset).
+ *   uz_stage_walk_flagged  d_flags [walk tasks]: the device's flags (uz_bam_walk_flags); h_flags [tasks of the stage] out: whose device descriptors are
+ *                          void; those tasks are walked here.  totals: [0] descriptors, [1] aux bytes held for the device
+ *   uz_stage_lookup        need [n]: members whose mate no walked task can answer; every distinct position is looked up through the index;
+ *                          jtask [n] out: the join task (n_tasks + k) that answers need[k]
+ *   uz_stage_extra         the descriptors from d0 / aux bytes from a0 on; look_tid: the reference of every look-up task so far (or NULL) */
+int uz_stage_walk_flagged(uz_stage *s, const int32_t *d_flags, int32_t *h_flags, int64_t totals[2]);
+int uz_stage_lookup(uz_stage *s, int64_t n, const uz_need_rec *need, int32_t *jtask, int64_t totals[2]);
+int uz_stage_extra(const uz_stage *s, int64_t d0, int64_t a0, uz_walk_desc *desc, uint8_t *aux, int32_t *look_tid);
+int64_t uz_stage_n_lookup_tasks(const uz_stage *s);
 void uz_stage_kept_sizes(const uz_stage *s, int64_t out[8]); /* ... [7] name bytes of the kept records */
 /* the kept record that brought name id ids[k] first (ids == NULL: ids 0 .. n - 1): its name is the id's (uz_reads_from_bam returns the kept records' names) */
 int uz_stage_name_records(const uz_stage *s, const uint32_t *ids, int64_t n, int64_t *rec);

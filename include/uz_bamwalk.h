@@ -31,9 +31,24 @@ typedef struct uz_walk_desc {
 } uz_walk_desc;
 
 #define UZ_WALK_SRC_AUX (1ULL << 63)
+/* uz_walk_desc.task of a record the HOST walked for the device's joins (uz_stage_walk_flagged, uz_stage_lookup): bit 31 + the join task it belongs
+ * to -- a task of the stage, or n_tasks + k for the k-th look-up through the index; without the bit: the device's own walk task */
+#define UZ_WALK_TASK_JOIN 0x80000000u
+
+/* a member of the joins whose mate the walked tasks cannot answer (uz_bam_join -> uz_stage_lookup): its name, and where its mate is said to lie */
+typedef struct uz_need_rec {
+    uint64_t h1;
+    uint32_t h2, l_name;
+    int32_t mtid, mpos;
+    uint32_t who; /* the device's index of the asking record */
+    uint32_t pad;
+} uz_need_rec;
 
 /* the walk plan as flat arrays (uz_stage_walk_plan fills them, uz_bam_walk reads them) */
-#define UZ_WALK_TASK_COLS 10 /* int32 per task: tid, b (first position behind its reach), span0, span1, reach0, reach1, fetch0, fetch1, fetch_max_len, 0 */
+#define UZ_WALK_TASK_COLS 10 /* int32 per task: tid, b (first position behind its reach), span0, span1, reach0, reach1, fetch0, fetch1, fetch_max_len, host */
+/* host (column 9): the task of the stage this walk task is a part of (uz_stage_walk_plan cuts a stage task into sub-tasks: groups of its reach
+ * intervals, each a chain of its own for the device).  The sub-tasks of one stage task stand next to each other, in order, and the column never
+ * decreases: the mate-candidate sets and the batch-wide joins are per stage task (uz_bam_walk refuses a plan that breaks this). */
 #define UZ_WALK_SPAN_COLS 6  /* int64 per span: beg voff, end voff, buf_beg, buf_end, blk0, blk1 (its gathered blocks, indices into the block table) */
 /* reach: int32 [2 n_reach] (a, b); fetch: int32 [3 n_fetch] (lo, hi, extra); blk_coff: int64 [n_blocks] file offset of every gathered block
  * (the block table of uz_stage_gather_blocks: out_off[k] .. out_off[k + 1] are its bytes in the inflated buffer) */

@@ -1743,6 +1743,10 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
             const int32_t *tc = task + UZ_WALK_TASK_COLS * (size_t)t;
             UZ_REQUIRE(tc[2] >= 0 && tc[2] <= tc[3] && tc[3] <= n_spans && tc[4] >= 0 && tc[4] <= tc[5] && tc[5] <= n_reach && tc[6] >= 0 && tc[6] <= tc[7] && tc[7] <= n_fetch,
                        UZ_E_ARG, "walk plan: a task names spans, reach intervals or fetches outside the arrays");
+            // column 9: the stage task a walk task belongs to -- its sub-tasks adjacent and in order (the hash sets of k_tab_insert / k_desc_filter and
+            // the joins find a stage task's first sub-task by walking back over equal values)
+            UZ_REQUIRE(tc[9] >= 0 && (t == 0 ? true : (tc[9] == tc[9 - UZ_WALK_TASK_COLS] || tc[9] == tc[9 - UZ_WALK_TASK_COLS] + 1)), UZ_E_ARG,
+                       "walk plan: column 9 (the stage task of a walk task) must start at or above 0 and go up by at most one from task to task");
         }
         for (int64_t k = 0; k < n_spans; k++) {
             const int64_t *sc = span + UZ_WALK_SPAN_COLS * (size_t)k;

@@ -487,6 +487,12 @@ struct uz_stage {
     std::vector<SubTask> subs;       // built by the walk plan (build_subtasks)
     std::vector<uint8_t> sub_preflag; // per host task: a sub-task starts in a block the gather did not list -- the host walks the task itself
     bool desc = false; // the descriptor route (uz_bam_stage_finish_desc): the walk ran on the device, the host holds no record bytes
+    // the joins on the device (uz_bam_join, csrc/k_bamjoin.hip): what the host still contributes are the records it walks itself -- the tasks the
+    // device handed back (uz_stage_walk_flagged) and mates looked up through the index (uz_stage_lookup) -- as descriptors whose bytes lie in `xaux`
+    std::vector<uz_walk_desc> xdesc;
+    std::vector<uint8_t> xaux;
+    std::vector<int32_t> look_tid; // the reference of every look-up task (join task n_tasks + k)
+    bool joined = false;
     const uint8_t *inflated = nullptr;
     int64_t n_pre_blocks = 0, pre_bytes = 0;
     std::vector<uint64_t> tup_key;
@@ -782,6 +788,56 @@ void mates_in_task(const uz_stage &P, Task &T, Scratch &W, size_t ti) {
 // a mate looked up through the index: the records overlapping [mpos, mpos + 1) of the mate's reference, walked like a fetch
 struct Lookup { int64_t who; int32_t mtid, mpos; };
 
+// A mate looked up through the index: the records of reference `mtid` overlapping [mpos, mpos + 1), walked like a one-base fetch -- no fetch returns
+// them (nothing is direct) -- of which those are kept whose name somebody asks for: asked(h1, h2, length, the name's bytes).
+template <class Asked>
+void lookup_walk(const uz_stage &P, Task &T, int32_t mtid, int32_t mpos, Inflater &inf, Asked asked) {
+    const uz_bamsrc &S = *P.src;
+    T.tid = mtid; T.a = mpos; T.b = mpos + 1; T.f0 = T.f1 = 0;
+    T.by_hash = P.desc;
+    spans_for(S.refs[(size_t)mtid], T.a, T.b, T.spans);
+    Stream s(S, inf);
+    bool stop = false;
+    for (size_t ci = 0; ci < T.spans.size() && !stop; ci++) {
+        s.seek(T.spans[ci].beg);
+        for (;;) {
+            uint64_t voff;
+            const uint8_t *p;
+            uint32_t bs;
+            if (!s.next(voff, p, bs)) { stop = true; break; }
+            if (voff >= T.spans[ci].end) break;
+            const int32_t tid2 = rdi32(p), pos = rdi32(p + 4);
+            if (tid2 != T.tid) { if (tid2 < 0 || tid2 > T.tid) { stop = true; break; } s.advance(bs); continue; }
+            if (pos > mpos) { stop = true; break; }
+            const uint32_t l_name = p[8], ncig = rd16(p + 12);
+            const uint16_t fl = rd16(p + 14);
+            const int32_t lseq = rdi32(p + 16);
+            if (lseq < 0 || lseq > 0xFFFF) fail(UZ_IO_E_RANGE, "record too long for the 16-bit length columns (l_seq %d)", lseq);
+            if (l_name < 1 || 32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block (or has no read name)");
+            const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
+            T.n_walked++;
+            if (end > mpos) {
+                const uint64_t h = hash_name(p + 32, (size_t)l_name - 1);
+                const uint32_t h2 = P.desc ? uz_name_hash2(p + 32, l_name - 1) : 0u;
+                if (asked(h, h2, l_name - 1, p + 32)) {
+                    WRec r;
+                    memset(&r, 0, sizeof(r));
+                    r.voff = voff; r.pos = pos; r.end = end; r.flag = fl; r.mapq = p[9];
+                    r.n_cigar = (uint16_t)ncig; r.l_seq = (uint16_t)lseq;
+                    r.mtid = rdi32(p + 20); r.mpos = rdi32(p + 24); r.tlen = rdi32(p + 28);
+                    r.mate_ref = -2; r.nhash = h; r.keep = 0;
+                    r.umask = P.opt.masks ? (uint16_t)0 : (uint16_t)UZ_UMASK_ALL;
+                    if (P.desc) keep_raw(T, r, p, bs);
+                    else extract(T, r, p, bs, P.opt, P.opt.all_bases);
+                    T.recs.push_back(r);
+                }
+            }
+            s.advance(bs);
+        }
+    }
+    T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks;
+}
+
 // first half of the plan: fetches -> reach intervals -> tasks with their file spans
 void plan_begin(uz_stage &P, int64_t n_fetch, const int32_t *tid, const int32_t *lo, const int32_t *hi, const uint16_t *extra, int threads) {
     const uz_bamsrc &S = *P.src;
@@ -1020,59 +1076,15 @@ void plan_finish(uz_stage &P, const uz_walk_desc *d = nullptr, const int64_t *d_
             parallel_dynamic((int64_t)first.size(), std::max(1, w), [&](int64_t g, int k) {
                 Task &T = P.tasks[base + (size_t)g];
                 const Lookup &q = need[first[(size_t)g]];
-                T.tid = q.mtid; T.a = q.mpos; T.b = q.mpos + 1; T.f0 = T.f1 = 0;
-                T.by_hash = P.desc;
-                spans_for(S.refs[(size_t)q.mtid], T.a, T.b, T.spans);
-                // walk: every record overlapping the position, no fetch (nothing is direct), keep those whose name is asked for
-                Inflater &inf = *infs[(size_t)k];
-                Stream s(S, inf);
                 const size_t k1 = (size_t)g + 1 < first.size() ? first[(size_t)g + 1] : need.size();
-                bool stop = false;
-                for (size_t ci = 0; ci < T.spans.size() && !stop; ci++) {
-                    s.seek(T.spans[ci].beg);
-                    for (;;) {
-                        uint64_t voff;
-                        const uint8_t *p;
-                        uint32_t bs;
-                        if (!s.next(voff, p, bs)) { stop = true; break; }
-                        if (voff >= T.spans[ci].end) break;
-                        const int32_t tid2 = rdi32(p), pos = rdi32(p + 4);
-                        if (tid2 != T.tid) { if (tid2 < 0 || tid2 > T.tid) { stop = true; break; } s.advance(bs); continue; }
-                        if (pos > q.mpos) { stop = true; break; }
-                        const uint32_t l_name = p[8], ncig = rd16(p + 12);
-                        const uint16_t fl = rd16(p + 14);
-                        const int32_t lseq = rdi32(p + 16);
-                        if (lseq < 0 || lseq > 0xFFFF) fail(UZ_IO_E_RANGE, "record too long for the 16-bit length columns (l_seq %d)", lseq);
-                        if (l_name < 1 || 32 + (size_t)l_name + 4 * (size_t)ncig > (size_t)bs) fail(UZ_IO_E_FORMAT, "alignment record overruns its block (or has no read name)");
-                        const int32_t end = endpos_of(p, pos, fl, ncig, l_name);
-                        T.n_walked++;
-                        if (end > q.mpos) {
-                            const uint64_t h = hash_name(p + 32, (size_t)l_name - 1);
-                            const uint32_t h2 = P.desc ? uz_name_hash2(p + 32, l_name - 1) : 0u;
-                            bool asked = false;
-                            for (size_t u = first[(size_t)g]; u < k1 && !asked; u++) {
-                                const WRec &x = rec_of(P, need[u].who);
-                                const Task &TX = P.tasks[(size_t)(need[u].who >> 32)];
-                                asked = x.nhash == h && x.l_name == l_name - 1 &&
-                                        (P.desc ? x.nhash2 == h2 : memcmp(TX.names.data() + x.name_at, p + 32, x.l_name) == 0);
-                            }
-                            if (asked) {
-                                WRec r;
-                                memset(&r, 0, sizeof(r));
-                                r.voff = voff; r.pos = pos; r.end = end; r.flag = fl; r.mapq = p[9];
-                                r.n_cigar = (uint16_t)ncig; r.l_seq = (uint16_t)lseq;
-                                r.mtid = rdi32(p + 20); r.mpos = rdi32(p + 24); r.tlen = rdi32(p + 28);
-                                r.mate_ref = -2; r.nhash = h; r.keep = 0;
-                                r.umask = P.opt.masks ? (uint16_t)0 : (uint16_t)UZ_UMASK_ALL;
-                                if (P.desc) keep_raw(T, r, p, bs);
-                                else extract(T, r, p, bs, P.opt, P.opt.all_bases);
-                                T.recs.push_back(r);
-                            }
-                        }
-                        s.advance(bs);
+                lookup_walk(P, T, q.mtid, q.mpos, *infs[(size_t)k], [&](uint64_t h, uint32_t h2, uint32_t l_name, const uint8_t *name) {
+                    for (size_t u = first[(size_t)g]; u < k1; u++) {
+                        const WRec &x = rec_of(P, need[u].who);
+                        const Task &TX = P.tasks[(size_t)(need[u].who >> 32)];
+                        if (x.nhash == h && x.l_name == l_name && (P.desc ? x.nhash2 == h2 : memcmp(TX.names.data() + x.name_at, name, x.l_name) == 0)) return true;
                     }
-                }
-                T.file_bytes = s.file_bytes; T.n_blocks = s.n_blocks;
+                    return false;
+                });
             });
             // answers: first match in file order
             for (size_t g = 0; g < first.size(); g++) {
@@ -1873,6 +1885,112 @@ int uz_stage_walk_host(uz_stage *P, uz_walk_desc *out, int64_t cap, int64_t *d_f
             if (!P->twin[i].empty()) memcpy(out + d_first[i], P->twin[i].data(), P->twin[i].size() * sizeof(uz_walk_desc));
     });
 }
+
+/* ---- the joins on the device (include/uz_bamwalk.h: uz_bam_join).  The host's share of that route: the records it has to walk itself, handed to the
+ * device as descriptors (task = UZ_WALK_TASK_JOIN | join task: the stage task, or n_tasks + k for the k-th look-up through the index) whose bytes lie
+ * in the batch's aux store (src = UZ_WALK_SRC_AUX | offset of the fixed part). */
+namespace {
+void x_append(uz_stage &P, const Task &T, const WRec &r, const std::vector<uint8_t> &raw, uint32_t jtask, bool direct) {
+    uz_walk_desc x;
+    memset(&x, 0, sizeof(x));
+    x.voff = r.voff; x.h1 = r.nhash; x.h2 = r.nhash2;
+    x.src = UZ_WALK_SRC_AUX | (uint64_t)(P.xaux.size() + 4);
+    x.pos = r.pos; x.end = r.end; x.tlen = r.tlen; x.mpos = r.mpos; x.mtid = r.mtid;
+    x.task = UZ_WALK_TASK_JOIN | jtask; x.flag = r.flag; x.l_seq = r.l_seq; x.n_cigar = r.n_cigar; x.mapq = r.mapq; x.l_name = r.l_name;
+    x.direct = direct ? 1 : 0;
+    P.xdesc.push_back(x);
+    P.xaux.insert(P.xaux.end(), raw.begin() + r.pay_at, raw.begin() + r.pay_at + r.cigar_at); // (keep_raw: pay_at = its block_size field, cigar_at = 4 + block_size)
+}
+} // namespace
+
+/* d_flags [n walk tasks]: what the device's walk said of every walk task (uz_bam_walk_flags).  h_flags [n tasks of the stage] out: the tasks whose
+ * device descriptors are void -- the host walks those itself, here; totals: [0] descriptors, [1] aux bytes the stage holds for the device now */
+int uz_stage_walk_flagged(uz_stage *P, const int32_t *d_flags, int32_t *h_flags, int64_t totals[2]) {
+    if (!P || !P->begun || P->finished || !h_flags || !totals) { last_error = "uz_stage_walk_flagged: a plan that was begun and not yet finished"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        build_subtasks(*P);
+        P->desc = true;
+        P->joined = true;
+        for (Task &T : P->tasks) T.by_hash = true;
+        const size_t nt = P->tasks.size();
+        for (size_t i = 0; i < nt; i++) h_flags[i] = (!P->sub_preflag.empty() && P->sub_preflag[i]) ? UZ_WALK_TASK_INCOMPLETE : 0;
+        for (size_t u = 0; u < P->subs.size(); u++) h_flags[(size_t)P->subs[u].host] |= d_flags ? d_flags[u] : 0;
+        Scratch W;
+        for (size_t i = 0; i < nt; i++) {
+            if (!h_flags[i]) continue;
+            Task &T = P->tasks[i];
+            walk_task(*P, T, W, i, false);
+            // the mate candidates, as finish_task keeps them: the fetched records and those that share a name hash with one
+            std::vector<uint64_t> &dn = W.dn;
+            dn.clear();
+            for (const WRec &r : W.all) if (r.keep == 2) dn.push_back(r.nhash);
+            std::sort(dn.begin(), dn.end());
+            dn.erase(std::unique(dn.begin(), dn.end()), dn.end());
+            for (const WRec &r : W.all)
+                if (r.keep == 2 || std::binary_search(dn.begin(), dn.end(), r.nhash)) x_append(*P, T, r, W.tmp.raw, (uint32_t)i, r.keep == 2);
+            P->io_stats[0] += T.file_bytes; P->io_stats[1] += T.n_blocks; P->io_stats[2] += T.n_walked; P->io_stats[6] += T.n_pre;
+        }
+        totals[0] = (int64_t)P->xdesc.size(); totals[1] = (int64_t)P->xaux.size();
+    });
+}
+
+/* Mates nobody walked: need [n] -- the device's list of members whose mate position lies in no reach interval, or whose name the covering task does
+ * not hold.  Every distinct (reference, position) becomes a look-up task (the records overlapping it, through the index; kept: those with an asking
+ * name); jtask [n] out: the join task that answers need[k].  totals as above. */
+int uz_stage_lookup(uz_stage *P, int64_t n, const uz_need_rec *need, int32_t *jtask, int64_t totals[2]) {
+    if (!P || !P->joined || n < 0 || (n && (!need || !jtask)) || !totals) { last_error = "uz_stage_lookup: behind uz_stage_walk_flagged"; return UZ_IO_E_ARG; }
+    return guarded([&] {
+        const int32_t n_ref = (int32_t)P->src->contigs.size();
+        std::vector<int64_t> ord((size_t)n);
+        for (int64_t k = 0; k < n; k++) {
+            if (need[k].mtid < 0 || need[k].mtid >= n_ref) fail(UZ_IO_E_ARG, "uz_stage_lookup: a mate reference outside the file's");
+            ord[(size_t)k] = k;
+        }
+        std::sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) {
+            const uz_need_rec &a = need[x], &b = need[y];
+            return a.mtid < b.mtid || (a.mtid == b.mtid && (a.mpos < b.mpos || (a.mpos == b.mpos && x < y)));
+        });
+        std::vector<size_t> first; // look-ups of one position share a task
+        for (size_t k = 0; k < ord.size(); k++)
+            if (k == 0 || need[ord[k]].mtid != need[ord[k - 1]].mtid || need[ord[k]].mpos != need[ord[k - 1]].mpos) first.push_back(k);
+        const size_t base = P->look_tid.size();
+        std::vector<Task> xt(first.size());
+        const int w = (int)std::min<int64_t>(std::max(1, P->threads), std::max<int64_t>(1, (int64_t)first.size()));
+        std::vector<std::unique_ptr<Inflater>> infs((size_t)w);
+        for (auto &p : infs) p.reset(new Inflater());
+        parallel_dynamic((int64_t)first.size(), w, [&](int64_t g, int k) {
+            const size_t k0 = first[(size_t)g], k1 = (size_t)g + 1 < first.size() ? first[(size_t)g + 1] : ord.size();
+            const uz_need_rec &q = need[ord[k0]];
+            lookup_walk(*P, xt[(size_t)g], q.mtid, q.mpos, *infs[(size_t)k], [&](uint64_t h, uint32_t h2, uint32_t l_name, const uint8_t *) {
+                for (size_t u = k0; u < k1; u++) {
+                    const uz_need_rec &x = need[ord[u]];
+                    if (x.h1 == h && x.h2 == h2 && x.l_name == l_name) return true;
+                }
+                return false;
+            });
+        });
+        for (size_t g = 0; g < first.size(); g++) {
+            const size_t k1 = g + 1 < first.size() ? first[g + 1] : ord.size();
+            const uint32_t jt = (uint32_t)(P->tasks.size() + base + g);
+            for (size_t u = first[g]; u < k1; u++) jtask[ord[u]] = (int32_t)jt;
+            P->look_tid.push_back(xt[g].tid);
+            for (const WRec &r : xt[g].recs) x_append(*P, xt[g], r, xt[g].raw, jt, false);
+            P->io_stats[0] += xt[g].file_bytes; P->io_stats[1] += xt[g].n_blocks; P->io_stats[2] += xt[g].n_walked;
+        }
+        P->io_stats[5] += n;
+        totals[0] = (int64_t)P->xdesc.size(); totals[1] = (int64_t)P->xaux.size();
+    });
+}
+
+/* the descriptors from d0 on and the aux bytes from a0 on, as the two calls above left them; look_tid [look-up tasks so far] or NULL */
+int uz_stage_extra(const uz_stage *P, int64_t d0, int64_t a0, uz_walk_desc *desc, uint8_t *aux, int32_t *look_tid) {
+    if (!P || d0 < 0 || a0 < 0 || d0 > (int64_t)P->xdesc.size() || a0 > (int64_t)P->xaux.size()) { last_error = "uz_stage_extra: offsets beyond what the stage holds"; return UZ_IO_E_ARG; }
+    if (desc && d0 < (int64_t)P->xdesc.size()) memcpy(desc, P->xdesc.data() + d0, (P->xdesc.size() - (size_t)d0) * sizeof(uz_walk_desc));
+    if (aux && a0 < (int64_t)P->xaux.size()) memcpy(aux, P->xaux.data() + a0, P->xaux.size() - (size_t)a0);
+    if (look_tid && !P->look_tid.empty()) memcpy(look_tid, P->look_tid.data(), P->look_tid.size() * sizeof(int32_t));
+    return 0;
+}
+int64_t uz_stage_n_lookup_tasks(const uz_stage *P) { return P ? (int64_t)P->look_tid.size() : 0; }
 
 /* parity aid (tests/test_stage_desc.py): the kept records of ANY finished plan, in output order -- virtual offset, name id, mate, 1 when the
  * record travels with bases */

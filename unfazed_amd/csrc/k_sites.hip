@@ -887,8 +887,12 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
             if (c->find_pin_cap < 2 * obr) {
                 if (c->find_pin) (void)hipHostFree(c->find_pin);
                 c->find_pin = nullptr;
-                c->find_pin_cap = 2 * obr + obr / 2 + 4096;
-                UZ_HIP(hipHostMalloc((void **)&c->find_pin, c->find_pin_cap, hipHostMallocDefault));
+                c->find_pin_cap = 0; // (set again only once the new block exists: a failed allocation must not leave a capacity behind)
+                const size_t want = 2 * obr + obr / 2 + 4096;
+                uint8_t *pin = nullptr;
+                UZ_HIP(hipHostMalloc((void **)&pin, want, hipHostMallocDefault));
+                c->find_pin = pin;
+                c->find_pin_cap = want;
             }
             uz_kcopy(c, c->find_pin, c->cand_off.p, ob);
             uz_kcopy(c, c->find_pin + obr, c->het_off.p, ob);

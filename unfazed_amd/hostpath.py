@@ -589,8 +589,13 @@ class PhasingHost:
         parts = [idxs[cuts[k]: cuts[k + 1]] for k in range(len(cuts) - 1)]
 
         from . import pipeline
-        lag = 1  # (chunks of a few thousand DNMs: the first read stage should start as early as it can)
-        ahead = int(os.environ.get("UZ_HOST_AHEAD", 3))  # BAM stages in flight beside the chunk on the device (native code: the interpreter lock is released; bench.py's own loop runs three)
+        # (chunks of a few thousand DNMs: the first read stage should start as early as it can.  The lag is fixed HERE, UZ_PIPE_LAG is not
+        # honoured on this route: the staging slots below are counted from it, and a slot re-staged while the upload of chunk k - 2 still
+        # reads its page-locked buffers would corrupt that chunk's records silently)
+        lag = 1
+        # BAM stages in flight beside the chunk on the device (native code: the interpreter lock is released; bench.py's own loop runs three).
+        # Held to the device's walk slots (csrc/uz_ctx.hpp WALK_SLOTS = 4): chunk k still owns one while stage k + ahead asks for another
+        ahead = max(1, min(int(os.environ.get("UZ_HOST_AHEAD", 3)), 3))
         n_slots = lag + 1 + ahead  # a slot is staged into again once the read stage of the chunk it held has been collected
 
         def stage(k):
@@ -626,6 +631,10 @@ class PhasingHost:
                     # not in a pass over the whole batch behind the pipeline
                     with _Sec("evidence"):
                         res["built"] = self._evidence_lists(res, range(len(part)), table)
+                # The strings exist (or nobody asked for lists): the chunk's names are let go.  They resolve ids lazily out of the staging slot's
+                # page-locked buffers -- kept, they would pin every chunk's stage plan until the call returns, and once the slot is staged into
+                # again they would answer with another chunk's names.
+                table.qnames = None
                 for j, i in enumerate(part):
                     results[i] = (res, j, table)
 
@@ -635,12 +644,23 @@ class PhasingHost:
             chunks = [dict(a=cuts[k], b=cuts[k + 1], dnms=self._dnms_view_of(parts[k], dnms, prep, found, cutoff), records=records, sites=None)
                       for k in range(len(parts))]
             trace = [] if os.environ.get("UZ_HOST_TRACE") else None  # development aid: ms per pipeline step (find, collect, queue, records + upload)
-            pipeline.run_pipelined(self.backend, params, mode, len(idxs), chunks, fid=fam, lag=lag, on_done=done, trace=trace)
+            pipeline.run_pipelined(self.backend, params, mode, len(idxs), chunks, fid=fam, lag=lag, on_done=done, trace=trace, env_lag=False)
             if trace:
                 print("[uz] chunked batch, ms per step:", trace[0], file=sys.stderr)
         return True
 
-    def run_read_phasing(
+    def run_read_phasing(self, dnms, pedigrees, *args, **kwargs):
+        """run_read_phasing_impl, and whatever it raises behind find() -- a reference KeyError mimicked in pass 1, an I/O error of a BAM stage --
+        the caller's DNMs carry their `candidate_sites` / `het_sites`: the reference annotates in find(), before any phasing work starts
+        (informative_site_finder.py:341-343), and find(defer_attach=True) only postpones the dict building behind the first BAM stages."""
+        box = []
+        try:
+            return self.run_read_phasing_impl(dnms, pedigrees, *args, _attach_box=box, **kwargs)
+        finally:
+            for attach in box:
+                attach()  # (idempotent: a no-op once the lists are attached)
+
+    def run_read_phasing_impl(
         self,
         dnms,
         pedigrees,
@@ -656,6 +676,7 @@ class PhasingHost:
         readlen,
         want_lists=True,
         sv=False,
+        _attach_box=None,
     ):
         """reference snv_phaser.py:206-299 (+ multithread_read_phasing :87-203); with sv=True the
         SV variant sv_phaser.py:176-266 (+ :88-173): no REF/ALT lookup, reads collected by
@@ -674,6 +695,8 @@ class PhasingHost:
         if ret is None:
             return records
         attach_sites = info["attach"]
+        if _attach_box is not None:
+            _attach_box.append(attach_sites)
         found = info["found"]
         # pass 1: host-side filters in the reference's order; collect the device batch per kid
         plan = []  # (dnm index, action)

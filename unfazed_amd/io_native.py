@@ -34,6 +34,7 @@ IO_EXPORTS = [
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
     "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums", "uz_stage_merge_subtasks", "uz_bam_stage_finish_sub",
+    "uz_stage_walk_flagged", "uz_stage_lookup", "uz_stage_extra", "uz_stage_n_lookup_tasks",
 ]
 
 
@@ -188,6 +189,11 @@ def load():
     lib.uz_packed_block_sums.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.uz_stage_merge_subtasks.argtypes = [C.c_void_p] * 8
     lib.uz_bam_stage_finish_sub.argtypes = [C.c_void_p] * 5
+    lib.uz_stage_walk_flagged.argtypes = [C.c_void_p] * 4
+    lib.uz_stage_lookup.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.uz_stage_extra.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.uz_stage_n_lookup_tasks.argtypes = [C.c_void_p]
+    lib.uz_stage_n_lookup_tasks.restype = C.c_int64
     _LIB = lib
     return lib
 
@@ -647,7 +653,9 @@ WALK_DESC = np.dtype([("voff", "<u8"), ("src", "<u8"), ("h1", "<u8"), ("pos", "<
                       ("h2", "<u4"), ("task", "<u4"), ("flag", "<u2"), ("l_seq", "<u2"), ("n_cigar", "<u2"), ("mapq", "u1"), ("l_name", "u1"), ("direct", "u1"),
                       ("pad8", "u1"), ("pad16", "<u2")])
 KEPT_REC = np.dtype([("src", "<u8"), ("qname", "<u4"), ("mate", "<i4"), ("cig_off", "<u4"), ("unit_off", "<u4"), ("seq_off", "<u4"), ("name_off", "<u4")])
-assert WALK_DESC.itemsize == 64 and KEPT_REC.itemsize == 32
+NEED_REC = np.dtype([("h1", "<u8"), ("h2", "<u4"), ("l_name", "<u4"), ("mtid", "<i4"), ("mpos", "<i4"), ("who", "<u4"), ("pad", "<u4")])
+assert WALK_DESC.itemsize == 64 and KEPT_REC.itemsize == 32 and NEED_REC.itemsize == 32
+WALK_TASK_JOIN = 0x80000000
 WALK_TASK_COLS, WALK_SPAN_COLS = 10, 6
 KEPT_NO_SEQ = 0xFFFFFFFF
 WALK_SRC_AUX = 1 << 63

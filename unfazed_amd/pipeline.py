@@ -30,7 +30,7 @@ import numpy as np
 
 
 def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = False, fid=None, trace: Optional[list] = None, lag: Optional[int] = None,
-                  on_done: Optional[Callable] = None) -> Dict[str, np.ndarray]:
+                  on_done: Optional[Callable] = None, env_lag: bool = True) -> Dict[str, np.ndarray]:
     """One pass over the batch -> per-DNM status / counts / origin / evidence (+ etype / cnv_counts for cnv).
     on_done(k, results of chunk k): called when the read stage of chunk k has been collected and before the next one is queued -- the moment its
     vote lists can still be fetched (uz_phase_votes).  lag: read stages queued this many finds behind (None: from the chunk size); a caller that
@@ -106,7 +106,8 @@ def run_pipelined(eng, P, mode, n: int, chunks: Sequence[dict], cnv: bool = Fals
         # two finds ahead pays when a chunk's copy + header build is long (100 k DNMs in 8 chunks of 12.5 k: 12.27 -> 11.9 ms; config 5's three heavy
         # chunks: 4.6 -> 4.5 ms); the three small chunks of a 12.5 k-DNM shard only start their first read stage later (2.45 -> 2.7 ms)
         lag = 2 if (cnv or n >= 8000 * max(1, K)) else 1
-    lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid)
+    if env_lag:  # (a caller that counted its staging buffers from the lag it passed switches the override off)
+        lag = int(os.environ.get("UZ_PIPE_LAG", lag))  # (development aid)
     lag = max(0, min(int(lag), 2, K - 1)) if K > 1 else 1
     site_stage(0)
     if K > 1:
