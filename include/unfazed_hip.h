@@ -125,6 +125,29 @@ int uz_bam_walk(uz_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, int64_t n_
 int uz_crc32_blocks(uz_ctx *ctx, const uint8_t *data, int64_t n_blocks, const int64_t *off, const uint32_t *want, int64_t *first_bad);
 int uz_bam_walk_fetch(uz_ctx *ctx, int walk_id, uz_walk_desc *desc, int64_t *d_first, int32_t *d_flags, int64_t *d_walked);
 int uz_bam_walk_release(uz_ctx *ctx, int walk_id);
+/* ---- The batch-wide joins of a walked batch ON THE DEVICE (csrc/k_bamjoin.hip): mate() for every fetched record and every mate of a mate
+ * (read_collector.py:400, :185), the names numbered by first appearance (the name-keyed tables of read_collector.py:226-234), file order, the
+ * offsets of the record table -- through round 5 the host's uz_bam_stage_finish_desc over descriptors that crossed the link.  The descriptors stay
+ * in the batch's slot; the host contributes only the records it has to walk itself (unfazed_io.h: uz_stage_walk_flagged, uz_stage_lookup), as
+ * descriptors of its own (uz_walk_desc.task = UZ_WALK_TASK_JOIN | join task, .src = UZ_WALK_SRC_AUX | offset in the aux bytes).
+ *   uz_bam_walk_flags   what the walk said of every walk task (d_flags, d_walked [n_tasks]) -> uz_stage_walk_flagged
+ *   uz_bam_join         first call: n_host tasks of the stage, h_flags [n_host] (the tasks the host walked: their device descriptors are void),
+ *                       n_ref references, all_bases; every call: xdesc [n_x] / xaux [xaux_bytes] = what the host walked SINCE the last call,
+ *                       look_tid [n_look] = the reference of every look-up task so far, need_jtask = the answers to the last call's needs
+ *                       (NULL on the first call).  -> *n_need > 0: the closure needs the index (uz_bam_join_needs -> uz_stage_lookup -> call again);
+ *                       *n_need == 0: finished, totals = records, name ids, CIGAR words, row units, base-row units, name bytes
+ *   uz_bam_join_fetch   parity / debug: the kept records in output order (any pointer may be NULL); contig_off [n_ref + 1], max_span [n_ref]
+ *   uz_reads_from_walk  the record table, unpacked from the bytes in HBM through the kept list in HBM (releases the batch).  want_names: the read
+ *                       names stay on the device with the table and uz_reads_names answers name ids (off [n + 1]; buf NULL or too small: *need only)
+ *   uz_walk_slot_stats  [0] device allocations the slots have made, [1] outgrown blocks parked, [2] their bytes, [4..7] the slots' inflated-bytes room */
+int uz_bam_walk_flags(uz_ctx *ctx, int walk_id, int32_t *d_flags, int64_t *d_walked);
+int uz_bam_join(uz_ctx *ctx, int walk_id, int32_t n_host, const int32_t *h_flags, int32_t n_ref, int all_bases, const uz_walk_desc *xdesc, int64_t n_x, const uint8_t *xaux,
+                int64_t xaux_bytes, const int32_t *look_tid, int64_t n_look, const int32_t *need_jtask, int64_t *n_need, int64_t totals[8]);
+int uz_bam_join_needs(uz_ctx *ctx, int walk_id, uz_need_rec *need);
+int uz_bam_join_fetch(uz_ctx *ctx, int walk_id, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases, uz_kept_rec *kept, int64_t *contig_off, int32_t *max_span);
+int uz_reads_from_walk(uz_ctx *ctx, int walk_id, int32_t min_base_qual, int want_names, int *reads_id, int64_t totals[8]);
+int uz_reads_names(uz_ctx *ctx, int reads_id, const uint32_t *ids, int64_t n, int64_t *off, uint8_t *buf, int64_t cap, int64_t *need);
+int uz_walk_slot_stats(uz_ctx *ctx, int64_t out[8]);
 int uz_reads_from_bam(uz_ctx *ctx, int walk_id, const uz_kept_rec *kept, int64_t n, const uint8_t *aux, int64_t aux_bytes, const int64_t *contig_off,
                       const int32_t *max_span, int32_t n_contigs, int64_t n_cigar_total, int64_t n_row_units, int64_t n_seq_units, uint32_t n_qnames,
                       int32_t min_base_qual, uint8_t *names_out /* NULL, or [names_bytes]: the kept records' read names back to back (uz_kept_rec.name_off) */,

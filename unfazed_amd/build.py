@@ -8,7 +8,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["abi.hip", "k_sites.hip", "k_reads.hip", "k_inflate.hip", "k_bamwalk.hip"]
+SRC = ["abi.hip", "k_sites.hip", "k_reads.hip", "k_inflate.hip", "k_bamwalk.hip", "k_bamjoin.hip"]
 DEFAULT_FLAGS = []
 LIB = os.path.join(_HERE, "libunfazed_hip.so")
 

@@ -420,7 +420,17 @@ void uz_destroy(uz_ctx *c) {
         if (w.s0) (void)hipStreamDestroy(w.s0);
         if (w.s1) (void)hipStreamDestroy(w.s1);
         if (w.ev) (void)hipEventDestroy(w.ev);
+        w.comp.release(); w.out.release(); w.in_off.release(); w.out_off.release(); w.blk_coff.release(); w.span.release(); w.count.release(); w.first.release();
+        w.walked.release(); w.task.release(); w.reach.release(); w.fetch.release(); w.flags.release(); w.iflags.release(); w.blk_crc.release(); w.desc.release();
+        w.desc_kept.release(); w.n_direct.release(); w.tab_first.release(); w.kcount.release(); w.kfirst.release(); w.tab.release();
+        auto &J = w.join;
+        J.jtask.release(); J.keep.release(); J.mate.release(); J.target.release(); J.h_flags.release(); J.jt_tid.release(); J.reach_a.release(); J.reach_host.release();
+        J.cnt.release(); J.cspan.release(); J.look_tid.release(); J.reach_key.release(); J.totals.release(); J.hkey_in.release(); J.hkey.release(); J.fkey_in.release();
+        J.fkey.release(); J.ccount.release(); J.hval_in.release(); J.hperm.release(); J.inv.release(); J.fval_in.release(); J.fidx.release(); J.front0.release();
+        J.front1.release(); J.need.release(); J.first.release(); J.runid.release(); J.pos_of_k.release(); J.fo.release(); J.name_rec.release(); J.gidx.release();
+        J.tmp.release(); J.aux.release(); J.s5_in.release(); J.s5_out.release(); J.need_rec.release(); J.kept.release();
     }
+    for (auto &b : c->walk_park) (void)hipFree(b.first);
     for (FindSlot &a : c->find_alt) {
         a.cnt_c.release(); a.cnt_h.release(); a.win_range.release(); a.cand_off.release(); a.het_off.release();
         a.cand_idx.release(); a.het_idx.release(); a.cand_flags.release();
@@ -1754,13 +1764,43 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                        UZ_E_ARG, "walk plan: a span names blocks or bytes outside the block table");
         }
         UZ_HIP(hipSetDevice(c->device));
+        // one pass: every task writes its descriptors into a slice sized for the most records its bytes can hold (a record is at least 36 bytes)
+        std::vector<int64_t> first((size_t)n_tasks + 1, 0);
+        for (int32_t t = 0; t < n_tasks; t++) {
+            const int32_t *tc = task + UZ_WALK_TASK_COLS * (size_t)t;
+            int64_t cap = 0;
+            for (int32_t sp = tc[2]; sp < tc[3]; sp++) cap += (span[UZ_WALK_SPAN_COLS * (size_t)sp + 3] - span[UZ_WALK_SPAN_COLS * (size_t)sp + 2]) / 36 + 1;
+            first[(size_t)t + 1] = first[(size_t)t] + cap;
+        }
+        // The slot: a free one whose large buffers already hold this batch -- the smallest such (best fit) --, else one that has never been
+        // used, else the smallest (it is grown to the largest sizes ANY batch of this context has asked for: a slot grows once).  Nothing is
+        // freed while batches are in flight (hipFree waits for the whole device -- round 5: a process's second call, whose larger last chunk met
+        // another slot than in the first call, stood still for 0.9 s): an outgrown block is parked (DevBuf::ensure_parked).
+        const size_t need_out = (size_t)out_bytes + uz_bam_walk_pad(), need_comp = (size_t)comp_bytes + 1024, need_desc = (size_t)first.back() + 1;
         int k = -1;
         {
             std::lock_guard<std::mutex> lk(c->err_mu);
-            for (int i = 0; i < uz_ctx::WALK_SLOTS && k < 0; i++)
-                if (!c->walk[i].busy) { k = i; c->walk[i].busy = true; }
+            int fit = -1, fresh = -1, small = -1, busy = 0;
+            for (int i = 0; i < uz_ctx::WALK_SLOTS; i++) {
+                const uz_ctx::WalkSlot &s = c->walk[i];
+                if (s.busy) { busy++; continue; }
+                if (s.out.cap >= need_out && s.comp.cap >= need_comp && s.desc.cap >= need_desc) { if (fit < 0 || s.out.cap < c->walk[fit].out.cap) fit = i; }
+                else if (s.out.cap == 0) { if (fresh < 0) fresh = i; }
+                else if (small < 0 || s.out.cap < c->walk[small].out.cap) small = i;
+            }
+            k = fit >= 0 ? fit : fresh >= 0 ? fresh : small;
+            if (k >= 0) c->walk[k].busy = true;
+            if (busy == 0 && k >= 0) { // nothing of an earlier batch is in flight: what was parked can go (only worth a device-wide wait when it is a lot)
+                std::lock_guard<std::mutex> lk2(c->walk_mu);
+                size_t parked = 0;
+                for (auto &b : c->walk_park) parked += b.second;
+                if (parked > ((size_t)24 << 30)) {
+                    for (auto &b : c->walk_park) (void)hipFree(b.first);
+                    c->walk_park.clear();
+                }
+            }
         }
-        UZ_REQUIRE(k >= 0, UZ_E_STATE, "four walked batches are waiting for uz_reads_from_bam / uz_bam_walk_release");
+        UZ_REQUIRE(k >= 0, UZ_E_STATE, "four walked batches are waiting for uz_reads_from_bam / uz_reads_from_walk / uz_bam_walk_release");
         uz_ctx::WalkSlot &w = c->walk[k];
         try {
             // streams of the slot's own: the blocks of the next batch go up and are inflated while this one is still walked (two calls may run at once)
@@ -1770,19 +1810,23 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 UZ_HIP(hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
             }
             hipStream_t st = w.s0;
-            w.n_blocks = n_blocks; w.out_bytes = out_bytes; w.n_tasks = n_tasks; w.n_desc = 0;
-            w.comp.ensure((size_t)comp_bytes + 1024); w.out.ensure((size_t)out_bytes + uz_bam_walk_pad());
-            w.in_off.ensure((size_t)n_blocks + 1); w.out_off.ensure((size_t)n_blocks + 1); w.blk_coff.ensure((size_t)n_blocks + 1);
-            w.task.ensure((size_t)n_tasks * UZ_WALK_TASK_COLS + 1); w.span.ensure((size_t)n_spans * UZ_WALK_SPAN_COLS + 1);
-            w.reach.ensure((size_t)n_reach * 2 + 1); w.fetch.ensure((size_t)n_fetch * 3 + 1);
-            w.count.ensure((size_t)n_tasks + 1); w.first.ensure((size_t)n_tasks + 2); w.walked.ensure((size_t)n_tasks + 1); w.flags.ensure((size_t)n_tasks + 1);
-            w.n_direct.ensure((size_t)n_tasks + 1); w.tab_first.ensure((size_t)n_tasks + 2); w.kcount.ensure((size_t)n_tasks + 1); w.kfirst.ensure((size_t)n_tasks + 2);
+            w.n_blocks = n_blocks; w.out_bytes = out_bytes; w.n_tasks = n_tasks; w.n_desc = 0; w.n_reach = n_reach;
+            w.max_host = n_tasks ? task[UZ_WALK_TASK_COLS * (size_t)(n_tasks - 1) + 9] : -1;
+            w.join.started = false; w.join.done = false; w.join.n_need = 0; w.join.n_all = 0; w.join.n_dev = 0; w.join.aux_bytes = 0; w.join.n_look = 0;
+            uz_walk_grow(c, w.comp, need_comp, 0); uz_walk_grow(c, w.out, need_out, 1);
+            uz_walk_grow(c, w.in_off, (size_t)n_blocks + 1, 2); uz_walk_grow(c, w.out_off, (size_t)n_blocks + 1, 3); uz_walk_grow(c, w.blk_coff, (size_t)n_blocks + 1, 4);
+            uz_walk_grow(c, w.task, (size_t)n_tasks * UZ_WALK_TASK_COLS + 1, 5); uz_walk_grow(c, w.span, (size_t)n_spans * UZ_WALK_SPAN_COLS + 1, 6);
+            uz_walk_grow(c, w.reach, (size_t)n_reach * 2 + 1, 7); uz_walk_grow(c, w.fetch, (size_t)n_fetch * 3 + 1, 8);
+            uz_walk_grow(c, w.count, (size_t)n_tasks + 1, 9); uz_walk_grow(c, w.first, (size_t)n_tasks + 2, 10); uz_walk_grow(c, w.walked, (size_t)n_tasks + 1, 11);
+            uz_walk_grow(c, w.flags, (size_t)n_tasks + 1, 12);
+            uz_walk_grow(c, w.n_direct, (size_t)n_tasks + 1, 13); uz_walk_grow(c, w.tab_first, (size_t)n_tasks + 2, 14); uz_walk_grow(c, w.kcount, (size_t)n_tasks + 1, 15);
+            uz_walk_grow(c, w.kfirst, (size_t)n_tasks + 2, 16);
             // the blocks in slices of ~8 k on two streams, as uz_bgzf_inflate_to_host sends them: slice i + 1 goes up while slice i is inflated
             std::vector<int64_t> cut{0};
             for (int64_t b = 1; b <= n_blocks; b++)
                 if (b == n_blocks || (b - cut.back() >= 8192 && n_blocks - b >= 4096)) cut.push_back(b);
             const size_t ns = cut.size() - 1;
-            w.iflags.ensure(2 * ns + 8); w.blk_crc.ensure((size_t)n_blocks + 1);
+            uz_walk_grow(c, w.iflags, 2 * ns + 8, 17); uz_walk_grow(c, w.blk_crc, (size_t)n_blocks + 1, 18);
             std::vector<int32_t> iflags(2 * ns + 4, 0);
             if (n_blocks) {
                 hipStream_t s2[2] = {w.s0, w.s1};
@@ -1810,16 +1854,8 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
             }
             int64_t tab_total = 0, kept = 0;
             if (n_tasks) {
-                // one pass: every task writes its descriptors into a slice sized for the most records its bytes can hold (a record is at least 36 bytes)
-                std::vector<int64_t> first((size_t)n_tasks + 1, 0);
-                for (int32_t t = 0; t < n_tasks; t++) {
-                    const int32_t *tc = task + UZ_WALK_TASK_COLS * (size_t)t;
-                    int64_t cap = 0;
-                    for (int32_t sp = tc[2]; sp < tc[3]; sp++) cap += (span[UZ_WALK_SPAN_COLS * (size_t)sp + 3] - span[UZ_WALK_SPAN_COLS * (size_t)sp + 2]) / 36 + 1;
-                    first[(size_t)t + 1] = first[(size_t)t] + cap;
-                }
                 w.n_desc_all = first.back();
-                w.desc.ensure((size_t)first.back() + 1);
+                uz_walk_grow(c, w.desc, need_desc, 19);
                 UZ_HIP(hipMemcpyAsync(w.first.p, first.data(), ((size_t)n_tasks + 1) * 8, hipMemcpyHostToDevice, st));
                 UZ_HIP(hipMemcpyAsync(w.task.p, task, (size_t)n_tasks * UZ_WALK_TASK_COLS * 4, hipMemcpyHostToDevice, st));
                 if (n_spans) UZ_HIP(hipMemcpyAsync(w.span.p, span, (size_t)n_spans * UZ_WALK_SPAN_COLS * 8, hipMemcpyHostToDevice, st));
@@ -1830,7 +1866,7 @@ int uz_bam_walk(uz_ctx *c, const uint8_t *comp, int64_t comp_bytes, int64_t n_bl
                 UZ_HIP(hipMemcpyAsync(&tab_total, w.tab_first.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
                 UZ_HIP(hipStreamSynchronize(st)); // (the pageable `first` has been read; the hash sets' size is known)
                 // the descriptors the host's joins can need at all (direct, or sharing a name hash with a direct record of the task) are counted
-                w.tab.ensure((size_t)tab_total + 1);
+                uz_walk_grow(c, w.tab, (size_t)tab_total + 1, 20);
                 UZ_HIP(hipMemsetAsync(w.tab.p, 0, (size_t)tab_total * 8, st));
                 uz_launch_desc_filter(c, st, false, n_tasks, w.desc.p, w.first.p, w.count.p, w.task.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, nullptr);
                 UZ_HIP(hipMemcpyAsync(&kept, w.kfirst.p + n_tasks, 8, hipMemcpyDeviceToHost, st));
@@ -1869,7 +1905,7 @@ int uz_bam_walk_fetch(uz_ctx *c, int walk_id, uz_walk_desc *desc, int64_t *d_fir
         hipStream_t st = w.s0;
         const int32_t nt = w.n_tasks;
         if (nt == 0) { d_first[0] = 0; return; }
-        w.desc_kept.ensure((size_t)w.n_desc + 1);
+        uz_walk_grow(c, w.desc_kept, (size_t)w.n_desc + 1, 41);
         uz_launch_desc_filter(c, st, true, nt, w.desc.p, w.first.p, w.count.p, w.task.p, w.tab_first.p, w.tab.p, w.kcount.p, w.kfirst.p, w.desc_kept.p);
         if (w.n_desc) UZ_HIP(hipMemcpyAsync(desc, w.desc_kept.p, (size_t)w.n_desc * sizeof(uz_walk_desc), hipMemcpyDeviceToHost, st));
         UZ_HIP(hipMemcpyAsync(d_first, w.kfirst.p, (size_t)(nt + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1884,6 +1920,166 @@ int uz_bam_walk_release(uz_ctx *c, int walk_id) {
         UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS, UZ_E_ARG, "bad walk id");
         std::lock_guard<std::mutex> lk(c->err_mu);
         c->walk[walk_id].busy = false;
+    });
+}
+
+// ---- the batch-wide joins on the device (csrc/k_bamjoin.hip)
+int uz_bam_walk_flags(uz_ctx *c, int walk_id, int32_t *d_flags, int64_t *d_walked) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        uz_ctx::WalkSlot &w = c->walk[walk_id];
+        if (w.n_tasks == 0) return;
+        if (d_flags) UZ_HIP(hipMemcpyAsync(d_flags, w.flags.p, (size_t)w.n_tasks * 4, hipMemcpyDeviceToHost, w.s0));
+        if (d_walked) UZ_HIP(hipMemcpyAsync(d_walked, w.walked.p, (size_t)w.n_tasks * 8, hipMemcpyDeviceToHost, w.s0));
+        UZ_HIP(hipStreamSynchronize(w.s0));
+    });
+}
+
+int uz_bam_join(uz_ctx *c, int walk_id, int32_t n_host, const int32_t *h_flags, int32_t n_ref, int all_bases, const uz_walk_desc *xdesc, int64_t n_x, const uint8_t *xaux,
+                int64_t xaux_bytes, const int32_t *look_tid, int64_t n_look, const int32_t *need_jtask, int64_t *n_need, int64_t totals[8]) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        UZ_REQUIRE(n_need != nullptr, UZ_E_ARG, "null output");
+        uz_ctx::WalkSlot &w = c->walk[walk_id];
+        UZ_REQUIRE(n_host > w.max_host, UZ_E_ARG, "uz_bam_join: the plan names more tasks of the stage (column 9) than n_host");
+        for (int64_t k = 0; k < n_x; k++)
+            UZ_REQUIRE((xdesc[k].task & UZ_WALK_TASK_JOIN) && (xdesc[k].src & UZ_WALK_SRC_AUX), UZ_E_ARG, "uz_bam_join: a descriptor of the host without its join task or outside the aux bytes");
+        JoinPlanHost P;
+        P.n_host = n_host; P.n_ref = n_ref; P.h_flags = h_flags; P.all_bases = all_bases != 0;
+        uz_join_run(c, w, P, xdesc, n_x, xaux, xaux_bytes, look_tid, n_look, need_jtask);
+        *n_need = w.join.n_need;
+        if (totals) for (int k = 0; k < 8; k++) totals[k] = w.join.done ? w.join.tot_h[k] : 0;
+    });
+}
+
+int uz_bam_join_needs(uz_ctx *c, int walk_id, uz_need_rec *need) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy && need, UZ_E_ARG, "bad walk id");
+        uz_join_needs(c, c->walk[walk_id], need);
+    });
+}
+
+int uz_bam_join_fetch(uz_ctx *c, int walk_id, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases, uz_kept_rec *kept, int64_t *contig_off, int32_t *max_span) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy, UZ_E_ARG, "bad walk id");
+        uz_ctx::WalkSlot &w = c->walk[walk_id];
+        uz_join_fetch(c, w, voff, qname, mate, bases, kept);
+        if (contig_off) for (size_t k = 0; k < w.join.contig_off_h.size(); k++) contig_off[k] = w.join.contig_off_h[k];
+        if (max_span) for (int32_t k = 0; k < w.join.n_ref; k++) max_span[k] = w.join.max_span_h[(size_t)k];
+    });
+}
+
+int uz_walk_slot_stats(uz_ctx *c, int64_t out[8]) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(out != nullptr, UZ_E_ARG, "null output");
+        std::lock_guard<std::mutex> lk(c->walk_mu);
+        size_t parked = 0;
+        for (auto &b : c->walk_park) parked += b.second;
+        out[0] = c->walk_allocs; out[1] = (int64_t)c->walk_park.size(); out[2] = (int64_t)parked; out[3] = 0;
+        for (int i = 0; i < uz_ctx::WALK_SLOTS && i < 4; i++) out[4 + i] = (int64_t)c->walk[i].out.cap;
+    });
+}
+
+// The table of a batch whose joins ran on the device: the kept list lies in the slot (uz_bam_join), the records are unpacked where they lie.
+int uz_reads_from_walk(uz_ctx *c, int walk_id, int32_t min_base_qual, int want_names, int *reads_id, int64_t totals[8]) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(walk_id >= 0 && walk_id < uz_ctx::WALK_SLOTS && c->walk[walk_id].busy && reads_id, UZ_E_ARG, "bad walk id");
+        uz_ctx::WalkSlot &w = c->walk[walk_id];
+        auto &J = w.join;
+        UZ_REQUIRE(J.done, UZ_E_STATE, "uz_reads_from_walk: the joins of this batch are not finished (uz_bam_join until it needs nothing)");
+        const int64_t n = J.tot_h[JT_N], n_cigar_total = J.tot_h[JT_CIGAR], n_row_units = J.tot_h[JT_UNITS], n_seq_units = J.tot_h[JT_SEQ_UNITS], names_bytes = J.tot_h[JT_NAME_BYTES];
+        const int64_t n_qnames = J.tot_h[JT_QNAMES];
+        const int32_t n_contigs = J.n_ref;
+        UZ_REQUIRE(n < (int64_t)0x7FFFFFF0 && n_cigar_total < ((int64_t)1 << 32) && n_row_units < ((int64_t)1 << 32) && names_bytes < ((int64_t)1 << 32), UZ_E_RANGE,
+                   "uz_reads_from_walk: the batch does not fit the table's 32-bit offsets");
+        if (totals) for (int k = 0; k < 8; k++) totals[k] = J.tot_h[k];
+        DevBlock blk;
+        uz_kept_rec *d_kept = nullptr;
+        uint8_t *mapq = nullptr, *aux_col = nullptr, *seq4 = nullptr, *d_names = nullptr;
+        int64_t *d_coff = nullptr;
+        int32_t *d_span = nullptr, *start = nullptr, *tlen = nullptr, *mate = nullptr, *err = nullptr;
+        uint32_t *qname = nullptr, *cigar = nullptr, *plane = nullptr, *name_rec = nullptr;
+        uint16_t *flag = nullptr, *l_seq = nullptr, *n_cigar = nullptr;
+        for (int pass = 0; pass < 2; pass++) {
+            Carver cv(pass ? blk.p : nullptr);
+            d_coff = cv.take<int64_t>((size_t)n_contigs + 1); d_span = cv.take<int32_t>((size_t)n_contigs + 1); err = cv.take<int32_t>(4);
+            start = cv.take<int32_t>((size_t)n); tlen = cv.take<int32_t>((size_t)n); mate = cv.take<int32_t>((size_t)n); qname = cv.take<uint32_t>((size_t)n);
+            flag = cv.take<uint16_t>((size_t)n); l_seq = cv.take<uint16_t>((size_t)n); n_cigar = cv.take<uint16_t>((size_t)n);
+            mapq = cv.take<uint8_t>((size_t)n); aux_col = cv.take<uint8_t>((size_t)n);
+            cigar = cv.take<uint32_t>((size_t)n_cigar_total); seq4 = cv.take<uint8_t>((size_t)n_seq_units * UZ_SEQ4_UNIT_BYTES);
+            plane = cv.take<uint32_t>((size_t)n_row_units);
+            if (want_names) { d_kept = cv.take<uz_kept_rec>((size_t)n); name_rec = cv.take<uint32_t>((size_t)n_qnames); d_names = cv.take<uint8_t>((size_t)names_bytes); }
+            if (!pass) blk = uz_block_get(c, cv.off + 256);
+        }
+        int id = -1;
+        try {
+            hipStream_t st = c->stream; // (the joins ran on the slot's stream and were waited for: uz_bam_join returns behind them)
+            UZ_HIP(hipMemcpyAsync(d_coff, J.contig_off_h.data(), ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice, st));
+            if (n_contigs) UZ_HIP(hipMemcpyAsync(d_span, J.max_span_h.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, st));
+            UZ_HIP(hipMemsetAsync(err, 0, 16, st));
+            uz_launch_bam_extract(c, st, n, w.out.p, w.out_bytes, J.aux.p, J.aux_bytes, J.kept.p, min_base_qual, start, tlen, mate, qname, flag, l_seq, n_cigar, mapq, aux_col,
+                                  cigar, seq4, plane, err, want_names ? d_names : nullptr, n_cigar_total, n_row_units, n_seq_units, names_bytes);
+            if (want_names && n) {
+                UZ_HIP(hipMemcpyAsync(d_kept, J.kept.p, (size_t)n * sizeof(uz_kept_rec), hipMemcpyDeviceToDevice, st));
+                if (n_qnames) UZ_HIP(hipMemcpyAsync(name_rec, J.name_rec.p, (size_t)n_qnames * 4, hipMemcpyDeviceToDevice, st));
+            }
+            int32_t e = 0;
+            UZ_HIP(hipMemcpyAsync(&e, err, 4, hipMemcpyDeviceToHost, st));
+            UZ_HIP(hipStreamSynchronize(st));
+            UZ_REQUIRE(e != 2, UZ_E_RANGE, "uz_reads_from_walk: an offset of the kept list points beyond the stores its totals declare");
+            UZ_REQUIRE(e == 0, UZ_E_RANGE, "uz_reads_from_walk: a kept record lies outside the walked bytes, or overruns its block_size");
+            uz_reads_packed_view v;
+            memset(&v, 0, sizeof(v));
+            v.n_segs = n; v.n_contigs = n_contigs; v.contig_off = d_coff; v.max_span = d_span;
+            v.start = start; v.tlen = tlen; v.mate = mate; v.qname = qname; v.flag = flag; v.l_seq = l_seq; v.n_cigar = n_cigar; v.mapq = mapq; v.aux = aux_col;
+            v.n_cigar_total = n_cigar_total; v.cigar = cigar; v.n_row_units = n_row_units; v.n_seq_units = n_seq_units; v.seq4 = seq4;
+            v.qlow = reinterpret_cast<const uint8_t *>(plane); v.min_base_qual = min_base_qual; v.n_qnames = (uint32_t)n_qnames;
+            const int rc = uz_reads_adopt_device(c, &v, &id);
+            if (rc) throw UzError{rc, c->err};
+            ReadsDev &r = c->reads[(size_t)id];
+            r.mirror = blk;
+            if (want_names) { r.kept_list = d_kept; r.name_rec = name_rec; r.names = d_names; r.names_bytes = names_bytes; }
+        } catch (...) { uz_block_put(c, blk); throw; }
+        { std::lock_guard<std::mutex> lk(c->err_mu); w.busy = false; }
+        *reads_id = id;
+    });
+}
+
+// the read names of name ids of such a table: off [n + 1] (host), the bytes back to back into buf (cap bytes; NULL / too small: only *need is set)
+int uz_reads_names(uz_ctx *c, int reads_id, const uint32_t *ids, int64_t n, int64_t *off, uint8_t *buf, int64_t cap, int64_t *need) {
+    return guarded(c, [&] {
+        UZ_REQUIRE(reads_id >= 0 && (size_t)reads_id < c->reads.size() && c->reads[(size_t)reads_id].live, UZ_E_ARG, "bad reads id");
+        ReadsDev &r = c->reads[(size_t)reads_id];
+        UZ_REQUIRE(r.kept_list && r.name_rec, UZ_E_STATE, "uz_reads_names: a table built by uz_reads_from_walk with names");
+        UZ_REQUIRE(n >= 0 && (n == 0 || (ids && off)) && need, UZ_E_ARG, "bad arguments");
+        *need = 0;
+        if (off) off[0] = 0;
+        if (n == 0) return;
+        for (int64_t k = 0; k < n; k++) UZ_REQUIRE(ids[k] < r.n_qnames, UZ_E_ARG, "uz_reads_names: a name id out of range");
+        hipStream_t st = c->stream;
+        uint32_t *d_ids = nullptr, *d_len = nullptr, *d_off = nullptr;
+        uint8_t *d_out = nullptr;
+        std::vector<uint32_t> len((size_t)n);
+        UZ_HIP(hipMalloc((void **)&d_ids, (size_t)n * 4)); UZ_HIP(hipMalloc((void **)&d_len, (size_t)n * 4)); UZ_HIP(hipMalloc((void **)&d_off, (size_t)n * 4));
+        try {
+            UZ_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, st));
+            uz_launch_name_lens(c, st, n, d_ids, r.name_rec, r.kept_list, r.n, r.names_bytes, d_len);
+            UZ_HIP(hipMemcpyAsync(len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            UZ_HIP(hipStreamSynchronize(st));
+            for (int64_t k = 0; k < n; k++) off[k + 1] = off[k] + (int64_t)len[(size_t)k];
+            *need = off[n];
+            if (buf && cap >= off[n] && off[n] > 0) {
+                UZ_REQUIRE(off[n] < ((int64_t)1 << 32), UZ_E_RANGE, "uz_reads_names: more than 4 GiB of names");
+                std::vector<uint32_t> o32((size_t)n);
+                for (int64_t k = 0; k < n; k++) o32[(size_t)k] = (uint32_t)off[k];
+                UZ_HIP(hipMalloc((void **)&d_out, (size_t)off[n] + 64));
+                UZ_HIP(hipMemcpyAsync(d_off, o32.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+                uz_launch_name_gather(c, st, n, d_ids, r.name_rec, r.kept_list, r.names, d_len, d_off, d_out);
+                UZ_HIP(hipMemcpyAsync(buf, d_out, (size_t)off[n], hipMemcpyDeviceToHost, st));
+                UZ_HIP(hipStreamSynchronize(st));
+            }
+        } catch (...) { (void)hipFree(d_ids); (void)hipFree(d_len); (void)hipFree(d_off); if (d_out) (void)hipFree(d_out); throw; }
+        (void)hipFree(d_ids); (void)hipFree(d_len); (void)hipFree(d_off); if (d_out) (void)hipFree(d_out);
     });
 }
 

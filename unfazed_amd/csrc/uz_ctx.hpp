@@ -47,6 +47,22 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+    // The same for buffers that grow while OTHER work is running on the device (the slots of walked batches: uz_bam_walk on a decoder's thread,
+    // beside the read stage of another chunk): hipFree waits for the whole device, so the block that was outgrown is parked, not freed (the
+    // context frees the parked blocks when it is destroyed, or at a moment no walked batch is in flight), and the new one is sized for the largest
+    // request any buffer of this kind has seen (*hi: a slot that grows once then fits every batch the process has staged).
+    // used > 0: the first `used` elements are carried over (on stream st).
+    void ensure_parked(size_t n, size_t *hi, std::vector<std::pair<void *, size_t>> &park, size_t used = 0, hipStream_t st = nullptr) {
+        if (hi && n > *hi) *hi = n;
+        if (n <= cap) return;
+        const size_t base = hi ? *hi : n, want = base + base / 4 + 64;
+        T *q = nullptr;
+        UZ_HIP(hipMalloc((void **)&q, want * sizeof(T)));
+        if (p && used) UZ_HIP(hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (p) park.push_back({(void *)p, cap * sizeof(T)});
+        p = q;
+        cap = want;
+    }
 };
 
 // what a set of window lists was computed for
@@ -179,6 +195,12 @@ struct ReadsDev {
     const void *col_pk = nullptr; // pk_sums of RecColumns, for the deferred header build
     const void *col_b[4] = {nullptr, nullptr, nullptr, nullptr};
     int32_t col_bwide = 0;
+    // a table built from a batch joined on the device (uz_reads_from_walk with names): the kept list, the record that brought every name id first and
+    // the read names of the records, all in `mirror` -- uz_reads_names answers ids from them
+    const uz_kept_rec *kept_list = nullptr;
+    const uint32_t *name_rec = nullptr;
+    const uint8_t *names = nullptr;
+    int64_t names_bytes = 0;
 };
 
 // DNM batch staged on the device
@@ -285,13 +307,37 @@ struct uz_ctx {
         DevBuf<uz_walk_desc> desc, desc_kept;
         DevBuf<int64_t> n_direct, tab_first, kcount, kfirst;
         DevBuf<unsigned long long> tab;
-        int64_t n_blocks = 0, out_bytes = 0, n_desc = 0, n_desc_all = 0;
-        int32_t n_tasks = 0;
+        int64_t n_blocks = 0, out_bytes = 0, n_desc = 0, n_desc_all = 0, n_reach = 0;
+        int32_t n_tasks = 0, max_host = -1; // (max_host: the last walk task's stage task, column 9 of the plan)
         hipStream_t s0 = nullptr, s1 = nullptr; // the slot's own streams (blocks up + inflate in slices on both, the walk on the first)
         hipEvent_t ev = nullptr;
+        // the batch-wide joins on the device (k_bamjoin.hip, uz_bam_join): all descriptors of the batch -- the device's own (desc_kept[0 .. n_dev)) and
+        // behind them what the host walked itself (tasks handed back, mates looked up through the index) -- with their join state
+        struct Join {
+            int64_t n_dev = 0, n_all = 0, aux_bytes = 0;
+            int32_t n_host = 0, n_look = 0, n_ref = 0, round = 0;
+            int64_t n_need = 0;
+            bool filled = false, started = false, done = false, all_bases = false;
+            DevBuf<int32_t> jtask, keep, mate, target, h_flags, jt_tid, reach_a, reach_host, cnt, cspan, look_tid;
+            DevBuf<int64_t> reach_key, totals;
+            DevBuf<unsigned long long> hkey_in, hkey, fkey_in, fkey, ccount;
+            DevBuf<uint32_t> hval_in, hperm, inv, fval_in, fidx, front0, front1, need, first, runid, pos_of_k, fo, name_rec;
+            DevBuf<int32_t> gidx;
+            DevBuf<uint8_t> tmp, aux, s5_in, s5_out;
+            DevBuf<uz_need_rec> need_rec;
+            DevBuf<uz_kept_rec> kept;
+            int64_t tot_h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; // the totals of the finished join (k_bamjoin.hip: JT_*)
+            std::vector<int64_t> contig_off_h;
+            std::vector<int32_t> max_span_h;
+        } join;
     };
     static constexpr int WALK_SLOTS = 4;
     WalkSlot walk[WALK_SLOTS];
+    // growth of the slots' buffers (DevBuf::ensure_parked): the largest request every kind of buffer has seen, and the blocks that were outgrown
+    size_t walk_hi[96] = {0};
+    std::vector<std::pair<void *, size_t>> walk_park;
+    int64_t walk_allocs = 0; // device allocations the slots have made (uz_walk_slot_stats: a process whose batches stopped growing makes none)
+    std::mutex walk_mu;      // guards the three above (walks and joins of different slots run on different decoder threads)
 
     // last phase (k_reads.hip)
     bool phase_valid = false;
@@ -305,6 +351,18 @@ struct uz_ctx {
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> event_pool;
 };
+
+// a buffer of a walk slot grown without a hipFree (DevBuf::ensure_parked); kind: which of uz_ctx::walk_hi remembers the largest request
+template <typename T>
+inline void uz_walk_grow(uz_ctx *c, DevBuf<T> &b, size_t n, int kind, size_t used = 0, hipStream_t st = nullptr) {
+    if (n <= b.cap) {
+        if (n > c->walk_hi[kind]) { std::lock_guard<std::mutex> lk(c->walk_mu); if (n > c->walk_hi[kind]) c->walk_hi[kind] = n; }
+        return;
+    }
+    std::lock_guard<std::mutex> lk(c->walk_mu);
+    b.ensure_parked(n, &c->walk_hi[kind], c->walk_park, used, st);
+    c->walk_allocs++;
+}
 
 // profiling helpers (abi.hip)
 void uz_prof_begin(uz_ctx *c, int kernel, hipEvent_t *a, hipEvent_t *b);
@@ -413,6 +471,27 @@ void uz_launch_bam_walk(uz_ctx *c, hipStream_t st, int n_tasks, const uint8_t *b
 void uz_launch_desc_filter(uz_ctx *c, hipStream_t st, bool fill, int n_tasks, const uz_walk_desc *in, const int64_t *first, const int64_t *count,
                            const int32_t *task, const int64_t *tab_first, unsigned long long *tab, int64_t *kcount, int64_t *kfirst, uz_walk_desc *out);
 size_t uz_bam_walk_pad(); // bytes the inflated buffer must be padded by (the walk's LDS windows read past the last record)
+// the batch-wide joins on the device (k_bamjoin.hip).  Totals of a finished join (WalkSlot::Join::tot_h):
+enum { JT_N = 0, JT_QNAMES = 1, JT_CIGAR = 2, JT_UNITS = 3, JT_SEQ_UNITS = 4, JT_NAME_BYTES = 5, JT_ERR = 6, JT_COUNT = 8 };
+struct JoinPlanHost { // what the host knows when it starts the joins of a walked batch
+    int32_t n_host = 0, n_ref = 0;
+    const int32_t *h_flags = nullptr; // [n_host]: the tasks the host walked itself (their device descriptors are void)
+    bool all_bases = false;
+};
+// first call: fills the filtered descriptors, sets the tables up.  Every call: appends what the host walked since the last one (x [n_x], aux bytes),
+// sets the answers to the last call's needs (need_jtask [n_need of the last call]) and runs the closure until it needs the host again (-> n_need > 0:
+// uz_join_needs) or is finished (n_need == 0: the kept list, its offsets and totals are in place)
+void uz_join_run(uz_ctx *c, uz_ctx::WalkSlot &w, const JoinPlanHost &P, const uz_walk_desc *x, int64_t n_x, const uint8_t *xaux, int64_t xaux_bytes,
+                 const int32_t *look_tid, int64_t n_look, const int32_t *need_jtask);
+void uz_join_needs(uz_ctx *c, uz_ctx::WalkSlot &w, uz_need_rec *out);
+// debug / parity: the kept records of a finished join in output order
+void uz_join_fetch(uz_ctx *c, uz_ctx::WalkSlot &w, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases, uz_kept_rec *kept);
+// the read names of name ids (a table built by uz_reads_from_walk with names): lengths, then bytes
+void uz_launch_name_lens(uz_ctx *c, hipStream_t st, int64_t n_ids, const uint32_t *ids, const uint32_t *name_rec, const uz_kept_rec *kept, int64_t n_recs, int64_t names_bytes,
+                         uint32_t *len);
+void uz_launch_name_gather(uz_ctx *c, hipStream_t st, int64_t n_ids, const uint32_t *ids, const uint32_t *name_rec, const uz_kept_rec *kept, const uint8_t *names,
+                           const uint32_t *len, const uint32_t *off, uint8_t *out);
+void uz_scan_u32(uz_ctx *c, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n, DevBuf<uint8_t> &tmp); // exclusive sum
 void uz_launch_bam_extract(uz_ctx *c, hipStream_t st, int64_t n, const uint8_t *buf, int64_t buf_bytes, const uint8_t *aux, int64_t aux_bytes, const uz_kept_rec *kept,
                            int thr, int32_t *start, int32_t *tlen, int32_t *mate, uint32_t *qname, uint16_t *flag, uint16_t *l_seq, uint16_t *n_cigar, uint8_t *mapq,
                            uint8_t *aux_col, uint32_t *cigar, uint8_t *seq4, uint32_t *plane, int32_t *err, uint8_t *names, int64_t n_cigar_total, int64_t n_row_units,

@@ -19,6 +19,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_PHASE, K_SIZING, K_CNV = 0, 1, 2, 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
     "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host", "uz_bam_walk", "uz_crc32_blocks", "uz_bam_walk_fetch", "uz_bam_walk_release", "uz_reads_from_bam",
+    "uz_bam_walk_flags", "uz_bam_join", "uz_bam_join_needs", "uz_bam_join_fetch", "uz_reads_from_walk", "uz_reads_names", "uz_walk_slot_stats",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -63,6 +64,13 @@ def load_library(path: Optional[str] = None):
     L.uz_bam_walk_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     L.uz_bam_walk_release.argtypes = [vp, C.c_int]
     L.uz_reads_from_bam.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.c_uint32, C.c_int32, vp, C.c_int64, vp]
+    L.uz_bam_walk_flags.argtypes = [vp, C.c_int, vp, vp]
+    L.uz_bam_join.argtypes = [vp, C.c_int, C.c_int32, vp, C.c_int32, C.c_int, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, vp, vp]
+    L.uz_bam_join_needs.argtypes = [vp, C.c_int, vp]
+    L.uz_bam_join_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.uz_reads_from_walk.argtypes = [vp, C.c_int, C.c_int32, C.c_int, vp, vp]
+    L.uz_reads_names.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp]
+    L.uz_walk_slot_stats.argtypes = [vp, vp]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -430,6 +438,69 @@ class HipEngine:
                 raise UnfazedHipError("uz_bam_walk_fetch: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
         return desc[:n], d_first, d_flags[:nt], d_walked[:nt], wid.value
 
+    # ---- the joins of a walked batch on the device (csrc/k_bamjoin.hip): the primitives io_native.BamSource.select_kept(join=engine) drives
+    def walk(self, plan: dict):
+        """uz_bam_walk alone: blocks up, inflated, checked and walked in HBM -> (walk id, descriptors the joins can need).  Nothing comes down."""
+        wid, nd = C.c_int(-1), C.c_int64(0)
+        nt = int(plan["task"].shape[0])
+        with self._walk_sem:
+            rc = self.L.uz_bam_walk(self.h, plan["comp"].ctypes.data, int(plan["comp_bytes"]), int(plan["n_blocks"]), plan["in_off"].ctypes.data,
+                                    plan["out_off"].ctypes.data, plan["blk_coff"].ctypes.data,
+                                    plan["blk_crc"].ctypes.data if plan.get("blk_crc") is not None and os.environ.get("UZ_WALK_CRC", "1") != "0" else None, nt, plan["task"].ctypes.data, int(plan["span"].shape[0]),
+                                    plan["span"].ctypes.data, int(plan["reach"].shape[0]), plan["reach"].ctypes.data, int(plan["fetch"].shape[0]),
+                                    plan["fetch"].ctypes.data, C.byref(wid), C.byref(nd))
+            if rc != 0:
+                raise UnfazedHipError("uz_bam_walk: %s" % (self.L.uz_last_error(self.h) or b"").decode(errors="replace"))
+        return wid.value, int(nd.value)
+
+    def walk_flags(self, token: int, nt: int):
+        d_flags, d_walked = np.zeros(max(1, nt), np.int32), np.zeros(max(1, nt), np.int64)
+        self._ck(self.L.uz_bam_walk_flags(self.h, int(token), d_flags.ctypes.data, d_walked.ctypes.data), "uz_bam_walk_flags")
+        return d_flags[:nt], d_walked[:nt]
+
+    def join(self, token: int, n_host: int, h_flags, n_ref: int, all_bases: bool, xdesc=None, xaux=None, look_tid=None, need_jtask=None):
+        """one call of uz_bam_join -> (needs, totals [8])"""
+        nn, tot = C.c_int64(0), np.zeros(8, np.int64)
+        nx = 0 if xdesc is None else int(xdesc.size)
+        na = 0 if xaux is None else int(xaux.size)
+        nl = 0 if look_tid is None else int(look_tid.size)
+        self._ck(self.L.uz_bam_join(self.h, int(token), int(n_host), h_flags.ctypes.data if h_flags is not None else None, int(n_ref), 1 if all_bases else 0,
+                                      xdesc.ctypes.data if nx else None, nx, xaux.ctypes.data if na else None, na, look_tid.ctypes.data if nl else None, nl,
+                                      need_jtask.ctypes.data if need_jtask is not None else None, C.byref(nn), tot.ctypes.data), "uz_bam_join")
+        return int(nn.value), tot
+
+    def join_needs(self, token: int, n: int):
+        from . import io_native
+        need = np.zeros(max(1, n), io_native.NEED_REC)
+        self._ck(self.L.uz_bam_join_needs(self.h, int(token), need.ctypes.data), "uz_bam_join_needs")
+        return need[:n]
+
+    def join_fetch(self, token: int, n: int, n_ref: int):
+        """parity / debug: the kept records of a finished join in output order -> dict(voff, qname, mate, bases, kept, contig_off, max_span)"""
+        from . import io_native
+        out = dict(voff=np.zeros(max(1, n), np.uint64), qname=np.zeros(max(1, n), np.uint32), mate=np.zeros(max(1, n), np.int32), bases=np.zeros(max(1, n), np.uint8),
+                   kept=np.zeros(max(1, n), io_native.KEPT_REC), contig_off=np.zeros(n_ref + 1, np.int64), max_span=np.zeros(max(1, n_ref), np.int32))
+        self._ck(self.L.uz_bam_join_fetch(self.h, int(token), *(out[k].ctypes.data for k in ("voff", "qname", "mate", "bases", "kept", "contig_off", "max_span"))), "uz_bam_join_fetch")
+        return {k: (v[:n] if k in ("voff", "qname", "mate", "bases", "kept") else v) for k, v in out.items()}
+
+    def reads_names(self, rid: int, ids) -> list:
+        """the read names of name ids of a table built from a batch joined on the device (uz_reads_names)"""
+        ids = np.ascontiguousarray(ids, np.uint32)
+        n = int(ids.size)
+        if n == 0:
+            return []
+        off, need = np.zeros(n + 1, np.int64), C.c_int64(0)
+        self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, None, 0, C.byref(need)), "uz_reads_names")
+        buf = np.zeros(max(1, int(need.value)), np.uint8)
+        self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, buf.ctypes.data, int(buf.size), C.byref(need)), "uz_reads_names")
+        mv, o = memoryview(buf), off.tolist()
+        return [str(mv[o[k]: o[k + 1]], "utf-8") for k in range(n)]
+
+    def walk_slot_stats(self) -> dict:
+        z = np.zeros(8, np.int64)
+        self._ck(self.L.uz_walk_slot_stats(self.h, z.ctypes.data), "uz_walk_slot_stats")
+        return dict(allocations=int(z[0]), parked_blocks=int(z[1]), parked_bytes=int(z[2]), slot_room=[int(x) for x in z[4:8]])
+
     def crc32_blocks(self, data: np.ndarray, off: np.ndarray, want: np.ndarray) -> int:
         """k_bgzf_crc32 on blocks data[off[k]:off[k+1]] (<= 64 KiB each) against want[k] -> -1, or a block whose CRC-32 differs (uz_crc32_blocks)"""
         data = np.ascontiguousarray(data, np.uint8)
@@ -446,6 +517,14 @@ class HipEngine:
         """The table of a batch walked on the device (kb: io_native.KeptBatch of select_kept(walk=self.bam_walk)): unpacked from the bytes in HBM.
         names: the read names of the kept records come back too (kb.qnames then maps the name ids of the result lists to strings)."""
         rid = C.c_int(-1)
+        if getattr(kb, "joined", False):  # the joins ran on the device: the kept list lies in the batch's slot (uz_reads_from_walk)
+            from . import io_native
+            tot = np.zeros(8, np.int64)
+            self._ck(self.L.uz_reads_from_walk(self.h, int(kb.token), int(kb.min_base_qual), 1 if names else 0, C.byref(rid), tot.ctypes.data), "uz_reads_from_walk")
+            kb.token = None
+            if names:
+                kb.qnames = io_native.DeviceNames(self, rid.value, int(kb.n_qnames))
+            return rid.value
         nb = int(kb.n_name_bytes) if names else 0
         alloc = getattr(kb, "_alloc", None)
         buf = (alloc(max(1, nb)) if alloc is not None else np.empty(max(1, nb), np.uint8)) if names else None

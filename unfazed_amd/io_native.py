@@ -720,12 +720,33 @@ class _KeptNames(Sequence):
         return [str(mv[x:y], "utf-8") for x, y in zip(a.tolist(), b.tolist())]
 
 
+class DeviceNames(Sequence):
+    """name id -> query name of a batch whose joins ran on the device: the names stay in HBM with the table (uz_reads_from_walk) and the ids a
+    chunk's result lists name -- a few per cent of its names -- are answered by uz_reads_names.  Valid while the table lives."""
+
+    def __init__(self, engine, rid: int, n_names: int):
+        self._eng, self._rid, self._n = engine, int(rid), int(n_names)
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.take(np.arange(*i.indices(self._n), dtype=np.uint32))
+        return self._eng.reads_names(self._rid, np.array([int(i)], np.uint32))[0]
+
+    def take(self, ids) -> list:
+        return self._eng.reads_names(self._rid, np.asarray(ids))
+
+
 class KeptBatch:
     """What BamSource.select_kept returns: the records fetch() + mate() hand the reference for a batch, as the list the device packs its record
-    table from (uz_kept_rec), with the table's sizes.  `.plan`: the gathered BGZF blocks and the walk plan the device worked from."""
+    table from (uz_kept_rec), with the table's sizes.  `.plan`: the gathered BGZF blocks and the walk plan the device worked from.
+    joined: the joins ran on the device too (select_kept(join=engine)) -- the list lies in the batch's slot in HBM, `.kept` is None."""
     qnames = None
     token = None
     _release = None
+    joined = False
 
     def __del__(self):  # (dropped before its table was built -- a failed join, an abandoned pipeline: the inflated bytes on the device are given up)
         if self.token is not None and self._release is not None:
@@ -737,6 +758,16 @@ class KeptBatch:
 
     def set_names(self, buf: np.ndarray):
         self.qnames = _KeptNames(buf, self.kept["name_off"], int(self.n_name_bytes), int(self.n_qnames), self._stage)
+
+
+def _stage_extra(lib, sh, tot, d0, a0):
+    """what the stage holds for the device from descriptor d0 / aux byte a0 on (uz_stage_extra) -> (descriptors, aux bytes, reference of every look-up task)"""
+    nd, na = int(tot[0]) - d0, int(tot[1]) - a0
+    x, aux = np.zeros(max(1, nd), WALK_DESC), np.zeros(max(1, na), np.uint8)
+    nl = int(lib.uz_stage_n_lookup_tasks(sh.ptr))
+    lt = np.zeros(max(1, nl), np.int32)
+    _check(lib, lib.uz_stage_extra(sh.ptr, d0, a0, x.ctypes.data, aux.ctypes.data, lt.ctypes.data))
+    return x[:nd], aux[:na], lt[:nl]
 
 
 class BamSource:
@@ -840,7 +871,62 @@ class BamSource:
         out._stage = sh
         return out
 
-    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None, small_tasks=None, merge=False) -> "KeptBatch":
+    def _joined_on_the_device(self, dev, sh, plan, n_host, nt, min_base_qual, all_bases, release, t0, t1) -> "KeptBatch":
+        """select_kept(join=dev): walk AND joins on the device (dev: HipEngine -- walk / walk_flags / join / join_needs).  Nothing of the batch's
+        records comes down the link: up go the compressed blocks and the plan, down come the walk tasks' flags, the totals -- and, when the file has
+        them, the short list of mates only the index can answer (uz_stage_lookup), whose records go up as descriptors + bytes."""
+        lib = self.lib
+        token, n_desc = dev.walk(plan)
+        t2 = time.perf_counter()
+        try:
+            d_flags, d_walked = dev.walk_flags(token, nt)
+            if os.environ.get("UZ_TEST_FLAG_EVERY"):  # test hook: every n-th walk task counts as handed back by the device -- the host walks its stage task
+                d_flags = d_flags.copy()
+                d_flags[:: max(1, int(os.environ["UZ_TEST_FLAG_EVERY"]))] |= 1
+            h_flags = np.zeros(max(1, n_host), np.int32)
+            tot = (C.c_int64 * 2)()
+            _check(lib, lib.uz_stage_walk_flagged(sh.ptr, np.ascontiguousarray(d_flags, np.int32).ctypes.data if nt else None, h_flags.ctypes.data, tot))
+            d0 = a0 = 0
+            x, aux, lt = _stage_extra(lib, sh, tot, d0, a0)
+            d0, a0 = int(tot[0]), int(tot[1])
+            need_ans, rounds, n_lookups = None, 0, 0
+            while True:
+                n_need, totals = dev.join(token, n_host, h_flags, len(self.contigs), all_bases, x, aux, lt, need_ans)
+                rounds += 1
+                if n_need == 0:
+                    break
+                if rounds > 64:
+                    raise IoError(-4, "the mate closure of the batch did not end after 64 trips through the index")
+                need = dev.join_needs(token, n_need)
+                need_ans = np.zeros(n_need, np.int32)
+                _check(lib, lib.uz_stage_lookup(sh.ptr, int(n_need), need.ctypes.data, need_ans.ctypes.data, tot))
+                n_lookups += n_need
+                x, aux, lt = _stage_extra(lib, sh, tot, d0, a0)
+                d0, a0 = int(tot[0]), int(tot[1])
+        except BaseException:
+            if release is not None:
+                release(token)
+            raise
+        t3 = time.perf_counter()
+        out = KeptBatch()
+        out.joined, out.token, out._release = True, token, release
+        out.n, out.n_qnames, out.n_cigar_total, out.n_row_units, out.n_seq_units, out.n_name_bytes = (int(v) for v in totals[:6])
+        out.n_aux, out.host_tasks, out.kept = a0, int(np.count_nonzero(h_flags[:n_host])), None
+        out.n_desc, out.n_extra_desc, out.join_calls = int(n_desc), d0, rounds
+        io = (C.c_int64 * 8)()
+        lib.uz_stage_io_stats(sh.ptr, io)
+        out.io_stats = dict(zip(("file_bytes_read", "blocks_inflated", "records_walked", "records_kept", "reach_intervals", "index_mate_lookups",
+                                 "blocks_from_the_device", "gathered_bytes"), (int(v) for v in io)))
+        out.io_stats["records_walked"] += int(d_walked.sum())
+        out.io_stats["records_kept"] = out.n
+        out.timing = dict(plan=t1 - t0, walk=t2 - t1, joins=t3 - t2, kept=0.0, mates=0.0, numbering=0.0)
+        out.plan, out.desc, out.d_first, out.d_flags = plan, None, None, d_flags
+        out.min_base_qual, out.n_contigs, out.all_bases = int(min_base_qual), len(self.contigs), bool(all_bases)
+        out._stage = sh
+        return out
+
+    def select_kept(self, contig, lo, hi, min_base_qual: int, walk=None, all_bases=False, alloc=None, extra=None, release=None, small_tasks=None, merge=False,
+                    join=None) -> "KeptBatch":
         """The same batch through the device's walk (include/uz_bamwalk.h): the blocks are gathered, `walk(plan)` inflates them in HBM and walks
         them there (HipEngine.bam_walk -> descriptors, d_first, d_flags, d_walked; None: the host's twin uz_stage_walk_host -- tests), the
         batch-wide joins run here on the descriptors, and the answer is the list of kept records for uz_reads_from_bam.
@@ -856,7 +942,7 @@ class BamSource:
             extra = np.ascontiguousarray(extra, np.uint16)
         ia = alloc or (lambda nbytes: np.empty(max(16, nbytes), np.uint8))
         if small_tasks is None:  # (a plan for the device's walk takes smaller tasks: one wavefront walks a task)
-            small_tasks = walk is not None and os.environ.get("UZ_STAGE_SUBTASKS", "1") != "0"  # (0: the stage's own tasks as walk tasks -- a development aid)
+            small_tasks = (walk is not None or join is not None) and os.environ.get("UZ_STAGE_SUBTASKS", "1") != "0"  # (0: the stage's own tasks as walk tasks -- a development aid)
         flags = (STAGE_ALL_BASES if all_bases else 0) | (STAGE_SMALL_TASKS if small_tasks else 0)
         st = C.c_void_p()
         t0 = time.perf_counter()
@@ -882,6 +968,8 @@ class BamSource:
         plan = dict(comp=comp, comp_bytes=int(cb.value), in_off=in_off[: nb.value], out_off=out_off, out_bytes=int(ob.value), n_blocks=int(nb.value),
                     task=task[:nt], span=span[:nsp], reach=reach[:nr], fetch=fetch[:nf], blk_coff=blk_coff[:nblk], blk_crc=blk_crc[:nblk], n_ref=len(self.contigs))
         t1 = time.perf_counter()
+        if join is not None:
+            return self._joined_on_the_device(join, sh, plan, n_host, nt, int(min_base_qual), bool(all_bases), release, t0, t1)
         if walk is None:  # the host's twin
             d_first, d_walked = np.zeros(n_host + 1, np.int64), np.zeros(max(1, n_host), np.int64)
             _check(self.lib, self.lib.uz_stage_walk_host(sh.ptr, None, 0, d_first.ctypes.data, d_walked.ctypes.data))
