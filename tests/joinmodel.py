@@ -103,7 +103,10 @@ def run(lib, stage, desc, d_first, d_flags, plan, n_ref, all_bases=False):
                     continue
                 xr = D[i]
                 fl = int(xr["flag"])
-                if not ((fl & FPAIRED) and not (fl & FMUNMAP) and 0 <= int(xr["mtid"]) < n_ref):
+                # a copy that will be folded away -- another copy of the same record is a member and wins the fold -- asks for nothing (without this
+                # rule two mates outside every reach interval look each other up for ever: every answer of the index is a new copy)
+                folds = any(e != i and D["voff"][e] == xr["voff"] and (keep[e] > keep[i] or (keep[e] == keep[i] and e < i)) for e in groups.get(int(xr["h1"]), ()))
+                if folds or not ((fl & FPAIRED) and not (fl & FMUNMAP) and 0 <= int(xr["mtid"]) < n_ref):
                     mate[i] = -1
                     continue
                 tc = target[i] if i in target else R.covering(int(xr["mtid"]), int(xr["mpos"]))
@@ -173,4 +176,4 @@ def run(lib, stage, desc, d_first, d_flags, plan, n_ref, all_bases=False):
     mate_out = np.where(m >= 0, gidx[np.maximum(m, 0)], -1)
     bases = (keep[surv] == 2) | bool(all_bases)
     return dict(voff=D["voff"][surv], qname=qname.astype(np.uint32), mate=mate_out.astype(np.int32), bases=bases, n_qnames=int(is_first.sum()),
-                src=D["src"][surv], lookups=n_lookups, n_extra=int(tot[0]), h_flags=h_flags)
+                src=D["src"][surv], lookups=n_lookups, n_extra=int(tot[0]), h_flags=h_flags, trips=_round)

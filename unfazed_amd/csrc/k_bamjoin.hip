@@ -166,17 +166,32 @@ __global__ __launch_bounds__(256) void k_join_round(JoinArgs a, int r) {
                 const uz_walk_desc &x = a.D[i];
                 const uint32_t fl = x.flag;
                 const int32_t mtid = x.mtid, mpos = x.mpos;
-                if (!((fl & FPAIRED) && !(fl & FMUNMAP) && mtid >= 0 && mtid < a.n_ref)) a.mate[i] = -1; // (io_stage.cpp: wants_mate)
+                const unsigned long long h = (unsigned long long)x.h1;
+                int64_t p = a.inv[i];
+                while (p > 0 && a.hkey[p - 1] == h) p--;
+                // A copy that will be folded away (the same record met by another task, or found once more through the index, whose other copy is a
+                // member already and wins the fold: fetched, or as good and earlier) asks for nothing: only its survivor's mate is ever read.  Without
+                // this rule two mates outside every reach interval look each other up for ever -- every answer of the index is a NEW copy of the
+                // partner, which asks for a new copy of the first (the host's loop runs into its cap of 64 generations there).
+                bool folds = false;
+                {
+                    const unsigned long long v = x.voff;
+                    const int32_t ki = a.keep[i];
+                    for (int64_t q = p; q < a.n && a.hkey[q] == h; q++) {
+                        const uint32_t e = a.hperm[q];
+                        if (e == i || a.D[e].voff != v) continue;
+                        const int32_t ke = a.keep[e];
+                        if (ke > ki || (ke == ki && ke != 0 && e < i)) folds = true;
+                    }
+                }
+                if (folds || !((fl & FPAIRED) && !(fl & FMUNMAP) && mtid >= 0 && mtid < a.n_ref)) a.mate[i] = -1; // (io_stage.cpp: wants_mate)
                 else {
                     const int32_t tgt = a.target[i];
                     const int32_t tc = tgt >= 0 ? tgt : covering(a, mtid, mpos);
                     if (tc < 0) need = true;
                     else {
-                        const unsigned long long h = (unsigned long long)x.h1;
                         const uint32_t h2 = x.h2, want = (fl ^ (FREAD1 | FREAD2)) & (FREAD1 | FREAD2);
                         const uint8_t ln = x.l_name;
-                        int64_t p = a.inv[i];
-                        while (p > 0 && a.hkey[p - 1] == h) p--;
                         bool seen = false;
                         unsigned long long best_v = KEY_NONE;
                         for (; p < a.n && a.hkey[p] == h; p++) {
