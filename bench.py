@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--feed-walk", choices=("device", "host"), default="device",
                     help="feed pass: where the BAM records are walked -- device: the inflated blocks stay in HBM, k_bam_walk hands the host 64-byte descriptors, "
                          "the table is unpacked from HBM (include/uz_bamwalk.h); host: uz_bam_stage_* walks them on the host's cores (the link form)")
+    ap.add_argument("--feed-joins", choices=("device", "host"), default="device",
+                    help="feed pass, device walk: where mate() + closure + name numbering run -- device: over the descriptors where they lie in HBM (csrc/k_bamjoin.hip: "
+                         "nothing of the records crosses the link); host: the descriptors come down, uz_bam_stage_finish_sub joins them, the kept list goes up (round 5)")
     ap.add_argument("--feed-inflate", choices=("device", "host"), default="device",
                     help="feed pass: who inflates the BGZF blocks of the BAM -- the device (uz_bgzf_inflate_to_host) or the host's cores")
     ap.add_argument("--feed-level", type=int, default=6, help="deflate level of the files written for the feed pass (samtools / bgzip default: 6)")
@@ -553,11 +556,12 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         from unfazed_amd.engine import PinnedPair
         on_device = args.feed_inflate == "device"
         dev_walk = args.feed_walk == "device" and on_device
+        dev_joins = dev_walk and args.feed_joins == "device"
         ipairs = [PinnedPair() for _ in range(NB)] if on_device else None  # ... and its gathered / inflated BGZF blocks through ipairs[k % NB]
         slab_bytes = [0] * NB
         acc = dict(vcf_s=0.0, bam_s=0.0, site_records=0, walked=0, kept=0, file_bytes=0, blocks=0, spans=0.0, walk=0.0, mates=0.0, numbering=0.0, fill=0.0,
                    link_bytes=0, lookups=0, dev_blocks=0, dev_out_bytes=0, dev_inflate_s=0.0, gather_s=0.0, blocks_dev=0,
-                   w_plan=0.0, w_walk=0.0, w_joins=0.0, w_kept=0.0, w_desc=0, w_host_tasks=0, w_tasks=0, w_aux=0)
+                   w_plan=0.0, w_walk=0.0, w_joins=0.0, w_kept=0.0, w_desc=0, w_host_tasks=0, w_tasks=0, w_aux=0, w_join_calls=0)
 
         def io_dev(packed):
             return packed.io_stats.get("blocks_from_the_device", 0)
@@ -594,6 +598,20 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 pool.new_slab(want)
             if on_device:
                 ipairs[k % NB].start()
+            if dev_walk and dev_joins:  # the blocks go up, are inflated, walked AND joined in HBM: down come the walk tasks' flags and the table's totals
+                pa = ipairs[k % NB].alloc
+                kb = src.select_kept(f[0], f[1], f[2], int(P.min_gt_qual), join=eng, alloc=pa, release=eng.bam_walk_release)
+                acc["bam_s"] += time.perf_counter() - t
+                io, tm = kb.io_stats, kb.timing
+                acc["walked"] += io["records_walked"]; acc["kept"] += io["records_kept"]; acc["lookups"] += io["index_mate_lookups"]
+                acc["dev_blocks"] += kb.plan["n_blocks"]; acc["dev_out_bytes"] += kb.plan["out_bytes"]; acc["file_bytes"] += kb.plan["comp_bytes"]
+                acc["w_plan"] += tm["plan"]; acc["w_walk"] += tm["walk"]; acc["w_joins"] += tm["joins"]
+                acc["w_desc"] += int(kb.n_desc); acc["w_host_tasks"] += int(kb.host_tasks); acc["w_tasks"] += int(kb.plan["task"].shape[0]); acc["w_aux"] += int(kb.n_aux)
+                acc["w_join_calls"] += int(kb.join_calls)
+                plan_bytes = sum(int(v.nbytes) for key, v in kb.plan.items() if isinstance(v, np.ndarray) and key != "comp")
+                acc["link_bytes"] += int(kb.plan["comp_bytes"]) + plan_bytes + int(kb.n_extra_desc) * 64 + int(kb.n_aux) + int(kb.plan["task"].shape[0]) * 12
+                kb.plan = None
+                return kb
             if dev_walk:  # the blocks go up, are inflated and walked in HBM; descriptors come back, the joins run here, the kept list goes up
                 pa = ipairs[k % NB].alloc
                 kb = src.select_kept(f[0], f[1], f[2], int(P.min_gt_qual), walk=lambda plan: eng.bam_walk(plan, alloc=pa), alloc=pa, release=eng.bam_walk_release)
@@ -678,7 +696,9 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         return {
             "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "seconds_of_every_pass": [round(x, 3) for x in els],
             "result_mismatches_vs_resident": mism,
-            "walk": "device (k_bam_walk: one wavefront per walk task; the host runs the batch-wide joins on 64-byte descriptors)" if dev_walk else "host (uz_bam_stage_*)",
+            "walk": ("device (k_bam_walk: one wavefront per walk task; mate() closure, name numbering, file order and the table's offsets on the device too: csrc/k_bamjoin.hip)" if dev_joins
+                     else "device (k_bam_walk: one wavefront per walk task; the host runs the batch-wide joins on 64-byte descriptors)") if dev_walk else "host (uz_bam_stage_*)",
+            "joins": "device" if dev_joins else "host",
             "inflate": ("device (k_bgzf_inflate: one wavefront per BGZF block; blocks the walk did not announce: " + io_native.inflate_backend() + ")") if on_device
                        else io_native.inflate_backend(),
             "device_inflate": None if not on_device else {"blocks": acc["dev_blocks"], "out_GB": round(acc["dev_out_bytes"] / 1e9, 3),
@@ -691,11 +711,17 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
             "device_walk": None if not dev_walk else {
                 "kernels": "k_bgzf_inflate + k_bgzf_crc32, k_bam_walk (one wavefront per walk task), k_tab_insert + k_desc_filter, k_bam_extract (csrc/k_inflate.hip, k_bamwalk.hip)", "tasks": acc["w_tasks"],
                 "tasks_walked_by_the_host": acc["w_host_tasks"], "descriptors": acc["w_desc"], "aux_bytes": acc["w_aux"],
-                "seconds_busy": {"plan+gather": round(acc["w_plan"], 3), "upload+inflate+walk+descriptors_down": round(acc["w_walk"], 3),
-                                 "joins_on_the_host": round(acc["w_joins"], 3), "kept_list": round(acc["w_kept"], 3)},
+                "seconds_busy": ({"plan+gather": round(acc["w_plan"], 3), "upload+inflate+walk": round(acc["w_walk"], 3),
+                                  "joins_on_the_device (flags down, the host's own walks, uz_bam_join until it needs nothing)": round(acc["w_joins"], 3),
+                                  "joins_on_the_host": 0.0, "kept_list": 0.0} if dev_joins else
+                                 {"plan+gather": round(acc["w_plan"], 3), "upload+inflate+walk+descriptors_down": round(acc["w_walk"], 3),
+                                  "joins_on_the_host": round(acc["w_joins"], 3), "kept_list": round(acc["w_kept"], 3)}),
+                "join_calls": acc["w_join_calls"] if dev_joins else None,
                 "link_bytes_per_dnm": round(acc["link_bytes"] / m, 1),
-                "note": "the inflated bytes (out_GB) never cross the link: up go the compressed blocks and the kept list (32 B per record), down come the "
-                        "descriptors (64 B per record inside a reach interval)"},
+                "note": ("the inflated bytes (out_GB) and the descriptors never cross the link: up go the compressed blocks, the walk plan and what the host walked itself "
+                         "(tasks handed back, mates looked up through the index: descriptors + bytes), down come the walk tasks' flags and the table's totals") if dev_joins else
+                        ("the inflated bytes (out_GB) never cross the link: up go the compressed blocks and the kept list (32 B per record), down come the "
+                         "descriptors (64 B per record inside a reach interval)")},
             "host_threads": io_native.default_threads(), "host_cpu_quota": io_native.cpu_quota() or None,
             "host_processors": os.cpu_count(),
             "bam": {"records": st_b["records"], "file_GB": round(st_b["file_bytes"] / 1e9, 3), "raw_GB": round(st_b["raw_bytes"] / 1e9, 3), "blocks": st_b["blocks"],

@@ -108,6 +108,22 @@ def load_library(path: Optional[str] = None):
     return L
 
 
+class _CappedWalk:
+    """the engine's walk / join primitives for io_native.BamSource.select_kept(join=...), with the cap on a walked batch's inflated bytes applied
+    where the plan is first seen"""
+
+    def __init__(self, eng, cap: int):
+        self._eng, self._cap = eng, int(cap)
+
+    def walk(self, plan):
+        if int(plan["out_bytes"]) > self._cap:
+            raise _WalkTooLarge()
+        return self._eng.walk(plan)
+
+    def __getattr__(self, name):
+        return getattr(self._eng, name)
+
+
 class _WalkTooLarge(Exception):
     """the blocks of a batch inflate to more than the device walk keeps in HBM (HipEngine.stage_reads falls back to the host route)"""
 
@@ -276,12 +292,16 @@ class HipEngine:
                     raise _WalkTooLarge()
                 return self.bam_walk(plan, alloc=pair.alloc)
             try:
-                kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=walk, all_bases=bool(all_bases), alloc=pair.alloc, extra=fex,
-                                     release=self.bam_walk_release)
+                # (UZ_JOINS=host: the descriptors come down and the host joins them, round 5's route; default: the joins on the device too, k_bamjoin.hip)
+                dev_joins = os.environ.get("UZ_JOINS", "device") == "device"
+                kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=None if dev_joins else walk, join=_CappedWalk(self, cap) if dev_joins else None,
+                                     all_bases=bool(all_bases), alloc=pair.alloc, extra=fex, release=self.bam_walk_release)
             except _WalkTooLarge:
                 kb = None
             if kb is not None:
                 rid = self.reads_from_bam(kb, names=True)
+                if getattr(kb, "joined", False):  # (this caller may free the table before it asks for names: they come down now, all of them)
+                    kb.qnames = kb.qnames.frozen()
                 names = type("StagedNames", (), {})()
                 names.qnames, names.io_stats, names.timing = kb.qnames, kb.io_stats, kb.timing
                 return rid, names
@@ -341,9 +361,10 @@ class HipEngine:
                     raise _WalkTooLarge()
                 return self.bam_walk(plan, alloc=pair.alloc)
             try:
-                kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=walk, all_bases=bool(all_bases), alloc=pair.alloc, extra=fex,
-                                     release=self.bam_walk_release)
-                kb._alloc = pair.alloc  # (the names of its records come back into page-locked memory of the same set: reads_from_bam)
+                dev_joins = os.environ.get("UZ_JOINS", "device") == "device"  # (as upload_reads_staged)
+                kb = src.select_kept(fc, flo, fhi, int(min_base_qual), walk=None if dev_joins else walk, join=_CappedWalk(self, cap) if dev_joins else None,
+                                     all_bases=bool(all_bases), alloc=pair.alloc, extra=fex, release=self.bam_walk_release)
+                kb._alloc = pair.alloc  # (host joins: the names of its records come back into page-locked memory of the same set: reads_from_bam)
                 return kb
             except _WalkTooLarge:
                 pass
@@ -483,18 +504,22 @@ class HipEngine:
         self._ck(self.L.uz_bam_join_fetch(self.h, int(token), *(out[k].ctypes.data for k in ("voff", "qname", "mate", "bases", "kept", "contig_off", "max_span"))), "uz_bam_join_fetch")
         return {k: (v[:n] if k in ("voff", "qname", "mate", "bases", "kept") else v) for k, v in out.items()}
 
-    def reads_names(self, rid: int, ids) -> list:
-        """the read names of name ids of a table built from a batch joined on the device (uz_reads_names)"""
+    def reads_names_raw(self, rid: int, ids):
+        """the read names of name ids of a table built from a batch joined on the device (uz_reads_names) -> (bytes back to back, off [n + 1])"""
         ids = np.ascontiguousarray(ids, np.uint32)
         n = int(ids.size)
-        if n == 0:
-            return []
         off, need = np.zeros(n + 1, np.int64), C.c_int64(0)
+        if n == 0:
+            return np.zeros(1, np.uint8), off
         self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, None, 0, C.byref(need)), "uz_reads_names")
         buf = np.zeros(max(1, int(need.value)), np.uint8)
         self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, buf.ctypes.data, int(buf.size), C.byref(need)), "uz_reads_names")
+        return buf, off
+
+    def reads_names(self, rid: int, ids) -> list:
+        buf, off = self.reads_names_raw(rid, ids)
         mv, o = memoryview(buf), off.tolist()
-        return [str(mv[o[k]: o[k + 1]], "utf-8") for k in range(n)]
+        return [str(mv[o[k]: o[k + 1]], "utf-8") for k in range(len(o) - 1)]
 
     def walk_slot_stats(self) -> dict:
         z = np.zeros(8, np.int64)

@@ -738,6 +738,30 @@ class DeviceNames(Sequence):
     def take(self, ids) -> list:
         return self._eng.reads_names(self._rid, np.asarray(ids))
 
+    def frozen(self) -> "_FrozenNames":
+        """every name, on the host: for a caller that frees the table before it asks"""
+        buf, off = self._eng.reads_names_raw(self._rid, np.arange(self._n, dtype=np.uint32))
+        return _FrozenNames(buf, off)
+
+
+class _FrozenNames(Sequence):
+    def __init__(self, buf: np.ndarray, off: np.ndarray):
+        self._buf, self._off = buf, off
+
+    def __len__(self):
+        return int(self._off.size) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        i = int(i)
+        return self._buf[int(self._off[i]): int(self._off[i + 1])].tobytes().decode()
+
+    def take(self, ids) -> list:
+        ids = np.asarray(ids, np.int64)
+        mv = memoryview(self._buf)
+        return [str(mv[x:y], "utf-8") for x, y in zip(self._off[ids].tolist(), self._off[ids + 1].tolist())]
+
 
 class KeptBatch:
     """What BamSource.select_kept returns: the records fetch() + mate() hand the reference for a batch, as the list the device packs its record
