@@ -11,7 +11,7 @@ k = pd.read_csv('gpurun_out/tlf/run_kernel_trace.csv')
 k['dur'] = (k.End_Timestamp - k.Start_Timestamp) / 1e3
 k['nm'] = k.Kernel_Name.str.replace('void ', '').str.replace('(anonymous namespace)::', '', regex=False).str.split('(').str[0].str[:36]
 g = k.groupby('nm').dur.agg(['count', 'median', 'max', 'sum']).sort_values('sum', ascending=False)
-print(g[g.index.str.contains('bam|inflate|crc|desc_filter|tab_insert|pack_rec|off_block|phase|extract|walk')].to_string())
+print(g[g.index.str.contains('bam|inflate|crc|desc_filter|tab_insert|pack_rec|off_block|phase|extract|walk|join|final|radix|sort|scan|inverse|need|lookback|site|window')].to_string())
 try:
     m = pd.read_csv('gpurun_out/tlf/run_memory_copy_trace.csv')
     m['dur'] = (m.End_Timestamp - m.Start_Timestamp) / 1e3

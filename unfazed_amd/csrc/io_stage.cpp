@@ -313,6 +313,7 @@ struct Task { // reach intervals of one reference whose file spans meet (walked 
     std::vector<uint8_t> pay;        // per record with has_pay: seq2 units | listed bases (pos u16, two-bit code) | exceptions (pos u16, code u8, pad) | positions (u16) | plane row
     int64_t n_walked = 0, file_bytes = 0, n_blocks = 0, n_pre = 0;
     std::vector<PreBlk> pre;         // blocks of this task inflated elsewhere (uz_stage_gather_blocks / uz_stage_set_inflated)
+    std::vector<int64_t> span_stop;  // per span: the file offset of the last block gathered for it (uz_stage_gather_blocks), -1 none
     bool by_hash = false;            // descriptor route: no name bytes on the host, two names are equal when both hashes and the lengths agree
     std::vector<uint8_t> raw;        // descriptor route: the bytes (block_size field included) of the kept records of a task the host walked itself
     // sizes of the kept records (filled by the numbering pass)
@@ -1516,14 +1517,24 @@ int uz_stage_gather_blocks(uz_stage *P, uint8_t *comp, int64_t cap, int64_t *in_
                 for (int64_t i = i0; i < i1; i++) {
                     Task &T = P->tasks[(size_t)i];
                     T.pre.clear();
+                    T.span_stop.assign(T.spans.size(), -1);
                     int64_t last = -1;
-                    for (const Chunk &c : T.spans) {
+                    for (size_t ci = 0; ci < T.spans.size(); ci++) {
+                        const Chunk &c = T.spans[ci];
                         int64_t coff = (int64_t)(c.beg >> 16);
                         const int64_t stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16); // (inclusive: the block that holds the end)
-                        while (coff <= stop) {
+                        // One block more where the estimate cut the span short: est_end is the first record that OVERLAPS the window behind the task's
+                        // reach -- a read that starts in front of the window's edge -- and the walk goes on to the first record that STARTS at or behind
+                        // the reach's end, a read length of records further: usually the same block, now and then the next one (round 5: such a task
+                        // ended "incomplete" on the device and was walked again by the host, two of 2 059 per feed pass -- with the joins on the device
+                        // the one thing left that makes the host inflate and walk).
+                        int extra = (int64_t)(c.end >> 16) > stop ? 1 : 0;
+                        while (coff <= stop || extra > 0) {
+                            if (coff > stop) extra--;
                             BlockHdr h;
                             if (!block_at(S, coff, h)) break;
                             if (coff > last) { T.pre.push_back(PreBlk{coff, 0, h.isize, h.crc, (uint32_t)h.blen, (uint32_t)(h.cdata - (size_t)coff)}); last = coff; }
+                            T.span_stop[ci] = coff;
                             coff += (int64_t)h.blen;
                         }
                     }
@@ -1702,7 +1713,7 @@ int uz_stage_walk_plan(uz_stage *P, int32_t *task, int64_t *span, int32_t *reach
                 const Chunk &c = T.spans[sp];
                 const uint64_t beg = sp == (size_t)S.s0 ? S.beg : c.beg;
                 int64_t *sc = span + UZ_WALK_SPAN_COLS * si++;
-                const int64_t c0 = (int64_t)(beg >> 16), stop = (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16);
+                const int64_t c0 = (int64_t)(beg >> 16), stop = sp < T.span_stop.size() ? T.span_stop[sp] : (int64_t)(std::min(c.end, std::max(T.est_end, c.beg)) >> 16);
                 auto lo = std::lower_bound(T.pre.begin(), T.pre.end(), c0, [](const PreBlk &b, int64_t key) { return b.coff < key; });
                 auto hi = std::upper_bound(T.pre.begin(), T.pre.end(), stop, [](int64_t key, const PreBlk &b) { return key < b.coff; });
                 sc[0] = (int64_t)beg; sc[1] = (int64_t)c.end;

@@ -148,7 +148,10 @@ class HipEngine:
         self._params = None
         import threading
         self._inflate_lock = threading.Lock()
-        self._walk_sem = threading.BoundedSemaphore(int(os.environ.get("UZ_WALKS_AT_ONCE", "1")))
+        # walked batches on the device at once, each on its slot's own streams.  Round 5 (the host's joins the bound): two measured 10 % slower than
+        # one; with the joins on the device the device's chain is the bound and a batch's walk -- a latency-bound kernel of ~1 900 wavefronts -- leaves
+        # the chip to the next batch's inflate: 1 / 2 / 3 at once = 117 / 130 / 128 k DNMs/s in bench.py's feed pass
+        self._walk_sem = threading.BoundedSemaphore(int(os.environ.get("UZ_WALKS_AT_ONCE", "2")))
         self._inflate_bufs = None  # PinnedPair of upload_reads_staged
         self._stage_pool = None    # PinnedPool of upload_reads_staged: the staged columns' page-locked block, kept from batch to batch
         self._chunk_pools = [None, None]  # stage_reads: two alternating sets of page-locked buffers (columns; gathered / inflated blocks)
@@ -442,7 +445,7 @@ class HipEngine:
         from . import io_native
         wid, nd = C.c_int(-1), C.c_int64(0)
         nt = int(plan["task"].shape[0])
-        with self._walk_sem:  # (one batch at a time by default: two at once -- each on its slot's own streams -- measured 10 % slower, UZ_WALKS_AT_ONCE=2)
+        with self._walk_sem:  # (UZ_WALKS_AT_ONCE batches at a time)
             rc = self.L.uz_bam_walk(self.h, plan["comp"].ctypes.data, int(plan["comp_bytes"]), int(plan["n_blocks"]), plan["in_off"].ctypes.data,
                                     plan["out_off"].ctypes.data, plan["blk_coff"].ctypes.data,
                                     plan["blk_crc"].ctypes.data if plan.get("blk_crc") is not None and os.environ.get("UZ_WALK_CRC", "1") != "0" else None, nt, plan["task"].ctypes.data, int(plan["span"].shape[0]),

@@ -576,11 +576,10 @@ class PhasingHost:
         src = stager(bam)
         fam = self.family(kid, pedigrees[kid]["dad"], pedigrees[kid]["mom"])
         cutoff = self.kid_cutoff(kid, bam, readlen, stdevs, insert_size_max_sample)
-        # The first chunk half-size (nothing hides its decode), the rest in EQUAL chunks of at most `chunk` DNMs.  No chunk larger than the others:
-        # a walked batch keeps its blocks, inflated bytes and descriptors in one of four device slots (abi.hip uz_bam_walk: the first free one), a
-        # slot that meets a larger batch than it has held grows through hipFree + hipMalloc of gigabytes with every stream of the device waiting,
-        # and a tail joined to the last chunk (4 700 DNMs after five of 3 400) did that to the SECOND call of a process, whose timing puts the
-        # large chunk on another slot than the first call's: 1.3 ... 1.7 s instead of 0.6
+        # The first chunk half-size (nothing hides its decode), the rest in equal chunks of at most `chunk` DNMs (a short tail is spread over them,
+        # not joined to the last one: the read stage of a larger last chunk is what nothing hides).  (Round 5 needed equal chunks for another reason --
+        # a device slot that met a larger batch grew through hipFree + hipMalloc with every stream waiting; the slots are chosen best-fit and grow
+        # without a free since round 6: abi.hip uz_bam_walk, tests/test_bamjoin_gpu.py::test_slots_grow_once.)
         n_all, first = len(idxs), min(len(idxs), chunk // 2)
         k_rest = max(1, -(-(n_all - first) // chunk))
         size = -(-(n_all - first) // k_rest)
