@@ -52,8 +52,7 @@ int uz_bam_decode(const char *path, int threads, uz_bam **out);
 int uz_bam_decode_regions(const char *path, const char *bai_path, int64_t n_iv, const int32_t *tid, const int32_t *lo, const int32_t *hi,
                           int64_t head_records, int threads, uz_bam **out);
 /* what the last decode touched: [0] compressed file bytes read, [1] BGZF blocks inflated, [2] records walked, [3] records kept */
-/* The same table from an UNCOMPRESSED BAM stream in memory (magic, header text, references, records): what the CRAM record
- * layer produces. */
+/* The same table from an UNCOMPRESSED BAM stream in memory (magic, header text, references, records) */
 int uz_bam_decode_memory(const uint8_t *stream, int64_t n, int threads, uz_bam **out);
 void uz_bam_io_stats(const uz_bam *h, int64_t out[4]);
 void uz_bam_free(uz_bam *h);
@@ -74,33 +73,8 @@ int64_t uz_bam_tlen_head(const uz_bam *h, int32_t *out, int64_t cap);
 /* wall-clock seconds of the stages of the last decode: [0] read, [1] inflate, [2] columns, [3] names + mates */
 void uz_bam_timing(const uz_bam *h, double out[4]);
 
-/* ------------------------------------------------------------------ CRAM (block codec; the container / slice / record
- * layer is unfazed_amd/io_cram.py -- what pysam.AlignmentFile(path, "rc", reference_filename=...) does for the reference,
- * read_collector.py:372-373) */
-/* rANS 4x8 (CRAM 3.0 block method 4), order 0 and 1: `in` is the whole block payload (order byte, two sizes, tables,
- * states, stream); `n_out` must equal the size the payload declares. */
-int uz_rans4x8_decode(const uint8_t *in, int64_t n_in, uint8_t *out, int64_t n_out);
-/* The record layer of one CRAM 3.0 slice: the container's compression header and the slice's blocks, already inflated by the
- * caller, -> the slice's alignment records as uncompressed BAM records (block_size word included, an `SA:Z:*` tag on records
- * that carry an SA tag, no other tags), malloc'ed: release with uz_io_free.  uz_bam_decode_memory builds the table from them.
- * Multi-reference slices (ref_id -2) are not taken (UZ_IO_E_ARG): the Python layer decodes those. */
-typedef struct uz_cram_slice {
-    const uint8_t *comp_header; /* content of the compression header block */
-    int64_t n_comp_header;
-    int32_t ref_id, start, span, n_records; /* slice header */
-    int64_t counter;                        /* number of the slice's first record in the file (generated read names) */
-    const uint8_t *core;                    /* core data block */
-    int64_t n_core;
-    int32_t n_ext; /* external blocks: content ids, contents, sizes */
-    const int32_t *ext_id;
-    const uint8_t *const *ext;
-    const int64_t *n_ext_bytes;
-    const uint8_t *ref; /* reference bases of ref_id, upper case, from 0-based position ref_start0 on (the FASTA window of the */
-    int64_t ref_start0; /* slice, or its embedded reference); NULL for a slice of unmapped reads                             */
-    int64_t n_ref;
-} uz_cram_slice;
-int uz_cram_slice_to_bam(const uz_cram_slice *s, uint8_t **bam, int64_t *n_bam);
-void uz_io_free(void *p);
+/* (CRAM input is refused by the session with a clear message -- unfazed_amd/session.py -- since round 6: the decoder of rounds 2 - 5 could only be held
+ * against the repo's own writer, never against htslib, and an alignment decoder that nothing pins is not something to phase variants through.) */
 
 /* ------------------------------------------------------------------ VCF */
 typedef struct uz_vcf uz_vcf;

@@ -162,3 +162,16 @@ print("ok", n0)
 """ % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, path)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+def test_cram_input_is_refused_with_the_way_out(tmp_path):
+    """the reference opens CRAM through pysam (read_collector.py:372-373); this build has no decoder it could pin against htslib and says so"""
+    from unfazed_amd import session
+    p = tmp_path / "kid.cram"
+    p.write_bytes(b"CRAM\x03\x00" + b"\x00" * 64)
+    with pytest.raises(session.CramNotSupported, match="samtools view -b"):
+        session.load_reads(str(p))
+    lazy = session._LazyReads(1000)
+    for call in (lambda: lazy.indexed(str(p)), lambda: lazy.header(str(p)), lambda: lazy.regions(str(p), [0], [1], [2])):
+        with pytest.raises(session.CramNotSupported):
+            call()

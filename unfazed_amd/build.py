@@ -66,7 +66,7 @@ def _compile(lib, srcs, inc, csrc, extra_flags, verbose):
     return lib
 
 
-IO_SRC = ["io_bam.cpp", "io_vcf.cpp", "io_pack.cpp", "io_cram.cpp", "io_stage.cpp"]
+IO_SRC = ["io_bam.cpp", "io_vcf.cpp", "io_pack.cpp", "io_stage.cpp"]
 IO_LIB = os.path.join(_HERE, "libunfazed_io.so")
 
 

@@ -3,7 +3,7 @@ minimal BAM writer used to build test inputs.
 
 Replaces what the reference gets from pysam.AlignmentFile:
 records in file order with flag, mapq, reference_start, CIGAR, mate contig / position,
-tlen, query name, sequence, qualities and the presence of an SA tag.  (CRAM: io_cram.py.)
+tlen, query name, sequence, qualities and the presence of an SA tag.
 The whole file is decoded once ("decoded once on the host"); region queries and mate lookups
 then run on the column table (unfazed_amd.model.ReadsTable).  A native decoder is listed under
 "next" in DESIGN.md; this one favours clarity.

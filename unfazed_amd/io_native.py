@@ -29,24 +29,13 @@ IO_EXPORTS = [
     "uz_vcf_contig", "uz_vcf_ref", "uz_vcf_alt", "uz_vcf_header", "uz_vcf_line", "uz_vcf_info", "uz_vcf_is_bcf",
     "uz_reads_pack_sizes", "uz_reads_pack_exceptions", "uz_reads_pack_lists", "uz_reads_pack_end_derivable", "uz_reads_pack_cigar_omitted", "uz_reads_pack", "uz_reads_source_open", "uz_reads_source_close", "uz_reads_select_plan",
     "uz_select_n_records", "uz_select_n_cigar_total", "uz_select_n_row_units", "uz_select_n_seq_units", "uz_select_n_bl", "uz_select_n_bl_units", "uz_select_bl_wide", "uz_select_n_exc", "uz_select_n_qlow_pos", "uz_select_qlow_pos_wide", "uz_select_end_derivable", "uz_select_n_cigar_omitted", "uz_select_n_tuples", "uz_select_n_esc16", "uz_select_n_esc16_start8", "uz_select_n_esc16_narrow8", "uz_select_pair8_ok", "uz_select_n_esc16_pair8", "uz_select_n_new_names", "uz_select_qname_map",
-    "uz_reads_select_fill", "uz_select_free", "uz_rans4x8_decode", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
-    "uz_cram_slice_to_bam", "uz_io_free", "uz_bam_decode_memory",
+    "uz_reads_select_fill", "uz_select_free", "uz_vcf_decode_regions", "uz_vcf_index_names", "uz_vcf_io_stats",
+    "uz_bam_decode_memory",
     "uz_bamsrc_open", "uz_bamsrc_close", "uz_bamsrc_n_contigs", "uz_bamsrc_contig_name", "uz_bamsrc_contig_length", "uz_bamsrc_tlen_head",
     "uz_index_summary", "uz_inflate_backend", "uz_io_default_threads", "uz_io_cpu_quota", "uz_bam_stage_plan", "uz_bam_stage_begin", "uz_bam_stage_finish", "uz_stage_gather_blocks", "uz_stage_set_inflated", "uz_stage_sizes", "uz_stage_io_stats", "uz_stage_timing", "uz_stage_fill", "uz_stage_qname", "uz_stage_qnames",
     "uz_stage_free", "uz_stage_walk_plan_sizes", "uz_stage_walk_plan", "uz_bam_stage_finish_desc", "uz_stage_kept_sizes", "uz_stage_kept", "uz_stage_walk_host", "uz_stage_kept_debug", "uz_stage_name_records", "uz_packed_block_sums", "uz_stage_merge_subtasks", "uz_bam_stage_finish_sub",
     "uz_stage_walk_flagged", "uz_stage_lookup", "uz_stage_extra", "uz_stage_n_lookup_tasks",
 ]
-
-
-class CramSlice(C.Structure):
-    """uz_cram_slice (include/unfazed_io.h)"""
-    _fields_ = [
-        ("comp_header", C.c_char_p), ("n_comp_header", C.c_int64),
-        ("ref_id", C.c_int32), ("start", C.c_int32), ("span", C.c_int32), ("n_records", C.c_int32), ("counter", C.c_int64),
-        ("core", C.c_char_p), ("n_core", C.c_int64),
-        ("n_ext", C.c_int32), ("ext_id", C.POINTER(C.c_int32)), ("ext", C.POINTER(C.c_char_p)), ("n_ext_bytes", C.POINTER(C.c_int64)),
-        ("ref", C.c_char_p), ("ref_start0", C.c_int64), ("n_ref", C.c_int64),
-    ]
 
 
 class VcfView(C.Structure):
@@ -93,10 +82,6 @@ def load():
     lib.uz_bam_qname.restype = C.c_void_p
     lib.uz_bam_tlen_head.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.uz_bam_tlen_head.restype = C.c_int64
-    lib.uz_rans4x8_decode.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
-    lib.uz_cram_slice_to_bam.argtypes = [C.POINTER(CramSlice), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
-    lib.uz_io_free.argtypes = [C.c_void_p]
-    lib.uz_io_free.restype = None
     lib.uz_bam_decode_memory.argtypes = [C.c_char_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
     lib.uz_bam_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.uz_bam_timing.restype = None
@@ -209,47 +194,12 @@ def _check(lib, rc: int) -> None:
         raise IoError(rc, (lib.uz_io_last_error() or b"").decode(errors="replace"))
 
 
-def cram_slice_to_bam(comp_header: bytes, ref_id: int, start: int, span: int, n_records: int, counter: int, core: bytes, ext: dict,
-                      ref: bytes = None, ref_start0: int = 0) -> bytes:
-    """uz_cram_slice_to_bam: the records of one CRAM slice as uncompressed BAM records (ext: {content id: block bytes})"""
-    lib = load()
-    s = CramSlice()
-    s.comp_header, s.n_comp_header = comp_header, len(comp_header)
-    s.ref_id, s.start, s.span, s.n_records, s.counter = int(ref_id), int(start), int(span), int(n_records), int(counter)
-    s.core, s.n_core = core, len(core)
-    ids = sorted(ext)
-    s.n_ext = len(ids)
-    id_arr = (C.c_int32 * max(1, len(ids)))(*ids)
-    ptr_arr = (C.c_char_p * max(1, len(ids)))(*[bytes(ext[i]) for i in ids])
-    len_arr = (C.c_int64 * max(1, len(ids)))(*[len(ext[i]) for i in ids])
-    s.ext_id, s.ext, s.n_ext_bytes = id_arr, ptr_arr, len_arr
-    s.ref, s.ref_start0, s.n_ref = (ref, int(ref_start0), len(ref)) if ref is not None else (None, 0, 0)
-    out, n = C.c_void_p(), C.c_int64(0)
-    _check(lib, lib.uz_cram_slice_to_bam(C.byref(s), C.byref(out), C.byref(n)))
-    try:
-        return C.string_at(out.value, n.value)
-    finally:
-        lib.uz_io_free(out)
-
-
 def read_bam_stream_table(stream: bytes, threads: int = 0, insert_size_max_sample: int = 1000000) -> ReadsTable:
     """uncompressed BAM stream in memory (magic, header, references, records) -> ReadsTable (uz_bam_decode_memory)"""
     lib = load()
     hp = C.c_void_p()
     _check(lib, lib.uz_bam_decode_memory(stream, len(stream), int(threads), C.byref(hp)))
     return _table_from_handle(lib, _Handle(hp.value, lib.uz_bam_free), insert_size_max_sample)
-
-
-def rans4x8_decode(data: bytes) -> bytes:
-    """payload of a CRAM block compressed with rANS 4x8 -> its bytes (uz_rans4x8_decode)"""
-    import struct
-    lib = load()
-    if len(data) < 9:
-        raise IoError(-2, "rANS block shorter than its header")
-    (n_out,) = struct.unpack_from("<I", data, 5)
-    out = C.create_string_buffer(max(1, n_out))
-    _check(lib, lib.uz_rans4x8_decode(data, len(data), out, n_out))
-    return out.raw[:n_out]
 
 
 def _arr(ptr, n: int, dtype) -> np.ndarray:

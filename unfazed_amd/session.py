@@ -113,26 +113,25 @@ def load_sites(name_or_table, regions=None) -> (str, SitesTable):
     return name_or_table, _SITES[name_or_table]
 
 
-_CRAM_REF: Dict[str, str] = {}
+class CramNotSupported(RuntimeError):
+    """CRAM input (read_collector.py:372-373 opens it through pysam with `-r`): refused.  Rounds 2 - 5 carried a CRAM 3.0 decoder that could only be
+    held against this repo's own writer -- the image has no htslib to pin it against, the reference ships no CRAM file -- and an alignment decoder
+    nothing pins is not something to phase variants through; it was removed in round 6."""
+
+    def __init__(self, name: str):
+        super().__init__("%s: CRAM input is not supported by this build -- convert it first (samtools view -b -T ref.fa -o kid.bam kid.cram; "
+                         "samtools index kid.bam)" % name)
 
 
 def set_cram_reference(name: str, fasta: Optional[str]) -> None:
-    """the FASTA a CRAM is decoded against (`-r / --reference`; read_collector.py:372-373 passes it to pysam)"""
-    if fasta:
-        _CRAM_REF[name] = fasta
+    """`-r / --reference` (unfazed.py:97-126): accepted for the reference's command line; no decoder reads it (CramNotSupported)"""
 
 
 def load_reads(name: str, insert_size_max_sample: int = 1000000) -> ReadsTable:
     if name not in _READS:
-        if name[-4:] == "cram" and not _python_io():
-            from .io_cram import read_cram_table
-            t = read_cram_table(name, _CRAM_REF.get(name), threads=_io_threads(), insert_size_max_sample=insert_size_max_sample)
-        elif name[-4:] == "cram":
-            from .io_cram import read_cram
-            contigs, segs = read_cram(name, _CRAM_REF.get(name))
-            t = ReadsTable.from_segments(segs, contigs)
-            t.tlen_head = np.array([s.tlen for s in segs[: int(insert_size_max_sample) + 1]], dtype=np.int32)
-        elif _python_io():
+        if name[-4:] == "cram":
+            raise CramNotSupported(name)
+        if _python_io():
             from .io_bam import read_bam
             contigs, segs = read_bam(name)
             t = ReadsTable.from_segments(segs, contigs)
@@ -164,8 +163,7 @@ class _LazyReads(dict):
         if bam in _READS or bam in self or os.environ.get("UZ_IO_INDEX", "1") == "0" or not os.path.isfile(bam):
             return False
         if bam.endswith(".cram"):
-            from .io_cram import crai_path
-            return crai_path(bam) is not None
+            raise CramNotSupported(bam)
         if _python_io():
             return False
         from .io_native import bam_index_path
@@ -173,20 +171,8 @@ class _LazyReads(dict):
 
     def header(self, bam: str) -> ReadsTable:
         if bam not in self._headers:
-            if bam.endswith(".cram") and not _python_io():
-                # the head of the file: whole slices until insert_size_max_sample + 1 records are there
-                from .io_cram import read_cram_table
-                full = read_cram_table(bam, _CRAM_REF.get(bam), max_records=int(self.cap) + 1, threads=_io_threads(),
-                                       insert_size_max_sample=self.cap)
-                t = ReadsTable(full.contigs)
-                t.tlen_head = full.tlen_head
-                self._headers[bam] = t
-            elif bam.endswith(".cram"):
-                from .io_cram import read_cram
-                contigs, segs = read_cram(bam, _CRAM_REF.get(bam), max_records=int(self.cap) + 1)
-                t = ReadsTable(contigs)
-                t.tlen_head = np.array([s.tlen for s in segs[: int(self.cap) + 1]], dtype=np.int32)
-                self._headers[bam] = t
+            if bam.endswith(".cram"):
+                raise CramNotSupported(bam)
             elif self.stager(bam) is not None:
                 src = self.stager(bam)
                 t = ReadsTable(src.contigs)
@@ -215,13 +201,8 @@ class _LazyReads(dict):
         return self._stagers[bam]
 
     def regions(self, bam: str, tid, lo, hi) -> ReadsTable:
-        if bam.endswith(".cram") and not _python_io():
-            from .io_cram import read_cram_regions_table
-            return read_cram_regions_table(bam, _CRAM_REF.get(bam), tid, lo, hi, threads=_io_threads())
         if bam.endswith(".cram"):
-            from .io_cram import read_cram_regions
-            contigs, segs = read_cram_regions(bam, _CRAM_REF.get(bam), tid, lo, hi)
-            return ReadsTable.from_segments(segs, contigs)
+            raise CramNotSupported(bam)
         from .io_native import read_bam_regions
         return read_bam_regions(bam, tid, lo, hi, threads=_io_threads(), insert_size_max_sample=0)
 
