@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--feed-dnms", type=int, default=int(os.environ.get("UZ_BENCH_FEED_DNMS", 20000)),
                     help="DNMs of the files -> results pass (`feed` / `value_e2e`): their pile-ups are written as a real BAM + BAI, the sites table as "
                          "a BGZF VCF + TBI, and decoded back through the indexes inside the timed region (0 = skip)")
+    ap.add_argument("--feed-filler-dnms", type=int, default=int(os.environ.get("UZ_BENCH_FEED_FILLER_DNMS", 5000)),
+                    help="DNMs of the `feed_filler` pass: the files -> results pass on a BAM whose gaps between the pile-ups are filled with read pairs (0 = skip)")
+    ap.add_argument("--feed-filler", type=float, default=30.0, help="coverage of the filler between the pile-ups of the `feed_filler` pass")
     ap.add_argument("--feed-chunk", type=int, default=3400, help="DNMs per chunk of the files -> results pass (scripts/feed_sweep.sh, two boxes: 1500 / 2500 / 3400 / 4000 / 5000 = 23.7 / 24.6 / 25.9 / 24.3 / 22.5 k DNMs/s)")
     ap.add_argument("--feed-reps", type=int, default=3, help="timed passes of the feed leg (the median is reported)")
     ap.add_argument("--feed-walk", choices=("device", "host"), default="device",
@@ -419,7 +422,7 @@ def main():
         except Exception:
             issue_model = None
 
-    feed = None
+    feed = feed_filler = None
     if rank == 0 and world == 1 and not cnv and args.feed_dnms > 0:
         if getattr(bind_near_gpu, "compact", None):  # the files -> results pass is host work: 2 q CPUs next to each other, next to the GPU
             os.sched_setaffinity(0, bind_near_gpu.compact)
@@ -428,6 +431,19 @@ def main():
         feed = feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool)
         if feed is not None:
             feed["host_cpus_bound_to"] = len(os.sched_getaffinity(0))
+        if feed is not None and args.feed_filler_dnms > 0 and args.feed_walk == "device" and args.feed_inflate == "device":
+            # The same pass on a file that looks like a file: the first --feed-filler-dnms DNMs, once with the gaps between their
+            # pile-ups filled at 30 x -- bins with a lead-in, records to walk past between two reach intervals -- and once without, so that the two
+            # differ in nothing but the filler
+            ff = feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool, dnms=args.feed_filler_dnms, filler=args.feed_filler, lite=True, cutoff_of_the_pile_ups=cutoff)
+            f0 = feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool, dnms=args.feed_filler_dnms, filler=0.0, lite=True)
+            ff["same_dnms_without_filler"] = {k: f0[k] for k in ("value_e2e", "seconds_of_every_pass", "result_mismatches_vs_resident", "blocks_inflated_per_dnm",
+                                                               "inflated_MB_per_dnm", "records_walked_per_record_kept", "link_bytes_per_dnm", "host_cpu_seconds_per_pass")}
+            ff["same_dnms_without_filler"]["bam"] = f0["bam"]
+            ff["note"] = ("read pairs at %g x in every gap between the pile-ups (and 64 kb beyond a contig's first / last one): what bamfile.fetch meets on a whole-genome "
+                          "file, read_collector.py:385, :167 -- the walk starts where the linear index puts the first record of a 16 kb window and walks past "
+                          "what lies in front of the reach" % args.feed_filler)
+            feed_filler = ff
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu and args.cpu_dnms > 0:
@@ -485,6 +501,7 @@ def main():
             "cpu_baseline": cpu,
             "value_e2e": feed["value_e2e"] if feed else None,
             "feed": feed,
+            "feed_filler": feed_filler,
             "config5": config5,
             "kernels_ms_per_step": kern_ms(prof_r),
             "calls": {"phased": phased, "correct_vs_truth": correct, "status_counts": np.bincount(status, minlength=6).tolist(),
@@ -504,7 +521,7 @@ def main():
         dist.destroy_process_group()
 
 
-def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
+def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool, dnms=None, filler=0.0, lite=False, cutoff_of_the_pile_ups=None):
     """Files -> results (what feeds the timed step).  The pile-ups of the first `--feed-dnms` DNMs are written as a
     real coordinate-sorted BAM + BAI (samtools layout, deflate level 6) and the WHOLE sites table as a BGZF VCF + TBI (synth/uzfiles.cpp:
     outside the timing).  Timed, per chunk of DNMs and with the real dependency inside the timer:
@@ -520,7 +537,9 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
     from unfazed_amd import abi, io_native
     from unfazed_amd.hostpath import concordant_cutoff
     from unfazed_amd.staging import fetch_points
-    m_want = min(args.feed_dnms, ev.n)
+    # dnms / filler / lite: the `feed_filler` leg -- fewer DNMs, the gaps between their pile-ups filled with read pairs at `filler`-fold coverage
+    # (bigsynth.write_bam(filler=...)), and only the pass itself timed (no product call, no CPU decode)
+    m_want = min(dnms if dnms is not None else args.feed_dnms, ev.n)
     c_hi = cl.of_dnm(m_want - 1) + 1
     m = int(cl.d0[c_hi - 1] + cl.nd[c_hi - 1])  # whole clusters
     base = args.feed_dir
@@ -530,7 +549,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
     try:
         t0 = time.perf_counter()
         bam = os.path.join(d, "kid.bam")
-        st_b = bigsynth.write_bam(bam, cfg, sc, ev, cl, 0, c_hi, level=args.feed_level, tags=True, threads=0)
+        st_b = bigsynth.write_bam(bam, cfg, sc, ev, cl, 0, c_hi, level=args.feed_level, tags=True, threads=0, filler=float(filler), filler_reach=65536)
         t1 = time.perf_counter()
         vcf = os.path.join(d, "sites.vcf.gz")
         st_v = bigsynth.write_vcf(vcf, sc, level=args.feed_level, threads=0)
@@ -540,6 +559,12 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         tbx = {nm: i for i, nm in enumerate(names)}
         bam_tid = {nm: i for i, nm in enumerate(src.contigs)}
         cutoff = concordant_cutoff(src.tlen_head, P.readlen, 3)
+        cutoff_file = cutoff
+        if filler and cutoff_of_the_pile_ups is not None:
+            # The insert cutoff is an estimate from the HEAD of the alignment file (read_collector.py:11-25): a file with filler in front of its first
+            # pile-up has another head, its estimate differs from the pile-ups' in the third digit, and a handful of reads near the cutoff change sides.
+            # The pass is held against the resident results, so it phases with THEIR cutoff; both are in the line.
+            cutoff = float(cutoff_of_the_pile_ups)
         sd = int(P.search_dist) + 2
         cuts = list(range(0, m, max(1, args.feed_chunk))) + [m]
         if args.feed_walk == "device" and args.feed_inflate == "device" and len(cuts) > 3:
@@ -675,14 +700,45 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
                 acc["host_cpu_s"] = time.process_time() - c_t  # (the library's worker threads included)
                 return time.perf_counter() - t
 
+        def throttled():  # the cgroup's CPU throttle: periods in which the quota ran out, and the time waited (cpu.stat)
+            try:
+                kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+                return int(kv.get("nr_throttled", 0)), int(kv.get("throttled_usec", 0))
+            except Exception:
+                return 0, 0
+
+        per_pass = []
+
+        def watched_pass():
+            a0, t0_ = eng.walk_slot_stats()["allocations"], throttled()
+            el_ = run_pass()
+            t1_ = throttled()
+            per_pass.append({"seconds": round(el_, 3), "device_allocations_by_the_walk_slots": eng.walk_slot_stats()["allocations"] - a0,
+                             "cgroup_throttled_periods": t1_[0] - t0_[0], "cgroup_throttled_ms": round((t1_[1] - t0_[1]) / 1e3, 1)})
+            return el_
         run_pass()  # warm-up: page cache, pinned blocks, code
-        els = sorted(run_pass() for _ in range(max(1, args.feed_reps)))
+        els = sorted(watched_pass() for _ in range(max(1, args.feed_reps)))
         el = els[len(els) // 2]  # the median pass (the stage statistics below are the last pass's)
         for pool in pools:
             pool.free_all()
         for ip in ipairs or []:
             ip.free_all()
         mism = sum(int((np.asarray(out[k]) != np.asarray(res_r[k][:m])).sum()) for k in out)
+        if lite:
+            return {
+                "dnms": m, "chunks": K, "filler_coverage": float(filler), "insert_cutoff_used": round(float(cutoff), 3), "insert_cutoff_of_this_files_head": round(float(cutoff_file), 3),
+                "value_e2e": round(m / el, 1), "seconds": round(el, 3),
+                "seconds_of_every_pass": [round(x, 3) for x in els], "result_mismatches_vs_resident": mism,
+                "bam": {"records": st_b["records"], "file_GB": round(st_b["file_bytes"] / 1e9, 3), "raw_GB": round(st_b["raw_bytes"] / 1e9, 3), "blocks": st_b["blocks"],
+                        "write_s": round(t1 - t0, 1)},
+                "blocks_inflated_per_dnm": round(acc["dev_blocks"] / m, 2), "inflated_MB_per_dnm": round(acc["dev_out_bytes"] / m / 1e6, 3),
+                "records_walked_per_record_kept": round(acc["walked"] / max(1, acc["kept"]), 2), "records_kept_per_dnm": round(acc["kept"] / m, 1),
+                "descriptors_left_in_hbm_per_dnm": round(acc["w_desc"] / m, 1), "tasks": acc["w_tasks"], "tasks_walked_by_the_host": acc["w_host_tasks"],
+                "index_mate_lookups": acc["lookups"], "link_bytes_per_dnm": round(acc["link_bytes"] / m, 1),
+                "host_cpu_seconds_per_pass": round(float(acc.get("host_cpu_s", 0.0)), 3),
+                "seconds_busy": {"plan+gather": round(acc["w_plan"], 3), "upload+inflate+walk": round(acc["w_walk"], 3), "joins": round(acc["w_joins"], 3),
+                                 "sites_decode": round(acc["vcf_s"], 3)},
+            }
         product = product_e2e(bam, vcf, sc, ev, m, res_r) if not os.environ.get("UZ_BENCH_NO_PRODUCT") else None
         # the CPU path's decode of the same files: the whole BAM (it holds only these pile-ups) + the same windows of the VCF
         t = time.perf_counter()
@@ -695,6 +751,7 @@ def feed_e2e(args, eng, sc, ev, cl, cfg, P, mode, res_r, PinnedPool):
         raw_per_rec = st_b["raw_bytes"] / max(1, st_b["records"])
         return {
             "dnms": m, "chunks": K, "value_e2e": round(m / el, 1), "seconds": round(el, 3), "seconds_of_every_pass": [round(x, 3) for x in els],
+            "every_pass": per_pass,
             "result_mismatches_vs_resident": mism,
             "walk": ("device (k_bam_walk: one wavefront per walk task; mate() closure, name numbering, file order and the table's offsets on the device too: csrc/k_bamjoin.hip)" if dev_joins
                      else "device (k_bam_walk: one wavefront per walk task; the host runs the batch-wide joins on 64-byte descriptors)") if dev_walk else "host (uz_bam_stage_*)",

@@ -148,6 +148,9 @@ int uz_bam_join_fetch(uz_ctx *ctx, int walk_id, uint64_t *voff, uint32_t *qname,
 int uz_reads_from_walk(uz_ctx *ctx, int walk_id, int32_t min_base_qual, int want_names, int *reads_id, int64_t totals[8]);
 int uz_reads_names(uz_ctx *ctx, int reads_id, const uint32_t *ids, int64_t n, int64_t *off, uint8_t *buf, int64_t cap, int64_t *need);
 int uz_walk_slot_stats(uz_ctx *ctx, int64_t out[8]);
+/* every free slot among the first n_slots grown, now, to the largest sizes any batch of this context has asked for (a pipeline that will keep
+ * n_slots batches in flight calls it once a first batch is through: no later batch's walk then pays for a slot's first gigabytes) */
+int uz_walk_reserve(uz_ctx *ctx, int n_slots);
 int uz_reads_from_bam(uz_ctx *ctx, int walk_id, const uz_kept_rec *kept, int64_t n, const uint8_t *aux, int64_t aux_bytes, const int64_t *contig_off,
                       const int32_t *max_span, int32_t n_contigs, int64_t n_cigar_total, int64_t n_row_units, int64_t n_seq_units, uint32_t n_qnames,
                       int32_t min_base_qual, uint8_t *names_out /* NULL, or [names_bytes]: the kept records' read names back to back (uz_kept_rec.name_off) */,

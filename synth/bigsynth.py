@@ -191,9 +191,11 @@ def _names_array(names):
     return arr
 
 
-def write_bam(path, cfg, sc, dn, cl, c0=0, c1=None, contig_len=None, level=6, tags=True, threads=0, bai=True):
+def write_bam(path, cfg, sc, dn, cl, c0=0, c1=None, contig_len=None, level=6, tags=True, threads=0, bai=True, filler=0.0, filler_reach=65536):
     """Clusters [c0, c1) as a coordinate-sorted BAM (+ BAI next to it): the records reads_cpu() generates for the same range,
-    query names qname_of(global pair).  -> dict(records, raw_bytes, file_bytes, blocks)"""
+    query names qname_of(global pair).  -> dict(records, raw_bytes, file_bytes, blocks)
+    filler: coverage of read pairs laid into the gaps BETWEEN the clusters (and filler_reach bases in front of / behind a contig's first / last
+    cluster of the range) -- a file with records everywhere, as a real one has; none of them can be returned by a fetch of the clusters' DNMs."""
     L = C.CDLL(build_files())
     c1 = cl.n if c1 is None else c1
     S, D, K, keep = _host_structs(cfg, sc, dn, cl)
@@ -205,10 +207,10 @@ def write_bam(path, cfg, sc, dn, cl, c0=0, c1=None, contig_len=None, level=6, ta
     names = _names_array(sc.contig_names)
     stats = (C.c_int64 * 4)()
     err = C.create_string_buffer(256)
-    L.uzs_write_bam.restype = C.c_int
-    rc = L.uzs_write_bam(os.fsencode(path), os.fsencode(path + ".bai") if bai else None, C.byref(cfg), C.byref(S), C.byref(D), C.byref(K),
-                         C.c_int32(c0), C.c_int32(c1), names, C.c_void_p(lens.ctypes.data), C.c_int(level), C.c_int(1 if tags else 0),
-                         C.c_int(threads), stats, err, C.c_int(256))
+    L.uzs_write_bam_filler.restype = C.c_int
+    rc = L.uzs_write_bam_filler(os.fsencode(path), os.fsencode(path + ".bai") if bai else None, C.byref(cfg), C.byref(S), C.byref(D), C.byref(K),
+                                C.c_int32(c0), C.c_int32(c1), names, C.c_void_p(lens.ctypes.data), C.c_int(level), C.c_int(1 if tags else 0),
+                                C.c_int(threads), C.c_double(float(filler)), C.c_int64(int(filler_reach)), stats, err, C.c_int(256))
     if rc != 0:
         raise RuntimeError("uzs_write_bam: " + err.value.decode())
     return dict(zip(("records", "raw_bytes", "file_bytes", "blocks"), (int(x) for x in stats)))

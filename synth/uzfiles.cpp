@@ -246,12 +246,111 @@ extern "C" {
 // query name of pair `pair` (global pair number): what the BAM carries; the decoders intern names in file order
 int uzs_qname(int64_t pair, char *buf) { return snprintf(buf, 40, "UZSYN:30X:1:%03d:%07d", (int)(pair % 997), (int)(pair / 997)); }
 
+} // extern "C"
+
+namespace {
+// FILLER: the file between the pile-ups.  A real 30 x file holds records everywhere; the index-driven readers meet them as the lead-in of a
+// 16 kb bin in front of a window and as records to walk past between two reach intervals.  Read pairs at `cov`-fold coverage laid into [g0, g1) --
+// a gap between two clusters -- whole inside it with a margin, so that no fetch of the batch can ever return one (the phasing results are those of
+// the file without filler): hashed bases, the pile-ups' quality profile, names of their own ("UZFIL:...").
+inline int filler_insert(uint64_t h) { // the pile-ups' own template-length distribution (uzsynth.h: uzs_segment)
+    int ins = 450;
+    for (int j = 0; j < 4; j++) ins += (int)((h >> (20 + 8 * j)) & 0xFF) * 100 / 256 - 50;
+    return ins;
+}
+void emit_filler(Part &P, const uzs_cfg *cf, int32_t tid, int64_t g0, int64_t g1, double cov, int tags, uint64_t gap_id, std::vector<uint64_t> &keys,
+                 std::vector<uint8_t> &rec) {
+    const int L = UZS_READLEN;
+    const int64_t margin = 200;
+    g0 += margin; g1 -= margin;
+    if (g1 - g0 < 1200) return;
+    const int64_t np = (int64_t)((double)(g1 - g0) * cov / (2.0 * L));
+    if (np <= 0) return;
+    keys.clear();
+    const int64_t span = (g1 - g0) - 700;
+    for (int64_t k = 0; k < np; k++) {
+        const uint64_t h = uzs_h(cf->seed ^ 0xF111E5ULL, gap_id, (uint64_t)k, 7);
+        const int64_t cell = span / np > 0 ? span / np : 1;
+        const int64_t fs = g0 + k * span / np + (int64_t)((h >> 8) % (uint64_t)cell);
+        const int ins = filler_insert(h);
+        keys.push_back(((uint64_t)fs << 24) | ((uint64_t)k << 1));
+        keys.push_back(((uint64_t)(fs + ins - L) << 24) | ((uint64_t)k << 1) | 1ULL);
+    }
+    if (np >= (1 << 22)) return; // (23 bits of pair number in the key)
+    std::sort(keys.begin(), keys.end());
+    for (uint64_t key : keys) {
+        const int64_t start = (int64_t)(key >> 24), k = (int64_t)((key >> 1) & 0x3FFFFF);
+        const int which = (int)(key & 1);
+        const uint64_t h = uzs_h(cf->seed ^ 0xF111E5ULL, gap_id, (uint64_t)k, 7);
+        const int64_t cell = span / np > 0 ? span / np : 1;
+        const int64_t fs = g0 + k * span / np + (int64_t)((h >> 8) % (uint64_t)cell);
+        const int ins = filler_insert(h);
+        const int64_t mate_start = which ? fs : fs + ins - L;
+        const uint16_t flag = (uint16_t)(0x1 | 0x2 | (which ? 0x10 : 0x20) | (which ? 0x80 : 0x40));
+        char name[48];
+        const int ln = snprintf(name, sizeof(name), "UZFIL:%llx:%06lld", (unsigned long long)(gap_id & 0xFFFFFFFFFFULL), (long long)k) + 1;
+        rec.clear();
+        put32(rec, 0);
+        put32(rec, tid);
+        put32(rec, (int32_t)start);
+        rec.push_back((uint8_t)ln);
+        rec.push_back((uint8_t)60);
+        const uint16_t bin = (uint16_t)reg2bin(start, start + L), nops = 1;
+        rec.insert(rec.end(), (const uint8_t *)&bin, (const uint8_t *)&bin + 2);
+        rec.insert(rec.end(), (const uint8_t *)&nops, (const uint8_t *)&nops + 2);
+        rec.insert(rec.end(), (const uint8_t *)&flag, (const uint8_t *)&flag + 2);
+        put32(rec, L);
+        put32(rec, tid);
+        put32(rec, (int32_t)mate_start);
+        put32(rec, which ? -ins : ins);
+        rec.insert(rec.end(), name, name + ln);
+        put32(rec, (int32_t)((uint32_t)L << 4));
+        const uint64_t bseed = uzs_mix(h ^ (uint64_t)(which + 1));
+        for (int b = 0; b < L; b += 2) { // (the reference's bases, as the pile-ups carry them: the same compressibility)
+            auto code = [](uint8_t ch) -> uint8_t { return ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 4 : ch == 'T' ? 8 : 15; };
+            const uint8_t b0 = uzs_refbase(tid, start + b), b1 = b + 1 < L ? uzs_refbase(tid, start + b + 1) : 0;
+            rec.push_back((uint8_t)((code(b0) << 4) | (b + 1 < L ? code(b1) : 0)));
+        }
+        for (int b = 0; b < L; b++) {
+            const uint64_t hb = uzs_mix(bseed + (uint64_t)b * 0x9E3779B97F4A7C15ULL);
+            rec.push_back((uint8_t)(((hb >> 24) % 100) < 3 ? 12 : 37));
+        }
+        if (tags) {
+            const uint8_t nm[] = {'N', 'M', 'C', (uint8_t)(h & 3)};
+            rec.insert(rec.end(), nm, nm + 4);
+            char md[16];
+            const int lm = snprintf(md, sizeof(md), "MDZ%d", L);
+            rec.insert(rec.end(), md, md + lm + 1);
+            const uint8_t as[] = {'A', 'S', 'C', (uint8_t)(L - (int)(h & 3) * 5), 'X', 'S', 'C', (uint8_t)((h >> 8) % 40)};
+            rec.insert(rec.end(), as, as + 8);
+            const char rg[] = "RGZgrp1";
+            rec.insert(rec.end(), rg, rg + sizeof(rg));
+        }
+        const int32_t bs = (int32_t)rec.size() - 4;
+        memcpy(rec.data(), &bs, 4);
+        P.add_record(tid, start, start + L, rec.data(), rec.size());
+    }
+}
+} // namespace
+
+extern "C" {
+
 /* The records of clusters [c0, c1) as a coordinate-sorted BAM + BAI.  `tags`: 1 = every record carries the usual aligner tags
  * (NM, MD, AS, XS, RG: ~40 bytes the readers have to walk past).  stats: [0] records, [1] uncompressed bytes, [2] file bytes,
- * [3] BGZF blocks.  Returns 0, or a negative number with a message in err (cap bytes). */
+ * [3] BGZF blocks.  Returns 0, or a negative number with a message in err (cap bytes).
+ * filler_cov > 0: the gaps between the clusters -- and filler_reach bases in front of a contig's first and behind its last cluster of the range --
+ * are filled with read pairs at that coverage (emit_filler): a file that looks like a file, not like a list of pile-ups. */
+int uzs_write_bam_filler(const char *bam_path, const char *bai_path, const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, const uzs_clusters *C,
+                         int32_t c0, int32_t c1, const char *const *contig_names, const int32_t *contig_len, int level, int tags, int threads,
+                         double filler_cov, int64_t filler_reach, int64_t *stats, char *err, int cap);
 int uzs_write_bam(const char *bam_path, const char *bai_path, const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, const uzs_clusters *C,
                   int32_t c0, int32_t c1, const char *const *contig_names, const int32_t *contig_len, int level, int tags, int threads,
                   int64_t *stats, char *err, int cap) {
+    return uzs_write_bam_filler(bam_path, bai_path, cf, S, D, C, c0, c1, contig_names, contig_len, level, tags, threads, 0.0, 0, stats, err, cap);
+}
+int uzs_write_bam_filler(const char *bam_path, const char *bai_path, const uzs_cfg *cf, const uzs_sites *S, const uzs_dnms *D, const uzs_clusters *C,
+                         int32_t c0, int32_t c1, const char *const *contig_names, const int32_t *contig_len, int level, int tags, int threads,
+                         double filler_cov, int64_t filler_reach, int64_t *stats, char *err, int cap) {
     auto fail = [&](const char *m) { if (err && cap > 0) snprintf(err, (size_t)cap, "%s", m); return -1; };
     if (!bam_path || !cf || !S || !D || !C || c1 < c0) return fail("bad argument");
     if (threads <= 0) threads = default_threads();
@@ -292,7 +391,13 @@ int uzs_write_bam(const char *bam_path, const char *bai_path, const uzs_cfg *cf,
         std::vector<uint32_t> keys(UZS_MAXSEG);
         std::vector<uint8_t> rec;
         uint8_t sq[UZS_ROW], ql[UZS_ROW];
+        std::vector<uint64_t> fkeys;
         for (int32_t c = cut[(size_t)k]; c < cut[(size_t)k + 1] && P.err.empty(); c++) {
+            if (filler_cov > 0) { // the gap in front of the cluster (its worker writes it: the parts stay in file order)
+                const bool first_of_contig = c == c0 || C->contig[c - 1] != C->contig[c];
+                const int64_t g0 = first_of_contig ? std::max<int64_t>(0, (int64_t)C->lo[c] - filler_reach) : (int64_t)C->hi[c - 1];
+                emit_filler(P, cf, C->contig[c], g0, C->lo[c], filler_cov, tags, (uint64_t)c * 2, fkeys, rec);
+            }
             const int nseg = (int)(2 * (C->pair_off[c + 1] - C->pair_off[c]));
             if (nseg > UZS_MAXSEG) { P.err = "a cluster holds more than UZS_MAXSEG records"; break; }
             for (int slot = 0; slot < nseg; slot++) {
@@ -350,6 +455,8 @@ int uzs_write_bam(const char *bam_path, const char *bai_path, const uzs_cfg *cf,
                 memcpy(rec.data(), &bs, 4);
                 P.add_record(tid, s.start, s.end, rec.data(), rec.size());
             }
+            if (filler_cov > 0 && (c + 1 == c1 || C->contig[c + 1] != tid)) // behind the contig's last cluster of the range
+                emit_filler(P, cf, tid, C->hi[c], std::min<int64_t>((int64_t)C->hi[c] + filler_reach, contig_len[tid]), filler_cov, tags, (uint64_t)c * 2 + 1, fkeys, rec);
         }
         P.finish();
     });

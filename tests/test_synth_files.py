@@ -116,3 +116,43 @@ def test_vcf_regions_through_the_native_tbi(workload):
     for c, a, b in zip(ref, lo, hi):
         keep |= (tid_of == c) & (sc.pos < b) & (sc.pos + np.where((sc.sflags & 1) & (np.arange(sc.n) % 2 == 0), 2, 1) > a)
     assert np.array_equal(part.pos, sc.pos[keep])
+
+
+def test_filler_between_the_pile_ups_changes_nothing_a_fetch_returns(workload, tmp_path):
+    """write_bam(filler=30): read pairs in the gaps between the clusters -- the file is coordinate-sorted, its index reaches every window through
+    bins that now hold a lead-in, the walk meets records it has to pass, and a batch's staged records are those of the file without filler."""
+    from unfazed_amd import abi
+    w = workload
+    bam = str(tmp_path / "filled.bam")
+    st = bigsynth.write_bam(bam, w["cfg"], w["sc"], w["dn"], w["cl"], contig_len=w["lens"], level=1, threads=3, filler=30.0, filler_reach=40000)
+    assert st["records"] > 2 * w["bam_stats"]["records"]
+    t = io_native.read_bam_table(bam, threads=2)
+    assert t.start.size == st["records"]
+    for c in range(len(w["lens"])):  # coordinate-sorted inside every contig
+        a, b = int(t.contig_off[c]), int(t.contig_off[c + 1])
+        assert (np.diff(t.start[a:b].astype(np.int64)) >= 0).all()
+    fill = np.array([nm.startswith("UZFIL:") for nm in t.qnames])
+    assert fill.any() and (~fill).sum() == w["bam_stats"]["records"] // 2
+    assert np.array_equal(t.qname[t.mate[t.mate >= 0]], t.qname[t.mate >= 0])  # mates name each other
+    # the same fetches on both files: the same records (by name, flag and start), however the virtual offsets moved
+    dn = w["dn"]
+    rng = np.random.default_rng(9)
+    c, lo, hi = [], [], []
+    for i in range(dn.n):
+        c.append(dn.contig[i]); lo.append(dn.start[i] - 1); hi.append(dn.start[i] + 1)
+        for p in np.sort(rng.integers(dn.start[i] - 5000, dn.start[i] + 5000, 6)):
+            c.append(dn.contig[i]); lo.append(int(p)); hi.append(int(p) + 1)
+    fc, flo, fhi = np.array(c, np.int32), np.array(lo, np.int32), np.array(hi, np.int32)
+    got = []
+    for path in (w["bam"], bam):
+        src = io_native.BamSource(path, threads=3)
+        pk = src.select(fc, flo, fhi, 20)
+        n = int(pk.view.n_segs)
+        wc = abi.wide_columns(pk)
+        names = pk.qnames.take(wc["qname"][:n]) if hasattr(pk.qnames, "take") else [pk.qnames[int(q)] for q in wc["qname"][:n]]
+        got.append((n, wc["start"][:n].copy(), wc["tlen"][:n].copy(), wc["mate"][:n].copy(), names, pk.io_stats["records_walked"]))
+    assert got[0][0] == got[1][0] > 0
+    for k in (1, 2, 3):
+        assert np.array_equal(got[0][k], got[1][k])
+    assert got[0][4] == got[1][4] and not any(nm.startswith("UZFIL:") for nm in got[1][4])
+    assert got[1][5] > 1.5 * got[0][5]  # ... but the walk went past the filler to get there

@@ -1969,6 +1969,44 @@ int uz_bam_join_fetch(uz_ctx *c, int walk_id, uint64_t *voff, uint32_t *qname, i
     });
 }
 
+// Every free slot grown to the largest sizes any batch of this context has asked for, NOW -- by a caller that has just finished a batch and knows
+// that more are coming (a staged pipeline keeps up to four in flight): a slot's first use otherwise pays for gigabytes of hipMalloc inside some later
+// batch's walk (a pass of bench.py's feed leg that met a fresh slot took 0.7 s instead of 0.17).  n_slots: how many slots the caller will have in use.
+int uz_walk_reserve(uz_ctx *c, int n_slots) {
+    return guarded(c, [&] {
+        UZ_HIP(hipSetDevice(c->device));
+        for (int i = 0; i < uz_ctx::WALK_SLOTS && i < n_slots; i++) {
+            uz_ctx::WalkSlot &w = c->walk[i];
+            {
+                std::lock_guard<std::mutex> lk(c->err_mu);
+                if (w.busy) continue;
+                w.busy = true; // (nobody takes it while it grows)
+            }
+            try {
+                auto hi = [&](int kind) { std::lock_guard<std::mutex> lk(c->walk_mu); return c->walk_hi[kind]; };
+                auto &J = w.join;
+#define UZ_RSV(buf, kind) do { const size_t h__ = hi(kind); if (h__) uz_walk_grow(c, buf, h__, kind); } while (0)
+                UZ_RSV(w.comp, 0); UZ_RSV(w.out, 1); UZ_RSV(w.in_off, 2); UZ_RSV(w.out_off, 3); UZ_RSV(w.blk_coff, 4); UZ_RSV(w.task, 5); UZ_RSV(w.span, 6); UZ_RSV(w.reach, 7);
+                UZ_RSV(w.fetch, 8); UZ_RSV(w.count, 9); UZ_RSV(w.first, 10); UZ_RSV(w.walked, 11); UZ_RSV(w.flags, 12); UZ_RSV(w.n_direct, 13); UZ_RSV(w.tab_first, 14);
+                UZ_RSV(w.kcount, 15); UZ_RSV(w.kfirst, 16); UZ_RSV(w.iflags, 17); UZ_RSV(w.blk_crc, 18); UZ_RSV(w.desc, 19); UZ_RSV(w.tab, 20);
+                UZ_RSV(J.tmp, 40); UZ_RSV(w.desc_kept, 41); UZ_RSV(J.jtask, 42); UZ_RSV(J.keep, 43); UZ_RSV(J.mate, 44); UZ_RSV(J.target, 45); UZ_RSV(J.hkey_in, 46);
+                UZ_RSV(J.hval_in, 47); UZ_RSV(J.hkey, 48); UZ_RSV(J.hperm, 49); UZ_RSV(J.inv, 50); UZ_RSV(J.front0, 51); UZ_RSV(J.front1, 52); UZ_RSV(J.need, 53);
+                UZ_RSV(J.cnt, 54); UZ_RSV(J.aux, 55); UZ_RSV(J.jt_tid, 56); UZ_RSV(J.reach_key, 57); UZ_RSV(J.reach_a, 58); UZ_RSV(J.reach_host, 59); UZ_RSV(J.h_flags, 60);
+                UZ_RSV(J.fkey_in, 63); UZ_RSV(J.fkey, 64); UZ_RSV(J.fval_in, 65); UZ_RSV(J.fidx, 66); UZ_RSV(J.first, 67); UZ_RSV(J.runid, 68); UZ_RSV(J.pos_of_k, 69);
+                UZ_RSV(J.fo, 70); UZ_RSV(J.gidx, 71); UZ_RSV(J.s5_in, 72); UZ_RSV(J.s5_out, 73); UZ_RSV(J.kept, 74); UZ_RSV(J.name_rec, 75); UZ_RSV(J.ccount, 76);
+                UZ_RSV(J.cspan, 77); UZ_RSV(J.totals, 78);
+#undef UZ_RSV
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(c->err_mu);
+                w.busy = false;
+                throw;
+            }
+            std::lock_guard<std::mutex> lk(c->err_mu);
+            w.busy = false;
+        }
+    });
+}
+
 int uz_walk_slot_stats(uz_ctx *c, int64_t out[8]) {
     return guarded(c, [&] {
         UZ_REQUIRE(out != nullptr, UZ_E_ARG, "null output");

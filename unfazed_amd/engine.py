@@ -19,7 +19,7 @@ K_SITE_SCAN, K_WINDOW_COUNT, K_WINDOW_FILL, K_PHASE, K_SIZING, K_CNV = 0, 1, 2, 
 EXPORTS = [
     "uz_create", "uz_destroy", "uz_last_error", "uz_sync", "uz_set_params",
     "uz_sites_upload", "uz_family_upload", "uz_sites_family_upload_async", "uz_reads_upload", "uz_reads_upload_packed", "uz_reads_wait", "uz_reads_headers", "uz_bgzf_inflate", "uz_bgzf_inflate_to_host", "uz_bam_walk", "uz_crc32_blocks", "uz_bam_walk_fetch", "uz_bam_walk_release", "uz_reads_from_bam",
-    "uz_bam_walk_flags", "uz_bam_join", "uz_bam_join_needs", "uz_bam_join_fetch", "uz_reads_from_walk", "uz_reads_names", "uz_walk_slot_stats",
+    "uz_bam_walk_flags", "uz_bam_join", "uz_bam_join_needs", "uz_bam_join_fetch", "uz_reads_from_walk", "uz_reads_names", "uz_walk_slot_stats", "uz_walk_reserve",
     "uz_pinned_alloc", "uz_pinned_free",
     "uz_sites_adopt_device", "uz_family_adopt_device", "uz_reads_adopt_device",
     "uz_sites_free", "uz_reads_free", "uz_drop_derived",
@@ -71,6 +71,7 @@ def load_library(path: Optional[str] = None):
     L.uz_reads_from_walk.argtypes = [vp, C.c_int, C.c_int32, C.c_int, vp, vp]
     L.uz_reads_names.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp]
     L.uz_walk_slot_stats.argtypes = [vp, vp]
+    L.uz_walk_reserve.argtypes = [vp, C.c_int]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uz_pinned_free.argtypes = [vp]
     L.uz_pinned_free.restype = None
@@ -550,6 +551,11 @@ class HipEngine:
             tot = np.zeros(8, np.int64)
             self._ck(self.L.uz_reads_from_walk(self.h, int(kb.token), int(kb.min_base_qual), 1 if names else 0, C.byref(rid), tot.ctypes.data), "uz_reads_from_walk")
             kb.token = None
+            # a batch is through and its sizes are known: the other slots a pipeline will use grow to them now, not inside a later batch's walk
+            # (a no-op once they have; UZ_WALK_RESERVE=0 leaves the slots to grow at first use)
+            self._walked = getattr(self, "_walked", 0) + 1
+            if self._walked in (1, 2, 4) and os.environ.get("UZ_WALK_RESERVE", "1") != "0":
+                self._ck(self.L.uz_walk_reserve(self.h, 4), "uz_walk_reserve")
             if names:
                 kb.qnames = io_native.DeviceNames(self, rid.value, int(kb.n_qnames))
             return rid.value
