@@ -103,3 +103,50 @@ def test_long_reads_travel_as_lists_with_two_byte_positions(tmp_path, hip_lib):
     assert len(rows) >= 3 and lists == rows and err_l == err_r
     assert walked == rows and err_w == err_r and len(seen) == 2
     assert seen[0][0] == 0 and seen[1][0] > 100 and seen[1][1] == 1 and seen[1][2] < seen[0][2]
+
+
+def test_two_threads_phase_at_once(tmp_path, hip_lib):
+    """phase_snvs from two threads of one process (the call toggled the interpreter's collector per call and shared the device context):
+    the calls take turns on the device (session.DEVICE_LOCK), the collector's pause is counted across them, both get the records a lone call gets,
+    with the device's joins (the default) and with the host's"""
+    import gc
+    import gzip
+    import threading
+    from filesio import dump_dataset, write_bai, write_bgzf_text, write_tbi
+    ds = make_small(SmallConfig(seed=911, n_dnms=30, cluster_prob=0.5))
+    paths = dump_dataset(ds, str(tmp_path))
+    for b in paths["bams"].values():
+        write_bai(b)
+    text = gzip.open(paths["sites"], "rt").read()
+    write_bgzf_text(paths["sites"], text)
+    write_tbi(paths["sites"])
+    alone, err_a, n = _run(paths, ds, {"UZ_HOST_CHUNKS": "1", "UZ_HOST_CHUNK_DNMS": "7"})
+    host_joins, err_h, _ = _run(paths, ds, {"UZ_HOST_CHUNKS": "1", "UZ_HOST_CHUNK_DNMS": "7", "UZ_JOINS": "host"})
+    assert host_joins == alone and err_h == err_a and len(alone) >= 4
+    from unfazed_amd.snv_phaser import phase_snvs
+    kid = ds.dnms[0]["kid"]
+    out, errs = [None, None], []
+
+    def call(k):
+        try:
+            dnms = [dict(chrom=d["chrom"], start=d["start"], end=d["end"], kid=d["kid"], vartype="POINT", bam=paths["bams"][d["kid"]], cram_ref=None)
+                    for d in ds.dnms if d["kid"] == kid]
+            out[k] = norm_records(phase_snvs(dnms, [kid], ds.pedigrees, paths["sites"], 2, "38", False, 10 ** 9, True, [0.0, 0.2], [0.8, 1.0], [0.2, 0.8], 20, 10,
+                                             5000, 1000000, 3, 1, 151, 5))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    os.environ["UZ_HOST_CHUNKS"], os.environ["UZ_HOST_CHUNK_DNMS"] = "1", "7"
+    try:
+        assert gc.isenabled()
+        ts = [threading.Thread(target=call, args=(k,)) for k in (0, 1)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        os.environ.pop("UZ_HOST_CHUNKS", None)
+        os.environ.pop("UZ_HOST_CHUNK_DNMS", None)
+    assert not errs, errs
+    assert out[0] == alone and out[1] == alone
+    assert gc.isenabled()

@@ -163,3 +163,38 @@ def test_a_chunks_result_lists_as_strings_in_one_pass_equal_the_lists_built_entr
     assert not gc.isenabled()  # (it was off before the call: it stays off)
     if was:
         gc.enable()
+
+
+def test_the_gc_pause_is_counted_across_threads():
+    """session.no_gc_pauses: the collector pauses while any phasing call is in flight and comes back with the last one out, whatever the threads'
+    interleaving; a caller who had it off keeps it off"""
+    import gc
+    import threading
+    from unfazed_amd import session
+    assert gc.isenabled()
+    inside, go, seen = threading.Barrier(3), threading.Event(), []
+
+    def call(hold):
+        with session.no_gc_pauses():
+            seen.append(gc.isenabled())
+            inside.wait()
+            if hold:
+                go.wait()
+        seen.append(("out", gc.isenabled()))
+
+    ts = [threading.Thread(target=call, args=(h,)) for h in (False, True)]
+    for t in ts:
+        t.start()
+    inside.wait()          # both are inside
+    ts[0].join()           # the first one leaves: the other is still phasing
+    assert not gc.isenabled()
+    go.set()
+    ts[1].join()
+    assert gc.isenabled() and seen[:2] == [False, False]
+    gc.disable()
+    try:
+        with session.no_gc_pauses():
+            assert not gc.isenabled()
+        assert not gc.isenabled()  # the caller's own setting is what is left behind
+    finally:
+        gc.enable()

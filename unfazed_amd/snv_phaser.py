@@ -12,7 +12,7 @@ def phase_snvs(
     ab_homref, ab_homalt, ab_het, min_gt_qual, min_depth, search_dist, insert_size_max_sample,
     stdevs, min_map_qual, readlen, split_error_margin, evidence_min_ratio=10,
 ):
-    with session.no_gc_pauses():
+    with session.DEVICE_LOCK, session.no_gc_pauses():
         for bam, ref in {(dn.get("bam", ""), dn.get("cram_ref")) for dn in dnms}:  # a CRAM is decoded against the FASTA its DNMs carry (unfazed.py:270, read_collector.py:372-373)
             session.set_cram_reference(bam, ref)
         host = session.host_for(sites, insert_size_max_sample, dnms=dnms, search_dist=search_dist)
