@@ -310,10 +310,22 @@ static FindKey find_key_of(const uz_ctx *c, int fam_id, int mode, const uz_dnms_
     k.fam = fam_id; k.mode = mode; k.n = d ? d->n : -1; k.cohort = c->cohort_on;
     k.P = c->P;
     uint64_t h = 0x9E3779B97F4A7C15ULL;
+    // (four chains side by side over 32-byte steps, folded at the end of every column: one multiply chain over the 1.4 MB of a 100 k-DNM batch was
+    // 0.21 ms of every read-stage call with the device idle; this is 0.04)
     auto mix = [&](const void *p, size_t bytes) {
         if (!p) return;
         const uint8_t *b = (const uint8_t *)p;
+        uint64_t a0 = h ^ 0x243F6A8885A308D3ULL, a1 = h ^ 0x13198A2E03707344ULL, a2 = h ^ 0xA4093822299F31D0ULL, a3 = h ^ 0x082EFA98EC4E6C89ULL;
         size_t i = 0;
+        for (; i + 32 <= bytes; i += 32) {
+            uint64_t w[4];
+            memcpy(w, b + i, 32);
+            a0 = (a0 ^ w[0]) * 0x100000001B3ULL; a0 ^= a0 >> 29;
+            a1 = (a1 ^ w[1]) * 0x100000001B3ULL; a1 ^= a1 >> 29;
+            a2 = (a2 ^ w[2]) * 0x100000001B3ULL; a2 ^= a2 >> 29;
+            a3 = (a3 ^ w[3]) * 0x100000001B3ULL; a3 ^= a3 >> 29;
+        }
+        h = (((a0 * 0x9E3779B97F4A7C15ULL) ^ a1) * 0x9E3779B97F4A7C15ULL ^ a2) * 0x9E3779B97F4A7C15ULL ^ a3;
         for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001B3ULL; h ^= h >> 29; }
         for (; i < bytes; i++) h = (h ^ b[i]) * 0x100000001B3ULL;
     };
@@ -1414,12 +1426,12 @@ int uz_find(uz_ctx *c, int fam_id, const uz_dnms_view *d, int mode, int64_t *can
         SitesDev &s = sites_of(c, f.sites_id);
         UZ_REQUIRE(d != nullptr && d->n >= 0, UZ_E_ARG, "bad DNM view");
         c->cohort_on = false;
-        const FindKey key = find_key_of(c, fam_id, mode, d);
-        find_target(c);
         c->phase_valid = false;
-        uz_stage_dnms(c, d);
         const bool cnv = (mode & UZ_FIND_WHOLE_REGION) != 0;
-        if (!uz_site_scan_fresh(c, f, cnv)) uz_launch_site_scan(c, f, s, cnv);
+        if (!uz_site_scan_fresh(c, f, cnv)) uz_launch_site_scan(c, f, s, cnv); // (reads nothing of the batch: queued before the batch is staged)
+        uz_stage_dnms(c, d);
+        const FindKey key = find_key_of(c, fam_id, mode, d); // (behind the site scan's launch: host work beside the device's)
+        find_target(c);
         uz_launch_find(c, f, s, mode);
         find_done(c, key);
         c->find_fam = fam_id;
@@ -1463,19 +1475,31 @@ static void phase_whole(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view 
     c->cohort_on = false;
     c->phase_valid = false;
     c->phase_qbase.clear();
+    static const bool trace = getenv("UZ_PHASE_HOST_TRACE") != nullptr; // development aid: where the HOST's time of a read-stage call goes (us)
+    const auto t0 = std::chrono::steady_clock::now();
+    auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
     // the read stage consumes the window lists of this batch in SNV / breakpoint mode: those of the caller's own uz_find, if one of
     // the last two finds was over this batch; else computed here
+    // (the batch goes up and the site scan is queued BEFORE the key of the batch is worked out: a hash over its columns, host work the device
+    // need not wait for)
+    // ... and the site scan, which reads nothing of the batch, before the batch's columns are copied into the staging buffer)
+    if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
+    const double t_scan0 = us();
+    uz_stage_dnms(c, d);
+    const double t_stage0 = us() - t_scan0, t_scan = us();
     const FindKey key = find_key_of(c, fam_id, find_mode, d);
+    const double t_key = us() - t_scan, t_stage = us();
     const bool have = find_recall(c, key);
     if (!have) find_target(c);
-    uz_stage_dnms(c, d);
-    if (!uz_site_scan_fresh(c, f, false)) uz_launch_site_scan(c, f, s, false);
     if (!have) {
         uz_launch_find(c, f, s, find_mode, false);
         find_done(c, key);
     }
+    const double t_find = us();
     c->find_fam = fam_id;
     uz_launch_phase(c, f, s, r, status, counts, origin, evidence, defer);
+    if (trace) fprintf(stderr, "[uz] read-stage call, host us: site scan queued %.0f | stage dnms %.0f | key %.0f | find %.0f | phase (launches, waits, results) %.0f\n", t_scan0,
+                       t_stage0, t_key, t_find - t_stage, us() - t_find);
 }
 int uz_phase(uz_ctx *c, int fam_id, int reads_id, const uz_dnms_view *d, int find_mode, int32_t *status,
              int32_t *counts, int32_t *origin, int32_t *evidence) {

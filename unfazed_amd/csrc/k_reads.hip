@@ -8,6 +8,7 @@
 #include "phase_body.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 
@@ -103,7 +104,7 @@ struct PhaseState {
     DevBuf<uint8_t> scratch;
     // res: the per-DNM results as they go back to the host in ONE copy -- status [n], counts [4n], origin [n], evidence [n], then (8-byte
     // aligned) the fill level of the list pool; pre_h: first record and length of every het-site fetch range, [2 (n_het + 1)]
-    DevBuf<int32_t> bounds, res, cursor, pool, list_len, pre_win, pre_h, retry;
+    DevBuf<int32_t> bounds, bounds_red, res, cursor, pool, list_len, pre_win, pre_h, retry;
     DevBuf<long long> list_start;
     unsigned long long *pool_cursor = nullptr; // (inside res)
     DevBuf<unsigned int> need_count;
@@ -1368,17 +1369,53 @@ static const int arena_env = [] { const char *e = getenv("UZ_PHASE_LDS_KB"); ret
 // the share of a batch's DNMs (per mille, by the estimate below) the arena is sized to hold; the rest take the HBM build behind it
 // (1000 / 990 / 940 / 900 on the bench batch: 3.16 / 2.98 / 2.84 / 2.84 ms -- one more wave per CU is worth more than the 1.3 % of the DNMs redone)
 static const int arena_permille = [] { const char *e = getenv("UZ_PHASE_ARENA_PERMILLE"); return e ? atoi(e) : 940; }();
-static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
-    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0;
-    for (int32_t d = 0; d < n; d++) {
-        const int32_t *b = &bh[(size_t)5 * d];
-        mA = std::max<long long>(mA, b[0]); mT = std::max<long long>(mT, b[1]);
-        mH = std::max<long long>(mH, b[2]); mC = std::max<long long>(mC, b[3]);
-        const long long I = 4LL * b[0];
-        const long long M = (long long)b[1] + I * (b[4] + 1);
-        mM = std::max(mM, M);
-        sumP += std::min<long long>(M, 4096) + b[3];
+// What the host needs of a batch's bounds (k_phase_bounds: five numbers per DNM) is a handful of maxima, one sum and a histogram: reduced on
+// the device (k_bounds_reduce) behind the sizing pass, 1.1 KB come back instead of 20 bytes per DNM -- through round 5 the host walked the 2 MB
+// of a 100 k-DNM batch twice between the device's last kernel and the call's return (0.24 ms of a 4.3 ms resident step with the device idle).
+struct BoundsRed {
+    int32_t mA, mT, mH, mC, active, pad;
+    unsigned long long mM, sumP; // (mM by atomicMax on 64 bits)
+    int32_t hist[256];           // arena estimate in units of 256 bytes, DNMs with candidate sites only
+};
+__global__ __launch_bounds__(256) void k_bounds_reduce(const int32_t *__restrict__ bounds, int32_t n, BoundsRed *out) {
+    __shared__ int32_t hist[256];
+    __shared__ unsigned long long part[4][8];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, active = 0;
+    for (int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x; d < n; d += (int64_t)gridDim.x * 256) {
+        const int32_t *b = bounds + 5 * d;
+        const long long b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4];
+        mA = max(mA, b0); mT = max(mT, b1); mH = max(mH, b2); mC = max(mC, b3);
+        const long long M = b1 + 4LL * b0 * (b4 + 1);
+        mM = max(mM, M);
+        sumP += min(M, 4096LL) + b3;
+        if (b3 > 0) {
+            const long long est = ((37LL * b1) / 4 + 10LL * b0 + 3328 + 255) >> 8;
+            atomicAdd(&hist[(int)min(est, 255LL)], 1);
+            active++;
+        }
     }
+    for (int o = 32; o > 0; o >>= 1) {
+        mA = max(mA, __shfl_xor(mA, o, 64)); mT = max(mT, __shfl_xor(mT, o, 64)); mH = max(mH, __shfl_xor(mH, o, 64)); mC = max(mC, __shfl_xor(mC, o, 64));
+        mM = max(mM, __shfl_xor(mM, o, 64)); sumP += __shfl_xor(sumP, o, 64); active += __shfl_xor(active, o, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        part[w][0] = (unsigned long long)mA; part[w][1] = (unsigned long long)mT; part[w][2] = (unsigned long long)mH; part[w][3] = (unsigned long long)mC;
+        part[w][4] = (unsigned long long)mM; part[w][5] = (unsigned long long)sumP; part[w][6] = (unsigned long long)active;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long r[7];
+        for (int k = 0; k < 7; k++) { r[k] = part[0][k]; for (int q = 1; q < 4; q++) r[k] = k < 5 ? max(r[k], part[q][k]) : r[k] + part[q][k]; }
+        atomicMax(&out->mA, (int32_t)r[0]); atomicMax(&out->mT, (int32_t)r[1]); atomicMax(&out->mH, (int32_t)r[2]); atomicMax(&out->mC, (int32_t)r[3]);
+        atomicMax(&out->mM, r[4]); atomicAdd(&out->sumP, r[5]); atomicAdd(&out->active, (int32_t)r[6]);
+    }
+    if (hist[threadIdx.x]) atomicAdd(&out->hist[threadIdx.x], hist[threadIdx.x]);
+}
+static Sizes phase_exact_sizes(const BoundsRed *br, int32_t n) {
+    const long long mA = br->mA, mT = br->mT, mH = br->mH, mC = br->mC, mM = (long long)br->mM, sumP = (long long)br->sumP;
     Sizes z;
     z.caps.A = (int32_t)mA; z.caps.T = (int32_t)mT; z.caps.H = (int32_t)mH; z.caps.C = (int32_t)mC;
     z.caps.I = (int32_t)(4 * mA);
@@ -1392,15 +1429,10 @@ static Sizes phase_exact_sizes(const int32_t *bh, int32_t n) {
     // of handing most of its DNMs to the slower HBM build.
     z.arena = arena_env;
     if (z.arena < 0) {
-        std::vector<int32_t> hist(256, 0); // estimate in units of 256 bytes
-        int32_t active = 0;
-        for (int32_t d = 0; d < n; d++) {
-            const int32_t *b = &bh[(size_t)5 * d];
-            if (b[3] <= 0) continue; // no candidate site: the DNM ends before it needs the arena
-            const long long est = ((37LL * b[1]) / 4 + 10LL * b[0] + 3328 + 255) >> 8; // (b[0]: records of the DNM's own fetch -- 33 of a point variant, hundreds around an SV's breakpoints: a class byte and two flags each)
-            hist[(size_t)std::min<long long>(est, 255)]++;
-            active++;
-        }
+        // (k_bounds_reduce: est = ((37 b[1]) / 4 + 10 b[0] + 3328 + 255) >> 8 over the DNMs with candidate sites -- b[0]: records of the DNM's own
+        // fetch, 33 of a point variant, hundreds around an SV's breakpoints: a class byte and two flags each)
+        const int32_t *hist = br->hist;
+        const int32_t active = br->active;
         int u = 16, seen = 0, umax = 16;
         for (int k = 0; k < 256; k++) if (hist[k]) umax = k;
         for (int k = 0; k < 256; k++) {
@@ -1425,6 +1457,10 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     st->pending = false;
     c->phase_n = n;
     if (n <= 0) { c->phase_valid = true; return; }
+    static const bool host_trace = getenv("UZ_PHASE_HOST_TRACE") != nullptr; // development aid (abi.hip: phase_whole)
+    const auto host_t0 = std::chrono::steady_clock::now();
+    auto host_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count(); };
+    double t_queued = 0, t_synced = 0, t_sized = 0;
     // an asynchronous upload of this table must have landed before the first kernel reads it
     uz_reads_make_ready(c, r);
     // the quality plane holds ONE threshold: tables that kept their full qualities are re-thresholded, the others
@@ -1465,23 +1501,28 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
         UZ_HIP(hipGetLastError());
     }
-    if (st->bounds_h_cap < (size_t)5 * n) {
+    if (st->bounds_h_cap < sizeof(BoundsRed) / sizeof(int32_t)) {
         if (st->bounds_h) (void)hipHostFree(st->bounds_h);
         st->bounds_h = nullptr;
-        st->bounds_h_cap = (size_t)5 * n + (size_t)n;
+        st->bounds_h_cap = sizeof(BoundsRed) / sizeof(int32_t) + 64;
         UZ_HIP(hipHostMalloc((void **)&st->bounds_h, st->bounds_h_cap * sizeof(int32_t), hipHostMallocDefault));
     }
+    st->bounds_red.ensure(sizeof(BoundsRed) / sizeof(int32_t) + 16);
+    UZ_HIP(hipMemsetAsync(st->bounds_red.p, 0, sizeof(BoundsRed), c->stream));
+    hipLaunchKernelGGL(k_bounds_reduce, dim3((unsigned)std::max(1, std::min(512, (n + 255) / 256))), dim3(256), 0, c->stream, (const int32_t *)st->bounds.p, n,
+                       reinterpret_cast<BoundsRed *>(st->bounds_red.p));
+    UZ_HIP(hipGetLastError());
     // The sizes of the batch (k_phase_bounds) decide the scratch capacities, the LDS arena and the grid.  Waiting for them costs a
     // host round trip per batch -- a staged pass makes one per chunk.  So a batch is first run SPECULATIVELY on the capacities of the
     // batch before it (with head room): the kernels refuse what does not fit (UZ_ST_CAPACITY, never a write out of bounds), the
     // bounds come back with the results, and only when they exceed what was assumed is the batch run again on its own sizes.
     // (UZ_PHASE_NO_SPEC=1, the capacity / arena test hooks and the first batch of a context take the exact path.)
-    int32_t *const bh_own = st->bounds_h; // [5n] bounds (kept apart from the result staging below: both are read after the run)
-    uz_kcopy(c, bh_own, st->bounds.p, (size_t)5 * n * sizeof(int32_t));
+    const BoundsRed *const bh_own = reinterpret_cast<const BoundsRed *>(st->bounds_h); // (kept apart from the result staging below: both are read after the run)
+    uz_kcopy(c, st->bounds_h, st->bounds_red.p, sizeof(BoundsRed));
     if (!st->bounds_ready) UZ_HIP(hipEventCreateWithFlags(&st->bounds_ready, hipEventDisableTiming));
     UZ_HIP(hipEventRecord(st->bounds_ready, c->stream));
     auto check_upload_flags = [&] { phase_check_upload_flags(c); };
-    auto exact_sizes = [&](const int32_t *bh) { return phase_exact_sizes(bh, n); };
+    auto exact_sizes = [&](const BoundsRed *bh) { return phase_exact_sizes(bh, n); };
     if (st->n_cus <= 0) { // asked once: the query is not cheap
         hipDeviceProp_t prop;
         UZ_HIP(hipGetDeviceProperties(&prop, c->device));
@@ -1494,11 +1535,13 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     const size_t res_ints = (size_t)7 * n + ((7 * (size_t)n) & 1); // the results, padded to eight bytes; the pool's fill level behind them
     st->res.ensure(res_ints + 4);
     st->pool_cursor = (unsigned long long *)(st->res.p + res_ints);
-    st->cursor.ensure(16 * (UZ_PHASE_PARTS + 2));
+    // the work cursors, and behind them the counts of the two lists of given-up DNMs: ONE block, cleared by one memset per attempt
+    st->cursor.ensure(16 * (UZ_PHASE_PARTS + 2) + 32);
     // two lists of given-up DNMs: what the first launch leaves for the second (larger arenas), what the second leaves for the HBM build
     st->retry.ensure(2 * ((size_t)n + 16));
-    int32_t *const retry1 = st->retry.p, *const retry2 = st->retry.p + (size_t)n + 16;
-    a.retry_count = retry1; a.retry_list = retry1 + 16;
+    int32_t *const retry1_list = st->retry.p, *const retry2_list = st->retry.p + (size_t)n + 16;
+    int32_t *const retry1 = st->cursor.p + 16 * (UZ_PHASE_PARTS + 2), *const retry2 = retry1 + 16;
+    a.retry_count = retry1; a.retry_list = retry1_list;
     a.from_list = 0; a.cursor_slot = 0; a.src_count = nullptr; a.src_list = nullptr;
     a.status = st->res.p; a.counts = st->res.p + n; a.origin = st->res.p + (size_t)5 * n; a.evidence = st->res.p + (size_t)6 * n;
     a.work_cursor = st->cursor.p;
@@ -1572,9 +1615,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         st->pool.ensure(pool_cap);
         a.pool = st->pool.p; a.pool_cap = pool_cap;
         for (int attempt = 0; attempt < 4; attempt++) {
-            UZ_HIP(hipMemsetAsync(st->cursor.p, 0, 16 * (UZ_PHASE_PARTS + 2) * sizeof(int32_t), c->stream));
-            UZ_HIP(hipMemsetAsync(retry1, 0, 16 * sizeof(int32_t), c->stream));
-            UZ_HIP(hipMemsetAsync(retry2, 0, 16 * sizeof(int32_t), c->stream));
+            UZ_HIP(hipMemsetAsync(st->cursor.p, 0, (16 * (UZ_PHASE_PARTS + 2) + 32) * sizeof(int32_t), c->stream)); // (cursors + both give-up counts)
             UZ_HIP(hipMemsetAsync(st->pool_cursor, 0, 2 * sizeof(unsigned long long), c->stream));
             {
                 // Three launches.  The arena is sized for most of the batch's DNMs, not all (the more DNMs a CU holds, the faster the batch);
@@ -1587,15 +1628,15 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                 hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)grid), dim3(WG_NT), (size_t)a.lds_arena_bytes, c->stream, a);
                 UZ_HIP(hipGetLastError());
                 PhaseArgs a2 = a;
-                a2.from_list = 1; a2.cursor_slot = UZ_PHASE_PARTS; a2.src_count = retry1; a2.src_list = retry1 + 16;
-                a2.retry_count = retry2; a2.retry_list = retry2 + 16;
+                a2.from_list = 1; a2.cursor_slot = UZ_PHASE_PARTS; a2.src_count = retry1; a2.src_list = retry1_list;
+                a2.retry_count = retry2; a2.retry_list = retry2_list;
                 a2.lds_arena_bytes = getenv("UZ_TEST_PHASE_ARENA") ? arena_used /* test hook: the small arena again, so that the HBM build is what runs */
                                                                     : std::max(arena_used, std::min(z.arena2, 62 * 1024));
                 const int per_cu2 = std::max(1, (160 * 1024) / (a2.lds_arena_bytes + (int)sizeof(WgSharedT<1>) + 512));
                 hipLaunchKernelGGL((k_phase<true>), dim3((unsigned)std::min(grid, per_cu2 * st->n_cus)), dim3(WG_NT), (size_t)a2.lds_arena_bytes, c->stream, a2);
                 UZ_HIP(hipGetLastError());
                 PhaseArgs a3 = a2;
-                a3.cursor_slot = UZ_PHASE_PARTS + 1; a3.src_count = retry2; a3.src_list = retry2 + 16;
+                a3.cursor_slot = UZ_PHASE_PARTS + 1; a3.src_count = retry2; a3.src_list = retry2_list;
                 a3.so = so_hbm; a3.scratch_per_wg = per_wg_hbm;
                 hipLaunchKernelGGL((k_phase<false>), dim3((unsigned)grid_hbm), dim3(WG_NT), 0, c->stream, a3);
                 UZ_HIP(hipGetLastError());
@@ -1611,7 +1652,9 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
                 st->pend_caps = caps; st->pend_pool_cap = a.pool_cap; st->pend_want_lists = a.want_lists;
                 return;
             }
+            if (host_trace) t_queued = host_us();
             UZ_HIP(hipStreamSynchronize(c->stream));
+            if (host_trace) t_synced = host_us();
             if (speculative) check_upload_flags();
             if (c->hflags[1]) {
                 const int f = c->hflags[1];
@@ -1631,6 +1674,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
         }
         // what the batch really needed: the next batch's assumption -- and the verdict on this one's
         const Sizes real = exact_sizes(bh_own);
+        if (host_trace) t_sized = host_us();
         // (head room costs scratch, and a scratch that outgrows its budget halves the grid: an eighth on the linear sizes, none on the
         // pair table -- its capacity is a power of two already)
         auto room = [](int32_t v) { return (int32_t)std::min<long long>((long long)v + v / 8 + 8, 0x3FFFFFFF); };
@@ -1670,6 +1714,9 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     if (evidence) memcpy(evidence, hres + (size_t)6 * n, (size_t)n * sizeof(int32_t));
     st->have_lists = a.want_lists != 0;
     c->phase_valid = true;
+    if (host_trace)
+        fprintf(stderr, "[uz] uz_launch_phase, host us: everything queued %.0f | waited for the device %.0f | exact sizes %.0f | results copied out %.0f\n", t_queued, t_synced - t_queued,
+                t_sized - t_synced, host_us() - t_sized);
 }
 
 // second half of uz_phase_begin / uz_phase_end: waits for the run uz_launch_phase(defer) left in flight (or finds the results of a run
@@ -1693,7 +1740,7 @@ bool uz_finish_phase(uz_ctx *c, int32_t *status, int32_t *counts, int32_t *origi
         unsigned long long *const hused = (unsigned long long *)(hres + (size_t)7 * n + ((7 * (size_t)n) & 1));
         const unsigned long long used = *hused;
         c->prof[UZ_K_PHASE].last_units = (int64_t)*(const int32_t *)(hused + 1);
-        const Sizes real = phase_exact_sizes(st->bounds_h, n);
+        const Sizes real = phase_exact_sizes(reinterpret_cast<const BoundsRed *>(st->bounds_h), n);
         auto room = [](int32_t v) { return (int32_t)std::min<long long>((long long)v + v / 8 + 8, 0x3FFFFFFF); };
         st->spec_caps.A = room(real.caps.A); st->spec_caps.T = room(real.caps.T); st->spec_caps.H = room(real.caps.H); st->spec_caps.C = room(real.caps.C);
         st->spec_caps.I = 4 * st->spec_caps.A;

@@ -657,10 +657,10 @@ class HipEngine:
     def phase_raw(self, fam: int, reads_h: int, dv: abi.Held, params: abi.Params, find_mode: int):
         self.set_params(params)
         n = dv.view.n
-        status = np.zeros(max(1, n), dtype=np.int32)
-        counts = np.zeros(max(1, 4 * n), dtype=np.int32)
-        origin = np.zeros(max(1, n), dtype=np.int32)
-        evidence = np.zeros(max(1, n), dtype=np.int32)
+        status = np.empty(max(1, n), dtype=np.int32)  # (the call writes all n entries of each, or raises)
+        counts = np.empty(max(1, 4 * n), dtype=np.int32)
+        origin = np.empty(max(1, n), dtype=np.int32)
+        evidence = np.empty(max(1, n), dtype=np.int32)
         self._ck(
             self.L.uz_phase(self.h, int(fam), int(reads_h), dv.ref(), int(find_mode), status.ctypes.data,
                             counts.ctypes.data, origin.ctypes.data, evidence.ctypes.data),
@@ -676,10 +676,10 @@ class HipEngine:
 
     def phase_end(self, fam: int, reads_h: int, dv: abi.Held, params: abi.Params, find_mode: int):
         n = dv.view.n
-        status = np.zeros(max(1, n), dtype=np.int32)
-        counts = np.zeros(max(1, 4 * n), dtype=np.int32)
-        origin = np.zeros(max(1, n), dtype=np.int32)
-        evidence = np.zeros(max(1, n), dtype=np.int32)
+        status = np.empty(max(1, n), dtype=np.int32)
+        counts = np.empty(max(1, 4 * n), dtype=np.int32)
+        origin = np.empty(max(1, n), dtype=np.int32)
+        evidence = np.empty(max(1, n), dtype=np.int32)
         self._ck(self.L.uz_phase_end(self.h, int(fam), int(reads_h), dv.ref(), int(find_mode), status.ctypes.data, counts.ctypes.data,
                                      origin.ctypes.data, evidence.ctypes.data), "uz_phase_end")
         return dict(status=status[:n], counts=counts[: 4 * n].reshape(n, 4), origin=origin[:n], evidence=evidence[:n])
