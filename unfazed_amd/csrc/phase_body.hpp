@@ -429,6 +429,11 @@ UZ_DEV long long uz_lower_bound_c(const RD &R, long long lo, long long hi, long 
 // Measured (round 5): sizing pass 0.40 -> 0.38 ms per 100 k DNMs, config 5 0.136 -> 0.104 -- less than the chains' lengths promised, because what
 // bounds the pass is the NUMBER of probes: ~1 450 per DNM, every one a 16-byte header in a line of its own for most of a search, and a CU's L1
 // takes one line per cycle (145 M probes over 256 CUs: ~0.2 ms before anything else).  Fewer probes, not shorter chains, is what is left.
+// (Round 6 tried the obvious way to fewer probes and measured it SLOWER: interpolation search -- the first probes along the line between the
+// bracket's ends, every other one from the fourth on a bisection -- is three or four probes per search on a pile-up's evenly spaced starts, but
+// the chains of a wavefront advance in lockstep, 640 of them, and the wave takes as many steps as its unluckiest chain: close to bisection's
+// eleven again; and the probe's arithmetic (two conversions, a reciprocal, clamps, the bracket's end values kept per chain) took the kernel from
+// 120 to 142 registers -- 190 in a first 64-bit version -- and from 1 600 to 5 000 instructions: 0.37 -> 0.73 ms.  Bisection stays.)
 template <int N>
 UZ_DEV void uz_lower_bounds_start(const RecA *ra, long long lo, long long hi, const long long (&v)[N], const bool (&on)[N], int32_t (&res)[N]) {
     int32_t l[N], h[N];
