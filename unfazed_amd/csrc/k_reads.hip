@@ -752,10 +752,51 @@ __global__ __launch_bounds__(256, 3) void k_pack_link(int64_t n, RecColumns c_in
     if (t < UZ_PK_SUMS) { s_run[t] = sums[UZ_PK_SUMS * (size_t)blockIdx.x + t]; s_nxt[t] = sums[UZ_PK_SUMS * ((size_t)blockIdx.x + 1) + t]; }
     if (c.n_esc16 > 0 && t < 2) esc_span[t] = esc_lower_bound(c.esc16_key, c.n_esc16, s0 + (int64_t)t * UZ_PL_SPAN);
     // the byte columns of the span and the dictionary (independent of the sums: requested beside them)
-    for (int k = t; k < cnt; k += 256) { s_tup[k] = c.tup[s0 + k]; s_sd[k] = c.start_d8[s0 + k]; s_pd[k] = c.pair_d8[s0 + k]; }
+    for (int k = t; k < cnt; k += 256) { s_sd[k] = c.start_d8[s0 + k]; s_pd[k] = c.pair_d8[s0 + k]; }
     for (int k = t; k < UZ_PL_SPAN; k += 256) s_back[k] = 0;
     for (int k = t; k < UZ_PL_SPAN / 4; k += 256) s_named[k] = 0u;
-    __syncthreads();
+    if (c.tup8 == nullptr) {
+        for (int k = t; k < cnt; k += 256) s_tup[k] = c.tup[s0 + k];
+        __syncthreads();
+    } else {
+        // The dictionary index arrives in ONE byte (uz_types.h tup8: its place among the 255 most frequent combinations, or 255 and the 16-bit
+        // index in an escape list whose offsets are given per span of 1 024 records -- this workgroup's span).  Rounds 5's k_tup_expand rebuilt the
+        // 16-bit column in HBM in front of this kernel (1 byte read + 2 written per record, and this kernel read the 2 again: 0.35 ms of a staged
+        // step's chip time, a launch per table); the span's indices are now rebuilt where they are used, in LDS: four records per lane, an
+        // escaped record's place = the span's offset + the escapes in front of it (a block scan of the lanes' counts).  The same checks: a span
+        // whose escapes are not the number its two offsets name, an escape beyond the list, an index beyond the dictionary -> hflags[0].
+        __shared__ uint16_t s_hot[256];
+        __shared__ uint32_t s_tsum[4];
+        s_hot[t] = c.tup_hot[t];
+        const int64_t base = s0 + 4 * t;
+        uint32_t w = 0;
+        if (base + 4 <= n) w = *reinterpret_cast<const uint32_t *>(c.tup8 + base);
+        else for (int k = 0; k < 4; k++) if (base + k < n) w |= (uint32_t)c.tup8[base + k] << (8 * k);
+        uint32_t ne = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) ne += (base + k < n && ((w >> (8 * k)) & 0xFFu) == 255u) ? 1u : 0u;
+        const uint32_t inc = wv_incl_scan(ne);
+        if (lane == 63) s_tsum[wv] = inc;
+        __syncthreads();
+        uint32_t before = inc - ne;
+        for (int k = 0; k < wv; k++) before += s_tsum[k];
+        const uint32_t x0 = c.tup_esc_off[blockIdx.x], x1 = c.tup_esc_off[blockIdx.x + 1];
+        if (t == 255 && before + ne != x1 - x0) hflags[0] = 1;
+        uint32_t at = x0 + before;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b = (w >> (8 * k)) & 0xFFu;
+            uint32_t val = s_hot[b];
+            if (b == 255u && base + k < n) {
+                if ((int64_t)at < c.n_tup_esc && at < x1) val = c.tup_esc[at];
+                else { val = 0; hflags[0] = 1; }
+                at++;
+            }
+            if (val >= (uint32_t)n_tup) { val = 0; if (base + k < n) hflags[0] = 1; }
+            s_tup[4 * t + k] = (uint16_t)val;
+        }
+        __syncthreads();
+    }
     PK_TICK(0); // columns + sums rows
     // the dictionary entry of a round's record is requested a round ahead (the first one here, beside the lists)
     auto dict_of = [&](int k) -> uint4 {
@@ -1207,11 +1248,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     static_assert(sizeof(RecA) == 16 && sizeof(RecB) == 16, "record headers are two 16-byte words");
     if (r.n <= 0) return;
     RecColumns col = col_in;
-    if (col.tup8) { // the one-byte dictionary index: the 16-bit column first (everything below reads col.tup)
-        hipLaunchKernelGGL(k_tup_expand, dim3((unsigned)((r.n + UZ_TUP8_SPAN - 1) / UZ_TUP8_SPAN)), dim3(256), 0, st, (int64_t)r.n, col.tup8, col.tup_hot, col.tup_esc,
-                           col.tup_esc_off, col.n_tup_esc, (int32_t)col.n_tup, col.tup_out, c->hflags);
-        col.tup = col.tup_out;
-    }
+    if (col.tup8) col.tup = col.tup_out; // the one-byte dictionary index: the 16-bit column is rebuilt below, in HBM (k_tup_expand) or in k_pack_link's LDS
     col.pk_shift = uz_pk_shift(r.n);
     const unsigned nb = (unsigned)((r.n + (1 << col.pk_shift) - 1) >> col.pk_shift);
     unsigned long long *sums = (unsigned long long *)off_scratch;
@@ -1227,6 +1264,17 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     // every span against them), or counted here
     static const bool no_host_sums = getenv("UZ_BUILD_OWN_SUMS") != nullptr; // (development aid: ignore the packer's)
     const bool host_sums = col.pk_sums != nullptr && !no_host_sums;
+    static const bool no_lds_build = getenv("UZ_BUILD_FROM_MEMORY") != nullptr; // (development aid: k_pack_rec for every table)
+    // (with host sums the scratch of the span sums is free: it holds the packed dictionary)
+    const bool from_lds = link_form && host_sums && col.pk_shift == UZ_PK_SHIFT_SMALL && col.n_tup >= 1 && (size_t)col.n_tup * sizeof(uint4) <= uz_rec_scratch_bytes(r.n) &&
+                          !col.qpos_wide && !col.bl_wide && (col.tup_n_bl == nullptr || col.bl_pos != nullptr) && !no_lds_build;
+    static const bool expand_in_hbm = getenv("UZ_TUP8_IN_HBM") != nullptr; // (development aid: round 5's k_tup_expand in front of k_pack_link too)
+    const bool fold_tup8 = col.tup8 != nullptr && from_lds && !expand_in_hbm && (1 << col.pk_shift) == UZ_TUP8_SPAN;
+    if (col.tup8 && !fold_tup8) { // every other build reads the 16-bit column from memory: rebuilt there first
+        hipLaunchKernelGGL(k_tup_expand, dim3((unsigned)((r.n + UZ_TUP8_SPAN - 1) / UZ_TUP8_SPAN)), dim3(256), 0, st, (int64_t)r.n, col.tup8, col.tup_hot, col.tup_esc,
+                           col.tup_esc_off, col.n_tup_esc, (int32_t)col.n_tup, col.tup_out, c->hflags);
+        col.tup8 = nullptr; // (the kernels below read col.tup)
+    }
     if (host_sums) sums = const_cast<unsigned long long *>(col.pk_sums);
     else if (link_form) hipLaunchKernelGGL((k_off_block_sums<true>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
     else hipLaunchKernelGGL((k_off_block_sums<false>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, sums);
@@ -1238,10 +1286,6 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
 #define UZ_PACK_LAUNCH(L, S)                                                                                                                              \
     hipLaunchKernelGGL((k_pack_rec<L, S>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, want, (RecA *)r.rec_a, \
                        (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags, host_sums ? 1 : 0)
-    static const bool no_lds_build = getenv("UZ_BUILD_FROM_MEMORY") != nullptr; // (development aid: k_pack_rec for every table)
-    // (with host sums the scratch of the span sums is free: it holds the packed dictionary)
-    const bool from_lds = link_form && host_sums && col.pk_shift == UZ_PK_SHIFT_SMALL && col.n_tup >= 1 && (size_t)col.n_tup * sizeof(uint4) <= uz_rec_scratch_bytes(r.n) &&
-                          !col.qpos_wide && !col.bl_wide && (col.tup_n_bl == nullptr || col.bl_pos != nullptr) && !no_lds_build;
     static const bool build_log = getenv("UZ_BUILD_LOG") != nullptr; // (development aid)
     if (build_log)
         fprintf(stderr, "[uz_build_records] n %lld link_form %d host_sums %d pk_shift %d n_tup %lld qpos_wide %d bl_wide %d -> from_lds %d\n", (long long)r.n, (int)link_form,
