@@ -72,7 +72,7 @@ def test_all_bases(workload):
     model_vs_stage(workload["bam"], fc, flo, fhi, fex, all_bases=True)
 
 
-@pytest.mark.parametrize("slack", ["0", "40", "300"])
+@pytest.mark.parametrize("slack", ["0", "300"])
 def test_mates_through_the_index(workload, slack, monkeypatch):
     """a small reach slack pushes the mates out of the reach intervals: they come back from uz_stage_lookup as descriptors in the aux store, and the
     closure goes on from them"""
@@ -91,7 +91,7 @@ def test_tasks_the_device_hands_back(workload):
 
 def test_tasks_handed_back_and_mates_through_the_index(workload, monkeypatch):
     monkeypatch.setenv("UZ_STAGE_SLACK", "60")
-    fc, flo, fhi, fex = fetches_of(workload, 2, 4)
+    fc, flo, fhi, fex = fetches_of(workload, 5, 3)  # (the model is plain Python: a small batch)
     ref, got = model_vs_stage(workload["bam"], fc, flo, fhi, fex, flag_every=2)
     assert got["lookups"] > 0 and got["h_flags"].any()
 
@@ -107,7 +107,7 @@ def _small_fetches(ds, full, seed, n_het):
     return np.array(c, np.int32), np.array(lo, np.int32), np.array(hi, np.int32), np.array(ex, np.uint16)
 
 
-@pytest.mark.parametrize("seed,readlen", [(31, 151), (33, 301)])
+@pytest.mark.parametrize("seed,readlen", [(33, 301)])
 def test_odd_records_from_a_python_written_bam(tmp_path, seed, readlen, monkeypatch):
     """synth.small's pile-ups written by the Python BAM writer: duplicates, secondary / supplementary copies with SA tags, mates unmapped or on other
     contigs, overlapping mates -- mate() on a name with more than two records, names that share no pair"""
