@@ -1,10 +1,11 @@
 #!/bin/bash
 # development aid (GPU box): the kernel timeline of ONE staged step of config 5 with the host's HIP calls beside it -- what runs
 # when, where the device idles, and what the host is doing meanwhile
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf $GRAFT_REPO_ROOT/gpurun_out/cnvtl
-rocprofv3 --output-format csv --kernel-trace --hip-runtime-trace -d $GRAFT_REPO_ROOT/gpurun_out/cnvtl -o run -- python3 $GRAFT_REPO_ROOT/bench.py --workload cnv --no-cpu --steps 3 --warmup 2 ${CNV_ARGS} > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
+rm -rf "$ROOT/gpurun_out/cnvtl"
+rocprofv3 --output-format csv --kernel-trace --hip-runtime-trace -d $ROOT/gpurun_out/cnvtl -o run -- python3 $ROOT/bench.py --workload cnv --no-cpu --steps 3 --warmup 2 ${CNV_ARGS} > /dev/null 2>&1
+cd $ROOT
 ls gpurun_out/cnvtl
 python3 - <<'P'
 import pandas as pd, numpy as np

@@ -21,7 +21,8 @@ shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, "%s_bench_k
 shutil.copy(os.path.join(src, "pmc_summary.json"), os.path.join(dst, "%s_pmc_summary.json" % rnd))
 for extra, name in (("staged_kernel_stats.csv", "%s_bench_staged_kernel_stats.csv"), ("bench_staged_under_rocprof.json", "%s_bench_staged_under_rocprof.json"),
                     ("feed_kernel_stats.csv", "%s_bench_feed_kernel_stats.csv"), ("bench_feed_under_rocprof.json", "%s_bench_feed_under_rocprof.json"),
-                    ("feed_pmc.txt", "%s_feed_pmc.txt"), ("inflate_pmc.json", "%s_inflate_pmc.json")):
+                    ("feed_pmc.txt", "%s_feed_pmc.txt"), ("inflate_pmc.json", "%s_inflate_pmc.json"), ("resident_timeline.json", "%s_resident_timeline.json"),
+                    ("bench_line.json", "%s_bench_line.json"), ("bench_line_shard12500.json", "%s_bench_line_shard12500.json")):
     if os.path.exists(os.path.join(src, extra)):
         shutil.copy(os.path.join(src, extra), os.path.join(dst, name % rnd))
 line = json.loads([x for x in open(os.path.join(src, "stats.log")) if x.startswith("{")][-1])

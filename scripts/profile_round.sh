@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$ROOT/bench.py --no-staged --no-cpu --steps 3 --warmup 1 --feed-dnms 0 --no-config5"
 # counters only for the product's kernels (the synthetic generator's launches would be serialised and counted too)
-ONLY='--kernel-include-regex k_phase|k_site_scan|k_window|k_pack_rec|k_pack_link|k_expand_seq2|k_cnv'
+ONLY='--kernel-include-regex k_phase|k_site_scan|k_window|k_pack_rec|k_pack_link|k_expand_seq2|k_cnv|k_bounds_reduce'
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o run -- python3 $ARGS > $OUT/stats.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_FLAT SQ_INSTS_LDS -d $OUT/sq -o run -- python3 $ARGS > $OUT/sq.log 2>&1
 rocprofv3 $ONLY --output-format csv --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU -d $OUT/insts -o run -- python3 $ARGS > $OUT/insts.log 2>&1
@@ -56,7 +56,7 @@ cd $ROOT
 find $OUT/feed -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/feed_kernel_stats.csv
 grep "^{" $OUT/feed.log | tail -1 > $OUT/bench_feed_under_rocprof.json
 cd /tmp
-FONLY='--kernel-include-regex k_bam_walk|k_bam_extract|k_desc_filter|k_tab_insert|k_bgzf_crc32|k_bgzf_inflate'
+FONLY='--kernel-include-regex k_bam_walk|k_bam_extract|k_desc_filter|k_tab_insert|k_bgzf_crc32|k_bgzf_inflate|k_join_|k_final_'
 UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/feedpmc -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feedpmc.log 2>&1
 UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc FETCH_SIZE -d $OUT/feedfetch -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feedfetch.log 2>&1
 UZ_BENCH_NO_PRODUCT=1 rocprofv3 $FONLY --output-format csv --kernel-trace --pmc WRITE_SIZE -d $OUT/feedwrite -o run -- python3 $ROOT/bench.py --no-cpu --no-config5 --no-staged --steps 1 --warmup 0 > $OUT/feedwrite.log 2>&1
@@ -96,3 +96,14 @@ print(json.dumps(res))
 P
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete
 
+
+# one resident step as a timeline (every kernel and copy in order, the gaps between them): resident_timeline.json
+cd $ROOT
+bash scripts/resident_timeline.sh > $OUT/resident_timeline.txt 2>&1
+cp gpurun_out/resident_timeline.json $OUT/resident_timeline.json 2>/dev/null
+# the driver's command, last: the bench line of the round
+cd $ROOT
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.log 2> $OUT/bench_line.err
+grep "^{" $OUT/bench_line.log | tail -1 > $OUT/bench_line.json
+python3 bench.py --no-cpu --no-config5 --feed-dnms 0 --dnms 12500 --steps 20 --warmup 5 2>/dev/null | grep "^{" | tail -1 > $OUT/bench_line_shard12500.json
+du -sh $OUT
