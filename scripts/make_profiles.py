@@ -112,3 +112,26 @@ if "SQ_INSTS_VALU" in cp and "GRBM_GUI_ACTIVE" in cp:
     issue["kernel_source_sha"] = KSHA
     json.dump(issue, open(os.path.join(dst, "phase_issue.json"), "w"), indent=1)
     print(json.dumps(issue, indent=1))
+
+
+# the register question: rocprofv3's VGPR column against the code object's own metadata (scripts/isa_stats.py -> profiles/<round>_isa_stats.json,
+# which needs no GPU: run it before this script) -- and what each caps
+try:
+    isa = json.load(open(os.path.join(dst, "%s_isa_stats.json" % rnd)))
+    isa = isa.get("kernels", isa)
+    kp = next(v for k, v in isa.items() if "k_phase<true>" in k)
+    pi_path = os.path.join(dst, "phase_issue.json")
+    pi = json.load(open(pi_path))
+    total = int(kp.get("vgpr_count", 0)) + int(kp.get("agpr_count", 0))
+    alloc = (total + 7) // 8 * 8
+    pi["vgpr_rocprof_column"] = pi.get("vgpr")
+    pi["vgpr_count_code_object"] = int(kp.get("vgpr_count", 0))
+    pi["agpr_count_code_object"] = int(kp.get("agpr_count", 0))
+    pi["sgpr_spill_count_code_object"] = int(kp.get("sgpr_spill_count", 0))
+    pi["waves_per_simd_the_registers_allow"] = 512 // alloc if alloc else None
+    pi["occupancy_note"] = ("the code object's metadata is what the hardware allocates by (blocks of 8 of a SIMD's 512 registers per lane): %d -> %d -> %d waves per SIMD, "
+                            "the same four the LDS arenas leave room for (16 single-wave workgroups per CU) -- BOTH cap the read stage at four, not the arena alone; "
+                            "a fifth wave needs <= 96 registers AND arenas <= 8 KB.  rocprofv3's VGPR_Count column (%s) is not that number" % (total, alloc, 512 // alloc, pi.get("vgpr")))
+    json.dump(pi, open(pi_path, "w"), indent=1)
+except Exception as e:  # noqa: BLE001
+    print("no ISA statistics beside the profile (%s): phase_issue.json keeps rocprofv3's column only" % e, file=sys.stderr)
