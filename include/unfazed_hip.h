@@ -138,7 +138,7 @@ int uz_bam_walk_release(uz_ctx *ctx, int walk_id);
  *                       *n_need == 0: finished, totals = records, name ids, CIGAR words, row units, base-row units, name bytes
  *   uz_bam_join_fetch   parity / debug: the kept records in output order (any pointer may be NULL); contig_off [n_ref + 1], max_span [n_ref]
  *   uz_reads_from_walk  the record table, unpacked from the bytes in HBM through the kept list in HBM (releases the batch).  want_names: the read
- *                       names stay on the device with the table and uz_reads_names answers name ids (off [n + 1]; buf NULL or too small: *need only)
+ *                       names stay on the device with the table and uz_reads_names answers name ids (off [n + 1], the bytes in the context's page-locked memory)
  *   uz_walk_slot_stats  [0] device allocations the slots have made, [1] outgrown blocks parked, [2] their bytes, [4..7] the slots' inflated-bytes room */
 int uz_bam_walk_flags(uz_ctx *ctx, int walk_id, int32_t *d_flags, int64_t *d_walked);
 int uz_bam_join(uz_ctx *ctx, int walk_id, int32_t n_host, const int32_t *h_flags, int32_t n_ref, int all_bases, const uz_walk_desc *xdesc, int64_t n_x, const uint8_t *xaux,
@@ -146,7 +146,8 @@ int uz_bam_join(uz_ctx *ctx, int walk_id, int32_t n_host, const int32_t *h_flags
 int uz_bam_join_needs(uz_ctx *ctx, int walk_id, uz_need_rec *need);
 int uz_bam_join_fetch(uz_ctx *ctx, int walk_id, uint64_t *voff, uint32_t *qname, int32_t *mate, uint8_t *bases, uz_kept_rec *kept, int64_t *contig_off, int32_t *max_span);
 int uz_reads_from_walk(uz_ctx *ctx, int walk_id, int32_t min_base_qual, int want_names, int *reads_id, int64_t totals[8]);
-int uz_reads_names(uz_ctx *ctx, int reads_id, const uint32_t *ids, int64_t n, int64_t *off, uint8_t *buf, int64_t cap, int64_t *need);
+int uz_reads_names(uz_ctx *ctx, int reads_id, const uint32_t *ids, int64_t n, int64_t *off /* [n + 1] */,
+                   const uint8_t **bytes /* out: the names back to back in the context's page-locked memory, valid until the next call */);
 int uz_walk_slot_stats(uz_ctx *ctx, int64_t out[8]);
 /* every free slot among the first n_slots grown, now, to the largest sizes any batch of this context has asked for (a pipeline that will keep
  * n_slots batches in flight calls it once a first batch is through: no later batch's walk then pays for a slot's first gigabytes) */

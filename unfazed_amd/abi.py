@@ -650,18 +650,15 @@ def dnms_view(
     mult: Optional[Sequence[int]] = None,
 ) -> Held:
     n = len(start)
+    # REF then ALT of every DNM, back to back: the offsets from the lengths in one pass (a store per DNM into a numpy array was 20 ms per 20 k DNMs)
+    lens = np.empty(2 * n, dtype=np.int64)
+    lens[0::2] = np.fromiter(map(len, refs), np.int64, n)
+    lens[1::2] = np.fromiter(map(len, alts), np.int64, n)
     off = np.zeros(2 * n + 1, dtype=np.uint32)
-    blob: List[bytes] = []
-    o = 0
-    for d in range(n):
-        off[2 * d] = o
-        blob.append(refs[d])
-        o += len(refs[d])
-        off[2 * d + 1] = o
-        blob.append(alts[d])
-        o += len(alts[d])
-    off[2 * n] = o
-    alleles = np.frombuffer(b"".join(blob) + b"\0", dtype=np.uint8).copy()
+    np.cumsum(lens, out=lens)
+    assert n == 0 or lens[-1] < (1 << 32)
+    off[1:] = lens
+    alleles = np.frombuffer(b"".join(x for pair in zip(refs, alts) for x in pair) + b"\0", dtype=np.uint8).copy()
     arrs = dict(
         contig=_c(contig, np.int32),
         rcontig=_c(rcontig, np.int32),

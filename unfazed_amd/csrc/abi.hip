@@ -419,6 +419,8 @@ void uz_destroy(uz_ctx *c) {
     if (c->dn_stage_done) (void)hipEventDestroy(c->dn_stage_done);
     if (c->dn_stage) (void)hipHostFree(c->dn_stage);
     if (c->find_pin) (void)hipHostFree(c->find_pin);
+    if (c->nm_pin) (void)hipHostFree(c->nm_pin);
+    c->nm_ids.release(); c->nm_len.release(); c->nm_off.release(); c->nm_out.release();
     c->ab_lut.release(); c->win_range.release();
     c->dn_fam.release(); c->dn_cutoff.release(); c->fam_cls.release();
     c->cnv_counts.release(); c->cnv_pos.release(); c->cnv_origin.release(); c->cnv_evidence.release(); c->cnv_etype.release(); c->cnv_rb.release();
@@ -2107,41 +2109,53 @@ int uz_reads_from_walk(uz_ctx *c, int walk_id, int32_t min_base_qual, int want_n
     });
 }
 
-// the read names of name ids of such a table: off [n + 1] (host), the bytes back to back into buf (cap bytes; NULL / too small: only *need is set)
-int uz_reads_names(uz_ctx *c, int reads_id, const uint32_t *ids, int64_t n, int64_t *off, uint8_t *buf, int64_t cap, int64_t *need) {
+// the read names of name ids of such a table: off [n + 1] (host) and the bytes back to back in page-locked memory of the CONTEXT (valid until the
+// next call).  The context's own buffers, grown as needed, and copy kernels out of them: a first version made and freed four device blocks per call --
+// hipFree waits for the whole device, the next chunk's read stage included: 8 ms per chunk on the calling thread, a tenth of the product's drop-in call.
+int uz_reads_names(uz_ctx *c, int reads_id, const uint32_t *ids, int64_t n, int64_t *off, const uint8_t **bytes) {
     return guarded(c, [&] {
         UZ_REQUIRE(reads_id >= 0 && (size_t)reads_id < c->reads.size() && c->reads[(size_t)reads_id].live, UZ_E_ARG, "bad reads id");
         ReadsDev &r = c->reads[(size_t)reads_id];
         UZ_REQUIRE(r.kept_list && r.name_rec, UZ_E_STATE, "uz_reads_names: a table built by uz_reads_from_walk with names");
-        UZ_REQUIRE(n >= 0 && (n == 0 || (ids && off)) && need, UZ_E_ARG, "bad arguments");
-        *need = 0;
-        if (off) off[0] = 0;
+        UZ_REQUIRE(n >= 0 && off && bytes && (n == 0 || ids), UZ_E_ARG, "bad arguments");
+        off[0] = 0;
+        *bytes = nullptr;
         if (n == 0) return;
         for (int64_t k = 0; k < n; k++) UZ_REQUIRE(ids[k] < r.n_qnames, UZ_E_ARG, "uz_reads_names: a name id out of range");
         hipStream_t st = c->stream;
-        uint32_t *d_ids = nullptr, *d_len = nullptr, *d_off = nullptr;
-        uint8_t *d_out = nullptr;
-        std::vector<uint32_t> len((size_t)n);
-        UZ_HIP(hipMalloc((void **)&d_ids, (size_t)n * 4)); UZ_HIP(hipMalloc((void **)&d_len, (size_t)n * 4)); UZ_HIP(hipMalloc((void **)&d_off, (size_t)n * 4));
-        try {
-            UZ_HIP(hipMemcpyAsync(d_ids, ids, (size_t)n * 4, hipMemcpyHostToDevice, st));
-            uz_launch_name_lens(c, st, n, d_ids, r.name_rec, r.kept_list, r.n, r.names_bytes, d_len);
-            UZ_HIP(hipMemcpyAsync(len.data(), d_len, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-            UZ_HIP(hipStreamSynchronize(st));
-            for (int64_t k = 0; k < n; k++) off[k + 1] = off[k] + (int64_t)len[(size_t)k];
-            *need = off[n];
-            if (buf && cap >= off[n] && off[n] > 0) {
-                UZ_REQUIRE(off[n] < ((int64_t)1 << 32), UZ_E_RANGE, "uz_reads_names: more than 4 GiB of names");
-                std::vector<uint32_t> o32((size_t)n);
-                for (int64_t k = 0; k < n; k++) o32[(size_t)k] = (uint32_t)off[k];
-                UZ_HIP(hipMalloc((void **)&d_out, (size_t)off[n] + 64));
-                UZ_HIP(hipMemcpyAsync(d_off, o32.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-                uz_launch_name_gather(c, st, n, d_ids, r.name_rec, r.kept_list, r.names, d_len, d_off, d_out);
-                UZ_HIP(hipMemcpyAsync(buf, d_out, (size_t)off[n], hipMemcpyDeviceToHost, st));
-                UZ_HIP(hipStreamSynchronize(st));
-            }
-        } catch (...) { (void)hipFree(d_ids); (void)hipFree(d_len); (void)hipFree(d_off); if (d_out) (void)hipFree(d_out); throw; }
-        (void)hipFree(d_ids); (void)hipFree(d_len); (void)hipFree(d_off); if (d_out) (void)hipFree(d_out);
+        auto pin = [&](size_t bytes_needed) {
+            if (c->nm_pin_cap >= bytes_needed) return;
+            if (c->nm_pin) (void)hipHostFree(c->nm_pin);
+            c->nm_pin = nullptr; c->nm_pin_cap = 0;
+            const size_t want = bytes_needed + bytes_needed / 4 + 4096;
+            uint8_t *p = nullptr;
+            UZ_HIP(hipHostMalloc((void **)&p, want, hipHostMallocDefault));
+            c->nm_pin = p; c->nm_pin_cap = want;
+        };
+        c->nm_ids.ensure((size_t)n + 16); c->nm_len.ensure((size_t)n + 16); c->nm_off.ensure((size_t)n + 16);
+        pin((size_t)n * 4 + 64);
+        memcpy(c->nm_pin, ids, (size_t)n * 4);
+        uz_kcopy(c, c->nm_ids.p, c->nm_pin, (size_t)n * 4);
+        uz_launch_name_lens(c, st, n, c->nm_ids.p, r.name_rec, r.kept_list, r.n, r.names_bytes, c->nm_len.p);
+        UZ_HIP(hipStreamSynchronize(st)); // (the ids have left the staging block)
+        uz_kcopy(c, c->nm_pin, c->nm_len.p, (size_t)n * 4);
+        UZ_HIP(hipStreamSynchronize(st));
+        const uint32_t *len = reinterpret_cast<const uint32_t *>(c->nm_pin);
+        for (int64_t k = 0; k < n; k++) off[k + 1] = off[k] + (int64_t)len[k];
+        const int64_t total = off[n];
+        UZ_REQUIRE(total < ((int64_t)1 << 32), UZ_E_RANGE, "uz_reads_names: more than 4 GiB of names");
+        if (total == 0) { *bytes = c->nm_pin; return; }
+        std::vector<uint32_t> o32((size_t)n);
+        for (int64_t k = 0; k < n; k++) o32[(size_t)k] = (uint32_t)off[k];
+        pin(std::max((size_t)n * 4, (size_t)total) + 64);
+        memcpy(c->nm_pin, o32.data(), (size_t)n * 4);
+        c->nm_out.ensure((size_t)total + 64);
+        uz_kcopy(c, c->nm_off.p, c->nm_pin, (size_t)n * 4);
+        uz_launch_name_gather(c, st, n, c->nm_ids.p, r.name_rec, r.kept_list, r.names, c->nm_len.p, c->nm_off.p, c->nm_out.p);
+        UZ_HIP(hipStreamSynchronize(st)); // (the offsets have left the staging block before the names land in it)
+        uz_kcopy(c, c->nm_pin, c->nm_out.p, ((size_t)total + 3) & ~(size_t)3);
+        UZ_HIP(hipStreamSynchronize(st));
+        *bytes = c->nm_pin;
     });
 }
 

@@ -1427,18 +1427,30 @@ __global__ __launch_bounds__(256) void k_bounds_reduce(const int32_t *__restrict
     hist[threadIdx.x] = 0;
     __syncthreads();
     long long mA = 0, mT = 0, mH = 0, mC = 0, mM = 0, sumP = 0, active = 0;
-    for (int64_t d = (int64_t)blockIdx.x * 256 + threadIdx.x; d < n; d += (int64_t)gridDim.x * 256) {
-        const int32_t *b = bounds + 5 * d;
-        const long long b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4];
+    int bin = -1;
+    for (int64_t d0 = (int64_t)blockIdx.x * 256; d0 < n; d0 += (int64_t)gridDim.x * 256) { // (whole wavefronts stay in the loop: the ballots below)
+        const int64_t d = d0 + threadIdx.x;
+        const bool in = d < n;
+        const int32_t *b = bounds + 5 * (in ? d : 0);
+        const long long b0 = in ? b[0] : 0, b1 = in ? b[1] : 0, b2 = in ? b[2] : 0, b3 = in ? b[3] : 0, b4 = in ? b[4] : 0;
         mA = max(mA, b0); mT = max(mT, b1); mH = max(mH, b2); mC = max(mC, b3);
         const long long M = b1 + 4LL * b0 * (b4 + 1);
         mM = max(mM, M);
         sumP += min(M, 4096LL) + b3;
         if (b3 > 0) {
             const long long est = ((37LL * b1) / 4 + 10LL * b0 + 3328 + 255) >> 8;
-            atomicAdd(&hist[(int)min(est, 255LL)], 1);
+            bin = (int)min(est, 255LL);
             active++;
         }
+        // (a batch's estimates fall into a handful of bins: one LDS atomic per distinct bin of the wavefront, not 64 on the same word)
+        unsigned long long left = __ballot(bin >= 0);
+        while (left) {
+            const int bb = __shfl(bin, __ffsll((long long)left) - 1, 64);
+            const unsigned long long m = __ballot(bin == bb);
+            if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) atomicAdd(&hist[bb], (int32_t)__popcll(m));
+            left &= ~m;
+        }
+        bin = -1;
     }
     for (int o = 32; o > 0; o >>= 1) {
         mA = max(mA, __shfl_xor(mA, o, 64)); mT = max(mT, __shfl_xor(mT, o, 64)); mH = max(mH, __shfl_xor(mH, o, 64)); mC = max(mC, __shfl_xor(mC, o, 64));

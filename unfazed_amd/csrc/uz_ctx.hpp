@@ -339,6 +339,12 @@ struct uz_ctx {
     int64_t walk_allocs = 0; // device allocations the slots have made (uz_walk_slot_stats: a process whose batches stopped growing makes none)
     std::mutex walk_mu;      // guards the three above (walks and joins of different slots run on different decoder threads)
 
+    // uz_reads_names: ids / lengths / offsets / bytes on the device and one page-locked staging block, kept from call to call
+    DevBuf<uint32_t> nm_ids, nm_len, nm_off;
+    DevBuf<uint8_t> nm_out;
+    uint8_t *nm_pin = nullptr;
+    size_t nm_pin_cap = 0;
+
     // last phase (k_reads.hip)
     bool phase_valid = false;
     bool phase_open = false; // uz_phase_begin without its uz_phase_end

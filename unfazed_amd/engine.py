@@ -69,7 +69,7 @@ def load_library(path: Optional[str] = None):
     L.uz_bam_join_needs.argtypes = [vp, C.c_int, vp]
     L.uz_bam_join_fetch.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.uz_reads_from_walk.argtypes = [vp, C.c_int, C.c_int32, C.c_int, vp, vp]
-    L.uz_reads_names.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp]
+    L.uz_reads_names.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp]
     L.uz_walk_slot_stats.argtypes = [vp, vp]
     L.uz_walk_reserve.argtypes = [vp, C.c_int]
     L.uz_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -512,18 +512,17 @@ class HipEngine:
         """the read names of name ids of a table built from a batch joined on the device (uz_reads_names) -> (bytes back to back, off [n + 1])"""
         ids = np.ascontiguousarray(ids, np.uint32)
         n = int(ids.size)
-        off, need = np.zeros(n + 1, np.int64), C.c_int64(0)
+        off, ptr = np.zeros(n + 1, np.int64), C.c_void_p()
         if n == 0:
             return np.zeros(1, np.uint8), off
-        self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, None, 0, C.byref(need)), "uz_reads_names")
-        buf = np.zeros(max(1, int(need.value)), np.uint8)
-        self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, buf.ctypes.data, int(buf.size), C.byref(need)), "uz_reads_names")
+        self._ck(self.L.uz_reads_names(self.h, int(rid), ids.ctypes.data, n, off.ctypes.data, C.byref(ptr)), "uz_reads_names")
+        total = int(off[-1])
+        buf = np.frombuffer(C.string_at(ptr.value, total), np.uint8) if total else np.zeros(1, np.uint8)  # (a copy: the context's block is the next call's)
         return buf, off
 
     def reads_names(self, rid: int, ids) -> list:
-        buf, off = self.reads_names_raw(rid, ids)
-        mv, o = memoryview(buf), off.tolist()
-        return [str(mv[o[k]: o[k + 1]], "utf-8") for k in range(len(o) - 1)]
+        from .io_native import names_of_buffer
+        return names_of_buffer(*self.reads_names_raw(rid, ids))
 
     def walk_slot_stats(self) -> dict:
         z = np.zeros(8, np.int64)

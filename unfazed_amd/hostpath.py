@@ -597,20 +597,28 @@ class PhasingHost:
         ahead = max(1, min(int(os.environ.get("UZ_HOST_AHEAD", 3)), 3))
         n_slots = lag + 1 + ahead  # a slot is staged into again once the read stage of the chunk it held has been collected
 
-        def stage(k):
+        # A chunk's fetch list is made HERE, on the calling thread, before its stage is handed to a worker: the list is a few milliseconds of Python
+        # and numpy, and on a worker it waited for the interpreter lock the main thread holds while it builds site dicts and evidence strings
+        # (0.08 s of waiting per call for 0.016 s of work, `UZ_HOST_TRACE=1`); the workers are left with native code that needs no lock.
+        def fetches(k):
             with _Sec("fetches_of"):
-                fc, flo, fhi, fex, has_sv = self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
+                return self._fetches_of(parts[k], dnms, prep, found, params, cutoff)
+
+        def stage(k, f):
+            fc, flo, fhi, fex, has_sv = f
             with _Sec("stage_reads"):
                 return self.backend.stage_reads(src, fc, flo, fhi, fex, int(params.min_gt_qual), all_bases=bool(params.no_extended), wide_no_units=has_sv, slot=k % n_slots)
 
         with ThreadPoolExecutor(ahead) as ex:
-            futs = {k: ex.submit(stage, k) for k in range(min(ahead, len(parts)))}
+            futs = {}
+            for k in range(min(ahead, len(parts))):
+                futs[k] = ex.submit(stage, k, fetches(k))
             names = {}
 
             def records(k, het_off, het_idx):  # (the pipeline's own find has just returned: the fetches were derived from the batch's find already)
                 packed = futs.pop(k).result()
                 if k + ahead < len(parts):
-                    futs[k + ahead] = ex.submit(stage, k + ahead)  # decoded beside the device work of this chunk and the next
+                    futs[k + ahead] = ex.submit(stage, k + ahead, fetches(k + ahead))  # decoded beside the device work of this chunk and the next
                 names[k] = packed  # (its `.qnames`: at once for the link form, once the table is built for a batch walked on the device)
                 return packed
 
@@ -640,6 +648,8 @@ class PhasingHost:
             if while_first_stages is not None:
                 with _Sec("attach"):
                     while_first_stages()  # host work that nothing below waits for, beside the native decode of the first chunks
+                    # (on a thread of its own it gains nothing: the chunk pipeline is bound by the device's chain since the joins run there, and the
+                    # interpreter lock only moves the waiting around -- measured, round 6)
             chunks = [dict(a=cuts[k], b=cuts[k + 1], dnms=self._dnms_view_of(parts[k], dnms, prep, found, cutoff), records=records, sites=None)
                       for k in range(len(parts))]
             trace = [] if os.environ.get("UZ_HOST_TRACE") else None  # development aid: ms per pipeline step (find, collect, queue, records + upload)

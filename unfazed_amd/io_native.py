@@ -670,6 +670,18 @@ class _KeptNames(Sequence):
         return [str(mv[x:y], "utf-8") for x, y in zip(a.tolist(), b.tolist())]
 
 
+def names_of_buffer(buf: np.ndarray, off: np.ndarray) -> list:
+    """read names lying back to back in `buf` (off [n + 1]) as strings: the buffer decoded ONCE and cut (a SAM read name is printable ASCII, so
+    byte offsets are character offsets; half the time of a decode per name: 150 k names in 32 ms instead of 58); anything else, name by name"""
+    o = off.tolist()
+    try:
+        text = buf[: o[-1]].tobytes().decode("ascii")
+    except UnicodeDecodeError:
+        mv = memoryview(buf)
+        return [str(mv[x:y], "utf-8") for x, y in zip(o[:-1], o[1:])]
+    return [text[x:y] for x, y in zip(o[:-1], o[1:])]
+
+
 class DeviceNames(Sequence):
     """name id -> query name of a batch whose joins ran on the device: the names stay in HBM with the table (uz_reads_from_walk) and the ids a
     chunk's result lists name -- a few per cent of its names -- are answered by uz_reads_names.  Valid while the table lives."""
