@@ -88,6 +88,12 @@ extern "C" int emu_phase(const uz_params *P, const uz_sites_view *S, const uz_re
     std::vector<int32_t> coarse((size_t)(n >> 12) + 2);
     for (int64_t k = 0; (k << 12) < n; k++) coarse[k] = Rv->start[k << 12];
     R.coarse = coarse.data();
+    std::vector<int32_t> mid_idx((size_t)(n >> 6) + 2);
+    for (int64_t k = 0; (k << 6) < n; k++) mid_idx[k] = Rv->start[k << 6];
+    R.mid = mid_idx.data();
+    std::vector<int32_t> mid8((size_t)(n >> 3) + 16);
+    for (int64_t k = 0; (k << 3) < n; k++) mid8[k] = Rv->start[k << 3];
+    R.mid8 = mid8.data();
     for (int64_t i = 0; i < n; i++) { // the QC word as the header build makes it
         int nonmatch = 0, none = 0;
         for (int k = 0; k < (int)rb[i].n_cigar; k++) uz_cigar_op_counts(cigar[(size_t)ra[i].cigar_off + k], nonmatch, none);

@@ -720,7 +720,7 @@ int uz_family_adopt_device(uz_ctx *c, int sites_id, const uz_family_view *v, int
 } // extern "C"
 
 // ---- alignment records -> HBM ---------------------------------------------------------------------------
-// Layout of a table's block: [record headers | flag word | QC word | coarse | contig tables] then, for
+// Layout of a table's block: [record headers | flag word | QC word | coarse + mid search index | contig tables] then, for
 // uploads, [cigar | seq4 | qlow] (+ the full qualities of an ASCII upload) and the staged fixed-width columns
 // the headers are built from.
 static void carve_common(Carver &cv, ReadsDev &r) {
@@ -733,6 +733,8 @@ static void carve_common(Carver &cv, ReadsDev &r) {
     r.umask = cv.take<uint16_t>(n);
     r.qs = cv.take<uint16_t>(n);
     r.coarse = cv.take<int32_t>((n >> 12) + 2);
+    r.mid = cv.take<int32_t>((n >> 6) + 2);
+    r.mid8 = cv.take<int32_t>((n >> 3) + 16); // (read eight entries at a time: uz_mid8_refine)
     r.contig_off = cv.take<int64_t>((size_t)r.n_contigs + 1);
     r.max_span = cv.take<int32_t>((size_t)r.n_contigs + 1);
 }

@@ -22,19 +22,141 @@ namespace {
 // record's QC bits depend on nothing but the record -- the header build (k_pack_rec) writes them once, as a word that
 // keeps the mapping quality beside the parameter-independent bits, and the readers apply --min-map-qual (uz_qc_of).
 
-// one 16-lane group per DNM (a DNM has about ten het sites, each costing two binary searches)
-__global__ __launch_bounds__(256) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {
-    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int lane = threadIdx.x & 15;
+// The sizing pass: one UZ_BW_LANES-lane group per DNM (a DNM has about ten het sites, each costing two lower bounds over its contig's records;
+// UZ_BW_SITES items per lane side by side).  What the pass pays for is (a) the length of a DNM's chain of dependent loads and (b) every probe of
+// every lane -- about two cycles of its CU each, whether the line is in a cache or not.  So the lanes of a group do TOGETHER what every chain
+// would do alike: the first steps of all of a DNM's searches run over the same entries of the index -- its ranges lie within a few thousand
+// records of each other -- and take the group one 16-ary search over the coarse index (three steps instead of twelve, 48 probes instead of
+// 264) and one over the mid entries under that coarse cell; the UZ_BW_STAGE mid entries from the DNM's lowest bound on go into LDS (coalesced
+// loads), where every chain finds its 64-record cell without a probe; what is left per chain is one 32-byte load of the cell's eight mid8
+// entries and three steps over the eight record headers under one of them -- ONE line.  A chain beyond the staged entries (a window of more than
+// UZ_BW_STAGE x 64 records) takes the levels on its own (uz_lower_bounds_c).
+// Round 6, per 100 k DNMs of the bench batch: 0.375 ms (a DNM's window first, its ranges inside it: 43 dependent loads, 120 registers) -> 0.30 (no
+// window, mid index) -> 0.22 (32-bit chains: 62 registers, eight waves per SIMD instead of four) -> 0.22 (the group's shared steps: the set-up and
+// the shared steps are 0.036 of it -- the rest was the last six steps over the record headers, ~4 lines of HBM traffic per chain) -> 0.150 (mid8).
+#ifndef UZ_BW_LANES
+#define UZ_BW_LANES 16
+#endif
+#ifndef UZ_BW_MIN_WAVES
+#define UZ_BW_MIN_WAVES 1
+#endif
+#ifndef UZ_BW_STAGE
+#define UZ_BW_STAGE 64
+#endif
+// first k of [a, b) with ld(k) >= v, else b -- by the GL lanes of a group together (a, b, v uniform over the group; gbase: the group's first lane
+// in its wavefront).  Every step: GL probes spread evenly over the bracket, the number of probes below v is the bracket's next GL-th.
+template <int GL, typename F>
+__device__ __forceinline__ int32_t grp_lower_bound(F ld, int32_t a, int32_t b, int32_t v, int lane, int gbase) {
+    constexpr int SH = GL == 64 ? 6 : GL == 32 ? 5 : GL == 16 ? 4 : GL == 8 ? 3 : GL == 4 ? 2 : GL == 2 ? 1 : 0;
+    const unsigned long long gmask = GL == 64 ? ~0ull : ((1ull << GL) - 1ull);
+    while (a < b) {
+        const int32_t chunk = ((b - a) + GL - 1) >> SH;
+        const int32_t q = a + lane * chunk;
+        const bool below = q < b && ld(q) < v;
+        const int cnt = __popcll((__ballot(below) >> gbase) & gmask); // (sorted: the probes below v are the first cnt)
+        const int32_t a0 = a;
+        if (cnt > 0) a = a0 + (cnt - 1) * chunk + 1;
+        if (cnt < GL && a0 + cnt * chunk < b) b = a0 + cnt * chunk;
+    }
+    return a;
+}
+__global__ __launch_bounds__(256, UZ_BW_MIN_WAVES) void k_phase_bounds(PhaseArgs a, int32_t *bounds /* [5n] */) {
+    constexpr int GL = UZ_BW_LANES, NCH = 2 * UZ_BW_SITES;
+    static_assert(GL == 1 || GL == 2 || GL == 4 || GL == 8 || GL == 16 || GL == 32 || GL == 64, "a group is a power of two inside a wavefront");
+    __shared__ int32_t s_stage[256 / GL][UZ_BW_STAGE];
+    const int64_t g = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / GL;
+    const int lane = threadIdx.x & (GL - 1), gbase = (threadIdx.x & 63) & ~(GL - 1);
     const int d = g < a.n ? (int)g : a.n - 1; // whole groups stay converged for the shuffles below
     long long tp = 0;
     int mh = 0;
     int32_t *b = bounds + 5 * (size_t)d;
-    if (g < a.n) uz_phase_bounds(a, d, b, lane, 16, tp, mh);
+    if (g < a.n) {
+        const int nc = (int)(a.cand_off[d + 1] - a.cand_off[d]), nh = (int)(a.het_off[d + 1] - a.het_off[d]);
+        if (lane == 0) {
+            b[0] = b[1] = b[4] = 0;
+            b[2] = nh; b[3] = nc;
+            for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
+        }
+        const RD &R = a.R;
+        const int tid = a.rcontig[d];
+        const bool tid_ok = tid >= 0 && tid < R.n_contigs;
+        const int32_t clo = tid_ok ? (int32_t)R.contig_off[tid] : 0, chi = tid_ok ? (int32_t)R.contig_off[tid + 1] : 0;
+        if (nc > 0 && (!R.mid || !tid_ok || chi - clo <= 128)) { // no index to share: every chain on its own
+            uz_phase_bounds_w(a, d, b, lane, GL, tp, mh,
+                              [&R, clo, chi](const long long (&v)[NCH], const bool (&on)[NCH], long long (&r)[NCH]) { uz_lower_bounds_c<NCH>(R, clo, chi, v, on, r); });
+        } else if (nc > 0) {
+            // the DNM's lowest bound: of its own fetch (a point variant's) or of its first het site's (the list is sorted)
+            const long long span = R.max_span[tid];
+            const bool point = a.vartype[d] == UZ_VT_POINT;
+            long long vmin_ = 0x7FFFFFFFLL;
+            if (point) {
+                const long long position = a.dstart[d];
+                vmin_ = ((a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1) - span;
+            }
+            if (!a.no_extended && nh > 0) {
+                const long long v0 = (long long)a.spos[a.het_idx[a.het_off[d]]] - span;
+                if (v0 < vmin_) vmin_ = v0;
+            }
+            const int32_t vmin = uz_clamp_i32(vmin_);
+            int32_t lo0 = clo, hi0 = chi;
+            if (R.coarse && chi - clo > 8192) {
+                const int32_t kl = (clo + 4095) >> 12, kh = chi >> 12;
+                const int32_t *cx = R.coarse;
+                const int32_t a0 = grp_lower_bound<GL>([cx](int32_t k) { return cx[k]; }, kl, kh > kl ? kh : kl, vmin, lane, gbase);
+                if (kh > kl) { lo0 = a0 > kl ? ((a0 - 1) << 12) : clo; hi0 = a0 < kh ? (a0 << 12) : chi; }
+            }
+            const int32_t *mx = R.mid;
+            const int32_t kl_m = (clo + 63) >> 6, kh_m = chi >> 6; // the contig's mid entries
+            const int32_t ml = (lo0 + 63) >> 6, mhi = hi0 >> 6;
+            int32_t lo1 = lo0; // lower_bound(vmin) is not below lo1
+            if (mhi > ml) {
+                const int32_t m0 = grp_lower_bound<GL>([mx](int32_t k) { return mx[k]; }, ml, mhi, vmin, lane, gbase);
+                if (m0 > ml) lo1 = (m0 - 1) << 6;
+            }
+            int32_t s0 = (lo1 + 63) >> 6;
+            if (s0 < kl_m) s0 = kl_m;
+            int32_t s_end = s0 + UZ_BW_STAGE < kh_m ? s0 + UZ_BW_STAGE : kh_m;
+            if (s_end < s0) s_end = s0;
+            const int32_t cnt = s_end - s0;
+            int32_t *sm = s_stage[threadIdx.x / GL];
+            for (int i = lane; i < cnt; i += GL) sm[i] = mx[s0 + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the group is inside one wavefront: its LDS accesses are in order; the fences are for the compiler)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const bool whole = s_end == kh_m; // the staged entries reach the contig's end
+            uz_phase_bounds_w(a, d, b, lane, GL, tp, mh, [&R, clo, chi, sm, s0, cnt, lo1, whole](const long long (&v_)[NCH], const bool (&on)[NCH], long long (&r)[NCH]) {
+                int32_t x[NCH], y[NCH], v[NCH];
+                bool far[NCH], any_far = false;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        tp += __shfl_xor(tp, o, 16);
-        const int m2 = __shfl_xor(mh, o, 16);
+                for (int s = 0; s < NCH; s++) { v[s] = uz_clamp_i32(v_[s]); x[s] = 0; y[s] = on[s] ? cnt : 0; }
+                uz_lb_level<NCH>([sm](int32_t k) { return sm[k]; }, x, y, v, 0); // its 64-record cell, in LDS
+#pragma unroll
+                for (int s = 0; s < NCH; s++) {
+                    const int32_t k = x[s];
+                    far[s] = on[s] && k == cnt && !whole;
+                    any_far |= far[s];
+                    x[s] = k > 0 ? ((s0 + k - 1) << 6) : lo1;
+                    y[s] = (on[s] && !far[s]) ? (k < cnt ? ((s0 + k) << 6) : chi) : x[s];
+                    if (!on[s]) x[s] = y[s] = clo;
+                }
+                if (R.mid8) uz_mid8_refine<NCH>(R.mid8, x, y, v);
+                const RecA *rx = R.ra;
+                uz_lb_level<NCH>([rx](int32_t k) { return rx[k].start; }, x, y, v, clo);
+#pragma unroll
+                for (int s = 0; s < NCH; s++) r[s] = x[s];
+                if (any_far) { // beyond the staged entries
+                    long long rf[NCH];
+                    uz_lower_bounds_c<NCH>(R, clo, chi, v_, far, rf);
+#pragma unroll
+                    for (int s = 0; s < NCH; s++) if (far[s]) r[s] = rf[s];
+                }
+            });
+        }
+    }
+#pragma unroll
+    for (int o = GL >> 1; o > 0; o >>= 1) {
+        tp += __shfl_xor(tp, o, GL);
+        const int m2 = __shfl_xor(mh, o, GL);
         mh = m2 > mh ? m2 : mh;
     }
     if (g < a.n && lane == 0) {
@@ -132,9 +254,14 @@ struct PhaseState {
     bool force_exact = false; // the next run skips the speculative sizing (a batch that outgrew it is run again on its own sizes)
 };
 
-__global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse) {
+__global__ void k_build_coarse(const RecA *ra, int64_t n, int32_t *coarse, int32_t *mid_idx, int32_t *mid8) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if ((k << 12) < n) coarse[k] = ra[k << 12].start;
+    if ((k << 3) < n) {
+        const int32_t st = ra[k << 3].start;
+        mid8[k] = st;
+        if ((k & 7) == 0) mid_idx[k >> 3] = st;
+        if ((k & 511) == 0) coarse[k >> 9] = st;
+    }
 }
 
 // ---- record headers from the staged columns -------------------------------------------------------------
@@ -385,7 +512,7 @@ __device__ unsigned long long uz_pack_ticks[16];
 template <bool LINK, bool SELF>
 __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, PkWant want, RecA *ra, RecB *rb,
                                                   uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
-                                                  uint16_t *qs, int32_t *coarse, int32_t *hflags, int host_sums) {
+                                                  uint16_t *qs, int32_t *coarse, int32_t *mid_idx, int32_t *mid8, int32_t *hflags, int host_sums) {
     RecColumns c = uz_columns_of<LINK>(c_in);
     __shared__ uint32_t wsum[UZ_PK_SCANNED][4];
     __shared__ int64_t esc_span[2];
@@ -561,7 +688,13 @@ __global__ __launch_bounds__(256) void k_pack_rec(int64_t n, RecColumns c_in, co
             PK_TICK(4); // CIGAR
             int low_for_qc = 0; // (an ASCII upload has no counts yet: uz_build_qlow sets the bit that depends on them)
             uz_pack_rec(A, B, st0, en0, cg, sq, mt0, qn0, (uint16_t)ls, (uint16_t)nc, tl0);
-            if ((i & 4095) == 0) coarse[i >> 12] = st0; // the coarse search index: start of every 4096th record
+            if ((i & 7) == 0) { // the search index: start of every 4096th record (coarse), of every 64th (mid) and of every 8th (mid8)
+                mid8[i >> 3] = st0;
+                if ((i & 63) == 0) {
+                    mid_idx[i >> 6] = st0;
+                    if ((i & 4095) == 0) coarse[i >> 12] = st0;
+                }
+            }
             ra[i] = A;
             rb[i] = B;
             fm[i] = uz_pack_fm(rs.flag, rs.mapq, ax);
@@ -728,7 +861,7 @@ __global__ __launch_bounds__(256) void k_pack_dict(RecColumns c, int32_t n_tup, 
 }
 __global__ __launch_bounds__(256, 3) void k_pack_link(int64_t n, RecColumns c_in, const unsigned long long *__restrict__ sums, int32_t n_tup, const uint4 *__restrict__ dict, RecA *ra, RecB *rb,
                                                      uint32_t *fm, uint32_t *qoff, uint8_t *nlow, uint16_t *umask_out, uint32_t *plane_out,
-                                                     uint16_t *qs, int32_t *coarse, int32_t *hflags) {
+                                                     uint16_t *qs, int32_t *coarse, int32_t *mid_idx, int32_t *mid8, int32_t *hflags) {
     RecColumns c = uz_columns_of<true>(c_in);
     __shared__ uint16_t s_tup[UZ_PL_SPAN];
     __shared__ uint8_t s_sd[UZ_PL_SPAN], s_pd[UZ_PL_SPAN];
@@ -976,7 +1109,13 @@ __global__ __launch_bounds__(256, 3) void k_pack_link(int64_t n, RecColumns c_in
                 // (else: its FIRST lies in the span before this one -- k_pair_link -- or nowhere: the totals of the packer's sums tell)
             } else if (named) hflags[0] = 8; // named as a mate, but not a SECOND record
             // (a FIRST whose SECOND lies in the next span: k_pair_link)
-            if ((i & 4095) == 0) coarse[i >> 12] = st0; // the coarse search index: start of every 4096th record
+            if ((i & 7) == 0) { // the search index: start of every 4096th record (coarse), of every 64th (mid) and of every 8th (mid8)
+                mid8[i >> 3] = st0;
+                if ((i & 63) == 0) {
+                    mid_idx[i >> 6] = st0;
+                    if ((i & 4095) == 0) coarse[i >> 12] = st0;
+                }
+            }
             fm[i] = uz_pack_fm(flag, mapq, ax);
             const int units = (int)UZ_ROW_UNITS(ls);
             umask_out[i] = (uint16_t)(nb ? (um | UZ_UMASK_LISTED) : um);
@@ -1144,7 +1283,7 @@ RD make_rd(const ReadsDev &r) {
     RD R;
     R.ra = (const RecA *)r.rec_a; R.rb = (const RecB *)r.rec_b; R.fm = r.fm;
     R.contig_off = r.contig_off; R.max_span = r.max_span; R.n_contigs = r.n_contigs;
-    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.umask = r.umask; R.qs = r.qs; R.min_map_qual = 0; R.coarse = r.coarse;
+    R.cigar = r.cigar; R.seq4 = r.seq4; R.qlow = r.qlow; R.qoff = r.qoff; R.nlow = r.nlow; R.umask = r.umask; R.qs = r.qs; R.min_map_qual = 0; R.coarse = r.coarse; R.mid = r.mid; R.mid8 = r.mid8;
     R.err = nullptr; // set by the launcher of the per-DNM kernel
     return R;
 }
@@ -1285,7 +1424,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     if (!self && !host_sums) hipLaunchKernelGGL(k_off_scan_sums, dim3(1), dim3(256), 0, st, (int64_t)nb, sums, want, c->hflags);
 #define UZ_PACK_LAUNCH(L, S)                                                                                                                              \
     hipLaunchKernelGGL((k_pack_rec<L, S>), dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, want, (RecA *)r.rec_a, \
-                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags, host_sums ? 1 : 0)
+                       (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, r.mid, r.mid8, c->hflags, host_sums ? 1 : 0)
     static const bool build_log = getenv("UZ_BUILD_LOG") != nullptr; // (development aid)
     if (build_log)
         fprintf(stderr, "[uz_build_records] n %lld link_form %d host_sums %d pk_shift %d n_tup %lld qpos_wide %d bl_wide %d -> from_lds %d\n", (long long)r.n, (int)link_form,
@@ -1293,7 +1432,7 @@ void uz_build_records(uz_ctx *c, hipStream_t st, ReadsDev &r, const RecColumns &
     if (from_lds) {
         hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((col.n_tup + 255) / 256)), dim3(256), 0, st, col, (int32_t)col.n_tup, (uint4 *)off_scratch);
         hipLaunchKernelGGL(k_pack_link, dim3(nb), dim3(256), 0, st, (int64_t)r.n, col, (const unsigned long long *)sums, (int32_t)col.n_tup, (const uint4 *)off_scratch, (RecA *)r.rec_a,
-                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, c->hflags);
+                           (RecB *)r.rec_b, r.fm, r.qoff, r.nlow, r.umask, reinterpret_cast<uint32_t *>(r.qlow), r.qs, r.coarse, r.mid, r.mid8, c->hflags);
     } else if (link_form) { if (self) UZ_PACK_LAUNCH(true, true); else UZ_PACK_LAUNCH(true, false); }
     else { if (self) UZ_PACK_LAUNCH(false, true); else UZ_PACK_LAUNCH(false, false); }
 #undef UZ_PACK_LAUNCH
@@ -1355,8 +1494,8 @@ void uz_concat_table(uz_ctx *c, hipStream_t st, ReadsDev &dst, const ReadsDev &s
 
 void uz_finish_table(uz_ctx *c, hipStream_t st, ReadsDev &r) {
     if (r.n <= 0) return;
-    const int64_t nk = (r.n >> 12) + 2;
-    hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse);
+    const int64_t nk = (r.n >> 3) + 2;
+    hipLaunchKernelGGL(k_build_coarse, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, st, (const RecA *)r.rec_a, (int64_t)r.n, r.coarse, r.mid, r.mid8);
     UZ_HIP(hipGetLastError());
 }
 
@@ -1421,6 +1560,11 @@ struct BoundsRed {
     unsigned long long mM, sumP; // (mM by atomicMax on 64 bits)
     int32_t hist[256];           // arena estimate in units of 256 bytes, DNMs with candidate sites only
 };
+// (every workgroup ends with ~17 atomics on ONE 1 KB record, which the L2 takes one after the other -- ~5 ns each: 391 workgroups were 37 us for
+// a pass over 2 MB; a few dozen workgroups walking more DNMs each are not)
+#ifndef UZ_BR_BLOCKS
+#define UZ_BR_BLOCKS 48
+#endif
 __global__ __launch_bounds__(256) void k_bounds_reduce(const int32_t *__restrict__ bounds, int32_t n, BoundsRed *out) {
     __shared__ int32_t hist[256];
     __shared__ unsigned long long part[4][8];
@@ -1551,7 +1695,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     // DNMs without candidates leave their het ranges untouched: they must read as empty
     UZ_HIP(hipMemsetAsync(st->pre_h.p, 0, 2 * ((size_t)c->n_het + 1) * sizeof(int32_t), c->stream));
     {
-        const unsigned nb = (unsigned)(((int64_t)n * 16 + 255) / 256);
+        const unsigned nb = (unsigned)(((int64_t)n * UZ_BW_LANES + 255) / 256);
         ProfScope ps(c, UZ_K_SIZING);
         UZ_TRACE("k_phase_bounds");
         hipLaunchKernelGGL(k_phase_bounds, dim3(nb), dim3(256), 0, c->stream, a, st->bounds.p);
@@ -1565,7 +1709,7 @@ void uz_launch_phase(uz_ctx *c, FamilyDev &f, const SitesDev &s, ReadsDev &r, in
     }
     st->bounds_red.ensure(sizeof(BoundsRed) / sizeof(int32_t) + 16);
     UZ_HIP(hipMemsetAsync(st->bounds_red.p, 0, sizeof(BoundsRed), c->stream));
-    hipLaunchKernelGGL(k_bounds_reduce, dim3((unsigned)std::max(1, std::min(512, (n + 255) / 256))), dim3(256), 0, c->stream, (const int32_t *)st->bounds.p, n,
+    hipLaunchKernelGGL(k_bounds_reduce, dim3((unsigned)std::max(1, std::min(UZ_BR_BLOCKS, (n + 255) / 256))), dim3(256), 0, c->stream, (const int32_t *)st->bounds.p, n,
                        reinterpret_cast<BoundsRed *>(st->bounds_red.p));
     UZ_HIP(hipGetLastError());
     // The sizes of the batch (k_phase_bounds) decide the scratch capacities, the LDS arena and the grid.  Waiting for them costs a

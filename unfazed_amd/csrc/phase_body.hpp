@@ -40,6 +40,9 @@
 #define UZ_TICK_INIT ((void)0)
 #endif
 
+#ifndef UZ_BW_SITES
+#define UZ_BW_SITES 1 // items (het sites, a point variant's own fetch) a lane of the sizing pass searches side by side (uz_phase_bounds_w)
+#endif
 #ifndef UZ_PHASE_K
 #define UZ_PHASE_K 3 // entries a lane works on at once in the finder pass (phase D): their loads are in flight together (2 / 3 / 4: 3.02 / 2.97 / 3.09 ms per 100 k DNMs; 4 spills vector registers)
 #endif
@@ -98,6 +101,8 @@ struct RD { // alignment records of one table (device pointers)
                            // --min-map-qual where the bits are used: no per-batch QC pass)
     int32_t min_map_qual;
     const int32_t *coarse; // start of every 4096th record (L2-resident search index), may be null
+    const int32_t *mid;    // start of every 64th record (second level of the search index: 4 B per 64 records, 64 entries = two lines per coarse cell), may be null
+    const int32_t *mid8;   // start of every 8th record (third level: the eight entries of a 64-record cell are 32 bytes, the eight headers under one of them ONE line), may be null
 };
 
 // ---- per-record QC (goodread read_collector.py:28-53 and the two CIGAR counts of :190-203, :405-408)
@@ -406,128 +411,125 @@ UZ_DEV long long uz_lower_bound_start(const RecA *ra, long long lo, long long hi
     return lo;
 }
 
-// lower bound on the start column with the first steps taken on the coarse index: a plain binary
-// search over a 1 GB column is ~25 dependent HBM misses; the index keeps all but the last dozen in L2.
-UZ_DEV long long uz_lower_bound_c(const RD &R, long long lo, long long hi, long long v) {
-    if (R.coarse && hi - lo > 8192) {
-        const long long kl = (lo + 4095) >> 12, kh = hi >> 12;
-        long long a = kl, b = kh;
-        while (a < b) {
-            const long long mid = a + ((b - a) >> 1);
-            if ((long long)R.coarse[mid] < v) a = mid + 1; else b = mid;
-        }
-        const long long nlo = a > kl ? ((a - 1) << 12) : lo;
-        const long long nhi = a < kh ? (a << 12) : hi;
-        lo = nlo; hi = nhi;
-    }
-    return uz_lower_bound_start(R.ra, lo, hi, v);
-}
-
-// N lower bounds over the start field at once: res[s] = the first record of [lo, hi) whose start is not below v[s] (as an offset from lo), chains
-// with on[s] false left at 0.  The N searches advance in lockstep, every step's N loads issued before the first of them is looked at: a binary
-// search is a chain of dependent loads at ~1 us each under load (~110 per DNM taken one search at a time, ~35 with a DNM's searches side by side).
-// Measured (round 5): sizing pass 0.40 -> 0.38 ms per 100 k DNMs, config 5 0.136 -> 0.104 -- less than the chains' lengths promised, because what
-// bounds the pass is the NUMBER of probes: ~1 450 per DNM, every one a 16-byte header in a line of its own for most of a search, and a CU's L1
-// takes one line per cycle (145 M probes over 256 CUs: ~0.2 ms before anything else).  Fewer probes, not shorter chains, is what is left.
-// (Round 6 tried the obvious way to fewer probes and measured it SLOWER: interpolation search -- the first probes along the line between the
-// bracket's ends, every other one from the fourth on a bisection -- is three or four probes per search on a pile-up's evenly spaced starts, but
-// the chains of a wavefront advance in lockstep, 640 of them, and the wave takes as many steps as its unluckiest chain: close to bisection's
-// eleven again; and the probe's arithmetic (two conversions, a reciprocal, clamps, the bracket's end values kept per chain) took the kernel from
-// 120 to 142 registers -- 190 in a first 64-bit version -- and from 1 600 to 5 000 instructions: 0.37 -> 0.73 ms.  Bisection stays.)
-template <int N>
-UZ_DEV void uz_lower_bounds_start(const RecA *ra, long long lo, long long hi, const long long (&v)[N], const bool (&on)[N], int32_t (&res)[N]) {
-    int32_t l[N], h[N];
-    const int32_t n = (int32_t)(hi - lo);
-#pragma unroll
-    for (int s = 0; s < N; s++) { l[s] = 0; h[s] = (on[s] && n > 0) ? n : 0; }
-    if (n > 0) {
-        for (;;) {
-            bool any = false;
-            long long x[N];
-            int32_t mid[N];
-#pragma unroll
-            for (int s = 0; s < N; s++) {
-                const bool act = l[s] < h[s];
-                any |= act;
-                mid[s] = act ? l[s] + ((h[s] - l[s]) >> 1) : 0; // (an idle chain reads the range's first record again: no branch around the load)
-                x[s] = (long long)ra[lo + mid[s]].start;
-            }
-            if (!any) break;
-#pragma unroll
-            for (int s = 0; s < N; s++)
-                if (l[s] < h[s]) { if (x[s] < v[s]) l[s] = mid[s] + 1; else h[s] = mid[s]; }
-        }
-    }
-#pragma unroll
-    for (int s = 0; s < N; s++) res[s] = l[s];
-}
-// ... and N lower bounds over a whole contig's records [clo, chi), the first steps on the coarse index (uz_lower_bound_c), likewise side by side
-template <int N>
-UZ_DEV void uz_lower_bounds_c(const RD &R, long long clo, long long chi, const long long (&v)[N], long long (&res)[N]) {
-    long long lo[N], hi[N];
-#pragma unroll
-    for (int s = 0; s < N; s++) { lo[s] = clo; hi[s] = chi; }
-    if (R.coarse && chi - clo > 8192) {
-        const long long kl = (clo + 4095) >> 12, kh = chi >> 12;
-        long long a[N], b[N];
-#pragma unroll
-        for (int s = 0; s < N; s++) { a[s] = kl; b[s] = kh; }
-        for (;;) {
-            bool any = false;
-            long long x[N], mid[N];
-#pragma unroll
-            for (int s = 0; s < N; s++) {
-                const bool act = a[s] < b[s];
-                any |= act;
-                mid[s] = act ? a[s] + ((b[s] - a[s]) >> 1) : kl;
-                x[s] = (kl < kh) ? (long long)R.coarse[mid[s]] : 0;
-            }
-            if (!any) break;
-#pragma unroll
-            for (int s = 0; s < N; s++)
-                if (a[s] < b[s]) { if (x[s] < v[s]) a[s] = mid[s] + 1; else b[s] = mid[s]; }
-        }
-#pragma unroll
-        for (int s = 0; s < N; s++) { lo[s] = a[s] > kl ? ((a[s] - 1) << 12) : clo; hi[s] = a[s] < kh ? (a[s] << 12) : chi; }
-    }
-    for (;;) { // the last steps: every chain inside its own stretch of the column
+// Lower bounds on the start column, N of them side by side: the searches advance in lockstep, every step's N loads issued before the first of
+// them is looked at -- a binary search is a chain of dependent loads at ~1 us each under load.  A plain binary search over a 1 GB column is ~25
+// dependent HBM misses; the index levels keep all but a handful in L2 / L1.
+// (Round 5: a DNM's window first and its 22 ranges inside it, side by side: 0.40 -> 0.38 ms per 100 k DNMs.  Round 6 tried interpolation search
+// inside the window -- the first probes along the line between the bracket's ends, every other one from the fourth on a bisection: three or four
+// probes per search on a pile-up's evenly spaced starts, but the chains of a wavefront advance in lockstep, 640 of them, and the wave takes as
+// many steps as its unluckiest chain: close to bisection's eleven again; and the probe's arithmetic took the kernel from 120 to 142 registers and
+// from 1 600 to 5 000 instructions: 0.37 -> 0.73 ms.  What worked instead is below: a second index level and no window.)
+// N lower bounds over a whole contig's records [clo, chi) on three levels: the coarse index (every 4096th start:
+// 180 KB for the bench's table, L2-resident -- ~12 steps), the mid index (every 64th start: the 64 entries under a coarse cell are two cache
+// lines -- 6 steps, one or two misses) and the 64 record headers under a mid cell (1 KB -- 6 steps, about three misses).  Round 6: the twelve
+// last steps used to go over the record headers alone, every one a 16-byte header in a line of its own -- 12 dependent misses per search.
+// Chains with on[s] false take no step (their loads read the contig's first record) and return clo.
+// (record indices and positions are below 2^31 -- abi.hip refuses larger tables -- so the chains keep 32-bit state: half the registers of a
+// 64-bit version, twice the waves per SIMD: the pass is bound by the length of its chains of dependent loads times the rounds of waves the
+// chip needs for a batch)
+// One level: N lower bounds over ld(k), k in [a[s], b[s]), until every bracket is empty.
+// (Tried in round 6 and dropped: by QUARTERS -- three probes per chain and step, issued together: a level of 64 entries in three dependent
+// loads instead of six, the coarse index in six instead of twelve.  0.22 -> 0.26 ms per 100 k DNMs: the pass pays for every probe of every
+// lane about two cycles of its CU -- 620 -> ~1 000 probes per DNM cost more than twelve steps less of the chain gave back.)
+template <int N, typename F>
+UZ_DEV void uz_lb_level(F ld, int32_t (&a)[N], int32_t (&b)[N], const int32_t (&v)[N], int32_t idle) {
+    for (;;) {
         bool any = false;
-        long long x[N], mid[N];
+        int32_t x[N], mid[N];
 #pragma unroll
         for (int s = 0; s < N; s++) {
-            const bool act = lo[s] < hi[s];
+            const bool act = a[s] < b[s];
             any |= act;
-            mid[s] = act ? lo[s] + ((hi[s] - lo[s]) >> 1) : clo;
-            x[s] = (clo < chi) ? (long long)R.ra[mid[s]].start : 0;
+            mid[s] = act ? a[s] + ((b[s] - a[s]) >> 1) : idle; // (an idle chain reads one entry again: no branch around the load)
+            x[s] = ld(mid[s]);
         }
         if (!any) break;
 #pragma unroll
         for (int s = 0; s < N; s++)
-            if (lo[s] < hi[s]) { if (x[s] < v[s]) lo[s] = mid[s] + 1; else hi[s] = mid[s]; }
+            if (a[s] < b[s]) { if (x[s] < v[s]) a[s] = mid[s] + 1; else b[s] = mid[s]; }
     }
+}
+UZ_DEV int32_t uz_clamp_i32(long long v) { return v < -0x7FFFFFFFLL ? -0x7FFFFFFF : (v > 0x7FFFFFFFLL ? 0x7FFFFFFF : (int32_t)v); } // (starts are int32: a value beyond either end compares like the end)
+// The third level: a bracket [x, y) of records -- at most one 64-record cell, normally -- cut down to the eight records under one entry of mid8.
+// The last steps of a search used to probe the record headers of its 64-record cell: a 16-byte header per probe, about four lines of the eight
+// the cell spans -- and the sizing pass, 22 searches per DNM, was bound by that HBM traffic (round 6: 0.17 of its 0.22 ms).  The cell's eight
+// entries are one 32-byte load; the eight headers under an entry are one line.
+template <int N>
+UZ_DEV void uz_mid8_refine(const int32_t *mid8, int32_t (&x)[N], int32_t (&y)[N], const int32_t (&v)[N]) {
+    int32_t e[N][8], cell[N];
+#pragma unroll
+    for (int s = 0; s < N; s++) {
+        cell[s] = x[s] >> 6;
+        const int32_t *p = static_cast<const int32_t *>(__builtin_assume_aligned(mid8 + ((size_t)cell[s] << 3), 32)); // (the array is aligned, a cell is eight entries: two 16-byte loads)
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[s][j] = p[j];
+    }
+#pragma unroll
+    for (int s = 0; s < N; s++) {
+        int32_t nx = x[s], ny = y[s];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int32_t r = (cell[s] << 6) + 8 * j;
+            const bool valid = r > x[s] && r < y[s]; // (entries outside the bracket -- or beyond the table: never written -- decide nothing)
+            if (valid && e[s][j] < v[s]) nx = r > nx ? r : nx;
+            if (valid && !(e[s][j] < v[s])) ny = r < ny ? r : ny;
+        }
+        x[s] = nx; y[s] = ny;
+    }
+}
+template <int N>
+UZ_DEV void uz_lower_bounds_c(const RD &R, long long clo_, long long chi_, const long long (&v_)[N], const bool (&on)[N], long long (&res)[N]) {
+    const int32_t clo = (int32_t)clo_, chi = (int32_t)chi_;
+    int32_t lo[N], hi[N], v[N];
+#pragma unroll
+    for (int s = 0; s < N; s++) {
+        lo[s] = clo; hi[s] = on[s] ? chi : clo;
+        v[s] = uz_clamp_i32(v_[s]);
+    }
+    if (clo >= chi) {
+#pragma unroll
+        for (int s = 0; s < N; s++) res[s] = clo;
+        return;
+    }
+    if (R.coarse && chi - clo > 8192) {
+        const int32_t kl = (clo + 4095) >> 12, kh = chi >> 12;
+        int32_t a[N], b[N];
+#pragma unroll
+        for (int s = 0; s < N; s++) { a[s] = kl; b[s] = (on[s] && kh > kl) ? kh : kl; }
+        const int32_t *cx = R.coarse;
+        uz_lb_level<N>([cx](int32_t k) { return cx[k]; }, a, b, v, kl);
+#pragma unroll
+        for (int s = 0; s < N; s++)
+            if (on[s] && kh > kl) { lo[s] = a[s] > kl ? ((a[s] - 1) << 12) : clo; hi[s] = a[s] < kh ? (a[s] << 12) : chi; }
+    }
+    if (R.mid && chi - clo > 128) { // every chain inside its own stretch of the mid index
+        int32_t a[N], b[N], kl[N], kh[N];
+#pragma unroll
+        for (int s = 0; s < N; s++) { kl[s] = (lo[s] + 63) >> 6; kh[s] = hi[s] >> 6; a[s] = kl[s]; b[s] = kh[s] > kl[s] ? kh[s] : kl[s]; }
+        const int32_t *mx = R.mid;
+        uz_lb_level<N>([mx](int32_t k) { return mx[k]; }, a, b, v, clo >> 6);
+#pragma unroll
+        for (int s = 0; s < N; s++)
+            if (kh[s] > kl[s]) {
+                const int32_t nlo = a[s] > kl[s] ? ((a[s] - 1) << 6) : lo[s], nhi = a[s] < kh[s] ? (a[s] << 6) : hi[s];
+                lo[s] = nlo; hi[s] = nhi;
+            }
+    }
+    if (R.mid8) uz_mid8_refine<N>(R.mid8, lo, hi, v);
+    const RecA *rx = R.ra; // the last steps: every chain inside its own stretch of the column
+    uz_lb_level<N>([rx](int32_t k) { return rx[k].start; }, lo, hi, v, clo);
 #pragma unroll
     for (int s = 0; s < N; s++) res[s] = lo[s];
 }
+template <int N>
+UZ_DEV void uz_lower_bounds_c(const RD &R, long long clo, long long chi, const long long (&v)[N], long long (&res)[N]) {
+    bool on[N];
+#pragma unroll
+    for (int s = 0; s < N; s++) on[s] = true;
+    uz_lower_bounds_c<N>(R, clo, chi, v, on, res);
+}
 
 // (pysam fetch(contig, lo, hi): candidates are records with start in [lo - max_span, hi); the caller still tests end > lo)
-// record range covering every fetch of one DNM: the DNM position and all of its het sites
-UZ_DEV void uz_dnm_window(const PhaseArgs &a, int d, long long &wa, long long &wb) {
-    const long long position = a.dstart[d];
-    long long lo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1, hi = position + 1;
-    const long long h0 = a.het_off[d], h1 = a.het_off[d + 1];
-    if (h1 > h0 && !a.no_extended) { // the het list is sorted by position
-        const long long p0 = a.spos[a.het_idx[h0]], p1 = a.spos[a.het_idx[h1 - 1]];
-        if (p0 < lo) lo = p0;
-        if (p1 + 1 > hi) hi = p1 + 1;
-    }
-    // (both bounds side by side; the second over the whole contig instead of from the first on: the same answer, hi > lo - max_span)
-    const int tid = a.rcontig[d];
-    if (tid < 0 || tid >= a.R.n_contigs) { wa = wb = 0; return; }
-    const long long v[2] = {lo - a.R.max_span[tid], hi};
-    long long r[2];
-    uz_lower_bounds_c<2>(a.R, a.R.contig_off[tid], a.R.contig_off[tid + 1], v, r);
-    wa = r[0]; wb = r[1];
-}
 
 // index of `pos` in get_reference_positions(full_length=True), -1 if absent
 // The fixed-width fields a base lookup needs, fetched together (one memory round trip) before the
@@ -821,12 +823,12 @@ UZ_DEV int uz_sv_decide(const RD &R, const PhaseArgs &a, double cutoff, const Sv
 // (Tried in round 4 and dropped: the window found by the 16 lanes of a DNM's group together, 16 probes per round -- seven rounds instead of ~24
 // dependent loads.  0.40 -> 0.49 ms for 100 k DNMs: the first rounds of a 16-ary search land all over a 3 GB column, cold in every cache and
 // TLB, where a binary search takes its first twelve steps on the 180 KB coarse index that stays in L2.)
-// (the window [wa, wb) of the DNM -- uz_dnm_window -- is an argument)
-// (Tried in round 5 and dropped: no sizing kernel for a batch run speculatively, every wave of the read stage working out the fetch ranges of
-// its own DNM when it takes the DNM up -- window bounds by the 64 lanes together, the window's start column staged once into the empty
-// arena, every range searched there.  ~25 dependent round trips at ~1 us under load, later ~12: 0.7 ms per 100 k DNMs inside the read stage
-// against 0.42 ms for the kernel below, which has every DNM of the batch in flight at once.)
-UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long wa, long long wb, long long &t_part, int &mh_part) {
+// (Round 6: no window of the DNM first and the ranges searched inside it -- two dependent searches, ~23 dependent misses -- but every range straight
+// over the contig on the three levels of uz_lower_bounds_c: ~12 L2 hits and ~4 misses per chain, the chains of a DNM side by side over its lanes.
+// A point variant's own fetch is item 0 of the DNM's list, its het sites follow: no chain that is idle in every lane but one.)
+// search(v, on, r): the 2 x UZ_BW_SITES lower bounds of a lane's items over the DNM's contig (uz_lower_bounds_c, or the sizing kernel's staged form)
+template <typename SEARCH>
+UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part, SEARCH search) {
     const RD &R = a.R;
     const long long h0 = a.het_off[d];
     const int nh = (int)(a.het_off[d + 1] - h0);
@@ -834,6 +836,7 @@ UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, i
     const int tid = a.rcontig[d];
     const bool tid_ok = tid >= 0 && tid < R.n_contigs;
     const long long span = tid_ok ? R.max_span[tid] : 0;
+    const long long clo = tid_ok ? R.contig_off[tid] : 0, chi = tid_ok ? R.contig_off[tid + 1] : 0;
     const bool point = a.vartype[d] == UZ_VT_POINT;
     if (lane == 0 && !point) { // collect_reads_sv fetches +-cutoff around both breakpoints (:478-497): four bounds over the contig, side by side
         long long fa = 0, fb = 0, fa2 = 0, fb2 = 0;
@@ -842,55 +845,55 @@ UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, i
             long long lo1 = (long long)a.dstart[d] - icut, lo2 = (long long)a.dend[d] - icut;
             if (lo1 < 0) lo1 = 0;
             if (lo2 < 0) lo2 = 0;
-            const long long v[4] = {lo1 - span, (long long)a.dstart[d] + icut, lo2 - span, (long long)a.dend[d] + icut};
-            long long r[4];
-            uz_lower_bounds_c<4>(R, R.contig_off[tid], R.contig_off[tid + 1], v, r);
-            fa = r[0]; fb = r[1] > r[0] ? r[1] : r[0]; fa2 = r[2]; fb2 = r[3] > r[2] ? r[3] : r[2];
+            // (two bounds at a time: four chains of three probes would set the register count of the whole pass)
+            const long long v1[2] = {lo1 - span, (long long)a.dstart[d] + icut}, v2[2] = {lo2 - span, (long long)a.dend[d] + icut};
+            long long r1[2], r2[2];
+            uz_lower_bounds_c<2>(R, clo, chi, v1, r1);
+            uz_lower_bounds_c<2>(R, clo, chi, v2, r2);
+            fa = r1[0]; fb = r1[1] > r1[0] ? r1[1] : r1[0]; fa2 = r2[0]; fb2 = r2[1] > r2[0] ? r2[1] : r2[0];
         }
         b[0] = (int32_t)((fb - fa) + (fb2 - fa2));
         a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
         a.pre_win[4 * d + 2] = (int32_t)fa2; a.pre_win[4 * d + 3] = (int32_t)fb2;
     }
-    // The fetch ranges of the het sites, UZ_BW_SITES per lane at a time with their 2 x UZ_BW_SITES searches side by side (uz_lower_bounds_start);
-    // lane 0's first batch carries the two bounds of a point variant's own fetch along.  The walks back to the first het site a record ending at
-    // a site could still reach go side by side too (two dependent loads per step each).
-    constexpr int SITES = 4, NCH = 2 * SITES + 2;
-    bool first = true;
-    for (int hb0 = lane; hb0 < nh || (first && lane == 0 && point); hb0 += nlanes * SITES) {
-        long long v[NCH], hp[SITES];
+    // The items of the DNM: a point variant's own fetch (item 0), then the fetch ranges of its het sites -- UZ_BW_SITES items per lane at a time, their
+    // 2 x UZ_BW_SITES searches side by side.  The walks back to the first het site a record ending at a site could still reach go side by side too
+    // (two dependent loads per step each).
+    constexpr int SITES = UZ_BW_SITES, NCH = 2 * SITES;
+    const int own = point ? 1 : 0;
+    const int n_items = own + (a.no_extended ? 0 : nh);
+    for (int t0 = lane; t0 < n_items; t0 += nlanes * SITES) {
+        long long v[NCH], hp[SITES], r[NCH];
         bool on[NCH];
-        int hs[SITES];
+        int hs[SITES]; // het site of the item; -1: the DNM's own fetch; nh: no item
 #pragma unroll
         for (int j = 0; j < SITES; j++) {
-            hs[j] = hb0 + j * nlanes;
-            const bool in = hs[j] < nh && !a.no_extended;
-            hp[j] = in ? (long long)a.spos[a.het_idx[h0 + hs[j]]] : 0;
-            v[2 * j] = hp[j] - span; v[2 * j + 1] = hp[j] + 1;
-            on[2 * j] = on[2 * j + 1] = in && tid_ok;
+            const int t = t0 + j * nlanes;
+            hs[j] = t < n_items ? t - own : nh;
+            if (hs[j] < 0) {
+                const long long position = a.dstart[d];
+                const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
+                hp[j] = position;
+                v[2 * j] = flo - span; v[2 * j + 1] = position + 1;
+            } else {
+                hp[j] = hs[j] < nh ? (long long)a.spos[a.het_idx[h0 + hs[j]]] : 0;
+                v[2 * j] = hp[j] - span; v[2 * j + 1] = hp[j] + 1;
+            }
+            on[2 * j] = on[2 * j + 1] = hs[j] < nh && tid_ok;
         }
-        const bool own = first && lane == 0 && point;
-        const long long position = a.dstart[d];
-        const long long flo = (a.dflags[d] & UZ_DF_FETCH_FALLBACK) ? position : position - 1;
-        v[2 * SITES] = flo - span; v[2 * SITES + 1] = position + 1;
-        on[2 * SITES] = on[2 * SITES + 1] = own && tid_ok;
-        int32_t r[NCH];
-        uz_lower_bounds_start<NCH>(R.ra, wa, wb, v, on, r);
-        if (own) {
-            const long long fa = tid_ok ? wa + r[2 * SITES] : 0, fb = tid_ok ? wa + (r[2 * SITES + 1] > r[2 * SITES] ? r[2 * SITES + 1] : r[2 * SITES]) : 0;
-            b[0] = (int32_t)(fb - fa);
-            a.pre_win[4 * d] = (int32_t)fa; a.pre_win[4 * d + 1] = (int32_t)fb;
-            a.pre_win[4 * d + 2] = 0; a.pre_win[4 * d + 3] = 0;
-        }
-        first = false;
-        if (a.no_extended) break;
+        search(v, on, r);
         int left[SITES];
 #pragma unroll
         for (int j = 0; j < SITES; j++) {
             left[j] = hs[j];
-            if (hs[j] < nh) {
-                const long long ha = tid_ok ? wa + r[2 * j] : 0, hb = tid_ok ? wa + (r[2 * j + 1] > r[2 * j] ? r[2 * j + 1] : r[2 * j]) : 0;
-                a.pre_ha[h0 + hs[j]] = (int32_t)ha; a.pre_hl[h0 + hs[j]] = (int32_t)(hb - ha);
-                t_part += hb - ha;
+            const long long ra_ = tid_ok ? r[2 * j] : 0, rb_ = tid_ok ? (r[2 * j + 1] > r[2 * j] ? r[2 * j + 1] : r[2 * j]) : 0;
+            if (hs[j] < 0) {
+                b[0] = (int32_t)(rb_ - ra_);
+                a.pre_win[4 * d] = (int32_t)ra_; a.pre_win[4 * d + 1] = (int32_t)rb_;
+                a.pre_win[4 * d + 2] = 0; a.pre_win[4 * d + 3] = 0;
+            } else if (hs[j] < nh) {
+                a.pre_ha[h0 + hs[j]] = (int32_t)ra_; a.pre_hl[h0 + hs[j]] = (int32_t)(rb_ - ra_);
+                t_part += rb_ - ra_;
             }
         }
         for (;;) { // first het site (the list is sorted) a record ending at hp could still reach back to
@@ -898,17 +901,17 @@ UZ_DEV void uz_phase_bounds_w(const PhaseArgs &a, int d, int32_t *b, int lane, i
             long long q[SITES];
 #pragma unroll
             for (int j = 0; j < SITES; j++) {
-                const bool act = hs[j] < nh && left[j] > 0;
+                const bool act = hs[j] >= 0 && hs[j] < nh && left[j] > 0;
                 q[j] = act ? (long long)a.spos[a.het_idx[h0 + left[j] - 1]] : 0;
             }
 #pragma unroll
             for (int j = 0; j < SITES; j++)
-                if (hs[j] < nh && left[j] > 0 && q[j] >= hp[j] - span - 1) { left[j]--; any = true; }
+                if (hs[j] >= 0 && hs[j] < nh && left[j] > 0 && q[j] >= hp[j] - span - 1) { left[j]--; any = true; }
             if (!any) break;
         }
 #pragma unroll
         for (int j = 0; j < SITES; j++)
-            if (hs[j] < nh && hs[j] - left[j] + 1 > mh_part) mh_part = hs[j] - left[j] + 1;
+            if (hs[j] >= 0 && hs[j] < nh && hs[j] - left[j] + 1 > mh_part) mh_part = hs[j] - left[j] + 1;
     }
 }
 UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int nlanes, long long &t_part, int &mh_part) {
@@ -920,9 +923,13 @@ UZ_DEV void uz_phase_bounds(const PhaseArgs &a, int d, int32_t *b, int lane, int
         for (int k = 0; k < 4; k++) a.pre_win[4 * d + k] = 0;
     }
     if (nc <= 0) return;
-    long long wa, wb;
-    uz_dnm_window(a, d, wa, wb);
-    uz_phase_bounds_w(a, d, b, lane, nlanes, wa, wb, t_part, mh_part);
+    const RD &R = a.R;
+    const int tid = a.rcontig[d];
+    const bool tid_ok = tid >= 0 && tid < R.n_contigs;
+    const long long clo = tid_ok ? R.contig_off[tid] : 0, chi = tid_ok ? R.contig_off[tid + 1] : 0;
+    constexpr int NCH = 2 * UZ_BW_SITES;
+    uz_phase_bounds_w(a, d, b, lane, nlanes, t_part, mh_part,
+                      [&R, clo, chi](const long long (&v)[NCH], const bool (&on)[NCH], long long (&r)[NCH]) { uz_lower_bounds_c<NCH>(R, clo, chi, v, on, r); });
 }
 
 // ------------------------------------------------------------------ one DNM
@@ -948,7 +955,7 @@ UZ_DEV void uz_args_load(PhaseArgs &a, PhaseArgsK &ap) {
     UZ_P(cutoff_d) UZ_P(spos) UZ_P(sref) UZ_P(salt) UZ_P(cand_off) UZ_P(het_off) UZ_P(cand_idx) UZ_P(het_idx) UZ_P(cand_flags)
     UZ_P(rcontig) UZ_P(dstart) UZ_P(dend) UZ_P(dflags) UZ_P(vartype) UZ_P(allele_off) UZ_P(alleles)
     UZ_P(R.ra) UZ_P(R.rb) UZ_P(R.fm) UZ_P(R.contig_off) UZ_P(R.max_span) UZ_V(R.n_contigs) UZ_P(R.cigar) UZ_P(R.seq4) UZ_P(R.qlow) UZ_P(R.qoff)
-    UZ_P(R.nlow) UZ_P(R.umask) UZ_P(R.err) UZ_P(R.qs) UZ_V(R.min_map_qual) UZ_P(R.coarse)
+    UZ_P(R.nlow) UZ_P(R.umask) UZ_P(R.err) UZ_P(R.qs) UZ_V(R.min_map_qual) UZ_P(R.coarse) UZ_P(R.mid) UZ_P(R.mid8)
     UZ_P(status) UZ_P(counts) UZ_P(origin) UZ_P(evidence) UZ_V(want_lists) UZ_P(pool) UZ_V(pool_cap) UZ_P(pool_cursor) UZ_P(list_start) UZ_P(list_len)
     UZ_P(work_cursor) UZ_P(retry_count) UZ_P(retry_list) UZ_V(from_list) UZ_V(cursor_slot) UZ_P(src_count) UZ_P(src_list) UZ_P(scratch) UZ_V(scratch_per_wg)
     UZ_V(caps.A) UZ_V(caps.T) UZ_V(caps.H) UZ_V(caps.C) UZ_V(caps.I) UZ_V(caps.M) UZ_V(lds_arena_bytes)

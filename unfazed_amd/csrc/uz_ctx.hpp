@@ -163,6 +163,8 @@ struct ReadsDev {
     uint32_t *qual_off16 = nullptr;
     uint16_t *qs = nullptr;    // per-record QC word (phase_body.hpp: uz_qs_word), written by the header build
     int32_t *coarse = nullptr; // start of every 4096th record
+    int32_t *mid = nullptr;    // start of every 64th record (phase_body.hpp: uz_lower_bounds_c)
+    int32_t *mid8 = nullptr;   // start of every 8th record (uz_mid8_refine)
     hipEvent_t ready = nullptr; // asynchronous uploads: recorded behind the last copy of the upload
     bool pending = false;       // the copies may still be in flight and the headers not built yet: the first use waits (uz_reads_make_ready)
     // The header build of an asynchronous upload is queued with the upload on a stream of its own (uz_ctx::build_stream), behind the
