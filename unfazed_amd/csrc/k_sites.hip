@@ -425,24 +425,28 @@ __global__ __launch_bounds__(256) void k_window_wave(WinArgs a, int32_t *cnt_c, 
             const bool small_event = (en - st) < 20;
             const unsigned long long below = lane ? (~0ULL >> (64 - lane)) : 0ULL;
             for (int k = 0; k < nw; k++) {
+                // (count pass: the window's first site by a 64-ary search, its end by walking -- a window holds about a round of sites, and a second
+                // search was four more dependent loads in front of the walk: the pass is bound by its chain, 100 k waves in ~12 rounds of the chip)
                 int64_t lo, hi;
                 if (FILL) { lo = a.range[4 * (int64_t)d + 2 * k]; hi = a.range[4 * (int64_t)d + 2 * k + 1]; }
-                else {
-                    lo = lower_bound_wave(a.pos, clo, chi, w[k][0] - 1, lane);
-                    hi = lower_bound_wave(a.pos, lo, chi, w[k][1], lane);
-                    if (lane == 0) { a.range[4 * (int64_t)d + 2 * k] = lo; a.range[4 * (int64_t)d + 2 * k + 1] = hi; }
-                }
+                else { lo = lower_bound_wave(a.pos, clo, chi, w[k][0] - 1, lane); hi = chi; }
                 for (int64_t b = lo; b < hi; b += 64) {
                     const int64_t sidx = b + lane;
                     bool is_c = false, is_h = false;
                     uint32_t cl = 0;
-                    if (sidx < hi) {
+                    bool in = sidx < hi;
+                    if (in) {
                         cl = cls[sidx];
                         const int32_t p = a.pos[sidx];
-                        if (cl && !(small_event && p >= st && p < en)) { // :253-256
+                        if (!FILL) in = (int64_t)p < w[k][1]; // (as lower_bound(pos, w[k][1]): the sites below it)
+                        if (in && cl && !(small_event && p >= st && p < en)) { // :253-256
                             is_c = (cl & UZ_CL_CAND) != 0;
                             is_h = (cl & UZ_CL_HET) != 0;
                         }
+                    }
+                    if (!FILL) {
+                        const int n_in = __popcll(__ballot(in)); // (sorted: a prefix of the lanes)
+                        if (n_in < 64) hi = b + n_in;            // the window ends in this round
                     }
                     const unsigned long long bc = __ballot(is_c), bh = __ballot(is_h);
                     if (FILL) {
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(256) void k_window_wave(WinArgs a, int32_t *cnt_c, 
                     }
                     nc += __popcll(bc); nh += __popcll(bh);
                 }
+                if (!FILL && lane == 0) { a.range[4 * (int64_t)d + 2 * k] = lo; a.range[4 * (int64_t)d + 2 * k + 1] = hi; }
             }
             nc *= mult; nh *= mult;
         }
@@ -529,47 +534,71 @@ __global__ __launch_bounds__(256) void k_window_region(WinArgs a, int32_t *cnt_c
     if (!FILL && lane == 0) { cnt_c[d] = (int32_t)nc; cnt_h[d] = (int32_t)nh; }
 }
 
-// exclusive scan of two count arrays into int64 offsets (n+1 entries); one workgroup walks the
-// arrays in tiles of 4096 counts (coalesced 16-byte loads, wave-shuffle scan, int64 carry)
-__global__ __launch_bounds__(1024) void k_scan2(int32_t n, const int32_t *c0, const int32_t *c1, int64_t *o0, int64_t *o1) {
-    __shared__ int wsum[2][16];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    int64_t carry0 = 0, carry1 = 0;
-    for (int32_t base = 0; base < n; base += 4096) {
-        const int32_t i0 = base + 4 * t;
-        int v0[4] = {0, 0, 0, 0}, v1[4] = {0, 0, 0, 0};
-        if (i0 + 3 < n) {
-            const int4 a = *reinterpret_cast<const int4 *>(c0 + i0), b = *reinterpret_cast<const int4 *>(c1 + i0);
-            v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v0[3] = a.w;
-            v1[0] = b.x; v1[1] = b.y; v1[2] = b.z; v1[3] = b.w;
-        } else {
-            for (int k = 0; k < 4; k++) if (i0 + k < n) { v0[k] = c0[i0 + k]; v1[k] = c1[i0 + k]; }
-        }
-        const int s0 = v0[0] + v0[1] + v0[2] + v0[3], s1 = v1[0] + v1[1] + v1[2] + v1[3];
-        int in0 = s0, in1 = s1;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int u0 = __shfl_up(in0, off, 64), u1 = __shfl_up(in1, off, 64);
-            if (lane >= off) { in0 += u0; in1 += u1; }
-        }
-        __syncthreads(); // wsum of the previous tile has been read
-        if (lane == 63) { wsum[0][wv] = in0; wsum[1][wv] = in1; }
-        __syncthreads();
-        int64_t p0 = carry0, p1 = carry1, t0 = 0, t1 = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) {
-            const int a = wsum[0][w], b = wsum[1][w];
-            if (w < wv) { p0 += a; p1 += b; }
-            t0 += a; t1 += b;
-        }
-        p0 += in0 - s0; p1 += in1 - s1;
-        for (int k = 0; k < 4; k++) {
-            if (i0 + k < n) { o0[i0 + k] = p0; o1[i0 + k] = p1; }
-            p0 += v0[k]; p1 += v1[k];
-        }
-        carry0 += t0; carry1 += t1;
+// exclusive scan of two count arrays into int64 offsets (n+1 entries), a tile of 4096 counts per workgroup: the tiles' sums first
+// (k_scan2_sums), then every workgroup adds up the sums of the tiles before its own and scans its tile (coalesced 16-byte loads,
+// wave-shuffle scan).  (Through round 6 ONE workgroup walked the arrays tile by tile: 88 us for the 100 k DNMs of the bench batch,
+// 3.5 us per tile of load latency and two barriers with the rest of the chip idle.)
+__device__ __forceinline__ void scan2_load(int32_t n, int32_t i0, const int32_t *c0, const int32_t *c1, int (&v0)[4], int (&v1)[4]) {
+    v0[0] = v0[1] = v0[2] = v0[3] = 0; v1[0] = v1[1] = v1[2] = v1[3] = 0;
+    if (i0 + 3 < n) {
+        const int4 a = *reinterpret_cast<const int4 *>(c0 + i0), b = *reinterpret_cast<const int4 *>(c1 + i0);
+        v0[0] = a.x; v0[1] = a.y; v0[2] = a.z; v0[3] = a.w;
+        v1[0] = b.x; v1[1] = b.y; v1[2] = b.z; v1[3] = b.w;
+    } else {
+        for (int k = 0; k < 4; k++) if (i0 + k < n) { v0[k] = c0[i0 + k]; v1[k] = c1[i0 + k]; }
     }
-    if (t == 0) { o0[n] = carry0; o1[n] = carry1; }
+}
+__global__ __launch_bounds__(1024) void k_scan2_sums(int32_t n, const int32_t *c0, const int32_t *c1, int64_t *part /* [2 tiles] */) {
+    __shared__ long long wsum[2][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int v0[4], v1[4];
+    scan2_load(n, (int32_t)blockIdx.x * 4096 + 4 * t, c0, c1, v0, v1);
+    long long s0 = (long long)v0[0] + v0[1] + v0[2] + v0[3], s1 = (long long)v1[0] + v1[1] + v1[2] + v1[3];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+    if (lane == 0) { wsum[0][wv] = s0; wsum[1][wv] = s1; }
+    __syncthreads();
+    if (t < 2) {
+        long long a = 0;
+        for (int w = 0; w < 16; w++) a += wsum[t][w];
+        part[2 * (size_t)blockIdx.x + t] = a;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan2(int32_t n, const int32_t *c0, const int32_t *c1, const int64_t *__restrict__ part, int64_t *o0, int64_t *o1) {
+    __shared__ int wsum[2][16];
+    __shared__ long long csum[2][16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int32_t i0 = (int32_t)blockIdx.x * 4096 + 4 * t;
+    int v0[4], v1[4];
+    scan2_load(n, i0, c0, c1, v0, v1);
+    long long q0 = 0, q1 = 0; // the tiles before this one
+    for (int b = t; b < (int)blockIdx.x; b += 1024) { q0 += part[2 * (size_t)b]; q1 += part[2 * (size_t)b + 1]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { q0 += __shfl_xor(q0, off, 64); q1 += __shfl_xor(q1, off, 64); }
+    const int s0 = v0[0] + v0[1] + v0[2] + v0[3], s1 = v1[0] + v1[1] + v1[2] + v1[3];
+    int in0 = s0, in1 = s1;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u0 = __shfl_up(in0, off, 64), u1 = __shfl_up(in1, off, 64);
+        if (lane >= off) { in0 += u0; in1 += u1; }
+    }
+    if (lane == 63) { wsum[0][wv] = in0; wsum[1][wv] = in1; }
+    if (lane == 0) { csum[0][wv] = q0; csum[1][wv] = q1; }
+    __syncthreads();
+    int64_t base0 = 0, base1 = 0, pre0 = 0, pre1 = 0, tot0 = 0, tot1 = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const int a = wsum[0][w], b = wsum[1][w];
+        if (w < wv) { pre0 += a; pre1 += b; }
+        tot0 += a; tot1 += b;
+        base0 += csum[0][w]; base1 += csum[1][w];
+    }
+    int64_t p0 = base0 + pre0 + (in0 - s0), p1 = base1 + pre1 + (in1 - s1);
+    for (int k = 0; k < 4; k++) {
+        if (i0 + k < n) { o0[i0 + k] = p0; o1[i0 + k] = p1; }
+        p0 += v0[k]; p1 += v1[k];
+    }
+    if (t == 0 && blockIdx.x == gridDim.x - 1) { o0[n] = base0 + tot0; o1[n] = base1 + tot1; }
 }
 
 // K6: allele-balance phasing of a DEL / DUP from the whole-region candidate list (phase_by_snvs, sv_phaser.py:71-85:
@@ -853,7 +882,11 @@ void uz_launch_find(uz_ctx *c, FamilyDev &f, const SitesDev &s, int mode, bool h
                                    (const int64_t *)nullptr, (const int64_t *)nullptr, (int32_t *)nullptr,
                                    (uint8_t *)nullptr, (int32_t *)nullptr);
             UZ_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_scan2, dim3(1), dim3(1024), 0, c->stream, n, c->cnt_c.p, c->cnt_h.p, c->cand_off.p,
+            const unsigned tiles = (unsigned)(((int64_t)n + 4095) / 4096);
+            c->scan_part.ensure((size_t)2 * tiles);
+            hipLaunchKernelGGL(k_scan2_sums, dim3(tiles), dim3(1024), 0, c->stream, n, c->cnt_c.p, c->cnt_h.p, c->scan_part.p);
+            UZ_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_scan2, dim3(tiles), dim3(1024), 0, c->stream, n, c->cnt_c.p, c->cnt_h.p, (const int64_t *)c->scan_part.p, c->cand_off.p,
                                c->het_off.p);
             UZ_HIP(hipGetLastError());
         }

@@ -259,6 +259,7 @@ struct uz_ctx {
     size_t find_pin_cap = 0;
     size_t dn_stage_cap = 0;
     hipEvent_t dn_stage_done = nullptr; // behind the copies out of dn_stage: a batch queued by uz_phase_begin may still be reading it
+    DevBuf<int64_t> scan_part;   // tile sums of the find's two count arrays (k_scan2_sums -> k_scan2)
     DevBuf<int32_t> cnt_c, cnt_h;
     DevBuf<int64_t> win_range;
     DevBuf<int64_t> cand_off, het_off;
