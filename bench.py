@@ -57,6 +57,7 @@ def parse():
     ap.add_argument("--chunks", type=int, default=0, help="DNM chunks of the staged pass (uploads overlap the kernels); 0 = from the shard size "
                     "(shard.chunk_plan: >= 12.5 k DNMs per chunk, at least 3)")
     ap.add_argument("--sites16", action="store_true", help="staged pass: the genotype columns of the site windows in 16 bits (default: the eight-bit link form)")
+    ap.add_argument("--no-streamed", action="store_true", help="skip the streamed form of the staged pass (`streamed` in the line)")
     ap.add_argument("--first-chunk", type=float, default=None, help="size of the first chunk of the staged pass relative to the others (default: shard.chunk_plan's: 1.0 for a batch of four chunks or more, else 0.5)")
     ap.add_argument("--last-chunk", type=float, default=0.7, help="size of the last chunk of the staged pass relative to the others")
     ap.add_argument("--one-site-table", action="store_true", help="staged pass: one site stage for the whole batch in front of the chunks (default: a site stage per chunk, pipelined with the record uploads)")
@@ -336,7 +337,30 @@ def main():
         if trace:
             print("[staged step, ms] site stage 0, then per chunk: find (behind the read stage of chunk k - 2) | its results | enqueue records, the site windows of chunk k + 2 | queue the read stage of chunk k - 1 (config 5: + allele balance of chunk k - 2); last read stages:", trace[-2:], file=sys.stderr)
         mism = sum(int((np.asarray(res_s[k]) != np.asarray(res_r[k])).sum()) for k in res_r)
-        staged = dict(host_cpu_s=host_cpu_staged, elapsed=el_s, prof=prof_s, bytes=st["read_bytes"] + st["site_bytes"], read_bytes=st["read_bytes"], records=st["records"],
+        # The same steps as ONE stream of chunks (what a cohort run hands the pipeline: batch after batch): the first uploads of a step travel beside
+        # the last read stages of the step before, so the head and the tail of the pipeline are paid once, not per step.  Reported beside `value`
+        # (which stays the step-by-step pass: every step collected before the next one starts), never instead of it.
+        streamed = None
+        if not args.one_site_table and not args.no_streamed and world == 1:
+            S = max(2, args.steps)
+            rep = [dict(c, a=c["a"] + s_ * n, b=c["b"] + s_ * n) for s_ in range(S) for c in chunks]
+            pipeline.run_pipelined(eng, P, mode, 2 * n, rep[: 2 * len(chunks)], cnv=cnv)  # (warm-up: two steps' worth)
+            eng.sync()
+            import gc
+            gc.collect()
+            gc_was = gc.isenabled()
+            gc.disable()
+            t0 = time.perf_counter()
+            out_st = pipeline.run_pipelined(eng, P, mode, S * n, rep, cnv=cnv)
+            eng.sync()
+            el_st = time.perf_counter() - t0
+            if gc_was:
+                gc.enable()
+            mism_st = sum(int((np.asarray(out_st[k][s_ * n:(s_ + 1) * n]) != np.asarray(res_r[k])).sum()) for k in res_r for s_ in range(S))
+            streamed = {"value": round(n * S / el_st, 1), "unit": "DNMs/s", "ms_per_step": round(el_st / S * 1e3, 3), "steps": S, "chunks": len(rep),
+                        "result_mismatches_vs_resident": int(mism_st),
+                        "note": "the same %d steps handed to the pipeline as one stream of chunks (batch after batch, as a cohort run does): a step's first uploads overlap the read stages of the step before; `value` is the step-by-step pass" % S}
+        staged = dict(streamed=streamed, host_cpu_s=host_cpu_staged, elapsed=el_s, prof=prof_s, bytes=st["read_bytes"] + st["site_bytes"], read_bytes=st["read_bytes"], records=st["records"],
                       decode_s=t_dec, mismatches_vs_resident=mism, chunks=len(chunks),
                       sites=st["sites"], site_stage="whole batch" if args.one_site_table else "per chunk")
         res = res_s
@@ -515,6 +539,10 @@ def main():
                            "chunks": staged["chunks"], "decode_s": round(staged["decode_s"], 1),
                            "result_mismatches_vs_resident": staged["mismatches_vs_resident"]}
             out["kernels_ms_per_step_staged"] = kern_ms(staged["prof"])
+            if staged.get("streamed"):
+                st_ = dict(staged["streamed"])
+                st_["link_achieved_GBps"] = round(staged["bytes"] / (st_["ms_per_step"] * 1e-3) / 1e9, 2)
+                out["streamed"] = st_
         print(json.dumps(out))
     wl.free()
     if dist is not None:
