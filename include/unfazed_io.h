@@ -96,15 +96,16 @@ typedef struct uz_vcf_view {
 } uz_vcf_view;
 
 int uz_vcf_decode(const char *path, int threads, uz_vcf **out);
-/* Region decode through the tabix index (`tbi_path` NULL: NAME.tbi next to the file): only the BGZF blocks the index names
- * for the intervals are read and inflated.  The table holds the header and, in file order, the records that overlap an
+/* Region decode through the file's index (`tbi_path` NULL: NAME.tbi next to the file, else NAME.csi): only the BGZF blocks the
+ * index names for the intervals are read and inflated.  The table holds the header and, in file order, the records that overlap an
  * interval [lo, hi) (0-based) of reference `ref[k]` (an index into uz_vcf_index_names) -- what `vcf(region)` hands the
- * reference per DNM (informative_site_finder.py:42, :399-420, :566); a record is kept once however many intervals it
- * overlaps.  Text VCF only (BCF carries a CSI index: decoded whole). */
+ * reference per DNM (informative_site_finder.py:42, :399-420, :566, and :41-43, :213 for a .bcf); a record is kept once however many
+ * intervals it overlaps.  A BGZF VCF goes through a TBI or a CSI (`tabix -C`: any min_shift / depth), a BCF through its CSI
+ * (`bcftools index`): its references are the header's contigs by id, a record overlaps by POS and rlen. */
 int uz_vcf_decode_regions(const char *path, const char *tbi_path, int64_t n_iv, const int32_t *ref, const int32_t *lo, const int32_t *hi,
                           int threads, uz_vcf **out);
-/* sequence names of the tabix index, in the order of their first record in the file, each NUL-terminated, into buf; returns the
- * bytes needed (call with cap 0 first) or a negative UZ_IO_E_* */
+/* sequence names of the index, each NUL-terminated, into buf -- a text file's in the order of their first record in the file (the
+ * TBI's, or the CSI's aux block), a BCF's the header's contigs by id; returns the bytes needed (call with cap 0 first) or a negative UZ_IO_E_* */
 int64_t uz_vcf_index_names(const char *path, const char *tbi_path, char *buf, int64_t cap);
 /* What the index readers make of a BAI (kind 0) or TBI (kind 1) file, for checks against an independent reader: per reference six
  * numbers -- bins (the 37450 pseudo-bin left out), chunks in them, linear-index entries, sum of the chunks' begins, of their ends, of

@@ -14,7 +14,7 @@ print(' '.join(os.path.join('$ROOT', 'unfazed_amd', 'csrc', s) for s in build.IO
 g++ -O1 -g -std=c++17 -fPIC -shared -pthread -fsanitize=address,undefined -fno-omit-frame-pointer \
     -Wall -Wno-unused-parameter -I $ROOT/include -I $ROOT/unfazed_amd/csrc $SRCS -lz -ldl -o $OUT/libunfazed_io_san.so
 cd $ROOT
-TESTS=${@:-tests/test_io_native.py tests/test_io_stage.py tests/test_pack_select.py tests/test_index_refdata.py tests/test_synth_files.py tests/test_refdata_plumbing.py}
+TESTS=${@:-tests/test_io_native.py tests/test_io_csi.py tests/test_io_stage.py tests/test_pack_select.py tests/test_index_refdata.py tests/test_synth_files.py tests/test_refdata_plumbing.py}
 LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 \
 UBSAN_OPTIONS=print_stacktrace=1 UZ_IO_LIB=$OUT/libunfazed_io_san.so python3 -m pytest $TESTS -x -q -s -m "not gpu" -p no:cacheprovider 2>&1 | tee $OUT/log.txt | grep -v "^    #" | tail -40
 echo "sanitizer findings:"; grep -c "runtime error\|ERROR: AddressSanitizer" $OUT/log.txt || true

@@ -259,3 +259,137 @@ def write_tbi(vcf_gz_path, tbi_path=None):
             fh.write(_bgzf_block(blob[i: i + 60000]))
         fh.write(_bgzf_block(b""))
     return tbi_path
+
+
+def _inflated_blocks(path):
+    """(compressed offset, offset in the inflated stream, inflated length) of every BGZF block + the inflated stream"""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    blocks, p, u = [], 0, 0
+    data = bytearray()
+    while p < len(raw):
+        xlen = struct.unpack_from("<H", raw, p + 10)[0]
+        bsize = struct.unpack_from("<H", raw, p + 16)[0] + 1
+        payload = zlib.decompress(raw[p + 12 + xlen: p + bsize - 8], -15)
+        blocks.append((p, u, len(payload)))
+        data += payload
+        p += bsize
+        u += len(payload)
+    return blocks, bytes(data)
+
+
+def write_csi(path, csi_path=None, min_shift=14, depth=5):
+    """A CSI index (SAM/CSI spec, CSIv1) for a BGZF-compressed, position-sorted VCF -- as `tabix -C` -- or for a BCF -- as
+    `bcftools index`: bins of a scheme min_shift / depth wide, a left-most offset per bin (the offset of the first record that overlaps
+    the bin's first window or starts behind it: what htslib derives from its linear index), the pseudo-bin with the counts.  The
+    references of a BCF are its header's contig ids; a text file's names travel in the aux block (the tabix header).  Test infrastructure."""
+    import bisect
+    import struct
+    from unfazed_amd.io_bam import _bgzf_block
+    blocks, data = _inflated_blocks(path)
+    starts = [b[1] for b in blocks]
+
+    def voff(uo):
+        k = bisect.bisect_right(starts, uo) - 1
+        while k + 1 < len(blocks) and uo - blocks[k][1] >= blocks[k][2]:
+            k += 1
+        return (blocks[k][0] << 16) | (uo - blocks[k][1])
+
+    recs = []  # (reference, pos0, end, v0, v1) in file order
+    names = []
+    is_bcf = data[:5] == b"BCF\x02\x02"
+    if is_bcf:
+        off = 9 + struct.unpack_from("<I", data, 5)[0]
+        while off + 8 <= len(data):
+            ls, li = struct.unpack_from("<II", data, off)
+            chrom, pos0, rlen = struct.unpack_from("<iii", data, off + 8)
+            recs.append((chrom, pos0, pos0 + max(1, rlen), voff(off), voff(off + 8 + ls + li) if off + 8 + ls + li < len(data) else (voff(off + 8 + ls + li - 1) + 1)))
+            off += 8 + ls + li
+        n_ref = max([r[0] for r in recs] + [-1]) + 1
+    else:
+        off, n = 0, len(data)
+        while off < n:
+            e = data.find(b"\n", off)
+            if e < 0:
+                e = n
+            line = data[off:e]
+            if line and not line.startswith(b"#"):
+                f = line.split(b"\t")
+                chrom, pos0 = f[0].decode(), int(f[1]) - 1
+                end = pos0 + max(1, len(f[3]))
+                if len(f) > 7:
+                    for kv in f[7].split(b";"):
+                        if kv.startswith(b"END="):
+                            try:
+                                end = max(end, int(kv[4:]))
+                            except ValueError:
+                                pass
+                if not names or names[-1] != chrom:
+                    assert chrom not in names, "records are not grouped by contig"
+                    names.append(chrom)
+                recs.append((len(names) - 1, pos0, end, voff(off), voff(min(e + 1, n)) if e + 1 < n else voff(e) + 1))
+            off = e + 1
+        n_ref = len(names)
+
+    def reg2bin(beg, end):
+        end -= 1
+        s, t = min_shift, ((1 << (depth * 3)) - 1) // 7
+        for l in range(depth, 0, -1):
+            if beg >> s == end >> s:
+                return t + (beg >> s)
+            s += 3
+            t -= 1 << ((l - 1) * 3)
+        return 0
+
+    bins = [dict() for _ in range(n_ref)]
+    linear = [dict() for _ in range(n_ref)]
+    span = [[None, None, 0] for _ in range(n_ref)]
+    for t, pos0, end, v0, v1 in recs:
+        ch = bins[t].setdefault(reg2bin(pos0, end), [])
+        if ch and ch[-1][1] == v0:
+            ch[-1][1] = v1
+        else:
+            ch.append([v0, v1])
+        for w in range(pos0 >> min_shift, ((end - 1) >> min_shift) + 1):
+            linear[t].setdefault(w, v0)
+        span[t][0] = v0 if span[t][0] is None else span[t][0]
+        span[t][1] = v1
+        span[t][2] += 1
+    if is_bcf:
+        aux = b""
+    else:
+        nm = b"".join(x.encode() + b"\0" for x in names)
+        aux = struct.pack("<iiiiiii", 2, 1, 2, 0, ord("#"), 0, len(nm)) + nm
+    out = bytearray(b"CSI\x01" + struct.pack("<iii", min_shift, depth, len(aux)) + aux + struct.pack("<i", n_ref))
+    pseudo = ((1 << (depth * 3 + 3)) - 1) // 7 + 1
+    for t in range(n_ref):
+        n_win = (max(linear[t]) + 1) if linear[t] else 0
+        lin = [linear[t].get(w, 0) for w in range(n_win)]
+        for w in range(n_win - 2, -1, -1):
+            if lin[w] == 0:
+                lin[w] = lin[w + 1]
+
+        def loff(b):  # the first window of the bin, in windows of the lowest level
+            l, first = 0, 0
+            while b >= first + (1 << (3 * l)):
+                first += 1 << (3 * l)
+                l += 1
+            w = (b - first) << (3 * (depth - l))
+            return lin[w] if w < n_win else 0
+
+        out += struct.pack("<i", len(bins[t]) + (1 if span[t][2] else 0))
+        for b in sorted(bins[t]):
+            out += struct.pack("<IQi", b, loff(b), len(bins[t][b]))
+            for v0, v1 in bins[t][b]:
+                out += struct.pack("<QQ", v0, v1)
+        if span[t][2]:
+            out += struct.pack("<IQi", pseudo, 0, 2) + struct.pack("<QQQQ", span[t][0], span[t][1], span[t][2], 0)
+    out += struct.pack("<Q", 0)
+    csi_path = csi_path or path + ".csi"
+    with open(csi_path, "wb") as fh:
+        blob = bytes(out)
+        for i in range(0, len(blob), 60000):
+            fh.write(_bgzf_block(blob[i: i + 60000]))
+        fh.write(_bgzf_block(b""))
+    return csi_path

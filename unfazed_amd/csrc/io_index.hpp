@@ -1,5 +1,7 @@
 // io_index.hpp -- BGZF random access and the binning indexes (BAI for BAM, TBI for tabix-indexed text such as .vcf.gz):
 // the per-reference layout (bins with chunks of virtual file offsets + a 16 kb linear index) is the same in both files.
+// CSI (the index `bcftools index` writes next to a BCF, and `tabix -C` next to a text file): the same bins over a
+// scheme of its own width and depth, a left-most offset per bin instead of the linear index.
 // Shared by the region decoders of io_bam.cpp (uz_bam_decode_regions) and io_vcf.cpp (uz_vcf_decode_regions).
 #pragma once
 #include <fcntl.h>
@@ -175,5 +177,99 @@ inline void chunks_for(const BaiRef &ref, const std::vector<Iv> &ivs, std::vecto
     }
 }
 
+
+// ---- CSI (SAM/CSI spec: CSIv1): magic, min_shift, depth, l_aux, aux, n_ref x { n_bin x { bin, loffset, n_chunk x { beg, end } } }
+struct CsiBin { uint32_t bin; uint64_t loff; std::vector<Chunk> chunks; };
+struct CsiRef { std::vector<CsiBin> bins; }; // sorted by bin number
+struct Csi {
+    int32_t min_shift = 14, depth = 5;
+    std::vector<uint8_t> aux; // a text file's tabix header (format, columns, names); empty for a BCF
+    std::vector<CsiRef> refs;
+};
+
+inline Csi parse_csi(const uint8_t *d, size_t N, const char *path) {
+    if (N < 16 || memcmp(d, "CSI\1", 4) != 0) fail(UZ_IO_E_FORMAT, "%s is not a CSI index", path);
+    Csi x;
+    x.min_shift = rdi32(d + 4); x.depth = rdi32(d + 8);
+    const int32_t l_aux = rdi32(d + 12);
+    if (x.min_shift < 1 || x.min_shift > 30 || x.depth < 1 || x.depth > 9 || x.min_shift + 3 * x.depth > 40) fail(UZ_IO_E_FORMAT, "corrupt index %s: binning %d / %d", path, x.min_shift, x.depth);
+    if (l_aux < 0 || 16 + (size_t)l_aux + 4 > N) fail(UZ_IO_E_FORMAT, "truncated index %s", path);
+    x.aux.assign(d + 16, d + 16 + l_aux);
+    size_t off = 16 + (size_t)l_aux;
+    auto need = [&](size_t k) { if (off + k > N) fail(UZ_IO_E_FORMAT, "truncated index %s", path); };
+    const int32_t n_ref = rdi32(d + off); off += 4;
+    if (n_ref < 0 || (size_t)n_ref > N) fail(UZ_IO_E_FORMAT, "corrupt index %s: bad reference count %d", path, n_ref);
+    const uint32_t pseudo = (uint32_t)((((uint64_t)1 << (3 * (x.depth + 1))) - 1) / 7 + 1); // the bin that holds counts, not chunks
+    x.refs.resize((size_t)n_ref);
+    for (int32_t r = 0; r < n_ref; r++) {
+        need(4);
+        const int32_t n_bin = rdi32(d + off); off += 4;
+        if (n_bin < 0 || (size_t)n_bin > (N - off) / 16) fail(UZ_IO_E_FORMAT, "corrupt index %s: bad bin count %d", path, n_bin);
+        for (int32_t b = 0; b < n_bin; b++) {
+            need(16);
+            CsiBin cb;
+            cb.bin = rd32(d + off);
+            memcpy(&cb.loff, d + off + 4, 8);
+            const int32_t n_chunk = rdi32(d + off + 12);
+            off += 16;
+            if (n_chunk < 0 || (size_t)n_chunk > (N - off) / 16) fail(UZ_IO_E_FORMAT, "corrupt index %s: bad chunk count %d", path, n_chunk);
+            if (cb.bin != pseudo)
+                for (int32_t k = 0; k < n_chunk; k++) {
+                    Chunk c;
+                    memcpy(&c.beg, d + off + 16 * (size_t)k, 8);
+                    memcpy(&c.end, d + off + 16 * (size_t)k + 8, 8);
+                    cb.chunks.push_back(c);
+                }
+            off += (size_t)n_chunk * 16;
+            if (cb.bin != pseudo) x.refs[(size_t)r].bins.push_back(std::move(cb));
+        }
+        std::sort(x.refs[(size_t)r].bins.begin(), x.refs[(size_t)r].bins.end(), [](const CsiBin &a, const CsiBin &b) { return a.bin < b.bin; });
+    }
+    return x;
+}
+
+// chunks of the file that can hold records overlapping the intervals of one reference (sorted, merged): the bins of every level that
+// overlap an interval (the scheme's reg2bins), cut at the left-most offset of the lowest bin that holds the interval's start -- or, where
+// the index has no such bin, of the nearest bin before it on its level, else of its parent, and so on up (the spec's rule for loffset)
+inline void chunks_for_csi(const Csi &x, const CsiRef &ref, const std::vector<Iv> &ivs, std::vector<Chunk> &out) {
+    std::vector<Chunk> cs;
+    const int64_t maxpos = (int64_t)1 << (x.min_shift + 3 * x.depth);
+    auto find = [&](uint32_t b) -> const CsiBin * {
+        auto it = std::lower_bound(ref.bins.begin(), ref.bins.end(), b, [](const CsiBin &a, uint32_t key) { return a.bin < key; });
+        return it != ref.bins.end() && it->bin == b ? &*it : nullptr;
+    };
+    for (const Iv &iv : ivs) {
+        int64_t beg = std::max<int64_t>(iv.lo, 0), end = std::min<int64_t>(iv.hi, maxpos);
+        if (beg >= maxpos) continue;
+        if (end <= beg) end = beg + 1;
+        uint64_t min_off = 0;
+        {
+            uint32_t bin = (uint32_t)((((uint64_t)1 << (3 * x.depth)) - 1) / 7 + (uint64_t)(beg >> x.min_shift)); // the lowest level's bin of `beg`
+            const CsiBin *hit = nullptr;
+            while (bin) {
+                if ((hit = find(bin))) break;
+                const uint32_t parent = (bin - 1) >> 3, first = (parent << 3) + 1;
+                bin = bin > first ? bin - 1 : parent;
+            }
+            if (!bin) hit = find(0);
+            min_off = hit ? hit->loff : 0;
+        }
+        int s = x.min_shift + 3 * x.depth;
+        uint64_t t = 0;
+        for (int l = 0; l <= x.depth; l++, s -= 3) {
+            const uint64_t b0 = t + (uint64_t)(beg >> s), b1 = t + (uint64_t)((end - 1) >> s);
+            auto it = std::lower_bound(ref.bins.begin(), ref.bins.end(), (uint32_t)b0, [](const CsiBin &a, uint32_t key) { return a.bin < key; });
+            for (; it != ref.bins.end() && it->bin <= b1; ++it)
+                for (const Chunk &c : it->chunks)
+                    if (c.end > min_off) cs.push_back(Chunk{std::max(c.beg, min_off), c.end});
+            t += (uint64_t)1 << (3 * l);
+        }
+    }
+    std::sort(cs.begin(), cs.end(), [](const Chunk &a, const Chunk &b) { return a.beg < b.beg || (a.beg == b.beg && a.end < b.end); });
+    for (const Chunk &c : cs) {
+        if (!out.empty() && c.beg <= out.back().end) out.back().end = std::max(out.back().end, c.end);
+        else out.push_back(c);
+    }
+}
 
 } // namespace uzio

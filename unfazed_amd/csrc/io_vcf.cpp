@@ -448,17 +448,143 @@ Tbi read_tbi_file(const char *path, int threads) {
     return t;
 }
 
+// the index next to a sites file: the one named, else <path>.tbi, else <path>.csi (a BCF's index, or a text file's by `tabix -C`)
 std::string tbi_path_for(const char *path, const char *tbi_path) {
     if (tbi_path && *tbi_path) return tbi_path;
-    return std::string(path) + ".tbi";
+    const std::string t = std::string(path) + ".tbi", c = std::string(path) + ".csi";
+    struct stat st;
+    if (stat(t.c_str(), &st) != 0 && stat(c.c_str(), &st) == 0) return c;
+    return t;
+}
+
+// TBI or CSI behind one face: the names of the references (a BCF's come from its header: bcf_header_contigs) and the chunks of an interval
+struct RegionIndex {
+    std::shared_ptr<const Tbi> tbi;
+    std::shared_ptr<const Csi> csi;
+    std::vector<std::string> names;
+    size_t n_refs() const { return tbi ? tbi->refs.size() : csi->refs.size(); }
+    void chunks(int32_t r, const Iv &iv, std::vector<Chunk> &out) const {
+        if (tbi) chunks_for(tbi->refs[(size_t)r], std::vector<Iv>{iv}, out);
+        else chunks_for_csi(*csi, csi->refs[(size_t)r], std::vector<Iv>{iv}, out);
+    }
+};
+
+std::shared_ptr<const Csi> read_csi(const char *path, int threads) { // (kept for the next call like a TBI: read_tbi)
+    static std::mutex mu;
+    static std::map<std::string, std::pair<std::pair<int64_t, int64_t>, std::shared_ptr<const Csi>>> cache;
+    struct stat st;
+    if (stat(path, &st) != 0) fail(UZ_IO_E_OPEN, "cannot open %s", path);
+    const std::pair<int64_t, int64_t> stamp{(int64_t)st.st_size, (int64_t)st.st_mtim.tv_sec * 1000000000LL + st.st_mtim.tv_nsec};
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(path);
+        if (it != cache.end() && it->second.first == stamp) return it->second.second;
+    }
+    Bytes f = read_file(path);
+    bool gz = false;
+    Bytes raw = inflate_all(f, threads, &gz);
+    auto x = std::make_shared<const Csi>(parse_csi(raw.data(), raw.size(), path));
+    std::lock_guard<std::mutex> g(mu);
+    if (cache.size() >= 8) cache.clear();
+    cache[path] = {stamp, x};
+    return x;
+}
+
+bool index_is_csi(const char *path) { // by its first BGZF block's first bytes
+    FileRd f(path);
+    Inflated inf;
+    z_stream z;
+    std::vector<uint8_t> cbuf;
+    if (!inflate_one(f, 0, inf, z, cbuf, nullptr, nullptr) || inf.bytes.size() < 4) fail(UZ_IO_E_FORMAT, "%s is not a TBI or CSI index", path);
+    return memcmp(inf.bytes.data(), "CSI\1", 4) == 0;
+}
+
+// the contigs of a BCF header in the order of their ids (IDX= when present, else order of appearance)
+std::vector<std::string> bcf_header_contigs(const uint8_t *D, size_t N) {
+    std::vector<std::string> out;
+    if (N < 9 || memcmp(D, "BCF\2", 4) != 0) return out;
+    const size_t l_text = rd32(D + 5);
+    if (9 + l_text > N) fail(UZ_IO_E_FORMAT, "truncated BCF header");
+    const char *H = (const char *)D + 9;
+    size_t p = 0;
+    while (p < l_text) {
+        const char *nl = (const char *)memchr(H + p, '\n', l_text - p);
+        const size_t e = nl ? (size_t)(nl - H) : l_text;
+        if (e - p > 10 && memcmp(H + p, "##contig=<", 10) == 0) {
+            const std::string line(H + p, e - p);
+            auto field = [&](const char *key) -> std::string {
+                const std::string k = std::string(key) + "=";
+                size_t a = line.find("<" + k);
+                if (a == std::string::npos) a = line.find("," + k);
+                if (a == std::string::npos) return "";
+                a += 1 + k.size();
+                size_t b = a;
+                while (b < line.size() && line[b] != ',' && line[b] != '>') b++;
+                return line.substr(a, b - a);
+            };
+            const std::string id = field("ID"), ix = field("IDX");
+            if (!id.empty()) {
+                long idx = ix.empty() ? -1 : strtol(ix.c_str(), nullptr, 10);
+                if (idx < 0) { bool seen = false; for (auto &x : out) seen |= x == id; if (seen) { p = e + 1; continue; } idx = (long)out.size(); }
+                if ((size_t)idx >= out.size()) out.resize((size_t)idx + 1);
+                out[(size_t)idx] = id;
+            }
+        }
+        p = e + 1;
+    }
+    return out;
+}
+
+// the bytes of a BCF's header (magic, l_text, text) from the head of the file; empty when the file is not a BCF
+std::vector<uint8_t> bcf_header_bytes(const FileRd &file, int64_t *file_bytes, int64_t *blocks, int64_t *next_coff) {
+    Inflated inf;
+    z_stream z;
+    std::vector<uint8_t> cbuf;
+    if (!inflate_one(file, 0, inf, z, cbuf, file_bytes, blocks)) return {};
+    if (inf.bytes.size() < 9 || memcmp(inf.bytes.data(), "BCF\2", 4) != 0) return {};
+    const size_t need = 9 + (size_t)rd32(inf.bytes.data() + 5);
+    while (inf.bytes.size() < need)
+        if (!inflate_one(file, inf.next_coff, inf, z, cbuf, file_bytes, blocks)) fail(UZ_IO_E_FORMAT, "truncated BCF header");
+    if (next_coff) *next_coff = inf.next_coff;
+    return std::vector<uint8_t>(inf.bytes.begin(), inf.bytes.begin() + (long)need);
+}
+
+RegionIndex load_region_index(const char *path, const char *idx_path, int threads) {
+    const std::string ip = tbi_path_for(path, idx_path);
+    RegionIndex ix;
+    if (!index_is_csi(ip.c_str())) {
+        ix.tbi = read_tbi(ip.c_str(), threads);
+        ix.names = ix.tbi->names;
+        return ix;
+    }
+    ix.csi = read_csi(ip.c_str(), threads);
+    const std::vector<uint8_t> &aux = ix.csi->aux;
+    if (aux.size() >= 28) { // a text file's tabix header: format, col_seq, col_beg, col_end, meta, skip, l_nm, names
+        const int32_t format = rdi32(aux.data()), l_nm = rdi32(aux.data() + 24);
+        if ((format & 0xFFFF) != 2) fail(UZ_IO_E_FORMAT, "%s indexes a file that is not VCF (format %d)", ip.c_str(), format);
+        if (l_nm < 0 || 28 + (size_t)l_nm > aux.size()) fail(UZ_IO_E_FORMAT, "truncated index %s", ip.c_str());
+        size_t a = 28;
+        const size_t stop = 28 + (size_t)l_nm;
+        while (a < stop) {
+            const void *zz = memchr(aux.data() + a, 0, stop - a);
+            const size_t e = zz ? (size_t)((const uint8_t *)zz - aux.data()) : stop;
+            ix.names.emplace_back((const char *)aux.data() + a, e - a);
+            a = e + 1;
+        }
+    } else { // a BCF: its references are the header's contigs, by id
+        FileRd file(path);
+        const std::vector<uint8_t> hb = bcf_header_bytes(file, nullptr, nullptr, nullptr);
+        if (hb.empty()) fail(UZ_IO_E_FORMAT, "%s has no reference names and %s is not a BCF", ip.c_str(), path);
+        ix.names = bcf_header_contigs(hb.data(), hb.size());
+    }
+    if (ix.names.size() < ix.csi->refs.size()) ix.names.resize(ix.csi->refs.size());
+    return ix;
 }
 
 void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n_iv, const int32_t *iv_ref, const int32_t *iv_lo,
                     const int32_t *iv_hi, int threads) {
-    const std::string tp = tbi_path_for(path, tbi_path);
-    const std::shared_ptr<const Tbi> tbi_p = read_tbi(tp.c_str(), threads);
-    const Tbi &tbi = *tbi_p;
-    const int32_t n_ref = (int32_t)tbi.names.size();
+    const RegionIndex tbi = load_region_index(path, tbi_path, threads);
+    const int32_t n_ref = (int32_t)tbi.n_refs();
     std::vector<std::vector<Iv>> ivs((size_t)n_ref);
     for (int64_t k = 0; k < n_iv; k++) {
         if (iv_ref[k] < 0 || iv_ref[k] >= n_ref) fail(UZ_IO_E_ARG, "interval %lld names reference %d of %d", (long long)k, iv_ref[k], n_ref);
@@ -471,9 +597,15 @@ void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n
     std::vector<uint8_t> cbuf;
     std::string text;
     int64_t file_bytes = 0, blocks = 0, walked = 0, kept = 0;
+    int64_t bcf_body = 0; // a BCF: the compressed offset behind its header's last block (unused)
+    int64_t hb_bytes = 0, hb_blocks = 0;
+    const std::vector<uint8_t> bcf_head = bcf_header_bytes(file, &hb_bytes, &hb_blocks, &bcf_body);
+    const bool is_bcf = !bcf_head.empty();
+    if (is_bcf) { file_bytes += hb_bytes; blocks += hb_blocks; } // (a text file's header blocks are read, and counted, below)
     try {
         // header: blocks from the start of the file until a line that does not start with '#'
-        {
+        if (is_bcf) text.assign((const char *)bcf_head.data(), bcf_head.size());
+        else {
             Inflated inf;
             size_t at = 0;
             bool done = false;
@@ -507,7 +639,7 @@ void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n
             std::vector<Chunk> chunks;
             for (const Iv &iv : merged) {
                 std::vector<Chunk> one;
-                chunks_for(tbi.refs[(size_t)r], std::vector<Iv>{iv}, one);
+                tbi.chunks(r, iv, one);
                 chunks.insert(chunks.end(), one.begin(), one.end());
             }
             std::sort(chunks.begin(), chunks.end(), [](const Chunk &a, const Chunk &b) { return a.beg < b.beg || (a.beg == b.beg && a.end < b.end); });
@@ -533,6 +665,36 @@ void decode_regions(uz_vcf &V, const char *path, const char *tbi_path, int64_t n
             Inflated inf;
             if (!inflate_one(file, (int64_t)(ck.beg >> 16), inf, z, cbuf, &file_bytes, &blocks)) return;
             size_t at = (size_t)(ck.beg & 0xFFFF), blk = 0;
+            if (is_bcf) {
+                // records of the binary form: l_shared, l_indiv, then CHROM (the header's contig id: the index's reference), POS (0-based), rlen
+                for (;;) {
+                    bool eof = false;
+                    while (at + 8 > inf.bytes.size() && !eof) eof = !inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks);
+                    if (at >= inf.bytes.size()) break;
+                    if (at + 8 > inf.bytes.size()) fail(UZ_IO_E_FORMAT, "truncated BCF record");
+                    while (blk + 1 < inf.block_at.size() && inf.block_at[blk + 1].second <= at) blk++;
+                    if ((((uint64_t)inf.block_at[blk].first << 16) | (uint64_t)(at - inf.block_at[blk].second)) >= ck.end) break;
+                    const size_t ls = rd32(inf.bytes.data() + at), li = rd32(inf.bytes.data() + at + 4);
+                    if (ls < 24) fail(UZ_IO_E_FORMAT, "bad BCF record (l_shared %zu)", ls);
+                    while (at + 8 + ls + li > inf.bytes.size())
+                        if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) fail(UZ_IO_E_FORMAT, "truncated BCF record");
+                    const uint8_t *q = inf.bytes.data() + at + 8;
+                    const int32_t chrom = rdi32(q);
+                    const long long pos0 = rdi32(q + 4), rlen = rdi32(q + 8);
+                    walked++;
+                    if (chrom == r) {
+                        if (pos0 >= (long long)last_hi) break;
+                        const long long end = pos0 + std::max<long long>(1, rlen);
+                        auto iv = std::upper_bound(merged.begin(), merged.end(), pos0, [](long long key, const Iv &x) { return key < (long long)x.hi; });
+                        if (iv != merged.end() && (long long)iv->lo < end) {
+                            text.append((const char *)inf.bytes.data() + at, 8 + ls + li);
+                            kept++;
+                        }
+                    }
+                    at += 8 + ls + li;
+                }
+                return;
+            }
             for (;;) {
                 while (at >= inf.bytes.size())
                     if (!inflate_one(file, inf.next_coff, inf, z, cbuf, &file_bytes, &blocks)) return;
@@ -831,8 +993,7 @@ int64_t uz_vcf_index_names(const char *path, const char *tbi_path, char *buf, in
     int64_t total = -1;
     const int rc = guarded([&] {
         if (!path) fail(UZ_IO_E_ARG, "uz_vcf_index_names: bad arguments");
-        const std::shared_ptr<const Tbi> tp = read_tbi(tbi_path_for(path, tbi_path).c_str(), 1);
-        const Tbi &t = *tp;
+        const RegionIndex t = load_region_index(path, tbi_path, 1);
         std::string all;
         for (const std::string &n : t.names) { all += n; all.push_back('\0'); }
         if (buf && cap >= (int64_t)all.size()) memcpy(buf, all.data(), all.size());

@@ -328,9 +328,12 @@ class _Strings(Sequence):
 
 
 def tabix_index_path(path: str):
-    """the .tbi next to a BGZF-compressed VCF, or None"""
-    cand = path + ".tbi"
-    return cand if path.endswith(".gz") and os.path.isfile(cand) else None
+    """the index next to a sites file -- <path>.tbi next to a BGZF-compressed VCF, else <path>.csi next to that or next to a BCF -- or None"""
+    if path.endswith(".gz") and os.path.isfile(path + ".tbi"):
+        return path + ".tbi"
+    if (path.endswith(".gz") or path.endswith(".bcf")) and os.path.isfile(path + ".csi"):
+        return path + ".csi"
+    return None
 
 
 def tabix_contigs(path: str, tbi: str = None) -> list:
