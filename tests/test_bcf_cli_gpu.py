@@ -32,6 +32,13 @@ def test_bcf_inputs_match_text_inputs(tmp_path, hip_lib):
         outs.append(r.stdout)
     assert outs[0] == outs[1]
     assert len(outs[0].strip().split("\n")) >= 2
+    # ... and with the BCF's CSI index next to it (bcftools index): the sites of the batch's windows only, the same BED
+    from tests.filesio import write_csi
+    from unfazed_amd import io_native
+    write_csi(sites_bcf)
+    assert io_native.tabix_index_path(sites_bcf) == sites_bcf + ".csi"
+    r = subprocess.run([sys.executable, "-m", "unfazed_amd", "-d", dnm_bcf, "-s", sites_bcf] + base, cwd=ROOT, check=True, capture_output=True, text=True)
+    assert r.stdout == outs[0]
     r = subprocess.run([sys.executable, "-m", "unfazed_amd", "-d", dnm_bcf, "-s", sites_bcf] + base[:-4] + ["-o", "vcf"] + base[-2:],
                        cwd=ROOT, capture_output=True, text=True)
     assert r.returncode != 0 and "BCF" in (r.stderr + r.stdout)
