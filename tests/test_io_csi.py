@@ -171,3 +171,36 @@ def test_corrupt_csi_indexes_are_refused(tmp_path):
             io_native.tabix_contigs(path)
     put(raw)
     assert io_native.read_vcf_table_regions(path, [0], [0], [100000]).pos.size > 0
+
+
+@pytest.mark.parametrize("name", ["trio_hets_snvs_chr22.vcf.gz", "trio_hets_svs_chr22.vcf.gz", "trio_svs_chr22.vcf.gz"])
+@pytest.mark.parametrize("min_shift,depth", [(14, 5), (13, 6)])
+def test_csi_route_equals_the_real_tbi_route_on_the_reference_files(tmp_path, name, min_shift, depth):
+    """files bgzip wrote and tabix indexed (the reference's test/data, held as fixtures under tests/golden/refdata): a CSI of this repo's writer
+    next to a copy of the file gives, interval set by interval set, the table the file's own TBI gives"""
+    import shutil
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "golden", "refdata", name)
+    path = os.path.join(str(tmp_path), name)
+    shutil.copy(src, path)
+    write_csi(path, min_shift=min_shift, depth=depth)
+    assert io_native.tabix_index_path(path) == path + ".csi" and io_native.tabix_index_path(src) == src + ".tbi"
+    assert io_native.tabix_contigs(path) == io_native.tabix_contigs(src)
+    full = io_native.read_vcf_table(src, threads=2)
+    pos, end = np.asarray(full.pos, np.int64), np.asarray(full.end, np.int64)
+    rng = np.random.default_rng(len(name) + depth)
+    lo_all, hi_all = int(pos.min()), int(end.max())
+    kept = 0
+    for trial in range(120):
+        k = int(rng.integers(1, 6))
+        width = int(rng.choice([1, 10, 1000, 20000, 300000]))
+        lo = rng.integers(max(0, lo_all - 5000), hi_all + 5000, k)
+        hi = lo + rng.integers(1, width + 1, k)
+        ref = np.zeros(k, np.int32)
+        a = io_native.read_vcf_table_regions(src, ref, lo, hi, threads=2)
+        b = io_native.read_vcf_table_regions(path, ref, lo, hi, threads=2)
+        for col in ("pos", "end", "gt", "ref_depth", "alt_depth", "gq", "sflags"):
+            assert np.array_equal(getattr(a, col), getattr(b, col)), (trial, col, lo, hi)
+        assert list(a.lines) == list(b.lines)
+        kept += int(a.pos.size)
+    assert kept > 0  # (the snvs file holds a few dozen records: what counts is that every set agrees)
